@@ -1,0 +1,239 @@
+/*
+ * auroralz.h -- C ABI of the MI355X-native batched LZ codec ("auroralz").
+ *
+ * This is the drop-in boundary for the LZ match-copy hot path of
+ * Venomalia/AuroraLib.Compression.  The reference is pure managed C# and has
+ * no FFI of its own; every entry point below replaces one managed interface
+ * of the reference (cited as file:line under /root/reference) and is what a
+ * C# `[DllImport("auroralz")]` shim binds.
+ *
+ * Rules of the ABI: extern "C", plain pointers and sizes, POD structs with
+ * fixed-width fields, no ownership crosses the boundary (the caller owns all
+ * src/dst buffers; the library owns its device scratch inside alz_ctx /
+ * alz_plan).  Functions return 0 on success or a negative ALZ_E_* code for API
+ * level failures (bad argument, HIP failure, no device).  Per-stream decode
+ * outcomes are reported in alz_result.status (ALZ_ST_*), mirroring the
+ * reference's exceptions.
+ *
+ * There is NO CPU fallback behind this ABI: every decode/encode runs on the
+ * GPU through the hand-written gfx950 kernels.  Without a device alz_create()
+ * fails with ALZ_E_NO_DEVICE.
+ */
+#ifndef AURORALZ_H
+#define AURORALZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALZ_ABI_VERSION 1
+
+/* ---- formats: the headerless bodies on the hot path ---- */
+typedef enum alz_format {
+    ALZ_FMT_LZSS       = 0,  /* LZSS.DecompressHeaderless    src/AuroraLib.Compression/Formats/Common/LZSS.cs:91-130   */
+    ALZ_FMT_LZ10       = 1,  /* LZ10.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/LZ10.cs:82-111 */
+    ALZ_FMT_LZ11       = 2,  /* LZ11.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/LZ11.cs:83-133 */
+    ALZ_FMT_YAZ0       = 3,  /* Yaz0.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/Yaz0.cs:91-92 (Yay0 body, one cursor) */
+    ALZ_FMT_YAY0       = 4,  /* Yay0.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/Yay0.cs:99-144 (three cursors) */
+    ALZ_FMT_MIO0       = 5,  /* MIO0.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/MIO0.cs:105-149 */
+    ALZ_FMT_PRS_BE     = 6,  /* PRS.DecompressHeaderless(.., Endian.Big)    src/AuroraLib.Compression.Sega/Sega/PRS.cs:59-102 */
+    ALZ_FMT_PRS_LE     = 7,  /* PRS.DecompressHeaderless(.., Endian.Little) same body, LSB-first flags + LE u16 */
+    ALZ_FMT_LZ4_BLOCK  = 8,  /* LZ4.DecompressBlockHeaderless src/AuroraLib.Compression/Formats/Common/LZ4.cs:176-200 */
+    ALZ_FMT_LZO        = 9,  /* LZO.DecompressHeaderless     src/AuroraLib.Compression/Formats/Common/LZO.cs:49-139 */
+    ALZ_FMT_SNAPPY_RAW = 10, /* Snappy.DecompressHeaderless  src/AuroraLib.Compression/Formats/Common/Snappy.cs:205-250 */
+    ALZ_FMT_COUNT      = 11
+} alz_format;
+
+/* ---- per-stream status: the reference's exception types ---- */
+typedef enum alz_status {
+    ALZ_ST_OK                   = 0,
+    ALZ_ST_INPUT_TRUNCATED      = 1, /* EndOfStreamException / IndexOutOfRangeException */
+    ALZ_ST_OUTPUT_SIZE_MISMATCH = 2, /* DecompressedSizeException (LZ10.cs:107-110 '>', LZSS.cs:126-129 '!=') */
+    ALZ_ST_OUTPUT_CAPACITY      = 3, /* NotSupportedException of a fixed-size destination */
+    ALZ_ST_BAD_TOKEN            = 4  /* reference-undefined input the library refuses (Snappy copy-4 distance > window) */
+} alz_status;
+
+/* ---- API-level error codes ---- */
+#define ALZ_OK            0
+#define ALZ_E_INVALID    -1  /* bad argument */
+#define ALZ_E_NO_DEVICE  -2  /* no HIP device / runtime */
+#define ALZ_E_HIP        -3  /* a HIP call failed; see alz_last_error() */
+#define ALZ_E_NOMEM      -4
+#define ALZ_E_UNSUPPORTED -5
+#define ALZ_E_FORMAT     -6  /* container header invalid (InvalidIdentifierException) */
+#define ALZ_E_STREAM     -7  /* single-stream helper: per-stream status != OK (status is returned separately) */
+
+/*
+ * LzProperties of the generic LZSS body (src/AuroraLib.Compression/LzProperties.cs:9-97).
+ * Only consulted for ALZ_FMT_LZSS streams; all other formats have fixed geometry.
+ * Defaults (all zero) mean LZSS.DefaultProperties = LzProperties((byte)12, 4, 2)
+ * (LZSS.cs:33): window_bits 12, length_bits 4, min_length 3, windows_start 0xFEE.
+ */
+typedef struct alz_lz_properties {
+    uint8_t  window_bits;    /* LzProperties.WindowsBits  (7..16 supported on the GPU path) */
+    uint8_t  length_bits;    /* LzProperties.LengthBits   */
+    uint8_t  min_length;     /* LzProperties.MinLength    */
+    uint8_t  reserved0;
+    uint32_t windows_start;  /* LzProperties.WindowsStart */
+    uint32_t max_distance;   /* LzProperties.MaxDistance  (== 1 << window_bits for the bit-based ctor) */
+    uint32_t reserved1;
+} alz_lz_properties;
+
+/*
+ * One stream of a batch.  Offsets are relative to the src_base / dst_base
+ * passed to the batch call, so one descriptor table serves host and device
+ * resident buffers alike.
+ *
+ * decom_len : the `decomLength` argument of the reference's DecompressHeaderless
+ *             (LZSS/LZ10/LZ11/YAZ0/YAY0/MIO0).  Ignored by PRS/LZ4/LZO (no size
+ *             field, terminated by token / end of input) and by SNAPPY_RAW
+ *             (varint inside the body).
+ * aux0/aux1 : YAY0/MIO0 only: compressedDataPointer / uncompressedDataPointer
+ *             relative to the first flag byte (Yay0.cs:60, MIO0.cs:61).
+ * dst_cap   : bytes the library may write at dst_off.  Never exceeded.
+ */
+typedef struct alz_stream {
+    uint64_t src_off;
+    uint64_t dst_off;
+    uint32_t src_len;
+    uint32_t dst_cap;
+    uint32_t decom_len;
+    uint32_t aux0;
+    uint32_t aux1;
+    uint32_t format;     /* alz_format */
+} alz_stream;
+
+typedef struct alz_result {
+    uint32_t dst_len;    /* bytes written at dst_off (<= dst_cap) */
+    uint32_t src_used;   /* source bytes consumed; the reference leaves source.Position there
+                            (Yay0.cs:89-90, MIO0.cs:92-93, LZSS.cs:68).  Defined when status is OK or SIZE_MISMATCH. */
+    int32_t  status;     /* alz_status */
+    uint32_t reserved;
+} alz_result;
+
+/* CompressionSettings (src/AuroraLib.Compression/CompressionSettings.cs:11-84) */
+typedef struct alz_settings {
+    int32_t quality;          /* 0..15; presets Fastest 0, Fast 4, Balanced 8 (default), High 12, Maximum 15 */
+    int32_t max_window_bits;  /* 0 = auto */
+    int32_t strategy;         /* 0 Default, 1 CompatibilityMode (no self-overlapping matches) */
+    int32_t min_distance;     /* 0 = format default; 2 = LZ10/LZ11 GbaVramCompatibilityMode (LZ10.cs:25-33) */
+} alz_settings;
+
+typedef struct alz_ctx  alz_ctx;   /* one HIP device + one HIP stream; single-threaded */
+typedef struct alz_plan alz_plan;  /* a prepared batch: descriptors resident in HBM, grouped per format */
+
+/* ---------------------------------------------------------------- context */
+int         alz_abi_version(void);
+int         alz_device_count(void);
+int         alz_create(int device, alz_ctx** out);
+void        alz_destroy(alz_ctx* ctx);
+const char* alz_last_error(void);          /* thread-local text of the last failure */
+int         alz_device_info(alz_ctx* ctx, char* name, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
+
+/* ----------------------------------------------- decode: host buffers in/out
+ * Replaces the loop a managed caller writes around the static
+ * `DecompressHeaderless(Stream source, Stream destination, uint decomLength)`
+ * bodies -- the uniform raw-decoder delegate of
+ * src/AuroraLib.Compression.CLI/Commands/BruteForceCommand.cs:88-133.
+ * src_base/dst_base are HOST pointers; the call uploads, decodes on the GPU,
+ * downloads and returns.  `props` may be NULL (LZSS defaults). */
+int alz_decode_batch(alz_ctx* ctx, const alz_lz_properties* props, uint32_t n,
+                     const uint8_t* src_base, size_t src_bytes,
+                     const alz_stream* streams,
+                     uint8_t* dst_base, size_t dst_bytes,
+                     alz_result* results);
+
+/* Single stream: backs ICompressionDecoder.Decompress(Stream, Stream) of one format class
+ * (src/AuroraLib.Compression/Interfaces/ICompressionDecoder.cs:24) after the managed shim parsed the header. */
+int alz_decode(alz_ctx* ctx, uint32_t format, const alz_lz_properties* props,
+               const uint8_t* src, uint32_t src_len, uint32_t decom_len, uint32_t aux0, uint32_t aux1,
+               uint8_t* dst, uint32_t dst_cap, alz_result* result);
+
+/* -------------------------------------------- decode: device-resident batches
+ * The measured path: payload already in HBM, output left in HBM.
+ * alz_plan_create uploads the descriptor table and groups it per format (one
+ * kernel launch per format present).  alz_plan_execute only enqueues kernels
+ * on `hip_stream` (a hipStream_t, or NULL for the context's own stream) and
+ * does not synchronise.  d_src_base / d_dst_base are DEVICE pointers. */
+int  alz_plan_create(alz_ctx* ctx, const alz_lz_properties* props, uint32_t n,
+                     const alz_stream* streams, alz_plan** out);
+int  alz_plan_execute(alz_ctx* ctx, alz_plan* plan, const void* d_src_base, void* d_dst_base, void* hip_stream);
+/* Runs `iters` executions bracketed by HIP events on the launch stream and returns the
+ * mean milliseconds per execution (kernel time as seen by the device). Synchronises. */
+int  alz_plan_execute_timed(alz_ctx* ctx, alz_plan* plan, const void* d_src_base, void* d_dst_base,
+                            int iters, float* mean_ms);
+int  alz_plan_results(alz_ctx* ctx, alz_plan* plan, alz_result* results); /* synchronises, copies n results */
+void alz_plan_destroy(alz_ctx* ctx, alz_plan* plan);
+
+/* ------------------------------------------------------------- encode
+ * Replaces the static `CompressHeaderless(ReadOnlySpan<byte>, Stream, CompressionSettings)`
+ * bodies (e.g. LZSS.cs:132-160, LZ10.cs:113-137) + LzChainMatchFinder
+ * (src/AuroraLib.Compression/MatchFinder/LzChainMatchFinder.cs:157-212).
+ * For encode, alz_stream.src_* describe the RAW input and dst_* the compressed
+ * output capacity; results[i].dst_len is the compressed size.  For YAY0/MIO0
+ * the three sections are written flags|tokens|literals and aux0/aux1 of the
+ * result are returned in alz_encode_aux. */
+typedef struct alz_encode_aux { uint32_t aux0; uint32_t aux1; } alz_encode_aux;
+int alz_encode_batch(alz_ctx* ctx, const alz_lz_properties* props, const alz_settings* settings, uint32_t n,
+                     const uint8_t* src_base, size_t src_bytes,
+                     const alz_stream* streams,
+                     uint8_t* dst_base, size_t dst_bytes,
+                     alz_result* results, alz_encode_aux* aux /* may be NULL */);
+
+/* ------------------------------------------------ device memory helpers
+ * For hosts without their own HIP allocator (the C# shim, the test harness). */
+int alz_device_malloc(alz_ctx* ctx, size_t bytes, void** d_ptr);
+int alz_device_free(alz_ctx* ctx, void* d_ptr);
+int alz_memcpy_h2d(alz_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int alz_memcpy_d2h(alz_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int alz_memset_d(alz_ctx* ctx, void* d_dst, int value, size_t bytes);
+int alz_synchronize(alz_ctx* ctx);
+
+/* ------------------------------------------------ container layer (host side)
+ * The managed part of the reference's format classes restated above the
+ * ABI: header parse/emit + endianness retry, body on the GPU.  One function
+ * per ICompressionAlgorithm member.  `container` values are alz_container. */
+typedef enum alz_container {
+    ALZ_C_LZSS   = 0,  /* "LZSS"+BE size+BE csize+0      LZSS.cs:53-88   */
+    ALZ_C_LZ10   = 1,  /* 0x10 + u24 LE size             LZ10.cs:47-80   */
+    ALZ_C_LZ11   = 2,  /* 0x11 + u24 LE size             LZ11.cs:43-81   */
+    ALZ_C_YAZ0   = 3,  /* "Yaz0"+size+align+0            Yaz0.cs:58-88   */
+    ALZ_C_YAY0   = 4,  /* "Yay0"+size+tokOff+litOff      Yay0.cs:50-77   */
+    ALZ_C_MIO0   = 5,  /* "MIO0"+size+tokOff+litOff      MIO0.cs:51-79   */
+    ALZ_C_PRS    = 6,  /* headerless                     PRS.cs:38-57    */
+    ALZ_C_LZ4_LEGACY = 7, /* 0x184C2102 + blocks         LZ4.cs:96-111,120-135 */
+    ALZ_C_LZO    = 8,  /* headerless                     LZO.cs:42-47    */
+    ALZ_C_SNAPPY = 9,  /* framed "sNaPpY"                Snappy.cs:39-107 */
+    ALZ_C_COUNT  = 10
+} alz_container;
+
+typedef struct alz_container_options {
+    uint32_t big_endian;          /* IEndianDependentFormat.FormatByteOrder: 1 = Endian.Big (default for Yaz0/Yay0/MIO0/PRS) */
+    uint32_t memory_alignment;    /* Yaz0.MemoryAlignment (Yaz0.cs:39) */
+    alz_lz_properties lz;         /* LZSS geometry */
+} alz_container_options;
+
+/* IProvidesDecompressedSize.GetDecompressedSize (Interfaces/IProvidesDecompressedSize.cs:20) */
+int alz_container_decompressed_size(uint32_t container, const alz_container_options* opt,
+                                    const uint8_t* src, size_t src_len, uint32_t* size_out);
+/* IFormatInfoProvider.IsMatch (e.g. LZ10.cs:36-41): 1 match, 0 no match */
+int alz_container_is_match(uint32_t container, const uint8_t* src, size_t src_len);
+/* ICompressionDecoder.Decompress(Stream, Stream).  On ALZ_E_STREAM, *status holds the alz_status. */
+int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_container_options* opt,
+                             const uint8_t* src, size_t src_len,
+                             uint8_t* dst, size_t dst_cap, size_t* dst_len, size_t* src_used, int32_t* status);
+/* ICompressionEncoder.Compress(ReadOnlySpan<byte>, Stream, CompressionSettings) */
+int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container_options* opt,
+                           const alz_settings* settings,
+                           const uint8_t* src, size_t src_len,
+                           uint8_t* dst, size_t dst_cap, size_t* dst_len);
+/* worst-case compressed size for dst_cap sizing */
+size_t alz_container_compress_bound(uint32_t container, size_t src_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURORALZ_H */

@@ -1,0 +1,1363 @@
+/*
+ * alz_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See alz_oracle.h for the rules.  Plain C11, no dependencies.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this file against the
+ * reference's own fixtures (Test.lz KAT XXH64 11520079745250749767, round-trip
+ * matrix, published ratios).  Paths below are relative to /root/reference/src.
+ *
+ * Frozen definitions of reference-undefined behaviour:
+ *  E1  distance == 0            -> behaves as distance == W (self copy of the ring slot)
+ *  E2  source before stream start -> 0x00 (the rented ring is treated as zero-filled)
+ *  E3  distance > W             -> only reachable by Snappy copy-4; refused with ALZ_ST_BAD_TOKEN
+ *  E4  last match overshoots the declared size -> bytes are written (up to dst_cap), then SIZE_MISMATCH
+ *  E5  decoding stops at the first token whose output would exceed dst_cap: the
+ *      bytes below dst_cap are written, status is SIZE_MISMATCH if the format has
+ *      a declared size, the token crosses it and dst_cap >= decom_len, else CAPACITY.
+ *  E6  a read past the end of the input ends decoding with INPUT_TRUNCATED at
+ *      that read (a literal run that does not fit the input is not copied).
+ */
+#include "alz_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ============================================================ hashes */
+
+#define P64_1 11400714785074694791ULL
+#define P64_2 14029467366897019727ULL
+#define P64_3 1609587929392839161ULL
+#define P64_4 9650029242287828579ULL
+#define P64_5 2870177450012600261ULL
+
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static inline uint64_t rd64le(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32le(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+static inline uint64_t xxh64_round(uint64_t acc, uint64_t in) {
+    acc += in * P64_2; acc = rotl64(acc, 31); acc *= P64_1; return acc;
+}
+static inline uint64_t xxh64_merge(uint64_t acc, uint64_t v) {
+    v = xxh64_round(0, v); acc ^= v; acc = acc * P64_1 + P64_4; return acc;
+}
+
+uint64_t oracle_xxh64(const void* data, size_t len, uint64_t seed) {
+    const uint8_t* p = (const uint8_t*)data; const uint8_t* end = p + len; uint64_t h;
+    if (len >= 32) {
+        const uint8_t* lim = end - 32;
+        uint64_t v1 = seed + P64_1 + P64_2, v2 = seed + P64_2, v3 = seed, v4 = seed - P64_1;
+        do {
+            v1 = xxh64_round(v1, rd64le(p)); p += 8; v2 = xxh64_round(v2, rd64le(p)); p += 8;
+            v3 = xxh64_round(v3, rd64le(p)); p += 8; v4 = xxh64_round(v4, rd64le(p)); p += 8;
+        } while (p <= lim);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xxh64_merge(h, v1); h = xxh64_merge(h, v2); h = xxh64_merge(h, v3); h = xxh64_merge(h, v4);
+    } else {
+        h = seed + P64_5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= xxh64_round(0, rd64le(p)); h = rotl64(h, 27) * P64_1 + P64_4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32le(p) * P64_1; h = rotl64(h, 23) * P64_2 + P64_3; p += 4; }
+    while (p < end) { h ^= (*p) * P64_5; h = rotl64(h, 11) * P64_1; p++; }
+    h ^= h >> 33; h *= P64_2; h ^= h >> 29; h *= P64_3; h ^= h >> 32;
+    return h;
+}
+
+#define P32_1 2654435761U
+#define P32_2 2246822519U
+#define P32_3 3266489917U
+#define P32_4 668265263U
+#define P32_5 374761393U
+
+uint32_t oracle_xxh32(const void* data, size_t len, uint32_t seed) {
+    const uint8_t* p = (const uint8_t*)data; const uint8_t* end = p + len; uint32_t h;
+    if (len >= 16) {
+        const uint8_t* lim = end - 16;
+        uint32_t v1 = seed + P32_1 + P32_2, v2 = seed + P32_2, v3 = seed, v4 = seed - P32_1;
+        do {
+            v1 = rotl32(v1 + rd32le(p) * P32_2, 13) * P32_1; p += 4;
+            v2 = rotl32(v2 + rd32le(p) * P32_2, 13) * P32_1; p += 4;
+            v3 = rotl32(v3 + rd32le(p) * P32_2, 13) * P32_1; p += 4;
+            v4 = rotl32(v4 + rd32le(p) * P32_2, 13) * P32_1; p += 4;
+        } while (p <= lim);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+        h = seed + P32_5;
+    }
+    h += (uint32_t)len;
+    while (p + 4 <= end) { h = rotl32(h + rd32le(p) * P32_3, 17) * P32_4; p += 4; }
+    while (p < end) { h = rotl32(h + (*p) * P32_5, 11) * P32_1; p++; }
+    h ^= h >> 15; h *= P32_2; h ^= h >> 13; h *= P32_3; h ^= h >> 16;
+    return h;
+}
+
+/* CRC-32C (Castagnoli), table driven; Formats/../CRC32c.cs is the reference's own. */
+uint32_t oracle_crc32c(const void* data, size_t len) {
+    static uint32_t table[256]; static int init = 0;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78U : c >> 1;
+            table[i] = c;
+        }
+        init = 1;
+    }
+    uint32_t crc = 0xFFFFFFFFU; const uint8_t* p = (const uint8_t*)data;
+    for (size_t i = 0; i < len; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc ^ 0xFFFFFFFFU;
+}
+
+/* ============================================================ geometry */
+
+/* LzProperties(byte distanceBits, byte lengthBits, byte threshold)  LzProperties.cs:57-66 */
+void oracle_lz_properties_bits(uint8_t distance_bits, uint8_t length_bits, uint8_t threshold, alz_lz_properties* out) {
+    memset(out, 0, sizeof(*out));
+    out->window_bits = distance_bits;
+    out->length_bits = length_bits;
+    out->min_length = (uint8_t)(threshold + 1);
+    out->max_distance = 1u << distance_bits;
+    out->windows_start = out->max_distance - (1u << length_bits) - threshold;
+}
+
+static alz_lz_properties lzss_effective(const alz_lz_properties* p) {
+    alz_lz_properties d;
+    if (!p || p->window_bits == 0) oracle_lz_properties_bits(12, 4, 2, &d); /* LZSS.DefaultProperties LZSS.cs:33 */
+    else { d = *p; if (d.max_distance == 0) d.max_distance = 1u << d.window_bits; }
+    return d;
+}
+
+/* ============================================================ source cursor */
+
+typedef struct { const uint8_t* p; uint32_t len; uint32_t pos; int eof; } cur_t;
+
+/* Stream.ReadUInt8(): throws EndOfStreamException at EOF (AuroraLib.Core) */
+static inline int cur_u8(cur_t* c) { if (c->pos >= c->len) { c->eof = 1; return 0; } return c->p[c->pos++]; }
+/* Stream.ReadByte(): -1 at EOF */
+static inline int cur_byte(cur_t* c) { if (c->pos >= c->len) return -1; return c->p[c->pos++]; }
+
+/* ============================================================ LzWindows (IO/LzWindows.cs:15-280) */
+
+typedef struct {
+    int flat;           /* 0: ring + flush exactly as LzWindows; 1: flat out[q]=out[q-d] model */
+    uint8_t* ring; uint32_t W, mask, pos;
+    uint8_t* dst; uint64_t cap;
+    uint64_t flushed;   /* destination.Position (ring mode) / produced (flat mode) */
+    int overflow; uint64_t attempted_end;
+} win_t;
+
+static inline uint64_t win_produced(const win_t* w) { return w->flat ? w->flushed : w->flushed + w->pos; }
+
+/* E5: clip a token of `len` bytes against dst_cap */
+static inline uint32_t win_clip(win_t* w, uint64_t len) {
+    uint64_t pr = win_produced(w);
+    if (pr + len > w->cap) { w->overflow = 1; w->attempted_end = pr + len; return (uint32_t)(w->cap - pr); }
+    return (uint32_t)len;
+}
+
+/* FlushToDestination / _Destination.Write  LzWindows.cs:219,247 */
+static inline void ring_out(win_t* w, const uint8_t* buf, uint32_t len) {
+    memcpy(w->dst + w->flushed, buf, len); /* never beyond cap: tokens are clipped first */
+    w->flushed += len;
+}
+
+/* InternWrite  LzWindows.cs:192-227 */
+static void ring_intern_write(win_t* w, const uint8_t* src, uint32_t len) {
+    if (!len) return;
+    uint32_t pos = w->pos, W = w->W;
+    if (W > pos + len) {
+        memmove(w->ring + pos, src, len);
+        w->pos += len;
+    } else {
+        uint32_t left = W - pos, remaining = len - left;
+        if (left > 0) memmove(w->ring + pos, src, left);
+        ring_out(w, w->ring, W);
+        if (remaining != 0) memmove(w->ring, src + len - remaining, remaining);
+        w->pos = remaining;
+    }
+}
+
+/* BackCopy  LzWindows.cs:72-100 (len already clipped by the caller) */
+static void win_back_copy(win_t* w, uint32_t distance, uint32_t length) {
+    if (w->flat) {
+        uint32_t d = distance ? distance : w->W; /* E1 */
+        uint64_t q = w->flushed;
+        for (uint32_t i = 0; i < length; i++, q++) w->dst[q] = (q >= d) ? w->dst[q - d] : 0; /* E2 */
+        w->flushed = q;
+        return;
+    }
+    int64_t len = length;
+    while (len > 0) {
+        uint32_t chunk = (uint32_t)len;
+        uint32_t srcPos = (w->pos - distance) & w->mask;
+        if (distance < (uint32_t)len && distance != 0) chunk = distance;
+        if (srcPos + chunk > w->W) chunk = w->W - srcPos;
+        ring_intern_write(w, w->ring + srcPos, chunk);
+        len -= chunk;
+    }
+}
+
+/* OffsetCopy  LzWindows.cs:108-115 */
+static void win_offset_copy(win_t* w, uint32_t offset, uint32_t length) {
+    uint32_t pos = w->flat ? (uint32_t)(w->flushed & w->mask) : w->pos;
+    uint32_t distance = pos >= offset ? pos - offset : pos - offset + w->W;
+    win_back_copy(w, distance, length);
+}
+
+/* WriteByte  LzWindows.cs:232-237 */
+static inline void win_write_byte(win_t* w, uint8_t v) {
+    if (w->flat) { w->dst[w->flushed++] = v; return; }
+    w->ring[w->pos] = v;
+    w->pos = (w->pos + 1) & w->mask;
+    if (w->pos == 0) ring_out(w, w->ring, w->W);
+}
+
+/* Write(span)  LzWindows.cs:168-190 */
+static void win_write(win_t* w, const uint8_t* buf, uint32_t len) {
+    if (w->flat) { memcpy(w->dst + w->flushed, buf, len); w->flushed += len; return; }
+    uint32_t W = w->W;
+    if (len < W) { ring_intern_write(w, buf, len); return; }
+    uint32_t off = 0;
+    while (len - off >= W) { ring_intern_write(w, buf + off, W); off += W; }
+    if (off < len) ring_intern_write(w, buf + off, len - off);
+}
+
+/* CopyFrom(Stream, length)  LzWindows.cs:124-135; caller guarantees the input holds `length` bytes (E6) */
+static void win_copy_from(win_t* w, cur_t* c, uint32_t length) {
+    if (w->flat) { memcpy(w->dst + w->flushed, c->p + c->pos, length); w->flushed += length; c->pos += length; return; }
+    while (length != 0) {
+        uint32_t l = w->W - w->pos; if (length < l) l = length;
+        memcpy(w->ring + w->pos, c->p + c->pos, l); c->pos += l;
+        w->pos = (w->pos + l) & w->mask;
+        length -= l;
+        if (w->pos == 0) ring_out(w, w->ring, w->W);
+    }
+}
+
+/* Dispose  LzWindows.cs:269-278 */
+static void win_dispose(win_t* w) {
+    if (!w->flat && w->pos != 0) { ring_out(w, w->ring, w->pos); w->pos = 0; }
+}
+
+/* ============================================================ FlagReader (IO/FlagReader.cs:12-103), 8-bit flags */
+
+typedef struct { cur_t* c; int bits_left; int cur; int msb_first; } flag_t;
+
+/* Readbit  FlagReader.cs:53-65 */
+static inline int flag_readbit(flag_t* f) {
+    if (f->bits_left == 0) { f->cur = cur_u8(f->c); f->bits_left = 8; }
+    int shift = f->msb_first ? f->bits_left - 1 : 8 - f->bits_left;
+    f->bits_left--;
+    return (f->cur >> shift) & 1;
+}
+
+/* ============================================================ decoders */
+
+typedef struct { int has_size; int bad_token; uint32_t src_used; } dec_info;
+
+/* LZSS.DecompressHeaderless  Formats/Common/LZSS.cs:91-130 */
+static void dec_lzss(const alz_lz_properties* lz, cur_t* c, win_t* w, uint32_t size) {
+    flag_t flag = { c, 0, 0, 0 };                       /* FlagReader(source, Endian.Little)  :95 */
+    uint32_t f = (1u << lz->length_bits) - 1;            /* GetLengthBitsFlag */
+    uint32_t n = lz->max_distance - 1;                   /* GetWindowsFlag */
+    while (win_produced(w) < size) {                     /* :104 */
+        int bit = flag_readbit(&flag); if (c->eof) return;
+        if (bit) {
+            int b = cur_u8(c); if (c->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);               /* :107 */
+        } else {
+            int b1 = cur_u8(c); if (c->eof) return;
+            int b2 = cur_u8(c); if (c->eof) return;
+            uint32_t offset = ((uint32_t)(b2 >> lz->length_bits) << 8) | (uint32_t)b1;   /* :115 */
+            uint32_t length = ((uint32_t)b2 & f) + lz->min_length;                       /* :116 */
+            offset = (lz->max_distance + offset - lz->windows_start) & n;                /* :117 */
+            uint32_t cl = win_clip(w, length);
+            win_offset_copy(w, offset, cl);                                              /* :119 */
+            if (w->overflow) return;
+        }
+    }
+}
+
+/* LZ10.DecompressHeaderless  Nintendo/LZ10.cs:82-111 */
+static void dec_lz10(cur_t* c, win_t* w, uint32_t size) {
+    flag_t flag = { c, 0, 0, 1 };                        /* FlagReader(source, Endian.Big) :88 */
+    while (win_produced(w) < size) {
+        int bit = flag_readbit(&flag); if (c->eof) return;
+        if (bit) {
+            int b1 = cur_u8(c); if (c->eof) return;
+            int b2 = cur_u8(c); if (c->eof) return;
+            uint32_t distance = (uint32_t)(((b1 & 0xf) << 8) | b2) + 1;                  /* :96 */
+            uint32_t length = (uint32_t)(b1 >> 4) + 3;                                   /* :97 */
+            uint32_t cl = win_clip(w, length);
+            win_back_copy(w, distance, cl);
+            if (w->overflow) return;
+        } else {
+            int b = cur_u8(c); if (c->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);                                               /* :102 */
+        }
+    }
+}
+
+/* LZ11.DecompressHeaderless  Nintendo/LZ11.cs:83-133 */
+static void dec_lz11(cur_t* c, win_t* w, uint32_t size) {
+    flag_t flag = { c, 0, 0, 1 };
+    while (win_produced(w) < size) {
+        int bit = flag_readbit(&flag); if (c->eof) return;
+        if (bit) {
+            uint32_t distance, length;
+            int b1 = cur_u8(c); if (c->eof) return;
+            int b2 = cur_u8(c); if (c->eof) return;
+            if ((b1 >> 4) == 0) {                                                         /* :98-104 */
+                int b3 = cur_u8(c); if (c->eof) return;
+                distance = (uint32_t)(((b2 & 0xf) << 8) | b3) + 1;
+                length = (uint32_t)(((b1 & 0xf) << 4) | (b2 >> 4)) + 17;
+            } else if ((b1 >> 4) == 1) {                                                  /* :105-112 */
+                int b3 = cur_u8(c); if (c->eof) return;
+                int b4 = cur_u8(c); if (c->eof) return;
+                distance = (uint32_t)(((b3 & 0xf) << 8) | b4) + 1;
+                length = (uint32_t)(((b1 & 0xf) << 12) | (b2 << 4) | (b3 >> 4)) + 273;
+            } else {                                                                      /* :113-118 */
+                distance = (uint32_t)(((b1 & 0xf) << 8) | b2) + 1;
+                length = (uint32_t)(b1 >> 4) + 1;
+            }
+            uint32_t cl = win_clip(w, length);
+            win_back_copy(w, distance, cl);
+            if (w->overflow) return;
+        } else {
+            int b = cur_u8(c); if (c->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);
+        }
+    }
+}
+
+/* Yay0.DecompressHeaderless(FlagReader, compressed, uncompressed, dest, len)  Nintendo/Yay0.cs:110-144.
+ * Yaz0 passes the same stream for all three cursors (Yaz0.cs:91-92). */
+static void dec_yay0(cur_t* fc, cur_t* cc, cur_t* uc, win_t* w, uint32_t size) {
+    flag_t flag = { fc, 0, 0, 1 };
+    while (win_produced(w) < size) {
+        int bit = flag_readbit(&flag); if (fc->eof) return;
+        if (bit) {
+            int b = cur_u8(uc); if (uc->eof) return;                                     /* :120 */
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);
+        } else {
+            int b1 = cur_u8(cc); if (cc->eof) return;
+            int b2 = cur_u8(cc); if (cc->eof) return;
+            uint32_t distance = (uint32_t)(((b1 & 0x0F) << 8) | b2) + 1;                 /* :127 */
+            int length = b1 >> 4;
+            if (length == 0) length = cur_byte(uc) + 0x12;   /* ReadByte(): -1 at EOF => 17   :130-131 */
+            else length += 2;                                                            /* :133 */
+            uint32_t cl = win_clip(w, (uint32_t)length);
+            win_back_copy(w, distance, cl);
+            if (w->overflow) return;
+        }
+    }
+}
+
+/* MIO0.DecompressHeaderless(ReadOnlySpan<byte>, ...)  Nintendo/MIO0.cs:105-149 */
+static void dec_mio0(cur_t* c, win_t* w, uint32_t size, uint32_t cptr, uint32_t uptr, uint32_t* used) {
+    uint32_t fptr = 0; int maskBits = 0, mask = 0;
+    while (win_produced(w) < size) {
+        if (maskBits == 0) {
+            if (fptr >= c->len) { c->eof = 1; break; }
+            mask = c->p[fptr++]; maskBits = 8;                                           /* :117-121 */
+        }
+        if ((mask & 0x80) == 0x80) {
+            if (uptr >= c->len) { c->eof = 1; break; }
+            uint8_t b = c->p[uptr++];
+            if (win_clip(w, 1) < 1) break;
+            win_write_byte(w, b);                                                        /* :125 */
+        } else {
+            if (cptr >= c->len) { c->eof = 1; break; }
+            int b1 = c->p[cptr++];
+            if (cptr >= c->len) { c->eof = 1; break; }
+            int b2 = c->p[cptr++];
+            uint32_t distance = (uint32_t)(((b1 & 0x0F) << 8) | b2) + 1;                 /* :133 */
+            uint32_t length = (uint32_t)(b1 >> 4) + 3;                                   /* :134 */
+            uint32_t cl = win_clip(w, length);
+            win_back_copy(w, distance, cl);
+            if (w->overflow) break;
+        }
+        mask <<= 1; maskBits--;                                                          /* :140-141 */
+    }
+    *used = cptr > uptr ? cptr : uptr;                                                   /* :148 */
+}
+
+/* PRS.DecompressHeaderless(Stream, Stream, Endian)  Sega/PRS.cs:59-102.  Returns 1 when the terminator was read. */
+static int dec_prs(cur_t* c, win_t* w, int big) {
+    flag_t flag = { c, 0, 0, big };                      /* FlagReader(source, order): bit order = byte order :62 */
+    while (c->pos < c->len) {                            /* :64 */
+        int bit = flag_readbit(&flag); if (c->eof) return 0;
+        if (bit) {
+            int b = cur_u8(c); if (c->eof) return 0;
+            if (win_clip(w, 1) < 1) return 0;
+            win_write_byte(w, (uint8_t)b);                                               /* :68 */
+        } else {
+            int distance, length;
+            int bit2 = flag_readbit(&flag); if (c->eof) return 0;
+            if (bit2) {
+                int x0 = cur_u8(c); if (c->eof) return 0;
+                int x1 = cur_u8(c); if (c->eof) return 0;
+                distance = big ? ((x0 << 8) | x1) : ((x1 << 8) | x0);                    /* ReadUInt16(order) :75 */
+                if (distance == 0) return 1;                                             /* :77-80 */
+                length = distance & 7;
+                distance = 0x2000 - (distance >> 3);                                     /* :83 */
+                if (length == 0) { int e = cur_u8(c); if (c->eof) return 0; length = e + 1; } /* :86 */
+                else length += 2;                                                        /* :90 */
+            } else {
+                int v = 0;                                                               /* ReadInt(2, true) FlagReader.cs:88-98 */
+                for (int i = 0; i < 2; i++) { v <<= 1; int b = flag_readbit(&flag); if (c->eof) return 0; if (b) v |= 1; }
+                length = v + 2;                                                          /* :95 */
+                int e = cur_u8(c); if (c->eof) return 0;
+                distance = 0x100 - e;                                                    /* :96 */
+            }
+            uint32_t cl = win_clip(w, (uint32_t)length);
+            win_back_copy(w, (uint32_t)distance, cl);
+            if (w->overflow) return 0;
+        }
+    }
+    c->eof = 1;                                          /* throw new EndOfStreamException() :101 */
+    return 0;
+}
+
+/* LZ4.DecompressBlockHeaderless(ReadOnlySpan<byte>, LzWindows)  Formats/Common/LZ4.cs:176-200 */
+static void dec_lz4(cur_t* c, win_t* w) {
+    const uint8_t* s = c->p; uint32_t n = c->len; uint32_t sp = 0;
+    while (sp < n) {
+        uint32_t token = s[sp++];
+        uint64_t plain = token >> 4;
+        if (plain == 0xF) {                              /* ReadExtension :241-252 */
+            uint32_t b;
+            do { if (sp >= n) { c->eof = 1; c->pos = sp; return; } b = s[sp++]; plain += b; } while (b == 255);
+        }
+        if (plain > (uint64_t)(n - sp)) { c->eof = 1; c->pos = sp; return; }            /* Slice throws :187 */
+        uint32_t cl = win_clip(w, plain);
+        win_write(w, s + sp, cl);
+        if (w->overflow) { c->pos = sp; return; }
+        sp += (uint32_t)plain;
+        if (sp >= n) break;                                                              /* :190 */
+        uint64_t mlen = token & 0xF;
+        if (sp + 2 > n) { c->eof = 1; c->pos = sp; return; }
+        uint32_t dist = (uint32_t)s[sp] | ((uint32_t)s[sp + 1] << 8); sp += 2;          /* :195 */
+        if (mlen == 0xF) {
+            uint32_t b;
+            do { if (sp >= n) { c->eof = 1; c->pos = sp; return; } b = s[sp++]; mlen += b; } while (b == 255);
+        }
+        cl = win_clip(w, mlen + 4);
+        win_back_copy(w, dist, cl);                                                      /* :198 */
+        if (w->overflow) { c->pos = sp; return; }
+    }
+    c->pos = sp;
+}
+
+/* LZO.ReadExtendedInt  Formats/Common/LZO.cs:252-262 */
+static uint32_t lzo_ext(cur_t* c) {
+    int b; uint32_t length = 0;
+    while ((b = cur_byte(c)) == 0) length += 255;
+    if (b == -1) { c->eof = 1; return 0; }
+    return length + (uint32_t)b;
+}
+
+/* LZO.DecompressHeaderless  Formats/Common/LZO.cs:49-139.  Returns 1 when the end marker was read. */
+static int dec_lzo(cur_t* c, win_t* w) {
+    int flag; uint32_t length, distance, plain = 0;
+    flag = cur_byte(c); if (flag < 0) { c->eof = 1; return 0; }                          /* :56 (E6) */
+    if (flag > 17) {                                                                     /* :59-64 */
+        length = (uint32_t)flag - 17;
+        if (length > c->len - c->pos) { c->eof = 1; return 0; }
+        uint32_t cl = win_clip(w, length);
+        win_copy_from(w, c, cl);
+        if (w->overflow) return 0;
+        flag = cur_byte(c); if (flag < 0) { c->eof = 1; return 0; }
+    }
+    do {
+        int flagcode = flag >> 4;
+        if (flagcode == 0) {
+            if (plain == 0) {                                                            /* :72-82 */
+                length = 3 + (uint32_t)flag;
+                if (length == 3) { length = 18 + lzo_ext(c); if (c->eof) return 0; }
+                plain = 4;
+                if (length > c->len - c->pos) { c->eof = 1; return 0; }
+                uint32_t cl = win_clip(w, length);
+                win_copy_from(w, c, cl);
+                if (w->overflow) return 0;
+                continue;
+            } else if (plain <= 3) {                                                     /* :83-88 */
+                int d = cur_byte(c); if (d < 0) { c->eof = 1; return 0; }
+                distance = ((uint32_t)d << 2) + ((uint32_t)flag >> 2) + 1;
+                length = 2;
+            } else {                                                                     /* :89-94 */
+                int d = cur_byte(c); if (d < 0) { c->eof = 1; return 0; }
+                distance = ((uint32_t)d << 2) + ((uint32_t)flag >> 2) + (2048 + 1);
+                length = 3;
+            }
+        } else if (flagcode == 1) {                                                      /* :96-109 */
+            length = 2 + ((uint32_t)flag & 0x7);
+            if (length == 2) { length = 9 + lzo_ext(c); if (c->eof) return 0; }
+            distance = 16384 + (((uint32_t)flag & 0x8) << 11);
+            flag = cur_byte(c); if (flag < 0) { c->eof = 1; return 0; }
+            int hi = cur_byte(c); if (hi < 0) { c->eof = 1; return 0; }
+            distance |= ((uint32_t)hi << 6) | ((uint32_t)flag >> 2);
+            if (distance == 16384) return 1;
+        } else if (flagcode <= 3) {                                                      /* :110-119 */
+            length = 2 + ((uint32_t)flag & 0x1f);
+            if (length == 2) { length = 33 + lzo_ext(c); if (c->eof) return 0; }
+            flag = cur_byte(c); if (flag < 0) { c->eof = 1; return 0; }
+            int hi = cur_byte(c); if (hi < 0) { c->eof = 1; return 0; }
+            distance = (((uint32_t)hi << 6) | ((uint32_t)flag >> 2)) + 1;
+        } else if (flagcode <= 7) {                                                      /* :120-125 */
+            length = 3 + (((uint32_t)flag >> 5) & 0x1);
+            int d = cur_byte(c); if (d < 0) { c->eof = 1; return 0; }
+            distance = ((uint32_t)d << 3) + (((uint32_t)flag >> 2) & 0x7) + 1;
+        } else {                                                                         /* :126-131 */
+            length = 5 + (((uint32_t)flag >> 5) & 0x3);
+            int d = cur_byte(c); if (d < 0) { c->eof = 1; return 0; }
+            distance = ((uint32_t)d << 3) + (((uint32_t)flag & 0x1c) >> 2) + 1;
+        }
+        plain = (uint32_t)flag & 0x3;                                                    /* :132 */
+        uint32_t cl = win_clip(w, length);
+        win_back_copy(w, distance, cl);                                                  /* :133 */
+        if (w->overflow) return 0;
+        if (plain > c->len - c->pos) { c->eof = 1; return 0; }
+        cl = win_clip(w, plain);
+        win_copy_from(w, c, cl);                                                         /* :134 */
+        if (w->overflow) return 0;
+    } while ((flag = cur_byte(c)) != -1);                                                /* :136 */
+    c->eof = 1;                                                                          /* :137 */
+    return 0;
+}
+
+/* Snappy.ReadDecompressedSize  Formats/Common/Snappy.cs:109-122 */
+static uint32_t snappy_varint(cur_t* c) {
+    uint32_t result = 0; int shift = 0; int b = -1;
+    while ((b & 0x80) != 0) {
+        b = cur_u8(c); if (c->eof) return 0;
+        result |= (uint32_t)(b & 0x7F) << (shift & 31);  /* C# masks the shift count */
+        shift += 7;
+    }
+    return result;
+}
+
+/* Snappy.DecompressHeaderless  Formats/Common/Snappy.cs:205-250 */
+static void dec_snappy(cur_t* c, win_t* w, dec_info* info) {
+    uint32_t size = snappy_varint(c); if (c->eof) return;
+    while (win_produced(w) < size) {
+        int tag = cur_byte(c); if (tag < 0) { c->eof = 1; return; }
+        int type = tag & 3; uint32_t length = (uint32_t)tag >> 2; uint32_t distance;
+        if (type == 0) {                                                                 /* :221-234 */
+            if (length >= 60) {
+                int lenBytes = (int)length - 59; length = 0;
+                for (int i = 0; i < lenBytes; i++) { int b = cur_byte(c); if (b < 0) { c->eof = 1; return; } length |= (uint32_t)b << (8 * i); }
+            }
+            uint32_t run = length + 1;                     /* CopyFrom(source, length + 1) */
+            if (run > c->len - c->pos) { c->eof = 1; return; }
+            uint32_t cl = win_clip(w, run);
+            win_copy_from(w, c, cl);
+            if (w->overflow) return;
+            continue;
+        } else if (type == 1) {                                                          /* :235-239 */
+            length = (length & 0x7) + 3;
+            int b = cur_byte(c); if (b < 0) { c->eof = 1; return; }
+            distance = (((uint32_t)tag >> 5) << 8) | (uint32_t)b;
+        } else if (type == 2) {                                                          /* :240-243 */
+            int b0 = cur_u8(c); if (c->eof) return;
+            int b1 = cur_u8(c); if (c->eof) return;
+            distance = (uint32_t)b0 | ((uint32_t)b1 << 8);
+        } else {                                                                         /* :244-247 */
+            if (c->len - c->pos < 4) { c->eof = 1; return; }
+            distance = rd32le(c->p + c->pos); c->pos += 4;
+            if (distance > w->W) { info->bad_token = 1; return; }                        /* E3 */
+        }
+        uint32_t cl = win_clip(w, length + 1);
+        win_back_copy(w, distance, cl);                                                  /* :248 */
+        if (w->overflow) return;
+    }
+}
+
+static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
+    switch (format) {
+    case ALZ_FMT_LZSS: return lz->window_bits;
+    case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: return 12; /* LZ10.cs:25 ... */
+    case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
+    case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
+    default: return 12;
+    }
+}
+
+static void decode_one(const alz_lz_properties* props, const alz_stream* s, const uint8_t* src_base, uint8_t* dst_base,
+                       alz_result* r, int flat) {
+    alz_lz_properties lz = lzss_effective(props);
+    cur_t c = { src_base + s->src_off, s->src_len, 0, 0 };
+    win_t w; memset(&w, 0, sizeof(w));
+    int wb = fmt_window_bits(s->format, &lz);
+    w.flat = flat; w.W = 1u << wb; w.mask = w.W - 1;
+    w.dst = dst_base + s->dst_off; w.cap = s->dst_cap;
+    if (!flat) w.ring = (uint8_t*)calloc(w.W, 1); /* E2: zero-filled */
+    dec_info info = { 0, 0, 0 };
+    int terminated = 1; uint32_t used = 0; int used_set = 0;
+    uint32_t size = s->decom_len;
+
+    switch (s->format) {
+    case ALZ_FMT_LZSS: info.has_size = 1; dec_lzss(&lz, &c, &w, size); break;
+    case ALZ_FMT_LZ10: info.has_size = 1; dec_lz10(&c, &w, size); break;
+    case ALZ_FMT_LZ11: info.has_size = 1; dec_lz11(&c, &w, size); break;
+    case ALZ_FMT_YAZ0: info.has_size = 1; dec_yay0(&c, &c, &c, &w, size); break;
+    case ALZ_FMT_YAY0: {
+        info.has_size = 1;
+        if (s->aux0 > s->src_len || s->aux1 > s->src_len) { c.eof = 1; break; }        /* Slice throws  Yay0.cs:102-103 */
+        cur_t cc = { c.p + s->aux0, s->src_len - s->aux0, 0, 0 };
+        cur_t uc = { c.p + s->aux1, s->src_len - s->aux1, 0, 0 };
+        dec_yay0(&c, &cc, &uc, &w, size);
+        if (cc.eof || uc.eof) c.eof = 1;
+        uint32_t a = s->aux0 + cc.pos, b = s->aux1 + uc.pos;                             /* Yay0.cs:107 */
+        used = a > b ? a : b; used_set = 1;
+        break;
+    }
+    case ALZ_FMT_MIO0: info.has_size = 1; dec_mio0(&c, &w, size, s->aux0, s->aux1, &used); used_set = 1; break;
+    case ALZ_FMT_PRS_BE: terminated = dec_prs(&c, &w, 1); break;
+    case ALZ_FMT_PRS_LE: terminated = dec_prs(&c, &w, 0); break;
+    case ALZ_FMT_LZ4_BLOCK: dec_lz4(&c, &w); break;
+    case ALZ_FMT_LZO: terminated = dec_lzo(&c, &w); break;
+    case ALZ_FMT_SNAPPY_RAW: dec_snappy(&c, &w, &info); break;
+    default: info.bad_token = 1; break;
+    }
+    (void)terminated;
+    win_dispose(&w);
+    if (!flat) free(w.ring);
+
+    uint64_t produced = win_produced(&w);
+    r->dst_len = (uint32_t)produced;
+    r->src_used = used_set ? used : c.pos;
+    r->reserved = 0;
+    if (c.eof) r->status = ALZ_ST_INPUT_TRUNCATED;
+    else if (info.bad_token) r->status = ALZ_ST_BAD_TOKEN;
+    else if (w.overflow)
+        r->status = (info.has_size && w.attempted_end > size && w.cap >= size) ? ALZ_ST_OUTPUT_SIZE_MISMATCH : ALZ_ST_OUTPUT_CAPACITY;
+    else if (info.has_size && produced > size) r->status = ALZ_ST_OUTPUT_SIZE_MISMATCH; /* LZ10.cs:107 '>' ; LZSS.cs:126 '!=' (same: loop ran to >= size) */
+    else r->status = ALZ_ST_OK;
+}
+
+void oracle_decode_stream(const alz_lz_properties* props, const alz_stream* s, const uint8_t* src_base, uint8_t* dst_base, alz_result* r) {
+    decode_one(props, s, src_base, dst_base, r, 0);
+}
+void oracle_decode_stream_flat(const alz_lz_properties* props, const alz_stream* s, const uint8_t* src_base, uint8_t* dst_base, alz_result* r) {
+    decode_one(props, s, src_base, dst_base, r, 1);
+}
+
+/* ---- batch over host threads (streams striped) ---- */
+typedef struct {
+    const alz_lz_properties* props; const alz_settings* settings; uint32_t n; const uint8_t* src_base; const alz_stream* streams;
+    uint8_t* dst_base; alz_result* results; alz_encode_aux* aux; int tid, nthreads; int encode;
+} job_t;
+
+static void* batch_worker(void* arg) {
+    job_t* j = (job_t*)arg;
+    for (uint32_t i = (uint32_t)j->tid; i < j->n; i += (uint32_t)j->nthreads) {
+        const alz_stream* s = &j->streams[i];
+        if (!j->encode) {
+            decode_one(j->props, s, j->src_base, j->dst_base, &j->results[i], 0);
+        } else {
+            alz_encode_aux a = { 0, 0 };
+            int64_t sz = oracle_encode_stream(s->format, j->props, j->settings, j->src_base + s->src_off, s->src_len,
+                                              j->dst_base + s->dst_off, s->dst_cap, &a);
+            j->results[i].dst_len = sz < 0 ? 0 : (uint32_t)sz;
+            j->results[i].src_used = s->src_len;
+            j->results[i].status = sz == -1 ? ALZ_ST_OUTPUT_CAPACITY : sz < 0 ? ALZ_ST_BAD_TOKEN : ALZ_ST_OK;
+            j->results[i].reserved = 0;
+            if (j->aux) j->aux[i] = a;
+        }
+    }
+    return NULL;
+}
+
+static int run_batch(job_t* proto) {
+    int nt = proto->nthreads < 1 ? 1 : proto->nthreads;
+    if (nt > 256) nt = 256;
+    if (nt == 1) { proto->tid = 0; proto->nthreads = 1; batch_worker(proto); return 0; }
+    pthread_t th[256]; job_t jobs[256];
+    for (int t = 0; t < nt; t++) { jobs[t] = *proto; jobs[t].tid = t; jobs[t].nthreads = nt; pthread_create(&th[t], NULL, batch_worker, &jobs[t]); }
+    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+    return 0;
+}
+
+int oracle_decode_batch(const alz_lz_properties* props, uint32_t n, const uint8_t* src_base, const alz_stream* streams,
+                        uint8_t* dst_base, alz_result* results, int nthreads) {
+    job_t j = { props, NULL, n, src_base, streams, dst_base, results, NULL, 0, nthreads, 0 };
+    return run_batch(&j);
+}
+
+int oracle_encode_batch(const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
+                        const alz_stream* streams, uint8_t* dst_base, alz_result* results, alz_encode_aux* aux, int nthreads) {
+    job_t j = { props, settings, n, src_base, streams, dst_base, results, aux, 0, nthreads, 1 };
+    return run_batch(&j);
+}
+
+/* ============================================================ encoder side */
+
+typedef struct { uint8_t* p; size_t len, cap; int fail; int owned; } buf_t;
+
+static void buf_put(buf_t* b, const void* data, size_t n) {
+    if (b->fail) return;
+    if (b->len + n > b->cap) {
+        if (!b->owned) { b->fail = 1; return; }
+        size_t nc = b->cap ? b->cap * 2 : 256; while (nc < b->len + n) nc *= 2;
+        b->p = (uint8_t*)realloc(b->p, nc); b->cap = nc;
+    }
+    memcpy(b->p + b->len, data, n); b->len += n;
+}
+static inline void buf_u8(buf_t* b, uint32_t v) { uint8_t x = (uint8_t)v; buf_put(b, &x, 1); }
+static inline void buf_u16be(buf_t* b, uint32_t v) { uint8_t x[2] = { (uint8_t)(v >> 8), (uint8_t)v }; buf_put(b, x, 2); }
+static inline void buf_u16le(buf_t* b, uint32_t v) { uint8_t x[2] = { (uint8_t)v, (uint8_t)(v >> 8) }; buf_put(b, x, 2); }
+static inline void buf_u32be(buf_t* b, uint32_t v) { uint8_t x[4] = { (uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v }; buf_put(b, x, 4); }
+static inline void buf_u32le(buf_t* b, uint32_t v) { uint8_t x[4] = { (uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24) }; buf_put(b, x, 4); }
+static buf_t buf_owned(void) { buf_t b = { NULL, 0, 0, 0, 1 }; return b; }
+static void buf_free(buf_t* b) { if (b->owned) free(b->p); b->p = NULL; }
+
+/* FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags) */
+typedef struct { buf_t* base; buf_t buffer; int bits_left; int cur; int msb_first; } fw_t;
+
+static void fw_init(fw_t* f, buf_t* base, int msb_first) { f->base = base; f->buffer = buf_owned(); f->bits_left = 8; f->cur = 0; f->msb_first = msb_first; }
+/* Flush  FlagWriter.cs:111-127 */
+static void fw_flush(fw_t* f) {
+    if (f->bits_left != 8) { buf_u8(f->base, (uint32_t)f->cur); f->bits_left = 8; f->cur = 0; }
+    if (f->buffer.len != 0) { buf_put(f->base, f->buffer.p, f->buffer.len); f->buffer.len = 0; }
+}
+/* WriteBit  FlagWriter.cs:70-80 */
+static void fw_bit(fw_t* f, int bit) {
+    if (bit) { int shift = f->msb_first ? f->bits_left - 1 : 8 - f->bits_left; f->cur |= 1 << shift; }
+    f->bits_left--;
+    if (f->bits_left == 0) fw_flush(f);
+}
+/* FlushIfNecessary  FlagWriter.cs:132-139 */
+static void fw_flush_if_necessary(fw_t* f) {
+    if (f->bits_left == 8 && f->buffer.len != 0) { buf_put(f->base, f->buffer.p, f->buffer.len); f->buffer.len = 0; }
+}
+static void fw_dispose(fw_t* f) { fw_flush(f); buf_free(&f->buffer); }
+
+/* LzChainMatchFinder  MatchFinder/LzChainMatchFinder.cs:13-372 */
+typedef struct {
+    int minLen, maxLen, minDist, maxDist;
+    int chainMask, hashBits, hashMask, maxChain; uint32_t minMask;
+    int lazy, noSelfOverlap;
+    int* head; int* chain; int* minTable;
+    int position;
+} mf_t;
+
+typedef struct { int offset, distance, length; } lzmatch_t;
+typedef struct { int windowBits, maxLen, minLen, maxDist, minDist; } fmt_props;
+
+static int isqrt_floor(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) r++; return r; }
+
+/* GetMaxChain  LzChainMatchFinder.cs:111-119 */
+static int mf_max_chain(int q) {
+    if (q < 6) return q + 1;
+    if (q >= 11) return 1 << (q - 5);
+    int b = 1 << (q >> 1);
+    return b | (b >> (q & 1));
+}
+
+/* Reset  LzChainMatchFinder.cs:125-132 */
+static void mf_reset(mf_t* m) {
+    m->position = 0;
+    for (int i = 0; i <= m->hashMask; i++) m->head[i] = -1;
+    if (m->maxChain != 1) for (int i = 0; i <= m->chainMask; i++) m->chain[i] = -1;
+    if (m->minTable) for (int i = 0; i < 65536; i++) m->minTable[i] = -1;
+}
+
+/* ctor  LzChainMatchFinder.cs:42-109 */
+static void mf_init(mf_t* m, const fmt_props* p, const alz_settings* st) {
+    int q = st ? st->quality : 8;
+    memset(m, 0, sizeof(*m));
+    m->minLen = p->minLen; m->maxLen = p->maxLen; m->minDist = p->minDist; m->maxDist = p->maxDist;
+    int windowsBits = p->windowBits;
+    int maxWindowBits = st ? st->max_window_bits : 0;
+    if (maxWindowBits != 0) {
+        if (windowsBits < maxWindowBits) windowsBits = maxWindowBits;
+        if (m->maxDist < (1 << maxWindowBits)) m->maxDist = 1 << maxWindowBits;
+    }
+    m->lazy = 3 + q / 3;
+    m->noSelfOverlap = st ? (st->strategy & 1) : 0;
+    m->hashBits = 15 + isqrt_floor(2 * q);
+    m->hashMask = (1 << m->hashBits) - 1;
+    m->head = (int*)malloc(sizeof(int) << m->hashBits);
+    m->maxChain = mf_max_chain(q);
+    if (m->maxChain == 1) { m->chain = NULL; m->chainMask = 0; }
+    else {
+        int cb = 17 + isqrt_floor(2 * q); if (cb > windowsBits) cb = windowsBits;
+        m->chain = (int*)malloc(sizeof(int) << cb); m->chainMask = (1 << cb) - 1;
+    }
+    if (q >= 10 && m->minLen < 4) { m->minMask = 0xFFFFFFFFu >> ((4 - m->minLen) * 8); m->minTable = (int*)malloc(sizeof(int) * 65536); }
+    mf_reset(m);
+}
+static void mf_free(mf_t* m) { free(m->head); free(m->chain); free(m->minTable); }
+
+/* ComputeHash  LzChainMatchFinder.cs:288-299 */
+static inline void mf_hash(const mf_t* m, const uint8_t* d, int* h4, int* hm) {
+    uint32_t v = rd32le(d); uint32_t mn = v & m->minMask;
+    v *= 2654435761u; mn *= 2654435761u;
+    *h4 = (int)(v >> (32 - m->hashBits)) & m->hashMask;
+    *hm = (int)((mn >> 16) & 0xFFFF);
+}
+static inline int mf_next(const mf_t* m, int pos) { return m->chain ? m->chain[pos & m->chainMask] : -1; } /* GetNext :285, NoChainTable :41 */
+/* Insert  :134-144 */
+static inline void mf_insert(mf_t* m, int pos, int h4, int hm) {
+    if (m->chainMask != 0) m->chain[pos & m->chainMask] = m->head[h4];
+    m->head[h4] = pos;
+    if (m->minTable) m->minTable[hm] = pos;
+}
+/* GetMatchLength  :338-357 */
+static inline int mf_match_len(const uint8_t* a, const uint8_t* b, int max) {
+    int len = 0;
+    while (len + 8 <= max) {
+        uint64_t diff = rd64le(a + len) ^ rd64le(b + len);
+        if (diff != 0) return len + (__builtin_ctzll(diff) >> 3);
+        len += 8;
+    }
+    while (len < max && a[len] == b[len]) len++;
+    return len;
+}
+/* ScoreMatch (single LzProperties)  :301-308 */
+static inline int mf_score(const mf_t* m, int* len, int dist) {
+    if (m->noSelfOverlap && *len > dist) *len = dist;
+    return *len - m->minLen;
+}
+
+/* MatchSearch  :214-246 (ChainMatches :248-282 inlined) */
+static void mf_search(mf_t* m, const uint8_t* data, int dataLength, int pos, int attempts, int* bestDistance, int* bestLength) {
+    const uint8_t* dp = data + pos; int h4, hm;
+    mf_hash(m, dp, &h4, &hm);
+    int cur = m->head[h4];
+    int bestPossible = dataLength - pos; if (bestPossible > m->maxLen) bestPossible = m->maxLen;
+    *bestDistance = 0; *bestLength = 0; int bestScore = -1;
+    while (cur != -1 && attempts-- > 0) {
+        int distance = pos - cur;
+        if (distance > m->maxDist) break;
+        if (distance < m->minDist) { cur = mf_next(m, cur); continue; }
+        int len = mf_match_len(dp, data + cur, bestPossible);
+        int score = mf_score(m, &len, distance);
+        if (score > bestScore) {
+            bestScore = score; *bestLength = len; *bestDistance = distance;
+            if (*bestLength == bestPossible) break;
+        }
+        cur = mf_next(m, cur);
+    }
+    if (*bestLength == 0 && m->minTable) {                                               /* :226-243 */
+        cur = m->minTable[hm];
+        if (cur != -1) {
+            int distance = pos - cur;
+            if (distance < m->minDist) distance = m->minDist;
+            /* oracle guard: the reference would read before the span when pos < distance (undefined) */
+            if (distance <= m->maxDist && pos - distance >= 0) {
+                *bestLength = mf_match_len(dp, data + pos - distance, bestPossible);
+                (void)mf_score(m, bestLength, distance);
+                *bestDistance = distance;
+            }
+        }
+    }
+    mf_insert(m, pos, h4, hm);
+}
+
+/* FindNextBestMatch  :157-212 */
+static lzmatch_t mf_find(mf_t* m, const uint8_t* data, int length) {
+    int limit = length - 4;
+    while (m->position <= limit) {
+        int bestDistance, bestLength;
+        mf_search(m, data, length, m->position, m->maxChain, &bestDistance, &bestLength);
+        if (bestLength < m->minLen) { m->position++; continue; }
+        int skip = 0;
+        if (bestLength <= m->lazy && m->position + 1 <= limit) {
+            int nextPos = m->position + 1, nd, nl;
+            mf_search(m, data, length, nextPos, m->maxChain, &nd, &nl);
+            if (nl > bestLength) { bestLength = nl; bestDistance = nd; m->position = nextPos; }
+            else skip++;
+        }
+        lzmatch_t match = { m->position, bestDistance, bestLength };
+        int end = m->position + bestLength;
+        m->position++;
+        m->position += skip;
+        while (m->position < end && m->position <= limit) {
+            int h4, hm; mf_hash(m, data + m->position, &h4, &hm);
+            mf_insert(m, m->position, h4, hm); m->position++;
+        }
+        return match;
+    }
+    m->position = length;
+    lzmatch_t end = { length, 0, 0 };
+    return end;
+}
+
+/* per-format LzProperties */
+static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const alz_settings* st) {
+    fmt_props p = { 12, 18, 3, 0x1000, 1 };
+    switch (format) {
+    case ALZ_FMT_LZSS: {
+        alz_lz_properties lz = lzss_effective(lzp);
+        p.windowBits = lz.window_bits; p.minLen = lz.min_length;
+        p.maxLen = (1 << lz.length_bits) + lz.min_length - 1; p.maxDist = (int)lz.max_distance; p.minDist = 1; break;
+    }
+    case ALZ_FMT_LZ10: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                   /* LZ10.cs:25 */
+    case ALZ_FMT_LZ11: p = (fmt_props){ 12, 0x4000, 3, 0x1000, 1 }; break;               /* LZ11.cs:25 */
+    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: p = (fmt_props){ 12, 0xff + 0x12, 3, 0x1000, 1 }; break; /* Yay0.cs:27 */
+    case ALZ_FMT_MIO0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                   /* MIO0.cs:28 */
+    case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: p = (fmt_props){ 13, 0x100, 2, 0x1FFF, 1 }; break; /* PRS.cs:21 */
+    case ALZ_FMT_LZ4_BLOCK: p = (fmt_props){ 16, 0x7FFFFFFF, 4, 0xFFFF, 1 }; break;      /* LZ4.cs:29 */
+    case ALZ_FMT_LZO: p = (fmt_props){ 16, 0x7FFFFFFF, 3, 0xBFFF, 1 }; break;            /* LZO.cs:24 */
+    case ALZ_FMT_SNAPPY_RAW: p = (fmt_props){ 15, 64, 4, 0x8000, 1 }; break;             /* Snappy.cs:28 */
+    default: break;
+    }
+    if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
+    return p;
+}
+
+/* LZSS.CompressHeaderless  LZSS.cs:132-160 */
+static void enc_lzss(const alz_lz_properties* lzp, const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    alz_lz_properties lz = lzss_effective(lzp);
+    fmt_props p = props_for(ALZ_FMT_LZSS, lzp, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 0);
+    int sp = 0; uint32_t nmask = lz.max_distance - 1, f = (1u << lz.length_bits) - 1;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 1); }
+        if (match.length == 0) break;
+        uint32_t offset = (lz.windows_start + (uint32_t)sp - (uint32_t)match.distance) & nmask;
+        uint32_t v = (offset & 0xFF) | ((offset & 0xFF00) << lz.length_bits) | ((((uint32_t)match.length - lz.min_length) & f) << 8);
+        buf_u16le(&flag.buffer, v & 0xFFFF);
+        fw_bit(&flag, 0);
+        sp += match.length;
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
+/* LZ10.CompressHeaderless  LZ10.cs:113-137 */
+static void enc_lz10(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_LZ10, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 1);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 0); }
+        if (match.length == 0) break;
+        buf_u16be(&flag.buffer, (uint32_t)(((match.length - 3) << 12) | ((match.distance - 1) & 0xFFF)) & 0xFFFF);
+        sp += match.length;
+        fw_bit(&flag, 1);
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
+/* LZ11.CompressHeaderless  LZ11.cs:135-171 */
+static void enc_lz11(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_LZ11, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 1);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 0); }
+        if (match.length == 0) break;
+        if (match.length <= 16) {
+            buf_u16be(&flag.buffer, (uint32_t)(((match.length - 1) << 12) | ((match.distance - 1) & 0xFFF)) & 0xFFFF);
+        } else if (match.length <= 272) {
+            buf_u8(&flag.buffer, (uint32_t)(((match.length - 17) & 0xFF) >> 4));
+            buf_u16be(&flag.buffer, (uint32_t)(((match.length - 17) << 12) | ((match.distance - 1) & 0xFFF)) & 0xFFFF);
+        } else {
+            buf_u32be(&flag.buffer, 0x10000000u | ((uint32_t)((match.length - 273) & 0xFFFF) << 12) | (uint32_t)((match.distance - 1) & 0xFFF));
+        }
+        sp += match.length;
+        fw_bit(&flag, 1);
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
+/* Yay0.CompressHeaderless(source, compressedData, uncompressedData, FlagWriter, settings)  Yay0.cs:152-184.
+ * Yaz0 passes flag.Buffer for both data streams (Yaz0.cs:94-98). */
+static void enc_yay0_core(const alz_settings* st, const uint8_t* src, int n, buf_t* comp, buf_t* uncomp, fw_t* flag, uint32_t format) {
+    fmt_props p = props_for(format, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(uncomp, src[sp++]); fw_bit(flag, 1); }
+        if (match.length == 0) break;
+        if (match.length < 18) {
+            buf_u16be(comp, (uint32_t)((match.distance - 1) | ((match.length - 2) << 12)) & 0xFFFF);
+        } else {
+            buf_u16be(comp, (uint32_t)((match.distance - 1) & 0xFFF));
+            buf_u8(uncomp, (uint32_t)(match.length - 0x12));
+        }
+        sp += match.length;
+        fw_bit(flag, 0);
+    }
+    mf_free(&m);
+}
+
+/* MIO0.CompressHeaderless  MIO0.cs:159-184 */
+static void enc_mio0_core(const alz_settings* st, const uint8_t* src, int n, buf_t* comp, buf_t* uncomp, fw_t* flag) {
+    fmt_props p = props_for(ALZ_FMT_MIO0, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(uncomp, src[sp++]); fw_bit(flag, 1); }
+        if (match.length == 0) break;
+        buf_u16be(comp, (uint32_t)((match.distance - 1) | ((match.length - 3) << 12)) & 0xFFFF);
+        sp += match.length;
+        fw_bit(flag, 0);
+    }
+    mf_free(&m);
+}
+
+/* PRS.CompressHeaderless  PRS.cs:104-159 */
+static void enc_prs(const alz_settings* st, const uint8_t* src, int n, buf_t* out, int big) {
+    fmt_props p = props_for(ALZ_FMT_PRS_BE, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, big);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 1); }
+        if (match.length == 0) break;
+        if (match.length == 2 && match.distance > 0x100) continue;                       /* :124-125 */
+        sp += match.length;
+        int distance = -match.distance; int length = match.length;
+        fw_bit(&flag, 0);
+        if (distance >= -0x100 && length <= 5) {
+            fw_bit(&flag, 0);
+            fw_bit(&flag, ((length - 2) >> 1) & 1); fw_bit(&flag, (length - 2) & 1);       /* WriteInt(length-2, 2, true) */
+            buf_u8(&flag.buffer, (uint32_t)distance & 0xFF);
+            fw_flush_if_necessary(&flag);
+        } else {
+            if (length > 9) {
+                uint32_t v = (uint32_t)(distance << 3) & 0xFFFF;
+                if (big) buf_u16be(&flag.buffer, v); else buf_u16le(&flag.buffer, v);
+                buf_u8(&flag.buffer, (uint32_t)(length - 1));
+            } else {
+                uint32_t v = (uint32_t)((distance << 3) | (length - 2)) & 0xFFFF;
+                if (big) buf_u16be(&flag.buffer, v); else buf_u16le(&flag.buffer, v);
+            }
+            fw_bit(&flag, 1);
+        }
+    }
+    fw_bit(&flag, 0);
+    buf_u8(&flag.buffer, 0); buf_u8(&flag.buffer, 0);
+    fw_bit(&flag, 1);
+    fw_dispose(&flag); mf_free(&m);
+}
+
+/* LZ4.WriteExtension  LZ4.cs:254-268 */
+static void lz4_write_ext(buf_t* out, int length) {
+    length -= 0xF;
+    if (length >= 0) {
+        int b;
+        do { b = length < 0xFF ? length : 0xFF; buf_u8(out, (uint32_t)b); length -= b; } while (b == 0xFF);
+    }
+}
+
+/* LZ4.CompressBlockHeaderless  LZ4.cs:202-238; returns -2 where the reference throws (n < 5) */
+static int enc_lz4(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    if (n < 5) return -2;                                /* source.Slice(0, Length - 5) throws */
+    fmt_props p = props_for(ALZ_FMT_LZ4_BLOCK, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0, plain, token; int en = n - 5;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, en);
+        plain = match.offset - sp;
+        token = (plain > 0xF ? 0xF : plain) << 4;
+        if (match.length != 0) token |= (match.length - 4 > 0xF ? 0xF : match.length - 4);
+        else { plain = n - sp; token = (plain > 0xF ? 0xF : plain) << 4; }
+        buf_u8(out, (uint32_t)token);
+        lz4_write_ext(out, plain);
+        buf_put(out, src + sp, (size_t)plain);
+        sp += plain;
+        if (sp >= n) break;
+        buf_u16le(out, (uint32_t)match.distance & 0xFFFF);
+        lz4_write_ext(out, match.length - 4);
+        sp += match.length;
+    }
+    mf_free(&m);
+    return 0;
+}
+
+/* LZO.WriteExtendedInt  LZO.cs:263-271 */
+static void lzo_write_ext(buf_t* out, int v) { while (v > 255) { buf_u8(out, 0); v -= 255; } buf_u8(out, (uint32_t)v); }
+
+/* LZO.CompressHeaderless  LZO.cs:141-250; returns -2 where the reference would throw */
+static int enc_lzo(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    if (n < 0x10) {                                                                      /* :143-152 */
+        buf_u8(out, (uint32_t)(17 + n)); buf_put(out, src, (size_t)n);
+        buf_u8(out, 0x11); buf_u8(out, 0); buf_u8(out, 0);
+        return 0;
+    }
+    fmt_props p = props_for(ALZ_FMT_LZO, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0, rc = 0;
+    lzmatch_t match = mf_find(&m, src, n), next = mf_find(&m, src, n);
+    while (sp != n) {
+        int plain = match.offset - sp;
+        if (plain != 0) {
+            if (plain < 4) {                                                             /* :167-172 */
+                int dif = 4 - plain;
+                match.offset += dif; match.length -= dif;
+                plain = 4;
+            }
+            if (plain > 18) { buf_u8(out, 0); lzo_write_ext(out, plain - 18); }
+            else buf_u8(out, (uint32_t)(plain - 3));
+            if (sp + plain > n) { rc = -2; break; }      /* Slice would throw */
+            buf_put(out, src + sp, (size_t)plain);
+            sp += plain;
+        }
+        if (match.length >= 3) {                                                         /* _lz.MinLength :187 */
+            sp += match.length;
+            plain = next.offset - sp;
+            if (plain > 3) plain = 0;
+            if (plain < 0) { rc = -2; break; }
+            if (match.length <= 8 && match.distance <= 2048) {
+                uint32_t flag = (uint32_t)(plain | (((match.distance - 1) & 0x7) << 2)) & 0xFF;
+                if (match.length <= 4) buf_u8(out, flag | 0x40 | (uint32_t)((match.length - 3) << 5));
+                else buf_u8(out, flag | 0x80 | (uint32_t)((match.length - 5) << 5));
+                buf_u8(out, (uint32_t)((match.distance - 1) >> 3));
+            } else if (match.distance <= 16384) {
+                if (match.length > 33) { buf_u8(out, 0x20); lzo_write_ext(out, match.length - 33); }
+                else buf_u8(out, 0x20 | (uint32_t)(match.length - 2));
+                buf_u8(out, (uint32_t)(plain | ((match.distance - 1) << 2)));
+                buf_u8(out, (uint32_t)((match.distance - 1) >> 6));
+            } else {
+                const int hFlag = 0x4000;
+                int distance = match.distance - hFlag;
+                uint32_t flag = (uint32_t)(0x10 | ((distance & hFlag) >> 11)) & 0xFF;
+                if (match.length > 9) { buf_u8(out, flag); lzo_write_ext(out, match.length - 9); }
+                else buf_u8(out, flag | (uint32_t)(match.length - 2));
+                buf_u8(out, (uint32_t)(plain | (distance << 2)));
+                buf_u8(out, (uint32_t)(distance >> 6));
+            }
+            if (sp + plain > n) { rc = -2; break; }
+            buf_put(out, src + sp, (size_t)plain);
+            sp += plain;
+        }
+        match = next;
+        next = mf_find(&m, src, n);
+    }
+    buf_u8(out, 0x11); buf_u8(out, 0); buf_u8(out, 0);
+    mf_free(&m);
+    return rc;
+}
+
+/* Snappy.CompressHeaderless  Snappy.cs:124-203 */
+static void enc_snappy(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_SNAPPY_RAW, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int v = n;
+    while (v >= 0x80) { buf_u8(out, (uint32_t)(v | 0x80)); v >>= 7; }
+    buf_u8(out, (uint32_t)v);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        if (plain > 0) {
+            if (plain <= 60) buf_u8(out, (uint32_t)((plain - 1) << 2));
+            else {
+                int len = plain - 1;
+                if (len <= 0xFF) { buf_u8(out, 60 << 2); buf_u8(out, (uint32_t)len); }
+                else if (len <= 0xFFFF) { buf_u8(out, 61 << 2); buf_u16le(out, (uint32_t)len); }
+                else if (len <= 0xFFFFFF) { buf_u8(out, 62 << 2); buf_u8(out, (uint32_t)len); buf_u8(out, (uint32_t)len >> 8); buf_u8(out, (uint32_t)len >> 16); }
+                else { buf_u8(out, 63 << 2); buf_u32le(out, (uint32_t)len); }
+            }
+            buf_put(out, src + sp, (size_t)plain);
+            sp += plain;
+        }
+        if (match.length == 0) break;
+        sp += match.length;
+        if (match.distance < 2048 && match.length >= 4 && match.length <= 11) {
+            buf_u8(out, (uint32_t)(1 | ((match.length - 4) << 2) | ((match.distance >> 8) << 5)));
+            buf_u8(out, (uint32_t)match.distance);
+        } else {
+            buf_u8(out, (uint32_t)(2 | ((match.length - 1) << 2)));
+            buf_u16le(out, (uint32_t)match.distance & 0xFFFF);
+        }
+    }
+    mf_free(&m);
+}
+
+int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, const alz_settings* settings,
+                             const uint8_t* src, size_t n, uint8_t* dst, size_t cap, alz_encode_aux* aux) {
+    buf_t out = { dst, 0, cap, 0, 0 };
+    alz_settings dflt = { 8, 0, 0, 0 };
+    const alz_settings* st = settings ? settings : &dflt;
+    int rc = 0;
+    if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
+    switch (format) {
+    case ALZ_FMT_LZSS: enc_lzss(props, st, src, (int)n, &out); break;
+    case ALZ_FMT_LZ10: enc_lz10(st, src, (int)n, &out); break;
+    case ALZ_FMT_LZ11: enc_lz11(st, src, (int)n, &out); break;
+    case ALZ_FMT_YAZ0: {                                                                 /* Yaz0.cs:94-98 */
+        fw_t flag; fw_init(&flag, &out, 1);
+        enc_yay0_core(st, src, (int)n, &flag.buffer, &flag.buffer, &flag, ALZ_FMT_YAZ0);
+        fw_dispose(&flag); break;
+    }
+    case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: {                                              /* Yay0.cs:62-77 / MIO0.cs:64-79 */
+        buf_t flags = buf_owned(), comp = buf_owned(), uncomp = buf_owned();
+        fw_t flag; fw_init(&flag, &flags, 1);
+        if (format == ALZ_FMT_YAY0) enc_yay0_core(st, src, (int)n, &comp, &uncomp, &flag, ALZ_FMT_YAY0);
+        else enc_mio0_core(st, src, (int)n, &comp, &uncomp, &flag);
+        fw_dispose(&flag);
+        if (aux) { aux->aux0 = (uint32_t)flags.len; aux->aux1 = (uint32_t)(flags.len + comp.len); }
+        buf_put(&out, flags.p, flags.len); buf_put(&out, comp.p, comp.len); buf_put(&out, uncomp.p, uncomp.len);
+        buf_free(&flags); buf_free(&comp); buf_free(&uncomp);
+        break;
+    }
+    case ALZ_FMT_PRS_BE: enc_prs(st, src, (int)n, &out, 1); break;
+    case ALZ_FMT_PRS_LE: enc_prs(st, src, (int)n, &out, 0); break;
+    case ALZ_FMT_LZ4_BLOCK: rc = enc_lz4(st, src, (int)n, &out); break;
+    case ALZ_FMT_LZO: rc = enc_lzo(st, src, (int)n, &out); break;
+    case ALZ_FMT_SNAPPY_RAW: enc_snappy(st, src, (int)n, &out); break;
+    default: return -2;
+    }
+    if (out.fail) return -1;
+    if (rc < 0) return rc;
+    return (int64_t)out.len;
+}
+
+/* ============================================================ containers */
+
+static uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+static uint32_t rd32(const uint8_t* p, int big) { return big ? be32(p) : rd32le(p); }
+static uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00) | ((v << 8) & 0xFF0000) | (v << 24); }
+static void wr32(uint8_t* p, uint32_t v, int big) {
+    if (big) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+    else { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+}
+
+/* header of LZ10 / LZ11: id byte, u24 LE size, 0 => u32 LE (LZ10.cs:47-57).  Returns header length or -1. */
+static int nin_header(const uint8_t* src, size_t len, uint8_t id, uint32_t* size) {
+    if (len < 4 || src[0] != id) return -1;
+    uint32_t s = (uint32_t)src[1] | ((uint32_t)src[2] << 8) | ((uint32_t)src[3] << 16);
+    if (s != 0) { *size = s; return 4; }
+    if (len < 8) return -1;
+    *size = rd32le(src + 4); return 8;
+}
+
+int oracle_container_decompressed_size(uint32_t container, const alz_container_options* opt, const uint8_t* src, size_t len, uint32_t* size_out) {
+    int big = opt ? (int)opt->big_endian : 1;
+    switch (container) {
+    case ALZ_C_LZSS: if (len < 8 || memcmp(src, "LZSS", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* LZSS.cs:45-50 */
+    case ALZ_C_LZ10: return nin_header(src, len, 0x10, size_out) < 0 ? ALZ_E_FORMAT : 0;
+    case ALZ_C_LZ11: return nin_header(src, len, 0x11, size_out) < 0 ? ALZ_E_FORMAT : 0;
+    case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
+    case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
+    case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* MIO0.cs:41-48 */
+    default: return ALZ_E_UNSUPPORTED;
+    }
+}
+
+static void run_stream(uint32_t format, const alz_lz_properties* lz, const uint8_t* body, uint32_t body_len, uint32_t size,
+                       uint32_t aux0, uint32_t aux1, uint8_t* dst, size_t dst_cap, alz_result* r) {
+    alz_stream s; memset(&s, 0, sizeof(s));
+    s.src_off = 0; s.src_len = body_len; s.dst_off = 0; s.dst_cap = dst_cap > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)dst_cap;
+    s.decom_len = size; s.aux0 = aux0; s.aux1 = aux1; s.format = format;
+    decode_one(lz, &s, body, dst, r, 0);
+}
+
+int oracle_container_decompress(uint32_t container, const alz_container_options* opt, const uint8_t* src, size_t len,
+                                uint8_t* dst, size_t dst_cap, size_t* dst_len, size_t* src_used, int32_t* status) {
+    int big = opt ? (int)opt->big_endian : 1;
+    const alz_lz_properties* lz = opt ? &opt->lz : NULL;
+    alz_result r; memset(&r, 0, sizeof(r));
+    uint32_t size = 0; size_t hdr = 0;
+    switch (container) {
+    case ALZ_C_LZSS:                                                                     /* LZSS.cs:53-69 */
+        if (len < 16 || memcmp(src, "LZSS", 4)) return ALZ_E_FORMAT;
+        size = be32(src + 4); hdr = 16;
+        run_stream(ALZ_FMT_LZSS, lz, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZ10: case ALZ_C_LZ11: {                                                  /* LZ10.cs:60-64 */
+        int h = nin_header(src, len, container == ALZ_C_LZ10 ? 0x10 : 0x11, &size);
+        if (h < 0) return ALZ_E_FORMAT;
+        hdr = (size_t)h;
+        run_stream(container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_YAZ0:                                                                     /* Yaz0.cs:58-79 */
+        if (len < 16 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT;
+        size = rd32(src + 4, big); hdr = 16;
+        run_stream(ALZ_FMT_YAZ0, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        if (r.status != ALZ_ST_OK)                                                       /* catch (Exception): try other order */
+            run_stream(ALZ_FMT_YAZ0, NULL, src + hdr, (uint32_t)(len - hdr), bswap32(size), 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_YAY0: case ALZ_C_MIO0: {                                                  /* Yay0.cs:50-60 / MIO0.cs:51-61 */
+        if (len < 16 || memcmp(src, container == ALZ_C_YAY0 ? "Yay0" : "MIO0", 4)) return ALZ_E_FORMAT;
+        /* DetectByteOrder<uint>(3) lives in the unvendored AuroraLib.Core: parity unpinned; the caller's FormatByteOrder is used */
+        size = rd32(src + 4, big); uint32_t cp = rd32(src + 8, big), up = rd32(src + 12, big); hdr = 16;
+        run_stream(container == ALZ_C_YAY0 ? ALZ_FMT_YAY0 : ALZ_FMT_MIO0, NULL, src + hdr, (uint32_t)(len - hdr), size, cp - 0x10, up - 0x10, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_PRS: {                                                                    /* PRS.cs:42-57: detected order first, then the other */
+        run_stream(big ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
+        if (r.status != ALZ_ST_OK) run_stream(big ? ALZ_FMT_PRS_LE : ALZ_FMT_PRS_BE, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_LZO: run_stream(ALZ_FMT_LZO, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r); break;
+    default: return ALZ_E_UNSUPPORTED;
+    }
+    if (dst_len) *dst_len = r.dst_len;
+    if (src_used) *src_used = hdr + r.src_used;
+    if (status) *status = r.status;
+    return r.status == ALZ_ST_OK ? 0 : ALZ_E_STREAM;
+}
+
+int oracle_container_compress(uint32_t container, const alz_container_options* opt, const alz_settings* settings,
+                              const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* dst_len) {
+    int big = opt ? (int)opt->big_endian : 1;
+    const alz_lz_properties* lz = opt ? &opt->lz : NULL;
+    size_t hdr = 0; int64_t body; alz_encode_aux aux;
+    alz_settings st = settings ? *settings : (alz_settings){ 8, 0, 0, 0 };
+    switch (container) {
+    case ALZ_C_LZSS:                                                                     /* LZSS.cs:72-88 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        memcpy(dst, "LZSS", 4); wr32(dst + 4, (uint32_t)n, 1); wr32(dst + 8, 0, 1); wr32(dst + 12, 0, 1); hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_LZSS, lz, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        wr32(dst + 8, (uint32_t)body, 1);
+        break;
+    case ALZ_C_LZ10: case ALZ_C_LZ11: {                                                  /* LZ10.cs:67-80 */
+        uint8_t id = container == ALZ_C_LZ10 ? 0x10 : 0x11;
+        if (cap < 8) return ALZ_E_NOMEM;
+        if (n <= 0xFFFFFF) { wr32(dst, id | ((uint32_t)n << 8), 0); hdr = 4; }
+        else { wr32(dst, id, 0); wr32(dst + 4, (uint32_t)n, 0); hdr = 8; }
+        if (container == ALZ_C_LZ10 && st.min_distance == 0) st.min_distance = 2;        /* GbaVramCompatibilityMode default true LZ10.cs:33 */
+        body = oracle_encode_stream(container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    }
+    case ALZ_C_YAZ0:                                                                     /* Yaz0.cs:82-89 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        memcpy(dst, "Yaz0", 4); wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, opt ? opt->memory_alignment : 0, big); wr32(dst + 12, 0, 0); hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_YAZ0, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    case ALZ_C_YAY0: case ALZ_C_MIO0:                                                    /* Yay0.cs:62-77 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        memcpy(dst, container == ALZ_C_YAY0 ? "Yay0" : "MIO0", 4); hdr = 16;
+        body = oracle_encode_stream(container == ALZ_C_YAY0 ? ALZ_FMT_YAY0 : ALZ_FMT_MIO0, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
+        if (body < 0) return ALZ_E_NOMEM;
+        wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, 0x10 + aux.aux0, big); wr32(dst + 12, 0x10 + aux.aux1, big);
+        break;
+    case ALZ_C_PRS:
+        body = oracle_encode_stream(big ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE, NULL, &st, src, n, dst, cap, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    case ALZ_C_LZO:
+        body = oracle_encode_stream(ALZ_FMT_LZO, NULL, &st, src, n, dst, cap, NULL);
+        if (body < 0) return body == -1 ? ALZ_E_NOMEM : ALZ_E_INVALID;
+        break;
+    default: return ALZ_E_UNSUPPORTED;
+    }
+    if (dst_len) *dst_len = hdr + (size_t)body;
+    return 0;
+}
