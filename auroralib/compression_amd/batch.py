@@ -1,0 +1,112 @@
+"""Thin object layer over the batch half of the C ABI (context, plans, device buffers)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+from ._lib import check, load
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return a
+
+
+class Context:
+    """alz_ctx: one HIP device + one HIP stream."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.alz_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.alz_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int(), C.c_uint64()
+        check(self.lib.alz_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    # ---- host-buffer decode (upload, decode on GPU, download)
+    def decode_batch(self, streams, src, dst_bytes, lz=None):
+        n = len(streams)
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.zeros(max(dst_bytes, 1), dtype=np.uint8)
+        res = (A.Result * n)()
+        check(self.lib.alz_decode_batch(self.h, C.byref(lz) if lz is not None else None, n, _vp(src), src.nbytes, streams, _vp(dst), dst_bytes, res))
+        return dst, res
+
+    def decode(self, fmt, src, decom_len=0, cap=None, aux0=0, aux1=0, lz=None):
+        src = bytes(src)
+        cap = decom_len if cap is None else cap
+        dst = C.create_string_buffer(max(cap, 1))
+        r = A.Result()
+        check(self.lib.alz_decode(self.h, fmt, C.byref(lz) if lz is not None else None, src, len(src), decom_len, aux0, aux1, dst, cap, C.byref(r)))
+        return dst.raw[:r.dst_len], r
+
+    # ---- device memory
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.alz_device_malloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def free(self, p):
+        check(self.lib.alz_device_free(self.h, p))
+
+    def h2d(self, d, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.lib.alz_memcpy_h2d(self.h, d, _vp(arr), arr.nbytes))
+
+    def d2h(self, d, nbytes, offset=0):
+        out = np.empty(nbytes, dtype=np.uint8)
+        check(self.lib.alz_memcpy_d2h(self.h, _vp(out), C.c_void_p(d.value + offset), nbytes))
+        return out
+
+    def memset(self, d, value, nbytes):
+        check(self.lib.alz_memset_d(self.h, d, value, nbytes))
+
+    def synchronize(self):
+        check(self.lib.alz_synchronize(self.h))
+
+
+class Plan:
+    """alz_plan: descriptor table resident in HBM, grouped per format."""
+
+    def __init__(self, ctx, streams, lz=None):
+        self.ctx, self.n = ctx, len(streams)
+        h = C.c_void_p()
+        check(ctx.lib.alz_plan_create(ctx.h, C.byref(lz) if lz is not None else None, self.n, streams, C.byref(h)))
+        self.h = h
+
+    def execute(self, d_src, d_dst, hip_stream=None):
+        check(self.ctx.lib.alz_plan_execute(self.ctx.h, self.h, d_src, d_dst, hip_stream))
+
+    def execute_timed(self, d_src, d_dst, iters=1):
+        ms = C.c_float()
+        check(self.ctx.lib.alz_plan_execute_timed(self.ctx.h, self.h, d_src, d_dst, iters, C.byref(ms)))
+        return ms.value
+
+    def results(self):
+        res = (A.Result * self.n)()
+        check(self.ctx.lib.alz_plan_results(self.ctx.h, self.h, res))
+        return res
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.alz_plan_destroy(self.ctx.h, self.h)
+            self.h = None

@@ -1,0 +1,351 @@
+// alz_decode_serial.h -- exact, wave-uniform token parsers for every format on the hot path.
+//
+// These are the "reference semantics" decoders of the GPU build: one token at a
+// time, parse state in SGPRs, the byte work (match copy / literal runs) spread
+// over the 64 lanes by OutWin.  They implement every frozen edge definition
+// (E1-E6) and are what the lane-parallel fast paths fall back to
+// at stream tails.  Each function cites the reference body it replaces
+// (paths relative to /root/reference/src).
+#pragma once
+#include "alz_device.h"
+#include "auroralz.h"
+
+struct DecState {
+    u32 p;              // input offset (wave-uniform)
+    u32 bits;           // FlagReader.BitsLeft
+    u32 flag;           // FlagReader.CurrentFlag
+    bool eof, ovf, bad, done;
+    u64 attempted_end;  // E5 bookkeeping
+};
+
+__device__ __forceinline__ void dec_state_init(DecState& s) {
+    s.p = 0; s.bits = 0; s.flag = 0; s.eof = false; s.ovf = false; s.bad = false; s.done = false; s.attempted_end = 0;
+}
+
+// E5: clip a token of `len` bytes against dst_cap
+template <class OW>
+__device__ __forceinline__ u32 clip_token(const OW& out, DecState& s, u64 len) {
+    u64 end = (u64)out.produced + len;
+    if (end > (u64)out.cap) { s.ovf = true; s.attempted_end = end; return out.cap - out.produced; }
+    return (u32)len;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LZSS.DecompressHeaderless  Formats/Common/LZSS.cs:91-130  (flags LSB-first, bit 1 = literal)
+template <class OW>
+__device__ void dec_lzss_serial(InCache& in, OW& out, DecState& s, u32 src_len, u32 size,
+                                u32 length_bits, u32 min_length, u32 windows_start, u32 max_distance, u32 W) {
+    const u32 f = (1u << length_bits) - 1u, n = max_distance - 1u;
+    while (out.produced < size) {
+        in.ensure(s.p, 8);
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        u32 bit = (s.flag >> (8 - s.bits)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            u32 b = in.peek1(s.p); s.p++;
+            if (clip_token(out, s, 1) < 1) return;
+            out.put_byte(b);
+        } else {
+            if (s.p + 2 > src_len) { s.eof = true; return; }
+            u32 w = in.peek4(s.p); s.p += 2;
+            u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF;
+            u32 offset = ((b2 >> length_bits) << 8) | b1;
+            u32 length = (b2 & f) + min_length;
+            offset = (max_distance + offset - windows_start) & n;
+            u32 pos = out.produced & (W - 1);                  // LzWindows.OffsetCopy  IO/LzWindows.cs:108-115
+            u32 distance = pos >= offset ? pos - offset : pos - offset + W;
+            u32 cl = clip_token(out, s, length);
+            out.back_copy(distance, cl, W);
+            if (s.ovf) return;
+        }
+    }
+}
+
+// LZ10.DecompressHeaderless  Nintendo/LZ10.cs:82-111 ; LZ11.DecompressHeaderless  Nintendo/LZ11.cs:83-133
+template <class OW, bool LZ11>
+__device__ void dec_lz1x_serial(InCache& in, OW& out, DecState& s, u32 src_len, u32 size) {
+    while (out.produced < size) {
+        in.ensure(s.p, 8);
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p + 2 > src_len) { s.eof = true; return; }
+            u32 w = in.peek4(s.p);
+            u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF, b3 = (w >> 16) & 0xFF, b4 = w >> 24;
+            u32 distance, length;
+            if (LZ11 && (b1 >> 4) == 0) {
+                if (s.p + 3 > src_len) { s.eof = true; return; }
+                distance = (((b2 & 0xF) << 8) | b3) + 1; length = (((b1 & 0xF) << 4) | (b2 >> 4)) + 17; s.p += 3;
+            } else if (LZ11 && (b1 >> 4) == 1) {
+                if (s.p + 4 > src_len) { s.eof = true; return; }
+                distance = (((b3 & 0xF) << 8) | b4) + 1; length = (((b1 & 0xF) << 12) | (b2 << 4) | (b3 >> 4)) + 273; s.p += 4;
+            } else {
+                distance = (((b1 & 0xF) << 8) | b2) + 1; length = (b1 >> 4) + (LZ11 ? 1 : 3); s.p += 2;
+            }
+            u32 cl = clip_token(out, s, length);
+            out.back_copy(distance, cl, 4096);
+            if (s.ovf) return;
+        } else {
+            if (s.p >= src_len) { s.eof = true; return; }
+            u32 b = in.peek1(s.p); s.p++;
+            if (clip_token(out, s, 1) < 1) return;
+            out.put_byte(b);
+        }
+    }
+}
+
+// Yaz0: Yay0.DecompressHeaderless with all three cursors on one stream  Nintendo/Yay0.cs:110-144, Yaz0.cs:91-92
+template <class OW>
+__device__ void dec_yaz0_serial(InCache& in, OW& out, DecState& s, u32 src_len, u32 size) {
+    while (out.produced < size) {
+        in.ensure(s.p, 8);
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            u32 b = in.peek1(s.p); s.p++;
+            if (clip_token(out, s, 1) < 1) return;
+            out.put_byte(b);
+        } else {
+            if (s.p + 2 > src_len) { s.eof = true; return; }
+            u32 w = in.peek4(s.p); s.p += 2;
+            u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF, b3 = (w >> 16) & 0xFF;
+            u32 distance = (((b1 & 0x0F) << 8) | b2) + 1;
+            u32 length = b1 >> 4;
+            if (length == 0) {                                   // ReadByte(): -1 at EOF => 17   Yay0.cs:130-131
+                if (s.p < src_len) { length = b3 + 0x12; s.p++; } else length = 17;
+            } else length += 2;
+            u32 cl = clip_token(out, s, length);
+            out.back_copy(distance, cl, 4096);
+            if (s.ovf) return;
+        }
+    }
+}
+
+// Yay0 (three cursors)  Nintendo/Yay0.cs:99-144 ; MIO0  Nintendo/MIO0.cs:105-149
+// fc: flags from 0, cc: tokens from aux0, uc: literals from aux1; each cursor bounded by its slice length.
+template <class OW, bool MIO0>
+__device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, OW& out, DecState& s, u32 src_len, u32 size,
+                                   u32 cptr0, u32 uptr0, u32& used) {
+    u32 fp = 0, cp = cptr0, up = uptr0;
+    while (out.produced < size) {
+        if (s.bits == 0) {
+            if (fp >= src_len) { s.eof = true; break; }
+            fin.ensure(fp, 1); s.flag = fin.peek1(fp); fp++; s.bits = 8;
+        }
+        u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (up >= src_len) { s.eof = true; break; }
+            uin.ensure(up, 1); u32 b = uin.peek1(up); up++;
+            if (clip_token(out, s, 1) < 1) break;
+            out.put_byte(b);
+        } else {
+            if (cp + 2 > src_len) { s.eof = true; if (MIO0 && cp < src_len) cp++; break; }
+            cin.ensure(cp, 4); u32 w = cin.peek4(cp); cp += 2;
+            u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF;
+            u32 distance = (((b1 & 0x0F) << 8) | b2) + 1;
+            u32 length;
+            if (MIO0) length = (b1 >> 4) + 3;
+            else {
+                length = b1 >> 4;
+                if (length == 0) {
+                    if (up < src_len) { uin.ensure(up, 1); length = uin.peek1(up) + 0x12; up++; } else length = 17;
+                } else length += 2;
+            }
+            u32 cl = clip_token(out, s, length);
+            out.back_copy(distance, cl, 4096);
+            if (s.ovf) break;
+        }
+    }
+    used = cp > up ? cp : up;
+}
+
+// PRS.DecompressHeaderless(Stream, Stream, Endian)  Sega/PRS.cs:59-102
+template <class OW, bool BIG>
+__device__ void dec_prs_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
+#define PRS_READBIT(dst)                                                                       \
+    do {                                                                                       \
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; } \
+        dst = BIG ? (s.flag >> (s.bits - 1)) & 1u : (s.flag >> (8 - s.bits)) & 1u; s.bits--;   \
+    } while (0)
+    while (s.p < src_len) {
+        in.ensure(s.p, 16);
+        u32 bit; PRS_READBIT(bit);
+        if (bit) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            u32 b = in.peek1(s.p); s.p++;
+            if (clip_token(out, s, 1) < 1) return;
+            out.put_byte(b);
+        } else {
+            u32 distance, length, bit2; PRS_READBIT(bit2);
+            if (bit2) {
+                if (s.p + 2 > src_len) { s.eof = true; return; }
+                u32 w = in.peek4(s.p); s.p += 2;
+                u32 x0 = w & 0xFF, x1 = (w >> 8) & 0xFF;
+                u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);
+                if (v == 0) { s.done = true; return; }
+                length = v & 7; distance = 0x2000 - (v >> 3);
+                if (length == 0) { if (s.p >= src_len) { s.eof = true; return; } length = ((w >> 16) & 0xFF) + 1; s.p++; }
+                else length += 2;
+            } else {
+                u32 h, l; PRS_READBIT(h); PRS_READBIT(l);
+                length = ((h << 1) | l) + 2;
+                if (s.p >= src_len) { s.eof = true; return; }
+                distance = 0x100 - in.peek1(s.p); s.p++;
+            }
+            u32 cl = clip_token(out, s, length);
+            out.back_copy(distance, cl, 8192);
+            if (s.ovf) return;
+        }
+    }
+    s.eof = true;   // EndOfStreamException  PRS.cs:101
+#undef PRS_READBIT
+}
+
+// LZ4.DecompressBlockHeaderless  Formats/Common/LZ4.cs:176-200
+template <class OW>
+__device__ void dec_lz4_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
+    while (s.p < src_len) {
+        in.ensure(s.p, 8);
+        u32 token = in.peek1(s.p); s.p++;
+        u64 plain = token >> 4;
+        if (plain == 0xF) {
+            u32 b;
+            do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); b = in.peek1(s.p); s.p++; plain += b; } while (b == 255);
+        }
+        if (plain > (u64)(src_len - s.p)) { s.eof = true; return; }
+        u32 cl = clip_token(out, s, plain);
+        out.copy_from(in, s.p, cl);
+        if (s.ovf) return;
+        s.p += (u32)plain;
+        if (s.p >= src_len) break;
+        u64 mlen = token & 0xF;
+        if (s.p + 2 > src_len) { s.eof = true; return; }
+        in.ensure(s.p, 4);
+        u32 w = in.peek4(s.p); s.p += 2;
+        u32 dist = w & 0xFFFF;
+        if (mlen == 0xF) {
+            u32 b;
+            do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); b = in.peek1(s.p); s.p++; mlen += b; } while (b == 255);
+        }
+        cl = clip_token(out, s, mlen + 4);
+        out.back_copy(dist, cl, 65536);
+        if (s.ovf) return;
+    }
+}
+
+// LZO.DecompressHeaderless  Formats/Common/LZO.cs:49-139
+template <class OW>
+__device__ void dec_lzo_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
+#define LZO_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
+#define LZO_EXT(dst) do { u32 b_, acc_ = 0; for (;;) { LZO_BYTE(b_); if (b_ != 0) break; acc_ += 255; } dst = acc_ + b_; } while (0)
+    u32 flag, length, distance, plain = 0;
+    LZO_BYTE(flag);
+    if (flag > 17) {
+        length = flag - 17;
+        if (length > src_len - s.p) { s.eof = true; return; }
+        u32 cl = clip_token(out, s, length);
+        out.copy_from(in, s.p, cl); if (s.ovf) return;
+        s.p += length;
+        LZO_BYTE(flag);
+    }
+    for (;;) {
+        u32 flagcode = flag >> 4;
+        bool literal_op = false;
+        if (flagcode == 0) {
+            if (plain == 0) {
+                length = 3 + flag;
+                if (length == 3) { u32 e; LZO_EXT(e); length = 18 + e; }
+                plain = 4;
+                if (length > src_len - s.p) { s.eof = true; return; }
+                u32 cl = clip_token(out, s, length);
+                out.copy_from(in, s.p, cl); if (s.ovf) return;
+                s.p += length;
+                literal_op = true;
+            } else if (plain <= 3) {
+                u32 d; LZO_BYTE(d); distance = (d << 2) + (flag >> 2) + 1; length = 2;
+            } else {
+                u32 d; LZO_BYTE(d); distance = (d << 2) + (flag >> 2) + (2048 + 1); length = 3;
+            }
+        } else if (flagcode == 1) {
+            length = 2 + (flag & 0x7);
+            if (length == 2) { u32 e; LZO_EXT(e); length = 9 + e; }
+            distance = 16384 + ((flag & 0x8) << 11);
+            LZO_BYTE(flag);
+            u32 hi; LZO_BYTE(hi);
+            distance |= (hi << 6) | (flag >> 2);
+            if (distance == 16384) { s.done = true; return; }
+        } else if (flagcode <= 3) {
+            length = 2 + (flag & 0x1f);
+            if (length == 2) { u32 e; LZO_EXT(e); length = 33 + e; }
+            LZO_BYTE(flag);
+            u32 hi; LZO_BYTE(hi);
+            distance = ((hi << 6) | (flag >> 2)) + 1;
+        } else if (flagcode <= 7) {
+            length = 3 + ((flag >> 5) & 0x1);
+            u32 d; LZO_BYTE(d); distance = (d << 3) + ((flag >> 2) & 0x7) + 1;
+        } else {
+            length = 5 + ((flag >> 5) & 0x3);
+            u32 d; LZO_BYTE(d); distance = (d << 3) + ((flag & 0x1c) >> 2) + 1;
+        }
+        if (!literal_op) {
+            plain = flag & 0x3;
+            u32 cl = clip_token(out, s, length);
+            out.back_copy(distance, cl, 65536); if (s.ovf) return;
+            if (plain > src_len - s.p) { s.eof = true; return; }
+            cl = clip_token(out, s, plain);
+            out.copy_from(in, s.p, cl); if (s.ovf) return;
+            s.p += plain;
+        }
+        if (s.p >= src_len) { s.eof = true; return; }          // ReadByte() == -1 -> EndOfStreamException  LZO.cs:136-137
+        in.ensure(s.p, 1); flag = in.peek1(s.p); s.p++;
+    }
+#undef LZO_BYTE
+#undef LZO_EXT
+}
+
+// Snappy.DecompressHeaderless  Formats/Common/Snappy.cs:205-250 (+ varint :109-122)
+template <class OW>
+__device__ void dec_snappy_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
+#define SN_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
+    u32 size = 0, shift = 0, b = 0x80;
+    while (b & 0x80) { SN_BYTE(b); size |= (b & 0x7F) << (shift & 31); shift += 7; }
+    while (out.produced < size) {
+        u32 tag; SN_BYTE(tag);
+        u32 type = tag & 3, length = tag >> 2, distance;
+        if (type == 0) {
+            if (length >= 60) {
+                u32 lenBytes = length - 59; length = 0;
+                for (u32 i = 0; i < lenBytes; i++) { u32 x; SN_BYTE(x); length |= x << (8 * i); }
+            }
+            u32 run = length + 1;
+            if (run > src_len - s.p) { s.eof = true; return; }
+            u32 cl = clip_token(out, s, run);
+            out.copy_from(in, s.p, cl); if (s.ovf) return;
+            s.p += run;
+            continue;
+        } else if (type == 1) {
+            length = (length & 0x7) + 3;
+            u32 x; SN_BYTE(x); distance = ((tag >> 5) << 8) | x;
+        } else if (type == 2) {
+            if (s.p + 2 > src_len) { s.eof = true; return; }
+            in.ensure(s.p, 4); distance = in.peek4(s.p) & 0xFFFF; s.p += 2;
+        } else {
+            if (src_len - s.p < 4) { s.eof = true; return; }
+            in.ensure(s.p, 4); distance = in.peek4(s.p); s.p += 4;
+            if (distance > 65536u) { s.bad = true; return; }    // E3
+        }
+        u32 cl = clip_token(out, s, (u64)length + 1);
+        out.back_copy(distance, cl, 65536); if (s.ovf) return;
+    }
+#undef SN_BYTE
+}
+
+// status resolution, identical to oracle/alz_oracle.c decode_one()
+__device__ __forceinline__ int resolve_status(const DecState& s, bool has_size, u32 produced, u32 size, u32 cap) {
+    if (s.eof) return ALZ_ST_INPUT_TRUNCATED;
+    if (s.bad) return ALZ_ST_BAD_TOKEN;
+    if (s.ovf) return (has_size && s.attempted_end > (u64)size && cap >= size) ? ALZ_ST_OUTPUT_SIZE_MISMATCH : ALZ_ST_OUTPUT_CAPACITY;
+    if (has_size && produced > size) return ALZ_ST_OUTPUT_SIZE_MISMATCH;
+    return ALZ_ST_OK;
+}

@@ -1,0 +1,261 @@
+// alz_host.cpp -- context / plan management and the batch entry points of include/auroralz.h.
+// Compiled by hipcc as host code; everything that computes runs in alz_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "alz_internal.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ALZ_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct alz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // grow-only staging for the host-buffer entry points
+    void* d_src = nullptr; size_t d_src_cap = 0;
+    void* d_dst = nullptr; size_t d_dst_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct alz_plan {
+    uint32_t n = 0;
+    alz_lz_properties lz{};
+    alz_stream* d_streams = nullptr;
+    alz_result* d_results = nullptr;
+    uint32_t* d_index = nullptr;            // concatenated per-format index lists
+    uint32_t fmt_off[ALZ_FMT_COUNT] = {0};
+    uint32_t fmt_cnt[ALZ_FMT_COUNT] = {0};
+};
+
+static alz_lz_properties effective_lz(const alz_lz_properties* p) {
+    alz_lz_properties lz;
+    if (!p || p->window_bits == 0) {           // LZSS.DefaultProperties = LzProperties((byte)12, 4, 2)  LZSS.cs:33
+        memset(&lz, 0, sizeof(lz)); lz.window_bits = 12; lz.length_bits = 4; lz.min_length = 3; lz.max_distance = 4096; lz.windows_start = 0xFEE;
+    } else { lz = *p; if (lz.max_distance == 0) lz.max_distance = 1u << lz.window_bits; }
+    return lz;
+}
+
+extern "C" {
+
+int alz_abi_version(void) { return ALZ_ABI_VERSION; }
+const char* alz_last_error(void) { return g_err; }
+
+int alz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int alz_create(int device, alz_ctx** out) {
+    if (!out) return fail(ALZ_E_INVALID, "alz_create: out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ALZ_E_NO_DEVICE, "no HIP device: the auroralz ABI has no CPU fallback");
+    if (device < 0 || device >= n) return fail(ALZ_E_INVALID, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    alz_ctx* c = new (std::nothrow) alz_ctx();
+    if (!c) return fail(ALZ_E_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) { delete c; return fail(ALZ_E_HIP, "context creation failed: %s", hipGetErrorString(e)); }
+    *out = c;
+    return ALZ_OK;
+}
+
+void alz_destroy(alz_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_src) (void)hipFree(c->d_src);
+    if (c->d_dst) (void)hipFree(c->d_dst);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int alz_device_info(alz_ctx* c, char* name, size_t name_cap, int* cu_count, uint64_t* hbm_bytes) {
+    if (!c) return fail(ALZ_E_INVALID, "ctx is NULL");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, c->device));
+    if (name && name_cap) { snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName); }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return ALZ_OK;
+}
+
+// ---------------------------------------------------------------- device memory helpers
+int alz_device_malloc(alz_ctx* c, size_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) return fail(ALZ_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return ALZ_OK;
+}
+int alz_device_free(alz_ctx* c, void* d_ptr) {
+    if (!c) return fail(ALZ_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipFree(d_ptr));
+    return ALZ_OK;
+}
+int alz_memcpy_h2d(alz_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    if (!c) return fail(ALZ_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ALZ_OK;
+}
+int alz_memcpy_d2h(alz_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    if (!c) return fail(ALZ_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ALZ_OK;
+}
+int alz_memset_d(alz_ctx* c, void* d_dst, int value, size_t bytes) {
+    if (!c) return fail(ALZ_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(d_dst, value, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ALZ_OK;
+}
+int alz_synchronize(alz_ctx* c) {
+    if (!c) return fail(ALZ_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ALZ_OK;
+}
+
+// ---------------------------------------------------------------- plans
+void alz_plan_destroy(alz_ctx* c, alz_plan* p) {
+    if (!p) return;
+    if (c) (void)hipSetDevice(c->device);
+    if (p->d_streams) (void)hipFree(p->d_streams);
+    if (p->d_results) (void)hipFree(p->d_results);
+    if (p->d_index) (void)hipFree(p->d_index);
+    delete p;
+}
+
+int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const alz_stream* streams, alz_plan** out) {
+    if (!c || !out || (n && !streams)) return fail(ALZ_E_INVALID, "alz_plan_create: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    alz_lz_properties lz = effective_lz(props);
+    std::vector<uint32_t> cnt(ALZ_FMT_COUNT, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
+        cnt[streams[i].format]++;
+    }
+    if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8))
+        return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path (window_bits 8..16, length_bits 1..8)");
+    alz_plan* p = new (std::nothrow) alz_plan();
+    if (!p) return fail(ALZ_E_NOMEM, "out of host memory");
+    p->n = n; p->lz = lz;
+    std::vector<uint32_t> index(n ? n : 1);
+    uint32_t off = 0;
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) { p->fmt_off[f] = off; p->fmt_cnt[f] = cnt[f]; off += cnt[f]; }
+    std::vector<uint32_t> fill(ALZ_FMT_COUNT, 0);
+    for (uint32_t i = 0; i < n; i++) { uint32_t f = streams[i].format; index[p->fmt_off[f] + fill[f]++] = i; }
+    size_t nn = n ? n : 1;
+    hipError_t e = hipMalloc((void**)&p->d_streams, nn * sizeof(alz_stream));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_results, nn * sizeof(alz_result));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_index, nn * sizeof(uint32_t));
+    if (e == hipSuccess && n) e = hipMemcpyAsync(p->d_streams, streams, n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(p->d_index, index.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_results, 0xFF, nn * sizeof(alz_result), c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
+    *out = p;
+    return ALZ_OK;
+}
+
+int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, void* hip_stream) {
+    if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+        if (!p->fmt_cnt[f]) continue;
+        hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz);
+        if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
+    }
+    return ALZ_OK;
+}
+
+int alz_plan_execute_timed(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, int iters, float* mean_ms) {
+    if (!c || !p || iters < 1 || !mean_ms) return fail(ALZ_E_INVALID, "alz_plan_execute_timed: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; i++) { int rc = alz_plan_execute(c, p, d_src_base, d_dst_base, nullptr); if (rc) return rc; }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *mean_ms = ms / (float)iters;
+    return ALZ_OK;
+}
+
+int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
+    if (!c || !p || (p->n && !results)) return fail(ALZ_E_INVALID, "alz_plan_results: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (p->n) HIP_TRY(hipMemcpy(results, p->d_results, p->n * sizeof(alz_result), hipMemcpyDeviceToHost));
+    return ALZ_OK;
+}
+
+// ---------------------------------------------------------------- host-buffer entry points
+static int grow(alz_ctx* c, void** buf, size_t* cap, size_t need) {
+    if (*cap >= need) return ALZ_OK;
+    if (*buf) { HIP_TRY(hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    size_t want = need + need / 4 + 4096;
+    HIP_TRY(hipMalloc(buf, want));
+    *cap = want;
+    return ALZ_OK;
+}
+
+int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const uint8_t* src_base, size_t src_bytes,
+                     const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results) {
+    if (!c || (n && (!streams || !results))) return fail(ALZ_E_INVALID, "alz_decode_batch: bad argument");
+    for (uint32_t i = 0; i < n; i++) {
+        if (streams[i].src_off + streams[i].src_len > src_bytes) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
+        if (streams[i].dst_off + streams[i].dst_cap > dst_bytes) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return rc;
+    if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return rc;
+    if (src_bytes) HIP_TRY(hipMemcpyAsync(c->d_src, src_base, src_bytes, hipMemcpyHostToDevice, c->stream));
+    alz_plan* p = nullptr;
+    if ((rc = alz_plan_create(c, props, n, streams, &p))) return rc;
+    rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);
+    if (!rc) rc = alz_plan_results(c, p, results);
+    if (!rc) {
+        // copy back only what each stream produced (outputs of different streams may interleave with caller data)
+        for (uint32_t i = 0; i < n && !rc; i++) {
+            if (!results[i].dst_len) continue;
+            hipError_t e = hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len,
+                                          hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(ALZ_E_HIP, "download failed: %s", hipGetErrorString(e));
+        }
+        if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(ALZ_E_HIP, "sync failed: %s", hipGetErrorString(e)); }
+    }
+    alz_plan_destroy(c, p);
+    return rc;
+}
+
+int alz_decode(alz_ctx* c, uint32_t format, const alz_lz_properties* props, const uint8_t* src, uint32_t src_len, uint32_t decom_len,
+               uint32_t aux0, uint32_t aux1, uint8_t* dst, uint32_t dst_cap, alz_result* result) {
+    if (!result) return fail(ALZ_E_INVALID, "alz_decode: result is NULL");
+    alz_stream s; memset(&s, 0, sizeof(s));
+    s.src_len = src_len; s.dst_cap = dst_cap; s.decom_len = decom_len; s.aux0 = aux0; s.aux1 = aux1; s.format = format;
+    return alz_decode_batch(c, props, 1, src, src_len, &s, dst, dst_cap, result);
+}
+
+}  // extern "C"

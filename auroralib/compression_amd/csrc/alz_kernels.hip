@@ -1,0 +1,114 @@
+// alz_kernels.hip -- gfx950 decode kernels + launch wrappers (one launch per format present in a plan).
+//
+// Grid mapping: one 64-thread workgroup (= one wavefront) per stream.  A batch of
+// 10 000 streams therefore launches 10 000 workgroups >> 256 CUs; consecutive
+// workgroups land on different XCDs round-robin and each stream's input, LDS
+// window and output are private to its wave, so there is no inter-workgroup
+// traffic and no L2 sharing to arrange.
+#include <hip/hip_runtime.h>
+
+#include "alz_decode_serial.h"
+#include "alz_internal.h"
+
+#define ALZ_INCACHE_BYTES (2048 + 16)
+
+template <bool FB>
+__device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status) {
+    if (lane == 0) { r->dst_len = out.produced; r->src_used = src_used; r->status = status; r->reserved = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic exact kernel: FMT selects the parser at compile time.
+template <int FMT, bool FB>
+__global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                               const alz_stream* __restrict__ streams,
+                                                               const u32* __restrict__ index_list, u32 count,
+                                                               alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
+    extern __shared__ uint4 smem[];
+    u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    u8* dst = dst_base + st.dst_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
+
+    u8* lds = reinterpret_cast<u8*>(smem);
+    OutWin<FB> out; out.init(dst, cap, lds, lw, lane);
+    u8* inc_lds = lds + lw;
+    InCache in; in.init(src, src_len, inc_lds, lane);
+    DecState s; dec_state_init(s);
+    bool has_size = false; u32 used = 0; bool used_set = false;
+
+    if constexpr (FMT == ALZ_FMT_LZSS) {
+        has_size = true;
+        u32 W = 1u << lz.window_bits;
+        dec_lzss_serial(in, out, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, W);
+    } else if constexpr (FMT == ALZ_FMT_LZ10) {
+        has_size = true; dec_lz1x_serial<OutWin<FB>, false>(in, out, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_LZ11) {
+        has_size = true; dec_lz1x_serial<OutWin<FB>, true>(in, out, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_YAZ0) {
+        has_size = true; dec_yaz0_serial(in, out, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0) {
+        has_size = true;
+        const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
+        if (FMT == ALZ_FMT_YAY0 && (a0 > src_len || a1 > src_len)) s.eof = true;   // Slice() throws  Yay0.cs:102-103
+        else {
+            InCache cin, uin;
+            cin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); cin.seek(a0 < src_len ? a0 : 0);
+            uin.init(src, src_len, inc_lds + 2 * ALZ_INCACHE_BYTES, lane); uin.seek(a1 < src_len ? a1 : 0);
+            dec_3cursor_serial<OutWin<FB>, FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, src_len, size, a0, a1, used);
+            used_set = true;
+        }
+    } else if constexpr (FMT == ALZ_FMT_PRS_BE) {
+        dec_prs_serial<OutWin<FB>, true>(in, out, s, src_len);
+    } else if constexpr (FMT == ALZ_FMT_PRS_LE) {
+        dec_prs_serial<OutWin<FB>, false>(in, out, s, src_len);
+    } else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) {
+        dec_lz4_serial(in, out, s, src_len);
+    } else if constexpr (FMT == ALZ_FMT_LZO) {
+        dec_lzo_serial(in, out, s, src_len);
+    } else if constexpr (FMT == ALZ_FMT_SNAPPY_RAW) {
+        dec_snappy_serial(in, out, s, src_len);
+    }
+    out.finish();
+    write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap));
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (host)
+
+template <int FMT, bool FB>
+static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
+                                alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
+    size_t lds = lw + (size_t)ncaches * ALZ_INCACHE_BYTES;
+    hipLaunchKernelGGL((alz_decode_serial_kernel<FMT, FB>), dim3(count), dim3(64), lds, stream, src, dst, streams, index, count, results, lz, lw);
+    return hipGetLastError();
+}
+
+hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
+                             u32 count, alz_result* results, const alz_lz_properties* lzp) {
+    if (count == 0) return hipSuccess;
+    const u8* s = (const u8*)src; u8* d = (u8*)dst;
+    alz_lz_properties lz = *lzp;
+    switch (fmt) {
+    case ALZ_FMT_LZSS: {
+        u32 W = 1u << lz.window_bits;
+        if (W <= 8192) return launch_serial<ALZ_FMT_LZSS, false>(stream, s, d, streams, index, count, results, lz, W, 1);
+        return launch_serial<ALZ_FMT_LZSS, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    }
+    case ALZ_FMT_LZ10: return launch_serial<ALZ_FMT_LZ10, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_LZ11: return launch_serial<ALZ_FMT_LZ11, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_YAZ0: return launch_serial<ALZ_FMT_YAZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_YAY0: return launch_serial<ALZ_FMT_YAY0, false>(stream, s, d, streams, index, count, results, lz, 4096, 3);
+    case ALZ_FMT_MIO0: return launch_serial<ALZ_FMT_MIO0, false>(stream, s, d, streams, index, count, results, lz, 4096, 3);
+    case ALZ_FMT_PRS_BE: return launch_serial<ALZ_FMT_PRS_BE, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_PRS_LE: return launch_serial<ALZ_FMT_PRS_LE, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_LZ4_BLOCK: return launch_serial<ALZ_FMT_LZ4_BLOCK, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_LZO: return launch_serial<ALZ_FMT_LZO, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_SNAPPY_RAW: return launch_serial<ALZ_FMT_SNAPPY_RAW, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    default: return hipErrorInvalidValue;
+    }
+}

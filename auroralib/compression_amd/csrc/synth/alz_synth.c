@@ -1,0 +1,373 @@
+/*
+ * alz_synth.c -- seeded token-level generators of synthetic compressed streams
+ * (SURVEY.md section 8d "Concrete synthetic inputs").  Host-side C, no GPU.
+ *
+ * Streams are generated directly in compressed form: the generator only tracks
+ * how many bytes the stream will decode to, so it runs in O(compressed size).
+ * PRNG: splitmix64, seed = base_seed + stream_index.
+ *
+ * Token mix for the flag-byte formats (LZSS/LZ10/LZ11/Yaz0/Yay0/MIO0/PRS):
+ *   literal w.p. 0.5 (uniform byte); match length uniform over [min, min(max,18)]
+ *   w.p. 0.9 else uniform over the format's long range; distance uniform in
+ *   [1, min(produced, W)], forced to 1 w.p. 0.05 (RLE), < length w.p. 0.1
+ *   (self-overlap); the last token is clipped so the stream ends exactly at the
+ *   target size.
+ * LZ4/LZO/Snappy: literal run geometric(mean 6), match length min+geometric(mean 10),
+ *   distance uniform in [1, min(produced, Dmax)].
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "auroralz.h"
+
+typedef struct { uint64_t s; } rng_t;
+static inline uint64_t rng_next(rng_t* r) {
+    uint64_t z = (r->s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline uint32_t rng_range(rng_t* r, uint32_t lo, uint32_t hi) { /* inclusive */
+    return lo + (uint32_t)(rng_next(r) % (uint64_t)(hi - lo + 1));
+}
+static inline double rng_unit(rng_t* r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+static inline uint32_t rng_geometric(rng_t* r, double mean) { /* >= 0, mean `mean` */
+    double u = rng_unit(r); if (u <= 0) u = 1e-300;
+    double p = 1.0 / (mean + 1.0);
+    return (uint32_t)floor(log(u) / log(1.0 - p));
+}
+
+/* output sink that can also just count */
+typedef struct { uint8_t* p; size_t len, cap; int fail; } out_t;
+static inline void o_put(out_t* o, const void* d, size_t n) {
+    if (o->p) { if (o->len + n > o->cap) { o->fail = 1; } else memcpy(o->p + o->len, d, n); }
+    o->len += n;
+}
+static inline void o_u8(out_t* o, uint32_t v) { uint8_t x = (uint8_t)v; o_put(o, &x, 1); }
+
+/* flag byte accumulator: flag byte is emitted before the payload of its 8 tokens */
+typedef struct { out_t* base; uint8_t payload[8 * 8 + 16]; int plen; int bits_left; int cur; int msb; } fw_t;
+static void fw_init(fw_t* f, out_t* base, int msb) { f->base = base; f->plen = 0; f->bits_left = 8; f->cur = 0; f->msb = msb; }
+static void fw_flush(fw_t* f) {
+    if (f->bits_left != 8) { o_u8(f->base, (uint32_t)f->cur); f->bits_left = 8; f->cur = 0; }
+    if (f->plen) { o_put(f->base, f->payload, (size_t)f->plen); f->plen = 0; }
+}
+static void fw_bit(fw_t* f, int bit) {
+    if (bit) { int sh = f->msb ? f->bits_left - 1 : 8 - f->bits_left; f->cur |= 1 << sh; }
+    if (--f->bits_left == 0) fw_flush(f);
+}
+static inline void fw_pay(fw_t* f, uint32_t v) { f->payload[f->plen++] = (uint8_t)v; }
+static void fw_flush_if_necessary(fw_t* f) { if (f->bits_left == 8 && f->plen) { o_put(f->base, f->payload, (size_t)f->plen); f->plen = 0; } }
+
+typedef struct { uint32_t len, dist; } tok_t;
+
+/* draw a match for a stream that has produced `produced` bytes and may still produce `rem` */
+static tok_t draw_match(rng_t* r, uint32_t produced, uint32_t rem, uint32_t minlen, uint32_t shortmax,
+                        uint32_t longlo, uint32_t longhi, uint32_t maxdist) {
+    tok_t t;
+    if (longhi && rng_unit(r) >= 0.9) t.len = rng_range(r, longlo, longhi);
+    else t.len = rng_range(r, minlen, shortmax);
+    if (t.len > rem) t.len = rem;
+    uint32_t maxd = produced < maxdist ? produced : maxdist;
+    double u = rng_unit(r);
+    if (u < 0.05) t.dist = 1;
+    else if (u < 0.15 && t.len > 1) { uint32_t hi = t.len - 1 < maxd ? t.len - 1 : maxd; t.dist = rng_range(r, 1, hi); }
+    else t.dist = rng_range(r, 1, maxd);
+    return t;
+}
+
+static alz_lz_properties lzss_eff(const alz_lz_properties* p) {
+    alz_lz_properties d;
+    if (!p || p->window_bits == 0) { memset(&d, 0, sizeof(d)); d.window_bits = 12; d.length_bits = 4; d.min_length = 3; d.max_distance = 4096; d.windows_start = 0xFEE; }
+    else { d = *p; if (!d.max_distance) d.max_distance = 1u << d.window_bits; }
+    return d;
+}
+
+/* ---- flag-byte family ---- */
+static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* r, uint32_t target, out_t* out, alz_encode_aux* aux) {
+    alz_lz_properties lz = lzss_eff(props);
+    uint32_t minlen = 3, shortmax = 18, longlo = 0, longhi = 0, W = 4096;
+    int msb = 1;
+    switch (format) {
+    case ALZ_FMT_LZSS: msb = 0; minlen = lz.min_length; shortmax = (1u << lz.length_bits) + lz.min_length - 1; if (shortmax > 18 && lz.length_bits <= 4) shortmax = 18;
+        if (lz.length_bits > 4) { longlo = 19; longhi = (1u << lz.length_bits) + lz.min_length - 1; shortmax = 18; }
+        W = 1u << lz.window_bits; break;
+    case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: break;
+    case ALZ_FMT_LZ11: longlo = 17; longhi = 272; break;
+    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: longlo = 18; longhi = 273; break;
+    default: break;
+    }
+    int three = (format == ALZ_FMT_YAY0 || format == ALZ_FMT_MIO0);
+    /* three-section formats buffer tokens/literals separately */
+    out_t flags = { NULL, 0, 0, 0 }, comp = { NULL, 0, 0, 0 }, unc = { NULL, 0, 0, 0 };
+    uint8_t *fb = NULL, *cb = NULL, *ub = NULL;
+    if (three && out->p) {
+        size_t cap = (size_t)target + (target >> 2) + 64;
+        fb = (uint8_t*)malloc(cap / 8 + 64); cb = (uint8_t*)malloc(cap); ub = (uint8_t*)malloc(cap);
+        flags.p = fb; flags.cap = cap / 8 + 64; comp.p = cb; comp.cap = cap; unc.p = ub; unc.cap = cap;
+    }
+    fw_t fw; fw_init(&fw, three ? &flags : out, msb);
+    uint32_t produced = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        int lit = produced == 0 || rem < minlen || rng_unit(r) < 0.5;
+        if (lit) {
+            uint32_t b = (uint32_t)(rng_next(r) & 0xFF);
+            switch (format) {
+            case ALZ_FMT_LZSS: fw_pay(&fw, b); fw_bit(&fw, 1); break;
+            case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: fw_pay(&fw, b); fw_bit(&fw, 0); break;
+            case ALZ_FMT_YAZ0: fw_pay(&fw, b); fw_bit(&fw, 1); break;
+            default: o_u8(&unc, b); fw_bit(&fw, 1); break; /* YAY0 / MIO0 */
+            }
+            produced++;
+            continue;
+        }
+        tok_t t = draw_match(r, produced, rem, minlen, shortmax, longlo, longhi, W);
+        if (format == ALZ_FMT_LZ11 && rng_unit(r) < 0.002 && rem > 273) { t.len = rng_range(r, 273, rem < 2000 ? rem : 2000); }
+        uint32_t d1 = t.dist - 1;
+        switch (format) {
+        case ALZ_FMT_LZSS: {
+            uint32_t off = (lz.windows_start + produced - t.dist) & (W - 1);
+            fw_pay(&fw, off & 0xFF);
+            fw_pay(&fw, ((off >> 8) << lz.length_bits) | ((t.len - lz.min_length) & ((1u << lz.length_bits) - 1)));
+            fw_bit(&fw, 0); break;
+        }
+        case ALZ_FMT_LZ10: fw_pay(&fw, ((t.len - 3) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); fw_bit(&fw, 1); break;
+        case ALZ_FMT_LZ11:
+            if (t.len <= 16) { fw_pay(&fw, ((t.len - 1) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
+            else if (t.len <= 272) { uint32_t l = t.len - 17; fw_pay(&fw, l >> 4); fw_pay(&fw, ((l & 0xF) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
+            else { uint32_t l = t.len - 273; fw_pay(&fw, 0x10 | (l >> 12)); fw_pay(&fw, (l >> 4) & 0xFF); fw_pay(&fw, ((l & 0xF) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
+            fw_bit(&fw, 1); break;
+        case ALZ_FMT_YAZ0:
+            if (t.len < 18) { fw_pay(&fw, ((t.len - 2) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
+            else { fw_pay(&fw, d1 >> 8); fw_pay(&fw, d1 & 0xFF); fw_pay(&fw, t.len - 0x12); }
+            fw_bit(&fw, 0); break;
+        case ALZ_FMT_YAY0:
+            if (t.len < 18) { o_u8(&comp, ((t.len - 2) << 4) | (d1 >> 8)); o_u8(&comp, d1 & 0xFF); }
+            else { o_u8(&comp, d1 >> 8); o_u8(&comp, d1 & 0xFF); o_u8(&unc, t.len - 0x12); }
+            fw_bit(&fw, 0); break;
+        default: /* MIO0 */
+            o_u8(&comp, ((t.len - 3) << 4) | (d1 >> 8)); o_u8(&comp, d1 & 0xFF); fw_bit(&fw, 0); break;
+        }
+        produced += t.len;
+    }
+    fw_flush(&fw);
+    if (three) {
+        if (aux) { aux->aux0 = (uint32_t)flags.len; aux->aux1 = (uint32_t)(flags.len + comp.len); }
+        if (out->p) { o_put(out, fb, flags.len); o_put(out, cb, comp.len); o_put(out, ub, unc.len); }
+        else out->len += flags.len + comp.len + unc.len;
+        if (flags.fail || comp.fail || unc.fail) out->fail = 1;
+        free(fb); free(cb); free(ub);
+    }
+}
+
+/* ---- PRS (Sega/PRS.cs:104-159 emission rules) ---- */
+static void gen_prs(rng_t* r, uint32_t target, out_t* out, int big) {
+    fw_t fw; fw_init(&fw, out, big);
+    uint32_t produced = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        int lit = produced == 0 || rem < 2 || rng_unit(r) < 0.5;
+        if (lit) { fw_pay(&fw, (uint32_t)(rng_next(r) & 0xFF)); fw_bit(&fw, 1); produced++; continue; }
+        tok_t t = draw_match(r, produced, rem, 2, 18, 10, 256, 0x1FFF);
+        if (t.len == 2 && t.dist > 0x100) t.dist = rng_range(r, 1, produced < 0x100 ? produced : 0x100);
+        fw_bit(&fw, 0);
+        if (t.dist <= 0x100 && t.len <= 5) {
+            fw_bit(&fw, 0);
+            fw_bit(&fw, ((t.len - 2) >> 1) & 1); fw_bit(&fw, (t.len - 2) & 1);
+            fw_pay(&fw, (0x100 - t.dist) & 0xFF);
+            fw_flush_if_necessary(&fw);
+        } else {
+            uint32_t v = ((0x2000 - t.dist) << 3) & 0xFFFF;
+            if (t.len > 9) { if (big) { fw_pay(&fw, v >> 8); fw_pay(&fw, v & 0xFF); } else { fw_pay(&fw, v & 0xFF); fw_pay(&fw, v >> 8); } fw_pay(&fw, t.len - 1); }
+            else { v |= (t.len - 2); if (big) { fw_pay(&fw, v >> 8); fw_pay(&fw, v & 0xFF); } else { fw_pay(&fw, v & 0xFF); fw_pay(&fw, v >> 8); } }
+            fw_bit(&fw, 1);
+        }
+        produced += t.len;
+    }
+    fw_bit(&fw, 0); fw_pay(&fw, 0); fw_pay(&fw, 0); fw_bit(&fw, 1);
+    fw_flush(&fw);
+}
+
+static void put_rand(out_t* o, rng_t* r, uint32_t n) {
+    while (n >= 8) { uint64_t v = rng_next(r); o_put(o, &v, 8); n -= 8; }
+    if (n) { uint64_t v = rng_next(r); o_put(o, &v, n); }
+}
+
+static tok_t draw_match_seq(rng_t* r, uint32_t produced, uint32_t rem, uint32_t minlen, uint32_t maxlen, uint32_t maxdist) {
+    tok_t t;
+    if (rng_unit(r) < 0.1) t.len = rng_range(r, 19, 300); else t.len = minlen + rng_geometric(r, 10.0);
+    if (t.len > maxlen) t.len = maxlen;
+    if (t.len > rem) t.len = rem;
+    uint32_t maxd = produced < maxdist ? produced : maxdist;
+    double u = rng_unit(r);
+    if (u < 0.05) t.dist = 1;
+    else if (u < 0.15 && t.len > 1) { uint32_t hi = t.len - 1 < maxd ? t.len - 1 : maxd; t.dist = rng_range(r, 1, hi); }
+    else t.dist = rng_range(r, 1, maxd);
+    return t;
+}
+
+/* ---- LZ4 block ---- */
+static void lz4_ext(out_t* o, uint32_t len) { if (len >= 15) { len -= 15; while (len >= 255) { o_u8(o, 255); len -= 255; } o_u8(o, len); } }
+static void gen_lz4(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    for (;;) {
+        uint32_t rem = target - produced;
+        uint32_t lit = rng_geometric(r, 6.0); if (produced == 0 && lit == 0) lit = 1;
+        /* final sequence: literals only, at least 5 bytes where the block allows it */
+        if (lit + 4 + 5 > rem) {
+            lit = rem;
+            o_u8(out, (lit > 15 ? 15 : lit) << 4); lz4_ext(out, lit); put_rand(out, r, lit);
+            return;
+        }
+        tok_t t = draw_match_seq(r, produced + lit, rem - lit - 5, 4, 0x7FFFFFFF, 65535);
+        if (t.len < 4) t.len = 4;
+        o_u8(out, ((lit > 15 ? 15 : lit) << 4) | (t.len - 4 > 15 ? 15 : t.len - 4));
+        lz4_ext(out, lit); put_rand(out, r, lit);
+        o_u8(out, t.dist & 0xFF); o_u8(out, t.dist >> 8);
+        lz4_ext(out, t.len - 4);
+        produced += lit + t.len;
+    }
+}
+
+/* ---- Snappy raw ---- */
+static void gen_snappy(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t v = target; while (v >= 0x80) { o_u8(out, v | 0x80); v >>= 7; } o_u8(out, v);
+    uint32_t produced = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        uint32_t lit = 1 + rng_geometric(r, 5.0); if (lit > rem) lit = rem;
+        if (rng_unit(r) < 0.01) { lit = rng_range(r, 61, 400); if (lit > rem) lit = rem; }
+        if (lit <= 60) o_u8(out, (lit - 1) << 2);
+        else if (lit - 1 <= 0xFF) { o_u8(out, 60 << 2); o_u8(out, lit - 1); }
+        else { o_u8(out, 61 << 2); o_u8(out, (lit - 1) & 0xFF); o_u8(out, (lit - 1) >> 8); }
+        put_rand(out, r, lit); produced += lit; rem -= lit;
+        if (rem < 4) { if (rem) { o_u8(out, (rem - 1) << 2); put_rand(out, r, rem); produced += rem; } continue; }
+        tok_t t = draw_match_seq(r, produced, rem, 4, 64, 65535);
+        if (t.len < 4) t.len = 4;
+        if (t.dist < 2048 && t.len <= 11) { o_u8(out, 1 | ((t.len - 4) << 2) | ((t.dist >> 8) << 5)); o_u8(out, t.dist & 0xFF); }
+        else { o_u8(out, 2 | ((t.len - 1) << 2)); o_u8(out, t.dist & 0xFF); o_u8(out, t.dist >> 8); }
+        produced += t.len;
+    }
+}
+
+/* ---- LZO (opcode forms of Formats/Common/LZO.cs:141-250) ---- */
+static void lzo_ext(out_t* o, uint32_t v) { while (v > 255) { o_u8(o, 0); v -= 255; } o_u8(o, v); }
+static void gen_lzo(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    if (target < 16) { /* LZO.cs:143-152 */
+        o_u8(out, 17 + target); put_rand(out, r, target); o_u8(out, 0x11); o_u8(out, 0); o_u8(out, 0); return;
+    }
+    /* initial literal run >= 4 via the "plain copy" opcode (plain == 0 state) */
+    uint32_t pending = 4 + rng_geometric(r, 4.0); if (pending > target) pending = target;
+    for (;;) {
+        /* emit a literal run of `pending` (>= 4) bytes */
+        if (pending) {
+            if (pending > 18) { o_u8(out, 0); lzo_ext(out, pending - 18); } else o_u8(out, pending - 3);
+            put_rand(out, r, pending); produced += pending;
+        }
+        /* matches, each followed by 0..3 trailing literals, until we need a long run again */
+        for (;;) {
+            uint32_t rem = target - produced;
+            if (rem < 3) {
+                /* finish: trailing bytes must ride on a literal opcode of >= 4; rewind is impossible, so emit a
+                   minimal match chain: rem in {0,1,2}.  rem==0: done.  else encode them as trailing literals of a
+                   length-3 match drawn earlier -- handled by always keeping rem >= 3 + tail below. */
+                goto done;
+            }
+            tok_t t = draw_match_seq(r, produced, rem, 3, 0x7FFFFFFF, 0xBFFF);
+            if (t.len < 3) t.len = 3;
+            uint32_t after = rem - t.len;
+            /* choose trailing literal count so that the remainder never becomes 1..2 bytes of orphan literals */
+            uint32_t tail = rng_range(r, 0, 3);
+            uint32_t longrun = 0;
+            if (rng_unit(r) < 0.35) { tail = 0; longrun = 4 + rng_geometric(r, 4.0); }
+            if (tail > after) tail = after;
+            after -= tail;
+            if (longrun) { if (longrun > after) { if (after >= 4) longrun = after; else { longrun = 0; } } after -= longrun; }
+            if (after > 0 && after < 3) { /* absorb the orphan bytes */
+                if (longrun) { longrun += after; }
+                else if (tail + after <= 3) { tail += after; }
+                else { t.len += after; }
+                after = 0;
+            }
+            /* encode match */
+            if (t.len <= 8 && t.dist <= 2048) {
+                uint32_t flag = tail | (((t.dist - 1) & 7) << 2);
+                if (t.len <= 4) o_u8(out, flag | 0x40 | ((t.len - 3) << 5)); else o_u8(out, flag | 0x80 | ((t.len - 5) << 5));
+                o_u8(out, (t.dist - 1) >> 3);
+            } else if (t.dist <= 16384) {
+                if (t.len > 33) { o_u8(out, 0x20); lzo_ext(out, t.len - 33); } else o_u8(out, 0x20 | (t.len - 2));
+                o_u8(out, (tail | ((t.dist - 1) << 2)) & 0xFF); o_u8(out, (t.dist - 1) >> 6);
+            } else {
+                uint32_t d = t.dist - 0x4000; uint32_t flag = 0x10 | ((d & 0x4000) >> 11);
+                if (t.len > 9) { o_u8(out, flag); lzo_ext(out, t.len - 9); } else o_u8(out, flag | (t.len - 2));
+                o_u8(out, (tail | (d << 2)) & 0xFF); o_u8(out, (d >> 6) & 0xFF);
+            }
+            put_rand(out, r, tail);
+            produced += t.len + tail;
+            if (longrun) { pending = longrun; break; }
+            if (produced >= target) goto done;
+        }
+        if (produced >= target) break;
+    }
+done:
+    o_u8(out, 0x11); o_u8(out, 0); o_u8(out, 0);
+}
+
+/* one stream; dst may be NULL to only measure.  Returns compressed size (or -1 on overflow). */
+int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64_t seed, uint32_t target,
+                         uint8_t* dst, size_t cap, alz_encode_aux* aux) {
+    rng_t r = { seed };
+    out_t out = { dst, 0, cap, 0 };
+    if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
+    switch (format) {
+    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
+        gen_flagfmt(format, props, &r, target, &out, aux); break;
+    case ALZ_FMT_PRS_BE: gen_prs(&r, target, &out, 1); break;
+    case ALZ_FMT_PRS_LE: gen_prs(&r, target, &out, 0); break;
+    case ALZ_FMT_LZ4_BLOCK: gen_lz4(&r, target, &out); break;
+    case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
+    case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
+    default: return -2;
+    }
+    return out.fail ? -1 : (int64_t)out.len;
+}
+
+typedef struct {
+    const uint32_t* formats; uint32_t format; const alz_lz_properties* props; uint64_t base_seed; uint32_t n;
+    const uint32_t* targets; uint32_t target; uint8_t* dst; const uint64_t* offs; uint32_t* sizes; alz_encode_aux* aux;
+    int tid, nt;
+} sjob_t;
+
+static void* synth_worker(void* arg) {
+    sjob_t* j = (sjob_t*)arg;
+    for (uint32_t i = (uint32_t)j->tid; i < j->n; i += (uint32_t)j->nt) {
+        uint32_t fmt = j->formats ? j->formats[i] : j->format;
+        uint32_t tgt = j->targets ? j->targets[i] : j->target;
+        alz_encode_aux a;
+        if (!j->dst) j->sizes[i] = (uint32_t)alz_synth_stream(fmt, j->props, j->base_seed + i, tgt, NULL, 0, &a);
+        else (void)alz_synth_stream(fmt, j->props, j->base_seed + i, tgt, j->dst + j->offs[i], j->sizes[i], &a);
+        if (j->aux) j->aux[i] = a;
+    }
+    return NULL;
+}
+
+/* Two-pass batch: call with dst == NULL to get sizes[], lay the streams out, call again with dst/offs. */
+int alz_synth_batch(const uint32_t* formats, uint32_t format, const alz_lz_properties* props, uint64_t base_seed, uint32_t n,
+                    const uint32_t* targets, uint32_t target, uint8_t* dst, const uint64_t* offs, uint32_t* sizes,
+                    alz_encode_aux* aux, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256]; sjob_t jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        sjob_t j = { formats, format, props, base_seed, n, targets, target, dst, offs, sizes, aux, t, nthreads };
+        jobs[t] = j;
+        if (nthreads == 1) synth_worker(&jobs[0]); else pthread_create(&th[t], NULL, synth_worker, &jobs[t]);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    return 0;
+}

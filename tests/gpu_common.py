@@ -1,0 +1,54 @@
+"""Helpers shared by the -m gpu parity tests: run a batch through the C ABI and through the oracle, compare bit-exactly."""
+import numpy as np
+
+import oracle_lib as O
+from auroralib.compression_amd import _abi as A
+from auroralib.compression_amd import synth
+
+_ctx = None
+
+
+def ctx():
+    global _ctx
+    if _ctx is None:
+        from auroralib.compression_amd.batch import Context
+        _ctx = Context(0)
+    return _ctx
+
+
+def compare_batch(streams, src, dst_bytes, lz=None, what=""):
+    """Decode on the GPU (host-buffer ABI) and with the oracle; every result field and every output byte must match."""
+    n = len(streams)
+    g_dst, g_res = ctx().decode_batch(streams, src, dst_bytes, lz=lz)
+    o_dst, o_res = O.decode_batch(streams, src, dst_bytes, lz=lz, nthreads=8)
+    gr, orr, sr = synth.result_records(g_res), synth.result_records(o_res), synth.stream_records(streams)
+    bad = np.nonzero((gr["status"] != orr["status"]) | (gr["dst_len"] != orr["dst_len"]))[0]
+    assert bad.size == 0, "%s: stream %d: gpu(status=%d,len=%d) oracle(status=%d,len=%d)" % (
+        what, bad[0], gr["status"][bad[0]], gr["dst_len"][bad[0]], orr["status"][bad[0]], orr["dst_len"][bad[0]])
+    ok = (orr["status"] == A.ST_OK) | (orr["status"] == A.ST_OUTPUT_SIZE_MISMATCH)
+    badu = np.nonzero(ok & (gr["src_used"] != orr["src_used"]))[0]
+    assert badu.size == 0, "%s: stream %d src_used gpu=%d oracle=%d" % (what, badu[0] if badu.size else -1, gr["src_used"][badu[0]], orr["src_used"][badu[0]])
+    for i in range(n):
+        a, ln = int(sr["dst_off"][i]), int(orr["dst_len"][i])
+        if not np.array_equal(g_dst[a:a + ln], o_dst[a:a + ln]):
+            d = np.nonzero(g_dst[a:a + ln] != o_dst[a:a + ln])[0]
+            raise AssertionError("%s: stream %d differs at byte %d of %d (gpu=%d oracle=%d), %d bytes differ" % (
+                what, i, d[0], ln, g_dst[a + d[0]], o_dst[a + d[0]], d.size))
+    return gr, g_dst
+
+
+def pack_streams(items, dst_align=16, dst_slack=0):
+    """items: list of dicts(fmt, src(bytes), decom_len, cap(optional), aux0, aux1). Returns (streams, src array, dst_bytes)."""
+    n = len(items)
+    streams = (A.Stream * n)()
+    chunks, so, do = [], 0, 0
+    for i, it in enumerate(items):
+        b = bytes(it["src"])
+        cap = it.get("cap", it.get("decom_len", 0))
+        streams[i] = A.Stream(so, do, len(b), cap, it.get("decom_len", 0), it.get("aux0", 0), it.get("aux1", 0), it["fmt"])
+        pad = (-len(b)) % 16 + it.get("src_misalign", 0)
+        chunks.append(b + bytes(pad))
+        so += len(b) + pad
+        do += (cap + dst_slack + dst_align - 1) // dst_align * dst_align + it.get("dst_misalign", 0)
+    src = np.frombuffer(b"".join(chunks) + bytes(64), dtype=np.uint8).copy()
+    return streams, src, do + 64

@@ -1,0 +1,71 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol declared in
+include/auroralz.h, struct layouts match, and the product path refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from auroralib.compression_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "auroralz.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(alz_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from auroralib.compression_amd import _lib
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 20
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert lib.alz_abi_version() == A.ABI_VERSION
+
+
+def test_struct_layouts():
+    assert C.sizeof(A.Stream) == 40 and A.Stream.format.offset == 36
+    assert C.sizeof(A.Result) == 16 and C.sizeof(A.LzProperties) == 16 and C.sizeof(A.Settings) == 16
+    lz = A.LzProperties.from_bits(12, 4, 2)
+    assert (lz.window_bits, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance) == (12, 4, 3, 0xFEE, 4096)
+    lz = A.LzProperties.from_bits(10, 6, 2)
+    assert (lz.windows_start, lz.max_distance) == (958, 1024)
+
+
+def test_single_hip_runtime_in_process():
+    from auroralib.compression_amd import _lib
+    _lib.load()
+    maps = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(maps) == 1, maps
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU the product path must fail loudly, never route through a CPU decoder."""
+    from auroralib.compression_amd import _lib
+    lib = _lib.load()
+    if lib.alz_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from auroralib.compression_amd.batch import Context
+    with pytest.raises(_lib.AlzError) as ei:
+        Context(0)
+    assert ei.value.code == A.E_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """The oracle is test infrastructure: nothing under auroralib/ may import, link or dlopen it."""
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "auroralib")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".c", ".sh")):
+                t = open(os.path.join(dp, f), errors="replace").read()
+                if "liboracle" in t or "alz_oracle" in t or "oracle_lib" in t:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    import subprocess
+    so = os.path.join(ROOT, "auroralib", "compression_amd", "libauroralz.so")
+    needed = subprocess.run(["objdump", "-p", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
