@@ -126,8 +126,8 @@ __device__ void dec_yaz0_serial(InCache& in, OW& out, DecState& s, u32 src_len, 
 // fc: flags from 0, cc: tokens from aux0, uc: literals from aux1; each cursor bounded by its slice length.
 template <class OW, bool MIO0>
 __device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, OW& out, DecState& s, u32 src_len, u32 size,
-                                   u32 cptr0, u32 uptr0, u32& used) {
-    u32 fp = 0, cp = cptr0, up = uptr0;
+                                   u32 fptr0, u32 cptr0, u32 uptr0, u32& used) {
+    u32 fp = fptr0, cp = cptr0, up = uptr0;
     while (out.produced < size) {
         if (s.bits == 0) {
             if (fp >= src_len) { s.eof = true; break; }

@@ -49,6 +49,8 @@ static alz_lz_properties effective_lz(const alz_lz_properties* p) {
 extern "C" {
 
 int alz_abi_version(void) { return ALZ_ABI_VERSION; }
+/* not in the public header: test hook that selects the exact serial kernels for every format (still the GPU path) */
+void alz_debug_force_serial(int on) { alz_set_force_serial(on); }
 const char* alz_last_error(void) { return g_err; }
 
 int alz_device_count(void) {

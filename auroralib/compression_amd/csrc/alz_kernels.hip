@@ -7,7 +7,7 @@
 // traffic and no L2 sharing to arrange.
 #include <hip/hip_runtime.h>
 
-#include "alz_decode_serial.h"
+#include "alz_decode_fast.h"
 #include "alz_internal.h"
 
 #define ALZ_INCACHE_BYTES (2048 + 16)
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
             InCache cin, uin;
             cin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); cin.seek(a0 < src_len ? a0 : 0);
             uin.init(src, src_len, inc_lds + 2 * ALZ_INCACHE_BYTES, lane); uin.seek(a1 < src_len ? a1 : 0);
-            dec_3cursor_serial<OutWin<FB>, FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, src_len, size, a0, a1, used);
+            dec_3cursor_serial<OutWin<FB>, FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, src_len, size, 0, a0, a1, used);
             used_set = true;
         }
     } else if constexpr (FMT == ALZ_FMT_PRS_BE) {
@@ -78,6 +78,64 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lane-parallel kernel of the flag-byte family (alz_decode_fast.h); the exact serial parser finishes the tail.
+template <int FMT>
+__global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                             const alz_stream* __restrict__ streams,
+                                                             const u32* __restrict__ index_list, u32 count,
+                                                             alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
+    extern __shared__ uint4 smem[];
+    u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    u8* dst = dst_base + st.dst_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr int NC = THREE ? 3 : 1;
+
+    u8* lds = reinterpret_cast<u8*>(smem);
+    OutWin<false> out; out.init(dst, cap, lds, lw, lane);
+    u8* inc_lds = lds + lw;
+    u8* segmark = inc_lds + NC * ALZ_INCACHE_BYTES;
+    segmark[lane] = 0;
+    InCache in; in.init(src, src_len, inc_lds, lane);
+    DecState s; dec_state_init(s);
+    u32 used = 0; bool used_set = false;
+    bool fin = false;
+
+    if constexpr (!THREE) {
+        FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
+        gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
+        while (!fin && out.produced < size && s.p + 128u <= src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, segmark, lane, gm);
+        if (!fin) {
+            if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, out, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
+            else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<OutWin<false>, false>(in, out, s, src_len, size);
+            else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<OutWin<false>, true>(in, out, s, src_len, size);
+            else dec_yaz0_serial(in, out, s, src_len, size);
+        }
+    } else {
+        const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
+        if (FMT == ALZ_FMT_YAY0 && (a0 > src_len || a1 > src_len)) s.eof = true;   // Slice() throws  Yay0.cs:102-103
+        else {
+            InCache cin, uin;
+            cin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); cin.seek(a0 < src_len ? a0 : 0);
+            uin.init(src, src_len, inc_lds + 2 * ALZ_INCACHE_BYTES, lane); uin.seek(a1 < src_len ? a1 : 0);
+            u32 fp = 0, cp = a0, up = a1;
+            while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len)
+                fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, segmark, lane, fp, cp, up);
+            used = cp > up ? cp : up;
+            if (!fin) dec_3cursor_serial<OutWin<false>, FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, src_len, size, fp, cp, up, used);
+            used_set = true;
+        }
+    }
+    out.finish();
+    write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, true, out.produced, size, cap));
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 
 template <int FMT, bool FB>
@@ -88,12 +146,38 @@ static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, cons
     return hipGetLastError();
 }
 
+template <int FMT>
+static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
+                              alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
+    size_t lds = lw + (size_t)ncaches * ALZ_INCACHE_BYTES + 64;
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3(count), dim3(64), lds, stream, src, dst, streams, index, count, results, lz, lw);
+    return hipGetLastError();
+}
+
+static bool g_force_serial = false;
+void alz_set_force_serial(int on) { g_force_serial = on != 0; }
+
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
                              u32 count, alz_result* results, const alz_lz_properties* lzp) {
     if (count == 0) return hipSuccess;
     const u8* s = (const u8*)src; u8* d = (u8*)dst;
     alz_lz_properties lz = *lzp;
-    switch (fmt) {
+    if (!g_force_serial) {
+        switch (fmt) {   // lane-parallel kernels
+        case ALZ_FMT_LZSS: {
+            u32 W = 1u << lz.window_bits;
+            if (W <= 8192 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS>(stream, s, d, streams, index, count, results, lz, W, 1);
+            break;
+        }
+        case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+        case ALZ_FMT_LZ11: return launch_fast<ALZ_FMT_LZ11>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+        case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+        case ALZ_FMT_YAY0: return launch_fast<ALZ_FMT_YAY0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
+        case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
+        default: break;
+        }
+    }
+    switch (fmt) {       // exact serial kernels
     case ALZ_FMT_LZSS: {
         u32 W = 1u << lz.window_bits;
         if (W <= 8192) return launch_serial<ALZ_FMT_LZSS, false>(stream, s, d, streams, index, count, results, lz, W, 1);

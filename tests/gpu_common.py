@@ -19,8 +19,20 @@ def ctx():
 def compare_batch(streams, src, dst_bytes, lz=None, what=""):
     """Decode on the GPU (host-buffer ABI) and with the oracle; every result field and every output byte must match."""
     n = len(streams)
-    g_dst, g_res = ctx().decode_batch(streams, src, dst_bytes, lz=lz)
     o_dst, o_res = O.decode_batch(streams, src, dst_bytes, lz=lz, nthreads=8)
+    # both GPU kernel families: the lane-parallel kernels (default dispatch) and the exact serial kernels
+    for serial in (1, 0):
+        ctx().lib.alz_debug_force_serial(serial)
+        try:
+            g_dst, g_res = ctx().decode_batch(streams, src, dst_bytes, lz=lz)
+        finally:
+            ctx().lib.alz_debug_force_serial(0)
+        gr, g_dst = _check(streams, g_dst, g_res, o_dst, o_res, what + (" [serial kernels]" if serial else " [fast kernels]"))
+    return gr, g_dst
+
+
+def _check(streams, g_dst, g_res, o_dst, o_res, what):
+    n = len(streams)
     gr, orr, sr = synth.result_records(g_res), synth.result_records(o_res), synth.stream_records(streams)
     bad = np.nonzero((gr["status"] != orr["status"]) | (gr["dst_len"] != orr["dst_len"]))[0]
     assert bad.size == 0, "%s: stream %d: gpu(status=%d,len=%d) oracle(status=%d,len=%d)" % (
