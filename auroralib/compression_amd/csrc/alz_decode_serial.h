@@ -341,7 +341,7 @@ __device__ void dec_snappy_serial(InCache& in, OW& out, DecState& s, u32 src_len
 #undef SN_BYTE
 }
 
-// status resolution, identical to oracle/alz_oracle.c decode_one()
+// status resolution (precedence: truncated > bad token > E5 capacity/size > overshoot), see DESIGN.md "Status rules"
 __device__ __forceinline__ int resolve_status(const DecState& s, bool has_size, u32 produced, u32 size, u32 cap) {
     if (s.eof) return ALZ_ST_INPUT_TRUNCATED;
     if (s.bad) return ALZ_ST_BAD_TOKEN;

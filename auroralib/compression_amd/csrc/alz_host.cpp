@@ -260,4 +260,12 @@ int alz_decode(alz_ctx* c, uint32_t format, const alz_lz_properties* props, cons
     return alz_decode_batch(c, props, 1, src, src_len, &s, dst, dst_cap, result);
 }
 
+int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
+                     size_t src_bytes, const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
+    (void)props; (void)settings; (void)src_base; (void)src_bytes; (void)streams; (void)dst_base; (void)dst_bytes; (void)results; (void)aux;
+    if (!c) return fail(ALZ_E_INVALID, "alz_encode_batch: ctx is NULL");
+    if (n == 0) return ALZ_OK;
+    return fail(ALZ_E_UNSUPPORTED, "alz_encode_batch: the GPU encoder is not built into this library yet (no CPU fallback exists)");
+}
+
 }  // extern "C"
