@@ -27,19 +27,26 @@ __device__ __forceinline__ u32 wave_bperm(u32 src_lane, u32 v) { return (u32)__b
 __device__ __forceinline__ u32 wave_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ u32 mbcnt64(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 
-// inclusive prefix sum over the 64 lanes
+// inclusive prefix sum over the 64 lanes: DPP row shifts inside the 16-lane rows, then row broadcasts (gfx9 DPP)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_add(u32 v) {
+    return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = wave_bperm((u32)(lane - d) & 63u, v);
-        if (lane >= d) v += t;
-    }
+    (void)lane;
+    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 -> rows 2,3
     return v;
 }
 
-// descriptor of a token for the byte phase: bit0 literal, bits 1..8 literal value, bits 9.. distance
-#define ALZ_DESC_LIT(b) (1u | ((b) << 1))
-#define ALZ_DESC_MATCH(d) ((d) << 9)
+// descriptor of a token for the byte phase: bit31 literal, bits 17..24 literal value, bits 0..16 distance
+#define ALZ_DESC_LIT(b) (0x80000000u | ((b) << 17))
+#define ALZ_DESC_MATCH(d) (d)
+#define ALZ_DESC_DIST(x) ((x) & 0x1FFFFu)
 
 struct FastGeom {           // LZSS geometry (other formats ignore it)
     u32 length_bits, min_length, windows_start, max_distance, W;
@@ -73,48 +80,54 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
     }
     last_tend = wave_readlane(tend, lastk);
     if (LZSS) {
-        if (!(desc & 1u)) {
-            u32 offset = desc >> 9;
+        if (!(desc >> 31)) {
+            u32 offset = ALZ_DESC_DIST(desc);
             u32 pos = (O + off) & (W - 1);
             u32 d = (pos - offset) & (W - 1);
             if (d == 0) d = W;                               // E1
             desc = ALZ_DESC_MATCH(d);
         }
     }
+    // ---- byte phase: 64 output bytes per step, one per lane
     int tbase = -1;
+    const u32 omask = out.lw_mask, oshift = out.oshift;
+    u8* const win = out.win;
+    u32 relm = keep ? off : 0xFFFFFF00u;                     // my token's start relative to the current step (huge: no start)
+    u32 qs = O + (u32)lane + oshift;                         // slot coordinate of this lane's byte in the current step
+    const u32 dummy = 64u + (u32)lane;
     for (u32 X = 0; X < T; X += 64) {
-        u32 nseg = T - X; if (nseg > 64) nseg = 64;
-        u32 rel = off - X;
-        if (keep && rel < 64u) segmark[rel] = 1;
+        const u32 nseg = T - X;                              // >= 64 for every step but the last
+        segmark[relm < 64u ? relm : dummy] = 1;              // token starts of this step -> 64-entry mark array
         wave_sync();
-        u32 mk = segmark[lane];
+        const u32 mk = segmark[lane];
         segmark[lane] = 0;
-        u64 M = __ballot(mk != 0);
-        int t = tbase + (int)mbcnt64(M) + (mk != 0 ? 1 : 0);
+        const u64 M = __ballot(mk != 0);
+        const int t = tbase + (int)mbcnt64(M) + (mk != 0 ? 1 : 0);
         tbase += (int)__popcll(M);
-        u32 dsc = wave_bperm((u32)t & 63u, desc);
-        const u32 q = O + X + (u32)lane;
-        const bool act = (u32)lane < nseg;
-        u32 val = (dsc >> 1) & 0xFFu;
-        int sl = -1;
-        if (act && !(dsc & 1u)) {
-            u32 dist = dsc >> 9;
-            val = 0;                                         // E2: before the stream start
-            if (dist <= q) {
-                u32 sp = q - dist;
-                if (sp >= O + X) sl = (int)(sp - (O + X));   // produced inside this very step
-                else val = out.win[out.slot(sp)];
-            }
-        }
-        while (__ballot(sl >= 0)) {                          // pointer jumping: at most 6 rounds
-            u32 fv = wave_bperm((u32)sl & 63u, val);
-            int fs = (int)wave_bperm((u32)sl & 63u, (u32)sl);
+        const u32 dsc = wave_bperm((u32)t, desc);
+        const u32 dist = ALZ_DESC_DIST(dsc);
+        const bool ismatch = (int)dsc >= 0;
+        u32 wv = win[(qs - dist) & omask];                   // source byte (unused garbage for literals)
+        if (O + X < W) { if (dist > qs - oshift) wv = 0; }   // E2: only the first W bytes can point before the stream start
+        u32 val = ismatch ? wv : ((dsc >> 17) & 0xFFu);
+        // a source produced inside this very step <=> dist <= lane: resolve by pointer jumping (at most 6 rounds)
+        int sl = (ismatch && dist <= (u32)lane && (u32)lane < nseg) ? (int)((u32)lane - dist) : -1;
+        while (__ballot(sl >= 0)) {
+            const u32 fv = wave_bperm((u32)sl, val);
+            const int fs = (int)wave_bperm((u32)sl, (u32)sl);
             if (sl >= 0) { if (fs < 0) { val = fv; sl = -1; } else sl = fs; }
         }
-        if (act) out.win[out.slot(q)] = (u8)val;
-        wave_sync();
-        out.produced = O + X + nseg;
-        out.flush_blocks();
+        if (nseg >= 64u) {
+            win[qs & omask] = (u8)val;
+            wave_sync();
+            out.produced = O + X + 64u;
+        } else {
+            if ((u32)lane < nseg) win[qs & omask] = (u8)val;
+            wave_sync();
+            out.produced = O + X + nseg;
+        }
+        qs += 64u; relm -= 64u;
+        if (out.produced - out.flushed >= out.fl) out.flush_blocks();
     }
     return fin;
 }

@@ -10,7 +10,7 @@
 #include "alz_decode_fast.h"
 #include "alz_internal.h"
 
-#define ALZ_INCACHE_BYTES (2048 + 16)
+#define ALZ_INCACHE_BYTES (2048 + 32)
 
 template <bool FB>
 __device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status) {
@@ -96,11 +96,12 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr int NC = THREE ? 3 : 1;
 
+    // LDS layout (compile-time offsets so they fold into the DS instructions): marks | input caches | window
     u8* lds = reinterpret_cast<u8*>(smem);
-    OutWin<false> out; out.init(dst, cap, lds, lw, lane);
-    u8* inc_lds = lds + lw;
-    u8* segmark = inc_lds + NC * ALZ_INCACHE_BYTES;
-    segmark[lane] = 0;
+    u8* segmark = lds;
+    u8* inc_lds = lds + 128;
+    OutWin<false> out; out.init(dst, cap, lds + 128 + NC * ALZ_INCACHE_BYTES, lw, lane);
+    segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
     u32 used = 0; bool used_set = false;
@@ -149,7 +150,7 @@ static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, cons
 template <int FMT>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
-    size_t lds = lw + (size_t)ncaches * ALZ_INCACHE_BYTES + 64;
+    size_t lds = lw + (size_t)ncaches * ALZ_INCACHE_BYTES + 128;
     hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3(count), dim3(64), lds, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
