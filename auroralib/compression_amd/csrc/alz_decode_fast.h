@@ -88,34 +88,41 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
             desc = ALZ_DESC_MATCH(d);
         }
     }
-    // ---- byte phase: 64 output bytes per step, one per lane
-    int tbase = -1;
+    // ---- byte phase: 64 output bytes per step, one per lane.  The kernel is bound by VALU issue (about one wave
+    // instruction per cycle per CU), so the step is written for the fewest vector instructions:
+    //   * token lanes mark the lane where their output ENDS inside the step; the token of byte L is then
+    //     (#tokens ended before the step) + (#marks below L) = one mbcnt pair, no correction term;
+    //   * a match descriptor IS its distance (literal descriptors have bit 31 set), so the source slot is
+    //     (slot - descriptor) & mask and "source inside this very step" is the unsigned test descriptor <= lane;
+    //   * the pointer-jumping machinery only runs in steps where that test fires for some lane.
+    int tbase = 0;                                           // tokens that ended before the current step
     const u32 omask = out.lw_mask, oshift = out.oshift;
     u8* const win = out.win;
-    u32 relm = keep ? off : 0xFFFFFF00u;                     // my token's start relative to the current step (huge: no start)
+    u32 relm = keep ? end - 1u : 0xFFFFFF00u;                // my token's LAST byte relative to the current step (huge: none)
     u32 qs = O + (u32)lane + oshift;                         // slot coordinate of this lane's byte in the current step
     const u32 dummy = 64u + (u32)lane;
     for (u32 X = 0; X < T; X += 64) {
         const u32 nseg = T - X;                              // >= 64 for every step but the last
-        segmark[relm < 64u ? relm : dummy] = 1;              // token starts of this step -> 64-entry mark array
+        segmark[relm < 64u ? relm : dummy] = 1;
         wave_sync();
         const u32 mk = segmark[lane];
         segmark[lane] = 0;
         const u64 M = __ballot(mk != 0);
-        const int t = tbase + (int)mbcnt64(M) + (mk != 0 ? 1 : 0);
+        const u32 t = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, (u32)tbase));
         tbase += (int)__popcll(M);
-        const u32 dsc = wave_bperm((u32)t, desc);
-        const u32 dist = ALZ_DESC_DIST(dsc);
-        const bool ismatch = (int)dsc >= 0;
-        u32 wv = win[(qs - dist) & omask];                   // source byte (unused garbage for literals)
-        if (O + X < W) { if (dist > qs - oshift) wv = 0; }   // E2: only the first W bytes can point before the stream start
-        u32 val = ismatch ? wv : ((dsc >> 17) & 0xFFu);
-        // a source produced inside this very step <=> dist <= lane: resolve by pointer jumping (at most 6 rounds)
-        int sl = (ismatch && dist <= (u32)lane && (u32)lane < nseg) ? (int)((u32)lane - dist) : -1;
-        while (__ballot(sl >= 0)) {
-            const u32 fv = wave_bperm((u32)sl, val);
-            const int fs = (int)wave_bperm((u32)sl, (u32)sl);
-            if (sl >= 0) { if (fs < 0) { val = fv; sl = -1; } else sl = fs; }
+        const u32 dsc = wave_bperm(t, desc);                 // match: the distance itself; literal: bit31 | value << 17
+        u32 wv = win[(qs - dsc) & omask];                    // source byte (garbage for literals, never used)
+        if (O + X < W) { if (dsc > qs - oshift) wv = 0; }    // E2: only the first W bytes can point before the stream start
+        u32 val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
+        // a source produced inside this very step <=> distance <= lane
+        if (__ballot(dsc <= (u32)lane && (u32)lane < nseg)) {
+            // pointer jumping (at most 6 rounds), one packed ds_bpermute per round: value | source lane << 8, 0x40 = resolved
+            u32 st = val | (((dsc <= (u32)lane && (u32)lane < nseg) ? ((u32)lane - dsc) : 0x40u) << 8);
+            do {
+                const u32 f = wave_bperm(st >> 8, st);
+                if (st < 0x4000u) st = (f >= 0x4000u) ? f : ((st & 0xFFu) | (f & 0xFF00u));
+            } while (__ballot(st < 0x4000u));
+            val = st & 0xFFu;
         }
         if (nseg >= 64u) {
             win[qs & omask] = (u8)val;
