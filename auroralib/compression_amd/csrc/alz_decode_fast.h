@@ -52,11 +52,51 @@ struct FastGeom {           // LZSS geometry (other formats ignore it)
     u32 length_bits, min_length, windows_start, max_distance, W;
 };
 
+// One step of the byte phase: 64 consecutive output bytes, one per lane.  The kernel is bound by VALU issue (one wave
+// instruction per 4 cycles per SIMD), so the step is written for the fewest vector instructions:
+//   * token lanes mark the lane where their output ENDS inside the step; the token of byte L is then
+//     (#tokens ended before the step) + (#marks below L): one mbcnt pair, fused with the x4 of the bpermute address;
+//   * a match descriptor IS its distance (literal descriptors have bit 31 set), so the source slot is
+//     (slot - descriptor) & mask and "source inside this very step" is the unsigned test descriptor <= lane;
+//   * pointer jumping only runs in steps where that test fires for some lane;
+//   * EARLY (first W bytes of a stream: sources may lie before the stream start, E2) and !FULL (last, partial step)
+//     are separate instantiations so the steady state does not pay for them.
+template <class OW, u32 OMASK, bool EARLY, bool FULL>
+__device__ __forceinline__ void byte_step(OW& out, u8* segmark, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32 nseg) {
+    const u32 omask = OMASK ? OMASK : out.lw_mask;
+    u8* const win = out.win;
+    segmark[relm < 64u ? relm : 64u + (u32)lane] = 1;
+    wave_sync();
+    const u32 mk = segmark[lane];
+    segmark[lane] = 0;
+    const u64 M = __ballot(mk != 0);
+    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
+    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);   // match: the distance; literal: bit31 | value << 17
+    tbase4 += 4u * (u32)__popcll(M);
+    u32 wv = win[(qs - dsc) & omask];                        // source byte (garbage for literals, never used)
+    if (EARLY) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
+    u32 val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
+    const bool instep = FULL ? (dsc <= (u32)lane) : (dsc <= (u32)lane && (u32)lane < nseg);   // source produced inside this very step
+    if (__ballot(instep)) {
+        // pointer jumping (at most 6 rounds), one packed ds_bpermute per round: value | source lane << 8, 0x40 = resolved
+        u32 st = val | ((instep ? ((u32)lane - dsc) : 0x40u) << 8);
+        do {
+            const u32 f = wave_bperm(st >> 8, st);
+            if (st < 0x4000u) st = (f >= 0x4000u) ? f : ((st & 0xFFu) | (f & 0xFF00u));
+        } while (__ballot(st < 0x4000u));
+        val = st & 0xFFu;
+    }
+    if (FULL) win[qs & omask] = (u8)val;
+    else if ((u32)lane < nseg) win[qs & omask] = (u8)val;
+    wave_sync();
+    qs += 64u; relm -= 64u;
+}
+
 // Shared back end.  Per-lane token: valid, len (>=1), desc, tend = input offset just past the token (relative to the
 // iteration's base).  For LZSS the descriptor holds the ring OFFSET and is turned into a distance here, once the
 // token's output position is known (LzWindows.OffsetCopy  IO/LzWindows.cs:108-115).
 // Returns true when the stream is finished (declared size reached, or capacity hit).
-template <class OW, bool LZSS>
+template <class OW, bool LZSS, u32 OMASK>
 __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark,
                                           int lane, u32& last_tend, u32 W) {
     u32 end = wave_incl_scan(valid ? len : 0u, lane);
@@ -88,54 +128,15 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
             desc = ALZ_DESC_MATCH(d);
         }
     }
-    // ---- byte phase: 64 output bytes per step, one per lane.  The kernel is bound by VALU issue (about one wave
-    // instruction per cycle per CU), so the step is written for the fewest vector instructions:
-    //   * token lanes mark the lane where their output ENDS inside the step; the token of byte L is then
-    //     (#tokens ended before the step) + (#marks below L) = one mbcnt pair, no correction term;
-    //   * a match descriptor IS its distance (literal descriptors have bit 31 set), so the source slot is
-    //     (slot - descriptor) & mask and "source inside this very step" is the unsigned test descriptor <= lane;
-    //   * the pointer-jumping machinery only runs in steps where that test fires for some lane.
-    int tbase = 0;                                           // tokens that ended before the current step
-    const u32 omask = out.lw_mask, oshift = out.oshift;
-    u8* const win = out.win;
+    // ---- byte phase (byte_step below): 64 output bytes per step, one per lane
+    u32 tbase4 = 0;                                          // 4 x (tokens that ended before the current step)
     u32 relm = keep ? end - 1u : 0xFFFFFF00u;                // my token's LAST byte relative to the current step (huge: none)
-    u32 qs = O + (u32)lane + oshift;                         // slot coordinate of this lane's byte in the current step
-    const u32 dummy = 64u + (u32)lane;
-    for (u32 X = 0; X < T; X += 64) {
-        const u32 nseg = T - X;                              // >= 64 for every step but the last
-        segmark[relm < 64u ? relm : dummy] = 1;
-        wave_sync();
-        const u32 mk = segmark[lane];
-        segmark[lane] = 0;
-        const u64 M = __ballot(mk != 0);
-        const u32 t = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, (u32)tbase));
-        tbase += (int)__popcll(M);
-        const u32 dsc = wave_bperm(t, desc);                 // match: the distance itself; literal: bit31 | value << 17
-        u32 wv = win[(qs - dsc) & omask];                    // source byte (garbage for literals, never used)
-        if (O + X < W) { if (dsc > qs - oshift) wv = 0; }    // E2: only the first W bytes can point before the stream start
-        u32 val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
-        // a source produced inside this very step <=> distance <= lane
-        if (__ballot(dsc <= (u32)lane && (u32)lane < nseg)) {
-            // pointer jumping (at most 6 rounds), one packed ds_bpermute per round: value | source lane << 8, 0x40 = resolved
-            u32 st = val | (((dsc <= (u32)lane && (u32)lane < nseg) ? ((u32)lane - dsc) : 0x40u) << 8);
-            do {
-                const u32 f = wave_bperm(st >> 8, st);
-                if (st < 0x4000u) st = (f >= 0x4000u) ? f : ((st & 0xFFu) | (f & 0xFF00u));
-            } while (__ballot(st < 0x4000u));
-            val = st & 0xFFu;
-        }
-        if (nseg >= 64u) {
-            win[qs & omask] = (u8)val;
-            wave_sync();
-            out.produced = O + X + 64u;
-        } else {
-            if ((u32)lane < nseg) win[qs & omask] = (u8)val;
-            wave_sync();
-            out.produced = O + X + nseg;
-        }
-        qs += 64u; relm -= 64u;
-        if (out.produced - out.flushed >= out.fl) out.flush_blocks();
-    }
+    u32 qs = O + (u32)lane + out.oshift;                     // slot coordinate of this lane's byte in the current step
+    u32 X = 0;
+    // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
+    while (X + 64u <= T && O + X < W) { byte_step<OW, OMASK, true, true>(out, segmark, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    while (X + 64u <= T) { byte_step<OW, OMASK, false, true>(out, segmark, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    if (X < T) { byte_step<OW, OMASK, true, false>(out, segmark, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
     return fin;
 }
 
@@ -217,7 +218,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
         }
     }
     u32 last_tend;
-    const bool fin = fast_emit<OW, FMT == ALZ_FMT_LZSS>(out, s, size, valid, len, desc, tend, segmark, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, FMT == ALZ_FMT_LZSS, (FMT == ALZ_FMT_LZSS ? 0u : 4095u)>(out, s, size, valid, len, desc, tend, segmark, lane, last_tend, gm.W);
     s.p = p + (fin ? last_tend : g);
     return fin;
 }
@@ -248,7 +249,7 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     // cursors after this token, packed so one readlane recovers both (c: 8 bits is enough for <=128, u: <=64)
     const u32 tend = ((2u * (midx + (lit ? 0u : 1u))) << 8) | (uidx + (usesu ? 1u : 0u));
     u32 last;
-    const bool fin = fast_emit<OW, false>(out, s, size, true, len, desc, tend, segmark, lane, last, 4096);
+    const bool fin = fast_emit<OW, false, 4095u>(out, s, size, true, len, desc, tend, segmark, lane, last, 4096);
     if (fin) { cp += last >> 8; up += last & 0xFFu; }
     else { cp += 2u * (u32)__popcll(~lm); up += (u32)__popcll(um); fp += 8; }
     return fin;

@@ -84,7 +84,11 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
                                                              const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, u32 count,
                                                              alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
-    extern __shared__ uint4 smem[];
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr int NC = THREE ? 3 : 1;
+    constexpr int LWMAX = (FMT == ALZ_FMT_LZSS) ? 8192 : 4096;
+    // static LDS (absolute addresses fold into the DS instructions' offset fields): marks | input caches | window
+    __shared__ __attribute__((aligned(16))) u8 lds[128 + NC * ALZ_INCACHE_BYTES + LWMAX];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -93,11 +97,6 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
     const u8* src = src_base + st.src_off;
     u8* dst = dst_base + st.dst_off;
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
-    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
-    constexpr int NC = THREE ? 3 : 1;
-
-    // LDS layout (compile-time offsets so they fold into the DS instructions): marks | input caches | window
-    u8* lds = reinterpret_cast<u8*>(smem);
     u8* segmark = lds;
     u8* inc_lds = lds + 128;
     OutWin<false> out; out.init(dst, cap, lds + 128 + NC * ALZ_INCACHE_BYTES, lw, lane);
@@ -150,8 +149,8 @@ static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, cons
 template <int FMT>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
-    size_t lds = lw + (size_t)ncaches * ALZ_INCACHE_BYTES + 128;
-    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3(count), dim3(64), lds, stream, src, dst, streams, index, count, results, lz, lw);
+    (void)ncaches;
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3(count), dim3(64), 0, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
 
