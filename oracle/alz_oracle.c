@@ -1264,6 +1264,43 @@ static void run_stream(uint32_t format, const alz_lz_properties* lz, const uint8
     decode_one(lz, &s, body, dst, r, 0);
 }
 
+/* PRS.ValidateByteOrder  Sega/PRS.cs:171-218 */
+static int prs_validate(const uint8_t* src, size_t len, int big) {
+    cur_t c = { src, (uint32_t)len, 0, 0 }; flag_t flag = { &c, 0, 0, big };
+    int i = 3; uint64_t buffer = 0;
+    while (c.pos < c.len) {
+        int bit = flag_readbit(&flag); if (c.eof) return 0;
+        if (bit) { c.pos++; buffer++; continue; }
+        uint32_t distance, length;
+        int bit2 = flag_readbit(&flag); if (c.eof) return 0;
+        if (bit2) {
+            int x0 = cur_u8(&c), x1 = cur_u8(&c); if (c.eof) return 0;
+            uint32_t v = big ? (uint32_t)((x0 << 8) | x1) : (uint32_t)((x1 << 8) | x0);
+            if (v == 0) return 1;
+            length = v & 7; distance = 0x2000 - (v >> 3);
+            if (length == 0) { int e = cur_u8(&c); if (c.eof) return 0; length = (uint32_t)e + 1; } else length += 2;
+        } else {
+            int h = flag_readbit(&flag); if (c.eof) return 0;
+            int l = flag_readbit(&flag); if (c.eof) return 0;
+            length = (uint32_t)((h << 1) | l) + 2;
+            int e = cur_u8(&c); if (c.eof) return 0;
+            distance = 0x100 - (uint32_t)e;
+        }
+        if (distance > buffer) return 0;
+        if (i == 0) return 1;
+        i--; buffer += length;
+    }
+    return 0;
+}
+/* PRS.GetByteOrder  Sega/PRS.cs:161-169: 1 little, 2 big, 0 none */
+static int prs_byte_order(const uint8_t* src, size_t len) {
+    if (len == 0) return 0;
+    uint8_t f = src[0];
+    if (f > 12 && (f & 1) == 1 && prs_validate(src, len, 0)) return 1;
+    if ((f & 128) == 128 && prs_validate(src, len, 1)) return 2;
+    return 0;
+}
+
 int oracle_container_decompress(uint32_t container, const alz_container_options* opt, const uint8_t* src, size_t len,
                                 uint8_t* dst, size_t dst_cap, size_t* dst_len, size_t* src_used, int32_t* status) {
     int big = opt ? (int)opt->big_endian : 1;
@@ -1298,8 +1335,10 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         break;
     }
     case ALZ_C_PRS: {                                                                    /* PRS.cs:42-57: detected order first, then the other */
-        run_stream(big ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
-        if (r.status != ALZ_ST_OK) run_stream(big ? ALZ_FMT_PRS_LE : ALZ_FMT_PRS_BE, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
+        int first_big = prs_byte_order(src, len) == 2;   /* GetByteOrder(source) == Endian.Big ? Big : Little */
+        (void)big;
+        run_stream(first_big ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
+        if (r.status != ALZ_ST_OK) run_stream(first_big ? ALZ_FMT_PRS_LE : ALZ_FMT_PRS_BE, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
         break;
     }
     case ALZ_C_LZO: run_stream(ALZ_FMT_LZO, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r); break;

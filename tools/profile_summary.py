@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--pmc", nargs="*", default=[], help="dirs of extra --pmc passes (SQ_*/GRBM_* counters)")
     ap.add_argument("--note", default="")
     ap.add_argument("--cmd", default="")
     a = ap.parse_args()
@@ -54,6 +55,21 @@ def main():
         avg = sum(vals) / len(vals)
         lines += ["", "## %s (separate `--pmc %s` pass)" % (label, label), "",
                   "dispatches of alz_* kernels: %d; mean raw counter = %.1f KiB; corrected bytes per launch = %.0f (x%.0f, gfx950 rule)" % (len(vals), avg, avg * 1024 * mult, mult)]
+    if a.pmc:
+        import collections
+        acc = collections.OrderedDict()
+        for d in a.pmc:
+            for r in rows(d, "counter_collection.csv"):
+                if "alz_" in r["Kernel_Name"]:
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        lines += ["", "## PMC counters (separate `--pmc` passes, mean per dispatch of the alz_* kernel)", "", "| counter | mean |", "|---|---|"]
+        for k, v in acc.items():
+            lines.append("| %s | %.4g |" % (k, sum(v) / len(v)))
+        g = acc.get("GRBM_GUI_ACTIVE"); va = acc.get("SQ_ACTIVE_INST_VALU"); vi = acc.get("SQ_INSTS_VALU")
+        if g and va:
+            cyc = sum(g) / len(g) / 8.0            # counter is summed over the 8 XCDs
+            busy = sum(va) / len(va) * 4.0 / 1024.0 / cyc   # SQ_ACTIVE_* count quad-cycles; 1024 SIMDs
+            lines += ["", "derived: %.3g shader cycles per dispatch; VALU busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / cycles = %.0f %%" % (cyc, busy * 100)]
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
