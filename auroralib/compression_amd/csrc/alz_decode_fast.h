@@ -25,6 +25,12 @@
 
 __device__ __forceinline__ u32 wave_bperm(u32 src_lane, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 __device__ __forceinline__ u32 wave_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+// v_writelane_b32: write a wave-uniform value into one lane of a VGPR (no clang builtin in ROCm 7.2).  gfx9 allows one
+// SGPR on the constant bus, so the lane select travels in M0 (what LLVM's own lowering of llvm.amdgcn.writelane does).
+__device__ __forceinline__ u32 wave_writelane(u32 old, u32 val, u32 lane) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
+    return old;
+}
 __device__ __forceinline__ u32 mbcnt64(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 
 // inclusive prefix sum over the 64 lanes: DPP row shifts inside the 16-lane rows, then row broadcasts (gfx9 DPP)
@@ -61,9 +67,20 @@ struct FastGeom {           // LZSS geometry (other formats ignore it)
 //   * pointer jumping only runs in steps where that test fires for some lane;
 //   * EARLY (first W bytes of a stream: sources may lie before the stream start, E2) and !FULL (last, partial step)
 //     are separate instantiations so the steady state does not pay for them.
-template <class OW, u32 OMASK, bool EARLY, bool FULL>
-__device__ __forceinline__ void byte_step(OW& out, u8* segmark, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32 nseg) {
-    const u32 omask = OMASK ? OMASK : out.lw_mask;
+// compile-time configuration of the byte phase
+//   OMASK    window mask when it is a compile-time constant (0: use out.lw_mask)
+//   LZSS     descriptors hold ring offsets that become distances once the output position is known
+//   LITRUN   bit-31 descriptors are literal RUNS copied from the LDS input cache (LZ4/LZO/Snappy): the low 30 bits are
+//            (input-cache index - window-slot coordinate) of the run, so byte q reads inlds[(slot(q) + desc) & 2047];
+//            otherwise bit-31 descriptors carry ONE literal byte in bits 17..24 (flag-byte formats, PRS)
+//   FALLBACK the LDS window is shorter than the format's window (64 KiB formats keep 8 KiB): older sources are read
+//            back from the stream's own output in HBM (L2-served loads; flush_to() made them visible)
+template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_>
+struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_; };
+
+template <class OW, class CFG, bool EARLY, bool FULL>
+__device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32 nseg) {
+    const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
     u8* const win = out.win;
     segmark[relm < 64u ? relm : 64u + (u32)lane] = 1;
     wave_sync();
@@ -71,11 +88,22 @@ __device__ __forceinline__ void byte_step(OW& out, u8* segmark, int lane, u32 de
     segmark[lane] = 0;
     const u64 M = __ballot(mk != 0);
     const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
-    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);   // match: the distance; literal: bit31 | value << 17
+    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);   // match: the distance; literal: bit31 | ...
     tbase4 += 4u * (u32)__popcll(M);
     u32 wv = win[(qs - dsc) & omask];                        // source byte (garbage for literals, never used)
+    if (CFG::FALLBACK) {
+        const bool far = (int)dsc >= 0 && dsc > omask + 1u - 64u;      // older than the LDS window: already flushed to HBM
+        if (__ballot(far)) {
+            const u32 q = qs - out.oshift;
+            u32 g = 0;
+            if (far && dsc <= q) g = (u32)__hip_atomic_load(out.dst + (q - dsc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (far) wv = g;
+        }
+    }
     if (EARLY) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
-    u32 val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
+    u32 val;
+    if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
+    else val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
     const bool instep = FULL ? (dsc <= (u32)lane) : (dsc <= (u32)lane && (u32)lane < nseg);   // source produced inside this very step
     if (__ballot(instep)) {
         // pointer jumping (at most 6 rounds), one packed ds_bpermute per round: value | source lane << 8, 0x40 = resolved
@@ -96,9 +124,9 @@ __device__ __forceinline__ void byte_step(OW& out, u8* segmark, int lane, u32 de
 // iteration's base).  For LZSS the descriptor holds the ring OFFSET and is turned into a distance here, once the
 // token's output position is known (LzWindows.OffsetCopy  IO/LzWindows.cs:108-115).
 // Returns true when the stream is finished (declared size reached, or capacity hit).
-template <class OW, bool LZSS, u32 OMASK>
+template <class OW, class CFG>
 __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark,
-                                          int lane, u32& last_tend, u32 W) {
+                                          const u8* inlds, int lane, u32& last_tend, u32 W) {
     u32 end = wave_incl_scan(valid ? len : 0u, lane);
     u32 off = end - len;
     const u32 O = out.produced;
@@ -119,7 +147,7 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
         T = room; fin = true;
     }
     last_tend = wave_readlane(tend, lastk);
-    if (LZSS) {
+    if (CFG::LZSS) {
         if (!(desc >> 31)) {
             u32 offset = ALZ_DESC_DIST(desc);
             u32 pos = (O + off) & (W - 1);
@@ -134,9 +162,9 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
     u32 qs = O + (u32)lane + out.oshift;                     // slot coordinate of this lane's byte in the current step
     u32 X = 0;
     // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
-    while (X + 64u <= T && O + X < W) { byte_step<OW, OMASK, true, true>(out, segmark, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-    while (X + 64u <= T) { byte_step<OW, OMASK, false, true>(out, segmark, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-    if (X < T) { byte_step<OW, OMASK, true, false>(out, segmark, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    while (X + 64u <= T) { byte_step<OW, CFG, false, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    if (X < T) { byte_step<OW, CFG, true, false>(out, segmark, inlds, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
     return fin;
 }
 
@@ -218,7 +246,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
         }
     }
     u32 last_tend;
-    const bool fin = fast_emit<OW, FMT == ALZ_FMT_LZSS, (FMT == ALZ_FMT_LZSS ? 0u : 4095u)>(out, s, size, valid, len, desc, tend, segmark, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, EmitCfg<(FMT == ALZ_FMT_LZSS ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
     s.p = p + (fin ? last_tend : g);
     return fin;
 }
@@ -249,8 +277,83 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     // cursors after this token, packed so one readlane recovers both (c: 8 bits is enough for <=128, u: <=64)
     const u32 tend = ((2u * (midx + (lit ? 0u : 1u))) << 8) | (uidx + (usesu ? 1u : 0u));
     u32 last;
-    const bool fin = fast_emit<OW, false, 4095u>(out, s, size, true, len, desc, tend, segmark, lane, last, 4096);
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, true, len, desc, tend, segmark, nullptr, lane, last, 4096);
     if (fin) { cp += last >> 8; up += last & 0xFFu; }
     else { cp += 2u * (u32)__popcll(~lm); up += (u32)__popcll(um); fp += 8; }
     return fin;
 }
+
+
+struct EmitRet { u32 produced, flushed, ovf, att_lo, att_hi; };
+
+// out-of-line execution of one token queue (arguments travel in VGPRs under the device calling convention; the
+// wave-uniform ones are re-scalarised on entry)
+template <class OW, class CFG>
+__device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u32 lw_mask, u32 fl, u32 oshift, u32 cap, u32 produced, u32 flushed,
+                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qlen, u32 qdesc) {
+    OW out;
+    out.dst = reinterpret_cast<u8*>(((u64)uni((u32)((u64)dst >> 32)) << 32) | uni((u32)(u64)dst));
+    out.win = win; out.lw_mask = uni(lw_mask); out.fl = uni(fl); out.oshift = uni(oshift); out.cap = uni(cap);
+    out.produced = uni(produced); out.flushed = uni(flushed); out.lane = lane;
+    DecState s; dec_state_init(s);
+    u32 last;
+    fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < uni(nt), qlen, qdesc, 0u, segmark, inlds, lane, last, uni(W));
+    EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = s.ovf ? 1u : 0u;
+    r.att_lo = (u32)s.attempted_end; r.att_hi = (u32)(s.attempted_end >> 32);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// QueueSink: the serial parsers of alz_decode_serial.h (PRS, LZ4, LZO, Snappy -- grammars whose token boundaries can
+// only be found sequentially) run on the scalar unit and merely RECORD tokens, one per lane (v_writelane); every 64
+// tokens -- or when the input cache has to move, or a literal run is too long to stay resident -- the queue is executed
+// by the lane-parallel byte phase.  Parsing needs the input only, never the output, so it is decoupled from the copy.
+template <class OW, class CFG>
+struct QueueSink {
+    OW& out; DecState& s; u8* segmark; const u8* inlds; int lane; u32 W;
+    u32 qlen, qdesc;          // per-lane token registers
+    u32 nt, qbytes;           // tokens queued, bytes they will produce (wave-uniform)
+    __device__ __forceinline__ QueueSink(OW& o, DecState& st, u8* sm, const u8* il, int ln, u32 w)
+        : out(o), s(st), segmark(sm), inlds(il), lane(ln), W(w), qlen(0), qdesc(0), nt(0), qbytes(0) {}
+    __device__ __forceinline__ u32 produced() const { return out.produced + qbytes; }
+    __device__ __forceinline__ void flush() {
+        if (nt == 0) return;
+        // ONE out-of-line copy of the byte phase per kernel: the sink operations are inlined at every token site of the
+        // parsers, and inlining the byte phase there as well made 100+ KB kernels that thrash the instruction cache
+        const EmitRet r = queue_emit_call<OW, CFG>(out.dst, out.win, out.lw_mask, out.fl, out.oshift, out.cap, out.produced, out.flushed,
+                                                   lane, segmark, inlds, W, nt, qlen, qdesc);
+        out.produced = uni(r.produced); out.flushed = uni(r.flushed);
+        if (uni(r.ovf)) { s.ovf = true; s.attempted_end = ((u64)uni(r.att_hi) << 32) | uni(r.att_lo); }
+        nt = 0; qbytes = 0;
+    }
+    __device__ __forceinline__ void ensure(InCache& in, u32 p, u32 need) {
+        if (p + in.lo + need > in.cb + 2048u || p + in.lo < in.cb) { flush(); in.ensure(p, need); }   // queued literal runs point into the cache
+    }
+    __device__ __forceinline__ bool push(u32 len, u32 desc) {
+        qlen = wave_writelane(qlen, uni(len), uni(nt));
+        qdesc = wave_writelane(qdesc, uni(desc), uni(nt));
+        nt++; qbytes += len;
+        if (nt == 64u || qbytes >= 0x40000000u) flush();
+        return !s.ovf;
+    }
+    __device__ __forceinline__ bool lit(u32 b) { return push(1u, ALZ_DESC_LIT(b)); }
+    __device__ __forceinline__ bool match(u32 dist, u64 len, u32 w) {
+        if (len == 0) return true;
+        if (len >= 0x40000000ull || (u64)produced() + len > (u64)out.cap) {      // rare: exact E5 handling on the serial path
+            flush(); if (s.ovf) return false;
+            u32 cl = clip_token(out, s, len); out.back_copy(dist, cl, w); return !s.ovf;
+        }
+        return push((u32)len, ALZ_DESC_MATCH(dist ? dist : w));                 // E1
+    }
+    __device__ __forceinline__ bool run(InCache& in, u32 p, u64 len) {
+        if (len == 0) return true;
+        if (len > 1024u || (u64)produced() + len > (u64)out.cap) {
+            flush(); if (s.ovf) return false;
+            u32 cl = clip_token(out, s, len); out.copy_from(in, p, cl); return !s.ovf;
+        }
+        ensure(in, p, (u32)len);
+        // byte q of the run reads inlds[(slot(q) + d) & 2047]:  d = cache index of the run - slot coordinate of its first byte
+        const u32 d = in.idx(p) - (produced() + out.oshift);
+        return push((u32)len, 0x80000000u | (d & 0x3FFFFFFFu));
+    }
+};

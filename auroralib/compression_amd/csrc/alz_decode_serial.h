@@ -30,21 +30,36 @@ __device__ __forceinline__ u32 clip_token(const OW& out, DecState& s, u64 len) {
     return (u32)len;
 }
 
+// The parsers below are written once against a SINK.  DirectSink executes every token immediately on the window
+// (exact serial semantics).  QueueSink (alz_decode_fast.h) only records tokens in lane registers and executes 64 of
+// them at a time through the lane-parallel byte phase.  Every sink operation returns false once decoding must stop
+// (capacity reached, E5); the parser then returns and the kernel resolves the status.
+template <class OW>
+struct DirectSink {
+    OW& out; DecState& s;
+    __device__ __forceinline__ DirectSink(OW& o, DecState& st) : out(o), s(st) {}
+    __device__ __forceinline__ u32 produced() const { return out.produced; }
+    __device__ __forceinline__ void ensure(InCache& in, u32 p, u32 need) { in.ensure(p, need); }
+    __device__ __forceinline__ bool lit(u32 b) { if (clip_token(out, s, 1) < 1) return false; out.put_byte(b); return true; }
+    __device__ __forceinline__ bool match(u32 dist, u64 len, u32 W) { u32 cl = clip_token(out, s, len); out.back_copy(dist, cl, W); return !s.ovf; }
+    __device__ __forceinline__ bool run(InCache& in, u32 p, u64 len) { u32 cl = clip_token(out, s, len); out.copy_from(in, p, cl); return !s.ovf; }
+    __device__ __forceinline__ void flush() {}
+};
+
 // ---------------------------------------------------------------------------------------------
 // LZSS.DecompressHeaderless  Formats/Common/LZSS.cs:91-130  (flags LSB-first, bit 1 = literal)
-template <class OW>
-__device__ void dec_lzss_serial(InCache& in, OW& out, DecState& s, u32 src_len, u32 size,
+template <class SK>
+__device__ void dec_lzss_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size,
                                 u32 length_bits, u32 min_length, u32 windows_start, u32 max_distance, u32 W) {
     const u32 f = (1u << length_bits) - 1u, n = max_distance - 1u;
-    while (out.produced < size) {
-        in.ensure(s.p, 8);
+    while (sk.produced() < size) {
+        sk.ensure(in, s.p, 8);
         if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
         u32 bit = (s.flag >> (8 - s.bits)) & 1u; s.bits--;
         if (bit) {
             if (s.p >= src_len) { s.eof = true; return; }
             u32 b = in.peek1(s.p); s.p++;
-            if (clip_token(out, s, 1) < 1) return;
-            out.put_byte(b);
+            if (!sk.lit(b)) return;
         } else {
             if (s.p + 2 > src_len) { s.eof = true; return; }
             u32 w = in.peek4(s.p); s.p += 2;
@@ -52,20 +67,18 @@ __device__ void dec_lzss_serial(InCache& in, OW& out, DecState& s, u32 src_len, 
             u32 offset = ((b2 >> length_bits) << 8) | b1;
             u32 length = (b2 & f) + min_length;
             offset = (max_distance + offset - windows_start) & n;
-            u32 pos = out.produced & (W - 1);                  // LzWindows.OffsetCopy  IO/LzWindows.cs:108-115
+            u32 pos = sk.produced() & (W - 1);                // LzWindows.OffsetCopy  IO/LzWindows.cs:108-115
             u32 distance = pos >= offset ? pos - offset : pos - offset + W;
-            u32 cl = clip_token(out, s, length);
-            out.back_copy(distance, cl, W);
-            if (s.ovf) return;
+            if (!sk.match(distance, length, W)) return;
         }
     }
 }
 
 // LZ10.DecompressHeaderless  Nintendo/LZ10.cs:82-111 ; LZ11.DecompressHeaderless  Nintendo/LZ11.cs:83-133
-template <class OW, bool LZ11>
-__device__ void dec_lz1x_serial(InCache& in, OW& out, DecState& s, u32 src_len, u32 size) {
-    while (out.produced < size) {
-        in.ensure(s.p, 8);
+template <class SK, bool LZ11>
+__device__ void dec_lz1x_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
+    while (sk.produced() < size) {
+        sk.ensure(in, s.p, 8);
         if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
         u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
         if (bit) {
@@ -82,30 +95,26 @@ __device__ void dec_lz1x_serial(InCache& in, OW& out, DecState& s, u32 src_len, 
             } else {
                 distance = (((b1 & 0xF) << 8) | b2) + 1; length = (b1 >> 4) + (LZ11 ? 1 : 3); s.p += 2;
             }
-            u32 cl = clip_token(out, s, length);
-            out.back_copy(distance, cl, 4096);
-            if (s.ovf) return;
+            if (!sk.match(distance, length, 4096)) return;
         } else {
             if (s.p >= src_len) { s.eof = true; return; }
             u32 b = in.peek1(s.p); s.p++;
-            if (clip_token(out, s, 1) < 1) return;
-            out.put_byte(b);
+            if (!sk.lit(b)) return;
         }
     }
 }
 
 // Yaz0: Yay0.DecompressHeaderless with all three cursors on one stream  Nintendo/Yay0.cs:110-144, Yaz0.cs:91-92
-template <class OW>
-__device__ void dec_yaz0_serial(InCache& in, OW& out, DecState& s, u32 src_len, u32 size) {
-    while (out.produced < size) {
-        in.ensure(s.p, 8);
+template <class SK>
+__device__ void dec_yaz0_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
+    while (sk.produced() < size) {
+        sk.ensure(in, s.p, 8);
         if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
         u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
         if (bit) {
             if (s.p >= src_len) { s.eof = true; return; }
             u32 b = in.peek1(s.p); s.p++;
-            if (clip_token(out, s, 1) < 1) return;
-            out.put_byte(b);
+            if (!sk.lit(b)) return;
         } else {
             if (s.p + 2 > src_len) { s.eof = true; return; }
             u32 w = in.peek4(s.p); s.p += 2;
@@ -115,33 +124,30 @@ __device__ void dec_yaz0_serial(InCache& in, OW& out, DecState& s, u32 src_len, 
             if (length == 0) {                                   // ReadByte(): -1 at EOF => 17   Yay0.cs:130-131
                 if (s.p < src_len) { length = b3 + 0x12; s.p++; } else length = 17;
             } else length += 2;
-            u32 cl = clip_token(out, s, length);
-            out.back_copy(distance, cl, 4096);
-            if (s.ovf) return;
+            if (!sk.match(distance, length, 4096)) return;
         }
     }
 }
 
 // Yay0 (three cursors)  Nintendo/Yay0.cs:99-144 ; MIO0  Nintendo/MIO0.cs:105-149
 // fc: flags from 0, cc: tokens from aux0, uc: literals from aux1; each cursor bounded by its slice length.
-template <class OW, bool MIO0>
-__device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, OW& out, DecState& s, u32 src_len, u32 size,
+template <class SK, bool MIO0>
+__device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, SK& sk, DecState& s, u32 src_len, u32 size,
                                    u32 fptr0, u32 cptr0, u32 uptr0, u32& used) {
     u32 fp = fptr0, cp = cptr0, up = uptr0;
-    while (out.produced < size) {
+    while (sk.produced() < size) {
         if (s.bits == 0) {
             if (fp >= src_len) { s.eof = true; break; }
-            fin.ensure(fp, 1); s.flag = fin.peek1(fp); fp++; s.bits = 8;
+            sk.ensure(fin, fp, 1); s.flag = fin.peek1(fp); fp++; s.bits = 8;
         }
         u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
         if (bit) {
             if (up >= src_len) { s.eof = true; break; }
-            uin.ensure(up, 1); u32 b = uin.peek1(up); up++;
-            if (clip_token(out, s, 1) < 1) break;
-            out.put_byte(b);
+            sk.ensure(uin, up, 1); u32 b = uin.peek1(up); up++;
+            if (!sk.lit(b)) break;
         } else {
             if (cp + 2 > src_len) { s.eof = true; if (MIO0 && cp < src_len) cp++; break; }
-            cin.ensure(cp, 4); u32 w = cin.peek4(cp); cp += 2;
+            sk.ensure(cin, cp, 4); u32 w = cin.peek4(cp); cp += 2;
             u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF;
             u32 distance = (((b1 & 0x0F) << 8) | b2) + 1;
             u32 length;
@@ -149,33 +155,30 @@ __device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, OW&
             else {
                 length = b1 >> 4;
                 if (length == 0) {
-                    if (up < src_len) { uin.ensure(up, 1); length = uin.peek1(up) + 0x12; up++; } else length = 17;
+                    if (up < src_len) { sk.ensure(uin, up, 1); length = uin.peek1(up) + 0x12; up++; } else length = 17;
                 } else length += 2;
             }
-            u32 cl = clip_token(out, s, length);
-            out.back_copy(distance, cl, 4096);
-            if (s.ovf) break;
+            if (!sk.match(distance, length, 4096)) break;
         }
     }
     used = cp > up ? cp : up;
 }
 
 // PRS.DecompressHeaderless(Stream, Stream, Endian)  Sega/PRS.cs:59-102
-template <class OW, bool BIG>
-__device__ void dec_prs_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
+template <class SK, bool BIG>
+__device__ void dec_prs_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
 #define PRS_READBIT(dst)                                                                       \
     do {                                                                                       \
         if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; } \
         dst = BIG ? (s.flag >> (s.bits - 1)) & 1u : (s.flag >> (8 - s.bits)) & 1u; s.bits--;   \
     } while (0)
     while (s.p < src_len) {
-        in.ensure(s.p, 16);
+        sk.ensure(in, s.p, 16);
         u32 bit; PRS_READBIT(bit);
         if (bit) {
             if (s.p >= src_len) { s.eof = true; return; }
             u32 b = in.peek1(s.p); s.p++;
-            if (clip_token(out, s, 1) < 1) return;
-            out.put_byte(b);
+            if (!sk.lit(b)) return;
         } else {
             u32 distance, length, bit2; PRS_READBIT(bit2);
             if (bit2) {
@@ -193,9 +196,7 @@ __device__ void dec_prs_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
                 if (s.p >= src_len) { s.eof = true; return; }
                 distance = 0x100 - in.peek1(s.p); s.p++;
             }
-            u32 cl = clip_token(out, s, length);
-            out.back_copy(distance, cl, 8192);
-            if (s.ovf) return;
+            if (!sk.match(distance, length, 8192)) return;
         }
     }
     s.eof = true;   // EndOfStreamException  PRS.cs:101
@@ -203,49 +204,44 @@ __device__ void dec_prs_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
 }
 
 // LZ4.DecompressBlockHeaderless  Formats/Common/LZ4.cs:176-200
-template <class OW>
-__device__ void dec_lz4_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
+template <class SK>
+__device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
     while (s.p < src_len) {
-        in.ensure(s.p, 8);
+        sk.ensure(in, s.p, 8);
         u32 token = in.peek1(s.p); s.p++;
         u64 plain = token >> 4;
         if (plain == 0xF) {
             u32 b;
-            do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); b = in.peek1(s.p); s.p++; plain += b; } while (b == 255);
+            do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); b = in.peek1(s.p); s.p++; plain += b; } while (b == 255);
         }
         if (plain > (u64)(src_len - s.p)) { s.eof = true; return; }
-        u32 cl = clip_token(out, s, plain);
-        out.copy_from(in, s.p, cl);
-        if (s.ovf) return;
+        if (!sk.run(in, s.p, plain)) return;
         s.p += (u32)plain;
         if (s.p >= src_len) break;
         u64 mlen = token & 0xF;
         if (s.p + 2 > src_len) { s.eof = true; return; }
-        in.ensure(s.p, 4);
+        sk.ensure(in, s.p, 4);
         u32 w = in.peek4(s.p); s.p += 2;
         u32 dist = w & 0xFFFF;
         if (mlen == 0xF) {
             u32 b;
-            do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); b = in.peek1(s.p); s.p++; mlen += b; } while (b == 255);
+            do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); b = in.peek1(s.p); s.p++; mlen += b; } while (b == 255);
         }
-        cl = clip_token(out, s, mlen + 4);
-        out.back_copy(dist, cl, 65536);
-        if (s.ovf) return;
+        if (!sk.match(dist, mlen + 4, 65536)) return;
     }
 }
 
 // LZO.DecompressHeaderless  Formats/Common/LZO.cs:49-139
-template <class OW>
-__device__ void dec_lzo_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
-#define LZO_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
+template <class SK>
+__device__ void dec_lzo_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
+#define LZO_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
 #define LZO_EXT(dst) do { u32 b_, acc_ = 0; for (;;) { LZO_BYTE(b_); if (b_ != 0) break; acc_ += 255; } dst = acc_ + b_; } while (0)
     u32 flag, length, distance, plain = 0;
     LZO_BYTE(flag);
     if (flag > 17) {
         length = flag - 17;
         if (length > src_len - s.p) { s.eof = true; return; }
-        u32 cl = clip_token(out, s, length);
-        out.copy_from(in, s.p, cl); if (s.ovf) return;
+        if (!sk.run(in, s.p, length)) return;
         s.p += length;
         LZO_BYTE(flag);
     }
@@ -258,8 +254,7 @@ __device__ void dec_lzo_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
                 if (length == 3) { u32 e; LZO_EXT(e); length = 18 + e; }
                 plain = 4;
                 if (length > src_len - s.p) { s.eof = true; return; }
-                u32 cl = clip_token(out, s, length);
-                out.copy_from(in, s.p, cl); if (s.ovf) return;
+                if (!sk.run(in, s.p, length)) return;
                 s.p += length;
                 literal_op = true;
             } else if (plain <= 3) {
@@ -290,27 +285,25 @@ __device__ void dec_lzo_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
         }
         if (!literal_op) {
             plain = flag & 0x3;
-            u32 cl = clip_token(out, s, length);
-            out.back_copy(distance, cl, 65536); if (s.ovf) return;
+            if (!sk.match(distance, length, 65536)) return;
             if (plain > src_len - s.p) { s.eof = true; return; }
-            cl = clip_token(out, s, plain);
-            out.copy_from(in, s.p, cl); if (s.ovf) return;
+            if (!sk.run(in, s.p, plain)) return;
             s.p += plain;
         }
         if (s.p >= src_len) { s.eof = true; return; }          // ReadByte() == -1 -> EndOfStreamException  LZO.cs:136-137
-        in.ensure(s.p, 1); flag = in.peek1(s.p); s.p++;
+        sk.ensure(in, s.p, 1); flag = in.peek1(s.p); s.p++;
     }
 #undef LZO_BYTE
 #undef LZO_EXT
 }
 
 // Snappy.DecompressHeaderless  Formats/Common/Snappy.cs:205-250 (+ varint :109-122)
-template <class OW>
-__device__ void dec_snappy_serial(InCache& in, OW& out, DecState& s, u32 src_len) {
-#define SN_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } in.ensure(s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
+template <class SK>
+__device__ void dec_snappy_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
+#define SN_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
     u32 size = 0, shift = 0, b = 0x80;
     while (b & 0x80) { SN_BYTE(b); size |= (b & 0x7F) << (shift & 31); shift += 7; }
-    while (out.produced < size) {
+    while (sk.produced() < size) {
         u32 tag; SN_BYTE(tag);
         u32 type = tag & 3, length = tag >> 2, distance;
         if (type == 0) {
@@ -320,8 +313,7 @@ __device__ void dec_snappy_serial(InCache& in, OW& out, DecState& s, u32 src_len
             }
             u32 run = length + 1;
             if (run > src_len - s.p) { s.eof = true; return; }
-            u32 cl = clip_token(out, s, run);
-            out.copy_from(in, s.p, cl); if (s.ovf) return;
+            if (!sk.run(in, s.p, run)) return;
             s.p += run;
             continue;
         } else if (type == 1) {
@@ -329,14 +321,13 @@ __device__ void dec_snappy_serial(InCache& in, OW& out, DecState& s, u32 src_len
             u32 x; SN_BYTE(x); distance = ((tag >> 5) << 8) | x;
         } else if (type == 2) {
             if (s.p + 2 > src_len) { s.eof = true; return; }
-            in.ensure(s.p, 4); distance = in.peek4(s.p) & 0xFFFF; s.p += 2;
+            sk.ensure(in, s.p, 4); distance = in.peek4(s.p) & 0xFFFF; s.p += 2;
         } else {
             if (src_len - s.p < 4) { s.eof = true; return; }
-            in.ensure(s.p, 4); distance = in.peek4(s.p); s.p += 4;
+            sk.ensure(in, s.p, 4); distance = in.peek4(s.p); s.p += 4;
             if (distance > 65536u) { s.bad = true; return; }    // E3
         }
-        u32 cl = clip_token(out, s, (u64)length + 1);
-        out.back_copy(distance, cl, 65536); if (s.ovf) return;
+        if (!sk.match(distance, (u64)length + 1, 65536)) return;
     }
 #undef SN_BYTE
 }

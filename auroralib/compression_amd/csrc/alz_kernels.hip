@@ -40,17 +40,19 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
     bool has_size = false; u32 used = 0; bool used_set = false;
+    typedef DirectSink<OutWin<FB>> SK;
+    SK sk(out, s);
 
     if constexpr (FMT == ALZ_FMT_LZSS) {
         has_size = true;
         u32 W = 1u << lz.window_bits;
-        dec_lzss_serial(in, out, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, W);
+        dec_lzss_serial(in, sk, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, W);
     } else if constexpr (FMT == ALZ_FMT_LZ10) {
-        has_size = true; dec_lz1x_serial<OutWin<FB>, false>(in, out, s, src_len, size);
+        has_size = true; dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_LZ11) {
-        has_size = true; dec_lz1x_serial<OutWin<FB>, true>(in, out, s, src_len, size);
+        has_size = true; dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_YAZ0) {
-        has_size = true; dec_yaz0_serial(in, out, s, src_len, size);
+        has_size = true; dec_yaz0_serial(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0) {
         has_size = true;
         const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
@@ -59,19 +61,19 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
             InCache cin, uin;
             cin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); cin.seek(a0 < src_len ? a0 : 0);
             uin.init(src, src_len, inc_lds + 2 * ALZ_INCACHE_BYTES, lane); uin.seek(a1 < src_len ? a1 : 0);
-            dec_3cursor_serial<OutWin<FB>, FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, src_len, size, 0, a0, a1, used);
+            dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, 0, a0, a1, used);
             used_set = true;
         }
     } else if constexpr (FMT == ALZ_FMT_PRS_BE) {
-        dec_prs_serial<OutWin<FB>, true>(in, out, s, src_len);
+        dec_prs_serial<SK, true>(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_PRS_LE) {
-        dec_prs_serial<OutWin<FB>, false>(in, out, s, src_len);
+        dec_prs_serial<SK, false>(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) {
-        dec_lz4_serial(in, out, s, src_len);
+        dec_lz4_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_LZO) {
-        dec_lzo_serial(in, out, s, src_len);
+        dec_lzo_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_SNAPPY_RAW) {
-        dec_snappy_serial(in, out, s, src_len);
+        dec_snappy_serial(in, sk, s, src_len);
     }
     out.finish();
     write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap));
@@ -111,10 +113,12 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
         gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
         while (!fin && out.produced < size && s.p + 128u <= src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, segmark, lane, gm);
         if (!fin) {
-            if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, out, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
-            else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<OutWin<false>, false>(in, out, s, src_len, size);
-            else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<OutWin<false>, true>(in, out, s, src_len, size);
-            else dec_yaz0_serial(in, out, s, src_len, size);
+            typedef DirectSink<OutWin<false>> SK;
+            SK sk(out, s);
+            if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, sk, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
+            else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
+            else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
+            else dec_yaz0_serial(in, sk, s, src_len, size);
         }
     } else {
         const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
@@ -127,12 +131,50 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
             while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len)
                 fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, segmark, lane, fp, cp, up);
             used = cp > up ? cp : up;
-            if (!fin) dec_3cursor_serial<OutWin<false>, FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, src_len, size, fp, cp, up, used);
+            if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up, used); }
             used_set = true;
         }
     }
     out.finish();
     write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, true, out.produced, size, cap));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token-queue kernel (PRS, LZ4, LZO, Snappy): scalar parse into a 64-token queue, lane-parallel execution (QueueSink).
+template <int FMT>
+__global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                              const alz_stream* __restrict__ streams,
+                                                              const u32* __restrict__ index_list, u32 count,
+                                                              alz_result* __restrict__ results) {
+    constexpr bool PRS = (FMT == ALZ_FMT_PRS_BE || FMT == ALZ_FMT_PRS_LE);
+    constexpr u32 LW = 8192;                       // PRS: the whole window; 64 KiB formats: the recent 8 KiB, older sources from HBM
+    __shared__ __attribute__((aligned(16))) u8 lds[128 + ALZ_INCACHE_BYTES + LW];
+    u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    u8* dst = dst_base + st.dst_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap);
+    u8* segmark = lds;
+    u8* inc_lds = lds + 128;
+    typedef OutWin<!PRS> OW;
+    OW out; out.init(dst, cap, lds + 128 + ALZ_INCACHE_BYTES, LW, lane);
+    segmark[lane] = 0; segmark[64 + lane] = 0;
+    InCache in; in.init(src, src_len, inc_lds, lane);
+    DecState s; dec_state_init(s);
+    typedef EmitCfg<LW - 1u, false, !PRS, !PRS> CFG;
+    typedef QueueSink<OW, CFG> SK;
+    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : 65536u);
+    if constexpr (FMT == ALZ_FMT_PRS_BE) dec_prs_serial<SK, true>(in, sk, s, src_len);
+    else if constexpr (FMT == ALZ_FMT_PRS_LE) dec_prs_serial<SK, false>(in, sk, s, src_len);
+    else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) dec_lz4_serial(in, sk, s, src_len);
+    else if constexpr (FMT == ALZ_FMT_LZO) dec_lzo_serial(in, sk, s, src_len);
+    else dec_snappy_serial(in, sk, s, src_len);
+    sk.flush();                                    // tokens parsed before an error/terminator are part of the output
+    out.finish();
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0, cap));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,6 +193,12 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
     (void)ncaches;
     hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3(count), dim3(64), 0, stream, src, dst, streams, index, count, results, lz, lw);
+    return hipGetLastError();
+}
+
+template <int FMT>
+static hipError_t launch_queue(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count, alz_result* results) {
+    hipLaunchKernelGGL((alz_decode_queue_kernel<FMT>), dim3(count), dim3(64), 0, stream, src, dst, streams, index, count, results);
     return hipGetLastError();
 }
 
@@ -174,6 +222,11 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_YAY0: return launch_fast<ALZ_FMT_YAY0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
+        case ALZ_FMT_PRS_BE: return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_PRS_LE: return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_LZ4_BLOCK: return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_LZO: return launch_queue<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_SNAPPY_RAW: return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
         default: break;
         }
     }

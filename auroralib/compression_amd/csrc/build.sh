@@ -14,7 +14,7 @@ s = importlib.util.find_spec("torch")
 print(os.path.join(os.path.dirname(s.origin), "lib") if s else "")
 PY
 )"
-FLAGS="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+FLAGS="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-inline-asm"
 mkdir -p "$HERE/_obj"
 for f in alz_kernels.hip alz_host.cpp alz_container.cpp; do
   [ -f "$HERE/$f" ] || continue
