@@ -46,6 +46,7 @@ def load():
     lib.alz_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     lib.alz_decode_batch.argtypes = [vp, vp, u32, vp, sz, vp, vp, sz, vp]
     lib.alz_decode.argtypes = [vp, u32, vp, vp, u32, u32, u32, u32, vp, u32, vp]
+    lib.alz_encode_batch.argtypes = [vp, vp, vp, u32, vp, sz, vp, vp, sz, vp, vp]
     lib.alz_plan_create.argtypes = [vp, vp, u32, vp, C.POINTER(vp)]
     lib.alz_plan_execute.argtypes = [vp, vp, vp, vp, vp]
     lib.alz_plan_execute_timed.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]

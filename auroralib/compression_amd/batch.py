@@ -59,6 +59,19 @@ class Context:
         check(self.lib.alz_decode(self.h, fmt, C.byref(lz) if lz is not None else None, src, len(src), decom_len, aux0, aux1, dst, cap, C.byref(r)))
         return dst.raw[:r.dst_len], r
 
+    # ---- host-buffer encode
+    def encode_batch(self, streams, src, dst_bytes, quality=8, lz=None, strategy=0, min_distance=0, max_window_bits=0):
+        """alz_encode_batch: streams describe RAW inputs (src_*) and compressed-output capacity (dst_*)."""
+        n = len(streams)
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        dst = np.zeros(max(dst_bytes, 1), dtype=np.uint8)
+        res = (A.Result * n)()
+        aux = (A.EncodeAux * n)()
+        st = A.Settings(quality, max_window_bits, strategy, min_distance)
+        check(self.lib.alz_encode_batch(self.h, C.byref(lz) if lz is not None else None, C.byref(st), n, _vp(src), src.nbytes, streams,
+                                        _vp(dst), dst_bytes, res, aux))
+        return dst, res, aux
+
     # ---- device memory
     def malloc(self, nbytes):
         p = C.c_void_p()

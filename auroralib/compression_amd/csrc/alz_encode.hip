@@ -1,0 +1,516 @@
+// alz_encode.hip -- batched GPU encoder, bit-identical to the reference's greedy/lazy hash-chain encoder.
+//
+// Replaces MatchFinder/LzChainMatchFinder.cs:13-372 + IO/FlagWriter.cs:13-147 + the CompressHeaderless bodies
+// (LZSS.cs:132-160, LZ10.cs:113-137, LZ11.cs:135-171, Yay0.cs:152-184, MIO0.cs:159-184, PRS.cs:104-159, LZ4.cs:202-238,
+// LZO.cs:141-250, Snappy.cs:130-203).
+//
+// The reference finder looks strictly sequential (its hash tables mutate per position), but it has a property that
+// makes it data-parallel: EVERY position below the cursor has been inserted exactly once, in increasing order, by the
+// time a position is searched (searched positions are inserted by MatchSearch :245, skipped ones by the fill loop
+// :199-203).  Hence
+//     head[h] at the moment position p is searched == the largest q < p with hash(q) == hash(p)   =: prev(p)
+//     chain[q & mask]                                == prev(q)   (slots are only reused beyond maxDistance, where the
+//                                                                  chain walk has already stopped :259-260)
+// so MatchSearch(p) is a PURE function of the data, and the parse (FindNextBestMatch :157-212) only consumes it.
+// Three kernels:
+//   A  enc_prev_kernel    one wavefront per stream: prev(p) for the 4-byte hash (and the min-length hash when
+//                         quality >= 10), 64 positions per step against a head table in HBM scratch; duplicates inside
+//                         a step are ordered with a small LDS contest + ballots.
+//   B  enc_match_kernel   one lane per position: the chain walk of MatchSearch/ChainMatches (:214-282) over prev(),
+//                         embarrassingly parallel; writes (distance, length) per position.
+//   C  enc_emit_kernel    one lane per stream: the greedy/lazy parse over the match array and the token emission of
+//                         the format (FlagWriter order), the only sequential part.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "alz_device.h"
+#include "alz_internal.h"
+
+namespace {
+
+struct EncGeom {           // per-format LzProperties + finder parameters
+    int min_len, max_len, min_dist, max_dist;
+    int max_chain, lazy, hash_bits, use_min_table, no_self_overlap;
+    u32 min_mask;
+    // LZSS
+    u32 length_bits, lz_min_length, windows_start, lz_max_distance;
+};
+
+__device__ __forceinline__ u32 load32(const u8* p) {
+    return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+}
+
+// ---------------------------------------------------------------------------------------------- kernel A
+template <bool MINT>
+__global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                      const u32* __restrict__ index_list, u32 count, u32 first_slot,
+                                                      int* __restrict__ head4_all, int* __restrict__ headm_all,
+                                                      int* __restrict__ prev4, int* __restrict__ prevm,
+                                                      const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    __shared__ u8 slot_owner[256];
+    __shared__ u8 slot_flag[256];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;            // LZ4 searches source[0 : n-5]  (LZ4.cs:208)
+    const int limit = n - 4;                              // FindNextBestMatch :159
+    int* head4 = head4_all + ((size_t)(first_slot + bid) << g.hash_bits);
+    int* headm = MINT ? headm_all + ((size_t)(first_slot + bid) << 16) : nullptr;
+    int* p4 = prev4 + pos_off[sid];
+    int* pm = MINT ? prevm + pos_off[sid] : nullptr;
+    for (int i = lane; i < 256; i += 64) slot_flag[i] = 0;
+    __syncthreads();
+    for (int c = 0; c <= limit; c += 64) {
+        const int pos = c + lane;
+        const bool act = pos <= limit;
+        u32 v = act ? load32(data + pos) : 0u;
+        for (int pass = 0; pass < (MINT ? 2 : 1); pass++) {
+            // ComputeHash  LzChainMatchFinder.cs:288-299
+            u32 h = pass == 0 ? (((v * 2654435761u) >> (32 - g.hash_bits)) & ((1u << g.hash_bits) - 1u))
+                              : ((((v & g.min_mask) * 2654435761u) >> 16) & 0xFFFFu);
+            int* head = pass == 0 ? head4 : headm;
+            // lanes that share a hash inside this step must see each other in position order
+            const u32 slot = h & 255u;
+            if (act) slot_owner[slot] = (u8)lane;
+            __syncthreads();
+            const bool lost = act && slot_owner[slot] != (u8)lane;
+            if (lost) slot_flag[slot] = 1;
+            __syncthreads();
+            bool contested = act && slot_flag[slot] != 0;
+            __syncthreads();
+            if (lost) slot_flag[slot] = 0;
+            int old = -1;
+            if (act) old = __hip_atomic_load(&head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int prev = old;
+            bool writer = act;
+            u64 todo = __ballot(contested);
+            while (todo) {
+                const int l0 = (int)__builtin_ctzll(todo);
+                const u32 hv = (u32)__builtin_amdgcn_readlane((int)h, l0);
+                const u64 grp = __ballot(contested && h == hv);
+                if (contested && h == hv) {
+                    const u64 below = grp & ((1ull << lane) - 1ull);
+                    if (below) prev = c + 63 - (int)__builtin_clzll(below);
+                    writer = (grp >> lane) <= 1ull;                    // highest lane of the group owns the new head
+                }
+                todo &= ~grp;
+            }
+            if (writer) head[h] = pos;
+            if (act) { if (pass == 0) p4[pos] = prev; else pm[pos] = prev; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // head stores reach L2 before the next step reads them
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- kernel B
+// Kernel B bounds the bytes it compares per candidate: on degenerate data (long runs) every position would otherwise
+// compare to the end of the stream although the parse only ever visits a handful of them.  A capped position is stored
+// as ALZ_CAPPED and recomputed exactly -- same function, no cap -- by the emit kernel if the parse really visits it.
+#define ALZ_LEN_CAP 2048
+#define ALZ_CAPPED 0xFFFFFFFFu
+
+// GetMatchLength  LzChainMatchFinder.cs:338-357
+__device__ __forceinline__ int match_len(const u8* a, const u8* b, int max) {
+    int len = 0;
+    while (len + 4 <= max) {
+        const u32 x = load32(a + len) ^ load32(b + len);
+        if (x) return len + (__builtin_ctz(x) >> 3);
+        len += 4;
+    }
+    while (len < max && a[len] == b[len]) len++;
+    return len;
+}
+
+// MatchSearch :214-246 with ChainMatches :248-282 as a pure function of (data, prev); returns false when CAP > 0 and a
+// candidate still matched after CAP bytes
+template <bool MINT>
+__device__ __forceinline__ bool match_search(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
+                                             int& best_d, int& best_l) {
+    const u8* dp = data + pos;
+    int cur = p4[pos];
+    int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+    const int cmp_max = (cap > 0 && best_possible > cap) ? cap : best_possible;
+    best_d = 0; best_l = 0; int best_score = -1;
+    int attempts = g.max_chain;
+    while (cur != -1 && attempts-- > 0) {
+        const int dist = pos - cur;
+        if (dist > g.max_dist) break;
+        if (dist < g.min_dist) { cur = p4[cur]; continue; }
+        int len = match_len(dp, data + cur, cmp_max);
+        if (len == cmp_max && cmp_max < best_possible) return false;
+        if (g.no_self_overlap && len > dist) len = dist;             // ScoreMatch :301-308
+        const int score = len - g.min_len;
+        if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
+        cur = p4[cur];
+    }
+    if (MINT && best_l == 0) {                                          // small-match fallback :226-243
+        const int c2 = pm[pos];
+        if (c2 != -1) {
+            int dist = pos - c2;
+            if (dist < g.min_dist) dist = g.min_dist;
+            if (dist <= g.max_dist && pos - dist >= 0) {
+                int len = match_len(dp, data + pos - dist, cmp_max);
+                if (len == cmp_max && cmp_max < best_possible) return false;
+                if (g.no_self_overlap && len > dist) len = dist;
+                best_l = len; best_d = dist;
+            }
+        }
+    }
+    return true;
+}
+
+template <bool MINT>
+__global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                        const u32* __restrict__ index_list, const int* __restrict__ prev4,
+                                                        const int* __restrict__ prevm, uint2* __restrict__ match,
+                                                        const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    const u32 sid = index_list[blockIdx.y];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;
+    const int* p4 = prev4 + pos_off[sid];
+    const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
+    uint2* m = match + pos_off[sid];
+    for (int pos = (int)(blockIdx.x * 256 + threadIdx.x); pos <= limit; pos += (int)(gridDim.x * 256)) {
+        int bd, bl;
+        if (match_search<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl)) m[pos] = make_uint2((u32)bd, (u32)bl);
+        else m[pos] = make_uint2(ALZ_CAPPED, ALZ_CAPPED);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- kernel C
+struct Out {                 // bounded byte sink of one stream
+    u8* p; u32 len, cap; bool fail;
+    __device__ __forceinline__ void put(u32 b) { if (len < cap) p[len] = (u8)b; else fail = true; len++; }
+    __device__ __forceinline__ void put16be(u32 v) { put(v >> 8); put(v & 0xFF); }
+    __device__ __forceinline__ void put16le(u32 v) { put(v & 0xFF); put(v >> 8); }
+    __device__ __forceinline__ void copy(const u8* s, u32 n) { for (u32 i = 0; i < n; i++) put(s[i]); }
+};
+
+// FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags): the flag byte goes out before the payload of its tokens
+struct FlagW {
+    Out* base; u8 payload[40]; int plen, bits_left, cur; bool msb;
+    __device__ void init(Out* b, bool m) { base = b; plen = 0; bits_left = 8; cur = 0; msb = m; }
+    __device__ void flush() {
+        if (bits_left != 8) { base->put((u32)cur); bits_left = 8; cur = 0; }
+        for (int i = 0; i < plen; i++) base->put(payload[i]);
+        plen = 0;
+    }
+    __device__ void bit(int b) { if (b) cur |= 1 << (msb ? bits_left - 1 : 8 - bits_left); if (--bits_left == 0) flush(); }
+    __device__ void pay(u32 v) { payload[plen++] = (u8)v; }
+    __device__ void flush_if_necessary() { if (bits_left == 8 && plen) { for (int i = 0; i < plen; i++) base->put(payload[i]); plen = 0; } }
+};
+
+struct Match { int offset, distance, length; };
+
+// FindNextBestMatch  LzChainMatchFinder.cs:157-212 over the precomputed MatchSearch results
+struct Finder {
+    const uint2* m; int n, limit, position, min_len, lazy;
+    const u8* data; const int* p4; const int* pm; const EncGeom* g;
+    __device__ uint2 get(int pos) const {
+        uint2 r = m[pos];
+        if (r.y == ALZ_CAPPED) {                     // capped by kernel B: recompute this one exactly
+            int bd, bl;
+            if (g->use_min_table) match_search<true>(data, n, pos, p4, pm, *g, 0, bd, bl); else match_search<false>(data, n, pos, p4, pm, *g, 0, bd, bl);
+            r = make_uint2((u32)bd, (u32)bl);
+        }
+        return r;
+    }
+    __device__ Match next() {
+        while (position <= limit) {
+            uint2 r = get(position);
+            int bl = (int)r.y, bd = (int)r.x;
+            if (bl < min_len) { position++; continue; }
+            int skip = 0;
+            if (bl <= lazy && position + 1 <= limit) {
+                const uint2 r2 = get(position + 1);
+                if ((int)r2.y > bl) { bl = (int)r2.y; bd = (int)r2.x; position++; }
+                else skip = 1;
+            }
+            Match out = { position, bd, bl };
+            const int end = position + bl;
+            position += 1 + skip;
+            int stop = end < limit + 1 ? end : limit + 1;
+            if (position < stop) position = stop;
+            return out;
+        }
+        position = n;
+        Match e = { n, 0, 0 };
+        return e;
+    }
+};
+
+__device__ void lz4_ext(Out& o, int length) {                // LZ4.WriteExtension  LZ4.cs:254-268
+    length -= 0xF;
+    if (length >= 0) { int b; do { b = length < 0xFF ? length : 0xFF; o.put((u32)b); length -= b; } while (b == 0xFF); }
+}
+__device__ void lzo_ext(Out& o, int v) { while (v > 255) { o.put(0); v -= 255; } o.put((u32)v); }   // LZO.WriteExtendedInt
+
+template <int FMT>
+__global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                      const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                      u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                      const int* __restrict__ prev4, const int* __restrict__ prevm,
+                                                      u8* __restrict__ side, alz_result* __restrict__ results,
+                                                      alz_encode_aux* __restrict__ aux, EncGeom g) {
+    const u32 i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= count) return;
+    const u32 sid = index_list[i];
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const int n = (int)st.src_len;
+    Out out = { dst_base + st.dst_off, 0, st.dst_cap, false };
+    Finder mf; mf.m = match + pos_off[sid]; mf.position = 0; mf.min_len = g.min_len; mf.lazy = g.lazy;
+    mf.n = (FMT == ALZ_FMT_LZ4_BLOCK) ? n - 5 : n; mf.limit = mf.n - 4;
+    mf.data = src; mf.p4 = prev4 + pos_off[sid]; mf.pm = g.use_min_table ? prevm + pos_off[sid] : nullptr; mf.g = &g;
+    int status = ALZ_ST_OK; u32 a0 = 0, a1 = 0;
+    int sp = 0;
+
+    if constexpr (FMT == ALZ_FMT_LZSS) {                                  // LZSS.cs:132-160
+        FlagW fw; fw.init(&out, false);
+        const u32 nmask = g.lz_max_distance - 1, f = (1u << g.length_bits) - 1;
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(1); }
+            if (mt.length == 0) break;
+            const u32 offset = (g.windows_start + (u32)sp - (u32)mt.distance) & nmask;
+            const u32 v = (offset & 0xFF) | ((offset & 0xFF00) << g.length_bits) | ((((u32)mt.length - g.lz_min_length) & f) << 8);
+            fw.pay(v & 0xFF); fw.pay((v >> 8) & 0xFF); fw.bit(0);
+            sp += mt.length;
+        }
+        fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZ11) {      // LZ10.cs:113-137, LZ11.cs:135-171
+        FlagW fw; fw.init(&out, true);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(0); }
+            if (mt.length == 0) break;
+            const u32 d1 = (u32)(mt.distance - 1) & 0xFFF;
+            if (FMT == ALZ_FMT_LZ10) { const u32 v = (((u32)mt.length - 3) << 12 | d1) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
+            else if (mt.length <= 16) { const u32 v = (((u32)mt.length - 1) << 12 | d1) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
+            else if (mt.length <= 272) { fw.pay((((u32)mt.length - 17) & 0xFF) >> 4); const u32 v = (((u32)mt.length - 17) << 12 | d1) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
+            else { const u32 v = 0x10000000u | ((((u32)mt.length - 273) & 0xFFFF) << 12) | d1; fw.pay(v >> 24); fw.pay((v >> 16) & 0xFF); fw.pay((v >> 8) & 0xFF); fw.pay(v & 0xFF); }
+            sp += mt.length;
+            fw.bit(1);
+        }
+        fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_YAZ0) {                             // Yaz0.cs:94-98 over Yay0.cs:152-184
+        FlagW fw; fw.init(&out, true);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(1); }
+            if (mt.length == 0) break;
+            if (mt.length < 18) { const u32 v = ((u32)(mt.distance - 1) | (((u32)mt.length - 2) << 12)) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
+            else { const u32 v = (u32)(mt.distance - 1) & 0xFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); fw.pay((u32)mt.length - 0x12); }
+            sp += mt.length;
+            fw.bit(0);
+        }
+        fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0) {      // Yay0.cs:62-77,152-184 / MIO0.cs:64-79,159-184
+        // three sections: flags go straight to dst, tokens and literals to side buffers, concatenated afterwards
+        u8* sb = side + 2 * pos_off[sid];
+        Out comp = { sb, 0, (u32)n + 16, false };
+        Out unc = { sb + n + 16, 0, (u32)n + 16, false };
+        FlagW fw; fw.init(&out, true);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { unc.put(src[sp++]); fw.bit(1); }
+            if (mt.length == 0) break;
+            if (FMT == ALZ_FMT_MIO0) comp.put16be(((u32)(mt.distance - 1) | (((u32)mt.length - 3) << 12)) & 0xFFFF);
+            else if (mt.length < 18) comp.put16be(((u32)(mt.distance - 1) | (((u32)mt.length - 2) << 12)) & 0xFFFF);
+            else { comp.put16be((u32)(mt.distance - 1) & 0xFFF); unc.put((u32)mt.length - 0x12); }
+            sp += mt.length;
+            fw.bit(0);
+        }
+        fw.flush();
+        a0 = out.len; a1 = out.len + comp.len;
+        out.copy(comp.p, comp.len); out.copy(unc.p, unc.len);
+    } else if constexpr (FMT == ALZ_FMT_PRS_BE || FMT == ALZ_FMT_PRS_LE) {  // PRS.cs:104-159
+        constexpr bool big = FMT == ALZ_FMT_PRS_BE;
+        FlagW fw; fw.init(&out, big);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(1); }
+            if (mt.length == 0) break;
+            if (mt.length == 2 && mt.distance > 0x100) continue;
+            sp += mt.length;
+            const int distance = -mt.distance, length = mt.length;
+            fw.bit(0);
+            if (distance >= -0x100 && length <= 5) {
+                fw.bit(0); fw.bit(((length - 2) >> 1) & 1); fw.bit((length - 2) & 1);
+                fw.pay((u32)distance & 0xFF);
+                fw.flush_if_necessary();
+            } else {
+                u32 v = (u32)(distance << 3) & 0xFFFF;
+                if (length <= 9) v |= (u32)(length - 2);
+                if (big) { fw.pay(v >> 8); fw.pay(v & 0xFF); } else { fw.pay(v & 0xFF); fw.pay(v >> 8); }
+                if (length > 9) fw.pay((u32)(length - 1));
+                fw.bit(1);
+            }
+        }
+        fw.bit(0); fw.pay(0); fw.pay(0); fw.bit(1);
+        fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) {                        // LZ4.cs:202-238
+        if (n < 5) status = ALZ_ST_BAD_TOKEN;                               // source.Slice(0, Length - 5) throws
+        else for (;;) {
+            Match mt = mf.next();
+            int plain = mt.offset - sp;
+            int token = (plain > 0xF ? 0xF : plain) << 4;
+            if (mt.length != 0) token |= (mt.length - 4 > 0xF ? 0xF : mt.length - 4);
+            else { plain = n - sp; token = (plain > 0xF ? 0xF : plain) << 4; }
+            out.put((u32)token);
+            lz4_ext(out, plain);
+            out.copy(src + sp, (u32)plain);
+            sp += plain;
+            if (sp >= n) break;
+            out.put16le((u32)mt.distance & 0xFFFF);
+            lz4_ext(out, mt.length - 4);
+            sp += mt.length;
+        }
+    } else if constexpr (FMT == ALZ_FMT_LZO) {                              // LZO.cs:141-250
+        if (n < 0x10) { out.put((u32)(17 + n)); out.copy(src, (u32)n); out.put(0x11); out.put(0); out.put(0); }
+        else {
+            Match mt = mf.next(), nx = mf.next();
+            while (sp != n) {
+                int plain = mt.offset - sp;
+                if (plain != 0) {
+                    if (plain < 4) { const int dif = 4 - plain; mt.offset += dif; mt.length -= dif; plain = 4; }
+                    if (plain > 18) { out.put(0); lzo_ext(out, plain - 18); } else out.put((u32)(plain - 3));
+                    if (sp + plain > n) { status = ALZ_ST_BAD_TOKEN; break; }
+                    out.copy(src + sp, (u32)plain); sp += plain;
+                }
+                if (mt.length >= 3) {
+                    sp += mt.length;
+                    plain = nx.offset - sp;
+                    if (plain > 3) plain = 0;
+                    if (plain < 0) { status = ALZ_ST_BAD_TOKEN; break; }
+                    if (mt.length <= 8 && mt.distance <= 2048) {
+                        const u32 flag = (u32)(plain | (((mt.distance - 1) & 0x7) << 2)) & 0xFF;
+                        if (mt.length <= 4) out.put(flag | 0x40 | (u32)((mt.length - 3) << 5)); else out.put(flag | 0x80 | (u32)((mt.length - 5) << 5));
+                        out.put((u32)((mt.distance - 1) >> 3));
+                    } else if (mt.distance <= 16384) {
+                        if (mt.length > 33) { out.put(0x20); lzo_ext(out, mt.length - 33); } else out.put(0x20 | (u32)(mt.length - 2));
+                        out.put((u32)(plain | ((mt.distance - 1) << 2)) & 0xFF); out.put((u32)((mt.distance - 1) >> 6) & 0xFF);
+                    } else {
+                        const int distance = mt.distance - 0x4000;
+                        const u32 flag = (u32)(0x10 | ((distance & 0x4000) >> 11)) & 0xFF;
+                        if (mt.length > 9) { out.put(flag); lzo_ext(out, mt.length - 9); } else out.put(flag | (u32)(mt.length - 2));
+                        out.put((u32)(plain | (distance << 2)) & 0xFF); out.put((u32)(distance >> 6) & 0xFF);
+                    }
+                    if (sp + plain > n) { status = ALZ_ST_BAD_TOKEN; break; }
+                    out.copy(src + sp, (u32)plain); sp += plain;
+                }
+                mt = nx; nx = mf.next();
+            }
+            out.put(0x11); out.put(0); out.put(0);
+        }
+    } else {                                                                // Snappy.cs:124-203
+        int v = n; while (v >= 0x80) { out.put((u32)(v | 0x80) & 0xFF); v >>= 7; } out.put((u32)v);
+        for (;;) {
+            Match mt = mf.next();
+            const int plain = mt.offset - sp;
+            if (plain > 0) {
+                if (plain <= 60) out.put((u32)((plain - 1) << 2));
+                else {
+                    const int len = plain - 1;
+                    if (len <= 0xFF) { out.put(60 << 2); out.put((u32)len); }
+                    else if (len <= 0xFFFF) { out.put(61 << 2); out.put16le((u32)len); }
+                    else if (len <= 0xFFFFFF) { out.put(62 << 2); out.put((u32)len & 0xFF); out.put(((u32)len >> 8) & 0xFF); out.put(((u32)len >> 16) & 0xFF); }
+                    else { out.put(63 << 2); out.put16le((u32)len & 0xFFFF); out.put16le((u32)len >> 16); }
+                }
+                out.copy(src + sp, (u32)plain); sp += plain;
+            }
+            if (mt.length == 0) break;
+            sp += mt.length;
+            if (mt.distance < 2048 && mt.length >= 4 && mt.length <= 11) { out.put((u32)(1 | ((mt.length - 4) << 2) | ((mt.distance >> 8) << 5))); out.put((u32)mt.distance & 0xFF); }
+            else { out.put((u32)(2 | ((mt.length - 1) << 2)) & 0xFF); out.put16le((u32)mt.distance & 0xFFFF); }
+        }
+    }
+    if (out.fail && status == ALZ_ST_OK) status = ALZ_ST_OUTPUT_CAPACITY;
+    alz_result r; r.dst_len = out.fail ? 0u : out.len; r.src_used = st.src_len; r.status = status; r.reserved = 0;
+    results[sid] = r;
+    if (aux) { aux[sid].aux0 = a0; aux[sid].aux1 = a1; }
+}
+
+int isqrt_floor(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) r++; return r; }
+
+}  // namespace
+
+// quality -> finder parameters  LzChainMatchFinder.cs:108-119 ; per-format LzProperties
+bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits) {
+    EncGeom g; memset(&g, 0, sizeof(g));
+    int wb = 12;
+    switch (fmt) {
+    case ALZ_FMT_LZSS:
+        wb = lz->window_bits; g.min_len = lz->min_length; g.max_len = (1 << lz->length_bits) + lz->min_length - 1; g.max_dist = (int)lz->max_distance; break;
+    case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;
+    case ALZ_FMT_LZ11: g.min_len = 3; g.max_len = 0x4000; g.max_dist = 0x1000; break;
+    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: g.min_len = 3; g.max_len = 0xff + 0x12; g.max_dist = 0x1000; break;
+    case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: wb = 13; g.min_len = 2; g.max_len = 0x100; g.max_dist = 0x1FFF; break;
+    case ALZ_FMT_LZ4_BLOCK: wb = 16; g.min_len = 4; g.max_len = 0x7FFFFFFF; g.max_dist = 0xFFFF; break;
+    case ALZ_FMT_LZO: wb = 16; g.min_len = 3; g.max_len = 0x7FFFFFFF; g.max_dist = 0xBFFF; break;
+    case ALZ_FMT_SNAPPY_RAW: wb = 15; g.min_len = 4; g.max_len = 64; g.max_dist = 0x8000; break;
+    default: return false;
+    }
+    g.min_dist = st->min_distance > 0 ? st->min_distance : 1;
+    const int q = st->quality;
+    g.max_chain = q < 6 ? q + 1 : q >= 11 ? 1 << (q - 5) : ((1 << (q >> 1)) | ((1 << (q >> 1)) >> (q & 1)));
+    g.lazy = 3 + q / 3;
+    g.hash_bits = 15 + isqrt_floor(2 * q);
+    g.no_self_overlap = st->strategy & 1;
+    g.use_min_table = (q >= 10 && g.min_len < 4) ? 1 : 0;
+    g.min_mask = g.use_min_table ? (0xFFFFFFFFu >> ((4 - g.min_len) * 8)) : 0u;
+    g.length_bits = lz->length_bits; g.lz_min_length = lz->min_length; g.windows_start = lz->windows_start; g.lz_max_distance = lz->max_distance;
+    // the chain table of the reference has 1 << min(17 + floor(sqrt(2q)), windowsBits) slots; the prev() identity needs
+    // it to cover maxDistance, which holds for every format geometry of the reference
+    const int chain_bits = (17 + isqrt_floor(2 * q)) < wb ? (17 + isqrt_floor(2 * q)) : wb;
+    if (g.max_chain != 1 && (1 << chain_bits) < g.max_dist) return false;
+    memcpy(out_geom, &g, sizeof(g));
+    if (window_bits) *window_bits = wb;
+    return true;
+}
+
+size_t alz_encode_geom_size(void) { return sizeof(EncGeom); }
+int alz_encode_geom_hash_bits(const void* geom) { return ((const EncGeom*)geom)->hash_bits; }
+int alz_encode_geom_min_table(const void* geom) { return ((const EncGeom*)geom)->use_min_table; }
+
+template <int FMT>
+static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
+                        const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
+    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3((count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
+}
+
+hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
+                             uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
+                             const uint64_t* d_pos_off, void* d_side, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
+    if (count == 0) return hipSuccess;
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
+    const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
+    if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
+    else hipLaunchKernelGGL((enc_prev_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
+    u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
+    if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+    else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+    const uint2* m = (const uint2*)d_match; u8* side = (u8*)d_side;
+    switch (fmt) {
+    case ALZ_FMT_LZSS: launch_emit<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ10: launch_emit<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ11: launch_emit<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAZ0: launch_emit<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAY0: launch_emit<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_MIO0: launch_emit<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_PRS_LE: launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ4_BLOCK: launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

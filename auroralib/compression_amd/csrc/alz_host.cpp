@@ -260,12 +260,97 @@ int alz_decode(alz_ctx* c, uint32_t format, const alz_lz_properties* props, cons
     return alz_decode_batch(c, props, 1, src, src_len, &s, dst, dst_cap, result);
 }
 
+// Device buffers of one encode call, freed on every exit path
+struct EncScratch {
+    std::vector<void*> bufs;
+    ~EncScratch() { for (void* p : bufs) if (p) (void)hipFree(p); }
+    hipError_t alloc(void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) bufs.push_back(*p); return e; }
+};
+
 int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
                      size_t src_bytes, const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
-    (void)props; (void)settings; (void)src_base; (void)src_bytes; (void)streams; (void)dst_base; (void)dst_bytes; (void)results; (void)aux;
-    if (!c) return fail(ALZ_E_INVALID, "alz_encode_batch: ctx is NULL");
+    if (!c || (n && (!streams || !results || !dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch: bad argument");
     if (n == 0) return ALZ_OK;
-    return fail(ALZ_E_UNSUPPORTED, "alz_encode_batch: the GPU encoder is not built into this library yet (no CPU fallback exists)");
+    alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
+    if (st.quality < 0 || st.quality > 15) return fail(ALZ_E_INVALID, "quality %d outside 0..15 (CompressionSettings.cs:38-50)", st.quality);
+    if (st.max_window_bits != 0) return fail(ALZ_E_UNSUPPORTED, "CompressionSettings.MaxWindowBits != 0 is not supported by the GPU encoder");
+    alz_lz_properties lz = effective_lz(props);
+    std::vector<uint32_t> cnt(ALZ_FMT_COUNT, 0);
+    std::vector<uint64_t> pos_off(n);
+    uint64_t total = 0; uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
+        if (streams[i].src_off + streams[i].src_len > src_bytes) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
+        if (streams[i].dst_off + streams[i].dst_cap > dst_bytes) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+        if (streams[i].src_len > 0x7FFFFF00u) return fail(ALZ_E_UNSUPPORTED, "stream %u: inputs above 2 GiB are not supported", i);
+        cnt[streams[i].format]++;
+        pos_off[i] = total; total += (uint64_t)streams[i].src_len + 16;
+        if (streams[i].src_len > max_len) max_len = streams[i].src_len;
+    }
+    if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
+        return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
+    std::vector<unsigned char> geom(ALZ_FMT_COUNT * alz_encode_geom_size());
+    int hash_bits = 0; bool any_min = false;
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+        if (!cnt[f]) continue;
+        void* g = geom.data() + f * alz_encode_geom_size();
+        if (!alz_encode_geometry(f, &lz, &st, g, nullptr)) return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", f);
+        hash_bits = alz_encode_geom_hash_bits(g);
+        any_min = any_min || alz_encode_geom_min_table(g);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return rc;
+    if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return rc;
+    // streams are processed in chunks so that the per-stream head tables (4 B << hash_bits each) stay bounded
+    const uint32_t CH = 4096;
+    EncScratch sc;
+    alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
+    uint64_t* d_pos = nullptr; int *d_head4 = nullptr, *d_headm = nullptr, *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr;
+    const uint32_t chn = n < CH ? n : CH;
+    hipError_t e = sc.alloc((void**)&d_streams, (size_t)n * sizeof(alz_stream));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_results, (size_t)n * sizeof(alz_result));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_aux, (size_t)n * sizeof(alz_encode_aux));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_head4, ((size_t)chn << hash_bits) * sizeof(int));
+    if (e == hipSuccess && any_min) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
+    if (e == hipSuccess && any_min) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int));
+    if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
+    if (e == hipSuccess && (cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0])) e = sc.alloc(&d_side, (size_t)total * 2 + 64);
+    if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
+    std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
+    { uint32_t off = 0; for (int f = 0; f < ALZ_FMT_COUNT; f++) { foff[f] = off; off += cnt[f]; } }
+    for (uint32_t i = 0; i < n; i++) { uint32_t f = streams[i].format; index[foff[f] + fill[f]++] = i; }
+    if (src_bytes) HIP_TRY(hipMemcpyAsync(c->d_src, src_base, src_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_streams, streams, (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_pos, pos_off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
+    HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+        const void* g = geom.data() + f * alz_encode_geom_size();
+        for (uint32_t done = 0; done < cnt[f]; done += CH) {
+            const uint32_t k = cnt[f] - done < CH ? cnt[f] - done : CH;
+            HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
+            if (alz_encode_geom_min_table(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
+            e = alz_launch_encode(f, c->stream, c->d_src, c->d_dst, d_streams, d_index + foff[f] + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
+                                  d_match, d_pos, d_side, d_results, d_aux, g);
+            if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", f, hipGetErrorString(e));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(results, d_results, (size_t)n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
+    std::vector<alz_encode_aux> haux(n);
+    HIP_TRY(hipMemcpyAsync(haux.data(), d_aux, (size_t)n * sizeof(alz_encode_aux), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        if (aux) aux[i] = haux[i];
+        if (results[i].status == ALZ_ST_OK && results[i].dst_len)
+            HIP_TRY(hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ALZ_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,104 @@
+"""-m gpu: the GPU encoder (alz_encode_batch) against the oracle's restatement of LzChainMatchFinder + FlagWriter +
+CompressHeaderless: compressed bytes must be IDENTICAL, for every format and quality class, and decode back."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from auroralib.compression_amd import _abi as A
+from auroralib.compression_amd import synth
+from gpu_common import ctx
+
+pytestmark = pytest.mark.gpu
+ALL = list(range(A.FMT_COUNT))
+
+
+def _encode_and_compare(fmt, raws, quality, **kw):
+    n = len(raws)
+    streams = (A.Stream * n)()
+    so = do = 0
+    chunks = []
+    for i, r in enumerate(raws):
+        cap = len(r) + len(r) // 4 + 64
+        streams[i] = A.Stream(so, do, len(r), cap, 0, 0, 0, fmt)
+        pad = (-len(r)) % 16
+        chunks.append(bytes(r) + bytes(pad))
+        so += len(r) + pad
+        do += (cap + 15) // 16 * 16
+    src = np.frombuffer(b"".join(chunks) + bytes(64), dtype=np.uint8).copy()
+    dst, res, aux = ctx().encode_batch(streams, src, do + 64, quality=quality, **kw)
+    for i, r in enumerate(raws):
+        try:
+            want, waux = O.encode_stream(fmt, r, quality=quality, **kw)
+        except ValueError:
+            assert res[i].status != A.ST_OK, (A.FORMAT_NAMES[fmt], i, "oracle refuses, gpu accepted")
+            continue
+        assert res[i].status == A.ST_OK, (A.FORMAT_NAMES[fmt], quality, i, len(r), res[i].status)
+        got = bytes(dst[streams[i].dst_off:streams[i].dst_off + res[i].dst_len])
+        if got != want:
+            k = next((j for j in range(min(len(got), len(want))) if got[j] != want[j]), min(len(got), len(want)))
+            raise AssertionError("%s q%d stream %d (%d B): gpu %d B vs oracle %d B, first difference at %d" % (
+                A.FORMAT_NAMES[fmt], quality, i, len(r), len(got), len(want), k))
+        assert (aux[i].aux0, aux[i].aux1) == (waux.aux0, waux.aux1)
+
+
+@pytest.mark.parametrize("fmt", ALL)
+@pytest.mark.parametrize("quality", [0, 4, 8, 12, 15])
+def test_encode_bit_identical_bmp(fmt, quality, test_bmp):
+    raws = [test_bmp[:10], test_bmp[:10240], test_bmp[100000:100000 + 65536], test_bmp[500000:500000 + 30000], test_bmp[4096:4096 + 262144]]
+    if quality >= 12:
+        raws = raws[:4]
+    _encode_and_compare(fmt, raws, quality)
+
+
+@pytest.mark.parametrize("fmt", ALL)
+def test_encode_edge_inputs(fmt):
+    rng = np.random.default_rng(5)
+    raws = [b"", b"a", b"ab", b"abc", b"abcd", b"abcde", bytes(5), bytes(15), bytes(16), bytes(17), bytes(0x100), bytes(5000), bytes(70000),
+            b"ab" * 3000, b"abc" * 1000 + b"x", bytes(rng.integers(0, 256, 3000, dtype=np.uint8)),
+            bytes(rng.integers(0, 4, 20000, dtype=np.uint8)), (b"0123456789" * 30 + bytes(rng.integers(0, 256, 50, dtype=np.uint8))) * 20]
+    for q in (0, 8, 15):
+        _encode_and_compare(fmt, raws, q)
+
+
+@pytest.mark.parametrize("fmt", [A.FMT_LZ10, A.FMT_LZ11])
+def test_encode_vram_mode(fmt, test_bmp):
+    _encode_and_compare(fmt, [test_bmp[:20000], bytes(300)], 8, min_distance=2)
+    _encode_and_compare(fmt, [test_bmp[:20000], bytes(300)], 15, min_distance=2)
+
+
+def test_encode_compatibility_mode(test_bmp):
+    _encode_and_compare(A.FMT_LZSS, [test_bmp[:20000], bytes(300), b"ab" * 500], 8, strategy=1)
+
+
+def test_encode_lzss_geometries(test_bmp):
+    for bits in [(10, 6, 2), (12, 4, 2), (8, 4, 2)]:
+        _encode_and_compare(A.FMT_LZSS, [test_bmp[:30000], bytes(1000)], 8, lz=A.LzProperties.from_bits(*bits))
+
+
+def test_encode_synthetic_decoded_batch():
+    """cfg5-style: raw buffers obtained by decoding synthetic LZSS streams, compressed as LZSS(12,4,2) at Q0 and Q8."""
+    b = synth.make_batch(A.FMT_LZSS, 24, 65536, synth.seed_for(5))
+    dst, res = O.decode_batch(b.streams, b.src, b.dst_bytes, nthreads=4)
+    recs = synth.stream_records(b.streams)
+    raws = [bytes(dst[int(recs["dst_off"][i]):int(recs["dst_off"][i]) + 65536]) for i in range(b.n)]
+    for q in (0, 8):
+        _encode_and_compare(A.FMT_LZSS, raws, q)
+
+
+def test_encode_capacity_too_small(test_bmp):
+    raw = test_bmp[:10240]
+    streams = (A.Stream * 1)(A.Stream(0, 0, len(raw), 100, 0, 0, 0, A.FMT_LZ10))
+    dst, res, aux = ctx().encode_batch(streams, np.frombuffer(raw + bytes(64), dtype=np.uint8), 4096, quality=8)
+    assert res[0].status == A.ST_OUTPUT_CAPACITY
+
+
+def test_container_compress_roundtrip(test_bmp):
+    """ICompressionEncoder.Compress through the format-class mirror == the oracle's container bytes, and decodes back."""
+    from auroralib.compression_amd import formats as F
+    raw = test_bmp[:10240]
+    for cls, cont in [(F.LZSS, A.C_LZSS), (F.LZ10, A.C_LZ10), (F.LZ11, A.C_LZ11), (F.Yaz0, A.C_YAZ0), (F.Yay0, A.C_YAY0), (F.MIO0, A.C_MIO0), (F.PRS, A.C_PRS), (F.LZO, A.C_LZO)]:
+        for s in (F.CompressionSettings.Fastest, F.CompressionSettings.Balanced, F.CompressionSettings.Maximum):
+            f = cls()
+            comp = f.Compress(raw, s)
+            assert comp == O.container_compress(cont, raw, quality=s.Quality), (cls.__name__, s.Quality)
+            assert f.Decompress(comp, capacity=len(raw) + 300) == raw
