@@ -437,6 +437,223 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
     if (aux) { aux[sid].aux0 = a0; aux[sid].aux1 = a1; }
 }
 
+// ---------------------------------------------------------------------------------------------- kernels C1 + C2
+// Lane-parallel emission for the flag-byte formats (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0).
+//
+// C1 (enc_roles_kernel, one wavefront per stream): the greedy/lazy parse.  For 64 consecutive positions at a time every
+//    lane evaluates "what FindNextBestMatch does if its cursor is HERE" (no token / match here / literal + match at the
+//    next position, and where the cursor goes), then the real cursor hops through the window with v_readlane.  Output:
+//    one bit per position, "a match token starts here" (the match itself is match[p]).
+// C2 (enc_emit_par_kernel, one wavefront per stream): with the match starts known everything else is prefix sums over
+//    positions: covered positions (prefix max of match ends), literals, token index (-> flag group and bit), payload
+//    offsets.  Token lanes store their payload bytes; flag bytes are accumulated in LDS and stored when their group
+//    completes.  FlagWriter order (IO/FlagWriter.cs:70-80,111-127): flag byte, then the payload of its 8 tokens.
+
+__device__ __forceinline__ u32 scan_add(u32 v) {            // inclusive wave prefix sum (gfx9 DPP)
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+__device__ __forceinline__ u32 scan_max(u32 v) {            // inclusive wave prefix max
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); v = v > t ? v : t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = v > t ? v : t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = v > t ? v : t;
+    return v;
+}
+
+__global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                       const u32* __restrict__ index_list, u32 count, uint2* __restrict__ match,
+                                                       const u64* __restrict__ pos_off, const int* __restrict__ prev4,
+                                                       const int* __restrict__ prevm, u64* __restrict__ startmask, EncGeom g) {
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len;
+    const int limit = n - 4;
+    uint2* m = match + pos_off[sid];
+    const int* p4 = prev4 + pos_off[sid];
+    const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
+    u64* mask = startmask + (pos_off[sid] >> 6);
+    int cur = 0;                    // cursor of FindNextBestMatch (absolute position)
+    while (cur <= limit) {
+        const int P = cur & ~63;    // window that holds the cursor (windows the cursor jumps over keep their zero mask)
+        const int p = P + lane;
+        // match[p] and match[p+1] (positions above `limit` were never searched: no match)
+        uint2 a = make_uint2(0, 0), b = make_uint2(0, 0);
+        if (p <= limit) a = m[p];
+        if (p + 1 <= limit) b = m[p + 1];
+        const bool capped = a.y == ALZ_CAPPED || b.y == ALZ_CAPPED;
+        int jump = 1, startrel = 0;   // startrel: 0 no token here, 1 match starts here, 2 literal here + match at p + 1
+        if (!capped && p <= limit && (int)a.y >= g.min_len) {
+            const int l0 = (int)a.y, l1 = (int)b.y;
+            const bool lazyc = l0 <= g.lazy && p + 1 <= limit;
+            if (lazyc && l1 > l0) { startrel = 2; const int e = p + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 2 > stop ? p + 2 : stop) - p; }
+            else { startrel = 1; const int skip = lazyc ? 1 : 0; const int e = p + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 1 + skip > stop ? p + 1 + skip : stop) - p; }
+        }
+        u64 bits = 0;
+        int rel = cur - P;
+        while (rel < 64 && P + rel <= limit) {
+            int j, sr;
+            if (__builtin_amdgcn_readlane((int)capped, rel)) {
+                // kernel B capped a candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour
+                const int q = P + rel;
+                int d0, l0, d1 = 0, l1 = 0;
+                if (g.use_min_table) match_search<true>(data, n, q, p4, pm, g, 0, d0, l0); else match_search<false>(data, n, q, p4, pm, g, 0, d0, l0);
+                if (q + 1 <= limit) { if (g.use_min_table) match_search<true>(data, n, q + 1, p4, pm, g, 0, d1, l1); else match_search<false>(data, n, q + 1, p4, pm, g, 0, d1, l1); }
+                if (lane == 0) { m[q] = make_uint2((u32)d0, (u32)l0); if (q + 1 <= limit) m[q + 1] = make_uint2((u32)d1, (u32)l1); }
+                j = 1; sr = 0;
+                if (l0 >= g.min_len) {
+                    const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
+                    if (lazyc && l1 > l0) { sr = 2; const int e = q + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 2 > stop ? q + 2 : stop) - q; }
+                    else { sr = 1; const int skip = lazyc ? 1 : 0; const int e = q + l0; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 1 + skip > stop ? q + 1 + skip : stop) - q; }
+                }
+            } else {
+                j = __builtin_amdgcn_readlane(jump, rel);
+                sr = __builtin_amdgcn_readlane(startrel, rel);
+            }
+            if (sr == 1) bits |= 1ull << rel;
+            else if (sr == 2) { if (rel + 1 < 64) bits |= 1ull << (rel + 1); else if (lane == 0) mask[(P >> 6) + 1] = 1ull; }   // start in lane 0 of the next window
+            rel += j;
+        }
+        if (lane == 0) mask[P >> 6] |= bits;      // the mask array is zeroed before the launch
+        cur = P + rel;
+    }
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                          const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          const u64* __restrict__ startmask, u8* __restrict__ side,
+                                                          alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || THREE);   // flag bit of a literal token
+    constexpr bool MSB = (FMT != ALZ_FMT_LZSS);
+    __shared__ u32 flagacc[16];
+    __shared__ u32 gofs[16];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 n = st.src_len;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    const uint2* m = match + pos_off[sid];
+    const u64* mask = startmask + (pos_off[sid] >> 6);
+    u8* compb = THREE ? side + 2 * pos_off[sid] : nullptr;            // token section (Yay0/MIO0)
+    u8* uncb = THREE ? side + 2 * pos_off[sid] + n + 16 : nullptr;    // literal section
+    if (lane < 16) { flagacc[lane] = 0; gofs[lane] = 0; }
+    __syncthreads();
+    u32 tok_base = 0;       // tokens emitted before the window
+    u32 pay_base = 0;       // payload bytes before the window (THREE: token-section bytes)
+    u32 unc_base = 0;       // THREE: literal-section bytes before the window
+    u32 cover = 0;          // end of the last match seen so far
+    bool fail = false;
+    for (u32 P = 0; P < n; P += 64) {
+        const u32 p = P + (u32)lane;
+        const u64 sm = mask[P >> 6];
+        const bool start = ((sm >> lane) & 1ull) && p < n;
+        uint2 mt = make_uint2(0, 0);
+        if (start) mt = m[p];
+        const u32 mend = start ? p + mt.y : 0u;
+        const u32 pmax = scan_max(mend);                               // inclusive
+        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
+        if (before < cover) before = cover;
+        const bool lit = !start && p < n && p >= before;
+        const bool tok = start || lit;
+        const u64 tm = __ballot(tok);
+        const u32 ti = tok_base + __builtin_amdgcn_mbcnt_hi((u32)(tm >> 32), __builtin_amdgcn_mbcnt_lo((u32)tm, 0u));
+        // payload of my token
+        u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, psize = 0, usize = 0;
+        if (lit) { b0 = src[p]; psize = 1; }
+        else if (start) {
+            const u32 d1 = (mt.x - 1u) & 0xFFFu, len = mt.y;
+            if (FMT == ALZ_FMT_LZSS) {
+                const u32 offset = (g.windows_start + p - mt.x) & (g.lz_max_distance - 1u);
+                const u32 v = (offset & 0xFFu) | ((offset & 0xFF00u) << g.length_bits) | (((len - g.lz_min_length) & ((1u << g.length_bits) - 1u)) << 8);
+                b0 = v & 0xFF; b1 = (v >> 8) & 0xFF; psize = 2;
+            } else if (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_MIO0) {
+                const u32 v = (((len - 3u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
+            } else if (FMT == ALZ_FMT_LZ11) {
+                if (len <= 16) { const u32 v = (((len - 1u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
+                else if (len <= 272) { b0 = ((len - 17u) & 0xFFu) >> 4; const u32 v = (((len - 17u) << 12) | d1) & 0xFFFFu; b1 = v >> 8; b2 = v & 0xFF; psize = 3; }
+                else { const u32 v = 0x10000000u | (((len - 273u) & 0xFFFFu) << 12) | d1; b0 = v >> 24; b1 = (v >> 16) & 0xFF; b2 = (v >> 8) & 0xFF; b3 = v & 0xFF; psize = 4; }
+            } else {   // YAZ0 / YAY0
+                if (len < 18) { const u32 v = (d1 | ((len - 2u) << 12)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
+                else { b0 = d1 >> 8; b1 = d1 & 0xFF; b2 = len - 0x12u; psize = 3; }
+            }
+        }
+        if (THREE) {   // literals (and Yay0's long-length byte) live in their own section
+            if (lit) { usize = 1; psize = 0; }
+            else if (start && FMT == ALZ_FMT_YAY0 && psize == 3) { usize = 1; psize = 2; }
+        }
+        const u32 pincl = scan_add(psize);
+        const u32 poff = pay_base + pincl - psize;
+        const u32 uincl = THREE ? scan_add(usize) : 0u;
+        const u32 uoff = unc_base + uincl - usize;
+        const u32 group = ti >> 3, bitpos = ti & 7u;
+        // flag bytes: the first token of a group fixes the flag byte's position, the last one stores it
+        const u32 flag_off = THREE ? group : poff + group;             // interleaved: flag g sits right before the payload of token 8g
+        if (tok && bitpos == 0) { gofs[group & 15u] = flag_off; flagacc[group & 15u] = 0; }
+        __syncthreads();
+        if (tok) {
+            const u32 bitv = (lit ? LIT_BIT : !LIT_BIT) ? 1u : 0u;
+            if (bitv) atomicOr(&flagacc[group & 15u], 1u << (MSB ? 7u - bitpos : bitpos));
+        }
+        __syncthreads();
+        if (tok) {
+            if (bitpos == 7) { const u32 fo = gofs[group & 15u]; if (fo < cap) dst[fo] = (u8)flagacc[group & 15u]; else fail = true; }
+            if (!THREE) {
+                const u32 o = poff + group + 1u;
+                if (o + psize <= cap) { dst[o] = (u8)b0; if (psize > 1) dst[o + 1] = (u8)b1; if (psize > 2) dst[o + 2] = (u8)b2; if (psize > 3) dst[o + 3] = (u8)b3; }
+                else fail = true;
+            } else {
+                if (lit) uncb[uoff] = (u8)b0;
+                else { compb[poff] = (u8)b0; compb[poff + 1] = (u8)b1; if (usize) uncb[uoff] = (u8)b2; }
+            }
+        }
+        __syncthreads();
+        tok_base += (u32)__popcll(tm);
+        pay_base += (u32)__builtin_amdgcn_readlane((int)pincl, 63);
+        if (THREE) unc_base += (u32)__builtin_amdgcn_readlane((int)uincl, 63);
+        const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
+        if (wmax > cover) cover = wmax;
+    }
+    // Dispose(): a partial flag byte is written with its unused bits zero (FlagWriter.cs:141-145)
+    const u32 nflags = (tok_base + 7u) >> 3;
+    if ((tok_base & 7u) != 0 && lane == 0) { const u32 gi = (tok_base >> 3); const u32 fo = gofs[gi & 15u]; if (fo < cap) dst[fo] = (u8)flagacc[gi & 15u]; else fail = true; }
+    u32 total;
+    if (!THREE) total = pay_base + nflags;
+    else {
+        total = nflags + pay_base + unc_base;
+        if (total <= cap) {
+            for (u32 i = (u32)lane; i < pay_base; i += 64) dst[nflags + i] = compb[i];
+            for (u32 i = (u32)lane; i < unc_base; i += 64) dst[nflags + pay_base + i] = uncb[i];
+        } else fail = true;
+        if (lane == 0 && aux) { aux[sid].aux0 = nflags; aux[sid].aux1 = nflags + pay_base; }
+    }
+    if (total > cap) fail = true;
+    const bool anyfail = __ballot(fail) != 0;
+    if (lane == 0) {
+        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
+        results[sid] = r;
+        if (!THREE && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+    }
+}
+
 int isqrt_floor(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) r++; return r; }
 
 }  // namespace
@@ -485,9 +702,16 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
     hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3((count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
 }
 
+template <int FMT>
+static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, uint2* match,
+                            const u64* pos_off, const int* prev4, const int* prevm, u64* mask, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
+    hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g);
+    hipLaunchKernelGGL((enc_emit_par_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, mask, side, results, aux, g);
+}
+
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
-                             const uint64_t* d_pos_off, void* d_side, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
+                             const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
     if (count == 0) return hipSuccess;
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
@@ -499,12 +723,12 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
     const uint2* m = (const uint2*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
-    case ALZ_FMT_LZSS: launch_emit<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ10: launch_emit<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ11: launch_emit<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_YAZ0: launch_emit<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_YAY0: launch_emit<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_MIO0: launch_emit<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ10: launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ11: launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_PRS_LE: launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ4_BLOCK: launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

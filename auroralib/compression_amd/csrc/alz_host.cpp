@@ -284,7 +284,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
         if (streams[i].dst_off + streams[i].dst_cap > dst_bytes) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
         if (streams[i].src_len > 0x7FFFFF00u) return fail(ALZ_E_UNSUPPORTED, "stream %u: inputs above 2 GiB are not supported", i);
         cnt[streams[i].format]++;
-        pos_off[i] = total; total += (uint64_t)streams[i].src_len + 16;
+        pos_off[i] = total; total += ((uint64_t)streams[i].src_len + 16 + 63) & ~63ull;   // 64-aligned: one start-mask word per 64 positions
         if (streams[i].src_len > max_len) max_len = streams[i].src_len;
     }
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
@@ -306,7 +306,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     const uint32_t CH = 4096;
     EncScratch sc;
     alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
-    uint64_t* d_pos = nullptr; int *d_head4 = nullptr, *d_headm = nullptr, *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr;
+    uint64_t* d_pos = nullptr; int *d_head4 = nullptr, *d_headm = nullptr, *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr, *d_mask = nullptr;
     const uint32_t chn = n < CH ? n : CH;
     hipError_t e = sc.alloc((void**)&d_streams, (size_t)n * sizeof(alz_stream));
     if (e == hipSuccess) e = sc.alloc((void**)&d_results, (size_t)n * sizeof(alz_result));
@@ -319,6 +319,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (e == hipSuccess && any_min) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int));
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
     if (e == hipSuccess && (cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0])) e = sc.alloc(&d_side, (size_t)total * 2 + 64);
+    if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
     { uint32_t off = 0; for (int f = 0; f < ALZ_FMT_COUNT; f++) { foff[f] = off; off += cnt[f]; } }
@@ -329,6 +330,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     HIP_TRY(hipMemcpyAsync(d_pos, pos_off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
     HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
+    HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)total / 8 + 64, c->stream));
     for (int f = 0; f < ALZ_FMT_COUNT; f++) {
         const void* g = geom.data() + f * alz_encode_geom_size();
         for (uint32_t done = 0; done < cnt[f]; done += CH) {
@@ -336,7 +338,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
             HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
             if (alz_encode_geom_min_table(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
             e = alz_launch_encode(f, c->stream, c->d_src, c->d_dst, d_streams, d_index + foff[f] + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
-                                  d_match, d_pos, d_side, d_results, d_aux, g);
+                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
     }
