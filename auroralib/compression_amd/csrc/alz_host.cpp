@@ -222,6 +222,34 @@ static int grow(alz_ctx* c, void** buf, size_t* cap, size_t need) {
     return ALZ_OK;
 }
 
+// Download per-stream outputs: one bulk copy when the produced ranges are reasonably dense, else one copy per stream.
+static int download_outputs(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
+    uint64_t lo = ~0ull, hi = 0, sum = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
+        const uint64_t a = streams[i].dst_off, b = a + results[i].dst_len;
+        if (a < lo) lo = a; if (b > hi) hi = b; sum += results[i].dst_len;
+    }
+    if (sum == 0) return ALZ_OK;
+    if (hi - lo <= 2 * sum + (64ull << 20)) {
+        // the caller's bytes between streams are preserved: stage through a bounce buffer and copy each stream out
+        std::vector<uint8_t> bounce(hi - lo);
+        HIP_TRY(hipMemcpyAsync(bounce.data(), (const uint8_t*)c->d_dst + lo, hi - lo, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < n; i++) {
+            if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
+            memcpy(dst_base + streams[i].dst_off, bounce.data() + (streams[i].dst_off - lo), results[i].dst_len);
+        }
+        return ALZ_OK;
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
+        HIP_TRY(hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ALZ_OK;
+}
+
 int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const uint8_t* src_base, size_t src_bytes,
                      const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results) {
     if (!c || (n && (!streams || !results))) return fail(ALZ_E_INVALID, "alz_decode_batch: bad argument");
@@ -238,16 +266,7 @@ int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, con
     if ((rc = alz_plan_create(c, props, n, streams, &p))) return rc;
     rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);
     if (!rc) rc = alz_plan_results(c, p, results);
-    if (!rc) {
-        // copy back only what each stream produced (outputs of different streams may interleave with caller data)
-        for (uint32_t i = 0; i < n && !rc; i++) {
-            if (!results[i].dst_len) continue;
-            hipError_t e = hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len,
-                                          hipMemcpyDeviceToHost, c->stream);
-            if (e != hipSuccess) rc = fail(ALZ_E_HIP, "download failed: %s", hipGetErrorString(e));
-        }
-        if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(ALZ_E_HIP, "sync failed: %s", hipGetErrorString(e)); }
-    }
+    if (!rc) rc = download_outputs(c, n, streams, results, dst_base, false);   // copy back only what each stream produced
     alz_plan_destroy(c, p);
     return rc;
 }
@@ -346,12 +365,8 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     std::vector<alz_encode_aux> haux(n);
     HIP_TRY(hipMemcpyAsync(haux.data(), d_aux, (size_t)n * sizeof(alz_encode_aux), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (uint32_t i = 0; i < n; i++) {
-        if (aux) aux[i] = haux[i];
-        if (results[i].status == ALZ_ST_OK && results[i].dst_len)
-            HIP_TRY(hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len, hipMemcpyDeviceToHost, c->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
+    if ((rc = download_outputs(c, n, streams, results, dst_base, true))) return rc;
     return ALZ_OK;
 }
 
