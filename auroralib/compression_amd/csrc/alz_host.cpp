@@ -26,6 +26,9 @@ struct alz_ctx {
     void* d_src = nullptr; size_t d_src_cap = 0;
     void* d_dst = nullptr; size_t d_dst_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // fork/join resources for per-format kernels of a mixed batch (they are independent: run them concurrently)
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct alz_plan {
@@ -71,6 +74,8 @@ int alz_create(int device, alz_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming); }
     if (e != hipSuccess) { delete c; return fail(ALZ_E_HIP, "context creation failed: %s", hipGetErrorString(e)); }
     *out = c;
     return ALZ_OK;
@@ -83,6 +88,8 @@ void alz_destroy(alz_ctx* c) {
     if (c->d_dst) (void)hipFree(c->d_dst);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (int i = 0; i < 4; i++) { if (c->join[i]) (void)hipEventDestroy(c->join[i]); if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -183,11 +190,29 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
 int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, void* hip_stream) {
     if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    int nfmt = 0;
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) nfmt += p->fmt_cnt[f] ? 1 : 0;
+    if (nfmt <= 1) {
+        for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+            if (!p->fmt_cnt[f]) continue;
+            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz);
+            if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
+        }
+        return ALZ_OK;
+    }
+    // mixed batch: one kernel per format, forked onto side streams so that they share the GPU (each format alone may
+    // have far fewer streams than the device has wave slots), joined back into the caller's stream
+    HIP_TRY(hipEventRecord(c->fork, s));
+    int k = 0; bool used[4] = {false, false, false, false};
     for (int f = 0; f < ALZ_FMT_COUNT; f++) {
         if (!p->fmt_cnt[f]) continue;
-        hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz);
+        hipStream_t a = c->aux[k & 3];
+        if (!used[k & 3]) { HIP_TRY(hipStreamWaitEvent(a, c->fork, 0)); used[k & 3] = true; }
+        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz);
         if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
+        k++;
     }
+    for (int i = 0; i < 4; i++) if (used[i]) { HIP_TRY(hipEventRecord(c->join[i], c->aux[i])); HIP_TRY(hipStreamWaitEvent(s, c->join[i], 0)); }
     return ALZ_OK;
 }
 

@@ -21,6 +21,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+def measured_traffic(fmt, n, kib):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 rule) for this
+    exact workload, or None when it has not been profiled (profiles/traffic.json)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return t.get("%s:%d:%d" % (fmt, n, kib))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -37,6 +47,7 @@ def main():
     from auroralib.compression_amd import _abi as A
     from auroralib.compression_amd import synth
     from auroralib.compression_amd.batch import Context, Plan
+    from auroralib.compression_amd.sharding import reduce_step_time, shard_seed, whole_job_value
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -50,11 +61,14 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    fmt = A.FORMAT_NAMES.index(args.format)
     target = args.stream_kib * 1024
     n = args.streams
+    if args.format == "mixed":   # BASELINE.json configs[3]: LZ10/LZ11/Yaz0/PRS interleaved, per-format kernel dispatch
+        fmt = np.array([[A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_PRS_BE][i % 4] for i in range(n)], dtype=np.uint32)
+    else:
+        fmt = A.FORMAT_NAMES.index(args.format)
     # seed = 0xA17A0000 + 1000*config + stream index; ranks get disjoint stream indices
-    batch = synth.make_batch(fmt, n, target, synth.seed_for(2, rank * n))
+    batch = synth.make_batch(fmt, n, target, shard_seed(2, rank, n))
     recs = synth.stream_records(batch.streams)
     comp_bytes = int(recs["src_len"].astype(np.int64).sum())
     decomp_bytes = int(n) * target
@@ -80,10 +94,7 @@ def main():
         plan.execute(d_src, d_dst)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = reduce_step_time(dt, dist, device="cuda" if dist is not None else None)
 
     # dominant kernel, HIP events on the launch stream (device time per launch)
     kernel_ms = plan.execute_timed(d_src, d_dst, iters=max(3, min(args.steps, 10)))
@@ -119,7 +130,7 @@ def main():
                          % (n, args.stream_kib, args.format, reps, cores)}
 
     if rank == 0:
-        value = decomp_bytes * world * args.steps / dt / 2**30
+        value = whole_job_value(decomp_bytes, world, args.steps, dt)
         algo_bytes = comp_bytes + decomp_bytes
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
@@ -132,7 +143,7 @@ def main():
                        "format": args.format, "streams_per_gpu": n, "stream_bytes": target, "compressed_bytes_per_gpu": comp_bytes,
                        "parallelism": "stream-sharded x%d, no collective" % world, "parity_ok": ok, "verified_vs_oracle": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.format, n, args.stream_kib),
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,
         }
