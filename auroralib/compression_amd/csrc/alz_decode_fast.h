@@ -28,7 +28,8 @@ __device__ __forceinline__ u32 wave_readlane(u32 v, u32 l) { return (u32)__built
 // v_writelane_b32: write a wave-uniform value into one lane of a VGPR (no clang builtin in ROCm 7.2).  gfx9 allows one
 // SGPR on the constant bus, so the lane select travels in M0 (what LLVM's own lowering of llvm.amdgcn.writelane does).
 __device__ __forceinline__ u32 wave_writelane(u32 old, u32 val, u32 lane) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
+    u32 tmp;   // the value goes through an SGPR (v_writelane takes no literal constants)
+    asm volatile("s_mov_b32 %1, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old), "=&s"(tmp) : "s"(val), "s"(lane) : "m0");
     return old;
 }
 __device__ __forceinline__ u32 mbcnt64(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
@@ -120,6 +121,45 @@ __device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds,
     qs += 64u; relm -= 64u;
 }
 
+// Two-pass form of the step for configurations with HBM read-back (see fast_emit): map_step finds the descriptor of
+// this lane's byte, copy_step moves the byte.
+__device__ __forceinline__ u32 map_step(u8* segmark, int lane, u32 desc, u32& relm, u32& tbase4) {
+    segmark[relm < 64u ? relm : 64u + (u32)lane] = 1;
+    wave_sync();
+    const u32 mk = segmark[lane];
+    segmark[lane] = 0;
+    const u64 M = __ballot(mk != 0);
+    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
+    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);
+    tbase4 += 4u * (u32)__popcll(M);
+    relm -= 64u;
+    return dsc;
+}
+
+template <class OW, class CFG>
+__device__ __forceinline__ void copy_step(OW& out, const u8* inlds, int lane, u32 dsc, u32 far, u32& qs, u32 nseg, bool early) {
+    const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
+    u8* const win = out.win;
+    u32 wv = win[(qs - dsc) & omask];
+    if (far) wv = far & 0xFFu;                               // read back from HBM by pass 1
+    if (early) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
+    u32 val;
+    if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
+    else val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
+    const bool instep = dsc <= (u32)lane && (u32)lane < nseg;
+    if (__ballot(instep)) {
+        u32 st = val | ((instep ? ((u32)lane - dsc) : 0x40u) << 8);
+        do {
+            const u32 f = wave_bperm(st >> 8, st);
+            if (st < 0x4000u) st = (f >= 0x4000u) ? f : ((st & 0xFFu) | (f & 0xFF00u));
+        } while (__ballot(st < 0x4000u));
+        val = st & 0xFFu;
+    }
+    if ((u32)lane < nseg) win[qs & omask] = (u8)val;
+    wave_sync();
+    qs += 64u;
+}
+
 // Shared back end.  Per-lane token: valid, len (>=1), desc, tend = input offset just past the token (relative to the
 // iteration's base).  For LZSS the descriptor holds the ring OFFSET and is turned into a distance here, once the
 // token's output position is known (LzWindows.OffsetCopy  IO/LzWindows.cs:108-115).
@@ -156,15 +196,47 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
             desc = ALZ_DESC_MATCH(d);
         }
     }
-    // ---- byte phase (byte_step below): 64 output bytes per step, one per lane
+    // ---- byte phase: 64 output bytes per step, one per lane
     u32 tbase4 = 0;                                          // 4 x (tokens that ended before the current step)
     u32 relm = keep ? end - 1u : 0xFFFFFF00u;                // my token's LAST byte relative to the current step (huge: none)
     u32 qs = O + (u32)lane + out.oshift;                     // slot coordinate of this lane's byte in the current step
     u32 X = 0;
-    // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
-    while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-    while (X + 64u <= T) { byte_step<OW, CFG, false, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-    if (X < T) { byte_step<OW, CFG, true, false>(out, segmark, inlds, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    if constexpr (CFG::FALLBACK) {
+        // Sources older than the LDS window come back from HBM (1-2 us each).  They are independent of everything this
+        // batch produces, so the step is split: pass 1 maps bytes to tokens for up to 16 steps and issues ALL their
+        // read-backs at once, pass 2 copies.  (For LDS-only configs this split costs more instructions than it saves.)
+        constexpr int NB = 16;
+        while (X < T) {
+            const u32 nb = T - X < 64u * NB ? T - X : 64u * NB;
+            const u32 nsteps = (nb + 63u) >> 6;
+            u32 dsc[NB], far[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                dsc[k] = 0x80000000u; far[k] = 0;
+                if ((u32)k < nsteps) {
+                    dsc[k] = map_step(segmark, lane, desc, relm, tbase4);
+                    const u32 q = qs + 64u * (u32)k - out.oshift;
+                    const u32 d = dsc[k];
+                    if ((int)d >= 0 && d > out.lw_mask + 1u - 64u && d <= q)
+                        far[k] = 0x100u | (u32)__hip_atomic_load(out.dst + (q - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                if ((u32)k < nsteps) {
+                    const u32 nseg = nb - 64u * (u32)k;
+                    copy_step<OW, CFG>(out, inlds, lane, dsc[k], far[k], qs, nseg < 64u ? nseg : 64u, O + X < W);
+                    X += nseg < 64u ? nseg : 64u; out.produced = O + X;
+                    if (out.produced - out.flushed >= out.fl) out.flush_blocks();
+                }
+            }
+        }
+    } else {
+        // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
+        while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+        while (X + 64u <= T) { byte_step<OW, CFG, false, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+        if (X < T) { byte_step<OW, CFG, true, false>(out, segmark, inlds, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+    }
     return fin;
 }
 
@@ -286,18 +358,27 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
 
 struct EmitRet { u32 produced, flushed, ovf, att_lo, att_hi; };
 
+// A queued token is ONE 32-bit word per lane: [31:18] length (1..16383), [17] literal flag, [16:0] match distance /
+// literal byte / low bits of the literal-run cache offset.
+#define ALZ_TOK_MATCH(len, dist) (((len) << 18) | (dist))
+#define ALZ_TOK_LIT(len, lo) (((len) << 18) | 0x20000u | (lo))
+#define ALZ_TOK_MAXLEN 16383u
+
 // out-of-line execution of one token queue (arguments travel in VGPRs under the device calling convention; the
 // wave-uniform ones are re-scalarised on entry)
 template <class OW, class CFG>
 __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u32 lw_mask, u32 fl, u32 oshift, u32 cap, u32 produced, u32 flushed,
-                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qlen, u32 qdesc) {
+                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qtok) {
     OW out;
     out.dst = reinterpret_cast<u8*>(((u64)uni((u32)((u64)dst >> 32)) << 32) | uni((u32)(u64)dst));
     out.win = win; out.lw_mask = uni(lw_mask); out.fl = uni(fl); out.oshift = uni(oshift); out.cap = uni(cap);
     out.produced = uni(produced); out.flushed = uni(flushed); out.lane = lane;
     DecState s; dec_state_init(s);
+    const u32 len = qtok >> 18, lo = qtok & 0x1FFFFu;
+    u32 desc = lo;
+    if (qtok & 0x20000u) desc = CFG::LITRUN ? (0x80000000u | lo) : ALZ_DESC_LIT(lo & 0xFFu);
     u32 last;
-    fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < uni(nt), qlen, qdesc, 0u, segmark, inlds, lane, last, uni(W));
+    fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < uni(nt), len, desc, 0u, segmark, inlds, lane, last, uni(W));
     EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = s.ovf ? 1u : 0u;
     r.att_lo = (u32)s.attempted_end; r.att_hi = (u32)(s.attempted_end >> 32);
     return r;
@@ -311,17 +392,17 @@ __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u
 template <class OW, class CFG>
 struct QueueSink {
     OW& out; DecState& s; u8* segmark; const u8* inlds; int lane; u32 W;
-    u32 qlen, qdesc;          // per-lane token registers
+    u32 qtok;                 // per-lane token register
     u32 nt, qbytes;           // tokens queued, bytes they will produce (wave-uniform)
     __device__ __forceinline__ QueueSink(OW& o, DecState& st, u8* sm, const u8* il, int ln, u32 w)
-        : out(o), s(st), segmark(sm), inlds(il), lane(ln), W(w), qlen(0), qdesc(0), nt(0), qbytes(0) {}
+        : out(o), s(st), segmark(sm), inlds(il), lane(ln), W(w), qtok(0), nt(0), qbytes(0) {}
     __device__ __forceinline__ u32 produced() const { return out.produced + qbytes; }
     __device__ __forceinline__ void flush() {
         if (nt == 0) return;
         // ONE out-of-line copy of the byte phase per kernel: the sink operations are inlined at every token site of the
         // parsers, and inlining the byte phase there as well made 100+ KB kernels that thrash the instruction cache
         const EmitRet r = queue_emit_call<OW, CFG>(out.dst, out.win, out.lw_mask, out.fl, out.oshift, out.cap, out.produced, out.flushed,
-                                                   lane, segmark, inlds, W, nt, qlen, qdesc);
+                                                   lane, segmark, inlds, W, nt, qtok);
         out.produced = uni(r.produced); out.flushed = uni(r.flushed);
         if (uni(r.ovf)) { s.ovf = true; s.attempted_end = ((u64)uni(r.att_hi) << 32) | uni(r.att_lo); }
         nt = 0; qbytes = 0;
@@ -329,21 +410,24 @@ struct QueueSink {
     __device__ __forceinline__ void ensure(InCache& in, u32 p, u32 need) {
         if (p + in.lo + need > in.cb + 2048u || p + in.lo < in.cb) { flush(); in.ensure(p, need); }   // queued literal runs point into the cache
     }
-    __device__ __forceinline__ bool push(u32 len, u32 desc) {
-        qlen = wave_writelane(qlen, uni(len), uni(nt));
-        qdesc = wave_writelane(qdesc, uni(desc), uni(nt));
+    // record one packed token (len <= ALZ_TOK_MAXLEN); the caller keeps nt < 64
+    __device__ __forceinline__ void push_word(u32 word, u32 len) {
+        qtok = wave_writelane(qtok, uni(word), uni(nt));
         nt++; qbytes += len;
+    }
+    __device__ __forceinline__ bool push(u32 word, u32 len) {
+        push_word(uni(word), uni(len));
         if (nt == 64u || qbytes >= 0x40000000u) flush();
         return !s.ovf;
     }
-    __device__ __forceinline__ bool lit(u32 b) { return push(1u, ALZ_DESC_LIT(b)); }
+    __device__ __forceinline__ bool lit(u32 b) { return push(ALZ_TOK_LIT(1u, b & 0xFFu), 1u); }
     __device__ __forceinline__ bool match(u32 dist, u64 len, u32 w) {
         if (len == 0) return true;
-        if (len >= 0x40000000ull || (u64)produced() + len > (u64)out.cap) {      // rare: exact E5 handling on the serial path
+        if (len > ALZ_TOK_MAXLEN || (u64)produced() + len > (u64)out.cap) {       // rare: long token / exact E5 handling on the serial path
             flush(); if (s.ovf) return false;
             u32 cl = clip_token(out, s, len); out.back_copy(dist, cl, w); return !s.ovf;
         }
-        return push((u32)len, ALZ_DESC_MATCH(dist ? dist : w));                 // E1
+        return push(ALZ_TOK_MATCH((u32)len, dist ? dist : w), (u32)len);         // E1
     }
     __device__ __forceinline__ bool run(InCache& in, u32 p, u64 len) {
         if (len == 0) return true;
@@ -354,6 +438,91 @@ struct QueueSink {
         ensure(in, p, (u32)len);
         // byte q of the run reads inlds[(slot(q) + d) & 2047]:  d = cache index of the run - slot coordinate of its first byte
         const u32 d = in.idx(p) - (produced() + out.oshift);
-        return push((u32)len, 0x80000000u | (d & 0x3FFFFFFFu));
+        return push(ALZ_TOK_LIT((u32)len, d & 2047u), (u32)len);
     }
 };
+
+// wave-uniform little-endian 8 bytes at input offset p (caller guarantees residency)
+__device__ __forceinline__ u64 peek8(const InCache& in, u32 p) {
+    const u32 i = in.idx(p);
+    const u32* w = reinterpret_cast<const u32*>(in.lds + (i & ~3u));
+    const u32 w0 = w[0], w1 = w[1], w2 = w[2];
+    const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, i & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, i & 3u);
+    return ((u64)uni(hi) << 32) | uni(lo);
+}
+
+// Lean parse loops for the bulk of a stream: no bounds checks (the caller guarantees >= 1100 input bytes ahead and a
+// resident cache), tokens decoded from an 8-byte scalar window.  Anything unusual (terminator, a token that does not fit
+// the packed queue word, a literal run reaching past the guaranteed region) stops the loop; the exact parser of
+// alz_decode_serial.h then handles that token.  Returns the number of tokens pushed.
+
+// LZ4.DecompressBlockHeaderless  Formats/Common/LZ4.cs:176-200
+template <class SK>
+__device__ __forceinline__ void lz4_fast_parse(InCache& in, SK& sk, DecState& s, u32 limit) {
+    u32 pp = s.p;
+    u32 oo = sk.produced() + sk.out.oshift;                  // slot coordinate of the next output byte
+    const u32 room = sk.out.cap - (sk.produced());           // stop before the capacity rule (E5) could apply
+    u32 made = 0;
+    while (sk.nt <= 62u && pp < limit) {
+        const u64 w = peek8(in, pp);
+        const u32 tok = (u32)w & 0xFFu;
+        u32 L = tok >> 4, M = tok & 15u;
+        u32 q = pp + 1u;
+        u32 dist;
+        if (L < 6u) dist = (u32)(w >> (8u * (1u + L))) & 0xFFFFu;           // literals and offset inside the window
+        else {
+            if (L == 15u) { u32 b; do { b = in.peek1(q); q++; L += b; } while (b == 255u && L < 1200u); }
+            if (L > 1000u || q + L + 3u > limit) break;
+            dist = in.peek4(q + L) & 0xFFFFu;
+        }
+        const u32 litpos = q;
+        q += L + 2u;
+        if (M == 15u) { u32 b; do { b = in.peek1(q); q++; M += b; } while (b == 255u && M < 16000u); }
+        M += 4u;
+        if (M > ALZ_TOK_MAXLEN || q > limit || made + L + M > room) break;
+        if (L) { sk.push_word(ALZ_TOK_LIT(L, (in.idx(litpos) - oo) & 2047u), L); oo += L; }
+        sk.push_word(ALZ_TOK_MATCH(M, dist ? dist : 65536u), M); oo += M;
+        made += L + M;
+        pp = q;
+    }
+    s.p = pp;
+}
+
+// PRS.DecompressHeaderless  Sega/PRS.cs:59-102
+template <class SK, bool BIG>
+__device__ __forceinline__ void prs_fast_parse(InCache& in, SK& sk, DecState& s, u32 limit) {
+    u32 pp = s.p, bits = s.bits, flag = s.flag;
+    const u32 room = sk.out.cap - sk.produced();
+    u32 made = 0;
+    while (sk.nt <= 63u && pp < limit) {
+        const u64 w = peek8(in, pp);
+        u32 k = 0;                                           // bytes of the window consumed by this token
+        u32 fl2 = flag, nb = bits;
+#define PRS_BIT(dst) do { if (nb == 0) { fl2 = (u32)(w >> (8u * k)) & 0xFFu; k++; nb = 8; } \
+                          dst = BIG ? (fl2 >> (nb - 1u)) & 1u : (fl2 >> (8u - nb)) & 1u; nb--; } while (0)   /* same (bits, flag) convention as dec_prs_serial */
+        u32 b; PRS_BIT(b);
+        u32 word, len;
+        if (b) { word = ALZ_TOK_LIT(1u, (u32)(w >> (8u * k)) & 0xFFu); k++; len = 1; }
+        else {
+            u32 b2; PRS_BIT(b2);
+            u32 dist;
+            if (b2) {
+                const u32 x0 = (u32)(w >> (8u * k)) & 0xFFu, x1 = (u32)(w >> (8u * k + 8u)) & 0xFFu; k += 2;
+                const u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);
+                if (v == 0) break;                                   // terminator: leave it to the exact parser
+                len = v & 7u; dist = 0x2000u - (v >> 3);
+                if (len == 0) { len = ((u32)(w >> (8u * k)) & 0xFFu) + 1u; k++; } else len += 2u;
+            } else {
+                u32 h, l; PRS_BIT(h); PRS_BIT(l);
+                len = ((h << 1) | l) + 2u;
+                dist = 0x100u - ((u32)(w >> (8u * k)) & 0xFFu); k++;
+            }
+            word = ALZ_TOK_MATCH(len, dist);
+        }
+#undef PRS_BIT
+        if (made + len > room) break;
+        sk.push_word(word, len);
+        made += len; pp += k; bits = nb; flag = fl2;
+    }
+    s.p = pp; s.bits = bits; s.flag = flag;
+}

@@ -166,13 +166,14 @@ __device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, SK&
 
 // PRS.DecompressHeaderless(Stream, Stream, Endian)  Sega/PRS.cs:59-102
 template <class SK, bool BIG>
-__device__ void dec_prs_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
+__device__ void dec_prs_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 max_tokens = 0xFFFFFFFFu) {
 #define PRS_READBIT(dst)                                                                       \
     do {                                                                                       \
         if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; } \
         dst = BIG ? (s.flag >> (s.bits - 1)) & 1u : (s.flag >> (8 - s.bits)) & 1u; s.bits--;   \
     } while (0)
     while (s.p < src_len) {
+        if (max_tokens-- == 0) return;
         sk.ensure(in, s.p, 16);
         u32 bit; PRS_READBIT(bit);
         if (bit) {
@@ -205,8 +206,9 @@ __device__ void dec_prs_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
 
 // LZ4.DecompressBlockHeaderless  Formats/Common/LZ4.cs:176-200
 template <class SK>
-__device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
+__device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 max_tokens = 0xFFFFFFFFu) {
     while (s.p < src_len) {
+        if (max_tokens-- == 0) return;
         sk.ensure(in, s.p, 8);
         u32 token = in.peek1(s.p); s.p++;
         u64 plain = token >> 4;
