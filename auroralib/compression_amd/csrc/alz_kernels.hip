@@ -11,6 +11,9 @@
 #include "alz_internal.h"
 
 #define ALZ_INCACHE_BYTES (2048 + 32)
+#ifndef ALZ_QUEUE_LW
+#define ALZ_QUEUE_LW 4096
+#endif
 
 template <bool FB>
 __device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status) {
@@ -147,7 +150,10 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
                                                               const u32* __restrict__ index_list, u32 count,
                                                               alz_result* __restrict__ results) {
     constexpr bool PRS = (FMT == ALZ_FMT_PRS_BE || FMT == ALZ_FMT_PRS_LE);
-    constexpr u32 LW = 8192;                       // PRS: the whole window; 64 KiB formats: the recent 8 KiB, older sources from HBM
+    // These kernels are bound by the latency of one wave's scalar parse, so waves per CU matter more than LDS hits:
+    // only the most recent 4 KiB of the window stay in LDS (6.3 KB per wave -> 25 waves per CU instead of 15), older
+    // sources are read back from the stream's own output in HBM, batched per token queue.
+    constexpr u32 LW = PRS ? 8192u : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
     __shared__ __attribute__((aligned(16))) u8 lds[128 + ALZ_INCACHE_BYTES + LW];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
