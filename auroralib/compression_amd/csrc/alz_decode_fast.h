@@ -254,7 +254,7 @@ __device__ __forceinline__ u32 mask_window(u64 lo, u64 hi, int i) {
 
 // Interleaved formats.  Precondition: s.bits == 0 (group boundary), s.p + 128 <= src_len, out.produced < size.
 template <int FMT, class OW>
-__device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecState& s, u32 size, u8* segmark, int lane, const FastGeom& gm) {
+__device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecState& s, u32 size, u32 src_len, bool& to_serial, u8* segmark, int lane, const FastGeom& gm) {
     typedef FamTraits<FMT> TR;
     const u32 p = s.p;
     in.ensure(p, 128);
@@ -262,19 +262,26 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     u32 l3 = 0, l4 = 0;
     if (TR::H3) { u64 lo = __ballot((x0 >> 4) == 0), hi = __ballot((x1 >> 4) == 0); l3 = mask_window(lo, hi, lane); }
     if (TR::H4) { u64 lo = __ballot((x0 >> 4) == 1), hi = __ballot((x1 >> 4) == 1); l4 = mask_window(lo, hi, lane); }
-    // speculative walk of "the group that starts at byte p + lane"
+    // speculative walk of "the group that starts at byte p + lane": group size + what a token lane needs to find its
+    // offset.  Formats whose token size depends only on the flag bit (LZSS, LZ10) need no walk at all: the offset of token
+    // k is 1 + k + popcount(match bits before k).  Otherwise `info` packs (token size - 1) as 8 nibbles and a token lane
+    // sums the nibbles below its own with one v_dot8_u32_u4.
     const u32 mbits = TR::LIT1 ? (~x0 & 0xFFu) : x0;          // bit set = match token
-    u32 r = 1, rp0 = 0, rp1 = 0;
+    u32 gsize, info;
+    if (!TR::H3 && !TR::H4) { gsize = 9u + (u32)__popc(mbits); info = mbits; }
+    else {
+        u32 r = 1; info = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const u32 m = (mbits >> (TR::MSB ? 7 - k : k)) & 1u;
-        u32 extra = m;
-        if (TR::H3) extra += m & (l3 >> r);
-        if (TR::H4) extra += (m & (l4 >> r)) << 1;
-        if (k < 4) rp0 |= (r << (6 * k)) | (m << (24 + k)); else rp1 |= (r << (6 * (k - 4))) | (m << (24 + k - 4));
-        r += 1u + extra;
+        for (int k = 0; k < 8; k++) {
+            const u32 m = (mbits >> (TR::MSB ? 7 - k : k)) & 1u;
+            u32 extra = m;
+            if (TR::H3) extra += m & (l3 >> r);
+            if (TR::H4) extra += (m & (l4 >> r)) << 1;
+            info |= extra << (4 * k);
+            r += 1u + extra;
+        }
+        gsize = r;
     }
-    const u32 gsize = r;
     // real group chain
     u32 g = 0, ng = 0, gstart = 0;
 #pragma unroll
@@ -287,12 +294,17 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     }
     // lane 8j+k = token k of group j
     const u32 k = (u32)lane & 7u;
-    const bool valid = ((u32)lane >> 3) < ng;
-    const u32 w0 = wave_bperm(gstart, rp0), w1 = wave_bperm(gstart, rp1);
-    const u32 w = k < 4 ? w0 : w1;
-    const u32 kk = k & 3u;
-    const u32 to = gstart + ((w >> (6 * kk)) & 63u);
-    const u32 m = (w >> (24 + kk)) & 1u;
+    const bool ingroup = ((u32)lane >> 3) < ng;
+    const u32 inf = wave_bperm(gstart, info);
+    u32 m, to;
+    if (!TR::H3 && !TR::H4) {
+        m = (inf >> (TR::MSB ? 7u - k : k)) & 1u;
+        const u32 before = TR::MSB ? (u32)__popc(inf >> (8u - k)) : (u32)__popc(inf & ((1u << k) - 1u));
+        to = gstart + 1u + k + before;
+    } else {
+        m = ((inf >> (4u * k)) & 0xFu) != 0u;
+        to = gstart + 1u + k + (u32)__builtin_amdgcn_udot8(inf & ((1u << (4u * k)) - 1u), 0x11111111u, 0u, false);
+    }
     const u32 ti = in.idx(p + to);
     const u32 b1 = in.lds[ti], b2 = in.lds[ti + 1];
     u32 len = 1, desc = ALZ_DESC_LIT(b1), tend = to + 1;
@@ -317,10 +329,24 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
             if (nib == 0) { len = b3 + 0x12u; tend = to + 3; } else { len = nib + 2u; tend = to + 2; }
         }
     }
+    // Near the end of the input the window holds bytes past src_len: only tokens that lie completely inside the input are
+    // real (token offsets grow with the lane, so they form a prefix).  The first token that does not is left to the exact
+    // parser together with the flag-reader state it needs (E6, and Yay0.cs:130-131's length-byte-at-EOF rule).
+    const u32 inlim = src_len - p;
+    const bool valid = ingroup && tend <= inlim;
+    const bool cut = __ballot(ingroup && tend > inlim) != 0;
+    if (cut && __ballot(valid) == 0) { to_serial = true; return false; }
     u32 last_tend;
     const bool fin = fast_emit<OW, EmitCfg<(FMT == ALZ_FMT_LZSS ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
-    s.p = p + (fin ? last_tend : g);
-    return fin;
+    if (fin) { s.p = p + last_tend; return true; }
+    if (!cut) { s.p = p + g; return false; }
+    // stopped inside a group: hand (position, remaining flag bits, flag byte) to the serial parser
+    const u32 lk = (u32)__popcll(__ballot(valid)) - 1u;
+    s.p = p + wave_readlane(tend, lk);
+    s.bits = 7u - (lk & 7u);
+    s.flag = in.peek1(p + wave_readlane(gstart, lk));
+    to_serial = true;
+    return false;
 }
 
 // Three-cursor formats (Yay0 / MIO0).  Precondition: s.bits == 0, fp + 8 <= src_len, cp + 128 <= src_len, up + 64 <= src_len.

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
     if constexpr (!THREE) {
         FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
         gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
-        while (!fin && out.produced < size && s.p + 128u <= src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, segmark, lane, gm);
+        bool to_serial = false;   // the fast loop runs to the last complete token of the input; the exact parser finishes
+        while (!fin && !to_serial && out.produced < size && s.p < src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, src_len, to_serial, segmark, lane, gm);
         if (!fin) {
             typedef DirectSink<OutWin<false>> SK;
             SK sk(out, s);
