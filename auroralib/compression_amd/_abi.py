@@ -16,6 +16,9 @@ E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_FORMAT, E_STREAM = -1, 
 
 # alz_container
 C_LZSS, C_LZ10, C_LZ11, C_YAZ0, C_YAY0, C_MIO0, C_PRS, C_LZ4_LEGACY, C_LZO, C_SNAPPY = range(10)
+C_GCLZ, C_CXLZ, C_LZ_3DS, C_COMP, C_YAZ1, C_AKLZ, C_LZ01, C_LZSEGA, C_LEVEL5LZSS, C_LZON, C_LZ77, C_LEVEL5 = range(10, 22)
+LZ77_LZ10, LZ77_LZ11, LZ77_CHUNKLZ10 = 0x10, 0x11, 0xF7
+LEVEL5_ONLYSAVE, LEVEL5_LZ10 = 0, 1
 
 
 class LzProperties(C.Structure):
@@ -49,7 +52,7 @@ class EncodeAux(C.Structure):
 
 
 class ContainerOptions(C.Structure):
-    _fields_ = [("big_endian", C.c_uint32), ("memory_alignment", C.c_uint32), ("lz", LzProperties)]
+    _fields_ = [("big_endian", C.c_uint32), ("memory_alignment", C.c_uint32), ("lz", LzProperties), ("variant", C.c_uint32), ("chunk_size", C.c_uint32)]
 
 
 assert C.sizeof(Stream) == 40 and C.sizeof(Result) == 16 and C.sizeof(LzProperties) == 16

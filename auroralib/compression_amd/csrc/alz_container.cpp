@@ -97,6 +97,9 @@ int prs_byte_order(const uint8_t* src, size_t len) {
     return 0;
 }
 
+const uint8_t kAklzMagic[12] = { 'A', 'K', 'L', 'Z', '~', '?', 'Q', 'd', '=', 0xCC, 0xCC, 0xCD };   // "AKLZ~?Qd=\xCC\xCC\xCD"  AKLZ.cs:16
+const uint8_t kLzonMagic[8] = { 'L', 'Z', 'O', 'n', 0x00, 0x2F, 0xF1, 0x71 };                           // LZOn.cs:17
+
 uint32_t clamp32(size_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; }
 
 int run_body(alz_ctx* ctx, uint32_t fmt, const alz_lz_properties* lz, const uint8_t* body, size_t body_len, uint32_t size,
@@ -119,6 +122,23 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // Yaz0.cs:50-55
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return ALZ_OK;        // Yay0.cs:41-47 (always Endian.Big)
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // MIO0.cs:41-48
+    case ALZ_C_GCLZ: if (len < 4 || memcmp(src, "GCLZ", 4)) return ALZ_E_FORMAT; return alz_container_decompressed_size(ALZ_C_LZ10, opt, src + 4, len - 4, size_out);   // GCLZ.cs:32-37
+    case ALZ_C_CXLZ: if (len < 4 || memcmp(src, "CXLZ", 4)) return ALZ_E_FORMAT; return alz_container_decompressed_size(ALZ_C_LZ10, opt, src + 4, len - 4, size_out);
+    case ALZ_C_LZ_3DS: if (len < 8 || memcmp(src, "3DS-LZ\r\n", 8)) return ALZ_E_FORMAT; return alz_container_decompressed_size(ALZ_C_LZ10, opt, src + 8, len - 8, size_out);
+    case ALZ_C_COMP: if (len < 4 || memcmp(src, "COMP", 4)) return ALZ_E_FORMAT; return alz_container_decompressed_size(ALZ_C_LZ11, opt, src + 4, len - 4, size_out);
+    case ALZ_C_YAZ1: if (len < 8 || memcmp(src, "Yaz1", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;
+    case ALZ_C_AKLZ: if (len < 16 || memcmp(src, kAklzMagic, 12)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return ALZ_OK;          // AKLZ.cs:33-38
+    case ALZ_C_LZ01: if (len < 12 || memcmp(src, "LZ01", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 8); return ALZ_OK;                // LZ01.cs:37-43
+    case ALZ_C_LZSEGA: if (len < 8) return ALZ_E_FORMAT; *size_out = le32(src + 4); return ALZ_OK;                                        // LZSega.cs:41-46
+    case ALZ_C_LEVEL5LZSS: if (len < 16 || memcmp(src, "SSZL", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 12); return ALZ_OK;        // Level5LZSS.cs:33-39
+    case ALZ_C_LZON: if (len < 12 || memcmp(src, kLzonMagic, 8)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return ALZ_OK;            // LZOn.cs:33-38
+    case ALZ_C_LZ77: {                                                                                                                     // LZ77.cs:45-54
+        if (len < 8 || memcmp(src, "LZ77", 4)) return ALZ_E_FORMAT;
+        uint32_t s = (uint32_t)src[5] | ((uint32_t)src[6] << 8) | ((uint32_t)src[7] << 16);
+        if (s == 0) { if (len < 12) return ALZ_E_FORMAT; s = le32(src + 8); }
+        *size_out = s; return ALZ_OK;
+    }
+    case ALZ_C_LEVEL5: if (len < 5) return ALZ_E_FORMAT; *size_out = src[4] == 0x78 ? le32(src) : le32(src) >> 3; return ALZ_OK;          // Level5.cs:55-60
     default: return ALZ_E_UNSUPPORTED;   // PRS / LZO / LZ4 / Snappy do not implement IProvidesDecompressedSize
     }
 }
@@ -137,6 +157,17 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_LZO: { if (len == 0) return 0; int f = src[0]; return (f > 11 && f < 0x20) || f < 0x10; }   // LZO.cs:33-39 (no extension given)
     case ALZ_C_LZ4_LEGACY: return len > 0x10 && le32(src) == 0x184C2102u;                   // LZ4Legacy.cs:28-29
     case ALZ_C_SNAPPY: { static const uint8_t id[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 }; return len > 0x10 && !memcmp(src, id, 10); }  // Snappy.cs:36-37
+    case ALZ_C_GCLZ: return len > 0x8 && !memcmp(src, "GCLZ", 4) && alz_container_is_match(ALZ_C_LZ10, src + 4, len - 4);
+    case ALZ_C_CXLZ: return len > 0x8 && !memcmp(src, "CXLZ", 4) && alz_container_is_match(ALZ_C_LZ10, src + 4, len - 4);
+    case ALZ_C_LZ_3DS: return len > 0x10 && !memcmp(src, "3DS-LZ\r\n", 8);
+    case ALZ_C_COMP: return len > 0x8 && !memcmp(src, "COMP", 4) && alz_container_is_match(ALZ_C_LZ11, src + 4, len - 4);
+    case ALZ_C_YAZ1: return len > 0x10 && !memcmp(src, "Yaz1", 4);
+    case ALZ_C_AKLZ: return len > 0x10 && !memcmp(src, kAklzMagic, 12);
+    case ALZ_C_LZ01: return len > 0x10 && !memcmp(src, "LZ01", 4);
+    case ALZ_C_LZSEGA: { if (len < 0x12) return 0; const uint32_t cs = le32(src), ds = le32(src + 4); return (cs == len - 8 || cs == len) && ds != 0 && (src[8] & 1) == 1; }   // LZSega.cs:27-38
+    case ALZ_C_LEVEL5LZSS: return len > 0x10 && !memcmp(src, "SSZL", 4) && le32(src + 4) == 0;
+    case ALZ_C_LZON: return len > 0x10 && !memcmp(src, kLzonMagic, 8);
+    case ALZ_C_LZ77: return len > 0x8 && !memcmp(src, "LZ77", 4) && (src[4] == 0x10 || src[4] == 0x11 || src[4] == 0x24 || src[4] == 0x28 || src[4] == 0x30 || src[4] == 0xF7);
     default: return 0;
     }
 }
@@ -187,6 +218,103 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
     case ALZ_C_LZO:                                                                         // LZO.cs:42-43
         rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src, len, 0, 0, 0, dst, dst_cap, &r);
         break;
+    case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                 // magic + inner file  GCLZ.cs:47-51
+        const char* magic = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
+        const size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4;
+        if (len < ml || memcmp(src, magic, ml)) return ALZ_E_FORMAT;
+        size_t used = 0;
+        rc = alz_container_decompress(ctx, container == ALZ_C_COMP ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, src + ml, len - ml, dst, dst_cap, dst_len, &used, status);
+        if (src_used) *src_used = ml + used;
+        return rc;
+    }
+    case ALZ_C_YAZ1:                                                                        // Yaz1.cs: Yaz0 with another magic
+        if (len < 16 || memcmp(src, "Yaz1", 4)) return ALZ_E_FORMAT;
+        size = rd32(src + 4, big); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_YAZ0, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        if (rc == ALZ_OK && r.status != ALZ_ST_OK) rc = run_body(ctx, ALZ_FMT_YAZ0, nullptr, src + hdr, len - hdr, bswap32(size), 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_AKLZ:                                                                        // AKLZ.cs:41-46
+        if (len < 16 || memcmp(src, kAklzMagic, 12)) return ALZ_E_FORMAT;
+        size = be32(src + 12); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZ01:                                                                        // LZ01.cs:47-62
+        if (len < 16 || memcmp(src, "LZ01", 4)) return ALZ_E_FORMAT;
+        size = le32(src + 8); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZSEGA:                                                                      // LZSega.cs:49-54
+        if (len < 8) return ALZ_E_FORMAT;
+        size = le32(src + 4); hdr = 8;
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LEVEL5LZSS:                                                                  // Level5LZSS.cs:42-59
+        if (len < 16 || memcmp(src, "SSZL", 4)) return ALZ_E_FORMAT;
+        size = le32(src + 12); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZON:                                                                        // LZOn.cs:41-60
+        if (len < 16 || memcmp(src, kLzonMagic, 8)) return ALZ_E_FORMAT;
+        size = be32(src + 8); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src + hdr, len - hdr, 0, 0, 0, dst, dst_cap, &r);
+        if (rc == ALZ_OK && r.status == ALZ_ST_OK && r.dst_len != size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // DecompressedSizeException.ThrowIfMismatch
+        break;
+    case ALZ_C_LEVEL5: {                                                                    // Level5.cs:62-110
+        if (len < 4) return ALZ_E_FORMAT;
+        const uint32_t ts = le32(src); hdr = 4;
+        if (len > 4 && src[4] == 0x78) return ALZ_E_UNSUPPORTED;                            // zlib payload: BCL code, out of scope
+        size = ts >> 3;
+        if ((ts & 7) == ALZ_LEVEL5_ONLYSAVE) {
+            if (len - hdr < size) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+            if (dst_cap < size) { r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+            memcpy(dst, src + hdr, size); r.dst_len = size; r.src_used = size; r.status = ALZ_ST_OK;
+        } else if ((ts & 7) == ALZ_LEVEL5_LZ10) rc = run_body(ctx, ALZ_FMT_LZ10, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        else return ALZ_E_UNSUPPORTED;                                                      // RLE / Huffman: not LZ
+        break;
+    }
+    case ALZ_C_LZ77: {                                                                      // LZ77.cs:105-153
+        if (len < 8 || memcmp(src, "LZ77", 4)) return ALZ_E_FORMAT;
+        const uint32_t type = src[4];
+        size = (uint32_t)src[5] | ((uint32_t)src[6] << 8) | ((uint32_t)src[7] << 16); hdr = 8;
+        if (size == 0) { if (len < 12) return ALZ_E_FORMAT; size = le32(src + 8); hdr = 12; }
+        if (type == ALZ_LZ77_LZ10 || type == ALZ_LZ77_LZ11) {
+            rc = run_body(ctx, type == ALZ_LZ77_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+            break;
+        }
+        if (type != ALZ_LZ77_CHUNKLZ10) return ALZ_E_UNSUPPORTED;                            // RLE30 / HUF20: not LZ
+        // ChunkLZ10: u16 end offsets until (last + position == length), then one LZ10 FILE per chunk.  The chunks are
+        // independent streams: they go to the GPU as ONE batch.
+        std::vector<uint32_t> ends; size_t pos = hdr;
+        for (;;) {
+            if (pos + 2 > len) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+            ends.push_back((uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8)); pos += 2;
+            if (ends.back() + pos == len) break;
+        }
+        if (r.status == ALZ_ST_INPUT_TRUNCATED) break;
+        const size_t header_end = pos;
+        std::vector<alz_stream> st(ends.size()); std::vector<alz_result> rs(ends.size());
+        uint64_t out_off = 0; bool bad = false;
+        for (size_t i = 0; i < ends.size() && !bad; i++) {
+            const size_t a = header_end + (i ? ends[i - 1] : 0);
+            uint32_t csz = 0; const int h = a < len ? nin_header(src + a, len - a, 0x10, &csz) : -1;
+            if (h < 0) { bad = true; break; }
+            memset(&st[i], 0, sizeof(alz_stream));
+            st[i].src_off = a + (size_t)h; st[i].src_len = clamp32(len - a - (size_t)h); st[i].dst_off = out_off;
+            st[i].dst_cap = clamp32(out_off < dst_cap ? dst_cap - out_off : 0); st[i].decom_len = csz; st[i].format = ALZ_FMT_LZ10;
+            out_off += csz;
+        }
+        if (bad) return ALZ_E_FORMAT;
+        rc = alz_decode_batch(ctx, nullptr, (uint32_t)st.size(), src, len, st.data(), dst, dst_cap, rs.data());
+        if (rc != ALZ_OK) return rc;
+        r.status = ALZ_ST_OK; r.dst_len = 0;
+        for (size_t i = 0; i < rs.size(); i++) {
+            if (rs[i].status != ALZ_ST_OK) { r.status = rs[i].status; r.dst_len = (uint32_t)(st[i].dst_off + rs[i].dst_len); break; }
+            r.dst_len = (uint32_t)(st[i].dst_off + rs[i].dst_len);
+        }
+        if (r.status == ALZ_ST_OK && r.dst_len > size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // LZ77.cs:146-149
+        r.src_used = (uint32_t)(header_end + ends.back() - hdr);
+        break;
+    }
     default: return ALZ_E_UNSUPPORTED;
     }
     if (rc != ALZ_OK) return rc;
@@ -208,8 +336,82 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     const bool big = opt ? opt->big_endian != 0 : true;
     const alz_lz_properties* lz = opt ? &opt->lz : nullptr;
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
+    // ---- wrappers that prepend a magic to another container / have their own small header
+    switch (container) {
+    case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                 // GCLZ.cs:40-44
+        const char* magic = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
+        const size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4;
+        if (cap < ml) return ALZ_E_NOMEM;
+        memcpy(dst, magic, ml);
+        size_t inner = 0;
+        int rc2 = alz_container_compress(ctx, container == ALZ_C_COMP ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, settings, src, n, dst + ml, cap - ml, &inner);
+        if (dst_len) *dst_len = ml + inner;
+        return rc2;
+    }
+    case ALZ_C_LZ77: {                                                                      // LZ77.cs:56-102
+        const uint32_t type = opt && opt->variant ? opt->variant : ALZ_LZ77_LZ10;
+        const size_t chunk = opt && opt->chunk_size ? opt->chunk_size : 0x1000;
+        if (cap < 8) return ALZ_E_NOMEM;
+        memcpy(dst, "LZ77", 4);
+        if (type == ALZ_LZ77_LZ10 || type == ALZ_LZ77_LZ11 || (type == ALZ_LZ77_CHUNKLZ10 && chunk >= n)) {
+            size_t inner = 0;
+            int rc2 = alz_container_compress(ctx, type == ALZ_LZ77_LZ11 ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, settings, src, n, dst + 4, cap - 4, &inner);
+            if (dst_len) *dst_len = 4 + inner;
+            return rc2;
+        }
+        if (type != ALZ_LZ77_CHUNKLZ10) return ALZ_E_UNSUPPORTED;
+        if (n > 0xFFFFFF) return ALZ_E_INVALID;
+        // ChunkLZ10: every chunk is an independent LZ10 file -> ONE encode batch on the GPU
+        const size_t segs = (n + chunk - 1) / chunk;
+        const size_t header_end = 8 + 2 * segs;
+        if (cap < header_end) return ALZ_E_NOMEM;
+        wr32(dst + 4, (uint32_t)type | ((uint32_t)n << 8), false);
+        std::vector<alz_stream> stv(segs); std::vector<alz_result> rs(segs);
+        const size_t slot = chunk + chunk / 4 + 64;
+        std::vector<uint8_t> tmp(segs * slot);
+        alz_settings st2; if (settings) st2 = *settings; else { st2.quality = 8; st2.max_window_bits = 0; st2.strategy = 0; }
+        st2.min_distance = 2;                                                                // new LZ10(): GbaVramCompatibilityMode = true
+        for (size_t i = 0; i < segs; i++) {
+            memset(&stv[i], 0, sizeof(alz_stream));
+            stv[i].src_off = i * chunk; stv[i].src_len = (uint32_t)((n - i * chunk) < chunk ? (n - i * chunk) : chunk);
+            stv[i].dst_off = i * slot; stv[i].dst_cap = (uint32_t)slot; stv[i].format = ALZ_FMT_LZ10;
+        }
+        int rc2 = alz_encode_batch(ctx, nullptr, &st2, (uint32_t)segs, src, n, stv.data(), tmp.data(), tmp.size(), rs.data(), nullptr);
+        if (rc2 != ALZ_OK) return rc2;
+        size_t pos = header_end;
+        for (size_t i = 0; i < segs; i++) {
+            if (rs[i].status != ALZ_ST_OK) return ALZ_E_INVALID;
+            if (pos + 4 + rs[i].dst_len > cap) return ALZ_E_NOMEM;
+            wr32(dst + pos, 0x10u | (stv[i].src_len << 8), false);                           // LZ10 header of the chunk (LZ10.cs:69-71)
+            memcpy(dst + pos + 4, tmp.data() + i * slot, rs[i].dst_len);
+            pos += 4 + rs[i].dst_len;
+            const size_t endoff = pos - header_end;
+            if (endoff > 0xFFFF) return ALZ_E_INVALID;                                        // "chunks too large to process"  LZ77.cs:92-95
+            dst[8 + 2 * i] = (uint8_t)endoff; dst[8 + 2 * i + 1] = (uint8_t)(endoff >> 8);
+        }
+        if (dst_len) *dst_len = pos;
+        return ALZ_OK;
+    }
+    case ALZ_C_LEVEL5: {                                                                    // Level5.cs:112-146
+        uint32_t type = opt && opt->variant ? opt->variant : ALZ_LEVEL5_LZ10;
+        if (st.quality == 0) type = ALZ_LEVEL5_ONLYSAVE;
+        if (cap < 4) return ALZ_E_NOMEM;
+        wr32(dst, type | ((uint32_t)n << 3), false);
+        if (type == ALZ_LEVEL5_ONLYSAVE) { if (cap < 4 + n) return ALZ_E_NOMEM; memcpy(dst + 4, src, n); if (dst_len) *dst_len = 4 + n; return ALZ_OK; }
+        if (type != ALZ_LEVEL5_LZ10) return ALZ_E_UNSUPPORTED;
+        break;
+    }
+    default: break;
+    }
     size_t hdr = 0; uint32_t fmt;
     switch (container) {
+    case ALZ_C_YAZ1: fmt = ALZ_FMT_YAZ0; hdr = 16; break;
+    case ALZ_C_AKLZ: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
+    case ALZ_C_LZ01: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
+    case ALZ_C_LZSEGA: fmt = ALZ_FMT_LZSS; hdr = 8; lz = nullptr; break;
+    case ALZ_C_LEVEL5LZSS: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
+    case ALZ_C_LZON: fmt = ALZ_FMT_LZO; hdr = 16; break;
+    case ALZ_C_LEVEL5: fmt = ALZ_FMT_LZ10; hdr = 4; if (st.min_distance == 0) st.min_distance = 2; break;   // LZ10.CompressHeaderless default gbaVramCompatibilityMode = true
     case ALZ_C_LZSS: fmt = ALZ_FMT_LZSS; hdr = 16; break;
     case ALZ_C_LZ10: fmt = ALZ_FMT_LZ10; hdr = n <= 0xFFFFFF ? 4 : 8; if (st.min_distance == 0) st.min_distance = 2; break;   // GbaVramCompatibilityMode = true  LZ10.cs:33
     case ALZ_C_LZ11: fmt = ALZ_FMT_LZ11; hdr = n <= 0xFFFFFF ? 4 : 8; break;
@@ -235,6 +437,13 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
         if (n <= 0xFFFFFF) wr32(dst, id | ((uint32_t)n << 8), false); else { wr32(dst, id, false); wr32(dst + 4, (uint32_t)n, false); }
         break;
     }
+    case ALZ_C_YAZ1: memcpy(dst, "Yaz1", 4); wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, opt ? opt->memory_alignment : 0, big); wr32(dst + 12, 0, false); break;
+    case ALZ_C_AKLZ: memcpy(dst, kAklzMagic, 12); wr32(dst + 12, (uint32_t)n, true); break;                                                        // AKLZ.cs:50-55
+    case ALZ_C_LZ01: memcpy(dst, "LZ01", 4); wr32(dst + 4, (uint32_t)(hdr + r.dst_len), false); wr32(dst + 8, (uint32_t)n, false); wr32(dst + 12, 0, false); break;   // LZ01.cs:65-82
+    case ALZ_C_LZSEGA: wr32(dst, r.dst_len, false); wr32(dst + 4, (uint32_t)n, false); break;                                                      // LZSega.cs:57-67
+    case ALZ_C_LEVEL5LZSS: memcpy(dst, "SSZL", 4); wr32(dst + 4, 0, false); wr32(dst + 8, r.dst_len, false); wr32(dst + 12, (uint32_t)n, false); break;   // Level5LZSS.cs:62-72
+    case ALZ_C_LZON: memcpy(dst, kLzonMagic, 8); wr32(dst + 8, (uint32_t)n, true); wr32(dst + 12, r.dst_len, true); break;                          // LZOn.cs:63-79
+    case ALZ_C_LEVEL5: break;                                                                                                                       // header written above
     case ALZ_C_YAZ0: memcpy(dst, "Yaz0", 4); wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, opt ? opt->memory_alignment : 0, big); wr32(dst + 12, 0, false); break;   // Yaz0.cs:82-89
     case ALZ_C_YAY0: case ALZ_C_MIO0:                                                                                                          // Yay0.cs:62-77
         memcpy(dst, container == ALZ_C_YAY0 ? "Yay0" : "MIO0", 4); wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, 0x10 + aux.aux0, big); wr32(dst + 12, 0x10 + aux.aux1, big); break;

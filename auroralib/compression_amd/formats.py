@@ -56,11 +56,14 @@ class _Format:
         self.FormatByteOrder = "Big"      # IEndianDependentFormat.FormatByteOrder default (Yaz0.cs:30, PRS.cs:24)
         self.MemoryAlignment = 0          # Yaz0.MemoryAlignment
         self.lz = None
+        self.Type = 0                     # LZ77.Type / Level5.Type (0 = class default)
+        self.ChunkSize = 0                # LZ77.ChunkSize (0 = 0x1000)
 
     def _opt(self):
         o = A.ContainerOptions()
         o.big_endian = 1 if self.FormatByteOrder == "Big" else 0
         o.memory_alignment = self.MemoryAlignment
+        o.variant, o.chunk_size = self.Type, self.ChunkSize
         if self.lz is not None:
             o.lz = self.lz
         return o
@@ -158,5 +161,57 @@ class LZO(_Format):
     container, provides_size = A.C_LZO, False
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO]
+# header-only wrappers over the same GPU bodies
+class GCLZ(_Format):
+    container = A.C_GCLZ
+
+
+class CXLZ(_Format):
+    container = A.C_CXLZ
+
+
+class LZ_3DS(_Format):
+    container = A.C_LZ_3DS
+
+
+class COMP(_Format):
+    container = A.C_COMP
+
+
+class Yaz1(_Format):
+    container = A.C_YAZ1
+
+
+class AKLZ(_Format):
+    container = A.C_AKLZ
+
+
+class LZ01(_Format):
+    container = A.C_LZ01
+
+
+class LZSega(_Format):
+    container = A.C_LZSEGA
+
+
+class Level5LZSS(_Format):
+    container = A.C_LEVEL5LZSS
+
+
+class LZOn(_Format):
+    container = A.C_LZON
+
+
+class LZ77(_Format):
+    """src/AuroraLib.Compression.Nintendo/Nintendo/LZ77.cs -- Type: LZ10 (default) / LZ11 / ChunkLZ10."""
+    container = A.C_LZ77
+    LZ10, LZ11, ChunkLZ10 = A.LZ77_LZ10, A.LZ77_LZ11, A.LZ77_CHUNKLZ10
+
+
+class Level5(_Format):
+    container = A.C_LEVEL5
+    OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
+
+
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "AlzError"]

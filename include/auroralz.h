@@ -207,13 +207,35 @@ typedef enum alz_container {
     ALZ_C_LZ4_LEGACY = 7, /* 0x184C2102 + blocks         LZ4.cs:96-111,120-135 */
     ALZ_C_LZO    = 8,  /* headerless                     LZO.cs:42-47    */
     ALZ_C_SNAPPY = 9,  /* framed "sNaPpY"                Snappy.cs:39-107 */
-    ALZ_C_COUNT  = 10
+    /* header-only wrappers over the same bodies */
+    ALZ_C_GCLZ   = 10, /* "GCLZ" + LZ10 file             src/AuroraLib.Compression.Nintendo/Nintendo/GCLZ.cs        */
+    ALZ_C_CXLZ   = 11, /* "CXLZ" + LZ10 file             src/AuroraLib.Compression.Nintendo/Sega/CXLZ.cs            */
+    ALZ_C_LZ_3DS = 12, /* "3DS-LZ\r\n" + LZ10 file       src/AuroraLib.Compression.Nintendo/Nintendo/3DS-LZ.cs      */
+    ALZ_C_COMP   = 13, /* "COMP" + LZ11 file             src/AuroraLib.Compression.Nintendo/Sega/COMP.cs            */
+    ALZ_C_YAZ1   = 14, /* Yaz0 with magic "Yaz1"         src/AuroraLib.Compression.Nintendo/Nintendo/Yaz1.cs        */
+    ALZ_C_AKLZ   = 15, /* 12-byte magic + BE size + LZSS src/AuroraLib.Compression.Sega/Sega/AKLZ.cs:41-56          */
+    ALZ_C_LZ01   = 16, /* "LZ01"+csize+size+0 + LZSS     src/AuroraLib.Compression.Sega/Sega/LZ01.cs:47-83          */
+    ALZ_C_LZSEGA = 17, /* csize+size + LZSS              src/AuroraLib.Compression.Sega/Sega/LZSega.cs:49-68        */
+    ALZ_C_LEVEL5LZSS = 18, /* "SSZL"+0+csize+size + LZSS src/AuroraLib.Compression.Nintendo/Level5/Level5LZSS.cs:42-72 */
+    ALZ_C_LZON   = 19, /* "LZOn"+002FF171+BE size+csize + LZO  src/AuroraLib.Compression.Nintendo/Nintendo/LZOn.cs:41-79 */
+    ALZ_C_LZ77   = 20, /* "LZ77"+type: LZ10 / LZ11 / ChunkLZ10 (independent 4 KiB chunks = one GPU batch)  Nintendo/LZ77.cs:56-153 */
+    ALZ_C_LEVEL5 = 21, /* u32 type|size<<3: OnlySave / LZ10   src/AuroraLib.Compression.Nintendo/Level5/Level5.cs:62-146 */
+    ALZ_C_COUNT  = 22
 } alz_container;
+
+/* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */
+#define ALZ_LZ77_LZ10      0x10u
+#define ALZ_LZ77_LZ11      0x11u
+#define ALZ_LZ77_CHUNKLZ10 0xF7u
+#define ALZ_LEVEL5_ONLYSAVE 0u
+#define ALZ_LEVEL5_LZ10     1u
 
 typedef struct alz_container_options {
     uint32_t big_endian;          /* IEndianDependentFormat.FormatByteOrder: 1 = Endian.Big (default for Yaz0/Yay0/MIO0/PRS) */
     uint32_t memory_alignment;    /* Yaz0.MemoryAlignment (Yaz0.cs:39) */
     alz_lz_properties lz;         /* LZSS geometry */
+    uint32_t variant;             /* LZ77.Type / Level5.Type when compressing; 0 = the class default (LZ10) */
+    uint32_t chunk_size;          /* LZ77.ChunkSize (default 0x1000) */
 } alz_container_options;
 
 /* IProvidesDecompressedSize.GetDecompressedSize (Interfaces/IProvidesDecompressedSize.cs:20) */

@@ -1234,6 +1234,9 @@ static void wr32(uint8_t* p, uint32_t v, int big) {
     else { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 }
 
+static const uint8_t AKLZ_MAGIC[12] = { 'A', 'K', 'L', 'Z', '~', '?', 'Q', 'd', '=', 0xCC, 0xCC, 0xCD };   /* Sega/AKLZ.cs:16 */
+static const uint8_t LZON_MAGIC[8] = { 'L', 'Z', 'O', 'n', 0x00, 0x2F, 0xF1, 0x71 };                           /* Nintendo/LZOn.cs:17 */
+
 /* header of LZ10 / LZ11: id byte, u24 LE size, 0 => u32 LE (LZ10.cs:47-57).  Returns header length or -1. */
 static int nin_header(const uint8_t* src, size_t len, uint8_t id, uint32_t* size) {
     if (len < 4 || src[0] != id) return -1;
@@ -1252,6 +1255,26 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* MIO0.cs:41-48 */
+    /* header-only wrappers */
+    case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_COMP: {
+        const char* m = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : "COMP";
+        if (len < 4 || memcmp(src, m, 4)) return ALZ_E_FORMAT;
+        return oracle_container_decompressed_size(container == ALZ_C_COMP ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, src + 4, len - 4, size_out);
+    }
+    case ALZ_C_LZ_3DS: if (len < 8 || memcmp(src, "3DS-LZ\r\n", 8)) return ALZ_E_FORMAT; return oracle_container_decompressed_size(ALZ_C_LZ10, opt, src + 8, len - 8, size_out);
+    case ALZ_C_YAZ1: if (len < 8 || memcmp(src, "Yaz1", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;
+    case ALZ_C_AKLZ: if (len < 16 || memcmp(src, AKLZ_MAGIC, 12)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;     /* Sega/AKLZ.cs:33-38 */
+    case ALZ_C_LZ01: if (len < 12 || memcmp(src, "LZ01", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;          /* Sega/LZ01.cs:37-43 */
+    case ALZ_C_LZSEGA: if (len < 8) return ALZ_E_FORMAT; *size_out = rd32le(src + 4); return 0;                                  /* Sega/LZSega.cs:41-46 */
+    case ALZ_C_LEVEL5LZSS: if (len < 16 || memcmp(src, "SSZL", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 12); return 0;  /* Level5/Level5LZSS.cs:33-39 */
+    case ALZ_C_LZON: if (len < 12 || memcmp(src, LZON_MAGIC, 8)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return 0;       /* Nintendo/LZOn.cs:33-38 */
+    case ALZ_C_LZ77: {                                                                                                           /* Nintendo/LZ77.cs:45-54 */
+        if (len < 8 || memcmp(src, "LZ77", 4)) return ALZ_E_FORMAT;
+        uint32_t sz = (uint32_t)src[5] | ((uint32_t)src[6] << 8) | ((uint32_t)src[7] << 16);
+        if (sz == 0) { if (len < 12) return ALZ_E_FORMAT; sz = rd32le(src + 8); }
+        *size_out = sz; return 0;
+    }
+    case ALZ_C_LEVEL5: if (len < 5) return ALZ_E_FORMAT; *size_out = src[4] == 0x78 ? rd32le(src) : rd32le(src) >> 3; return 0;  /* Level5/Level5.cs:55-60 */
     default: return ALZ_E_UNSUPPORTED;
     }
 }
@@ -1342,6 +1365,95 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         break;
     }
     case ALZ_C_LZO: run_stream(ALZ_FMT_LZO, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r); break;
+    case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                /* magic + inner file */
+        const char* m = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
+        size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4, used = 0;
+        if (len < ml || memcmp(src, m, ml)) return ALZ_E_FORMAT;
+        int rc = oracle_container_decompress(container == ALZ_C_COMP ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, src + ml, len - ml, dst, dst_cap, dst_len, &used, status);
+        if (src_used) *src_used = ml + used;
+        return rc;
+    }
+    case ALZ_C_YAZ1:
+        if (len < 16 || memcmp(src, "Yaz1", 4)) return ALZ_E_FORMAT;
+        size = rd32(src + 4, big); hdr = 16;
+        run_stream(ALZ_FMT_YAZ0, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        if (r.status != ALZ_ST_OK) run_stream(ALZ_FMT_YAZ0, NULL, src + hdr, (uint32_t)(len - hdr), bswap32(size), 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_AKLZ:                                                                       /* Sega/AKLZ.cs:41-46 */
+        if (len < 16 || memcmp(src, AKLZ_MAGIC, 12)) return ALZ_E_FORMAT;
+        size = be32(src + 12); hdr = 16;
+        run_stream(ALZ_FMT_LZSS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZ01:                                                                       /* Sega/LZ01.cs:47-62 */
+        if (len < 16 || memcmp(src, "LZ01", 4)) return ALZ_E_FORMAT;
+        size = rd32le(src + 8); hdr = 16;
+        run_stream(ALZ_FMT_LZSS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZSEGA:                                                                     /* Sega/LZSega.cs:49-54 */
+        if (len < 8) return ALZ_E_FORMAT;
+        size = rd32le(src + 4); hdr = 8;
+        run_stream(ALZ_FMT_LZSS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LEVEL5LZSS:                                                                 /* Level5/Level5LZSS.cs:42-59 */
+        if (len < 16 || memcmp(src, "SSZL", 4)) return ALZ_E_FORMAT;
+        size = rd32le(src + 12); hdr = 16;
+        run_stream(ALZ_FMT_LZSS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_LZON:                                                                       /* Nintendo/LZOn.cs:41-60 */
+        if (len < 16 || memcmp(src, LZON_MAGIC, 8)) return ALZ_E_FORMAT;
+        size = be32(src + 8); hdr = 16;
+        run_stream(ALZ_FMT_LZO, NULL, src + hdr, (uint32_t)(len - hdr), 0, 0, 0, dst, dst_cap, &r);
+        if (r.status == ALZ_ST_OK && r.dst_len != size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;
+        break;
+    case ALZ_C_LEVEL5: {                                                                   /* Level5/Level5.cs:62-110 */
+        if (len < 4) return ALZ_E_FORMAT;
+        uint32_t ts = rd32le(src); hdr = 4;
+        if (len > 4 && src[4] == 0x78) return ALZ_E_UNSUPPORTED;
+        size = ts >> 3;
+        if ((ts & 7) == ALZ_LEVEL5_ONLYSAVE) {
+            if (len - hdr < size) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+            if (dst_cap < size) { r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+            memcpy(dst, src + hdr, size); r.dst_len = size; r.src_used = size; r.status = ALZ_ST_OK;
+        } else if ((ts & 7) == ALZ_LEVEL5_LZ10) run_stream(ALZ_FMT_LZ10, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        else return ALZ_E_UNSUPPORTED;
+        break;
+    }
+    case ALZ_C_LZ77: {                                                                     /* Nintendo/LZ77.cs:105-153 */
+        if (len < 8 || memcmp(src, "LZ77", 4)) return ALZ_E_FORMAT;
+        uint32_t type = src[4];
+        size = (uint32_t)src[5] | ((uint32_t)src[6] << 8) | ((uint32_t)src[7] << 16); hdr = 8;
+        if (size == 0) { if (len < 12) return ALZ_E_FORMAT; size = rd32le(src + 8); hdr = 12; }
+        if (type == ALZ_LZ77_LZ10 || type == ALZ_LZ77_LZ11) {
+            run_stream(type == ALZ_LZ77_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+            break;
+        }
+        if (type != ALZ_LZ77_CHUNKLZ10) return ALZ_E_UNSUPPORTED;
+        /* ChunkLZ10: u16 end offsets until last + position == length; one LZ10 file per chunk, decoded in order */
+        size_t pos = hdr, nseg = 0, ends_cap = 65536; uint32_t* ends = (uint32_t*)malloc(ends_cap * sizeof(uint32_t));
+        int trunc = 0;
+        for (;;) {
+            if (pos + 2 > len || nseg >= ends_cap) { trunc = 1; break; }
+            ends[nseg++] = (uint32_t)src[pos] | ((uint32_t)src[pos + 1] << 8); pos += 2;
+            if (ends[nseg - 1] + pos == len) break;
+        }
+        if (trunc) { free(ends); r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size_t header_end = pos; uint64_t out_off = 0;
+        r.status = ALZ_ST_OK; r.dst_len = 0;
+        for (size_t i = 0; i < nseg; i++) {
+            size_t a = header_end + (i ? ends[i - 1] : 0); uint32_t csz = 0;
+            int h = a < len ? nin_header(src + a, len - a, 0x10, &csz) : -1;
+            if (h < 0) { free(ends); return ALZ_E_FORMAT; }
+            alz_result cr;
+            run_stream(ALZ_FMT_LZ10, NULL, src + a + h, (uint32_t)(len - a - h), csz, 0, 0, dst + out_off, out_off < dst_cap ? dst_cap - out_off : 0, &cr);
+            r.dst_len = (uint32_t)(out_off + cr.dst_len);
+            if (cr.status != ALZ_ST_OK) { r.status = cr.status; break; }
+            out_off += csz;
+        }
+        if (r.status == ALZ_ST_OK && r.dst_len > size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;
+        r.src_used = (uint32_t)(header_end + ends[nseg - 1] - hdr);
+        free(ends);
+        break;
+    }
     default: return ALZ_E_UNSUPPORTED;
     }
     if (dst_len) *dst_len = r.dst_len;
@@ -1357,6 +1469,95 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
     size_t hdr = 0; int64_t body; alz_encode_aux aux;
     alz_settings st = settings ? *settings : (alz_settings){ 8, 0, 0, 0 };
     switch (container) {
+    case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                /* e.g. Nintendo/GCLZ.cs:40-44 */
+        const char* m = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
+        size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4, inner = 0;
+        if (cap < ml) return ALZ_E_NOMEM;
+        memcpy(dst, m, ml);
+        int rc = oracle_container_compress(container == ALZ_C_COMP ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, settings, src, n, dst + ml, cap - ml, &inner);
+        if (dst_len) *dst_len = ml + inner;
+        return rc;
+    }
+    case ALZ_C_YAZ1:
+        if (cap < 16) return ALZ_E_NOMEM;
+        memcpy(dst, "Yaz1", 4); wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, opt ? opt->memory_alignment : 0, big); wr32(dst + 12, 0, 0); hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_YAZ0, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    case ALZ_C_AKLZ:                                                                       /* Sega/AKLZ.cs:50-55 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        memcpy(dst, AKLZ_MAGIC, 12); wr32(dst + 12, (uint32_t)n, 1); hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_LZSS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    case ALZ_C_LZ01:                                                                       /* Sega/LZ01.cs:65-82 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_LZSS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "LZ01", 4); wr32(dst + 4, (uint32_t)(hdr + body), 0); wr32(dst + 8, (uint32_t)n, 0); wr32(dst + 12, 0, 0);
+        break;
+    case ALZ_C_LZSEGA:                                                                     /* Sega/LZSega.cs:57-67 */
+        if (cap < 8) return ALZ_E_NOMEM;
+        hdr = 8;
+        body = oracle_encode_stream(ALZ_FMT_LZSS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        wr32(dst, (uint32_t)body, 0); wr32(dst + 4, (uint32_t)n, 0);
+        break;
+    case ALZ_C_LEVEL5LZSS:                                                                 /* Level5/Level5LZSS.cs:62-72 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_LZSS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "SSZL", 4); wr32(dst + 4, 0, 0); wr32(dst + 8, (uint32_t)body, 0); wr32(dst + 12, (uint32_t)n, 0);
+        break;
+    case ALZ_C_LZON:                                                                       /* Nintendo/LZOn.cs:63-79 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_LZO, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return body == -1 ? ALZ_E_NOMEM : ALZ_E_INVALID;
+        memcpy(dst, LZON_MAGIC, 8); wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, (uint32_t)body, 1);
+        break;
+    case ALZ_C_LEVEL5: {                                                                   /* Level5/Level5.cs:112-146 */
+        uint32_t type = opt && opt->variant ? opt->variant : ALZ_LEVEL5_LZ10;
+        if (st.quality == 0) type = ALZ_LEVEL5_ONLYSAVE;
+        if (cap < 4) return ALZ_E_NOMEM;
+        wr32(dst, type | ((uint32_t)n << 3), 0); hdr = 4;
+        if (type == ALZ_LEVEL5_ONLYSAVE) { if (cap < 4 + n) return ALZ_E_NOMEM; memcpy(dst + 4, src, n); body = (int64_t)n; break; }
+        if (type != ALZ_LEVEL5_LZ10) return ALZ_E_UNSUPPORTED;
+        if (st.min_distance == 0) st.min_distance = 2;
+        body = oracle_encode_stream(ALZ_FMT_LZ10, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    }
+    case ALZ_C_LZ77: {                                                                     /* Nintendo/LZ77.cs:56-102 */
+        uint32_t type = opt && opt->variant ? opt->variant : ALZ_LZ77_LZ10;
+        size_t chunk = opt && opt->chunk_size ? opt->chunk_size : 0x1000;
+        if (cap < 8) return ALZ_E_NOMEM;
+        memcpy(dst, "LZ77", 4);
+        if (type == ALZ_LZ77_LZ10 || type == ALZ_LZ77_LZ11 || (type == ALZ_LZ77_CHUNKLZ10 && chunk >= n)) {
+            size_t inner = 0;
+            int rc = oracle_container_compress(type == ALZ_LZ77_LZ11 ? ALZ_C_LZ11 : ALZ_C_LZ10, opt, settings, src, n, dst + 4, cap - 4, &inner);
+            if (dst_len) *dst_len = 4 + inner;
+            return rc;
+        }
+        if (type != ALZ_LZ77_CHUNKLZ10) return ALZ_E_UNSUPPORTED;
+        if (n > 0xFFFFFF) return ALZ_E_INVALID;
+        size_t segs = (n + chunk - 1) / chunk, header_end = 8 + 2 * segs, pos = header_end;
+        if (cap < header_end) return ALZ_E_NOMEM;
+        wr32(dst + 4, type | ((uint32_t)n << 8), 0);
+        for (size_t i = 0; i < segs; i++) {
+            size_t a = i * chunk, sz = n - a < chunk ? n - a : chunk, inner = 0;
+            int rc = oracle_container_compress(ALZ_C_LZ10, opt, settings, src + a, sz, dst + pos, cap - pos, &inner);
+            if (rc) return rc;
+            pos += inner;
+            size_t endoff = pos - header_end;
+            if (endoff > 0xFFFF) return ALZ_E_INVALID;
+            dst[8 + 2 * i] = (uint8_t)endoff; dst[8 + 2 * i + 1] = (uint8_t)(endoff >> 8);
+        }
+        if (dst_len) *dst_len = pos;
+        return 0;
+    }
     case ALZ_C_LZSS:                                                                     /* LZSS.cs:72-88 */
         if (cap < 16) return ALZ_E_NOMEM;
         memcpy(dst, "LZSS", 4); wr32(dst + 4, (uint32_t)n, 1); wr32(dst + 8, 0, 1); wr32(dst + 12, 0, 1); hdr = 16;

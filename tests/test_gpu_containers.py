@@ -55,3 +55,34 @@ def test_exceptions(test_bmp):
     bad = bytes([0x10]) + (4000).to_bytes(3, "little") + comp[4:]     # declared size smaller than the stream decodes to
     with pytest.raises(F.DecompressedSizeException):
         F.LZ10().Decompress(bad)
+
+
+WRAPPERS = [(F.GCLZ, A.C_GCLZ), (F.CXLZ, A.C_CXLZ), (F.LZ_3DS, A.C_LZ_3DS), (F.COMP, A.C_COMP), (F.Yaz1, A.C_YAZ1), (F.AKLZ, A.C_AKLZ),
+            (F.LZ01, A.C_LZ01), (F.LZSega, A.C_LZSEGA), (F.Level5LZSS, A.C_LEVEL5LZSS), (F.LZOn, A.C_LZON), (F.LZ77, A.C_LZ77), (F.Level5, A.C_LEVEL5)]
+
+
+@pytest.mark.parametrize("cls,container", WRAPPERS)
+def test_wrapper_formats_roundtrip(cls, container, test_bmp):
+    """Header-only wrappers over the GPU bodies: Compress == oracle bytes, Decompress == original."""
+    for size, q in ((10, 4), (10240, 8), (70000, 0), (10240, 15)):
+        raw = test_bmp[:size]
+        f = cls()
+        comp = f.Compress(raw, F.CompressionSettings(q))
+        assert comp == O.container_compress(container, raw, quality=q), (cls.__name__, size, q)
+        assert f.Decompress(comp, capacity=len(raw) + 300) == raw
+
+
+def test_lz77_chunklz10_is_one_gpu_batch(test_bmp):
+    """ChunkLZ10: independent 4 KiB LZ10 chunks, encoded and decoded as one batch."""
+    raw = test_bmp[:60000]           # the u16 end offsets cap a ChunkLZ10 file at 64 KiB of compressed chunks (LZ77.cs:92-95)
+    f = F.LZ77()
+    f.Type = F.LZ77.ChunkLZ10
+    comp = f.Compress(raw, F.CompressionSettings.Balanced)
+    assert comp == O.container_compress(A.C_LZ77, raw, quality=8, variant=A.LZ77_CHUNKLZ10)
+    assert f.Decompress(comp, capacity=len(raw)) == raw
+    f2 = F.LZ77(); f2.Type = F.LZ77.LZ11
+    c2 = f2.Compress(raw[:30000])
+    assert c2 == O.container_compress(A.C_LZ77, raw[:30000], quality=8, variant=A.LZ77_LZ11) and f2.Decompress(c2) == raw[:30000]
+    from auroralib.compression_amd._lib import AlzError
+    with pytest.raises(AlzError):      # "chunks too large to process"
+        f.Compress(test_bmp[:400000], F.CompressionSettings.Fastest)
