@@ -50,8 +50,8 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
     return v;
 }
 
-// descriptor of a token for the byte phase: bit31 literal, bits 17..24 literal value, bits 0..16 distance
-#define ALZ_DESC_LIT(b) (0x80000000u | ((b) << 17))
+// descriptor of a token for the byte phase: bit31 literal (bits 0..7 the byte), else bits 0..16 the distance
+#define ALZ_DESC_LIT(b) (0x80000000u | (b))
 #define ALZ_DESC_MATCH(d) (d)
 #define ALZ_DESC_DIST(x) ((x) & 0x1FFFFu)
 
@@ -83,7 +83,7 @@ template <class OW, class CFG, bool EARLY, bool FULL>
 __device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32 nseg) {
     const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
     u8* const win = out.win;
-    segmark[relm < 64u ? relm : 64u + (u32)lane] = 1;
+    { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }   // slots 64..127 are never read
     wave_sync();
     const u32 mk = segmark[lane];
     segmark[lane] = 0;
@@ -102,18 +102,20 @@ __device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds,
         }
     }
     if (EARLY) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
-    u32 val;
+    u32 val;                                                 // only the low byte is ever stored
     if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
-    else val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
+    else val = ((int)dsc < 0) ? dsc : wv;
     const bool instep = FULL ? (dsc <= (u32)lane) : (dsc <= (u32)lane && (u32)lane < nseg);   // source produced inside this very step
     if (__ballot(instep)) {
-        // pointer jumping (at most 6 rounds), one packed ds_bpermute per round: value | source lane << 8, 0x40 = resolved
-        u32 st = val | ((instep ? ((u32)lane - dsc) : 0x40u) << 8);
+        // pointer jumping (at most 6 rounds), one ds_bpermute per round.  State word: resolved lanes hold their byte with
+        // bit 16 set; unresolved lanes hold (source lane) << 10, i.e. the bpermute address << 8.  An unresolved lane simply
+        // takes over its source's word: that is either the byte (resolved) or the source's source (jump).
+        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
         do {
-            const u32 f = wave_bperm(st >> 8, st);
-            if (st < 0x4000u) st = (f >= 0x4000u) ? f : ((st & 0xFFu) | (f & 0xFF00u));
-        } while (__ballot(st < 0x4000u));
-        val = st & 0xFFu;
+            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
+            if (st < 0x10000u) st = f;
+        } while (__ballot(st < 0x10000u));
+        val = st;
     }
     if (FULL) win[qs & omask] = (u8)val;
     else if ((u32)lane < nseg) win[qs & omask] = (u8)val;
@@ -124,7 +126,7 @@ __device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds,
 // Two-pass form of the step for configurations with HBM read-back (see fast_emit): map_step finds the descriptor of
 // this lane's byte, copy_step moves the byte.
 __device__ __forceinline__ u32 map_step(u8* segmark, int lane, u32 desc, u32& relm, u32& tbase4) {
-    segmark[relm < 64u ? relm : 64u + (u32)lane] = 1;
+    { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }
     wave_sync();
     const u32 mk = segmark[lane];
     segmark[lane] = 0;
@@ -145,19 +147,56 @@ __device__ __forceinline__ void copy_step(OW& out, const u8* inlds, int lane, u3
     if (early) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
     u32 val;
     if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
-    else val = ((int)dsc < 0) ? ((dsc >> 17) & 0xFFu) : wv;
+    else val = ((int)dsc < 0) ? dsc : wv;
     const bool instep = dsc <= (u32)lane && (u32)lane < nseg;
     if (__ballot(instep)) {
-        u32 st = val | ((instep ? ((u32)lane - dsc) : 0x40u) << 8);
+        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
         do {
-            const u32 f = wave_bperm(st >> 8, st);
-            if (st < 0x4000u) st = (f >= 0x4000u) ? f : ((st & 0xFFu) | (f & 0xFF00u));
-        } while (__ballot(st < 0x4000u));
-        val = st & 0xFFu;
+            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
+            if (st < 0x10000u) st = f;
+        } while (__ballot(st < 0x10000u));
+        val = st;
     }
     if ((u32)lane < nseg) win[qs & omask] = (u8)val;
     wave_sync();
     qs += 64u;
+}
+
+// Software-pipelined steady-state step: copies step k with the descriptors found one step earlier and maps step k+1.
+// The two halves are independent, so their LDS round trips overlap: the dependent chain per step shrinks from
+// (mark read -> bpermute -> window read -> window write) to max(mark read -> bpermute, window read -> window write).
+// `dsc` holds the descriptors of the current step on entry and of the next step on return; relm / tbase4 belong to the
+// mapping side (one step ahead of qs).
+template <class OW, class CFG>
+__device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32& dsc) {
+    const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
+    u8* const win = out.win;
+    { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }
+    wave_sync();
+    const u32 wv = win[(qs - dsc) & omask];                  // copy side: source byte of step k
+    u32 lv = 0;
+    if (CFG::LITRUN) lv = inlds[(qs + dsc) & 2047u];
+    const u32 mk = segmark[lane];                            // map side: marks of step k+1
+    segmark[lane] = 0;
+    const u64 M = __ballot(mk != 0);
+    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
+    const u32 dscn = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);
+    tbase4 += 4u * (u32)__popcll(M);
+    u32 val;
+    if (CFG::LITRUN) val = ((int)dsc < 0) ? lv : wv;
+    else val = ((int)dsc < 0) ? dsc : wv;
+    const bool instep = dsc <= (u32)lane;
+    if (__ballot(instep)) {
+        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
+        do {
+            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
+            if (st < 0x10000u) st = f;
+        } while (__ballot(st < 0x10000u));
+        val = st;
+    }
+    win[qs & omask] = (u8)val;
+    wave_sync();
+    qs += 64u; relm -= 64u; dsc = dscn;
 }
 
 // Shared back end.  Per-lane token: valid, len (>=1), desc, tend = input offset just past the token (relative to the
@@ -234,8 +273,41 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
     } else {
         // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
         while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-        while (X + 64u <= T) { byte_step<OW, CFG, false, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+        // steady state: flush checks only where the output crosses a flush-block boundary (the loop in between is a bare
+        // counter: the kernel is bound by instruction issue per wave, scalar instructions included)
+        u32 nleft = (T - X) >> 6;
+#ifndef ALZ_EXP
+#define ALZ_EXP 0
+#endif
+#if ALZ_EXP == 1
+        while (nleft) {
+            const u32 pos = O + X + out.oshift;
+            u32 nb = (out.fl - (pos & (out.fl - 1u)) + 63u) >> 6;
+            if (nb > nleft) nb = nleft;
+            for (u32 k = nb; k; k--) byte_step<OW, CFG, false, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u);
+            X += 64u * nb; nleft -= nb; out.produced = O + X;
+            if (out.produced - out.flushed >= out.fl) out.flush_blocks();
+        }
         if (X < T) { byte_step<OW, CFG, true, false>(out, segmark, inlds, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
+#else
+        u32 dsc = 0; bool have = false;
+        if (nleft) {
+            dsc = map_step(segmark, lane, desc, relm, tbase4); have = true;      // pipeline prologue: descriptors of the first step
+            do {
+                const u32 pos = O + X + out.oshift;
+                u32 nb = (out.fl - (pos & (out.fl - 1u)) + 63u) >> 6;
+                if (nb > nleft) nb = nleft;
+                for (u32 k = nb; k; k--) fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc);
+                X += 64u * nb; nleft -= nb; out.produced = O + X;
+                if (out.produced - out.flushed >= out.fl) out.flush_blocks();
+            } while (nleft);
+        }
+        if (X < T) {                                          // last, partial step (its descriptors may already be mapped)
+            if (!have) dsc = map_step(segmark, lane, desc, relm, tbase4);
+            copy_step<OW, CFG>(out, inlds, lane, dsc, 0u, qs, T - X, true);
+            out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks();
+        }
+#endif
     }
     return fin;
 }
