@@ -72,7 +72,8 @@ struct FastGeom {           // LZSS geometry (other formats ignore it)
 //   OMASK    window mask when it is a compile-time constant (0: use out.lw_mask)
 //   LZSS     descriptors hold ring offsets that become distances once the output position is known
 //   LITRUN   bit-31 descriptors are literal RUNS copied from the LDS input cache (LZ4/LZO/Snappy): the low 30 bits are
-//            (input-cache index - window-slot coordinate) of the run, so byte q reads inlds[(slot(q) + desc) & 2047];
+//            (input-cache index - window-slot coordinate) of the run, so byte q reads inlds[(slot(q) + desc) & 2047]
+//            (tokens carry the cache index; fast_emit subtracts the slot coordinate once the output offset is known);
 //            otherwise bit-31 descriptors carry ONE literal byte in bits 17..24 (flag-byte formats, PRS)
 //   FALLBACK the LDS window is shorter than the format's window (64 KiB formats keep 8 KiB): older sources are read
 //            back from the stream's own output in HBM (L2-served loads; flush_to() made them visible)
@@ -226,6 +227,9 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
         T = room; fin = true;
     }
     last_tend = wave_readlane(tend, lastk);
+    if (CFG::LITRUN) {                                        // literal run: (input-cache index of the run) - (slot coordinate of its first byte)
+        if (desc >> 31) desc = 0x80000000u | ((desc - (O + off + out.oshift)) & 2047u);
+    }
     if (CFG::LZSS) {
         if (!(desc >> 31)) {
             u32 offset = ALZ_DESC_DIST(desc);
@@ -534,9 +538,7 @@ struct QueueSink {
             u32 cl = clip_token(out, s, len); out.copy_from(in, p, cl); return !s.ovf;
         }
         ensure(in, p, (u32)len);
-        // byte q of the run reads inlds[(slot(q) + d) & 2047]:  d = cache index of the run - slot coordinate of its first byte
-        const u32 d = in.idx(p) - (produced() + out.oshift);
-        return push(ALZ_TOK_LIT((u32)len, d & 2047u), (u32)len);
+        return push(ALZ_TOK_LIT((u32)len, in.idx(p)), (u32)len);   // the run is addressed by its input-cache index (< 2048)
     }
 };
 
@@ -558,7 +560,6 @@ __device__ __forceinline__ u64 peek8(const InCache& in, u32 p) {
 template <class SK>
 __device__ __forceinline__ void lz4_fast_parse(InCache& in, SK& sk, DecState& s, u32 limit) {
     u32 pp = s.p;
-    u32 oo = sk.produced() + sk.out.oshift;                  // slot coordinate of the next output byte
     const u32 room = sk.out.cap - (sk.produced());           // stop before the capacity rule (E5) could apply
     u32 made = 0;
     while (sk.nt <= 62u && pp < limit) {
@@ -578,12 +579,82 @@ __device__ __forceinline__ void lz4_fast_parse(InCache& in, SK& sk, DecState& s,
         if (M == 15u) { u32 b; do { b = in.peek1(q); q++; M += b; } while (b == 255u && M < 16000u); }
         M += 4u;
         if (M > ALZ_TOK_MAXLEN || q > limit || made + L + M > room) break;
-        if (L) { sk.push_word(ALZ_TOK_LIT(L, (in.idx(litpos) - oo) & 2047u), L); oo += L; }
-        sk.push_word(ALZ_TOK_MATCH(M, dist ? dist : 65536u), M); oo += M;
+        if (L) sk.push_word(ALZ_TOK_LIT(L, in.idx(litpos)), L);
+        sk.push_word(ALZ_TOK_MATCH(M, dist ? dist : 65536u), M);
         made += L + M;
         pp = q;
     }
     s.p = pp;
+}
+
+// Lane-parallel LZ4 parse.  Where a sequence starts can only be found by walking the chain of sequences, but what the
+// walk needs -- the size of "the sequence that would start at this byte" -- depends on that byte and at most two length
+// bytes, so every lane computes it for its own byte of a 256-byte window (4 x 64) and the walk itself is one v_readlane
+// per sequence on the scalar unit.  The lanes that turned out to start a sequence build its two tokens (literal run,
+// match) and compact them into the queue through a 64-dword LDS staging array; the byte phase executes them.
+// Sequences with a second length-extension byte (run >= 270 / match >= 274 bytes) stop the walk and are left to the
+// exact parser.  Preconditions: queue empty, >= 1100 input bytes ahead of s.p, cache covers [p, p + 1024).
+// Returns false when nothing was parsed (first sequence unusual, or the batch would not fit the output capacity).
+template <class SK>
+__device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane) {
+    const u32 p = s.p;
+    const u32 i0 = in.idx(p);
+    u32 tokb[4], runl[4], mlen[4], offp[4], nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;        // cache index of "my" byte
+        const u32 b = in.lds[pos];
+        const u32 e1 = in.lds[pos + 1];
+        const u32 L0 = b >> 4, M0 = b & 15u;
+        const u32 L = L0 + (L0 == 15u ? e1 : 0u);
+        const u32 lp = pos + 1u + (L0 == 15u ? 1u : 0u);      // first literal
+        const u32 op = lp + L;                                // offset bytes
+        const u32 em = in.lds[(op + 2u) & 2047u];             // match length extension (if any); masked: garbage lanes may point anywhere
+        const u32 M = M0 + 4u + (M0 == 15u ? em : 0u);
+        const bool bad = (L0 == 15u && e1 == 255u) || (M0 == 15u && em == 255u);
+        tokb[w] = lp; runl[w] = L; mlen[w] = M; offp[w] = op;
+        nx[w] = bad ? 0u : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
+    }
+    // walk the chain (scalar): sequence starts as one 64-bit mask per window
+    u64 mask[4] = {0ull, 0ull, 0ull, 0ull};
+    u32 sp = 0, nseq = 0;
+    bool stop = false;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        while (!stop && sp < 64u * (u32)(w + 1)) {
+            const u32 n = wave_readlane(nx[w], sp & 63u);
+            if (n == 0u || nseq == 32u) { stop = true; break; }
+            mask[w] |= 1ull << (sp & 63u);
+            sp += n; nseq++;
+        }
+    }
+    if (nseq == 0u) return false;
+    // tokens: starting lanes write (literal run?, match) at their rank
+    u32 base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (mask[w]) {
+            const bool st = (mask[w] >> lane) & 1ull;
+            const u64 litm = __ballot(st && runl[w] != 0u);
+            const u32 rank = base + mbcnt64(mask[w]) + mbcnt64(litm);
+            if (st) {
+                const u32 dist = (u32)in.lds[offp[w]] | ((u32)in.lds[offp[w] + 1u] << 8);
+                u32 r = rank;
+                if (runl[w]) { stage[r] = ALZ_TOK_LIT(runl[w], tokb[w]); r++; }
+                stage[r] = ALZ_TOK_MATCH(mlen[w], dist ? dist : 65536u);      // E1
+            }
+            base += (u32)__popcll(mask[w]) + (u32)__popcll(litm);
+        }
+    }
+    wave_sync();
+    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
+    wave_sync();
+    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
+    sk.qtok = qt; sk.nt = base; sk.qbytes = total;
+    s.p = p + sp;
+    sk.flush();
+    return true;
 }
 
 // PRS.DecompressHeaderless  Sega/PRS.cs:59-102

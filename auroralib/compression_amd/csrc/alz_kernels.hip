@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     // only the most recent 4 KiB of the window stay in LDS (6.3 KB per wave -> 25 waves per CU instead of 15), older
     // sources are read back from the stream's own output in HBM, batched per token queue.
     constexpr u32 LW = PRS ? 8192u : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
-    __shared__ __attribute__((aligned(16))) u8 lds[128 + ALZ_INCACHE_BYTES + LW];
+    // static LDS: marks (128) | token staging (256) | input cache | window
+    __shared__ __attribute__((aligned(16))) u8 lds[384 + ALZ_INCACHE_BYTES + LW];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -165,9 +166,10 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     u8* dst = dst_base + st.dst_off;
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap);
     u8* segmark = lds;
-    u8* inc_lds = lds + 128;
+    u32* stage = reinterpret_cast<u32*>(lds + 128);
+    u8* inc_lds = lds + 384;
     typedef OutWin<!PRS> OW;
-    OW out; out.init(dst, cap, lds + 128 + ALZ_INCACHE_BYTES, LW, lane);
+    OW out; out.init(dst, cap, lds + 384 + ALZ_INCACHE_BYTES, LW, lane);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
@@ -183,7 +185,11 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
                 const u32 before = s.p;
                 if constexpr (FMT == ALZ_FMT_PRS_BE) prs_fast_parse<SK, true>(in, sk, s, s.p + 1000u);
                 else if constexpr (FMT == ALZ_FMT_PRS_LE) prs_fast_parse<SK, false>(in, sk, s, s.p + 1000u);
-                else lz4_fast_parse(in, sk, s, s.p + 1000u);
+                else {
+                    if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                    lz4_lane_parse(in, sk, s, stage, lane);
+                    if (s.ovf) break;
+                }
                 if (sk.nt >= 62u) { sk.flush(); if (s.ovf) break; }
                 if (s.p != before) continue;                      // made progress: next batch
             }
