@@ -615,17 +615,34 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
         tokb[w] = lp; runl[w] = L; mlen[w] = M; offp[w] = op;
         nx[w] = bad ? 0u : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
     }
-    // walk the chain (scalar): sequence starts as one 64-bit mask per window
+    // walk the chain (scalar): sequence starts as one 64-bit mask per window.  Hand-scheduled: ten scalar-unit
+    // instructions per sequence (the compiler's version of this loop spent ~25, mostly shuffling the mask registers).
+    // The five instructions between the s_add and the next v_readlane cover the SALU-write -> lane-select hazard.
     u64 mask[4] = {0ull, 0ull, 0ull, 0ull};
-    u32 sp = 0, nseq = 0;
-    bool stop = false;
+    u32 sp = 0, nseq = 0, stop = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        while (!stop && sp < 64u * (u32)(w + 1)) {
-            const u32 n = wave_readlane(nx[w], sp & 63u);
-            if (n == 0u || nseq == 32u) { stop = true; break; }
-            mask[w] |= 1ull << (sp & 63u);
-            sp += n; nseq++;
+        if (!stop && sp < 64u * (u32)(w + 1)) {
+            u32 n;
+            asm volatile(
+                "1:\n\t"
+                "v_readlane_b32 %[n], %[nx], %[sp]\n\t"
+                "s_cmp_eq_u32 %[n], 0\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_bitset1_b64 %[mask], %[sp]\n\t"
+                "s_add_u32 %[sp], %[sp], %[n]\n\t"
+                "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                "s_cmp_ge_u32 %[cnt], 32\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_branch 3f\n"
+                "2:\n\t"
+                "s_mov_b32 %[stop], 1\n"
+                "3:\n\t"
+                : [n] "=&s"(n), [sp] "+s"(sp), [mask] "+s"(mask[w]), [cnt] "+s"(nseq), [stop] "+s"(stop)
+                : [nx] "v"(nx[w]), [lim] "s"(64u * (u32)(w + 1))
+                : "scc");
         }
     }
     if (nseq == 0u) return false;
