@@ -515,10 +515,10 @@ struct QueueSink {
     // record one packed token (len <= ALZ_TOK_MAXLEN); the caller keeps nt < 64
     __device__ __forceinline__ void push_word(u32 word, u32 len) {
         qtok = wave_writelane(qtok, uni(word), uni(nt));
-        nt++; qbytes += len;
+        nt = uni(nt + 1u); qbytes = uni(qbytes + len);   // uni(): tells the compiler the queue state is wave-uniform
     }
     __device__ __forceinline__ bool push(u32 word, u32 len) {
-        push_word(uni(word), uni(len));
+        push_word(word, len);
         if (nt == 64u || qbytes >= 0x40000000u) flush();
         return !s.ovf;
     }
@@ -677,8 +677,9 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
 // PRS.DecompressHeaderless  Sega/PRS.cs:59-102
 template <class SK, bool BIG>
 __device__ __forceinline__ void prs_fast_parse(InCache& in, SK& sk, DecState& s, u32 limit) {
-    u32 pp = s.p, bits = s.bits, flag = s.flag;
-    const u32 room = sk.out.cap - sk.produced();
+    u32 pp = uni(s.p), bits = uni(s.bits), flag = uni(s.flag);
+    const u32 room = uni(sk.out.cap - sk.produced());      // (uni: keeps the whole loop on the scalar unit)
+    limit = uni(limit);
     u32 made = 0;
     while (sk.nt <= 63u && pp < limit) {
         const u64 w = peek8(in, pp);
