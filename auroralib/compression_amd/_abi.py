@@ -12,11 +12,13 @@ FORMAT_NAMES = ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_l
 ST_OK, ST_INPUT_TRUNCATED, ST_OUTPUT_SIZE_MISMATCH, ST_OUTPUT_CAPACITY, ST_BAD_TOKEN = range(5)
 
 # API errors
-E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_FORMAT, E_STREAM = -1, -2, -3, -4, -5, -6, -7
+E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_FORMAT, E_STREAM, E_CHECKSUM = -1, -2, -3, -4, -5, -6, -7, -8
 
 # alz_container
 C_LZSS, C_LZ10, C_LZ11, C_YAZ0, C_YAY0, C_MIO0, C_PRS, C_LZ4_LEGACY, C_LZO, C_SNAPPY = range(10)
 C_GCLZ, C_CXLZ, C_LZ_3DS, C_COMP, C_YAZ1, C_AKLZ, C_LZ01, C_LZSEGA, C_LEVEL5LZSS, C_LZON, C_LZ77, C_LEVEL5 = range(10, 22)
+C_LZ4_FRAME = 22
+C_COUNT = 23
 LZ77_LZ10, LZ77_LZ11, LZ77_CHUNKLZ10 = 0x10, 0x11, 0xF7
 LEVEL5_ONLYSAVE, LEVEL5_LZ10 = 0, 1
 

@@ -107,6 +107,331 @@ int run_body(alz_ctx* ctx, uint32_t fmt, const alz_lz_properties* lz, const uint
     return alz_decode(ctx, fmt, lz, body, clamp32(body_len), size, aux0, aux1, dst, clamp32(cap), r);
 }
 
+// ---------------------------------------------------------------------------------------------- checksums (host side)
+// XXH32 (the LZ4 frame format's checksum; the reference takes it as LZ4.HashAlgorithm, LZ4.Frame.cs:17-18)
+inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+uint32_t xxh32(const uint8_t* p, size_t len, uint32_t seed) {
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const uint8_t* end = p + len; uint32_t h;
+    if (len >= 16) {
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = rotl32(v1 + le32(p) * P2, 13) * P1; v2 = rotl32(v2 + le32(p + 4) * P2, 13) * P1;
+            v3 = rotl32(v3 + le32(p + 8) * P2, 13) * P1; v4 = rotl32(v4 + le32(p + 12) * P2, 13) * P1; p += 16;
+        } while (p + 16 <= end);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else h = seed + P5;
+    h += (uint32_t)len;
+    while (p + 4 <= end) { h = rotl32(h + le32(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; p++; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+// CRC-32C (Castagnoli, reflected 0x82F63B78), slicing-by-1 table; Snappy.cs:87 masks it with CRCMask (:252)
+uint32_t crc32c(const uint8_t* p, size_t len) {
+    static uint32_t table[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u))); table[i] = c; } init = true; }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < len; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+inline uint32_t snappy_crc_mask(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + 0xa282ead8u; }
+
+const uint8_t kSnappyId[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 };                // Snappy.cs:17
+
+inline bool lz4_magic_defined(uint32_t v) { return v == 0x184C2102u || v == 0x184D2204u || (v >= 0x184D2A50u && v <= 0x184D2A5Fu); }   // LZ4.Frame.cs:50-70
+
+struct DevBuf {   // device allocation released on every exit path
+    alz_ctx* c; void* p;
+    explicit DevBuf(alz_ctx* ctx) : c(ctx), p(nullptr) {}
+    ~DevBuf() { if (p) alz_device_free(c, p); }
+};
+
+struct Lz4Block { size_t off; uint32_t len; bool raw; };
+
+// LZ4.Decompress  Formats/Common/LZ4.cs:50-93 (+ ReadLZ4L :96-111, DecompressLZ4FrameHeader  LZ4.Frame.cs:107-174).
+// The file and the output stay in HBM for the whole call.  Blocks that cannot reference each other (legacy frames:
+// a fresh LzWindows per block, LZ4.cs:164; frames with the block-independence flag) go to the GPU as ONE batch at
+// nominal offsets; blocks of a linked frame share one window (LZ4.Frame.cs:120) and run in order, each with the
+// frame's earlier output as history (alz_stream.aux0).  Checksums are verified as with LZ4.HashAlgorithm = XXH32.
+int lz4_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* dst_len, size_t* src_used, int32_t* status) {
+    DevBuf d_src(ctx), d_dst(ctx);
+    int rc;
+    if ((rc = alz_device_malloc(ctx, len + 64, &d_src.p)) != ALZ_OK) return rc;
+    if ((rc = alz_device_malloc(ctx, cap + 64, &d_dst.p)) != ALZ_OK) return rc;
+    if (len && (rc = alz_memcpy_h2d(ctx, d_src.p, src, len)) != ALZ_OK) return rc;
+    size_t pos = 0, out = 0; int32_t st = ALZ_ST_OK;
+
+    // runs `n` streams and returns their results
+    auto run = [&](std::vector<alz_stream>& ss, std::vector<alz_result>& rs) -> int {
+        alz_plan* pl = nullptr; rs.resize(ss.size());
+        int e = alz_plan_create(ctx, nullptr, (uint32_t)ss.size(), ss.data(), &pl);
+        if (e != ALZ_OK) return e;
+        e = alz_plan_execute(ctx, pl, d_src.p, d_dst.p, nullptr);
+        if (e == ALZ_OK) e = alz_plan_results(ctx, pl, rs.data());
+        alz_plan_destroy(ctx, pl);
+        return e;
+    };
+    // blocks in order, each seeing `out - origin` bytes of history when `linked`
+    auto run_sequential = [&](const std::vector<Lz4Block>& bl, size_t first, size_t origin, bool linked) -> int {
+        for (size_t i = first; i < bl.size() && st == ALZ_ST_OK; i++) {
+            if (bl[i].raw) {
+                if (out + bl[i].len > cap) { st = ALZ_ST_OUTPUT_CAPACITY; break; }
+                int e = alz_memcpy_h2d(ctx, (uint8_t*)d_dst.p + out, src + bl[i].off, bl[i].len); if (e != ALZ_OK) return e;
+                out += bl[i].len; continue;
+            }
+            std::vector<alz_stream> ss(1); std::vector<alz_result> rs;
+            memset(&ss[0], 0, sizeof(alz_stream));
+            const size_t hist = linked ? out - origin : 0;
+            ss[0].src_off = bl[i].off; ss[0].src_len = bl[i].len; ss[0].dst_off = out; ss[0].dst_cap = clamp32(out < cap ? cap - out : 0);
+            if ((uint64_t)ss[0].dst_cap + hist > 0xFFFFFF00ull) return ALZ_E_UNSUPPORTED;
+            ss[0].aux0 = (uint32_t)hist; ss[0].format = ALZ_FMT_LZ4_BLOCK;
+            int e = run(ss, rs); if (e != ALZ_OK) return e;
+            out += rs[0].dst_len;
+            if (rs[0].status != ALZ_ST_OK) st = rs[0].status;
+        }
+        return ALZ_OK;
+    };
+    // independent blocks: one batch, block k at origin + k * nominal; falls back to in-order decoding from the first
+    // block that did not fill its nominal slot
+    auto run_independent = [&](const std::vector<Lz4Block>& bl, uint32_t nominal) -> int {
+        if (bl.size() <= 1) return run_sequential(bl, 0, out, false);
+        const size_t origin = out;
+        std::vector<alz_stream> ss; std::vector<size_t> idx;
+        for (size_t i = 0; i < bl.size(); i++) {
+            const size_t o = origin + i * (size_t)nominal;
+            if (bl[i].raw) continue;
+            alz_stream s; memset(&s, 0, sizeof(s));
+            s.src_off = bl[i].off; s.src_len = bl[i].len; s.dst_off = o < cap ? o : cap;
+            s.dst_cap = clamp32(o < cap ? (cap - o < nominal ? cap - o : nominal) : 0); s.format = ALZ_FMT_LZ4_BLOCK;
+            ss.push_back(s); idx.push_back(i);
+        }
+        std::vector<alz_result> rs;
+        if (!ss.empty()) { int e = run(ss, rs); if (e != ALZ_OK) return e; }
+        size_t k = 0;
+        for (size_t i = 0; i < bl.size(); i++) {
+            const size_t o = origin + i * (size_t)nominal;
+            uint32_t produced; int32_t bst = ALZ_ST_OK;
+            if (bl[i].raw) {
+                produced = bl[i].len;
+                if (out != o || out + produced > cap) return run_sequential(bl, i, origin, false);
+                int e = alz_memcpy_h2d(ctx, (uint8_t*)d_dst.p + out, src + bl[i].off, produced); if (e != ALZ_OK) return e;
+            } else { produced = rs[k].dst_len; bst = rs[k].status; k++; if (out != o) return run_sequential(bl, i, origin, false); }
+            if (bst == ALZ_ST_OUTPUT_CAPACITY && o + nominal <= cap) return run_sequential(bl, i, origin, false);   // the block is larger than nominal
+            out = o + produced;
+            if (bst != ALZ_ST_OK) { st = bst; return ALZ_OK; }
+        }
+        return ALZ_OK;
+    };
+
+    while (pos < len && st == ALZ_ST_OK) {
+        if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t magic = le32(src + pos); pos += 4;
+    again:
+        if (magic == 0x184C2102u) {                                                      // legacy  LZ4.cs:96-111
+            if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            uint32_t bs = le32(src + pos); pos += 4;
+            std::vector<Lz4Block> bl; bool next = false, eof_flag = false, trunc = false;
+            for (;;) {
+                if (bs > len - pos) { trunc = true; break; }
+                bl.push_back(Lz4Block{ pos, bs, false }); pos += bs;
+                if (pos >= len) break;                                                   // ReadByte() == -1
+                if (src[pos] == 0xFF) { pos++; eof_flag = true; break; }                 // (sbyte)0xFF == -1: the EOF flag
+                if (pos + 4 > len) { trunc = true; break; }
+                bs = le32(src + pos); pos += 4;
+                if (lz4_magic_defined(bs)) { next = true; break; }
+            }
+            if ((rc = run_independent(bl, 0x800000u)) != ALZ_OK) return rc;
+            if (st == ALZ_ST_OK && trunc) st = ALZ_ST_INPUT_TRUNCATED;
+            if (st != ALZ_ST_OK) break;
+            if (next) { magic = bs; goto again; }
+            (void)eof_flag;
+            break;                                                                       // blockSize == 0: Decompress returns
+        } else if (magic == 0x184D2204u) {                                               // frame  LZ4.Frame.cs:107-174
+            const size_t frame_start = out;
+            if (pos + 2 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            const uint32_t flg = src[pos], bd = src[pos + 1]; pos += 2;
+            uint32_t bmax;
+            switch ((bd & 0x70) >> 4) { case 4: bmax = 0x10000; break; case 5: bmax = 0x40000; break; case 6: bmax = 0x100000; break; case 7: bmax = 0x400000; break; default: return ALZ_E_FORMAT; }
+            uint64_t content = 0;
+            if (flg & 8) { if (pos + 8 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; } content = (uint64_t)le32(src + pos) | ((uint64_t)le32(src + pos + 4) << 32); pos += 8; }
+            if (flg & 1) { if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; } pos += 4; }
+            if (pos + 1 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            pos += 1;                                                                    // HeaderChecksum: read, not verified
+            if (flg & 1) return ALZ_E_UNSUPPORTED;                                       // external dictionaries  LZ4.Frame.cs:113-114
+            std::vector<Lz4Block> bl; bool trunc = false;
+            for (;;) {
+                if (pos + 4 > len) { trunc = true; break; }
+                const uint32_t bsz = le32(src + pos); pos += 4;
+                if (bsz == 0) break;                                                     // EndMark
+                const bool raw = (bsz & 0x80000000u) != 0; const uint32_t n = bsz & 0x7FFFFFFFu;
+                if (n > bmax) return ALZ_E_FORMAT;
+                if (n > len - pos) { trunc = true; break; }
+                const size_t boff = pos; pos += n;
+                if (flg & 16) {                                                          // block checksum over the stored bytes
+                    if (pos + 4 > len) { trunc = true; break; }
+                    if (le32(src + pos) != xxh32(src + boff, n, 0)) return ALZ_E_CHECKSUM;
+                    pos += 4;
+                }
+                bl.push_back(Lz4Block{ boff, n, raw });
+            }
+            if (flg & 32) rc = run_independent(bl, bmax); else rc = run_sequential(bl, 0, frame_start, true);
+            if (rc != ALZ_OK) return rc;
+            if (st == ALZ_ST_OK && trunc) st = ALZ_ST_INPUT_TRUNCATED;
+            if (st != ALZ_ST_OK) break;
+            if ((flg & 8) && (uint64_t)(out - frame_start) != content) { st = ALZ_ST_OUTPUT_SIZE_MISMATCH; break; }   // LZ4.Frame.cs:152-155
+            if (flg & 4) {                                                               // content checksum
+                if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                if (out > frame_start && (rc = alz_memcpy_d2h(ctx, dst + frame_start, (uint8_t*)d_dst.p + frame_start, out - frame_start)) != ALZ_OK) return rc;
+                if (le32(src + pos) != xxh32(dst + frame_start, out - frame_start, 0)) return ALZ_E_CHECKSUM;
+                pos += 4;
+            }
+        } else if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {                        // skippable
+            if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            const uint32_t n = le32(src + pos); pos += 4;
+            pos = (uint64_t)pos + n > len ? len : pos + n;
+        } else { pos -= 4; break; }                                                      // not a frame: stop in front of it
+    }
+    if (out && (rc = alz_memcpy_d2h(ctx, dst, d_dst.p, out)) != ALZ_OK) return rc;
+    if (dst_len) *dst_len = out;
+    if (src_used) *src_used = pos;
+    if (status) *status = st;
+    return st == ALZ_ST_OK ? ALZ_OK : ALZ_E_STREAM;
+}
+
+// Compresses `n` bytes as independent blocks of `block` bytes in ONE GPU batch; block i's compressed bytes land at
+// tmp + i * slot.  (LZ4: a new LzChainMatchFinder per block, LZ4.cs:205; Snappy: matchFinder.Reset() per chunk, :86)
+int encode_blocks(alz_ctx* ctx, uint32_t fmt, const alz_settings* st, const uint8_t* src, size_t n, size_t block, std::vector<uint8_t>& tmp, size_t& slot,
+                  std::vector<alz_result>& rs) {
+    const size_t nb = (n + block - 1) / block;
+    slot = (block + block / 4 + 64 + 255) & ~(size_t)255;
+    tmp.resize(nb * slot + 64);
+    std::vector<alz_stream> ss(nb); rs.resize(nb);
+    for (size_t i = 0; i < nb; i++) {
+        memset(&ss[i], 0, sizeof(alz_stream));
+        ss[i].src_off = i * block; ss[i].src_len = (uint32_t)(n - i * block < block ? n - i * block : block);
+        ss[i].dst_off = i * slot; ss[i].dst_cap = (uint32_t)slot; ss[i].format = fmt;
+    }
+    return nb ? alz_encode_batch(ctx, nullptr, st, (uint32_t)nb, src, n, ss.data(), tmp.data(), tmp.size(), rs.data(), nullptr) : ALZ_OK;
+}
+
+// LZ4.Compress  LZ4.cs:113-160 (legacy) / CompressLZ4FrameHeader  LZ4.Frame.cs:176-229.  `Flags &= IsVersion1`
+// (LZ4.Frame.cs:184) leaves only the version bit: the frame written never carries a content size or checksums.
+int lz4_file_compress(alz_ctx* ctx, bool legacy, uint32_t block_size, const alz_settings* st, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* dst_len) {
+    size_t o = 0;
+    if (cap < 16) return ALZ_E_NOMEM;
+    if (legacy) { wr32(dst, 0x184C2102u, false); o = 4; block_size = 0x800000u; }       // (int)BlockMaxSizes.Block4MB * 2
+    else {
+        uint8_t bdb;
+        switch (block_size) { case 0: block_size = 0x400000; bdb = 0x70; break; case 0x10000: bdb = 0x40; break; case 0x40000: bdb = 0x50; break;
+                              case 0x100000: bdb = 0x60; break; case 0x400000: bdb = 0x70; break; default: return ALZ_E_INVALID; }
+        wr32(dst, 0x184D2204u, false); dst[4] = 0x40; dst[5] = bdb; dst[6] = (uint8_t)((xxh32(dst + 4, 2, 0) >> 8) & 0xFF); o = 7;
+    }
+    if (n && n % block_size != 0 && n % block_size < 5) return ALZ_E_INVALID;            // source.Slice(0, Length - 5) throws  LZ4.cs:208
+    std::vector<uint8_t> tmp; std::vector<alz_result> rs; size_t slot = 0;
+    int rc = encode_blocks(ctx, ALZ_FMT_LZ4_BLOCK, st, src, n, block_size, tmp, slot, rs);
+    if (rc != ALZ_OK) return rc;
+    for (size_t i = 0; i < rs.size(); i++) {
+        const size_t bl = n - i * block_size < block_size ? n - i * block_size : block_size;
+        if (rs[i].status != ALZ_ST_OK) return rs[i].status == ALZ_ST_OUTPUT_CAPACITY ? ALZ_E_NOMEM : ALZ_E_INVALID;
+        if (!legacy && rs[i].dst_len >= block_size) {                                    // buffer.Position >= (int)BlockSize: stored
+            if (o + 4 + bl > cap) return ALZ_E_NOMEM;
+            wr32(dst + o, (uint32_t)bl | 0x80000000u, false); memcpy(dst + o + 4, src + i * block_size, bl); o += 4 + bl;
+        } else {
+            if (o + 4 + rs[i].dst_len > cap) return ALZ_E_NOMEM;
+            wr32(dst + o, rs[i].dst_len, false); memcpy(dst + o + 4, tmp.data() + i * slot, rs[i].dst_len); o += 4 + rs[i].dst_len;
+        }
+    }
+    if (legacy) { if (o + 1 > cap) return ALZ_E_NOMEM; dst[o++] = 0xFF; }                // EOF flag
+    else { if (o + 4 > cap) return ALZ_E_NOMEM; wr32(dst + o, 0, false); o += 4; }       // EndMark
+    if (dst_len) *dst_len = o;
+    return ALZ_OK;
+}
+
+inline uint32_t snappy_varint(const uint8_t* p, size_t len, size_t* used) {            // Snappy.ReadDecompressedSize  Snappy.cs:109-122
+    uint32_t v = 0; int shift = 0; size_t i = 0; int b = 0x80;
+    while ((b & 0x80) && i < len) { b = p[i++]; if (shift < 32) v |= (uint32_t)(b & 0x7F) << shift; shift += 7; }
+    if (used) *used = i;
+    return v;
+}
+
+// Snappy.Decompress  Formats/Common/Snappy.cs:39-69.  Every compressed chunk declares its size, so all chunks of a file
+// decode as ONE GPU batch; CRCs are skipped as in the reference.  The managed decoder continues wherever a chunk's body
+// stopped; here a chunk whose body does not end at its declared length is refused (ALZ_E_FORMAT).
+int snappy_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* dst_len, size_t* src_used, int32_t* status) {
+    if (len < 10 || memcmp(src, kSnappyId, 10)) return ALZ_E_FORMAT;
+    size_t pos = 10; uint64_t out = 0; int32_t st = ALZ_ST_OK;
+    std::vector<alz_stream> ss; std::vector<uint32_t> clen;
+    struct Raw { size_t off; uint32_t n; uint64_t out; }; std::vector<Raw> raws;
+    while (pos < len) {
+        if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+        const uint32_t type = src[pos], cl = (uint32_t)src[pos + 1] | ((uint32_t)src[pos + 2] << 8) | ((uint32_t)src[pos + 3] << 16); pos += 4;
+        if (type == 0) {
+            if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            const size_t body = pos + 4;
+            const uint32_t size = snappy_varint(src + body, len - body, nullptr);
+            alz_stream s; memset(&s, 0, sizeof(s));
+            s.src_off = body; s.src_len = clamp32(len - body); s.dst_off = out < cap ? out : cap;
+            s.dst_cap = clamp32(out < cap ? (cap - out < size ? cap - out : size) : 0); s.format = ALZ_FMT_SNAPPY_RAW;
+            ss.push_back(s); clen.push_back(cl);
+            out += size; pos = (uint64_t)pos + cl > len ? len : pos + cl;
+        } else if (type == 1) {
+            if (pos + 4 > len || cl < 4) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            uint32_t n = cl - 4; if (n > len - pos - 4) n = (uint32_t)(len - pos - 4);    // SubStream.CopyTo copies what is there
+            raws.push_back(Raw{ pos + 4, n, out }); out += n; pos += 4 + n;
+        } else {
+            if (type >= 0x02 && type <= 0x7F) return ALZ_E_FORMAT;                       // reserved unskippable chunk  Snappy.cs:61-62
+            pos = (uint64_t)pos + cl > len ? len : pos + cl;
+        }
+    }
+    std::vector<alz_result> rs(ss.size());
+    if (!ss.empty()) { int rc = alz_decode_batch(ctx, nullptr, (uint32_t)ss.size(), src, len, ss.data(), dst, cap, rs.data()); if (rc != ALZ_OK) return rc; }
+    // first failing chunk in file order decides status and length
+    size_t produced = (size_t)(out < cap ? out : cap); int32_t fst = ALZ_ST_OK; uint64_t fail_at = ~0ull;
+    for (size_t i = 0; i < ss.size(); i++) {
+        const uint32_t size = snappy_varint(src + ss[i].src_off, len - ss[i].src_off, nullptr);
+        int32_t cs = rs[i].status;
+        if (cs == ALZ_ST_OK && rs[i].dst_len < size) cs = ALZ_ST_OUTPUT_CAPACITY;        // the declared size did not fit dst
+        if (cs == ALZ_ST_OK && (uint64_t)rs[i].src_used + 4 != clen[i]) return ALZ_E_FORMAT;
+        if (cs != ALZ_ST_OK) { fst = cs; fail_at = ss[i].dst_off; produced = (size_t)(ss[i].dst_off + rs[i].dst_len); break; }
+    }
+    for (const Raw& r : raws) {
+        if (r.out >= fail_at) break;
+        if (r.out + r.n > cap) { if (fst == ALZ_ST_OK || r.out < fail_at) { fst = ALZ_ST_OUTPUT_CAPACITY; produced = (size_t)r.out; } break; }
+        memcpy(dst + r.out, src + r.off, r.n);
+    }
+    if (fst == ALZ_ST_OK && st != ALZ_ST_OK) fst = st;
+    if (dst_len) *dst_len = produced;
+    if (src_used) *src_used = pos;
+    if (status) *status = fst;
+    return fst == ALZ_ST_OK ? ALZ_OK : ALZ_E_STREAM;
+}
+
+// Snappy.Compress  Formats/Common/Snappy.cs:71-107
+int snappy_file_compress(alz_ctx* ctx, const alz_settings* st, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* dst_len) {
+    if (cap < 10) return ALZ_E_NOMEM;
+    memcpy(dst, kSnappyId, 10);
+    size_t o = 10;
+    std::vector<uint8_t> tmp; std::vector<alz_result> rs; size_t slot = 0;
+    int rc = encode_blocks(ctx, ALZ_FMT_SNAPPY_RAW, st, src, n, 0x10000, tmp, slot, rs);
+    if (rc != ALZ_OK) return rc;
+    for (size_t i = 0; i < rs.size(); i++) {
+        const size_t cs = n - i * 0x10000 < 0x10000 ? n - i * 0x10000 : 0x10000;
+        if (rs[i].status != ALZ_ST_OK) return ALZ_E_INVALID;
+        const uint32_t crc = snappy_crc_mask(crc32c(src + i * 0x10000, cs));
+        const bool stored = rs[i].dst_len >= cs;                                         // buffer.Length >= chunkSize
+        const size_t body = stored ? cs : rs[i].dst_len;
+        if (o + 8 + body > cap) return ALZ_E_NOMEM;
+        dst[o] = stored ? 1 : 0;
+        dst[o + 1] = (uint8_t)(body + 4); dst[o + 2] = (uint8_t)((body + 4) >> 8); dst[o + 3] = (uint8_t)((body + 4) >> 16);
+        wr32(dst + o + 4, crc, false);
+        memcpy(dst + o + 8, stored ? src + i * 0x10000 : tmp.data() + i * slot, body);
+        o += 8 + body;
+    }
+    if (dst_len) *dst_len = o;
+    return ALZ_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -132,6 +457,20 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZSEGA: if (len < 8) return ALZ_E_FORMAT; *size_out = le32(src + 4); return ALZ_OK;                                        // LZSega.cs:41-46
     case ALZ_C_LEVEL5LZSS: if (len < 16 || memcmp(src, "SSZL", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 12); return ALZ_OK;        // Level5LZSS.cs:33-39
     case ALZ_C_LZON: if (len < 12 || memcmp(src, kLzonMagic, 8)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return ALZ_OK;            // LZOn.cs:33-38
+    case ALZ_C_LZ4_FRAME:   // not an IProvidesDecompressedSize in the reference; offered where the descriptor carries ContentSize
+        if (len < 15 || le32(src) != 0x184D2204u || !(src[4] & 8) || le32(src + 10) != 0) return ALZ_E_UNSUPPORTED;
+        *size_out = le32(src + 6); return ALZ_OK;
+    case ALZ_C_SNAPPY: {    // same: the sum of the chunks' declared sizes
+        if (len < 10 || memcmp(src, kSnappyId, 10)) return ALZ_E_FORMAT;
+        size_t pos = 10; uint64_t total = 0;
+        while (pos + 4 <= len) {
+            const uint32_t type = src[pos], cl = (uint32_t)src[pos + 1] | ((uint32_t)src[pos + 2] << 8) | ((uint32_t)src[pos + 3] << 16); pos += 4;
+            if (type == 0) total += pos + 4 <= len ? snappy_varint(src + pos + 4, len - pos - 4, nullptr) : 0;
+            else if (type == 1) total += cl >= 4 ? cl - 4 : 0;
+            pos += cl;
+        }
+        *size_out = (uint32_t)total; return ALZ_OK;
+    }
     case ALZ_C_LZ77: {                                                                                                                     // LZ77.cs:45-54
         if (len < 8 || memcmp(src, "LZ77", 4)) return ALZ_E_FORMAT;
         uint32_t s = (uint32_t)src[5] | ((uint32_t)src[6] << 8) | ((uint32_t)src[7] << 16);
@@ -156,7 +495,8 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_PRS: return len > 0x4 && prs_byte_order(src, len) != 0;                      // PRS.cs:33-34
     case ALZ_C_LZO: { if (len == 0) return 0; int f = src[0]; return (f > 11 && f < 0x20) || f < 0x10; }   // LZO.cs:33-39 (no extension given)
     case ALZ_C_LZ4_LEGACY: return len > 0x10 && le32(src) == 0x184C2102u;                   // LZ4Legacy.cs:28-29
-    case ALZ_C_SNAPPY: { static const uint8_t id[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 }; return len > 0x10 && !memcmp(src, id, 10); }  // Snappy.cs:36-37
+    case ALZ_C_LZ4_FRAME: return len > 0x10 && lz4_magic_defined(le32(src));                // LZ4.cs:38-39
+    case ALZ_C_SNAPPY: return len > 0x10 && !memcmp(src, kSnappyId, 10);                    // Snappy.cs:36-37
     case ALZ_C_GCLZ: return len > 0x8 && !memcmp(src, "GCLZ", 4) && alz_container_is_match(ALZ_C_LZ10, src + 4, len - 4);
     case ALZ_C_CXLZ: return len > 0x8 && !memcmp(src, "CXLZ", 4) && alz_container_is_match(ALZ_C_LZ10, src + 4, len - 4);
     case ALZ_C_LZ_3DS: return len > 0x10 && !memcmp(src, "3DS-LZ\r\n", 8);
@@ -218,6 +558,10 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
     case ALZ_C_LZO:                                                                         // LZO.cs:42-43
         rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src, len, 0, 0, 0, dst, dst_cap, &r);
         break;
+    case ALZ_C_LZ4_LEGACY: case ALZ_C_LZ4_FRAME:                                            // LZ4Legacy.Decompress -> LZ4.Decompress
+        return lz4_file_decompress(ctx, src, len, dst, dst_cap, dst_len, src_used, status);
+    case ALZ_C_SNAPPY:
+        return snappy_file_decompress(ctx, src, len, dst, dst_cap, dst_len, src_used, status);
     case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                 // magic + inner file  GCLZ.cs:47-51
         const char* magic = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
         const size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4;
@@ -325,7 +669,8 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
 }
 
 size_t alz_container_compress_bound(uint32_t container, size_t n) {
-    (void)container;
+    if (container == ALZ_C_SNAPPY) return 10 + n + (n / 0x10000 + 1) * 8 + 64;      // stored chunks bound the size
+    if (container == ALZ_C_LZ4_FRAME || container == ALZ_C_LZ4_LEGACY) return n + n / 200 + (n / 0x10000 + 1) * 8 + 64;
     return n + n / 4 + 64;   // flag-byte formats: <= 9/8 n + header; LZ4/LZO/Snappy literal-run overhead n/255
 }
 
@@ -338,6 +683,9 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
     // ---- wrappers that prepend a magic to another container / have their own small header
     switch (container) {
+    case ALZ_C_LZ4_LEGACY: return lz4_file_compress(ctx, true, 0, &st, src, n, dst, cap, dst_len);
+    case ALZ_C_LZ4_FRAME: return lz4_file_compress(ctx, false, opt ? opt->chunk_size : 0, &st, src, n, dst, cap, dst_len);
+    case ALZ_C_SNAPPY: return snappy_file_compress(ctx, &st, src, n, dst, cap, dst_len);
     case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                 // GCLZ.cs:40-44
         const char* magic = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
         const size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4;

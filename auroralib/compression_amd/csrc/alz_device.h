@@ -127,6 +127,17 @@ struct OutWin {
     }
     __device__ __forceinline__ u32 slot(u32 q) const { return (q + oshift) & lw_mask; }
 
+    // History (LZ4 frames with linked blocks, LZ4.Frame.cs:120: one LzWindows for all blocks of a frame): the caller
+    // passed dst - hist as `dst`; the first `hist` bytes are output of earlier blocks and count as already produced.
+    // The most recent LW of them are loaded into the ring, older ones are reached through the HBM read-back path.
+    __device__ void preload(u32 hist) {
+        const u32 lw = lw_mask + 1;
+        const u32 n = hist < lw ? hist : lw;
+        for (u32 i = (u32)lane; i < n; i += ALZ_WAVE) { const u32 pos = hist - n + i; win[slot(pos)] = dst[pos]; }
+        wave_sync();
+        produced = hist; flushed = hist;
+    }
+
     // store [flushed, limit) to HBM; 16 B granules aligned in LDS and HBM, ragged ends bytewise
     __device__ void flush_to(u32 limit) {
         wave_sync();

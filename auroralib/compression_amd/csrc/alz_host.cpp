@@ -162,6 +162,10 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
     std::vector<uint32_t> cnt(ALZ_FMT_COUNT, 0);
     for (uint32_t i = 0; i < n; i++) {
         if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
+        if (streams[i].format == ALZ_FMT_LZ4_BLOCK && streams[i].aux0) {   // history in front of dst_off
+            if (streams[i].aux0 > streams[i].dst_off) return fail(ALZ_E_INVALID, "stream %u: history %u exceeds dst_off", i, streams[i].aux0);
+            if ((uint64_t)streams[i].aux0 + streams[i].dst_cap > 0xFFFFFF00ull) return fail(ALZ_E_UNSUPPORTED, "stream %u: history + dst_cap exceed 4 GiB", i);
+        }
         cnt[streams[i].format]++;
     }
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8))
@@ -287,6 +291,10 @@ int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, con
     if ((rc = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return rc;
     if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return rc;
     if (src_bytes) HIP_TRY(hipMemcpyAsync(c->d_src, src_base, src_bytes, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t i = 0; i < n; i++)   // LZ4 blocks that continue a frame's window: their history has to be in HBM too
+        if (streams[i].format == ALZ_FMT_LZ4_BLOCK && streams[i].aux0 && streams[i].aux0 <= streams[i].dst_off)
+            HIP_TRY(hipMemcpyAsync((uint8_t*)c->d_dst + streams[i].dst_off - streams[i].aux0, dst_base + streams[i].dst_off - streams[i].aux0,
+                                   streams[i].aux0, hipMemcpyHostToDevice, c->stream));
     alz_plan* p = nullptr;
     if ((rc = alz_plan_create(c, props, n, streams, &p))) return rc;
     rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);

@@ -16,8 +16,8 @@
 #endif
 
 template <bool FB>
-__device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status) {
-    if (lane == 0) { r->dst_len = out.produced; r->src_used = src_used; r->status = status; r->reserved = 0; }
+__device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status, u32 hist = 0) {
+    if (lane == 0) { r->dst_len = out.produced - hist; r->src_used = src_used; r->status = status; r->reserved = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -35,10 +35,15 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
     u8* dst = dst_base + st.dst_off;
-    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
+    const u32 src_len = uni(st.src_len), size = uni(st.decom_len);
+    u32 cap = uni(st.dst_cap);
+    // LZ4 block with history (alz_stream.aux0): the stream continues the window of earlier blocks of its frame
+    const u32 hist = (FMT == ALZ_FMT_LZ4_BLOCK) ? uni(st.aux0) : 0u;
+    dst -= hist; cap += hist;
 
     u8* lds = reinterpret_cast<u8*>(smem);
     OutWin<FB> out; out.init(dst, cap, lds, lw, lane);
+    if (hist) out.preload(hist);
     u8* inc_lds = lds + lw;
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         dec_snappy_serial(in, sk, s, src_len);
     }
     out.finish();
-    write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap));
+    write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap), hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -164,12 +169,16 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
     u8* dst = dst_base + st.dst_off;
-    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap);
+    const u32 src_len = uni(st.src_len);
+    u32 cap = uni(st.dst_cap);
+    const u32 hist = (FMT == ALZ_FMT_LZ4_BLOCK) ? uni(st.aux0) : 0u;      // LZ4 frames with linked blocks (see OutWin::preload)
+    dst -= hist; cap += hist;
     u8* segmark = lds;
     u32* stage = reinterpret_cast<u32*>(lds + 128);
     u8* inc_lds = lds + 384;
     typedef OutWin<!PRS> OW;
     OW out; out.init(dst, cap, lds + 384 + ALZ_INCACHE_BYTES, LW, lane);
+    if (hist) out.preload(hist);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     else dec_snappy_serial(in, sk, s, src_len);
     sk.flush();                                    // tokens parsed before an error/terminator are part of the output
     out.finish();
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0, cap));
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0, cap), hist);
 }
 
 // ------------------------------------------------------------------------------------------------

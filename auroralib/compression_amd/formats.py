@@ -22,6 +22,10 @@ class InvalidIdentifierException(ValueError):
     pass
 
 
+class InvalidDataException(ValueError):
+    """System.IO.InvalidDataException (LZ4 frame checksum mismatch, LZ4.Frame.cs:27)."""
+
+
 class CompressionSettings:
     """src/AuroraLib.Compression/CompressionSettings.cs:11-84"""
 
@@ -84,10 +88,20 @@ class _Format:
         return size.value
 
     def Decompress(self, data, capacity=None):
-        """ICompressionDecoder.Decompress: returns the decompressed bytes; raises the reference's exception types."""
+        """ICompressionDecoder.Decompress: returns the decompressed bytes; raises the reference's exception types.
+        Formats without a size field grow the destination until it fits (a managed Stream grows by itself)."""
         data = bytes(data)
+        if capacity is None and not self.provides_size:
+            cap = max(len(data) * 8, 1 << 16)
+            while True:
+                try:
+                    return self.Decompress(data, cap)
+                except BufferError:
+                    if cap >= 1 << 31:
+                        raise
+                    cap *= 4
         if capacity is None:
-            capacity = self.GetDecompressedSize(data) + 273 if self.provides_size else max(len(data) * 40, 1 << 16)
+            capacity = self.GetDecompressedSize(data) + 273
         o = self._opt()
         dst = C.create_string_buffer(max(capacity, 1))
         dl, su, st = C.c_size_t(), C.c_size_t(), C.c_int32()
@@ -96,6 +110,8 @@ class _Format:
         rc = lib.alz_container_decompress(_context().h, self.container, C.byref(o), data, len(data), dst, capacity, C.byref(dl), C.byref(su), C.byref(st))
         if rc == A.E_FORMAT:
             raise InvalidIdentifierException()
+        if rc == A.E_CHECKSUM:
+            raise InvalidDataException("Checksum mismatch")
         if rc == A.E_STREAM:
             if st.value == A.ST_INPUT_TRUNCATED:
                 raise EndOfStreamException()
@@ -202,6 +218,31 @@ class LZOn(_Format):
     container = A.C_LZON
 
 
+class LZ4(_Format):
+    """src/AuroraLib.Compression/Formats/Common/LZ4.cs + LZ4.Frame.cs: frame (default), legacy and skippable frames.
+    BlockSize: 0x10000 / 0x40000 / 0x100000 / 0x400000 (default).  As in the reference, Compress writes a descriptor with
+    only the version flag (`Flags &= IsVersion1`, LZ4.Frame.cs:184)."""
+    container = A.C_LZ4_FRAME
+    provides_size = False
+    Block64KB, Block256KB, Block1MB, Block4MB = 0x10000, 0x40000, 0x100000, 0x400000
+
+    def __init__(self, BlockSize=0):
+        super().__init__()
+        self.ChunkSize = BlockSize
+
+
+class LZ4Legacy(_Format):
+    """src/AuroraLib.Compression/Formats/Common/LZ4Legacy.cs"""
+    container = A.C_LZ4_LEGACY
+    provides_size = False
+
+
+class Snappy(_Format):
+    """src/AuroraLib.Compression/Formats/Common/Snappy.cs (framing format, 64 KiB chunks)."""
+    container = A.C_SNAPPY
+    provides_size = False
+
+
 class LZ77(_Format):
     """src/AuroraLib.Compression.Nintendo/Nintendo/LZ77.cs -- Type: LZ10 (default) / LZ11 / ChunkLZ10."""
     container = A.C_LZ77
@@ -213,5 +254,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, LZ77, Level5]
-__all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "AlzError"]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, LZ77, Level5]
+__all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

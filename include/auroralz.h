@@ -65,6 +65,7 @@ typedef enum alz_status {
 #define ALZ_E_UNSUPPORTED -5
 #define ALZ_E_FORMAT     -6  /* container header invalid (InvalidIdentifierException) */
 #define ALZ_E_STREAM     -7  /* single-stream helper: per-stream status != OK (status is returned separately) */
+#define ALZ_E_CHECKSUM   -8  /* LZ4 frame block / content checksum mismatch (InvalidDataException, LZ4.Frame.cs:22-28) */
 
 /*
  * LzProperties of the generic LZSS body (src/AuroraLib.Compression/LzProperties.cs:9-97).
@@ -91,8 +92,12 @@ typedef struct alz_lz_properties {
  *             (LZSS/LZ10/LZ11/YAZ0/YAY0/MIO0).  Ignored by PRS/LZ4/LZO (no size
  *             field, terminated by token / end of input) and by SNAPPY_RAW
  *             (varint inside the body).
- * aux0/aux1 : YAY0/MIO0 only: compressedDataPointer / uncompressedDataPointer
+ * aux0/aux1 : YAY0/MIO0: compressedDataPointer / uncompressedDataPointer
  *             relative to the first flag byte (Yay0.cs:60, MIO0.cs:61).
+ *             LZ4_BLOCK: aux0 = history, the number of bytes in front of dst_off
+ *             (<= dst_off) that are earlier output of the same LZ4 frame and may
+ *             be referenced by matches -- one LzWindows serves all blocks of a
+ *             frame (LZ4.Frame.cs:120).  0 = a fresh window (LZ4.cs:164).
  * dst_cap   : bytes the library may write at dst_off.  Never exceeded.
  */
 typedef struct alz_stream {
@@ -204,9 +209,9 @@ typedef enum alz_container {
     ALZ_C_YAY0   = 4,  /* "Yay0"+size+tokOff+litOff      Yay0.cs:50-77   */
     ALZ_C_MIO0   = 5,  /* "MIO0"+size+tokOff+litOff      MIO0.cs:51-79   */
     ALZ_C_PRS    = 6,  /* headerless                     PRS.cs:38-57    */
-    ALZ_C_LZ4_LEGACY = 7, /* 0x184C2102 + blocks         LZ4.cs:96-111,120-135 */
+    ALZ_C_LZ4_LEGACY = 7, /* LZ4Legacy: 0x184C2102 + u32-sized independent 8 MiB blocks + 0xFF   LZ4Legacy.cs, LZ4.cs:96-111,120-135 */
     ALZ_C_LZO    = 8,  /* headerless                     LZO.cs:42-47    */
-    ALZ_C_SNAPPY = 9,  /* framed "sNaPpY"                Snappy.cs:39-107 */
+    ALZ_C_SNAPPY = 9,  /* framed "sNaPpY": 64 KiB chunks (one GPU batch) + masked CRC-32C   Snappy.cs:39-107 */
     /* header-only wrappers over the same bodies */
     ALZ_C_GCLZ   = 10, /* "GCLZ" + LZ10 file             src/AuroraLib.Compression.Nintendo/Nintendo/GCLZ.cs        */
     ALZ_C_CXLZ   = 11, /* "CXLZ" + LZ10 file             src/AuroraLib.Compression.Nintendo/Sega/CXLZ.cs            */
@@ -220,7 +225,9 @@ typedef enum alz_container {
     ALZ_C_LZON   = 19, /* "LZOn"+002FF171+BE size+csize + LZO  src/AuroraLib.Compression.Nintendo/Nintendo/LZOn.cs:41-79 */
     ALZ_C_LZ77   = 20, /* "LZ77"+type: LZ10 / LZ11 / ChunkLZ10 (independent 4 KiB chunks = one GPU batch)  Nintendo/LZ77.cs:56-153 */
     ALZ_C_LEVEL5 = 21, /* u32 type|size<<3: OnlySave / LZ10   src/AuroraLib.Compression.Nintendo/Level5/Level5.cs:62-146 */
-    ALZ_C_COUNT  = 22
+    ALZ_C_LZ4_FRAME = 22, /* LZ4: frame 0x184D2204 (descriptor, linked or independent blocks, xxHash32 block / content
+                             checksums), legacy and skippable frames, concatenated   LZ4.cs:50-93, LZ4.Frame.cs:107-215 */
+    ALZ_C_COUNT  = 23
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */
@@ -235,7 +242,8 @@ typedef struct alz_container_options {
     uint32_t memory_alignment;    /* Yaz0.MemoryAlignment (Yaz0.cs:39) */
     alz_lz_properties lz;         /* LZSS geometry */
     uint32_t variant;             /* LZ77.Type / Level5.Type when compressing; 0 = the class default (LZ10) */
-    uint32_t chunk_size;          /* LZ77.ChunkSize (default 0x1000) */
+    uint32_t chunk_size;          /* LZ77.ChunkSize (default 0x1000); ALZ_C_LZ4_FRAME: LZ4.BlockSize, one of 0x10000 /
+                                     0x40000 / 0x100000 / 0x400000 (0 = the class default Block4MB, LZ4.cs:33) */
 } alz_container_options;
 
 /* IProvidesDecompressedSize.GetDecompressedSize (Interfaces/IProvidesDecompressedSize.cs:20) */

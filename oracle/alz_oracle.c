@@ -596,6 +596,10 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     int wb = fmt_window_bits(s->format, &lz);
     w.flat = flat; w.W = 1u << wb; w.mask = w.W - 1;
     w.dst = dst_base + s->dst_off; w.cap = s->dst_cap;
+    /* LZ4 block continuing the window of earlier blocks of its frame (alz_stream.aux0 = history bytes in front of
+       dst_off, LZ4.Frame.cs:120): decoded in the flat model with the origin moved back by the history */
+    uint32_t hist = s->format == ALZ_FMT_LZ4_BLOCK ? s->aux0 : 0;
+    if (hist) { flat = 1; w.flat = 1; w.dst -= hist; w.cap += hist; w.flushed = hist; }
     if (!flat) w.ring = (uint8_t*)calloc(w.W, 1); /* E2: zero-filled */
     dec_info info = { 0, 0, 0 };
     int terminated = 1; uint32_t used = 0; int used_set = 0;
@@ -629,7 +633,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     win_dispose(&w);
     if (!flat) free(w.ring);
 
-    uint64_t produced = win_produced(&w);
+    uint64_t produced = win_produced(&w) - hist;
     r->dst_len = (uint32_t)produced;
     r->src_used = used_set ? used : c.pos;
     r->reserved = 0;
@@ -1246,6 +1250,8 @@ static int nin_header(const uint8_t* src, size_t len, uint8_t id, uint32_t* size
     *size = rd32le(src + 4); return 8;
 }
 
+static const uint8_t SNAPPY_ID[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 };
+
 int oracle_container_decompressed_size(uint32_t container, const alz_container_options* opt, const uint8_t* src, size_t len, uint32_t* size_out) {
     int big = opt ? (int)opt->big_endian : 1;
     switch (container) {
@@ -1275,6 +1281,21 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
         *size_out = sz; return 0;
     }
     case ALZ_C_LEVEL5: if (len < 5) return ALZ_E_FORMAT; *size_out = src[4] == 0x78 ? rd32le(src) : rd32le(src) >> 3; return 0;  /* Level5/Level5.cs:55-60 */
+    case ALZ_C_LZ4_FRAME:   /* not an IProvidesDecompressedSize in the reference; offered where the descriptor carries ContentSize */
+        if (len < 15 || rd32le(src) != 0x184D2204u || !(src[4] & 8)) return ALZ_E_UNSUPPORTED;
+        if (rd32le(src + 10) != 0) return ALZ_E_UNSUPPORTED;
+        *size_out = rd32le(src + 6); return 0;
+    case ALZ_C_SNAPPY: {    /* same: the sum of the chunks' declared sizes */
+        if (len < 10 || memcmp(src, SNAPPY_ID, 10)) return ALZ_E_FORMAT;
+        size_t pos = 10; uint64_t total = 0;
+        while (pos + 4 <= len) {
+            uint32_t type = src[pos], cl = (uint32_t)src[pos + 1] | ((uint32_t)src[pos + 2] << 8) | ((uint32_t)src[pos + 3] << 16); pos += 4;
+            if (type == 0) { cur_t c = { src + pos + 4, pos + 4 <= len ? (uint32_t)(len - pos - 4) : 0, 0, 0 }; total += snappy_varint(&c); }
+            else if (type == 1) total += cl >= 4 ? cl - 4 : 0;
+            pos += cl;
+        }
+        *size_out = (uint32_t)total; return 0;
+    }
     default: return ALZ_E_UNSUPPORTED;
     }
 }
@@ -1286,6 +1307,190 @@ static void run_stream(uint32_t format, const alz_lz_properties* lz, const uint8
     s.decom_len = size; s.aux0 = aux0; s.aux1 = aux1; s.format = format;
     decode_one(lz, &s, body, dst, r, 0);
 }
+
+/* ============================================================ LZ4 frame / legacy and Snappy framing */
+
+static int lz4_magic_defined(uint32_t v) {                     /* Enum.IsDefined(typeof(FrameTypes), v)  LZ4.Frame.cs:50-70 */
+    return v == 0x184C2102u || v == 0x184D2204u || (v >= 0x184D2A50u && v <= 0x184D2A5Fu);
+}
+
+/* LZ4.Decompress  Formats/Common/LZ4.cs:50-93, ReadLZ4L :96-111, DecompressLZ4FrameHeader  LZ4.Frame.cs:107-174.
+   Checksums are verified as with LZ4.HashAlgorithm = XXH32 (what the CLI and the test-suite install). */
+static int lz4_file_decompress(const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* dst_len, size_t* src_used, int32_t* status) {
+    size_t pos = 0, out = 0; int32_t st = ALZ_ST_OK; int rc = 0;
+    while (pos < len && st == ALZ_ST_OK && rc == 0) {
+        if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t magic = rd32le(src + pos); pos += 4;
+    again:
+        if (magic == 0x184C2102u) {                                                       /* legacy: independent blocks */
+            if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            uint32_t bs = rd32le(src + pos); pos += 4;
+            int next = 0;
+            for (;;) {
+                if (bs > len - pos) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                alz_result r;
+                run_stream(ALZ_FMT_LZ4_BLOCK, NULL, src + pos, bs, 0, 0, 0, dst + out, out < cap ? cap - out : 0, &r);   /* fresh LzWindows per block  LZ4.cs:164 */
+                out += r.dst_len; pos += bs;
+                if (r.status != ALZ_ST_OK) { st = r.status; break; }
+                if (pos >= len) break;                                                    /* ReadByte() == -1 */
+                if (src[pos] == 0xFF) { pos++; goto done; }                               /* (sbyte)0xFF == -1: the EOF flag; Decompress returns */
+                if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                bs = rd32le(src + pos); pos += 4;
+                if (lz4_magic_defined(bs)) { next = 1; break; }
+            }
+            if (st != ALZ_ST_OK) break;
+            if (next) { magic = bs; goto again; }                                         /* "Mixed LZ4 Legacy and LZ4 Frame" */
+            goto done;                                                                    /* blockSize == 0: EOF */
+        } else if (magic == 0x184D2204u) {
+            size_t frame_start = out;
+            if (pos + 2 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            uint32_t flg = src[pos], bd = src[pos + 1]; pos += 2;
+            uint32_t bmax;
+            switch ((bd & 0x70) >> 4) { case 4: bmax = 0x10000; break; case 5: bmax = 0x40000; break; case 6: bmax = 0x100000; break; case 7: bmax = 0x400000; break; default: return ALZ_E_FORMAT; }
+            uint64_t content = 0;
+            if (flg & 8) { if (pos + 8 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; } content = (uint64_t)rd32le(src + pos) | ((uint64_t)rd32le(src + pos + 4) << 32); pos += 8; }
+            if (flg & 1) { if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; } pos += 4; }
+            if (pos + 1 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            pos += 1;                                                                     /* HeaderChecksum: read, not verified */
+            if (flg & 1) return ALZ_E_UNSUPPORTED;                                        /* external dictionaries  LZ4.Frame.cs:113-114 */
+            /* one window for all blocks of the frame (LZ4.Frame.cs:120): ring mode, exactly LzWindows */
+            win_t w; memset(&w, 0, sizeof(w));
+            w.W = 65536; w.mask = 65535; w.dst = dst + out; w.cap = out < cap ? cap - out : 0;
+            w.ring = (uint8_t*)calloc(w.W, 1);
+            for (;;) {
+                if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                uint32_t bsz = rd32le(src + pos); pos += 4;
+                if (bsz == 0) break;                                                      /* EndMark */
+                int raw = (bsz & 0x80000000u) != 0; uint32_t n = bsz & 0x7FFFFFFFu;
+                if (n > bmax) { rc = ALZ_E_FORMAT; break; }                               /* buffer.AsSpan(0, n) on a BlockMaxSize buffer */
+                if (n > len - pos) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                const uint8_t* blk = src + pos; pos += n;
+                if (flg & 16) {                                                           /* block checksum */
+                    if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                    if (rd32le(src + pos) != oracle_xxh32(blk, n, 0)) { rc = ALZ_E_CHECKSUM; break; }
+                    pos += 4;
+                }
+                if (raw) { uint32_t cl = win_clip(&w, n); win_write(&w, blk, cl); }
+                else { cur_t c = { blk, n, 0, 0 }; dec_lz4(&c, &w); if (c.eof) { st = ALZ_ST_INPUT_TRUNCATED; } }
+                if (w.overflow) { st = ALZ_ST_OUTPUT_CAPACITY; }
+                if (st != ALZ_ST_OK) break;
+            }
+            win_dispose(&w);
+            out += (size_t)win_produced(&w);
+            free(w.ring);
+            if (rc || st != ALZ_ST_OK) break;
+            if ((flg & 8) && (uint64_t)(out - frame_start) != content) { st = ALZ_ST_OUTPUT_SIZE_MISMATCH; break; }   /* LZ4.Frame.cs:152-155 */
+            if (flg & 4) {                                                                /* content checksum */
+                if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+                if (rd32le(src + pos) != oracle_xxh32(dst + frame_start, out - frame_start, 0)) { rc = ALZ_E_CHECKSUM; break; }
+                pos += 4;
+            }
+        } else if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {                         /* skippable */
+            if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            uint32_t n = rd32le(src + pos); pos += 4;
+            pos = (uint64_t)pos + n > len ? len : pos + n;                                /* Position += n (may pass the end: loop ends) */
+        } else { pos -= 4; break; }                                                       /* not a frame: stop in front of it */
+    }
+done:
+    if (dst_len) *dst_len = out;
+    if (src_used) *src_used = pos;
+    if (status) *status = st;
+    if (rc) return rc;
+    return st == ALZ_ST_OK ? 0 : ALZ_E_STREAM;
+}
+
+/* LZ4.Compress  LZ4.cs:113-160 (legacy) / CompressLZ4FrameHeader  LZ4.Frame.cs:176-229.
+   `Flags &= FrameDescriptorFlags.IsVersion1` (LZ4.Frame.cs:184) leaves only the version bit, so the frame written never
+   carries a content size or checksums, whatever LZ4.Flags held. */
+static int lz4_file_compress(int legacy, uint32_t block_size, const alz_settings* st, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* dst_len) {
+    size_t o = 0;
+    if (cap < 16) return ALZ_E_NOMEM;
+    if (legacy) { wr32(dst, 0x184C2102u, 0); o = 4; block_size = 0x800000; }             /* (int)BlockMaxSizes.Block4MB * 2 */
+    else {
+        uint8_t bdb;
+        switch (block_size) { case 0: block_size = 0x400000; bdb = 0x70; break; case 0x10000: bdb = 0x40; break; case 0x40000: bdb = 0x50; break;
+                              case 0x100000: bdb = 0x60; break; case 0x400000: bdb = 0x70; break; default: return ALZ_E_INVALID; }
+        wr32(dst, 0x184D2204u, 0); dst[4] = 0x40; dst[5] = bdb; dst[6] = (uint8_t)((oracle_xxh32(dst + 4, 2, 0) >> 8) & 0xFF); o = 7;
+    }
+    size_t sp = 0;
+    while (sp != n) {
+        size_t bl = n - sp < block_size ? n - sp : block_size;
+        if (bl < 5) return ALZ_E_INVALID;                                                 /* source.Slice(0, Length - 5) throws  LZ4.cs:208 */
+        if (o + 4 > cap) return ALZ_E_NOMEM;
+        int64_t c = oracle_encode_stream(ALZ_FMT_LZ4_BLOCK, NULL, st, src + sp, bl, dst + o + 4, cap - o - 4, NULL);
+        if (c == -1) {                                                                    /* does not fit: it can still be a stored block */
+            if (legacy || o + 4 + bl > cap) return ALZ_E_NOMEM;
+            c = (int64_t)block_size;
+        } else if (c < 0) return ALZ_E_INVALID;
+        if (!legacy && c >= (int64_t)block_size) {                                        /* buffer.Position >= (int)BlockSize: stored */
+            wr32(dst + o, (uint32_t)bl | 0x80000000u, 0); memcpy(dst + o + 4, src + sp, bl); o += 4 + bl;
+        } else { wr32(dst + o, (uint32_t)c, 0); o += 4 + (size_t)c; }
+        sp += bl;
+    }
+    if (legacy) { if (o + 1 > cap) return ALZ_E_NOMEM; dst[o++] = 0xFF; }                 /* EOF flag */
+    else { if (o + 4 > cap) return ALZ_E_NOMEM; wr32(dst + o, 0, 0); o += 4; }            /* EndMark */
+    if (dst_len) *dst_len = o;
+    return 0;
+}
+
+static uint32_t snappy_crc_mask(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + 0xa282ead8u; }   /* Snappy.cs:252 */
+
+/* Snappy.Decompress  Formats/Common/Snappy.cs:39-69: chunks are decoded from where the previous one stopped; CRCs are skipped */
+static int snappy_file_decompress(const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* dst_len, size_t* src_used, int32_t* status) {
+    if (len < 10 || memcmp(src, SNAPPY_ID, 10)) return ALZ_E_FORMAT;
+    size_t pos = 10, out = 0; int32_t st = ALZ_ST_OK;
+    while (pos < len) {
+        if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t type = src[pos], cl = (uint32_t)src[pos + 1] | ((uint32_t)src[pos + 2] << 8) | ((uint32_t)src[pos + 3] << 16); pos += 4;
+        if (type == 0) {
+            if (pos + 4 > len) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            pos += 4;
+            alz_result r;
+            run_stream(ALZ_FMT_SNAPPY_RAW, NULL, src + pos, (uint32_t)(len - pos), 0, 0, 0, dst + out, out < cap ? cap - out : 0, &r);
+            out += r.dst_len; pos += r.src_used;
+            if (r.status != ALZ_ST_OK) { st = r.status; break; }
+        } else if (type == 1) {
+            if (pos + 4 > len || cl < 4) { st = ALZ_ST_INPUT_TRUNCATED; break; }
+            pos += 4;
+            uint32_t n = cl - 4; if (n > len - pos) n = (uint32_t)(len - pos);            /* SubStream.CopyTo copies what is there */
+            if (out + n > cap) { st = ALZ_ST_OUTPUT_CAPACITY; break; }
+            memcpy(dst + out, src + pos, n); out += n; pos += n;
+        } else {
+            if (type >= 0x02 && type <= 0x7F) return ALZ_E_FORMAT;                        /* reserved unskippable chunk */
+            pos = (uint64_t)pos + cl > len ? len : pos + cl;
+        }
+    }
+    if (dst_len) *dst_len = out;
+    if (src_used) *src_used = pos;
+    if (status) *status = st;
+    return st == ALZ_ST_OK ? 0 : ALZ_E_STREAM;
+}
+
+/* Snappy.Compress  Formats/Common/Snappy.cs:71-107: 64 KiB chunks, match finder reset per chunk */
+static int snappy_file_compress(const alz_settings* st, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* dst_len) {
+    if (cap < 10) return ALZ_E_NOMEM;
+    memcpy(dst, SNAPPY_ID, 10);
+    size_t o = 10, pos = 0;
+    uint8_t* tmp = (uint8_t*)malloc(0x10000 + 0x10000 / 6 + 64);
+    while (pos < n) {
+        size_t cs = n - pos < 0x10000 ? n - pos : 0x10000;
+        int64_t c = oracle_encode_stream(ALZ_FMT_SNAPPY_RAW, NULL, st, src + pos, cs, tmp, 0x10000 + 0x10000 / 6 + 64, NULL);
+        if (c < 0) { free(tmp); return ALZ_E_INVALID; }
+        uint32_t crc = snappy_crc_mask(oracle_crc32c(src + pos, cs));
+        int stored = (size_t)c >= cs;
+        size_t body = stored ? cs : (size_t)c;
+        if (o + 8 + body > cap) { free(tmp); return ALZ_E_NOMEM; }
+        dst[o] = stored ? 1 : 0;
+        dst[o + 1] = (uint8_t)(body + 4); dst[o + 2] = (uint8_t)((body + 4) >> 8); dst[o + 3] = (uint8_t)((body + 4) >> 16);
+        wr32(dst + o + 4, crc, 0);
+        memcpy(dst + o + 8, stored ? src + pos : tmp, body);
+        o += 8 + body; pos += cs;
+    }
+    free(tmp);
+    if (dst_len) *dst_len = o;
+    return 0;
+}
+
 
 /* PRS.ValidateByteOrder  Sega/PRS.cs:171-218 */
 static int prs_validate(const uint8_t* src, size_t len, int big) {
@@ -1365,6 +1570,9 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         break;
     }
     case ALZ_C_LZO: run_stream(ALZ_FMT_LZO, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r); break;
+    case ALZ_C_LZ4_LEGACY: case ALZ_C_LZ4_FRAME:                                          /* LZ4Legacy.Decompress -> LZ4.Decompress */
+        return lz4_file_decompress(src, len, dst, dst_cap, dst_len, src_used, status);
+    case ALZ_C_SNAPPY: return snappy_file_decompress(src, len, dst, dst_cap, dst_len, src_used, status);
     case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                /* magic + inner file */
         const char* m = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
         size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4, used = 0;
@@ -1469,6 +1677,9 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
     size_t hdr = 0; int64_t body; alz_encode_aux aux;
     alz_settings st = settings ? *settings : (alz_settings){ 8, 0, 0, 0 };
     switch (container) {
+    case ALZ_C_LZ4_LEGACY: return lz4_file_compress(1, 0, &st, src, n, dst, cap, dst_len);
+    case ALZ_C_LZ4_FRAME: return lz4_file_compress(0, opt ? opt->chunk_size : 0, &st, src, n, dst, cap, dst_len);
+    case ALZ_C_SNAPPY: return snappy_file_compress(&st, src, n, dst, cap, dst_len);
     case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                /* e.g. Nintendo/GCLZ.cs:40-44 */
         const char* m = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
         size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4, inner = 0;

@@ -127,7 +127,9 @@ def container_decompress(container, data, cap=None, big_endian=True, lz=None):
     dl, su, st = C.c_size_t(), C.c_size_t(), C.c_int32()
     rc = lib.oracle_container_decompress(container, C.byref(o), data, len(data), dst, cap, C.byref(dl), C.byref(su), C.byref(st))
     if rc not in (0, A.E_STREAM):
-        raise ValueError("container_decompress rc=%d" % rc)
+        e = ValueError("container_decompress rc=%d" % rc)
+        e.rc = rc
+        raise e
     return dst.raw[:dl.value], st.value
 
 

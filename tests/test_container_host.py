@@ -64,3 +64,85 @@ def test_lz77_chunk_mode_oracle(test_bmp):
     assert st == A.ST_OK and out == raw
     small = O.container_compress(A.C_LZ77, raw[:1000], quality=8, variant=A.LZ77_CHUNKLZ10)   # ChunkSize >= length: plain LZ10 file
     assert small[4] == 0x10
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY.md 8f rank 2
+import struct  # noqa: E402
+
+import framing_cases as FC  # noqa: E402
+
+
+def test_checksum_known_answers():
+    """XXH32 / CRC-32C published test vectors, and the frame-descriptor checksum bytes every `lz4` file starts with."""
+    assert O.xxh32(b"") == 0x02CC5D05 and O.xxh32(b"abc") == 0x32D153FF
+    assert O.crc32c(b"123456789") == 0xE3069283
+    assert (O.xxh32(bytes([0x64, 0x40])) >> 8) & 0xFF == 0xA7      # 04 22 4D 18 64 40 A7: the lz4 CLI's default header
+    assert (O.xxh32(bytes([0x40, 0x70])) >> 8) & 0xFF == 0xDF
+
+
+@pytest.mark.parametrize("container,kw", [(A.C_LZ4_FRAME, {}), (A.C_LZ4_FRAME, {"chunk_size": 0x10000}), (A.C_LZ4_LEGACY, {}), (A.C_SNAPPY, {})])
+def test_framing_oracle_roundtrip(container, kw, test_bmp):
+    """EncodingAndDecodingMatchTest for LZ4 (frame default), LZ4Legacy and Snappy (CompressionAlgorithmTest.cs:81-139)."""
+    for raw, q in ((test_bmp[:10], 4), (test_bmp[:10240], 8), (test_bmp[:10240], 15), (test_bmp[:300000], 0), (bytes(0x100), 0)):
+        comp = O.container_compress(container, raw, quality=q, **kw)
+        out, st = O.container_decompress(container, comp, cap=len(raw) + 64)
+        assert st == A.ST_OK and out == raw
+        cls = {A.C_LZ4_FRAME: F.LZ4, A.C_LZ4_LEGACY: F.LZ4Legacy, A.C_SNAPPY: F.Snappy}[container]
+        if len(comp) > 0x11:
+            assert cls().IsMatch(comp)                                   # DataRecognitionTest (:60-80)
+    comp = O.container_compress(container, test_bmp[:200000], quality=0, **kw)
+    if container == A.C_LZ4_FRAME:
+        bd = 0x40 if kw else 0x70
+        assert comp[:7] == bytes([0x04, 0x22, 0x4D, 0x18, 0x40, bd, (O.xxh32(bytes([0x40, bd])) >> 8) & 0xFF])   # Flags &= IsVersion1
+        assert comp[-4:] == bytes(4)                                      # EndMark, no content checksum
+    elif container == A.C_LZ4_LEGACY:
+        assert comp[:4] == bytes([0x02, 0x21, 0x4C, 0x18]) and comp[-1] == 0xFF
+        assert struct.unpack("<I", comp[4:8])[0] == len(comp) - 9         # one block (< 8 MiB)
+    else:
+        assert comp[:10] == bytes([0xff, 6, 0, 0]) + b"sNaPpY" and comp[10] == 0
+        n0 = int.from_bytes(comp[11:14], "little")
+        assert struct.unpack("<I", comp[14:18])[0] == ((lambda c: (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF)(O.crc32c(test_bmp[:0x10000])))
+        assert comp[10 + 4 + n0] in (0, 1)                                # next chunk header follows the declared length
+
+
+def test_snappy_stored_chunk_and_skippable():
+    import os
+    raw = os.urandom(70000)                                               # incompressible: stored chunks (Snappy.cs:89-96)
+    comp = O.container_compress(A.C_SNAPPY, raw, quality=8)
+    assert comp[10] == 1 and int.from_bytes(comp[11:14], "little") == 0x10000 + 4
+    out, st = O.container_decompress(A.C_SNAPPY, comp, cap=len(raw))
+    assert st == A.ST_OK and out == raw
+    assert O.container_decompressed_size(A.C_SNAPPY, comp) == len(raw)
+    padded = comp[:10] + bytes([0xFE, 3, 0, 0, 1, 2, 3]) + comp[10:]      # skippable chunk 0x80..0xFE
+    out, st = O.container_decompress(A.C_SNAPPY, padded, cap=len(raw))
+    assert st == A.ST_OK and out == raw
+    with pytest.raises(ValueError):                                       # reserved unskippable chunk 0x02..0x7F
+        O.container_decompress(A.C_SNAPPY, comp[:10] + bytes([0x02, 0, 0, 0]) + comp[10:], cap=len(raw))
+
+
+def test_lz4_linked_frame_oracle():
+    """Blocks of a frame share one window (LZ4.Frame.cs:120): matches reach into earlier blocks."""
+    blocks, expect = FC.lz4_linked_blocks(7, 5, 30000)
+    for flg in (0x40, 0x40 | 4 | 16, 0x40 | 8, 0x40 | 4 | 8 | 16):
+        frame = FC.lz4_frame(blocks, O.xxh32, flg=flg, bd=0x40, content=expect)
+        out, st = O.container_decompress(A.C_LZ4_FRAME, frame, cap=len(expect) + 16)
+        assert st == A.ST_OK and out == expect
+    bad = bytearray(FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 4, bd=0x40, content=expect)); bad[-1] ^= 1
+    with pytest.raises(ValueError) as e:
+        O.container_decompress(A.C_LZ4_FRAME, bytes(bad), cap=len(expect) + 16)
+    assert e.value.rc == A.E_CHECKSUM
+    wrong = FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 8, bd=0x40, content=expect, content_size=len(expect) + 1)
+    out, st = O.container_decompress(A.C_LZ4_FRAME, wrong, cap=len(expect) + 16)
+    assert st == A.ST_OUTPUT_SIZE_MISMATCH                                 # LZ4.Frame.cs:152-155
+    # legacy: a fresh window per block (LZ4.cs:164) -> references across blocks read zeros (E2), not the earlier block
+    b2, e2 = FC.lz4_linked_blocks(9, 1, 5000)
+    leg = FC.lz4_legacy([b2[0], b2[0]])
+    out, st = O.container_decompress(A.C_LZ4_LEGACY, leg, cap=2 * len(e2))
+    assert st == A.ST_OK and out == e2 + e2
+    # frames concatenate; a skippable frame in between is skipped; trailing junk stops the loop (LZ4.cs:50-93)
+    f1 = FC.lz4_frame(blocks[:1], O.xxh32)
+    skip = struct.pack("<II", 0x184D2A53, 5) + b"hello"
+    cat = f1 + skip + leg + b"\x01\x02\x03\x04junk"
+    e1 = FC.lz4_linked_blocks(7, 1, 30000)[1]
+    out, st = O.container_decompress(A.C_LZ4_FRAME, cat, cap=len(e1) + 2 * len(e2) + 16)
+    assert st == A.ST_OK and out == e1 + e2 + e2

@@ -86,3 +86,91 @@ def test_lz77_chunklz10_is_one_gpu_batch(test_bmp):
     from auroralib.compression_amd._lib import AlzError
     with pytest.raises(AlzError):      # "chunks too large to process"
         f.Compress(test_bmp[:400000], F.CompressionSettings.Fastest)
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY.md 8f rank 2
+import struct  # noqa: E402
+
+import framing_cases as FC  # noqa: E402
+
+FRAMED = [(F.LZ4, A.C_LZ4_FRAME, {}), (F.LZ4, A.C_LZ4_FRAME, {"chunk_size": 0x10000}), (F.LZ4Legacy, A.C_LZ4_LEGACY, {}), (F.Snappy, A.C_SNAPPY, {})]
+
+
+@pytest.mark.parametrize("cls,container,kw", FRAMED)
+def test_framing_roundtrip(cls, container, kw, test_bmp):
+    """LZ4 frame / legacy and Snappy framing: GPU Compress == the oracle's bytes (blocks / chunks as one GPU batch),
+    GPU Decompress == original (EncodingAndDecodingMatchTest incl. _LZ4Frame, CompressionAlgorithmTest.cs:81-139)."""
+    for size, q in ((10, 4), (10240, 8), (10240, 15), (300000, 0), (1024 * 1024, 0)):
+        raw = test_bmp[:size]
+        f = cls(kw["chunk_size"]) if kw else cls()
+        comp = f.Compress(raw, F.CompressionSettings(q))
+        assert comp == O.container_compress(container, raw, quality=q, **kw), (cls.__name__, size, q)
+        assert f.Decompress(comp) == raw
+        assert f.last_src_used == len(comp)
+    assert cls().Decompress(O.container_compress(container, bytes(0x100), quality=0, **kw)) == bytes(0x100)   # DataRecognitionTest
+
+
+def test_snappy_stored_and_skippable_chunks():
+    raw = os.urandom(70000) + bytes(70000) + os.urandom(100)
+    f = F.Snappy()
+    comp = f.Compress(raw)
+    assert comp == O.container_compress(A.C_SNAPPY, raw, quality=8) and comp[10] == 1
+    assert f.Decompress(comp) == raw
+    padded = comp[:10] + bytes([0xFE, 3, 0, 0, 1, 2, 3]) + comp[10:]
+    assert f.Decompress(padded) == raw
+    with pytest.raises(F.InvalidIdentifierException):
+        f.Decompress(comp[:10] + bytes([0x02, 0, 0, 0]) + comp[10:])
+    with pytest.raises(BufferError):
+        f.Decompress(comp, capacity=100000)
+    with pytest.raises(F.EndOfStreamException):
+        f.Decompress(comp[:len(comp) - 50])
+
+
+def test_lz4_linked_frames():
+    """One window per frame (LZ4.Frame.cs:120): blocks run in order, each with the frame's earlier output as history
+    (alz_stream.aux0); results equal the oracle's single ring window and the byte-wise model."""
+    blocks, expect = FC.lz4_linked_blocks(7, 5, 30000)
+    f = F.LZ4()
+    for flg in (0x40, 0x40 | 4 | 16, 0x40 | 8, 0x40 | 4 | 8 | 16):
+        frame = FC.lz4_frame(blocks, O.xxh32, flg=flg, bd=0x40, content=expect)
+        assert O.container_decompress(A.C_LZ4_FRAME, frame, cap=len(expect) + 16) == (expect, A.ST_OK)
+        assert f.Decompress(frame) == expect
+    blocks2, expect2 = FC.lz4_linked_blocks(11, 3, 200000)                 # far references: history beyond the LDS window
+    assert f.Decompress(FC.lz4_frame(blocks2, O.xxh32, bd=0x50)) == expect2
+    bad = bytearray(FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 4, bd=0x40, content=expect)); bad[-1] ^= 1
+    with pytest.raises(F.InvalidDataException):
+        f.Decompress(bytes(bad))
+    bad = bytearray(FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 16, bd=0x40, content=expect)); bad[20] ^= 1
+    with pytest.raises(F.InvalidDataException):
+        f.Decompress(bytes(bad))
+    with pytest.raises(F.DecompressedSizeException):
+        f.Decompress(FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 8, bd=0x40, content=expect, content_size=len(expect) + 1))
+    with pytest.raises(F.EndOfStreamException):
+        f.Decompress(FC.lz4_frame(blocks, O.xxh32)[:-30])
+    # frames concatenate, skippable frames are skipped, anything else ends the file (LZ4.cs:50-93)
+    b2, e2 = FC.lz4_linked_blocks(9, 1, 5000)
+    leg = FC.lz4_legacy([b2[0], b2[0]])
+    cat = FC.lz4_frame(blocks[:1], O.xxh32) + struct.pack("<II", 0x184D2A53, 5) + b"hello" + leg + b"\x01\x02\x03\x04junk"
+    e1 = FC.lz4_linked_blocks(7, 1, 30000)[1]
+    assert f.Decompress(cat) == e1 + e2 + e2 == O.container_decompress(A.C_LZ4_FRAME, cat, cap=1 << 20)[0]
+    assert F.LZ4Legacy().Decompress(leg) == e2 + e2
+
+
+def test_lz4_independent_blocks_are_one_batch(test_bmp):
+    """Frames with the block-independence flag and legacy files: all blocks in one GPU batch at nominal offsets; a block
+    that does not fill its slot (any but the last) falls back to in-order decoding."""
+    raw = test_bmp[:0x70000] + os.urandom(0x10000) + test_bmp[:100000]     # the random 64 KiB block is stored
+    frame = bytearray(O.container_compress(A.C_LZ4_FRAME, raw, quality=0, chunk_size=0x10000))
+    assert any(struct.unpack("<I", frame[i:i + 4])[0] == 0x80010000 for i in range(7, len(frame) - 4))
+    frame[4] |= 32                                                        # block independence (the header checksum is not verified)
+    assert F.LZ4().Decompress(bytes(frame)) == raw
+    # short blocks in the middle: nominal offsets are wrong from the second block on
+    pieces = [test_bmp[:0x10000], test_bmp[0x10000:0x10000 + 5000], test_bmp[0x20000:0x30000]]
+    blocks = [O.encode_stream(A.FMT_LZ4_BLOCK, p, quality=4)[0] for p in pieces]
+    assert F.LZ4().Decompress(FC.lz4_frame(blocks, O.xxh32, flg=0x60, bd=0x40)) == b"".join(pieces)
+    assert F.LZ4Legacy().Decompress(FC.lz4_legacy(blocks)) == b"".join(pieces)
+    # legacy at its real block size (8 MiB): two blocks, nominal offsets hold
+    big = (test_bmp[:4096] * 2200)[:0x800000 + 300000]
+    comp = O.container_compress(A.C_LZ4_LEGACY, big, quality=0)
+    assert struct.unpack("<I", comp[4:8])[0] + 8 < len(comp) - 5            # a second block follows
+    assert F.LZ4Legacy().Decompress(comp) == big
