@@ -185,28 +185,33 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     typedef EmitCfg<LW - 1u, false, !PRS, !PRS> CFG;
     typedef QueueSink<OW, CFG> SK;
     SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : 65536u);
-    if constexpr (PRS || FMT == ALZ_FMT_LZ4_BLOCK) {
-        // bulk of the stream: lean parse loops (alz_decode_fast.h) while >= 1100 input bytes remain; every token they
-        // decline, and the tail of the stream, goes through the exact parser one token at a time
+    if constexpr (PRS) {
+        // bulk of the stream: lane-assisted parse (prs_lane_parse) while >= 1100 input bytes remain; every token it
+        // declines, and the tail of the stream, goes through the exact parser one token at a time
+        constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
+        u32 fl = 1u;                                             // normalised flag register (no bits pending)
+        for (;;) {
+            if (s.p + 1100u <= src_len && !s.done) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                if (prs_lane_parse<SK, BIG>(in, sk, s, stage, lane, fl)) { if (s.ovf || s.done) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            prs_from_norm<BIG>(fl, s.bits, s.flag);
+            dec_prs_serial<SK, BIG>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+            fl = prs_to_norm<BIG>(s.bits, s.flag);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
+    } else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) {
+        // bulk of the stream: lane-parallel sequence parse while >= 1100 input bytes remain, exact parser otherwise
         for (;;) {
             if (s.p + 1100u <= src_len) {
                 sk.ensure(in, s.p, 1024);                        // cache covers [p, p + 1024); flushes the queue if it has to move
-                const u32 before = s.p;
-                if constexpr (FMT == ALZ_FMT_PRS_BE) prs_fast_parse<SK, true>(in, sk, s, s.p + 1000u);
-                else if constexpr (FMT == ALZ_FMT_PRS_LE) prs_fast_parse<SK, false>(in, sk, s, s.p + 1000u);
-                else {
-                    if (sk.nt) { sk.flush(); if (s.ovf) break; }
-                    lz4_lane_parse(in, sk, s, stage, lane);
-                    if (s.ovf) break;
-                }
-                if (sk.nt >= 62u) { sk.flush(); if (s.ovf) break; }
-                if (s.p != before) continue;                      // made progress: next batch
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                if (lz4_lane_parse(in, sk, s, stage, lane)) { if (s.ovf) break; continue; }
             }
-            // exact single step (also: everything near the end of the input)
             const bool tail = s.p + 1100u > src_len;
-            if constexpr (FMT == ALZ_FMT_PRS_BE) dec_prs_serial<SK, true>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
-            else if constexpr (FMT == ALZ_FMT_PRS_LE) dec_prs_serial<SK, false>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
-            else dec_lz4_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+            dec_lz4_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
     }
