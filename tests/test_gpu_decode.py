@@ -125,3 +125,19 @@ def test_unaligned_buffers():
         items.append(dict(fmt=A.FMT_LZ4_BLOCK, src=O.encode_stream(A.FMT_LZ4_BLOCK, s + s, quality=4)[0], decom_len=0, cap=len(s) * 2, src_misalign=3, dst_misalign=5))
     streams, src, dst_bytes = pack_streams(items, dst_slack=8)
     compare_batch(streams, src, dst_bytes, what="unaligned")
+
+
+def test_prs_terminator_inside_the_bulk_path(test_bmp):
+    """PRS ends at its zero word (PRS.cs:78-79) wherever that is: with >= 1100 bytes of trailing data the terminator is met by
+    the lane-assisted parser, not by the tail parser; src_used must stop right behind it."""
+    import os
+    items = []
+    for fmt in (A.FMT_PRS_BE, A.FMT_PRS_LE):
+        for size, q in ((30000, 8), (5000, 0), (200, 4)):
+            raw = test_bmp[3000:3000 + size]
+            comp, _ = O.encode_stream(fmt, raw, quality=q)
+            for tail in (os.urandom(3000), bytes(2000), comp):
+                items.append(dict(fmt=fmt, src=comp + tail, decom_len=0, cap=size + 64))
+    streams, src, dst_bytes = pack_streams(items)
+    gr, _ = compare_batch(streams, src, dst_bytes, what="prs trailing data")
+    assert (gr["status"] == 0).all()
