@@ -587,6 +587,43 @@ __device__ __forceinline__ void lz4_fast_parse(InCache& in, SK& sk, DecState& s,
     s.p = pp;
 }
 
+// Walk of a chain of variable-size elements over a 256-byte window (4 x 64): nx[w] holds, per lane, the size of "the
+// element that would start at byte 64 w + lane" (0 = stop here: unusual element).  Returns the element starts as one
+// 64-bit mask per window, the offset of the first element not taken, and the count (<= maxn).  Runs on the scalar unit,
+// hand-scheduled: ten instructions per element (the compiler's version of this loop spent ~25, mostly shuffling the mask
+// registers); the five instructions between the s_add and the next v_readlane cover the SALU-write -> lane-select hazard.
+__device__ __forceinline__ void lane_walk4(const u32 (&nx)[4], u32 maxn, u64 (&mask)[4], u32& sp_out, u32& n_out) {
+    mask[0] = mask[1] = mask[2] = mask[3] = 0ull;
+    u32 sp = 0, nseq = 0, stop = 0;
+    maxn = uni(maxn);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (!stop && sp < 64u * (u32)(w + 1)) {
+            u32 n;
+            asm volatile(
+                "1:\n\t"
+                "v_readlane_b32 %[n], %[nx], %[sp]\n\t"
+                "s_cmp_eq_u32 %[n], 0\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_bitset1_b64 %[mask], %[sp]\n\t"
+                "s_add_u32 %[sp], %[sp], %[n]\n\t"
+                "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                "s_cmp_ge_u32 %[cnt], %[maxn]\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_branch 3f\n"
+                "2:\n\t"
+                "s_mov_b32 %[stop], 1\n"
+                "3:\n\t"
+                : [n] "=&s"(n), [sp] "+s"(sp), [mask] "+s"(mask[w]), [cnt] "+s"(nseq), [stop] "+s"(stop)
+                : [nx] "v"(nx[w]), [lim] "s"(64u * (u32)(w + 1)), [maxn] "s"(maxn)
+                : "scc");
+        }
+    }
+    sp_out = sp; n_out = nseq;
+}
+
 // Lane-parallel LZ4 parse.  Where a sequence starts can only be found by walking the chain of sequences, but what the
 // walk needs -- the size of "the sequence that would start at this byte" -- depends on that byte and at most two length
 // bytes, so every lane computes it for its own byte of a 256-byte window (4 x 64) and the walk itself is one v_readlane
@@ -615,36 +652,8 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
         tokb[w] = lp; runl[w] = L; mlen[w] = M; offp[w] = op;
         nx[w] = bad ? 0u : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
     }
-    // walk the chain (scalar): sequence starts as one 64-bit mask per window.  Hand-scheduled: ten scalar-unit
-    // instructions per sequence (the compiler's version of this loop spent ~25, mostly shuffling the mask registers).
-    // The five instructions between the s_add and the next v_readlane cover the SALU-write -> lane-select hazard.
-    u64 mask[4] = {0ull, 0ull, 0ull, 0ull};
-    u32 sp = 0, nseq = 0, stop = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (!stop && sp < 64u * (u32)(w + 1)) {
-            u32 n;
-            asm volatile(
-                "1:\n\t"
-                "v_readlane_b32 %[n], %[nx], %[sp]\n\t"
-                "s_cmp_eq_u32 %[n], 0\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_bitset1_b64 %[mask], %[sp]\n\t"
-                "s_add_u32 %[sp], %[sp], %[n]\n\t"
-                "s_add_u32 %[cnt], %[cnt], 1\n\t"
-                "s_cmp_ge_u32 %[cnt], 32\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_branch 3f\n"
-                "2:\n\t"
-                "s_mov_b32 %[stop], 1\n"
-                "3:\n\t"
-                : [n] "=&s"(n), [sp] "+s"(sp), [mask] "+s"(mask[w]), [cnt] "+s"(nseq), [stop] "+s"(stop)
-                : [nx] "v"(nx[w]), [lim] "s"(64u * (u32)(w + 1))
-                : "scc");
-        }
-    }
+    u64 mask[4]; u32 sp, nseq;
+    lane_walk4(nx, 32u, mask, sp, nseq);
     if (nseq == 0u) return false;
     // tokens: starting lanes write (literal run?, match) at their rank
     u32 base = 0;
@@ -668,6 +677,63 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
     wave_sync();
     const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
     if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
+    sk.qtok = qt; sk.nt = base; sk.qbytes = total;
+    s.p = p + sp;
+    sk.flush();
+    return true;
+}
+
+// Lane-parallel Snappy parse (Snappy.cs:205-250): an element's size depends on its tag byte and, for literals of 61+
+// bytes, on one or two length bytes -- the same per-byte speculation + scalar walk as LZ4, one token per element.
+// `limit` = bytes the batch may still produce (declared size and capacity).  Elements the walk does not take (literals
+// above 700 bytes, 4-byte copies beyond the window) are left to the exact parser.
+template <class SK>
+__device__ __forceinline__ bool snappy_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32 limit) {
+    const u32 p = s.p;
+    const u32 i0 = in.idx(p);
+    u32 tok[4], nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2], e3 = in.lds[pos + 3], e4 = in.lds[pos + 4];
+        const u32 type = b & 3u, hi = b >> 2;
+        u32 n, t;
+        if (type == 0u) {
+            u32 len, hdr;
+            if (hi < 60u) { len = hi + 1u; hdr = 1u; }
+            else if (hi == 60u) { len = e1 + 1u; hdr = 2u; }
+            else if (hi == 61u) { len = (e1 | (e2 << 8)) + 1u; hdr = 3u; }
+            else { len = 0xFFFFu; hdr = 0u; }
+            n = len > 700u ? 0u : hdr + len;                           // the run has to stay inside the resident input cache
+            t = ALZ_TOK_LIT(len & 0x3FFu, (pos + hdr) & 2047u);
+        } else if (type == 1u) {
+            const u32 d = ((b >> 5) << 8) | e1;
+            n = 2u; t = ALZ_TOK_MATCH((hi & 7u) + 4u, d ? d : 65536u);
+        } else if (type == 2u) {
+            const u32 d = e1 | (e2 << 8);
+            n = 3u; t = ALZ_TOK_MATCH(hi + 1u, d ? d : 65536u);
+        } else {
+            const u32 d = e1 | (e2 << 8) | (e3 << 16) | (e4 << 24);
+            n = d > 65536u ? 0u : 5u; t = ALZ_TOK_MATCH(hi + 1u, d ? (d & 0x1FFFFu) : 65536u);   // E3: beyond the window -> exact parser (BAD_TOKEN)
+        }
+        tok[w] = t; nx[w] = n;
+    }
+    u64 mask[4]; u32 sp, nel;
+    lane_walk4(nx, 64u, mask, sp, nel);
+    if (nel == 0u) return false;
+    u32 base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (mask[w]) {
+            if ((mask[w] >> lane) & 1ull) stage[base + mbcnt64(mask[w])] = tok[w];
+            base += (u32)__popcll(mask[w]);
+        }
+    }
+    wave_sync();
+    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
+    wave_sync();
+    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    if (total > limit) return false;                           // size / capacity rules stay with the exact parser
     sk.qtok = qt; sk.nt = base; sk.qbytes = total;
     s.p = p + sp;
     sk.flush();

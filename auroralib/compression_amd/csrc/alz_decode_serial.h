@@ -301,11 +301,15 @@ __device__ void dec_lzo_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
 
 // Snappy.DecompressHeaderless  Formats/Common/Snappy.cs:205-250 (+ varint :109-122)
 template <class SK>
-__device__ void dec_snappy_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
+__device__ void dec_snappy_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32& size, bool& have_size, u32 max_tokens = 0xFFFFFFFFu) {
 #define SN_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
-    u32 size = 0, shift = 0, b = 0x80;
-    while (b & 0x80) { SN_BYTE(b); size |= (b & 0x7F) << (shift & 31); shift += 7; }
+    if (!have_size) {                                                     // ReadDecompressedSize  Snappy.cs:109-122
+        u32 shift = 0, b = 0x80; size = 0;
+        while (b & 0x80) { SN_BYTE(b); size |= (b & 0x7F) << (shift & 31); shift += 7; }
+        have_size = true;
+    }
     while (sk.produced() < size) {
+        if (max_tokens-- == 0) return;
         u32 tag; SN_BYTE(tag);
         u32 type = tag & 3, length = tag >> 2, distance;
         if (type == 0) {

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     } else if constexpr (FMT == ALZ_FMT_LZO) {
         dec_lzo_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_SNAPPY_RAW) {
-        dec_snappy_serial(in, sk, s, src_len);
+        u32 sz = 0; bool have = false;
+        dec_snappy_serial(in, sk, s, src_len, sz, have);
     }
     out.finish();
     write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap), hist);
@@ -216,7 +217,22 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
         }
     }
     else if constexpr (FMT == ALZ_FMT_LZO) dec_lzo_serial(in, sk, s, src_len);
-    else dec_snappy_serial(in, sk, s, src_len);
+    else {
+        // Snappy: varint size, then elements until the output reaches it; lane-parallel parse for the bulk
+        u32 size = 0; bool have = false;
+        for (;;) {
+            if (have && s.p + 1100u <= src_len) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                if (out.produced >= size) break;
+                const u32 lim = (size < cap ? size : cap) - out.produced;
+                if (out.produced < cap && snappy_lane_parse(in, sk, s, stage, lane, lim)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_snappy_serial(in, sk, s, src_len, size, have, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
+        }
+    }
     sk.flush();                                    // tokens parsed before an error/terminator are part of the output
     out.finish();
     write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0, cap), hist);
