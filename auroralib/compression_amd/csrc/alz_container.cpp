@@ -802,3 +802,166 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
 }
 
 }  // extern "C"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- batch producers
+
+// header of a single-body container at p -> stream descriptor (offsets relative to p); false: not decodable from here
+static bool describe_stream(uint32_t container, bool big, const uint8_t* p, size_t n, alz_stream* s, size_t* hdr) {
+    memset(s, 0, sizeof(*s));
+    uint32_t size = 0;
+    switch (container) {
+    case ALZ_C_LZSS: if (n < 16) return false; size = be32(p + 4); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_LZ10: case ALZ_C_LZ11: { const int h = nin_header(p, n, container == ALZ_C_LZ10 ? 0x10 : 0x11, &size); if (h < 0) return false; *hdr = (size_t)h; s->format = container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11; break; }
+    case ALZ_C_YAZ0: case ALZ_C_YAZ1: if (n < 16) return false; size = rd32(p + 4, big); *hdr = 16; s->format = ALZ_FMT_YAZ0; break;
+    case ALZ_C_YAY0: case ALZ_C_MIO0:
+        if (n < 16) return false;
+        size = rd32(p + 4, big); s->aux0 = rd32(p + 8, big) - 0x10; s->aux1 = rd32(p + 12, big) - 0x10; *hdr = 16;
+        s->format = container == ALZ_C_YAY0 ? ALZ_FMT_YAY0 : ALZ_FMT_MIO0; break;
+    case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {
+        const size_t ml = container == ALZ_C_LZ_3DS ? 8 : 4; size_t ih = 0;
+        if (n < ml || !describe_stream(container == ALZ_C_COMP ? ALZ_C_LZ11 : ALZ_C_LZ10, big, p + ml, n - ml, s, &ih)) return false;
+        *hdr = ml + ih; return true;
+    }
+    case ALZ_C_AKLZ: if (n < 16) return false; size = be32(p + 12); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_LZ01: if (n < 16) return false; size = le32(p + 8); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_LZSEGA: if (n < 8) return false; size = le32(p + 4); *hdr = 8; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_LEVEL5LZSS: if (n < 16) return false; size = le32(p + 12); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
+    default: return false;
+    }
+    s->decom_len = size;
+    return true;
+}
+
+static const struct { const char* name; uint32_t format; uint8_t wb, lb, th; } kBrute[ALZ_BRUTE_DECODERS] = {   // BruteForceCommand.cs:96-131, the decoders on the path
+    { "LZO", ALZ_FMT_LZO, 0, 0, 0 }, { "LZ4", ALZ_FMT_LZ4_BLOCK, 0, 0, 0 },
+    { "LZSS (12, 4, 2)", ALZ_FMT_LZSS, 12, 4, 2 }, { "LZSS (12, 4, 3)", ALZ_FMT_LZSS, 12, 4, 3 },
+    { "LZSS (10, 6, 2)", ALZ_FMT_LZSS, 10, 6, 2 }, { "LZSS (10, 6, 3)", ALZ_FMT_LZSS, 10, 6, 3 },
+    { "LZSS0", ALZ_FMT_LZSS, 12, 4, 2 },                                   // LzProperties(0x1000, 0xF + 3, 3, 0xFEE) == (12, 4, 2)  LZSS.cs:34
+    { "PRS big", ALZ_FMT_PRS_BE, 0, 0, 0 }, { "PRS Little", ALZ_FMT_PRS_LE, 0, 0, 0 },
+    { "LZ10", ALZ_FMT_LZ10, 0, 0, 0 }, { "LZ11", ALZ_FMT_LZ11, 0, 0, 0 }, { "Yaz0", ALZ_FMT_YAZ0, 0, 0, 0 },
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* alz_brute_decoder_name(uint32_t i) { return i < ALZ_BRUTE_DECODERS ? kBrute[i].name : nullptr; }
+
+int alz_brute_force(alz_ctx* ctx, const uint8_t* raw, size_t raw_len, uint32_t expected_size, uint8_t* dst, size_t slot, alz_result* results) {
+    if (!ctx || (!raw && raw_len) || !dst || !results || slot < expected_size || raw_len > 0xFFFFFFFFull) return ALZ_E_INVALID;
+    DevBuf d_src(ctx), d_dst(ctx);
+    int rc;
+    const size_t dslot = (slot + 255) & ~(size_t)255;
+    if ((rc = alz_device_malloc(ctx, raw_len + 64, &d_src.p)) != ALZ_OK) return rc;
+    if ((rc = alz_device_malloc(ctx, dslot * ALZ_BRUTE_DECODERS + 64, &d_dst.p)) != ALZ_OK) return rc;
+    if (raw_len && (rc = alz_memcpy_h2d(ctx, d_src.p, raw, raw_len)) != ALZ_OK) return rc;
+    bool done[ALZ_BRUTE_DECODERS] = { false };
+    for (uint32_t g = 0; g < ALZ_BRUTE_DECODERS; g++) {                     // one batch per LZSS geometry, one for all fixed formats
+        if (done[g]) continue;
+        std::vector<alz_stream> ss; std::vector<uint32_t> who;
+        for (uint32_t i = g; i < ALZ_BRUTE_DECODERS; i++) {
+            if (done[i]) continue;
+            const bool same = kBrute[g].format == ALZ_FMT_LZSS ? (kBrute[i].format == ALZ_FMT_LZSS && kBrute[i].wb == kBrute[g].wb && kBrute[i].lb == kBrute[g].lb && kBrute[i].th == kBrute[g].th)
+                                                               : kBrute[i].format != ALZ_FMT_LZSS;
+            if (!same) continue;
+            alz_stream s; memset(&s, 0, sizeof(s));
+            s.src_len = (uint32_t)raw_len; s.dst_off = (uint64_t)i * dslot; s.dst_cap = expected_size; s.decom_len = expected_size; s.format = kBrute[i].format;
+            ss.push_back(s); who.push_back(i); done[i] = true;
+        }
+        alz_lz_properties lz; memset(&lz, 0, sizeof(lz));
+        if (kBrute[g].format == ALZ_FMT_LZSS) {                            // LzProperties(byte, byte, byte)  LzProperties.cs:57-66
+            lz.window_bits = kBrute[g].wb; lz.length_bits = kBrute[g].lb; lz.min_length = (uint8_t)(kBrute[g].th + 1);
+            lz.max_distance = 1u << kBrute[g].wb; lz.windows_start = lz.max_distance - (1u << kBrute[g].lb) - kBrute[g].th;
+        }
+        alz_plan* pl = nullptr; std::vector<alz_result> rs(ss.size());
+        if ((rc = alz_plan_create(ctx, kBrute[g].format == ALZ_FMT_LZSS ? &lz : nullptr, (uint32_t)ss.size(), ss.data(), &pl)) != ALZ_OK) return rc;
+        rc = alz_plan_execute(ctx, pl, d_src.p, d_dst.p, nullptr);
+        if (rc == ALZ_OK) rc = alz_plan_results(ctx, pl, rs.data());
+        alz_plan_destroy(ctx, pl);
+        if (rc != ALZ_OK) return rc;
+        for (size_t k = 0; k < who.size(); k++) {
+            results[who[k]] = rs[k];
+            if (rs[k].dst_len && (rc = alz_memcpy_d2h(ctx, dst + (size_t)who[k] * slot, (uint8_t*)d_dst.p + (size_t)who[k] * dslot, rs[k].dst_len)) != ALZ_OK) return rc;
+        }
+    }
+    return ALZ_OK;
+}
+
+int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, const alz_container_options* opt, const uint8_t* src, size_t len,
+                       uint8_t* dst, size_t dst_cap, alz_scan_hit* hits, uint32_t max_hits, uint32_t* nhits, size_t* dst_used) {
+    if (!ctx || !containers || !nc || (!src && len) || !nhits || (max_hits && !hits)) return ALZ_E_INVALID;
+    const bool big = opt ? opt->big_endian != 0 : true;
+    *nhits = 0; if (dst_used) *dst_used = 0;
+    const alz_lz_properties* lzp = nullptr;                                 // LZSS geometry: only the LZSS container itself may be non-default
+    bool wrapper_lzss = false;
+    for (uint32_t k = 0; k < nc; k++) {
+        if (containers[k] >= ALZ_C_COUNT) return ALZ_E_INVALID;
+        switch (containers[k]) {
+        case ALZ_C_LZSS: if (opt && opt->lz.window_bits) lzp = &opt->lz; break;
+        case ALZ_C_AKLZ: case ALZ_C_LZ01: case ALZ_C_LZSEGA: case ALZ_C_LEVEL5LZSS: wrapper_lzss = true; break;
+        case ALZ_C_LZ10: case ALZ_C_LZ11: case ALZ_C_YAZ0: case ALZ_C_YAZ1: case ALZ_C_YAY0: case ALZ_C_MIO0:
+        case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: break;
+        default: return ALZ_E_UNSUPPORTED;
+        }
+    }
+    if (lzp && wrapper_lzss) return ALZ_E_UNSUPPORTED;                      // one LZSS geometry per batch
+    // 1. candidates: every offset some container identifies
+    struct Cand { size_t off; uint32_t container; alz_stream st; size_t hdr; };
+    std::vector<Cand> cands;
+    const uint32_t kMaxStream = 256u << 20;
+    for (size_t i = 0; i < len; i++) {
+        for (uint32_t k = 0; k < nc; k++) {
+            if (!alz_container_is_match(containers[k], src + i, len - i)) continue;
+            Cand c; c.off = i; c.container = containers[k];
+            if (describe_stream(containers[k], big, src + i, len - i, &c.st, &c.hdr) && c.st.decom_len <= kMaxStream && c.hdr <= len - i) cands.push_back(c);
+            break;                                                          // Identify(): the first match decides
+        }
+    }
+    if (cands.empty()) return ALZ_OK;
+    DevBuf d_src(ctx), d_dst(ctx);
+    int rc;
+    if ((rc = alz_device_malloc(ctx, len + 64, &d_src.p)) != ALZ_OK) return rc;
+    if ((rc = alz_memcpy_h2d(ctx, d_src.p, src, len)) != ALZ_OK) return rc;
+    const uint64_t kRound = 1ull << 30;
+    size_t d_cap = 0, next_free = 0, used = 0;
+    size_t ci = 0;
+    while (ci < cands.size()) {
+        // 2. one round: as many candidates as fit kRound bytes of output
+        std::vector<alz_stream> ss; std::vector<size_t> who; uint64_t arena = 0;
+        while (ci < cands.size()) {
+            Cand& c = cands[ci];
+            if (c.off < next_free) { ci++; continue; }                      // already inside an accepted stream
+            const uint64_t need = ((uint64_t)c.st.decom_len + 255) & ~255ull;
+            if (!ss.empty() && arena + need > kRound) break;
+            alz_stream s = c.st;
+            s.src_off = c.off + c.hdr; s.src_len = clamp32(len - c.off - c.hdr); s.dst_off = arena; s.dst_cap = s.decom_len;
+            ss.push_back(s); who.push_back(ci); arena += need; ci++;
+        }
+        if (ss.empty()) break;
+        if (arena + 64 > d_cap) { if (d_dst.p) { alz_device_free(ctx, d_dst.p); d_dst.p = nullptr; } d_cap = (size_t)arena + 64; if ((rc = alz_device_malloc(ctx, d_cap, &d_dst.p)) != ALZ_OK) return rc; }
+        alz_plan* pl = nullptr; std::vector<alz_result> rs(ss.size());
+        if ((rc = alz_plan_create(ctx, lzp, (uint32_t)ss.size(), ss.data(), &pl)) != ALZ_OK) return rc;
+        rc = alz_plan_execute(ctx, pl, d_src.p, d_dst.p, nullptr);
+        if (rc == ALZ_OK) rc = alz_plan_results(ctx, pl, rs.data());
+        alz_plan_destroy(ctx, pl);
+        if (rc != ALZ_OK) return rc;
+        // 3. replay the walk over this round's results
+        for (size_t k = 0; k < ss.size(); k++) {
+            const Cand& c = cands[who[k]];
+            if (c.off < next_free) continue;
+            if (rs[k].status != ALZ_ST_OK || rs[k].dst_len <= 0x10) continue;   // exception, or destination.Length <= 0x10
+            if (*nhits >= max_hits || used + rs[k].dst_len > dst_cap) { if (dst_used) *dst_used = used; return ALZ_E_NOMEM; }
+            if ((rc = alz_memcpy_d2h(ctx, dst + used, (uint8_t*)d_dst.p + ss[k].dst_off, rs[k].dst_len)) != ALZ_OK) return rc;
+            alz_scan_hit& h = hits[(*nhits)++];
+            h.start = c.off; h.end = c.off + c.hdr + rs[k].src_used; h.dst_off = used; h.dst_len = rs[k].dst_len; h.container = c.container;
+            used += rs[k].dst_len;
+            next_free = (size_t)h.end;
+        }
+    }
+    if (dst_used) *dst_used = used;
+    return ALZ_OK;
+}
+
+}  // extern "C"

@@ -263,6 +263,38 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
 /* worst-case compressed size for dst_cap sizing */
 size_t alz_container_compress_bound(uint32_t container, size_t src_len);
 
+/* ------------------------------------------------ batch producers
+ * The two places in the reference that issue many independent decodes, restated as callers of the batched path.
+ *
+ * alz_container_scan: ScanDecompressCommand (src/AuroraLib.Compression.CLI/Commands/ScanDecompressCommand.cs:12-104).
+ * Walks `src` byte by byte; at every offset the first container of `containers` whose IsMatch accepts identifies the
+ * format (FormatService.Formats.Identify, :62); the stream is decoded and kept when it decodes without an exception
+ * and yields more than 0x10 bytes (:85), the walk then continues behind it (:98), otherwise at the next byte (:100).
+ * Here every candidate offset is decoded in ONE GPU batch (rounds of <= 1 GiB of output) and the walk is replayed over
+ * the results.  Supported: the containers with a size header and one body (LZSS, LZ10, LZ11, YAZ0, YAY0, MIO0, GCLZ,
+ * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS); the Yaz0 byte-order retry is not attempted.
+ * Outputs of the accepted streams are packed into dst in file order; ALZ_E_NOMEM when dst or hits is too small
+ * (nhits / dst_used then describe what fitted). */
+typedef struct alz_scan_hit {
+    uint64_t start;      /* offset of the stream in src */
+    uint64_t end;        /* source.Position after Decompress */
+    uint64_t dst_off;    /* its output inside dst */
+    uint32_t dst_len;
+    uint32_t container;  /* alz_container that identified it */
+} alz_scan_hit;
+int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t n_containers, const alz_container_options* opt,
+                       const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_cap,
+                       alz_scan_hit* hits, uint32_t max_hits, uint32_t* nhits, size_t* dst_used);
+
+/* alz_brute_force: BruteForceCommand (src/AuroraLib.Compression.CLI/Commands/BruteForceCommand.cs:24-133): one raw
+ * buffer, every raw decoder of the path tried against a fixed destination of `expected_size` bytes -- one GPU batch per
+ * LZSS geometry.  Decoder i writes to dst + i * slot (slot >= expected_size); it "successfully unpacked the file" (:42)
+ * when results[i].status == ALZ_ST_OK and results[i].dst_len == expected_size. */
+#define ALZ_BRUTE_DECODERS 12
+const char* alz_brute_decoder_name(uint32_t i);   /* the names of GetRawDecodersList (:96-131), e.g. "LZSS (10, 6, 2)" */
+int alz_brute_force(alz_ctx* ctx, const uint8_t* raw, size_t raw_len, uint32_t expected_size,
+                    uint8_t* dst, size_t slot, alz_result* results /* [ALZ_BRUTE_DECODERS] */);
+
 #ifdef __cplusplus
 }
 #endif
