@@ -38,52 +38,66 @@ __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi
 // global address mod 16 and every 16 B granule is aligned in both LDS and HBM.
 struct InCache {
     const u8* gbase;  // src - ishift  (16 B aligned)
-    u8* lds;          // 2048 B, 16 B aligned
+    u8* lds;          // 2 * ch bytes, 16 B aligned
     u32 lo, hi;       // valid a-range [lo, hi)
-    u32 cb;           // a-coordinate of lds[0]; multiple of 1024
-    uint4 pf;         // this lane's 16 B of the chunk at cb + 2048 (prefetched)
+    u32 cb;           // a-coordinate of lds[0]; multiple of ch
+    u32 ch;           // chunk size: 1024 (16 B per lane and load) or 256 (4 B per lane: 544 B of LDS instead of 2 080 --
+                      // what lets the flag-family kernels keep 32 waves per CU)
+    uint4 pf;         // this lane's part of the chunk at cb + 2 ch (prefetched; .x only when ch == 256)
     int lane;
 
     __device__ __forceinline__ uint4 load_chunk(u32 ca) const {
-        u32 ga = ca + 16u * (u32)lane;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (ga + 16u > lo && ga < hi) v = *reinterpret_cast<const uint4*>(gbase + ga);
+        if (ch == 1024u) {
+            u32 ga = ca + 16u * (u32)lane;
+            if (ga + 16u > lo && ga < hi) v = *reinterpret_cast<const uint4*>(gbase + ga);
+        } else {
+            u32 ga = ca + 4u * (u32)lane;
+            if (ga + 4u > lo && ga < hi) v.x = *reinterpret_cast<const u32*>(gbase + ga);
+        }
         return v;
     }
-    __device__ __forceinline__ void init(const u8* src, u32 len, u8* lds_, int lane_) {
+    __device__ __forceinline__ void store_chunk(u32 half, uint4 v) {
+        if (ch == 1024u) *reinterpret_cast<uint4*>(lds + half * 1024u + 16 * lane) = v;
+        else *reinterpret_cast<u32*>(lds + half * 256u + 4 * lane) = v.x;
+    }
+    __device__ __forceinline__ void init(const u8* src, u32 len, u8* lds_, int lane_, u32 chunk = 1024u) {
         u32 ishift = (u32)(reinterpret_cast<uintptr_t>(src) & 15u);
-        gbase = src - ishift; lds = lds_; lo = ishift; hi = ishift + len; lane = lane_; cb = 0;
-        uint4 c0 = load_chunk(0), c1 = load_chunk(1024);
-        pf = load_chunk(2048);
-        *reinterpret_cast<uint4*>(lds + 16 * lane) = c0;
-        *reinterpret_cast<uint4*>(lds + 1024 + 16 * lane) = c1;
+        gbase = src - ishift; lds = lds_; lo = ishift; hi = ishift + len; lane = lane_; cb = 0; ch = chunk;
+        uint4 c0 = load_chunk(0), c1 = load_chunk(ch);
+        pf = load_chunk(2u * ch);
+        store_chunk(0, c0); store_chunk(1, c1);
         wave_sync();
     }
-    // reposition so that lds[0] is the 1 KiB chunk containing input offset p (used by seeks)
+    // reposition so that lds[0] is the chunk containing input offset p (used by seeks)
     __device__ __forceinline__ void seek(u32 p) {
         u32 a = p + lo;
-        cb = a & ~1023u;
-        uint4 c0 = load_chunk(cb), c1 = load_chunk(cb + 1024);
-        pf = load_chunk(cb + 2048);
+        cb = a & ~(ch - 1u);
+        uint4 c0 = load_chunk(cb), c1 = load_chunk(cb + ch);
+        pf = load_chunk(cb + 2u * ch);
         wave_sync();
-        *reinterpret_cast<uint4*>(lds + 16 * lane) = c0;
-        *reinterpret_cast<uint4*>(lds + 1024 + 16 * lane) = c1;
+        store_chunk(0, c0); store_chunk(1, c1);
         wave_sync();
     }
     __device__ __forceinline__ void advance() {
         wave_sync();
-        uint4 up = *reinterpret_cast<const uint4*>(lds + 1024 + 16 * lane);
-        *reinterpret_cast<uint4*>(lds + 16 * lane) = up;
-        *reinterpret_cast<uint4*>(lds + 1024 + 16 * lane) = pf;
-        cb += 1024;
-        pf = load_chunk(cb + 2048);
+        if (ch == 1024u) {
+            uint4 up = *reinterpret_cast<const uint4*>(lds + 1024 + 16 * lane);
+            *reinterpret_cast<uint4*>(lds + 16 * lane) = up;
+        } else {
+            u32 up = *reinterpret_cast<const u32*>(lds + 256 + 4 * lane);
+            *reinterpret_cast<u32*>(lds + 4 * lane) = up;
+        }
+        store_chunk(1, pf);
+        cb += ch;
+        pf = load_chunk(cb + 2u * ch);
         wave_sync();
     }
-    // make [p, p+need) resident (need <= 1024); p is wave-uniform and only moves forward
+    // make [p, p+need) resident (need <= ch); p is wave-uniform and only moves forward
     __device__ __forceinline__ void ensure(u32 p, u32 need) {
         u32 a = p + lo;
-        if (a - cb >= 2048u + 1024u) { seek(p); return; }   // far jump (never on the sequential path)
-        while (a + need > cb + 2048u) advance();
+        if (a - cb >= 3u * ch) { seek(p); return; }   // far jump (never on the sequential path)
+        while (a + need > cb + 2u * ch) advance();
     }
     __device__ __forceinline__ u32 idx(u32 p) const { return p + lo - cb; }
     // per-lane byte at input offset p (p may differ per lane); caller guarantees residency

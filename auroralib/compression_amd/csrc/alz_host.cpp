@@ -54,6 +54,8 @@ extern "C" {
 int alz_abi_version(void) { return ALZ_ABI_VERSION; }
 /* not in the public header: test hook that selects the exact serial kernels for every format (still the GPU path) */
 void alz_debug_force_serial(int on) { alz_set_force_serial(on); }
+/* not in the public header: resident waves per CU of the production kernel of `format` (tuning aid) */
+int alz_debug_occupancy(int format) { return alz_kernel_occupancy(format); }
 const char* alz_last_error(void) { return g_err; }
 
 int alz_device_count(void) {

@@ -12,6 +12,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, voi
 // debug/test switch: route every format through the exact serial kernels (still GPU; used by the parity tests to
 // cover both kernel families)
 void alz_set_force_serial(int on);
+int alz_kernel_occupancy(int fmt);   // resident waves per CU of the production decode kernel (tuning aid)
 
 // ---- encoder (alz_encode.hip)
 bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits);

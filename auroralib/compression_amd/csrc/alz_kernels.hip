@@ -6,11 +6,19 @@
 // window and output are private to its wave, so there is no inter-workgroup
 // traffic and no L2 sharing to arrange.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "alz_decode_fast.h"
 #include "alz_internal.h"
 
 #define ALZ_INCACHE_BYTES (2048 + 32)
+#define ALZ_INCACHE_SMALL (512 + 32)     /* 256-byte chunks: lane-parallel flag-family kernels */
+#ifndef ALZ_FAST_ATTR
+#define ALZ_FAST_ATTR
+#endif
+#ifndef ALZ_WPB
+#define ALZ_WPB 1                        /* waves (= streams) per workgroup of the lane-parallel kernels */
+#endif
 #ifndef ALZ_QUEUE_LW
 #define ALZ_QUEUE_LW 4096
 #endif
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
 // ------------------------------------------------------------------------------------------------
 // Lane-parallel kernel of the flag-byte family (alz_decode_fast.h); the exact serial parser finishes the tail.
 template <int FMT>
-__global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+__global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                              const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, u32 count,
                                                              alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
@@ -99,10 +107,18 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
     constexpr int NC = THREE ? 3 : 1;
     constexpr int LWMAX = (FMT == ALZ_FMT_LZSS) ? 8192 : 4096;
     // static LDS (absolute addresses fold into the DS instructions' offset fields): marks | input caches | window
-    __shared__ __attribute__((aligned(16))) u8 lds[128 + NC * ALZ_INCACHE_BYTES + LWMAX];
-    u32 bid = blockIdx.x;
+    // (the waves of a workgroup never interact: several streams share a workgroup only because a CU holds more waves than
+    // single-wave workgroups)
+    // input caches: 1 KiB chunks where there is one (16 B/lane loads), 256 B chunks for the three-cursor formats -- with three
+    // big caches a CU would hold 15 waves instead of 24 (measured: Yay0 585 -> 758, MIO0 379 -> 481 GiB/s)
+    constexpr u32 CHUNK = THREE ? 256u : 1024u;
+    constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : ALZ_INCACHE_BYTES;
+    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][128 + NC * CACHE + LWMAX];
+    const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
+    u8* const lds = lds_all[wid];
+    u32 bid = blockIdx.x * ALZ_WPB + wid;
     if (bid >= count) return;
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63u);
     const u32 sid = index_list ? index_list[bid] : bid;
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
@@ -110,9 +126,9 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
     u8* segmark = lds;
     u8* inc_lds = lds + 128;
-    OutWin<false> out; out.init(dst, cap, lds + 128 + NC * ALZ_INCACHE_BYTES, lw, lane);
+    OutWin<false> out; out.init(dst, cap, lds + 128 + NC * CACHE, lw, lane);
     segmark[lane] = 0; segmark[64 + lane] = 0;
-    InCache in; in.init(src, src_len, inc_lds, lane);
+    InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
     u32 used = 0; bool used_set = false;
     bool fin = false;
@@ -135,8 +151,8 @@ __global__ __launch_bounds__(64) void alz_decode_fast_kernel(const u8* __restric
         if (FMT == ALZ_FMT_YAY0 && (a0 > src_len || a1 > src_len)) s.eof = true;   // Slice() throws  Yay0.cs:102-103
         else {
             InCache cin, uin;
-            cin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); cin.seek(a0 < src_len ? a0 : 0);
-            uin.init(src, src_len, inc_lds + 2 * ALZ_INCACHE_BYTES, lane); uin.seek(a1 < src_len ? a1 : 0);
+            cin.init(src, src_len, inc_lds + CACHE, lane, CHUNK); cin.seek(a0 < src_len ? a0 : 0);
+            uin.init(src, src_len, inc_lds + 2 * CACHE, lane, CHUNK); uin.seek(a1 < src_len ? a1 : 0);
             u32 fp = 0, cp = a0, up = a1;
             while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len)
                 fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, segmark, lane, fp, cp, up);
@@ -253,7 +269,9 @@ template <int FMT>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
     (void)ncaches;
-    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3(count), dim3(64), 0, stream, src, dst, streams, index, count, results, lz, lw);
+    static int pad = -1;
+    if (pad < 0) { const char* e = getenv("ALZ_OCC_PAD"); pad = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
 
@@ -261,6 +279,26 @@ template <int FMT>
 static hipError_t launch_queue(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count, alz_result* results) {
     hipLaunchKernelGGL((alz_decode_queue_kernel<FMT>), dim3(count), dim3(64), 0, stream, src, dst, streams, index, count, results);
     return hipGetLastError();
+}
+
+// test / tuning hook: resident workgroups (= waves) per CU of the production kernel of `fmt`
+int alz_kernel_occupancy(int fmt) {
+    int n = 0; hipError_t e = hipErrorInvalidValue;
+    switch (fmt) {
+    case ALZ_FMT_LZSS: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZSS>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_LZ10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ10>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_LZ11: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ11>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_YAZ0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_YAZ0>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_YAY0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_YAY0>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_MIO0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_MIO0>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_PRS_BE: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_PRS_BE>, 64, 0); break;
+    case ALZ_FMT_PRS_LE: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_PRS_LE>, 64, 0); break;
+    case ALZ_FMT_LZ4_BLOCK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZ4_BLOCK>, 64, 0); break;
+    case ALZ_FMT_LZO: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZO>, 64, 0); break;
+    case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
+    default: break;
+    }
+    return e == hipSuccess ? n : -1;
 }
 
 static bool g_force_serial = false;
