@@ -98,14 +98,13 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
 
 // ------------------------------------------------------------------------------------------------
 // Lane-parallel kernel of the flag-byte family (alz_decode_fast.h); the exact serial parser finishes the tail.
-template <int FMT>
+template <int FMT, int LWMAX = 4096>
 __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                              const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, u32 count,
                                                              alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr int NC = THREE ? 3 : 1;
-    constexpr int LWMAX = (FMT == ALZ_FMT_LZSS) ? 8192 : 4096;
     // static LDS (absolute addresses fold into the DS instructions' offset fields): marks | input caches | window
     // (the waves of a workgroup never interact: several streams share a workgroup only because a CU holds more waves than
     // single-wave workgroups)
@@ -265,13 +264,13 @@ static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, cons
     return hipGetLastError();
 }
 
-template <int FMT>
+template <int FMT, int LWMAX = 4096>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
     (void)ncaches;
     static int pad = -1;
     if (pad < 0) { const char* e = getenv("ALZ_OCC_PAD"); pad = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
 
@@ -313,7 +312,9 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         switch (fmt) {   // lane-parallel kernels
         case ALZ_FMT_LZSS: {
             u32 W = 1u << lz.window_bits;
-            if (W <= 8192 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS>(stream, s, d, streams, index, count, results, lz, W, 1);
+            // LDS window sized for the geometry: 4 KiB windows (the LZSS default and every wrapper) keep 24 waves per CU
+            if (W <= 4096 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096>(stream, s, d, streams, index, count, results, lz, W, 1);
+            if (W <= 8192 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 8192>(stream, s, d, streams, index, count, results, lz, W, 1);
             break;
         }
         case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1);
