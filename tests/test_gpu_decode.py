@@ -141,3 +141,37 @@ def test_prs_terminator_inside_the_bulk_path(test_bmp):
     streams, src, dst_bytes = pack_streams(items)
     gr, _ = compare_batch(streams, src, dst_bytes, what="prs trailing data")
     assert (gr["status"] == 0).all()
+
+
+@pytest.mark.parametrize("fmt", ALL)
+def test_fuzz_garbage_and_mutations(fmt, test_bmp):
+    """Malformed input: random bytes, valid streams with bit flips / splices, wrong declared sizes.  Every result (status,
+    lengths, bytes below dst_len) must equal the oracle's; nothing may hang or write past dst_cap."""
+    import random
+    rng = random.Random(1234 + fmt)
+    items = []
+    raw = test_bmp[7000:7000 + 30000]
+    comp, aux = O.encode_stream(fmt, raw, quality=4)
+    for k in range(96):
+        kind = k % 4
+        if kind == 0:                                     # pure noise, lengths around every threshold of the bulk parsers
+            n = rng.choice([0, 1, 2, 7, 63, 64, 129, 1000, 1099, 1100, 1101, 1500, 4000, 9000])
+            src = bytes(rng.randrange(256) for _ in range(n))
+        elif kind == 1:                                   # bit flips in a valid stream
+            b = bytearray(comp)
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            src = bytes(b)
+        elif kind == 2:                                   # noise spliced into a valid stream
+            cut = rng.randrange(len(comp))
+            src = comp[:cut] + bytes(rng.randrange(256) for _ in range(rng.randrange(1, 3000))) + comp[cut:]
+        else:                                             # biased noise (many zeros / 0xFF: long runs, terminators, extensions)
+            n = rng.randrange(1100, 6000)
+            src = bytes(rng.choice([0, 0, 0xFF, 0x0F, 0xF0, rng.randrange(256)]) for _ in range(n))
+        decl = rng.choice([len(raw), len(raw), 100, 70000, 0])
+        cap = rng.choice([decl, decl + 300, max(decl, 1) // 2, 70000])
+        three = fmt in (A.FMT_YAY0, A.FMT_MIO0)            # aux = section offsets there (LZ4: aux0 would be frame history)
+        items.append(dict(fmt=fmt, src=src, decom_len=decl, cap=cap, aux0=aux.aux0 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0),
+                          aux1=aux.aux1 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0)))
+    streams, src, dst_bytes = pack_streams(items, dst_slack=32)
+    compare_batch(streams, src, dst_bytes, what="fuzz " + A.FORMAT_NAMES[fmt])
