@@ -741,6 +741,136 @@ __device__ __forceinline__ bool snappy_lane_parse(InCache& in, SK& sk, DecState&
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Lane-parallel LZO1X parse (LZO.cs:49-139).  What an instruction is depends on its first byte and, for the opcodes
+// below 16, on ONE piece of state -- whether the previous instruction copied 0, 1-3 or 4+ literals (LZO.cs:55) -- so every
+// lane works out "the instruction that would start at my byte" for both cases (state A: no pending literals -> a
+// literal run; state B/C: a 2-byte match of length 2 / 3) and the scalar walk carries the state from instruction to
+// instruction.  Each instruction yields a match token plus, when its low two bits say so, a run of 1-3 trailing
+// literals.  Length extensions of more than one byte, the end marker and anything else unusual stop the walk.
+
+// walk over a 256-byte window: `pk` per lane = [8:0] size and [10:9] next state when entered in state A, [19:11] and
+// [21:20] the same for states B / C.  Outputs: instruction starts per window, and per window the starts that were
+// entered in state B resp. C.  state: 0 = A, 1 = B (1-3 literals pending), 2 = C (a literal run came before).
+__device__ __forceinline__ void lzo_walk4(const u32 (&pk)[4], u64 (&mask)[4], u64 (&mb)[4], u64 (&mc)[4], u32& sp_out, u32& n_out, u32& state_io) {
+    u32 sp = 0, cnt = 0, stop = 0, state = uni(state_io);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        mask[w] = 0ull; mb[w] = 0ull; mc[w] = 0ull;
+        if (!stop && sp < 64u * (u32)(w + 1)) {
+            u32 v, n, sh;
+            asm volatile(
+                "1:\n\t"
+                "v_readlane_b32 %[v], %[pk], %[sp]\n\t"
+                "s_cmp_eq_u32 %[state], 0\n\t"
+                "s_cselect_b32 %[sh], 0, 11\n\t"
+                "s_lshr_b32 %[v], %[v], %[sh]\n\t"
+                "s_and_b32 %[n], %[v], 0x1ff\n\t"
+                "s_cbranch_scc0 2f\n\t"                         // size 0: not an instruction the walk takes
+                "s_bitset1_b64 %[mask], %[sp]\n\t"
+                "s_cmp_eq_u32 %[state], 1\n\t"
+                "s_cbranch_scc0 4f\n\t"
+                "s_bitset1_b64 %[mb], %[sp]\n"
+                "4:\n\t"
+                "s_cmp_eq_u32 %[state], 2\n\t"
+                "s_cbranch_scc0 5f\n\t"
+                "s_bitset1_b64 %[mc], %[sp]\n"
+                "5:\n\t"
+                "s_bfe_u32 %[state], %[v], 0x20009\n\t"         // bits [10:9]: the state the instruction leaves behind
+                "s_add_u32 %[sp], %[sp], %[n]\n\t"
+                "s_add_u32 %[cnt], %[cnt], 1\n\t"
+                "s_cmp_ge_u32 %[cnt], 32\n\t"
+                "s_cbranch_scc1 2f\n\t"
+                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_branch 3f\n"
+                "2:\n\t"
+                "s_mov_b32 %[stop], 1\n"
+                "3:\n\t"
+                : [v] "=&s"(v), [n] "=&s"(n), [sh] "=&s"(sh), [sp] "+s"(sp), [mask] "+s"(mask[w]), [mb] "+s"(mb[w]), [mc] "+s"(mc[w]),
+                  [cnt] "+s"(cnt), [stop] "+s"(stop), [state] "+s"(state)
+                : [pk] "v"(pk[w]), [lim] "s"(64u * (u32)(w + 1))
+                : "scc");
+        }
+    }
+    sp_out = sp; n_out = cnt; state_io = state;
+}
+
+// "the instruction that would start at cache index pos": sizes / next states for the walk (TOK = false) or the tokens of
+// the instruction entered in `state` (TOK = true: first token, and the trailing-literal token or 0)
+template <bool TOK>
+__device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 state, u32& second) {
+    const u32 f = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2], e3 = in.lds[pos + 3];
+    second = 0;
+    if (f >= 16u) {                                              // opcodes that do not depend on the state
+        u32 len, dist, t, size;
+        bool bad = false;
+        if (f < 64u) {                                           // M4 (16..31) / M3 (32..63): length [+ 1 extension byte] + 2 bytes
+            const u32 lm = f < 32u ? 7u : 31u;
+            const bool ext = (f & lm) == 0u;
+            len = ext ? (f < 32u ? 9u : 33u) + e1 : 2u + (f & lm);
+            bad = ext && e1 == 0u;                               // a second extension byte: exact parser
+            const u32 b0 = ext ? e2 : e1, b1 = ext ? e3 : e2;
+            if (f < 32u) { dist = (16384u + ((f & 8u) << 11)) | (b1 << 6) | (b0 >> 2); bad = bad || dist == 16384u; }   // end marker
+            else dist = ((b1 << 6) | (b0 >> 2)) + 1u;
+            t = b0 & 3u; size = (ext ? 4u : 3u) + t;
+        } else if (f < 128u) { len = 3u + ((f >> 5) & 1u); dist = (e1 << 3) + ((f >> 2) & 7u) + 1u; t = f & 3u; size = 2u + t; }
+        else { len = 5u + ((f >> 5) & 3u); dist = (e1 << 3) + ((f & 0x1cu) >> 2) + 1u; t = f & 3u; size = 2u + t; }
+        if (TOK) { if (t) second = ALZ_TOK_LIT(t, (pos + size - t) & 2047u); return ALZ_TOK_MATCH(len, dist); }
+        const u32 sz = bad ? 0u : size, nx = t ? 1u : 0u;
+        return sz | (nx << 9) | (sz << 11) | (nx << 20);
+    }
+    const bool ext = f == 0u;                                    // state A: literal run  LZO.cs:75-85
+    const u32 len = ext ? 18u + e1 : 3u + f;
+    const u32 t = f & 3u;                                        // states B / C: 2-byte match of length 2 / 3  LZO.cs:86-97
+    if (TOK) {
+        if (state == 0u) return ALZ_TOK_LIT(len, (pos + (ext ? 2u : 1u)) & 2047u);
+        if (t) second = ALZ_TOK_LIT(t, (pos + 2u) & 2047u);
+        return state == 1u ? ALZ_TOK_MATCH(2u, (e1 << 2) + (f >> 2) + 1u) : ALZ_TOK_MATCH(3u, (e1 << 2) + (f >> 2) + 2049u);
+    }
+    const u32 sizeA = (ext && e1 == 0u) ? 0u : (ext ? 2u : 1u) + len;
+    return sizeA | (2u << 9) | ((2u + t) << 11) | ((t ? 1u : 0u) << 20);
+}
+
+// Preconditions: queue empty, >= 1100 input bytes ahead of s.p (an instruction boundary), cache covers [p, p + 1024).
+template <class SK>
+__device__ __forceinline__ bool lzo_lane_parse(InCache& in, SK& sk, DecState& s, LzoState& ls, u32* stage, int lane) {
+    const u32 p = s.p;
+    const u32 i0 = in.idx(p);
+    u32 pk[4], dummy;
+#pragma unroll
+    for (int w = 0; w < 4; w++) pk[w] = lzo_interpret<false>(in, i0 + 64u * (u32)w + (u32)lane, 0u, dummy);
+    u64 mask[4], mb[4], mc[4]; u32 sp, ninstr;
+    u32 state = ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u);
+    lzo_walk4(pk, mask, mb, mc, sp, ninstr, state);
+    if (ninstr == 0u) return false;
+    u32 base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (mask[w]) {                                           // tokens only where the walk found instructions, in the state it found them
+            const bool st = (mask[w] >> lane) & 1ull;
+            const u32 est = ((mb[w] >> lane) & 1ull) ? 1u : (((mc[w] >> lane) & 1ull) ? 2u : 0u);
+            u32 tl;
+            const u32 first = lzo_interpret<true>(in, i0 + 64u * (u32)w + (u32)lane, est, tl);
+            const bool second = st && tl != 0u;
+            const u64 sm = __ballot(second);
+            const u32 rank = base + mbcnt64(mask[w]) + mbcnt64(sm);
+            if (st) { stage[rank] = first; if (second) stage[rank + 1u] = tl; }
+            base += (u32)__popcll(mask[w]) + (u32)__popcll(sm);
+        }
+    }
+    wave_sync();
+    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
+    wave_sync();
+    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
+    sk.qtok = qt; sk.nt = base; sk.qbytes = total;
+    s.p = p + sp;
+    ls.plain = state == 0u ? 0u : (state == 1u ? 1u : 4u);
+    sk.flush();
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // PRS: control bits and data bytes interleave, and a flag byte is fetched at the moment a bit is needed -- possibly in the
 // middle of a token -- so where tokens start depends on everything before them.  What CAN be done for all bytes at once
 // is what a token would BE if it started at a given byte: every lane interprets "its" byte as a literal, a short match

@@ -233,67 +233,74 @@ __device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u3
     }
 }
 
-// LZO.DecompressHeaderless  Formats/Common/LZO.cs:49-139
+// LZO.DecompressHeaderless  Formats/Common/LZO.cs:49-139.  Resumable at instruction boundaries: `ls` carries the one
+// piece of decoder state that crosses instructions (the literal count of the previous instruction, LZO.cs:55) and s.p
+// always points at the next instruction's first byte.
+struct LzoState { u32 plain; bool started; };
+__device__ __forceinline__ void lzo_state_init(LzoState& ls) { ls.plain = 0; ls.started = false; }
+
 template <class SK>
-__device__ void dec_lzo_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
-#define LZO_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); dst = in.peek1(s.p); s.p++; } while (0)
-#define LZO_EXT(dst) do { u32 b_, acc_ = 0; for (;;) { LZO_BYTE(b_); if (b_ != 0) break; acc_ += 255; } dst = acc_ + b_; } while (0)
-    u32 flag, length, distance, plain = 0;
-    LZO_BYTE(flag);
-    if (flag > 17) {
-        length = flag - 17;
-        if (length > src_len - s.p) { s.eof = true; return; }
-        if (!sk.run(in, s.p, length)) return;
-        s.p += length;
+__device__ void dec_lzo_serial(InCache& in, SK& sk, DecState& s, u32 src_len, LzoState& ls, u32 max_instr = 0xFFFFFFFFu) {
+    // residency is established once per instruction (16 bytes cover every fixed-size header); only the unbounded
+    // length-extension loop asks again -- one ensure() per byte made this parser 50 KB of code under QueueSink
+#define LZO_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } dst = in.peek1(s.p); s.p++; } while (0)
+#define LZO_EXT(dst) do { u32 b_, acc_ = 0; for (;;) { sk.ensure(in, s.p, 1); LZO_BYTE(b_); if (b_ != 0) break; acc_ += 255; } sk.ensure(in, s.p, 16); dst = acc_ + b_; } while (0)
+    u32 flag, length, distance;
+    if (!ls.started) {                                    // the first byte may announce an initial literal run  LZO.cs:58-66
+        ls.started = true;
+        sk.ensure(in, s.p, 16);
         LZO_BYTE(flag);
+        if (flag > 17) {
+            length = flag - 17;
+            if (length > src_len - s.p) { s.eof = true; return; }
+            if (!sk.run(in, s.p, length)) return;
+            s.p += length;
+        } else s.p--;                                     // an ordinary instruction: read again below
     }
     for (;;) {
+        if (max_instr-- == 0) return;
+        sk.ensure(in, s.p, 16);
+        LZO_BYTE(flag);                                   // ReadByte() == -1 -> EndOfStreamException  LZO.cs:136-137
+        u32 plain = ls.plain;
         u32 flagcode = flag >> 4;
         bool literal_op = false;
         if (flagcode == 0) {
             if (plain == 0) {
                 length = 3 + flag;
                 if (length == 3) { u32 e; LZO_EXT(e); length = 18 + e; }
-                plain = 4;
+                ls.plain = 4;
                 if (length > src_len - s.p) { s.eof = true; return; }
                 if (!sk.run(in, s.p, length)) return;
                 s.p += length;
                 literal_op = true;
-            } else if (plain <= 3) {
-                u32 d; LZO_BYTE(d); distance = (d << 2) + (flag >> 2) + 1; length = 2;
             } else {
-                u32 d; LZO_BYTE(d); distance = (d << 2) + (flag >> 2) + (2048 + 1); length = 3;
+                u32 d; LZO_BYTE(d);
+                if (plain <= 3) { distance = (d << 2) + (flag >> 2) + 1; length = 2; }
+                else { distance = (d << 2) + (flag >> 2) + (2048 + 1); length = 3; }
             }
-        } else if (flagcode == 1) {
-            length = 2 + (flag & 0x7);
-            if (length == 2) { u32 e; LZO_EXT(e); length = 9 + e; }
-            distance = 16384 + ((flag & 0x8) << 11);
-            LZO_BYTE(flag);
-            u32 hi; LZO_BYTE(hi);
-            distance |= (hi << 6) | (flag >> 2);
-            if (distance == 16384) { s.done = true; return; }
         } else if (flagcode <= 3) {
-            length = 2 + (flag & 0x1f);
-            if (length == 2) { u32 e; LZO_EXT(e); length = 33 + e; }
+            const bool m4 = flagcode == 1;
+            const u32 lm = m4 ? 0x7u : 0x1fu;
+            length = 2 + (flag & lm);
+            if (length == 2) { u32 e; LZO_EXT(e); length = (m4 ? 9u : 33u) + e; }
+            const u32 base = m4 ? 16384u + ((flag & 0x8) << 11) : 0u;
             LZO_BYTE(flag);
             u32 hi; LZO_BYTE(hi);
-            distance = ((hi << 6) | (flag >> 2)) + 1;
-        } else if (flagcode <= 7) {
-            length = 3 + ((flag >> 5) & 0x1);
-            u32 d; LZO_BYTE(d); distance = (d << 3) + ((flag >> 2) & 0x7) + 1;
+            if (m4) { distance = base | (hi << 6) | (flag >> 2); if (distance == 16384) { s.done = true; return; } }
+            else distance = ((hi << 6) | (flag >> 2)) + 1;
         } else {
-            length = 5 + ((flag >> 5) & 0x3);
-            u32 d; LZO_BYTE(d); distance = (d << 3) + ((flag & 0x1c) >> 2) + 1;
+            u32 d; LZO_BYTE(d);
+            if (flagcode <= 7) { length = 3 + ((flag >> 5) & 0x1); distance = (d << 3) + ((flag >> 2) & 0x7) + 1; }
+            else { length = 5 + ((flag >> 5) & 0x3); distance = (d << 3) + ((flag & 0x1c) >> 2) + 1; }
         }
         if (!literal_op) {
             plain = flag & 0x3;
+            ls.plain = plain;
             if (!sk.match(distance, length, 65536)) return;
             if (plain > src_len - s.p) { s.eof = true; return; }
             if (!sk.run(in, s.p, plain)) return;
             s.p += plain;
         }
-        if (s.p >= src_len) { s.eof = true; return; }          // ReadByte() == -1 -> EndOfStreamException  LZO.cs:136-137
-        sk.ensure(in, s.p, 1); flag = in.peek1(s.p); s.p++;
     }
 #undef LZO_BYTE
 #undef LZO_EXT

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     } else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) {
         dec_lz4_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_LZO) {
-        dec_lzo_serial(in, sk, s, src_len);
+        LzoState ls; lzo_state_init(ls);
+        dec_lzo_serial(in, sk, s, src_len, ls);
     } else if constexpr (FMT == ALZ_FMT_SNAPPY_RAW) {
         u32 sz = 0; bool have = false;
         dec_snappy_serial(in, sk, s, src_len, sz, have);
@@ -231,7 +232,19 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
     }
-    else if constexpr (FMT == ALZ_FMT_LZO) dec_lzo_serial(in, sk, s, src_len);
+    else if constexpr (FMT == ALZ_FMT_LZO) {
+        LzoState ls; lzo_state_init(ls);
+        for (;;) {
+            if (ls.started && s.p + 1100u <= src_len) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                if (lzo_lane_parse(in, sk, s, ls, stage, lane)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_lzo_serial(in, sk, s, src_len, ls, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
+    }
     else {
         // Snappy: varint size, then elements until the output reaches it; lane-parallel parse for the bulk
         u32 size = 0; bool have = false;
