@@ -23,6 +23,10 @@
 #pragma once
 #include "alz_decode_serial.h"
 
+#ifndef ALZ_NB
+#define ALZ_NB 8    /* steps whose HBM read-backs are issued together (two-pass byte phase of the 64 KiB formats) */
+#endif
+
 __device__ __forceinline__ u32 wave_bperm(u32 src_lane, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 __device__ __forceinline__ u32 wave_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 // v_writelane_b32: write a wave-uniform value into one lane of a VGPR (no clang builtin in ROCm 7.2).  gfx9 allows one
@@ -248,7 +252,7 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
         // Sources older than the LDS window come back from HBM (1-2 us each).  They are independent of everything this
         // batch produces, so the step is split: pass 1 maps bytes to tokens for up to 16 steps and issues ALL their
         // read-backs at once, pass 2 copies.  (For LDS-only configs this split costs more instructions than it saves.)
-        constexpr int NB = 16;
+        constexpr int NB = ALZ_NB;
         while (X < T) {
             const u32 nb = T - X < 64u * NB ? T - X : 64u * NB;
             const u32 nsteps = (nb + 63u) >> 6;
