@@ -19,6 +19,9 @@
 #ifndef ALZ_WPB
 #define ALZ_WPB 1                        /* waves (= streams) per workgroup of the lane-parallel kernels */
 #endif
+#ifndef ALZ_PRS_LW
+#define ALZ_PRS_LW 8192
+#endif
 #ifndef ALZ_QUEUE_LW
 #define ALZ_QUEUE_LW 4096
 #endif
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     // These kernels are bound by the latency of one wave's scalar parse, so waves per CU matter more than LDS hits:
     // only the most recent 4 KiB of the window stay in LDS (6.3 KB per wave -> 25 waves per CU instead of 15), older
     // sources are read back from the stream's own output in HBM, batched per token queue.
-    constexpr u32 LW = PRS ? 8192u : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
+    constexpr bool PRSFB = (ALZ_PRS_LW < 8192);             // PRS with a window smaller than its 8 KiB: read-back like the 64 KiB formats
+    constexpr u32 LW = PRS ? (u32)ALZ_PRS_LW : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
     // static LDS: marks (128) | token staging (256) | input cache | window
     __shared__ __attribute__((aligned(16))) u8 lds[384 + ALZ_INCACHE_BYTES + LW];
     u32 bid = blockIdx.x;
@@ -193,13 +197,13 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     u8* segmark = lds;
     u32* stage = reinterpret_cast<u32*>(lds + 128);
     u8* inc_lds = lds + 384;
-    typedef OutWin<!PRS> OW;
+    typedef OutWin<(!PRS || PRSFB)> OW;
     OW out; out.init(dst, cap, lds + 384 + ALZ_INCACHE_BYTES, LW, lane);
     if (hist) out.preload(hist);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
-    typedef EmitCfg<LW - 1u, false, !PRS, !PRS> CFG;
+    typedef EmitCfg<LW - 1u, false, !PRS, (!PRS || PRSFB)> CFG;
     typedef QueueSink<OW, CFG> SK;
     SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : 65536u);
     if constexpr (PRS) {

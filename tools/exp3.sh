@@ -1,14 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for nb in 16 12 8 6; do
+for lw in 8192 4096; do
   rm -rf auroralib/compression_amd/csrc/_obj
-  ALZ_EXTRA_FLAGS="-DALZ_NB=$nb" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1
-  for f in lz4_block snappy_raw lzo; do
-  echo -n "NB=$nb $f "
+  ALZ_EXTRA_FLAGS="-DALZ_PRS_LW=$lw" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1
+  for f in prs_be mixed; do
+  echo -n "PRS_LW=$lw $f "
   python bench.py --no-cpu-baseline --steps 10 --format $f 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['back_to_back']['value'], d['roofline']['kernel_ms'], d['config']['parity_ok'])"
   done
 done
-python3 -c "
-from auroralib.compression_amd._lib import load
-from auroralib.compression_amd.batch import Context
-c = Context(0); l = load()
-print('occupancy:', [l.alz_debug_occupancy(f) for f in range(11)])"
