@@ -18,8 +18,13 @@
 //        the same 64-byte step by pointer jumping over ds_bpermute, writes the window; 1 KiB blocks are written back
 //        to HBM coalesced as they complete.
 //
-// The serial decoders (alz_decode_serial.h) remain the exact reference: the fast loop only runs while at least 128
-// input bytes remain (so no token can be truncated) and hands the stream tail to them.
+// The serial decoders (alz_decode_serial.h) remain the exact reference: the fast loop runs to the last complete token of
+// the input and hands the stream tail -- and every error path -- to them.
+//
+// Second half of the file: the token queue (QueueSink) that lets the byte phase execute tokens of ANY grammar, and the
+// lane-assisted parsers that fill it for the grammars whose token boundaries can only be found by walking the stream:
+// LZ4 / Snappy / LZO (per-byte speculation "the element that would start here" + a scalar v_readlane walk) and PRS
+// (per-byte token interpretations + a scalar walk over a VGPR-resident window with the flag register in an SGPR).
 #pragma once
 #include "alz_decode_serial.h"
 
@@ -546,51 +551,6 @@ struct QueueSink {
     }
 };
 
-// wave-uniform little-endian 8 bytes at input offset p (caller guarantees residency)
-__device__ __forceinline__ u64 peek8(const InCache& in, u32 p) {
-    const u32 i = in.idx(p);
-    const u32* w = reinterpret_cast<const u32*>(in.lds + (i & ~3u));
-    const u32 w0 = w[0], w1 = w[1], w2 = w[2];
-    const u32 lo = __builtin_amdgcn_alignbyte(w1, w0, i & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, i & 3u);
-    return ((u64)uni(hi) << 32) | uni(lo);
-}
-
-// Lean parse loops for the bulk of a stream: no bounds checks (the caller guarantees >= 1100 input bytes ahead and a
-// resident cache), tokens decoded from an 8-byte scalar window.  Anything unusual (terminator, a token that does not fit
-// the packed queue word, a literal run reaching past the guaranteed region) stops the loop; the exact parser of
-// alz_decode_serial.h then handles that token.  Returns the number of tokens pushed.
-
-// LZ4.DecompressBlockHeaderless  Formats/Common/LZ4.cs:176-200
-template <class SK>
-__device__ __forceinline__ void lz4_fast_parse(InCache& in, SK& sk, DecState& s, u32 limit) {
-    u32 pp = s.p;
-    const u32 room = sk.out.cap - (sk.produced());           // stop before the capacity rule (E5) could apply
-    u32 made = 0;
-    while (sk.nt <= 62u && pp < limit) {
-        const u64 w = peek8(in, pp);
-        const u32 tok = (u32)w & 0xFFu;
-        u32 L = tok >> 4, M = tok & 15u;
-        u32 q = pp + 1u;
-        u32 dist;
-        if (L < 6u) dist = (u32)(w >> (8u * (1u + L))) & 0xFFFFu;           // literals and offset inside the window
-        else {
-            if (L == 15u) { u32 b; do { b = in.peek1(q); q++; L += b; } while (b == 255u && L < 1200u); }
-            if (L > 1000u || q + L + 3u > limit) break;
-            dist = in.peek4(q + L) & 0xFFFFu;
-        }
-        const u32 litpos = q;
-        q += L + 2u;
-        if (M == 15u) { u32 b; do { b = in.peek1(q); q++; M += b; } while (b == 255u && M < 16000u); }
-        M += 4u;
-        if (M > ALZ_TOK_MAXLEN || q > limit || made + L + M > room) break;
-        if (L) sk.push_word(ALZ_TOK_LIT(L, in.idx(litpos)), L);
-        sk.push_word(ALZ_TOK_MATCH(M, dist ? dist : 65536u), M);
-        made += L + M;
-        pp = q;
-    }
-    s.p = pp;
-}
-
 // Walk of a chain of variable-size elements over a 256-byte window (4 x 64): nx[w] holds, per lane, the size of "the
 // element that would start at byte 64 w + lane" (0 = stop here: unusual element).  Returns the element starts as one
 // 64-bit mask per window, the offset of the first element not taken, and the count (<= maxn).  Runs on the scalar unit,
@@ -1010,44 +970,4 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
     if (term) s.done = true;                                   // PRS.cs:78-79: the zero word ends the stream
     sk.flush();
     return true;
-}
-
-// PRS.DecompressHeaderless  Sega/PRS.cs:59-102
-template <class SK, bool BIG>
-__device__ __forceinline__ void prs_fast_parse(InCache& in, SK& sk, DecState& s, u32 limit) {
-    u32 pp = uni(s.p), bits = uni(s.bits), flag = uni(s.flag);
-    const u32 room = uni(sk.out.cap - sk.produced());      // (uni: keeps the whole loop on the scalar unit)
-    limit = uni(limit);
-    u32 made = 0;
-    while (sk.nt <= 63u && pp < limit) {
-        const u64 w = peek8(in, pp);
-        u32 k = 0;                                           // bytes of the window consumed by this token
-        u32 fl2 = flag, nb = bits;
-#define PRS_BIT(dst) do { if (nb == 0) { fl2 = (u32)(w >> (8u * k)) & 0xFFu; k++; nb = 8; } \
-                          dst = BIG ? (fl2 >> (nb - 1u)) & 1u : (fl2 >> (8u - nb)) & 1u; nb--; } while (0)   /* same (bits, flag) convention as dec_prs_serial */
-        u32 b; PRS_BIT(b);
-        u32 word, len;
-        if (b) { word = ALZ_TOK_LIT(1u, (u32)(w >> (8u * k)) & 0xFFu); k++; len = 1; }
-        else {
-            u32 b2; PRS_BIT(b2);
-            u32 dist;
-            if (b2) {
-                const u32 x0 = (u32)(w >> (8u * k)) & 0xFFu, x1 = (u32)(w >> (8u * k + 8u)) & 0xFFu; k += 2;
-                const u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);
-                if (v == 0) break;                                   // terminator: leave it to the exact parser
-                len = v & 7u; dist = 0x2000u - (v >> 3);
-                if (len == 0) { len = ((u32)(w >> (8u * k)) & 0xFFu) + 1u; k++; } else len += 2u;
-            } else {
-                u32 h, l; PRS_BIT(h); PRS_BIT(l);
-                len = ((h << 1) | l) + 2u;
-                dist = 0x100u - ((u32)(w >> (8u * k)) & 0xFFu); k++;
-            }
-            word = ALZ_TOK_MATCH(len, dist);
-        }
-#undef PRS_BIT
-        if (made + len > room) break;
-        sk.push_word(word, len);
-        made += len; pp += k; bits = nb; flag = fl2;
-    }
-    s.p = pp; s.bits = bits; s.flag = flag;
 }
