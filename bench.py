@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--streams", type=int, default=10000)
     ap.add_argument("--stream-kib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the byte comparison with the CPU baseline's output")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight per GPU: 2 (default) = double buffered on two HIP streams / two "
                     "output buffers, so the tail of one batch (few streams left, the chip half empty) overlaps the head of the next; "
                     "1 = the steps run back to back on one stream.  The back-to-back figure is always measured and reported too.")
@@ -128,20 +128,13 @@ def main():
     # dominant kernel, HIP events on the launch stream (device time per launch)
     kernel_ms = plan.execute_timed(d_src, d_dst, iters=max(3, min(args.steps, 10)))
 
-    # parity of what was just measured: every status OK, every length right, sampled outputs bit-exact vs the oracle
+    # what was just measured decoded completely: every status OK, every length right (GPU results only)
     res = synth.result_records(plan.results())
     ok = bool((res["status"] == 0).all() and (res["dst_len"] == target).all())
     verified = None
-    if not args.no_verify and rank == 0:
-        import oracle_lib as O
-        k = min(n, 256)
-        sub = (A.Stream * k)(*[batch.streams[i] for i in range(k)])
-        o_dst, o_res = O.decode_batch(sub, batch.src, batch.dst_bytes, nthreads=os.cpu_count() or 1)
-        span = int(recs["dst_off"][k - 1]) + target
-        g = ctx.d2h(d_dst, span)
-        verified = bool(np.array_equal(g[:span], o_dst[:span]))
-        ok = ok and verified
 
+    # cpu_baseline leg -- the only place that touches oracle/: the C restatement decodes the same batch on the host cores
+    # (timed), and because it then holds the reference output anyway, the GPU's bytes are compared with it
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         import oracle_lib as O
@@ -157,6 +150,17 @@ def main():
         cpu = {"value": round(decomp_bytes * reps / tcpu / 2**30, 3), "unit": "GiB/s", "cores": cores, "kind": "port",
                "sample": "full batch (%d x %d KiB %s) x %d passes, C restatement of the managed ring+flush path, %d host threads"
                          % (n, args.stream_kib, args.format, reps, cores)}
+        if not args.no_verify:
+            k = min(n, 1024)
+            span = int(recs["dst_off"][k - 1]) + target
+            g = ctx.d2h(d_dst, span)
+            verified = True
+            for i in range(k):                            # stream by stream (gaps between streams are not output)
+                a = int(recs["dst_off"][i])
+                if not np.array_equal(g[a:a + target], o_dst[a:a + target]):
+                    verified = False
+                    break
+            ok = ok and verified
 
     if rank == 0:
         value = whole_job_value(decomp_bytes, world, args.steps, dt)
