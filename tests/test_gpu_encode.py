@@ -102,3 +102,31 @@ def test_container_compress_roundtrip(test_bmp):
             comp = f.Compress(raw, s)
             assert comp == O.container_compress(cont, raw, quality=s.Quality), (cls.__name__, s.Quality)
             assert f.Decompress(comp, capacity=len(raw) + 300) == raw
+
+
+def test_encode_matches_committed_vectors(test_bmp):
+    """The GPU encoder against tests/golden/oracle_vectors.json -- no oracle involved at run time: every body of the
+    round-trip matrix as ONE encode batch per quality, lengths and XXH64 digests compared with the committed ones."""
+    import json
+    import os
+    import xxhash
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+    by_q = {}
+    for key, v in vec["bodies"].items():
+        name, size, q = key.split(":")
+        by_q.setdefault(int(q[1:]), []).append((A.FORMAT_NAMES.index(name), int(size), v, key))
+    for q, items in by_q.items():
+        n = len(items)
+        raw = np.frombuffer(test_bmp[:max(s for _, s, _, _ in items)] + bytes(64), dtype=np.uint8).copy()
+        streams = (A.Stream * n)()
+        off = 0
+        for i, (fmt, size, _, _) in enumerate(items):
+            cap = size + size // 4 + 64
+            streams[i] = A.Stream(0, off, size, cap, 0, 0, 0, fmt)
+            off += (cap + 255) // 256 * 256
+        dst, res, aux = ctx().encode_batch(streams, raw, off + 64, quality=q)
+        auxv = np.frombuffer(aux, dtype=np.uint32).reshape(n, 2)
+        for i, (fmt, size, (length, digest, a0, a1), key) in enumerate(items):
+            assert res[i].status == 0 and res[i].dst_len == length, key
+            body = bytes(dst[int(streams[i].dst_off):int(streams[i].dst_off) + length])
+            assert xxhash.xxh64(body).hexdigest() == digest and (int(auxv[i, 0]), int(auxv[i, 1])) == (a0, a1), key

@@ -133,3 +133,18 @@ def test_published_ratio_q15(container, test_bmp):
     # percentage points BELOW the published ratio for the 4 KiB-window formats (LZO: exact).  Benchmarks.md
     # carries no commit id; the current LzChainMatchFinder source is what the oracle restates.
     assert round(len(comp) / len(raw) * 100, 2) == pytest.approx(RATIO_PINS_Q15[container], abs=0.09), len(comp)
+
+
+def test_committed_oracle_vectors(test_bmp):
+    """tests/golden/oracle_vectors.json (made by tests/golden/make_vectors.py): the encoders' output for the round-trip
+    matrix is frozen -- any drift of the restatement shows up here, not as a silent change of what 'parity' means."""
+    import json
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+    for key, (length, digest, a0, a1) in vec["bodies"].items():
+        name, size, q = key.split(":")
+        comp, aux = O.encode_stream(A.FORMAT_NAMES.index(name), test_bmp[:int(size)], quality=int(q[1:]))
+        assert (len(comp), "%016x" % O.xxh64(comp), aux.aux0, aux.aux1) == (length, digest, a0, a1), key
+    for key, (length, digest) in vec["containers"].items():
+        name, size, q = key.split(":")
+        comp = O.container_compress(getattr(A, "C_" + name), test_bmp[:int(size)], quality=int(q[1:]))
+        assert (len(comp), "%016x" % O.xxh64(comp)) == (length, digest), key
