@@ -178,7 +178,7 @@ __device__ __forceinline__ void copy_step(OW& out, const u8* inlds, int lane, u3
 // `dsc` holds the descriptors of the current step on entry and of the next step on return; relm / tbase4 belong to the
 // mapping side (one step ahead of qs).
 template <class OW, class CFG>
-__device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32& dsc) {
+__device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, const u32 dsc, u32& dsc_next) {
     const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
     u8* const win = out.win;
     { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }
@@ -206,7 +206,7 @@ __device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds
     }
     win[qs & omask] = (u8)val;
     wave_sync();
-    qs += 64u; relm -= 64u; dsc = dscn;
+    qs += 64u; relm -= 64u; dsc_next = dscn;
 }
 
 // Shared back end.  Per-lane token: valid, len (>=1), desc, tend = input offset just past the token (relative to the
@@ -310,7 +310,12 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
                 const u32 pos = O + X + out.oshift;
                 u32 nb = (out.fl - (pos & (out.fl - 1u)) + 63u) >> 6;
                 if (nb > nleft) nb = nleft;
-                for (u32 k = nb; k; k--) fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc);
+                u32 k = nb, dsc2;                               // two steps per trip: the descriptors ping-pong between two registers
+                for (; k >= 2u; k -= 2u) {
+                    fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc, dsc2);
+                    fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc2, dsc);
+                }
+                if (k) { fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc, dsc2); dsc = dsc2; }
                 X += 64u * nb; nleft -= nb; out.produced = O + X;
                 if (out.produced - out.flushed >= out.fl) out.flush_blocks();
             } while (nleft);
