@@ -69,3 +69,28 @@ def test_product_does_not_reference_oracle():
     so = os.path.join(ROOT, "auroralib", "compression_amd", "libauroralz.so")
     needed = subprocess.run(["objdump", "-p", so], capture_output=True, text=True).stdout
     assert "oracle" not in needed
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/auroralz.h is the contract a C / C# / Go host binds: it must compile as strict C99 and the symbols must
+    link from plain C (no C++ name mangling, no torch or HIP types in the signatures)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "host.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "auroralz.h"
+int main(void) {
+    alz_stream s; alz_result r; alz_container_options o; alz_scan_hit h;
+    (void)s; (void)r; (void)o; (void)h;
+    if (sizeof(alz_stream) != 40 || sizeof(alz_result) != 16 || sizeof(alz_lz_properties) != 16) return 2;
+    printf("%d %d %s\n", alz_abi_version(), (int)ALZ_C_COUNT, alz_brute_decoder_name(4));
+    return alz_container_is_match(ALZ_C_YAZ0, (const uint8_t*)"Yaz0\0\0\1\0\0\0\0\0\0\0\0\0xxxxxxxx", 24) == 1 ? 0 : 3;
+}
+""")
+    exe = tmp_path / "host"
+    libdir = os.path.join(root, "auroralib", "compression_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lauroralz", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert out[0] == str(A.ABI_VERSION) and out[1] == str(A.C_COUNT) and " ".join(out[2:]) == "LZSS (10, 6, 2)"
