@@ -18,7 +18,8 @@ E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_FORMAT, E_STREAM, E_CHE
 C_LZSS, C_LZ10, C_LZ11, C_YAZ0, C_YAY0, C_MIO0, C_PRS, C_LZ4_LEGACY, C_LZO, C_SNAPPY = range(10)
 C_GCLZ, C_CXLZ, C_LZ_3DS, C_COMP, C_YAZ1, C_AKLZ, C_LZ01, C_LZSEGA, C_LEVEL5LZSS, C_LZON, C_LZ77, C_LEVEL5 = range(10, 22)
 C_LZ4_FRAME = 22
-C_COUNT = 23
+C_MDB4, C_FCMP, C_IECP, C_GCZ, C_ECD, C_SDPC = range(23, 29)
+C_COUNT = 29
 LZ77_LZ10, LZ77_LZ11, LZ77_CHUNKLZ10 = 0x10, 0x11, 0xF7
 LEVEL5_ONLYSAVE, LEVEL5_LZ10 = 0, 1
 

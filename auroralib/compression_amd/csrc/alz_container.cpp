@@ -457,6 +457,14 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZSEGA: if (len < 8) return ALZ_E_FORMAT; *size_out = le32(src + 4); return ALZ_OK;                                        // LZSega.cs:41-46
     case ALZ_C_LEVEL5LZSS: if (len < 16 || memcmp(src, "SSZL", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 12); return ALZ_OK;        // Level5LZSS.cs:33-39
     case ALZ_C_LZON: if (len < 12 || memcmp(src, kLzonMagic, 8)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return ALZ_OK;            // LZOn.cs:33-38
+    case ALZ_C_MDB4: if (len < 12 || memcmp(src, "MDB4", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 8); return ALZ_OK;               // MDB4.cs:25-31
+    case ALZ_C_FCMP: case ALZ_C_IECP: case ALZ_C_SDPC:                                                                                     // FCMP.cs:28-33
+        if (len < 8 || memcmp(src, container == ALZ_C_FCMP ? "FCMP" : container == ALZ_C_IECP ? "IECP" : "SDPC", 4)) return ALZ_E_FORMAT;
+        *size_out = le32(src + 4); return ALZ_OK;
+    case ALZ_C_GCZ: if (len < 4) return ALZ_E_FORMAT; *size_out = le32(src); return ALZ_OK;                                                // GCZ.cs:30
+    case ALZ_C_ECD:                                                                                                                        // ECD.cs:34-43
+        if (len < 16 || memcmp(src, "ECD", 3)) return ALZ_E_FORMAT;
+        *size_out = (uint64_t)be32(src + 8) + 0x10 > len ? 0u : be32(src + 12); return ALZ_OK;
     case ALZ_C_LZ4_FRAME:   // not an IProvidesDecompressedSize in the reference; offered where the descriptor carries ContentSize
         if (len < 15 || le32(src) != 0x184D2204u || !(src[4] & 8) || le32(src + 10) != 0) return ALZ_E_UNSUPPORTED;
         *size_out = le32(src + 6); return ALZ_OK;
@@ -507,6 +515,12 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_LZSEGA: { if (len < 0x12) return 0; const uint32_t cs = le32(src), ds = le32(src + 4); return (cs == len - 8 || cs == len) && ds != 0 && (src[8] & 1) == 1; }   // LZSega.cs:27-38
     case ALZ_C_LEVEL5LZSS: return len > 0x10 && !memcmp(src, "SSZL", 4) && le32(src + 4) == 0;
     case ALZ_C_LZON: return len > 0x10 && !memcmp(src, kLzonMagic, 8);
+    case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
+    case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
+    case ALZ_C_IECP: return len > 0x10 && !memcmp(src, "IECP", 4);
+    case ALZ_C_GCZ: return 0;                                                               // extension ".gcz" required (GCZ.cs:23-28): no file name here
+    case ALZ_C_ECD: return len > 0x10 && !memcmp(src, "ECD", 3) && (uint64_t)be32(src + 8) + 0x10 <= len && be32(src + 12) != 0;   // ECD.cs:29-30
+    case ALZ_C_SDPC: return len > 0x10 && !memcmp(src, "SDPC", 4) && le32(src + 4) != 0;
     case ALZ_C_LZ77: return len > 0x8 && !memcmp(src, "LZ77", 4) && (src[4] == 0x10 || src[4] == 0x11 || src[4] == 0x24 || src[4] == 0x28 || src[4] == 0x30 || src[4] == 0xF7);
     default: return 0;
     }
@@ -603,6 +617,49 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src + hdr, len - hdr, 0, 0, 0, dst, dst_cap, &r);
         if (rc == ALZ_OK && r.status == ALZ_ST_OK && r.dst_len != size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // DecompressedSizeException.ThrowIfMismatch
         break;
+    case ALZ_C_MDB4:                                                                        // MDB4.cs:33-50
+        if (len < 4 || memcmp(src, "MDB4", 4)) return ALZ_E_FORMAT;
+        if (len < 32) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = le32(src + 8); hdr = 32;
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_FCMP: case ALZ_C_IECP: case ALZ_C_GCZ: {                                     // FCMP.cs:36-41, IECP.cs:35-39, GCZ.cs:32-36
+        const char* magic = container == ALZ_C_FCMP ? "FCMP" : "IECP";
+        const size_t ml = container == ALZ_C_GCZ ? 0 : 4;
+        hdr = ml + (container == ALZ_C_FCMP ? 8 : 4);
+        if (len < ml || (ml && memcmp(src, magic, 4))) return ALZ_E_FORMAT;
+        if (len < hdr) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = le32(src + ml);
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_SDPC:                                                                        // SDPC.cs:34-47
+        if (len < 4 || memcmp(src, "SDPC", 4)) return ALZ_E_FORMAT;
+        if (len < 8) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = le32(src + 4); hdr = 8;
+        rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src + hdr, len - hdr, 0, 0, 0, dst, dst_cap, &r);
+        if (rc == ALZ_OK && r.status == ALZ_ST_OK && r.dst_len > size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // '>' only  SDPC.cs:43
+        break;
+    case ALZ_C_ECD: {                                                                       // ECD.cs:45-71
+        if (len < 3 || memcmp(src, "ECD", 3)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        const bool compressed = src[3] == 1;
+        const uint32_t plain = be32(src + 4); size = be32(src + 12); hdr = 16;
+        if (!compressed) {                                                                  // source.CopyTo(destination)
+            const size_t n = len - hdr;
+            if (n > dst_cap) { memcpy(dst, src + hdr, dst_cap); r.dst_len = clamp32(dst_cap); r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+            memcpy(dst, src + hdr, n); r.dst_len = clamp32(n); r.src_used = clamp32(n); r.status = ALZ_ST_OK;
+            break;
+        }
+        if ((uint64_t)plain > len - hdr) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }      // ReadByte() == -1 would write 0xFF bytes: refused
+        if (plain > dst_cap) { r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+        memcpy(dst, src + hdr, plain);
+        alz_lz_properties e; memset(&e, 0, sizeof(e));                                      // LzProperties(0x400, 0x42, 3, 0x3BE) == (10, 6, 2)  ECD.cs:15
+        e.window_bits = 10; e.length_bits = 6; e.min_length = 3; e.windows_start = 0x3BE; e.max_distance = 0x400;
+        rc = run_body(ctx, ALZ_FMT_LZSS, &e, src + hdr + plain, len - hdr - plain, size - plain, 0, 0, dst + plain, dst_cap - plain, &r);
+        r.dst_len += plain; r.src_used += plain;
+        break;
+    }
     case ALZ_C_LEVEL5: {                                                                    // Level5.cs:62-110
         if (len < 4) return ALZ_E_FORMAT;
         const uint32_t ts = le32(src); hdr = 4;
@@ -683,6 +740,33 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
     // ---- wrappers that prepend a magic to another container / have their own small header
     switch (container) {
+    case ALZ_C_ECD: {                                                                       // ECD.cs:73-109
+        const bool compressed = st.quality != 0 && n > 0x10;
+        const uint32_t plain = compressed ? 4u : 0u;                                        // ECD.PlainSize default
+        if (cap < 16 + (compressed ? plain : n)) return ALZ_E_NOMEM;
+        memcpy(dst, "ECD", 3);
+        if (compressed) {
+            alz_lz_properties e; memset(&e, 0, sizeof(e));
+            e.window_bits = 10; e.length_bits = 6; e.min_length = 3; e.windows_start = 0x3BE; e.max_distance = 0x400;
+            alz_stream s1; memset(&s1, 0, sizeof(s1));
+            s1.src_len = clamp32(n - plain); s1.dst_cap = clamp32(cap - 16 - plain); s1.format = ALZ_FMT_LZSS;
+            alz_result r1;
+            int rc1 = alz_encode_batch(ctx, &e, &st, 1, src + plain, n - plain, &s1, dst + 16 + plain, cap - 16 - plain, &r1, nullptr);
+            if (rc1 != ALZ_OK) return rc1;
+            if (r1.status == ALZ_ST_OK && (uint64_t)plain + r1.dst_len < n) {
+                dst[3] = 1; wr32(dst + 4, plain, true); wr32(dst + 8, plain + r1.dst_len, true); wr32(dst + 12, (uint32_t)n, true);
+                memcpy(dst + 16, src, plain);
+                if (dst_len) *dst_len = 16 + plain + r1.dst_len;
+                return ALZ_OK;
+            }
+            if (r1.status != ALZ_ST_OK && r1.status != ALZ_ST_OUTPUT_CAPACITY) return ALZ_E_INVALID;
+            if (cap < 16 + n) return ALZ_E_NOMEM;                                           // compression was ineffective: stored  ECD.cs:99-104
+        }
+        dst[3] = 0; wr32(dst + 4, 0, true); wr32(dst + 8, (uint32_t)n, true); wr32(dst + 12, (uint32_t)n, true);
+        memcpy(dst + 16, src, n);
+        if (dst_len) *dst_len = 16 + n;
+        return ALZ_OK;
+    }
     case ALZ_C_LZ4_LEGACY: return lz4_file_compress(ctx, true, 0, &st, src, n, dst, cap, dst_len);
     case ALZ_C_LZ4_FRAME: return lz4_file_compress(ctx, false, opt ? opt->chunk_size : 0, &st, src, n, dst, cap, dst_len);
     case ALZ_C_SNAPPY: return snappy_file_compress(ctx, &st, src, n, dst, cap, dst_len);
@@ -759,6 +843,11 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZSEGA: fmt = ALZ_FMT_LZSS; hdr = 8; lz = nullptr; break;
     case ALZ_C_LEVEL5LZSS: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
     case ALZ_C_LZON: fmt = ALZ_FMT_LZO; hdr = 16; break;
+    case ALZ_C_MDB4: fmt = ALZ_FMT_LZSS; hdr = 32; lz = nullptr; break;
+    case ALZ_C_FCMP: fmt = ALZ_FMT_LZSS; hdr = 12; lz = nullptr; break;
+    case ALZ_C_IECP: fmt = ALZ_FMT_LZSS; hdr = 8; lz = nullptr; break;
+    case ALZ_C_GCZ: fmt = ALZ_FMT_LZSS; hdr = 4; lz = nullptr; break;
+    case ALZ_C_SDPC: fmt = ALZ_FMT_LZO; hdr = 8; break;
     case ALZ_C_LEVEL5: fmt = ALZ_FMT_LZ10; hdr = 4; if (st.min_distance == 0) st.min_distance = 2; break;   // LZ10.CompressHeaderless default gbaVramCompatibilityMode = true
     case ALZ_C_LZSS: fmt = ALZ_FMT_LZSS; hdr = 16; break;
     case ALZ_C_LZ10: fmt = ALZ_FMT_LZ10; hdr = n <= 0xFFFFFF ? 4 : 8; if (st.min_distance == 0) st.min_distance = 2; break;   // GbaVramCompatibilityMode = true  LZ10.cs:33
@@ -791,6 +880,11 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZSEGA: wr32(dst, r.dst_len, false); wr32(dst + 4, (uint32_t)n, false); break;                                                      // LZSega.cs:57-67
     case ALZ_C_LEVEL5LZSS: memcpy(dst, "SSZL", 4); wr32(dst + 4, 0, false); wr32(dst + 8, r.dst_len, false); wr32(dst + 12, (uint32_t)n, false); break;   // Level5LZSS.cs:62-72
     case ALZ_C_LZON: memcpy(dst, kLzonMagic, 8); wr32(dst + 8, (uint32_t)n, true); wr32(dst + 12, r.dst_len, true); break;                          // LZOn.cs:63-79
+    case ALZ_C_MDB4: memcpy(dst, "MDB4", 4); wr32(dst + 4, (uint32_t)n + 1, false); wr32(dst + 8, (uint32_t)n, false); wr32(dst + 12, 16 + r.dst_len, false); memset(dst + 16, 0, 16); break;   // MDB4.cs:52-72
+    case ALZ_C_FCMP: memcpy(dst, "FCMP", 4); wr32(dst + 4, (uint32_t)n, false); wr32(dst + 8, 305397760u, false); break;                          // FCMP.cs:43-50
+    case ALZ_C_IECP: memcpy(dst, "IECP", 4); wr32(dst + 4, (uint32_t)n, false); break;                                                          // IECP.cs:41-46
+    case ALZ_C_GCZ: wr32(dst, (uint32_t)n, false); break;                                                                                       // GCZ.cs:38-42
+    case ALZ_C_SDPC: memcpy(dst, "SDPC", 4); wr32(dst + 4, (uint32_t)n, false); break;                                                          // SDPC.cs:49-54
     case ALZ_C_LEVEL5: break;                                                                                                                       // header written above
     case ALZ_C_YAZ0: memcpy(dst, "Yaz0", 4); wr32(dst + 4, (uint32_t)n, big); wr32(dst + 8, opt ? opt->memory_alignment : 0, big); wr32(dst + 12, 0, false); break;   // Yaz0.cs:82-89
     case ALZ_C_YAY0: case ALZ_C_MIO0:                                                                                                          // Yay0.cs:62-77
@@ -828,6 +922,9 @@ static bool describe_stream(uint32_t container, bool big, const uint8_t* p, size
     case ALZ_C_LZ01: if (n < 16) return false; size = le32(p + 8); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
     case ALZ_C_LZSEGA: if (n < 8) return false; size = le32(p + 4); *hdr = 8; s->format = ALZ_FMT_LZSS; break;
     case ALZ_C_LEVEL5LZSS: if (n < 16) return false; size = le32(p + 12); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_MDB4: if (n < 32) return false; size = le32(p + 8); *hdr = 32; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_FCMP: if (n < 12) return false; size = le32(p + 4); *hdr = 12; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_IECP: if (n < 8) return false; size = le32(p + 4); *hdr = 8; s->format = ALZ_FMT_LZSS; break;
     default: return false;
     }
     s->decom_len = size;
@@ -900,7 +997,7 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, co
         if (containers[k] >= ALZ_C_COUNT) return ALZ_E_INVALID;
         switch (containers[k]) {
         case ALZ_C_LZSS: if (opt && opt->lz.window_bits) lzp = &opt->lz; break;
-        case ALZ_C_AKLZ: case ALZ_C_LZ01: case ALZ_C_LZSEGA: case ALZ_C_LEVEL5LZSS: wrapper_lzss = true; break;
+        case ALZ_C_AKLZ: case ALZ_C_LZ01: case ALZ_C_LZSEGA: case ALZ_C_LEVEL5LZSS: case ALZ_C_MDB4: case ALZ_C_FCMP: case ALZ_C_IECP: wrapper_lzss = true; break;
         case ALZ_C_LZ10: case ALZ_C_LZ11: case ALZ_C_YAZ0: case ALZ_C_YAZ1: case ALZ_C_YAY0: case ALZ_C_MIO0:
         case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: break;
         default: return ALZ_E_UNSUPPORTED;

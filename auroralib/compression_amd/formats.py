@@ -243,6 +243,33 @@ class Snappy(_Format):
     provides_size = False
 
 
+class MDB4(_Format):
+    """src/AuroraLib.Compression-Extended/Specialized/MDB4.cs"""
+    container = A.C_MDB4
+
+
+class FCMP(_Format):
+    container = A.C_FCMP
+
+
+class IECP(_Format):
+    container = A.C_IECP
+
+
+class GCZ(_Format):
+    """Konami/GCZ.cs -- recognised by its file extension only, so IsMatch(data) is always False here."""
+    container = A.C_GCZ
+
+
+class ECD(_Format):
+    """Specialized/ECD.cs -- 4 plain bytes + LZSS(10,6,2); stored when Quality == 0 or compression does not pay."""
+    container = A.C_ECD
+
+
+class SDPC(_Format):
+    container = A.C_SDPC
+
+
 class LZ77(_Format):
     """src/AuroraLib.Compression.Nintendo/Nintendo/LZ77.cs -- Type: LZ10 (default) / LZ11 / ChunkLZ10."""
     container = A.C_LZ77
@@ -254,5 +281,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, LZ77, Level5]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

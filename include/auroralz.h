@@ -227,7 +227,14 @@ typedef enum alz_container {
     ALZ_C_LEVEL5 = 21, /* u32 type|size<<3: OnlySave / LZ10   src/AuroraLib.Compression.Nintendo/Level5/Level5.cs:62-146 */
     ALZ_C_LZ4_FRAME = 22, /* LZ4: frame 0x184D2204 (descriptor, linked or independent blocks, xxHash32 block / content
                              checksums), legacy and skippable frames, concatenated   LZ4.cs:50-93, LZ4.Frame.cs:107-215 */
-    ALZ_C_COUNT  = 23
+    /* more header-only wrappers (the reference's .Extended assembly) */
+    ALZ_C_MDB4   = 23, /* "MDB4"+(n+1)+n+csize+16 zero bytes + LZSS   src/AuroraLib.Compression-Extended/Specialized/MDB4.cs:33-72 */
+    ALZ_C_FCMP   = 24, /* "FCMP"+n+0x12340000 + LZSS               src/AuroraLib.Compression-Extended/Marvelous/FCMP.cs:36-50    */
+    ALZ_C_IECP   = 25, /* "IECP"+n + LZSS                          src/AuroraLib.Compression-Extended/Marvelous/IECP.cs:35-46    */
+    ALZ_C_GCZ    = 26, /* n + LZSS (recognised by file extension only: IsMatch is always 0 here)   Konami/GCZ.cs:23-42          */
+    ALZ_C_ECD    = 27, /* "ECD"+flag+BE plain/csize/size; 4 plain bytes + LZSS(10,6,2), or stored   Specialized/ECD.cs:45-109   */
+    ALZ_C_SDPC   = 28, /* "SDPC"+n + LZO                           src/AuroraLib.Compression-Extended/Specialized/SDPC.cs:34-54 */
+    ALZ_C_COUNT  = 29
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */
@@ -272,7 +279,7 @@ size_t alz_container_compress_bound(uint32_t container, size_t src_len);
  * and yields more than 0x10 bytes (:85), the walk then continues behind it (:98), otherwise at the next byte (:100).
  * Here every candidate offset is decoded in ONE GPU batch (rounds of <= 1 GiB of output) and the walk is replayed over
  * the results.  Supported: the containers with a size header and one body (LZSS, LZ10, LZ11, YAZ0, YAY0, MIO0, GCLZ,
- * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS); the Yaz0 byte-order retry is not attempted.
+ * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS, MDB4, FCMP, IECP); the Yaz0 byte-order retry is not attempted.
  * Outputs of the accepted streams are packed into dst in file order; ALZ_E_NOMEM when dst or hits is too small
  * (nhits / dst_used then describe what fitted). */
 typedef struct alz_scan_hit {

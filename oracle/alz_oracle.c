@@ -1281,6 +1281,14 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
         *size_out = sz; return 0;
     }
     case ALZ_C_LEVEL5: if (len < 5) return ALZ_E_FORMAT; *size_out = src[4] == 0x78 ? rd32le(src) : rd32le(src) >> 3; return 0;  /* Level5/Level5.cs:55-60 */
+    case ALZ_C_MDB4: if (len < 12 || memcmp(src, "MDB4", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;            /* Specialized/MDB4.cs:25-31 */
+    case ALZ_C_FCMP: case ALZ_C_IECP: case ALZ_C_SDPC:                                                                             /* Marvelous/FCMP.cs:28-33 */
+        if (len < 8 || memcmp(src, container == ALZ_C_FCMP ? "FCMP" : container == ALZ_C_IECP ? "IECP" : "SDPC", 4)) return ALZ_E_FORMAT;
+        *size_out = rd32le(src + 4); return 0;
+    case ALZ_C_GCZ: if (len < 4) return ALZ_E_FORMAT; *size_out = rd32le(src); return 0;                                            /* Konami/GCZ.cs:30 */
+    case ALZ_C_ECD:                                                                                                                /* Specialized/ECD.cs:34-43 */
+        if (len < 16 || memcmp(src, "ECD", 3)) return ALZ_E_FORMAT;
+        *size_out = (uint64_t)be32(src + 8) + 0x10 > len ? 0u : be32(src + 12); return 0;
     case ALZ_C_LZ4_FRAME:   /* not an IProvidesDecompressedSize in the reference; offered where the descriptor carries ContentSize */
         if (len < 15 || rd32le(src) != 0x184D2204u || !(src[4] & 8)) return ALZ_E_UNSUPPORTED;
         if (rd32le(src + 10) != 0) return ALZ_E_UNSUPPORTED;
@@ -1572,6 +1580,47 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
     case ALZ_C_LZO: run_stream(ALZ_FMT_LZO, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r); break;
     case ALZ_C_LZ4_LEGACY: case ALZ_C_LZ4_FRAME:                                          /* LZ4Legacy.Decompress -> LZ4.Decompress */
         return lz4_file_decompress(src, len, dst, dst_cap, dst_len, src_used, status);
+    case ALZ_C_MDB4:                                                                     /* Specialized/MDB4.cs:33-50 */
+        if (len < 4 || memcmp(src, "MDB4", 4)) return ALZ_E_FORMAT;
+        if (len < 32) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = rd32le(src + 8); hdr = 32;
+        run_stream(ALZ_FMT_LZSS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_FCMP: case ALZ_C_IECP: case ALZ_C_GCZ: {                                  /* FCMP.cs:36-41, IECP.cs:35-39, GCZ.cs:32-36 */
+        size_t ml = container == ALZ_C_GCZ ? 0 : 4;
+        hdr = ml + (container == ALZ_C_FCMP ? 8 : 4);
+        if (len < ml || (ml && memcmp(src, container == ALZ_C_FCMP ? "FCMP" : "IECP", 4))) return ALZ_E_FORMAT;
+        if (len < hdr) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = rd32le(src + ml);
+        run_stream(ALZ_FMT_LZSS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_SDPC:                                                                     /* Specialized/SDPC.cs:34-47 */
+        if (len < 4 || memcmp(src, "SDPC", 4)) return ALZ_E_FORMAT;
+        if (len < 8) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = rd32le(src + 4); hdr = 8;
+        run_stream(ALZ_FMT_LZO, NULL, src + hdr, (uint32_t)(len - hdr), 0, 0, 0, dst, dst_cap, &r);
+        if (r.status == ALZ_ST_OK && r.dst_len > size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;
+        break;
+    case ALZ_C_ECD: {                                                                    /* Specialized/ECD.cs:45-71 */
+        if (len < 3 || memcmp(src, "ECD", 3)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        int compressed = src[3] == 1;
+        uint32_t plain = be32(src + 4); size = be32(src + 12); hdr = 16;
+        if (!compressed) {
+            size_t n = len - hdr;
+            if (n > dst_cap) { memcpy(dst, src + hdr, dst_cap); r.dst_len = (uint32_t)dst_cap; r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+            memcpy(dst, src + hdr, n); r.dst_len = (uint32_t)n; r.src_used = (uint32_t)n; r.status = ALZ_ST_OK;
+            break;
+        }
+        if ((uint64_t)plain > len - hdr) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        if (plain > dst_cap) { r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+        memcpy(dst, src + hdr, plain);
+        alz_lz_properties e; oracle_lz_properties_bits(10, 6, 2, &e);                    /* LzProperties(0x400, 0x42, 3, 0x3BE)  ECD.cs:15 */
+        run_stream(ALZ_FMT_LZSS, &e, src + hdr + plain, (uint32_t)(len - hdr - plain), size - plain, 0, 0, dst + plain, dst_cap - plain, &r);
+        r.dst_len += plain; r.src_used += plain;
+        break;
+    }
     case ALZ_C_SNAPPY: return snappy_file_decompress(src, len, dst, dst_cap, dst_len, src_used, status);
     case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: {                /* magic + inner file */
         const char* m = container == ALZ_C_GCLZ ? "GCLZ" : container == ALZ_C_CXLZ ? "CXLZ" : container == ALZ_C_COMP ? "COMP" : "3DS-LZ\r\n";
@@ -1677,6 +1726,43 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
     size_t hdr = 0; int64_t body; alz_encode_aux aux;
     alz_settings st = settings ? *settings : (alz_settings){ 8, 0, 0, 0 };
     switch (container) {
+    case ALZ_C_ECD: {                                                                      /* Specialized/ECD.cs:73-109 */
+        int compressed = st.quality != 0 && n > 0x10;
+        uint32_t plain = compressed ? 4u : 0u;
+        if (cap < 16 + (compressed ? plain : n)) return ALZ_E_NOMEM;
+        memcpy(dst, "ECD", 3);
+        if (compressed) {
+            alz_lz_properties e; oracle_lz_properties_bits(10, 6, 2, &e);
+            int64_t b = oracle_encode_stream(ALZ_FMT_LZSS, &e, &st, src + plain, n - plain, dst + 16 + plain, cap - 16 - plain, NULL);
+            if (b < -1) return ALZ_E_INVALID;
+            if (b >= 0 && (uint64_t)plain + (uint64_t)b < n) {
+                dst[3] = 1; wr32(dst + 4, plain, 1); wr32(dst + 8, plain + (uint32_t)b, 1); wr32(dst + 12, (uint32_t)n, 1);
+                memcpy(dst + 16, src, plain);
+                if (dst_len) *dst_len = 16 + plain + (size_t)b;
+                return 0;
+            }
+            if (cap < 16 + n) return ALZ_E_NOMEM;
+        }
+        dst[3] = 0; wr32(dst + 4, 0, 1); wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, (uint32_t)n, 1);
+        memcpy(dst + 16, src, n);
+        if (dst_len) *dst_len = 16 + n;
+        return 0;
+    }
+    case ALZ_C_MDB4: case ALZ_C_FCMP: case ALZ_C_IECP: case ALZ_C_GCZ: case ALZ_C_SDPC: {
+        hdr = container == ALZ_C_MDB4 ? 32 : container == ALZ_C_FCMP ? 12 : container == ALZ_C_GCZ ? 4 : 8;
+        if (cap < hdr) return ALZ_E_NOMEM;
+        body = oracle_encode_stream(container == ALZ_C_SDPC ? ALZ_FMT_LZO : ALZ_FMT_LZSS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return body == -1 ? ALZ_E_NOMEM : ALZ_E_INVALID;
+        switch (container) {
+        case ALZ_C_MDB4: memcpy(dst, "MDB4", 4); wr32(dst + 4, (uint32_t)n + 1, 0); wr32(dst + 8, (uint32_t)n, 0); wr32(dst + 12, 16 + (uint32_t)body, 0); memset(dst + 16, 0, 16); break;
+        case ALZ_C_FCMP: memcpy(dst, "FCMP", 4); wr32(dst + 4, (uint32_t)n, 0); wr32(dst + 8, 305397760u, 0); break;
+        case ALZ_C_IECP: memcpy(dst, "IECP", 4); wr32(dst + 4, (uint32_t)n, 0); break;
+        case ALZ_C_GCZ: wr32(dst, (uint32_t)n, 0); break;
+        default: memcpy(dst, "SDPC", 4); wr32(dst + 4, (uint32_t)n, 0); break;
+        }
+        if (dst_len) *dst_len = hdr + (size_t)body;
+        return 0;
+    }
     case ALZ_C_LZ4_LEGACY: return lz4_file_compress(1, 0, &st, src, n, dst, cap, dst_len);
     case ALZ_C_LZ4_FRAME: return lz4_file_compress(0, opt ? opt->chunk_size : 0, &st, src, n, dst, cap, dst_len);
     case ALZ_C_SNAPPY: return snappy_file_compress(&st, src, n, dst, cap, dst_len);

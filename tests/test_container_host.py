@@ -36,7 +36,8 @@ def test_large_nintendo_header():
 
 
 WRAPPERS = [(F.GCLZ, A.C_GCLZ), (F.CXLZ, A.C_CXLZ), (F.LZ_3DS, A.C_LZ_3DS), (F.COMP, A.C_COMP), (F.Yaz1, A.C_YAZ1), (F.AKLZ, A.C_AKLZ),
-            (F.LZ01, A.C_LZ01), (F.LZSega, A.C_LZSEGA), (F.Level5LZSS, A.C_LEVEL5LZSS), (F.LZOn, A.C_LZON), (F.LZ77, A.C_LZ77), (F.Level5, A.C_LEVEL5)]
+            (F.LZ01, A.C_LZ01), (F.LZSega, A.C_LZSEGA), (F.Level5LZSS, A.C_LEVEL5LZSS), (F.LZOn, A.C_LZON), (F.LZ77, A.C_LZ77), (F.Level5, A.C_LEVEL5),
+            (F.MDB4, A.C_MDB4), (F.FCMP, A.C_FCMP), (F.IECP, A.C_IECP), (F.GCZ, A.C_GCZ), (F.ECD, A.C_ECD), (F.SDPC, A.C_SDPC)]
 
 
 @pytest.mark.parametrize("cls,container", WRAPPERS)
@@ -48,7 +49,7 @@ def test_wrapper_headers_host_vs_oracle(cls, container, test_bmp):
         assert st == A.ST_OK and out == raw
         f = cls()
         assert f.GetDecompressedSize(comp) == len(raw) == O.container_decompressed_size(container, comp)
-        if container != A.C_LEVEL5:          # Level5.IsMatch leans on file extensions / zlib probing: not mirrored
+        if container not in (A.C_LEVEL5, A.C_GCZ):   # Level5 / GCZ lean on file extensions (and zlib probing): not mirrored
             assert f.IsMatch(comp)
 
 
