@@ -444,6 +444,8 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZSS: if (len < 8 || memcmp(src, "LZSS", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return ALZ_OK;        // LZSS.cs:45-50
     case ALZ_C_LZ10: return nin_header(src, len, 0x10, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ10.cs:44-57
     case ALZ_C_LZ11: return nin_header(src, len, 0x11, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ11.cs:40-53
+    case ALZ_C_LZ40: return nin_header(src, len, 0x40, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ40.cs:40-52
+    case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ60.cs:29-41
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // Yaz0.cs:50-55
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return ALZ_OK;        // Yay0.cs:41-47 (always Endian.Big)
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // MIO0.cs:41-48
@@ -515,6 +517,8 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_LZSEGA: { if (len < 0x12) return 0; const uint32_t cs = le32(src), ds = le32(src + 4); return (cs == len - 8 || cs == len) && ds != 0 && (src[8] & 1) == 1; }   // LZSega.cs:27-38
     case ALZ_C_LEVEL5LZSS: return len > 0x10 && !memcmp(src, "SSZL", 4) && le32(src + 4) == 0;
     case ALZ_C_LZON: return len > 0x10 && !memcmp(src, kLzonMagic, 8);
+    case ALZ_C_LZ40: case ALZ_C_LZ60:                                                       // "no distinct header, recognition is inaccurate"  LZ40.cs:36-38
+        return len > 0x8 && src[0] == (container == ALZ_C_LZ40 ? 0x40 : 0x60) && ((src[1] | src[2] | src[3]) != 0 || le32(src + 4) != 0);
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
     case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
     case ALZ_C_IECP: return len > 0x10 && !memcmp(src, "IECP", 4);
@@ -617,6 +621,13 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src + hdr, len - hdr, 0, 0, 0, dst, dst_cap, &r);
         if (rc == ALZ_OK && r.status == ALZ_ST_OK && r.dst_len != size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // DecompressedSizeException.ThrowIfMismatch
         break;
+    case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                     // LZ40.cs:54-61, LZ60.cs:43-47
+        int h = nin_header(src, len, container == ALZ_C_LZ40 ? 0x40 : 0x60, &size);
+        if (h < 0) return ALZ_E_FORMAT;
+        hdr = (size_t)h;
+        rc = run_body(ctx, ALZ_FMT_LZ40, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
     case ALZ_C_MDB4:                                                                        // MDB4.cs:33-50
         if (len < 4 || memcmp(src, "MDB4", 4)) return ALZ_E_FORMAT;
         if (len < 32) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
@@ -852,6 +863,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZSS: fmt = ALZ_FMT_LZSS; hdr = 16; break;
     case ALZ_C_LZ10: fmt = ALZ_FMT_LZ10; hdr = n <= 0xFFFFFF ? 4 : 8; if (st.min_distance == 0) st.min_distance = 2; break;   // GbaVramCompatibilityMode = true  LZ10.cs:33
     case ALZ_C_LZ11: fmt = ALZ_FMT_LZ11; hdr = n <= 0xFFFFFF ? 4 : 8; break;
+    case ALZ_C_LZ40: case ALZ_C_LZ60: fmt = ALZ_FMT_LZ40; hdr = n <= 0xFFFFFF ? 4 : 8; break;   // GbaVramCompatibilityMode = false  LZ40.cs:29
     case ALZ_C_YAZ0: fmt = ALZ_FMT_YAZ0; hdr = 16; break;
     case ALZ_C_YAY0: fmt = ALZ_FMT_YAY0; hdr = 16; break;
     case ALZ_C_MIO0: fmt = ALZ_FMT_MIO0; hdr = 16; break;
@@ -869,8 +881,8 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     if (r.status != ALZ_ST_OK) return ALZ_E_INVALID;
     switch (container) {
     case ALZ_C_LZSS: memcpy(dst, "LZSS", 4); wr32(dst + 4, (uint32_t)n, true); wr32(dst + 8, r.dst_len, true); wr32(dst + 12, 0, true); break;   // LZSS.cs:72-88
-    case ALZ_C_LZ10: case ALZ_C_LZ11: {                                                                                                        // LZ10.cs:67-80
-        const uint8_t id = container == ALZ_C_LZ10 ? 0x10 : 0x11;
+    case ALZ_C_LZ10: case ALZ_C_LZ11: case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                                      // LZ10.cs:67-80, LZ40.cs:64-77
+        const uint8_t id = container == ALZ_C_LZ10 ? 0x10 : container == ALZ_C_LZ11 ? 0x11 : container == ALZ_C_LZ40 ? 0x40 : 0x60;
         if (n <= 0xFFFFFF) wr32(dst, id | ((uint32_t)n << 8), false); else { wr32(dst, id, false); wr32(dst + 4, (uint32_t)n, false); }
         break;
     }
@@ -908,6 +920,7 @@ static bool describe_stream(uint32_t container, bool big, const uint8_t* p, size
     switch (container) {
     case ALZ_C_LZSS: if (n < 16) return false; size = be32(p + 4); *hdr = 16; s->format = ALZ_FMT_LZSS; break;
     case ALZ_C_LZ10: case ALZ_C_LZ11: { const int h = nin_header(p, n, container == ALZ_C_LZ10 ? 0x10 : 0x11, &size); if (h < 0) return false; *hdr = (size_t)h; s->format = container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11; break; }
+    case ALZ_C_LZ40: case ALZ_C_LZ60: { const int h = nin_header(p, n, container == ALZ_C_LZ40 ? 0x40 : 0x60, &size); if (h < 0) return false; *hdr = (size_t)h; s->format = ALZ_FMT_LZ40; break; }
     case ALZ_C_YAZ0: case ALZ_C_YAZ1: if (n < 16) return false; size = rd32(p + 4, big); *hdr = 16; s->format = ALZ_FMT_YAZ0; break;
     case ALZ_C_YAY0: case ALZ_C_MIO0:
         if (n < 16) return false;
@@ -999,7 +1012,7 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, co
         case ALZ_C_LZSS: if (opt && opt->lz.window_bits) lzp = &opt->lz; break;
         case ALZ_C_AKLZ: case ALZ_C_LZ01: case ALZ_C_LZSEGA: case ALZ_C_LEVEL5LZSS: case ALZ_C_MDB4: case ALZ_C_FCMP: case ALZ_C_IECP: wrapper_lzss = true; break;
         case ALZ_C_LZ10: case ALZ_C_LZ11: case ALZ_C_YAZ0: case ALZ_C_YAZ1: case ALZ_C_YAY0: case ALZ_C_MIO0:
-        case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: break;
+        case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: case ALZ_C_LZ40: case ALZ_C_LZ60: break;
         default: return ALZ_E_UNSUPPORTED;
         }
     }

@@ -331,10 +331,13 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
 }
 
 template <int FMT> struct FamTraits;
-template <> struct FamTraits<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT1 = true,  H3 = false, H4 = false; };
-template <> struct FamTraits<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false; };
-template <> struct FamTraits<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true; };
-template <> struct FamTraits<ALZ_FMT_YAZ0> { static constexpr bool MSB = true,  LIT1 = true,  H3 = true,  H4 = false; };
+// MSB: flag bits MSB first; LIT1: flag bit 1 = literal; H3 / H4: a match whose size nibble is 0 / 1 has 3 / 4 bytes; NIBLO: that
+// nibble is the low one of the first token byte (LZ40) instead of the high one; NEG: the flag byte is stored negated (LZ40)
+template <> struct FamTraits<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT1 = true,  H3 = false, H4 = false, NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true,  NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_YAZ0> { static constexpr bool MSB = true,  LIT1 = true,  H3 = true,  H4 = false, NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_LZ40> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true,  NIBLO = true,  NEG = true; };
 
 // bits [i, i+32) of the 128-bit mask hi:lo, i = 0..63
 __device__ __forceinline__ u32 mask_window(u64 lo, u64 hi, int i) {
@@ -350,13 +353,14 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     in.ensure(p, 128);
     const u32 x0 = in.byte_at(p + (u32)lane), x1 = in.byte_at(p + 64u + (u32)lane);
     u32 l3 = 0, l4 = 0;
-    if (TR::H3) { u64 lo = __ballot((x0 >> 4) == 0), hi = __ballot((x1 >> 4) == 0); l3 = mask_window(lo, hi, lane); }
-    if (TR::H4) { u64 lo = __ballot((x0 >> 4) == 1), hi = __ballot((x1 >> 4) == 1); l4 = mask_window(lo, hi, lane); }
+    const u32 n0 = TR::NIBLO ? (x0 & 0xFu) : (x0 >> 4), n1 = TR::NIBLO ? (x1 & 0xFu) : (x1 >> 4);
+    if (TR::H3) { u64 lo = __ballot(n0 == 0), hi = __ballot(n1 == 0); l3 = mask_window(lo, hi, lane); }
+    if (TR::H4) { u64 lo = __ballot(n0 == 1), hi = __ballot(n1 == 1); l4 = mask_window(lo, hi, lane); }
     // speculative walk of "the group that starts at byte p + lane": group size + what a token lane needs to find its
     // offset.  Formats whose token size depends only on the flag bit (LZSS, LZ10) need no walk at all: the offset of token
     // k is 1 + k + popcount(match bits before k).  Otherwise `info` packs (token size - 1) as 8 nibbles and a token lane
     // sums the nibbles below its own with one v_dot8_u32_u4.
-    const u32 mbits = TR::LIT1 ? (~x0 & 0xFFu) : x0;          // bit set = match token
+    const u32 mbits = TR::NEG ? ((0u - x0) & 0xFFu) : (TR::LIT1 ? (~x0 & 0xFFu) : x0);   // bit set = match token
     u32 gsize, info;
     if (!TR::H3 && !TR::H4) { gsize = 9u + (u32)__popc(mbits); info = mbits; }
     else {
@@ -412,6 +416,11 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
             if (nib == 0) { desc = ALZ_DESC_MATCH((((b2 & 0xFu) << 8) | b3) + 1u); len = (((b1 & 0xFu) << 4) | (b2 >> 4)) + 17u; tend = to + 3; }
             else if (nib == 1) { desc = ALZ_DESC_MATCH((((b3 & 0xFu) << 8) | b4) + 1u); len = (((b1 & 0xFu) << 12) | (b2 << 4) | (b3 >> 4)) + 273u; tend = to + 4; }
             else { desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 1u); len = nib + 1u; tend = to + 2; }
+        } else if (FMT == ALZ_FMT_LZ40) {
+            const u32 b3 = in.lds[ti + 2], b4 = in.lds[ti + 3];
+            const u32 nib = b1 & 0xFu, d = (b1 >> 4) | (b2 << 4);
+            desc = ALZ_DESC_MATCH(d ? d : 4096u);                // E1: 0 is what 4096 wraps to
+            if (nib == 0) { len = b3 + 16u; tend = to + 3; } else if (nib == 1) { len = (b3 | (b4 << 8)) + 272u; tend = to + 4; } else { len = nib; tend = to + 2; }
         } else {  // YAZ0
             const u32 b3 = in.lds[ti + 2];
             const u32 nib = b1 >> 4;
@@ -435,6 +444,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     s.p = p + wave_readlane(tend, lk);
     s.bits = 7u - (lk & 7u);
     s.flag = in.peek1(p + wave_readlane(gstart, lk));
+    if (TR::NEG) s.flag = (0u - s.flag) & 0xFFu;
     to_serial = true;
     return false;
 }

@@ -104,6 +104,32 @@ __device__ void dec_lz1x_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u
     }
 }
 
+// LZ40.DecompressHeaderless  Nintendo/LZ40.cs:80-132 (also LZ60's body).  s.flag holds the flag byte already negated
+// (:92), bits MSB first, 1 = match; tokens are u16 LE distance << 4 | length nibble, nibble 0 / 1 = one / two more
+// length bytes; distance 0 is what the encoder writes for 4096 (E1).
+template <class SK>
+__device__ void dec_lz40_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
+    while (sk.produced() < size) {
+        sk.ensure(in, s.p, 8);
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = (0u - in.peek1(s.p)) & 0xFFu; s.p++; s.bits = 8; }
+        u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p + 2 > src_len) { s.eof = true; return; }
+            u32 w = in.peek4(s.p);
+            u32 v = w & 0xFFFFu, b3 = (w >> 16) & 0xFF, b4 = w >> 24;
+            u32 length = v & 0xFu, distance = v >> 4;
+            if (length == 0) { if (s.p + 3 > src_len) { s.eof = true; return; } length = b3 + 16u; s.p += 3; }
+            else if (length == 1) { if (s.p + 4 > src_len) { s.eof = true; return; } length = (b3 | (b4 << 8)) + 272u; s.p += 4; }
+            else s.p += 2;
+            if (!sk.match(distance, length, 4096)) return;
+        } else {
+            if (s.p >= src_len) { s.eof = true; return; }
+            u32 b = in.peek1(s.p); s.p++;
+            if (!sk.lit(b)) return;
+        }
+    }
+}
+
 // Yaz0: Yay0.DecompressHeaderless with all three cursors on one stream  Nintendo/Yay0.cs:110-144, Yaz0.cs:91-92
 template <class SK>
 __device__ void dec_yaz0_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {

@@ -194,10 +194,10 @@ struct Out {                 // bounded byte sink of one stream
 
 // FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags): the flag byte goes out before the payload of its tokens
 struct FlagW {
-    Out* base; u8 payload[40]; int plen, bits_left, cur; bool msb;
-    __device__ void init(Out* b, bool m) { base = b; plen = 0; bits_left = 8; cur = 0; msb = m; }
+    Out* base; u8 payload[40]; int plen, bits_left, cur; bool msb, neg;
+    __device__ void init(Out* b, bool m, bool negate = false) { base = b; plen = 0; bits_left = 8; cur = 0; msb = m; neg = negate; }
     __device__ void flush() {
-        if (bits_left != 8) { base->put((u32)cur); bits_left = 8; cur = 0; }
+        if (bits_left != 8) { base->put(neg ? (u32)(0 - cur) & 0xFFu : (u32)cur); bits_left = 8; cur = 0; }   // LZ40: i => WriteByte((byte)-i)
         for (int i = 0; i < plen; i++) base->put(payload[i]);
         plen = 0;
     }
@@ -295,6 +295,20 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             else if (mt.length <= 16) { const u32 v = (((u32)mt.length - 1) << 12 | d1) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
             else if (mt.length <= 272) { fw.pay((((u32)mt.length - 17) & 0xFF) >> 4); const u32 v = (((u32)mt.length - 17) << 12 | d1) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
             else { const u32 v = 0x10000000u | ((((u32)mt.length - 273) & 0xFFFF) << 12) | d1; fw.pay(v >> 24); fw.pay((v >> 16) & 0xFF); fw.pay((v >> 8) & 0xFF); fw.pay(v & 0xFF); }
+            sp += mt.length;
+            fw.bit(1);
+        }
+        fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_LZ40) {                             // LZ40.cs:134-176
+        FlagW fw; fw.init(&out, true, true);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(0); }
+            if (mt.length == 0) break;
+            const u32 dv = ((u32)mt.distance << 4) & 0xFFFFu;
+            if (mt.length < 16) { const u32 v = dv | (u32)mt.length; fw.pay(v & 0xFF); fw.pay(v >> 8); }
+            else if (mt.length < 272) { fw.pay(dv & 0xFF); fw.pay(dv >> 8); fw.pay((u32)mt.length - 16); }
+            else { const u32 v = dv | 1u, l = ((u32)mt.length - 272u) & 0xFFFFu; fw.pay(v & 0xFF); fw.pay(v >> 8); fw.pay(l & 0xFF); fw.pay(l >> 8); }
             sp += mt.length;
             fw.bit(1);
         }
@@ -587,6 +601,11 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
                 b0 = v & 0xFF; b1 = (v >> 8) & 0xFF; psize = 2;
             } else if (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_MIO0) {
                 const u32 v = (((len - 3u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
+            } else if (FMT == ALZ_FMT_LZ40) {                          // u16 LE distance << 4 | length (+ 1 or 2 length bytes)
+                const u32 dv = (mt.x << 4) & 0xFFFFu;
+                if (len < 16) { const u32 v = dv | len; b0 = v & 0xFF; b1 = v >> 8; psize = 2; }
+                else if (len < 272) { b0 = dv & 0xFF; b1 = dv >> 8; b2 = len - 16u; psize = 3; }
+                else { const u32 v = dv | 1u, l = (len - 272u) & 0xFFFFu; b0 = v & 0xFF; b1 = v >> 8; b2 = l & 0xFF; b3 = l >> 8; psize = 4; }
             } else if (FMT == ALZ_FMT_LZ11) {
                 if (len <= 16) { const u32 v = (((len - 1u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
                 else if (len <= 272) { b0 = ((len - 17u) & 0xFFu) >> 4; const u32 v = (((len - 17u) << 12) | d1) & 0xFFFFu; b1 = v >> 8; b2 = v & 0xFF; psize = 3; }
@@ -615,7 +634,7 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
         }
         __syncthreads();
         if (tok) {
-            if (bitpos == 7) { const u32 fo = gofs[group & 15u]; if (fo < cap) dst[fo] = (u8)flagacc[group & 15u]; else fail = true; }
+            if (bitpos == 7) { const u32 fo = gofs[group & 15u]; if (fo < cap) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - flagacc[group & 15u] : flagacc[group & 15u]); else fail = true; }
             if (!THREE) {
                 const u32 o = poff + group + 1u;
                 if (o + psize <= cap) { dst[o] = (u8)b0; if (psize > 1) dst[o + 1] = (u8)b1; if (psize > 2) dst[o + 2] = (u8)b2; if (psize > 3) dst[o + 3] = (u8)b3; }
@@ -634,7 +653,7 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
     }
     // Dispose(): a partial flag byte is written with its unused bits zero (FlagWriter.cs:141-145)
     const u32 nflags = (tok_base + 7u) >> 3;
-    if ((tok_base & 7u) != 0 && lane == 0) { const u32 gi = (tok_base >> 3); const u32 fo = gofs[gi & 15u]; if (fo < cap) dst[fo] = (u8)flagacc[gi & 15u]; else fail = true; }
+    if ((tok_base & 7u) != 0 && lane == 0) { const u32 gi = (tok_base >> 3); const u32 fo = gofs[gi & 15u]; if (fo < cap) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - flagacc[gi & 15u] : flagacc[gi & 15u]); else fail = true; }
     u32 total;
     if (!THREE) total = pay_base + nflags;
     else {
@@ -666,7 +685,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_LZSS:
         wb = lz->window_bits; g.min_len = lz->min_length; g.max_len = (1 << lz->length_bits) + lz->min_length - 1; g.max_dist = (int)lz->max_distance; break;
     case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;
-    case ALZ_FMT_LZ11: g.min_len = 3; g.max_len = 0x4000; g.max_dist = 0x1000; break;
+    case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: g.min_len = 3; g.max_len = 0x4000; g.max_dist = 0x1000; break;
     case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: g.min_len = 3; g.max_len = 0xff + 0x12; g.max_dist = 0x1000; break;
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: wb = 13; g.min_len = 2; g.max_len = 0x100; g.max_dist = 0x1FFF; break;
     case ALZ_FMT_LZ4_BLOCK: wb = 16; g.min_len = 4; g.max_len = 0x7FFFFFFF; g.max_dist = 0xFFFF; break;
@@ -726,6 +745,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ10: launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ11: launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ40: launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;

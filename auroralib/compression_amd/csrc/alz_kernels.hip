@@ -70,6 +70,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         has_size = true; dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_LZ11) {
         has_size = true; dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_LZ40) {
+        has_size = true; dec_lz40_serial(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_YAZ0) {
         has_size = true; dec_yaz0_serial(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0) {
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
             if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, sk, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
             else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
             else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
+            else if constexpr (FMT == ALZ_FMT_LZ40) dec_lz40_serial(in, sk, s, src_len, size);
             else dec_yaz0_serial(in, sk, s, src_len, size);
         }
     } else {
@@ -304,6 +307,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_LZSS: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZSS>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_LZ10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ10>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_LZ11: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ11>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_LZ40: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ40>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_YAZ0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_YAZ0>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_YAY0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_YAY0>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_MIO0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_MIO0>, 64 * ALZ_WPB, 0); break;
@@ -336,6 +340,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         }
         case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_LZ11: return launch_fast<ALZ_FMT_LZ11>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+        case ALZ_FMT_LZ40: return launch_fast<ALZ_FMT_LZ40>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_YAY0: return launch_fast<ALZ_FMT_YAY0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
@@ -355,6 +360,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     }
     case ALZ_FMT_LZ10: return launch_serial<ALZ_FMT_LZ10, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_LZ11: return launch_serial<ALZ_FMT_LZ11, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_LZ40: return launch_serial<ALZ_FMT_LZ40, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_YAZ0: return launch_serial<ALZ_FMT_YAZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_YAY0: return launch_serial<ALZ_FMT_YAY0, false>(stream, s, d, streams, index, count, results, lz, 4096, 3);
     case ALZ_FMT_MIO0: return launch_serial<ALZ_FMT_MIO0, false>(stream, s, d, streams, index, count, results, lz, 4096, 3);

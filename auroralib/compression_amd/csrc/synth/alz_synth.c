@@ -49,10 +49,10 @@ static inline void o_put(out_t* o, const void* d, size_t n) {
 static inline void o_u8(out_t* o, uint32_t v) { uint8_t x = (uint8_t)v; o_put(o, &x, 1); }
 
 /* flag byte accumulator: flag byte is emitted before the payload of its 8 tokens */
-typedef struct { out_t* base; uint8_t payload[8 * 8 + 16]; int plen; int bits_left; int cur; int msb; } fw_t;
-static void fw_init(fw_t* f, out_t* base, int msb) { f->base = base; f->plen = 0; f->bits_left = 8; f->cur = 0; f->msb = msb; }
+typedef struct { out_t* base; uint8_t payload[8 * 8 + 16]; int plen; int bits_left; int cur; int msb; int neg; } fw_t;
+static void fw_init(fw_t* f, out_t* base, int msb) { f->base = base; f->plen = 0; f->bits_left = 8; f->cur = 0; f->msb = msb; f->neg = 0; }
 static void fw_flush(fw_t* f) {
-    if (f->bits_left != 8) { o_u8(f->base, (uint32_t)f->cur); f->bits_left = 8; f->cur = 0; }
+    if (f->bits_left != 8) { o_u8(f->base, (uint32_t)(f->neg ? (-f->cur) & 0xFF : f->cur)); f->bits_left = 8; f->cur = 0; }   /* LZ40 stores the flag byte negated */
     if (f->plen) { o_put(f->base, f->payload, (size_t)f->plen); f->plen = 0; }
 }
 static void fw_bit(fw_t* f, int bit) {
@@ -97,6 +97,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
         W = 1u << lz.window_bits; break;
     case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: break;
     case ALZ_FMT_LZ11: longlo = 17; longhi = 272; break;
+    case ALZ_FMT_LZ40: shortmax = 15; longlo = 16; longhi = 271; break;
     case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: longlo = 18; longhi = 273; break;
     default: break;
     }
@@ -110,6 +111,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
         flags.p = fb; flags.cap = cap / 8 + 64; comp.p = cb; comp.cap = cap; unc.p = ub; unc.cap = cap;
     }
     fw_t fw; fw_init(&fw, three ? &flags : out, msb);
+    fw.neg = format == ALZ_FMT_LZ40;
     uint32_t produced = 0;
     while (produced < target) {
         uint32_t rem = target - produced;
@@ -118,7 +120,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             uint32_t b = (uint32_t)(rng_next(r) & 0xFF);
             switch (format) {
             case ALZ_FMT_LZSS: fw_pay(&fw, b); fw_bit(&fw, 1); break;
-            case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: fw_pay(&fw, b); fw_bit(&fw, 0); break;
+            case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: fw_pay(&fw, b); fw_bit(&fw, 0); break;
             case ALZ_FMT_YAZ0: fw_pay(&fw, b); fw_bit(&fw, 1); break;
             default: o_u8(&unc, b); fw_bit(&fw, 1); break; /* YAY0 / MIO0 */
             }
@@ -126,7 +128,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             continue;
         }
         tok_t t = draw_match(r, produced, rem, minlen, shortmax, longlo, longhi, W);
-        if (format == ALZ_FMT_LZ11 && rng_unit(r) < 0.002 && rem > 273) { t.len = rng_range(r, 273, rem < 2000 ? rem : 2000); }
+        if ((format == ALZ_FMT_LZ11 || format == ALZ_FMT_LZ40) && rng_unit(r) < 0.002 && rem > 273) { t.len = rng_range(r, 273, rem < 2000 ? rem : 2000); }
         uint32_t d1 = t.dist - 1;
         switch (format) {
         case ALZ_FMT_LZSS: {
@@ -141,6 +143,13 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             else if (t.len <= 272) { uint32_t l = t.len - 17; fw_pay(&fw, l >> 4); fw_pay(&fw, ((l & 0xF) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
             else { uint32_t l = t.len - 273; fw_pay(&fw, 0x10 | (l >> 12)); fw_pay(&fw, (l >> 4) & 0xFF); fw_pay(&fw, ((l & 0xF) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
             fw_bit(&fw, 1); break;
+        case ALZ_FMT_LZ40: {                                   /* u16 LE distance << 4 | length; distance 4096 wraps to 0 (LZ40.cs:158-171) */
+            uint32_t dv = (t.dist << 4) & 0xFFFF;
+            if (t.len < 16) { uint32_t v = dv | t.len; fw_pay(&fw, v & 0xFF); fw_pay(&fw, v >> 8); }
+            else if (t.len < 272) { fw_pay(&fw, dv & 0xFF); fw_pay(&fw, dv >> 8); fw_pay(&fw, t.len - 16); }
+            else { uint32_t v = dv | 1, l = t.len - 272; fw_pay(&fw, v & 0xFF); fw_pay(&fw, v >> 8); fw_pay(&fw, l & 0xFF); fw_pay(&fw, l >> 8); }
+            fw_bit(&fw, 1); break;
+        }
         case ALZ_FMT_YAZ0:
             if (t.len < 18) { fw_pay(&fw, ((t.len - 2) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
             else { fw_pay(&fw, d1 >> 8); fw_pay(&fw, d1 & 0xFF); fw_pay(&fw, t.len - 0x12); }
@@ -325,7 +334,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     out_t out = { dst, 0, cap, 0 };
     if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
     switch (format) {
-    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
+    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
         gen_flagfmt(format, props, &r, target, &out, aux); break;
     case ALZ_FMT_PRS_BE: gen_prs(&r, target, &out, 1); break;
     case ALZ_FMT_PRS_LE: gen_prs(&r, target, &out, 0); break;

@@ -243,6 +243,16 @@ class Snappy(_Format):
     provides_size = False
 
 
+class LZ40(_Format):
+    """src/AuroraLib.Compression.Nintendo/Nintendo/LZ40.cs -- LZ11-like tokens, little endian, negated flag bytes."""
+    container = A.C_LZ40
+
+
+class LZ60(_Format):
+    """src/AuroraLib.Compression.Nintendo/Nintendo/LZ60.cs -- identifier 0x60 over LZ40's body."""
+    container = A.C_LZ60
+
+
 class MDB4(_Format):
     """src/AuroraLib.Compression-Extended/Specialized/MDB4.cs"""
     container = A.C_MDB4
@@ -281,5 +291,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ77, Level5]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

@@ -44,7 +44,8 @@ typedef enum alz_format {
     ALZ_FMT_LZ4_BLOCK  = 8,  /* LZ4.DecompressBlockHeaderless src/AuroraLib.Compression/Formats/Common/LZ4.cs:176-200 */
     ALZ_FMT_LZO        = 9,  /* LZO.DecompressHeaderless     src/AuroraLib.Compression/Formats/Common/LZO.cs:49-139 */
     ALZ_FMT_SNAPPY_RAW = 10, /* Snappy.DecompressHeaderless  src/AuroraLib.Compression/Formats/Common/Snappy.cs:205-250 */
-    ALZ_FMT_COUNT      = 11
+    ALZ_FMT_LZ40       = 11, /* LZ40.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/LZ40.cs:80-132 (also the body of LZ60) */
+    ALZ_FMT_COUNT      = 12
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -89,7 +90,7 @@ typedef struct alz_lz_properties {
  * resident buffers alike.
  *
  * decom_len : the `decomLength` argument of the reference's DecompressHeaderless
- *             (LZSS/LZ10/LZ11/YAZ0/YAY0/MIO0).  Ignored by PRS/LZ4/LZO (no size
+ *             (LZSS/LZ10/LZ11/LZ40/YAZ0/YAY0/MIO0).  Ignored by PRS/LZ4/LZO (no size
  *             field, terminated by token / end of input) and by SNAPPY_RAW
  *             (varint inside the body).
  * aux0/aux1 : YAY0/MIO0: compressedDataPointer / uncompressedDataPointer
@@ -234,7 +235,9 @@ typedef enum alz_container {
     ALZ_C_GCZ    = 26, /* n + LZSS (recognised by file extension only: IsMatch is always 0 here)   Konami/GCZ.cs:23-42          */
     ALZ_C_ECD    = 27, /* "ECD"+flag+BE plain/csize/size; 4 plain bytes + LZSS(10,6,2), or stored   Specialized/ECD.cs:45-109   */
     ALZ_C_SDPC   = 28, /* "SDPC"+n + LZO                           src/AuroraLib.Compression-Extended/Specialized/SDPC.cs:34-54 */
-    ALZ_C_COUNT  = 29
+    ALZ_C_LZ40   = 29, /* 0x40 + u24 LE size + LZ40 body (negated MSB-first flag bytes, LE tokens)   Nintendo/LZ40.cs:40-77 */
+    ALZ_C_LZ60   = 30, /* 0x60 + u24 LE size + the same body                                         Nintendo/LZ60.cs:29-58 */
+    ALZ_C_COUNT  = 31
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */
@@ -279,7 +282,8 @@ size_t alz_container_compress_bound(uint32_t container, size_t src_len);
  * and yields more than 0x10 bytes (:85), the walk then continues behind it (:98), otherwise at the next byte (:100).
  * Here every candidate offset is decoded in ONE GPU batch (rounds of <= 1 GiB of output) and the walk is replayed over
  * the results.  Supported: the containers with a size header and one body (LZSS, LZ10, LZ11, YAZ0, YAY0, MIO0, GCLZ,
- * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS, MDB4, FCMP, IECP); the Yaz0 byte-order retry is not attempted.
+ * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS, MDB4, FCMP, IECP, LZ40, LZ60); the Yaz0 byte-order retry is not
+ * attempted.
  * Outputs of the accepted streams are packed into dst in file order; ALZ_E_NOMEM when dst or hits is too small
  * (nhits / dst_used then describe what fitted). */
 typedef struct alz_scan_hit {

@@ -334,6 +334,33 @@ static void dec_lz11(cur_t* c, win_t* w, uint32_t size) {
     }
 }
 
+/* LZ40.DecompressHeaderless  Nintendo/LZ40.cs:80-132: the flag byte is stored negated (:92), bits MSB first, 1 = match;
+   tokens are u16 LE distance << 4 | length nibble, nibble 0 / 1 = one / two more length bytes. */
+static void dec_lz40(cur_t* c, win_t* w, uint32_t size) {
+    int flag = 0, flagbits = 0;
+    while (win_produced(w) < size) {
+        if (flagbits == 0) {
+            int b = cur_byte(c);                                                          /* ReadByte(): -1 at EOF, (byte)-(-1) = 1 */
+            flag = (-b) & 0xFF; flagbits = 8;
+        }
+        if (flag & 0x80) {
+            int x0 = cur_u8(c); if (c->eof) return;
+            int x1 = cur_u8(c); if (c->eof) return;
+            uint32_t v = (uint32_t)x0 | ((uint32_t)x1 << 8), length = v & 0xF, distance = v >> 4;
+            if (length == 0) { int e = cur_u8(c); if (c->eof) return; length = (uint32_t)e + 16; }            /* :101-105 */
+            else if (length == 1) { int e0 = cur_u8(c); if (c->eof) return; int e1 = cur_u8(c); if (c->eof) return; length = ((uint32_t)e0 | ((uint32_t)e1 << 8)) + 272; }
+            uint32_t cl = win_clip(w, length);
+            win_back_copy(w, distance, cl);
+            if (w->overflow) return;
+        } else {
+            int b = cur_u8(c); if (c->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);
+        }
+        flag <<= 1; flagbits--;
+    }
+}
+
 /* Yay0.DecompressHeaderless(FlagReader, compressed, uncompressed, dest, len)  Nintendo/Yay0.cs:110-144.
  * Yaz0 passes the same stream for all three cursors (Yaz0.cs:91-92). */
 static void dec_yay0(cur_t* fc, cur_t* cc, cur_t* uc, win_t* w, uint32_t size) {
@@ -581,7 +608,7 @@ static void dec_snappy(cur_t* c, win_t* w, dec_info* info) {
 static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     switch (format) {
     case ALZ_FMT_LZSS: return lz->window_bits;
-    case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: return 12; /* LZ10.cs:25 ... */
+    case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: return 12; /* LZ10.cs:25 ... */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
@@ -609,6 +636,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_LZSS: info.has_size = 1; dec_lzss(&lz, &c, &w, size); break;
     case ALZ_FMT_LZ10: info.has_size = 1; dec_lz10(&c, &w, size); break;
     case ALZ_FMT_LZ11: info.has_size = 1; dec_lz11(&c, &w, size); break;
+    case ALZ_FMT_LZ40: info.has_size = 1; dec_lz40(&c, &w, size); break;
     case ALZ_FMT_YAZ0: info.has_size = 1; dec_yay0(&c, &c, &c, &w, size); break;
     case ALZ_FMT_YAY0: {
         info.has_size = 1;
@@ -722,12 +750,12 @@ static buf_t buf_owned(void) { buf_t b = { NULL, 0, 0, 0, 1 }; return b; }
 static void buf_free(buf_t* b) { if (b->owned) free(b->p); b->p = NULL; }
 
 /* FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags) */
-typedef struct { buf_t* base; buf_t buffer; int bits_left; int cur; int msb_first; } fw_t;
+typedef struct { buf_t* base; buf_t buffer; int bits_left; int cur; int msb_first; int negate; } fw_t;
 
-static void fw_init(fw_t* f, buf_t* base, int msb_first) { f->base = base; f->buffer = buf_owned(); f->bits_left = 8; f->cur = 0; f->msb_first = msb_first; }
+static void fw_init(fw_t* f, buf_t* base, int msb_first) { f->base = base; f->buffer = buf_owned(); f->bits_left = 8; f->cur = 0; f->msb_first = msb_first; f->negate = 0; }
 /* Flush  FlagWriter.cs:111-127 */
 static void fw_flush(fw_t* f) {
-    if (f->bits_left != 8) { buf_u8(f->base, (uint32_t)f->cur); f->bits_left = 8; f->cur = 0; }
+    if (f->bits_left != 8) { buf_u8(f->base, (uint32_t)(f->negate ? (-f->cur) & 0xFF : f->cur)); f->bits_left = 8; f->cur = 0; }   /* LZ40: i => WriteByte((byte)-i) */
     if (f->buffer.len != 0) { buf_put(f->base, f->buffer.p, f->buffer.len); f->buffer.len = 0; }
 }
 /* WriteBit  FlagWriter.cs:70-80 */
@@ -905,6 +933,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     }
     case ALZ_FMT_LZ10: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                   /* LZ10.cs:25 */
     case ALZ_FMT_LZ11: p = (fmt_props){ 12, 0x4000, 3, 0x1000, 1 }; break;               /* LZ11.cs:25 */
+    case ALZ_FMT_LZ40: p = (fmt_props){ 12, 0x4000, 3, 0x1000, 1 }; break;               /* LZ40.cs:25 */
     case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: p = (fmt_props){ 12, 0xff + 0x12, 3, 0x1000, 1 }; break; /* Yay0.cs:27 */
     case ALZ_FMT_MIO0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                   /* MIO0.cs:28 */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: p = (fmt_props){ 13, 0x100, 2, 0x1FFF, 1 }; break; /* PRS.cs:21 */
@@ -972,6 +1001,25 @@ static void enc_lz11(const alz_settings* st, const uint8_t* src, int n, buf_t* o
         } else {
             buf_u32be(&flag.buffer, 0x10000000u | ((uint32_t)((match.length - 273) & 0xFFFF) << 12) | (uint32_t)((match.distance - 1) & 0xFFF));
         }
+        sp += match.length;
+        fw_bit(&flag, 1);
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
+/* LZ40.CompressHeaderless  LZ40.cs:134-176 */
+static void enc_lz40(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_LZ40, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 1); flag.negate = 1;
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 0); }
+        if (match.length == 0) break;
+        if (match.length < 16) buf_u16le(&flag.buffer, (uint32_t)((match.distance << 4) | match.length) & 0xFFFF);
+        else if (match.length < 272) { buf_u16le(&flag.buffer, (uint32_t)(match.distance << 4) & 0xFFFF); buf_u8(&flag.buffer, (uint32_t)(match.length - 16)); }
+        else { buf_u16le(&flag.buffer, (uint32_t)((match.distance << 4) | 1) & 0xFFFF); buf_u16le(&flag.buffer, (uint32_t)(match.length - 272) & 0xFFFF); }
         sp += match.length;
         fw_bit(&flag, 1);
     }
@@ -1200,6 +1248,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_LZSS: enc_lzss(props, st, src, (int)n, &out); break;
     case ALZ_FMT_LZ10: enc_lz10(st, src, (int)n, &out); break;
     case ALZ_FMT_LZ11: enc_lz11(st, src, (int)n, &out); break;
+    case ALZ_FMT_LZ40: enc_lz40(st, src, (int)n, &out); break;
     case ALZ_FMT_YAZ0: {                                                                 /* Yaz0.cs:94-98 */
         fw_t flag; fw_init(&flag, &out, 1);
         enc_yay0_core(st, src, (int)n, &flag.buffer, &flag.buffer, &flag, ALZ_FMT_YAZ0);
@@ -1258,6 +1307,8 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZSS: if (len < 8 || memcmp(src, "LZSS", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* LZSS.cs:45-50 */
     case ALZ_C_LZ10: return nin_header(src, len, 0x10, size_out) < 0 ? ALZ_E_FORMAT : 0;
     case ALZ_C_LZ11: return nin_header(src, len, 0x11, size_out) < 0 ? ALZ_E_FORMAT : 0;
+    case ALZ_C_LZ40: return nin_header(src, len, 0x40, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ40.cs:40-52 */
+    case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ60.cs:29-41 */
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* MIO0.cs:41-48 */
@@ -1554,6 +1605,13 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         if (h < 0) return ALZ_E_FORMAT;
         hdr = (size_t)h;
         run_stream(container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                  /* LZ40.cs:54-61, LZ60.cs:43-47 */
+        int h = nin_header(src, len, container == ALZ_C_LZ40 ? 0x40 : 0x60, &size);
+        if (h < 0) return ALZ_E_FORMAT;
+        hdr = (size_t)h;
+        run_stream(ALZ_FMT_LZ40, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
         break;
     }
     case ALZ_C_YAZ0:                                                                     /* Yaz0.cs:58-79 */
@@ -1869,6 +1927,15 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         else { wr32(dst, id, 0); wr32(dst + 4, (uint32_t)n, 0); hdr = 8; }
         if (container == ALZ_C_LZ10 && st.min_distance == 0) st.min_distance = 2;        /* GbaVramCompatibilityMode default true LZ10.cs:33 */
         body = oracle_encode_stream(container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    }
+    case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                  /* LZ40.cs:64-77, LZ60.cs:49-61 */
+        uint8_t id = container == ALZ_C_LZ40 ? 0x40 : 0x60;
+        if (cap < 8) return ALZ_E_NOMEM;
+        if (n <= 0xFFFFFF) { wr32(dst, id | ((uint32_t)n << 8), 0); hdr = 4; }
+        else { wr32(dst, id, 0); wr32(dst + 4, (uint32_t)n, 0); hdr = 8; }
+        body = oracle_encode_stream(ALZ_FMT_LZ40, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);   /* GbaVramCompatibilityMode = false */
         if (body < 0) return ALZ_E_NOMEM;
         break;
     }
