@@ -4,9 +4,9 @@ import ctypes as C
 ABI_VERSION = 1
 
 # alz_format
-FMT_LZSS, FMT_LZ10, FMT_LZ11, FMT_YAZ0, FMT_YAY0, FMT_MIO0, FMT_PRS_BE, FMT_PRS_LE, FMT_LZ4_BLOCK, FMT_LZO, FMT_SNAPPY_RAW, FMT_LZ40 = range(12)
-FMT_COUNT = 12
-FORMAT_NAMES = ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_le", "lz4_block", "lzo", "snappy_raw", "lz40"]
+FMT_LZSS, FMT_LZ10, FMT_LZ11, FMT_YAZ0, FMT_YAY0, FMT_MIO0, FMT_PRS_BE, FMT_PRS_LE, FMT_LZ4_BLOCK, FMT_LZO, FMT_SNAPPY_RAW, FMT_LZ40, FMT_LZHUDSON, FMT_SMSR00 = range(14)
+FMT_COUNT = 14
+FORMAT_NAMES = ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_le", "lz4_block", "lzo", "snappy_raw", "lz40", "lzhudson", "smsr00"]
 
 # alz_status
 ST_OK, ST_INPUT_TRUNCATED, ST_OUTPUT_SIZE_MISMATCH, ST_OUTPUT_CAPACITY, ST_BAD_TOKEN = range(5)
@@ -18,8 +18,8 @@ E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_FORMAT, E_STREAM, E_CHE
 C_LZSS, C_LZ10, C_LZ11, C_YAZ0, C_YAY0, C_MIO0, C_PRS, C_LZ4_LEGACY, C_LZO, C_SNAPPY = range(10)
 C_GCLZ, C_CXLZ, C_LZ_3DS, C_COMP, C_YAZ1, C_AKLZ, C_LZ01, C_LZSEGA, C_LEVEL5LZSS, C_LZON, C_LZ77, C_LEVEL5 = range(10, 22)
 C_LZ4_FRAME = 22
-C_MDB4, C_FCMP, C_IECP, C_GCZ, C_ECD, C_SDPC, C_LZ40, C_LZ60 = range(23, 31)
-C_COUNT = 31
+C_MDB4, C_FCMP, C_IECP, C_GCZ, C_ECD, C_SDPC, C_LZ40, C_LZ60, C_LZHUDSON, C_SMSR00 = range(23, 33)
+C_COUNT = 33
 LZ77_LZ10, LZ77_LZ11, LZ77_CHUNKLZ10 = 0x10, 0x11, 0xF7
 LEVEL5_ONLYSAVE, LEVEL5_LZ10 = 0, 1
 

@@ -445,6 +445,8 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZ10: return nin_header(src, len, 0x10, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ10.cs:44-57
     case ALZ_C_LZ11: return nin_header(src, len, 0x11, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ11.cs:40-53
     case ALZ_C_LZ40: return nin_header(src, len, 0x40, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ40.cs:40-52
+    case ALZ_C_LZHUDSON: if (len < 4) return ALZ_E_FORMAT; *size_out = be32(src); return ALZ_OK;                                        // LZHudson.cs:30-31
+    case ALZ_C_SMSR00: if (len < 12 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return ALZ_OK;          // SMSR00.cs:33-39
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ60.cs:29-41
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // Yaz0.cs:50-55
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return ALZ_OK;        // Yay0.cs:41-47 (always Endian.Big)
@@ -519,6 +521,8 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_LZON: return len > 0x10 && !memcmp(src, kLzonMagic, 8);
     case ALZ_C_LZ40: case ALZ_C_LZ60:                                                       // "no distinct header, recognition is inaccurate"  LZ40.cs:36-38
         return len > 0x8 && src[0] == (container == ALZ_C_LZ40 ? 0x40 : 0x60) && ((src[1] | src[2] | src[3]) != 0 || le32(src + 4) != 0);
+    case ALZ_C_LZHUDSON: return len > 0x8 && le32(src) != 0;                                // (+ the file extension when one is given)  LZHudson.cs:27-28
+    case ALZ_C_SMSR00: return len > 0x10 && !memcmp(src, "SMSR00", 6);                      // SMSR00.cs:30-31
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
     case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
     case ALZ_C_IECP: return len > 0x10 && !memcmp(src, "IECP", 4);
@@ -620,6 +624,17 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_LZO, nullptr, src + hdr, len - hdr, 0, 0, 0, dst, dst_cap, &r);
         if (rc == ALZ_OK && r.status == ALZ_ST_OK && r.dst_len != size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // DecompressedSizeException.ThrowIfMismatch
+        break;
+    case ALZ_C_LZHUDSON:                                                                    // LZHudson.cs:33-37
+        if (len < 4) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = be32(src); hdr = 4;
+        rc = run_body(ctx, ALZ_FMT_LZHUDSON, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_SMSR00:                                                                      // SMSR00.cs:41-48
+        if (len < 6 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = be32(src + 8); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
         break;
     case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                     // LZ40.cs:54-61, LZ60.cs:43-47
         int h = nin_header(src, len, container == ALZ_C_LZ40 ? 0x40 : 0x60, &size);
@@ -864,6 +879,8 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZ10: fmt = ALZ_FMT_LZ10; hdr = n <= 0xFFFFFF ? 4 : 8; if (st.min_distance == 0) st.min_distance = 2; break;   // GbaVramCompatibilityMode = true  LZ10.cs:33
     case ALZ_C_LZ11: fmt = ALZ_FMT_LZ11; hdr = n <= 0xFFFFFF ? 4 : 8; break;
     case ALZ_C_LZ40: case ALZ_C_LZ60: fmt = ALZ_FMT_LZ40; hdr = n <= 0xFFFFFF ? 4 : 8; break;   // GbaVramCompatibilityMode = false  LZ40.cs:29
+    case ALZ_C_LZHUDSON: fmt = ALZ_FMT_LZHUDSON; hdr = 4; break;
+    case ALZ_C_SMSR00: fmt = ALZ_FMT_SMSR00; hdr = 16; break;
     case ALZ_C_YAZ0: fmt = ALZ_FMT_YAZ0; hdr = 16; break;
     case ALZ_C_YAY0: fmt = ALZ_FMT_YAY0; hdr = 16; break;
     case ALZ_C_MIO0: fmt = ALZ_FMT_MIO0; hdr = 16; break;
@@ -892,6 +909,8 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZSEGA: wr32(dst, r.dst_len, false); wr32(dst + 4, (uint32_t)n, false); break;                                                      // LZSega.cs:57-67
     case ALZ_C_LEVEL5LZSS: memcpy(dst, "SSZL", 4); wr32(dst + 4, 0, false); wr32(dst + 8, r.dst_len, false); wr32(dst + 12, (uint32_t)n, false); break;   // Level5LZSS.cs:62-72
     case ALZ_C_LZON: memcpy(dst, kLzonMagic, 8); wr32(dst + 8, (uint32_t)n, true); wr32(dst + 12, r.dst_len, true); break;                          // LZOn.cs:63-79
+    case ALZ_C_LZHUDSON: wr32(dst, (uint32_t)n, true); break;                                                                                   // LZHudson.cs:39-43
+    case ALZ_C_SMSR00: memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, true); wr32(dst + 12, 16 + aux.aux0, true); break;   // SMSR00.cs:58-63
     case ALZ_C_MDB4: memcpy(dst, "MDB4", 4); wr32(dst + 4, (uint32_t)n + 1, false); wr32(dst + 8, (uint32_t)n, false); wr32(dst + 12, 16 + r.dst_len, false); memset(dst + 16, 0, 16); break;   // MDB4.cs:52-72
     case ALZ_C_FCMP: memcpy(dst, "FCMP", 4); wr32(dst + 4, (uint32_t)n, false); wr32(dst + 8, 305397760u, false); break;                          // FCMP.cs:43-50
     case ALZ_C_IECP: memcpy(dst, "IECP", 4); wr32(dst + 4, (uint32_t)n, false); break;                                                          // IECP.cs:41-46

@@ -190,6 +190,59 @@ __device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, SK&
     used = cp > up ? cp : up;
 }
 
+// LZHudson.DecompressHeaderless  HudsonSoft/LZHudson.cs:53: Yay0.DecompressHeaderless with all three cursors on one stream
+// (like Yaz0) and FlagReader(source, Endian.Big, 4, Endian.Big): 32-bit big-endian flag words, MSB first
+template <class SK>
+__device__ void dec_lzhudson_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
+    while (sk.produced() < size) {
+        sk.ensure(in, s.p, 8);
+        if (s.bits == 0) {
+            if (s.p + 4 > src_len) { s.eof = true; s.p = src_len; return; }      // ReadInt32 past the end: EndOfStreamException
+            s.flag = __builtin_bswap32(in.peek4(s.p)); s.p += 4; s.bits = 32;
+        }
+        u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            u32 b = in.peek1(s.p); s.p++;
+            if (!sk.lit(b)) return;
+        } else {
+            if (s.p + 2 > src_len) { s.eof = true; return; }
+            u32 w = in.peek4(s.p); s.p += 2;
+            u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF, b3 = (w >> 16) & 0xFF;
+            u32 distance = (((b1 & 0x0F) << 8) | b2) + 1, length = b1 >> 4;
+            if (length == 0) { if (s.p < src_len) { length = b3 + 0x12; s.p++; } else length = 17; }   // ReadByte() == -1 -> 17  Yay0.cs:130-131
+            else length += 2;
+            if (!sk.match(distance, length, 4096)) return;
+        }
+    }
+}
+
+// SMSR00.DecompressHeaderless  Nintendo/SMSR00.cs:85-131: cin walks the code section [0, codes_len) -- 16-bit big-endian
+// masks (MSB first, 1 = literal) each followed by the match words of its 16 tokens --, uin the literal section behind it
+template <class SK>
+__device__ void dec_smsr00_serial(InCache& cin, InCache& uin, SK& sk, DecState& s, u32 src_len, u32 size, u32 codes_len, u32& used) {
+    u32 cp = 0, up = codes_len;
+    while (sk.produced() < size) {
+        if (s.bits == 0) {
+            if (cp + 2 > codes_len) { s.eof = true; break; }                      // codes[codePointer++]: IndexOutOfRangeException
+            sk.ensure(cin, cp, 4); const u32 w = cin.peek4(cp); cp += 2;
+            s.flag = ((w & 0xFF) << 8) | ((w >> 8) & 0xFF); s.bits = 16;
+        }
+        u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (up >= src_len) { s.eof = true; break; }
+            sk.ensure(uin, up, 1); u32 b = uin.peek1(up); up++;
+            if (!sk.lit(b)) break;
+        } else {
+            if (cp + 2 > codes_len) { s.eof = true; break; }
+            sk.ensure(cin, cp, 4); const u32 w = cin.peek4(cp); cp += 2;
+            const u32 data = ((w & 0xFF) << 8) | ((w >> 8) & 0xFF);
+            if (!sk.match((data & 0x0FFF) + 1, (data >> 12) + 3, 4096)) break;
+        }
+    }
+    used = up;                                                                      // source.Position: behind the literals read
+}
+
 // PRS.DecompressHeaderless(Stream, Stream, Endian)  Sega/PRS.cs:59-102
 template <class SK, bool BIG>
 __device__ void dec_prs_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 max_tokens = 0xFFFFFFFFu) {

@@ -194,16 +194,21 @@ struct Out {                 // bounded byte sink of one stream
 
 // FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags): the flag byte goes out before the payload of its tokens
 struct FlagW {
-    Out* base; u8 payload[40]; int plen, bits_left, cur; bool msb, neg;
-    __device__ void init(Out* b, bool m, bool negate = false) { base = b; plen = 0; bits_left = 8; cur = 0; msb = m; neg = negate; }
+    Out* base; u8 payload[104]; int plen, bits_left, width; u32 cur; bool msb, neg;
+    // nbytes 1: byte flags (optionally stored negated, LZ40); 2 / 4: big-endian flag words (SMSR00 / LZHudson)
+    __device__ void init(Out* b, bool m, bool negate = false, int nbytes = 1) { base = b; plen = 0; width = 8 * nbytes; bits_left = width; cur = 0; msb = m; neg = negate; }
     __device__ void flush() {
-        if (bits_left != 8) { base->put(neg ? (u32)(0 - cur) & 0xFFu : (u32)cur); bits_left = 8; cur = 0; }   // LZ40: i => WriteByte((byte)-i)
+        if (bits_left != width) {
+            if (width == 8) base->put(neg ? (0u - cur) & 0xFFu : cur);      // LZ40: i => WriteByte((byte)-i)
+            else for (int i = width - 8; i >= 0; i -= 8) base->put((cur >> i) & 0xFFu);
+            bits_left = width; cur = 0;
+        }
         for (int i = 0; i < plen; i++) base->put(payload[i]);
         plen = 0;
     }
-    __device__ void bit(int b) { if (b) cur |= 1 << (msb ? bits_left - 1 : 8 - bits_left); if (--bits_left == 0) flush(); }
+    __device__ void bit(int b) { if (b) cur |= 1u << (msb ? bits_left - 1 : width - bits_left); if (--bits_left == 0) flush(); }
     __device__ void pay(u32 v) { payload[plen++] = (u8)v; }
-    __device__ void flush_if_necessary() { if (bits_left == 8 && plen) { for (int i = 0; i < plen; i++) base->put(payload[i]); plen = 0; } }
+    __device__ void flush_if_necessary() { if (bits_left == width && plen) { for (int i = 0; i < plen; i++) base->put(payload[i]); plen = 0; } }
 };
 
 struct Match { int offset, distance, length; };
@@ -325,6 +330,33 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             fw.bit(0);
         }
         fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_LZHUDSON) {                         // LZHudson.cs:55-59: Yay0's tokens, one stream, 32-bit BE flag words
+        FlagW fw; fw.init(&out, true, false, 4);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(1); }
+            if (mt.length == 0) break;
+            if (mt.length < 18) { const u32 v = ((u32)(mt.distance - 1) | (((u32)mt.length - 2) << 12)) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); }
+            else { const u32 v = (u32)(mt.distance - 1) & 0xFFF; fw.pay(v >> 8); fw.pay(v & 0xFF); fw.pay((u32)mt.length - 0x12); }
+            sp += mt.length;
+            fw.bit(0);
+        }
+        fw.flush();
+    } else if constexpr (FMT == ALZ_FMT_SMSR00) {                           // SMSR00.cs:133-137 over MIO0.cs:159-184: codes | literals
+        u8* sb = side + 2 * pos_off[sid];
+        Out unc = { sb, 0, (u32)n + 16, false };
+        FlagW fw; fw.init(&out, true, false, 2);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { unc.put(src[sp++]); fw.bit(1); }
+            if (mt.length == 0) break;
+            const u32 v = ((u32)(mt.distance - 1) | (((u32)mt.length - 3) << 12)) & 0xFFFF; fw.pay(v >> 8); fw.pay(v & 0xFF);
+            sp += mt.length;
+            fw.bit(0);
+        }
+        fw.flush();
+        a0 = out.len; a1 = 0;
+        out.copy(unc.p, unc.len);
     } else if constexpr (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0) {      // Yay0.cs:62-77,152-184 / MIO0.cs:64-79,159-184
         // three sections: flags go straight to dst, tokens and literals to side buffers, concatenated afterwards
         u8* sb = side + 2 * pos_off[sid];
@@ -684,9 +716,9 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     switch (fmt) {
     case ALZ_FMT_LZSS:
         wb = lz->window_bits; g.min_len = lz->min_length; g.max_len = (1 << lz->length_bits) + lz->min_length - 1; g.max_dist = (int)lz->max_distance; break;
-    case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;
+    case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;
     case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: g.min_len = 3; g.max_len = 0x4000; g.max_dist = 0x1000; break;
-    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: g.min_len = 3; g.max_len = 0xff + 0x12; g.max_dist = 0x1000; break;
+    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_LZHUDSON: g.min_len = 3; g.max_len = 0xff + 0x12; g.max_dist = 0x1000; break;
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: wb = 13; g.min_len = 2; g.max_len = 0x100; g.max_dist = 0x1FFF; break;
     case ALZ_FMT_LZ4_BLOCK: wb = 16; g.min_len = 4; g.max_len = 0x7FFFFFFF; g.max_dist = 0xFFFF; break;
     case ALZ_FMT_LZO: wb = 16; g.min_len = 3; g.max_len = 0x7FFFFFFF; g.max_dist = 0xBFFF; break;
@@ -749,6 +781,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_PRS_LE: launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ4_BLOCK: launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

@@ -372,7 +372,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
     if (e == hipSuccess && any_min) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int));
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
-    if (e == hipSuccess && (cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0])) e = sc.alloc(&d_side, (size_t)total * 2 + 64);
+    if (e == hipSuccess && (cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00])) e = sc.alloc(&d_side, (size_t)total * 2 + 64);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);

@@ -72,6 +72,18 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         has_size = true; dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_LZ40) {
         has_size = true; dec_lz40_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_LZHUDSON) {
+        has_size = true; dec_lzhudson_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_SMSR00) {
+        has_size = true;
+        const u32 a0 = uni(st.aux0);
+        if (a0 > src_len) s.eof = true;                                   // ReadExactly(buffer, 0, codesLength) throws  SMSR00.cs:76
+        else {
+            InCache uin;
+            uin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); uin.seek(a0 < src_len ? a0 : 0);
+            dec_smsr00_serial(in, uin, sk, s, src_len, size, a0, used);
+            used_set = true;
+        }
     } else if constexpr (FMT == ALZ_FMT_YAZ0) {
         has_size = true; dec_yaz0_serial(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0) {
@@ -316,6 +328,8 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_LZ4_BLOCK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZ4_BLOCK>, 64, 0); break;
     case ALZ_FMT_LZO: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZO>, 64, 0); break;
     case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
+    case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_serial_kernel<ALZ_FMT_LZHUDSON, false>, 64, 4096 + ALZ_INCACHE_BYTES); break;
+    case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_serial_kernel<ALZ_FMT_SMSR00, false>, 64, 4096 + 2 * ALZ_INCACHE_BYTES); break;
     default: break;
     }
     return e == hipSuccess ? n : -1;
@@ -361,6 +375,8 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_LZ10: return launch_serial<ALZ_FMT_LZ10, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_LZ11: return launch_serial<ALZ_FMT_LZ11, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_LZ40: return launch_serial<ALZ_FMT_LZ40, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_LZHUDSON: return launch_serial<ALZ_FMT_LZHUDSON, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_SMSR00: return launch_serial<ALZ_FMT_SMSR00, false>(stream, s, d, streams, index, count, results, lz, 4096, 2);
     case ALZ_FMT_YAZ0: return launch_serial<ALZ_FMT_YAZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_YAY0: return launch_serial<ALZ_FMT_YAY0, false>(stream, s, d, streams, index, count, results, lz, 4096, 3);
     case ALZ_FMT_MIO0: return launch_serial<ALZ_FMT_MIO0, false>(stream, s, d, streams, index, count, results, lz, 4096, 3);

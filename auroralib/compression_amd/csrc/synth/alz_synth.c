@@ -49,18 +49,23 @@ static inline void o_put(out_t* o, const void* d, size_t n) {
 static inline void o_u8(out_t* o, uint32_t v) { uint8_t x = (uint8_t)v; o_put(o, &x, 1); }
 
 /* flag byte accumulator: flag byte is emitted before the payload of its 8 tokens */
-typedef struct { out_t* base; uint8_t payload[8 * 8 + 16]; int plen; int bits_left; int cur; int msb; int neg; } fw_t;
-static void fw_init(fw_t* f, out_t* base, int msb) { f->base = base; f->plen = 0; f->bits_left = 8; f->cur = 0; f->msb = msb; f->neg = 0; }
+typedef struct { out_t* base; uint8_t payload[32 * 4 + 16]; int plen; int bits_left; uint32_t cur; int msb; int neg; int nbytes; } fw_t;
+static void fw_init(fw_t* f, out_t* base, int msb) { f->base = base; f->plen = 0; f->bits_left = 8; f->cur = 0; f->msb = msb; f->neg = 0; f->nbytes = 1; }
+static void fw_width(fw_t* f, int nbytes) { f->nbytes = nbytes; f->bits_left = 8 * nbytes; }   /* big-endian flag words (LZHudson 4, SMSR00 2) */
 static void fw_flush(fw_t* f) {
-    if (f->bits_left != 8) { o_u8(f->base, (uint32_t)(f->neg ? (-f->cur) & 0xFF : f->cur)); f->bits_left = 8; f->cur = 0; }   /* LZ40 stores the flag byte negated */
+    if (f->bits_left != 8 * f->nbytes) {
+        if (f->nbytes == 1) o_u8(f->base, f->neg ? (0u - f->cur) & 0xFFu : f->cur);   /* LZ40 stores the flag byte negated */
+        else for (int i = f->nbytes - 1; i >= 0; i--) o_u8(f->base, (f->cur >> (8 * i)) & 0xFFu);
+        f->bits_left = 8 * f->nbytes; f->cur = 0;
+    }
     if (f->plen) { o_put(f->base, f->payload, (size_t)f->plen); f->plen = 0; }
 }
 static void fw_bit(fw_t* f, int bit) {
-    if (bit) { int sh = f->msb ? f->bits_left - 1 : 8 - f->bits_left; f->cur |= 1 << sh; }
+    if (bit) { int sh = f->msb ? f->bits_left - 1 : 8 * f->nbytes - f->bits_left; f->cur |= 1u << sh; }
     if (--f->bits_left == 0) fw_flush(f);
 }
 static inline void fw_pay(fw_t* f, uint32_t v) { f->payload[f->plen++] = (uint8_t)v; }
-static void fw_flush_if_necessary(fw_t* f) { if (f->bits_left == 8 && f->plen) { o_put(f->base, f->payload, (size_t)f->plen); f->plen = 0; } }
+static void fw_flush_if_necessary(fw_t* f) { if (f->bits_left == 8 * f->nbytes && f->plen) { o_put(f->base, f->payload, (size_t)f->plen); f->plen = 0; } }
 
 typedef struct { uint32_t len, dist; } tok_t;
 
@@ -98,20 +103,25 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
     case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: break;
     case ALZ_FMT_LZ11: longlo = 17; longhi = 272; break;
     case ALZ_FMT_LZ40: shortmax = 15; longlo = 16; longhi = 271; break;
-    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: longlo = 18; longhi = 273; break;
+    case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_LZHUDSON: longlo = 18; longhi = 273; break;
+    case ALZ_FMT_SMSR00: break;
     default: break;
     }
     int three = (format == ALZ_FMT_YAY0 || format == ALZ_FMT_MIO0);
+    int smsr = (format == ALZ_FMT_SMSR00);     /* codes (masks + match words through the flag writer) | literals */
     /* three-section formats buffer tokens/literals separately */
     out_t flags = { NULL, 0, 0, 0 }, comp = { NULL, 0, 0, 0 }, unc = { NULL, 0, 0, 0 };
     uint8_t *fb = NULL, *cb = NULL, *ub = NULL;
-    if (three && out->p) {
+    if ((three || smsr) && out->p) {
         size_t cap = (size_t)target + (target >> 2) + 64;
-        fb = (uint8_t*)malloc(cap / 8 + 64); cb = (uint8_t*)malloc(cap); ub = (uint8_t*)malloc(cap);
-        flags.p = fb; flags.cap = cap / 8 + 64; comp.p = cb; comp.cap = cap; unc.p = ub; unc.cap = cap;
+        const size_t fcap = smsr ? cap : cap / 8 + 64;     /* SMSR00: the flag writer's stream is the whole code section */
+        fb = (uint8_t*)malloc(fcap); cb = (uint8_t*)malloc(cap); ub = (uint8_t*)malloc(cap);
+        flags.p = fb; flags.cap = fcap; comp.p = cb; comp.cap = cap; unc.p = ub; unc.cap = cap;
     }
-    fw_t fw; fw_init(&fw, three ? &flags : out, msb);
+    fw_t fw; fw_init(&fw, (three || smsr) ? &flags : out, msb);
     fw.neg = format == ALZ_FMT_LZ40;
+    if (format == ALZ_FMT_LZHUDSON) fw_width(&fw, 4);
+    if (smsr) fw_width(&fw, 2);
     uint32_t produced = 0;
     while (produced < target) {
         uint32_t rem = target - produced;
@@ -121,8 +131,8 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             switch (format) {
             case ALZ_FMT_LZSS: fw_pay(&fw, b); fw_bit(&fw, 1); break;
             case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: fw_pay(&fw, b); fw_bit(&fw, 0); break;
-            case ALZ_FMT_YAZ0: fw_pay(&fw, b); fw_bit(&fw, 1); break;
-            default: o_u8(&unc, b); fw_bit(&fw, 1); break; /* YAY0 / MIO0 */
+            case ALZ_FMT_YAZ0: case ALZ_FMT_LZHUDSON: fw_pay(&fw, b); fw_bit(&fw, 1); break;
+            default: o_u8(&unc, b); fw_bit(&fw, 1); break; /* YAY0 / MIO0 / SMSR00 */
             }
             produced++;
             continue;
@@ -150,7 +160,8 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             else { uint32_t v = dv | 1, l = t.len - 272; fw_pay(&fw, v & 0xFF); fw_pay(&fw, v >> 8); fw_pay(&fw, l & 0xFF); fw_pay(&fw, l >> 8); }
             fw_bit(&fw, 1); break;
         }
-        case ALZ_FMT_YAZ0:
+        case ALZ_FMT_SMSR00: fw_pay(&fw, ((t.len - 3) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); fw_bit(&fw, 0); break;
+        case ALZ_FMT_YAZ0: case ALZ_FMT_LZHUDSON:
             if (t.len < 18) { fw_pay(&fw, ((t.len - 2) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
             else { fw_pay(&fw, d1 >> 8); fw_pay(&fw, d1 & 0xFF); fw_pay(&fw, t.len - 0x12); }
             fw_bit(&fw, 0); break;
@@ -164,7 +175,12 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
         produced += t.len;
     }
     fw_flush(&fw);
-    if (three) {
+    if (smsr) {
+        if (aux) { aux->aux0 = (uint32_t)flags.len; aux->aux1 = 0; }
+        if (out->p) { o_put(out, fb, flags.len); o_put(out, ub, unc.len); } else out->len += flags.len + unc.len;
+        if (flags.fail || unc.fail) out->fail = 1;
+        free(fb); free(cb); free(ub);
+    } else if (three) {
         if (aux) { aux->aux0 = (uint32_t)flags.len; aux->aux1 = (uint32_t)(flags.len + comp.len); }
         if (out->p) { o_put(out, fb, flags.len); o_put(out, cb, comp.len); o_put(out, ub, unc.len); }
         else out->len += flags.len + comp.len + unc.len;
@@ -335,6 +351,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
     switch (format) {
     case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
+    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00:
         gen_flagfmt(format, props, &r, target, &out, aux); break;
     case ALZ_FMT_PRS_BE: gen_prs(&r, target, &out, 1); break;
     case ALZ_FMT_PRS_LE: gen_prs(&r, target, &out, 0); break;

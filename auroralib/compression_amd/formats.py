@@ -253,6 +253,16 @@ class LZ60(_Format):
     container = A.C_LZ60
 
 
+class LZHudson(_Format):
+    """src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs -- Yay0's grammar, one stream, 32-bit flag words."""
+    container = A.C_LZHUDSON
+
+
+class SMSR00(_Format):
+    """src/AuroraLib.Compression.Nintendo/Nintendo/SMSR00.cs -- 16-bit masks + MIO0 tokens | literals."""
+    container = A.C_SMSR00
+
+
 class MDB4(_Format):
     """src/AuroraLib.Compression-Extended/Specialized/MDB4.cs"""
     container = A.C_MDB4
@@ -291,5 +301,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZ77, Level5]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

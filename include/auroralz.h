@@ -45,7 +45,11 @@ typedef enum alz_format {
     ALZ_FMT_LZO        = 9,  /* LZO.DecompressHeaderless     src/AuroraLib.Compression/Formats/Common/LZO.cs:49-139 */
     ALZ_FMT_SNAPPY_RAW = 10, /* Snappy.DecompressHeaderless  src/AuroraLib.Compression/Formats/Common/Snappy.cs:205-250 */
     ALZ_FMT_LZ40       = 11, /* LZ40.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/LZ40.cs:80-132 (also the body of LZ60) */
-    ALZ_FMT_COUNT      = 12
+    ALZ_FMT_LZHUDSON   = 12, /* LZHudson.DecompressHeaderless: the Yay0 grammar on ONE stream with 32-bit big-endian flag words
+                                src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:53 (exact serial kernel only) */
+    ALZ_FMT_SMSR00     = 13, /* SMSR00.DecompressHeaderless: u16 BE codes (16-bit masks + MIO0 tokens) | literals; aux0 = length of the
+                                code section   src/AuroraLib.Compression.Nintendo/Nintendo/SMSR00.cs:70-131 (exact serial kernel only) */
+    ALZ_FMT_COUNT      = 14
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -90,11 +94,12 @@ typedef struct alz_lz_properties {
  * resident buffers alike.
  *
  * decom_len : the `decomLength` argument of the reference's DecompressHeaderless
- *             (LZSS/LZ10/LZ11/LZ40/YAZ0/YAY0/MIO0).  Ignored by PRS/LZ4/LZO (no size
+ *             (LZSS/LZ10/LZ11/LZ40/YAZ0/YAY0/MIO0/LZHUDSON/SMSR00).  Ignored by PRS/LZ4/LZO (no size
  *             field, terminated by token / end of input) and by SNAPPY_RAW
  *             (varint inside the body).
  * aux0/aux1 : YAY0/MIO0: compressedDataPointer / uncompressedDataPointer
  *             relative to the first flag byte (Yay0.cs:60, MIO0.cs:61).
+ *             SMSR00: aux0 = bytes of the code section (the literal section follows it).
  *             LZ4_BLOCK: aux0 = history, the number of bytes in front of dst_off
  *             (<= dst_off) that are earlier output of the same LZ4 frame and may
  *             be referenced by matches -- one LzWindows serves all blocks of a
@@ -237,7 +242,9 @@ typedef enum alz_container {
     ALZ_C_SDPC   = 28, /* "SDPC"+n + LZO                           src/AuroraLib.Compression-Extended/Specialized/SDPC.cs:34-54 */
     ALZ_C_LZ40   = 29, /* 0x40 + u24 LE size + LZ40 body (negated MSB-first flag bytes, LE tokens)   Nintendo/LZ40.cs:40-77 */
     ALZ_C_LZ60   = 30, /* 0x60 + u24 LE size + the same body                                         Nintendo/LZ60.cs:29-58 */
-    ALZ_C_COUNT  = 31
+    ALZ_C_LZHUDSON = 31, /* BE size + LZHudson body                 src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:33-51 */
+    ALZ_C_SMSR00 = 32, /* "SMSR00"+u16 0+BE size+BE literal pointer + codes | literals   Nintendo/SMSR00.cs:41-66 */
+    ALZ_C_COUNT  = 33
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

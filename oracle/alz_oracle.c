@@ -242,14 +242,19 @@ static void win_dispose(win_t* w) {
 
 /* ============================================================ FlagReader (IO/FlagReader.cs:12-103), 8-bit flags */
 
-typedef struct { cur_t* c; int bits_left; int cur; int msb_first; } flag_t;
+typedef struct { cur_t* c; int bits_left; int cur; int msb_first; int nbytes; /* 0/1: byte flags; 2 / 4: big-endian flag words */ } flag_t;
 
 /* Readbit  FlagReader.cs:53-65 */
 static inline int flag_readbit(flag_t* f) {
-    if (f->bits_left == 0) { f->cur = cur_u8(f->c); f->bits_left = 8; }
-    int shift = f->msb_first ? f->bits_left - 1 : 8 - f->bits_left;
+    const int width = f->nbytes > 1 ? 8 * f->nbytes : 8;
+    if (f->bits_left == 0) {                                                             /* ReadNextFlag  FlagReader.cs:40-47 */
+        if (f->nbytes > 1) { uint32_t v = 0; for (int i = 0; i < f->nbytes; i++) v = (v << 8) | (uint32_t)cur_u8(f->c); f->cur = (int)v; }
+        else f->cur = cur_u8(f->c);
+        f->bits_left = width;
+    }
+    int shift = f->msb_first ? f->bits_left - 1 : width - f->bits_left;
     f->bits_left--;
-    return (f->cur >> shift) & 1;
+    return (int)(((uint32_t)f->cur >> shift) & 1u);
 }
 
 /* ============================================================ decoders */
@@ -258,7 +263,7 @@ typedef struct { int has_size; int bad_token; uint32_t src_used; } dec_info;
 
 /* LZSS.DecompressHeaderless  Formats/Common/LZSS.cs:91-130 */
 static void dec_lzss(const alz_lz_properties* lz, cur_t* c, win_t* w, uint32_t size) {
-    flag_t flag = { c, 0, 0, 0 };                       /* FlagReader(source, Endian.Little)  :95 */
+    flag_t flag = { c, 0, 0, 0, 1 };                     /* FlagReader(source, Endian.Little)  :95 */
     uint32_t f = (1u << lz->length_bits) - 1;            /* GetLengthBitsFlag */
     uint32_t n = lz->max_distance - 1;                   /* GetWindowsFlag */
     while (win_produced(w) < size) {                     /* :104 */
@@ -282,7 +287,7 @@ static void dec_lzss(const alz_lz_properties* lz, cur_t* c, win_t* w, uint32_t s
 
 /* LZ10.DecompressHeaderless  Nintendo/LZ10.cs:82-111 */
 static void dec_lz10(cur_t* c, win_t* w, uint32_t size) {
-    flag_t flag = { c, 0, 0, 1 };                        /* FlagReader(source, Endian.Big) :88 */
+    flag_t flag = { c, 0, 0, 1, 1 };                        /* FlagReader(source, Endian.Big) :88 */
     while (win_produced(w) < size) {
         int bit = flag_readbit(&flag); if (c->eof) return;
         if (bit) {
@@ -303,7 +308,7 @@ static void dec_lz10(cur_t* c, win_t* w, uint32_t size) {
 
 /* LZ11.DecompressHeaderless  Nintendo/LZ11.cs:83-133 */
 static void dec_lz11(cur_t* c, win_t* w, uint32_t size) {
-    flag_t flag = { c, 0, 0, 1 };
+    flag_t flag = { c, 0, 0, 1, 1 };
     while (win_produced(w) < size) {
         int bit = flag_readbit(&flag); if (c->eof) return;
         if (bit) {
@@ -363,8 +368,8 @@ static void dec_lz40(cur_t* c, win_t* w, uint32_t size) {
 
 /* Yay0.DecompressHeaderless(FlagReader, compressed, uncompressed, dest, len)  Nintendo/Yay0.cs:110-144.
  * Yaz0 passes the same stream for all three cursors (Yaz0.cs:91-92). */
-static void dec_yay0(cur_t* fc, cur_t* cc, cur_t* uc, win_t* w, uint32_t size) {
-    flag_t flag = { fc, 0, 0, 1 };
+static void dec_yay0_w(cur_t* fc, cur_t* cc, cur_t* uc, win_t* w, uint32_t size, int flag_bytes) {
+    flag_t flag = { fc, 0, 0, 1, flag_bytes };
     while (win_produced(w) < size) {
         int bit = flag_readbit(&flag); if (fc->eof) return;
         if (bit) {
@@ -382,6 +387,32 @@ static void dec_yay0(cur_t* fc, cur_t* cc, cur_t* uc, win_t* w, uint32_t size) {
             win_back_copy(w, distance, cl);
             if (w->overflow) return;
         }
+    }
+}
+
+static void dec_yay0(cur_t* fc, cur_t* cc, cur_t* uc, win_t* w, uint32_t size) { dec_yay0_w(fc, cc, uc, w, size, 1); }
+
+/* SMSR00.DecompressHeaderless(Stream uncompressed, ReadOnlySpan<ushort> codes, ...)  Nintendo/SMSR00.cs:85-131:
+   codes = 16-bit big-endian words: a mask (MSB first, 1 = literal) followed by the match words of its 16 tokens */
+static void dec_smsr00(cur_t* codes, cur_t* lit, win_t* w, uint32_t size) {
+    uint32_t mask = 0; int bits = 0;
+    while (win_produced(w) < size) {
+        if (bits == 0) {
+            if (codes->pos + 2 > codes->len) { codes->eof = 1; return; }                 /* codes[codePointer++]: IndexOutOfRange */
+            mask = ((uint32_t)codes->p[codes->pos] << 8) | codes->p[codes->pos + 1]; codes->pos += 2; bits = 16;
+        }
+        if (mask & 0x8000u) {
+            int b = cur_u8(lit); if (lit->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);
+        } else {
+            if (codes->pos + 2 > codes->len) { codes->eof = 1; return; }
+            uint32_t data = ((uint32_t)codes->p[codes->pos] << 8) | codes->p[codes->pos + 1]; codes->pos += 2;
+            uint32_t cl = win_clip(w, (data >> 12) + 3);
+            win_back_copy(w, (data & 0x0FFF) + 1, cl);
+            if (w->overflow) return;
+        }
+        mask = (mask << 1) & 0xFFFFu; bits--;
     }
 }
 
@@ -416,7 +447,7 @@ static void dec_mio0(cur_t* c, win_t* w, uint32_t size, uint32_t cptr, uint32_t 
 
 /* PRS.DecompressHeaderless(Stream, Stream, Endian)  Sega/PRS.cs:59-102.  Returns 1 when the terminator was read. */
 static int dec_prs(cur_t* c, win_t* w, int big) {
-    flag_t flag = { c, 0, 0, big };                      /* FlagReader(source, order): bit order = byte order :62 */
+    flag_t flag = { c, 0, 0, big, 1 };                      /* FlagReader(source, order): bit order = byte order :62 */
     while (c->pos < c->len) {                            /* :64 */
         int bit = flag_readbit(&flag); if (c->eof) return 0;
         if (bit) {
@@ -608,7 +639,8 @@ static void dec_snappy(cur_t* c, win_t* w, dec_info* info) {
 static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     switch (format) {
     case ALZ_FMT_LZSS: return lz->window_bits;
-    case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: return 12; /* LZ10.cs:25 ... */
+    case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
+    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: return 12; /* LZ10.cs:25 ... */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
@@ -637,6 +669,17 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_LZ10: info.has_size = 1; dec_lz10(&c, &w, size); break;
     case ALZ_FMT_LZ11: info.has_size = 1; dec_lz11(&c, &w, size); break;
     case ALZ_FMT_LZ40: info.has_size = 1; dec_lz40(&c, &w, size); break;
+    case ALZ_FMT_LZHUDSON: info.has_size = 1; dec_yay0_w(&c, &c, &c, &w, size, 4); break;   /* FlagReader(source, Endian.Big, 4, Endian.Big)  LZHudson.cs:53 */
+    case ALZ_FMT_SMSR00: {
+        info.has_size = 1;
+        if (s->aux0 > s->src_len) { c.eof = 1; break; }                                     /* ReadExactly(buffer, 0, codesLength) throws */
+        cur_t codes = { c.p, s->aux0, 0, 0 };
+        cur_t lit = { c.p + s->aux0, s->src_len - s->aux0, 0, 0 };
+        dec_smsr00(&codes, &lit, &w, size);
+        if (codes.eof || lit.eof) c.eof = 1;
+        used = s->aux0 + lit.pos; used_set = 1;                                             /* source.Position: behind the codes + literals read */
+        break;
+    }
     case ALZ_FMT_YAZ0: info.has_size = 1; dec_yay0(&c, &c, &c, &w, size); break;
     case ALZ_FMT_YAY0: {
         info.has_size = 1;
@@ -750,23 +793,28 @@ static buf_t buf_owned(void) { buf_t b = { NULL, 0, 0, 0, 1 }; return b; }
 static void buf_free(buf_t* b) { if (b->owned) free(b->p); b->p = NULL; }
 
 /* FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags) */
-typedef struct { buf_t* base; buf_t buffer; int bits_left; int cur; int msb_first; int negate; } fw_t;
+typedef struct { buf_t* base; buf_t buffer; int bits_left; uint32_t cur; int msb_first; int negate; int nbytes; } fw_t;
 
-static void fw_init(fw_t* f, buf_t* base, int msb_first) { f->base = base; f->buffer = buf_owned(); f->bits_left = 8; f->cur = 0; f->msb_first = msb_first; f->negate = 0; }
+static void fw_init(fw_t* f, buf_t* base, int msb_first) { f->base = base; f->buffer = buf_owned(); f->bits_left = 8; f->cur = 0; f->msb_first = msb_first; f->negate = 0; f->nbytes = 1; }
+static void fw_set_width(fw_t* f, int nbytes) { f->nbytes = nbytes; f->bits_left = 8 * nbytes; }   /* FlagWriter(dest, Endian.Big, flagSize, Endian.Big) */
 /* Flush  FlagWriter.cs:111-127 */
 static void fw_flush(fw_t* f) {
-    if (f->bits_left != 8) { buf_u8(f->base, (uint32_t)(f->negate ? (-f->cur) & 0xFF : f->cur)); f->bits_left = 8; f->cur = 0; }   /* LZ40: i => WriteByte((byte)-i) */
+    if (f->bits_left != 8 * f->nbytes) {
+        if (f->nbytes == 1) buf_u8(f->base, f->negate ? (0u - f->cur) & 0xFFu : f->cur);   /* LZ40: i => WriteByte((byte)-i) */
+        else for (int i = f->nbytes - 1; i >= 0; i--) buf_u8(f->base, (f->cur >> (8 * i)) & 0xFFu);
+        f->bits_left = 8 * f->nbytes; f->cur = 0;
+    }
     if (f->buffer.len != 0) { buf_put(f->base, f->buffer.p, f->buffer.len); f->buffer.len = 0; }
 }
 /* WriteBit  FlagWriter.cs:70-80 */
 static void fw_bit(fw_t* f, int bit) {
-    if (bit) { int shift = f->msb_first ? f->bits_left - 1 : 8 - f->bits_left; f->cur |= 1 << shift; }
+    if (bit) { int shift = f->msb_first ? f->bits_left - 1 : 8 * f->nbytes - f->bits_left; f->cur |= 1u << shift; }
     f->bits_left--;
     if (f->bits_left == 0) fw_flush(f);
 }
 /* FlushIfNecessary  FlagWriter.cs:132-139 */
 static void fw_flush_if_necessary(fw_t* f) {
-    if (f->bits_left == 8 && f->buffer.len != 0) { buf_put(f->base, f->buffer.p, f->buffer.len); f->buffer.len = 0; }
+    if (f->bits_left == 8 * f->nbytes && f->buffer.len != 0) { buf_put(f->base, f->buffer.p, f->buffer.len); f->buffer.len = 0; }
 }
 static void fw_dispose(fw_t* f) { fw_flush(f); buf_free(&f->buffer); }
 
@@ -934,6 +982,8 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_LZ10: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                   /* LZ10.cs:25 */
     case ALZ_FMT_LZ11: p = (fmt_props){ 12, 0x4000, 3, 0x1000, 1 }; break;               /* LZ11.cs:25 */
     case ALZ_FMT_LZ40: p = (fmt_props){ 12, 0x4000, 3, 0x1000, 1 }; break;               /* LZ40.cs:25 */
+    case ALZ_FMT_LZHUDSON: p = (fmt_props){ 12, 0xff + 18, 3, 0x1000, 1 }; break;         /* LZHudson.cs:20 */
+    case ALZ_FMT_SMSR00: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                 /* SMSR00.cs:25 */
     case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: p = (fmt_props){ 12, 0xff + 0x12, 3, 0x1000, 1 }; break; /* Yay0.cs:27 */
     case ALZ_FMT_MIO0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                   /* MIO0.cs:28 */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: p = (fmt_props){ 13, 0x100, 2, 0x1FFF, 1 }; break; /* PRS.cs:21 */
@@ -1254,6 +1304,21 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
         enc_yay0_core(st, src, (int)n, &flag.buffer, &flag.buffer, &flag, ALZ_FMT_YAZ0);
         fw_dispose(&flag); break;
     }
+    case ALZ_FMT_LZHUDSON: {                                                             /* LZHudson.cs:55-59 */
+        fw_t flag; fw_init(&flag, &out, 1); fw_set_width(&flag, 4);
+        enc_yay0_core(st, src, (int)n, &flag.buffer, &flag.buffer, &flag, ALZ_FMT_LZHUDSON);
+        fw_dispose(&flag); break;
+    }
+    case ALZ_FMT_SMSR00: {                                                               /* SMSR00.cs:133-137, :52-66 */
+        buf_t codes = buf_owned(), uncomp = buf_owned();
+        fw_t flag; fw_init(&flag, &codes, 1); fw_set_width(&flag, 2);
+        enc_mio0_core(st, src, (int)n, &flag.buffer, &uncomp, &flag);
+        fw_dispose(&flag);
+        if (aux) { aux->aux0 = (uint32_t)codes.len; aux->aux1 = 0; }
+        buf_put(&out, codes.p, codes.len); buf_put(&out, uncomp.p, uncomp.len);
+        buf_free(&codes); buf_free(&uncomp);
+        break;
+    }
     case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: {                                              /* Yay0.cs:62-77 / MIO0.cs:64-79 */
         buf_t flags = buf_owned(), comp = buf_owned(), uncomp = buf_owned();
         fw_t flag; fw_init(&flag, &flags, 1);
@@ -1308,6 +1373,8 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZ10: return nin_header(src, len, 0x10, size_out) < 0 ? ALZ_E_FORMAT : 0;
     case ALZ_C_LZ11: return nin_header(src, len, 0x11, size_out) < 0 ? ALZ_E_FORMAT : 0;
     case ALZ_C_LZ40: return nin_header(src, len, 0x40, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ40.cs:40-52 */
+    case ALZ_C_LZHUDSON: if (len < 4) return ALZ_E_FORMAT; *size_out = be32(src); return 0;                                        /* LZHudson.cs:30-31 */
+    case ALZ_C_SMSR00: if (len < 12 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return 0;          /* SMSR00.cs:33-39 */
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ60.cs:29-41 */
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
@@ -1553,7 +1620,7 @@ static int snappy_file_compress(const alz_settings* st, const uint8_t* src, size
 
 /* PRS.ValidateByteOrder  Sega/PRS.cs:171-218 */
 static int prs_validate(const uint8_t* src, size_t len, int big) {
-    cur_t c = { src, (uint32_t)len, 0, 0 }; flag_t flag = { &c, 0, 0, big };
+    cur_t c = { src, (uint32_t)len, 0, 0 }; flag_t flag = { &c, 0, 0, big, 1 };
     int i = 3; uint64_t buffer = 0;
     while (c.pos < c.len) {
         int bit = flag_readbit(&flag); if (c.eof) return 0;
@@ -1605,6 +1672,19 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         if (h < 0) return ALZ_E_FORMAT;
         hdr = (size_t)h;
         run_stream(container == ALZ_C_LZ10 ? ALZ_FMT_LZ10 : ALZ_FMT_LZ11, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_LZHUDSON:                                                                 /* LZHudson.cs:33-37 */
+        if (len < 4) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = be32(src); hdr = 4;
+        run_stream(ALZ_FMT_LZHUDSON, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
+    case ALZ_C_SMSR00: {                                                                 /* SMSR00.cs:41-48 */
+        if (len < 6 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = be32(src + 8); hdr = 16;
+        uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
+        run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
         break;
     }
     case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                  /* LZ40.cs:54-61, LZ60.cs:43-47 */
@@ -1930,6 +2010,19 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         if (body < 0) return ALZ_E_NOMEM;
         break;
     }
+    case ALZ_C_LZHUDSON:                                                                 /* LZHudson.cs:39-43 */
+        if (cap < 4) return ALZ_E_NOMEM;
+        wr32(dst, (uint32_t)n, 1); hdr = 4;
+        body = oracle_encode_stream(ALZ_FMT_LZHUDSON, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    case ALZ_C_SMSR00:                                                                   /* SMSR00.cs:50-66 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
     case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                  /* LZ40.cs:64-77, LZ60.cs:49-61 */
         uint8_t id = container == ALZ_C_LZ40 ? 0x40 : 0x60;
         if (cap < 8) return ALZ_E_NOMEM;

@@ -41,7 +41,7 @@ def test_lzss_static_decoding_kat():
 
 
 HEADERLESS = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_PRS_LE,
-              A.FMT_LZ4_BLOCK, A.FMT_LZO, A.FMT_SNAPPY_RAW, A.FMT_LZ40]
+              A.FMT_LZ4_BLOCK, A.FMT_LZO, A.FMT_SNAPPY_RAW, A.FMT_LZ40, A.FMT_LZHUDSON, A.FMT_SMSR00]
 
 
 def _roundtrip(fmt, raw, quality, **kw):
