@@ -32,6 +32,7 @@
 #define ALZ_NB 8    /* steps whose HBM read-backs are issued together (two-pass byte phase of the 64 KiB formats) */
 #endif
 
+__device__ __forceinline__ u64 wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ u32 wave_bperm(u32 src_lane, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 __device__ __forceinline__ u32 wave_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 // v_writelane_b32: write a wave-uniform value into one lane of a VGPR (no clang builtin in ROCm 7.2).  gfx9 allows one
@@ -478,6 +479,43 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, true, len, desc, tend, segmark, nullptr, lane, last, 4096);
     if (fin) { cp += last >> 8; up += last & 0xFFu; }
     else { cp += 2u * (u32)__popcll(~lm); up += (u32)__popcll(um); fp += 8; }
+    return fin;
+}
+
+// SMSR00 (Nintendo/SMSR00.cs:85-131): 16-bit big-endian masks and the match words of their 16 tokens share one code
+// stream, literals have their own.  A group's size depends on its mask alone (1 + number of 0 bits), so the chain of the
+// four groups of an iteration is three v_readlane hops over "1 + popcount of the word at my lane"; lane 16 j + k is token k
+// of group j, its match word sits (zero bits before k) words behind the mask, its literal at the prefix count of 1 bits.
+// Precondition: s.bits == 0, cp + 136 <= codes_len (4 masks + 64 match words), up + 64 <= src_len.
+template <class OW>
+__device__ __forceinline__ bool fast_iter_smsr00(InCache& cin, InCache& uin, OW& out, DecState& s, u32 size, u8* segmark, int lane, u32& cp, u32& up) {
+    cin.ensure(cp, 136); uin.ensure(up, 64);
+    const u32 wi = cin.idx(cp + 2u * (u32)lane);
+    const u32 w = ((u32)cin.lds[wi] << 8) | cin.lds[wi + 1];          // the code word at my lane, big endian
+    const u32 gsize = 1u + (u32)__popc(~w & 0xFFFFu);                 // if a group started here
+    const u32 g0 = 0u, g1 = g0 + wave_readlane(gsize, g0), g2 = g1 + wave_readlane(gsize, g1), g3 = g2 + wave_readlane(gsize, g2);
+    const u32 gend = g3 + wave_readlane(gsize, g3);
+    const u32 j = (u32)lane >> 4, k = (u32)lane & 15u;
+    const u32 gstart = j == 0u ? g0 : (j == 1u ? g1 : (j == 2u ? g2 : g3));
+    const u32 m0 = wave_readlane(w, g0), m1 = wave_readlane(w, g1), m2 = wave_readlane(w, g2), m3 = wave_readlane(w, g3);
+    const u32 mask = j == 0u ? m0 : (j == 1u ? m1 : (j == 2u ? m2 : m3));
+    const bool lit = (mask >> (15u - k)) & 1u;                        // MSB first, 1 = literal
+    const u32 mbefore = (u32)__popc((~mask & 0xFFFFu) >> (16u - k));  // match tokens of my group before me (k = 0: shift by 16 -> 0)
+    const u64 lm = wave_ballot(lit);
+    const u32 uidx = mbcnt64(lm);
+    u32 len = 1, desc;
+    if (lit) desc = ALZ_DESC_LIT(uin.byte_at(up + uidx));
+    else {
+        const u32 ci = cin.idx(cp + 2u * (gstart + 1u + mbefore));
+        const u32 data = ((u32)cin.lds[ci] << 8) | cin.lds[ci + 1];
+        desc = ALZ_DESC_MATCH((data & 0x0FFFu) + 1u); len = (data >> 12) + 3u;
+    }
+    // cursors after this token, packed so one readlane recovers both: code words (<= 68) << 8 | literals (<= 64)
+    const u32 tend = ((gstart + 1u + mbefore + (lit ? 0u : 1u)) << 8) | (uidx + (lit ? 1u : 0u));
+    u32 last;
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, true, len, desc, tend, segmark, nullptr, lane, last, 4096);
+    if (fin) { cp += 2u * (last >> 8); up += last & 0xFFu; }
+    else { cp += 2u * gend; up += (u32)__popcll(lm); }
     return fin;
 }
 

@@ -220,8 +220,9 @@ __device__ void dec_lzhudson_serial(InCache& in, SK& sk, DecState& s, u32 src_le
 // SMSR00.DecompressHeaderless  Nintendo/SMSR00.cs:85-131: cin walks the code section [0, codes_len) -- 16-bit big-endian
 // masks (MSB first, 1 = literal) each followed by the match words of its 16 tokens --, uin the literal section behind it
 template <class SK>
-__device__ void dec_smsr00_serial(InCache& cin, InCache& uin, SK& sk, DecState& s, u32 src_len, u32 size, u32 codes_len, u32& used) {
-    u32 cp = 0, up = codes_len;
+__device__ void dec_smsr00_serial(InCache& cin, InCache& uin, SK& sk, DecState& s, u32 src_len, u32 size, u32 codes_len, u32& used,
+                                  u32 cp0 = 0, u32 up0 = 0xFFFFFFFFu) {
+    u32 cp = cp0, up = up0 == 0xFFFFFFFFu ? codes_len : up0;        // (resumed behind the lane-parallel loop at a mask boundary)
     while (sk.produced() < size) {
         if (s.bits == 0) {
             if (cp + 2 > codes_len) { s.eof = true; break; }                      // codes[codePointer++]: IndexOutOfRangeException

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
                                                              const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, u32 count,
                                                              alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
-    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
-    constexpr int NC = THREE ? 3 : 1;
+    constexpr bool SMSR = (FMT == ALZ_FMT_SMSR00);                    // code stream + literal stream
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0 || SMSR);   // (several input cursors: small caches)
+    constexpr int NC = SMSR ? 2 : (THREE ? 3 : 1);
     // static LDS (absolute addresses fold into the DS instructions' offset fields): marks | input caches | window
     // (the waves of a workgroup never interact: several streams share a workgroup only because a CU holds more waves than
     // single-wave workgroups)
@@ -163,6 +164,19 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
             else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
             else if constexpr (FMT == ALZ_FMT_LZ40) dec_lz40_serial(in, sk, s, src_len, size);
             else dec_yaz0_serial(in, sk, s, src_len, size);
+        }
+    } else if constexpr (SMSR) {
+        const u32 a0 = uni(st.aux0);                                       // length of the code section
+        if (a0 > src_len) s.eof = true;                                    // ReadExactly(buffer, 0, codesLength) throws  SMSR00.cs:76
+        else {
+            InCache uin;
+            uin.init(src, src_len, inc_lds + CACHE, lane, CHUNK); uin.seek(a0 < src_len ? a0 : 0);
+            u32 cp = 0, up = a0;
+            while (!fin && out.produced < size && (u64)cp + 136u <= a0 && (u64)up + 64u <= src_len)
+                fin = fast_iter_smsr00(in, uin, out, s, size, segmark, lane, cp, up);
+            used = up;
+            if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_smsr00_serial(in, uin, sk, s, src_len, size, a0, used, cp, up); }
+            used_set = true;
         }
     } else {
         const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
@@ -329,7 +343,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_LZO: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZO>, 64, 0); break;
     case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
     case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_serial_kernel<ALZ_FMT_LZHUDSON, false>, 64, 4096 + ALZ_INCACHE_BYTES); break;
-    case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_serial_kernel<ALZ_FMT_SMSR00, false>, 64, 4096 + 2 * ALZ_INCACHE_BYTES); break;
+    case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_SMSR00>, 64 * ALZ_WPB, 0); break;
     default: break;
     }
     return e == hipSuccess ? n : -1;
@@ -358,6 +372,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_YAY0: return launch_fast<ALZ_FMT_YAY0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
+        case ALZ_FMT_SMSR00: return launch_fast<ALZ_FMT_SMSR00>(stream, s, d, streams, index, count, results, lz, 4096, 2);
         case ALZ_FMT_PRS_BE: return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_PRS_LE: return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZ4_BLOCK: return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
