@@ -170,7 +170,7 @@ def test_fuzz_garbage_and_mutations(fmt, test_bmp):
             src = bytes(rng.choice([0, 0, 0xFF, 0x0F, 0xF0, rng.randrange(256)]) for _ in range(n))
         decl = rng.choice([len(raw), len(raw), 100, 70000, 0])
         cap = rng.choice([decl, decl + 300, max(decl, 1) // 2, 70000])
-        three = fmt in (A.FMT_YAY0, A.FMT_MIO0)            # aux = section offsets there (LZ4: aux0 would be frame history)
+        three = fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_SMSR00)   # aux = section offsets there (LZ4: aux0 would be frame history)
         items.append(dict(fmt=fmt, src=src, decom_len=decl, cap=cap, aux0=aux.aux0 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0),
                           aux1=aux.aux1 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0)))
     streams, src, dst_bytes = pack_streams(items, dst_slack=32)
