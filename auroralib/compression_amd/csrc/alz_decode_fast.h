@@ -482,6 +482,64 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     return fin;
 }
 
+// LZHudson (HudsonSoft/LZHudson.cs:53): Yaz0's tokens behind 32-bit big-endian flag words -- four flag bytes, then the 32
+// tokens they describe.  One flag word per iteration (lanes 8r..8r+7 are the tokens of its r-th flag byte): the start of run
+// r + 1 is known once run r has been walked, but the walk itself -- "8 tokens with flag byte f start at my byte: how long are
+// they?" -- runs on all lanes at once for the (wave-uniform) flag byte of the round, so the chain is four rounds of one
+// speculative walk + one v_readlane.  A run that starts beyond byte 63 of the window (only possible behind > 20 three-byte
+// matches) waits for the next iteration, which resumes inside the flag word (s.flag / s.bits, the serial parser's state).
+// Precondition: s.bits in {0, 8, 16, 24, 32}, s.p + 128 <= src_len, out.produced < size.
+template <class OW>
+__device__ __forceinline__ bool fast_iter_lzhudson(InCache& in, OW& out, DecState& s, u32 size, u8* segmark, int lane) {
+    const u32 p = s.p;
+    in.ensure(p, 128);
+    const u32 x0 = in.byte_at(p + (u32)lane), x1 = in.byte_at(p + 64u + (u32)lane);
+    const u64 zlo = __ballot((x0 >> 4) == 0), zhi = __ballot((x1 >> 4) == 0);
+    const u32 l3 = mask_window(zlo, zhi, lane);                  // bit r: the byte r behind mine has a zero high nibble (3-byte match)
+    u32 F = uni(s.flag), nb = uni(s.bits), T = 0;                 // T: start of the next run, relative to p
+    if (nb == 0) {
+        F = (wave_readlane(x0, 0u) << 24) | (wave_readlane(x0, 1u) << 16) | (wave_readlane(x0, 2u) << 8) | wave_readlane(x0, 3u);
+        nb = 32; T = 4;
+    }
+    const u32 nruns = nb >> 3;
+    u32 tstart = 0, infosel = 0, done = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if ((u32)r < nruns && T <= 63u && done == (u32)r) {        // (wave-uniform)
+            const u32 mbits = ~(F >> (nb - 8u * (u32)(r + 1))) & 0xFFu;   // flag byte of run r, MSB first, 1 = literal; set = match
+            u32 rr = 0, info = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 m = (mbits >> (7 - k)) & 1u;
+                const u32 extra = m + (m & (l3 >> rr));
+                info |= extra << (4 * k);
+                rr += 1u + extra;
+            }
+            const u32 inf = wave_readlane(info, T);
+            if (((u32)lane >> 3) == (u32)r) { tstart = T; infosel = inf; }
+            T += wave_readlane(rr, T);
+            done = (u32)r + 1u;
+        }
+    }
+    const u32 k = (u32)lane & 7u;
+    const bool valid = (u32)lane < 8u * done;
+    const u32 m = ((infosel >> (4u * k)) & 0xFu) != 0u;
+    const u32 to = tstart + k + (u32)__builtin_amdgcn_udot8(infosel & ((1u << (4u * k)) - 1u), 0x11111111u, 0u, false);
+    const u32 ti = in.idx(p + to);
+    const u32 b1 = in.lds[ti], b2 = in.lds[ti + 1], b3 = in.lds[ti + 2];
+    u32 len = 1, desc = ALZ_DESC_LIT(b1), tend = to + 1;
+    if (m) {
+        const u32 nib = b1 >> 4;
+        desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 1u);
+        if (nib == 0) { len = b3 + 0x12u; tend = to + 3; } else { len = nib + 2u; tend = to + 2; }
+    }
+    u32 last_tend;
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, 4096);
+    s.p = fin ? p + last_tend : p + T;
+    s.flag = F; s.bits = nb - 8u * done;
+    return fin;
+}
+
 // SMSR00 (Nintendo/SMSR00.cs:85-131): 16-bit big-endian masks and the match words of their 16 tokens share one code
 // stream, literals have their own.  A group's size depends on its mask alone (1 + number of 0 bits), so the chain of the
 // four groups of an iteration is three v_readlane hops over "1 + popcount of the word at my lane"; lane 16 j + k is token k

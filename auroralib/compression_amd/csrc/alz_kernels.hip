@@ -151,7 +151,10 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     u32 used = 0; bool used_set = false;
     bool fin = false;
 
-    if constexpr (!THREE) {
+    if constexpr (FMT == ALZ_FMT_LZHUDSON) {
+        while (!fin && out.produced < size && (u64)s.p + 128u <= src_len) fin = fast_iter_lzhudson(in, out, s, size, segmark, lane);
+        if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
+    } else if constexpr (!THREE) {
         FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
         gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
         bool to_serial = false;   // the fast loop runs to the last complete token of the input; the exact parser finishes
@@ -342,7 +345,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_LZ4_BLOCK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZ4_BLOCK>, 64, 0); break;
     case ALZ_FMT_LZO: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZO>, 64, 0); break;
     case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
-    case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_serial_kernel<ALZ_FMT_LZHUDSON, false>, 64, 4096 + ALZ_INCACHE_BYTES); break;
+    case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZHUDSON>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_SMSR00>, 64 * ALZ_WPB, 0); break;
     default: break;
     }
@@ -373,6 +376,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_YAY0: return launch_fast<ALZ_FMT_YAY0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_SMSR00: return launch_fast<ALZ_FMT_SMSR00>(stream, s, d, streams, index, count, results, lz, 4096, 2);
+        case ALZ_FMT_LZHUDSON: return launch_fast<ALZ_FMT_LZHUDSON>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_PRS_BE: return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_PRS_LE: return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZ4_BLOCK: return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);

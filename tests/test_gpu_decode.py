@@ -83,6 +83,28 @@ def test_real_data_roundtrip(fmt, test_bmp):
 
 
 @pytest.mark.parametrize("fmt", ALL)
+def test_run_heavy_roundtrip(fmt):
+    """Degenerate inputs the lane-parallel parsers see least of in Test.bmp: one repeated byte (every token a maximum-length
+    match with its extension byte), short periods, runs broken by single literals."""
+    import random
+    rng = random.Random(77 + fmt)
+    raws = [bytes(200000), b"\xAB" * 70001, b"abc" * 30000, bytes(rng.randrange(256) for _ in range(5000)) * 30,
+            b"".join(bytes([rng.randrange(256)]) * rng.choice([1, 2, 3, 17, 18, 19, 272, 273, 274, 300, 5000]) for _ in range(400)),
+            b"".join((bytes([rng.randrange(256)]) * rng.randrange(1, 40)) for _ in range(6000))]
+    items = []
+    for k, raw in enumerate(raws):
+        comp, aux = O.encode_stream(fmt, raw, quality=[0, 8, 15][k % 3])
+        items.append(dict(fmt=fmt, src=comp, decom_len=len(raw), aux0=aux.aux0, aux1=aux.aux1))
+    streams, src, dst_bytes = pack_streams(items)
+    gr, g_dst = compare_batch(streams, src, dst_bytes, what="runs " + A.FORMAT_NAMES[fmt])
+    assert (gr["status"] == 0).all()
+    recs = synth.stream_records(streams)
+    for k, raw in enumerate(raws):
+        a = int(recs["dst_off"][k])
+        assert bytes(g_dst[a:a + len(raw)]) == raw
+
+
+@pytest.mark.parametrize("fmt", ALL)
 def test_truncated_inputs(fmt, test_bmp):
     """EndOfStreamException paths: every prefix length class of a valid stream."""
     raw = test_bmp[1000:1000 + 3000]
