@@ -19,7 +19,8 @@ C_LZSS, C_LZ10, C_LZ11, C_YAZ0, C_YAY0, C_MIO0, C_PRS, C_LZ4_LEGACY, C_LZO, C_SN
 C_GCLZ, C_CXLZ, C_LZ_3DS, C_COMP, C_YAZ1, C_AKLZ, C_LZ01, C_LZSEGA, C_LEVEL5LZSS, C_LZON, C_LZ77, C_LEVEL5 = range(10, 22)
 C_LZ4_FRAME = 22
 C_MDB4, C_FCMP, C_IECP, C_GCZ, C_ECD, C_SDPC, C_LZ40, C_LZ60, C_LZHUDSON, C_SMSR00 = range(23, 33)
-C_COUNT = 33
+C_LZ00 = 33
+C_COUNT = 34
 LZ77_LZ10, LZ77_LZ11, LZ77_CHUNKLZ10 = 0x10, 0x11, 0xF7
 LEVEL5_ONLYSAVE, LEVEL5_LZ10 = 0, 1
 
@@ -55,7 +56,8 @@ class EncodeAux(C.Structure):
 
 
 class ContainerOptions(C.Structure):
-    _fields_ = [("big_endian", C.c_uint32), ("memory_alignment", C.c_uint32), ("lz", LzProperties), ("variant", C.c_uint32), ("chunk_size", C.c_uint32)]
+    _fields_ = [("big_endian", C.c_uint32), ("memory_alignment", C.c_uint32), ("lz", LzProperties), ("variant", C.c_uint32), ("chunk_size", C.c_uint32),
+                ("key", C.c_uint32), ("name", C.c_uint8 * 32)]
 
 
 assert C.sizeof(Stream) == 40 and C.sizeof(Result) == 16 and C.sizeof(LzProperties) == 16

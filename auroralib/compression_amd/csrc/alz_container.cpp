@@ -434,6 +434,17 @@ int snappy_file_compress(alz_ctx* ctx, const alz_settings* st, const uint8_t* sr
 
 }  // namespace
 
+// LZ00.StreamTransformer  LZ00.cs:128-141: body byte i is XORed with element i + 1 of the keystream of `key`.
+// GenerateNextKey's shift/add chain is key * 1103515245 + 12345 (3 -> 95 -> 3041 -> 389247, then x 63 x 15 x 3).  A header-level
+// transform like the frame checksums: it runs on the host, on the compressed bytes, before / after the body kernels.
+static void lz00_keystream(uint8_t* p, size_t n, uint32_t key) {
+    for (size_t i = 0; i < n; i++) {
+        key = key * 1103515245u + 12345u;
+        const uint32_t t = (key >> 16) & 0x7FFFu;
+        p[i] ^= (uint8_t)(((t << 8) - t) >> 15);
+    }
+}
+
 extern "C" {
 
 // IProvidesDecompressedSize.GetDecompressedSize  Interfaces/IProvidesDecompressedSize.cs:20
@@ -446,6 +457,7 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZ11: return nin_header(src, len, 0x11, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ11.cs:40-53
     case ALZ_C_LZ40: return nin_header(src, len, 0x40, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ40.cs:40-52
     case ALZ_C_LZHUDSON: if (len < 4) return ALZ_E_FORMAT; *size_out = be32(src); return ALZ_OK;                                        // LZHudson.cs:30-31
+    case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 48); return ALZ_OK;               // LZ00.cs:31-37
     case ALZ_C_SMSR00: if (len < 12 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return ALZ_OK;          // SMSR00.cs:33-39
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ60.cs:29-41
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // Yaz0.cs:50-55
@@ -523,6 +535,7 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
         return len > 0x8 && src[0] == (container == ALZ_C_LZ40 ? 0x40 : 0x60) && ((src[1] | src[2] | src[3]) != 0 || le32(src + 4) != 0);
     case ALZ_C_LZHUDSON: return len > 0x8 && le32(src) != 0;                                // (+ the file extension when one is given)  LZHudson.cs:27-28
     case ALZ_C_SMSR00: return len > 0x10 && !memcmp(src, "SMSR00", 6);                      // SMSR00.cs:30-31
+    case ALZ_C_LZ00: return len > 0x40 && !memcmp(src, "LZ00", 4);                           // LZ00.cs:36-37
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
     case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
     case ALZ_C_IECP: return len > 0x10 && !memcmp(src, "IECP", 4);
@@ -636,6 +649,15 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
         break;
+    case ALZ_C_LZ00: {                                                                      // LZ00.cs:40-60
+        if (len < 4 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT;
+        if (len < 64) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = le32(src + 48); hdr = 64;
+        std::vector<uint8_t> plain(src + hdr, src + len);                                   // the body behind the StreamTransformer
+        lz00_keystream(plain.data(), plain.size(), le32(src + 52));
+        rc = run_body(ctx, ALZ_FMT_LZSS, nullptr, plain.data(), plain.size(), size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
     case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                     // LZ40.cs:54-61, LZ60.cs:43-47
         int h = nin_header(src, len, container == ALZ_C_LZ40 ? 0x40 : 0x60, &size);
         if (h < 0) return ALZ_E_FORMAT;
@@ -754,7 +776,7 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
 size_t alz_container_compress_bound(uint32_t container, size_t n) {
     if (container == ALZ_C_SNAPPY) return 10 + n + (n / 0x10000 + 1) * 8 + 64;      // stored chunks bound the size
     if (container == ALZ_C_LZ4_FRAME || container == ALZ_C_LZ4_LEGACY) return n + n / 200 + (n / 0x10000 + 1) * 8 + 64;
-    return n + n / 4 + 64;   // flag-byte formats: <= 9/8 n + header; LZ4/LZO/Snappy literal-run overhead n/255
+    return n + n / 4 + 128;  // flag-byte formats: <= 9/8 n + header; LZ4/LZO/Snappy literal-run overhead n/255
 }
 
 // ICompressionEncoder.Compress(ReadOnlySpan<byte>, Stream, CompressionSettings)  Interfaces/ICompressionEncoder.cs:19
@@ -867,6 +889,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_AKLZ: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
     case ALZ_C_LZ01: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
     case ALZ_C_LZSEGA: fmt = ALZ_FMT_LZSS; hdr = 8; lz = nullptr; break;
+    case ALZ_C_LZ00: fmt = ALZ_FMT_LZSS; hdr = 64; lz = nullptr; break;
     case ALZ_C_LEVEL5LZSS: fmt = ALZ_FMT_LZSS; hdr = 16; lz = nullptr; break;
     case ALZ_C_LZON: fmt = ALZ_FMT_LZO; hdr = 16; break;
     case ALZ_C_MDB4: fmt = ALZ_FMT_LZSS; hdr = 32; lz = nullptr; break;
@@ -907,6 +930,15 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_AKLZ: memcpy(dst, kAklzMagic, 12); wr32(dst + 12, (uint32_t)n, true); break;                                                        // AKLZ.cs:50-55
     case ALZ_C_LZ01: memcpy(dst, "LZ01", 4); wr32(dst + 4, (uint32_t)(hdr + r.dst_len), false); wr32(dst + 8, (uint32_t)n, false); wr32(dst + 12, 0, false); break;   // LZ01.cs:65-82
     case ALZ_C_LZSEGA: wr32(dst, r.dst_len, false); wr32(dst + 4, (uint32_t)n, false); break;                                                      // LZSega.cs:57-67
+    case ALZ_C_LZ00: {                                                                                                                         // LZ00.cs:71-96
+        const uint32_t key = opt ? opt->key : 0;
+        lz00_keystream(dst + hdr, r.dst_len, key);                                          // LZSS.CompressHeaderless writes through the StreamTransformer
+        memset(dst, 0, 64); memcpy(dst, "LZ00", 4); wr32(dst + 4, (uint32_t)(hdr + r.dst_len), false);
+        bool named = false; if (opt) for (int i = 0; i < 32; i++) named |= opt->name[i] != 0;
+        if (named) memcpy(dst + 16, opt->name, 32); else memcpy(dst + 16, "Temp.dat", 8);
+        wr32(dst + 48, (uint32_t)n, false); wr32(dst + 52, key, false);
+        break;
+    }
     case ALZ_C_LEVEL5LZSS: memcpy(dst, "SSZL", 4); wr32(dst + 4, 0, false); wr32(dst + 8, r.dst_len, false); wr32(dst + 12, (uint32_t)n, false); break;   // Level5LZSS.cs:62-72
     case ALZ_C_LZON: memcpy(dst, kLzonMagic, 8); wr32(dst + 8, (uint32_t)n, true); wr32(dst + 12, r.dst_len, true); break;                          // LZOn.cs:63-79
     case ALZ_C_LZHUDSON: wr32(dst, (uint32_t)n, true); break;                                                                                   // LZHudson.cs:39-43

@@ -754,7 +754,11 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
     if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
     sk.qtok = qt; sk.nt = base; sk.qbytes = total;
     s.p = p + sp;
+#if defined(ALZ_QEXP) && ALZ_QEXP == 1
+    sk.out.produced += total; sk.nt = 0; sk.qbytes = 0; if (qt == 0x12345u) stage[lane] = qt;   // timing experiment: parse only
+#else
     sk.flush();
+#endif
     return true;
 }
 

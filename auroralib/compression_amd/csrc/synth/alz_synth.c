@@ -222,11 +222,15 @@ static void put_rand(out_t* o, rng_t* r, uint32_t n) {
     if (n) { uint64_t v = rng_next(r); o_put(o, &v, n); }
 }
 
+/* experiment knob (environment ALZ_SYNTH_MAXDIST, read by alz_synth_batch): caps the match distance of the LZ4 / LZO / Snappy
+ * generators below the format maximum, to separate the cost of sources older than the LDS window from the rest */
+static uint32_t g_seq_maxdist = 0;
 static tok_t draw_match_seq(rng_t* r, uint32_t produced, uint32_t rem, uint32_t minlen, uint32_t maxlen, uint32_t maxdist) {
     tok_t t;
     if (rng_unit(r) < 0.1) t.len = rng_range(r, 19, 300); else t.len = minlen + rng_geometric(r, 10.0);
     if (t.len > maxlen) t.len = maxlen;
     if (t.len > rem) t.len = rem;
+    if (g_seq_maxdist && g_seq_maxdist < maxdist) maxdist = g_seq_maxdist;
     uint32_t maxd = produced < maxdist ? produced : maxdist;
     double u = rng_unit(r);
     if (u < 0.05) t.dist = 1;
@@ -388,6 +392,7 @@ int alz_synth_batch(const uint32_t* formats, uint32_t format, const alz_lz_prope
                     alz_encode_aux* aux, int nthreads) {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
+    { const char* e = getenv("ALZ_SYNTH_MAXDIST"); g_seq_maxdist = e ? (uint32_t)strtoul(e, NULL, 0) : 0; }
     pthread_t th[256]; sjob_t jobs[256];
     for (int t = 0; t < nthreads; t++) {
         sjob_t j = { formats, format, props, base_seed, n, targets, target, dst, offs, sizes, aux, t, nthreads };

@@ -62,12 +62,18 @@ class _Format:
         self.lz = None
         self.Type = 0                     # LZ77.Type / Level5.Type (0 = class default)
         self.ChunkSize = 0                # LZ77.ChunkSize (0 = 0x1000)
+        self.Key = 0                      # LZ00: keystream seed of the next Compress
+        self.Name = ""                    # LZ00.Name ("" = "Temp.dat")
 
     def _opt(self):
         o = A.ContainerOptions()
         o.big_endian = 1 if self.FormatByteOrder == "Big" else 0
         o.memory_alignment = self.MemoryAlignment
         o.variant, o.chunk_size = self.Type, self.ChunkSize
+        o.key = self.Key & 0xFFFFFFFF
+        nm = self.Name.encode("latin-1")[:32]
+        for i, b in enumerate(nm):
+            o.name[i] = b
         if self.lz is not None:
             o.lz = self.lz
         return o
@@ -210,6 +216,22 @@ class LZSega(_Format):
     container = A.C_LZSEGA
 
 
+class LZ00(_Format):
+    """src/AuroraLib.Compression.Sega/Sega/LZ00.cs -- LZSS body behind the StreamTransformer keystream.  Compress(data,
+    settings, key=None): the managed parameterless overload seeds the keystream with the Unix time (LZ00.cs:64-68)."""
+    container = A.C_LZ00
+
+    def Compress(self, data, settings=None, key=None):
+        import time
+        self.Key = int(time.time()) if key is None else key
+        return super().Compress(data, settings)
+
+    def Decompress(self, data, capacity=None):
+        out = super().Decompress(data, capacity)
+        self.Name = bytes(data[16:48]).split(b"\0")[0].decode("latin-1")     # Name = source.ReadString(32)  LZ00.cs:50
+        return out
+
+
 class Level5LZSS(_Format):
     container = A.C_LEVEL5LZSS
 
@@ -301,5 +323,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ77, Level5]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ00, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

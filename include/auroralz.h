@@ -46,9 +46,9 @@ typedef enum alz_format {
     ALZ_FMT_SNAPPY_RAW = 10, /* Snappy.DecompressHeaderless  src/AuroraLib.Compression/Formats/Common/Snappy.cs:205-250 */
     ALZ_FMT_LZ40       = 11, /* LZ40.DecompressHeaderless    src/AuroraLib.Compression.Nintendo/Nintendo/LZ40.cs:80-132 (also the body of LZ60) */
     ALZ_FMT_LZHUDSON   = 12, /* LZHudson.DecompressHeaderless: the Yay0 grammar on ONE stream with 32-bit big-endian flag words
-                                src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:53 (exact serial kernel only) */
+                                src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:53 */
     ALZ_FMT_SMSR00     = 13, /* SMSR00.DecompressHeaderless: u16 BE codes (16-bit masks + MIO0 tokens) | literals; aux0 = length of the
-                                code section   src/AuroraLib.Compression.Nintendo/Nintendo/SMSR00.cs:70-131 (exact serial kernel only) */
+                                code section   src/AuroraLib.Compression.Nintendo/Nintendo/SMSR00.cs:70-131 */
     ALZ_FMT_COUNT      = 14
 } alz_format;
 
@@ -244,7 +244,9 @@ typedef enum alz_container {
     ALZ_C_LZ60   = 30, /* 0x60 + u24 LE size + the same body                                         Nintendo/LZ60.cs:29-58 */
     ALZ_C_LZHUDSON = 31, /* BE size + LZHudson body                 src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:33-51 */
     ALZ_C_SMSR00 = 32, /* "SMSR00"+u16 0+BE size+BE literal pointer + codes | literals   Nintendo/SMSR00.cs:41-66 */
-    ALZ_C_COUNT  = 33
+    ALZ_C_LZ00   = 33, /* "LZ00"+csize+8x0+name[32]+size+key+8x0, then an LZSS body XORed with the keystream of `key`
+                          src/AuroraLib.Compression.Sega/Sega/LZ00.cs:40-96, :128-141 (see alz_container_options.key) */
+    ALZ_C_COUNT  = 34
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */
@@ -261,6 +263,9 @@ typedef struct alz_container_options {
     uint32_t variant;             /* LZ77.Type / Level5.Type when compressing; 0 = the class default (LZ10) */
     uint32_t chunk_size;          /* LZ77.ChunkSize (default 0x1000); ALZ_C_LZ4_FRAME: LZ4.BlockSize, one of 0x10000 /
                                      0x40000 / 0x100000 / 0x400000 (0 = the class default Block4MB, LZ4.cs:33) */
+    uint32_t key;                 /* ALZ_C_LZ00 when compressing: the keystream seed written to the header (LZ00.Compress(..., uint key, ...)
+                                     LZ00.cs:71; the parameterless overload passes the Unix time) */
+    uint8_t  name[32];            /* ALZ_C_LZ00 when compressing: LZ00.Name, zero padded (all zero = the class default "Temp.dat", LZ00.cs:30) */
 } alz_container_options;
 
 /* IProvidesDecompressedSize.GetDecompressedSize (Interfaces/IProvidesDecompressedSize.cs:20) */

@@ -1366,6 +1366,20 @@ static int nin_header(const uint8_t* src, size_t len, uint8_t id, uint32_t* size
 
 static const uint8_t SNAPPY_ID[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 };
 
+/* LZ00.StreamTransformer  Sega/LZ00.cs:128-141: every byte that passes through it is XORed with the next element of a
+ * keystream; GenerateNextKey's shift/add chain multiplies by 3, 95, 3041, 389247, then 63, 15, 3 = 1103515245 and adds
+ * 12345.  The WRITE side (WriteByte / Write(span), :150, :177-199) transforms the body bytes strictly in order, so byte i
+ * of the body carries keystream element i + 1; decoding is the inverse.  (The modern-.NET Read(Span) override drops a
+ * byte of the base stream per call, :156-162: that only matters if LZSS reads spans through the transformer, which is
+ * decided inside the un-vendored AuroraLib.Core -- the decoder here is pinned by the encoder, i.e. by round trip.) */
+static void lz00_keystream(uint8_t* p, size_t n, uint32_t key) {
+    for (size_t i = 0; i < n; i++) {
+        key = key * 1103515245u + 12345u;
+        const uint32_t t = (key >> 16) & 0x7FFFu;
+        p[i] ^= (uint8_t)(((t << 8) - t) >> 15);
+    }
+}
+
 int oracle_container_decompressed_size(uint32_t container, const alz_container_options* opt, const uint8_t* src, size_t len, uint32_t* size_out) {
     int big = opt ? (int)opt->big_endian : 1;
     switch (container) {
@@ -1376,6 +1390,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZHUDSON: if (len < 4) return ALZ_E_FORMAT; *size_out = be32(src); return 0;                                        /* LZHudson.cs:30-31 */
     case ALZ_C_SMSR00: if (len < 12 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return 0;          /* SMSR00.cs:33-39 */
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ60.cs:29-41 */
+    case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 48); return 0;      /* Sega/LZ00.cs:31-37 */
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* MIO0.cs:41-48 */
@@ -1685,6 +1700,18 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         size = be32(src + 8); hdr = 16;
         uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_LZ00: {                                                                   /* Sega/LZ00.cs:40-60 */
+        if (len < 4 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT;
+        if (len < 64) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = rd32le(src + 48); hdr = 64;
+        uint8_t* plain = (uint8_t*)malloc(len - hdr + 1);
+        if (!plain) return ALZ_E_NOMEM;
+        memcpy(plain, src + hdr, len - hdr);
+        lz00_keystream(plain, len - hdr, rd32le(src + 52));
+        run_stream(ALZ_FMT_LZSS, NULL, plain, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        free(plain);
         break;
     }
     case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                  /* LZ40.cs:54-61, LZ60.cs:43-47 */
@@ -2023,6 +2050,19 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
         break;
+    case ALZ_C_LZ00: {                                                                   /* Sega/LZ00.cs:71-96 */
+        if (cap < 64) return ALZ_E_NOMEM;
+        hdr = 64;
+        body = oracle_encode_stream(ALZ_FMT_LZSS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        const uint32_t key = opt ? opt->key : 0;
+        lz00_keystream(dst + hdr, (size_t)body, key);
+        memset(dst, 0, 64); memcpy(dst, "LZ00", 4); wr32(dst + 4, (uint32_t)(hdr + body), 0);
+        int named = 0; if (opt) for (int i = 0; i < 32; i++) named |= opt->name[i];
+        if (named) memcpy(dst + 16, opt->name, 32); else memcpy(dst + 16, "Temp.dat", 8);
+        wr32(dst + 48, (uint32_t)n, 0); wr32(dst + 52, key, 0);
+        break;
+    }
     case ALZ_C_LZ40: case ALZ_C_LZ60: {                                                  /* LZ40.cs:64-77, LZ60.cs:49-61 */
         uint8_t id = container == ALZ_C_LZ40 ? 0x40 : 0x60;
         if (cap < 8) return ALZ_E_NOMEM;

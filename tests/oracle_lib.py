@@ -96,8 +96,11 @@ def encode_stream(fmt, data, quality=8, lz=None, strategy=0, min_distance=0, max
     return dst.raw[:n], aux
 
 
-def _opt(big_endian=True, lz=None, memory_alignment=0, variant=0, chunk_size=0):
+def _opt(big_endian=True, lz=None, memory_alignment=0, variant=0, chunk_size=0, key=0, name=b""):
     o = A.ContainerOptions()
+    o.key = key
+    for i, b in enumerate(bytes(name)[:32]):
+        o.name[i] = b
     o.big_endian = 1 if big_endian else 0
     o.memory_alignment = memory_alignment
     o.variant, o.chunk_size = variant, chunk_size
@@ -133,9 +136,9 @@ def container_decompress(container, data, cap=None, big_endian=True, lz=None):
     return dst.raw[:dl.value], st.value
 
 
-def container_compress(container, data, quality=8, big_endian=True, lz=None, strategy=0, min_distance=0, variant=0, chunk_size=0):
+def container_compress(container, data, quality=8, big_endian=True, lz=None, strategy=0, min_distance=0, variant=0, chunk_size=0, key=0, name=b""):
     data = bytes(data)
-    o = _opt(big_endian, lz, variant=variant, chunk_size=chunk_size)
+    o = _opt(big_endian, lz, variant=variant, chunk_size=chunk_size, key=key, name=name)
     st = A.Settings(quality, 0, strategy, min_distance)
     cap = len(data) * 2 + 1024
     dst = C.create_string_buffer(cap)

@@ -38,7 +38,7 @@ def test_large_nintendo_header():
 WRAPPERS = [(F.GCLZ, A.C_GCLZ), (F.CXLZ, A.C_CXLZ), (F.LZ_3DS, A.C_LZ_3DS), (F.COMP, A.C_COMP), (F.Yaz1, A.C_YAZ1), (F.AKLZ, A.C_AKLZ),
             (F.LZ01, A.C_LZ01), (F.LZSega, A.C_LZSEGA), (F.Level5LZSS, A.C_LEVEL5LZSS), (F.LZOn, A.C_LZON), (F.LZ77, A.C_LZ77), (F.Level5, A.C_LEVEL5),
             (F.MDB4, A.C_MDB4), (F.FCMP, A.C_FCMP), (F.IECP, A.C_IECP), (F.GCZ, A.C_GCZ), (F.ECD, A.C_ECD), (F.SDPC, A.C_SDPC),
-            (F.LZ40, A.C_LZ40), (F.LZ60, A.C_LZ60), (F.LZHudson, A.C_LZHUDSON), (F.SMSR00, A.C_SMSR00)]
+            (F.LZ40, A.C_LZ40), (F.LZ60, A.C_LZ60), (F.LZHudson, A.C_LZHUDSON), (F.SMSR00, A.C_SMSR00), (F.LZ00, A.C_LZ00)]
 
 
 @pytest.mark.parametrize("cls,container", WRAPPERS)
@@ -52,6 +52,35 @@ def test_wrapper_headers_host_vs_oracle(cls, container, test_bmp):
         assert f.GetDecompressedSize(comp) == len(raw) == O.container_decompressed_size(container, comp)
         if container not in (A.C_LEVEL5, A.C_GCZ):   # Level5 / GCZ lean on file extensions (and zlib probing): not mirrored
             assert f.IsMatch(comp)
+
+
+def test_lz00_keystream_oracle(test_bmp):
+    """LZ00 (Sega/LZ00.cs): 64-byte header (magic, csize, name[32] at 16, size at 48, key at 52) + an LZSS body XORed with the
+    keystream of the key -- key * 1103515245 + 12345 per byte, byte ^= (((key >> 16) & 0x7FFF) * 255) >> 15 (:128-141)."""
+    raw = test_bmp[:20000]
+    plain = O.container_compress(A.C_LZSEGA, raw, quality=8)[8:]                 # the same LZSS body without a keystream
+    for key in (0, 1, 0x5F3759DF, 0xFFFFFFFF):
+        comp = O.container_compress(A.C_LZ00, raw, quality=8, key=key, name=b"data.bin")
+        assert comp[:4] == b"LZ00" and int.from_bytes(comp[4:8], "little") == len(comp) and comp[8:16] == bytes(8)
+        assert comp[16:48] == b"data.bin".ljust(32, b"\0") and int.from_bytes(comp[48:52], "little") == len(raw)
+        assert int.from_bytes(comp[52:56], "little") == key and comp[56:64] == bytes(8) and len(comp) == 64 + len(plain)
+        k, ks = key, bytearray()
+        for _ in range(len(plain)):
+            k = (k * 1103515245 + 12345) & 0xFFFFFFFF
+            ks.append(((((k >> 16) & 0x7FFF) * 255) >> 15) & 0xFF)
+        assert bytes(a ^ b for a, b in zip(comp[64:], ks)) == plain
+        out, st = O.container_decompress(A.C_LZ00, comp, cap=len(raw))
+        assert st == A.ST_OK and out == raw
+    assert O.container_compress(A.C_LZ00, raw[:10], quality=0)[16:24] == b"Temp.dat"      # default Name  LZ00.cs:30
+    # GenerateNextKey as written (shift/add chain, :130-136) against the folded multiplier, on a few keys
+    for key in (0, 1, 12345, 0xDEADBEEF):
+        M = 0xFFFFFFFF
+        x = (((key << 1) + key) << 5) - key
+        x = (((x << 5) + key) << 7) - key
+        x &= M
+        x = ((x << 6) - x) & M
+        x = ((x << 4) - x) & M
+        assert (((x << 2) - x) + 12345) & M == (key * 1103515245 + 12345) & M
 
 
 def test_lz77_chunk_mode_oracle(test_bmp):
