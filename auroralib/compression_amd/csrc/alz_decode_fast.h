@@ -699,6 +699,40 @@ __device__ __forceinline__ void lane_walk4(const u32 (&nx)[4], u32 maxn, u64 (&m
     sp_out = sp; n_out = nseq;
 }
 
+// Walk of a chain of variable-size elements over a 256-byte window (4 x 64), second form: nx[w] holds, per lane, the size
+// of "the element that would start at byte 64 w + lane" (ALZ_NX_BAD: unusual element, stop in front of it).  Lane j of
+// `spos` receives the start offset of the j-th element (v_writelane takes one SGPR + M0, so the element counter lives in
+// M0); returns the offset of the first element not taken and the count.  The CU's single scalar unit is what bounds the
+// parsers, so the loop is cut to four scalar instructions per element: an unusual element has a size that leaves every
+// window (found and undone afterwards), and the element limit is checked once per window -- a window is entered while
+// fewer than `enter_below` elements have been taken (the caller knows how many one window can add).
+#define ALZ_NX_BAD 0x1000u
+__device__ __forceinline__ void lane_walk_pos(const u32 (&nx)[4], u32 enter_below, u32& spos_out, u32& sp_out, u32& n_out) {
+    u32 spos = 0, sp = 0, cnt = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (cnt < enter_below && sp < 64u * (u32)(w + 1)) {
+            u32 n;
+            asm volatile(
+                "s_mov_b32 m0, %[cnt]\n\t"
+                "s_nop 1\n"
+                "1:\n\t"
+                "v_readlane_b32 %[n], %[nx], %[sp]\n\t"
+                "v_writelane_b32 %[spos], %[sp], m0\n\t"
+                "s_add_u32 m0, m0, 1\n\t"
+                "s_add_u32 %[sp], %[sp], %[n]\n\t"
+                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                "s_mov_b32 %[cnt], m0\n\t"
+                : [n] "=&s"(n), [sp] "+s"(sp), [spos] "+v"(spos), [cnt] "+s"(cnt)
+                : [nx] "v"(nx[w]), [lim] "s"(64u * (u32)(w + 1))
+                : "scc", "m0");
+        }
+    }
+    if (sp >= ALZ_NX_BAD) { cnt -= 1u; sp = wave_readlane(spos, cnt); }     // the last element counted was an unusual one
+    spos_out = spos; sp_out = sp; n_out = cnt;
+}
+
 // Lane-parallel LZ4 parse.  Where a sequence starts can only be found by walking the chain of sequences, but what the
 // walk needs -- the size of "the sequence that would start at this byte" -- depends on that byte and at most two length
 // bytes, so every lane computes it for its own byte of a 256-byte window (4 x 64) and the walk itself is one v_readlane
@@ -711,42 +745,45 @@ template <class SK>
 __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane) {
     const u32 p = s.p;
     const u32 i0 = in.idx(p);
-    u32 tokb[4], runl[4], mlen[4], offp[4], nx[4];
+    // 1. speculation: only the SIZE of "the sequence that would start at my byte" (the fields of the real sequences are
+    //    decoded once, after the walk, by one lane per sequence)
+    u32 nx[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const u32 pos = i0 + 64u * (u32)w + (u32)lane;        // cache index of "my" byte
         const u32 b = in.lds[pos];
         const u32 e1 = in.lds[pos + 1];
         const u32 L0 = b >> 4, M0 = b & 15u;
-        const u32 L = L0 + (L0 == 15u ? e1 : 0u);
-        const u32 lp = pos + 1u + (L0 == 15u ? 1u : 0u);      // first literal
-        const u32 op = lp + L;                                // offset bytes
+        const u32 lx = L0 == 15u ? e1 + 1u : 0u;              // literal-length extension byte + its value
+        const u32 op = pos + 1u + L0 + lx;                    // offset bytes
         const u32 em = in.lds[(op + 2u) & 2047u];             // match length extension (if any); masked: garbage lanes may point anywhere
-        const u32 M = M0 + 4u + (M0 == 15u ? em : 0u);
         const bool bad = (L0 == 15u && e1 == 255u) || (M0 == 15u && em == 255u);
-        tokb[w] = lp; runl[w] = L; mlen[w] = M; offp[w] = op;
-        nx[w] = bad ? 0u : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
+        nx[w] = bad ? ALZ_NX_BAD : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
     }
-    u64 mask[4]; u32 sp, nseq;
-    lane_walk4(nx, 32u, mask, sp, nseq);
+    // 2. the walk; lane j receives the start offset of the j-th sequence (a window holds <= 22 sequences: lanes suffice)
+    u32 spos, sp, nseq;
+    lane_walk_pos(nx, 32u, spos, sp, nseq);
+    if (nseq > 32u) { nseq = 32u; sp = wave_readlane(spos, 32u); }
     if (nseq == 0u) return false;
-    // tokens: starting lanes write (literal run?, match) at their rank
-    u32 base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (mask[w]) {
-            const bool st = (mask[w] >> lane) & 1ull;
-            const u64 litm = __ballot(st && runl[w] != 0u);
-            const u32 rank = base + mbcnt64(mask[w]) + mbcnt64(litm);
-            if (st) {
-                const u32 dist = (u32)in.lds[offp[w]] | ((u32)in.lds[offp[w] + 1u] << 8);
-                u32 r = rank;
-                if (runl[w]) { stage[r] = ALZ_TOK_LIT(runl[w], tokb[w]); r++; }
-                stage[r] = ALZ_TOK_MATCH(mlen[w], dist ? dist : 65536u);      // E1
-            }
-            base += (u32)__popcll(mask[w]) + (u32)__popcll(litm);
-        }
+    // 3. one lane per sequence: fields, then (literal run?, match) into the queue order
+    const bool st = (u32)lane < nseq;
+    const u32 pos = i0 + spos;
+    const u32 b = in.lds[pos], e1 = in.lds[pos + 1];
+    const u32 L0 = b >> 4, M0 = b & 15u;
+    const u32 L = L0 + (L0 == 15u ? e1 : 0u);
+    const u32 lp = pos + 1u + (L0 == 15u ? 1u : 0u);
+    const u32 op = lp + L;
+    const u32 d0 = in.lds[op & 2047u], d1 = in.lds[(op + 1u) & 2047u], em = in.lds[(op + 2u) & 2047u];
+    const u32 M = M0 + 4u + (M0 == 15u ? em : 0u);
+    const u32 dist = d0 | (d1 << 8);
+    const u64 litm = __ballot(st && L != 0u);
+    const u32 rank = (u32)lane + mbcnt64(litm);
+    if (st) {
+        u32 r = rank;
+        if (L) { stage[r] = ALZ_TOK_LIT(L, lp); r++; }
+        stage[r] = ALZ_TOK_MATCH(M, dist ? dist : 65536u);          // E1
     }
+    const u32 base = nseq + (u32)__popcll(litm);
     wave_sync();
     const u32 qt = (u32)lane < base ? stage[lane] : 0u;
     wave_sync();
@@ -768,52 +805,49 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
 // above 700 bytes, 4-byte copies beyond the window) are left to the exact parser.
 template <class SK>
 __device__ __forceinline__ bool snappy_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32 limit) {
+    (void)stage;
     const u32 p = s.p;
     const u32 i0 = in.idx(p);
-    u32 tok[4], nx[4];
+    // 1. speculation: the size of "the element that would start at my byte"
+    u32 nx[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const u32 pos = i0 + 64u * (u32)w + (u32)lane;
-        const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2], e3 = in.lds[pos + 3], e4 = in.lds[pos + 4];
+        const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2];
         const u32 type = b & 3u, hi = b >> 2;
-        u32 n, t;
+        u32 n = type + 1u;                                              // copies with a 1- / 2-byte offset: 2 / 3 bytes
         if (type == 0u) {
-            u32 len, hdr;
-            if (hi < 60u) { len = hi + 1u; hdr = 1u; }
-            else if (hi == 60u) { len = e1 + 1u; hdr = 2u; }
-            else if (hi == 61u) { len = (e1 | (e2 << 8)) + 1u; hdr = 3u; }
-            else { len = 0xFFFFu; hdr = 0u; }
-            n = len > 700u ? 0u : hdr + len;                           // the run has to stay inside the resident input cache
-            t = ALZ_TOK_LIT(len & 0x3FFu, (pos + hdr) & 2047u);
-        } else if (type == 1u) {
-            const u32 d = ((b >> 5) << 8) | e1;
-            n = 2u; t = ALZ_TOK_MATCH((hi & 7u) + 4u, d ? d : 65536u);
-        } else if (type == 2u) {
-            const u32 d = e1 | (e2 << 8);
-            n = 3u; t = ALZ_TOK_MATCH(hi + 1u, d ? d : 65536u);
-        } else {
-            const u32 d = e1 | (e2 << 8) | (e3 << 16) | (e4 << 24);
-            n = d > 65536u ? 0u : 5u; t = ALZ_TOK_MATCH(hi + 1u, d ? (d & 0x1FFFFu) : 65536u);   // E3: beyond the window -> exact parser (BAD_TOKEN)
+            const u32 len = hi < 60u ? hi + 1u : (hi == 60u ? e1 + 1u : (e1 | (e2 << 8)) + 1u);
+            const u32 hdr = hi < 60u ? 1u : hi - 58u;
+            n = (hi > 61u || len > 700u) ? ALZ_NX_BAD : hdr + len;      // the run has to stay inside the resident input cache
         }
-        tok[w] = t; nx[w] = n;
+        if (type == 3u) n = ALZ_NX_BAD;                                 // 4-byte offsets (E3 check included) stay with the exact parser
+        nx[w] = n;
     }
-    u64 mask[4]; u32 sp, nel;
-    lane_walk4(nx, 64u, mask, sp, nel);
+    // 2. the walk: one token per element, lane j = j-th element (a window holds <= 32 elements)
+    u32 spos, sp, nel;
+    lane_walk_pos(nx, 33u, spos, sp, nel);
     if (nel == 0u) return false;
-    u32 base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (mask[w]) {
-            if ((mask[w] >> lane) & 1ull) stage[base + mbcnt64(mask[w])] = tok[w];
-            base += (u32)__popcll(mask[w]);
-        }
+    // 3. the elements' tokens
+    const u32 pos = i0 + spos;
+    const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2];
+    const u32 type = b & 3u, hi = b >> 2;
+    u32 t;
+    if (type == 0u) {
+        const u32 len = hi < 60u ? hi + 1u : (hi == 60u ? e1 + 1u : (e1 | (e2 << 8)) + 1u);
+        const u32 hdr = hi < 60u ? 1u : hi - 58u;
+        t = ALZ_TOK_LIT(len & 0x3FFu, (pos + hdr) & 2047u);
+    } else if (type == 1u) {
+        const u32 d = ((b >> 5) << 8) | e1;
+        t = ALZ_TOK_MATCH((hi & 7u) + 4u, d ? d : 65536u);
+    } else {
+        const u32 d = e1 | (e2 << 8);
+        t = ALZ_TOK_MATCH(hi + 1u, d ? d : 65536u);
     }
-    wave_sync();
-    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
-    wave_sync();
+    const u32 qt = (u32)lane < nel ? t : 0u;
     const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
     if (total > limit) return false;                           // size / capacity rules stay with the exact parser
-    sk.qtok = qt; sk.nt = base; sk.qbytes = total;
+    sk.qtok = qt; sk.nt = nel; sk.qbytes = total;
     s.p = p + sp;
     sk.flush();
     return true;
