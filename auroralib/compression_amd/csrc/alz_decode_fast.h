@@ -662,44 +662,7 @@ struct QueueSink {
     }
 };
 
-// Walk of a chain of variable-size elements over a 256-byte window (4 x 64): nx[w] holds, per lane, the size of "the
-// element that would start at byte 64 w + lane" (0 = stop here: unusual element).  Returns the element starts as one
-// 64-bit mask per window, the offset of the first element not taken, and the count (<= maxn).  Runs on the scalar unit,
-// hand-scheduled: ten instructions per element (the compiler's version of this loop spent ~25, mostly shuffling the mask
-// registers); the five instructions between the s_add and the next v_readlane cover the SALU-write -> lane-select hazard.
-__device__ __forceinline__ void lane_walk4(const u32 (&nx)[4], u32 maxn, u64 (&mask)[4], u32& sp_out, u32& n_out) {
-    mask[0] = mask[1] = mask[2] = mask[3] = 0ull;
-    u32 sp = 0, nseq = 0, stop = 0;
-    maxn = uni(maxn);
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (!stop && sp < 64u * (u32)(w + 1)) {
-            u32 n;
-            asm volatile(
-                "1:\n\t"
-                "v_readlane_b32 %[n], %[nx], %[sp]\n\t"
-                "s_cmp_eq_u32 %[n], 0\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_bitset1_b64 %[mask], %[sp]\n\t"
-                "s_add_u32 %[sp], %[sp], %[n]\n\t"
-                "s_add_u32 %[cnt], %[cnt], 1\n\t"
-                "s_cmp_ge_u32 %[cnt], %[maxn]\n\t"
-                "s_cbranch_scc1 2f\n\t"
-                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
-                "s_cbranch_scc1 1b\n\t"
-                "s_branch 3f\n"
-                "2:\n\t"
-                "s_mov_b32 %[stop], 1\n"
-                "3:\n\t"
-                : [n] "=&s"(n), [sp] "+s"(sp), [mask] "+s"(mask[w]), [cnt] "+s"(nseq), [stop] "+s"(stop)
-                : [nx] "v"(nx[w]), [lim] "s"(64u * (u32)(w + 1)), [maxn] "s"(maxn)
-                : "scc");
-        }
-    }
-    sp_out = sp; n_out = nseq;
-}
-
-// Walk of a chain of variable-size elements over a 256-byte window (4 x 64), second form: nx[w] holds, per lane, the size
+// Walk of a chain of variable-size elements over a 256-byte window (4 x 64): nx[w] holds, per lane, the size
 // of "the element that would start at byte 64 w + lane" (ALZ_NX_BAD: unusual element, stop in front of it).  Lane j of
 // `spos` receives the start offset of the j-th element (v_writelane takes one SGPR + M0, so the element counter lives in
 // M0); returns the offset of the first element not taken and the count.  The CU's single scalar unit is what bounds the
@@ -861,51 +824,44 @@ __device__ __forceinline__ bool snappy_lane_parse(InCache& in, SK& sk, DecState&
 // instruction.  Each instruction yields a match token plus, when its low two bits say so, a run of 1-3 trailing
 // literals.  Length extensions of more than one byte, the end marker and anything else unusual stop the walk.
 
-// walk over a 256-byte window: `pk` per lane = [8:0] size and [10:9] next state when entered in state A, [19:11] and
-// [21:20] the same for states B / C.  Outputs: instruction starts per window, and per window the starts that were
-// entered in state B resp. C.  state: 0 = A, 1 = B (1-3 literals pending), 2 = C (a literal run came before).
-__device__ __forceinline__ void lzo_walk4(const u32 (&pk)[4], u64 (&mask)[4], u64 (&mb)[4], u64 (&mc)[4], u32& sp_out, u32& n_out, u32& state_io) {
-    u32 sp = 0, cnt = 0, stop = 0, state = uni(state_io);
+// walk over a 256-byte window: `pk` per lane = [8:0] size (511: not an instruction the walk takes) and [10:9] next state
+// when entered in state A, [19:11] and [21:20] the same for states B / C.  state: 0 = A, 1 = B (1-3 literals pending),
+// 2 = C (a literal run came before).  Lane j of `spos` receives (start offset | entry state << 9) of the j-th
+// instruction; same loop discipline as lane_walk_pos (an instruction has >= 2 bytes: <= 32 per window).
+__device__ __forceinline__ void lzo_walk_pos(const u32 (&pk)[4], u32& spos_out, u32& sp_out, u32& n_out, u32& state_io) {
+    u32 spos = 0, sp = 0, cnt = 0, state = uni(state_io), n = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        mask[w] = 0ull; mb[w] = 0ull; mc[w] = 0ull;
-        if (!stop && sp < 64u * (u32)(w + 1)) {
-            u32 v, n, sh;
+        if (cnt < 32u && sp < 64u * (u32)(w + 1)) {
+            u32 v, sh, t;
             asm volatile(
+                "s_mov_b32 m0, %[cnt]\n\t"
+                "s_nop 1\n"
                 "1:\n\t"
                 "v_readlane_b32 %[v], %[pk], %[sp]\n\t"
                 "s_cmp_eq_u32 %[state], 0\n\t"
                 "s_cselect_b32 %[sh], 0, 11\n\t"
+                "s_lshl_b32 %[t], %[state], 9\n\t"
+                "s_or_b32 %[t], %[t], %[sp]\n\t"
                 "s_lshr_b32 %[v], %[v], %[sh]\n\t"
+                "v_writelane_b32 %[spos], %[t], m0\n\t"
                 "s_and_b32 %[n], %[v], 0x1ff\n\t"
-                "s_cbranch_scc0 2f\n\t"                         // size 0: not an instruction the walk takes
-                "s_bitset1_b64 %[mask], %[sp]\n\t"
-                "s_cmp_eq_u32 %[state], 1\n\t"
-                "s_cbranch_scc0 4f\n\t"
-                "s_bitset1_b64 %[mb], %[sp]\n"
-                "4:\n\t"
-                "s_cmp_eq_u32 %[state], 2\n\t"
-                "s_cbranch_scc0 5f\n\t"
-                "s_bitset1_b64 %[mc], %[sp]\n"
-                "5:\n\t"
                 "s_bfe_u32 %[state], %[v], 0x20009\n\t"         // bits [10:9]: the state the instruction leaves behind
+                "s_add_u32 m0, m0, 1\n\t"
                 "s_add_u32 %[sp], %[sp], %[n]\n\t"
-                "s_add_u32 %[cnt], %[cnt], 1\n\t"
-                "s_cmp_ge_u32 %[cnt], 32\n\t"
-                "s_cbranch_scc1 2f\n\t"
                 "s_cmp_lt_u32 %[sp], %[lim]\n\t"
                 "s_cbranch_scc1 1b\n\t"
-                "s_branch 3f\n"
-                "2:\n\t"
-                "s_mov_b32 %[stop], 1\n"
-                "3:\n\t"
-                : [v] "=&s"(v), [n] "=&s"(n), [sh] "=&s"(sh), [sp] "+s"(sp), [mask] "+s"(mask[w]), [mb] "+s"(mb[w]), [mc] "+s"(mc[w]),
-                  [cnt] "+s"(cnt), [stop] "+s"(stop), [state] "+s"(state)
+                "s_mov_b32 %[cnt], m0\n\t"
+                : [v] "=&s"(v), [n] "+s"(n), [sh] "=&s"(sh), [t] "=&s"(t), [sp] "+s"(sp), [spos] "+v"(spos), [cnt] "+s"(cnt), [state] "+s"(state)
                 : [pk] "v"(pk[w]), [lim] "s"(64u * (u32)(w + 1))
-                : "scc");
+                : "scc", "m0");
         }
     }
-    sp_out = sp; n_out = cnt; state_io = state;
+    bool undo = n == 511u;                                       // the last instruction counted was one the walk does not take
+    if (undo) cnt -= 1u;
+    if (cnt > 32u) { cnt = 32u; undo = true; }
+    if (undo) { const u32 v = wave_readlane(spos, cnt); sp = v & 0x1FFu; state = v >> 9; }   // resume in front of the first one not taken
+    spos_out = spos; sp_out = sp; n_out = cnt; state_io = state;
 }
 
 // "the instruction that would start at cache index pos": sizes / next states for the walk (TOK = false) or the tokens of
@@ -929,7 +885,7 @@ __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 sta
         } else if (f < 128u) { len = 3u + ((f >> 5) & 1u); dist = (e1 << 3) + ((f >> 2) & 7u) + 1u; t = f & 3u; size = 2u + t; }
         else { len = 5u + ((f >> 5) & 3u); dist = (e1 << 3) + ((f & 0x1cu) >> 2) + 1u; t = f & 3u; size = 2u + t; }
         if (TOK) { if (t) second = ALZ_TOK_LIT(t, (pos + size - t) & 2047u); return ALZ_TOK_MATCH(len, dist); }
-        const u32 sz = bad ? 0u : size, nx = t ? 1u : 0u;
+        const u32 sz = bad ? 511u : size, nx = t ? 1u : 0u;
         return sz | (nx << 9) | (sz << 11) | (nx << 20);
     }
     const bool ext = f == 0u;                                    // state A: literal run  LZO.cs:75-85
@@ -940,7 +896,7 @@ __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 sta
         if (t) second = ALZ_TOK_LIT(t, (pos + 2u) & 2047u);
         return state == 1u ? ALZ_TOK_MATCH(2u, (e1 << 2) + (f >> 2) + 1u) : ALZ_TOK_MATCH(3u, (e1 << 2) + (f >> 2) + 2049u);
     }
-    const u32 sizeA = (ext && e1 == 0u) ? 0u : (ext ? 2u : 1u) + len;
+    const u32 sizeA = (ext && e1 == 0u) ? 511u : (ext ? 2u : 1u) + len;
     return sizeA | (2u << 9) | ((2u + t) << 11) | ((t ? 1u : 0u) << 20);
 }
 
@@ -952,25 +908,19 @@ __device__ __forceinline__ bool lzo_lane_parse(InCache& in, SK& sk, DecState& s,
     u32 pk[4], dummy;
 #pragma unroll
     for (int w = 0; w < 4; w++) pk[w] = lzo_interpret<false>(in, i0 + 64u * (u32)w + (u32)lane, 0u, dummy);
-    u64 mask[4], mb[4], mc[4]; u32 sp, ninstr;
+    u32 spos, sp, ninstr;
     u32 state = ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u);
-    lzo_walk4(pk, mask, mb, mc, sp, ninstr, state);
+    lzo_walk_pos(pk, spos, sp, ninstr, state);
     if (ninstr == 0u) return false;
-    u32 base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        if (mask[w]) {                                           // tokens only where the walk found instructions, in the state it found them
-            const bool st = (mask[w] >> lane) & 1ull;
-            const u32 est = ((mb[w] >> lane) & 1ull) ? 1u : (((mc[w] >> lane) & 1ull) ? 2u : 0u);
-            u32 tl;
-            const u32 first = lzo_interpret<true>(in, i0 + 64u * (u32)w + (u32)lane, est, tl);
-            const bool second = st && tl != 0u;
-            const u64 sm = __ballot(second);
-            const u32 rank = base + mbcnt64(mask[w]) + mbcnt64(sm);
-            if (st) { stage[rank] = first; if (second) stage[rank + 1u] = tl; }
-            base += (u32)__popcll(mask[w]) + (u32)__popcll(sm);
-        }
-    }
+    // one lane per instruction, in the state the walk entered it: match / run token + trailing-literal token
+    const bool st = (u32)lane < ninstr;
+    u32 tl;
+    const u32 first = lzo_interpret<true>(in, i0 + (spos & 0x1FFu), spos >> 9, tl);
+    const bool second = st && tl != 0u;
+    const u64 sm = __ballot(second);
+    const u32 rank = (u32)lane + mbcnt64(sm);
+    if (st) { stage[rank] = first; if (second) stage[rank + 1u] = tl; }
+    const u32 base = ninstr + (u32)__popcll(sm);
     wave_sync();
     const u32 qt = (u32)lane < base ? stage[lane] : 0u;
     wave_sync();
