@@ -214,9 +214,18 @@ __device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds
 // iteration's base).  For LZSS the descriptor holds the ring OFFSET and is turned into a distance here, once the
 // token's output position is known (LzWindows.OffsetCopy  IO/LzWindows.cs:108-115).
 // Returns true when the stream is finished (declared size reached, or capacity hit).
+//
+// The state of one batch of tokens between its phases.  Configurations with HBM read-back run in two halves --
+// emit_begin (token prologue, byte -> token map of the first ALZ_NB steps, ALL their read-backs issued) and emit_finish
+// (the copies) -- so that a caller can do independent work (parse the next batch) while the read-backs are in flight.
+struct EmitState {
+    u32 desc, relm, qs, tbase4, T, X, O, W, nb, nsteps;
+    u32 dsc[ALZ_NB], far[ALZ_NB];
+    bool fin;
+};
+
 template <class OW, class CFG>
-__device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark,
-                                          const u8* inlds, int lane, u32& last_tend, u32 W) {
+__device__ __forceinline__ void emit_prologue(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, int lane, u32& last_tend, u32 W, EmitState& e) {
     u32 end = wave_incl_scan(valid ? len : 0u, lane);
     u32 off = end - len;
     const u32 O = out.produced;
@@ -249,61 +258,77 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
             desc = ALZ_DESC_MATCH(d);
         }
     }
-    // ---- byte phase: 64 output bytes per step, one per lane
-    u32 tbase4 = 0;                                          // 4 x (tokens that ended before the current step)
-    u32 relm = keep ? end - 1u : 0xFFFFFF00u;                // my token's LAST byte relative to the current step (huge: none)
-    u32 qs = O + (u32)lane + out.oshift;                     // slot coordinate of this lane's byte in the current step
-    u32 X = 0;
-    if constexpr (CFG::FALLBACK) {
-        // Sources older than the LDS window come back from HBM (1-2 us each).  They are independent of everything this
-        // batch produces, so the step is split: pass 1 maps bytes to tokens for up to 16 steps and issues ALL their
-        // read-backs at once, pass 2 copies.  (For LDS-only configs this split costs more instructions than it saves.)
-        constexpr int NB = ALZ_NB;
-        while (X < T) {
-            const u32 nb = T - X < 64u * NB ? T - X : 64u * NB;
-            const u32 nsteps = (nb + 63u) >> 6;
-            u32 dsc[NB], far[NB];
+    e.desc = desc; e.O = O; e.T = T; e.X = 0; e.W = W; e.fin = fin;
+    e.tbase4 = 0;                                            // 4 x (tokens that ended before the current step)
+    e.relm = keep ? end - 1u : 0xFFFFFF00u;                  // my token's LAST byte relative to the current step (huge: none)
+    e.qs = O + (u32)lane + out.oshift;                       // slot coordinate of this lane's byte in the current step
+}
+
+// Sources older than the LDS window come back from HBM (1-2 us each).  They are independent of everything the batch
+// produces, so the byte phase is split: emit_map maps bytes to tokens for up to ALZ_NB steps and issues ALL their
+// read-backs at once, emit_copy moves the bytes.  (For LDS-only configs this split costs more instructions than it saves.)
+template <class OW, class CFG>
+__device__ __forceinline__ void emit_map(OW& out, u8* segmark, int lane, EmitState& e) {
+    constexpr int NB = ALZ_NB;
+    e.nb = e.T - e.X < 64u * NB ? e.T - e.X : 64u * NB;
+    e.nsteps = (e.nb + 63u) >> 6;
 #pragma unroll
-            for (int k = 0; k < NB; k++) {
-                dsc[k] = 0x80000000u; far[k] = 0;
-                if ((u32)k < nsteps) {
-                    dsc[k] = map_step(segmark, lane, desc, relm, tbase4);
-                    const u32 q = qs + 64u * (u32)k - out.oshift;
-                    const u32 d = dsc[k];
-                    if ((int)d >= 0 && d > out.lw_mask + 1u - 64u && d <= q)
-                        far[k] = 0x100u | (u32)__hip_atomic_load(out.dst + (q - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-                if ((u32)k < nsteps) {
-                    const u32 nseg = nb - 64u * (u32)k;
-                    copy_step<OW, CFG>(out, inlds, lane, dsc[k], far[k], qs, nseg < 64u ? nseg : 64u, O + X < W);
-                    X += nseg < 64u ? nseg : 64u; out.produced = O + X;
-                    if (out.produced - out.flushed >= out.fl) out.flush_blocks();
-                }
-            }
+    for (int k = 0; k < NB; k++) {
+        e.dsc[k] = 0x80000000u; e.far[k] = 0;
+        if ((u32)k < e.nsteps) {
+            e.dsc[k] = map_step(segmark, lane, e.desc, e.relm, e.tbase4);
+            const u32 q = e.qs + 64u * (u32)k - out.oshift;
+            const u32 d = e.dsc[k];
+            if ((int)d >= 0 && d > out.lw_mask + 1u - 64u && d <= q)
+                e.far[k] = 0x100u | (u32)__hip_atomic_load(out.dst + (q - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+template <class OW, class CFG>
+__device__ __forceinline__ void emit_copy(OW& out, const u8* inlds, int lane, EmitState& e) {
+    constexpr int NB = ALZ_NB;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        if ((u32)k < e.nsteps) {
+            const u32 nseg = e.nb - 64u * (u32)k;
+            copy_step<OW, CFG>(out, inlds, lane, e.dsc[k], e.far[k], e.qs, nseg < 64u ? nseg : 64u, e.O + e.X < e.W);
+            e.X += nseg < 64u ? nseg : 64u; out.produced = e.O + e.X;
+            if (out.produced - out.flushed >= out.fl) out.flush_blocks();
+        }
+    }
+}
+template <class OW, class CFG>
+__device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark, int lane, u32& last_tend, u32 W, EmitState& e) {
+    emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
+    e.nsteps = 0;
+    if (e.X < e.T) emit_map<OW, CFG>(out, segmark, lane, e);
+}
+template <class OW, class CFG>
+__device__ __forceinline__ void emit_finish(OW& out, u8* segmark, const u8* inlds, int lane, EmitState& e) {
+    if (e.nsteps) emit_copy<OW, CFG>(out, inlds, lane, e);
+    while (e.X < e.T) { emit_map<OW, CFG>(out, segmark, lane, e); emit_copy<OW, CFG>(out, inlds, lane, e); }
+}
+
+template <class OW, class CFG>
+__device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark,
+                                          const u8* inlds, int lane, u32& last_tend, u32 W) {
+    if constexpr (CFG::FALLBACK) {
+        EmitState e;
+        emit_begin<OW, CFG>(out, s, size, valid, len, desc, tend, segmark, lane, last_tend, W, e);
+        emit_finish<OW, CFG>(out, segmark, inlds, lane, e);
+        return e.fin;
     } else {
+        EmitState e;
+        emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
+        desc = e.desc;
+        const u32 O = e.O, T = e.T;
+        u32 X = 0, relm = e.relm, qs = e.qs, tbase4 = 0;
+        const bool fin = e.fin;
         // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
         while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
         // steady state: flush checks only where the output crosses a flush-block boundary (the loop in between is a bare
         // counter: the kernel is bound by instruction issue per wave, scalar instructions included)
         u32 nleft = (T - X) >> 6;
-#ifndef ALZ_EXP
-#define ALZ_EXP 0
-#endif
-#if ALZ_EXP == 1
-        while (nleft) {
-            const u32 pos = O + X + out.oshift;
-            u32 nb = (out.fl - (pos & (out.fl - 1u)) + 63u) >> 6;
-            if (nb > nleft) nb = nleft;
-            for (u32 k = nb; k; k--) byte_step<OW, CFG, false, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u);
-            X += 64u * nb; nleft -= nb; out.produced = O + X;
-            if (out.produced - out.flushed >= out.fl) out.flush_blocks();
-        }
-        if (X < T) { byte_step<OW, CFG, true, false>(out, segmark, inlds, lane, desc, relm, qs, tbase4, T - X); out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-#else
         u32 dsc = 0; bool have = false;
         if (nleft) {
             dsc = map_step(segmark, lane, desc, relm, tbase4); have = true;      // pipeline prologue: descriptors of the first step
@@ -326,9 +351,8 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
             copy_step<OW, CFG>(out, inlds, lane, dsc, 0u, qs, T - X, true);
             out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks();
         }
-#endif
+        return fin;
     }
-    return fin;
 }
 
 template <int FMT> struct FamTraits;
@@ -704,9 +728,9 @@ __device__ __forceinline__ void lane_walk_pos(const u32 (&nx)[4], u32 enter_belo
 // Sequences with a second length-extension byte (run >= 270 / match >= 274 bytes) stop the walk and are left to the
 // exact parser.  Preconditions: queue empty, >= 1100 input bytes ahead of s.p, cache covers [p, p + 1024).
 // Returns false when nothing was parsed (first sequence unusual, or the batch would not fit the output capacity).
-template <class SK>
-__device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane) {
-    const u32 p = s.p;
+// One round: tokens of up to 32 sequences starting at input offset p -> qt (one per lane, nt of them), the bytes they
+// produce and the input bytes they cover.  Touches the input cache and `stage` only.
+__device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
     // 1. speculation: only the SIZE of "the sequence that would start at my byte" (the fields of the real sequences are
     //    decoded once, after the walk, by one lane per sequence)
@@ -750,26 +774,55 @@ __device__ __forceinline__ bool lz4_lane_parse(InCache& in, SK& sk, DecState& s,
     wave_sync();
     const u32 qt = (u32)lane < base ? stage[lane] : 0u;
     wave_sync();
-    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
-    if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
-    sk.qtok = qt; sk.nt = base; sk.qbytes = total;
-    s.p = p + sp;
-#if defined(ALZ_QEXP) && ALZ_QEXP == 1
-    sk.out.produced += total; sk.nt = 0; sk.qbytes = 0; if (qt == 0x12345u) stage[lane] = qt;   // timing experiment: parse only
-#else
-    sk.flush();
-#endif
+    qt_out = qt; nt_out = base; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
     return true;
 }
 
+// Rounds of a lane-parallel parser executed through the byte phase, software-pipelined: the read-backs of round k (sources
+// older than the LDS window, 1-2 us from HBM) are issued by emit_begin, round k + 1 is parsed while they are in flight,
+// then emit_finish copies round k.  Parsing needs the input cache only -- which must not move while literal runs of round
+// k still point into it, so the pipeline drains whenever the cache has to slide.  `parse(p, qt, nt, total, adv)` yields the
+// tokens of one round starting at input offset p (false: nothing parsed) and `commit()` accepts it (parser state).
+// A round is only taken while its output stays below `maxout` (capacity / declared size: those rules stay with the exact
+// parser).  Preconditions: queue empty, >= 1100 input bytes ahead of s.p, cache covers [s.p, s.p + 1024).
+template <class OW, class CFG, class PARSE>
+__device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState& s, u32 src_len, u8* segmark, const u8* inlds, int lane,
+                                                 u32 W, u32 maxout, PARSE& parse) {
+    u32 qt, nt, total, adv;
+    if (!parse(s.p, qt, nt, total, adv)) return false;
+    if (total > maxout - out.produced) return false;
+    for (;;) {
+        parse.commit();
+        s.p += adv;
+        EmitState e; u32 last;
+        const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
+        const u32 desc = (qt & 0x20000u) ? (0x80000000u | lo) : lo;
+        emit_begin<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, lane, last, W, e);
+        bool more = false;
+        u32 qt2 = 0, nt2 = 0, total2 = 0, adv2 = 0;
+        const u32 p = s.p;
+        if ((u64)p + 1100u <= src_len && !(p + in.lo + 1024u > in.cb + 2048u)) {       // next round: input ahead, cache already covers it
+            more = parse(p, qt2, nt2, total2, adv2);
+            if (more && total2 > maxout - (e.O + e.T)) more = false;
+        }
+        emit_finish<OW, CFG>(out, segmark, inlds, lane, e);
+        if (!more) break;
+        qt = qt2; nt = nt2; total = total2; adv = adv2;
+    }
+    return true;
+}
+
+struct Lz4Rounds {
+    InCache& in; u32* stage; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return lz4_parse_round(in, p, stage, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
 // Lane-parallel Snappy parse (Snappy.cs:205-250): an element's size depends on its tag byte and, for literals of 61+
 // bytes, on one or two length bytes -- the same per-byte speculation + scalar walk as LZ4, one token per element.
-// `limit` = bytes the batch may still produce (declared size and capacity).  Elements the walk does not take (literals
-// above 700 bytes, 4-byte copies beyond the window) are left to the exact parser.
-template <class SK>
-__device__ __forceinline__ bool snappy_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32 limit) {
-    (void)stage;
-    const u32 p = s.p;
+// Elements the walk does not take (literals above 700 bytes, copies with 4-byte offsets) are left to the exact parser.
+__device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
     // 1. speculation: the size of "the element that would start at my byte"
     u32 nx[4];
@@ -808,13 +861,15 @@ __device__ __forceinline__ bool snappy_lane_parse(InCache& in, SK& sk, DecState&
         t = ALZ_TOK_MATCH(hi + 1u, d ? d : 65536u);
     }
     const u32 qt = (u32)lane < nel ? t : 0u;
-    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
-    if (total > limit) return false;                           // size / capacity rules stay with the exact parser
-    sk.qtok = qt; sk.nt = nel; sk.qbytes = total;
-    s.p = p + sp;
-    sk.flush();
+    qt_out = qt; nt_out = nel; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
     return true;
 }
+struct SnappyRounds {
+    InCache& in; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return snappy_parse_round(in, p, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // Lane-parallel LZO1X parse (LZO.cs:49-139).  What an instruction is depends on its first byte and, for the opcodes
@@ -901,15 +956,13 @@ __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 sta
 }
 
 // Preconditions: queue empty, >= 1100 input bytes ahead of s.p (an instruction boundary), cache covers [p, p + 1024).
-template <class SK>
-__device__ __forceinline__ bool lzo_lane_parse(InCache& in, SK& sk, DecState& s, LzoState& ls, u32* stage, int lane) {
-    const u32 p = s.p;
+// `state` (0 = A, 1 = B, 2 = C) is the walk's state in front of the round on entry, behind it on return.
+__device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& state, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
     u32 pk[4], dummy;
 #pragma unroll
     for (int w = 0; w < 4; w++) pk[w] = lzo_interpret<false>(in, i0 + 64u * (u32)w + (u32)lane, 0u, dummy);
     u32 spos, sp, ninstr;
-    u32 state = ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u);
     lzo_walk_pos(pk, spos, sp, ninstr, state);
     if (ninstr == 0u) return false;
     // one lane per instruction, in the state the walk entered it: match / run token + trailing-literal token
@@ -924,14 +977,18 @@ __device__ __forceinline__ bool lzo_lane_parse(InCache& in, SK& sk, DecState& s,
     wave_sync();
     const u32 qt = (u32)lane < base ? stage[lane] : 0u;
     wave_sync();
-    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
-    if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
-    sk.qtok = qt; sk.nt = base; sk.qbytes = total;
-    s.p = p + sp;
-    ls.plain = state == 0u ? 0u : (state == 1u ? 1u : 4u);
-    sk.flush();
+    qt_out = qt; nt_out = base; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
     return true;
 }
+struct LzoRounds {
+    InCache& in; u32* stage; int lane; u32 state, pending;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) {
+        pending = state;
+        return lzo_parse_round(in, p, stage, lane, pending, qt, nt, total, adv);
+    }
+    __device__ __forceinline__ void commit() { state = pending; }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // PRS: control bits and data bytes interleave, and a flag byte is fetched at the moment a bit is needed -- possibly in the

@@ -320,7 +320,7 @@ struct LzoState { u32 plain; bool started; };
 __device__ __forceinline__ void lzo_state_init(LzoState& ls) { ls.plain = 0; ls.started = false; }
 
 template <class SK>
-__device__ void dec_lzo_serial(InCache& in, SK& sk, DecState& s, u32 src_len, LzoState& ls, u32 max_instr = 0xFFFFFFFFu) {
+__device__ __forceinline__ void dec_lzo_serial(InCache& in, SK& sk, DecState& s, u32 src_len, LzoState& ls, u32 max_instr = 0xFFFFFFFFu) {
     // residency is established once per instruction (16 bytes cover every fixed-size header); only the unbounded
     // length-extension loop asks again -- one ensure() per byte made this parser 50 KB of code under QueueSink
 #define LZO_BYTE(dst) do { if (s.p >= src_len) { s.eof = true; return; } dst = in.peek1(s.p); s.p++; } while (0)

@@ -261,7 +261,8 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             if (s.p + 1100u <= src_len) {
                 sk.ensure(in, s.p, 1024);                        // cache covers [p, p + 1024); flushes the queue if it has to move
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
-                if (lz4_lane_parse(in, sk, s, stage, lane)) { if (s.ovf) break; continue; }
+                Lz4Rounds rounds{in, stage, lane};
+                if (pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, cap, rounds)) { if (s.ovf) break; continue; }
             }
             const bool tail = s.p + 1100u > src_len;
             dec_lz4_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
@@ -274,7 +275,12 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             if (ls.started && s.p + 1100u <= src_len) {
                 sk.ensure(in, s.p, 1024);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
-                if (lzo_lane_parse(in, sk, s, ls, stage, lane)) { if (s.ovf) break; continue; }
+                LzoRounds rounds{in, stage, lane, ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u), 0u};
+                if (pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, cap, rounds)) {
+                    ls.plain = rounds.state == 0u ? 0u : (rounds.state == 1u ? 1u : 4u);
+                    if (s.ovf) break;
+                    continue;
+                }
             }
             const bool tail = s.p + 1100u > src_len;
             dec_lzo_serial(in, sk, s, src_len, ls, tail ? 0xFFFFFFFFu : 1u);
@@ -289,8 +295,8 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
                 sk.ensure(in, s.p, 1024);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 if (out.produced >= size) break;
-                const u32 lim = (size < cap ? size : cap) - out.produced;
-                if (out.produced < cap && snappy_lane_parse(in, sk, s, stage, lane, lim)) { if (s.ovf) break; continue; }
+                SnappyRounds rounds{in, lane};
+                if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
             }
             const bool tail = s.p + 1100u > src_len;
             dec_snappy_serial(in, sk, s, src_len, size, have, tail ? 0xFFFFFFFFu : 1u);
