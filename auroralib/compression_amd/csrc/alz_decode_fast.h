@@ -666,7 +666,13 @@ struct QueueSink {
         if (nt == 64u || qbytes >= 0x40000000u) flush();
         return !s.ovf;
     }
-    __device__ __forceinline__ bool lit(u32 b) { return push(ALZ_TOK_LIT(1u, b & 0xFFu), 1u); }
+    __device__ __forceinline__ bool lit(u32 b) {
+        if (produced() >= out.cap) {                                             // E5 at its exact place in the stream (the parser must not run on)
+            flush(); if (s.ovf) return false;
+            (void)clip_token(out, s, 1u); return false;
+        }
+        return push(ALZ_TOK_LIT(1u, b & 0xFFu), 1u);
+    }
     __device__ __forceinline__ bool match(u32 dist, u64 len, u32 w) {
         if (len == 0) return true;
         if (len > ALZ_TOK_MAXLEN || (u64)produced() + len > (u64)out.cap) {       // rare: long token / exact E5 handling on the serial path

@@ -29,6 +29,11 @@ def handcrafted_items():
     # LZO: first byte > 17 literal run then end marker; and empty input
     items.append(dict(fmt=A.FMT_LZO, src=bytes([17 + 5, 1, 2, 3, 4, 5, 0x11, 0, 0]), decom_len=0, cap=64))
     items.append(dict(fmt=A.FMT_LZO, src=b"", decom_len=0, cap=64))
+    # PRS: the destination fills up (E5) in front of the place where the input ends -- the capacity error comes first
+    # in stream order, although a queueing parser only notices it when the queue is executed
+    for f in (A.FMT_PRS_BE, A.FMT_PRS_LE):
+        for cap in (0, 1, 4, 8, 9):
+            items.append(dict(fmt=f, src=bytes([0xFF]) + b"ABCDEFGH" + bytes([0xFF]) + b"IJK", decom_len=0, cap=cap))
     for f in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_MIO0, A.FMT_YAY0):
         items.append(dict(fmt=f, src=b"", decom_len=0, cap=0))
         items.append(dict(fmt=f, src=b"", decom_len=10, cap=10))
