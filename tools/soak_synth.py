@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""usage (GPU box): python tools/soak_synth.py [first_seed] [count]
+Differential soak: synthetic batches of every format under other seeds and ragged sizes, and oracle-encoded windows of
+Test.bmp at every quality, GPU (production kernels) against the oracle.  Not part of the test suite (minutes)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from auroralib.compression_amd import _abi as A  # noqa: E402
+from auroralib.compression_amd import synth  # noqa: E402
+from gpu_common import compare_batch, pack_streams  # noqa: E402
+
+
+def main():
+    s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 777
+    cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    lz = open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read()
+    bmp, st = O.container_decompress(A.C_LZSS, lz, lz=A.LzProperties.from_bits(10, 6, 2))
+    assert st == 0
+    bad = 0
+    for k in range(cnt):
+        seed = s0 + 7919 * k
+        rng = np.random.default_rng(seed)
+        for fmt in range(A.FMT_COUNT):
+            try:
+                sizes = rng.integers(1, 200000, size=48).astype(np.uint32)
+                b = synth.make_batch(fmt, len(sizes), sizes, seed * 100 + fmt)
+                compare_batch(b.streams, b.src, b.dst_bytes, what="synth %s seed %d" % (A.FORMAT_NAMES[fmt], seed))
+                items = []
+                for _ in range(6):
+                    off = int(rng.integers(0, len(bmp) - 300000)); size = int(rng.integers(1, 300000)); q = int(rng.integers(0, 16))
+                    raw = bmp[off:off + size]
+                    comp, aux = O.encode_stream(fmt, raw, quality=q)
+                    items.append(dict(fmt=fmt, src=comp, decom_len=len(raw), aux0=aux.aux0, aux1=aux.aux1))
+                streams, src, dst_bytes = pack_streams(items)
+                gr, _ = compare_batch(streams, src, dst_bytes, what="real %s seed %d" % (A.FORMAT_NAMES[fmt], seed))
+                assert (gr["status"] == 0).all()
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH", e)
+        print("seed", seed, "done", flush=True)
+    print("soak finished:", bad, "mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
