@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from auroralib.compression_amd import _abi as A  # noqa: E402
 from auroralib.compression_amd import synth  # noqa: E402
-from gpu_common import compare_batch, pack_streams  # noqa: E402
+from gpu_common import compare_batch, ctx, pack_streams  # noqa: E402
 
 
 def main():
@@ -40,6 +40,33 @@ def main():
                 streams, src, dst_bytes = pack_streams(items)
                 gr, _ = compare_batch(streams, src, dst_bytes, what="real %s seed %d" % (A.FORMAT_NAMES[fmt], seed))
                 assert (gr["status"] == 0).all()
+                # encoder: windows (some degenerate) as one batch at one quality, bytes + aux against the oracle's encoder
+                q = int(rng.integers(0, 16))
+                raws = []
+                for j in range(8):
+                    off = int(rng.integers(0, len(bmp) - 150000)); size = int(rng.integers(1, 150000))
+                    r = bmp[off:off + size]
+                    if j == 6: r = bytes([int(rng.integers(0, 256))]) * size
+                    if j == 7: r = (bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8)) * (size // 2 + 1))[:size]
+                    if fmt == A.FMT_LZ4_BLOCK and len(r) < 5: r = r + bytes(5)
+                    raws.append(r)
+                n = len(raws)
+                es = (A.Stream * n)()
+                so = do = 0
+                for i, r in enumerate(raws):
+                    cap = len(r) + len(r) // 4 + 64
+                    es[i] = A.Stream(so, do, len(r), cap, 0, 0, 0, fmt)
+                    so += (len(r) + 15) // 16 * 16; do += (cap + 255) // 256 * 256
+                buf = np.zeros(so + 64, dtype=np.uint8)
+                for i, r in enumerate(raws):
+                    buf[int(es[i].src_off):int(es[i].src_off) + len(r)] = np.frombuffer(r, dtype=np.uint8)
+                dst, res, aux = ctx().encode_batch(es, buf, do + 64, quality=q)
+                auxv = np.frombuffer(aux, dtype=np.uint32).reshape(n, 2)
+                for i, r in enumerate(raws):
+                    comp, a = O.encode_stream(fmt, r, quality=q)
+                    got = bytes(dst[int(es[i].dst_off):int(es[i].dst_off) + int(res[i].dst_len)])
+                    assert res[i].status == 0 and got == comp and (int(auxv[i, 0]), int(auxv[i, 1])) == (a.aux0, a.aux1), \
+                        "encode %s seed %d q%d stream %d len %d: gpu %d bytes, oracle %d" % (A.FORMAT_NAMES[fmt], seed, q, i, len(r), res[i].dst_len, len(comp))
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH", e)
