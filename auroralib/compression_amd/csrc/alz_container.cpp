@@ -434,6 +434,35 @@ int snappy_file_compress(alz_ctx* ctx, const alz_settings* st, const uint8_t* sr
 
 }  // namespace
 
+// FastLZ.Validate  FastLZ.cs:246-291 (sic: only streams whose first byte is below 0x20, i.e. level 1, pass)
+static bool fastlz_validate(const uint8_t* s, size_t n) {
+    size_t pos = 0;
+    int ctrl = pos < n ? s[pos++] : -1;
+    const int level = (ctrl >> 5) + 1;
+    if (level != 0 && level != 1) return false;
+    int i = 3; long buffer = 0;
+    while (ctrl != -1) {
+        if (ctrl >= 32) {
+            int length = (ctrl >> 5) - 1, distance = (ctrl & 31) << 8;
+            if (length == 6) length += pos < n ? s[pos++] : -1;
+            ctrl = pos < n ? s[pos++] : -1;
+            distance |= ctrl;
+            if (ctrl == -1 || length < 0) return false;             // end of stream
+            if (distance + 1 > buffer) return false;                // reaches before the start of the window
+            if (i-- == 0) return true;
+            buffer += length + 3;
+        } else {
+            ctrl++;
+            buffer += ctrl;
+            if (pos + (size_t)ctrl > n) return false;
+            pos += (size_t)ctrl;
+        }
+        if (pos >= n) return i < 3;
+        ctrl = s[pos++];
+    }
+    return false;
+}
+
 // LZ00.StreamTransformer  LZ00.cs:128-141: body byte i is XORed with element i + 1 of the keystream of `key`.
 // GenerateNextKey's shift/add chain is key * 1103515245 + 12345 (3 -> 95 -> 3041 -> 389247, then x 63 x 15 x 3).  A header-level
 // transform like the frame checksums: it runs on the host, on the compressed bytes, before / after the body kernels.
@@ -536,6 +565,7 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_LZHUDSON: return len > 0x8 && le32(src) != 0;                                // (+ the file extension when one is given)  LZHudson.cs:27-28
     case ALZ_C_SMSR00: return len > 0x10 && !memcmp(src, "SMSR00", 6);                      // SMSR00.cs:30-31
     case ALZ_C_LZ00: return len > 0x40 && !memcmp(src, "LZ00", 4);                           // LZ00.cs:36-37
+    case ALZ_C_FASTLZ: return len > 0x4 && fastlz_validate(src, len);                        // FastLZ.cs:34-35
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
     case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
     case ALZ_C_IECP: return len > 0x10 && !memcmp(src, "IECP", 4);
@@ -648,6 +678,9 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
+        break;
+    case ALZ_C_FASTLZ:                                                                      // FastLZ.cs:40-52: the rest of the stream is the body
+        rc = run_body(ctx, ALZ_FMT_FASTLZ, nullptr, src, len, 0, 0, 0, dst, dst_cap, &r);
         break;
     case ALZ_C_LZ00: {                                                                      // LZ00.cs:40-60
         if (len < 4 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT;
@@ -909,6 +942,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_MIO0: fmt = ALZ_FMT_MIO0; hdr = 16; break;
     case ALZ_C_PRS: fmt = big ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE; break;
     case ALZ_C_LZO: fmt = ALZ_FMT_LZO; break;
+    case ALZ_C_FASTLZ: fmt = ALZ_FMT_FASTLZ; break;                                             // FastLZ.cs:162-163 (level 1: MaxWindowBits stays 0)
     default: return ALZ_E_UNSUPPORTED;
     }
     if (cap < hdr) return ALZ_E_NOMEM;

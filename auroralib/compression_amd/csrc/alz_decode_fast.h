@@ -877,6 +877,51 @@ struct SnappyRounds {
     __device__ __forceinline__ void commit() {}
 };
 
+// Lane-parallel FastLZ parse (FastLZ.cs:63-160): an element is a control byte plus 1..32 literals, or a match of 2-3 bytes
+// (level 1) / 2-5 bytes (level 2: a second length byte of 255 chains on -> exact parser; offset 0x1FFF is followed by a
+// 16-bit big-endian extension).  One token per element, lane j = element j.  Never sees the stream's first byte.
+__device__ __forceinline__ bool fastlz_parse_round(InCache& in, u32 p, int lane, u32 level, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    const bool l2 = level == 2u;
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2];
+        u32 n = b + 2u;                                                  // literal run: control byte + (b + 1) literals
+        if (b >= 32u) {
+            const bool ext = (b >> 5) == 7u;
+            const u32 low = ext ? e2 : e1;
+            n = ext ? 3u : 2u;
+            if (l2 && (b & 31u) == 31u && low == 255u) n += 2u;
+            if (l2 && ext && e1 == 255u) n = ALZ_NX_BAD;
+        }
+        nx[w] = n;
+    }
+    u32 spos, sp, nel;
+    lane_walk_pos(nx, 33u, spos, sp, nel);                               // elements have >= 2 bytes: <= 32 per window
+    if (nel == 0u) return false;
+    const u32 pos = i0 + spos;
+    const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2];
+    u32 t = ALZ_TOK_LIT(b + 1u, (pos + 1u) & 2047u);
+    if (b >= 32u) {
+        const bool ext = (b >> 5) == 7u;
+        const u32 lowp = pos + (ext ? 2u : 1u);
+        u32 ofs = ((b & 31u) << 8) | (ext ? e2 : e1);
+        if (l2 && ofs == 0x1FFFu) ofs = (((u32)in.lds[(lowp + 1u) & 2047u] << 8) | in.lds[(lowp + 2u) & 2047u]) + 0x1FFFu;
+        t = ALZ_TOK_MATCH((b >> 5) + 2u + (ext ? e1 : 0u), ofs + 1u);
+    }
+    const u32 qt = (u32)lane < nel ? t : 0u;
+    qt_out = qt; nt_out = nel; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    return true;
+}
+struct FastlzRounds {
+    InCache& in; int lane; u32 level;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return fastlz_parse_round(in, p, lane, level, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Lane-parallel LZO1X parse (LZO.cs:49-139).  What an instruction is depends on its first byte and, for the opcodes
 // below 16, on ONE piece of state -- whether the previous instruction copied 0, 1-3 or 4+ literals (LZO.cs:55) -- so every

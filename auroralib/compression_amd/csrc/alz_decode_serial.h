@@ -313,6 +313,51 @@ __device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u3
     }
 }
 
+// FastLZ.DecompressHeaderless  Formats/Common/FastLZ.cs:54-160 (levels 1 and 2).  Resumable at token boundaries: `fz`
+// carries the level (top bits of the stream's first byte) and s.p always points at the next control byte; s.done is set
+// when the input ends behind a token (the only way a FastLZ stream ends, :96).
+struct FastlzState { u32 level; bool started; };
+__device__ __forceinline__ void fastlz_state_init(FastlzState& fz) { fz.level = 0; fz.started = false; }
+__device__ __forceinline__ u32 fastlz_window(const FastlzState& fz) { return fz.level == 2u ? 131072u : 8192u; }   // _lz1 / _lz2[1] WindowsBits  :22-27
+
+template <class SK>
+__device__ __forceinline__ void dec_fastlz_serial(InCache& in, SK& sk, DecState& s, u32 src_len, FastlzState& fz, u32 max_tokens = 0xFFFFFFFFu) {
+    if (!fz.started) {
+        if (src_len == 0) { s.eof = true; return; }                                  // source[0]: IndexOutOfRangeException  :57
+        sk.ensure(in, 0, 1);
+        fz.level = (in.peek1(0) >> 5) + 1u;
+        if (fz.level != 1u && fz.level != 2u) { s.bad = true; return; }             // InvalidDataException  :60
+    }
+    for (;;) {
+        if (max_tokens-- == 0) return;
+        sk.ensure(in, s.p, 8);
+        u32 ctrl = in.peek1(s.p); s.p++;
+        if (!fz.started) { ctrl &= 31u; fz.started = true; }                         // :67 / :109
+        if (ctrl >= 32u) {
+            u64 len = (ctrl >> 5) - 1u; u32 ofs = (ctrl & 31u) << 8;
+            if (len == 6u) {
+                if (fz.level == 1u) { if (s.p >= src_len) { s.eof = true; return; } len += in.peek1(s.p); s.p++; }
+                else { u32 b; do { if (s.p >= src_len) { s.eof = true; return; } sk.ensure(in, s.p, 1); b = in.peek1(s.p); s.p++; len += b; } while (b == 255u); }
+            }
+            if (s.p >= src_len) { s.eof = true; return; }
+            sk.ensure(in, s.p, 4);
+            ofs |= in.peek1(s.p); s.p++;
+            if (fz.level == 2u && ofs == 0x1FFFu) {                                  // large offset extension  :138-143
+                if (s.p + 2u > src_len) { s.eof = true; return; }
+                const u32 w = in.peek4(s.p); s.p += 2;
+                ofs = (((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu)) + 0x1FFFu;
+            }
+            if (!sk.match(ofs + 1u, len + 3u, fastlz_window(fz))) return;
+        } else {
+            ctrl++;
+            if (ctrl > src_len - s.p) { s.eof = true; return; }                      // Slice throws  :91
+            if (!sk.run(in, s.p, ctrl)) return;
+            s.p += ctrl;
+        }
+        if (s.p >= src_len) { s.done = true; return; }                               // :96
+    }
+}
+
 // LZO.DecompressHeaderless  Formats/Common/LZO.cs:49-139.  Resumable at instruction boundaries: `ls` carries the one
 // piece of decoder state that crosses instructions (the literal count of the previous instruction, LZO.cs:55) and s.p
 // always points at the next instruction's first byte.

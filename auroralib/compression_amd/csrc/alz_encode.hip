@@ -455,6 +455,22 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_FASTLZ) {                           // FastLZ.cs:162-245, level 1 (level 2 needs MaxWindowBits > 13, refused by the host)
+        for (;;) {
+            Match mt = mf.next();
+            int plain = mt.offset - sp;
+            while (plain > 0) {                                             // literal runs of 1..32
+                const int chunk = plain < 32 ? plain : 32;
+                out.put((u32)(chunk - 1));
+                out.copy(src + sp, (u32)chunk); sp += chunk; plain -= chunk;
+            }
+            if (mt.length == 0) break;
+            const int length = mt.length - 3, distance = mt.distance - 1;
+            out.put((u32)((((length < 6 ? length : 6) + 1) << 5) | (distance >> 8)));
+            if (length >= 6) out.put((u32)(length - 6));
+            out.put((u32)distance & 0xFF);
+            sp += mt.length;
+        }
     } else {                                                                // Snappy.cs:124-203
         int v = n; while (v >= 0x80) { out.put((u32)(v | 0x80) & 0xFF); v >>= 7; } out.put((u32)v);
         for (;;) {
@@ -723,6 +739,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_LZ4_BLOCK: wb = 16; g.min_len = 4; g.max_len = 0x7FFFFFFF; g.max_dist = 0xFFFF; break;
     case ALZ_FMT_LZO: wb = 16; g.min_len = 3; g.max_len = 0x7FFFFFFF; g.max_dist = 0xBFFF; break;
     case ALZ_FMT_SNAPPY_RAW: wb = 15; g.min_len = 4; g.max_len = 64; g.max_dist = 0x8000; break;
+    case ALZ_FMT_FASTLZ: wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; break;      // level 1  FastLZ.cs:22
     default: return false;
     }
     g.min_dist = st->min_distance > 0 ? st->min_distance : 1;
@@ -788,6 +805,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZ4_BLOCK: launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

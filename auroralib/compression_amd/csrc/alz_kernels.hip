@@ -109,6 +109,9 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     } else if constexpr (FMT == ALZ_FMT_SNAPPY_RAW) {
         u32 sz = 0; bool have = false;
         dec_snappy_serial(in, sk, s, src_len, sz, have);
+    } else if constexpr (FMT == ALZ_FMT_FASTLZ) {
+        FastlzState fz; fastlz_state_init(fz);
+        dec_fastlz_serial(in, sk, s, src_len, fz);
     }
     out.finish();
     write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap), hist);
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     DecState s; dec_state_init(s);
     typedef EmitCfg<LW - 1u, false, !PRS, (!PRS || PRSFB)> CFG;
     typedef QueueSink<OW, CFG> SK;
-    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : 65536u);
+    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : (FMT == ALZ_FMT_FASTLZ ? 131072u : 65536u));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
     if constexpr (PRS) {
         // bulk of the stream: lane-assisted parse (prs_lane_parse) while >= 1100 input bytes remain; every token it
         // declines, and the tail of the stream, goes through the exact parser one token at a time
@@ -284,6 +287,20 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             }
             const bool tail = s.p + 1100u > src_len;
             dec_lzo_serial(in, sk, s, src_len, ls, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
+    }
+    else if constexpr (FMT == ALZ_FMT_FASTLZ) {
+        FastlzState fz; fastlz_state_init(fz);
+        for (;;) {
+            if (fz.started && s.p + 1100u <= src_len) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                FastlzRounds rounds{in, lane, fz.level};
+                if (pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, fastlz_window(fz), cap, rounds)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_fastlz_serial(in, sk, s, src_len, fz, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
     }
@@ -351,6 +368,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_LZ4_BLOCK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZ4_BLOCK>, 64, 0); break;
     case ALZ_FMT_LZO: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZO>, 64, 0); break;
     case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
+    case ALZ_FMT_FASTLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_FASTLZ>, 64, 0); break;
     case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZHUDSON>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_SMSR00>, 64 * ALZ_WPB, 0); break;
     default: break;
@@ -388,6 +406,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_LZ4_BLOCK: return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZO: return launch_queue<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_SNAPPY_RAW: return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_FASTLZ: return launch_queue<ALZ_FMT_FASTLZ>(stream, s, d, streams, index, count, results);
         default: break;
         }
     }
@@ -410,6 +429,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_LZ4_BLOCK: return launch_serial<ALZ_FMT_LZ4_BLOCK, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_LZO: return launch_serial<ALZ_FMT_LZO, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_SNAPPY_RAW: return launch_serial<ALZ_FMT_SNAPPY_RAW, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_FASTLZ: return launch_serial<ALZ_FMT_FASTLZ, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     default: return hipErrorInvalidValue;
     }
 }

@@ -283,6 +283,40 @@ static void gen_snappy(rng_t* r, uint32_t target, out_t* out) {
     }
 }
 
+/* ---- FastLZ (Formats/Common/FastLZ.cs:63-160): level 1 (8 KiB window, one length byte) or level 2 (length chains,
+ * 16-bit offset extension); the level is drawn from the stream's seed ---- */
+static void gen_fastlz(rng_t* r, uint32_t target, out_t* out) {
+    const int level2 = rng_unit(r) < 0.5;
+    uint32_t produced = 0; int first = 1;
+    if (target == 0) { o_u8(out, level2 ? 0x20 : 0x00); o_u8(out, 0x55); return; }   /* (a stream cannot be empty: one literal, clipped by capacity) */
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        uint32_t lit = rng_geometric(r, 6.0); if (first && lit == 0) lit = 1;
+        if (lit > rem) lit = rem;
+        while (lit) {                                                  /* runs of 1..32 */
+            uint32_t chunk = lit < 32 ? lit : 32;
+            o_u8(out, (chunk - 1) | (first && level2 ? 0x20 : 0)); first = 0;
+            put_rand(out, r, chunk); produced += chunk; lit -= chunk;
+        }
+        rem = target - produced;
+        if (rem < 3) { if (rem) { o_u8(out, rem - 1); put_rand(out, r, rem); produced += rem; } continue; }
+        tok_t t = draw_match_seq(r, produced, rem, 3, level2 ? 0x7FFFFFFF : 264, level2 ? 0x11FFF : 0x2000);
+        if (t.len < 3) t.len = 3;
+        if (level2 && rng_unit(r) < 0.02 && rem > 600) t.len = rng_range(r, 264, rem < 3000 ? rem : 3000);   /* chained length bytes */
+        uint32_t length = t.len - 3, distance = t.dist - 1;
+        uint32_t sd = level2 && distance > 0x1FFF ? 0x1FFF : distance;
+        o_u8(out, (((length < 6 ? length : 6) + 1) << 5) | (sd >> 8));
+        if (length >= 6) {
+            length -= 6;
+            while (level2 && length >= 255) { o_u8(out, 255); length -= 255; }
+            o_u8(out, length);
+        }
+        o_u8(out, sd & 0xFF);
+        if (level2 && distance >= 0x1FFF) { distance -= 0x1FFF; o_u8(out, distance >> 8); o_u8(out, distance & 0xFF); }
+        produced += t.len;
+    }
+}
+
 /* ---- LZO (opcode forms of Formats/Common/LZO.cs:141-250) ---- */
 static void lzo_ext(out_t* o, uint32_t v) { while (v > 255) { o_u8(o, 0); v -= 255; } o_u8(o, v); }
 static void gen_lzo(rng_t* r, uint32_t target, out_t* out) {
@@ -360,6 +394,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_PRS_BE: gen_prs(&r, target, &out, 1); break;
     case ALZ_FMT_PRS_LE: gen_prs(&r, target, &out, 0); break;
     case ALZ_FMT_LZ4_BLOCK: gen_lz4(&r, target, &out); break;
+    case ALZ_FMT_FASTLZ: gen_fastlz(&r, target, &out); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
     default: return -2;

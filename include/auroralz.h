@@ -49,7 +49,9 @@ typedef enum alz_format {
                                 src/AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:53 */
     ALZ_FMT_SMSR00     = 13, /* SMSR00.DecompressHeaderless: u16 BE codes (16-bit masks + MIO0 tokens) | literals; aux0 = length of the
                                 code section   src/AuroraLib.Compression.Nintendo/Nintendo/SMSR00.cs:70-131 */
-    ALZ_FMT_COUNT      = 14
+    ALZ_FMT_FASTLZ     = 14, /* FastLZ.DecompressHeaderless (levels 1 and 2; the level is the top 3 bits of the first byte)
+                                src/AuroraLib.Compression/Formats/Common/FastLZ.cs:54-160.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_COUNT      = 15
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -246,7 +248,9 @@ typedef enum alz_container {
     ALZ_C_SMSR00 = 32, /* "SMSR00"+u16 0+BE size+BE literal pointer + codes | literals   Nintendo/SMSR00.cs:41-66 */
     ALZ_C_LZ00   = 33, /* "LZ00"+csize+8x0+name[32]+size+key+8x0, then an LZSS body XORed with the keystream of `key`
                           src/AuroraLib.Compression.Sega/Sega/LZ00.cs:40-96, :128-141 (see alz_container_options.key) */
-    ALZ_C_COUNT  = 34
+    ALZ_C_FASTLZ = 34, /* headerless FastLZ stream, levels 1 / 2 (IsMatch = FastLZ.Validate; written at level 1)
+                          src/AuroraLib.Compression/Formats/Common/FastLZ.cs:29-52, :246-291 */
+    ALZ_C_COUNT  = 35
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

@@ -512,6 +512,44 @@ static void dec_lz4(cur_t* c, win_t* w) {
     c->pos = sp;
 }
 
+/* FastLZ.DecompressHeaderless  Formats/Common/FastLZ.cs:54-160 (span based: reads past the end are
+ * IndexOutOfRange / ArgumentOutOfRange exceptions -> INPUT_TRUNCATED; an unknown level is InvalidDataException). */
+static void dec_fastlz(cur_t* c, win_t* w, dec_info* info) {
+    const uint8_t* s = c->p; uint32_t n = c->len; uint32_t sp = 0;
+    if (n == 0) { c->eof = 1; return; }                                                  /* source[0]  :57 */
+    int level = (s[0] >> 5) + 1;
+    if (level != 1 && level != 2) { info->bad_token = 1; return; }                       /* :60 */
+    uint32_t ctrl = s[sp++] & 31u;                                                       /* :67 / :109 */
+    for (;;) {
+        if (ctrl >= 32) {
+            uint64_t len = (ctrl >> 5) - 1; uint32_t ofs = (ctrl & 31u) << 8;
+            if (len == 6) {
+                if (level == 1) { if (sp >= n) { c->eof = 1; c->pos = sp; return; } len += s[sp++]; }          /* :79-80 */
+                else { uint32_t b; do { if (sp >= n) { c->eof = 1; c->pos = sp; return; } b = s[sp++]; len += b; } while (b == 255); }   /* :124-132 */
+            }
+            if (sp >= n) { c->eof = 1; c->pos = sp; return; }
+            ofs |= s[sp++];
+            if (level == 2 && ofs == 0x1FFF) {                                           /* :138-143 */
+                if (sp + 2 > n) { c->eof = 1; c->pos = sp; return; }
+                ofs = ((uint32_t)s[sp] << 8) | s[sp + 1]; sp += 2; ofs += 0x1FFF;
+            }
+            uint32_t cl = win_clip(w, len + 3);
+            win_back_copy(w, ofs + 1, cl);                                               /* :84 / :145 */
+            if (w->overflow) { c->pos = sp; return; }
+        } else {
+            ctrl++;
+            if (ctrl > n - sp) { c->eof = 1; c->pos = sp; return; }                      /* Slice throws  :91 */
+            uint32_t cl = win_clip(w, ctrl);
+            win_write(w, s + sp, cl);
+            if (w->overflow) { c->pos = sp; return; }
+            sp += ctrl;
+        }
+        if (sp >= n) break;                                                              /* :96 */
+        ctrl = s[sp++];
+    }
+    c->pos = sp;
+}
+
 /* LZO.ReadExtendedInt  Formats/Common/LZO.cs:252-262 */
 static uint32_t lzo_ext(cur_t* c) {
     int b; uint32_t length = 0;
@@ -653,6 +691,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     cur_t c = { src_base + s->src_off, s->src_len, 0, 0 };
     win_t w; memset(&w, 0, sizeof(w));
     int wb = fmt_window_bits(s->format, &lz);
+    if (s->format == ALZ_FMT_FASTLZ) wb = (s->src_len && (c.p[0] >> 5) == 1) ? 17 : 13;   /* _lz1 / _lz2[1] WindowsBits  FastLZ.cs:22-27 */
     w.flat = flat; w.W = 1u << wb; w.mask = w.W - 1;
     w.dst = dst_base + s->dst_off; w.cap = s->dst_cap;
     /* LZ4 block continuing the window of earlier blocks of its frame (alz_stream.aux0 = history bytes in front of
@@ -698,6 +737,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_LZ4_BLOCK: dec_lz4(&c, &w); break;
     case ALZ_FMT_LZO: terminated = dec_lzo(&c, &w); break;
     case ALZ_FMT_SNAPPY_RAW: dec_snappy(&c, &w, &info); break;
+    case ALZ_FMT_FASTLZ: dec_fastlz(&c, &w, &info); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -990,6 +1030,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_LZ4_BLOCK: p = (fmt_props){ 16, 0x7FFFFFFF, 4, 0xFFFF, 1 }; break;      /* LZ4.cs:29 */
     case ALZ_FMT_LZO: p = (fmt_props){ 16, 0x7FFFFFFF, 3, 0xBFFF, 1 }; break;            /* LZO.cs:24 */
     case ALZ_FMT_SNAPPY_RAW: p = (fmt_props){ 15, 64, 4, 0x8000, 1 }; break;             /* Snappy.cs:28 */
+    case ALZ_FMT_FASTLZ: p = (fmt_props){ 13, 255 + 3 + 6, 3, 0x2000, 1 }; break;        /* level 1  FastLZ.cs:22 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1287,6 +1328,34 @@ static void enc_snappy(const alz_settings* st, const uint8_t* src, int n, buf_t*
     mf_free(&m);
 }
 
+/* FastLZ.CompressHeaderless, level 1  Formats/Common/FastLZ.cs:162-245.  (Level 2 -- chosen only for sources >= 64 KiB at
+ * Quality > 4 when the caller sets MaxWindowBits > 13, :164 -- needs the finder's multi-property scoring and is not
+ * restated: refused.) */
+static int enc_fastlz(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    if (n >= 0x10000 && st->quality > 4 && st->max_window_bits > 13) return ALZ_E_UNSUPPORTED;
+    fmt_props p = props_for(ALZ_FMT_FASTLZ, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain > 0) {                                                              /* :178-198 */
+            int chunk = plain < 32 ? plain : 32;
+            buf_u8(out, (uint32_t)(chunk - 1));
+            buf_put(out, src + sp, (size_t)chunk);
+            sp += chunk; plain -= chunk;
+        }
+        if (match.length == 0) break;
+        int length = match.length - 3, distance = match.distance - 1;
+        buf_u8(out, (uint32_t)((((length < 6 ? length : 6) + 1) << 5) | (distance >> 8)));
+        if (length >= 6) buf_u8(out, (uint32_t)(length - 6));
+        buf_u8(out, (uint32_t)distance & 0xFF);
+        sp += match.length;
+    }
+    mf_free(&m);
+    return 0;
+}
+
 int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, const alz_settings* settings,
                              const uint8_t* src, size_t n, uint8_t* dst, size_t cap, alz_encode_aux* aux) {
     buf_t out = { dst, 0, cap, 0, 0 };
@@ -1335,6 +1404,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_LZ4_BLOCK: rc = enc_lz4(st, src, (int)n, &out); break;
     case ALZ_FMT_LZO: rc = enc_lzo(st, src, (int)n, &out); break;
     case ALZ_FMT_SNAPPY_RAW: enc_snappy(st, src, (int)n, &out); break;
+    case ALZ_FMT_FASTLZ: rc = enc_fastlz(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1365,6 +1435,36 @@ static int nin_header(const uint8_t* src, size_t len, uint8_t id, uint32_t* size
 }
 
 static const uint8_t SNAPPY_ID[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 };
+
+/* FastLZ.Validate  Formats/Common/FastLZ.cs:246-291 (IsMatch: Position + 4 < Length && Validate) */
+static int fastlz_validate(const uint8_t* s, size_t n) {
+    size_t pos = 0;
+    int ctrl = pos < n ? s[pos++] : -1;
+    int level = (ctrl >> 5) + 1;
+    if (level != 0 && level != 1) return 0;                         /* (sic: only a first byte below 0x20 passes) */
+    int i = 3; long buffer = 0;
+    while (ctrl != -1) {
+        if (ctrl >= 32) {
+            int length = (ctrl >> 5) - 1, distance = (ctrl & 31) << 8;
+            if (length == 6) length += pos < n ? s[pos++] : -1;
+            ctrl = pos < n ? s[pos++] : -1;
+            distance |= ctrl;
+            if (ctrl == -1 || length < 0) return 0;
+            if (distance + 1 > buffer) return 0;
+            if (i-- == 0) return 1;
+            buffer += length + 3;
+        } else {
+            ctrl++;
+            buffer += ctrl;
+            if (pos + (size_t)ctrl > n) return 0;
+            pos += (size_t)ctrl;
+        }
+        if (pos >= n) return i < 3;
+        ctrl = s[pos++];
+    }
+    return 0;
+}
+int oracle_fastlz_validate(const uint8_t* s, size_t n) { return n > 4 && fastlz_validate(s, n); }
 
 /* LZ00.StreamTransformer  Sega/LZ00.cs:128-141: every byte that passes through it is XORed with the next element of a
  * keystream; GenerateNextKey's shift/add chain multiplies by 3, 95, 3041, 389247, then 63, 15, 3 = 1103515245 and adds
@@ -1702,6 +1802,9 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
         break;
     }
+    case ALZ_C_FASTLZ:                                                                   /* FastLZ.cs:40-52: the whole rest of the stream is the body */
+        run_stream(ALZ_FMT_FASTLZ, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
+        break;
     case ALZ_C_LZ00: {                                                                   /* Sega/LZ00.cs:40-60 */
         if (len < 4 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT;
         if (len < 64) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
@@ -2050,6 +2153,13 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
         break;
+    case ALZ_C_FASTLZ: {                                                                 /* FastLZ.cs:162-163 */
+        hdr = 0;
+        body = oracle_encode_stream(ALZ_FMT_FASTLZ, NULL, &st, src, n, dst, cap, NULL);
+        if (body == ALZ_E_UNSUPPORTED) return ALZ_E_UNSUPPORTED;
+        if (body < 0) return ALZ_E_NOMEM;
+        break;
+    }
     case ALZ_C_LZ00: {                                                                   /* Sega/LZ00.cs:71-96 */
         if (cap < 64) return ALZ_E_NOMEM;
         hdr = 64;

@@ -54,6 +54,36 @@ def test_wrapper_headers_host_vs_oracle(cls, container, test_bmp):
             assert f.IsMatch(comp)
 
 
+def test_fastlz_oracle_and_validate(test_bmp):
+    """FastLZ (Formats/Common/FastLZ.cs): headerless, level in the top bits of the first byte; IsMatch = Validate (:246-291),
+    which -- as written -- accepts level-1 streams only; no IProvidesDecompressedSize."""
+    import ctypes as C
+    for raw, q in ((bytes(0x100), 0), (test_bmp[:10240], 8), (test_bmp[:70000], 15), (test_bmp[:7], 4)):
+        comp = O.container_compress(A.C_FASTLZ, raw, quality=q)
+        assert comp[0] < 0x20                                                       # level 1: first control byte is a literal run
+        out, st = O.container_decompress(A.C_FASTLZ, comp, cap=len(raw) + 16)
+        assert st == A.ST_OK and out == raw
+        assert F.FastLZ().IsMatch(comp) == bool(O.lib.oracle_fastlz_validate(comp, len(comp)))
+        if len(raw) >= 0x100:
+            assert F.FastLZ().IsMatch(comp)                                         # DataRecognitionTest (CompressionAlgorithmTest.cs:60-80)
+    with pytest.raises(NotImplementedError):
+        F.FastLZ().GetDecompressedSize(b"\x00\x41")
+    # hand-made level 2 stream: literal run "abcde" (first byte carries the level), match d=5 l=3+6+255+4 via chained length
+    # bytes, then a far match through the 16-bit offset extension (distance 0x1FFF + 1 + 0 reaches before the start: zeros)
+    l2 = bytes([0x20 | 4]) + b"abcde" + bytes([0xE0, 255, 4, 4]) + bytes([0x3F, 0xFF, 0x00, 0x00])
+    out, st = O.container_decompress(A.C_FASTLZ, l2, cap=4096)
+    assert st == A.ST_OK and len(out) == 5 + (3 + 6 + 255 + 4) + 3
+    assert out[:5] == b"abcde" and out[5:5 + 268] == (b"abcde" * 60)[:268] and out[-3:] == bytes(3)
+    assert not F.FastLZ().IsMatch(l2)                                               # (sic) Validate rejects level 2
+    rng = __import__("random").Random(5)
+    for _ in range(300):                                                            # Validate on noise: product == oracle
+        blob = bytes(rng.choice([0, 1, 3, 0x1F, 0x20, 0x41, 0xE0, 0xFF, rng.randrange(256)]) for _ in range(rng.randrange(0, 40)))
+        assert F.FastLZ().IsMatch(blob) == bool(O.lib.oracle_fastlz_validate(blob, len(blob))), blob.hex()
+    for bad in (b"", bytes([0x40, 1, 2])):                                          # empty: IndexOutOfRange; level 3: InvalidDataException
+        out, st = O.container_decompress(A.C_FASTLZ, bad, cap=64)
+        assert st == (A.ST_INPUT_TRUNCATED if not bad else A.ST_BAD_TOKEN)
+
+
 def test_lz00_keystream_oracle(test_bmp):
     """LZ00 (Sega/LZ00.cs): 64-byte header (magic, csize, name[32] at 16, size at 48, key at 52) + an LZSS body XORed with the
     keystream of the key -- key * 1103515245 + 12345 per byte, byte ^= (((key >> 16) & 0x7FFF) * 255) >> 15 (:128-141)."""
