@@ -313,6 +313,40 @@ __device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u3
     }
 }
 
+// CNX2.DecompressHeaderless  Sega/CNX2.cs:83-139: two flag bits per token, first bit = bit 0 (FlagReader Endian.Little,
+// ReadInt(2)  FlagReader.cs:75-87).  0: skip n bytes and drop the rest of the flag byte; 1: literal; 2: match (big-endian
+// u16: distance - 1 in the high 11 bits, length - 4 in the low 5); 3: n literals.  Resumable at token boundaries
+// (s.flag / s.bits hold the flag byte, shifted as bits are consumed).
+template <class SK>
+__device__ __forceinline__ void dec_cnx2_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size, u32 max_tokens = 0xFFFFFFFFu) {
+    while (sk.produced() < size) {
+        if (max_tokens-- == 0) return;
+        sk.ensure(in, s.p, 8);
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        const u32 code = s.flag & 3u; s.flag >>= 2; s.bits -= 2;
+        if (code == 0u) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            const u32 n = in.peek1(s.p); s.p += 1u + n;                              // source.Position += length (may pass the end)  :98
+            s.bits = 0;                                                              // flag.Reset()
+        } else if (code == 1u) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            if (!sk.run(in, s.p, 1)) return;
+            s.p++;
+        } else if (code == 2u) {
+            if (s.p >= src_len || s.p + 2u > src_len) { s.eof = true; return; }
+            const u32 w = in.peek4(s.p); s.p += 2;
+            const u32 pair = ((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu);
+            if (!sk.match((pair >> 5) + 1u, (u64)(pair & 0x1Fu) + 4u, 2048)) return;
+        } else {
+            if (s.p >= src_len) { s.eof = true; return; }
+            const u32 n = in.peek1(s.p); s.p++;
+            if (n > src_len - s.p) { s.eof = true; return; }                         // LzWindows.CopyFrom -> ReadExactly throws
+            if (!sk.run(in, s.p, n)) return;
+            s.p += n;
+        }
+    }
+}
+
 // FastLZ.DecompressHeaderless  Formats/Common/FastLZ.cs:54-160 (levels 1 and 2).  Resumable at token boundaries: `fz`
 // carries the level (top bits of the stream's first byte) and s.p always points at the next control byte; s.done is set
 // when the input ends behind a token (the only way a FastLZ stream ends, :96).

@@ -455,6 +455,32 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_CNX2) {                             // CNX2.cs:140-172
+        // FlagWriter order without its buffer (a flag byte's payload can be four 256-byte runs): the flag byte's slot is
+        // reserved when its first code is written and patched when the fourth is (or at the end): the same bytes
+        u32 flagpos = 0, cur = 0, ncodes = 0;
+        auto code = [&](u32 v) {
+            cur |= v << (2u * ncodes);
+            if (++ncodes == 4u) { if (flagpos < out.cap) out.p[flagpos] = (u8)cur; cur = 0; ncodes = 0; }
+        };
+        auto reserve = [&]() { if (ncodes == 0u) { flagpos = out.len; out.put(0); } };
+        for (;;) {
+            Match mt = mf.next();
+            int plain = mt.offset - sp;
+            while (plain != 0) {
+                const int length = plain < 255 ? plain : 255;
+                reserve();
+                if (length == 1) { out.put(src[sp]); code(1); }
+                else { out.put((u32)length); out.copy(src + sp, (u32)length); code(3); }
+                sp += length; plain -= length;
+            }
+            if (mt.length == 0) break;
+            reserve();
+            out.put16be((u32)((((mt.distance - 1) & 0x7FF) << 5) | ((mt.length - 4) & 0x1F)));
+            sp += mt.length;
+            code(2);
+        }
+        if (ncodes && flagpos < out.cap) out.p[flagpos] = (u8)cur;
     } else if constexpr (FMT == ALZ_FMT_FASTLZ) {                           // FastLZ.cs:162-245, level 1 (level 2 needs MaxWindowBits > 13, refused by the host)
         for (;;) {
             Match mt = mf.next();
@@ -740,6 +766,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_LZO: wb = 16; g.min_len = 3; g.max_len = 0x7FFFFFFF; g.max_dist = 0xBFFF; break;
     case ALZ_FMT_SNAPPY_RAW: wb = 15; g.min_len = 4; g.max_len = 64; g.max_dist = 0x8000; break;
     case ALZ_FMT_FASTLZ: wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; break;      // level 1  FastLZ.cs:22
+    case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
     default: return false;
     }
     g.min_dist = st->min_distance > 0 ? st->min_distance : 1;
@@ -806,6 +833,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -112,6 +112,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     } else if constexpr (FMT == ALZ_FMT_FASTLZ) {
         FastlzState fz; fastlz_state_init(fz);
         dec_fastlz_serial(in, sk, s, src_len, fz);
+    } else if constexpr (FMT == ALZ_FMT_CNX2) {
+        has_size = true; dec_cnx2_serial(in, sk, s, src_len, size);
     }
     out.finish();
     write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap), hist);
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     // These kernels are bound by the latency of one wave's scalar parse, so waves per CU matter more than LDS hits:
     // only the most recent 4 KiB of the window stay in LDS (6.3 KB per wave -> 25 waves per CU instead of 15), older
     // sources are read back from the stream's own output in HBM, batched per token queue.
+    constexpr bool CNX = (FMT == ALZ_FMT_CNX2);             // 2 KiB window: all of it in LDS, literal runs from the input cache
     constexpr bool PRSFB = (ALZ_PRS_LW < 8192);             // PRS with a window smaller than its 8 KiB: read-back like the 64 KiB formats
     constexpr u32 LW = PRS ? (u32)ALZ_PRS_LW : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
     // static LDS: marks (128) | token staging (256) | input cache | window
@@ -232,15 +235,16 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     u8* segmark = lds;
     u32* stage = reinterpret_cast<u32*>(lds + 128);
     u8* inc_lds = lds + 384;
-    typedef OutWin<(!PRS || PRSFB)> OW;
+    constexpr bool FB = CNX ? false : (!PRS || PRSFB);
+    typedef OutWin<FB> OW;
     OW out; out.init(dst, cap, lds + 384 + ALZ_INCACHE_BYTES, LW, lane);
     if (hist) out.preload(hist);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane);
     DecState s; dec_state_init(s);
-    typedef EmitCfg<LW - 1u, false, !PRS, (!PRS || PRSFB)> CFG;
+    typedef EmitCfg<LW - 1u, false, !PRS, FB> CFG;
     typedef QueueSink<OW, CFG> SK;
-    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : (FMT == ALZ_FMT_FASTLZ ? 131072u : 65536u));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
+    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : (FMT == ALZ_FMT_FASTLZ ? 131072u : (CNX ? 2048u : 65536u)));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
     if constexpr (PRS) {
         // bulk of the stream: lane-assisted parse (prs_lane_parse) while >= 1100 input bytes remain; every token it
         // declines, and the tail of the stream, goes through the exact parser one token at a time
@@ -290,6 +294,9 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
     }
+    else if constexpr (CNX) {
+        dec_cnx2_serial(in, sk, s, src_len, uni(st.decom_len));          // exact parser on the scalar unit, tokens executed 64 at a time
+    }
     else if constexpr (FMT == ALZ_FMT_FASTLZ) {
         FastlzState fz; fastlz_state_init(fz);
         for (;;) {
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     }
     sk.flush();                                    // tokens parsed before an error/terminator are part of the output
     out.finish();
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0, cap), hist);
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, CNX, out.produced, CNX ? uni(st.decom_len) : 0u, cap), hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,6 +376,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_LZO: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZO>, 64, 0); break;
     case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
     case ALZ_FMT_FASTLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_FASTLZ>, 64, 0); break;
+    case ALZ_FMT_CNX2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNX2>, 64, 0); break;
     case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZHUDSON>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_SMSR00>, 64 * ALZ_WPB, 0); break;
     default: break;
@@ -407,6 +415,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_LZO: return launch_queue<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_SNAPPY_RAW: return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_FASTLZ: return launch_queue<ALZ_FMT_FASTLZ>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_CNX2: return launch_queue<ALZ_FMT_CNX2>(stream, s, d, streams, index, count, results);
         default: break;
         }
     }
@@ -430,6 +439,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_LZO: return launch_serial<ALZ_FMT_LZO, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_SNAPPY_RAW: return launch_serial<ALZ_FMT_SNAPPY_RAW, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_FASTLZ: return launch_serial<ALZ_FMT_FASTLZ, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_CNX2: return launch_serial<ALZ_FMT_CNX2, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     default: return hipErrorInvalidValue;
     }
 }

@@ -317,6 +317,40 @@ static void gen_fastlz(rng_t* r, uint32_t target, out_t* out) {
     }
 }
 
+/* ---- CNX2 (Sega/CNX2.cs:83-139): 2-bit codes, four per flag byte (LSB first); code 0 (skip n bytes, drop the rest of the
+ * flag byte) is sprinkled in although the managed encoder never writes it ---- */
+static void gen_cnx2(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    uint8_t pay[4 * 260]; uint32_t plen = 0, flag = 0, ncodes = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced, code;
+        double u = rng_unit(r);
+        if (u < 0.01) code = 0; else if (u < 0.40) code = 1; else if (u < 0.50 || rem < 4) code = 3; else code = 2;
+        if (code == 2 && produced == 0) code = 1;
+        flag |= code << (2 * ncodes); ncodes++;
+        if (code == 0) {                                              /* skip: the decoder jumps over n junk bytes and resets the flag reader */
+            uint32_t n = rng_range(r, 0, 40);
+            pay[plen++] = (uint8_t)n; for (uint32_t i = 0; i < n; i++) pay[plen++] = (uint8_t)rng_next(r);
+            o_u8(out, flag); o_put(out, pay, plen); plen = 0; flag = 0; ncodes = 0;
+            continue;
+        } else if (code == 1) { pay[plen++] = (uint8_t)rng_next(r); produced += 1; }
+        else if (code == 3) {
+            uint32_t n = rng_unit(r) < 0.1 ? rng_range(r, 0, 255) : 2 + rng_geometric(r, 6.0);
+            if (n > 255) n = 255; if (n > rem) n = rem;
+            pay[plen++] = (uint8_t)n; for (uint32_t i = 0; i < n; i++) pay[plen++] = (uint8_t)rng_next(r);
+            produced += n;
+        } else {
+            tok_t t = draw_match(r, produced, rem, 4, 35, 0, 0, 2048);
+            if (t.len < 4) t.len = 4;                                  /* (rem >= 4 here) */
+            uint32_t v = ((t.dist - 1) << 5) | (t.len - 4);
+            pay[plen++] = (uint8_t)(v >> 8); pay[plen++] = (uint8_t)v;
+            produced += t.len;
+        }
+        if (ncodes == 4) { o_u8(out, flag); o_put(out, pay, plen); plen = 0; flag = 0; ncodes = 0; }
+    }
+    if (ncodes) { o_u8(out, flag); o_put(out, pay, plen); }
+}
+
 /* ---- LZO (opcode forms of Formats/Common/LZO.cs:141-250) ---- */
 static void lzo_ext(out_t* o, uint32_t v) { while (v > 255) { o_u8(o, 0); v -= 255; } o_u8(o, v); }
 static void gen_lzo(rng_t* r, uint32_t target, out_t* out) {
@@ -395,6 +429,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_PRS_LE: gen_prs(&r, target, &out, 0); break;
     case ALZ_FMT_LZ4_BLOCK: gen_lz4(&r, target, &out); break;
     case ALZ_FMT_FASTLZ: gen_fastlz(&r, target, &out); break;
+    case ALZ_FMT_CNX2: gen_cnx2(&r, target, &out); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
     default: return -2;

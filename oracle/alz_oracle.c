@@ -512,6 +512,48 @@ static void dec_lz4(cur_t* c, win_t* w) {
     c->pos = sp;
 }
 
+/* CNX2.DecompressHeaderless  Sega/CNX2.cs:83-139: FlagReader(source, Endian.Little), ReadInt(2) = two bits, first one is
+ * bit 0 (FlagReader.cs:75-87); code 0 skips `n` bytes and drops the rest of the flag byte (Reset, :102). */
+static void dec_cnx2(cur_t* c, win_t* w, uint32_t size) {
+    flag_t flag = { c, 0, 0, 0, 1 };
+    while (win_produced(w) < size) {                                                     /* :90 */
+        int b0 = flag_readbit(&flag); if (c->eof) return;
+        int b1 = flag_readbit(&flag); if (c->eof) return;
+        switch (b0 | (b1 << 1)) {
+        case 0: {                                                                        /* :96-100 */
+            int n = cur_u8(c); if (c->eof) return;
+            c->pos += (uint32_t)n;                                                       /* source.Position += length (may pass the end) */
+            flag.bits_left = 0;
+            break;
+        }
+        case 1: {                                                                        /* :103-105 */
+            int b = cur_u8(c); if (c->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);
+            break;
+        }
+        case 2: {                                                                        /* :108-114 */
+            int h = cur_u8(c); if (c->eof) return;
+            int l = cur_u8(c); if (c->eof) return;
+            uint32_t pair = ((uint32_t)h << 8) | (uint32_t)l;
+            uint32_t cl = win_clip(w, (pair & 0x1F) + 4);
+            win_back_copy(w, (pair >> 5) + 1, cl);
+            if (w->overflow) return;
+            break;
+        }
+        default: {                                                                       /* :117-120  LzWindows.CopyFrom -> ReadExactly */
+            int n = cur_u8(c); if (c->eof) return;
+            if (c->pos > c->len || (uint32_t)n > c->len - c->pos) { c->eof = 1; return; }
+            uint32_t cl = win_clip(w, (uint32_t)n);
+            win_write(w, c->p + c->pos, cl);
+            if (w->overflow) return;
+            c->pos += (uint32_t)n;
+            break;
+        }
+        }
+    }
+}
+
 /* FastLZ.DecompressHeaderless  Formats/Common/FastLZ.cs:54-160 (span based: reads past the end are
  * IndexOutOfRange / ArgumentOutOfRange exceptions -> INPUT_TRUNCATED; an unknown level is InvalidDataException). */
 static void dec_fastlz(cur_t* c, win_t* w, dec_info* info) {
@@ -680,6 +722,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
     case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: return 12; /* LZ10.cs:25 ... */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
+    case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
     }
@@ -738,6 +781,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_LZO: terminated = dec_lzo(&c, &w); break;
     case ALZ_FMT_SNAPPY_RAW: dec_snappy(&c, &w, &info); break;
     case ALZ_FMT_FASTLZ: dec_fastlz(&c, &w, &info); break;
+    case ALZ_FMT_CNX2: info.has_size = 1; dec_cnx2(&c, &w, size); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -1031,6 +1075,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_LZO: p = (fmt_props){ 16, 0x7FFFFFFF, 3, 0xBFFF, 1 }; break;            /* LZO.cs:24 */
     case ALZ_FMT_SNAPPY_RAW: p = (fmt_props){ 15, 64, 4, 0x8000, 1 }; break;             /* Snappy.cs:28 */
     case ALZ_FMT_FASTLZ: p = (fmt_props){ 13, 255 + 3 + 6, 3, 0x2000, 1 }; break;        /* level 1  FastLZ.cs:22 */
+    case ALZ_FMT_CNX2: p = (fmt_props){ 11, 0x1F + 4, 4, 0x800, 1 }; break;               /* CNX2.cs:25 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1328,6 +1373,28 @@ static void enc_snappy(const alz_settings* st, const uint8_t* src, int n, buf_t*
     mf_free(&m);
 }
 
+/* CNX2.CompressHeaderless  Sega/CNX2.cs:140-172: FlagWriter(destination, Endian.Little), WriteInt(v, 2) = bit 0 first */
+static void enc_cnx2(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_CNX2, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 0);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) {
+            int length = plain < 255 ? plain : 255;
+            if (length == 1) { buf_u8(&flag.buffer, src[sp]); fw_bit(&flag, 1); fw_bit(&flag, 0); }
+            else { buf_u8(&flag.buffer, (uint32_t)length); buf_put(&flag.buffer, src + sp, (size_t)length); fw_bit(&flag, 1); fw_bit(&flag, 1); }
+            sp += length; plain -= length;
+        }
+        if (match.length == 0) break;
+        buf_u16be(&flag.buffer, (uint32_t)((((match.distance - 1) & 0x7FF) << 5) | ((match.length - 4) & 0x1F)));
+        sp += match.length;
+        fw_bit(&flag, 0); fw_bit(&flag, 1);
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
 /* FastLZ.CompressHeaderless, level 1  Formats/Common/FastLZ.cs:162-245.  (Level 2 -- chosen only for sources >= 64 KiB at
  * Quality > 4 when the caller sets MaxWindowBits > 13, :164 -- needs the finder's multi-property scoring and is not
  * restated: refused.) */
@@ -1405,6 +1472,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_LZO: rc = enc_lzo(st, src, (int)n, &out); break;
     case ALZ_FMT_SNAPPY_RAW: enc_snappy(st, src, (int)n, &out); break;
     case ALZ_FMT_FASTLZ: rc = enc_fastlz(st, src, (int)n, &out); break;
+    case ALZ_FMT_CNX2: enc_cnx2(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1491,6 +1559,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_SMSR00: if (len < 12 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return 0;          /* SMSR00.cs:33-39 */
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ60.cs:29-41 */
     case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 48); return 0;      /* Sega/LZ00.cs:31-37 */
+    case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;    /* Sega/CNX2.cs:36-42 */
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* MIO0.cs:41-48 */
@@ -1802,6 +1871,12 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
         break;
     }
+    case ALZ_C_CNX2:                                                                     /* Sega/CNX2.cs:45-62 */
+        if (len < 4 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = be32(src + 12); hdr = 16;
+        run_stream(ALZ_FMT_CNX2, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
     case ALZ_C_FASTLZ:                                                                   /* FastLZ.cs:40-52: the whole rest of the stream is the body */
         run_stream(ALZ_FMT_FASTLZ, NULL, src, (uint32_t)len, 0, 0, 0, dst, dst_cap, &r);
         break;
@@ -2152,6 +2227,13 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_CNX2:                                                                     /* Sega/CNX2.cs:64-81: Extension "DEC" padded with 0x10 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_CNX2, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "CNX\x02" "DEC\x10", 8); wr32(dst + 8, (uint32_t)body, 1); wr32(dst + 12, (uint32_t)n, 1);
         break;
     case ALZ_C_FASTLZ: {                                                                 /* FastLZ.cs:162-163 */
         hdr = 0;
