@@ -6,6 +6,7 @@
 // argument meaning and error behaviour as the managed classes (cited per function, paths relative to
 // /root/reference/src).  A C# shim would keep (1) in managed code and P/Invoke only alz_decode/alz_encode_batch
 // (INTEGRATION.md); hosts without the managed library use these entry points instead.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -488,6 +489,10 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZHUDSON: if (len < 4) return ALZ_E_FORMAT; *size_out = be32(src); return ALZ_OK;                                        // LZHudson.cs:30-31
     case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 48); return ALZ_OK;               // LZ00.cs:31-37
     case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return ALZ_OK;             // CNX2.cs:36-42
+    case ALZ_C_BLZ: {                                                                                                                      // BLZ.cs:32-41
+        if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;                                                                              // "Invalid BLZ header."
+        *size_out = le32(src + len - 4) + (le32(src + len - 8) & 0xFFFFFFu); return ALZ_OK;
+    }
     case ALZ_C_SMSR00: if (len < 12 || memcmp(src, "SMSR00", 6)) return ALZ_E_FORMAT; *size_out = be32(src + 8); return ALZ_OK;          // SMSR00.cs:33-39
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : ALZ_OK;                                  // LZ60.cs:29-41
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return ALZ_OK;   // Yaz0.cs:50-55
@@ -568,6 +573,7 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_LZ00: return len > 0x40 && !memcmp(src, "LZ00", 4);                           // LZ00.cs:36-37
     case ALZ_C_FASTLZ: return len > 0x4 && fastlz_validate(src, len);                        // FastLZ.cs:34-35
     case ALZ_C_CNX2: return len > 0x10 && !memcmp(src, "CNX\x02", 4);                        // CNX2.cs:33-34
+    case ALZ_C_BLZ: return len >= 8 && (le32(src + len - 8) & 0xFFFFFFu) == len && src[len - 5] >= 8;   // BLZ.cs:28-30 (the footer spans the whole stream)
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
     case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
     case ALZ_C_IECP: return len > 0x10 && !memcmp(src, "IECP", 4);
@@ -681,6 +687,24 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
         break;
+    case ALZ_C_BLZ: {                                                                       // BLZ.cs:43-69
+        if (len < 8) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        const uint32_t csz = le32(src + len - 8) & 0xFFFFFFu, hp = src[len - 5];
+        if (hp < 8) return ALZ_E_FORMAT;                                                    // "Invalid BLZ header."
+        size = le32(src + len - 4) + csz;
+        if (csz > len || hp > csz) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        const uint32_t code = csz - hp;
+        if ((uint64_t)size > dst_cap) { r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+        // the managed code walks both spans from their ends (BLZ.cs:99-101): the body kernel sees the code section
+        // reversed and leaves the output reversed -- two host-side passes around the match-copy work, like the checksums
+        std::vector<uint8_t> rev(src + (len - csz), src + (len - csz) + code);
+        std::reverse(rev.begin(), rev.end());
+        rc = run_body(ctx, ALZ_FMT_BLZ, nullptr, rev.data(), code, size, 0, 0, dst, size, &r);
+        if (rc == ALZ_OK && r.status == ALZ_ST_OK) std::reverse(dst, dst + size);
+        else r.dst_len = 0;                                                                 // nothing reaches the destination when the body throws (:62-64)
+        r.src_used = clamp32(len); hdr = 0;
+        break;
+    }
     case ALZ_C_CNX2:                                                                        // CNX2.cs:45-62
         if (len < 4 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT;
         if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
@@ -911,6 +935,26 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
             dst[8 + 2 * i] = (uint8_t)endoff; dst[8 + 2 * i + 1] = (uint8_t)(endoff >> 8);
         }
         if (dst_len) *dst_len = pos;
+        return ALZ_OK;
+    }
+    case ALZ_C_BLZ: {                                                                       // BLZ.cs:71-95, :137-150
+        std::vector<uint8_t> rev(src, src + n);                                             // "Our LZMatcher only works in one direction."
+        std::reverse(rev.begin(), rev.end());
+        std::vector<uint8_t> body(n + n / 4 + 64);
+        alz_stream s; memset(&s, 0, sizeof(s));
+        s.src_len = clamp32(n); s.dst_cap = clamp32(body.size()); s.format = ALZ_FMT_BLZ;
+        alz_result r; alz_encode_aux aux;
+        int rc = alz_encode_batch(ctx, nullptr, &st, 1, rev.data(), n, &s, body.data(), body.size(), &r, &aux);
+        if (rc != ALZ_OK) return rc;
+        if (r.status != ALZ_ST_OK) return r.status == ALZ_ST_OUTPUT_CAPACITY ? ALZ_E_NOMEM : ALZ_E_INVALID;
+        uint32_t total = r.dst_len + 8u; const uint32_t pad = (16u - (total % 16u)) % 16u; total += pad;
+        if (cap < total) return ALZ_E_NOMEM;
+        std::reverse_copy(body.begin(), body.begin() + r.dst_len, dst);                     // the managed buffer is filled from its end: stored back to front
+        memset(dst + r.dst_len, 0xFF, pad);
+        uint8_t* f = dst + r.dst_len + pad;
+        f[0] = (uint8_t)total; f[1] = (uint8_t)(total >> 8); f[2] = (uint8_t)(total >> 16); f[3] = (uint8_t)(8u + pad);
+        wr32(f + 4, (uint32_t)((int64_t)n - (int64_t)total), false);
+        if (dst_len) *dst_len = total;
         return ALZ_OK;
     }
     case ALZ_C_LEVEL5: {                                                                    // Level5.cs:112-146

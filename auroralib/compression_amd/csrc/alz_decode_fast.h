@@ -360,6 +360,7 @@ template <int FMT> struct FamTraits;
 // nibble is the low one of the first token byte (LZ40) instead of the high one; NEG: the flag byte is stored negated (LZ40)
 template <> struct FamTraits<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT1 = true,  H3 = false, H4 = false, NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_BLZ>  { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };   // LZ10's grammar in stream order, distance - 3
 template <> struct FamTraits<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true,  NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_YAZ0> { static constexpr bool MSB = true,  LIT1 = true,  H3 = true,  H4 = false, NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_LZ40> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true,  NIBLO = true,  NEG = true; };
@@ -435,6 +436,8 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
             desc = ALZ_DESC_MATCH(offset); tend = to + 2;
         } else if (FMT == ALZ_FMT_LZ10) {
             desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 1u); len = (b1 >> 4) + 3u; tend = to + 2;
+        } else if (FMT == ALZ_FMT_BLZ) {
+            desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 3u); len = (b1 >> 4) + 3u; tend = to + 2;   // BLZ.cs:117-118
         } else if (FMT == ALZ_FMT_LZ11) {
             const u32 b3 = in.lds[ti + 2], b4 = in.lds[ti + 3];
             const u32 nib = b1 >> 4;
@@ -461,7 +464,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     const bool cut = __ballot(ingroup && tend > inlim) != 0;
     if (cut && __ballot(valid) == 0) { to_serial = true; return false; }
     u32 last_tend;
-    const bool fin = fast_emit<OW, EmitCfg<(FMT == ALZ_FMT_LZSS ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
     if (fin) { s.p = p + last_tend; return true; }
     if (!cut) { s.p = p + g; return false; }
     // stopped inside a group: hand (position, remaining flag bits, flag byte) to the serial parser

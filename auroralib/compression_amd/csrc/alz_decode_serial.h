@@ -313,6 +313,37 @@ __device__ void dec_lz4_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u3
     }
 }
 
+// BLZ.DecompressHeaderless  Nintendo/BLZ.cs:97-135 in stream order (the managed code walks both spans from their ends: src is
+// the code section reversed, the output comes out reversed; the container layer does both reversals).  L = length of the
+// destination span.  Flags MSB first, 1 = match (big-endian u16: length - 3 in the high nibble, distance - 3 below).  A match
+// is cut silently where the span ends (:121); a literal there, a read behind the input, or a match source beyond the span
+// are IndexOutOfRangeExceptions.  Decoding ends when the input is used up.
+// `until`: return at the first flag-byte boundary where that much output exists (the lane-parallel loop takes over).
+template <class SK>
+__device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 L, u32 until = 0xFFFFFFFFu) {
+    while (s.p < src_len) {
+        if (s.bits == 0 && sk.produced() >= until) return;
+        sk.ensure(in, s.p, 8);
+        if (s.bits == 0) { s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        const u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (!bit) {
+            if (sk.produced() >= L) { sk.flush(); if (!s.ovf) { s.ovf = true; s.attempted_end = (u64)sk.produced() + 1u; } return; }   // destination[--dst]
+            if (s.p >= src_len) { s.eof = true; return; }                            // source[--src]
+            if (!sk.lit(in.peek1(s.p))) return;
+            s.p++;
+        } else {
+            if (s.p + 2u > src_len) { s.eof = true; s.p = src_len; return; }
+            const u32 w = in.peek4(s.p); s.p += 2;
+            const u32 inf = ((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu);
+            const u32 dist = (inf & 0x0FFFu) + 3u; u32 len = (inf >> 12) + 3u;
+            const u32 room = L - sk.produced();
+            if (len > room) len = room;
+            if (len && dist > sk.produced()) { s.bad = true; return; }               // destination[dst - 1 + distance]
+            if (len && !sk.match(dist, len, 8192)) return;
+        }
+    }
+}
+
 // CNX2.DecompressHeaderless  Sega/CNX2.cs:83-139: two flag bits per token, first bit = bit 0 (FlagReader Endian.Little,
 // ReadInt(2)  FlagReader.cs:75-87).  0: skip n bytes and drop the rest of the flag byte; 1: literal; 2: match (big-endian
 // u16: distance - 1 in the high 11 bits, length - 4 in the low 5); 3: n literals.  Resumable at token boundaries

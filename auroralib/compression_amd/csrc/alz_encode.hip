@@ -673,6 +673,8 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
                 const u32 offset = (g.windows_start + p - mt.x) & (g.lz_max_distance - 1u);
                 const u32 v = (offset & 0xFFu) | ((offset & 0xFF00u) << g.length_bits) | (((len - g.lz_min_length) & ((1u << g.length_bits) - 1u)) << 8);
                 b0 = v & 0xFF; b1 = (v >> 8) & 0xFF; psize = 2;
+            } else if (FMT == ALZ_FMT_BLZ) {                           // BLZ.cs:172: distance - 3
+                const u32 v = (((len - 3u) << 12) | ((mt.x - 3u) & 0xFFFu)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
             } else if (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_MIO0) {
                 const u32 v = (((len - 3u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
             } else if (FMT == ALZ_FMT_LZ40) {                          // u16 LE distance << 4 | length (+ 1 or 2 length bytes)
@@ -767,9 +769,10 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_SNAPPY_RAW: wb = 15; g.min_len = 4; g.max_len = 64; g.max_dist = 0x8000; break;
     case ALZ_FMT_FASTLZ: wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; break;      // level 1  FastLZ.cs:22
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
+    case ALZ_FMT_BLZ: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;                          // BLZ.cs:24 (+ minDistance 3 below)
     default: return false;
     }
-    g.min_dist = st->min_distance > 0 ? st->min_distance : 1;
+    g.min_dist = st->min_distance > 0 ? st->min_distance : (fmt == ALZ_FMT_BLZ ? 3 : 1);
     const int q = st->quality;
     g.max_chain = q < 6 ? q + 1 : q >= 11 ? 1 << (q - 5) : ((1 << (q >> 1)) | ((1 << (q >> 1)) >> (q & 1)));
     g.lazy = 3 + q / 3;
@@ -825,6 +828,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

@@ -114,9 +114,13 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         dec_fastlz_serial(in, sk, s, src_len, fz);
     } else if constexpr (FMT == ALZ_FMT_CNX2) {
         has_size = true; dec_cnx2_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_BLZ) {
+        has_size = true; dec_blz_serial(in, sk, s, src_len, size < cap ? size : cap);
     }
     out.finish();
-    write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, has_size, out.produced, size, cap), hist);
+    int status = resolve_status(s, has_size, out.produced, size, cap);
+    if (FMT == ALZ_FMT_BLZ && status == ALZ_ST_OK && out.produced != size) status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // the span must be full  BLZ.cs:131
+    write_result(&results[sid], lane, out, used_set ? used : s.p, status, hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -156,7 +160,20 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     u32 used = 0; bool used_set = false;
     bool fin = false;
 
-    if constexpr (FMT == ALZ_FMT_LZHUDSON) {
+    if constexpr (FMT == ALZ_FMT_BLZ) {
+        // exact parser while a match could still point beyond the span (an error here, not zeros) and for the end of the
+        // stream (matches cut at the span end, the span-must-be-full rule); LZ10's lane-parallel loop in between, kept away
+        // from the span end by more than one iteration can produce (64 tokens x 18 bytes)
+        typedef DirectSink<OutWin<false>> SK; SK sk(out, s);
+        const u32 L = size < cap ? size : cap;
+        dec_blz_serial(in, sk, s, src_len, L, 4098u);
+        if (!s.eof && !s.bad && !s.ovf) {
+            FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
+            bool to_serial = false;
+            while (!to_serial && (u64)out.produced + 1152u < L && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, L, src_len, to_serial, segmark, lane, gm);
+            dec_blz_serial(in, sk, s, src_len, L);
+        }
+    } else if constexpr (FMT == ALZ_FMT_LZHUDSON) {
         while (!fin && out.produced < size && (u64)s.p + 128u <= src_len) fin = fast_iter_lzhudson(in, out, s, size, segmark, lane);
         if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
     } else if constexpr (!THREE) {
@@ -202,7 +219,9 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         }
     }
     out.finish();
-    write_result(&results[sid], lane, out, used_set ? used : s.p, resolve_status(s, true, out.produced, size, cap));
+    int status = resolve_status(s, true, out.produced, size, cap);
+    if (FMT == ALZ_FMT_BLZ && status == ALZ_ST_OK && out.produced != size) status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // the span must be full  BLZ.cs:131
+    write_result(&results[sid], lane, out, used_set ? used : s.p, status);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,6 +396,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_SNAPPY_RAW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_SNAPPY_RAW>, 64, 0); break;
     case ALZ_FMT_FASTLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_FASTLZ>, 64, 0); break;
     case ALZ_FMT_CNX2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNX2>, 64, 0); break;
+    case ALZ_FMT_BLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_BLZ, 8192>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZHUDSON>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_SMSR00>, 64 * ALZ_WPB, 0); break;
     default: break;
@@ -416,6 +436,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_SNAPPY_RAW: return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_FASTLZ: return launch_queue<ALZ_FMT_FASTLZ>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_CNX2: return launch_queue<ALZ_FMT_CNX2>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_BLZ: return launch_fast<ALZ_FMT_BLZ, 8192>(stream, s, d, streams, index, count, results, lz, 8192, 1);
         default: break;
         }
     }
@@ -440,6 +461,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_SNAPPY_RAW: return launch_serial<ALZ_FMT_SNAPPY_RAW, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_FASTLZ: return launch_serial<ALZ_FMT_FASTLZ, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_CNX2: return launch_serial<ALZ_FMT_CNX2, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_BLZ: return launch_serial<ALZ_FMT_BLZ, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     default: return hipErrorInvalidValue;
     }
 }

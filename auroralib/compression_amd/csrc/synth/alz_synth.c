@@ -351,6 +351,27 @@ static void gen_cnx2(rng_t* r, uint32_t target, out_t* out) {
     if (ncodes) { o_u8(out, flag); o_put(out, pay, plen); }
 }
 
+/* ---- BLZ in stream order (Nintendo/BLZ.cs:97-135 read back to front): flag bytes MSB first, 1 = match, big-endian u16
+ * (length - 3) << 12 | (distance - 3); the stream ends exactly where the output is full ---- */
+static void gen_blz(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    uint8_t pay[16]; uint32_t plen = 0, flag = 0, nbits = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        int match = produced >= 3 && rem >= 3 && rng_unit(r) < 0.5;
+        if (match) {
+            tok_t t = draw_match(r, produced, rem, 3, 18, 0, 0, 4098);
+            if (t.dist < 3) t.dist = 3;
+            if (t.len < 3) t.len = 3;
+            uint32_t v = ((t.len - 3) << 12) | (t.dist - 3);
+            pay[plen++] = (uint8_t)(v >> 8); pay[plen++] = (uint8_t)v;
+            flag |= 0x80u >> nbits; produced += t.len;
+        } else { pay[plen++] = (uint8_t)rng_next(r); produced += 1; }
+        if (++nbits == 8) { o_u8(out, flag); o_put(out, pay, plen); plen = 0; flag = 0; nbits = 0; }
+    }
+    if (nbits) { o_u8(out, flag); o_put(out, pay, plen); }
+}
+
 /* ---- LZO (opcode forms of Formats/Common/LZO.cs:141-250) ---- */
 static void lzo_ext(out_t* o, uint32_t v) { while (v > 255) { o_u8(o, 0); v -= 255; } o_u8(o, v); }
 static void gen_lzo(rng_t* r, uint32_t target, out_t* out) {
@@ -430,6 +451,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_LZ4_BLOCK: gen_lz4(&r, target, &out); break;
     case ALZ_FMT_FASTLZ: gen_fastlz(&r, target, &out); break;
     case ALZ_FMT_CNX2: gen_cnx2(&r, target, &out); break;
+    case ALZ_FMT_BLZ: gen_blz(&r, target, &out); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
     default: return -2;

@@ -216,6 +216,11 @@ class LZSega(_Format):
     container = A.C_LZSEGA
 
 
+class BLZ(_Format):
+    """src/AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs -- backwards LZ: code section stored back to front + footer."""
+    container = A.C_BLZ
+
+
 class CNX2(_Format):
     """src/AuroraLib.Compression.Sega/Sega/CNX2.cs -- 2-bit codes (skip / literal / match / literal run), 2 KiB window."""
     container = A.C_CNX2
@@ -334,5 +339,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ00, FastLZ, CNX2, LZ77, Level5]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ00, FastLZ, CNX2, BLZ, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

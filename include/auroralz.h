@@ -53,7 +53,11 @@ typedef enum alz_format {
                                 src/AuroraLib.Compression/Formats/Common/FastLZ.cs:54-160.  SURVEY.md 8f rank 4. */
     ALZ_FMT_CNX2       = 15, /* CNX2.DecompressHeaderless: 2-bit codes (skip / literal / match / literal run), 2 KiB window
                                 src/AuroraLib.Compression.Sega/Sega/CNX2.cs:83-139.  SURVEY.md 8f rank 4. */
-    ALZ_FMT_COUNT      = 16
+    ALZ_FMT_BLZ        = 16, /* BLZ.DecompressHeaderless in stream order: the managed code walks both spans from their ends
+                                (src/AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:97-135), so `src` is the code section REVERSED and
+                                `dst` receives the output REVERSED (alz_container_* does both reversals); decom_len = the length of
+                                the destination span.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_COUNT      = 17
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -252,8 +256,10 @@ typedef enum alz_container {
                           src/AuroraLib.Compression.Sega/Sega/LZ00.cs:40-96, :128-141 (see alz_container_options.key) */
     ALZ_C_FASTLZ = 34, /* headerless FastLZ stream, levels 1 / 2 (IsMatch = FastLZ.Validate; written at level 1)
                           src/AuroraLib.Compression/Formats/Common/FastLZ.cs:29-52, :246-291 */
+    ALZ_C_BLZ    = 36, /* code section (stored back to front) + 0xFF padding + u24 LE total size + header size + i32 LE size delta
+                          src/AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:28-95 */
     ALZ_C_CNX2   = 35, /* "CNX\x02" + extension[4] + BE csize + BE size + CNX2 body   src/AuroraLib.Compression.Sega/Sega/CNX2.cs:45-81 */
-    ALZ_C_COUNT  = 36
+    ALZ_C_COUNT  = 37
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

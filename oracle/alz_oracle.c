@@ -512,6 +512,34 @@ static void dec_lz4(cur_t* c, win_t* w) {
     c->pos = sp;
 }
 
+/* BLZ.DecompressHeaderless  Nintendo/BLZ.cs:97-135, restated in stream order: both spans are walked from their ends, so
+ * here `c` is the code section reversed and the window receives the output reversed (the container layer reverses both).
+ * L = length of the destination span.  A match is cut silently where the span ends (:121 `dst > 0`); a literal there, a
+ * read behind the input, or a match source beyond the span end are IndexOutOfRangeExceptions; decoding stops when the
+ * input is used up and the span must then be full (:131). */
+static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* short_out) {
+    const uint8_t* s = c->p; uint32_t n = c->len, sp = 0; uint32_t flags = 0, mask = 0;
+    uint64_t L = size < w->cap ? size : w->cap;
+    while (sp < n) {                                                                     /* :104 */
+        if ((mask >>= 1) == 0) { flags = s[sp++]; mask = 0x80; }
+        if ((flags & mask) == 0) {
+            if (win_produced(w) >= L) { w->overflow = 1; w->attempted_end = win_produced(w) + 1; c->pos = sp; return; }   /* destination[--dst] */
+            if (sp >= n) { c->eof = 1; c->pos = sp; return; }                            /* source[--src] */
+            win_write_byte(w, s[sp++]);
+        } else {
+            if (sp + 2 > n) { c->eof = 1; c->pos = n; return; }
+            uint32_t inf = ((uint32_t)s[sp] << 8) | s[sp + 1]; sp += 2;
+            uint32_t distance = (inf & 0x0FFF) + 3, length = ((inf >> 12) & 0xF) + 3;
+            uint64_t room = L - win_produced(w);
+            if (length > room) length = (uint32_t)room;
+            if (length && distance > win_produced(w)) { info->bad_token = 1; c->pos = sp; return; }   /* destination[dst - 1 + distance] */
+            win_back_copy(w, distance, length);
+        }
+    }
+    c->pos = sp;
+    if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
+}
+
 /* CNX2.DecompressHeaderless  Sega/CNX2.cs:83-139: FlagReader(source, Endian.Little), ReadInt(2) = two bits, first one is
  * bit 0 (FlagReader.cs:75-87); code 0 skips `n` bytes and drops the rest of the flag byte (Reset, :102). */
 static void dec_cnx2(cur_t* c, win_t* w, uint32_t size) {
@@ -723,6 +751,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: return 12; /* LZ10.cs:25 ... */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
+    case ALZ_FMT_BLZ: return 13;                           /* flat spans in the managed code; distances reach 0xFFF + 3 */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
     }
@@ -743,7 +772,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     if (hist) { flat = 1; w.flat = 1; w.dst -= hist; w.cap += hist; w.flushed = hist; }
     if (!flat) w.ring = (uint8_t*)calloc(w.W, 1); /* E2: zero-filled */
     dec_info info = { 0, 0, 0 };
-    int terminated = 1; uint32_t used = 0; int used_set = 0;
+    int terminated = 1; uint32_t used = 0; int used_set = 0; int blz_short = 0;
     uint32_t size = s->decom_len;
 
     switch (s->format) {
@@ -782,6 +811,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_SNAPPY_RAW: dec_snappy(&c, &w, &info); break;
     case ALZ_FMT_FASTLZ: dec_fastlz(&c, &w, &info); break;
     case ALZ_FMT_CNX2: info.has_size = 1; dec_cnx2(&c, &w, size); break;
+    case ALZ_FMT_BLZ: info.has_size = 1; dec_blz(&c, &w, size, &info, &blz_short); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -796,7 +826,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     else if (info.bad_token) r->status = ALZ_ST_BAD_TOKEN;
     else if (w.overflow)
         r->status = (info.has_size && w.attempted_end > size && w.cap >= size) ? ALZ_ST_OUTPUT_SIZE_MISMATCH : ALZ_ST_OUTPUT_CAPACITY;
-    else if (info.has_size && produced > size) r->status = ALZ_ST_OUTPUT_SIZE_MISMATCH; /* LZ10.cs:107 '>' ; LZSS.cs:126 '!=' (same: loop ran to >= size) */
+    else if (info.has_size && (produced > size || blz_short)) r->status = ALZ_ST_OUTPUT_SIZE_MISMATCH; /* LZ10.cs:107 '>' ; LZSS.cs:126 '!=' (same: loop ran to >= size); BLZ.cs:131 */
     else r->status = ALZ_ST_OK;
 }
 
@@ -1076,6 +1106,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_SNAPPY_RAW: p = (fmt_props){ 15, 64, 4, 0x8000, 1 }; break;             /* Snappy.cs:28 */
     case ALZ_FMT_FASTLZ: p = (fmt_props){ 13, 255 + 3 + 6, 3, 0x2000, 1 }; break;        /* level 1  FastLZ.cs:22 */
     case ALZ_FMT_CNX2: p = (fmt_props){ 11, 0x1F + 4, 4, 0x800, 1 }; break;               /* CNX2.cs:25 */
+    case ALZ_FMT_BLZ: p = (fmt_props){ 12, 18, 3, 0x1000, 3 }; break;                     /* BLZ.cs:24 (minDistance 3) */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1373,6 +1404,25 @@ static void enc_snappy(const alz_settings* st, const uint8_t* src, int n, buf_t*
     mf_free(&m);
 }
 
+/* BLZ.CompressHeaderless  Nintendo/BLZ.cs:137-216 in stream order (src = the raw data reversed, :148-150): the managed code
+ * fills its buffer from the end, flag byte first, so read backwards it is a flag byte (MSB first, 1 = match) followed by
+ * its tokens; a flag byte exists only if a token follows it (:180-197). */
+static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_BLZ, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 1);
+    int sp = 0;
+    while (sp < n) {                                                                     /* :152 */
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 0); }
+        if (match.length == 0) break;
+        buf_u16be(&flag.buffer, (uint32_t)(((match.length - 3) << 12) | ((match.distance - 3) & 0xFFF)) & 0xFFFF);
+        sp += match.length;
+        fw_bit(&flag, 1);
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
 /* CNX2.CompressHeaderless  Sega/CNX2.cs:140-172: FlagWriter(destination, Endian.Little), WriteInt(v, 2) = bit 0 first */
 static void enc_cnx2(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
     fmt_props p = props_for(ALZ_FMT_CNX2, NULL, st);
@@ -1473,6 +1523,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_SNAPPY_RAW: enc_snappy(st, src, (int)n, &out); break;
     case ALZ_FMT_FASTLZ: rc = enc_fastlz(st, src, (int)n, &out); break;
     case ALZ_FMT_CNX2: enc_cnx2(st, src, (int)n, &out); break;
+    case ALZ_FMT_BLZ: enc_blz(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1560,6 +1611,11 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ60.cs:29-41 */
     case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 48); return 0;      /* Sega/LZ00.cs:31-37 */
     case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;    /* Sega/CNX2.cs:36-42 */
+    case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
+        if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
+        uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
+        *size_out = rd32le(src + len - 4) + csz; return 0;
+    }
     case ALZ_C_YAZ0: if (len < 8 || memcmp(src, "Yaz0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* Yaz0.cs:50-55 */
     case ALZ_C_YAY0: if (len < 8 || memcmp(src, "Yay0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 4); return 0;           /* Yay0.cs:41-47 reads Endian.Big */
     case ALZ_C_MIO0: if (len < 8 || memcmp(src, "MIO0", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 4, big); return 0;      /* MIO0.cs:41-48 */
@@ -1869,6 +1925,26 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         size = be32(src + 8); hdr = 16;
         uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_BLZ: {                                                                    /* Nintendo/BLZ.cs:43-69 */
+        if (len < 8) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
+        uint32_t hp = src[len - 5];
+        if (hp < 8) return ALZ_E_FORMAT;                                                 /* "Invalid BLZ header." */
+        size = rd32le(src + len - 4) + csz;
+        if (csz > len || hp > csz) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }         /* Position before the stream start / negative codeSize */
+        uint32_t code = csz - hp;
+        if ((uint64_t)size > dst_cap) { r.status = ALZ_ST_OUTPUT_CAPACITY; break; }
+        uint8_t* rev = (uint8_t*)malloc(code + 1); uint8_t* tmp = (uint8_t*)malloc((size_t)size + 1);
+        if (!rev || !tmp) { free(rev); free(tmp); return ALZ_E_NOMEM; }
+        const uint8_t* cs = src + (len - csz);
+        for (uint32_t i = 0; i < code; i++) rev[i] = cs[code - 1 - i];
+        run_stream(ALZ_FMT_BLZ, NULL, rev, code, size, 0, 0, tmp, size, &r);
+        if (r.status == ALZ_ST_OK) for (uint32_t i = 0; i < size; i++) dst[i] = tmp[size - 1 - i];
+        else r.dst_len = 0;                                                              /* the managed code writes nothing when the body throws (:62-64) */
+        free(rev); free(tmp);
+        r.src_used = (uint32_t)len; hdr = 0;
         break;
     }
     case ALZ_C_CNX2:                                                                     /* Sega/CNX2.cs:45-62 */
@@ -2228,6 +2304,24 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
         break;
+    case ALZ_C_BLZ: {                                                                    /* Nintendo/BLZ.cs:71-95 */
+        uint8_t* rev = (uint8_t*)malloc(n + 1); uint8_t* tmp = (uint8_t*)malloc(n + n / 4 + 64);
+        if (!rev || !tmp) { free(rev); free(tmp); return ALZ_E_NOMEM; }
+        for (size_t i = 0; i < n; i++) rev[i] = src[n - 1 - i];
+        body = oracle_encode_stream(ALZ_FMT_BLZ, NULL, &st, rev, n, tmp, n + n / 4 + 64, NULL);
+        free(rev);
+        if (body < 0) { free(tmp); return ALZ_E_NOMEM; }
+        uint32_t total = (uint32_t)body + 8; uint32_t pad = (16 - (total % 16)) % 16; total += pad;
+        if (cap < total) { free(tmp); return ALZ_E_NOMEM; }
+        for (int64_t i = 0; i < body; i++) dst[i] = tmp[body - 1 - i];                   /* the buffer was filled from its end: stored back to front */
+        free(tmp);
+        memset(dst + body, 0xFF, pad);
+        uint8_t* f = dst + body + pad;
+        f[0] = (uint8_t)total; f[1] = (uint8_t)(total >> 8); f[2] = (uint8_t)(total >> 16); f[3] = (uint8_t)(8 + pad);
+        wr32(f + 4, (uint32_t)((int64_t)n - (int64_t)total), 0);
+        hdr = 0; body = total;
+        break;
+    }
     case ALZ_C_CNX2:                                                                     /* Sega/CNX2.cs:64-81: Extension "DEC" padded with 0x10 */
         if (cap < 16) return ALZ_E_NOMEM;
         hdr = 16;
