@@ -39,7 +39,9 @@ def main():
                     items.append(dict(fmt=fmt, src=comp, decom_len=len(raw), aux0=aux.aux0, aux1=aux.aux1))
                 streams, src, dst_bytes = pack_streams(items)
                 gr, _ = compare_batch(streams, src, dst_bytes, what="real %s seed %d" % (A.FORMAT_NAMES[fmt], seed))
-                assert (gr["status"] == 0).all()
+                # (LZO: the managed encoder can drop a shortened match and write two literal-run instructions in a row, which its
+                #  own decoder reads differently -- DESIGN.md, reference quirks; the oracle reproduces that, so no OK assertion)
+                assert fmt == A.FMT_LZO or (gr["status"] == 0).all(), "real %s seed %d: status not OK" % (A.FORMAT_NAMES[fmt], seed)
                 # encoder: windows (some degenerate) as one batch at one quality, bytes + aux against the oracle's encoder
                 q = int(rng.integers(0, 16))
                 raws = []
