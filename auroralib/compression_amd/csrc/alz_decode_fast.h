@@ -804,18 +804,28 @@ __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState&
     for (;;) {
         parse.commit();
         s.p += adv;
-        EmitState e; u32 last;
+        u32 last;
         const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
         const u32 desc = (qt & 0x20000u) ? (0x80000000u | lo) : lo;
-        emit_begin<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, lane, last, W, e);
         bool more = false;
         u32 qt2 = 0, nt2 = 0, total2 = 0, adv2 = 0;
         const u32 p = s.p;
-        if ((u64)p + 1100u <= src_len && !(p + in.lo + 1024u > in.cb + 2048u)) {       // next round: input ahead, cache already covers it
-            more = parse(p, qt2, nt2, total2, adv2);
-            if (more && total2 > maxout - (e.O + e.T)) more = false;
+        const bool ahead = (u64)p + 1100u <= src_len && !(p + in.lo + 1024u > in.cb + 2048u);   // next round: input ahead, cache already covers it
+        if constexpr (CFG::FALLBACK) {
+            EmitState e;
+            emit_begin<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, lane, last, W, e);
+            if (ahead) {
+                more = parse(p, qt2, nt2, total2, adv2);
+                if (more && total2 > maxout - (e.O + e.T)) more = false;
+            }
+            emit_finish<OW, CFG>(out, segmark, inlds, lane, e);
+        } else {                                                   // whole window in LDS: nothing to overlap, the fused byte phase is cheaper
+            (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, inlds, lane, last, W);
+            if (ahead && !s.ovf) {
+                more = parse(p, qt2, nt2, total2, adv2);
+                if (more && total2 > maxout - out.produced) more = false;
+            }
         }
-        emit_finish<OW, CFG>(out, segmark, inlds, lane, e);
         if (!more) break;
         qt = qt2; nt = nt2; total = total2; adv = adv2;
     }
@@ -877,6 +887,72 @@ __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane,
 struct SnappyRounds {
     InCache& in; int lane;
     __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return snappy_parse_round(in, p, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
+// Lane-parallel CNX2 parse (CNX2.cs:83-139).  The unit of speculation is the GROUP -- a flag byte and the up to four
+// tokens its 2-bit codes announce --: every lane works out how long "the group that would start at my byte" is (four
+// dependent steps, because a literal run's length byte decides where the next token starts), the scalar walk hops from
+// group to group, and lane 4 g + k then decodes token k of the g-th real group (codes 0 -- skip, which also drops the rest
+// of its flag byte -- and empty runs yield no token, so the tokens are compacted through `stage`).  Groups longer than 700
+// bytes are left to the exact parser.  Precondition: at a flag-byte boundary (s.bits == 0).  `total` is reported one too
+// high so that the round in which the output reaches the declared size is refused: what follows that point in the group
+// must not be consumed (the exact parser stops there).
+__device__ __forceinline__ void cnx2_step(const InCache& in, u32 base, u32 f, int k, u32& off, bool& live, u32& code, u32& b) {
+    code = (f >> (2 * k)) & 3u;
+    b = in.lds[(base + off) & 2047u];
+    const u32 sz = code == 1u ? 1u : (code == 2u ? 2u : 1u + b);
+    if (!live) code = 0xFFu;                                         // behind a skip: not a token
+    off += live ? sz : 0u;
+    live = live && code != 0u;
+}
+__device__ __forceinline__ bool cnx2_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 f = in.lds[pos];
+        u32 off = 1, code, b; bool live = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnx2_step(in, pos, f, k, off, live, code, b);
+        nx[w] = off > 700u ? ALZ_NX_BAD : off;
+    }
+    u32 spos, sp, ng;
+    lane_walk_pos(nx, 16u, spos, sp, ng);                              // a group has >= 2 bytes: <= 32 per window
+    if (ng > 16u) { ng = 16u; sp = wave_readlane(spos, 16u); }         // 16 groups x 4 tokens fill the queue
+    if (ng == 0u) return false;
+    const u32 g = (u32)lane >> 2;
+    const u32 gs = i0 + wave_bperm(g, spos);
+    const u32 f = in.lds[gs & 2047u];
+    u32 off = 1, code = 0, b = 0; bool live = true;
+    u32 toff = 1, tcode = 0xFFu, tb = 0;                               // my token: offset of its first byte, code, that byte
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 o = off;
+        cnx2_step(in, gs, f, k, off, live, code, b);
+        if (((u32)lane & 3u) == (u32)k) { toff = o; tcode = code; tb = b; }
+    }
+    const u32 tp = gs + toff;
+    u32 t = 0;
+    if (tcode == 1u) t = ALZ_TOK_LIT(1u, tp & 2047u);
+    else if (tcode == 2u) { const u32 pair = (tb << 8) | in.lds[(tp + 1u) & 2047u]; t = ALZ_TOK_MATCH((pair & 0x1Fu) + 4u, (pair >> 5) + 1u); }
+    else if (tcode == 3u && tb != 0u) t = ALZ_TOK_LIT(tb, (tp + 1u) & 2047u);
+    const bool valid = g < ng && t != 0u;
+    const u64 vm = __ballot(valid);
+    const u32 nv = (u32)__popcll(vm);
+    if (nv == 0u) return false;
+    if (valid) stage[mbcnt64(vm)] = t;
+    wave_sync();
+    const u32 qt = (u32)lane < nv ? stage[lane] : 0u;
+    wave_sync();
+    qt_out = qt; nt_out = nv; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63) + 1u;
+    return true;
+}
+struct Cnx2Rounds {
+    InCache& in; u32* stage; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return cnx2_parse_round(in, p, stage, lane, qt, nt, total, adv); }
     __device__ __forceinline__ void commit() {}
 };
 

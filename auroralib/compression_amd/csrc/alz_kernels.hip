@@ -314,7 +314,20 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
         }
     }
     else if constexpr (CNX) {
-        dec_cnx2_serial(in, sk, s, src_len, uni(st.decom_len));          // exact parser on the scalar unit, tokens executed 64 at a time
+        // bulk: lane-parallel rounds of whole groups while >= 1100 input bytes remain; the exact parser for a group the
+        // rounds decline, to get back to a flag-byte boundary, and for the end of the stream
+        const u32 size = uni(st.decom_len);
+        for (;;) {
+            if (s.bits == 0 && s.p + 1100u <= src_len && sk.produced() < size) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                Cnx2Rounds rounds{in, stage, lane};
+                if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 2048u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_cnx2_serial(in, sk, s, src_len, size, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
+        }
     }
     else if constexpr (FMT == ALZ_FMT_FASTLZ) {
         FastlzState fz; fastlz_state_init(fz);
