@@ -1254,6 +1254,10 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
     sk.qtok = qt; sk.nt = nt; sk.qbytes = total;
     s.p = p + pos; fl_io = fl;
     if (term) s.done = true;                                   // PRS.cs:78-79: the zero word ends the stream
+#if defined(ALZ_QEXP) && ALZ_QEXP == 2
+    sk.out.produced += total; sk.nt = 0; sk.qbytes = 0; if (qt == 0x12345u) stage[lane] = qt;   // timing experiment: parse only
+#else
     sk.flush();
+#endif
     return true;
 }
