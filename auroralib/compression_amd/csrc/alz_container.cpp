@@ -1090,6 +1090,9 @@ static const struct { const char* name; uint32_t format; uint8_t wb, lb, th; } k
     { "LZSS0", ALZ_FMT_LZSS, 12, 4, 2 },                                   // LzProperties(0x1000, 0xF + 3, 3, 0xFEE) == (12, 4, 2)  LZSS.cs:34
     { "PRS big", ALZ_FMT_PRS_BE, 0, 0, 0 }, { "PRS Little", ALZ_FMT_PRS_LE, 0, 0, 0 },
     { "LZ10", ALZ_FMT_LZ10, 0, 0, 0 }, { "LZ11", ALZ_FMT_LZ11, 0, 0, 0 }, { "Yaz0", ALZ_FMT_YAZ0, 0, 0, 0 },
+    { "LZ40", ALZ_FMT_LZ40, 0, 0, 0 }, { "LZHudson", ALZ_FMT_LZHUDSON, 0, 0, 0 },
+    // (the command's "BLZ" entry decodes into MemoryStream.GetBuffer() and never advances Position, :121 -- it cannot
+    //  report success, so it is not offered here)
 };
 
 }  // namespace
