@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -356,8 +357,12 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     int rc;
     if ((rc = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return rc;
     if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return rc;
-    // streams are processed in chunks so that the per-stream head tables (4 B << hash_bits each) stay bounded
-    const uint32_t CH = 4096;
+    // streams are processed in chunks so that the per-stream head tables (4 B << hash_bits each) stay bounded: 16 GiB of
+    // tables per chunk (Q0: every stream at once, Q8: 8 192, Q15: 4 096) -- kernel A is bound by the latency of its
+    // head-table round trips, so a chunk should at least fill the device's 8 192 wave slots
+    uint32_t CH = 4096;
+    { const uint64_t per = (uint64_t)sizeof(int) << hash_bits; const uint64_t fit = (16ull << 30) / per; if (fit > CH) CH = fit > 0x100000ull ? 0x100000u : (uint32_t)fit; }
+    if (const char* e = getenv("ALZ_ENC_CHUNK")) { const long v = atol(e); if (v >= 64) CH = (uint32_t)v; }   // tuning knob
     EncScratch sc;
     alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
     uint64_t* d_pos = nullptr; int *d_head4 = nullptr, *d_headm = nullptr, *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr, *d_mask = nullptr;
