@@ -21,10 +21,14 @@
 // The serial decoders (alz_decode_serial.h) remain the exact reference: the fast loop runs to the last complete token of
 // the input and hands the stream tail -- and every error path -- to them.
 //
+// (Also here: the lane-parallel iterations of SMSR00 and LZHudson; BLZ runs LZ10's iteration with its own distance bias.)
+//
 // Second half of the file: the token queue (QueueSink) that lets the byte phase execute tokens of ANY grammar, and the
 // lane-assisted parsers that fill it for the grammars whose token boundaries can only be found by walking the stream:
-// LZ4 / Snappy / LZO (per-byte speculation "the element that would start here" + a scalar v_readlane walk) and PRS
-// (per-byte token interpretations + a scalar walk over a VGPR-resident window with the flag register in an SGPR).
+// LZ4 / Snappy / LZO / FastLZ (per-byte speculation "the element that would start here" + a scalar v_readlane walk that
+// hands element j to lane j), CNX2 (the same with whole flag-byte groups as elements) and PRS (per-byte token
+// interpretations + a scalar walk over a VGPR-resident window with the flag register in an SGPR).  pipelined_rounds
+// executes the rounds of the first five, overlapping the HBM read-backs of one round with the parse of the next.
 #pragma once
 #include "alz_decode_serial.h"
 

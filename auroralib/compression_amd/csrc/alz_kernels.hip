@@ -225,7 +225,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 }
 
 // ------------------------------------------------------------------------------------------------
-// Token-queue kernel (PRS, LZ4, LZO, Snappy): scalar parse into a 64-token queue, lane-parallel execution (QueueSink).
+// Token-queue kernel (PRS, LZ4, LZO, Snappy, FastLZ, CNX2): lane-assisted / scalar parse into a 64-token queue, lane-parallel
+// execution (pipelined_rounds for the bulk, QueueSink behind the exact parsers).
 template <int FMT>
 __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                               const alz_stream* __restrict__ streams,
