@@ -364,6 +364,7 @@ template <int FMT> struct FamTraits;
 // nibble is the low one of the first token byte (LZ40) instead of the high one; NEG: the flag byte is stored negated (LZ40)
 template <> struct FamTraits<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT1 = true,  H3 = false, H4 = false, NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_CLZ0> { static constexpr bool MSB = false, LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_BLZ>  { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };   // LZ10's grammar in stream order, distance - 3
 template <> struct FamTraits<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true,  NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_YAZ0> { static constexpr bool MSB = true,  LIT1 = true,  H3 = true,  H4 = false, NIBLO = false, NEG = false; };
@@ -440,6 +441,8 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
             desc = ALZ_DESC_MATCH(offset); tend = to + 2;
         } else if (FMT == ALZ_FMT_LZ10) {
             desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 1u); len = (b1 >> 4) + 3u; tend = to + 2;
+        } else if (FMT == ALZ_FMT_CLZ0) {
+            desc = ALZ_DESC_MATCH(0x1000u - (b1 | ((b2 >> 4) << 8))); len = (b2 & 0xFu) + 3u; tend = to + 2;   // CLZ0.cs:76-78
         } else if (FMT == ALZ_FMT_BLZ) {
             desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 3u); len = (b1 >> 4) + 3u; tend = to + 2;   // BLZ.cs:117-118
         } else if (FMT == ALZ_FMT_LZ11) {

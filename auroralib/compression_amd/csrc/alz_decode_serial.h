@@ -104,6 +104,27 @@ __device__ void dec_lz1x_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u
     }
 }
 
+// CLZ0.DecompressHeaderless  Marvelous/CLZ0.cs:64-97: flags LSB first, 1 = match; delta = b1 | (b2 >> 4) << 8, distance = 0x1000 - delta,
+// length = (b2 & 15) + 3.  (ReadByte() == -1 inside a match is refused as truncated input, see the oracle.)
+template <class SK>
+__device__ void dec_clz0_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
+    while (sk.produced() < size) {
+        sk.ensure(in, s.p, 8);
+        if (s.bits == 0) { if (s.p >= src_len) { s.eof = true; return; } s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        const u32 bit = (s.flag >> (8 - s.bits)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p + 2 > src_len) { s.eof = true; s.p = src_len; return; }
+            const u32 w = in.peek4(s.p); s.p += 2;
+            const u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF;
+            if (!sk.match(0x1000u - (b1 | ((b2 >> 4) << 8)), (b2 & 0xFu) + 3u, 4096)) return;
+        } else {
+            if (s.p >= src_len) { s.eof = true; return; }
+            const u32 b = in.peek1(s.p); s.p++;
+            if (!sk.lit(b)) return;
+        }
+    }
+}
+
 // LZ40.DecompressHeaderless  Nintendo/LZ40.cs:80-132 (also LZ60's body).  s.flag holds the flag byte already negated
 // (:92), bits MSB first, 1 = match; tokens are u16 LE distance << 4 | length nibble, nibble 0 / 1 = one / two more
 // length bytes; distance 0 is what the encoder writes for 4096 (E1).

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || THREE);   // flag bit of a literal token
-    constexpr bool MSB = (FMT != ALZ_FMT_LZSS);
+    constexpr bool MSB = (FMT != ALZ_FMT_LZSS && FMT != ALZ_FMT_CLZ0);
     __shared__ u32 flagacc[16];
     __shared__ u32 gofs[16];
     const u32 bid = blockIdx.x;
@@ -673,6 +673,8 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
                 const u32 offset = (g.windows_start + p - mt.x) & (g.lz_max_distance - 1u);
                 const u32 v = (offset & 0xFFu) | ((offset & 0xFF00u) << g.length_bits) | (((len - g.lz_min_length) & ((1u << g.length_bits) - 1u)) << 8);
                 b0 = v & 0xFF; b1 = (v >> 8) & 0xFF; psize = 2;
+            } else if (FMT == ALZ_FMT_CLZ0) {                          // CLZ0.cs:121-124: delta = 0x1000 - distance
+                const u32 delta = 0x1000u - mt.x; b0 = delta & 0xFF; b1 = ((len - 3u) | ((delta >> 8) << 4)) & 0xFF; psize = 2;
             } else if (FMT == ALZ_FMT_BLZ) {                           // BLZ.cs:172: distance - 3
                 const u32 v = (((len - 3u) << 12) | ((mt.x - 3u) & 0xFFFu)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
             } else if (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_MIO0) {
@@ -760,7 +762,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     switch (fmt) {
     case ALZ_FMT_LZSS:
         wb = lz->window_bits; g.min_len = lz->min_length; g.max_len = (1 << lz->length_bits) + lz->min_length - 1; g.max_dist = (int)lz->max_distance; break;
-    case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;
+    case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;
     case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: g.min_len = 3; g.max_len = 0x4000; g.max_dist = 0x1000; break;
     case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_LZHUDSON: g.min_len = 3; g.max_len = 0xff + 0x12; g.max_dist = 0x1000; break;
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: wb = 13; g.min_len = 2; g.max_len = 0x100; g.max_dist = 0x1FFF; break;
@@ -828,6 +830,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_CLZ0: launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

@@ -57,7 +57,9 @@ typedef enum alz_format {
                                 (src/AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:97-135), so `src` is the code section REVERSED and
                                 `dst` receives the output REVERSED (alz_container_* does both reversals); decom_len = the length of
                                 the destination span.  SURVEY.md 8f rank 4. */
-    ALZ_FMT_COUNT      = 17
+    ALZ_FMT_CLZ0       = 17, /* CLZ0.DecompressHeaderless: LZSS family, flags LSB first with 1 = match, distance = 0x1000 - delta
+                                src/AuroraLib.Compression-Extended/Marvelous/CLZ0.cs:64-97.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_COUNT      = 18
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -258,8 +260,9 @@ typedef enum alz_container {
                           src/AuroraLib.Compression/Formats/Common/FastLZ.cs:29-52, :246-291 */
     ALZ_C_BLZ    = 36, /* code section (stored back to front) + 0xFF padding + u24 LE total size + header size + i32 LE size delta
                           src/AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:28-95 */
+    ALZ_C_CLZ0   = 37, /* "CLZ\0" + BE size + BE 0 + BE size + CLZ0 body   src/AuroraLib.Compression-Extended/Marvelous/CLZ0.cs:41-62 */
     ALZ_C_CNX2   = 35, /* "CNX\x02" + extension[4] + BE csize + BE size + CNX2 body   src/AuroraLib.Compression.Sega/Sega/CNX2.cs:45-81 */
-    ALZ_C_COUNT  = 37
+    ALZ_C_COUNT  = 38
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

@@ -540,6 +540,28 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* CLZ0.DecompressHeaderless  Marvelous/CLZ0.cs:64-97: FlagReader(source, Endian.Little), 1 = match.  (The two match
+ * bytes are read with Stream.ReadByte(), which returns -1 at the end instead of throwing: the managed code then copies 18
+ * bytes from a garbage distance before its next flag read throws EndOfStreamException -- refused here before the copy.) */
+static void dec_clz0(cur_t* c, win_t* w, uint32_t size) {
+    flag_t flag = { c, 0, 0, 0, 1 };
+    while (win_produced(w) < size) {
+        int bit = flag_readbit(&flag); if (c->eof) return;
+        if (bit) {
+            int b1 = cur_u8(c); if (c->eof) return;
+            int b2 = cur_u8(c); if (c->eof) return;
+            uint32_t delta = (uint32_t)b1 | ((uint32_t)(b2 >> 4) << 8);                  /* :76 */
+            uint32_t cl = win_clip(w, ((uint32_t)b2 & 0x0F) + 3);
+            win_back_copy(w, 0x1000 - delta, cl);                                        /* :77-80 */
+            if (w->overflow) return;
+        } else {
+            int b = cur_u8(c); if (c->eof) return;
+            if (win_clip(w, 1) < 1) return;
+            win_write_byte(w, (uint8_t)b);
+        }
+    }
+}
+
 /* CNX2.DecompressHeaderless  Sega/CNX2.cs:83-139: FlagReader(source, Endian.Little), ReadInt(2) = two bits, first one is
  * bit 0 (FlagReader.cs:75-87); code 0 skips `n` bytes and drops the rest of the flag byte (Reset, :102). */
 static void dec_cnx2(cur_t* c, win_t* w, uint32_t size) {
@@ -748,7 +770,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     switch (format) {
     case ALZ_FMT_LZSS: return lz->window_bits;
     case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
-    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: return 12; /* LZ10.cs:25 ... */
+    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: return 12; /* LZ10.cs:25 ... CLZ0.cs:24 */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
     case ALZ_FMT_BLZ: return 13;                           /* flat spans in the managed code; distances reach 0xFFF + 3 */
@@ -812,6 +834,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_FASTLZ: dec_fastlz(&c, &w, &info); break;
     case ALZ_FMT_CNX2: info.has_size = 1; dec_cnx2(&c, &w, size); break;
     case ALZ_FMT_BLZ: info.has_size = 1; dec_blz(&c, &w, size, &info, &blz_short); break;
+    case ALZ_FMT_CLZ0: info.has_size = 1; dec_clz0(&c, &w, size); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -1107,6 +1130,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_FASTLZ: p = (fmt_props){ 13, 255 + 3 + 6, 3, 0x2000, 1 }; break;        /* level 1  FastLZ.cs:22 */
     case ALZ_FMT_CNX2: p = (fmt_props){ 11, 0x1F + 4, 4, 0x800, 1 }; break;               /* CNX2.cs:25 */
     case ALZ_FMT_BLZ: p = (fmt_props){ 12, 18, 3, 0x1000, 3 }; break;                     /* BLZ.cs:24 (minDistance 3) */
+    case ALZ_FMT_CLZ0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                    /* CLZ0.cs:24 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1423,6 +1447,25 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* CLZ0.CompressHeaderless  Marvelous/CLZ0.cs:99-130 */
+static void enc_clz0(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_CLZ0, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 0);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 0); }
+        if (match.length == 0) break;
+        int delta = 0x1000 - match.distance;
+        buf_u8(&flag.buffer, (uint32_t)delta & 0xFF);
+        buf_u8(&flag.buffer, (uint32_t)((match.length - 3) | ((delta >> 8) << 4)) & 0xFF);
+        sp += match.length;
+        fw_bit(&flag, 1);
+    }
+    fw_dispose(&flag); mf_free(&m);
+}
+
 /* CNX2.CompressHeaderless  Sega/CNX2.cs:140-172: FlagWriter(destination, Endian.Little), WriteInt(v, 2) = bit 0 first */
 static void enc_cnx2(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
     fmt_props p = props_for(ALZ_FMT_CNX2, NULL, st);
@@ -1524,6 +1567,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_FASTLZ: rc = enc_fastlz(st, src, (int)n, &out); break;
     case ALZ_FMT_CNX2: enc_cnx2(st, src, (int)n, &out); break;
     case ALZ_FMT_BLZ: enc_blz(st, src, (int)n, &out); break;
+    case ALZ_FMT_CLZ0: enc_clz0(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1611,6 +1655,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZ60: return nin_header(src, len, 0x60, size_out) < 0 ? ALZ_E_FORMAT : 0;          /* LZ60.cs:29-41 */
     case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 48); return 0;      /* Sega/LZ00.cs:31-37 */
     case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;    /* Sega/CNX2.cs:36-42 */
+    case ALZ_C_CLZ0: if (len < 16 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;      /* Marvelous/CLZ0.cs:33-39 */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
         uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
@@ -1927,6 +1972,12 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
         break;
     }
+    case ALZ_C_CLZ0:                                                                     /* Marvelous/CLZ0.cs:41-51 */
+        if (len < 4 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = be32(src + 12); hdr = 16;
+        run_stream(ALZ_FMT_CLZ0, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
     case ALZ_C_BLZ: {                                                                    /* Nintendo/BLZ.cs:43-69 */
         if (len < 8) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
         uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
@@ -2303,6 +2354,13 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_CLZ0:                                                                     /* Marvelous/CLZ0.cs:53-62 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_CLZ0, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "CLZ\0", 4); wr32(dst + 4, (uint32_t)n, 1); wr32(dst + 8, 0, 1); wr32(dst + 12, (uint32_t)n, 1);
         break;
     case ALZ_C_BLZ: {                                                                    /* Nintendo/BLZ.cs:71-95 */
         uint8_t* rev = (uint8_t*)malloc(n + 1); uint8_t* tmp = (uint8_t*)malloc(n + n / 4 + 64);
