@@ -490,6 +490,7 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 48); return ALZ_OK;               // LZ00.cs:31-37
     case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return ALZ_OK;             // CNX2.cs:36-42
     case ALZ_C_CLZ0: if (len < 16 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return ALZ_OK;               // CLZ0.cs:33-39
+    case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 8); return ALZ_OK;                  // CNS.cs:36-42
     case ALZ_C_BLZ: {                                                                                                                      // BLZ.cs:32-41
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;                                                                              // "Invalid BLZ header."
         *size_out = le32(src + len - 4) + (le32(src + len - 8) & 0xFFFFFFu); return ALZ_OK;
@@ -575,6 +576,7 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_FASTLZ: return len > 0x4 && fastlz_validate(src, len);                        // FastLZ.cs:34-35
     case ALZ_C_CNX2: return len > 0x10 && !memcmp(src, "CNX\x02", 4);                        // CNX2.cs:33-34
     case ALZ_C_CLZ0: return len > 0x10 && !memcmp(src, "CLZ\0", 4);                          // CLZ0.cs:30-31
+    case ALZ_C_CNS: return len > 0x10 && !memcmp(src, "@CNS", 4);                            // CNS.cs:33-34
     case ALZ_C_BLZ: return len >= 8 && (le32(src + len - 8) & 0xFFFFFFu) == len && src[len - 5] >= 8;   // BLZ.cs:28-30 (the footer spans the whole stream)
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
     case ALZ_C_FCMP: return len > 0x10 && !memcmp(src, "FCMP", 4);
@@ -688,6 +690,12 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
+        break;
+    case ALZ_C_CNS:                                                                         // CNS.cs:44-55
+        if (len < 4 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = le32(src + 8); hdr = 16;
+        rc = run_body(ctx, ALZ_FMT_CNS, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
         break;
     case ALZ_C_CLZ0:                                                                        // CLZ0.cs:41-51
         if (len < 4 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT;
@@ -1004,6 +1012,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZO: fmt = ALZ_FMT_LZO; break;
     case ALZ_C_CNX2: fmt = ALZ_FMT_CNX2; hdr = 16; break;
     case ALZ_C_CLZ0: fmt = ALZ_FMT_CLZ0; hdr = 16; break;
+    case ALZ_C_CNS: if (n < 4) return ALZ_E_INVALID; fmt = ALZ_FMT_CNS; hdr = 16; break;          // source[3]: IndexOutOfRangeException  CNS.cs:61
     case ALZ_C_FASTLZ: fmt = ALZ_FMT_FASTLZ; break;                                             // FastLZ.cs:162-163 (level 1: MaxWindowBits stays 0)
     default: return ALZ_E_UNSUPPORTED;
     }
@@ -1035,6 +1044,9 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
         wr32(dst + 48, (uint32_t)n, false); wr32(dst + 52, key, false);
         break;
     }
+    case ALZ_C_CNS:                                                                                                                                // CNS.cs:57-75
+        memcpy(dst, "@CNS", 4); memcpy(dst + 4, (src[0] == 0x00 && src[1] == 0x20 && src[2] == 0xAF && src[3] == 0x30) ? "TPL\0" : "PAK\0", 4);
+        wr32(dst + 8, (uint32_t)n, false); wr32(dst + 12, 0, false); break;
     case ALZ_C_CLZ0: memcpy(dst, "CLZ\0", 4); wr32(dst + 4, (uint32_t)n, true); wr32(dst + 8, 0, true); wr32(dst + 12, (uint32_t)n, true); break;           // CLZ0.cs:53-62
     case ALZ_C_CNX2: memcpy(dst, "CNX\x02" "DEC\x10", 8); wr32(dst + 8, r.dst_len, true); wr32(dst + 12, (uint32_t)n, true); break;               // CNX2.cs:64-81 (Extension "DEC", padded with 0x10)
     case ALZ_C_LEVEL5LZSS: memcpy(dst, "SSZL", 4); wr32(dst + 4, 0, false); wr32(dst + 8, r.dst_len, false); wr32(dst + 12, (uint32_t)n, false); break;   // Level5LZSS.cs:62-72

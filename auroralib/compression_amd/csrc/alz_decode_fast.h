@@ -963,6 +963,34 @@ struct Cnx2Rounds {
     __device__ __forceinline__ void commit() {}
 };
 
+// Lane-parallel CNS parse (CNS.cs:77-108): an element is a control byte + its literals, or a control byte + a distance byte.
+// One token per element, lane j = element j; empty literal runs are left to the exact parser.  `total` is reported one too
+// high for the same reason as in cnx2_parse_round (nothing behind the declared size may be consumed).
+__device__ __forceinline__ bool cns_parse_round(InCache& in, u32 p, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 b = in.lds[i0 + 64u * (u32)w + (u32)lane];
+        nx[w] = b >= 0x80u ? 2u : (b == 0u ? ALZ_NX_BAD : b + 1u);
+    }
+    u32 spos, sp, nel;
+    lane_walk_pos(nx, 33u, spos, sp, nel);                               // elements have >= 2 bytes: <= 32 per window
+    if (nel == 0u) return false;
+    const u32 pos = i0 + spos;
+    const u32 b = in.lds[pos], e1 = in.lds[pos + 1];
+    const u32 t = b >= 0x80u ? ALZ_TOK_MATCH((b & 0x7Fu) + 3u, e1 + 1u) : ALZ_TOK_LIT(b, (pos + 1u) & 2047u);
+    const u32 qt = (u32)lane < nel ? t : 0u;
+    qt_out = qt; nt_out = nel; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63) + 1u;
+    return true;
+}
+struct CnsRounds {
+    InCache& in; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return cns_parse_round(in, p, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
 // Lane-parallel FastLZ parse (FastLZ.cs:63-160): an element is a control byte plus 1..32 literals, or a match of 2-3 bytes
 // (level 1) / 2-5 bytes (level 2: a second length byte of 255 chains on -> exact parser; offset 0x1FFF is followed by a
 // 16-bit big-endian extension).  One token per element, lane j = element j.  Never sees the stream's first byte.

@@ -365,6 +365,27 @@ __device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s,
     }
 }
 
+// CNS.DecompressHeaderless  Specialized/CNS.cs:77-108: control byte c < 0x80 = c literals, else a match of (c & 0x7F) + 3 bytes at
+// distance next byte + 1 (256-byte window).  Resumable at element boundaries.
+template <class SK>
+__device__ __forceinline__ void dec_cns_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size, u32 max_tokens = 0xFFFFFFFFu) {
+    while (sk.produced() < size) {
+        if (max_tokens-- == 0) return;
+        sk.ensure(in, s.p, 8);
+        if (s.p >= src_len) { s.eof = true; return; }
+        const u32 c = in.peek1(s.p); s.p++;
+        if ((c & 0x80u) == 0u) {
+            if (c > src_len - s.p) { s.eof = true; return; }                         // LzWindows.CopyFrom -> ReadExactly throws
+            if (!sk.run(in, s.p, c)) return;
+            s.p += c;
+        } else {
+            if (s.p >= src_len) { s.eof = true; return; }
+            const u32 d = in.peek1(s.p); s.p++;
+            if (!sk.match(d + 1u, (u64)(c & 0x7Fu) + 3u, 256)) return;
+        }
+    }
+}
+
 // CNX2.DecompressHeaderless  Sega/CNX2.cs:83-139: two flag bits per token, first bit = bit 0 (FlagReader Endian.Little,
 // ReadInt(2)  FlagReader.cs:75-87).  0: skip n bytes and drop the rest of the flag byte; 1: literal; 2: match (big-endian
 // u16: distance - 1 in the high 11 bits, length - 4 in the low 5); 3: n literals.  Resumable at token boundaries

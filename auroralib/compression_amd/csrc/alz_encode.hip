@@ -455,6 +455,19 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_CNS) {                              // CNS.cs:111-141
+        for (;;) {
+            Match mt = mf.next();
+            int plain = mt.offset - sp;
+            while (plain != 0) {
+                const int length = plain < 127 ? plain : 127;
+                out.put((u32)length); out.copy(src + sp, (u32)length);
+                sp += length; plain -= length;
+            }
+            if (mt.length == 0) break;
+            out.put((u32)(0x80 | (mt.length - 3))); out.put((u32)(mt.distance - 1));
+            sp += mt.length;
+        }
     } else if constexpr (FMT == ALZ_FMT_CNX2) {                             // CNX2.cs:140-172
         // FlagWriter order without its buffer (a flag byte's payload can be four 256-byte runs): the flag byte's slot is
         // reserved when its first code is written and patched when the fourth is (or at the end): the same bytes
@@ -771,6 +784,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_SNAPPY_RAW: wb = 15; g.min_len = 4; g.max_len = 64; g.max_dist = 0x8000; break;
     case ALZ_FMT_FASTLZ: wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; break;      // level 1  FastLZ.cs:22
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
+    case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
     case ALZ_FMT_BLZ: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;                          // BLZ.cs:24 (+ minDistance 3 below)
     default: return false;
     }
@@ -840,6 +854,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_CNS: launch_emit<ALZ_FMT_CNS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     default: return hipErrorInvalidValue;
     }

@@ -374,6 +374,23 @@ static void gen_blz(rng_t* r, uint32_t target, out_t* out) {
     if (nbits) { o_u8(out, flag); o_put(out, pay, plen); }
 }
 
+/* ---- CNS (Specialized/CNS.cs:77-108): control byte < 0x80 = literal run, else match (c & 0x7F) + 3 at distance byte + 1 ---- */
+static void gen_cns(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        if (produced == 0 || rem < 3 || rng_unit(r) < 0.4) {
+            uint32_t n = rng_unit(r) < 0.05 ? rng_range(r, 0, 127) : 1 + rng_geometric(r, 5.0);
+            if (n > 127) n = 127; if (n > rem) n = rem;
+            o_u8(out, n); put_rand(out, r, n); produced += n;
+        } else {
+            tok_t t = draw_match(r, produced, rem, 3, 18, 19, 130, 256);
+            if (t.len < 3) t.len = 3;
+            o_u8(out, 0x80 | (t.len - 3)); o_u8(out, t.dist - 1); produced += t.len;
+        }
+    }
+}
+
 /* ---- LZO (opcode forms of Formats/Common/LZO.cs:141-250) ---- */
 static void lzo_ext(out_t* o, uint32_t v) { while (v > 255) { o_u8(o, 0); v -= 255; } o_u8(o, v); }
 static void gen_lzo(rng_t* r, uint32_t target, out_t* out) {
@@ -455,6 +472,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_FASTLZ: gen_fastlz(&r, target, &out); break;
     case ALZ_FMT_CNX2: gen_cnx2(&r, target, &out); break;
     case ALZ_FMT_BLZ: gen_blz(&r, target, &out); break;
+    case ALZ_FMT_CNS: gen_cns(&r, target, &out); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
     default: return -2;

@@ -540,6 +540,25 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* CNS.DecompressHeaderless  Specialized/CNS.cs:77-108 */
+static void dec_cns(cur_t* c, win_t* w, uint32_t size) {
+    while (win_produced(w) < size) {                                                     /* :83 */
+        int length = cur_u8(c); if (c->eof) return;
+        if ((length & 0x80) == 0) {                                                      /* LzWindows.CopyFrom -> ReadExactly */
+            if ((uint32_t)length > c->len - c->pos) { c->eof = 1; return; }
+            uint32_t cl = win_clip(w, (uint32_t)length);
+            win_write(w, c->p + c->pos, cl);
+            if (w->overflow) return;
+            c->pos += (uint32_t)length;
+        } else {
+            int d = cur_u8(c); if (c->eof) return;
+            uint32_t cl = win_clip(w, ((uint32_t)length & 0x7F) + 3);
+            win_back_copy(w, (uint32_t)d + 1, cl);                                       /* :95-98 */
+            if (w->overflow) return;
+        }
+    }
+}
+
 /* CLZ0.DecompressHeaderless  Marvelous/CLZ0.cs:64-97: FlagReader(source, Endian.Little), 1 = match.  (The two match
  * bytes are read with Stream.ReadByte(), which returns -1 at the end instead of throwing: the managed code then copies 18
  * bytes from a garbage distance before its next flag read throws EndOfStreamException -- refused here before the copy.) */
@@ -773,6 +792,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: return 12; /* LZ10.cs:25 ... CLZ0.cs:24 */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
+    case ALZ_FMT_CNS: return 8;                            /* CNS.cs:24 ceil(log2 0x100) */
     case ALZ_FMT_BLZ: return 13;                           /* flat spans in the managed code; distances reach 0xFFF + 3 */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
@@ -835,6 +855,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_CNX2: info.has_size = 1; dec_cnx2(&c, &w, size); break;
     case ALZ_FMT_BLZ: info.has_size = 1; dec_blz(&c, &w, size, &info, &blz_short); break;
     case ALZ_FMT_CLZ0: info.has_size = 1; dec_clz0(&c, &w, size); break;
+    case ALZ_FMT_CNS: info.has_size = 1; dec_cns(&c, &w, size); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -1131,6 +1152,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_CNX2: p = (fmt_props){ 11, 0x1F + 4, 4, 0x800, 1 }; break;               /* CNX2.cs:25 */
     case ALZ_FMT_BLZ: p = (fmt_props){ 12, 18, 3, 0x1000, 3 }; break;                     /* BLZ.cs:24 (minDistance 3) */
     case ALZ_FMT_CLZ0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                    /* CLZ0.cs:24 */
+    case ALZ_FMT_CNS: p = (fmt_props){ 8, 130, 3, 0x100, 1 }; break;                      /* CNS.cs:24 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1447,6 +1469,27 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* CNS.CompressHeaderless  Specialized/CNS.cs:111-141 (its FlagWriter never receives a bit: nothing written by it) */
+static void enc_cns(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_CNS, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) {
+            int length = plain < 127 ? plain : 127;
+            buf_u8(out, (uint32_t)length); buf_put(out, src + sp, (size_t)length);
+            sp += length; plain -= length;
+        }
+        if (match.length == 0) break;
+        buf_u8(out, (uint32_t)(0x80 | (match.length - 3)));
+        buf_u8(out, (uint32_t)(match.distance - 1));
+        sp += match.length;
+    }
+    mf_free(&m);
+}
+
 /* CLZ0.CompressHeaderless  Marvelous/CLZ0.cs:99-130 */
 static void enc_clz0(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
     fmt_props p = props_for(ALZ_FMT_CLZ0, NULL, st);
@@ -1568,6 +1611,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_CNX2: enc_cnx2(st, src, (int)n, &out); break;
     case ALZ_FMT_BLZ: enc_blz(st, src, (int)n, &out); break;
     case ALZ_FMT_CLZ0: enc_clz0(st, src, (int)n, &out); break;
+    case ALZ_FMT_CNS: enc_cns(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1656,6 +1700,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZ00: if (len < 52 || memcmp(src, "LZ00", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 48); return 0;      /* Sega/LZ00.cs:31-37 */
     case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;    /* Sega/CNX2.cs:36-42 */
     case ALZ_C_CLZ0: if (len < 16 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;      /* Marvelous/CLZ0.cs:33-39 */
+    case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;         /* Specialized/CNS.cs:36-42 */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
         uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
@@ -1972,6 +2017,12 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
         break;
     }
+    case ALZ_C_CNS:                                                                      /* Specialized/CNS.cs:44-55 */
+        if (len < 4 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT;
+        if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = rd32le(src + 8); hdr = 16;
+        run_stream(ALZ_FMT_CNS, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
     case ALZ_C_CLZ0:                                                                     /* Marvelous/CLZ0.cs:41-51 */
         if (len < 4 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT;
         if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
@@ -2354,6 +2405,16 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_CNS:                                                                      /* Specialized/CNS.cs:57-75 */
+        if (n < 4) return ALZ_E_INVALID;                                                 /* source[3]: IndexOutOfRangeException */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_CNS, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "@CNS", 4);
+        memcpy(dst + 4, (src[0] == 0x00 && src[1] == 0x20 && src[2] == 0xAF && src[3] == 0x30) ? "TPL\0" : "PAK\0", 4);
+        wr32(dst + 8, (uint32_t)n, 0); wr32(dst + 12, 0, 0);
         break;
     case ALZ_C_CLZ0:                                                                     /* Marvelous/CLZ0.cs:53-62 */
         if (cap < 16) return ALZ_E_NOMEM;
