@@ -364,6 +364,7 @@ template <int FMT> struct FamTraits;
 // nibble is the low one of the first token byte (LZ40) instead of the high one; NEG: the flag byte is stored negated (LZ40)
 template <> struct FamTraits<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT1 = true,  H3 = false, H4 = false, NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };
+template <> struct FamTraits<ALZ_FMT_LZ02> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = false, NIBLO = true,  NEG = false; };   // (the 2-byte terminator also has nibble 0: nothing behind it counts)
 template <> struct FamTraits<ALZ_FMT_CLZ0> { static constexpr bool MSB = false, LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };
 template <> struct FamTraits<ALZ_FMT_BLZ>  { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false, NIBLO = false, NEG = false; };   // LZ10's grammar in stream order, distance - 3
 template <> struct FamTraits<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true,  NIBLO = false, NEG = false; };
@@ -433,6 +434,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     const u32 ti = in.idx(p + to);
     const u32 b1 = in.lds[ti], b2 = in.lds[ti + 1];
     u32 len = 1, desc = ALZ_DESC_LIT(b1), tend = to + 1;
+    bool term = false;                                           // LZ02: this token is the terminator
     if (m) {
         if (FMT == ALZ_FMT_LZSS) {
             u32 offset = ((b2 >> gm.length_bits) << 8) | b1;
@@ -441,6 +443,11 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
             desc = ALZ_DESC_MATCH(offset); tend = to + 2;
         } else if (FMT == ALZ_FMT_LZ10) {
             desc = ALZ_DESC_MATCH((((b1 & 0xFu) << 8) | b2) + 1u); len = (b1 >> 4) + 3u; tend = to + 2;
+        } else if (FMT == ALZ_FMT_LZ02) {                    // LZ02.cs:88-103
+            const u32 b3 = in.lds[ti + 2];
+            const u32 nib = b1 & 0xFu, d = ((b1 & 0xF0u) << 4) | b2;
+            desc = ALZ_DESC_MATCH(d ? d : 4096u);                // E1
+            if (nib == 0) { len = b3 + 17u; tend = to + 3; term = d == 0u; } else { len = nib + 1u; tend = to + 2; }
         } else if (FMT == ALZ_FMT_CLZ0) {
             desc = ALZ_DESC_MATCH(0x1000u - (b1 | ((b2 >> 4) << 8))); len = (b2 & 0xFu) + 3u; tend = to + 2;   // CLZ0.cs:76-78
         } else if (FMT == ALZ_FMT_BLZ) {
@@ -467,12 +474,24 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     // real (token offsets grow with the lane, so they form a prefix).  The first token that does not is left to the exact
     // parser together with the flag-reader state it needs (E6, and Yay0.cs:130-131's length-byte-at-EOF rule).
     const u32 inlim = src_len - p;
-    const bool valid = ingroup && tend <= inlim;
-    const bool cut = __ballot(ingroup && tend > inlim) != 0;
+    bool valid = ingroup && tend <= inlim;
+    bool cut = __ballot(ingroup && tend > inlim) != 0;
+    if (FMT == ALZ_FMT_LZ02) {                                    // the terminator and everything behind it: exact parser (same hand-over)
+        const u64 tm = __ballot(valid && term);
+        if (tm) { valid = valid && (u32)lane < (u32)__builtin_ctzll(tm); cut = true; }
+    }
     if (cut && __ballot(valid) == 0) { to_serial = true; return false; }
     u32 last_tend;
     const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
-    if (fin) { s.p = p + last_tend; return true; }
+    if (fin) {
+        s.p = p + last_tend;
+        if (FMT == ALZ_FMT_LZ02) {                                // not the end of an LZ02 stream: the exact parser goes on to the terminator
+            const u32 lk = (u32)__builtin_ctzll(__ballot(valid && tend == last_tend) | (1ull << 63));
+            s.bits = 7u - (lk & 7u);
+            s.flag = in.peek1(p + wave_readlane(gstart, lk));
+        }
+        return true;
+    }
     if (!cut) { s.p = p + g; return false; }
     // stopped inside a group: hand (position, remaining flag bits, flag byte) to the serial parser
     const u32 lk = (u32)__popcll(__ballot(valid)) - 1u;

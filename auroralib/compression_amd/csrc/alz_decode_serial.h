@@ -365,6 +365,35 @@ __device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s,
     }
 }
 
+// LZ02.DecompressHeaderless  Camelot/LZ02.cs:77-115: flags MSB first, 1 = match: b1 b2 = DDDDLLLL DDDDDDDD, length = nibble + 1;
+// nibble 0: distance 0 is the terminator (s.done), otherwise a third byte holds length - 17.  Runs until the terminator --
+// the declared size is only compared there -- or until the input ends (EndOfStreamException).
+template <class SK>
+__device__ void dec_lz02_serial(InCache& in, SK& sk, DecState& s, u32 src_len) {
+    for (;;) {
+        if (s.p >= src_len) { s.eof = true; return; }                                // while (source.Position < source.Length) ... throw  :83, :114
+        sk.ensure(in, s.p, 8);
+        if (s.bits == 0) { s.flag = in.peek1(s.p); s.p++; s.bits = 8; }
+        const u32 bit = (s.flag >> (s.bits - 1)) & 1u; s.bits--;
+        if (bit) {
+            if (s.p + 2 > src_len) { s.eof = true; s.p = src_len; return; }
+            const u32 w = in.peek4(s.p); s.p += 2;
+            const u32 b1 = w & 0xFF, b2 = (w >> 8) & 0xFF;
+            const u32 distance = ((b1 & 0xF0u) << 4) | b2; u32 length = (b1 & 0xFu) + 1u;
+            if (length == 1u) {
+                if (distance == 0u) { s.done = true; return; }
+                if (s.p >= src_len) { s.eof = true; return; }
+                length = ((w >> 16) & 0xFF) + 17u; s.p++;
+            }
+            if (!sk.match(distance, length, 4096)) return;
+        } else {
+            if (s.p >= src_len) { s.eof = true; return; }
+            const u32 b = in.peek1(s.p); s.p++;
+            if (!sk.lit(b)) return;
+        }
+    }
+}
+
 // CNS.DecompressHeaderless  Specialized/CNS.cs:77-108: control byte c < 0x80 = c literals, else a match of (c & 0x7F) + 3 bytes at
 // distance next byte + 1 (256-byte window).  Resumable at element boundaries.
 template <class SK>

@@ -455,6 +455,20 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_LZ02) {                             // LZ02.cs:117-151
+        FlagW fw; fw.init(&out, true);
+        for (;;) {
+            Match mt = mf.next();
+            for (int plain = mt.offset - sp; plain != 0; plain--) { fw.pay(src[sp++]); fw.bit(0); }
+            if (mt.length == 0) break;
+            const u32 length = mt.length > 16 ? 0u : (u32)mt.length - 1u;
+            fw.pay((((u32)mt.distance >> 8) << 4) | length); fw.pay((u32)mt.distance & 0xFF);
+            if (length == 0) fw.pay((u32)mt.length - 17u);
+            sp += mt.length;
+            fw.bit(1);
+        }
+        fw.pay(0); fw.pay(0); fw.bit(1);                                    // terminator
+        fw.flush();
     } else if constexpr (FMT == ALZ_FMT_CNS) {                              // CNS.cs:111-141
         for (;;) {
             Match mt = mf.next();
@@ -785,6 +799,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_FASTLZ: wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; break;      // level 1  FastLZ.cs:22
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
     case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
+    case ALZ_FMT_LZ02: g.min_len = 3; g.max_len = 272; g.max_dist = 0xFFF; break;                         // LZ02.cs:23
     case ALZ_FMT_BLZ: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;                          // BLZ.cs:24 (+ minDistance 3 below)
     default: return false;
     }
@@ -854,6 +869,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ02: launch_emit<ALZ_FMT_LZ02>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_CNS: launch_emit<ALZ_FMT_CNS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     default: return hipErrorInvalidValue;

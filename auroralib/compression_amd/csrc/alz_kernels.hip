@@ -116,6 +116,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         dec_fastlz_serial(in, sk, s, src_len, fz);
     } else if constexpr (FMT == ALZ_FMT_CNX2) {
         has_size = true; dec_cnx2_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_LZ02) {
+        has_size = true; dec_lz02_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_CNS) {
         has_size = true; dec_cns_serial(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_BLZ) {
@@ -177,6 +179,13 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
             while (!to_serial && (u64)out.produced + 1152u < L && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, L, src_len, to_serial, segmark, lane, gm);
             dec_blz_serial(in, sk, s, src_len, L);
         }
+    } else if constexpr (FMT == ALZ_FMT_LZ02) {
+        // no declared size inside the loop: the stream runs to its terminator (the size is compared there); only the
+        // capacity bounds the lane-parallel iterations, and an exactly full destination still has to see the terminator
+        FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
+        bool to_serial = false;
+        while (!s.ovf && !to_serial && out.produced < cap && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, cap, src_len, to_serial, segmark, lane, gm);
+        if (!s.ovf) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_lz02_serial(in, sk, s, src_len); }
     } else if constexpr (FMT == ALZ_FMT_LZHUDSON) {
         while (!fin && out.produced < size && (u64)s.p + 128u <= src_len) fin = fast_iter_lzhudson(in, out, s, size, segmark, lane);
         if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
@@ -433,6 +442,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_CNS: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNS>, 64, 0); break;
     case ALZ_FMT_BLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_BLZ, 8192>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_CLZ0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_CLZ0>, 64 * ALZ_WPB, 0); break;
+    case ALZ_FMT_LZ02: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ02>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_LZHUDSON: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZHUDSON>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_SMSR00: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_SMSR00>, 64 * ALZ_WPB, 0); break;
     default: break;
@@ -475,6 +485,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_CNS: return launch_queue<ALZ_FMT_CNS>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_BLZ: return launch_fast<ALZ_FMT_BLZ, 8192>(stream, s, d, streams, index, count, results, lz, 8192, 1);
         case ALZ_FMT_CLZ0: return launch_fast<ALZ_FMT_CLZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+        case ALZ_FMT_LZ02: return launch_fast<ALZ_FMT_LZ02>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         default: break;
         }
     }
@@ -502,6 +513,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_CNS: return launch_serial<ALZ_FMT_CNS, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_BLZ: return launch_serial<ALZ_FMT_BLZ, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_CLZ0: return launch_serial<ALZ_FMT_CLZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_LZ02: return launch_serial<ALZ_FMT_LZ02, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     default: return hipErrorInvalidValue;
     }
 }

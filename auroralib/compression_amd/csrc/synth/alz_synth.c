@@ -102,6 +102,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
         W = 1u << lz.window_bits; break;
     case ALZ_FMT_LZ10: case ALZ_FMT_MIO0: break;
     case ALZ_FMT_CLZ0: msb = 0; break;
+    case ALZ_FMT_LZ02: shortmax = 16; longlo = 17; longhi = 272; W = 4095; break;
     case ALZ_FMT_LZ11: longlo = 17; longhi = 272; break;
     case ALZ_FMT_LZ40: shortmax = 15; longlo = 16; longhi = 271; break;
     case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_LZHUDSON: longlo = 18; longhi = 273; break;
@@ -131,7 +132,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             uint32_t b = (uint32_t)(rng_next(r) & 0xFF);
             switch (format) {
             case ALZ_FMT_LZSS: fw_pay(&fw, b); fw_bit(&fw, 1); break;
-            case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_CLZ0: fw_pay(&fw, b); fw_bit(&fw, 0); break;
+            case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_CLZ0: case ALZ_FMT_LZ02: fw_pay(&fw, b); fw_bit(&fw, 0); break;
             case ALZ_FMT_YAZ0: case ALZ_FMT_LZHUDSON: fw_pay(&fw, b); fw_bit(&fw, 1); break;
             default: o_u8(&unc, b); fw_bit(&fw, 1); break; /* YAY0 / MIO0 / SMSR00 */
             }
@@ -149,6 +150,10 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
             fw_bit(&fw, 0); break;
         }
         case ALZ_FMT_LZ10: fw_pay(&fw, ((t.len - 3) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); fw_bit(&fw, 1); break;
+        case ALZ_FMT_LZ02:                                     /* DDDDLLLL DDDDDDDD [+ length - 17]  LZ02.cs:136-141 */
+            if (t.len <= 16) { fw_pay(&fw, ((t.dist >> 8) << 4) | (t.len - 1)); fw_pay(&fw, t.dist & 0xFF); }
+            else { fw_pay(&fw, (t.dist >> 8) << 4); fw_pay(&fw, t.dist & 0xFF); fw_pay(&fw, t.len - 17); }
+            fw_bit(&fw, 1); break;
         case ALZ_FMT_CLZ0: { uint32_t delta = 0x1000 - t.dist; fw_pay(&fw, delta & 0xFF); fw_pay(&fw, (t.len - 3) | ((delta >> 8) << 4)); fw_bit(&fw, 1); break; }   /* CLZ0.cs:121-124 */
         case ALZ_FMT_LZ11:
             if (t.len <= 16) { fw_pay(&fw, ((t.len - 1) << 4) | (d1 >> 8)); fw_pay(&fw, d1 & 0xFF); }
@@ -176,6 +181,7 @@ static void gen_flagfmt(uint32_t format, const alz_lz_properties* props, rng_t* 
         }
         produced += t.len;
     }
+    if (format == ALZ_FMT_LZ02) { fw_pay(&fw, 0); fw_pay(&fw, 0); fw_bit(&fw, 1); }   /* terminator */
     fw_flush(&fw);
     if (smsr) {
         if (aux) { aux->aux0 = (uint32_t)flags.len; aux->aux1 = 0; }
@@ -462,7 +468,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     out_t out = { dst, 0, cap, 0 };
     if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
     switch (format) {
-    case ALZ_FMT_CLZ0:
+    case ALZ_FMT_CLZ0: case ALZ_FMT_LZ02:
     case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
     case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00:
         gen_flagfmt(format, props, &r, target, &out, aux); break;

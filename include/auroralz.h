@@ -62,7 +62,10 @@ typedef enum alz_format {
     ALZ_FMT_CNS        = 18, /* CNS.DecompressHeaderless: control byte < 0x80 = that many literals, else a match of (c & 0x7F) + 3 bytes
                                 at distance next byte + 1; 256-byte window
                                 src/AuroraLib.Compression-Extended/Specialized/CNS.cs:77-108.  SURVEY.md 8f rank 4. */
-    ALZ_FMT_COUNT      = 19
+    ALZ_FMT_LZ02       = 19, /* LZ02.DecompressHeaderless: flags MSB first, 1 = match (DDDDLLLL DDDDDDDD [+ length byte]), ends at the
+                                terminator token, not at the declared size
+                                src/AuroraLib.Compression-Extended/Camelot/LZ02.cs:77-115.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_COUNT      = 20
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -265,8 +268,9 @@ typedef enum alz_container {
                           src/AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:28-95 */
     ALZ_C_CLZ0   = 37, /* "CLZ\0" + BE size + BE 0 + BE size + CLZ0 body   src/AuroraLib.Compression-Extended/Marvelous/CLZ0.cs:41-62 */
     ALZ_C_CNS    = 38, /* "@CNS" + extension[4] + LE size + 0 + CNS body   src/AuroraLib.Compression-Extended/Specialized/CNS.cs:44-75 */
+    ALZ_C_LZ02   = 39, /* type byte (1 / 2) + u24 BE size + LZ02 body [+ extension data]   src/AuroraLib.Compression-Extended/Camelot/LZ02.cs:60-75 */
     ALZ_C_CNX2   = 35, /* "CNX\x02" + extension[4] + BE csize + BE size + CNX2 body   src/AuroraLib.Compression.Sega/Sega/CNX2.cs:45-81 */
-    ALZ_C_COUNT  = 39
+    ALZ_C_COUNT  = 40
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

@@ -540,6 +540,35 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* LZ02.DecompressHeaderless  Camelot/LZ02.cs:77-115: runs until the terminator token (distance 0, length nibble 0), where only
+ * MORE output than declared is an error (:97-100); input that ends first is EndOfStreamException (:114).  Returns 1 at the
+ * terminator. */
+static int dec_lz02(cur_t* c, win_t* w) {
+    flag_t flag = { c, 0, 0, 1, 1 };
+    while (c->pos < c->len) {                                                            /* :83 */
+        int bit = flag_readbit(&flag); if (c->eof) return 0;
+        if (bit) {
+            int b1 = cur_u8(c); if (c->eof) return 0;
+            int b2 = cur_u8(c); if (c->eof) return 0;
+            uint32_t distance = ((uint32_t)(b1 & 0xF0) << 4) | (uint32_t)b2, length = ((uint32_t)b1 & 0xF) + 1;
+            if (length == 1) {
+                if (distance == 0) return 1;                                             /* :95-101 */
+                int b3 = cur_u8(c); if (c->eof) return 0;
+                length = (uint32_t)b3 + 17;
+            }
+            uint32_t cl = win_clip(w, length);
+            win_back_copy(w, distance, cl);                                              /* :105 */
+            if (w->overflow) return 0;
+        } else {
+            int b = cur_u8(c); if (c->eof) return 0;
+            if (win_clip(w, 1) < 1) return 0;
+            win_write_byte(w, (uint8_t)b);
+        }
+    }
+    c->eof = 1;                                                                          /* :114 */
+    return 0;
+}
+
 /* CNS.DecompressHeaderless  Specialized/CNS.cs:77-108 */
 static void dec_cns(cur_t* c, win_t* w, uint32_t size) {
     while (win_produced(w) < size) {                                                     /* :83 */
@@ -789,7 +818,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     switch (format) {
     case ALZ_FMT_LZSS: return lz->window_bits;
     case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
-    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: return 12; /* LZ10.cs:25 ... CLZ0.cs:24 */
+    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: case ALZ_FMT_LZ02: return 12; /* LZ10.cs:25 ... CLZ0.cs:24 */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
     case ALZ_FMT_CNS: return 8;                            /* CNS.cs:24 ceil(log2 0x100) */
@@ -856,6 +885,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_BLZ: info.has_size = 1; dec_blz(&c, &w, size, &info, &blz_short); break;
     case ALZ_FMT_CLZ0: info.has_size = 1; dec_clz0(&c, &w, size); break;
     case ALZ_FMT_CNS: info.has_size = 1; dec_cns(&c, &w, size); break;
+    case ALZ_FMT_LZ02: info.has_size = 1; terminated = dec_lz02(&c, &w); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -1153,6 +1183,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_BLZ: p = (fmt_props){ 12, 18, 3, 0x1000, 3 }; break;                     /* BLZ.cs:24 (minDistance 3) */
     case ALZ_FMT_CLZ0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                    /* CLZ0.cs:24 */
     case ALZ_FMT_CNS: p = (fmt_props){ 8, 130, 3, 0x100, 1 }; break;                      /* CNS.cs:24 */
+    case ALZ_FMT_LZ02: p = (fmt_props){ 12, 272, 3, 0xFFF, 1 }; break;                    /* LZ02.cs:23 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1469,6 +1500,27 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* LZ02.CompressHeaderless  Camelot/LZ02.cs:117-151 */
+static void enc_lz02(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_LZ02, NULL, st);
+    mf_t m; mf_init(&m, &p, st); fw_t flag; fw_init(&flag, out, 1);
+    int sp = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        int plain = match.offset - sp;
+        while (plain != 0) { plain--; buf_u8(&flag.buffer, src[sp++]); fw_bit(&flag, 0); }
+        if (match.length == 0) break;
+        int length = match.length > 16 ? 0 : match.length - 1;
+        buf_u8(&flag.buffer, (uint32_t)(((match.distance >> 8) << 4) | length) & 0xFF);
+        buf_u8(&flag.buffer, (uint32_t)match.distance & 0xFF);
+        if (length == 0) buf_u8(&flag.buffer, (uint32_t)(match.length - 17));
+        sp += match.length;
+        fw_bit(&flag, 1);
+    }
+    buf_u8(&flag.buffer, 0); buf_u8(&flag.buffer, 0); fw_bit(&flag, 1);                  /* terminator  :147-149 */
+    fw_dispose(&flag); mf_free(&m);
+}
+
 /* CNS.CompressHeaderless  Specialized/CNS.cs:111-141 (its FlagWriter never receives a bit: nothing written by it) */
 static void enc_cns(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
     fmt_props p = props_for(ALZ_FMT_CNS, NULL, st);
@@ -1612,6 +1664,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_BLZ: enc_blz(st, src, (int)n, &out); break;
     case ALZ_FMT_CLZ0: enc_clz0(st, src, (int)n, &out); break;
     case ALZ_FMT_CNS: enc_cns(st, src, (int)n, &out); break;
+    case ALZ_FMT_LZ02: enc_lz02(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1701,6 +1754,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_CNX2: if (len < 16 || memcmp(src, "CNX\x02", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;    /* Sega/CNX2.cs:36-42 */
     case ALZ_C_CLZ0: if (len < 16 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;      /* Marvelous/CLZ0.cs:33-39 */
     case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;         /* Specialized/CNS.cs:36-42 */
+    case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3]; return 0;   /* Camelot/LZ02.cs:49-58 */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
         uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
@@ -2017,6 +2071,12 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
         break;
     }
+    case ALZ_C_LZ02:                                                                     /* Camelot/LZ02.cs:60-64 */
+        if (len < 1 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT;
+        if (len < 4) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        size = ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3]; hdr = 4;
+        run_stream(ALZ_FMT_LZ02, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
+        break;
     case ALZ_C_CNS:                                                                      /* Specialized/CNS.cs:44-55 */
         if (len < 4 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT;
         if (len < 16) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
@@ -2405,6 +2465,13 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_LZ02:                                                                     /* Camelot/LZ02.cs:66-75 (no extension data: DataType.Default) */
+        if (cap < 4) return ALZ_E_NOMEM;
+        hdr = 4;
+        body = oracle_encode_stream(ALZ_FMT_LZ02, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        dst[0] = 1; dst[1] = (uint8_t)(n >> 16); dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)n;
         break;
     case ALZ_C_CNS:                                                                      /* Specialized/CNS.cs:57-75 */
         if (n < 4) return ALZ_E_INVALID;                                                 /* source[3]: IndexOutOfRangeException */
