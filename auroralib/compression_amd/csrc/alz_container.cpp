@@ -435,6 +435,25 @@ int snappy_file_compress(alz_ctx* ctx, const alz_settings* st, const uint8_t* sr
 
 }  // namespace
 
+// RefPack.InternalReadHeader  RefPack.cs:77-102: flags + 0xFB + size [+ compressed size], optionally behind a u32 compressed size
+// (version 2).  Returns the header length, or an ALZ_E_* code.
+static int refpack_header(const uint8_t* src, size_t len, uint32_t* size) {
+    size_t pos = 0;
+    if (len < 2) return ALZ_E_FORMAT;
+    if (src[1] != 0xFB) {                                            // not version 1 / 3: a pre-header must follow  :81-90
+        if (len < 6 || src[4] != 0x10 || src[5] != 0xFB) return ALZ_E_FORMAT;
+        pos = 4;
+    }
+    const uint8_t flag = src[pos]; pos += 2;
+    if (!(flag & 0x10)) return ALZ_E_UNSUPPORTED;                    // NotSupportedException("No supported Flag")  :92-93
+    const bool wide = (flag & 0x80) != 0; const size_t n = wide ? 4 : 3;
+    if (len < pos + n) return ALZ_E_FORMAT;
+    *size = wide ? be32(src + pos) : (be32(src + pos - 1) & 0xFFFFFFu);
+    pos += n;
+    if (flag & 1) pos += n;                                          // StoresCompressedSize
+    return (int)pos;
+}
+
 // FastLZ.Validate  FastLZ.cs:246-291 (sic: only streams whose first byte is below 0x20, i.e. level 1, pass)
 static bool fastlz_validate(const uint8_t* s, size_t n) {
     size_t pos = 0;
@@ -492,6 +511,7 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_CLZ0: if (len < 16 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return ALZ_OK;               // CLZ0.cs:33-39
     case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 8); return ALZ_OK;                  // CNS.cs:36-42
     case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = be32(src) & 0xFFFFFFu; return ALZ_OK;   // LZ02.cs:49-58
+    case ALZ_C_REFPACK: { const int h = refpack_header(src, len, size_out); return h < 0 ? h : ALZ_OK; }                                     // RefPack.cs:56-62
     case ALZ_C_BLZ: {                                                                                                                      // BLZ.cs:32-41
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;                                                                              // "Invalid BLZ header."
         *size_out = le32(src + len - 4) + (le32(src + len - 8) & 0xFFFFFFu); return ALZ_OK;
@@ -578,6 +598,9 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_CNX2: return len > 0x10 && !memcmp(src, "CNX\x02", 4);                        // CNX2.cs:33-34
     case ALZ_C_CLZ0: return len > 0x10 && !memcmp(src, "CLZ\0", 4);                          // CLZ0.cs:30-31
     case ALZ_C_CNS: return len > 0x10 && !memcmp(src, "@CNS", 4);                            // CNS.cs:33-34
+    case ALZ_C_REFPACK:                                                                      // RefPack.cs:40-53 (versions 1 / 3, or version 2 behind its pre-header)
+        return len > 0x8 && (((src[0] & 0x2E) == 0 && (src[0] & 0x10) && src[1] == 0xFB && (be32(src + 1) & 0xFFFFFFu) != 0) ||
+                             (le32(src) != 0 && src[4] == 0x10 && src[5] == 0xFB && (be32(src + 5) & 0xFFFFFFu) != 0));
     case ALZ_C_LZ02: return len > 0x8 && (src[0] == 1 || src[0] == 2) && (be32(src) & 0xFFFFFFu) != 0 && (src[4] & 0x80) == 0;   // LZ02.cs:28-35 (no extension given)
     case ALZ_C_BLZ: return len >= 8 && (le32(src + len - 8) & 0xFFFFFFu) == len && src[len - 5] >= 8;   // BLZ.cs:28-30 (the footer spans the whole stream)
     case ALZ_C_MDB4: return len > 0x10 && !memcmp(src, "MDB4", 4);
@@ -693,6 +716,14 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
         break;
+    case ALZ_C_REFPACK: {                                                                   // RefPack.cs:64-75
+        const int h = refpack_header(src, len, &size);
+        if (h < 0) return h;
+        hdr = (size_t)h;
+        if (len < hdr) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        rc = run_body(ctx, ALZ_FMT_REFPACK, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
     case ALZ_C_LZ02:                                                                        // LZ02.cs:60-64
         if (len < 1 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT;
         if (len < 4) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
@@ -1021,6 +1052,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_CNX2: fmt = ALZ_FMT_CNX2; hdr = 16; break;
     case ALZ_C_CLZ0: fmt = ALZ_FMT_CLZ0; hdr = 16; break;
     case ALZ_C_LZ02: fmt = ALZ_FMT_LZ02; hdr = 4; break;
+    case ALZ_C_REFPACK: if (n >= 0xFFFFFF) return ALZ_E_UNSUPPORTED; fmt = ALZ_FMT_REFPACK; hdr = 9; break;   // "RefPack Version 2 does not support files over 16MB."  RefPack.cs:110-111
     case ALZ_C_CNS: if (n < 4) return ALZ_E_INVALID; fmt = ALZ_FMT_CNS; hdr = 16; break;          // source[3]: IndexOutOfRangeException  CNS.cs:61
     case ALZ_C_FASTLZ: fmt = ALZ_FMT_FASTLZ; break;                                             // FastLZ.cs:162-163 (level 1: MaxWindowBits stays 0)
     default: return ALZ_E_UNSUPPORTED;
@@ -1053,6 +1085,8 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
         wr32(dst + 48, (uint32_t)n, false); wr32(dst + 52, key, false);
         break;
     }
+    case ALZ_C_REFPACK:                                                                                                                            // RefPack.cs:105-125: Options = Default | UsePreHeader -> version 2
+        wr32(dst, (uint32_t)(hdr + r.dst_len - 4), false); dst[4] = 0x10; dst[5] = 0xFB; dst[6] = (uint8_t)(n >> 16); dst[7] = (uint8_t)(n >> 8); dst[8] = (uint8_t)n; break;
     case ALZ_C_LZ02: dst[0] = 1; dst[1] = (uint8_t)(n >> 16); dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)n; break;                                  // LZ02.cs:66-75 (DataType.Default: no extension data)
     case ALZ_C_CNS:                                                                                                                                // CNS.cs:57-75
         memcpy(dst, "@CNS", 4); memcpy(dst + 4, (src[0] == 0x00 && src[1] == 0x20 && src[2] == 0xAF && src[3] == 0x30) ? "TPL\0" : "PAK\0", 4);

@@ -704,7 +704,7 @@ struct QueueSink {
     }
     __device__ __forceinline__ bool match(u32 dist, u64 len, u32 w) {
         if (len == 0) return true;
-        if (len > ALZ_TOK_MAXLEN || (u64)produced() + len > (u64)out.cap) {       // rare: long token / exact E5 handling on the serial path
+        if (len > ALZ_TOK_MAXLEN || dist > 0x1FFFFu || (u64)produced() + len > (u64)out.cap) {   // rare: long token / distance beyond the token word (RefPack's 131 072) / exact E5 handling on the serial path
             flush(); if (s.ovf) return false;
             u32 cl = clip_token(out, s, len); out.back_copy(dist, cl, w); return !s.ovf;
         }
@@ -979,6 +979,63 @@ __device__ __forceinline__ bool cnx2_parse_round(InCache& in, u32 p, u32* stage,
 struct Cnx2Rounds {
     InCache& in; u32* stage; int lane;
     __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return cnx2_parse_round(in, p, stage, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
+// Lane-parallel RefPack parse (RefPack.cs:177-245): an element is a prefix byte, 0-3 data bytes and its literals (0-3 in front
+// of a match, 4..112 alone).  Like LZ4, an element yields a literal-run token and / or a match token, compacted through
+// `stage`.  The end token and a distance of 131 072 (beyond the token word) are left to the exact parser.
+__device__ __forceinline__ bool refpack_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 b = in.lds[pos], e1 = in.lds[pos + 1];
+        u32 n;
+        if (b < 0x80u) n = 2u + (b & 3u);
+        else if (b < 0xC0u) n = 3u + (e1 >> 6);
+        else if (b < 0xE0u) n = 4u + (b & 3u);
+        else n = b >= 0xFCu ? ALZ_NX_BAD : 5u + (b & 0x1Fu) * 4u;
+        nx[w] = n;
+    }
+    u32 spos, sp, nel;
+    lane_walk_pos(nx, 32u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
+    if (nel > 32u) { nel = 32u; sp = wave_readlane(spos, 32u); }         // two tokens per element fill the queue
+    if (nel == 0u) return false;
+    const bool st = (u32)lane < nel;
+    const u32 pos = i0 + spos;
+    const u32 b = in.lds[pos], d0 = in.lds[pos + 1], d1 = in.lds[(pos + 2u) & 2047u], d2 = in.lds[(pos + 3u) & 2047u];
+    u32 plain, length = 0, distance = 1, hdr;
+    if (b < 0x80u) { hdr = 2; plain = b & 3u; length = ((b & 0x1Cu) >> 2) + 3u; distance = (((b & 0x60u) << 3) | d0) + 1u; }
+    else if (b < 0xC0u) { hdr = 3; plain = d0 >> 6; length = (b & 0x3Fu) + 4u; distance = (((d0 & 0x3Fu) << 8) | d1) + 1u; }
+    else if (b < 0xE0u) { hdr = 4; plain = b & 3u; length = (((b & 0x0Cu) << 6) | d2) + 5u; distance = (((((b & 0x10u) << 4) | d0) << 8) | d1) + 1u; }
+    else { hdr = 1; plain = (b & 0x1Fu) * 4u + 4u; }
+    if (__ballot(st && distance > 0x1FFFFu)) {                           // cut the round in front of the first such element
+        const u32 first = (u32)__builtin_ctzll(__ballot(st && distance > 0x1FFFFu));
+        if (first == 0u) return false;
+        nel = first; sp = wave_readlane(spos, first);
+    }
+    const bool st2 = (u32)lane < nel;
+    const u64 litm = __ballot(st2 && plain != 0u), mm = __ballot(st2 && length != 0u);
+    const u32 rank = mbcnt64(litm) + mbcnt64(mm);
+    if (st2) {
+        u32 r = rank;
+        if (plain) { stage[r] = ALZ_TOK_LIT(plain, (pos + hdr) & 2047u); r++; }
+        if (length) stage[r] = ALZ_TOK_MATCH(length, distance);
+    }
+    const u32 base = (u32)__popcll(litm) + (u32)__popcll(mm);
+    wave_sync();
+    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
+    wave_sync();
+    if (base == 0u) return false;
+    qt_out = qt; nt_out = base; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    return true;
+}
+struct RefpackRounds {
+    InCache& in; u32* stage; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return refpack_parse_round(in, p, stage, lane, qt, nt, total, adv); }
     __device__ __forceinline__ void commit() {}
 };
 

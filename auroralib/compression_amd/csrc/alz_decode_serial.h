@@ -365,6 +365,34 @@ __device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s,
     }
 }
 
+// RefPack.DecompressHeaderless  EA/RefPack.cs:177-245: prefix byte selects the form -- 0DDLLLPP D, 10LLLLLL PPDDDDDD D,
+// 110DLLPP D D L (0-3 literals, then a match), 111PPPPP (4..112 literals), 111111PP (0-3 literals, the end: s.done).
+// Resumable at element boundaries.  Runs to the end token; the declared size is only compared there.
+template <class SK>
+__device__ __forceinline__ void dec_refpack_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 max_tokens = 0xFFFFFFFFu) {
+    for (;;) {
+        if (max_tokens-- == 0) return;
+        if (s.p >= src_len) { s.eof = true; return; }                                // while (source.Position < source.Length) ... throw
+        sk.ensure(in, s.p, 8);
+        const u32 w = in.peek4(s.p);
+        const u32 prefix = w & 0xFF, d0 = (w >> 8) & 0xFF, d1 = (w >> 16) & 0xFF, d2 = w >> 24;
+        u32 plain, length = 0, distance = 0, hdr;
+        if ((prefix & 0x80u) == 0u) { hdr = 2; plain = prefix & 3u; length = ((prefix & 0x1Cu) >> 2) + 3u; distance = (((prefix & 0x60u) << 3) | d0) + 1u; }
+        else if ((prefix & 0x40u) == 0u) { hdr = 3; plain = d0 >> 6; length = (prefix & 0x3Fu) + 4u; distance = (((d0 & 0x3Fu) << 8) | d1) + 1u; }
+        else if ((prefix & 0x20u) == 0u) { hdr = 4; plain = prefix & 3u; length = (((prefix & 0x0Cu) << 6) | d2) + 5u; distance = (((((prefix & 0x10u) << 4) | d0) << 8) | d1) + 1u; }
+        else { hdr = 1; plain = (prefix & 0x1Fu) * 4u + 4u; }
+        if (hdr > src_len - s.p) { s.eof = true; s.p = src_len; return; }             // ReadUInt8 throws
+        s.p += hdr;
+        const bool end = hdr == 1u && plain > 0x70u;
+        if (end) plain = prefix & 3u;
+        if (plain > src_len - s.p) { s.eof = true; return; }                         // LzWindows.CopyFrom -> ReadExactly throws
+        if (!sk.run(in, s.p, plain)) return;
+        s.p += plain;
+        if (end) { s.done = true; return; }
+        if (length && !sk.match(distance, length, 131072)) return;
+    }
+}
+
 // LZ02.DecompressHeaderless  Camelot/LZ02.cs:77-115: flags MSB first, 1 = match: b1 b2 = DDDDLLLL DDDDDDDD, length = nibble + 1;
 // nibble 0: distance 0 is the terminator (s.done), otherwise a third byte holds length - 17.  Runs until the terminator --
 // the declared size is only compared there -- or until the input ends (EndOfStreamException).

@@ -35,6 +35,8 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
     u32 min_mask;
     // LZSS
     u32 length_bits, lz_min_length, windows_start, lz_max_distance;
+    // the LzProperties[] form of the finder (RefPack): ScoreMatch takes the first set that admits a candidate
+    int nprops, p_max_len[3], p_min_len[3], p_max_dist[3], p_min_dist[3];
 };
 
 __device__ __forceinline__ u32 load32(const u8* p) {
@@ -125,6 +127,20 @@ __device__ __forceinline__ int match_len(const u8* a, const u8* b, int max) {
     return len;
 }
 
+// ScoreMatch  LzChainMatchFinder.cs:301-321
+__device__ __forceinline__ int score_match(const EncGeom& g, int& len, int dist) {
+    if (g.no_self_overlap && len > dist) len = dist;
+    if (g.nprops <= 1) return len - g.min_len;
+    for (int i = 0; i < g.nprops; i++) {
+        if (dist <= g.p_max_dist[i] && len >= g.p_min_len[i] && dist >= g.p_min_dist[i]) {
+            if (len > g.p_max_len[i]) len = g.p_max_len[i];
+            return len - g.p_min_len[i];
+        }
+    }
+    len = 0;
+    return -1;
+}
+
 // MatchSearch :214-246 with ChainMatches :248-282 as a pure function of (data, prev); returns false when CAP > 0 and a
 // candidate still matched after CAP bytes
 template <bool MINT>
@@ -142,8 +158,7 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
         if (dist < g.min_dist) { cur = p4[cur]; continue; }
         int len = match_len(dp, data + cur, cmp_max);
         if (len == cmp_max && cmp_max < best_possible) return false;
-        if (g.no_self_overlap && len > dist) len = dist;             // ScoreMatch :301-308
-        const int score = len - g.min_len;
+        const int score = score_match(g, len, dist);
         if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
         cur = p4[cur];
     }
@@ -155,7 +170,7 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
             if (dist <= g.max_dist && pos - dist >= 0) {
                 int len = match_len(dp, data + pos - dist, cmp_max);
                 if (len == cmp_max && cmp_max < best_possible) return false;
-                if (g.no_self_overlap && len > dist) len = dist;
+                (void)score_match(g, len, dist);
                 best_l = len; best_d = dist;
             }
         }
@@ -455,6 +470,27 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_REFPACK) {                          // RefPack.cs:247-303
+        int plain = 0;
+        for (;;) {
+            Match mt = mf.next();
+            plain = mt.offset - sp;
+            while (plain > 3) {                                             // runs of 4..112 literals, multiples of four
+                int c = (plain > 0x70 ? 0x70 : plain) / 4 - 1;
+                out.put((u32)(0xE0 | c));
+                c = c * 4 + 4;
+                out.copy(src + sp, (u32)c); sp += c; plain -= c;
+            }
+            if (mt.length == 0) break;
+            const int d1 = mt.distance - 1;
+            if (mt.length <= 10 && mt.distance <= 0x400) { out.put((u32)(plain | ((d1 & 0x300) >> 3) | ((mt.length - 3) << 2))); out.put((u32)d1 & 0xFF); }
+            else if (mt.length >= 4 && mt.length <= 67 && mt.distance <= 0x4000) { out.put((u32)(0x80 | (mt.length - 4))); out.put((u32)((d1 >> 8) | (plain << 6)) & 0xFF); out.put((u32)d1 & 0xFF); }
+            else { out.put((u32)(0xC0 | ((d1 >> 16) << 4) | (((mt.length - 5) >> 8) << 2) | plain) & 0xFF); out.put((u32)(d1 >> 8) & 0xFF); out.put((u32)d1 & 0xFF); out.put((u32)(mt.length - 5) & 0xFF); }
+            out.copy(src + sp, (u32)plain);
+            sp += plain + mt.length;
+            plain = 0;
+        }
+        out.put((u32)(0xFC | plain)); out.copy(src + sp, (u32)plain);     // the end token carries the last 0-3 literals
     } else if constexpr (FMT == ALZ_FMT_LZ02) {                             // LZ02.cs:117-151
         FlagW fw; fw.init(&out, true);
         for (;;) {
@@ -800,6 +836,13 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
     case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
     case ALZ_FMT_LZ02: g.min_len = 3; g.max_len = 272; g.max_dist = 0xFFF; break;                         // LZ02.cs:23
+    case ALZ_FMT_REFPACK:                                                                                   // RefPack.cs:29-34: three sets; the globals are the loosest of each (LzChainMatchFinder.cs:55-69)
+        wb = 17; g.min_len = 3; g.max_len = 1028; g.max_dist = 0x20000; g.nprops = 3;
+        g.p_max_dist[0] = 0x20000; g.p_max_len[0] = 1028; g.p_min_len[0] = 5;
+        g.p_max_dist[1] = 0x4000;  g.p_max_len[1] = 67;   g.p_min_len[1] = 4;
+        g.p_max_dist[2] = 0x400;   g.p_max_len[2] = 10;   g.p_min_len[2] = 3;
+        g.p_min_dist[0] = g.p_min_dist[1] = g.p_min_dist[2] = 1;
+        break;
     case ALZ_FMT_BLZ: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;                          // BLZ.cs:24 (+ minDistance 3 below)
     default: return false;
     }
@@ -869,6 +912,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_REFPACK: launch_emit<ALZ_FMT_REFPACK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ02: launch_emit<ALZ_FMT_LZ02>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_CNS: launch_emit<ALZ_FMT_CNS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

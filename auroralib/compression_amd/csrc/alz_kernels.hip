@@ -116,6 +116,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         dec_fastlz_serial(in, sk, s, src_len, fz);
     } else if constexpr (FMT == ALZ_FMT_CNX2) {
         has_size = true; dec_cnx2_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_REFPACK) {
+        has_size = true; dec_refpack_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_LZ02) {
         has_size = true; dec_lz02_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_CNS) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     DecState s; dec_state_init(s);
     typedef EmitCfg<LW - 1u, false, !PRS, FB> CFG;
     typedef QueueSink<OW, CFG> SK;
-    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : (FMT == ALZ_FMT_FASTLZ ? 131072u : (CNS ? 256u : (CNX ? 2048u : 65536u))));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
+    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : ((FMT == ALZ_FMT_FASTLZ || FMT == ALZ_FMT_REFPACK) ? 131072u : (CNS ? 256u : (CNX ? 2048u : 65536u))));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
     if constexpr (PRS) {
         // bulk of the stream: lane-assisted parse (prs_lane_parse) while >= 1100 input bytes remain; every token it
         // declines, and the tail of the stream, goes through the exact parser one token at a time
@@ -359,6 +361,19 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
         }
     }
+    else if constexpr (FMT == ALZ_FMT_REFPACK) {
+        for (;;) {
+            if (s.p + 1100u <= src_len) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                RefpackRounds rounds{in, stage, lane};
+                if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 131072u, cap, rounds)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_refpack_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
+    }
     else if constexpr (FMT == ALZ_FMT_FASTLZ) {
         FastlzState fz; fastlz_state_init(fz);
         for (;;) {
@@ -391,7 +406,8 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     }
     sk.flush();                                    // tokens parsed before an error/terminator are part of the output
     out.finish();
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, CNX, out.produced, CNX ? uni(st.decom_len) : 0u, cap), hist);
+    constexpr bool SIZED = CNX || FMT == ALZ_FMT_REFPACK;       // (RefPack: only more output than declared is an error, checked at the end token)
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, SIZED, out.produced, SIZED ? uni(st.decom_len) : 0u, cap), hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,6 +456,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_FASTLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_FASTLZ>, 64, 0); break;
     case ALZ_FMT_CNX2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNX2>, 64, 0); break;
     case ALZ_FMT_CNS: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNS>, 64, 0); break;
+    case ALZ_FMT_REFPACK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_REFPACK>, 64, 0); break;
     case ALZ_FMT_BLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_BLZ, 8192>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_CLZ0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_CLZ0>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_LZ02: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ02>, 64 * ALZ_WPB, 0); break;
@@ -483,6 +500,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_FASTLZ: return launch_queue<ALZ_FMT_FASTLZ>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_CNX2: return launch_queue<ALZ_FMT_CNX2>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_CNS: return launch_queue<ALZ_FMT_CNS>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_REFPACK: return launch_queue<ALZ_FMT_REFPACK>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_BLZ: return launch_fast<ALZ_FMT_BLZ, 8192>(stream, s, d, streams, index, count, results, lz, 8192, 1);
         case ALZ_FMT_CLZ0: return launch_fast<ALZ_FMT_CLZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_LZ02: return launch_fast<ALZ_FMT_LZ02>(stream, s, d, streams, index, count, results, lz, 4096, 1);
@@ -511,6 +529,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_FASTLZ: return launch_serial<ALZ_FMT_FASTLZ, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_CNX2: return launch_serial<ALZ_FMT_CNX2, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_CNS: return launch_serial<ALZ_FMT_CNS, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_REFPACK: return launch_serial<ALZ_FMT_REFPACK, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_BLZ: return launch_serial<ALZ_FMT_BLZ, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_CLZ0: return launch_serial<ALZ_FMT_CLZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_LZ02: return launch_serial<ALZ_FMT_LZ02, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);

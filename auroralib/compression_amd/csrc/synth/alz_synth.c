@@ -380,6 +380,36 @@ static void gen_blz(rng_t* r, uint32_t target, out_t* out) {
     if (nbits) { o_u8(out, flag); o_put(out, pay, plen); }
 }
 
+/* ---- RefPack (EA/RefPack.cs:177-245): 0-3 literals + a match in one of three forms, literal runs of 4..112 (multiples of
+ * four), and the end token with the last 0-3 literals ---- */
+static void gen_refpack(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    for (;;) {
+        uint32_t rem = target - produced;
+        uint32_t lit = rng_geometric(r, 4.0); if (produced == 0 && lit == 0) lit = 1;
+        if (lit + 3 > rem) {                                           /* finish: runs of multiples of four, then the end token */
+            lit = rem;
+            while (lit > 3) { uint32_t c = (lit > 0x70 ? 0x70 : lit) / 4; o_u8(out, 0xE0 | (c - 1)); put_rand(out, r, 4 * c); lit -= 4 * c; }
+            o_u8(out, 0xFC | lit); put_rand(out, r, lit);
+            return;
+        }
+        while (lit > 3) { uint32_t c = (lit > 0x70 ? 0x70 : lit) / 4; o_u8(out, 0xE0 | (c - 1)); put_rand(out, r, 4 * c); produced += 4 * c; lit -= 4 * c; }
+        rem = target - produced;
+        tok_t t = draw_match_seq(r, produced + lit, rem - lit, 3, 1028, 0x20000);
+        if (t.len < 3) t.len = 3;
+        if (t.len == 3 && t.dist > 0x400) t.dist = rng_range(r, 1, 0x400);      /* only the short form holds length 3 ... */
+        if (t.len == 4 && t.dist > 0x4000) t.dist = rng_range(r, 1, 0x4000);    /* ... and only short / medium length 4 */
+        const uint32_t d1 = t.dist - 1;
+        const int can_s = t.len <= 10 && t.dist <= 0x400, can_m = t.len >= 4 && t.len <= 67 && t.dist <= 0x4000, can_l = t.len >= 5;
+        const double u = rng_unit(r);                                            /* mostly the shortest form, sometimes a longer one */
+        if (can_s && (u < 0.8 || (!can_m && !can_l))) { o_u8(out, lit | ((d1 & 0x300) >> 3) | ((t.len - 3) << 2)); o_u8(out, d1 & 0xFF); }
+        else if (can_m && (u < 0.95 || !can_l)) { o_u8(out, 0x80 | (t.len - 4)); o_u8(out, (d1 >> 8) | (lit << 6)); o_u8(out, d1 & 0xFF); }
+        else { o_u8(out, 0xC0 | ((d1 >> 16) << 4) | (((t.len - 5) >> 8) << 2) | lit); o_u8(out, (d1 >> 8) & 0xFF); o_u8(out, d1 & 0xFF); o_u8(out, (t.len - 5) & 0xFF); }
+        put_rand(out, r, lit);
+        produced += lit + t.len;
+    }
+}
+
 /* ---- CNS (Specialized/CNS.cs:77-108): control byte < 0x80 = literal run, else match (c & 0x7F) + 3 at distance byte + 1 ---- */
 static void gen_cns(rng_t* r, uint32_t target, out_t* out) {
     uint32_t produced = 0;
@@ -479,6 +509,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_CNX2: gen_cnx2(&r, target, &out); break;
     case ALZ_FMT_BLZ: gen_blz(&r, target, &out); break;
     case ALZ_FMT_CNS: gen_cns(&r, target, &out); break;
+    case ALZ_FMT_REFPACK: gen_refpack(&r, target, &out); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
     default: return -2;

@@ -540,6 +540,51 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* RefPack.DecompressHeaderless  EA/RefPack.cs:177-245.  Returns 1 at the end token (0xFC-0xFF). */
+static int dec_refpack(cur_t* c, win_t* w) {
+    while (c->pos < c->len) {                                                            /* :183 */
+        uint32_t plain, length = 0, distance = 0;
+        int prefix = cur_u8(c); if (c->eof) return 0;
+        if ((prefix & 0x80) == 0) {                                                      /* 0DDLLLPP DDDDDDDD */
+            int d0 = cur_u8(c); if (c->eof) return 0;
+            plain = (uint32_t)prefix & 3; length = (((uint32_t)prefix & 0x1C) >> 2) + 3;
+            distance = ((((uint32_t)prefix & 0x60) << 3) | (uint32_t)d0) + 1;
+        } else if ((prefix & 0x40) == 0) {                                               /* 10LLLLLL PPDDDDDD DDDDDDDD */
+            int d0 = cur_u8(c); if (c->eof) return 0;
+            int d1 = cur_u8(c); if (c->eof) return 0;
+            plain = (uint32_t)d0 >> 6; length = ((uint32_t)prefix & 0x3F) + 4;
+            distance = ((((uint32_t)d0 & 0x3F) << 8) | (uint32_t)d1) + 1;
+        } else if ((prefix & 0x20) == 0) {                                               /* 110DLLPP DDDDDDDD DDDDDDDD LLLLLLLL */
+            int d0 = cur_u8(c); if (c->eof) return 0;
+            int d1 = cur_u8(c); if (c->eof) return 0;
+            int d2 = cur_u8(c); if (c->eof) return 0;
+            plain = (uint32_t)prefix & 3; length = ((((uint32_t)prefix & 0x0C) << 6) | (uint32_t)d2) + 5;
+            distance = ((((((uint32_t)prefix & 0x10) << 4) | (uint32_t)d0) << 8) | (uint32_t)d1) + 1;
+        } else {                                                                         /* 111PPPPP */
+            plain = ((uint32_t)prefix & 0x1F) * 4 + 4;
+            if (plain > 0x70) {                                                          /* 111111PP: the end  :222-232 */
+                plain = (uint32_t)prefix & 3;
+                if (plain > c->len - c->pos) { c->eof = 1; return 0; }
+                uint32_t cl = win_clip(w, plain);
+                win_write(w, c->p + c->pos, cl);
+                if (w->overflow) return 0;
+                c->pos += plain;
+                return 1;
+            }
+        }
+        if (plain > c->len - c->pos) { c->eof = 1; return 0; }                           /* LzWindows.CopyFrom -> ReadExactly */
+        uint32_t cl = win_clip(w, plain);
+        win_write(w, c->p + c->pos, cl);
+        if (w->overflow) return 0;
+        c->pos += plain;
+        cl = win_clip(w, length);
+        win_back_copy(w, distance, cl);                                                  /* :236 (length 0 behind a literal run) */
+        if (w->overflow) return 0;
+    }
+    c->eof = 1;                                                                          /* :238 */
+    return 0;
+}
+
 /* LZ02.DecompressHeaderless  Camelot/LZ02.cs:77-115: runs until the terminator token (distance 0, length nibble 0), where only
  * MORE output than declared is an error (:97-100); input that ends first is EndOfStreamException (:114).  Returns 1 at the
  * terminator. */
@@ -822,6 +867,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
     case ALZ_FMT_CNS: return 8;                            /* CNS.cs:24 ceil(log2 0x100) */
+    case ALZ_FMT_REFPACK: return 17;                       /* RefPack.cs:31 ceil(log2 0x20000) */
     case ALZ_FMT_BLZ: return 13;                           /* flat spans in the managed code; distances reach 0xFFF + 3 */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
@@ -886,6 +932,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_CLZ0: info.has_size = 1; dec_clz0(&c, &w, size); break;
     case ALZ_FMT_CNS: info.has_size = 1; dec_cns(&c, &w, size); break;
     case ALZ_FMT_LZ02: info.has_size = 1; terminated = dec_lz02(&c, &w); break;
+    case ALZ_FMT_REFPACK: info.has_size = 1; terminated = dec_refpack(&c, &w); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -1013,6 +1060,8 @@ typedef struct {
     int lazy, noSelfOverlap;
     int* head; int* chain; int* minTable;
     int position;
+    int nprops;                                  /* > 1: the LzProperties[] form of the constructor (:42-69), ScoreMatch walks them (:301-321) */
+    struct { int maxLen, minLen, maxDist, minDist; } props[3];
 } mf_t;
 
 typedef struct { int offset, distance, length; } lzmatch_t;
@@ -1037,11 +1086,21 @@ static void mf_reset(mf_t* m) {
 }
 
 /* ctor  LzChainMatchFinder.cs:42-109 */
-static void mf_init(mf_t* m, const fmt_props* p, const alz_settings* st) {
+static void mf_init_multi(mf_t* m, const fmt_props* p, int np, const alz_settings* st) {
     int q = st ? st->quality : 8;
     memset(m, 0, sizeof(*m));
-    m->minLen = p->minLen; m->maxLen = p->maxLen; m->minDist = p->minDist; m->maxDist = p->maxDist;
-    int windowsBits = p->windowBits;
+    /* global constraints: the loosest of each over all property sets (:55-69) */
+    m->minLen = p[0].minLen; m->maxLen = p[0].maxLen; m->minDist = p[0].minDist; m->maxDist = p[0].maxDist;
+    int windowsBits = p[0].windowBits;
+    m->nprops = np;
+    for (int i = 0; i < np; i++) {
+        if (m->minLen > p[i].minLen) m->minLen = p[i].minLen;
+        if (m->maxLen < p[i].maxLen) m->maxLen = p[i].maxLen;
+        if (m->minDist > p[i].minDist) m->minDist = p[i].minDist;
+        if (m->maxDist < p[i].maxDist) m->maxDist = p[i].maxDist;
+        if (windowsBits < p[i].windowBits) windowsBits = p[i].windowBits;
+        m->props[i].maxLen = p[i].maxLen; m->props[i].minLen = p[i].minLen; m->props[i].maxDist = p[i].maxDist; m->props[i].minDist = p[i].minDist;
+    }
     int maxWindowBits = st ? st->max_window_bits : 0;
     if (maxWindowBits != 0) {
         if (windowsBits < maxWindowBits) windowsBits = maxWindowBits;
@@ -1061,6 +1120,7 @@ static void mf_init(mf_t* m, const fmt_props* p, const alz_settings* st) {
     if (q >= 10 && m->minLen < 4) { m->minMask = 0xFFFFFFFFu >> ((4 - m->minLen) * 8); m->minTable = (int*)malloc(sizeof(int) * 65536); }
     mf_reset(m);
 }
+static void mf_init(mf_t* m, const fmt_props* p, const alz_settings* st) { mf_init_multi(m, p, 1, st); }
 static void mf_free(mf_t* m) { free(m->head); free(m->chain); free(m->minTable); }
 
 /* ComputeHash  LzChainMatchFinder.cs:288-299 */
@@ -1088,10 +1148,18 @@ static inline int mf_match_len(const uint8_t* a, const uint8_t* b, int max) {
     while (len < max && a[len] == b[len]) len++;
     return len;
 }
-/* ScoreMatch (single LzProperties)  :301-308 */
+/* ScoreMatch  :301-321 */
 static inline int mf_score(const mf_t* m, int* len, int dist) {
     if (m->noSelfOverlap && *len > dist) *len = dist;
-    return *len - m->minLen;
+    if (m->nprops <= 1) return *len - m->minLen;
+    for (int i = 0; i < m->nprops; i++) {                    /* the first property set that admits the match */
+        if (dist <= m->props[i].maxDist && *len >= m->props[i].minLen && dist >= m->props[i].minDist) {
+            if (*len > m->props[i].maxLen) *len = m->props[i].maxLen;
+            return *len - m->props[i].minLen;
+        }
+    }
+    *len = 0;
+    return -1;
 }
 
 /* MatchSearch  :214-246 (ChainMatches :248-282 inlined) */
@@ -1500,6 +1568,46 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* RefPack.CompressHeaderless  EA/RefPack.cs:247-303: three property sets (long / medium / short form), the finder scores a
+ * candidate with the first one that admits it (LzChainMatchFinder.cs:301-321) */
+static void enc_refpack(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    const fmt_props props[3] = { { 17, 1028, 5, 0x20000, 1 }, { 14, 67, 4, 0x4000, 1 }, { 10, 10, 3, 0x400, 1 } };   /* RefPack.cs:29-34 */
+    mf_t m; mf_init_multi(&m, props, 3, st);
+    int sp = 0, plain = 0;
+    for (;;) {
+        lzmatch_t match = mf_find(&m, src, n);
+        plain = match.offset - sp;
+        while (plain > 3) {                                                              /* :257-265 */
+            int copyflag = (plain > 0x70 ? 0x70 : plain) / 4 - 1;
+            buf_u8(out, (uint32_t)(0xE0 | copyflag));
+            copyflag = copyflag * 4 + 4;
+            buf_put(out, src + sp, (size_t)copyflag);
+            sp += copyflag; plain -= copyflag;
+        }
+        if (match.length == 0) break;
+        int d1 = match.distance - 1;
+        if (match.length <= 10 && match.distance <= 0x400) {
+            buf_u8(out, (uint32_t)(plain | ((d1 & 0x300) >> 3) | ((match.length - 3) << 2)));
+            buf_u8(out, (uint32_t)d1 & 0xFF);
+        } else if (match.length >= 4 && match.length <= 67 && match.distance <= 0x4000) {
+            buf_u8(out, (uint32_t)(0x80 | (match.length - 4)));
+            buf_u8(out, (uint32_t)((d1 >> 8) | (plain << 6)) & 0xFF);
+            buf_u8(out, (uint32_t)d1 & 0xFF);
+        } else {
+            buf_u8(out, (uint32_t)(0xC0 | ((d1 >> 16) << 4) | (((match.length - 5) >> 8) << 2) | plain) & 0xFF);
+            buf_u8(out, (uint32_t)(d1 >> 8) & 0xFF);
+            buf_u8(out, (uint32_t)d1 & 0xFF);
+            buf_u8(out, (uint32_t)(match.length - 5) & 0xFF);
+        }
+        buf_put(out, src + sp, (size_t)plain);
+        sp += plain + match.length;
+        plain = 0;
+    }
+    buf_u8(out, (uint32_t)(0xFC | plain));                                               /* :300-301 */
+    buf_put(out, src + sp, (size_t)plain);
+    mf_free(&m);
+}
+
 /* LZ02.CompressHeaderless  Camelot/LZ02.cs:117-151 */
 static void enc_lz02(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
     fmt_props p = props_for(ALZ_FMT_LZ02, NULL, st);
@@ -1665,6 +1773,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_CLZ0: enc_clz0(st, src, (int)n, &out); break;
     case ALZ_FMT_CNS: enc_cns(st, src, (int)n, &out); break;
     case ALZ_FMT_LZ02: enc_lz02(st, src, (int)n, &out); break;
+    case ALZ_FMT_REFPACK: enc_refpack(st, src, (int)n, &out); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1695,6 +1804,25 @@ static int nin_header(const uint8_t* src, size_t len, uint8_t id, uint32_t* size
 }
 
 static const uint8_t SNAPPY_ID[10] = { 0xff, 0x06, 0x00, 0x00, 0x73, 0x4e, 0x61, 0x50, 0x70, 0x59 };
+
+/* RefPack.InternalReadHeader  EA/RefPack.cs:77-102: flags + 0xFB + size [+ compressed size], optionally behind a u32 compressed
+ * size (version 2).  Returns the header length, or an ALZ_E_* code. */
+static int refpack_header(const uint8_t* src, size_t len, uint32_t* size) {
+    size_t pos = 0;
+    if (len < 2) return ALZ_E_FORMAT;
+    if (src[1] != 0xFB) {                                            /* not version 1 / 3: a pre-header must follow  :81-90 */
+        if (len < 6 || src[4] != 0x10 || src[5] != 0xFB) return ALZ_E_FORMAT;
+        pos = 4;
+    }
+    uint8_t flag = src[pos]; pos += 2;
+    if (!(flag & 0x10)) return ALZ_E_UNSUPPORTED;                    /* NotSupportedException("No supported Flag")  :92-93 */
+    int wide = (flag & 0x80) != 0, n = wide ? 4 : 3;
+    if (len < pos + (size_t)n) return ALZ_E_FORMAT;
+    *size = wide ? be32(src + pos) : (((uint32_t)src[pos] << 16) | ((uint32_t)src[pos + 1] << 8) | src[pos + 2]);
+    pos += (size_t)n;
+    if (flag & 1) pos += (size_t)n;                                  /* StoresCompressedSize */
+    return (int)pos;
+}
 
 /* FastLZ.Validate  Formats/Common/FastLZ.cs:246-291 (IsMatch: Position + 4 < Length && Validate) */
 static int fastlz_validate(const uint8_t* s, size_t n) {
@@ -1755,6 +1883,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_CLZ0: if (len < 16 || memcmp(src, "CLZ\0", 4)) return ALZ_E_FORMAT; *size_out = be32(src + 12); return 0;      /* Marvelous/CLZ0.cs:33-39 */
     case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;         /* Specialized/CNS.cs:36-42 */
     case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3]; return 0;   /* Camelot/LZ02.cs:49-58 */
+    case ALZ_C_REFPACK: { int h = refpack_header(src, len, size_out); return h < 0 ? h : 0; }                                  /* EA/RefPack.cs:56-62 */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
         uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
@@ -2069,6 +2198,14 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         size = be32(src + 8); hdr = 16;
         uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_REFPACK: {                                                                /* EA/RefPack.cs:64-75 */
+        int h = refpack_header(src, len, &size);
+        if (h < 0) return h;
+        hdr = (size_t)h;
+        if (len < hdr) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        run_stream(ALZ_FMT_REFPACK, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
         break;
     }
     case ALZ_C_LZ02:                                                                     /* Camelot/LZ02.cs:60-64 */
@@ -2465,6 +2602,14 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_REFPACK:                                                                  /* EA/RefPack.cs:105-125: Options = Default | UsePreHeader -> version 2 */
+        if (n >= 0xFFFFFF) return ALZ_E_UNSUPPORTED;                                     /* "RefPack Version 2 does not support files over 16MB." */
+        if (cap < 9) return ALZ_E_NOMEM;
+        hdr = 9;
+        body = oracle_encode_stream(ALZ_FMT_REFPACK, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        wr32(dst, (uint32_t)(hdr + body - 4), 0); dst[4] = 0x10; dst[5] = 0xFB; dst[6] = (uint8_t)(n >> 16); dst[7] = (uint8_t)(n >> 8); dst[8] = (uint8_t)n;
         break;
     case ALZ_C_LZ02:                                                                     /* Camelot/LZ02.cs:66-75 (no extension data: DataType.Default) */
         if (cap < 4) return ALZ_E_NOMEM;
