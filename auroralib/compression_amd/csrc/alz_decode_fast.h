@@ -982,6 +982,48 @@ struct Cnx2Rounds {
     __device__ __forceinline__ void commit() {}
 };
 
+// Lane-parallel WFLZ parse (WFLZ.cs:130-159): an element is a 4-byte block + its literals and yields a match token and / or a
+// literal-run token -- in that order.  The end block is left to the exact parser.
+template <bool BIG>
+__device__ __forceinline__ bool wflz_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 length = in.lds[pos + 2], plain = in.lds[pos + 3];
+        nx[w] = (length | plain) == 0u ? ALZ_NX_BAD : 4u + plain;
+    }
+    u32 spos, sp, nel;
+    lane_walk_pos(nx, 32u, spos, sp, nel);                               // a block has >= 4 bytes: <= 16 per window
+    if (nel > 32u) { nel = 32u; sp = wave_readlane(spos, 32u); }         // two tokens per block fill the queue
+    if (nel == 0u) return false;
+    const bool st = (u32)lane < nel;
+    const u32 pos = i0 + spos;
+    const u32 b0 = in.lds[pos], b1 = in.lds[pos + 1], length = in.lds[pos + 2], plain = in.lds[pos + 3];
+    const u32 dist = BIG ? ((b0 << 8) | b1) : (b0 | (b1 << 8));
+    const u64 mm = __ballot(st && length != 0u), litm = __ballot(st && plain != 0u);
+    const u32 rank = mbcnt64(mm) + mbcnt64(litm);
+    if (st) {
+        u32 r = rank;
+        if (length) { stage[r] = ALZ_TOK_MATCH(length + 4u, dist ? dist : 65536u); r++; }      // E1
+        if (plain) stage[r] = ALZ_TOK_LIT(plain, (pos + 4u) & 2047u);
+    }
+    const u32 base = (u32)__popcll(mm) + (u32)__popcll(litm);
+    wave_sync();
+    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
+    wave_sync();
+    qt_out = qt; nt_out = base; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    return true;
+}
+template <bool BIG>
+struct WflzRounds {
+    InCache& in; u32* stage; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return wflz_parse_round<BIG>(in, p, stage, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
 // Lane-parallel RefPack parse (RefPack.cs:177-245): an element is a prefix byte, 0-3 data bytes and its literals (0-3 in front
 // of a match, 4..112 alone).  Like LZ4, an element yields a literal-run token and / or a match token, compacted through
 // `stage`.  The end token and a distance of 131 072 (beyond the token word) are left to the exact parser.

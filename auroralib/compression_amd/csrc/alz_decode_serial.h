@@ -365,6 +365,27 @@ __device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s,
     }
 }
 
+// WFLZ.DecompressHeaderless  WayForward/WFLZ.cs:130-159: blocks of (u16 distance, length - 4 or 0, literal count), each followed by
+// its literals; the match comes first; 0 / 0 / 0 ends the stream (s.done).  Resumable at block boundaries.
+template <class SK, bool BIG>
+__device__ __forceinline__ void dec_wflz_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 max_tokens = 0xFFFFFFFFu) {
+    for (;;) {
+        if (max_tokens-- == 0) return;
+        if (s.p + 4u > src_len || s.p + 4u < s.p) { s.eof = true; return; }           // Slice / indexer throw  :138-140
+        sk.ensure(in, s.p, 8);
+        const u32 w = in.peek4(s.p); s.p += 4;
+        const u32 dist = BIG ? (((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu)) : (w & 0xFFFFu);
+        const u32 length = (w >> 16) & 0xFFu, plain = w >> 24;
+        if (length != 0u) { if (!sk.match(dist, (u64)length + 4u, 65536)) return; }
+        else if (plain == 0u) { s.done = true; return; }
+        if (plain != 0u) {
+            if (plain > src_len - s.p) { s.eof = true; return; }                     // Slice throws  :155
+            if (!sk.run(in, s.p, plain)) return;
+            s.p += plain;
+        }
+    }
+}
+
 // RefPack.DecompressHeaderless  EA/RefPack.cs:177-245: prefix byte selects the form -- 0DDLLLPP D, 10LLLLLL PPDDDDDD D,
 // 110DLLPP D D L (0-3 literals, then a match), 111PPPPP (4..112 literals), 111111PP (0-3 literals, the end: s.done).
 // Resumable at element boundaries.  Runs to the end token; the declared size is only compared there.

@@ -470,6 +470,23 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_WFLZ || FMT == ALZ_FMT_WFLZ_BE) {   // WFLZ.cs:161-196
+        Match mt = { 0, 0, 0 }, nx = mf.next();
+        int plain = nx.offset;
+        for (;;) {
+            const u32 bp = (u32)(plain < 255 ? plain : 255), d = (u32)mt.distance & 0xFFFFu;
+            if (FMT == ALZ_FMT_WFLZ_BE) out.put16be(d); else out.put16le(d);
+            out.put(mt.length == 0 ? 0u : (u32)(mt.length - 4)); out.put(bp);
+            plain -= (int)bp;
+            sp += mt.length;
+            out.copy(src + sp, bp); sp += (int)bp;
+            if (plain == 0) {
+                if (sp == n) break;
+                mt = nx; nx = mf.next();
+                plain = nx.offset - (mt.offset + mt.length);
+            } else { mt.offset = 0; mt.distance = 0; mt.length = 0; }
+        }
+        out.put(0); out.put(0); out.put(0); out.put(0);                     // end block
     } else if constexpr (FMT == ALZ_FMT_REFPACK) {                          // RefPack.cs:247-303
         int plain = 0;
         for (;;) {
@@ -836,6 +853,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
     case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
     case ALZ_FMT_LZ02: g.min_len = 3; g.max_len = 272; g.max_dist = 0xFFF; break;                         // LZ02.cs:23
+    case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: wb = 16; g.min_len = 5; g.max_len = 255; g.max_dist = 0xFFFF; break;   // WFLZ.cs:20
     case ALZ_FMT_REFPACK:                                                                                   // RefPack.cs:29-34: three sets; the globals are the loosest of each (LzChainMatchFinder.cs:55-69)
         wb = 17; g.min_len = 3; g.max_len = 1028; g.max_dist = 0x20000; g.nprops = 3;
         g.p_max_dist[0] = 0x20000; g.p_max_len[0] = 1028; g.p_min_len[0] = 5;
@@ -912,6 +930,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_WFLZ: launch_emit<ALZ_FMT_WFLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_WFLZ_BE: launch_emit<ALZ_FMT_WFLZ_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_REFPACK: launch_emit<ALZ_FMT_REFPACK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ02: launch_emit<ALZ_FMT_LZ02>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_CNS: launch_emit<ALZ_FMT_CNS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

@@ -116,6 +116,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         dec_fastlz_serial(in, sk, s, src_len, fz);
     } else if constexpr (FMT == ALZ_FMT_CNX2) {
         has_size = true; dec_cnx2_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_WFLZ || FMT == ALZ_FMT_WFLZ_BE) {
+        dec_wflz_serial<SK, FMT == ALZ_FMT_WFLZ_BE>(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_REFPACK) {
         has_size = true; dec_refpack_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_LZ02) {
@@ -361,6 +363,20 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
         }
     }
+    else if constexpr (FMT == ALZ_FMT_WFLZ || FMT == ALZ_FMT_WFLZ_BE) {
+        constexpr bool BIG = (FMT == ALZ_FMT_WFLZ_BE);
+        for (;;) {
+            if (s.p + 1100u <= src_len) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                WflzRounds<BIG> rounds{in, stage, lane};
+                if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, cap, rounds)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_wflz_serial<SK, BIG>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
+    }
     else if constexpr (FMT == ALZ_FMT_REFPACK) {
         for (;;) {
             if (s.p + 1100u <= src_len) {
@@ -457,6 +473,8 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_CNX2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNX2>, 64, 0); break;
     case ALZ_FMT_CNS: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_CNS>, 64, 0); break;
     case ALZ_FMT_REFPACK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_REFPACK>, 64, 0); break;
+    case ALZ_FMT_WFLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_WFLZ>, 64, 0); break;
+    case ALZ_FMT_WFLZ_BE: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_WFLZ_BE>, 64, 0); break;
     case ALZ_FMT_BLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_BLZ, 8192>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_CLZ0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_CLZ0>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_LZ02: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_LZ02>, 64 * ALZ_WPB, 0); break;
@@ -501,6 +519,8 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_CNX2: return launch_queue<ALZ_FMT_CNX2>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_CNS: return launch_queue<ALZ_FMT_CNS>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_REFPACK: return launch_queue<ALZ_FMT_REFPACK>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_WFLZ: return launch_queue<ALZ_FMT_WFLZ>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_WFLZ_BE: return launch_queue<ALZ_FMT_WFLZ_BE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_BLZ: return launch_fast<ALZ_FMT_BLZ, 8192>(stream, s, d, streams, index, count, results, lz, 8192, 1);
         case ALZ_FMT_CLZ0: return launch_fast<ALZ_FMT_CLZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
         case ALZ_FMT_LZ02: return launch_fast<ALZ_FMT_LZ02>(stream, s, d, streams, index, count, results, lz, 4096, 1);
@@ -530,6 +550,8 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_CNX2: return launch_serial<ALZ_FMT_CNX2, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_CNS: return launch_serial<ALZ_FMT_CNS, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_REFPACK: return launch_serial<ALZ_FMT_REFPACK, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_WFLZ: return launch_serial<ALZ_FMT_WFLZ, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
+    case ALZ_FMT_WFLZ_BE: return launch_serial<ALZ_FMT_WFLZ_BE, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_BLZ: return launch_serial<ALZ_FMT_BLZ, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_CLZ0: return launch_serial<ALZ_FMT_CLZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
     case ALZ_FMT_LZ02: return launch_serial<ALZ_FMT_LZ02, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);

@@ -410,6 +410,25 @@ static void gen_refpack(rng_t* r, uint32_t target, out_t* out) {
     }
 }
 
+/* ---- WFLZ (WayForward/WFLZ.cs:130-159): blocks of (u16 distance, length - 4, literal count) + literals; 0/0/0 ends ---- */
+static void gen_wflz(rng_t* r, uint32_t target, out_t* out, int big) {
+    uint32_t produced = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        tok_t t = { 0, 0 };
+        if (produced > 0 && rem >= 5 && rng_unit(r) < 0.85) { t = draw_match_seq(r, produced, rem, 5, 255, 65535); if (t.len < 5) t.len = 5; }
+        rem -= t.len;
+        uint32_t lit = rng_unit(r) < 0.03 ? rng_range(r, 0, 255) : rng_geometric(r, 5.0);
+        if (lit > 255) lit = 255; if (lit > rem) lit = rem;
+        if (t.len == 0 && lit == 0) lit = 1;                             /* (0/0/0 would be the end block) */
+        if (big) { o_u8(out, t.dist >> 8); o_u8(out, t.dist & 0xFF); } else { o_u8(out, t.dist & 0xFF); o_u8(out, t.dist >> 8); }
+        o_u8(out, t.len ? t.len - 4 : 0); o_u8(out, lit);
+        put_rand(out, r, lit);
+        produced += t.len + lit;
+    }
+    o_u8(out, 0); o_u8(out, 0); o_u8(out, 0); o_u8(out, 0);
+}
+
 /* ---- CNS (Specialized/CNS.cs:77-108): control byte < 0x80 = literal run, else match (c & 0x7F) + 3 at distance byte + 1 ---- */
 static void gen_cns(rng_t* r, uint32_t target, out_t* out) {
     uint32_t produced = 0;
@@ -510,6 +529,8 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_BLZ: gen_blz(&r, target, &out); break;
     case ALZ_FMT_CNS: gen_cns(&r, target, &out); break;
     case ALZ_FMT_REFPACK: gen_refpack(&r, target, &out); break;
+    case ALZ_FMT_WFLZ: gen_wflz(&r, target, &out, 0); break;
+    case ALZ_FMT_WFLZ_BE: gen_wflz(&r, target, &out, 1); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;
     default: return -2;

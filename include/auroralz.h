@@ -68,7 +68,11 @@ typedef enum alz_format {
     ALZ_FMT_REFPACK    = 20, /* RefPack.DecompressHeaderless: prefix byte + 1-3 data bytes = 0-3 literals + a match (three forms), 0xE0-0xFB =
                                 4-112 literals, 0xFC-0xFF = 0-3 literals and the end; 128 KiB window; the declared size is only
                                 compared at the end   src/AuroraLib.Compression-Extended/EA/RefPack.cs:177-245.  SURVEY.md 8f rank 4. */
-    ALZ_FMT_COUNT      = 21
+    ALZ_FMT_WFLZ       = 21, /* WFLZ.DecompressHeaderless(.., Endian.Little): 4-byte blocks (u16 distance, length - 4, literal count) each
+                                followed by its literals; block 0/0/0 ends the stream
+                                src/AuroraLib.Compression-Extended/WayForward/WFLZ.cs:130-159.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_WFLZ_BE    = 22, /* WFLZ.DecompressHeaderless(.., Endian.Big): the same body with big-endian distance words */
+    ALZ_FMT_COUNT      = 23
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -274,8 +278,10 @@ typedef enum alz_container {
     ALZ_C_LZ02   = 39, /* type byte (1 / 2) + u24 BE size + LZ02 body [+ extension data]   src/AuroraLib.Compression-Extended/Camelot/LZ02.cs:60-75 */
     ALZ_C_REFPACK = 40, /* [u32 LE compressed size] + flags + 0xFB + BE u24/u32 size [+ compressed size] + RefPack body; written with
                           the pre-header (version 2)   src/AuroraLib.Compression-Extended/EA/RefPack.cs:38-175 */
+    ALZ_C_WFLZ   = 41, /* "WFLZ" + compressed size + size (FormatByteOrder, default little) + WFLZ body
+                          src/AuroraLib.Compression-Extended/WayForward/WFLZ.cs:36-105 */
     ALZ_C_CNX2   = 35, /* "CNX\x02" + extension[4] + BE csize + BE size + CNX2 body   src/AuroraLib.Compression.Sega/Sega/CNX2.cs:45-81 */
-    ALZ_C_COUNT  = 41
+    ALZ_C_COUNT  = 42
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

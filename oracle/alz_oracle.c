@@ -540,6 +540,29 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* WFLZ.DecompressHeaderless  WayForward/WFLZ.cs:130-159 (span based: reads past the end are exceptions -> INPUT_TRUNCATED) */
+static void dec_wflz(cur_t* c, win_t* w, int big) {
+    const uint8_t* s = c->p; uint32_t n = c->len, sp = 0;
+    for (;;) {
+        if (sp + 4 > n) { c->eof = 1; c->pos = sp; return; }                             /* Slice / indexer throw  :138-140 */
+        uint32_t dist = big ? (((uint32_t)s[sp] << 8) | s[sp + 1]) : ((uint32_t)s[sp] | ((uint32_t)s[sp + 1] << 8));
+        uint32_t length = s[sp + 2], plain = s[sp + 3];
+        sp += 4;
+        if (length != 0) {
+            uint32_t cl = win_clip(w, length + 4);
+            win_back_copy(w, dist, cl);                                                  /* :146 */
+            if (w->overflow) { c->pos = sp; return; }
+        } else if (plain == 0) { c->pos = sp; return; }                                  /* :148-151 */
+        if (plain != 0) {
+            if (plain > n - sp) { c->eof = 1; c->pos = sp; return; }                     /* Slice throws  :155 */
+            uint32_t cl = win_clip(w, plain);
+            win_write(w, s + sp, cl);
+            if (w->overflow) { c->pos = sp; return; }
+            sp += plain;
+        }
+    }
+}
+
 /* RefPack.DecompressHeaderless  EA/RefPack.cs:177-245.  Returns 1 at the end token (0xFC-0xFF). */
 static int dec_refpack(cur_t* c, win_t* w) {
     while (c->pos < c->len) {                                                            /* :183 */
@@ -869,7 +892,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     case ALZ_FMT_CNS: return 8;                            /* CNS.cs:24 ceil(log2 0x100) */
     case ALZ_FMT_REFPACK: return 17;                       /* RefPack.cs:31 ceil(log2 0x20000) */
     case ALZ_FMT_BLZ: return 13;                           /* flat spans in the managed code; distances reach 0xFFF + 3 */
-    case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
+    case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
     }
 }
@@ -933,6 +956,8 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_CNS: info.has_size = 1; dec_cns(&c, &w, size); break;
     case ALZ_FMT_LZ02: info.has_size = 1; terminated = dec_lz02(&c, &w); break;
     case ALZ_FMT_REFPACK: info.has_size = 1; terminated = dec_refpack(&c, &w); break;
+    case ALZ_FMT_WFLZ: dec_wflz(&c, &w, 0); break;
+    case ALZ_FMT_WFLZ_BE: dec_wflz(&c, &w, 1); break;
     default: info.bad_token = 1; break;
     }
     (void)terminated;
@@ -1252,6 +1277,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_CLZ0: p = (fmt_props){ 12, 18, 3, 0x1000, 1 }; break;                    /* CLZ0.cs:24 */
     case ALZ_FMT_CNS: p = (fmt_props){ 8, 130, 3, 0x100, 1 }; break;                      /* CNS.cs:24 */
     case ALZ_FMT_LZ02: p = (fmt_props){ 12, 272, 3, 0xFFF, 1 }; break;                    /* LZ02.cs:23 */
+    case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: p = (fmt_props){ 16, 255, 5, 0xFFFF, 1 }; break;   /* WFLZ.cs:20 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1568,6 +1594,33 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* WFLZ.CompressHeaderless  WayForward/WFLZ.cs:161-196 */
+static void enc_wflz(const alz_settings* st, const uint8_t* src, int n, buf_t* out, int big) {
+    fmt_props p = props_for(ALZ_FMT_WFLZ, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0;
+    lzmatch_t match = { 0, 0, 0 }, next = mf_find(&m, src, n);
+    int plain = next.offset;
+    for (;;) {
+        uint32_t bp = (uint32_t)(plain < 255 ? plain : 255), d = (uint32_t)match.distance & 0xFFFF;
+        if (big) buf_u16be(out, d); else buf_u16le(out, d);
+        buf_u8(out, match.length == 0 ? 0u : (uint32_t)(match.length - 4));
+        buf_u8(out, bp);
+        plain -= (int)bp;
+        sp += match.length;
+        buf_put(out, src + sp, bp);
+        sp += (int)bp;
+        if (plain == 0) {
+            if (sp == n) break;
+            match = next;
+            next = mf_find(&m, src, n);
+            plain = next.offset - (match.offset + match.length);
+        } else { match.offset = 0; match.distance = 0; match.length = 0; }
+    }
+    buf_u32le(out, 0);                                                                   /* end block */
+    mf_free(&m);
+}
+
 /* RefPack.CompressHeaderless  EA/RefPack.cs:247-303: three property sets (long / medium / short form), the finder scores a
  * candidate with the first one that admits it (LzChainMatchFinder.cs:301-321) */
 static void enc_refpack(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
@@ -1774,6 +1827,8 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_CNS: enc_cns(st, src, (int)n, &out); break;
     case ALZ_FMT_LZ02: enc_lz02(st, src, (int)n, &out); break;
     case ALZ_FMT_REFPACK: enc_refpack(st, src, (int)n, &out); break;
+    case ALZ_FMT_WFLZ: enc_wflz(st, src, (int)n, &out, 0); break;
+    case ALZ_FMT_WFLZ_BE: enc_wflz(st, src, (int)n, &out, 1); break;
     default: return -2;
     }
     if (out.fail) return -1;
@@ -1884,6 +1939,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;         /* Specialized/CNS.cs:36-42 */
     case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3]; return 0;   /* Camelot/LZ02.cs:49-58 */
     case ALZ_C_REFPACK: { int h = refpack_header(src, len, size_out); return h < 0 ? h : 0; }                                  /* EA/RefPack.cs:56-62 */
+    case ALZ_C_WFLZ: if (len < 12 || memcmp(src, "WFLZ", 4)) return ALZ_E_FORMAT; *size_out = (opt && opt->big_endian) ? be32(src + 8) : rd32le(src + 8); return 0;   /* WFLZ.cs:41-48 (FormatByteOrder defaults to little) */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
         uint32_t csz = (uint32_t)src[len - 8] | ((uint32_t)src[len - 7] << 8) | ((uint32_t)src[len - 6] << 16);
@@ -2198,6 +2254,18 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         size = be32(src + 8); hdr = 16;
         uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_WFLZ: {                                                                   /* WayForward/WFLZ.cs:50-86 */
+        if (len < 4 || memcmp(src, "WFLZ", 4)) return ALZ_E_FORMAT;
+        if (len < 12) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        const int wbig = opt && opt->big_endian;
+        uint32_t csz = wbig ? be32(src + 4) : rd32le(src + 4);
+        size = wbig ? be32(src + 8) : rd32le(src + 8); hdr = 12;
+        if (csz > len - hdr) csz = (uint32_t)(len - hdr);                                /* Stream.Read returns what is there; the body then runs off its end */
+        run_stream(wbig ? ALZ_FMT_WFLZ_BE : ALZ_FMT_WFLZ, NULL, src + hdr, csz, 0, 0, 0, dst, dst_cap, &r);
+        if (r.status == ALZ_ST_OK && r.dst_len != size) r.status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   /* '!='  :82-85 */
+        r.src_used = csz;                                                                /* the whole compressed span is read up front */
         break;
     }
     case ALZ_C_REFPACK: {                                                                /* EA/RefPack.cs:64-75 */
@@ -2603,6 +2671,15 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
         break;
+    case ALZ_C_WFLZ: {                                                                   /* WayForward/WFLZ.cs:89-105 */
+        const int wbig = opt && opt->big_endian;
+        if (cap < 12) return ALZ_E_NOMEM;
+        hdr = 12;
+        body = oracle_encode_stream(wbig ? ALZ_FMT_WFLZ_BE : ALZ_FMT_WFLZ, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memcpy(dst, "WFLZ", 4); wr32(dst + 4, (uint32_t)body, wbig); wr32(dst + 8, (uint32_t)n, wbig);
+        break;
+    }
     case ALZ_C_REFPACK:                                                                  /* EA/RefPack.cs:105-125: Options = Default | UsePreHeader -> version 2 */
         if (n >= 0xFFFFFF) return ALZ_E_UNSUPPORTED;                                     /* "RefPack Version 2 does not support files over 16MB." */
         if (cap < 9) return ALZ_E_NOMEM;

@@ -84,6 +84,29 @@ def test_fastlz_oracle_and_validate(test_bmp):
         assert st == (A.ST_INPUT_TRUNCATED if not bad else A.ST_BAD_TOKEN)
 
 
+def test_wflz_oracle_both_byte_orders(test_bmp):
+    """WFLZ (WayForward/WFLZ.cs): "WFLZ" + compressed size + size in FormatByteOrder (default little), body of 4-byte blocks."""
+    for big in (False, True):
+        for raw, q in ((test_bmp[:10240], 8), (test_bmp[:100], 4), (bytes(0x100), 0), (b"", 8)):
+            comp = O.container_compress(A.C_WFLZ, raw, quality=q, big_endian=big)
+            order = "big" if big else "little"
+            assert comp[:4] == b"WFLZ" and int.from_bytes(comp[4:8], order) == len(comp) - 12 and int.from_bytes(comp[8:12], order) == len(raw)
+            assert comp[-4:] == bytes(4)                                            # the end block
+            out, st = O.container_decompress(A.C_WFLZ, comp, cap=len(raw) + 300, big_endian=big)
+            assert st == A.ST_OK and out == raw
+            f = F.WFLZ()
+            assert f.FormatByteOrder == "Little"
+            f.FormatByteOrder = "Big" if big else "Little"
+            assert f.GetDecompressedSize(comp) == len(raw) == O.container_decompressed_size(A.C_WFLZ, comp, big_endian=big)
+            assert f.IsMatch(comp) == (len(comp) > 0x10)
+        # a wrong size field: DecompressedSizeException in both directions ('!=', WFLZ.cs:82-85)
+        comp = bytearray(O.container_compress(A.C_WFLZ, test_bmp[:5000], quality=8, big_endian=big))
+        for wrong in (4999, 5001):
+            comp[8:12] = wrong.to_bytes(4, "big" if big else "little")
+            out, st = O.container_decompress(A.C_WFLZ, bytes(comp), cap=6000, big_endian=big)
+            assert st == A.ST_OUTPUT_SIZE_MISMATCH and len(out) == 5000
+
+
 def test_lz00_keystream_oracle(test_bmp):
     """LZ00 (Sega/LZ00.cs): 64-byte header (magic, csize, name[32] at 16, size at 48, key at 52) + an LZSS body XORed with the
     keystream of the key -- key * 1103515245 + 12345 per byte, byte ^= (((key >> 16) & 0x7FFF) * 255) >> 15 (:128-141)."""

@@ -75,6 +75,22 @@ def test_wrapper_formats_roundtrip(cls, container, test_bmp):
         assert f.Decompress(comp, capacity=len(raw) + 300) == raw
 
 
+def test_wflz_both_byte_orders(test_bmp):
+    """WFLZ: FormatByteOrder selects the body variant; Compress == oracle bytes, Decompress == original, '!=' size rule."""
+    for big in (False, True):
+        for size, q in ((10, 4), (10240, 8), (70000, 0), (200000, 15)):
+            raw = test_bmp[:size]
+            f = F.WFLZ()
+            f.FormatByteOrder = "Big" if big else "Little"
+            comp = f.Compress(raw, F.CompressionSettings(q))
+            assert comp == O.container_compress(A.C_WFLZ, raw, quality=q, big_endian=big), (big, size, q)
+            assert f.Decompress(comp, capacity=len(raw) + 300) == raw
+        bad = bytearray(comp)
+        bad[8:12] = (len(raw) + 1).to_bytes(4, "big" if big else "little")
+        with pytest.raises(F.DecompressedSizeException):
+            f.Decompress(bytes(bad), capacity=len(raw) + 300)
+
+
 def test_lz77_chunklz10_is_one_gpu_batch(test_bmp):
     """ChunkLZ10: independent 4 KiB LZ10 chunks, encoded and decoded as one batch."""
     raw = test_bmp[:60000]           # the u16 end offsets cap a ChunkLZ10 file at 64 KiB of compressed chunks (LZ77.cs:92-95)
