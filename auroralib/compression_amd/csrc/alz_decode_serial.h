@@ -365,6 +365,57 @@ __device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s,
     }
 }
 
+// LZShrek.DecompressHeaderless  Activision/LZShrek.cs:73-119 (span based).  A group is a flag (literal count field << 3 | matches - 1),
+// the literals, then 1..8 matches; count / distance fields: 0-29 in the flag, 30 = 30 + next byte, 31 = 286 + next u16 LE
+// (ReadDistance :176-190); a match length 1..7 sits in its flag, 0 = a length byte follows (0 there: the end, s.done).
+// Resumable between tokens: s.bits = matches still to come in the current group.  A distance beyond the 4 KiB window is a
+// bad token (see the oracle).
+template <class SK>
+__device__ __forceinline__ bool shrek_field(InCache& in, SK& sk, DecState& s, u32 src_len, u32 flag, u32& v) {
+    v = flag >> 3;
+    if (v == 0x1Eu) { if (s.p >= src_len) { s.eof = true; return false; } sk.ensure(in, s.p, 1); v += in.peek1(s.p); s.p++; }
+    else if (v == 0x1Fu) {
+        if (s.p + 2u > src_len) { s.eof = true; s.p = src_len; return false; }
+        sk.ensure(in, s.p, 4); v = 286u + (in.peek4(s.p) & 0xFFFFu); s.p += 2;
+    }
+    return true;
+}
+template <class SK>
+__device__ __forceinline__ void dec_lzshrek_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 max_tokens = 0xFFFFFFFFu) {
+    for (;;) {
+        if (max_tokens-- == 0) return;
+        if (s.bits == 0) {                                                           // group start
+            if (s.p >= src_len) { s.eof = true; return; }                            // while (sourcePointer < source.Length) ... throw  :80, :118
+            sk.ensure(in, s.p, 8);
+            const u32 flag = in.peek1(s.p); s.p++;
+            u32 unc;
+            if (!shrek_field(in, sk, s, src_len, flag, unc)) return;
+            s.bits = (flag & 7u) + 1u;
+            if (unc != 0u) {
+                if (unc > src_len - s.p) { s.eof = true; return; }                   // Slice throws  :88
+                if (!sk.run(in, s.p, unc)) return;
+                s.p += unc;
+                continue;                                                            // (the run counts as one token)
+            }
+        }
+        if (s.p >= src_len) { s.eof = true; return; }
+        sk.ensure(in, s.p, 8);
+        const u32 flag = in.peek1(s.p); s.p++;
+        u32 length = flag & 7u;
+        if (length == 0u) {
+            if (s.p >= src_len) { s.eof = true; return; }
+            length = in.peek1(s.p); s.p++;
+            if (length == 0u) { s.done = true; return; }                             // end  :100-107
+            length += 7u;
+        }
+        u32 d;
+        if (!shrek_field(in, sk, s, src_len, flag, d)) return;
+        if (d + 1u > 0x1000u) { s.bad = true; return; }
+        s.bits--;
+        if (!sk.match(d + 1u, length, 4096)) return;
+    }
+}
+
 // WFLZ.DecompressHeaderless  WayForward/WFLZ.cs:130-159: blocks of (u16 distance, length - 4 or 0, literal count), each followed by
 // its literals; the match comes first; 0 / 0 / 0 ends the stream (s.done).  Resumable at block boundaries.
 template <class SK, bool BIG>

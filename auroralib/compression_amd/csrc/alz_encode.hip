@@ -470,6 +470,34 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_LZSHREK) {                          // LZShrek.cs:121-174
+        u8 buffer[32]; int blen;
+        Match mt = mf.next();
+        while (sp != n) {
+            const int plain = mt.offset - sp; int clen = 0;
+            const u8* unc = src + sp;
+            sp += plain;
+            blen = 0;
+            while (mt.length != 0 && clen < 8 && mt.offset == sp) {
+                const int lf = mt.length > 7 ? 0 : mt.length;
+                const int df = mt.distance > 30 ? (mt.distance > 286 ? 0x1F : 0x1E) : mt.distance - 1;
+                buffer[blen++] = (u8)((df << 3) | lf);
+                if (lf == 0) buffer[blen++] = (u8)(mt.length - 7);
+                if (df == 0x1E) buffer[blen++] = (u8)(mt.distance - 31);
+                else if (df == 0x1F) { const u32 v = (u32)(mt.distance - 287) & 0xFFFFu; buffer[blen++] = (u8)v; buffer[blen++] = (u8)(v >> 8); }
+                sp += mt.length;
+                mt = mf.next();
+                if (mt.length == 0 || clen >= 7 || mt.offset != sp) break;
+                clen++;
+            }
+            const int uf = plain > 29 ? (plain > 285 ? 0x1F : 0x1E) : plain;
+            out.put((u32)((uf << 3) | clen) & 0xFF);
+            if (uf == 0x1E) out.put((u32)(plain - 30) & 0xFF);
+            else if (uf == 0x1F) out.put16le((u32)(plain - 286) & 0xFFFF);
+            out.copy(unc, (u32)plain);
+            for (int i = 0; i < blen; i++) out.put(buffer[i]);
+        }
+        out.put(0); out.put(0); out.put(0); out.put(0);
     } else if constexpr (FMT == ALZ_FMT_WFLZ || FMT == ALZ_FMT_WFLZ_BE) {   // WFLZ.cs:161-196
         Match mt = { 0, 0, 0 }, nx = mf.next();
         int plain = nx.offset;
@@ -853,6 +881,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
     case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
     case ALZ_FMT_LZ02: g.min_len = 3; g.max_len = 272; g.max_dist = 0xFFF; break;                         // LZ02.cs:23
+    case ALZ_FMT_LZSHREK: g.min_len = 3; g.max_len = 262; g.max_dist = 0x1000; break;                     // LZShrek.cs:20
     case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: wb = 16; g.min_len = 5; g.max_len = 255; g.max_dist = 0xFFFF; break;   // WFLZ.cs:20
     case ALZ_FMT_REFPACK:                                                                                   // RefPack.cs:29-34: three sets; the globals are the loosest of each (LzChainMatchFinder.cs:55-69)
         wb = 17; g.min_len = 3; g.max_len = 1028; g.max_dist = 0x20000; g.nprops = 3;
@@ -930,6 +959,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZSHREK: launch_emit<ALZ_FMT_LZSHREK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_WFLZ: launch_emit<ALZ_FMT_WFLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_WFLZ_BE: launch_emit<ALZ_FMT_WFLZ_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_REFPACK: launch_emit<ALZ_FMT_REFPACK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

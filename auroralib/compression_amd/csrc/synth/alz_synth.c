@@ -410,6 +410,50 @@ static void gen_refpack(rng_t* r, uint32_t target, out_t* out) {
     }
 }
 
+/* ---- LZShrek (Activision/LZShrek.cs:73-119): groups of flag (literal count field << 3 | matches - 1) + literals + 1..8 matches;
+ * a match = flag (distance field << 3 | length 1..7, 0 = length byte follows) [+ length - 7] [+ distance extension] ---- */
+static void shrek_field(out_t* o, uint32_t v, uint32_t low) {        /* v: 0..65821 */
+    if (v > 285) { o_u8(o, (0x1F << 3) | low); }
+    else if (v > 29) { o_u8(o, (0x1E << 3) | low); }
+    else o_u8(o, (v << 3) | low);
+}
+static void gen_lzshrek(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t produced = 0;
+    while (produced < target) {
+        uint32_t rem = target - produced;
+        uint32_t lit = rng_unit(r) < 0.02 ? rng_range(r, 30, 700) : rng_geometric(r, 6.0); if (produced == 0 && lit == 0) lit = 1;
+        if (lit > rem) lit = rem;
+        rem -= lit;
+        /* the matches of the group: drawn first, because the flag in front of the literals counts them */
+        tok_t ms[8]; uint32_t nm = 0, pos = produced + lit;
+        uint32_t want = 1 + (uint32_t)(rng_next(r) & 7);
+        while (nm < want && rem >= 3) {
+            tok_t t = draw_match(r, pos, rem, 3, 18, 19, 262, 4096);
+            if (t.len < 1) t.len = 1;
+            ms[nm++] = t; pos += t.len; rem -= t.len;
+        }
+        if (nm == 0) {                                                 /* no room for a match: the remaining bytes as literals, then the end */
+            lit += rem;
+            shrek_field(out, lit, 0);
+            if (lit > 285) { o_u8(out, (lit - 286) & 0xFF); o_u8(out, (lit - 286) >> 8); } else if (lit > 29) o_u8(out, lit - 30);
+            put_rand(out, r, lit);
+            produced += lit;
+            break;
+        }
+        shrek_field(out, lit, nm - 1);
+        if (lit > 285) { o_u8(out, (lit - 286) & 0xFF); o_u8(out, (lit - 286) >> 8); } else if (lit > 29) o_u8(out, lit - 30);
+        put_rand(out, r, lit);
+        for (uint32_t i = 0; i < nm; i++) {
+            uint32_t d = ms[i].dist - 1, len = ms[i].len;
+            shrek_field(out, d, len > 7 ? 0 : len);
+            if (len > 7) o_u8(out, len - 7);
+            if (d > 285) { o_u8(out, (d - 286) & 0xFF); o_u8(out, (d - 286) >> 8); } else if (d > 29) o_u8(out, d - 30);
+        }
+        produced = pos;
+    }
+    o_u8(out, 0); o_u8(out, 0); o_u8(out, 0); o_u8(out, 0);            /* end: a group whose first match has length byte 0 */
+}
+
 /* ---- WFLZ (WayForward/WFLZ.cs:130-159): blocks of (u16 distance, length - 4, literal count) + literals; 0/0/0 ends ---- */
 static void gen_wflz(rng_t* r, uint32_t target, out_t* out, int big) {
     uint32_t produced = 0;
@@ -530,6 +574,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_CNS: gen_cns(&r, target, &out); break;
     case ALZ_FMT_REFPACK: gen_refpack(&r, target, &out); break;
     case ALZ_FMT_WFLZ: gen_wflz(&r, target, &out, 0); break;
+    case ALZ_FMT_LZSHREK: gen_lzshrek(&r, target, &out); break;
     case ALZ_FMT_WFLZ_BE: gen_wflz(&r, target, &out, 1); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;

@@ -72,7 +72,11 @@ typedef enum alz_format {
                                 followed by its literals; block 0/0/0 ends the stream
                                 src/AuroraLib.Compression-Extended/WayForward/WFLZ.cs:130-159.  SURVEY.md 8f rank 4. */
     ALZ_FMT_WFLZ_BE    = 22, /* WFLZ.DecompressHeaderless(.., Endian.Big): the same body with big-endian distance words */
-    ALZ_FMT_COUNT      = 23
+    ALZ_FMT_LZSHREK    = 23, /* LZShrek.DecompressHeaderless: groups of (flag: literal count | match count - 1) + literals + 1..8 matches with
+                                variable-length length / distance fields; ends at a zero length byte; 4 KiB window (a distance beyond it --
+                                encodable, but the managed decoder wraps it around its ring -- is BAD_TOKEN)
+                                src/AuroraLib.Compression-Extended/Activision/LZShrek.cs:73-119.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_COUNT      = 24
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -280,8 +284,9 @@ typedef enum alz_container {
                           the pre-header (version 2)   src/AuroraLib.Compression-Extended/EA/RefPack.cs:38-175 */
     ALZ_C_WFLZ   = 41, /* "WFLZ" + compressed size + size (FormatByteOrder, default little) + WFLZ body
                           src/AuroraLib.Compression-Extended/WayForward/WFLZ.cs:36-105 */
+    ALZ_C_LZSHREK = 42, /* u32 LE 0x10 + size + compressed size + 0 + LZShrek body   src/AuroraLib.Compression-Extended/Activision/LZShrek.cs:22-71 */
     ALZ_C_CNX2   = 35, /* "CNX\x02" + extension[4] + BE csize + BE size + CNX2 body   src/AuroraLib.Compression.Sega/Sega/CNX2.cs:45-81 */
-    ALZ_C_COUNT  = 42
+    ALZ_C_COUNT  = 43
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

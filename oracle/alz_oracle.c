@@ -540,6 +540,51 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* LZShrek.ReadDistance  Activision/LZShrek.cs:176-190: 0-29 in the flag, 30 = 30 + next byte, 31 = 286 + next u16 LE.  -1: input ended. */
+static int64_t shrek_field(const uint8_t* s, uint32_t n, uint32_t* sp, uint32_t flag) {
+    uint32_t v = flag >> 3;
+    if (v == 0x1E) { if (*sp >= n) return -1; v += s[(*sp)++]; }
+    else if (v == 0x1F) { if (*sp + 2 > n) { *sp = n; return -1; } v = 286u + s[*sp] + ((uint32_t)s[*sp + 1] << 8); *sp += 2; }
+    return v;
+}
+/* LZShrek.DecompressHeaderless  Activision/LZShrek.cs:73-119 (span based).  Returns 1 at the end marker.  A distance beyond the
+ * 4 KiB window is encodable (up to 65 822) but the managed decoder wraps it around its ring: refused as a bad token. */
+static int dec_lzshrek(cur_t* c, win_t* w, dec_info* info) {
+    const uint8_t* s = c->p; uint32_t n = c->len, sp = 0;
+    while (sp < n) {                                                                     /* :80 */
+        uint32_t flag = s[sp++];
+        uint32_t compressed = (flag & 7) + 1;
+        int64_t unc = shrek_field(s, n, &sp, flag);
+        if (unc < 0) { c->eof = 1; c->pos = sp; return 0; }
+        if (unc != 0) {
+            if ((uint64_t)unc > n - sp) { c->eof = 1; c->pos = sp; return 0; }           /* Slice throws  :88 */
+            uint32_t cl = win_clip(w, (uint32_t)unc);
+            win_write(w, s + sp, cl);
+            if (w->overflow) { c->pos = sp; return 0; }
+            sp += (uint32_t)unc;
+        }
+        for (uint32_t i = 0; i < compressed; i++) {
+            if (sp >= n) { c->eof = 1; c->pos = sp; return 0; }
+            flag = s[sp++];
+            uint32_t length = flag & 7;
+            if (length == 0) {
+                if (sp >= n) { c->eof = 1; c->pos = sp; return 0; }
+                length = s[sp++];
+                if (length == 0) { c->pos = sp; return 1; }                              /* end  :100-107 */
+                length += 7;
+            }
+            int64_t d = shrek_field(s, n, &sp, flag);
+            if (d < 0) { c->eof = 1; c->pos = sp; return 0; }
+            if (d + 1 > 0x1000) { info->bad_token = 1; c->pos = sp; return 0; }
+            uint32_t cl = win_clip(w, length);
+            win_back_copy(w, (uint32_t)d + 1, cl);                                       /* :113-115 */
+            if (w->overflow) { c->pos = sp; return 0; }
+        }
+    }
+    c->eof = 1; c->pos = sp;                                                             /* :118 */
+    return 0;
+}
+
 /* WFLZ.DecompressHeaderless  WayForward/WFLZ.cs:130-159 (span based: reads past the end are exceptions -> INPUT_TRUNCATED) */
 static void dec_wflz(cur_t* c, win_t* w, int big) {
     const uint8_t* s = c->p; uint32_t n = c->len, sp = 0;
@@ -886,7 +931,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     switch (format) {
     case ALZ_FMT_LZSS: return lz->window_bits;
     case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0:
-    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: case ALZ_FMT_LZ02: return 12; /* LZ10.cs:25 ... CLZ0.cs:24 */
+    case ALZ_FMT_LZHUDSON: case ALZ_FMT_SMSR00: case ALZ_FMT_CLZ0: case ALZ_FMT_LZ02: case ALZ_FMT_LZSHREK: return 12; /* LZ10.cs:25 ... CLZ0.cs:24 */
     case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 13;   /* PRS.cs:21 ceil(log2 0x1FFF) */
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
     case ALZ_FMT_CNS: return 8;                            /* CNS.cs:24 ceil(log2 0x100) */
@@ -957,6 +1002,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_LZ02: info.has_size = 1; terminated = dec_lz02(&c, &w); break;
     case ALZ_FMT_REFPACK: info.has_size = 1; terminated = dec_refpack(&c, &w); break;
     case ALZ_FMT_WFLZ: dec_wflz(&c, &w, 0); break;
+    case ALZ_FMT_LZSHREK: info.has_size = 1; terminated = dec_lzshrek(&c, &w, &info); break;
     case ALZ_FMT_WFLZ_BE: dec_wflz(&c, &w, 1); break;
     default: info.bad_token = 1; break;
     }
@@ -1278,6 +1324,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_CNS: p = (fmt_props){ 8, 130, 3, 0x100, 1 }; break;                      /* CNS.cs:24 */
     case ALZ_FMT_LZ02: p = (fmt_props){ 12, 272, 3, 0xFFF, 1 }; break;                    /* LZ02.cs:23 */
     case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: p = (fmt_props){ 16, 255, 5, 0xFFFF, 1 }; break;   /* WFLZ.cs:20 */
+    case ALZ_FMT_LZSHREK: p = (fmt_props){ 12, 262, 3, 0x1000, 1 }; break;                /* LZShrek.cs:20 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1594,6 +1641,42 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* LZShrek.CompressHeaderless  Activision/LZShrek.cs:121-174: a group = flag (literal count field << 3 | matches - 1), the
+ * literals, then the matches that follow each other without a gap (at most 8) */
+static void enc_lzshrek(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_LZSHREK, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    int sp = 0;
+    uint8_t buffer[8 * 4]; int blen;
+    lzmatch_t match = mf_find(&m, src, n);
+    while (sp != n) {                                                                    /* :129 */
+        int plain = match.offset - sp, compressedLength = 0;
+        const uint8_t* unc = src + sp;
+        sp += plain;
+        blen = 0;
+        while (match.length != 0 && compressedLength < 8 && match.offset == sp) {        /* :136 */
+            int lengthflag = match.length > 7 ? 0 : match.length;
+            int distanceflag = match.distance > 30 ? (match.distance > 286 ? 0x1F : 0x1E) : match.distance - 1;
+            buffer[blen++] = (uint8_t)((distanceflag << 3) | lengthflag);
+            if (lengthflag == 0) buffer[blen++] = (uint8_t)(match.length - 7);
+            if (distanceflag == 0x1E) buffer[blen++] = (uint8_t)(match.distance - 31);
+            else if (distanceflag == 0x1F) { uint32_t v = (uint32_t)(match.distance - 287) & 0xFFFF; buffer[blen++] = (uint8_t)v; buffer[blen++] = (uint8_t)(v >> 8); }
+            sp += match.length;
+            match = mf_find(&m, src, n);
+            if (match.length == 0 || compressedLength >= 7 || match.offset != sp) break;  /* :155-157 */
+            compressedLength++;
+        }
+        int uflag = plain > 29 ? (plain > 285 ? 0x1F : 0x1E) : plain;
+        buf_u8(out, (uint32_t)((uflag << 3) | compressedLength) & 0xFF);
+        if (uflag == 0x1E) buf_u8(out, (uint32_t)(plain - 30) & 0xFF);
+        else if (uflag == 0x1F) buf_u16le(out, (uint32_t)(plain - 286) & 0xFFFF);
+        buf_put(out, unc, (size_t)plain);
+        buf_put(out, buffer, (size_t)blen);
+    }
+    buf_u32le(out, 0);                                                                   /* destination.Write(0)  :173 */
+    mf_free(&m);
+}
+
 /* WFLZ.CompressHeaderless  WayForward/WFLZ.cs:161-196 */
 static void enc_wflz(const alz_settings* st, const uint8_t* src, int n, buf_t* out, int big) {
     fmt_props p = props_for(ALZ_FMT_WFLZ, NULL, st);
@@ -1828,6 +1911,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_LZ02: enc_lz02(st, src, (int)n, &out); break;
     case ALZ_FMT_REFPACK: enc_refpack(st, src, (int)n, &out); break;
     case ALZ_FMT_WFLZ: enc_wflz(st, src, (int)n, &out, 0); break;
+    case ALZ_FMT_LZSHREK: enc_lzshrek(st, src, (int)n, &out); break;
     case ALZ_FMT_WFLZ_BE: enc_wflz(st, src, (int)n, &out, 1); break;
     default: return -2;
     }
@@ -1939,6 +2023,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_CNS: if (len < 12 || memcmp(src, "@CNS", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 8); return 0;         /* Specialized/CNS.cs:36-42 */
     case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3]; return 0;   /* Camelot/LZ02.cs:49-58 */
     case ALZ_C_REFPACK: { int h = refpack_header(src, len, size_out); return h < 0 ? h : 0; }                                  /* EA/RefPack.cs:56-62 */
+    case ALZ_C_LZSHREK: if (len < 8) return ALZ_E_FORMAT; *size_out = rd32le(src + 4); return 0;                                 /* Activision/LZShrek.cs:28-33 */
     case ALZ_C_WFLZ: if (len < 12 || memcmp(src, "WFLZ", 4)) return ALZ_E_FORMAT; *size_out = (opt && opt->big_endian) ? be32(src + 8) : rd32le(src + 8); return 0;   /* WFLZ.cs:41-48 (FormatByteOrder defaults to little) */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
@@ -2254,6 +2339,15 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         size = be32(src + 8); hdr = 16;
         uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_LZSHREK: {                                                                /* Activision/LZShrek.cs:35-53 */
+        if (len < 12) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t offset = rd32le(src), csz = rd32le(src + 8);
+        size = rd32le(src + 4);
+        if (offset > len || csz > len - offset) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }   /* Seek + ReadExactly */
+        run_stream(ALZ_FMT_LZSHREK, NULL, src + offset, csz, size, 0, 0, dst, dst_cap, &r);
+        r.src_used = csz; hdr = offset;
         break;
     }
     case ALZ_C_WFLZ: {                                                                   /* WayForward/WFLZ.cs:50-86 */
@@ -2670,6 +2764,13 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_LZSHREK:                                                                  /* Activision/LZShrek.cs:60-71 */
+        if (cap < 16) return ALZ_E_NOMEM;
+        hdr = 16;
+        body = oracle_encode_stream(ALZ_FMT_LZSHREK, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        wr32(dst, 0x10, 0); wr32(dst + 4, (uint32_t)n, 0); wr32(dst + 8, (uint32_t)body, 0); wr32(dst + 12, 0, 0);
         break;
     case ALZ_C_WFLZ: {                                                                   /* WayForward/WFLZ.cs:89-105 */
         const int wbig = opt && opt->big_endian;
