@@ -4,9 +4,9 @@ import ctypes as C
 ABI_VERSION = 1
 
 # alz_format
-FMT_LZSS, FMT_LZ10, FMT_LZ11, FMT_YAZ0, FMT_YAY0, FMT_MIO0, FMT_PRS_BE, FMT_PRS_LE, FMT_LZ4_BLOCK, FMT_LZO, FMT_SNAPPY_RAW, FMT_LZ40, FMT_LZHUDSON, FMT_SMSR00, FMT_FASTLZ, FMT_CNX2, FMT_BLZ, FMT_CLZ0, FMT_CNS, FMT_LZ02, FMT_REFPACK, FMT_WFLZ, FMT_WFLZ_BE, FMT_LZSHREK = range(24)
-FMT_COUNT = 24
-FORMAT_NAMES = ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_le", "lz4_block", "lzo", "snappy_raw", "lz40", "lzhudson", "smsr00", "fastlz", "cnx2", "blz", "clz0", "cns", "lz02", "refpack", "wflz", "wflz_be", "lzshrek"]
+FMT_LZSS, FMT_LZ10, FMT_LZ11, FMT_YAZ0, FMT_YAY0, FMT_MIO0, FMT_PRS_BE, FMT_PRS_LE, FMT_LZ4_BLOCK, FMT_LZO, FMT_SNAPPY_RAW, FMT_LZ40, FMT_LZHUDSON, FMT_SMSR00, FMT_FASTLZ, FMT_CNX2, FMT_BLZ, FMT_CLZ0, FMT_CNS, FMT_LZ02, FMT_REFPACK, FMT_WFLZ, FMT_WFLZ_BE, FMT_LZSHREK, FMT_HIG = range(25)
+FMT_COUNT = 25
+FORMAT_NAMES = ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_le", "lz4_block", "lzo", "snappy_raw", "lz40", "lzhudson", "smsr00", "fastlz", "cnx2", "blz", "clz0", "cns", "lz02", "refpack", "wflz", "wflz_be", "lzshrek", "hig"]
 
 # alz_status
 ST_OK, ST_INPUT_TRUNCATED, ST_OUTPUT_SIZE_MISMATCH, ST_OUTPUT_CAPACITY, ST_BAD_TOKEN = range(5)
@@ -29,7 +29,8 @@ C_LZ02 = 39
 C_REFPACK = 40
 C_WFLZ = 41
 C_LZSHREK = 42
-C_COUNT = 43
+C_HIG = 43
+C_COUNT = 44
 LZ77_LZ10, LZ77_LZ11, LZ77_CHUNKLZ10 = 0x10, 0x11, 0xF7
 LEVEL5_ONLYSAVE, LEVEL5_LZ10 = 0, 1
 

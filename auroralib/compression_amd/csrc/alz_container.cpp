@@ -513,6 +513,7 @@ int alz_container_decompressed_size(uint32_t container, const alz_container_opti
     case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = be32(src) & 0xFFFFFFu; return ALZ_OK;   // LZ02.cs:49-58
     case ALZ_C_REFPACK: { const int h = refpack_header(src, len, size_out); return h < 0 ? h : ALZ_OK; }                                     // RefPack.cs:56-62
     case ALZ_C_LZSHREK: if (len < 8) return ALZ_E_FORMAT; *size_out = le32(src + 4); return ALZ_OK;                                           // LZShrek.cs:28-33
+    case ALZ_C_HIG: if (len < 0x40 || memcmp(src, "HIG!", 4)) return ALZ_E_FORMAT; *size_out = le32(src + 0x3C); return ALZ_OK;              // HIG.cs:39-45
     case ALZ_C_WFLZ: if (len < 12 || memcmp(src, "WFLZ", 4)) return ALZ_E_FORMAT; *size_out = rd32(src + 8, opt && opt->big_endian); return ALZ_OK;   // WFLZ.cs:41-48 (FormatByteOrder defaults to little)
     case ALZ_C_BLZ: {                                                                                                                      // BLZ.cs:32-41
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;                                                                              // "Invalid BLZ header."
@@ -601,6 +602,7 @@ int alz_container_is_match(uint32_t container, const uint8_t* src, size_t len) {
     case ALZ_C_CLZ0: return len > 0x10 && !memcmp(src, "CLZ\0", 4);                          // CLZ0.cs:30-31
     case ALZ_C_CNS: return len > 0x10 && !memcmp(src, "@CNS", 4);                            // CNS.cs:33-34
     case ALZ_C_WFLZ: return len > 0x10 && !memcmp(src, "WFLZ", 4);                           // WFLZ.cs:38-39
+    case ALZ_C_HIG: return len > 0x8 && !memcmp(src, "HIG!", 4);                             // HIG.cs:36-37
     case ALZ_C_LZSHREK: return len > 0x10 && le32(src) == 0x10 && le32(src + 4) != 0 && le32(src + 8) == len - 0x10 && le32(src + 12) == 0;   // LZShrek.cs:25-26
     case ALZ_C_REFPACK:                                                                      // RefPack.cs:40-53 (versions 1 / 3, or version 2 behind its pre-header)
         return len > 0x8 && (((src[0] & 0x2E) == 0 && (src[0] & 0x10) && src[1] == 0xFB && (be32(src + 1) & 0xFFFFFFu) != 0) ||
@@ -720,6 +722,17 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
         size = be32(src + 8); hdr = 16;
         rc = run_body(ctx, ALZ_FMT_SMSR00, nullptr, src + hdr, len - hdr, size, be32(src + 12) - 16u, 0, dst, dst_cap, &r);   // uncompressedDataPointer - source.Position
         break;
+    case ALZ_C_HIG: {                                                                       // HIG.cs:47-80
+        if (len < 4 || memcmp(src, "HIG!", 4)) return ALZ_E_FORMAT;
+        if (len < 0x40) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t start = le32(src + 4); const uint32_t ver = le32(src + 0x38);
+        size = le32(src + 0x3C);
+        if (ver == 5 || ver == 6) start = 0xC0;                                             // extension header 0x40-0xC0: compressed size + path
+        if (start > len) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        hdr = start;
+        rc = run_body(ctx, ALZ_FMT_HIG, nullptr, src + hdr, len - hdr, size, 0, 0, dst, dst_cap, &r);
+        break;
+    }
     case ALZ_C_LZSHREK: {                                                                   // LZShrek.cs:35-53
         if (len < 12) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
         const uint32_t offset = le32(src), csz = le32(src + 8);
@@ -921,7 +934,7 @@ int alz_container_decompress(alz_ctx* ctx, uint32_t container, const alz_contain
 size_t alz_container_compress_bound(uint32_t container, size_t n) {
     if (container == ALZ_C_SNAPPY) return 10 + n + (n / 0x10000 + 1) * 8 + 64;      // stored chunks bound the size
     if (container == ALZ_C_LZ4_FRAME || container == ALZ_C_LZ4_LEGACY) return n + n / 200 + (n / 0x10000 + 1) * 8 + 64;
-    return n + n / 4 + 128;  // flag-byte formats: <= 9/8 n + header; LZ4/LZO/Snappy literal-run overhead n/255
+    return n + n / 4 + 256;  // (HIG header: 0xC0) flag-byte formats: <= 9/8 n + header; LZ4/LZO/Snappy literal-run overhead n/255
 }
 
 // ICompressionEncoder.Compress(ReadOnlySpan<byte>, Stream, CompressionSettings)  Interfaces/ICompressionEncoder.cs:19
@@ -1079,6 +1092,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     case ALZ_C_LZ02: fmt = ALZ_FMT_LZ02; hdr = 4; break;
     case ALZ_C_WFLZ: fmt = (opt && opt->big_endian) ? ALZ_FMT_WFLZ_BE : ALZ_FMT_WFLZ; hdr = 12; break;
     case ALZ_C_LZSHREK: fmt = ALZ_FMT_LZSHREK; hdr = 16; break;
+    case ALZ_C_HIG: fmt = ALZ_FMT_HIG; hdr = 0xC0; break;                                      // Version 6 (the class default): 0x40 header + 0x80 extension
     case ALZ_C_REFPACK: if (n >= 0xFFFFFF) return ALZ_E_UNSUPPORTED; fmt = ALZ_FMT_REFPACK; hdr = 9; break;   // "RefPack Version 2 does not support files over 16MB."  RefPack.cs:110-111
     case ALZ_C_CNS: if (n < 4) return ALZ_E_INVALID; fmt = ALZ_FMT_CNS; hdr = 16; break;          // source[3]: IndexOutOfRangeException  CNS.cs:61
     case ALZ_C_FASTLZ: fmt = ALZ_FMT_FASTLZ; break;                                             // FastLZ.cs:162-163 (level 1: MaxWindowBits stays 0)
@@ -1114,6 +1128,9 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
     }
     case ALZ_C_REFPACK:                                                                                                                            // RefPack.cs:105-125: Options = Default | UsePreHeader -> version 2
         wr32(dst, (uint32_t)(hdr + r.dst_len - 4), false); dst[4] = 0x10; dst[5] = 0xFB; dst[6] = (uint8_t)(n >> 16); dst[7] = (uint8_t)(n >> 8); dst[8] = (uint8_t)n; break;
+    case ALZ_C_HIG:                                                                                                                                // HIG.cs:82-124
+        memset(dst, 0, 0xC0); memcpy(dst, "HIG!", 4); wr32(dst + 0x38, 6, false); wr32(dst + 0x3C, (uint32_t)n, false);
+        wr32(dst + 0x40, r.dst_len, false); memcpy(dst + 0x44, "C:\\HIG\\PROJECTS\\test.mb.wad.conf", 32); break;
     case ALZ_C_LZSHREK: wr32(dst, 0x10, false); wr32(dst + 4, (uint32_t)n, false); wr32(dst + 8, r.dst_len, false); wr32(dst + 12, 0, false); break;   // LZShrek.cs:60-71
     case ALZ_C_WFLZ: { const bool wbig = opt && opt->big_endian; memcpy(dst, "WFLZ", 4); wr32(dst + 4, r.dst_len, wbig); wr32(dst + 8, (uint32_t)n, wbig); break; }   // WFLZ.cs:89-105
     case ALZ_C_LZ02: dst[0] = 1; dst[1] = (uint8_t)(n >> 16); dst[2] = (uint8_t)(n >> 8); dst[3] = (uint8_t)n; break;                                  // LZ02.cs:66-75 (DataType.Default: no extension data)

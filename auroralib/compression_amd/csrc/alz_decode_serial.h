@@ -365,6 +365,66 @@ __device__ __forceinline__ void dec_blz_serial(InCache& in, SK& sk, DecState& s,
     }
 }
 
+// HIG.DecompressHeaderless  Specialized/HIG.cs:126-212: an initial literal block (count byte + 2, or 0 + u16 LE count), then while the output
+// is short of the declared size: a match -- LLLD DDPP D (length 4-9), 110L LLLL DDDD DDPP D (4-35), 111D LLLL [L | 0 LL] DDDD DDPP D
+// (3-65 535) -- followed by the literals its PP field announces (3: none, 1, 2, 0: a counted block).  32 KiB window.
+template <class SK>
+__device__ __forceinline__ bool hig_raw(InCache& in, SK& sk, DecState& s, u32 src_len) {
+    if (s.p >= src_len) { s.eof = true; return false; }                              // ReadByte() == -1: a count of 1 that ReadExactly fails on
+    sk.ensure(in, s.p, 4);
+    u32 plain = in.peek1(s.p) + 2u; s.p++;
+    if (plain == 2u) {
+        if (s.p + 2u > src_len) { s.eof = true; s.p = src_len; return false; }
+        plain = in.peek4(s.p) & 0xFFFFu; s.p += 2;
+    }
+    if (plain > src_len - s.p) { s.eof = true; return false; }                       // LzWindows.CopyFrom -> ReadExactly throws
+    if (!sk.run(in, s.p, plain)) return false;
+    s.p += plain;
+    return true;
+}
+template <class SK>
+__device__ __forceinline__ void dec_hig_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
+    if (!hig_raw(in, sk, s, src_len)) return;
+    while (sk.produced() < size) {
+        if (s.p >= src_len) { s.eof = true; return; }
+        sk.ensure(in, s.p, 8);
+        const u32 b = in.peek1(s.p); s.p++;
+        u32 length = b >> 5, distance, plain;
+        if (length < 6u) { length += 4u; distance = (b & 0x1Cu) << 6; plain = b & 3u; }
+        else {
+            if (length == 6u) { length = (b & 0x1Fu) + 4u; distance = 0; }
+            else {
+                length = (b & 0xFu) + 3u; distance = (b & 0x10u) << 10;
+                if (length == 3u) {
+                    if (s.p >= src_len) { s.eof = true; return; }
+                    length = in.peek1(s.p) + 18u; s.p++;
+                    if (length == 18u) {
+                        if (s.p + 2u > src_len) { s.eof = true; s.p = src_len; return; }
+                        sk.ensure(in, s.p, 4);
+                        const u32 w = in.peek4(s.p); s.p += 2;
+                        length = ((w & 0xFFu) << 8) | ((w >> 8) & 0xFFu);
+                    }
+                }
+            }
+            if (s.p >= src_len) { s.eof = true; return; }
+            sk.ensure(in, s.p, 4);
+            const u32 b2 = in.peek1(s.p); s.p++;
+            distance |= (b2 & 0xFCu) << 6; plain = b2 & 3u;
+        }
+        if (s.p >= src_len) { s.eof = true; return; }
+        distance |= in.peek1(s.p); s.p++;
+        if (length && !sk.match(distance, length, 32768)) return;                    // (E1: distance 0 = the window size)
+        if (plain == 0u) { if (!hig_raw(in, sk, s, src_len)) return; }
+        else if (plain < 3u) {                                                       // WriteByte(ReadUInt8()) once or twice: read, then write
+            for (u32 i = 0; i < plain; i++) {
+                if (s.p >= src_len) { s.eof = true; return; }
+                const u32 at = s.p; s.p++;
+                if (!sk.run(in, at, 1)) return;
+            }
+        }
+    }
+}
+
 // LZShrek.DecompressHeaderless  Activision/LZShrek.cs:73-119 (span based).  A group is a flag (literal count field << 3 | matches - 1),
 // the literals, then 1..8 matches; count / distance fields: 0-29 in the flag, 30 = 30 + next byte, 31 = 286 + next u16 LE
 // (ReadDistance :176-190); a match length 1..7 sits in its flag, 0 = a length byte follows (0 there: the end, s.done).

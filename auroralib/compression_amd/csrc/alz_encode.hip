@@ -470,6 +470,49 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             }
             out.put(0x11); out.put(0); out.put(0);
         }
+    } else if constexpr (FMT == ALZ_FMT_HIG) {                              // HIG.cs:214-323
+        auto put_raw = [&](int plain) {                                     // count - 2 in a byte, or 0 + the count as (ushort)
+            if (plain <= 255 + 2) out.put((u32)(plain - 2) & 0xFF); else { out.put(0); out.put16le((u32)plain & 0xFFFF); }
+        };
+        Match nx, mt = mf.next();
+        int plain = mt.offset;
+        if (plain < 2) {                                                    // the initial block holds at least 2 bytes  :223-232
+            mt.length -= plain + 1; mt.offset = 2;
+            plain = 2;
+            if (mt.length < g.min_len) { mt = mf.next(); plain = mt.offset; }
+        }
+        put_raw(plain);
+        out.copy(src, (u32)plain);
+        sp = plain;
+        while (mt.length != 0) {
+            nx = mf.next();
+            plain = nx.offset - (mt.offset + mt.length);
+            int b = plain == 0 ? 3 : (plain == 1 ? 1 : (plain == 2 ? 2 : 0));
+            if (mt.distance <= 0x7FF && mt.length <= 5 + 4) {
+                b |= ((mt.length - 4) << 5) | ((mt.distance >> 6) & 0x1C);
+                out.put((u32)b & 0xFF);
+            } else {
+                if (mt.distance <= 0x3FFF && mt.length <= 31 + 4) out.put((u32)(0xC0 | (mt.length - 4)));
+                else {
+                    const int length = mt.length <= 15 + 3 ? mt.length - 3 : 0;
+                    out.put((u32)(0xE0 | ((mt.distance >> 10) & 0x10) | length));
+                    if (length == 0) {
+                        if (mt.length <= 255 + 18) out.put((u32)(mt.length - 18) & 0xFF);
+                        else { out.put(0); out.put16be((u32)mt.length & 0xFFFF); }
+                    }
+                }
+                b |= (mt.distance >> 6) & 0xFC;
+                out.put((u32)b & 0xFF);
+            }
+            out.put((u32)mt.distance & 0xFF);
+            sp += mt.length;
+            if (plain != 0) {
+                if (plain > 2) put_raw(plain);
+                out.copy(src + sp, (u32)plain);
+                sp += plain;
+            }
+            mt = nx;
+        }
     } else if constexpr (FMT == ALZ_FMT_LZSHREK) {                          // LZShrek.cs:121-174
         u8 buffer[32]; int blen;
         Match mt = mf.next();
@@ -882,6 +925,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
     case ALZ_FMT_LZ02: g.min_len = 3; g.max_len = 272; g.max_dist = 0xFFF; break;                         // LZ02.cs:23
     case ALZ_FMT_LZSHREK: g.min_len = 3; g.max_len = 262; g.max_dist = 0x1000; break;                     // LZShrek.cs:20
+    case ALZ_FMT_HIG: wb = 15; g.min_len = 4; g.max_len = 0xFFFF; g.max_dist = 0x7FFF; break;               // HIG.cs:28
     case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: wb = 16; g.min_len = 5; g.max_len = 255; g.max_dist = 0xFFFF; break;   // WFLZ.cs:20
     case ALZ_FMT_REFPACK:                                                                                   // RefPack.cs:29-34: three sets; the globals are the loosest of each (LzChainMatchFinder.cs:55-69)
         wb = 17; g.min_len = 3; g.max_len = 1028; g.max_dist = 0x20000; g.nprops = 3;
@@ -959,6 +1003,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZSHREK: launch_emit<ALZ_FMT_LZSHREK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_WFLZ: launch_emit<ALZ_FMT_WFLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_WFLZ_BE: launch_emit<ALZ_FMT_WFLZ_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;

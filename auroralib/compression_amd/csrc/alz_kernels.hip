@@ -116,6 +116,8 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
         dec_fastlz_serial(in, sk, s, src_len, fz);
     } else if constexpr (FMT == ALZ_FMT_CNX2) {
         has_size = true; dec_cnx2_serial(in, sk, s, src_len, size);
+    } else if constexpr (FMT == ALZ_FMT_HIG) {
+        has_size = true; dec_hig_serial(in, sk, s, src_len, size);
     } else if constexpr (FMT == ALZ_FMT_LZSHREK) {
         has_size = true; dec_lzshrek_serial(in, sk, s, src_len);
     } else if constexpr (FMT == ALZ_FMT_WFLZ || FMT == ALZ_FMT_WFLZ_BE) {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     DecState s; dec_state_init(s);
     typedef EmitCfg<LW - 1u, false, !PRS, FB> CFG;
     typedef QueueSink<OW, CFG> SK;
-    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : ((FMT == ALZ_FMT_FASTLZ || FMT == ALZ_FMT_REFPACK) ? 131072u : (CNS ? 256u : (SHREK ? 4096u : (CNX ? 2048u : 65536u)))));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
+    SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : ((FMT == ALZ_FMT_FASTLZ || FMT == ALZ_FMT_REFPACK) ? 131072u : FMT == ALZ_FMT_HIG ? 32768u : (CNS ? 256u : (SHREK ? 4096u : (CNX ? 2048u : 65536u)))));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
     if constexpr (PRS) {
         // bulk of the stream: lane-assisted parse (prs_lane_parse) while >= 1100 input bytes remain; every token it
         // declines, and the tail of the stream, goes through the exact parser one token at a time
@@ -335,6 +337,9 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
             dec_lzo_serial(in, sk, s, src_len, ls, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
+    }
+    else if constexpr (FMT == ALZ_FMT_HIG) {
+        dec_hig_serial(in, sk, s, src_len, uni(st.decom_len));           // exact parser on the scalar unit, tokens executed 64 at a time
     }
     else if constexpr (SHREK) {
         dec_lzshrek_serial(in, sk, s, src_len);                          // exact parser on the scalar unit, tokens executed 64 at a time
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     }
     sk.flush();                                    // tokens parsed before an error/terminator are part of the output
     out.finish();
-    constexpr bool SIZED = CNX || FMT == ALZ_FMT_REFPACK;       // (RefPack: only more output than declared is an error, checked at the end token)
+    constexpr bool SIZED = CNX || FMT == ALZ_FMT_REFPACK || FMT == ALZ_FMT_HIG;       // (RefPack: only more output than declared is an error, checked at the end token)
     write_result(&results[sid], lane, out, s.p, resolve_status(s, SIZED, out.produced, SIZED ? uni(st.decom_len) : 0u, cap), hist);
 }
 
@@ -481,6 +486,7 @@ int alz_kernel_occupancy(int fmt) {
     case ALZ_FMT_REFPACK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_REFPACK>, 64, 0); break;
     case ALZ_FMT_WFLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_WFLZ>, 64, 0); break;
     case ALZ_FMT_LZSHREK: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_LZSHREK>, 64, 0); break;
+    case ALZ_FMT_HIG: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_HIG>, 64, 0); break;
     case ALZ_FMT_WFLZ_BE: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_queue_kernel<ALZ_FMT_WFLZ_BE>, 64, 0); break;
     case ALZ_FMT_BLZ: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_BLZ, 8192>, 64 * ALZ_WPB, 0); break;
     case ALZ_FMT_CLZ0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_fast_kernel<ALZ_FMT_CLZ0>, 64 * ALZ_WPB, 0); break;
@@ -528,6 +534,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_REFPACK: return launch_queue<ALZ_FMT_REFPACK>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_WFLZ: return launch_queue<ALZ_FMT_WFLZ>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZSHREK: return launch_queue<ALZ_FMT_LZSHREK>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_HIG: return launch_queue<ALZ_FMT_HIG>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_WFLZ_BE: return launch_queue<ALZ_FMT_WFLZ_BE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_BLZ: return launch_fast<ALZ_FMT_BLZ, 8192>(stream, s, d, streams, index, count, results, lz, 8192, 1);
         case ALZ_FMT_CLZ0: return launch_fast<ALZ_FMT_CLZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1);
@@ -560,6 +567,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
     case ALZ_FMT_REFPACK: return launch_serial<ALZ_FMT_REFPACK, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_WFLZ: return launch_serial<ALZ_FMT_WFLZ, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_LZSHREK: return launch_serial<ALZ_FMT_LZSHREK, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);
+    case ALZ_FMT_HIG: return launch_serial<ALZ_FMT_HIG, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_WFLZ_BE: return launch_serial<ALZ_FMT_WFLZ_BE, true>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_BLZ: return launch_serial<ALZ_FMT_BLZ, false>(stream, s, d, streams, index, count, results, lz, 8192, 1);
     case ALZ_FMT_CLZ0: return launch_serial<ALZ_FMT_CLZ0, false>(stream, s, d, streams, index, count, results, lz, 4096, 1);

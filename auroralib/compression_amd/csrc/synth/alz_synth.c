@@ -410,6 +410,49 @@ static void gen_refpack(rng_t* r, uint32_t target, out_t* out) {
     }
 }
 
+/* ---- HIG (Specialized/HIG.cs:126-212): initial literal block, then matches in three forms, each followed by 0 / 1 / 2 / counted literals ---- */
+static void hig_raw(out_t* out, rng_t* r, uint32_t n) {                /* count byte n - 2 (1..255), or 0 + the count as u16 LE */
+    if (n >= 3 && n <= 257) o_u8(out, n - 2);
+    else { o_u8(out, 0); o_u8(out, n & 0xFF); o_u8(out, n >> 8); }
+    put_rand(out, r, n);
+}
+static void gen_hig(rng_t* r, uint32_t target, out_t* out) {
+    uint32_t first = 2 + rng_geometric(r, 6.0);
+    if (first > target || target - first < 4) first = target;          /* a match needs 4 bytes: never leave 1..3 */
+    hig_raw(out, r, first);
+    uint32_t produced = first;
+    while (produced < target) {
+        uint32_t rem = target - produced;                              /* >= 4 */
+        tok_t t = draw_match_seq(r, produced, rem, 4, 0xFFFF, 0x7FFF);
+        if (t.len < 4) t.len = 4;
+        if (rng_unit(r) < 0.01 && rem > 400) t.len = rng_range(r, 274, rem < 5000 ? rem : 5000);
+        uint32_t after = rem - t.len;
+        uint32_t plain = rng_unit(r) < 0.3 ? 0 : rng_geometric(r, 3.0);
+        if (rng_unit(r) < 0.01) plain = rng_range(r, 250, 700);
+        if (plain > after) plain = after;
+        if (after - plain < 4) plain = after;                          /* the rest as literals: no room for another match */
+        const uint32_t pf = plain == 0 ? 3 : (plain == 1 ? 1 : (plain == 2 ? 2 : 0));
+        const int f1 = t.dist <= 0x7FF && t.len <= 9, f2 = t.dist <= 0x3FFF && t.len <= 35;
+        const double u = rng_unit(r);
+        if (f1 && u < 0.8) o_u8(out, pf | ((t.len - 4) << 5) | ((t.dist >> 6) & 0x1C));
+        else {
+            if (f2 && u < 0.95) o_u8(out, 0xC0 | (t.len - 4));
+            else {
+                const uint32_t l = t.len <= 18 ? t.len - 3 : 0;
+                o_u8(out, 0xE0 | ((t.dist >> 10) & 0x10) | l);
+                if (l == 0) {
+                    if (t.len <= 273) o_u8(out, t.len - 18);
+                    else { o_u8(out, 0); o_u8(out, t.len >> 8); o_u8(out, t.len & 0xFF); }
+                }
+            }
+            o_u8(out, pf | ((t.dist >> 6) & 0xFC));
+        }
+        o_u8(out, t.dist & 0xFF);
+        if (plain > 2) hig_raw(out, r, plain); else put_rand(out, r, plain);
+        produced += t.len + plain;
+    }
+}
+
 /* ---- LZShrek (Activision/LZShrek.cs:73-119): groups of flag (literal count field << 3 | matches - 1) + literals + 1..8 matches;
  * a match = flag (distance field << 3 | length 1..7, 0 = length byte follows) [+ length - 7] [+ distance extension] ---- */
 static void shrek_field(out_t* o, uint32_t v, uint32_t low) {        /* v: 0..65821 */
@@ -575,6 +618,7 @@ int64_t alz_synth_stream(uint32_t format, const alz_lz_properties* props, uint64
     case ALZ_FMT_REFPACK: gen_refpack(&r, target, &out); break;
     case ALZ_FMT_WFLZ: gen_wflz(&r, target, &out, 0); break;
     case ALZ_FMT_LZSHREK: gen_lzshrek(&r, target, &out); break;
+    case ALZ_FMT_HIG: gen_hig(&r, target, &out); break;
     case ALZ_FMT_WFLZ_BE: gen_wflz(&r, target, &out, 1); break;
     case ALZ_FMT_LZO: gen_lzo(&r, target, &out); break;
     case ALZ_FMT_SNAPPY_RAW: gen_snappy(&r, target, &out); break;

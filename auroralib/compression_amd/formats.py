@@ -216,6 +216,11 @@ class LZSega(_Format):
     container = A.C_LZSEGA
 
 
+class HIG(_Format):
+    """src/AuroraLib.Compression-Extended/Specialized/HIG.cs -- High Impact Games WAD LZ; writes version 6 with the default path."""
+    container = A.C_HIG
+
+
 class LZShrek(_Format):
     """src/AuroraLib.Compression-Extended/Activision/LZShrek.cs -- groups of literals + up to eight matches."""
     container = A.C_LZSHREK
@@ -373,5 +378,5 @@ class Level5(_Format):
     OnlySave, LZ10 = A.LEVEL5_ONLYSAVE, A.LEVEL5_LZ10
 
 
-ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ00, FastLZ, CNX2, BLZ, CLZ0, CNS, LZ02, RefPack, WFLZ, LZShrek, LZ77, Level5]
+ALL_FORMATS = [LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0, PRS, LZO, LZ4, LZ4Legacy, Snappy, GCLZ, CXLZ, LZ_3DS, COMP, Yaz1, AKLZ, LZ01, LZSega, Level5LZSS, LZOn, MDB4, FCMP, IECP, GCZ, ECD, SDPC, LZ40, LZ60, LZHudson, SMSR00, LZ00, FastLZ, CNX2, BLZ, CLZ0, CNS, LZ02, RefPack, WFLZ, LZShrek, HIG, LZ77, Level5]
 __all__ = [c.__name__ for c in ALL_FORMATS] + ["CompressionSettings", "DecompressedSizeException", "EndOfStreamException", "InvalidIdentifierException", "InvalidDataException", "AlzError"]

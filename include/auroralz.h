@@ -76,7 +76,10 @@ typedef enum alz_format {
                                 variable-length length / distance fields; ends at a zero length byte; 4 KiB window (a distance beyond it --
                                 encodable, but the managed decoder wraps it around its ring -- is BAD_TOKEN)
                                 src/AuroraLib.Compression-Extended/Activision/LZShrek.cs:73-119.  SURVEY.md 8f rank 4. */
-    ALZ_FMT_COUNT      = 24
+    ALZ_FMT_HIG        = 24, /* HIG.DecompressHeaderless: an initial literal block, then matches (three forms, lengths to 65 535, 32 KiB
+                                window) each followed by 0 / 1 / 2 / counted literals
+                                src/AuroraLib.Compression-Extended/Specialized/HIG.cs:126-212.  SURVEY.md 8f rank 4. */
+    ALZ_FMT_COUNT      = 25
 } alz_format;
 
 /* ---- per-stream status: the reference's exception types ---- */
@@ -285,8 +288,10 @@ typedef enum alz_container {
     ALZ_C_WFLZ   = 41, /* "WFLZ" + compressed size + size (FormatByteOrder, default little) + WFLZ body
                           src/AuroraLib.Compression-Extended/WayForward/WFLZ.cs:36-105 */
     ALZ_C_LZSHREK = 42, /* u32 LE 0x10 + size + compressed size + 0 + LZShrek body   src/AuroraLib.Compression-Extended/Activision/LZShrek.cs:22-71 */
+    ALZ_C_HIG    = 43, /* "HIG!" + 15 ints (data offset, ..., version, size) [+ compressed size + path[0x7C] for versions 5 / 6] + HIG body
+                          src/AuroraLib.Compression-Extended/Specialized/HIG.cs:47-124 */
     ALZ_C_CNX2   = 35, /* "CNX\x02" + extension[4] + BE csize + BE size + CNX2 body   src/AuroraLib.Compression.Sega/Sega/CNX2.cs:45-81 */
-    ALZ_C_COUNT  = 43
+    ALZ_C_COUNT  = 44
 } alz_container;
 
 /* alz_container_options.variant for ALZ_C_LZ77 (LZ77.CompressionType, LZ77.cs:156-164) and ALZ_C_LEVEL5 (Level5.cs:151-159) */

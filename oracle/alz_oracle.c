@@ -540,6 +540,60 @@ static void dec_blz(cur_t* c, win_t* w, uint32_t size, dec_info* info, int* shor
     if (win_produced(w) != size) *short_out = 1;                                         /* :131 DecompressedSizeException */
 }
 
+/* HIG literal block: count byte + 2, or 0 followed by a u16 LE count (HIG.cs:136-139, :189-193); Stream.ReadByte() == -1 gives a count
+ * of 1 that ReadExactly then fails on: truncated either way.  Returns 0 when decoding has to stop. */
+static int hig_raw(cur_t* c, win_t* w) {
+    int b = cur_u8(c); if (c->eof) return 0;
+    uint32_t plain = (uint32_t)b + 2;
+    if (plain == 2) {
+        int lo = cur_u8(c); if (c->eof) return 0;
+        int hi = cur_u8(c); if (c->eof) return 0;
+        plain = (uint32_t)lo | ((uint32_t)hi << 8);
+    }
+    if (c->pos > c->len || plain > c->len - c->pos) { c->eof = 1; return 0; }            /* LzWindows.CopyFrom -> ReadExactly */
+    uint32_t cl = win_clip(w, plain);
+    win_write(w, c->p + c->pos, cl);
+    if (w->overflow) return 0;
+    c->pos += plain;
+    return 1;
+}
+/* HIG.DecompressHeaderless  Specialized/HIG.cs:126-212 */
+static void dec_hig(cur_t* c, win_t* w, uint32_t size) {
+    if (!hig_raw(c, w)) return;                                                          /* initial RAW block  :136-139 */
+    while (win_produced(w) < size) {                                                     /* :141 */
+        int b = cur_u8(c); if (c->eof) return;
+        uint32_t length = (uint32_t)b >> 5, distance, plain;
+        if (length < 6) {                                                                /* LLLD DDPP  DDDD DDDD */
+            length += 4; distance = ((uint32_t)b & 0x1C) << 6; plain = (uint32_t)b & 3;
+        } else {
+            if (length == 6) { length = ((uint32_t)b & 0x1F) + 4; distance = 0; }        /* 110L LLLL  DDDD DDPP  DDDD DDDD */
+            else {                                                                       /* 111D LLLL ... */
+                length = ((uint32_t)b & 0xF) + 3; distance = ((uint32_t)b & 0x10) << 10;
+                if (length == 3) {
+                    int l = cur_u8(c); if (c->eof) return;
+                    length = (uint32_t)l + 18;
+                    if (length == 18) { int h = cur_u8(c); if (c->eof) return; int lo = cur_u8(c); if (c->eof) return; length = ((uint32_t)h << 8) | (uint32_t)lo; }
+                }
+            }
+            int b2 = cur_u8(c); if (c->eof) return;
+            distance |= ((uint32_t)b2 & 0xFC) << 6; plain = (uint32_t)b2 & 3;
+        }
+        int last = cur_u8(c); if (c->eof) return;
+        distance |= (uint32_t)last;
+        uint32_t cl = win_clip(w, length);
+        win_back_copy(w, distance, cl);                                                  /* :184 */
+        if (w->overflow) return;
+        if (plain == 0) { if (!hig_raw(c, w)) return; }                                  /* :187-204 */
+        else if (plain < 3) {
+            for (uint32_t i = 0; i < plain; i++) {
+                int v = cur_u8(c); if (c->eof) return;
+                if (win_clip(w, 1) < 1) return;
+                win_write_byte(w, (uint8_t)v);
+            }
+        }
+    }
+}
+
 /* LZShrek.ReadDistance  Activision/LZShrek.cs:176-190: 0-29 in the flag, 30 = 30 + next byte, 31 = 286 + next u16 LE.  -1: input ended. */
 static int64_t shrek_field(const uint8_t* s, uint32_t n, uint32_t* sp, uint32_t flag) {
     uint32_t v = flag >> 3;
@@ -936,6 +990,7 @@ static int fmt_window_bits(uint32_t format, const alz_lz_properties* lz) {
     case ALZ_FMT_CNX2: return 11;                          /* CNX2.cs:25 ceil(log2 0x800) */
     case ALZ_FMT_CNS: return 8;                            /* CNS.cs:24 ceil(log2 0x100) */
     case ALZ_FMT_REFPACK: return 17;                       /* RefPack.cs:31 ceil(log2 0x20000) */
+    case ALZ_FMT_HIG: return 15;                           /* HIG.cs:28 ceil(log2 0x7FFF) */
     case ALZ_FMT_BLZ: return 13;                           /* flat spans in the managed code; distances reach 0xFFF + 3 */
     case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_LZO: case ALZ_FMT_SNAPPY_RAW: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: return 16; /* LZ4.cs:29, LZO.cs:24, Snappy.cs:213 */
     default: return 12;
@@ -1003,6 +1058,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     case ALZ_FMT_REFPACK: info.has_size = 1; terminated = dec_refpack(&c, &w); break;
     case ALZ_FMT_WFLZ: dec_wflz(&c, &w, 0); break;
     case ALZ_FMT_LZSHREK: info.has_size = 1; terminated = dec_lzshrek(&c, &w, &info); break;
+    case ALZ_FMT_HIG: info.has_size = 1; dec_hig(&c, &w, size); break;
     case ALZ_FMT_WFLZ_BE: dec_wflz(&c, &w, 1); break;
     default: info.bad_token = 1; break;
     }
@@ -1325,6 +1381,7 @@ static fmt_props props_for(uint32_t format, const alz_lz_properties* lzp, const 
     case ALZ_FMT_LZ02: p = (fmt_props){ 12, 272, 3, 0xFFF, 1 }; break;                    /* LZ02.cs:23 */
     case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: p = (fmt_props){ 16, 255, 5, 0xFFFF, 1 }; break;   /* WFLZ.cs:20 */
     case ALZ_FMT_LZSHREK: p = (fmt_props){ 12, 262, 3, 0x1000, 1 }; break;                /* LZShrek.cs:20 */
+    case ALZ_FMT_HIG: p = (fmt_props){ 15, 0xFFFF, 4, 0x7FFF, 1 }; break;                 /* HIG.cs:28 */
     default: break;
     }
     if (st && st->min_distance > 0) p.minDist = st->min_distance;                        /* _lzVram LZ10.cs:30 */
@@ -1641,6 +1698,57 @@ static void enc_blz(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
     fw_dispose(&flag); mf_free(&m);
 }
 
+/* HIG literal block  HIG.cs:234-243, :303-313: count - 2 in a byte, or 0 + the count as (ushort) */
+static void hig_put_raw(buf_t* out, int plain) {
+    if (plain <= 255 + 2) buf_u8(out, (uint32_t)(plain - 2) & 0xFF);
+    else { buf_u8(out, 0); buf_u16le(out, (uint32_t)plain & 0xFFFF); }
+}
+/* HIG.CompressHeaderless  Specialized/HIG.cs:214-323 */
+static void enc_hig(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
+    fmt_props p = props_for(ALZ_FMT_HIG, NULL, st);
+    mf_t m; mf_init(&m, &p, st);
+    lzmatch_t next, match = mf_find(&m, src, n);
+    int plain = match.offset;
+    if (plain < 2) {                                                                     /* the initial block holds at least 2 bytes  :223-232 */
+        match.length -= plain + 1; match.offset = 2;
+        plain = 2;
+        if (match.length < p.minLen) { match = mf_find(&m, src, n); plain = match.offset; }
+    }
+    hig_put_raw(out, plain);
+    buf_put(out, src, (size_t)plain);                                                    /* (inputs below 2 bytes give a count byte of 0xFE / 0xFF: not decodable, as in the managed code) */
+    int sp = plain;
+    while (match.length != 0) {
+        next = mf_find(&m, src, n);
+        plain = next.offset - (match.offset + match.length);
+        int b = plain == 0 ? 3 : (plain == 1 ? 1 : (plain == 2 ? 2 : 0));
+        if (match.distance <= 0x7FF && match.length <= 5 + 4) {
+            b |= ((match.length - 4) << 5) | ((match.distance >> 6) & 0x1C);
+            buf_u8(out, (uint32_t)b & 0xFF);
+        } else {
+            if (match.distance <= 0x3FFF && match.length <= 31 + 4) buf_u8(out, (uint32_t)(0xC0 | (match.length - 4)));
+            else {
+                int length = match.length <= 15 + 3 ? match.length - 3 : 0;
+                buf_u8(out, (uint32_t)(0xE0 | ((match.distance >> 10) & 0x10) | length));
+                if (length == 0) {
+                    if (match.length <= 255 + 18) buf_u8(out, (uint32_t)(match.length - 18) & 0xFF);
+                    else { buf_u8(out, 0); buf_u16be(out, (uint32_t)match.length & 0xFFFF); }
+                }
+            }
+            b |= (match.distance >> 6) & 0xFC;
+            buf_u8(out, (uint32_t)b & 0xFF);
+        }
+        buf_u8(out, (uint32_t)match.distance & 0xFF);
+        sp += match.length;
+        if (plain != 0) {
+            if (plain > 2) hig_put_raw(out, plain);
+            buf_put(out, src + sp, (size_t)plain);
+            sp += plain;
+        }
+        match = next;
+    }
+    mf_free(&m);
+}
+
 /* LZShrek.CompressHeaderless  Activision/LZShrek.cs:121-174: a group = flag (literal count field << 3 | matches - 1), the
  * literals, then the matches that follow each other without a gap (at most 8) */
 static void enc_lzshrek(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
@@ -1912,6 +2020,7 @@ int64_t oracle_encode_stream(uint32_t format, const alz_lz_properties* props, co
     case ALZ_FMT_REFPACK: enc_refpack(st, src, (int)n, &out); break;
     case ALZ_FMT_WFLZ: enc_wflz(st, src, (int)n, &out, 0); break;
     case ALZ_FMT_LZSHREK: enc_lzshrek(st, src, (int)n, &out); break;
+    case ALZ_FMT_HIG: enc_hig(st, src, (int)n, &out); break;
     case ALZ_FMT_WFLZ_BE: enc_wflz(st, src, (int)n, &out, 1); break;
     default: return -2;
     }
@@ -2024,6 +2133,7 @@ int oracle_container_decompressed_size(uint32_t container, const alz_container_o
     case ALZ_C_LZ02: if (len < 4 || (src[0] != 1 && src[0] != 2)) return ALZ_E_FORMAT; *size_out = ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3]; return 0;   /* Camelot/LZ02.cs:49-58 */
     case ALZ_C_REFPACK: { int h = refpack_header(src, len, size_out); return h < 0 ? h : 0; }                                  /* EA/RefPack.cs:56-62 */
     case ALZ_C_LZSHREK: if (len < 8) return ALZ_E_FORMAT; *size_out = rd32le(src + 4); return 0;                                 /* Activision/LZShrek.cs:28-33 */
+    case ALZ_C_HIG: if (len < 0x40 || memcmp(src, "HIG!", 4)) return ALZ_E_FORMAT; *size_out = rd32le(src + 0x3C); return 0;       /* Specialized/HIG.cs:39-45 */
     case ALZ_C_WFLZ: if (len < 12 || memcmp(src, "WFLZ", 4)) return ALZ_E_FORMAT; *size_out = (opt && opt->big_endian) ? be32(src + 8) : rd32le(src + 8); return 0;   /* WFLZ.cs:41-48 (FormatByteOrder defaults to little) */
     case ALZ_C_BLZ: {                                                                                                       /* Nintendo/BLZ.cs:32-41 */
         if (len < 8 || src[len - 5] < 8) return ALZ_E_FORMAT;
@@ -2339,6 +2449,17 @@ int oracle_container_decompress(uint32_t container, const alz_container_options*
         size = be32(src + 8); hdr = 16;
         uint32_t up = be32(src + 12);                                                    /* uncompressedDataPointer - source.Position */
         run_stream(ALZ_FMT_SMSR00, NULL, src + hdr, (uint32_t)(len - hdr), size, up - 16, 0, dst, dst_cap, &r);
+        break;
+    }
+    case ALZ_C_HIG: {                                                                    /* Specialized/HIG.cs:47-80 */
+        if (len < 4 || memcmp(src, "HIG!", 4)) return ALZ_E_FORMAT;
+        if (len < 0x40) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        uint32_t start = rd32le(src + 4), ver = rd32le(src + 0x38);
+        size = rd32le(src + 0x3C);
+        if (ver == 5 || ver == 6) start = 0xC0;                                          /* extension header 0x40-0xC0: compressed size + path */
+        if (start > len) { r.status = ALZ_ST_INPUT_TRUNCATED; break; }
+        hdr = start;
+        run_stream(ALZ_FMT_HIG, NULL, src + hdr, (uint32_t)(len - hdr), size, 0, 0, dst, dst_cap, &r);
         break;
     }
     case ALZ_C_LZSHREK: {                                                                /* Activision/LZShrek.cs:35-53 */
@@ -2764,6 +2885,14 @@ int oracle_container_compress(uint32_t container, const alz_container_options* o
         body = oracle_encode_stream(ALZ_FMT_SMSR00, NULL, &st, src, n, dst + hdr, cap - hdr, &aux);
         if (body < 0) return ALZ_E_NOMEM;
         memcpy(dst, "SMSR00", 6); dst[6] = 0; dst[7] = 0; wr32(dst + 8, (uint32_t)n, 1); wr32(dst + 12, 16 + aux.aux0, 1);
+        break;
+    case ALZ_C_HIG:                                                                      /* Specialized/HIG.cs:82-124: Version 6, the default path string */
+        if (cap < 0xC0) return ALZ_E_NOMEM;
+        hdr = 0xC0;
+        body = oracle_encode_stream(ALZ_FMT_HIG, NULL, &st, src, n, dst + hdr, cap - hdr, NULL);
+        if (body < 0) return ALZ_E_NOMEM;
+        memset(dst, 0, 0xC0); memcpy(dst, "HIG!", 4); wr32(dst + 0x38, 6, 0); wr32(dst + 0x3C, (uint32_t)n, 0);
+        wr32(dst + 0x40, (uint32_t)body, 0); memcpy(dst + 0x44, "C:\\HIG\\PROJECTS\\test.mb.wad.conf", 32);
         break;
     case ALZ_C_LZSHREK:                                                                  /* Activision/LZShrek.cs:60-71 */
         if (cap < 16) return ALZ_E_NOMEM;

@@ -60,7 +60,7 @@ def test_exceptions(test_bmp):
 WRAPPERS = [(F.GCLZ, A.C_GCLZ), (F.CXLZ, A.C_CXLZ), (F.LZ_3DS, A.C_LZ_3DS), (F.COMP, A.C_COMP), (F.Yaz1, A.C_YAZ1), (F.AKLZ, A.C_AKLZ),
             (F.LZ01, A.C_LZ01), (F.LZSega, A.C_LZSEGA), (F.Level5LZSS, A.C_LEVEL5LZSS), (F.LZOn, A.C_LZON), (F.LZ77, A.C_LZ77), (F.Level5, A.C_LEVEL5),
             (F.MDB4, A.C_MDB4), (F.FCMP, A.C_FCMP), (F.IECP, A.C_IECP), (F.GCZ, A.C_GCZ), (F.ECD, A.C_ECD), (F.SDPC, A.C_SDPC),
-            (F.LZ40, A.C_LZ40), (F.LZ60, A.C_LZ60), (F.LZHudson, A.C_LZHUDSON), (F.SMSR00, A.C_SMSR00), (F.LZ00, A.C_LZ00), (F.FastLZ, A.C_FASTLZ), (F.CNX2, A.C_CNX2), (F.BLZ, A.C_BLZ), (F.CLZ0, A.C_CLZ0), (F.CNS, A.C_CNS), (F.LZ02, A.C_LZ02), (F.RefPack, A.C_REFPACK), (F.LZShrek, A.C_LZSHREK)]
+            (F.LZ40, A.C_LZ40), (F.LZ60, A.C_LZ60), (F.LZHudson, A.C_LZHUDSON), (F.SMSR00, A.C_SMSR00), (F.LZ00, A.C_LZ00), (F.FastLZ, A.C_FASTLZ), (F.CNX2, A.C_CNX2), (F.BLZ, A.C_BLZ), (F.CLZ0, A.C_CLZ0), (F.CNS, A.C_CNS), (F.LZ02, A.C_LZ02), (F.RefPack, A.C_REFPACK), (F.LZShrek, A.C_LZSHREK), (F.HIG, A.C_HIG)]
 
 
 @pytest.mark.parametrize("cls,container", WRAPPERS)

