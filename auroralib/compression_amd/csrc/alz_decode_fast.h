@@ -982,6 +982,75 @@ struct Cnx2Rounds {
     __device__ __forceinline__ void commit() {}
 };
 
+// Lane-parallel HIG parse (HIG.cs:141-206): an element is a match (2-6 header bytes in three forms) and the literals its PP field
+// announces (none, 1, 2, or a counted block); it yields a match token and / or a literal-run token, in that order.  Counted
+// blocks above 700 literals and lengths beyond the token word are left to the exact parser, as is the initial literal block.
+// `total` is reported one too high (the loop stops at the declared size: nothing behind that point may be consumed).
+__device__ __forceinline__ void hig_element(const InCache& in, u32 pos, u32& hdr, u32& length, u32& distance, u32& rawp, u32& cnt) {
+    const u32 b = in.lds[pos & 2047u], e1 = in.lds[(pos + 1u) & 2047u];
+    u32 pp, L = b >> 5;
+    if (L < 6u) { hdr = 2; length = L + 4u; distance = (b & 0x1Cu) << 6; pp = b & 3u; }
+    else {
+        u32 b2p;
+        if (L == 6u) { length = (b & 0x1Fu) + 4u; distance = 0; b2p = pos + 1u; }
+        else {
+            length = (b & 0xFu) + 3u; distance = (b & 0x10u) << 10; b2p = pos + 1u;
+            if (length == 3u) {
+                length = e1 + 18u; b2p = pos + 2u;
+                if (length == 18u) { length = ((u32)in.lds[(pos + 2u) & 2047u] << 8) | in.lds[(pos + 3u) & 2047u]; b2p = pos + 4u; }
+            }
+        }
+        const u32 b2 = in.lds[b2p & 2047u];
+        distance |= (b2 & 0xFCu) << 6; pp = b2 & 3u;
+        hdr = b2p - pos + 2u;
+    }
+    distance |= in.lds[(pos + hdr - 1u) & 2047u];
+    rawp = pos + hdr; cnt = pp == 3u ? 0u : pp;
+    if (pp == 0u) {
+        const u32 c = in.lds[rawp & 2047u];
+        if (c != 0u) { cnt = c + 2u; rawp += 1u; }
+        else { cnt = (u32)in.lds[(rawp + 1u) & 2047u] | ((u32)in.lds[(rawp + 2u) & 2047u] << 8); rawp += 3u; }
+    }
+}
+__device__ __forceinline__ bool hig_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        u32 hdr, length, distance, rawp, cnt;
+        hig_element(in, pos, hdr, length, distance, rawp, cnt);
+        nx[w] = (cnt > 700u || length > ALZ_TOK_MAXLEN) ? ALZ_NX_BAD : (rawp - pos) + cnt;
+    }
+    u32 spos, sp, nel;
+    lane_walk_pos(nx, 32u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
+    if (nel > 32u) { nel = 32u; sp = wave_readlane(spos, 32u); }         // two tokens per element fill the queue
+    if (nel == 0u) return false;
+    const bool st = (u32)lane < nel;
+    u32 hdr, length, distance, rawp, cnt;
+    hig_element(in, i0 + spos, hdr, length, distance, rawp, cnt);
+    const u64 mm = __ballot(st && length != 0u), litm = __ballot(st && cnt != 0u);
+    const u32 rank = mbcnt64(mm) + mbcnt64(litm);
+    if (st) {
+        u32 r = rank;
+        if (length) { stage[r] = ALZ_TOK_MATCH(length, distance ? distance : 32768u); r++; }   // E1
+        if (cnt) stage[r] = ALZ_TOK_LIT(cnt, rawp & 2047u);
+    }
+    const u32 base = (u32)__popcll(mm) + (u32)__popcll(litm);
+    wave_sync();
+    const u32 qt = (u32)lane < base ? stage[lane] : 0u;
+    wave_sync();
+    if (base == 0u) return false;
+    qt_out = qt; nt_out = base; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63) + 1u;
+    return true;
+}
+struct HigRounds {
+    InCache& in; u32* stage; int lane;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) { return hig_parse_round(in, p, stage, lane, qt, nt, total, adv); }
+    __device__ __forceinline__ void commit() {}
+};
+
 // Lane-parallel WFLZ parse (WFLZ.cs:130-159): an element is a 4-byte block + its literals and yields a match token and / or a
 // literal-run token -- in that order.  The end block is left to the exact parser.
 template <bool BIG>

@@ -382,10 +382,12 @@ __device__ __forceinline__ bool hig_raw(InCache& in, SK& sk, DecState& s, u32 sr
     s.p += plain;
     return true;
 }
+// Resumable at match boundaries: s.bits = 1 once the initial literal block is out.
 template <class SK>
-__device__ __forceinline__ void dec_hig_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size) {
-    if (!hig_raw(in, sk, s, src_len)) return;
+__device__ __forceinline__ void dec_hig_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u32 size, u32 max_tokens = 0xFFFFFFFFu) {
+    if (s.bits == 0) { if (!hig_raw(in, sk, s, src_len)) return; s.bits = 1; }
     while (sk.produced() < size) {
+        if (max_tokens-- == 0) return;
         if (s.p >= src_len) { s.eof = true; return; }
         sk.ensure(in, s.p, 8);
         const u32 b = in.peek1(s.p); s.p++;

@@ -339,7 +339,18 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
         }
     }
     else if constexpr (FMT == ALZ_FMT_HIG) {
-        dec_hig_serial(in, sk, s, src_len, uni(st.decom_len));           // exact parser on the scalar unit, tokens executed 64 at a time
+        const u32 size = uni(st.decom_len);
+        for (;;) {
+            if (s.bits != 0 && s.p + 1100u <= src_len && sk.produced() < size) {     // (behind the initial literal block)
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                HigRounds rounds{in, stage, lane};
+                if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 32768u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_hig_serial(in, sk, s, src_len, size, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
+        }
     }
     else if constexpr (SHREK) {
         dec_lzshrek_serial(in, sk, s, src_len);                          // exact parser on the scalar unit, tokens executed 64 at a time
