@@ -982,6 +982,104 @@ struct Cnx2Rounds {
     __device__ __forceinline__ void commit() {}
 };
 
+// Lane-parallel LZShrek parse (LZShrek.cs:73-119).  What an element is depends on one piece of state -- how many matches the
+// current group still owes: none = a group header (flag + its literals), otherwise a match -- so, as for LZO, every lane
+// interprets its byte both ways and the scalar walk carries the state: pk = [9:0] size as a header (0x3FF: not taken),
+// [13:10] the group's match count, [26:14] size as a match (0x1000: not taken -- the end marker, a distance beyond the
+// window).  Lane j of `spos` receives (start offset | state in front of it << 10) of the j-th element.
+__device__ __forceinline__ void shrek_walk_pos(const u32 (&pk)[4], u32& spos_out, u32& sp_out, u32& n_out, u32& state_io) {
+    u32 spos = 0, sp = 0, cnt = 0, state = uni(state_io), n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (cnt < 64u && n < 0x3FFu && sp < 64u * (u32)(w + 1)) {
+            u32 v, t;
+            asm volatile(
+                "s_mov_b32 m0, %[cnt]\n\t"
+                "s_nop 1\n"
+                "1:\n\t"
+                "v_readlane_b32 %[v], %[pk], %[sp]\n\t"
+                "s_lshl_b32 %[t], %[state], 10\n\t"
+                "s_or_b32 %[t], %[t], %[sp]\n\t"
+                "s_cmp_eq_u32 %[state], 0\n\t"
+                "v_writelane_b32 %[spos], %[t], m0\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "s_and_b32 %[n], %[v], 0x3ff\n\t"                  // a group header: its size, and the matches it announces
+                "s_bfe_u32 %[state], %[v], 0x4000a\n\t"
+                "s_branch 3f\n"
+                "2:\n\t"
+                "s_bfe_u32 %[n], %[v], 0xd000e\n\t"                 // a match
+                "s_sub_u32 %[state], %[state], 1\n"
+                "3:\n\t"
+                "s_add_u32 m0, m0, 1\n\t"
+                "s_add_u32 %[sp], %[sp], %[n]\n\t"
+                "s_cmp_ge_u32 m0, 64\n\t"
+                "s_cbranch_scc1 4f\n\t"
+                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n"
+                "4:\n\t"
+                "s_mov_b32 %[cnt], m0\n\t"
+                : [v] "=&s"(v), [n] "+s"(n), [t] "=&s"(t), [sp] "+s"(sp), [spos] "+v"(spos), [cnt] "+s"(cnt), [state] "+s"(state)
+                : [pk] "v"(pk[w]), [lim] "s"(64u * (u32)(w + 1))
+                : "scc", "m0");
+        }
+    }
+    if (n >= 0x3FFu) { cnt -= 1u; const u32 v = wave_readlane(spos, cnt); sp = v & 0x3FFu; state = v >> 10; }   // undo the element not taken
+    spos_out = spos; sp_out = sp; n_out = cnt; state_io = state;
+}
+__device__ __forceinline__ u32 shrek_count(u32 v, u32 x, u32 y) { return v < 30u ? v : (v == 30u ? 30u + x : 286u + x + (y << 8)); }
+__device__ __forceinline__ bool lzshrek_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& state, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
+    const u32 i0 = in.idx(p);
+    u32 pk[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2], e3 = in.lds[pos + 3];
+        const u32 v = b >> 3, ext = v == 30u ? 1u : (v == 31u ? 2u : 0u);
+        const u32 lits = shrek_count(v, e1, e2);
+        const u32 sizeH = lits > 700u ? 0x3FFu : 1u + ext + lits;
+        const u32 lenb = (b & 7u) == 0u ? 1u : 0u;
+        const u32 x = lenb ? e2 : e1, y = lenb ? e3 : e2;
+        const u32 dist = shrek_count(v, x, y) + 1u;
+        const bool badm = (lenb && e1 == 0u) || dist > 0x1000u;
+        const u32 sizeM = badm ? 0x1000u : 1u + lenb + ext;
+        pk[w] = sizeH | (((b & 7u) + 1u) << 10) | (sizeM << 14);
+    }
+    u32 spos, sp, nel;
+    shrek_walk_pos(pk, spos, sp, nel, state);
+    if (nel == 0u) return false;
+    const bool st = (u32)lane < nel;
+    const u32 pos = i0 + (spos & 0x3FFu);
+    const bool header = (spos >> 10) == 0u;
+    const u32 b = in.lds[pos & 2047u], e1 = in.lds[(pos + 1u) & 2047u], e2 = in.lds[(pos + 2u) & 2047u], e3 = in.lds[(pos + 3u) & 2047u];
+    const u32 v = b >> 3, ext = v == 30u ? 1u : (v == 31u ? 2u : 0u);
+    u32 t;
+    if (header) { const u32 lits = shrek_count(v, e1, e2); t = lits ? ALZ_TOK_LIT(lits, (pos + 1u + ext) & 2047u) : 0u; }
+    else {
+        const u32 lenb = (b & 7u) == 0u ? 1u : 0u;
+        const u32 len = lenb ? e1 + 7u : (b & 7u);
+        t = ALZ_TOK_MATCH(len, shrek_count(v, lenb ? e2 : e1, lenb ? e3 : e2) + 1u);
+    }
+    const bool valid = st && t != 0u;
+    const u64 vm = __ballot(valid);
+    const u32 nv = (u32)__popcll(vm);
+    if (nv == 0u) return false;                                          // (only empty group headers: the exact parser steps over them)
+    if (valid) stage[mbcnt64(vm)] = t;
+    wave_sync();
+    const u32 qt = (u32)lane < nv ? stage[lane] : 0u;
+    wave_sync();
+    qt_out = qt; nt_out = nv; adv_out = sp;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    return true;
+}
+struct LzshrekRounds {
+    InCache& in; u32* stage; int lane; u32 state, pending;
+    __device__ __forceinline__ bool operator()(u32 p, u32& qt, u32& nt, u32& total, u32& adv) {
+        pending = state;
+        return lzshrek_parse_round(in, p, stage, lane, pending, qt, nt, total, adv);
+    }
+    __device__ __forceinline__ void commit() { state = pending; }
+};
+
 // Lane-parallel HIG parse (HIG.cs:141-206): an element is a match (2-6 header bytes in three forms) and the literals its PP field
 // announces (none, 1, 2, or a counted block); it yields a match token and / or a literal-run token, in that order.  Counted
 // blocks above 700 literals and lengths beyond the token word are left to the exact parser, as is the initial literal block.

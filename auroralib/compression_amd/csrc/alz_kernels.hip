@@ -353,7 +353,21 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
         }
     }
     else if constexpr (SHREK) {
-        dec_lzshrek_serial(in, sk, s, src_len);                          // exact parser on the scalar unit, tokens executed 64 at a time
+        for (;;) {
+            if (s.p + 1100u <= src_len) {
+                sk.ensure(in, s.p, 1024);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                LzshrekRounds rounds{in, stage, lane, s.bits, 0u};           // s.bits: matches the current group still owes (the exact parser's state)
+                if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 4096u, cap, rounds)) {
+                    s.bits = rounds.state;
+                    if (s.ovf) break;
+                    continue;
+                }
+            }
+            const bool tail = s.p + 1100u > src_len;
+            dec_lzshrek_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
     }
     else if constexpr (CNS) {
         const u32 size = uni(st.decom_len);
