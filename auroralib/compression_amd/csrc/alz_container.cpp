@@ -1203,6 +1203,8 @@ static const struct { const char* name; uint32_t format; uint8_t wb, lb, th; } k
     { "PRS big", ALZ_FMT_PRS_BE, 0, 0, 0 }, { "PRS Little", ALZ_FMT_PRS_LE, 0, 0, 0 },
     { "LZ10", ALZ_FMT_LZ10, 0, 0, 0 }, { "LZ11", ALZ_FMT_LZ11, 0, 0, 0 }, { "Yaz0", ALZ_FMT_YAZ0, 0, 0, 0 },
     { "LZ40", ALZ_FMT_LZ40, 0, 0, 0 }, { "LZHudson", ALZ_FMT_LZHUDSON, 0, 0, 0 },
+    { "RefPack", ALZ_FMT_REFPACK, 0, 0, 0 }, { "LZ02", ALZ_FMT_LZ02, 0, 0, 0 }, { "CLZ0", ALZ_FMT_CLZ0, 0, 0, 0 }, { "CNS", ALZ_FMT_CNS, 0, 0, 0 },
+    { "LZShrek", ALZ_FMT_LZSHREK, 0, 0, 0 },
     // (the command's "BLZ" entry decodes into MemoryStream.GetBuffer() and never advances Position, :121 -- it cannot
     //  report success, so it is not offered here)
 };

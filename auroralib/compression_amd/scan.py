@@ -44,7 +44,7 @@ def brute_force(raw, expected_size):
     on the GPU path.  Returns {decoder name: (success, status, output bytes)}; success == "successfully unpacked"."""
     raw = bytes(raw)
     lib = load()
-    nd = 14
+    nd = 19
     slot = max(expected_size, 1)
     dst = C.create_string_buffer(slot * nd)
     res = (A.Result * nd)()

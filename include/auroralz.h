@@ -358,7 +358,7 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t n_cont
  * buffer, every raw decoder of the path tried against a fixed destination of `expected_size` bytes -- one GPU batch per
  * LZSS geometry.  Decoder i writes to dst + i * slot (slot >= expected_size); it "successfully unpacked the file" (:42)
  * when results[i].status == ALZ_ST_OK and results[i].dst_len == expected_size. */
-#define ALZ_BRUTE_DECODERS 14
+#define ALZ_BRUTE_DECODERS 19
 const char* alz_brute_decoder_name(uint32_t i);   /* the names of GetRawDecodersList (:96-131), e.g. "LZSS (10, 6, 2)" */
 int alz_brute_force(alz_ctx* ctx, const uint8_t* raw, size_t raw_len, uint32_t expected_size,
                     uint8_t* dst, size_t slot, alz_result* results /* [ALZ_BRUTE_DECODERS] */);

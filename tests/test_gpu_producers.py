@@ -105,13 +105,15 @@ def test_brute_force(test_bmp):
     lz1062 = A.LzProperties.from_bits(10, 6, 2)
     cases = [("LZ10", A.FMT_LZ10, None), ("LZ11", A.FMT_LZ11, None), ("Yaz0", A.FMT_YAZ0, None), ("PRS big", A.FMT_PRS_BE, None),
              ("PRS Little", A.FMT_PRS_LE, None), ("LZO", A.FMT_LZO, None), ("LZ4", A.FMT_LZ4_BLOCK, None),
-             ("LZSS (12, 4, 2)", A.FMT_LZSS, None), ("LZSS (10, 6, 2)", A.FMT_LZSS, lz1062), ("LZ40", A.FMT_LZ40, None), ("LZHudson", A.FMT_LZHUDSON, None)]
-    names = ["LZO", "LZ4", "LZSS (12, 4, 2)", "LZSS (12, 4, 3)", "LZSS (10, 6, 2)", "LZSS (10, 6, 3)", "LZSS0", "PRS big", "PRS Little", "LZ10", "LZ11", "Yaz0", "LZ40", "LZHudson"]
+             ("LZSS (12, 4, 2)", A.FMT_LZSS, None), ("LZSS (10, 6, 2)", A.FMT_LZSS, lz1062), ("LZ40", A.FMT_LZ40, None), ("LZHudson", A.FMT_LZHUDSON, None),
+             ("RefPack", A.FMT_REFPACK, None), ("LZ02", A.FMT_LZ02, None), ("CLZ0", A.FMT_CLZ0, None), ("CNS", A.FMT_CNS, None), ("LZShrek", A.FMT_LZSHREK, None)]
+    names = ["LZO", "LZ4", "LZSS (12, 4, 2)", "LZSS (12, 4, 3)", "LZSS (10, 6, 2)", "LZSS (10, 6, 3)", "LZSS0", "PRS big", "PRS Little", "LZ10", "LZ11", "Yaz0", "LZ40", "LZHudson", "RefPack", "LZ02", "CLZ0", "CNS", "LZShrek"]
     fmts = {"LZO": (A.FMT_LZO, None), "LZ4": (A.FMT_LZ4_BLOCK, None), "LZSS (12, 4, 2)": (A.FMT_LZSS, A.LzProperties.from_bits(12, 4, 2)),
             "LZSS (12, 4, 3)": (A.FMT_LZSS, A.LzProperties.from_bits(12, 4, 3)), "LZSS (10, 6, 2)": (A.FMT_LZSS, lz1062),
             "LZSS (10, 6, 3)": (A.FMT_LZSS, A.LzProperties.from_bits(10, 6, 3)), "LZSS0": (A.FMT_LZSS, A.LzProperties.from_bits(12, 4, 2)),
             "PRS big": (A.FMT_PRS_BE, None), "PRS Little": (A.FMT_PRS_LE, None), "LZ10": (A.FMT_LZ10, None), "LZ11": (A.FMT_LZ11, None), "Yaz0": (A.FMT_YAZ0, None),
-            "LZ40": (A.FMT_LZ40, None), "LZHudson": (A.FMT_LZHUDSON, None)}
+            "LZ40": (A.FMT_LZ40, None), "LZHudson": (A.FMT_LZHUDSON, None), "RefPack": (A.FMT_REFPACK, None), "LZ02": (A.FMT_LZ02, None),
+            "CLZ0": (A.FMT_CLZ0, None), "CNS": (A.FMT_CNS, None), "LZShrek": (A.FMT_LZSHREK, None)}
     for name, fmt, lz in cases:
         comp, _ = O.encode_stream(fmt, raw, quality=8, lz=lz)
         res = S.brute_force(comp, len(raw))
