@@ -1189,6 +1189,16 @@ static bool describe_stream(uint32_t container, bool big, const uint8_t* p, size
     case ALZ_C_MDB4: if (n < 32) return false; size = le32(p + 8); *hdr = 32; s->format = ALZ_FMT_LZSS; break;
     case ALZ_C_FCMP: if (n < 12) return false; size = le32(p + 4); *hdr = 12; s->format = ALZ_FMT_LZSS; break;
     case ALZ_C_IECP: if (n < 8) return false; size = le32(p + 4); *hdr = 8; s->format = ALZ_FMT_LZSS; break;
+    case ALZ_C_CNX2: if (n < 16) return false; size = be32(p + 12); *hdr = 16; s->format = ALZ_FMT_CNX2; break;
+    case ALZ_C_CLZ0: if (n < 16) return false; size = be32(p + 12); *hdr = 16; s->format = ALZ_FMT_CLZ0; break;
+    case ALZ_C_CNS: if (n < 16) return false; size = le32(p + 8); *hdr = 16; s->format = ALZ_FMT_CNS; break;
+    case ALZ_C_SMSR00: if (n < 16) return false; size = be32(p + 8); s->aux0 = be32(p + 12) - 16u; *hdr = 16; s->format = ALZ_FMT_SMSR00; break;
+    case ALZ_C_HIG: {
+        if (n < 0x40) return false;
+        const uint32_t ver = le32(p + 0x38); const size_t start = (ver == 5 || ver == 6) ? 0xC0 : le32(p + 4);
+        if (start > n) return false;
+        size = le32(p + 0x3C); *hdr = start; s->format = ALZ_FMT_HIG; break;
+    }
     default: return false;
     }
     s->decom_len = size;
@@ -1268,7 +1278,8 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, co
         case ALZ_C_LZSS: if (opt && opt->lz.window_bits) lzp = &opt->lz; break;
         case ALZ_C_AKLZ: case ALZ_C_LZ01: case ALZ_C_LZSEGA: case ALZ_C_LEVEL5LZSS: case ALZ_C_MDB4: case ALZ_C_FCMP: case ALZ_C_IECP: wrapper_lzss = true; break;
         case ALZ_C_LZ10: case ALZ_C_LZ11: case ALZ_C_YAZ0: case ALZ_C_YAZ1: case ALZ_C_YAY0: case ALZ_C_MIO0:
-        case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: case ALZ_C_LZ40: case ALZ_C_LZ60: break;
+        case ALZ_C_GCLZ: case ALZ_C_CXLZ: case ALZ_C_LZ_3DS: case ALZ_C_COMP: case ALZ_C_LZ40: case ALZ_C_LZ60:
+        case ALZ_C_CNX2: case ALZ_C_CLZ0: case ALZ_C_CNS: case ALZ_C_SMSR00: case ALZ_C_HIG: break;
         default: return ALZ_E_UNSUPPORTED;
         }
     }

@@ -87,6 +87,25 @@ def test_scan_finds_embedded_streams(test_bmp):
     assert only == replay_scan(image, [F.Yaz0]) and all(h[2] == A.C_YAZ0 for h in only) and len(only) >= 2
 
 
+def test_scan_rank4_containers(test_bmp):
+    """The magic-carrying containers added with SURVEY 8f rank 4 (and SMSR00) as scan targets."""
+    rng = random.Random(7)
+    parts, truth, pos = [], [], 0
+    for c, size, q in [(A.C_CNX2, 20000, 8), (A.C_CLZ0, 9000, 4), (A.C_CNS, 30000, 8), (A.C_HIG, 15000, 8), (A.C_SMSR00, 12000, 8), (A.C_CNX2, 70000, 0)]:
+        j = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 500)))
+        parts.append(j); pos += len(j)
+        off = rng.randrange(0, len(test_bmp) - size)
+        raw = test_bmp[off:off + size]
+        comp = O.container_compress(c, raw, quality=q)
+        truth.append((pos, c, raw)); parts.append(comp); pos += len(comp)
+    image = b"".join(parts) + bytes(rng.randrange(256) for _ in range(200))
+    classes = [F.CNX2, F.CLZ0, F.CNS, F.HIG, F.SMSR00]
+    hits = S.scan(image, classes)
+    assert hits == replay_scan(image, classes)
+    got = {(h[0], h[2]): h[3] for h in hits}
+    assert sum(1 for pos, c, raw in truth if got.get((pos, c)) == raw) == len(truth)
+
+
 def test_scan_nested_and_adjacent(test_bmp):
     """A stream whose payload contains another stream's bytes: the walk continues behind the outer one (:98)."""
     inner = O.container_compress(A.C_LZ10, test_bmp[:3000], quality=8)
