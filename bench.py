@@ -136,7 +136,7 @@ def main():
     # cpu_baseline leg -- the only place that touches oracle/: the C restatement decodes the same batch on the host cores
     # (timed), and because it then holds the reference output anyway, the GPU's bytes are compared with it
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # (N = 1 only: a reported baseline, never part of the timed region)
         import oracle_lib as O
         cores = os.cpu_count() or 1
         o_dst = np.ones(batch.dst_bytes, dtype=np.uint8)  # pre-touched
