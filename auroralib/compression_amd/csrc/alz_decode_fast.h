@@ -666,6 +666,7 @@ __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u
 // by the lane-parallel byte phase.  Parsing needs the input only, never the output, so it is decoupled from the copy.
 template <class OW, class CFG>
 struct QueueSink {
+    typedef OW OWT; typedef CFG CFGT;
     OW& out; DecState& s; u8* segmark; const u8* inlds; int lane; u32 W;
     u32 qtok;                 // per-lane token register
     u32 nt, qbytes;           // tokens queued, bytes they will produce (wave-uniform)
@@ -1577,7 +1578,14 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
 #if defined(ALZ_QEXP) && ALZ_QEXP == 2
     sk.out.produced += total; sk.nt = 0; sk.qbytes = 0; if (qt == 0x12345u) stage[lane] = qt;   // timing experiment: parse only
 #else
-    sk.flush();
+    {   // executed in line (the out-of-line queue_emit_call stays with the exact parser's token sites): a round is only ~30
+        // tokens, the call's argument traffic was a tenth of it
+        sk.nt = 0; sk.qbytes = 0;
+        const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
+        const u32 desc = (qt & 0x20000u) ? ALZ_DESC_LIT(lo & 0xFFu) : lo;
+        u32 last;
+        (void)fast_emit<typename SK::OWT, typename SK::CFGT>(sk.out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, sk.segmark, sk.inlds, lane, last, sk.W);
+    }
 #endif
     return true;
 }
