@@ -838,6 +838,13 @@ __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState&
         u32 qt2 = 0, nt2 = 0, total2 = 0, adv2 = 0;
         const u32 p = s.p;
         const bool ahead = (u64)p + 1100u <= src_len && !(p + in.lo + 1024u > in.cb + 2048u);   // next round: input ahead, cache already covers it
+#if defined(ALZ_QEXP) && ALZ_QEXP == 3
+        out.produced += total; (void)len; (void)desc; (void)last;                       // timing experiment: parse only
+        if (ahead) { more = parse(p, qt2, nt2, total2, adv2); if (more && total2 > maxout - out.produced) more = false; }
+        if (!more) break;
+        qt = qt2; nt = nt2; total = total2; adv = adv2;
+        continue;
+#endif
         if constexpr (CFG::FALLBACK) {
             EmitState e;
             emit_begin<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, lane, last, W, e);
