@@ -1,6 +1,6 @@
-# timing experiment: LZ4 parse-only build (ALZ_QEXP=1) vs the full kernel, with and without sources beyond the LDS window
+# timing experiment: LZ4 parse-only build (ALZ_QEXP=3) vs the full kernel, with and without sources beyond the LDS window
 cd $GRAFT_REPO_ROOT
-for q in 1 0; do
+for q in 3 0; do
   rm -rf auroralib/compression_amd/csrc/_obj
   ALZ_EXTRA_FLAGS="-DALZ_QEXP=$q" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1
   for md in 0 3000; do
