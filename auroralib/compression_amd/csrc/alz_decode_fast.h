@@ -32,6 +32,9 @@
 #pragma once
 #include "alz_decode_serial.h"
 
+#ifndef ALZ_QRUN
+#define ALZ_QRUN 200u   /* longest literal run / element a lane-parallel round takes: window (256) + element stay inside one 512-byte cache chunk */
+#endif
 #ifndef ALZ_NB
 #define ALZ_NB 8    /* steps whose HBM read-backs are issued together (two-pass byte phase of the 64 KiB formats) */
 #endif
@@ -684,7 +687,7 @@ struct QueueSink {
         nt = 0; qbytes = 0;
     }
     __device__ __forceinline__ void ensure(InCache& in, u32 p, u32 need) {
-        if (p + in.lo + need > in.cb + 2048u || p + in.lo < in.cb) { flush(); in.ensure(p, need); }   // queued literal runs point into the cache
+        if (p + in.lo + need > in.cb + 2u * in.ch || p + in.lo < in.cb) { flush(); in.ensure(p, need); }   // queued literal runs point into the cache
     }
     // record one packed token (len <= ALZ_TOK_MAXLEN); the caller keeps nt < 64
     __device__ __forceinline__ void push_word(u32 word, u32 len) {
@@ -713,7 +716,7 @@ struct QueueSink {
     }
     __device__ __forceinline__ bool run(InCache& in, u32 p, u64 len) {
         if (len == 0) return true;
-        if (len > 1024u || (u64)produced() + len > (u64)out.cap) {
+        if (len > in.ch || (u64)produced() + len > (u64)out.cap) {
             flush(); if (s.ovf) return false;
             u32 cl = clip_token(out, s, len); out.copy_from(in, p, cl); return !s.ovf;
         }
@@ -780,7 +783,7 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
         const u32 lx = L0 == 15u ? e1 + 1u : 0u;              // literal-length extension byte + its value
         const u32 op = pos + 1u + L0 + lx;                    // offset bytes
         const u32 em = in.lds[(op + 2u) & 2047u];             // match length extension (if any); masked: garbage lanes may point anywhere
-        const bool bad = (L0 == 15u && e1 == 255u) || (M0 == 15u && em == 255u);
+        const bool bad = (L0 == 15u && e1 == 255u) || (M0 == 15u && em == 255u) || L0 + lx > ALZ_QRUN;   // (second extension bytes; a run beyond the resident cache chunk)
         nx[w] = bad ? ALZ_NX_BAD : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
     }
     // 2. the walk; lane j receives the start offset of the j-th sequence (a window holds <= 22 sequences: lanes suffice)
@@ -837,7 +840,7 @@ __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState&
         bool more = false;
         u32 qt2 = 0, nt2 = 0, total2 = 0, adv2 = 0;
         const u32 p = s.p;
-        const bool ahead = (u64)p + 1100u <= src_len && !(p + in.lo + 1024u > in.cb + 2048u);   // next round: input ahead, cache already covers it
+        const bool ahead = (u64)p + in.ch + 76u <= src_len && !(p + in.lo + in.ch > in.cb + 2u * in.ch);   // next round: input ahead, cache already covers it
 #if defined(ALZ_QEXP) && ALZ_QEXP == 3
         out.produced += total; (void)len; (void)desc; (void)last;                       // timing experiment: parse only
         if (ahead) { more = parse(p, qt2, nt2, total2, adv2); if (more && total2 > maxout - out.produced) more = false; }
@@ -874,7 +877,7 @@ struct Lz4Rounds {
 
 // Lane-parallel Snappy parse (Snappy.cs:205-250): an element's size depends on its tag byte and, for literals of 61+
 // bytes, on one or two length bytes -- the same per-byte speculation + scalar walk as LZ4, one token per element.
-// Elements the walk does not take (literals above 700 bytes, copies with 4-byte offsets) are left to the exact parser.
+// Elements the walk does not take (literals above 200 bytes, copies with 4-byte offsets) are left to the exact parser.
 __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
     // 1. speculation: the size of "the element that would start at my byte"
@@ -888,7 +891,7 @@ __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane,
         if (type == 0u) {
             const u32 len = hi < 60u ? hi + 1u : (hi == 60u ? e1 + 1u : (e1 | (e2 << 8)) + 1u);
             const u32 hdr = hi < 60u ? 1u : hi - 58u;
-            n = (hi > 61u || len > 700u) ? ALZ_NX_BAD : hdr + len;      // the run has to stay inside the resident input cache
+            n = (hi > 61u || len > ALZ_QRUN) ? ALZ_NX_BAD : hdr + len;      // the run has to stay inside the resident input cache
         }
         if (type == 3u) n = ALZ_NX_BAD;                                 // 4-byte offsets (E3 check included) stay with the exact parser
         nx[w] = n;
@@ -950,7 +953,7 @@ __device__ __forceinline__ bool cnx2_parse_round(InCache& in, u32 p, u32* stage,
         u32 off = 1, code, b; bool live = true;
 #pragma unroll
         for (int k = 0; k < 4; k++) cnx2_step(in, pos, f, k, off, live, code, b);
-        nx[w] = off > 700u ? ALZ_NX_BAD : off;
+        nx[w] = off > 700u ? ALZ_NX_BAD : off;                           // (CNX2 keeps 1 KiB cache chunks: a group can be four 256-byte runs)
     }
     u32 spos, sp, ng;
     lane_walk_pos(nx, 16u, spos, sp, ng);                              // a group has >= 2 bytes: <= 32 per window
@@ -1044,7 +1047,7 @@ __device__ __forceinline__ bool lzshrek_parse_round(InCache& in, u32 p, u32* sta
         const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2], e3 = in.lds[pos + 3];
         const u32 v = b >> 3, ext = v == 30u ? 1u : (v == 31u ? 2u : 0u);
         const u32 lits = shrek_count(v, e1, e2);
-        const u32 sizeH = lits > 700u ? 0x3FFu : 1u + ext + lits;
+        const u32 sizeH = lits > ALZ_QRUN ? 0x3FFu : 1u + ext + lits;
         const u32 lenb = (b & 7u) == 0u ? 1u : 0u;
         const u32 x = lenb ? e2 : e1, y = lenb ? e3 : e2;
         const u32 dist = shrek_count(v, x, y) + 1u;
@@ -1090,7 +1093,7 @@ struct LzshrekRounds {
 
 // Lane-parallel HIG parse (HIG.cs:141-206): an element is a match (2-6 header bytes in three forms) and the literals its PP field
 // announces (none, 1, 2, or a counted block); it yields a match token and / or a literal-run token, in that order.  Counted
-// blocks above 700 literals and lengths beyond the token word are left to the exact parser, as is the initial literal block.
+// blocks above 200 literals and lengths beyond the token word are left to the exact parser, as is the initial literal block.
 // `total` is reported one too high (the loop stops at the declared size: nothing behind that point may be consumed).
 __device__ __forceinline__ void hig_element(const InCache& in, u32 pos, u32& hdr, u32& length, u32& distance, u32& rawp, u32& cnt) {
     const u32 b = in.lds[pos & 2047u], e1 = in.lds[(pos + 1u) & 2047u];
@@ -1126,7 +1129,7 @@ __device__ __forceinline__ bool hig_parse_round(InCache& in, u32 p, u32* stage, 
         const u32 pos = i0 + 64u * (u32)w + (u32)lane;
         u32 hdr, length, distance, rawp, cnt;
         hig_element(in, pos, hdr, length, distance, rawp, cnt);
-        nx[w] = (cnt > 700u || length > ALZ_TOK_MAXLEN) ? ALZ_NX_BAD : (rawp - pos) + cnt;
+        nx[w] = (cnt > ALZ_QRUN || length > ALZ_TOK_MAXLEN) ? ALZ_NX_BAD : (rawp - pos) + cnt;
     }
     u32 spos, sp, nel;
     lane_walk_pos(nx, 32u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
@@ -1167,7 +1170,7 @@ __device__ __forceinline__ bool wflz_parse_round(InCache& in, u32 p, u32* stage,
     for (int w = 0; w < 4; w++) {
         const u32 pos = i0 + 64u * (u32)w + (u32)lane;
         const u32 length = in.lds[pos + 2], plain = in.lds[pos + 3];
-        nx[w] = (length | plain) == 0u ? ALZ_NX_BAD : 4u + plain;
+        nx[w] = ((length | plain) == 0u || plain > ALZ_QRUN) ? ALZ_NX_BAD : 4u + plain;
     }
     u32 spos, sp, nel;
     lane_walk_pos(nx, 32u, spos, sp, nel);                               // a block has >= 4 bytes: <= 16 per window
@@ -1409,7 +1412,7 @@ __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 sta
         if (t) second = ALZ_TOK_LIT(t, (pos + 2u) & 2047u);
         return state == 1u ? ALZ_TOK_MATCH(2u, (e1 << 2) + (f >> 2) + 1u) : ALZ_TOK_MATCH(3u, (e1 << 2) + (f >> 2) + 2049u);
     }
-    const u32 sizeA = (ext && e1 == 0u) ? 511u : (ext ? 2u : 1u) + len;
+    const u32 sizeA = ((ext && e1 == 0u) || len > ALZ_QRUN) ? 511u : (ext ? 2u : 1u) + len;   // (a run beyond the resident cache chunk: exact parser)
     return sizeA | (2u << 9) | ((2u + t) << 11) | ((t ? 1u : 0u) << 20);
 }
 

@@ -41,7 +41,7 @@ struct InCache {
     u8* lds;          // 2 * ch bytes, 16 B aligned
     u32 lo, hi;       // valid a-range [lo, hi)
     u32 cb;           // a-coordinate of lds[0]; multiple of ch
-    u32 ch;           // chunk size: 1024 (16 B per lane and load) or 256 (4 B per lane: 544 B of LDS instead of 2 080 --
+    u32 ch;           // chunk size: 1024 (16 B per lane and load), 512 (8 B: the queue kernels) or 256 (4 B per lane: 544 B of LDS instead of 2 080 --
                       // what lets the flag-family kernels keep 32 waves per CU)
     uint4 pf;         // this lane's part of the chunk at cb + 2 ch (prefetched; .x only when ch == 256)
     int lane;
@@ -51,6 +51,9 @@ struct InCache {
         if (ch == 1024u) {
             u32 ga = ca + 16u * (u32)lane;
             if (ga + 16u > lo && ga < hi) v = *reinterpret_cast<const uint4*>(gbase + ga);
+        } else if (ch == 512u) {
+            u32 ga = ca + 8u * (u32)lane;
+            if (ga + 8u > lo && ga < hi) { const uint2 t = *reinterpret_cast<const uint2*>(gbase + ga); v.x = t.x; v.y = t.y; }
         } else {
             u32 ga = ca + 4u * (u32)lane;
             if (ga + 4u > lo && ga < hi) v.x = *reinterpret_cast<const u32*>(gbase + ga);
@@ -59,6 +62,7 @@ struct InCache {
     }
     __device__ __forceinline__ void store_chunk(u32 half, uint4 v) {
         if (ch == 1024u) *reinterpret_cast<uint4*>(lds + half * 1024u + 16 * lane) = v;
+        else if (ch == 512u) *reinterpret_cast<uint2*>(lds + half * 512u + 8 * lane) = make_uint2(v.x, v.y);
         else *reinterpret_cast<u32*>(lds + half * 256u + 4 * lane) = v.x;
     }
     __device__ __forceinline__ void init(const u8* src, u32 len, u8* lds_, int lane_, u32 chunk = 1024u) {
@@ -84,6 +88,9 @@ struct InCache {
         if (ch == 1024u) {
             uint4 up = *reinterpret_cast<const uint4*>(lds + 1024 + 16 * lane);
             *reinterpret_cast<uint4*>(lds + 16 * lane) = up;
+        } else if (ch == 512u) {
+            uint2 up = *reinterpret_cast<const uint2*>(lds + 512 + 8 * lane);
+            *reinterpret_cast<uint2*>(lds + 8 * lane) = up;
         } else {
             u32 up = *reinterpret_cast<const u32*>(lds + 256 + 4 * lane);
             *reinterpret_cast<u32*>(lds + 4 * lane) = up;
@@ -224,7 +231,7 @@ struct OutWin {
     __device__ void copy_from(InCache& in, u32 p, u32 len) {
         u32 off = 0;
         while (off < len) {
-            u32 n = len - off; if (n > fl) n = fl;
+            u32 n = len - off; if (n > fl) n = fl; if (n > in.ch) n = in.ch;
             in.ensure(p + off, n);
             u32 c = produced;
             for (u32 j = (u32)lane; j < n; j += ALZ_WAVE) win[slot(c + j)] = (u8)in.byte_at(p + off + j);

@@ -264,7 +264,10 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     constexpr bool PRSFB = (ALZ_PRS_LW < 8192);             // PRS with a window smaller than its 8 KiB: read-back like the 64 KiB formats
     constexpr u32 LW = PRS ? (u32)ALZ_PRS_LW : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
     // static LDS: marks (128) | token staging (256) | input cache | window
-    __shared__ __attribute__((aligned(16))) u8 lds[384 + ALZ_INCACHE_BYTES + LW];
+    // input cache of two 512-byte chunks (PRS, CNX2: 1 KiB chunks): a round looks at most 256 + ALZ_QRUN bytes ahead, and 1 KiB less LDS
+    // per wave is four more waves per CU for the 4 KiB-window formats
+    constexpr u32 QCH = (PRS || FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
+    __shared__ __attribute__((aligned(16))) u8 lds[384 + QCACHE + LW];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -281,41 +284,41 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     u8* inc_lds = lds + 384;
     constexpr bool FB = CNX ? false : (!PRS || PRSFB);
     typedef OutWin<FB> OW;
-    OW out; out.init(dst, cap, lds + 384 + ALZ_INCACHE_BYTES, LW, lane);
+    OW out; out.init(dst, cap, lds + 384 + QCACHE, LW, lane);
     if (hist) out.preload(hist);
     segmark[lane] = 0; segmark[64 + lane] = 0;
-    InCache in; in.init(src, src_len, inc_lds, lane);
+    InCache in; in.init(src, src_len, inc_lds, lane, QCH);
     DecState s; dec_state_init(s);
     typedef EmitCfg<LW - 1u, false, !PRS, FB> CFG;
     typedef QueueSink<OW, CFG> SK;
     SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : ((FMT == ALZ_FMT_FASTLZ || FMT == ALZ_FMT_REFPACK) ? 131072u : FMT == ALZ_FMT_HIG ? 32768u : (CNS ? 256u : (SHREK ? 4096u : (CNX ? 2048u : 65536u)))));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
     if constexpr (PRS) {
-        // bulk of the stream: lane-assisted parse (prs_lane_parse) while >= 1100 input bytes remain; every token it
+        // bulk of the stream: lane-assisted parse (prs_lane_parse) while enough input bytes remain; every token it
         // declines, and the tail of the stream, goes through the exact parser one token at a time
         constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
         u32 fl = 1u;                                             // normalised flag register (no bits pending)
         for (;;) {
-            if (s.p + 1100u <= src_len && !s.done) {
-                sk.ensure(in, s.p, 1024);
+            if (s.p + QAHEAD <= src_len && !s.done) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 if (prs_lane_parse<SK, BIG>(in, sk, s, stage, lane, fl)) { if (s.ovf || s.done) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             prs_from_norm<BIG>(fl, s.bits, s.flag);
             dec_prs_serial<SK, BIG>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
             fl = prs_to_norm<BIG>(s.bits, s.flag);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
     } else if constexpr (FMT == ALZ_FMT_LZ4_BLOCK) {
-        // bulk of the stream: lane-parallel sequence parse while >= 1100 input bytes remain, exact parser otherwise
+        // bulk of the stream: lane-parallel sequence parse while enough input bytes remain, exact parser otherwise
         for (;;) {
-            if (s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);                        // cache covers [p, p + 1024); flushes the queue if it has to move
+            if (s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);                        // cache covers [p, p + 1024); flushes the queue if it has to move
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 Lz4Rounds rounds{in, stage, lane};
                 if (pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_lz4_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
@@ -323,8 +326,8 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     else if constexpr (FMT == ALZ_FMT_LZO) {
         LzoState ls; lzo_state_init(ls);
         for (;;) {
-            if (ls.started && s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);
+            if (ls.started && s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 LzoRounds rounds{in, stage, lane, ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u), 0u};
                 if (pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, cap, rounds)) {
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
                     continue;
                 }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_lzo_serial(in, sk, s, src_len, ls, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
@@ -341,21 +344,21 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     else if constexpr (FMT == ALZ_FMT_HIG) {
         const u32 size = uni(st.decom_len);
         for (;;) {
-            if (s.bits != 0 && s.p + 1100u <= src_len && sk.produced() < size) {     // (behind the initial literal block)
-                sk.ensure(in, s.p, 1024);
+            if (s.bits != 0 && s.p + QAHEAD <= src_len && sk.produced() < size) {     // (behind the initial literal block)
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 HigRounds rounds{in, stage, lane};
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 32768u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_hig_serial(in, sk, s, src_len, size, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
         }
     }
     else if constexpr (SHREK) {
         for (;;) {
-            if (s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);
+            if (s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 LzshrekRounds rounds{in, stage, lane, s.bits, 0u};           // s.bits: matches the current group still owes (the exact parser's state)
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 4096u, cap, rounds)) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
                     continue;
                 }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_lzshrek_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
@@ -372,29 +375,29 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     else if constexpr (CNS) {
         const u32 size = uni(st.decom_len);
         for (;;) {
-            if (s.p + 1100u <= src_len && sk.produced() < size) {
-                sk.ensure(in, s.p, 1024);
+            if (s.p + QAHEAD <= src_len && sk.produced() < size) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 CnsRounds rounds{in, lane};
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 256u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_cns_serial(in, sk, s, src_len, size, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
         }
     }
     else if constexpr (CNX) {
-        // bulk: lane-parallel rounds of whole groups while >= 1100 input bytes remain; the exact parser for a group the
+        // bulk: lane-parallel rounds of whole groups while enough input bytes remain; the exact parser for a group the
         // rounds decline, to get back to a flag-byte boundary, and for the end of the stream
         const u32 size = uni(st.decom_len);
         for (;;) {
-            if (s.bits == 0 && s.p + 1100u <= src_len && sk.produced() < size) {
-                sk.ensure(in, s.p, 1024);
+            if (s.bits == 0 && s.p + QAHEAD <= src_len && sk.produced() < size) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 Cnx2Rounds rounds{in, stage, lane};
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 2048u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_cnx2_serial(in, sk, s, src_len, size, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
         }
@@ -402,26 +405,26 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     else if constexpr (FMT == ALZ_FMT_WFLZ || FMT == ALZ_FMT_WFLZ_BE) {
         constexpr bool BIG = (FMT == ALZ_FMT_WFLZ_BE);
         for (;;) {
-            if (s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);
+            if (s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 WflzRounds<BIG> rounds{in, stage, lane};
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_wflz_serial<SK, BIG>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
     }
     else if constexpr (FMT == ALZ_FMT_REFPACK) {
         for (;;) {
-            if (s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);
+            if (s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 RefpackRounds rounds{in, stage, lane};
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 131072u, cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_refpack_serial(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
@@ -429,13 +432,13 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     else if constexpr (FMT == ALZ_FMT_FASTLZ) {
         FastlzState fz; fastlz_state_init(fz);
         for (;;) {
-            if (fz.started && s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);
+            if (fz.started && s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 FastlzRounds rounds{in, lane, fz.level};
                 if (pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, fastlz_window(fz), cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_fastlz_serial(in, sk, s, src_len, fz, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || s.done) break;
         }
@@ -444,14 +447,14 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
         // Snappy: varint size, then elements until the output reaches it; lane-parallel parse for the bulk
         u32 size = 0; bool have = false;
         for (;;) {
-            if (have && s.p + 1100u <= src_len) {
-                sk.ensure(in, s.p, 1024);
+            if (have && s.p + QAHEAD <= src_len) {
+                sk.ensure(in, s.p, QCH);
                 if (sk.nt) { sk.flush(); if (s.ovf) break; }
                 if (out.produced >= size) break;
                 SnappyRounds rounds{in, lane};
                 if (out.produced < cap && pipelined_rounds<OW, CFG>(in, out, s, src_len, segmark, inc_lds, lane, 65536u, size < cap ? size : cap, rounds)) { if (s.ovf) break; continue; }
             }
-            const bool tail = s.p + 1100u > src_len;
+            const bool tail = s.p + QAHEAD > src_len;
             dec_snappy_serial(in, sk, s, src_len, size, have, tail ? 0xFFFFFFFFu : 1u);
             if (tail || s.eof || s.ovf || s.bad || sk.produced() >= size) break;
         }
