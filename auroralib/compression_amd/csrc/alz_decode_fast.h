@@ -765,7 +765,7 @@ __device__ __forceinline__ void lane_walk_pos(const u32 (&nx)[4], u32 enter_belo
 // per sequence on the scalar unit.  The lanes that turned out to start a sequence build its two tokens (literal run,
 // match) and compact them into the queue through a 64-dword LDS staging array; the byte phase executes them.
 // Sequences with a second length-extension byte (run >= 270 / match >= 274 bytes) stop the walk and are left to the
-// exact parser.  Preconditions: queue empty, >= 1100 input bytes ahead of s.p, cache covers [p, p + 1024).
+// exact parser.  Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p, cache covers [p, p + chunk).
 // Returns false when nothing was parsed (first sequence unusual, or the batch would not fit the output capacity).
 // One round: tokens of up to 32 sequences starting at input offset p -> qt (one per lane, nt of them), the bytes they
 // produce and the input bytes they cover.  Touches the input cache and `stage` only.
@@ -824,7 +824,7 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
 // k still point into it, so the pipeline drains whenever the cache has to slide.  `parse(p, qt, nt, total, adv)` yields the
 // tokens of one round starting at input offset p (false: nothing parsed) and `commit()` accepts it (parser state).
 // A round is only taken while its output stays below `maxout` (capacity / declared size: those rules stay with the exact
-// parser).  Preconditions: queue empty, >= 1100 input bytes ahead of s.p, cache covers [s.p, s.p + 1024).
+// parser).  Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p, cache covers [s.p, s.p + chunk).
 template <class OW, class CFG, class PARSE>
 __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState& s, u32 src_len, u8* segmark, const u8* inlds, int lane,
                                                  u32 W, u32 maxout, PARSE& parse) {
@@ -1416,7 +1416,7 @@ __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 sta
     return sizeA | (2u << 9) | ((2u + t) << 11) | ((t ? 1u : 0u) << 20);
 }
 
-// Preconditions: queue empty, >= 1100 input bytes ahead of s.p (an instruction boundary), cache covers [p, p + 1024).
+// Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p (an instruction boundary), cache covers [p, p + chunk).
 // `state` (0 = A, 1 = B, 2 = C) is the walk's state in front of the round on entry, behind it on return.
 __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& state, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
@@ -1477,7 +1477,7 @@ __device__ __forceinline__ void prs_from_norm(u32 fl, u32& bits, u32& flag) {
     flag = BIG ? (__builtin_bitreverse32(r) >> (32u - nb)) : (r << (8u - nb));
 }
 
-// Preconditions: queue empty, >= 1100 input bytes ahead of s.p, cache covers [p, p + 1024).  `fl` is the normalised flag
+// Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p, cache covers [p, p + chunk).  `fl` is the normalised flag
 // register (prs_to_norm).  Returns false (state untouched) when nothing could be parsed or the batch does not fit dst.
 template <class SK, bool BIG>
 __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32& fl_io) {

@@ -264,9 +264,9 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     constexpr bool PRSFB = (ALZ_PRS_LW < 8192);             // PRS with a window smaller than its 8 KiB: read-back like the 64 KiB formats
     constexpr u32 LW = PRS ? (u32)ALZ_PRS_LW : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
     // static LDS: marks (128) | token staging (256) | input cache | window
-    // input cache of two 512-byte chunks (PRS, CNX2: 1 KiB chunks): a round looks at most 256 + ALZ_QRUN bytes ahead, and 1 KiB less LDS
+    // input cache of two 512-byte chunks (CNX2: 1 KiB chunks): a round looks at most 256 + ALZ_QRUN bytes ahead, and 1 KiB less LDS
     // per wave is four more waves per CU for the 4 KiB-window formats
-    constexpr u32 QCH = (PRS || FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
+    constexpr u32 QCH = (FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
     __shared__ __attribute__((aligned(16))) u8 lds[384 + QCACHE + LW];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
