@@ -152,8 +152,11 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     // single-wave workgroups)
     // input caches: 1 KiB chunks where there is one (16 B/lane loads), 256 B chunks for the three-cursor formats -- with three
     // big caches a CU would hold 15 waves instead of 24 (measured: Yay0 585 -> 758, MIO0 379 -> 481 GiB/s)
-    constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : 1024u);      // (8 KiB windows: 17 instead of 15 waves per CU)
-    constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : (LWMAX > 4096 ? 2u * 512u + 32u : ALZ_INCACHE_BYTES);
+#ifndef ALZ_FAST_CHUNK
+#define ALZ_FAST_CHUNK 1024
+#endif
+    constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
+    constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
     __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][128 + NC * CACHE + LWMAX];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
