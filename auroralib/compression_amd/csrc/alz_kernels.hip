@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
                                                               alz_result* __restrict__ results) {
     constexpr bool PRS = (FMT == ALZ_FMT_PRS_BE || FMT == ALZ_FMT_PRS_LE);
     // These kernels are bound by the latency of one wave's scalar parse, so waves per CU matter more than LDS hits:
-    // only the most recent 4 KiB of the window stay in LDS (6.3 KB per wave -> 25 waves per CU instead of 15), older
+    // only the most recent 4 KiB of the window stay in LDS (5.4 KB per wave -> 28 waves per CU instead of 15), older
     // sources are read back from the stream's own output in HBM, batched per token queue.
     constexpr bool CNS = (FMT == ALZ_FMT_CNS);
     constexpr bool SHREK = (FMT == ALZ_FMT_LZSHREK);        // 4 KiB window, literal runs: the same configuration
