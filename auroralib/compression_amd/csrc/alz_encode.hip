@@ -22,6 +22,7 @@
 //                         the format (FlagWriter order), the only sequential part.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "alz_device.h"
@@ -105,6 +106,106 @@ __global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src
             if (act) { if (pass == 0) p4[pos] = prev; else pm[pos] = prev; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // head stores reach L2 before the next step reads them
+    }
+}
+
+// Kernel A for windows up to 4 KiB: the same prev() links, from LDS instead of per-stream head tables in HBM.  A candidate
+// further back than maxDistance ends every chain walk of kernel B (`dist > g.max_dist: break`), so only the most recent
+// 4096 positions have to be remembered -- and for those a hash table with chaining fits the LDS: T[hash & 4095] = ring
+// index of the most recent position in that bucket, nxt[ring] = the bucket's previous one, tag[ring] = full hash | lap.
+// prev(p) = the first position on its bucket's chain whose FULL hash equals p's (a link further back than 4096, or none,
+// is stored as -1: kernel B treats both alike).  Per step of 64 positions: lanes of one bucket are found with a small
+// contest + ballots (rare on ordinary data, one group on runs), every lane walks its chain in the state BEFORE the step,
+// then the step's positions are linked in, in position order.  32.5 KB of LDS per stream (65 KB with the min-length
+// table): five streams per CU.  OPT-IN ONLY (ALZ_ENC_LDS_PREV): correct, but slower than the HBM tables -- see alz_launch_encode.
+template <bool MINT>
+__global__ __launch_bounds__(64) void enc_prev_lds_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                          const u32* __restrict__ index_list, u32 count,
+                                                          int* __restrict__ prev4, int* __restrict__ prevm,
+                                                          const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    constexpr int NT = MINT ? 2 : 1;
+    __shared__ u16 T[NT][4096];
+    __shared__ u16 nxt[NT][4096];
+    __shared__ u32 tag[NT][4096];
+    __shared__ u8 slot_owner[256];
+    __shared__ u8 slot_flag[256];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;
+    int* p4 = prev4 + pos_off[sid];
+    int* pm = MINT ? prevm + pos_off[sid] : nullptr;
+    for (int t = 0; t < NT; t++) for (int i = lane; i < 4096; i += 64) { T[t][i] = 0xFFFFu; nxt[t][i] = 0xFFFFu; tag[t][i] = 0u; }
+    for (int i = lane; i < 256; i += 64) slot_flag[i] = 0;
+    __syncthreads();
+    const u64 lanes_below = (1ull << lane) - 1ull;
+    for (int c = 0; c <= limit; c += 64) {
+        const int pos = c + lane;
+        const bool act = pos <= limit;
+        const u32 v = act ? load32(data + pos) : 0u;
+        for (int pass = 0; pass < NT; pass++) {
+            const u32 h = pass == 0 ? (((v * 2654435761u) >> (32 - g.hash_bits)) & ((1u << g.hash_bits) - 1u))
+                                    : ((((v & g.min_mask) * 2654435761u) >> 16) & 0xFFFFu);
+            const u32 slot = h & 4095u, ring = (u32)pos & 4095u;
+            // lanes that share a bucket inside this step
+            const u32 key = slot & 255u;
+            if (act) slot_owner[key] = (u8)lane;
+            __syncthreads();
+            const bool lost = act && slot_owner[key] != (u8)lane;
+            if (lost) slot_flag[key] = 1;
+            __syncthreads();
+            const bool contested = act && slot_flag[key] != 0;
+            __syncthreads();
+            if (lost) slot_flag[key] = 0;
+            const u32 old = act ? (u32)T[pass][slot] : 0xFFFFu;
+            int predlane = -1, instep = -1; bool writer = act;
+            u64 todo = __ballot(contested);
+            while (todo) {
+                const int l0 = (int)__builtin_ctzll(todo);
+                const u32 sl = (u32)__builtin_amdgcn_readlane((int)slot, l0);
+                const bool mine = contested && slot == sl;
+                const u64 grp = __ballot(mine);
+                if (mine) {
+                    const u64 below = grp & lanes_below;
+                    if (below) predlane = 63 - (int)__builtin_clzll(below);
+                    writer = (grp >> lane) <= 1ull;                      // the highest lane of the bucket becomes its head
+                }
+                u64 sub = grp;                                           // same full hash inside the bucket: the in-step predecessor
+                while (sub) {
+                    const int m0 = (int)__builtin_ctzll(sub);
+                    const u32 hh = (u32)__builtin_amdgcn_readlane((int)h, m0);
+                    const u64 sg = __ballot(mine && h == hh);
+                    if (mine && h == hh) { const u64 b2 = sg & lanes_below; if (b2) instep = c + 63 - (int)__builtin_clzll(b2); }
+                    sub &= ~sg;
+                }
+                todo &= ~grp;
+            }
+            // the chain as it was before this step
+            int prev = instep;
+            if (act && instep < 0) {
+                u32 cand = old; int bound = pos;
+                while (cand != 0xFFFFu) {
+                    const u32 w = tag[pass][cand];
+                    const int q = (int)(((w >> 20) << 12) | cand);
+                    if (q >= bound || pos - q > 4096) break;             // a stale link (its ring slot was reused) or out of the window
+                    if ((w & 0xFFFFFu) == h) { prev = q; break; }
+                    bound = q; cand = nxt[pass][cand];
+                }
+            }
+            if (act) { if (pass == 0) p4[pos] = prev; else pm[pos] = prev; }
+            __syncthreads();
+            // link the step in, in position order
+            if (act) {
+                tag[pass][ring] = h | (((u32)pos >> 12) << 20);
+                nxt[pass][ring] = predlane >= 0 ? (u16)(((u32)c + (u32)predlane) & 4095u) : (u16)old;
+                if (writer) T[pass][slot] = (u16)ring;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -979,7 +1080,15 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
+    // ALZ_ENC_LDS_PREV=1 selects the LDS-resident variant of kernel A for windows up to 4 KiB.  Bit-identical, but measured
+    // 3x SLOWER than the head tables in HBM (258 against 80 ms at Q0, tools/exp14.sh): 32 KB of LDS per stream leaves five
+    // waves per CU, and nothing hides the ~40 dependent LDS round trips of a step then, while 32 waves per CU hide the HBM ones.
+    static const bool lds_prev = getenv("ALZ_ENC_LDS_PREV") != nullptr;
+    if (lds_prev && g.max_dist <= 4096 && max_len < (1u << 24)) {
+        if (g.use_min_table) hipLaunchKernelGGL((enc_prev_lds_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+        else hipLaunchKernelGGL((enc_prev_lds_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    }
+    else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     else hipLaunchKernelGGL((enc_prev_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
