@@ -254,7 +254,52 @@ static int grow(alz_ctx* c, void** buf, size_t* cap, size_t need) {
     return ALZ_OK;
 }
 
-// Download per-stream outputs: one bulk copy when the produced ranges are reasonably dense, else one copy per stream.
+// Sparse outputs (compressed streams in worst-case-sized slots, batches with failed streams): one workgroup per stream packs
+// the produced bytes into a dense device buffer, so that ONE copy crosses PCIe instead of one per stream.  `to` is congruent
+// to `from` modulo 16, which keeps the 16-byte body of the copy aligned on both sides.
+struct pack_item { uint64_t from, to; uint32_t len, pad; };
+__global__ void __launch_bounds__(256) alz_pack_outputs_kernel(const uint8_t* __restrict__ base, uint8_t* __restrict__ pack, const pack_item* __restrict__ items) {
+    const pack_item it = items[blockIdx.x];
+    const uint8_t* s = base + it.from;
+    uint8_t* d = pack + it.to;
+    uint32_t head = (16u - (uint32_t)(it.from & 15)) & 15u;
+    if (head > it.len) head = it.len;
+    for (uint32_t k = threadIdx.x; k < head; k += blockDim.x) d[k] = s[k];
+    const uint32_t body = (it.len - head) >> 4;
+    const uint4* s4 = (const uint4*)(s + head);
+    uint4* d4 = (uint4*)(d + head);
+    for (uint32_t k = threadIdx.x; k < body; k += blockDim.x) d4[k] = s4[k];
+    for (uint32_t k = head + (body << 4) + threadIdx.x; k < it.len; k += blockDim.x) d[k] = s[k];
+}
+
+// false = could not pack (no device memory for the dense copy): the caller falls back to one copy per stream
+static bool download_packed(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
+    std::vector<pack_item> items;
+    uint64_t cur = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
+        const uint64_t to = cur + (streams[i].dst_off & 15);
+        items.push_back(pack_item{streams[i].dst_off, to, results[i].dst_len, i});
+        cur = (to + results[i].dst_len + 15) & ~15ull;
+    }
+    void *d_items = nullptr, *d_pack = nullptr;
+    if (hipMalloc(&d_items, items.size() * sizeof(pack_item)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMalloc(&d_pack, cur) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_items); return false; }
+    std::vector<uint8_t> bounce(cur);
+    hipError_t e = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(pack_item), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        alz_pack_outputs_kernel<<<dim3((uint32_t)items.size()), dim3(256), 0, c->stream>>>((const uint8_t*)c->d_dst, (uint8_t*)d_pack, (const pack_item*)d_items);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(bounce.data(), d_pack, cur, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_items); (void)hipFree(d_pack);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (const pack_item& it : items) memcpy(dst_base + it.from, bounce.data() + it.to, it.len);
+    return true;
+}
+
+// Download per-stream outputs: one bulk copy when the produced ranges are reasonably dense, else packed on the device first.
 static int download_outputs(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
     uint64_t lo = ~0ull, hi = 0, sum = 0;
     for (uint32_t i = 0; i < n; i++) {
@@ -274,6 +319,7 @@ static int download_outputs(alz_ctx* c, uint32_t n, const alz_stream* streams, c
         }
         return ALZ_OK;
     }
+    if (n >= 16 && download_packed(c, n, streams, results, dst_base, only_ok)) return ALZ_OK;
     for (uint32_t i = 0; i < n; i++) {
         if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
         HIP_TRY(hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len, hipMemcpyDeviceToHost, c->stream));

@@ -153,6 +153,35 @@ def test_unaligned_buffers():
     compare_batch(streams, src, dst_bytes, what="unaligned")
 
 
+def test_sparse_outputs_are_packed_on_the_device():
+    """Host-buffer API with outputs far apart (slots much larger than what the streams produce, every alignment, some
+    streams failing): the produced bytes come back through the device-side pack + one copy (alz_host.cpp, download_packed),
+    and the caller's bytes between them are untouched."""
+    import ctypes as C
+    from auroralib.compression_amd.batch import _vp, check
+    n, stride = 48, 3 << 20
+    b = synth.make_batch(A.FMT_YAZ0, n, np.array([1 + 977 * i for i in range(n)], dtype=np.uint32), synth.seed_for(78))
+    recs = synth.stream_records(b.streams)
+    recs["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64(stride) + (np.arange(n, dtype=np.uint64) * np.uint64(7)) % np.uint64(23)
+    recs["dst_cap"] = recs["decom_len"]
+    recs["src_len"][5] //= 2                                   # a truncated stream: partial output, not OK
+    recs["decom_len"][9] += 3                                  # declared size never reached
+    dst_bytes = n * stride
+    o_dst, o_res = O.decode_batch(b.streams, b.src, dst_bytes)
+    c = ctx()
+    g_dst = np.full(dst_bytes, 0xA5, dtype=np.uint8)
+    g_res = (A.Result * n)()
+    check(c.lib.alz_decode_batch(c.h, None, n, _vp(b.src), b.src.nbytes, b.streams, _vp(g_dst), dst_bytes, g_res))
+    gr, orr = synth.result_records(g_res), synth.result_records(o_res)
+    assert (gr["status"] == orr["status"]).all() and (gr["dst_len"] == orr["dst_len"]).all() and gr["status"][5] != 0
+    keep = np.ones(dst_bytes, dtype=bool)
+    for i in range(n):
+        a, ln = int(recs["dst_off"][i]), int(gr["dst_len"][i])
+        assert bytes(g_dst[a:a + ln]) == bytes(o_dst[a:a + ln]), i
+        keep[a:a + ln] = False
+    assert (g_dst[keep] == 0xA5).all()
+
+
 def test_prs_terminator_inside_the_bulk_path(test_bmp):
     """PRS ends at its zero word (PRS.cs:78-79) wherever that is: with >= 1100 bytes of trailing data the terminator is met by
     the lane-assisted parser, not by the tail parser; src_used must stop right behind it."""

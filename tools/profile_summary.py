@@ -38,7 +38,7 @@ def main():
     if a.stats:
         lines += ["## kernel stats (`rocprofv3 --kernel-trace --stats`)", "", "| kernel | calls | avg ms | min ms | max ms | % |", "|---|---|---|---|---|---|"]
         for r in rows(a.stats, "kernel_stats.csv"):
-            name = r["Name"].split("(")[0]
+            name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
             lines.append("| `%s` | %s | %.4f | %.4f | %.4f | %s |" % (name, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, r["Percentage"]))
         tr = [r for r in rows(a.stats, "kernel_trace.csv") if "alz_" in r.get("Kernel_Name", "")]
         if tr:
