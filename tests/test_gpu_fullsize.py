@@ -1,0 +1,88 @@
+"""-m gpu: BASELINE.json's configurations at their FULL single-GPU sizes.  The oracle decodes the same batch on all host
+cores (a fraction of a second per GiB), so the decode cases are still byte-for-byte; the compression case (cfg5; configurations numbered from 1 as in DESIGN.md), whose
+oracle would take minutes at this size, is checked through size-independent properties: encode -> decode round trip of
+the whole batch on the GPU, every status OK, and bit-identity with the oracle on a sample of the streams."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from auroralib.compression_amd import _abi as A
+from auroralib.compression_amd import synth
+from gpu_common import ctx
+
+pytestmark = pytest.mark.gpu
+CORES = os.cpu_count() or 8
+
+
+def _decode_and_compare(fmt, n, size, seed):
+    b = synth.make_batch(fmt, n, size, seed)
+    o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes, nthreads=CORES)
+    g_dst, g_res = ctx().decode_batch(b.streams, b.src, b.dst_bytes)
+    gr, orr = synth.result_records(g_res), synth.result_records(o_res)
+    for f in ("status", "dst_len", "src_used"):
+        assert np.array_equal(gr[f], orr[f]), f
+    assert (gr["status"] == 0).all() and (gr["dst_len"] == size).all()
+    assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes])
+    # checksum of checksums: one number that pins the whole batch (and the generator) in the log of a failing run
+    recs = synth.stream_records(b.streams)
+    step = max(1, n // 64)
+    sums = [O.xxh64(bytes(g_dst[int(recs["dst_off"][i]):int(recs["dst_off"][i]) + size])) for i in range(0, n, step)]
+    assert O.xxh64(np.array(sums, dtype=np.uint64).tobytes()) == O.xxh64(np.array(
+        [O.xxh64(bytes(o_dst[int(recs["dst_off"][i]):int(recs["dst_off"][i]) + size])) for i in range(0, n, step)], dtype=np.uint64).tobytes())
+    return b, g_dst
+
+
+def test_cfg2_yaz0_10000_x_64k():
+    _decode_and_compare(A.FMT_YAZ0, 10000, 65536, synth.seed_for(2, 7))
+
+
+def test_metric_config_yaz0_10000_x_256k():
+    """The batch bench.py times by default (same generator seed)."""
+    _decode_and_compare(A.FMT_YAZ0, 10000, 262144, synth.seed_for(2))
+
+
+def test_cfg3_lz4_blocks_256k():
+    """cfg3's stream shape; 10 000 of its 100 000 blocks (the full count is 24 GiB of output: tools/cfg34.sh times it)."""
+    _decode_and_compare(A.FMT_LZ4_BLOCK, 10000, 262144, synth.seed_for(3))
+
+
+def test_cfg4_mixed_shard():
+    """What each of 8 GPUs gets of cfg4's 40 000 mixed streams: 5 000, formats interleaved, per-format kernel dispatch."""
+    n = 5000
+    fm = np.array([[A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_PRS_BE][i % 4] for i in range(n)], dtype=np.uint32)
+    _decode_and_compare(fm, n, 262144, synth.seed_for(4))
+
+
+@pytest.mark.parametrize("quality", [0, 8])
+def test_cfg5_lzss_compression_10000_x_256k(quality):
+    n, size = 10000, 262144
+    b = synth.make_batch(A.FMT_LZSS, n, size, synth.seed_for(5))
+    raw, res = ctx().decode_batch(b.streams, b.src, b.dst_bytes)
+    recs = synth.stream_records(b.streams)
+    cap = size + size // 4 + 64
+    streams = (A.Stream * n)()
+    r2 = synth.stream_records(streams)
+    r2["src_off"], r2["src_len"] = recs["dst_off"], size
+    r2["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64((cap + 255) // 256 * 256)
+    r2["dst_cap"], r2["format"] = cap, A.FMT_LZSS
+    dst_bytes = int(r2["dst_off"][-1]) + cap + 64
+    comp, eres, aux = ctx().encode_batch(streams, raw, dst_bytes, quality=quality)
+    er = synth.result_records(eres)
+    assert (er["status"] == 0).all()
+    assert (er["dst_len"] < size).all()                       # every synthetic buffer compresses
+    # round trip of the whole batch on the GPU
+    s3 = (A.Stream * n)()
+    r3 = synth.stream_records(s3)
+    r3["src_off"], r3["src_len"], r3["dst_off"], r3["dst_cap"], r3["decom_len"], r3["format"] = r2["dst_off"], er["dst_len"], recs["dst_off"], size, size, A.FMT_LZSS
+    back, dres = ctx().decode_batch(s3, comp, b.dst_bytes)
+    dr = synth.result_records(dres)
+    assert (dr["status"] == 0).all() and np.array_equal(dr["src_used"], er["dst_len"])
+    assert np.array_equal(back[:b.dst_bytes], raw[:b.dst_bytes])
+    # bit-identity with the oracle's encoder on a sample
+    for i in range(0, n, n // 16):
+        a = int(recs["dst_off"][i])
+        want, _ = O.encode_stream(A.FMT_LZSS, bytes(raw[a:a + size]), quality=quality)
+        o = int(r2["dst_off"][i])
+        assert bytes(comp[o:o + int(er["dst_len"][i])]) == want, i
