@@ -533,8 +533,11 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     const u32 tend = ((2u * (midx + (lit ? 0u : 1u))) << 8) | (uidx + (usesu ? 1u : 0u));
     u32 last;
     const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, true, len, desc, tend, segmark, nullptr, lane, last, 4096);
-    if (fin) { cp += last >> 8; up += last & 0xFFu; }
-    else { cp += 2u * (u32)__popcll(~lm); up += (u32)__popcll(um); fp += 8; }
+    // (selects, not an if / else of "+=" through the references: the compiler sinks those stores into ONE store through a
+    // pointer phi of &up / &fp before inlining, and the cursors then live in scratch memory for the whole kernel)
+    cp += fin ? (last >> 8) : 2u * (u32)__popcll(~lm);
+    up += fin ? (last & 0xFFu) : (u32)__popcll(um);
+    fp += fin ? 0u : 8u;
     return fin;
 }
 

@@ -179,8 +179,9 @@ __device__ void dec_yaz0_serial(InCache& in, SK& sk, DecState& s, u32 src_len, u
 // Yay0 (three cursors)  Nintendo/Yay0.cs:99-144 ; MIO0  Nintendo/MIO0.cs:105-149
 // fc: flags from 0, cc: tokens from aux0, uc: literals from aux1; each cursor bounded by its slice length.
 template <class SK, bool MIO0>
-__device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, SK& sk, DecState& s, u32 src_len, u32 size,
-                                   u32 fptr0, u32 cptr0, u32 uptr0, u32& used) {
+__device__ u32 dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, SK& sk, DecState& s, u32 src_len, u32 size,
+                                  u32 fptr0, u32 cptr0, u32 uptr0) {    // returns the input bytes used (by value: a
+                                                                        // reference to a caller's local puts it in scratch)
     u32 fp = fptr0, cp = cptr0, up = uptr0;
     while (sk.produced() < size) {
         if (s.bits == 0) {
@@ -208,7 +209,7 @@ __device__ void dec_3cursor_serial(InCache& fin, InCache& cin, InCache& uin, SK&
             if (!sk.match(distance, length, 4096)) break;
         }
     }
-    used = cp > up ? cp : up;
+    return cp > up ? cp : up;
 }
 
 // LZHudson.DecompressHeaderless  HudsonSoft/LZHudson.cs:53: Yay0.DecompressHeaderless with all three cursors on one stream

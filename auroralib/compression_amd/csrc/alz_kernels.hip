@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
             InCache cin, uin;
             cin.init(src, src_len, inc_lds + ALZ_INCACHE_BYTES, lane); cin.seek(a0 < src_len ? a0 : 0);
             uin.init(src, src_len, inc_lds + 2 * ALZ_INCACHE_BYTES, lane); uin.seek(a1 < src_len ? a1 : 0);
-            dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, 0, a0, a1, used);
+            used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, 0, a0, a1);
             used_set = true;
         }
     } else if constexpr (FMT == ALZ_FMT_PRS_BE) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
             while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len)
                 fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, segmark, lane, fp, cp, up);
             used = cp > up ? cp : up;
-            if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up, used); }
+            if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up); }
             used_set = true;
         }
     }
