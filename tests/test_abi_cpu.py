@@ -94,3 +94,24 @@ int main(void) {
                            "-L", libdir, "-lauroralz", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert out[0] == str(A.ABI_VERSION) and out[1] == str(A.C_COUNT) and " ".join(out[2:]) == "LZSS (10, 6, 2)"
+
+
+def test_decode_kernels_use_no_scratch(tmp_path):
+    """Every decode kernel keeps its state in registers and LDS: a non-zero private segment means a local ended up in
+    scratch memory (it did once: store sinking through a pointer phi put the Yay0 / MIO0 cursors there, -25 %)."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/llvm-readelf")):
+        pytest.skip("no llvm binutils")
+    so = shutil.copy(os.path.join(ROOT, "auroralib", "compression_amd", "libauroralz.so"), tmp_path / "lib.so")
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    seen = {}
+    for co in tmp_path.glob("lib.so.*gfx950"):
+        notes = subprocess.run([llvm + "/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        for name, priv in re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes):
+            seen[name] = int(priv)
+    dec = {k: v for k, v in seen.items() if "alz_decode_" in k}
+    assert len(dec) >= 25, sorted(seen)
+    assert all(v == 0 for v in dec.values()), {k: v for k, v in dec.items() if v}
