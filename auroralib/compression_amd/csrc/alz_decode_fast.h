@@ -30,7 +30,7 @@
 // interpretations + a scalar walk over a VGPR-resident window with the flag register in an SGPR).  pipelined_rounds
 // executes the rounds of the first five, overlapping the HBM read-backs of one round with the parse of the next.
 #pragma once
-#include "alz_decode_serial.h"
+#include "alz_emit_chunk.h"
 
 #ifndef ALZ_QRUN
 #define ALZ_QRUN 200u   /* longest literal run / element a lane-parallel round takes: window (256) + element stay inside one 512-byte cache chunk */
@@ -39,9 +39,6 @@
 #define ALZ_NB 8    /* steps whose HBM read-backs are issued together (two-pass byte phase of the 64 KiB formats) */
 #endif
 
-__device__ __forceinline__ u64 wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ u32 wave_bperm(u32 src_lane, u32 v) { return (u32)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
-__device__ __forceinline__ u32 wave_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 // v_writelane_b32: write a wave-uniform value into one lane of a VGPR (no clang builtin in ROCm 7.2).  gfx9 allows one
 // SGPR on the constant bus, so the lane select travels in M0 (what LLVM's own lowering of llvm.amdgcn.writelane does).
 __device__ __forceinline__ u32 wave_writelane(u32 old, u32 val, u32 lane) {
@@ -49,318 +46,10 @@ __device__ __forceinline__ u32 wave_writelane(u32 old, u32 val, u32 lane) {
     asm volatile("s_mov_b32 %1, %2\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old), "=&s"(tmp) : "s"(val), "s"(lane) : "m0");
     return old;
 }
-__device__ __forceinline__ u32 mbcnt64(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
-
-// inclusive prefix sum over the 64 lanes: DPP row shifts inside the 16-lane rows, then row broadcasts (gfx9 DPP)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ u32 dpp_add(u32 v) {
-    return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
-    (void)lane;
-    v = dpp_add<0x111, 0xF>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xF>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xF>(v);   // row_shr:8
-    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 -> rows 1,3
-    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-// descriptor of a token for the byte phase: bit31 literal (bits 0..7 the byte), else bits 0..16 the distance
-#define ALZ_DESC_LIT(b) (0x80000000u | (b))
-#define ALZ_DESC_MATCH(d) (d)
-#define ALZ_DESC_DIST(x) ((x) & 0x1FFFFu)
 
 struct FastGeom {           // LZSS geometry (other formats ignore it)
     u32 length_bits, min_length, windows_start, max_distance, W;
 };
-
-// One step of the byte phase: 64 consecutive output bytes, one per lane.  The kernel is bound by VALU issue (one wave
-// instruction per 4 cycles per SIMD), so the step is written for the fewest vector instructions:
-//   * token lanes mark the lane where their output ENDS inside the step; the token of byte L is then
-//     (#tokens ended before the step) + (#marks below L): one mbcnt pair, fused with the x4 of the bpermute address;
-//   * a match descriptor IS its distance (literal descriptors have bit 31 set), so the source slot is
-//     (slot - descriptor) & mask and "source inside this very step" is the unsigned test descriptor <= lane;
-//   * pointer jumping only runs in steps where that test fires for some lane;
-//   * EARLY (first W bytes of a stream: sources may lie before the stream start, E2) and !FULL (last, partial step)
-//     are separate instantiations so the steady state does not pay for them.
-// compile-time configuration of the byte phase
-//   OMASK    window mask when it is a compile-time constant (0: use out.lw_mask)
-//   LZSS     descriptors hold ring offsets that become distances once the output position is known
-//   LITRUN   bit-31 descriptors are literal RUNS copied from the LDS input cache (LZ4/LZO/Snappy): the low 30 bits are
-//            (input-cache index - window-slot coordinate) of the run, so byte q reads inlds[(slot(q) + desc) & 2047]
-//            (tokens carry the cache index; fast_emit subtracts the slot coordinate once the output offset is known);
-//            otherwise bit-31 descriptors carry ONE literal byte in bits 17..24 (flag-byte formats, PRS)
-//   FALLBACK the LDS window is shorter than the format's window (64 KiB formats keep 8 KiB): older sources are read
-//            back from the stream's own output in HBM (L2-served loads; flush_to() made them visible)
-template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_>
-struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_; };
-
-template <class OW, class CFG, bool EARLY, bool FULL>
-__device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32 nseg) {
-    const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
-    u8* const win = out.win;
-    { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }   // slots 64..127 are never read
-    wave_sync();
-    const u32 mk = segmark[lane];
-    segmark[lane] = 0;
-    const u64 M = __ballot(mk != 0);
-    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
-    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);   // match: the distance; literal: bit31 | ...
-    tbase4 += 4u * (u32)__popcll(M);
-    u32 wv = win[(qs - dsc) & omask];                        // source byte (garbage for literals, never used)
-    if (CFG::FALLBACK) {
-        const bool far = (int)dsc >= 0 && dsc > omask + 1u - 64u;      // older than the LDS window: already flushed to HBM
-        if (__ballot(far)) {
-            const u32 q = qs - out.oshift;
-            u32 g = 0;
-            if (far && dsc <= q) g = (u32)__hip_atomic_load(out.dst + (q - dsc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (far) wv = g;
-        }
-    }
-    if (EARLY) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
-    u32 val;                                                 // only the low byte is ever stored
-    if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
-    else val = ((int)dsc < 0) ? dsc : wv;
-    const bool instep = FULL ? (dsc <= (u32)lane) : (dsc <= (u32)lane && (u32)lane < nseg);   // source produced inside this very step
-    if (__ballot(instep)) {
-        // pointer jumping (at most 6 rounds), one ds_bpermute per round.  State word: resolved lanes hold their byte with
-        // bit 16 set; unresolved lanes hold (source lane) << 10, i.e. the bpermute address << 8.  An unresolved lane simply
-        // takes over its source's word: that is either the byte (resolved) or the source's source (jump).
-        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
-        do {
-            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
-            if (st < 0x10000u) st = f;
-        } while (__ballot(st < 0x10000u));
-        val = st;
-    }
-    if (FULL) win[qs & omask] = (u8)val;
-    else if ((u32)lane < nseg) win[qs & omask] = (u8)val;
-    wave_sync();
-    qs += 64u; relm -= 64u;
-}
-
-// Two-pass form of the step for configurations with HBM read-back (see fast_emit): map_step finds the descriptor of
-// this lane's byte, copy_step moves the byte.
-__device__ __forceinline__ u32 map_step(u8* segmark, int lane, u32 desc, u32& relm, u32& tbase4) {
-    { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }
-    wave_sync();
-    const u32 mk = segmark[lane];
-    segmark[lane] = 0;
-    const u64 M = __ballot(mk != 0);
-    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
-    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);
-    tbase4 += 4u * (u32)__popcll(M);
-    relm -= 64u;
-    return dsc;
-}
-
-template <class OW, class CFG>
-__device__ __forceinline__ void copy_step(OW& out, const u8* inlds, int lane, u32 dsc, u32 far, u32& qs, u32 nseg, bool early) {
-    const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
-    u8* const win = out.win;
-    u32 wv = win[(qs - dsc) & omask];
-    if (far) wv = far & 0xFFu;                               // read back from HBM by pass 1
-    if (early) { if (dsc > qs - out.oshift) wv = 0; }        // E2: before the stream start
-    u32 val;
-    if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
-    else val = ((int)dsc < 0) ? dsc : wv;
-    const bool instep = dsc <= (u32)lane && (u32)lane < nseg;
-    if (__ballot(instep)) {
-        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
-        do {
-            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
-            if (st < 0x10000u) st = f;
-        } while (__ballot(st < 0x10000u));
-        val = st;
-    }
-    if ((u32)lane < nseg) win[qs & omask] = (u8)val;
-    wave_sync();
-    qs += 64u;
-}
-
-// Software-pipelined steady-state step: copies step k with the descriptors found one step earlier and maps step k+1.
-// The two halves are independent, so their LDS round trips overlap: the dependent chain per step shrinks from
-// (mark read -> bpermute -> window read -> window write) to max(mark read -> bpermute, window read -> window write).
-// `dsc` holds the descriptors of the current step on entry and of the next step on return; relm / tbase4 belong to the
-// mapping side (one step ahead of qs).
-template <class OW, class CFG>
-__device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, const u32 dsc, u32& dsc_next) {
-    const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
-    u8* const win = out.win;
-    { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }
-    wave_sync();
-    const u32 wv = win[(qs - dsc) & omask];                  // copy side: source byte of step k
-    u32 lv = 0;
-    if (CFG::LITRUN) lv = inlds[(qs + dsc) & 2047u];
-    const u32 mk = segmark[lane];                            // map side: marks of step k+1
-    segmark[lane] = 0;
-    const u64 M = __ballot(mk != 0);
-    const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
-    const u32 dscn = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + tbase4), (int)desc);
-    tbase4 += 4u * (u32)__popcll(M);
-    u32 val;
-    if (CFG::LITRUN) val = ((int)dsc < 0) ? lv : wv;
-    else val = ((int)dsc < 0) ? dsc : wv;
-    const bool instep = dsc <= (u32)lane;
-    if (__ballot(instep)) {
-        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
-        do {
-            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
-            if (st < 0x10000u) st = f;
-        } while (__ballot(st < 0x10000u));
-        val = st;
-    }
-    win[qs & omask] = (u8)val;
-    wave_sync();
-    qs += 64u; relm -= 64u; dsc_next = dscn;
-}
-
-// Shared back end.  Per-lane token: valid, len (>=1), desc, tend = input offset just past the token (relative to the
-// iteration's base).  For LZSS the descriptor holds the ring OFFSET and is turned into a distance here, once the
-// token's output position is known (LzWindows.OffsetCopy  IO/LzWindows.cs:108-115).
-// Returns true when the stream is finished (declared size reached, or capacity hit).
-//
-// The state of one batch of tokens between its phases.  Configurations with HBM read-back run in two halves --
-// emit_begin (token prologue, byte -> token map of the first ALZ_NB steps, ALL their read-backs issued) and emit_finish
-// (the copies) -- so that a caller can do independent work (parse the next batch) while the read-backs are in flight.
-struct EmitState {
-    u32 desc, relm, qs, tbase4, T, X, O, W, nb, nsteps;
-    u32 dsc[ALZ_NB], far[ALZ_NB];
-    bool fin;
-};
-
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_prologue(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, int lane, u32& last_tend, u32 W, EmitState& e) {
-    u32 end = wave_incl_scan(valid ? len : 0u, lane);
-    u32 off = end - len;
-    const u32 O = out.produced;
-    const u32 left = size - O;                               // > 0 (caller guarantees produced < size)
-    bool keep = valid && off < left;                         // the token exists in the stream (prefix of lanes)
-    u64 km = __ballot(keep);
-    u32 nk = (u32)__popcll(km);
-    u32 nvalid = (u32)__popcll(__ballot(valid));
-    u32 Tend = wave_readlane(end, nk - 1);
-    bool fin = nk < nvalid || Tend >= left;
-    u32 lastk = nk - 1;
-    u32 T = Tend;
-    const u32 room = out.cap - O;
-    if (Tend > room) {                                       // E5: first token whose output would exceed dst_cap
-        u64 om = __ballot(keep && end > room);
-        lastk = (u32)__builtin_ctzll(om);
-        s.ovf = true; s.attempted_end = (u64)O + wave_readlane(end, lastk);
-        T = room; fin = true;
-    }
-    last_tend = wave_readlane(tend, lastk);
-    if (CFG::LITRUN) {                                        // literal run: (input-cache index of the run) - (slot coordinate of its first byte)
-        if (desc >> 31) desc = 0x80000000u | ((desc - (O + off + out.oshift)) & 2047u);
-    }
-    if (CFG::LZSS) {
-        if (!(desc >> 31)) {
-            u32 offset = ALZ_DESC_DIST(desc);
-            u32 pos = (O + off) & (W - 1);
-            u32 d = (pos - offset) & (W - 1);
-            if (d == 0) d = W;                               // E1
-            desc = ALZ_DESC_MATCH(d);
-        }
-    }
-    e.desc = desc; e.O = O; e.T = T; e.X = 0; e.W = W; e.fin = fin;
-    e.tbase4 = 0;                                            // 4 x (tokens that ended before the current step)
-    e.relm = keep ? end - 1u : 0xFFFFFF00u;                  // my token's LAST byte relative to the current step (huge: none)
-    e.qs = O + (u32)lane + out.oshift;                       // slot coordinate of this lane's byte in the current step
-}
-
-// Sources older than the LDS window come back from HBM (1-2 us each).  They are independent of everything the batch
-// produces, so the byte phase is split: emit_map maps bytes to tokens for up to ALZ_NB steps and issues ALL their
-// read-backs at once, emit_copy moves the bytes.  (For LDS-only configs this split costs more instructions than it saves.)
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_map(OW& out, u8* segmark, int lane, EmitState& e) {
-    constexpr int NB = ALZ_NB;
-    e.nb = e.T - e.X < 64u * NB ? e.T - e.X : 64u * NB;
-    e.nsteps = (e.nb + 63u) >> 6;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        e.dsc[k] = 0x80000000u; e.far[k] = 0;
-        if ((u32)k < e.nsteps) {
-            e.dsc[k] = map_step(segmark, lane, e.desc, e.relm, e.tbase4);
-            const u32 q = e.qs + 64u * (u32)k - out.oshift;
-            const u32 d = e.dsc[k];
-            if ((int)d >= 0 && d > out.lw_mask + 1u - 64u && d <= q)
-                e.far[k] = 0x100u | (u32)__hip_atomic_load(out.dst + (q - d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_copy(OW& out, const u8* inlds, int lane, EmitState& e) {
-    constexpr int NB = ALZ_NB;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        if ((u32)k < e.nsteps) {
-            const u32 nseg = e.nb - 64u * (u32)k;
-            copy_step<OW, CFG>(out, inlds, lane, e.dsc[k], e.far[k], e.qs, nseg < 64u ? nseg : 64u, e.O + e.X < e.W);
-            e.X += nseg < 64u ? nseg : 64u; out.produced = e.O + e.X;
-            if (out.produced - out.flushed >= out.fl) out.flush_blocks();
-        }
-    }
-}
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark, int lane, u32& last_tend, u32 W, EmitState& e) {
-    emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
-    e.nsteps = 0;
-    if (e.X < e.T) emit_map<OW, CFG>(out, segmark, lane, e);
-}
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_finish(OW& out, u8* segmark, const u8* inlds, int lane, EmitState& e) {
-    if (e.nsteps) emit_copy<OW, CFG>(out, inlds, lane, e);
-    while (e.X < e.T) { emit_map<OW, CFG>(out, segmark, lane, e); emit_copy<OW, CFG>(out, inlds, lane, e); }
-}
-
-template <class OW, class CFG>
-__device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* segmark,
-                                          const u8* inlds, int lane, u32& last_tend, u32 W) {
-    if constexpr (CFG::FALLBACK) {
-        EmitState e;
-        emit_begin<OW, CFG>(out, s, size, valid, len, desc, tend, segmark, lane, last_tend, W, e);
-        emit_finish<OW, CFG>(out, segmark, inlds, lane, e);
-        return e.fin;
-    } else {
-        EmitState e;
-        emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
-        desc = e.desc;
-        const u32 O = e.O, T = e.T;
-        u32 X = 0, relm = e.relm, qs = e.qs, tbase4 = 0;
-        const bool fin = e.fin;
-        // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
-        while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-        // steady state: flush checks only where the output crosses a flush-block boundary (the loop in between is a bare
-        // counter: the kernel is bound by instruction issue per wave, scalar instructions included)
-        u32 nleft = (T - X) >> 6;
-        u32 dsc = 0; bool have = false;
-        if (nleft) {
-            dsc = map_step(segmark, lane, desc, relm, tbase4); have = true;      // pipeline prologue: descriptors of the first step
-            do {
-                const u32 pos = O + X + out.oshift;
-                u32 nb = (out.fl - (pos & (out.fl - 1u)) + 63u) >> 6;
-                if (nb > nleft) nb = nleft;
-                u32 k = nb, dsc2;                               // two steps per trip: the descriptors ping-pong between two registers
-                for (; k >= 2u; k -= 2u) {
-                    fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc, dsc2);
-                    fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc2, dsc);
-                }
-                if (k) { fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc, dsc2); dsc = dsc2; }
-                X += 64u * nb; nleft -= nb; out.produced = O + X;
-                if (out.produced - out.flushed >= out.fl) out.flush_blocks();
-            } while (nleft);
-        }
-        if (X < T) {                                          // last, partial step (its descriptors may already be mapped)
-            if (!have) dsc = map_step(segmark, lane, desc, relm, tbase4);
-            copy_step<OW, CFG>(out, inlds, lane, dsc, 0u, qs, T - X, true);
-            out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks();
-        }
-        return fin;
-    }
-}
 
 template <int FMT> struct FamTraits;
 // MSB: flag bits MSB first; LIT1: flag bit 1 = literal; H3 / H4: a match whose size nibble is 0 / 1 has 3 / 4 bytes; NIBLO: that
@@ -654,6 +343,7 @@ __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u
     out.dst = reinterpret_cast<u8*>(((u64)uni((u32)((u64)dst >> 32)) << 32) | uni((u32)(u64)dst));
     out.win = win; out.lw_mask = uni(lw_mask); out.fl = uni(fl); out.oshift = uni(oshift); out.cap = uni(cap);
     out.produced = uni(produced); out.flushed = uni(flushed); out.lane = lane;
+    out.slack_dirty = true;                                  // (the exact parsers' byte-wise writers may have run in between)
     DecState s; dec_state_init(s);
     const u32 len = qtok >> 18, lo = qtok & 0x1FFFFu;
     u32 desc = lo;

@@ -25,6 +25,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define ALZ_WAVE 64
+#define ALZ_WIN_SLACK 32u   /* bytes behind an LDS ring that mirror its head (chunked byte phase) */
 
 __device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_sync() {
@@ -136,14 +137,18 @@ struct OutWin {
     u32 produced;    // bytes decoded so far (wave-uniform)
     u32 flushed;     // bytes already stored to HBM (wave-uniform)
     int lane;
+    // The chunked byte phase (alz_emit_chunk.h) moves dword-aligned pieces of up to 24 bytes, which may run past the end of
+    // the ring: kernels that use it allocate ALZ_WIN_SLACK bytes behind the ring that mirror its first bytes.  The byte-wise
+    // writers below only touch the ring proper and mark the mirror stale; the chunked phase refreshes it before it reads.
+    bool slack_dirty;
 
-    __device__ __forceinline__ void init(u8* dst_, u32 cap_, u8* win_, u32 lw, int lane_) {
+    __device__ __forceinline__ void init(u8* dst_, u32 cap_, u8* win_, u32 lw, int lane_, u32 slack = 0) {
         dst = dst_; cap = cap_; win = win_; lw_mask = lw - 1; lane = lane_;
         fl = lw >= 4096 ? 1024u : (lw >> 2);
         oshift = (u32)(reinterpret_cast<uintptr_t>(dst_) & 15u);
-        produced = 0; flushed = 0;
+        produced = 0; flushed = 0; slack_dirty = false;
         // E2: the reference's rented ring is treated as zero-filled
-        for (u32 i = 16u * (u32)lane; i < lw; i += 16u * ALZ_WAVE) *reinterpret_cast<uint4*>(win + i) = make_uint4(0, 0, 0, 0);
+        for (u32 i = 16u * (u32)lane; i < lw + slack; i += 16u * ALZ_WAVE) *reinterpret_cast<uint4*>(win + i) = make_uint4(0, 0, 0, 0);
         wave_sync();
     }
     __device__ __forceinline__ u32 slot(u32 q) const { return (q + oshift) & lw_mask; }
@@ -156,7 +161,7 @@ struct OutWin {
         const u32 n = hist < lw ? hist : lw;
         for (u32 i = (u32)lane; i < n; i += ALZ_WAVE) { const u32 pos = hist - n + i; win[slot(pos)] = dst[pos]; }
         wave_sync();
-        produced = hist; flushed = hist;
+        produced = hist; flushed = hist; slack_dirty = true;
     }
 
     // store [flushed, limit) to HBM; 16 B granules aligned in LDS and HBM, ragged ends bytewise
@@ -186,7 +191,7 @@ struct OutWin {
     // one literal byte (wave-uniform value)
     __device__ __forceinline__ void put_byte(u32 b) {
         if (lane == 0) win[slot(produced)] = (u8)b;
-        produced += 1;
+        produced += 1; slack_dirty = true;
         if (((produced + oshift) & (fl - 1)) == 0) flush_blocks();
     }
 
@@ -195,6 +200,7 @@ struct OutWin {
     // min(rem, done + d) bytes are a copy shifted by P = done + d (a multiple of d), all sources < produced.
     __device__ void back_copy(u32 d, u32 len, u32 dw) {
         if (d == 0) d = dw;                                   // E1
+        slack_dirty = true;
         const u32 lw = lw_mask + 1;
         u32 done = 0, P = d;                                  // P: multiple of d, P <= done + d
         while (done < len) {
@@ -230,6 +236,7 @@ struct OutWin {
     // literal run straight from the input cache (LzWindows.CopyFrom / Write); len clipped, input residency handled here
     __device__ void copy_from(InCache& in, u32 p, u32 len) {
         u32 off = 0;
+        slack_dirty = true;
         while (off < len) {
             u32 n = len - off; if (n > fl) n = fl; if (n > in.ch) n = in.ch;
             in.ensure(p + off, n);

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #endif
     constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][128 + NC * CACHE + LWMAX];
+    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][ALZ_EMIT_SCRATCH + NC * CACHE + LWMAX + ALZ_WIN_SLACK];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
     u32 bid = blockIdx.x * ALZ_WPB + wid;
@@ -169,8 +169,9 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     u8* dst = dst_base + st.dst_off;
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
     u8* segmark = lds;
-    u8* inc_lds = lds + 128;
-    OutWin<false> out; out.init(dst, cap, lds + 128 + NC * CACHE, lw, lane);
+    u8* inc_lds = lds + ALZ_EMIT_SCRATCH;
+    (void)lw;                                                // the ring is LWMAX whatever the format's window: the byte phase writes up to ~1.1 KiB ahead
+    OutWin<false> out; out.init(dst, cap, lds + ALZ_EMIT_SCRATCH + NC * CACHE, LWMAX, lane, ALZ_WIN_SLACK);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
@@ -266,11 +267,11 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     constexpr bool CNX = (FMT == ALZ_FMT_CNX2 || CNS || SHREK);      // 2 KiB / 256 B windows: all of it in LDS, literal runs from the input cache
     constexpr bool PRSFB = (ALZ_PRS_LW < 8192);             // PRS with a window smaller than its 8 KiB: read-back like the 64 KiB formats
     constexpr u32 LW = PRS ? (u32)ALZ_PRS_LW : ALZ_QUEUE_LW;   // PRS: its whole 8 KiB window (half of its matches would otherwise go to HBM)
-    // static LDS: marks (128) | token staging (256) | input cache | window
+    // static LDS: byte-phase scratch (marks + token table) | token staging (256) | input cache | window + mirror
     // input cache of two 512-byte chunks (CNX2: 1 KiB chunks): a round looks at most 256 + ALZ_QRUN bytes ahead, and 1 KiB less LDS
     // per wave is four more waves per CU for the 4 KiB-window formats
     constexpr u32 QCH = (FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
-    __shared__ __attribute__((aligned(16))) u8 lds[384 + QCACHE + LW];
+    __shared__ __attribute__((aligned(16))) u8 lds[ALZ_EMIT_SCRATCH + 256 + QCACHE + LW + ALZ_WIN_SLACK];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -283,11 +284,11 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     const u32 hist = (FMT == ALZ_FMT_LZ4_BLOCK) ? uni(st.aux0) : 0u;      // LZ4 frames with linked blocks (see OutWin::preload)
     dst -= hist; cap += hist;
     u8* segmark = lds;
-    u32* stage = reinterpret_cast<u32*>(lds + 128);
-    u8* inc_lds = lds + 384;
+    u32* stage = reinterpret_cast<u32*>(lds + ALZ_EMIT_SCRATCH);
+    u8* inc_lds = lds + ALZ_EMIT_SCRATCH + 256;
     constexpr bool FB = CNX ? false : (!PRS || PRSFB);
     typedef OutWin<FB> OW;
-    OW out; out.init(dst, cap, lds + 384 + QCACHE, LW, lane);
+    OW out; out.init(dst, cap, lds + ALZ_EMIT_SCRATCH + 256 + QCACHE, LW, lane, ALZ_WIN_SLACK);
     if (hist) out.preload(hist);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, QCH);
