@@ -30,7 +30,7 @@
 // interpretations + a scalar walk over a VGPR-resident window with the flag register in an SGPR).  pipelined_rounds
 // executes the rounds of the first five, overlapping the HBM read-backs of one round with the parse of the next.
 #pragma once
-#include "alz_emit_chunk.h"
+#include "alz_emit_byte.h"
 
 #ifndef ALZ_QRUN
 #define ALZ_QRUN 200u   /* longest literal run / element a lane-parallel round takes: window (256) + element stay inside one 512-byte cache chunk */

@@ -89,7 +89,7 @@ struct EmitState {
     bool kept, fin;      // this lane's token is executed; the stream is finished after this batch
     u32 off, clen;       // output offset of the token inside the batch, its length after the size / capacity cuts
     u32 desc;            // distance | literal byte | cache index of a run
-    u32 O, T;            // output position of the batch, bytes it produces
+    u32 O, T, W;         // output position of the batch, bytes it produces, the format's window (E2 of the byte phase)
 };
 
 // Token prologue.  Per-lane token: valid, len (>= 1), desc, tend = input offset just past the token.  For LZSS the
@@ -128,21 +128,46 @@ __device__ __forceinline__ void emit_prologue(OW& out, DecState& s, u32 size, bo
     }
     e.kept = keep && off < T;
     e.off = off; e.clen = (T - off < len) ? T - off : len;
-    e.desc = desc; e.O = O; e.T = T; e.fin = fin;
+    e.desc = desc; e.O = O; e.T = T; e.W = W; e.fin = fin;
 }
 
-// the stores of one chunk: dword 0 under the head mask, dwords 1 .. jt - 1 whole, dword jt under the tail mask.  CHK: only
-// the dwords whose address lies in [lo, lo + span)
-template <bool CHK>
-__device__ __forceinline__ void chunk_store(bool wr, u32 base, u32 lo, u32 span, u32 jt, u32 Mh, u32 Mt, u32 E0, u32 E1, u32 E2, u32 E3, u32 Et) {
-    typedef __attribute__((address_space(3))) u32 lds_u32;
-#define ALZ_IN(j) (!CHK || (base + 4u * (j) - lo) < span)
-    if (wr && ALZ_IN(0u)) lds_mskor(base, Mh, E0 & Mh);
-    if (wr && 1u < jt && ALZ_IN(1u)) *(lds_u32*)(uintptr_t)(base + 4u) = E1;
-    if (wr && 2u < jt && ALZ_IN(2u)) *(lds_u32*)(uintptr_t)(base + 8u) = E2;
-    if (wr && 3u < jt && ALZ_IN(3u)) *(lds_u32*)(uintptr_t)(base + 12u) = E3;
-    if (wr && jt != 0u && ALZ_IN(jt)) lds_mskor(base + 4u * jt, Mt, Et & Mt);
-#undef ALZ_IN
+// The five window dwords of a chunk, stored under their byte masks (ds_mskor_b32; a zero mask leaves the dword alone).
+__device__ __forceinline__ void chunk_store(bool wr, u32 base, u32 M0, u32 M1, u32 M2, u32 M3, u32 M4, u32 E0, u32 E1, u32 E2, u32 E3, u32 E4) {
+    if (wr) {
+        lds_mskor(base, M0, E0 & M0); lds_mskor(base + 4u, M1, E1 & M1); lds_mskor(base + 8u, M2, E2 & M2);
+        lds_mskor(base + 12u, M3, E3 & M3); lds_mskor(base + 16u, M4, E4 & M4);
+    }
+}
+// A chunk that crosses the end of the ring, or lies in its first bytes, is stored a second time: only the dwords on the
+// other side of the seam (the mirror behind the ring, see OutWin::slack_dirty).  a0 = offset of dword 0 in the ring.
+__device__ __forceinline__ void chunk_mirror(bool wr, u32 wbase, u32 a0, u32 LW, u32 jt, u32 M0, u32 M1, u32 M2, u32 M3, u32 M4, u32 E0, u32 E1, u32 E2, u32 E3, u32 E4) {
+    const bool cross = wr && a0 + 4u * jt >= LW, head = wr && a0 < ALZ_WIN_SLACK;
+    if (wave_ballot(cross || head)) {
+        const u32 a1 = cross ? a0 - LW : a0 + LW, lo = cross ? 0u : LW;          // wanted: lo <= a1 + 4 j < lo + slack
+#define ALZ_MM(j, M) ((a1 + 4u * (j) - lo) < ALZ_WIN_SLACK ? (M) : 0u)
+        chunk_store(cross || head, wbase + a1, ALZ_MM(0u, M0), ALZ_MM(1u, M1), ALZ_MM(2u, M2), ALZ_MM(3u, M3), ALZ_MM(4u, M4), E0, E1, E2, E3, E4);
+#undef ALZ_MM
+    }
+}
+// byte mask of window dword j from the 20-bit byte map of the chunk (bit x = window byte x belongs to the chunk)
+__device__ __forceinline__ u32 chunk_mask(u32 bmap, u32 j) {
+    const u32 nib = (bmap >> (4u * j)) & 0xFu;
+    return ((nib * 0x204081u) & 0x01010101u) * 0xFFu;
+}
+// 24 source bytes at a dword-aligned LDS address, funnelled to the five window dwords (t = byte offset of the first one)
+__device__ __forceinline__ void chunk_read(const lds_u8* sbase, u32 t, u32& N0, u32& N1, u32& N2, u32& N3, u32& N4) {
+    const alz_v4 ra = *reinterpret_cast<const __attribute__((address_space(3))) alz_v4*>(sbase);
+    const alz_v2 rb = *reinterpret_cast<const __attribute__((address_space(3))) alz_v2*>(sbase + 16);
+    N0 = __builtin_amdgcn_alignbyte(ra.y, ra.x, t); N1 = __builtin_amdgcn_alignbyte(ra.z, ra.y, t);
+    N2 = __builtin_amdgcn_alignbyte(ra.w, ra.z, t); N3 = __builtin_amdgcn_alignbyte(rb.x, ra.w, t);
+    N4 = __builtin_amdgcn_alignbyte(rb.y, rb.x, t);
+}
+// dword-periodic patterns (distance 1, 2, 4): pattern P0.. = window bytes b..; window byte x is P[(x - b) mod d]
+__device__ __forceinline__ void chunk_rep(u32 d, u32 b, u32& N0, u32& N1, u32& N2, u32& N3, u32& N4) {
+    const u32 p = __builtin_amdgcn_alignbyte(N1, N0, b);
+    const u32 u = d == 1u ? (p & 0xFFu) * 0x01010101u : (d == 2u ? (p & 0xFFFFu) * 0x00010001u : p);
+    const u32 w = __builtin_amdgcn_alignbyte(u, u, (4u - b) & 3u);
+    N0 = w; N1 = w; N2 = w; N3 = w; N4 = w;
 }
 
 // One step of the byte phase: every active lane moves one chunk -- n <= 16 bytes at output position q, bytes i0.. of its
@@ -150,14 +175,15 @@ __device__ __forceinline__ void chunk_store(bool wr, u32 base, u32 lo, u32 span,
 // (+ i0), otherwise the window at distance d.  Xs = output position up to which everything is final (the step's own
 // output starts there).  LATER: step >= 1 of a token that runs alone (sources are folded to lie before Xs).
 template <class OW, class CFG, bool LATER>
-__device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u32 q, u32 n, u32 i0, bool run, u32 d, u32 Xs,
+__device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u32 q, u32 n, u32 i0, bool run, u32 d, bool dchunks, u32 Xs,
                                            bool lit, u32 litq, u32 litb) {
     const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
     const u32 LW = omask + 1u;
     u8* const win = out.win;
+    const u32 wbase = lds_addr(win);
     const u32 qa = q + out.oshift;
     const u32 b = qa & 3u;                                  // the chunk starts at byte b of its first window dword
-    const u32 A0 = lds_addr(win) + (qa & omask & ~3u);
+    const u32 a0 = qa & omask & ~3u;
     const bool isrun = CFG::LITRUN && run;
     const bool m = act && !isrun;
     // ---- where the bytes come from
@@ -170,9 +196,9 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
             const u32 a = x + dd - 1u;
             const u32 D = a - umod24(a, dd);
             if (ovl) sp = q - D;
-        } else if (wave_ballot(ovl && i0 != 0u && !rep)) {  // the pattern in front of the token (+ its first chunk)
-            const u32 r = umod24(i0, ovl ? d : 1u);
-            if (ovl) sp = q - i0 - d + (rep ? 0u : r);
+        } else if (wave_ballot(ovl && i0 != 0u && !rep && !dchunks)) {  // the pattern in front of the token (+ its first chunk)
+            const u32 r = umod24(i0, ovl ? d : 1u);                 // (dchunks: the token's chunks are d bytes, i0 is a multiple of d)
+            if (ovl) sp = q - i0 - d + ((rep || dchunks) ? 0u : r);
         } else if (ovl) sp = q - i0 - d;
     }
     bool dep = m && (int)(sp + (rep ? d : n) - Xs) > 0;     // the source reaches into this step's own output
@@ -182,14 +208,14 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
     // source window: the 20 bytes that land in the chunk's five window dwords start at source byte -b
     u32 sa;                                                 // LDS byte address of that window (ring / input cache)
     if (isrun) sa = lds_addr(inlds) + d + i0 - b;
-    else sa = lds_addr(win) + ((sp + out.oshift - b) & omask);
+    else sa = wbase + ((sp + out.oshift - b) & omask);
     const u32 t = sa & 3u;
     const lds_u8* const sbase = (const lds_u8*)(uintptr_t)(sa & ~3u);
-    // ---- masks of the head and tail dword
-    const u32 e = b + n;                                    // 1..19
-    const u32 jt = (e - 1u) >> 2;                           // last dword touched (0..4)
-    const u32 Mh = (0xFFFFFFFFu >> (32u - 8u * (e < 4u ? e : 4u))) & (0xFFFFFFFFu << (8u * b));
-    const u32 Mt = 0xFFFFFFFFu >> (32u - 8u * (((e - 1u) & 3u) + 1u));
+    // ---- byte masks of the five window dwords
+    const u32 bmap = ((1u << n) - 1u) << b;
+    const u32 jt = (b + n - 1u) >> 2;                       // last dword touched (0..4)
+    const u32 M0 = chunk_mask(bmap, 0u), M1 = chunk_mask(bmap, 1u), M2 = chunk_mask(bmap, 2u), M3 = chunk_mask(bmap, 3u), M4 = chunk_mask(bmap, 4u);
+    // ---- pass 1: every chunk
     u32 E0 = 0, E1 = 0, E2 = 0, E3 = 0, E4 = 0;
     if (CFG::FALLBACK) {
         if (wave_ballot(far)) {
@@ -213,52 +239,32 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
             }
         }
     }
-    bool first = true;
-    for (;;) {
-        // ---- read (pass 0: every chunk that lives in LDS; later passes: the dependent ones)
-        u32 N0 = 0, N1 = 0, N2 = 0, N3 = 0, N4 = 0;
-        if (first ? (act && !far) : dep) {
-            const alz_v4 ra = *reinterpret_cast<const __attribute__((address_space(3))) alz_v4*>(sbase);
-            const alz_v2 rb = *reinterpret_cast<const __attribute__((address_space(3))) alz_v2*>(sbase + 16);
-            N0 = __builtin_amdgcn_alignbyte(ra.y, ra.x, t); N1 = __builtin_amdgcn_alignbyte(ra.z, ra.y, t);
-            N2 = __builtin_amdgcn_alignbyte(ra.w, ra.z, t); N3 = __builtin_amdgcn_alignbyte(rb.x, ra.w, t);
-            N4 = __builtin_amdgcn_alignbyte(rb.y, rb.x, t);
-        }
-        if (wave_ballot(rep)) {
-            if (rep) {                                      // pattern P0.. = window bytes b..; window byte x is P[(x - b) mod d]
-                const u32 p = __builtin_amdgcn_alignbyte(N1, N0, b);
-                const u32 u = d == 1u ? (p & 0xFFu) * 0x01010101u : (d == 2u ? (p & 0xFFFFu) * 0x00010001u : p);
-                const u32 w = __builtin_amdgcn_alignbyte(u, u, (4u - b) & 3u);
-                N0 = w; N1 = w; N2 = w; N3 = w; N4 = w;
-            }
-        }
-        bool wr;
-        if (first) {
-            if (CFG::FALLBACK) { if (far) { N0 = E0; N1 = E1; N2 = E2; N3 = E3; N4 = E4; } }
-            // single literals: stored after the step's reads (their slots may still hold the bytes a distance == W match wants)
-            if (wave_ballot(lit)) {
-                const u32 sl = (litq + out.oshift) & omask;
-                if (lit) win[sl] = (u8)litb;
-                if (wave_ballot(lit && sl < ALZ_WIN_SLACK)) { if (lit && sl < ALZ_WIN_SLACK) win[sl + LW] = (u8)litb; }
-            }
-            wr = act;
-        } else {
-            wr = dep && (N0 != E0 || N1 != E1 || N2 != E2 || N3 != E3 || N4 != E4);
-            if (!wave_ballot(wr)) break;
-        }
-        if (wr) { E0 = N0; E1 = N1; E2 = N2; E3 = N3; E4 = N4; }
-        // ---- write: head dword under its byte mask, whole dwords, tail dword under its mask
-        const u32 Et = jt == 1u ? E1 : (jt == 2u ? E2 : (jt == 3u ? E3 : E4));
-        chunk_store<false>(wr, A0, 0, 0, jt, Mh, Mt, E0, E1, E2, E3, Et);
-        {   // a chunk that crosses the end of the ring, or lies in its first bytes, is stored a second time (the mirror behind
-            // the ring, see OutWin::slack_dirty): only the dwords on the other side of the seam
-            const u32 a0 = A0 - lds_addr(win);
-            const bool cross = wr && a0 + 4u * jt >= LW, head = wr && a0 < ALZ_WIN_SLACK;
-            if (wave_ballot(cross || head))
-                chunk_store<true>(cross || head, cross ? A0 - LW : A0 + LW, lds_addr(win) + (cross ? 0u : LW), ALZ_WIN_SLACK, jt, Mh, Mt, E0, E1, E2, E3, Et);
-        }
-        first = false;
-        if (!wave_ballot(dep)) break;
+    if (act && !far) chunk_read(sbase, t, E0, E1, E2, E3, E4);
+    if (wave_ballot(rep)) { if (rep) chunk_rep(d, b, E0, E1, E2, E3, E4); }
+    // single literals: stored after the step's reads (their slots may still hold the bytes a distance == W match wants)
+    if (wave_ballot(lit)) {
+        const u32 sl = (litq + out.oshift) & omask;
+        if (lit) win[sl] = (u8)litb;
+        if (wave_ballot(lit && sl < ALZ_WIN_SLACK)) { if (lit && sl < ALZ_WIN_SLACK) win[sl + LW] = (u8)litb; }
+    }
+    chunk_store(act, wbase + a0, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
+    chunk_mirror(act, wbase, a0, LW, jt, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
+#ifdef ALZ_EMIT_STATS
+    out.st_steps++; out.st_passes++; out.st_chunks += (u32)__popcll(wave_ballot(act)); out.st_dep += (u32)__popcll(wave_ballot(dep));
+#endif
+    // ---- chunks whose source reaches into this step's own output: read again until nothing changes
+    while (wave_ballot(dep)) {
+        u32 N0 = E0, N1 = E1, N2 = E2, N3 = E3, N4 = E4;
+        if (dep) chunk_read(sbase, t, N0, N1, N2, N3, N4);
+        if (wave_ballot(rep && dep)) { if (rep && dep) chunk_rep(d, b, N0, N1, N2, N3, N4); }
+        const bool wr = dep && (N0 != E0 || N1 != E1 || N2 != E2 || N3 != E3 || N4 != E4);
+        if (!wave_ballot(wr)) break;
+#ifdef ALZ_EMIT_STATS
+        out.st_passes++;
+#endif
+        E0 = N0; E1 = N1; E2 = N2; E3 = N3; E4 = N4;
+        chunk_store(wr, wbase + a0, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
+        chunk_mirror(wr, wbase, a0, LW, jt, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
     }
 }
 
@@ -286,7 +292,16 @@ __device__ __forceinline__ void emit_steps(OW& out, u8* scratch, const u8* inlds
         const u32 seg1 = longm ? (u32)__builtin_ctzll(longm) : 64u;
         // ---- tokens seg0 .. seg1 - 1: mapped steps of 64 chunks
         const bool inseg = (u32)lane >= seg0 && (u32)lane < seg1;
-        const u32 nch = (ism && inseg) ? (e.clen + 15u) >> 4 : 0u;
+        // chunk size: 16 bytes -- except for a self-overlapping match whose distance d < 16 is not 1, 2 or 4 (those are
+        // replicated in registers): its chunks are d bytes, so that every one of them is a plain copy of the d pattern bytes
+        // in front of the token (no chunk ever reads what another chunk of its token writes)
+        const bool tsm = ism && inseg && !isrun && dfield < 16u && dfield < e.clen && dfield != 1u && dfield != 2u && dfield != 4u;
+        u32 cs = 16u, nch = (ism && inseg) ? (e.clen + 15u) >> 4 : 0u;
+        if (wave_ballot(tsm)) {
+            const u32 dd = tsm ? dfield : 1u;
+            const u32 a = e.clen + dd - 1u;
+            if (tsm) { cs = dd; nch = (u32)((float)(a - umod24(a, dd)) * __builtin_amdgcn_rcpf((float)dd) + 0.5f); }   // ceil(len / d): an exact multiple of d over d
+        }
         const bool lits = islit && inseg;
         const u32 segO = O + (seg0 < 64u ? wave_readlane(e.off, seg0) : 0u);   // output position of the segment (table offsets are relative to it)
         if (wave_ballot(nch != 0u || lits)) {
@@ -294,14 +309,14 @@ __device__ __forceinline__ void emit_steps(OW& out, u8* scratch, const u8* inlds
             const u32 cstart = cend - nch;
             const u32 total = wave_readlane(cend, 63);
             const u64 cm = wave_ballot(nch != 0u);
-            if (nch) table[mbcnt64(cm)] = make_uint2(dfield | (isrun ? 0x20000u : 0u) | ((e.clen - 1u) << 18), (e.off - (segO - O)) | (cstart << 17));
+            if (nch) table[mbcnt64(cm)] = make_uint2(dfield | (isrun ? 0x20000u : 0u) | ((e.clen - 1u) << 18) | ((cs - 1u) << 28), (e.off - (segO - O)) | (cstart << 16));
             u32 relm = nch ? cend - 1u : 0xFFFFFF00u;        // my token's LAST chunk relative to the current step (huge: none)
             u32 rbase = 0;
             const u32 nsteps = (total >> 6) + 1u;
             for (u32 k = 0; k < nsteps; k++) {
                 const u32 cid0 = k << 6;
                 const u32 nact = total - cid0 < 64u ? total - cid0 : 64u;
-                bool act = false; u32 q = 0, n = 1, i0 = 0, d = 1; bool run = false;
+                bool act = false; u32 q = 0, n = 1, i0 = 0, d = 1; bool run = false, dch = false;
                 if (nact) {
                     { const u32 dump = 64u + (u32)lane; segmark[relm < dump ? relm : dump] = 1; }   // slots 64..127 are never read
                     wave_sync();
@@ -311,13 +326,13 @@ __device__ __forceinline__ void emit_steps(OW& out, u8* scratch, const u8* inlds
                     const uint2 tk = table[(rbase + mbcnt64(M)) & 63u];
                     rbase += (u32)__popcll(M);
                     act = (u32)lane < nact;
-                    const u32 tlen = (tk.x >> 18) + 1u, toff = tk.y & 0x1FFFFu, tcs = tk.y >> 17;
-                    i0 = (cid0 + (u32)lane - tcs) << 4;
-                    if (act) { n = tlen - i0 < 16u ? tlen - i0 : 16u; d = tk.x & 0x1FFFFu; run = (tk.x & 0x20000u) != 0u; }
+                    const u32 tlen = ((tk.x >> 18) & 0x3FFu) + 1u, toff = tk.y & 0xFFFFu, tcs = tk.y >> 16, csz = (tk.x >> 28) + 1u;
+                    i0 = (cid0 + (u32)lane - tcs) * csz;
+                    if (act) { n = tlen - i0 < csz ? tlen - i0 : csz; d = tk.x & 0x1FFFFu; run = (tk.x & 0x20000u) != 0u; dch = csz != 16u; }
                     else i0 = 0;
                     q = segO + toff + i0;
                 }
-                chunk_copy<OW, CFG, false>(out, inlds, act, q, n, i0, run, d, Xs, lits && (cstart >> 6) == k, O + e.off, e.desc & 0xFFu);
+                chunk_copy<OW, CFG, false>(out, inlds, act, q, n, i0, run, d, dch, Xs, lits && (cstart >> 6) == k, O + e.off, e.desc & 0xFFu);
                 relm -= 64u;
                 // everything in front of the first chunk of the next step (or, behind the last step, of the next segment) is final
                 Xs = nact == 64u ? wave_readlane(q + n, 63) : (seg1 < 64u ? O + wave_readlane(e.off, seg1) : O + e.T);
@@ -337,8 +352,8 @@ __device__ __forceinline__ void emit_steps(OW& out, u8* scratch, const u8* inlds
                 const u32 i0 = base + 16u * (u32)lane;
                 const bool act = i0 < tlen;
                 const u32 n = act ? (tlen - i0 < 16u ? tlen - i0 : 16u) : 1u;
-                if (base == 0) chunk_copy<OW, CFG, false>(out, inlds, act, s0 + i0, n, act ? i0 : 0u, trun, td, Xs, false, 0u, 0u);
-                else chunk_copy<OW, CFG, true>(out, inlds, act, s0 + i0, n, act ? i0 : 0u, trun, td, Xs, false, 0u, 0u);
+                if (base == 0) chunk_copy<OW, CFG, false>(out, inlds, act, s0 + i0, n, act ? i0 : 0u, trun, td, false, Xs, false, 0u, 0u);
+                else chunk_copy<OW, CFG, true>(out, inlds, act, s0 + i0, n, act ? i0 : 0u, trun, td, false, Xs, false, 0u, 0u);
                 Xs = s0 + (tlen - base < 1024u ? tlen : base + 1024u);
                 out.produced = Xs;
                 if (out.produced - out.flushed >= out.fl) out.flush_blocks();
@@ -351,22 +366,3 @@ __device__ __forceinline__ void emit_steps(OW& out, u8* scratch, const u8* inlds
     if (out.produced - out.flushed >= out.fl) out.flush_blocks();
 }
 
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch, int lane, u32& last_tend, u32 W, EmitState& e) {
-    (void)scratch;
-    emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
-}
-template <class OW, class CFG>
-__device__ __forceinline__ void emit_finish(OW& out, u8* scratch, const u8* inlds, int lane, EmitState& e) {
-    emit_steps<OW, CFG>(out, scratch, inlds, lane, e);
-}
-
-// Returns true when the stream is finished (declared size reached, or capacity hit).
-template <class OW, class CFG>
-__device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch,
-                                          const u8* inlds, int lane, u32& last_tend, u32 W) {
-    EmitState e;
-    emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
-    emit_steps<OW, CFG>(out, scratch, inlds, lane, e);
-    return e.fin;
-}

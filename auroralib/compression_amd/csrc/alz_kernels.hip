@@ -29,6 +29,10 @@
 template <bool FB>
 __device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status, u32 hist = 0) {
     if (lane == 0) { r->dst_len = out.produced - hist; r->src_used = src_used; r->status = status; r->reserved = 0; }
+#ifdef ALZ_EMIT_STATS
+    // experiment build: (steps, passes, chunks, dependent chunks) of the byte phase, 4 x 8 bits of per-step averages x 16
+    if (lane == 0 && out.st_steps) r->reserved = (out.st_steps & 0xFFFFu) | ((out.st_passes * 16u / out.st_steps) << 16) | ((out.st_chunks * 2u / out.st_steps) << 24);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #endif
     constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][ALZ_EMIT_SCRATCH + NC * CACHE + LWMAX + ALZ_WIN_SLACK];
+    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][128 + NC * CACHE + LWMAX];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
     u32 bid = blockIdx.x * ALZ_WPB + wid;
@@ -169,9 +173,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     u8* dst = dst_base + st.dst_off;
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
     u8* segmark = lds;
-    u8* inc_lds = lds + ALZ_EMIT_SCRATCH;
-    (void)lw;                                                // the ring is LWMAX whatever the format's window: the byte phase writes up to ~1.1 KiB ahead
-    OutWin<false> out; out.init(dst, cap, lds + ALZ_EMIT_SCRATCH + NC * CACHE, LWMAX, lane, ALZ_WIN_SLACK);
+    u8* inc_lds = lds + 128;
+    OutWin<false> out; out.init(dst, cap, lds + 128 + NC * CACHE, lw, lane);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
@@ -271,7 +274,9 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     // input cache of two 512-byte chunks (CNX2: 1 KiB chunks): a round looks at most 256 + ALZ_QRUN bytes ahead, and 1 KiB less LDS
     // per wave is four more waves per CU for the 4 KiB-window formats
     constexpr u32 QCH = (FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
-    __shared__ __attribute__((aligned(16))) u8 lds[ALZ_EMIT_SCRATCH + 256 + QCACHE + LW + ALZ_WIN_SLACK];
+    constexpr bool FB = CNX ? false : (!PRS || PRSFB);
+    constexpr u32 SCR = FB ? ALZ_EMIT_SCRATCH : 128u, SLACK = FB ? ALZ_WIN_SLACK : 0u;     // (chunked byte phase: token table + ring mirror)
+    __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + SLACK];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -284,11 +289,10 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     const u32 hist = (FMT == ALZ_FMT_LZ4_BLOCK) ? uni(st.aux0) : 0u;      // LZ4 frames with linked blocks (see OutWin::preload)
     dst -= hist; cap += hist;
     u8* segmark = lds;
-    u32* stage = reinterpret_cast<u32*>(lds + ALZ_EMIT_SCRATCH);
-    u8* inc_lds = lds + ALZ_EMIT_SCRATCH + 256;
-    constexpr bool FB = CNX ? false : (!PRS || PRSFB);
+    u32* stage = reinterpret_cast<u32*>(lds + SCR);
+    u8* inc_lds = lds + SCR + 256;
     typedef OutWin<FB> OW;
-    OW out; out.init(dst, cap, lds + ALZ_EMIT_SCRATCH + 256 + QCACHE, LW, lane, ALZ_WIN_SLACK);
+    OW out; out.init(dst, cap, lds + SCR + 256 + QCACHE, LW, lane, SLACK);
     if (hist) out.preload(hist);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, QCH);
