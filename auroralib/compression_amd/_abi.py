@@ -1,7 +1,7 @@
 """ctypes mirror of include/auroralz.h (POD structs, enums).  No logic here."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # alz_format
 FMT_LZSS, FMT_LZ10, FMT_LZ11, FMT_YAZ0, FMT_YAY0, FMT_MIO0, FMT_PRS_BE, FMT_PRS_LE, FMT_LZ4_BLOCK, FMT_LZO, FMT_SNAPPY_RAW, FMT_LZ40, FMT_LZHUDSON, FMT_SMSR00, FMT_FASTLZ, FMT_CNX2, FMT_BLZ, FMT_CLZ0, FMT_CNS, FMT_LZ02, FMT_REFPACK, FMT_WFLZ, FMT_WFLZ_BE, FMT_LZSHREK, FMT_HIG = range(25)

@@ -42,6 +42,16 @@ class Context:
         check(self.lib.alz_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)))
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
+    def set_exact_kernels(self, on):
+        """Kernel family of this context: the exact one-token-at-a-time kernels instead of the lane-parallel ones."""
+        check(self.lib.alz_ctx_set_exact_kernels(self.h, 1 if on else 0))
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=10):
+        """Measured device-to-device copy bandwidth in GB/s (bytes read + written): the second roofline denominator."""
+        v = C.c_double()
+        check(self.lib.alz_measure_copy_bandwidth(self.h, nbytes, iters, C.byref(v)))
+        return v.value
+
     # ---- host-buffer decode (upload, decode on GPU, download)
     def decode_batch(self, streams, src, dst_bytes, lz=None):
         n = len(streams)
@@ -123,3 +133,27 @@ class Plan:
         if self.h:
             self.ctx.lib.alz_plan_destroy(self.ctx.h, self.h)
             self.h = None
+
+
+def partition_batch(streams, n_parts):
+    """alz_partition_batch: greedy LPT partition of a batch (host code, no GPU).  Returns (part_of np.uint32[n], cost np.uint64[n_parts])."""
+    lib = load()
+    n = len(streams)
+    part = np.zeros(max(n, 1), dtype=np.uint32)
+    cost = np.zeros(n_parts, dtype=np.uint64)
+    check(lib.alz_partition_batch(n, streams, n_parts, _vp(part), _vp(cost)))
+    return part[:n], cost
+
+
+def decode_batch_multi(ctxs, streams, src, dst_bytes, lz=None):
+    """alz_decode_batch_multi: ONE batch over several contexts (one per GPU; host threads inside the library)."""
+    lib = load()
+    n = len(streams)
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros(max(dst_bytes, 1), dtype=np.uint8)
+    res = (A.Result * n)()
+    part = np.zeros(max(n, 1), dtype=np.uint32)
+    hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    check(lib.alz_decode_batch_multi(hs, len(ctxs), C.byref(lz) if lz is not None else None, n, _vp(src), src.nbytes, streams,
+                                     _vp(dst), dst_bytes, res, _vp(part)))
+    return dst, res, part[:n]

@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "alz_internal.h"
@@ -30,7 +33,17 @@ struct alz_ctx {
     // fork/join resources for per-format kernels of a mixed batch (they are independent: run them concurrently)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
+    // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
+    // one piece overlaps the PCIe transfer of the other
+    void* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    // grow-only scratch of download_packed (item table + dense copy)
+    void* d_items = nullptr; size_t d_items_cap = 0;
+    void* d_pack = nullptr; size_t d_pack_cap = 0;
 };
+
+static const size_t kPinBytes = 32u << 20;
 
 struct alz_plan {
     uint32_t n = 0;
@@ -53,8 +66,11 @@ static alz_lz_properties effective_lz(const alz_lz_properties* p) {
 extern "C" {
 
 int alz_abi_version(void) { return ALZ_ABI_VERSION; }
-/* not in the public header: test hook that selects the exact serial kernels for every format (still the GPU path) */
-void alz_debug_force_serial(int on) { alz_set_force_serial(on); }
+int alz_ctx_set_exact_kernels(alz_ctx* c, int on) {
+    if (!c) return fail(ALZ_E_INVALID, "ctx is NULL");
+    c->exact = on != 0;
+    return ALZ_OK;
+}
 /* not in the public header: resident waves per CU of the production kernel of `format` (tuning aid) */
 int alz_debug_occupancy(int format) { return alz_kernel_occupancy(format); }
 const char* alz_last_error(void) { return g_err; }
@@ -89,6 +105,9 @@ void alz_destroy(alz_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->d_src) (void)hipFree(c->d_src);
     if (c->d_dst) (void)hipFree(c->d_dst);
+    if (c->d_items) (void)hipFree(c->d_items);
+    if (c->d_pack) (void)hipFree(c->d_pack);
+    for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -196,31 +215,41 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
 
 int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, void* hip_stream) {
     if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
+    HIP_TRY(hipSetDevice(c->device));                 // (a host thread may hold contexts of several devices)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     int nfmt = 0;
     for (int f = 0; f < ALZ_FMT_COUNT; f++) nfmt += p->fmt_cnt[f] ? 1 : 0;
     if (nfmt <= 1) {
         for (int f = 0; f < ALZ_FMT_COUNT; f++) {
             if (!p->fmt_cnt[f]) continue;
-            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz);
+            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
         return ALZ_OK;
     }
     // mixed batch: one kernel per format, forked onto side streams so that they share the GPU (each format alone may
-    // have far fewer streams than the device has wave slots), joined back into the caller's stream
+    // have far fewer streams than the device has wave slots), joined back into the caller's stream -- also when a launch
+    // fails half way (the side streams that already started are joined, then the error is reported)
     HIP_TRY(hipEventRecord(c->fork, s));
-    int k = 0; bool used[4] = {false, false, false, false};
-    for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+    int k = 0, rc = ALZ_OK; bool used[4] = {false, false, false, false};
+    for (int f = 0; f < ALZ_FMT_COUNT && rc == ALZ_OK; f++) {
         if (!p->fmt_cnt[f]) continue;
         hipStream_t a = c->aux[k & 3];
-        if (!used[k & 3]) { HIP_TRY(hipStreamWaitEvent(a, c->fork, 0)); used[k & 3] = true; }
-        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz);
-        if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
+        if (!used[k & 3]) {
+            hipError_t w = hipStreamWaitEvent(a, c->fork, 0);
+            if (w != hipSuccess) { rc = fail(ALZ_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(w)); break; }
+            used[k & 3] = true;
+        }
+        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact);
+        if (e != hipSuccess) rc = fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         k++;
     }
-    for (int i = 0; i < 4; i++) if (used[i]) { HIP_TRY(hipEventRecord(c->join[i], c->aux[i])); HIP_TRY(hipStreamWaitEvent(s, c->join[i], 0)); }
-    return ALZ_OK;
+    for (int i = 0; i < 4; i++) if (used[i]) {
+        hipError_t e = hipEventRecord(c->join[i], c->aux[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join[i], 0);
+        if (e != hipSuccess && rc == ALZ_OK) rc = fail(ALZ_E_HIP, "joining the side streams failed: %s", hipGetErrorString(e));
+    }
+    return rc;
 }
 
 int alz_plan_execute_timed(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, int iters, float* mean_ms) {
@@ -245,6 +274,62 @@ int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
 }
 
 // ---------------------------------------------------------------- host-buffer entry points
+// off + len <= total without wrapping (offsets are caller-supplied 64-bit values)
+static inline bool range_ok(uint64_t off, uint64_t len, uint64_t total) { return off <= total && len <= total - off; }
+
+static int ensure_pinned(alz_ctx* c) {
+    if (c->pin[0]) return ALZ_OK;
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+    }
+    c->pin_cap = kPinBytes;
+    return ALZ_OK;
+}
+// host (pageable) -> device through the two pinned buffers: the memcpy of piece k + 1 overlaps the DMA of piece k
+static int staged_h2d(alz_ctx* c, void* d_dst, const uint8_t* h_src, size_t bytes) {
+    if (!bytes) return ALZ_OK;
+    if (bytes < (1u << 20) || ensure_pinned(c) != ALZ_OK) {
+        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+        return ALZ_OK;
+    }
+    size_t done = 0; int k = 0; bool used[2] = {false, false};
+    while (done < bytes) {
+        const size_t n = bytes - done < c->pin_cap ? bytes - done : c->pin_cap;
+        if (used[k]) HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        memcpy(c->pin[k], h_src + done, n);
+        HIP_TRY(hipMemcpyAsync((uint8_t*)d_dst + done, c->pin[k], n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
+        used[k] = true; done += n; k ^= 1;
+    }
+    return ALZ_OK;
+}
+// device -> host (pageable), the same way: the DMA of piece k + 1 runs while piece k is copied out of its pinned buffer
+static int staged_d2h(alz_ctx* c, uint8_t* h_dst, const void* d_src, size_t bytes) {
+    if (!bytes) return ALZ_OK;
+    if (bytes < (1u << 20) || ensure_pinned(c) != ALZ_OK) {
+        HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ALZ_OK;
+    }
+    size_t issued = 0, copied = 0; int k = 0;
+    size_t len[2] = {0, 0};
+    {   const size_t n = bytes < c->pin_cap ? bytes : c->pin_cap;
+        HIP_TRY(hipMemcpyAsync(c->pin[0], d_src, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->pin_ev[0], c->stream)); len[0] = n; issued = n; }
+    while (copied < bytes) {
+        if (issued < bytes) {
+            const size_t n = bytes - issued < c->pin_cap ? bytes - issued : c->pin_cap;
+            HIP_TRY(hipMemcpyAsync(c->pin[k ^ 1], (const uint8_t*)d_src + issued, n, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->pin_ev[k ^ 1], c->stream)); len[k ^ 1] = n; issued += n;
+        }
+        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        memcpy(h_dst + copied, c->pin[k], len[k]);
+        copied += len[k]; k ^= 1;
+    }
+    return ALZ_OK;
+}
+
 static int grow(alz_ctx* c, void** buf, size_t* cap, size_t need) {
     if (*cap >= need) return ALZ_OK;
     if (*buf) { HIP_TRY(hipFree(*buf)); *buf = nullptr; *cap = 0; }
@@ -272,74 +357,101 @@ __global__ void __launch_bounds__(256) alz_pack_outputs_kernel(const uint8_t* __
     for (uint32_t k = head + (body << 4) + threadIdx.x; k < it.len; k += blockDim.x) d[k] = s[k];
 }
 
+// one produced range: `len` bytes at device offset `dev` (relative to ctx->d_dst) that belong at `host`
+struct out_seg { uint64_t dev; uint8_t* host; uint32_t len; };
+
 // false = could not pack (no device memory for the dense copy): the caller falls back to one copy per stream
-static bool download_packed(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
+static bool download_packed(alz_ctx* c, const std::vector<out_seg>& segs) {
     std::vector<pack_item> items;
+    items.reserve(segs.size());
     uint64_t cur = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
-        const uint64_t to = cur + (streams[i].dst_off & 15);
-        items.push_back(pack_item{streams[i].dst_off, to, results[i].dst_len, i});
-        cur = (to + results[i].dst_len + 15) & ~15ull;
+    for (const out_seg& g : segs) {
+        const uint64_t to = cur + (g.dev & 15);
+        items.push_back(pack_item{g.dev, to, g.len, 0});
+        cur = (to + g.len + 15) & ~15ull;
     }
-    void *d_items = nullptr, *d_pack = nullptr;
-    if (hipMalloc(&d_items, items.size() * sizeof(pack_item)) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMalloc(&d_pack, cur) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_items); return false; }
+    // (scratch of the context, grown on demand: no hipMalloc / hipFree per call)
+    if (grow(c, &c->d_items, &c->d_items_cap, items.size() * sizeof(pack_item)) != ALZ_OK) { (void)hipGetLastError(); return false; }
+    if (grow(c, &c->d_pack, &c->d_pack_cap, cur + 16) != ALZ_OK) { (void)hipGetLastError(); return false; }
     std::vector<uint8_t> bounce(cur);
-    hipError_t e = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(pack_item), hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(pack_item), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        alz_pack_outputs_kernel<<<dim3((uint32_t)items.size()), dim3(256), 0, c->stream>>>((const uint8_t*)c->d_dst, (uint8_t*)d_pack, (const pack_item*)d_items);
+        alz_pack_outputs_kernel<<<dim3((uint32_t)items.size()), dim3(256), 0, c->stream>>>((const uint8_t*)c->d_dst, (uint8_t*)c->d_pack, (const pack_item*)c->d_items);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(bounce.data(), d_pack, cur, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_items); (void)hipFree(d_pack);
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    for (const pack_item& it : items) memcpy(dst_base + it.from, bounce.data() + it.to, it.len);
+    if (staged_d2h(c, bounce.data(), c->d_pack, cur) != ALZ_OK) { (void)hipGetLastError(); return false; }
+    for (size_t i = 0; i < segs.size(); i++) memcpy(segs[i].host, bounce.data() + items[i].to, segs[i].len);
     return true;
 }
 
-// Download per-stream outputs: one bulk copy when the produced ranges are reasonably dense, else packed on the device first.
-static int download_outputs(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
-    uint64_t lo = ~0ull, hi = 0, sum = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
-        const uint64_t a = streams[i].dst_off, b = a + results[i].dst_len;
-        if (a < lo) lo = a; if (b > hi) hi = b; sum += results[i].dst_len;
+// Download the produced ranges: through the pinned staging buffers window by window when they are reasonably dense (the
+// caller's bytes between streams are never touched), else packed on the device first.
+static int download_segs(alz_ctx* c, std::vector<out_seg>& segs) {
+    if (segs.empty()) return ALZ_OK;
+    std::sort(segs.begin(), segs.end(), [](const out_seg& a, const out_seg& b) { return a.dev < b.dev; });
+    uint64_t lo = segs.front().dev, hi = 0, sum = 0;
+    for (const out_seg& g : segs) { if (g.dev + g.len > hi) hi = g.dev + g.len; sum += g.len; }
+    if (hi - lo > 2 * sum + (64ull << 20)) {
+        if (segs.size() >= 16 && download_packed(c, segs)) return ALZ_OK;
+        for (const out_seg& g : segs) HIP_TRY(hipMemcpyAsync(g.host, (const uint8_t*)c->d_dst + g.dev, g.len, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return ALZ_OK;
     }
-    if (sum == 0) return ALZ_OK;
-    if (hi - lo <= 2 * sum + (64ull << 20)) {
-        // the caller's bytes between streams are preserved: stage through a bounce buffer and copy each stream out
+    if (ensure_pinned(c) != ALZ_OK) {                        // no pinned memory: one bounce buffer
         std::vector<uint8_t> bounce(hi - lo);
         HIP_TRY(hipMemcpyAsync(bounce.data(), (const uint8_t*)c->d_dst + lo, hi - lo, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        for (uint32_t i = 0; i < n; i++) {
-            if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
-            memcpy(dst_base + streams[i].dst_off, bounce.data() + (streams[i].dst_off - lo), results[i].dst_len);
-        }
+        for (const out_seg& g : segs) memcpy(g.host, bounce.data() + (g.dev - lo), g.len);
         return ALZ_OK;
     }
-    if (n >= 16 && download_packed(c, n, streams, results, dst_base, only_ok)) return ALZ_OK;
+    // windows of the device range [lo, hi): the DMA of window w + 1 overlaps the copy-out of window w
+    const uint64_t W = c->pin_cap;
+    const uint64_t nwin = (hi - lo + W - 1) / W;
+    size_t first = 0;                                        // first segment that may still overlap the current window
+    auto issue = [&](uint64_t w, int k) -> hipError_t {
+        const uint64_t a = lo + w * W, n = hi - a < W ? hi - a : W;
+        hipError_t e = hipMemcpyAsync(c->pin[k], (const uint8_t*)c->d_dst + a, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k], c->stream);
+        return e;
+    };
+    HIP_TRY(issue(0, 0));
+    for (uint64_t w = 0; w < nwin; w++) {
+        const int k = (int)(w & 1);
+        if (w + 1 < nwin) HIP_TRY(issue(w + 1, k ^ 1));
+        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        const uint64_t a = lo + w * W, b = a + W;
+        while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
+        for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
+            const uint64_t s0 = segs[i].dev > a ? segs[i].dev : a, s1 = segs[i].dev + segs[i].len < b ? segs[i].dev + segs[i].len : b;
+            if (s1 > s0) memcpy(segs[i].host + (s0 - segs[i].dev), (const uint8_t*)c->pin[k] + (s0 - a), s1 - s0);
+        }
+    }
+    return ALZ_OK;
+}
+
+static int download_outputs(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
+    std::vector<out_seg> segs;
+    segs.reserve(n);
     for (uint32_t i = 0; i < n; i++) {
         if (!results[i].dst_len || (only_ok && results[i].status != ALZ_ST_OK)) continue;
-        HIP_TRY(hipMemcpyAsync(dst_base + streams[i].dst_off, (const uint8_t*)c->d_dst + streams[i].dst_off, results[i].dst_len, hipMemcpyDeviceToHost, c->stream));
+        segs.push_back(out_seg{streams[i].dst_off, dst_base + streams[i].dst_off, results[i].dst_len});
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return ALZ_OK;
+    return download_segs(c, segs);
 }
 
 int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const uint8_t* src_base, size_t src_bytes,
                      const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results) {
     if (!c || (n && (!streams || !results))) return fail(ALZ_E_INVALID, "alz_decode_batch: bad argument");
     for (uint32_t i = 0; i < n; i++) {
-        if (streams[i].src_off + streams[i].src_len > src_bytes) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
-        if (streams[i].dst_off + streams[i].dst_cap > dst_bytes) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+        if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
+        if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return rc;
     if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return rc;
-    if (src_bytes) HIP_TRY(hipMemcpyAsync(c->d_src, src_base, src_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = staged_h2d(c, c->d_src, src_base, src_bytes))) return rc;
     for (uint32_t i = 0; i < n; i++)   // LZ4 blocks that continue a frame's window: their history has to be in HBM too
         if (streams[i].format == ALZ_FMT_LZ4_BLOCK && streams[i].aux0 && streams[i].aux0 <= streams[i].dst_off)
             HIP_TRY(hipMemcpyAsync((uint8_t*)c->d_dst + streams[i].dst_off - streams[i].aux0, dst_base + streams[i].dst_off - streams[i].aux0,
@@ -381,8 +493,8 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     uint64_t total = 0; uint32_t max_len = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
-        if (streams[i].src_off + streams[i].src_len > src_bytes) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
-        if (streams[i].dst_off + streams[i].dst_cap > dst_bytes) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+        if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
+        if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
         if (streams[i].src_len > 0x7FFFFF00u) return fail(ALZ_E_UNSUPPORTED, "stream %u: inputs above 2 GiB are not supported", i);
         cnt[streams[i].format]++;
         pos_off[i] = total; total += ((uint64_t)streams[i].src_len + 16 + 63) & ~63ull;   // 64-aligned: one start-mask word per 64 positions
@@ -429,7 +541,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
     { uint32_t off = 0; for (int f = 0; f < ALZ_FMT_COUNT; f++) { foff[f] = off; off += cnt[f]; } }
     for (uint32_t i = 0; i < n; i++) { uint32_t f = streams[i].format; index[foff[f] + fill[f]++] = i; }
-    if (src_bytes) HIP_TRY(hipMemcpyAsync(c->d_src, src_base, src_bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = staged_h2d(c, c->d_src, src_base, src_bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(d_streams, streams, (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_pos, pos_off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -453,6 +565,176 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
     if ((rc = download_outputs(c, n, streams, results, dst_base, true))) return rc;
+    return ALZ_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU: one batch over several contexts
+// Decode cost per output byte of a format relative to the fastest one (x64; from the measured per-format rates)
+static uint32_t format_weight(uint32_t fmt) {
+    switch (fmt) {
+    case ALZ_FMT_YAY0: return 54;
+    case ALZ_FMT_YAZ0: case ALZ_FMT_LZ02: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: return 64;
+    case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: return 76;
+    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_CLZ0: case ALZ_FMT_CNS: case ALZ_FMT_LZHUDSON: case ALZ_FMT_LZSHREK: return 92;
+    case ALZ_FMT_CNX2: case ALZ_FMT_HIG: return 110;
+    case ALZ_FMT_BLZ: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_FASTLZ: case ALZ_FMT_REFPACK: return 140;
+    default: return 190;                                     // PRS, LZO, Snappy
+    }
+}
+
+int alz_partition_batch(uint32_t n, const alz_stream* streams, uint32_t n_parts, uint32_t* part_of, uint64_t* part_cost) {
+    if ((n && (!streams || !part_of)) || n_parts == 0) return fail(ALZ_E_INVALID, "alz_partition_batch: bad argument");
+    std::vector<uint64_t> cost(n), load(n_parts, 0);
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t f = streams[i].format < ALZ_FMT_COUNT ? streams[i].format : 0;
+        const uint64_t out = streams[i].decom_len && streams[i].decom_len < streams[i].dst_cap ? streams[i].decom_len : streams[i].dst_cap;
+        cost[i] = (out + 4096) * format_weight(f);           // (+ a fixed share: a wave per stream, header / tail handling)
+        order[i] = i;
+    }
+    // greedy LPT: longest job first onto the least loaded part (equal jobs, as in the metric's batches, are dealt round-robin)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t best = 0;
+        for (uint32_t q = 1; q < n_parts; q++) if (load[q] < load[best]) best = q;
+        part_of[order[k]] = best; load[best] += cost[order[k]];
+    }
+    if (part_cost) for (uint32_t q = 0; q < n_parts; q++) part_cost[q] = load[q];
+    return ALZ_OK;
+}
+
+struct in_seg { uint64_t dev; const uint8_t* host; uint32_t len; };
+// packed device range <- scattered host ranges (segments sorted by device offset), window by window through the pinned buffers
+static int upload_segs(alz_ctx* c, void* d_base, const std::vector<in_seg>& segs, uint64_t total) {
+    if (segs.empty() || total == 0) return ALZ_OK;
+    if (ensure_pinned(c) != ALZ_OK) {
+        for (const in_seg& g : segs) if (g.len) HIP_TRY(hipMemcpyAsync((uint8_t*)d_base + g.dev, g.host, g.len, hipMemcpyHostToDevice, c->stream));
+        return ALZ_OK;
+    }
+    const uint64_t W = c->pin_cap;
+    size_t first = 0; bool used[2] = {false, false};
+    for (uint64_t a = 0, w = 0; a < total; a += W, w++) {
+        const int k = (int)(w & 1);
+        const uint64_t b = a + W < total ? a + W : total;
+        if (used[k]) HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
+        for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
+            const uint64_t s0 = segs[i].dev > a ? segs[i].dev : a, s1 = segs[i].dev + segs[i].len < b ? segs[i].dev + segs[i].len : b;
+            if (s1 > s0) memcpy((uint8_t*)c->pin[k] + (s0 - a), segs[i].host + (s0 - segs[i].dev), s1 - s0);
+        }
+        HIP_TRY(hipMemcpyAsync((uint8_t*)d_base + a, c->pin[k], b - a, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
+        used[k] = true;
+    }
+    return ALZ_OK;
+}
+
+// One context's share of a batch: its streams are packed into device buffers of their own (16-byte aligned inputs, 256-byte
+// aligned outputs), so every device receives and returns only the bytes of its share.
+static int decode_share(alz_ctx* c, const alz_lz_properties* props, const std::vector<uint32_t>& idx, const uint8_t* src_base,
+                        const alz_stream* streams, uint8_t* dst_base, alz_result* results) {
+    const uint32_t m = (uint32_t)idx.size();
+    if (m == 0) return ALZ_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<alz_stream> ds(m);
+    std::vector<in_seg> ins; ins.reserve(m);
+    uint64_t so = 0, dof = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        const alz_stream& st = streams[idx[j]];
+        const uint64_t hist = (st.format == ALZ_FMT_LZ4_BLOCK) ? st.aux0 : 0;
+        ds[j] = st;
+        ds[j].src_off = so; ins.push_back(in_seg{so, src_base + st.src_off, st.src_len});
+        so += ((uint64_t)st.src_len + 15) & ~15ull;
+        dof = (dof + hist + 255) & ~255ull;
+        ds[j].dst_off = dof;
+        dof = (dof + st.dst_cap + 255) & ~255ull;
+    }
+    int rc;
+    if ((rc = grow(c, &c->d_src, &c->d_src_cap, so + 64))) return rc;
+    if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dof + 64))) return rc;
+    if ((rc = upload_segs(c, c->d_src, ins, so))) return rc;
+    for (uint32_t j = 0; j < m; j++) {                       // LZ4 blocks that continue a frame's window: their history travels too
+        const alz_stream& st = streams[idx[j]];
+        if (st.format == ALZ_FMT_LZ4_BLOCK && st.aux0)
+            HIP_TRY(hipMemcpyAsync((uint8_t*)c->d_dst + ds[j].dst_off - st.aux0, dst_base + st.dst_off - st.aux0, st.aux0, hipMemcpyHostToDevice, c->stream));
+    }
+    alz_plan* p = nullptr;
+    if ((rc = alz_plan_create(c, props, m, ds.data(), &p))) return rc;
+    std::vector<alz_result> rs(m);
+    rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);
+    if (!rc) rc = alz_plan_results(c, p, rs.data());
+    alz_plan_destroy(c, p);
+    if (rc) return rc;
+    std::vector<out_seg> outs; outs.reserve(m);
+    for (uint32_t j = 0; j < m; j++) {
+        results[idx[j]] = rs[j];
+        if (rs[j].dst_len) outs.push_back(out_seg{ds[j].dst_off, dst_base + streams[idx[j]].dst_off, rs[j].dst_len});
+    }
+    return download_segs(c, outs);
+}
+
+int alz_decode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_properties* props, uint32_t n,
+                           const uint8_t* src_base, size_t src_bytes, const alz_stream* streams,
+                           uint8_t* dst_base, size_t dst_bytes, alz_result* results, uint32_t* part_of_out) {
+    if (!ctxs || n_ctx == 0 || n_ctx > 64 || (n && (!streams || !results))) return fail(ALZ_E_INVALID, "alz_decode_batch_multi: bad argument");
+    for (uint32_t q = 0; q < n_ctx; q++) {
+        if (!ctxs[q]) return fail(ALZ_E_INVALID, "alz_decode_batch_multi: context %u is NULL", q);
+        for (uint32_t r = 0; r < q; r++) if (ctxs[r] == ctxs[q]) return fail(ALZ_E_INVALID, "alz_decode_batch_multi: context %u is listed twice (a context is single-threaded)", q);
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
+        if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
+        if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+        if (streams[i].format == ALZ_FMT_LZ4_BLOCK && streams[i].aux0 > streams[i].dst_off) return fail(ALZ_E_INVALID, "stream %u: history %u exceeds dst_off", i, streams[i].aux0);
+    }
+    std::vector<uint32_t> part(n ? n : 1);
+    int rc = alz_partition_batch(n, streams, n_ctx, part.data(), nullptr);
+    if (rc) return rc;
+    if (part_of_out) for (uint32_t i = 0; i < n; i++) part_of_out[i] = part[i];
+    std::vector<std::vector<uint32_t>> idx(n_ctx);
+    for (uint32_t i = 0; i < n; i++) idx[part[i]].push_back(i);        // (ascending inside a share: source order)
+    // one host thread per context (a context is single-threaded; distinct contexts run concurrently), no collective: the
+    // shares are independent (a fresh LzWindows per stream, LZ10.cs:86)
+    std::vector<int> rcs(n_ctx, ALZ_OK);
+    std::vector<std::string> errs(n_ctx);
+    auto work = [&](uint32_t q) {
+        rcs[q] = decode_share(ctxs[q], props, idx[q], src_base, streams, dst_base, results);
+        if (rcs[q]) errs[q] = g_err;
+    };
+    if (n_ctx == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t q = 1; q < n_ctx; q++) th.emplace_back(work, q);
+        work(0);
+        for (std::thread& t : th) t.join();
+    }
+    for (uint32_t q = 0; q < n_ctx; q++) if (rcs[q]) return fail(rcs[q], "context %u (device %d): %s", q, ctxs[q]->device, errs[q].c_str());
+    return ALZ_OK;
+}
+
+// ---------------------------------------------------------------- measurement helper: device copy bandwidth
+__global__ void __launch_bounds__(256) alz_copy_kernel(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+int alz_measure_copy_bandwidth(alz_ctx* c, size_t bytes, int iters, double* gb_per_s) {
+    if (!c || !gb_per_s || iters < 1 || bytes < (1u << 20)) return fail(ALZ_E_INVALID, "alz_measure_copy_bandwidth: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc(&a, bytes));
+    hipError_t e = hipMalloc(&b, bytes);
+    if (e != hipSuccess) { (void)hipFree(a); return fail(ALZ_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    const size_t n16 = bytes / 16;
+    (void)hipMemsetAsync(a, 1, bytes, c->stream);
+    alz_copy_kernel<<<dim3(256 * 16), dim3(256), 0, c->stream>>>((const uint4*)a, (uint4*)b, n16);      // warm-up
+    (void)hipEventRecord(c->ev0, c->stream);
+    for (int i = 0; i < iters; i++) alz_copy_kernel<<<dim3(256 * 16), dim3(256), 0, c->stream>>>((const uint4*)a, (uint4*)b, n16);
+    (void)hipEventRecord(c->ev1, c->stream);
+    e = hipEventSynchronize(c->ev1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (e != hipSuccess) return fail(ALZ_E_HIP, "copy kernel failed: %s", hipGetErrorString(e));
+    *gb_per_s = 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9;   // bytes read + bytes written
     return ALZ_OK;
 }
 

@@ -6,12 +6,9 @@
 #include "auroralz.h"
 
 // enqueue the decode kernel of one format over `count` streams (index list selects them; NULL = 0..count-1)
+// `exact`: the exact one-token-at-a-time kernels (alz_ctx_set_exact_kernels) instead of the lane-parallel ones
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams,
-                             const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz);
-
-// debug/test switch: route every format through the exact serial kernels (still GPU; used by the parity tests to
-// cover both kernel families)
-void alz_set_force_serial(int on);
+                             const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact);
 int alz_kernel_occupancy(int fmt);   // resident waves per CU of the production decode kernel (tuning aid)
 
 // ---- encoder (alz_encode.hip)

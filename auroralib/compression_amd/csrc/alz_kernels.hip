@@ -534,15 +534,12 @@ int alz_kernel_occupancy(int fmt) {
     return e == hipSuccess ? n : -1;
 }
 
-static bool g_force_serial = false;
-void alz_set_force_serial(int on) { g_force_serial = on != 0; }
-
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
-                             u32 count, alz_result* results, const alz_lz_properties* lzp) {
+                             u32 count, alz_result* results, const alz_lz_properties* lzp, bool exact) {
     if (count == 0) return hipSuccess;
     const u8* s = (const u8*)src; u8* d = (u8*)dst;
     alz_lz_properties lz = *lzp;
-    if (!g_force_serial) {
+    if (!exact) {
         switch (fmt) {   // lane-parallel kernels
         case ALZ_FMT_LZSS: {
             u32 W = 1u << lz.window_bits;

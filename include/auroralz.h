@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALZ_ABI_VERSION 1
+#define ALZ_ABI_VERSION 2
 
 /* ---- formats: the headerless bodies on the hot path ---- */
 typedef enum alz_format {
@@ -173,6 +173,10 @@ int         alz_create(int device, alz_ctx** out);
 void        alz_destroy(alz_ctx* ctx);
 const char* alz_last_error(void);          /* thread-local text of the last failure */
 int         alz_device_info(alz_ctx* ctx, char* name, size_t name_cap, int* cu_count, uint64_t* hbm_bytes);
+/* Kernel family of a context.  0 (default): the lane-parallel production kernels.  1: the exact kernels -- one token at a
+ * time, the statement-for-statement GPU restatement of the managed bodies; every lane-parallel kernel hands its stream
+ * tails and error paths to them.  A verification mode (the parity tests run every case through both families). */
+int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
 
 /* ----------------------------------------------- decode: host buffers in/out
  * Replaces the loop a managed caller writes around the static
@@ -186,6 +190,21 @@ int alz_decode_batch(alz_ctx* ctx, const alz_lz_properties* props, uint32_t n,
                      const alz_stream* streams,
                      uint8_t* dst_base, size_t dst_bytes,
                      alz_result* results);
+
+/* The same call over several contexts = several GPUs of one node: the batch is partitioned by
+ * alz_partition_batch, each share is packed, uploaded, decoded and downloaded by its own host thread on its own context
+ * (one context per device; ctxs[] must not repeat a context), no collective -- streams are independent (a fresh LzWindows
+ * per Decompress call, src/AuroraLib.Compression.Nintendo/Nintendo/LZ10.cs:86).  part_of_out (may be NULL) receives the
+ * index into ctxs[] that decoded stream i.  Results are identical to alz_decode_batch on any one of the contexts. */
+int alz_decode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_properties* props, uint32_t n,
+                           const uint8_t* src_base, size_t src_bytes,
+                           const alz_stream* streams,
+                           uint8_t* dst_base, size_t dst_bytes,
+                           alz_result* results, uint32_t* part_of_out);
+/* Greedy LPT partition of a batch over n_parts devices, balanced by decompressed bytes x a per-format cost (the host-side
+ * partitioning of SURVEY.md 8e).  part_of[i] = part of stream i; part_cost[n_parts] (may be NULL) = the load of each part.
+ * Pure host code: one process per GPU (bench.py --scaling strong) uses it to pick its share of ONE batch. */
+int alz_partition_batch(uint32_t n, const alz_stream* streams, uint32_t n_parts, uint32_t* part_of, uint64_t* part_cost);
 
 /* Single stream: backs ICompressionDecoder.Decompress(Stream, Stream) of one format class
  * (src/AuroraLib.Compression/Interfaces/ICompressionDecoder.cs:24) after the managed shim parsed the header. */
@@ -232,6 +251,9 @@ int alz_memcpy_h2d(alz_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int alz_memcpy_d2h(alz_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int alz_memset_d(alz_ctx* ctx, void* d_dst, int value, size_t bytes);
 int alz_synchronize(alz_ctx* ctx);
+/* Measurement helper ("achievable copy bandwidth as a second denominator"): a 16 B/lane device-to-device copy
+ * kernel over `bytes`, `iters` times; *gb_per_s = (bytes read + bytes written) / time. */
+int alz_measure_copy_bandwidth(alz_ctx* ctx, size_t bytes, int iters, double* gb_per_s);
 
 /* ------------------------------------------------ container layer (host side)
  * The managed part of the reference's format classes restated above the

@@ -22,11 +22,11 @@ def compare_batch(streams, src, dst_bytes, lz=None, what=""):
     o_dst, o_res = O.decode_batch(streams, src, dst_bytes, lz=lz, nthreads=8)
     # both GPU kernel families: the lane-parallel kernels (default dispatch) and the exact serial kernels
     for serial in (1, 0):
-        ctx().lib.alz_debug_force_serial(serial)
+        ctx().set_exact_kernels(serial)
         try:
             g_dst, g_res = ctx().decode_batch(streams, src, dst_bytes, lz=lz)
         finally:
-            ctx().lib.alz_debug_force_serial(0)
+            ctx().set_exact_kernels(0)
         gr, g_dst = _check(streams, g_dst, g_res, o_dst, o_res, what + (" [serial kernels]" if serial else " [fast kernels]"))
     return gr, g_dst
 

@@ -112,6 +112,12 @@ def test_decode_kernels_use_no_scratch(tmp_path):
         notes = subprocess.run([llvm + "/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
         for name, priv in re.findall(r"\.name:\s+(\S+)\n\s+\.private_segment_fixed_size:\s+(\d+)", notes):
             seen[name] = int(priv)
+        for name, spills in re.findall(r"\.name:\s+(\S+)\n(?:\s+\.\w+:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", notes):
+            assert int(spills) == 0 or "alz_decode_" not in name, (name, spills)
     dec = {k: v for k, v in seen.items() if "alz_decode_" in k}
     assert len(dec) >= 25, sorted(seen)
-    assert all(v == 0 for v in dec.values()), {k: v for k, v in dec.items() if v}
+    # The queue kernels of the 64 KiB formats call the chunked byte phase out of line from the exact parsers' token sites
+    # (queue_emit_call, one copy per kernel: inlining it at every site made 100 KB kernels); that callee saves ONE
+    # callee-saved VGPR of the calling convention on its frame -- 8 bytes, outside every loop.  Anything beyond that is a local in
+    # scratch memory.
+    assert all(v == 0 or (v <= 8 and "alz_decode_queue_kernel" in k) for k, v in dec.items()), {k: v for k, v in dec.items() if v}
