@@ -63,6 +63,7 @@ def load():
     lib.alz_decode_batch_multi.argtypes = [C.POINTER(vp), u32, vp, u32, vp, sz, vp, vp, sz, vp, vp]
     lib.alz_partition_batch.argtypes = [u32, vp, u32, vp, vp]
     lib.alz_measure_copy_bandwidth.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]
+    lib.alz_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if lib.alz_abi_version() != A.ABI_VERSION:
         raise ImportError("libauroralz.so ABI %d != python mirror %d" % (lib.alz_abi_version(), A.ABI_VERSION))
     _lib = lib

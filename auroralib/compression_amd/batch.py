@@ -52,6 +52,11 @@ class Context:
         check(self.lib.alz_measure_copy_bandwidth(self.h, nbytes, iters, C.byref(v)))
         return v.value
 
+    def last_kernel_ms(self):
+        v = C.c_float()
+        check(self.lib.alz_last_kernel_ms(self.h, C.byref(v)))
+        return v.value
+
     # ---- host-buffer decode (upload, decode on GPU, download)
     def decode_batch(self, streams, src, dst_bytes, lz=None):
         n = len(streams)

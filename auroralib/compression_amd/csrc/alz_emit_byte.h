@@ -169,7 +169,10 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
 // ---------------------------------------------------------------------------------------------------------------
 // The back end a configuration uses: the chunked phase where sources come back from HBM (the 64 KiB formats: one 20-byte
 // read per chunk instead of one byte per lane), the byte phase where the whole window lives in LDS.
-template <class CFG> struct EmitUsesChunks { static constexpr bool value = CFG::FALLBACK; };
+#ifndef ALZ_CHUNKS_ALL
+#define ALZ_CHUNKS_ALL 0     /* experiment: 1 = the chunked phase for every configuration */
+#endif
+template <class CFG> struct EmitUsesChunks { static constexpr bool value = CFG::FALLBACK || ALZ_CHUNKS_ALL; };
 
 template <class OW, class CFG>
 __device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch, int lane, u32& last_tend, u32 W, EmitState& e) {

@@ -33,6 +33,7 @@ struct alz_ctx {
     // fork/join resources for per-format kernels of a mixed batch (they are independent: run them concurrently)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_kernel_ms = 0.f;                // device time of the kernels of the last timed / encode call (HIP events on the launch stream)
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
     // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
     // one piece overlaps the PCIe transfer of the other
@@ -262,6 +263,7 @@ int alz_plan_execute_timed(alz_ctx* c, alz_plan* p, const void* d_src_base, void
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *mean_ms = ms / (float)iters;
+    c->last_kernel_ms = *mean_ms;
     return ALZ_OK;
 }
 
@@ -548,6 +550,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
     HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
     HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)total / 8 + 64, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (int f = 0; f < ALZ_FMT_COUNT; f++) {
         const void* g = geom.data() + f * alz_encode_geom_size();
         for (uint32_t done = 0; done < cnt[f]; done += CH) {
@@ -559,10 +562,12 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
     }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipMemcpyAsync(results, d_results, (size_t)n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
     std::vector<alz_encode_aux> haux(n);
     HIP_TRY(hipMemcpyAsync(haux.data(), d_aux, (size_t)n * sizeof(alz_encode_aux), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_kernel_ms = ms; }   // table resets + the encode kernels
     for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
     if ((rc = download_outputs(c, n, streams, results, dst_base, true))) return rc;
     return ALZ_OK;
@@ -713,8 +718,21 @@ int alz_decode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_pr
 }
 
 // ---------------------------------------------------------------- measurement helper: device copy bandwidth
-__global__ void __launch_bounds__(256) alz_copy_kernel(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+typedef unsigned int alz_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) alz_copy_kernel(const alz_u4* __restrict__ a, alz_u4* __restrict__ b, size_t n16) {
+    // four 16-byte loads in flight per lane, then four stores (a block moves 16 KiB per trip)
+    const size_t stride = (size_t)gridDim.x * 1024;
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 768 < n16; i += stride) {
+        const alz_u4 v0 = __builtin_nontemporal_load(a + i), v1 = __builtin_nontemporal_load(a + i + 256), v2 = __builtin_nontemporal_load(a + i + 512), v3 = __builtin_nontemporal_load(a + i + 768);
+        __builtin_nontemporal_store(v0, b + i); __builtin_nontemporal_store(v1, b + i + 256); __builtin_nontemporal_store(v2, b + i + 512); __builtin_nontemporal_store(v3, b + i + 768);
+    }
+    for (; i < n16; i += 256) b[i] = a[i];
+}
+int alz_last_kernel_ms(alz_ctx* c, float* ms) {
+    if (!c || !ms) return fail(ALZ_E_INVALID, "bad argument");
+    *ms = c->last_kernel_ms;
+    return ALZ_OK;
 }
 int alz_measure_copy_bandwidth(alz_ctx* c, size_t bytes, int iters, double* gb_per_s) {
     if (!c || !gb_per_s || iters < 1 || bytes < (1u << 20)) return fail(ALZ_E_INVALID, "alz_measure_copy_bandwidth: bad argument");
@@ -725,9 +743,9 @@ int alz_measure_copy_bandwidth(alz_ctx* c, size_t bytes, int iters, double* gb_p
     if (e != hipSuccess) { (void)hipFree(a); return fail(ALZ_E_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
     const size_t n16 = bytes / 16;
     (void)hipMemsetAsync(a, 1, bytes, c->stream);
-    alz_copy_kernel<<<dim3(256 * 16), dim3(256), 0, c->stream>>>((const uint4*)a, (uint4*)b, n16);      // warm-up
+    alz_copy_kernel<<<dim3(256 * 8), dim3(256), 0, c->stream>>>((const alz_u4*)a, (alz_u4*)b, n16);      // warm-up
     (void)hipEventRecord(c->ev0, c->stream);
-    for (int i = 0; i < iters; i++) alz_copy_kernel<<<dim3(256 * 16), dim3(256), 0, c->stream>>>((const uint4*)a, (uint4*)b, n16);
+    for (int i = 0; i < iters; i++) alz_copy_kernel<<<dim3(256 * 8), dim3(256), 0, c->stream>>>((const alz_u4*)a, (alz_u4*)b, n16);
     (void)hipEventRecord(c->ev1, c->stream);
     e = hipEventSynchronize(c->ev1);
     float ms = 0;

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #endif
     constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][128 + NC * CACHE + LWMAX];
+    constexpr u32 FSCR = ALZ_CHUNKS_ALL ? ALZ_EMIT_SCRATCH : 128u, FSLACK = ALZ_CHUNKS_ALL ? ALZ_WIN_SLACK : 0u;   // (experiment build: chunked byte phase)
+    __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][FSCR + NC * CACHE + LWMAX + FSLACK];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
     u32 bid = blockIdx.x * ALZ_WPB + wid;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     u8* dst = dst_base + st.dst_off;
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
     u8* segmark = lds;
-    u8* inc_lds = lds + 128;
-    OutWin<false> out; out.init(dst, cap, lds + 128 + NC * CACHE, lw, lane);
+    u8* inc_lds = lds + FSCR;
+    OutWin<false> out; out.init(dst, cap, lds + FSCR + NC * CACHE, ALZ_CHUNKS_ALL ? (u32)LWMAX : lw, lane, FSLACK);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restri
     // per wave is four more waves per CU for the 4 KiB-window formats
     constexpr u32 QCH = (FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
     constexpr bool FB = CNX ? false : (!PRS || PRSFB);
-    constexpr u32 SCR = FB ? ALZ_EMIT_SCRATCH : 128u, SLACK = FB ? ALZ_WIN_SLACK : 0u;     // (chunked byte phase: token table + ring mirror)
+    constexpr u32 SCR = (FB || ALZ_CHUNKS_ALL) ? ALZ_EMIT_SCRATCH : 128u, SLACK = (FB || ALZ_CHUNKS_ALL) ? ALZ_WIN_SLACK : 0u;     // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + SLACK];
     u32 bid = blockIdx.x;
     if (bid >= count) return;

@@ -631,6 +631,7 @@ typedef struct {
     const uint32_t* formats; uint32_t format; const alz_lz_properties* props; uint64_t base_seed; uint32_t n;
     const uint32_t* targets; uint32_t target; uint8_t* dst; const uint64_t* offs; uint32_t* sizes; alz_encode_aux* aux;
     int tid, nt;
+    const uint64_t* seeds;      /* optional: seed of stream i (else base_seed + i) */
 } sjob_t;
 
 static void* synth_worker(void* arg) {
@@ -639,15 +640,16 @@ static void* synth_worker(void* arg) {
         uint32_t fmt = j->formats ? j->formats[i] : j->format;
         uint32_t tgt = j->targets ? j->targets[i] : j->target;
         alz_encode_aux a;
-        if (!j->dst) j->sizes[i] = (uint32_t)alz_synth_stream(fmt, j->props, j->base_seed + i, tgt, NULL, 0, &a);
-        else (void)alz_synth_stream(fmt, j->props, j->base_seed + i, tgt, j->dst + j->offs[i], j->sizes[i], &a);
+        const uint64_t seed = j->seeds ? j->seeds[i] : j->base_seed + i;
+        if (!j->dst) j->sizes[i] = (uint32_t)alz_synth_stream(fmt, j->props, seed, tgt, NULL, 0, &a);
+        else (void)alz_synth_stream(fmt, j->props, seed, tgt, j->dst + j->offs[i], j->sizes[i], &a);
         if (j->aux) j->aux[i] = a;
     }
     return NULL;
 }
 
 /* Two-pass batch: call with dst == NULL to get sizes[], lay the streams out, call again with dst/offs. */
-int alz_synth_batch(const uint32_t* formats, uint32_t format, const alz_lz_properties* props, uint64_t base_seed, uint32_t n,
+int alz_synth_batch_seeds(const uint32_t* formats, uint32_t format, const alz_lz_properties* props, uint64_t base_seed, const uint64_t* seeds, uint32_t n,
                     const uint32_t* targets, uint32_t target, uint8_t* dst, const uint64_t* offs, uint32_t* sizes,
                     alz_encode_aux* aux, int nthreads) {
     if (nthreads < 1) nthreads = 1;
@@ -655,10 +657,16 @@ int alz_synth_batch(const uint32_t* formats, uint32_t format, const alz_lz_prope
     { const char* e = getenv("ALZ_SYNTH_MAXDIST"); g_seq_maxdist = e ? (uint32_t)strtoul(e, NULL, 0) : 0; }
     pthread_t th[256]; sjob_t jobs[256];
     for (int t = 0; t < nthreads; t++) {
-        sjob_t j = { formats, format, props, base_seed, n, targets, target, dst, offs, sizes, aux, t, nthreads };
+        sjob_t j = { formats, format, props, base_seed, n, targets, target, dst, offs, sizes, aux, t, nthreads, seeds };
         jobs[t] = j;
         if (nthreads == 1) synth_worker(&jobs[0]); else pthread_create(&th[t], NULL, synth_worker, &jobs[t]);
     }
     if (nthreads > 1) for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
     return 0;
+}
+
+int alz_synth_batch(const uint32_t* formats, uint32_t format, const alz_lz_properties* props, uint64_t base_seed, uint32_t n,
+                    const uint32_t* targets, uint32_t target, uint8_t* dst, const uint64_t* offs, uint32_t* sizes,
+                    alz_encode_aux* aux, int nthreads) {
+    return alz_synth_batch_seeds(formats, format, props, base_seed, NULL, n, targets, target, dst, offs, sizes, aux, nthreads);
 }

@@ -30,8 +30,8 @@ def _load():
         _lib = C.CDLL(_SO)
         _lib.alz_synth_stream.restype = C.c_int64
         _lib.alz_synth_stream.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
-        _lib.alz_synth_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.alz_synth_batch_seeds.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return _lib
 
 
@@ -56,24 +56,27 @@ class Batch:
         return int(np.asarray(self.targets, dtype=np.uint64).sum())
 
 
-def make_batch(formats, n, target, base_seed, lz=None, nthreads=None, dst_align=256, dst_slack=0):
+def make_batch(formats, n, target, base_seed, lz=None, nthreads=None, dst_align=256, dst_slack=0, seeds=None):
     """Generate n streams decoding to `target` bytes each (int or array).  `formats` is one alz_format or an
-    array of n.  Streams are packed 16-byte aligned in `src`; outputs are laid out `dst_align`-aligned."""
+    array of n.  Streams are packed 16-byte aligned in `src`; outputs are laid out `dst_align`-aligned.
+    Stream i is seeded with base_seed + i, or with seeds[i] (a rank's share of ONE batch: the global stream indices)."""
     lib = _load()
-    nthreads = nthreads or os.cpu_count() or 1
+    nthreads = nthreads or len(os.sched_getaffinity(0)) or 1
+    sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+    sdp = None if sd is None else sd.ctypes.data_as(C.c_void_p)
     fm = np.full(n, formats, dtype=np.uint32) if np.isscalar(formats) else np.ascontiguousarray(formats, dtype=np.uint32)
     tg = np.full(n, target, dtype=np.uint32) if np.isscalar(target) else np.ascontiguousarray(target, dtype=np.uint32)
     sizes = np.zeros(n, dtype=np.uint32)
     aux = (A.EncodeAux * n)()
     lzp = C.byref(lz) if lz is not None else None
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib.alz_synth_batch(vp(fm), 0, lzp, base_seed, n, vp(tg), 0, None, None, vp(sizes), aux, nthreads)
+    lib.alz_synth_batch_seeds(vp(fm), 0, lzp, base_seed, sdp, n, vp(tg), 0, None, None, vp(sizes), aux, nthreads)
     offs = np.zeros(n, dtype=np.uint64)
     al = (sizes.astype(np.uint64) + 15) & ~np.uint64(15)
     offs[1:] = np.cumsum(al)[:-1]
     total = int(offs[-1] + al[-1]) if n else 0
     src = np.zeros(total + 64, dtype=np.uint8)
-    lib.alz_synth_batch(vp(fm), 0, lzp, base_seed, n, vp(tg), 0, vp(src), vp(offs), vp(sizes), aux, nthreads)
+    lib.alz_synth_batch_seeds(vp(fm), 0, lzp, base_seed, sdp, n, vp(tg), 0, vp(src), vp(offs), vp(sizes), aux, nthreads)
     caps = tg.astype(np.uint64) + np.uint64(dst_slack)
     dal = (caps + np.uint64(dst_align - 1)) & ~np.uint64(dst_align - 1)
     doffs = np.zeros(n, dtype=np.uint64)

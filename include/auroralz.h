@@ -254,6 +254,9 @@ int alz_synchronize(alz_ctx* ctx);
 /* Measurement helper ("achievable copy bandwidth as a second denominator"): a 16 B/lane device-to-device copy
  * kernel over `bytes`, `iters` times; *gb_per_s = (bytes read + bytes written) / time. */
 int alz_measure_copy_bandwidth(alz_ctx* ctx, size_t bytes, int iters, double* gb_per_s);
+/* Device time (HIP events on the launch stream) of the kernels of the last alz_plan_execute_timed (mean per execution) or
+ * alz_encode_batch (hash-table resets + all encode kernels of the call) on this context. */
+int alz_last_kernel_ms(alz_ctx* ctx, float* ms);
 
 /* ------------------------------------------------ container layer (host side)
  * The managed part of the reference's format classes restated above the
