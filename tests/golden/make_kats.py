@@ -1,0 +1,515 @@
+#!/usr/bin/env python3
+"""make_kats.py -- hand-assembled known-answer tests for the eleven north-star decode bodies.
+
+This script does NOT call the oracle, the library or any decoder.  Every case is written down as a list of operations
+    ("lit", bytes)      literal bytes
+    ("copy", d, n)      n bytes from distance d (out[q] = out[q - d], LzWindows.BackCopy  IO/LzWindows.cs:72-100)
+and two independent things are derived from that list:
+  * the expected OUTPUT: the operations applied to a plain Python bytearray (expand());
+  * the compressed STREAM: the operations written in the token encoding the cited C# decoder reads -- one small writer per
+    format below, each line next to the decoder statement it is the inverse of (paths under /root/reference/src).
+A decoder that disagrees with the C# field layout therefore fails these vectors even when its own encoder agrees with it
+(the round-trip matrix cannot see that).  The vectors cover every token form of every body: each length class and its
+extension bytes at their boundaries, distance extremes, self-overlapping copies, partial last flag groups, the lazy flag
+fetch of PRS in both bit orders, the LZO `plain` states (and its "> 17" first byte quirk) and the Yaz0 length-byte-at-EOF rule.
+
+Output: tests/golden/kat_<format>.json (committed).  tests/test_kat.py checks the oracle against them (CPU suite) and the
+HIP path through the C ABI (-m gpu); tests/test_kat.py also re-runs this script and compares, so the files cannot drift.
+"""
+import base64
+import json
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def expand(ops):
+    out = bytearray()
+    for op in ops:
+        if op[0] == "lit":
+            out += bytes(op[1])
+        else:
+            d, n = op[1], op[2]
+            assert 1 <= d <= len(out), (d, len(out))
+            for _ in range(n):
+                out.append(out[-d])
+    return bytes(out)
+
+
+def tokens(ops):
+    """literal runs split into single literals (the flag-byte formats have one flag bit per literal byte)"""
+    for op in ops:
+        if op[0] == "lit":
+            for b in bytes(op[1]):
+                yield ("lit", b)
+        else:
+            yield op
+
+
+# ------------------------------------------------------------------------------------------------ flag-byte family
+class Flags8:
+    """8-bit flag byte written in FRONT of the payload of its (up to) 8 tokens: the decoder fetches a flag byte when it has no
+    bit left (FlagReader.Readbit  IO/FlagReader.cs:52-64) and the payload of a token right after its bit."""
+
+    def __init__(self, msb_first):
+        self.msb, self.out, self.pos, self.n = msb_first, bytearray(), None, 0
+
+    def bit(self, v):
+        if self.n == 0:
+            self.pos = len(self.out); self.out.append(0); self.n = 8
+        shift = self.n - 1 if self.msb else 8 - self.n          # FlagReader.cs:60
+        self.out[self.pos] |= (1 if v else 0) << shift
+        self.n -= 1
+
+
+def enc_lzss(ops, wbits=12, lbits=4, thr=2):
+    """LZSS.DecompressHeaderless  AuroraLib.Compression/Formats/Common/LZSS.cs:91-130; LzProperties bit ctor LzProperties.cs:57-66"""
+    W, minlen = 1 << wbits, thr + 1
+    ws = W - (1 << lbits) - thr                                   # WindowsStart (LzProperties.cs:63)
+    f, pos = Flags8(msb_first=False), 0                           # :95 flags LSB first
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(1); f.out.append(t[1]); pos += 1                # :106-108
+        else:
+            _, d, n = t
+            assert minlen <= n <= minlen + (1 << lbits) - 1 and 1 <= d <= W
+            ring = (pos - d) % W                                  # address OffsetCopy must resolve to  LzWindows.cs:108-115
+            off = (ring + ws) % W                                 # :117 off = (MaxDistance + off - WindowsStart) & (MaxDistance - 1)
+            f.bit(0); f.out.append(off & 0xFF); f.out.append(((off >> 8) << lbits) | (n - minlen))   # :115-116
+            pos += n
+    return bytes(f.out)
+
+
+def enc_lz10(ops):
+    """LZ10.DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/LZ10.cs:82-111"""
+    f = Flags8(msb_first=True)                                    # :88
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(0); f.out.append(t[1])                          # :102
+        else:
+            _, d, n = t
+            assert 3 <= n <= 18 and 1 <= d <= 4096
+            f.bit(1); f.out.append(((n - 3) << 4) | ((d - 1) >> 8)); f.out.append((d - 1) & 0xFF)   # :94-98
+    return bytes(f.out)
+
+
+def enc_lz11(ops):
+    """LZ11.DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/LZ11.cs:83-133"""
+    f = Flags8(msb_first=True)
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(0); f.out.append(t[1])
+        else:
+            _, d, n = t
+            assert 1 <= d <= 4096
+            f.bit(1)
+            if n <= 16:                                           # :113-118  n = (b1 >> 4) + 1  (3..16: nibbles 0 and 1 are taken)
+                assert n >= 3
+                f.out += bytes([((n - 1) << 4) | ((d - 1) >> 8), (d - 1) & 0xFF])
+            elif n <= 272:                                        # :98-104  n = ((b1 & 0xF) << 4 | b2 >> 4) + 17
+                v = n - 17
+                f.out += bytes([v >> 4, ((v & 0xF) << 4) | ((d - 1) >> 8), (d - 1) & 0xFF])
+            else:                                                 # :105-112  n = ((b1 & 0xF) << 12 | b2 << 4 | b3 >> 4) + 273
+                v = n - 273
+                assert v < (1 << 16)
+                f.out += bytes([0x10 | (v >> 12), (v >> 4) & 0xFF, ((v & 0xF) << 4) | ((d - 1) >> 8), (d - 1) & 0xFF])
+    return bytes(f.out)
+
+
+def yay0_token(d, n):
+    """Yay0.DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/Yay0.cs:124-134: (two token bytes, length byte or None)"""
+    assert 1 <= d <= 4096 and 3 <= n <= 0x111
+    if n <= 17:
+        return bytes([((n - 2) << 4) | ((d - 1) >> 8), (d - 1) & 0xFF]), None     # :133 n = (b1 >> 4) + 2
+    return bytes([(d - 1) >> 8, (d - 1) & 0xFF]), n - 0x12                         # :130-131 n = ReadByte() + 0x12
+
+
+def enc_yaz0(ops, drop_last_length_byte=False):
+    """Yaz0 = Yay0.DecompressHeaderless with all three cursors on one stream  Yaz0.cs:91-92, Yay0.cs:110-144"""
+    f = Flags8(msb_first=True)
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(1); f.out.append(t[1])                          # Yay0.cs:118-121: bit 1 = literal
+        else:
+            tok, lb = yay0_token(t[1], t[2])
+            f.bit(0); f.out += tok
+            if lb is not None:
+                f.out.append(lb)
+    out = bytes(f.out)
+    return out[:-1] if drop_last_length_byte else out
+
+
+def enc_3cursor(ops, mio0):
+    """Yay0 (Yay0.cs:99-144) / MIO0 (MIO0.cs:105-149): flags | tokens | literals (+ Yay0's length bytes).  Returns
+    (stream, aux0 = token section offset, aux1 = literal section offset), all relative to the first flag byte."""
+    flags, toks, lits = Flags8(msb_first=True), bytearray(), bytearray()
+    for t in tokens(ops):
+        if t[0] == "lit":
+            flags.bit(1); lits.append(t[1])
+        else:
+            _, d, n = t
+            flags.bit(0)
+            if mio0:
+                assert 3 <= n <= 18 and 1 <= d <= 4096
+                toks += bytes([((n - 3) << 4) | ((d - 1) >> 8), (d - 1) & 0xFF])   # MIO0.cs:129-136
+            else:
+                tok, lb = yay0_token(d, n)
+                toks += tok
+                if lb is not None:
+                    lits.append(lb)                               # Yay0.cs:130: the length byte comes from the literal stream
+    fl = bytes(flags.out)
+    fl += bytes((-len(fl)) % 4)                                   # the writers pad the flag section to 4 bytes (Yay0.cs:70-77)
+    return fl + bytes(toks) + bytes(lits), len(fl), len(fl) + len(toks)
+
+
+# ------------------------------------------------------------------------------------------------ PRS
+class LazyFlags:
+    """FlagReader over the SAME stream as the data (PRS.cs:62): a flag byte sits wherever the decoder happens to be when it
+    needs a bit and has none left -- possibly between the bits of one token.  Bit order = byte order (PRS.cs:62)."""
+
+    def __init__(self, big):
+        self.big, self.out, self.pos, self.n = big, bytearray(), None, 0
+
+    def bit(self, v):
+        if self.n == 0:
+            self.pos = len(self.out); self.out.append(0); self.n = 8
+        shift = self.n - 1 if self.big else 8 - self.n
+        self.out[self.pos] |= (1 if v else 0) << shift
+        self.n -= 1
+
+
+def enc_prs(ops, big, terminate=True):
+    """PRS.DecompressHeaderless  AuroraLib.Compression.Sega/Sega/PRS.cs:59-102"""
+    f = LazyFlags(big)
+    u16 = (lambda v: bytes([v >> 8, v & 0xFF])) if big else (lambda v: bytes([v & 0xFF, v >> 8]))
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(1); f.out.append(t[1])                          # :66-69
+        else:
+            d, n = t[1], t[2]
+            if d <= 0x100 and 2 <= n <= 5 and not (len(t) > 3 and t[3] in ("long", "ext")):
+                f.bit(0); f.bit(0)                                # :93-97 short: ReadInt(2, reverse) = first bit is the high one
+                f.bit((n - 2) >> 1); f.bit((n - 2) & 1)
+                f.out.append((0x100 - d) & 0xFF)
+            else:
+                assert 1 <= d <= 0x1FFF and 1 <= n <= 0x100
+                f.bit(0); f.bit(1)                                # :73-91 long
+                if 3 <= n <= 9 and not (len(t) > 3 and t[3] == "ext"):
+                    f.out += u16(((0x2000 - d) << 3) | (n - 2))   # :82-90 n = (v & 7) + 2
+                else:
+                    f.out += u16((0x2000 - d) << 3); f.out.append(n - 1)   # :84-86 n = ReadUInt8() + 1
+    if terminate:
+        f.bit(0); f.bit(1); f.out += b"\x00\x00"                  # :75-80
+    return bytes(f.out)
+
+
+# ------------------------------------------------------------------------------------------------ LZ4 / LZO / Snappy
+def lz4_ext(v):
+    """ReadExtension  LZ4.cs:241-252: 15 in the nibble, then bytes of 255 and one byte < 255"""
+    if v < 15:
+        return b""
+    v -= 15
+    out = bytearray()
+    while v >= 255:
+        out.append(255); v -= 255
+    out.append(v)
+    return bytes(out)
+
+
+def enc_lz4(ops):
+    """LZ4.DecompressBlockHeaderless  AuroraLib.Compression/Formats/Common/LZ4.cs:176-200: sequences of (literals, match); the
+    block ends with a literals-only sequence (:190)."""
+    out, i = bytearray(), 0
+    ops = list(ops)
+    while i < len(ops):
+        lit = b""
+        if ops[i][0] == "lit":
+            lit = bytes(ops[i][1]); i += 1
+        if i < len(ops):
+            _, d, n = ops[i]; i += 1
+            assert n >= 4 and 1 <= d <= 0xFFFF
+            out.append((min(len(lit), 15) << 4) | min(n - 4, 15))
+            out += lz4_ext(len(lit)) + lit + bytes([d & 0xFF, d >> 8]) + lz4_ext(n - 4)
+            if i == len(ops):                                     # a block cannot end behind a match: empty last sequence
+                out.append(0)
+        else:
+            out.append(min(len(lit), 15) << 4); out += lz4_ext(len(lit)) + lit
+    return bytes(out)
+
+
+def lzo_ext(v):
+    """ReadExtendedInt  LZO.cs:252-262: zero bytes count 255 each, then one non-zero byte"""
+    out = bytearray()
+    while v > 255:
+        out.append(0); v -= 255
+    assert v >= 1
+    out.append(v)
+    return bytes(out)
+
+
+def enc_lzo(ops, first_run_quirk=False):
+    """LZO.DecompressHeaderless  AuroraLib.Compression/Formats/Common/LZO.cs:49-139.  ops: ("lit", bytes) runs and
+    ("copy", d, n, form) with form in M1a (2 bytes, after 1-3 literals), M1b (3 bytes, after a run), M2, M2b, M3, M4.  The
+    0-3 literals that FOLLOW a match ride in the low bits of its last header byte (`plain = flag & 3` :131)."""
+    out, ops = bytearray(), list(ops)
+    i = 0
+    if first_run_quirk:                                           # :59-64 first byte > 17: that many - 17 literals, plain stays 0
+        lit = bytes(ops[0][1]); assert 1 <= len(lit) <= 238
+        out.append(17 + len(lit)); out += lit; i = 1
+    while i < len(ops):
+        op = ops[i]
+        if op[0] == "lit":                                        # state plain == 0: a literal run of 4.. bytes  :75-85
+            lit = bytes(op[1]); assert len(lit) >= 4
+            if len(lit) <= 18:
+                out.append(len(lit) - 3)
+            else:
+                out.append(0); out += lzo_ext(len(lit) - 18)
+            out += lit; i += 1
+            continue
+        _, d, n, form = op
+        trail = b""
+        if i + 1 < len(ops) and ops[i + 1][0] == "lit" and len(ops[i + 1][1]) <= 3 and not (len(ops[i + 1]) > 2 and ops[i + 1][2] == "run"):
+            trail = bytes(ops[i + 1][1]); i += 1
+        p = len(trail)
+        if form == "M1a":                                         # :86-91 after 1-3 literals: length 2, distance 1..1024
+            assert n == 2 and 1 <= d <= 1024
+            out += bytes([(((d - 1) & 3) << 2) | p, (d - 1) >> 2])
+        elif form == "M1b":                                       # :92-97 after a literal run: length 3, distance 2049..3072
+            assert n == 3 and 2049 <= d <= 3072
+            out += bytes([(((d - 2049) & 3) << 2) | p, (d - 2049) >> 2])
+        elif form == "M2":                                        # :122-127 01LD DDPP: length 3-4, distance 1..2048
+            assert n in (3, 4) and 1 <= d <= 2048
+            out += bytes([0x40 | ((n - 3) << 5) | (((d - 1) & 7) << 2) | p, (d - 1) >> 3])
+        elif form == "M2b":                                       # :128-133 1LLD DDPP: length 5-8
+            assert 5 <= n <= 8 and 1 <= d <= 2048
+            out += bytes([0x80 | ((n - 5) << 5) | (((d - 1) & 7) << 2) | p, (d - 1) >> 3])
+        elif form == "M3":                                        # :111-120 001L LLLL: length 3-33 or 33 + ext, distance 1..16384
+            assert n >= 3 and 1 <= d <= 16384
+            if n <= 33:
+                out.append(0x20 | (n - 2))
+            else:
+                out.append(0x20); out += lzo_ext(n - 33)
+            out += bytes([(((d - 1) & 0x3F) << 2) | p, (d - 1) >> 6])
+        else:                                                     # M4 :98-110 0001 HLLL: length 3-9 or 9 + ext, distance 16385..49151
+            assert form == "M4" and n >= 3 and 16385 <= d <= 49151
+            h = (d - 16384) >> 14
+            if n <= 9:
+                out.append(0x10 | (h << 3) | (n - 2))
+            else:
+                out.append(0x10 | (h << 3)); out += lzo_ext(n - 9)
+            low = (d - 16384) & 0x3FFF
+            out += bytes([((low & 0x3F) << 2) | p, low >> 6])
+        out += trail
+        i += 1
+    out += bytes([0x11, 0x00, 0x00])                              # :107-109 end marker: code 1, distance 16384
+    return bytes(out)
+
+
+def enc_snappy(ops):
+    """Snappy.DecompressHeaderless  AuroraLib.Compression/Formats/Common/Snappy.cs:205-250, varint size :109-122"""
+    total = len(expand(ops))
+    out, v = bytearray(), total
+    while True:
+        b = v & 0x7F; v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            break
+    for op in ops:
+        if op[0] == "lit":
+            lit = bytes(op[1]); n = len(lit)
+            if n <= 60:
+                out.append((n - 1) << 2)                          # :221-233 tag >> 2 < 60: that + 1 literals
+            elif n <= 256:
+                out += bytes([60 << 2, n - 1])                    # 60: one length byte
+            else:
+                out += bytes([61 << 2, (n - 1) & 0xFF, (n - 1) >> 8])   # 61: two length bytes, little endian
+            out += lit
+        else:
+            _, d, n = op[:3]
+            form = op[3] if len(op) > 3 else None
+            if form != "copy2" and 4 <= n <= 11 and d < 2048:
+                out += bytes([1 | ((n - 4) << 2) | ((d >> 8) << 5), d & 0xFF])   # :235-239
+            else:
+                assert 1 <= n <= 64 and d <= 0xFFFF
+                out += bytes([2 | ((n - 1) << 2), d & 0xFF, d >> 8])             # :240-243
+    return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------------ the cases
+def pat(n, seed):
+    """n distinct-looking bytes (no generator state: a formula)"""
+    return bytes((seed * 37 + i * 29 + (i * i) // 7) & 0xFF for i in range(n))
+
+
+def case(name, fmt, src, ops, cite, lz=None, aux0=0, aux1=0, decom_len=None, src_used=None, note=""):
+    exp = expand(ops)
+    # expected bytes: zlib + base64 (the long cases are repetitive by construction: 60 KiB of output in 200 bytes of JSON)
+    c = {"name": name, "format": fmt, "src": src.hex(), "expect_len": len(exp), "expect_zlib_b64": base64.b64encode(zlib.compress(exp, 9)).decode(),
+         "decom_len": len(exp) if decom_len is None else decom_len,
+         "aux0": aux0, "aux1": aux1, "cite": cite}
+    if lz:
+        c["lz"] = lz
+    if src_used is not None:
+        c["src_used"] = src_used
+    if note:
+        c["note"] = note
+    return c
+
+
+def build():
+    K = {}
+    A, B, C3 = pat(9, 1), pat(20, 2), pat(5, 3)
+
+    # ---- LZSS (12, 4, 2): lengths 3..18, distances 1..4096
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x00\xff"), ("copy", 3, 7), ("copy", 30, 18), ("lit", b"Z")]
+    K.setdefault("lzss", []).append(case("default geometry: min / max length, distance 1 (RLE) and 3, partial last flag byte", "lzss", enc_lzss(ops), ops, "LZSS.cs:91-130"))
+    big = [("lit", pat(60, 7))] + [("copy", 60, 18)] * 226 + [("lit", b"\x01\x02\x03\x04")] + [("copy", 4096, 18), ("copy", 4095, 3), ("copy", 2048, 5)]
+    K["lzss"].append(case("distance 4096 = the whole window (ring address == write position), 4095, across the 0xFEE ring origin", "lzss", enc_lzss(big), big, "LZSS.cs:115-119, LzWindows.cs:108-115"))
+    ops = [("lit", B), ("copy", 20, 66), ("copy", 1, 3), ("lit", b"q"), ("copy", 64, 40)]
+    K["lzss"].append(case("KAT geometry LzProperties((byte)10, 6, 2): W 1024, lengths 3..66, WindowsStart 958", "lzss", enc_lzss(ops, 10, 6, 2), ops,
+                          "CompressionTest/CompressionAlgorithmTest.cs:31-48, LzProperties.cs:57-66", lz={"window_bits": 10, "length_bits": 6, "min_length": 3, "windows_start": 958, "max_distance": 1024}))
+    # ---- LZ10
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x10\x20"), ("copy", 2, 9), ("copy", 33, 17)]
+    K.setdefault("lz10", []).append(case("lengths 3 / 9 / 17 / 18, distances 1, 2 and beyond one flag group", "lz10", enc_lz10(ops), ops, "LZ10.cs:82-111"))
+    big = [("lit", pat(64, 9))] + [("copy", 64, 18)] * 224 + [("copy", 4096, 18), ("copy", 4095, 3), ("lit", b"end")]
+    K["lz10"].append(case("distance 4096 (12 bits all set) and 4095", "lz10", enc_lz10(big), big, "LZ10.cs:94-98"))
+    ops = [("lit", b"\xAA")] + [("copy", 1, 3)] * 8 + [("lit", b"\xBB")]
+    K["lz10"].append(case("a flag byte of eight matches (0xFF) followed by a one-literal group (0x00)", "lz10", enc_lz10(ops), ops, "LZ10.cs:88-102"))
+    # ---- LZ11
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 4, 16), ("copy", 1, 17), ("copy", 7, 272), ("lit", b"\x7f"), ("copy", 100, 273), ("copy", 300, 1000)]
+    K.setdefault("lz11", []).append(case("2-byte form 3 / 16, 3-byte form 17 / 272, 4-byte form 273 / 1000", "lz11", enc_lz11(ops), ops, "LZ11.cs:83-133"))
+    ops = [("lit", pat(16, 4)), ("copy", 16, 65808), ("lit", b"!")]
+    K["lz11"].append(case("the longest token: 4-byte form with all length bits set (65 808 bytes)", "lz11", enc_lz11(ops), ops, "LZ11.cs:105-112"))
+    big = [("lit", pat(50, 5)), ("copy", 50, 4046), ("copy", 4096, 273), ("copy", 4095, 17), ("copy", 4096, 3)]
+    K["lz11"].append(case("distance 4096 in each of the three forms' distance fields", "lz11", enc_lz11(big), big, "LZ11.cs:98-118"))
+    # ---- Yaz0
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 5, 17), ("copy", 1, 18), ("copy", 2, 273), ("lit", b"\x00"), ("copy", 21, 100)]
+    K.setdefault("yaz0", []).append(case("2-byte form 3 / 17, 3-byte form 18 (length byte 0) / 273 (0xFF) / 100", "yaz0", enc_yaz0(ops), ops, "Yay0.cs:110-144, Yaz0.cs:91-92"))
+    big = [("lit", pat(40, 6)), ("copy", 40, 273)] + [("copy", 313, 273)] * 14 + [("copy", 4096, 39), ("copy", 4095, 3), ("lit", b"ok")]
+    K["yaz0"].append(case("distance 4096 and 4095", "yaz0", enc_yaz0(big), big, "Yay0.cs:127"))
+    ops = [("lit", C3), ("copy", 5, 17)]
+    K["yaz0"].append(case("ReadByte() == -1 at the end of the input: a 3-byte token whose length byte is missing copies 0x12 - 1 = 17 bytes",
+                          "yaz0", enc_yaz0([("lit", C3), ("copy", 5, 18)], drop_last_length_byte=True), ops, "Yay0.cs:130-131"))
+    # ---- Yay0 / MIO0
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 5, 17), ("copy", 1, 18), ("lit", b"\x42\x43"), ("copy", 2, 273), ("copy", 30, 60), ("lit", b"\x99")]
+    s, a0, a1 = enc_3cursor(ops, mio0=False)
+    K.setdefault("yay0", []).append(case("three sections; the length bytes of the 3-byte form interleave with the literals", "yay0", s, ops, "Yay0.cs:99-144", aux0=a0, aux1=a1, src_used=len(s)))
+    big = [("lit", pat(33, 8)), ("copy", 33, 273)] + [("copy", 306, 273)] * 14 + [("copy", 4096, 19), ("copy", 4095, 4)]
+    s, a0, a1 = enc_3cursor(big, mio0=False)
+    K["yay0"].append(case("distance 4096 / 4095; two flag bytes padded to a 4-byte flag section", "yay0", s, big, "Yay0.cs:127", aux0=a0, aux1=a1, src_used=len(s)))
+    ops = [("lit", b"\x01")] + [("copy", 1, 3)] * 31 + [("lit", b"\x02")]
+    s, a0, a1 = enc_3cursor(ops, mio0=False)
+    K["yay0"].append(case("33 tokens: five flag bytes, the last one with a single bit used", "yay0", s, ops, "Yay0.cs:113-121", aux0=a0, aux1=a1, src_used=len(s)))
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x42"), ("copy", 2, 10), ("copy", 12, 18)]
+    s, a0, a1 = enc_3cursor(ops, mio0=True)
+    K.setdefault("mio0", []).append(case("lengths 3 / 10 / 18", "mio0", s, ops, "MIO0.cs:105-149", aux0=a0, aux1=a1, src_used=len(s)))
+    big = [("lit", pat(64, 10))] + [("copy", 64, 18)] * 224 + [("copy", 4096, 18), ("copy", 4095, 3)]
+    s, a0, a1 = enc_3cursor(big, mio0=True)
+    K["mio0"].append(case("distance 4096 / 4095", "mio0", s, big, "MIO0.cs:129-136", aux0=a0, aux1=a1, src_used=len(s)))
+    ops = [("lit", b"\xEE")] + [("copy", 1, 3)] * 8
+    s, a0, a1 = enc_3cursor(ops, mio0=True)
+    K["mio0"].append(case("nine tokens: a full flag byte and one bit of the next", "mio0", s, ops, "MIO0.cs:117-123", aux0=a0, aux1=a1, src_used=len(s)))
+    # ---- PRS, both bit orders
+    for big_e, fmt in ((True, "prs_be"), (False, "prs_le")):
+        ops = [("lit", A), ("copy", 9, 2), ("copy", 1, 5), ("copy", 2, 256), ("copy", 13, 3), ("lit", b"\x31\x32\x33\x34"), ("copy", 4, 3, "long"), ("copy", 270, 9), ("copy", 7, 1, "ext"), ("copy", 11, 6, "ext")]
+        K.setdefault(fmt, []).append(case("short matches 2 / 5 / 3, long matches 3 (forced long form) / 9, length byte forms 256 and 1; flag bytes land inside tokens",
+                                          fmt, enc_prs(ops, big_e), ops, "PRS.cs:59-102, FlagReader.cs:52-100", decom_len=0))
+        far = [("lit", pat(70, 11))] + [("copy", 70, 256)] * 32 + [("copy", 0x1FFF, 9), ("copy", 0x100, 5), ("copy", 0x101, 3), ("lit", b"\xfe")]
+        K[fmt].append(case("distance 0x1FFF (13 bits), 0x100 (short form, offset byte 0) and 0x101 (first long-only distance)", fmt, enc_prs(far, big_e), far,
+                           "PRS.cs:82-97", decom_len=0))
+        ops = [("lit", b"ab"), ("copy", 2, 4)] * 5 + [("lit", b"\x00")]
+        K[fmt].append(case("the 2-bit length of a short match split across two flag bytes", fmt, enc_prs(ops, big_e), ops, "PRS.cs:95, FlagReader.cs:75-100", decom_len=0))
+    # ---- LZ4 block
+    ops = [("lit", A), ("copy", 9, 4), ("copy", 1, 18), ("lit", pat(15, 12)), ("copy", 3, 19), ("lit", pat(270, 13)), ("copy", 100, 274), ("copy", 300, 530), ("lit", b"tail!")]
+    K.setdefault("lz4_block", []).append(case("literal counts 9 / 0 / 15 (extension byte 0) / 270 (255 + 0); match lengths 4 / 18 / 19 (ext 0) / 274 (255 + 0) / 530 (255, 255, 1)",
+                                              "lz4_block", enc_lz4(ops), ops, "LZ4.cs:176-200, :241-252", decom_len=0))
+    far = [("lit", pat(80, 14))] + [("copy", 80, 1000)] * 66 + [("copy", 0xFFFF, 40), ("copy", 0x8000, 4), ("lit", b"12345")]
+    K["lz4_block"].append(case("distance 0xFFFF and 0x8000 (u16 little endian)", "lz4_block", enc_lz4(far), far, "LZ4.cs:195", decom_len=0))
+    ops = [("lit", b"x"), ("copy", 1, 4)]
+    K["lz4_block"].append(case("a block that ends right behind a match: the input is exhausted at the next token byte", "lz4_block", enc_lz4(ops)[:-1], ops, "LZ4.cs:180, :190", decom_len=0))
+    # ---- LZO
+    ops = [("lit", pat(3100, 16)), ("copy", 2049, 3, "M1b"), ("lit", b"\x01"), ("copy", 1, 2, "M1a"), ("lit", b"\x02\x03"), ("copy", 1024, 2, "M1a"), ("lit", b"\x04\x05\x06"),
+           ("copy", 5, 3, "M2"), ("copy", 2048, 4, "M2"), ("lit", pat(18, 17), "run"), ("copy", 3072, 3, "M1b"), ("copy", 9, 8, "M2b"), ("copy", 2048, 5, "M2b"),
+           ("copy", 1, 33, "M3"), ("copy", 3000, 34, "M3"), ("copy", 100, 600, "M3"), ("lit", pat(19, 18), "run"), ("copy", 7, 3, "M3")]
+    K.setdefault("lzo", []).append(case("every opcode class below 16 KiB: literal runs 3100 (18 + 255 x 12 + 22) / 18 / 19, M1 after 1-3 literals (length 2) and after a run (length 3, "
+                                        "distance 2049 / 3072), M2 3 / 4, M2b 5 / 8, M3 3 / 33 / 34 / 600, trailing literals 0-3 in the low bits", "lzo", enc_lzo(ops), ops, "LZO.cs:49-139, :252-262", decom_len=0))
+    far = [("lit", pat(200, 19))] + [("copy", 200, 2000, "M3")] * 25 + [("copy", 16384, 34, "M3"), ("copy", 16385, 3, "M4"), ("copy", 49151, 9, "M4"), ("lit", b"\x09"), ("copy", 32768, 10, "M4"), ("copy", 20000, 700, "M4")]
+    K["lzo"].append(case("M3 at its largest distance 16384; M4: distances 16385 / 32768 / 49151 (the H bit), lengths 3 / 9 / 10 / 700", "lzo", enc_lzo(far), far, "LZO.cs:98-110", decom_len=0))
+    ops = [("lit", pat(5, 20)), ("lit", pat(4, 21)), ("copy", 3, 4, "M2")]
+    K["lzo"].append(case("first byte > 17: an initial run of (byte - 17) literals that leaves plain at 0, so the next opcode < 16 is a literal RUN (canonical LZO1X would read a match)",
+                         "lzo", enc_lzo(ops, first_run_quirk=True), [("lit", pat(5, 20) + pat(4, 21)), ("copy", 3, 4)], "LZO.cs:51, :59-64, :75-85", decom_len=0))
+    # ---- Snappy
+    ops = [("lit", A), ("copy", 9, 4), ("copy", 1, 11), ("lit", pat(60, 22)), ("copy", 2047, 5), ("lit", pat(61, 23)), ("copy", 70, 4, "copy2"), ("copy", 3, 64), ("copy", 5, 1, "copy2"), ("lit", pat(300, 24)), ("copy", 400, 12)]
+    ops[4] = ("copy", 60, 5)
+    K.setdefault("snappy_raw", []).append(case("literal tags 9 / 60 (largest inline) / 61 (one length byte) / 300 (two length bytes); copy-1 lengths 4 / 11; copy-2 lengths 4 / 64 / 1 / 12",
+                                               "snappy_raw", enc_snappy(ops), ops, "Snappy.cs:205-250, :109-122", decom_len=0))
+    far = [("lit", pat(90, 25))] + [("copy", 90, 64)] * 1030 + [("copy", 0xFFFF, 64), ("copy", 2047, 11), ("copy", 2048, 11), ("lit", b"z")]
+    K["snappy_raw"].append(case("distance 0xFFFF (copy-2), 2047 (largest copy-1) and 2048; a three-byte varint size", "snappy_raw", enc_snappy(far), far, "Snappy.cs:235-243", decom_len=0))
+    ops = [("lit", b"\x00")]
+    K["snappy_raw"].append(case("the shortest stream: size 1, one literal", "snappy_raw", enc_snappy(ops), ops, "Snappy.cs:221-233", decom_len=0))
+    return K
+
+
+def be32(v):
+    return bytes([(v >> 24) & 0xFF, (v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
+
+
+def le32(v):
+    return bytes([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF, (v >> 24) & 0xFF])
+
+
+def build_containers():
+    """Container files assembled by hand from the header code of the format classes (not from the library's or the oracle's
+    header layer, which share a mould): magic / size fields / section pointers in front of a body from the writers above."""
+    out = []
+
+    def cont(name, container, blob, ops, cite, big_endian=1, note=""):
+        exp = expand(ops)
+        c = {"name": name, "container": container, "file": blob.hex(), "expect_len": len(exp),
+             "expect_zlib_b64": base64.b64encode(zlib.compress(exp, 9)).decode(), "big_endian": big_endian, "cite": cite}
+        if note:
+            c["note"] = note
+        out.append(c)
+
+    ops = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x10\x20"), ("copy", 2, 9), ("copy", 33, 17)]
+    n = len(expand(ops))
+    cont("0x10 + u24 LE size", "LZ10", bytes([0x10, n & 0xFF, (n >> 8) & 0xFF, (n >> 16) & 0xFF]) + enc_lz10(ops), ops, "LZ10.cs:47-57, :67-80")
+    cont("0x10 + zero u24 + u32 LE size (the form for sizes above 0xFFFFFF, legal for any size)", "LZ10", bytes([0x10, 0, 0, 0]) + le32(n) + enc_lz10(ops), ops, "LZ10.cs:52-54")
+    ops11 = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 4, 16), ("copy", 1, 17), ("copy", 7, 272), ("lit", b"\x7f"), ("copy", 100, 273)]
+    n = len(expand(ops11))
+    cont("0x11 + u24 LE size", "LZ11", bytes([0x11, n & 0xFF, (n >> 8) & 0xFF, (n >> 16) & 0xFF]) + enc_lz11(ops11), ops11, "LZ11.cs:43-53")
+    opsy = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 5, 17), ("copy", 1, 18), ("copy", 2, 273), ("lit", b"\x00"), ("copy", 21, 100)]
+    n = len(expand(opsy))
+    cont("\"Yaz0\" + BE size + BE alignment + 0", "YAZ0", b"Yaz0" + be32(n) + be32(0x20) + be32(0) + enc_yaz0(opsy), opsy, "Yaz0.cs:58-64, :84-87")
+    cont("little-endian size field: the first attempt reads a size of 0x%08X, fails, and the byte-swapped retry succeeds" % int.from_bytes(le32(n), "big"), "YAZ0",
+         b"Yaz0" + le32(n) + le32(0) + le32(0) + enc_yaz0(opsy), opsy, "Yaz0.cs:66-78")
+    for magic, cname, mio in ((b"Yay0", "YAY0", False), (b"MIO0", "MIO0", True)):
+        o = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x42"), ("copy", 2, 10), ("copy", 12, 18)] if mio else \
+            [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 5, 17), ("copy", 1, 18), ("lit", b"\x42\x43"), ("copy", 2, 273), ("copy", 30, 60), ("lit", b"\x99")]
+        body, a0, a1 = enc_3cursor(o, mio0=mio)
+        n = len(expand(o))
+        cont("\"%s\" + BE size + token pointer + literal pointer (both from the start of the file), flags at 0x10" % magic.decode(), cname,
+             magic + be32(n) + be32(0x10 + a0) + be32(0x10 + a1) + body, o, "Yay0.cs:50-60, :70-77" if not mio else "MIO0.cs:51-61, :72-79")
+    opss = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x00\xff"), ("copy", 3, 7), ("copy", 30, 18), ("lit", b"Z")]
+    body = enc_lzss(opss)
+    cont("\"LZSS\" + BE size + BE compressed size + BE 0", "LZSS", b"LZSS" + be32(len(expand(opss))) + be32(len(body)) + be32(0) + body, opss, "LZSS.cs:53-88")
+    return out
+
+
+def main():
+    with open(os.path.join(HERE, "kat_containers.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_kats.py (headers assembled by hand from the format classes; no decoder, no header layer involved)",
+                   "cases": build_containers()}, f, indent=1)
+        f.write("\n")
+    K = build()
+    for fmt, cases in sorted(K.items()):
+        with open(os.path.join(HERE, "kat_%s.json" % fmt), "w") as f:
+            json.dump({"format": fmt, "generator": "tests/golden/make_kats.py (hand-assembled from the cited C# lines; no decoder involved)", "cases": cases}, f, indent=1)
+            f.write("\n")
+    print("wrote %d files, %d cases" % (len(K), sum(len(v) for v in K.values())))
+
+
+if __name__ == "__main__":
+    main()
