@@ -1,0 +1,120 @@
+// AmdBody.cs -- what every format class of this assembly shares: move the rest of a Stream through a native body decode /
+// encode and map the per-stream status back to the exception the managed body would have thrown.
+using AuroraLib.Compression.Exceptions;
+using System;
+using System.Buffers;
+using System.IO;
+
+namespace AuroraLib.Compression.Amd
+{
+    internal static unsafe class AmdBody
+    {
+        /// <summary>How a body treats its declared size (resolve_status of the kernels mirrors the same rules).</summary>
+        internal enum SizeRule { None, OvershootOnly /* LZ10.cs:107 '>' */, MustMatch /* LZSS.cs:126 '!=' */ }
+
+        /// <summary>Reads what is left of <paramref name="source"/> (netstandard2.0: no Stream.ReadExactly).</summary>
+        internal static byte[] RentRest(Stream source, out int length)
+        {
+            long rest = source.Length - source.Position;
+            if (rest > int.MaxValue - 64) throw new NotSupportedException("streams above 2 GiB are not supported by the native body");
+            length = (int)rest;
+            byte[] buf = ArrayPool<byte>.Shared.Rent(length + 16);
+            int done = 0;
+            while (done < length)
+            {
+                int n = source.Read(buf, done, length - done);
+                if (n <= 0) throw new EndOfStreamException();
+                done += n;
+            }
+            return buf;
+        }
+
+        /// <summary>
+        /// The replacement of a static DecompressHeaderless(Stream source, Stream destination, uint decomLength): the body runs in
+        /// alz_decode, the output is written to <paramref name="destination"/> (partial output too, as the managed bodies leave
+        /// it), <c>source.Position</c> ends just past the consumed bytes (Yay0.cs:89-90, MIO0.cs:92-93, LZSS.cs:68) and the
+        /// status becomes the managed exception.  <paramref name="capacity"/>: bytes the body may produce (declared size plus the
+        /// longest token for bodies that may overshoot it; a guess that is doubled on OUTPUT_CAPACITY for bodies without a size).
+        /// </summary>
+        internal static void Decode(AlzFormat format, AlzLzProperties* props, Stream source, Stream destination, uint decomLength,
+                                    uint aux0, uint aux1, uint capacity, bool hasSize)
+        {
+            byte[] src = RentRest(source, out int srcLen);
+            try
+            {
+                for (;;)
+                {
+                    byte[] dst = ArrayPool<byte>.Shared.Rent((int)Math.Min(capacity, int.MaxValue - 64));
+                    try
+                    {
+                        AlzResult r;
+                        lock (AmdContext.Lock)
+                            fixed (byte* ps = src, pd = dst)
+                                AmdContext.Check(Native.alz_decode(AmdContext.Handle, (uint)format, props, ps, (uint)srcLen, decomLength, aux0, aux1,
+                                                                   pd, (uint)Math.Min(capacity, (uint)dst.Length), &r));
+                        if (!hasSize && r.Status == (int)AlzStatus.OutputCapacity && capacity < 0x7FFF0000u)
+                        {
+                            capacity = capacity < 0x3FFF0000u ? capacity * 2 : 0x7FFF0000u;    // a managed destination Stream simply grows
+                            continue;
+                        }
+                        destination.Write(dst, 0, (int)r.DstLen);
+                        if (source.CanSeek && (r.Status == (int)AlzStatus.Ok || r.Status == (int)AlzStatus.OutputSizeMismatch))
+                            source.Position -= srcLen - (int)r.SrcUsed;
+                        ThrowForStatus((AlzStatus)r.Status, decomLength, r.DstLen);
+                        return;
+                    }
+                    finally { ArrayPool<byte>.Shared.Return(dst); }
+                }
+            }
+            finally { ArrayPool<byte>.Shared.Return(src); }
+        }
+
+        /// <summary>INTEGRATION.md section 3: per-stream status -> the exception of the managed body.</summary>
+        internal static void ThrowForStatus(AlzStatus status, long expected, long actual)
+        {
+            switch (status)
+            {
+                case AlzStatus.Ok: return;
+                case AlzStatus.InputTruncated: throw new EndOfStreamException();                    // PRS.cs:101, LZO.cs:138
+                case AlzStatus.OutputSizeMismatch: throw new DecompressedSizeException(expected, actual);   // LZ10.cs:107-110, LZSS.cs:126-129
+                case AlzStatus.OutputCapacity: throw new NotSupportedException("destination too small");  // CompressionExtension.cs:43-50
+                default: throw new InvalidDataException("token outside the format (reference-undefined input)");
+            }
+        }
+
+        /// <summary>
+        /// The replacement of a static CompressHeaderless(ReadOnlySpan&lt;byte&gt;, Stream, CompressionSettings): alz_encode_batch
+        /// with one entry.  Returns the section offsets of Yay0 / MIO0 (flags | tokens | literals are written back to back).
+        /// </summary>
+        internal static AlzEncodeAux Encode(AlzFormat format, AlzLzProperties* props, ReadOnlySpan<byte> source, Stream destination,
+                                            CompressionSettings settings, int minDistance)
+        {
+            int cap = source.Length + source.Length / 4 + 64;                  // worst case of every body on the path
+            byte[] dst = ArrayPool<byte>.Shared.Rent(cap);
+            try
+            {
+                AlzStream st = new AlzStream { SrcOff = 0, DstOff = 0, SrcLen = (uint)source.Length, DstCap = (uint)cap, Format = (uint)format };
+                AlzSettings s = new AlzSettings { Quality = settings.Quality, MaxWindowBits = settings.MaxWindowBits,
+                                                  Strategy = (int)settings.Strategy, MinDistance = minDistance };
+                AlzResult r; AlzEncodeAux aux;
+                lock (AmdContext.Lock)
+                    fixed (byte* ps = source, pd = dst)
+                        AmdContext.Check(Native.alz_encode_batch(AmdContext.Handle, props, &s, 1, ps, (UIntPtr)(uint)source.Length, &st,
+                                                                 pd, (UIntPtr)(uint)cap, &r, &aux));
+                if (r.Status != (int)AlzStatus.Ok) throw new InvalidOperationException("native encoder status " + r.Status);
+                destination.Write(dst, 0, (int)r.DstLen);
+                return aux;
+            }
+            finally { ArrayPool<byte>.Shared.Return(dst); }
+        }
+
+        /// <summary>True when a single stream of this size should run on the GPU rather than on the managed body.</summary>
+        internal static bool UseGpu(uint decomLength) => AmdContext.Available && decomLength >= AmdContext.SingleStreamThreshold;
+
+        internal static AlzLzProperties ToNative(LzProperties lz) => new AlzLzProperties
+        {
+            WindowBits = lz.WindowsBits, LengthBits = lz.LengthBits, MinLength = (byte)lz.MinLength,
+            WindowsStart = (uint)lz.WindowsStart, MaxDistance = (uint)lz.MaxDistance
+        };
+    }
+}

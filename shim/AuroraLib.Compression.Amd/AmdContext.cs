@@ -1,0 +1,59 @@
+// AmdContext.cs -- one native context per process and device, behind a lock (alz_ctx is single-threaded: one HIP stream).
+using System;
+using System.Runtime.InteropServices;
+
+namespace AuroraLib.Compression.Amd
+{
+    /// <summary>
+    /// Owner of the native context.  When no HIP device (or no native library) is present, <see cref="Available"/> is false and
+    /// every format class of this assembly runs the managed body of the class it mirrors: the native library has no CPU path.
+    /// </summary>
+    public static class AmdContext
+    {
+        private static readonly object Gate = new object();
+        private static IntPtr _ctx;
+        private static bool _probed, _available;
+
+        /// <summary>Streams whose decompressed size is below this run on the managed body: ONE stream is one wavefront --
+        /// a lone 256 KiB stream takes ~1.3 ms on the GPU (0.2 GiB/s) against 0.4-0.9 GiB/s of the managed loop
+        /// (Benchmarks.md); the GPU pays off for batches (<see cref="BatchDecoder"/>) and for whole files of the framed /
+        /// chunked formats, which the library splits into a batch itself.</summary>
+        public static uint SingleStreamThreshold { get; set; } = uint.MaxValue;
+
+        public static bool Available
+        {
+            get
+            {
+                lock (Gate)
+                {
+                    if (!_probed)
+                    {
+                        _probed = true;
+                        try
+                        {
+                            _available = Native.alz_abi_version() == 2 && Native.alz_device_count() > 0 && Native.alz_create(0, out _ctx) == 0;
+                        }
+                        catch (DllNotFoundException) { _available = false; }
+                        catch (EntryPointNotFoundException) { _available = false; }
+                    }
+                    return _available;
+                }
+            }
+        }
+
+        internal static IntPtr Handle => Available ? _ctx : throw new InvalidOperationException("no HIP device: " + LastError());
+        internal static object Lock => Gate;
+
+        internal static string LastError()
+        {
+            try { return Marshal.PtrToStringAnsi(Native.alz_last_error()) ?? string.Empty; }
+            catch (DllNotFoundException) { return "libauroralz not found"; }
+        }
+
+        internal static void Check(int rc)
+        {
+            if (rc != 0)
+                throw new InvalidOperationException("auroralz error " + rc + ": " + LastError());
+        }
+    }
+}
