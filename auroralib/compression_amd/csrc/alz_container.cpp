@@ -148,6 +148,26 @@ struct DevBuf {   // device allocation released on every exit path
     ~DevBuf() { if (p) alz_device_free(c, p); }
 };
 
+// Does any match of this LZ4 block point in front of the block's own output?  (A walk over the sequences: input only.)
+static bool lz4_block_reaches_back(const uint8_t* b, uint32_t n) {
+    uint64_t produced = 0; uint32_t p = 0;
+    while (p < n) {
+        const uint32_t tok = b[p++];
+        uint64_t lit = tok >> 4;
+        if (lit == 15) { uint32_t x; do { if (p >= n) return false; x = b[p++]; lit += x; } while (x == 255); }
+        if (lit > n - p) return false;                                  // truncated: the decoder reports it
+        p += (uint32_t)lit; produced += lit;
+        if (p >= n) break;
+        if (p + 2 > n) return false;
+        const uint32_t dist = b[p] | (b[p + 1] << 8); p += 2;
+        uint64_t ml = tok & 15;
+        if (ml == 15) { uint32_t x; do { if (p >= n) return false; x = b[p++]; ml += x; } while (x == 255); }
+        if (dist > produced) return true;
+        produced += ml + 4;
+    }
+    return false;
+}
+
 struct Lz4Block { size_t off; uint32_t len; bool raw; };
 
 // LZ4.Decompress  Formats/Common/LZ4.cs:50-93 (+ ReadLZ4L :96-111, DecompressLZ4FrameHeader  LZ4.Frame.cs:107-174).
@@ -276,7 +296,12 @@ int lz4_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* d
                 }
                 bl.push_back(Lz4Block{ boff, n, raw });
             }
-            if (flg & 32) rc = run_independent(bl, bmax); else rc = run_sequential(bl, 0, frame_start, true);
+            // The managed reader keeps ONE LzWindows for all blocks of a frame whatever the independence flag says
+            // (LZ4.Frame.cs:120), so a frame that is flagged independent but whose blocks still reach into earlier output decodes
+            // there.  Blocks go out as one batch only when a walk over their sequences (host, input only) shows that none does.
+            bool indep = (flg & 32) != 0;
+            for (size_t i = 1; indep && i < bl.size(); i++) if (!bl[i].raw && lz4_block_reaches_back(src + bl[i].off, bl[i].len)) indep = false;
+            if (indep) rc = run_independent(bl, bmax); else rc = run_sequential(bl, 0, frame_start, true);
             if (rc != ALZ_OK) return rc;
             if (st == ALZ_ST_OK && trunc) st = ALZ_ST_INPUT_TRUNCATED;
             if (st != ALZ_ST_OK) break;
@@ -1328,9 +1353,27 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, co
         for (size_t k = 0; k < ss.size(); k++) {
             const Cand& c = cands[who[k]];
             if (c.off < next_free) continue;
+            const uint8_t* d_out = (uint8_t*)d_dst.p + ss[k].dst_off;
+            DevBuf d_retry(ctx);
+            if (rs[k].status != ALZ_ST_OK && (c.container == ALZ_C_YAZ0 || c.container == ALZ_C_YAZ1)) {
+                // Yaz0.Decompress catches the failure and decodes again with the size field read in the other byte order
+                // (Yaz0.cs:66-78): one more single-stream decode for this candidate
+                alz_stream s2 = ss[k];
+                s2.decom_len = __builtin_bswap32(s2.decom_len); s2.dst_cap = s2.decom_len; s2.dst_off = 0;
+                if (s2.decom_len <= kMaxStream) {
+                    if ((rc = alz_device_malloc(ctx, (size_t)s2.decom_len + 64, &d_retry.p)) != ALZ_OK) return rc;
+                    alz_plan* p2 = nullptr;
+                    if ((rc = alz_plan_create(ctx, lzp, 1, &s2, &p2)) != ALZ_OK) return rc;
+                    rc = alz_plan_execute(ctx, p2, d_src.p, d_retry.p, nullptr);
+                    if (rc == ALZ_OK) rc = alz_plan_results(ctx, p2, &rs[k]);
+                    alz_plan_destroy(ctx, p2);
+                    if (rc != ALZ_OK) return rc;
+                    d_out = (const uint8_t*)d_retry.p;
+                }
+            }
             if (rs[k].status != ALZ_ST_OK || rs[k].dst_len <= 0x10) continue;   // exception, or destination.Length <= 0x10
             if (*nhits >= max_hits || used + rs[k].dst_len > dst_cap) { if (dst_used) *dst_used = used; return ALZ_E_NOMEM; }
-            if ((rc = alz_memcpy_d2h(ctx, dst + used, (uint8_t*)d_dst.p + ss[k].dst_off, rs[k].dst_len)) != ALZ_OK) return rc;
+            if ((rc = alz_memcpy_d2h(ctx, dst + used, d_out, rs[k].dst_len)) != ALZ_OK) return rc;
             alz_scan_hit& h = hits[(*nhits)++];
             h.start = c.off; h.end = c.off + c.hdr + rs[k].src_used; h.dst_off = used; h.dst_len = rs[k].dst_len; h.container = c.container;
             used += rs[k].dst_len;

@@ -106,6 +106,18 @@ class _Format:
                     if cap >= 1 << 31:
                         raise
                     cap *= 4
+        if capacity is None and getattr(self, "size_either_order", False):
+            # Yaz0.Decompress retries with the size field byte-swapped (Yaz0.cs:66-78) into a stream that grows by itself: the
+            # capacity is the reading in FormatByteOrder unless that one is absurd, the other reading when it was not enough
+            n = self.GetDecompressedSize(data)
+            m = int.from_bytes(n.to_bytes(4, "big"), "little")
+            first = n if n <= (256 << 20) else m
+            try:
+                return self.Decompress(data, first + 273)
+            except BufferError:
+                if max(n, m) <= first or max(n, m) > (1 << 31):
+                    raise
+                return self.Decompress(data, max(n, m) + 273)
         if capacity is None:
             capacity = self.GetDecompressedSize(data) + 273
         o = self._opt()
@@ -164,6 +176,7 @@ class LZ11(_Format):
 
 
 class Yaz0(_Format):
+    size_either_order = True
     container = A.C_YAZ0
 
 
@@ -201,6 +214,7 @@ class COMP(_Format):
 
 
 class Yaz1(_Format):
+    size_either_order = True
     container = A.C_YAZ1
 
 

@@ -364,9 +364,8 @@ size_t alz_container_compress_bound(uint32_t container, size_t src_len);
  * and yields more than 0x10 bytes (:85), the walk then continues behind it (:98), otherwise at the next byte (:100).
  * Here every candidate offset is decoded in ONE GPU batch (rounds of <= 1 GiB of output) and the walk is replayed over
  * the results.  Supported: the containers with a size header and one body (LZSS, LZ10, LZ11, YAZ0, YAY0, MIO0, GCLZ,
- * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS, MDB4, FCMP, IECP, LZ40, LZ60, CNX2, CLZ0, CNS, SMSR00, HIG); the Yaz0
- * byte-order retry is not
- * attempted.
+ * CXLZ, LZ_3DS, COMP, YAZ1, AKLZ, LZ01, LZSEGA, LEVEL5LZSS, MDB4, FCMP, IECP, LZ40, LZ60, CNX2, CLZ0, CNS, SMSR00, HIG).  A Yaz0 /
+ * Yaz1 candidate that fails is decoded once more with its size field byte-swapped, as Yaz0.Decompress does (Yaz0.cs:66-78).
  * Outputs of the accepted streams are packed into dst in file order; ALZ_E_NOMEM when dst or hits is too small
  * (nhits / dst_used then describe what fitted). */
 typedef struct alz_scan_hit {

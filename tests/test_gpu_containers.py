@@ -175,6 +175,18 @@ def test_lz4_linked_frames():
     assert F.LZ4Legacy().Decompress(leg) == e2 + e2
 
 
+def test_lz4_frame_flagged_independent_whose_blocks_still_reach_back():
+    """The managed reader uses ONE LzWindows for all blocks of a frame whatever the block-independence flag says
+    (LZ4.Frame.cs:120), so such a frame decodes there: the library walks the blocks' sequences on the host and
+    decodes the frame in order when any match points in front of its block."""
+    blocks, expect = FC.lz4_linked_blocks(21, 4, 20000)
+    frame = FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 32 | 4, bd=0x40, content=expect)
+    assert O.container_decompress(A.C_LZ4_FRAME, frame, cap=len(expect) + 16) == (expect, A.ST_OK)
+    assert F.LZ4().Decompress(frame) == expect
+    # without a content checksum nothing else would have caught it
+    assert F.LZ4().Decompress(FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 32, bd=0x40)) == expect
+
+
 def test_lz4_independent_blocks_are_one_batch(test_bmp):
     """Frames with the block-independence flag and legacy files: all blocks in one GPU batch at nominal offsets; a block
     that does not fill its slot (any but the last) falls back to in-order decoding."""

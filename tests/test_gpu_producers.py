@@ -148,3 +148,19 @@ def test_brute_force(test_bmp):
             ok = o_res[0].status == A.ST_OK and o_res[0].dst_len == len(raw)
             assert res[n2][0] == ok and res[n2][1] == o_res[0].status, (name, n2)
             assert res[n2][2] == bytes(o_dst[:o_res[0].dst_len]), (name, n2)
+
+
+def test_scan_retries_a_failed_yaz0_candidate_with_the_size_byte_swapped(test_bmp):
+    """Yaz0.Decompress catches the failure of the first attempt and decodes again with the size field read in the other byte
+    order (Yaz0.cs:66-78); the scan does the same for a candidate that fails.  Size 0x00020000 reads as 0x200 big-endian, and
+    the token that crosses byte 0x200 of this stream is a long match: the first attempt overshoots its declared size."""
+    raw = test_bmp[5000:5300] + bytes(1000) + test_bmp[7000:7000 + 0x20000 - 1300]
+    assert len(raw) == 0x20000
+    body = O.encode_stream(A.FMT_YAZ0, raw, quality=8)[0]
+    first, r = O.decode_stream(A.FMT_YAZ0, body, decom_len=0x200, cap=0x200 + 300)
+    assert r.status == A.ST_OUTPUT_SIZE_MISMATCH                      # the big-endian reading fails ...
+    le_file = b"Yaz0" + (0x20000).to_bytes(4, "little") + bytes(8) + body
+    junk = bytes(range(7, 200))
+    hits = S.scan(junk + le_file + junk, [F.Yaz0])
+    assert len(hits) == 1 and hits[0][0] == len(junk) and hits[0][3] == raw and hits[0][1] == len(junk) + len(le_file)   # ... the retry decodes
+    assert F.Yaz0().Decompress(le_file) == raw                        # (Decompress itself always retried)
