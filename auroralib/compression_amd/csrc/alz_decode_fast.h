@@ -338,12 +338,12 @@ struct EmitRet { u32 produced, flushed, ovf, att_lo, att_hi; };
 // wave-uniform ones are re-scalarised on entry)
 template <class OW, class CFG>
 __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u32 lw_mask, u32 fl, u32 oshift, u32 cap, u32 produced, u32 flushed,
-                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qtok) {
+                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qtok, u32 dirty = 1u) {
     OW out;
     out.dst = reinterpret_cast<u8*>(((u64)uni((u32)((u64)dst >> 32)) << 32) | uni((u32)(u64)dst));
     out.win = win; out.lw_mask = uni(lw_mask); out.fl = uni(fl); out.oshift = uni(oshift); out.cap = uni(cap);
     out.produced = uni(produced); out.flushed = uni(flushed); out.lane = lane;
-    out.slack_dirty = true;                                  // (the exact parsers' byte-wise writers may have run in between)
+    out.slack_dirty = uni(dirty) != 0u;                      // (the exact parsers' byte-wise writers may have run in between)
     DecState s; dec_state_init(s);
     const u32 len = qtok >> 18, lo = qtok & 0x1FFFFu;
     u32 desc = lo;
@@ -352,6 +352,24 @@ __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u
     fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < uni(nt), len, desc, 0u, segmark, inlds, lane, last, uni(W));
     EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = s.ovf ? 1u : 0u;
     r.att_lo = (u32)s.attempted_end; r.att_hi = (u32)(s.attempted_end >> 32);
+    return r;
+}
+
+// out-of-line, token-by-token execution of a queue on the window (chunked configurations, see QueueSink::flush): small enough
+// to live in the caller-saved registers of the calling convention
+template <class OW>
+__device__ __attribute__((noinline)) EmitRet queue_serial_call(u8* dst, u8* win, u32 lw_mask, u32 fl, u32 oshift, u32 cap, u32 produced, u32 flushed,
+                                                               int lane, const u8* inlds, u32 W, u32 nt, u32 qtok) {
+    OW out;
+    out.dst = reinterpret_cast<u8*>(((u64)uni((u32)((u64)dst >> 32)) << 32) | uni((u32)(u64)dst));
+    out.win = win; out.lw_mask = uni(lw_mask); out.fl = uni(fl); out.oshift = uni(oshift); out.cap = uni(cap);
+    out.produced = uni(produced); out.flushed = uni(flushed); out.lane = lane; out.slack_dirty = true;
+    const u32 n = uni(nt), w = uni(W);
+    for (u32 j = 0; j < n; j++) {
+        const u32 t = wave_readlane(qtok, j), len = t >> 18, lo = t & 0x1FFFFu;
+        if (t & 0x20000u) out.copy_lds(inlds + lo, len); else out.back_copy(lo, len, w);
+    }
+    EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = 0; r.att_lo = 0; r.att_hi = 0;
     return r;
 }
 
@@ -371,6 +389,16 @@ struct QueueSink {
     __device__ __forceinline__ u32 produced() const { return out.produced + qbytes; }
     __device__ __forceinline__ void flush() {
         if (nt == 0) return;
+        if constexpr (EmitUsesChunks<CFG>::value) {
+            // Chunked configurations: the sink only serves the exact parser -- stream tails and the odd token the lane-parallel
+            // rounds decline, one or two tokens at a time -- so its queue is executed token by token on the window (E5 was
+            // checked when the tokens were queued).  The chunked phase itself is inlined ONCE, in pipelined_rounds: called out
+            // of line it needed 98 registers (4 waves per SIMD) where the inlined copy needs 80.
+            const EmitRet r = queue_serial_call<OW>(out.dst, out.win, out.lw_mask, out.fl, out.oshift, out.cap, out.produced, out.flushed, lane, inlds, W, nt, qtok);
+            out.produced = uni(r.produced); out.flushed = uni(r.flushed); out.slack_dirty = true;
+            nt = 0; qbytes = 0;
+            return;
+        }
         // ONE out-of-line copy of the byte phase per kernel: the sink operations are inlined at every token site of the
         // parsers, and inlining the byte phase there as well made 100+ KB kernels that thrash the instruction cache
         const EmitRet r = queue_emit_call<OW, CFG>(out.dst, out.win, out.lw_mask, out.fl, out.oshift, out.cap, out.produced, out.flushed,
@@ -541,15 +569,9 @@ __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState&
         qt = qt2; nt = nt2; total = total2; adv = adv2;
         continue;
 #endif
-        if constexpr (CFG::FALLBACK) {
-            EmitState e;
-            emit_begin<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, lane, last, W, e);
-            if (ahead) {
-                more = parse(p, qt2, nt2, total2, adv2);
-                if (more && total2 > maxout - (e.O + e.T)) more = false;
-            }
-            emit_finish<OW, CFG>(out, segmark, inlds, lane, e);
-        } else {                                                   // whole window in LDS: nothing to overlap, the fused byte phase is cheaper
+        {   // (round 1 parsed round k + 1 between the issue and the use of round k's HBM read-backs; the chunked phase reads a far
+            // source as one 20-byte load per chunk right where it needs it, and keeping a round's token state alive across the
+            // parse cost more registers -- a wave per SIMD -- than the overlap gained)
             (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, inlds, lane, last, W);
             if (ahead && !s.ovf) {
                 more = parse(p, qt2, nt2, total2, adv2);

@@ -239,6 +239,20 @@ struct OutWin {
         }
     }
 
+    // literal run that is already resident in LDS (a queued token of the lane-parallel parsers: `src` points into the input cache)
+    __device__ __forceinline__ void copy_lds(const u8* src, u32 len) {
+        u32 off = 0;
+        slack_dirty = true;
+        while (off < len) {
+            u32 n = len - off; if (n > fl) n = fl;
+            u32 c = produced;
+            for (u32 j = (u32)lane; j < n; j += ALZ_WAVE) win[slot(c + j)] = src[off + j];
+            wave_sync();
+            produced = c + n; off += n;
+            flush_blocks();
+        }
+    }
+
     // literal run straight from the input cache (LzWindows.CopyFrom / Write); len clipped, input residency handled here
     __device__ void copy_from(InCache& in, u32 p, u32 len) {
         u32 off = 0;

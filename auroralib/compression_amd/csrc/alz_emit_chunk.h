@@ -209,11 +209,13 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
     u32 sa;                                                 // LDS byte address of that window (ring / input cache)
     if (isrun) sa = lds_addr(inlds) + d + i0 - b;
     else sa = wbase + ((sp + out.oshift - b) & omask);
-    const u32 t = sa & 3u;
-    const lds_u8* const sbase = (const lds_u8*)(uintptr_t)(sa & ~3u);
+    // (t = sa & 3 and the aligned address are re-derived from `sa` at every read, the last dword touched at every mirror check:
+    // three registers fewer across the passes -- these kernels sit at the 80-register step of 6 waves per SIMD)
+#define ALZ_SBASE ((const lds_u8*)(uintptr_t)(sa & ~3u))
+#define ALZ_ST (sa & 3u)
+#define ALZ_JT ((b + n - 1u) >> 2)
     // ---- byte masks of the five window dwords
     const u32 bmap = ((1u << n) - 1u) << b;
-    const u32 jt = (b + n - 1u) >> 2;                       // last dword touched (0..4)
     const u32 M0 = chunk_mask(bmap, 0u), M1 = chunk_mask(bmap, 1u), M2 = chunk_mask(bmap, 2u), M3 = chunk_mask(bmap, 3u), M4 = chunk_mask(bmap, 4u);
     // ---- pass 1: every chunk
     u32 E0 = 0, E1 = 0, E2 = 0, E3 = 0, E4 = 0;
@@ -239,7 +241,7 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
             }
         }
     }
-    if (act && !far) chunk_read(sbase, t, E0, E1, E2, E3, E4);
+    if (act && !far) chunk_read(ALZ_SBASE, ALZ_ST, E0, E1, E2, E3, E4);
     if (wave_ballot(rep)) { if (rep) chunk_rep(d, b, E0, E1, E2, E3, E4); }
     // single literals: stored after the step's reads (their slots may still hold the bytes a distance == W match wants)
     if (wave_ballot(lit)) {
@@ -248,14 +250,14 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
         if (wave_ballot(lit && sl < ALZ_WIN_SLACK)) { if (lit && sl < ALZ_WIN_SLACK) win[sl + LW] = (u8)litb; }
     }
     chunk_store(act, wbase + a0, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
-    chunk_mirror(act, wbase, a0, LW, jt, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
+    chunk_mirror(act, wbase, a0, LW, ALZ_JT, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
 #ifdef ALZ_EMIT_STATS
     out.st_steps++; out.st_passes++; out.st_chunks += (u32)__popcll(wave_ballot(act)); out.st_dep += (u32)__popcll(wave_ballot(dep));
 #endif
     // ---- chunks whose source reaches into this step's own output: read again until nothing changes
     while (wave_ballot(dep)) {
         u32 N0 = E0, N1 = E1, N2 = E2, N3 = E3, N4 = E4;
-        if (dep) chunk_read(sbase, t, N0, N1, N2, N3, N4);
+        if (dep) chunk_read(ALZ_SBASE, ALZ_ST, N0, N1, N2, N3, N4);
         if (wave_ballot(rep && dep)) { if (rep && dep) chunk_rep(d, b, N0, N1, N2, N3, N4); }
         const bool wr = dep && (N0 != E0 || N1 != E1 || N2 != E2 || N3 != E3 || N4 != E4);
         if (!wave_ballot(wr)) break;
@@ -264,8 +266,11 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
 #endif
         E0 = N0; E1 = N1; E2 = N2; E3 = N3; E4 = N4;
         chunk_store(wr, wbase + a0, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
-        chunk_mirror(wr, wbase, a0, LW, jt, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
+        chunk_mirror(wr, wbase, a0, LW, ALZ_JT, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
     }
+#undef ALZ_SBASE
+#undef ALZ_ST
+#undef ALZ_JT
 }
 
 // Execution of one batch of tokens (after emit_prologue).  `scratch`: ALZ_EMIT_SCRATCH bytes of LDS (marks zeroed by the

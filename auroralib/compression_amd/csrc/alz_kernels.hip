@@ -258,7 +258,10 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 // Token-queue kernel (PRS, LZ4, LZO, Snappy, FastLZ, CNX2): lane-assisted / scalar parse into a 64-token queue, lane-parallel
 // execution (pipelined_rounds for the bulk, QueueSink behind the exact parsers).
 template <int FMT>
-__global__ __launch_bounds__(64) void alz_decode_queue_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+#ifndef ALZ_QUEUE_WAVES
+#define ALZ_QUEUE_WAVES 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_QUEUE_WAVES, 8))) void alz_decode_queue_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                               const alz_stream* __restrict__ streams,
                                                               const u32* __restrict__ index_list, u32 count,
                                                               alz_result* __restrict__ results) {
