@@ -261,7 +261,7 @@ template <int FMT>
 #ifndef ALZ_QUEUE_WAVES
 #define ALZ_QUEUE_WAVES 6
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALZ_QUEUE_WAVES, 8))) void alz_decode_queue_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_FMT_LZO ? 5 : ALZ_QUEUE_WAVES, 8))) void alz_decode_queue_kernel(   /* (LZO: 81 registers; forcing 80 spills one) */const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                               const alz_stream* __restrict__ streams,
                                                               const u32* __restrict__ index_list, u32 count,
                                                               alz_result* __restrict__ results) {
