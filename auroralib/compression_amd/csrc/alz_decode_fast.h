@@ -174,7 +174,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     }
     if (cut && __ballot(valid) == 0) { to_serial = true; return false; }
     u32 last_tend;
-    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
     if (fin) {
         s.p = p + last_tend;
         if (FMT == ALZ_FMT_LZ02) {                                // not the end of an LZ02 stream: the exact parser goes on to the terminator

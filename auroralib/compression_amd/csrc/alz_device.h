@@ -128,6 +128,7 @@ struct InCache {
 // Coordinates: ao = q + oshift, oshift = (address of dst) & 15.
 template <bool GLOBAL_FALLBACK>
 struct OutWin {
+    static constexpr bool FB = GLOBAL_FALLBACK;
     u8* dst;         // global output of this stream
     u8* win;         // LDS, LW bytes, 16 B aligned
     u32 lw_mask;     // LW - 1

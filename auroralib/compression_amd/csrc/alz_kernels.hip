@@ -143,7 +143,9 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
 
 // ------------------------------------------------------------------------------------------------
 // Lane-parallel kernel of the flag-byte family (alz_decode_fast.h); the exact serial parser finishes the tail.
-template <int FMT, int LWMAX = 4096>
+// FBK: the format's window is longer than the LDS ring (LZSS with 14..16 window bits): sources older than the ring come back
+// from the stream's own output in HBM, through the chunked byte phase, as in the 64 KiB queue kernels
+template <int FMT, int LWMAX = 4096, bool FBK = false>
 __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                              const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, u32 count,
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #endif
     constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    constexpr u32 FSCR = ALZ_CHUNKS_ALL ? ALZ_EMIT_SCRATCH : 128u, FSLACK = ALZ_CHUNKS_ALL ? ALZ_WIN_SLACK : 0u;   // (experiment build: chunked byte phase)
+    constexpr u32 FSCR = (ALZ_CHUNKS_ALL || FBK) ? ALZ_EMIT_SCRATCH : 128u, FSLACK = (ALZ_CHUNKS_ALL || FBK) ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][FSCR + NC * CACHE + LWMAX + FSLACK];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
     u8* segmark = lds;
     u8* inc_lds = lds + FSCR;
-    OutWin<false> out; out.init(dst, cap, lds + FSCR + NC * CACHE, ALZ_CHUNKS_ALL ? (u32)LWMAX : lw, lane, FSLACK);
+    typedef OutWin<FBK> OWF;
+    OWF out; out.init(dst, cap, lds + FSCR + NC * CACHE, (ALZ_CHUNKS_ALL || FBK) ? (u32)LWMAX : lw, lane, FSLACK);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         // exact parser while a match could still point beyond the span (an error here, not zeros) and for the end of the
         // stream (matches cut at the span end, the span-must-be-full rule); LZ10's lane-parallel loop in between, kept away
         // from the span end by more than one iteration can produce (64 tokens x 18 bytes)
-        typedef DirectSink<OutWin<false>> SK; SK sk(out, s);
+        typedef DirectSink<OWF> SK; SK sk(out, s);
         const u32 L = size < cap ? size : cap;
         dec_blz_serial(in, sk, s, src_len, L, 4098u);
         if (!s.eof && !s.bad && !s.ovf) {
@@ -201,17 +204,17 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
         bool to_serial = false;
         while (!s.ovf && !to_serial && out.produced < cap && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, cap, src_len, to_serial, segmark, lane, gm);
-        if (!s.ovf) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_lz02_serial(in, sk, s, src_len); }
+        if (!s.ovf) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_lz02_serial(in, sk, s, src_len); }
     } else if constexpr (FMT == ALZ_FMT_LZHUDSON) {
         while (!fin && out.produced < size && (u64)s.p + 128u <= src_len) fin = fast_iter_lzhudson(in, out, s, size, segmark, lane);
-        if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
+        if (!fin) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
     } else if constexpr (!THREE) {
         FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
         gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
         bool to_serial = false;   // the fast loop runs to the last complete token of the input; the exact parser finishes
         while (!fin && !to_serial && out.produced < size && s.p < src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, src_len, to_serial, segmark, lane, gm);
         if (!fin) {
-            typedef DirectSink<OutWin<false>> SK;
+            typedef DirectSink<OWF> SK;
             SK sk(out, s);
             if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, sk, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
             else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
             while (!fin && out.produced < size && (u64)cp + 136u <= a0 && (u64)up + 64u <= src_len)
                 fin = fast_iter_smsr00(in, uin, out, s, size, segmark, lane, cp, up);
             used = up;
-            if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); dec_smsr00_serial(in, uin, sk, s, src_len, size, a0, used, cp, up); }
+            if (!fin) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_smsr00_serial(in, uin, sk, s, src_len, size, a0, used, cp, up); }
             used_set = true;
         }
     } else {
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
             while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len)
                 fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, segmark, lane, fp, cp, up);
             used = cp > up ? cp : up;
-            if (!fin) { typedef DirectSink<OutWin<false>> SK; SK sk(out, s); used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up); }
+            if (!fin) { typedef DirectSink<OWF> SK; SK sk(out, s); used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up); }
             used_set = true;
         }
     }
@@ -488,13 +491,13 @@ static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, cons
     return hipGetLastError();
 }
 
-template <int FMT, int LWMAX = 4096>
+template <int FMT, int LWMAX = 4096, bool FBK = false>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
     (void)ncaches;
     static int pad = -1;
     if (pad < 0) { const char* e = getenv("ALZ_OCC_PAD"); pad = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
 
@@ -550,6 +553,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
             // LDS window sized for the geometry: 4 KiB windows (the LZSS default and every wrapper) keep 24 waves per CU
             if (W <= 4096 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096>(stream, s, d, streams, index, count, results, lz, W, 1);
             if (W <= 8192 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 8192>(stream, s, d, streams, index, count, results, lz, W, 1);
+            if (W <= 65536 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096, true>(stream, s, d, streams, index, count, results, lz, W, 1);   // 14..16 window bits (LzProperties.cs:57-66)
             break;
         }
         case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1);

@@ -65,6 +65,26 @@ def test_lzss_geometries():
         compare_batch(b.streams, b.src, b.dst_bytes, lz=lz, what="lzss%r" % (bits,))
 
 
+@pytest.mark.parametrize("bits", [(14, 4, 2), (15, 6, 2), (16, 8, 2)])
+def test_lzss_windows_beyond_the_lds_ring(bits, test_bmp):
+    """14..16 window bits (LzProperties.cs:57-66): the lane-parallel kernel keeps 4 KiB of the window in LDS and reads older
+    sources back from the stream's own output (chunked byte phase) -- full-length synthetic streams, whose distances reach the
+    whole window, and oracle-encoded Test.bmp at two qualities; truncation and capacity cuts included."""
+    lz = A.LzProperties.from_bits(*bits)
+    b = synth.make_batch(A.FMT_LZSS, 48, np.array([262144, 70000, 200000, 65537] * 12, dtype=np.uint32), synth.seed_for(71, bits[0]), lz=lz)
+    compare_batch(b.streams, b.src, b.dst_bytes, lz=lz, what="wide lzss%r" % (bits,))
+    items = []
+    for off, size, q in [(0, 300000, 8), (50000, 262144, 0), (7, 100000, 15)]:
+        raw = test_bmp[off:off + size]
+        body, _ = O.encode_stream(A.FMT_LZSS, raw, quality=q, lz=lz)
+        items.append(dict(fmt=A.FMT_LZSS, src=body, decom_len=size))
+        items.append(dict(fmt=A.FMT_LZSS, src=body[:len(body) * 2 // 3], decom_len=size))            # truncated
+        items.append(dict(fmt=A.FMT_LZSS, src=body, decom_len=size, cap=size // 2))                  # capacity
+        items.append(dict(fmt=A.FMT_LZSS, src=body, decom_len=size - 1000, cap=size))                # declared size too small
+    streams, src, dst_bytes = pack_streams(items)
+    compare_batch(streams, src, dst_bytes, lz=lz, what="wide lzss bmp%r" % (bits,))
+
+
 @pytest.mark.parametrize("fmt", ALL)
 def test_real_data_roundtrip(fmt, test_bmp):
     """Oracle-encoded windows of Test.bmp (the reference's round-trip corpus) decode bit-exactly on the GPU."""
