@@ -109,6 +109,110 @@ __global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src
     }
 }
 
+// Kernel A, hash-partitioned (round 2): NC wavefronts per stream; wavefront `cls` owns the positions whose hash has
+// (h & (NC - 1)) == cls.  The classes touch disjoint head-table entries, so the wavefronts of a stream never talk to each
+// other, and each of them walks only 1 / NC of the table steps -- the dependent HBM round trips that make one stream take
+// 18 ms whatever the device does meanwhile.  Every wavefront still scans the whole input (a dword pair + v_alignbyte per
+// position: cheap next to a table round trip) and queues its own positions, in order, until 64 are there.
+// (Not for the min-length table of quality >= 10: that one is keyed by another hash.)
+template <int NC>
+__global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                            const u32* __restrict__ index_list, u32 count,
+                                                            int* __restrict__ head4_all, int* __restrict__ prev4,
+                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    __shared__ u8 slot_owner[256];
+    __shared__ u8 slot_flag[256];
+    __shared__ u32 qpos[320], qh[320];
+    const u32 bid = blockIdx.x / NC, cls = blockIdx.x % NC;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;
+    int* head = head4_all + ((size_t)bid << g.hash_bits);
+    int* p4 = prev4 + pos_off[sid];
+    for (int i = lane; i < 256; i += 64) slot_flag[i] = 0;
+    __syncthreads();
+    u32 qn = 0;
+    for (int c = 0; c <= limit || qn; c += 256) {
+        if (c <= limit) {
+            // four groups of 64 positions per trip: their eight loads are in flight together
+            u32 hh[4]; bool ac[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int pos = c + 64 * k + lane;
+                ac[k] = pos <= limit;
+                u32 v = 0;
+                if (ac[k]) {
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(data + pos);
+                    const u32* w = reinterpret_cast<const u32*>(a & ~(uintptr_t)3);
+                    v = __builtin_amdgcn_alignbyte(w[1], w[0], (u32)(a & 3));            // (source buffers carry 64 bytes of slack)
+                }
+                hh[k] = ((v * 2654435761u) >> (32 - g.hash_bits)) & ((1u << g.hash_bits) - 1u);   // ComputeHash  LzChainMatchFinder.cs:288-299
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool mine = ac[k] && (hh[k] & (u32)(NC - 1)) == cls;
+                const u64 m = __ballot(mine);
+                if (mine) { const u32 r = qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); qpos[r] = (u32)(c + 64 * k + lane); qh[r] = hh[k]; }
+                qn += (u32)__popcll(m);
+            }
+            __syncthreads();
+        }
+        const bool last = c + 256 > limit;
+        while (qn >= 64u || (last && qn)) {
+            const u32 nstep = qn < 64u ? qn : 64u;
+            const bool act = (u32)lane < nstep;
+            const u32 h = act ? qh[lane] : 0u;
+            const int pos = act ? (int)qpos[lane] : 0;
+            // lanes that share a hash inside this step must see each other in position order
+            const u32 slot = (h >> 3) & 255u;                     // (the low bits are the class)
+            if (act) slot_owner[slot] = (u8)lane;
+            __syncthreads();
+            const bool lost = act && slot_owner[slot] != (u8)lane;
+            if (lost) slot_flag[slot] = 1;
+            __syncthreads();
+            const bool contested = act && slot_flag[slot] != 0;
+            __syncthreads();
+            if (lost) slot_flag[slot] = 0;
+            int old = -1;
+            if (act) old = __hip_atomic_load(&head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int prev = old;
+            bool writer = act;
+            u64 todo = __ballot(contested);
+            while (todo) {
+                const int l0 = (int)__builtin_ctzll(todo);
+                const u32 hv = (u32)__builtin_amdgcn_readlane((int)h, l0);
+                const u64 grp = __ballot(contested && h == hv);
+                const u64 below = grp & ((1ull << lane) - 1ull);
+                const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
+                const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);   // position of the next lower lane of my group
+                if (contested && h == hv) {
+                    if (below) prev = pp;
+                    writer = (grp >> lane) <= 1ull;                    // highest lane of the group owns the new head
+                }
+                todo &= ~grp;
+            }
+            if (writer) head[h] = pos;
+            if (act) p4[pos] = prev;
+            // the rest of the queue moves down
+            for (u32 base = 0; 64u + base < qn; base += 64u) {          // (in place, front to back: a slice is read before it is overwritten)
+                const bool mv = 64u + base + (u32)lane < qn;
+                u32 mv_p = 0, mv_h = 0;
+                if (mv) { mv_p = qpos[64u + base + lane]; mv_h = qh[64u + base + lane]; }
+                __syncthreads();
+                if (mv) { qpos[base + lane] = mv_p; qh[base + lane] = mv_h; }
+                __syncthreads();
+            }
+            qn -= nstep;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // head stores reach L2 before the next step reads them
+            __syncthreads();
+        }
+    }
+}
+
 // Kernel A for windows up to 4 KiB: the same prev() links, from LDS instead of per-stream head tables in HBM.  A candidate
 // further back than maxDistance ends every chain walk of kernel B (`dist > g.max_dist: break`), so only the most recent
 // 4096 positions have to be remembered -- and for those a hash table with chaining fits the LDS: T[hash & 4095] = ring
@@ -1089,7 +1193,25 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         else hipLaunchKernelGGL((enc_prev_lds_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     }
     else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
-    else hipLaunchKernelGGL((enc_prev_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
+    else {
+        // Experiment knobs (round 2, tools/enc_split.sh; both bit-identical, neither pays): ALZ_ENC_SPLIT = wavefronts per stream of the
+        // hash-partitioned kernel A, ALZ_ENC_ACHUNK = streams per pass of kernel A with the head tables reused from pass to pass
+        // (256 streams x 128 KB fit the L2 caches).  cfg5 at Q0, all kernels: 141 ms as is; 131-139 with 2 / 4 / 8 wavefronts per
+        // stream; 140-188 with passes of 1 024 / 512 / 256 streams.  So neither the chain of dependent table round trips per stream
+        // nor the HBM sector traffic alone is what bounds kernel A at 10 000 streams.
+        static const int split = getenv("ALZ_ENC_SPLIT") ? atoi(getenv("ALZ_ENC_SPLIT")) : 1;      // wavefronts per stream (1, 2, 4, 8)
+        static const int ach_env = getenv("ALZ_ENC_ACHUNK") ? atoi(getenv("ALZ_ENC_ACHUNK")) : 0;  // streams per pass of kernel A (0: all)
+        const u32 ach = ach_env > 0 ? (u32)ach_env : count;
+        for (u32 off = 0; off < count; off += ach) {
+            const u32 k = count - off < ach ? count - off : ach;
+            if (off) (void)hipMemsetAsync(d_head4, 0xFF, ((size_t)k << g.hash_bits) * sizeof(int), stream);   // (the caller reset it for the first pass)
+            const u32* ix = d_index + off;
+            if (split >= 8) hipLaunchKernelGGL((enc_prev_split_kernel<8>), dim3(k * 8u), dim3(64), 0, stream, src, d_streams, ix, k, d_head4, d_prev4, d_pos_off, g, tail);
+            else if (split >= 4) hipLaunchKernelGGL((enc_prev_split_kernel<4>), dim3(k * 4u), dim3(64), 0, stream, src, d_streams, ix, k, d_head4, d_prev4, d_pos_off, g, tail);
+            else if (split >= 2) hipLaunchKernelGGL((enc_prev_split_kernel<2>), dim3(k * 2u), dim3(64), 0, stream, src, d_streams, ix, k, d_head4, d_prev4, d_pos_off, g, tail);
+            else hipLaunchKernelGGL((enc_prev_kernel<false>), dim3(k), dim3(64), 0, stream, src, d_streams, ix, k, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
+        }
+    }
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
     else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
