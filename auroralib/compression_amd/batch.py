@@ -58,10 +58,14 @@ class Context:
         return v.value
 
     # ---- host-buffer decode (upload, decode on GPU, download)
-    def decode_batch(self, streams, src, dst_bytes, lz=None):
+    def decode_batch(self, streams, src, dst_bytes, lz=None, dst=None):
+        """alz_decode_batch on host buffers.  `dst`: a caller-owned uint8 array of >= dst_bytes to decode into (default: a new one)."""
         n = len(streams)
         src = np.ascontiguousarray(src, dtype=np.uint8)
-        dst = np.zeros(max(dst_bytes, 1), dtype=np.uint8)
+        if dst is None:
+            dst = np.zeros(max(dst_bytes, 1), dtype=np.uint8)
+        elif dst.dtype != np.uint8 or not dst.flags.c_contiguous or dst.nbytes < dst_bytes:
+            raise ValueError("dst must be a contiguous uint8 array of at least dst_bytes")
         res = (A.Result * n)()
         check(self.lib.alz_decode_batch(self.h, C.byref(lz) if lz is not None else None, n, _vp(src), src.nbytes, streams, _vp(dst), dst_bytes, res))
         return dst, res

@@ -7,14 +7,71 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
+#include <sched.h>
 
 #include "alz_internal.h"
 
 static thread_local char g_err[512] = "";
+
+// Host copies between the caller's (pageable) buffers and the pinned staging buffers run on a few threads: one core moves
+// ~10 GB/s, a PCIe 5 x16 link ~55 GB/s, so a single memcpy loop left the link idle three quarters of the time.  One pool per
+// context (the multi-GPU entry points drive one context per device from their own threads).  ALZ_COPY_THREADS overrides the
+// thread count (1 = copy inline).
+struct copy_job { uint8_t* dst; const uint8_t* src; size_t len; };
+class copy_pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    const copy_job* jobs = nullptr; size_t njobs = 0;
+    std::atomic<size_t> next{0};
+    size_t pending = 0; uint64_t gen = 0; bool stop = false;
+    void work() { for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < njobs;) memcpy(jobs[i].dst, jobs[i].src, jobs[i].len); }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            work();
+            { std::lock_guard<std::mutex> l(m); if (--pending == 0) done_cv.notify_one(); }
+        }
+    }
+public:
+    static int default_threads() {
+        if (const char* e = getenv("ALZ_COPY_THREADS")) { const int v = atoi(e); return v < 1 ? 1 : (v > 64 ? 64 : v); }
+        cpu_set_t set; int n = 1;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+        n /= 2;
+        return n < 1 ? 1 : (n > 16 ? 16 : n);
+    }
+    explicit copy_pool(int nthreads) { for (int i = 1; i < nthreads; i++) th.emplace_back([this] { loop(); }); }
+    ~copy_pool() {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv.notify_all();
+        for (std::thread& t : th) t.join();
+    }
+    // runs every job; returns when all are done (the calling thread takes its share)
+    void run(const std::vector<copy_job>& v) {
+        size_t bytes = 0;
+        for (const copy_job& j : v) bytes += j.len;
+        if (th.empty() || bytes < (1u << 20)) { for (const copy_job& j : v) memcpy(j.dst, j.src, j.len); return; }
+        { std::lock_guard<std::mutex> l(m); jobs = v.data(); njobs = v.size(); next.store(0); pending = th.size(); gen++; }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(m);
+        done_cv.wait(l, [&] { return pending == 0; });
+    }
+};
+// one copy, cut into pieces the pool can spread
+static void add_copy(std::vector<copy_job>& v, uint8_t* dst, const uint8_t* src, size_t len) {
+    const size_t piece = 1u << 20;
+    for (size_t o = 0; o < len; o += piece) v.push_back(copy_job{dst + o, src + o, len - o < piece ? len - o : piece});
+}
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -42,6 +99,9 @@ struct alz_ctx {
     // grow-only scratch of download_packed (item table + dense copy)
     void* d_items = nullptr; size_t d_items_cap = 0;
     void* d_pack = nullptr; size_t d_pack_cap = 0;
+    copy_pool* pool = nullptr;                 // created with the pinned buffers
+    std::vector<copy_job> jobs;                // (scratch of the staging loops)
+    void copy(uint8_t* dst, const uint8_t* src, size_t len) { jobs.clear(); add_copy(jobs, dst, src, len); pool->run(jobs); }
 };
 
 static const size_t kPinBytes = 32u << 20;
@@ -114,6 +174,7 @@ void alz_destroy(alz_ctx* c) {
     if (c->fork) (void)hipEventDestroy(c->fork);
     for (int i = 0; i < 4; i++) { if (c->join[i]) (void)hipEventDestroy(c->join[i]); if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c->pool;
     delete c;
 }
 
@@ -280,12 +341,14 @@ int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
 static inline bool range_ok(uint64_t off, uint64_t len, uint64_t total) { return off <= total && len <= total - off; }
 
 static int ensure_pinned(alz_ctx* c) {
-    if (c->pin[0]) return ALZ_OK;
+    if (c->pin_cap) return ALZ_OK;
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        if (!c->pin[i]) HIP_TRY(hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
+        if (!c->pin_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
     }
-    c->pin_cap = kPinBytes;
+    if (!c->pool) c->pool = new (std::nothrow) copy_pool(copy_pool::default_threads());
+    if (!c->pool) return fail(ALZ_E_NOMEM, "out of memory");
+    c->pin_cap = kPinBytes;                                  // (set last: everything above exists from here on)
     return ALZ_OK;
 }
 // host (pageable) -> device through the two pinned buffers: the memcpy of piece k + 1 overlaps the DMA of piece k
@@ -299,7 +362,7 @@ static int staged_h2d(alz_ctx* c, void* d_dst, const uint8_t* h_src, size_t byte
     while (done < bytes) {
         const size_t n = bytes - done < c->pin_cap ? bytes - done : c->pin_cap;
         if (used[k]) HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
-        memcpy(c->pin[k], h_src + done, n);
+        c->copy((uint8_t*)c->pin[k], h_src + done, n);
         HIP_TRY(hipMemcpyAsync((uint8_t*)d_dst + done, c->pin[k], n, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
         used[k] = true; done += n; k ^= 1;
@@ -326,7 +389,7 @@ static int staged_d2h(alz_ctx* c, uint8_t* h_dst, const void* d_src, size_t byte
             HIP_TRY(hipEventRecord(c->pin_ev[k ^ 1], c->stream)); len[k ^ 1] = n; issued += n;
         }
         HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
-        memcpy(h_dst + copied, c->pin[k], len[k]);
+        c->copy(h_dst + copied, (const uint8_t*)c->pin[k], len[k]);
         copied += len[k]; k ^= 1;
     }
     return ALZ_OK;
@@ -383,7 +446,9 @@ static bool download_packed(alz_ctx* c, const std::vector<out_seg>& segs) {
     }
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
     if (staged_d2h(c, bounce.data(), c->d_pack, cur) != ALZ_OK) { (void)hipGetLastError(); return false; }
-    for (size_t i = 0; i < segs.size(); i++) memcpy(segs[i].host, bounce.data() + items[i].to, segs[i].len);
+    c->jobs.clear();
+    for (size_t i = 0; i < segs.size(); i++) add_copy(c->jobs, segs[i].host, bounce.data() + items[i].to, segs[i].len);
+    if (c->pool) c->pool->run(c->jobs); else for (const copy_job& j : c->jobs) memcpy(j.dst, j.src, j.len);
     return true;
 }
 
@@ -424,10 +489,12 @@ static int download_segs(alz_ctx* c, std::vector<out_seg>& segs) {
         HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
         const uint64_t a = lo + w * W, b = a + W;
         while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
+        c->jobs.clear();
         for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
             const uint64_t s0 = segs[i].dev > a ? segs[i].dev : a, s1 = segs[i].dev + segs[i].len < b ? segs[i].dev + segs[i].len : b;
-            if (s1 > s0) memcpy(segs[i].host + (s0 - segs[i].dev), (const uint8_t*)c->pin[k] + (s0 - a), s1 - s0);
+            if (s1 > s0) add_copy(c->jobs, segs[i].host + (s0 - segs[i].dev), (const uint8_t*)c->pin[k] + (s0 - a), s1 - s0);
         }
+        c->pool->run(c->jobs);
     }
     return ALZ_OK;
 }
@@ -623,10 +690,12 @@ static int upload_segs(alz_ctx* c, void* d_base, const std::vector<in_seg>& segs
         const uint64_t b = a + W < total ? a + W : total;
         if (used[k]) HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
         while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
+        c->jobs.clear();
         for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
             const uint64_t s0 = segs[i].dev > a ? segs[i].dev : a, s1 = segs[i].dev + segs[i].len < b ? segs[i].dev + segs[i].len : b;
-            if (s1 > s0) memcpy((uint8_t*)c->pin[k] + (s0 - a), segs[i].host + (s0 - segs[i].dev), s1 - s0);
+            if (s1 > s0) add_copy(c->jobs, (uint8_t*)c->pin[k] + (s0 - a), segs[i].host + (s0 - segs[i].dev), s1 - s0);
         }
+        c->pool->run(c->jobs);
         HIP_TRY(hipMemcpyAsync((uint8_t*)d_base + a, c->pin[k], b - a, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
         used[k] = true;
