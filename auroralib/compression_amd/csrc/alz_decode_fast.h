@@ -35,6 +35,12 @@
 #ifndef ALZ_QRUN
 #define ALZ_QRUN 200u   /* longest literal run / element a lane-parallel round takes: window (256) + element stay inside one 512-byte cache chunk */
 #endif
+#ifndef ALZ_WIDE_FLAT
+#define ALZ_WIDE_FLAT 1   /* groups start in the first 128 (not 64) input bytes of an iteration: formats without a group walk (LZSS, LZ10, CLZ0, BLZ) */
+#endif
+#ifndef ALZ_WIDE_WALK
+#define ALZ_WIDE_WALK 1   /* ... and formats with one (LZ11, Yaz0, LZ40, LZ02): a second speculative walk per lane */
+#endif
 #ifndef ALZ_NB
 #define ALZ_NB 8    /* steps whose HBM read-backs are issued together (two-pass byte phase of the 64 KiB formats) */
 #endif
@@ -73,47 +79,62 @@ __device__ __forceinline__ u32 mask_window(u64 lo, u64 hi, int i) {
 template <int FMT, class OW>
 __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecState& s, u32 size, u32 src_len, bool& to_serial, u8* segmark, int lane, const FastGeom& gm) {
     typedef FamTraits<FMT> TR;
+    constexpr bool WALK = TR::H3 || TR::H4;
+    // WIDE: groups may start anywhere in the first 128 input bytes instead of the first 64 (every lane speculates for two
+    // bytes).  With ~13 input bytes per group only five of the eight group slots were filled per iteration; the fixed cost of
+    // an iteration (chain, token decode, prologue) is now spread over all eight.
+    constexpr bool WIDE = WALK ? (ALZ_WIDE_WALK != 0) : (ALZ_WIDE_FLAT != 0);
     const u32 p = s.p;
-    in.ensure(p, 128);
+    in.ensure(p, WIDE ? 224 : 128);
     const u32 x0 = in.byte_at(p + (u32)lane), x1 = in.byte_at(p + 64u + (u32)lane);
-    u32 l3 = 0, l4 = 0;
-    const u32 n0 = TR::NIBLO ? (x0 & 0xFu) : (x0 >> 4), n1 = TR::NIBLO ? (x1 & 0xFu) : (x1 >> 4);
-    if (TR::H3) { u64 lo = __ballot(n0 == 0), hi = __ballot(n1 == 0); l3 = mask_window(lo, hi, lane); }
-    if (TR::H4) { u64 lo = __ballot(n0 == 1), hi = __ballot(n1 == 1); l4 = mask_window(lo, hi, lane); }
-    // speculative walk of "the group that starts at byte p + lane": group size + what a token lane needs to find its
+    u32 l3 = 0, l4 = 0, l3b = 0, l4b = 0;
+    if (WALK) {
+        const u32 n0 = TR::NIBLO ? (x0 & 0xFu) : (x0 >> 4), n1 = TR::NIBLO ? (x1 & 0xFu) : (x1 >> 4);
+        u32 n2 = 0;
+        if (WIDE) { const u32 x2 = in.byte_at(p + 128u + (u32)lane); n2 = TR::NIBLO ? (x2 & 0xFu) : (x2 >> 4); }
+        if (TR::H3) { const u64 lo = __ballot(n0 == 0), hi = __ballot(n1 == 0); l3 = mask_window(lo, hi, lane); if (WIDE) l3b = mask_window(hi, __ballot(n2 == 0), lane); }
+        if (TR::H4) { const u64 lo = __ballot(n0 == 1), hi = __ballot(n1 == 1); l4 = mask_window(lo, hi, lane); if (WIDE) l4b = mask_window(hi, __ballot(n2 == 1), lane); }
+    }
+    // speculative walk of "the group that starts at byte xb": group size + what a token lane needs to find its
     // offset.  Formats whose token size depends only on the flag bit (LZSS, LZ10) need no walk at all: the offset of token
     // k is 1 + k + popcount(match bits before k).  Otherwise `info` packs (token size - 1) as 8 nibbles and a token lane
     // sums the nibbles below its own with one v_dot8_u32_u4.
-    const u32 mbits = TR::NEG ? ((0u - x0) & 0xFFu) : (TR::LIT1 ? (~x0 & 0xFFu) : x0);   // bit set = match token
-    u32 gsize, info;
-    if (!TR::H3 && !TR::H4) { gsize = 9u + (u32)__popc(mbits); info = mbits; }
-    else {
-        u32 r = 1; info = 0;
+    auto spec = [&](u32 xb, u32 w3, u32 w4, u32& gsize, u32& info) {
+        const u32 mbits = TR::NEG ? ((0u - xb) & 0xFFu) : (TR::LIT1 ? (~xb & 0xFFu) : xb);   // bit set = match token
+        if (!WALK) { gsize = 9u + (u32)__popc(mbits); info = mbits; }
+        else {
+            u32 r = 1; info = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const u32 m = (mbits >> (TR::MSB ? 7 - k : k)) & 1u;
-            u32 extra = m;
-            if (TR::H3) extra += m & (l3 >> r);
-            if (TR::H4) extra += (m & (l4 >> r)) << 1;
-            info |= extra << (4 * k);
-            r += 1u + extra;
+            for (int k = 0; k < 8; k++) {
+                const u32 m = (mbits >> (TR::MSB ? 7 - k : k)) & 1u;
+                u32 extra = m;
+                if (TR::H3) extra += m & (w3 >> r);
+                if (TR::H4) extra += (m & (w4 >> r)) << 1;
+                info |= extra << (4 * k);
+                r += 1u + extra;
+            }
+            gsize = r;
         }
-        gsize = r;
-    }
+    };
+    u32 gsize, info, gsize1 = 0, info1 = 0;
+    spec(x0, l3, l4, gsize, info);
+    if (WIDE) spec(x1, l3b, l4b, gsize1, info1);
     // real group chain
     u32 g = 0, ng = 0, gstart = 0;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-        if (g < 64u) {
+        if (g < (WIDE ? 128u : 64u)) {
             if ((lane >> 3) == it) gstart = g;
-            g += wave_readlane(gsize, g);
+            if (WIDE) g += g < 64u ? wave_readlane(gsize, g) : wave_readlane(gsize1, g - 64u);
+            else g += wave_readlane(gsize, g);
             ng = (u32)it + 1u;
         }
     }
     // lane 8j+k = token k of group j
     const u32 k = (u32)lane & 7u;
     const bool ingroup = ((u32)lane >> 3) < ng;
-    const u32 inf = wave_bperm(gstart, info);
+    u32 inf = wave_bperm(gstart & 63u, info);
+    if (WIDE) { const u32 inf1 = wave_bperm(gstart & 63u, info1); inf = gstart < 64u ? inf : inf1; }
     u32 m, to;
     if (!TR::H3 && !TR::H4) {
         m = (inf >> (TR::MSB ? 7u - k : k)) & 1u;
