@@ -48,6 +48,57 @@ def test_cfg3_lz4_blocks_256k():
     _decode_and_compare(A.FMT_LZ4_BLOCK, 10000, 262144, synth.seed_for(3))
 
 
+def test_cfg3_lz4_100000_blocks_full_count():
+    """BASELINE configs[2] at its stated count: 100 000 independent LZ4 blocks x 256 KiB decoded as ONE device-resident batch
+    (24.4 GiB of output), generated part by part like bench.py's cfg3 entry.  Every status / length / src_used is compared with
+    the oracle's, and every part is downloaded and compared byte for byte (the oracle decodes a 2.4 GiB part in seconds on the
+    host cores)."""
+    import ctypes as C
+    from auroralib.compression_amd.batch import Plan
+    c = ctx()
+    n, size, parts = 100000, 262144, 10
+    per = n // parts
+    streams = (A.Stream * n)()
+    rec = synth.stream_records(streams)
+    batches, offs, src_total = [], [], 0
+    for p in range(parts):
+        b = synth.make_batch(A.FMT_LZ4_BLOCK, per, size, synth.seed_for(3) + p * per)
+        r = synth.stream_records(b.streams)
+        sl = slice(p * per, (p + 1) * per)
+        rec["src_off"][sl] = r["src_off"] + src_total
+        rec["src_len"][sl], rec["dst_cap"][sl], rec["decom_len"][sl], rec["format"][sl] = r["src_len"], size, size, A.FMT_LZ4_BLOCK
+        rec["dst_off"][sl] = (np.arange(per, dtype=np.uint64) + np.uint64(p * per)) * np.uint64(size)
+        batches.append(b); offs.append(src_total)
+        src_total += (b.src.nbytes + 63) // 64 * 64
+    d_src, d_dst = c.malloc(src_total + 64), c.malloc(n * size + 64)
+    plan = None
+    try:
+        for b, off in zip(batches, offs):
+            c.h2d(C.c_void_p(d_src.value + off), b.src)
+        plan = Plan(c, streams)
+        plan.execute(d_src, d_dst)
+        c.synchronize()
+        gr = synth.result_records(plan.results())
+        assert (gr["status"] == 0).all() and (gr["dst_len"] == size).all()
+        sums = []
+        for p, b in enumerate(batches):
+            o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes, nthreads=min(CORES, 32))
+            orr = synth.result_records(o_res)
+            sl = slice(p * per, (p + 1) * per)
+            for f in ("status", "dst_len", "src_used"):
+                assert np.array_equal(gr[f][sl], orr[f]), (p, f)
+            r = synth.stream_records(b.streams)
+            assert (r["dst_off"] == np.arange(per, dtype=np.uint64) * np.uint64(size)).all()      # the generator packs its outputs
+            g = c.d2h(d_dst, per * size, offset=p * per * size)
+            assert np.array_equal(g, o_dst[:per * size]), p
+            sums.append(O.xxh64(g[::64].tobytes()))
+        assert len(set(sums)) == parts                            # (ten different parts)
+    finally:
+        if plan is not None:
+            plan.close()
+        c.free(d_src); c.free(d_dst)
+
+
 def test_cfg4_mixed_shard():
     """What each of 8 GPUs gets of cfg4's 40 000 mixed streams: 5 000, formats interleaved, per-format kernel dispatch."""
     n = 5000
