@@ -282,6 +282,7 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
     return ALZ_OK;
 }
 
+static uint32_t format_weight(uint32_t fmt);
 int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, void* hip_stream) {
     if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
     HIP_TRY(hipSetDevice(c->device));                 // (a host thread may hold contexts of several devices)
@@ -299,9 +300,15 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     // mixed batch: one kernel per format, forked onto side streams so that they share the GPU (each format alone may
     // have far fewer streams than the device has wave slots), joined back into the caller's stream -- also when a launch
     // fails half way (the side streams that already started are joined, then the error is reported)
+    // The format whose streams take longest goes first (PRS before the flag-byte family): a launch ends with its slowest
+    // stream, and a stream's own time hardly depends on how many others of its format there are.
+    int order[ALZ_FMT_COUNT];
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) order[f] = f;
+    std::stable_sort(order, order + ALZ_FMT_COUNT, [](int a, int b) { return format_weight((uint32_t)a) > format_weight((uint32_t)b); });
     HIP_TRY(hipEventRecord(c->fork, s));
     int k = 0, rc = ALZ_OK; bool used[4] = {false, false, false, false};
-    for (int f = 0; f < ALZ_FMT_COUNT && rc == ALZ_OK; f++) {
+    for (int oi = 0; oi < ALZ_FMT_COUNT && rc == ALZ_OK; oi++) {
+        const int f = order[oi];
         if (!p->fmt_cnt[f]) continue;
         hipStream_t a = c->aux[k & 3];
         if (!used[k & 3]) {
