@@ -1216,28 +1216,28 @@ __device__ __forceinline__ void prs_from_norm(u32 fl, u32& bits, u32& flag) {
     flag = BIG ? (__builtin_bitreverse32(r) >> (32u - nb)) : (r << (8u - nb));
 }
 
-// Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p, cache covers [p, p + chunk).  `fl` is the normalised flag
-// register (prs_to_norm).  Returns false (state untouched) when nothing could be parsed or the batch does not fit dst.
-template <class SK, bool BIG>
-__device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32& fl_io) {
-    const u32 p = s.p;
-    const u32 i0 = in.idx(p) + (u32)lane;
-    const u32 x0 = in.lds[i0], x1 = in.lds[i0 + 1], x2 = in.lds[i0 + 2];
+// One window of the walk: the 64 input bytes at cache index i0 (lane = byte), tokens that START at window positions <= limit
+// (<= 60: a token's last flag / data byte then still lies inside the window).  Returns the position behind the last token taken,
+// the flag register, the terminator flag and -- per lane -- the token "its" byte turned out to be (tokm: the bytes that are one).
+template <bool BIG>
+__device__ __forceinline__ void prs_walk_window(const InCache& in, u32 i0, int lane, u32 limit, u32& pos_out, u32& fl_io, u32& term_out, u64& tokm, u32& tok_out) {
+    const u32 x0 = in.lds[i0 + (u32)lane], x1 = in.lds[i0 + (u32)lane + 1], x2 = in.lds[i0 + (u32)lane + 2];
     const u32 xf = (BIG ? (__builtin_bitreverse32(x0) >> 24) : x0) | 0x100u;           // flag byte in consumption order + sentinel
     const u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);                             // long match word  PRS.cs:75-77
     const u64 zerom = __ballot(v == 0u);                                                // terminator
     const u64 extm = __ballot((v & 7u) == 0u);                                          // length in a third byte
     u64 litm = 0, shm = 0, lgm = 0, hm = 0, lm = 0;
-    u32 pos = 0, fl = fl_io, term = 0, t0, t1;
+    u32 pos = 0, fl = fl_io, term = 0;
+    u32 t4;
+    u64 t0 = 0, t1 = 0, t23;                                 // (64-bit: the walk shifts them into the hm / lm masks)
+    // (the common path of every token type falls through its flag-register checks: the reloads -- one control bit in eight -- sit
+    // out of line, so a literal costs ONE taken branch, the loop's own)
     asm volatile(
         "Lprs_top_%=:\n\t"
-        "s_cmp_gt_u32 %[pos], 60\n\t"
+        "s_cmp_gt_u32 %[pos], %[limit]\n\t"
         "s_cbranch_scc1 Lprs_end_%=\n\t"
         "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc0 Lprs_a_%=\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n"
+        "s_cbranch_scc1 Lprs_ra_%=\n"
         "Lprs_a_%=:\n\t"
         "s_bitcmp1_b32 %[fl], 0\n\t"
         "s_cbranch_scc0 Lprs_match_%=\n\t"
@@ -1248,10 +1248,7 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
         "Lprs_match_%=:\n\t"
         "s_lshr_b32 %[fl], %[fl], 1\n\t"
         "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc0 Lprs_b_%=\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n"
+        "s_cbranch_scc1 Lprs_rb_%=\n"
         "Lprs_b_%=:\n\t"
         "s_bitcmp1_b32 %[fl], 0\n\t"
         "s_cbranch_scc0 Lprs_short_%=\n\t"
@@ -1260,52 +1257,58 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
         "s_cbranch_scc1 Lprs_term_%=\n\t"
         "s_bitset1_b64 %[lgm], %[pos]\n\t"
         "s_bitcmp1_b64 %[extm], %[pos]\n\t"
-        "s_cselect_b32 %[t0], 3, 2\n\t"
-        "s_add_u32 %[pos], %[pos], %[t0]\n\t"
+        "s_cselect_b32 %[t4], 3, 2\n\t"
+        "s_add_u32 %[pos], %[pos], %[t4]\n\t"
         "s_branch Lprs_top_%=\n"
-        "Lprs_term_%=:\n\t"
-        "s_add_u32 %[pos], %[pos], 2\n\t"
-        "s_mov_b32 %[term], 1\n\t"
-        "s_branch Lprs_end_%=\n"
         "Lprs_short_%=:\n\t"
         "s_lshr_b32 %[fl], %[fl], 1\n\t"                       // short match: two more bits
         "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc0 Lprs_c_%=\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n"
+        "s_cbranch_scc1 Lprs_rc_%=\n"
         "Lprs_c_%=:\n\t"
         "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cselect_b32 %[t0], 1, 0\n\t"
+        "s_cselect_b64 %[t0], 1, 0\n\t"
         "s_lshr_b32 %[fl], %[fl], 1\n\t"
         "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc0 Lprs_d_%=\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n"
+        "s_cbranch_scc1 Lprs_rd_%=\n"
         "Lprs_d_%=:\n\t"
         "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cselect_b32 %[t1], 1, 0\n\t"
+        "s_cselect_b64 %[t1], 1, 0\n\t"
         "s_lshr_b32 %[fl], %[fl], 1\n\t"
         "s_bitset1_b64 %[shm], %[pos]\n\t"
-        "s_cmp_eq_u32 %[t0], 1\n\t"
-        "s_cbranch_scc0 Lprs_e_%=\n\t"
-        "s_bitset1_b64 %[hm], %[pos]\n"
-        "Lprs_e_%=:\n\t"
-        "s_cmp_eq_u32 %[t1], 1\n\t"
-        "s_cbranch_scc0 Lprs_f_%=\n\t"
-        "s_bitset1_b64 %[lm], %[pos]\n"
-        "Lprs_f_%=:\n\t"
+        "s_lshl_b64 %[t23], %[t0], %[pos]\n\t"                 // (t0 / t1 are 0 / 1 in 64-bit register pairs)
+        "s_or_b64 %[hm], %[hm], %[t23]\n\t"
+        "s_lshl_b64 %[t23], %[t1], %[pos]\n\t"
+        "s_or_b64 %[lm], %[lm], %[t23]\n\t"
         "s_add_u32 %[pos], %[pos], 1\n\t"
         "s_branch Lprs_top_%=\n"
+        "Lprs_ra_%=:\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
+        "s_add_u32 %[pos], %[pos], 1\n\t"
+        "s_branch Lprs_a_%=\n"
+        "Lprs_rb_%=:\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
+        "s_add_u32 %[pos], %[pos], 1\n\t"
+        "s_branch Lprs_b_%=\n"
+        "Lprs_rc_%=:\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
+        "s_add_u32 %[pos], %[pos], 1\n\t"
+        "s_branch Lprs_c_%=\n"
+        "Lprs_rd_%=:\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
+        "s_add_u32 %[pos], %[pos], 1\n\t"
+        "s_branch Lprs_d_%=\n"
+        "Lprs_term_%=:\n\t"
+        "s_add_u32 %[pos], %[pos], 2\n\t"
+        "s_mov_b32 %[term], 1\n"
         "Lprs_end_%=:\n\t"
         : [pos] "+s"(pos), [fl] "+s"(fl), [litm] "+s"(litm), [shm] "+s"(shm), [lgm] "+s"(lgm), [hm] "+s"(hm), [lm] "+s"(lm),
-          [term] "+s"(term), [t0] "=&s"(t0), [t1] "=&s"(t1)
-        : [xf] "v"(xf), [zerom] "s"(zerom), [extm] "s"(extm)
+          [term] "+s"(term), [t0] "+s"(t0), [t1] "+s"(t1), [t23] "=&s"(t23), [t4] "=&s"(t4)
+        : [xf] "v"(xf), [zerom] "s"(zerom), [extm] "s"(extm), [limit] "s"(limit)
         : "scc");
-    const u64 allm = litm | shm | lgm;
-    const u32 nt = (u32)__popcll(allm);
-    if (nt == 0u && !term) return false;
     // token of "my" byte under the interpretation the walk chose  PRS.cs:66-97
     u32 tok = ALZ_TOK_LIT(1u, x0);
     if ((shm >> lane) & 1ull) {
@@ -1315,7 +1318,33 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
         const u32 len = (v & 7u) ? (v & 7u) + 2u : x2 + 1u;
         tok = ALZ_TOK_MATCH(len, 0x2000u - (v >> 3));
     }
+    pos_out = pos; fl_io = fl; term_out = term; tokm = litm | shm | lgm; tok_out = tok;
+}
+
+// Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p, cache covers [p, p + chunk).  `fl` is the normalised flag
+// register (prs_to_norm).  Returns false (state untouched) when nothing could be parsed or the batch does not fit dst.
+// A window of 64 input bytes holds ~30 tokens of the synthetic mix, which left half of the lanes of the byte phase (and of its
+// token prologue) idle; so a second window follows the first where the queue has room for what it can hold at most (8
+// literals per 9 bytes): ~48 tokens per round.
+template <class SK, bool BIG>
+__device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32& fl_io) {
+    const u32 p = s.p;
+    u32 pos, fl = fl_io, term, tok; u64 allm;
+    prs_walk_window<BIG>(in, in.idx(p), lane, 60u, pos, fl, term, allm, tok);
+    u32 nt = (u32)__popcll(allm);
+    if (nt == 0u && !term) return false;
     if ((allm >> lane) & 1ull) stage[mbcnt64(allm)] = tok;
+#if !defined(ALZ_PRS_ONE_WINDOW)
+    if (!term && nt <= 48u) {
+        const u32 room = 64u - nt;
+        u32 limit = ((room - 2u) * 9u) / 8u - 1u;            // tokens that start at positions 0..limit: <= ceil((limit + 1) * 8 / 9) + 1 <= room
+        if (limit > 60u) limit = 60u;
+        u32 pos2, term2, tok2; u64 m2;
+        prs_walk_window<BIG>(in, in.idx(p + pos), lane, limit, pos2, fl, term2, m2, tok2);
+        if ((m2 >> lane) & 1ull) stage[nt + mbcnt64(m2)] = tok2;
+        nt += (u32)__popcll(m2); pos += pos2; term = term2;
+    }
+#endif
     wave_sync();
     const u32 qt = (u32)lane < nt ? stage[lane] : 0u;
     wave_sync();
