@@ -254,13 +254,23 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
 #ifdef ALZ_EMIT_STATS
     out.st_steps++; out.st_passes++; out.st_chunks += (u32)__popcll(wave_ballot(act)); out.st_dep += (u32)__popcll(wave_ballot(dep));
 #endif
-    // ---- chunks whose source reaches into this step's own output: read again until nothing changes
-    while (wave_ballot(dep)) {
+    // ---- chunks whose source reaches into this step's own output: read again until nothing changes.  Chunks ascend with the
+    // lane, so when every such source ends in front of the FIRST dependent chunk it was written by pass 1 and one more pass is
+    // final -- the common case (a match right behind the token it copies): no third read to find that nothing changed.
+    const u64 depm = wave_ballot(dep);
+    bool shallow = false;
+    if (depm) {
+        const u32 dmin = wave_readlane(q, (u32)__builtin_ctzll(depm));
+        shallow = !wave_ballot(dep && (int)(sp + (rep ? d : n) - dmin) > 0);
+    }
+    bool again = depm != 0;
+    while (again) {
         u32 N0 = E0, N1 = E1, N2 = E2, N3 = E3, N4 = E4;
         if (dep) chunk_read(ALZ_SBASE, ALZ_ST, N0, N1, N2, N3, N4);
         if (wave_ballot(rep && dep)) { if (rep && dep) chunk_rep(d, b, N0, N1, N2, N3, N4); }
         const bool wr = dep && (N0 != E0 || N1 != E1 || N2 != E2 || N3 != E3 || N4 != E4);
         if (!wave_ballot(wr)) break;
+        again = !shallow;
 #ifdef ALZ_EMIT_STATS
         out.st_passes++;
 #endif
