@@ -99,6 +99,7 @@ struct alz_ctx {
     // grow-only scratch of download_packed (item table + dense copy)
     void* d_items = nullptr; size_t d_items_cap = 0;
     void* d_pack = nullptr; size_t d_pack_cap = 0;
+    void* d_plan = nullptr; size_t d_plan_cap = 0;   // plan arrays of the host-buffer entry points (no hipMalloc / hipFree per call)
     copy_pool* pool = nullptr;                 // created with the pinned buffers
     std::vector<copy_job> jobs;                // (scratch of the staging loops)
     void copy(uint8_t* dst, const uint8_t* src, size_t len) { jobs.clear(); add_copy(jobs, dst, src, len); pool->run(jobs); }
@@ -114,6 +115,7 @@ struct alz_plan {
     uint32_t* d_index = nullptr;            // concatenated per-format index lists
     uint32_t fmt_off[ALZ_FMT_COUNT] = {0};
     uint32_t fmt_cnt[ALZ_FMT_COUNT] = {0};
+    bool borrowed = false;                  // the three device arrays live in the context's plan scratch (host-buffer entry points)
 };
 
 static alz_lz_properties effective_lz(const alz_lz_properties* p) {
@@ -168,6 +170,7 @@ void alz_destroy(alz_ctx* c) {
     if (c->d_dst) (void)hipFree(c->d_dst);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_pack) (void)hipFree(c->d_pack);
+    if (c->d_plan) (void)hipFree(c->d_plan);
     for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -233,13 +236,19 @@ int alz_synchronize(alz_ctx* c) {
 void alz_plan_destroy(alz_ctx* c, alz_plan* p) {
     if (!p) return;
     if (c) (void)hipSetDevice(c->device);
-    if (p->d_streams) (void)hipFree(p->d_streams);
-    if (p->d_results) (void)hipFree(p->d_results);
-    if (p->d_index) (void)hipFree(p->d_index);
+    if (!p->borrowed) {
+        if (p->d_streams) (void)hipFree(p->d_streams);
+        if (p->d_results) (void)hipFree(p->d_results);
+        if (p->d_index) (void)hipFree(p->d_index);
+    }
     delete p;
 }
 
-int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const alz_stream* streams, alz_plan** out) {
+static int grow(alz_ctx* c, void** buf, size_t* cap, size_t need);
+// `scratch`: the plan's device arrays come out of the context's grow-only plan scratch (one plan at a time: the host-buffer
+// entry points, which create, run and drop a plan inside one call -- a hipMalloc / hipFree trio per call cost more than the
+// kernel of a small batch)
+static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const alz_stream* streams, alz_plan** out, bool scratch) {
     if (!c || !out || (n && !streams)) return fail(ALZ_E_INVALID, "alz_plan_create: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     alz_lz_properties lz = effective_lz(props);
@@ -270,9 +279,17 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
     for (int f = 0; f < ALZ_FMT_COUNT; f++)
         if (cnt[f] > 1) std::stable_sort(index.begin() + p->fmt_off[f], index.begin() + p->fmt_off[f] + cnt[f], [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
     size_t nn = n ? n : 1;
-    hipError_t e = hipMalloc((void**)&p->d_streams, nn * sizeof(alz_stream));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_results, nn * sizeof(alz_result));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_index, nn * sizeof(uint32_t));
+    hipError_t e = hipSuccess;
+    if (scratch) {
+        const size_t a = (nn * sizeof(alz_stream) + 255) & ~(size_t)255, b = (nn * sizeof(alz_result) + 255) & ~(size_t)255;
+        if (int rc = grow(c, &c->d_plan, &c->d_plan_cap, a + b + nn * sizeof(uint32_t))) { delete p; return rc; }
+        p->borrowed = true;
+        p->d_streams = (alz_stream*)c->d_plan; p->d_results = (alz_result*)((uint8_t*)c->d_plan + a); p->d_index = (uint32_t*)((uint8_t*)c->d_plan + a + b);
+    } else {
+        e = hipMalloc((void**)&p->d_streams, nn * sizeof(alz_stream));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_results, nn * sizeof(alz_result));
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_index, nn * sizeof(uint32_t));
+    }
     if (e == hipSuccess && n) e = hipMemcpyAsync(p->d_streams, streams, n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(p->d_index, index.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_results, 0xFF, nn * sizeof(alz_result), c->stream);
@@ -280,6 +297,9 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
     if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
     *out = p;
     return ALZ_OK;
+}
+int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, const alz_stream* streams, alz_plan** out) {
+    return plan_create(c, props, n, streams, out, false);
 }
 
 static uint32_t format_weight(uint32_t fmt);
@@ -540,7 +560,7 @@ int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, con
             HIP_TRY(hipMemcpyAsync((uint8_t*)c->d_dst + streams[i].dst_off - streams[i].aux0, dst_base + streams[i].dst_off - streams[i].aux0,
                                    streams[i].aux0, hipMemcpyHostToDevice, c->stream));
     alz_plan* p = nullptr;
-    if ((rc = alz_plan_create(c, props, n, streams, &p))) return rc;
+    if ((rc = plan_create(c, props, n, streams, &p, true))) return rc;
     rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);
     if (!rc) rc = alz_plan_results(c, p, results);
     if (!rc) rc = download_outputs(c, n, streams, results, dst_base, false);   // copy back only what each stream produced
@@ -747,7 +767,7 @@ static int decode_share(alz_ctx* c, const alz_lz_properties* props, const std::v
             HIP_TRY(hipMemcpyAsync((uint8_t*)c->d_dst + ds[j].dst_off - st.aux0, dst_base + st.dst_off - st.aux0, st.aux0, hipMemcpyHostToDevice, c->stream));
     }
     alz_plan* p = nullptr;
-    if ((rc = alz_plan_create(c, props, m, ds.data(), &p))) return rc;
+    if ((rc = plan_create(c, props, m, ds.data(), &p, true))) return rc;
     std::vector<alz_result> rs(m);
     rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);
     if (!rc) rc = alz_plan_results(c, p, rs.data());
