@@ -46,6 +46,10 @@ class Context:
         """Kernel family of this context: the exact one-token-at-a-time kernels instead of the lane-parallel ones."""
         check(self.lib.alz_ctx_set_exact_kernels(self.h, 1 if on else 0))
 
+    def release_scratch(self):
+        """alz_ctx_release_scratch: return the grow-only staging / encoder scratch of the host-buffer calls to the device."""
+        check(self.lib.alz_ctx_release_scratch(self.h))
+
     def copy_bandwidth(self, nbytes=1 << 30, iters=10):
         """Measured device-to-device copy bandwidth in GB/s (bytes read + written): the second roofline denominator."""
         v = C.c_double()

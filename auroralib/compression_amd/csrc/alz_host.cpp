@@ -20,6 +20,19 @@
 
 static thread_local char g_err[512] = "";
 
+// ALZ_TIMING=1: phase times of the host-buffer entry points on stderr (a tuning aid)
+#include <chrono>
+struct phase_timer {
+    bool on; const char* what; std::chrono::steady_clock::time_point t;
+    explicit phase_timer(const char* w) : on(getenv("ALZ_TIMING") != nullptr), what(w), t(std::chrono::steady_clock::now()) {}
+    void mark(const char* phase) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[alz timing] %s: %s %.1f ms\n", what, phase, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 // Host copies between the caller's (pageable) buffers and the pinned staging buffers run on a few threads: one core moves
 // ~10 GB/s, a PCIe 5 x16 link ~55 GB/s, so a single memcpy loop left the link idle three quarters of the time.  One pool per
 // context (the multi-GPU entry points drive one context per device from their own threads).  ALZ_COPY_THREADS overrides the
@@ -100,6 +113,9 @@ struct alz_ctx {
     void* d_items = nullptr; size_t d_items_cap = 0;
     void* d_pack = nullptr; size_t d_pack_cap = 0;
     void* d_plan = nullptr; size_t d_plan_cap = 0;   // plan arrays of the host-buffer entry points (no hipMalloc / hipFree per call)
+    // encoder scratch (head tables, prev links, matches, masks ...: ~48 GB for 10 000 x 256 KiB at quality 8), one grow-only slot
+    // per purpose: allocating and freeing it per call cost 1-2 s, four times the kernels.  alz_ctx_release_scratch() returns it.
+    void* enc_buf[12] = {nullptr}; size_t enc_cap[12] = {0};
     copy_pool* pool = nullptr;                 // created with the pinned buffers
     std::vector<copy_job> jobs;                // (scratch of the staging loops)
     void copy(uint8_t* dst, const uint8_t* src, size_t len) { jobs.clear(); add_copy(jobs, dst, src, len); pool->run(jobs); }
@@ -163,14 +179,11 @@ int alz_create(int device, alz_ctx** out) {
     return ALZ_OK;
 }
 
+static void release_scratch(alz_ctx* c);
 void alz_destroy(alz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->d_src) (void)hipFree(c->d_src);
-    if (c->d_dst) (void)hipFree(c->d_dst);
-    if (c->d_items) (void)hipFree(c->d_items);
-    if (c->d_pack) (void)hipFree(c->d_pack);
-    if (c->d_plan) (void)hipFree(c->d_plan);
+    release_scratch(c);
     for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -204,17 +217,19 @@ int alz_device_free(alz_ctx* c, void* d_ptr) {
     HIP_TRY(hipFree(d_ptr));
     return ALZ_OK;
 }
+static int staged_h2d(alz_ctx* c, void* d_dst, const uint8_t* h_src, size_t bytes);
+static int staged_d2h(alz_ctx* c, uint8_t* h_dst, const void* d_src, size_t bytes);
 int alz_memcpy_h2d(alz_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
     if (!c) return fail(ALZ_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (int rc = staged_h2d(c, d_dst, (const uint8_t*)h_src, bytes)) return rc;      // (pageable memory: through the pinned buffers + copy threads)
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ALZ_OK;
 }
 int alz_memcpy_d2h(alz_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
     if (!c) return fail(ALZ_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (int rc = staged_d2h(c, (uint8_t*)h_dst, d_src, bytes)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ALZ_OK;
 }
@@ -460,29 +475,62 @@ __global__ void __launch_bounds__(256) alz_pack_outputs_kernel(const uint8_t* __
 struct out_seg { uint64_t dev; uint8_t* host; uint32_t len; };
 
 // false = could not pack (no device memory for the dense copy): the caller falls back to one copy per stream
+// Segments sorted by `dev` (offsets relative to d_base), pinned buffers present: windows of the device range go through the two
+// pinned buffers -- the DMA of window w + 1 overlaps the copy-out of window w, which the context's copy threads spread.  Only
+// the segments' own bytes are written on the host side.
+static int download_windows(alz_ctx* c, const void* d_base, const std::vector<out_seg>& segs) {
+    uint64_t lo = segs.front().dev, hi = 0;
+    for (const out_seg& g : segs) if (g.dev + g.len > hi) hi = g.dev + g.len;
+    const uint64_t W = c->pin_cap;
+    const uint64_t nwin = (hi - lo + W - 1) / W;
+    size_t first = 0;                                        // first segment that may still overlap the current window
+    auto issue = [&](uint64_t w, int k) -> hipError_t {
+        const uint64_t a = lo + w * W, n = hi - a < W ? hi - a : W;
+        hipError_t e = hipMemcpyAsync(c->pin[k], (const uint8_t*)d_base + a, n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k], c->stream);
+        return e;
+    };
+    HIP_TRY(issue(0, 0));
+    for (uint64_t w = 0; w < nwin; w++) {
+        const int k = (int)(w & 1);
+        if (w + 1 < nwin) HIP_TRY(issue(w + 1, k ^ 1));
+        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        const uint64_t a = lo + w * W, b = a + W;
+        while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
+        c->jobs.clear();
+        for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
+            const uint64_t s0 = segs[i].dev > a ? segs[i].dev : a, s1 = segs[i].dev + segs[i].len < b ? segs[i].dev + segs[i].len : b;
+            if (s1 > s0) add_copy(c->jobs, segs[i].host + (s0 - segs[i].dev), (const uint8_t*)c->pin[k] + (s0 - a), s1 - s0);
+        }
+        c->pool->run(c->jobs);
+    }
+    return ALZ_OK;
+}
+
+// false = could not pack (no device memory for the dense copy, no pinned memory): the caller falls back to one copy per stream
 static bool download_packed(alz_ctx* c, const std::vector<out_seg>& segs) {
+    if (ensure_pinned(c) != ALZ_OK) { (void)hipGetLastError(); return false; }
     std::vector<pack_item> items;
-    items.reserve(segs.size());
+    std::vector<out_seg> packed;                             // the same segments at their offsets in the dense copy
+    items.reserve(segs.size()); packed.reserve(segs.size());
     uint64_t cur = 0;
     for (const out_seg& g : segs) {
         const uint64_t to = cur + (g.dev & 15);
         items.push_back(pack_item{g.dev, to, g.len, 0});
+        packed.push_back(out_seg{to, g.host, g.len});
         cur = (to + g.len + 15) & ~15ull;
     }
     // (scratch of the context, grown on demand: no hipMalloc / hipFree per call)
     if (grow(c, &c->d_items, &c->d_items_cap, items.size() * sizeof(pack_item)) != ALZ_OK) { (void)hipGetLastError(); return false; }
     if (grow(c, &c->d_pack, &c->d_pack_cap, cur + 16) != ALZ_OK) { (void)hipGetLastError(); return false; }
-    std::vector<uint8_t> bounce(cur);
     hipError_t e = hipMemcpyAsync(c->d_items, items.data(), items.size() * sizeof(pack_item), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         alz_pack_outputs_kernel<<<dim3((uint32_t)items.size()), dim3(256), 0, c->stream>>>((const uint8_t*)c->d_dst, (uint8_t*)c->d_pack, (const pack_item*)c->d_items);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (staged_d2h(c, bounce.data(), c->d_pack, cur) != ALZ_OK) { (void)hipGetLastError(); return false; }
-    c->jobs.clear();
-    for (size_t i = 0; i < segs.size(); i++) add_copy(c->jobs, segs[i].host, bounce.data() + items[i].to, segs[i].len);
-    if (c->pool) c->pool->run(c->jobs); else for (const copy_job& j : c->jobs) memcpy(j.dst, j.src, j.len);
+    // (items is read by the asynchronous upload above: the first window's event wait below orders the two)
+    if (download_windows(c, c->d_pack, packed) != ALZ_OK) { (void)hipGetLastError(); return false; }
     return true;
 }
 
@@ -506,31 +554,7 @@ static int download_segs(alz_ctx* c, std::vector<out_seg>& segs) {
         for (const out_seg& g : segs) memcpy(g.host, bounce.data() + (g.dev - lo), g.len);
         return ALZ_OK;
     }
-    // windows of the device range [lo, hi): the DMA of window w + 1 overlaps the copy-out of window w
-    const uint64_t W = c->pin_cap;
-    const uint64_t nwin = (hi - lo + W - 1) / W;
-    size_t first = 0;                                        // first segment that may still overlap the current window
-    auto issue = [&](uint64_t w, int k) -> hipError_t {
-        const uint64_t a = lo + w * W, n = hi - a < W ? hi - a : W;
-        hipError_t e = hipMemcpyAsync(c->pin[k], (const uint8_t*)c->d_dst + a, n, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k], c->stream);
-        return e;
-    };
-    HIP_TRY(issue(0, 0));
-    for (uint64_t w = 0; w < nwin; w++) {
-        const int k = (int)(w & 1);
-        if (w + 1 < nwin) HIP_TRY(issue(w + 1, k ^ 1));
-        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
-        const uint64_t a = lo + w * W, b = a + W;
-        while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
-        c->jobs.clear();
-        for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
-            const uint64_t s0 = segs[i].dev > a ? segs[i].dev : a, s1 = segs[i].dev + segs[i].len < b ? segs[i].dev + segs[i].len : b;
-            if (s1 > s0) add_copy(c->jobs, segs[i].host + (s0 - segs[i].dev), (const uint8_t*)c->pin[k] + (s0 - a), s1 - s0);
-        }
-        c->pool->run(c->jobs);
-    }
-    return ALZ_OK;
+    return download_windows(c, c->d_dst, segs);
 }
 
 static int download_outputs(alz_ctx* c, uint32_t n, const alz_stream* streams, const alz_result* results, uint8_t* dst_base, bool only_ok) {
@@ -578,10 +602,36 @@ int alz_decode(alz_ctx* c, uint32_t format, const alz_lz_properties* props, cons
 
 // Device buffers of one encode call, freed on every exit path
 struct EncScratch {
-    std::vector<void*> bufs;
-    ~EncScratch() { for (void* p : bufs) if (p) (void)hipFree(p); }
-    hipError_t alloc(void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) bufs.push_back(*p); return e; }
+    alz_ctx* c; int slot = 0;
+    explicit EncScratch(alz_ctx* ctx) : c(ctx) {}
+    // slots are handed out in call order; `want` = false skips one (its buffer, if any, stays for a later call)
+    hipError_t alloc(void** p, size_t bytes, bool want = true) {
+        const int k = slot++;
+        if (!want) { *p = nullptr; return hipSuccess; }
+        if (bytes < 16) bytes = 16;
+        if (c->enc_cap[k] < bytes) {
+            if (c->enc_buf[k]) { (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
+            hipError_t e = hipMalloc(&c->enc_buf[k], bytes);
+            if (e != hipSuccess) { c->enc_buf[k] = nullptr; return e; }
+            c->enc_cap[k] = bytes;
+        }
+        *p = c->enc_buf[k];
+        return hipSuccess;
+    }
 };
+static void release_scratch(alz_ctx* c) {
+    for (int k = 0; k < 12; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
+    void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan};
+    size_t* caps[] = {&c->d_src_cap, &c->d_dst_cap, &c->d_items_cap, &c->d_pack_cap, &c->d_plan_cap};
+    for (int i = 0; i < 5; i++) { if (*bufs[i]) (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
+}
+int alz_ctx_release_scratch(alz_ctx* c) {
+    if (!c) return fail(ALZ_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    release_scratch(c);
+    return ALZ_OK;
+}
 
 int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
                      size_t src_bytes, const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
@@ -591,6 +641,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (st.quality < 0 || st.quality > 15) return fail(ALZ_E_INVALID, "quality %d outside 0..15 (CompressionSettings.cs:38-50)", st.quality);
     if (st.max_window_bits != 0) return fail(ALZ_E_UNSUPPORTED, "CompressionSettings.MaxWindowBits != 0 is not supported by the GPU encoder");
     alz_lz_properties lz = effective_lz(props);
+    phase_timer tm("alz_encode_batch");
     std::vector<uint32_t> cnt(ALZ_FMT_COUNT, 0);
     std::vector<uint64_t> pos_off(n);
     uint64_t total = 0; uint32_t max_len = 0;
@@ -624,7 +675,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     uint32_t CH = 4096;
     { const uint64_t per = (uint64_t)sizeof(int) << hash_bits; const uint64_t fit = (16ull << 30) / per; if (fit > CH) CH = fit > 0x100000ull ? 0x100000u : (uint32_t)fit; }
     if (const char* e = getenv("ALZ_ENC_CHUNK")) { const long v = atol(e); if (v >= 64) CH = (uint32_t)v; }   // tuning knob
-    EncScratch sc;
+    EncScratch sc(c);
     alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
     uint64_t* d_pos = nullptr; int *d_head4 = nullptr, *d_headm = nullptr, *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr, *d_mask = nullptr;
     const uint32_t chn = n < CH ? n : CH;
@@ -634,17 +685,19 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_head4, ((size_t)chn << hash_bits) * sizeof(int));
-    if (e == hipSuccess && any_min) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int), any_min);
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
-    if (e == hipSuccess && any_min) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
-    if (e == hipSuccess && (cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00])) e = sc.alloc(&d_side, (size_t)total * 2 + 64);   // section buffers
+    if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
+    tm.mark("validate + allocate");
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
     { uint32_t off = 0; for (int f = 0; f < ALZ_FMT_COUNT; f++) { foff[f] = off; off += cnt[f]; } }
     for (uint32_t i = 0; i < n; i++) { uint32_t f = streams[i].format; index[foff[f] + fill[f]++] = i; }
     if ((rc = staged_h2d(c, c->d_src, src_base, src_bytes))) return rc;
+    tm.mark("upload");
     HIP_TRY(hipMemcpyAsync(d_streams, streams, (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_pos, pos_off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -669,8 +722,10 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     HIP_TRY(hipMemcpyAsync(haux.data(), d_aux, (size_t)n * sizeof(alz_encode_aux), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_kernel_ms = ms; }   // table resets + the encode kernels
+    tm.mark("kernels");
     for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
     if ((rc = download_outputs(c, n, streams, results, dst_base, true))) return rc;
+    tm.mark("download");
     return ALZ_OK;
 }
 

@@ -177,6 +177,12 @@ int         alz_device_info(alz_ctx* ctx, char* name, size_t name_cap, int* cu_c
  * time, the statement-for-statement GPU restatement of the managed bodies; every lane-parallel kernel hands its stream
  * tails and error paths to them.  A verification mode (the parity tests run every case through both families). */
 int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
+/* The host-buffer entry points keep their device staging buffers and the encoder's scratch (head tables, links, matches: ~18
+ * bytes per input byte + the head tables of the streams in flight) in the context and only ever grow them, so that a caller
+ * working through batch after batch does not pay a device allocation per call.  This returns all of it to the device (the
+ * managed side has no counterpart: ArrayPool<int>.Shared keeps LzChainMatchFinder's tables the same way,
+ * MatchFinder/LzChainMatchFinder.cs:85-104, :323-334). */
+int         alz_ctx_release_scratch(alz_ctx* ctx);
 
 /* ----------------------------------------------- decode: host buffers in/out
  * Replaces the loop a managed caller writes around the static

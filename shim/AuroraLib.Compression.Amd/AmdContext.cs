@@ -41,6 +41,15 @@ namespace AuroraLib.Compression.Amd
             }
         }
 
+        /// <summary>Returns the native context's grow-only device buffers (staging, encoder tables) to the device.</summary>
+        public static void ReleaseScratch()
+        {
+            lock (Gate)
+            {
+                if (_available) Check(Native.alz_ctx_release_scratch(_ctx));
+            }
+        }
+
         internal static IntPtr Handle => Available ? _ctx : throw new InvalidOperationException("no HIP device: " + LastError());
         internal static object Lock => Gate;
 

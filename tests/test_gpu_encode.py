@@ -130,3 +130,19 @@ def test_encode_matches_committed_vectors(test_bmp):
             assert res[i].status == 0 and res[i].dst_len == length, key
             body = bytes(dst[int(streams[i].dst_off):int(streams[i].dst_off) + length])
             assert xxhash.xxh64(body).hexdigest() == digest and (int(auxv[i, 0]), int(auxv[i, 1])) == (a0, a1), key
+
+
+def test_scratch_is_reused_and_can_be_released(test_bmp):
+    """The context keeps the encoder's device scratch between calls (alz_host.cpp: enc_buf) -- a second, smaller or larger call
+    on dirty buffers and a call after alz_ctx_release_scratch give the same bytes as the first."""
+    big = [test_bmp[4096:4096 + 200000], test_bmp[:70000]]
+    small = [test_bmp[1000:1000 + 5000]]
+    _encode_and_compare(A.FMT_YAY0, big, 8)            # (allocates the section buffers too)
+    _encode_and_compare(A.FMT_LZSS, small, 12)         # smaller batch, larger hash table, min table: dirty slots
+    _encode_and_compare(A.FMT_LZ4_BLOCK, big, 0)
+    ctx().release_scratch()
+    _encode_and_compare(A.FMT_LZSS, big, 8)
+    b = synth.make_batch(A.FMT_YAZ0, 8, 50000, 99)
+    g_dst, g_res = ctx().decode_batch(b.streams, b.src, b.dst_bytes)   # decode staging was released as well
+    o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes)
+    assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes])
