@@ -482,9 +482,12 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
                                                       u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
                                                       const int* __restrict__ prev4, const int* __restrict__ prevm,
                                                       u8* __restrict__ side, alz_result* __restrict__ results,
-                                                      alz_encode_aux* __restrict__ aux, EncGeom g) {
-    const u32 i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= count) return;
+                                                      alz_encode_aux* __restrict__ aux, EncGeom g, u32 lone) {
+    // lone: ONE stream per wavefront, lane 0 works.  Sixty-four streams per wavefront executed the union of 64 divergent token
+    // paths with their flag-writer state in scratch memory: PRS 1 900 ms per 10 000 x 256 KiB against the 280 ms of the four
+    // kernels in front of it; a lone lane per wavefront is latency bound instead, and 10 000 wavefronts hide each other's latency.
+    const u32 i = lone ? blockIdx.x : blockIdx.x * 64 + threadIdx.x;
+    if (i >= count || (lone && threadIdx.x != 0)) return;
     const u32 sid = index_list[i];
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
@@ -1167,7 +1170,8 @@ int alz_encode_geom_min_table(const void* geom) { return ((const EncGeom*)geom)-
 template <int FMT>
 static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
                         const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
-    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3((count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
+    static const int lone = getenv("ALZ_ENC_EMIT_LONE") ? atoi(getenv("ALZ_ENC_EMIT_LONE")) : 1;
+    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(lone ? count : (count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g, (u32)lone);
 }
 
 template <int FMT>

@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/enc_formats.sh [quality] -- encode 10 000 x 256 KiB per format: kernel ms (HIP events inside alz_encode_batch) and host-API rate
 cd $GRAFT_REPO_ROOT
 q=${1:-8}
-for f in lzss lz10 lz11 yaz0 yay0 mio0 prs_be lz4_block lzo snappy_raw; do
+for f in ${FORMATS:-lzss lz10 lz11 yaz0 yay0 mio0 prs_be lz4_block lzo snappy_raw}; do
 python3 - $f $q <<'PY'
 import sys, time, numpy as np
 sys.path.insert(0, '.')
