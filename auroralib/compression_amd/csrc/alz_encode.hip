@@ -40,9 +40,9 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
     int nprops, p_max_len[3], p_min_len[3], p_max_dist[3], p_min_dist[3];
 };
 
-__device__ __forceinline__ u32 load32(const u8* p) {
-    return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
-}
+// (global memory takes unaligned dword / qword loads: one global_load_dword instead of four byte loads and three shifts)
+__device__ __forceinline__ u32 load32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ u64 load64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 
 // ---------------------------------------------------------------------------------------------- kernel A
 template <bool MINT>
@@ -323,7 +323,12 @@ __global__ __launch_bounds__(64) void enc_prev_lds_kernel(const u8* __restrict__
 // GetMatchLength  LzChainMatchFinder.cs:338-357
 __device__ __forceinline__ int match_len(const u8* a, const u8* b, int max) {
     int len = 0;
-    while (len + 4 <= max) {
+    while (len + 8 <= max) {
+        const u64 x = load64(a + len) ^ load64(b + len);
+        if (x) return len + (__builtin_ctzll(x) >> 3);
+        len += 8;
+    }
+    if (len + 4 <= max) {
         const u32 x = load32(a + len) ^ load32(b + len);
         if (x) return len + (__builtin_ctz(x) >> 3);
         len += 4;
