@@ -938,13 +938,24 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
     const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
     u64* mask = startmask + (pos_off[sid] >> 6);
     int cur = 0;                    // cursor of FindNextBestMatch (absolute position)
+    // The window behind the current one is loaded one iteration ahead (the cursor nearly always walks into it: a stream is
+    // 4 096 windows, and the load's latency was exposed once per window), and match[p + 1] comes from the neighbour lane.
+    int Pn = -1;                    // window held in `nx` (-1: none)
+    uint2 nx = make_uint2(0, 0);
     while (cur <= limit) {
         const int P = cur & ~63;    // window that holds the cursor (windows the cursor jumps over keep their zero mask)
         const int p = P + lane;
         // match[p] and match[p+1] (positions above `limit` were never searched: no match)
-        uint2 a = make_uint2(0, 0), b = make_uint2(0, 0);
-        if (p <= limit) a = m[p];
-        if (p + 1 <= limit) b = m[p + 1];
+        uint2 a = make_uint2(0, 0);
+        if (P == Pn) a = nx; else if (p <= limit) a = m[p];
+        nx = make_uint2(0, 0); Pn = P + 64;
+        if (p + 64 <= limit) nx = m[p + 64];
+        uint2 b;
+        b.x = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.x); b.y = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.y);
+        {   // lane 63's neighbour is the first position of the next window
+            const u32 n0x = (u32)__builtin_amdgcn_readlane((int)nx.x, 0), n0y = (u32)__builtin_amdgcn_readlane((int)nx.y, 0);
+            if (lane == 63) b = make_uint2(n0x, n0y);
+        }
         const bool capped = a.y == ALZ_CAPPED || b.y == ALZ_CAPPED;
         int jump = 1, startrel = 0;   // startrel: 0 no token here, 1 match starts here, 2 literal here + match at p + 1
         if (!capped && p <= limit && (int)a.y >= g.min_len) {
@@ -955,7 +966,30 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
         }
         u64 bits = 0;
         int rel = cur - P;
-        while (rel < 64 && P + rel <= limit) {
+        // The walk over the window: a chain of "cursor += jump[cursor]" hops, ~18 per window.  Written in C++ each hop is three
+        // v_readlane and ~30 scalar instructions, and with 32 waves per CU the kernel was bound by the CU's one scalar unit
+        // (24.6 ms per 10 000 x 256 KiB).  Without capped candidates in the window the hop is five instructions: the visited lanes
+        // are collected as a bit mask, and the token starts follow from two ballots.
+        if (__ballot(capped) == 0) {
+            u64 M = 0; u32 r = (u32)rel, j;
+            const u32 lim = (u32)(limit + 1 - P) < 64u ? (u32)(limit + 1 - P) : 64u;     // (r < lim on entry: cur <= limit)
+            asm volatile(
+                "s_nop 3\n"
+                "1:\n\t"
+                "s_bitset1_b64 %[M], %[r]\n\t"
+                "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                "s_add_u32 %[r], %[r], %[j]\n\t"
+                "s_cmp_lt_u32 %[r], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                : [jump] "v"(jump), [lim] "s"(lim)
+                : "scc");
+            const u64 s1 = __ballot(startrel == 1) & M, s2 = __ballot(startrel == 2) & M;
+            bits = s1 | (s2 << 1);
+            if ((s2 >> 63) && lane == 0) mask[(P >> 6) + 1] = 1ull;          // start in lane 0 of the next window
+            rel = (int)r;
+        }
+        else while (rel < 64 && P + rel <= limit) {
             int j, sr;
             if (__builtin_amdgcn_readlane((int)capped, rel)) {
                 // kernel B capped a candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour
@@ -964,6 +998,7 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 if (g.use_min_table) match_search<true>(data, n, q, p4, pm, g, 0, d0, l0); else match_search<false>(data, n, q, p4, pm, g, 0, d0, l0);
                 if (q + 1 <= limit) { if (g.use_min_table) match_search<true>(data, n, q + 1, p4, pm, g, 0, d1, l1); else match_search<false>(data, n, q + 1, p4, pm, g, 0, d1, l1); }
                 if (lane == 0) { m[q] = make_uint2((u32)d0, (u32)l0); if (q + 1 <= limit) m[q + 1] = make_uint2((u32)d1, (u32)l1); }
+                if (q + 1 >= P + 64) Pn = -1;                           // (the window loaded ahead no longer matches memory)
                 j = 1; sr = 0;
                 if (l0 >= g.min_len) {
                     const bool lazyc = l0 <= g.lazy && q + 1 <= limit;

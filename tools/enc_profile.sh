@@ -1,7 +1,7 @@
-# usage (GPU box): bash tools/enc_profile.sh  -- kernel stats of the compression path (cfg5) at Q0 and Q8 -> gpurun_out/r01_final_encode.md
+# usage (GPU box): bash tools/enc_profile.sh  -- kernel stats of the compression path (cfg5) at Q0 and Q8 -> gpurun_out/r02_encode.md
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/r01_final_encode.md
+OUT=gpurun_out/r02_encode.md
 echo "# rocprofv3 summary: compression path (cfg5: LZSS(12,4,2), 10 000 x 256 KiB)" > $OUT
 for q in 0 8; do
   D=gpurun_out/prof_enc_q$q; rm -rf $D; mkdir -p $D
