@@ -38,6 +38,7 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
     u32 length_bits, lz_min_length, windows_start, lz_max_distance;
     // the LzProperties[] form of the finder (RefPack): ScoreMatch takes the first set that admits a candidate
     int nprops, p_max_len[3], p_min_len[3], p_max_dist[3], p_min_dist[3];
+    int variant;           // FastLZ: 1 = level 2 (token format + the two property sets)
 };
 
 // (global memory takes unaligned dword / qword loads: one global_load_dword instead of four byte loads and three shifts)
@@ -845,20 +846,28 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
             code(2);
         }
         if (ncodes && flagpos < out.cap) out.p[flagpos] = (u8)cur;
-    } else if constexpr (FMT == ALZ_FMT_FASTLZ) {                           // FastLZ.cs:162-245, level 1 (level 2 needs MaxWindowBits > 13, refused by the host)
+    } else if constexpr (FMT == ALZ_FMT_FASTLZ) {                           // FastLZ.cs:162-245, levels 1 and 2 (g.variant)
+        const bool level2 = g.variant == 1;
+        bool first = level2;                                                // the level tag rides on the first literal run
         for (;;) {
             Match mt = mf.next();
             int plain = mt.offset - sp;
             while (plain > 0) {                                             // literal runs of 1..32
                 const int chunk = plain < 32 ? plain : 32;
-                out.put((u32)(chunk - 1));
+                out.put((u32)(chunk - 1) | (first ? 0x20u : 0u)); first = false;
                 out.copy(src + sp, (u32)chunk); sp += chunk; plain -= chunk;
             }
             if (mt.length == 0) break;
-            const int length = mt.length - 3, distance = mt.distance - 1;
-            out.put((u32)((((length < 6 ? length : 6) + 1) << 5) | (distance >> 8)));
-            if (length >= 6) out.put((u32)(length - 6));
-            out.put((u32)distance & 0xFF);
+            int length = mt.length - 3, distance = mt.distance - 1;
+            const int sd = level2 ? (distance < 0x1FFF ? distance : 0x1FFF) : distance;
+            out.put((u32)((((length < 6 ? length : 6) + 1) << 5) | (sd >> 8)) & 0xFFu);
+            if (length >= 6) {
+                length -= 6;
+                while (level2 && length >= 255) { out.put(255); length -= 255; }
+                out.put((u32)length & 0xFFu);
+            }
+            out.put((u32)sd & 0xFF);
+            if (level2 && distance >= 0x1FFF) { distance -= 0x1FFF; out.put((u32)(distance >> 8) & 0xFFu); out.put((u32)distance & 0xFFu); }
             sp += mt.length;
         }
     } else {                                                                // Snappy.cs:124-203
@@ -1155,7 +1164,7 @@ int isqrt_floor(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) r++; return r
 }  // namespace
 
 // quality -> finder parameters  LzChainMatchFinder.cs:108-119 ; per-format LzProperties
-bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits) {
+bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits, int variant) {
     EncGeom g; memset(&g, 0, sizeof(g));
     int wb = 12;
     switch (fmt) {
@@ -1168,7 +1177,14 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     case ALZ_FMT_LZ4_BLOCK: wb = 16; g.min_len = 4; g.max_len = 0x7FFFFFFF; g.max_dist = 0xFFFF; break;
     case ALZ_FMT_LZO: wb = 16; g.min_len = 3; g.max_len = 0x7FFFFFFF; g.max_dist = 0xBFFF; break;
     case ALZ_FMT_SNAPPY_RAW: wb = 15; g.min_len = 4; g.max_len = 64; g.max_dist = 0x8000; break;
-    case ALZ_FMT_FASTLZ: wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; break;      // level 1  FastLZ.cs:22
+    case ALZ_FMT_FASTLZ:
+        if (variant == 1) {                                                                                 // level 2: two sets  FastLZ.cs:23-27 (WindowsBits = ceil(log2(0x11FFF)) = 17)
+            wb = 17; g.min_len = 3; g.max_len = 0x7FFFFFFF; g.max_dist = 0x11FFF; g.nprops = 2; g.variant = 1;
+            g.p_max_dist[0] = 0x1FFF;  g.p_max_len[0] = 0x7FFFFFFF; g.p_min_len[0] = 3;
+            g.p_max_dist[1] = 0x11FFF; g.p_max_len[1] = 0x7FFFFFFF; g.p_min_len[1] = 5;
+            g.p_min_dist[0] = g.p_min_dist[1] = 1;
+        } else { wb = 13; g.min_len = 3; g.max_len = 255 + 3 + 6; g.max_dist = 0x2000; }                    // level 1  FastLZ.cs:22
+        break;
     case ALZ_FMT_CNX2: wb = 11; g.min_len = 4; g.max_len = 0x1F + 4; g.max_dist = 0x800; break;             // CNX2.cs:25
     case ALZ_FMT_CNS: wb = 8; g.min_len = 3; g.max_len = 130; g.max_dist = 0x100; break;                    // CNS.cs:24
     case ALZ_FMT_LZ02: g.min_len = 3; g.max_len = 272; g.max_dist = 0xFFF; break;                         // LZ02.cs:23
@@ -1184,6 +1200,10 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
         break;
     case ALZ_FMT_BLZ: g.min_len = 3; g.max_len = 18; g.max_dist = 0x1000; break;                          // BLZ.cs:24 (+ minDistance 3 below)
     default: return false;
+    }
+    if (st->max_window_bits != 0) {                                  // LzChainMatchFinder.cs:70-74 (the host only lets FastLZ through)
+        if (wb < st->max_window_bits) wb = st->max_window_bits;
+        if (g.max_dist < (1 << st->max_window_bits)) g.max_dist = 1 << st->max_window_bits;
     }
     g.min_dist = st->min_distance > 0 ? st->min_distance : (fmt == ALZ_FMT_BLZ ? 3 : 1);
     const int q = st->quality;

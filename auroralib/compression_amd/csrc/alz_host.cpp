@@ -633,35 +633,45 @@ int alz_ctx_release_scratch(alz_ctx* c) {
     return ALZ_OK;
 }
 
+// FastLZ.CompressHeaderless picks level 2 per source  FastLZ.cs:169-175
+static inline bool fastlz_level2(const alz_settings& st, uint32_t src_len) { return src_len >= 0x10000u && st.quality > 4 && st.max_window_bits > 13; }
+
 int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
                      size_t src_bytes, const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
     if (!c || (n && (!streams || !results || !dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch: bad argument");
     if (n == 0) return ALZ_OK;
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
     if (st.quality < 0 || st.quality > 15) return fail(ALZ_E_INVALID, "quality %d outside 0..15 (CompressionSettings.cs:38-50)", st.quality);
-    if (st.max_window_bits != 0) return fail(ALZ_E_UNSUPPORTED, "CompressionSettings.MaxWindowBits != 0 is not supported by the GPU encoder");
+    if (st.max_window_bits < 0 || st.max_window_bits > 24) return fail(ALZ_E_INVALID, "max_window_bits %d outside 0..24", st.max_window_bits);
     alz_lz_properties lz = effective_lz(props);
     phase_timer tm("alz_encode_batch");
     std::vector<uint32_t> cnt(ALZ_FMT_COUNT, 0);
     std::vector<uint64_t> pos_off(n);
-    uint64_t total = 0; uint32_t max_len = 0;
+    uint64_t total = 0; uint32_t max_len = 0, n_fastlz2 = 0;
     for (uint32_t i = 0; i < n; i++) {
         if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
         if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
         if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
         if (streams[i].src_len > 0x7FFFFF00u) return fail(ALZ_E_UNSUPPORTED, "stream %u: inputs above 2 GiB are not supported", i);
+        // MaxWindowBits only means something to FastLZ (level 2 for sources >= 64 KiB at Quality > 4, FastLZ.cs:169-175); for
+        // every other format it would merely let the finder return distances the format cannot store
+        if (st.max_window_bits != 0 && streams[i].format != ALZ_FMT_FASTLZ)
+            return fail(ALZ_E_UNSUPPORTED, "CompressionSettings.MaxWindowBits != 0 is only supported for FastLZ by the GPU encoder");
         cnt[streams[i].format]++;
+        if (streams[i].format == ALZ_FMT_FASTLZ && fastlz_level2(st, streams[i].src_len)) n_fastlz2++;
         pos_off[i] = total; total += ((uint64_t)streams[i].src_len + 16 + 63) & ~63ull;   // 64-aligned: one start-mask word per 64 positions
         if (streams[i].src_len > max_len) max_len = streams[i].src_len;
     }
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
-    std::vector<unsigned char> geom(ALZ_FMT_COUNT * alz_encode_geom_size());
+    std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
     int hash_bits = 0; bool any_min = false;
-    for (int f = 0; f < ALZ_FMT_COUNT; f++) {
-        if (!cnt[f]) continue;
+    for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
+        const bool lvl2 = f == ALZ_FMT_COUNT;
+        if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
         void* g = geom.data() + f * alz_encode_geom_size();
-        if (!alz_encode_geometry(f, &lz, &st, g, nullptr)) return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", f);
+        if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &st, g, nullptr, lvl2 ? 1 : 0))
+            return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
         hash_bits = alz_encode_geom_hash_bits(g);
         any_min = any_min || alz_encode_geom_min_table(g);
     }
@@ -696,6 +706,9 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
     { uint32_t off = 0; for (int f = 0; f < ALZ_FMT_COUNT; f++) { foff[f] = off; off += cnt[f]; } }
     for (uint32_t i = 0; i < n; i++) { uint32_t f = streams[i].format; index[foff[f] + fill[f]++] = i; }
+    if (n_fastlz2)                                           // FastLZ: the level-1 streams first, then the level-2 ones (own geometry, own launch)
+        std::stable_partition(index.begin() + foff[ALZ_FMT_FASTLZ], index.begin() + foff[ALZ_FMT_FASTLZ] + cnt[ALZ_FMT_FASTLZ],
+                              [&](uint32_t i) { return !fastlz_level2(st, streams[i].src_len); });
     if ((rc = staged_h2d(c, c->d_src, src_base, src_bytes))) return rc;
     tm.mark("upload");
     HIP_TRY(hipMemcpyAsync(d_streams, streams, (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
@@ -705,15 +718,19 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
     HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)total / 8 + 64, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+    for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
+        const bool lvl2 = f == ALZ_FMT_COUNT;
+        const int fmt = lvl2 ? ALZ_FMT_FASTLZ : f;
+        const uint32_t first = foff[fmt] + (lvl2 ? cnt[fmt] - n_fastlz2 : 0u);
+        const uint32_t count = lvl2 ? n_fastlz2 : cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u);
         const void* g = geom.data() + f * alz_encode_geom_size();
-        for (uint32_t done = 0; done < cnt[f]; done += CH) {
-            const uint32_t k = cnt[f] - done < CH ? cnt[f] - done : CH;
+        for (uint32_t done = 0; done < count; done += CH) {
+            const uint32_t k = count - done < CH ? count - done : CH;
             HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
             if (alz_encode_geom_min_table(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
-            e = alz_launch_encode(f, c->stream, c->d_src, c->d_dst, d_streams, d_index + foff[f] + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
+            e = alz_launch_encode(fmt, c->stream, c->d_src, c->d_dst, d_streams, d_index + first + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
                                   d_match, d_pos, d_side, d_mask, d_results, d_aux, g);
-            if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", f, hipGetErrorString(e));
+            if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

@@ -12,7 +12,7 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, voi
 int alz_kernel_occupancy(int fmt);   // resident waves per CU of the production decode kernel (tuning aid)
 
 // ---- encoder (alz_encode.hip)
-bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits);
+bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits, int variant = 0);   // variant 1: FastLZ level 2
 size_t alz_encode_geom_size(void);
 int alz_encode_geom_hash_bits(const void* geom);
 int alz_encode_geom_min_table(const void* geom);

@@ -158,7 +158,9 @@ typedef struct alz_result {
 /* CompressionSettings (src/AuroraLib.Compression/CompressionSettings.cs:11-84) */
 typedef struct alz_settings {
     int32_t quality;          /* 0..15; presets Fastest 0, Fast 4, Balanced 8 (default), High 12, Maximum 15 */
-    int32_t max_window_bits;  /* 0 = auto */
+    int32_t max_window_bits;  /* 0 = auto.  Only FastLZ takes another value (> 13 selects level 2 for sources >= 64 KiB at
+                               * quality > 4, Formats/Common/FastLZ.cs:169-175); refused (ALZ_E_UNSUPPORTED) for every other format,
+                               * where it would merely let the finder return distances the format cannot store */
     int32_t strategy;         /* 0 Default, 1 CompatibilityMode (no self-overlapping matches) */
     int32_t min_distance;     /* 0 = format default; 2 = LZ10/LZ11 GbaVramCompatibilityMode (LZ10.cs:25-33) */
 } alz_settings;

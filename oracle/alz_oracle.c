@@ -1935,28 +1935,47 @@ static void enc_cnx2(const alz_settings* st, const uint8_t* src, int n, buf_t* o
     fw_dispose(&flag); mf_free(&m);
 }
 
-/* FastLZ.CompressHeaderless, level 1  Formats/Common/FastLZ.cs:162-245.  (Level 2 -- chosen only for sources >= 64 KiB at
- * Quality > 4 when the caller sets MaxWindowBits > 13, :164 -- needs the finder's multi-property scoring and is not
- * restated: refused.) */
+/* FastLZ.CompressHeaderless  Formats/Common/FastLZ.cs:162-245.  Level 2 is chosen for sources >= 64 KiB at Quality > 4 when the
+ * caller sets MaxWindowBits > 13 (:169-175); its finder takes two property sets -- short matches (distance <= 0x1FFF, min 3) and
+ * long ones (<= 0x11FFF, min 5), :23-27 -- and ScoreMatch admits a candidate with the first set that fits it. */
 static int enc_fastlz(const alz_settings* st, const uint8_t* src, int n, buf_t* out) {
-    if (n >= 0x10000 && st->quality > 4 && st->max_window_bits > 13) return ALZ_E_UNSUPPORTED;
-    fmt_props p = props_for(ALZ_FMT_FASTLZ, NULL, st);
-    mf_t m; mf_init(&m, &p, st);
-    int sp = 0;
+    const int level2 = n >= 0x10000 && st->quality > 4 && st->max_window_bits > 13;
+    const fmt_props lz1 = { 13, 255 + 3 + 6, 3, 0x2000, 1 };                              /* :22 */
+    const fmt_props lz2[2] = { { 13, 0x7FFFFFFF, 3, 0x1FFF, 1 }, { 17, 0x7FFFFFFF, 5, 0x11FFF, 1 } };   /* WindowsBits = ceil(log2(windowsSize))  LzProperties.cs:58 */
+    mf_t m;
+    if (level2) mf_init_multi(&m, lz2, 2, st);
+    else {
+        fmt_props p = lz1;
+        if (st->min_distance > 0) p.minDist = st->min_distance;
+        mf_init_multi(&m, &p, 1, st);                                                    /* (one set: _lzProperties stays null, :52-53) */
+    }
+    int sp = 0, level2First = level2;
     for (;;) {
         lzmatch_t match = mf_find(&m, src, n);
         int plain = match.offset - sp;
-        while (plain > 0) {                                                              /* :178-198 */
+        while (plain > 0) {                                                              /* :181-198 */
             int chunk = plain < 32 ? plain : 32;
-            buf_u8(out, (uint32_t)(chunk - 1));
+            uint32_t ctrl = (uint32_t)(chunk - 1);
+            if (level2First) { ctrl |= 1u << 5; level2First = 0; }                        /* the level tag rides on the first literal run */
+            buf_u8(out, ctrl);
             buf_put(out, src + sp, (size_t)chunk);
             sp += chunk; plain -= chunk;
         }
         if (match.length == 0) break;
-        int length = match.length - 3, distance = match.distance - 1;
-        buf_u8(out, (uint32_t)((((length < 6 ? length : 6) + 1) << 5) | (distance >> 8)));
-        if (length >= 6) buf_u8(out, (uint32_t)(length - 6));
-        buf_u8(out, (uint32_t)distance & 0xFF);
+        int length = match.length - 3, distance = match.distance - 1;                    /* :204-206 */
+        int shortDistance = level2 ? (distance < 0x1FFF ? distance : 0x1FFF) : distance;
+        buf_u8(out, (uint32_t)(((((length < 6 ? length : 6) + 1) << 5) | (shortDistance >> 8)) & 0xFF));
+        if (length >= 6) {                                                               /* :214-225 */
+            length -= 6;
+            while (level2 && length >= 255) { buf_u8(out, 255); length -= 255; }
+            buf_u8(out, (uint32_t)length & 0xFF);
+        }
+        buf_u8(out, (uint32_t)shortDistance & 0xFF);
+        if (level2 && distance >= 0x1FFF) {                                              /* :229-235 */
+            distance -= 0x1FFF;
+            buf_u8(out, (uint32_t)(distance >> 8) & 0xFF);
+            buf_u8(out, (uint32_t)distance & 0xFF);
+        }
         sp += match.length;
     }
     mf_free(&m);

@@ -146,3 +146,33 @@ def test_scratch_is_reused_and_can_be_released(test_bmp):
     g_dst, g_res = ctx().decode_batch(b.streams, b.src, b.dst_bytes)   # decode staging was released as well
     o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes)
     assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes])
+
+
+@pytest.mark.parametrize("quality,mwb", [(5, 14), (8, 17), (12, 16), (8, 13), (4, 17), (15, 15)])
+def test_fastlz_level2(quality, mwb, test_bmp):
+    """FastLZ.CompressHeaderless picks level 2 per source (>= 64 KiB, Quality > 4, MaxWindowBits > 13  FastLZ.cs:169-175): two
+    property sets in the finder, long distances, 255-chains of length bytes.  One batch mixes sources on both sides of the 64 KiB
+    line; bytes identical to the oracle's, and what was written decodes back."""
+    raws = [test_bmp[:200000], test_bmp[300000:300000 + 65536], test_bmp[1000:1000 + 65535], test_bmp[:5000],
+            bytes(70000), (b"0123456789abcdef" * 40 + bytes(np.random.default_rng(3).integers(0, 256, 100, dtype=np.uint8))) * 150]
+    _encode_and_compare(A.FMT_FASTLZ, raws, quality, max_window_bits=mwb)
+    if mwb > 13 and quality > 4:                               # the level-2 streams decode (level 1 with an enlarged finder window does not: the reference's own footgun)
+        big = [r for r in raws if len(r) >= 0x10000]
+        items = []
+        for r in big:
+            comp, aux = O.encode_stream(A.FMT_FASTLZ, r, quality=quality, max_window_bits=mwb)
+            assert comp[0] >> 5 == 1
+            items.append(dict(fmt=A.FMT_FASTLZ, src=comp, decom_len=len(r)))
+        from gpu_common import compare_batch, pack_streams
+        streams, src, dst_bytes = pack_streams(items)
+        gr, g_dst = compare_batch(streams, src, dst_bytes, what="fastlz level 2")
+        assert (gr["status"] == 0).all()
+        recs = synth.stream_records(streams)
+        for i, r in enumerate(big):
+            a = int(recs["dst_off"][i])
+            assert bytes(g_dst[a:a + len(r)]) == bytes(r)
+
+
+def test_max_window_bits_is_fastlz_only(test_bmp):
+    with pytest.raises(Exception):
+        _encode_and_compare(A.FMT_LZ10, [test_bmp[:5000]], 8, max_window_bits=14)
