@@ -312,6 +312,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
         // declines, and the tail of the stream, goes through the exact parser one token at a time
         constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
         u32 fl = 1u;                                             // normalised flag register (no bits pending)
+#ifndef ALZ_PRS_PRIO
+#define ALZ_PRS_PRIO 2
+#endif
+        // A PRS stream is one long chain of dependent scalar instructions (2.5 ms alone for 256 KiB, three times a Yaz0 stream): in a
+        // mixed batch its waves decide when the launch ends, so they take precedence over the other formats' waves on their CU.
+        if (ALZ_PRS_PRIO) __builtin_amdgcn_s_setprio(ALZ_PRS_PRIO);
         for (;;) {
             if (s.p + QAHEAD <= src_len && !s.done) {
                 sk.ensure(in, s.p, QCH);
