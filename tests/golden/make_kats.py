@@ -452,6 +452,45 @@ def build():
     return K
 
 
+def xxh32(data, seed=0):
+    """xxHash32 as published (Yann Collet's specification), written out here so that the vectors depend on nothing of ours."""
+    P1, P2, P3, P4, P5 = 2654435761, 2246822519, 3266489917, 668265263, 374761393
+    M = 0xFFFFFFFF
+    rotl = lambda x, r: ((x << r) | (x >> (32 - r))) & M
+    n, i = len(data), 0
+    if n >= 16:
+        v = [(seed + P1 + P2) & M, (seed + P2) & M, seed & M, (seed - P1) & M]
+        while i + 16 <= n:
+            for k in range(4):
+                w = int.from_bytes(data[i + 4 * k:i + 4 * k + 4], "little")
+                v[k] = (rotl((v[k] + w * P2) & M, 13) * P1) & M
+            i += 16
+        h = (rotl(v[0], 1) + rotl(v[1], 7) + rotl(v[2], 12) + rotl(v[3], 18)) & M
+    else:
+        h = (seed + P5) & M
+    h = (h + n) & M
+    while i + 4 <= n:
+        h = (rotl((h + int.from_bytes(data[i:i + 4], "little") * P3) & M, 17) * P4) & M
+        i += 4
+    while i < n:
+        h = (rotl((h + data[i] * P5) & M, 11) * P1) & M
+        i += 1
+    h ^= h >> 15; h = (h * P2) & M
+    h ^= h >> 13; h = (h * P3) & M
+    h ^= h >> 16
+    return h
+
+
+def crc32c(data):
+    """CRC-32C (Castagnoli), bit by bit: reflected polynomial 0x82F63B78, initial value and final XOR 0xFFFFFFFF."""
+    c = 0xFFFFFFFF
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+    return c ^ 0xFFFFFFFF
+
+
 def be32(v):
     return bytes([(v >> 24) & 0xFF, (v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
 
@@ -495,6 +534,62 @@ def build_containers():
     opss = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x00\xff"), ("copy", 3, 7), ("copy", 30, 18), ("lit", b"Z")]
     body = enc_lzss(opss)
     cont("\"LZSS\" + BE size + BE compressed size + BE 0", "LZSS", b"LZSS" + be32(len(expand(opss))) + be32(len(body)) + be32(0) + body, opss, "LZSS.cs:53-88")
+
+    # ---- wrappers that only put a magic in front of another container (cls: the format class of the Python mirror that reads it)
+    def cont2(name, container, cls, blob, ops, cite, provides_size=True, **kw):
+        cont(name, container, blob, ops, cite, **kw)
+        out[-1]["cls"] = cls
+        out[-1]["provides_size"] = provides_size
+
+    ops = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x10\x20"), ("copy", 2, 9), ("copy", 33, 17)]
+    n = len(expand(ops))
+    lz10file = bytes([0x10, n & 0xFF, (n >> 8) & 0xFF, (n >> 16) & 0xFF]) + enc_lz10(ops)
+    cont2("\"GCLZ\" in front of an LZ10 file", "GCLZ", "GCLZ", b"GCLZ" + lz10file, ops, "GCLZ.cs:33-55")
+    cont2("\"CXLZ\" in front of an LZ10 file", "CXLZ", "CXLZ", b"CXLZ" + lz10file, ops, "CXLZ.cs:34-56")
+    n = len(expand(ops11))
+    cont2("\"COMP\" in front of an LZ11 file", "COMP", "COMP", b"COMP" + bytes([0x11, n & 0xFF, (n >> 8) & 0xFF, (n >> 16) & 0xFF]) + enc_lz11(ops11), ops11, "COMP.cs:34-56")
+    n = len(expand(opsy))
+    cont2("\"Yaz1\": Yaz0's header under another magic", "YAZ1", "Yaz1", b"Yaz1" + be32(n) + be32(0) + be32(0) + enc_yaz0(opsy), opsy, "Yaz1.cs:19-33, Yaz0.cs:58-64")
+    opso = [("lit", pat(20, 30)), ("copy", 20, 8, "M2b"), ("copy", 3, 4, "M2"), ("lit", b"q"), ("copy", 21, 6, "M2b"), ("lit", pat(5, 31))]
+    body = enc_lzo(opso)
+    plain = [(o[0],) + tuple(o[1:3]) for o in opso]
+    cont2("\"LZOn\" 00 2F F1 71 + BE size + BE compressed size + an LZO stream with its end marker", "LZON", "LZOn",
+          b"LZOn\x00\x2f\xf1\x71" + be32(len(expand(plain))) + be32(len(body)) + body, plain, "LZOn.cs:41-60")
+
+    # ---- LZ4: legacy frames and LZ4 frames
+    b1 = [("lit", pat(12, 40)), ("copy", 12, 8), ("copy", 1, 30), ("lit", pat(5, 41))]
+    b2 = [("lit", pat(7, 42)), ("copy", 3, 20), ("lit", pat(6, 43))]
+    blk1, blk2 = enc_lz4(b1), enc_lz4(b2)
+    cont2("legacy frame: magic 0x184C2102 + (u32 LE block size + block) x 2, ended by the end of the file; every block starts a new window", "LZ4_LEGACY", "LZ4Legacy",
+          le32(0x184C2102) + le32(len(blk1)) + blk1 + le32(len(blk2)) + blk2, b1 + b2, "LZ4.cs:50-58, :96-111, :162-175", provides_size=False)
+    raw2 = pat(23, 44)
+    desc = bytes([0x40 | 0x20, 0x40])                                  # version 01, independent blocks; 64 KiB blocks
+    frame = le32(0x184D2204) + desc + bytes([(xxh32(desc) >> 8) & 0xFF]) + le32(len(blk1)) + blk1 + le32(0x80000000 | len(raw2)) + raw2 + le32(0)
+    cont2("LZ4 frame: descriptor FLG / BD / header checksum byte, a compressed block, an UNCOMPRESSED block (size with bit 31), EndMark", "LZ4_FRAME", "LZ4",
+          frame, b1 + [("lit", raw2)], "LZ4.Frame.cs:107-150, LZ4.FrameDescriptor.cs:18-44", provides_size=False)
+    # linked blocks (no independence flag): the second block copies from the first block's output; content size, block and content checksums
+    b3 = [("lit", pat(4, 45)), ("copy", 30, 12), ("copy", 5, 4)]      # distance 30 reaches into block 1's output
+    blk3 = enc_lz4(b3)
+    content = expand(b1 + b3)
+    desc = bytes([0x40 | 0x10 | 0x08 | 0x04, 0x50]) + len(content).to_bytes(8, "little")
+    frame = le32(0x184D2204) + desc + bytes([(xxh32(desc) >> 8) & 0xFF]) + le32(len(blk1)) + blk1 + le32(xxh32(blk1)) + le32(len(blk3)) + blk3 + le32(xxh32(blk3)) + le32(0) + le32(xxh32(content))
+    cont2("LZ4 frame with linked blocks (one window for the frame), ContentSize, block checksums and a content checksum (xxHash32, seed 0)", "LZ4_FRAME", "LZ4",
+          frame, b1 + b3, "LZ4.Frame.cs:120, :136-138, :152-173", provides_size=False)
+    skip = le32(0x184D2A53) + le32(5) + b"SKIP!"
+    cont2("a skippable frame (magic 0x184D2A50..5F + u32 size) between two frames of one file", "LZ4_FRAME", "LZ4",
+          le32(0x184C2102) + le32(len(blk2)) + blk2 + skip + le32(0x184D2204) + bytes([0x60, 0x40]) + bytes([(xxh32(bytes([0x60, 0x40])) >> 8) & 0xFF]) + le32(len(blk1)) + blk1 + le32(0),
+          b2 + b1, "LZ4.cs:52-93", provides_size=False)
+
+    # ---- Snappy framing
+    s1 = [("lit", pat(9, 50)), ("copy", 9, 4), ("copy", 1, 11), ("lit", pat(3, 51))]
+    sb = enc_snappy(s1)
+    rawc = pat(17, 52)
+    ident = b"\xff\x06\x00\x00sNaPpY"
+    def u24(v): return bytes([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF])
+    def mask(c): return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    blob = ident + b"\x00" + u24(4 + len(sb)) + le32(mask(crc32c(expand(s1)))) + sb + b"\xfe" + u24(3) + b"pad" + b"\x01" + u24(4 + len(rawc)) + le32(mask(crc32c(rawc))) + rawc + b"\x80" + u24(2) + b"zz"
+    cont2("stream identifier + a compressed chunk (masked CRC-32C, raw Snappy body) + a padding chunk (0xFE) + an uncompressed chunk + a skippable chunk (0x80)", "SNAPPY", "Snappy",
+          blob, s1 + [("lit", rawc)], "Snappy.cs:39-68", provides_size=False)
     return out
 
 
