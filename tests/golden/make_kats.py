@@ -556,6 +556,16 @@ def build_containers():
     cont2("\"LZOn\" 00 2F F1 71 + BE size + BE compressed size + an LZO stream with its end marker", "LZON", "LZOn",
           b"LZOn\x00\x2f\xf1\x71" + be32(len(expand(plain))) + be32(len(body)) + body, plain, "LZOn.cs:41-60")
 
+    # ---- the LZSS-bodied wrappers (LZSS.DefaultProperties and Lzss0Properties are the same geometry: LZSS.cs:33-34)
+    body = enc_lzss(opss); n = len(expand(opss))
+    cont2("\"AKLZ~?Qd=\\xCC\\xCC\\xCD\" (12 bytes) + BE size + LZSS body", "AKLZ", "AKLZ", b"AKLZ\x7e\x3f\x51\x64\x3d\xcc\xcc\xcd" + be32(n) + body, opss, "AKLZ.cs:14, :35-40")
+    cont2("\"LZ01\" + LE file length + LE size + LE 0 + LZSS body", "LZ01", "LZ01", b"LZ01" + le32(16 + len(body)) + le32(n) + le32(0) + body, opss, "LZ01.cs:37-52")
+    cont2("no magic: LE compressed size (the body's) + LE size + LZSS body (whose first flag byte has bit 0 set: IsMatch)", "LZSEGA", "LZSega", le32(len(body)) + le32(n) + body, opss, "LZSega.cs:21-33, :41-46")
+    cont2("\"SSZL\" + LE 0 + LE compressed size + LE size + LZSS body", "LEVEL5LZSS", "Level5LZSS", b"SSZL" + le32(0) + le32(len(body)) + le32(n) + body, opss, "Level5LZSS.cs:23-24, :34-49")
+    cont2("\"MDB4\" + LE size + 1 + LE size + LE compressed size + 16 zero bytes + LZSS body", "MDB4", "MDB4", b"MDB4" + le32(n + 1) + le32(n) + le32(len(body)) + bytes(16) + body, opss, "MDB4.cs:33-50, :57-64")
+    cont2("\"FCMP\" + LE size + LE 305397760 + LZSS body", "FCMP", "FCMP", b"FCMP" + le32(n) + le32(305397760) + body, opss, "FCMP.cs:35-41, :47-48")
+    cont2("\"IECP\" + LE size + LZSS body", "IECP", "IECP", b"IECP" + le32(n) + body, opss, "IECP.cs:34-39")
+
     # ---- LZ4: legacy frames and LZ4 frames
     b1 = [("lit", pat(12, 40)), ("copy", 12, 8), ("copy", 1, 30), ("lit", pat(5, 41))]
     b2 = [("lit", pat(7, 42)), ("copy", 3, 20), ("lit", pat(6, 43))]
