@@ -566,6 +566,15 @@ def build_containers():
     cont2("\"FCMP\" + LE size + LE 305397760 + LZSS body", "FCMP", "FCMP", b"FCMP" + le32(n) + le32(305397760) + body, opss, "FCMP.cs:35-41, :47-48")
     cont2("\"IECP\" + LE size + LZSS body", "IECP", "IECP", b"IECP" + le32(n) + body, opss, "IECP.cs:34-39")
 
+    cont2("no magic: LE size + LZSS body; recognised by the file extension only, so IsMatch on bytes alone is false", "GCZ", "GCZ", le32(n) + body, opss, "GCZ.cs:29-41")
+    out[-1]["is_match"] = False
+    opse = [("lit", pat(11, 60)), ("copy", 11, 3), ("copy", 1, 66), ("lit", b"\x01\x02"), ("copy", 70, 40), ("copy", 2, 5)]
+    plain4, bodye = pat(4, 61), enc_lzss(opse, wbits=10, lbits=6, thr=2)
+    cont2("\"ECD\" + 1 (compressed) + BE plain size + BE compressed size + BE size + 4 plain bytes + LZSS(0x400, 0x42, 3, 0x3BE) body", "ECD", "ECD",
+          b"ECD\x01" + be32(4) + be32(4 + len(bodye)) + be32(4 + len(expand(opse))) + plain4 + bodye, [("lit", plain4)] + opse, "ECD.cs:18, :44-80")
+    bodyo = enc_lzo(opso)
+    cont2("\"SDPC\" + LE size + an LZO stream", "SDPC", "SDPC", b"SDPC" + le32(len(expand(plain))) + bodyo, plain, "SDPC.cs:31-32, :44-57")
+
     # ---- LZ4: legacy frames and LZ4 frames
     b1 = [("lit", pat(12, 40)), ("copy", 12, 8), ("copy", 1, 30), ("lit", pat(5, 41))]
     b2 = [("lit", pat(7, 42)), ("copy", 3, 20), ("lit", pat(6, 43))]
