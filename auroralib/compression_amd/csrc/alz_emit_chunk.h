@@ -152,7 +152,8 @@ __device__ __forceinline__ void chunk_mirror(bool wr, u32 wbase, u32 a0, u32 LW,
 // byte mask of window dword j from the 20-bit byte map of the chunk (bit x = window byte x belongs to the chunk)
 __device__ __forceinline__ u32 chunk_mask(u32 bmap, u32 j) {
     const u32 nib = (bmap >> (4u * j)) & 0xFu;
-    return ((nib * 0x204081u) & 0x01010101u) * 0xFFu;
+    const u32 t = (nib * 0x204081u) & 0x01010101u;          // bit k of the nibble -> bit 0 of byte k (a 24-bit multiply: full rate)
+    return (t << 8) - t;                                    // x 0xFF without v_mul_lo_u32 (a quarter-rate instruction)
 }
 // 24 source bytes at a dword-aligned LDS address, funnelled to the five window dwords (t = byte offset of the first one)
 __device__ __forceinline__ void chunk_read(const lds_u8* sbase, u32 t, u32& N0, u32& N1, u32& N2, u32& N3, u32& N4) {
