@@ -164,6 +164,126 @@ def enc_3cursor(ops, mio0):
     return fl + bytes(toks) + bytes(lits), len(fl), len(fl) + len(toks)
 
 
+def enc_clz0(ops):
+    """CLZ0.DecompressHeaderless  AuroraLib.Compression-Extended/Marvelous/CLZ0.cs:66-100: flags LSB first (FlagReader(source, Endian.Little) :70),
+    bit 1 = match; two bytes: low 8 bits of the window delta, then delta[11:8] << 4 | (length - 3); distance = 0x1000 - delta."""
+    f = Flags8(msb_first=False)
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(0); f.out.append(t[1])                          # :89-92
+        else:
+            _, d, n = t
+            assert 3 <= n <= 18 and 1 <= d <= 4096
+            delta = 0x1000 - d                                    # :82
+            f.bit(1); f.out += bytes([delta & 0xFF, ((delta >> 8) << 4) | (n - 3)])   # :78-83
+    return bytes(f.out)
+
+
+def enc_lz02(ops, terminate=True):
+    """LZ02.DecompressHeaderless  AuroraLib.Compression-Extended/Camelot/LZ02.cs:84-121: flags MSB first, bit 1 = match: DDDDLLLL DDDDDDDD,
+    length = nibble + 1 (2..16); nibble 0: distance 0 is the END of the stream, otherwise a third byte holds length - 17 (17..272).  A
+    distance field of 0 under a non-zero nibble reaches LzWindows.BackCopy as 0, i.e. one whole window (4096)."""
+    f = Flags8(msb_first=True)
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(0); f.out.append(t[1])                          # :114-117
+        else:
+            _, d, n = t
+            f.bit(1)
+            if 2 <= n <= 16:
+                assert 1 <= d <= 4096
+                dd = d & 0xFFF                                    # 4096 -> 0
+                f.out += bytes([((dd >> 8) << 4) | (n - 1), dd & 0xFF])            # :92-96
+            else:
+                assert 17 <= n <= 272 and 1 <= d <= 4095
+                f.out += bytes([(d >> 8) << 4, d & 0xFF, n - 17])                  # :98-109
+    if terminate:
+        f.bit(1); f.out += bytes([0, 0])                          # :100-107
+    return bytes(f.out)
+
+
+def enc_lz40(ops):
+    """LZ40.DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/LZ40.cs:84-132: the flag byte is stored NEGATED (flag = (byte)-ReadByte()
+    :97), consumed from bit 7 down, bit 1 = match: a little-endian u16 distance << 4 | length (2..15); length field 0: + one byte, length - 16
+    (16..271); length field 1: + a little-endian u16, length - 272 (272..65 807).  Distance field 0 = one whole window."""
+    f = Flags8(msb_first=True)
+    flagpos = []
+    for t in tokens(ops):
+        if f.n == 0:
+            flagpos.append(len(f.out))
+        if t[0] == "lit":
+            f.bit(0); f.out.append(t[1])                          # :123-126
+        else:
+            _, d, n = t
+            assert 1 <= d <= 4096
+            dd = (d & 0xFFF) << 4
+            f.bit(1)
+            if 2 <= n <= 15:
+                f.out += bytes([(dd | n) & 0xFF, (dd | n) >> 8])                   # :103-105
+            elif n <= 271:
+                f.out += bytes([dd & 0xFF, dd >> 8, n - 16])                       # :108-112
+            else:
+                v = n - 272
+                assert v < (1 << 16)
+                f.out += bytes([(dd | 1) & 0xFF, (dd | 1) >> 8, v & 0xFF, v >> 8])  # :113-117
+    out = bytearray(f.out)
+    for q in flagpos:
+        out[q] = (-out[q]) & 0xFF
+    return bytes(out)
+
+
+class FlagsWide:
+    """FlagReader with a flag word of `nbytes` bytes, big endian, consumed from the top bit down (FlagReader(source, Endian.Big, n, Endian.Big)):
+    the word sits where the decoder is when it needs a bit and has none left, i.e. in front of the payload of its first token."""
+
+    def __init__(self, nbytes):
+        self.w, self.out, self.pos, self.n = nbytes, bytearray(), None, 0
+
+    def bit(self, v):
+        if self.n == 0:
+            self.pos = len(self.out); self.out += bytes(self.w); self.n = 8 * self.w
+        k = self.n - 1                                            # bit index in the word, MSB first
+        if v:
+            self.out[self.pos + (self.w - 1 - k // 8)] |= 1 << (k % 8)
+        self.n -= 1
+
+
+def enc_lzhudson(ops):
+    """LZHudson.DecompressHeaderless  AuroraLib.Compression.Nintendo/HudsonSoft/LZHudson.cs:52-53: Yay0's tokens (Yay0.cs:110-144) behind 32-bit
+    big-endian flag words, all three cursors on one stream."""
+    f = FlagsWide(4)
+    for t in tokens(ops):
+        if t[0] == "lit":
+            f.bit(1); f.out.append(t[1])
+        else:
+            tok, lb = yay0_token(t[1], t[2])
+            f.bit(0); f.out += tok
+            if lb is not None:
+                f.out.append(lb)
+    return bytes(f.out)
+
+
+def enc_smsr00(ops):
+    """SMSR00.DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/SMSR00.cs:85-131: a code section of big-endian u16 words -- 16-bit
+    masks consumed from bit 15 down (1 = literal) and, interleaved in consumption order, one word per match: (length - 3) << 12 |
+    (distance - 1) -- followed by the literal section.  Returns (stream, aux0 = length of the code section)."""
+    codes, lits, mpos, nbits = bytearray(), bytearray(), None, 0
+    for t in tokens(ops):
+        if nbits == 0:
+            mpos = len(codes); codes += bytes(2); nbits = 16       # :101-105
+        k = nbits - 1
+        if t[0] == "lit":
+            codes[mpos + (1 - k // 8)] |= 1 << (k % 8)            # :107-110
+            lits.append(t[1])
+        else:
+            _, d, n = t
+            assert 3 <= n <= 18 and 1 <= d <= 4096
+            v = ((n - 3) << 12) | (d - 1)                         # :113-117
+            codes += bytes([v >> 8, v & 0xFF])
+        nbits -= 1
+    return bytes(codes) + bytes(lits), len(codes)
+
+
 # ------------------------------------------------------------------------------------------------ PRS
 class LazyFlags:
     """FlagReader over the SAME stream as the data (PRS.cs:62): a flag byte sits wherever the decoder happens to be when it
@@ -449,6 +569,29 @@ def build():
     K["snappy_raw"].append(case("distance 0xFFFF (copy-2), 2047 (largest copy-1) and 2048; a three-byte varint size", "snappy_raw", enc_snappy(far), far, "Snappy.cs:235-243", decom_len=0))
     ops = [("lit", b"\x00")]
     K["snappy_raw"].append(case("the shortest stream: size 1, one literal", "snappy_raw", enc_snappy(ops), ops, "Snappy.cs:221-233", decom_len=0))
+    # ---- the other flag-byte formats of the lane-parallel kernel family: CLZ0, LZ02, LZ40, LZHudson, SMSR00
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x10\x20"), ("copy", 2, 9), ("copy", 33, 17)]
+    K.setdefault("clz0", []).append(case("lengths 3 / 9 / 17 / 18, distances 1, 2 and 33; flags LSB first", "clz0", enc_clz0(ops), ops, "CLZ0.cs:66-100"))
+    big = [("lit", pat(64, 9))] + [("copy", 64, 18)] * 224 + [("copy", 4096, 18), ("copy", 4095, 3), ("copy", 256, 4), ("copy", 255, 5), ("lit", b"end")]
+    K["clz0"].append(case("distance 4096 (delta 0), 4095 (delta 1), 256 / 255 (the delta's low byte wraps)", "clz0", enc_clz0(big), big, "CLZ0.cs:78-83"))
+    ops = [("lit", A), ("copy", 9, 2), ("copy", 1, 16), ("copy", 4, 17), ("copy", 7, 272), ("lit", b"\x7f"), ("copy", 255, 100), ("copy", 256, 3)]
+    K.setdefault("lz02", []).append(case("2-byte form 2 / 16 / 3, 3-byte form 17 / 272 / 100, the terminator token", "lz02", enc_lz02(ops), ops, "LZ02.cs:84-121"))
+    big = [("lit", pat(50, 5)), ("copy", 50, 272)] + [("copy", 322, 272)] * 14 + [("copy", 4095, 17), ("copy", 4096, 16), ("copy", 4096, 2), ("lit", b"ok")]
+    K["lz02"].append(case("distance 4095 in the 3-byte form; a distance field of 0 under a non-zero length nibble = one whole window", "lz02", enc_lz02(big), big, "LZ02.cs:92-109, LzWindows.cs:72-100"))
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 1, 15), ("copy", 4, 16), ("copy", 7, 271), ("lit", b"\x7f"), ("copy", 100, 272), ("copy", 300, 1000), ("copy", 2, 2)]
+    K.setdefault("lz40", []).append(case("2-byte form 3 / 15 / 2, 3-byte form 16 / 271, 4-byte form 272 / 1000; negated flag bytes", "lz40", enc_lz40(ops), ops, "LZ40.cs:84-132"))
+    big = [("lit", pat(50, 5)), ("copy", 50, 4046), ("copy", 4096, 271), ("copy", 4095, 15), ("copy", 4096, 3), ("copy", 4096, 300)]
+    K["lz40"].append(case("a distance field of 0 (= 4096) in each of the three forms, and 4095", "lz40", enc_lz40(big), big, "LZ40.cs:103-119"))
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 5, 17), ("copy", 1, 18), ("copy", 2, 273), ("lit", b"\x00"), ("copy", 21, 100)] + [("lit", pat(3, 70 + i)) if i % 3 else ("copy", 7, 4) for i in range(30)]
+    K.setdefault("lzhudson", []).append(case("Yaz0's token forms behind two 32-bit big-endian flag words (the second one partial)", "lzhudson", enc_lzhudson(ops), ops, "LZHudson.cs:52-53, Yay0.cs:110-144"))
+    big = [("lit", pat(40, 6)), ("copy", 40, 273)] + [("copy", 313, 273)] * 14 + [("copy", 4096, 39), ("copy", 4095, 3), ("lit", b"ok")]
+    K["lzhudson"].append(case("distance 4096 and 4095", "lzhudson", enc_lzhudson(big), big, "Yay0.cs:127"))
+    ops = [("lit", A), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x42"), ("copy", 2, 10), ("copy", 12, 18)] + [("lit", pat(2, 80 + i)) if i % 2 else ("copy", 5, 6) for i in range(20)]
+    st, a0 = enc_smsr00(ops)
+    K.setdefault("smsr00", []).append(case("masks of 16 tokens and the match words between them, literals in their own section (three masks, the last one partial)", "smsr00", st, ops, "SMSR00.cs:85-131", aux0=a0))
+    big = [("lit", pat(64, 9))] + [("copy", 64, 18)] * 224 + [("copy", 4096, 18), ("copy", 4095, 3), ("lit", b"end")]
+    st, a0 = enc_smsr00(big)
+    K["smsr00"].append(case("distance 4096 (12 bits all set) and 4095", "smsr00", st, big, "SMSR00.cs:113-117", aux0=a0))
     return K
 
 

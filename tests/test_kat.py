@@ -44,9 +44,12 @@ def _expect(c):
 
 def test_every_north_star_body_has_at_least_three_vectors():
     names = {os.path.basename(f)[4:-5] for f in glob.glob(os.path.join(GOLD, "kat_*.json"))} - {"containers"}
-    assert names == {"lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_le", "lz4_block", "lzo", "snappy_raw"}
+    north = {"lzss", "lz10", "lz11", "yaz0", "yay0", "mio0", "prs_be", "prs_le", "lz4_block", "lzo", "snappy_raw"}
+    more = {"clz0", "lz02", "lz40", "lzhudson", "smsr00"}      # the other flag-byte formats of the lane-parallel kernel family (two each)
+    assert names == north | more
     for f in glob.glob(os.path.join(GOLD, "kat_*.json")):
-        assert len(json.load(open(f))["cases"]) >= 3, f
+        name = os.path.basename(f)[4:-5]
+        assert len(json.load(open(f))["cases"]) >= (3 if name in north or name == "containers" else 2), f
 
 
 def _format_class(c):
