@@ -284,6 +284,40 @@ def enc_smsr00(ops):
     return bytes(codes) + bytes(lits), len(codes)
 
 
+def enc_fastlz(ops, level):
+    """FastLZ.DecompressHeaderless  AuroraLib.Compression/Formats/Common/FastLZ.cs:63-160: control bytes; below 32: a run of ctrl + 1 literals
+    (the FIRST control byte carries level - 1 in its top three bits, :66, :74); otherwise a match: (ctrl >> 5) - 1 = length - 3 (6 = extended),
+    13-bit distance - 1.  Level 1: one extension byte.  Level 2: extension bytes chained while they are 255 (:118-126), and a distance field
+    of 0x1FFF announces two more big-endian bytes holding distance - 1 - 0x1FFF (:131-137)."""
+    out, first = bytearray(), True
+    for op in ops:
+        if op[0] == "lit":
+            lit = bytes(op[1])
+            for i in range(0, len(lit), 32):
+                run = lit[i:i + 32]
+                out.append((len(run) - 1) | (((level - 1) << 5) if first else 0)); first = False
+                out += run
+        else:
+            assert not first                                       # a stream starts with literals
+            _, d, n = op
+            length, dist = n - 3, d - 1
+            assert length >= 0
+            sd = min(dist, 0x1FFF) if level == 2 else dist
+            assert sd <= 0x1FFF and (level == 2 or length <= 6 + 255)
+            out.append(((min(length, 6) + 1) << 5) | (sd >> 8))
+            if length >= 6:
+                rest = length - 6
+                while level == 2 and rest >= 255:
+                    out.append(255); rest -= 255
+                out.append(rest)
+            out.append(sd & 0xFF)
+            if level == 2 and dist >= 0x1FFF:
+                ext = dist - 0x1FFF
+                assert ext <= 0xFFFF
+                out += bytes([ext >> 8, ext & 0xFF])
+    return bytes(out)
+
+
 # ------------------------------------------------------------------------------------------------ PRS
 class LazyFlags:
     """FlagReader over the SAME stream as the data (PRS.cs:62): a flag byte sits wherever the decoder happens to be when it
@@ -592,6 +626,15 @@ def build():
     big = [("lit", pat(64, 9))] + [("copy", 64, 18)] * 224 + [("copy", 4096, 18), ("copy", 4095, 3), ("lit", b"end")]
     st, a0 = enc_smsr00(big)
     K["smsr00"].append(case("distance 4096 (12 bits all set) and 4095", "smsr00", st, big, "SMSR00.cs:113-117", aux0=a0))
+    # ---- FastLZ, both levels (level 2 is what the round-2 encoder work writes)
+    ops = [("lit", pat(1, 90)), ("copy", 1, 3), ("lit", pat(32, 91)), ("copy", 33, 8), ("lit", pat(33, 92)), ("copy", 2, 264), ("copy", 256, 9), ("copy", 100, 100)]
+    K.setdefault("fastlz", []).append(case("level 1: literal runs of 1 / 32 / 33 (two control bytes), match lengths 3 / 8 / 9 (extension byte 0) / 264 (255) / 100", "fastlz", enc_fastlz(ops, 1), ops, "FastLZ.cs:71-105", decom_len=0))
+    far = [("lit", pat(64, 93))] + [("copy", 64, 264)] * 31 + [("copy", 8192, 5), ("copy", 8191, 3), ("lit", b"z")]
+    K["fastlz"].append(case("level 1: distance 8192 (all 13 bits set) and 8191", "fastlz", enc_fastlz(far, 1), far, "FastLZ.cs:84-91", decom_len=0))
+    ops = [("lit", pat(20, 94)), ("copy", 20, 3), ("copy", 1, 9), ("copy", 7, 263), ("copy", 7, 264), ("copy", 5, 265), ("copy", 3, 1000), ("lit", pat(40, 95)), ("copy", 40, 519)]
+    K["fastlz"].append(case("level 2 (tag in the first control byte): length extension 0 / 254 / 255 + 0 / 255 + 1 / 255 x 3 + 226 / 255 x 2 + 0", "fastlz", enc_fastlz(ops, 2), ops, "FastLZ.cs:107-160", decom_len=0))
+    far = [("lit", pat(64, 96))] + [("copy", 64, 1000)] * 74 + [("copy", 8191, 4), ("copy", 8192, 5), ("copy", 8193, 6), ("copy", 73727, 3), ("copy", 73727, 700), ("lit", b"!")]
+    K["fastlz"].append(case("level 2: distance 8191 (short form), 8192 (field 0x1FFF + extension 0), 8193, and 73 727 = 0x1FFF + 0xFFFF + 1, the largest", "fastlz", enc_fastlz(far, 2), far, "FastLZ.cs:128-139", decom_len=0))
     return K
 
 
