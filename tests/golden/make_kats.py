@@ -318,6 +318,46 @@ def enc_fastlz(ops, level):
     return bytes(out)
 
 
+def enc_cns(ops):
+    """CNS.DecompressHeaderless  AuroraLib.Compression-Extended/Specialized/CNS.cs:66-98: a length byte; bit 7 clear: that many literals follow
+    (0..127); bit 7 set: (byte & 0x7F) + 3 bytes from distance next byte + 1 (1..256)."""
+    out = bytearray()
+    for op in ops:
+        if op[0] == "lit":
+            lit = bytes(op[1])
+            for i in range(0, len(lit), 127):
+                run = lit[i:i + 127]
+                out.append(len(run)); out += run                  # :79-82
+        else:
+            _, d, n = op
+            assert 3 <= n <= 130 and 1 <= d <= 256
+            out += bytes([0x80 | (n - 3), d - 1])                 # :83-90
+    return bytes(out)
+
+
+def enc_wflz(ops, big):
+    """WFLZ.DecompressHeaderless  AuroraLib.Compression-Extended/WayForward/WFLZ.cs:82-112: blocks of u16 distance (byte order of the file), length
+    byte (+ 4 = 5..259; 0 = no match), literal count byte, then the literals; a block of zero length and zero literals ends the stream."""
+    out, i, ops = bytearray(), 0, list(ops)
+    def block(d, n, lit):
+        out.extend([(d >> 8) & 0xFF, d & 0xFF] if big else [d & 0xFF, (d >> 8) & 0xFF])
+        out.append(n - 4 if n else 0); out.append(len(lit)); out.extend(lit)
+    while i < len(ops):
+        d = n = 0
+        if ops[i][0] == "copy":
+            _, d, n = ops[i]; i += 1
+            assert 5 <= n <= 259 and 1 <= d <= 0xFFFF
+        lit = b""
+        if i < len(ops) and ops[i][0] == "lit":
+            lit = bytes(ops[i][1]); i += 1
+        first = lit[:255]
+        block(d, n, first)                                        # :95-107
+        for k in range(255, len(lit), 255):
+            block(0, 0, lit[k:k + 255])                           # literals only: length 0, count != 0
+    block(0, 0, b"")                                              # :100-103
+    return bytes(out)
+
+
 # ------------------------------------------------------------------------------------------------ PRS
 class LazyFlags:
     """FlagReader over the SAME stream as the data (PRS.cs:62): a flag byte sits wherever the decoder happens to be when it
@@ -635,6 +675,17 @@ def build():
     K["fastlz"].append(case("level 2 (tag in the first control byte): length extension 0 / 254 / 255 + 0 / 255 + 1 / 255 x 3 + 226 / 255 x 2 + 0", "fastlz", enc_fastlz(ops, 2), ops, "FastLZ.cs:107-160", decom_len=0))
     far = [("lit", pat(64, 96))] + [("copy", 64, 1000)] * 74 + [("copy", 8191, 4), ("copy", 8192, 5), ("copy", 8193, 6), ("copy", 73727, 3), ("copy", 73727, 700), ("lit", b"!")]
     K["fastlz"].append(case("level 2: distance 8191 (short form), 8192 (field 0x1FFF + extension 0), 8193, and 73 727 = 0x1FFF + 0xFFFF + 1, the largest", "fastlz", enc_fastlz(far, 2), far, "FastLZ.cs:128-139", decom_len=0))
+    # ---- CNS and WFLZ (token-queue kernels, one-byte / four-byte headers)
+    ops = [("lit", pat(3, 100)), ("copy", 3, 3), ("copy", 1, 130), ("lit", pat(127, 101)), ("copy", 127, 64), ("lit", pat(128, 102)), ("copy", 256, 5), ("copy", 255, 4), ("lit", b"")]
+    K.setdefault("cns", []).append(case("literal runs 3 / 127 / 128 (two headers) / 0, match lengths 3 / 130 / 64, distances 1 / 3 / 255 / 256 (one byte + 1)", "cns", enc_cns(ops), ops, "CNS.cs:66-98"))
+    ops = [("lit", b"a"), ("copy", 1, 129), ("lit", b"b")]
+    K["cns"].append(case("the shortest shapes: one literal, an overlapping match, one literal", "cns", enc_cns(ops), ops, "CNS.cs:79-90"))
+    for big in (False, True):
+        name = "wflz_be" if big else "wflz"
+        ops = [("lit", pat(9, 110)), ("copy", 9, 5), ("copy", 1, 259), ("lit", pat(255, 111)), ("copy", 300, 100), ("lit", pat(256, 112)), ("copy", 2, 6)]
+        K.setdefault(name, []).append(case("match lengths 5 / 259 / 100 / 6, literal counts 9 / 0 / 255 / 256 (a literal-only block follows) / 0, the end block", name, enc_wflz(ops, big), ops, "WFLZ.cs:82-112", decom_len=0))
+        far = [("lit", pat(200, 113))] + [("copy", 200, 259)] * 253 + [("copy", 0xFFFF, 5), ("copy", 0x0100, 7), ("copy", 0x00FF, 9), ("lit", b"!")]
+        K[name].append(case("distance 0xFFFF, 0x0100 and 0x00FF (the two distance bytes in the file's byte order)", name, enc_wflz(far, big), far, "WFLZ.cs:90-99", decom_len=0))
     return K
 
 
