@@ -951,9 +951,13 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
     // 4 096 windows, and the load's latency was exposed once per window), and match[p + 1] comes from the neighbour lane.
     int Pn = -1;                    // window held in `nx` (-1: none)
     uint2 nx = make_uint2(0, 0);
+    u32 carryw = 0xFFFFFFFFu;       // window whose lane 0 starts a token found by the window in front of it (none: ~0)
     while (cur <= limit) {
         const int P = cur & ~63;    // window that holds the cursor (windows the cursor jumps over keep their zero mask)
         const int p = P + lane;
+        const bool carry_in = carryw == ((u32)P >> 6);
+        if (!carry_in && carryw != 0xFFFFFFFFu && lane == 0) mask[carryw] = 1ull;     // (that window is jumped over: its only bit)
+        carryw = 0xFFFFFFFFu;
         // match[p] and match[p+1] (positions above `limit` were never searched: no match)
         uint2 a = make_uint2(0, 0);
         if (P == Pn) a = nx; else if (p <= limit) a = m[p];
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
             if (lazyc && l1 > l0) { startrel = 2; const int e = p + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 2 > stop ? p + 2 : stop) - p; }
             else { startrel = 1; const int skip = lazyc ? 1 : 0; const int e = p + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 1 + skip > stop ? p + 1 + skip : stop) - p; }
         }
-        u64 bits = 0;
+        u64 bits = carry_in ? 1ull : 0ull;
         int rel = cur - P;
         // The walk over the window: a chain of "cursor += jump[cursor]" hops, ~18 per window.  Written in C++ each hop is three
         // v_readlane and ~30 scalar instructions, and with 32 waves per CU the kernel was bound by the CU's one scalar unit
@@ -994,8 +998,8 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 : [jump] "v"(jump), [lim] "s"(lim)
                 : "scc");
             const u64 s1 = __ballot(startrel == 1) & M, s2 = __ballot(startrel == 2) & M;
-            bits = s1 | (s2 << 1);
-            if ((s2 >> 63) && lane == 0) mask[(P >> 6) + 1] = 1ull;          // start in lane 0 of the next window
+            bits |= s1 | (s2 << 1);
+            if (s2 >> 63) carryw = ((u32)P >> 6) + 1u;                         // start in lane 0 of the next window
             rel = (int)r;
         }
         else while (rel < 64 && P + rel <= limit) {
@@ -1019,12 +1023,14 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 sr = __builtin_amdgcn_readlane(startrel, rel);
             }
             if (sr == 1) bits |= 1ull << rel;
-            else if (sr == 2) { if (rel + 1 < 64) bits |= 1ull << (rel + 1); else if (lane == 0) mask[(P >> 6) + 1] = 1ull; }   // start in lane 0 of the next window
+            else if (sr == 2) { if (rel + 1 < 64) bits |= 1ull << (rel + 1); else carryw = ((u32)P >> 6) + 1u; }   // start in lane 0 of the next window
             rel += j;
         }
-        if (lane == 0) mask[P >> 6] |= bits;      // the mask array is zeroed before the launch
+        if (bits && lane == 0) mask[P >> 6] = bits;      // (a plain store: the mask array is zeroed before the launch, a window is visited once,
+                                                         //  and the one bit another window contributes travels in `carryw` -- no load per window)
         cur = P + rel;
     }
+    if (carryw != 0xFFFFFFFFu && lane == 0) mask[carryw] = 1ull;
 }
 
 template <int FMT>
