@@ -389,6 +389,58 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
     return true;
 }
 
+// The same function as kernel B runs it (the exact recomputations inside the roles / emit kernels keep the plain form above: the
+// serial emit kernels, one lane per wavefront, ran 12 % slower with this body inlined).  MatchSearch :214-246 with ChainMatches
+// :248-282; returns false when CAP > 0 and a
+// candidate still matched after CAP bytes
+template <bool MINT>
+__device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
+                                             int& best_d, int& best_l) {
+    const u8* dp = data + pos;
+    int cur = p4[pos];
+    int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+    const int cmp_max = (cap > 0 && best_possible > cap) ? cap : best_possible;
+    best_d = 0; best_l = 0; int best_score = -1;
+    int attempts = g.max_chain;
+    // Most candidates differ from the position inside their first eight bytes: that compare is one load against the position's
+    // own first qword (read once) and a count of trailing zeros; only a candidate that survives it enters the compare loop.
+    // (The kernel was bound by the scalar unit -- 87 scalar instructions per candidate, the exec-mask bookkeeping of two nested
+    // divergent loops with early exits -- not by its loads: L1 serves 90 % of them.)
+    const bool wide = cmp_max >= 8;
+    const u64 head = wide ? load64(dp) : 0ull;
+    bool capped = false;
+    while (cur != -1 && attempts-- > 0) {
+        const int dist = pos - cur;
+        if (dist > g.max_dist) break;
+        if (dist >= g.min_dist) {
+            int len;
+            if (wide) {
+                const u64 x = head ^ load64(data + cur);
+                len = x ? (__builtin_ctzll(x) >> 3) : 8 + match_len(dp + 8, data + cur + 8, cmp_max - 8);
+            } else len = match_len(dp, data + cur, cmp_max);
+            if (len == cmp_max && cmp_max < best_possible) { capped = true; break; }
+            const int score = score_match(g, len, dist);
+            if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
+        }
+        cur = p4[cur];
+    }
+    if (capped) return false;
+    if (MINT && best_l == 0) {                                          // small-match fallback :226-243
+        const int c2 = pm[pos];
+        if (c2 != -1) {
+            int dist = pos - c2;
+            if (dist < g.min_dist) dist = g.min_dist;
+            if (dist <= g.max_dist && pos - dist >= 0) {
+                int len = match_len(dp, data + pos - dist, cmp_max);
+                if (len == cmp_max && cmp_max < best_possible) return false;
+                (void)score_match(g, len, dist);
+                best_l = len; best_d = dist;
+            }
+        }
+    }
+    return true;
+}
+
 template <bool MINT>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
@@ -404,7 +456,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     uint2* m = match + pos_off[sid];
     for (int pos = (int)(blockIdx.x * 256 + threadIdx.x); pos <= limit; pos += (int)(gridDim.x * 256)) {
         int bd, bl;
-        if (match_search<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl)) m[pos] = make_uint2((u32)bd, (u32)bl);
+        if (match_search_b<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl)) m[pos] = make_uint2((u32)bd, (u32)bl);
         else m[pos] = make_uint2(ALZ_CAPPED, ALZ_CAPPED);
     }
 }
