@@ -401,28 +401,38 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
     const int cmp_max = (cap > 0 && best_possible > cap) ? cap : best_possible;
     best_d = 0; best_l = 0; int best_score = -1;
-    int attempts = g.max_chain;
-    // Most candidates differ from the position inside their first eight bytes: that compare is one load against the position's
-    // own first qword (read once) and a count of trailing zeros; only a candidate that survives it enters the compare loop.
-    // (The kernel was bound by the scalar unit -- 87 scalar instructions per candidate, the exec-mask bookkeeping of two nested
-    // divergent loops with early exits -- not by its loads: L1 serves 90 % of them.)
-    const bool wide = cmp_max >= 8;
-    const u64 head = wide ? load64(dp) : 0ull;
-    bool capped = false;
-    while (cur != -1 && attempts-- > 0) {
-        const int dist = pos - cur;
-        if (dist > g.max_dist) break;
-        if (dist >= g.min_dist) {
-            int len;
-            if (wide) {
-                const u64 x = head ^ load64(data + cur);
-                len = x ? (__builtin_ctzll(x) >> 3) : 8 + match_len(dp + 8, data + cur + 8, cmp_max - 8);
-            } else len = match_len(dp, data + cur, cmp_max);
-            if (len == cmp_max && cmp_max < best_possible) { capped = true; break; }
-            const int score = score_match(g, len, dist);
-            if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
+    // The candidate loop is written for the wave, not for the lane: a fixed trip count (maxChain) with a per-lane `act` flag, one
+    // wave-uniform exit test, and straight-line, predicated code in between -- the first eight bytes of a candidate are one load
+    // against the position's own first qword (read once) and a count of trailing zeros; only a candidate that survives it enters the
+    // compare loop.  As two nested divergent loops with early exits the kernel was bound by the CU's scalar unit (79 % busy: 87
+    // scalar instructions of exec-mask bookkeeping per candidate), not by its loads (L1 serves 90 % of them).  Reading eight bytes
+    // at a candidate or at the position may run up to four bytes past the stream: inside the staging buffer's slack, never compared
+    // (lengths are clamped to cmp_max).
+    const u64 head = load64(dp);
+    bool act = cur != -1, capped = false;
+    const int chain = g.max_chain;
+    for (int it = 0; it < chain; it++) {
+        if (!__ballot(act)) break;
+        const int c = act ? cur : 0;
+        const int dist = pos - c;
+        const u64 x = head ^ load64(data + c);
+        const int nxt = p4[c];
+        const bool within = act && dist <= g.max_dist;                  // beyond maxDistance the walk ends  :259-260
+        const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
+        int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+        const bool more = ok && x == 0ull && cmp_max > 8;
+        if (__ballot(more)) { if (more) len = 8 + match_len(dp + 8, data + c + 8, cmp_max - 8); }
+        if (len > cmp_max) len = cmp_max;
+        bool stop = !within;
+        if (ok) {
+            if (len == cmp_max && cmp_max < best_possible) { capped = true; stop = true; }
+            else {
+                const int score = score_match(g, len, dist);
+                if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) stop = true; }
+            }
         }
-        cur = p4[cur];
+        cur = nxt;
+        act = act && !stop && cur != -1;
     }
     if (capped) return false;
     if (MINT && best_l == 0) {                                          // small-match fallback :226-243
