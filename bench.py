@@ -478,6 +478,7 @@ def cfg5(ctx, np, A, synth):
     dst_bytes = int(r2["dst_off"][-1]) + cap + 64
     out = []
     for q in (0, 8):
+        ctx.encode_batch(streams, raw, dst_bytes, quality=q)       # (first call at a quality: the context grows its device scratch -- head tables, links)
         t0 = time.perf_counter()
         dst, eres, aux = ctx.encode_batch(streams, raw, dst_bytes, quality=q)
         host_s = time.perf_counter() - t0
