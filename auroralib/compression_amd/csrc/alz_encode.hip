@@ -45,6 +45,8 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
 __device__ __forceinline__ u32 load32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ u64 load64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 
+__device__ __forceinline__ u32 scan_add(u32 v);
+
 // ---------------------------------------------------------------------------------------------- kernel A
 template <bool MINT>
 __global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
@@ -107,6 +109,107 @@ __global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src
             if (act) { if (pass == 0) p4[pos] = prev; else pm[pos] = prev; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // head stores reach L2 before the next step reads them
+    }
+}
+
+// Kernel A for windows up to 4 KiB WITHOUT the head table -- a round-2 experiment, bit-identical, kept behind ALZ_ENC_PREV_BLOCK=1
+// because it LOSES: 165 ms per 10 000 x 256 KiB against the 80 (Q0) / 103 (Q8) of enc_prev_kernel.  Kernel B stops at maxDistance, so
+// prev(p) only matters when it lies inside the window, and whatever lies further back may as well be "none" (the chain walk ends
+// either way: LzChainMatchFinder.cs:259-260).  The positions of a stream are cut into blocks of W >= maxDistance; a block looks at
+// its own W positions and the W in front of them, and finds prev() for its own by a counting sort on LDS: bucket = top 12 hash
+// bits, stable inside a bucket because ONE wavefront places the positions in order (lanes that meet in a bucket inside one step
+// are ranked by lane), so the previous position with the same hash is the first equal tag found walking back from a position's
+// own slot.  Every block is independent -- 640 000 of them per launch -- and touches global memory only to read its 2 W input
+// bytes and to write W links.  Why it loses: 52 KB of LDS per block leave three wavefronts per CU, and the placement is a chain
+// of dependent LDS round trips per 64 positions (count + prefix 31 ms, ordered placement 69 ms, walks 65 ms: `-DALZ_PBEXP`
+// builds of round 2); the order-free variant (plain atomics, whole-bucket scans) is quadratic in the buckets that runs of equal
+// bytes fill (1 815 ms on the synthetic data); bucket = LOW hash bits was 4x slower at 19 hash bits (uneven buckets).  A radix
+// sort over four wavefronts per block needs two 32 KB key buffers (two blocks per CU) and ~96 dependent steps: no better.
+#define ALZ_PB_BITS 12
+#define ALZ_PB_N (1u << ALZ_PB_BITS)
+template <bool MINT>
+__global__ __launch_bounds__(64) void enc_prev_block_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                            const u32* __restrict__ index_list, u32 count,
+                                                            int* __restrict__ prev4, int* __restrict__ prevm,
+                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip, u32 W) {
+    // (one wavefront per block: its LDS instructions execute in order, so a read sees every lane's earlier writes -- the phases
+    // below are separated by compiler barriers only, never by a wait for outstanding LDS traffic)
+    extern __shared__ u32 pb_lds[];
+    u32* cnt = pb_lds;                                     // per bucket: (first slot << 16) | slots filled so far
+    u32* keys = pb_lds + ALZ_PB_N;                         // 2 W sorted keys: tag << 14 | position relative to the block's input range
+    u8* owner = reinterpret_cast<u8*>(keys + 2u * W);      // contest table of a step: the lane that claimed a bucket last
+    const u32 sid = index_list[blockIdx.y];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;                               // FindNextBestMatch :159
+    const int out_lo = (int)(blockIdx.x * W);
+    if (out_lo > limit) return;
+    const int lane = (int)threadIdx.x;
+    const int out_hi = (int)(out_lo + W) <= limit + 1 ? (int)(out_lo + W) : limit + 1;
+    const int in_lo = blockIdx.x ? out_lo - (int)W : 0;
+    const int N = out_hi - in_lo;                          // <= 2 W
+    const u8* base = data + in_lo;
+    for (int pass = 0; pass < (MINT ? 2 : 1); pass++) {
+        int* out = (pass == 0 ? prev4 : prevm) + pos_off[sid] + in_lo;
+        const u32 hb = pass == 0 ? (u32)g.hash_bits : 16u, tshift = hb - ALZ_PB_BITS, mmask = pass == 0 ? 0xFFFFFFFFu : g.min_mask;
+        // ComputeHash  LzChainMatchFinder.cs:288-299; bucket = its top 12 bits (the well-mixed end of a multiplicative hash: with
+        // the low 12 bits of a 19-bit hash the buckets of this data were so uneven that the kernel ran 4x longer), tag = the rest
+        auto hash_of = [&](u32 v) -> u32 { return (((v & mmask) * 2654435761u) >> (32u - hb)) & ((1u << hb) - 1u); };
+        for (u32 i = (u32)lane; i < ALZ_PB_N; i += 64u) cnt[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        // 1. bucket sizes
+#pragma unroll 4
+        for (int i = lane; i < N; i += 64) atomicAdd(&cnt[hash_of(load32(base + i)) >> tshift], 1u);
+        __builtin_amdgcn_wave_barrier();
+        // 2. first slot of every bucket (exclusive prefix sum over the 4 096 counters, 64 per trip)
+        u32 run = 0;
+        for (u32 b0 = 0; b0 < ALZ_PB_N; b0 += 64u) {
+            const u32 c = cnt[b0 + (u32)lane];
+            const u32 inc = scan_add(c);
+            cnt[b0 + (u32)lane] = (run + inc - c) << 16;
+            run += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 3. positions in order, 64 per step: place them, then walk back inside the bucket to the previous equal tag
+        u32 vnext = lane < N ? load32(base + lane) : 0u;
+        for (int c0 = 0; c0 < N; c0 += 64) {
+            const int i = c0 + lane;
+            const bool act = i < N;
+            const u32 h = hash_of(vnext);
+            vnext = i + 64 < N ? load32(base + i + 64) : 0u;            // (the next step's bytes travel while this one works)
+            const u32 b = h >> tshift, tag = h & ((1u << tshift) - 1u);
+            // lanes that meet in a bucket inside this step are ranked by lane, the lowest of them reserves the slots for all
+            if (act) owner[b] = (u8)lane;
+            __builtin_amdgcn_wave_barrier();
+            const bool lost = act && owner[b] != (u8)lane;
+            u32 rank = 0, group = 1, lead = (u32)lane;
+            u64 todo = __ballot(lost);
+            while (todo) {
+                const u32 bv = (u32)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(todo));
+                const u64 grp = __ballot(act && b == bv);
+                if (act && b == bv) {
+                    rank = __builtin_amdgcn_mbcnt_hi((u32)(grp >> 32), __builtin_amdgcn_mbcnt_lo((u32)grp, 0u));
+                    group = (u32)__popcll(grp); lead = (u32)__builtin_ctzll(grp);
+                }
+                todo &= ~grp;
+            }
+            u32 x = 0;
+            if (act && rank == 0u) x = atomicAdd(&cnt[b], group);
+            if (__ballot(rank != 0u)) x = (u32)__builtin_amdgcn_ds_bpermute((int)(lead << 2), (int)x);
+            const u32 first = x >> 16, slot = first + (x & 0xFFFFu) + rank;
+            if (act) keys[slot] = (tag << 14) | (u32)i;
+            __builtin_amdgcn_wave_barrier();
+            if (act && in_lo + i >= out_lo) {
+                int prev = -1;
+                for (u32 t = slot; t > first; t--) {
+                    const u32 k = keys[t - 1u];
+                    if ((k >> 14) == tag) { prev = in_lo + (int)(k & 0x3FFFu); break; }
+                }
+                out[i] = prev;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -1291,6 +1394,11 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     return true;
 }
 
+// the head-table-free kernel A (enc_prev_block_kernel, an experiment): windows up to 4 KiB (its LDS footprint is 20 KB + 8 bytes per window byte)
+bool alz_encode_uses_block_prev(const void* geom) {
+    static const int on = getenv("ALZ_ENC_PREV_BLOCK") ? atoi(getenv("ALZ_ENC_PREV_BLOCK")) : 0;      // experiment: slower than the head tables (see enc_prev_block_kernel)
+    return on && ((const EncGeom*)geom)->max_dist <= 4096;
+}
 size_t alz_encode_geom_size(void) { return sizeof(EncGeom); }
 int alz_encode_geom_hash_bits(const void* geom) { return ((const EncGeom*)geom)->hash_bits; }
 int alz_encode_geom_min_table(const void* geom) { return ((const EncGeom*)geom)->use_min_table; }
@@ -1323,6 +1431,13 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (lds_prev && g.max_dist <= 4096 && max_len < (1u << 24)) {
         if (g.use_min_table) hipLaunchKernelGGL((enc_prev_lds_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
         else hipLaunchKernelGGL((enc_prev_lds_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    }
+    else if (alz_encode_uses_block_prev(&g)) {
+        u32 W = 2048; while ((int)W < g.max_dist) W <<= 1;
+        const size_t lds = (size_t)(ALZ_PB_N + 2u * W) * 4u + ALZ_PB_N;
+        const dim3 grid((max_len + W - 1) / W ? (max_len + W - 1) / W : 1u, count);
+        if (g.use_min_table) hipLaunchKernelGGL((enc_prev_block_kernel<true>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
+        else hipLaunchKernelGGL((enc_prev_block_kernel<false>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
     }
     else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     else {

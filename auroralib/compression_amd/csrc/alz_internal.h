@@ -14,6 +14,7 @@ int alz_kernel_occupancy(int fmt);   // resident waves per CU of the production 
 // ---- encoder (alz_encode.hip)
 bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits, int variant = 0);   // variant 1: FastLZ level 2
 size_t alz_encode_geom_size(void);
+bool alz_encode_uses_block_prev(const void* geom);   // kernel A without head tables (windows up to 4 KiB)
 int alz_encode_geom_hash_bits(const void* geom);
 int alz_encode_geom_min_table(const void* geom);
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
