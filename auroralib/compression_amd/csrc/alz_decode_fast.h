@@ -1326,10 +1326,12 @@ __device__ __forceinline__ void prs_walk_window(const InCache& in, u32 i0, int l
 // A window of 64 input bytes holds ~30 tokens of the synthetic mix, which left half of the lanes of the byte phase (and of its
 // token prologue) idle; so a second window follows the first where the queue has room for what it can hold at most (8
 // literals per 9 bytes): ~48 tokens per round.
-template <class SK, bool BIG>
-__device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32& fl_io) {
-    const u32 p = s.p;
-    u32 pos, fl = fl_io, term, tok; u64 allm;
+// The parse of one round on its own (no window, no output): tokens of up to two walk windows starting at input offset p -> qt (one
+// per lane, nt of them), the bytes they produce, the input they cover, the flag register behind them, "the terminator was read".
+// Touches the input cache and `stage` only.  Returns false when nothing could be parsed.
+template <bool BIG>
+__device__ __forceinline__ bool prs_parse_round(InCache& in, u32 p, u32 fl_in, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out, u32& fl_out, u32& term_out) {
+    u32 pos, fl = fl_in, term, tok; u64 allm;
     prs_walk_window<BIG>(in, in.idx(p), lane, 60u, pos, fl, term, allm, tok);
     u32 nt = (u32)__popcll(allm);
     if (nt == 0u && !term) return false;
@@ -1348,7 +1350,16 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
     wave_sync();
     const u32 qt = (u32)lane < nt ? stage[lane] : 0u;
     wave_sync();
-    const u32 total = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    qt_out = qt; nt_out = nt; adv_out = pos; fl_out = fl; term_out = term;
+    total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
+    return true;
+}
+
+template <class SK, bool BIG>
+__device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s, u32* stage, int lane, u32& fl_io) {
+    const u32 p = s.p;
+    u32 qt, nt, total, pos, fl, term;
+    if (!prs_parse_round<BIG>(in, p, fl_io, stage, lane, qt, nt, total, pos, fl, term)) return false;
     if (total > sk.out.cap - sk.out.produced) return false;   // the capacity rule (E5) stays with the exact parser
     sk.qtok = qt; sk.nt = nt; sk.qbytes = total;
     s.p = p + pos; fl_io = fl;

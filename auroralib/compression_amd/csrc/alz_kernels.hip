@@ -487,7 +487,104 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
 }
 
 // ------------------------------------------------------------------------------------------------
+// PRS with TWO wavefronts per stream: wavefront 0 walks (prs_parse_round: input cache + scalar walk, no window), wavefront 1
+// executes (the byte phase on the window); a round's tokens cross in a two-slot LDS mailbox, one workgroup barrier per round.  A PRS
+// stream alone is a chain of ~46 000 dependent token steps: ~60 cycles of scalar walk and ~70 of byte phase per token, one after
+// the other on a single wavefront (2.5 ms per 256 KiB) -- which is what a small or mixed batch waits for (cfg4's shard: 3.3 ms for
+// 1 250 PRS streams of 2.5-2.9 ms).  Here round k + 1 is parsed while round k is executed.  The walker stops at the first round
+// it cannot take (input tail, a round that would not fit the capacity, nothing parsed): wavefront 1 then carries on alone from
+// that position with the one-wavefront loop of alz_decode_queue_kernel (exact parser included).
+template <int FMT>
+__global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                              const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results) {
+    constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
+    constexpr u32 LW = 8192u, QCH = 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u, SCR = 128u;
+    constexpr u32 MB = 64u + 8u;                              // mailbox slot: 64 tokens + {nt | stop, total, position behind, flag register, terminator}
+    __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + 256 + QCACHE + 2u * MB * 4u];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool walker = threadIdx.x < 64u;
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap);
+    u32* mbox = reinterpret_cast<u32*>(lds + SCR + 256 + QCACHE + LW + 256 + QCACHE);
+    if (walker) {
+        u32* stage = reinterpret_cast<u32*>(lds + SCR + 256 + QCACHE + LW);
+        InCache in; in.init(src, src_len, lds + SCR + 256 + QCACHE + LW + 256, lane, QCH);
+        u32 p = 0, fl = 1u, produced = 0;
+        for (u32 k = 0;; k++) {
+            u32 qt = 0, nt = 0, total = 0, adv = 0, fl2 = fl, term = 0;
+            bool ok = (u64)p + QAHEAD <= src_len;
+            if (ok) { in.ensure(p, QCH); ok = prs_parse_round<BIG>(in, p, fl, stage, lane, qt, nt, total, adv, fl2, term); }
+            if (ok && total > cap - produced) ok = false;         // the capacity rule (E5) stays with the exact parser
+            u32* slot = mbox + (k & 1u) * MB;
+            slot[lane] = qt;
+            if (lane == 0) { slot[64] = ok ? nt : 0xFFFFFFFFu; slot[65] = total; slot[66] = ok ? p + adv : p; slot[67] = ok ? fl2 : fl; slot[68] = term; }
+            __syncthreads();                                       // round k is in the mailbox (and round k - 1 has been executed)
+            if (!ok || term) return;
+            p += adv; fl = fl2; produced += total;
+        }
+    }
+    // ---- the executing wavefront
+    u8* dst = dst_base + st.dst_off;
+    u8* segmark = lds;
+    u32* stage = reinterpret_cast<u32*>(lds + SCR);
+    u8* inc_lds = lds + SCR + 256;
+    typedef OutWin<false> OW;
+    OW out; out.init(dst, cap, lds + SCR + 256 + QCACHE, LW, lane, 0u);
+    segmark[lane] = 0; segmark[64 + lane] = 0;
+    DecState s; dec_state_init(s);
+    typedef EmitCfg<LW - 1u, false, false, false> CFG;
+    typedef QueueSink<OW, CFG> SK;
+    __builtin_amdgcn_s_setprio(2);
+    u32 fl = 1u;
+    for (u32 k = 0;; k++) {
+        __syncthreads();
+        const u32* slot = mbox + (k & 1u) * MB;
+        const u32 qt = slot[lane], nt = uni(slot[64]), p2 = uni(slot[66]);
+        fl = uni(slot[67]);
+        const u32 term = uni(slot[68]);
+        s.p = p2;
+        if (nt == 0xFFFFFFFFu) break;                              // the walker stopped in front of this round
+        const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
+        const u32 desc = (qt & 0x20000u) ? ALZ_DESC_LIT(lo & 0xFFu) : lo;
+        u32 last;
+        (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, inc_lds, lane, last, 8192u);
+        if (term) { s.done = true; break; }                        // PRS.cs:78-79: the zero word ends the stream
+    }
+    SK sk(out, s, segmark, inc_lds, lane, 8192u);
+    if (!s.done && !s.ovf) {
+        // alone from here: the loop of alz_decode_queue_kernel
+        InCache in; in.init(src, src_len, inc_lds, lane, QCH);
+        for (;;) {
+            if (s.p + QAHEAD <= src_len && !s.done) {
+                sk.ensure(in, s.p, QCH);
+                if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                if (prs_lane_parse<SK, BIG>(in, sk, s, stage, lane, fl)) { if (s.ovf || s.done) break; continue; }
+            }
+            const bool tail = s.p + QAHEAD > src_len;
+            prs_from_norm<BIG>(fl, s.bits, s.flag);
+            dec_prs_serial<SK, BIG>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+            fl = prs_to_norm<BIG>(s.bits, s.flag);
+            if (tail || s.eof || s.ovf || s.bad || s.done) break;
+        }
+    }
+    sk.flush();
+    out.finish();
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
+
+// PRS: two wavefronts per stream (alz_decode_prs2_kernel)?  ALZ_PRS2: 0 never, 1 always, otherwise (default) for launches the GPU
+// cannot fill with one wavefront per stream anyway
+static bool prs_two_waves(u32 count) {
+    static const int mode = getenv("ALZ_PRS2") ? atoi(getenv("ALZ_PRS2")) : 1;
+    return mode == 1 || (mode == 2 && count <= 4096u);
+}
 
 template <int FMT, bool FB>
 static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
@@ -570,8 +667,10 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_SMSR00: return launch_fast<ALZ_FMT_SMSR00>(stream, s, d, streams, index, count, results, lz, 4096, 2);
         case ALZ_FMT_LZHUDSON: return launch_fast<ALZ_FMT_LZHUDSON>(stream, s, d, streams, index, count, results, lz, 4096, 1);
-        case ALZ_FMT_PRS_BE: return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
-        case ALZ_FMT_PRS_LE: return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_PRS_BE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_BE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results); return hipGetLastError(); }
+                             return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_PRS_LE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results); return hipGetLastError(); }
+                             return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZ4_BLOCK: return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZO: return launch_queue<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_SNAPPY_RAW: return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
