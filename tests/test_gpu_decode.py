@@ -250,3 +250,28 @@ def test_fuzz_garbage_and_mutations(fmt, test_bmp):
                           aux1=aux.aux1 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0)))
     streams, src, dst_bytes = pack_streams(items, dst_slack=32)
     compare_batch(streams, src, dst_bytes, what="fuzz " + A.FORMAT_NAMES[fmt])
+
+
+def test_prs_one_wavefront_kernel_still_agrees():
+    """PRS runs on two wavefronts per stream by default (alz_decode_prs2_kernel); ALZ_PRS2=0 selects the one-wavefront queue kernel,
+    whose loop the second wavefront also falls back to.  The switch is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as O\n"
+        "from auroralib.compression_amd import _abi as A, synth\n"
+        "from auroralib.compression_amd.batch import Context\n"
+        "sizes = np.array([1, 7, 300, 5000, 70000, 262144, 100001, 64], dtype=np.uint32)\n"
+        "for fmt in (A.FMT_PRS_BE, A.FMT_PRS_LE):\n"
+        "    b = synth.make_batch(fmt, len(sizes), sizes, 4242)\n"
+        "    o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes)\n"
+        "    g_dst, g_res = Context(0).decode_batch(b.streams, b.src, b.dst_bytes)\n"
+        "    gr, orr = synth.result_records(g_res), synth.result_records(o_res)\n"
+        "    assert all(np.array_equal(gr[f], orr[f]) for f in ('status', 'dst_len', 'src_used'))\n"
+        "    assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes])\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALZ_PRS2="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
