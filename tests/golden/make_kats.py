@@ -28,6 +28,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def expand(ops):
     out = bytearray()
     for op in ops:
+        if op[0] == "skip":                                       # (CNX2: bytes the decoder jumps over)
+            continue
         if op[0] == "lit":
             out += bytes(op[1])
         else:
@@ -355,6 +357,109 @@ def enc_wflz(ops, big):
         for k in range(255, len(lit), 255):
             block(0, 0, lit[k:k + 255])                           # literals only: length 0, count != 0
     block(0, 0, b"")                                              # :100-103
+    return bytes(out)
+
+
+def enc_cnx2(ops):
+    """CNX2.DecompressHeaderless  AuroraLib.Compression.Sega/Sega/CNX2.cs:89-127: 2-bit codes, read LSB first from 8-bit flags (FlagReader
+    (source, Endian.Little) + ReadInt(2): the first bit read is bit 0 of the code).  1: one literal.  3: a count byte and that many
+    literals.  2: a big-endian u16, distance - 1 in its top 11 bits, length - 4 in its low 5.  0: a count byte, that many bytes are
+    SKIPPED, and the rest of the flag byte is dropped (flag.Reset())."""
+    f = Flags8(msb_first=False)
+    def code(c):
+        f.bit(c & 1); f.bit(c >> 1)                               # FlagReader.ReadInt :75-87
+    for op in ops:
+        if op[0] == "lit":
+            lit = bytes(op[1])
+            if len(op) > 2 and op[2] == "run":                    # :117-120
+                assert len(lit) <= 255
+                code(3); f.out.append(len(lit)); f.out += lit
+            else:
+                for b in lit:
+                    code(1); f.out.append(b)                      # :104-106
+        elif op[0] == "skip":                                     # :97-101
+            code(0); f.out.append(len(op[1])); f.out += bytes(op[1]); f.n = 0
+        else:
+            _, d, n = op[:3]
+            assert 4 <= n <= 35 and 1 <= d <= 2048
+            v = ((d - 1) << 5) | (n - 4)                          # :109-114
+            code(2); f.out += bytes([v >> 8, v & 0xFF])
+    return bytes(f.out)
+
+
+def enc_refpack(ops):
+    """RefPack.DecompressHeaderless  AuroraLib.Compression-Extended/EA/RefPack.cs:190-245: every command first copies 0-3 literals (P) and then a
+    match.  0DDLLLPP D: length 3-10, distance 1-1024.  10LLLLLL PPDDDDDD D: 4-67, 1-16 384.  110DLLPP D D L: 5-1 028, 1-131 072.
+    111PPPPP: 4 x (P + 1) literals (4-112), no match; 111111PP: P literals and the END.  A copy op may name its form ("short", "medium",
+    "long"); literal runs in front of a match are written as 4-112 blocks with the last 0-3 bytes riding on the match command."""
+    out, pending = bytearray(), b""
+    def flush_blocks():
+        nonlocal pending
+        while len(pending) >= 4:
+            n = min(len(pending) // 4 * 4, 112)
+            out.append(0xE0 | (n // 4 - 1)); out.extend(pending[:n]); pending = pending[n:]     # :229-232, :240
+    for op in ops:
+        if op[0] == "lit":
+            pending += bytes(op[1])
+            continue
+        _, d, n = op[:3]
+        form = op[3] if len(op) > 3 else ("short" if 3 <= n <= 10 and d <= 1024 else "medium" if 4 <= n <= 67 and d <= 16384 else "long")
+        flush_blocks()
+        p = len(pending); assert p <= 3
+        if form == "short":
+            assert 3 <= n <= 10 and 1 <= d <= 1024
+            out += bytes([(((d - 1) >> 8) << 5) | ((n - 3) << 2) | p, (d - 1) & 0xFF])            # :200-207
+        elif form == "medium":
+            assert 4 <= n <= 67 and 1 <= d <= 16384
+            out += bytes([0x80 | (n - 4), (p << 6) | ((d - 1) >> 8), (d - 1) & 0xFF])             # :208-217
+        else:
+            assert 5 <= n <= 1028 and 1 <= d <= 131072
+            out += bytes([0xC0 | (((d - 1) >> 16) << 4) | (((n - 5) >> 8) << 2) | p, ((d - 1) >> 8) & 0xFF, (d - 1) & 0xFF, (n - 5) & 0xFF])   # :218-228
+        out.extend(pending); pending = b""
+    flush_blocks()
+    out.append(0xFC | len(pending)); out.extend(pending)                                           # :233-239
+    return bytes(out)
+
+
+def enc_lzshrek(ops):
+    """LZShrek.DecompressHeaderless  AuroraLib.Compression-Extended/Activision/LZShrek.cs:72-119, ReadDistance :176-192: groups of a header byte --
+    (matches in the group - 1) in its low 3 bits, the literal count in its top 5 (0-29; 30: + one byte; 31: 286 + a little-endian u16) --
+    the literals, then 1-8 match commands: length 1-7 in the low 3 bits (0: the next byte + 7, and a next byte of 0 ENDS the stream),
+    distance - 1 in the top 5 bits with the same escapes."""
+    def dist_field(v):                                            # ReadDistance: 0-29 inline, 30-285 one byte, 286-65 821 two
+        if v < 30:
+            return v, b""
+        if v < 286:
+            return 30, bytes([v - 30])
+        assert v <= 286 + 0xFFFF
+        return 31, bytes([(v - 286) & 0xFF, (v - 286) >> 8])
+    def match_cmd(d, n):
+        f, ext = dist_field(d - 1)
+        if 1 <= n <= 7:
+            return bytes([(f << 3) | n]) + ext                    # :96-97, :113
+        assert 8 <= n <= 262
+        return bytes([f << 3, n - 7]) + ext                       # :99-110: the length byte comes BEFORE the distance bytes
+    out, i, ops = bytearray(), 0, list(ops)
+    while i < len(ops):
+        lit = b""
+        if ops[i][0] == "lit":
+            lit = bytes(ops[i][1]); i += 1
+        ms = []
+        while i < len(ops) and ops[i][0] == "copy" and len(ms) < 8:
+            ms.append(ops[i]); i += 1
+        last = i >= len(ops)
+        cmds = [match_cmd(m[1], m[2]) for m in ms]
+        if last and len(cmds) < 8:
+            cmds.append(bytes([0, 0])); last = False              # the end marker rides as one more command of this group  :101-108
+            done = True
+        else:
+            done = False
+        assert cmds
+        f, ext = dist_field(len(lit))
+        out += bytes([(f << 3) | (len(cmds) - 1)]) + ext + lit + b"".join(cmds)                    # :84-92
+        if i >= len(ops) and not done:
+            out += bytes([0, 0, 0])                               # a group of its own for the end marker: no literals, one command = END
+            break
     return bytes(out)
 
 
@@ -686,6 +791,24 @@ def build():
         K.setdefault(name, []).append(case("match lengths 5 / 259 / 100 / 6, literal counts 9 / 0 / 255 / 256 (a literal-only block follows) / 0, the end block", name, enc_wflz(ops, big), ops, "WFLZ.cs:82-112", decom_len=0))
         far = [("lit", pat(200, 113))] + [("copy", 200, 259)] * 253 + [("copy", 0xFFFF, 5), ("copy", 0x0100, 7), ("copy", 0x00FF, 9), ("lit", b"!")]
         K[name].append(case("distance 0xFFFF, 0x0100 and 0x00FF (the two distance bytes in the file's byte order)", name, enc_wflz(far, big), far, "WFLZ.cs:90-99", decom_len=0))
+    # ---- CNX2 (2-bit codes)
+    ops = [("lit", pat(5, 120)), ("copy", 5, 4), ("copy", 1, 35), ("lit", pat(255, 121), "run"), ("copy", 200, 20), ("lit", b"x", "run"), ("skip", b"\xde\xad\xbe"),
+           ("lit", pat(3, 122)), ("copy", 2, 5), ("lit", b"", "run"), ("lit", b"z")]
+    K.setdefault("cnx2", []).append(case("codes 1 / 2 / 3 / 0: single literals, runs of 255 / 1 / 0, match lengths 4 / 35 / 20 / 5, a 3-byte skip that also drops the rest of its flag byte",
+                                         "cnx2", enc_cnx2(ops), ops, "CNX2.cs:89-127"))
+    far = [("lit", pat(200, 123), "run")] + [("copy", 200, 35)] * 60 + [("copy", 2048, 4), ("copy", 2047, 35), ("copy", 33, 4), ("copy", 32, 4), ("lit", b"!")]
+    K["cnx2"].append(case("distance 2048 (all 11 bits), 2047, 33 / 32 (the bit that crosses the pair's byte boundary)", "cnx2", enc_cnx2(far), far, "CNX2.cs:109-114"))
+    # ---- RefPack and LZShrek
+    ops = [("lit", pat(2, 130)), ("copy", 2, 3), ("copy", 1, 10), ("lit", pat(3, 131)), ("copy", 5, 4, "medium"), ("copy", 9, 67), ("lit", pat(4, 132)), ("copy", 11, 5, "long"),
+           ("lit", pat(113, 133)), ("copy", 100, 1028), ("lit", pat(7, 134)), ("copy", 1024, 3), ("lit", b"end")]
+    K.setdefault("refpack", []).append(case("short 3 / 10, medium 4 / 67, long 5 / 1 028; 0-3 literals on a command, blocks of 4 / 112, an end command with 3 literals", "refpack", enc_refpack(ops), ops, "RefPack.cs:190-245"))
+    far = [("lit", pat(64, 135))] + [("copy", 64, 1028)] * 130 + [("copy", 1025, 4, "medium"), ("copy", 16384, 4), ("copy", 16385, 5), ("copy", 65536, 6, "long"), ("copy", 131072, 7), ("lit", b"")]
+    K["refpack"].append(case("distance 1 025 (medium), 16 384, 16 385 (long), 65 536 and 131 072 (the 17th distance bit in the prefix); an end command without literals", "refpack", enc_refpack(far), far, "RefPack.cs:208-228"))
+    ops = [("lit", pat(29, 140)), ("copy", 29, 1), ("copy", 1, 7), ("copy", 30, 8), ("lit", pat(30, 141)), ("copy", 31, 262), ("lit", pat(285, 142)), ("copy", 286, 100), ("lit", pat(286, 143)),
+           ("copy", 287, 2), ("copy", 3, 3), ("copy", 3, 3), ("copy", 3, 3), ("copy", 3, 3), ("copy", 3, 3), ("copy", 3, 3), ("copy", 3, 3), ("copy", 2, 5), ("lit", b"z")]
+    K.setdefault("lzshrek", []).append(case("literal counts 29 / 30 / 285 / 286 (the escapes), match lengths 1 / 7 / 8 / 262, distances 29-31 / 286 / 287, a full group of eight commands", "lzshrek", enc_lzshrek(ops), ops, "LZShrek.cs:72-119, :176-192"))
+    far = [("lit", pat(100, 144))] + [("copy", 100, 262)] * 16 + [("copy", 4096, 9), ("copy", 4095, 3)]
+    K["lzshrek"].append(case("distance 4096 and 4095 (two-byte escape); the stream ends on a match, the end marker is a group of its own", "lzshrek", enc_lzshrek(far), far, "LZShrek.cs:113, :183-188"))
     return K
 
 
