@@ -463,6 +463,57 @@ def enc_lzshrek(ops):
     return bytes(out)
 
 
+def enc_hig(ops):
+    """HIG.DecompressHeaderless  AuroraLib.Compression-Extended/Specialized/HIG.cs:91-164: a raw block, then (match, raw block) pairs until the size
+    is reached.  Raw block in front: a byte n - 2 (3-257 literals) or 0 + a little-endian u16.  Match, by its first byte's top 3 bits:
+    0-5: LLLDDDPP D, length 4-9, 11-bit distance; 6: 110LLLLL DDDDDDPP D, length 4-35, 14 bits; 7: 111DLLLL [ext] DDDDDDPP D, length 4-18
+    from the nibble, nibble 0 = next byte + 18 (19-273), that byte 0 = a big-endian u16; 15 bits.  PP after a match: 1 / 2 literals,
+    3 none, 0 another counted raw block.  The distance field is the distance itself (no + 1)."""
+    ops = list(ops)
+    out = bytearray()
+    def raw(lit):                                                 # :100-103, :146-150
+        n = len(lit)
+        if 3 <= n <= 257:
+            out.append(n - 2)
+        else:
+            out.append(0); out.extend([n & 0xFF, n >> 8])
+        out.extend(lit)
+    assert ops[0][0] == "lit"
+    raw(bytes(ops[0][1])); i = 1
+    while i < len(ops):
+        _, d, n = ops[i][:3]
+        form = ops[i][3] if len(ops[i]) > 3 else None
+        i += 1
+        lit = b""
+        if i < len(ops) and ops[i][0] == "lit":
+            lit = bytes(ops[i][1]); i += 1
+        pp = 3 if len(lit) == 0 else (len(lit) if len(lit) <= 2 else 0)
+        assert 1 <= d <= 0x7FFF
+        if form is None:
+            form = "A" if 4 <= n <= 9 and d <= 2047 else "B" if 4 <= n <= 35 and d <= 16383 else "C"
+        if form == "A":                                           # :111-116
+            assert 4 <= n <= 9 and d <= 2047
+            out += bytes([((n - 4) << 5) | ((d >> 8) << 2) | pp, d & 0xFF])
+        elif form == "B":                                         # :119-124, :141-145
+            assert 4 <= n <= 35 and d <= 16383
+            out += bytes([0xC0 | (n - 4), ((d >> 8) << 2) | pp, d & 0xFF])
+        else:                                                     # :125-145
+            hi = (d >> 14) << 4
+            if 4 <= n <= 18 and form != "C16" and form != "C8":
+                out.append(0xE0 | hi | (n - 3))
+            elif 19 <= n <= 273 and form != "C16":
+                out += bytes([0xE0 | hi, n - 18])
+            else:
+                assert n <= 0xFFFF
+                out += bytes([0xE0 | hi, 0, n >> 8, n & 0xFF])
+            out += bytes([(((d >> 8) & 0x3F) << 2) | pp, d & 0xFF])
+        if pp == 0:
+            raw(lit)
+        else:
+            out.extend(lit)
+    return bytes(out)
+
+
 # ------------------------------------------------------------------------------------------------ PRS
 class LazyFlags:
     """FlagReader over the SAME stream as the data (PRS.cs:62): a flag byte sits wherever the decoder happens to be when it
@@ -809,6 +860,12 @@ def build():
     K.setdefault("lzshrek", []).append(case("literal counts 29 / 30 / 285 / 286 (the escapes), match lengths 1 / 7 / 8 / 262, distances 29-31 / 286 / 287, a full group of eight commands", "lzshrek", enc_lzshrek(ops), ops, "LZShrek.cs:72-119, :176-192"))
     far = [("lit", pat(100, 144))] + [("copy", 100, 262)] * 16 + [("copy", 4096, 9), ("copy", 4095, 3)]
     K["lzshrek"].append(case("distance 4096 and 4095 (two-byte escape); the stream ends on a match, the end marker is a group of its own", "lzshrek", enc_lzshrek(far), far, "LZShrek.cs:113, :183-188"))
+    # ---- HIG
+    ops = [("lit", pat(5, 150)), ("copy", 5, 4), ("lit", b"a"), ("copy", 1, 9), ("lit", b"bc"), ("copy", 3, 10), ("copy", 7, 35), ("lit", pat(3, 151)), ("copy", 20, 18, "C"), ("lit", pat(257, 152)),
+           ("copy", 256, 19), ("lit", pat(258, 153)), ("copy", 100, 273), ("copy", 2, 274), ("copy", 9, 4, "C"), ("copy", 9, 1000)]
+    K.setdefault("hig", []).append(case("forms A 4 / 9, B 10 / 35, C nibble 18 / 4, C byte 19 / 273, C u16 274 / 1 000; raw blocks after a match: 1, 2, none, 3 / 257 (one byte), 258 (u16)", "hig", enc_hig(ops), ops, "HIG.cs:91-164"))
+    far = [("lit", b"")] if False else [("lit", pat(300, 154))] + [("copy", 300, 1000)] * 33 + [("copy", 2047, 4), ("copy", 2048, 5), ("copy", 16383, 6), ("copy", 16384, 7), ("copy", 32767, 8), ("lit", b"!")]
+    K["hig"].append(case("distance 2 047 (form A), 2 048 and 16 383 (B), 16 384 and 32 767 (C: the 15th bit in the first byte); a u16 raw block in front", "hig", enc_hig(far), far, "HIG.cs:114, :123, :128, :142-145"))
     return K
 
 
