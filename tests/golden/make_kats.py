@@ -992,6 +992,30 @@ def build_containers():
     bodyo = enc_lzo(opso)
     cont2("\"SDPC\" + LE size + an LZO stream", "SDPC", "SDPC", b"SDPC" + le32(len(expand(plain))) + bodyo, plain, "SDPC.cs:31-32, :44-57")
 
+    # ---- BLZ: the file is read from its END (footer, then the code backwards), and the output is written from its end as well
+    def enc_blz_file(ops):
+        """BLZ.Decompress / DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:60-135: in the order the decoder consumes them, the
+        code bytes are LZ10-like -- flags MSB first (:104-108), bit 1 = two bytes, high then low: (length - 3) << 12 | (distance - 3) (:116-119) --
+        describing the output from its LAST byte to its first; the file holds them reversed, followed by u24 LE compressed size, u8 footer +
+        padding size (8), i32 LE (decompressed - compressed size)."""
+        f = Flags8(msb_first=True)
+        for t in tokens(ops):
+            if t[0] == "lit":
+                f.bit(0); f.out.append(t[1])
+            else:
+                _, d, n = t
+                assert 3 <= n <= 18 and 3 <= d <= 4098
+                v = ((n - 3) << 12) | (d - 3)
+                f.bit(1); f.out += bytes([v >> 8, v & 0xFF])
+        code = bytes(f.out)[::-1]
+        csize, dsize = len(code) + 8, len(expand(ops))
+        return code + bytes([csize & 0xFF, (csize >> 8) & 0xFF, csize >> 16, 8]) + ((dsize - csize) & 0xFFFFFFFF).to_bytes(4, "little")
+    opsb = [("lit", pat(9, 160)), ("copy", 9, 3), ("copy", 3, 18), ("lit", b"\x10\x20"), ("copy", 4, 9), ("copy", 33, 17)] + [("copy", 20, 18)] * 230 + [("copy", 4098, 5), ("copy", 4097, 3), ("lit", b"#")]
+    cont2("read backwards: lengths 3 / 9 / 17 / 18, distances 3 (the smallest), 4 097 and 4 098 (all 12 bits + 3); footer without padding", "BLZ", "BLZ",
+          enc_blz_file(opsb), opsb, "BLZ.cs:60-135")
+    exp = expand(opsb)[::-1]                                       # what the ops describe is the output back to front
+    out[-1]["expect_len"] = len(exp); out[-1]["expect_zlib_b64"] = base64.b64encode(zlib.compress(exp, 9)).decode()
+
     # ---- LZ4: legacy frames and LZ4 frames
     b1 = [("lit", pat(12, 40)), ("copy", 12, 8), ("copy", 1, 30), ("lit", pat(5, 41))]
     b2 = [("lit", pat(7, 42)), ("copy", 3, 20), ("lit", pat(6, 43))]
