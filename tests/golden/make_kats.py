@@ -992,6 +992,26 @@ def build_containers():
     bodyo = enc_lzo(opso)
     cont2("\"SDPC\" + LE size + an LZO stream", "SDPC", "SDPC", b"SDPC" + le32(len(expand(plain))) + bodyo, plain, "SDPC.cs:31-32, :44-57")
 
+    # ---- the headers of the other flag-byte formats
+    ops40 = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 15), ("copy", 4, 16), ("copy", 7, 271), ("lit", b"\x7f"), ("copy", 100, 272), ("copy", 300, 1000), ("copy", 2, 2)]
+    n = len(expand(ops40))
+    cont2("0x40 + u24 LE size + LZ40 body", "LZ40", "LZ40", bytes([0x40, n & 0xFF, (n >> 8) & 0xFF, n >> 16]) + enc_lz40(ops40), ops40, "LZ40.cs:44-61")
+    cont2("0x60 + zero u24 + u32 LE size + LZ40 body", "LZ60", "LZ60", bytes([0x60, 0, 0, 0]) + le32(n) + enc_lz40(ops40), ops40, "LZ60.cs:30-32, LZ40.cs:49-51")
+    opsh = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 5, 17), ("copy", 1, 18), ("copy", 2, 273), ("lit", b"\x00"), ("copy", 21, 100)] + [("lit", pat(3, 70 + i)) if i % 3 else ("copy", 7, 4) for i in range(30)]
+    cont2("BE size + Yaz0's tokens behind 32-bit flag words", "LZHUDSON", "LZHudson", be32(len(expand(opsh))) + enc_lzhudson(opsh), opsh, "LZHudson.cs:31-46")
+    opsm = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x42"), ("copy", 2, 10), ("copy", 12, 18)] + [("lit", pat(2, 80 + i)) if i % 2 else ("copy", 5, 6) for i in range(20)]
+    st, a0 = enc_smsr00(opsm)
+    cont2("\"SMSR00\" + 2 bytes + BE size + BE pointer to the literal section (from the start of the file); codes at 0x10", "SMSR00", "SMSR00",
+          b"SMSR00\x00\x00" + be32(len(expand(opsm))) + be32(0x10 + a0) + st, opsm, "SMSR00.cs:36-37, :68-75")
+    opsc = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x10\x20"), ("copy", 2, 9), ("copy", 33, 17)]
+    n = len(expand(opsc))
+    cont2("\"CLZ\\0\" + BE size + BE 0 + BE size + CLZ0 body", "CLZ0", "CLZ0", b"CLZ\x00" + be32(n) + be32(0) + be32(n) + enc_clz0(opsc), opsc, "CLZ0.cs:33-34, :54-64")
+    opsn = [("lit", pat(3, 100)), ("copy", 3, 3), ("copy", 1, 130), ("lit", pat(127, 101)), ("copy", 127, 64), ("lit", pat(128, 102)), ("copy", 256, 5)]
+    cont2("\"@CNS\" + a four-character extension + LE size + 4 zero bytes + CNS body", "CNS", "CNS", b"@CNSbin\x00" + le32(len(expand(opsn))) + bytes(4) + enc_cns(opsn), opsn, "CNS.cs:38-39, :54-64")
+    ops02 = [("lit", pat(9, 1)), ("copy", 9, 2), ("copy", 1, 16), ("copy", 4, 17), ("copy", 7, 272), ("lit", b"\x7f"), ("copy", 255, 100), ("copy", 256, 3)]
+    n = len(expand(ops02))
+    cont2("type byte 1 + u24 BE size + LZ02 body with its terminator", "LZ02", "LZ02", bytes([1, n >> 16, (n >> 8) & 0xFF, n & 0xFF]) + enc_lz02(ops02), ops02, "LZ02.cs:52-65")
+
     # ---- BLZ: the file is read from its END (footer, then the code backwards), and the output is written from its end as well
     def enc_blz_file(ops):
         """BLZ.Decompress / DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:60-135: in the order the decoder consumes them, the
