@@ -1012,6 +1012,25 @@ def build_containers():
     n = len(expand(ops02))
     cont2("type byte 1 + u24 BE size + LZ02 body with its terminator", "LZ02", "LZ02", bytes([1, n >> 16, (n >> 8) & 0xFF, n & 0xFF]) + enc_lz02(ops02), ops02, "LZ02.cs:52-65")
 
+    # ---- headers of the token-queue formats
+    opsx = [("lit", pat(5, 120)), ("copy", 5, 4), ("copy", 1, 35), ("lit", pat(255, 121), "run"), ("copy", 200, 20), ("lit", b"x", "run"), ("lit", pat(3, 122)), ("copy", 2, 5), ("lit", b"z")]
+    bodyx = enc_cnx2(opsx)
+    cont2("\"CNX\\x02\" + a four-character extension + BE compressed size + BE size + CNX2 body", "CNX2", "CNX2", b"CNX\x02bin\x00" + be32(len(bodyx)) + be32(len(expand(opsx))) + bodyx, opsx, "CNX2.cs:38-39, :54-70")
+    opsr = [("lit", pat(2, 130)), ("copy", 2, 3), ("copy", 1, 10), ("lit", pat(3, 131)), ("copy", 5, 4, "medium"), ("copy", 9, 67), ("lit", pat(4, 132)), ("copy", 11, 5, "long"), ("lit", pat(113, 133)), ("copy", 100, 1028), ("lit", b"end")]
+    bodyr = enc_refpack(opsr); n = len(expand(opsr))
+    cont2("version 1: flag 0x10 + 0xFB + u24 BE size + RefPack body", "REFPACK", "RefPack", bytes([0x10, 0xFB, n >> 16, (n >> 8) & 0xFF, n & 0xFF]) + bodyr, opsr, "RefPack.cs:45-54, :77-102")
+    cont2("version 2: LE size of the rest of the file, then the version-1 header", "REFPACK", "RefPack", le32(5 + len(bodyr)) + bytes([0x10, 0xFB, n >> 16, (n >> 8) & 0xFF, n & 0xFF]) + bodyr, opsr, "RefPack.cs:83-90, :107-124")
+    opsw = [("lit", pat(9, 110)), ("copy", 9, 5), ("copy", 1, 259), ("lit", pat(255, 111)), ("copy", 300, 100), ("lit", pat(256, 112)), ("copy", 2, 6)]
+    bodyw = enc_wflz(opsw, False)
+    cont2("\"WFLZ\" + LE compressed size + LE size + WFLZ blocks (little endian, the default byte order)", "WFLZ", "WFLZ", b"WFLZ" + le32(len(bodyw)) + le32(len(expand(opsw))) + bodyw, opsw, "WFLZ.cs:42-43, :57-86", big_endian=0)
+    opsk = [("lit", pat(29, 140)), ("copy", 29, 1), ("copy", 1, 7), ("copy", 30, 8), ("lit", pat(30, 141)), ("copy", 31, 262), ("lit", b"z")]
+    bodyk = enc_lzshrek(opsk)
+    cont2("LE 0x10 (body offset) + LE size + LE body length + LE 0, body at 0x10", "LZSHREK", "LZShrek", le32(0x10) + le32(len(expand(opsk))) + le32(len(bodyk)) + le32(0) + bodyk, opsk, "LZShrek.cs:30-31, :43-60")
+    opsg = [("lit", pat(5, 150)), ("copy", 5, 4), ("lit", b"a"), ("copy", 1, 9), ("lit", b"bc"), ("copy", 3, 10), ("copy", 7, 35), ("lit", pat(3, 151)), ("copy", 20, 18, "C"), ("copy", 2, 274)]
+    hdr = b"HIG!" + le32(0x40) + bytes(4 * 12) + le32(1) + le32(len(expand(opsg)))
+    assert len(hdr) == 0x40
+    cont2("64-byte header: \"HIG!\", body offset (0x40) in word 1, version in word 14, size in word 15", "HIG", "HIG", hdr + enc_hig(opsg), opsg, "HIG.cs:46-47, :58-90")
+
     # ---- BLZ: the file is read from its END (footer, then the code backwards), and the output is written from its end as well
     def enc_blz_file(ops):
         """BLZ.Decompress / DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:60-135: in the order the decoder consumes them, the
