@@ -1031,6 +1031,43 @@ def build_containers():
     assert len(hdr) == 0x40
     cont2("64-byte header: \"HIG!\", body offset (0x40) in word 1, version in word 14, size in word 15", "HIG", "HIG", hdr + enc_hig(opsg), opsg, "HIG.cs:46-47, :58-90")
 
+    # ---- LZ10 / LZ11 / LZSS behind further wrappers
+    opsl = [("lit", pat(9, 1)), ("copy", 9, 3), ("copy", 1, 18), ("lit", b"\x10\x20"), ("copy", 2, 9), ("copy", 33, 17)]
+    nl = len(expand(opsl))
+    lz10body = enc_lz10(opsl)
+    lz10f = bytes([0x10, nl & 0xFF, (nl >> 8) & 0xFF, nl >> 16]) + lz10body
+    cont2("\"3DS-LZ\\r\\n\" in front of an LZ10 file", "LZ_3DS", "LZ_3DS", b"3DS-LZ\r\n" + lz10f, opsl, "3DS-LZ.cs:24-39")
+    cont2("LE u32: size << 3 | 1 (LZ10), then the LZ10 body", "LEVEL5", "Level5", le32((nl << 3) | 1) + lz10body, opsl, "Level5.cs:62-98, :151-159")
+    out[-1]["skip_is_match"] = True                               # (IsMatch runs LZ10.Validate over the body: not asserted here)
+    cont2("\"LZ77\" + type 0x10 + u24 LE size + LZ10 body", "LZ77", "LZ77", b"LZ77" + bytes([0x10, nl & 0xFF, (nl >> 8) & 0xFF, nl >> 16]) + lz10body, opsl, "LZ77.cs:112-124")
+    n11 = len(expand(ops11))
+    cont2("\"LZ77\" + type 0x11 + u24 LE size + LZ11 body", "LZ77", "LZ77", b"LZ77" + bytes([0x11, n11 & 0xFF, (n11 >> 8) & 0xFF, n11 >> 16]) + enc_lz11(ops11), ops11, "LZ77.cs:125-127")
+    ch2 = [("lit", pat(7, 170)), ("copy", 7, 18), ("copy", 3, 3), ("lit", b"!")]
+    n2 = len(expand(ch2))
+    f2 = bytes([0x10, n2 & 0xFF, (n2 >> 8) & 0xFF, n2 >> 16]) + enc_lz10(ch2)
+    ntot = nl + n2
+    ends = [len(lz10f), len(lz10f) + len(f2)]
+    table = b"".join(bytes([e & 0xFF, e >> 8]) for e in ends)
+    cont2("\"LZ77\" + type 0xF7 (ChunkLZ10) + u24 LE total size + u16 LE chunk end offsets (relative to the end of the table, the last one reaching the end of the file) + one LZ10 FILE per chunk",
+          "LZ77", "LZ77", b"LZ77" + bytes([0xF7, ntot & 0xFF, (ntot >> 8) & 0xFF, ntot >> 16]) + table + lz10f + f2, opsl + [("lit", expand(ch2))], "LZ77.cs:137-160")
+    # LZ00: the LZSS body is XORed with a keystream, one step of the generator per byte read  LZ00.cs:128-141
+    def lz00_crypt(data, key):
+        M, outb = 0xFFFFFFFF, bytearray()
+        for v in data:
+            x = ((key << 1) + key) & M                             # (((((((Key << 1) + Key) << 5) - Key) << 5) + Key) << 7) - Key, in 32 bits
+            x = ((x << 5) - key) & M
+            x = ((x << 5) + key) & M
+            x = ((x << 7) - key) & M
+            x = ((x << 6) - x) & M
+            x = ((x << 4) - x) & M
+            key = (((x << 2) - x) + 12345) & M
+            t = (key >> 16) & 0x7FFF
+            outb.append((v ^ ((((t << 8) - t) & M) >> 15)) & 0xFF)
+        return bytes(outb)
+    body = enc_lzss(opss); n = len(expand(opss)); key = 0x1234ABCD
+    cont2("\"LZ00\" + LE file length + 8 bytes + a 32-byte name + LE size + LE key + 8 bytes, then the LZSS body under the keystream", "LZ00", "LZ00",
+          b"LZ00" + le32(0x40 + len(body)) + bytes(8) + b"kat.bin".ljust(32, b"\x00") + le32(n) + le32(key) + bytes(8) + lz00_crypt(body, key), opss, "LZ00.cs:37-38, :62-82, :128-141")
+
     # ---- BLZ: the file is read from its END (footer, then the code backwards), and the output is written from its end as well
     def enc_blz_file(ops):
         """BLZ.Decompress / DecompressHeaderless  AuroraLib.Compression.Nintendo/Nintendo/BLZ.cs:60-135: in the order the decoder consumes them, the
