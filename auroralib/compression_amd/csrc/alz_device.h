@@ -129,6 +129,7 @@ struct InCache {
 template <bool GLOBAL_FALLBACK>
 struct OutWin {
     static constexpr bool FB = GLOBAL_FALLBACK;
+    static constexpr bool PUBLISH = false;   // (see WalkOut in alz_emit_byte.h)
     u8* dst;         // global output of this stream
     u8* win;         // LDS, LW bytes, 16 B aligned
     u32 lw_mask;     // LW - 1

@@ -185,12 +185,36 @@ __device__ __forceinline__ void emit_finish(OW& out, u8* scratch, const u8* inld
     else byte_emit_steps<OW, CFG>(out, scratch, inlds, lane, e);
 }
 
+// The "window" of a wavefront that only PARSES (two wavefronts per stream, alz_decode_fast2_kernel): it knows how far the output has
+// got and how much room there is -- all the token prologue needs -- and hands every batch of tokens, prologue done, to the
+// executing wavefront through a two-slot LDS mailbox: per lane (length after the cuts | 0 = not executed, offset, descriptor), per
+// batch (kind, output position, bytes, window).  One workgroup barrier per batch.
+#define ALZ_MBOX_WORDS (3u * 64u + 16u)
+struct WalkOut {
+    static constexpr bool FB = false;
+    static constexpr bool PUBLISH = true;
+    u32 produced, cap;
+    u32* mbox; u32 k;
+    __device__ __forceinline__ void publish(const EmitState& e, int lane) {
+        u32* slot = mbox + (k & 1u) * ALZ_MBOX_WORDS;
+        slot[lane] = e.kept ? e.clen : 0u; slot[64 + lane] = e.off; slot[128 + lane] = e.desc;
+        if (lane == 0) { slot[192] = 1u; slot[193] = e.O; slot[194] = e.T; slot[195] = e.W; }
+        __syncthreads();
+        k++;
+    }
+};
+
 // Returns true when the stream is finished (declared size reached, or capacity hit).
 template <class OW, class CFG>
 __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch,
                                           const u8* inlds, int lane, u32& last_tend, u32 W) {
     EmitState e;
     emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
+    if constexpr (OW::PUBLISH) {                               // a parsing wavefront: the batch goes to the executing one
+        out.publish(e, lane);
+        out.produced = e.O + e.T;
+        return e.fin;
+    } else {
 #if defined(ALZ_EXP) && ALZ_EXP == 1
     out.produced = e.O + e.T; out.flushed = out.produced & ~1023u;       // timing experiment: front end + token prologue only (no output)
     if (e.kept && e.clen == 0x12345u) scratch[lane] = (u8)e.desc;
@@ -198,4 +222,5 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
     emit_finish<OW, CFG>(out, scratch, inlds, lane, e);
 #endif
     return e.fin;
+    }
 }

@@ -327,7 +327,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     if (nfmt <= 1) {
         for (int f = 0; f < ALZ_FMT_COUNT; f++) {
             if (!p->fmt_cnt[f]) continue;
-            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact);
+            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
         return ALZ_OK;
@@ -351,7 +351,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
             if (w != hipSuccess) { rc = fail(ALZ_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(w)); break; }
             used[k & 3] = true;
         }
-        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact);
+        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n);
         if (e != hipSuccess) rc = fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         k++;
     }

@@ -8,7 +8,7 @@
 // enqueue the decode kernel of one format over `count` streams (index list selects them; NULL = 0..count-1)
 // `exact`: the exact one-token-at-a-time kernels (alz_ctx_set_exact_kernels) instead of the lane-parallel ones
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams,
-                             const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact);
+                             const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact, uint32_t batch_total = 0)   /* batch_total: streams of ALL formats of the batch this launch belongs to (0 = count) */;
 int alz_kernel_occupancy(int fmt);   // resident waves per CU of the production decode kernel (tuning aid)
 
 // ---- encoder (alz_encode.hip)

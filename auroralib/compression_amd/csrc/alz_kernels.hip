@@ -487,6 +487,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
 }
 
 // ------------------------------------------------------------------------------------------------
+// The single-cursor flag-byte formats with TWO wavefronts per stream, for launches that cannot fill the GPU with one (a CU holds
+// ~24 streams either way: below ~6 000 streams the time of a launch is the time of ONE stream -- 1.1 ms per 256 KiB of Yaz0, front
+// end and byte phase taking turns on a single wavefront).  Wavefront 0 runs the front end and the token prologue of
+// fast_iter_interleaved unchanged, on a WalkOut instead of a window: every batch of tokens goes through an LDS mailbox to
+// wavefront 1, which owns the window and runs the byte phase (byte_emit_steps); one workgroup barrier per batch.  When the fast loop
+// ends (stream finished, or its tail left to the exact parser) the walker hands over its parser state and leaves; wavefront 1 finishes
+// alone exactly as the one-wavefront kernel does.
+template <int FMT>
+__global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                               const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results,
+                                                               alz_lz_properties lz, u32 lw) {
+    constexpr u32 CHUNK = 1024u, CACHE = 2u * CHUNK + 32u, FSCR = 128u, LWMAX = 4096u;
+    __shared__ __attribute__((aligned(16))) u8 lds[FSCR + CACHE + LWMAX + CACHE + 2u * ALZ_MBOX_WORDS * 4u];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
+    u32* mbox = reinterpret_cast<u32*>(lds + FSCR + CACHE + LWMAX + CACHE);
+    FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
+    gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
+    if (threadIdx.x < 64u) {
+        // ---- the parsing wavefront
+        InCache in; in.init(src, src_len, lds + FSCR + CACHE + LWMAX, lane, CHUNK);
+        DecState s; dec_state_init(s);
+        WalkOut out; out.produced = 0; out.cap = cap; out.mbox = mbox; out.k = 0;
+        bool fin = false, to_serial = false;
+        while (!fin && !to_serial && out.produced < size && s.p < src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, src_len, to_serial, nullptr, lane, gm);
+        u32* slot = mbox + (out.k & 1u) * ALZ_MBOX_WORDS;
+        if (lane == 0) {
+            slot[192] = 2u; slot[193] = s.p; slot[194] = s.bits; slot[195] = s.flag; slot[196] = fin ? 1u : 0u; slot[197] = s.ovf ? 1u : 0u;
+            slot[198] = (u32)s.attempted_end; slot[199] = (u32)(s.attempted_end >> 32);
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- the executing wavefront
+    u8* dst = dst_base + st.dst_off;
+    u8* segmark = lds;
+    u8* inc_lds = lds + FSCR;
+    typedef OutWin<false> OWF;
+    OWF out; out.init(dst, cap, lds + FSCR + CACHE, lw, lane, 0u);
+    segmark[lane] = 0; segmark[64 + lane] = 0;
+    DecState s; dec_state_init(s);
+    typedef EmitCfg<(FMT == ALZ_FMT_LZSS ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, false> CFG;
+    bool fin = false;
+    for (u32 k = 0;; k++) {
+        __syncthreads();
+        const u32* slot = mbox + (k & 1u) * ALZ_MBOX_WORDS;
+        const u32 kind = uni(slot[192]);
+        if (kind == 2u) {
+            s.p = uni(slot[193]); s.bits = uni(slot[194]); s.flag = uni(slot[195]); fin = uni(slot[196]) != 0u;
+            s.ovf = uni(slot[197]) != 0u; s.attempted_end = ((u64)uni(slot[199]) << 32) | uni(slot[198]);
+            break;
+        }
+        EmitState e;
+        e.clen = slot[lane]; e.kept = e.clen != 0u; e.off = slot[64 + lane]; e.desc = slot[128 + lane];
+        e.O = uni(slot[193]); e.T = uni(slot[194]); e.W = uni(slot[195]); e.fin = false;
+        byte_emit_steps<OWF, CFG>(out, segmark, nullptr, lane, e);
+    }
+    if (!fin) {
+        InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
+        typedef DirectSink<OWF> SK;
+        SK sk(out, s);
+        if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, sk, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
+        else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
+        else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
+        else if constexpr (FMT == ALZ_FMT_LZ40) dec_lz40_serial(in, sk, s, src_len, size);
+        else if constexpr (FMT == ALZ_FMT_CLZ0) dec_clz0_serial(in, sk, s, src_len, size);
+        else dec_yaz0_serial(in, sk, s, src_len, size);
+    }
+    out.finish();
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, true, out.produced, size, cap));
+}
+
+// ------------------------------------------------------------------------------------------------
 // PRS with TWO wavefronts per stream: wavefront 0 walks (prs_parse_round: input cache + scalar walk, no window), wavefront 1
 // executes (the byte phase on the window); a round's tokens cross in a two-slot LDS mailbox, one workgroup barrier per round.  A PRS
 // stream alone is a chain of ~46 000 dependent token steps: ~60 cycles of scalar walk and ~70 of byte phase per token, one after
@@ -578,6 +656,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
+static thread_local u32 t_batch_total = 0;     // streams of the whole batch the current launch belongs to (alz_launch_decode)
 
 // PRS: two wavefronts per stream (alz_decode_prs2_kernel)?  ALZ_PRS2: 0 never, 1 always, otherwise (default) for launches the GPU
 // cannot fill with one wavefront per stream anyway
@@ -600,6 +679,15 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
     (void)ncaches;
     static int pad = -1;
     if (pad < 0) { const char* e = getenv("ALZ_OCC_PAD"); pad = e ? atoi(e) : 0; }
+    // launches that cannot fill the GPU with one wavefront per stream: two per stream (alz_decode_fast2_kernel).  ALZ_FAST2: 0 never,
+    // 1 always, otherwise the stream count below which a launch is bound by the time of one stream
+    if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40 || FMT == ALZ_FMT_CLZ0 || FMT == ALZ_FMT_YAZ0)) {
+        static const int two = getenv("ALZ_FAST2") ? atoi(getenv("ALZ_FAST2")) : 3072;
+        if (two == 1 || (two > 1 && t_batch_total <= (u32)two)) {        // (a mixed batch fills the GPU with all its formats together)
+            hipLaunchKernelGGL((alz_decode_fast2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lz, lw);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
@@ -645,8 +733,9 @@ int alz_kernel_occupancy(int fmt) {
 }
 
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
-                             u32 count, alz_result* results, const alz_lz_properties* lzp, bool exact) {
+                             u32 count, alz_result* results, const alz_lz_properties* lzp, bool exact, u32 batch_total) {
     if (count == 0) return hipSuccess;
+    t_batch_total = batch_total > count ? batch_total : count;
     const u8* s = (const u8*)src; u8* d = (u8*)dst;
     alz_lz_properties lz = *lzp;
     if (!exact) {
