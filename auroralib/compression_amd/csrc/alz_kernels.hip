@@ -564,6 +564,84 @@ __global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restr
     write_result(&results[sid], lane, out, s.p, resolve_status(s, true, out.produced, size, cap));
 }
 
+// The same for the three-cursor formats (Yay0 / MIO0): the walker owns three small input caches (flags, tokens, literals) and hands over
+// its three cursors at the end.
+template <int FMT>
+__global__ __launch_bounds__(128) void alz_decode_fast2c_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                                const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, u32 lw) {
+    constexpr u32 CHUNK = 256u, CACHE = ALZ_INCACHE_SMALL, FSCR = 128u, LWMAX = 4096u;
+    __shared__ __attribute__((aligned(16))) u8 lds[FSCR + 3u * CACHE + LWMAX + 3u * CACHE + 2u * ALZ_MBOX_WORDS * 4u];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
+    const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
+    u32* mbox = reinterpret_cast<u32*>(lds + FSCR + 3u * CACHE + LWMAX + 3u * CACHE);
+    const bool bad = FMT == ALZ_FMT_YAY0 && (a0 > src_len || a1 > src_len);        // Slice() throws  Yay0.cs:102-103
+    if (threadIdx.x < 64u) {
+        // ---- the parsing wavefront
+        u8* wl = lds + FSCR + 3u * CACHE + LWMAX;
+        DecState s; dec_state_init(s);
+        WalkOut out; out.produced = 0; out.cap = cap; out.mbox = mbox; out.k = 0;
+        bool fin = false;
+        u32 fp = 0, cp = a0, up = a1;
+        if (!bad) {
+            InCache in, cin, uin;
+            in.init(src, src_len, wl, lane, CHUNK);
+            cin.init(src, src_len, wl + CACHE, lane, CHUNK); cin.seek(a0 < src_len ? a0 : 0);
+            uin.init(src, src_len, wl + 2 * CACHE, lane, CHUNK); uin.seek(a1 < src_len ? a1 : 0);
+            while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len)
+                fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, nullptr, lane, fp, cp, up);
+        }
+        u32* slot = mbox + (out.k & 1u) * ALZ_MBOX_WORDS;
+        if (lane == 0) {
+            slot[192] = 2u; slot[193] = fp; slot[194] = cp; slot[195] = up; slot[196] = fin ? 1u : 0u; slot[197] = s.ovf ? 1u : 0u;
+            slot[198] = (u32)s.attempted_end; slot[199] = (u32)(s.attempted_end >> 32);
+        }
+        __syncthreads();
+        return;
+    }
+    // ---- the executing wavefront
+    u8* dst = dst_base + st.dst_off;
+    u8* segmark = lds;
+    u8* inc_lds = lds + FSCR;
+    typedef OutWin<false> OWF;
+    OWF out; out.init(dst, cap, lds + FSCR + 3u * CACHE, lw, lane, 0u);
+    segmark[lane] = 0; segmark[64 + lane] = 0;
+    DecState s; dec_state_init(s);
+    typedef EmitCfg<4095u, false, false, false> CFG;
+    bool fin = false;
+    u32 fp = 0, cp = a0, up = a1;
+    for (u32 k = 0;; k++) {
+        __syncthreads();
+        const u32* slot = mbox + (k & 1u) * ALZ_MBOX_WORDS;
+        if (uni(slot[192]) == 2u) {
+            fp = uni(slot[193]); cp = uni(slot[194]); up = uni(slot[195]); fin = uni(slot[196]) != 0u;
+            s.ovf = uni(slot[197]) != 0u; s.attempted_end = ((u64)uni(slot[199]) << 32) | uni(slot[198]);
+            break;
+        }
+        EmitState e;
+        e.clen = slot[lane]; e.kept = e.clen != 0u; e.off = slot[64 + lane]; e.desc = slot[128 + lane];
+        e.O = uni(slot[193]); e.T = uni(slot[194]); e.W = uni(slot[195]); e.fin = false;
+        byte_emit_steps<OWF, CFG>(out, segmark, nullptr, lane, e);
+    }
+    u32 used = cp > up ? cp : up;
+    if (bad) s.eof = true;
+    else if (!fin) {
+        InCache in, cin, uin;
+        in.init(src, src_len, inc_lds, lane, CHUNK); in.seek(fp < src_len ? fp : 0);
+        cin.init(src, src_len, inc_lds + CACHE, lane, CHUNK); cin.seek(cp < src_len ? cp : 0);
+        uin.init(src, src_len, inc_lds + 2 * CACHE, lane, CHUNK); uin.seek(up < src_len ? up : 0);
+        typedef DirectSink<OWF> SK; SK sk(out, s);
+        used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up);
+    }
+    out.finish();
+    write_result(&results[sid], lane, out, bad ? s.p : used, resolve_status(s, true, out.produced, size, cap));
+}
+
 // ------------------------------------------------------------------------------------------------
 // PRS with TWO wavefronts per stream: wavefront 0 walks (prs_parse_round: input cache + scalar walk, no window), wavefront 1
 // executes (the byte phase on the window); a round's tokens cross in a two-slot LDS mailbox, one workgroup barrier per round.  A PRS
@@ -685,6 +763,13 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
         static const int two = getenv("ALZ_FAST2") ? atoi(getenv("ALZ_FAST2")) : 3072;
         if (two == 1 || (two > 1 && t_batch_total <= (u32)two)) {        // (a mixed batch fills the GPU with all its formats together)
             hipLaunchKernelGGL((alz_decode_fast2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lz, lw);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0)) {
+        static const int two = getenv("ALZ_FAST2") ? atoi(getenv("ALZ_FAST2")) : 3072;
+        if (two == 1 || (two > 1 && t_batch_total <= (u32)two)) {
+            hipLaunchKernelGGL((alz_decode_fast2c_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lw);
             return hipGetLastError();
         }
     }

@@ -275,3 +275,35 @@ def test_prs_one_wavefront_kernel_still_agrees():
     env = dict(os.environ, ALZ_PRS2="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("switch", ["0", "1"])
+def test_flag_formats_agree_on_one_and_two_wavefronts(switch):
+    """The flag-byte formats pick one or two wavefronts per stream by the size of the launch (ALZ_FAST2: 0 never, 1 always, n = up to n
+    streams); both kernels must give the oracle's bytes, lengths, consumed input and status for valid, truncated and noisy streams."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, random, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as O\n"
+        "from auroralib.compression_amd import _abi as A, synth\n"
+        "from auroralib.compression_amd.batch import Context\n"
+        "ctx = Context(0)\n"
+        "sizes = np.array([1, 7, 300, 5000, 70000, 262144, 100001, 64], dtype=np.uint32)\n"
+        "rng = random.Random(99)\n"
+        "for fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0):\n"
+        "    b = synth.make_batch(fmt, len(sizes), sizes, 4242)\n"
+        "    for damaged in (False, True):\n"
+        "        src = b.src.copy()\n"
+        "        if damaged:\n"
+        "            for _ in range(40): src[rng.randrange(len(src))] ^= 1 << rng.randrange(8)\n"
+        "        o_dst, o_res = O.decode_batch(b.streams, src, b.dst_bytes)\n"
+        "        g_dst, g_res = ctx.decode_batch(b.streams, src, b.dst_bytes)\n"
+        "        gr, orr = synth.result_records(g_res), synth.result_records(o_res)\n"
+        "        assert all(np.array_equal(gr[f], orr[f]) for f in ('status', 'dst_len', 'src_used')), (fmt, damaged)\n"
+        "        assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes]), (fmt, damaged)\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALZ_FAST2=switch)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
