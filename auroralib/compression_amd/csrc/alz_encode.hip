@@ -317,6 +317,146 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
     }
 }
 
+// Kernel A with the head table in LDS: ONE workgroup of 16 wavefronts per stream, one stream per CU.  The table of 2^15 entries is
+// 128 KB of the CU's 160; a finder with more hash bits takes 2^(hashBits - 15) passes over the stream, pass k owning the hashes whose
+// top bits are k (entries of different hashes never meet, so the passes are independent).  Inside a pass the table is cut into 16
+// classes (the top four bits of the 15-bit index), class c belonging to wavefront c alone: the positions of a chunk of 2 048 are
+// hashed by all wavefronts together (128 each), ranked per class with ballots, and written in position order into 16 LDS queues;
+// every owner then takes its queue 64 entries at a time -- old head, in-step duplicates (found with the table itself: write,
+// read back, losers mark, winners see the mark), new head, prev() out to HBM -- with no barrier inside: an owner's table words,
+// queue and step state are private to it, and the LDS executes one wavefront's operations in order.  Two workgroup barriers per
+// chunk.  A class that would overflow its queue (runs of equal bytes: one hash, one class) makes the chunk go through one
+// wavefront's 128 positions at a time.  prev() comes out exactly as from the table in HBM.
+#define ALZ_CU_QCAP 448u
+#define ALZ_CU_U 2
+__global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                           const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
+                                                           const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    __shared__ int T[1 << 15];
+    __shared__ u32 Q[16][ALZ_CU_QCAP];
+    __shared__ u32 cnts[16][16];                  // [wavefront][class]: entries of the current chunk
+    __shared__ u32 qpub[32];                      // [class]: ring index behind the queue's last entry; [16 + class]: entries waiting
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;
+    int* p4 = prev4 + pos_off[sid];
+    volatile int* Tv = T;
+    const u32 hb = (u32)g.hash_bits, hmask = (1u << hb) - 1u;
+    const u32 npass = 1u << (hb - 15u);
+    const u64 lanes_below = (1ull << lane) - 1ull;
+    constexpr int CH = 1024 * ALZ_CU_U;
+    for (u32 pass = 0; pass < npass; pass++) {
+        for (u32 i = threadIdx.x; i < (1u << 15); i += 1024u) T[i] = -1;
+        u32 qhead = 0, qn = 0;                    // the queue of class w (this wavefront's)
+        if (lane == 0) { qpub[w] = 0; qpub[16 + w] = 0; }
+        __syncthreads();
+        for (int cbase = 0; cbase <= limit; cbase += CH) {
+            // ---- 1. hash my 128 positions, rank them per class
+            u32 ent[ALZ_CU_U], cls[ALZ_CU_U], rank[ALZ_CU_U];
+            u32 scnt[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) scnt[c] = 0;
+#pragma unroll
+            for (int u = 0; u < ALZ_CU_U; u++) {
+                const int pos = cbase + (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane;
+                const bool act = pos <= limit;
+                const u32 v = act ? load32(data + pos) : 0u;
+                const u32 h = ((v * 2654435761u) >> (32u - hb)) & hmask;         // ComputeHash  LzChainMatchFinder.cs:288-299
+                const u32 idx = h & 0x7FFFu;
+                const bool keep = act && (h >> 15) == pass;
+                cls[u] = keep ? (idx >> 11) : 16u;
+                ent[u] = ((u32)pos & 0x1FFFFu) | (idx << 17);
+                rank[u] = 0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    const u64 m = __ballot(cls[u] == (u32)c);
+                    if (cls[u] == (u32)c) rank[u] = scnt[c] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    scnt[c] += (u32)__popcll(m);
+                }
+            }
+            {   u32 cv = 0;
+#pragma unroll
+                for (int c = 0; c < 16; c++) if (lane == c) cv = scnt[c];
+                if (lane < 16) cnts[w][lane] = cv;
+            }
+            __syncthreads();
+            // ---- 2. where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
+            u32 before = 0, tot = 0, tail_c = 0, wait_c = 0;
+            if (lane < 16) {
+#pragma unroll
+                for (u32 ww = 0; ww < 16; ww++) { const u32 x = cnts[ww][lane]; tot += x; if (ww < w) before += x; }
+                tail_c = qpub[lane]; wait_c = qpub[16 + lane];
+            }
+            const bool last = cbase + CH > limit;
+            const bool drain = last || ((((u32)cbase / (u32)CH) & 31u) == 31u);       // (entries keep 17 bits of their position)
+            const int cend1 = cbase + CH - 1;
+            const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
+            const u32 rounds = narrow ? 16u : 1u;
+            for (u32 r = 0; r < rounds; r++) {
+                if (narrow) {
+                    if (r) { __syncthreads(); if (lane < 16) { tail_c = qpub[lane]; } }
+                    before = 0; tot = lane < 16 ? cnts[r][lane] : 0u;
+                }
+                if (!narrow || r == w) {
+                    const u32 base_c = tail_c + before;
+#pragma unroll
+                    for (int u = 0; u < ALZ_CU_U; u++) {
+                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)base_c);
+                        if (cls[u] < 16u) {
+                            u32 slot = b + rank[u];
+                            while (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
+                            Q[cls[u]][slot] = ent[u];
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- 3. my class: full steps of 64 (everything when the queue has to drain)
+                qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
+                while (qn >= 64u || (drain && (!narrow || r == 15u) && qn)) {
+                    const u32 nstep = qn < 64u ? qn : 64u;
+                    const bool actl = (u32)lane < nstep;
+                    u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
+                    const u32 e = actl ? Q[w][slot] : 0u;
+                    const int pos = cend1 - (int)(((u32)cend1 - e) & 0x1FFFFu);
+                    const u32 idx = e >> 17;
+                    int old = -1; bool contested = false;
+                    if (actl) {
+                        old = Tv[idx];
+                        Tv[idx] = pos;
+                    }
+                    if (actl && Tv[idx] != pos) Tv[idx] = -2;            // I lost my word to another lane of this step: mark it
+                    if (actl) contested = Tv[idx] == -2;
+                    int prev = old; bool writer = false;
+                    u64 todo = __ballot(contested);
+                    while (todo) {
+                        const int l0 = (int)__builtin_ctzll(todo);
+                        const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
+                        const bool mine = contested && idx == iv;
+                        const u64 grp = __ballot(mine);
+                        const u64 below = grp & lanes_below;
+                        const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
+                        const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);       // position of the next lower lane of my group
+                        if (mine) { if (below) prev = pp; writer = (grp >> lane) <= 1ull; }  // the highest lane of a group owns the new head
+                        todo &= ~grp;
+                    }
+                    if (writer) Tv[idx] = pos;
+                    if (actl) p4[pos] = prev;
+                    qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
+                    qn -= nstep;
+                }
+                if (lane == 0) { u32 t = qhead + qn; if (t >= ALZ_CU_QCAP) t -= ALZ_CU_QCAP; qpub[w] = t; qpub[16 + w] = qn; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Kernel A for windows up to 4 KiB: the same prev() links, from LDS instead of per-stream head tables in HBM.  A candidate
 // further back than maxDistance ends every chain walk of kernel B (`dist > g.max_dist: break`), so only the most recent
 // 4096 positions have to be remembered -- and for those a hash table with chaining fits the LDS: T[hash & 4095] = ring
@@ -1417,6 +1557,12 @@ static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, co
     hipLaunchKernelGGL((enc_emit_par_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, mask, side, results, aux, g);
 }
 
+// kernel A with the table in LDS: the largest number of passes it is used for (ALZ_ENC_PREV_CU; 0 = never)
+static int prev_cu_passes() {
+    static const int v = getenv("ALZ_ENC_PREV_CU") ? atoi(getenv("ALZ_ENC_PREV_CU")) : 1;
+    return v;
+}
+
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
@@ -1439,6 +1585,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         if (g.use_min_table) hipLaunchKernelGGL((enc_prev_block_kernel<true>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
         else hipLaunchKernelGGL((enc_prev_block_kernel<false>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
     }
+    else if (!g.use_min_table && prev_cu_passes() > 0 && g.hash_bits >= 15 && (1 << (g.hash_bits - 15)) <= prev_cu_passes())
+        hipLaunchKernelGGL(enc_prev_cu_kernel, dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
     else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     else {
         // Experiment knobs (round 2, tools/enc_split.sh; both bit-identical, neither pays): ALZ_ENC_SPLIT = wavefronts per stream of the
