@@ -320,15 +320,17 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 // Kernel A with the head table in LDS: ONE workgroup of 16 wavefronts per stream, one stream per CU.  The table of 2^15 entries is
 // 128 KB of the CU's 160; a finder with more hash bits takes 2^(hashBits - 15) passes over the stream, pass k owning the hashes whose
 // top bits are k (entries of different hashes never meet, so the passes are independent).  Inside a pass the table is cut into 16
-// classes (the top four bits of the 15-bit index), class c belonging to wavefront c alone: the positions of a chunk of 2 048 are
-// hashed by all wavefronts together (128 each), ranked per class with ballots, and written in position order into 16 LDS queues;
+// classes (the top four bits of the 15-bit index), class c belonging to wavefront c alone: the positions of a chunk of 4 096 are
+// hashed by all wavefronts together (256 each), ranked per class with ballots, and written in position order into 16 LDS queues;
 // every owner then takes its queue 64 entries at a time -- old head, in-step duplicates (found with the table itself: write,
 // read back, losers mark, winners see the mark), new head, prev() out to HBM -- with no barrier inside: an owner's table words,
 // queue and step state are private to it, and the LDS executes one wavefront's operations in order.  Two workgroup barriers per
 // chunk.  A class that would overflow its queue (runs of equal bytes: one hash, one class) makes the chunk go through one
-// wavefront's 128 positions at a time.  prev() comes out exactly as from the table in HBM.
+// wavefront's 256 positions at a time.  prev() comes out exactly as from the table in HBM.
 #define ALZ_CU_QCAP 448u
+#ifndef ALZ_CU_U
 #define ALZ_CU_U 2
+#endif
 __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                            const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
@@ -356,8 +358,11 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         u32 qhead = 0, qn = 0;                    // the queue of class w (this wavefront's)
         if (lane == 0) { qpub[w] = 0; qpub[16 + w] = 0; }
         __syncthreads();
+        u32 vnext[ALZ_CU_U];                      // the dwords of the next chunk's positions, loaded one chunk ahead
+#pragma unroll
+        for (int u = 0; u < ALZ_CU_U; u++) { const int pos = (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane; vnext[u] = pos <= limit ? load32(data + pos) : 0u; }
         for (int cbase = 0; cbase <= limit; cbase += CH) {
-            // ---- 1. hash my 128 positions, rank them per class
+            // ---- 1. hash my positions, rank them per class
             u32 ent[ALZ_CU_U], cls[ALZ_CU_U], rank[ALZ_CU_U];
             u32 scnt[16];
 #pragma unroll
@@ -366,19 +371,24 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
             for (int u = 0; u < ALZ_CU_U; u++) {
                 const int pos = cbase + (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane;
                 const bool act = pos <= limit;
-                const u32 v = act ? load32(data + pos) : 0u;
+                const u32 v = vnext[u];
+                vnext[u] = pos + CH <= limit ? load32(data + pos + CH) : 0u;
                 const u32 h = ((v * 2654435761u) >> (32u - hb)) & hmask;         // ComputeHash  LzChainMatchFinder.cs:288-299
                 const u32 idx = h & 0x7FFFu;
                 const bool keep = act && (h >> 15) == pass;
                 cls[u] = keep ? (idx >> 11) : 16u;
                 ent[u] = ((u32)pos & 0x1FFFFu) | (idx << 17);
                 rank[u] = 0;
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 2
+                { const u64 m = __ballot(cls[u] < 16u); rank[u] = scnt[0] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); scnt[0] += (u32)__popcll(m); if (cls[u] < 16u) cls[u] = 0; }   // timing experiment: one class
+#else
 #pragma unroll
                 for (int c = 0; c < 16; c++) {
                     const u64 m = __ballot(cls[u] == (u32)c);
                     if (cls[u] == (u32)c) rank[u] = scnt[c] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
                     scnt[c] += (u32)__popcll(m);
                 }
+#endif
             }
             {   u32 cv = 0;
 #pragma unroll
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 tail_c = qpub[lane]; wait_c = qpub[16 + lane];
             }
             const bool last = cbase + CH > limit;
-            const bool drain = last || ((((u32)cbase / (u32)CH) & 31u) == 31u);       // (entries keep 17 bits of their position)
+            const bool drain = last || (((u32)(cbase + CH) & 0xFFFFu) == 0u);      // (entries keep 17 bits of their position: none waits longer than 64 Ki positions)
             const int cend1 = cbase + CH - 1;
             const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
             const u32 rounds = narrow ? 16u : 1u;
@@ -418,6 +428,9 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 __syncthreads();
                 // ---- 3. my class: full steps of 64 (everything when the queue has to drain)
                 qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
+                qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
+#endif
                 while (qn >= 64u || (drain && (!narrow || r == 15u) && qn)) {
                     const u32 nstep = qn < 64u ? qn : 64u;
                     const bool actl = (u32)lane < nstep;
@@ -432,18 +445,22 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                     if (actl && Tv[idx] != pos) Tv[idx] = -2;            // I lost my word to another lane of this step: mark it
                     if (actl) contested = Tv[idx] == -2;
-                    int prev = old; bool writer = false;
+                    bool writer = false;
+                    u64 mygrp = 0;                                            // the lanes of my group (one loop trip per group: scalar work only)
                     u64 todo = __ballot(contested);
                     while (todo) {
                         const int l0 = (int)__builtin_ctzll(todo);
                         const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
-                        const bool mine = contested && idx == iv;
-                        const u64 grp = __ballot(mine);
-                        const u64 below = grp & lanes_below;
+                        const u64 grp = __ballot(contested && idx == iv);
+                        if (idx == iv) mygrp = grp;
+                        todo &= ~grp;
+                    }
+                    int prev = old;
+                    if (__ballot(contested)) {
+                        const u64 below = mygrp & lanes_below;
                         const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
                         const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);       // position of the next lower lane of my group
-                        if (mine) { if (below) prev = pp; writer = (grp >> lane) <= 1ull; }  // the highest lane of a group owns the new head
-                        todo &= ~grp;
+                        if (contested) { if (below) prev = pp; writer = (mygrp >> lane) <= 1ull; }   // the highest lane of a group owns the new head
                     }
                     if (writer) Tv[idx] = pos;
                     if (actl) p4[pos] = prev;
