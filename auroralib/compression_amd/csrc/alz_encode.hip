@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                            const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    __shared__ int T[1 << 15];
+    __shared__ int T[(1 << 15) + 64];
     __shared__ u32 Q[16][ALZ_CU_QCAP];
     __shared__ u32 cnts[16][16];                  // [wavefront][class]: entries of the current chunk
     __shared__ u32 qpub[32];                      // [class]: ring index behind the queue's last entry; [16 + class]: entries waiting
@@ -348,7 +348,10 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     const int n = (int)st.src_len - tail_skip;
     const int limit = n - 4;
     int* p4 = prev4 + pos_off[sid];
-    volatile int* Tv = T;
+    // (volatile, and in the LDS address space -- a generic volatile pointer turns into flat_load / flat_store sc0 sc1 with a full
+    // s_waitcnt vmcnt(0) each: the steps below write a word and read it back to see the other lanes' writes)
+    typedef __attribute__((address_space(3))) volatile int lds_vint;
+    lds_vint* Tv = (lds_vint*)T;
     const u32 hb = (u32)g.hash_bits, hmask = (1u << hb) - 1u;
     const u32 npass = 1u << (hb - 15u);
     const u64 lanes_below = (1ull << lane) - 1ull;
@@ -363,10 +366,8 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         for (int u = 0; u < ALZ_CU_U; u++) { const int pos = (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane; vnext[u] = pos <= limit ? load32(data + pos) : 0u; }
         for (int cbase = 0; cbase <= limit; cbase += CH) {
             // ---- 1. hash my positions, rank them per class
-            u32 ent[ALZ_CU_U], cls[ALZ_CU_U], rank[ALZ_CU_U];
-            u32 scnt[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) scnt[c] = 0;
+            u32 ent[ALZ_CU_U], cls[ALZ_CU_U], rank[ALZ_CU_U], prior[ALZ_CU_U];
+            u32 cntv = 0;                         // lane c < 16: entries of class c among my positions so far
 #pragma unroll
             for (int u = 0; u < ALZ_CU_U; u++) {
                 const int pos = cbase + (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane;
@@ -378,23 +379,24 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 const bool keep = act && (h >> 15) == pass;
                 cls[u] = keep ? (idx >> 11) : 16u;
                 ent[u] = ((u32)pos & 0x1FFFFu) | (idx << 17);
-                rank[u] = 0;
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 2
-                { const u64 m = __ballot(cls[u] < 16u); rank[u] = scnt[0] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); scnt[0] += (u32)__popcll(m); if (cls[u] < 16u) cls[u] = 0; }   // timing experiment: one class
-#else
+                // the lanes of a class = AND over the four bit planes of the class number (plane or its complement); every lane
+                // forms the mask of its own class (its rank) and the mask of class (lane & 15) (the count), without a loop over classes
+                const u64 valid = __ballot(keep);
+                u64 pl[4];
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    const u64 m = __ballot(cls[u] == (u32)c);
-                    if (cls[u] == (u32)c) rank[u] = scnt[c] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                    scnt[c] += (u32)__popcll(m);
+                for (int b = 0; b < 4; b++) pl[b] = __ballot((cls[u] >> b) & 1u);
+                u64 mine = valid, cm = valid;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const u64 s1 = (u64)0 - (u64)((cls[u] >> b) & 1u), s2 = (u64)0 - (u64)(((u32)lane >> b) & 1u);
+                    mine &= ~(pl[b] ^ s1);
+                    cm &= ~(pl[b] ^ s2);
                 }
-#endif
+                rank[u] = __builtin_amdgcn_mbcnt_hi((u32)(mine >> 32), __builtin_amdgcn_mbcnt_lo((u32)mine, 0u));
+                prior[u] = cntv;
+                cntv += (u32)__popcll(cm);
             }
-            {   u32 cv = 0;
-#pragma unroll
-                for (int c = 0; c < 16; c++) if (lane == c) cv = scnt[c];
-                if (lane < 16) cnts[w][lane] = cv;
-            }
+            if (lane < 16) cnts[w][lane] = cntv;
             __syncthreads();
             // ---- 2. where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
             u32 before = 0, tot = 0, tail_c = 0, wait_c = 0;
@@ -414,10 +416,9 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     before = 0; tot = lane < 16 ? cnts[r][lane] : 0u;
                 }
                 if (!narrow || r == w) {
-                    const u32 base_c = tail_c + before;
 #pragma unroll
                     for (int u = 0; u < ALZ_CU_U; u++) {
-                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)base_c);
+                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)(tail_c + before + prior[u]));
                         if (cls[u] < 16u) {
                             u32 slot = b + rank[u];
                             while (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
@@ -435,35 +436,49 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     const u32 nstep = qn < 64u ? qn : 64u;
                     const bool actl = (u32)lane < nstep;
                     u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
-                    const u32 e = actl ? Q[w][slot] : 0u;
+                    const u32 e = Q[w][slot];
                     const int pos = cend1 - (int)(((u32)cend1 - e) & 0x1FFFFu);
-                    const u32 idx = e >> 17;
-                    int old = -1; bool contested = false;
-                    if (actl) {
-                        old = Tv[idx];
-                        Tv[idx] = pos;
+                    const u32 idx = actl ? e >> 17 : 0x8000u + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
+                    // Lanes of one step that share a table word find each other THROUGH the word: everybody writes, the losers write
+                    // again.  A lane alone reads its own position twice; the two lanes of a pair each read the other's position once
+                    // (the winner of the first round in the second, the loser in the first): no loop.  Only a lane that loses twice
+                    // proves a group of three or more; those groups are marked and ordered with ballots.
+                    const int old = Tv[idx];
+                    Tv[idx] = pos;
+                    const int r1 = Tv[idx];
+                    const bool lost1 = r1 != pos;
+                    if (lost1) Tv[idx] = pos;
+                    const int r2 = Tv[idx];
+                    const bool dbl = lost1 && r2 != pos;
+                    bool big = false;
+                    if (__ballot(dbl)) {
+                        if (dbl) Tv[idx] = -2;
+                        big = Tv[idx] == -2;
                     }
-                    if (actl && Tv[idx] != pos) Tv[idx] = -2;            // I lost my word to another lane of this step: mark it
-                    if (actl) contested = Tv[idx] == -2;
-                    bool writer = false;
-                    u64 mygrp = 0;                                            // the lanes of my group (one loop trip per group: scalar work only)
-                    u64 todo = __ballot(contested);
-                    while (todo) {
-                        const int l0 = (int)__builtin_ctzll(todo);
-                        const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
-                        const u64 grp = __ballot(contested && idx == iv);
-                        if (idx == iv) mygrp = grp;
-                        todo &= ~grp;
-                    }
-                    int prev = old;
-                    if (__ballot(contested)) {
+                    const int partner = lost1 ? r1 : r2;                     // (my own position when I am alone)
+                    int prev = partner < pos ? partner : old;
+                    bool writer = !lost1 && r2 < pos;                        // the word holds my partner, and I am behind it
+                    if (__ballot(big)) {
+                        u64 mygrp = 0;                                        // the lanes of my group (one loop trip per group: scalar work only)
+                        u64 todo = __ballot(big);
+                        while (todo) {
+                            const int l0 = (int)__builtin_ctzll(todo);
+                            const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
+                            const u64 grp = __ballot(idx == iv);
+                            if (idx == iv) mygrp = grp;
+                            todo &= ~grp;
+                        }
                         const u64 below = mygrp & lanes_below;
                         const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
                         const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);       // position of the next lower lane of my group
-                        if (contested) { if (below) prev = pp; writer = (mygrp >> lane) <= 1ull; }   // the highest lane of a group owns the new head
+                        if (big) { prev = below ? pp : old; writer = (mygrp >> lane) <= 1ull; }   // the highest lane of a group owns the new head
                     }
                     if (writer) Tv[idx] = pos;
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
+                    if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
+#else
                     if (actl) p4[pos] = prev;
+#endif
                     qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                     qn -= nstep;
                 }
