@@ -376,9 +376,31 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 vnext[u] = pos + CH <= limit ? load32(data + pos + CH) : 0u;
                 const u32 h = ((v * 2654435761u) >> (32u - hb)) & hmask;         // ComputeHash  LzChainMatchFinder.cs:288-299
                 const u32 idx = h & 0x7FFFu;
-                const bool keep = act && (h >> 15) == pass;
+                bool keep = act && (h >> 15) == pass;
+                // Runs (one byte, one pixel repeated) give every position the hash of a neighbour, all of them in one class.  A position
+                // whose hash also belongs to one of the four lanes below it (same row of 16) has its prev() right there; if one of the
+                // four lanes above has it too, nobody ever reads what it would write into the table: it stays out of the queue.
+                // Without such a lane above it only writes (flag bit 16), without one below it is an ordinary entry.
+                u32 wonly = 0;
+                {
+                    const u32 hk = keep ? h : ~(u32)lane;                    // (never equal to a real hash, nor to a neighbour's)
+                    const u64 m1 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x111, 0xF, 0xF, false));
+                    const u64 m2 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x112, 0xF, 0xF, false));
+                    const u64 m3 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x113, 0xF, 0xF, false));
+                    const u64 m4 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x114, 0xF, 0xF, false));
+                    const u64 hasp = m1 | m2 | m3 | m4;
+                    if (hasp) {
+                        const u64 hass = (m1 >> 1) | (m2 >> 2) | (m3 >> 3) | (m4 >> 4);
+                        const u64 me = 1ull << lane;
+                        if (hasp & me) {
+                            const int d = (m1 & me) ? 1 : (m2 & me) ? 2 : (m3 & me) ? 3 : 4;
+                            p4[pos] = pos - d;
+                            if (hass & me) keep = false; else wonly = 1u << 16;
+                        }
+                    }
+                }
                 cls[u] = keep ? (idx >> 11) : 16u;
-                ent[u] = ((u32)pos & 0x1FFFFu) | (idx << 17);
+                ent[u] = ((u32)pos & 0xFFFFu) | wonly | (idx << 17);
                 // the lanes of a class = AND over the four bit planes of the class number (plane or its complement); every lane
                 // forms the mask of its own class (its rank) and the mask of class (lane & 15) (the count), without a loop over classes
                 const u64 valid = __ballot(keep);
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 tail_c = qpub[lane]; wait_c = qpub[16 + lane];
             }
             const bool last = cbase + CH > limit;
-            const bool drain = last || (((u32)(cbase + CH) & 0xFFFFu) == 0u);      // (entries keep 17 bits of their position: none waits longer than 64 Ki positions)
+            const bool drain = last || (((u32)(cbase + CH) & 0x7FFFu) == 0u);      // (entries keep 16 bits of their position: none waits longer than 32 Ki positions)
             const int cend1 = cbase + CH - 1;
             const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
             const u32 rounds = narrow ? 16u : 1u;
@@ -437,7 +459,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     const bool actl = (u32)lane < nstep;
                     u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
                     const u32 e = Q[w][slot];
-                    const int pos = cend1 - (int)(((u32)cend1 - e) & 0x1FFFFu);
+                    const int pos = cend1 - (int)(((u32)cend1 - e) & 0xFFFFu);
                     const u32 idx = actl ? e >> 17 : 0x8000u + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
                     // Lanes of one step that share a table word find each other THROUGH the word: everybody writes, the losers write
                     // again.  A lane alone reads its own position twice; the two lanes of a pair each read the other's position once
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
 #if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
                     if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
 #else
-                    if (actl) p4[pos] = prev;
+                    if (actl && !(e & 0x10000u)) p4[pos] = prev;
 #endif
                     qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                     qn -= nstep;
