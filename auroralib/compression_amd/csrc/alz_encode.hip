@@ -24,6 +24,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "alz_device.h"
 #include "alz_internal.h"
@@ -327,17 +328,23 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 // queue and step state are private to it, and the LDS executes one wavefront's operations in order.  Two workgroup barriers per
 // chunk.  A class that would overflow its queue (runs of equal bytes: one hash, one class) makes the chunk go through one
 // wavefront's 256 positions at a time.  prev() comes out exactly as from the table in HBM.
-#define ALZ_CU_QCAP 448u
+#define ALZ_CU_QCAP 352u
+#ifndef ALZ_CU_FILL4
+#define ALZ_CU_FILL4 3u       /* several passes: quarters of `stage` a slice fills on average */
+#endif
 #ifndef ALZ_CU_U
 #define ALZ_CU_U 2
 #endif
 __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                            const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    constexpr int U = ALZ_CU_U;
     __shared__ int T[(1 << 15) + 64];
     __shared__ u32 Q[16][ALZ_CU_QCAP];
+    __shared__ u32 stage[16][U * 64];             // several passes: a wavefront's entries of this pass, gathered from its slice
     __shared__ u32 cnts[16][16];                  // [wavefront][class]: entries of the current chunk
     __shared__ u32 qpub[32];                      // [class]: ring index behind the queue's last entry; [16 + class]: entries waiting
+    __shared__ u32 spill[3];                      // a slice held more entries of this pass than `stage` takes (one flag per call, three in rotation)
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)(threadIdx.x & 63u);
@@ -355,55 +362,62 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     const u32 hb = (u32)g.hash_bits, hmask = (1u << hb) - 1u;
     const u32 npass = 1u << (hb - 15u);
     const u64 lanes_below = (1ull << lane) - 1ull;
-    constexpr int CH = 1024 * ALZ_CU_U;
+    constexpr int CH = 1024 * U;
+    // several passes: a wavefront looks at SB groups of 64 positions per chunk and keeps what belongs to the pass -- 3/4 of what
+    // `stage` takes on average
+    static_assert(U <= 2, "a chunk of several passes must stay below 32 Ki positions");
+    const int SB = npass == 1u ? U : (int)(npass * (u32)U * ALZ_CU_FILL4 / 4u);
+    const int CHM = 1024 * SB;
+    if (threadIdx.x < 3u) spill[threadIdx.x] = 0;
     for (u32 pass = 0; pass < npass; pass++) {
         for (u32 i = threadIdx.x; i < (1u << 15); i += 1024u) T[i] = -1;
         u32 qhead = 0, qn = 0;                    // the queue of class w (this wavefront's)
         if (lane == 0) { qpub[w] = 0; qpub[16 + w] = 0; }
         __syncthreads();
-        u32 vnext[ALZ_CU_U];                      // the dwords of the next chunk's positions, loaded one chunk ahead
-#pragma unroll
-        for (int u = 0; u < ALZ_CU_U; u++) { const int pos = (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane; vnext[u] = pos <= limit ? load32(data + pos) : 0u; }
-        for (int cbase = 0; cbase <= limit; cbase += CH) {
-            // ---- 1. hash my positions, rank them per class
-            u32 ent[ALZ_CU_U], cls[ALZ_CU_U], rank[ALZ_CU_U], prior[ALZ_CU_U];
-            u32 cntv = 0;                         // lane c < 16: entries of class c among my positions so far
-#pragma unroll
-            for (int u = 0; u < ALZ_CU_U; u++) {
-                const int pos = cbase + (int)((w * ALZ_CU_U + (u32)u) * 64u) + lane;
-                const bool act = pos <= limit;
-                const u32 v = vnext[u];
-                vnext[u] = pos + CH <= limit ? load32(data + pos + CH) : 0u;
-                const u32 h = ((v * 2654435761u) >> (32u - hb)) & hmask;         // ComputeHash  LzChainMatchFinder.cs:288-299
-                const u32 idx = h & 0x7FFFu;
-                bool keep = act && (h >> 15) == pass;
+        int since = 0;                            // positions since the queues were last emptied (entries keep 16 bits of theirs)
+
+        // One group of 64 positions at `pos`: the entry of my position, or none.
+        auto entry_of = [&](int pos, u32 v, bool direct, u32& e, int hi = 0x7FFFFFFF) -> bool {
+            const bool act = pos <= limit && pos < hi;             // (`hi`: a multiple of 64 -- whole groups in or out)
+            const u32 h = ((v * 2654435761u) >> (32u - hb)) & hmask;             // ComputeHash  LzChainMatchFinder.cs:288-299
+            bool keep = act && (h >> 15) == pass;
+            u32 wonly = 0;
+            if (direct) {
                 // Runs (one byte, one pixel repeated) give every position the hash of a neighbour, all of them in one class.  A position
                 // whose hash also belongs to one of the four lanes below it (same row of 16) has its prev() right there; if one of the
                 // four lanes above has it too, nobody ever reads what it would write into the table: it stays out of the queue.
                 // Without such a lane above it only writes (flag bit 16), without one below it is an ordinary entry.
-                u32 wonly = 0;
-                {
-                    const u32 hk = keep ? h : ~(u32)lane;                    // (never equal to a real hash, nor to a neighbour's)
-                    const u64 m1 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x111, 0xF, 0xF, false));
-                    const u64 m2 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x112, 0xF, 0xF, false));
-                    const u64 m3 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x113, 0xF, 0xF, false));
-                    const u64 m4 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x114, 0xF, 0xF, false));
-                    const u64 hasp = m1 | m2 | m3 | m4;
-                    if (hasp) {
-                        const u64 hass = (m1 >> 1) | (m2 >> 2) | (m3 >> 3) | (m4 >> 4);
-                        const u64 me = 1ull << lane;
-                        if (hasp & me) {
-                            const int d = (m1 & me) ? 1 : (m2 & me) ? 2 : (m3 & me) ? 3 : 4;
-                            p4[pos] = pos - d;
-                            if (hass & me) keep = false; else wonly = 1u << 16;
-                        }
+                const u32 hk = keep ? h : ~(u32)lane;                        // (never equal to a real hash, nor to a neighbour's)
+                const u64 m1 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x111, 0xF, 0xF, false));
+                const u64 m2 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x112, 0xF, 0xF, false));
+                const u64 m3 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x113, 0xF, 0xF, false));
+                const u64 m4 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x114, 0xF, 0xF, false));
+                const u64 hasp = m1 | m2 | m3 | m4;
+                if (hasp) {
+                    const u64 hass = (m1 >> 1) | (m2 >> 2) | (m3 >> 3) | (m4 >> 4);
+                    const u64 me = 1ull << lane;
+                    if (hasp & me) {
+                        const int d = (m1 & me) ? 1 : (m2 & me) ? 2 : (m3 & me) ? 3 : 4;
+                        p4[pos] = pos - d;
+                        if (hass & me) keep = false; else wonly = 1u << 16;
                     }
                 }
-                cls[u] = keep ? (idx >> 11) : 16u;
-                ent[u] = ((u32)pos & 0xFFFFu) | wonly | (idx << 17);
+            }
+            e = ((u32)pos & 0xFFFFu) | wonly | ((h & 0x7FFFu) << 17);
+            return keep;
+        };
+
+        // The rest of a chunk, from the (at most U x 64) entries a wavefront found in it: ranks per class, the queues, the steps.
+        // `par` >= 0: give up (false) behind the first barrier if some wavefront could not hold its entries.
+        auto finish = [&](const u32 (&ent)[U], const bool (&keep)[U], int cend, int clen, int par) -> bool {
+            u32 cls[U], rank[U], prior[U];
+            u32 cntv = 0;                         // lane c < 16: entries of class c among mine so far
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                cls[u] = keep[u] ? ent[u] >> 28 : 16u;
                 // the lanes of a class = AND over the four bit planes of the class number (plane or its complement); every lane
                 // forms the mask of its own class (its rank) and the mask of class (lane & 15) (the count), without a loop over classes
-                const u64 valid = __ballot(keep);
+                const u64 valid = __ballot(keep[u]);
                 u64 pl[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) pl[b] = __ballot((cls[u] >> b) & 1u);
@@ -420,16 +434,18 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
             }
             if (lane < 16) cnts[w][lane] = cntv;
             __syncthreads();
-            // ---- 2. where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
+            if (par >= 0 && spill[par]) return false;
+            // ---- where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
             u32 before = 0, tot = 0, tail_c = 0, wait_c = 0;
             if (lane < 16) {
 #pragma unroll
                 for (u32 ww = 0; ww < 16; ww++) { const u32 x = cnts[ww][lane]; tot += x; if (ww < w) before += x; }
                 tail_c = qpub[lane]; wait_c = qpub[16 + lane];
             }
-            const bool last = cbase + CH > limit;
-            const bool drain = last || (((u32)(cbase + CH) & 0x7FFFu) == 0u);      // (entries keep 16 bits of their position: none waits longer than 32 Ki positions)
-            const int cend1 = cbase + CH - 1;
+            const bool last = cend > limit;
+            const bool drain = last || since + clen >= 32768;     // (nothing waits longer than 32 Ki positions + a chunk: 16 bits tell where it was)
+            since = drain ? 0 : since + clen;
+            const int cend1 = cend - 1;
             const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
             const u32 rounds = narrow ? 16u : 1u;
             for (u32 r = 0; r < rounds; r++) {
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 }
                 if (!narrow || r == w) {
 #pragma unroll
-                    for (int u = 0; u < ALZ_CU_U; u++) {
+                    for (int u = 0; u < U; u++) {
                         const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)(tail_c + before + prior[u]));
                         if (cls[u] < 16u) {
                             u32 slot = b + rank[u];
@@ -449,11 +465,8 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                 }
                 __syncthreads();
-                // ---- 3. my class: full steps of 64 (everything when the queue has to drain)
+                // ---- my class: full steps of 64 (everything when the queue has to drain)
                 qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
-                qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
-#endif
                 while (qn >= 64u || (drain && (!narrow || r == 15u) && qn)) {
                     const u32 nstep = qn < 64u ? qn : 64u;
                     const bool actl = (u32)lane < nstep;
@@ -496,15 +509,100 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                         if (big) { prev = below ? pp : old; writer = (mygrp >> lane) <= 1ull; }   // the highest lane of a group owns the new head
                     }
                     if (writer) Tv[idx] = pos;
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
-                    if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
-#else
                     if (actl && !(e & 0x10000u)) p4[pos] = prev;
-#endif
                     qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                     qn -= nstep;
                 }
                 if (lane == 0) { u32 t = qhead + qn; if (t >= ALZ_CU_QCAP) t -= ALZ_CU_QCAP; qpub[w] = t; qpub[16 + w] = qn; }
+            }
+            return true;
+        };
+        if (npass == 1u) {
+            u32 vnext[U];                         // the dwords of the next chunk's positions, loaded one chunk ahead
+#pragma unroll
+            for (int u = 0; u < U; u++) { const int pos = (int)((w * U + (u32)u) * 64u) + lane; vnext[u] = load32(data + (pos < limit ? pos : (limit > 0 ? limit : 0))); }
+            for (int cbase = 0; cbase <= limit; cbase += CH) {
+                u32 ent[U]; bool keep[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int pos = cbase + (int)((w * U + (u32)u) * 64u) + lane;
+                    const u32 v = vnext[u];
+                    vnext[u] = load32(data + (pos + CH < limit ? pos + CH : limit));
+                    keep[u] = entry_of(pos, v, true, ent[u]);
+                }
+                (void)finish(ent, keep, cbase + CH, CH, -1);
+            }
+        } else {
+            // Several passes.  A piece of work is `sbn` groups of 64 positions per wavefront starting at `from`: every wavefront keeps what
+            // its slice holds of this pass (through `stage`, in position order, at most U x 64 entries).  If some slice held more, nothing
+            // is done and the piece is cut in two; a half that fails again goes position by position (1 024 U at a time, every entry
+            // straight from its position: a hash all over the chunk).  One loop, one call of finish(): the pieces wait on a small stack.
+            auto scan = [&](int from, auto sbc) -> u32 {
+                constexpr int SBN = decltype(sbc)::value;
+                const int p0 = from + (int)(w * (u32)SBN * 64u) + lane;
+                u32 vv[SBN];                      // the whole slice in flight at once; no branch around a load (behind one, each waits for the one before)
+#pragma unroll
+                for (int sb = 0; sb < SBN; sb++) { const int q = p0 + sb * 64; vv[sb] = load32(data + (q < limit ? q : limit)); }
+                u32 fill = 0;
+#pragma unroll
+                for (int sb = 0; sb < SBN; sb++) {
+                    u32 e; const bool kp = entry_of(p0 + sb * 64, vv[sb], false, e);
+                    const u64 m = __ballot(kp);
+                    const u32 at = fill + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    if (kp && at < (u32)(U * 64)) stage[w][at] = e;
+                    fill += (u32)__popcll(m);
+                }
+                return fill;
+            };
+            u32 par = 0;
+            int nxt = 0;                          // the next chunk starts here
+            int pf[3], ps[3], pl[3], np = 0;      // pieces waiting: from, groups of 64 per wavefront, level (0 chunk, 1 half, 2 position by position)
+            for (;;) {
+                if (np == 0) {
+                    if (nxt > limit) break;
+                    pf[0] = nxt; ps[0] = SB; pl[0] = 0; np = 1; nxt += CHM;
+                }
+                np--;
+                const int from = np == 0 ? pf[0] : np == 1 ? pf[1] : pf[2];
+                const int sbn = np == 0 ? ps[0] : np == 1 ? ps[1] : ps[2];
+                const int lvl = np == 0 ? pl[0] : np == 1 ? pl[1] : pl[2];
+                if (from > limit) continue;
+                u32 ent[U]; bool keep[U];
+                int cend, flag = -1;
+                if (lvl < 2) {
+                    par = par == 2u ? 0u : par + 1u;
+                    if (threadIdx.x == 0) spill[par == 2u ? 0u : par + 1u] = 0;      // (the flag of the call after this one; last read two calls ago)
+                    u32 fill = 0;
+                    switch (sbn) {
+                    case 24: fill = scan(from, std::integral_constant<int, 24>{}); break;
+                    case 12: fill = scan(from, std::integral_constant<int, 12>{}); break;
+                    case 6: fill = scan(from, std::integral_constant<int, 6>{}); break;
+                    case 3: fill = scan(from, std::integral_constant<int, 3>{}); break;
+                    case 2: fill = scan(from, std::integral_constant<int, 2>{}); break;
+                    default: fill = scan(from, std::integral_constant<int, 1>{}); break;
+                    }
+                    const bool over = fill > (u32)(U * 64);
+                    if (over && lane == 0) spill[par] = 1;
+#pragma unroll
+                    for (int u = 0; u < U; u++) { keep[u] = !over && 64u * (u32)u + (u32)lane < fill; ent[u] = stage[w][64 * u + lane]; }
+                    cend = from + sbn * 1024; flag = (int)par;
+                } else {
+                    const int to = from + sbn * 1024;
+                    cend = from + CH < to ? from + CH : to;                  // (`to` need not be a multiple of 1 024 U away)
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int pos = from + (int)((w * U + (u32)u) * 64u) + lane;
+                        keep[u] = entry_of(pos, load32(data + (pos < limit ? pos : limit)), true, ent[u], cend);
+                    }
+                    if (cend < to) { pf[np] = cend; ps[np] = (to - cend) / 1024; pl[np] = 2; np++; }
+                }
+                if (!finish(ent, keep, cend, cend - from, flag)) {
+                    const int sba = sbn / 2, sbb = sbn - sba;
+                    const int nl = sba == 0 ? 2 : lvl + 1;
+                    // (the second half first: the stack gives the first half back first)
+                    if (sba) { pf[np] = from + sba * 1024; ps[np] = sbb; pl[np] = nl; np++; pf[np] = from; ps[np] = sba; pl[np] = nl; np++; }
+                    else { pf[np] = from; ps[np] = sbn; pl[np] = 2; np++; }
+                }
             }
         }
         __syncthreads();
@@ -1613,7 +1711,7 @@ static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, co
 
 // kernel A with the table in LDS: the largest number of passes it is used for (ALZ_ENC_PREV_CU; 0 = never)
 static int prev_cu_passes() {
-    static const int v = getenv("ALZ_ENC_PREV_CU") ? atoi(getenv("ALZ_ENC_PREV_CU")) : 1;
+    static const int v = getenv("ALZ_ENC_PREV_CU") ? atoi(getenv("ALZ_ENC_PREV_CU")) : 16;
     return v;
 }
 
