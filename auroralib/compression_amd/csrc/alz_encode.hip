@@ -467,6 +467,9 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 __syncthreads();
                 // ---- my class: full steps of 64 (everything when the queue has to drain)
                 qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
+                qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
+#endif
                 while (qn >= 64u || (drain && (!narrow || r == 15u) && qn)) {
                     const u32 nstep = qn < 64u ? qn : 64u;
                     const bool actl = (u32)lane < nstep;
@@ -474,41 +477,39 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     const u32 e = Q[w][slot];
                     const int pos = cend1 - (int)(((u32)cend1 - e) & 0xFFFFu);
                     const u32 idx = actl ? e >> 17 : 0x8000u + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
-                    // Lanes of one step that share a table word find each other THROUGH the word: everybody writes, the losers write
-                    // again.  A lane alone reads its own position twice; the two lanes of a pair each read the other's position once
-                    // (the winner of the first round in the second, the loser in the first): no loop.  Only a lane that loses twice
-                    // proves a group of three or more; those groups are marked and ordered with ballots.
-                    const int old = Tv[idx];
-                    Tv[idx] = pos;
-                    const int r1 = Tv[idx];
-                    const bool lost1 = r1 != pos;
-                    if (lost1) Tv[idx] = pos;
-                    const int r2 = Tv[idx];
-                    const bool dbl = lost1 && r2 != pos;
-                    bool big = false;
-                    if (__ballot(dbl)) {
-                        if (dbl) Tv[idx] = -2;
-                        big = Tv[idx] == -2;
-                    }
-                    const int partner = lost1 ? r1 : r2;                     // (my own position when I am alone)
-                    int prev = partner < pos ? partner : old;
-                    bool writer = !lost1 && r2 < pos;                        // the word holds my partner, and I am behind it
-                    if (__ballot(big)) {
-                        u64 mygrp = 0;                                        // the lanes of my group (one loop trip per group: scalar work only)
-                        u64 todo = __ballot(big);
+                    // ONE exchange per lane: my position in, the word's previous content out.  Lanes of one step that share a word are
+                    // served one after the other; served in lane order (= position order) each of them gets exactly its prev() -- the
+                    // head from before the step for the first, the lane before for the others -- and the last one leaves the new head.
+                    // Any other order hands some lane a position BEHIND its own (a chain of increasing positions is the lane order),
+                    // so `got > pos` anywhere in the step proves it; only then are those groups ordered by hand: the old head is the
+                    // smallest value the group got back (it lies before every position of the step), the rest follows from the lanes.
+                    const int got = __hip_atomic_exchange(&T[idx], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    int prev = got;
+#if defined(ALZ_CU_SLOWTEST)
+                    const u64 bad = __ballot(actl && got >= __builtin_amdgcn_readfirstlane(pos));   // test build: every group goes the long way
+#else
+                    const u64 bad = __ballot(actl && got > pos);
+#endif
+                    if (bad) {
+                        u64 mygrp = 0; int ghead = 0;
+                        u64 todo = bad;
                         while (todo) {
                             const int l0 = (int)__builtin_ctzll(todo);
                             const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
                             const u64 grp = __ballot(idx == iv);
-                            if (idx == iv) mygrp = grp;
+                            int mn = 0x7FFFFFFF;
+                            for (u64 g2 = grp; g2; g2 &= g2 - 1ull) { const int r = __builtin_amdgcn_readlane(got, (int)__builtin_ctzll(g2)); mn = r < mn ? r : mn; }
+                            if (idx == iv) { mygrp = grp; ghead = mn; }
                             todo &= ~grp;
                         }
                         const u64 below = mygrp & lanes_below;
                         const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
                         const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);       // position of the next lower lane of my group
-                        if (big) { prev = below ? pp : old; writer = (mygrp >> lane) <= 1ull; }   // the highest lane of a group owns the new head
+                        if (mygrp) {
+                            prev = below ? pp : ghead;
+                            if ((mygrp >> lane) <= 1ull) Tv[idx] = pos;                      // the highest lane of a group leaves the new head
+                        }
                     }
-                    if (writer) Tv[idx] = pos;
                     if (actl && !(e & 0x10000u)) p4[pos] = prev;
                     qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                     qn -= nstep;
