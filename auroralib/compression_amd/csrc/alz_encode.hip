@@ -1716,6 +1716,16 @@ static int prev_cu_passes() {
     return v;
 }
 
+static bool uses_cu_prev(const EncGeom& g) {
+    return !g.use_min_table && prev_cu_passes() > 0 && g.hash_bits >= 15 && (1 << (g.hash_bits - 15)) <= prev_cu_passes();
+}
+// false: kernel A keeps its head table in LDS, the caller need not provide (or reset) tables in HBM
+bool alz_encode_needs_head_tables(const void* geom) {
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    if (getenv("ALZ_ENC_LDS_PREV") || alz_encode_uses_block_prev(geom)) return true;     // (experiments: keep the plain set-up)
+    return !uses_cu_prev(g);
+}
+
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
@@ -1738,7 +1748,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         if (g.use_min_table) hipLaunchKernelGGL((enc_prev_block_kernel<true>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
         else hipLaunchKernelGGL((enc_prev_block_kernel<false>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
     }
-    else if (!g.use_min_table && prev_cu_passes() > 0 && g.hash_bits >= 15 && (1 << (g.hash_bits - 15)) <= prev_cu_passes())
+    else if (uses_cu_prev(g))
         hipLaunchKernelGGL(enc_prev_cu_kernel, dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
     else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     else {

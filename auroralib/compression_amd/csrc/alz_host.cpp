@@ -665,7 +665,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
     std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
-    int hash_bits = 0; bool any_min = false;
+    int hash_bits = 0; bool any_min = false, any_tables = false;
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
@@ -674,6 +674,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
         hash_bits = alz_encode_geom_hash_bits(g);
         any_min = any_min || alz_encode_geom_min_table(g);
+        any_tables = any_tables || alz_encode_needs_head_tables(g);
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
@@ -684,6 +685,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     // head-table round trips, so a chunk should at least fill the device's 8 192 wave slots
     uint32_t CH = 4096;
     { const uint64_t per = (uint64_t)sizeof(int) << hash_bits; const uint64_t fit = (16ull << 30) / per; if (fit > CH) CH = fit > 0x100000ull ? 0x100000u : (uint32_t)fit; }
+    if (!any_tables) CH = 0x100000u;                         // (kernel A with its table in LDS: nothing to bound)
     if (const char* e = getenv("ALZ_ENC_CHUNK")) { const long v = atol(e); if (v >= 64) CH = (uint32_t)v; }   // tuning knob
     EncScratch sc(c);
     alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
@@ -694,7 +696,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (e == hipSuccess) e = sc.alloc((void**)&d_aux, (size_t)n * sizeof(alz_encode_aux));
     if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
-    if (e == hipSuccess) e = sc.alloc((void**)&d_head4, ((size_t)chn << hash_bits) * sizeof(int));
+    if (e == hipSuccess) e = sc.alloc((void**)&d_head4, ((size_t)chn << hash_bits) * sizeof(int), any_tables);
     if (e == hipSuccess) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int), any_min);
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
@@ -726,7 +728,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
         const void* g = geom.data() + f * alz_encode_geom_size();
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
-            HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
+            if (alz_encode_needs_head_tables(g)) HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
             if (alz_encode_geom_min_table(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
             e = alz_launch_encode(fmt, c->stream, c->d_src, c->d_dst, d_streams, d_index + first + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
                                   d_match, d_pos, d_side, d_mask, d_results, d_aux, g);

@@ -16,6 +16,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
 size_t alz_encode_geom_size(void);
 bool alz_encode_uses_block_prev(const void* geom);   // kernel A without head tables (windows up to 4 KiB)
 int alz_encode_geom_hash_bits(const void* geom);
+bool alz_encode_needs_head_tables(const void* geom);   // false: kernel A keeps its table in LDS (enc_prev_cu_kernel)
 int alz_encode_geom_min_table(const void* geom);
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
