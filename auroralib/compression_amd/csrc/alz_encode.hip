@@ -328,17 +328,23 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 // queue and step state are private to it, and the LDS executes one wavefront's operations in order.  Two workgroup barriers per
 // chunk.  A class that would overflow its queue (runs of equal bytes: one hash, one class) makes the chunk go through one
 // wavefront's 256 positions at a time.  prev() comes out exactly as from the table in HBM.
-#define ALZ_CU_QCAP 352u
+#ifdef ALZ_CU_DEBUG
+__device__ unsigned long long alz_cu_dbg[8];     // pieces tried / failed per level, position-by-position chunks, narrow chunks
+#define ALZ_CU_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&alz_cu_dbg[i], 1ull); } while (0)
+#else
+#define ALZ_CU_COUNT(i) do { } while (0)
+#endif
 #ifndef ALZ_CU_FILL4
-#define ALZ_CU_FILL4 3u       /* several passes: quarters of `stage` a slice fills on average */
+#define ALZ_CU_FILL4 2u       /* several passes: quarters of `stage` a slice fills on average */
 #endif
-#ifndef ALZ_CU_U
-#define ALZ_CU_U 2
-#endif
+// U: groups of 64 entries a wavefront brings to a chunk -- 2 for one pass (a chunk of 2 048 positions), 3 for several (`stage` holds 192
+// entries per wavefront, a slice fills half of that on average: the synthetic streams overfilled a 128-entry stage at 3/4 in a third of
+// their chunks)
+template <int U>
 __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                            const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    constexpr int U = ALZ_CU_U;
+    constexpr u32 ALZ_CU_QCAP = U == 2 ? 352u : 288u;          // (LDS: the table, the queues, the staging rows -- 160 KB)
     __shared__ int T[(1 << 15) + 64];
     __shared__ u32 Q[16][ALZ_CU_QCAP];
     __shared__ u32 stage[16][U * 64];             // several passes: a wavefront's entries of this pass, gathered from its slice
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     constexpr int CH = 1024 * U;
     // several passes: a wavefront looks at SB groups of 64 positions per chunk and keeps what belongs to the pass -- 3/4 of what
     // `stage` takes on average
-    static_assert(U <= 2, "a chunk of several passes must stay below 32 Ki positions");
+    static_assert(U * ALZ_CU_FILL4 <= 6, "a chunk of several passes must stay below 32 Ki positions");
     const int SB = npass == 1u ? U : (int)(npass * (u32)U * ALZ_CU_FILL4 / 4u);
     const int CHM = 1024 * SB;
     if (threadIdx.x < 3u) spill[threadIdx.x] = 0;
@@ -435,42 +441,11 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
             if (lane < 16) cnts[w][lane] = cntv;
             __syncthreads();
             if (par >= 0 && spill[par]) return false;
-            // ---- where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
-            u32 before = 0, tot = 0, tail_c = 0, wait_c = 0;
-            if (lane < 16) {
-#pragma unroll
-                for (u32 ww = 0; ww < 16; ww++) { const u32 x = cnts[ww][lane]; tot += x; if (ww < w) before += x; }
-                tail_c = qpub[lane]; wait_c = qpub[16 + lane];
-            }
-            const bool last = cend > limit;
-            const bool drain = last || since + clen >= 32768;     // (nothing waits longer than 32 Ki positions + a chunk: 16 bits tell where it was)
-            since = drain ? 0 : since + clen;
-            const int cend1 = cend - 1;
-            const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
-            const u32 rounds = narrow ? 16u : 1u;
-            for (u32 r = 0; r < rounds; r++) {
-                if (narrow) {
-                    if (r) { __syncthreads(); if (lane < 16) { tail_c = qpub[lane]; } }
-                    before = 0; tot = lane < 16 ? cnts[r][lane] : 0u;
-                }
-                if (!narrow || r == w) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)(tail_c + before + prior[u]));
-                        if (cls[u] < 16u) {
-                            u32 slot = b + rank[u];
-                            while (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
-                            Q[cls[u]][slot] = ent[u];
-                        }
-                    }
-                }
-                __syncthreads();
-                // ---- my class: full steps of 64 (everything when the queue has to drain)
-                qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
-                qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
-#endif
-                while (qn >= 64u || (drain && (!narrow || r == 15u) && qn)) {
+            // my class: full steps of 64 (everything when `all`), then tell the others where my queue stands.  (Tried: at most 2-3 steps per
+            // chunk, so that a burst in one class spreads over the chunks behind it, and a catch-up round before the 16-round fallback:
+            // no gain at 1, 4 or 16 passes -- what the owners wait for is not a burst.)
+            auto steps = [&](bool all, int cend1) {
+                while (qn >= 64u || (all && qn)) {
                     const u32 nstep = qn < 64u ? qn : 64u;
                     const bool actl = (u32)lane < nstep;
                     u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
@@ -510,11 +485,53 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                             if ((mygrp >> lane) <= 1ull) Tv[idx] = pos;                      // the highest lane of a group leaves the new head
                         }
                     }
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
+                    if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
+#else
                     if (actl && !(e & 0x10000u)) p4[pos] = prev;
+#endif
                     qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                     qn -= nstep;
                 }
                 if (lane == 0) { u32 t = qhead + qn; if (t >= ALZ_CU_QCAP) t -= ALZ_CU_QCAP; qpub[w] = t; qpub[16 + w] = qn; }
+            };
+            // ---- where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
+            u32 before = 0, tot = 0, tail_c = 0, wait_c = 0;
+            if (lane < 16) {
+#pragma unroll
+                for (u32 ww = 0; ww < 16; ww++) { const u32 x = cnts[ww][lane]; tot += x; if (ww < w) before += x; }
+                tail_c = qpub[lane]; wait_c = qpub[16 + lane];
+            }
+            const bool last = cend > limit;
+            const bool drain = last || since + clen >= 32768;     // (nothing waits longer than 32 Ki positions + a chunk: 16 bits tell where it was)
+            since = drain ? 0 : since + clen;
+            const int cend1 = cend - 1;
+            const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
+            const u32 rounds = narrow ? 16u : 1u;
+            if (narrow) ALZ_CU_COUNT(5);
+            for (u32 r = 0; r < rounds; r++) {
+                if (narrow) {
+                    if (r) { __syncthreads(); if (lane < 16) { tail_c = qpub[lane]; } }
+                    before = 0; tot = lane < 16 ? cnts[r][lane] : 0u;
+                }
+                if (!narrow || r == w) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)(tail_c + before + prior[u]));
+                        if (cls[u] < 16u) {
+                            u32 slot = b + rank[u];
+                            while (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
+                            Q[cls[u]][slot] = ent[u];
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- my class: full steps of 64 (everything when the queue has to drain)
+                qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
+                qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
+#endif
+                steps(drain && (!narrow || r == 15u), cend1);
             }
             return true;
         };
@@ -571,6 +588,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 u32 ent[U]; bool keep[U];
                 int cend, flag = -1;
                 if (lvl < 2) {
+                    ALZ_CU_COUNT(lvl);
                     par = par == 2u ? 0u : par + 1u;
                     if (threadIdx.x == 0) spill[par == 2u ? 0u : par + 1u] = 0;      // (the flag of the call after this one; last read two calls ago)
                     u32 fill = 0;
@@ -588,6 +606,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     for (int u = 0; u < U; u++) { keep[u] = !over && 64u * (u32)u + (u32)lane < fill; ent[u] = stage[w][64 * u + lane]; }
                     cend = from + sbn * 1024; flag = (int)par;
                 } else {
+                    ALZ_CU_COUNT(4);
                     const int to = from + sbn * 1024;
                     cend = from + CH < to ? from + CH : to;                  // (`to` need not be a multiple of 1 024 U away)
 #pragma unroll
@@ -597,7 +616,12 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                     if (cend < to) { pf[np] = cend; ps[np] = (to - cend) / 1024; pl[np] = 2; np++; }
                 }
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 4
+                if (ent[0] == 0x12345u && keep[0]) p4[0] = 1;             // timing experiment: the slices only
+                continue;
+#endif
                 if (!finish(ent, keep, cend, cend - from, flag)) {
+                    ALZ_CU_COUNT(2 + lvl);
                     const int sba = sbn / 2, sbb = sbn - sba;
                     const int nl = sba == 0 ? 2 : lvl + 1;
                     // (the second half first: the stack gives the first half back first)
@@ -1716,6 +1740,12 @@ static int prev_cu_passes() {
     return v;
 }
 
+#ifdef ALZ_CU_DEBUG
+extern "C" void alz_cu_debug_counters(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(alz_cu_dbg), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(alz_cu_dbg), z, sizeof(z)); }
+}
+#endif
 static bool uses_cu_prev(const EncGeom& g) {
     return !g.use_min_table && prev_cu_passes() > 0 && g.hash_bits >= 15 && (1 << (g.hash_bits - 15)) <= prev_cu_passes();
 }
@@ -1749,7 +1779,10 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         else hipLaunchKernelGGL((enc_prev_block_kernel<false>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
     }
     else if (uses_cu_prev(g))
-        hipLaunchKernelGGL(enc_prev_cu_kernel, dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
+    {
+        if (g.hash_bits == 15) hipLaunchKernelGGL((enc_prev_cu_kernel<2>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
+        else hipLaunchKernelGGL((enc_prev_cu_kernel<3>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
+    }
     else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     else {
         // Experiment knobs (round 2, tools/enc_split.sh; both bit-identical, neither pays): ALZ_ENC_SPLIT = wavefronts per stream of the
