@@ -417,28 +417,23 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         // `par` >= 0: give up (false) behind the first barrier if some wavefront could not hold its entries.
         auto finish = [&](const u32 (&ent)[U], const bool (&keep)[U], int cend, int clen, int par) -> bool {
             u32 cls[U], rank[U], prior[U];
-            u32 cntv = 0;                         // lane c < 16: entries of class c among mine so far
+            if (lane < 16) cnts[w][lane] = 0;     // my row: entries of class c among mine (the last lane of a class keeps it up to date)
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 cls[u] = keep[u] ? ent[u] >> 28 : 16u;
-                // the lanes of a class = AND over the four bit planes of the class number (plane or its complement); every lane
-                // forms the mask of its own class (its rank) and the mask of class (lane & 15) (the count), without a loop over classes
+                // the lanes of a class = AND over the four bit planes of the class number (plane or its complement): every lane
+                // forms the mask of its own class, without a loop over classes; its rank is the count of lower lanes in it
                 const u64 valid = __ballot(keep[u]);
                 u64 pl[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) pl[b] = __ballot((cls[u] >> b) & 1u);
-                u64 mine = valid, cm = valid;
+                u64 mine = valid;
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const u64 s1 = (u64)0 - (u64)((cls[u] >> b) & 1u), s2 = (u64)0 - (u64)(((u32)lane >> b) & 1u);
-                    mine &= ~(pl[b] ^ s1);
-                    cm &= ~(pl[b] ^ s2);
-                }
+                for (int b = 0; b < 4; b++) { const u64 s1 = (u64)0 - (u64)((cls[u] >> b) & 1u); mine &= ~(pl[b] ^ s1); }
                 rank[u] = __builtin_amdgcn_mbcnt_hi((u32)(mine >> 32), __builtin_amdgcn_mbcnt_lo((u32)mine, 0u));
-                prior[u] = cntv;
-                cntv += (u32)__popcll(cm);
+                prior[u] = u == 0 ? 0u : cnts[w][cls[u] & 15u];            // what my earlier groups brought to my class
+                if (keep[u] && (mine >> lane) <= 1ull) cnts[w][cls[u]] = prior[u] + rank[u] + 1u;
             }
-            if (lane < 16) cnts[w][lane] = cntv;
             __syncthreads();
             if (par >= 0 && spill[par]) return false;
             // my class: full steps of 64 (everything when `all`), then tell the others where my queue stands.  (Tried: at most 2-3 steps per
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 if (!narrow || r == w) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)(tail_c + before + prior[u]));
+                        const u32 b = (u32)__builtin_amdgcn_ds_bpermute((int)((cls[u] & 15u) << 2), (int)(tail_c + before)) + prior[u];
                         if (cls[u] < 16u) {
                             u32 slot = b + rank[u];
                             while (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
