@@ -393,11 +393,11 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 // whose hash also belongs to one of the four lanes below it (same row of 16) has its prev() right there; if one of the
                 // four lanes above has it too, nobody ever reads what it would write into the table: it stays out of the queue.
                 // Without such a lane above it only writes (flag bit 16), without one below it is an ordinary entry.
-                const u32 hk = keep ? h : ~(u32)lane;                        // (never equal to a real hash, nor to a neighbour's)
-                const u64 m1 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x111, 0xF, 0xF, false));
-                const u64 m2 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x112, 0xF, 0xF, false));
-                const u64 m3 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x113, 0xF, 0xF, false));
-                const u64 m4 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp((int)~hk, (int)hk, 0x114, 0xF, 0xF, false));
+                const u32 hk = keep ? h + 1u : 0x80000000u | (u32)lane;      // (never 0 = what a shift brings in from outside the row, never equal to a real hash or to a neighbour's)
+                const u64 m1 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp(0, (int)hk, 0x111, 0xF, 0xF, true));
+                const u64 m2 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp(0, (int)hk, 0x112, 0xF, 0xF, true));
+                const u64 m3 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp(0, (int)hk, 0x113, 0xF, 0xF, true));
+                const u64 m4 = __ballot(hk == (u32)__builtin_amdgcn_update_dpp(0, (int)hk, 0x114, 0xF, 0xF, true));
                 const u64 hasp = m1 | m2 | m3 | m4;
                 if (hasp) {
                     const u64 hass = (m1 >> 1) | (m2 >> 2) | (m3 >> 3) | (m4 >> 4);
