@@ -823,7 +823,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     // scalar instructions of exec-mask bookkeeping per candidate), not by its loads (L1 serves 90 % of them).  Reading eight bytes
     // at a candidate or at the position may run up to four bytes past the stream: inside the staging buffer's slack, never compared
     // (lengths are clamped to cmp_max).
-    const u64 head = load64(dp);
+    const u64 head = load64(dp), head2 = load64(dp + 8);
     bool act = cur != -1, capped = false;
     const int chain = g.max_chain;
     for (int it = 0; it < chain; it++) {
@@ -836,10 +836,27 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
         const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
-        if (__ballot(more)) { if (more) len = 8 + match_len(dp + 8, data + c + 8, cmp_max - 8); }
+        if (__ballot(more)) {
+            // the second eight bytes the same way (most formats' matches end inside them); the compare loop only behind sixteen
+            const u64 y = head2 ^ load64(data + (more ? c : 0) + 8);
+            if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
+            const bool more2 = more && y == 0ull && cmp_max > 16;
+            if (__ballot(more2)) { if (more2) len = 16 + match_len(dp + 16, data + c + 16, cmp_max - 16); }
+        }
         if (len > cmp_max) len = cmp_max;
         bool stop = !within;
-        if (ok) {
+        if (g.nprops <= 1) {
+            // (selects, not branches: nested ifs on per-lane conditions cost ~30 scalar instructions of exec-mask bookkeeping per
+            // candidate, and the CU's one scalar unit is what bounds this kernel)
+            const bool hitcap = ok && len == cmp_max && cmp_max < best_possible;
+            int l2 = len;
+            if (g.no_self_overlap && l2 > dist) l2 = dist;                   // ScoreMatch  :301-321, one property set
+            const int score = l2 - g.min_len;
+            const bool better = ok && !hitcap && score > best_score;
+            best_score = better ? score : best_score; best_l = better ? l2 : best_l; best_d = better ? dist : best_d;
+            capped = capped || hitcap;
+            stop = stop || hitcap || (better && l2 == best_possible);
+        } else if (ok) {
             if (len == cmp_max && cmp_max < best_possible) { capped = true; stop = true; }
             else {
                 const int score = score_match(g, len, dist);
