@@ -831,7 +831,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
         const int c = act ? cur : 0;
         const int dist = pos - c;
         const u64 x = head ^ load64(data + c);
-        const int nxt = p4[c];
+        const int nxt = it + 1 < chain ? p4[c] : -1;                    // (the last candidate's link is never followed: at maxChain 1 that is every one)
         const bool within = act && dist <= g.max_dist;                  // beyond maxDistance the walk ends  :259-260
         const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
