@@ -121,3 +121,29 @@ def test_decode_kernels_use_no_scratch(tmp_path):
     # callee-saved VGPR of the calling convention on its frame -- 8 bytes, outside every loop.  Anything beyond that is a local in
     # scratch memory.
     assert all(v == 0 or (v <= 8 and "alz_decode_queue_kernel" in k) for k, v in dec.items()), {k: v for k, v in dec.items() if v}
+
+
+def test_lds_table_kernel_fits_one_cu(tmp_path):
+    """Kernel A of the encoder (enc_prev_cu_kernel: head table, queues and staging rows in LDS, one workgroup of 1 024 threads per CU)
+    must fit the 160 KB of LDS and the 128 registers a wavefront of such a workgroup gets, without spilling."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(llvm + "/llvm-objdump") and os.path.exists(llvm + "/llvm-readelf")):
+        pytest.skip("no llvm binutils")
+    so = shutil.copy(os.path.join(ROOT, "auroralib", "compression_amd", "libauroralz.so"), tmp_path / "lib.so")
+    subprocess.run([llvm + "/llvm-objdump", "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    found = 0
+    for co in tmp_path.glob("lib.so.*gfx950"):
+        notes = subprocess.run([llvm + "/llvm-readelf", "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        for block in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            if not name or "enc_prev_cu_kernel" not in name.group(1):
+                continue
+            found += 1
+            lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", block).group(1))
+            priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
+            vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
+            assert 128 * 1024 < lds <= 160 * 1024 and priv == 0 and vgpr <= 128, (name.group(1), lds, priv, vgpr)
+    assert found == 2            # one pass (2 groups of 64 entries per wavefront and chunk), several passes (3)
