@@ -413,6 +413,66 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
             return keep;
         };
 
+        // my class: full steps of 64 (everything when `all`), then tell the others where my queue stands.  (Tried: at most 2-3 steps per
+        // chunk, so that a burst in one class spreads over the chunks behind it, and a catch-up round before the 16-round fallback:
+        // no gain at 1, 4 or 16 passes -- what the owners wait for is not a burst.)
+        auto steps = [&](bool all, int cend1) {
+            while (qn >= 64u || (all && qn)) {
+                const u32 nstep = qn < 64u ? qn : 64u;
+                const bool actl = (u32)lane < nstep;
+                u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
+                const u32 e = Q[w][slot];
+                const int pos = cend1 - (int)(((u32)cend1 - e) & 0xFFFFu);
+                const u32 idx = actl ? e >> 17 : 0x8000u + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
+                // ONE exchange per lane: my position in, the word's previous content out.  Lanes of one step that share a word are
+                // served one after the other; served in lane order (= position order) each of them gets exactly its prev() -- the
+                // head from before the step for the first, the lane before for the others -- and the last one leaves the new head.
+                // Any other order hands some lane a position BEHIND its own (a chain of increasing positions is the lane order),
+                // so `got > pos` anywhere in the step proves it; only then are those groups ordered by hand: the old head is the
+                // smallest value the group got back (it lies before every position of the step), the rest follows from the lanes.
+                const int got = __hip_atomic_exchange(&T[idx], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                int prev = got;
+#if defined(ALZ_CU_SLOWTEST)
+                const u64 bad = __ballot(actl && got >= __builtin_amdgcn_readfirstlane(pos));   // test build: every group goes the long way
+#else
+                const u64 bad = __ballot(actl && got > pos);
+#endif
+                if (bad) {
+                    u64 mygrp = 0; int ghead = 0;
+                    u64 todo = bad;
+                    while (todo) {
+                        const int l0 = (int)__builtin_ctzll(todo);
+                        const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
+                        const u64 grp = __ballot(idx == iv);
+                        int mn = 0x7FFFFFFF;
+                        for (u64 g2 = grp; g2; g2 &= g2 - 1ull) { const int r = __builtin_amdgcn_readlane(got, (int)__builtin_ctzll(g2)); mn = r < mn ? r : mn; }
+                        if (idx == iv) { mygrp = grp; ghead = mn; }
+                        todo &= ~grp;
+                    }
+                    const u64 below = mygrp & lanes_below;
+                    const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
+                    const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);       // position of the next lower lane of my group
+                    if (mygrp) {
+                        prev = below ? pp : ghead;
+                        if ((mygrp >> lane) <= 1ull) Tv[idx] = pos;                      // the highest lane of a group leaves the new head
+                    }
+                }
+#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
+                if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
+#else
+                if (actl && !(e & 0x10000u)) p4[pos] = prev;
+#endif
+                qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
+                qn -= nstep;
+            }
+            if (lane == 0) { u32 t = qhead + qn; if (t >= ALZ_CU_QCAP) t -= ALZ_CU_QCAP; qpub[w] = t; qpub[16 + w] = qn; }
+        };
+        // The steps of a chunk wait until the next chunk's entries are being found: half of the wavefronts (two of the four on every
+        // SIMD) take them first and hash afterwards, the other half hash and rank first -- the steps are chains of LDS round trips, the
+        // hashing and ranking is vector work, and both lie between the same two barriers.
+        bool pend = false, pend_all = false; int pend_cend1 = 0;
+        const bool late = ((w >> 2) & 1u) != 0u;
+        auto run_pending = [&]() { if (pend) { steps(pend_all, pend_cend1); pend = false; } };
         // The rest of a chunk, from the (at most U x 64) entries a wavefront found in it: ranks per class, the queues, the steps.
         // `par` >= 0: give up (false) behind the first barrier if some wavefront could not hold its entries.
         auto finish = [&](const u32 (&ent)[U], const bool (&keep)[U], int cend, int clen, int par) -> bool {
@@ -434,62 +494,9 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 prior[u] = u == 0 ? 0u : cnts[w][cls[u] & 15u];            // what my earlier groups brought to my class
                 if (keep[u] && (mine >> lane) <= 1ull) cnts[w][cls[u]] = prior[u] + rank[u] + 1u;
             }
+            run_pending();                        // (the late half; the early half has none left here)
             __syncthreads();
             if (par >= 0 && spill[par]) return false;
-            // my class: full steps of 64 (everything when `all`), then tell the others where my queue stands.  (Tried: at most 2-3 steps per
-            // chunk, so that a burst in one class spreads over the chunks behind it, and a catch-up round before the 16-round fallback:
-            // no gain at 1, 4 or 16 passes -- what the owners wait for is not a burst.)
-            auto steps = [&](bool all, int cend1) {
-                while (qn >= 64u || (all && qn)) {
-                    const u32 nstep = qn < 64u ? qn : 64u;
-                    const bool actl = (u32)lane < nstep;
-                    u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
-                    const u32 e = Q[w][slot];
-                    const int pos = cend1 - (int)(((u32)cend1 - e) & 0xFFFFu);
-                    const u32 idx = actl ? e >> 17 : 0x8000u + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
-                    // ONE exchange per lane: my position in, the word's previous content out.  Lanes of one step that share a word are
-                    // served one after the other; served in lane order (= position order) each of them gets exactly its prev() -- the
-                    // head from before the step for the first, the lane before for the others -- and the last one leaves the new head.
-                    // Any other order hands some lane a position BEHIND its own (a chain of increasing positions is the lane order),
-                    // so `got > pos` anywhere in the step proves it; only then are those groups ordered by hand: the old head is the
-                    // smallest value the group got back (it lies before every position of the step), the rest follows from the lanes.
-                    const int got = __hip_atomic_exchange(&T[idx], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    int prev = got;
-#if defined(ALZ_CU_SLOWTEST)
-                    const u64 bad = __ballot(actl && got >= __builtin_amdgcn_readfirstlane(pos));   // test build: every group goes the long way
-#else
-                    const u64 bad = __ballot(actl && got > pos);
-#endif
-                    if (bad) {
-                        u64 mygrp = 0; int ghead = 0;
-                        u64 todo = bad;
-                        while (todo) {
-                            const int l0 = (int)__builtin_ctzll(todo);
-                            const u32 iv = (u32)__builtin_amdgcn_readlane((int)idx, l0);
-                            const u64 grp = __ballot(idx == iv);
-                            int mn = 0x7FFFFFFF;
-                            for (u64 g2 = grp; g2; g2 &= g2 - 1ull) { const int r = __builtin_amdgcn_readlane(got, (int)__builtin_ctzll(g2)); mn = r < mn ? r : mn; }
-                            if (idx == iv) { mygrp = grp; ghead = mn; }
-                            todo &= ~grp;
-                        }
-                        const u64 below = mygrp & lanes_below;
-                        const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
-                        const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);       // position of the next lower lane of my group
-                        if (mygrp) {
-                            prev = below ? pp : ghead;
-                            if ((mygrp >> lane) <= 1ull) Tv[idx] = pos;                      // the highest lane of a group leaves the new head
-                        }
-                    }
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
-                    if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
-#else
-                    if (actl && !(e & 0x10000u)) p4[pos] = prev;
-#endif
-                    qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
-                    qn -= nstep;
-                }
-                if (lane == 0) { u32 t = qhead + qn; if (t >= ALZ_CU_QCAP) t -= ALZ_CU_QCAP; qpub[w] = t; qpub[16 + w] = qn; }
-            };
             // ---- where my entries go: lanes 0..15 hold, for class = lane, the entries of the wavefronts before mine and of all
             u32 before = 0, tot = 0, tail_c = 0, wait_c = 0;
             if (lane < 16) {
@@ -526,7 +533,9 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
 #if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
                 qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
 #endif
-                steps(drain && (!narrow || r == 15u), cend1);
+                if (narrow) steps(drain && r == 15u, cend1);
+                else if (npass != 1u) steps(drain, cend1);             // (several passes: waiting gains nothing, measured)
+                else { pend = true; pend_all = drain; pend_cend1 = cend1; }
             }
             return true;
         };
@@ -535,6 +544,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
 #pragma unroll
             for (int u = 0; u < U; u++) { const int pos = (int)((w * U + (u32)u) * 64u) + lane; vnext[u] = load32(data + (pos < limit ? pos : (limit > 0 ? limit : 0))); }
             for (int cbase = 0; cbase <= limit; cbase += CH) {
+                if (!late) run_pending();
                 u32 ent[U]; bool keep[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -580,6 +590,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 const int sbn = np == 0 ? ps[0] : np == 1 ? ps[1] : ps[2];
                 const int lvl = np == 0 ? pl[0] : np == 1 ? pl[1] : pl[2];
                 if (from > limit) continue;
+                if (!late) run_pending();
                 u32 ent[U]; bool keep[U];
                 int cend, flag = -1;
                 if (lvl < 2) {
@@ -625,6 +636,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 }
             }
         }
+        run_pending();
         __syncthreads();
     }
 }
