@@ -11,8 +11,8 @@ import csv,glob,sys,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for fn in glob.glob(sys.argv[1]+'/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(fn)):
-        k=r['Kernel_Name'].split('(')[0][-28:]
-        if 'enc_' in k: acc[k][r['Counter_Name']]+=float(r['Counter_Value'])
+        k=''
+        if 'enc_' in r['Kernel_Name']: acc[r['Kernel_Name'][r['Kernel_Name'].find('enc_'):][:24]][r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in acc.items(): print(k, {a:'%.3g'%b for a,b in v.items()})
 PY
   find $D -name "*.csv" -size +1M -delete
