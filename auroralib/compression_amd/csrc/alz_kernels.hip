@@ -694,7 +694,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
     DecState s; dec_state_init(s);
     typedef EmitCfg<LW - 1u, false, false, false> CFG;
     typedef QueueSink<OW, CFG> SK;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(ALZ_PRS_PRIO);
     u32 fl = 1u;
     for (u32 k = 0;; k++) {
         __syncthreads();
