@@ -1570,12 +1570,21 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
     u32 unc_base = 0;       // THREE: literal-section bytes before the window
     u32 cover = 0;          // end of the last match seen so far
     bool fail = false;
+    // (mask word, match and source byte of a window are loaded while the window before it is emitted: as a chain mask -> match
+    // inside the iteration, 39 wavefronts per CU left two memory round trips per window exposed)
+    u64 sm_n = n ? mask[0] : 0ull;
+    uint2 mt_n = (u32)lane < n ? m[lane] : make_uint2(0, 0);
+    u32 sb_n = (u32)lane < n ? src[lane] : 0u;
     for (u32 P = 0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
-        const u64 sm = mask[P >> 6];
+        const u64 sm = sm_n;
+        const uint2 mt_all = mt_n;
+        const u32 sb = sb_n;
+        if (P + 64 < n) sm_n = mask[(P >> 6) + 1];
+        if (p + 64 < n) { mt_n = m[p + 64]; sb_n = src[p + 64]; }
         const bool start = ((sm >> lane) & 1ull) && p < n;
         uint2 mt = make_uint2(0, 0);
-        if (start) mt = m[p];
+        if (start) mt = mt_all;
         const u32 mend = start ? p + mt.y : 0u;
         const u32 pmax = scan_max(mend);                               // inclusive
         u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
@@ -1586,7 +1595,7 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
         const u32 ti = tok_base + __builtin_amdgcn_mbcnt_hi((u32)(tm >> 32), __builtin_amdgcn_mbcnt_lo((u32)tm, 0u));
         // payload of my token
         u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, psize = 0, usize = 0;
-        if (lit) { b0 = src[p]; psize = 1; }
+        if (lit) { b0 = sb; psize = 1; }
         else if (start) {
             const u32 d1 = (mt.x - 1u) & 0xFFFu, len = mt.y;
             if (FMT == ALZ_FMT_LZSS) {
