@@ -174,7 +174,7 @@ int alz_create(int device, alz_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming); }
-    if (e != hipSuccess) { delete c; return fail(ALZ_E_HIP, "context creation failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { alz_destroy(c); return fail(ALZ_E_HIP, "context creation failed: %s", hipGetErrorString(e)); }   // (what was created so far goes with it)
     *out = c;
     return ALZ_OK;
 }
