@@ -779,6 +779,21 @@ __device__ __forceinline__ int score_match(const EncGeom& g, int& len, int dist)
     return -1;
 }
 
+// GetMatchLength behind the first sixteen bytes, for the wavefront: eight bytes per trip for every lane that is still equal, no byte
+// loop at the end (a trip reads up to seven bytes past the length that counts: inside the staging slack, clamped by the caller).
+// As a per-lane loop with a byte tail, every trip of kernel B's loop paid the dependent byte loads of its slowest lane.
+__device__ __forceinline__ int wave_match_tail(const u8* a, const u8* b, int max, bool go) {
+    int l = 16;
+    while (__ballot(go)) {
+        const u64 z = load64(a + (go ? l : 0)) ^ load64(b + (go ? l : 0));
+        if (go) {
+            if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; }
+            else { l += 8; if (l >= max) go = false; }
+        }
+    }
+    return l;
+}
+
 // MatchSearch :214-246 with ChainMatches :248-282 as a pure function of (data, prev); returns false when CAP > 0 and a
 // candidate still matched after CAP bytes
 template <bool MINT>
@@ -853,7 +868,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
             const u64 y = head2 ^ load64(data + (more ? c : 0) + 8);
             if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
             const bool more2 = more && y == 0ull && cmp_max > 16;
-            if (__ballot(more2)) { if (more2) len = 16 + match_len(dp + 16, data + c + 16, cmp_max - 16); }
+            if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
         }
         if (len > cmp_max) len = cmp_max;
         bool stop = !within;
