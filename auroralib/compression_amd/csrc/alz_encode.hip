@@ -48,6 +48,13 @@ __device__ __forceinline__ u64 load64(const u8* p) { u64 v; __builtin_memcpy(&v,
 
 __device__ __forceinline__ u32 scan_add(u32 v);
 
+#ifdef ALZ_CU_DEBUG
+__device__ unsigned long long alz_cu_dbg[8];     // pieces tried / failed per level, position-by-position chunks, narrow chunks; kernel B: lanes with a candidate, trips of its loop
+#define ALZ_CU_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&alz_cu_dbg[i], 1ull); } while (0)
+#else
+#define ALZ_CU_COUNT(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------- kernel A
 template <bool MINT>
 __global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
@@ -328,12 +335,6 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 // queue and step state are private to it, and the LDS executes one wavefront's operations in order.  Two workgroup barriers per
 // chunk.  A class that would overflow its queue (runs of equal bytes: one hash, one class) makes the chunk go through one
 // wavefront's 256 positions at a time.  prev() comes out exactly as from the table in HBM.
-#ifdef ALZ_CU_DEBUG
-__device__ unsigned long long alz_cu_dbg[8];     // pieces tried / failed per level, position-by-position chunks, narrow chunks
-#define ALZ_CU_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&alz_cu_dbg[i], 1ull); } while (0)
-#else
-#define ALZ_CU_COUNT(i) do { } while (0)
-#endif
 #ifndef ALZ_CU_FILL4
 #define ALZ_CU_FILL4 2u       /* several passes: quarters of `stage` a slice fills on average */
 #endif
@@ -855,6 +856,9 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     const int chain = g.max_chain;
     for (int it = 0; it < chain; it++) {
         if (!__ballot(act)) break;
+#ifdef ALZ_CU_DEBUG
+        { const unsigned long long na = (unsigned long long)__popcll(__ballot(act)); if ((threadIdx.x & 63u) == 0) { atomicAdd(&alz_cu_dbg[6], na); atomicAdd(&alz_cu_dbg[7], 1ull); } }
+#endif
         const int c = act ? cur : 0;
         const int dist = pos - c;
         const u64 x = head ^ load64(data + c);

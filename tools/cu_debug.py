@@ -21,4 +21,4 @@ out = (ctypes.c_ulonglong * 8)()
 lib.alz_cu_debug_counters(out, 1)
 ctx.encode_batch(streams, raw, int(r2["dst_off"][-1]) + cap + 64, quality=q)
 lib.alz_cu_debug_counters(out, 1)
-print("q%d: chunks %d failed %d | halves %d failed %d | position-by-position chunks %d | narrow %d" % (q, out[0], out[2], out[1], out[3], out[4], out[5]))
+print("q%d: chunks %d failed %d | halves %d failed %d | position-by-position chunks %d | narrow %d | kernel B: %.1f of 64 lanes with a candidate over %d trips" % (q, out[0], out[2], out[1], out[3], out[4], out[5], out[6] / max(1, out[7]), out[7]))
