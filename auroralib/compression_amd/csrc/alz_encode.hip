@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 template <int U>
 __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                            const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
-                                                           const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+                                                           int* __restrict__ prevm, const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
     constexpr u32 ALZ_CU_QCAP = U == 2 ? 352u : 288u;          // (LDS: the table, the queues, the staging rows -- 160 KB)
     __shared__ int T[(1 << 15) + 64];
     __shared__ u32 Q[16][ALZ_CU_QCAP];
@@ -361,22 +361,30 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
     const int limit = n - 4;
-    int* p4 = prev4 + pos_off[sid];
+    int* const p4a = prev4 + pos_off[sid];
+    int* const pma = g.use_min_table ? prevm + pos_off[sid] : nullptr;
     // (volatile, and in the LDS address space -- a generic volatile pointer turns into flat_load / flat_store sc0 sc1 with a full
     // s_waitcnt vmcnt(0) each: the steps below write a word and read it back to see the other lanes' writes)
     typedef __attribute__((address_space(3))) volatile int lds_vint;
     lds_vint* Tv = (lds_vint*)T;
     const u32 hb = (u32)g.hash_bits, hmask = (1u << hb) - 1u;
-    const u32 npass = 1u << (hb - 15u);
+    // passes: 2^(hashBits - 15) for the 4-byte hash, and for finders with the min-length table (quality >= 10: keyed by another hash,
+    // 16 bits, links into their own array) two more
+    const u32 npass4 = 1u << (hb - 15u), npassm = g.use_min_table ? 2u : 0u;
     const u64 lanes_below = (1ull << lane) - 1ull;
     constexpr int CH = 1024 * U;
     // several passes: a wavefront looks at SB groups of 64 positions per chunk and keeps what belongs to the pass -- 3/4 of what
     // `stage` takes on average
     static_assert(U * ALZ_CU_FILL4 <= 6, "a chunk of several passes must stay below 32 Ki positions");
-    const int SB = npass == 1u ? U : (int)(npass * (u32)U * ALZ_CU_FILL4 / 4u);
-    const int CHM = 1024 * SB;
     if (threadIdx.x < 3u) spill[threadIdx.x] = 0;
-    for (u32 pass = 0; pass < npass; pass++) {
+    for (u32 pass_all = 0; pass_all < npass4 + npassm; pass_all++) {
+        const bool mt = pass_all >= npass4;       // a pass of the min-length table
+        const u32 pass = mt ? pass_all - npass4 : pass_all;
+        const u32 npass = mt ? 2u : npass4;       // passes of this pass's table
+        int* const p4 = mt ? pma : p4a;           // where this pass's links go
+        int SB = npass == 1u ? U : (int)(npass * (u32)U * ALZ_CU_FILL4 / 4u);
+        if (SB > 24) SB = 24;                     // (a slice stays below 32 Ki positions: 32 passes fill their staging rows a quarter)
+        const int CHM = 1024 * SB;
         for (u32 i = threadIdx.x; i < (1u << 15); i += 1024u) T[i] = -1;
         u32 qhead = 0, qn = 0;                    // the queue of class w (this wavefront's)
         if (lane == 0) { qpub[w] = 0; qpub[16 + w] = 0; }
@@ -386,7 +394,8 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         // One group of 64 positions at `pos`: the entry of my position, or none.
         auto entry_of = [&](int pos, u32 v, bool direct, u32& e, int hi = 0x7FFFFFFF) -> bool {
             const bool act = pos <= limit && pos < hi;             // (`hi`: a multiple of 64 -- whole groups in or out)
-            const u32 h = ((v * 2654435761u) >> (32u - hb)) & hmask;             // ComputeHash  LzChainMatchFinder.cs:288-299
+            const u32 h = mt ? ((((v & g.min_mask) * 2654435761u) >> 16) & 0xFFFFu)                                  // :226-243
+                             : (((v * 2654435761u) >> (32u - hb)) & hmask);                                       // ComputeHash  :288-299
             bool keep = act && (h >> 15) == pass;
             u32 wonly = 0;
             if (direct) {
@@ -1788,7 +1797,7 @@ static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, co
 
 // kernel A with the table in LDS: the largest number of passes it is used for (ALZ_ENC_PREV_CU; 0 = never)
 static int prev_cu_passes() {
-    static const int v = getenv("ALZ_ENC_PREV_CU") ? atoi(getenv("ALZ_ENC_PREV_CU")) : 16;
+    static const int v = getenv("ALZ_ENC_PREV_CU") ? atoi(getenv("ALZ_ENC_PREV_CU")) : 34;
     return v;
 }
 
@@ -1799,7 +1808,7 @@ extern "C" void alz_cu_debug_counters(unsigned long long* out, int reset) {
 }
 #endif
 static bool uses_cu_prev(const EncGeom& g) {
-    return !g.use_min_table && prev_cu_passes() > 0 && g.hash_bits >= 15 && (1 << (g.hash_bits - 15)) <= prev_cu_passes();
+    return prev_cu_passes() > 0 && g.hash_bits >= 15 && g.hash_bits <= 20 && (1 << (g.hash_bits - 15)) + (g.use_min_table ? 2 : 0) <= prev_cu_passes();
 }
 // false: kernel A keeps its head table in LDS, the caller need not provide (or reset) tables in HBM
 bool alz_encode_needs_head_tables(const void* geom) {
@@ -1832,8 +1841,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     }
     else if (uses_cu_prev(g))
     {
-        if (g.hash_bits == 15) hipLaunchKernelGGL((enc_prev_cu_kernel<2>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
-        else hipLaunchKernelGGL((enc_prev_cu_kernel<3>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_pos_off, g, tail);
+        if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+        else hipLaunchKernelGGL((enc_prev_cu_kernel<3>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     }
     else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
     else {

@@ -697,7 +697,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_head4, ((size_t)chn << hash_bits) * sizeof(int), any_tables);
-    if (e == hipSuccess) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int), any_min);
+    if (e == hipSuccess) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int), any_min && any_tables);
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
@@ -729,7 +729,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
             if (alz_encode_needs_head_tables(g)) HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
-            if (alz_encode_geom_min_table(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
+            if (alz_encode_geom_min_table(g) && alz_encode_needs_head_tables(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
             e = alz_launch_encode(fmt, c->stream, c->d_src, c->d_dst, d_streams, d_index + first + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
                                   d_match, d_pos, d_side, d_mask, d_results, d_aux, g);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));

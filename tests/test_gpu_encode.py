@@ -178,15 +178,18 @@ def test_max_window_bits_is_fastlz_only(test_bmp):
         _encode_and_compare(A.FMT_LZ10, [test_bmp[:5000]], 8, max_window_bits=14)
 
 
-@pytest.mark.parametrize("quality", [0, 1, 3, 6, 8])
+@pytest.mark.parametrize("quality", [0, 1, 3, 6, 8, 10, 12, 15])
 def test_prev_links_through_the_lds_table(quality, test_bmp):
     """Kernel A with the head table in LDS (enc_prev_cu_kernel): 1, 2, 4, 8 and 16 passes (hashBits 15..19), streams whose positions pile
-    up in one hash class (runs, short and long periods: the queue overflow paths), stream ends on and around every chunk boundary."""
+    up in one hash class (runs, short and long periods: the queue overflow paths), stream ends on and around every chunk boundary.
+    Quality >= 10 adds the two passes of the min-length table (its own hash, its own links); 15 has 32 + 2 passes."""
     rng = np.random.default_rng(77 + quality)
     noise = bytes(rng.integers(0, 256, 70000, dtype=np.uint8))
     raws = [bytes(300000), b"\x01\x02\x03" * 50000, bytes(range(7)) * 9000, bytes(range(23)) * 5000, noise[:100] * 700,
             noise, noise[:24576 + 3], noise[:24575 + 3], noise[:2048 + 3], noise[:2047 + 3], noise[:2049 + 3], noise[:12288 + 4], noise[:3], noise[:4], noise[:5], noise[:67],
             bytes(40000) + noise[:30000] + bytes(range(5)) * 6000 + noise[:500] * 40, test_bmp[:200000],
             bytes(rng.integers(0, 3, 120000, dtype=np.uint8)), (noise[:300] + bytes(900)) * 100]
+    if quality >= 10:                                                   # (the CPU restatement walks chains of up to 1 024 candidates there)
+        raws = [r[:60000] for r in raws]
     _encode_and_compare(A.FMT_LZSS, raws, quality)
     _encode_and_compare(A.FMT_LZ4_BLOCK, raws[3:12], quality)          # (searches stop five bytes before the end: LZ4.cs:208)
