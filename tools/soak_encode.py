@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """usage (GPU box): python tools/soak_encode.py [first_seed] [count]
 Differential soak of the ENCODER: batches of raw buffers of many shapes (noise, runs, periods of 1..5000, few symbols, bitmap slices,
-mixtures; 1 B .. 3 MB) at qualities 0..9 in several formats, GPU output against the CPU restatement byte for byte.  Aimed at kernel A's
+mixtures; 1 B .. 3 MB) at qualities 0..15 in several formats, GPU output against the CPU restatement byte for byte.  Aimed at kernel A's
 queue / pass / drain logic (enc_prev_cu_kernel).  Not part of the test suite (minutes)."""
 import os
 import sys
@@ -56,9 +56,11 @@ def main():
         seed = s0 + 7919 * k
         rng = np.random.default_rng(seed)
         for fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_LZ11):
-            q = int(rng.integers(0, 10))
+            q = int(rng.integers(0, 16))
             sizes = [int(rng.choice([1, 3, 4, 5, 63, 64, 65, 2047, 2048, 2049, 3071, 3072, 3073, 24575, 24576, 24577, 32768, 65536, 65537])) for _ in range(6)]
             sizes += [int(rng.integers(1, 400000)) for _ in range(8)] + [int(rng.integers(400000, 3000000))]
+            if q >= 10:                                     # (chains of up to 1 024 candidates on the CPU side)
+                sizes = [min(s, 150000) for s in sizes]
             raws = [shapes(rng, bmp, s) for s in sizes]
             n = len(raws)
             streams = (A.Stream * n)()
