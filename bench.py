@@ -494,7 +494,7 @@ def cfg5(ctx, np, A, synth):
         out.append({"name": "cfg5_q%d" % q, "workload": "BASELINE configs[4]: LZSS(12,4,2) compression, parallel hash-chain match-find + emit, 10 000 x 256 KiB, quality %d, 1 GPU" % q,
                     "value": round(n * size / (kernel_ms * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(kernel_ms, 3),
                     "host_api_GiB_s": round(n * size / host_s / 2**30, 3), "ratio": round(comp / (n * size), 4), "parity_ok": ok,
-                    "roofline": roofline(n * size + comp, kernel_ms)})
+                    "roofline": roofline(n * size + comp, kernel_ms, measured_traffic("lzss_encode_q%d" % q, n, size // 1024))})
     return out
 
 
