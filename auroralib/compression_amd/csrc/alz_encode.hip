@@ -923,6 +923,137 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     return true;
 }
 
+// Kernel B for finders that look at several candidates per position (maxChain >= 4), in two phases per wavefront and block of 128
+// positions.  With one position per lane for the whole walk a wavefront goes on until its last lane is done: at Q8 14.7 of 64 lanes
+// have a candidate in an average trip (28.8 at Q4).  Here the chains are walked first -- links only: p4[.], the distance rules, the
+// attempt count -- and every candidate that ChainMatches would compare goes into an LDS list as (position, step, candidate); then the
+// list is worked off 64 pairs at a time, every lane comparing.  MatchSearch keeps the FIRST candidate of the best score (a later one
+// must be strictly better), and a candidate that reaches the longest possible match ends the walk -- nothing behind it could be
+// strictly better -- so the result is the maximum over all listed pairs of (score, earliest step): one 64-bit LDS atomic max per pair,
+// key = score + 1 | 4095 - step | length | distance.  A pair that runs into kernel B's length cap marks its position (ALZ_CAPPED, as
+// before: the parse recomputes it exactly if it ever visits it); that can only happen where no candidate can reach the longest
+// possible match, so the order of the two events in the sequential walk does not matter.
+#define ALZ_DENSE_POS 128
+#define ALZ_DENSE_LIST 512
+template <bool MINT>
+__global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                             const u32* __restrict__ index_list, const int* __restrict__ prev4,
+                                                             const int* __restrict__ prevm, uint2* __restrict__ match,
+                                                             const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    __shared__ u32 lpos[ALZ_DENSE_LIST];          // position inside the block | step << 8
+    __shared__ int lcand[ALZ_DENSE_LIST];
+    __shared__ unsigned long long best[ALZ_DENSE_POS];
+    __shared__ u32 capf[ALZ_DENSE_POS];
+    const u32 sid = index_list[blockIdx.y];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;
+    const long long base64 = (long long)blockIdx.x * ALZ_DENSE_POS;
+    if (base64 > (long long)limit) return;
+    const int base = (int)base64;
+    const int* p4 = prev4 + pos_off[sid];
+    const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
+    uint2* m = match + pos_off[sid];
+    const int lane = (int)threadIdx.x;
+    const int chain = g.max_chain;
+#pragma unroll
+    for (int r = 0; r < ALZ_DENSE_POS / 64; r++) { best[64 * r + lane] = 0ull; capf[64 * r + lane] = 0u; }
+    u32 ln = 0;                                   // pairs in the list (wave-uniform)
+
+    // the pairs of the list, 64 at a time
+    auto work_off = [&]() {
+        for (u32 i0 = 0; i0 < ln; i0 += 64u) {
+            const bool on = i0 + (u32)lane < ln;
+            const u32 lp = on ? lpos[i0 + lane] : 0u;
+            const int c = on ? lcand[i0 + lane] : 0;
+            const u32 pl = lp & 0xFFu, step = lp >> 8;
+            const int pos = base + (int)pl;
+            const u8* dp = data + pos;
+            const int dist = pos - c;
+            int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+            const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
+            const u64 x = load64(dp) ^ load64(data + c);
+            int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+            const bool more = on && x == 0ull && cmp_max > 8;
+            if (__ballot(more)) {
+                const u64 y = load64(dp + 8) ^ load64(data + (more ? c : 0) + 8);
+                if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
+                const bool more2 = more && y == 0ull && cmp_max > 16;
+                if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
+            }
+            if (len > cmp_max) len = cmp_max;
+            if (on) {
+                if (len == cmp_max && cmp_max < best_possible) capf[pl] = 1u;
+                else {
+                    const int score = score_match(g, len, dist);               // (may shorten len: CompatibilityMode, property sets)
+                    if (score >= 0) {
+                        const unsigned long long key = ((unsigned long long)(u32)(score + 1) << 52) | ((unsigned long long)(4095u - step) << 40) |
+                                                       ((unsigned long long)(u32)len << 28) | (unsigned long long)(u32)dist;
+                        (void)__hip_atomic_fetch_max(&best[pl], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+            }
+        }
+        ln = 0;
+    };
+
+    // ---- 1. the chains, links only
+#pragma unroll 1
+    for (int r = 0; r < ALZ_DENSE_POS / 64; r++) {
+        const int pos = base + 64 * r + lane;
+        int cur = pos <= limit ? p4[pos] : -1;
+        bool act = cur != -1;
+        for (int it = 0; it < chain; it++) {
+            if (!__ballot(act)) break;
+            const int c = act ? cur : 0;
+            const int dist = pos - c;
+            const int nxt = (act && it + 1 < chain) ? p4[c] : -1;               // (the last candidate's link is never followed)
+            const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
+            const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
+            const u64 om = __ballot(ok);
+            if (om) {
+                const u32 k = (u32)__popcll(om);
+                if (ln + k > ALZ_DENSE_LIST) work_off();
+                if (ok) {
+                    const u32 at = ln + __builtin_amdgcn_mbcnt_hi((u32)(om >> 32), __builtin_amdgcn_mbcnt_lo((u32)om, 0u));
+                    lpos[at] = (u32)(64 * r + lane) | ((u32)it << 8);
+                    lcand[at] = c;
+                }
+                ln += k;
+            }
+            cur = nxt;
+            act = within && cur != -1;
+        }
+    }
+    work_off();
+
+    // ---- 2. every position's match
+#pragma unroll 1
+    for (int r = 0; r < ALZ_DENSE_POS / 64; r++) {
+        const int pl = 64 * r + lane, pos = base + pl;
+        if (pos > limit) continue;
+        const unsigned long long key = best[pl];
+        bool capped = capf[pl] != 0u;
+        int best_l = (int)((key >> 28) & 0xFFFu), best_d = (int)(key & 0xFFFFFFFu);
+        if (MINT && !capped && best_l == 0) {                                  // small-match fallback :226-243
+            const int c2 = pm[pos];
+            if (c2 != -1) {
+                int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+                const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
+                int dist = pos - c2;
+                if (dist < g.min_dist) dist = g.min_dist;
+                if (dist <= g.max_dist && pos - dist >= 0) {
+                    int len = match_len(data + pos, data + pos - dist, cmp_max);
+                    if (len == cmp_max && cmp_max < best_possible) capped = true;
+                    else { (void)score_match(g, len, dist); best_l = len; best_d = dist; }
+                }
+            }
+        }
+        m[pos] = capped ? make_uint2(ALZ_CAPPED, ALZ_CAPPED) : make_uint2((u32)best_d, (u32)best_l);
+    }
+}
+
 template <bool MINT>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
@@ -1865,7 +1996,13 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         }
     }
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
-    if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+    static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 4;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
+    if (dense_chain > 0 && g.max_chain >= dense_chain && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {
+        u32 bd = (max_len + ALZ_DENSE_POS - 1u) / ALZ_DENSE_POS; if (bd == 0) bd = 1;
+        if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+        else hipLaunchKernelGGL((enc_match_dense_kernel<false>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+    }
+    else if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
     else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
     const uint2* m = (const uint2*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
