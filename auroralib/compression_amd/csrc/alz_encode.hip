@@ -923,7 +923,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     return true;
 }
 
-// Kernel B for finders that look at several candidates per position (maxChain >= 4), in two phases per wavefront and block of 128
+// Kernel B for finders that look at several candidates per position (maxChain >= 4), in two phases per wavefront and block of 64
 // positions.  With one position per lane for the whole walk a wavefront goes on until its last lane is done: at Q8 14.7 of 64 lanes
 // have a candidate in an average trip (28.8 at Q4).  Here the chains are walked first -- links only: p4[.], the distance rules, the
 // attempt count -- and every candidate that ChainMatches would compare goes into an LDS list as (position, step, candidate); then the
@@ -933,8 +933,12 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
 // key = score + 1 | 4095 - step | length | distance.  A pair that runs into kernel B's length cap marks its position (ALZ_CAPPED, as
 // before: the parse recomputes it exactly if it ever visits it); that can only happen where no candidate can reach the longest
 // possible match, so the order of the two events in the sequential walk does not matter.
-#define ALZ_DENSE_POS 128
-#define ALZ_DENSE_LIST 512
+#ifndef ALZ_DENSE_POS
+#define ALZ_DENSE_POS 64
+#endif
+#ifndef ALZ_DENSE_LIST
+#define ALZ_DENSE_LIST 256
+#endif
 template <bool MINT>
 __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev4,
@@ -963,6 +967,9 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 
     // the pairs of the list, 64 at a time
     auto work_off = [&]() {
+#if defined(ALZ_DENSE_EXP) && ALZ_DENSE_EXP == 1
+        ln = 0; return;                           // timing experiment: the chains only
+#endif
         for (u32 i0 = 0; i0 < ln; i0 += 64u) {
             const bool on = i0 + (u32)lane < ln;
             const u32 lp = on ? lpos[i0 + lane] : 0u;
