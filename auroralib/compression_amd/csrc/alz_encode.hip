@@ -933,13 +933,10 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
 // key = score + 1 | 4095 - step | length | distance.  A pair that runs into kernel B's length cap marks its position (ALZ_CAPPED, as
 // before: the parse recomputes it exactly if it ever visits it); that can only happen where no candidate can reach the longest
 // possible match, so the order of the two events in the sequential walk does not matter.
-#ifndef ALZ_DENSE_POS
-#define ALZ_DENSE_POS 64
-#endif
-#ifndef ALZ_DENSE_LIST
+// DYN (maxChain >= 8, blocks of 256 positions): in the first phase a lane whose walk has ended takes the next position of the block --
+// 59 -> 54 ms at Q8; at Q4 (five candidates at most) the fixed assignment in blocks of 64 is the faster one (36.8 against 38.0 ms).
 #define ALZ_DENSE_LIST 256
-#endif
-template <bool MINT>
+template <bool MINT, bool DYN, int ALZ_DENSE_POS>
 __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                              const int* __restrict__ prevm, uint2* __restrict__ match,
@@ -1006,6 +1003,38 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     };
 
     // ---- 1. the chains, links only
+    if constexpr (DYN) {   // a lane whose walk has ended takes the next position of the block (its first link is loaded now and looked at a trip later)
+        const int npos = limit - base + 1 < ALZ_DENSE_POS ? limit - base + 1 : ALZ_DENSE_POS;
+        int nextp = 0, pl = 0, pos = 0, cur = -1, it = 0;
+        bool act = false, fresh = false;
+        for (;;) {
+            if (fresh) { act = cur != -1; fresh = false; }
+            const u64 idle = __ballot(!act);
+            if (idle && nextp < npos) {
+                const int np = nextp + (int)__builtin_amdgcn_mbcnt_hi((u32)(idle >> 32), __builtin_amdgcn_mbcnt_lo((u32)idle, 0u));
+                nextp += (int)__popcll(idle);
+                if (!act && np < npos) { pl = np; pos = base + np; cur = p4[pos]; it = 0; fresh = true; }
+            }
+            if (!__ballot(act || fresh)) break;
+            const int c = act ? cur : 0;
+            const int dist = pos - c;
+            const int nxt = (act && it + 1 < chain) ? p4[c] : -1;               // (the last candidate's link is never followed)
+            const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
+            const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
+            const u64 om = __ballot(ok);
+            if (om) {
+                const u32 k = (u32)__popcll(om);
+                if (ln + k > ALZ_DENSE_LIST) work_off();
+                if (ok) {
+                    const u32 at = ln + __builtin_amdgcn_mbcnt_hi((u32)(om >> 32), __builtin_amdgcn_mbcnt_lo((u32)om, 0u));
+                    lpos[at] = (u32)pl | ((u32)it << 8);
+                    lcand[at] = c;
+                }
+                ln += k;
+            }
+            if (act) { it++; cur = nxt; act = within && cur != -1 && it < chain; }
+        }
+    } else {
 #pragma unroll 1
     for (int r = 0; r < ALZ_DENSE_POS / 64; r++) {
         const int pos = base + 64 * r + lane;
@@ -1032,6 +1061,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             cur = nxt;
             act = within && cur != -1;
         }
+    }
     }
     work_off();
 
@@ -2005,9 +2035,15 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 4;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
     if (dense_chain > 0 && g.max_chain >= dense_chain && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {
-        u32 bd = (max_len + ALZ_DENSE_POS - 1u) / ALZ_DENSE_POS; if (bd == 0) bd = 1;
-        if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
-        else hipLaunchKernelGGL((enc_match_dense_kernel<false>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+        const bool dyn = g.max_chain >= 8;
+        u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1;
+        if (dyn) {
+            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+            else hipLaunchKernelGGL((enc_match_dense_kernel<false, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+        } else {
+            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+            else hipLaunchKernelGGL((enc_match_dense_kernel<false, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+        }
     }
     else if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
     else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
