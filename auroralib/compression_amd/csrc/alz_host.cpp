@@ -686,6 +686,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     uint32_t CH = 4096;
     { const uint64_t per = (uint64_t)sizeof(int) << hash_bits; const uint64_t fit = (16ull << 30) / per; if (fit > CH) CH = fit > 0x100000ull ? 0x100000u : (uint32_t)fit; }
     if (!any_tables) CH = 0x100000u;                         // (kernel A with its table in LDS: nothing to bound)
+    if (CH > 65535u) CH = 65535u;                            // (a launch carries the stream in gridDim.y; 70 000 went through on this runtime, the cap is caution)
     if (const char* e = getenv("ALZ_ENC_CHUNK")) { const long v = atol(e); if (v >= 64) CH = (uint32_t)v; }   // tuning knob
     EncScratch sc(c);
     alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
