@@ -2033,6 +2033,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         }
     }
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
+    { static const int cap = getenv("ALZ_ENC_MATCH_BX") ? atoi(getenv("ALZ_ENC_MATCH_BX")) : 128; if (cap > 0 && bx > (u32)cap) bx = (u32)cap; }   // (blocks per stream: a thread of 128 blocks takes eight positions of a 256 KiB stream; one position per thread, ten million blocks per launch: 18.6 against 17.4 ms)
     static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 4;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
     if (dense_chain > 0 && g.max_chain >= dense_chain && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {
         const bool dyn = g.max_chain >= 8;
