@@ -923,7 +923,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     return true;
 }
 
-// Kernel B for finders that look at several candidates per position (maxChain >= 4), in two phases per wavefront and block of 64
+// Kernel B for finders that look at several candidates per position (maxChain >= 3), in two phases per wavefront and block of 64
 // positions.  With one position per lane for the whole walk a wavefront goes on until its last lane is done: at Q8 14.7 of 64 lanes
 // have a candidate in an average trip (28.8 at Q4).  Here the chains are walked first -- links only: p4[.], the distance rules, the
 // attempt count -- and every candidate that ChainMatches would compare goes into an LDS list as (position, step, candidate); then the
@@ -2034,7 +2034,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     }
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     { static const int cap = getenv("ALZ_ENC_MATCH_BX") ? atoi(getenv("ALZ_ENC_MATCH_BX")) : 128; if (cap > 0 && bx > (u32)cap) bx = (u32)cap; }   // (blocks per stream: a thread of 128 blocks takes eight positions of a 256 KiB stream; one position per thread, ten million blocks per launch: 18.6 against 17.4 ms)
-    static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 4;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
+    static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 3;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
     if (dense_chain > 0 && g.max_chain >= dense_chain && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1;
