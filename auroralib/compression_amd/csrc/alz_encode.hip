@@ -382,6 +382,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         const u32 pass = mt ? pass_all - npass4 : pass_all;
         const u32 npass = mt ? 2u : npass4;       // passes of this pass's table
         int* const p4 = mt ? pma : p4a;           // where this pass's links go
+        const u32 vmask = mt ? g.min_mask : 0xFFFFFFFFu, hshift = mt ? 16u : 32u - hb, hmask2 = mt ? 0xFFFFu : hmask;
         int SB = npass == 1u ? U : (int)(npass * (u32)U * ALZ_CU_FILL4 / 4u);
         if (SB > 24) SB = 24;                     // (a slice stays below 32 Ki positions: 32 passes fill their staging rows a quarter)
         const int CHM = 1024 * SB;
@@ -394,8 +395,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         // One group of 64 positions at `pos`: the entry of my position, or none.
         auto entry_of = [&](int pos, u32 v, bool direct, u32& e, int hi = 0x7FFFFFFF) -> bool {
             const bool act = pos <= limit && pos < hi;             // (`hi`: a multiple of 64 -- whole groups in or out)
-            const u32 h = mt ? ((((v & g.min_mask) * 2654435761u) >> 16) & 0xFFFFu)                                  // :226-243
-                             : (((v * 2654435761u) >> (32u - hb)) & hmask);                                       // ComputeHash  :288-299
+            const u32 h = (((v & vmask) * 2654435761u) >> hshift) & hmask2;      // ComputeHash :288-299 / the min-length table's :226-243 (one multiply either way)
             bool keep = act && (h >> 15) == pass;
             u32 wonly = 0;
             if (direct) {
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 // the lanes of a class = AND over the four bit planes of the class number (plane or its complement): every lane
                 // forms the mask of its own class, without a loop over classes; its rank is the count of lower lanes in it
                 const u64 valid = __ballot(keep[u]);
+                if (valid == 0ull) { rank[u] = 0; prior[u] = 0; continue; }     // (several passes: the third group of a slice is empty more often than not)
                 u64 pl[4];
 #pragma unroll
                 for (int b = 0; b < 4; b++) pl[b] = __ballot((cls[u] >> b) & 1u);
