@@ -1950,21 +1950,60 @@ size_t alz_encode_geom_size(void) { return sizeof(EncGeom); }
 int alz_encode_geom_hash_bits(const void* geom) { return ((const EncGeom*)geom)->hash_bits; }
 int alz_encode_geom_min_table(const void* geom) { return ((const EncGeom*)geom)->use_min_table; }
 
-// LZ4 blocks (LZ4.cs:202-238) from the start mask of the roles walk: every match start is one sequence -- token, literal-length
-// bytes, the literals since the match before it, offset, match-length bytes -- whose size follows from the two lengths, so a prefix
-// sum over the window places them all; the literals of the sequences (and the literal-only last one) are copied by the whole
-// wavefront.  The serial form (one lane per stream, a byte at a time) took 161 ms per 10 000 x 256 KiB.
+// LZ4 blocks (LZ4.cs:202-238) and raw Snappy (Snappy.cs:124-203) from the start mask of the roles walk: every match start is one
+// sequence -- LZ4: token, literal-length bytes, the literals since the match before it, offset, match-length bytes; Snappy: a literal
+// element (tag, 0-4 length bytes, the literals) if there are any, then a copy element of two or three bytes -- whose size follows from
+// the two lengths and the distance, so a prefix sum over the window places them all; the literals of the sequences (and the
+// literal-only end) are copied by the whole wavefront.  The serial form (one lane per stream, a byte at a time) took 161 ms (LZ4) per
+// 10 000 x 256 KiB.
 __device__ __forceinline__ u32 lz4_extn(u32 v) { return v >= 15u ? 1u + (v - 15u) / 255u : 0u; }    // bytes of LZ4.WriteExtension  LZ4.cs:254-268
 __device__ __forceinline__ void wave_copy(u8* d, const u8* s, u32 len, int lane) {
     u32 i = 0;
     for (; i + 256u <= len; i += 256u) { const u32 v = load32(s + i + 4u * (u32)lane); __builtin_memcpy(d + i + 4u * (u32)lane, &v, 4); }
     for (u32 j = i + (u32)lane; j < len; j += 64u) d[j] = s[j];
 }
-__global__ __launch_bounds__(64) void enc_emit_lz4_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+template <int FMT> struct SeqFmt;
+template <> struct SeqFmt<ALZ_FMT_LZ4_BLOCK> {
+    static __device__ __forceinline__ u32 lit_hdr(u32 L) { return 1u + lz4_extn(L); }                         // the token and the literal-length bytes
+    static __device__ __forceinline__ u32 match_size(u32, u32 M) { return 2u + lz4_extn(M - 4u); }
+    static __device__ __forceinline__ void put_lit_hdr(u8* q, u32 L, u32 M, bool last) {
+        *q++ = (u8)(((L > 15u ? 15u : L) << 4) | (last ? 0u : (M - 4u > 15u ? 15u : M - 4u)));
+        if (L >= 15u) { u32 v = L - 15u; while (v >= 255u) { *q++ = 255; v -= 255u; } *q++ = (u8)v; }
+    }
+    static __device__ __forceinline__ void put_match(u8* q, u32 D, u32 M) {
+        *q++ = (u8)(D & 0xFFu); *q++ = (u8)((D >> 8) & 0xFFu);
+        if (M - 4u >= 15u) { u32 v = M - 4u - 15u; while (v >= 255u) { *q++ = 255; v -= 255u; } *q++ = (u8)v; }
+    }
+};
+template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
+    static __device__ __forceinline__ u32 lit_hdr(u32 L) {                                                     // Snappy.cs:160-186
+        if (L == 0u) return 0u;
+        const u32 len = L - 1u;
+        return L <= 60u ? 1u : len <= 0xFFu ? 2u : len <= 0xFFFFu ? 3u : len <= 0xFFFFFFu ? 4u : 5u;
+    }
+    static __device__ __forceinline__ u32 match_size(u32 D, u32 M) { return (D < 2048u && M >= 4u && M <= 11u) ? 2u : 3u; }    // :188-201
+    static __device__ __forceinline__ void put_lit_hdr(u8* q, u32 L, u32, bool) {
+        if (L == 0u) return;
+        const u32 len = L - 1u;
+        if (L <= 60u) *q = (u8)(len << 2);
+        else if (len <= 0xFFu) { q[0] = 60u << 2; q[1] = (u8)len; }
+        else if (len <= 0xFFFFu) { q[0] = 61u << 2; q[1] = (u8)(len & 0xFFu); q[2] = (u8)(len >> 8); }
+        else if (len <= 0xFFFFFFu) { q[0] = 62u << 2; q[1] = (u8)(len & 0xFFu); q[2] = (u8)((len >> 8) & 0xFFu); q[3] = (u8)(len >> 16); }
+        else { q[0] = 63u << 2; q[1] = (u8)(len & 0xFFu); q[2] = (u8)((len >> 8) & 0xFFu); q[3] = (u8)((len >> 16) & 0xFFu); q[4] = (u8)(len >> 24); }
+    }
+    static __device__ __forceinline__ void put_match(u8* q, u32 D, u32 M) {
+        if (D < 2048u && M >= 4u && M <= 11u) { q[0] = (u8)(1u | ((M - 4u) << 2) | ((D >> 8) << 5)); q[1] = (u8)(D & 0xFFu); }
+        else { q[0] = (u8)((2u | ((M - 1u) << 2)) & 0xFFu); q[1] = (u8)(D & 0xFFu); q[2] = (u8)((D >> 8) & 0xFFu); }
+    }
+};
+template <int FMT>
+__global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
                                                           u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
                                                           const u64* __restrict__ startmask, alz_result* __restrict__ results,
                                                           alz_encode_aux* __restrict__ aux) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -1975,7 +2014,7 @@ __global__ __launch_bounds__(64) void enc_emit_lz4_kernel(const u8* __restrict__
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
     if (lane == 0 && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
-    if (n < 5u) {                                                             // source.Slice(0, Length - 5) throws
+    if (LZ4 && n < 5u) {                                                      // source.Slice(0, Length - 5) throws
         if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
         return;
     }
@@ -1984,7 +2023,12 @@ __global__ __launch_bounds__(64) void enc_emit_lz4_kernel(const u8* __restrict__
     u32 cover = 0;          // end of the last match = first literal not yet written
     u32 obase = 0;          // bytes written before the window
     bool fail = false;
-    u64 sm_n = mask[0];
+    if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
+        const u32 k = n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u;
+        if (k <= cap) { if (lane == 0) { u32 v = n, q = 0; while (v >= 0x80u) { dst[q++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[q] = (u8)v; } } else fail = true;
+        obase = k;
+    }
+    u64 sm_n = n ? mask[0] : 0ull;
     uint2 mt_n = (u32)lane < n ? m[lane] : make_uint2(0, 0);
     for (u32 P = 0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
@@ -2000,26 +2044,22 @@ __global__ __launch_bounds__(64) void enc_emit_lz4_kernel(const u8* __restrict__
         u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
         if (before < cover) before = cover;
         const u32 L = start ? p - before : 0u;
-        const u32 le = lz4_extn(L), me = lz4_extn(M - 4u);
-        const u32 esz = start ? 1u + le + L + 2u + me : 0u;
+        const u32 lh = start ? F::lit_hdr(L) : 0u;
+        const u32 esz = start ? lh + L + F::match_size(D, M) : 0u;
         const u32 incl = scan_add(esz);
         const u32 off = obase + incl - esz;
         const bool fits = start && off + esz <= cap;
         if (start && !fits) fail = true;
         if (fits) {
-            u32 q = off;
-            dst[q++] = (u8)(((L > 15u ? 15u : L) << 4) | (M - 4u > 15u ? 15u : M - 4u));
-            if (L >= 15u) { u32 v = L - 15u; while (v >= 255u) { dst[q++] = 255; v -= 255u; } dst[q++] = (u8)v; }
-            if (L <= 16u) for (u32 i = 0; i < L; i++) dst[q + i] = src[before + i];
-            q += L;
-            dst[q++] = (u8)(D & 0xFFu); dst[q++] = (u8)((D >> 8) & 0xFFu);
-            if (M - 4u >= 15u) { u32 v = M - 4u - 15u; while (v >= 255u) { dst[q++] = 255; v -= 255u; } dst[q++] = (u8)v; }
+            F::put_lit_hdr(dst + off, L, M, false);
+            if (L <= 16u) for (u32 i = 0; i < L; i++) dst[off + lh + i] = src[before + i];
+            F::put_match(dst + off + lh + L, D, M);
         }
         u64 longs = __ballot(fits && L > 16u);                                 // long literal runs: the whole wavefront copies
         while (longs) {
             const int l0 = (int)__builtin_ctzll(longs);
             const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)L, l0);
-            const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + 1u + le), l0);
+            const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), l0);
             wave_copy(dst + dq, src + so, len, lane);
             longs &= longs - 1ull;
         }
@@ -2027,18 +2067,14 @@ __global__ __launch_bounds__(64) void enc_emit_lz4_kernel(const u8* __restrict__
         const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
         if (wmax > cover) cover = wmax;
     }
-    // the last sequence: the remaining literals (at least five), no match
-    const u32 plain = n - cover, le = lz4_extn(plain);
-    const u32 total = obase + 1u + le + plain;
+    // the end: the remaining literals (LZ4: at least five, always a sequence; Snappy: an element only if there are any)
+    const u32 plain = n - cover, lh = (LZ4 || plain) ? F::lit_hdr(plain) : 0u;
+    const u32 total = obase + lh + plain;
     if (total > cap) fail = true;
     const bool anyfail = __ballot(fail) != 0ull;
-    if (!anyfail) {
-        if (lane == 0) {
-            u32 q = obase;
-            dst[q++] = (u8)((plain > 15u ? 15u : plain) << 4);
-            if (plain >= 15u) { u32 v = plain - 15u; while (v >= 255u) { dst[q++] = 255; v -= 255u; } dst[q++] = (u8)v; }
-        }
-        wave_copy(dst + obase + 1u + le, src + cover, plain, lane);
+    if (!anyfail && (LZ4 || plain)) {
+        if (lane == 0) F::put_lit_hdr(dst + obase, plain, 4u, true);
+        wave_copy(dst + obase + lh, src + cover, plain, lane);
     }
     if (lane == 0) {
         alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
@@ -2164,11 +2200,17 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
         if (par) {
             hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
-            hipLaunchKernelGGL(enc_emit_lz4_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+            hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         } else launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g);
         break; }
     case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_SNAPPY_RAW: launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_SNAPPY_RAW: {
+        static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
+        if (par) {
+            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+            hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        } else launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g);
+        break; }
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZSHREK: launch_emit<ALZ_FMT_LZSHREK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
