@@ -12,14 +12,18 @@
 //     chain[q & mask]                                == prev(q)   (slots are only reused beyond maxDistance, where the
 //                                                                  chain walk has already stopped :259-260)
 // so MatchSearch(p) is a PURE function of the data, and the parse (FindNextBestMatch :157-212) only consumes it.
-// Three kernels:
-//   A  enc_prev_kernel    one wavefront per stream: prev(p) for the 4-byte hash (and the min-length hash when
-//                         quality >= 10), 64 positions per step against a head table in HBM scratch; duplicates inside
-//                         a step are ordered with a small LDS contest + ballots.
-//   B  enc_match_kernel   one lane per position: the chain walk of MatchSearch/ChainMatches (:214-282) over prev(),
-//                         embarrassingly parallel; writes (distance, length) per position.
-//   C  enc_emit_kernel    one lane per stream: the greedy/lazy parse over the match array and the token emission of
-//                         the format (FlagWriter order), the only sequential part.
+// Three stages:
+//   A  enc_prev_cu_kernel       prev(p) for the 4-byte hash (and the min-length hash when quality >= 10): one workgroup of 16
+//                               wavefronts per stream, the head table in LDS, 2^(hashBits - 15) passes.  (enc_prev_kernel: the
+//                               same links through head tables in HBM scratch, one wavefront per stream -- the first form, kept
+//                               behind ALZ_ENC_PREV_CU=0; enc_prev_split / _lds / _block: measured experiments.)
+//   B  enc_match_kernel         one lane per position: the chain walk of MatchSearch/ChainMatches (:214-282) over prev(),
+//                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
+//                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
+//   C  enc_roles_kernel         the greedy/lazy parse as a walk over the match array (one wavefront per stream): a bit per token
+//                               start; then enc_emit_par_kernel (flag-bit formats) or enc_emit_seq_kernel (LZ4, Snappy) place
+//                               every token with prefix sums.  enc_emit_kernel: parse + emission on one lane per stream, for the
+//                               formats that have no parallel emit yet.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
