@@ -1125,23 +1125,30 @@ struct Out {                 // bounded byte sink of one stream
     __device__ __forceinline__ void copy(const u8* s, u32 n) { for (u32 i = 0; i < n; i++) put(s[i]); }
 };
 
-// FlagWriter  IO/FlagWriter.cs:13-147 (8-bit flags): the flag byte goes out before the payload of its tokens
+// FlagWriter  IO/FlagWriter.cs:13-147: the flag byte (or big-endian flag word) goes out before the payload of its tokens.  The managed
+// writer buffers the payload until the flag is complete; here the flag's place is reserved when its first bit arrives, the payload that
+// follows goes straight to the output and the flag is filled in when it is complete -- the same bytes in the same order, without a
+// payload array per lane in scratch memory (a memory round trip per byte for the one lane that works: PRS 323 ms of emit).  Only payload
+// that arrives while NO flag is open has to wait (at most the bytes of one token): whether a flag goes in front of it is decided by what
+// comes next -- a bit (yes), flush_if_necessary() or the end (no).
 struct FlagW {
-    Out* base; u8 payload[104]; int plen, bits_left, width; u32 cur; bool msb, neg;
+    Out* base; int bits_left, width; u32 cur, slot; bool msb, neg, open; unsigned long long pend; int npend;
     // nbytes 1: byte flags (optionally stored negated, LZ40); 2 / 4: big-endian flag words (SMSR00 / LZHudson)
-    __device__ void init(Out* b, bool m, bool negate = false, int nbytes = 1) { base = b; plen = 0; width = 8 * nbytes; bits_left = width; cur = 0; msb = m; neg = negate; }
-    __device__ void flush() {
-        if (bits_left != width) {
-            if (width == 8) base->put(neg ? (0u - cur) & 0xFFu : cur);      // LZ40: i => WriteByte((byte)-i)
-            else for (int i = width - 8; i >= 0; i -= 8) base->put((cur >> i) & 0xFFu);
-            bits_left = width; cur = 0;
-        }
-        for (int i = 0; i < plen; i++) base->put(payload[i]);
-        plen = 0;
+    __device__ void init(Out* b, bool m, bool negate = false, int nbytes = 1) { base = b; width = 8 * nbytes; bits_left = width; cur = 0; slot = 0; msb = m; neg = negate; open = false; pend = 0; npend = 0; }
+    __device__ void put_pending() { for (int i = 0; i < npend; i++) base->put((u32)(pend >> (8 * i)) & 0xFFu); npend = 0; pend = 0; }
+    __device__ void close_flag() {
+        if (width == 8) { if (slot < base->cap) base->p[slot] = (u8)(neg ? (0u - cur) & 0xFFu : cur); }     // LZ40: i => WriteByte((byte)-i)
+        else { u32 k = 0; for (int i = width - 8; i >= 0; i -= 8, k++) if (slot + k < base->cap) base->p[slot + k] = (u8)((cur >> i) & 0xFFu); }
+        bits_left = width; cur = 0; open = false;
     }
-    __device__ void bit(int b) { if (b) cur |= 1u << (msb ? bits_left - 1 : width - bits_left); if (--bits_left == 0) flush(); }
-    __device__ void pay(u32 v) { payload[plen++] = (u8)v; }
-    __device__ void flush_if_necessary() { if (bits_left == width && plen) { for (int i = 0; i < plen; i++) base->put(payload[i]); plen = 0; } }
+    __device__ void flush() { if (open) close_flag(); put_pending(); }
+    __device__ void bit(int b) {
+        if (!open) { slot = base->len; for (int i = 0; i < width; i += 8) base->put(0); open = true; put_pending(); }
+        if (b) cur |= 1u << (msb ? bits_left - 1 : width - bits_left);
+        if (--bits_left == 0) close_flag();
+    }
+    __device__ void pay(u32 v) { if (open) base->put(v); else { pend |= (unsigned long long)(v & 0xFFu) << (8 * npend); npend++; } }
+    __device__ void flush_if_necessary() { if (!open) put_pending(); }
 };
 
 struct Match { int offset, distance, length; };
@@ -1159,7 +1166,33 @@ struct Finder {
         }
         return r;
     }
+    // With the start mask of the roles walk (one bit per match the parse takes, set at its first byte) the parse is already done:
+    // the next match is the next set bit, and only ITS entry of the match array is read -- the walk below reads one entry per
+    // position (two where the lazy rule looks ahead), each a memory round trip for the one lane that works.
+    const u64* mask = nullptr; int widx = -1; u64 wbits = 0, wnext = 0;
+    __device__ Match next_masked() {
+        const int nwords = (limit >> 6) + 1;                      // (limit >= 0 here)
+        for (;;) {
+            if (wbits == 0ull) {
+                widx++;
+                if (widx >= nwords) break;
+                wbits = widx == 0 ? mask[0] : wnext;
+                if (widx + 1 < nwords) wnext = mask[widx + 1];       // (the word after this one is on its way while this one is used)
+                continue;
+            }
+            const int b = (int)__builtin_ctzll(wbits);
+            wbits &= wbits - 1ull;
+            const int p = widx * 64 + b;
+            const uint2 r = m[p];                                    // (exact: the roles walk has recomputed what kernel B had capped)
+            Match out = { p, (int)r.x, (int)r.y };
+            return out;
+        }
+        position = n;
+        Match e = { n, 0, 0 };
+        return e;
+    }
     __device__ Match next() {
+        if (mask) { if (limit < 0) { position = n; Match e = { n, 0, 0 }; return e; } return next_masked(); }
         while (position <= limit) {
             uint2 r = get(position);
             int bl = (int)r.y, bd = (int)r.x;
@@ -1195,7 +1228,7 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
                                                       u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
                                                       const int* __restrict__ prev4, const int* __restrict__ prevm,
                                                       u8* __restrict__ side, alz_result* __restrict__ results,
-                                                      alz_encode_aux* __restrict__ aux, EncGeom g, u32 lone) {
+                                                      alz_encode_aux* __restrict__ aux, EncGeom g, u32 lone, const u64* __restrict__ startmask) {
     // lone: ONE stream per wavefront, lane 0 works.  Sixty-four streams per wavefront executed the union of 64 divergent token
     // paths with their flag-writer state in scratch memory: PRS 1 900 ms per 10 000 x 256 KiB against the 280 ms of the four
     // kernels in front of it; a lone lane per wavefront is latency bound instead, and 10 000 wavefronts hide each other's latency.
@@ -1209,6 +1242,7 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
     Finder mf; mf.m = match + pos_off[sid]; mf.position = 0; mf.min_len = g.min_len; mf.lazy = g.lazy;
     mf.n = (FMT == ALZ_FMT_LZ4_BLOCK) ? n - 5 : n; mf.limit = mf.n - 4;
     mf.data = src; mf.p4 = prev4 + pos_off[sid]; mf.pm = g.use_min_table ? prevm + pos_off[sid] : nullptr; mf.g = &g;
+    mf.mask = startmask ? startmask + (pos_off[sid] >> 6) : nullptr;
     int status = ALZ_ST_OK; u32 a0 = 0, a1 = 0;
     int sp = 0;
 
@@ -2088,9 +2122,14 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
 
 template <int FMT>
 static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
-                        const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
+                        const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g,
+                        u64* mask = nullptr) {
     static const int lone = getenv("ALZ_ENC_EMIT_LONE") ? atoi(getenv("ALZ_ENC_EMIT_LONE")) : 1;
-    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(lone ? count : (count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g, (u32)lone);
+    static const int masked = getenv("ALZ_ENC_EMIT_MASK") ? atoi(getenv("ALZ_ENC_EMIT_MASK")) : 1;     // the parse from the roles walk's start mask
+    const int tail = FMT == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
+    if (mask && masked) hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, (uint2*)match, pos_off, prev4, prevm, mask, g, tail);
+    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(lone ? count : (count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g, (u32)lone,
+                       (const u64*)((mask && masked) ? mask : nullptr));
 }
 
 template <int FMT>
@@ -2196,34 +2235,34 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_CLZ0: launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_PRS_LE: launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_PRS_LE: launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_LZ4_BLOCK: {
         static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
         if (par) {
             hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
             hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g);
+        } else launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
         break; }
-    case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_SNAPPY_RAW: {
         static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
         if (par) {
             hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
             hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g);
+        } else launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
         break; }
-    case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZSHREK: launch_emit<ALZ_FMT_LZSHREK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_WFLZ: launch_emit<ALZ_FMT_WFLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_WFLZ_BE: launch_emit<ALZ_FMT_WFLZ_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_REFPACK: launch_emit<ALZ_FMT_REFPACK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ02: launch_emit<ALZ_FMT_LZ02>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_CNS: launch_emit<ALZ_FMT_CNS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
-    case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g); break;
+    case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_LZSHREK: launch_emit<ALZ_FMT_LZSHREK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_WFLZ: launch_emit<ALZ_FMT_WFLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_WFLZ_BE: launch_emit<ALZ_FMT_WFLZ_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_REFPACK: launch_emit<ALZ_FMT_REFPACK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_LZ02: launch_emit<ALZ_FMT_LZ02>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_CNS: launch_emit<ALZ_FMT_CNS>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
