@@ -1122,7 +1122,14 @@ struct Out {                 // bounded byte sink of one stream
     __device__ __forceinline__ void put(u32 b) { if (len < cap) p[len] = (u8)b; else fail = true; len++; }
     __device__ __forceinline__ void put16be(u32 v) { put(v >> 8); put(v & 0xFF); }
     __device__ __forceinline__ void put16le(u32 v) { put(v & 0xFF); put(v >> 8); }
-    __device__ __forceinline__ void copy(const u8* s, u32 n) { for (u32 i = 0; i < n; i++) put(s[i]); }
+    __device__ __forceinline__ void copy(const u8* s, u32 n) {       // a literal run: eight bytes at a time where it fits (sources carry 64 bytes of slack)
+        if (len <= cap && n <= cap - len) {
+            u32 i = 0;
+            for (; i + 8u <= n; i += 8u) { const u64 v = load64(s + i); __builtin_memcpy(p + len + i, &v, 8); }
+            for (; i < n; i++) p[len + i] = s[i];
+            len += n;
+        } else for (u32 i = 0; i < n; i++) put(s[i]);
+    }
 };
 
 // FlagWriter  IO/FlagWriter.cs:13-147: the flag byte (or big-endian flag word) goes out before the payload of its tokens.  The managed
