@@ -21,7 +21,7 @@
 //                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
 //   C  enc_roles_kernel         the greedy/lazy parse as a walk over the match array (one wavefront per stream): a bit per token
-//                               start; then enc_emit_par_kernel (flag-bit formats) or enc_emit_seq_kernel (LZ4, Snappy) place
+//                               start; then enc_emit_par_kernel (flag-bit formats), enc_emit_seq_kernel (LZ4, Snappy) or enc_emit_prs_kernel place
 //                               every token with prefix sums.  enc_emit_kernel: parse + emission on one lane per stream, for the
 //                               formats that have no parallel emit yet.
 #include <hip/hip_runtime.h>
@@ -2127,6 +2127,140 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
     }
 }
 
+// PRS (PRS.cs:104-159) from the start mask: tokens of one, two or four flag bits.  With B = the flag bits written before a token's
+// payload is handed to the flag writer (a literal's before its bit, a short match's behind its four bits, a long match's between its two)
+// the payload lands behind floor(B / 8) + 1 flag bytes -- the byte its bits belong to is in place before it -- except for the offset byte
+// of a short match whose four bits just completed a flag byte: the writer is told to let it out at once (flush_if_necessary), in front
+// of the next flag byte.  The flag byte k stands in front of the first payload with B >= 8 k (behind it, if that is such an offset byte).
+// So two prefix sums (bits, payload bytes) place everything; flag bytes collect their bits in LDS and are stored by the token that owns
+// their last bit, as in enc_emit_par_kernel.  A match of length 2 further than 0x100 back is not written as a match (its bytes go out as
+// literals; the parse has moved on behind it either way).
+template <bool BIG>
+__global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                          const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          const u64* __restrict__ startmask, alz_result* __restrict__ results,
+                                                          alz_encode_aux* __restrict__ aux) {
+    __shared__ u32 flagacc[64];
+    __shared__ u32 gofs[64];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 n = st.src_len;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    const uint2* m = match + pos_off[sid];
+    const u64* mask = startmask + (pos_off[sid] >> 6);
+    flagacc[lane] = 0; gofs[lane] = 0;
+    __syncthreads();
+    u32 bit_base = 0;       // flag bits before the window
+    u32 pay_base = 0;       // payload bytes before the window
+    u32 cover = 0;          // end of the last match written as a match
+    u32 lastk = 0xFFFFFFFFu;    // flag byte of the last payload before the window (none yet)
+    bool fail = false;
+    u64 sm_n = n ? mask[0] : 0ull;
+    uint2 mt_n = (u32)lane < n ? m[lane] : make_uint2(0, 0);
+    u32 sb_n = (u32)lane < n ? src[lane] : 0u;
+    // one more trip behind the data for the end token (bit 0, two zero bytes, bit 1) on lane 0
+    for (u32 P = 0; P < n + 64u; P += 64) {
+        const bool tail = P >= n;
+        if (tail && P > ((n + 63u) & ~63u)) break;                             // (exactly one trip behind the last window)
+        const u32 p = P + (u32)lane;
+        const u64 sm = tail ? 0ull : sm_n;
+        const uint2 mt_all = mt_n;
+        const u32 sb = sb_n;
+        if (!tail) { if (P + 64 < n) sm_n = mask[(P >> 6) + 1]; if (p + 64 < n) { mt_n = m[p + 64]; sb_n = src[p + 64]; } }
+        bool start = !tail && ((sm >> lane) & 1ull) && p < n;
+        uint2 mt = make_uint2(0, 0);
+        if (start) mt = mt_all;
+        if (start && mt.y == 2u && mt.x > 0x100u) start = false;               // PRS.cs: not worth a long match -- literals
+        const u32 mend = start ? p + mt.y : 0u;
+        const u32 pmax = scan_max(mend);                                       // inclusive
+        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
+        if (before < cover) before = cover;
+        const bool lit = !tail && !start && p < n && p >= before;
+        const bool endtok = tail && lane == 0;
+        const bool shortm = start && mt.x <= 0x100u && mt.y <= 5u;
+        const bool longm = (start && !shortm) || endtok;
+        const bool tok = lit || start || endtok;
+        const u32 nbits = lit ? 1u : shortm ? 4u : longm ? 2u : 0u;
+        const u32 psize = lit ? 1u : shortm ? 1u : endtok ? 2u : longm ? (mt.y > 9u ? 3u : 2u) : 0u;
+        const u32 bincl = scan_add(nbits), pincl = scan_add(psize);
+        const u32 B0 = bit_base + bincl - nbits;                               // my first bit
+        const u32 pidx = pay_base + pincl - psize;                             // my first payload byte among all payload bytes
+        const u32 Bp = B0 + (lit ? 0u : shortm ? 4u : 1u);                     // bits written when my payload is handed over
+        const bool special = shortm && (Bp & 7u) == 0u;
+        const u32 kp = Bp >> 3;                                                // the flag byte my payload waits for (special: the one it follows)
+        const u32 out = kp + 1u - (special ? 1u : 0u) + pidx;                  // where my payload goes
+        // the flag byte kp stands in front of the first payload with B >= 8 kp: that is me if the payload before mine had a smaller one
+        // (kp never falls and rises by at most one from token to token: two payloads are at most five bits apart)
+        const u32 kinc = scan_max(tok ? kp + 1u : 0u);                          // the latest kp + 1 up to and including my lane
+        const u32 kexc = (u32)__builtin_amdgcn_update_dpp(0, (int)kinc, 0x138, 0xF, 0xF, false);
+        const u32 prevk = kexc ? kexc - 1u : lastk;
+        const bool opener = tok && (prevk == 0xFFFFFFFFu || prevk < kp);
+        if (opener) { gofs[kp & 63u] = kp + pidx + (special ? 1u : 0u); }
+        __syncthreads();
+        // my bits into their flag bytes (a token may straddle two)
+        if (tok) {
+            // bit values in order: literal 1; short 0,0,b1,b0; long 0 .. 1
+            const u32 l2 = mt.y - 2u;
+            const u32 pattern = lit ? 1u : shortm ? ((((l2 >> 1) & 1u) << 2) | ((l2 & 1u) << 3)) : 2u;   // bit i of `pattern` = my i-th flag bit
+#pragma unroll
+            for (u32 i = 0; i < 4u; i++) {
+                if (i < nbits && ((pattern >> i) & 1u)) {
+                    const u32 b = B0 + i;
+                    atomicOr(&flagacc[(b >> 3) & 63u], 1u << (BIG ? 7u - (b & 7u) : (b & 7u)));
+                }
+            }
+        }
+        __syncthreads();
+        if (tok) {
+            // the flag bytes whose last bit is mine are complete: store them
+#pragma unroll
+            for (u32 i = 0; i < 4u; i++) {
+                const u32 b = B0 + i;
+                if (i < nbits && (b & 7u) == 7u) {
+                    const u32 k = b >> 3, fo = gofs[k & 63u];
+                    if (fo < cap) dst[fo] = (u8)flagacc[k & 63u]; else fail = true;
+                    flagacc[k & 63u] = 0;
+                }
+            }
+            // payload
+            if (out + psize <= cap) {
+                if (lit) dst[out] = (u8)sb;
+                else if (shortm) dst[out] = (u8)((0u - mt.x) & 0xFFu);
+                else if (endtok) { dst[out] = 0; dst[out + 1] = 0; }
+                else {
+                    u32 v = ((0u - mt.x) << 3) & 0xFFFFu;
+                    if (mt.y <= 9u) v |= mt.y - 2u;
+                    if (BIG) { dst[out] = (u8)(v >> 8); dst[out + 1] = (u8)(v & 0xFFu); } else { dst[out] = (u8)(v & 0xFFu); dst[out + 1] = (u8)(v >> 8); }
+                    if (mt.y > 9u) dst[out + 2] = (u8)(mt.y - 1u);
+                }
+            } else fail = true;
+        }
+        __syncthreads();
+        bit_base += (u32)__builtin_amdgcn_readlane((int)bincl, 63);
+        pay_base += (u32)__builtin_amdgcn_readlane((int)pincl, 63);
+        {   const u32 last = (u32)__builtin_amdgcn_readlane((int)kinc, 63); if (last) lastk = last - 1u; }
+        const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
+        if (wmax > cover) cover = wmax;
+    }
+    // Dispose(): a partial flag byte goes out with its unused bits zero
+    const u32 nflags = (bit_base + 7u) >> 3;
+    if ((bit_base & 7u) != 0u && lane == 0) { const u32 k = bit_base >> 3, fo = gofs[k & 63u]; if (fo < cap) dst[fo] = (u8)flagacc[k & 63u]; else fail = true; }
+    const u32 total = nflags + pay_base;
+    if (total > cap) fail = true;
+    const bool anyfail = __ballot(fail) != 0ull;
+    if (lane == 0) {
+        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
+        results[sid] = r;
+        if (aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+    }
+}
+
 template <int FMT>
 static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
                         const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g,
@@ -2244,8 +2378,20 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
-    case ALZ_FMT_PRS_BE: launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
-    case ALZ_FMT_PRS_LE: launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_PRS_BE: {
+        static const int par = getenv("ALZ_ENC_PRS_PAR") ? atoi(getenv("ALZ_ENC_PRS_PAR")) : 1;
+        if (par) {
+            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+            hipLaunchKernelGGL((enc_emit_prs_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        } else launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        break; }
+    case ALZ_FMT_PRS_LE: {
+        static const int par = getenv("ALZ_ENC_PRS_PAR") ? atoi(getenv("ALZ_ENC_PRS_PAR")) : 1;
+        if (par) {
+            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+            hipLaunchKernelGGL((enc_emit_prs_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        } else launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        break; }
     case ALZ_FMT_LZ4_BLOCK: {
         static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
         if (par) {

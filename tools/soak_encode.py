@@ -55,7 +55,7 @@ def main():
     for k in range(cnt):
         seed = s0 + 7919 * k
         rng = np.random.default_rng(seed)
-        for fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_LZ11, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_LZO, A.FMT_LZHUDSON, A.FMT_REFPACK):
+        for fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_LZ11, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO, A.FMT_LZHUDSON, A.FMT_REFPACK):
             q = int(rng.integers(0, 16))
             sizes = [int(rng.choice([1, 3, 4, 5, 63, 64, 65, 2047, 2048, 2049, 3071, 3072, 3073, 24575, 24576, 24577, 32768, 65536, 65537])) for _ in range(6)]
             sizes += [int(rng.integers(1, 400000)) for _ in range(8)] + [int(rng.integers(400000, 3000000))]
