@@ -1788,8 +1788,9 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
                                                           const u64* __restrict__ startmask, u8* __restrict__ side,
                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
-    constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || THREE);   // flag bit of a literal token
+    constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZHUDSON || THREE);   // flag bit of a literal token
     constexpr bool MSB = (FMT != ALZ_FMT_LZSS && FMT != ALZ_FMT_CLZ0);
+    constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;    // LZHudson: Yay0's tokens behind 32-bit big-endian flag words  LZHudson.cs:55-59
     __shared__ u32 flagacc[16];
     __shared__ u32 gofs[16];
     const u32 bid = blockIdx.x;
@@ -1872,20 +1873,24 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
         const u32 poff = pay_base + pincl - psize;
         const u32 uincl = THREE ? scan_add(usize) : 0u;
         const u32 uoff = unc_base + uincl - usize;
-        const u32 group = ti >> 3, bitpos = ti & 7u;
+        const u32 group = ti / FBITS, bitpos = ti % FBITS;
         // flag bytes: the first token of a group fixes the flag byte's position, the last one stores it
-        const u32 flag_off = THREE ? group : poff + group;             // interleaved: flag g sits right before the payload of token 8g
+        const u32 flag_off = THREE ? group : poff + FB * group;        // interleaved: flag g sits right before the payload of its first token
         if (tok && bitpos == 0) { gofs[group & 15u] = flag_off; flagacc[group & 15u] = 0; }
         __syncthreads();
         if (tok) {
             const u32 bitv = (lit ? LIT_BIT : !LIT_BIT) ? 1u : 0u;
-            if (bitv) atomicOr(&flagacc[group & 15u], 1u << (MSB ? 7u - bitpos : bitpos));
+            if (bitv) atomicOr(&flagacc[group & 15u], 1u << (MSB ? FBITS - 1u - bitpos : bitpos));
         }
         __syncthreads();
         if (tok) {
-            if (bitpos == 7) { const u32 fo = gofs[group & 15u]; if (fo < cap) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - flagacc[group & 15u] : flagacc[group & 15u]); else fail = true; }
+            if (bitpos == FBITS - 1u) {
+                const u32 fo = gofs[group & 15u], acc = flagacc[group & 15u];
+                if (fo + FB <= cap) { if (FB == 1u) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc); else { dst[fo] = (u8)(acc >> 24); dst[fo + 1] = (u8)(acc >> 16); dst[fo + 2] = (u8)(acc >> 8); dst[fo + 3] = (u8)acc; } }
+                else fail = true;
+            }
             if (!THREE) {
-                const u32 o = poff + group + 1u;
+                const u32 o = poff + FB * (group + 1u);
                 if (o + psize <= cap) { dst[o] = (u8)b0; if (psize > 1) dst[o + 1] = (u8)b1; if (psize > 2) dst[o + 2] = (u8)b2; if (psize > 3) dst[o + 3] = (u8)b3; }
                 else fail = true;
             } else {
@@ -1901,8 +1906,12 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
         if (wmax > cover) cover = wmax;
     }
     // Dispose(): a partial flag byte is written with its unused bits zero (FlagWriter.cs:141-145)
-    const u32 nflags = (tok_base + 7u) >> 3;
-    if ((tok_base & 7u) != 0 && lane == 0) { const u32 gi = (tok_base >> 3); const u32 fo = gofs[gi & 15u]; if (fo < cap) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - flagacc[gi & 15u] : flagacc[gi & 15u]); else fail = true; }
+    const u32 nflags = FB * ((tok_base + FBITS - 1u) / FBITS);          // (bytes)
+    if ((tok_base % FBITS) != 0 && lane == 0) {
+        const u32 gi = tok_base / FBITS; const u32 fo = gofs[gi & 15u], acc = flagacc[gi & 15u];
+        if (fo + FB <= cap) { if (FB == 1u) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc); else { dst[fo] = (u8)(acc >> 24); dst[fo + 1] = (u8)(acc >> 16); dst[fo + 2] = (u8)(acc >> 8); dst[fo + 3] = (u8)acc; } }
+        else fail = true;
+    }
     u32 total;
     if (!THREE) total = pay_base + nflags;
     else {
@@ -2376,7 +2385,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_CLZ0: launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZHUDSON: launch_emit<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
         static const int par = getenv("ALZ_ENC_PRS_PAR") ? atoi(getenv("ALZ_ENC_PRS_PAR")) : 1;
