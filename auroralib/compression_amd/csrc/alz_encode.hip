@@ -2270,6 +2270,190 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     }
 }
 
+// LZO1X (LZO.cs:141-250) from the start mask.  The writer is sequential only at the head of a stream: a match that 1-3 literals precede
+// is cut at its front so that four go out, and a match cut below three bytes is not written -- which can leave 1-3 literals in front of
+// the next one.  Once a match HAS been written the state is clean for good: what follows it is 0-3 literals, which ride in its token
+// and go out right behind it, or four and more, a literal run of its own.  So lane 0 walks the head the reference's way until the first
+// match is out, and from there every match start is one unit -- (a literal run of >= 4, if one precedes it), its token in one of three
+// forms, the 0-3 literals behind it -- whose size follows from its own numbers and the position of the next start: a prefix sum
+// places the units, the wavefront copies the long runs.
+__device__ __forceinline__ u32 lzo_extn(u32 v) { return 1u + (v - 1u) / 255u; }                       // bytes of LZO.WriteExtendedInt(v), v >= 1
+__device__ __forceinline__ u32 lzo_put_ext(u8* q, u32 v) { u32 k = 0; while (v > 255u) { q[k++] = 0; v -= 255u; } q[k++] = (u8)v; return k; }
+__device__ __forceinline__ u32 lzo_lit_size(u32 L) { return L > 18u ? 1u + lzo_extn(L - 18u) : 1u; }  // the run's length token (L >= 4)
+__device__ __forceinline__ u32 lzo_put_lit(u8* q, u32 L) { if (L > 18u) { q[0] = 0; return 1u + lzo_put_ext(q + 1, L - 18u); } q[0] = (u8)(L - 3u); return 1u; }
+__device__ __forceinline__ u32 lzo_match_size(u32 D, u32 M) {
+    if (M <= 8u && D <= 2048u) return 2u;
+    if (D <= 16384u) return (M > 33u ? 1u + lzo_extn(M - 33u) : 1u) + 2u;
+    return (M > 9u ? 1u + lzo_extn(M - 9u) : 1u) + 2u;
+}
+__device__ __forceinline__ u32 lzo_put_match(u8* q, u32 D, u32 M, u32 emb) {                          // emb: the 0-3 literals that follow, in the token's low bits
+    if (M <= 8u && D <= 2048u) {
+        const u32 flag = (emb | (((D - 1u) & 7u) << 2)) & 0xFFu;
+        q[0] = (u8)(M <= 4u ? (flag | 0x40u | ((M - 3u) << 5)) : (flag | 0x80u | ((M - 5u) << 5)));
+        q[1] = (u8)((D - 1u) >> 3);
+        return 2u;
+    }
+    u32 k;
+    if (D <= 16384u) {
+        if (M > 33u) { q[0] = 0x20; k = 1u + lzo_put_ext(q + 1, M - 33u); } else { q[0] = (u8)(0x20u | (M - 2u)); k = 1u; }
+        q[k] = (u8)((emb | ((D - 1u) << 2)) & 0xFFu); q[k + 1] = (u8)(((D - 1u) >> 6) & 0xFFu);
+        return k + 2u;
+    }
+    const u32 d2 = D - 0x4000u, flag = (0x10u | ((d2 & 0x4000u) >> 11)) & 0xFFu;
+    if (M > 9u) { q[0] = (u8)flag; k = 1u + lzo_put_ext(q + 1, M - 9u); } else { q[0] = (u8)(flag | (M - 2u)); k = 1u; }
+    q[k] = (u8)((emb | (d2 << 2)) & 0xFFu); q[k + 1] = (u8)((d2 >> 6) & 0xFFu);
+    return k + 2u;
+}
+__global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                          const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          const u64* __restrict__ startmask, alz_result* __restrict__ results,
+                                                          alz_encode_aux* __restrict__ aux) {
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 n = st.src_len;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    const uint2* m = match + pos_off[sid];
+    const u64* mask = startmask + (pos_off[sid] >> 6);
+    const u32 nwords = n >= 4u ? ((n - 4u) >> 6) + 1u : 0u;                   // mask words that can hold a start
+    auto finish = [&](u32 total, bool fail, int status) {
+        if (lane == 0) {
+            alz_result r; r.dst_len = (fail || status != ALZ_ST_OK) ? 0u : total; r.src_used = n;
+            r.status = status != ALZ_ST_OK ? status : (fail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK); r.reserved = 0;
+            results[sid] = r;
+            if (aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+        }
+    };
+    // the next start at or behind `from` (n: none)
+    auto next_start = [&](u32 from) -> u32 {
+        for (u32 wi = from >> 6; wi < nwords; wi++) {
+            u64 w = mask[wi];
+            if (wi == (from >> 6)) w &= ~0ull << (from & 63u);
+            if (w) return wi * 64u + (u32)__builtin_ctzll(w);
+        }
+        return n;
+    };
+    // ---- the head, the reference's way, on lane 0 (everything here is wave-uniform: the other lanes follow along and do not store)
+    u32 sp = 0, olen = 0; bool fail = false; int status = ALZ_ST_OK;
+    auto put = [&](u32 b) { if (olen < cap) { if (lane == 0) dst[olen] = (u8)b; } else fail = true; olen++; };
+    auto copy = [&](u32 from, u32 len) { for (u32 i = 0; i < len; i++) put(src[from + i]); };
+    if (n < 0x10u) {
+        put(17u + n); copy(0, n); put(0x11); put(0); put(0);
+        finish(olen, fail, status);
+        return;
+    }
+    u32 mo = next_start(0), ml = 0, md = 0;                                   // mt: offset, length, distance
+    if (mo < n) { const uint2 r = m[mo]; md = r.x; ml = r.y; }
+    u32 mbit = mo;                                                            // mt's bit in the mask (mo itself may be moved below)
+    bool clean = false;
+    while (sp != n && !clean) {
+        u32 plain = mo - sp;
+        if (plain != 0u) {
+            if (plain < 4u) { const u32 dif = 4u - plain; mo += dif; ml = ml > dif ? ml - dif : 0u; plain = 4u; }
+            if (plain > 18u) { put(0); u32 v = plain - 18u; while (v > 255u) { put(0); v -= 255u; } put(v); } else put(plain - 3u);
+            if (sp + plain > n) { status = ALZ_ST_BAD_TOKEN; break; }
+            copy(sp, plain); sp += plain;
+        }
+        // the finder's next match: the next bit of the mask
+        u32 no = mbit < n ? next_start(mbit + 1u) : n, nl = 0, nd = 0;
+        if (no < n) { const uint2 r = m[no]; nd = r.x; nl = r.y; }
+        if (ml >= 3u) {
+            sp += ml;
+            u32 emb = no - sp;
+            if (no < sp) { status = ALZ_ST_BAD_TOKEN; break; }
+            if (emb > 3u) emb = 0;
+            {   // (tokens are short except for their extension bytes: written through put() byte by byte)
+                if (ml <= 8u && md <= 2048u) {
+                    const u32 flag = (emb | (((md - 1u) & 7u) << 2)) & 0xFFu;
+                    put(ml <= 4u ? (flag | 0x40u | ((ml - 3u) << 5)) : (flag | 0x80u | ((ml - 5u) << 5))); put((md - 1u) >> 3);
+                } else if (md <= 16384u) {
+                    if (ml > 33u) { put(0x20); u32 v = ml - 33u; while (v > 255u) { put(0); v -= 255u; } put(v); } else put(0x20u | (ml - 2u));
+                    put((emb | ((md - 1u) << 2)) & 0xFFu); put(((md - 1u) >> 6) & 0xFFu);
+                } else {
+                    const u32 d2 = md - 0x4000u, flag = (0x10u | ((d2 & 0x4000u) >> 11)) & 0xFFu;
+                    if (ml > 9u) { put(flag); u32 v = ml - 9u; while (v > 255u) { put(0); v -= 255u; } put(v); } else put(flag | (ml - 2u));
+                    put((emb | (d2 << 2)) & 0xFFu); put((d2 >> 6) & 0xFFu);
+                }
+            }
+            if (sp + emb > n) { status = ALZ_ST_BAD_TOKEN; break; }
+            copy(sp, emb); sp += emb;
+            clean = true;                                                      // from here on: 0 or >= 4 literals in front of every match
+        }
+        mo = no; mbit = no; ml = nl; md = nd;
+    }
+    if (status != ALZ_ST_OK || sp == n) {
+        if (status == ALZ_ST_OK) { put(0x11); put(0); put(0); }
+        finish(olen, fail, status);
+        return;
+    }
+    // ---- the rest: one unit per match start at or behind sp
+    const u32 sp0 = sp;
+    u32 cover = sp0, obase = olen;
+    for (u32 P = sp0 & ~63u; P < n; P += 64) {
+        const u32 p = P + (u32)lane;
+        const u64 sm = (P >> 6) < nwords ? mask[P >> 6] : 0ull;
+        const bool start = ((sm >> lane) & 1ull) && p >= mo && p < n;          // (mo: the first match not yet written)
+        if (__ballot(start) == 0ull) continue;
+        uint2 mt = make_uint2(0, 0);
+        if (start) mt = m[p];
+        const u32 M = mt.y, D = mt.x;
+        const u32 mend = start ? p + M : 0u;
+        const u32 pmax = scan_max(mend);
+        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);
+        if (before < cover) before = cover;
+        const u32 Lb = start ? p - before : 0u;                                // literals since the match before (0-3: that one carried them)
+        u32 emb = 0;
+        if (start) {                                                           // the next start (or the end of the data) within three bytes behind my match
+#pragma unroll
+            for (u32 kk = 0; kk < 4u; kk++) {
+                const u32 q = mend + kk;
+                const bool hit = q >= n || (((q >> 6) < nwords) && ((mask[q >> 6] >> (q & 63u)) & 1ull));
+                if (hit) { emb = q >= n ? n - mend : kk; break; }
+            }
+        }
+        const u32 lsz = Lb >= 4u ? lzo_lit_size(Lb) : 0u, lcp = Lb >= 4u ? Lb : 0u;
+        const u32 esz = start ? lsz + lcp + lzo_match_size(D, M) + emb : 0u;
+        const u32 incl = scan_add(esz);
+        const u32 off = obase + incl - esz;
+        const bool fits = start && off + esz <= cap;
+        if (start && !fits) fail = true;
+        if (fits) {
+            u32 q = off;
+            if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); if (Lb <= 16u) for (u32 i = 0; i < Lb; i++) dst[q + i] = src[before + i]; q += Lb; }
+            q += lzo_put_match(dst + q, D, M, emb);
+            for (u32 i = 0; i < emb; i++) dst[q + i] = src[mend + i];
+        }
+        u64 longs = __ballot(fits && Lb > 16u);
+        while (longs) {
+            const int l0 = (int)__builtin_ctzll(longs);
+            const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)Lb, l0);
+            const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lsz), l0);
+            wave_copy(dst + dq, src + so, len, lane);
+            longs &= longs - 1ull;
+        }
+        obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
+        if (wmax > cover) cover = wmax;
+    }
+    // ---- behind the last match: 0-3 literals went out with it; four and more are a run of their own; then the end token
+    u32 rest = n - cover;
+    if (rest <= 3u) rest = 0u;
+    const u32 lsz = rest ? lzo_lit_size(rest) : 0u;
+    const u32 total = obase + lsz + rest + 3u;
+    if (total > cap) fail = true;
+    const bool anyfail = __ballot(fail) != 0ull;
+    if (!anyfail) {
+        if (rest) { if (lane == 0) (void)lzo_put_lit(dst + obase, rest); wave_copy(dst + obase + lsz, src + cover, rest, lane); }
+        if (lane == 0) { dst[total - 3u] = 0x11; dst[total - 2u] = 0; dst[total - 1u] = 0; }
+    }
+    finish(total, anyfail, ALZ_ST_OK);
+}
+
 template <int FMT>
 static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
                         const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g,
@@ -2408,7 +2592,13 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         } else launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
         break; }
-    case ALZ_FMT_LZO: launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
+    case ALZ_FMT_LZO: {
+        static const int par = getenv("ALZ_ENC_LZO_PAR") ? atoi(getenv("ALZ_ENC_LZO_PAR")) : 1;
+        if (par) {
+            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+            hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        } else launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        break; }
     case ALZ_FMT_SNAPPY_RAW: {
         static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
         if (par) {
