@@ -21,7 +21,7 @@
 //                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
 //   C  enc_roles_kernel         the greedy/lazy parse as a walk over the match array (one wavefront per stream): a bit per token
-//                               start; then enc_emit_par_kernel (flag-bit formats), enc_emit_seq_kernel (LZ4, Snappy) or enc_emit_prs_kernel place
+//                               start; then enc_emit_par_kernel (flag-bit formats), enc_emit_seq_kernel (LZ4, Snappy), enc_emit_prs_kernel or enc_emit_lzo_kernel place
 //                               every token with prefix sums.  enc_emit_kernel: parse + emission on one lane per stream, for the
 //                               formats that have no parallel emit yet.
 #include <hip/hip_runtime.h>
@@ -2394,13 +2394,18 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
     // ---- the rest: one unit per match start at or behind sp
     const u32 sp0 = sp;
     u32 cover = sp0, obase = olen;
-    for (u32 P = sp0 & ~63u; P < n; P += 64) {
+    const u32 P0 = sp0 & ~63u;
+    u64 sm_n = (P0 >> 6) < nwords ? mask[P0 >> 6] : 0ull;                     // (mask word and matches of a window are loaded one window ahead)
+    uint2 mt_n = P0 + (u32)lane < n ? m[P0 + (u32)lane] : make_uint2(0, 0);
+    for (u32 P = P0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
-        const u64 sm = (P >> 6) < nwords ? mask[P >> 6] : 0ull;
+        const u64 sm = sm_n;
+        const uint2 mt_all = mt_n;
+        if (P + 64 < n) { sm_n = ((P >> 6) + 1u) < nwords ? mask[(P >> 6) + 1u] : 0ull; if (p + 64 < n) mt_n = m[p + 64]; }
         const bool start = ((sm >> lane) & 1ull) && p >= mo && p < n;          // (mo: the first match not yet written)
         if (__ballot(start) == 0ull) continue;
         uint2 mt = make_uint2(0, 0);
-        if (start) mt = m[p];
+        if (start) mt = mt_all;
         const u32 M = mt.y, D = mt.x;
         const u32 mend = start ? p + M : 0u;
         const u32 pmax = scan_max(mend);
