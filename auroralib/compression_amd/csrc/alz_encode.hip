@@ -955,14 +955,15 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
     const int limit = n - 4;
-    const long long base64 = (long long)blockIdx.x * ALZ_DENSE_POS;
-    if (base64 > (long long)limit) return;
-    const int base = (int)base64;
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
     uint2* m = match + pos_off[sid];
     const int lane = (int)threadIdx.x;
     const int chain = g.max_chain;
+  // (the grid holds at most 4 096 workgroups per stream: a stream longer than 4 096 blocks -- and a batch whose longest stream is far
+  //  longer than the others -- goes round; up to that length a workgroup has one block, which is the faster arrangement)
+  for (long long base64 = (long long)blockIdx.x * ALZ_DENSE_POS; base64 <= (long long)limit; base64 += (long long)gridDim.x * ALZ_DENSE_POS) {
+    const int base = (int)base64;
 #pragma unroll
     for (int r = 0; r < ALZ_DENSE_POS / 64; r++) { best[64 * r + lane] = 0ull; capf[64 * r + lane] = 0u; }
     u32 ln = 0;                                   // pairs in the list (wave-uniform)
@@ -1094,6 +1095,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
         }
         m[pos] = capped ? make_uint2(ALZ_CAPPED, ALZ_CAPPED) : make_uint2((u32)best_d, (u32)best_l);
     }
+  }
 }
 
 template <bool MINT>
@@ -2552,7 +2554,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 3;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
     if (dense_chain > 0 && g.max_chain >= dense_chain && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {
         const bool dyn = g.max_chain >= 8;
-        u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1;
+        u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         if (dyn) {
             if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
             else hipLaunchKernelGGL((enc_match_dense_kernel<false, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
