@@ -2052,6 +2052,9 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
         else { q[0] = (u8)((2u | ((M - 1u) << 2)) & 0xFFu); q[1] = (u8)(D & 0xFFu); q[2] = (u8)((D >> 8) & 0xFFu); }
     }
 };
+#ifndef ALZ_SEQ_LANE_LIT
+#define ALZ_SEQ_LANE_LIT 4u      /* literal runs up to this long are copied by their own lane, longer ones by the wavefront (4: 15.8 ms, 16: 17.8) */
+#endif
 template <int FMT>
 __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
@@ -2108,10 +2111,10 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
         if (start && !fits) fail = true;
         if (fits) {
             F::put_lit_hdr(dst + off, L, M, false);
-            if (L <= 16u) for (u32 i = 0; i < L; i++) dst[off + lh + i] = src[before + i];
+            if (L <= ALZ_SEQ_LANE_LIT) for (u32 i = 0; i < L; i++) dst[off + lh + i] = src[before + i];
             F::put_match(dst + off + lh + L, D, M);
         }
-        u64 longs = __ballot(fits && L > 16u);                                 // long literal runs: the whole wavefront copies
+        u64 longs = __ballot(fits && L > ALZ_SEQ_LANE_LIT);                      // longer literal runs: the whole wavefront copies
         while (longs) {
             const int l0 = (int)__builtin_ctzll(longs);
             const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)L, l0);
