@@ -2309,6 +2309,9 @@ __device__ __forceinline__ u32 lzo_put_match(u8* q, u32 D, u32 M, u32 emb) {    
     q[k] = (u8)((emb | (d2 << 2)) & 0xFFu); q[k + 1] = (u8)((d2 >> 6) & 0xFFu);
     return k + 2u;
 }
+#ifndef ALZ_LZO_LANE_LIT
+#define ALZ_LZO_LANE_LIT 4u
+#endif
 __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
                                                           u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
@@ -2434,11 +2437,11 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
         if (start && !fits) fail = true;
         if (fits) {
             u32 q = off;
-            if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); if (Lb <= 16u) for (u32 i = 0; i < Lb; i++) dst[q + i] = src[before + i]; q += Lb; }
+            if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); if (Lb <= ALZ_LZO_LANE_LIT) for (u32 i = 0; i < Lb; i++) dst[q + i] = src[before + i]; q += Lb; }
             q += lzo_put_match(dst + q, D, M, emb);
             for (u32 i = 0; i < emb; i++) dst[q + i] = src[mend + i];
         }
-        u64 longs = __ballot(fits && Lb > 16u);
+        u64 longs = __ballot(fits && Lb > ALZ_LZO_LANE_LIT);
         while (longs) {
             const int l0 = (int)__builtin_ctzll(longs);
             const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)Lb, l0);
