@@ -31,6 +31,7 @@
 // executes the rounds of the first five, overlapping the HBM read-backs of one round with the parse of the next.
 #pragma once
 #include "alz_emit_byte.h"
+#include "alz_prs_table.h"
 
 #ifndef ALZ_QRUN
 #define ALZ_QRUN 200u   /* longest literal run / element a lane-parallel round takes: window (256) + element stay inside one 512-byte cache chunk */
@@ -1216,141 +1217,154 @@ __device__ __forceinline__ void prs_from_norm(u32 fl, u32& bits, u32& flag) {
     flag = BIG ? (__builtin_bitreverse32(r) >> (32u - nb)) : (r << (8u - nb));
 }
 
-// One window of the walk: the 64 input bytes at cache index i0 (lane = byte), tokens that START at window positions <= limit
-// (<= 60: a token's last flag / data byte then still lies inside the window).  Returns the position behind the last token taken,
-// the flag register, the terminator flag and -- per lane -- the token "its" byte turned out to be (tokm: the bytes that are one).
+// The walk advances by a GROUP -- a flag byte and the data bytes of the tokens whose last control bit lies in it, about five tokens
+// (alz_prs_table.h) -- instead of by a token: per group one v_readlane (the flag byte), one s_load_dword (the table entry of (entry
+// state, flag byte), from the scalar cache), and per long match in the group (at most four) one s_bitcmp1_b64 + s_addc_u32: is the
+// bit of "the low three bits of the word here are zero" set where that match's data starts -- the only data a group's size depends
+// on.  ~30 scalar instructions per group against ~65 for its tokens one by one (round 2), and none of them touches a token: what the
+// walk leaves behind is, per group, (position of its flag byte | entry state << 11) in lane j of `gw`.
+//
+// One window: the 64 input bytes at cache index i0 + base (lane = byte); groups that START at window positions <= 49 (a group has at
+// most 14 bytes: all of it lies inside the window).  pos / stw: window position and state << 11 in front of the next group.
+#ifndef ALZ_PRS_NWIN
+#define ALZ_PRS_NWIN 2      /* windows per round: ~26 tokens each on the synthetic mix */
+#endif
+static __device__ const AlzPrsTable g_alz_prs_table = alz_make_prs_table();
+
 template <bool BIG>
-__device__ __forceinline__ void prs_walk_window(const InCache& in, u32 i0, int lane, u32 limit, u32& pos_out, u32& fl_io, u32& term_out, u64& tokm, u32& tok_out) {
-    const u32 x0 = in.lds[i0 + (u32)lane], x1 = in.lds[i0 + (u32)lane + 1], x2 = in.lds[i0 + (u32)lane + 2];
-    const u32 xf = (BIG ? (__builtin_bitreverse32(x0) >> 24) : x0) | 0x100u;           // flag byte in consumption order + sentinel
-    const u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);                             // long match word  PRS.cs:75-77
-    const u64 zerom = __ballot(v == 0u);                                                // terminator
-    const u64 extm = __ballot((v & 7u) == 0u);                                          // length in a third byte
-    u64 litm = 0, shm = 0, lgm = 0, hm = 0, lm = 0;
-    u32 pos = 0, fl = fl_io, term = 0;
-    u32 t4;
-    u64 t0 = 0, t1 = 0, t23;                                 // (64-bit: the walk shifts them into the hm / lm masks)
-    // (the common path of every token type falls through its flag-register checks: the reloads -- one control bit in eight -- sit
-    // out of line, so a literal costs ONE taken branch, the loop's own)
+__device__ __forceinline__ void prs_walk_groups(const InCache& in, u32 i0, int lane, u32 base, u32& pos_out, u32& stw_io, u32& gw_io, u32& ng_io) {
+    const u32 b0 = in.lds[i0 + base + (u32)lane];
+    u32 lowb = b0;                                                 // the byte that holds the low bits of "the word that starts here"  PRS.cs:75-77
+    if (BIG) lowb = in.lds[i0 + base + (u32)lane + 1u];
+    const u32 xf8 = (BIG ? (__builtin_bitreverse32(b0) >> 24) : b0) << 3;   // flag byte in consumption order, as a table offset (8-byte entries)
+    const u64 extm = __ballot((lowb & 7u) == 0u);                  // a long match here has its length in a third byte  PRS.cs:85-90
+    const u32* tab = g_alz_prs_table.w;
+    u32 pos = 0, stw = stw_io, gw = gw_io, cnt = ng_io;
+    u32 off, ent, w, nl, a;
     asm volatile(
-        "Lprs_top_%=:\n\t"
-        "s_cmp_gt_u32 %[pos], %[limit]\n\t"
-        "s_cbranch_scc1 Lprs_end_%=\n\t"
-        "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc1 Lprs_ra_%=\n"
-        "Lprs_a_%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cbranch_scc0 Lprs_match_%=\n\t"
-        "s_lshr_b32 %[fl], %[fl], 1\n\t"                       // literal
-        "s_bitset1_b64 %[litm], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
-        "s_branch Lprs_top_%=\n"
-        "Lprs_match_%=:\n\t"
-        "s_lshr_b32 %[fl], %[fl], 1\n\t"
-        "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc1 Lprs_rb_%=\n"
-        "Lprs_b_%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cbranch_scc0 Lprs_short_%=\n\t"
-        "s_lshr_b32 %[fl], %[fl], 1\n\t"                       // long match
-        "s_bitcmp1_b64 %[zerom], %[pos]\n\t"
-        "s_cbranch_scc1 Lprs_term_%=\n\t"
-        "s_bitset1_b64 %[lgm], %[pos]\n\t"
-        "s_bitcmp1_b64 %[extm], %[pos]\n\t"
-        "s_cselect_b32 %[t4], 3, 2\n\t"
-        "s_add_u32 %[pos], %[pos], %[t4]\n\t"
-        "s_branch Lprs_top_%=\n"
-        "Lprs_short_%=:\n\t"
-        "s_lshr_b32 %[fl], %[fl], 1\n\t"                       // short match: two more bits
-        "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc1 Lprs_rc_%=\n"
-        "Lprs_c_%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cselect_b64 %[t0], 1, 0\n\t"
-        "s_lshr_b32 %[fl], %[fl], 1\n\t"
-        "s_cmp_eq_u32 %[fl], 1\n\t"
-        "s_cbranch_scc1 Lprs_rd_%=\n"
-        "Lprs_d_%=:\n\t"
-        "s_bitcmp1_b32 %[fl], 0\n\t"
-        "s_cselect_b64 %[t1], 1, 0\n\t"
-        "s_lshr_b32 %[fl], %[fl], 1\n\t"
-        "s_bitset1_b64 %[shm], %[pos]\n\t"
-        "s_lshl_b64 %[t23], %[t0], %[pos]\n\t"                 // (t0 / t1 are 0 / 1 in 64-bit register pairs)
-        "s_or_b64 %[hm], %[hm], %[t23]\n\t"
-        "s_lshl_b64 %[t23], %[t1], %[pos]\n\t"
-        "s_or_b64 %[lm], %[lm], %[t23]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
-        "s_branch Lprs_top_%=\n"
-        "Lprs_ra_%=:\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
-        "s_branch Lprs_a_%=\n"
-        "Lprs_rb_%=:\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
-        "s_branch Lprs_b_%=\n"
-        "Lprs_rc_%=:\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
-        "s_branch Lprs_c_%=\n"
-        "Lprs_rd_%=:\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 %[fl], %[xf], %[pos]\n\t"
-        "s_add_u32 %[pos], %[pos], 1\n\t"
-        "s_branch Lprs_d_%=\n"
-        "Lprs_term_%=:\n\t"
-        "s_add_u32 %[pos], %[pos], 2\n\t"
-        "s_mov_b32 %[term], 1\n"
-        "Lprs_end_%=:\n\t"
-        : [pos] "+s"(pos), [fl] "+s"(fl), [litm] "+s"(litm), [shm] "+s"(shm), [lgm] "+s"(lgm), [hm] "+s"(hm), [lm] "+s"(lm),
-          [term] "+s"(term), [t0] "+s"(t0), [t1] "+s"(t1), [t23] "=&s"(t23), [t4] "=&s"(t4)
-        : [xf] "v"(xf), [zerom] "s"(zerom), [extm] "s"(extm), [limit] "s"(limit)
-        : "scc");
-    // token of "my" byte under the interpretation the walk chose  PRS.cs:66-97
-    u32 tok = ALZ_TOK_LIT(1u, x0);
-    if ((shm >> lane) & 1ull) {
-        const u32 len = 2u + ((u32)((hm >> lane) & 1ull) << 1) + (u32)((lm >> lane) & 1ull);
-        tok = ALZ_TOK_MATCH(len, 0x100u - x0);
-    } else if ((lgm >> lane) & 1ull) {
-        const u32 len = (v & 7u) ? (v & 7u) + 2u : x2 + 1u;
-        tok = ALZ_TOK_MATCH(len, 0x2000u - (v >> 3));
-    }
-    pos_out = pos; fl_io = fl; term_out = term; tokm = litm | shm | lgm; tok_out = tok;
+        "s_mov_b32 m0, %[cnt]\n\t"
+        "s_nop 0\n"
+        "Lpg_top_%=:\n\t"
+        "s_cmp_gt_u32 %[pos], 49\n\t"
+        "s_cbranch_scc1 Lpg_end_%=\n\t"
+        "v_readlane_b32 %[off], %[xf8], %[pos]\n\t"
+        "s_add_u32 %[w], %[pos], %[base]\n\t"
+        "s_or_b32 %[off], %[off], %[stw]\n\t"
+        "s_load_dword %[ent], %[tab], %[off]\n\t"
+        "s_or_b32 %[w], %[w], %[stw]\n\t"
+        "s_nop 0\n\t"
+        "v_writelane_b32 %[gw], %[w], m0\n\t"
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_and_b32 %[stw], %[ent], 0x3800\n\t"
+        "s_bfe_u32 %[nl], %[ent], 0x30004\n\t"
+        "s_cmp_eq_u32 %[nl], 0\n\t"
+        "s_cbranch_scc1 Lpg_done_%=\n\t"
+        "s_bfe_u32 %[a], %[ent], 0x40010\n\t"                     // long match 0: where its data starts
+        "s_add_u32 %[a], %[a], %[pos]\n\t"
+        "s_bitcmp1_b64 %[extm], %[a]\n\t"
+        "s_addc_u32 %[pos], %[pos], 0\n\t"                        // a third byte: everything behind it moves by one
+        "s_cmp_eq_u32 %[nl], 1\n\t"
+        "s_cbranch_scc1 Lpg_done_%=\n\t"
+        "s_bfe_u32 %[a], %[ent], 0x40014\n\t"
+        "s_add_u32 %[a], %[a], %[pos]\n\t"
+        "s_bitcmp1_b64 %[extm], %[a]\n\t"
+        "s_addc_u32 %[pos], %[pos], 0\n\t"
+        "s_cmp_eq_u32 %[nl], 2\n\t"
+        "s_cbranch_scc1 Lpg_done_%=\n\t"
+        "s_bfe_u32 %[a], %[ent], 0x40018\n\t"
+        "s_add_u32 %[a], %[a], %[pos]\n\t"
+        "s_bitcmp1_b64 %[extm], %[a]\n\t"
+        "s_addc_u32 %[pos], %[pos], 0\n\t"
+        "s_cmp_eq_u32 %[nl], 3\n\t"
+        "s_cbranch_scc1 Lpg_done_%=\n\t"
+        "s_bfe_u32 %[a], %[ent], 0x4001c\n\t"
+        "s_add_u32 %[a], %[a], %[pos]\n\t"
+        "s_bitcmp1_b64 %[extm], %[a]\n\t"
+        "s_addc_u32 %[pos], %[pos], 0\n"
+        "Lpg_done_%=:\n\t"
+        "s_and_b32 %[a], %[ent], 15\n\t"
+        "s_add_u32 %[pos], %[pos], %[a]\n\t"
+        "s_branch Lpg_top_%=\n"
+        "Lpg_end_%=:\n\t"
+        "s_mov_b32 %[cnt], m0\n\t"
+        : [pos] "+&s"(pos), [stw] "+&s"(stw), [gw] "+&v"(gw), [cnt] "+&s"(cnt), [off] "=&s"(off), [ent] "=&s"(ent), [w] "=&s"(w), [nl] "=&s"(nl), [a] "=&s"(a)
+        : [xf8] "v"(xf8), [extm] "s"(extm), [tab] "s"(tab), [base] "s"(base)
+        : "scc", "m0", "memory");
+    pos_out = pos; stw_io = stw; gw_io = gw; ng_io = cnt;
 }
 
-// Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p, cache covers [p, p + chunk).  `fl` is the normalised flag
-// register (prs_to_norm).  Returns false (state untouched) when nothing could be parsed or the batch does not fit dst.
-// A window of 64 input bytes holds ~30 tokens of the synthetic mix, which left half of the lanes of the byte phase (and of its
-// token prologue) idle; so a second window follows the first where the queue has room for what it can hold at most (8
-// literals per 9 bytes): ~48 tokens per round.
-// The parse of one round on its own (no window, no output): tokens of up to two walk windows starting at input offset p -> qt (one
-// per lane, nt of them), the bytes they produce, the input they cover, the flag register behind them, "the terminator was read".
-// Touches the input cache and `stage` only.  Returns false when nothing could be parsed.
+// The parse of one round on its own (no window, no output): the tokens of the groups of ALZ_PRS_NWIN walk windows starting at input
+// offset p -> qt (one per lane, nt of them), the bytes they produce, the input they cover, the flag register behind them, "the
+// terminator was read".  `fl` is the normalised flag register (prs_to_norm); a round starts and ends between two groups, where the
+// register holds nothing but the unfinished token's bits ("", "0", "00", "00h"): any other register is declined (the exact parser
+// takes tokens until one ends a flag byte).  Touches the input cache and `stage` only.  Preconditions: one cache chunk + 76 input
+// bytes ahead of p, cache covers [p, p + chunk).  Returns false (state untouched) when nothing could be parsed.
+//
+// Behind the walk lane r becomes token r of the round: the groups' token counts (table) give every group its first rank, a mark per
+// group and one mbcnt give every token its group, and the token finds its data the way the walk found the group's size -- the
+// third bytes of the long matches in front of it, one LDS byte each.
 template <bool BIG>
 __device__ __forceinline__ bool prs_parse_round(InCache& in, u32 p, u32 fl_in, u32* stage, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out, u32& fl_out, u32& term_out) {
-    u32 pos, fl = fl_in, term, tok; u64 allm;
-    prs_walk_window<BIG>(in, in.idx(p), lane, 60u, pos, fl, term, allm, tok);
-    u32 nt = (u32)__popcll(allm);
-    if (nt == 0u && !term) return false;
-    if ((allm >> lane) & 1ull) stage[mbcnt64(allm)] = tok;
-#if !defined(ALZ_PRS_ONE_WINDOW)
-    if (!term && nt <= 48u) {
-        const u32 room = 64u - nt;
-        u32 limit = ((room - 2u) * 9u) / 8u - 1u;            // tokens that start at positions 0..limit: <= ceil((limit + 1) * 8 / 9) + 1 <= room
-        if (limit > 60u) limit = 60u;
-        u32 pos2, term2, tok2; u64 m2;
-        prs_walk_window<BIG>(in, in.idx(p + pos), lane, limit, pos2, fl, term2, m2, tok2);
-        if ((m2 >> lane) & 1ull) stage[nt + mbcnt64(m2)] = tok2;
-        nt += (u32)__popcll(m2); pos += pos2; term = term2;
+    u32 st;
+    if (fl_in == 1u) st = 0u; else if (fl_in == 2u) st = 1u; else if (fl_in == 4u) st = 2u; else if (fl_in == 8u) st = 3u; else if (fl_in == 12u) st = 4u;
+    else return false;
+    const u32 i0 = in.idx(p);
+    u32 stw = st << 11, gw = 0, ng = 0, base = 0;
+#pragma unroll
+    for (int w = 0; w < ALZ_PRS_NWIN; w++) {
+        u32 pos;
+        prs_walk_groups<BIG>(in, i0, lane, base, pos, stw, gw, ng);
+        base += pos;
     }
-#endif
+    gw = wave_writelane(gw, base | stw, ng);                        // what follows the last group: where the round ends if nothing is cut
+    // ---- group lanes: tokens per group, first rank of every group
+    const bool isg = (u32)lane < ng;
+    const u32 gpos = isg ? (gw & 0xFFu) : 0u, gst = isg ? ((gw >> 11) & 7u) : 0u;
+    const u32 fb = in.lds[i0 + gpos];
+    const u32 fn = BIG ? (__builtin_bitreverse32(fb) >> 24) : fb;
+    const uint2 T = *reinterpret_cast<const uint2*>(g_alz_prs_table.w + 2u * (gst * 256u + fn));
+    const u32 ntok = isg ? ((T.x >> 7) & 7u) + 1u : 0u;
+    const u32 rin = wave_incl_scan(ntok, lane);
+    const u32 ngk = (u32)__popcll(__ballot(isg && rin <= 64u));     // the groups that fit the 64 token lanes (a prefix; >= 1)
+    u32 nt = wave_readlane(rin, ngk - 1u);
+    stage[lane] = 0u;
     wave_sync();
-    const u32 qt = (u32)lane < nt ? stage[lane] : 0u;
+    if ((u32)lane < ngk) stage[rin - 1u] = 1u;                     // the last token of every group
     wave_sync();
-    qt_out = qt; nt_out = nt; adv_out = pos; fl_out = fl; term_out = term;
+    const u32 g = mbcnt64(__ballot(stage[lane] != 0u));            // groups that end in front of me = my group
+    const u32 gw2 = gw | ((rin - ntok) << 16);
+    const u32 gv = wave_bperm(g, gw2), tx = wave_bperm(g, T.x), ty = wave_bperm(g, T.y);
+    // ---- token lanes
+    const u32 tpos = gv & 0xFFu, k = ((u32)lane - (gv >> 16)) & 7u;
+    const u32 code = (ty >> (3u * k)) & 7u;
+    const u32 nlb = (u32)__popc((ty >> 24) & ((1u << k) - 1u));    // long matches of my group in front of me
+    u32 E = 0;                                                     // third bytes in front of me
+    const u32 gb = i0 + tpos + (BIG ? 1u : 0u);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (__ballot((u32)j < nlb)) {
+            const u32 b = in.lds[gb + ((tx >> (16 + 4 * j)) & 15u) + E];
+            E += ((u32)j < nlb && (b & 7u) == 0u) ? 1u : 0u;
+        }
+    }
+    const u32 dend = tpos + 1u + k + nlb + E;                      // my data: k - nlb one-byte tokens and nlb long matches in front of it
+    const u32 dp = i0 + dend;
+    const u32 x0 = in.lds[dp], x1 = in.lds[dp + 1u], x2 = in.lds[dp + 2u];
+    const u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);       // long match word  PRS.cs:75-77
+    u32 tok = ALZ_TOK_LIT(1u, x0);                                 // PRS.cs:66-97
+    if (code & 4u) tok = ALZ_TOK_MATCH(2u + (code & 3u), 0x100u - x0);
+    else if (code == 1u) tok = ALZ_TOK_MATCH((v & 7u) ? (v & 7u) + 2u : x2 + 1u, 0x2000u - (v >> 3));
+    u32 adv, stx, term = 0;
+    const u64 tm = __ballot((u32)lane < nt && code == 1u && v == 0u);   // PRS.cs:78-79: the zero word ends the stream
+    if (tm) {
+        const u32 t = (u32)__builtin_ctzll(tm);
+        nt = t; term = 1u; adv = wave_readlane(dend, t) + 2u; stx = 0u;
+    } else { const u32 e = wave_readlane(gw, ngk); adv = e & 0xFFu; stx = (e >> 11) & 7u; }
+    if (nt == 0u && !term) return false;
+    const u32 qt = (u32)lane < nt ? tok : 0u;
+    qt_out = qt; nt_out = nt; adv_out = adv; term_out = term;
+    fl_out = stx == 0u ? 1u : (stx == 1u ? 2u : (stx == 2u ? 4u : (stx == 3u ? 8u : 12u)));
     total_out = wave_readlane(wave_incl_scan(qt >> 18, lane), 63);
     return true;
 }

@@ -40,7 +40,15 @@ namespace AuroraLib.Compression.Amd
                                     uint aux0, uint aux1, uint capacity, bool hasSize)
         {
             byte[] src = RentRest(source, out int srcLen);
-            try
+            try { DecodeRented(format, props, src, srcLen, source, destination, decomLength, aux0, aux1, capacity, hasSize); }
+            finally { ArrayPool<byte>.Shared.Return(src); }
+        }
+
+        /// <summary>The same over a buffer that already holds the rest of <paramref name="source"/> (whose position is at its end):
+        /// formats that may decode one input twice (PRS: the other byte order, PRS.cs:42-57) rent it once.</summary>
+        internal static void DecodeRented(AlzFormat format, AlzLzProperties* props, byte[] src, int srcLen, Stream source, Stream destination,
+                                          uint decomLength, uint aux0, uint aux1, uint capacity, bool hasSize)
+        {
             {
                 for (;;)
                 {
@@ -66,7 +74,6 @@ namespace AuroraLib.Compression.Amd
                     finally { ArrayPool<byte>.Shared.Return(dst); }
                 }
             }
-            finally { ArrayPool<byte>.Shared.Return(src); }
         }
 
         /// <summary>INTEGRATION.md section 3: per-stream status -> the exception of the managed body.</summary>
@@ -110,6 +117,13 @@ namespace AuroraLib.Compression.Amd
 
         /// <summary>True when a single stream of this size should run on the GPU rather than on the managed body.</summary>
         internal static bool UseGpu(uint decomLength) => AmdContext.Available && decomLength >= AmdContext.SingleStreamThreshold;
+
+        /// <summary>True when ONE buffer should be compressed by the native encoder.  The native finder takes the format's own
+        /// window only: a caller's <c>MaxWindowBits</c> (LzChainMatchFinder.cs:69-73) is honoured by the managed encoder, except
+        /// for FastLZ, whose level-2 switch it is (FastLZ.cs:163-170).</summary>
+        internal static bool UseGpuForCompress(AlzFormat format, int sourceLength, CompressionSettings settings)
+            => (settings.MaxWindowBits == 0 || format == AlzFormat.FastLZ)
+               && (uint)sourceLength >= AmdContext.SingleStreamCompressThreshold && AmdContext.Available;
 
         internal static AlzLzProperties ToNative(LzProperties lz) => new AlzLzProperties
         {

@@ -20,6 +20,12 @@ namespace AuroraLib.Compression.Amd
         /// chunked formats, which the library splits into a batch itself.</summary>
         public static uint SingleStreamThreshold { get; set; } = uint.MaxValue;
 
+        /// <summary>The same switch for <c>Compress</c> / <c>CompressHeaderless</c> of ONE buffer: sources shorter than this run on
+        /// the managed encoder.  The greedy / lazy walk of one stream is a serial job for one wavefront (34 MB: 1.1 s against
+        /// 0.13 s on one CPU core, INTEGRATION.md section 1), so the default is "never"; the GPU encoder is reached through
+        /// <see cref="BatchEncoder.CompressMany"/> and through the framed containers, which split a file into a batch.</summary>
+        public static uint SingleStreamCompressThreshold { get; set; } = uint.MaxValue;
+
         public static bool Available
         {
             get

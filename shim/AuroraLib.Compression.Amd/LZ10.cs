@@ -66,7 +66,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <summary>LZ10.CompressHeaderless (LZ10.cs:113-137) + LzChainMatchFinder: bit-identical output at every quality.</summary>
         public static unsafe void CompressHeaderless(ReadOnlySpan<byte> source, Stream destination, CompressionSettings settings = default, bool gbaVramCompatibilityMode = true)
         {
-            if (!AmdContext.Available) { Managed.LZ10.CompressHeaderless(source, destination, settings, gbaVramCompatibilityMode); return; }
+            if (!AmdBody.UseGpuForCompress(AlzFormat.LZ10, source.Length, settings)) { Managed.LZ10.CompressHeaderless(source, destination, settings, gbaVramCompatibilityMode); return; }
             AmdBody.Encode(AlzFormat.LZ10, null, source, destination, settings, gbaVramCompatibilityMode ? 2 : 1);
         }
     }

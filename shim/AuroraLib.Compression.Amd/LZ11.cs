@@ -65,7 +65,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <summary>LZ11.CompressHeaderless (LZ11.cs:135-171).</summary>
         public static unsafe void CompressHeaderless(ReadOnlySpan<byte> source, Stream destination, CompressionSettings settings = default, bool gbaVramCompatibilityMode = false)
         {
-            if (!AmdContext.Available) { Managed.LZ11.CompressHeaderless(source, destination, settings, gbaVramCompatibilityMode); return; }
+            if (!AmdBody.UseGpuForCompress(AlzFormat.LZ11, source.Length, settings)) { Managed.LZ11.CompressHeaderless(source, destination, settings, gbaVramCompatibilityMode); return; }
             AmdBody.Encode(AlzFormat.LZ11, null, source, destination, settings, gbaVramCompatibilityMode ? 2 : 1);
         }
     }

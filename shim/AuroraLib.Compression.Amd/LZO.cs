@@ -37,7 +37,7 @@ namespace AuroraLib.Compression.Amd.Common
         /// <summary>LZO.CompressHeaderless (LZO.cs:141-250), quirks included (the literal-run padding of :167-172).</summary>
         public static unsafe void CompressHeaderless(ReadOnlySpan<byte> source, Stream destination, CompressionSettings settings = default)
         {
-            if (!AmdContext.Available) { Managed.LZO.CompressHeaderless(source, destination, settings); return; }
+            if (!AmdBody.UseGpuForCompress(AlzFormat.LZO, source.Length, settings)) { Managed.LZO.CompressHeaderless(source, destination, settings); return; }
             AmdBody.Encode(AlzFormat.LZO, null, source, destination, settings, 0);
         }
     }

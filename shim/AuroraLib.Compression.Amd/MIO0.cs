@@ -52,7 +52,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <inheritdoc/>
         public void Compress(ReadOnlySpan<byte> source, Stream destination, CompressionSettings settings = default)   // MIO0.cs:63-80
         {
-            if (!AmdContext.Available) { var m = new Managed.MIO0 { FormatByteOrder = FormatByteOrder }; m.Compress(source, destination, settings); return; }
+            if (!AmdBody.UseGpuForCompress(AlzFormat.MIO0, source.Length, settings)) { var m = new Managed.MIO0 { FormatByteOrder = FormatByteOrder }; m.Compress(source, destination, settings); return; }
             using (MemoryStream body = new MemoryStream())
             {
                 // the native encoder writes flags | tokens | literals back to back and reports where the sections start

@@ -1,6 +1,5 @@
 // PRS.cs -- drop-in for AuroraLib.Compression.Formats.Sega.PRS (src/AuroraLib.Compression.Sega/Sega/PRS.cs).
 using AuroraLib.Compression.Interfaces;
-using AuroraLib.Compression.IO;
 using AuroraLib.Core.Format;
 using AuroraLib.Core.IO;
 using System;
@@ -17,85 +16,102 @@ namespace AuroraLib.Compression.Amd.Sega
         public IFormatInfo Info => _info;
 
         /// <inheritdoc/>
-        public Endian FormatByteOrder { get; set; } = Endian.Little;     // PRS.cs:24
+        public Endian FormatByteOrder { get; set; } = Endian.Big;        // PRS.cs:23 (the static CompressHeaderless defaults to Little, :104)
 
         /// <inheritdoc/>
         public bool IsMatch(Stream stream, ReadOnlySpan<char> fileNameAndExtension = default)
-            => Managed.PRS.IsMatchStatic(stream, fileNameAndExtension);   // PRS.cs:31-32 (byte-order detection on the last bytes)
+            => Managed.PRS.IsMatchStatic(stream, fileNameAndExtension);   // PRS.cs:31-32 (byte-order detection on the first tokens)
 
         /// <inheritdoc/>
         public void Decompress(Stream source, Stream destination) => DecompressHeaderless(source, destination);
 
-        /// <summary>PRS.DecompressHeaderless(Stream, Stream) (PRS.cs:42-57): detected byte order first, the other one when that throws.</summary>
+        /// <summary>PRS.DecompressHeaderless(Stream, Stream) (PRS.cs:42-57): the byte order the stream opens plausibly in first, the
+        /// other one when that attempt throws.  The rest of the source is read ONCE; both attempts decode the same buffer.</summary>
         public static void DecompressHeaderless(Stream source, Stream destination)
         {
             if (!AmdBody.UseGpu((uint)Math.Min(uint.MaxValue, (source.Length - source.Position) * 4))) { Managed.PRS.DecompressHeaderless(source, destination); return; }
-            Endian detected = GetByteOrder(source) == Endian.Big ? Endian.Big : Endian.Little;
-            long sourcePos = source.Position, destinationPos = destination.Position;
+            long destinationPos = destination.Position;
+            byte[] body = AmdBody.RentRest(source, out int length);
             try
             {
-                DecompressHeaderless(source, destination, detected);
+                // PRS.cs:44, :160-169: little-endian is asked first, big-endian second, neither means little-endian
+                Endian first = !PrsOpening.LooksLike(body, length, Endian.Little) && PrsOpening.LooksLike(body, length, Endian.Big) ? Endian.Big : Endian.Little;
+                try { Decode(body, length, source, destination, first); }
+                catch (Exception)
+                {
+                    destination.Seek(destinationPos, SeekOrigin.Begin);
+                    Decode(body, length, source, destination, first == Endian.Big ? Endian.Little : Endian.Big);
+                }
             }
-            catch (Exception)
-            {
-                source.Seek(sourcePos, SeekOrigin.Begin);
-                destination.Seek(destinationPos, SeekOrigin.Begin);
-                DecompressHeaderless(source, destination, detected == Endian.Big ? Endian.Little : Endian.Big);
-            }
+            finally { System.Buffers.ArrayPool<byte>.Shared.Return(body); }
         }
 
         /// <summary>PRS.DecompressHeaderless(Stream, Stream, Endian) (PRS.cs:59-102): no size anywhere -- the stream runs to its
         /// zero word; the destination capacity starts at 8x the input and doubles while the body reports OUTPUT_CAPACITY.</summary>
-        public static unsafe void DecompressHeaderless(Stream source, Stream destination, Endian order)
+        public static void DecompressHeaderless(Stream source, Stream destination, Endian order)
         {
-            long rest = source.Length - source.Position;
-            uint guess = (uint)Math.Min(0x7FFF0000L, Math.Max(4096L, rest * 8));
-            AmdBody.Decode(order == Endian.Big ? AlzFormat.PrsBE : AlzFormat.PrsLE, null, source, destination, 0, 0, 0, guess, false);
+            byte[] body = AmdBody.RentRest(source, out int length);
+            try { Decode(body, length, source, destination, order); }
+            finally { System.Buffers.ArrayPool<byte>.Shared.Return(body); }
         }
 
-        // PRS.cs:161-218 (private there): which bit / byte order do the first tokens make sense in?
-        private static Endian? GetByteOrder(Stream stream)
+        private static unsafe void Decode(byte[] body, int length, Stream source, Stream destination, Endian order)
         {
-            byte flag = stream.PeekByte();
-            if (flag > 12 && (flag & 0x1) == 1 && ValidateByteOrder(stream, Endian.Little))
-                return Endian.Little;
-            if ((flag & 128) == 128 && ValidateByteOrder(stream, Endian.Big))
-                return Endian.Big;
-            return null;
+            uint guess = (uint)Math.Min(0x7FFF0000L, Math.Max(4096L, (long)length * 8));
+            AmdBody.DecodeRented(order == Endian.Big ? AlzFormat.PrsBE : AlzFormat.PrsLE, null, body, length, source, destination, 0, 0, 0, guess, false);
         }
 
-        private static bool ValidateByteOrder(Stream stream, Endian order)
+        /// <summary>
+        /// The reference picks its first attempt by looking at how the stream opens (PRS.cs:161-218, private there): a first flag
+        /// byte that starts with a literal bit in the order in question, followed by tokens whose first four matches all reach
+        /// back no further than the bytes produced so far (or by the zero word).  Restated over the rented buffer: a bit cursor
+        /// over bytes, no Stream and no FlagReader.
+        /// </summary>
+        private static class PrsOpening
         {
-            int i = 3, produced = 0;
-            long startPos = stream.Position;
-            FlagReader flag = new FlagReader(stream, order);
-            try
+            internal static bool LooksLike(byte[] d, int n, Endian order)
             {
-                while (stream.Position < stream.Length)
+                if (n == 0) return false;
+                bool big = order == Endian.Big;
+                if (big ? (d[0] & 0x80) == 0 : !(d[0] > 12 && (d[0] & 1) == 1)) return false;     // PRS.cs:164-169
+                int at = 0, held = 0, left = 0, written = 0, matchesToSee = 4;
+                while (at < n)
                 {
-                    if (flag.Readbit()) { stream.Position++; produced++; continue; }
-                    int distance, length;
-                    if (flag.Readbit())
+                    int kind = 0;                                         // control bits of one token: "1", "01", "00hl"
+                    int extra = 0;
+                    for (int need = 1; need > 0; need--)
                     {
-                        distance = stream.ReadUInt16(order);
-                        if (distance == 0) return true;
-                        length = distance & 7;
-                        distance = 0x2000 - (distance >> 3);
-                        length = length == 0 ? stream.ReadUInt8() + 1 : length + 2;
+                        if (left == 0) { if (at >= n) return false; held = d[at++]; left = 8; }
+                        int bit = big ? (held >> (left - 1)) & 1 : (held >> (8 - left)) & 1;
+                        left--;
+                        if (kind == 0) { if (bit == 1) kind = 1; else { kind = 2; need = 2; } }
+                        else if (kind == 2) { if (bit == 1) kind = 3; else { kind = 4; need = 3; } }
+                        else extra = (extra << 1) | bit;
+                    }
+                    if (kind == 1) { at++; written++; continue; }
+                    int reach, span;
+                    if (kind == 3)
+                    {
+                        if (at + 2 > n) return false;
+                        int word = big ? (d[at] << 8) | d[at + 1] : (d[at + 1] << 8) | d[at];
+                        at += 2;
+                        if (word == 0) return true;
+                        reach = 0x2000 - (word >> 3);
+                        if ((word & 7) != 0) span = (word & 7) + 2;
+                        else { if (at >= n) return false; span = d[at++] + 1; }
                     }
                     else
                     {
-                        length = flag.ReadInt(2, true) + 2;
-                        distance = 0x100 - stream.ReadUInt8();
+                        if (at >= n) return false;
+                        span = extra + 2;
+                        reach = 0x100 - d[at++];
                     }
-                    if (distance > produced) return false;
-                    if (i == 0) return true;
-                    i--;
-                    produced += length;
+                    if (reach > written) return false;
+                    if (--matchesToSee == 0) return true;
+                    written += span;
                 }
                 return false;
             }
-            finally { stream.Position = startPos; }
         }
 
         /// <inheritdoc/>
@@ -105,7 +121,7 @@ namespace AuroraLib.Compression.Amd.Sega
         /// <summary>PRS.CompressHeaderless (PRS.cs:104-159).</summary>
         public static unsafe void CompressHeaderless(ReadOnlySpan<byte> source, Stream destination, Endian order = Endian.Little, CompressionSettings settings = default)
         {
-            if (!AmdContext.Available) { Managed.PRS.CompressHeaderless(source, destination, order, settings); return; }
+            if (!AmdBody.UseGpuForCompress(order == Endian.Big ? AlzFormat.PrsBE : AlzFormat.PrsLE, source.Length, settings)) { Managed.PRS.CompressHeaderless(source, destination, order, settings); return; }
             AmdBody.Encode(order == Endian.Big ? AlzFormat.PrsBE : AlzFormat.PrsLE, null, source, destination, settings, 0);
         }
     }

@@ -52,7 +52,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <inheritdoc/>
         public void Compress(ReadOnlySpan<byte> source, Stream destination, CompressionSettings settings = default)   // Yay0.cs:62-78
         {
-            if (!AmdContext.Available) { var m = new Managed.Yay0 { FormatByteOrder = FormatByteOrder }; m.Compress(source, destination, settings); return; }
+            if (!AmdBody.UseGpuForCompress(AlzFormat.Yay0, source.Length, settings)) { var m = new Managed.Yay0 { FormatByteOrder = FormatByteOrder }; m.Compress(source, destination, settings); return; }
             using (MemoryStream body = new MemoryStream())
             {
                 // the native encoder writes flags | tokens | literals back to back and reports where the sections start

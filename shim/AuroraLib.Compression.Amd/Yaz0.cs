@@ -73,7 +73,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <summary>Yaz0.CompressHeaderless (Yaz0.cs:94-127).</summary>
         public static unsafe void CompressHeaderless(ReadOnlySpan<byte> source, Stream destination, CompressionSettings settings = default)
         {
-            if (!AmdContext.Available) { Managed.Yaz0.CompressHeaderless(source, destination, settings); return; }
+            if (!AmdBody.UseGpuForCompress(AlzFormat.Yaz0, source.Length, settings)) { Managed.Yaz0.CompressHeaderless(source, destination, settings); return; }
             AmdBody.Encode(AlzFormat.Yaz0, null, source, destination, settings, 0);
         }
     }
