@@ -1310,14 +1310,21 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, co
     }
     if (lzp && wrapper_lzss) return ALZ_E_UNSUPPORTED;                      // one LZSS geometry per batch
     // 1. candidates: every offset some container identifies
-    struct Cand { size_t off; uint32_t container; alz_stream st; size_t hdr; };
+    struct Cand { size_t off; uint32_t container; alz_stream st; size_t hdr; bool swapped; };
     std::vector<Cand> cands;
     const uint32_t kMaxStream = 256u << 20;
     for (size_t i = 0; i < len; i++) {
         for (uint32_t k = 0; k < nc; k++) {
             if (!alz_container_is_match(containers[k], src + i, len - i)) continue;
-            Cand c; c.off = i; c.container = containers[k];
-            if (describe_stream(containers[k], big, src + i, len - i, &c.st, &c.hdr) && c.st.decom_len <= kMaxStream && c.hdr <= len - i) cands.push_back(c);
+            Cand c; c.off = i; c.container = containers[k]; c.swapped = false;
+            if (describe_stream(containers[k], big, src + i, len - i, &c.st, &c.hdr) && c.hdr <= len - i) {
+                // Yaz0 / Yaz1: a size that only makes sense in the other byte order (Yaz0.cs:66-78 -- the first attempt runs out of input,
+                // the second one reads the field reversed) is decoded with the reversed size at once; nothing is retried behind it
+                if ((c.container == ALZ_C_YAZ0 || c.container == ALZ_C_YAZ1) && c.st.decom_len > kMaxStream && __builtin_bswap32(c.st.decom_len) <= kMaxStream) {
+                    c.st.decom_len = __builtin_bswap32(c.st.decom_len); c.swapped = true;
+                }
+                if (c.st.decom_len <= kMaxStream) cands.push_back(c);
+            }
             break;                                                          // Identify(): the first match decides
         }
     }
@@ -1355,7 +1362,7 @@ int alz_container_scan(alz_ctx* ctx, const uint32_t* containers, uint32_t nc, co
             if (c.off < next_free) continue;
             const uint8_t* d_out = (uint8_t*)d_dst.p + ss[k].dst_off;
             DevBuf d_retry(ctx);
-            if (rs[k].status != ALZ_ST_OK && (c.container == ALZ_C_YAZ0 || c.container == ALZ_C_YAZ1)) {
+            if (rs[k].status != ALZ_ST_OK && !c.swapped && (c.container == ALZ_C_YAZ0 || c.container == ALZ_C_YAZ1)) {
                 // Yaz0.Decompress catches the failure and decodes again with the size field read in the other byte order
                 // (Yaz0.cs:66-78): one more single-stream decode for this candidate
                 alz_stream s2 = ss[k];

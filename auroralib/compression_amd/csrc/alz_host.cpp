@@ -109,6 +109,7 @@ struct alz_ctx {
     // one piece overlaps the PCIe transfer of the other
     void* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};                     // pin_ev[k] was recorded behind a DMA on pin[k] and nobody has waited for it yet
     // grow-only scratch of download_packed (item table + dense copy)
     void* d_items = nullptr; size_t d_items_cap = 0;
     void* d_pack = nullptr; size_t d_pack_cap = 0;
@@ -400,6 +401,17 @@ static int ensure_pinned(alz_ctx* c) {
     c->pin_cap = kPinBytes;                                  // (set last: everything above exists from here on)
     return ALZ_OK;
 }
+// A pinned buffer is only touched by the host once the DMA recorded on it has completed -- also across calls: the flag lives in
+// the context, so a second staging call that follows at once (or one that follows a call that returned early with an error)
+// waits for the first call's DMA instead of overwriting its source.
+static int pin_wait(alz_ctx* c, int k) {
+    if (c->pin_busy[k]) { HIP_TRY(hipEventSynchronize(c->pin_ev[k])); c->pin_busy[k] = false; }
+    return ALZ_OK;
+}
+static int pin_mark(alz_ctx* c, int k) {
+    HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream)); c->pin_busy[k] = true;
+    return ALZ_OK;
+}
 // host (pageable) -> device through the two pinned buffers: the memcpy of piece k + 1 overlaps the DMA of piece k
 static int staged_h2d(alz_ctx* c, void* d_dst, const uint8_t* h_src, size_t bytes) {
     if (!bytes) return ALZ_OK;
@@ -407,14 +419,14 @@ static int staged_h2d(alz_ctx* c, void* d_dst, const uint8_t* h_src, size_t byte
         HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
         return ALZ_OK;
     }
-    size_t done = 0; int k = 0; bool used[2] = {false, false};
+    size_t done = 0; int k = 0, rc;
     while (done < bytes) {
         const size_t n = bytes - done < c->pin_cap ? bytes - done : c->pin_cap;
-        if (used[k]) HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        if ((rc = pin_wait(c, k))) return rc;
         c->copy((uint8_t*)c->pin[k], h_src + done, n);
         HIP_TRY(hipMemcpyAsync((uint8_t*)d_dst + done, c->pin[k], n, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
-        used[k] = true; done += n; k ^= 1;
+        if ((rc = pin_mark(c, k))) return rc;
+        done += n; k ^= 1;
     }
     return ALZ_OK;
 }
@@ -426,18 +438,20 @@ static int staged_d2h(alz_ctx* c, uint8_t* h_dst, const void* d_src, size_t byte
         HIP_TRY(hipStreamSynchronize(c->stream));
         return ALZ_OK;
     }
-    size_t issued = 0, copied = 0; int k = 0;
+    size_t issued = 0, copied = 0; int k = 0, rc;
     size_t len[2] = {0, 0};
     {   const size_t n = bytes < c->pin_cap ? bytes : c->pin_cap;
-        HIP_TRY(hipMemcpyAsync(c->pin[0], d_src, n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(c->pin_ev[0], c->stream)); len[0] = n; issued = n; }
+        HIP_TRY(hipMemcpyAsync(c->pin[0], d_src, n, hipMemcpyDeviceToHost, c->stream));   // (stream order keeps it behind an earlier DMA out of pin[0])
+        if ((rc = pin_mark(c, 0))) return rc;
+        len[0] = n; issued = n; }
     while (copied < bytes) {
         if (issued < bytes) {
             const size_t n = bytes - issued < c->pin_cap ? bytes - issued : c->pin_cap;
             HIP_TRY(hipMemcpyAsync(c->pin[k ^ 1], (const uint8_t*)d_src + issued, n, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipEventRecord(c->pin_ev[k ^ 1], c->stream)); len[k ^ 1] = n; issued += n;
+            if ((rc = pin_mark(c, k ^ 1))) return rc;
+            len[k ^ 1] = n; issued += n;
         }
-        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        if ((rc = pin_wait(c, k))) return rc;
         c->copy(h_dst + copied, (const uint8_t*)c->pin[k], len[k]);
         copied += len[k]; k ^= 1;
     }
@@ -488,13 +502,14 @@ static int download_windows(alz_ctx* c, const void* d_base, const std::vector<ou
         const uint64_t a = lo + w * W, n = hi - a < W ? hi - a : W;
         hipError_t e = hipMemcpyAsync(c->pin[k], (const uint8_t*)d_base + a, n, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipEventRecord(c->pin_ev[k], c->stream);
+        if (e == hipSuccess) c->pin_busy[k] = true;
         return e;
     };
     HIP_TRY(issue(0, 0));
     for (uint64_t w = 0; w < nwin; w++) {
         const int k = (int)(w & 1);
         if (w + 1 < nwin) HIP_TRY(issue(w + 1, k ^ 1));
-        HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        { const int rcw = pin_wait(c, k); if (rcw) return rcw; }
         const uint64_t a = lo + w * W, b = a + W;
         while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
         c->jobs.clear();
@@ -573,6 +588,8 @@ int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, con
     for (uint32_t i = 0; i < n; i++) {
         if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
         if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+        if (streams[i].format == ALZ_FMT_LZ4_BLOCK && streams[i].aux0 > streams[i].dst_off)   // (as alz_decode_batch_multi: the history lies in front of the block's output)
+            return fail(ALZ_E_INVALID, "stream %u: LZ4 history (aux0) reaches in front of the destination buffer", i);
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
@@ -793,11 +810,11 @@ static int upload_segs(alz_ctx* c, void* d_base, const std::vector<in_seg>& segs
         return ALZ_OK;
     }
     const uint64_t W = c->pin_cap;
-    size_t first = 0; bool used[2] = {false, false};
+    size_t first = 0; int rcp;
     for (uint64_t a = 0, w = 0; a < total; a += W, w++) {
         const int k = (int)(w & 1);
         const uint64_t b = a + W < total ? a + W : total;
-        if (used[k]) HIP_TRY(hipEventSynchronize(c->pin_ev[k]));
+        if ((rcp = pin_wait(c, k))) return rcp;
         while (first < segs.size() && segs[first].dev + segs[first].len <= a) first++;
         c->jobs.clear();
         for (size_t i = first; i < segs.size() && segs[i].dev < b; i++) {
@@ -806,8 +823,7 @@ static int upload_segs(alz_ctx* c, void* d_base, const std::vector<in_seg>& segs
         }
         c->pool->run(c->jobs);
         HIP_TRY(hipMemcpyAsync((uint8_t*)d_base + a, c->pin[k], b - a, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(c->pin_ev[k], c->stream));
-        used[k] = true;
+        if ((rcp = pin_mark(c, k))) return rcp;
     }
     return ALZ_OK;
 }

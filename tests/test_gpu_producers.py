@@ -164,3 +164,16 @@ def test_scan_retries_a_failed_yaz0_candidate_with_the_size_byte_swapped(test_bm
     hits = S.scan(junk + le_file + junk, [F.Yaz0])
     assert len(hits) == 1 and hits[0][0] == len(junk) and hits[0][3] == raw and hits[0][1] == len(junk) + len(le_file)   # ... the retry decodes
     assert F.Yaz0().Decompress(le_file) == raw                        # (Decompress itself always retried)
+
+
+def test_scan_keeps_a_yaz0_candidate_whose_first_size_reading_is_absurd(test_bmp):
+    """A little-endian size with a non-zero low byte (0x00012345) reads big-endian as 0x45230100 -- more than any stream the scan
+    takes: the managed first attempt runs out of input and the retry reads the field reversed (Yaz0.cs:66-78); the scan decodes such
+    a candidate with the reversed size at once instead of dropping it."""
+    raw = test_bmp[9000:9000 + 0x12345]
+    body = O.encode_stream(A.FMT_YAZ0, raw, quality=8)[0]
+    le_file = b"Yaz0" + (0x12345).to_bytes(4, "little") + bytes(8) + body
+    junk = bytes(range(3, 120))
+    hits = S.scan(junk + le_file + junk, [F.Yaz0])
+    assert len(hits) == 1 and hits[0][0] == len(junk) and hits[0][3] == raw and hits[0][1] == len(junk) + len(le_file)
+    assert F.Yaz0().Decompress(le_file) == raw

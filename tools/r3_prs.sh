@@ -1,7 +1,7 @@
-# usage (GPU box): bash tools/r3_prs.sh  -- PRS parity tests, then kernel ms of PRS (product build and variants under build/variants/prs_*.so)
+# usage (GPU box): bash tools/r3_prs.sh  -- kernel ms of PRS (product build and variants under build/variants/prs_*.so), then counters of the product build
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -x -q -k "prs or PRS or mixed or kat" 2>&1 | tail -5
-bash tools/ab.sh prs_be prs_le yaz0
+bash tools/ab.sh prs_be
+ALZ_PRS2=0 bash tools/ab.sh prs_be
 cp auroralib/compression_amd/libauroralz.so /tmp/keep.so
 for v in build/variants/prs_*.so; do
   [ -f "$v" ] || continue
@@ -9,3 +9,6 @@ for v in build/variants/prs_*.so; do
   echo "== $v"; bash tools/ab.sh prs_be
 done
 cp /tmp/keep.so auroralib/compression_amd/libauroralz.so
+bash tools/gpu_profile.sh r03_prs_be prs_be > /dev/null 2>&1
+tail -28 gpurun_out/r03_prs_be.md
+bash tools/ab.sh lzo lz4_block snappy_raw mixed
