@@ -47,6 +47,8 @@ def load():
     lib.alz_decode_batch.argtypes = [vp, vp, u32, vp, sz, vp, vp, sz, vp]
     lib.alz_decode.argtypes = [vp, u32, vp, vp, u32, u32, u32, u32, vp, u32, vp]
     lib.alz_encode_batch.argtypes = [vp, vp, vp, u32, vp, sz, vp, vp, sz, vp, vp]
+    lib.alz_encode_batch_device.argtypes = [vp, vp, vp, u32, vp, sz, vp, vp, sz, vp, vp]
+    lib.alz_encode_batch_multi.argtypes = [C.POINTER(vp), u32, vp, vp, u32, vp, sz, vp, vp, sz, vp, vp, vp]
     lib.alz_plan_create.argtypes = [vp, vp, u32, vp, C.POINTER(vp)]
     lib.alz_plan_execute.argtypes = [vp, vp, vp, vp, vp]
     lib.alz_plan_execute_timed.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]
@@ -60,6 +62,7 @@ def load():
     lib.alz_memset_d.argtypes = [vp, vp, C.c_int, sz]
     lib.alz_synchronize.argtypes = [vp]
     lib.alz_ctx_set_exact_kernels.argtypes = [vp, C.c_int]
+    lib.alz_ctx_set_kernel_variant.argtypes = [vp, C.c_int]
     lib.alz_ctx_release_scratch.argtypes = [vp]
     lib.alz_decode_batch_multi.argtypes = [C.POINTER(vp), u32, vp, u32, vp, sz, vp, vp, sz, vp, vp]
     lib.alz_partition_batch.argtypes = [u32, vp, u32, vp, vp]

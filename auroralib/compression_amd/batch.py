@@ -46,6 +46,10 @@ class Context:
         """Kernel family of this context: the exact one-token-at-a-time kernels instead of the lane-parallel ones."""
         check(self.lib.alz_ctx_set_exact_kernels(self.h, 1 if on else 0))
 
+    def set_kernel_variant(self, variant):
+        """alz_ctx_set_kernel_variant: 0 the library chooses, 1 / 2 one / two wavefronts per stream where both shapes exist."""
+        check(self.lib.alz_ctx_set_kernel_variant(self.h, variant))
+
     def release_scratch(self):
         """alz_ctx_release_scratch: return the grow-only staging / encoder scratch of the host-buffer calls to the device."""
         check(self.lib.alz_ctx_release_scratch(self.h))
@@ -94,6 +98,17 @@ class Context:
         check(self.lib.alz_encode_batch(self.h, C.byref(lz) if lz is not None else None, C.byref(st), n, _vp(src), src.nbytes, streams,
                                         _vp(dst), dst_bytes, res, aux))
         return dst, res, aux
+
+    def encode_batch_device(self, streams, d_src, src_bytes, d_dst, dst_bytes, quality=8, lz=None, strategy=0, min_distance=0, max_window_bits=0):
+        """alz_encode_batch_device: raw buffers already in HBM at d_src, compressed streams left in HBM at d_dst (offsets of
+        `streams` are relative to the two device pointers).  Returns (results, aux); last_kernel_ms() is the device time."""
+        n = len(streams)
+        res = (A.Result * n)()
+        aux = (A.EncodeAux * n)()
+        st = A.Settings(quality, max_window_bits, strategy, min_distance)
+        check(self.lib.alz_encode_batch_device(self.h, C.byref(lz) if lz is not None else None, C.byref(st), n, d_src, src_bytes, streams,
+                                               d_dst, dst_bytes, res, aux))
+        return res, aux
 
     # ---- device memory
     def malloc(self, nbytes):
@@ -170,3 +185,19 @@ def decode_batch_multi(ctxs, streams, src, dst_bytes, lz=None):
     check(lib.alz_decode_batch_multi(hs, len(ctxs), C.byref(lz) if lz is not None else None, n, _vp(src), src.nbytes, streams,
                                      _vp(dst), dst_bytes, res, _vp(part)))
     return dst, res, part[:n]
+
+
+def encode_batch_multi(ctxs, streams, src, dst_bytes, quality=8, lz=None, strategy=0, min_distance=0, max_window_bits=0):
+    """alz_encode_batch_multi: ONE batch of raw buffers over several contexts (one per GPU; host threads inside the library)."""
+    lib = load()
+    n = len(streams)
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros(max(dst_bytes, 1), dtype=np.uint8)
+    res = (A.Result * n)()
+    aux = (A.EncodeAux * n)()
+    part = np.zeros(max(n, 1), dtype=np.uint32)
+    st = A.Settings(quality, max_window_bits, strategy, min_distance)
+    hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    check(lib.alz_encode_batch_multi(hs, len(ctxs), C.byref(lz) if lz is not None else None, C.byref(st), n, _vp(src), src.nbytes, streams,
+                                     _vp(dst), dst_bytes, res, aux, _vp(part)))
+    return dst, res, aux, part[:n]

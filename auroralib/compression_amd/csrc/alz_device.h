@@ -143,7 +143,7 @@ struct OutWin {
     // the ring: kernels that use it allocate ALZ_WIN_SLACK bytes behind the ring that mirror its first bytes.  The byte-wise
     // writers below only touch the ring proper and mark the mirror stale; the chunked phase refreshes it before it reads.
     bool slack_dirty;
-#ifdef ALZ_EMIT_STATS
+#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
     u32 st_steps, st_passes, st_chunks, st_dep;   // experiment build only: steps, passes, chunks, dependent chunks of the byte phase
 #endif
 
@@ -152,7 +152,7 @@ struct OutWin {
         fl = lw >= 4096 ? 1024u : (lw >> 2);
         oshift = (u32)(reinterpret_cast<uintptr_t>(dst_) & 15u);
         produced = 0; flushed = 0; slack_dirty = false;
-#ifdef ALZ_EMIT_STATS
+#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
         st_steps = st_passes = st_chunks = st_dep = 0;
 #endif
         // E2: the reference's rented ring is treated as zero-filled

@@ -215,7 +215,7 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
         out.produced = e.O + e.T;
         return e.fin;
     } else {
-#if defined(ALZ_EXP) && ALZ_EXP == 1
+#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EXP) && ALZ_EXP == 1
     out.produced = e.O + e.T; out.flushed = out.produced & ~1023u;       // timing experiment: front end + token prologue only (no output)
     if (e.kept && e.clen == 0x12345u) scratch[lane] = (u8)e.desc;
 #else

@@ -14,9 +14,11 @@
 // so MatchSearch(p) is a PURE function of the data, and the parse (FindNextBestMatch :157-212) only consumes it.
 // Three stages:
 //   A  enc_prev_cu_kernel       prev(p) for the 4-byte hash (and the min-length hash when quality >= 10): one workgroup of 16
-//                               wavefronts per stream, the head table in LDS, 2^(hashBits - 15) passes.  (enc_prev_kernel: the
-//                               same links through head tables in HBM scratch, one wavefront per stream -- the first form, kept
-//                               behind ALZ_ENC_PREV_CU=0; enc_prev_split / _lds / _block: measured experiments.)
+//                               wavefronts per stream, the head table in LDS.  Matches that reach back at most 8 KiB (every
+//                               format but LZ4 / LZO / Snappy / FastLZ / RefPack ...): ONE pass whatever the hash width, through a
+//                               14-bit table and a ring of tags and skip links; otherwise 2^(hashBits - 15) passes.  (The earlier
+//                               forms -- head tables in HBM, a counting sort, hash-partitioned wavefronts, one wavefront per
+//                               stream on LDS -- are in the history of this file and in DESIGN.md 4.5 with their numbers.)
 //   B  enc_match_kernel         one lane per position: the chain walk of MatchSearch/ChainMatches (:214-282) over prev(),
 //                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
@@ -52,283 +54,8 @@ __device__ __forceinline__ u64 load64(const u8* p) { u64 v; __builtin_memcpy(&v,
 
 __device__ __forceinline__ u32 scan_add(u32 v);
 
-#ifdef ALZ_CU_DEBUG
-__device__ unsigned long long alz_cu_dbg[8];     // pieces tried / failed per level, position-by-position chunks, narrow chunks; kernel B: lanes with a candidate, trips of its loop
-#define ALZ_CU_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&alz_cu_dbg[i], 1ull); } while (0)
-#else
-#define ALZ_CU_COUNT(i) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------------------- kernel A
-template <bool MINT>
-__global__ __launch_bounds__(64) void enc_prev_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
-                                                      const u32* __restrict__ index_list, u32 count, u32 first_slot,
-                                                      int* __restrict__ head4_all, int* __restrict__ headm_all,
-                                                      int* __restrict__ prev4, int* __restrict__ prevm,
-                                                      const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    __shared__ u8 slot_owner[256];
-    __shared__ u8 slot_flag[256];
-    const u32 bid = blockIdx.x;
-    if (bid >= count) return;
-    const int lane = (int)threadIdx.x;
-    const u32 sid = index_list[bid];
-    const alz_stream st = streams[sid];
-    const u8* data = src_base + st.src_off;
-    const int n = (int)st.src_len - tail_skip;            // LZ4 searches source[0 : n-5]  (LZ4.cs:208)
-    const int limit = n - 4;                              // FindNextBestMatch :159
-    int* head4 = head4_all + ((size_t)(first_slot + bid) << g.hash_bits);
-    int* headm = MINT ? headm_all + ((size_t)(first_slot + bid) << 16) : nullptr;
-    int* p4 = prev4 + pos_off[sid];
-    int* pm = MINT ? prevm + pos_off[sid] : nullptr;
-    for (int i = lane; i < 256; i += 64) slot_flag[i] = 0;
-    __syncthreads();
-    for (int c = 0; c <= limit; c += 64) {
-        const int pos = c + lane;
-        const bool act = pos <= limit;
-        u32 v = act ? load32(data + pos) : 0u;
-        for (int pass = 0; pass < (MINT ? 2 : 1); pass++) {
-            // ComputeHash  LzChainMatchFinder.cs:288-299
-            u32 h = pass == 0 ? (((v * 2654435761u) >> (32 - g.hash_bits)) & ((1u << g.hash_bits) - 1u))
-                              : ((((v & g.min_mask) * 2654435761u) >> 16) & 0xFFFFu);
-            int* head = pass == 0 ? head4 : headm;
-            // lanes that share a hash inside this step must see each other in position order
-            const u32 slot = h & 255u;
-            if (act) slot_owner[slot] = (u8)lane;
-            __syncthreads();
-            const bool lost = act && slot_owner[slot] != (u8)lane;
-            if (lost) slot_flag[slot] = 1;
-            __syncthreads();
-            bool contested = act && slot_flag[slot] != 0;
-            __syncthreads();
-            if (lost) slot_flag[slot] = 0;
-            int old = -1;
-            if (act) old = __hip_atomic_load(&head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int prev = old;
-            bool writer = act;
-            u64 todo = __ballot(contested);
-            while (todo) {
-                const int l0 = (int)__builtin_ctzll(todo);
-                const u32 hv = (u32)__builtin_amdgcn_readlane((int)h, l0);
-                const u64 grp = __ballot(contested && h == hv);
-                if (contested && h == hv) {
-                    const u64 below = grp & ((1ull << lane) - 1ull);
-                    if (below) prev = c + 63 - (int)__builtin_clzll(below);
-                    writer = (grp >> lane) <= 1ull;                    // highest lane of the group owns the new head
-                }
-                todo &= ~grp;
-            }
-            if (writer) head[h] = pos;
-            if (act) { if (pass == 0) p4[pos] = prev; else pm[pos] = prev; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // head stores reach L2 before the next step reads them
-    }
-}
-
-// Kernel A for windows up to 4 KiB WITHOUT the head table -- a round-2 experiment, bit-identical, kept behind ALZ_ENC_PREV_BLOCK=1
-// because it LOSES: 165 ms per 10 000 x 256 KiB against the 80 (Q0) / 103 (Q8) of enc_prev_kernel.  Kernel B stops at maxDistance, so
-// prev(p) only matters when it lies inside the window, and whatever lies further back may as well be "none" (the chain walk ends
-// either way: LzChainMatchFinder.cs:259-260).  The positions of a stream are cut into blocks of W >= maxDistance; a block looks at
-// its own W positions and the W in front of them, and finds prev() for its own by a counting sort on LDS: bucket = top 12 hash
-// bits, stable inside a bucket because ONE wavefront places the positions in order (lanes that meet in a bucket inside one step
-// are ranked by lane), so the previous position with the same hash is the first equal tag found walking back from a position's
-// own slot.  Every block is independent -- 640 000 of them per launch -- and touches global memory only to read its 2 W input
-// bytes and to write W links.  Why it loses: 52 KB of LDS per block leave three wavefronts per CU, and the placement is a chain
-// of dependent LDS round trips per 64 positions (count + prefix 31 ms, ordered placement 69 ms, walks 65 ms: `-DALZ_PBEXP`
-// builds of round 2); the order-free variant (plain atomics, whole-bucket scans) is quadratic in the buckets that runs of equal
-// bytes fill (1 815 ms on the synthetic data); bucket = LOW hash bits was 4x slower at 19 hash bits (uneven buckets).  A radix
-// sort over four wavefronts per block needs two 32 KB key buffers (two blocks per CU) and ~96 dependent steps: no better.
-#define ALZ_PB_BITS 12
-#define ALZ_PB_N (1u << ALZ_PB_BITS)
-template <bool MINT>
-__global__ __launch_bounds__(64) void enc_prev_block_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
-                                                            const u32* __restrict__ index_list, u32 count,
-                                                            int* __restrict__ prev4, int* __restrict__ prevm,
-                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip, u32 W) {
-    // (one wavefront per block: its LDS instructions execute in order, so a read sees every lane's earlier writes -- the phases
-    // below are separated by compiler barriers only, never by a wait for outstanding LDS traffic)
-    extern __shared__ u32 pb_lds[];
-    u32* cnt = pb_lds;                                     // per bucket: (first slot << 16) | slots filled so far
-    u32* keys = pb_lds + ALZ_PB_N;                         // 2 W sorted keys: tag << 14 | position relative to the block's input range
-    u8* owner = reinterpret_cast<u8*>(keys + 2u * W);      // contest table of a step: the lane that claimed a bucket last
-    const u32 sid = index_list[blockIdx.y];
-    const alz_stream st = streams[sid];
-    const u8* data = src_base + st.src_off;
-    const int n = (int)st.src_len - tail_skip;
-    const int limit = n - 4;                               // FindNextBestMatch :159
-    const int out_lo = (int)(blockIdx.x * W);
-    if (out_lo > limit) return;
-    const int lane = (int)threadIdx.x;
-    const int out_hi = (int)(out_lo + W) <= limit + 1 ? (int)(out_lo + W) : limit + 1;
-    const int in_lo = blockIdx.x ? out_lo - (int)W : 0;
-    const int N = out_hi - in_lo;                          // <= 2 W
-    const u8* base = data + in_lo;
-    for (int pass = 0; pass < (MINT ? 2 : 1); pass++) {
-        int* out = (pass == 0 ? prev4 : prevm) + pos_off[sid] + in_lo;
-        const u32 hb = pass == 0 ? (u32)g.hash_bits : 16u, tshift = hb - ALZ_PB_BITS, mmask = pass == 0 ? 0xFFFFFFFFu : g.min_mask;
-        // ComputeHash  LzChainMatchFinder.cs:288-299; bucket = its top 12 bits (the well-mixed end of a multiplicative hash: with
-        // the low 12 bits of a 19-bit hash the buckets of this data were so uneven that the kernel ran 4x longer), tag = the rest
-        auto hash_of = [&](u32 v) -> u32 { return (((v & mmask) * 2654435761u) >> (32u - hb)) & ((1u << hb) - 1u); };
-        for (u32 i = (u32)lane; i < ALZ_PB_N; i += 64u) cnt[i] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        // 1. bucket sizes
-#pragma unroll 4
-        for (int i = lane; i < N; i += 64) atomicAdd(&cnt[hash_of(load32(base + i)) >> tshift], 1u);
-        __builtin_amdgcn_wave_barrier();
-        // 2. first slot of every bucket (exclusive prefix sum over the 4 096 counters, 64 per trip)
-        u32 run = 0;
-        for (u32 b0 = 0; b0 < ALZ_PB_N; b0 += 64u) {
-            const u32 c = cnt[b0 + (u32)lane];
-            const u32 inc = scan_add(c);
-            cnt[b0 + (u32)lane] = (run + inc - c) << 16;
-            run += (u32)__builtin_amdgcn_readlane((int)inc, 63);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // 3. positions in order, 64 per step: place them, then walk back inside the bucket to the previous equal tag
-        u32 vnext = lane < N ? load32(base + lane) : 0u;
-        for (int c0 = 0; c0 < N; c0 += 64) {
-            const int i = c0 + lane;
-            const bool act = i < N;
-            const u32 h = hash_of(vnext);
-            vnext = i + 64 < N ? load32(base + i + 64) : 0u;            // (the next step's bytes travel while this one works)
-            const u32 b = h >> tshift, tag = h & ((1u << tshift) - 1u);
-            // lanes that meet in a bucket inside this step are ranked by lane, the lowest of them reserves the slots for all
-            if (act) owner[b] = (u8)lane;
-            __builtin_amdgcn_wave_barrier();
-            const bool lost = act && owner[b] != (u8)lane;
-            u32 rank = 0, group = 1, lead = (u32)lane;
-            u64 todo = __ballot(lost);
-            while (todo) {
-                const u32 bv = (u32)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(todo));
-                const u64 grp = __ballot(act && b == bv);
-                if (act && b == bv) {
-                    rank = __builtin_amdgcn_mbcnt_hi((u32)(grp >> 32), __builtin_amdgcn_mbcnt_lo((u32)grp, 0u));
-                    group = (u32)__popcll(grp); lead = (u32)__builtin_ctzll(grp);
-                }
-                todo &= ~grp;
-            }
-            u32 x = 0;
-            if (act && rank == 0u) x = atomicAdd(&cnt[b], group);
-            if (__ballot(rank != 0u)) x = (u32)__builtin_amdgcn_ds_bpermute((int)(lead << 2), (int)x);
-            const u32 first = x >> 16, slot = first + (x & 0xFFFFu) + rank;
-            if (act) keys[slot] = (tag << 14) | (u32)i;
-            __builtin_amdgcn_wave_barrier();
-            if (act && in_lo + i >= out_lo) {
-                int prev = -1;
-                for (u32 t = slot; t > first; t--) {
-                    const u32 k = keys[t - 1u];
-                    if ((k >> 14) == tag) { prev = in_lo + (int)(k & 0x3FFFu); break; }
-                }
-                out[i] = prev;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-// Kernel A, hash-partitioned (round 2): NC wavefronts per stream; wavefront `cls` owns the positions whose hash has
-// (h & (NC - 1)) == cls.  The classes touch disjoint head-table entries, so the wavefronts of a stream never talk to each
-// other, and each of them walks only 1 / NC of the table steps -- the dependent HBM round trips that make one stream take
-// 18 ms whatever the device does meanwhile.  Every wavefront still scans the whole input (a dword pair + v_alignbyte per
-// position: cheap next to a table round trip) and queues its own positions, in order, until 64 are there.
-// (Not for the min-length table of quality >= 10: that one is keyed by another hash.)
-template <int NC>
-__global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
-                                                            const u32* __restrict__ index_list, u32 count,
-                                                            int* __restrict__ head4_all, int* __restrict__ prev4,
-                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    __shared__ u8 slot_owner[256];
-    __shared__ u8 slot_flag[256];
-    __shared__ u32 qpos[320], qh[320];
-    const u32 bid = blockIdx.x / NC, cls = blockIdx.x % NC;
-    if (bid >= count) return;
-    const int lane = (int)threadIdx.x;
-    const u32 sid = index_list[bid];
-    const alz_stream st = streams[sid];
-    const u8* data = src_base + st.src_off;
-    const int n = (int)st.src_len - tail_skip;
-    const int limit = n - 4;
-    int* head = head4_all + ((size_t)bid << g.hash_bits);
-    int* p4 = prev4 + pos_off[sid];
-    for (int i = lane; i < 256; i += 64) slot_flag[i] = 0;
-    __syncthreads();
-    u32 qn = 0;
-    for (int c = 0; c <= limit || qn; c += 256) {
-        if (c <= limit) {
-            // four groups of 64 positions per trip: their eight loads are in flight together
-            u32 hh[4]; bool ac[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int pos = c + 64 * k + lane;
-                ac[k] = pos <= limit;
-                u32 v = 0;
-                if (ac[k]) {
-                    const uintptr_t a = reinterpret_cast<uintptr_t>(data + pos);
-                    const u32* w = reinterpret_cast<const u32*>(a & ~(uintptr_t)3);
-                    v = __builtin_amdgcn_alignbyte(w[1], w[0], (u32)(a & 3));            // (source buffers carry 64 bytes of slack)
-                }
-                hh[k] = ((v * 2654435761u) >> (32 - g.hash_bits)) & ((1u << g.hash_bits) - 1u);   // ComputeHash  LzChainMatchFinder.cs:288-299
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool mine = ac[k] && (hh[k] & (u32)(NC - 1)) == cls;
-                const u64 m = __ballot(mine);
-                if (mine) { const u32 r = qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); qpos[r] = (u32)(c + 64 * k + lane); qh[r] = hh[k]; }
-                qn += (u32)__popcll(m);
-            }
-            __syncthreads();
-        }
-        const bool last = c + 256 > limit;
-        while (qn >= 64u || (last && qn)) {
-            const u32 nstep = qn < 64u ? qn : 64u;
-            const bool act = (u32)lane < nstep;
-            const u32 h = act ? qh[lane] : 0u;
-            const int pos = act ? (int)qpos[lane] : 0;
-            // lanes that share a hash inside this step must see each other in position order
-            const u32 slot = (h >> 3) & 255u;                     // (the low bits are the class)
-            if (act) slot_owner[slot] = (u8)lane;
-            __syncthreads();
-            const bool lost = act && slot_owner[slot] != (u8)lane;
-            if (lost) slot_flag[slot] = 1;
-            __syncthreads();
-            const bool contested = act && slot_flag[slot] != 0;
-            __syncthreads();
-            if (lost) slot_flag[slot] = 0;
-            int old = -1;
-            if (act) old = __hip_atomic_load(&head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int prev = old;
-            bool writer = act;
-            u64 todo = __ballot(contested);
-            while (todo) {
-                const int l0 = (int)__builtin_ctzll(todo);
-                const u32 hv = (u32)__builtin_amdgcn_readlane((int)h, l0);
-                const u64 grp = __ballot(contested && h == hv);
-                const u64 below = grp & ((1ull << lane) - 1ull);
-                const int from = below ? 63 - (int)__builtin_clzll(below) : lane;
-                const int pp = __builtin_amdgcn_ds_bpermute(from << 2, pos);   // position of the next lower lane of my group
-                if (contested && h == hv) {
-                    if (below) prev = pp;
-                    writer = (grp >> lane) <= 1ull;                    // highest lane of the group owns the new head
-                }
-                todo &= ~grp;
-            }
-            if (writer) head[h] = pos;
-            if (act) p4[pos] = prev;
-            // the rest of the queue moves down
-            for (u32 base = 0; 64u + base < qn; base += 64u) {          // (in place, front to back: a slice is read before it is overwritten)
-                const bool mv = 64u + base + (u32)lane < qn;
-                u32 mv_p = 0, mv_h = 0;
-                if (mv) { mv_p = qpos[64u + base + lane]; mv_h = qh[64u + base + lane]; }
-                __syncthreads();
-                if (mv) { qpos[base + lane] = mv_p; qh[base + lane] = mv_h; }
-                __syncthreads();
-            }
-            qn -= nstep;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // head stores reach L2 before the next step reads them
-            __syncthreads();
-        }
-    }
-}
-
 // Kernel A with the head table in LDS: ONE workgroup of 16 wavefronts per stream, one stream per CU.  The table of 2^15 entries is
 // 128 KB of the CU's 160; a finder with more hash bits takes 2^(hashBits - 15) passes over the stream, pass k owning the hashes whose
 // top bits are k (entries of different hashes never meet, so the passes are independent).  Inside a pass the table is cut into 16
@@ -345,14 +72,27 @@ __global__ __launch_bounds__(64) void enc_prev_split_kernel(const u8* __restrict
 // U: groups of 64 entries a wavefront brings to a chunk -- 2 for one pass (a chunk of 2 048 positions), 3 for several (`stage` holds 192
 // entries per wavefront, a slice fills half of that on average: the synthetic streams overfilled a 128-entry stage at 3/4 in a third of
 // their chunks)
-template <int U>
+// WIN (formats whose matches reach back at most 8 KiB: a finder with more than 15 hash bits would take 2^(hashBits - 15) passes): ONE
+// pass whatever the hash width.  The table is indexed by the low 14 hash bits only, so an exchange hands a position the previous one
+// of its table word -- a chain through ALL hashes that share the word -- and the position finds its prev() by walking that chain to
+// the first entry whose remaining hash bits (the tag) equal its own.  Kernel B never follows a link beyond maxDistance (:259-260), so
+// the walk ends there with "none", and only the last 16 Ki positions have to be remembered: a ring of one tag byte (written where the
+// position is hashed) and one 16-bit link (written by the owner of the word) per position -- 48 KB beside a 64 KB table.  Inside
+// 8 KiB a 14-bit word is shared by half a random position on average, so the walk is short; what the passes cost -- every pass hashes
+// the whole stream again, 67 of 138 ms at quality 8 -- is gone.  Entries wait for their step at most DRW positions, so that no ring
+// slot is overwritten (by the position 16 Ki further on) while a walk may still read it.
+template <int U, bool WIN>
 __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                            const u32* __restrict__ index_list, u32 count, int* __restrict__ prev4,
                                                            int* __restrict__ prevm, const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
     constexpr u32 ALZ_CU_QCAP = U == 2 ? 352u : 288u;          // (LDS: the table, the queues, the staging rows -- 160 KB)
-    __shared__ int T[(1 << 15) + 64];
+    constexpr u32 TB = WIN ? 14u : 15u;           // table bits
+    constexpr u32 RING = 16384u, RM = RING - 1u;  // WIN: positions remembered
+    __shared__ int T[(1 << TB) + 64];
     __shared__ u32 Q[16][ALZ_CU_QCAP];
-    __shared__ u32 stage[16][U * 64];             // several passes: a wavefront's entries of this pass, gathered from its slice
+    __shared__ u32 stage[16][WIN ? 1 : U * 64];   // several passes: a wavefront's entries of this pass, gathered from its slice
+    __shared__ u8 tagring[WIN ? RING : 1u];       // WIN: the hash bits above the table index, per position
+    __shared__ u16 linkring[WIN ? RING : 1u];     // WIN: distance to the previous entry of the same table word that has ANOTHER tag (0: none)
     __shared__ u32 cnts[16][16];                  // [wavefront][class]: entries of the current chunk
     __shared__ u32 qpub[32];                      // [class]: ring index behind the queue's last entry; [16 + class]: entries waiting
     __shared__ u32 spill[3];                      // a slice held more entries of this pass than `stage` takes (one flag per call, three in rotation)
@@ -374,7 +114,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     const u32 hb = (u32)g.hash_bits, hmask = (1u << hb) - 1u;
     // passes: 2^(hashBits - 15) for the 4-byte hash, and for finders with the min-length table (quality >= 10: keyed by another hash,
     // 16 bits, links into their own array) two more
-    const u32 npass4 = 1u << (hb - 15u), npassm = g.use_min_table ? 2u : 0u;
+    const u32 npass4 = WIN ? 1u : 1u << (hb - 15u), npassm = g.use_min_table ? (WIN ? 1u : 2u) : 0u;
     const u64 lanes_below = (1ull << lane) - 1ull;
     constexpr int CH = 1024 * U;
     // several passes: a wavefront looks at SB groups of 64 positions per chunk and keeps what belongs to the pass -- 3/4 of what
@@ -384,13 +124,13 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     for (u32 pass_all = 0; pass_all < npass4 + npassm; pass_all++) {
         const bool mt = pass_all >= npass4;       // a pass of the min-length table
         const u32 pass = mt ? pass_all - npass4 : pass_all;
-        const u32 npass = mt ? 2u : npass4;       // passes of this pass's table
+        const u32 npass = WIN ? 1u : (mt ? 2u : npass4);       // passes of this pass's table
         int* const p4 = mt ? pma : p4a;           // where this pass's links go
         const u32 vmask = mt ? g.min_mask : 0xFFFFFFFFu, hshift = mt ? 16u : 32u - hb, hmask2 = mt ? 0xFFFFu : hmask;
         int SB = npass == 1u ? U : (int)(npass * (u32)U * ALZ_CU_FILL4 / 4u);
         if (SB > 24) SB = 24;                     // (a slice stays below 32 Ki positions: 32 passes fill their staging rows a quarter)
         const int CHM = 1024 * SB;
-        for (u32 i = threadIdx.x; i < (1u << 15); i += 1024u) T[i] = -1;
+        for (u32 i = threadIdx.x; i < (1u << TB); i += 1024u) T[i] = -1;
         u32 qhead = 0, qn = 0;                    // the queue of class w (this wavefront's)
         if (lane == 0) { qpub[w] = 0; qpub[16 + w] = 0; }
         __syncthreads();
@@ -400,7 +140,8 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         auto entry_of = [&](int pos, u32 v, bool direct, u32& e, int hi = 0x7FFFFFFF) -> bool {
             const bool act = pos <= limit && pos < hi;             // (`hi`: a multiple of 64 -- whole groups in or out)
             const u32 h = (((v & vmask) * 2654435761u) >> hshift) & hmask2;      // ComputeHash :288-299 / the min-length table's :226-243 (one multiply either way)
-            bool keep = act && (h >> 15) == pass;
+            bool keep = act && (WIN || (h >> 15) == pass);
+            if (WIN) { if (act) tagring[(u32)pos & RM] = (u8)(h >> TB); }
             u32 wonly = 0;
             if (direct) {
                 // Runs (one byte, one pixel repeated) give every position the hash of a neighbour, all of them in one class.  A position
@@ -423,7 +164,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                 }
             }
-            e = ((u32)pos & 0xFFFFu) | wonly | ((h & 0x7FFFu) << 17);
+            e = ((u32)pos & 0xFFFFu) | wonly | (WIN ? (h & 0x3FFFu) << 18 : (h & 0x7FFFu) << 17);
             return keep;
         };
 
@@ -437,7 +178,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 u32 slot = qhead + (u32)lane; if (slot >= ALZ_CU_QCAP) slot -= ALZ_CU_QCAP;
                 const u32 e = Q[w][slot];
                 const int pos = cend1 - (int)(((u32)cend1 - e) & 0xFFFFu);
-                const u32 idx = actl ? e >> 17 : 0x8000u + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
+                const u32 idx = actl ? e >> (WIN ? 18 : 17) : (1u << TB) + (u32)lane;        // (idle lanes: a private word behind the table, no exec masks below)
                 // ONE exchange per lane: my position in, the word's previous content out.  Lanes of one step that share a word are
                 // served one after the other; served in lane order (= position order) each of them gets exactly its prev() -- the
                 // head from before the step for the first, the lane before for the others -- and the last one leaves the new head.
@@ -446,7 +187,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 // smallest value the group got back (it lies before every position of the step), the rest follows from the lanes.
                 const int got = __hip_atomic_exchange(&T[idx], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 int prev = got;
-#if defined(ALZ_CU_SLOWTEST)
+#if defined(ALZ_EXPERIMENTS) && defined(ALZ_CU_SLOWTEST)
                 const u64 bad = __ballot(actl && got >= __builtin_amdgcn_readfirstlane(pos));   // test build: every group goes the long way
 #else
                 const u64 bad = __ballot(actl && got > pos);
@@ -471,11 +212,64 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                         if ((mygrp >> lane) <= 1ull) Tv[idx] = pos;                      // the highest lane of a group leaves the new head
                     }
                 }
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 3
-                if (actl && prev == 0x12345678) p4[pos] = prev;          // timing experiment: no stores
-#else
+                if (WIN) {
+                    // `prev` = the previous position of my table word, whatever its hash.  The ring keeps per position its tag and ONE link:
+                    // the previous entry of its word with ANOTHER tag (what lies between has the position's own tag, so a walker that
+                    // stands on the position with a different tag may skip it: a run of one 4-byte pattern -- dozens of entries in one
+                    // word -- costs a walker one hop, not dozens).  My own link follows from prev's tag and link; then I walk: prev has
+                    // my tag (two positions in three), or I hop from tag run to tag run until one has it or maxDistance is behind me.
+                    // Lanes of this step that share a word see each other's links: reads of a round precede its writes (one
+                    // wavefront's LDS operations execute in order), and any link written so far is a valid, if shorter, skip.
+                    const u32 me = (u32)pos & RM;
+                    const u32 mytag = tagring[me];
+                    const int p0 = __builtin_amdgcn_readfirstlane(pos);        // candidates >= p0 are lanes of this step
+                    const bool has = actl && prev >= 0 && (u32)(pos - prev) <= 0xFFFFu;
+                    const u32 cs = (u32)(has ? prev : pos) & RM;
+                    const u32 t0 = tagring[cs], l0 = linkring[cs];
+                    const bool same = has && t0 == mytag, instep = has && prev >= p0;
+                    u32 mylink = 0;
+                    if (has) {
+                        if (!same || instep) mylink = (u32)(pos - prev);      // (same tag inside the step: provisional, refined below)
+                        else { const u32 far = (u32)(pos - prev) + l0; mylink = (l0 != 0u && far <= 0xFFFFu) ? far : 0u; }
+                    }
+                    if (actl) linkring[me] = (u16)mylink;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    bool chase = same && instep;                               // a chain of my tag inside the step: pointer jumping over it
+                    while (__ballot(chase)) {
+                        const int x = pos - (int)mylink;
+                        const u32 lx = linkring[(u32)(chase ? x : pos) & RM];
+                        const int y = x - (int)lx;
+                        const u32 ty = tagring[(u32)((chase && lx != 0u) ? y : pos) & RM];
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        if (chase) {
+                            const u32 far = mylink + lx;
+                            const bool ok = lx != 0u && far <= 0xFFFFu;
+                            mylink = ok ? far : 0u;
+                            chase = ok && y >= p0 && ty == mytag;
+                            linkring[me] = (u16)mylink;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    }
+                    const bool need = actl && !(e & 0x10000u);
+                    const bool inwin = has && pos - prev <= g.max_dist;
+                    int res = (same && inwin) ? prev : -1;
+                    int cand = prev;
+                    bool go = need && inwin && !same;
+                    if (go && !instep) {                                       // prev's link is final unless prev is a lane of this step
+                        if (l0 == 0u) go = false; else { cand -= (int)l0; go = pos - cand <= g.max_dist; }
+                    }
+                    while (__ballot(go)) {
+                        const u32 cs2 = (u32)(go ? cand : pos) & RM;
+                        const u32 t = tagring[cs2], dl = linkring[cs2];
+                        if (go) {
+                            if (t == mytag) { res = cand; go = false; }
+                            else if (dl == 0u) go = false;
+                            else { cand -= (int)dl; go = pos - cand <= g.max_dist; }
+                        }
+                    }
+                    prev = res;
+                }
                 if (actl && !(e & 0x10000u)) p4[pos] = prev;
-#endif
                 qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                 qn -= nstep;
             }
@@ -520,12 +314,14 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 tail_c = qpub[lane]; wait_c = qpub[16 + lane];
             }
             const bool last = cend > limit;
-            const bool drain = last || since + clen >= 32768;     // (nothing waits longer than 32 Ki positions + a chunk: 16 bits tell where it was)
+            // (nothing waits longer than 32 Ki positions + a chunk: 16 bits tell where it was.  WIN: no longer than the rings allow --
+            // a slot is reused 16 Ki positions on, walks reach back maxDistance, steps run one chunk behind the hashing)
+            const int drw = WIN ? ((int)(RING / (u32)CH) - (g.max_dist + CH - 1) / CH - 1) * CH : 32768;
+            const bool drain = last || since + clen >= drw;
             since = drain ? 0 : since + clen;
             const int cend1 = cend - 1;
             const bool narrow = __ballot(lane < 16 && wait_c + tot > ALZ_CU_QCAP) != 0ull;   // (the same answer in every wavefront)
             const u32 rounds = narrow ? 16u : 1u;
-            if (narrow) ALZ_CU_COUNT(5);
             for (u32 r = 0; r < rounds; r++) {
                 if (narrow) {
                     if (r) { __syncthreads(); if (lane < 16) { tail_c = qpub[lane]; } }
@@ -545,16 +341,13 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 __syncthreads();
                 // ---- my class: full steps of 64 (everything when the queue has to drain)
                 qn += (u32)__builtin_amdgcn_readlane((int)tot, (int)w);
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 1
-                qhead += qn; while (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP; qn = 0;      // timing experiment: no table steps
-#endif
                 if (narrow) steps(drain && r == 15u, cend1);
                 else if (npass != 1u) steps(drain, cend1);             // (several passes: waiting gains nothing, measured)
                 else { pend = true; pend_all = drain; pend_cend1 = cend1; }
             }
             return true;
         };
-        if (npass == 1u) {
+        if (WIN || npass == 1u) {
             u32 vnext[U];                         // the dwords of the next chunk's positions, loaded one chunk ahead
 #pragma unroll
             for (int u = 0; u < U; u++) { const int pos = (int)((w * U + (u32)u) * 64u) + lane; vnext[u] = load32(data + (pos < limit ? pos : (limit > 0 ? limit : 0))); }
@@ -570,7 +363,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 }
                 (void)finish(ent, keep, cbase + CH, CH, -1);
             }
-        } else {
+        } else if constexpr (!WIN) {
             // Several passes.  A piece of work is `sbn` groups of 64 positions per wavefront starting at `from`: every wavefront keeps what
             // its slice holds of this pass (through `stage`, in position order, at most U x 64 entries).  If some slice held more, nothing
             // is done and the piece is cut in two; a half that fails again goes position by position (1 024 U at a time, every entry
@@ -609,7 +402,6 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 u32 ent[U]; bool keep[U];
                 int cend, flag = -1;
                 if (lvl < 2) {
-                    ALZ_CU_COUNT(lvl);
                     par = par == 2u ? 0u : par + 1u;
                     if (threadIdx.x == 0) spill[par == 2u ? 0u : par + 1u] = 0;      // (the flag of the call after this one; last read two calls ago)
                     u32 fill = 0;
@@ -627,7 +419,6 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     for (int u = 0; u < U; u++) { keep[u] = !over && 64u * (u32)u + (u32)lane < fill; ent[u] = stage[w][64 * u + lane]; }
                     cend = from + sbn * 1024; flag = (int)par;
                 } else {
-                    ALZ_CU_COUNT(4);
                     const int to = from + sbn * 1024;
                     cend = from + CH < to ? from + CH : to;                  // (`to` need not be a multiple of 1 024 U away)
 #pragma unroll
@@ -637,12 +428,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                     if (cend < to) { pf[np] = cend; ps[np] = (to - cend) / 1024; pl[np] = 2; np++; }
                 }
-#if defined(ALZ_CU_EXP) && ALZ_CU_EXP == 4
-                if (ent[0] == 0x12345u && keep[0]) p4[0] = 1;             // timing experiment: the slices only
-                continue;
-#endif
                 if (!finish(ent, keep, cend, cend - from, flag)) {
-                    ALZ_CU_COUNT(2 + lvl);
                     const int sba = sbn / 2, sbb = sbn - sba;
                     const int nl = sba == 0 ? 2 : lvl + 1;
                     // (the second half first: the stack gives the first half back first)
@@ -656,110 +442,6 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     }
 }
 
-// Kernel A for windows up to 4 KiB: the same prev() links, from LDS instead of per-stream head tables in HBM.  A candidate
-// further back than maxDistance ends every chain walk of kernel B (`dist > g.max_dist: break`), so only the most recent
-// 4096 positions have to be remembered -- and for those a hash table with chaining fits the LDS: T[hash & 4095] = ring
-// index of the most recent position in that bucket, nxt[ring] = the bucket's previous one, tag[ring] = full hash | lap.
-// prev(p) = the first position on its bucket's chain whose FULL hash equals p's (a link further back than 4096, or none,
-// is stored as -1: kernel B treats both alike).  Per step of 64 positions: lanes of one bucket are found with a small
-// contest + ballots (rare on ordinary data, one group on runs), every lane walks its chain in the state BEFORE the step,
-// then the step's positions are linked in, in position order.  32.5 KB of LDS per stream (65 KB with the min-length
-// table): five streams per CU.  OPT-IN ONLY (ALZ_ENC_LDS_PREV): correct, but slower than the HBM tables -- see alz_launch_encode.
-template <bool MINT>
-__global__ __launch_bounds__(64) void enc_prev_lds_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
-                                                          const u32* __restrict__ index_list, u32 count,
-                                                          int* __restrict__ prev4, int* __restrict__ prevm,
-                                                          const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    constexpr int NT = MINT ? 2 : 1;
-    __shared__ u16 T[NT][4096];
-    __shared__ u16 nxt[NT][4096];
-    __shared__ u32 tag[NT][4096];
-    __shared__ u8 slot_owner[256];
-    __shared__ u8 slot_flag[256];
-    const u32 bid = blockIdx.x;
-    if (bid >= count) return;
-    const int lane = (int)threadIdx.x;
-    const u32 sid = index_list[bid];
-    const alz_stream st = streams[sid];
-    const u8* data = src_base + st.src_off;
-    const int n = (int)st.src_len - tail_skip;
-    const int limit = n - 4;
-    int* p4 = prev4 + pos_off[sid];
-    int* pm = MINT ? prevm + pos_off[sid] : nullptr;
-    for (int t = 0; t < NT; t++) for (int i = lane; i < 4096; i += 64) { T[t][i] = 0xFFFFu; nxt[t][i] = 0xFFFFu; tag[t][i] = 0u; }
-    for (int i = lane; i < 256; i += 64) slot_flag[i] = 0;
-    __syncthreads();
-    const u64 lanes_below = (1ull << lane) - 1ull;
-    for (int c = 0; c <= limit; c += 64) {
-        const int pos = c + lane;
-        const bool act = pos <= limit;
-        const u32 v = act ? load32(data + pos) : 0u;
-        for (int pass = 0; pass < NT; pass++) {
-            const u32 h = pass == 0 ? (((v * 2654435761u) >> (32 - g.hash_bits)) & ((1u << g.hash_bits) - 1u))
-                                    : ((((v & g.min_mask) * 2654435761u) >> 16) & 0xFFFFu);
-            const u32 slot = h & 4095u, ring = (u32)pos & 4095u;
-            // lanes that share a bucket inside this step
-            const u32 key = slot & 255u;
-            if (act) slot_owner[key] = (u8)lane;
-            __syncthreads();
-            const bool lost = act && slot_owner[key] != (u8)lane;
-            if (lost) slot_flag[key] = 1;
-            __syncthreads();
-            const bool contested = act && slot_flag[key] != 0;
-            __syncthreads();
-            if (lost) slot_flag[key] = 0;
-            const u32 old = act ? (u32)T[pass][slot] : 0xFFFFu;
-            int predlane = -1, instep = -1; bool writer = act;
-            u64 todo = __ballot(contested);
-            while (todo) {
-                const int l0 = (int)__builtin_ctzll(todo);
-                const u32 sl = (u32)__builtin_amdgcn_readlane((int)slot, l0);
-                const bool mine = contested && slot == sl;
-                const u64 grp = __ballot(mine);
-                if (mine) {
-                    const u64 below = grp & lanes_below;
-                    if (below) predlane = 63 - (int)__builtin_clzll(below);
-                    writer = (grp >> lane) <= 1ull;                      // the highest lane of the bucket becomes its head
-                }
-                u64 sub = grp;                                           // same full hash inside the bucket: the in-step predecessor
-                while (sub) {
-                    const int m0 = (int)__builtin_ctzll(sub);
-                    const u32 hh = (u32)__builtin_amdgcn_readlane((int)h, m0);
-                    const u64 sg = __ballot(mine && h == hh);
-                    if (mine && h == hh) { const u64 b2 = sg & lanes_below; if (b2) instep = c + 63 - (int)__builtin_clzll(b2); }
-                    sub &= ~sg;
-                }
-                todo &= ~grp;
-            }
-            // the chain as it was before this step
-            int prev = instep;
-            if (act && instep < 0) {
-                u32 cand = old; int bound = pos;
-                while (cand != 0xFFFFu) {
-                    const u32 w = tag[pass][cand];
-                    const int q = (int)(((w >> 20) << 12) | cand);
-                    if (q >= bound || pos - q > 4096) break;             // a stale link (its ring slot was reused) or out of the window
-                    if ((w & 0xFFFFFu) == h) { prev = q; break; }
-                    bound = q; cand = nxt[pass][cand];
-                }
-            }
-            if (act) { if (pass == 0) p4[pos] = prev; else pm[pos] = prev; }
-            __syncthreads();
-            // link the step in, in position order
-            if (act) {
-                tag[pass][ring] = h | (((u32)pos >> 12) << 20);
-                nxt[pass][ring] = predlane >= 0 ? (u16)(((u32)c + (u32)predlane) & 4095u) : (u16)old;
-                if (writer) T[pass][slot] = (u16)ring;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------- kernel B
-// Kernel B bounds the bytes it compares per candidate: on degenerate data (long runs) every position would otherwise
-// compare to the end of the stream although the parse only ever visits a handful of them.  A capped position is stored
-// as ALZ_CAPPED and recomputed exactly -- same function, no cap -- by the emit kernel if the parse really visits it.
 #define ALZ_LEN_CAP 2048
 #define ALZ_CAPPED 0xFFFFFFFFu
 
@@ -870,9 +552,6 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     const int chain = g.max_chain;
     for (int it = 0; it < chain; it++) {
         if (!__ballot(act)) break;
-#ifdef ALZ_CU_DEBUG
-        { const unsigned long long na = (unsigned long long)__popcll(__ballot(act)); if ((threadIdx.x & 63u) == 0) { atomicAdd(&alz_cu_dbg[6], na); atomicAdd(&alz_cu_dbg[7], 1ull); } }
-#endif
         const int c = act ? cur : 0;
         const int dist = pos - c;
         const u64 x = head ^ load64(data + c);
@@ -970,9 +649,6 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 
     // the pairs of the list, 64 at a time
     auto work_off = [&]() {
-#if defined(ALZ_DENSE_EXP) && ALZ_DENSE_EXP == 1
-        ln = 0; return;                           // timing experiment: the chains only
-#endif
         for (u32 i0 = 0; i0 < ln; i0 += 64u) {
             const bool on = i0 + (u32)lane < ln;
             const u32 lp = on ? lpos[i0 + lane] : 0u;
@@ -1997,11 +1673,6 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     return true;
 }
 
-// the head-table-free kernel A (enc_prev_block_kernel, an experiment): windows up to 4 KiB (its LDS footprint is 20 KB + 8 bytes per window byte)
-bool alz_encode_uses_block_prev(const void* geom) {
-    static const int on = getenv("ALZ_ENC_PREV_BLOCK") ? atoi(getenv("ALZ_ENC_PREV_BLOCK")) : 0;      // experiment: slower than the head tables (see enc_prev_block_kernel)
-    return on && ((const EncGeom*)geom)->max_dist <= 4096;
-}
 size_t alz_encode_geom_size(void) { return sizeof(EncGeom); }
 int alz_encode_geom_hash_bits(const void* geom) { return ((const EncGeom*)geom)->hash_bits; }
 int alz_encode_geom_min_table(const void* geom) { return ((const EncGeom*)geom)->use_min_table; }
@@ -2471,12 +2142,12 @@ template <int FMT>
 static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
                         const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g,
                         u64* mask = nullptr) {
-    static const int lone = getenv("ALZ_ENC_EMIT_LONE") ? atoi(getenv("ALZ_ENC_EMIT_LONE")) : 1;
-    static const int masked = getenv("ALZ_ENC_EMIT_MASK") ? atoi(getenv("ALZ_ENC_EMIT_MASK")) : 1;     // the parse from the roles walk's start mask
+    // one stream per wavefront (lane 0 parses and emits; 64 streams per wavefront were the union of 64 divergent token paths), the
+    // parse from the roles walk's start mask
     const int tail = FMT == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    if (mask && masked) hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, (uint2*)match, pos_off, prev4, prevm, mask, g, tail);
-    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(lone ? count : (count + 63) / 64), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g, (u32)lone,
-                       (const u64*)((mask && masked) ? mask : nullptr));
+    if (mask) hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, (uint2*)match, pos_off, prev4, prevm, mask, g, tail);
+    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g, 1u,
+                       (const u64*)mask);
 }
 
 template <int FMT>
@@ -2486,79 +2157,27 @@ static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, co
     hipLaunchKernelGGL((enc_emit_par_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, mask, side, results, aux, g);
 }
 
-// kernel A with the table in LDS: the largest number of passes it is used for (ALZ_ENC_PREV_CU; 0 = never)
-static int prev_cu_passes() {
-    static const int v = getenv("ALZ_ENC_PREV_CU") ? atoi(getenv("ALZ_ENC_PREV_CU")) : 34;
-    return v;
-}
-
-#ifdef ALZ_CU_DEBUG
-extern "C" void alz_cu_debug_counters(unsigned long long* out, int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(alz_cu_dbg), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(alz_cu_dbg), z, sizeof(z)); }
-}
-#endif
-static bool uses_cu_prev(const EncGeom& g) {
-    return prev_cu_passes() > 0 && g.hash_bits >= 15 && g.hash_bits <= 20 && (1 << (g.hash_bits - 15)) + (g.use_min_table ? 2 : 0) <= prev_cu_passes();
-}
-// false: kernel A keeps its head table in LDS, the caller need not provide (or reset) tables in HBM
-bool alz_encode_needs_head_tables(const void* geom) {
-    EncGeom g; memcpy(&g, geom, sizeof(g));
-    if (getenv("ALZ_ENC_LDS_PREV") || alz_encode_uses_block_prev(geom)) return true;     // (experiments: keep the plain set-up)
-    return !uses_cu_prev(g);
+// one pass over the stream whatever the hash width: formats whose matches reach back at most 8 KiB (enc_prev_cu_kernel<2, true>)
+static bool uses_win_prev(const EncGeom& g) {
+    return g.max_dist <= 8192 && (g.hash_bits > 15 || g.use_min_table);
 }
 
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
-                             uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
+                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
     if (count == 0) return hipSuccess;
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    // ALZ_ENC_LDS_PREV=1 selects the LDS-resident variant of kernel A for windows up to 4 KiB.  Bit-identical, but measured
-    // 3x SLOWER than the head tables in HBM (258 against 80 ms at Q0, tools/exp14.sh): 32 KB of LDS per stream leaves five
-    // waves per CU, and nothing hides the ~40 dependent LDS round trips of a step then, while 32 waves per CU hide the HBM ones.
-    static const bool lds_prev = getenv("ALZ_ENC_LDS_PREV") != nullptr;
-    if (lds_prev && g.max_dist <= 4096 && max_len < (1u << 24)) {
-        if (g.use_min_table) hipLaunchKernelGGL((enc_prev_lds_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
-        else hipLaunchKernelGGL((enc_prev_lds_kernel<false>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
-    }
-    else if (alz_encode_uses_block_prev(&g)) {
-        u32 W = 2048; while ((int)W < g.max_dist) W <<= 1;
-        const size_t lds = (size_t)(ALZ_PB_N + 2u * W) * 4u + ALZ_PB_N;
-        const dim3 grid((max_len + W - 1) / W ? (max_len + W - 1) / W : 1u, count);
-        if (g.use_min_table) hipLaunchKernelGGL((enc_prev_block_kernel<true>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
-        else hipLaunchKernelGGL((enc_prev_block_kernel<false>), grid, dim3(64), lds, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail, W);
-    }
-    else if (uses_cu_prev(g))
-    {
-        if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
-        else hipLaunchKernelGGL((enc_prev_cu_kernel<3>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
-    }
-    else if (g.use_min_table) hipLaunchKernelGGL((enc_prev_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
-    else {
-        // Experiment knobs (round 2, tools/enc_split.sh; both bit-identical, neither pays): ALZ_ENC_SPLIT = wavefronts per stream of the
-        // hash-partitioned kernel A, ALZ_ENC_ACHUNK = streams per pass of kernel A with the head tables reused from pass to pass
-        // (256 streams x 128 KB fit the L2 caches).  cfg5 at Q0, all kernels: 141 ms as is; 131-139 with 2 / 4 / 8 wavefronts per
-        // stream; 140-188 with passes of 1 024 / 512 / 256 streams.  So neither the chain of dependent table round trips per stream
-        // nor the HBM sector traffic alone is what bounds kernel A at 10 000 streams.
-        static const int split = getenv("ALZ_ENC_SPLIT") ? atoi(getenv("ALZ_ENC_SPLIT")) : 1;      // wavefronts per stream (1, 2, 4, 8)
-        static const int ach_env = getenv("ALZ_ENC_ACHUNK") ? atoi(getenv("ALZ_ENC_ACHUNK")) : 0;  // streams per pass of kernel A (0: all)
-        const u32 ach = ach_env > 0 ? (u32)ach_env : count;
-        for (u32 off = 0; off < count; off += ach) {
-            const u32 k = count - off < ach ? count - off : ach;
-            if (off) (void)hipMemsetAsync(d_head4, 0xFF, ((size_t)k << g.hash_bits) * sizeof(int), stream);   // (the caller reset it for the first pass)
-            const u32* ix = d_index + off;
-            if (split >= 8) hipLaunchKernelGGL((enc_prev_split_kernel<8>), dim3(k * 8u), dim3(64), 0, stream, src, d_streams, ix, k, d_head4, d_prev4, d_pos_off, g, tail);
-            else if (split >= 4) hipLaunchKernelGGL((enc_prev_split_kernel<4>), dim3(k * 4u), dim3(64), 0, stream, src, d_streams, ix, k, d_head4, d_prev4, d_pos_off, g, tail);
-            else if (split >= 2) hipLaunchKernelGGL((enc_prev_split_kernel<2>), dim3(k * 2u), dim3(64), 0, stream, src, d_streams, ix, k, d_head4, d_prev4, d_pos_off, g, tail);
-            else hipLaunchKernelGGL((enc_prev_kernel<false>), dim3(k), dim3(64), 0, stream, src, d_streams, ix, k, 0u, d_head4, d_headm, d_prev4, d_prevm, d_pos_off, g, tail);
-        }
-    }
+    // kernel A: the head table in LDS (hashBits = 15 + floor(sqrt(2 Q)) = 15..20, LzChainMatchFinder.cs:108-119) -- one pass with the
+    // tag / link rings where matches reach back at most 8 KiB, otherwise 2^(hashBits - 15) passes (+ 2 for the min-length table)
+    if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
+    if (uses_win_prev(g)) hipLaunchKernelGGL((enc_prev_cu_kernel<2, true>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    else if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    else hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
-    { static const int cap = getenv("ALZ_ENC_MATCH_BX") ? atoi(getenv("ALZ_ENC_MATCH_BX")) : 128; if (cap > 0 && bx > (u32)cap) bx = (u32)cap; }   // (blocks per stream: a thread of 128 blocks takes eight positions of a 256 KiB stream; one position per thread, ten million blocks per launch: 18.6 against 17.4 ms)
-    static const int dense_chain = getenv("ALZ_ENC_MATCH_DENSE") ? atoi(getenv("ALZ_ENC_MATCH_DENSE")) : 3;   // smallest maxChain that takes enc_match_dense_kernel (0: never)
-    if (dense_chain > 0 && g.max_chain >= dense_chain && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {
+    if (bx > 128u) bx = 128u;   // (blocks per stream: a thread of 128 blocks takes eight positions of a 256 KiB stream; one position per thread, ten million blocks per launch: 18.6 against 17.4 ms)
+    if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {                  // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         if (dyn) {
@@ -2585,39 +2204,24 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
-        static const int par = getenv("ALZ_ENC_PRS_PAR") ? atoi(getenv("ALZ_ENC_PRS_PAR")) : 1;
-        if (par) {
-            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-            hipLaunchKernelGGL((enc_emit_prs_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_PRS_BE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL((enc_emit_prs_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_PRS_LE: {
-        static const int par = getenv("ALZ_ENC_PRS_PAR") ? atoi(getenv("ALZ_ENC_PRS_PAR")) : 1;
-        if (par) {
-            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-            hipLaunchKernelGGL((enc_emit_prs_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_PRS_LE>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL((enc_emit_prs_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_LZ4_BLOCK: {
-        static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
-        if (par) {
-            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
-            hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
+        hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_LZO: {
-        static const int par = getenv("ALZ_ENC_LZO_PAR") ? atoi(getenv("ALZ_ENC_LZO_PAR")) : 1;
-        if (par) {
-            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-            hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_SNAPPY_RAW: {
-        static const int par = getenv("ALZ_ENC_LZ4_PAR") ? atoi(getenv("ALZ_ENC_LZ4_PAR")) : 1;
-        if (par) {
-            hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-            hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-        } else launch_emit<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;

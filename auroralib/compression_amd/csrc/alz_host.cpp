@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <functional>
 #include <thread>
 #include <vector>
 #include <sched.h>
@@ -105,6 +106,7 @@ struct alz_ctx {
     hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_kernel_ms = 0.f;                // device time of the kernels of the last timed / encode call (HIP events on the launch stream)
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
+    int variant = 0;                           // alz_ctx_set_kernel_variant
     // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
     // one piece overlaps the PCIe transfer of the other
     void* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0;
@@ -146,6 +148,11 @@ static alz_lz_properties effective_lz(const alz_lz_properties* p) {
 extern "C" {
 
 int alz_abi_version(void) { return ALZ_ABI_VERSION; }
+int alz_ctx_set_kernel_variant(alz_ctx* c, int variant) {
+    if (!c || variant < 0 || variant > 2) return fail(ALZ_E_INVALID, "alz_ctx_set_kernel_variant: bad argument");
+    c->variant = variant;
+    return ALZ_OK;
+}
 int alz_ctx_set_exact_kernels(alz_ctx* c, int on) {
     if (!c) return fail(ALZ_E_INVALID, "ctx is NULL");
     c->exact = on != 0;
@@ -328,7 +335,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     if (nfmt <= 1) {
         for (int f = 0; f < ALZ_FMT_COUNT; f++) {
             if (!p->fmt_cnt[f]) continue;
-            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n);
+            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
         return ALZ_OK;
@@ -352,7 +359,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
             if (w != hipSuccess) { rc = fail(ALZ_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(w)); break; }
             used[k & 3] = true;
         }
-        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n);
+        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
         if (e != hipSuccess) rc = fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         k++;
     }
@@ -653,10 +660,13 @@ int alz_ctx_release_scratch(alz_ctx* c) {
 // FastLZ.CompressHeaderless picks level 2 per source  FastLZ.cs:169-175
 static inline bool fastlz_level2(const alz_settings& st, uint32_t src_len) { return src_len >= 0x10000u && st.quality > 4 && st.max_window_bits > 13; }
 
-int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
-                     size_t src_bytes, const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
-    if (!c || (n && (!streams || !results || !dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch: bad argument");
-    if (n == 0) return ALZ_OK;
+// The encode of one batch with everything on the device: `streams` (a host table) holds offsets relative to d_src / d_dst, which
+// the caller has filled / will read.  `upload(d_src, d_dst)` runs once the arguments are validated and the scratch exists -- the
+// host-buffer entry points grow their device buffers and stage their input there (a refused batch never touches the device);
+// the device-resident entry point just hands its two pointers over.
+static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, size_t src_bytes, const alz_stream* streams,
+                       size_t dst_bytes, alz_result* results, alz_encode_aux* aux, const std::function<int(const void*&, void*&)>& upload) {
+    const void* d_src_base = nullptr; void* d_dst_base = nullptr;
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
     if (st.quality < 0 || st.quality > 15) return fail(ALZ_E_INVALID, "quality %d outside 0..15 (CompressionSettings.cs:38-50)", st.quality);
     if (st.max_window_bits < 0 || st.max_window_bits > 24) return fail(ALZ_E_INVALID, "max_window_bits %d outside 0..24", st.max_window_bits);
@@ -682,40 +692,28 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
     std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
-    int hash_bits = 0; bool any_min = false, any_tables = false;
+    bool any_min = false;
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
         void* g = geom.data() + f * alz_encode_geom_size();
         if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &st, g, nullptr, lvl2 ? 1 : 0))
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
-        hash_bits = alz_encode_geom_hash_bits(g);
         any_min = any_min || alz_encode_geom_min_table(g);
-        any_tables = any_tables || alz_encode_needs_head_tables(g);
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if ((rc = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return rc;
-    if ((rc = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return rc;
-    // streams are processed in chunks so that the per-stream head tables (4 B << hash_bits each) stay bounded: 16 GiB of
-    // tables per chunk (Q0: every stream at once, Q8: 8 192, Q15: 4 096) -- kernel A is bound by the latency of its
-    // head-table round trips, so a chunk should at least fill the device's 8 192 wave slots
-    uint32_t CH = 4096;
-    { const uint64_t per = (uint64_t)sizeof(int) << hash_bits; const uint64_t fit = (16ull << 30) / per; if (fit > CH) CH = fit > 0x100000ull ? 0x100000u : (uint32_t)fit; }
-    if (!any_tables) CH = 0x100000u;                         // (kernel A with its table in LDS: nothing to bound)
-    if (CH > 65535u) CH = 65535u;                            // (a launch carries the stream in gridDim.y; 70 000 went through on this runtime, the cap is caution)
-    if (const char* e = getenv("ALZ_ENC_CHUNK")) { const long v = atol(e); if (v >= 64) CH = (uint32_t)v; }   // tuning knob
+    // (kernel A keeps its hash table in LDS: no per-stream tables in HBM, nothing that bounds the streams of a launch but the grid:
+    // a launch carries the stream in gridDim.y; 70 000 went through on this runtime, the cap is caution)
+    const uint32_t CH = 65535u;
     EncScratch sc(c);
     alz_stream* d_streams = nullptr; alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; uint32_t* d_index = nullptr;
-    uint64_t* d_pos = nullptr; int *d_head4 = nullptr, *d_headm = nullptr, *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr, *d_mask = nullptr;
-    const uint32_t chn = n < CH ? n : CH;
+    uint64_t* d_pos = nullptr; int *d_prev4 = nullptr, *d_prevm = nullptr; void *d_match = nullptr, *d_side = nullptr, *d_mask = nullptr;
     hipError_t e = sc.alloc((void**)&d_streams, (size_t)n * sizeof(alz_stream));
     if (e == hipSuccess) e = sc.alloc((void**)&d_results, (size_t)n * sizeof(alz_result));
     if (e == hipSuccess) e = sc.alloc((void**)&d_aux, (size_t)n * sizeof(alz_encode_aux));
     if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
-    if (e == hipSuccess) e = sc.alloc((void**)&d_head4, ((size_t)chn << hash_bits) * sizeof(int), any_tables);
-    if (e == hipSuccess) e = sc.alloc((void**)&d_headm, ((size_t)chn << 16) * sizeof(int), any_min && any_tables);
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
@@ -729,7 +727,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     if (n_fastlz2)                                           // FastLZ: the level-1 streams first, then the level-2 ones (own geometry, own launch)
         std::stable_partition(index.begin() + foff[ALZ_FMT_FASTLZ], index.begin() + foff[ALZ_FMT_FASTLZ] + cnt[ALZ_FMT_FASTLZ],
                               [&](uint32_t i) { return !fastlz_level2(st, streams[i].src_len); });
-    if ((rc = staged_h2d(c, c->d_src, src_base, src_bytes))) return rc;
+    if ((rc = upload(d_src_base, d_dst_base))) return rc;
     tm.mark("upload");
     HIP_TRY(hipMemcpyAsync(d_streams, streams, (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -746,9 +744,7 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
         const void* g = geom.data() + f * alz_encode_geom_size();
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
-            if (alz_encode_needs_head_tables(g)) HIP_TRY(hipMemsetAsync(d_head4, 0xFF, ((size_t)k << alz_encode_geom_hash_bits(g)) * sizeof(int), c->stream));   // Reset(): tables = -1  :125-132
-            if (alz_encode_geom_min_table(g) && alz_encode_needs_head_tables(g)) HIP_TRY(hipMemsetAsync(d_headm, 0xFF, ((size_t)k << 16) * sizeof(int), c->stream));
-            e = alz_launch_encode(fmt, c->stream, c->d_src, c->d_dst, d_streams, d_index + first + done, k, max_len, d_head4, d_headm, d_prev4, d_prevm,
+            e = alz_launch_encode(fmt, c->stream, d_src_base, d_dst_base, d_streams, d_index + first + done, k, max_len, d_prev4, d_prevm,
                                   d_match, d_pos, d_side, d_mask, d_results, d_aux, g);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));
         }
@@ -761,9 +757,32 @@ int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_setti
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_kernel_ms = ms; }   // table resets + the encode kernels
     tm.mark("kernels");
     for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
-    if ((rc = download_outputs(c, n, streams, results, dst_base, true))) return rc;
-    tm.mark("download");
     return ALZ_OK;
+}
+
+int alz_encode_batch(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const uint8_t* src_base,
+                     size_t src_bytes, const alz_stream* streams, uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
+    if (!c || (n && (!streams || !results || !dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch: bad argument");
+    if (n == 0) return ALZ_OK;
+    int rc = encode_core(c, props, settings, n, src_bytes, streams, dst_bytes, results, aux, [&](const void*& ds, void*& dd) {
+        int r;
+        if ((r = grow(c, &c->d_src, &c->d_src_cap, src_bytes + 64))) return r;
+        if ((r = grow(c, &c->d_dst, &c->d_dst_cap, dst_bytes + 64))) return r;
+        ds = c->d_src; dd = c->d_dst;
+        return staged_h2d(c, c->d_src, src_base, src_bytes);
+    });
+    if (rc) return rc;
+    return download_outputs(c, n, streams, results, dst_base, true);
+}
+
+// The same with the raw buffers already in HBM and the compressed streams left there (alz_stream offsets are relative to the two
+// device pointers): what a caller that produces its input on the device uses, and what a benchmark times -- kernels, no PCIe.
+int alz_encode_batch_device(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, const void* d_src_base,
+                            size_t src_bytes, const alz_stream* streams, void* d_dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux) {
+    if (!c || (n && (!streams || !results || !d_src_base || !d_dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch_device: bad argument");
+    if (n == 0) return ALZ_OK;
+    return encode_core(c, props, settings, n, src_bytes, streams, dst_bytes, results, aux,
+                       [&](const void*& ds, void*& dd) { ds = d_src_base; dd = d_dst_base; return (int)ALZ_OK; });
 }
 
 // ---------------------------------------------------------------- multi-GPU: one batch over several contexts
@@ -898,6 +917,87 @@ int alz_decode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_pr
     std::vector<std::string> errs(n_ctx);
     auto work = [&](uint32_t q) {
         rcs[q] = decode_share(ctxs[q], props, idx[q], src_base, streams, dst_base, results);
+        if (rcs[q]) errs[q] = g_err;
+    };
+    if (n_ctx == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t q = 1; q < n_ctx; q++) th.emplace_back(work, q);
+        work(0);
+        for (std::thread& t : th) t.join();
+    }
+    for (uint32_t q = 0; q < n_ctx; q++) if (rcs[q]) return fail(rcs[q], "context %u (device %d): %s", q, ctxs[q]->device, errs[q].c_str());
+    return ALZ_OK;
+}
+
+// One context's share of an encode batch: its raw buffers are packed into a device buffer of their own, the compressed streams come
+// back from worst-case-sized slots.
+static int encode_share(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, const std::vector<uint32_t>& idx,
+                        const uint8_t* src_base, const alz_stream* streams, uint8_t* dst_base, alz_result* results, alz_encode_aux* aux) {
+    const uint32_t m = (uint32_t)idx.size();
+    if (m == 0) return ALZ_OK;
+    std::vector<alz_stream> ds(m);
+    std::vector<in_seg> ins; ins.reserve(m);
+    uint64_t so = 0, dof = 0;
+    for (uint32_t j = 0; j < m; j++) {
+        const alz_stream& st = streams[idx[j]];
+        ds[j] = st;
+        ds[j].src_off = so; ins.push_back(in_seg{so, src_base + st.src_off, st.src_len});
+        so += ((uint64_t)st.src_len + 16 + 15) & ~15ull;    // (the match finder reads up to 16 bytes past a buffer: never another stream's)
+        ds[j].dst_off = dof;
+        dof = (dof + st.dst_cap + 255) & ~255ull;
+    }
+    std::vector<alz_result> rs(m);
+    std::vector<alz_encode_aux> ax(m);
+    int rc = encode_core(c, props, settings, m, (size_t)so, ds.data(), (size_t)dof, rs.data(), ax.data(), [&](const void*& dsrc, void*& ddst) {
+        int r;
+        if ((r = grow(c, &c->d_src, &c->d_src_cap, so + 64))) return r;
+        if ((r = grow(c, &c->d_dst, &c->d_dst_cap, dof + 64))) return r;
+        dsrc = c->d_src; ddst = c->d_dst;
+        return upload_segs(c, c->d_src, ins, so);
+    });
+    if (rc) return rc;
+    std::vector<out_seg> outs; outs.reserve(m);
+    for (uint32_t j = 0; j < m; j++) {
+        results[idx[j]] = rs[j];
+        if (aux) aux[idx[j]] = ax[j];
+        if (rs[j].dst_len && rs[j].status == ALZ_ST_OK) outs.push_back(out_seg{ds[j].dst_off, dst_base + streams[idx[j]].dst_off, rs[j].dst_len});
+    }
+    return download_segs(c, outs);
+}
+
+// alz_encode_batch over several contexts (one per GPU): streams are independent -- a fresh LzChainMatchFinder per CompressHeaderless
+// call (LZSS.cs:135) -- so the batch is dealt out by raw size (LPT) and every share runs on its own device, no collective.
+int alz_encode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_properties* props, const alz_settings* settings, uint32_t n,
+                           const uint8_t* src_base, size_t src_bytes, const alz_stream* streams,
+                           uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux, uint32_t* part_of_out) {
+    if (!ctxs || n_ctx == 0 || n_ctx > 64 || (n && (!streams || !results || !dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch_multi: bad argument");
+    for (uint32_t q = 0; q < n_ctx; q++) {
+        if (!ctxs[q]) return fail(ALZ_E_INVALID, "alz_encode_batch_multi: context %u is NULL", q);
+        for (uint32_t r = 0; r < q; r++) if (ctxs[r] == ctxs[q]) return fail(ALZ_E_INVALID, "alz_encode_batch_multi: context %u is listed twice (a context is single-threaded)", q);
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        if (streams[i].format >= ALZ_FMT_COUNT) return fail(ALZ_E_INVALID, "stream %u: unknown format %u", i, streams[i].format);
+        if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
+        if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
+    }
+    // greedy LPT over the raw sizes (the cost of an encode is its positions), longest first onto the least loaded context
+    std::vector<uint32_t> part(n ? n : 1), order(n);
+    std::vector<uint64_t> load(n_ctx, 0);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return streams[a].src_len > streams[b].src_len; });
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t best = 0;
+        for (uint32_t q = 1; q < n_ctx; q++) if (load[q] < load[best]) best = q;
+        part[order[k]] = best; load[best] += (uint64_t)streams[order[k]].src_len + 4096;
+    }
+    if (part_of_out) for (uint32_t i = 0; i < n; i++) part_of_out[i] = part[i];
+    std::vector<std::vector<uint32_t>> idx(n_ctx);
+    for (uint32_t i = 0; i < n; i++) idx[part[i]].push_back(i);
+    std::vector<int> rcs(n_ctx, ALZ_OK);
+    std::vector<std::string> errs(n_ctx);
+    auto work = [&](uint32_t q) {
+        rcs[q] = encode_share(ctxs[q], props, settings, idx[q], src_base, streams, dst_base, results, aux);
         if (rcs[q]) errs[q] = g_err;
     };
     if (n_ctx == 1) work(0);

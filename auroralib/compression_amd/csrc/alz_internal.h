@@ -8,16 +8,14 @@
 // enqueue the decode kernel of one format over `count` streams (index list selects them; NULL = 0..count-1)
 // `exact`: the exact one-token-at-a-time kernels (alz_ctx_set_exact_kernels) instead of the lane-parallel ones
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams,
-                             const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact, uint32_t batch_total = 0)   /* batch_total: streams of ALL formats of the batch this launch belongs to (0 = count) */;
+                             const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact, uint32_t batch_total = 0, int variant = 0)   /* batch_total: streams of ALL formats of the batch this launch belongs to (0 = count); variant: alz_ctx_set_kernel_variant */;
 int alz_kernel_occupancy(int fmt);   // resident waves per CU of the production decode kernel (tuning aid)
 
 // ---- encoder (alz_encode.hip)
 bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits, int variant = 0);   // variant 1: FastLZ level 2
 size_t alz_encode_geom_size(void);
-bool alz_encode_uses_block_prev(const void* geom);   // kernel A without head tables (windows up to 4 KiB)
 int alz_encode_geom_hash_bits(const void* geom);
-bool alz_encode_needs_head_tables(const void* geom);   // false: kernel A keeps its table in LDS (enc_prev_cu_kernel)
 int alz_encode_geom_min_table(const void* geom);
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
-                             uint32_t count, uint32_t max_len, int* d_head4, int* d_headm, int* d_prev4, int* d_prevm, void* d_match,
+                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom);

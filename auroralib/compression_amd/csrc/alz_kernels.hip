@@ -29,7 +29,7 @@
 template <bool FB>
 __device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status, u32 hist = 0) {
     if (lane == 0) { r->dst_len = out.produced - hist; r->src_used = src_used; r->status = status; r->reserved = 0; }
-#ifdef ALZ_EMIT_STATS
+#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
     // experiment build: (steps, passes, chunks, dependent chunks) of the byte phase, 4 x 8 bits of per-step averages x 16
     if (lane == 0 && out.st_steps) r->reserved = (out.st_steps & 0xFFFFu) | ((out.st_passes * 16u / out.st_steps) << 16) | ((out.st_chunks * 2u / out.st_steps) << 24);
 #endif
@@ -165,6 +165,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
     constexpr u32 FSCR = (ALZ_CHUNKS_ALL || FBK) ? ALZ_EMIT_SCRATCH : 128u, FSLACK = (ALZ_CHUNKS_ALL || FBK) ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][FSCR + NC * CACHE + LWMAX + FSLACK];
+    constexpr bool WTAB = ALZ_WALK_TABLE && ALZ_WPB == 1 && (FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZ02);
+    __shared__ u16 wtab[WTAB ? 64 : 1];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
     u32 bid = blockIdx.x * ALZ_WPB + wid;
@@ -180,6 +182,13 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     typedef OutWin<FBK> OWF;
     OWF out; out.init(dst, cap, lds + FSCR + NC * CACHE, (ALZ_CHUNKS_ALL || FBK) ? (u32)LWMAX : lw, lane, FSLACK);
     segmark[lane] = 0; segmark[64 + lane] = 0;
+    if (WTAB) walk_table_init(wtab, lane);
+#ifndef ALZ_FAST_PRIO_SHORT
+#define ALZ_FAST_PRIO_SHORT 0
+#endif
+    // In a mixed batch that is resident all at once the launch ends with its slowest streams: the short-token formats (at most 18
+    // bytes per match: LZ10 1.5 ms alone per 256 KiB against 1.1 for Yaz0 / LZ11 / PRS) take precedence on their SIMD.
+    if (ALZ_FAST_PRIO_SHORT && (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_CLZ0 || FMT == ALZ_FMT_MIO0)) __builtin_amdgcn_s_setprio(ALZ_FAST_PRIO_SHORT);
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
     u32 used = 0; bool used_set = false;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         const u32 L = size < cap ? size : cap;
         dec_blz_serial(in, sk, s, src_len, L, 4098u);
         if (!s.eof && !s.bad && !s.ovf) {
-            FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
+            FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096; gm.wtab = nullptr;
             bool to_serial = false;
             while (!to_serial && (u64)out.produced + 1152u < L && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, L, src_len, to_serial, segmark, lane, gm);
             dec_blz_serial(in, sk, s, src_len, L);
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     } else if constexpr (FMT == ALZ_FMT_LZ02) {
         // no declared size inside the loop: the stream runs to its terminator (the size is compared there); only the
         // capacity bounds the lane-parallel iterations, and an exactly full destination still has to see the terminator
-        FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
+        FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096; gm.wtab = WTAB ? wtab : nullptr;
         bool to_serial = false;
         while (!s.ovf && !to_serial && out.produced < cap && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, cap, src_len, to_serial, segmark, lane, gm);
         if (!s.ovf) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_lz02_serial(in, sk, s, src_len); }
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         if (!fin) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
     } else if constexpr (!THREE) {
         FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
-        gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
+        gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits; gm.wtab = WTAB ? wtab : nullptr;
         bool to_serial = false;   // the fast loop runs to the last complete token of the input; the exact parser finishes
         while (!fin && !to_serial && out.produced < size && s.p < src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, src_len, to_serial, segmark, lane, gm);
         if (!fin) {
@@ -510,8 +519,12 @@ __global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restr
     u32* mbox = reinterpret_cast<u32*>(lds + FSCR + CACHE + LWMAX + CACHE);
     FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
     gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
+    constexpr bool WTAB = ALZ_WALK_TABLE && FMT == ALZ_FMT_YAZ0;
+    __shared__ u16 wtab[WTAB ? 64 : 1];
+    gm.wtab = WTAB ? wtab : nullptr;
     if (threadIdx.x < 64u) {
         // ---- the parsing wavefront
+        if (WTAB) walk_table_init(wtab, lane);
         InCache in; in.init(src, src_len, lds + FSCR + CACHE + LWMAX, lane, CHUNK);
         DecState s; dec_state_init(s);
         WalkOut out; out.produced = 0; out.cap = cap; out.mbox = mbox; out.k = 0;
@@ -735,13 +748,13 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 static thread_local u32 t_batch_total = 0;     // streams of the whole batch the current launch belongs to (alz_launch_decode)
+static thread_local int t_variant = 0;         // alz_ctx_set_kernel_variant: 0 automatic, 1 one wavefront per stream, 2 two where such a kernel exists
 
-// PRS: two wavefronts per stream (alz_decode_prs2_kernel)?  ALZ_PRS2: 0 never, 1 always, otherwise (default) for launches the GPU
-// cannot fill with one wavefront per stream anyway
-static bool prs_two_waves(u32 count) {
-    static const int mode = getenv("ALZ_PRS2") ? atoi(getenv("ALZ_PRS2")) : 1;
-    return mode == 1 || (mode == 2 && count <= 4096u);
-}
+// PRS: two wavefronts per stream (alz_decode_prs2_kernel) unless the context asks for one
+static bool prs_two_waves(u32 count) { (void)count; return t_variant != 1; }
+// the flag-byte formats: two wavefronts per stream for launches that cannot fill the GPU with one -- below this many streams in the
+// whole batch a launch is bound by the time of ONE stream (a mixed batch fills the GPU with all its formats together)
+static bool fast_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= 3072u); }
 
 template <int FMT, bool FB>
 static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
@@ -755,25 +768,20 @@ template <int FMT, int LWMAX = 4096, bool FBK = false>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
                               alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
     (void)ncaches;
-    static int pad = -1;
-    if (pad < 0) { const char* e = getenv("ALZ_OCC_PAD"); pad = e ? atoi(e) : 0; }
-    // launches that cannot fill the GPU with one wavefront per stream: two per stream (alz_decode_fast2_kernel).  ALZ_FAST2: 0 never,
-    // 1 always, otherwise the stream count below which a launch is bound by the time of one stream
+    // launches that cannot fill the GPU with one wavefront per stream: two per stream (alz_decode_fast2_kernel)
     if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40 || FMT == ALZ_FMT_CLZ0 || FMT == ALZ_FMT_YAZ0)) {
-        static const int two = getenv("ALZ_FAST2") ? atoi(getenv("ALZ_FAST2")) : 3072;
-        if (two == 1 || (two > 1 && t_batch_total <= (u32)two)) {        // (a mixed batch fills the GPU with all its formats together)
+        if (fast_two_waves()) {
             hipLaunchKernelGGL((alz_decode_fast2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lz, lw);
             return hipGetLastError();
         }
     }
     if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0)) {
-        static const int two = getenv("ALZ_FAST2") ? atoi(getenv("ALZ_FAST2")) : 3072;
-        if (two == 1 || (two > 1 && t_batch_total <= (u32)two)) {
+        if (fast_two_waves()) {
             hipLaunchKernelGGL((alz_decode_fast2c_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lw);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), (size_t)pad, stream, src, dst, streams, index, count, results, lz, lw);
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), 0, stream, src, dst, streams, index, count, results, lz, lw);
     return hipGetLastError();
 }
 
@@ -818,9 +826,10 @@ int alz_kernel_occupancy(int fmt) {
 }
 
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
-                             u32 count, alz_result* results, const alz_lz_properties* lzp, bool exact, u32 batch_total) {
+                             u32 count, alz_result* results, const alz_lz_properties* lzp, bool exact, u32 batch_total, int variant) {
     if (count == 0) return hipSuccess;
     t_batch_total = batch_total > count ? batch_total : count;
+    t_variant = variant;
     const u8* s = (const u8*)src; u8* d = (u8*)dst;
     alz_lz_properties lz = *lzp;
     if (!exact) {

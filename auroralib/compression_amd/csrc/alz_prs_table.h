@@ -15,7 +15,7 @@
 //
 // Entry = two 32-bit words.
 //   word 0 (the scalar walk):  [3:0]   1 + data bytes of the group without the third bytes (the distance to the next flag byte)
-//                              [6:4]   long matches in the group (0..4)
+//                              [4], [5], [6], [10]  the group has at least 1, 2, 3, 4 long matches (one s_bitcmp0 each, no field to extract)
 //                              [9:7]   tokens in the group - 1
 //                              [13:11] exit state
 //                              [16+4k+3 : 16+4k]  long match k: offset of its first data byte from the flag byte, without the
@@ -56,7 +56,8 @@ constexpr AlzPrsTable alz_make_prs_table() {
                 if (code[k] == 1u) { w1 |= 1u << (24u + k); w0 |= off << (16u + 4u * nlong); nlong++; off += 2; }
                 else off += 1;
             }
-            w0 |= off | (nlong << 4) | ((ntok - 1u) << 7) | (exit_state << 11);
+            const uint32_t atleast = (nlong >= 1u ? 0x10u : 0u) | (nlong >= 2u ? 0x20u : 0u) | (nlong >= 3u ? 0x40u : 0u) | (nlong >= 4u ? 0x400u : 0u);
+            w0 |= off | atleast | ((ntok - 1u) << 7) | (exit_state << 11);
             t.w[2u * (st * 256u + f)] = w0;
             t.w[2u * (st * 256u + f) + 1u] = w1;
         }
@@ -69,7 +70,7 @@ constexpr bool alz_check_prs_table() {
     const AlzPrsTable t = alz_make_prs_table();
     for (uint32_t e = 0; e < ALZ_PRS_STATES * 256u; e++) {
         const uint32_t w0 = t.w[2u * e];
-        const uint32_t nlong = (w0 >> 4) & 7u, size = w0 & 15u;
+        const uint32_t nlong = ((w0 >> 4) & 1u) + ((w0 >> 5) & 1u) + ((w0 >> 6) & 1u) + ((w0 >> 10) & 1u), size = w0 & 15u;
         if (nlong > 4u || size < 2u || size > 13u || ((w0 >> 11) & 7u) >= ALZ_PRS_STATES) return false;
         for (uint32_t k = 0; k < nlong; k++) if (((w0 >> (16u + 4u * k)) & 15u) + 2u > size) return false;
     }

@@ -7,13 +7,6 @@ def shard_seed(config, rank, streams_per_rank):
     return 0xA17A0000 + 1000 * config + rank * streams_per_rank
 
 
-def shard_range(n_total, rank, world):
-    """Contiguous, balanced index range of `rank` when ONE batch of n_total streams is split (strong scaling)."""
-    base, extra = divmod(n_total, world)
-    lo = rank * base + min(rank, extra)
-    return lo, lo + base + (1 if rank < extra else 0)
-
-
 def reduce_step_time(seconds, dist=None, device=None):
     """MAX over ranks of the time of the timed region."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -56,7 +56,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--format", default="yaz0")
+    ap.add_argument("--mode", choices=["decode", "encode"], default="decode",
+                    help="decode: the headline metric.  encode: BASELINE.json configs[4] (compression, 1 -> 8 GPUs) -- every rank compresses its own "
+                         "raw buffers, resident in HBM, through alz_encode_batch_device")
+    ap.add_argument("--quality", type=int, default=0, help="--mode encode: CompressionSettings.Quality (0 / 15 are the reference's published levels, 8 its default)")
+    ap.add_argument("--format", default=None, help="default: yaz0 (decode), lzss (encode)")
     ap.add_argument("--streams", type=int, default=10000, help="streams per GPU (weak scaling) or in the whole batch (strong scaling)")
     ap.add_argument("--stream-kib", type=int, default=256)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -141,6 +145,8 @@ def decode_config(name, workload, ctx, batch, Plan, synth, np, steps, fmt_name, 
 
 def main():
     args = parse_args()
+    if args.format is None:
+        args.format = "yaz0" if args.mode == "decode" else "lzss"
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         spawn_ranks(args)                       # (before anything touches HIP or imports torch)
@@ -174,6 +180,9 @@ def main():
     red_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else None
 
     target = args.stream_kib * 1024
+    if args.mode == "encode":
+        run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_time, rank, local_rank, world, dist, torch, red_dev)
+        return
     if args.scaling == "strong" and world >= 1:
         # ONE batch of --streams streams: the library's partitioner decides which rank decodes which stream (it only looks at
         # format, decom_len and dst_cap, so the table needs no payload yet); a rank generates exactly its own streams
@@ -299,6 +308,114 @@ def main():
         print(json.dumps(out))
     main_db.close()
     ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_time, rank, local_rank, world, dist, torch, red_dev):
+    """BASELINE.json configs[4] on N GPUs: every rank compresses its own raw buffers -- decoded synthetic LZSS streams, so they are
+    compressible, produced and kept in HBM -- with alz_encode_batch_device; a step is one such call (all encode
+    kernels of the batch, compressed streams left in HBM).  Buffers are independent (a fresh LzChainMatchFinder per call,
+    LZSS.cs:135): no data-path collective.  --scaling strong: ONE batch of --streams buffers dealt out by index."""
+    target = args.stream_kib * 1024
+    fmt = A.FORMAT_NAMES.index(args.format)
+    if args.scaling == "strong":
+        mine = np.arange(rank, args.streams, world)
+        n = len(mine)
+        b = synth.make_batch(A.FMT_LZSS, n, target, 0, seeds=(synth.seed_for(5) + mine).astype(np.uint64))
+        parallelism = "ONE batch of %d buffers dealt out x%d by index (equal sizes), no collective" % (args.streams, world)
+    else:
+        n = args.streams
+        b = synth.make_batch(A.FMT_LZSS, n, target, shard_seed(5, rank, n))
+        parallelism = "buffer-sharded x%d, every rank its own batch, no collective" % world
+    ctx = Context(local_rank)
+    raw_db = DeviceBatch(ctx, b, Plan)                        # the raw buffers: decoded on the device, never leave it
+    raw_db.plan.execute(raw_db.d_src, raw_db.d_dst); ctx.synchronize()
+    rres = synth.result_records(raw_db.plan.results())
+    recs = synth.stream_records(b.streams)
+    cap = target + target // 4 + 64
+    capal = (cap + 255) // 256 * 256
+    streams = (A.Stream * n)()
+    r2 = synth.stream_records(streams)
+    r2["src_off"], r2["src_len"] = recs["dst_off"], target
+    r2["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64(capal)
+    r2["dst_cap"], r2["format"] = cap, fmt
+    dst_bytes = n * capal + 64
+    d_out = ctx.malloc(dst_bytes)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    def step():
+        return ctx.encode_batch_device(streams, raw_db.d_dst, b.dst_bytes, d_out, dst_bytes, quality=args.quality)
+    for _ in range(max(1, args.warmup)):                      # (the first call at a quality grows the context's scratch: links, matches)
+        eres, aux = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eres, aux = step()
+    barrier()
+    dt = reduce_step_time(time.perf_counter() - t0, dist, device=red_dev)
+    kernel_ms = ctx.last_kernel_ms()
+    er = synth.result_records(eres)
+    comp = int(er["dst_len"].astype(np.int64).sum())
+    ok = bool((rres["status"] == 0).all() and (er["status"] == 0).all())
+    # what was written decodes back to the raw buffers (on the device), and the first buffers are the managed encoder's bytes
+    verified = None
+    if not args.no_verify:
+        s3 = (A.Stream * n)()
+        r3 = synth.stream_records(s3)
+        r3["src_off"], r3["src_len"], r3["dst_off"], r3["dst_cap"], r3["decom_len"], r3["format"] = r2["dst_off"], er["dst_len"], recs["dst_off"], target, target, fmt
+        ax = np.frombuffer(aux, dtype=np.uint32).reshape(n, 2)
+        r3["aux0"], r3["aux1"] = ax[:, 0], ax[:, 1]
+        d_back = ctx.malloc(b.dst_bytes + 64)
+        pl = Plan(ctx, s3)
+        pl.execute(d_out, d_back); ctx.synchronize()
+        bres = synth.result_records(pl.results())
+        k = min(n, 256)
+        span = int(recs["dst_off"][k - 1]) + target
+        g_raw, g_back = ctx.d2h(raw_db.d_dst, span), ctx.d2h(d_back, span)
+        verified = bool((bres["status"] == 0).all() and (bres["dst_len"] == target).all())
+        for i in range(k):
+            a = int(recs["dst_off"][i])
+            verified = verified and bool(np.array_equal(g_raw[a:a + target], g_back[a:a + target]))
+        import oracle_lib as O
+        for i in range(min(n, 2)):
+            a = int(recs["dst_off"][i])
+            want, _ = O.encode_stream(fmt, bytes(g_raw[a:a + target]), quality=args.quality)
+            got = ctx.d2h(d_out, int(er["dst_len"][i]), offset=int(r2["dst_off"][i]))
+            verified = verified and bytes(got) == want
+        pl.close(); ctx.free(d_back)
+        ok = ok and verified
+    raw_bytes = float(n) * target
+    if dist is not None:
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev or "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok = bool(t.item() > 0.5)
+        tb = torch.tensor([raw_bytes, float(comp), float(n)], dtype=torch.float64, device=red_dev or "cpu"); dist.all_reduce(tb)
+        job_raw, job_comp, job_n = float(tb[0].item()), float(tb[1].item()), int(tb[2].item())
+    else:
+        job_raw, job_comp, job_n = raw_bytes, float(comp), n
+    if rank == 0:
+        out = {
+            "metric": "compressed raw GiB/s (whole job; BASELINE configs[4]: %s compression, 10k x 256KiB buffers per GPU)" % args.format,
+            "value": round(job_raw * args.steps / dt / 2**30, 3), "unit": "GiB/s of raw input", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "%s compression at quality %d (LzChainMatchFinder + CompressHeaderless on the GPU, bit-identical), %d x %d KiB raw buffers %s "
+                                   "(decoded synthetic LZSS streams, SURVEY 8d), device-resident" % (args.format, args.quality, args.streams, args.stream_kib,
+                                                                                                      "per GPU" if args.scaling == "weak" else "in ONE batch"),
+                       "mode": "encode", "format": args.format, "quality": args.quality, "streams_this_rank": n, "streams_whole_job": job_n, "stream_bytes": target,
+                       "compressed_bytes_whole_job": int(job_comp), "ratio": round(job_comp / job_raw, 4), "parallelism": parallelism,
+                       "parity_ok": ok, "verified_roundtrip_and_vs_oracle": verified},
+            "roofline": roofline(raw_bytes + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (args.format, args.quality), n, args.stream_kib)),
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    ctx.free(d_out); raw_db.close(); ctx.close()
     if dist is not None:
         dist.destroy_process_group()
     if not ok:
@@ -463,7 +580,7 @@ def cfg3(ctx, np, A, synth, Plan):
 
 def cfg5(ctx, np, A, synth):
     """BASELINE configs[4] on one GPU: LZSS(12,4,2) compression of 10 000 x 256 KiB raw buffers (decoded synthetic LZSS
-    streams, so they are compressible) at Q0 and Q8 through alz_encode_batch; the kernel time (hash-table resets + the four
+    streams, so they are compressible) at Q0, Q8 and Q15 through alz_encode_batch; the kernel time (hash-table resets + the four
     encode kernels) comes from HIP events inside the call, the host figure includes upload, download and the pack kernel."""
     n, size = 10000, 262144
     b = synth.make_batch(A.FMT_LZSS, n, size, synth.seed_for(5))
@@ -477,7 +594,7 @@ def cfg5(ctx, np, A, synth):
     r2["dst_cap"], r2["format"] = cap, A.FMT_LZSS
     dst_bytes = int(r2["dst_off"][-1]) + cap + 64
     out = []
-    for q in (0, 8):
+    for q in (0, 8, 15):                                      # (0 / 15: the levels the reference publishes; 8: its default)
         ctx.encode_batch(streams, raw, dst_bytes, quality=q)       # (first call at a quality: the context grows its device scratch -- head tables, links)
         t0 = time.perf_counter()
         dst, eres, aux = ctx.encode_batch(streams, raw, dst_bytes, quality=q)

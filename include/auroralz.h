@@ -179,6 +179,11 @@ int         alz_device_info(alz_ctx* ctx, char* name, size_t name_cap, int* cu_c
  * time, the statement-for-statement GPU restatement of the managed bodies; every lane-parallel kernel hands its stream
  * tails and error paths to them.  A verification mode (the parity tests run every case through both families). */
 int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
+/* Several production kernels exist in two shapes: one wavefront per stream (a full GPU: most streams resident) and two --
+ * one parses, one copies -- for launches that cannot fill the GPU anyway (a lone stream, a small batch).  0 (default): the
+ * library chooses by the size of the batch; 1 / 2: always the one- / two-wavefront shape where both exist.  Results are
+ * identical; a tuning and verification hook (the library reads no environment variable for kernel selection). */
+int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
 /* The host-buffer entry points keep their device staging buffers and the encoder's scratch (head tables, links, matches: ~18
  * bytes per input byte + the head tables of the streams in flight) in the context and only ever grow them, so that a caller
  * working through batch after batch does not pay a device allocation per call.  This returns all of it to the device (the
@@ -250,6 +255,24 @@ int alz_encode_batch(alz_ctx* ctx, const alz_lz_properties* props, const alz_set
                      const alz_stream* streams,
                      uint8_t* dst_base, size_t dst_bytes,
                      alz_result* results, alz_encode_aux* aux /* may be NULL */);
+
+/* The same with the raw buffers already in HBM and the compressed streams left there: alz_stream.src_off / dst_off are
+ * relative to the two DEVICE pointers.  What a caller that produces its input on the device uses, and what bench.py times
+ * (kernels, no PCIe); alz_last_kernel_ms() reports the device time of the call. */
+int alz_encode_batch_device(alz_ctx* ctx, const alz_lz_properties* props, const alz_settings* settings, uint32_t n,
+                            const void* d_src_base, size_t src_bytes,
+                            const alz_stream* streams,
+                            void* d_dst_base, size_t dst_bytes,
+                            alz_result* results, alz_encode_aux* aux /* may be NULL */);
+/* alz_encode_batch over several contexts (one per GPU), as alz_decode_batch_multi: every CompressHeaderless call builds its own
+ * LzChainMatchFinder (src/AuroraLib.Compression/Formats/Common/LZSS.cs:135), so the buffers of a batch are independent; the
+ * library deals them out by raw size (longest first onto the least loaded context), every context receives and returns only
+ * its share, one host thread per context, no collective.  part_of_out (may be NULL): the context each stream ran on.  The
+ * output is byte-identical to alz_encode_batch on one context. */
+int alz_encode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_properties* props, const alz_settings* settings, uint32_t n,
+                           const uint8_t* src_base, size_t src_bytes, const alz_stream* streams,
+                           uint8_t* dst_base, size_t dst_bytes, alz_result* results, alz_encode_aux* aux /* may be NULL */,
+                           uint32_t* part_of_out /* may be NULL */);
 
 /* ------------------------------------------------ device memory helpers
  * For hosts without their own HIP allocator (the C# shim, the test harness). */

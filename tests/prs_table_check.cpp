@@ -40,7 +40,7 @@ int main() {
             if (big) { uint32_t r = 0; for (int i = 0; i < 8; i++) r |= ((f >> i) & 1u) << (7 - i); f = r; }
             const uint32_t w0 = T.w[2 * (st * 256 + f)], w1 = T.w[2 * (st * 256 + f) + 1];
             // scalar side: size of the group
-            uint32_t B = pos; const uint32_t nl = (w0 >> 4) & 7u;
+            uint32_t B = pos; const uint32_t nl = ((w0 >> 4) & 1u) + ((w0 >> 5) & 1u) + ((w0 >> 6) & 1u) + ((w0 >> 10) & 1u);
             for (uint32_t k = 0; k < nl; k++) B += ext_at(d, B + ((w0 >> (16 + 4 * k)) & 15u), big != 0) ? 1u : 0u;
             // token side
             const uint32_t ntok = ((w0 >> 7) & 7u) + 1u;

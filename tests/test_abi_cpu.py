@@ -146,4 +146,20 @@ def test_lds_table_kernel_fits_one_cu(tmp_path):
             priv = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
             vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
             assert 128 * 1024 < lds <= 160 * 1024 and priv == 0 and vgpr <= 128, (name.group(1), lds, priv, vgpr)
-    assert found == 2            # one pass (2 groups of 64 entries per wavefront and chunk), several passes (3)
+    assert found == 3            # one pass (2 groups of 64 entries per wavefront and chunk), several passes (3), one pass with the tag / link rings (windows up to 8 KiB)
+
+
+def test_library_reads_no_environment_switch_but_the_two_documented():
+    """Kernel selection is an API (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant), never the caller's environment: the only
+    variables the library looks at are ALZ_COPY_THREADS (host copy threads of the staging path) and ALZ_TIMING (phase times on
+    stderr).  Experiment code is compiled in only with -DALZ_EXPERIMENTS, which build.sh never sets."""
+    import re
+    blob = open(os.path.join(ROOT, "auroralib", "compression_amd", "libauroralz.so"), "rb").read()
+    names = set(m.group(0).decode() for m in re.finditer(rb"ALZ_[A-Z0-9_]{3,}", blob))
+    env_like = {n for n in names if not n.startswith(("ALZ_E_", "ALZ_ST_", "ALZ_FMT_", "ALZ_C_"))}
+    assert env_like <= {"ALZ_COPY_THREADS", "ALZ_TIMING"}, env_like
+    for f in ("alz_kernels.hip", "alz_encode.hip", "alz_host.cpp", "alz_container.cpp", "alz_decode_fast.h"):
+        text = open(os.path.join(ROOT, "auroralib", "compression_amd", "csrc", f)).read()
+        for m in re.finditer(r'getenv\("(\w+)"\)', text):
+            assert m.group(1) in ("ALZ_COPY_THREADS", "ALZ_TIMING"), (f, m.group(1))
+    assert "ALZ_EXPERIMENTS" not in open(os.path.join(ROOT, "auroralib", "compression_amd", "csrc", "build.sh")).read()

@@ -252,58 +252,55 @@ def test_fuzz_garbage_and_mutations(fmt, test_bmp):
     compare_batch(streams, src, dst_bytes, what="fuzz " + A.FORMAT_NAMES[fmt])
 
 
+def _agrees_with_the_oracle(c, fmts, damaged_too):
+    import random
+    sizes = np.array([1, 7, 300, 5000, 70000, 262144, 100001, 64], dtype=np.uint32)
+    rng = random.Random(99)
+    for fmt in fmts:
+        b = synth.make_batch(fmt, len(sizes), sizes, 4242)
+        for damaged in ((False, True) if damaged_too else (False,)):
+            src = b.src.copy()
+            if damaged:
+                for _ in range(40):
+                    src[rng.randrange(len(src))] ^= 1 << rng.randrange(8)
+            o_dst, o_res = O.decode_batch(b.streams, src, b.dst_bytes)
+            g_dst, g_res = c.decode_batch(b.streams, src, b.dst_bytes)
+            gr, orr = synth.result_records(g_res), synth.result_records(o_res)
+            assert all(np.array_equal(gr[f], orr[f]) for f in ("status", "dst_len", "src_used")), (fmt, damaged)
+            assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes]), (fmt, damaged)
+
+
 def test_prs_one_wavefront_kernel_still_agrees():
-    """PRS runs on two wavefronts per stream by default (alz_decode_prs2_kernel); ALZ_PRS2=0 selects the one-wavefront queue kernel,
-    whose loop the second wavefront also falls back to.  The switch is read once per process, hence the child process."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import oracle_lib as O\n"
-        "from auroralib.compression_amd import _abi as A, synth\n"
-        "from auroralib.compression_amd.batch import Context\n"
-        "sizes = np.array([1, 7, 300, 5000, 70000, 262144, 100001, 64], dtype=np.uint32)\n"
-        "for fmt in (A.FMT_PRS_BE, A.FMT_PRS_LE):\n"
-        "    b = synth.make_batch(fmt, len(sizes), sizes, 4242)\n"
-        "    o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes)\n"
-        "    g_dst, g_res = Context(0).decode_batch(b.streams, b.src, b.dst_bytes)\n"
-        "    gr, orr = synth.result_records(g_res), synth.result_records(o_res)\n"
-        "    assert all(np.array_equal(gr[f], orr[f]) for f in ('status', 'dst_len', 'src_used'))\n"
-        "    assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes])\n"
-        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ALZ_PRS2="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    """PRS runs on two wavefronts per stream by default (alz_decode_prs2_kernel); alz_ctx_set_kernel_variant(1) selects the
+    one-wavefront queue kernel, whose loop the second wavefront also falls back to."""
+    from auroralib.compression_amd.batch import Context
+    with Context(0) as c:
+        c.set_kernel_variant(1)
+        _agrees_with_the_oracle(c, (A.FMT_PRS_BE, A.FMT_PRS_LE), True)
 
 
-@pytest.mark.parametrize("switch", ["0", "1"])
-def test_flag_formats_agree_on_one_and_two_wavefronts(switch):
-    """The flag-byte formats pick one or two wavefronts per stream by the size of the launch (ALZ_FAST2: 0 never, 1 always, n = up to n
-    streams); both kernels must give the oracle's bytes, lengths, consumed input and status for valid, truncated and noisy streams."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, random, numpy as np\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import oracle_lib as O\n"
-        "from auroralib.compression_amd import _abi as A, synth\n"
-        "from auroralib.compression_amd.batch import Context\n"
-        "ctx = Context(0)\n"
-        "sizes = np.array([1, 7, 300, 5000, 70000, 262144, 100001, 64], dtype=np.uint32)\n"
-        "rng = random.Random(99)\n"
-        "for fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0):\n"
-        "    b = synth.make_batch(fmt, len(sizes), sizes, 4242)\n"
-        "    for damaged in (False, True):\n"
-        "        src = b.src.copy()\n"
-        "        if damaged:\n"
-        "            for _ in range(40): src[rng.randrange(len(src))] ^= 1 << rng.randrange(8)\n"
-        "        o_dst, o_res = O.decode_batch(b.streams, src, b.dst_bytes)\n"
-        "        g_dst, g_res = ctx.decode_batch(b.streams, src, b.dst_bytes)\n"
-        "        gr, orr = synth.result_records(g_res), synth.result_records(o_res)\n"
-        "        assert all(np.array_equal(gr[f], orr[f]) for f in ('status', 'dst_len', 'src_used')), (fmt, damaged)\n"
-        "        assert np.array_equal(g_dst[:b.dst_bytes], o_dst[:b.dst_bytes]), (fmt, damaged)\n"
-        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ALZ_FAST2=switch)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+@pytest.mark.parametrize("variant", [1, 2])
+def test_flag_formats_agree_on_one_and_two_wavefronts(variant):
+    """The flag-byte formats pick one or two wavefronts per stream by the size of the batch (alz_ctx_set_kernel_variant: 1 / 2 force
+    either shape); both kernels must give the oracle's bytes, lengths, consumed input and status for valid and noisy streams."""
+    from auroralib.compression_amd.batch import Context
+    with Context(0) as c:
+        c.set_kernel_variant(variant)
+        _agrees_with_the_oracle(c, (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0), True)
+
+
+def test_cfg1_whole_test_bmp_lz10_at_the_default_quality(test_bmp):
+    """BASELINE.json configs[0]: "LZ10 decompress of Test.bmp via the ICompressionAlgorithm path" -- the whole 1 048 726-byte file,
+    compressed at the default quality 8 (the managed encoder's bytes: the oracle's), through the LZ10 class of the host mirror:
+    IsMatch, GetDecompressedSize, Decompress -- on both kernel families -- and the GPU encoder writes the same file."""
+    from auroralib.compression_amd import formats as F
+    comp = O.container_compress(A.C_LZ10, test_bmp, quality=8)
+    lz10 = F.LZ10()
+    assert lz10.IsMatch(comp) and lz10.GetDecompressedSize(comp) == len(test_bmp) == 1048726
+    for serial in (1, 0):
+        F._context().set_exact_kernels(serial)                    # (the format classes keep a context of their own)
+        try:
+            assert lz10.Decompress(comp) == test_bmp
+        finally:
+            F._context().set_exact_kernels(0)
+    assert lz10.Compress(test_bmp, F.CompressionSettings(quality=8)) == comp

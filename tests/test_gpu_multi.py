@@ -85,3 +85,70 @@ def test_bad_arguments_are_refused():
             c.decode_batch(st, np.zeros(64, dtype=np.uint8), 64)
         with pytest.raises(AlzError):
             decode_batch_multi([c], st, np.zeros(64, dtype=np.uint8), 64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The compression configuration on N devices (BASELINE.json configs[4]: "LZSS compression ... 1 -> 8 GPUs scaling"): the same batch
+# through alz_encode_batch_multi over N contexts and through alz_encode_batch on one must write the same bytes -- which
+# tests/test_gpu_encode.py in turn compares with the oracle's restatement of the managed encoder.
+def _raw_batch(n, fmts, seed):
+    rng = np.random.default_rng(seed)
+    b = synth.make_batch(A.FMT_LZSS, n, 40000, synth.seed_for(5))
+    raw, res = Context(0).decode_batch(b.streams, b.src, b.dst_bytes)
+    recs = synth.stream_records(b.streams)
+    streams = (A.Stream * n)()
+    do = 0
+    for i in range(n):
+        ln = int(rng.integers(1, 40000)) if i % 5 else 40000          # ragged: the partitioner has something to balance
+        cap = ln + ln // 4 + 64
+        streams[i] = A.Stream(int(recs["dst_off"][i]), do, ln, cap, 0, 0, 0, fmts[i % len(fmts)])
+        do += (cap + 255) // 256 * 256
+    return streams, raw, do + 64
+
+
+@pytest.mark.parametrize("nctx", [1, 2, 3, 8])
+@pytest.mark.parametrize("quality", [0, 8])
+def test_encode_batch_over_n_contexts_writes_the_bytes_of_one(nctx, quality):
+    from auroralib.compression_amd.batch import encode_batch_multi
+    streams, raw, dst_bytes = _raw_batch(203, [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_PRS_BE, A.FMT_LZ4_BLOCK], 11)
+    one = Context(0)
+    ctxs = [Context(0) for _ in range(nctx)]
+    try:
+        d1, r1, a1 = one.encode_batch(streams, raw, dst_bytes, quality=quality)
+        dn, rn, an, part = encode_batch_multi(ctxs, streams, raw, dst_bytes, quality=quality)
+    finally:
+        one.close()
+        for c in ctxs:
+            c.close()
+    assert set(part.tolist()) == set(range(nctx))
+    for i in range(len(streams)):
+        assert (rn[i].status, rn[i].dst_len) == (r1[i].status, r1[i].dst_len) and r1[i].status == A.ST_OK, i
+        assert (an[i].aux0, an[i].aux1) == (a1[i].aux0, a1[i].aux1), i
+        a = streams[i].dst_off
+        assert np.array_equal(dn[a:a + rn[i].dst_len], d1[a:a + r1[i].dst_len]), i
+    # and one of them against the oracle's encoder, so that "the same" is "the managed encoder's"
+    k = 7
+    want, _ = O.encode_stream(streams[k].format, bytes(raw[streams[k].src_off:streams[k].src_off + streams[k].src_len]), quality=quality)
+    assert bytes(dn[streams[k].dst_off:streams[k].dst_off + rn[k].dst_len]) == want
+
+
+def test_device_resident_encode_leaves_the_same_streams_in_hbm():
+    """alz_encode_batch_device: raw buffers already in HBM, compressed streams left in HBM -- the entry bench.py times for the
+    compression configuration.  Same bytes as the host-buffer call."""
+    streams, raw, dst_bytes = _raw_batch(64, [A.FMT_LZSS], 3)
+    c = Context(0)
+    try:
+        d1, r1, a1 = c.encode_batch(streams, raw, dst_bytes, quality=8)
+        d_src, d_dst = c.malloc(raw.nbytes + 64), c.malloc(dst_bytes + 64)
+        c.h2d(d_src, raw)
+        c.memset(d_dst, 0, dst_bytes)
+        r2, a2 = c.encode_batch_device(streams, d_src, raw.nbytes, d_dst, dst_bytes, quality=8)
+        assert c.last_kernel_ms() > 0
+        out = c.d2h(d_dst, dst_bytes)
+        c.free(d_src); c.free(d_dst)
+    finally:
+        c.close()
+    for i in range(len(streams)):
+        assert (r2[i].status, r2[i].dst_len) == (r1[i].status, r1[i].dst_len), i
+        a = streams[i].dst_off
+        assert np.array_equal(out[a:a + r2[i].dst_len], d1[a:a + r1[i].dst_len]), i
