@@ -183,12 +183,6 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     OWF out; out.init(dst, cap, lds + FSCR + NC * CACHE, (ALZ_CHUNKS_ALL || FBK) ? (u32)LWMAX : lw, lane, FSLACK);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     if (WTAB) walk_table_init(wtab, lane);
-#ifndef ALZ_FAST_PRIO_SHORT
-#define ALZ_FAST_PRIO_SHORT 0
-#endif
-    // In a mixed batch that is resident all at once the launch ends with its slowest streams: the short-token formats (at most 18
-    // bytes per match: LZ10 1.5 ms alone per 256 KiB against 1.1 for Yaz0 / LZ11 / PRS) take precedence on their SIMD.
-    if (ALZ_FAST_PRIO_SHORT && (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_CLZ0 || FMT == ALZ_FMT_MIO0)) __builtin_amdgcn_s_setprio(ALZ_FAST_PRIO_SHORT);
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
     u32 used = 0; bool used_set = false;

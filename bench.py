@@ -525,7 +525,10 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
         if "cfg5" in want:
             out.extend(cfg5(ctx, np, A, synth))
         if "realistic" in want:
-            out.append(realistic(ctx, np, A, synth, Plan, steps))
+            # the reference benchmarks every algorithm on Test.bmp (Benchmarks/Benchmarks/TestAllAlgorithms.cs:26-69): the same data
+            # per north-star format, as 256 KiB windows
+            for f in ("yaz0", "lz10", "lz11", "prs_be", "lz4_block"):
+                out.append(realistic(ctx, np, A, synth, Plan, steps, f))
     except Exception as e:                                   # report what ran; the headline line must still come out
         out.append({"name": "error", "error": repr(e)})
     return out
@@ -615,10 +618,11 @@ def cfg5(ctx, np, A, synth):
     return out
 
 
-def realistic(ctx, np, A, synth, Plan, steps):
+def realistic(ctx, np, A, synth, Plan, steps, fmt_name="yaz0"):
     """SURVEY.md 8d's second data set: the 256 KiB windows of the reference's Test.bmp at a stride of 4 KiB (193 windows),
-    Yaz0-encoded at the default quality by the GPU encoder (bit-identical to the managed encoder, tests/test_gpu_encode.py),
+    encoded at the default quality by the GPU encoder (bit-identical to the managed encoder, tests/test_gpu_encode.py),
     repeated to 10 000 streams.  Test.bmp itself is recovered from the reference's own fixture Test.lz on the GPU."""
+    fmt = A.FORMAT_NAMES.index(fmt_name)
     from auroralib.compression_amd import formats as F
     lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
     bmp = np.frombuffer(lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read()), dtype=np.uint8)
@@ -631,7 +635,7 @@ def realistic(ctx, np, A, synth, Plan, steps):
     r = synth.stream_records(st)
     r["src_off"], r["src_len"] = np.arange(nw, dtype=np.uint64) * np.uint64(size), size
     r["dst_off"] = np.arange(nw, dtype=np.uint64) * np.uint64((cap + 255) // 256 * 256)
-    r["dst_cap"], r["format"] = cap, A.FMT_YAZ0
+    r["dst_cap"], r["format"] = cap, fmt
     enc, eres, aux = ctx.encode_batch(st, raw, int(r["dst_off"][-1]) + cap + 64, quality=8)
     er = synth.result_records(eres)
     # the batch: 10 000 streams, stream i = window i mod nw (payload packed once per window)
@@ -647,7 +651,7 @@ def realistic(ctx, np, A, synth, Plan, steps):
     w = np.arange(n) % nw
     s2["src_off"], s2["src_len"] = offs[w], er["dst_len"][w]
     s2["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64(size)
-    s2["dst_cap"], s2["decom_len"], s2["format"] = size, size, A.FMT_YAZ0
+    s2["dst_cap"], s2["decom_len"], s2["format"] = size, size, fmt
 
     class B:
         pass
@@ -661,9 +665,10 @@ def realistic(ctx, np, A, synth, Plan, steps):
         g = ctx.d2h(db.d_dst, nw * size)
         ok = ok and bool(np.array_equal(g, raw))                                  # the first nw streams are the windows themselves
         comp = int(s2["src_len"].astype(np.int64).sum())
-        return {"name": "realistic_yaz0", "workload": "Yaz0 decode of the %d 256 KiB windows of Test.bmp (stride 4 KiB, GPU-encoded at Q8, ratio %.3f), repeated to 10 000 streams"
-                % (nw, comp / (n * size)), "value": round(n * size * steps / dt / 2**30, 3), "unit": "GiB/s", "steps": steps,
-                "ms_per_step": round(dt / steps * 1e3, 4), "parity_ok": ok, "roofline": roofline(comp + n * size, kernel_ms)}
+        return {"name": "realistic_" + fmt_name, "workload": "%s decode of the %d 256 KiB windows of Test.bmp (stride 4 KiB, GPU-encoded at Q8, ratio %.3f), repeated to 10 000 streams"
+                % (fmt_name, nw, comp / (n * size)), "value": round(n * size * steps / dt / 2**30, 3), "unit": "GiB/s", "steps": steps,
+                "ms_per_step": round(dt / steps * 1e3, 4), "parity_ok": ok,
+                "roofline": roofline(comp + n * size, kernel_ms, measured_traffic("realistic_" + fmt_name, n, size // 1024))}
     finally:
         db.close()
 

@@ -1,9 +1,9 @@
-# usage (GPU box): bash tools/enc_profile.sh  -- kernel stats of the compression path (cfg5) at Q0 and Q8 -> gpurun_out/r02_encode.md
+# usage (GPU box): bash tools/enc_profile.sh  -- kernel stats of the compression path (cfg5) at Q0, Q8 and Q15 -> gpurun_out/r03_encode.md
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/r02_encode.md
+OUT=gpurun_out/r03_encode.md
 echo "# rocprofv3 summary: compression path (cfg5: LZSS(12,4,2), 10 000 x 256 KiB)" > $OUT
-for q in 0 8; do
+for q in 0 8 15; do
   D=gpurun_out/prof_enc_q$q; rm -rf $D; mkdir -p $D
   rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 tools/bench_encode.py --quality $q --reps 1 > $D/log.txt 2>&1
   python3 tools/profile_summary.py $D/sum.md --stats $D --cmd "rocprofv3 --kernel-trace --stats -- python3 tools/bench_encode.py --quality $q --reps 1" > /dev/null

@@ -1,6 +1,4 @@
-# usage (GPU box): bash tools/r3_run.sh  -- round-3 work list: parity of what changed, then timings
 cd $GRAFT_REPO_ROOT
-timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -8
-bash tools/ab.sh yaz0 lz02 prs_be lz11
-for q in 0 8; do bash tools/enc_kernels.sh lzss $q; done
-python bench.py --mode encode --quality 8 --steps 3 --warmup 1 2>&1 | tail -1 | cut -c1-1500
+echo "== fuzz soak"; bash tools/soak.sh 9100 12 2>&1 | tail -14
+echo "== synth soak"; timeout 1200 python tools/soak_synth.py 4100 6 2>&1 | tail -6
+echo "== encode soak"; timeout 1500 python tools/soak_encode.py 8100 8 2>&1 | tail -8

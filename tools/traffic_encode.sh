@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/traffic_encode.sh -- HBM traffic of the compression kernels (cfg5, Q0 and Q8): FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for q in 0 8; do
+for q in 0 8 15; do
   for c in FETCH_SIZE WRITE_SIZE; do
     D=gpurun_out/traffic_enc_q${q}_$c; rm -rf $D; mkdir -p $D
     rocprofv3 --pmc $c --output-format csv -d $D -- python3 tools/bench_encode.py --quality $q --reps 1 > $D/log.txt 2>&1
