@@ -560,11 +560,10 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     }
     // 2. the walk; lane j receives the start offset of the j-th sequence (a window holds <= 22 sequences: lanes suffice)
     u32 spos, sp, nseq;
-    lane_walk_pos(nx, 32u, spos, sp, nseq);
-    if (nseq > 32u) { nseq = 32u; sp = wave_readlane(spos, 32u); }
+    lane_walk_pos(nx, 33u, spos, sp, nseq);
     if (nseq == 0u) return false;
-    // 3. one lane per sequence: fields, then (literal run?, match) into the queue order
-    const bool st = (u32)lane < nseq;
+    // 3. one lane per sequence: fields, then (literal run?, match) into the queue order (the sequences whose tokens fit its 64 slots)
+    bool st = (u32)lane < nseq;
     const u32 pos = i0 + spos;
     const u32 b = in.lds[pos], e1 = in.lds[pos + 1];
     const u32 L0 = b >> 4, M0 = b & 15u;
@@ -574,8 +573,12 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     const u32 d0 = in.lds[op & 2047u], d1 = in.lds[(op + 1u) & 2047u], em = in.lds[(op + 2u) & 2047u];
     const u32 M = M0 + 4u + (M0 == 15u ? em : 0u);
     const u32 dist = d0 | (d1 << 8);
-    const u64 litm = __ballot(st && L != 0u);
+    u64 litm = __ballot(st && L != 0u);
     const u32 rank = (u32)lane + mbcnt64(litm);
+    {
+        const u32 keep = (u32)__popcll(__ballot(st && rank + (L ? 2u : 1u) <= 64u));
+        if (keep < nseq) { nseq = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; litm = __ballot(st && L != 0u); }
+    }
     if (st) {
         u32 r = rank;
         if (L) { stage[r] = ALZ_TOK_LIT(L, lp); r++; }
@@ -898,14 +901,17 @@ __device__ __forceinline__ bool hig_parse_round(InCache& in, u32 p, u32* stage, 
         nx[w] = (cnt > ALZ_QRUN || length > ALZ_TOK_MAXLEN) ? ALZ_NX_BAD : (rawp - pos) + cnt;
     }
     u32 spos, sp, nel;
-    lane_walk_pos(nx, 32u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
-    if (nel > 32u) { nel = 32u; sp = wave_readlane(spos, 32u); }         // two tokens per element fill the queue
+    lane_walk_pos(nx, 33u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
     if (nel == 0u) return false;
-    const bool st = (u32)lane < nel;
+    bool st = (u32)lane < nel;
     u32 hdr, length, distance, rawp, cnt;
     hig_element(in, i0 + spos, hdr, length, distance, rawp, cnt);
-    const u64 mm = __ballot(st && length != 0u), litm = __ballot(st && cnt != 0u);
+    u64 mm = __ballot(st && length != 0u), litm = __ballot(st && cnt != 0u);
     const u32 rank = mbcnt64(mm) + mbcnt64(litm);
+    {   // the elements whose tokens fit the 64 slots of the queue
+        const u32 keep = (u32)__popcll(__ballot(st && rank + (length ? 1u : 0u) + (cnt ? 1u : 0u) <= 64u));
+        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; mm = __ballot(st && length != 0u); litm = __ballot(st && cnt != 0u); }
+    }
     if (st) {
         u32 r = rank;
         if (length) { stage[r] = ALZ_TOK_MATCH(length, distance ? distance : 32768u); r++; }   // E1
@@ -939,15 +945,18 @@ __device__ __forceinline__ bool wflz_parse_round(InCache& in, u32 p, u32* stage,
         nx[w] = ((length | plain) == 0u || plain > ALZ_QRUN) ? ALZ_NX_BAD : 4u + plain;
     }
     u32 spos, sp, nel;
-    lane_walk_pos(nx, 32u, spos, sp, nel);                               // a block has >= 4 bytes: <= 16 per window
-    if (nel > 32u) { nel = 32u; sp = wave_readlane(spos, 32u); }         // two tokens per block fill the queue
+    lane_walk_pos(nx, 33u, spos, sp, nel);                               // a block has >= 4 bytes: <= 16 per window
     if (nel == 0u) return false;
-    const bool st = (u32)lane < nel;
+    bool st = (u32)lane < nel;
     const u32 pos = i0 + spos;
     const u32 b0 = in.lds[pos], b1 = in.lds[pos + 1], length = in.lds[pos + 2], plain = in.lds[pos + 3];
     const u32 dist = BIG ? ((b0 << 8) | b1) : (b0 | (b1 << 8));
-    const u64 mm = __ballot(st && length != 0u), litm = __ballot(st && plain != 0u);
+    u64 mm = __ballot(st && length != 0u), litm = __ballot(st && plain != 0u);
     const u32 rank = mbcnt64(mm) + mbcnt64(litm);
+    {   // the blocks whose tokens fit the 64 slots of the queue
+        const u32 keep = (u32)__popcll(__ballot(st && rank + (length ? 1u : 0u) + (plain ? 1u : 0u) <= 64u));
+        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; mm = __ballot(st && length != 0u); litm = __ballot(st && plain != 0u); }
+    }
     if (st) {
         u32 r = rank;
         if (length) { stage[r] = ALZ_TOK_MATCH(length + 4u, dist ? dist : 65536u); r++; }      // E1
@@ -986,8 +995,7 @@ __device__ __forceinline__ bool refpack_parse_round(InCache& in, u32 p, u32* sta
         nx[w] = n;
     }
     u32 spos, sp, nel;
-    lane_walk_pos(nx, 32u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
-    if (nel > 32u) { nel = 32u; sp = wave_readlane(spos, 32u); }         // two tokens per element fill the queue
+    lane_walk_pos(nx, 33u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
     if (nel == 0u) return false;
     const bool st = (u32)lane < nel;
     const u32 pos = i0 + spos;
@@ -1002,9 +1010,13 @@ __device__ __forceinline__ bool refpack_parse_round(InCache& in, u32 p, u32* sta
         if (first == 0u) return false;
         nel = first; sp = wave_readlane(spos, first);
     }
-    const bool st2 = (u32)lane < nel;
-    const u64 litm = __ballot(st2 && plain != 0u), mm = __ballot(st2 && length != 0u);
+    bool st2 = (u32)lane < nel;
+    u64 litm = __ballot(st2 && plain != 0u), mm = __ballot(st2 && length != 0u);
     const u32 rank = mbcnt64(litm) + mbcnt64(mm);
+    {   // the elements whose tokens fit the 64 slots of the queue
+        const u32 keep = (u32)__popcll(__ballot(st2 && rank + (plain ? 1u : 0u) + (length ? 1u : 0u) <= 64u));
+        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st2 = (u32)lane < keep; litm = __ballot(st2 && plain != 0u); mm = __ballot(st2 && length != 0u); }
+    }
     if (st2) {
         u32 r = rank;
         if (plain) { stage[r] = ALZ_TOK_LIT(plain, (pos + hdr) & 2047u); r++; }
@@ -1114,7 +1126,7 @@ __device__ __forceinline__ void lzo_walk_pos(const u32 (&pk)[4], u32& spos_out, 
     u32 spos = 0, sp = 0, cnt = 0, state = uni(state_io), n = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        if (cnt < 32u && sp < 64u * (u32)(w + 1)) {
+        if (cnt < 33u && sp < 64u * (u32)(w + 1)) {          // (a window of 64 bytes adds at most 32 instructions: lane j <= 63)
             u32 v, sh, t;
             asm volatile(
                 "s_mov_b32 m0, %[cnt]\n\t"
@@ -1139,10 +1151,8 @@ __device__ __forceinline__ void lzo_walk_pos(const u32 (&pk)[4], u32& spos_out, 
                 : "scc", "m0");
         }
     }
-    bool undo = n == 511u;                                       // the last instruction counted was one the walk does not take
-    if (undo) cnt -= 1u;
-    if (cnt > 32u) { cnt = 32u; undo = true; }
-    if (undo) { const u32 v = wave_readlane(spos, cnt); sp = v & 0x1FFu; state = v >> 9; }   // resume in front of the first one not taken
+    const bool undo = n == 511u;                                 // the last instruction counted was one the walk does not take
+    if (undo) { cnt -= 1u; const u32 v = wave_readlane(spos, cnt); sp = v & 0x1FFu; state = v >> 9; }   // resume in front of the first one not taken
     spos_out = spos; sp_out = sp; n_out = cnt; state_io = state;
 }
 
@@ -1192,13 +1202,21 @@ __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, 
     u32 spos, sp, ninstr;
     lzo_walk_pos(pk, spos, sp, ninstr, state);
     if (ninstr == 0u) return false;
-    // one lane per instruction, in the state the walk entered it: match / run token + trailing-literal token
-    const bool st = (u32)lane < ninstr;
+    // one lane per instruction, in the state the walk entered it: match / run token + trailing-literal token.  The walk takes as
+    // many instructions as its windows hold (up to 64; round 2 stopped at 32 whatever they yield, ~39 tokens); the round keeps those
+    // whose tokens fit the 64 slots of the queue and resumes in front of the first one that does not.
     u32 tl;
     const u32 first = lzo_interpret<true>(in, i0 + (spos & 0x1FFu), spos >> 9, tl);
-    const bool second = st && tl != 0u;
-    const u64 sm = __ballot(second);
+    bool st = (u32)lane < ninstr;
+    bool second = st && tl != 0u;
+    u64 sm = __ballot(second);
     const u32 rank = (u32)lane + mbcnt64(sm);
+    const u32 keep = (u32)__popcll(__ballot(st && rank + (second ? 2u : 1u) <= 64u));
+    if (keep < ninstr) {
+        ninstr = keep;
+        const u32 v = wave_readlane(spos, keep); sp = v & 0x1FFu; state = v >> 9;
+        st = (u32)lane < keep; second = second && st; sm = __ballot(second);
+    }
     if (st) { stage[rank] = first; if (second) stage[rank + 1u] = tl; }
     const u32 base = ninstr + (u32)__popcll(sm);
     wave_sync();

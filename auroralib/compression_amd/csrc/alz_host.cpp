@@ -102,7 +102,7 @@ struct alz_ctx {
     void* d_dst = nullptr; size_t d_dst_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // fork/join resources for per-format kernels of a mixed batch (they are independent: run them concurrently)
-    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};    // side streams of a mixed launch (with the launch stream: four lanes = the runtime's four hardware queues)
     hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_kernel_ms = 0.f;                // device time of the kernels of the last timed / encode call (HIP events on the launch stream)
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
@@ -181,7 +181,8 @@ int alz_create(int device, alz_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming); }
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
     if (e != hipSuccess) { alz_destroy(c); return fail(ALZ_E_HIP, "context creation failed: %s", hipGetErrorString(e)); }   // (what was created so far goes with it)
     *out = c;
     return ALZ_OK;
@@ -196,7 +197,8 @@ void alz_destroy(alz_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->fork) (void)hipEventDestroy(c->fork);
-    for (int i = 0; i < 4; i++) { if (c->join[i]) (void)hipEventDestroy(c->join[i]); if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]); }
+    for (int i = 0; i < 4; i++) if (c->join[i]) (void)hipEventDestroy(c->join[i]);
+    for (int i = 0; i < 3; i++) if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c->pool;
     delete c;
@@ -326,6 +328,18 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
 }
 
 static uint32_t format_weight(uint32_t fmt);
+// Time of ONE 256 KiB stream alone on the GPU, in units of 10 us (measured: DESIGN.md 4.4 / 8): what orders the kernels of a mixed launch
+static uint32_t format_latency(uint32_t fmt) {
+    switch (fmt) {
+    case ALZ_FMT_YAY0: return 91;
+    case ALZ_FMT_YAZ0: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_LZ02: case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: return 109;
+    case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: return 125;
+    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_CLZ0: case ALZ_FMT_CNS: case ALZ_FMT_LZHUDSON: case ALZ_FMT_LZSHREK: return 154;
+    case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_FASTLZ: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: case ALZ_FMT_HIG: case ALZ_FMT_CNX2: return 170;
+    case ALZ_FMT_BLZ: case ALZ_FMT_REFPACK: case ALZ_FMT_SNAPPY_RAW: return 200;
+    default: return 240;                                     // LZO
+    }
+}
 int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, void* hip_stream) {
     if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
     HIP_TRY(hipSetDevice(c->device));                 // (a host thread may hold contexts of several devices)
@@ -343,28 +357,32 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     // mixed batch: one kernel per format, forked onto side streams so that they share the GPU (each format alone may
     // have far fewer streams than the device has wave slots), joined back into the caller's stream -- also when a launch
     // fails half way (the side streams that already started are joined, then the error is reported)
-    // The format whose streams take longest goes first (PRS before the flag-byte family): a launch ends with its slowest
+    // The format whose streams take longest ALONE goes first: a mixed launch is resident all at once and ends with its slowest
     // stream, and a stream's own time hardly depends on how many others of its format there are.
+    // Four lanes: the caller's stream itself and three side streams.  Round 2 forked onto FOUR side streams; with the caller's
+    // stream that made five, the HIP runtime maps streams onto four hardware queues, and rocprofv3 showed the fourth kernel of
+    // the cfg4 shard waiting in the queue of the third until that had finished (3.09 ms for kernels of 2.2 / 1.8 / 1.8 / 1.3 ms).
     int order[ALZ_FMT_COUNT];
     for (int f = 0; f < ALZ_FMT_COUNT; f++) order[f] = f;
-    std::stable_sort(order, order + ALZ_FMT_COUNT, [](int a, int b) { return format_weight((uint32_t)a) > format_weight((uint32_t)b); });
+    std::stable_sort(order, order + ALZ_FMT_COUNT, [](int a, int b) { return format_latency((uint32_t)a) > format_latency((uint32_t)b); });
     HIP_TRY(hipEventRecord(c->fork, s));
     int k = 0, rc = ALZ_OK; bool used[4] = {false, false, false, false};
     for (int oi = 0; oi < ALZ_FMT_COUNT && rc == ALZ_OK; oi++) {
         const int f = order[oi];
         if (!p->fmt_cnt[f]) continue;
-        hipStream_t a = c->aux[k & 3];
-        if (!used[k & 3]) {
+        const int lane = k & 3;                             // lane 0: the caller's stream; 1..3: side streams
+        hipStream_t a = lane == 0 ? s : c->aux[lane - 1];
+        if (lane != 0 && !used[lane]) {
             hipError_t w = hipStreamWaitEvent(a, c->fork, 0);
             if (w != hipSuccess) { rc = fail(ALZ_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(w)); break; }
-            used[k & 3] = true;
+            used[lane] = true;
         }
         hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
         if (e != hipSuccess) rc = fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         k++;
     }
-    for (int i = 0; i < 4; i++) if (used[i]) {
-        hipError_t e = hipEventRecord(c->join[i], c->aux[i]);
+    for (int i = 1; i < 4; i++) if (used[i]) {
+        hipError_t e = hipEventRecord(c->join[i], c->aux[i - 1]);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join[i], 0);
         if (e != hipSuccess && rc == ALZ_OK) rc = fail(ALZ_E_HIP, "joining the side streams failed: %s", hipGetErrorString(e));
     }
@@ -789,13 +807,13 @@ int alz_encode_batch_device(alz_ctx* c, const alz_lz_properties* props, const al
 // Decode cost per output byte of a format relative to the fastest one (x64; from the measured per-format rates)
 static uint32_t format_weight(uint32_t fmt) {
     switch (fmt) {
-    case ALZ_FMT_YAY0: return 54;
+    case ALZ_FMT_YAY0: return 55;
     case ALZ_FMT_YAZ0: case ALZ_FMT_LZ02: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: return 64;
-    case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: return 76;
-    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_CLZ0: case ALZ_FMT_CNS: case ALZ_FMT_LZHUDSON: case ALZ_FMT_LZSHREK: return 92;
-    case ALZ_FMT_CNX2: case ALZ_FMT_HIG: return 110;
-    case ALZ_FMT_BLZ: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_FASTLZ: case ALZ_FMT_REFPACK: return 140;
-    default: return 190;                                     // PRS, LZO, Snappy
+    case ALZ_FMT_MIO0: case ALZ_FMT_SMSR00: return 78;
+    case ALZ_FMT_LZSS: case ALZ_FMT_LZ10: case ALZ_FMT_CLZ0: case ALZ_FMT_CNS: case ALZ_FMT_LZHUDSON: case ALZ_FMT_LZSHREK: return 83;
+    case ALZ_FMT_CNX2: case ALZ_FMT_HIG: case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: case ALZ_FMT_LZ4_BLOCK: case ALZ_FMT_FASTLZ: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: return 109;
+    case ALZ_FMT_BLZ: case ALZ_FMT_REFPACK: case ALZ_FMT_SNAPPY_RAW: return 140;
+    default: return 171;                                     // LZO
     }
 }
 

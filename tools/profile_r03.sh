@@ -34,3 +34,15 @@ cfg2 yaz0 10000 64
 cfg4_shard mixed 5000 256
 cfg3_100000 lz4_block 100000 256
 LIST
+# the Test.bmp windows (bench.py --configs realistic: five formats), a 64-stream headline batch beside them
+D=gpurun_out/prof_r03_realistic; rm -rf $D; mkdir -p $D
+B="python3 bench.py --streams 64 --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-extras --configs realistic --inflight 1"
+rocprofv3 --kernel-trace --output-format csv -d $D/stats -- $B > $D/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- $B > $D/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- $B > $D/write.log 2>&1
+python3 tools/trace_by_grid.py gpurun_out/r03_realistic.md "realistic: the 256 KiB windows of Test.bmp, 10 000 streams per format (yaz0, lz10, lz11, prs_be, lz4_block)" 5000 --stats $D/stats --fetch $D/fetch --write $D/write --cmd "rocprofv3 --kernel-trace -- $B"
+find $D -name "*.csv" -size +2M -delete
+grep '^{' $D/stats.log | tail -1 | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+for c in d.get('configs') or []: print(c.get('name'), c.get('value'), c.get('ms_per_step'), c.get('roofline',{}).get('kernel_ms'), c.get('parity_ok'), c.get('error',''))"

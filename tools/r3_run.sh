@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-echo "== fuzz soak"; bash tools/soak.sh 9100 12 2>&1 | tail -14
-echo "== synth soak"; timeout 1200 python tools/soak_synth.py 4100 6 2>&1 | tail -6
-echo "== encode soak"; timeout 1500 python tools/soak_encode.py 8100 8 2>&1 | tail -8
+timeout 1700 python -m pytest tests -m gpu -q 2>&1 | tail -5
+bash tools/ab.sh lzo lz4_block snappy_raw fastlz cns hig wflz refpack mixed
+bash tools/cfg4_quick.sh
+for q in 0 8; do bash tools/enc_kernels.sh lzss $q; done
