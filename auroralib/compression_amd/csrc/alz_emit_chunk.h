@@ -65,8 +65,11 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
 //            literal byte (flag-byte formats, PRS)
 //   FALLBACK the LDS ring is shorter than the format's window (64 KiB formats keep 4 KiB): older sources are read back
 //            from the stream's own output in HBM (flush_to() made them visible)
-template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_>
-struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_; };
+//   RUNGLOBAL literal runs are read from the stream's INPUT in global memory (`inlds` is then src + the offset that turns a run's
+//            cache index into an input offset), like a far source: the executing wavefront of a two-wavefront kernel has no
+//            input cache of its own while the parsing wavefront slides its cache as it pleases
+template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_, bool RUNGLOBAL_ = false>
+struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_, RUNGLOBAL = RUNGLOBAL_; };
 
 typedef u32 alz_v4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 / 8 bytes at a dword-aligned address
 typedef u32 alz_v2 __attribute__((ext_vector_type(2), aligned(4)));
@@ -186,6 +189,7 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
     const u32 b = qa & 3u;                                  // the chunk starts at byte b of its first window dword
     const u32 a0 = qa & omask & ~3u;
     const bool isrun = CFG::LITRUN && run;
+    const bool grun = CFG::RUNGLOBAL && act && isrun;        // a literal run that comes from global memory
     const bool m = act && !isrun;
     // ---- where the bytes come from
     const bool ovl = m && d < i0 + n;                       // the plain source range q - d .. would reach into the token itself
@@ -208,7 +212,7 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
     if (CFG::FALLBACK) far = m && q - sp > LW - 1536u;      // older than the ring keeps intact: already flushed to HBM (never dep)
     // source window: the 20 bytes that land in the chunk's five window dwords start at source byte -b
     u32 sa;                                                 // LDS byte address of that window (ring / input cache)
-    if (isrun) sa = lds_addr(inlds) + d + i0 - b;
+    if (isrun) sa = CFG::RUNGLOBAL ? wbase : lds_addr(inlds) + d + i0 - b;
     else sa = wbase + ((sp + out.oshift - b) & omask);
     // (t = sa & 3 and the aligned address are re-derived from `sa` at every read, the last dword touched at every mirror check:
     // three registers fewer across the passes -- these kernels sit at the 80-register step of 6 waves per SIMD)
@@ -221,9 +225,10 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
     // ---- pass 1: every chunk
     u32 E0 = 0, E1 = 0, E2 = 0, E3 = 0, E4 = 0;
     if (CFG::FALLBACK) {
-        if (wave_ballot(far)) {
+        if (wave_ballot(far || grun)) {
             const u32 fp = sp - b;                          // position of the window's first byte
-            if (wave_ballot(far && (int)fp < 0)) {          // E2 / the very start of the stream: byte-wise, zero in front of position 0
+            const bool slow = wave_ballot(far && (int)fp < 0) != 0ull;   // E2 / the very start of the stream: byte-wise, zero in front of position 0
+            if (slow) {
                 if (far) {
 #pragma unroll 1
                     for (u32 j = 0; j < 5u; j++) {          // (E0..E4 as a shift register: no indexed array, no scratch)
@@ -233,8 +238,10 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
                         E0 = E1; E1 = E2; E2 = E3; E3 = E4; E4 = w;
                     }
                 }
-            } else if (far) {
-                const u8* gp = out.dst + fp;
+            }
+            const bool gl = (far && !slow) || grun;          // one 20-byte read: a far source from the stream's output, a literal run from its input
+            if (gl) {
+                const u8* gp = grun ? inlds + d + i0 - b : out.dst + fp;
                 uint4 g; u32 g4;
                 asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
                              : "=&v"(g), "=&v"(g4) : "v"(gp) : "memory");
@@ -242,7 +249,7 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
             }
         }
     }
-    if (act && !far) chunk_read(ALZ_SBASE, ALZ_ST, E0, E1, E2, E3, E4);
+    if (act && !far && !grun) chunk_read(ALZ_SBASE, ALZ_ST, E0, E1, E2, E3, E4);
     if (wave_ballot(rep)) { if (rep) chunk_rep(d, b, E0, E1, E2, E3, E4); }
     // single literals: stored after the step's reads (their slots may still hold the bytes a distance == W match wants)
     if (wave_ballot(lit)) {

@@ -740,6 +740,130 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// LZ4 / LZO / Snappy with TWO wavefronts per stream (round 3), as PRS: wavefront 0 parses rounds (input cache + element walk, no
+// window), wavefront 1 executes them (chunked byte phase on the window, far sources from HBM); a round's tokens cross in a two-slot
+// LDS mailbox, one workgroup barrier per round.  Parse and copy were about equal halves of the one-wavefront kernel, taking turns;
+// and its rounds drained whenever the input cache had to slide, because a round's literal-run tokens point into the cache.  Here the
+// executing wavefront reads a literal run from the stream's INPUT in global memory -- one 20-byte read per chunk, the very read it
+// does for a far source (the bytes are in this CU's L1: the parsing wavefront fetched them a moment ago) -- so the parser's cache is
+// the parser's alone.  What the rounds do not take (an element with a second length-extension byte, the stream's head and tail, the
+// capacity rule) goes to the exact parser on wavefront 1, which then tells the parser where and in which state to go on.
+template <int FMT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_FMT_LZO ? 5 : ALZ_QUEUE_WAVES, 8)))
+void alz_decode_queue2_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                              const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results) {
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK, LZO = FMT == ALZ_FMT_LZO, SNAPPY = FMT == ALZ_FMT_SNAPPY_RAW;
+    static_assert(LZ4 || LZO || SNAPPY, "formats with lane-parallel rounds and literal runs");
+    constexpr u32 LW = ALZ_QUEUE_LW, QCH = 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u, SCR = ALZ_EMIT_SCRATCH, SLACK = ALZ_WIN_SLACK;
+    constexpr u32 MB = 64u + 8u;                              // mailbox slot: 64 tokens + {nt | stop, total, round start, its cache index, parser state}
+    // executing wavefront: byte-phase scratch | staging | input cache (exact parser only) | window + mirror;  parsing wavefront: staging | input cache;
+    // mailbox (two slots) | control words (go / done, position, parser state, bytes produced, output limit)
+    __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + SLACK + 256 + QCACHE + 2u * MB * 4u + 64u];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool walker = threadIdx.x < 64u;
+    const u32 sid = index_list ? index_list[bid] : bid;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 src_len = uni(st.src_len);
+    u32 cap = uni(st.dst_cap);
+    const u32 hist = LZ4 ? uni(st.aux0) : 0u;                 // LZ4 frames with linked blocks (see OutWin::preload)
+    cap += hist;
+    u8* const wl = lds + SCR + 256 + QCACHE + LW + SLACK;
+    u32* const mbox = reinterpret_cast<u32*>(wl + 256 + QCACHE);
+    u32* const ctl = mbox + 2u * MB;
+    if (walker) {
+        u32* stage = reinterpret_cast<u32*>(wl);
+        InCache in; in.init(src, src_len, wl + 256, lane, QCH);
+        __syncthreads();                                       // the executing wavefront has read the stream's head
+        if (!uni(ctl[0])) return;
+        u32 p = uni(ctl[1]), state = uni(ctl[2]), produced = uni(ctl[3]);
+        const u32 maxout = uni(ctl[4]);
+        for (u32 k = 0;; k++) {
+            u32 qt = 0, nt = 0, total = 0, adv = 0, st2 = state;
+            bool ok = (u64)p + QAHEAD <= src_len && produced < maxout;
+            if (ok) {
+                in.ensure(p, QCH);
+                if constexpr (LZ4) { Lz4Rounds r{in, stage, lane}; ok = r(p, qt, nt, total, adv); }
+                else if constexpr (LZO) { LzoRounds r{in, stage, lane, state, 0u}; ok = r(p, qt, nt, total, adv); st2 = r.pending; }
+                else { SnappyRounds r{in, lane}; ok = r(p, qt, nt, total, adv); }
+            }
+            if (ok && total > maxout - produced) ok = false;   // the size / capacity rules stay with the exact parser
+            u32* slot = mbox + (k & 1u) * MB;
+            slot[lane] = qt;
+            if (lane == 0) { slot[64] = ok ? nt : 0xFFFFFFFFu; slot[65] = total; slot[66] = p; slot[67] = ok ? in.idx(p) : 0u; slot[68] = state; }
+            __syncthreads();                                   // message k is in the mailbox (and round k - 1 has been executed)
+            if (!ok) {
+                __syncthreads();                               // the exact parser has taken what the rounds did not
+                if (!uni(ctl[0])) return;
+                p = uni(ctl[1]); state = uni(ctl[2]); produced = uni(ctl[3]);
+                continue;
+            }
+            p += adv; state = st2; produced += total;
+        }
+    }
+    // ---- the executing wavefront
+    u8* dst = dst_base + st.dst_off - hist;
+    u8* segmark = lds;
+    u8* inc_lds = lds + SCR + 256;
+    typedef OutWin<true> OW;
+    OW out; out.init(dst, cap, lds + SCR + 256 + QCACHE, LW, lane, SLACK);
+    if (hist) out.preload(hist);
+    segmark[lane] = 0; segmark[64 + lane] = 0;
+    InCache in; in.init(src, src_len, inc_lds, lane, QCH);
+    DecState s; dec_state_init(s);
+    typedef EmitCfg<LW - 1u, false, true, true> CFG;          // the exact parser's tokens: literal runs from this wavefront's input cache
+    typedef EmitCfg<LW - 1u, false, true, true, true> CFG2;   // the parser's rounds: literal runs from the stream's input in global memory
+    typedef QueueSink<OW, CFG> SK;
+    SK sk(out, s, segmark, inc_lds, lane, 65536u);
+    LzoState ls; lzo_state_init(ls);
+    u32 size = 0; bool have = false;
+    // what the rounds do not take: one element through the exact parser (everything that is left once the input tail is reached);
+    // true: the stream is finished
+    auto serial_step = [&]() -> bool {
+        const bool tail = (u64)s.p + QAHEAD > src_len;
+        const u32 n = tail ? 0xFFFFFFFFu : 1u;
+        if constexpr (LZ4) dec_lz4_serial(in, sk, s, src_len, n);
+        else if constexpr (LZO) dec_lzo_serial(in, sk, s, src_len, ls, n);
+        else dec_snappy_serial(in, sk, s, src_len, size, have, n);
+        sk.flush();
+        return tail || s.eof || s.ovf || s.bad || s.done || (SNAPPY && sk.produced() >= size);
+    };
+    // the head: until rounds may start (LZO: behind the first byte's rule; Snappy: behind the varint size; all: at least four bytes
+    // in, so that the 20-byte read of a literal run never starts in front of the stream)
+    bool fin = false;
+    while (!fin && !(s.p >= 4u && (!LZO || ls.started) && (!SNAPPY || have))) fin = serial_step();
+    if (lane == 0) {
+        ctl[0] = fin ? 0u : 1u; ctl[1] = s.p; ctl[2] = LZO ? (ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u)) : 0u; ctl[3] = out.produced;
+        ctl[4] = SNAPPY ? (size < cap ? size : cap) : cap;
+    }
+    __syncthreads();
+    if (!fin) for (u32 k = 0;; k++) {
+        __syncthreads();                                       // message k is in the mailbox
+        const u32* slot = mbox + (k & 1u) * MB;
+        const u32 qt = slot[lane], nt = uni(slot[64]);
+        if (nt == 0xFFFFFFFFu) {                               // the parser stopped in front of an element the rounds do not take
+            s.p = uni(slot[66]);
+            if (LZO) { const u32 ws = uni(slot[68]); ls.plain = ws == 0u ? 0u : (ws == 1u ? 1u : 4u); }
+            fin = serial_step();
+            if (lane == 0) { ctl[0] = fin ? 0u : 1u; ctl[1] = s.p; ctl[2] = LZO ? (ls.plain == 0u ? 0u : (ls.plain <= 3u ? 1u : 2u)) : 0u; ctl[3] = out.produced; }
+            __syncthreads();
+            if (fin) break;
+            continue;
+        }
+        const u8* runbase = src + uni(slot[66]) - uni(slot[67]);     // + a literal run's cache index = where the run lies in the input
+        const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
+        const u32 desc = (qt & 0x20000u) ? (0x80000000u | lo) : lo;
+        u32 last;
+        (void)fast_emit<OW, CFG2>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, runbase, lane, last, 65536u);
+    }
+    sk.flush();
+    out.finish();
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), hist);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
 static thread_local u32 t_batch_total = 0;     // streams of the whole batch the current launch belongs to (alz_launch_decode)
 static thread_local int t_variant = 0;         // alz_ctx_set_kernel_variant: 0 automatic, 1 one wavefront per stream, 2 two where such a kernel exists
@@ -776,6 +900,20 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
         }
     }
     hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), 0, stream, src, dst, streams, index, count, results, lz, lw);
+    return hipGetLastError();
+}
+
+// LZ4 / LZO / Snappy: two wavefronts per stream (alz_decode_queue2_kernel) for launches that cannot fill the GPU -- there a launch takes
+// as long as one stream, and parse and copy overlapping cut that by a fifth (256 KiB alone: LZ4 1.70 -> 1.37 ms).  A full GPU is
+// bound by throughput, and there the pair loses: the copying wavefront is the longer half and the parsing one waits for it (10 000
+// streams: LZ4 7.2 against 5.5 ms, LZO 9.2 against 8.2, Snappy 8.2 against 7.2).
+#ifndef ALZ_QUEUE2_MAX
+#define ALZ_QUEUE2_MAX 3072u   /* 2 500 streams: LZ4 2.15 against 2.44 ms, LZO 2.97 / 3.48, Snappy 2.45 / 3.17; 4 000: 3.59 / 2.74, 4.46 / 4.02, 3.97 / 3.54 */
+#endif
+static bool queue_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= ALZ_QUEUE2_MAX); }
+template <int FMT>
+static hipError_t launch_queue2(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count, alz_result* results) {
+    hipLaunchKernelGGL((alz_decode_queue2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results);
     return hipGetLastError();
 }
 
@@ -848,9 +986,12 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
                              return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_PRS_LE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results); return hipGetLastError(); }
                              return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
-        case ALZ_FMT_LZ4_BLOCK: return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
-        case ALZ_FMT_LZO: return launch_queue<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
-        case ALZ_FMT_SNAPPY_RAW: return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_LZ4_BLOCK: if (queue_two_waves()) return launch_queue2<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
+                                return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_LZO: if (queue_two_waves()) return launch_queue2<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
+                          return launch_queue<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results);
+        case ALZ_FMT_SNAPPY_RAW: if (queue_two_waves()) return launch_queue2<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
+                                 return launch_queue<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_FASTLZ: return launch_queue<ALZ_FMT_FASTLZ>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_CNX2: return launch_queue<ALZ_FMT_CNX2>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_CNS: return launch_queue<ALZ_FMT_CNS>(stream, s, d, streams, index, count, results);

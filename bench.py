@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the byte comparison with the CPU restatement")
     ap.add_argument("--no-extras", action="store_true", help="skip copy bandwidth and the end-to-end (host buffer) run")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight of the secondary, pipelined figure (1 = do not measure it)")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="alz_ctx_set_kernel_variant: 0 the library chooses, 1 / 2 one / two wavefronts per stream where both shapes exist (tuning)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--all-ranks-on-device", type=int, default=-1, help="smoke test: every rank uses this GPU (needs --dist-backend gloo)")
     return ap.parse_args()
@@ -205,6 +206,8 @@ def main():
     decomp_bytes = int(n) * target
 
     ctx = Context(local_rank)
+    if args.kernel_variant:
+        ctx.set_kernel_variant(args.kernel_variant)
     main_db = DeviceBatch(ctx, batch, Plan)
 
     def barrier():

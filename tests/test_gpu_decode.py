@@ -280,6 +280,16 @@ def test_prs_one_wavefront_kernel_still_agrees():
 
 
 @pytest.mark.parametrize("variant", [1, 2])
+def test_lz4_lzo_snappy_agree_on_one_and_two_wavefronts(variant):
+    """LZ4 / LZO / Snappy run on two wavefronts per stream in launches that cannot fill the GPU (alz_decode_queue2_kernel: one parses,
+    one executes, literal runs read from the input in global memory) and on one otherwise; alz_ctx_set_kernel_variant forces either."""
+    from auroralib.compression_amd.batch import Context
+    with Context(0) as c:
+        c.set_kernel_variant(variant)
+        _agrees_with_the_oracle(c, (A.FMT_LZ4_BLOCK, A.FMT_LZO, A.FMT_SNAPPY_RAW), True)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
 def test_flag_formats_agree_on_one_and_two_wavefronts(variant):
     """The flag-byte formats pick one or two wavefronts per stream by the size of the batch (alz_ctx_set_kernel_variant: 1 / 2 force
     either shape); both kernels must give the oracle's bytes, lengths, consumed input and status for valid and noisy streams."""
