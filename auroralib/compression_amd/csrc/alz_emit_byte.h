@@ -127,6 +127,9 @@ __device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds
 
 // Execution of one batch of tokens (after the shared emit_prologue of alz_emit_chunk.h), 64 output bytes per step.
 // `segmark`: 128 bytes of LDS (zeroed by the kernel), `inlds`: the LDS input cache literal runs point into.
+// (Round 3 tried the byte -> token mapping without the mark array -- every token sets one bit of a bitmap of the batch's output once per
+// 1 024 bytes, a step's 64 bits are two v_readlane away from a register copy of it, no LDS traffic per step: 7 % SLOWER on every byte-phase
+// format (Yaz0 3.50 against 3.27 ms, LZ10 4.49 / 4.23, PRS 5.92 / 5.57).  The mark chain runs beside the copy chain and is not what a step waits for.)
 template <class OW, class CFG>
 __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* inlds, int lane, const EmitState& e) {
     u32 desc = e.desc;
@@ -134,22 +137,20 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
         if (desc >> 31) desc = 0x80000000u | ((desc - (e.O + e.off + out.oshift)) & 2047u);
     }
     const u32 O = e.O, T = e.T, W = e.W;
-    u32 X = 0, tbase4 = 0;                                   // tbase4: 4 x (tokens that ended before the current step)
-    u32 relm = e.kept ? e.off + e.clen - 1u : 0xFFFFFF00u;   // my token's LAST byte relative to the current step (huge: none)
+    u32 X = 0;
     u32 qs = O + (u32)lane + out.oshift;                     // slot coordinate of this lane's byte in the current step
-    // steps that may still point before the stream start (E2) -- only inside the first W bytes of a stream
+    u32 tbase4 = 0;                                          // tbase4: 4 x (tokens that ended before the current step)
+    u32 relm = e.kept ? e.off + e.clen - 1u : 0xFFFFFF00u;   // my token's LAST byte relative to the current step (huge: none)
     while (X + 64u <= T && O + X < W) { byte_step<OW, CFG, true, true>(out, segmark, inlds, lane, desc, relm, qs, tbase4, 64u); X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks(); }
-    // steady state: flush checks only where the output crosses a flush-block boundary (the loop in between is a bare
-    // counter: the kernel is bound by instruction issue per wave, scalar instructions included)
     u32 nleft = (T - X) >> 6;
     u32 dsc = 0; bool have = false;
     if (nleft) {
-        dsc = map_step(segmark, lane, desc, relm, tbase4); have = true;      // pipeline prologue: descriptors of the first step
+        dsc = map_step(segmark, lane, desc, relm, tbase4); have = true;
         do {
             const u32 pos = O + X + out.oshift;
             u32 nb = (out.fl - (pos & (out.fl - 1u)) + 63u) >> 6;
             if (nb > nleft) nb = nleft;
-            u32 k = nb, dsc2;                               // two steps per trip: the descriptors ping-pong between two registers
+            u32 k = nb, dsc2;
             for (; k >= 2u; k -= 2u) {
                 fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc, dsc2);
                 fused_step<OW, CFG>(out, segmark, inlds, lane, desc, relm, qs, tbase4, dsc2, dsc);
@@ -159,7 +160,7 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
             if (out.produced - out.flushed >= out.fl) out.flush_blocks();
         } while (nleft);
     }
-    if (X < T) {                                              // last, partial step (its descriptors may already be mapped)
+    if (X < T) {
         if (!have) dsc = map_step(segmark, lane, desc, relm, tbase4);
         copy_step<OW, CFG>(out, inlds, lane, dsc, 0u, qs, T - X, true);
         out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks();

@@ -22,7 +22,7 @@ if a.cmd:
     lines += ["command: `%s`" % a.cmd, "", "(dispatches of alz_* kernels with at least %d workgroups: the named configuration; the small headline batch of the same run is left out)" % a.minwg, ""]
 per = collections.defaultdict(list)
 for r in rows(a.stats, "kernel_trace.csv"):
-    if "alz_" not in r["Kernel_Name"]:
+    if "alz_decode" not in r["Kernel_Name"]:
         continue
     wg = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
     if wg >= a.minwg:
@@ -36,7 +36,7 @@ for label, d, mult in (("FETCH_SIZE", a.fetch, 2.0), ("WRITE_SIZE", a.write, 1.0
         continue
     acc = collections.defaultdict(list)
     for r in rows(d, "counter_collection.csv"):
-        if "alz_" in r["Kernel_Name"] and r["Counter_Name"] == label and int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) >= a.minwg:
+        if "alz_decode" in r["Kernel_Name"] and r["Counter_Name"] == label and int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) >= a.minwg:
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     tot[label] = {k: sum(v) / len(v) * 1024 * mult for k, v in acc.items()}
     lines += ["", "## %s (separate `--pmc %s` pass)" % (label, label), "", "corrected bytes per launch (x%.0f, gfx950 rule), per kernel:" % mult, ""]
