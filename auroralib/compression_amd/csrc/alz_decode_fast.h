@@ -505,11 +505,17 @@ struct QueueSink {
 // FastLZ 5.90 -> 6.43 -- 12 / 21 / 9 % of the kernel; a two- or four-element hop (nx2 = nx + nx[. + nx] through LDS) would trade
 // ~100 scalar instructions per round for ~20 LDS ones and was not built.
 #define ALZ_NX_BAD 0x1000u
-__device__ __forceinline__ void lane_walk_pos(const u32 (&nx)[4], u32 enter_below, u32& spos_out, u32& sp_out, u32& n_out) {
+// `fill3` (round 3): the sizes of the FOURTH window, worked out only when the walk gets there -- with one-token elements of ~5 bytes the
+// first three windows already hold more than 32 elements and the fourth is never entered: a quarter of the speculation was for nothing.
+// (The first three stay eager: their LDS reads are in flight together.)
+struct NoFill3 { __device__ __forceinline__ void operator()(u32&) const {} };
+template <class F3 = NoFill3>
+__device__ __forceinline__ void lane_walk_pos(u32 (&nx)[4], u32 enter_below, u32& spos_out, u32& sp_out, u32& n_out, F3 fill3 = F3()) {
     u32 spos = 0, sp = 0, cnt = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         if (cnt < enter_below && sp < 64u * (u32)(w + 1)) {
+            if (w == 3) fill3(nx[3]);
             u32 n;
             asm volatile(
                 "s_mov_b32 m0, %[cnt]\n\t"
@@ -650,9 +656,7 @@ struct Lz4Rounds {
 __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
     // 1. speculation: the size of "the element that would start at my byte"
-    u32 nx[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
+    auto size_at = [&](int w) -> u32 {
         const u32 pos = i0 + 64u * (u32)w + (u32)lane;
         const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2];
         const u32 type = b & 3u, hi = b >> 2;
@@ -663,11 +667,15 @@ __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane,
             n = (hi > 61u || len > ALZ_QRUN) ? ALZ_NX_BAD : hdr + len;      // the run has to stay inside the resident input cache
         }
         if (type == 3u) n = ALZ_NX_BAD;                                 // 4-byte offsets (E3 check included) stay with the exact parser
-        nx[w] = n;
-    }
+        return n;
+    };
+    u32 nx[4];
+#pragma unroll
+    for (int w = 0; w < 3; w++) nx[w] = size_at(w);
+    nx[3] = 0;
     // 2. the walk: one token per element, lane j = j-th element (a window holds <= 32 elements)
     u32 spos, sp, nel;
-    lane_walk_pos(nx, 33u, spos, sp, nel);
+    lane_walk_pos(nx, 33u, spos, sp, nel, [&](u32& n3) { n3 = size_at(3); });
     if (nel == 0u) return false;
     // 3. the elements' tokens
     const u32 pos = i0 + spos;
@@ -1122,11 +1130,13 @@ struct FastlzRounds {
 // when entered in state A, [19:11] and [21:20] the same for states B / C.  state: 0 = A, 1 = B (1-3 literals pending),
 // 2 = C (a literal run came before).  Lane j of `spos` receives (start offset | entry state << 9) of the j-th
 // instruction; same loop discipline as lane_walk_pos (an instruction has >= 2 bytes: <= 32 per window).
-__device__ __forceinline__ void lzo_walk_pos(const u32 (&pk)[4], u32& spos_out, u32& sp_out, u32& n_out, u32& state_io) {
+template <class F3>
+__device__ __forceinline__ void lzo_walk_pos(u32 (&pk)[4], u32& spos_out, u32& sp_out, u32& n_out, u32& state_io, F3 fill3) {
     u32 spos = 0, sp = 0, cnt = 0, state = uni(state_io), n = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         if (cnt < 33u && sp < 64u * (u32)(w + 1)) {          // (a window of 64 bytes adds at most 32 instructions: lane j <= 63)
+            if (w == 3) fill3(pk[3]);
             u32 v, sh, t;
             asm volatile(
                 "s_mov_b32 m0, %[cnt]\n\t"
@@ -1198,9 +1208,10 @@ __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, 
     const u32 i0 = in.idx(p);
     u32 pk[4], dummy;
 #pragma unroll
-    for (int w = 0; w < 4; w++) pk[w] = lzo_interpret<false>(in, i0 + 64u * (u32)w + (u32)lane, 0u, dummy);
+    for (int w = 0; w < 3; w++) pk[w] = lzo_interpret<false>(in, i0 + 64u * (u32)w + (u32)lane, 0u, dummy);
+    pk[3] = 0;                                                   // (worked out when the walk gets there: usually it does not)
     u32 spos, sp, ninstr;
-    lzo_walk_pos(pk, spos, sp, ninstr, state);
+    lzo_walk_pos(pk, spos, sp, ninstr, state, [&](u32& p3) { u32 d2; p3 = lzo_interpret<false>(in, i0 + 192u + (u32)lane, 0u, d2); });
     if (ninstr == 0u) return false;
     // one lane per instruction, in the state the walk entered it: match / run token + trailing-literal token.  The walk takes as
     // many instructions as its windows hold (up to 64; round 2 stopped at 32 whatever they yield, ~39 tokens); the round keeps those

@@ -552,11 +552,14 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     const int chain = g.max_chain;
     for (int it = 0; it < chain; it++) {
         if (!__ballot(act)) break;
-        const int c = act ? cur : 0;
+        const int c = act ? cur : pos;
         const int dist = pos - c;
-        const u64 x = head ^ load64(data + c);
-        const int nxt = it + 1 < chain ? p4[c] : -1;                    // (the last candidate's link is never followed: at maxChain 1 that is every one)
         const bool within = act && dist <= g.max_dist;                  // beyond maxDistance the walk ends  :259-260
+        // (a candidate out of reach is not touched: the previous position with this hash usually lies further back than a 4 KiB window
+        //  reaches, anywhere in the stream -- an 8-byte read that misses every cache and is thrown away)
+        const int cl = within ? c : pos;
+        const u64 x = head ^ load64(data + cl);
+        const int nxt = (within && it + 1 < chain) ? p4[cl] : -1;       // (the last candidate's link is never followed: at maxChain 1 that is every one)
         const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
@@ -703,8 +706,8 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             if (!__ballot(act || fresh)) break;
             const int c = act ? cur : 0;
             const int dist = pos - c;
-            const int nxt = (act && it + 1 < chain) ? p4[c] : -1;               // (the last candidate's link is never followed)
             const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
+            const int nxt = (within && it + 1 < chain) ? p4[c] : -1;            // (the last candidate's link is never followed, nor that of a candidate out of reach)
             const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
             const u64 om = __ballot(ok);
             if (om) {
@@ -729,8 +732,8 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             if (!__ballot(act)) break;
             const int c = act ? cur : 0;
             const int dist = pos - c;
-            const int nxt = (act && it + 1 < chain) ? p4[c] : -1;               // (the last candidate's link is never followed)
             const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
+            const int nxt = (within && it + 1 < chain) ? p4[c] : -1;            // (the last candidate's link is never followed, nor that of a candidate out of reach)
             const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
             const u64 om = __ballot(ok);
             if (om) {
@@ -777,6 +780,13 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
   }
 }
 
+// (Tried in round 3: kernel B with the stream's window in LDS -- a workgroup of eight wavefronts copies the bytes and the links, as 16-bit
+// distances, of [base - 4096, base + 8192) into LDS and runs both phases of the dense kernel on LDS alone, candidate bytes from three aligned
+// dwords and v_alignbyte.  Memory traffic falls from 223 GB to about 40, but the kernel is not bound by it: 78 ms against 54 at quality 8,
+// 701 against 112 at quality 15.  Counters: the LDS pipe is 5 % busy, VALU + SALU issue 86 % at quality 8 -- the walk is bound by the
+// instructions of its trips, and the LDS form has more of them (address arithmetic, three reads and two alignbytes per eight bytes) at
+// half the wavefronts per CU (68 KB of LDS per workgroup); at quality 15 a workgroup waits for the one wavefront whose block holds a
+// 1024-step chain.  DESIGN.md 8.)
 template <bool MINT>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
@@ -2181,7 +2191,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     if (bx > 128u) bx = 128u;
     // (blocks per stream: a thread of 128 blocks takes eight positions of a 256 KiB stream; one position per thread, ten million blocks per launch: 18.6 against 17.4 ms)
-    if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {                  // (from maxChain 3 on: the chains first, the pairs 64 at a time)
+    if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {             // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         if (dyn) {

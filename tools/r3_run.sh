@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for f in lz4_block lzo snappy_raw; do for n in 1 640 1250 2500 4000; do for v in 1 2; do echo -n "$f streams=$n variant=$v: "; python bench.py --no-cpu-baseline --no-extras --configs none --no-verify --inflight 1 --steps 20 --format $f --streams $n --kernel-variant $v 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])"; done; done; done
+bash tools/profile_r03.sh lz4_block lzo mixed 2>&1 | grep -v amdgpu.ids
