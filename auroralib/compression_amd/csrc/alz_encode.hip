@@ -536,7 +536,7 @@ template <bool MINT>
 __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
                                              int& best_d, int& best_l) {
     const u8* dp = data + pos;
-    int cur = p4[pos];
+    int cur = __builtin_nontemporal_load(p4 + pos);                     // (each position's first link is read once, by this lane)
     int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
     const int cmp_max = (cap > 0 && best_possible > cap) ? cap : best_possible;
     best_d = 0; best_l = 0; int best_score = -1;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
                 }
             }
         }
-        m[pos] = capped ? make_uint2(ALZ_CAPPED, ALZ_CAPPED) : make_uint2((u32)best_d, (u32)best_l);
+        __builtin_nontemporal_store(capped ? 0xFFFFFFFFFFFFFFFFull : ((unsigned long long)(u32)best_l << 32) | (u32)best_d, reinterpret_cast<unsigned long long*>(m + pos));
     }
   }
 }
@@ -800,13 +800,26 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
     uint2* m = match + pos_off[sid];
-    for (int pos = (int)(blockIdx.x * 256 + threadIdx.x); pos <= limit; pos += (int)(gridDim.x * 256)) {
+    // A workgroup takes ONE contiguous range of the stream (round 3).  With the positions of a workgroup 32 Ki apart -- 256 here, 256 there --
+    // every group of 256 fetched its own 4 KiB of history into its XCD's L2: 30 GB of fetches for 2.6 GB of input, and this is the one
+    // kernel of the path that waits for memory (0.57 instructions per cycle and CU).
+    const int span = (((limit + 1 + (int)gridDim.x - 1) / (int)gridDim.x) + 255) & ~255;
+    const int first = (int)blockIdx.x * span;
+    const int last = first + span - 1 < limit ? first + span - 1 : limit;
+    for (int pos = first + (int)threadIdx.x; pos <= last; pos += 256) {
         int bd, bl;
-        if (match_search_b<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl)) m[pos] = make_uint2((u32)bd, (u32)bl);
-        else m[pos] = make_uint2(ALZ_CAPPED, ALZ_CAPPED);
+        const bool okm = match_search_b<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
+        const unsigned long long v = okm ? ((unsigned long long)(u32)bl << 32) | (u32)bd : 0xFFFFFFFFFFFFFFFFull;
+        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(m + pos));       // (written once, read by the next kernel: past the caches)
     }
 }
 
+// (Tried in round 3 for maxChain 1 (quality 0), where this kernel issues only 0.57 instructions per cycle and CU: four positions per thread
+// with the loads of every stage in flight together -- links and the positions' own sixteen bytes, then the candidates' sixteen bytes as one
+// load each, then the arithmetic: 16.7-17.1 ms against 16.8.  Neither the chain of dependent round trips nor the L1's lookups (0.77 per
+// cycle) is the bound: without the link loads (10.5 GB) the kernel takes 12.7 ms, without the scattered candidate loads 15.3 -- it moves
+// 18 GB in and 21 GB out (8 bytes of match per position) at ~2.4 TB/s, three streams per workgroup against a copy kernel's two at 5.8.
+// What would pay is fewer bytes per position in the arrays the kernels hand to each other: DESIGN.md 8.)
 // ---------------------------------------------------------------------------------------------- kernel C
 struct Out {                 // bounded byte sink of one stream
     u8* p; u32 len, cap; bool fail;
@@ -1399,9 +1412,10 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
         carryw = 0xFFFFFFFFu;
         // match[p] and match[p+1] (positions above `limit` were never searched: no match)
         uint2 a = make_uint2(0, 0);
-        if (P == Pn) a = nx; else if (p <= limit) a = m[p];
+        auto ldm = [&](int q) { const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(m + q)); return make_uint2((u32)v, (u32)(v >> 32)); };
+        if (P == Pn) a = nx; else if (p <= limit) a = ldm(p);
         nx = make_uint2(0, 0); Pn = P + 64;
-        if (p + 64 <= limit) nx = m[p + 64];
+        if (p + 64 <= limit) nx = ldm(p + 64);
         uint2 b;
         b.x = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.x); b.y = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.y);
         {   // lane 63's neighbour is the first position of the next window

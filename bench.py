@@ -395,6 +395,9 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
             verified = verified and bytes(got) == want
         pl.close(); ctx.free(d_back)
         ok = ok and verified
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_encode(ctx, raw_db, recs, r2, n, target, fmt, args, len(os.sched_getaffinity(0)), np, A)
     raw_bytes = float(n) * target
     if dist is not None:
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev or "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok = bool(t.item() > 0.5)
@@ -415,7 +418,7 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
                        "compressed_bytes_whole_job": int(job_comp), "ratio": round(job_comp / job_raw, 4), "parallelism": parallelism,
                        "parity_ok": ok, "verified_roundtrip_and_vs_oracle": verified},
             "roofline": roofline(raw_bytes + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (args.format, args.quality), n, args.stream_kib)),
-            "cpu_baseline": None,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     ctx.free(d_out); raw_db.close(); ctx.close()
@@ -480,6 +483,39 @@ def cpu_baseline(O, A, np, batch, recs, n, target, args, aff):
             "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota_cores": cpu_quota(),
             "sample": "first max(256, 64 T) of the %d x %d KiB %s streams per thread count T, %d passes at T = %d; C restatement of the managed "
                       "ring+flush path (oracle/alz_oracle.c), streams striped over threads" % (n, args.stream_kib, args.format, reps_all, aff)}
+
+
+def cpu_baseline_encode(ctx, raw_db, recs, r2, n, target, fmt, args, aff, np, A):
+    """Compression beside it: the C restatement of LzChainMatchFinder + CompressHeaderless (kind "port", oracle/alz_oracle.c) on the first
+    buffers of the measured batch, one thread and the cores this process may use; a bounded sample (a few seconds per thread count)."""
+    import ctypes as C
+    import oracle_lib as O
+    st = A.Settings(); st.quality = args.quality
+
+    def rate(nb, threads, budget):
+        span = int(recs["dst_off"][nb - 1]) + target
+        raw = np.frombuffer(ctx.d2h(raw_db.d_dst, span + 64), dtype=np.uint8).copy()
+        streams = (A.Stream * nb)()
+        C.memmove(streams, r2[:nb].tobytes(), nb * C.sizeof(A.Stream))
+        dst = np.ones(int(r2["dst_off"][nb - 1]) + int(r2["dst_cap"][nb - 1]) + 64, dtype=np.uint8)
+        res = (A.Result * nb)(); aux = (A.EncodeAux * nb)()
+        reps, t0 = 0, time.perf_counter()
+        while reps < 1 or (time.perf_counter() - t0 < budget and reps < 20):
+            O.lib.oracle_encode_batch(None, C.byref(st), nb, raw.ctypes.data, streams, dst.ctypes.data, res, aux, threads)
+            reps += 1
+        return nb * target * reps / (time.perf_counter() - t0) / 2**30, reps
+    sweep, reps_all, nb_all = {}, 0, 0
+    for t in sorted(set([1, aff])):
+        nb = min(n, max(32, 8 * t))
+        v, r = rate(nb, t, 6.0)
+        sweep[str(t)] = round(v, 4)
+        if t == aff:
+            reps_all, nb_all = r, nb
+    best_t = max(sweep, key=lambda k: sweep[k])
+    return {"value": sweep[best_t], "unit": "GiB/s of raw input", "cores": int(best_t), "kind": "port", "single_thread": sweep["1"],
+            "threads_sweep_GiB_s": sweep, "cpu_model": cpu_model(), "sched_affinity": aff, "cgroup_cpu_quota_cores": cpu_quota(),
+            "sample": "first %d of the %d x %d KiB raw buffers at quality %d, %d passes at T = %d; C restatement of LzChainMatchFinder + "
+                      "CompressHeaderless (oracle/alz_oracle.c), buffers striped over threads" % (nb_all, n, args.stream_kib, args.quality, reps_all, aff)}
 
 
 def run_extras(ctx, batch, recs, n, target, decomp_bytes, np, synth, A):
