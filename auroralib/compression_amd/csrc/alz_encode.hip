@@ -442,8 +442,33 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     }
 }
 
-#define ALZ_LEN_CAP 2048
+#define ALZ_LEN_CAP 2040
 #define ALZ_CAPPED 0xFFFFFFFFu
+
+// The match array kernel B hands to the parse and the emitters: ONE 32-bit entry per position (round 3; two words before) -- distance in
+// the low 21 bits, length in the 11 above.  Kernel B compares at most ALZ_LEN_CAP = 2 040 bytes, so its lengths fit; the two length codes
+// above them mean: ALZ_M_CAP -- kernel B ran into its cap here (the parse recomputes the position exactly if it ever visits it) --, and
+// ALZ_M_LONG -- an exact length of 2 046 or more, written by the parse for a match it TOOK: the length itself is the next entry (that
+// position lies inside the match: neither the parse nor an emitter ever looks at it as a position).  Finder geometries whose
+// maxDistance does not fit 21 bits (FastLZ with MaxWindowBits above 20) are refused by alz_encode_geom.
+typedef u32 mentry;
+#define ALZ_M_DBITS 21u
+#define ALZ_M_DMASK 0x1FFFFFu
+#define ALZ_M_LONG 0x7FEu
+#define ALZ_M_CAP 0x7FFu
+__device__ __forceinline__ mentry m_pack(u32 d, u32 l) { return (l << ALZ_M_DBITS) | d; }
+__device__ __forceinline__ uint2 m_unpack(mentry e) { const u32 l = e >> ALZ_M_DBITS; return make_uint2(e & ALZ_M_DMASK, l == ALZ_M_CAP ? ALZ_CAPPED : l); }
+// the (distance, length) of the entry a lane loaded for position p, behind the roles walk (nothing is capped any more); lanes that START
+// a token there get the exact length.  LONGS: the format has matches of 2 046 bytes or more.
+template <bool LONGS>
+__device__ __forceinline__ uint2 m_start(const mentry* m, u32 p, mentry e, bool start) {
+    uint2 r = make_uint2(e & ALZ_M_DMASK, e >> ALZ_M_DBITS);
+    if (LONGS) {
+        const bool lg = start && r.y == ALZ_M_LONG;
+        if (__ballot(lg)) { if (lg) r.y = m[p + 1]; }
+    }
+    return r;
+}
 
 // GetMatchLength  LzChainMatchFinder.cs:338-357
 __device__ __forceinline__ int match_len(const u8* a, const u8* b, int max) {
@@ -626,7 +651,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
 template <bool MINT, bool DYN, int ALZ_DENSE_POS>
 __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev4,
-                                                             const int* __restrict__ prevm, uint2* __restrict__ match,
+                                                             const int* __restrict__ prevm, mentry* __restrict__ match,
                                                              const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
     __shared__ u32 lpos[ALZ_DENSE_LIST];          // position inside the block | step << 8
     __shared__ int lcand[ALZ_DENSE_LIST];
@@ -639,7 +664,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     const int limit = n - 4;
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
-    uint2* m = match + pos_off[sid];
+    mentry* m = match + pos_off[sid];
     const int lane = (int)threadIdx.x;
     const int chain = g.max_chain;
   // (the grid holds at most 4 096 workgroups per stream: a stream longer than 4 096 blocks -- and a batch whose longest stream is far
@@ -775,7 +800,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
                 }
             }
         }
-        __builtin_nontemporal_store(capped ? 0xFFFFFFFFFFFFFFFFull : ((unsigned long long)(u32)best_l << 32) | (u32)best_d, reinterpret_cast<unsigned long long*>(m + pos));
+        __builtin_nontemporal_store(capped ? 0xFFFFFFFFu : m_pack((u32)best_d, (u32)best_l), m + pos);
     }
   }
 }
@@ -790,7 +815,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 template <bool MINT>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
-                                                        const int* __restrict__ prevm, uint2* __restrict__ match,
+                                                        const int* __restrict__ prevm, mentry* __restrict__ match,
                                                         const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
     const u32 sid = index_list[blockIdx.y];
     const alz_stream st = streams[sid];
@@ -799,7 +824,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     const int limit = n - 4;
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
-    uint2* m = match + pos_off[sid];
+    mentry* m = match + pos_off[sid];
     // A workgroup takes ONE contiguous range of the stream (round 3).  With the positions of a workgroup 32 Ki apart -- 256 here, 256 there --
     // every group of 256 fetched its own 4 KiB of history into its XCD's L2: 30 GB of fetches for 2.6 GB of input, and this is the one
     // kernel of the path that waits for memory (0.57 instructions per cycle and CU).
@@ -809,8 +834,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     for (int pos = first + (int)threadIdx.x; pos <= last; pos += 256) {
         int bd, bl;
         const bool okm = match_search_b<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
-        const unsigned long long v = okm ? ((unsigned long long)(u32)bl << 32) | (u32)bd : 0xFFFFFFFFFFFFFFFFull;
-        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(m + pos));       // (written once, read by the next kernel: past the caches)
+        __builtin_nontemporal_store(okm ? m_pack((u32)bd, (u32)bl) : 0xFFFFFFFFu, m + pos);   // (written once, read by the next kernel: past the caches)
     }
 }
 
@@ -864,25 +888,13 @@ struct FlagW {
 
 struct Match { int offset, distance, length; };
 
-// FindNextBestMatch  LzChainMatchFinder.cs:157-212 over the precomputed MatchSearch results
+// FindNextBestMatch  LzChainMatchFinder.cs:157-212 for the serial emitters: the parse is the start mask of the roles walk (one bit per
+// match it takes, set at the match's first byte), so the next match is the next set bit, and only ITS entry of the match array is read.
 struct Finder {
-    const uint2* m; int n, limit, position, min_len, lazy;
-    const u8* data; const int* p4; const int* pm; const EncGeom* g;
-    __device__ uint2 get(int pos) const {
-        uint2 r = m[pos];
-        if (r.y == ALZ_CAPPED) {                     // capped by kernel B: recompute this one exactly
-            int bd, bl;
-            if (g->use_min_table) match_search<true>(data, n, pos, p4, pm, *g, 0, bd, bl); else match_search<false>(data, n, pos, p4, pm, *g, 0, bd, bl);
-            r = make_uint2((u32)bd, (u32)bl);
-        }
-        return r;
-    }
-    // With the start mask of the roles walk (one bit per match the parse takes, set at its first byte) the parse is already done:
-    // the next match is the next set bit, and only ITS entry of the match array is read -- the walk below reads one entry per
-    // position (two where the lazy rule looks ahead), each a memory round trip for the one lane that works.
+    const mentry* m; int n, limit, position;
     const u64* mask = nullptr; int widx = -1; u64 wbits = 0, wnext = 0;
-    __device__ Match next_masked() {
-        const int nwords = (limit >> 6) + 1;                      // (limit >= 0 here)
+    __device__ Match next() {
+        const int nwords = limit >= 0 ? (limit >> 6) + 1 : 0;
         for (;;) {
             if (wbits == 0ull) {
                 widx++;
@@ -894,31 +906,9 @@ struct Finder {
             const int b = (int)__builtin_ctzll(wbits);
             wbits &= wbits - 1ull;
             const int p = widx * 64 + b;
-            const uint2 r = m[p];                                    // (exact: the roles walk has recomputed what kernel B had capped)
+            uint2 r = m_unpack(m[p]);                                // (exact: the roles walk has recomputed what kernel B had capped)
+            if (r.y == ALZ_M_LONG) r.y = m[p + 1];
             Match out = { p, (int)r.x, (int)r.y };
-            return out;
-        }
-        position = n;
-        Match e = { n, 0, 0 };
-        return e;
-    }
-    __device__ Match next() {
-        if (mask) { if (limit < 0) { position = n; Match e = { n, 0, 0 }; return e; } return next_masked(); }
-        while (position <= limit) {
-            uint2 r = get(position);
-            int bl = (int)r.y, bd = (int)r.x;
-            if (bl < min_len) { position++; continue; }
-            int skip = 0;
-            if (bl <= lazy && position + 1 <= limit) {
-                const uint2 r2 = get(position + 1);
-                if ((int)r2.y > bl) { bl = (int)r2.y; bd = (int)r2.x; position++; }
-                else skip = 1;
-            }
-            Match out = { position, bd, bl };
-            const int end = position + bl;
-            position += 1 + skip;
-            int stop = end < limit + 1 ? end : limit + 1;
-            if (position < stop) position = stop;
             return out;
         }
         position = n;
@@ -936,8 +926,7 @@ __device__ void lzo_ext(Out& o, int v) { while (v > 255) { o.put(0); v -= 255; }
 template <int FMT>
 __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                       const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                      u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
-                                                      const int* __restrict__ prev4, const int* __restrict__ prevm,
+                                                      u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
                                                       u8* __restrict__ side, alz_result* __restrict__ results,
                                                       alz_encode_aux* __restrict__ aux, EncGeom g, u32 lone, const u64* __restrict__ startmask) {
     // lone: ONE stream per wavefront, lane 0 works.  Sixty-four streams per wavefront executed the union of 64 divergent token
@@ -950,10 +939,9 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
     const u8* src = src_base + st.src_off;
     const int n = (int)st.src_len;
     Out out = { dst_base + st.dst_off, 0, st.dst_cap, false };
-    Finder mf; mf.m = match + pos_off[sid]; mf.position = 0; mf.min_len = g.min_len; mf.lazy = g.lazy;
+    Finder mf; mf.m = match + pos_off[sid]; mf.position = 0;
     mf.n = (FMT == ALZ_FMT_LZ4_BLOCK) ? n - 5 : n; mf.limit = mf.n - 4;
-    mf.data = src; mf.p4 = prev4 + pos_off[sid]; mf.pm = g.use_min_table ? prevm + pos_off[sid] : nullptr; mf.g = &g;
-    mf.mask = startmask ? startmask + (pos_off[sid] >> 6) : nullptr;
+    mf.mask = startmask + (pos_off[sid] >> 6);
     int status = ALZ_ST_OK; u32 a0 = 0, a1 = 0;
     int sp = 0;
 
@@ -1383,7 +1371,7 @@ __device__ __forceinline__ u32 scan_max(u32 v) {            // inclusive wave pr
 }
 
 __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
-                                                       const u32* __restrict__ index_list, u32 count, uint2* __restrict__ match,
+                                                       const u32* __restrict__ index_list, u32 count, mentry* __restrict__ match,
                                                        const u64* __restrict__ pos_off, const int* __restrict__ prev4,
                                                        const int* __restrict__ prevm, u64* __restrict__ startmask, EncGeom g, int tail_skip) {
     const u32 bid = blockIdx.x;
@@ -1394,7 +1382,7 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;            // LZ4 searches source[0 : n-5]  (LZ4.cs:208)
     const int limit = n - 4;
-    uint2* m = match + pos_off[sid];
+    mentry* m = match + pos_off[sid];
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
     u64* mask = startmask + (pos_off[sid] >> 6);
@@ -1412,7 +1400,8 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
         carryw = 0xFFFFFFFFu;
         // match[p] and match[p+1] (positions above `limit` were never searched: no match)
         uint2 a = make_uint2(0, 0);
-        auto ldm = [&](int q) { const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(m + q)); return make_uint2((u32)v, (u32)(v >> 32)); };
+        // (an ALZ_M_LONG entry -- or the raw length behind one -- is never looked at here: both lie at or inside a match this walk has taken)
+        auto ldm = [&](int q) { return m_unpack(__builtin_nontemporal_load(m + q)); };
         if (P == Pn) a = nx; else if (p <= limit) a = ldm(p);
         nx = make_uint2(0, 0); Pn = P + 64;
         if (p + 64 <= limit) nx = ldm(p + 64);
@@ -1463,13 +1452,25 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 int d0, l0, d1 = 0, l1 = 0;
                 if (g.use_min_table) match_search<true>(data, n, q, p4, pm, g, 0, d0, l0); else match_search<false>(data, n, q, p4, pm, g, 0, d0, l0);
                 if (q + 1 <= limit) { if (g.use_min_table) match_search<true>(data, n, q + 1, p4, pm, g, 0, d1, l1); else match_search<false>(data, n, q + 1, p4, pm, g, 0, d1, l1); }
-                if (lane == 0) { m[q] = make_uint2((u32)d0, (u32)l0); if (q + 1 <= limit) m[q + 1] = make_uint2((u32)d1, (u32)l1); }
                 if (q + 1 >= P + 64) Pn = -1;                           // (the window loaded ahead no longer matches memory)
                 j = 1; sr = 0;
                 if (l0 >= g.min_len) {
                     const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
                     if (lazyc && l1 > l0) { sr = 2; const int e = q + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 2 > stop ? q + 2 : stop) - q; }
                     else { sr = 1; const int skip = lazyc ? 1 : 0; const int e = q + l0; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 1 + skip > stop ? q + 1 + skip : stop) - q; }
+                }
+                // The exact results go back into the array: the match that is TAKEN in full (the emitters read it; 2 046 bytes or more: the
+                // length in the next entry, a position inside the match), the other one as far as an entry holds it -- q's is never looked
+                // at again, q + 1's is if the walk goes there next, and stays "capped" (recomputed then) when it is too long for an entry.
+                if (lane == 0) {
+                    if (sr == 1 && l0 >= (int)ALZ_M_LONG) { m[q] = m_pack((u32)d0, ALZ_M_LONG); m[q + 1] = (u32)l0; }
+                    else {
+                        m[q] = m_pack((u32)d0, l0 < (int)ALZ_M_LONG ? (u32)l0 : ALZ_M_LONG - 1u);
+                        if (q + 1 <= limit) {
+                            if (l1 < (int)ALZ_M_LONG) m[q + 1] = m_pack((u32)d1, (u32)l1);
+                            else if (sr == 2) { m[q + 1] = m_pack((u32)d1, ALZ_M_LONG); m[q + 2] = (u32)l1; }
+                        }
+                    }
                 }
             } else {
                 j = __builtin_amdgcn_readlane(jump, rel);
@@ -1489,7 +1490,7 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
 template <int FMT>
 __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
                                                           const u64* __restrict__ startmask, u8* __restrict__ side,
                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
@@ -1507,7 +1508,7 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
     const u32 n = st.src_len;
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
-    const uint2* m = match + pos_off[sid];
+    const mentry* m = match + pos_off[sid];
     const u64* mask = startmask + (pos_off[sid] >> 6);
     u8* compb = THREE ? side + 2 * pos_off[sid] : nullptr;            // token section (Yay0/MIO0)
     u8* uncb = THREE ? side + 2 * pos_off[sid] + n + 16 : nullptr;    // literal section
@@ -1521,16 +1522,17 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
     // (mask word, match and source byte of a window are loaded while the window before it is emitted: as a chain mask -> match
     // inside the iteration, 39 wavefronts per CU left two memory round trips per window exposed)
     u64 sm_n = n ? mask[0] : 0ull;
-    uint2 mt_n = (u32)lane < n ? m[lane] : make_uint2(0, 0);
+    mentry mt_n = (u32)lane < n ? m[lane] : 0u;
     u32 sb_n = (u32)lane < n ? src[lane] : 0u;
     for (u32 P = 0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
         const u64 sm = sm_n;
-        const uint2 mt_all = mt_n;
+        const mentry mt_raw = mt_n;
         const u32 sb = sb_n;
         if (P + 64 < n) sm_n = mask[(P >> 6) + 1];
         if (p + 64 < n) { mt_n = m[p + 64]; sb_n = src[p + 64]; }
         const bool start = ((sm >> lane) & 1ull) && p < n;
+        const uint2 mt_all = m_start<(FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40)>(m, p, mt_raw, start);
         uint2 mt = make_uint2(0, 0);
         if (start) mt = mt_all;
         const u32 mend = start ? p + mt.y : 0u;
@@ -1695,6 +1697,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     // it to cover maxDistance, which holds for every format geometry of the reference
     const int chain_bits = (17 + isqrt_floor(2 * q)) < wb ? (17 + isqrt_floor(2 * q)) : wb;
     if (g.max_chain != 1 && (1 << chain_bits) < g.max_dist) return false;
+    if (g.max_dist > (int)ALZ_M_DMASK) return false;                  // a distance has 21 bits in the match array (FastLZ with MaxWindowBits above 20: the caller's own encoder)
     memcpy(out_geom, &g, sizeof(g));
     if (window_bits) *window_bits = wb;
     return true;
@@ -1756,7 +1759,7 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
 template <int FMT>
 __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
                                                           const u64* __restrict__ startmask, alz_result* __restrict__ results,
                                                           alz_encode_aux* __restrict__ aux) {
     typedef SeqFmt<FMT> F;
@@ -1775,7 +1778,7 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
         if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
         return;
     }
-    const uint2* m = match + pos_off[sid];
+    const mentry* m = match + pos_off[sid];
     const u64* mask = startmask + (pos_off[sid] >> 6);
     u32 cover = 0;          // end of the last match = first literal not yet written
     u32 obase = 0;          // bytes written before the window
@@ -1786,15 +1789,16 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
         obase = k;
     }
     u64 sm_n = n ? mask[0] : 0ull;
-    uint2 mt_n = (u32)lane < n ? m[lane] : make_uint2(0, 0);
+    mentry mt_n = (u32)lane < n ? m[lane] : 0u;
     for (u32 P = 0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
         const u64 sm = sm_n;
-        const uint2 mt_all = mt_n;
+        const mentry mt_raw = mt_n;
         if (P + 64 < n) sm_n = mask[(P >> 6) + 1];
         if (p + 64 < n) mt_n = m[p + 64];
         if (sm == 0ull) continue;                                             // (no match starts here: the literals wait for the next one)
         const bool start = ((sm >> lane) & 1ull) != 0ull;
+        const uint2 mt_all = m_start<LZ4>(m, p, mt_raw, start);              // (a Snappy copy has at most 64 bytes)
         const u32 M = start ? mt_all.y : 0u, D = mt_all.x;
         const u32 mend = start ? p + M : 0u;
         const u32 pmax = scan_max(mend);                                       // inclusive
@@ -1850,7 +1854,7 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
 template <bool BIG>
 __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
                                                           const u64* __restrict__ startmask, alz_result* __restrict__ results,
                                                           alz_encode_aux* __restrict__ aux) {
     __shared__ u32 flagacc[64];
@@ -1864,7 +1868,7 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     const u32 n = st.src_len;
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
-    const uint2* m = match + pos_off[sid];
+    const mentry* m = match + pos_off[sid];
     const u64* mask = startmask + (pos_off[sid] >> 6);
     flagacc[lane] = 0; gofs[lane] = 0;
     __syncthreads();
@@ -1874,7 +1878,7 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     u32 lastk = 0xFFFFFFFFu;    // flag byte of the last payload before the window (none yet)
     bool fail = false;
     u64 sm_n = n ? mask[0] : 0ull;
-    uint2 mt_n = (u32)lane < n ? m[lane] : make_uint2(0, 0);
+    mentry mt_n = (u32)lane < n ? m[lane] : 0u;
     u32 sb_n = (u32)lane < n ? src[lane] : 0u;
     // one more trip behind the data for the end token (bit 0, two zero bytes, bit 1) on lane 0
     for (u32 P = 0; P < n + 64u; P += 64) {
@@ -1882,10 +1886,11 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
         if (tail && P > ((n + 63u) & ~63u)) break;                             // (exactly one trip behind the last window)
         const u32 p = P + (u32)lane;
         const u64 sm = tail ? 0ull : sm_n;
-        const uint2 mt_all = mt_n;
+        const mentry mt_raw = mt_n;
         const u32 sb = sb_n;
         if (!tail) { if (P + 64 < n) sm_n = mask[(P >> 6) + 1]; if (p + 64 < n) { mt_n = m[p + 64]; sb_n = src[p + 64]; } }
         bool start = !tail && ((sm >> lane) & 1ull) && p < n;
+        const uint2 mt_all = m_start<false>(m, p, mt_raw, start);           // (a PRS match has at most 256 bytes)
         uint2 mt = make_uint2(0, 0);
         if (start) mt = mt_all;
         if (start && mt.y == 2u && mt.x > 0x100u) start = false;               // PRS.cs: not worth a long match -- literals
@@ -2012,7 +2017,7 @@ __device__ __forceinline__ u32 lzo_put_match(u8* q, u32 D, u32 M, u32 emb) {    
 #endif
 __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                          u32 count, const uint2* __restrict__ match, const u64* __restrict__ pos_off,
+                                                          u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
                                                           const u64* __restrict__ startmask, alz_result* __restrict__ results,
                                                           alz_encode_aux* __restrict__ aux) {
     const u32 bid = blockIdx.x;
@@ -2024,7 +2029,7 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
     const u32 n = st.src_len;
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
-    const uint2* m = match + pos_off[sid];
+    const mentry* m = match + pos_off[sid];
     const u64* mask = startmask + (pos_off[sid] >> 6);
     const u32 nwords = n >= 4u ? ((n - 4u) >> 6) + 1u : 0u;                   // mask words that can hold a start
     auto finish = [&](u32 total, bool fail, int status) {
@@ -2054,7 +2059,7 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
         return;
     }
     u32 mo = next_start(0), ml = 0, md = 0;                                   // mt: offset, length, distance
-    if (mo < n) { const uint2 r = m[mo]; md = r.x; ml = r.y; }
+    if (mo < n) { uint2 r = m_unpack(m[mo]); if (r.y == ALZ_M_LONG) r.y = m[mo + 1]; md = r.x; ml = r.y; }
     u32 mbit = mo;                                                            // mt's bit in the mask (mo itself may be moved below)
     bool clean = false;
     while (sp != n && !clean) {
@@ -2067,7 +2072,7 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
         }
         // the finder's next match: the next bit of the mask
         u32 no = mbit < n ? next_start(mbit + 1u) : n, nl = 0, nd = 0;
-        if (no < n) { const uint2 r = m[no]; nd = r.x; nl = r.y; }
+        if (no < n) { uint2 r = m_unpack(m[no]); if (r.y == ALZ_M_LONG) r.y = m[no + 1]; nd = r.x; nl = r.y; }
         if (ml >= 3u) {
             sp += ml;
             u32 emb = no - sp;
@@ -2102,14 +2107,15 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
     u32 cover = sp0, obase = olen;
     const u32 P0 = sp0 & ~63u;
     u64 sm_n = (P0 >> 6) < nwords ? mask[P0 >> 6] : 0ull;                     // (mask word and matches of a window are loaded one window ahead)
-    uint2 mt_n = P0 + (u32)lane < n ? m[P0 + (u32)lane] : make_uint2(0, 0);
+    mentry mt_n = P0 + (u32)lane < n ? m[P0 + (u32)lane] : 0u;
     for (u32 P = P0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
         const u64 sm = sm_n;
-        const uint2 mt_all = mt_n;
+        const mentry mt_raw = mt_n;
         if (P + 64 < n) { sm_n = ((P >> 6) + 1u) < nwords ? mask[(P >> 6) + 1u] : 0ull; if (p + 64 < n) mt_n = m[p + 64]; }
         const bool start = ((sm >> lane) & 1ull) && p >= mo && p < n;          // (mo: the first match not yet written)
         if (__ballot(start) == 0ull) continue;
+        const uint2 mt_all = m_start<true>(m, p, mt_raw, start);
         uint2 mt = make_uint2(0, 0);
         if (start) mt = mt_all;
         const u32 M = mt.y, D = mt.x;
@@ -2166,19 +2172,19 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
 }
 
 template <int FMT>
-static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const uint2* match,
+static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, const mentry* match,
                         const u64* pos_off, const int* prev4, const int* prevm, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g,
                         u64* mask = nullptr) {
     // one stream per wavefront (lane 0 parses and emits; 64 streams per wavefront were the union of 64 divergent token paths), the
     // parse from the roles walk's start mask
     const int tail = FMT == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    if (mask) hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, (uint2*)match, pos_off, prev4, prevm, mask, g, tail);
-    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g, 1u,
+    if (mask) hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, (mentry*)match, pos_off, prev4, prevm, mask, g, tail);
+    hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, side, results, aux, g, 1u,
                        (const u64*)mask);
 }
 
 template <int FMT>
-static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, uint2* match,
+static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match,
                             const u64* pos_off, const int* prev4, const int* prevm, u64* mask, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
     hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0);
     hipLaunchKernelGGL((enc_emit_par_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, mask, side, results, aux, g);
@@ -2209,46 +2215,46 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         if (dyn) {
-            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
-            else hipLaunchKernelGGL((enc_match_dense_kernel<false, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+            else hipLaunchKernelGGL((enc_match_dense_kernel<false, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
         } else {
-            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
-            else hipLaunchKernelGGL((enc_match_dense_kernel<false, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
+            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+            else hipLaunchKernelGGL((enc_match_dense_kernel<false, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
         }
     }
-    else if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
-    else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (uint2*)d_match, d_pos_off, g, tail);
-    const uint2* m = (const uint2*)d_match; u8* side = (u8*)d_side;
+    else if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+    else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+    const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
-    case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ10: launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ11: launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ40: launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_CLZ0: launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ10: launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ11: launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ40: launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_CLZ0: launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL((enc_emit_prs_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_PRS_LE: {
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL((enc_emit_prs_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_LZ4_BLOCK: {
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
         hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_LZO: {
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_SNAPPY_RAW: {
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (uint2*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
+        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;

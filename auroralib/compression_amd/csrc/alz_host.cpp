@@ -734,7 +734,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
-    if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 8);
+    if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64);      // one 32-bit entry per position (alz_encode.hip: mentry)
     if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));

@@ -122,7 +122,7 @@ namespace AuroraLib.Compression.Amd
         /// window only: a caller's <c>MaxWindowBits</c> (LzChainMatchFinder.cs:69-73) is honoured by the managed encoder, except
         /// for FastLZ, whose level-2 switch it is (FastLZ.cs:163-170).</summary>
         internal static bool UseGpuForCompress(AlzFormat format, int sourceLength, CompressionSettings settings)
-            => (settings.MaxWindowBits == 0 || format == AlzFormat.FastLZ)
+            => (settings.MaxWindowBits == 0 || (format == AlzFormat.FastLZ && settings.MaxWindowBits <= 20))   // (the GPU finder keeps distances in 21 bits)
                && (uint)sourceLength >= AmdContext.SingleStreamCompressThreshold && AmdContext.Available;
 
         internal static AlzLzProperties ToNative(LzProperties lz) => new AlzLzProperties

@@ -193,3 +193,27 @@ def test_prev_links_through_the_lds_table(quality, test_bmp):
         raws = [r[:60000] for r in raws]
     _encode_and_compare(A.FMT_LZSS, raws, quality)
     _encode_and_compare(A.FMT_LZ4_BLOCK, raws[3:12], quality)          # (searches stop five bytes before the end: LZ4.cs:208)
+
+
+@pytest.mark.parametrize("quality", [0, 8, 15])
+def test_matches_beyond_the_match_array_entry(quality):
+    """A match-array entry holds lengths below 2 046; longer ones (kernel B caps its compare at 2 040 bytes and marks the position, the
+    parse recomputes it exactly) are written as an escape with the length in the NEXT entry -- for the match the parse takes, which may
+    be the one at the cursor (R repeated right behind junk) or the lazy neighbour's (a 3-byte match `q R0 R1` at the cursor, all of R
+    one byte on).  Formats whose lengths reach that far, windows that reach back to the first copy; zeros for the self-overlapping kind."""
+    rng = np.random.default_rng(5)
+    R = bytes(rng.integers(0, 256, 2600, dtype=np.uint8))
+    J1, J2 = bytes(rng.integers(0, 256, 40, dtype=np.uint8)), bytes(rng.integers(0, 256, 300, dtype=np.uint8))
+    lazy = b"q" + R[:2] + b"#" + J1 + R + J2 + b"q" + R + J1
+    direct = J1 + R + J2 + R + R[:2100] + J1
+    both = lazy + direct + bytes(2046) + b"z" + bytes(2047) + b"y" + bytes(2045) + b"x" + bytes(70000)
+    for fmt in (A.FMT_LZ11, A.FMT_LZ40, A.FMT_LZ4_BLOCK, A.FMT_LZO, A.FMT_SNAPPY_RAW, A.FMT_HIG, A.FMT_REFPACK, A.FMT_WFLZ, A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_LZ02):
+        _encode_and_compare(fmt, [lazy, direct, both, bytes(2046 + 1), bytes(2047 + 1), bytes(4100)], quality)
+    _encode_and_compare(A.FMT_FASTLZ, [lazy + bytes(66000), direct + bytes(66000), both], quality, max_window_bits=17)
+
+
+def test_window_bits_beyond_the_entry_are_refused(test_bmp):
+    """A distance has 21 bits in the match array: FastLZ with MaxWindowBits above 20 goes back to the caller's own encoder."""
+    _encode_and_compare(A.FMT_FASTLZ, [test_bmp[:70000]], 8, max_window_bits=20)
+    with pytest.raises(Exception):
+        _encode_and_compare(A.FMT_FASTLZ, [test_bmp[:70000]], 8, max_window_bits=21)

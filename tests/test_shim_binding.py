@@ -246,7 +246,7 @@ def test_single_stream_compress_stays_managed_by_default():
     ctx = open(os.path.join(SHIM, "AmdContext.cs")).read()
     assert re.search(r"public static uint SingleStreamCompressThreshold \{ get; set; \} = uint\.MaxValue;", ctx)
     body = open(os.path.join(SHIM, "AmdBody.cs")).read()
-    assert "settings.MaxWindowBits == 0 || format == AlzFormat.FastLZ" in body and "SingleStreamCompressThreshold" in body
+    assert "settings.MaxWindowBits == 0 || (format == AlzFormat.FastLZ && settings.MaxWindowBits <= 20)" in body and "SingleStreamCompressThreshold" in body
     for f in ("LZ10.cs", "LZ11.cs", "Yaz0.cs", "Yay0.cs", "MIO0.cs", "LZSS.cs", "LZO.cs", "PRS.cs"):
         t = _strip_comments(open(os.path.join(SHIM, f)).read())
         assert "AmdBody.UseGpuForCompress(" in t, f
