@@ -511,27 +511,35 @@ struct QueueSink {
 struct NoFill3 { __device__ __forceinline__ void operator()(u32&) const {} };
 template <class F3 = NoFill3>
 __device__ __forceinline__ void lane_walk_pos(u32 (&nx)[4], u32 enter_below, u32& spos_out, u32& sp_out, u32& n_out, F3 fill3 = F3()) {
-    u32 spos = 0, sp = 0, cnt = 0;
+    // (round 3: inside a window the offset runs 64 (w + 1) below zero, so that the carry of "offset += size" IS "left the window" and
+    // the loop needs no compare -- five instructions per element; v_readlane takes the low six bits, which are the offset's.  What
+    // the lanes received is put right afterwards from the element counts at the window ends.)
+    u32 spos = 0, sp = 0, cnt = 0, c0 = 0, c1 = 0, c2 = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         if (cnt < enter_below && sp < 64u * (u32)(w + 1)) {
             if (w == 3) fill3(nx[3]);
-            u32 n;
+            u32 n, t = sp - 64u * (u32)(w + 1);
             asm volatile(
                 "s_mov_b32 m0, %[cnt]\n\t"
                 "s_nop 1\n"
                 "1:\n\t"
-                "v_readlane_b32 %[n], %[nx], %[sp]\n\t"
-                "v_writelane_b32 %[spos], %[sp], m0\n\t"
+                "v_readlane_b32 %[n], %[nx], %[t]\n\t"
+                "v_writelane_b32 %[spos], %[t], m0\n\t"
                 "s_add_u32 m0, m0, 1\n\t"
-                "s_add_u32 %[sp], %[sp], %[n]\n\t"
-                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
-                "s_cbranch_scc1 1b\n\t"
+                "s_add_u32 %[t], %[t], %[n]\n\t"
+                "s_cbranch_scc0 1b\n\t"
                 "s_mov_b32 %[cnt], m0\n\t"
-                : [n] "=&s"(n), [sp] "+s"(sp), [spos] "+v"(spos), [cnt] "+s"(cnt)
-                : [nx] "v"(nx[w]), [lim] "s"(64u * (u32)(w + 1))
+                : [n] "=&s"(n), [t] "+s"(t), [spos] "+v"(spos), [cnt] "+s"(cnt)
+                : [nx] "v"(nx[w])
                 : "scc", "m0");
+            sp = t + 64u * (u32)(w + 1);
         }
+        if (w == 0) c0 = cnt; else if (w == 1) c1 = cnt; else if (w == 2) c2 = cnt;
+    }
+    {
+        const u32 l = (u32)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        spos += 64u + (l >= c0 ? 64u : 0u) + (l >= c1 ? 64u : 0u) + (l >= c2 ? 64u : 0u);
     }
     if (sp >= ALZ_NX_BAD) { cnt -= 1u; sp = wave_readlane(spos, cnt); }     // the last element counted was an unusual one
     spos_out = spos; sp_out = sp; n_out = cnt;

@@ -1428,6 +1428,22 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
         if (__ballot(capped) == 0) {
             u64 M = 0; u32 r = (u32)rel, j;
             const u32 lim = (u32)(limit + 1 - P) < 64u ? (u32)(limit + 1 - P) : 64u;     // (r < lim on entry: cur <= limit)
+            if (lim == 64u) {
+                // a full window: the cursor runs 64 below zero, so that the add's carry IS "left the window" -- four instructions per hop
+                // (s_bitset1 and v_readlane take the low six bits of it, which are the cursor's)
+                r -= 64u;
+                asm volatile(
+                    "s_nop 3\n"
+                    "1:\n\t"
+                    "s_bitset1_b64 %[M], %[r]\n\t"
+                    "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                    "s_add_u32 %[r], %[r], %[j]\n\t"
+                    "s_cbranch_scc0 1b\n\t"
+                    : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                    : [jump] "v"(jump)
+                    : "scc");
+                r += 64u;
+            } else
             asm volatile(
                 "s_nop 3\n"
                 "1:\n\t"
