@@ -46,7 +46,17 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
     // the LzProperties[] form of the finder (RefPack): ScoreMatch takes the first set that admits a candidate
     int nprops, p_max_len[3], p_min_len[3], p_max_dist[3], p_min_dist[3];
     int variant;           // FastLZ: 1 = level 2 (token format + the two property sets)
+    int link16;            // the 4-byte-hash links are 16-bit DISTANCES (0: none or out of reach): finders whose maxDistance fits, up to quality 10
 };
+
+// prev() of a position from the link array kernel A wrote: a position (or -1), or -- L16, maxDistance <= 65 535 -- a 16-bit distance,
+// 0 for "none".  A link longer than maxDistance ends a chain walk exactly as no link does (ChainMatches :259-260), so the distances
+// lose nothing, and the array is half the bytes for kernel A to write and kernel B to read (round 3).
+template <bool L16>
+__device__ __forceinline__ int link_at(const int* p4, int pos) {
+    if (L16) { const u32 d = reinterpret_cast<const unsigned short*>(p4)[pos]; return d ? pos - (int)d : -1; }
+    return p4[pos];
+}
 
 // (global memory takes unaligned dword / qword loads: one global_load_dword instead of four byte loads and three shifts)
 __device__ __forceinline__ u32 load32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     const u64 me = 1ull << lane;
                     if (hasp & me) {
                         const int d = (m1 & me) ? 1 : (m2 & me) ? 2 : (m3 & me) ? 3 : 4;
-                        p4[pos] = pos - d;
+                        if (!mt && g.link16) reinterpret_cast<unsigned short*>(p4)[pos] = (unsigned short)d; else p4[pos] = pos - d;
                         if (hass & me) keep = false; else wonly = 1u << 16;
                     }
                 }
@@ -269,7 +279,10 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                     prev = res;
                 }
-                if (actl && !(e & 0x10000u)) p4[pos] = prev;
+                if (actl && !(e & 0x10000u)) {
+                    if (!mt && g.link16) { const u32 dd = prev < 0 ? 0u : (u32)(pos - prev); reinterpret_cast<unsigned short*>(p4)[pos] = (unsigned short)(dd > 0xFFFFu ? 0u : dd); }
+                    else p4[pos] = prev;
+                }
                 qhead += nstep; if (qhead >= ALZ_CU_QCAP) qhead -= ALZ_CU_QCAP;
                 qn -= nstep;
             }
@@ -522,7 +535,8 @@ template <bool MINT>
 __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
                                              int& best_d, int& best_l) {
     const u8* dp = data + pos;
-    int cur = p4[pos];
+    auto lk = [&](int q) { return g.link16 ? link_at<true>(p4, q) : link_at<false>(p4, q); };
+    int cur = lk(pos);
     int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
     const int cmp_max = (cap > 0 && best_possible > cap) ? cap : best_possible;
     best_d = 0; best_l = 0; int best_score = -1;
@@ -530,12 +544,12 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
     while (cur != -1 && attempts-- > 0) {
         const int dist = pos - cur;
         if (dist > g.max_dist) break;
-        if (dist < g.min_dist) { cur = p4[cur]; continue; }
+        if (dist < g.min_dist) { cur = lk(cur); continue; }
         int len = match_len(dp, data + cur, cmp_max);
         if (len == cmp_max && cmp_max < best_possible) return false;
         const int score = score_match(g, len, dist);
         if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
-        cur = p4[cur];
+        cur = lk(cur);
     }
     if (MINT && best_l == 0) {                                          // small-match fallback :226-243
         const int c2 = pm[pos];
@@ -557,11 +571,13 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
 // serial emit kernels, one lane per wavefront, ran 12 % slower with this body inlined).  MatchSearch :214-246 with ChainMatches
 // :248-282; returns false when CAP > 0 and a
 // candidate still matched after CAP bytes
-template <bool MINT>
+template <bool MINT, bool L16>
 __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
                                              int& best_d, int& best_l) {
     const u8* dp = data + pos;
-    int cur = __builtin_nontemporal_load(p4 + pos);                     // (each position's first link is read once, by this lane)
+    int cur;                                                            // (each position's first link is read once, by this lane: past the caches)
+    if (L16) { const u32 d = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(p4) + pos); cur = d ? pos - (int)d : -1; }
+    else cur = __builtin_nontemporal_load(p4 + pos);
     int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
     const int cmp_max = (cap > 0 && best_possible > cap) ? cap : best_possible;
     best_d = 0; best_l = 0; int best_score = -1;
@@ -584,7 +600,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
         //  reaches, anywhere in the stream -- an 8-byte read that misses every cache and is thrown away)
         const int cl = within ? c : pos;
         const u64 x = head ^ load64(data + cl);
-        const int nxt = (within && it + 1 < chain) ? p4[cl] : -1;       // (the last candidate's link is never followed: at maxChain 1 that is every one)
+        const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, cl) : -1;   // (the last candidate's link is never followed: at maxChain 1 that is every one)
         const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
@@ -648,7 +664,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
 // DYN (maxChain >= 8, blocks of 256 positions): in the first phase a lane whose walk has ended takes the next position of the block --
 // 59 -> 54 ms at Q8; at Q4 (five candidates at most) the fixed assignment in blocks of 64 is the faster one (36.8 against 38.0 ms).
 #define ALZ_DENSE_LIST 256
-template <bool MINT, bool DYN, int ALZ_DENSE_POS>
+template <bool MINT, bool DYN, int ALZ_DENSE_POS, bool L16>
 __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                              const int* __restrict__ prevm, mentry* __restrict__ match,
@@ -726,13 +742,13 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             if (idle && nextp < npos) {
                 const int np = nextp + (int)__builtin_amdgcn_mbcnt_hi((u32)(idle >> 32), __builtin_amdgcn_mbcnt_lo((u32)idle, 0u));
                 nextp += (int)__popcll(idle);
-                if (!act && np < npos) { pl = np; pos = base + np; cur = p4[pos]; it = 0; fresh = true; }
+                if (!act && np < npos) { pl = np; pos = base + np; cur = link_at<L16>(p4, pos); it = 0; fresh = true; }
             }
             if (!__ballot(act || fresh)) break;
             const int c = act ? cur : 0;
             const int dist = pos - c;
             const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
-            const int nxt = (within && it + 1 < chain) ? p4[c] : -1;            // (the last candidate's link is never followed, nor that of a candidate out of reach)
+            const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, c) : -1;   // (the last candidate's link is never followed, nor that of a candidate out of reach)
             const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
             const u64 om = __ballot(ok);
             if (om) {
@@ -751,14 +767,14 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 #pragma unroll 1
     for (int r = 0; r < ALZ_DENSE_POS / 64; r++) {
         const int pos = base + 64 * r + lane;
-        int cur = pos <= limit ? p4[pos] : -1;
+        int cur = pos <= limit ? link_at<L16>(p4, pos) : -1;
         bool act = cur != -1;
         for (int it = 0; it < chain; it++) {
             if (!__ballot(act)) break;
             const int c = act ? cur : 0;
             const int dist = pos - c;
             const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
-            const int nxt = (within && it + 1 < chain) ? p4[c] : -1;            // (the last candidate's link is never followed, nor that of a candidate out of reach)
+            const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, c) : -1;   // (the last candidate's link is never followed, nor that of a candidate out of reach)
             const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
             const u64 om = __ballot(ok);
             if (om) {
@@ -812,7 +828,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 // instructions of its trips, and the LDS form has more of them (address arithmetic, three reads and two alignbytes per eight bytes) at
 // half the wavefronts per CU (68 KB of LDS per workgroup); at quality 15 a workgroup waits for the one wavefront whose block holds a
 // 1024-step chain.  DESIGN.md 8.)
-template <bool MINT>
+template <bool MINT, bool L16>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                         const int* __restrict__ prevm, mentry* __restrict__ match,
@@ -833,7 +849,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     const int last = first + span - 1 < limit ? first + span - 1 : limit;
     for (int pos = first + (int)threadIdx.x; pos <= last; pos += 256) {
         int bd, bl;
-        const bool okm = match_search_b<MINT>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
+        const bool okm = match_search_b<MINT, L16>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
         __builtin_nontemporal_store(okm ? m_pack((u32)bd, (u32)bl) : 0xFFFFFFFFu, m + pos);   // (written once, read by the next kernel: past the caches)
     }
 }
@@ -1713,6 +1729,9 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     // it to cover maxDistance, which holds for every format geometry of the reference
     const int chain_bits = (17 + isqrt_floor(2 * q)) < wb ? (17 + isqrt_floor(2 * q)) : wb;
     if (g.max_chain != 1 && (1 << chain_bits) < g.max_dist) return false;
+    // (16-bit links: 67 -> 57 GB of HBM traffic per 10 000 x 256 KiB at quality 0, 217 -> 143 at quality 8, times within 1 %; at quality 15 --
+    // chains of up to 1 024 links -- the subtraction per link costs kernel B 5 % (112.8 -> 118.7 ms): positions there)
+    g.link16 = (g.max_dist <= 0xFFFF && g.max_chain < 64) ? 1 : 0;
     if (g.max_dist > (int)ALZ_M_DMASK) return false;                  // a distance has 21 bits in the match array (FastLZ with MaxWindowBits above 20: the caller's own encoder)
     memcpy(out_geom, &g, sizeof(g));
     if (window_bits) *window_bits = wb;
@@ -2230,16 +2249,19 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {             // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
+#define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
+        const dim3 gd(bd, count);
         if (dyn) {
-            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
-            else hipLaunchKernelGGL((enc_match_dense_kernel<false, true, 256>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+            if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_dense_kernel<true, true, 256, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<true, true, 256, false>), gd, dim3(64)); }
+            else { if (g.link16) ALZ_LB((enc_match_dense_kernel<false, true, 256, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<false, true, 256, false>), gd, dim3(64)); }
         } else {
-            if (g.use_min_table) hipLaunchKernelGGL((enc_match_dense_kernel<true, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
-            else hipLaunchKernelGGL((enc_match_dense_kernel<false, false, 64>), dim3(bd, count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+            if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_dense_kernel<true, false, 64, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<true, false, 64, false>), gd, dim3(64)); }
+            else { if (g.link16) ALZ_LB((enc_match_dense_kernel<false, false, 64, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<false, false, 64, false>), gd, dim3(64)); }
         }
     }
-    else if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
-    else hipLaunchKernelGGL((enc_match_kernel<false>), dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail);
+    else if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
+    else { if (g.link16) ALZ_LB((enc_match_kernel<false, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
+#undef ALZ_LB
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
     case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
