@@ -668,7 +668,7 @@ template <bool MINT, bool DYN, int ALZ_DENSE_POS, bool L16>
 __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                              const int* __restrict__ prevm, mentry* __restrict__ match,
-                                                             const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+                                                             const u64* __restrict__ pos_off, EncGeom g, int tail_skip, u32 xlog) {
     __shared__ u32 lpos[ALZ_DENSE_LIST];          // position inside the block | step << 8
     __shared__ int lcand[ALZ_DENSE_LIST];
     __shared__ unsigned long long best[ALZ_DENSE_POS];
@@ -685,10 +685,15 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     const int chain = g.max_chain;
   // (the grid holds at most 4 096 workgroups per stream: a stream longer than 4 096 blocks -- and a batch whose longest stream is far
   //  longer than the others -- goes round; up to that length a workgroup has one block, which is the faster arrangement)
-  // (Tried in round 3: XCD k takes the k-th contiguous eighth of a stream's blocks, so that neighbouring blocks -- which read the same
-  // links and bytes -- meet in one L2: 61 ms against 54 at quality 8.  Dispatch order already runs a stream's blocks back to back, and
-  // eight of them in flight on eight XCDs share more through the memory-side cache than one XCD's run of them does through its L2.)
-  for (long long base64 = (long long)blockIdx.x * ALZ_DENSE_POS; base64 <= (long long)limit; base64 += (long long)gridDim.x * ALZ_DENSE_POS) {
+  // Which block: workgroups go to the eight XCDs in turn (blockIdx.x mod 8), so with block = blockIdx.x every block of 256 positions
+  // pulled its own window of links and bytes (12 KB for 4 096 positions back) into another L2: 99 GB of fetches per 2.6 GB of input at
+  // quality 8.  XCD k now takes RUNS of 2^xlog consecutive blocks, the runs dealt out in turn (gridDim.x is a multiple of 8 runs;
+  // xlog 0 is the old order).  Measured (quality 8, 256 positions per block): runs of 4 blocks 52.3 ms and 40 GB, of 16 53.8 / 15, of 32
+  // 58.4 / 12, an eighth of the stream per XCD 60.8 / 9 -- against 52.4 ms / 99 GB; with 64 positions per block (quality 4) the longest
+  // runs are also the fastest (35.6 -> 34.9 ms).
+  const u32 xk = blockIdx.x & 7u, xi = blockIdx.x >> 3;
+  const long long blk0 = (long long)(((((xi >> xlog) << 3) + xk) << xlog) + (xi & ((1u << xlog) - 1u)));
+  for (long long base64 = blk0 * ALZ_DENSE_POS; base64 <= (long long)limit; base64 += (long long)gridDim.x * ALZ_DENSE_POS) {
     const int base = (int)base64;
 #pragma unroll
     for (int r = 0; r < ALZ_DENSE_POS / 64; r++) { best[64 * r + lane] = 0ull; capf[64 * r + lane] = 0u; }
@@ -2249,7 +2254,10 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {             // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
-#define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
+        u32 xlog = !dyn ? 7u : g.max_chain < 64 ? 2u : 0u;           // runs of consecutive blocks per XCD (enc_match_dense_kernel; chains of 64 links and more -- quality 11 up -- lose with them: 112.8 -> 122.4 ms at quality 15)
+        while (xlog && (8u << xlog) > bd) xlog--;
+        if (xlog) bd = (bd + (8u << xlog) - 1u) / (8u << xlog) * (8u << xlog);
+#define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, xlog)
         const dim3 gd(bd, count);
         if (dyn) {
             if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_dense_kernel<true, true, 256, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<true, true, 256, false>), gd, dim3(64)); }
@@ -2259,6 +2267,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             else { if (g.link16) ALZ_LB((enc_match_dense_kernel<false, false, 64, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<false, false, 64, false>), gd, dim3(64)); }
         }
     }
+#undef ALZ_LB
+#define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
     else if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
     else { if (g.link16) ALZ_LB((enc_match_kernel<false, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
 #undef ALZ_LB
