@@ -2249,8 +2249,9 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     else if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
-    if (bx > 128u) bx = 128u;
-    // (blocks per stream: a thread of 128 blocks takes eight positions of a 256 KiB stream; one position per thread, ten million blocks per launch: 18.6 against 17.4 ms)
+    if (bx > 32u) bx = 32u;
+    // (workgroups per stream, each with one contiguous range: 32 -- 8 Ki positions of a 256 KiB stream, 4 KiB of history in front of them fetched
+    // again -- move 9.1 GB at quality 0, 128 move 12.7, both in 13.6 ms; one position per thread, ten million workgroups per launch: 18.6 ms)
     if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {             // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
