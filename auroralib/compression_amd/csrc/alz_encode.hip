@@ -23,9 +23,10 @@
 //                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
 //   C  enc_roles_kernel         the greedy/lazy parse as a walk over the match array (one wavefront per stream): a bit per token
-//                               start; then enc_emit_par_kernel (flag-bit formats), enc_emit_seq_kernel (LZ4, Snappy), enc_emit_prs_kernel or enc_emit_lzo_kernel place
-//                               every token with prefix sums.  enc_emit_kernel: parse + emission on one lane per stream, for the
-//                               formats that have no parallel emit yet.
+//                               start; then enc_emit_seq_kernel (LZ4, Snappy), enc_emit_prs_kernel or enc_emit_lzo_kernel place
+//                               every token with prefix sums.  The flag-bit formats (LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0 ...) do both in
+//                               ONE kernel, enc_parse_emit_kernel: the walk over a window, then its tokens, from the same registers.
+//                               enc_emit_kernel: emission on one lane per stream, for the formats that have no parallel emit yet.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -1366,7 +1367,7 @@ __global__ __launch_bounds__(64) void enc_emit_kernel(const u8* __restrict__ src
 //    lane evaluates "what FindNextBestMatch does if its cursor is HERE" (no token / match here / literal + match at the
 //    next position, and where the cursor goes), then the real cursor hops through the window with v_readlane.  Output:
 //    one bit per position, "a match token starts here" (the match itself is match[p]).
-// C2 (enc_emit_par_kernel, one wavefront per stream): with the match starts known everything else is prefix sums over
+// C2 (the second half of enc_parse_emit_kernel, one wavefront per stream): with the match starts known everything else is prefix sums over
 //    positions: covered positions (prefix max of match ends), literals, token index (-> flag group and bit), payload
 //    offsets.  Token lanes store their payload bytes; flag bytes are accumulated in LDS and stored when their group
 //    completes.  FlagWriter order (IO/FlagWriter.cs:70-80,111-127): flag byte, then the payload of its 8 tokens.
@@ -1524,12 +1525,18 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
     if (carryw != 0xFFFFFFFFu && lane == 0) mask[carryw] = 1ull;
 }
 
+// The parse and the emitter of the flag-bit formats in ONE kernel (round 3): enc_roles_kernel's walk over a window of 64 positions, then
+// the emitter's tokens of the same window, from the same registers.  As two kernels the parse wrote a start mask and the exact
+// matches it had recomputed, and the emitter read mask and match array again: 10.5 GB of the 53 the pipeline moved at quality 0, and
+// ~30 of the ~280 instructions the two spend per window.  The walk visits windows in order (one that lies inside a match has nothing
+// to parse, the emitter still passes it: it is covered); what the window in front found for THIS window's first position travels in
+// `carry`; a position kernel B had capped is recomputed exactly when the cursor stands on it and patched into the window's registers.
 template <int FMT>
-__global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
-                                                          const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                          u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
-                                                          const u64* __restrict__ startmask, u8* __restrict__ side,
-                                                          alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+__global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                            const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                            u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
+                                                            const int* __restrict__ prev4, const int* __restrict__ prevm, u8* __restrict__ side,
+                                                            alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZHUDSON || THREE);   // flag bit of a literal token
     constexpr bool MSB = (FMT != ALZ_FMT_LZSS && FMT != ALZ_FMT_CLZ0);
@@ -1542,11 +1549,14 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
     const u32 sid = index_list[bid];
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
+    const u8* data = src;
     const u32 n = st.src_len;
+    const int limit = (int)n - 4;                                        // FindNextBestMatch searches up to length - 4  :159
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
     const mentry* m = match + pos_off[sid];
-    const u64* mask = startmask + (pos_off[sid] >> 6);
+    const int* p4 = prev4 + pos_off[sid];
+    const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
     u8* compb = THREE ? side + 2 * pos_off[sid] : nullptr;            // token section (Yay0/MIO0)
     u8* uncb = THREE ? side + 2 * pos_off[sid] + n + 16 : nullptr;    // literal section
     if (lane < 16) { flagacc[lane] = 0; gofs[lane] = 0; }
@@ -1556,22 +1566,105 @@ __global__ __launch_bounds__(64) void enc_emit_par_kernel(const u8* __restrict__
     u32 unc_base = 0;       // THREE: literal-section bytes before the window
     u32 cover = 0;          // end of the last match seen so far
     bool fail = false;
-    // (mask word, match and source byte of a window are loaded while the window before it is emitted: as a chain mask -> match
-    // inside the iteration, 39 wavefronts per CU left two memory round trips per window exposed)
-    u64 sm_n = n ? mask[0] : 0ull;
-    mentry mt_n = (u32)lane < n ? m[lane] : 0u;
+    int cur = 0;            // cursor of FindNextBestMatch (absolute position)
+    bool carry = false;     // the window in front found a token that starts at this window's first position
+    // (match entry and source byte of a window are loaded while the window before it is worked on; positions above `limit` were never
+    // searched: no match)
+    auto ldm = [&](u32 q) { return (int)q <= limit ? m_unpack(__builtin_nontemporal_load(m + q)) : make_uint2(0, 0); };
+    uint2 a_n = ldm((u32)lane);
     u32 sb_n = (u32)lane < n ? src[lane] : 0u;
     for (u32 P = 0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
-        const u64 sm = sm_n;
-        const mentry mt_raw = mt_n;
+        uint2 a = a_n;
         const u32 sb = sb_n;
-        if (P + 64 < n) sm_n = mask[(P >> 6) + 1];
-        if (p + 64 < n) { mt_n = m[p + 64]; sb_n = src[p + 64]; }
+        a_n = ldm(p + 64u);
+        if (p + 64 < n) sb_n = src[p + 64];
+        u64 sm = carry ? 1ull : 0ull;
+        carry = false;
+        if (cur < (int)P + 64 && cur <= limit) {
+            // ---- the parse of this window (the body of enc_roles_kernel)
+            uint2 b;
+            b.x = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.x); b.y = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.y);
+            {   // lane 63's neighbour is the first position of the next window
+                const u32 n0x = (u32)__builtin_amdgcn_readlane((int)a_n.x, 0), n0y = (u32)__builtin_amdgcn_readlane((int)a_n.y, 0);
+                if (lane == 63) b = make_uint2(n0x, n0y);
+            }
+            const bool capped = a.y == ALZ_CAPPED || b.y == ALZ_CAPPED;
+            int jump = 1, startrel = 0;   // startrel: 0 no token here, 1 match starts here, 2 literal here + match at p + 1
+            if (!capped && (int)p <= limit && (int)a.y >= g.min_len) {
+                const int l0 = (int)a.y, l1 = (int)b.y, pi = (int)p;
+                const bool lazyc = l0 <= g.lazy && pi + 1 <= limit;
+                if (lazyc && l1 > l0) { startrel = 2; const int e = pi + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 2 > stop ? pi + 2 : stop) - pi; }
+                else { startrel = 1; const int skip = lazyc ? 1 : 0; const int e = pi + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 1 + skip > stop ? pi + 1 + skip : stop) - pi; }
+            }
+            int rel = cur - (int)P;
+            if (__ballot(capped) == 0) {
+                u64 M = 0; u32 r = (u32)rel, j;
+                const u32 lim = (u32)(limit + 1 - (int)P) < 64u ? (u32)(limit + 1 - (int)P) : 64u;     // (r < lim on entry: cur <= limit)
+                if (lim == 64u) {
+                    r -= 64u;                                                  // (the add's carry is "left the window": enc_roles_kernel)
+                    asm volatile(
+                        "s_nop 3\n"
+                        "1:\n\t"
+                        "s_bitset1_b64 %[M], %[r]\n\t"
+                        "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                        "s_add_u32 %[r], %[r], %[j]\n\t"
+                        "s_cbranch_scc0 1b\n\t"
+                        : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                        : [jump] "v"(jump)
+                        : "scc");
+                    r += 64u;
+                } else
+                asm volatile(
+                    "s_nop 3\n"
+                    "1:\n\t"
+                    "s_bitset1_b64 %[M], %[r]\n\t"
+                    "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                    "s_add_u32 %[r], %[r], %[j]\n\t"
+                    "s_cmp_lt_u32 %[r], %[lim]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                    : [jump] "v"(jump), [lim] "s"(lim)
+                    : "scc");
+                const u64 s1 = __ballot(startrel == 1) & M, s2 = __ballot(startrel == 2) & M;
+                sm |= s1 | (s2 << 1);
+                if (s2 >> 63) carry = true;                                    // start in lane 0 of the next window
+                rel = (int)r;
+            }
+            else while (rel < 64 && (int)P + rel <= limit) {
+                int j, sr;
+                if (__builtin_amdgcn_readlane((int)capped, rel)) {
+                    // kernel B capped a candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour, and put both
+                    // into the registers the emitter takes its matches from (the neighbour may be the next window's first position)
+                    const int q = (int)P + rel;
+                    int d0, l0, d1 = 0, l1 = 0;
+                    if (g.use_min_table) match_search<true>(data, (int)n, q, p4, pm, g, 0, d0, l0); else match_search<false>(data, (int)n, q, p4, pm, g, 0, d0, l0);
+                    if (q + 1 <= limit) { if (g.use_min_table) match_search<true>(data, (int)n, q + 1, p4, pm, g, 0, d1, l1); else match_search<false>(data, (int)n, q + 1, p4, pm, g, 0, d1, l1); }
+                    if (lane == rel) a = make_uint2((u32)d0, (u32)l0);
+                    if (q + 1 <= limit) {
+                        if (rel + 1 < 64) { if (lane == rel + 1) a = make_uint2((u32)d1, (u32)l1); }
+                        else if (lane == 0) a_n = make_uint2((u32)d1, (u32)l1);
+                    }
+                    j = 1; sr = 0;
+                    if (l0 >= g.min_len) {
+                        const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
+                        if (lazyc && l1 > l0) { sr = 2; const int e = q + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 2 > stop ? q + 2 : stop) - q; }
+                        else { sr = 1; const int skip = lazyc ? 1 : 0; const int e = q + l0; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 1 + skip > stop ? q + 1 + skip : stop) - q; }
+                    }
+                } else {
+                    j = __builtin_amdgcn_readlane(jump, rel);
+                    sr = __builtin_amdgcn_readlane(startrel, rel);
+                }
+                if (sr == 1) sm |= 1ull << rel;
+                else if (sr == 2) { if (rel + 1 < 64) sm |= 1ull << (rel + 1); else carry = true; }   // start in lane 0 of the next window
+                rel += j;
+            }
+            cur = (int)P + rel;
+        }
+        // ---- the tokens of this window: prefix sums over the start mask give every token its flag group and byte offset
         const bool start = ((sm >> lane) & 1ull) && p < n;
-        const uint2 mt_all = m_start<(FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40)>(m, p, mt_raw, start);
         uint2 mt = make_uint2(0, 0);
-        if (start) mt = mt_all;
+        if (start) mt = a;
         const u32 mend = start ? p + mt.y : 0u;
         const u32 pmax = scan_max(mend);                               // inclusive
         u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
@@ -1889,7 +1982,7 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
 // of a short match whose four bits just completed a flag byte: the writer is told to let it out at once (flush_if_necessary), in front
 // of the next flag byte.  The flag byte k stands in front of the first payload with B >= 8 k (behind it, if that is such an offset byte).
 // So two prefix sums (bits, payload bytes) place everything; flag bytes collect their bits in LDS and are stored by the token that owns
-// their last bit, as in enc_emit_par_kernel.  A match of length 2 further than 0x100 back is not written as a match (its bytes go out as
+// their last bit, as in enc_parse_emit_kernel.  A match of length 2 further than 0x100 back is not written as a match (its bytes go out as
 // literals; the parse has moved on behind it either way).
 template <bool BIG>
 __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
@@ -2226,8 +2319,8 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
 template <int FMT>
 static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match,
                             const u64* pos_off, const int* prev4, const int* prevm, u64* mask, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
-    hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0);
-    hipLaunchKernelGGL((enc_emit_par_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, mask, side, results, aux, g);
+    (void)mask;
+    hipLaunchKernelGGL((enc_parse_emit_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
 }
 
 // one pass over the stream whatever the hash width: formats whose matches reach back at most 8 KiB (enc_prev_cu_kernel<2, true>)
