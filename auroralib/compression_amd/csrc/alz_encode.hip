@@ -1396,9 +1396,11 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                                                        const u32* __restrict__ index_list, u32 count, mentry* __restrict__ match,
                                                        const u64* __restrict__ pos_off, const int* __restrict__ prev4,
                                                        const int* __restrict__ prevm, u64* __restrict__ startmask, EncGeom g, int tail_skip) {
+    __shared__ u8 hopmark[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
+    hopmark[lane] = 0;
     const u32 sid = index_list[bid];
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
@@ -1452,7 +1454,11 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
             const u32 lim = (u32)(limit + 1 - P) < 64u ? (u32)(limit + 1 - P) : 64u;     // (r < lim on entry: cur <= limit)
             if (lim == 64u) {
                 // a full window: the cursor runs 64 below zero, so that the add's carry IS "left the window" -- four instructions per hop
-                // (s_bitset1 and v_readlane take the low six bits of it, which are the cursor's)
+                // (s_bitset1 and v_readlane take the low six bits of it, which are the cursor's) -- and a hop is TWO tokens: jump2 = my
+                // jump + the jump of where it lands; the lanes in between are where the marked lanes' own jumps land (enc_parse_emit_kernel)
+                const u32 tgt = (u32)lane + (u32)jump;
+                const int jn = __builtin_amdgcn_ds_bpermute((int)((tgt < 64u ? tgt : (u32)lane) << 2), jump);
+                const int jump2 = tgt < 64u ? jump + jn : jump;
                 r -= 64u;
                 asm volatile(
                     "s_nop 3\n"
@@ -1462,9 +1468,14 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                     "s_add_u32 %[r], %[r], %[j]\n\t"
                     "s_cbranch_scc0 1b\n\t"
                     : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
-                    : [jump] "v"(jump)
+                    : [jump] "v"(jump2)
                     : "scc");
                 r += 64u;
+                if (((M >> lane) & 1ull) && tgt < 64u) hopmark[tgt] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                const u32 hm = hopmark[lane];
+                if (hm) hopmark[lane] = 0;
+                M |= __ballot(hm != 0u);
             } else
             asm volatile(
                 "s_nop 3\n"
@@ -1543,9 +1554,11 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
     constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;    // LZHudson: Yay0's tokens behind 32-bit big-endian flag words  LZHudson.cs:55-59
     __shared__ u32 flagacc[16];
     __shared__ u32 gofs[16];
+    __shared__ u8 hopmark[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
+    hopmark[lane] = 0;
     const u32 sid = index_list[bid];
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
@@ -1602,7 +1615,14 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
                 u64 M = 0; u32 r = (u32)rel, j;
                 const u32 lim = (u32)(limit + 1 - (int)P) < 64u ? (u32)(limit + 1 - (int)P) : 64u;     // (r < lim on entry: cur <= limit)
                 if (lim == 64u) {
-                    r -= 64u;                                                  // (the add's carry is "left the window": enc_roles_kernel)
+                    // Two tokens per hop: jump2 = my jump + the jump of where it lands (one ds_bpermute), so the scalar loop -- four
+                    // instructions per hop, ~18 tokens per window: the largest single item of this kernel -- runs half as often.  It
+                    // marks every second visited lane; the ones in between are where the marked lanes' own jumps land: scattered
+                    // through 64 bytes of LDS.  (The add's carry is "left the window": enc_roles_kernel.)
+                    const u32 tgt = (u32)lane + (u32)jump;                     // where my jump lands (>= 64: outside)
+                    const int jn = __builtin_amdgcn_ds_bpermute((int)((tgt < 64u ? tgt : (u32)lane) << 2), jump);
+                    const int jump2 = tgt < 64u ? jump + jn : jump;
+                    r -= 64u;
                     asm volatile(
                         "s_nop 3\n"
                         "1:\n\t"
@@ -1611,9 +1631,14 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
                         "s_add_u32 %[r], %[r], %[j]\n\t"
                         "s_cbranch_scc0 1b\n\t"
                         : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
-                        : [jump] "v"(jump)
+                        : [jump] "v"(jump2)
                         : "scc");
                     r += 64u;
+                    if (((M >> lane) & 1ull) && tgt < 64u) hopmark[tgt] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    const u32 hm = hopmark[lane];
+                    if (hm) hopmark[lane] = 0;
+                    M |= __ballot(hm != 0u);
                 } else
                 asm volatile(
                     "s_nop 3\n"
