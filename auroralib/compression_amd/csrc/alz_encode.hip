@@ -47,7 +47,7 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
     // the LzProperties[] form of the finder (RefPack): ScoreMatch takes the first set that admits a candidate
     int nprops, p_max_len[3], p_min_len[3], p_max_dist[3], p_min_dist[3];
     int variant;           // FastLZ: 1 = level 2 (token format + the two property sets)
-    int link16;            // the 4-byte-hash links are 16-bit DISTANCES (0: none or out of reach): finders whose maxDistance fits, up to quality 10
+    int link16;            // the 4-byte-hash links are 16-bit DISTANCES (0: none or out of reach): every finder whose maxDistance fits
 };
 
 // prev() of a position from the link array kernel A wrote: a position (or -1), or -- L16, maxDistance <= 65 535 -- a 16-bit distance,
@@ -712,15 +712,15 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             const int dist = pos - c;
             int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
             const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
-            const u64 x = load64(dp) ^ load64(data + c);
-            int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-            const bool more = on && x == 0ull && cmp_max > 8;
-            if (__ballot(more)) {
-                const u64 y = load64(dp + 8) ^ load64(data + (more ? c : 0) + 8);
-                if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
-                const bool more2 = more && y == 0ull && cmp_max > 16;
-                if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
-            }
+            // sixteen bytes of either side as ONE load each (round 3: eight, and eight more whenever some pair of the 64 had matched them --
+            // nearly always --: a second round trip per batch, and a scattered load costs the L1 one lookup per lane whatever its width;
+            // may run a few bytes past the stream: inside the staging slack, never compared)
+            u64 hv[2], cv[2];
+            __builtin_memcpy(hv, dp, 16); __builtin_memcpy(cv, data + c, 16);
+            const u64 x = hv[0] ^ cv[0], y = hv[1] ^ cv[1];
+            int len = x ? (int)(__builtin_ctzll(x) >> 3) : (y ? 8 + (int)(__builtin_ctzll(y) >> 3) : 16);
+            const bool more2 = on && len == 16 && cmp_max > 16;
+            if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
             if (len > cmp_max) len = cmp_max;
             if (on) {
                 if (len == cmp_max && cmp_max < best_possible) capf[pl] = 1u;
@@ -738,24 +738,46 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     };
 
     // ---- 1. the chains, links only
-    if constexpr (DYN) {   // a lane whose walk has ended takes the next position of the block (its first link is loaded now and looked at a trip later)
+    if constexpr (DYN) {
+        // A lane whose walk has ended takes the next position of the block.  The state a lane carries from trip to trip is integers only:
+        // the link it loaded in the trip before -- raw, i.e. a position or a 16-bit distance from `cbase` -- becomes its candidate at the
+        // top of the next trip, so the loads of a trip (the next link of the walking lanes, the first link of the lanes that took a new
+        // position) are in flight together and waited for once; "active" is "has a candidate", never a flag of its own (round 3: as
+        // per-lane booleans carried around the loop, `act` and `fresh` went through 0 / 1 registers and compares on every trip, and the
+        // conversion of a 16-bit link sat right behind its load).
         const int npos = limit - base + 1 < ALZ_DENSE_POS ? limit - base + 1 : ALZ_DENSE_POS;
-        int nextp = 0, pl = 0, pos = 0, cur = -1, it = 0;
-        bool act = false, fresh = false;
+        constexpr int NONE = L16 ? 0 : -1;
+        constexpr u32 IDLE = 0x7FFFFFFFu;                                   // the distance of a lane without a candidate
+        const u32 range = (u32)(g.max_dist - g.min_dist);
+        // (two registers for the two loads of a trip: one register, written under two different lane masks, made the second wait for the
+        // first.  What the lane state is kept as is the candidate's DISTANCE -- with 16-bit links the next one is this one plus the link --,
+        // and every lane condition below is ONE compare on it: a ballot of an AND of compares goes through a 0 / 1 register.)
+        int nextp = 0, pl = 0, pos = 0, it = 0, rawr = NONE, rawf = NONE; u32 dbase = 0;
         for (;;) {
-            if (fresh) { act = cur != -1; fresh = false; }
-            const u64 idle = __ballot(!act);
-            if (idle && nextp < npos) {
+            const int raw = L16 ? (rawr | rawf) : (rawr & rawf);            // (at most one of them holds a link; waits for the loads of the trip before)
+            const u32 dist = L16 ? (raw != 0 ? dbase + (u32)raw : IDLE) : (raw != -1 ? (u32)(pos - raw) : IDLE);
+            rawr = NONE; rawf = NONE;
+            it++;
+            const u64 actm = __ballot(dist != IDLE);
+            u64 refm = 0;
+            if (~actm && nextp < npos) {
+                const u64 idle = ~actm;
                 const int np = nextp + (int)__builtin_amdgcn_mbcnt_hi((u32)(idle >> 32), __builtin_amdgcn_mbcnt_lo((u32)idle, 0u));
                 nextp += (int)__popcll(idle);
-                if (!act && np < npos) { pl = np; pos = base + np; cur = link_at<L16>(p4, pos); it = 0; fresh = true; }
+                refm = __ballot(np < npos) & idle;
+                if (dist == IDLE && np < npos) {
+                    pl = np; pos = base + np; it = -1; dbase = 0;             // (its first candidate arrives a trip later, as step 0)
+                    if (L16) rawr = (int)reinterpret_cast<const unsigned short*>(p4)[pos]; else rawr = p4[pos];
+                }
             }
-            if (!__ballot(act || fresh)) break;
-            const int c = act ? cur : 0;
-            const int dist = pos - c;
-            const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
-            const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, c) : -1;   // (the last candidate's link is never followed, nor that of a candidate out of reach)
-            const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
+            if (!(actm | refm)) break;
+            const int c = pos - (int)dist;                                      // (meaningless on a lane without a candidate; never used there)
+            const bool within = dist <= (u32)g.max_dist;                        // beyond maxDistance the walk ends  :259-260
+            const bool ok = dist - (u32)g.min_dist <= range;                    // closer than minDistance: skipped, the walk goes on  :262-266
+            if (within && it + 1 < chain) {                                     // the link behind this candidate: next trip's candidate
+                if (L16) rawf = (int)reinterpret_cast<const unsigned short*>(p4)[c]; else rawf = p4[c];   // (the last candidate's link is never followed, nor that of one out of reach)
+                dbase = dist;
+            }
             const u64 om = __ballot(ok);
             if (om) {
                 const u32 k = (u32)__popcll(om);
@@ -767,7 +789,6 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
                 }
                 ln += k;
             }
-            if (act) { it++; cur = nxt; act = within && cur != -1 && it < chain; }
         }
     } else {
 #pragma unroll 1
@@ -1853,8 +1874,9 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     const int chain_bits = (17 + isqrt_floor(2 * q)) < wb ? (17 + isqrt_floor(2 * q)) : wb;
     if (g.max_chain != 1 && (1 << chain_bits) < g.max_dist) return false;
     // (16-bit links: 67 -> 57 GB of HBM traffic per 10 000 x 256 KiB at quality 0, 217 -> 143 at quality 8, times within 1 %; at quality 15 --
-    // chains of up to 1 024 links -- the subtraction per link costs kernel B 5 % (112.8 -> 118.7 ms): positions there)
-    g.link16 = (g.max_dist <= 0xFFFF && g.max_chain < 64) ? 1 : 0;
+    // chains of up to 1 024 links -- they cost kernel B 5 % while the conversion sat right behind the load, and gain 1 % (104.9 -> 103.6 ms)
+    // since the dense kernel converts a link at the top of the NEXT trip)
+    g.link16 = g.max_dist <= 0xFFFF ? 1 : 0;
     if (g.max_dist > (int)ALZ_M_DMASK) return false;                  // a distance has 21 bits in the match array (FastLZ with MaxWindowBits above 20: the caller's own encoder)
     memcpy(out_geom, &g, sizeof(g));
     if (window_bits) *window_bits = wb;
@@ -2373,7 +2395,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {             // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
-        u32 xlog = !dyn ? 7u : g.max_chain < 64 ? 2u : 0u;           // runs of consecutive blocks per XCD (enc_match_dense_kernel; chains of 64 links and more -- quality 11 up -- lose with them: 112.8 -> 122.4 ms at quality 15)
+        u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? 2u : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)
         while (xlog && (8u << xlog) > bd) xlog--;
         if (xlog) bd = (bd + (8u << xlog) - 1u) / (8u << xlog) * (8u << xlog);
 #define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, xlog)
