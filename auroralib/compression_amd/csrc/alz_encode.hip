@@ -88,7 +88,7 @@ __device__ __forceinline__ u32 scan_add(u32 v);
 // of its table word -- a chain through ALL hashes that share the word -- and the position finds its prev() by walking that chain to
 // the first entry whose remaining hash bits (the tag) equal its own.  Kernel B never follows a link beyond maxDistance (:259-260), so
 // the walk ends there with "none", and only the last 16 Ki positions have to be remembered: a ring of one tag byte (written where the
-// position is hashed) and one 16-bit link (written by the owner of the word) per position -- 48 KB beside a 64 KB table.  Inside
+// position is hashed) and one 16-bit link (written by the owner of the word) per position, in one dword -- 64 KB beside a 64 KB table.  Inside
 // 8 KiB a 14-bit word is shared by half a random position on average, so the walk is short; what the passes cost -- every pass hashes
 // the whole stream again, 67 of 138 ms at quality 8 -- is gone.  Entries wait for their step at most DRW positions, so that no ring
 // slot is overwritten (by the position 16 Ki further on) while a walk may still read it.
@@ -102,8 +102,12 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     __shared__ int T[(1 << TB) + 64];
     __shared__ u32 Q[16][ALZ_CU_QCAP];
     __shared__ u32 stage[16][WIN ? 1 : U * 64];   // several passes: a wavefront's entries of this pass, gathered from its slice
-    __shared__ u8 tagring[WIN ? RING : 1u];       // WIN: the hash bits above the table index, per position
-    __shared__ u16 linkring[WIN ? RING : 1u];     // WIN: distance to the previous entry of the same table word that has ANOTHER tag (0: none)
+    // WIN: per position, ONE dword -- byte 0 the hash bits above the table index (the tag), the upper half the distance to the previous
+    // entry of the same table word that has ANOTHER tag (0: none).  (As two arrays the walk below read the tag, waited, and only then
+    // read the link of the lanes that needed it: the compiler sinks the second read into the branch -- two LDS round trips per hop.)
+    __shared__ u32 ring[WIN ? RING : 1u];
+    u8* const ringb = reinterpret_cast<u8*>(ring);
+    unsigned short* const ringh = reinterpret_cast<unsigned short*>(ring);
     __shared__ u32 cnts[16][16];                  // [wavefront][class]: entries of the current chunk
     __shared__ u32 qpub[32];                      // [class]: ring index behind the queue's last entry; [16 + class]: entries waiting
     __shared__ u32 spill[3];                      // a slice held more entries of this pass than `stage` takes (one flag per call, three in rotation)
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
             const bool act = pos <= limit && pos < hi;             // (`hi`: a multiple of 64 -- whole groups in or out)
             const u32 h = (((v & vmask) * 2654435761u) >> hshift) & hmask2;      // ComputeHash :288-299 / the min-length table's :226-243 (one multiply either way)
             bool keep = act && (WIN || (h >> 15) == pass);
-            if (WIN) { if (act) tagring[(u32)pos & RM] = (u8)(h >> TB); }
+            if (WIN) { if (act) ringb[4u * ((u32)pos & RM)] = (u8)(h >> TB); }
             u32 wonly = 0;
             if (direct) {
                 // Runs (one byte, one pixel repeated) give every position the hash of a neighbour, all of them in one class.  A position
@@ -232,32 +236,32 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     // Lanes of this step that share a word see each other's links: reads of a round precede its writes (one
                     // wavefront's LDS operations execute in order), and any link written so far is a valid, if shorter, skip.
                     const u32 me = (u32)pos & RM;
-                    const u32 mytag = tagring[me];
+                    const u32 mytag = ring[me] & 0xFFu;
                     const int p0 = __builtin_amdgcn_readfirstlane(pos);        // candidates >= p0 are lanes of this step
                     const bool has = actl && prev >= 0 && (u32)(pos - prev) <= 0xFFFFu;
                     const u32 cs = (u32)(has ? prev : pos) & RM;
-                    const u32 t0 = tagring[cs], l0 = linkring[cs];
+                    const u32 e0 = ring[cs], t0 = e0 & 0xFFu, l0 = e0 >> 16;
                     const bool same = has && t0 == mytag, instep = has && prev >= p0;
                     u32 mylink = 0;
                     if (has) {
                         if (!same || instep) mylink = (u32)(pos - prev);      // (same tag inside the step: provisional, refined below)
                         else { const u32 far = (u32)(pos - prev) + l0; mylink = (l0 != 0u && far <= 0xFFFFu) ? far : 0u; }
                     }
-                    if (actl) linkring[me] = (u16)mylink;
+                    if (actl) ringh[2u * me + 1u] = (unsigned short)mylink;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
                     bool chase = same && instep;                               // a chain of my tag inside the step: pointer jumping over it
                     while (__ballot(chase)) {
                         const int x = pos - (int)mylink;
-                        const u32 lx = linkring[(u32)(chase ? x : pos) & RM];
+                        const u32 lx = ring[(u32)(chase ? x : pos) & RM] >> 16;
                         const int y = x - (int)lx;
-                        const u32 ty = tagring[(u32)((chase && lx != 0u) ? y : pos) & RM];
+                        const u32 ty = ring[(u32)((chase && lx != 0u) ? y : pos) & RM] & 0xFFu;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
                         if (chase) {
                             const u32 far = mylink + lx;
                             const bool ok = lx != 0u && far <= 0xFFFFu;
                             mylink = ok ? far : 0u;
                             chase = ok && y >= p0 && ty == mytag;
-                            linkring[me] = (u16)mylink;
+                            ringh[2u * me + 1u] = (unsigned short)mylink;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
                     }
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                     }
                     while (__ballot(go)) {
                         const u32 cs2 = (u32)(go ? cand : pos) & RM;
-                        const u32 t = tagring[cs2], dl = linkring[cs2];
+                        const u32 e2 = ring[cs2], t = e2 & 0xFFu, dl = e2 >> 16;
                         if (go) {
                             if (t == mytag) { res = cand; go = false; }
                             else if (dl == 0u) go = false;
