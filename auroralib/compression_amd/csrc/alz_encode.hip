@@ -797,16 +797,25 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     } else {
 #pragma unroll 1
     for (int r = 0; r < ALZ_DENSE_POS / 64; r++) {
+        // (the same integer-only lane state as above: the link loaded in a trip becomes the candidate at the top of the next one, the
+        // candidate is kept as its distance, every lane condition is one compare)
+        constexpr int NONE = L16 ? 0 : -1;
+        constexpr u32 IDLE = 0x7FFFFFFFu;
+        const u32 range = (u32)(g.max_dist - g.min_dist);
         const int pos = base + 64 * r + lane;
-        int cur = pos <= limit ? link_at<L16>(p4, pos) : -1;
-        bool act = cur != -1;
+        int raw = NONE; u32 dbase = 0;
+        if (pos <= limit) { if (L16) raw = (int)reinterpret_cast<const unsigned short*>(p4)[pos]; else raw = p4[pos]; }
         for (int it = 0; it < chain; it++) {
-            if (!__ballot(act)) break;
-            const int c = act ? cur : 0;
-            const int dist = pos - c;
-            const bool within = act && dist <= g.max_dist;                      // beyond maxDistance the walk ends  :259-260
-            const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, c) : -1;   // (the last candidate's link is never followed, nor that of a candidate out of reach)
-            const bool ok = within && dist >= g.min_dist;                       // closer than minDistance: skipped, the walk goes on  :262-266
+            const u32 dist = L16 ? (raw != 0 ? dbase + (u32)raw : IDLE) : (raw != -1 ? (u32)(pos - raw) : IDLE);
+            if (!__ballot(dist != IDLE)) break;
+            const int c = pos - (int)dist;                                      // (meaningless on a lane without a candidate; never used there)
+            const bool within = dist <= (u32)g.max_dist;                        // beyond maxDistance the walk ends  :259-260
+            const bool ok = dist - (u32)g.min_dist <= range;                    // closer than minDistance: skipped, the walk goes on  :262-266
+            raw = NONE;
+            if (within && it + 1 < chain) {                                     // (the last candidate's link is never followed, nor that of a candidate out of reach)
+                if (L16) raw = (int)reinterpret_cast<const unsigned short*>(p4)[c]; else raw = p4[c];
+                dbase = dist;
+            }
             const u64 om = __ballot(ok);
             if (om) {
                 const u32 k = (u32)__popcll(om);
@@ -818,8 +827,6 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
                 }
                 ln += k;
             }
-            cur = nxt;
-            act = within && cur != -1;
         }
     }
     }
