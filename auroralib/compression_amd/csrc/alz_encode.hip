@@ -152,10 +152,13 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
         int since = 0;                            // positions since the queues were last emptied (entries keep 16 bits of theirs)
 
         // One group of 64 positions at `pos`: the entry of my position, or none.
-        auto entry_of = [&](int pos, u32 v, bool direct, u32& e, int hi = 0x7FFFFFFF) -> bool {
+        // (`keepm`: the lanes that keep their entry, as a mask built from the ballots of the single compares -- the ballot of their AND goes
+        // through a 0 / 1 register and a compare, twice 24 times per slice in scan() below)
+        auto entry_of = [&](int pos, u32 v, bool direct, u32& e, int hi = 0x7FFFFFFF, u64* keepm = nullptr) -> bool {
             const bool act = pos <= limit && pos < hi;             // (`hi`: a multiple of 64 -- whole groups in or out)
             const u32 h = (((v & vmask) * 2654435761u) >> hshift) & hmask2;      // ComputeHash :288-299 / the min-length table's :226-243 (one multiply either way)
             bool keep = act && (WIN || (h >> 15) == pass);
+            if (keepm) *keepm = __ballot(pos <= limit) & (WIN ? ~0ull : __ballot((h >> 15) == pass));
             if (WIN) { if (act) ringb[4u * ((u32)pos & RM)] = (u8)(h >> TB); }
             u32 wonly = 0;
             if (direct) {
@@ -395,8 +398,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 u32 fill = 0;
 #pragma unroll
                 for (int sb = 0; sb < SBN; sb++) {
-                    u32 e; const bool kp = entry_of(p0 + sb * 64, vv[sb], false, e);
-                    const u64 m = __ballot(kp);
+                    u32 e; u64 m; const bool kp = entry_of(p0 + sb * 64, vv[sb], false, e, 0x7FFFFFFF, &m);
                     const u32 at = fill + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
                     if (kp && at < (u32)(U * 64)) stage[w][at] = e;
                     fill += (u32)__popcll(m);
