@@ -899,7 +899,9 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
 // load each, then the arithmetic: 16.7-17.1 ms against 16.8.  Neither the chain of dependent round trips nor the L1's lookups (0.77 per
 // cycle) is the bound: without the link loads (10.5 GB) the kernel takes 12.7 ms, without the scattered candidate loads 15.3 -- it moves
 // 18 GB in and 21 GB out (8 bytes of match per position) at ~2.4 TB/s, three streams per workgroup against a copy kernel's two at 5.8.
-// What would pay is fewer bytes per position in the arrays the kernels hand to each other: DESIGN.md 8.)
+// What would pay is fewer bytes per position in the arrays the kernels hand to each other: DESIGN.md 8.  Tried again at the end of the
+// round with the arrays at 2 + 4 bytes per position (19.5 GB per launch, 1.4 TB/s, 0.75 instructions per cycle): 13.8 ms either way;
+// one store in 64: 13.1, no scattered candidate loads: 12.5 -- no single stream of accesses is the bound.)
 // ---------------------------------------------------------------------------------------------- kernel C
 struct Out {                 // bounded byte sink of one stream
     u8* p; u32 len, cap; bool fail;
