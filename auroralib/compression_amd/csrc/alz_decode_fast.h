@@ -559,16 +559,29 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     const u32 i0 = in.idx(p);
     // 1. speculation: only the SIZE of "the sequence that would start at my byte" (the fields of the real sequences are
     //    decoded once, after the walk, by one lane per sequence)
-    u32 nx[4];
+    // (three loops, not one: written as one, the compiler kept the windows in program order -- token and extension byte of window 0, wait,
+    // its match-extension byte, wait, then window 1 ... -- eight dependent LDS round trips per round where two suffice)
+    u32 nx[4], bq[4], eq[4], opq[4], emq[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const u32 pos = i0 + 64u * (u32)w + (u32)lane;        // cache index of "my" byte
-        const u32 b = in.lds[pos];
-        const u32 e1 = in.lds[pos + 1];
+        bq[w] = in.lds[pos];
+        eq[w] = in.lds[pos + 1];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 L0 = bq[w] >> 4;
+        const u32 lx = L0 == 15u ? eq[w] + 1u : 0u;           // literal-length extension byte + its value
+        opq[w] = pos + 1u + L0 + lx;                          // offset bytes
+        emq[w] = in.lds[(opq[w] + 2u) & 2047u];               // match length extension (if any); masked: garbage lanes may point anywhere
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        const u32 b = bq[w], e1 = eq[w], em = emq[w], op = opq[w];
         const u32 L0 = b >> 4, M0 = b & 15u;
-        const u32 lx = L0 == 15u ? e1 + 1u : 0u;              // literal-length extension byte + its value
-        const u32 op = pos + 1u + L0 + lx;                    // offset bytes
-        const u32 em = in.lds[(op + 2u) & 2047u];             // match length extension (if any); masked: garbage lanes may point anywhere
+        const u32 lx = L0 == 15u ? e1 + 1u : 0u;
         const bool bad = (L0 == 15u && e1 == 255u) || (M0 == 15u && em == 255u) || L0 + lx > ALZ_QRUN;   // (second extension bytes; a run beyond the resident cache chunk)
         nx[w] = bad ? ALZ_NX_BAD : (op + 2u + (M0 == 15u ? 1u : 0u)) - pos;
     }
@@ -664,9 +677,7 @@ struct Lz4Rounds {
 __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
     // 1. speculation: the size of "the element that would start at my byte"
-    auto size_at = [&](int w) -> u32 {
-        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
-        const u32 b = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2];
+    auto size_of = [&](u32 b, u32 e1, u32 e2) -> u32 {
         const u32 type = b & 3u, hi = b >> 2;
         u32 n = type + 1u;                                              // copies with a 1- / 2-byte offset: 2 / 3 bytes
         if (type == 0u) {
@@ -677,9 +688,12 @@ __device__ __forceinline__ bool snappy_parse_round(InCache& in, u32 p, int lane,
         if (type == 3u) n = ALZ_NX_BAD;                                 // 4-byte offsets (E3 check included) stay with the exact parser
         return n;
     };
-    u32 nx[4];
+    auto size_at = [&](int w) -> u32 { const u32 pos = i0 + 64u * (u32)w + (u32)lane; return size_of(in.lds[pos], in.lds[pos + 1], in.lds[pos + 2]); };
+    u32 nx[4], sb[3][3];
 #pragma unroll
-    for (int w = 0; w < 3; w++) nx[w] = size_at(w);
+    for (int w = 0; w < 3; w++) { const u32 pos = i0 + 64u * (u32)w + (u32)lane; sb[w][0] = in.lds[pos]; sb[w][1] = in.lds[pos + 1]; sb[w][2] = in.lds[pos + 2]; }   // (all three windows' bytes in flight together)
+#pragma unroll
+    for (int w = 0; w < 3; w++) nx[w] = size_of(sb[w][0], sb[w][1], sb[w][2]);
     nx[3] = 0;
     // 2. the walk: one token per element, lane j = j-th element (a window holds <= 32 elements)
     u32 spos, sp, nel;
@@ -1177,8 +1191,14 @@ __device__ __forceinline__ void lzo_walk_pos(u32 (&pk)[4], u32& spos_out, u32& s
 // "the instruction that would start at cache index pos": sizes / next states for the walk (TOK = false) or the tokens of
 // the instruction entered in `state` (TOK = true: first token, and the trailing-literal token or 0)
 template <bool TOK>
+__device__ __forceinline__ u32 lzo_interpret_bytes(u32 pos, u32 f, u32 e1, u32 e2, u32 e3, u32 state, u32& second);
+template <bool TOK>
 __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 state, u32& second) {
     const u32 f = in.lds[pos], e1 = in.lds[pos + 1], e2 = in.lds[pos + 2], e3 = in.lds[pos + 3];
+    return lzo_interpret_bytes<TOK>(pos, f, e1, e2, e3, state, second);
+}
+template <bool TOK>
+__device__ __forceinline__ u32 lzo_interpret_bytes(u32 pos, u32 f, u32 e1, u32 e2, u32 e3, u32 state, u32& second) {
     second = 0;
     if (f >= 16u) {                                              // opcodes that do not depend on the state
         u32 len, dist, t, size;
@@ -1214,9 +1234,16 @@ __device__ __forceinline__ u32 lzo_interpret(const InCache& in, u32 pos, u32 sta
 // `state` (0 = A, 1 = B, 2 = C) is the walk's state in front of the round on entry, behind it on return.
 __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, int lane, u32& state, u32& qt_out, u32& nt_out, u32& total_out, u32& adv_out) {
     const u32 i0 = in.idx(p);
-    u32 pk[4], dummy;
+    u32 pk[4], dummy, fb[3][4];
+    // (the bytes of the three windows first, then the arithmetic: as one loop the compiler kept the windows in program order, three
+    // dependent LDS round trips where one suffices)
 #pragma unroll
-    for (int w = 0; w < 3; w++) pk[w] = lzo_interpret<false>(in, i0 + 64u * (u32)w + (u32)lane, 0u, dummy);
+    for (int w = 0; w < 3; w++) {
+        const u32 pos = i0 + 64u * (u32)w + (u32)lane;
+        fb[w][0] = in.lds[pos]; fb[w][1] = in.lds[pos + 1]; fb[w][2] = in.lds[pos + 2]; fb[w][3] = in.lds[pos + 3];
+    }
+#pragma unroll
+    for (int w = 0; w < 3; w++) pk[w] = lzo_interpret_bytes<false>(i0 + 64u * (u32)w + (u32)lane, fb[w][0], fb[w][1], fb[w][2], fb[w][3], 0u, dummy);
     pk[3] = 0;                                                   // (worked out when the walk gets there: usually it does not)
     u32 spos, sp, ninstr;
     lzo_walk_pos(pk, spos, sp, ninstr, state, [&](u32& p3) { u32 d2; p3 = lzo_interpret<false>(in, i0 + 192u + (u32)lane, 0u, d2); });
