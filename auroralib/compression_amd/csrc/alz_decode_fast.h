@@ -1148,44 +1148,49 @@ struct FastlzRounds {
 // instruction.  Each instruction yields a match token plus, when its low two bits say so, a run of 1-3 trailing
 // literals.  Length extensions of more than one byte, the end marker and anything else unusual stop the walk.
 
-// walk over a 256-byte window: `pk` per lane = [8:0] size (511: not an instruction the walk takes) and [10:9] next state
-// when entered in state A, [19:11] and [21:20] the same for states B / C.  state: 0 = A, 1 = B (1-3 literals pending),
-// 2 = C (a literal run came before).  Lane j of `spos` receives (start offset | entry state << 9) of the j-th
-// instruction; same loop discipline as lane_walk_pos (an instruction has >= 2 bytes: <= 32 per window).
+// walk over a 256-byte window: `pk` per lane = two halves of 16 bits, the low one for an instruction entered in state A, the high one for
+// states B / C: [8:0] size (511: not an instruction the walk takes), [10:9] the state it leaves behind, [15:11] the SHIFT that selects the
+// half of the NEXT instruction (16 if that state is B or C, else 0).  state: 0 = A, 1 = B (1-3 literals pending), 2 = C (a literal run
+// came before).  Lane j of `spos` receives (start offset | 256 if entered in B / C) of the j-th instruction; the exact state (B or C) a
+// lane takes from what the lane before it leaves behind (lzo_parse_round).  Round 3: nine scalar instructions per instruction where
+// there were thirteen -- the walk is two thirds of this kernel's scalar instructions --: what the loop carries is the shift, not the
+// state; the record is one shift-and-add; the add's carry is the window-exit test (the offset runs 64 (w + 1) below zero inside window
+// w: lane_walk_pos).  Same loop discipline as lane_walk_pos (an instruction has >= 2 bytes: <= 32 per window).
 template <class F3>
-__device__ __forceinline__ void lzo_walk_pos(u32 (&pk)[4], u32& spos_out, u32& sp_out, u32& n_out, u32& state_io, F3 fill3) {
-    u32 spos = 0, sp = 0, cnt = 0, state = uni(state_io), n = 0;
+__device__ __forceinline__ void lzo_walk_pos(u32 (&pk)[4], u32& spos_out, u32& sp_out, u32& n_out, u32 state_in, F3 fill3) {
+    u32 spos = 0, sp = 0, cnt = 0, sh = uni(state_in) ? 16u : 0u, n = 0, c0 = 0, c1 = 0, c2 = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         if (cnt < 33u && sp < 64u * (u32)(w + 1)) {          // (a window of 64 bytes adds at most 32 instructions: lane j <= 63)
             if (w == 3) fill3(pk[3]);
-            u32 v, sh, t;
+            u32 v, rec, t = sp - 64u * (u32)(w + 1);
             asm volatile(
                 "s_mov_b32 m0, %[cnt]\n\t"
                 "s_nop 1\n"
                 "1:\n\t"
-                "v_readlane_b32 %[v], %[pk], %[sp]\n\t"
-                "s_cmp_eq_u32 %[state], 0\n\t"
-                "s_cselect_b32 %[sh], 0, 11\n\t"
-                "s_lshl_b32 %[t], %[state], 9\n\t"
-                "s_or_b32 %[t], %[t], %[sp]\n\t"
+                "v_readlane_b32 %[v], %[pk], %[t]\n\t"
+                "s_lshl4_add_u32 %[rec], %[sh], %[t]\n\t"         // offset | 256 when entered in state B / C
                 "s_lshr_b32 %[v], %[v], %[sh]\n\t"
-                "v_writelane_b32 %[spos], %[t], m0\n\t"
+                "v_writelane_b32 %[spos], %[rec], m0\n\t"
                 "s_and_b32 %[n], %[v], 0x1ff\n\t"
-                "s_bfe_u32 %[state], %[v], 0x20009\n\t"         // bits [10:9]: the state the instruction leaves behind
+                "s_bfe_u32 %[sh], %[v], 0x5000b\n\t"            // bits [15:11]: the shift for the instruction behind this one
                 "s_add_u32 m0, m0, 1\n\t"
-                "s_add_u32 %[sp], %[sp], %[n]\n\t"
-                "s_cmp_lt_u32 %[sp], %[lim]\n\t"
-                "s_cbranch_scc1 1b\n\t"
+                "s_add_u32 %[t], %[t], %[n]\n\t"
+                "s_cbranch_scc0 1b\n\t"
                 "s_mov_b32 %[cnt], m0\n\t"
-                : [v] "=&s"(v), [n] "+s"(n), [sh] "=&s"(sh), [t] "=&s"(t), [sp] "+s"(sp), [spos] "+v"(spos), [cnt] "+s"(cnt), [state] "+s"(state)
-                : [pk] "v"(pk[w]), [lim] "s"(64u * (u32)(w + 1))
+                : [v] "=&s"(v), [n] "+s"(n), [sh] "+s"(sh), [rec] "=&s"(rec), [t] "+s"(t), [spos] "+v"(spos), [cnt] "+s"(cnt)
+                : [pk] "v"(pk[w])
                 : "scc", "m0");
+            sp = t + 64u * (u32)(w + 1);
         }
+        if (w == 0) c0 = cnt; else if (w == 1) c1 = cnt; else if (w == 2) c2 = cnt;
     }
-    const bool undo = n == 511u;                                 // the last instruction counted was one the walk does not take
-    if (undo) { cnt -= 1u; const u32 v = wave_readlane(spos, cnt); sp = v & 0x1FFu; state = v >> 9; }   // resume in front of the first one not taken
-    spos_out = spos; sp_out = sp; n_out = cnt; state_io = state;
+    {
+        const u32 l = (u32)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        spos += 64u + (l >= c0 ? 64u : 0u) + (l >= c1 ? 64u : 0u) + (l >= c2 ? 64u : 0u);
+    }
+    if (n == 511u) { cnt -= 1u; sp = wave_readlane(spos, cnt) & 0xFFu; }   // the last instruction counted was one the walk does not take: resume in front of it
+    spos_out = spos; sp_out = sp; n_out = cnt;
 }
 
 // "the instruction that would start at cache index pos": sizes / next states for the walk (TOK = false) or the tokens of
@@ -1216,7 +1221,8 @@ __device__ __forceinline__ u32 lzo_interpret_bytes(u32 pos, u32 f, u32 e1, u32 e
         else { len = 5u + ((f >> 5) & 3u); dist = (e1 << 3) + ((f & 0x1cu) >> 2) + 1u; t = f & 3u; size = 2u + t; }
         if (TOK) { if (t) second = ALZ_TOK_LIT(t, (pos + size - t) & 2047u); return ALZ_TOK_MATCH(len, dist); }
         const u32 sz = bad ? 511u : size, nx = t ? 1u : 0u;
-        return sz | (nx << 9) | (sz << 11) | (nx << 20);
+        const u32 half = sz | (nx << 9) | (nx << 15);            // (the shift behind it: 16 x (state != A))
+        return half | (half << 16);
     }
     const bool ext = f == 0u;                                    // state A: literal run  LZO.cs:75-85
     const u32 len = ext ? 18u + e1 : 3u + f;
@@ -1227,7 +1233,7 @@ __device__ __forceinline__ u32 lzo_interpret_bytes(u32 pos, u32 f, u32 e1, u32 e
         return state == 1u ? ALZ_TOK_MATCH(2u, (e1 << 2) + (f >> 2) + 1u) : ALZ_TOK_MATCH(3u, (e1 << 2) + (f >> 2) + 2049u);
     }
     const u32 sizeA = ((ext && e1 == 0u) || len > ALZ_QRUN) ? 511u : (ext ? 2u : 1u) + len;   // (a run beyond the resident cache chunk: exact parser)
-    return sizeA | (2u << 9) | ((2u + t) << 11) | ((t ? 1u : 0u) << 20);
+    return (sizeA | (2u << 9) | (16u << 11)) | (((2u + t) | ((t ? 1u : 0u) << 9) | ((t ? 16u : 0u) << 11)) << 16);
 }
 
 // Preconditions: queue empty, one cache chunk + 76 input bytes ahead of s.p (an instruction boundary), cache covers [p, p + chunk).
@@ -1248,11 +1254,18 @@ __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, 
     u32 spos, sp, ninstr;
     lzo_walk_pos(pk, spos, sp, ninstr, state, [&](u32& p3) { u32 d2; p3 = lzo_interpret<false>(in, i0 + 192u + (u32)lane, 0u, d2); });
     if (ninstr == 0u) return false;
+    // the exact state every instruction is entered in: what the instruction in front of it leaves behind (the first: the round's)
+    const u32 mypos = i0 + (spos & 0xFFu), mynz = (spos >> 8) & 1u;
+    const u32 mf = in.lds[mypos], me1 = in.lds[mypos + 1], me2 = in.lds[mypos + 2], me3 = in.lds[mypos + 3];
+    const u32 mypk = lzo_interpret_bytes<false>(mypos, mf, me1, me2, me3, 0u, dummy);
+    const u32 leaves = (mypk >> (mynz ? 25u : 9u)) & 3u;
+    const u32 before = wave_bperm(((u32)lane - 1u) & 63u, leaves);
+    const u32 mystate = lane == 0 ? uni(state) : before;
     // one lane per instruction, in the state the walk entered it: match / run token + trailing-literal token.  The walk takes as
     // many instructions as its windows hold (up to 64; round 2 stopped at 32 whatever they yield, ~39 tokens); the round keeps those
     // whose tokens fit the 64 slots of the queue and resumes in front of the first one that does not.
     u32 tl;
-    const u32 first = lzo_interpret<true>(in, i0 + (spos & 0x1FFu), spos >> 9, tl);
+    const u32 first = lzo_interpret_bytes<true>(mypos, mf, me1, me2, me3, mystate, tl);
     bool st = (u32)lane < ninstr;
     bool second = st && tl != 0u;
     u64 sm = __ballot(second);
@@ -1260,9 +1273,10 @@ __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, 
     const u32 keep = (u32)__popcll(__ballot(st && rank + (second ? 2u : 1u) <= 64u));
     if (keep < ninstr) {
         ninstr = keep;
-        const u32 v = wave_readlane(spos, keep); sp = v & 0x1FFu; state = v >> 9;
+        sp = wave_readlane(spos, keep) & 0xFFu;
         st = (u32)lane < keep; second = second && st; sm = __ballot(second);
     }
+    state = wave_readlane(leaves, ninstr - 1u);                  // (ninstr >= 1: an instruction has at most two tokens)
     if (st) { stage[rank] = first; if (second) stage[rank + 1u] = tl; }
     const u32 base = ninstr + (u32)__popcll(sm);
     wave_sync();
