@@ -1578,7 +1578,14 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
 // ~30 of the ~280 instructions the two spend per window.  The walk visits windows in order (one that lies inside a match has nothing
 // to parse, the emitter still passes it: it is covered); what the window in front found for THIS window's first position travels in
 // `carry`; a position kernel B had capped is recomputed exactly when the cursor stands on it and patched into the window's registers.
-template <int FMT>
+// SEARCH (finders that look at ONE candidate per position -- maxChain 1: quality 0 --, one property set, no min-length table, 16-bit
+// links): kernel B is in here as well.  What a position's match is does not depend on the parse, so the loads are issued ahead of it:
+// while window w is parsed and emitted, the matches of window w + 1 are worked out from bytes that arrived during the window before
+// (the lazy rule of the last position of w needs the first of w + 1), the candidates' bytes of window w + 2 are in flight, and so
+// are the links and the positions' own bytes of window w + 3: no match array at all (10.5 GB written, 13 GB read at quality 0),
+// and the search runs at the parse's instruction rate instead of waiting for its own loads (0.75 instructions per cycle as a kernel).
+// 32 bytes per side are compared from the prefetched registers; a longer match finishes in memory.
+template <int FMT, bool SEARCH>
 __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                             const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
                                                             u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
@@ -1620,13 +1627,57 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
     // (match entry and source byte of a window are loaded while the window before it is worked on; positions above `limit` were never
     // searched: no match)
     auto ldm = [&](u32 q) { return (int)q <= limit ? m_unpack(__builtin_nontemporal_load(m + q)) : make_uint2(0, 0); };
-    uint2 a_n = ldm((u32)lane);
+    // ---- SEARCH: the stages of the look-ahead.  L: link + 32 own bytes of a window; C: the 32 bytes of its candidates.
+    const unsigned short* lk16 = reinterpret_cast<const unsigned short*>(p4);
+    const u32 srange = (u32)(g.max_dist - g.min_dist);
+    u32 lkA = 0, lkB = 0; u64 ownA[4] = {0, 0, 0, 0}, ownB[4] = {0, 0, 0, 0}, cndB[4] = {0, 0, 0, 0};
+    auto clampq = [&](u32 q) { return (int)q <= limit ? q : (u32)(limit > 0 ? limit : 0); };             // (positions behind the last searched one: loads stay inside, results unused)
+    auto loadL = [&](u32 q, u32& lkv, u64 (&own)[4]) { const u32 qq = clampq(q); lkv = __builtin_nontemporal_load(lk16 + qq); __builtin_memcpy(own, data + qq, 32); };   // (may run a few bytes past the stream: staging slack)
+    auto loadC = [&](u32 q, u32 lkv, u64 (&cnd)[4]) { const u32 qq = clampq(q); const bool ok = lkv - (u32)g.min_dist <= srange; __builtin_memcpy(cnd, data + qq - (ok ? lkv : 0u), 32); };   // (a candidate out of reach is not touched)
+    auto matchof = [&](u32 q, u32 lkv, const u64 (&own)[4], const u64 (&cnd)[4]) -> uint2 {
+        if ((int)q > limit) return make_uint2(0, 0);
+        const bool ok = lkv - (u32)g.min_dist <= srange;                // a candidate (0: none), within maxDistance, not closer than minDistance (the walk would go on -- and at maxChain 1 it is over)  :259-266
+        int best_possible = (int)n - (int)q; if (best_possible > g.max_len) best_possible = g.max_len;
+        const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
+        const u64 x0 = own[0] ^ cnd[0], x1 = own[1] ^ cnd[1], x2 = own[2] ^ cnd[2], x3 = own[3] ^ cnd[3];
+        int len = x0 ? (int)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (int)(__builtin_ctzll(x1) >> 3) : x2 ? 16 + (int)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (int)(__builtin_ctzll(x3) >> 3) : 32;
+        bool go = ok && len == 32 && cmp_max > 32;
+        if (__ballot(go)) {                                              // GetMatchLength behind the prefetched bytes (wave_match_tail's loop)
+            const u8* pa = data + q; const u8* pb = data + q - (go ? lkv : 0u);
+            int l = 32;
+            while (__ballot(go)) {
+                const u64 z = load64(pa + (go ? l : 0)) ^ load64(pb + (go ? l : 0));
+                if (go) { if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; } else { l += 8; if (l >= cmp_max) go = false; } }
+            }
+            if (ok && len == 32 && cmp_max > 32) len = l;
+        }
+        if (len > cmp_max) len = cmp_max;
+        const bool hitcap = ok && len == cmp_max && cmp_max < best_possible;
+        int l2 = len;
+        if (g.no_self_overlap && l2 > (int)lkv) l2 = (int)lkv;          // ScoreMatch  :301-321, one property set
+        const bool take = ok && !hitcap && l2 >= g.min_len;
+        return hitcap ? make_uint2(ALZ_CAPPED, ALZ_CAPPED) : make_uint2(take ? lkv : 0u, take ? (u32)l2 : 0u);
+    };
+    uint2 a_n;
+    if (SEARCH) {
+        loadL((u32)lane, lkB, ownB); loadL(64u + (u32)lane, lkA, ownA);
+        loadC((u32)lane, lkB, cndB);
+        a_n = matchof((u32)lane, lkB, ownB, cndB);                      // window 0
+        lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
+        loadC(64u + (u32)lane, lkB, cndB);                              // window 1's candidates
+        loadL(128u + (u32)lane, lkA, ownA);                             // window 2's links and own bytes
+    } else a_n = ldm((u32)lane);
     u32 sb_n = (u32)lane < n ? src[lane] : 0u;
     for (u32 P = 0; P < n; P += 64) {
         const u32 p = P + (u32)lane;
         uint2 a = a_n;
         const u32 sb = sb_n;
-        a_n = ldm(p + 64u);
+        if (SEARCH) {
+            a_n = matchof(p + 64u, lkB, ownB, cndB);                    // window w + 1 (bytes that arrived during the window before)
+            lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
+            loadC(p + 128u, lkB, cndB);                                 // window w + 2's candidates
+            loadL(p + 192u, lkA, ownA);                                 // window w + 3's links and own bytes
+        } else a_n = ldm(p + 64u);
         if (p + 64 < n) sb_n = src[p + 64];
         u64 sm = carry ? 1ull : 0ull;
         carry = false;
@@ -2378,11 +2429,19 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
                        (const u64*)mask);
 }
 
+// one candidate per position and a format whose parse and emit are one kernel: the search is in that kernel too (no kernel B, no match array)
+static bool searches_in_the_parse(int fmt, const EncGeom& g) {
+    const bool par = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
+                     fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+    return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
+}
+
 template <int FMT>
 static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match,
                             const u64* pos_off, const int* prev4, const int* prevm, u64* mask, u8* side, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
     (void)mask;
-    hipLaunchKernelGGL((enc_parse_emit_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
+    if (searches_in_the_parse(FMT, g)) hipLaunchKernelGGL((enc_parse_emit_kernel<FMT, true>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
+    else hipLaunchKernelGGL((enc_parse_emit_kernel<FMT, false>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, prev4, prevm, side, results, aux, g);
 }
 
 // one pass over the stream whatever the hash width: formats whose matches reach back at most 8 KiB (enc_prev_cu_kernel<2, true>)
@@ -2407,7 +2466,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (bx > 32u) bx = 32u;
     // (workgroups per stream, each with one contiguous range: 32 -- 8 Ki positions of a 256 KiB stream, 4 KiB of history in front of them fetched
     // again -- move 9.1 GB at quality 0, 128 move 12.7, both in 13.6 ms; one position per thread, ten million workgroups per launch: 18.6 ms)
-    if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {             // (from maxChain 3 on: the chains first, the pairs 64 at a time)
+    if (searches_in_the_parse(fmt, g)) {}
+    else if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {        // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? 2u : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)
