@@ -1632,7 +1632,10 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
     const u32 srange = (u32)(g.max_dist - g.min_dist);
     u32 lkA = 0, lkB = 0; u64 ownA[4] = {0, 0, 0, 0}, ownB[4] = {0, 0, 0, 0}, cndB[4] = {0, 0, 0, 0};
     auto clampq = [&](u32 q) { return (int)q <= limit ? q : (u32)(limit > 0 ? limit : 0); };             // (positions behind the last searched one: loads stay inside, results unused)
-    auto loadL = [&](u32 q, u32& lkv, u64 (&own)[4]) { const u32 qq = clampq(q); lkv = __builtin_nontemporal_load(lk16 + qq); __builtin_memcpy(own, data + qq, 32); };   // (may run a few bytes past the stream: staging slack)
+    // (a position behind the last searched one has NO link: kernel A never wrote its slot -- the scratch is grow-only and never zeroed, so the
+    // slot holds whatever an earlier batch left there, and loadC would dereference data - that; a stream shorter than 4 bytes has no
+    // searched position at all.  The own bytes may run up to 28 bytes past the stream: the slack every source buffer has, auroralz.h)
+    auto loadL = [&](u32 q, u32& lkv, u64 (&own)[4]) { const u32 qq = clampq(q); lkv = (int)q <= limit ? (u32)__builtin_nontemporal_load(lk16 + qq) : 0u; __builtin_memcpy(own, data + qq, 32); };
     auto loadC = [&](u32 q, u32 lkv, u64 (&cnd)[4]) { const u32 qq = clampq(q); const bool ok = lkv - (u32)g.min_dist <= srange; __builtin_memcpy(cnd, data + qq - (ok ? lkv : 0u), 32); };   // (a candidate out of reach is not touched)
     auto matchof = [&](u32 q, u32 lkv, const u64 (&own)[4], const u64 (&cnd)[4]) -> uint2 {
         if ((int)q > limit) return make_uint2(0, 0);
@@ -2435,6 +2438,8 @@ static bool searches_in_the_parse(int fmt, const EncGeom& g) {
                      fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
     return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
 }
+
+int alz_encode_geom_needs_match(int fmt, const void* geom) { EncGeom g; memcpy(&g, geom, sizeof(g)); return searches_in_the_parse(fmt, g) ? 0 : 1; }
 
 template <int FMT>
 static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match,

@@ -218,7 +218,7 @@ int alz_device_info(alz_ctx* c, char* name, size_t name_cap, int* cu_count, uint
 int alz_device_malloc(alz_ctx* c, size_t bytes, void** d_ptr) {
     if (!c || !d_ptr) return fail(ALZ_E_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    HIP_TRY(hipMalloc(d_ptr, bytes + 64));              // (+ the read slack of the device-resident entry points, auroralz.h)
     return ALZ_OK;
 }
 int alz_device_free(alz_ctx* c, void* d_ptr) {
@@ -366,11 +366,17 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     for (int f = 0; f < ALZ_FMT_COUNT; f++) order[f] = f;
     std::stable_sort(order, order + ALZ_FMT_COUNT, [](int a, int b) { return format_latency((uint32_t)a) > format_latency((uint32_t)b); });
     HIP_TRY(hipEventRecord(c->fork, s));
-    int k = 0, rc = ALZ_OK; bool used[4] = {false, false, false, false};
+    // Formats beyond the fourth queue up behind an earlier kernel: each goes to the lane with the least work queued so far (longest
+    // first onto the least loaded lane; a kernel's share of the launch ~ its streams x the format's cost per byte) -- dealt round-robin,
+    // the fifth format waited behind the slowest kernel of all while the faster lanes drained.
+    int rc = ALZ_OK; bool used[4] = {false, false, false, false};
+    uint64_t load[4] = {0, 0, 0, 0};
     for (int oi = 0; oi < ALZ_FMT_COUNT && rc == ALZ_OK; oi++) {
         const int f = order[oi];
         if (!p->fmt_cnt[f]) continue;
-        const int lane = k & 3;                             // lane 0: the caller's stream; 1..3: side streams
+        int lane = 0;                                       // lane 0: the caller's stream; 1..3: side streams
+        for (int l = 1; l < 4; l++) if (load[l] < load[lane]) lane = l;
+        load[lane] += (uint64_t)p->fmt_cnt[f] * format_weight((uint32_t)f) + 1u;
         hipStream_t a = lane == 0 ? s : c->aux[lane - 1];
         if (lane != 0 && !used[lane]) {
             hipError_t w = hipStreamWaitEvent(a, c->fork, 0);
@@ -379,7 +385,6 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
         }
         hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
         if (e != hipSuccess) rc = fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
-        k++;
     }
     for (int i = 1; i < 4; i++) if (used[i]) {
         hipError_t e = hipEventRecord(c->join[i], c->aux[i - 1]);
@@ -682,8 +687,13 @@ static inline bool fastlz_level2(const alz_settings& st, uint32_t src_len) { ret
 // the caller has filled / will read.  `upload(d_src, d_dst)` runs once the arguments are validated and the scratch exists -- the
 // host-buffer entry points grow their device buffers and stage their input there (a refused batch never touches the device);
 // the device-resident entry point just hands its two pointers over.
+// `src_has_slack`: the source buffer has >= 64 readable bytes behind src_bytes (the library's own staging buffer).  A caller's device
+// buffer need not: the finder's look-ahead loads read up to 32 bytes past a stream's end, so the streams that end inside the last 64
+// bytes of the caller's buffer are copied into scratch with room behind them and searched there (their descriptors -- the device copy
+// only -- point at the copy; offsets are differences of device addresses).
 static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, size_t src_bytes, const alz_stream* streams,
-                       size_t dst_bytes, alz_result* results, alz_encode_aux* aux, const std::function<int(const void*&, void*&)>& upload) {
+                       size_t dst_bytes, alz_result* results, alz_encode_aux* aux, const std::function<int(const void*&, void*&)>& upload,
+                       bool src_has_slack = true) {
     const void* d_src_base = nullptr; void* d_dst_base = nullptr;
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
     if (st.quality < 0 || st.quality > 15) return fail(ALZ_E_INVALID, "quality %d outside 0..15 (CompressionSettings.cs:38-50)", st.quality);
@@ -710,7 +720,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
     std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
-    bool any_min = false;
+    bool any_min = false, any_match = false;
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
@@ -718,7 +728,13 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &st, g, nullptr, lvl2 ? 1 : 0))
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
         any_min = any_min || alz_encode_geom_min_table(g);
+        any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
     }
+    // streams whose look-ahead would leave the caller's source buffer (see above)
+    std::vector<uint32_t> tail_ix; size_t tail_bytes = 0;
+    if (!src_has_slack)
+        for (uint32_t i = 0; i < n; i++)
+            if (streams[i].src_off + streams[i].src_len + 64 > src_bytes) { tail_ix.push_back(i); tail_bytes += ((size_t)streams[i].src_len + 64 + 63) & ~(size_t)63; }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     // (kernel A keeps its hash table in LDS: no per-stream tables in HBM, nothing that bounds the streams of a launch but the grid:
@@ -734,9 +750,11 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int) + 256);   // (+ slack: the look-ahead of the fused parse kernel reads a link of an empty last stream)
     if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
-    if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64);      // one 32-bit entry per position (alz_encode.hip: mentry)
+    if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64, any_match);   // one 32-bit entry per position (alz_encode.hip: mentry); not when every launch searches inside its parse + emit kernel
     if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
+    void* d_tail = nullptr;
+    if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, !tail_ix.empty());
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
     tm.mark("validate + allocate");
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
@@ -747,7 +765,18 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
                               [&](uint32_t i) { return !fastlz_level2(st, streams[i].src_len); });
     if ((rc = upload(d_src_base, d_dst_base))) return rc;
     tm.mark("upload");
-    HIP_TRY(hipMemcpyAsync(d_streams, streams, (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
+    std::vector<alz_stream> moved;                               // (stays alive until the synchronise below: the copy is asynchronous)
+    if (!tail_ix.empty()) {
+        moved.assign(streams, streams + n);
+        size_t off = 0;
+        for (uint32_t i : tail_ix) {
+            uint8_t* to = (uint8_t*)d_tail + off;
+            if (streams[i].src_len) HIP_TRY(hipMemcpyAsync(to, (const uint8_t*)d_src_base + streams[i].src_off, streams[i].src_len, hipMemcpyDeviceToDevice, c->stream));
+            moved[i].src_off = (uint64_t)(uintptr_t)to - (uint64_t)(uintptr_t)d_src_base;
+            off += ((size_t)streams[i].src_len + 64 + 63) & ~(size_t)63;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_streams, moved.empty() ? streams : moved.data(), (size_t)n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_index, index.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_pos, pos_off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
@@ -800,7 +829,7 @@ int alz_encode_batch_device(alz_ctx* c, const alz_lz_properties* props, const al
     if (!c || (n && (!streams || !results || !d_src_base || !d_dst_base))) return fail(ALZ_E_INVALID, "alz_encode_batch_device: bad argument");
     if (n == 0) return ALZ_OK;
     return encode_core(c, props, settings, n, src_bytes, streams, dst_bytes, results, aux,
-                       [&](const void*& ds, void*& dd) { ds = d_src_base; dd = d_dst_base; return (int)ALZ_OK; });
+                       [&](const void*& ds, void*& dd) { ds = d_src_base; dd = d_dst_base; return (int)ALZ_OK; }, false);
 }
 
 // ---------------------------------------------------------------- multi-GPU: one batch over several contexts

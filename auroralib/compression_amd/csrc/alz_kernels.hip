@@ -27,7 +27,10 @@
 #endif
 
 template <bool FB>
-__device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status, u32 hist = 0) {
+__device__ __forceinline__ void write_result(alz_result* r, int lane, const OutWin<FB>& out, u32 src_used, int status, u32 src_len, u32 hist = 0) {
+    // src_used = source.Position after the call.  INPUT_TRUNCATED: the reader ran into the end of the input -- Position is there (where
+    // exactly a multi-byte read gave up is not something a caller can use; include/auroralz.h fixes it as src_len)
+    if (status == ALZ_ST_INPUT_TRUNCATED) src_used = src_len;
     if (lane == 0) { r->dst_len = out.produced - hist; r->src_used = src_used; r->status = status; r->reserved = 0; }
 #if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
     // experiment build: (steps, passes, chunks, dependent chunks) of the byte phase, 4 x 8 bits of per-step averages x 16
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(64) void alz_decode_serial_kernel(const u8* __restr
     out.finish();
     int status = resolve_status(s, has_size, out.produced, size, cap);
     if (FMT == ALZ_FMT_BLZ && status == ALZ_ST_OK && out.produced != size) status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // the span must be full  BLZ.cs:131
-    write_result(&results[sid], lane, out, used_set ? used : s.p, status, hist);
+    write_result(&results[sid], lane, out, used_set ? used : s.p, status, src_len, hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     out.finish();
     int status = resolve_status(s, true, out.produced, size, cap);
     if (FMT == ALZ_FMT_BLZ && status == ALZ_ST_OK && out.produced != size) status = ALZ_ST_OUTPUT_SIZE_MISMATCH;   // the span must be full  BLZ.cs:131
-    write_result(&results[sid], lane, out, used_set ? used : s.p, status);
+    write_result(&results[sid], lane, out, used_set ? used : s.p, status, src_len);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
     sk.flush();                                    // tokens parsed before an error/terminator are part of the output
     out.finish();
     constexpr bool SIZED = CNX || FMT == ALZ_FMT_REFPACK || FMT == ALZ_FMT_HIG;       // (RefPack: only more output than declared is an error, checked at the end token)
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, SIZED, out.produced, SIZED ? uni(st.decom_len) : 0u, cap), hist);
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, SIZED, out.produced, SIZED ? uni(st.decom_len) : 0u, cap), src_len, hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restr
         else dec_yaz0_serial(in, sk, s, src_len, size);
     }
     out.finish();
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, true, out.produced, size, cap));
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, true, out.produced, size, cap), src_len);
 }
 
 // The same for the three-cursor formats (Yay0 / MIO0): the walker owns three small input caches (flags, tokens, literals) and hands over
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(128) void alz_decode_fast2c_kernel(const u8* __rest
         used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up);
     }
     out.finish();
-    write_result(&results[sid], lane, out, bad ? s.p : used, resolve_status(s, true, out.produced, size, cap));
+    write_result(&results[sid], lane, out, bad ? s.p : used, resolve_status(s, true, out.produced, size, cap), src_len);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
     }
     sk.flush();
     out.finish();
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), 0u);
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), src_len, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -860,7 +863,7 @@ void alz_decode_queue2_kernel(const u8* __restrict__ src_base, u8* __restrict__ 
     }
     sk.flush();
     out.finish();
-    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), hist);
+    write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), src_len, hist);
 }
 
 // ------------------------------------------------------------------------------------------------

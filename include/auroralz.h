@@ -150,7 +150,10 @@ typedef struct alz_stream {
 typedef struct alz_result {
     uint32_t dst_len;    /* bytes written at dst_off (<= dst_cap) */
     uint32_t src_used;   /* source bytes consumed; the reference leaves source.Position there
-                            (Yay0.cs:89-90, MIO0.cs:92-93, LZSS.cs:68).  Defined when status is OK or SIZE_MISMATCH. */
+                            (Yay0.cs:89-90, MIO0.cs:92-93, LZSS.cs:68).  OK / OUTPUT_SIZE_MISMATCH / BAD_TOKEN: just behind the
+                            last token read.  INPUT_TRUNCATED: src_len (the reader ran into the end of the input).
+                            OUTPUT_CAPACITY: unspecified (the managed code throws from inside LzWindows' write to the
+                            caller's fixed-size stream; nothing reads Position after that). */
     int32_t  status;     /* alz_status */
     uint32_t reserved;
 } alz_result;
@@ -185,8 +188,10 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
  * library chooses by the size of the batch; 1 / 2: always the one- / two-wavefront shape where both exist.  Results are
  * identical; a tuning and verification hook (the library reads no environment variable for kernel selection). */
 int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
-/* The host-buffer entry points keep their device staging buffers and the encoder's scratch (head tables, links, matches: ~18
- * bytes per input byte + the head tables of the streams in flight) in the context and only ever grow them, so that a caller
+/* The host-buffer entry points keep their device staging buffers and the encoder's scratch (per input byte: a 16- or 32-bit link,
+ * a 32-bit match entry -- not at quality 0 for the flag-byte formats, whose search runs inside the emit kernel --, two bytes of
+ * section buffers for Yay0 / MIO0 / SMSR00, one bit of start mask; the finder's head tables live in LDS) in the context and only
+ * ever grow them, so that a caller
  * working through batch after batch does not pay a device allocation per call.  This returns all of it to the device (the
  * managed side has no counterpart: ArrayPool<int>.Shared keeps LzChainMatchFinder's tables the same way,
  * MatchFinder/LzChainMatchFinder.cs:85-104, :323-334). */
@@ -227,7 +232,10 @@ int alz_decode(alz_ctx* ctx, uint32_t format, const alz_lz_properties* props,
                uint8_t* dst, uint32_t dst_cap, alz_result* result);
 
 /* -------------------------------------------- decode: device-resident batches
- * The measured path: payload already in HBM, output left in HBM.
+ * The measured path: payload already in HBM, output left in HBM.  The kernels never WRITE outside a stream's
+ * [dst_off, dst_off + dst_len) (tests/test_gpu_canary.py); they READ the input in aligned 16-byte granules and, for the 64 KiB
+ * formats, up to 24 bytes beyond a source position of the stream's own output, so both device buffers need 64 readable bytes
+ * behind the end of their last stream -- alz_device_malloc adds that slack to every allocation by itself.
  * alz_plan_create uploads the descriptor table and groups it per format (one
  * kernel launch per format present).  alz_plan_execute only enqueues kernels
  * on `hip_stream` (a hipStream_t, or NULL for the context's own stream) and
@@ -259,7 +267,9 @@ int alz_encode_batch(alz_ctx* ctx, const alz_lz_properties* props, const alz_set
 
 /* The same with the raw buffers already in HBM and the compressed streams left there: alz_stream.src_off / dst_off are
  * relative to the two DEVICE pointers.  What a caller that produces its input on the device uses, and what bench.py times
- * (kernels, no PCIe); alz_last_kernel_ms() reports the device time of the call. */
+ * (kernels, no PCIe); alz_last_kernel_ms() reports the device time of the call.  Nothing outside [d_src_base, d_src_base +
+ * src_bytes) is read and nothing outside a stream's [dst_off, dst_off + dst_cap) is written: the finder's look-ahead loads run up
+ * to 32 bytes past a stream's end, so a stream that ends inside the last 64 bytes of the source buffer is searched in a scratch copy. */
 int alz_encode_batch_device(alz_ctx* ctx, const alz_lz_properties* props, const alz_settings* settings, uint32_t n,
                             const void* d_src_base, size_t src_bytes,
                             const alz_stream* streams,

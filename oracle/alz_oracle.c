@@ -1070,7 +1070,7 @@ static void decode_one(const alz_lz_properties* props, const alz_stream* s, cons
     r->dst_len = (uint32_t)produced;
     r->src_used = used_set ? used : c.pos;
     r->reserved = 0;
-    if (c.eof) r->status = ALZ_ST_INPUT_TRUNCATED;
+    if (c.eof) { r->status = ALZ_ST_INPUT_TRUNCATED; r->src_used = s->src_len; }   /* the reader ran into the end of the input: Position is there (auroralz.h) */
     else if (info.bad_token) r->status = ALZ_ST_BAD_TOKEN;
     else if (w.overflow)
         r->status = (info.has_size && w.attempted_end > size && w.cap >= size) ? ALZ_ST_OUTPUT_SIZE_MISMATCH : ALZ_ST_OUTPUT_CAPACITY;

@@ -38,3 +38,72 @@ def handcrafted_items():
         items.append(dict(fmt=f, src=b"", decom_len=0, cap=0))
         items.append(dict(fmt=f, src=b"", decom_len=10, cap=10))
     return items
+
+
+# ---- builders of the malformed / ragged batches (shared by the host-buffer parity tests of test_gpu_decode.py and the
+# device-resident canary tests of test_gpu_canary.py; they need the oracle's encoder, so they import it lazily)
+def truncated_items(fmt, bmp):
+    """EndOfStreamException paths: every prefix length class of a valid stream."""
+    import oracle_lib as O
+    raw = bmp[1000:1000 + 3000]
+    comp, aux = O.encode_stream(fmt, raw, quality=8)
+    cuts = sorted(set([0, 1, 2, 3, 4, 5, 8, 9, 17, len(comp) // 3, len(comp) // 2, len(comp) - 3, len(comp) - 2, len(comp) - 1]))
+    return [dict(fmt=fmt, src=comp[:c], decom_len=len(raw), cap=len(raw), aux0=aux.aux0, aux1=aux.aux1) for c in cuts if c >= 0]
+
+
+def capacity_items(fmt, bmp):
+    """E4/E5: declared size smaller than the stream decodes to (overshoot), destination smaller than the output."""
+    import oracle_lib as O
+    raw = bmp[2000:2000 + 20000]
+    comp, aux = O.encode_stream(fmt, raw, quality=8)
+    items = []
+    for decl, cap in [(20000, 20000), (19990, 19990), (19990, 20010), (10000, 10000), (10000, 10001), (20000, 5000), (20000, 0),
+                      (1, 1), (0, 0), (20000, 19999), (25000, 25000)]:
+        items.append(dict(fmt=fmt, src=comp, decom_len=decl, cap=cap, aux0=aux.aux0, aux1=aux.aux1))
+    return items
+
+
+def fuzz_items(fmt, bmp, seed=1234, count=96):
+    """Malformed input: random bytes, valid streams with bit flips / splices, wrong declared sizes."""
+    import random
+    import oracle_lib as O
+    rng = random.Random(seed + fmt)
+    items = []
+    raw = bmp[7000:7000 + 30000]
+    comp, aux = O.encode_stream(fmt, raw, quality=4)
+    for k in range(count):
+        kind = k % 4
+        if kind == 0:                                     # pure noise, lengths around every threshold of the bulk parsers
+            n = rng.choice([0, 1, 2, 7, 63, 64, 129, 1000, 1099, 1100, 1101, 1500, 4000, 9000])
+            src = bytes(rng.randrange(256) for _ in range(n))
+        elif kind == 1:                                   # bit flips in a valid stream
+            b = bytearray(comp)
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            src = bytes(b)
+        elif kind == 2:                                   # noise spliced into a valid stream
+            cut = rng.randrange(len(comp))
+            src = comp[:cut] + bytes(rng.randrange(256) for _ in range(rng.randrange(1, 3000))) + comp[cut:]
+        else:                                             # biased noise (many zeros / 0xFF: long runs, terminators, extensions)
+            n = rng.randrange(1100, 6000)
+            src = bytes(rng.choice([0, 0, 0xFF, 0x0F, 0xF0, rng.randrange(256)]) for _ in range(n))
+        decl = rng.choice([len(raw), len(raw), 100, 70000, 0])
+        cap = rng.choice([decl, decl + 300, max(decl, 1) // 2, 70000])
+        three = fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_SMSR00)   # aux = section offsets there (LZ4: aux0 would be frame history)
+        items.append(dict(fmt=fmt, src=src, decom_len=decl, cap=cap, aux0=aux.aux0 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0),
+                          aux1=aux.aux1 if kind in (1, 2) else (rng.randrange(0, 3000) if three else 0)))
+    return items
+
+
+def unaligned_items():
+    """src/dst offsets at every residue mod 16: the 16 B granule logic of InCache/OutWin."""
+    import oracle_lib as O
+    from auroralib.compression_amd import synth
+    items = []
+    b = synth.make_batch(A.FMT_YAZ0, 16, 5000, synth.seed_for(77))
+    recs = synth.stream_records(b.streams)
+    for i in range(16):
+        s = bytes(b.src[int(recs["src_off"][i]):int(recs["src_off"][i]) + int(recs["src_len"][i])])
+        items.append(dict(fmt=A.FMT_YAZ0, src=s, decom_len=5000, src_misalign=1, dst_misalign=1))
+        items.append(dict(fmt=A.FMT_LZ4_BLOCK, src=O.encode_stream(A.FMT_LZ4_BLOCK, s + s, quality=4)[0], decom_len=0, cap=len(s) * 2, src_misalign=3, dst_misalign=5))
+    return items
