@@ -15,6 +15,11 @@ def _vp(a):
     return a
 
 
+def device_count():
+    """alz_device_count: HIP devices visible to this process (0 without a GPU)."""
+    return int(load().alz_device_count())
+
+
 class Context:
     """alz_ctx: one HIP device + one HIP stream."""
 

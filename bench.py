@@ -10,7 +10,8 @@ figure with two batches in flight (the tail of one launch overlapping the head o
 
 On one GPU the same JSON line also carries (rank 0, skipped with --configs none):
   configs       BASELINE.json configs[1..4] at their stated sizes (cfg2 Yaz0 10 000 x 64 KiB, cfg3 LZ4 100 000 x 256 KiB, one
-                GPU's shard of cfg4 = 5 000 mixed LZ10/LZ11/Yaz0/PRS streams, cfg5 LZSS compression at Q0 and Q8) and the
+                GPU's shard of cfg4 = 5 000 mixed LZ10/LZ11/Yaz0/PRS streams, cfg5 compression as LZSS at Q0 / Q8 / Q15 and as
+                Yaz0 / LZ4 at Q0 / Q8), every other decode body of north_star on the headline's shape (body_<format>), and the
                 "realistic" data set of SURVEY.md 8d (the 256 KiB windows of the reference's Test.bmp, GPU-encoded), each
                 with its own roofline object from HIP events on the launch stream
   copy_bandwidth  a measured device-to-device copy (second roofline denominator)
@@ -39,6 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MIXED = ["lz10", "lz11", "yaz0", "prs_be"]
+BODIES = ["lzss", "lz10", "lz11", "yay0", "mio0", "prs_be", "lz4_block", "lzo", "snappy_raw"]   # (yaz0 is the headline itself)
 
 
 def measured_traffic(fmt, n, kib):
@@ -89,16 +91,40 @@ def spawn_ranks(args):
     sys.exit(p.returncode if p.returncode else (0 if lines else 4))
 
 
+def gather_rank_identities(ctx, torch, dist, rank, local_rank, world):
+    """Which GPU every rank ran on (device name, PCI bus id, uuid where the runtime reports one): a multi-GPU record must show N
+    DISTINCT devices.  Gathered on every rank (collective), reported by rank 0."""
+    me = {"rank": rank, "local_rank": local_rank, "device": ctx.info()["name"], "pid": os.getpid()}
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+            if hasattr(p, k):
+                me[k] = int(getattr(p, k))
+        if hasattr(p, "uuid"):
+            me["uuid"] = str(p.uuid)
+    except Exception as e:
+        me["props_error"] = repr(e)
+    if dist is None:
+        return [me]
+    allr = [None] * world
+    dist.all_gather_object(allr, me)
+    return allr
+
+
 def fmt_array(np, A, name, n, first=0):
     if name == "mixed":   # BASELINE.json configs[3]: LZ10/LZ11/Yaz0/PRS interleaved, per-format kernel dispatch
         return np.array([A.FORMAT_NAMES.index(MIXED[(first + i) % 4]) for i in range(n)], dtype=np.uint32)
     return np.full(n, A.FORMAT_NAMES.index(name), dtype=np.uint32)
 
 
+TRAFFIC_SOURCE = "profiles/traffic.json (rocprofv3 --pmc passes of this exact workload, FETCH_SIZE x2 + WRITE_SIZE per launch, committed; not re-measured in this run)"
+
+
 def roofline(algo_bytes, kernel_ms, traffic=None):
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
+            "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
+            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
 
 
 class DeviceBatch:
@@ -117,22 +143,23 @@ class DeviceBatch:
 
 
 def run_steps(db, steps, warmup, sync):
+    """W untimed launches, then EXACTLY K launches back to back on the context's stream between two `sync()`s.  Returns (wall seconds
+    of the K steps, mean device milliseconds per step): the HIP events that give the second are recorded on the launch stream right
+    around the same K launches (alz_plan_execute_timed), inside the wall-clock window -- one loop, two clocks."""
     for _ in range(warmup):
         db.plan.execute(db.d_src, db.d_dst)
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        db.plan.execute(db.d_src, db.d_dst)
+    kernel_ms = db.plan.execute_timed(db.d_src, db.d_dst, iters=steps)
     sync()
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, kernel_ms
 
 
 def decode_config(name, workload, ctx, batch, Plan, synth, np, steps, fmt_name, n, kib):
     """One named decode configuration on rank 0: K steps back to back + HIP-event kernel time + status / length check."""
     db = DeviceBatch(ctx, batch, Plan)
     try:
-        dt = run_steps(db, steps, 2, ctx.synchronize)
-        kernel_ms = db.plan.execute_timed(db.d_src, db.d_dst, iters=max(3, min(steps, 10)))
+        dt, kernel_ms = run_steps(db, steps, 2, ctx.synchronize)
         res = synth.result_records(db.plan.results())
         recs = synth.stream_records(batch.streams)
         ok = bool((res["status"] == 0).all() and (res["dst_len"] == recs["decom_len"]).all())
@@ -208,6 +235,7 @@ def main():
     ctx = Context(local_rank)
     if args.kernel_variant:
         ctx.set_kernel_variant(args.kernel_variant)
+    ranks = gather_rank_identities(ctx, torch, dist, rank, local_rank, world)
     main_db = DeviceBatch(ctx, batch, Plan)
 
     def barrier():
@@ -217,7 +245,8 @@ def main():
         ctx.synchronize()
 
     # ---- the timed region: EXACTLY K steps between barriers, one batch in flight
-    dt = reduce_step_time(run_steps(main_db, args.steps, args.warmup, barrier), dist, device=red_dev)
+    dt_local, kernel_ms = run_steps(main_db, args.steps, args.warmup, barrier)
+    dt = reduce_step_time(dt_local, dist, device=red_dev)
 
     # ---- secondary: the same steps with two batches in flight (two HIP streams, two plans, two output buffers)
     pipelined = None
@@ -246,8 +275,7 @@ def main():
         pipelined = {"value": round(total2 / dt2 / 2**30, 3), "unit": "GiB/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                      "batches_in_flight": args.inflight, "note": "caller-side overlap of consecutive batches on %d HIP streams / contexts" % args.inflight}
 
-    # dominant kernel, HIP events on the launch stream (device time per launch)
-    kernel_ms = main_db.plan.execute_timed(main_db.d_src, main_db.d_dst, iters=max(3, min(args.steps, 10)))
+    # (kernel_ms: the dominant kernel's device time per launch, HIP events on the launch stream around the K timed steps themselves)
 
     # what was just measured decoded completely: every status OK, every length right (GPU results only)
     res = synth.result_records(main_db.plan.results())
@@ -304,6 +332,7 @@ def main():
                        "pipelined": pipelined, "parity_ok": ok, "verified_vs_oracle": verified},
             "roofline": roofline(comp_bytes + decomp_bytes, kernel_ms, measured_traffic(args.format, n, args.stream_kib)),
             "cpu_baseline": cpu,
+            "ranks": ranks,
         }
         out.update(extras)
         if configs is not None:
@@ -334,6 +363,7 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
         b = synth.make_batch(A.FMT_LZSS, n, target, shard_seed(5, rank, n))
         parallelism = "buffer-sharded x%d, every rank its own batch, no collective" % world
     ctx = Context(local_rank)
+    ranks = gather_rank_identities(ctx, torch, dist, rank, local_rank, world)
     raw_db = DeviceBatch(ctx, b, Plan)                        # the raw buffers: decoded on the device, never leave it
     raw_db.plan.execute(raw_db.d_src, raw_db.d_dst); ctx.synchronize()
     rres = synth.result_records(raw_db.plan.results())
@@ -419,6 +449,7 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
                        "parity_ok": ok, "verified_roundtrip_and_vs_oracle": verified},
             "roofline": roofline(raw_bytes + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (args.format, args.quality), n, args.stream_kib)),
             "cpu_baseline": cpu,
+            "ranks": ranks,
         }
         print(json.dumps(out))
     ctx.free(d_out); raw_db.close(); ctx.close()
@@ -548,7 +579,7 @@ def run_extras(ctx, batch, recs, n, target, decomp_bytes, np, synth, A):
 
 
 def run_configs(args, ctx, np, A, synth, Plan, Context):
-    want = ["cfg2", "cfg3", "cfg4", "cfg5", "realistic"] if args.configs == "all" else args.configs.split(",")
+    want = ["cfg2", "cfg3", "cfg4", "cfg5", "bodies", "realistic"] if args.configs == "all" else args.configs.split(",")
     out = []
     steps = max(3, min(args.steps, 10))
     try:
@@ -562,7 +593,16 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             out.append(decode_config("cfg4_shard", "BASELINE configs[3], one GPU's shard: 5 000 of the 40 000 mixed LZ10/LZ11/Yaz0/PRS streams x 256 KiB, "
                                      "per-format kernels forked onto side streams", ctx, b, Plan, synth, np, steps, "mixed", 5000, 256))
         if "cfg5" in want:
-            out.extend(cfg5(ctx, np, A, synth))
+            out.extend(cfg5(ctx, np, A, synth, Plan))
+        if "bodies" in want:
+            # every other decode body north_star names, on the metric's own shape (10 000 x 256 KiB synthetic streams, one GPU): the
+            # per-format table of DESIGN.md 4.4 in the driver-run line
+            bsteps = max(3, min(args.steps, 5))
+            for f in BODIES:
+                b = synth.make_batch(A.FORMAT_NAMES.index(f), 10000, 262144, synth.seed_for(2))
+                out.append(decode_config("body_" + f, "%s decode, 10 000 x 256 KiB synthetic streams, 1 GPU (the headline's shape, another body)" % f,
+                                         ctx, b, Plan, synth, np, bsteps, f, 10000, 256))
+                del b
         if "realistic" in want:
             # the reference benchmarks every algorithm on Test.bmp (Benchmarks/Benchmarks/TestAllAlgorithms.cs:26-69): the same data
             # per north-star format, as 256 KiB windows
@@ -605,11 +645,9 @@ def cfg3(ctx, np, A, synth, Plan):
         steps = 3
         plan.execute(d_src, d_dst); ctx.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            plan.execute(d_src, d_dst)
+        kernel_ms = plan.execute_timed(d_src, d_dst, iters=steps)
         ctx.synchronize()
         dt = time.perf_counter() - t0
-        kernel_ms = plan.execute_timed(d_src, d_dst, iters=3)
         res = synth.result_records(plan.results())
         ok = bool((res["status"] == 0).all() and (res["dst_len"] == target).all())
         comp = int(rec["src_len"].astype(np.int64).sum())
@@ -620,40 +658,71 @@ def cfg3(ctx, np, A, synth, Plan):
         plan.close(); ctx.free(d_src); ctx.free(d_dst)
 
 
-def cfg5(ctx, np, A, synth):
-    """BASELINE configs[4] on one GPU: LZSS(12,4,2) compression of 10 000 x 256 KiB raw buffers (decoded synthetic LZSS
-    streams, so they are compressible) at Q0, Q8 and Q15 through alz_encode_batch; the kernel time (hash-table resets + the four
-    encode kernels) comes from HIP events inside the call, the host figure includes upload, download and the pack kernel."""
+def cfg5(ctx, np, A, synth, Plan):
+    """BASELINE configs[4] on one GPU: compression of 10 000 x 256 KiB raw buffers (decoded synthetic LZSS streams, so they are
+    compressible; produced on the device and kept there) through alz_encode_batch_device -- LZSS(12,4,2), the configuration's own
+    format, at Q0 / Q8 / Q15 (the levels the reference publishes and its default), and Yaz0 and LZ4 blocks at Q0 / Q8.  The kernel time
+    (every encode kernel of the call) comes from HIP events inside the call; what was written is decoded back on the device and the
+    first 256 buffers are compared byte for byte with the input."""
     n, size = 10000, 262144
     b = synth.make_batch(A.FMT_LZSS, n, size, synth.seed_for(5))
-    raw, res = ctx.decode_batch(b.streams, b.src, b.dst_bytes)
-    recs = synth.stream_records(b.streams)
-    cap = size + size // 4 + 64
-    streams = (A.Stream * n)()
-    r2 = synth.stream_records(streams)
-    r2["src_off"], r2["src_len"] = recs["dst_off"], size
-    r2["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64((cap + 255) // 256 * 256)
-    r2["dst_cap"], r2["format"] = cap, A.FMT_LZSS
-    dst_bytes = int(r2["dst_off"][-1]) + cap + 64
+    raw_db = DeviceBatch(ctx, b, Plan)
     out = []
-    for q in (0, 8, 15):                                      # (0 / 15: the levels the reference publishes; 8: its default)
-        ctx.encode_batch(streams, raw, dst_bytes, quality=q)       # (first call at a quality: the context grows its device scratch -- head tables, links)
-        t0 = time.perf_counter()
-        dst, eres, aux = ctx.encode_batch(streams, raw, dst_bytes, quality=q)
-        host_s = time.perf_counter() - t0
-        kernel_ms = ctx.last_kernel_ms()
-        er = synth.result_records(eres)
-        comp = int(er["dst_len"].astype(np.int64).sum())
-        # round trip on the GPU: what was written decodes back to the input
-        s3 = (A.Stream * n)()
-        r3 = synth.stream_records(s3)
-        r3["src_off"], r3["src_len"], r3["dst_off"], r3["dst_cap"], r3["decom_len"], r3["format"] = r2["dst_off"], er["dst_len"], recs["dst_off"], size, size, A.FMT_LZSS
-        back, dres = ctx.decode_batch(s3, dst, b.dst_bytes)
-        ok = bool((er["status"] == 0).all() and np.array_equal(back[:b.dst_bytes], raw[:b.dst_bytes]))
-        out.append({"name": "cfg5_q%d" % q, "workload": "BASELINE configs[4]: LZSS(12,4,2) compression, parallel hash-chain match-find + emit, 10 000 x 256 KiB, quality %d, 1 GPU" % q,
-                    "value": round(n * size / (kernel_ms * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(kernel_ms, 3),
-                    "host_api_GiB_s": round(n * size / host_s / 2**30, 3), "ratio": round(comp / (n * size), 4), "parity_ok": ok,
-                    "roofline": roofline(n * size + comp, kernel_ms, measured_traffic("lzss_encode_q%d" % q, n, size // 1024))})
+    d_out = d_back = None
+    try:
+        raw_db.plan.execute(raw_db.d_src, raw_db.d_dst); ctx.synchronize()
+        recs = synth.stream_records(b.streams)
+        cap = size + size // 4 + 64
+        capal = (cap + 255) // 256 * 256
+        dst_bytes = n * capal + 64
+        d_out = ctx.malloc(dst_bytes)
+        d_back = ctx.malloc(b.dst_bytes + 64)
+        k = 256
+        span = int(recs["dst_off"][k - 1]) + size
+        g_raw = ctx.d2h(raw_db.d_dst, span)
+        for fname, q in (("lzss", 0), ("lzss", 8), ("lzss", 15), ("yaz0", 0), ("yaz0", 8), ("lz4_block", 0), ("lz4_block", 8)):
+            fmt = A.FORMAT_NAMES.index(fname)
+            streams = (A.Stream * n)()
+            r2 = synth.stream_records(streams)
+            r2["src_off"], r2["src_len"] = recs["dst_off"], size
+            r2["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64(capal)
+            r2["dst_cap"], r2["format"] = cap, fmt
+            ctx.encode_batch_device(streams, raw_db.d_dst, b.dst_bytes, d_out, dst_bytes, quality=q)   # (first call at a quality: the context grows its device scratch)
+            t0 = time.perf_counter()
+            eres, aux = ctx.encode_batch_device(streams, raw_db.d_dst, b.dst_bytes, d_out, dst_bytes, quality=q)
+            call_s = time.perf_counter() - t0
+            kernel_ms = ctx.last_kernel_ms()
+            er = synth.result_records(eres)
+            comp = int(er["dst_len"].astype(np.int64).sum())
+            # round trip on the GPU: what was written decodes back to the input
+            s3 = (A.Stream * n)()
+            r3 = synth.stream_records(s3)
+            r3["src_off"], r3["src_len"], r3["dst_off"], r3["dst_cap"], r3["decom_len"], r3["format"] = r2["dst_off"], er["dst_len"], recs["dst_off"], size, size, fmt
+            ctx.memset(d_back, 0, b.dst_bytes)
+            pl = Plan(ctx, s3)
+            try:
+                pl.execute(d_out, d_back); ctx.synchronize()
+                bres = synth.result_records(pl.results())
+            finally:
+                pl.close()
+            g_back = ctx.d2h(d_back, span)
+            ok = bool((er["status"] == 0).all() and (bres["status"] == 0).all() and (bres["dst_len"] == size).all())
+            for i in range(k):
+                a = int(recs["dst_off"][i])
+                ok = ok and bool(np.array_equal(g_raw[a:a + size], g_back[a:a + size]))
+            name = ("cfg5_q%d" % q) if fname == "lzss" else ("cfg5_%s_q%d" % (fname, q))
+            out.append({"name": name, "workload": "BASELINE configs[4]: %s compression, parallel hash-chain match-find + emit, 10 000 x 256 KiB, quality %d, 1 GPU, device-resident"
+                        % ("LZSS(12,4,2)" if fname == "lzss" else fname, q),
+                        "value": round(n * size / (kernel_ms * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(kernel_ms, 3),
+                        "call_ms": round(call_s * 1e3, 3), "ratio": round(comp / (n * size), 4), "parity_ok": ok,
+                        "roofline": roofline(n * size + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (fname, q), n, size // 1024))})
+    finally:
+        if d_out is not None:
+            ctx.free(d_out)
+        if d_back is not None:
+            ctx.free(d_back)
+        raw_db.close()
+        ctx.release_scratch()                                  # (the encoder's grow-only scratch: ~20 GB at Q8; the configurations behind this one start clean)
     return out
 
 
@@ -697,8 +766,7 @@ def realistic(ctx, np, A, synth, Plan, steps, fmt_name="yaz0"):
     b = B(); b.src, b.streams, b.dst_bytes = src, streams, n * size
     db = DeviceBatch(ctx, b, Plan)
     try:
-        dt = run_steps(db, steps, 2, ctx.synchronize)
-        kernel_ms = db.plan.execute_timed(db.d_src, db.d_dst, iters=steps)
+        dt, kernel_ms = run_steps(db, steps, 2, ctx.synchronize)
         res = synth.result_records(db.plan.results())
         ok = bool((res["status"] == 0).all() and (res["dst_len"] == size).all())
         g = ctx.d2h(db.d_dst, nw * size)

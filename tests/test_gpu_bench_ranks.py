@@ -1,7 +1,8 @@
 """-m gpu: the N > 1 path of bench.py as it is launched by the driver -- one process per rank under torch.distributed.run, a
 barrier on both sides of the timed region, MAX of the step time over the ranks, every rank's parity check ANDed -- started as a
-CHILD process with two ranks.  The test box has one GPU, so both ranks use device 0 and rendezvous over gloo (RCCL wants one device
-per rank); everything else is the code the 8-GPU run executes."""
+CHILD process with two ranks.  On a box with >= 2 GPUs the ranks use DISTINCT devices and rendezvous over RCCL (the driver's own
+launch); on the one-GPU test box both ranks use device 0 and rendezvous over gloo (RCCL wants one device per rank) -- everything else
+is the code the 8-GPU run executes.  The JSON line names every rank's device (`ranks`), so a scaling record proves N distinct GPUs."""
 import json
 import os
 import subprocess
@@ -13,8 +14,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _ndev():
+    # (torch's count does not initialise the GPU on this image; alz_device_count() would, and a process that has touched the GPU must
+    # not fork + exec the ranks -- this file sorts first among the -m gpu tests, so the pytest process is still clean here)
+    import torch
+    return torch.cuda.device_count()
+
+
 def _bench(*extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--all-ranks-on-device", "0", "--steps", "2",
+    shared = ["--dist-backend", "gloo", "--all-ranks-on-device", "0"] if _ndev() < 2 else []       # >= 2 GPUs: one device per rank, RCCL
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + shared + ["--steps", "2",
            "--warmup", "1", "--configs", "none", "--no-extras", "--no-cpu-baseline", "--inflight", "1"] + list(extra)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
@@ -29,6 +38,12 @@ def test_two_ranks_weak_scaling_every_rank_its_own_batch():
     assert d["config"]["parity_ok"] is True and d["config"]["verified_vs_oracle"] is True
     assert d["config"]["streams_this_rank"] == 512 and d["config"]["streams_whole_job"] == 1024
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001            # both clocks around the same K launches
+    # every rank reports the device it ran on
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all("gfx950" in r["device"] for r in d["ranks"])
+    if _ndev() >= 2:
+        assert len({(r.get("pci_domain_id"), r.get("pci_bus_id"), r.get("pci_device_id"), r.get("uuid")) for r in d["ranks"]}) == 2, d["ranks"]
+        assert [r["local_rank"] for r in d["ranks"]] == [0, 1]
 
 
 def test_two_ranks_strong_scaling_one_mixed_batch_partitioned_by_the_library():
