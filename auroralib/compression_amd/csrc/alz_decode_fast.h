@@ -56,23 +56,7 @@ __device__ __forceinline__ u32 wave_writelane(u32 old, u32 val, u32 lane) {
 
 struct FastGeom {           // LZSS geometry (other formats ignore it)
     u32 length_bits, min_length, windows_start, max_distance, W;
-    const u16* wtab;        // the two-tokens-per-step table of the group walk (walk_table_init), or nullptr
 };
-
-// The speculative group walk of the formats whose only odd token is the 3-byte match (Yaz0, LZ02) two tokens at a time: what two
-// tokens occupy follows from their two flag bits and from four "a 3-byte match would start here" bits behind the walk's cursor
-// (the second token starts 1, 2 or 3 bytes behind the first) -- 64 combinations, one 16-bit entry each: [2:0] bytes of both
-// tokens, [9:8] / [13:12] (size - 1) of the first / second as the nibbles the token lanes sum.  Distinct entries lie in distinct
-// banks (64 entries, 128 bytes), equal keys broadcast.
-#ifndef ALZ_WALK_TABLE
-#define ALZ_WALK_TABLE 0   /* measured in round 3: 3.35 ms against 3.24 for Yaz0 (10 000 x 256 KiB) -- eight dependent LDS reads per iteration cost more than the 54 vector instructions they save; see DESIGN.md 8 */
-#endif
-__device__ __forceinline__ void walk_table_init(u16* tab, int lane) {
-    const u32 m1 = ((u32)lane >> 5) & 1u, m2 = ((u32)lane >> 4) & 1u, z = (u32)lane & 15u;
-    const u32 e1 = m1 + (m1 & z), s1 = 1u + e1;                    // z bit 0: the byte under the cursor
-    const u32 e2 = m2 + (m2 & (z >> s1));
-    tab[lane] = (u16)((s1 + 1u + e2) | (e1 << 8) | (e2 << 12));
-}
 
 template <int FMT> struct FamTraits;
 // MSB: flag bits MSB first; LIT1: flag bit 1 = literal; H3 / H4: a match whose size nibble is 0 / 1 has 3 / 4 bytes; NIBLO: that
@@ -119,17 +103,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     auto spec = [&](u32 xb, u32 w3, u32 w4, u32& gsize, u32& info) {
         const u32 mbits = TR::NEG ? ((0u - xb) & 0xFFu) : (TR::LIT1 ? (~xb & 0xFFu) : xb);   // bit set = match token
         if (!WALK) { gsize = 9u + (u32)__popc(mbits); info = mbits; }
-        else if (ALZ_WALK_TABLE && TR::H3 && !TR::H4 && TR::MSB && gm.wtab) {
-            u32 r = 1; info = 0;
-#pragma unroll
-            for (int k2 = 0; k2 < 4; k2++) {
-                const u32 key = (((mbits >> (6 - 2 * k2)) & 3u) << 4) | ((w3 >> r) & 15u);
-                const u32 e = gm.wtab[key];
-                info |= (e >> 8) << (8 * k2);
-                r += e & 7u;
-            }
-            gsize = r;
-        } else {
+        else {
             u32 r = 1; info = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -643,13 +617,6 @@ __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState&
         u32 qt2 = 0, nt2 = 0, total2 = 0, adv2 = 0;
         const u32 p = s.p;
         const bool ahead = (u64)p + in.ch + 76u <= src_len && !(p + in.lo + in.ch > in.cb + 2u * in.ch);   // next round: input ahead, cache already covers it
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_QEXP) && ALZ_QEXP == 3
-        out.produced += total; (void)len; (void)desc; (void)last;                       // timing experiment: parse only
-        if (ahead) { more = parse(p, qt2, nt2, total2, adv2); if (more && total2 > maxout - out.produced) more = false; }
-        if (!more) break;
-        qt = qt2; nt = nt2; total = total2; adv = adv2;
-        continue;
-#endif
         {   // (round 1 parsed round k + 1 between the issue and the use of round k's HBM read-backs; the chunked phase reads a far
             // source as one 20-byte load per chunk right where it needs it, and keeping a round's token state alive across the
             // parse cost more registers -- a wave per SIMD -- than the overlap gained)
@@ -1480,9 +1447,6 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
     sk.qtok = qt; sk.nt = nt; sk.qbytes = total;
     s.p = p + pos; fl_io = fl;
     if (term) s.done = true;                                   // PRS.cs:78-79: the zero word ends the stream
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_QEXP) && ALZ_QEXP == 2
-    sk.out.produced += total; sk.nt = 0; sk.qbytes = 0; if (qt == 0x12345u) stage[lane] = qt;   // timing experiment: parse only
-#else
     {   // executed in line (the out-of-line queue_emit_call stays with the exact parser's token sites): a round is only ~30
         // tokens, the call's argument traffic was a tenth of it
         sk.nt = 0; sk.qbytes = 0;
@@ -1491,6 +1455,5 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
         u32 last;
         (void)fast_emit<typename SK::OWT, typename SK::CFGT>(sk.out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, sk.segmark, sk.inlds, lane, last, sk.W);
     }
-#endif
     return true;
 }

@@ -170,10 +170,7 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
 // ---------------------------------------------------------------------------------------------------------------
 // The back end a configuration uses: the chunked phase where sources come back from HBM (the 64 KiB formats: one 20-byte
 // read per chunk instead of one byte per lane), the byte phase where the whole window lives in LDS.
-#ifndef ALZ_CHUNKS_ALL
-#define ALZ_CHUNKS_ALL 0     /* experiment: 1 = the chunked phase for every configuration */
-#endif
-template <class CFG> struct EmitUsesChunks { static constexpr bool value = CFG::FALLBACK || ALZ_CHUNKS_ALL; };
+template <class CFG> struct EmitUsesChunks { static constexpr bool value = CFG::FALLBACK; };
 
 template <class OW, class CFG>
 __device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch, int lane, u32& last_tend, u32 W, EmitState& e) {
@@ -216,12 +213,7 @@ __device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool v
         out.produced = e.O + e.T;
         return e.fin;
     } else {
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EXP) && ALZ_EXP == 1
-    out.produced = e.O + e.T; out.flushed = out.produced & ~1023u;       // timing experiment: front end + token prologue only (no output)
-    if (e.kept && e.clen == 0x12345u) scratch[lane] = (u8)e.desc;
-#else
     emit_finish<OW, CFG>(out, scratch, inlds, lane, e);
-#endif
     return e.fin;
     }
 }

@@ -259,9 +259,6 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
     }
     chunk_store(act, wbase + a0, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
     chunk_mirror(act, wbase, a0, LW, ALZ_JT, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
-    out.st_steps++; out.st_passes++; out.st_chunks += (u32)__popcll(wave_ballot(act)); out.st_dep += (u32)__popcll(wave_ballot(dep));
-#endif
     // ---- chunks whose source reaches into this step's own output: read again until nothing changes.  Chunks ascend with the
     // lane, so when every such source ends in front of the FIRST dependent chunk it was written by pass 1 and one more pass is
     // final -- the common case (a match right behind the token it copies): no third read to find that nothing changed.
@@ -279,9 +276,6 @@ __device__ __forceinline__ void chunk_copy(OW& out, const u8* inlds, bool act, u
         const bool wr = dep && (N0 != E0 || N1 != E1 || N2 != E2 || N3 != E3 || N4 != E4);
         if (!wave_ballot(wr)) break;
         again = !shallow;
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
-        out.st_passes++;
-#endif
         E0 = N0; E1 = N1; E2 = N2; E3 = N3; E4 = N4;
         chunk_store(wr, wbase + a0, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);
         chunk_mirror(wr, wbase, a0, LW, ALZ_JT, M0, M1, M2, M3, M4, E0, E1, E2, E3, E4);

@@ -205,11 +205,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
                 // smallest value the group got back (it lies before every position of the step), the rest follows from the lanes.
                 const int got = __hip_atomic_exchange(&T[idx], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 int prev = got;
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_CU_SLOWTEST)
-                const u64 bad = __ballot(actl && got >= __builtin_amdgcn_readfirstlane(pos));   // test build: every group goes the long way
-#else
                 const u64 bad = __ballot(actl && got > pos);
-#endif
                 if (bad) {
                     u64 mygrp = 0; int ghead = 0;
                     u64 todo = bad;

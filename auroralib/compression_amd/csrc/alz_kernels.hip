@@ -32,10 +32,6 @@ __device__ __forceinline__ void write_result(alz_result* r, int lane, const OutW
     // exactly a multi-byte read gave up is not something a caller can use; include/auroralz.h fixes it as src_len)
     if (status == ALZ_ST_INPUT_TRUNCATED) src_used = src_len;
     if (lane == 0) { r->dst_len = out.produced - hist; r->src_used = src_used; r->status = status; r->reserved = 0; }
-#if defined(ALZ_EXPERIMENTS) && defined(ALZ_EMIT_STATS)
-    // experiment build: (steps, passes, chunks, dependent chunks) of the byte phase, 4 x 8 bits of per-step averages x 16
-    if (lane == 0 && out.st_steps) r->reserved = (out.st_steps & 0xFFFFu) | ((out.st_passes * 16u / out.st_steps) << 16) | ((out.st_chunks * 2u / out.st_steps) << 24);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -166,10 +162,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #endif
     constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    constexpr u32 FSCR = (ALZ_CHUNKS_ALL || FBK) ? ALZ_EMIT_SCRATCH : 128u, FSLACK = (ALZ_CHUNKS_ALL || FBK) ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
+    constexpr u32 FSCR = FBK ? ALZ_EMIT_SCRATCH : 128u, FSLACK = FBK ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][FSCR + NC * CACHE + LWMAX + FSLACK];
-    constexpr bool WTAB = ALZ_WALK_TABLE && ALZ_WPB == 1 && (FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZ02);
-    __shared__ u16 wtab[WTAB ? 64 : 1];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
     u32 bid = blockIdx.x * ALZ_WPB + wid;
@@ -183,9 +177,8 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     u8* segmark = lds;
     u8* inc_lds = lds + FSCR;
     typedef OutWin<FBK> OWF;
-    OWF out; out.init(dst, cap, lds + FSCR + NC * CACHE, (ALZ_CHUNKS_ALL || FBK) ? (u32)LWMAX : lw, lane, FSLACK);
+    OWF out; out.init(dst, cap, lds + FSCR + NC * CACHE, FBK ? (u32)LWMAX : lw, lane, FSLACK);
     segmark[lane] = 0; segmark[64 + lane] = 0;
-    if (WTAB) walk_table_init(wtab, lane);
     InCache in; in.init(src, src_len, inc_lds, lane, CHUNK);
     DecState s; dec_state_init(s);
     u32 used = 0; bool used_set = false;
@@ -199,7 +192,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         const u32 L = size < cap ? size : cap;
         dec_blz_serial(in, sk, s, src_len, L, 4098u);
         if (!s.eof && !s.bad && !s.ovf) {
-            FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096; gm.wtab = nullptr;
+            FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
             bool to_serial = false;
             while (!to_serial && (u64)out.produced + 1152u < L && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, L, src_len, to_serial, segmark, lane, gm);
             dec_blz_serial(in, sk, s, src_len, L);
@@ -207,7 +200,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
     } else if constexpr (FMT == ALZ_FMT_LZ02) {
         // no declared size inside the loop: the stream runs to its terminator (the size is compared there); only the
         // capacity bounds the lane-parallel iterations, and an exactly full destination still has to see the terminator
-        FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096; gm.wtab = WTAB ? wtab : nullptr;
+        FastGeom gm; gm.length_bits = 4; gm.min_length = 3; gm.windows_start = 0; gm.max_distance = 4096; gm.W = 4096;
         bool to_serial = false;
         while (!s.ovf && !to_serial && out.produced < cap && s.p < src_len) (void)fast_iter_interleaved<FMT>(in, out, s, cap, src_len, to_serial, segmark, lane, gm);
         if (!s.ovf) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_lz02_serial(in, sk, s, src_len); }
@@ -216,7 +209,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
         if (!fin) { typedef DirectSink<OWF> SK; SK sk(out, s); dec_lzhudson_serial(in, sk, s, src_len, size); }
     } else if constexpr (!THREE) {
         FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
-        gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits; gm.wtab = WTAB ? wtab : nullptr;
+        gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
         bool to_serial = false;   // the fast loop runs to the last complete token of the input; the exact parser finishes
         while (!fin && !to_serial && out.produced < size && s.p < src_len) fin = fast_iter_interleaved<FMT>(in, out, s, size, src_len, to_serial, segmark, lane, gm);
         if (!fin) {
@@ -288,7 +281,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
     // per wave is four more waves per CU for the 4 KiB-window formats
     constexpr u32 QCH = (FMT == ALZ_FMT_CNX2) ? 1024u : 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u;
     constexpr bool FB = CNX ? false : (!PRS || PRSFB);
-    constexpr u32 SCR = (FB || ALZ_CHUNKS_ALL) ? ALZ_EMIT_SCRATCH : 128u, SLACK = (FB || ALZ_CHUNKS_ALL) ? ALZ_WIN_SLACK : 0u;     // (chunked byte phase: token table + ring mirror)
+    constexpr u32 SCR = FB ? ALZ_EMIT_SCRATCH : 128u, SLACK = FB ? ALZ_WIN_SLACK : 0u;     // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + SLACK];
     u32 bid = blockIdx.x;
     if (bid >= count) return;
@@ -516,12 +509,8 @@ __global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restr
     u32* mbox = reinterpret_cast<u32*>(lds + FSCR + CACHE + LWMAX + CACHE);
     FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
     gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
-    constexpr bool WTAB = ALZ_WALK_TABLE && FMT == ALZ_FMT_YAZ0;
-    __shared__ u16 wtab[WTAB ? 64 : 1];
-    gm.wtab = WTAB ? wtab : nullptr;
     if (threadIdx.x < 64u) {
         // ---- the parsing wavefront
-        if (WTAB) walk_table_init(wtab, lane);
         InCache in; in.init(src, src_len, lds + FSCR + CACHE + LWMAX, lane, CHUNK);
         DecState s; dec_state_init(s);
         WalkOut out; out.produced = 0; out.cap = cap; out.mbox = mbox; out.k = 0;
