@@ -15,6 +15,23 @@
 //   * pointer jumping only runs in steps where that test fires for some lane;
 //   * EARLY (first W bytes of a stream: sources may lie before the stream start, E2) and !FULL (last, partial step)
 //     are separate instantiations so the steady state does not pay for them.
+// Pointer jumping for the lanes whose source byte is produced inside the step itself (at most 6 rounds, one ds_bpermute per round).
+// State word: an unresolved lane holds 0x40000000 | (source lane << 2) -- which IS its ds_bpermute address: the instruction takes
+// (address / 4) mod 64 --, a resolved lane holds its value (a window byte, or a literal descriptor: bit 31 set), so "unresolved" is
+// the signed test word >= 0x40000000.  An unresolved lane simply takes over its source's word: that is either the value (resolved) or
+// the source's source (jump).  The predicate lives in a scalar register pair across the rounds: the compare that ends a round is the
+// select mask of the next -- two vector instructions per round (select, compare).
+__device__ __forceinline__ u32 pointer_jump(bool instep, u32 srclane, u32 val) {
+    u32 st = instep ? ((srclane << 2) | 0x40000000u) : val;
+    bool un = instep;
+    do {
+        const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)st, (int)st);
+        if (un) st = f;
+        un = (int)st >= 0x40000000;
+    } while (__ballot(un));
+    return st;
+}
+
 template <class OW, class CFG, bool EARLY, bool FULL>
 __device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds, int lane, u32 desc, u32& relm, u32& qs, u32& tbase4, u32 nseg) {
     const u32 omask = CFG::OMASK ? CFG::OMASK : out.lw_mask;
@@ -33,17 +50,7 @@ __device__ __forceinline__ void byte_step(OW& out, u8* segmark, const u8* inlds,
     if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
     else val = ((int)dsc < 0) ? dsc : wv;
     const bool instep = FULL ? (dsc <= (u32)lane) : (dsc <= (u32)lane && (u32)lane < nseg);   // source produced inside this very step
-    if (__ballot(instep)) {
-        // pointer jumping (at most 6 rounds), one ds_bpermute per round.  State word: resolved lanes hold their byte with
-        // bit 16 set; unresolved lanes hold (source lane) << 10, i.e. the bpermute address << 8.  An unresolved lane simply
-        // takes over its source's word: that is either the byte (resolved) or the source's source (jump).
-        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
-        do {
-            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
-            if (st < 0x10000u) st = f;
-        } while (__ballot(st < 0x10000u));
-        val = st;
-    }
+    if (__ballot(instep)) val = pointer_jump(instep, (u32)lane - dsc, val);
     if (FULL) win[qs & omask] = (u8)val;
     else if ((u32)lane < nseg) win[qs & omask] = (u8)val;
     wave_sync();
@@ -75,14 +82,7 @@ __device__ __forceinline__ void copy_step(OW& out, const u8* inlds, int lane, u3
     if (CFG::LITRUN) { const u32 lv = inlds[(qs + dsc) & 2047u]; val = ((int)dsc < 0) ? lv : wv; }
     else val = ((int)dsc < 0) ? dsc : wv;
     const bool instep = dsc <= (u32)lane && (u32)lane < nseg;
-    if (__ballot(instep)) {
-        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
-        do {
-            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
-            if (st < 0x10000u) st = f;
-        } while (__ballot(st < 0x10000u));
-        val = st;
-    }
+    if (__ballot(instep)) val = pointer_jump(instep, (u32)lane - dsc, val);
     if ((u32)lane < nseg) win[qs & omask] = (u8)val;
     wave_sync();
     qs += 64u;
@@ -112,14 +112,7 @@ __device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds
     if (CFG::LITRUN) val = ((int)dsc < 0) ? lv : wv;
     else val = ((int)dsc < 0) ? dsc : wv;
     const bool instep = dsc <= (u32)lane;
-    if (__ballot(instep)) {
-        u32 st = instep ? (((u32)lane - dsc) << 10) : (val | 0x10000u);
-        do {
-            const u32 f = (u32)__builtin_amdgcn_ds_bpermute((int)(st >> 8), (int)st);
-            if (st < 0x10000u) st = f;
-        } while (__ballot(st < 0x10000u));
-        val = st;
-    }
+    if (__ballot(instep)) val = pointer_jump(instep, (u32)lane - dsc, val);
     win[qs & omask] = (u8)val;
     wave_sync();
     qs += 64u; relm -= 64u; dsc_next = dscn;
