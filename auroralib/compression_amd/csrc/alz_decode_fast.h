@@ -133,7 +133,6 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     }
     // lane 8j+k = token k of group j
     const u32 k = (u32)lane & 7u;
-    const bool ingroup = ((u32)lane >> 3) < ng;
     u32 inf = wave_bperm(gstart & 63u, info);
     if (WIDE) { const u32 inf1 = wave_bperm(gstart & 63u, info1); inf = gstart < 64u ? inf : inf1; }
     u32 m, to;
@@ -188,19 +187,21 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     // real (token offsets grow with the lane, so they form a prefix).  The first token that does not is left to the exact
     // parser together with the flag-reader state it needs (E6, and Yay0.cs:130-131's length-byte-at-EOF rule).
     const u32 inlim = src_len - p;
-    bool valid = ingroup && tend <= inlim;
-    bool cut = __ballot(ingroup && tend > inlim) != 0;
+    const u64 ingm = lanes_below(8u * ng);                        // lanes of the groups found (a prefix: scalar)
+    const u64 fitm = wave_ballot(tend <= inlim);
+    u64 vm = ingm & fitm;                                         // the lanes that hold a real token
+    bool cut = (ingm & ~fitm) != 0;
     if (FMT == ALZ_FMT_LZ02) {                                    // the terminator and everything behind it: exact parser (same hand-over)
-        const u64 tm = __ballot(valid && term);
-        if (tm) { valid = valid && (u32)lane < (u32)__builtin_ctzll(tm); cut = true; }
+        const u64 tm = vm & wave_ballot(term);
+        if (tm) { vm &= lanes_below((u32)__builtin_ctzll(tm)); cut = true; }
     }
-    if (cut && __ballot(valid) == 0) { to_serial = true; return false; }
+    if (cut && vm == 0) { to_serial = true; return false; }
     u32 last_tend;
-    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB>>(out, s, size, vm, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
     if (fin) {
         s.p = p + last_tend;
         if (FMT == ALZ_FMT_LZ02) {                                // not the end of an LZ02 stream: the exact parser goes on to the terminator
-            const u32 lk = (u32)__builtin_ctzll(__ballot(valid && tend == last_tend) | (1ull << 63));
+            const u32 lk = (u32)__builtin_ctzll((vm & wave_ballot(tend == last_tend)) | (1ull << 63));
             s.bits = 7u - (lk & 7u);
             s.flag = in.peek1(p + wave_readlane(gstart, lk));
         }
@@ -208,7 +209,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     }
     if (!cut) { s.p = p + g; return false; }
     // stopped inside a group: hand (position, remaining flag bits, flag byte) to the serial parser
-    const u32 lk = (u32)__popcll(__ballot(valid)) - 1u;
+    const u32 lk = (u32)__popcll(vm) - 1u;
     s.p = p + wave_readlane(tend, lk);
     s.bits = 7u - (lk & 7u);
     s.flag = in.peek1(p + wave_readlane(gstart, lk));
@@ -243,7 +244,7 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     // cursors after this token, packed so one readlane recovers both (c: 8 bits is enough for <=128, u: <=64)
     const u32 tend = ((2u * (midx + (lit ? 0u : 1u))) << 8) | (uidx + (usesu ? 1u : 0u));
     u32 last;
-    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, true, len, desc, tend, segmark, nullptr, lane, last, 4096);
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, ~0ull, len, desc, tend, segmark, nullptr, lane, last, 4096);
     // (selects, not an if / else of "+=" through the references: the compiler sinks those stores into ONE store through a
     // pointer phi of &up / &fp before inlining, and the cursors then live in scratch memory for the whole kernel)
     cp += fin ? (last >> 8) : 2u * (u32)__popcll(~lm);
@@ -292,7 +293,6 @@ __device__ __forceinline__ bool fast_iter_lzhudson(InCache& in, OW& out, DecStat
         }
     }
     const u32 k = (u32)lane & 7u;
-    const bool valid = (u32)lane < 8u * done;
     const u32 m = ((infosel >> (4u * k)) & 0xFu) != 0u;
     const u32 to = tstart + k + (u32)__builtin_amdgcn_udot8(infosel & ((1u << (4u * k)) - 1u), 0x11111111u, 0u, false);
     const u32 ti = in.idx(p + to);
@@ -304,7 +304,7 @@ __device__ __forceinline__ bool fast_iter_lzhudson(InCache& in, OW& out, DecStat
         if (nib == 0) { len = b3 + 0x12u; tend = to + 3; } else { len = nib + 2u; tend = to + 2; }
     }
     u32 last_tend;
-    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, valid, len, desc, tend, segmark, nullptr, lane, last_tend, 4096);
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, lanes_below(8u * done), len, desc, tend, segmark, nullptr, lane, last_tend, 4096);
     s.p = fin ? p + last_tend : p + T;
     s.flag = F; s.bits = nb - 8u * done;
     return fin;
@@ -341,7 +341,7 @@ __device__ __forceinline__ bool fast_iter_smsr00(InCache& cin, InCache& uin, OW&
     // cursors after this token, packed so one readlane recovers both: code words (<= 68) << 8 | literals (<= 64)
     const u32 tend = ((gstart + 1u + mbefore + (lit ? 0u : 1u)) << 8) | (uidx + (lit ? 1u : 0u));
     u32 last;
-    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, true, len, desc, tend, segmark, nullptr, lane, last, 4096);
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, ~0ull, len, desc, tend, segmark, nullptr, lane, last, 4096);
     if (fin) { cp += 2u * (last >> 8); up += last & 0xFFu; }
     else { cp += 2u * gend; up += (u32)__popcll(lm); }
     return fin;
@@ -371,7 +371,7 @@ __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u
     u32 desc = lo;
     if (qtok & 0x20000u) desc = CFG::LITRUN ? (0x80000000u | lo) : ALZ_DESC_LIT(lo & 0xFFu);
     u32 last;
-    fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < uni(nt), len, desc, 0u, segmark, inlds, lane, last, uni(W));
+    fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, lanes_below(uni(nt)), len, desc, 0u, segmark, inlds, lane, last, uni(W));
     EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = s.ovf ? 1u : 0u;
     r.att_lo = (u32)s.attempted_end; r.att_hi = (u32)(s.attempted_end >> 32);
     return r;
@@ -620,7 +620,7 @@ __device__ __forceinline__ bool pipelined_rounds(InCache& in, OW& out, DecState&
         {   // (round 1 parsed round k + 1 between the issue and the use of round k's HBM read-backs; the chunked phase reads a far
             // source as one 20-byte load per chunk right where it needs it, and keeping a round's token state alive across the
             // parse cost more registers -- a wave per SIMD -- than the overlap gained)
-            (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, inlds, lane, last, W);
+            (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, lanes_below(nt), len, desc, 0u, segmark, inlds, lane, last, W);
             if (ahead && !s.ovf) {
                 more = parse(p, qt2, nt2, total2, adv2);
                 if (more && total2 > maxout - out.produced) more = false;
@@ -1453,7 +1453,7 @@ __device__ __forceinline__ bool prs_lane_parse(InCache& in, SK& sk, DecState& s,
         const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
         const u32 desc = (qt & 0x20000u) ? ALZ_DESC_LIT(lo & 0xFFu) : lo;
         u32 last;
-        (void)fast_emit<typename SK::OWT, typename SK::CFGT>(sk.out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, sk.segmark, sk.inlds, lane, last, sk.W);
+        (void)fast_emit<typename SK::OWT, typename SK::CFGT>(sk.out, s, 0xFFFFFFFFu, lanes_below(nt), len, desc, 0u, sk.segmark, sk.inlds, lane, last, sk.W);
     }
     return true;
 }

@@ -166,9 +166,9 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
 template <class CFG> struct EmitUsesChunks { static constexpr bool value = CFG::FALLBACK; };
 
 template <class OW, class CFG>
-__device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch, int lane, u32& last_tend, u32 W, EmitState& e) {
+__device__ __forceinline__ void emit_begin(OW& out, DecState& s, u32 size, u64 vm, u32 len, u32 desc, u32 tend, u8* scratch, int lane, u32& last_tend, u32 W, EmitState& e) {
     (void)scratch;
-    emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
+    emit_prologue<OW, CFG>(out, s, size, vm, len, desc, tend, lane, last_tend, W, e);
 }
 template <class OW, class CFG>
 __device__ __forceinline__ void emit_finish(OW& out, u8* scratch, const u8* inlds, int lane, EmitState& e) {
@@ -197,10 +197,10 @@ struct WalkOut {
 
 // Returns true when the stream is finished (declared size reached, or capacity hit).
 template <class OW, class CFG>
-__device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, u8* scratch,
+__device__ __forceinline__ bool fast_emit(OW& out, DecState& s, u32 size, u64 vm, u32 len, u32 desc, u32 tend, u8* scratch,
                                           const u8* inlds, int lane, u32& last_tend, u32 W) {
     EmitState e;
-    emit_prologue<OW, CFG>(out, s, size, valid, len, desc, tend, lane, last_tend, W, e);
+    emit_prologue<OW, CFG>(out, s, size, vm, len, desc, tend, lane, last_tend, W, e);
     if constexpr (OW::PUBLISH) {                               // a parsing wavefront: the batch goes to the executing one
         out.publish(e, lane);
         out.produced = e.O + e.T;

@@ -95,26 +95,32 @@ struct EmitState {
     u32 O, T, W;         // output position of the batch, bytes it produces, the format's window (E2 of the byte phase)
 };
 
-// Token prologue.  Per-lane token: valid, len (>= 1), desc, tend = input offset just past the token.  For LZSS the
+// mask of the lanes below n (n <= 64), on the scalar unit
+__device__ __forceinline__ u64 lanes_below(u32 n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+
+// Token prologue.  Per-lane token: len (>= 1), desc, tend = input offset just past the token; `vm` = the mask of the lanes that hold a
+// token (a scalar pair: every caller knows it as one -- a prefix of the lanes, or the ballot of one compare -- and a predicate that IS a
+// lane mask costs nothing to use, while the ballot of a compound predicate costs two vector instructions to materialise).  For LZSS the
 // descriptor holds the ring OFFSET and becomes a distance here, once the token's output position is known
 // (LzWindows.OffsetCopy  IO/LzWindows.cs:108-115).  The size / capacity rules (E4, E5) are prefix cuts.
 template <class OW, class CFG>
-__device__ __forceinline__ void emit_prologue(OW& out, DecState& s, u32 size, bool valid, u32 len, u32 desc, u32 tend, int lane, u32& last_tend, u32 W, EmitState& e) {
+__device__ __forceinline__ void emit_prologue(OW& out, DecState& s, u32 size, u64 vm, u32 len, u32 desc, u32 tend, int lane, u32& last_tend, u32 W, EmitState& e) {
+    const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);
     const u32 end = wave_incl_scan(valid ? len : 0u, lane);
     const u32 off = end - len;
     const u32 O = out.produced;
     const u32 left = size - O;                               // > 0 (caller guarantees produced < size)
-    const bool keep = valid && off < left;                   // the token exists in the stream (prefix of lanes)
-    const u64 km = wave_ballot(keep);
+    const u64 km = vm & wave_ballot(off < left);             // the token exists in the stream (prefix of lanes)
+    const bool keep = __builtin_amdgcn_inverse_ballot_w64(km);
     const u32 nk = (u32)__popcll(km);
-    const u32 nvalid = (u32)__popcll(wave_ballot(valid));
+    const u32 nvalid = (u32)__popcll(vm);
     const u32 Tend = wave_readlane(end, nk - 1);
     bool fin = nk < nvalid || Tend >= left;
     u32 lastk = nk - 1;
     u32 T = Tend;
     const u32 room = out.cap - O;
     if (Tend > room) {                                       // E5: first token whose output would exceed dst_cap
-        const u64 om = wave_ballot(keep && end > room);
+        const u64 om = km & wave_ballot(end > room);
         lastk = (u32)__builtin_ctzll(om);
         s.ovf = true; s.attempted_end = (u64)O + wave_readlane(end, lastk);
         T = room; fin = true;

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
         const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
         const u32 desc = (qt & 0x20000u) ? ALZ_DESC_LIT(lo & 0xFFu) : lo;
         u32 last;
-        (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, inc_lds, lane, last, 8192u);
+        (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, lanes_below(nt), len, desc, 0u, segmark, inc_lds, lane, last, 8192u);
         if (term) { s.done = true; break; }                        // PRS.cs:78-79: the zero word ends the stream
     }
     SK sk(out, s, segmark, inc_lds, lane, 8192u);
@@ -848,7 +848,7 @@ void alz_decode_queue2_kernel(const u8* __restrict__ src_base, u8* __restrict__ 
         const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
         const u32 desc = (qt & 0x20000u) ? (0x80000000u | lo) : lo;
         u32 last;
-        (void)fast_emit<OW, CFG2>(out, s, 0xFFFFFFFFu, (u32)lane < nt, len, desc, 0u, segmark, runbase, lane, last, 65536u);
+        (void)fast_emit<OW, CFG2>(out, s, 0xFFFFFFFFu, lanes_below(nt), len, desc, 0u, segmark, runbase, lane, last, 65536u);
     }
     sk.flush();
     out.finish();
