@@ -564,7 +564,7 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     lane_walk_pos(nx, 33u, spos, sp, nseq);
     if (nseq == 0u) return false;
     // 3. one lane per sequence: fields, then (literal run?, match) into the queue order (the sequences whose tokens fit its 64 slots)
-    bool st = (u32)lane < nseq;
+    bool st = (u32)lane < nseq; u64 stm = lanes_below(nseq);
     const u32 pos = i0 + spos;
     const u32 b = in.lds[pos], e1 = in.lds[pos + 1];
     const u32 L0 = b >> 4, M0 = b & 15u;
@@ -574,11 +574,13 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     const u32 d0 = in.lds[op & 2047u], d1 = in.lds[(op + 1u) & 2047u], em = in.lds[(op + 2u) & 2047u];
     const u32 M = M0 + 4u + (M0 == 15u ? em : 0u);
     const u32 dist = d0 | (d1 << 8);
-    u64 litm = __ballot(st && L != 0u);
+    // (masks of a prefix of lanes come from the scalar unit; a ballot of `prefix && x` would cost two vector instructions more than the ballot of x)
+    const u64 hasl = wave_ballot(L != 0u);
+    u64 litm = lanes_below(nseq) & hasl;
     const u32 rank = (u32)lane + mbcnt64(litm);
     {
-        const u32 keep = (u32)__popcll(__ballot(st && rank + (L ? 2u : 1u) <= 64u));
-        if (keep < nseq) { nseq = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; litm = __ballot(st && L != 0u); }
+        const u32 keep = (u32)__popcll(lanes_below(nseq) & wave_ballot(rank + (L ? 2u : 1u) <= 64u));
+        if (keep < nseq) { nseq = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; stm = lanes_below(keep); litm = lanes_below(keep) & hasl; }
     }
     if (st) {
         u32 r = rank;
@@ -824,7 +826,7 @@ __device__ __forceinline__ bool lzshrek_parse_round(InCache& in, u32 p, u32* sta
     u32 spos, sp, nel;
     shrek_walk_pos(pk, spos, sp, nel, state);
     if (nel == 0u) return false;
-    const bool st = (u32)lane < nel;
+    const bool st = (u32)lane < nel; u64 stm = lanes_below(nel);
     const u32 pos = i0 + (spos & 0x3FFu);
     const bool header = (spos >> 10) == 0u;
     const u32 b = in.lds[pos & 2047u], e1 = in.lds[(pos + 1u) & 2047u], e2 = in.lds[(pos + 2u) & 2047u], e3 = in.lds[(pos + 3u) & 2047u];
@@ -900,14 +902,14 @@ __device__ __forceinline__ bool hig_parse_round(InCache& in, u32 p, u32* stage, 
     u32 spos, sp, nel;
     lane_walk_pos(nx, 33u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
     if (nel == 0u) return false;
-    bool st = (u32)lane < nel;
+    bool st = (u32)lane < nel; u64 stm = lanes_below(nel);
     u32 hdr, length, distance, rawp, cnt;
     hig_element(in, i0 + spos, hdr, length, distance, rawp, cnt);
-    u64 mm = __ballot(st && length != 0u), litm = __ballot(st && cnt != 0u);
+    u64 mm = (stm & wave_ballot(length != 0u)), litm = (stm & wave_ballot(cnt != 0u));
     const u32 rank = mbcnt64(mm) + mbcnt64(litm);
     {   // the elements whose tokens fit the 64 slots of the queue
-        const u32 keep = (u32)__popcll(__ballot(st && rank + (length ? 1u : 0u) + (cnt ? 1u : 0u) <= 64u));
-        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; mm = __ballot(st && length != 0u); litm = __ballot(st && cnt != 0u); }
+        const u32 keep = (u32)__popcll((stm & wave_ballot(rank + (length ? 1u : 0u) + (cnt ? 1u : 0u) <= 64u)));
+        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; stm = lanes_below(keep); mm = (stm & wave_ballot(length != 0u)); litm = (stm & wave_ballot(cnt != 0u)); }
     }
     if (st) {
         u32 r = rank;
@@ -944,15 +946,15 @@ __device__ __forceinline__ bool wflz_parse_round(InCache& in, u32 p, u32* stage,
     u32 spos, sp, nel;
     lane_walk_pos(nx, 33u, spos, sp, nel);                               // a block has >= 4 bytes: <= 16 per window
     if (nel == 0u) return false;
-    bool st = (u32)lane < nel;
+    bool st = (u32)lane < nel; u64 stm = lanes_below(nel);
     const u32 pos = i0 + spos;
     const u32 b0 = in.lds[pos], b1 = in.lds[pos + 1], length = in.lds[pos + 2], plain = in.lds[pos + 3];
     const u32 dist = BIG ? ((b0 << 8) | b1) : (b0 | (b1 << 8));
-    u64 mm = __ballot(st && length != 0u), litm = __ballot(st && plain != 0u);
+    u64 mm = (stm & wave_ballot(length != 0u)), litm = (stm & wave_ballot(plain != 0u));
     const u32 rank = mbcnt64(mm) + mbcnt64(litm);
     {   // the blocks whose tokens fit the 64 slots of the queue
-        const u32 keep = (u32)__popcll(__ballot(st && rank + (length ? 1u : 0u) + (plain ? 1u : 0u) <= 64u));
-        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; mm = __ballot(st && length != 0u); litm = __ballot(st && plain != 0u); }
+        const u32 keep = (u32)__popcll((stm & wave_ballot(rank + (length ? 1u : 0u) + (plain ? 1u : 0u) <= 64u)));
+        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; stm = lanes_below(keep); mm = (stm & wave_ballot(length != 0u)); litm = (stm & wave_ballot(plain != 0u)); }
     }
     if (st) {
         u32 r = rank;
@@ -994,7 +996,7 @@ __device__ __forceinline__ bool refpack_parse_round(InCache& in, u32 p, u32* sta
     u32 spos, sp, nel;
     lane_walk_pos(nx, 33u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
     if (nel == 0u) return false;
-    const bool st = (u32)lane < nel;
+    const bool st = (u32)lane < nel; u64 stm = lanes_below(nel);
     const u32 pos = i0 + spos;
     const u32 b = in.lds[pos], d0 = in.lds[pos + 1], d1 = in.lds[(pos + 2u) & 2047u], d2 = in.lds[(pos + 3u) & 2047u];
     u32 plain, length = 0, distance = 1, hdr;
@@ -1002,17 +1004,17 @@ __device__ __forceinline__ bool refpack_parse_round(InCache& in, u32 p, u32* sta
     else if (b < 0xC0u) { hdr = 3; plain = d0 >> 6; length = (b & 0x3Fu) + 4u; distance = (((d0 & 0x3Fu) << 8) | d1) + 1u; }
     else if (b < 0xE0u) { hdr = 4; plain = b & 3u; length = (((b & 0x0Cu) << 6) | d2) + 5u; distance = (((((b & 0x10u) << 4) | d0) << 8) | d1) + 1u; }
     else { hdr = 1; plain = (b & 0x1Fu) * 4u + 4u; }
-    if (__ballot(st && distance > 0x1FFFFu)) {                           // cut the round in front of the first such element
-        const u32 first = (u32)__builtin_ctzll(__ballot(st && distance > 0x1FFFFu));
+    if ((stm & wave_ballot(distance > 0x1FFFFu))) {                           // cut the round in front of the first such element
+        const u32 first = (u32)__builtin_ctzll((stm & wave_ballot(distance > 0x1FFFFu)));
         if (first == 0u) return false;
         nel = first; sp = wave_readlane(spos, first);
     }
-    bool st2 = (u32)lane < nel;
-    u64 litm = __ballot(st2 && plain != 0u), mm = __ballot(st2 && length != 0u);
+    bool st2 = (u32)lane < nel; u64 st2m = lanes_below(nel);
+    u64 litm = (st2m & wave_ballot(plain != 0u)), mm = (st2m & wave_ballot(length != 0u));
     const u32 rank = mbcnt64(litm) + mbcnt64(mm);
     {   // the elements whose tokens fit the 64 slots of the queue
-        const u32 keep = (u32)__popcll(__ballot(st2 && rank + (plain ? 1u : 0u) + (length ? 1u : 0u) <= 64u));
-        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st2 = (u32)lane < keep; litm = __ballot(st2 && plain != 0u); mm = __ballot(st2 && length != 0u); }
+        const u32 keep = (u32)__popcll((st2m & wave_ballot(rank + (plain ? 1u : 0u) + (length ? 1u : 0u) <= 64u)));
+        if (keep < nel) { nel = keep; sp = wave_readlane(spos, keep); st2 = (u32)lane < keep; st2m = lanes_below(keep); litm = (st2m & wave_ballot(plain != 0u)); mm = (st2m & wave_ballot(length != 0u)); }
     }
     if (st2) {
         u32 r = rank;
@@ -1233,15 +1235,15 @@ __device__ __forceinline__ bool lzo_parse_round(InCache& in, u32 p, u32* stage, 
     // whose tokens fit the 64 slots of the queue and resumes in front of the first one that does not.
     u32 tl;
     const u32 first = lzo_interpret_bytes<true>(mypos, mf, me1, me2, me3, mystate, tl);
-    bool st = (u32)lane < ninstr;
+    bool st = (u32)lane < ninstr; u64 stm = lanes_below(ninstr);
     bool second = st && tl != 0u;
     u64 sm = __ballot(second);
     const u32 rank = (u32)lane + mbcnt64(sm);
-    const u32 keep = (u32)__popcll(__ballot(st && rank + (second ? 2u : 1u) <= 64u));
+    const u32 keep = (u32)__popcll((stm & wave_ballot(rank + (second ? 2u : 1u) <= 64u)));
     if (keep < ninstr) {
         ninstr = keep;
         sp = wave_readlane(spos, keep) & 0xFFu;
-        st = (u32)lane < keep; second = second && st; sm = __ballot(second);
+        st = (u32)lane < keep; stm = lanes_below(keep); second = second && st; sm = __ballot(second);
     }
     state = wave_readlane(leaves, ninstr - 1u);                  // (ninstr >= 1: an instruction has at most two tokens)
     if (st) { stage[rank] = first; if (second) stage[rank + 1u] = tl; }
