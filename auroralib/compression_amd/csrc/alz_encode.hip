@@ -1951,6 +1951,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
 size_t alz_encode_geom_size(void) { return sizeof(EncGeom); }
 int alz_encode_geom_hash_bits(const void* geom) { return ((const EncGeom*)geom)->hash_bits; }
 int alz_encode_geom_min_table(const void* geom) { return ((const EncGeom*)geom)->use_min_table; }
+int alz_encode_geom_max_dist(const void* geom) { return ((const EncGeom*)geom)->max_dist; }
 
 // LZ4 blocks (LZ4.cs:202-238) and raw Snappy (Snappy.cs:124-203) from the start mask of the roles walk: every match start is one
 // sequence -- LZ4: token, literal-length bytes, the literals since the match before it, offset, match-length bytes; Snappy: a literal

@@ -708,10 +708,6 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         if (!range_ok(streams[i].src_off, streams[i].src_len, src_bytes)) return fail(ALZ_E_INVALID, "stream %u: source range exceeds src_bytes", i);
         if (!range_ok(streams[i].dst_off, streams[i].dst_cap, dst_bytes)) return fail(ALZ_E_INVALID, "stream %u: destination range exceeds dst_bytes", i);
         if (streams[i].src_len > 0x7FFFFF00u) return fail(ALZ_E_UNSUPPORTED, "stream %u: inputs above 2 GiB are not supported", i);
-        // MaxWindowBits only means something to FastLZ (level 2 for sources >= 64 KiB at Quality > 4, FastLZ.cs:169-175); for
-        // every other format it would merely let the finder return distances the format cannot store
-        if (st.max_window_bits != 0 && streams[i].format != ALZ_FMT_FASTLZ)
-            return fail(ALZ_E_UNSUPPORTED, "CompressionSettings.MaxWindowBits != 0 is only supported for FastLZ by the GPU encoder");
         cnt[streams[i].format]++;
         if (streams[i].format == ALZ_FMT_FASTLZ && fastlz_level2(st, streams[i].src_len)) n_fastlz2++;
         pos_off[i] = total; total += ((uint64_t)streams[i].src_len + 16 + 63) & ~63ull;   // 64-aligned: one start-mask word per 64 positions
@@ -725,7 +721,20 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
         void* g = geom.data() + f * alz_encode_geom_size();
-        if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &st, g, nullptr, lvl2 ? 1 : 0))
+        alz_settings sf = st;
+        if (st.max_window_bits != 0 && f != ALZ_FMT_FASTLZ && !lvl2) {
+            // CompressionSettings.MaxWindowBits can only WIDEN the finder (windowsBits = max(.., maxWindowBits), maxDistance = max(.., 1 <<
+            // maxWindowBits)  MatchFinder/LzChainMatchFinder.cs:69-73): a value within the format's own window changes nothing, and the
+            // batch is encoded as with 0.  A larger one lets the managed finder return distances the format cannot store (FastLZ, whose
+            // level 2 is selected by it, aside): the caller's own encoder.
+            sf.max_window_bits = 0;
+            int wb0 = 0;
+            if (!alz_encode_geometry(f, &lz, &sf, g, &wb0, 0)) return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", f);
+            if (st.max_window_bits > wb0 || (1ll << st.max_window_bits) > (long long)alz_encode_geom_max_dist(g))
+                return fail(ALZ_E_UNSUPPORTED, "format %d: CompressionSettings.MaxWindowBits %d is beyond the format's window (%d bits, distances up to %d): "
+                            "the managed finder would return distances the format cannot store", f, st.max_window_bits, wb0, alz_encode_geom_max_dist(g));
+        }
+        if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &sf, g, nullptr, lvl2 ? 1 : 0))
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
         any_min = any_min || alz_encode_geom_min_table(g);
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);

@@ -161,10 +161,12 @@ typedef struct alz_result {
 /* CompressionSettings (src/AuroraLib.Compression/CompressionSettings.cs:11-84) */
 typedef struct alz_settings {
     int32_t quality;          /* 0..15; presets Fastest 0, Fast 4, Balanced 8 (default), High 12, Maximum 15 */
-    int32_t max_window_bits;  /* 0 = auto.  Only FastLZ takes another value (> 13 selects level 2 for sources >= 64 KiB at
-                               * quality > 4, Formats/Common/FastLZ.cs:169-175), up to 20: the finder on the device keeps a
-                               * distance in 21 bits; refused (ALZ_E_UNSUPPORTED) above that and for every other format,
-                               * where it would merely let the finder return distances the format cannot store */
+    int32_t max_window_bits;  /* 0 = auto.  The managed finder only ever WIDENS its window with it (windowsBits = max(format,
+                               * MaxWindowBits), maxDistance = max(format, 1 << MaxWindowBits); MatchFinder/LzChainMatchFinder.cs:
+                               * 69-73), so a value within the format's own window is accepted and changes nothing.  A larger one
+                               * is taken for FastLZ (> 13 selects level 2 for sources >= 64 KiB at quality > 4, Formats/Common/
+                               * FastLZ.cs:169-175) up to 20 -- the finder on the device keeps a distance in 21 bits -- and refused
+                               * (ALZ_E_UNSUPPORTED) otherwise: the managed finder would return distances the format cannot store */
     int32_t strategy;         /* 0 Default, 1 CompatibilityMode (no self-overlapping matches) */
     int32_t min_distance;     /* 0 = format default; 2 = LZ10/LZ11 GbaVramCompatibilityMode (LZ10.cs:25-33) */
 } alz_settings;

@@ -118,12 +118,31 @@ namespace AuroraLib.Compression.Amd
         /// <summary>True when a single stream of this size should run on the GPU rather than on the managed body.</summary>
         internal static bool UseGpu(uint decomLength) => AmdContext.Available && decomLength >= AmdContext.SingleStreamThreshold;
 
-        /// <summary>True when ONE buffer should be compressed by the native encoder.  The native finder takes the format's own
-        /// window only: a caller's <c>MaxWindowBits</c> (LzChainMatchFinder.cs:69-73) is honoured by the managed encoder, except
-        /// for FastLZ, whose level-2 switch it is (FastLZ.cs:163-170).</summary>
-        internal static bool UseGpuForCompress(AlzFormat format, int sourceLength, CompressionSettings settings)
-            => (settings.MaxWindowBits == 0 || (format == AlzFormat.FastLZ && settings.MaxWindowBits <= 20))   // (the GPU finder keeps distances in 21 bits)
+        /// <summary>True when ONE buffer should be compressed by the native encoder.  A caller's <c>MaxWindowBits</c> only ever WIDENS
+        /// the managed finder (LzChainMatchFinder.cs:69-73): within the format's own window it changes nothing and the native
+        /// encoder takes it; beyond it (where the managed finder returns distances the format cannot store) the call stays managed,
+        /// except for FastLZ, whose level-2 switch it is (FastLZ.cs:163-170).</summary>
+        internal static bool UseGpuForCompress(AlzFormat format, int sourceLength, CompressionSettings settings, LzProperties? lz = null)
+            => MaxWindowBitsOnGpu(format, settings.MaxWindowBits, lz)
                && (uint)sourceLength >= AmdContext.SingleStreamCompressThreshold && AmdContext.Available;
+
+        /// <summary>The rule of alz_encode_batch (include/auroralz.h, alz_settings.max_window_bits): 0, or within the format's window
+        /// (bits AND 1 &lt;&lt; bits &lt;= the largest distance of the format), or FastLZ up to 20 bits (the device finder keeps 21).</summary>
+        internal static bool MaxWindowBitsOnGpu(AlzFormat format, int bits, LzProperties? lz = null)
+        {
+            if (bits == 0) return true;
+            if (format == AlzFormat.FastLZ) return bits <= 20;
+            (int wb, int maxDistance) = format switch
+            {
+                AlzFormat.LZSS => lz.HasValue ? (lz.Value.WindowsBits, lz.Value.MaxDistance) : (12, 0x1000),
+                AlzFormat.PrsBE or AlzFormat.PrsLE => (13, 0x1FFF),
+                AlzFormat.LZ4Block => (16, 0xFFFF),
+                AlzFormat.LZO => (16, 0xBFFF),
+                AlzFormat.SnappyRaw => (15, 0x8000),
+                _ => (12, 0x1000),                                              // LZ10 / LZ11 / Yaz0 / Yay0 / MIO0
+            };
+            return bits <= wb && (1 << bits) <= maxDistance;
+        }
 
         internal static AlzLzProperties ToNative(LzProperties lz) => new AlzLzProperties
         {

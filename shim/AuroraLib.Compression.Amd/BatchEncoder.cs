@@ -40,8 +40,8 @@ namespace AuroraLib.Compression.Amd
             ulong so = 0, dof = 0;
             for (int i = 0; i < n; i++)
             {
-                if (settings.MaxWindowBits != 0 && (jobs[i].Format != AlzFormat.FastLZ || settings.MaxWindowBits > 20))
-                    throw new NotSupportedException("MaxWindowBits is honoured by the managed encoder only (LzChainMatchFinder.cs:69-73; FastLZ: up to 20 on the GPU)");
+                if (!AmdBody.MaxWindowBitsOnGpu(jobs[i].Format, settings.MaxWindowBits))
+                    throw new NotSupportedException("MaxWindowBits beyond the format's own window is honoured by the managed encoder only (LzChainMatchFinder.cs:69-73; FastLZ: up to 20 on the GPU)");
                 uint len = (uint)jobs[i].Data.Length, cap = len + len / 4 + 64;      // worst case of every body on the path
                 streams[i] = new AlzStream { SrcOff = so, DstOff = dof, SrcLen = len, DstCap = cap, Format = (uint)jobs[i].Format };
                 so += ((ulong)len + 15) & ~15ul;

@@ -67,7 +67,7 @@ namespace AuroraLib.Compression.Amd.Common
         public static unsafe void CompressHeaderless(ReadOnlySpan<byte> source, Stream destination, LzProperties lz, CompressionSettings settings = default)
         {
             bool native = lz.WindowsBits >= 8 && lz.WindowsBits <= 16 && lz.LengthBits >= 1 && lz.LengthBits <= 8 && lz.MaxDistance == (1 << lz.WindowsBits);
-            if (!native || !AmdBody.UseGpuForCompress(AlzFormat.LZSS, source.Length, settings)) { Managed.LZSS.CompressHeaderless(source, destination, lz, settings); return; }
+            if (!native || !AmdBody.UseGpuForCompress(AlzFormat.LZSS, source.Length, settings, lz)) { Managed.LZSS.CompressHeaderless(source, destination, lz, settings); return; }
             AlzLzProperties p = AmdBody.ToNative(lz);
             AmdBody.Encode(AlzFormat.LZSS, &p, source, destination, settings, 0);
         }

@@ -173,9 +173,19 @@ def test_fastlz_level2(quality, mwb, test_bmp):
             assert bytes(g_dst[a:a + len(r)]) == bytes(r)
 
 
-def test_max_window_bits_is_fastlz_only(test_bmp):
-    with pytest.raises(Exception):
-        _encode_and_compare(A.FMT_LZ10, [test_bmp[:5000]], 8, max_window_bits=14)
+def test_max_window_bits_within_and_beyond_the_format_window(test_bmp):
+    """CompressionSettings.MaxWindowBits only widens the managed finder (LzChainMatchFinder.cs:69-73): within the format's own window it
+    changes nothing -- the GPU encoder takes it and writes the oracle's bytes (which restates the max() rule) --, beyond it the managed
+    finder returns distances the format cannot store and the call is refused (FastLZ aside: test_fastlz_level2)."""
+    raws = [test_bmp[:30000], test_bmp[100000:100000 + 70000], bytes(3000)]
+    for fmt, ok_bits, bad_bits in ((A.FMT_LZ10, (8, 12), (13, 14)), (A.FMT_YAZ0, (10, 12), (13,)), (A.FMT_LZ4_BLOCK, (12, 15), (16, 17)),   # (LZ4: 1 << 16 > 0xFFFF)
+                                   (A.FMT_PRS_BE, (12,), (13,)), (A.FMT_LZO, (15,), (16,)), (A.FMT_SNAPPY_RAW, (15,), (16,)), (A.FMT_LZSS, (11, 12), (13,))):
+        for b in ok_bits:
+            for q in (0, 8):
+                _encode_and_compare(fmt, raws, q, max_window_bits=b)
+        for b in bad_bits:
+            with pytest.raises(Exception):
+                _encode_and_compare(fmt, raws[:1], 8, max_window_bits=b)
 
 
 @pytest.mark.parametrize("quality", [0, 1, 3, 6, 8, 10, 12, 15])

@@ -242,11 +242,18 @@ def test_dllimport_parameter_types_match_the_header():
 def test_single_stream_compress_stays_managed_by_default():
     """One buffer is a serial job for one wavefront: Compress / CompressHeaderless reach the native encoder only above
     AmdContext.SingleStreamCompressThreshold (default: never) -- BatchEncoder.CompressMany is the GPU entry point -- and a
-    caller's MaxWindowBits (which the native finder does not take) stays with the managed encoder."""
+    caller's MaxWindowBits beyond the format's own window (where the managed finder returns distances the format cannot store, and
+    alz_encode_batch answers ALZ_E_UNSUPPORTED) stays with the managed encoder; the shim's rule mirrors the library's per format."""
     ctx = open(os.path.join(SHIM, "AmdContext.cs")).read()
     assert re.search(r"public static uint SingleStreamCompressThreshold \{ get; set; \} = uint\.MaxValue;", ctx)
     body = open(os.path.join(SHIM, "AmdBody.cs")).read()
-    assert "settings.MaxWindowBits == 0 || (format == AlzFormat.FastLZ && settings.MaxWindowBits <= 20)" in body and "SingleStreamCompressThreshold" in body
+    assert "MaxWindowBitsOnGpu(format, settings.MaxWindowBits, lz)" in body and "SingleStreamCompressThreshold" in body
+    assert "if (format == AlzFormat.FastLZ) return bits <= 20;" in body and "return bits <= wb && (1 << bits) <= maxDistance;" in body
+    # the window table of the shim against the library's own (alz_encode.hip: alz_encode_geometry)
+    hip = open(os.path.join(ROOT, "auroralib", "compression_amd", "csrc", "alz_encode.hip")).read()
+    for name, wb, md in (("PRS_BE", 13, "0x1FFF"), ("LZ4_BLOCK", 16, "0xFFFF"), ("LZO", 16, "0xBFFF"), ("SNAPPY_RAW", 15, "0x8000")):
+        assert re.search(r"case ALZ_FMT_%s:[^\n]*wb = %d;[^\n]*g\.max_dist = %s;" % (name, wb, md), hip), name
+        assert "(%d, %s)" % (wb, md) in body, name
     for f in ("LZ10.cs", "LZ11.cs", "Yaz0.cs", "Yay0.cs", "MIO0.cs", "LZSS.cs", "LZO.cs", "PRS.cs"):
         t = _strip_comments(open(os.path.join(SHIM, f)).read())
         assert "AmdBody.UseGpuForCompress(" in t, f
