@@ -88,8 +88,23 @@ typedef enum alz_status {
     ALZ_ST_INPUT_TRUNCATED      = 1, /* EndOfStreamException / IndexOutOfRangeException */
     ALZ_ST_OUTPUT_SIZE_MISMATCH = 2, /* DecompressedSizeException (LZ10.cs:107-110 '>', LZSS.cs:126-129 '!=') */
     ALZ_ST_OUTPUT_CAPACITY      = 3, /* NotSupportedException of a fixed-size destination */
-    ALZ_ST_BAD_TOKEN            = 4  /* reference-undefined input the library refuses (Snappy copy-4 distance > window) */
+    ALZ_ST_BAD_TOKEN            = 4  /* reference-undefined input the library refuses: see E3 below */
 } alz_status;
+
+/*
+ * E3 -- a match distance beyond the window W of its format (encodable by Snappy's 4-byte-offset copy against its 64 KiB
+ * LzWindows, Snappy.cs:244-247 / :213, and by LZShrek's distances up to 65 822 against its 4 KiB one) -- is REFUSED with
+ * ALZ_ST_BAD_TOKEN; every other body cannot encode one.  A decision against SURVEY.md 8a-1, which froze E3 as "d mod W in
+ * Release": reading LzWindows.BackCopy (IO/LzWindows.cs:72-100) and InternWrite (:192-227) shows that the masked source
+ * position (`srcPos = (_Position - distance) & mask`) is what "d mod W" describes only while the masked distance is at least the
+ * chunk of the pass (`chunk = min(length, distance, W - srcPos)`: for distance > W nothing keeps it below the masked distance).
+ * Otherwise BackCopy hands Unsafe.CopyBlockUnaligned (cpblk) a source span that OVERLAPS its destination inside the ring -- a
+ * case ECMA-335 leaves unspecified (forward copy on one runtime, memmove on another): the managed Release output for such a token
+ * is not a function of the stream, so there is nothing to be bit-exact with.  Debug builds assert (:75).  The oracle and both kernel
+ * families agree on the refusal (tests/cases.py, tests/golden/kat_*.json); valid streams never contain such a token.
+ * E1 (distance 0 = W), E2 (sources before the stream start read 0x00), E4 / E5 (overshoot of the declared size / of dst_cap) are
+ * as SURVEY.md 8a-1 froze them.
+ */
 
 /* ---- API-level error codes ---- */
 #define ALZ_OK            0
