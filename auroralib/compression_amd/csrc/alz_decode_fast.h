@@ -104,13 +104,19 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
         const u32 mbits = TR::NEG ? ((0u - xb) & 0xFFu) : (TR::LIT1 ? (~xb & 0xFFu) : xb);   // bit set = match token
         if (!WALK) { gsize = 9u + (u32)__popc(mbits); info = mbits; }
         else {
+            // (five vector instructions per token for the formats with one odd size -- bit-field extracts of the flag bit and of the "3-byte
+            // match starts at the cursor" bit, extra = m * z + m as one v_mad_u32_u24, the cursor as one v_add3, the nibble as one v_lshl_or --
+            // where `m & (w3 >> r)` compiled to six + the packing of the nibbles afterwards)
             u32 r = 1; info = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const u32 m = (mbits >> (TR::MSB ? 7 - k : k)) & 1u;
-                u32 extra = m;
-                if (TR::H3) extra += m & (w3 >> r);
-                if (TR::H4) extra += (m & (w4 >> r)) << 1;
+                const u32 m = __builtin_amdgcn_ubfe(mbits, (u32)(TR::MSB ? 7 - k : k), 1u);
+                u32 extra;
+                if (TR::H3 && !TR::H4) { const u32 z = __builtin_amdgcn_ubfe(w3, r, 1u); asm("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(extra) : "v"(m), "v"(z)); }   // (left to itself the compiler writes (z + 1) & -m: one instruction more)
+                else {                                              // two odd sizes (LZ11, LZ40): z = 0 / 1 / 2 extra bytes of a match that starts at the cursor
+                    const u32 z = __builtin_amdgcn_ubfe(w3, r, 1u) + 2u * __builtin_amdgcn_ubfe(w4, r, 1u);
+                    asm("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(extra) : "v"(m), "v"(z));
+                }
                 info |= extra << (4 * k);
                 r += 1u + extra;
             }
