@@ -88,6 +88,9 @@ __device__ __forceinline__ void copy_step(OW& out, const u8* inlds, int lane, u3
     qs += 64u;
 }
 
+// (Round 4 also measured the mark write as `if (my token's step == the step being mapped) mark` with a scalar step counter -- one compare
+// instead of subtract + clamp, but a saved / restored exec mask around the store: 12 instead of 13 vector instructions per step and 3.03
+// against 2.97 ms per launch, PRS 5.63 against 5.50.  Not kept.)
 // (Round 4 measured the pipeline one stage deeper -- copy step k, fetch the descriptors of step k + 1 through addresses found a trip earlier,
 // map step k + 2, so that a trip waits for one LDS round trip instead of two dependent ones: Yaz0 3.02 against 2.97 ms per 10 000 x 256 KiB,
 // 959 against 979 GiB/s with two batches in flight; the 64 KiB streams of cfg2 gained 1.5 %.  Not kept.)
