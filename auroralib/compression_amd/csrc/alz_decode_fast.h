@@ -290,8 +290,9 @@ __device__ __forceinline__ bool fast_iter_lzhudson(InCache& in, OW& out, DecStat
             u32 rr = 0, info = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const u32 m = (mbits >> (7 - k)) & 1u;
-                const u32 extra = m + (m & (l3 >> rr));
+                const u32 m = __builtin_amdgcn_ubfe(mbits, (u32)(7 - k), 1u);
+                u32 extra;                                        // m * z + m (see fast_iter_interleaved)
+                { const u32 z = __builtin_amdgcn_ubfe(l3, rr, 1u); asm("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(extra) : "v"(m), "v"(z)); }
                 info |= extra << (4 * k);
                 rr += 1u + extra;
             }

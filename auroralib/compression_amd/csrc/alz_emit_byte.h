@@ -1,7 +1,7 @@
 // alz_emit_byte.h -- the byte-per-lane back end (round 1): 64 output bytes per step, one per lane.  It stays the back end of
 // every configuration whose whole window lives in LDS: on token-dense streams (the synthetic mix: ~7.5 output bytes per
 // token, every sixth match reaching into the 500 bytes in front of it) the chunked phase of alz_emit_chunk.h needs 3-4
-// re-read passes per step and loses (Yaz0 4.7 ms against 3.3 ms per 10 000 x 256 KiB), while this phase
+// re-read passes per step and loses (Yaz0 4.7 ms against 3.3 ms per 10 000 x 256 KiB; docs/EXPERIMENTS.md 4.4), while this phase
 // resolves sources inside its 64-byte step in registers (pointer jumping over ds_bpermute).
 #pragma once
 #include "alz_emit_chunk.h"

@@ -18,7 +18,7 @@
 //                               format but LZ4 / LZO / Snappy / FastLZ / RefPack ...): ONE pass whatever the hash width, through a
 //                               14-bit table and a ring of tags and skip links; otherwise 2^(hashBits - 15) passes.  (The earlier
 //                               forms -- head tables in HBM, a counting sort, hash-partitioned wavefronts, one wavefront per
-//                               stream on LDS -- are in the history of this file and in DESIGN.md 4.5 with their numbers.)
+//                               stream on LDS -- are in the history of this file and in docs/EXPERIMENTS.md 4.5 with their numbers.)
 //   B  enc_match_kernel         one lane per position: the chain walk of MatchSearch/ChainMatches (:214-282) over prev(),
 //                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 // 701 against 112 at quality 15.  Counters: the LDS pipe is 5 % busy, VALU + SALU issue 86 % at quality 8 -- the walk is bound by the
 // instructions of its trips, and the LDS form has more of them (address arithmetic, three reads and two alignbytes per eight bytes) at
 // half the wavefronts per CU (68 KB of LDS per workgroup); at quality 15 a workgroup waits for the one wavefront whose block holds a
-// 1024-step chain.  DESIGN.md 8.)
+// 1024-step chain.  docs/EXPERIMENTS.md 8.)
 template <bool MINT, bool L16>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
 // load each, then the arithmetic: 16.7-17.1 ms against 16.8.  Neither the chain of dependent round trips nor the L1's lookups (0.77 per
 // cycle) is the bound: without the link loads (10.5 GB) the kernel takes 12.7 ms, without the scattered candidate loads 15.3 -- it moves
 // 18 GB in and 21 GB out (8 bytes of match per position) at ~2.4 TB/s, three streams per workgroup against a copy kernel's two at 5.8.
-// What would pay is fewer bytes per position in the arrays the kernels hand to each other: DESIGN.md 8.  Tried again at the end of the
+// What would pay is fewer bytes per position in the arrays the kernels hand to each other: docs/EXPERIMENTS.md 8.  Tried again at the end of the
 // round with the arrays at 2 + 4 bytes per position (19.5 GB per launch, 1.4 TB/s, 0.75 instructions per cycle): 13.8 ms either way;
 // one store in 64: 13.1, no scattered candidate loads: 12.5 -- no single stream of accesses is the bound.)
 // ---------------------------------------------------------------------------------------------- kernel C

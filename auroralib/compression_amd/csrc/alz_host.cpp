@@ -328,7 +328,7 @@ int alz_plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, cons
 }
 
 static uint32_t format_weight(uint32_t fmt);
-// Time of ONE 256 KiB stream alone on the GPU, in units of 10 us (measured: DESIGN.md 4.4 / 8): what orders the kernels of a mixed launch
+// Time of ONE 256 KiB stream alone on the GPU, in units of 10 us (measured: docs/EXPERIMENTS.md 4.4 / 8): what orders the kernels of a mixed launch
 static uint32_t format_latency(uint32_t fmt) {
     switch (fmt) {
     case ALZ_FMT_YAY0: return 91;
@@ -842,7 +842,7 @@ int alz_encode_batch_device(alz_ctx* c, const alz_lz_properties* props, const al
 }
 
 // ---------------------------------------------------------------- multi-GPU: one batch over several contexts
-// Decode cost per output byte of a format relative to the fastest one (x64; from the measured per-format rates)
+// Decode cost per output byte of a format relative to the fastest one (x64; from the measured per-format rates, docs/EXPERIMENTS.md 4.4)
 static uint32_t format_weight(uint32_t fmt) {
     switch (fmt) {
     case ALZ_FMT_YAY0: return 55;

@@ -596,7 +596,7 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             out.extend(cfg5(ctx, np, A, synth, Plan))
         if "bodies" in want:
             # every other decode body north_star names, on the metric's own shape (10 000 x 256 KiB synthetic streams, one GPU): the
-            # per-format table of DESIGN.md 4.4 in the driver-run line
+            # per-format table of docs/EXPERIMENTS.md 4.4 in the driver-run line
             bsteps = max(3, min(args.steps, 5))
             for f in BODIES:
                 b = synth.make_batch(A.FORMAT_NAMES.index(f), 10000, 262144, synth.seed_for(2))
