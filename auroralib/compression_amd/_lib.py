@@ -64,6 +64,7 @@ def load():
     lib.alz_ctx_set_exact_kernels.argtypes = [vp, C.c_int]
     lib.alz_ctx_set_kernel_variant.argtypes = [vp, C.c_int]
     lib.alz_ctx_release_scratch.argtypes = [vp]
+    lib.alz_ctx_big_stream.argtypes = [vp, u32, C.POINTER(C.c_uint64)]
     lib.alz_decode_batch_multi.argtypes = [C.POINTER(vp), u32, vp, u32, vp, sz, vp, vp, sz, vp, vp]
     lib.alz_partition_batch.argtypes = [u32, vp, u32, vp, vp]
     lib.alz_measure_copy_bandwidth.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_double)]

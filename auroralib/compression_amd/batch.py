@@ -55,6 +55,13 @@ class Context:
         """alz_ctx_set_kernel_variant: 0 the library chooses, 1 / 2 one / two wavefronts per stream where both shapes exist."""
         check(self.lib.alz_ctx_set_kernel_variant(self.h, variant))
 
+    def big_stream(self, min_bytes=0):
+        """alz_ctx_big_stream: threshold of the whole-GPU path for ONE Yay0 / MIO0 stream (0 keeps it, 0xFFFFFFFF switches it off);
+        returns how often the path has been taken on this context."""
+        n = C.c_uint64()
+        check(self.lib.alz_ctx_big_stream(self.h, min_bytes, C.byref(n)))
+        return n.value
+
     def release_scratch(self):
         """alz_ctx_release_scratch: return the grow-only staging / encoder scratch of the host-buffer calls to the device."""
         check(self.lib.alz_ctx_release_scratch(self.h))

@@ -1,0 +1,285 @@
+// alz_big.hip -- ONE big stream on the whole GPU: the three-cursor formats (Yay0, MIO0).
+//
+// The production kernels give a stream one wavefront (or two): a lone 256 KiB stream takes 0.8 ms, a lone 1 MiB stream 3 ms -- below the
+// 0.40-0.79 GiB/s the managed decoders reach on one CPU core (the reference's own benchmark is ONE 1 000 KiB stream,
+// Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42).  Yay0 (Nintendo/Yay0.cs:110-144) and MIO0 (Nintendo/MIO0.cs:105-149) keep their
+// flag bits, match tokens and literals in three separate sections, so nothing about a token depends on the tokens before it except three
+// COUNTS: how many match tokens came before (where its two bytes are), how many bytes of the literal section are used up (where its
+// literal / Yay0's length byte is), and how many bytes of output exist (where it writes).  Counts are prefix sums:
+//
+//   tiles of 1 024 tokens (one wavefront each)            single workgroup
+//   K1  matches per tile (popcount of the flag bytes)     S   exclusive scan over the tiles
+//   K3  literal-section bytes per tile (Yay0 only)        S
+//   K5  output bytes per tile                             S
+//   K7  every token knows its three cursors: it writes, for each of its output bytes, either the byte (a literal) or the POSITION the
+//       byte is copied from -- for a self-overlapping match (distance < length) the position in front of the token that holds the same
+//       pattern byte (start - d + (j mod d)), so a byte's source always lies in front of its token and a source "before the stream
+//       start" (E2) is the literal 0x00
+//   J   pointer jumping over the output bytes: an unresolved byte takes over its source's entry -- the byte (done) or the source's source
+//       (jump); after r rounds an entry spans >= 2^r hops, the depth of a chain is at most the number of tokens: ceil(log2 tokens) + 1
+//       rounds, launched as that many kernels that return at once when the round before changed nothing
+//   W   the bytes go to the destination; the stream's result is written
+//
+// Only a stream that is VALID gets its result from here -- every read inside the input, the output ending exactly at the declared size,
+// room for it in the destination.  Anything else (truncated, overshooting or undershooting streams, a short destination) opens a gate
+// and the exact production kernel, enqueued behind this path, decodes the stream again with the reference's error semantics; for a valid
+// stream it finds the gate closed and returns.  So the statuses, src_used and partial outputs of malformed streams are the production
+// kernels', and parity for them is theirs (tests/test_gpu_big_stream.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "alz_internal.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define BIG_TILE 1024u          /* tokens per tile (one wavefront, 16 rounds of 64 tokens) */
+#define BIG_LIT 0x80000000u
+
+struct BigArgs {
+    const u8* src; u8* dst;
+    u32 src_len, size, aux0, aux1;
+    u32 ntok;                   // tokens looked at: min(size, 8 x flag bytes the input can hold) -- an upper bound of the tokens of the stream
+    u32 ntiles;
+};
+
+// ctl words
+enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
+
+__device__ __forceinline__ u32 big_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 big_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 big_dpp_add(u32 v) { return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ u32 big_incl_scan(u32 v) {
+    v = big_dpp_add<0x111, 0xF>(v); v = big_dpp_add<0x112, 0xF>(v); v = big_dpp_add<0x114, 0xF>(v); v = big_dpp_add<0x118, 0xF>(v);
+    v = big_dpp_add<0x142, 0xA>(v); v = big_dpp_add<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ u32 big_total(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
+
+// One round of 64 tokens, token index t0 + lane.  Cursors on entry: matches / literal-section bytes before token t0.
+struct BigTok { bool lit, oob; u32 len, dist, byte, mafter, uafter; };   // mafter / uafter: the two cursors BEHIND this token
+template <bool MIO0, bool NEED_U>
+__device__ __forceinline__ BigTok big_round(const BigArgs& a, u32 t0, u32 mbase, u32 ubase, u32& mcount, u32& ucount) {
+    const u32 lane = big_lane();
+    const u32 t = t0 + lane;
+    const u32 fi = t >> 3;
+    BigTok k; k.oob = fi >= a.src_len;
+    const u32 fb = k.oob ? 0xFFu : a.src[fi];
+    k.lit = (fb >> (7u - (t & 7u))) & 1u;                       // MSB first, 1 = literal  Yay0.cs:118, MIO0.cs:123
+    const u64 lm = __builtin_amdgcn_ballot_w64(k.lit);
+    const u32 midx = mbase + big_mbcnt(~lm);
+    mcount = (u32)__popcll(~lm);
+    u32 b1 = 0, b2 = 0;
+    if (!k.lit) {
+        const u64 cp = (u64)a.aux0 + 2ull * midx;
+        if (cp + 2u > a.src_len) k.oob = true; else { b1 = a.src[cp]; b2 = a.src[cp + 1]; }
+    }
+    k.dist = (((b1 & 0xFu) << 8) | b2) + 1u;
+    k.mafter = midx + (k.lit ? 0u : 1u);
+    k.byte = 0; k.len = 1;
+    if (MIO0) {
+        const u32 uidx = t - midx;                              // literals before me = tokens before me - matches before me
+        ucount = 64u - mcount;
+        k.uafter = uidx + (k.lit ? 1u : 0u);
+        if (k.lit) { const u64 up = (u64)a.aux1 + uidx; if (up >= a.src_len) k.oob = true; else k.byte = a.src[up]; }
+        else k.len = (b1 >> 4) + 3u;
+    } else {
+        const bool usesu = k.lit || (b1 >> 4) == 0u;            // a 3-byte match takes its length from the literal section  Yay0.cs:130-131
+        const u64 um = __builtin_amdgcn_ballot_w64(usesu);
+        ucount = (u32)__popcll(um);
+        const u32 uidx = ubase + big_mbcnt(um);
+        k.uafter = uidx + (usesu ? 1u : 0u);
+        if (NEED_U) {
+            u32 ub = 0;
+            if (usesu) { const u64 up = (u64)a.aux1 + uidx; if (up >= a.src_len) k.oob = true; else ub = a.src[up]; }   // (the managed ReadByte() == -1 rule is the exact kernel's)
+            if (k.lit) k.byte = ub; else k.len = (b1 >> 4) ? (b1 >> 4) + 2u : ub + 0x12u;
+        }
+    }
+    return k;
+}
+
+// K1: match tokens per tile
+__global__ __launch_bounds__(64) void big_count_matches(BigArgs a, u32* __restrict__ tile_m) {
+    const u32 tile = blockIdx.x, lane = big_lane();
+    u32 cnt = 0;
+    // 128 flag bytes per tile, two per lane
+    for (u32 j = 0; j < 2u; j++) {
+        const u32 fi = tile * (BIG_TILE / 8u) + j * 64u + lane;
+        const u32 t = fi * 8u;
+        if (t < a.ntok) {
+            const u32 fb = fi < a.src_len ? a.src[fi] : 0xFFu;
+            u32 nb = a.ntok - t; if (nb > 8u) nb = 8u;
+            const u32 m = (~fb & 0xFFu) >> (8u - nb);            // the match bits of the tokens that exist (MSB first)
+            cnt += (u32)__popc(m);
+        }
+    }
+    const u32 tot = big_total(big_incl_scan(cnt));
+    if (lane == 0) tile_m[tile] = tot;
+}
+
+// S: exclusive scan over the tiles, one workgroup; total (u64 clamped to 2^32 - 1) behind the last element
+__global__ __launch_bounds__(1024) void big_scan(const u32* __restrict__ in, u32* __restrict__ out, u32 n, u32* __restrict__ total_out) {
+    __shared__ u64 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (n + 1023u) / 1024u;
+    const u32 b = tid * per, e = b + per < n ? b + per : n;
+    u64 s = 0;
+    for (u32 i = b; i < e; i++) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u64 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u64 run = tid ? part[tid - 1] : 0;
+    for (u32 i = b; i < e; i++) { out[i] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)run; run += in[i]; }
+    if (tid == 1023u && total_out) { const u64 t = part[1023]; *total_out = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)t; }
+}
+
+// K3 / K5: per tile, the sum of a per-token quantity: WHAT 0 = literal-section bytes (Yay0), 1 = output bytes
+template <bool MIO0, int WHAT>
+__global__ __launch_bounds__(64) void big_tile_sum(BigArgs a, const u32* __restrict__ tile_mb, const u32* __restrict__ tile_ub, u32* __restrict__ tile_out) {
+    const u32 tile = blockIdx.x, lane = big_lane();
+    u32 mbase = tile_mb[tile], ubase = (!MIO0 && WHAT == 1) ? tile_ub[tile] : 0u;
+    u32 acc = 0;
+    for (u32 r = 0; r < BIG_TILE / 64u; r++) {
+        const u32 t0 = tile * BIG_TILE + r * 64u;
+        if (t0 >= a.ntok) break;
+        u32 mc, uc;
+        const BigTok k = big_round<MIO0, WHAT == 1>(a, t0, mbase, ubase, mc, uc);
+        const bool exists = t0 + lane < a.ntok;
+        if (WHAT == 0) acc += uc;                                // (wave-uniform; tokens behind ntok only exist in the last tile, whose count feeds no base)
+        else acc += exists ? k.len : 0u;
+        mbase += mc; ubase += uc;
+    }
+    if (WHAT == 0) { if (lane == 0) tile_out[tile] = acc; }
+    else { const u32 tot = big_total(big_incl_scan(acc)); if (lane == 0) tile_out[tile] = tot; }
+}
+
+// K7: the entries of the output bytes
+template <bool MIO0>
+__global__ __launch_bounds__(64) void big_emit(BigArgs a, const u32* __restrict__ tile_mb, const u32* __restrict__ tile_ub, const u32* __restrict__ tile_ob,
+                                               u32* __restrict__ val, u32* __restrict__ ctl) {
+    const u32 tile = blockIdx.x, lane = big_lane();
+    u32 mbase = tile_mb[tile], ubase = MIO0 ? 0u : tile_ub[tile], obase = tile_ob[tile];
+    if (obase >= a.size) return;                                 // (also the clamped bases of tiles behind an absurd total)
+    for (u32 r = 0; r < BIG_TILE / 64u; r++) {
+        const u32 t0 = tile * BIG_TILE + r * 64u;
+        if (t0 >= a.ntok || obase >= a.size) break;
+        u32 mc, uc;
+        const BigTok k = big_round<MIO0, true>(a, t0, mbase, ubase, mc, uc);
+        const bool exists = t0 + lane < a.ntok;
+        const u32 end = big_incl_scan(exists ? k.len : 0u);
+        const u32 off = obase + end - (exists ? k.len : 0u);
+        const bool kept = exists && off < a.size;                // a token of the stream (the loop of the managed decoder runs while produced < size)
+        if (kept) {
+            if (k.oob) ctl[C_BAD] = 1u;                          // it read past the input: the exact kernel reports where
+            const u32 stop = off + k.len;
+            if (stop > a.size) ctl[C_BAD] = 1u;                  // the last match overshoots the declared size (E4): the exact kernel's case
+            else if (stop == a.size) {                           // the stream ends here: source.Position = the further of the two cursors  Yay0.cs:107, MIO0.cs:148
+                const u32 cu = a.aux0 + 2u * k.mafter, uu = a.aux1 + k.uafter;
+                ctl[C_USED] = cu > uu ? cu : uu; ctl[C_END] = 1u;
+            }
+            if (k.lit) val[off] = BIG_LIT | k.byte;
+            else {
+                const u32 n = stop > a.size ? a.size - off : k.len;
+                u32 rr = 0;
+                for (u32 j = 0; j < n; j++) {                    // byte j copies start - d + (j mod d): the pattern in front of the token
+                    const u32 s = off + rr - k.dist;             // (wraps below zero in front of the stream start: E2 reads 0x00)
+                    val[off + j] = off + rr >= k.dist ? s : BIG_LIT;
+                    if (++rr == k.dist) rr = 0;
+                }
+            }
+        }
+        obase += big_total(end); mbase += mc; ubase += uc;
+    }
+}
+
+// J: one round of pointer jumping; flags[r] says whether round r left anything unresolved (flags[-1] of round 0 is preset to 1)
+__global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, const u32* __restrict__ flag_prev, u32* __restrict__ flag_cur) {
+    if (__builtin_nontemporal_load(flag_prev) == 0u) return;
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= n) return;
+    const u32 v = val[q];
+    if (v & BIG_LIT) return;
+    const u32 w = __hip_atomic_load(val + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    val[q] = w;
+    if (!(w & BIG_LIT)) *flag_cur = 1u;
+}
+
+// W: bytes out, result, gate
+__global__ __launch_bounds__(256) void big_write(BigArgs a, const u32* __restrict__ val, const u32* __restrict__ ctl, alz_result* __restrict__ result, u32* __restrict__ gate) {
+    const bool ok = ctl[C_BAD] == 0u && ctl[C_END] == 1u && ctl[C_TOTAL] >= a.size;
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (q == 0) {
+        if (ok) { alz_result r; r.dst_len = a.size; r.src_used = ctl[C_USED]; r.status = ALZ_ST_OK; r.reserved = 0; *result = r; *gate = 0u; }
+        else *gate = 1u;
+    }
+    if (!ok || q >= a.size) return;
+    a.dst[q] = (u8)val[q];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+static u32 big_ntok(const alz_stream& st) {
+    const u64 by_flags = 8ull * st.src_len;
+    return (u32)(by_flags < st.decom_len ? by_flags : st.decom_len);
+}
+static u32 big_rounds(u32 ntok) { u32 r = 1; while ((1ull << r) < ntok) r++; return r + 1u; }
+
+bool alz_big_eligible(int fmt, const alz_stream* st, uint32_t min_bytes) {
+    if (fmt != ALZ_FMT_YAY0 && fmt != ALZ_FMT_MIO0) return false;
+    if (st->decom_len < min_bytes || st->decom_len > 0x40000000u) return false;
+    if (st->dst_cap < st->decom_len || st->src_len == 0) return false;
+    if (st->aux0 > st->src_len || st->aux1 > st->src_len) return false;
+    return true;
+}
+
+size_t alz_big_scratch_bytes(const alz_stream* st) {
+    const u32 ntok = big_ntok(*st);
+    const size_t ntiles = (ntok + BIG_TILE - 1) / BIG_TILE;
+    return (size_t)st->decom_len * 4 + 6 * ((ntiles + 64) * 4) + (C_FLAGS + 40) * 4 + 256;
+}
+
+hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
+                          void* d_scratch, uint32_t* d_gate) {
+    BigArgs a;
+    a.src = (const u8*)d_src_base + st->src_off; a.dst = (u8*)d_dst_base + st->dst_off;
+    a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = st->aux0; a.aux1 = st->aux1;
+    a.ntok = big_ntok(*st);
+    a.ntiles = (a.ntok + BIG_TILE - 1) / BIG_TILE;
+    const size_t tl = ((size_t)a.ntiles + 64) * 4;
+    u8* p = (u8*)d_scratch;
+    u32* val = (u32*)p; p += (size_t)a.size * 4;
+    u32* tile_m = (u32*)p; p += tl; u32* tile_mb = (u32*)p; p += tl;
+    u32* tile_u = (u32*)p; p += tl; u32* tile_ub = (u32*)p; p += tl;
+    u32* tile_l = (u32*)p; p += tl; u32* tile_ob = (u32*)p; p += tl;
+    u32* ctl = (u32*)p;
+    const u32 rounds = big_rounds(a.ntok);
+    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
+    if (e != hipSuccess) return e;
+    const bool mio0 = fmt == ALZ_FMT_MIO0;
+    hipLaunchKernelGGL(big_count_matches, dim3(a.ntiles), dim3(64), 0, stream, a, tile_m);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_m, tile_mb, a.ntiles, (u32*)nullptr);
+    if (!mio0) {
+        hipLaunchKernelGGL((big_tile_sum<false, 0>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_u);
+        hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_u, tile_ub, a.ntiles, (u32*)nullptr);
+        hipLaunchKernelGGL((big_tile_sum<false, 1>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_l);
+    } else {
+        hipLaunchKernelGGL((big_tile_sum<true, 1>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_l);
+    }
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_l, tile_ob, a.ntiles, ctl + C_TOTAL);
+    if (mio0) hipLaunchKernelGGL((big_emit<true>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_ob, val, ctl);
+    else hipLaunchKernelGGL((big_emit<false>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_ob, val, ctl);
+    // round 0 always runs: its "previous flag" is a word that holds 1
+    e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
+    if (e != hipSuccess) return e;
+    const u32 nb = (a.size + 255u) / 256u;
+    for (u32 r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, a.size, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
+    hipLaunchKernelGGL(big_write, dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    return hipGetLastError();
+}

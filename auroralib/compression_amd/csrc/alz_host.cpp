@@ -107,6 +107,9 @@ struct alz_ctx {
     float last_kernel_ms = 0.f;                // device time of the kernels of the last timed / encode call (HIP events on the launch stream)
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
     int variant = 0;                           // alz_ctx_set_kernel_variant
+    uint32_t big_min = 96u << 10;              // a lone Yay0 / MIO0 stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
+    uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
+    void* d_bigbuf = nullptr; size_t d_bigbuf_cap = 0;   // its scratch for the plans of the host-buffer entry points (grow-only)
     // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
     // one piece overlaps the PCIe transfer of the other
     void* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0;
@@ -135,6 +138,8 @@ struct alz_plan {
     uint32_t fmt_off[ALZ_FMT_COUNT] = {0};
     uint32_t fmt_cnt[ALZ_FMT_COUNT] = {0};
     bool borrowed = false;                  // the three device arrays live in the context's plan scratch (host-buffer entry points)
+    // ONE big Yay0 / MIO0 stream: decoded by the whole GPU (alz_big.hip), the production kernel behind it only if that path declines
+    bool big = false, big_borrowed = false; alz_stream big_stream{}; void* d_big = nullptr; uint32_t* d_gate = nullptr;
 };
 
 static alz_lz_properties effective_lz(const alz_lz_properties* p) {
@@ -148,6 +153,12 @@ static alz_lz_properties effective_lz(const alz_lz_properties* p) {
 extern "C" {
 
 int alz_abi_version(void) { return ALZ_ABI_VERSION; }
+int alz_ctx_big_stream(alz_ctx* c, uint32_t min_bytes, uint64_t* launches_out) {
+    if (!c) return fail(ALZ_E_INVALID, "alz_ctx_big_stream: ctx is NULL");
+    if (min_bytes) c->big_min = min_bytes;
+    if (launches_out) *launches_out = c->big_launches;
+    return ALZ_OK;
+}
 int alz_ctx_set_kernel_variant(alz_ctx* c, int variant) {
     if (!c || variant < 0 || variant > 2) return fail(ALZ_E_INVALID, "alz_ctx_set_kernel_variant: bad argument");
     c->variant = variant;
@@ -266,6 +277,7 @@ void alz_plan_destroy(alz_ctx* c, alz_plan* p) {
         if (p->d_results) (void)hipFree(p->d_results);
         if (p->d_index) (void)hipFree(p->d_index);
     }
+    if (p->d_big && !p->big_borrowed) (void)hipFree(p->d_big);
     delete p;
 }
 
@@ -320,6 +332,13 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
     if (e == hipSuccess) e = hipMemsetAsync(p->d_results, 0xFF, nn * sizeof(alz_result), c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
+    if (n == 1 && !c->exact && c->variant == 0 && alz_big_eligible((int)streams[0].format, &streams[0], c->big_min)) {
+        // (its scratch -- 4 bytes per output byte -- belongs to the plan; when it cannot be had the production kernel decodes the stream alone)
+        const size_t need = alz_big_scratch_bytes(&streams[0]) + 64;
+        if (scratch) { if (grow(c, &c->d_bigbuf, &c->d_bigbuf_cap, need) == ALZ_OK) { p->d_big = c->d_bigbuf; p->big_borrowed = true; } }
+        else if (hipMalloc(&p->d_big, need) != hipSuccess) { p->d_big = nullptr; (void)hipGetLastError(); }
+        if (p->d_big) { p->big = true; p->big_stream = streams[0]; p->d_gate = (uint32_t*)((uint8_t*)p->d_big + need - 64); }
+    }
     *out = p;
     return ALZ_OK;
 }
@@ -344,6 +363,14 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
     HIP_TRY(hipSetDevice(c->device));                 // (a host thread may hold contexts of several devices)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (p->big && !c->exact && c->variant == 0) {
+        const int f = (int)p->big_stream.format;
+        hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_stream, p->d_results, p->d_big, p->d_gate);
+        if (e == hipSuccess) e = alz_launch_decode_gated(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], 1, p->d_results, &p->lz, p->d_gate);
+        if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream launch (format %d) failed: %s", f, hipGetErrorString(e));
+        c->big_launches++;
+        return ALZ_OK;
+    }
     int nfmt = 0;
     for (int f = 0; f < ALZ_FMT_COUNT; f++) nfmt += p->fmt_cnt[f] ? 1 : 0;
     if (nfmt <= 1) {
@@ -668,9 +695,9 @@ struct EncScratch {
 };
 static void release_scratch(alz_ctx* c) {
     for (int k = 0; k < 12; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
-    void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan};
-    size_t* caps[] = {&c->d_src_cap, &c->d_dst_cap, &c->d_items_cap, &c->d_pack_cap, &c->d_plan_cap};
-    for (int i = 0; i < 5; i++) { if (*bufs[i]) (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
+    void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan, &c->d_bigbuf};
+    size_t* caps[] = {&c->d_src_cap, &c->d_dst_cap, &c->d_items_cap, &c->d_pack_cap, &c->d_plan_cap, &c->d_bigbuf_cap};
+    for (int i = 0; i < 6; i++) { if (*bufs[i]) (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
 }
 int alz_ctx_release_scratch(alz_ctx* c) {
     if (!c) return fail(ALZ_E_INVALID, "ctx is NULL");

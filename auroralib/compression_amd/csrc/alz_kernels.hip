@@ -148,7 +148,8 @@ template <int FMT, int LWMAX = 4096, bool FBK = false>
 __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                              const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, u32 count,
-                                                             alz_result* __restrict__ results, alz_lz_properties lz, u32 lw) {
+                                                             alz_result* __restrict__ results, alz_lz_properties lz, u32 lw, const u32* __restrict__ gate) {
+    if (gate != nullptr && __builtin_nontemporal_load(gate) == 0u) return;   // (alz_launch_decode_gated: nothing to do unless the word is set)
     constexpr bool SMSR = (FMT == ALZ_FMT_SMSR00);                    // code stream + literal stream
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0 || SMSR);   // (several input cursors: small caches)
     constexpr int NC = SMSR ? 2 : (THREE ? 3 : 1);
@@ -567,7 +568,8 @@ __global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restr
 // its three cursors at the end.
 template <int FMT>
 __global__ __launch_bounds__(128) void alz_decode_fast2c_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
-                                                                const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, u32 lw) {
+                                                                const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, u32 lw, const u32* __restrict__ gate) {
+    if (gate != nullptr && __builtin_nontemporal_load(gate) == 0u) return;   // (alz_launch_decode_gated)
     constexpr u32 CHUNK = 256u, CACHE = ALZ_INCACHE_SMALL, FSCR = 128u, LWMAX = 4096u;
     __shared__ __attribute__((aligned(16))) u8 lds[FSCR + 3u * CACHE + LWMAX + 3u * CACHE + 2u * ALZ_MBOX_WORDS * 4u];
     const u32 bid = blockIdx.x;
@@ -876,7 +878,7 @@ static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, cons
 
 template <int FMT, int LWMAX = 4096, bool FBK = false>
 static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
-                              alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches) {
+                              alz_result* results, const alz_lz_properties& lz, u32 lw, int ncaches, const u32* gate = nullptr) {
     (void)ncaches;
     // launches that cannot fill the GPU with one wavefront per stream: two per stream (alz_decode_fast2_kernel)
     if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40 || FMT == ALZ_FMT_CLZ0 || FMT == ALZ_FMT_YAZ0)) {
@@ -887,11 +889,11 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
     }
     if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0)) {
         if (fast_two_waves()) {
-            hipLaunchKernelGGL((alz_decode_fast2c_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lw);
+            hipLaunchKernelGGL((alz_decode_fast2c_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lw, gate);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), 0, stream, src, dst, streams, index, count, results, lz, lw);
+    hipLaunchKernelGGL((alz_decode_fast_kernel<FMT, LWMAX, FBK>), dim3((count + ALZ_WPB - 1) / ALZ_WPB), dim3(64 * ALZ_WPB), 0, stream, src, dst, streams, index, count, results, lz, lw, gate);
     return hipGetLastError();
 }
 
@@ -947,6 +949,14 @@ int alz_kernel_occupancy(int fmt) {
     default: break;
     }
     return e == hipSuccess ? n : -1;
+}
+
+hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
+                                   u32 count, alz_result* results, const alz_lz_properties* lzp, const u32* gate) {
+    t_batch_total = count; t_variant = 0;
+    if (fmt == ALZ_FMT_YAY0) return launch_fast<ALZ_FMT_YAY0>(stream, (const u8*)src, (u8*)dst, streams, index, count, results, *lzp, 4096, 3, gate);
+    if (fmt == ALZ_FMT_MIO0) return launch_fast<ALZ_FMT_MIO0>(stream, (const u8*)src, (u8*)dst, streams, index, count, results, *lzp, 4096, 3, gate);
+    return hipErrorInvalidValue;
 }
 
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,

@@ -16,7 +16,7 @@ PY
 )"
 FLAGS="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-inline-asm"
 mkdir -p "$HERE/_obj"
-for f in alz_kernels.hip alz_encode.hip alz_host.cpp alz_container.cpp; do
+for f in alz_kernels.hip alz_encode.hip alz_big.hip alz_host.cpp alz_container.cpp; do
   [ -f "$HERE/$f" ] || continue
   o="$HERE/_obj/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ -n "$(find "$HERE" "$ROOT/include" -maxdepth 1 -name '*.h' -newer "$o" 2>/dev/null)" ]; then

@@ -87,6 +87,7 @@ namespace AuroraLib.Compression.Amd
         [DllImport(Lib)] internal static extern IntPtr alz_last_error();
         [DllImport(Lib)] internal static extern int alz_ctx_set_exact_kernels(IntPtr ctx, int on);
         [DllImport(Lib)] internal static extern int alz_ctx_release_scratch(IntPtr ctx);
+        [DllImport(Lib)] internal static extern int alz_ctx_big_stream(IntPtr ctx, uint minBytes, ulong* launchesOut);
 
         // one stream: backs Decompress(Stream, Stream) of one format class
         [DllImport(Lib)] internal static extern int alz_decode(IntPtr ctx, uint format, AlzLzProperties* props,

@@ -1,0 +1,138 @@
+"""-m gpu: ONE big Yay0 / MIO0 stream on the whole GPU (csrc/alz_big.hip, alz_ctx_big_stream) against the oracle.
+
+A batch of one stream of >= 96 KiB goes through prefix sums over its three sections and pointer jumping over its output bytes instead of
+through one or two wavefronts.  Valid streams must come out bit-exact with status / dst_len / src_used of the oracle; every malformed
+stream (truncated, overshooting, undershooting, short destination, cursors outside the input) must come out exactly as the exact kernel
+behind the path decodes it -- the path may only ever DECLINE such a stream.  The device-resident cases compare the whole destination buffer
+(0xA5 canary, guard regions), as tests/test_gpu_canary.py does."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from auroralib.compression_amd import _abi as A
+from auroralib.compression_amd import synth
+from auroralib.compression_amd.batch import Context, Plan
+
+pytestmark = pytest.mark.gpu
+FMTS = [A.FMT_YAY0, A.FMT_MIO0]
+OFF = 0xFFFFFFFF
+
+
+def _one(c, fmt, comp, decom_len, aux0, aux1, cap=None, expect_big=None, what=""):
+    """The stream through alz_decode (host buffers) and through a device-resident plan with a canary; both against the oracle."""
+    cap = decom_len if cap is None else cap
+    want, wr = O.decode_stream(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1)
+    before = c.big_stream()
+    got, r = c.decode(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1)
+    took = c.big_stream() - before
+    assert (r.status, r.dst_len) == (wr.status, wr.dst_len), (what, r.status, r.dst_len, wr.status, wr.dst_len)
+    if wr.status != A.ST_OUTPUT_CAPACITY:
+        assert r.src_used == wr.src_used, (what, r.src_used, wr.src_used)
+    assert got == want, what
+    if expect_big is not None:
+        assert (took > 0) == expect_big, (what, took)
+    # device-resident, whole buffer
+    G = 4096
+    src = np.frombuffer(bytes(comp) + bytes(64), dtype=np.uint8)
+    st = (A.Stream * 1)(A.Stream(0, 0, len(comp), cap, decom_len, aux0, aux1, fmt))
+    d_src, d_dst = c.malloc(src.nbytes), c.malloc(G + cap + G)
+    try:
+        c.h2d(d_src, src); c.memset(d_dst, 0xA5, G + cap + G)
+        p = Plan(c, st)
+        p.execute(d_src, C.c_void_p(d_dst.value + G))
+        pr = p.results()[0]
+        buf = c.d2h(d_dst, G + cap + G)
+        p.close()
+    finally:
+        c.free(d_src); c.free(d_dst)
+    assert (pr.status, pr.dst_len) == (wr.status, wr.dst_len), what
+    exp = np.full(G + cap + G, 0xA5, dtype=np.uint8)
+    exp[G:G + len(want)] = np.frombuffer(want, dtype=np.uint8)
+    assert np.array_equal(buf, exp), (what, int((buf != exp).sum()), int(np.flatnonzero(buf != exp)[0]) - G)
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_whole_test_bmp_as_one_stream(fmt, test_bmp):
+    """The reference's benchmark shape: one ~1 MiB stream (Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42), Q0 and the default Q8."""
+    with Context(0) as c:
+        for q in (0, 8):
+            comp, aux = O.encode_stream(fmt, test_bmp, quality=q)
+            _one(c, fmt, comp, len(test_bmp), aux.aux0, aux.aux1, expect_big=True, what="bmp q%d" % q)
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_synthetic_sizes_and_the_threshold(fmt):
+    """Sizes on both sides of the 96 KiB threshold, tile boundaries (1 024 tokens), 4 MiB; the path must be taken from the threshold on
+    and never below it, nor on contexts with forced kernels."""
+    with Context(0) as c:
+        for size in (98303, 98304, 100000, 131072 + 5, 262144, 1 << 20, (1 << 22) + 3):
+            b = synth.make_batch(fmt, 1, size, synth.seed_for(30 + fmt, size))
+            s = b.streams[0]
+            comp = bytes(b.src[s.src_off:s.src_off + s.src_len])
+            _one(c, fmt, comp, size, s.aux0, s.aux1, expect_big=size >= 98304, what="synthetic %d" % size)
+        b = synth.make_batch(fmt, 1, 300000, 7)
+        s = b.streams[0]
+        comp = bytes(b.src[s.src_off:s.src_off + s.src_len])
+        c.big_stream(OFF)
+        _one(c, fmt, comp, 300000, s.aux0, s.aux1, expect_big=False, what="switched off")
+        c.big_stream(64 << 10)
+        c.set_kernel_variant(1)
+        _one(c, fmt, comp, 300000, s.aux0, s.aux1, expect_big=False, what="forced variant")
+        c.set_kernel_variant(0)
+        c.set_exact_kernels(1)
+        _one(c, fmt, comp, 300000, s.aux0, s.aux1, expect_big=False, what="exact kernels")
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_degenerate_data(fmt):
+    """Runs (every byte a copy at distance 1: the deepest pointer chains), short periods, all literals, zeros."""
+    rng = np.random.default_rng(3)
+    raws = [bytes(400000), b"\xAB" * 300001, b"abc" * 100000, bytes(rng.integers(0, 256, 150000, dtype=np.uint8)),
+            bytes(rng.integers(0, 256, 5000, dtype=np.uint8)) * 60, b"".join(bytes([i & 255]) * (1 + i % 300) for i in range(2000))]
+    with Context(0) as c:
+        for k, raw in enumerate(raws):
+            for q in (0, 8):
+                comp, aux = O.encode_stream(fmt, raw, quality=q)
+                _one(c, fmt, comp, len(raw), aux.aux0, aux.aux1, expect_big=True, what="degenerate %d q%d" % (k, q))
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_malformed_streams_fall_through_to_the_exact_kernel(fmt, test_bmp):
+    """The path declines; what comes out is the production kernel's answer = the oracle's."""
+    import random
+    rng = random.Random(5 + fmt)
+    raw = test_bmp[:300000]
+    comp, aux = O.encode_stream(fmt, raw, quality=8)
+    n = len(raw)
+    with Context(0) as c:
+        cases = [(comp[:len(comp) // 2], n, n, aux.aux0, aux.aux1, "truncated input"),
+                 (comp[:len(comp) - 1], n, n, aux.aux0, aux.aux1, "one byte short"),
+                 (comp, n - 1000, n, aux.aux0, aux.aux1, "declared size too small (overshoot)"),
+                 (comp, n - 1, n - 1, aux.aux0, aux.aux1, "declared size one too small"),
+                 (comp, n + 5000, n + 5000, aux.aux0, aux.aux1, "declared size too large"),
+                 (comp, n, n - 4097, aux.aux0, aux.aux1, "short destination"),
+                 (comp, n, n, aux.aux0 + 2, aux.aux1, "token cursor off by one token"),
+                 (comp, n, n, aux.aux0, aux.aux1 + 1, "literal cursor off by one"),
+                 (comp, n, n, len(comp) + 7, aux.aux1, "token section outside the input"),
+                 (comp, n, n, aux.aux0, len(comp), "literal section at the end of the input"),
+                 (comp, n, n, 0, 0, "all three sections on top of each other")]
+        for _ in range(12):
+            b = bytearray(comp)
+            for _ in range(rng.randrange(1, 5)):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            cases.append((bytes(b), n, n, aux.aux0, aux.aux1, "bit flips"))
+        cases.append((bytes(rng.randrange(256) for _ in range(120000)), n, n, 20000, 60000, "noise"))
+        for src, decl, cap, a0, a1, what in cases:
+            _one(c, fmt, src, decl, a0, a1, cap=cap, what=what)
+
+
+def test_the_format_classes_reach_it(test_bmp):
+    """Decompress of the Yay0 / MIO0 classes of the host mirror (= ICompressionDecoder.Decompress on one file) takes the path."""
+    from auroralib.compression_amd import formats as F
+    for cls, cont in ((F.Yay0, A.C_YAY0), (F.MIO0, A.C_MIO0)):
+        comp = O.container_compress(cont, test_bmp, quality=8)
+        before = F._context().big_stream()
+        assert cls().Decompress(comp) == test_bmp
+        assert F._context().big_stream() > before, cls.__name__
