@@ -11,7 +11,8 @@ figure with two batches in flight (the tail of one launch overlapping the head o
 On one GPU the same JSON line also carries (rank 0, skipped with --configs none):
   configs       BASELINE.json configs[1..4] at their stated sizes (cfg2 Yaz0 10 000 x 64 KiB, cfg3 LZ4 100 000 x 256 KiB, one
                 GPU's shard of cfg4 = 5 000 mixed LZ10/LZ11/Yaz0/PRS streams, cfg5 compression as LZSS at Q0 / Q8 / Q15 and as
-                Yaz0 / LZ4 at Q0 / Q8), every other decode body of north_star on the headline's shape (body_<format>), and the
+                Yaz0 / LZ4 at Q0 / Q8), every other decode body of north_star on the headline's shape (body_<format>), ONE 1 000 KiB
+                stream of Test.bmp as Yay0 / MIO0 (the reference's own benchmark shape: single_<format>_q<Q>), and the
                 "realistic" data set of SURVEY.md 8d (the 256 KiB windows of the reference's Test.bmp, GPU-encoded), each
                 with its own roofline object from HIP events on the launch stream
   copy_bandwidth  a measured device-to-device copy (second roofline denominator)
@@ -579,7 +580,7 @@ def run_extras(ctx, batch, recs, n, target, decomp_bytes, np, synth, A):
 
 
 def run_configs(args, ctx, np, A, synth, Plan, Context):
-    want = ["cfg2", "cfg3", "cfg4", "cfg5", "bodies", "realistic"] if args.configs == "all" else args.configs.split(",")
+    want = ["cfg2", "cfg3", "cfg4", "cfg5", "bodies", "realistic", "single"] if args.configs == "all" else args.configs.split(",")
     out = []
     steps = max(3, min(args.steps, 10))
     try:
@@ -608,6 +609,8 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             # per north-star format, as 256 KiB windows
             for f in ("yaz0", "lz10", "lz11", "prs_be", "lz4_block"):
                 out.append(realistic(ctx, np, A, synth, Plan, steps, f))
+        if "single" in want:
+            out.extend(single_stream(ctx, np, A, synth, Plan))
     except Exception as e:                                   # report what ran; the headline line must still come out
         out.append({"name": "error", "error": repr(e)})
     return out
@@ -723,6 +726,59 @@ def cfg5(ctx, np, A, synth, Plan):
             ctx.free(d_back)
         raw_db.close()
         ctx.release_scratch()                                  # (the encoder's grow-only scratch: ~20 GB at Q8; the configurations behind this one start clean)
+    return out
+
+
+# Benchmarks.md (BenchmarkDotNet, Ryzen 7 3800X, .NET 8, one thread): MB/s of Decompress on the first 1 000 KiB of Test.bmp, Q0- / Q15-encoded input
+PUBLISHED_SINGLE = {("yay0", 0): (470.82, "Benchmarks.md:78"), ("yay0", 15): (824.11, "Benchmarks.md:80"),
+                    ("mio0", 0): (419.93, "Benchmarks.md:70"), ("mio0", 15): (419.39, "Benchmarks.md:72")}
+
+
+def single_stream(ctx, np, A, synth, Plan):
+    """The reference's OWN benchmark shape (Benchmarks/Benchmarks/TestAllAlgorithms.cs:37-69): ONE stream = the first 1 000 KiB of
+    Test.bmp, compressed at quality 0 / 15, then Decompress timed -- for the two formats whose single streams run on the whole GPU
+    (Yay0 / MIO0, csrc/alz_big.hip).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
+    class's Decompress(Stream, Stream) costs), `device_GiB_s` = the kernels alone; beside them the managed figure the reference
+    publishes for this exact input on its own machine (another CPU, no GPU: context, not a baseline measured here)."""
+    from auroralib.compression_amd import formats as F
+    lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
+    bmp = lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read())
+    raw = bytes(bmp[:1024000]); n = len(raw)
+    out = []
+    for fname in ("yay0", "mio0"):
+        fmt = A.FORMAT_NAMES.index(fname)
+        for q in (0, 15):
+            cap = n + n // 4 + 64
+            es = (A.Stream * 1)(A.Stream(0, 0, n, cap, 0, 0, 0, fmt))
+            enc, eres, eaux = ctx.encode_batch(es, np.frombuffer(raw + bytes(64), dtype=np.uint8), cap + 64, quality=q)
+            comp = bytes(enc[:eres[0].dst_len]); a0, a1 = eaux[0].aux0, eaux[0].aux1
+            st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, n, a0, a1, fmt))
+            d_src, d_dst = ctx.malloc(len(comp) + 64), ctx.malloc(n + 64)
+            try:
+                ctx.h2d(d_src, np.frombuffer(comp + bytes(64), dtype=np.uint8))
+                before = ctx.big_stream()
+                p = Plan(ctx, st)
+                p.execute(d_src, d_dst); ctx.synchronize()
+                dev_ms = p.execute_timed(d_src, d_dst, iters=20)
+                ok = p.results()[0].status == 0 and bytes(ctx.d2h(d_dst, n)) == raw
+                p.close()
+                whole_gpu = ctx.big_stream() > before
+            finally:
+                ctx.free(d_src); ctx.free(d_dst)
+            got, r = ctx.decode(fmt, comp, decom_len=n, aux0=a0, aux1=a1)
+            reps, t0 = 20, time.perf_counter()
+            for _ in range(reps):
+                got, r = ctx.decode(fmt, comp, decom_len=n, aux0=a0, aux1=a1)
+            wall_ms = (time.perf_counter() - t0) / reps * 1e3
+            ok = ok and r.status == 0 and got == raw
+            pub, where = PUBLISHED_SINGLE[(fname, q)]
+            out.append({"name": "single_%s_q%d" % (fname, q),
+                        "workload": "ONE %s stream: Test.bmp[0:1 024 000] compressed at quality %d (ratio %.4f), the reference's benchmark shape; alz_decode on host buffers"
+                                    % (fname, q, len(comp) / n),
+                        "value": round(n / (wall_ms * 1e-3) / 2**30, 3), "unit": "GiB/s", "ms_per_call": round(wall_ms, 4),
+                        "device_GiB_s": round(n / (dev_ms * 1e-3) / 2**30, 3), "kernel_ms": round(dev_ms, 4), "whole_gpu_path": whole_gpu, "parity_ok": ok,
+                        "published_managed": {"MB_per_s": pub, "GiB_s": round(pub * 1e6 / 2**30, 3), "where": where,
+                                              "hardware": "AMD Ryzen 7 3800X, .NET 8, one thread (BenchmarkDotNet); not measured here"}})
     return out
 
 

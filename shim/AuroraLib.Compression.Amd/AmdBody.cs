@@ -118,6 +118,10 @@ namespace AuroraLib.Compression.Amd
         /// <summary>True when a single stream of this size should run on the GPU rather than on the managed body.</summary>
         internal static bool UseGpu(uint decomLength) => AmdContext.Available && decomLength >= AmdContext.SingleStreamThreshold;
 
+        /// <summary>The same for ONE Yay0 / MIO0 stream, which the native library decodes on the whole GPU (alz_ctx_big_stream).</summary>
+        internal static bool UseGpuThreeSections(uint decomLength)
+            => AmdContext.Available && decomLength >= Math.Min(AmdContext.SingleStreamThreshold, AmdContext.BigStreamThreshold);
+
         /// <summary>True when ONE buffer should be compressed by the native encoder.  A caller's <c>MaxWindowBits</c> only ever WIDENS
         /// the managed finder (LzChainMatchFinder.cs:69-73): within the format's own window it changes nothing and the native
         /// encoder takes it; beyond it (where the managed finder returns distances the format cannot store) the call stays managed,

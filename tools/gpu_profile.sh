@@ -5,7 +5,7 @@ NAME=$1; FMT=$2; shift 2
 export TMPDIR=/tmp
 D=gpurun_out/prof_$NAME
 rm -rf $D; mkdir -p $D
-B="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify --no-extras --configs none --inflight 1 --format $FMT $@"
+B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify --no-extras --configs none --inflight 1 --format $FMT $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $B > $D/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- $B > $D/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- $B > $D/write.log 2>&1

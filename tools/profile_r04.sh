@@ -9,7 +9,7 @@ for f in ${@:-yaz0 lz10 lz11 yay0 mio0 lzss prs_be lz4_block lzo snappy_raw mixe
 done
 while read key fmt n kib extra; do
   D=gpurun_out/prof_r04_$key; rm -rf $D; mkdir -p $D
-  B="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify --no-extras --configs none --inflight 1 --format $fmt --streams $n --stream-kib $kib $extra"
+  B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-verify --no-extras --configs none --inflight 1 --format $fmt --streams $n --stream-kib $kib $extra"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $B > $D/stats.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- $B > $D/fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- $B > $D/write.log 2>&1
