@@ -223,31 +223,277 @@ __global__ __launch_bounds__(256) void big_write(BigArgs a, const u32* __restric
     a.dst[q] = (u8)val[q];
 }
 
+// ===============================================================================================================
+// The interleaved flag-byte formats (LZSS, LZ10, LZ11, Yaz0): flag bytes, literals and match tokens share ONE byte stream, so where a
+// group of eight tokens starts is only known once the group before it has been sized -- a linked list through the input.  But what a
+// group that started at byte p WOULD occupy is a pure function of the bytes behind p (the speculation the wavefront kernels run per lane,
+// alz_decode_fast.h), so:
+//
+//   P1  next[p] = p + size of "the group that starts at p", for EVERY input byte p
+//   P2  list ranking: the real group starts are the nodes reachable from 0.  Round k marks jump[p] for every marked p and squares the
+//       jump table (jump' = jump o jump, double-buffered: a round must see jumps of exactly 2^k hops, or nodes are skipped); after
+//       ceil(log2 groups) rounds every real start is marked (and the garbage "groups" behind the end of the stream, which the cut at
+//       the declared size never reaches)
+//   P3  prefix sums over the marks number the groups; P4 one thread per group decodes its eight tokens into (length, descriptor, end)
+//   P5  prefix sums over the lengths place the tokens in the output; P6 one thread per OUTPUT BYTE finds its token by binary search and
+//       writes its entry (the byte, or the position it copies from); then the pointer jumping and the write-out of the three-cursor path.
+struct BigGeom { u32 length_bits, min_length, windows_start, max_distance, W; };
+template <int FMT> struct BigFam;
+template <> struct BigFam<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT1 = true,  H3 = false, H4 = false; };   // LZSS.cs:95-119
+template <> struct BigFam<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false; };   // LZ10.cs:88-102
+template <> struct BigFam<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true;  };   // LZ11.cs:88-118
+template <> struct BigFam<ALZ_FMT_YAZ0> { static constexpr bool MSB = true,  LIT1 = true,  H3 = true,  H4 = false; };   // Yay0.cs:118-133 on one cursor
+
+#define BIG_OOB 0x40000000u
+enum { C_NG = 4, C_NT = 5 };
+
+template <int FMT>
+__device__ __forceinline__ u32 big_match_bits(u32 fb) { return BigFam<FMT>::LIT1 ? (~fb & 0xFFu) : fb; }
+template <int FMT>
+__device__ __forceinline__ bool big_is_match(u32 mbits, u32 k) { return (mbits >> (BigFam<FMT>::MSB ? 7u - k : k)) & 1u; }
+template <int FMT>
+__device__ __forceinline__ u32 big_token_size(const u8* src, u32 src_len, u32 pos, bool m) {
+    typedef BigFam<FMT> TR;
+    if (!m) return 1u;
+    if (!TR::H3 && !TR::H4) return 2u;
+    const u32 nib = pos < src_len ? (u32)src[pos] >> 4 : 0xFu;
+    if (TR::H3 && nib == 0u) return 3u;
+    if (TR::H4 && nib == 1u) return 4u;
+    return 2u;
+}
+
+// P1
+template <int FMT>
+__global__ __launch_bounds__(256) void big_group_sizes(const u8* __restrict__ src, u32 src_len, u32* __restrict__ next) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p > src_len) return;
+    if (p == src_len) { next[p] = src_len; return; }             // the end node points at itself
+    const u32 mbits = big_match_bits<FMT>(src[p]);
+    u32 r = 1;
+    if (!BigFam<FMT>::H3 && !BigFam<FMT>::H4) r = 9u + (u32)__popc(mbits);
+    else for (u32 k = 0; k < 8u; k++) r += big_token_size<FMT>(src, src_len, p + r, big_is_match<FMT>(mbits, k));
+    const u64 n = (u64)p + r;
+    next[p] = n > src_len ? src_len : (u32)n;
+}
+
+// P2: one round of list ranking
+__global__ __launch_bounds__(256) void big_rank_round(const u32* __restrict__ jump_a, u32* __restrict__ jump_b, u8* __restrict__ mark, u32 nodes) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= nodes) return;
+    const u32 j = jump_a[p];
+    if (mark[p]) mark[j] = 1;
+    jump_b[p] = jump_a[j];
+}
+
+// P3: marked positions per tile of 1 024 input bytes; after the scan, the group's number -> its position
+__global__ __launch_bounds__(64) void big_mark_count(const u8* __restrict__ mark, u32 src_len, u32* __restrict__ tile_c) {
+    const u32 tile = blockIdx.x, lane = big_lane();
+    u32 cnt = 0;
+    for (u32 j = 0; j < 16u; j++) { const u32 p = tile * 1024u + j * 64u + lane; if (p < src_len && mark[p]) cnt++; }
+    const u32 tot = big_total(big_incl_scan(cnt));
+    if (lane == 0) tile_c[tile] = tot;
+}
+__global__ __launch_bounds__(64) void big_mark_scatter(const u8* __restrict__ mark, u32 src_len, const u32* __restrict__ tile_b, u32* __restrict__ gpos) {
+    const u32 tile = blockIdx.x, lane = big_lane();
+    u32 base = tile_b[tile];
+    for (u32 j = 0; j < 16u; j++) {
+        const u32 p = tile * 1024u + j * 64u + lane;
+        const bool m = p < src_len && mark[p];
+        const u64 mm = __builtin_amdgcn_ballot_w64(m);
+        if (m) gpos[base + big_mbcnt(mm)] = p;
+        base += (u32)__popcll(mm);
+    }
+}
+
+// P4: the eight tokens of every group
+template <int FMT>
+__global__ __launch_bounds__(256) void big_group_tokens(const u8* __restrict__ src, u32 src_len, BigGeom gm, const u32* __restrict__ gpos, u32* __restrict__ ctl,
+                                                        u32* __restrict__ tlen, u32* __restrict__ tdesc, u32* __restrict__ tend) {
+    typedef BigFam<FMT> TR;
+    const u32 ng = ctl[C_NG];
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g == 0) ctl[C_NT] = 8u * ng;
+    if (g >= ng) return;
+    const u32 p = gpos[g];
+    const u32 mbits = big_match_bits<FMT>(src[p]);
+    u64 pos = (u64)p + 1u;
+    for (u32 k = 0; k < 8u; k++) {
+        const bool m = big_is_match<FMT>(mbits, k);
+        const u32 sz = big_token_size<FMT>(src, src_len, pos > src_len ? src_len : (u32)pos, m);
+        u32 len = 1, desc;
+        if (pos + sz > src_len) desc = BIG_LIT | BIG_OOB;          // the token does not lie inside the input (garbage behind the end, or a truncated stream)
+        else {
+            const u8* t = src + pos;
+            const u32 b1 = t[0];
+            if (!m) desc = BIG_LIT | b1;
+            else {
+                const u32 b2 = t[1];
+                if (FMT == ALZ_FMT_LZSS) {                       // LZSS.cs:115-119: a ring offset; it becomes a distance where the token's output position is known
+                    u32 offset = ((b2 >> gm.length_bits) << 8) | b1;
+                    len = (b2 & ((1u << gm.length_bits) - 1u)) + gm.min_length;
+                    desc = (gm.max_distance + offset - gm.windows_start) & (gm.max_distance - 1u);
+                } else if (FMT == ALZ_FMT_LZ10) { desc = (((b1 & 0xFu) << 8) | b2) + 1u; len = (b1 >> 4) + 3u; }
+                else if (FMT == ALZ_FMT_LZ11) {                  // LZ11.cs:98-118
+                    const u32 nib = b1 >> 4;
+                    if (nib == 0u) { const u32 b3 = t[2]; desc = (((b2 & 0xFu) << 8) | b3) + 1u; len = (((b1 & 0xFu) << 4) | (b2 >> 4)) + 17u; }
+                    else if (nib == 1u) { const u32 b3 = t[2], b4 = t[3]; desc = (((b3 & 0xFu) << 8) | b4) + 1u; len = (((b1 & 0xFu) << 12) | (b2 << 4) | (b3 >> 4)) + 273u; }
+                    else { desc = (((b1 & 0xFu) << 8) | b2) + 1u; len = nib + 1u; }
+                } else {                                         // Yaz0: Yay0.cs:127-133
+                    const u32 nib = b1 >> 4;
+                    desc = (((b1 & 0xFu) << 8) | b2) + 1u;
+                    len = nib ? nib + 2u : (u32)t[2] + 0x12u;
+                }
+            }
+        }
+        const u32 i = 8u * g + k;
+        tlen[i] = len; tdesc[i] = desc; tend[i] = pos + sz > src_len ? src_len : (u32)(pos + sz);
+        pos += sz;
+    }
+}
+
+// P5: token lengths per tile of 1 024 tokens; after the scan, every token's output offset (saturating: the garbage behind the end of the
+// stream may add up to anything, the binary search of P6 only needs the offsets to be monotone)
+__global__ __launch_bounds__(64) void big_len_count(const u32* __restrict__ tlen, const u32* __restrict__ ctl, u32* __restrict__ tile_l) {
+    const u32 tile = blockIdx.x, lane = big_lane(), nt = ctl[C_NT];
+    u32 acc = 0;
+    for (u32 j = 0; j < 16u; j++) { const u32 i = tile * 1024u + lane * 16u + j; if (i < nt) acc += tlen[i]; }   // (<= 16 x 65 808 per lane)
+    const u32 tot = big_total(big_incl_scan(acc));
+    if (lane == 0) tile_l[tile] = tile * 1024u < nt ? tot : 0u;
+}
+__global__ __launch_bounds__(64) void big_len_offsets(const u32* __restrict__ tlen, const u32* __restrict__ ctl, const u32* __restrict__ tile_b, u32* __restrict__ toff) {
+    const u32 tile = blockIdx.x, lane = big_lane(), nt = ctl[C_NT];
+    if (tile * 1024u >= nt) return;
+    u32 mine[16], acc = 0;
+    for (u32 j = 0; j < 16u; j++) { const u32 i = tile * 1024u + lane * 16u + j; mine[j] = i < nt ? tlen[i] : 0u; acc += mine[j]; }
+    const u32 incl = big_incl_scan(acc);
+    u64 run = (u64)tile_b[tile] + (incl - acc);
+    for (u32 j = 0; j < 16u; j++) {
+        const u32 i = tile * 1024u + lane * 16u + j;
+        if (i < nt) toff[i] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)run;
+        run += mine[j];
+    }
+}
+
+// P6: the entry of every output byte
+template <bool LZSS>
+__global__ __launch_bounds__(256) void big_emit_bytes(u32 size, BigGeom gm, const u32* __restrict__ toff, const u32* __restrict__ tlen, const u32* __restrict__ tdesc,
+                                                      const u32* __restrict__ tend, u32* __restrict__ val, u32* __restrict__ ctl) {
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= size) return;
+    const u32 nt = ctl[C_NT];
+    if (nt == 0u) { ctl[C_BAD] = 1u; return; }
+    u32 lo = 0, hi = nt;                                         // the last token whose offset is <= q
+    while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (toff[mid] <= q) lo = mid; else hi = mid; }
+    const u32 t = lo, off = toff[t], len = tlen[t], desc = tdesc[t];
+    const u32 j = q - off;
+    if (j >= len || (desc & BIG_OOB)) { ctl[C_BAD] = 1u; val[q] = BIG_LIT; return; }   // the tokens end in front of the declared size / a token of the stream reads past the input
+    if (q == size - 1u) {
+        if ((u64)off + len == size) { ctl[C_USED] = tend[t]; ctl[C_END] = 1u; }   // the stream ends with this token: source.Position is just behind it
+        else ctl[C_BAD] = 1u;                                    // the last match overshoots the declared size (E4): the exact kernel's case
+    }
+    if (desc & BIG_LIT) { val[q] = desc; return; }
+    u32 d = desc;
+    if (LZSS) { d = ((off & (gm.W - 1u)) - desc) & (gm.W - 1u); if (d == 0u) d = gm.W; }   // LzWindows.OffsetCopy  IO/LzWindows.cs:108-115; E1
+    const u32 r = j % d;                                         // byte j copies start - d + (j mod d): the pattern in front of the token
+    val[q] = off + r >= d ? off + r - d : BIG_LIT;               // (in front of the stream start: E2 reads 0x00)
+}
+
 // ---------------------------------------------------------------------------------------------------------------- host side
 static u32 big_ntok(const alz_stream& st) {
     const u64 by_flags = 8ull * st.src_len;
     return (u32)(by_flags < st.decom_len ? by_flags : st.decom_len);
 }
-static u32 big_rounds(u32 ntok) { u32 r = 1; while ((1ull << r) < ntok) r++; return r + 1u; }
+static u32 big_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r + 1u; }
+static bool big_three(int fmt) { return fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0; }
+static bool big_inter(int fmt) { return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_YAZ0; }
+static size_t big_al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-bool alz_big_eligible(int fmt, const alz_stream* st, uint32_t min_bytes) {
-    if (fmt != ALZ_FMT_YAY0 && fmt != ALZ_FMT_MIO0) return false;
+// layout of the scratch of the interleaved path
+struct InterLayout {
+    u32 nodes, max_ng, max_nt, mtiles, ttiles;
+    size_t val, jump_a, jump_b, mark, tile_c, tile_cb, gpos, tlen, tdesc, tend, toff, tile_l, tile_lb, ctl, total;
+    InterLayout(const alz_stream& st) {
+        nodes = st.src_len + 1u;
+        max_ng = st.src_len / 9u + 2u; max_nt = 8u * max_ng;
+        mtiles = (nodes + 1023u) / 1024u; ttiles = (max_nt + 1023u) / 1024u;
+        size_t o = 0;
+        val = o; o += big_al((size_t)st.decom_len * 4);
+        jump_a = o; o += big_al((size_t)nodes * 4); jump_b = o; o += big_al((size_t)nodes * 4);
+        mark = o; o += big_al((size_t)nodes + 64);
+        tile_c = o; o += big_al((size_t)(mtiles + 64) * 4); tile_cb = o; o += big_al((size_t)(mtiles + 64) * 4);
+        gpos = o; o += big_al((size_t)max_ng * 4);
+        tlen = o; o += big_al((size_t)max_nt * 4); tdesc = o; o += big_al((size_t)max_nt * 4);
+        tend = o; o += big_al((size_t)max_nt * 4); toff = o; o += big_al((size_t)max_nt * 4);
+        tile_l = o; o += big_al((size_t)(ttiles + 64) * 4); tile_lb = o; o += big_al((size_t)(ttiles + 64) * 4);
+        ctl = o; o += big_al((C_FLAGS + 40) * 4);
+        total = o;
+    }
+};
+
+bool alz_big_eligible(int fmt, const alz_stream* st, const alz_lz_properties* lz, uint32_t min_bytes) {
+    if (!big_three(fmt) && !big_inter(fmt)) return false;
     if (st->decom_len < min_bytes || st->decom_len > 0x40000000u) return false;
-    if (st->dst_cap < st->decom_len || st->src_len == 0) return false;
-    if (st->aux0 > st->src_len || st->aux1 > st->src_len) return false;
+    if (st->dst_cap < st->decom_len || st->src_len == 0 || st->src_len > 0x40000000u) return false;
+    if (big_three(fmt) && (st->aux0 > st->src_len || st->aux1 > st->src_len)) return false;
+    if (fmt == ALZ_FMT_LZSS && (lz->window_bits < 8 || lz->window_bits > 16 || lz->length_bits < 1 || lz->length_bits > 8 || lz->max_distance != (1u << lz->window_bits))) return false;
     return true;
 }
 
-size_t alz_big_scratch_bytes(const alz_stream* st) {
+size_t alz_big_scratch_bytes(int fmt, const alz_stream* st) {
+    if (big_inter(fmt)) return InterLayout(*st).total + 256;
     const u32 ntok = big_ntok(*st);
     const size_t ntiles = (ntok + BIG_TILE - 1) / BIG_TILE;
     return (size_t)st->decom_len * 4 + 6 * ((ntiles + 64) * 4) + (C_FLAGS + 40) * 4 + 256;
 }
 
-hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
-                          void* d_scratch, uint32_t* d_gate) {
+template <int FMT>
+static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, const BigGeom& gm, alz_result* d_result, u8* base, u32* d_gate) {
+    const InterLayout L(*st);
+    u32* val = (u32*)(base + L.val); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b); u8* mark = base + L.mark;
+    u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
+    u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
+    u32* tile_l = (u32*)(base + L.tile_l); u32* tile_lb = (u32*)(base + L.tile_lb); u32* ctl = (u32*)(base + L.ctl);
+    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)L.nodes + 64, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);                       // the first group starts at byte 0
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
+    if (e != hipSuccess) return e;
+    const u32 nbn = (L.nodes + 255u) / 256u;
+    hipLaunchKernelGGL((big_group_sizes<FMT>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
+    const u32 rr = big_rounds(L.max_ng);
+    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_c);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
+    hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_cb, gpos);
+    hipLaunchKernelGGL((big_group_tokens<FMT>), dim3((L.max_ng + 255u) / 256u), dim3(256), 0, stream, src, st->src_len, gm, gpos, ctl, tlen, tdesc, tend);
+    hipLaunchKernelGGL(big_len_count, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_l);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_l, tile_lb, L.ttiles, ctl + C_TOTAL);
+    hipLaunchKernelGGL(big_len_offsets, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_lb, toff);
+    const u32 nb = (st->decom_len + 255u) / 256u;
+    hipLaunchKernelGGL((big_emit_bytes<FMT == ALZ_FMT_LZSS>), dim3(nb), dim3(256), 0, stream, st->decom_len, gm, toff, tlen, tdesc, tend, val, ctl);
+    const u32 rounds = big_rounds(L.max_nt);
+    for (u32 r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->decom_len, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
+    BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
+    hipLaunchKernelGGL(big_write, dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    return hipGetLastError();
+}
+
+hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, const alz_lz_properties* lz,
+                          alz_result* d_result, void* d_scratch, uint32_t* d_gate) {
+    const u8* src = (const u8*)d_src_base + st->src_off; u8* dst = (u8*)d_dst_base + st->dst_off;
+    if (big_inter(fmt)) {
+        BigGeom gm; gm.length_bits = lz->length_bits; gm.min_length = lz->min_length; gm.windows_start = lz->windows_start;
+        gm.max_distance = lz->max_distance; gm.W = 1u << lz->window_bits;
+        switch (fmt) {
+        case ALZ_FMT_LZSS: return launch_inter<ALZ_FMT_LZSS>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
+        case ALZ_FMT_LZ10: return launch_inter<ALZ_FMT_LZ10>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
+        case ALZ_FMT_LZ11: return launch_inter<ALZ_FMT_LZ11>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
+        default: return launch_inter<ALZ_FMT_YAZ0>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
+        }
+    }
     BigArgs a;
-    a.src = (const u8*)d_src_base + st->src_off; a.dst = (u8*)d_dst_base + st->dst_off;
+    a.src = src; a.dst = dst;
     a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = st->aux0; a.aux1 = st->aux1;
     a.ntok = big_ntok(*st);
     a.ntiles = (a.ntok + BIG_TILE - 1) / BIG_TILE;

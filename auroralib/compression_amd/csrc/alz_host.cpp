@@ -332,9 +332,9 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
     if (e == hipSuccess) e = hipMemsetAsync(p->d_results, 0xFF, nn * sizeof(alz_result), c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
-    if (n == 1 && !c->exact && c->variant == 0 && alz_big_eligible((int)streams[0].format, &streams[0], c->big_min)) {
+    if (n == 1 && !c->exact && c->variant == 0 && alz_big_eligible((int)streams[0].format, &streams[0], &lz, c->big_min)) {
         // (its scratch -- 4 bytes per output byte -- belongs to the plan; when it cannot be had the production kernel decodes the stream alone)
-        const size_t need = alz_big_scratch_bytes(&streams[0]) + 64;
+        const size_t need = alz_big_scratch_bytes((int)streams[0].format, &streams[0]) + 64;
         if (scratch) { if (grow(c, &c->d_bigbuf, &c->d_bigbuf_cap, need) == ALZ_OK) { p->d_big = c->d_bigbuf; p->big_borrowed = true; } }
         else if (hipMalloc(&p->d_big, need) != hipSuccess) { p->d_big = nullptr; (void)hipGetLastError(); }
         if (p->d_big) { p->big = true; p->big_stream = streams[0]; p->d_gate = (uint32_t*)((uint8_t*)p->d_big + need - 64); }
@@ -365,7 +365,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (p->big && !c->exact && c->variant == 0) {
         const int f = (int)p->big_stream.format;
-        hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_stream, p->d_results, p->d_big, p->d_gate);
+        hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_stream, &p->lz, p->d_results, p->d_big, p->d_gate);
         if (e == hipSuccess) e = alz_launch_decode_gated(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], 1, p->d_results, &p->lz, p->d_gate);
         if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream launch (format %d) failed: %s", f, hipGetErrorString(e));
         c->big_launches++;

@@ -11,15 +11,15 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, voi
                              const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact, uint32_t batch_total = 0, int variant = 0)   /* batch_total: streams of ALL formats of the batch this launch belongs to (0 = count); variant: alz_ctx_set_kernel_variant */;
 int alz_kernel_occupancy(int fmt);
 // the same launch gated by a device word: the kernels return at once while *d_gate == 0 (alz_big.hip: the exact decode behind the
-// whole-GPU path of ONE big stream, needed only when that path declined the stream).  Yay0 / MIO0 only.
+// whole-GPU path of ONE big stream, needed only when that path declined the stream).  The formats of that path only.
 hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                                    uint32_t count, alz_result* d_results, const alz_lz_properties* lz, const uint32_t* d_gate);
 
-// ---- one big stream on the whole GPU (alz_big.hip): Yay0 / MIO0
-bool alz_big_eligible(int fmt, const alz_stream* st, uint32_t min_bytes);
-size_t alz_big_scratch_bytes(const alz_stream* st);
-hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
-                          void* d_scratch, uint32_t* d_gate);   // resident waves per CU of the production decode kernel (tuning aid)
+// ---- one big stream on the whole GPU (alz_big.hip): Yay0 / MIO0 (three sections) and LZSS / LZ10 / LZ11 / Yaz0 (one interleaved stream)
+bool alz_big_eligible(int fmt, const alz_stream* st, const alz_lz_properties* lz, uint32_t min_bytes);
+size_t alz_big_scratch_bytes(int fmt, const alz_stream* st);
+hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, const alz_lz_properties* lz,
+                          alz_result* d_result, void* d_scratch, uint32_t* d_gate);   // resident waves per CU of the production decode kernel (tuning aid)
 
 // ---- encoder (alz_encode.hip)
 bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits, int variant = 0);   // variant 1: FastLZ level 2

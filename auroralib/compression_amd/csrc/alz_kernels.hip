@@ -497,7 +497,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
 template <int FMT>
 __global__ __launch_bounds__(128) void alz_decode_fast2_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
                                                                const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results,
-                                                               alz_lz_properties lz, u32 lw) {
+                                                               alz_lz_properties lz, u32 lw, const u32* __restrict__ gate) {
+    if (gate != nullptr && __builtin_nontemporal_load(gate) == 0u) return;   // (alz_launch_decode_gated)
     constexpr u32 CHUNK = 1024u, CACHE = 2u * CHUNK + 32u, FSCR = 128u, LWMAX = 4096u;
     __shared__ __attribute__((aligned(16))) u8 lds[FSCR + CACHE + LWMAX + CACHE + 2u * ALZ_MBOX_WORDS * 4u];
     const u32 bid = blockIdx.x;
@@ -883,7 +884,7 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
     // launches that cannot fill the GPU with one wavefront per stream: two per stream (alz_decode_fast2_kernel)
     if constexpr (LWMAX == 4096 && !FBK && (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40 || FMT == ALZ_FMT_CLZ0 || FMT == ALZ_FMT_YAZ0)) {
         if (fast_two_waves()) {
-            hipLaunchKernelGGL((alz_decode_fast2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lz, lw);
+            hipLaunchKernelGGL((alz_decode_fast2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, lz, lw, gate);
             return hipGetLastError();
         }
     }
@@ -954,9 +955,23 @@ int alz_kernel_occupancy(int fmt) {
 hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,
                                    u32 count, alz_result* results, const alz_lz_properties* lzp, const u32* gate) {
     t_batch_total = count; t_variant = 0;
-    if (fmt == ALZ_FMT_YAY0) return launch_fast<ALZ_FMT_YAY0>(stream, (const u8*)src, (u8*)dst, streams, index, count, results, *lzp, 4096, 3, gate);
-    if (fmt == ALZ_FMT_MIO0) return launch_fast<ALZ_FMT_MIO0>(stream, (const u8*)src, (u8*)dst, streams, index, count, results, *lzp, 4096, 3, gate);
-    return hipErrorInvalidValue;
+    const u8* s = (const u8*)src; u8* d = (u8*)dst;
+    const alz_lz_properties lz = *lzp;
+    switch (fmt) {
+    case ALZ_FMT_YAY0: return launch_fast<ALZ_FMT_YAY0>(stream, s, d, streams, index, count, results, lz, 4096, 3, gate);
+    case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3, gate);
+    case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_LZ11: return launch_fast<ALZ_FMT_LZ11>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_LZSS: {                                      // (the same choice of window as alz_launch_decode)
+        const u32 W = 1u << lz.window_bits;
+        if (W <= 4096 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096>(stream, s, d, streams, index, count, results, lz, W, 1, gate);
+        if (W <= 8192 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 8192>(stream, s, d, streams, index, count, results, lz, W, 1, gate);
+        if (W <= 65536 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096, true>(stream, s, d, streams, index, count, results, lz, W, 1, gate);
+        return hipErrorInvalidValue;
+    }
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const u32* index,

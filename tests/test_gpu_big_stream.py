@@ -1,7 +1,9 @@
-"""-m gpu: ONE big Yay0 / MIO0 stream on the whole GPU (csrc/alz_big.hip, alz_ctx_big_stream) against the oracle.
+"""-m gpu: ONE big stream on the whole GPU (csrc/alz_big.hip, alz_ctx_big_stream) against the oracle: Yay0 / MIO0 (three sections: the
+cursors of a token are prefix sums) and LZSS / LZ10 / LZ11 / Yaz0 (one interleaved stream: the group starts come from list ranking over
+the input bytes).
 
-A batch of one stream of >= 96 KiB goes through prefix sums over its three sections and pointer jumping over its output bytes instead of
-through one or two wavefronts.  Valid streams must come out bit-exact with status / dst_len / src_used of the oracle; every malformed
+A batch of one stream of >= 96 KiB goes through that path and pointer jumping over its output bytes instead of through one or two
+wavefronts.  Valid streams must come out bit-exact with status / dst_len / src_used of the oracle; every malformed
 stream (truncated, overshooting, undershooting, short destination, cursors outside the input) must come out exactly as the exact kernel
 behind the path decodes it -- the path may only ever DECLINE such a stream.  The device-resident cases compare the whole destination buffer
 (0xA5 canary, guard regions), as tests/test_gpu_canary.py does."""
@@ -16,16 +18,17 @@ from auroralib.compression_amd import synth
 from auroralib.compression_amd.batch import Context, Plan
 
 pytestmark = pytest.mark.gpu
-FMTS = [A.FMT_YAY0, A.FMT_MIO0]
+FMTS = [A.FMT_YAY0, A.FMT_MIO0, A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0]
+THREE = (A.FMT_YAY0, A.FMT_MIO0)
 OFF = 0xFFFFFFFF
 
 
-def _one(c, fmt, comp, decom_len, aux0, aux1, cap=None, expect_big=None, what=""):
+def _one(c, fmt, comp, decom_len, aux0, aux1, cap=None, expect_big=None, what="", lz=None):
     """The stream through alz_decode (host buffers) and through a device-resident plan with a canary; both against the oracle."""
     cap = decom_len if cap is None else cap
-    want, wr = O.decode_stream(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1)
+    want, wr = O.decode_stream(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1, lz=lz)
     before = c.big_stream()
-    got, r = c.decode(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1)
+    got, r = c.decode(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1, lz=lz)
     took = c.big_stream() - before
     assert (r.status, r.dst_len) == (wr.status, wr.dst_len), (what, r.status, r.dst_len, wr.status, wr.dst_len)
     if wr.status != A.ST_OUTPUT_CAPACITY:
@@ -40,7 +43,7 @@ def _one(c, fmt, comp, decom_len, aux0, aux1, cap=None, expect_big=None, what=""
     d_src, d_dst = c.malloc(src.nbytes), c.malloc(G + cap + G)
     try:
         c.h2d(d_src, src); c.memset(d_dst, 0xA5, G + cap + G)
-        p = Plan(c, st)
+        p = Plan(c, st, lz)
         p.execute(d_src, C.c_void_p(d_dst.value + G))
         pr = p.results()[0]
         buf = c.d2h(d_dst, G + cap + G)
@@ -113,25 +116,42 @@ def test_malformed_streams_fall_through_to_the_exact_kernel(fmt, test_bmp):
                  (comp, n - 1, n - 1, aux.aux0, aux.aux1, "declared size one too small"),
                  (comp, n + 5000, n + 5000, aux.aux0, aux.aux1, "declared size too large"),
                  (comp, n, n - 4097, aux.aux0, aux.aux1, "short destination"),
-                 (comp, n, n, aux.aux0 + 2, aux.aux1, "token cursor off by one token"),
-                 (comp, n, n, aux.aux0, aux.aux1 + 1, "literal cursor off by one"),
-                 (comp, n, n, len(comp) + 7, aux.aux1, "token section outside the input"),
-                 (comp, n, n, aux.aux0, len(comp), "literal section at the end of the input"),
-                 (comp, n, n, 0, 0, "all three sections on top of each other")]
+                 (comp + bytes(5000), n, n, aux.aux0, aux.aux1, "trailing zeros behind the stream"),
+                 (comp + comp[:7000], n, n, aux.aux0, aux.aux1, "trailing data behind the stream")]
+        if fmt in THREE:
+            cases += [(comp, n, n, aux.aux0 + 2, aux.aux1, "token cursor off by one token"),
+                      (comp, n, n, aux.aux0, aux.aux1 + 1, "literal cursor off by one"),
+                      (comp, n, n, len(comp) + 7, aux.aux1, "token section outside the input"),
+                      (comp, n, n, aux.aux0, len(comp), "literal section at the end of the input"),
+                      (comp, n, n, 0, 0, "all three sections on top of each other")]
+        else:
+            cases += [(comp[1:], n, n, 0, 0, "first byte missing (every group misparsed)"),
+                      (comp[:1000] + comp[1001:], n, n, 0, 0, "one byte dropped in the middle")]
         for _ in range(12):
             b = bytearray(comp)
             for _ in range(rng.randrange(1, 5)):
                 b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
             cases.append((bytes(b), n, n, aux.aux0, aux.aux1, "bit flips"))
-        cases.append((bytes(rng.randrange(256) for _ in range(120000)), n, n, 20000, 60000, "noise"))
+        cases.append((bytes(rng.randrange(256) for _ in range(120000)), n, n, 20000 if fmt in THREE else 0, 60000 if fmt in THREE else 0, "noise"))
         for src, decl, cap, a0, a1, what in cases:
             _one(c, fmt, src, decl, a0, a1, cap=cap, what=what)
 
 
+def test_lzss_geometries_on_the_path(test_bmp):
+    """LZSS with other windows than the default 4 KiB: the path has no LDS ring, every window up to 64 KiB is the same code
+    (LzProperties.cs:57-66; the KAT geometry (10,6,2) included)."""
+    with Context(0) as c:
+        for bits in [(10, 6, 2), (12, 4, 2), (14, 4, 2), (16, 8, 2)]:
+            lz = A.LzProperties.from_bits(*bits)
+            for raw, q in ((test_bmp[:500000], 8), (bytes(200000), 0)):
+                comp, aux = O.encode_stream(A.FMT_LZSS, raw, quality=q, lz=lz)
+                _one(c, A.FMT_LZSS, comp, len(raw), 0, 0, expect_big=True, what="lzss%r q%d" % (bits, q), lz=lz)
+
+
 def test_the_format_classes_reach_it(test_bmp):
-    """Decompress of the Yay0 / MIO0 classes of the host mirror (= ICompressionDecoder.Decompress on one file) takes the path."""
+    """Decompress of the format classes of the host mirror (= ICompressionDecoder.Decompress on one file) takes the path."""
     from auroralib.compression_amd import formats as F
-    for cls, cont in ((F.Yay0, A.C_YAY0), (F.MIO0, A.C_MIO0)):
+    for cls, cont in ((F.Yay0, A.C_YAY0), (F.MIO0, A.C_MIO0), (F.Yaz0, A.C_YAZ0), (F.LZ10, A.C_LZ10), (F.LZ11, A.C_LZ11), (F.LZSS, A.C_LZSS)):
         comp = O.container_compress(cont, test_bmp, quality=8)
         before = F._context().big_stream()
         assert cls().Decompress(comp) == test_bmp

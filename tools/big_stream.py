@@ -1,5 +1,5 @@
 """usage (GPU box): python tools/big_stream.py  -- ONE stream of 256 KiB / 1 000 KiB / 4 MiB (the reference's benchmark: one 1 000 KiB stream of
-Test.bmp, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42) as Yay0 and MIO0: device time and alz_decode wall time with the whole-GPU path
+Test.bmp, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42) as Yay0 / MIO0 / Yaz0 / LZ10 / LZ11 / LZSS: device time and alz_decode wall time with the whole-GPU path
 (csrc/alz_big.hip) and with the production kernel alone."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ from auroralib.compression_amd.batch import Context, Plan
 
 bmp = O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0]
 c = Context(0)
-for fmt in (A.FMT_YAY0, A.FMT_MIO0):
+for fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_YAZ0, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZSS):
     for label, raw in (("Test.bmp[0:256 KiB]", bmp[:262144]), ("Test.bmp[0:1 000 KiB]", bmp[:1024000]), ("Test.bmp x 4 (4 MiB)", (bmp * 4)[:4 << 20])):
         comp, aux = O.encode_stream(fmt, raw, quality=8)
         n = len(raw)
