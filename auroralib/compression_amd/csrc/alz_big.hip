@@ -1,4 +1,5 @@
-// alz_big.hip -- ONE big stream on the whole GPU: the three-cursor formats (Yay0, MIO0).
+// alz_big.hip -- ONE big stream on the whole GPU: the three-section formats (Yay0, MIO0) here, the interleaved flag-byte formats (LZSS, LZ10,
+// LZ11, Yaz0) further down.
 //
 // The production kernels give a stream one wavefront (or two): a lone 256 KiB stream takes 0.8 ms, a lone 1 MiB stream 3 ms -- below the
 // 0.40-0.79 GiB/s the managed decoders reach on one CPU core (the reference's own benchmark is ONE 1 000 KiB stream,
@@ -11,10 +12,11 @@
 //   K1  matches per tile (popcount of the flag bytes)     S   exclusive scan over the tiles
 //   K3  literal-section bytes per tile (Yay0 only)        S
 //   K5  output bytes per tile                             S
-//   K7  every token knows its three cursors: it writes, for each of its output bytes, either the byte (a literal) or the POSITION the
-//       byte is copied from -- for a self-overlapping match (distance < length) the position in front of the token that holds the same
-//       pattern byte (start - d + (j mod d)), so a byte's source always lies in front of its token and a source "before the stream
-//       start" (E2) is the literal 0x00
+//   K7  every token knows its three cursors: (output offset, length, descriptor, source.Position behind it) per token
+//   B   one thread per OUTPUT byte finds its token by binary search over the offsets and writes its entry: either the byte (a literal) or
+//       the POSITION the byte is copied from -- for a self-overlapping match (distance < length) the position in front of the token that
+//       holds the same pattern byte (start - d + (j mod d)), so a byte's source always lies in front of its token and a source "before
+//       the stream start" (E2) is the literal 0x00
 //   J   pointer jumping over the output bytes: an unresolved byte takes over its source's entry -- the byte (done) or the source's source
 //       (jump); after r rounds an entry spans >= 2^r hops, the depth of a chain is at most the number of tokens: ceil(log2 tokens) + 1
 //       rounds, launched as that many kernels that return at once when the round before changed nothing
@@ -45,7 +47,8 @@ struct BigArgs {
 };
 
 // ctl words
-enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
+enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_NG = 4, C_NT = 5, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
+#define BIG_OOB 0x40000000u     /* a token that does not lie inside the input (descriptor bit) */
 
 __device__ __forceinline__ u32 big_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u32 big_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
@@ -160,40 +163,31 @@ __global__ __launch_bounds__(64) void big_tile_sum(BigArgs a, const u32* __restr
     else { const u32 tot = big_total(big_incl_scan(acc)); if (lane == 0) tile_out[tile] = tot; }
 }
 
-// K7: the entries of the output bytes
+// K7: every token's (output offset, length, descriptor, source.Position behind it) -- the per-byte entries are written by big_emit_bytes
+// (below: one thread per OUTPUT byte, binary search for its token), which the interleaved formats share
 template <bool MIO0>
 __global__ __launch_bounds__(64) void big_emit(BigArgs a, const u32* __restrict__ tile_mb, const u32* __restrict__ tile_ub, const u32* __restrict__ tile_ob,
-                                               u32* __restrict__ val, u32* __restrict__ ctl) {
+                                               u32* __restrict__ toff, u32* __restrict__ tlen, u32* __restrict__ tdesc, u32* __restrict__ tend) {
     const u32 tile = blockIdx.x, lane = big_lane();
-    u32 mbase = tile_mb[tile], ubase = MIO0 ? 0u : tile_ub[tile], obase = tile_ob[tile];
-    if (obase >= a.size) return;                                 // (also the clamped bases of tiles behind an absurd total)
+    u32 mbase = tile_mb[tile], ubase = MIO0 ? 0u : tile_ub[tile];
+    u64 obase = tile_ob[tile];
     for (u32 r = 0; r < BIG_TILE / 64u; r++) {
         const u32 t0 = tile * BIG_TILE + r * 64u;
-        if (t0 >= a.ntok || obase >= a.size) break;
+        if (t0 >= a.ntok) break;
+        const u32 t = t0 + lane;
+        if (obase >= a.size) { if (t < a.ntok) toff[t] = 0xFFFFFFFFu; continue; }   // behind the end of the stream: only the (monotone) offsets matter
         u32 mc, uc;
         const BigTok k = big_round<MIO0, true>(a, t0, mbase, ubase, mc, uc);
-        const bool exists = t0 + lane < a.ntok;
+        const bool exists = t < a.ntok;
         const u32 end = big_incl_scan(exists ? k.len : 0u);
-        const u32 off = obase + end - (exists ? k.len : 0u);
-        const bool kept = exists && off < a.size;                // a token of the stream (the loop of the managed decoder runs while produced < size)
-        if (kept) {
-            if (k.oob) ctl[C_BAD] = 1u;                          // it read past the input: the exact kernel reports where
-            const u32 stop = off + k.len;
-            if (stop > a.size) ctl[C_BAD] = 1u;                  // the last match overshoots the declared size (E4): the exact kernel's case
-            else if (stop == a.size) {                           // the stream ends here: source.Position = the further of the two cursors  Yay0.cs:107, MIO0.cs:148
-                const u32 cu = a.aux0 + 2u * k.mafter, uu = a.aux1 + k.uafter;
-                ctl[C_USED] = cu > uu ? cu : uu; ctl[C_END] = 1u;
-            }
-            if (k.lit) val[off] = BIG_LIT | k.byte;
-            else {
-                const u32 n = stop > a.size ? a.size - off : k.len;
-                u32 rr = 0;
-                for (u32 j = 0; j < n; j++) {                    // byte j copies start - d + (j mod d): the pattern in front of the token
-                    const u32 s = off + rr - k.dist;             // (wraps below zero in front of the stream start: E2 reads 0x00)
-                    val[off + j] = off + rr >= k.dist ? s : BIG_LIT;
-                    if (++rr == k.dist) rr = 0;
-                }
-            }
+        if (exists) {
+            const u64 off = obase + end - k.len;
+            toff[t] = off > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)off;
+            tlen[t] = k.len;
+            tdesc[t] = k.oob ? (BIG_LIT | BIG_OOB) : (k.lit ? (BIG_LIT | k.byte) : k.dist);
+            const u64 cu = (u64)a.aux0 + 2ull * k.mafter, uu = (u64)a.aux1 + k.uafter;   // source.Position = the further of the two cursors  Yay0.cs:107, MIO0.cs:148
+            const u64 mx = cu > uu ? cu : uu;
+            tend[t] = mx > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)mx;
         }
         obase += big_total(end); mbase += mc; ubase += uc;
     }
@@ -243,9 +237,6 @@ template <> struct BigFam<ALZ_FMT_LZSS> { static constexpr bool MSB = false, LIT
 template <> struct BigFam<ALZ_FMT_LZ10> { static constexpr bool MSB = true,  LIT1 = false, H3 = false, H4 = false; };   // LZ10.cs:88-102
 template <> struct BigFam<ALZ_FMT_LZ11> { static constexpr bool MSB = true,  LIT1 = false, H3 = true,  H4 = true;  };   // LZ11.cs:88-118
 template <> struct BigFam<ALZ_FMT_YAZ0> { static constexpr bool MSB = true,  LIT1 = true,  H3 = true,  H4 = false; };   // Yay0.cs:118-133 on one cursor
-
-#define BIG_OOB 0x40000000u
-enum { C_NG = 4, C_NT = 5 };
 
 template <int FMT>
 __device__ __forceinline__ u32 big_match_bits(u32 fb) { return BigFam<FMT>::LIT1 ? (~fb & 0xFFu) : fb; }
@@ -443,7 +434,7 @@ size_t alz_big_scratch_bytes(int fmt, const alz_stream* st) {
     if (big_inter(fmt)) return InterLayout(*st).total + 256;
     const u32 ntok = big_ntok(*st);
     const size_t ntiles = (ntok + BIG_TILE - 1) / BIG_TILE;
-    return (size_t)st->decom_len * 4 + 6 * ((ntiles + 64) * 4) + (C_FLAGS + 40) * 4 + 256;
+    return big_al((size_t)st->decom_len * 4) + 6 * big_al((ntiles + 64) * 4) + 4 * big_al((size_t)ntok * 4) + big_al((C_FLAGS + 40) * 4) + 256;
 }
 
 template <int FMT>
@@ -497,15 +488,18 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = st->aux0; a.aux1 = st->aux1;
     a.ntok = big_ntok(*st);
     a.ntiles = (a.ntok + BIG_TILE - 1) / BIG_TILE;
-    const size_t tl = ((size_t)a.ntiles + 64) * 4;
+    const size_t tl = big_al(((size_t)a.ntiles + 64) * 4), ta = big_al((size_t)a.ntok * 4);
     u8* p = (u8*)d_scratch;
-    u32* val = (u32*)p; p += (size_t)a.size * 4;
+    u32* val = (u32*)p; p += big_al((size_t)a.size * 4);
     u32* tile_m = (u32*)p; p += tl; u32* tile_mb = (u32*)p; p += tl;
     u32* tile_u = (u32*)p; p += tl; u32* tile_ub = (u32*)p; p += tl;
     u32* tile_l = (u32*)p; p += tl; u32* tile_ob = (u32*)p; p += tl;
+    u32* toff = (u32*)p; p += ta; u32* tlen = (u32*)p; p += ta; u32* tdesc = (u32*)p; p += ta; u32* tend = (u32*)p; p += ta;
     u32* ctl = (u32*)p;
     const u32 rounds = big_rounds(a.ntok);
     hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_NT), (int)a.ntok, 1, stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);   // round 0 of the jumping always runs: its "previous flag" holds 1
     if (e != hipSuccess) return e;
     const bool mio0 = fmt == ALZ_FMT_MIO0;
     hipLaunchKernelGGL(big_count_matches, dim3(a.ntiles), dim3(64), 0, stream, a, tile_m);
@@ -518,12 +512,11 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
         hipLaunchKernelGGL((big_tile_sum<true, 1>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_l);
     }
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_l, tile_ob, a.ntiles, ctl + C_TOTAL);
-    if (mio0) hipLaunchKernelGGL((big_emit<true>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_ob, val, ctl);
-    else hipLaunchKernelGGL((big_emit<false>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_ob, val, ctl);
-    // round 0 always runs: its "previous flag" is a word that holds 1
-    e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
-    if (e != hipSuccess) return e;
+    if (mio0) hipLaunchKernelGGL((big_emit<true>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_ob, toff, tlen, tdesc, tend);
+    else hipLaunchKernelGGL((big_emit<false>), dim3(a.ntiles), dim3(64), 0, stream, a, tile_mb, tile_ub, tile_ob, toff, tlen, tdesc, tend);
     const u32 nb = (a.size + 255u) / 256u;
+    BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
+    hipLaunchKernelGGL((big_emit_bytes<false>), dim3(nb), dim3(256), 0, stream, a.size, gm, toff, tlen, tdesc, tend, val, ctl);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, a.size, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     hipLaunchKernelGGL(big_write, dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);

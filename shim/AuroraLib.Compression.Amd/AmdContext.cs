@@ -20,11 +20,12 @@ namespace AuroraLib.Compression.Amd
         /// chunked formats, which the library splits into a batch itself.</summary>
         public static uint SingleStreamThreshold { get; set; } = uint.MaxValue;
 
-        /// <summary>Yay0 and MIO0 are the exception (round 4): their three sections make ONE stream a job for the whole GPU
-        /// (prefix sums for the cursors, pointer jumping for the copies: csrc/alz_big.hip) -- the reference's own benchmark input, one
-        /// 1 000 KiB stream of Test.bmp, decodes in 0.27-0.44 ms through <c>alz_decode</c> on host buffers (2.2-3.5 GiB/s) against
-        /// 0.40-0.79 GiB/s of the managed loop (Benchmarks.md:70-80).  A single Yay0 / MIO0 body of at least this many decompressed
-        /// bytes therefore goes to the GPU by default; the native library takes the whole-GPU path from 96 KiB on.</summary>
+        /// <summary>LZSS, LZ10, LZ11, Yaz0, Yay0 and MIO0 are the exception (round 4): ONE stream of these formats is a job for the whole
+        /// GPU (csrc/alz_big.hip: the group starts of the interleaved formats by list ranking over the input bytes, the cursors of the
+        /// three-section formats by prefix sums, the copies by pointer jumping over the output bytes) -- the reference's own benchmark
+        /// input, one 1 000 KiB stream of Test.bmp, decodes in 0.27-0.44 ms through <c>alz_decode</c> on host buffers (2.2-3.6 GiB/s)
+        /// against 0.32-0.91 GiB/s of the managed loops (Benchmarks.md:30-84).  A single body of these formats with at least this many
+        /// decompressed bytes therefore goes to the GPU by default; the native library takes the whole-GPU path from 96 KiB on.</summary>
         public static uint BigStreamThreshold { get; set; } = 96u << 10;
 
         /// <summary>The same switch for <c>Compress</c> / <c>CompressHeaderless</c> of ONE buffer: sources shorter than this run on

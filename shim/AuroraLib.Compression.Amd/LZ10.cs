@@ -46,7 +46,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <summary>LZ10.DecompressHeaderless (LZ10.cs:82-111): overshoot of the declared size is the error ('>', :107).</summary>
         public static unsafe void DecompressHeaderless(Stream source, Stream destination, uint decomLength)
         {
-            if (!AmdBody.UseGpu(decomLength)) { Managed.LZ10.DecompressHeaderless(source, destination, decomLength); return; }
+            if (!AmdBody.UseGpuBigStream(decomLength)) { Managed.LZ10.DecompressHeaderless(source, destination, decomLength); return; }
             AmdBody.Decode(AlzFormat.LZ10, null, source, destination, decomLength, 0, 0, decomLength + 18, true);
         }
 

@@ -45,7 +45,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <summary>LZ11.DecompressHeaderless (LZ11.cs:83-133); the longest token is 65 808 bytes.</summary>
         public static unsafe void DecompressHeaderless(Stream source, Stream destination, uint decomLength)
         {
-            if (!AmdBody.UseGpu(decomLength)) { Managed.LZ11.DecompressHeaderless(source, destination, decomLength); return; }
+            if (!AmdBody.UseGpuBigStream(decomLength)) { Managed.LZ11.DecompressHeaderless(source, destination, decomLength); return; }
             AmdBody.Decode(AlzFormat.LZ11, null, source, destination, decomLength, 0, 0, decomLength + 65808, true);
         }
 

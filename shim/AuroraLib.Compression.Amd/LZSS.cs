@@ -45,7 +45,7 @@ namespace AuroraLib.Compression.Amd.Common
         public static unsafe void DecompressHeaderless(Stream source, Stream destination, uint decomLength, LzProperties lz, byte initialFill = 0x0)
         {
             bool native = initialFill == 0 && lz.WindowsBits >= 8 && lz.WindowsBits <= 16 && lz.LengthBits >= 1 && lz.LengthBits <= 8;
-            if (!native || !AmdBody.UseGpu(decomLength)) { Managed.LZSS.DecompressHeaderless(source, destination, decomLength, lz, initialFill); return; }
+            if (!native || !AmdBody.UseGpuBigStream(decomLength)) { Managed.LZSS.DecompressHeaderless(source, destination, decomLength, lz, initialFill); return; }
             AlzLzProperties p = AmdBody.ToNative(lz);
             AmdBody.Decode(AlzFormat.LZSS, &p, source, destination, decomLength, 0, 0, decomLength + (uint)lz.MaxLength, true);
         }

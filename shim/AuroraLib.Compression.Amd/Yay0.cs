@@ -45,7 +45,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// pointers (relative to the first flag byte); source.Position ends behind the last section byte read (:89-90).</summary>
         public static unsafe void DecompressHeaderless(Stream source, Stream destination, uint decomLength, int compressedDataPointer, int uncompressedDataPointer)
         {
-            if (!AmdBody.UseGpuThreeSections(decomLength)) { Managed.Yay0.DecompressHeaderless(source, destination, decomLength, compressedDataPointer, uncompressedDataPointer); return; }
+            if (!AmdBody.UseGpuBigStream(decomLength)) { Managed.Yay0.DecompressHeaderless(source, destination, decomLength, compressedDataPointer, uncompressedDataPointer); return; }
             AmdBody.Decode(AlzFormat.Yay0, null, source, destination, decomLength, (uint)compressedDataPointer, (uint)uncompressedDataPointer, decomLength + 273, true);
         }
 

@@ -56,7 +56,7 @@ namespace AuroraLib.Compression.Amd.Nintendo
         /// <summary>Yaz0.DecompressHeaderless (Yaz0.cs:91-92 = Yay0.cs:110-144 with all three cursors on one stream).</summary>
         public static unsafe void DecompressHeaderless(Stream source, Stream destination, uint decomLength)
         {
-            if (!AmdBody.UseGpu(decomLength)) { Managed.Yaz0.DecompressHeaderless(source, destination, decomLength); return; }
+            if (!AmdBody.UseGpuBigStream(decomLength)) { Managed.Yaz0.DecompressHeaderless(source, destination, decomLength); return; }
             AmdBody.Decode(AlzFormat.Yaz0, null, source, destination, decomLength, 0, 0, decomLength + 273, true);
         }
 
