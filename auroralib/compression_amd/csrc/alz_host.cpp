@@ -128,6 +128,7 @@ struct alz_ctx {
 };
 
 static const size_t kPinBytes = 32u << 20;
+#define ALZ_BIG_MAX_STREAMS 8u              /* a batch of at most this many streams, all of them big, takes the whole-GPU path stream by stream */
 
 struct alz_plan {
     uint32_t n = 0;
@@ -139,7 +140,9 @@ struct alz_plan {
     uint32_t fmt_cnt[ALZ_FMT_COUNT] = {0};
     bool borrowed = false;                  // the three device arrays live in the context's plan scratch (host-buffer entry points)
     // ONE big Yay0 / MIO0 stream: decoded by the whole GPU (alz_big.hip), the production kernel behind it only if that path declines
-    bool big = false, big_borrowed = false; alz_stream big_stream{}; void* d_big = nullptr; uint32_t* d_gate = nullptr;
+    // (up to ALZ_BIG_MAX_STREAMS of them, one after the other: n streams through that path take n x ~0.1-0.3 ms, on wavefronts of their own
+    // they take as long as ONE of them, 1-5 ms per MiB)
+    bool big = false, big_borrowed = false; std::vector<alz_stream> big_streams; std::vector<uint32_t> big_pos; void* d_big = nullptr; uint32_t* d_gate = nullptr;
 };
 
 static alz_lz_properties effective_lz(const alz_lz_properties* p) {
@@ -332,12 +335,20 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
     if (e == hipSuccess) e = hipMemsetAsync(p->d_results, 0xFF, nn * sizeof(alz_result), c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
-    if (n == 1 && !c->exact && c->variant == 0 && alz_big_eligible((int)streams[0].format, &streams[0], &lz, c->big_min)) {
-        // (its scratch -- 4 bytes per output byte -- belongs to the plan; when it cannot be had the production kernel decodes the stream alone)
-        const size_t need = alz_big_scratch_bytes((int)streams[0].format, &streams[0]) + 64;
+    bool all_big = n >= 1 && n <= ALZ_BIG_MAX_STREAMS && !c->exact && c->variant == 0;
+    for (uint32_t i = 0; all_big && i < n; i++) all_big = alz_big_eligible((int)streams[i].format, &streams[i], &lz, c->big_min);
+    if (all_big) {
+        // (the scratch -- 4 bytes per output byte of the largest stream, they run one after the other -- belongs to the plan; when it cannot
+        // be had the production kernels decode the streams)
+        size_t need = 0;
+        for (uint32_t i = 0; i < n; i++) { const size_t b = alz_big_scratch_bytes((int)streams[i].format, &streams[i]) + 64; if (b > need) need = b; }
         if (scratch) { if (grow(c, &c->d_bigbuf, &c->d_bigbuf_cap, need) == ALZ_OK) { p->d_big = c->d_bigbuf; p->big_borrowed = true; } }
         else if (hipMalloc(&p->d_big, need) != hipSuccess) { p->d_big = nullptr; (void)hipGetLastError(); }
-        if (p->d_big) { p->big = true; p->big_stream = streams[0]; p->d_gate = (uint32_t*)((uint8_t*)p->d_big + need - 64); }
+        if (p->d_big) {
+            p->big = true; p->big_streams.assign(streams, streams + n); p->d_gate = (uint32_t*)((uint8_t*)p->d_big + need - 64);
+            p->big_pos.resize(n);
+            for (uint32_t k = 0; k < n; k++) p->big_pos[index[k]] = k;      // where stream i sits in the (per-format, cost-ordered) index list
+        }
     }
     *out = p;
     return ALZ_OK;
@@ -364,11 +375,13 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     HIP_TRY(hipSetDevice(c->device));                 // (a host thread may hold contexts of several devices)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (p->big && !c->exact && c->variant == 0) {
-        const int f = (int)p->big_stream.format;
-        hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_stream, &p->lz, p->d_results, p->d_big, p->d_gate);
-        if (e == hipSuccess) e = alz_launch_decode_gated(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], 1, p->d_results, &p->lz, p->d_gate);
-        if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream launch (format %d) failed: %s", f, hipGetErrorString(e));
-        c->big_launches++;
+        for (uint32_t i = 0; i < p->n; i++) {
+            const int f = (int)p->big_streams[i].format;
+            hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_streams[i], &p->lz, p->d_results + i, p->d_big, p->d_gate);
+            if (e == hipSuccess) e = alz_launch_decode_gated(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->big_pos[i], 1, p->d_results, &p->lz, p->d_gate);
+            if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream launch (format %d) failed: %s", f, hipGetErrorString(e));
+            c->big_launches++;
+        }
         return ALZ_OK;
     }
     int nfmt = 0;

@@ -156,3 +156,27 @@ def test_the_format_classes_reach_it(test_bmp):
         before = F._context().big_stream()
         assert cls().Decompress(comp) == test_bmp
         assert F._context().big_stream() > before, cls.__name__
+
+
+def test_a_handful_of_big_streams_in_one_batch(test_bmp):
+    """A batch of at most eight streams, ALL of them big, takes the path stream by stream (mixed formats, one of them damaged: that one
+    falls through to its exact kernel, the others do not); nine streams, or one small stream among them, run on the production kernels."""
+    from gpu_common import _check, pack_streams
+    fmts = [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_MIO0, A.FMT_LZ11, A.FMT_YAY0, A.FMT_LZSS]
+    items = []
+    for i, f in enumerate(fmts):
+        raw = test_bmp[i * 50000:i * 50000 + 200000 + 1000 * i]
+        comp, aux = O.encode_stream(f, raw, quality=[0, 8][i & 1])
+        if i == 3:
+            comp = comp[:len(comp) // 2]                       # truncated
+        items.append(dict(fmt=f, src=comp, decom_len=len(raw), aux0=aux.aux0, aux1=aux.aux1))
+    with Context(0) as c:
+        for extra, expect in (([], len(fmts)), ([dict(fmt=A.FMT_YAZ0, src=O.encode_stream(A.FMT_YAZ0, test_bmp[:1000], quality=4)[0], decom_len=1000)], 0),
+                              ([items[0]] * 3, 0)):
+            its = items + extra
+            streams, src, dst_bytes = pack_streams(its)
+            o_dst, o_res = O.decode_batch(streams, src, dst_bytes, nthreads=4)
+            before = c.big_stream()
+            g_dst, g_res = c.decode_batch(streams, src, dst_bytes)
+            assert c.big_stream() - before == expect, (len(its), c.big_stream() - before)
+            _check(streams, g_dst, g_res, o_dst, o_res, "handful of %d" % len(its))
