@@ -47,8 +47,9 @@ struct BigArgs {
 };
 
 // ctl words
-enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_NG = 4, C_NT = 5, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
+enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_NG = 4, C_NT = 5, C_SIZE = 6 /* the output size where only the device knows it (LZ4, Snappy) */, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
 #define BIG_OOB 0x40000000u     /* a token that does not lie inside the input (descriptor bit) */
+#define BIG_RUN 0x20000000u     /* a literal RUN: the low 29 bits are its position in the input (LZ4, Snappy) */
 
 __device__ __forceinline__ u32 big_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ u32 big_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
@@ -194,9 +195,10 @@ __global__ __launch_bounds__(64) void big_emit(BigArgs a, const u32* __restrict_
 }
 
 // J: one round of pointer jumping; flags[r] says whether round r left anything unresolved (flags[-1] of round 0 is preset to 1)
-__global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, const u32* __restrict__ flag_prev, u32* __restrict__ flag_cur) {
+__global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, const u32* __restrict__ dev_n, const u32* __restrict__ flag_prev, u32* __restrict__ flag_cur) {
     if (__builtin_nontemporal_load(flag_prev) == 0u) return;
     const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (dev_n) { const u32 m = *dev_n; if (m < n) n = m; }       // (entries exist only below the size the device found)
     if (q >= n) return;
     const u32 v = val[q];
     if (v & BIG_LIT) return;
@@ -206,14 +208,17 @@ __global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, co
 }
 
 // W: bytes out, result, gate
+// (DEVSIZE: the output size is ctl[C_SIZE], at most `a.size` = the room in the destination)
+template <bool DEVSIZE>
 __global__ __launch_bounds__(256) void big_write(BigArgs a, const u32* __restrict__ val, const u32* __restrict__ ctl, alz_result* __restrict__ result, u32* __restrict__ gate) {
-    const bool ok = ctl[C_BAD] == 0u && ctl[C_END] == 1u && ctl[C_TOTAL] >= a.size;
+    const u32 size = DEVSIZE ? ctl[C_SIZE] : a.size;
+    const bool ok = ctl[C_BAD] == 0u && ctl[C_END] == 1u && ctl[C_TOTAL] >= size && size <= a.size && (!DEVSIZE || size != 0u);
     const u32 q = blockIdx.x * 256u + threadIdx.x;
     if (q == 0) {
-        if (ok) { alz_result r; r.dst_len = a.size; r.src_used = ctl[C_USED]; r.status = ALZ_ST_OK; r.reserved = 0; *result = r; *gate = 0u; }
+        if (ok) { alz_result r; r.dst_len = size; r.src_used = ctl[C_USED]; r.status = ALZ_ST_OK; r.reserved = 0; *result = r; *gate = 0u; }
         else *gate = 1u;
     }
-    if (!ok || q >= a.size) return;
+    if (!ok || q >= size) return;
     a.dst[q] = (u8)val[q];
 }
 
@@ -366,10 +371,11 @@ __global__ __launch_bounds__(64) void big_len_offsets(const u32* __restrict__ tl
 }
 
 // P6: the entry of every output byte
-template <bool LZSS>
+template <bool LZSS, bool DEVSIZE = false>
 __global__ __launch_bounds__(256) void big_emit_bytes(u32 size, BigGeom gm, const u32* __restrict__ toff, const u32* __restrict__ tlen, const u32* __restrict__ tdesc,
-                                                      const u32* __restrict__ tend, u32* __restrict__ val, u32* __restrict__ ctl) {
+                                                      const u32* __restrict__ tend, u32* __restrict__ val, u32* __restrict__ ctl, const u8* __restrict__ src = nullptr) {
     const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (DEVSIZE) { const u32 m = ctl[C_SIZE]; if (m > size) { if (q == 0) ctl[C_BAD] = 1u; return; } size = m; }   // (more output than the destination holds: E5, the exact kernel's)
     if (q >= size) return;
     const u32 nt = ctl[C_NT];
     if (nt == 0u) { ctl[C_BAD] = 1u; return; }
@@ -382,12 +388,135 @@ __global__ __launch_bounds__(256) void big_emit_bytes(u32 size, BigGeom gm, cons
         if ((u64)off + len == size) { ctl[C_USED] = tend[t]; ctl[C_END] = 1u; }   // the stream ends with this token: source.Position is just behind it
         else ctl[C_BAD] = 1u;                                    // the last match overshoots the declared size (E4): the exact kernel's case
     }
-    if (desc & BIG_LIT) { val[q] = desc; return; }
+    if (desc & BIG_LIT) { val[q] = (desc & BIG_RUN) ? (BIG_LIT | src[(desc & 0x1FFFFFFFu) + j]) : desc; return; }
     u32 d = desc;
     if (LZSS) { d = ((off & (gm.W - 1u)) - desc) & (gm.W - 1u); if (d == 0u) d = gm.W; }   // LzWindows.OffsetCopy  IO/LzWindows.cs:108-115; E1
     const u32 r = j % d;                                         // byte j copies start - d + (j mod d): the pattern in front of the token
     val[q] = off + r >= d ? off + r - d : BIG_LIT;               // (in front of the stream start: E2 reads 0x00)
 }
+
+// ===============================================================================================================
+// Element streams: LZ4 blocks (Formats/Common/LZ4.cs:176-200) and raw Snappy (Formats/Common/Snappy.cs:205-250).  One byte stream of
+// variable-size elements; the size of "the element that would start at byte p" depends on the bytes behind p alone, so the same list
+// ranking finds the real element starts.  An LZ4 sequence yields two tokens (literal run, match), a Snappy element one; a literal run's
+// descriptor is its position in the input.  Neither body carries a size the host could read: LZ4 decodes its whole input, Snappy states
+// its size in a varint at the front -- the device finds it (ctl[C_SIZE]), the launch is sized by the room in the destination.
+// Elements with more than BIG_EXT length-extension bytes (runs / matches beyond ~512 KiB) and Snappy's 4-byte-offset copies beyond the
+// window (E3) are left to the exact kernel (the gate): the speculation runs for EVERY input byte and must be bounded (an input of n bytes
+// 0xFF costs n x BIG_EXT loop trips: 2 G for a megabyte, a few hundred microseconds of the whole GPU).
+#define BIG_EXT 2048u
+
+struct BigElem { u32 size; bool bad; u32 run_pos, run_len, mlen, dist; bool has_match; };
+
+// ReadExtension (LZ4.cs:241-252): bytes are added until one is not 0xFF -- eight at a time (a chain of a thousand 0xFF bytes, one dependent
+// load each, was 0.4 ms of latency for ONE lane: the Q15 encoding of Test.bmp has such matches).  False: the chain runs past the input
+// or past BIG_EXT bytes.
+__device__ __forceinline__ bool big_lz4_ext(const u8* src, u32 n, u32& sp, u32& len) {
+    for (u32 k = 0; k < BIG_EXT; k += 8u) {
+        if (sp + 8u <= n) {
+            u64 v; __builtin_memcpy(&v, src + sp, 8);
+            const u64 z = ~v;                                     // a byte that is not 0xFF leaves a non-zero byte here
+            if (z == 0ull) { len += 8u * 255u; sp += 8u; continue; }
+            const u32 i = (u32)__builtin_ctzll(z) >> 3;           // the first such byte
+            len += 255u * i + (u32)((v >> (8u * i)) & 0xFFu); sp += i + 1u;
+            return true;
+        }
+        for (u32 i = 0; i < 8u; i++) { if (sp >= n) return false; const u32 b = src[sp++]; len += b; if (b != 255u) return true; }
+    }
+    return false;
+}
+// LZ4 sequence at p (p < n)
+__device__ __forceinline__ BigElem big_lz4_elem(const u8* src, u32 n, u32 p) {
+    BigElem e; e.bad = false; e.has_match = false; e.run_len = 0; e.mlen = 0; e.dist = 0; e.run_pos = 0;
+    u32 sp = p;
+    const u32 tok = src[sp++];
+    u32 L = tok >> 4;
+    if (L == 15u && !big_lz4_ext(src, n, sp, L)) { e.bad = true; e.size = n - p; return e; }
+    if (L > n - sp) { e.bad = true; e.size = n - p; return e; }   // Slice throws  LZ4.cs:187
+    e.run_pos = sp; e.run_len = L;
+    sp += L;
+    if (sp >= n) { e.size = sp - p; return e; }                   // the last sequence has literals only  :190
+    if (sp + 2u > n) { e.bad = true; e.size = n - p; return e; }
+    e.dist = (u32)src[sp] | ((u32)src[sp + 1] << 8); sp += 2;     // :195
+    u32 M = tok & 15u;
+    if (M == 15u && !big_lz4_ext(src, n, sp, M)) { e.bad = true; e.size = n - p; return e; }
+    e.mlen = M + 4u; e.has_match = true;                          // :198
+    if (e.dist == 0u) e.dist = 65536u;                            // E1
+    e.size = sp - p;
+    return e;
+}
+// Snappy element at p; p == 0 is the varint in front (size = its length, run_len = the declared size)
+__device__ __forceinline__ BigElem big_snappy_elem(const u8* src, u32 n, u32 p) {
+    BigElem e; e.bad = false; e.has_match = false; e.run_len = 0; e.mlen = 0; e.dist = 0; e.run_pos = 0;
+    if (p == 0u) {                                                // ReadDecompressedSize  Snappy.cs:109-122
+        u32 result = 0, sh = 0, i = 0, b;
+        do { if (i >= n || i >= 5u) { e.bad = true; e.size = n; return e; } b = src[i++]; result |= (b & 0x7Fu) << (sh & 31u); sh += 7u; } while (b & 0x80u);
+        e.size = i; e.run_len = result;
+        return e;
+    }
+    const u32 tag = src[p], type = tag & 3u, hi = tag >> 2;
+    if (type == 0u) {
+        u32 hdr = 1, len = hi + 1u;
+        if (hi >= 60u) {
+            const u32 nb = hi - 59u;
+            if (p + 1u + nb > n) { e.bad = true; e.size = n - p; return e; }
+            u32 v = 0; for (u32 i = 0; i < nb; i++) v |= (u32)src[p + 1u + i] << (8u * i);
+            if (v >= 0x1FFFFFFFu) { e.bad = true; e.size = n - p; return e; }
+            len = v + 1u; hdr = 1u + nb;
+        }
+        if (len > n - p - hdr) { e.bad = true; e.size = n - p; return e; }
+        e.run_pos = p + hdr; e.run_len = len; e.size = hdr + len;
+        return e;
+    }
+    const u32 need = type == 1u ? 2u : (type == 2u ? 3u : 5u);
+    if (p + need > n) { e.bad = true; e.size = n - p; return e; }
+    e.has_match = true;
+    if (type == 1u) { e.mlen = (hi & 7u) + 4u; e.dist = ((tag >> 5) << 8) | src[p + 1]; }
+    else if (type == 2u) { e.mlen = hi + 1u; e.dist = (u32)src[p + 1] | ((u32)src[p + 2] << 8); }
+    else { e.mlen = hi + 1u; e.dist = (u32)src[p + 1] | ((u32)src[p + 2] << 8) | ((u32)src[p + 3] << 16) | ((u32)src[p + 4] << 24); if (e.dist > 65536u) e.bad = true; }   // E3: BAD_TOKEN in the exact kernel
+    if (e.dist == 0u) e.dist = 65536u;                            // E1
+    e.size = need;
+    return e;
+}
+template <bool LZ4>
+__global__ __launch_bounds__(256) void big_elem_sizes(const u8* __restrict__ src, u32 src_len, u32* __restrict__ next) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p > src_len) return;
+    if (p == src_len) { next[p] = src_len; return; }
+    const BigElem e = LZ4 ? big_lz4_elem(src, src_len, p) : big_snappy_elem(src, src_len, p);
+    const u64 nx = (u64)p + (e.size ? e.size : 1u);
+    next[p] = nx > src_len ? src_len : (u32)nx;
+}
+// the tokens of every real element: LZ4 two (run, match), Snappy one
+template <bool LZ4>
+__global__ __launch_bounds__(256) void big_elem_tokens(const u8* __restrict__ src, u32 src_len, const u32* __restrict__ gpos, u32* __restrict__ ctl,
+                                                       u32* __restrict__ tlen, u32* __restrict__ tdesc, u32* __restrict__ tend) {
+    const u32 ng = ctl[C_NG];
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    constexpr u32 TPE = LZ4 ? 2u : 1u;
+    if (g == 0) ctl[C_NT] = TPE * ng;
+    if (g >= ng) return;
+    const u32 p = gpos[g];
+    const BigElem e = LZ4 ? big_lz4_elem(src, src_len, p) : big_snappy_elem(src, src_len, p);
+    const u64 endp = (u64)p + e.size;
+    const u32 te = endp > src_len ? src_len : (u32)endp;
+    if (LZ4) {
+        if (e.bad) { tlen[2u * g] = 1u; tdesc[2u * g] = BIG_LIT | BIG_OOB; tlen[2u * g + 1u] = 0u; tdesc[2u * g + 1u] = BIG_LIT; }
+        else {
+            tlen[2u * g] = e.run_len; tdesc[2u * g] = BIG_LIT | BIG_RUN | e.run_pos;
+            tlen[2u * g + 1u] = e.has_match ? e.mlen : 0u; tdesc[2u * g + 1u] = e.has_match ? e.dist : BIG_LIT;
+        }
+        tend[2u * g] = te; tend[2u * g + 1u] = te;
+    } else {
+        if (p == 0u) { if (e.bad) ctl[C_BAD] = 1u; ctl[C_SIZE] = e.run_len; tlen[g] = 0u; tdesc[g] = BIG_LIT; }   // the varint: no output, the declared size
+        else if (e.bad) { tlen[g] = 1u; tdesc[g] = BIG_LIT | BIG_OOB; }
+        else if (e.has_match) { tlen[g] = e.mlen; tdesc[g] = e.dist; }
+        else { tlen[g] = e.run_len; tdesc[g] = BIG_LIT | BIG_RUN | e.run_pos; }
+        tend[g] = te;
+    }
+}
+// LZ4: the output size is what the tokens add up to (ctl[C_TOTAL], saturated) -- and the stream is over with its input
+__global__ void big_lz4_size(u32* __restrict__ ctl, u32 src_len) { ctl[C_SIZE] = ctl[C_TOTAL]; ctl[C_USED] = src_len; }
 
 // ---------------------------------------------------------------------------------------------------------------- host side
 static u32 big_ntok(const alz_stream& st) {
@@ -397,18 +526,22 @@ static u32 big_ntok(const alz_stream& st) {
 static u32 big_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r + 1u; }
 static bool big_three(int fmt) { return fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0; }
 static bool big_inter(int fmt) { return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_YAZ0; }
+static bool big_elem(int fmt) { return fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW; }
 static size_t big_al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // layout of the scratch of the interleaved path
 struct InterLayout {
     u32 nodes, max_ng, max_nt, mtiles, ttiles;
     size_t val, jump_a, jump_b, mark, tile_c, tile_cb, gpos, tlen, tdesc, tend, toff, tile_l, tile_lb, ctl, total;
-    InterLayout(const alz_stream& st) {
+    InterLayout(const alz_stream& st, int fmt = ALZ_FMT_YAZ0) {
         nodes = st.src_len + 1u;
-        max_ng = st.src_len / 9u + 2u; max_nt = 8u * max_ng;
+        if (fmt == ALZ_FMT_LZ4_BLOCK) { max_ng = st.src_len / 2u + 2u; max_nt = 2u * max_ng; }        // (a sequence has at least a token and -- all but the last -- an offset)
+        else if (fmt == ALZ_FMT_SNAPPY_RAW) { max_ng = st.src_len / 2u + 2u; max_nt = max_ng; }         // (an element has at least two bytes)
+        else { max_ng = st.src_len / 9u + 2u; max_nt = 8u * max_ng; }
+        const u32 out_bound = big_elem(fmt) ? st.dst_cap : st.decom_len;
         mtiles = (nodes + 1023u) / 1024u; ttiles = (max_nt + 1023u) / 1024u;
         size_t o = 0;
-        val = o; o += big_al((size_t)st.decom_len * 4);
+        val = o; o += big_al((size_t)out_bound * 4);
         jump_a = o; o += big_al((size_t)nodes * 4); jump_b = o; o += big_al((size_t)nodes * 4);
         mark = o; o += big_al((size_t)nodes + 64);
         tile_c = o; o += big_al((size_t)(mtiles + 64) * 4); tile_cb = o; o += big_al((size_t)(mtiles + 64) * 4);
@@ -422,7 +555,12 @@ struct InterLayout {
 };
 
 bool alz_big_eligible(int fmt, const alz_stream* st, const alz_lz_properties* lz, uint32_t min_bytes) {
-    if (!big_three(fmt) && !big_inter(fmt)) return false;
+    if (!big_three(fmt) && !big_inter(fmt) && !big_elem(fmt)) return false;
+    if (big_elem(fmt)) {                                          // no size in the descriptor: what the destination holds, and an input worth the launches
+        if (min_bytes == 0xFFFFFFFFu || st->dst_cap < min_bytes || st->dst_cap > 0x40000000u || st->src_len < 8192u || st->src_len > 0x10000000u) return false;
+        if (fmt == ALZ_FMT_LZ4_BLOCK && st->aux0 != 0u) return false;   // a block of a linked frame continues the window of its predecessors
+        return true;
+    }
     if (st->decom_len < min_bytes || st->decom_len > 0x40000000u) return false;
     if (st->dst_cap < st->decom_len || st->src_len == 0 || st->src_len > 0x40000000u) return false;
     if (big_three(fmt) && (st->aux0 > st->src_len || st->aux1 > st->src_len)) return false;
@@ -431,7 +569,7 @@ bool alz_big_eligible(int fmt, const alz_stream* st, const alz_lz_properties* lz
 }
 
 size_t alz_big_scratch_bytes(int fmt, const alz_stream* st) {
-    if (big_inter(fmt)) return InterLayout(*st).total + 256;
+    if (big_inter(fmt) || big_elem(fmt)) return InterLayout(*st, fmt).total + 256;
     const u32 ntok = big_ntok(*st);
     const size_t ntiles = (ntok + BIG_TILE - 1) / BIG_TILE;
     return big_al((size_t)st->decom_len * 4) + 6 * big_al((ntiles + 64) * 4) + 4 * big_al((size_t)ntok * 4) + big_al((C_FLAGS + 40) * 4) + 256;
@@ -464,15 +602,52 @@ static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const
     hipLaunchKernelGGL((big_emit_bytes<FMT == ALZ_FMT_LZSS>), dim3(nb), dim3(256), 0, stream, st->decom_len, gm, toff, tlen, tdesc, tend, val, ctl);
     const u32 rounds = big_rounds(L.max_nt);
     for (u32 r = 0; r < rounds; r++)
-        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->decom_len, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
+        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->decom_len, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
-    hipLaunchKernelGGL(big_write, dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    return hipGetLastError();
+}
+
+template <bool LZ4>
+static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate) {
+    const InterLayout L(*st, LZ4 ? ALZ_FMT_LZ4_BLOCK : ALZ_FMT_SNAPPY_RAW);
+    u32* val = (u32*)(base + L.val); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b); u8* mark = base + L.mark;
+    u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
+    u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
+    u32* tile_l = (u32*)(base + L.tile_l); u32* tile_lb = (u32*)(base + L.tile_lb); u32* ctl = (u32*)(base + L.ctl);
+    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)L.nodes + 64, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
+    if (e != hipSuccess) return e;
+    const u32 nbn = (L.nodes + 255u) / 256u;
+    hipLaunchKernelGGL((big_elem_sizes<LZ4>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
+    const u32 rr = big_rounds(L.max_ng);
+    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_c);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
+    hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_cb, gpos);
+    hipLaunchKernelGGL((big_elem_tokens<LZ4>), dim3((L.max_ng + 255u) / 256u), dim3(256), 0, stream, src, st->src_len, gpos, ctl, tlen, tdesc, tend);
+    hipLaunchKernelGGL(big_len_count, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_l);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_l, tile_lb, L.ttiles, ctl + C_TOTAL);
+    hipLaunchKernelGGL(big_len_offsets, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_lb, toff);
+    if (LZ4) hipLaunchKernelGGL(big_lz4_size, dim3(1), dim3(1), 0, stream, ctl, st->src_len);
+    const u32 nb = (st->dst_cap + 255u) / 256u;
+    BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
+    hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src);
+    const u32 rounds = big_rounds(L.max_nt);
+    for (u32 r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
+    BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
+    hipLaunchKernelGGL((big_write<true>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
     return hipGetLastError();
 }
 
 hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, const alz_lz_properties* lz,
                           alz_result* d_result, void* d_scratch, uint32_t* d_gate) {
     const u8* src = (const u8*)d_src_base + st->src_off; u8* dst = (u8*)d_dst_base + st->dst_off;
+    if (fmt == ALZ_FMT_LZ4_BLOCK) return launch_elem<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
+    if (fmt == ALZ_FMT_SNAPPY_RAW) return launch_elem<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (big_inter(fmt)) {
         BigGeom gm; gm.length_bits = lz->length_bits; gm.min_length = lz->min_length; gm.windows_start = lz->windows_start;
         gm.max_distance = lz->max_distance; gm.W = 1u << lz->window_bits;
@@ -518,7 +693,7 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
     hipLaunchKernelGGL((big_emit_bytes<false>), dim3(nb), dim3(256), 0, stream, a.size, gm, toff, tlen, tdesc, tend, val, ctl);
     for (u32 r = 0; r < rounds; r++)
-        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, a.size, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
-    hipLaunchKernelGGL(big_write, dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, a.size, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
+    hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
     return hipGetLastError();
 }

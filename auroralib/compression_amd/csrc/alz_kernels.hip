@@ -746,7 +746,8 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
 template <int FMT>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_FMT_LZO ? 5 : ALZ_QUEUE_WAVES, 8)))
 void alz_decode_queue2_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
-                              const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results) {
+                              const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, const u32* __restrict__ gate) {
+    if (gate != nullptr && __builtin_nontemporal_load(gate) == 0u) return;   // (alz_launch_decode_gated)
     constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK, LZO = FMT == ALZ_FMT_LZO, SNAPPY = FMT == ALZ_FMT_SNAPPY_RAW;
     static_assert(LZ4 || LZO || SNAPPY, "formats with lane-parallel rounds and literal runs");
     constexpr u32 LW = ALZ_QUEUE_LW, QCH = 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u, SCR = ALZ_EMIT_SCRATCH, SLACK = ALZ_WIN_SLACK;
@@ -907,8 +908,8 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
 #endif
 static bool queue_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= ALZ_QUEUE2_MAX); }
 template <int FMT>
-static hipError_t launch_queue2(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count, alz_result* results) {
-    hipLaunchKernelGGL((alz_decode_queue2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results);
+static hipError_t launch_queue2(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count, alz_result* results, const u32* gate = nullptr) {
+    hipLaunchKernelGGL((alz_decode_queue2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, gate);
     return hipGetLastError();
 }
 
@@ -963,6 +964,8 @@ hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src,
     case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_LZ11: return launch_fast<ALZ_FMT_LZ11>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_LZ4_BLOCK: return launch_queue2<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results, gate);   // (a lone stream: the two-wavefront shape)
+    case ALZ_FMT_SNAPPY_RAW: return launch_queue2<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results, gate);
     case ALZ_FMT_LZSS: {                                      // (the same choice of window as alz_launch_decode)
         const u32 W = 1u << lz.window_bits;
         if (W <= 4096 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096>(stream, s, d, streams, index, count, results, lz, W, 1, gate);

@@ -735,13 +735,15 @@ PUBLISHED_SINGLE = {("yay0", 0): (470.82, "Benchmarks.md:78"), ("yay0", 15): (82
                     ("yaz0", 0): (494.53, "Benchmarks.md:82"), ("yaz0", 15): (877.48, "Benchmarks.md:84"),
                     ("lz10", 0): (427.99, "Benchmarks.md:58"), ("lz10", 15): (429.68, "Benchmarks.md:60"),
                     ("lz11", 0): (560.85, "Benchmarks.md:62"), ("lz11", 15): (951.02, "Benchmarks.md:64"),
-                    ("lzss", 0): (330.31, "Benchmarks.md:30"), ("lzss", 15): (359.94, "Benchmarks.md:32")}
+                    ("lzss", 0): (330.31, "Benchmarks.md:30"), ("lzss", 15): (359.94, "Benchmarks.md:32"),
+                    ("lz4_block", 0): (747.58, "Benchmarks.md:22 (LZ4Legacy: this block behind an 8-byte header)"),
+                    ("lz4_block", 15): (2191.72, "Benchmarks.md:24 (LZ4Legacy: this block behind an 8-byte header)")}
 
 
 def single_stream(ctx, np, A, synth, Plan):
     """The reference's OWN benchmark shape (Benchmarks/Benchmarks/TestAllAlgorithms.cs:37-69): ONE stream = the first 1 000 KiB of
     Test.bmp, compressed at quality 0 / 15, then Decompress timed -- for the six formats whose single streams run on the whole GPU
-    (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0, csrc/alz_big.hip).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
+    (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / LZ4 blocks, csrc/alz_big.hip).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
     class's Decompress(Stream, Stream) costs), `device_GiB_s` = the kernels alone; beside them the managed figure the reference
     publishes for this exact input on its own machine (another CPU, no GPU: context, not a baseline measured here)."""
     from auroralib.compression_amd import formats as F
@@ -749,14 +751,15 @@ def single_stream(ctx, np, A, synth, Plan):
     bmp = lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read())
     raw = bytes(bmp[:1024000]); n = len(raw)
     out = []
-    for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss"):
+    for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "lz4_block"):
         fmt = A.FORMAT_NAMES.index(fname)
         for q in (0, 15):
             cap = n + n // 4 + 64
             es = (A.Stream * 1)(A.Stream(0, 0, n, cap, 0, 0, 0, fmt))
             enc, eres, eaux = ctx.encode_batch(es, np.frombuffer(raw + bytes(64), dtype=np.uint8), cap + 64, quality=q)
             comp = bytes(enc[:eres[0].dst_len]); a0, a1 = eaux[0].aux0, eaux[0].aux1
-            st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, n, a0, a1, fmt))
+            decl = 0 if fname == "lz4_block" else n                 # (an LZ4 block carries no size: the destination's room bounds it)
+            st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, decl, a0, a1, fmt))
             d_src, d_dst = ctx.malloc(len(comp) + 64), ctx.malloc(n + 64)
             try:
                 ctx.h2d(d_src, np.frombuffer(comp + bytes(64), dtype=np.uint8))
@@ -769,10 +772,10 @@ def single_stream(ctx, np, A, synth, Plan):
                 whole_gpu = ctx.big_stream() > before
             finally:
                 ctx.free(d_src); ctx.free(d_dst)
-            got, r = ctx.decode(fmt, comp, decom_len=n, aux0=a0, aux1=a1)
+            got, r = ctx.decode(fmt, comp, decom_len=decl, cap=n, aux0=a0, aux1=a1)
             reps, t0 = 20, time.perf_counter()
             for _ in range(reps):
-                got, r = ctx.decode(fmt, comp, decom_len=n, aux0=a0, aux1=a1)
+                got, r = ctx.decode(fmt, comp, decom_len=decl, cap=n, aux0=a0, aux1=a1)
             wall_ms = (time.perf_counter() - t0) / reps * 1e3
             ok = ok and r.status == 0 and got == raw
             pub, where = PUBLISHED_SINGLE[(fname, q)]

@@ -18,7 +18,8 @@ from auroralib.compression_amd import synth
 from auroralib.compression_amd.batch import Context, Plan
 
 pytestmark = pytest.mark.gpu
-FMTS = [A.FMT_YAY0, A.FMT_MIO0, A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0]
+FMTS = [A.FMT_YAY0, A.FMT_MIO0, A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW]
+ELEM = (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW)       # no size in the descriptor: the room in the destination bounds the launch
 THREE = (A.FMT_YAY0, A.FMT_MIO0)
 OFF = 0xFFFFFFFF
 
@@ -26,6 +27,8 @@ OFF = 0xFFFFFFFF
 def _one(c, fmt, comp, decom_len, aux0, aux1, cap=None, expect_big=None, what="", lz=None):
     """The stream through alz_decode (host buffers) and through a device-resident plan with a canary; both against the oracle."""
     cap = decom_len if cap is None else cap
+    if fmt in ELEM:
+        decom_len, aux0, aux1 = 0, 0, 0
     want, wr = O.decode_stream(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1, lz=lz)
     before = c.big_stream()
     got, r = c.decode(fmt, comp, decom_len=decom_len, cap=cap, aux0=aux0, aux1=aux1, lz=lz)
@@ -75,6 +78,8 @@ def test_synthetic_sizes_and_the_threshold(fmt):
             s = b.streams[0]
             comp = bytes(b.src[s.src_off:s.src_off + s.src_len])
             _one(c, fmt, comp, size, s.aux0, s.aux1, expect_big=size >= 98304, what="synthetic %d" % size)
+            if fmt in ELEM:                                    # a destination with room to spare (the usual case for a body without a size)
+                _one(c, fmt, comp, size, 0, 0, cap=size + 70000, expect_big=True, what="synthetic %d, roomy" % size)
         b = synth.make_batch(fmt, 1, 300000, 7)
         s = b.streams[0]
         comp = bytes(b.src[s.src_off:s.src_off + s.src_len])
@@ -98,7 +103,8 @@ def test_degenerate_data(fmt):
         for k, raw in enumerate(raws):
             for q in (0, 8):
                 comp, aux = O.encode_stream(fmt, raw, quality=q)
-                _one(c, fmt, comp, len(raw), aux.aux0, aux.aux1, expect_big=True, what="degenerate %d q%d" % (k, q))
+                # (LZ4 / Snappy: an input below 8 KiB is not worth the launches -- runs compress to a few hundred bytes)
+                _one(c, fmt, comp, len(raw), aux.aux0, aux.aux1, expect_big=(len(comp) >= 8192 if fmt in ELEM else True), what="degenerate %d q%d" % (k, q))
 
 
 @pytest.mark.parametrize("fmt", FMTS)
@@ -180,3 +186,17 @@ def test_a_handful_of_big_streams_in_one_batch(test_bmp):
             g_dst, g_res = c.decode_batch(streams, src, dst_bytes)
             assert c.big_stream() - before == expect, (len(its), c.big_stream() - before)
             _check(streams, g_dst, g_res, o_dst, o_res, "handful of %d" % len(its))
+
+
+def test_lz4_long_extensions_and_a_wall_of_ff():
+    """LZ4 length extensions: matches and runs of hundreds of KiB (chains of 0xFF bytes) stay on the path up to its bound and fall through
+    beyond it; an input that is nothing but 0xFF (every byte position speculates an extension chain up to the bound) finishes promptly."""
+    rng = np.random.default_rng(9)
+    noise = bytes(rng.integers(0, 256, 40000, dtype=np.uint8))
+    with Context(0) as c:
+        for raw, big in ((noise + bytes(300000) + noise, True), (noise + bytes(900000) + noise, False), (noise[:9000] + bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), True)):
+            comp, _ = O.encode_stream(A.FMT_LZ4_BLOCK, raw, quality=8)
+            _one(c, A.FMT_LZ4_BLOCK, comp, len(raw), 0, 0, what="lz4 long %d" % len(raw))
+        wall = b"\xFF" * 200000
+        _one(c, A.FMT_LZ4_BLOCK, wall, 0, 0, 0, cap=1 << 20, what="wall of 0xFF")
+        _one(c, A.FMT_SNAPPY_RAW, b"\xFF" * 100000, 0, 0, 0, cap=1 << 20, what="snappy wall of 0xFF")

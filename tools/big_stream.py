@@ -11,11 +11,12 @@ from auroralib.compression_amd.batch import Context, Plan
 
 bmp = O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0]
 c = Context(0)
-for fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_YAZ0, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZSS):
+for fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_YAZ0, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZSS, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW):
     for label, raw in (("Test.bmp[0:256 KiB]", bmp[:262144]), ("Test.bmp[0:1 000 KiB]", bmp[:1024000]), ("Test.bmp x 4 (4 MiB)", (bmp * 4)[:4 << 20])):
         comp, aux = O.encode_stream(fmt, raw, quality=8)
         n = len(raw)
-        st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, n, aux.aux0, aux.aux1, fmt))
+        sized = fmt not in (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW)       # (those two carry no size in the descriptor: the destination's room bounds them)
+        st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, n if sized else 0, aux.aux0, aux.aux1, fmt))
         src = np.frombuffer(comp + bytes(64), dtype=np.uint8)
         d_src, d_dst = c.malloc(src.nbytes), c.malloc(n + 64)
         c.h2d(d_src, src)
@@ -27,10 +28,10 @@ for fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_YAZ0, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ
             ms = p.execute_timed(d_src, d_dst, iters=10)
             ok = p.results()[0].status == 0 and bytes(c.d2h(d_dst, n)) == raw
             p.close()
-            c.decode(fmt, comp, decom_len=n, aux0=aux.aux0, aux1=aux.aux1)
+            c.decode(fmt, comp, decom_len=n if sized else 0, cap=n, aux0=aux.aux0, aux1=aux.aux1)
             t0 = time.perf_counter()
             for _ in range(10):
-                c.decode(fmt, comp, decom_len=n, aux0=aux.aux0, aux1=aux.aux1)
+                c.decode(fmt, comp, decom_len=n if sized else 0, cap=n, aux0=aux.aux0, aux1=aux.aux1)
             wall = (time.perf_counter() - t0) / 10 * 1e3
             out[mode] = (ms, wall, ok)
         print("%-5s %-22s ratio %.3f | " % (A.FORMAT_NAMES[fmt], label, len(comp) / n) + " | ".join(
