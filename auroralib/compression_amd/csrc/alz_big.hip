@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "alz_internal.h"
+#include "alz_prs_table.h"
 
 typedef uint8_t u8;
 typedef uint32_t u32;
@@ -47,7 +48,7 @@ struct BigArgs {
 };
 
 // ctl words
-enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_NG = 4, C_NT = 5, C_SIZE = 6 /* the output size where only the device knows it (LZ4, Snappy) */, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
+enum { C_BAD = 0, C_END = 1, C_USED = 2, C_TOTAL = 3, C_NG = 4, C_NT = 5, C_SIZE = 6 /* the output size where only the device knows it (LZ4, Snappy, PRS) */, C_TERM = 7 /* PRS: the first terminator token */, C_FLAGS = 8 /* .. C_FLAGS + rounds: "round r changed something" */ };
 #define BIG_OOB 0x40000000u     /* a token that does not lie inside the input (descriptor bit) */
 #define BIG_RUN 0x20000000u     /* a literal RUN: the low 29 bits are its position in the input (LZ4, Snappy) */
 
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64) void big_len_offsets(const u32* __restrict__ tl
 // P6: the entry of every output byte
 template <bool LZSS, bool DEVSIZE = false>
 __global__ __launch_bounds__(256) void big_emit_bytes(u32 size, BigGeom gm, const u32* __restrict__ toff, const u32* __restrict__ tlen, const u32* __restrict__ tdesc,
-                                                      const u32* __restrict__ tend, u32* __restrict__ val, u32* __restrict__ ctl, const u8* __restrict__ src = nullptr) {
+                                                      const u32* __restrict__ tend, u32* __restrict__ val, u32* __restrict__ ctl, const u8* __restrict__ src = nullptr, bool used_is_set = false) {
     const u32 q = blockIdx.x * 256u + threadIdx.x;
     if (DEVSIZE) { const u32 m = ctl[C_SIZE]; if (m > size) { if (q == 0) ctl[C_BAD] = 1u; return; } size = m; }   // (more output than the destination holds: E5, the exact kernel's)
     if (q >= size) return;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void big_emit_bytes(u32 size, BigGeom gm, cons
     const u32 j = q - off;
     if (j >= len || (desc & BIG_OOB)) { ctl[C_BAD] = 1u; val[q] = BIG_LIT; return; }   // the tokens end in front of the declared size / a token of the stream reads past the input
     if (q == size - 1u) {
-        if ((u64)off + len == size) { ctl[C_USED] = tend[t]; ctl[C_END] = 1u; }   // the stream ends with this token: source.Position is just behind it
+        if ((u64)off + len == size) { if (!used_is_set) ctl[C_USED] = tend[t]; ctl[C_END] = 1u; }   // the stream ends with this token: source.Position is just behind it (PRS: behind its terminator)
         else ctl[C_BAD] = 1u;                                    // the last match overshoots the declared size (E4): the exact kernel's case
     }
     if (desc & BIG_LIT) { val[q] = (desc & BIG_RUN) ? (BIG_LIT | src[(desc & 0x1FFFFFFFu) + j]) : desc; return; }
@@ -518,6 +519,98 @@ __global__ __launch_bounds__(256) void big_elem_tokens(const u8* __restrict__ sr
 // LZ4: the output size is what the tokens add up to (ctl[C_TOTAL], saturated) -- and the stream is over with its input
 __global__ void big_lz4_size(u32* __restrict__ ctl, u32 src_len) { ctl[C_SIZE] = ctl[C_TOTAL]; ctl[C_USED] = src_len; }
 
+// ===============================================================================================================
+// PRS (Sega/PRS.cs:59-102): control bits and data bytes interleave, and a flag byte is fetched when a bit is needed -- but every flag byte
+// is followed by the data of exactly the tokens whose LAST control bit lies in it (a group), and which tokens those are depends on the flag
+// byte and on how much of a token the flag byte before it left unfinished: five entry states (csrc/alz_prs_table.h, the table the wavefront
+// kernels walk with).  So the list to rank has one node per (input byte, entry state): next(p, s) = (p + size of the group, exit state),
+// where the only DATA the size depends on is, per long match of the group, whether the low three bits of its word are zero (a third byte
+// follows).  The stream has no size: it ends at the first long match whose word is zero (:78-79); the tokens in front of it add up to
+// the output size.
+__device__ const AlzPrsTable big_prs_table = alz_make_prs_table();
+__device__ __forceinline__ u32 big_rev8(u32 b) { return __builtin_bitreverse32(b) >> 24; }
+
+struct BigPrsGroup { u32 size, exit_state, ntok; bool oob; u32 w0, w1; };
+// the group whose flag byte is at p, entered in state st; thirds = bit k set: long match k has a third byte
+template <bool BIG>
+__device__ __forceinline__ BigPrsGroup big_prs_group(const u8* src, u32 n, u32 p, u32 st, u32& thirds) {
+    BigPrsGroup g; g.oob = false; thirds = 0;
+    const u32 f = BIG ? big_rev8(src[p]) : (u32)src[p];
+    g.w0 = big_prs_table.w[2u * (st * 256u + f)]; g.w1 = big_prs_table.w[2u * (st * 256u + f) + 1u];
+    g.exit_state = (g.w0 >> 11) & 7u; g.ntok = ((g.w0 >> 7) & 7u) + 1u;
+    u32 size = g.w0 & 15u;                                        // flag byte + data bytes without the third bytes
+    const u32 nlong = ((g.w0 >> 4) & 1u) + ((g.w0 >> 5) & 1u) + ((g.w0 >> 6) & 1u) + ((g.w0 >> 10) & 1u);
+    u32 extra = 0;
+    for (u32 k = 0; k < nlong; k++) {
+        const u64 at = (u64)p + ((g.w0 >> (16u + 4u * k)) & 15u) + extra;   // first data byte of long match k
+        if (at + 2u > n) { g.oob = true; break; }
+        const u32 lowbyte = BIG ? src[at + 1u] : src[at];        // the byte that holds the low three bits of the word
+        if ((lowbyte & 7u) == 0u) {
+            const u32 other = BIG ? src[at] : src[at + 1u];
+            if ((lowbyte | other) != 0u) { thirds |= 1u << k; extra++; }   // (the zero word is the terminator: no third byte)
+        }
+    }
+    g.size = size + extra;
+    return g;
+}
+template <bool BIG>
+__global__ __launch_bounds__(256) void big_prs_sizes(const u8* __restrict__ src, u32 src_len, u32* __restrict__ next) {
+    const u32 id = blockIdx.x * 256u + threadIdx.x;               // node = 5 p + state
+    const u32 p = id / ALZ_PRS_STATES, st = id - p * ALZ_PRS_STATES;
+    if (p > src_len) return;
+    if (p == src_len) { next[id] = id; return; }
+    u32 thirds;
+    const BigPrsGroup g = big_prs_group<BIG>(src, src_len, p, st, thirds);
+    const u64 np = (u64)p + g.size;
+    next[id] = (np >= src_len || g.oob) ? src_len * ALZ_PRS_STATES : (u32)np * ALZ_PRS_STATES + g.exit_state;
+}
+// up to eight tokens per group (unused slots: length 0)
+template <bool BIG>
+__global__ __launch_bounds__(256) void big_prs_tokens(const u8* __restrict__ src, u32 src_len, const u32* __restrict__ gpos, u32* __restrict__ ctl,
+                                                      u32* __restrict__ tlen, u32* __restrict__ tdesc, u32* __restrict__ tend) {
+    const u32 ng = ctl[C_NG];
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g == 0) ctl[C_NT] = 8u * ng;
+    if (g >= ng) return;
+    const u32 id = gpos[g], p = id / ALZ_PRS_STATES, st = id - p * ALZ_PRS_STATES;
+    u32 thirds;
+    const BigPrsGroup gr = big_prs_group<BIG>(src, src_len, p, st, thirds);
+    u64 pos = (u64)p + 1u;
+    u32 nl = 0;
+    for (u32 k = 0; k < 8u; k++) {
+        const u32 i = 8u * g + k;
+        u32 len = 0, desc = BIG_LIT;
+        if (k < gr.ntok) {
+            const u32 code = (gr.w1 >> (3u * k)) & 7u;
+            if (code == 0u) {                                     // literal  PRS.cs:66-70
+                if (pos + 1u > src_len) { len = 1; desc = BIG_LIT | BIG_OOB; } else { len = 1; desc = BIG_LIT | src[pos]; }
+                pos += 1;
+            } else if (code == 1u) {                              // long match  :73-90
+                const bool third = (thirds >> nl) & 1u; nl++;
+                const u32 need = third ? 3u : 2u;
+                if (pos + need > src_len) { len = 1; desc = BIG_LIT | BIG_OOB; }
+                else {
+                    const u32 x0 = src[pos], x1 = src[pos + 1];
+                    const u32 v = BIG ? ((x0 << 8) | x1) : ((x1 << 8) | x0);
+                    if (v == 0u) { len = 0; desc = BIG_LIT; atomicMin(ctl + C_TERM, i); }   // the terminator  :78-79
+                    else { desc = 0x2000u - (v >> 3); len = (v & 7u) ? (v & 7u) + 2u : (u32)src[pos + 2] + 1u; }
+                }
+                pos += need;
+            } else {                                              // short match  :91-96
+                if (pos + 1u > src_len) { len = 1; desc = BIG_LIT | BIG_OOB; } else { len = (code & 3u) + 2u; desc = 0x100u - src[pos]; }
+                pos += 1;
+            }
+        }
+        tlen[i] = len; tdesc[i] = desc; tend[i] = pos > src_len ? src_len : (u32)pos;
+    }
+}
+// the output ends in front of the first terminator; source.Position is just behind it
+__global__ void big_prs_size(u32* __restrict__ ctl, const u32* __restrict__ toff, const u32* __restrict__ tend) {
+    const u32 t = ctl[C_TERM];
+    if (t == 0xFFFFFFFFu || t >= ctl[C_NT]) { ctl[C_BAD] = 1u; ctl[C_SIZE] = 0u; return; }   // no terminator in the input: EndOfStreamException  :101
+    ctl[C_SIZE] = toff[t]; ctl[C_USED] = tend[t];
+}
+
 // ---------------------------------------------------------------------------------------------------------------- host side
 static u32 big_ntok(const alz_stream& st) {
     const u64 by_flags = 8ull * st.src_len;
@@ -526,7 +619,8 @@ static u32 big_ntok(const alz_stream& st) {
 static u32 big_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r + 1u; }
 static bool big_three(int fmt) { return fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0; }
 static bool big_inter(int fmt) { return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_YAZ0; }
-static bool big_elem(int fmt) { return fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW; }
+static bool big_prs(int fmt) { return fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE; }
+static bool big_elem(int fmt) { return fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW || big_prs(fmt); }
 static size_t big_al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // layout of the scratch of the interleaved path
@@ -535,7 +629,8 @@ struct InterLayout {
     size_t val, jump_a, jump_b, mark, tile_c, tile_cb, gpos, tlen, tdesc, tend, toff, tile_l, tile_lb, ctl, total;
     InterLayout(const alz_stream& st, int fmt = ALZ_FMT_YAZ0) {
         nodes = st.src_len + 1u;
-        if (fmt == ALZ_FMT_LZ4_BLOCK) { max_ng = st.src_len / 2u + 2u; max_nt = 2u * max_ng; }        // (a sequence has at least a token and -- all but the last -- an offset)
+        if (big_prs(fmt)) { nodes = (st.src_len + 1u) * ALZ_PRS_STATES; max_ng = st.src_len / 2u + 2u; max_nt = 8u * max_ng; }   // (a group has a flag byte and at least one data byte)
+        else if (fmt == ALZ_FMT_LZ4_BLOCK) { max_ng = st.src_len / 2u + 2u; max_nt = 2u * max_ng; }        // (a sequence has at least a token and -- all but the last -- an offset)
         else if (fmt == ALZ_FMT_SNAPPY_RAW) { max_ng = st.src_len / 2u + 2u; max_nt = max_ng; }         // (an element has at least two bytes)
         else { max_ng = st.src_len / 9u + 2u; max_nt = 8u * max_ng; }
         const u32 out_bound = big_elem(fmt) ? st.dst_cap : st.decom_len;
@@ -643,9 +738,48 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     return hipGetLastError();
 }
 
+template <bool BIG>
+static hipError_t launch_prs(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate) {
+    const InterLayout L(*st, BIG ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE);
+    u32* val = (u32*)(base + L.val); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b); u8* mark = base + L.mark;
+    u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
+    u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
+    u32* tile_l = (u32*)(base + L.tile_l); u32* tile_lb = (u32*)(base + L.tile_lb); u32* ctl = (u32*)(base + L.ctl);
+    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)L.nodes + 64, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);                       // node (byte 0, nothing pending)
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_TERM), -1, 1, stream);
+    if (e != hipSuccess) return e;
+    const u32 nbn = (L.nodes + 255u) / 256u;
+    const u32 real_nodes = L.nodes - ALZ_PRS_STATES;              // the nodes of the bytes that exist (the end node is the first behind them)
+    hipLaunchKernelGGL((big_prs_sizes<BIG>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
+    const u32 rr = big_rounds(L.max_ng);
+    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, real_nodes, tile_c);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
+    hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, real_nodes, tile_cb, gpos);
+    hipLaunchKernelGGL((big_prs_tokens<BIG>), dim3((L.max_ng + 255u) / 256u), dim3(256), 0, stream, src, st->src_len, gpos, ctl, tlen, tdesc, tend);
+    hipLaunchKernelGGL(big_len_count, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_l);
+    hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_l, tile_lb, L.ttiles, ctl + C_TOTAL);
+    hipLaunchKernelGGL(big_len_offsets, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_lb, toff);
+    hipLaunchKernelGGL(big_prs_size, dim3(1), dim3(1), 0, stream, ctl, toff, tend);
+    const u32 nb = (st->dst_cap + 255u) / 256u;
+    BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
+    hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src, true);
+    const u32 rounds = big_rounds(L.max_nt);
+    for (u32 r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
+    BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
+    hipLaunchKernelGGL((big_write<true>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    return hipGetLastError();
+}
+
 hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, const alz_lz_properties* lz,
                           alz_result* d_result, void* d_scratch, uint32_t* d_gate) {
     const u8* src = (const u8*)d_src_base + st->src_off; u8* dst = (u8*)d_dst_base + st->dst_off;
+    if (fmt == ALZ_FMT_PRS_BE) return launch_prs<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
+    if (fmt == ALZ_FMT_PRS_LE) return launch_prs<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (fmt == ALZ_FMT_LZ4_BLOCK) return launch_elem<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (fmt == ALZ_FMT_SNAPPY_RAW) return launch_elem<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (big_inter(fmt)) {

@@ -654,7 +654,8 @@ __global__ __launch_bounds__(128) void alz_decode_fast2c_kernel(const u8* __rest
 // that position with the one-wavefront loop of alz_decode_queue_kernel (exact parser included).
 template <int FMT>
 __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
-                                                              const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results) {
+                                                              const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, const u32* __restrict__ gate) {
+    if (gate != nullptr && __builtin_nontemporal_load(gate) == 0u) return;   // (alz_launch_decode_gated)
     constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
     constexpr u32 LW = 8192u, QCH = 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u, SCR = 128u;
     constexpr u32 MB = 64u + 8u;                              // mailbox slot: 64 tokens + {nt | stop, total, position behind, flag register, terminator}
@@ -964,6 +965,8 @@ hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src,
     case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_LZ11: return launch_fast<ALZ_FMT_LZ11>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_PRS_BE: hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_BE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, gate); return hipGetLastError();
+    case ALZ_FMT_PRS_LE: hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, gate); return hipGetLastError();
     case ALZ_FMT_LZ4_BLOCK: return launch_queue2<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results, gate);   // (a lone stream: the two-wavefront shape)
     case ALZ_FMT_SNAPPY_RAW: return launch_queue2<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results, gate);
     case ALZ_FMT_LZSS: {                                      // (the same choice of window as alz_launch_decode)
@@ -1002,9 +1005,9 @@ hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* src, void*
         case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3);
         case ALZ_FMT_SMSR00: return launch_fast<ALZ_FMT_SMSR00>(stream, s, d, streams, index, count, results, lz, 4096, 2);
         case ALZ_FMT_LZHUDSON: return launch_fast<ALZ_FMT_LZHUDSON>(stream, s, d, streams, index, count, results, lz, 4096, 1);
-        case ALZ_FMT_PRS_BE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_BE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results); return hipGetLastError(); }
+        case ALZ_FMT_PRS_BE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_BE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, (const u32*)nullptr); return hipGetLastError(); }
                              return launch_queue<ALZ_FMT_PRS_BE>(stream, s, d, streams, index, count, results);
-        case ALZ_FMT_PRS_LE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results); return hipGetLastError(); }
+        case ALZ_FMT_PRS_LE: if (prs_two_waves(count)) { hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, (const u32*)nullptr); return hipGetLastError(); }
                              return launch_queue<ALZ_FMT_PRS_LE>(stream, s, d, streams, index, count, results);
         case ALZ_FMT_LZ4_BLOCK: if (queue_two_waves()) return launch_queue2<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);
                                 return launch_queue<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results);

@@ -29,7 +29,7 @@ namespace AuroraLib.Compression.Amd.Sega
         /// other one when that attempt throws.  The rest of the source is read ONCE; both attempts decode the same buffer.</summary>
         public static void DecompressHeaderless(Stream source, Stream destination)
         {
-            if (!AmdBody.UseGpu((uint)Math.Min(uint.MaxValue, (source.Length - source.Position) * 4))) { Managed.PRS.DecompressHeaderless(source, destination); return; }
+            if (!AmdBody.UseGpuBigStream((uint)Math.Min(uint.MaxValue, (source.Length - source.Position) * 4))) { Managed.PRS.DecompressHeaderless(source, destination); return; }
             long destinationPos = destination.Position;
             byte[] body = AmdBody.RentRest(source, out int length);
             try
