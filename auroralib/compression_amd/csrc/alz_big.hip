@@ -611,6 +611,112 @@ __global__ void big_prs_size(u32* __restrict__ ctl, const u32* __restrict__ toff
     ctl[C_SIZE] = toff[t]; ctl[C_USED] = tend[t];
 }
 
+// ===============================================================================================================
+// LZO (Formats/Common/LZO.cs:49-139): what an instruction byte means depends on its first byte and, for the opcodes below 16, on how many
+// literals the instruction before it copied ("plain": 0, 1-3, or 4 after a literal-run instruction) -- three entry states, one list node
+// per (input byte, state).  An instruction yields up to two tokens (a match or a literal run, then 0-3 trailing literals); the stream
+// ends at the end marker (a code-1 instruction with distance 16 384, :107-109), which plays the part of PRS's terminator.  The first
+// byte of the stream is special (:59-64: above 17 it is a literal run, and the instruction behind it is entered with plain = 0 -- the
+// managed decoder's quirk, kept).
+#define BIG_LZO_STATES 3u
+struct BigLzo { u32 size, next_state; bool bad, term; u32 len0, desc0, len1, desc1; };
+// ReadExtendedInt (LZO.cs:252-262): zero bytes add 255 each until a non-zero byte -- eight at a time, as big_lz4_ext
+__device__ __forceinline__ bool big_lzo_ext(const u8* src, u32 n, u32& sp, u32& len) {
+    for (u32 k = 0; k < BIG_EXT; k += 8u) {
+        if (sp + 8u <= n) {
+            u64 v; __builtin_memcpy(&v, src + sp, 8);
+            if (v == 0ull) { len += 8u * 255u; sp += 8u; continue; }
+            const u32 i = (u32)__builtin_ctzll(v) >> 3;
+            len += 255u * i + (u32)((v >> (8u * i)) & 0xFFu); sp += i + 1u;
+            return true;
+        }
+        for (u32 i = 0; i < 8u; i++) { if (sp >= n) return false; const u32 b = src[sp++]; if (b) { len += b; return true; } len += 255u; }
+    }
+    return false;
+}
+__device__ __forceinline__ BigLzo big_lzo_instr(const u8* src, u32 n, u32 p, u32 st) {
+    BigLzo r; r.bad = false; r.term = false; r.len0 = r.len1 = 0; r.desc0 = r.desc1 = BIG_LIT; r.next_state = 0;
+    u32 sp = p;
+    u32 flag = src[sp++];
+    if (p == 0u && flag > 17u) {                                  // :59-64
+        const u32 len = flag - 17u;
+        if (len > n - sp) { r.bad = true; r.size = n - p; return r; }
+        r.len0 = len; r.desc0 = BIG_LIT | BIG_RUN | sp; r.size = 1u + len; r.next_state = 0;
+        return r;
+    }
+    const u32 code = flag >> 4;
+    u32 length, distance;
+    if (code == 0u) {
+        if (st == 0u) {                                           // a literal run  :72-82
+            length = 3u + flag;
+            if (length == 3u) { length = 18u; if (!big_lzo_ext(src, n, sp, length)) { r.bad = true; r.size = n - p; return r; } }
+            if (length > n - sp) { r.bad = true; r.size = n - p; return r; }
+            r.len0 = length; r.desc0 = BIG_LIT | BIG_RUN | sp; r.size = sp - p + length; r.next_state = 2;   // plain = 4
+            return r;
+        }
+        if (sp >= n) { r.bad = true; r.size = n - p; return r; }
+        const u32 d = src[sp++];
+        if (st == 1u) { distance = (d << 2) + (flag >> 2) + 1u; length = 2u; }              // :83-88
+        else { distance = (d << 2) + (flag >> 2) + 2049u; length = 3u; }                    // :89-94
+    } else if (code == 1u) {                                      // :96-109
+        length = 2u + (flag & 7u);
+        if (length == 2u) { length = 9u; if (!big_lzo_ext(src, n, sp, length)) { r.bad = true; r.size = n - p; return r; } }
+        distance = 16384u + ((flag & 8u) << 11);
+        if (sp + 2u > n) { r.bad = true; r.size = n - p; return r; }
+        flag = src[sp++]; const u32 hi = src[sp++];
+        distance |= (hi << 6) | (flag >> 2);
+        if (distance == 16384u) { r.term = true; r.size = sp - p; return r; }
+    } else if (code <= 3u) {                                      // :110-119
+        length = 2u + (flag & 0x1Fu);
+        if (length == 2u) { length = 33u; if (!big_lzo_ext(src, n, sp, length)) { r.bad = true; r.size = n - p; return r; } }
+        if (sp + 2u > n) { r.bad = true; r.size = n - p; return r; }
+        flag = src[sp++]; const u32 hi = src[sp++];
+        distance = ((hi << 6) | (flag >> 2)) + 1u;
+    } else if (code <= 7u) {                                      // :120-125
+        length = 3u + ((flag >> 5) & 1u);
+        if (sp >= n) { r.bad = true; r.size = n - p; return r; }
+        const u32 d = src[sp++];
+        distance = (d << 3) + ((flag >> 2) & 7u) + 1u;
+    } else {                                                      // :126-131
+        length = 5u + ((flag >> 5) & 3u);
+        if (sp >= n) { r.bad = true; r.size = n - p; return r; }
+        const u32 d = src[sp++];
+        distance = (d << 3) + ((flag & 0x1Cu) >> 2) + 1u;
+    }
+    const u32 plain = flag & 3u;                                  // :132
+    if (plain > n - sp) { r.bad = true; r.size = n - p; return r; }
+    r.len0 = length; r.desc0 = distance;
+    r.len1 = plain; r.desc1 = BIG_LIT | BIG_RUN | sp;
+    r.size = sp - p + plain; r.next_state = plain ? 1u : 0u;
+    return r;
+}
+__global__ __launch_bounds__(256) void big_lzo_sizes(const u8* __restrict__ src, u32 src_len, u32* __restrict__ next) {
+    const u32 id = blockIdx.x * 256u + threadIdx.x;               // node = 3 p + state
+    const u32 p = id / BIG_LZO_STATES, st = id - p * BIG_LZO_STATES;
+    if (p > src_len) return;
+    if (p == src_len) { next[id] = id; return; }
+    const BigLzo r = big_lzo_instr(src, src_len, p, st);
+    const u64 np = (u64)p + (r.size ? r.size : 1u);
+    next[id] = (np >= src_len || r.bad || r.term) ? src_len * BIG_LZO_STATES : (u32)np * BIG_LZO_STATES + r.next_state;
+}
+__global__ __launch_bounds__(256) void big_lzo_tokens(const u8* __restrict__ src, u32 src_len, const u32* __restrict__ gpos, u32* __restrict__ ctl,
+                                                      u32* __restrict__ tlen, u32* __restrict__ tdesc, u32* __restrict__ tend) {
+    const u32 ng = ctl[C_NG];
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g == 0) ctl[C_NT] = 2u * ng;
+    if (g >= ng) return;
+    const u32 id = gpos[g], p = id / BIG_LZO_STATES, st = id - p * BIG_LZO_STATES;
+    const BigLzo r = big_lzo_instr(src, src_len, p, st);
+    const u64 endp = (u64)p + r.size;
+    const u32 te = endp > src_len ? src_len : (u32)endp;
+    if (r.bad) { tlen[2u * g] = 1u; tdesc[2u * g] = BIG_LIT | BIG_OOB; tlen[2u * g + 1u] = 0u; tdesc[2u * g + 1u] = BIG_LIT; }
+    else {
+        if (r.term) atomicMin(ctl + C_TERM, 2u * g);
+        tlen[2u * g] = r.len0; tdesc[2u * g] = r.desc0; tlen[2u * g + 1u] = r.len1; tdesc[2u * g + 1u] = r.desc1;
+    }
+    tend[2u * g] = te; tend[2u * g + 1u] = te;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- host side
 static u32 big_ntok(const alz_stream& st) {
     const u64 by_flags = 8ull * st.src_len;
@@ -620,7 +726,7 @@ static u32 big_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r 
 static bool big_three(int fmt) { return fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0; }
 static bool big_inter(int fmt) { return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_YAZ0; }
 static bool big_prs(int fmt) { return fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE; }
-static bool big_elem(int fmt) { return fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW || big_prs(fmt); }
+static bool big_elem(int fmt) { return fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_LZO || big_prs(fmt); }
 static size_t big_al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // layout of the scratch of the interleaved path
@@ -630,6 +736,7 @@ struct InterLayout {
     InterLayout(const alz_stream& st, int fmt = ALZ_FMT_YAZ0) {
         nodes = st.src_len + 1u;
         if (big_prs(fmt)) { nodes = (st.src_len + 1u) * ALZ_PRS_STATES; max_ng = st.src_len / 2u + 2u; max_nt = 8u * max_ng; }   // (a group has a flag byte and at least one data byte)
+        else if (fmt == ALZ_FMT_LZO) { nodes = (st.src_len + 1u) * BIG_LZO_STATES; max_ng = st.src_len / 2u + 2u; max_nt = 2u * max_ng; }   // (an instruction has at least two bytes, all but a run of one)
         else if (fmt == ALZ_FMT_LZ4_BLOCK) { max_ng = st.src_len / 2u + 2u; max_nt = 2u * max_ng; }        // (a sequence has at least a token and -- all but the last -- an offset)
         else if (fmt == ALZ_FMT_SNAPPY_RAW) { max_ng = st.src_len / 2u + 2u; max_nt = max_ng; }         // (an element has at least two bytes)
         else { max_ng = st.src_len / 9u + 2u; max_nt = 8u * max_ng; }
@@ -738,9 +845,12 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     return hipGetLastError();
 }
 
-template <bool BIG>
-static hipError_t launch_prs(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate) {
-    const InterLayout L(*st, BIG ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE);
+// KIND 0 / 1: PRS little / big endian; 2: LZO -- the formats whose stream ends at a terminator token
+template <int KIND>
+static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate) {
+    constexpr bool BIG = KIND == 1;
+    constexpr u32 NST = KIND == 2 ? BIG_LZO_STATES : ALZ_PRS_STATES;
+    const InterLayout L(*st, KIND == 2 ? ALZ_FMT_LZO : (BIG ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE));
     u32* val = (u32*)(base + L.val); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b); u8* mark = base + L.mark;
     u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
     u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
@@ -752,14 +862,16 @@ static hipError_t launch_prs(hipStream_t stream, const u8* src, u8* dst, const a
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_TERM), -1, 1, stream);
     if (e != hipSuccess) return e;
     const u32 nbn = (L.nodes + 255u) / 256u;
-    const u32 real_nodes = L.nodes - ALZ_PRS_STATES;              // the nodes of the bytes that exist (the end node is the first behind them)
-    hipLaunchKernelGGL((big_prs_sizes<BIG>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
+    const u32 real_nodes = L.nodes - NST;                         // the nodes of the bytes that exist (the end node is the first behind them)
+    if (KIND == 2) hipLaunchKernelGGL(big_lzo_sizes, dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
+    else hipLaunchKernelGGL((big_prs_sizes<BIG>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
     const u32 rr = big_rounds(L.max_ng);
     for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
     hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, real_nodes, tile_c);
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
     hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, real_nodes, tile_cb, gpos);
-    hipLaunchKernelGGL((big_prs_tokens<BIG>), dim3((L.max_ng + 255u) / 256u), dim3(256), 0, stream, src, st->src_len, gpos, ctl, tlen, tdesc, tend);
+    if (KIND == 2) hipLaunchKernelGGL(big_lzo_tokens, dim3((L.max_ng + 255u) / 256u), dim3(256), 0, stream, src, st->src_len, gpos, ctl, tlen, tdesc, tend);
+    else hipLaunchKernelGGL((big_prs_tokens<BIG>), dim3((L.max_ng + 255u) / 256u), dim3(256), 0, stream, src, st->src_len, gpos, ctl, tlen, tdesc, tend);
     hipLaunchKernelGGL(big_len_count, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_l);
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_l, tile_lb, L.ttiles, ctl + C_TOTAL);
     hipLaunchKernelGGL(big_len_offsets, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_lb, toff);
@@ -778,8 +890,9 @@ static hipError_t launch_prs(hipStream_t stream, const u8* src, u8* dst, const a
 hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, const alz_lz_properties* lz,
                           alz_result* d_result, void* d_scratch, uint32_t* d_gate) {
     const u8* src = (const u8*)d_src_base + st->src_off; u8* dst = (u8*)d_dst_base + st->dst_off;
-    if (fmt == ALZ_FMT_PRS_BE) return launch_prs<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
-    if (fmt == ALZ_FMT_PRS_LE) return launch_prs<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
+    if (fmt == ALZ_FMT_PRS_BE) return launch_term<1>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
+    if (fmt == ALZ_FMT_PRS_LE) return launch_term<0>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
+    if (fmt == ALZ_FMT_LZO) return launch_term<2>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (fmt == ALZ_FMT_LZ4_BLOCK) return launch_elem<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (fmt == ALZ_FMT_SNAPPY_RAW) return launch_elem<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
     if (big_inter(fmt)) {

@@ -969,6 +969,7 @@ hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src,
     case ALZ_FMT_PRS_LE: hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, gate); return hipGetLastError();
     case ALZ_FMT_LZ4_BLOCK: return launch_queue2<ALZ_FMT_LZ4_BLOCK>(stream, s, d, streams, index, count, results, gate);   // (a lone stream: the two-wavefront shape)
     case ALZ_FMT_SNAPPY_RAW: return launch_queue2<ALZ_FMT_SNAPPY_RAW>(stream, s, d, streams, index, count, results, gate);
+    case ALZ_FMT_LZO: return launch_queue2<ALZ_FMT_LZO>(stream, s, d, streams, index, count, results, gate);
     case ALZ_FMT_LZSS: {                                      // (the same choice of window as alz_launch_decode)
         const u32 W = 1u << lz.window_bits;
         if (W <= 4096 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096>(stream, s, d, streams, index, count, results, lz, W, 1, gate);

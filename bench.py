@@ -12,7 +12,7 @@ On one GPU the same JSON line also carries (rank 0, skipped with --configs none)
   configs       BASELINE.json configs[1..4] at their stated sizes (cfg2 Yaz0 10 000 x 64 KiB, cfg3 LZ4 100 000 x 256 KiB, one
                 GPU's shard of cfg4 = 5 000 mixed LZ10/LZ11/Yaz0/PRS streams, cfg5 compression as LZSS at Q0 / Q8 / Q15 and as
                 Yaz0 / LZ4 at Q0 / Q8), every other decode body of north_star on the headline's shape (body_<format>), ONE 1 000 KiB
-                stream of Test.bmp as Yaz0 / Yay0 / MIO0 / LZ10 / LZ11 / LZSS / PRS / LZ4 (the reference's own benchmark shape: single_<format>_q<Q>), and the
+                stream of Test.bmp as Yaz0 / Yay0 / MIO0 / LZ10 / LZ11 / LZSS / PRS / LZO / LZ4 (the reference's own benchmark shape: single_<format>_q<Q>), and the
                 "realistic" data set of SURVEY.md 8d (the 256 KiB windows of the reference's Test.bmp, GPU-encoded), each
                 with its own roofline object from HIP events on the launch stream
   copy_bandwidth  a measured device-to-device copy (second roofline denominator)
@@ -737,6 +737,7 @@ PUBLISHED_SINGLE = {("yay0", 0): (470.82, "Benchmarks.md:78"), ("yay0", 15): (82
                     ("lz11", 0): (560.85, "Benchmarks.md:62"), ("lz11", 15): (951.02, "Benchmarks.md:64"),
                     ("lzss", 0): (330.31, "Benchmarks.md:30"), ("lzss", 15): (359.94, "Benchmarks.md:32"),
                     ("prs_be", 0): (459.77, "Benchmarks.md:94"), ("prs_be", 15): (900.58, "Benchmarks.md:96"),
+                    ("lzo", 0): (636.34, "Benchmarks.md:26"), ("lzo", 15): (1457.70, "Benchmarks.md:28"),
                     ("lz4_block", 0): (747.58, "Benchmarks.md:22 (LZ4Legacy: this block behind an 8-byte header)"),
                     ("lz4_block", 15): (2191.72, "Benchmarks.md:24 (LZ4Legacy: this block behind an 8-byte header)")}
 
@@ -744,7 +745,7 @@ PUBLISHED_SINGLE = {("yay0", 0): (470.82, "Benchmarks.md:78"), ("yay0", 15): (82
 def single_stream(ctx, np, A, synth, Plan):
     """The reference's OWN benchmark shape (Benchmarks/Benchmarks/TestAllAlgorithms.cs:37-69): ONE stream = the first 1 000 KiB of
     Test.bmp, compressed at quality 0 / 15, then Decompress timed -- for the six formats whose single streams run on the whole GPU
-    (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZ4 blocks, csrc/alz_big.hip).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
+    (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4 blocks, csrc/alz_big.hip).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
     class's Decompress(Stream, Stream) costs), `device_GiB_s` = the kernels alone; beside them the managed figure the reference
     publishes for this exact input on its own machine (another CPU, no GPU: context, not a baseline measured here)."""
     from auroralib.compression_amd import formats as F
@@ -752,14 +753,14 @@ def single_stream(ctx, np, A, synth, Plan):
     bmp = lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read())
     raw = bytes(bmp[:1024000]); n = len(raw)
     out = []
-    for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lz4_block"):
+    for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block"):
         fmt = A.FORMAT_NAMES.index(fname)
         for q in (0, 15):
             cap = n + n // 4 + 64
             es = (A.Stream * 1)(A.Stream(0, 0, n, cap, 0, 0, 0, fmt))
             enc, eres, eaux = ctx.encode_batch(es, np.frombuffer(raw + bytes(64), dtype=np.uint8), cap + 64, quality=q)
             comp = bytes(enc[:eres[0].dst_len]); a0, a1 = eaux[0].aux0, eaux[0].aux1
-            decl = 0 if fname in ("lz4_block", "prs_be") else n     # (an LZ4 block / a PRS stream carries no size: the destination's room bounds it)
+            decl = 0 if fname in ("lz4_block", "prs_be", "lzo") else n   # (an LZ4 block / a PRS or LZO stream carries no size: the destination's room bounds it)
             st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, decl, a0, a1, fmt))
             d_src, d_dst = ctx.malloc(len(comp) + 64), ctx.malloc(n + 64)
             try:

@@ -205,13 +205,13 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
  * library chooses by the size of the batch; 1 / 2: always the one- / two-wavefront shape where both exist.  Results are
  * identical; a tuning and verification hook (the library reads no environment variable for kernel selection). */
 int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
-/* ONE big stream: a batch of at most eight LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZ4-block / raw-Snappy streams (every body of the
- * path but LZO) of at least `min_bytes` of output each (default 96 KiB; PRS / LZ4 / Snappy, which carry no size in the descriptor: of
- * dst_cap, with at least 8 KiB of input) is decoded
+/* ONE big stream: a batch of at most eight LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4-block / raw-Snappy streams (all eleven
+ * north-star bodies) of at least `min_bytes` of output each (default 96 KiB; PRS / LZO / LZ4 / Snappy, which carry no size in the
+ * descriptor: of dst_cap, with at least 8 KiB of input) is decoded
  * stream by stream by the whole GPU instead of by one or two wavefronts per stream (csrc/alz_big.hip).  Yay0 / MIO0 keep flags, match tokens
  * and literals in three sections (Yay0.cs:99-108, MIO0.cs:105-116): every token's cursors are prefix sums.  The other four interleave them
  * in one byte stream, but what a group of eight tokens (LZ4: a sequence, Snappy: an element, PRS: the tokens behind one flag byte, per
- * entry state of its control-bit automaton) that started at byte p WOULD occupy is a function of the bytes behind p alone, so the real starts are found by list ranking over the input bytes.  Either way the copies are resolved by pointer jumping over the
+ * entry state of its control-bit automaton; LZO: an instruction, per class of the literal count before it) that started at byte p WOULD occupy is a function of the bytes behind p alone, so the real starts are found by list ranking over the input bytes.  Either way the copies are resolved by pointer jumping over the
  * output bytes.  So the single-stream call a format class's Decompress(Stream, Stream) makes (Interfaces/ICompressionDecoder.cs:24; the
  * reference's own benchmark is ONE 1 000 KiB stream, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42) does not fall behind the managed
  * decoder.  Results are identical: a stream that path cannot finish -- any malformed one -- is decoded by the exact kernel behind it.

@@ -118,7 +118,7 @@ namespace AuroraLib.Compression.Amd
         /// <summary>True when a single stream of this size should run on the GPU rather than on the managed body.</summary>
         internal static bool UseGpu(uint decomLength) => AmdContext.Available && decomLength >= AmdContext.SingleStreamThreshold;
 
-        /// <summary>The same for ONE LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS stream, which the native library decodes on the whole GPU
+        /// <summary>The same for ONE LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO stream, which the native library decodes on the whole GPU
         /// (alz_ctx_big_stream).</summary>
         internal static bool UseGpuBigStream(uint decomLength)
             => AmdContext.Available && decomLength >= Math.Min(AmdContext.SingleStreamThreshold, AmdContext.BigStreamThreshold);

@@ -26,7 +26,7 @@ namespace AuroraLib.Compression.Amd.Common
         public static unsafe void DecompressHeaderless(Stream source, Stream destination)
         {
             long rest = source.Length - source.Position;
-            if (!AmdBody.UseGpu((uint)Math.Min(uint.MaxValue, rest * 4))) { Managed.LZO.DecompressHeaderless(source, destination); return; }
+            if (!AmdBody.UseGpuBigStream((uint)Math.Min(uint.MaxValue, rest * 4))) { Managed.LZO.DecompressHeaderless(source, destination); return; }
             AmdBody.Decode(AlzFormat.LZO, null, source, destination, 0, 0, 0, (uint)Math.Min(0x7FFF0000L, Math.Max(4096L, rest * 8)), false);
         }
 

@@ -18,8 +18,8 @@ from auroralib.compression_amd import synth
 from auroralib.compression_amd.batch import Context, Plan
 
 pytestmark = pytest.mark.gpu
-FMTS = [A.FMT_YAY0, A.FMT_MIO0, A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE]
-ELEM = (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE)       # no size in the descriptor: the room in the destination bounds the launch
+FMTS = [A.FMT_YAY0, A.FMT_MIO0, A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO]
+ELEM = (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO)       # no size in the descriptor: the room in the destination bounds the launch
 THREE = (A.FMT_YAY0, A.FMT_MIO0)
 OFF = 0xFFFFFFFF
 

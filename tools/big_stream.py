@@ -11,11 +11,11 @@ from auroralib.compression_amd.batch import Context, Plan
 
 bmp = O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0]
 c = Context(0)
-for fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_YAZ0, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZSS, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE):
+for fmt in (A.FMT_YAY0, A.FMT_MIO0, A.FMT_YAZ0, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZSS, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_LZO):
     for label, raw in (("Test.bmp[0:256 KiB]", bmp[:262144]), ("Test.bmp[0:1 000 KiB]", bmp[:1024000]), ("Test.bmp x 4 (4 MiB)", (bmp * 4)[:4 << 20])):
         comp, aux = O.encode_stream(fmt, raw, quality=8)
         n = len(raw)
-        sized = fmt not in (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE)       # (those two carry no size in the descriptor: the destination's room bounds them)
+        sized = fmt not in (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO)       # (those two carry no size in the descriptor: the destination's room bounds them)
         st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, n if sized else 0, aux.aux0, aux.aux1, fmt))
         src = np.frombuffer(comp + bytes(64), dtype=np.uint8)
         d_src, d_dst = c.malloc(src.nbytes), c.malloc(n + 64)
