@@ -836,7 +836,9 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     if (LZ4) hipLaunchKernelGGL(big_lz4_size, dim3(1), dim3(1), 0, stream, ctl, st->src_len);
     const u32 nb = (st->dst_cap + 255u) / 256u;
     BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
-    hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src);
+    // (LZ4 decodes its WHOLE input -- sequences that add no output may follow the last output byte, e.g. a lone zero token --, so
+    // source.Position is the end of the input and not the end of the last token with output: found by tools/soak.sh, seed 9488)
+    hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src, LZ4);
     const u32 rounds = big_rounds(L.max_nt);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);

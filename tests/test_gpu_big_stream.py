@@ -200,3 +200,36 @@ def test_lz4_long_extensions_and_a_wall_of_ff():
         wall = b"\xFF" * 200000
         _one(c, A.FMT_LZ4_BLOCK, wall, 0, 0, 0, cap=1 << 20, what="wall of 0xFF")
         _one(c, A.FMT_SNAPPY_RAW, b"\xFF" * 100000, 0, 0, 0, cap=1 << 20, what="snappy wall of 0xFF")
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_big_stream_fuzz(fmt, test_bmp):
+    """Mutated big streams (bit flips, spliced noise, cuts, wrong sizes) under ALZ_FUZZ_SEED: whatever the whole-GPU path makes of them --
+    finishing them or handing them to the exact kernel -- status, lengths, src_used, every output byte and every byte AROUND the output
+    must be the oracle's (tools/soak.sh repeats this under other seeds)."""
+    import os
+    import random
+    rng = random.Random(int(os.environ.get("ALZ_FUZZ_SEED", "1234")) * 31 + fmt)
+    raw = test_bmp[30000:30000 + 180000]
+    comp, aux = O.encode_stream(fmt, raw, quality=4)
+    n = len(raw)
+    with Context(0) as c:
+        for k in range(16):
+            b = bytearray(comp)
+            kind = k % 4
+            if kind == 0:
+                for _ in range(rng.randrange(1, 4)):
+                    b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+            elif kind == 1:
+                cut = rng.randrange(len(b))
+                b[cut:cut] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 2000)))
+            elif kind == 2:
+                b = b[:rng.randrange(len(b) // 2, len(b))]
+            else:
+                i = rng.randrange(len(b) - 64)
+                b[i:i + rng.randrange(1, 64)] = bytes(rng.choice([0, 0xFF]) for _ in range(1))[:1] * 1
+            decl = rng.choice([n, n, n - 1, n + 1, n - rng.randrange(1, 5000)])
+            cap = rng.choice([decl, decl + 100, n + 4096])
+            if cap < 98304:
+                cap = 98304
+            _one(c, fmt, bytes(b), decl, aux.aux0, aux.aux1, cap=max(cap, decl) if fmt not in ELEM else cap, what="fuzz %d kind %d" % (k, kind))
