@@ -760,6 +760,7 @@ bool alz_big_eligible(int fmt, const alz_stream* st, const alz_lz_properties* lz
     if (!big_three(fmt) && !big_inter(fmt) && !big_elem(fmt)) return false;
     if (big_elem(fmt)) {                                          // no size in the descriptor: what the destination holds, and an input worth the launches
         if (min_bytes == 0xFFFFFFFFu || st->dst_cap < min_bytes || st->dst_cap > 0x40000000u || st->src_len < 8192u || st->src_len > 0x10000000u) return false;
+        if ((uint64_t)st->dst_cap > 32ull * st->src_len + 65536ull) return false;   // the launches are sized by the room in the destination: not for a destination far beyond what the input can plausibly yield
         if (fmt == ALZ_FMT_LZ4_BLOCK && st->aux0 != 0u) return false;   // a block of a linked frame continues the window of its predecessors
         return true;
     }
