@@ -128,7 +128,7 @@ struct alz_ctx {
 };
 
 static const size_t kPinBytes = 32u << 20;
-#define ALZ_BIG_MAX_STREAMS 8u              /* a batch of at most this many streams, all of them big, takes the whole-GPU path stream by stream */
+#define ALZ_BIG_MAX_STREAMS 32u             /* a batch of at most this many streams, all of them big, may take the whole-GPU path stream by stream (plan_create weighs it) */
 
 struct alz_plan {
     uint32_t n = 0;
@@ -140,8 +140,8 @@ struct alz_plan {
     uint32_t fmt_cnt[ALZ_FMT_COUNT] = {0};
     bool borrowed = false;                  // the three device arrays live in the context's plan scratch (host-buffer entry points)
     // ONE big Yay0 / MIO0 stream: decoded by the whole GPU (alz_big.hip), the production kernel behind it only if that path declines
-    // (up to ALZ_BIG_MAX_STREAMS of them, one after the other: n streams through that path take n x ~0.1-0.3 ms, on wavefronts of their own
-    // they take as long as ONE of them, 1-5 ms per MiB)
+    // (or a few of them, one after the other: n streams through that path take n x ~0.1-0.3 ms, on wavefronts of their own they take as
+    // long as the largest of them alone, 1-5 ms per MiB; plan_create weighs the two)
     bool big = false, big_borrowed = false; std::vector<alz_stream> big_streams; std::vector<uint32_t> big_pos; void* d_big = nullptr; uint32_t* d_gate = nullptr;
 };
 
@@ -337,6 +337,18 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
     if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
     bool all_big = n >= 1 && n <= ALZ_BIG_MAX_STREAMS && !c->exact && c->variant == 0;
     for (uint32_t i = 0; all_big && i < n; i++) all_big = alz_big_eligible((int)streams[i].format, &streams[i], &lz, c->big_min);
+    if (all_big && n > 1) {
+        // several big streams: one after the other through the whole-GPU path (measured: ~0.08 ms of launches + 0.1 ms per MiB of output
+        // each) against all of them side by side on wavefronts of their own, which takes as long as the LARGEST of them alone (~4.4 ms per
+        // MiB): 16 streams of 1 MiB 2.9 against 4.4 ms, 32 streams of 256 KiB 3.4 against 1.1
+        double t_big = 0, t_lone = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const double mib = (double)(streams[i].decom_len ? streams[i].decom_len : streams[i].dst_cap) / 1048576.0;
+            t_big += 0.08 + 0.1 * mib;
+            if (4.4 * mib > t_lone) t_lone = 4.4 * mib;
+        }
+        all_big = t_big < t_lone;
+    }
     if (all_big) {
         // (the scratch -- 4 bytes per output byte of the largest stream, they run one after the other -- belongs to the plan; when it cannot
         // be had the production kernels decode the streams)

@@ -205,7 +205,8 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
  * library chooses by the size of the batch; 1 / 2: always the one- / two-wavefront shape where both exist.  Results are
  * identical; a tuning and verification hook (the library reads no environment variable for kernel selection). */
 int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
-/* ONE big stream: a batch of at most eight LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4-block / raw-Snappy streams (all eleven
+/* ONE big stream: a batch of one -- or of a few, as long as one after the other on the whole GPU beats side by side on wavefronts of their
+ * own -- LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4-block / raw-Snappy streams (all eleven
  * north-star bodies) of at least `min_bytes` of output each (default 96 KiB; PRS / LZO / LZ4 / Snappy, which carry no size in the
  * descriptor: of dst_cap, with at least 8 KiB of input) is decoded
  * stream by stream by the whole GPU instead of by one or two wavefronts per stream (csrc/alz_big.hip).  Yay0 / MIO0 keep flags, match tokens
