@@ -117,7 +117,8 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
                     const u32 z = __builtin_amdgcn_ubfe(w3, r, 1u) + 2u * __builtin_amdgcn_ubfe(w4, r, 1u);
                     asm("v_mad_u32_u24 %0, %1, %2, %1" : "=v"(extra) : "v"(m), "v"(z));
                 }
-                info |= extra << (4 * k);
+                if (k == 0) info = extra;                          // (one v_lshl_or per token: left to itself the compiler shifts every nibble and ORs them in a tree, 11 instead of 7)
+                else asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(info) : "v"(extra), "n"(4 * k));
                 r += 1u + extra;
             }
             gsize = r;

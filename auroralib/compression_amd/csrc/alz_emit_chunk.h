@@ -113,9 +113,8 @@ __device__ __forceinline__ void emit_prologue(OW& out, DecState& s, u32 size, u6
     const u64 km = vm & wave_ballot(off < left);             // the token exists in the stream (prefix of lanes)
     const bool keep = __builtin_amdgcn_inverse_ballot_w64(km);
     const u32 nk = (u32)__popcll(km);
-    const u32 nvalid = (u32)__popcll(vm);
     const u32 Tend = wave_readlane(end, nk - 1);
-    bool fin = nk < nvalid || Tend >= left;
+    bool fin = km != vm || Tend >= left;                     // (km is a subset of vm: "fewer kept than valid" as one scalar compare of the masks; `nk < nvalid` became a 64-bit VECTOR compare)
     u32 lastk = nk - 1;
     u32 T = Tend;
     const u32 room = out.cap - O;
