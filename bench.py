@@ -156,17 +156,26 @@ def run_steps(db, steps, warmup, sync):
     return time.perf_counter() - t0, kernel_ms
 
 
+def best_of_two(db, steps, sync):
+    """The secondary configurations (not the headline, whose K steps are timed exactly once): two passes of K steps, the better wall
+    clock reported with its own device time -- one pass in eight showed a host-side stall of tens of milliseconds between two launches
+    (wall 14.5 ms per step around HIP events that measured 2.5) right after the previous configuration's buffers had been freed."""
+    a = run_steps(db, steps, 2, sync)
+    b = run_steps(db, steps, 0, sync)
+    return a if a[0] <= b[0] else b
+
+
 def decode_config(name, workload, ctx, batch, Plan, synth, np, steps, fmt_name, n, kib):
     """One named decode configuration on rank 0: K steps back to back + HIP-event kernel time + status / length check."""
     db = DeviceBatch(ctx, batch, Plan)
     try:
-        dt, kernel_ms = run_steps(db, steps, 2, ctx.synchronize)
+        dt, kernel_ms = best_of_two(db, steps, ctx.synchronize)
         res = synth.result_records(db.plan.results())
         recs = synth.stream_records(batch.streams)
         ok = bool((res["status"] == 0).all() and (res["dst_len"] == recs["decom_len"]).all())
         comp = int(recs["src_len"].astype(np.int64).sum()); dec = int(recs["decom_len"].astype(np.int64).sum())
         return {"name": name, "workload": workload, "value": round(dec * steps / dt / 2**30, 3), "unit": "GiB/s", "steps": steps,
-                "ms_per_step": round(dt / steps * 1e3, 4), "parity_ok": ok,
+                "ms_per_step": round(dt / steps * 1e3, 4), "timing": "best of two passes of %d steps" % steps, "parity_ok": ok,
                 "roofline": roofline(comp + dec, kernel_ms, measured_traffic(fmt_name, n, kib))}
     finally:
         db.close()
@@ -831,7 +840,7 @@ def realistic(ctx, np, A, synth, Plan, steps, fmt_name="yaz0"):
     b = B(); b.src, b.streams, b.dst_bytes = src, streams, n * size
     db = DeviceBatch(ctx, b, Plan)
     try:
-        dt, kernel_ms = run_steps(db, steps, 2, ctx.synchronize)
+        dt, kernel_ms = best_of_two(db, steps, ctx.synchronize)
         res = synth.result_records(db.plan.results())
         ok = bool((res["status"] == 0).all() and (res["dst_len"] == size).all())
         g = ctx.d2h(db.d_dst, nw * size)
