@@ -516,12 +516,30 @@ def cpu_baseline(O, A, np, batch, recs, n, target, args, aff):
         if t == aff:
             reps_all = r
     best_t = max(sweep, key=lambda k: sweep[k])
+    # ... and the reference's own benchmark shape on ONE core of this box: one 1 000 KiB stream of Test.bmp per body (what the
+    # `single_<format>_q0` entries of `configs` decode through alz_decode)
+    single = {}
+    try:
+        bmp = O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0]
+        raw1 = bytes(bmp[:1024000])
+        for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block"):
+            fmt = A.FORMAT_NAMES.index(fname)
+            comp, aux = O.encode_stream(fmt, raw1, quality=0)
+            sized = fname not in ("prs_be", "lzo", "lz4_block")
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 or time.perf_counter() - t0 < 0.25:
+                out, r = O.decode_stream(fmt, comp, decom_len=len(raw1) if sized else 0, cap=len(raw1), aux0=aux.aux0, aux1=aux.aux1)
+                reps += 1
+            single[fname] = round(len(raw1) * reps / (time.perf_counter() - t0) / 2**30, 3)
+    except Exception as e:
+        single = {"error": repr(e)}
     # `value` = the best thread count of the sweep, `cores` = the threads that run used.  Round 1 reported T = os.cpu_count()
     # = 256 at 10 GiB/s = 0.04 GiB/s per thread against 0.96 for one thread: the sweep shows where the scaling stops (a cgroup
     # CPU quota -- reported below -- and / or one NUMA node's memory: the output buffer is first touched by one thread)
     return {"value": sweep[best_t], "unit": "GiB/s", "cores": int(best_t), "kind": "port",
             "single_thread": sweep["1"], "all_allowed_cores": {"threads": aff, "value": sweep[str(aff)]}, "threads_sweep_GiB_s": sweep,
             "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota_cores": cpu_quota(),
+            "single_stream_one_thread_GiB_s": single,
             "sample": "first max(256, 64 T) of the %d x %d KiB %s streams per thread count T, %d passes at T = %d; C restatement of the managed "
                       "ring+flush path (oracle/alz_oracle.c), streams striped over threads" % (n, args.stream_kib, args.format, reps_all, aff)}
 
