@@ -1568,6 +1568,36 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
     if (carryw != 0xFFFFFFFFu && lane == 0) mask[carryw] = 1ull;
 }
 
+// The payload bytes of a match token of the flag-bit formats: `mt` = (distance, length) of the match that starts at position p.
+// (Shared by the batch kernel below and the whole-GPU path of ONE stream, alz_encode_big.h.)
+template <int FMT>
+__device__ __forceinline__ void flag_payload(const EncGeom& g, u32 p, uint2 mt, u32& b0, u32& b1, u32& b2, u32& b3, u32& psize) {
+    const u32 d1 = (mt.x - 1u) & 0xFFFu, len = mt.y;
+    if (FMT == ALZ_FMT_LZSS) {
+        const u32 offset = (g.windows_start + p - mt.x) & (g.lz_max_distance - 1u);
+        const u32 v = (offset & 0xFFu) | ((offset & 0xFF00u) << g.length_bits) | (((len - g.lz_min_length) & ((1u << g.length_bits) - 1u)) << 8);
+        b0 = v & 0xFF; b1 = (v >> 8) & 0xFF; psize = 2;
+    } else if (FMT == ALZ_FMT_CLZ0) {                          // CLZ0.cs:121-124: delta = 0x1000 - distance
+        const u32 delta = 0x1000u - mt.x; b0 = delta & 0xFF; b1 = ((len - 3u) | ((delta >> 8) << 4)) & 0xFF; psize = 2;
+    } else if (FMT == ALZ_FMT_BLZ) {                           // BLZ.cs:172: distance - 3
+        const u32 v = (((len - 3u) << 12) | ((mt.x - 3u) & 0xFFFu)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
+    } else if (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_MIO0) {
+        const u32 v = (((len - 3u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
+    } else if (FMT == ALZ_FMT_LZ40) {                          // u16 LE distance << 4 | length (+ 1 or 2 length bytes)
+        const u32 dv = (mt.x << 4) & 0xFFFFu;
+        if (len < 16) { const u32 v = dv | len; b0 = v & 0xFF; b1 = v >> 8; psize = 2; }
+        else if (len < 272) { b0 = dv & 0xFF; b1 = dv >> 8; b2 = len - 16u; psize = 3; }
+        else { const u32 v = dv | 1u, l = (len - 272u) & 0xFFFFu; b0 = v & 0xFF; b1 = v >> 8; b2 = l & 0xFF; b3 = l >> 8; psize = 4; }
+    } else if (FMT == ALZ_FMT_LZ11) {
+        if (len <= 16) { const u32 v = (((len - 1u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
+        else if (len <= 272) { b0 = ((len - 17u) & 0xFFu) >> 4; const u32 v = (((len - 17u) << 12) | d1) & 0xFFFFu; b1 = v >> 8; b2 = v & 0xFF; psize = 3; }
+        else { const u32 v = 0x10000000u | (((len - 273u) & 0xFFFFu) << 12) | d1; b0 = v >> 24; b1 = (v >> 16) & 0xFF; b2 = (v >> 8) & 0xFF; b3 = v & 0xFF; psize = 4; }
+    } else {   // YAZ0 / YAY0
+        if (len < 18) { const u32 v = (d1 | ((len - 2u) << 12)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
+        else { b0 = d1 >> 8; b1 = d1 & 0xFF; b2 = len - 0x12u; psize = 3; }
+    }
+}
+
 // The parse and the emitter of the flag-bit formats in ONE kernel (round 3): enc_roles_kernel's walk over a window of 64 positions, then
 // the emitter's tokens of the same window, from the same registers.  As two kernels the parse wrote a start mask and the exact
 // matches it had recomputed, and the emitter read mask and match array again: 10.5 GB of the 53 the pipeline moved at quality 0, and
@@ -1787,32 +1817,7 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
         // payload of my token
         u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, psize = 0, usize = 0;
         if (lit) { b0 = sb; psize = 1; }
-        else if (start) {
-            const u32 d1 = (mt.x - 1u) & 0xFFFu, len = mt.y;
-            if (FMT == ALZ_FMT_LZSS) {
-                const u32 offset = (g.windows_start + p - mt.x) & (g.lz_max_distance - 1u);
-                const u32 v = (offset & 0xFFu) | ((offset & 0xFF00u) << g.length_bits) | (((len - g.lz_min_length) & ((1u << g.length_bits) - 1u)) << 8);
-                b0 = v & 0xFF; b1 = (v >> 8) & 0xFF; psize = 2;
-            } else if (FMT == ALZ_FMT_CLZ0) {                          // CLZ0.cs:121-124: delta = 0x1000 - distance
-                const u32 delta = 0x1000u - mt.x; b0 = delta & 0xFF; b1 = ((len - 3u) | ((delta >> 8) << 4)) & 0xFF; psize = 2;
-            } else if (FMT == ALZ_FMT_BLZ) {                           // BLZ.cs:172: distance - 3
-                const u32 v = (((len - 3u) << 12) | ((mt.x - 3u) & 0xFFFu)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
-            } else if (FMT == ALZ_FMT_LZ10 || FMT == ALZ_FMT_MIO0) {
-                const u32 v = (((len - 3u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2;
-            } else if (FMT == ALZ_FMT_LZ40) {                          // u16 LE distance << 4 | length (+ 1 or 2 length bytes)
-                const u32 dv = (mt.x << 4) & 0xFFFFu;
-                if (len < 16) { const u32 v = dv | len; b0 = v & 0xFF; b1 = v >> 8; psize = 2; }
-                else if (len < 272) { b0 = dv & 0xFF; b1 = dv >> 8; b2 = len - 16u; psize = 3; }
-                else { const u32 v = dv | 1u, l = (len - 272u) & 0xFFFFu; b0 = v & 0xFF; b1 = v >> 8; b2 = l & 0xFF; b3 = l >> 8; psize = 4; }
-            } else if (FMT == ALZ_FMT_LZ11) {
-                if (len <= 16) { const u32 v = (((len - 1u) << 12) | d1) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
-                else if (len <= 272) { b0 = ((len - 17u) & 0xFFu) >> 4; const u32 v = (((len - 17u) << 12) | d1) & 0xFFFFu; b1 = v >> 8; b2 = v & 0xFF; psize = 3; }
-                else { const u32 v = 0x10000000u | (((len - 273u) & 0xFFFFu) << 12) | d1; b0 = v >> 24; b1 = (v >> 16) & 0xFF; b2 = (v >> 8) & 0xFF; b3 = v & 0xFF; psize = 4; }
-            } else {   // YAZ0 / YAY0
-                if (len < 18) { const u32 v = (d1 | ((len - 2u) << 12)) & 0xFFFFu; b0 = v >> 8; b1 = v & 0xFF; psize = 2; }
-                else { b0 = d1 >> 8; b1 = d1 & 0xFF; b2 = len - 0x12u; psize = 3; }
-            }
-        }
+        else if (start) flag_payload<FMT>(g, p, mt, b0, b1, b2, b3, psize);
         if (THREE) {   // literals (and Yay0's long-length byte) live in their own section
             if (lit) { usize = 1; psize = 0; }
             else if (start && FMT == ALZ_FMT_YAY0 && psize == 3) { usize = 1; psize = 2; }
@@ -2451,25 +2456,26 @@ static bool uses_win_prev(const EncGeom& g) {
     return g.max_dist <= 8192 && (g.hash_bits > 15 || g.use_min_table);
 }
 
-hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
-                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
-                             const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
-    if (count == 0) return hipSuccess;
-    EncGeom g; memcpy(&g, geom, sizeof(g));
-    const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
-    const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    // kernel A: the head table in LDS (hashBits = 15 + floor(sqrt(2 Q)) = 15..20, LzChainMatchFinder.cs:108-119) -- one pass with the
-    // tag / link rings where matches reach back at most 8 KiB, otherwise 2^(hashBits - 15) passes (+ 2 for the min-length table)
+// kernel A: the head table in LDS (hashBits = 15 + floor(sqrt(2 Q)) = 15..20, LzChainMatchFinder.cs:108-119) -- one pass with the
+// tag / link rings where matches reach back at most 8 KiB, otherwise 2^(hashBits - 15) passes (+ 2 for the min-length table)
+static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
+                              int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail) {
     if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
     if (uses_win_prev(g)) hipLaunchKernelGGL((enc_prev_cu_kernel<2, true>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    return hipSuccess;
+}
+
+// kernel B over `count` streams; `wg_cap`: workgroups per stream of the one-position-per-lane form (32 in a batch; a lone stream takes
+// as many as it has blocks of 256 positions)
+static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count, uint32_t max_len,
+                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g, int tail, u32 wg_cap) {
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
-    if (bx > 32u) bx = 32u;
+    if (bx > wg_cap) bx = wg_cap;
     // (workgroups per stream, each with one contiguous range: 32 -- 8 Ki positions of a 256 KiB stream, 4 KiB of history in front of them fetched
     // again -- move 9.1 GB at quality 0, 128 move 12.7, both in 13.6 ms; one position per thread, ten million workgroups per launch: 18.6 ms)
-    if (searches_in_the_parse(fmt, g)) {}
-    else if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {        // (from maxChain 3 on: the chains first, the pairs 64 at a time)
+    if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {        // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? 2u : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)
@@ -2484,12 +2490,25 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_dense_kernel<true, false, 64, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<true, false, 64, false>), gd, dim3(64)); }
             else { if (g.link16) ALZ_LB((enc_match_dense_kernel<false, false, 64, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<false, false, 64, false>), gd, dim3(64)); }
         }
-    }
 #undef ALZ_LB
+        return;
+    }
 #define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
-    else if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
+    if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
     else { if (g.link16) ALZ_LB((enc_match_kernel<false, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
 #undef ALZ_LB
+}
+
+hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
+                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
+                             const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
+    if (count == 0) return hipSuccess;
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
+    const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
+    const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    if (ea != hipSuccess) return ea;
+    if (!searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u);
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
     case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
@@ -2536,3 +2555,5 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     }
     return hipGetLastError();
 }
+
+#include "alz_encode_big.h"

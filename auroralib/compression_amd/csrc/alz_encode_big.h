@@ -1,0 +1,382 @@
+// alz_encode_big.h -- ONE big stream on the whole GPU, encoder side (included at the end of alz_encode.hip: same translation unit, same
+// EncGeom / match array / MatchSearch).
+//
+// The batch encoder gives a stream one workgroup for prev() (kernel A), and one wavefront for the parse and the emission: a lone
+// 1 000 KiB stream -- what the reference's own benchmark compresses, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42 -- takes 20-60 ms,
+// several times what the managed encoder needs on one CPU core.  Nothing in the pipeline is sequential by nature:
+//
+//   A'  prev(): the stream is cut into segments of S positions, and kernel A runs on "virtual streams" [j S - W, (j + 1) S) -- W >= maxDistance
+//       positions of warm-up in front of every segment.  A link found inside a virtual stream is the stream's link; one that would reach in
+//       front of it is longer than maxDistance, which ends a chain walk exactly as no link does (LzChainMatchFinder.cs:259-260).  The links
+//       of the warm-up positions are thrown away (the segment before has them right): benc_gather copies the rest into the arrays kernel B
+//       reads, min-length-table links moved from segment to stream positions.
+//   B   MatchSearch for every position: the batch kernels, unchanged, on as many workgroups as the stream has blocks.
+//   C   the greedy / lazy parse (FindNextBestMatch :157-212) is a walk "cursor += jump[cursor]", and jump[p] -- what the parse does IF its
+//       cursor is at p: no match, a match here, or a literal and the better match at p + 1 -- is a pure function of match[p] and match[p + 1].
+//       A linked list through the positions: the cursors are the nodes reachable from 0, found by list ranking (mark + square the jump
+//       table, ceil(log2 nodes) + 1 rounds, as alz_big.hip does for the decoders' group starts).
+//   D   with the cursors known every position knows whether a token starts on it and which; prefix sums over the positions give every
+//       token its number (-> flag group and bit), its payload offset and -- Yay0 / MIO0 -- its place in the literal section; the payload
+//       bytes go straight to the destination, the flag bits through a byte per token, one thread per flag group gathers them.
+//
+// A position whose candidate ran into kernel B's compare cap (2 040 bytes) is searched again exactly (what the batch parse does when its cursor
+// meets one) -- for EVERY such position here, not only the visited ones; beyond BENC_CAP_BUDGET of them (long runs in an LZ11 stream) the path
+// declines and the host runs the batch pipeline.  Output: bit-identical to the batch pipeline's, which is bit-identical to the oracle's.
+#pragma once
+
+namespace {
+
+#define BENC_TILE 1024u
+#define BENC_CAP_BUDGET 16384u
+enum { BC_BAD = 0, BC_CAPN = 1, BC_TAIL = 2, BC_T = 3, BC_P = 4, BC_U = 5, BC_WORDS = 16 };
+
+struct BencArgs {
+    const u8* data;          // the stream
+    u32 N;                   // its length
+    int n, limit;            // the finder's bound (N - tail) and the last position it searches (n - 4)
+    u32 nodes;               // limit + 2: the positions 0..limit and the end node limit + 1
+    u32 S, W, K, stride;     // segment length, warm-up, segments, ints per segment in the segment arrays
+};
+
+__device__ __forceinline__ u32 benc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 benc_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+__device__ __forceinline__ u32 benc_last(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
+
+// the virtual streams of A' (entries 0..K-1) and the real one (entry K) with their index list and array offsets
+__global__ __launch_bounds__(256) void benc_setup(alz_stream real, BencArgs a, alz_stream* __restrict__ vs, u32* __restrict__ vindex, u64* __restrict__ vpos) {
+    const u32 j = blockIdx.x * 256u + threadIdx.x;
+    if (j > a.K) return;
+    alz_stream s = real;
+    u64 po = 0;
+    if (j < a.K) {
+        const u32 first = j * a.S, start = first >= a.W ? first - a.W : 0u;
+        u32 end = first + a.S; if (end > (u32)a.limit + 1u) end = (u32)a.limit + 1u;
+        s.src_off = real.src_off + start;
+        s.src_len = end - start + 3u;            // the last hashed position is end - 1: four bytes
+        po = (u64)j * a.stride;
+    }
+    vs[j] = s; vindex[j] = j; vpos[j] = po;
+}
+
+// the links of the segments -> the arrays of the stream
+template <bool L16>
+__global__ __launch_bounds__(256) void benc_gather(BencArgs a, const int* __restrict__ seg4, const int* __restrict__ segm, int* __restrict__ fin4, int* __restrict__ finm) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if ((int)p > a.limit) return;
+    const u32 j = p / a.S, first = j * a.S, start = first >= a.W ? first - a.W : 0u, local = p - start;
+    const size_t off = (size_t)j * a.stride;
+    if (L16) reinterpret_cast<unsigned short*>(fin4)[p] = reinterpret_cast<const unsigned short*>(seg4 + off)[local];
+    else { const int v = seg4[off + local]; fin4[p] = v < 0 ? -1 : v + (int)start; }
+    if (segm) { const int v = segm[off + local]; finm[p] = v < 0 ? -1 : v + (int)start; }
+}
+
+// C: what FindNextBestMatch does if its cursor is at p (enc_roles_kernel's rule, one position per thread), exact matches
+template <bool MINT>
+__global__ __launch_bounds__(256) void benc_next(BencArgs a, EncGeom g, const int* __restrict__ p4, const int* __restrict__ pm, const mentry* __restrict__ match,
+                                                 u32* __restrict__ ml, u32* __restrict__ md, u32* __restrict__ next, u8* __restrict__ sr, u32* __restrict__ ctl) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.nodes) return;
+    const int limit = a.limit, pi = (int)p;
+    if (pi > limit) { next[p] = p; return; }                     // the end node
+    auto exact = [&](int q, int& d, int& l) {
+        const uint2 u = m_unpack(match[q]);
+        d = (int)u.x; l = (int)u.y;
+        if (u.y == ALZ_CAPPED) {                                  // kernel B stopped comparing at its cap: MatchSearch again, exactly
+            d = 0; l = 0;
+            if (atomicAdd(ctl + BC_CAPN, 1u) >= BENC_CAP_BUDGET) { ctl[BC_BAD] = 1u; return; }
+            (void)match_search<MINT>(a.data, a.n, q, p4, pm, g, 0, d, l);
+        }
+    };
+    int d0, l0, d1 = 0, l1 = 0;
+    exact(pi, d0, l0);
+    if (pi + 1 <= limit) exact(pi + 1, d1, l1);
+    int jump = 1; u32 s = 0;
+    if (l0 >= g.min_len) {
+        const bool lazyc = l0 <= g.lazy && pi + 1 <= limit;
+        if (lazyc && l1 > l0) { s = 2; const int e = pi + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 2 > stop ? pi + 2 : stop) - pi; }
+        else { s = 1; const int skip = lazyc ? 1 : 0; const int e = pi + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 1 + skip > stop ? pi + 1 + skip : stop) - pi; }
+    }
+    ml[p] = (u32)l0; md[p] = (u32)d0; sr[p] = (u8)s; next[p] = p + (u32)jump;
+}
+
+// one round of list ranking: every marked node marks where its jump lands, every jump is squared (double-buffered: a round must see
+// jumps of exactly 2^k hops)
+__global__ __launch_bounds__(256) void benc_rank_round(const u32* __restrict__ jump_a, u32* __restrict__ jump_b, u8* __restrict__ mark, u32 nodes) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= nodes) return;
+    const u32 j = jump_a[p];
+    if (mark[p]) mark[j] = 1;
+    jump_b[p] = jump_a[j];
+}
+
+// the last cursor: where the literals behind the parse start (the end of its match, at least limit + 1)
+// (its jump lands on the end node exactly when what it takes ends at or behind limit + 1 -- the one-hop jumps themselves are gone, squared)
+__global__ __launch_bounds__(256) void benc_tail(BencArgs a, const u8* __restrict__ sr, const u32* __restrict__ ml, const u8* __restrict__ mark, u32* __restrict__ ctl) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if ((int)p > a.limit || !mark[p]) return;
+    const u32 s = sr[p];
+    const u32 e = s == 1u ? p + ml[p] : s == 2u ? p + 1u + ml[p + 1u] : p + 1u;
+    if (e >= (u32)a.limit + 1u) ctl[BC_TAIL] = e;
+}
+
+template <int FMT> struct FlagFmt {
+    static constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    static constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZHUDSON || THREE);
+    static constexpr bool MSB = (FMT != ALZ_FMT_LZSS && FMT != ALZ_FMT_CLZ0);
+    static constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;
+};
+
+// The token that starts at position p, if any: 0 none, 1 a literal, 2 a match (its length in `len`)
+struct BencTok { u32 kind, len, dist; };
+__device__ __forceinline__ BencTok benc_token(const BencArgs& a, u32 p, u32 tail, const u8* mark, const u8* sr, const u32* ml, const u32* md) {
+    BencTok t; t.kind = 0; t.len = 0; t.dist = 0;
+    if (p >= a.N) return t;
+    const int limit = a.limit;
+    const bool cur = (int)p <= limit && mark[p];
+    const u32 s = cur ? sr[p] : 0u;
+    const bool after = p >= 1u && (int)(p - 1u) <= limit && mark[p - 1u] && sr[p - 1u] == 2u;   // the cursor in front took a literal and MY match
+    if ((cur && s == 1u) || after) { t.kind = 2; t.len = ml[p]; t.dist = md[p]; }
+    else if (cur || p >= tail) t.kind = 1;
+    return t;
+}
+template <int FMT>
+__device__ __forceinline__ void benc_sizes(const BencTok& t, u32& psize, u32& usize) {
+    typedef FlagFmt<FMT> F;
+    psize = 0; usize = 0;
+    if (t.kind == 1u) { if (F::THREE) usize = 1; else psize = 1; }
+    else if (t.kind == 2u) {
+        const u32 len = t.len;
+        if (FMT == ALZ_FMT_LZ40) psize = len < 16u ? 2u : len < 272u ? 3u : 4u;
+        else if (FMT == ALZ_FMT_LZ11) psize = len <= 16u ? 2u : len <= 272u ? 3u : 4u;
+        else if (FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZHUDSON) psize = len < 18u ? 2u : 3u;
+        else if (FMT == ALZ_FMT_YAY0) { psize = 2; usize = len < 18u ? 0u : 1u; }
+        else psize = 2;
+    }
+}
+
+// D1: tokens, payload bytes and literal-section bytes per tile of 1 024 positions
+template <int FMT>
+__global__ __launch_bounds__(64) void benc_count(BencArgs a, const u8* __restrict__ mark, const u8* __restrict__ sr, const u32* __restrict__ ml,
+                                                 const u32* __restrict__ md, const u32* __restrict__ ctl, u32* __restrict__ tile_t, u32* __restrict__ tile_p,
+                                                 u32* __restrict__ tile_u) {
+    const u32 tile = blockIdx.x, lane = benc_lane(), tail = ctl[BC_TAIL];
+    u32 ct = 0, cp = 0, cu = 0;
+    for (u32 r = 0; r < BENC_TILE / 64u; r++) {
+        const u32 p = tile * BENC_TILE + r * 64u + lane;
+        const BencTok t = benc_token(a, p, tail, mark, sr, ml, md);
+        u32 ps, us; benc_sizes<FMT>(t, ps, us);
+        ct += t.kind ? 1u : 0u; cp += ps; cu += us;
+    }
+    ct = benc_last(scan_add(ct)); cp = benc_last(scan_add(cp)); cu = benc_last(scan_add(cu));
+    if (lane == 0) { tile_t[tile] = ct; tile_p[tile] = cp; tile_u[tile] = cu; }
+}
+
+// exclusive scans over the tiles: workgroup k scans array k (in[k * pitch ..] -> out[k * pitch ..]), its total to ctl[BC_T + k]
+__global__ __launch_bounds__(1024) void benc_scan3(const u32* __restrict__ in, u32* __restrict__ out, u32 n, u32 pitch, u32* __restrict__ ctl) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x, k = blockIdx.x;
+    in += (size_t)k * pitch; out += (size_t)k * pitch;
+    const u32 per = (n + 1023u) / 1024u;
+    const u32 b = tid * per, e = b + per < n ? b + per : n;
+    u32 s = 0;
+    for (u32 i = b; i < e; i++) s += in[i];
+    part[tid] = s;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u32 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (u32 i = b; i < e; i++) { out[i] = run; run += in[i]; }
+    if (tid == 1023u) ctl[BC_T + k] = part[1023];
+}
+
+// D2: every token to its place.  The payload goes straight to the destination, the flag bit into a byte per token, and the first token of a
+// flag group notes where the group's flag byte(s) go (FlagWriter order: flag, then the payload of its tokens  IO/FlagWriter.cs:70-80,111-127)
+template <int FMT>
+__global__ __launch_bounds__(64) void benc_place(BencArgs a, EncGeom g, const u8* __restrict__ mark, const u8* __restrict__ sr, const u32* __restrict__ ml,
+                                                 const u32* __restrict__ md, const u32* __restrict__ ctl, const u32* __restrict__ base_t, const u32* __restrict__ base_p,
+                                                 const u32* __restrict__ base_u, u8* __restrict__ dst, u32 cap, u8* __restrict__ tokbit, u32* __restrict__ gofs) {
+    typedef FlagFmt<FMT> F;
+    const u32 tile = blockIdx.x, lane = benc_lane(), tail = ctl[BC_TAIL];
+    const u32 T = ctl[BC_T], P = ctl[BC_P], U = ctl[BC_U];
+    const u32 nflags = F::FB * ((T + F::FBITS - 1u) / F::FBITS);
+    if (ctl[BC_BAD] || (u64)nflags + P + U > cap) return;        // (declined, or no room: benc_result says so)
+    u32 tb = base_t[tile], pb = base_p[tile], ub = base_u[tile];
+    for (u32 r = 0; r < BENC_TILE / 64u; r++) {
+        const u32 p = tile * BENC_TILE + r * 64u + lane;
+        if (tile * BENC_TILE + r * 64u >= a.N) break;
+        const BencTok t = benc_token(a, p, tail, mark, sr, ml, md);
+        u32 psize, usize; benc_sizes<FMT>(t, psize, usize);
+        const bool tok = t.kind != 0u;
+        const u64 tm = __ballot(tok);
+        const u32 ti = tb + benc_mbcnt(tm);
+        const u32 pincl = scan_add(psize), poff = pb + pincl - psize;
+        const u32 uincl = F::THREE ? scan_add(usize) : 0u, uoff = ub + uincl - usize;
+        if (tok) {
+            const u32 group = ti / F::FBITS;
+            const bool lit = t.kind == 1u;
+            tokbit[ti] = (u8)((lit ? F::LIT_BIT : !F::LIT_BIT) ? 1u : 0u);
+            if (ti % F::FBITS == 0u) gofs[group] = F::THREE ? F::FB * group : poff + F::FB * group;
+            u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, ps = 0;
+            if (lit) b0 = a.data[p];
+            else flag_payload<FMT>(g, p, make_uint2(t.dist, t.len), b0, b1, b2, b3, ps);
+            if (!F::THREE) {
+                u8* o = dst + poff + F::FB * (group + 1u);
+                o[0] = (u8)b0; if (psize > 1u) o[1] = (u8)b1; if (psize > 2u) o[2] = (u8)b2; if (psize > 3u) o[3] = (u8)b3;
+            } else if (lit) dst[nflags + P + uoff] = (u8)b0;
+            else { dst[nflags + poff] = (u8)b0; dst[nflags + poff + 1u] = (u8)b1; if (usize) dst[nflags + P + uoff] = (u8)b2; }
+        }
+        tb += (u32)__popcll(tm); pb += benc_last(pincl); if (F::THREE) ub += benc_last(uincl);
+    }
+}
+
+// D3: one thread per flag group; the stream's result
+template <int FMT>
+__global__ __launch_bounds__(256) void benc_flags(BencArgs a, const u32* __restrict__ ctl, const u8* __restrict__ tokbit, const u32* __restrict__ gofs,
+                                                  u8* __restrict__ dst, u32 cap, alz_result* __restrict__ result, alz_encode_aux* __restrict__ aux) {
+    typedef FlagFmt<FMT> F;
+    const u32 T = ctl[BC_T], P = ctl[BC_P], U = ctl[BC_U];
+    const u32 ngroups = (T + F::FBITS - 1u) / F::FBITS, nflags = F::FB * ngroups;
+    const u64 total = (u64)nflags + P + U;
+    const bool declined = ctl[BC_BAD] != 0u, room = total <= cap;
+    const u32 gi = blockIdx.x * 256u + threadIdx.x;
+    if (gi == 0u && !declined) {
+        alz_result r; r.dst_len = room ? (u32)total : 0u; r.src_used = a.N; r.status = room ? ALZ_ST_OK : ALZ_ST_OUTPUT_CAPACITY; r.reserved = 0;
+        *result = r;
+        if (aux) { aux->aux0 = F::THREE && room ? nflags : 0u; aux->aux1 = F::THREE && room ? nflags + P : 0u; }
+    }
+    if (declined || !room || gi >= ngroups) return;
+    u32 acc = 0;
+    for (u32 k = 0; k < F::FBITS; k++) {
+        const u32 ti = gi * F::FBITS + k;
+        if (ti < T && tokbit[ti]) acc |= 1u << (F::MSB ? F::FBITS - 1u - k : k);
+    }
+    u8* o = dst + gofs[gi];
+    if (F::FB == 1u) o[0] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc);
+    else { o[0] = (u8)(acc >> 24); o[1] = (u8)(acc >> 16); o[2] = (u8)(acc >> 8); o[3] = (u8)acc; }
+}
+
+static size_t benc_al(size_t x) { return (x + 255) & ~(size_t)255; }
+static u32 benc_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r + 1u; }
+
+struct BencLayout {
+    BencArgs a;
+    u32 tiles;
+    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, mark, sr, tile_in, tile_out, tokbit, gofs, ctl, total;
+    BencLayout(const alz_stream& st, const EncGeom& g, int tail) {
+        a.data = nullptr; a.N = st.src_len; a.n = (int)st.src_len - tail; a.limit = a.n - 4;
+        a.nodes = (u32)a.limit + 2u;
+        a.W = ((u32)g.max_dist + 63u) & ~63u;
+        a.S = a.W <= 8192u ? 16384u : 2u * a.W;                   // (a segment costs kernel A its S + W positions: a quarter more than its share, or half)
+        a.K = ((u32)a.limit + a.S) / a.S;
+        a.stride = a.S + a.W + 64u;
+        tiles = (a.N + BENC_TILE - 1u) / BENC_TILE;
+        const size_t np = (size_t)a.N + 64;
+        size_t o = 0;
+        vs = o; o += benc_al((a.K + 1) * sizeof(alz_stream)); vindex = o; o += benc_al((a.K + 1) * 4); vpos = o; o += benc_al((a.K + 1) * 8);
+        seg4 = o; o += benc_al((size_t)a.K * a.stride * 4 + 256);
+        segm = o; if (g.use_min_table) o += benc_al((size_t)a.K * a.stride * 4 + 256);
+        fin4 = o; o += benc_al(np * 4 + 256);
+        finm = o; if (g.use_min_table) o += benc_al(np * 4);
+        match = o; o += benc_al(np * 4);
+        ml = o; o += benc_al(np * 4); md = o; o += benc_al(np * 4);
+        jump_a = o; o += benc_al(np * 4); jump_b = o; o += benc_al(np * 4);
+        mark = o; o += benc_al(np); sr = o; o += benc_al(np);
+        tile_in = o; o += benc_al((size_t)3 * (tiles + 64) * 4); tile_out = o; o += benc_al((size_t)3 * (tiles + 64) * 4);
+        tokbit = o; o += benc_al(np); gofs = o; o += benc_al((np / 8 + 64) * 4);
+        ctl = o; o += benc_al(BC_WORDS * 4);
+        total = o;
+    }
+};
+
+static bool benc_format(int fmt) {
+    return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
+           fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+}
+
+template <int FMT>
+static void benc_emit(hipStream_t stream, const BencLayout& L, const BencArgs& a, const EncGeom& g, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
+    const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
+    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    const u32 pitch = L.tiles + 64u;
+    hipLaunchKernelGGL((benc_count<FMT>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tin, tin + pitch, tin + 2 * pitch);
+    hipLaunchKernelGGL(benc_scan3, dim3(3), dim3(1024), 0, stream, tin, tout, L.tiles, pitch, ctl);
+    hipLaunchKernelGGL((benc_place<FMT>), dim3(L.tiles), dim3(64), 0, stream, a, g, mark, sr, ml, md, ctl, tout, tout + pitch, tout + 2 * pitch, dst, cap,
+                       base + L.tokbit, (u32*)(base + L.gofs));
+    const u32 maxgroups = (a.N + FlagFmt<FMT>::FBITS - 1u) / FlagFmt<FMT>::FBITS + 1u;
+    hipLaunchKernelGGL((benc_flags<FMT>), dim3((maxgroups + 255u) / 256u), dim3(256), 0, stream, a, ctl, base + L.tokbit, (const u32*)(base + L.gofs), dst, cap, d_result, d_aux);
+}
+
+}  // namespace
+
+bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, uint32_t min_bytes) {
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    if (!benc_format(fmt) || min_bytes == 0xFFFFFFFFu) return false;
+    if (st->src_len < min_bytes || st->src_len < 4096u || st->src_len > 0x20000000u) return false;
+    return g.nprops <= 1 && g.max_dist <= 0x8000 && g.hash_bits >= 15 && g.hash_bits <= 20;
+}
+
+size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream* st) {
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    return BencLayout(*st, g, fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0).total + 256;
+}
+
+// Enqueues the whole-GPU encode of ONE stream.  d_result / d_aux: the stream's slots; d_scratch: alz_encode_big_scratch_bytes();
+// *d_declined (a device word, the first of the scratch's control block is copied there) becomes 1 when the path gave the stream up
+// (nothing written to d_result then): the caller runs the batch pipeline.
+hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
+                                 alz_encode_aux* d_aux, void* d_scratch, uint32_t* d_declined, const void* geom) {
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
+    BencLayout L(*st, g, tail);
+    u8* base = (u8*)d_scratch;
+    BencArgs a = L.a; a.data = (const u8*)d_src_base + st->src_off;
+    alz_stream* vs = (alz_stream*)(base + L.vs); u32* vindex = (u32*)(base + L.vindex); u64* vpos = (u64*)(base + L.vpos);
+    int* seg4 = (int*)(base + L.seg4); int* segm = g.use_min_table ? (int*)(base + L.segm) : nullptr;
+    int* fin4 = (int*)(base + L.fin4); int* finm = g.use_min_table ? (int*)(base + L.finm) : nullptr;
+    mentry* match = (mentry*)(base + L.match);
+    u32* ml = (u32*)(base + L.ml); u32* md = (u32*)(base + L.md); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b);
+    u8* mark = base + L.mark; u8* sr = base + L.sr; u32* ctl = (u32*)(base + L.ctl);
+    hipError_t e = hipMemsetAsync(ctl, 0, BC_WORDS * 4, stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + BC_TAIL), a.limit + 1, 1, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)a.N + 64, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);                       // the cursor starts at position 0
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(benc_setup, dim3((a.K + 256u) / 256u), dim3(256), 0, stream, *st, a, vs, vindex, vpos);
+    // A': kernel A on the segments, then the links to where kernel B reads them
+    e = launch_prev(stream, (const u8*)d_src_base, vs, vindex, a.K, seg4, segm, vpos, g, 0);
+    if (e != hipSuccess) return e;
+    const u32 nbp = ((u32)a.limit + 256u) / 256u;
+    if (g.link16) hipLaunchKernelGGL((benc_gather<true>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm);
+    else hipLaunchKernelGGL((benc_gather<false>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm);
+    // B: on the real stream (entry K)
+    launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u);
+    // C: the parse
+    const u32 nbn = (a.nodes + 255u) / 256u;
+    if (g.use_min_table) hipLaunchKernelGGL((benc_next<true>), dim3(nbn), dim3(256), 0, stream, a, g, fin4, finm, match, ml, md, jump_a, sr, ctl);
+    else hipLaunchKernelGGL((benc_next<false>), dim3(nbn), dim3(256), 0, stream, a, g, fin4, finm, match, ml, md, jump_a, sr, ctl);
+    const u32 rr = benc_rounds(a.nodes);
+    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(benc_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, a.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    hipLaunchKernelGGL(benc_tail, dim3(nbn), dim3(256), 0, stream, a, sr, ml, mark, ctl);
+    // D: the tokens
+    u8* dst = (u8*)d_dst_base + st->dst_off;
+    switch (fmt) {
+    case ALZ_FMT_LZSS: benc_emit<ALZ_FMT_LZSS>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_LZ10: benc_emit<ALZ_FMT_LZ10>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_LZ11: benc_emit<ALZ_FMT_LZ11>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_LZ40: benc_emit<ALZ_FMT_LZ40>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_YAZ0: benc_emit<ALZ_FMT_YAZ0>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_YAY0: benc_emit<ALZ_FMT_YAY0>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_MIO0: benc_emit<ALZ_FMT_MIO0>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_CLZ0: benc_emit<ALZ_FMT_CLZ0>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_BLZ: benc_emit<ALZ_FMT_BLZ>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_LZHUDSON: benc_emit<ALZ_FMT_LZHUDSON>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    default: return hipErrorInvalidValue;
+    }
+    e = hipMemcpyAsync(d_declined, ctl + BC_BAD, 4, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}

@@ -107,6 +107,7 @@ struct alz_ctx {
     float last_kernel_ms = 0.f;                // device time of the kernels of the last timed / encode call (HIP events on the launch stream)
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
     int variant = 0;                           // alz_ctx_set_kernel_variant
+    uint64_t big_enc_launches = 0;             // streams the whole-GPU ENCODE path has taken (alz_encode_big.h)
     uint32_t big_min = 96u << 10;              // a lone Yay0 / MIO0 stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
     uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
     void* d_bigbuf = nullptr; size_t d_bigbuf_cap = 0;   // its scratch for the plans of the host-buffer entry points (grow-only)
@@ -159,7 +160,7 @@ int alz_abi_version(void) { return ALZ_ABI_VERSION; }
 int alz_ctx_big_stream(alz_ctx* c, uint32_t min_bytes, uint64_t* launches_out) {
     if (!c) return fail(ALZ_E_INVALID, "alz_ctx_big_stream: ctx is NULL");
     if (min_bytes) c->big_min = min_bytes;
-    if (launches_out) *launches_out = c->big_launches;
+    if (launches_out) *launches_out = c->big_launches + c->big_enc_launches;
     return ALZ_OK;
 }
 int alz_ctx_set_kernel_variant(alz_ctx* c, int variant) {
@@ -745,7 +746,7 @@ static inline bool fastlz_level2(const alz_settings& st, uint32_t src_len) { ret
 // only -- point at the copy; offsets are differences of device addresses).
 static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, uint32_t n, size_t src_bytes, const alz_stream* streams,
                        size_t dst_bytes, alz_result* results, alz_encode_aux* aux, const std::function<int(const void*&, void*&)>& upload,
-                       bool src_has_slack = true) {
+                       bool src_has_slack = true, bool no_big = false) {
     const void* d_src_base = nullptr; void* d_dst_base = nullptr;
     alz_settings st; if (settings) st = *settings; else { st.quality = 8; st.max_window_bits = 0; st.strategy = 0; st.min_distance = 0; }
     if (st.quality < 0 || st.quality > 15) return fail(ALZ_E_INVALID, "quality %d outside 0..15 (CompressionSettings.cs:38-50)", st.quality);
@@ -790,6 +791,70 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
         any_min = any_min || alz_encode_geom_min_table(g);
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
+    }
+    // ---- a handful of big streams: each of them on the whole GPU (alz_encode_big.h).  A stream the path declines (too many positions that
+    // need an exact second search) sends the whole call through the batch pipeline below.
+    if (!no_big && n <= 8 && c->big_min != 0xFFFFFFFFu && !c->exact && c->variant == 0) {
+        bool all = true; size_t sb = 0;
+        for (uint32_t i = 0; all && i < n; i++) {
+            const void* g = geom.data() + streams[i].format * alz_encode_geom_size();
+            all = streams[i].format != ALZ_FMT_FASTLZ && alz_encode_big_eligible((int)streams[i].format, g, &streams[i], c->big_min);
+            if (all) { const size_t b = alz_encode_big_scratch_bytes((int)streams[i].format, g, &streams[i]); if (b > sb) sb = b; }
+        }
+        if (all) {
+            HIP_TRY(hipSetDevice(c->device));
+            EncScratch sc(c);
+            alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; void *d_tail = nullptr, *d_big = nullptr, *skip = nullptr;
+            size_t tail_bytes = 0;
+            if (!src_has_slack)
+                for (uint32_t i = 0; i < n; i++)
+                    if (streams[i].src_off + streams[i].src_len + 64 > src_bytes) tail_bytes += ((size_t)streams[i].src_len + 64 + 63) & ~(size_t)63;
+            hipError_t e = sc.alloc(&skip, 0, false);                                   // (the batch pipeline's slots, in its order: the buffers are shared)
+            if (e == hipSuccess) e = sc.alloc((void**)&d_results, (size_t)n * sizeof(alz_result));
+            if (e == hipSuccess) e = sc.alloc((void**)&d_aux, (size_t)n * sizeof(alz_encode_aux));
+            for (int k = 3; k < 10 && e == hipSuccess; k++) e = sc.alloc(&skip, 0, false);
+            if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, tail_bytes != 0);
+            if (e == hipSuccess) e = sc.alloc(&d_big, sb + 64 + (size_t)n * 4);
+            if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
+            uint32_t* d_declined = (uint32_t*)((uint8_t*)d_big + ((sb + 63) & ~(size_t)63));
+            int rc;
+            if ((rc = upload(d_src_base, d_dst_base))) return rc;
+            tm.mark("upload");
+            HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
+            HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
+            HIP_TRY(hipMemsetAsync(d_declined, 0, (size_t)n * 4, c->stream));
+            HIP_TRY(hipEventRecord(c->ev0, c->stream));
+            size_t toff = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                alz_stream st1 = streams[i];
+                if (!src_has_slack && st1.src_off + st1.src_len + 64 > src_bytes) {      // its look-ahead would leave the caller's buffer
+                    uint8_t* to = (uint8_t*)d_tail + toff;
+                    HIP_TRY(hipMemcpyAsync(to, (const uint8_t*)d_src_base + st1.src_off, st1.src_len, hipMemcpyDeviceToDevice, c->stream));
+                    st1.src_off = (uint64_t)(uintptr_t)to - (uint64_t)(uintptr_t)d_src_base;
+                    toff += ((size_t)st1.src_len + 64 + 63) & ~(size_t)63;
+                }
+                e = alz_launch_encode_big((int)st1.format, c->stream, d_src_base, d_dst_base, &st1, d_results + i, d_aux + i, d_big, d_declined + i,
+                                          geom.data() + st1.format * alz_encode_geom_size());
+                if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream encode launch (format %u) failed: %s", st1.format, hipGetErrorString(e));
+            }
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            std::vector<uint32_t> declined(n);
+            std::vector<alz_encode_aux> haux(n);
+            HIP_TRY(hipMemcpyAsync(results, d_results, (size_t)n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(haux.data(), d_aux, (size_t)n * sizeof(alz_encode_aux), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(declined.data(), d_declined, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_kernel_ms = ms; }
+            tm.mark("kernels (big streams)");
+            bool any = false;
+            for (uint32_t i = 0; i < n; i++) any = any || declined[i] != 0u;
+            if (!any) {
+                c->big_enc_launches += n;
+                for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
+                return ALZ_OK;
+            }
+            return encode_core(c, props, settings, n, src_bytes, streams, dst_bytes, results, aux, upload, src_has_slack, true);
+        }
     }
     // streams whose look-ahead would leave the caller's source buffer (see above)
     std::vector<uint32_t> tail_ix; size_t tail_bytes = 0;
