@@ -2470,12 +2470,12 @@ static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_strea
 // kernel B over `count` streams; `wg_cap`: workgroups per stream of the one-position-per-lane form (32 in a batch; a lone stream takes
 // as many as it has blocks of 256 positions)
 static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count, uint32_t max_len,
-                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g, int tail, u32 wg_cap) {
+                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g, int tail, u32 wg_cap, bool dense_ok = true) {
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     if (bx > wg_cap) bx = wg_cap;
     // (workgroups per stream, each with one contiguous range: 32 -- 8 Ki positions of a 256 KiB stream, 4 KiB of history in front of them fetched
     // again -- move 9.1 GB at quality 0, 128 move 12.7, both in 13.6 ms; one position per thread, ten million workgroups per launch: 18.6 ms)
-    if (g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {        // (from maxChain 3 on: the chains first, the pairs 64 at a time)
+    if (dense_ok && g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {        // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
         u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? 2u : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)

@@ -10,7 +10,10 @@
 //       front of it is longer than maxDistance, which ends a chain walk exactly as no link does (LzChainMatchFinder.cs:259-260).  The links
 //       of the warm-up positions are thrown away (the segment before has them right): benc_gather copies the rest into the arrays kernel B
 //       reads, min-length-table links moved from segment to stream positions.
-//   B   MatchSearch for every position: the batch kernels, unchanged, on as many workgroups as the stream has blocks.
+//   B   MatchSearch for every position: the batch kernel with one position per lane (enc_match_kernel), on as many workgroups as the stream
+//       has blocks.  (Not the two-phase kernel the batches use from maxChain 3 on: it walks every chain to its end before it compares, and on
+//       a lone stream of real data -- Test.bmp: runs, repeated rows -- the walk that ends at the first candidate of full length is the faster
+//       one: 2.7 against 6.1 ms for Yaz0 at quality 15, 0.50 against 1.52 for LZSS.)
 //   C   the greedy / lazy parse (FindNextBestMatch :157-212) is a walk "cursor += jump[cursor]", and jump[p] -- what the parse does IF its
 //       cursor is at p: no match, a match here, or a literal and the better match at p + 1 -- is a pure function of match[p] and match[p + 1].
 //       A linked list through the positions: the cursors are the nodes reachable from 0, found by list ranking (mark + square the jump
@@ -20,14 +23,14 @@
 //       bytes go straight to the destination, the flag bits through a byte per token, one thread per flag group gathers them.
 //
 // A position whose candidate ran into kernel B's compare cap (2 040 bytes) is searched again exactly (what the batch parse does when its cursor
-// meets one) -- for EVERY such position here, not only the visited ones; beyond BENC_CAP_BUDGET of them (long runs in an LZ11 stream) the path
-// declines and the host runs the batch pipeline.  Output: bit-identical to the batch pipeline's, which is bit-identical to the oracle's.
+// meets one) -- for EVERY such position here, not only the visited ones: by a wavefront each (benc_exact).  Output: bit-identical to the
+// batch pipeline's, which is bit-identical to the oracle's.  (The path can decline a stream -- ctl[BC_BAD], the host then runs the batch
+// pipeline --; nothing does at present.)
 #pragma once
 
 namespace {
 
 #define BENC_TILE 1024u
-#define BENC_CAP_BUDGET 16384u
 enum { BC_BAD = 0, BC_CAPN = 1, BC_TAIL = 2, BC_T = 3, BC_P = 4, BC_U = 5, BC_WORDS = 16 };
 
 struct BencArgs {
@@ -70,33 +73,97 @@ __global__ __launch_bounds__(256) void benc_gather(BencArgs a, const int* __rest
     if (segm) { const int v = segm[off + local]; finm[p] = v < 0 ? -1 : v + (int)start; }
 }
 
-// C: what FindNextBestMatch does if its cursor is at p (enc_roles_kernel's rule, one position per thread), exact matches
+// C0: the match array -> (length, distance) per position; the positions whose candidate ran into kernel B's compare cap go onto a list
+__global__ __launch_bounds__(256) void benc_unpack(BencArgs a, const mentry* __restrict__ match, u32* __restrict__ ml, u32* __restrict__ md,
+                                                   u32* __restrict__ caplist, u32* __restrict__ ctl) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if ((int)p > a.limit) return;
+    const uint2 u = m_unpack(__builtin_nontemporal_load(match + p));
+    const bool capped = u.y == ALZ_CAPPED;
+    const u64 cm = __ballot(capped);
+    if (cm) {
+        u32 base = 0;
+        if (benc_lane() == 0u) base = atomicAdd(ctl + BC_CAPN, (u32)__popcll(cm));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (capped) caplist[base + benc_mbcnt(cm)] = p;
+    }
+    ml[p] = capped ? 0u : u.y; md[p] = capped ? 0u : u.x;
+}
+
+// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 512 bytes per trip, eight per lane (a trip may read up to seven
+// bytes behind `max`: inside the slack behind every source buffer, never counted)
+__device__ __forceinline__ int benc_wave_match_len(const u8* a, const u8* b, int max) {
+    const int lane = (int)benc_lane();
+    for (int base = 0; base < max; base += 512) {
+        const int off = base + 8 * lane;
+        const bool in = off < max;
+        const u64 x = in ? load64(a + off) ^ load64(b + off) : 0ull;
+        const u64 mm = __ballot(x != 0ull);
+        if (mm) {
+            const int l0 = (int)__builtin_ctzll(mm);
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, l0), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), l0);
+            const u64 xv = ((u64)hi << 32) | lo;
+            const int len = base + 8 * l0 + (int)(__builtin_ctzll(xv) >> 3);
+            return len < max ? len : max;
+        }
+    }
+    return max;
+}
+
+// C1: MatchSearch (:214-246, ChainMatches :248-282) again, exactly, for the listed positions -- one WAVEFRONT per position (the batch parse
+// does this on one lane, for the few capped positions its cursor meets; here every capped position is a possible cursor: the long runs of
+// an LZ11 stream are thousands of them, each with a match of up to 16 Ki bytes to measure)
 template <bool MINT>
-__global__ __launch_bounds__(256) void benc_next(BencArgs a, EncGeom g, const int* __restrict__ p4, const int* __restrict__ pm, const mentry* __restrict__ match,
-                                                 u32* __restrict__ ml, u32* __restrict__ md, u32* __restrict__ next, u8* __restrict__ sr, u32* __restrict__ ctl) {
+__global__ __launch_bounds__(64) void benc_exact(BencArgs a, EncGeom g, const int* __restrict__ p4, const int* __restrict__ pm, const u32* __restrict__ caplist,
+                                                 const u32* __restrict__ ctl, u32* __restrict__ ml, u32* __restrict__ md) {
+    const u32 count = ctl[BC_CAPN];
+    for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
+        const int pos = (int)caplist[i];
+        const u8* dp = a.data + pos;
+        auto lk = [&](int q) { return g.link16 ? link_at<true>(p4, q) : link_at<false>(p4, q); };
+        int cur = lk(pos);
+        int best_possible = a.n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+        int best_d = 0, best_l = 0, best_score = -1;
+        int attempts = g.max_chain;
+        while (cur != -1 && attempts-- > 0) {
+            const int dist = pos - cur;
+            if (dist > g.max_dist) break;
+            if (dist < g.min_dist) { cur = lk(cur); continue; }
+            int len = benc_wave_match_len(dp, a.data + cur, best_possible);
+            const int score = score_match(g, len, dist);
+            if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
+            cur = lk(cur);
+        }
+        if (MINT && best_l == 0) {                                          // small-match fallback :226-243
+            const int c2 = pm[pos];
+            if (c2 != -1) {
+                int dist = pos - c2;
+                if (dist < g.min_dist) dist = g.min_dist;
+                if (dist <= g.max_dist && pos - dist >= 0) {
+                    int len = benc_wave_match_len(dp, a.data + pos - dist, best_possible);
+                    (void)score_match(g, len, dist);
+                    best_l = len; best_d = dist;
+                }
+            }
+        }
+        if (benc_lane() == 0u) { ml[pos] = (u32)best_l; md[pos] = (u32)best_d; }
+    }
+}
+
+// C2: what FindNextBestMatch does if its cursor is at p (enc_roles_kernel's rule, one position per thread)
+__global__ __launch_bounds__(256) void benc_next(BencArgs a, EncGeom g, const u32* __restrict__ ml, u32* __restrict__ next, u8* __restrict__ sr) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= a.nodes) return;
     const int limit = a.limit, pi = (int)p;
     if (pi > limit) { next[p] = p; return; }                     // the end node
-    auto exact = [&](int q, int& d, int& l) {
-        const uint2 u = m_unpack(match[q]);
-        d = (int)u.x; l = (int)u.y;
-        if (u.y == ALZ_CAPPED) {                                  // kernel B stopped comparing at its cap: MatchSearch again, exactly
-            d = 0; l = 0;
-            if (atomicAdd(ctl + BC_CAPN, 1u) >= BENC_CAP_BUDGET) { ctl[BC_BAD] = 1u; return; }
-            (void)match_search<MINT>(a.data, a.n, q, p4, pm, g, 0, d, l);
-        }
-    };
-    int d0, l0, d1 = 0, l1 = 0;
-    exact(pi, d0, l0);
-    if (pi + 1 <= limit) exact(pi + 1, d1, l1);
+    const int l0 = (int)ml[p], l1 = pi + 1 <= limit ? (int)ml[p + 1u] : 0;
     int jump = 1; u32 s = 0;
     if (l0 >= g.min_len) {
         const bool lazyc = l0 <= g.lazy && pi + 1 <= limit;
         if (lazyc && l1 > l0) { s = 2; const int e = pi + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 2 > stop ? pi + 2 : stop) - pi; }
         else { s = 1; const int skip = lazyc ? 1 : 0; const int e = pi + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 1 + skip > stop ? pi + 1 + skip : stop) - pi; }
     }
-    ml[p] = (u32)l0; md[p] = (u32)d0; sr[p] = (u8)s; next[p] = p + (u32)jump;
+    sr[p] = (u8)s; next[p] = p + (u32)jump;
 }
 
 // one round of list ranking: every marked node marks where its jump lands, every jump is squared (double-buffered: a round must see
@@ -270,7 +337,7 @@ struct BencLayout {
         a.data = nullptr; a.N = st.src_len; a.n = (int)st.src_len - tail; a.limit = a.n - 4;
         a.nodes = (u32)a.limit + 2u;
         a.W = ((u32)g.max_dist + 63u) & ~63u;
-        a.S = a.W <= 8192u ? 16384u : 2u * a.W;                   // (a segment costs kernel A its S + W positions: a quarter more than its share, or half)
+        a.S = 16384u;                                             // (a segment costs kernel A its S + W positions)
         a.K = ((u32)a.limit + a.S) / a.S;
         a.stride = a.S + a.W + 64u;
         tiles = (a.N + BENC_TILE - 1u) / BENC_TILE;
@@ -294,7 +361,7 @@ struct BencLayout {
 
 static bool benc_format(int fmt) {
     return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
-           fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+           fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;
 }
 
 template <int FMT>
@@ -310,13 +377,139 @@ static void benc_emit(hipStream_t stream, const BencLayout& L, const BencArgs& a
     hipLaunchKernelGGL((benc_flags<FMT>), dim3((maxgroups + 255u) / 256u), dim3(256), 0, stream, a, ctl, base + L.tokbit, (const u32*)(base + L.gofs), dst, cap, d_result, d_aux);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LZ4 blocks and raw Snappy (enc_emit_seq_kernel's formats): a sequence = the literals since the last match + the match, so a match start
+// needs where the match in front of it ended -- a prefix MAX over the positions -- before its size is known, and the sizes' prefix SUM
+// before it can be written.  Three passes over tiles of 1 024 positions with the same body: 0 the tile's highest match end, 1 the tile's
+// bytes, 2 the bytes themselves; a scan over the tiles between them.  The literals behind the last match (LZ4: always a sequence) go out
+// through a kernel of their own, one byte per thread.
+enum { BC_COVER = 6, BC_SEQ = 7 };
+__global__ __launch_bounds__(1024) void benc_scanmax(const u32* __restrict__ in, u32* __restrict__ out, u32 n, u32* __restrict__ total_out) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (n + 1023u) / 1024u;
+    const u32 b = tid * per, e = b + per < n ? b + per : n;
+    u32 s = 0;
+    for (u32 i = b; i < e; i++) s = in[i] > s ? in[i] : s;
+    part[tid] = s;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u32 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        if (v > part[tid]) part[tid] = v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (u32 i = b; i < e; i++) { out[i] = run; run = in[i] > run ? in[i] : run; }
+    if (tid == 1023u) *total_out = part[1023];
+}
+
+__device__ __forceinline__ u32 benc_snappy_varint(u32 n) { return n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u; }
+
+template <int FMT>
+__device__ __forceinline__ u64 benc_seq_total(const BencArgs& a, const u32* ctl) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
+    const u32 plain = a.N - ctl[BC_COVER];
+    return (u64)(LZ4 ? 0u : benc_snappy_varint(a.N)) + ctl[BC_SEQ] + ((LZ4 || plain) ? F::lit_hdr(plain) : 0u) + plain;
+}
+
+template <int FMT, int PASS>
+__global__ __launch_bounds__(64) void benc_seq(BencArgs a, const u8* __restrict__ mark, const u8* __restrict__ sr, const u32* __restrict__ ml,
+                                               const u32* __restrict__ md, const u32* __restrict__ ctl, const u32* __restrict__ cover_base,
+                                               const u32* __restrict__ off_base, u32* __restrict__ tile_out, u8* __restrict__ dst, u32 cap) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
+    const u32 tile = blockIdx.x, lane = benc_lane();
+    if (PASS == 2 && (ctl[BC_BAD] || benc_seq_total<FMT>(a, ctl) > cap)) return;
+    u32 cover = PASS >= 1 ? cover_base[tile] : 0u;
+    u32 obase = PASS == 2 ? off_base[tile] + (LZ4 ? 0u : benc_snappy_varint(a.N)) : 0u;
+    for (u32 r = 0; r < BENC_TILE / 64u; r++) {
+        const u32 P = tile * BENC_TILE + r * 64u, p = P + lane;
+        if (P >= a.N) break;
+        const BencTok t = benc_token(a, p, 0xFFFFFFFFu, mark, sr, ml, md);
+        const bool start = t.kind == 2u;
+        if (__ballot(start) == 0ull) continue;                                // (no match starts here: the literals wait for the next one)
+        const u32 M = start ? t.len : 0u, D = t.dist;
+        const u32 mend = start ? p + M : 0u;
+        const u32 pmax = scan_max(mend);
+        if (PASS >= 1) {
+            u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
+            if (before < cover) before = cover;
+            const u32 L = start ? p - before : 0u;
+            const u32 lh = start ? F::lit_hdr(L) : 0u;
+            const u32 esz = start ? lh + L + F::match_size(D, M) : 0u;
+            const u32 incl = scan_add(esz);
+            if (PASS == 2) {
+                const u32 off = obase + incl - esz;
+                if (start) {
+                    F::put_lit_hdr(dst + off, L, M, false);
+                    if (L <= ALZ_SEQ_LANE_LIT) for (u32 i = 0; i < L; i++) dst[off + lh + i] = a.data[before + i];
+                    F::put_match(dst + off + lh + L, D, M);
+                }
+                u64 longs = __ballot(start && L > ALZ_SEQ_LANE_LIT);            // longer literal runs: the whole wavefront copies
+                while (longs) {
+                    const int l0 = (int)__builtin_ctzll(longs);
+                    const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)L, l0);
+                    const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), l0);
+                    wave_copy(dst + dq, a.data + so, len, (int)lane);
+                    longs &= longs - 1ull;
+                }
+            }
+            obase += benc_last(incl);
+        }
+        const u32 wmax = benc_last(pmax);
+        if (wmax > cover) cover = wmax;
+    }
+    if (PASS == 0 && lane == 0) tile_out[tile] = cover;
+    if (PASS == 1 && lane == 0) tile_out[tile] = obase;
+}
+
+// the literals behind the last match, and the stream's result
+template <int FMT>
+__global__ __launch_bounds__(256) void benc_seq_end(BencArgs a, const u32* __restrict__ ctl, u8* __restrict__ dst, u32 cap, alz_result* __restrict__ result,
+                                                    alz_encode_aux* __restrict__ aux) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
+    if (ctl[BC_BAD]) return;
+    const u64 total = benc_seq_total<FMT>(a, ctl);
+    const bool room = total <= cap;
+    const u32 cover = ctl[BC_COVER], plain = a.N - cover, k = LZ4 ? 0u : benc_snappy_varint(a.N);
+    const u32 lh = (LZ4 || plain) ? F::lit_hdr(plain) : 0u, obase = k + ctl[BC_SEQ];
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    if (q == 0u) {
+        alz_result r; r.dst_len = room ? (u32)total : 0u; r.src_used = a.N; r.status = room ? ALZ_ST_OK : ALZ_ST_OUTPUT_CAPACITY; r.reserved = 0;
+        *result = r;
+        if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
+        if (room) {
+            if (!LZ4) { u32 v = a.N, i = 0; while (v >= 0x80u) { dst[i++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[i] = (u8)v; }   // the decompressed length as a varint  Snappy.cs:126-135
+            if (LZ4 || plain) F::put_lit_hdr(dst + obase, plain, 4u, true);
+        }
+    }
+    if (room && q < plain) dst[obase + lh + q] = a.data[cover + q];
+}
+
+template <int FMT>
+static void benc_emit_seq(hipStream_t stream, const BencLayout& L, const BencArgs& a, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
+    const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
+    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    const u32 pitch = L.tiles + 64u;
+    hipLaunchKernelGGL((benc_seq<FMT, 0>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, (const u32*)nullptr, (const u32*)nullptr, tin, dst, cap);
+    hipLaunchKernelGGL(benc_scanmax, dim3(1), dim3(1024), 0, stream, tin, tout, L.tiles, ctl + BC_COVER);
+    hipLaunchKernelGGL((benc_seq<FMT, 1>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tout, (const u32*)nullptr, tin + pitch, dst, cap);
+    hipLaunchKernelGGL(benc_scan3, dim3(1), dim3(1024), 0, stream, tin + pitch, tout + pitch, L.tiles, pitch, ctl + (BC_SEQ - BC_T));
+    hipLaunchKernelGGL((benc_seq<FMT, 2>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tout, tout + pitch, (u32*)nullptr, dst, cap);
+    hipLaunchKernelGGL((benc_seq_end<FMT>), dim3((a.N + 255u) / 256u), dim3(256), 0, stream, a, ctl, dst, cap, d_result, d_aux);
+}
+
 }  // namespace
 
 bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, uint32_t min_bytes) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     if (!benc_format(fmt) || min_bytes == 0xFFFFFFFFu) return false;
     if (st->src_len < min_bytes || st->src_len < 4096u || st->src_len > 0x20000000u) return false;
-    return g.nprops <= 1 && g.max_dist <= 0x8000 && g.hash_bits >= 15 && g.hash_bits <= 20;
+    return g.nprops <= 1 && g.link16 && g.hash_bits >= 15 && g.hash_bits <= 20;
 }
 
 size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream* st) {
@@ -353,11 +546,16 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     if (g.link16) hipLaunchKernelGGL((benc_gather<true>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm);
     else hipLaunchKernelGGL((benc_gather<false>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm);
     // B: on the real stream (entry K)
-    launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u);
+    launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u, false);
     // C: the parse
     const u32 nbn = (a.nodes + 255u) / 256u;
-    if (g.use_min_table) hipLaunchKernelGGL((benc_next<true>), dim3(nbn), dim3(256), 0, stream, a, g, fin4, finm, match, ml, md, jump_a, sr, ctl);
-    else hipLaunchKernelGGL((benc_next<false>), dim3(nbn), dim3(256), 0, stream, a, g, fin4, finm, match, ml, md, jump_a, sr, ctl);
+    u32* caplist = jump_b;                                        // (the second jump table is free until the ranking)
+    hipLaunchKernelGGL(benc_unpack, dim3(nbp), dim3(256), 0, stream, a, match, ml, md, caplist, ctl);
+    if (g.max_len > ALZ_LEN_CAP) {                                // (only then can kernel B have capped anything)
+        if (g.use_min_table) hipLaunchKernelGGL((benc_exact<true>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, caplist, ctl, ml, md);
+        else hipLaunchKernelGGL((benc_exact<false>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, caplist, ctl, ml, md);
+    }
+    hipLaunchKernelGGL(benc_next, dim3(nbn), dim3(256), 0, stream, a, g, ml, jump_a, sr);
     const u32 rr = benc_rounds(a.nodes);
     for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(benc_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, a.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
     hipLaunchKernelGGL(benc_tail, dim3(nbn), dim3(256), 0, stream, a, sr, ml, mark, ctl);
@@ -374,6 +572,8 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     case ALZ_FMT_CLZ0: benc_emit<ALZ_FMT_CLZ0>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_BLZ: benc_emit<ALZ_FMT_BLZ>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_LZHUDSON: benc_emit<ALZ_FMT_LZHUDSON>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_LZ4_BLOCK: benc_emit_seq<ALZ_FMT_LZ4_BLOCK>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_SNAPPY_RAW: benc_emit_seq<ALZ_FMT_SNAPPY_RAW>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
     default: return hipErrorInvalidValue;
     }
     e = hipMemcpyAsync(d_declined, ctl + BC_BAD, 4, hipMemcpyDeviceToDevice, stream);

@@ -18,7 +18,7 @@ for fname in names:
         st = (A.Stream * 1)(A.Stream(0, 0, n, n + n // 4 + 64, 0, 0, 0, fmt))
         src = np.frombuffer(raw + bytes(64), dtype=np.uint8)
         row = []
-        for mode in ("big", "batch"):
+        for mode in os.environ.get("ALZ_SINGLE_MODES", "big,batch").split(","):
             c.big_stream(96 << 10 if mode == "big" else 0xFFFFFFFF)
             before = c.big_stream()
             c.encode_batch(st, src, n + n // 4 + 128, quality=q)
@@ -27,6 +27,7 @@ for fname in names:
             wall = (time.perf_counter() - t0) / 3 * 1e3
             row.append((wall, c.last_kernel_ms(), bytes(d[:r[0].dst_len]), c.big_stream() - before, (a[0].aux0, a[0].aux1)))
         t0 = time.perf_counter(); want, waux = O.encode_stream(fmt, raw, quality=q); cpu = (time.perf_counter() - t0) * 1e3
+        if len(row) < 2: row.append(row[0])
         print("%-6s q%-2d big: call %.2f ms (kernels %.2f, taken %d) = %.2f GiB/s | batch: call %.2f ms | C port one core %.2f ms = %.2f GiB/s | same bytes big %s batch %s aux %s"
               % (fname, q, row[0][0], row[0][1], row[0][3], n / row[0][0] / 2**30 * 1e3, row[1][0], cpu, n / cpu / 2**30 * 1e3,
                  row[0][2] == want, row[1][2] == want, row[0][4] == row[1][4]), flush=True)
