@@ -22,16 +22,19 @@
 //       token its number (-> flag group and bit), its payload offset and -- Yay0 / MIO0 -- its place in the literal section; the payload
 //       bytes go straight to the destination, the flag bits through a byte per token, one thread per flag group gathers them.
 //
-// A position whose candidate ran into kernel B's compare cap (2 040 bytes) is searched again exactly (what the batch parse does when its cursor
-// meets one) -- for EVERY such position here, not only the visited ones: by a wavefront each (benc_exact).  Output: bit-identical to the
-// batch pipeline's, which is bit-identical to the oracle's.  (The path can decline a stream -- ctl[BC_BAD], the host then runs the batch
-// pipeline --; nothing does at present.)
+// A position whose candidate ran into kernel B's compare cap (2 040 bytes) is searched again exactly, by a whole wavefront -- what the batch parse
+// does on one lane when its cursor meets one.  Not every such position (inside a run or a repeated row of Test.bmp every position is one, and
+// each would measure the whole rest of it: quadratic; 380 ms for Test.bmp as an LZ4 block at quality 15), only those somebody's cursor
+// could land on: every position with a known match asks for the place its cursor would go to, a searched one asks for its own target, and
+// so on until nobody asks (benc_request0 / benc_exact_g1 / benc_exact_rest).  What the true parse visits has been asked for by the position it
+// came from.  Output: bit-identical to the batch pipeline's, which is bit-identical to the oracle's.  (The path can decline a stream --
+// ctl[BC_BAD], the host then runs the batch pipeline --; nothing does at present.)
 #pragma once
 
 namespace {
 
 #define BENC_TILE 1024u
-enum { BC_BAD = 0, BC_CAPN = 1, BC_TAIL = 2, BC_T = 3, BC_P = 4, BC_U = 5, BC_WORDS = 16 };
+enum { BC_BAD = 0, BC_CAPN = 1, BC_TAIL = 2, BC_T = 3, BC_P = 4, BC_U = 5, BC_F0N = 8, BC_F1N = 9, BC_WORDS = 16 };
 
 struct BencArgs {
     const u8* data;          // the stream
@@ -73,80 +76,168 @@ __global__ __launch_bounds__(256) void benc_gather(BencArgs a, const int* __rest
     if (segm) { const int v = segm[off + local]; finm[p] = v < 0 ? -1 : v + (int)start; }
 }
 
-// C0: the match array -> (length, distance) per position; the positions whose candidate ran into kernel B's compare cap go onto a list
+// C0: the match array -> (length, distance) per position.  A position whose candidate ran into kernel B's compare cap has no length yet
+// (BENC_UNKNOWN) and state 1 ("capped, nobody has asked for it").
+#define BENC_UNKNOWN 0xFFFFFFFFu
 __global__ __launch_bounds__(256) void benc_unpack(BencArgs a, const mentry* __restrict__ match, u32* __restrict__ ml, u32* __restrict__ md,
-                                                   u32* __restrict__ caplist, u32* __restrict__ ctl) {
+                                                   u32* __restrict__ stt, u32* __restrict__ ctl) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if ((int)p > a.limit) return;
     const uint2 u = m_unpack(__builtin_nontemporal_load(match + p));
     const bool capped = u.y == ALZ_CAPPED;
     const u64 cm = __ballot(capped);
-    if (cm) {
-        u32 base = 0;
-        if (benc_lane() == 0u) base = atomicAdd(ctl + BC_CAPN, (u32)__popcll(cm));
-        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-        if (capped) caplist[base + benc_mbcnt(cm)] = p;
-    }
-    ml[p] = capped ? 0u : u.y; md[p] = capped ? 0u : u.x;
+    if (cm && benc_mbcnt(cm) == 0u && capped) atomicAdd(ctl + BC_CAPN, (u32)__popcll(cm));
+    ml[p] = capped ? BENC_UNKNOWN : u.y; md[p] = capped ? 0u : u.x;
+    if (stt) stt[p] = capped ? 1u : 0u;
 }
 
-// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 512 bytes per trip, eight per lane (a trip may read up to seven
-// bytes behind `max`: inside the slack behind every source buffer, never counted)
+// the rule of FindNextBestMatch (:157-212) for a cursor at p whose match has l0 bytes and whose neighbour's has l1: what it takes
+// (0 a literal, 1 the match here, 2 a literal and the neighbour's match) and where the cursor goes
+__device__ __forceinline__ u32 benc_rule(const EncGeom& g, int limit, int pi, int l0, int l1, u32& s) {
+    int jump = 1; s = 0;
+    if (l0 >= g.min_len) {
+        const bool lazyc = l0 <= g.lazy && pi + 1 <= limit;
+        if (lazyc && l1 > l0) { s = 2; const int e = pi + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 2 > stop ? pi + 2 : stop) - pi; }
+        else { s = 1; const int skip = lazyc ? 1 : 0; const int e = pi + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 1 + skip > stop ? pi + 1 + skip : stop) - pi; }
+    }
+    return (u32)(pi + jump);
+}
+__device__ __forceinline__ bool benc_lazy_needs(const EncGeom& g, int limit, int pi, int l0) { return l0 >= g.min_len && l0 <= g.lazy && pi + 1 <= limit; }
+
+// "somebody's cursor may land on x": a capped position is searched exactly once somebody asks
+__device__ __forceinline__ void benc_request(const BencArgs& a, u32 x, u32* stt, u32* front, u32* tail) {
+    if ((int)x > a.limit) return;
+    if (atomicCAS(stt + x, 1u, 2u) == 1u) front[atomicAdd(tail, 1u)] = x;
+}
+
+// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 2 KiB per trip -- four loads of eight bytes per lane in flight (a
+// trip may read up to 31 bytes behind `max`: inside the slack behind every source buffer, never counted)
 __device__ __forceinline__ int benc_wave_match_len(const u8* a, const u8* b, int max) {
     const int lane = (int)benc_lane();
-    for (int base = 0; base < max; base += 512) {
-        const int off = base + 8 * lane;
-        const bool in = off < max;
-        const u64 x = in ? load64(a + off) ^ load64(b + off) : 0ull;
-        const u64 mm = __ballot(x != 0ull);
-        if (mm) {
-            const int l0 = (int)__builtin_ctzll(mm);
-            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x, l0), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x >> 32), l0);
-            const u64 xv = ((u64)hi << 32) | lo;
-            const int len = base + 8 * l0 + (int)(__builtin_ctzll(xv) >> 3);
-            return len < max ? len : max;
+    for (int base = 0; base < max; base += 2048) {
+        u64 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int off = base + 512 * k + 8 * lane; x[k] = off < max ? load64(a + off) ^ load64(b + off) : 0ull; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u64 mm = __ballot(x[k] != 0ull);
+            if (mm) {
+                const int l0 = (int)__builtin_ctzll(mm);
+                const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x[k], l0), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x[k] >> 32), l0);
+                const u64 xv = ((u64)hi << 32) | lo;
+                const int len = base + 512 * k + 8 * l0 + (int)(__builtin_ctzll(xv) >> 3);
+                return len < max ? len : max;
+            }
         }
     }
     return max;
 }
 
-// C1: MatchSearch (:214-246, ChainMatches :248-282) again, exactly, for the listed positions -- one WAVEFRONT per position (the batch parse
-// does this on one lane, for the few capped positions its cursor meets; here every capped position is a possible cursor: the long runs of
-// an LZ11 stream are thousands of them, each with a match of up to 16 Ki bytes to measure)
+// MatchSearch (:214-246, ChainMatches :248-282) exactly, by the whole wavefront (wave-uniform control flow)
 template <bool MINT>
-__global__ __launch_bounds__(64) void benc_exact(BencArgs a, EncGeom g, const int* __restrict__ p4, const int* __restrict__ pm, const u32* __restrict__ caplist,
-                                                 const u32* __restrict__ ctl, u32* __restrict__ ml, u32* __restrict__ md) {
-    const u32 count = ctl[BC_CAPN];
-    for (u32 i = blockIdx.x; i < count; i += gridDim.x) {
-        const int pos = (int)caplist[i];
-        const u8* dp = a.data + pos;
-        auto lk = [&](int q) { return g.link16 ? link_at<true>(p4, q) : link_at<false>(p4, q); };
-        int cur = lk(pos);
-        int best_possible = a.n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
-        int best_d = 0, best_l = 0, best_score = -1;
-        int attempts = g.max_chain;
-        while (cur != -1 && attempts-- > 0) {
-            const int dist = pos - cur;
-            if (dist > g.max_dist) break;
-            if (dist < g.min_dist) { cur = lk(cur); continue; }
-            int len = benc_wave_match_len(dp, a.data + cur, best_possible);
-            const int score = score_match(g, len, dist);
-            if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
-            cur = lk(cur);
-        }
-        if (MINT && best_l == 0) {                                          // small-match fallback :226-243
-            const int c2 = pm[pos];
-            if (c2 != -1) {
-                int dist = pos - c2;
-                if (dist < g.min_dist) dist = g.min_dist;
-                if (dist <= g.max_dist && pos - dist >= 0) {
-                    int len = benc_wave_match_len(dp, a.data + pos - dist, best_possible);
-                    (void)score_match(g, len, dist);
-                    best_l = len; best_d = dist;
-                }
+__device__ __forceinline__ void benc_wave_search(const BencArgs& a, const EncGeom& g, const int* p4, const int* pm, int pos, int& best_d, int& best_l) {
+    const u8* dp = a.data + pos;
+    auto lk = [&](int q) { return g.link16 ? link_at<true>(p4, q) : link_at<false>(p4, q); };
+    int cur = lk(pos);
+    int best_possible = a.n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+    best_d = 0; best_l = 0; int best_score = -1;
+    int attempts = g.max_chain;
+    while (cur != -1 && attempts-- > 0) {
+        const int dist = pos - cur;
+        if (dist > g.max_dist) break;
+        if (dist < g.min_dist) { cur = lk(cur); continue; }
+        int len = benc_wave_match_len(dp, a.data + cur, best_possible);
+        const int score = score_match(g, len, dist);
+        if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
+        cur = lk(cur);
+    }
+    if (MINT && best_l == 0) {                                          // small-match fallback :226-243
+        const int c2 = pm[pos];
+        if (c2 != -1) {
+            int dist = pos - c2;
+            if (dist < g.min_dist) dist = g.min_dist;
+            if (dist <= g.max_dist && pos - dist >= 0) {
+                int len = benc_wave_match_len(dp, a.data + pos - dist, best_possible);
+                (void)score_match(g, len, dist);
+                best_l = len; best_d = dist;
             }
         }
-        if (benc_lane() == 0u) { ml[pos] = (u32)best_l; md[pos] = (u32)best_d; }
+    }
+}
+
+// C1a: who may land on a capped position?  Every position whose own match is known asks for the place its cursor would go to (or for its
+// neighbour, if the lazy rule needs the neighbour's length first); position 0 for itself.
+__global__ __launch_bounds__(256) void benc_request0(BencArgs a, EncGeom g, const u32* __restrict__ ml, u32* __restrict__ stt, u32* __restrict__ front, u32* __restrict__ ctl) {
+    if (ctl[BC_CAPN] == 0u) return;
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if ((int)p > a.limit) return;
+    const u32 l0 = ml[p];
+    if (l0 == BENC_UNKNOWN) { if (p == 0u) benc_request(a, 0u, stt, front, ctl + BC_F0N); return; }
+    u32 l1 = (int)p + 1 <= a.limit ? ml[p + 1u] : 0u;
+    if (l1 == BENC_UNKNOWN) {
+        if (benc_lazy_needs(g, a.limit, (int)p, (int)l0)) { benc_request(a, p + 1u, stt, front, ctl + BC_F0N); return; }   // (its own target follows when the neighbour is known)
+        l1 = 0;
+    }
+    u32 s;
+    benc_request(a, benc_rule(g, a.limit, (int)p, (int)l0, (int)l1, s), stt, front, ctl + BC_F0N);
+}
+
+// One requested position, by one wavefront: its match, exactly; then where ITS cursor would go -- another request -- and, if the position in
+// front of it was waiting for this length (lazy rule), that one's target too.
+template <bool MINT>
+__device__ __forceinline__ void benc_resolve(const BencArgs& a, const EncGeom& g, const int* p4, const int* pm, u32 c, u32* ml, u32* md, u32* stt, u32* front, u32* tail) {
+    const bool l0lane = benc_lane() == 0u;
+    auto known = [&](u32 q, int& d, int& l) -> bool {
+        const u32 v = __hip_atomic_load(ml + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == BENC_UNKNOWN) return false;
+        l = (int)v; d = (int)__hip_atomic_load(md + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    };
+    auto settle = [&](u32 q, int& d, int& l) {                        // the exact match of q (searched here unless somebody has already)
+        if (known(q, d, l)) return;
+        benc_wave_search<MINT>(a, g, p4, pm, (int)q, d, l);
+        if (l0lane) {
+            __hip_atomic_store(md + q, (u32)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ml + q, (u32)l, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the position in front of q, if its own match is known and short enough for the lazy rule, was waiting for this length
+        if (q >= 1u) {
+            int dq, lq;
+            if (stt[q - 1u] == 0u && known(q - 1u, dq, lq) && benc_lazy_needs(g, a.limit, (int)q - 1, lq)) {
+                u32 s; const u32 x = benc_rule(g, a.limit, (int)q - 1, lq, l, s);
+                if (l0lane) benc_request(a, x, stt, front, tail);
+            }
+        }
+    };
+    int d0, l0, d1 = 0, l1 = 0;
+    settle(c, d0, l0);
+    if (benc_lazy_needs(g, a.limit, (int)c, l0)) settle(c + 1u, d1, l1);
+    u32 s; const u32 x = benc_rule(g, a.limit, (int)c, l0, l1, s);
+    if (l0lane) benc_request(a, x, stt, front, tail);
+}
+
+// C1b: the first generation of requests, all wavefronts of the GPU; what they ask for goes onto a second list
+template <bool MINT>
+__global__ __launch_bounds__(64) void benc_exact_g1(BencArgs a, EncGeom g, const int* __restrict__ p4, const int* __restrict__ pm, u32* __restrict__ ml, u32* __restrict__ md,
+                                                    u32* __restrict__ stt, const u32* __restrict__ front0, u32* __restrict__ front1, u32* __restrict__ ctl) {
+    const u32 count = ctl[BC_F0N];
+    for (u32 i = blockIdx.x; i < count; i += gridDim.x) benc_resolve<MINT>(a, g, p4, pm, front0[i], ml, md, stt, front1, ctl + BC_F1N);
+}
+// C1c: the generations behind it -- a cursor that lands on a capped position from a capped position: few, and one after the other by
+// nature -- by ONE workgroup, level by level, until nobody asks any more
+template <bool MINT>
+__global__ __launch_bounds__(1024) void benc_exact_rest(BencArgs a, EncGeom g, const int* __restrict__ p4, const int* __restrict__ pm, u32* __restrict__ ml, u32* __restrict__ md,
+                                                        u32* __restrict__ stt, u32* __restrict__ front1, u32* __restrict__ ctl) {
+    const u32 w = threadIdx.x >> 6;
+    u32 f0 = 0;
+    for (;;) {
+        __syncthreads();
+        const u32 f1 = __hip_atomic_load(ctl + BC_F1N, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (f1 == f0) break;
+        for (u32 i = f0 + w; i < f1; i += 16u) benc_resolve<MINT>(a, g, p4, pm, front1[i], ml, md, stt, front1, ctl + BC_F1N);
+        __threadfence();
+        f0 = f1;
     }
 }
 
@@ -156,14 +247,12 @@ __global__ __launch_bounds__(256) void benc_next(BencArgs a, EncGeom g, const u3
     if (p >= a.nodes) return;
     const int limit = a.limit, pi = (int)p;
     if (pi > limit) { next[p] = p; return; }                     // the end node
-    const int l0 = (int)ml[p], l1 = pi + 1 <= limit ? (int)ml[p + 1u] : 0;
-    int jump = 1; u32 s = 0;
-    if (l0 >= g.min_len) {
-        const bool lazyc = l0 <= g.lazy && pi + 1 <= limit;
-        if (lazyc && l1 > l0) { s = 2; const int e = pi + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 2 > stop ? pi + 2 : stop) - pi; }
-        else { s = 1; const int skip = lazyc ? 1 : 0; const int e = pi + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 1 + skip > stop ? pi + 1 + skip : stop) - pi; }
-    }
-    sr[p] = (u8)s; next[p] = p + (u32)jump;
+    // (a capped position nobody asked for cannot be reached from position 0: what it says does not matter, as long as it says something)
+    u32 l0 = ml[p], l1 = pi + 1 <= limit ? ml[p + 1u] : 0u;
+    if (l0 == BENC_UNKNOWN) l0 = 0;
+    if (l1 == BENC_UNKNOWN) l1 = 0;
+    u32 s; const u32 x = benc_rule(g, limit, pi, (int)l0, (int)l1, s);
+    sr[p] = (u8)s; next[p] = x;
 }
 
 // one round of list ranking: every marked node marks where its jump lands, every jump is squared (double-buffered: a round must see
@@ -332,7 +421,7 @@ static u32 benc_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r
 struct BencLayout {
     BencArgs a;
     u32 tiles;
-    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, mark, sr, tile_in, tile_out, tokbit, gofs, ctl, total;
+    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, front1, mark, sr, tile_in, tile_out, tokbit, gofs, ctl, total;
     BencLayout(const alz_stream& st, const EncGeom& g, int tail) {
         a.data = nullptr; a.N = st.src_len; a.n = (int)st.src_len - tail; a.limit = a.n - 4;
         a.nodes = (u32)a.limit + 2u;
@@ -351,6 +440,7 @@ struct BencLayout {
         match = o; o += benc_al(np * 4);
         ml = o; o += benc_al(np * 4); md = o; o += benc_al(np * 4);
         jump_a = o; o += benc_al(np * 4); jump_b = o; o += benc_al(np * 4);
+        front1 = o; if (g.max_len > ALZ_LEN_CAP) o += benc_al(np * 4);
         mark = o; o += benc_al(np); sr = o; o += benc_al(np);
         tile_in = o; o += benc_al((size_t)3 * (tiles + 64) * 4); tile_out = o; o += benc_al((size_t)3 * (tiles + 64) * 4);
         tokbit = o; o += benc_al(np); gofs = o; o += benc_al((np / 8 + 64) * 4);
@@ -549,11 +639,19 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u, false);
     // C: the parse
     const u32 nbn = (a.nodes + 255u) / 256u;
-    u32* caplist = jump_b;                                        // (the second jump table is free until the ranking)
-    hipLaunchKernelGGL(benc_unpack, dim3(nbp), dim3(256), 0, stream, a, match, ml, md, caplist, ctl);
-    if (g.max_len > ALZ_LEN_CAP) {                                // (only then can kernel B have capped anything)
-        if (g.use_min_table) hipLaunchKernelGGL((benc_exact<true>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, caplist, ctl, ml, md);
-        else hipLaunchKernelGGL((benc_exact<false>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, caplist, ctl, ml, md);
+    const bool caps = g.max_len > ALZ_LEN_CAP;                    // (only then can kernel B have capped anything)
+    u32* stt = caps ? jump_a : nullptr;                           // (the jump tables are free until the ranking; the token-bit area until the emission)
+    u32* front0 = jump_b; u32* front1 = (u32*)(base + L.front1);
+    hipLaunchKernelGGL(benc_unpack, dim3(nbp), dim3(256), 0, stream, a, match, ml, md, stt, ctl);
+    if (caps) {
+        hipLaunchKernelGGL(benc_request0, dim3(nbp), dim3(256), 0, stream, a, g, ml, stt, front0, ctl);
+        if (g.use_min_table) {
+            hipLaunchKernelGGL((benc_exact_g1<true>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, ml, md, stt, front0, front1, ctl);
+            hipLaunchKernelGGL((benc_exact_rest<true>), dim3(1), dim3(1024), 0, stream, a, g, fin4, finm, ml, md, stt, front1, ctl);
+        } else {
+            hipLaunchKernelGGL((benc_exact_g1<false>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, ml, md, stt, front0, front1, ctl);
+            hipLaunchKernelGGL((benc_exact_rest<false>), dim3(1), dim3(1024), 0, stream, a, g, fin4, finm, ml, md, stt, front1, ctl);
+        }
     }
     hipLaunchKernelGGL(benc_next, dim3(nbn), dim3(256), 0, stream, a, g, ml, jump_a, sr);
     const u32 rr = benc_rounds(a.nodes);
