@@ -421,7 +421,7 @@ static u32 benc_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r
 struct BencLayout {
     BencArgs a;
     u32 tiles;
-    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, front1, mark, sr, tile_in, tile_out, tokbit, gofs, ctl, total;
+    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, front1, mark, sr, tile_in, tile_out, tokbit, bitv, gofs, ctl, total;
     BencLayout(const alz_stream& st, const EncGeom& g, int tail) {
         a.data = nullptr; a.N = st.src_len; a.n = (int)st.src_len - tail; a.limit = a.n - 4;
         a.nodes = (u32)a.limit + 2u;
@@ -429,7 +429,7 @@ struct BencLayout {
         a.S = 16384u;                                             // (a segment costs kernel A its S + W positions)
         a.K = ((u32)a.limit + a.S) / a.S;
         a.stride = a.S + a.W + 64u;
-        tiles = (a.N + BENC_TILE - 1u) / BENC_TILE;
+        tiles = (a.N + BENC_TILE - 1u) / BENC_TILE + 1u;         // (+ 1: PRS has a token behind the data)
         const size_t np = (size_t)a.N + 64;
         size_t o = 0;
         vs = o; o += benc_al((a.K + 1) * sizeof(alz_stream)); vindex = o; o += benc_al((a.K + 1) * 4); vpos = o; o += benc_al((a.K + 1) * 8);
@@ -443,7 +443,7 @@ struct BencLayout {
         front1 = o; if (g.max_len > ALZ_LEN_CAP) o += benc_al(np * 4);
         mark = o; o += benc_al(np); sr = o; o += benc_al(np);
         tile_in = o; o += benc_al((size_t)3 * (tiles + 64) * 4); tile_out = o; o += benc_al((size_t)3 * (tiles + 64) * 4);
-        tokbit = o; o += benc_al(np); gofs = o; o += benc_al((np / 8 + 64) * 4);
+        tokbit = o; o += benc_al(np); bitv = o; o += benc_al(2 * np + 64); gofs = o; o += benc_al((np / 4 + 64) * 4);
         ctl = o; o += benc_al(BC_WORDS * 4);
         total = o;
     }
@@ -451,7 +451,8 @@ struct BencLayout {
 
 static bool benc_format(int fmt) {
     return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
-           fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;
+           fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW ||
+           fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;
 }
 
 template <int FMT>
@@ -593,6 +594,106 @@ static void benc_emit_seq(hipStream_t stream, const BencLayout& L, const BencArg
     hipLaunchKernelGGL((benc_seq_end<FMT>), dim3((a.N + 255u) / 256u), dim3(256), 0, stream, a, ctl, dst, cap, d_result, d_aux);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PRS (enc_emit_prs_kernel's rules, PRS.cs:104-159): tokens of one, two or four flag bits.  With B0 = the flag bits in front of a token and
+// pidx = the payload bytes in front of it -- two prefix sums over the positions -- everything has its place: the payload behind
+// floor(Bp / 8) + 1 flag bytes (Bp: the bits written when the payload is handed over), the offset byte of a short match whose four bits
+// just completed a flag byte in FRONT of the next flag byte; flag byte k in front of the first payload that waits for it -- the smallest
+// (kp + pidx + special) among the tokens with kp = k: an atomic minimum.  The flag bits go through a byte per bit; one thread per flag
+// byte gathers them.  A match of length 2 further than 0x100 back is written as two literals; the end token (bit 0, two zero bytes, bit 1)
+// is the token of the position behind the data.
+enum { BC_BITS = 6, BC_PAY = 7 };
+struct BencPrs { u32 kind, len, dist, nbits, psize; bool shortm; };   // kind: 0 none, 1 literal, 2 match, 3 the end token
+__device__ __forceinline__ BencPrs benc_prs_token(const BencArgs& a, u32 p, u32 tail, const u8* mark, const u8* sr, const u32* ml, const u32* md) {
+    BencPrs r; r.kind = 0; r.len = 0; r.dist = 0; r.nbits = 0; r.psize = 0; r.shortm = false;
+    if (p > a.N) return r;
+    if (p == a.N) { r.kind = 3; r.nbits = 2; r.psize = 2; return r; }
+    const BencTok t = benc_token(a, p, tail, mark, sr, ml, md);
+    auto dropped = [](const BencTok& k) { return k.kind == 2u && k.len == 2u && k.dist > 0x100u; };   // PRS.cs: not worth a long match -- literals
+    if (t.kind == 2u && !dropped(t)) {
+        r.kind = 2; r.len = t.len; r.dist = t.dist;
+        r.shortm = t.dist <= 0x100u && t.len <= 5u;
+        r.nbits = r.shortm ? 4u : 2u; r.psize = r.shortm ? 1u : (t.len > 9u ? 3u : 2u);
+        return r;
+    }
+    bool lit = t.kind != 0u;                                       // a literal, or the first byte of a dropped match
+    if (!lit && p >= 1u) lit = dropped(benc_token(a, p - 1u, tail, mark, sr, ml, md));   // its second byte
+    if (lit) { r.kind = 1; r.nbits = 1; r.psize = 1; }
+    return r;
+}
+
+template <bool BIG, int PASS>
+__global__ __launch_bounds__(64) void benc_prs(BencArgs a, const u8* __restrict__ mark, const u8* __restrict__ sr, const u32* __restrict__ ml, const u32* __restrict__ md,
+                                               const u32* __restrict__ ctl, const u32* __restrict__ base_b, const u32* __restrict__ base_p, u32* __restrict__ tile_b,
+                                               u32* __restrict__ tile_p, u8* __restrict__ dst, u32 cap, u8* __restrict__ bitv, u32* __restrict__ gofs) {
+    const u32 tile = blockIdx.x, lane = benc_lane(), tail = ctl[BC_TAIL];
+    if (PASS == 1) { const u64 total = (u64)((ctl[BC_BITS] + 7u) >> 3) + ctl[BC_PAY]; if (ctl[BC_BAD] || total > cap) return; }
+    u32 bb = PASS == 1 ? base_b[tile] : 0u, pb = PASS == 1 ? base_p[tile] : 0u;
+    for (u32 r = 0; r < BENC_TILE / 64u; r++) {
+        const u32 P = tile * BENC_TILE + r * 64u, p = P + lane;
+        if (P > a.N) break;
+        const BencPrs t = benc_prs_token(a, p, tail, mark, sr, ml, md);
+        const u32 bincl = scan_add(t.nbits), pincl = scan_add(t.psize);
+        if (PASS == 1 && t.kind) {
+            const bool lit = t.kind == 1u, endtok = t.kind == 3u;
+            const u32 B0 = bb + bincl - t.nbits, pidx = pb + pincl - t.psize;
+            const u32 Bp = B0 + (lit ? 0u : t.shortm ? 4u : 1u);
+            const bool special = t.shortm && (Bp & 7u) == 0u;
+            const u32 kp = Bp >> 3;
+            const u32 out = kp + 1u - (special ? 1u : 0u) + pidx;
+            atomicMin(gofs + kp, kp + pidx + (special ? 1u : 0u));
+            const u32 l2 = t.len - 2u;
+            const u32 pattern = lit ? 1u : t.shortm ? ((((l2 >> 1) & 1u) << 2) | ((l2 & 1u) << 3)) : 2u;   // bit i of `pattern` = my i-th flag bit
+            for (u32 i = 0; i < t.nbits; i++) bitv[B0 + i] = (u8)((pattern >> i) & 1u);
+            if (lit) dst[out] = a.data[p];
+            else if (t.shortm) dst[out] = (u8)((0u - t.dist) & 0xFFu);
+            else if (endtok) { dst[out] = 0; dst[out + 1] = 0; }
+            else {
+                u32 v = ((0u - t.dist) << 3) & 0xFFFFu;
+                if (t.len <= 9u) v |= t.len - 2u;
+                if (BIG) { dst[out] = (u8)(v >> 8); dst[out + 1] = (u8)(v & 0xFFu); } else { dst[out] = (u8)(v & 0xFFu); dst[out + 1] = (u8)(v >> 8); }
+                if (t.len > 9u) dst[out + 2] = (u8)(t.len - 1u);
+            }
+        }
+        bb += benc_last(bincl); pb += benc_last(pincl);
+    }
+    if (PASS == 0 && lane == 0) { tile_b[tile] = bb; tile_p[tile] = pb; }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(256) void benc_prs_flags(BencArgs a, const u32* __restrict__ ctl, const u8* __restrict__ bitv, const u32* __restrict__ gofs,
+                                                      u8* __restrict__ dst, u32 cap, alz_result* __restrict__ result, alz_encode_aux* __restrict__ aux) {
+    const u32 bits = ctl[BC_BITS], nflags = (bits + 7u) >> 3;
+    const u64 total = (u64)nflags + ctl[BC_PAY];
+    const bool declined = ctl[BC_BAD] != 0u, room = total <= cap;
+    const u32 k = blockIdx.x * 256u + threadIdx.x;
+    if (k == 0u && !declined) {
+        alz_result r; r.dst_len = room ? (u32)total : 0u; r.src_used = a.N; r.status = room ? ALZ_ST_OK : ALZ_ST_OUTPUT_CAPACITY; r.reserved = 0;
+        *result = r;
+        if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
+    }
+    if (declined || !room || k >= nflags) return;
+    u32 acc = 0;
+    for (u32 i = 0; i < 8u; i++) { const u32 b = 8u * k + i; if (b < bits && bitv[b]) acc |= 1u << (BIG ? 7u - i : i); }   // (Dispose(): a partial flag byte goes out with its unused bits zero)
+    dst[gofs[k]] = (u8)acc;
+}
+
+template <bool BIG>
+static hipError_t benc_emit_prs(hipStream_t stream, const BencLayout& L, const BencArgs& a, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
+    const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
+    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    u8* bitv = base + L.bitv; u32* gofs = (u32*)(base + L.gofs);
+    const u32 pitch = L.tiles + 64u, tiles1 = a.N / BENC_TILE + 1u;            // (the tile of the position behind the data: the end token)
+    hipError_t e = hipMemsetAsync(gofs, 0xFF, ((size_t)a.N / 4 + 64) * 4, stream);   // (flag bytes: at most (2 N + 2) / 8 + 1)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((benc_prs<BIG, 0>), dim3(tiles1), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, (const u32*)nullptr, (const u32*)nullptr, tin, tin + pitch, dst, cap, bitv, gofs);
+    hipLaunchKernelGGL(benc_scan3, dim3(2), dim3(1024), 0, stream, tin, tout, tiles1, pitch, ctl + (BC_BITS - BC_T));
+    hipLaunchKernelGGL((benc_prs<BIG, 1>), dim3(tiles1), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tout, tout + pitch, (u32*)nullptr, (u32*)nullptr, dst, cap, bitv, gofs);
+    hipLaunchKernelGGL((benc_prs_flags<BIG>), dim3((a.N / 4u + 2u + 255u) / 256u), dim3(256), 0, stream, a, ctl, bitv, gofs, dst, cap, d_result, d_aux);
+    return hipSuccess;
+}
+
 }  // namespace
 
 bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, uint32_t min_bytes) {
@@ -672,6 +773,8 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     case ALZ_FMT_LZHUDSON: benc_emit<ALZ_FMT_LZHUDSON>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_LZ4_BLOCK: benc_emit_seq<ALZ_FMT_LZ4_BLOCK>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_SNAPPY_RAW: benc_emit_seq<ALZ_FMT_SNAPPY_RAW>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_PRS_BE: e = benc_emit_prs<true>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); if (e != hipSuccess) return e; break;
+    case ALZ_FMT_PRS_LE: e = benc_emit_prs<false>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); if (e != hipSuccess) return e; break;
     default: return hipErrorInvalidValue;
     }
     e = hipMemcpyAsync(d_declined, ctl + BC_BAD, 4, hipMemcpyDeviceToDevice, stream);
