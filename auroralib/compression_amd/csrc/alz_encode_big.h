@@ -452,7 +452,7 @@ struct BencLayout {
 static bool benc_format(int fmt) {
     return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
            fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW ||
-           fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;
+           fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE || fmt == ALZ_FMT_LZO;
 }
 
 template <int FMT>
@@ -694,6 +694,183 @@ static hipError_t benc_emit_prs(hipStream_t stream, const BencLayout& L, const B
     return hipSuccess;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LZO1X (enc_emit_lzo_kernel's rules, LZO.cs:141-250).  The writer is sequential only at the head of a stream, until the first match is out:
+// one wavefront walks it the reference's way (benc_lzo_head).  From there every match start is one unit -- a literal run of >= 4 in front
+// of it, its token, the 0-3 literals behind it -- whose size follows from its own numbers, the end of the match in front of it (prefix
+// max) and whether a start or the end of the data lies within three bytes behind it: the three passes of the sequence formats.
+enum { BC_LZ_SP0 = 10, BC_LZ_OB = 11, BC_LZ_MO = 12, BC_LZ_STATUS = 13, BC_LZ_DONE = 14, BC_LZ_FAIL = 15 };
+__device__ __forceinline__ void benc_wave_copy16(u8* d, const u8* s, u32 len, u32 lane) {
+    u32 i = 0;
+    for (; i + 1024u <= len; i += 1024u) { u64 v[2]; __builtin_memcpy(v, s + i + 16u * lane, 16); __builtin_memcpy(d + i + 16u * lane, v, 16); }
+    for (u32 j = i + lane; j < len; j += 64u) d[j] = s[j];
+}
+__global__ __launch_bounds__(64) void benc_lzo_head(BencArgs a, const u8* __restrict__ mark, const u8* __restrict__ sr, const u32* __restrict__ ml_, const u32* __restrict__ md_,
+                                                    u32* __restrict__ ctl, u8* __restrict__ dst, u32 cap) {
+    const u32 lane = benc_lane(), n = a.N;
+    if (ctl[BC_BAD]) return;
+    auto is_start = [&](u32 q) { return benc_token(a, q, 0xFFFFFFFFu, mark, sr, ml_, md_).kind == 2u; };
+    auto next_start = [&](u32 from) -> u32 {                       // the next start at or behind `from` (n: none)
+        for (u32 P = from & ~63u; (int)P <= a.limit; P += 64u) {
+            const u32 q = P + lane;
+            const u64 m = __ballot(q >= from && is_start(q));
+            if (m) return P + (u32)__builtin_ctzll(m);
+        }
+        return n;
+    };
+    u32 sp = 0, olen = 0; bool fail = false; int status = ALZ_ST_OK;
+    auto put = [&](u32 b) { if (olen < cap) { if (lane == 0) dst[olen] = (u8)b; } else fail = true; olen++; };
+    auto copy = [&](u32 from, u32 len) {
+        const u32 room = olen < cap ? cap - olen : 0u, k = len < room ? len : room;
+        benc_wave_copy16(dst + olen, a.data + from, k, lane);
+        if (k < len) fail = true;
+        olen += len;
+    };
+    u32 mo = next_start(0), ml = 0, md = 0;
+    if (mo < n) { ml = ml_[mo]; md = md_[mo]; }
+    u32 mbit = mo;
+    bool clean = false;
+    while (sp != n && !clean) {
+        u32 plain = mo - sp;
+        if (plain != 0u) {
+            if (plain < 4u) { const u32 dif = 4u - plain; mo += dif; ml = ml > dif ? ml - dif : 0u; plain = 4u; }
+            if (plain > 18u) { put(0); u32 v = plain - 18u; while (v > 255u) { put(0); v -= 255u; } put(v); } else put(plain - 3u);
+            if (sp + plain > n) { status = ALZ_ST_BAD_TOKEN; break; }
+            copy(sp, plain); sp += plain;
+        }
+        u32 no = mbit < n ? next_start(mbit + 1u) : n, nl = 0, nd = 0;
+        if (no < n) { nl = ml_[no]; nd = md_[no]; }
+        if (ml >= 3u) {
+            sp += ml;
+            u32 emb = no - sp;
+            if (no < sp) { status = ALZ_ST_BAD_TOKEN; break; }
+            if (emb > 3u) emb = 0;
+            u8 tok[8 + 4];                                          // (a token is short except for its extension bytes)
+            if (lzo_match_size(md, ml) <= 8u) { const u32 k = lzo_put_match(tok, md, ml, emb); for (u32 i = 0; i < k; i++) put(tok[i]); }
+            else if (md <= 16384u) { put(0x20); u32 v = ml - 33u; while (v > 255u) { put(0); v -= 255u; } put(v); put((emb | ((md - 1u) << 2)) & 0xFFu); put(((md - 1u) >> 6) & 0xFFu); }
+            else { const u32 d2 = md - 0x4000u, flag = (0x10u | ((d2 & 0x4000u) >> 11)) & 0xFFu; put(flag); u32 v = ml - 9u; while (v > 255u) { put(0); v -= 255u; } put(v); put((emb | (d2 << 2)) & 0xFFu); put((d2 >> 6) & 0xFFu); }
+            if (sp + emb > n) { status = ALZ_ST_BAD_TOKEN; break; }
+            copy(sp, emb); sp += emb;
+            clean = true;
+        }
+        mo = no; mbit = no; ml = nl; md = nd;
+    }
+    const bool done = status != ALZ_ST_OK || sp == n;
+    if (done && status == ALZ_ST_OK) { put(0x11); put(0); put(0); }
+    if (lane == 0) { ctl[BC_LZ_SP0] = sp; ctl[BC_LZ_OB] = olen; ctl[BC_LZ_MO] = mo; ctl[BC_LZ_STATUS] = (u32)status; ctl[BC_LZ_DONE] = done ? 1u : 0u; ctl[BC_LZ_FAIL] = fail ? 1u : 0u; }
+}
+
+// the literals behind the last match (0-3 went out with it), the end token: what the whole stream takes
+__device__ __forceinline__ u64 benc_lzo_total(const BencArgs& a, const u32* ctl, u32& rest, u32& lsz, u32& obase) {
+    const u32 cover = ctl[BC_COVER] > ctl[BC_LZ_SP0] ? ctl[BC_COVER] : ctl[BC_LZ_SP0];
+    rest = a.N - cover; if (rest <= 3u) rest = 0u;
+    lsz = rest ? lzo_lit_size(rest) : 0u;
+    obase = ctl[BC_LZ_OB] + ctl[BC_SEQ];
+    return (u64)obase + lsz + rest + 3u;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(64) void benc_lzo(BencArgs a, const u8* __restrict__ mark, const u8* __restrict__ sr, const u32* __restrict__ ml, const u32* __restrict__ md,
+                                               const u32* __restrict__ ctl, const u32* __restrict__ cover_base, const u32* __restrict__ off_base, u32* __restrict__ tile_out,
+                                               u8* __restrict__ dst, u32 cap) {
+    const u32 tile = blockIdx.x, lane = benc_lane(), n = a.N;
+    const u32 mo = ctl[BC_LZ_MO], sp0 = ctl[BC_LZ_SP0];
+    if (ctl[BC_BAD] || ctl[BC_LZ_DONE]) { if (PASS < 2 && lane == 0) tile_out[tile] = 0u; return; }
+    if (PASS == 2) { u32 r_, l_, o_; if (ctl[BC_LZ_FAIL] || benc_lzo_total(a, ctl, r_, l_, o_) > cap) return; }
+    u32 cover = PASS >= 1 ? cover_base[tile] : 0u;
+    if (cover < sp0) cover = sp0;
+    u32 obase = PASS == 2 ? ctl[BC_LZ_OB] + off_base[tile] : 0u;
+    auto is_start = [&](u32 q) { return benc_token(a, q, 0xFFFFFFFFu, mark, sr, ml, md).kind == 2u; };
+    for (u32 r = 0; r < BENC_TILE / 64u; r++) {
+        const u32 P = tile * BENC_TILE + r * 64u, p = P + lane;
+        if (P >= n) break;
+        const BencTok t = benc_token(a, p, 0xFFFFFFFFu, mark, sr, ml, md);
+        const bool start = t.kind == 2u && p >= mo;
+        if (__ballot(start) == 0ull) continue;
+        const u32 M = start ? t.len : 0u, D = t.dist;
+        const u32 mend = start ? p + M : 0u;
+        const u32 pmax = scan_max(mend);
+        if (PASS >= 1) {
+            u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);
+            if (before < cover) before = cover;
+            const u32 Lb = start ? p - before : 0u;
+            u32 emb = 0;
+            if (start) {
+                for (u32 kk = 0; kk < 4u; kk++) {
+                    const u32 q = mend + kk;
+                    const bool hit = q >= n || is_start(q);
+                    if (hit) { emb = q >= n ? n - mend : kk; break; }
+                }
+            }
+            const u32 lsz = Lb >= 4u ? lzo_lit_size(Lb) : 0u, lcp = Lb >= 4u ? Lb : 0u;
+            const u32 esz = start ? lsz + lcp + lzo_match_size(D, M) + emb : 0u;
+            const u32 incl = scan_add(esz);
+            if (PASS == 2) {
+                const u32 off = obase + incl - esz;
+                if (start) {
+                    u32 q = off;
+                    if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); if (Lb <= ALZ_LZO_LANE_LIT) for (u32 i = 0; i < Lb; i++) dst[q + i] = a.data[before + i]; q += Lb; }
+                    q += lzo_put_match(dst + q, D, M, emb);
+                    for (u32 i = 0; i < emb; i++) dst[q + i] = a.data[mend + i];
+                }
+                u64 longs = __ballot(start && Lb > ALZ_LZO_LANE_LIT);
+                while (longs) {
+                    const int l0 = (int)__builtin_ctzll(longs);
+                    const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)Lb, l0);
+                    const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lsz), l0);
+                    benc_wave_copy16(dst + dq, a.data + so, len, lane);
+                    longs &= longs - 1ull;
+                }
+            }
+            obase += benc_last(incl);
+        }
+        const u32 wmax = benc_last(pmax);
+        if (wmax > cover) cover = wmax;
+    }
+    if (PASS == 0 && lane == 0) tile_out[tile] = cover > sp0 ? cover : 0u;
+    if (PASS == 1 && lane == 0) tile_out[tile] = obase;
+}
+
+__global__ __launch_bounds__(256) void benc_lzo_end(BencArgs a, const u32* __restrict__ ctl, u8* __restrict__ dst, u32 cap, alz_result* __restrict__ result,
+                                                    alz_encode_aux* __restrict__ aux) {
+    if (ctl[BC_BAD]) return;
+    const u32 q = blockIdx.x * 256u + threadIdx.x;
+    const int status = (int)ctl[BC_LZ_STATUS];
+    alz_result r; r.src_used = a.N; r.reserved = 0;
+    if (ctl[BC_LZ_DONE]) {                                         // the head was the whole stream (or refused it)
+        const bool ok = status == ALZ_ST_OK && !ctl[BC_LZ_FAIL];
+        r.dst_len = ok ? ctl[BC_LZ_OB] : 0u; r.status = status != ALZ_ST_OK ? status : (ok ? ALZ_ST_OK : ALZ_ST_OUTPUT_CAPACITY);
+        if (q == 0u) { *result = r; if (aux) { aux->aux0 = 0; aux->aux1 = 0; } }
+        return;
+    }
+    u32 rest, lsz, obase;
+    const u64 total = benc_lzo_total(a, ctl, rest, lsz, obase);
+    const bool room = !ctl[BC_LZ_FAIL] && total <= cap;
+    if (q == 0u) {
+        r.dst_len = room ? (u32)total : 0u; r.status = room ? ALZ_ST_OK : ALZ_ST_OUTPUT_CAPACITY;
+        *result = r; if (aux) { aux->aux0 = 0; aux->aux1 = 0; }
+        if (room) {
+            if (rest) (void)lzo_put_lit(dst + obase, rest);
+            dst[total - 3u] = 0x11; dst[total - 2u] = 0; dst[total - 1u] = 0;
+        }
+    }
+    if (room && q < rest) dst[obase + lsz + q] = a.data[a.N - rest + q];
+}
+
+static void benc_emit_lzo(hipStream_t stream, const BencLayout& L, const BencArgs& a, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
+    const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
+    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    const u32 pitch = L.tiles + 64u;
+    hipLaunchKernelGGL(benc_lzo_head, dim3(1), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, dst, cap);
+    hipLaunchKernelGGL((benc_lzo<0>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, (const u32*)nullptr, (const u32*)nullptr, tin, dst, cap);
+    hipLaunchKernelGGL(benc_scanmax, dim3(1), dim3(1024), 0, stream, tin, tout, L.tiles, ctl + BC_COVER);
+    hipLaunchKernelGGL((benc_lzo<1>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tout, (const u32*)nullptr, tin + pitch, dst, cap);
+    hipLaunchKernelGGL(benc_scan3, dim3(1), dim3(1024), 0, stream, tin + pitch, tout + pitch, L.tiles, pitch, ctl + (BC_SEQ - BC_T));
+    hipLaunchKernelGGL((benc_lzo<2>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tout, tout + pitch, (u32*)nullptr, dst, cap);
+    hipLaunchKernelGGL(benc_lzo_end, dim3((a.N + 255u) / 256u), dim3(256), 0, stream, a, ctl, dst, cap, d_result, d_aux);
+}
+
 }  // namespace
 
 bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, uint32_t min_bytes) {
@@ -773,6 +950,7 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     case ALZ_FMT_LZHUDSON: benc_emit<ALZ_FMT_LZHUDSON>(stream, L, a, g, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_LZ4_BLOCK: benc_emit_seq<ALZ_FMT_LZ4_BLOCK>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_SNAPPY_RAW: benc_emit_seq<ALZ_FMT_SNAPPY_RAW>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
+    case ALZ_FMT_LZO: benc_emit_lzo(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); break;
     case ALZ_FMT_PRS_BE: e = benc_emit_prs<true>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); if (e != hipSuccess) return e; break;
     case ALZ_FMT_PRS_LE: e = benc_emit_prs<false>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); if (e != hipSuccess) return e; break;
     default: return hipErrorInvalidValue;
