@@ -107,25 +107,31 @@ __device__ __forceinline__ bool benc_lazy_needs(const EncGeom& g, int limit, int
 // "somebody's cursor may land on x": a capped position is searched exactly once somebody asks
 __device__ __forceinline__ void benc_request(const BencArgs& a, u32 x, u32* stt, u32* front, u32* tail) {
     if ((int)x > a.limit) return;
+    if (__hip_atomic_load(stt + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) return;      // (nearly every target: not a capped position -- a load, not an atomic)
     if (atomicCAS(stt + x, 1u, 2u) == 1u) front[atomicAdd(tail, 1u)] = x;
 }
 
-// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 2 KiB per trip -- four loads of eight bytes per lane in flight (a
-// trip may read up to 31 bytes behind `max`: inside the slack behind every source buffer, never counted)
+// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 4 KiB per trip -- four loads of sixteen bytes per lane and side in
+// flight (a trip may read up to 63 bytes behind `max`: inside the slack behind every source buffer, never counted)
 __device__ __forceinline__ int benc_wave_match_len(const u8* a, const u8* b, int max) {
     const int lane = (int)benc_lane();
-    for (int base = 0; base < max; base += 2048) {
-        u64 x[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const int off = base + 512 * k + 8 * lane; x[k] = off < max ? load64(a + off) ^ load64(b + off) : 0ull; }
+    for (int base = 0; base < max; base += 4096) {
+        u64 x[4][2];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const u64 mm = __ballot(x[k] != 0ull);
+            const int off = base + 1024 * k + 16 * lane;
+            u64 va[2] = {0, 0}, vb[2] = {0, 0};
+            if (off < max) { __builtin_memcpy(va, a + off, 16); __builtin_memcpy(vb, b + off, 16); }
+            x[k][0] = va[0] ^ vb[0]; x[k][1] = va[1] ^ vb[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u64 mm = __ballot((x[k][0] | x[k][1]) != 0ull);
             if (mm) {
                 const int l0 = (int)__builtin_ctzll(mm);
-                const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)x[k], l0), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(x[k] >> 32), l0);
-                const u64 xv = ((u64)hi << 32) | lo;
-                const int len = base + 512 * k + 8 * l0 + (int)(__builtin_ctzll(xv) >> 3);
+                const u64 lo = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x[k][0] >> 32), l0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x[k][0], l0);
+                const u64 hi = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x[k][1] >> 32), l0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x[k][1], l0);
+                const int len = base + 1024 * k + 16 * l0 + (lo ? (int)(__builtin_ctzll(lo) >> 3) : 8 + (int)(__builtin_ctzll(hi) >> 3));
                 return len < max ? len : max;
             }
         }

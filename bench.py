@@ -518,14 +518,18 @@ def cpu_baseline(O, A, np, batch, recs, n, target, args, aff):
     best_t = max(sweep, key=lambda k: sweep[k])
     # ... and the reference's own benchmark shape on ONE core of this box: one 1 000 KiB stream of Test.bmp per body (what the
     # `single_<format>_q0` entries of `configs` decode through alz_decode)
-    single = {}
+    single, single_c = {}, {}
     try:
         bmp = O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0]
         raw1 = bytes(bmp[:1024000])
-        for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block"):
+        for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block", "snappy_raw"):
             fmt = A.FORMAT_NAMES.index(fname)
+            for q in (0, 15):                                     # Compress, the C port of LzChainMatchFinder + the format's writer, one core
+                t0 = time.perf_counter(); comp, aux = O.encode_stream(fmt, raw1, quality=q); dt = time.perf_counter() - t0
+                t0 = time.perf_counter(); comp, aux = O.encode_stream(fmt, raw1, quality=q); dt = min(dt, time.perf_counter() - t0)
+                single_c["%s_q%d" % (fname, q)] = round(len(raw1) / dt / 2**30, 3)
             comp, aux = O.encode_stream(fmt, raw1, quality=0)
-            sized = fname not in ("prs_be", "lzo", "lz4_block")
+            sized = fname not in ("prs_be", "lzo", "lz4_block", "snappy_raw")
             reps, t0 = 0, time.perf_counter()
             while reps < 3 or time.perf_counter() - t0 < 0.25:
                 out, r = O.decode_stream(fmt, comp, decom_len=len(raw1) if sized else 0, cap=len(raw1), aux0=aux.aux0, aux1=aux.aux1)
@@ -539,7 +543,7 @@ def cpu_baseline(O, A, np, batch, recs, n, target, args, aff):
     return {"value": sweep[best_t], "unit": "GiB/s", "cores": int(best_t), "kind": "port",
             "single_thread": sweep["1"], "all_allowed_cores": {"threads": aff, "value": sweep[str(aff)]}, "threads_sweep_GiB_s": sweep,
             "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota_cores": cpu_quota(),
-            "single_stream_one_thread_GiB_s": single,
+            "single_stream_one_thread_GiB_s": single, "single_stream_compress_one_thread_GiB_s": single_c,
             "sample": "first max(256, 64 T) of the %d x %d KiB %s streams per thread count T, %d passes at T = %d; C restatement of the managed "
                       "ring+flush path (oracle/alz_oracle.c), streams striped over threads" % (n, args.stream_kib, args.format, reps_all, aff)}
 
@@ -766,13 +770,25 @@ PUBLISHED_SINGLE = {("yay0", 0): (470.82, "Benchmarks.md:78"), ("yay0", 15): (82
                     ("prs_be", 0): (459.77, "Benchmarks.md:94"), ("prs_be", 15): (900.58, "Benchmarks.md:96"),
                     ("lzo", 0): (636.34, "Benchmarks.md:26"), ("lzo", 15): (1457.70, "Benchmarks.md:28"),
                     ("lz4_block", 0): (747.58, "Benchmarks.md:22 (LZ4Legacy: this block behind an 8-byte header)"),
-                    ("lz4_block", 15): (2191.72, "Benchmarks.md:24 (LZ4Legacy: this block behind an 8-byte header)")}
+                    ("lz4_block", 15): (2191.72, "Benchmarks.md:24 (LZ4Legacy: this block behind an 8-byte header)"),
+                    ("snappy_raw", 0): (525.16, "Benchmarks.md:34"), ("snappy_raw", 15): (655.46, "Benchmarks.md:36")}
+# the same table's Compress rows (MB/s of raw input), CompressionLevel 0 / 15
+PUBLISHED_SINGLE_COMPRESS = {("yay0", 0): (229.43, "Benchmarks.md:77"), ("yay0", 15): (68.83, "Benchmarks.md:79"),
+                             ("mio0", 0): (179.70, "Benchmarks.md:69"), ("mio0", 15): (111.97, "Benchmarks.md:71"),
+                             ("yaz0", 0): (255.98, "Benchmarks.md:81"), ("yaz0", 15): (87.02, "Benchmarks.md:83"),
+                             ("lz10", 0): (194.28, "Benchmarks.md:57"), ("lz10", 15): (112.11, "Benchmarks.md:59"),
+                             ("lz11", 0): (246.42, "Benchmarks.md:61"), ("lz11", 15): (135.32, "Benchmarks.md:63"),
+                             ("lzss", 0): (188.34, "Benchmarks.md:29"), ("lzss", 15): (109.92, "Benchmarks.md:31"),
+                             ("prs_be", 0): (238.65, "Benchmarks.md:93"), ("prs_be", 15): (83.24, "Benchmarks.md:95"),
+                             ("lzo", 0): (289.24, "Benchmarks.md:25"), ("lzo", 15): (89.93, "Benchmarks.md:27"),
+                             ("lz4_block", 0): (260.67, "Benchmarks.md:21 (LZ4Legacy)"), ("lz4_block", 15): (103.50, "Benchmarks.md:23 (LZ4Legacy)"),
+                             ("snappy_raw", 0): (286.26, "Benchmarks.md:33"), ("snappy_raw", 15): (109.70, "Benchmarks.md:35")}
 
 
 def single_stream(ctx, np, A, synth, Plan):
     """The reference's OWN benchmark shape (Benchmarks/Benchmarks/TestAllAlgorithms.cs:37-69): ONE stream = the first 1 000 KiB of
-    Test.bmp, compressed at quality 0 / 15, then Decompress timed -- for the six formats whose single streams run on the whole GPU
-    (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4 blocks, csrc/alz_big.hip).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
+    Test.bmp, compressed at quality 0 / 15, then Compress and Decompress timed -- for the formats whose single streams run on the whole GPU
+    (LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4 blocks / Snappy: csrc/alz_big.hip decodes, csrc/alz_encode_big.h encodes).  `value` = alz_decode on HOST buffers (upload + kernels + download + the call: what a format
     class's Decompress(Stream, Stream) costs), `device_GiB_s` = the kernels alone; beside them the managed figure the reference
     publishes for this exact input on its own machine (another CPU, no GPU: context, not a baseline measured here)."""
     from auroralib.compression_amd import formats as F
@@ -780,14 +796,38 @@ def single_stream(ctx, np, A, synth, Plan):
     bmp = lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read())
     raw = bytes(bmp[:1024000]); n = len(raw)
     out = []
-    for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block"):
+    import json
+    import xxhash
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")))["benchmark"]    # (made by tests/golden/make_vectors.py)
+    rawsrc = np.frombuffer(raw + bytes(64), dtype=np.uint8)
+    for fname in ("yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block", "snappy_raw"):
         fmt = A.FORMAT_NAMES.index(fname)
         for q in (0, 15):
             cap = n + n // 4 + 64
             es = (A.Stream * 1)(A.Stream(0, 0, n, cap, 0, 0, 0, fmt))
-            enc, eres, eaux = ctx.encode_batch(es, np.frombuffer(raw + bytes(64), dtype=np.uint8), cap + 64, quality=q)
+            before = ctx.big_stream()
+            enc, eres, eaux = ctx.encode_batch(es, rawsrc, cap + 64, quality=q)
+            enc_whole_gpu = ctx.big_stream() > before
             comp = bytes(enc[:eres[0].dst_len]); a0, a1 = eaux[0].aux0, eaux[0].aux1
-            decl = 0 if fname in ("lz4_block", "prs_be", "lzo") else n   # (an LZ4 block / a PRS or LZO stream carries no size: the destination's room bounds it)
+            # ---- Compress: alz_encode_batch of ONE stream on host buffers (upload + kernels + download + the call: what a format class's
+            # Compress(ReadOnlySpan<byte>, Stream) costs), checked against the committed vector of this exact input
+            reps, t0, kms = 10, time.perf_counter(), 0.0
+            for _ in range(reps):
+                enc, eres, eaux = ctx.encode_batch(es, rawsrc, cap + 64, quality=q)
+                kms += ctx.last_kernel_ms()
+            cwall_ms = (time.perf_counter() - t0) / reps * 1e3
+            glen, gdig, ga0, ga1 = golden["%s:%d:q%d" % (fname, n, q)]
+            cok = (eres[0].status == 0 and eres[0].dst_len == glen and xxhash.xxh64(bytes(enc[:glen])).hexdigest() == gdig and
+                   (eaux[0].aux0, eaux[0].aux1) == (ga0, ga1))
+            cpub, cwhere = PUBLISHED_SINGLE_COMPRESS[(fname, q)]
+            out.append({"name": "single_compress_%s_q%d" % (fname, q),
+                        "workload": "ONE %s stream: Test.bmp[0:1 024 000] compressed at quality %d (ratio %.4f), the reference's benchmark shape; alz_encode_batch of one stream on host buffers"
+                                    % (fname, q, len(comp) / n),
+                        "value": round(n / (cwall_ms * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input", "ms_per_call": round(cwall_ms, 4),
+                        "kernel_ms": round(kms / reps, 4), "whole_gpu_path": enc_whole_gpu, "parity_ok": cok,
+                        "published_managed": {"MB_per_s": cpub, "GiB_s": round(cpub * 1e6 / 2**30, 3), "where": cwhere,
+                                              "hardware": "AMD Ryzen 7 3800X, .NET 8, one thread (BenchmarkDotNet); not measured here"}})
+            decl = 0 if fname in ("lz4_block", "prs_be", "lzo", "snappy_raw") else n   # (an LZ4 block / a PRS, LZO or Snappy body carries no size the descriptor states: the destination's room bounds it)
             st = (A.Stream * 1)(A.Stream(0, 0, len(comp), n, decl, a0, a1, fmt))
             d_src, d_dst = ctx.malloc(len(comp) + 64), ctx.malloc(n + 64)
             try:

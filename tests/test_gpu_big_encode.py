@@ -192,3 +192,25 @@ def test_compress_through_the_format_classes(test_bmp):
             f = cls()
             comp = f.Compress(test_bmp, s)
             assert comp == O.container_compress(cont, test_bmp, quality=s.Quality), (cls.__name__, s.Quality)
+
+
+def test_the_benchmark_input_against_committed_vectors(test_bmp):
+    """The reference's own benchmark input -- the first 1 000 KiB of Test.bmp at CompressionLevel 0 and 15 -- for the eleven north-star
+    bodies against tests/golden/oracle_vectors.json["benchmark"]: no oracle at run time (lengths, XXH64 digests, section offsets), and every
+    stream must have taken the whole-GPU path."""
+    import json
+    import os
+    import xxhash
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))["benchmark"]
+    assert len(vec) == 22
+    with Context(0) as c:
+        for key, (length, digest, a0, a1) in sorted(vec.items()):
+            name, size, q = key.split(":")
+            n = int(size)
+            raw = np.frombuffer(test_bmp[:n] + bytes(64), dtype=np.uint8)
+            st = (A.Stream * 1)(A.Stream(0, 0, n, _cap(n), 0, 0, 0, A.FORMAT_NAMES.index(name)))
+            before = c.big_stream()
+            dst, res, aux = c.encode_batch(st, raw, _cap(n) + 64, quality=int(q[1:]))
+            assert c.big_stream() - before == 1, key
+            assert (res[0].status, res[0].dst_len, res[0].src_used) == (A.ST_OK, length, n), key
+            assert xxhash.xxh64(bytes(dst[:length])).hexdigest() == digest and (aux[0].aux0, aux[0].aux1) == (a0, a1), key

@@ -157,7 +157,7 @@ def test_committed_oracle_vectors(test_bmp):
     matrix is frozen -- any drift of the restatement shows up here, not as a silent change of what 'parity' means."""
     import json
     vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
-    for key, (length, digest, a0, a1) in vec["bodies"].items():
+    for key, (length, digest, a0, a1) in list(vec["bodies"].items()) + list(vec["benchmark"].items()):   # (benchmark: the reference's own benchmark input, 1 000 KiB)
         name, size, q = key.split(":")
         comp, aux = O.encode_stream(A.FORMAT_NAMES.index(name), test_bmp[:int(size)], quality=int(q[1:]))
         assert (len(comp), "%016x" % O.xxh64(comp), aux.aux0, aux.aux1) == (length, digest, a0, a1), key
