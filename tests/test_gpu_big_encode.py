@@ -214,3 +214,25 @@ def test_the_benchmark_input_against_committed_vectors(test_bmp):
             assert c.big_stream() - before == 1, key
             assert (res[0].status, res[0].dst_len, res[0].src_used) == (A.ST_OK, length, n), key
             assert xxhash.xxh64(bytes(dst[:length])).hexdigest() == digest and (aux[0].aux0, aux[0].aux1) == (a0, a1), key
+
+
+@pytest.mark.parametrize("fmt", NORTH)
+def test_big_encode_fuzz(fmt, test_bmp):
+    """Random inputs under ALZ_FUZZ_SEED (tools/soak.sh repeats this under other seeds): mixtures of bitmap windows, noise of two to 256
+    symbols, runs, periodic pieces, at random lengths, qualities and destination sizes -- the bytes, the lengths and the statuses are the
+    oracle's."""
+    import os
+    import random
+    seed = int(os.environ.get("ALZ_FUZZ_SEED", "1234")) * 37 + fmt
+    rng = random.Random(seed)
+    with Context(0) as c:
+        for k in range(6):
+            size = rng.choice([98304, 98304 + rng.randrange(1, 70000), rng.randrange(100000, 400000), rng.randrange(100000, 1500000)])
+            raw = _mixed(size, seed * 8 + k, test_bmp)
+            if k % 3 == 2:                                         # long repeats: matches beyond kernel B's compare cap
+                piece = raw[:rng.randrange(2100, 9000)]
+                raw = (piece * (size // len(piece) + 1))[:size // 2] + raw[:size - size // 2]
+            q = rng.choice([0, 1, 2, 3, 5, 8, 9, 10, 12, 15]) if size < 500000 else rng.choice([0, 3, 8])
+            want_len = len(O.encode_stream(fmt, raw, quality=q)[0])
+            cap = rng.choice([_cap(len(raw)), want_len, want_len + rng.randrange(1, 100), max(1, want_len - rng.randrange(1, 100))])
+            _encode(c, [(fmt, raw)], q, caps=[cap], expect_big=True, what="fuzz %d (seed %d)" % (k, seed))

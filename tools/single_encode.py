@@ -14,7 +14,7 @@ c = Context(0)
 names = sys.argv[1:] or ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0"]
 for fname in names:
     fmt = A.FORMAT_NAMES.index(fname)
-    for q in (0, 8, 15):
+    for q in [int(x) for x in os.environ.get("ALZ_SINGLE_Q", "0,8,15").split(",")]:
         st = (A.Stream * 1)(A.Stream(0, 0, n, n + n // 4 + 64, 0, 0, 0, fmt))
         src = np.frombuffer(raw + bytes(64), dtype=np.uint8)
         row = []

@@ -1,9 +1,10 @@
 # usage (GPU box): bash tools/soak.sh [first_seed] [count]  -- the malformed-input differential tests under other seeds: the host-buffer
 # parity test (test_gpu_decode.py, fuzz) and the device-resident canary tests (test_gpu_canary.py: whole destination buffer compared,
-# both kernel families, both wave shapes)
+# both kernel families, both wave shapes), the whole-GPU decode of ONE mutated stream (test_gpu_big_stream.py) and the whole-GPU ENCODE of
+# random inputs (test_gpu_big_encode.py)
 cd $GRAFT_REPO_ROOT
 s0=${1:-5000}; n=${2:-20}
 for i in $(seq 0 $((n-1))); do
   seed=$((s0 + 97 * i))
-  ALZ_FUZZ_SEED=$seed timeout 600 python -m pytest tests/test_gpu_decode.py tests/test_gpu_canary.py tests/test_gpu_big_stream.py -q -m gpu -k "fuzz or canary_lzss" 2>&1 | grep -E "^FAILED|AssertionError|passed|failed" | sed "s/^/seed $seed: /" | head -8
+  ALZ_FUZZ_SEED=$seed timeout 600 python -m pytest tests/test_gpu_decode.py tests/test_gpu_canary.py tests/test_gpu_big_stream.py tests/test_gpu_big_encode.py -q -m gpu -k "fuzz or canary_lzss" 2>&1 | grep -E "^FAILED|AssertionError|passed|failed" | sed "s/^/seed $seed: /" | head -8
 done
