@@ -105,10 +105,20 @@ __device__ __forceinline__ u32 benc_rule(const EncGeom& g, int limit, int pi, in
 __device__ __forceinline__ bool benc_lazy_needs(const EncGeom& g, int limit, int pi, int l0) { return l0 >= g.min_len && l0 <= g.lazy && pi + 1 <= limit; }
 
 // "somebody's cursor may land on x": a capped position is searched exactly once somebody asks
-__device__ __forceinline__ void benc_request(const BencArgs& a, u32 x, u32* stt, u32* front, u32* tail) {
+// (`stride`: the format's longest match where that is a few KiB -- LZ11, LZ40: 16 Ki --, else 0.  Inside a long repeat every cursor takes a match
+// of exactly that length and lands on the next capped position: a chain of requests, one generation each -- 3.7 of the 7.4 ms of Test.bmp as
+// LZ11 at quality 12.  So a request also asks for the positions one, two, ... longest matches on while they are capped: wrong guesses cost a
+// search nobody needed, right ones bring the whole chain into the first, parallel generation.)
+__device__ __forceinline__ void benc_request(const BencArgs& a, u32 x, u32* stt, u32* front, u32* tail, u32 stride) {
     if ((int)x > a.limit) return;
     if (__hip_atomic_load(stt + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) return;      // (nearly every target: not a capped position -- a load, not an atomic)
-    if (atomicCAS(stt + x, 1u, 2u) == 1u) front[atomicAdd(tail, 1u)] = x;
+    if (atomicCAS(stt + x, 1u, 2u) != 1u) return;
+    front[atomicAdd(tail, 1u)] = x;
+    if (stride == 0u) return;
+    for (u32 k = 0, y = x + stride; k < 64u && (int)y <= a.limit; k++, y += stride) {
+        if (atomicCAS(stt + y, 1u, 2u) != 1u) break;
+        front[atomicAdd(tail, 1u)] = y;
+    }
 }
 
 // GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 4 KiB per trip -- four loads of sixteen bytes per lane and side in
@@ -175,17 +185,18 @@ __device__ __forceinline__ void benc_wave_search(const BencArgs& a, const EncGeo
 // neighbour, if the lazy rule needs the neighbour's length first); position 0 for itself.
 __global__ __launch_bounds__(256) void benc_request0(BencArgs a, EncGeom g, const u32* __restrict__ ml, u32* __restrict__ stt, u32* __restrict__ front, u32* __restrict__ ctl) {
     if (ctl[BC_CAPN] == 0u) return;
+    const u32 stride = g.max_len <= 65536 ? (u32)g.max_len : 0u;
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if ((int)p > a.limit) return;
     const u32 l0 = ml[p];
-    if (l0 == BENC_UNKNOWN) { if (p == 0u) benc_request(a, 0u, stt, front, ctl + BC_F0N); return; }
+    if (l0 == BENC_UNKNOWN) { if (p == 0u) benc_request(a, 0u, stt, front, ctl + BC_F0N, stride); return; }
     u32 l1 = (int)p + 1 <= a.limit ? ml[p + 1u] : 0u;
     if (l1 == BENC_UNKNOWN) {
-        if (benc_lazy_needs(g, a.limit, (int)p, (int)l0)) { benc_request(a, p + 1u, stt, front, ctl + BC_F0N); return; }   // (its own target follows when the neighbour is known)
+        if (benc_lazy_needs(g, a.limit, (int)p, (int)l0)) { benc_request(a, p + 1u, stt, front, ctl + BC_F0N, stride); return; }   // (its own target follows when the neighbour is known)
         l1 = 0;
     }
     u32 s;
-    benc_request(a, benc_rule(g, a.limit, (int)p, (int)l0, (int)l1, s), stt, front, ctl + BC_F0N);
+    benc_request(a, benc_rule(g, a.limit, (int)p, (int)l0, (int)l1, s), stt, front, ctl + BC_F0N, stride);
 }
 
 // One requested position, by one wavefront: its match, exactly; then where ITS cursor would go -- another request -- and, if the position in
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(256) void benc_request0(BencArgs a, EncGeom g, cons
 template <bool MINT>
 __device__ __forceinline__ void benc_resolve(const BencArgs& a, const EncGeom& g, const int* p4, const int* pm, u32 c, u32* ml, u32* md, u32* stt, u32* front, u32* tail) {
     const bool l0lane = benc_lane() == 0u;
+    const u32 stride = g.max_len <= 65536 ? (u32)g.max_len : 0u;
     auto known = [&](u32 q, int& d, int& l) -> bool {
         const u32 v = __hip_atomic_load(ml + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (v == BENC_UNKNOWN) return false;
@@ -211,7 +223,7 @@ __device__ __forceinline__ void benc_resolve(const BencArgs& a, const EncGeom& g
             int dq, lq;
             if (stt[q - 1u] == 0u && known(q - 1u, dq, lq) && benc_lazy_needs(g, a.limit, (int)q - 1, lq)) {
                 u32 s; const u32 x = benc_rule(g, a.limit, (int)q - 1, lq, l, s);
-                if (l0lane) benc_request(a, x, stt, front, tail);
+                if (l0lane) benc_request(a, x, stt, front, tail, stride);
             }
         }
     };
@@ -219,7 +231,7 @@ __device__ __forceinline__ void benc_resolve(const BencArgs& a, const EncGeom& g
     settle(c, d0, l0);
     if (benc_lazy_needs(g, a.limit, (int)c, l0)) settle(c + 1u, d1, l1);
     u32 s; const u32 x = benc_rule(g, a.limit, (int)c, l0, l1, s);
-    if (l0lane) benc_request(a, x, stt, front, tail);
+    if (l0lane) benc_request(a, x, stt, front, tail, stride);
 }
 
 // C1b: the first generation of requests, all wavefronts of the GPU; what they ask for goes onto a second list

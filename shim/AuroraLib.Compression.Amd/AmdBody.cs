@@ -129,7 +129,25 @@ namespace AuroraLib.Compression.Amd
         /// except for FastLZ, whose level-2 switch it is (FastLZ.cs:163-170).</summary>
         internal static bool UseGpuForCompress(AlzFormat format, int sourceLength, CompressionSettings settings, LzProperties? lz = null)
             => MaxWindowBitsOnGpu(format, settings.MaxWindowBits, lz)
-               && (uint)sourceLength >= AmdContext.SingleStreamCompressThreshold && AmdContext.Available;
+               && ((uint)sourceLength >= AmdContext.SingleStreamCompressThreshold || BigStreamCompress(format, sourceLength, settings, lz))
+               && AmdContext.Available;
+
+        /// <summary>ONE buffer the native encoder runs on the whole GPU (csrc/alz_encode_big.h; alz_encode_big_eligible): a format of that
+        /// path, at least <see cref="AmdContext.BigStreamThreshold"/> bytes, distances within 16-bit links, and a quality at which the path
+        /// beats the managed encoder (<see cref="AmdContext.BigStreamCompressMaxQuality"/>).</summary>
+        internal static bool BigStreamCompress(AlzFormat format, int sourceLength, CompressionSettings settings, LzProperties? lz = null)
+        {
+            switch (format)
+            {
+                case AlzFormat.LZSS: case AlzFormat.LZ10: case AlzFormat.LZ11: case AlzFormat.Yaz0: case AlzFormat.Yay0: case AlzFormat.MIO0:
+                case AlzFormat.PrsBE: case AlzFormat.PrsLE: case AlzFormat.LZ4Block: case AlzFormat.LZO: case AlzFormat.SnappyRaw:
+                case AlzFormat.LZ40: case AlzFormat.CLZ0: case AlzFormat.BLZ: case AlzFormat.LZHudson: break;
+                default: return false;
+            }
+            if (format == AlzFormat.LZSS && lz.HasValue && lz.Value.MaxDistance > 0xFFFF) return false;      // (16-bit links)
+            return (uint)sourceLength >= AmdContext.BigStreamThreshold && sourceLength <= 0x20000000
+                   && settings.Quality <= AmdContext.BigStreamCompressMaxQuality(format);
+        }
 
         /// <summary>The rule of alz_encode_batch (include/auroralz.h, alz_settings.max_window_bits): 0, or within the format's window
         /// (bits AND 1 &lt;&lt; bits &lt;= the largest distance of the format), or FastLZ up to 20 bits (the device finder keeps 21).</summary>

@@ -29,10 +29,21 @@ namespace AuroraLib.Compression.Amd
         public static uint BigStreamThreshold { get; set; } = 96u << 10;
 
         /// <summary>The same switch for <c>Compress</c> / <c>CompressHeaderless</c> of ONE buffer: sources shorter than this run on
-        /// the managed encoder.  The greedy / lazy walk of one stream is a serial job for one wavefront (34 MB: 1.1 s against
-        /// 0.13 s on one CPU core, INTEGRATION.md section 1), so the default is "never"; the GPU encoder is reached through
-        /// <see cref="BatchEncoder.CompressMany"/> and through the framed containers, which split a file into a batch.</summary>
+        /// the managed encoder.  In the batch pipeline the greedy / lazy walk of one stream is a serial job for one wavefront (34 MB:
+        /// 1.1 s against 0.13 s on one CPU core, INTEGRATION.md section 1), so the default is "never" for the formats that have no
+        /// whole-GPU encode path; the GPU encoder is reached through <see cref="BatchEncoder.CompressMany"/> and through the framed
+        /// containers, which split a file into a batch.</summary>
         public static uint SingleStreamCompressThreshold { get; set; } = uint.MaxValue;
+
+        /// <summary>ONE buffer of a format with a whole-GPU encode path (csrc/alz_encode_big.h, round 4: LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0,
+        /// PRS, LZ4 blocks, LZO, raw Snappy, LZ40, CLZ0, BLZ, LZHudson) of at least <see cref="BigStreamThreshold"/> bytes is compressed on the
+        /// GPU up to this <c>CompressionSettings.Quality</c>: the reference's benchmark input (1 000 KiB of Test.bmp) takes 0.36-0.58 ms
+        /// through <c>alz_encode_batch</c> at quality 0 (1.7-2.7 GiB/s against 0.17-0.27 of the managed encoders, Benchmarks.md) and
+        /// 0.6-4.9 ms at quality 15 -- except LZ4 / LZO from quality 10 on, where searching EVERY position of a 64 KiB window with chains of
+        /// 32-1 024 candidates costs more than the managed parse, which searches only the positions its cursor visits (15-16 ms against
+        /// 9.9-11.4 ms at quality 15).  15 = always.</summary>
+        public static int BigStreamCompressMaxQuality(AlzFormat format)
+            => (format == AlzFormat.LZ4Block || format == AlzFormat.LZO) ? 9 : 15;
 
         public static bool Available
         {
