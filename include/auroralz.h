@@ -216,8 +216,14 @@ int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
  * output bytes.  So the single-stream call a format class's Decompress(Stream, Stream) makes (Interfaces/ICompressionDecoder.cs:24; the
  * reference's own benchmark is ONE 1 000 KiB stream, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42) does not fall behind the managed
  * decoder.  Results are identical: a stream that path cannot finish -- any malformed one -- is decoded by the exact kernel behind it.
- * min_bytes: 0 keeps the current threshold, 0xFFFFFFFF switches the path off; launches_out (may be NULL) receives how often the path has
- * been taken on this context.  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take it. */
+ * The ENCODER has the same switch (csrc/alz_encode_big.h): an alz_encode_batch / _device call of at most eight buffers, each of at least
+ * `min_bytes` of one of these formats (and LZ40 / CLZ0 / BLZ / LZHudson; distances within 16 bits), is compressed buffer by buffer on the whole
+ * GPU -- prev() on overlapping segments, the greedy / lazy parse (FindNextBestMatch, MatchFinder/LzChainMatchFinder.cs:157-212) as list ranking
+ * over "where would a cursor at p go", the emission by prefix sums -- instead of by one workgroup and one wavefront per buffer: what
+ * a format class's Compress(ReadOnlySpan<byte>, Stream) makes of ONE buffer (Interfaces/ICompressionEncoder.cs; the reference's benchmark
+ * compresses ONE 1 000 KiB buffer, TestAllAlgorithms.cs:44-69).  The bytes are the same either way.
+ * min_bytes: 0 keeps the current threshold, 0xFFFFFFFF switches both paths off; launches_out (may be NULL) receives how many streams have
+ * taken either path on this context.  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take them. */
 int         alz_ctx_big_stream(alz_ctx* ctx, uint32_t min_bytes, uint64_t* launches_out);
 /* The host-buffer entry points keep their device staging buffers and the encoder's scratch (per input byte: a 16- or 32-bit link,
  * a 32-bit match entry -- not at quality 0 for the flag-byte formats, whose search runs inside the emit kernel --, two bytes of
