@@ -41,7 +41,7 @@ namespace AuroraLib.Compression.Amd
         /// through <c>alz_encode_batch</c> at quality 0 (1.7-2.7 GiB/s against 0.17-0.27 of the managed encoders, Benchmarks.md) and
         /// 0.6-4.9 ms at quality 15 -- except LZ4 / LZO from quality 10 on, where searching EVERY position of a 64 KiB window with chains of
         /// 32-1 024 candidates costs more than the managed parse, which searches only the positions its cursor visits (15-16 ms against
-        /// 9.9-11.4 ms at quality 15).  15 = always.</summary>
+        /// 9.7-11.1 ms at quality 15).  15 = always.</summary>
         public static int BigStreamCompressMaxQuality(AlzFormat format)
             => (format == AlzFormat.LZ4Block || format == AlzFormat.LZO) ? 9 : 15;
 
