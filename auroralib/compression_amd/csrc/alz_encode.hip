@@ -136,7 +136,11 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     // `stage` takes on average
     static_assert(U * ALZ_CU_FILL4 <= 6, "a chunk of several passes must stay below 32 Ki positions");
     if (threadIdx.x < 3u) spill[threadIdx.x] = 0;
-    for (u32 pass_all = 0; pass_all < npass4 + npassm; pass_all++) {
+    // (gridDim.y > 1: a workgroup per (stream, pass) -- the passes are independent; what the whole-GPU path of ONE stream launches, whose
+    // "streams" are a few dozen overlapping segments: alz_encode_big.h)
+    const u32 pfirst = gridDim.y > 1u ? blockIdx.y : 0u, plast = gridDim.y > 1u ? pfirst + 1u : npass4 + npassm;
+    if (pfirst >= npass4 + npassm) return;
+    for (u32 pass_all = pfirst; pass_all < plast; pass_all++) {
         const bool mt = pass_all >= npass4;       // a pass of the min-length table
         const u32 pass = mt ? pass_all - npass4 : pass_all;
         const u32 npass = WIN ? 1u : (mt ? 2u : npass4);       // passes of this pass's table
@@ -2459,11 +2463,14 @@ static bool uses_win_prev(const EncGeom& g) {
 // kernel A: the head table in LDS (hashBits = 15 + floor(sqrt(2 Q)) = 15..20, LzChainMatchFinder.cs:108-119) -- one pass with the
 // tag / link rings where matches reach back at most 8 KiB, otherwise 2^(hashBits - 15) passes (+ 2 for the min-length table)
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
-                              int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail) {
+                              int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes = false) {
     if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
     if (uses_win_prev(g)) hipLaunchKernelGGL((enc_prev_cu_kernel<2, true>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
-    else hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    else {
+        const u32 passes = (1u << (g.hash_bits - 15)) + (g.use_min_table ? 2u : 0u);       // (as the kernel counts them)
+        hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count, split_passes ? passes : 1u), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    }
     return hipSuccess;
 }
 
