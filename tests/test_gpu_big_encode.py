@@ -143,12 +143,17 @@ def test_settings_reach_the_path(test_bmp):
 
 
 def test_a_handful_of_streams_and_mixed_calls(test_bmp):
-    """Up to eight eligible streams take the path one after the other; a ninth, a small one or a format outside the path sends the whole
-    call through the batch pipeline -- with the same bytes."""
+    """A handful of eligible streams take the path one after the other while that beats side by side (at most 32); a small one or a format
+    outside the path sends the whole call through the batch pipeline -- with the same bytes."""
     with Context(0) as c:
         eight = [(NORTH[i % len(NORTH)], test_bmp[i * 50000:i * 50000 + 100000 + 1000 * i]) for i in range(8)]
         _encode(c, eight, 8, expect_big=True, what="eight")
-        _encode(c, eight + [(A.FMT_YAZ0, test_bmp[:100000])], 8, expect_big=False, what="nine")
+        _encode(c, eight + [(A.FMT_YAZ0, test_bmp[:100000])], 8, expect_big=True, what="nine")
+        # thirty of 100 KB each: side by side is the faster arrangement (the cost rule of encode_core); four of 1 MB among them change that
+        thirty = [(NORTH[i % len(NORTH)], test_bmp[i * 1000:i * 1000 + 100000]) for i in range(30)]
+        _encode(c, thirty, 4, expect_big=False, what="thirty small")
+        _encode(c, thirty[:10] + [(A.FMT_LZ10, test_bmp[:1000000 + i]) for i in range(4)], 4, expect_big=True, what="ten small, four of 1 MB")
+        _encode(c, [(A.FMT_LZ10, test_bmp[i:300000 + i]) for i in range(33)], 0, expect_big=False, what="thirty-three")
         _encode(c, eight[:3] + [(A.FMT_YAZ0, test_bmp[:5000])], 8, expect_big=False, what="one small")
         _encode(c, eight[:3] + [(A.FMT_REFPACK, test_bmp[:200000])], 8, expect_big=False, what="one RefPack (three property sets: not on the path)")
 
