@@ -17,7 +17,7 @@
 //   C   the greedy / lazy parse (FindNextBestMatch :157-212) is a walk "cursor += jump[cursor]", and jump[p] -- what the parse does IF its
 //       cursor is at p: no match, a match here, or a literal and the better match at p + 1 -- is a pure function of match[p] and match[p + 1].
 //       A linked list through the positions: the cursors are the nodes reachable from 0, found by list ranking (mark + square the jump
-//       table, ceil(log2 nodes) + 1 rounds, as alz_big.hip does for the decoders' group starts).
+//       table, as alz_big.hip does for the decoders' group starts) -- on two levels: inside tiles of 1 024 nodes in LDS, and over the tiles' exits.
 //   D   with the cursors known every position knows whether a token starts on it and which; prefix sums over the positions give every
 //       token its number (-> flag group and bit), its payload offset and -- Yay0 / MIO0 -- its place in the literal section; the payload
 //       bytes go straight to the destination, the flag bits through a byte per token, one thread per flag group gathers them.
@@ -263,18 +263,48 @@ __global__ __launch_bounds__(1024) void benc_exact_rest(BencArgs a, EncGeom g, c
     }
 }
 
-// C2: what FindNextBestMatch does if its cursor is at p (enc_roles_kernel's rule, one position per thread)
-__global__ __launch_bounds__(256) void benc_next(BencArgs a, EncGeom g, const u32* __restrict__ ml, u32* __restrict__ next, u8* __restrict__ sr) {
-    const u32 p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.nodes) return;
-    const int limit = a.limit, pi = (int)p;
-    if (pi > limit) { next[p] = p; return; }                     // the end node
-    // (a capped position nobody asked for cannot be reached from position 0: what it says does not matter, as long as it says something)
-    u32 l0 = ml[p], l1 = pi + 1 <= limit ? ml[p + 1u] : 0u;
-    if (l0 == BENC_UNKNOWN) l0 = 0;
-    if (l1 == BENC_UNKNOWN) l1 = 0;
-    u32 s; const u32 x = benc_rule(g, limit, pi, (int)l0, (int)l1, s);
-    sr[p] = (u8)s; next[p] = x;
+// C2: what FindNextBestMatch does if its cursor is at p (enc_roles_kernel's rule, one position per thread) -- and the first level of the
+// list ranking.  As 21 rounds over all nodes the ranking was 105 of the ~220 us a 1 000 KiB stream takes at quality 0 (a round is a launch:
+// ~5 us whatever it does).  A tile of 1 024 nodes fits LDS: ten rounds of pointer jumping there give every node its EXIT -- the first node of
+// its chain behind the tile; the chain of exits from node 0 has at most one node per tile, so the rounds over all nodes are
+// ceil(log2 tiles) + 1 = 11; they mark where the parse ENTERS each tile, and benc_tile_mark marks the cursors inside from there.
+// FROM_MATCH (formats kernel B cannot cap): straight from the match array, benc_unpack's job done here.
+#define BENC_RTILE 1024u
+template <bool FROM_MATCH>
+__global__ __launch_bounds__(1024) void benc_tile_exit(BencArgs a, EncGeom g, const mentry* __restrict__ match, u32* __restrict__ ml, u32* __restrict__ md,
+                                                       u32* __restrict__ next1, u32* __restrict__ exitj, u8* __restrict__ sr) {
+    __shared__ u32 J[BENC_RTILE];
+    const u32 ts = blockIdx.x * BENC_RTILE, te = ts + BENC_RTILE, tid = threadIdx.x, p = ts + tid;
+    const int limit = a.limit;
+    u32 x = 0xFFFFFFFFu;                                           // (a thread behind the last node: never inside a tile)
+    if (p < a.nodes) {
+        if ((int)p > limit) x = p;                                 // the end node points at itself
+        else {
+            u32 l0, l1 = 0;
+            if (FROM_MATCH) {
+                const uint2 u = m_unpack(__builtin_nontemporal_load(match + p));
+                l0 = u.y; ml[p] = u.y; md[p] = u.x;
+                if ((int)p + 1 <= limit) l1 = m_unpack(match[p + 1u]).y;
+            } else {
+                // (a capped position nobody asked for cannot be reached from position 0: what it says does not matter, as long as it says something)
+                l0 = ml[p]; if (l0 == BENC_UNKNOWN) l0 = 0;
+                if ((int)p + 1 <= limit) { l1 = ml[p + 1u]; if (l1 == BENC_UNKNOWN) l1 = 0; }
+            }
+            u32 s; x = benc_rule(g, limit, (int)p, (int)l0, (int)l1, s);
+            sr[p] = (u8)s;
+        }
+        next1[p] = x;
+    }
+    J[tid] = x;
+    __syncthreads();
+    for (u32 r = 0; r < 10u; r++) {
+        const u32 j = J[tid];
+        const u32 j2 = j < te ? J[j - ts] : j;                     // (j >= ts: a jump goes forward, the end node to itself)
+        __syncthreads();
+        J[tid] = j2;
+        __syncthreads();
+    }
+    if (p < a.nodes) exitj[p] = J[tid];
 }
 
 // one round of list ranking: every marked node marks where its jump lands, every jump is squared (double-buffered: a round must see
@@ -287,14 +317,33 @@ __global__ __launch_bounds__(256) void benc_rank_round(const u32* __restrict__ j
     jump_b[p] = jump_a[j];
 }
 
-// the last cursor: where the literals behind the parse start (the end of its match, at least limit + 1)
-// (its jump lands on the end node exactly when what it takes ends at or behind limit + 1 -- the one-hop jumps themselves are gone, squared)
-__global__ __launch_bounds__(256) void benc_tail(BencArgs a, const u8* __restrict__ sr, const u32* __restrict__ ml, const u8* __restrict__ mark, u32* __restrict__ ctl) {
-    const u32 p = blockIdx.x * 256u + threadIdx.x;
-    if ((int)p > a.limit || !mark[p]) return;
-    const u32 s = sr[p];
-    const u32 e = s == 1u ? p + ml[p] : s == 2u ? p + 1u + ml[p + 1u] : p + 1u;
-    if (e >= (u32)a.limit + 1u) ctl[BC_TAIL] = e;
+// the last level: the parse enters the tile at the node the rounds marked (at most one; node 0 in the first tile); eleven rounds of the same
+// ranking on the one-hop jumps in LDS mark the cursors inside.  The last cursor of all says where the literals behind the parse start (the
+// end of its match, at least limit + 1).
+__global__ __launch_bounds__(1024) void benc_tile_mark(BencArgs a, const u32* __restrict__ next1, const u8* __restrict__ sr, const u32* __restrict__ ml,
+                                                       u8* __restrict__ mark, u32* __restrict__ ctl) {
+    __shared__ u32 JA[BENC_RTILE], JB[BENC_RTILE], M[BENC_RTILE];
+    const u32 ts = blockIdx.x * BENC_RTILE, te = ts + BENC_RTILE, tid = threadIdx.x, p = ts + tid;
+    JA[tid] = p < a.nodes ? next1[p] : 0xFFFFFFFFu;
+    M[tid] = p < a.nodes ? mark[p] : 0u;
+    __syncthreads();
+    u32* ja = JA; u32* jb = JB;
+    for (u32 r = 0; r < 11u; r++) {
+        const u32 j = ja[tid];
+        const bool inside = j < te;
+        if (inside && M[tid]) M[j - ts] = 1u;
+        jb[tid] = inside ? ja[j - ts] : j;
+        __syncthreads();
+        u32* t = ja; ja = jb; jb = t;
+    }
+    if (p >= a.nodes) return;
+    const u32 m = M[tid];
+    mark[p] = (u8)m;
+    if (m && (int)p <= a.limit) {
+        const u32 s = sr[p];
+        const u32 e = s == 1u ? p + ml[p] : s == 2u ? p + 1u + ml[p + 1u] : p + 1u;
+        if (e >= (u32)a.limit + 1u) ctl[BC_TAIL] = e;
+    }
 }
 
 template <int FMT> struct FlagFmt {
@@ -443,7 +492,7 @@ static u32 benc_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r
 struct BencLayout {
     BencArgs a;
     u32 tiles;
-    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, front1, mark, sr, tile_in, tile_out, tokbit, bitv, gofs, ctl, total;
+    size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, next1, front1, mark, sr, tile_in, tile_out, tokbit, bitv, gofs, ctl, total;
     BencLayout(const alz_stream& st, const EncGeom& g, int tail) {
         a.data = nullptr; a.N = st.src_len; a.n = (int)st.src_len - tail; a.limit = a.n - 4;
         a.nodes = (u32)a.limit + 2u;
@@ -462,6 +511,7 @@ struct BencLayout {
         match = o; o += benc_al(np * 4);
         ml = o; o += benc_al(np * 4); md = o; o += benc_al(np * 4);
         jump_a = o; o += benc_al(np * 4); jump_b = o; o += benc_al(np * 4);
+        next1 = o; o += benc_al(np * 4);
         front1 = o; if (g.max_len > ALZ_LEN_CAP) o += benc_al(np * 4);
         mark = o; o += benc_al(np); sr = o; o += benc_al(np);
         tile_in = o; o += benc_al((size_t)3 * (tiles + 64) * 4); tile_out = o; o += benc_al((size_t)3 * (tiles + 64) * 4);
@@ -942,8 +992,8 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     const bool caps = g.max_len > ALZ_LEN_CAP;                    // (only then can kernel B have capped anything)
     u32* stt = caps ? jump_a : nullptr;                           // (the jump tables are free until the ranking; the token-bit area until the emission)
     u32* front0 = jump_b; u32* front1 = (u32*)(base + L.front1);
-    hipLaunchKernelGGL(benc_unpack, dim3(nbp), dim3(256), 0, stream, a, match, ml, md, stt, ctl);
     if (caps) {
+        hipLaunchKernelGGL(benc_unpack, dim3(nbp), dim3(256), 0, stream, a, match, ml, md, stt, ctl);
         hipLaunchKernelGGL(benc_request0, dim3(nbp), dim3(256), 0, stream, a, g, ml, stt, front0, ctl);
         if (g.use_min_table) {
             hipLaunchKernelGGL((benc_exact_g1<true>), dim3(4096), dim3(64), 0, stream, a, g, fin4, finm, ml, md, stt, front0, front1, ctl);
@@ -953,10 +1003,13 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
             hipLaunchKernelGGL((benc_exact_rest<false>), dim3(1), dim3(1024), 0, stream, a, g, fin4, finm, ml, md, stt, front1, ctl);
         }
     }
-    hipLaunchKernelGGL(benc_next, dim3(nbn), dim3(256), 0, stream, a, g, ml, jump_a, sr);
-    const u32 rr = benc_rounds(a.nodes);
+    const u32 rtiles = (a.nodes + BENC_RTILE - 1u) / BENC_RTILE;
+    u32* next1 = (u32*)(base + L.next1);
+    if (caps) hipLaunchKernelGGL((benc_tile_exit<false>), dim3(rtiles), dim3(1024), 0, stream, a, g, match, ml, md, next1, jump_a, sr);
+    else hipLaunchKernelGGL((benc_tile_exit<true>), dim3(rtiles), dim3(1024), 0, stream, a, g, match, ml, md, next1, jump_a, sr);
+    const u32 rr = benc_rounds(rtiles + 1u);
     for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(benc_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, a.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
-    hipLaunchKernelGGL(benc_tail, dim3(nbn), dim3(256), 0, stream, a, sr, ml, mark, ctl);
+    hipLaunchKernelGGL(benc_tile_mark, dim3(rtiles), dim3(1024), 0, stream, a, next1, sr, ml, mark, ctl);
     // D: the tokens
     u8* dst = (u8*)d_dst_base + st->dst_off;
     switch (fmt) {
