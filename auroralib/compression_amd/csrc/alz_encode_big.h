@@ -49,8 +49,11 @@ __device__ __forceinline__ u32 benc_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt
 __device__ __forceinline__ u32 benc_last(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
 
 // the virtual streams of A' (entries 0..K-1) and the real one (entry K) with their index list and array offsets
-__global__ __launch_bounds__(256) void benc_setup(alz_stream real, BencArgs a, alz_stream* __restrict__ vs, u32* __restrict__ vindex, u64* __restrict__ vpos) {
+__global__ __launch_bounds__(256) void benc_setup(alz_stream real, BencArgs a, alz_stream* __restrict__ vs, u32* __restrict__ vindex, u64* __restrict__ vpos,
+                                                  u32* __restrict__ ctl, alz_result* __restrict__ result, alz_encode_aux* __restrict__ aux) {
     const u32 j = blockIdx.x * 256u + threadIdx.x;
+    if (j < (u32)BC_WORDS) ctl[j] = j == (u32)BC_TAIL ? (u32)(a.limit + 1) : 0u;      // (the control words: zero, the literals behind the parse start at limit + 1 unless a match says otherwise)
+    if (j == 0u) { alz_result r; r.dst_len = 0xFFFFFFFFu; r.src_used = 0xFFFFFFFFu; r.status = -1; r.reserved = 0xFFFFFFFFu; *result = r; aux->aux0 = 0; aux->aux1 = 0; }
     if (j > a.K) return;
     alz_stream s = real;
     u64 po = 0;
@@ -66,9 +69,12 @@ __global__ __launch_bounds__(256) void benc_setup(alz_stream real, BencArgs a, a
 
 // the links of the segments -> the arrays of the stream
 template <bool L16>
-__global__ __launch_bounds__(256) void benc_gather(BencArgs a, const int* __restrict__ seg4, const int* __restrict__ segm, int* __restrict__ fin4, int* __restrict__ finm) {
+__global__ __launch_bounds__(256) void benc_gather(BencArgs a, const int* __restrict__ seg4, const int* __restrict__ segm, int* __restrict__ fin4, int* __restrict__ finm,
+                                                   u8* __restrict__ mark) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if ((int)p > a.limit) return;
+    mark[p] = p == 0u ? 1 : 0;                                     // the ranking's marks: the cursor starts at position 0
+    if ((int)p == a.limit) mark[p + 1u] = 0;                       // (the end node)
     const u32 j = p / a.S, first = j * a.S, start = first >= a.W ? first - a.W : 0u, local = p - start;
     const size_t off = (size_t)j * a.stride;
     if (L16) reinterpret_cast<unsigned short*>(fin4)[p] = reinterpret_cast<const unsigned short*>(seg4 + off)[local];
@@ -492,6 +498,7 @@ static u32 benc_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r
 struct BencLayout {
     BencArgs a;
     u32 tiles;
+    u32* ctl_dev = nullptr;      // the stream's control words (the caller's: they travel to the host with the result)
     size_t vs, vindex, vpos, seg4, segm, fin4, finm, match, ml, md, jump_a, jump_b, next1, front1, mark, sr, tile_in, tile_out, tokbit, bitv, gofs, ctl, total;
     BencLayout(const alz_stream& st, const EncGeom& g, int tail) {
         a.data = nullptr; a.N = st.src_len; a.n = (int)st.src_len - tail; a.limit = a.n - 4;
@@ -530,7 +537,7 @@ static bool benc_format(int fmt) {
 template <int FMT>
 static void benc_emit(hipStream_t stream, const BencLayout& L, const BencArgs& a, const EncGeom& g, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
     const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
-    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    u32* ctl = L.ctl_dev; u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
     const u32 pitch = L.tiles + 64u;
     hipLaunchKernelGGL((benc_count<FMT>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, tin, tin + pitch, tin + 2 * pitch);
     hipLaunchKernelGGL(benc_scan3, dim3(3), dim3(1024), 0, stream, tin, tout, L.tiles, pitch, ctl);
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(256) void benc_seq_end(BencArgs a, const u32* __res
 template <int FMT>
 static void benc_emit_seq(hipStream_t stream, const BencLayout& L, const BencArgs& a, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
     const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
-    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    u32* ctl = L.ctl_dev; u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
     const u32 pitch = L.tiles + 64u;
     hipLaunchKernelGGL((benc_seq<FMT, 0>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, (const u32*)nullptr, (const u32*)nullptr, tin, dst, cap);
     hipLaunchKernelGGL(benc_scanmax, dim3(1), dim3(1024), 0, stream, tin, tout, L.tiles, ctl + BC_COVER);
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(256) void benc_prs_flags(BencArgs a, const u32* __r
 template <bool BIG>
 static hipError_t benc_emit_prs(hipStream_t stream, const BencLayout& L, const BencArgs& a, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
     const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
-    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    u32* ctl = L.ctl_dev; u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
     u8* bitv = base + L.bitv; u32* gofs = (u32*)(base + L.gofs);
     const u32 pitch = L.tiles + 64u, tiles1 = a.N / BENC_TILE + 1u;            // (the tile of the position behind the data: the end token)
     hipError_t e = hipMemsetAsync(gofs, 0xFF, ((size_t)a.N / 4 + 64) * 4, stream);   // (flag bytes: at most (2 N + 2) / 8 + 1)
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(256) void benc_lzo_end(BencArgs a, const u32* __res
 
 static void benc_emit_lzo(hipStream_t stream, const BencLayout& L, const BencArgs& a, u8* base, u8* dst, u32 cap, alz_result* d_result, alz_encode_aux* d_aux) {
     const u8* mark = base + L.mark; const u8* sr = base + L.sr; const u32* ml = (const u32*)(base + L.ml); const u32* md = (const u32*)(base + L.md);
-    u32* ctl = (u32*)(base + L.ctl); u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
+    u32* ctl = L.ctl_dev; u32* tin = (u32*)(base + L.tile_in); u32* tout = (u32*)(base + L.tile_out);
     const u32 pitch = L.tiles + 64u;
     hipLaunchKernelGGL(benc_lzo_head, dim3(1), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, dst, cap);
     hipLaunchKernelGGL((benc_lzo<0>), dim3(L.tiles), dim3(64), 0, stream, a, mark, sr, ml, md, ctl, (const u32*)nullptr, (const u32*)nullptr, tin, dst, cap);
@@ -957,14 +964,15 @@ size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream*
     return BencLayout(*st, g, fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0).total + 256;
 }
 
-// Enqueues the whole-GPU encode of ONE stream.  d_result / d_aux: the stream's slots; d_scratch: alz_encode_big_scratch_bytes();
-// *d_declined (a device word, the first of the scratch's control block is copied there) becomes 1 when the path gave the stream up
-// (nothing written to d_result then): the caller runs the batch pipeline.
+// Enqueues the whole-GPU encode of ONE stream.  d_result / d_aux: the stream's slots; d_ctl: 16 control words of the stream (the caller
+// copies them to the host with the result: word 0 != 0 says the path gave the stream up -- nothing does at present -- and the caller runs
+// the batch pipeline); d_scratch: alz_encode_big_scratch_bytes().  Everything the path needs initialised it initialises itself.
 hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
-                                 alz_encode_aux* d_aux, void* d_scratch, uint32_t* d_declined, const void* geom) {
+                                 alz_encode_aux* d_aux, void* d_scratch, uint32_t* d_ctl, const void* geom) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     BencLayout L(*st, g, tail);
+    L.ctl_dev = d_ctl;
     u8* base = (u8*)d_scratch;
     BencArgs a = L.a; a.data = (const u8*)d_src_base + st->src_off;
     alz_stream* vs = (alz_stream*)(base + L.vs); u32* vindex = (u32*)(base + L.vindex); u64* vpos = (u64*)(base + L.vpos);
@@ -972,19 +980,15 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     int* fin4 = (int*)(base + L.fin4); int* finm = g.use_min_table ? (int*)(base + L.finm) : nullptr;
     mentry* match = (mentry*)(base + L.match);
     u32* ml = (u32*)(base + L.ml); u32* md = (u32*)(base + L.md); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b);
-    u8* mark = base + L.mark; u8* sr = base + L.sr; u32* ctl = (u32*)(base + L.ctl);
-    hipError_t e = hipMemsetAsync(ctl, 0, BC_WORDS * 4, stream);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + BC_TAIL), a.limit + 1, 1, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)a.N + 64, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);                       // the cursor starts at position 0
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(benc_setup, dim3((a.K + 256u) / 256u), dim3(256), 0, stream, *st, a, vs, vindex, vpos);
+    u8* mark = base + L.mark; u8* sr = base + L.sr; u32* ctl = d_ctl;
+    hipError_t e;
+    hipLaunchKernelGGL(benc_setup, dim3((a.K + 256u) / 256u), dim3(256), 0, stream, *st, a, vs, vindex, vpos, ctl, d_result, d_aux);
     // A': kernel A on the segments, then the links to where kernel B reads them
     e = launch_prev(stream, (const u8*)d_src_base, vs, vindex, a.K, seg4, segm, vpos, g, 0, true);        // (a workgroup per segment AND pass: 1.24 -> 0.3 ms for an LZ4 block at quality 8)
     if (e != hipSuccess) return e;
     const u32 nbp = ((u32)a.limit + 256u) / 256u;
-    if (g.link16) hipLaunchKernelGGL((benc_gather<true>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm);
-    else hipLaunchKernelGGL((benc_gather<false>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm);
+    if (g.link16) hipLaunchKernelGGL((benc_gather<true>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm, mark);
+    else hipLaunchKernelGGL((benc_gather<false>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm, mark);
     // B: on the real stream (entry K)
     launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u, false);
     // C: the parse
@@ -1030,7 +1034,5 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     case ALZ_FMT_PRS_LE: e = benc_emit_prs<false>(stream, L, a, base, dst, st->dst_cap, d_result, d_aux); if (e != hipSuccess) return e; break;
     default: return hipErrorInvalidValue;
     }
-    e = hipMemcpyAsync(d_declined, ctl + BC_BAD, 4, hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return e;
     return hipGetLastError();
 }

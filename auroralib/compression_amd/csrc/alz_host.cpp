@@ -29,7 +29,7 @@ struct phase_timer {
     void mark(const char* phase) {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
-        fprintf(stderr, "[alz timing] %s: %s %.1f ms\n", what, phase, std::chrono::duration<double, std::milli>(n - t).count());
+        fprintf(stderr, "[alz timing] %s: %s %.3f ms\n", what, phase, std::chrono::duration<double, std::milli>(n - t).count());
         t = n;
     }
 };
@@ -810,25 +810,25 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         if (all) {
             HIP_TRY(hipSetDevice(c->device));
             EncScratch sc(c);
-            alz_result* d_results = nullptr; alz_encode_aux* d_aux = nullptr; void *d_tail = nullptr, *d_big = nullptr, *skip = nullptr;
+            void *d_tail = nullptr, *d_big = nullptr, *skip = nullptr;
             size_t tail_bytes = 0;
             if (!src_has_slack)
                 for (uint32_t i = 0; i < n; i++)
                     if (streams[i].src_off + streams[i].src_len + 64 > src_bytes) tail_bytes += ((size_t)streams[i].src_len + 64 + 63) & ~(size_t)63;
-            hipError_t e = sc.alloc(&skip, 0, false);                                   // (the batch pipeline's slots, in its order: the buffers are shared)
-            if (e == hipSuccess) e = sc.alloc((void**)&d_results, (size_t)n * sizeof(alz_result));
-            if (e == hipSuccess) e = sc.alloc((void**)&d_aux, (size_t)n * sizeof(alz_encode_aux));
-            for (int k = 3; k < 10 && e == hipSuccess; k++) e = sc.alloc(&skip, 0, false);
+            // what travels back: per stream its result, its section offsets and the path's 16 control words -- one block, one copy
+            const size_t out_one = sizeof(alz_result) + sizeof(alz_encode_aux) + 16 * sizeof(uint32_t), sb_al = (sb + 255) & ~(size_t)255;
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < 10 && e == hipSuccess; k++) e = sc.alloc(&skip, 0, false);   // (the batch pipeline's slots, in its order: the buffers are shared)
             if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, tail_bytes != 0);
-            if (e == hipSuccess) e = sc.alloc(&d_big, sb + 64 + (size_t)n * 4);
+            if (e == hipSuccess) e = sc.alloc(&d_big, sb_al + (size_t)n * out_one + 64);
             if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
-            uint32_t* d_declined = (uint32_t*)((uint8_t*)d_big + ((sb + 63) & ~(size_t)63));
+            uint8_t* d_out = (uint8_t*)d_big + sb_al;
+            alz_result* d_results = (alz_result*)d_out;
+            alz_encode_aux* d_aux = (alz_encode_aux*)(d_out + (size_t)n * sizeof(alz_result));
+            uint32_t* d_ctl = (uint32_t*)(d_out + (size_t)n * (sizeof(alz_result) + sizeof(alz_encode_aux)));
             int rc;
             if ((rc = upload(d_src_base, d_dst_base))) return rc;
             tm.mark("upload");
-            HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
-            HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
-            HIP_TRY(hipMemsetAsync(d_declined, 0, (size_t)n * 4, c->stream));
             HIP_TRY(hipEventRecord(c->ev0, c->stream));
             size_t toff = 0;
             for (uint32_t i = 0; i < n; i++) {
@@ -839,23 +839,23 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
                     st1.src_off = (uint64_t)(uintptr_t)to - (uint64_t)(uintptr_t)d_src_base;
                     toff += ((size_t)st1.src_len + 64 + 63) & ~(size_t)63;
                 }
-                e = alz_launch_encode_big((int)st1.format, c->stream, d_src_base, d_dst_base, &st1, d_results + i, d_aux + i, d_big, d_declined + i,
+                e = alz_launch_encode_big((int)st1.format, c->stream, d_src_base, d_dst_base, &st1, d_results + i, d_aux + i, d_big, d_ctl + 16 * (size_t)i,
                                           geom.data() + st1.format * alz_encode_geom_size());
                 if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream encode launch (format %u) failed: %s", st1.format, hipGetErrorString(e));
             }
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            std::vector<uint32_t> declined(n);
-            std::vector<alz_encode_aux> haux(n);
-            HIP_TRY(hipMemcpyAsync(results, d_results, (size_t)n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(haux.data(), d_aux, (size_t)n * sizeof(alz_encode_aux), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipMemcpyAsync(declined.data(), d_declined, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            std::vector<uint8_t> hout((size_t)n * out_one);
+            HIP_TRY(hipMemcpyAsync(hout.data(), d_out, hout.size(), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_kernel_ms = ms; }
             tm.mark("kernels (big streams)");
+            const alz_encode_aux* haux = (const alz_encode_aux*)(hout.data() + (size_t)n * sizeof(alz_result));
+            const uint32_t* hctl = (const uint32_t*)(hout.data() + (size_t)n * (sizeof(alz_result) + sizeof(alz_encode_aux)));
             bool any = false;
-            for (uint32_t i = 0; i < n; i++) any = any || declined[i] != 0u;
+            for (uint32_t i = 0; i < n; i++) any = any || hctl[16 * (size_t)i] != 0u;
             if (!any) {
                 c->big_enc_launches += n;
+                memcpy(results, hout.data(), (size_t)n * sizeof(alz_result));
                 for (uint32_t i = 0; i < n; i++) if (aux) aux[i] = haux[i];
                 return ALZ_OK;
             }

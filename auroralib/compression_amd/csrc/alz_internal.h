@@ -35,4 +35,4 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
 bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, uint32_t min_bytes);
 size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream* st);
 hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
-                                 alz_encode_aux* d_aux, void* d_scratch, uint32_t* d_declined, const void* geom);
+                                 alz_encode_aux* d_aux, void* d_scratch, uint32_t* d_ctl /* 16 words */, const void* geom);
