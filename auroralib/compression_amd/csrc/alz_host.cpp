@@ -140,6 +140,7 @@ struct alz_plan {
     uint32_t fmt_off[ALZ_FMT_COUNT] = {0};
     uint32_t fmt_cnt[ALZ_FMT_COUNT] = {0};
     bool borrowed = false;                  // the three device arrays live in the context's plan scratch (host-buffer entry points)
+    std::vector<uint32_t> index_host;       // such a plan keeps its index list: its upload is not waited for (plan_create)
     // ONE big Yay0 / MIO0 stream: decoded by the whole GPU (alz_big.hip), the production kernel behind it only if that path declines
     // (or a few of them, one after the other: n streams through that path take n x ~0.1-0.3 ms, on wavefronts of their own they take as
     // long as the largest of them alone, 1-5 ms per MiB; plan_create weighs the two)
@@ -334,7 +335,11 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
     if (e == hipSuccess && n) e = hipMemcpyAsync(p->d_streams, streams, n * sizeof(alz_stream), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(p->d_index, index.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_results, 0xFF, nn * sizeof(alz_result), c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    // (a plan of the library's own -- one host-buffer call: created, executed, read, destroyed -- does not wait here: the caller's stream
+    // table outlives the call, the index list moves into the plan, and the kernels queue up behind the uploads; the one stream of a
+    // format class's Decompress call pays ~30 us for every synchronisation)
+    if (scratch) p->index_host = std::move(index);
+    else if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
     bool all_big = n >= 1 && n <= ALZ_BIG_MAX_STREAMS && !c->exact && c->variant == 0;
     for (uint32_t i = 0; all_big && i < n; i++) all_big = alz_big_eligible((int)streams[i].format, &streams[i], &lz, c->big_min);
@@ -360,7 +365,8 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
         if (p->d_big) {
             p->big = true; p->big_streams.assign(streams, streams + n); p->d_gate = (uint32_t*)((uint8_t*)p->d_big + need - 64);
             p->big_pos.resize(n);
-            for (uint32_t k = 0; k < n; k++) p->big_pos[index[k]] = k;      // where stream i sits in the (per-format, cost-ordered) index list
+            const std::vector<uint32_t>& ix = scratch ? p->index_host : index;
+            for (uint32_t k = 0; k < n; k++) p->big_pos[ix[k]] = k;      // where stream i sits in the (per-format, cost-ordered) index list
         }
     }
     *out = p;
@@ -464,8 +470,8 @@ int alz_plan_execute_timed(alz_ctx* c, alz_plan* p, const void* d_src_base, void
 int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
     if (!c || !p || (p->n && !results)) return fail(ALZ_E_INVALID, "alz_plan_results: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (p->n) HIP_TRY(hipMemcpyAsync(results, p->d_results, p->n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (p->n) HIP_TRY(hipMemcpy(results, p->d_results, p->n * sizeof(alz_result), hipMemcpyDeviceToHost));
     return ALZ_OK;
 }
 
