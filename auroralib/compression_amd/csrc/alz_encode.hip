@@ -578,7 +578,7 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
 // serial emit kernels, one lane per wavefront, ran 12 % slower with this body inlined).  MatchSearch :214-246 with ChainMatches
 // :248-282; returns false when CAP > 0 and a
 // candidate still matched after CAP bytes
-template <bool MINT, bool L16>
+template <bool MINT, bool L16, bool PRUNE = false>
 __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
                                              int& best_d, int& best_l) {
     const u8* dp = data + pos;
@@ -615,7 +615,19 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
             // the second eight bytes the same way (most formats' matches end inside them); the compare loop only behind sixteen
             const u64 y = head2 ^ load64(data + (more ? c : 0) + 8);
             if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
-            const bool more2 = more && y == 0ull && cmp_max > 16;
+            bool more2 = more && y == 0ull && cmp_max > 16;
+            if (PRUNE && g.nprops <= 1) {
+                // (ONE stream of real data -- alz_encode_big.h: a candidate wins only with a longer match than the best so far, so one whose
+                // bytes around offset best_l differ is not measured -- it counts as sixteen bytes, which cannot win.  In the repeated rows and
+                // runs of Test.bmp every candidate of a chain matches up to the same place, and the compare loop below runs for the whole
+                // wavefront as long as its longest lane: a 1 000 KiB Yaz0 stream at quality 8 0.58 -> 0.29 ms, an LZ4 block at quality 15 15 -> 5.8.)
+                const bool chk = more2 && best_l >= 16;
+                if (__ballot(chk)) {
+                    const int o = chk ? best_l - 7 : 0;
+                    const u64 pa = load64(dp + o), pb = load64(data + (chk ? c : pos) + o);
+                    if (chk && pa != pb) more2 = false;
+                }
+            }
             if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
         }
         if (len > cmp_max) len = cmp_max;
@@ -868,7 +880,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
 // instructions of its trips, and the LDS form has more of them (address arithmetic, three reads and two alignbytes per eight bytes) at
 // half the wavefronts per CU (68 KB of LDS per workgroup); at quality 15 a workgroup waits for the one wavefront whose block holds a
 // 1024-step chain.  docs/EXPERIMENTS.md 8.)
-template <bool MINT, bool L16>
+template <bool MINT, bool L16, bool PRUNE = false>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                         const int* __restrict__ prevm, mentry* __restrict__ match,
@@ -889,7 +901,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     const int last = first + span - 1 < limit ? first + span - 1 : limit;
     for (int pos = first + (int)threadIdx.x; pos <= last; pos += 256) {
         int bd, bl;
-        const bool okm = match_search_b<MINT, L16>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
+        const bool okm = match_search_b<MINT, L16, PRUNE>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
         __builtin_nontemporal_store(okm ? m_pack((u32)bd, (u32)bl) : 0xFFFFFFFFu, m + pos);   // (written once, read by the next kernel: past the caches)
     }
 }
@@ -2501,7 +2513,10 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
         return;
     }
 #define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
-    if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
+    if (!dense_ok && g.link16) {                                  // (the whole-GPU path of ONE stream: see PRUNE in match_search_b)
+        if (g.use_min_table) ALZ_LB((enc_match_kernel<true, true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, true, true>), dim3(bx, count), dim3(256));
+    }
+    else if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
     else { if (g.link16) ALZ_LB((enc_match_kernel<false, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
 #undef ALZ_LB
 }

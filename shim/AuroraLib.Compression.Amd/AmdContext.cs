@@ -37,13 +37,10 @@ namespace AuroraLib.Compression.Amd
 
         /// <summary>ONE buffer of a format with a whole-GPU encode path (csrc/alz_encode_big.h, round 4: LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0,
         /// PRS, LZ4 blocks, LZO, raw Snappy, LZ40, CLZ0, BLZ, LZHudson) of at least <see cref="BigStreamThreshold"/> bytes is compressed on the
-        /// GPU up to this <c>CompressionSettings.Quality</c>: the reference's benchmark input (1 000 KiB of Test.bmp) takes 0.36-0.58 ms
-        /// through <c>alz_encode_batch</c> at quality 0 (1.7-2.7 GiB/s against 0.17-0.27 of the managed encoders, Benchmarks.md) and
-        /// 0.6-4.9 ms at quality 15 -- except LZ4 / LZO from quality 10 on, where searching EVERY position of a 64 KiB window with chains of
-        /// 32-1 024 candidates costs more than the managed parse, which searches only the positions its cursor visits (15-16 ms against
-        /// 9.7-11.1 ms at quality 15).  15 = always.</summary>
-        public static int BigStreamCompressMaxQuality(AlzFormat format)
-            => (format == AlzFormat.LZ4Block || format == AlzFormat.LZO) ? 9 : 15;
+        /// GPU up to this <c>CompressionSettings.Quality</c>: the reference's benchmark input (1 000 KiB of Test.bmp) takes 0.27-0.52 ms
+        /// through <c>alz_encode_batch</c> at quality 0 (1.9-3.6 GiB/s against 0.17-0.27 of the managed encoders, Benchmarks.md) and
+        /// 0.6-6 ms at quality 15 (0.16-1.7 GiB/s against 0.06-0.13), so the default is "always" (15) for every format of the path.</summary>
+        public static int BigStreamCompressMaxQuality(AlzFormat format) => 15;
 
         public static bool Available
         {
