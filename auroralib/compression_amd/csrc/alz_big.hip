@@ -306,7 +306,6 @@ __global__ __launch_bounds__(64) void big_mark_scatter(const u8* __restrict__ ma
 template <int FMT>
 __global__ __launch_bounds__(256) void big_group_tokens(const u8* __restrict__ src, u32 src_len, BigGeom gm, const u32* __restrict__ gpos, u32* __restrict__ ctl,
                                                         u32* __restrict__ tlen, u32* __restrict__ tdesc, u32* __restrict__ tend) {
-    typedef BigFam<FMT> TR;
     const u32 ng = ctl[C_NG];
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     if (g == 0) ctl[C_NT] = 8u * ng;

@@ -575,7 +575,7 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     lane_walk_pos(nx, 33u, spos, sp, nseq);
     if (nseq == 0u) return false;
     // 3. one lane per sequence: fields, then (literal run?, match) into the queue order (the sequences whose tokens fit its 64 slots)
-    bool st = (u32)lane < nseq; u64 stm = lanes_below(nseq);
+    bool st = (u32)lane < nseq;
     const u32 pos = i0 + spos;
     const u32 b = in.lds[pos], e1 = in.lds[pos + 1];
     const u32 L0 = b >> 4, M0 = b & 15u;
@@ -591,7 +591,7 @@ __device__ __forceinline__ bool lz4_parse_round(InCache& in, u32 p, u32* stage, 
     const u32 rank = (u32)lane + mbcnt64(litm);
     {
         const u32 keep = (u32)__popcll(lanes_below(nseq) & wave_ballot(rank + (L ? 2u : 1u) <= 64u));
-        if (keep < nseq) { nseq = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; stm = lanes_below(keep); litm = lanes_below(keep) & hasl; }
+        if (keep < nseq) { nseq = keep; sp = wave_readlane(spos, keep); st = (u32)lane < keep; litm = lanes_below(keep) & hasl; }
     }
     if (st) {
         u32 r = rank;
@@ -837,7 +837,7 @@ __device__ __forceinline__ bool lzshrek_parse_round(InCache& in, u32 p, u32* sta
     u32 spos, sp, nel;
     shrek_walk_pos(pk, spos, sp, nel, state);
     if (nel == 0u) return false;
-    const bool st = (u32)lane < nel; u64 stm = lanes_below(nel);
+    const bool st = (u32)lane < nel;
     const u32 pos = i0 + (spos & 0x3FFu);
     const bool header = (spos >> 10) == 0u;
     const u32 b = in.lds[pos & 2047u], e1 = in.lds[(pos + 1u) & 2047u], e2 = in.lds[(pos + 2u) & 2047u], e3 = in.lds[(pos + 3u) & 2047u];
@@ -1007,7 +1007,7 @@ __device__ __forceinline__ bool refpack_parse_round(InCache& in, u32 p, u32* sta
     u32 spos, sp, nel;
     lane_walk_pos(nx, 33u, spos, sp, nel);                               // an element has >= 2 bytes: <= 32 per window
     if (nel == 0u) return false;
-    const bool st = (u32)lane < nel; u64 stm = lanes_below(nel);
+    const u64 stm = lanes_below(nel);
     const u32 pos = i0 + spos;
     const u32 b = in.lds[pos], d0 = in.lds[pos + 1], d1 = in.lds[(pos + 2u) & 2047u], d2 = in.lds[(pos + 3u) & 2047u];
     u32 plain, length = 0, distance = 1, hdr;

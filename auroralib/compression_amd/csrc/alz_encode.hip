@@ -687,12 +687,14 @@ template <bool MINT, bool DYN, int ALZ_DENSE_POS, bool L16>
 __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                              const int* __restrict__ prevm, mentry* __restrict__ match,
-                                                             const u64* __restrict__ pos_off, EncGeom g, int tail_skip, u32 xlog) {
+                                                             const u64* __restrict__ pos_off, EncGeom g, int tail_skip, u32 xlog,
+                                                             const u32* __restrict__ sel = nullptr) {
     __shared__ u32 lpos[ALZ_DENSE_LIST];          // position inside the block | step << 8
     __shared__ int lcand[ALZ_DENSE_LIST];
     __shared__ unsigned long long best[ALZ_DENSE_POS];
     __shared__ u32 capf[ALZ_DENSE_POS];
     const u32 sid = index_list[blockIdx.y];
+    const u32 selv = sel ? sel[sid] : 0u;         // (read together with the descriptor: as a test of its own in front of it, ten million workgroups paid one more round trip each)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
@@ -700,6 +702,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
     mentry* m = match + pos_off[sid];
+    if (selv & 1u) return;                        // (enc_probe_kernel gave this stream to the one-position-per-lane kernel)
     const int lane = (int)threadIdx.x;
     const int chain = g.max_chain;
   // (the grid holds at most 4 096 workgroups per stream: a stream longer than 4 096 blocks -- and a batch whose longest stream is far
@@ -884,8 +887,12 @@ template <bool MINT, bool L16, bool PRUNE = false>
 __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                         const u32* __restrict__ index_list, const int* __restrict__ prev4,
                                                         const int* __restrict__ prevm, mentry* __restrict__ match,
-                                                        const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    const u32 sid = index_list[blockIdx.y];
+                                                        const u64* __restrict__ pos_off, EncGeom g, int tail_skip, const u32* __restrict__ list = nullptr) {
+  // (`list`: the streams enc_probe_kernel gave to this kernel -- their number, then their ids; the grid's y is then smaller than the batch
+  // and goes round: a batch of which the probe gives this kernel nothing costs a few thousand empty workgroups, not count x 32)
+  const u32 ny = list ? list[0] : gridDim.y;
+  for (u32 y = blockIdx.y; y < ny; y += gridDim.y) {
+    const u32 sid = list ? list[1u + y] : index_list[y];
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
@@ -904,6 +911,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
         const bool okm = match_search_b<MINT, L16, PRUNE>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
         __builtin_nontemporal_store(okm ? m_pack((u32)bd, (u32)bl) : 0xFFFFFFFFu, m + pos);   // (written once, read by the next kernel: past the caches)
     }
+  }
 }
 
 // (Tried in round 3 for maxChain 1 (quality 0), where this kernel issues only 0.57 instructions per cycle and CU: four positions per thread
@@ -2472,6 +2480,46 @@ static bool uses_win_prev(const EncGeom& g) {
     return g.max_dist <= 8192 && (g.hash_bits > 15 || g.use_min_table);
 }
 
+// Which kernel B for a stream, from maxChain 3 on?  The two-phase kernel (chains first, the pairs 64 at a time) keeps its lanes busy where
+// candidates are many and short -- the synthetic batches: 94 against 138 ms per 10 000 x 256 KiB at quality 8 --, the one-position-per-lane
+// kernel ends a walk at the first candidate of full length and does not measure one that cannot win -- real data, runs and repeated rows:
+// 1 024 windows of Test.bmp as Yaz0 at quality 8 38 against 109 ms, as LZ4 blocks 59 against 293.  The probe looks at up to 1 024 positions
+// of the stream: how often do the sixteen bytes at the position equal the sixteen at its first candidate?  (The 256 KiB windows of Test.bmp: 74 % on
+// average -- the photographic ones 0.3 % --, the synthetic streams 0.8-4.3 %; the line is drawn at 25 %.  The probe, the second launch and the
+// test in the two-phase kernel cost a synthetic batch 0.7 ms of 94.)
+#ifndef ALZ_PROBE_THRESH16
+#define ALZ_PROBE_THRESH16 4u      /* sixteenths of the sampled positions */
+#endif
+template <bool L16>
+__global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                       const int* __restrict__ prev4, const u64* __restrict__ pos_off, EncGeom g, int tail_skip,
+                                                       u32* __restrict__ sel, u32* __restrict__ list, u32 thresh16) {
+    const u32 sid = index_list[blockIdx.x];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip, limit = n - 4;
+    const int* p4 = prev4 + pos_off[sid];
+    const int lane = (int)threadIdx.x;
+    if (limit < 64) { if (lane == 0) sel[sid] = 0u; return; }     // (a stream of a few bytes: whichever)
+    const int step = (limit + 1) / 1024 > 0 ? (limit + 1) / 1024 : 1;
+    u32 hit = 0, tot = 0;
+    for (int k = 0; k < 16; k++) {
+        const int pos = (k * 64 + lane) * step;
+        const bool in = pos <= limit;
+        int d = 0;
+        if (in) { if (L16) d = (int)reinterpret_cast<const unsigned short*>(p4)[pos]; else { const int c = p4[pos]; d = c < 0 ? 0 : pos - c; } }
+        const bool cand = in && d >= g.min_dist && d <= g.max_dist && d > 0;
+        bool eq = false;
+        if (cand) { u64 a[2], b[2]; __builtin_memcpy(a, data + pos, 16); __builtin_memcpy(b, data + pos - d, 16); eq = a[0] == b[0] && a[1] == b[1]; }
+        hit += (u32)__popcll(__ballot(eq)); tot += (u32)__popcll(__ballot(in));
+    }
+    if (lane == 0) {
+        const u32 mine = hit * 16u >= tot * thresh16 ? 1u : 0u;
+        sel[sid] = mine | ((tot ? hit * 1000u / tot : 0u) << 8);
+        if (mine) list[1u + atomicAdd(list, 1u)] = sid;
+    }
+}
+
 // kernel A: the head table in LDS (hashBits = 15 + floor(sqrt(2 Q)) = 15..20, LzChainMatchFinder.cs:108-119) -- one pass with the
 // tag / link rings where matches reach back at most 8 KiB, otherwise 2^(hashBits - 15) passes (+ 2 for the min-length table)
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
@@ -2489,7 +2537,7 @@ static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_strea
 // kernel B over `count` streams; `wg_cap`: workgroups per stream of the one-position-per-lane form (32 in a batch; a lone stream takes
 // as many as it has blocks of 256 positions)
 static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count, uint32_t max_len,
-                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g, int tail, u32 wg_cap, bool dense_ok = true) {
+                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g, int tail, u32 wg_cap, bool dense_ok = true, u32* d_sel = nullptr, u32 sel_pitch = 0) {
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     if (bx > wg_cap) bx = wg_cap;
     // (workgroups per stream, each with one contiguous range: 32 -- 8 Ki positions of a 256 KiB stream, 4 KiB of history in front of them fetched
@@ -2500,7 +2548,19 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
         u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? 2u : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)
         while (xlog && (8u << xlog) > bd) xlog--;
         if (xlog) bd = (bd + (8u << xlog) - 1u) / (8u << xlog) * (8u << xlog);
-#define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, xlog)
+        // (per stream: the two-phase kernel or the one-position-per-lane one -- enc_probe_kernel; both are launched, each leaves the other's streams alone)
+        const u32* sel = nullptr;
+        if (d_sel && g.link16 && g.nprops <= 1) {
+            const u32 thr = ALZ_PROBE_THRESH16;
+            u32* list = d_sel + sel_pitch;                          // [0]: how many streams, then their ids
+            (void)hipMemsetAsync(list, 0, 4, stream);
+            hipLaunchKernelGGL((enc_probe_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_pos_off, g, tail, d_sel, list, thr);
+            sel = d_sel;
+            const u32 gy = count < 512u ? count : 512u;
+            if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true, true, true>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
+            else hipLaunchKernelGGL((enc_match_kernel<false, true, true>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
+        }
+#define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, xlog, sel)
         const dim3 gd(bd, count);
         if (dyn) {
             if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_dense_kernel<true, true, 256, true>), gd, dim3(64)); else ALZ_LB((enc_match_dense_kernel<true, true, 256, false>), gd, dim3(64)); }
@@ -2523,14 +2583,15 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
 
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
-                             const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom) {
+                             const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
+                             uint32_t* d_sel, uint32_t sel_pitch) {
     if (count == 0) return hipSuccess;
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     if (ea != hipSuccess) return ea;
-    if (!searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u);
+    if (!searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u, true, d_sel, sel_pitch);
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
     case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;

@@ -122,7 +122,7 @@ struct alz_ctx {
     void* d_plan = nullptr; size_t d_plan_cap = 0;   // plan arrays of the host-buffer entry points (no hipMalloc / hipFree per call)
     // encoder scratch (head tables, prev links, matches, masks ...: ~48 GB for 10 000 x 256 KiB at quality 8), one grow-only slot
     // per purpose: allocating and freeing it per call cost 1-2 s, four times the kernels.  alz_ctx_release_scratch() returns it.
-    void* enc_buf[12] = {nullptr}; size_t enc_cap[12] = {0};
+    void* enc_buf[13] = {nullptr}; size_t enc_cap[13] = {0};
     copy_pool* pool = nullptr;                 // created with the pinned buffers
     std::vector<copy_job> jobs;                // (scratch of the staging loops)
     void copy(uint8_t* dst, const uint8_t* src, size_t len) { jobs.clear(); add_copy(jobs, dst, src, len); pool->run(jobs); }
@@ -726,7 +726,7 @@ struct EncScratch {
     }
 };
 static void release_scratch(alz_ctx* c) {
-    for (int k = 0; k < 12; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
+    for (int k = 0; k < 13; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
     void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan, &c->d_bigbuf};
     size_t* caps[] = {&c->d_src_cap, &c->d_dst_cap, &c->d_items_cap, &c->d_pack_cap, &c->d_plan_cap, &c->d_bigbuf_cap};
     for (int i = 0; i < 6; i++) { if (*bufs[i]) (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
@@ -801,7 +801,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     // ---- a handful of big streams: each of them on the whole GPU (alz_encode_big.h).  A stream the path declines (too many positions that
     // need an exact second search) sends the whole call through the batch pipeline below.
     // As in the decoder (plan_create): one after the other on the whole GPU while that beats side by side with a workgroup + a wavefront
-    // each -- measured at quality 0-8 on Test.bmp: ~0.15 ms + 0.12 ms per MiB on the whole GPU, ~22 ms per MiB of the LONGEST buffer side by side.
+    // each -- measured at quality 0-8 on Test.bmp (tools/mid_batch_encode.py): ~0.10 ms + 0.10 ms per MiB on the whole GPU, ~22 ms per MiB of the LONGEST buffer side by side.
     if (!no_big && n <= ALZ_BIG_MAX_STREAMS && c->big_min != 0xFFFFFFFFu && !c->exact && c->variant == 0) {
         bool all = true; size_t sb = 0;
         double t_big = 0, t_side = 0;
@@ -810,7 +810,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
             all = streams[i].format != ALZ_FMT_FASTLZ && alz_encode_big_eligible((int)streams[i].format, g, &streams[i], c->big_min);
             if (all) { const size_t b = alz_encode_big_scratch_bytes((int)streams[i].format, g, &streams[i]); if (b > sb) sb = b; }
             const double mib = streams[i].src_len / 1048576.0;
-            t_big += 0.15 + 0.12 * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;
+            t_big += 0.10 + 0.10 * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;
         }
         all = all && t_big < t_side;
         if (all) {
@@ -891,8 +891,10 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64, any_match);   // one 32-bit entry per position (alz_encode.hip: mentry); not when every launch searches inside its parse + emit kernel
     if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
-    void* d_tail = nullptr;
+    void* d_tail = nullptr; uint32_t* d_sel = nullptr;
     if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, !tail_ix.empty());
+    { void* skip_big = nullptr; if (e == hipSuccess) e = sc.alloc(&skip_big, 0, false); }        // (slot 11: the whole-GPU path's scratch)
+    if (e == hipSuccess) e = sc.alloc((void**)&d_sel, ((size_t)2 * n + 64) * sizeof(uint32_t), any_match);     // which kernel B per stream (enc_probe_kernel)
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
     tm.mark("validate + allocate");
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
@@ -930,7 +932,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
             e = alz_launch_encode(fmt, c->stream, d_src_base, d_dst_base, d_streams, d_index + first + done, k, max_len, d_prev4, d_prevm,
-                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g);
+                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g, d_sel, n);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));
         }
     }

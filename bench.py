@@ -640,6 +640,10 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             # per north-star format, as 256 KiB windows
             for f in ("yaz0", "lz10", "lz11", "prs_be", "lz4_block"):
                 out.append(realistic(ctx, np, A, synth, Plan, steps, f))
+            # ... and the other direction on that data: the encoder picks kernel B per stream (enc_probe_kernel: real data goes to the
+            # one-position-per-lane kernel, the synthetic batches of cfg5 to the two-phase one)
+            for f in ("yaz0", "lz4_block"):
+                out.append(realistic_compress(ctx, np, A, synth, f, 8))
         if "single" in want:
             out.extend(single_stream(ctx, np, A, synth, Plan))
     except Exception as e:                                   # report what ran; the headline line must still come out
@@ -910,6 +914,47 @@ def realistic(ctx, np, A, synth, Plan, steps, fmt_name="yaz0"):
                 "roofline": roofline(comp + n * size, kernel_ms, measured_traffic("realistic_" + fmt_name, n, size // 1024))}
     finally:
         db.close()
+
+
+def realistic_compress(ctx, np, A, synth, fmt_name, quality):
+    """1 024 windows of 256 KiB of Test.bmp (device-resident) through alz_encode_batch_device at the default quality: the batch encoder on
+    real data.  Checked by decoding eight of the streams back (the bytes themselves are pinned by tests/test_gpu_encode.py)."""
+    fmt = A.FORMAT_NAMES.index(fmt_name)
+    from auroralib.compression_amd import formats as F
+    lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
+    bmp = np.frombuffer(lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read()), dtype=np.uint8)
+    n, size = 1024, 262144
+    starts = [(i * (len(bmp) - size)) // (n - 1) for i in range(n)]
+    raw = np.concatenate([bmp[s:s + size] for s in starts])
+    cap = size + size // 4 + 64
+    st = (A.Stream * n)()
+    r = synth.stream_records(st)
+    r["src_off"], r["src_len"] = np.arange(n, dtype=np.uint64) * np.uint64(size), size
+    r["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64((cap + 255) // 256 * 256)
+    r["dst_cap"], r["format"] = cap, fmt
+    dst_bytes = int(r["dst_off"][-1]) + cap + 64
+    d_src, d_dst = ctx.malloc(raw.nbytes + 64), ctx.malloc(dst_bytes)
+    try:
+        ctx.h2d(d_src, raw)
+        ctx.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=quality)
+        ms = []
+        for _ in range(3):
+            res, aux = ctx.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=quality)
+            ms.append(ctx.last_kernel_ms())
+        rr = synth.result_records(res)
+        ok = bool((rr["status"] == 0).all())
+        for i in range(0, n, n // 8):
+            comp = bytes(ctx.d2h(d_dst, int(rr["dst_len"][i]), offset=int(r["dst_off"][i])))
+            sized = fmt_name not in ("lz4_block", "prs_be", "lzo", "snappy_raw")
+            got, dr = ctx.decode(fmt, comp, decom_len=size if sized else 0, cap=size, aux0=aux[i].aux0, aux1=aux[i].aux1)
+            ok = ok and dr.status == 0 and got == bytes(raw[i * size:(i + 1) * size])
+    finally:
+        ctx.free(d_src); ctx.free(d_dst)
+    best = min(ms)
+    return {"name": "realistic_compress_%s_q%d" % (fmt_name, quality),
+            "workload": "%s compression of %d windows of 256 KiB of Test.bmp at quality %d, device-resident (ratio %.3f)"
+                        % (fmt_name, n, quality, float(rr["dst_len"].astype(np.int64).sum()) / (n * size)),
+            "value": round(n * size / (best * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(best, 3), "parity_ok": ok}
 
 
 if __name__ == "__main__":

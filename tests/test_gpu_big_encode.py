@@ -151,7 +151,7 @@ def test_a_handful_of_streams_and_mixed_calls(test_bmp):
         _encode(c, eight + [(A.FMT_YAZ0, test_bmp[:100000])], 8, expect_big=True, what="nine")
         # thirty of 100 KB each: side by side is the faster arrangement (the cost rule of encode_core); four of 1 MB among them change that
         thirty = [(NORTH[i % len(NORTH)], test_bmp[i * 1000:i * 1000 + 100000]) for i in range(30)]
-        _encode(c, thirty, 4, expect_big=False, what="thirty small")
+        _encode(c, thirty, 4, expect_big=False, what="thirty small")                      # (30 x ~0.11 ms against ~2.1 ms side by side)
         _encode(c, thirty[:10] + [(A.FMT_LZ10, test_bmp[:1000000 + i]) for i in range(4)], 4, expect_big=True, what="ten small, four of 1 MB")
         _encode(c, [(A.FMT_LZ10, test_bmp[i:300000 + i]) for i in range(33)], 0, expect_big=False, what="thirty-three")
         _encode(c, eight[:3] + [(A.FMT_YAZ0, test_bmp[:5000])], 8, expect_big=False, what="one small")

@@ -1,0 +1,40 @@
+"""Encoder throughput against the number of streams in a batch (256 KiB windows of Test.bmp, device-resident): where the batch pipeline --
+one workgroup (kernel A) and one wavefront (parse + emission) per stream -- leaves the GPU idle."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+from auroralib.compression_amd import _abi as A
+from auroralib.compression_amd import synth
+from auroralib.compression_amd.batch import Context
+
+bmp = np.frombuffer(O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0], dtype=np.uint8)
+size = int(os.environ.get("ALZ_MID_SIZE", str(262144)))
+c = Context(0)
+for fname in sys.argv[1:] or ["lzss", "yaz0"]:
+    fmt = A.FORMAT_NAMES.index(fname)
+    for q in [int(x) for x in os.environ.get("ALZ_MID_Q", "0,8").split(",")]:
+        for n in [int(x) for x in os.environ.get("ALZ_MID_N", "1,8,32,33,64,128,256,512,1024,2048,4096").split(",")]:
+            starts = [(i * 4096) % (len(bmp) - size) for i in range(n)]
+            raw = np.concatenate([bmp[s:s + size] for s in starts])
+            cap = size + size // 4 + 64
+            st = (A.Stream * n)()
+            r = synth.stream_records(st)
+            r["src_off"], r["src_len"] = np.arange(n, dtype=np.uint64) * np.uint64(size), size
+            r["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64((cap + 255) // 256 * 256)
+            r["dst_cap"], r["format"] = cap, fmt
+            dst_bytes = int(r["dst_off"][-1]) + cap + 64
+            d_src, d_dst = c.malloc(raw.nbytes + 64), c.malloc(dst_bytes)
+            try:
+                c.h2d(d_src, raw)
+                before = c.big_stream()
+                c.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=q)
+                ms = []
+                for _ in range(3):
+                    res, aux = c.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=q); ms.append(c.last_kernel_ms())
+                big = c.big_stream() - before
+            finally:
+                c.free(d_src); c.free(d_dst)
+            ok = all(x.status == 0 for x in res)
+            print("%-6s q%d %5d x %d KiB: %8.3f ms kernels = %7.2f GiB/s  (whole-GPU path: %s, ok %s)" % (fname, q, n, size >> 10, min(ms), n * size / min(ms) / 2**30 * 1e3, big > 0, ok), flush=True)
