@@ -462,7 +462,17 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     }
 }
 
+#ifndef ALZ_LEN_CAP
 #define ALZ_LEN_CAP 2040
+#endif
+// The search inside the parse + emit kernel (quality 0) compares the 32 bytes it has prefetched and no more: a position whose candidate still
+// matches there is "capped", and searched exactly (by the whole wavefront, benc_wave_search) only if the cursor ever stands on it.  With the
+// cap at 2 040 every position inside a long match measured that match to its end -- in the runs and repeated rows of real data nearly all of
+// them, for the few the parse visits: 4 096 windows of Test.bmp as Yaz0 at quality 0 51 -> 19.6 ms, as LZ11 77 -> 24.9; the synthetic batches
+// (matches of at most 18 bytes) 42.5 ms either way.
+#ifndef ALZ_PARSE_CAP
+#define ALZ_PARSE_CAP 32
+#endif
 #define ALZ_CAPPED 0xFFFFFFFFu
 
 // The match array kernel B hands to the parse and the emitters: ONE 32-bit entry per position (round 3; two words before) -- distance in
@@ -572,6 +582,76 @@ __device__ __forceinline__ bool match_search(const u8* data, int n, int pos, con
         }
     }
     return true;
+}
+
+// ---- the exact search by a whole wavefront (wave-uniform control flow): what the parse kernels run when their cursor meets a position
+// kernel B (or the search inside the parse) had capped, and what the whole-GPU path of ONE stream runs for requested positions (alz_encode_big.h)
+__device__ __forceinline__ u32 benc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 benc_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
+__device__ __forceinline__ u32 benc_last(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
+
+// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 4 KiB per trip -- four loads of sixteen bytes per lane and side in
+// flight (a trip may read up to 63 bytes behind `max`: inside the slack behind every source buffer, never counted)
+__device__ __forceinline__ int benc_wave_match_len(const u8* a, const u8* b, int max) {
+    const int lane = (int)benc_lane();
+    for (int base = 0; base < max; base += 4096) {
+        u64 x[4][2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int off = base + 1024 * k + 16 * lane;
+            u64 va[2] = {0, 0}, vb[2] = {0, 0};
+            if (off < max) { __builtin_memcpy(va, a + off, 16); __builtin_memcpy(vb, b + off, 16); }
+            x[k][0] = va[0] ^ vb[0]; x[k][1] = va[1] ^ vb[1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u64 mm = __ballot((x[k][0] | x[k][1]) != 0ull);
+            if (mm) {
+                const int l0 = (int)__builtin_ctzll(mm);
+                const u64 lo = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x[k][0] >> 32), l0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x[k][0], l0);
+                const u64 hi = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x[k][1] >> 32), l0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x[k][1], l0);
+                const int len = base + 1024 * k + 16 * l0 + (lo ? (int)(__builtin_ctzll(lo) >> 3) : 8 + (int)(__builtin_ctzll(hi) >> 3));
+                return len < max ? len : max;
+            }
+        }
+    }
+    return max;
+}
+
+// MatchSearch (:214-246, ChainMatches :248-282) exactly, by the whole wavefront (wave-uniform control flow)
+template <bool MINT>
+__device__ __forceinline__ void benc_wave_search(const u8* data, int n, const EncGeom& g, const int* p4, const int* pm, int pos, int& best_d, int& best_l) {
+    const u8* dp = data + pos;
+    auto lk = [&](int q) { return g.link16 ? link_at<true>(p4, q) : link_at<false>(p4, q); };
+    int cur = lk(pos);
+    int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+    best_d = 0; best_l = 0; int best_score = -1;
+    int attempts = g.max_chain;
+    while (cur != -1 && attempts-- > 0) {
+        const int dist = pos - cur;
+        if (dist > g.max_dist) break;
+        if (dist < g.min_dist) { cur = lk(cur); continue; }
+        // (a candidate wins only with a strictly higher score, i.e. a longer match -- ScoreMatch :301-321 with one property set is the length,
+        // cut to the distance in CompatibilityMode --: one whose byte at offset best_l differs cannot be longer than best_l, and is not measured.
+        // In the repeated rows of Test.bmp every candidate of a chain matches up to the same place, tens of KiB on: 1.4 -> 0.3 ms for an LZ4 block at Q8)
+        if (g.nprops <= 1 && best_l > 0 && dp[best_l] != data[cur + best_l]) { cur = lk(cur); continue; }
+        int len = benc_wave_match_len(dp, data + cur, best_possible);
+        const int score = score_match(g, len, dist);
+        if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
+        cur = lk(cur);
+    }
+    if (MINT && best_l == 0) {                                          // small-match fallback :226-243
+        const int c2 = pm[pos];
+        if (c2 != -1) {
+            int dist = pos - c2;
+            if (dist < g.min_dist) dist = g.min_dist;
+            if (dist <= g.max_dist && pos - dist >= 0) {
+                int len = benc_wave_match_len(dp, data + pos - dist, best_possible);
+                (void)score_match(g, len, dist);
+                best_l = len; best_d = dist;
+            }
+        }
+    }
 }
 
 // The same function as kernel B runs it (the exact recomputations inside the roles / emit kernels keep the plain form above: the
@@ -1555,8 +1635,9 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 // kernel B capped a candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour
                 const int q = P + rel;
                 int d0, l0, d1 = 0, l1 = 0;
-                if (g.use_min_table) match_search<true>(data, n, q, p4, pm, g, 0, d0, l0); else match_search<false>(data, n, q, p4, pm, g, 0, d0, l0);
-                if (q + 1 <= limit) { if (g.use_min_table) match_search<true>(data, n, q + 1, p4, pm, g, 0, d1, l1); else match_search<false>(data, n, q + 1, p4, pm, g, 0, d1, l1); }
+                // (by the whole wavefront, 4 KiB per trip: as a plain loop on every lane a match of a few hundred bytes took ~10 us per cursor)
+                if (g.use_min_table) benc_wave_search<true>(data, n, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, n, g, p4, pm, q, d0, l0);
+                if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, n, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, n, g, p4, pm, q + 1, d1, l1); }
                 if (q + 1 >= P + 64) Pn = -1;                           // (the window loaded ahead no longer matches memory)
                 j = 1; sr = 0;
                 if (l0 >= g.min_len) {
@@ -1691,7 +1772,7 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
         if ((int)q > limit) return make_uint2(0, 0);
         const bool ok = lkv - (u32)g.min_dist <= srange;                // a candidate (0: none), within maxDistance, not closer than minDistance (the walk would go on -- and at maxChain 1 it is over)  :259-266
         int best_possible = (int)n - (int)q; if (best_possible > g.max_len) best_possible = g.max_len;
-        const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
+        const int cmp_max = best_possible > ALZ_PARSE_CAP ? ALZ_PARSE_CAP : best_possible;
         const u64 x0 = own[0] ^ cnd[0], x1 = own[1] ^ cnd[1], x2 = own[2] ^ cnd[2], x3 = own[3] ^ cnd[3];
         int len = x0 ? (int)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (int)(__builtin_ctzll(x1) >> 3) : x2 ? 16 + (int)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (int)(__builtin_ctzll(x3) >> 3) : 32;
         bool go = ok && len == 32 && cmp_max > 32;
@@ -1803,8 +1884,8 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
                     // into the registers the emitter takes its matches from (the neighbour may be the next window's first position)
                     const int q = (int)P + rel;
                     int d0, l0, d1 = 0, l1 = 0;
-                    if (g.use_min_table) match_search<true>(data, (int)n, q, p4, pm, g, 0, d0, l0); else match_search<false>(data, (int)n, q, p4, pm, g, 0, d0, l0);
-                    if (q + 1 <= limit) { if (g.use_min_table) match_search<true>(data, (int)n, q + 1, p4, pm, g, 0, d1, l1); else match_search<false>(data, (int)n, q + 1, p4, pm, g, 0, d1, l1); }
+                    if (g.use_min_table) benc_wave_search<true>(data, (int)n, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, (int)n, g, p4, pm, q, d0, l0);
+                    if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, (int)n, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, (int)n, g, p4, pm, q + 1, d1, l1); }
                     if (lane == rel) a = make_uint2((u32)d0, (u32)l0);
                     if (q + 1 <= limit) {
                         if (rel + 1 < 64) { if (lane == rel + 1) a = make_uint2((u32)d1, (u32)l1); }

@@ -44,10 +44,6 @@ struct BencArgs {
     u32 S, W, K, stride;     // segment length, warm-up, segments, ints per segment in the segment arrays
 };
 
-__device__ __forceinline__ u32 benc_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ u32 benc_mbcnt(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
-__device__ __forceinline__ u32 benc_last(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
-
 // the virtual streams of A' (entries 0..K-1) and the real one (entry K) with their index list and array offsets
 __global__ __launch_bounds__(256) void benc_setup(alz_stream real, BencArgs a, alz_stream* __restrict__ vs, u32* __restrict__ vindex, u64* __restrict__ vpos,
                                                   u32* __restrict__ ctl, alz_result* __restrict__ result, alz_encode_aux* __restrict__ aux) {
@@ -127,70 +123,6 @@ __device__ __forceinline__ void benc_request(const BencArgs& a, u32 x, u32* stt,
     }
 }
 
-// GetMatchLength (LzChainMatchFinder.cs:338-357) by the whole wavefront: 4 KiB per trip -- four loads of sixteen bytes per lane and side in
-// flight (a trip may read up to 63 bytes behind `max`: inside the slack behind every source buffer, never counted)
-__device__ __forceinline__ int benc_wave_match_len(const u8* a, const u8* b, int max) {
-    const int lane = (int)benc_lane();
-    for (int base = 0; base < max; base += 4096) {
-        u64 x[4][2];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int off = base + 1024 * k + 16 * lane;
-            u64 va[2] = {0, 0}, vb[2] = {0, 0};
-            if (off < max) { __builtin_memcpy(va, a + off, 16); __builtin_memcpy(vb, b + off, 16); }
-            x[k][0] = va[0] ^ vb[0]; x[k][1] = va[1] ^ vb[1];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u64 mm = __ballot((x[k][0] | x[k][1]) != 0ull);
-            if (mm) {
-                const int l0 = (int)__builtin_ctzll(mm);
-                const u64 lo = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x[k][0] >> 32), l0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x[k][0], l0);
-                const u64 hi = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(x[k][1] >> 32), l0) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)x[k][1], l0);
-                const int len = base + 1024 * k + 16 * l0 + (lo ? (int)(__builtin_ctzll(lo) >> 3) : 8 + (int)(__builtin_ctzll(hi) >> 3));
-                return len < max ? len : max;
-            }
-        }
-    }
-    return max;
-}
-
-// MatchSearch (:214-246, ChainMatches :248-282) exactly, by the whole wavefront (wave-uniform control flow)
-template <bool MINT>
-__device__ __forceinline__ void benc_wave_search(const BencArgs& a, const EncGeom& g, const int* p4, const int* pm, int pos, int& best_d, int& best_l) {
-    const u8* dp = a.data + pos;
-    auto lk = [&](int q) { return g.link16 ? link_at<true>(p4, q) : link_at<false>(p4, q); };
-    int cur = lk(pos);
-    int best_possible = a.n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
-    best_d = 0; best_l = 0; int best_score = -1;
-    int attempts = g.max_chain;
-    while (cur != -1 && attempts-- > 0) {
-        const int dist = pos - cur;
-        if (dist > g.max_dist) break;
-        if (dist < g.min_dist) { cur = lk(cur); continue; }
-        // (a candidate wins only with a strictly higher score, i.e. a longer match -- ScoreMatch :301-321 with one property set is the length,
-        // cut to the distance in CompatibilityMode --: one whose byte at offset best_l differs cannot be longer than best_l, and is not measured.
-        // In the repeated rows of Test.bmp every candidate of a chain matches up to the same place, tens of KiB on: 1.4 -> 0.3 ms for an LZ4 block at Q8)
-        if (g.nprops <= 1 && best_l > 0 && dp[best_l] != a.data[cur + best_l]) { cur = lk(cur); continue; }
-        int len = benc_wave_match_len(dp, a.data + cur, best_possible);
-        const int score = score_match(g, len, dist);
-        if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) break; }
-        cur = lk(cur);
-    }
-    if (MINT && best_l == 0) {                                          // small-match fallback :226-243
-        const int c2 = pm[pos];
-        if (c2 != -1) {
-            int dist = pos - c2;
-            if (dist < g.min_dist) dist = g.min_dist;
-            if (dist <= g.max_dist && pos - dist >= 0) {
-                int len = benc_wave_match_len(dp, a.data + pos - dist, best_possible);
-                (void)score_match(g, len, dist);
-                best_l = len; best_d = dist;
-            }
-        }
-    }
-}
-
 // C1a: who may land on a capped position?  Every position whose own match is known asks for the place its cursor would go to (or for its
 // neighbour, if the lazy rule needs the neighbour's length first); position 0 for itself.
 __global__ __launch_bounds__(256) void benc_request0(BencArgs a, EncGeom g, const u32* __restrict__ ml, u32* __restrict__ stt, u32* __restrict__ front, u32* __restrict__ ctl) {
@@ -223,7 +155,7 @@ __device__ __forceinline__ void benc_resolve(const BencArgs& a, const EncGeom& g
     };
     auto settle = [&](u32 q, int& d, int& l) {                        // the exact match of q (searched here unless somebody has already)
         if (known(q, d, l)) return;
-        benc_wave_search<MINT>(a, g, p4, pm, (int)q, d, l);
+        benc_wave_search<MINT>(a.data, a.n, g, p4, pm, (int)q, d, l);
         if (l0lane) {
             __hip_atomic_store(md + q, (u32)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ml + q, (u32)l, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
