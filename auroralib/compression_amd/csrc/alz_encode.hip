@@ -2654,11 +2654,9 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
         return;
     }
 #define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
-    if (!dense_ok && g.link16) {                                  // (the whole-GPU path of ONE stream: see PRUNE in match_search_b)
-        if (g.use_min_table) ALZ_LB((enc_match_kernel<true, true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, true, true>), dim3(bx, count), dim3(256));
-    }
-    else if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
-    else { if (g.link16) ALZ_LB((enc_match_kernel<false, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
+    // (PRUNE in match_search_b: a candidate that cannot win is not measured -- with 16-bit links, i.e. every finder but RefPack's and FastLZ level 2's)
+    if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
+    else { if (g.link16) ALZ_LB((enc_match_kernel<false, true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
 #undef ALZ_LB
 }
 
