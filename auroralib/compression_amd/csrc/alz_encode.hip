@@ -48,6 +48,7 @@ struct EncGeom {           // per-format LzProperties + finder parameters (SURVE
     int nprops, p_max_len[3], p_min_len[3], p_max_dist[3], p_min_dist[3];
     int variant;           // FastLZ: 1 = level 2 (token format + the two property sets)
     int link16;            // the 4-byte-hash links are 16-bit DISTANCES (0: none or out of reach): every finder whose maxDistance fits
+    int b_cap;             // kernel B stops comparing a candidate here and marks the position (the parse searches it exactly if its cursor ever stands on it)
 };
 
 // prev() of a position from the link array kernel A wrote: a position (or -1), or -- L16, maxDistance <= 65 535 -- a 16-bit distance,
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             const u8* dp = data + pos;
             const int dist = pos - c;
             int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
-            const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
+            const int cmp_max = best_possible > g.b_cap ? g.b_cap : best_possible;
             // sixteen bytes of either side as ONE load each (round 3: eight, and eight more whenever some pair of the 64 had matched them --
             // nearly always --: a second round trip per batch, and a scattered load costs the L1 one lookup per lane whatever its width;
             // may run a few bytes past the stream: inside the staging slack, never compared)
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
             const int c2 = pm[pos];
             if (c2 != -1) {
                 int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
-                const int cmp_max = best_possible > ALZ_LEN_CAP ? ALZ_LEN_CAP : best_possible;
+                const int cmp_max = best_possible > g.b_cap ? g.b_cap : best_possible;
                 int dist = pos - c2;
                 if (dist < g.min_dist) dist = g.min_dist;
                 if (dist <= g.max_dist && pos - dist >= 0) {
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     const int last = first + span - 1 < limit ? first + span - 1 : limit;
     for (int pos = first + (int)threadIdx.x; pos <= last; pos += 256) {
         int bd, bl;
-        const bool okm = match_search_b<MINT, L16, PRUNE>(data, n, pos, p4, pm, g, ALZ_LEN_CAP, bd, bl);
+        const bool okm = match_search_b<MINT, L16, PRUNE>(data, n, pos, p4, pm, g, g.b_cap, bd, bl);
         __builtin_nontemporal_store(okm ? m_pack((u32)bd, (u32)bl) : 0xFFFFFFFFu, m + pos);   // (written once, read by the next kernel: past the caches)
     }
   }
@@ -2052,6 +2053,7 @@ bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_setting
     // chains of up to 1 024 links -- they cost kernel B 5 % while the conversion sat right behind the load, and gain 1 % (104.9 -> 103.6 ms)
     // since the dense kernel converts a link at the top of the NEXT trip)
     g.link16 = g.max_dist <= 0xFFFF ? 1 : 0;
+    g.b_cap = ALZ_LEN_CAP;
     if (g.max_dist > (int)ALZ_M_DMASK) return false;                  // a distance has 21 bits in the match array (FastLZ with MaxWindowBits above 20: the caller's own encoder)
     memcpy(out_geom, &g, sizeof(g));
     if (window_bits) *window_bits = wb;
@@ -2615,10 +2617,25 @@ static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_strea
     return hipSuccess;
 }
 
+// Where kernel B stops comparing (EncGeom.b_cap).  A candidate that reaches the cap ends the walk of its position and marks it; the parse
+// searches a marked position exactly -- the whole chain, by the whole wavefront -- only if its cursor ever stands on it.  So a low cap moves
+// work from "every position inside a long match" to "the positions the parse visits": on real data (tools/bcap_sweep.sh: 1 024 - 2 048
+// windows of Test.bmp per format, ms per call at caps 2 040 / 256 / 48) it pays where a walk is short (quality 0-4, one to five candidates: LZ4
+// blocks Q0 43 / 31 / 23, Yaz0 Q1 34 / 34 / 25) and where it is very long (quality 11-15, 64 to 1 024 candidates, which the cap spares every
+// position of a long match: LZ11 Q12 686 / 401 / 164, LZ4 Q15 908 / 486 / 394); in between (quality 5-10, 6 to 32 candidates) the exact search of
+// a visited position costs more than the cap saves and 256 is the better line (LZ11 Q8 92 / 76 / 100).  Formats whose longest match is below 96
+// bytes (Snappy: 64) lose with any cap (Q0 20 -> 30 ms at 48): none.  The synthetic batches (matches of at most 18 bytes) never reach a cap.
+static int choose_b_cap(const EncGeom& g) {
+    if (g.max_len < 96) return ALZ_LEN_CAP;
+    const int cap = (g.max_chain <= 5 || g.max_chain >= 64) ? 48 : 256;
+    return g.max_len > cap ? cap : ALZ_LEN_CAP;
+}
+
 // kernel B over `count` streams; `wg_cap`: workgroups per stream of the one-position-per-lane form (32 in a batch; a lone stream takes
 // as many as it has blocks of 256 positions)
 static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count, uint32_t max_len,
-                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g, int tail, u32 wg_cap, bool dense_ok = true, u32* d_sel = nullptr, u32 sel_pitch = 0) {
+                         const int* d_prev4, const int* d_prevm, void* d_match, const uint64_t* d_pos_off, const EncGeom& g_in, int tail, u32 wg_cap, bool dense_ok = true, u32* d_sel = nullptr, u32 sel_pitch = 0) {
+    const EncGeom& g = g_in;
     u32 bx = (max_len + 255) / 256; if (bx == 0) bx = 1; if (bx > 4096) bx = 4096;
     if (bx > wg_cap) bx = wg_cap;
     // (workgroups per stream, each with one contiguous range: 32 -- 8 Ki positions of a 256 KiB stream, 4 KiB of history in front of them fetched
@@ -2666,6 +2683,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
                              uint32_t* d_sel, uint32_t sel_pitch) {
     if (count == 0) return hipSuccess;
     EncGeom g; memcpy(&g, geom, sizeof(g));
+    g.b_cap = choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);

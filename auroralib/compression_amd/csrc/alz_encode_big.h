@@ -451,7 +451,7 @@ struct BencLayout {
         ml = o; o += benc_al(np * 4); md = o; o += benc_al(np * 4);
         jump_a = o; o += benc_al(np * 4); jump_b = o; o += benc_al(np * 4);
         next1 = o; o += benc_al(np * 4);
-        front1 = o; if (g.max_len > ALZ_LEN_CAP) o += benc_al(np * 4);
+        front1 = o; if (g.max_len > g.b_cap) o += benc_al(np * 4);
         mark = o; o += benc_al(np); sr = o; o += benc_al(np);
         tile_in = o; o += benc_al((size_t)3 * (tiles + 64) * 4); tile_out = o; o += benc_al((size_t)3 * (tiles + 64) * 4);
         tokbit = o; o += benc_al(np); bitv = o; o += benc_al(2 * np + 64); gofs = o; o += benc_al((np / 4 + 64) * 4);
@@ -893,6 +893,7 @@ bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, ui
 
 size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream* st) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
+    g.b_cap = ALZ_LEN_CAP;                                        // (not choose_b_cap's: here EVERY capped position somebody may land on is searched, generation by generation -- Yaz0 at quality 0 0.17 -> 1.5 ms with the cap at 48, quality 12 1.1 -> 500)
     return BencLayout(*st, g, fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0).total + 256;
 }
 
@@ -902,6 +903,7 @@ size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream*
 hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, alz_result* d_result,
                                  alz_encode_aux* d_aux, void* d_scratch, uint32_t* d_ctl, const void* geom) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
+    g.b_cap = ALZ_LEN_CAP;                                        // (not choose_b_cap's: here EVERY capped position somebody may land on is searched, generation by generation -- Yaz0 at quality 0 0.17 -> 1.5 ms with the cap at 48, quality 12 1.1 -> 500)
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     BencLayout L(*st, g, tail);
     L.ctl_dev = d_ctl;
@@ -925,7 +927,7 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u, false);
     // C: the parse
     const u32 nbn = (a.nodes + 255u) / 256u;
-    const bool caps = g.max_len > ALZ_LEN_CAP;                    // (only then can kernel B have capped anything)
+    const bool caps = g.max_len > g.b_cap;                        // (only then can kernel B have capped anything)
     u32* stt = caps ? jump_a : nullptr;                           // (the jump tables are free until the ranking; the token-bit area until the emission)
     u32* front0 = jump_b; u32* front1 = (u32*)(base + L.front1);
     if (caps) {
