@@ -995,6 +995,108 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
   }
 }
 
+// The same search with the lanes kept busy: a lane whose walk has ended stores its result and takes the next position of its wavefront's
+// range, instead of waiting until the longest walk of its 64 positions is over.  On real data the walks are of very different lengths -- in a
+// run the first candidate has the full length and ends it, next to it a position goes through all 16 (quality 8); where it is used and what it
+// gains: launch_match.  One property set, 16-bit links, PRUNE as above; maxChain >= 3 (below that there is nothing to wait for).
+template <bool MINT>
+__global__ __launch_bounds__(256) void enc_match_dyn_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                            const u32* __restrict__ index_list, const int* __restrict__ prev4,
+                                                            const int* __restrict__ prevm, mentry* __restrict__ match,
+                                                            const u64* __restrict__ pos_off, EncGeom g, int tail_skip, const u32* __restrict__ list = nullptr) {
+  const u32 ny = list ? list[0] : gridDim.y;
+  for (u32 y = blockIdx.y; y < ny; y += gridDim.y) {
+    const u32 sid = list ? list[1u + y] : index_list[y];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int n = (int)st.src_len - tail_skip;
+    const int limit = n - 4;
+    const int* p4 = prev4 + pos_off[sid];
+    const unsigned short* p16 = reinterpret_cast<const unsigned short*>(p4);
+    const int* pm = MINT ? prevm + pos_off[sid] : nullptr;
+    mentry* m = match + pos_off[sid];
+    const int span = (((limit + 1 + (int)gridDim.x - 1) / (int)gridDim.x) + 255) & ~255;
+    const int first = (int)blockIdx.x * span;
+    const int last = first + span - 1 < limit ? first + span - 1 : limit;
+    const int wspan = span >> 2, w = (int)(threadIdx.x >> 6);
+    int nextp = first + w * wspan;                                       // (wave-uniform) the next position nobody has taken
+    const int wlast = nextp + wspan - 1 < last ? nextp + wspan - 1 : last;
+    const int chain = g.max_chain, cap = g.b_cap;
+    // lane state: the position (-1: none), its walk
+    int pos = -1, cur = -1, it = 0, best_l = 0, best_d = 0, best_score = -1, best_possible = 0, cmp_max = 0;
+    bool capped = false; u64 head = 0, head2 = 0;
+    for (;;) {
+        const u64 idle = __ballot(pos < 0);
+        if (idle && nextp <= wlast) {
+            const int np = nextp + (int)__builtin_amdgcn_mbcnt_hi((u32)(idle >> 32), __builtin_amdgcn_mbcnt_lo((u32)idle, 0u));
+            nextp += (int)__popcll(idle);
+            if (pos < 0 && np <= wlast) {
+                pos = np;
+                const u32 d = __builtin_nontemporal_load(p16 + pos); cur = d ? pos - (int)d : -1;
+                best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+                cmp_max = best_possible > cap ? cap : best_possible;
+                best_l = 0; best_d = 0; best_score = -1; capped = false; it = 0;
+                head = load64(data + pos); head2 = load64(data + pos + 8);
+            }
+        }
+        const bool have = pos >= 0;
+        if (!__ballot(have)) break;
+        const bool act = have && cur != -1;
+        const u8* dp = data + (have ? pos : 0);
+        // ---- one candidate (match_search_b's loop body, one property set)
+        const int c = act ? cur : pos;
+        const int dist = pos - c;
+        const bool within = act && dist <= g.max_dist;
+        const int cl = within ? c : (have ? pos : 0);
+        const u64 x = head ^ load64(data + cl);
+        const int nxt = (within && it + 1 < chain) ? link_at<true>(p4, cl) : -1;
+        const bool ok = within && dist >= g.min_dist;
+        int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+        const bool more = ok && x == 0ull && cmp_max > 8;
+        if (__ballot(more)) {
+            const u64 yv = head2 ^ load64(data + (more ? c : 0) + 8);
+            if (more) len = 8 + (yv ? (int)(__builtin_ctzll(yv) >> 3) : 8);
+            bool more2 = more && yv == 0ull && cmp_max > 16;
+            const bool chk = more2 && best_l >= 16;
+            if (__ballot(chk)) {
+                const int o = chk ? best_l - 7 : 0;
+                const u64 pa = load64(dp + o), pb = load64(data + (chk ? c : 0) + o);
+                if (chk && pa != pb) more2 = false;
+            }
+            if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
+        }
+        if (len > cmp_max) len = cmp_max;
+        const bool hitcap = ok && len == cmp_max && cmp_max < best_possible;
+        int l2 = len;
+        if (g.no_self_overlap && l2 > dist) l2 = dist;
+        const int score = l2 - g.min_len;
+        const bool better = ok && !hitcap && score > best_score;
+        best_score = better ? score : best_score; best_l = better ? l2 : best_l; best_d = better ? dist : best_d;
+        capped = capped || hitcap;
+        const bool stop = !within || hitcap || (better && l2 == best_possible);
+        cur = nxt; it++;
+        const bool goon = act && !stop && cur != -1;
+        if (have && !goon) {                                             // this position is done
+            bool okm = !capped;
+            if (MINT && okm && best_l == 0) {                            // small-match fallback :226-243
+                const int c2 = pm[pos];
+                if (c2 != -1) {
+                    int dd = pos - c2;
+                    if (dd < g.min_dist) dd = g.min_dist;
+                    if (dd <= g.max_dist && pos - dd >= 0) {
+                        int ln = match_len(dp, data + pos - dd, cmp_max);
+                        if (ln == cmp_max && cmp_max < best_possible) okm = false;
+                        else { (void)score_match(g, ln, dd); best_l = ln; best_d = dd; }
+                    }
+                }
+            }
+            __builtin_nontemporal_store(okm ? m_pack((u32)best_d, (u32)best_l) : 0xFFFFFFFFu, m + pos);
+            pos = -1;
+        }
+    }
+  }
+}
+
 // (Tried in round 3 for maxChain 1 (quality 0), where this kernel issues only 0.57 instructions per cycle and CU: four positions per thread
 // with the loads of every stage in flight together -- links and the positions' own sixteen bytes, then the candidates' sixteen bytes as one
 // load each, then the arithmetic: 16.7-17.1 ms against 16.8.  Neither the chain of dependent round trips nor the L1's lookups (0.77 per
@@ -2655,7 +2757,16 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
             hipLaunchKernelGGL((enc_probe_kernel<true>), dim3(count), dim3(64), 0, stream, src, d_streams, d_index, d_prev4, d_pos_off, g, tail, d_sel, list, thr);
             sel = d_sel;
             const u32 gy = count < 512u ? count : 512u;
-            if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true, true, true>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
+            // (lanes that take the next position when their walk ends -- enc_match_dyn_kernel -- where walks are long or compares short; with
+            // long matches AND walks of 6-32 candidates the lanes' compare loops fall out of step and every one of them runs for the whole
+            // wavefront: 1 024 windows at quality 8 as Yaz0 40 -> 47 ms, as LZ4 blocks 56 -> 63, but as LZSS 17.1 -> 14.1, and at quality 12
+            // Yaz0 139 -> 125, LZ11 ~160 -> 92, LZSS 40 -> 26)
+            const bool dynk = g.max_len <= 32 || g.max_chain >= 64;
+            if (dynk) {
+                if (g.use_min_table) hipLaunchKernelGGL((enc_match_dyn_kernel<true>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
+                else hipLaunchKernelGGL((enc_match_dyn_kernel<false>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
+            }
+            else if (g.use_min_table) hipLaunchKernelGGL((enc_match_kernel<true, true, true>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
             else hipLaunchKernelGGL((enc_match_kernel<false, true, true>), dim3(bx, gy), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, list);
         }
 #define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail, xlog, sel)
@@ -2671,6 +2782,10 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
         return;
     }
 #define ALZ_LB(K, grid, block) hipLaunchKernelGGL(K, grid, block, 0, stream, src, d_streams, d_index, d_prev4, d_prevm, (mentry*)d_match, d_pos_off, g, tail)
+    if (!dense_ok && g.max_chain >= 3 && g.max_len <= 32 && g.link16 && g.nprops <= 1) {   // (the whole-GPU path of ONE stream; short compares only: see above)
+        if (g.use_min_table) ALZ_LB((enc_match_dyn_kernel<true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_dyn_kernel<false>), dim3(bx, count), dim3(256));
+        return;
+    }
     // (PRUNE in match_search_b: a candidate that cannot win is not measured -- with 16-bit links, i.e. every finder but RefPack's and FastLZ level 2's)
     if (g.use_min_table) { if (g.link16) ALZ_LB((enc_match_kernel<true, true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<true, false>), dim3(bx, count), dim3(256)); }
     else { if (g.link16) ALZ_LB((enc_match_kernel<false, true, true>), dim3(bx, count), dim3(256)); else ALZ_LB((enc_match_kernel<false, false>), dim3(bx, count), dim3(256)); }
