@@ -2728,6 +2728,9 @@ static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_strea
 // a visited position costs more than the cap saves and 256 is the better line (LZ11 Q8 92 / 76 / 100).  Formats whose longest match is below 96
 // bytes (Snappy: 64) lose with any cap (Q0 20 -> 30 ms at 48): none.  The synthetic batches (matches of at most 18 bytes) never reach a cap.
 static int choose_b_cap(const EncGeom& g) {
+#ifdef ALZ_BCAP_FORCE                                              /* tools/bcap_sweep.sh: one cap for every quality (a build flag, not an environment variable) */
+    return g.max_len > ALZ_BCAP_FORCE ? ALZ_BCAP_FORCE : ALZ_LEN_CAP;
+#endif
     if (g.max_len < 96) return ALZ_LEN_CAP;
     const int cap = (g.max_chain <= 5 || g.max_chain >= 64) ? 48 : 256;
     return g.max_len > cap ? cap : ALZ_LEN_CAP;

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for cap in 2040 32 48; do
+for cap in 2040 128 64 48 32; do
   touch auroralib/compression_amd/csrc/alz_encode.hip
   ALZ_EXTRA_FLAGS="-DALZ_PARSE_CAP=$cap" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1
   echo "== ALZ_PARSE_CAP $cap"
