@@ -537,11 +537,16 @@ __device__ __forceinline__ int score_match(const EncGeom& g, int& len, int dist)
 // As a per-lane loop with a byte tail, every trip of kernel B's loop paid the dependent byte loads of its slowest lane.
 __device__ __forceinline__ int wave_match_tail(const u8* a, const u8* b, int max, bool go) {
     int l = 16;
+    // (sixteen bytes per side and trip, both loads of a side in flight together: the loop runs for the whole wavefront as long as its longest
+    // lane -- up to 32 trips of eight bytes for a Yaz0 match, 253 for a capped one -- and a trip is a memory round trip.  A trip may read up
+    // to fifteen bytes past the length that counts.)
     while (__ballot(go)) {
-        const u64 z = load64(a + (go ? l : 0)) ^ load64(b + (go ? l : 0));
+        const int o = go ? l : 0;
+        const u64 z0 = load64(a + o) ^ load64(b + o), z1 = load64(a + o + 8) ^ load64(b + o + 8);
         if (go) {
-            if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; }
-            else { l += 8; if (l >= max) go = false; }
+            if (z0) { l += (int)(__builtin_ctzll(z0) >> 3); go = false; }
+            else if (z1) { l += 8 + (int)(__builtin_ctzll(z1) >> 3); go = false; }
+            else { l += 16; if (l >= max) go = false; }
         }
     }
     return l;
