@@ -542,7 +542,9 @@ __device__ __forceinline__ int wave_match_tail(const u8* a, const u8* b, int max
     // to fifteen bytes past the length that counts.)
     while (__ballot(go)) {
         const int o = go ? l : 0;
-        const u64 z0 = load64(a + o) ^ load64(b + o), z1 = load64(a + o + 8) ^ load64(b + o + 8);
+        u64 va[2], vb[2];                                               // (ONE load per side: a scattered load costs the L1 a lookup per lane whatever its width, and the lookups are what bounds kernel B on real data)
+        __builtin_memcpy(va, a + o, 16); __builtin_memcpy(vb, b + o, 16);
+        const u64 z0 = va[0] ^ vb[0], z1 = va[1] ^ vb[1];
         if (go) {
             if (z0) { l += (int)(__builtin_ctzll(z0) >> 3); go = false; }
             else if (z1) { l += 8 + (int)(__builtin_ctzll(z1) >> 3); go = false; }
@@ -692,14 +694,15 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
         // (a candidate out of reach is not touched: the previous position with this hash usually lies further back than a 4 KiB window
         //  reaches, anywhere in the stream -- an 8-byte read that misses every cache and is thrown away)
         const int cl = within ? c : pos;
-        const u64 x = head ^ load64(data + cl);
+        u64 cv[2]; __builtin_memcpy(cv, data + cl, 16);                 // (the candidate's sixteen bytes as ONE load: the second eight cost no lookup of their own)
+        const u64 x = head ^ cv[0];
         const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, cl) : -1;   // (the last candidate's link is never followed: at maxChain 1 that is every one)
         const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
         if (__ballot(more)) {
             // the second eight bytes the same way (most formats' matches end inside them); the compare loop only behind sixteen
-            const u64 y = head2 ^ load64(data + (more ? c : 0) + 8);
+            const u64 y = head2 ^ cv[1];
             if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
             bool more2 = more && y == 0ull && cmp_max > 16;
             if (PRUNE && g.nprops <= 1) {
@@ -1053,13 +1056,14 @@ __global__ __launch_bounds__(256) void enc_match_dyn_kernel(const u8* __restrict
         const int dist = pos - c;
         const bool within = act && dist <= g.max_dist;
         const int cl = within ? c : (have ? pos : 0);
-        const u64 x = head ^ load64(data + cl);
+        u64 cv[2]; __builtin_memcpy(cv, data + cl, 16);
+        const u64 x = head ^ cv[0];
         const int nxt = (within && it + 1 < chain) ? link_at<true>(p4, cl) : -1;
         const bool ok = within && dist >= g.min_dist;
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
         if (__ballot(more)) {
-            const u64 yv = head2 ^ load64(data + (more ? c : 0) + 8);
+            const u64 yv = head2 ^ cv[1];
             if (more) len = 8 + (yv ? (int)(__builtin_ctzll(yv) >> 3) : 8);
             bool more2 = more && yv == 0ull && cmp_max > 16;
             const bool chk = more2 && best_l >= 16;
