@@ -282,6 +282,46 @@ __global__ __launch_bounds__(256) void big_rank_round(const u32* __restrict__ ju
     jump_b[p] = jump_a[j];
 }
 
+// P2 on two levels (round 4, from the encoder's whole-GPU path, alz_encode_big.h): a round over all nodes is a launch (~4 us whatever it
+// does), and ceil(log2 groups) + 1 = 15-18 of them were a third of a 1 000 KiB stream's time.  Jumps only go forward, so a tile of 1 024 nodes
+// can be ranked in LDS: ten rounds of pointer jumping give every node its EXIT -- the first node of its chain behind the tile (big_tile_exit);
+// the chain of exits from node 0 has at most one node per tile: ceil(log2 tiles) + 1 rounds over all nodes mark where the real chain ENTERS
+// each tile; eleven rounds of the same ranking on the one-hop jumps in LDS mark the real nodes inside (big_tile_mark).
+#define BIG_RTILE 1024u
+__global__ __launch_bounds__(1024) void big_tile_exit(const u32* __restrict__ next1, u32* __restrict__ exitj, u32 nodes) {
+    __shared__ u32 J[BIG_RTILE];
+    const u32 ts = blockIdx.x * BIG_RTILE, te = ts + BIG_RTILE, tid = threadIdx.x, p = ts + tid;
+    J[tid] = p < nodes ? next1[p] : 0xFFFFFFFFu;                  // (a thread behind the last node: never inside a tile)
+    __syncthreads();
+    for (u32 r = 0; r < 10u; r++) {
+        const u32 j = J[tid];
+        const u32 j2 = (j >= ts && j < te) ? J[j - ts] : j;       // (an end node points at itself)
+        __syncthreads();
+        J[tid] = j2;
+        __syncthreads();
+    }
+    if (p < nodes) exitj[p] = J[tid];
+}
+__global__ __launch_bounds__(1024) void big_tile_mark(const u32* __restrict__ next1, u8* __restrict__ mark, u32 nodes) {
+    __shared__ u32 JA[BIG_RTILE], JB[BIG_RTILE], M[BIG_RTILE];
+    const u32 ts = blockIdx.x * BIG_RTILE, te = ts + BIG_RTILE, tid = threadIdx.x, p = ts + tid;
+    JA[tid] = p < nodes ? next1[p] : 0xFFFFFFFFu;
+    M[tid] = p < nodes ? mark[p] : 0u;
+    __syncthreads();
+    u32* ja = JA; u32* jb = JB;
+    for (u32 r = 0; r < 11u; r++) {
+        const u32 j = ja[tid];
+        const bool inside = j >= ts && j < te;
+        if (inside && M[tid]) M[j - ts] = 1u;
+        jb[tid] = inside ? ja[j - ts] : j;
+        __syncthreads();
+        u32* t = ja; ja = jb; jb = t;
+    }
+    if (p < nodes) mark[p] = (u8)M[tid];
+}
+// the three launches of a list ranking: next1 = the one-hop jumps (kept), jump_a / jump_b = work tables, mark[0] = 1 set by the caller
+static void big_rank(hipStream_t stream, const u32* next1, u32* jump_a, u32* jump_b, u8* mark, u32 nodes);
+
 // P3: marked positions per tile of 1 024 input bytes; after the scan, the group's number -> its position
 __global__ __launch_bounds__(64) void big_mark_count(const u8* __restrict__ mark, u32 src_len, u32* __restrict__ tile_c) {
     const u32 tile = blockIdx.x, lane = big_lane();
@@ -722,6 +762,13 @@ static u32 big_ntok(const alz_stream& st) {
     return (u32)(by_flags < st.decom_len ? by_flags : st.decom_len);
 }
 static u32 big_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r + 1u; }
+static void big_rank(hipStream_t stream, const u32* next1, u32* jump_a, u32* jump_b, u8* mark, u32 nodes) {
+    const u32 rtiles = (nodes + BIG_RTILE - 1u) / BIG_RTILE, nbn = (nodes + 255u) / 256u;
+    hipLaunchKernelGGL(big_tile_exit, dim3(rtiles), dim3(1024), 0, stream, next1, jump_a, nodes);
+    const u32 rr = big_rounds(rtiles + 1u);
+    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    hipLaunchKernelGGL(big_tile_mark, dim3(rtiles), dim3(1024), 0, stream, next1, mark, nodes);
+}
 static bool big_three(int fmt) { return fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0; }
 static bool big_inter(int fmt) { return fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_YAZ0; }
 static bool big_prs(int fmt) { return fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE; }
@@ -731,7 +778,7 @@ static size_t big_al(size_t x) { return (x + 255) & ~(size_t)255; }
 // layout of the scratch of the interleaved path
 struct InterLayout {
     u32 nodes, max_ng, max_nt, mtiles, ttiles;
-    size_t val, jump_a, jump_b, mark, tile_c, tile_cb, gpos, tlen, tdesc, tend, toff, tile_l, tile_lb, ctl, total;
+    size_t val, jump_a, jump_b, next1, mark, tile_c, tile_cb, gpos, tlen, tdesc, tend, toff, tile_l, tile_lb, ctl, total;
     InterLayout(const alz_stream& st, int fmt = ALZ_FMT_YAZ0) {
         nodes = st.src_len + 1u;
         if (big_prs(fmt)) { nodes = (st.src_len + 1u) * ALZ_PRS_STATES; max_ng = st.src_len / 2u + 2u; max_nt = 8u * max_ng; }   // (a group has a flag byte and at least one data byte)
@@ -743,7 +790,7 @@ struct InterLayout {
         mtiles = (nodes + 1023u) / 1024u; ttiles = (max_nt + 1023u) / 1024u;
         size_t o = 0;
         val = o; o += big_al((size_t)out_bound * 4);
-        jump_a = o; o += big_al((size_t)nodes * 4); jump_b = o; o += big_al((size_t)nodes * 4);
+        jump_a = o; o += big_al((size_t)nodes * 4); jump_b = o; o += big_al((size_t)nodes * 4); next1 = o; o += big_al((size_t)nodes * 4);
         mark = o; o += big_al((size_t)nodes + 64);
         tile_c = o; o += big_al((size_t)(mtiles + 64) * 4); tile_cb = o; o += big_al((size_t)(mtiles + 64) * 4);
         gpos = o; o += big_al((size_t)max_ng * 4);
@@ -790,9 +837,9 @@ static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
     if (e != hipSuccess) return e;
     const u32 nbn = (L.nodes + 255u) / 256u;
-    hipLaunchKernelGGL((big_group_sizes<FMT>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
-    const u32 rr = big_rounds(L.max_ng);
-    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    u32* next1 = (u32*)(base + L.next1);
+    hipLaunchKernelGGL((big_group_sizes<FMT>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, next1);
+    big_rank(stream, next1, jump_a, jump_b, mark, L.nodes);
     hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_c);
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
     hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_cb, gpos);
@@ -823,9 +870,9 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
     if (e != hipSuccess) return e;
     const u32 nbn = (L.nodes + 255u) / 256u;
-    hipLaunchKernelGGL((big_elem_sizes<LZ4>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
-    const u32 rr = big_rounds(L.max_ng);
-    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    u32* next1 = (u32*)(base + L.next1);
+    hipLaunchKernelGGL((big_elem_sizes<LZ4>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, next1);
+    big_rank(stream, next1, jump_a, jump_b, mark, L.nodes);
     hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_c);
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
     hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, st->src_len, tile_cb, gpos);
@@ -865,10 +912,10 @@ static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const 
     if (e != hipSuccess) return e;
     const u32 nbn = (L.nodes + 255u) / 256u;
     const u32 real_nodes = L.nodes - NST;                         // the nodes of the bytes that exist (the end node is the first behind them)
-    if (KIND == 2) hipLaunchKernelGGL(big_lzo_sizes, dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
-    else hipLaunchKernelGGL((big_prs_sizes<BIG>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, jump_a);
-    const u32 rr = big_rounds(L.max_ng);
-    for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, L.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
+    u32* next1 = (u32*)(base + L.next1);
+    if (KIND == 2) hipLaunchKernelGGL(big_lzo_sizes, dim3(nbn), dim3(256), 0, stream, src, st->src_len, next1);
+    else hipLaunchKernelGGL((big_prs_sizes<BIG>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, next1);
+    big_rank(stream, next1, jump_a, jump_b, mark, L.nodes);
     hipLaunchKernelGGL(big_mark_count, dim3(L.mtiles), dim3(64), 0, stream, mark, real_nodes, tile_c);
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_c, tile_cb, L.mtiles, ctl + C_NG);
     hipLaunchKernelGGL(big_mark_scatter, dim3(L.mtiles), dim3(64), 0, stream, mark, real_nodes, tile_cb, gpos);
