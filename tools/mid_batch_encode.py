@@ -10,6 +10,13 @@ from auroralib.compression_amd import synth
 from auroralib.compression_amd.batch import Context
 
 bmp = np.frombuffer(O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0], dtype=np.uint8)
+if os.environ.get("ALZ_MID_DATA") == "text":              # the repository's own sources and documents: program text and prose instead of a bitmap
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "**", "*.md"), recursive=True) + glob.glob(os.path.join(ROOT, "**", "*.hip"), recursive=True) +
+                   glob.glob(os.path.join(ROOT, "**", "*.h"), recursive=True) + glob.glob(os.path.join(ROOT, "**", "*.py"), recursive=True) +
+                   glob.glob(os.path.join(ROOT, "**", "*.cs"), recursive=True) + glob.glob(os.path.join(ROOT, "**", "*.cpp"), recursive=True))
+    bmp = np.frombuffer(b"".join(open(f, "rb").read() for f in files if "gpurun_out" not in f), dtype=np.uint8)
+    print("text corpus: %d files, %d bytes" % (len(files), len(bmp)))
 size = int(os.environ.get("ALZ_MID_SIZE", str(262144)))
 c = Context(0)
 for fname in sys.argv[1:] or ["lzss", "yaz0"]:
