@@ -803,11 +803,14 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     // As in the decoder (plan_create): one after the other on the whole GPU while that beats side by side with a workgroup + a wavefront
     // each -- measured at quality 0-8 on Test.bmp (tools/mid_batch_encode.py): ~0.10 ms + 0.10 ms per MiB on the whole GPU, ~22 ms per MiB of the LONGEST buffer side by side.
     if (!no_big && n <= ALZ_BIG_MAX_STREAMS && c->big_min != 0xFFFFFFFFu && !c->exact && c->variant == 0) {
+        // (from 8 KiB on -- not the decoder's 96 KiB: ONE buffer of 8 KiB takes 0.08 ms of kernels this way and 0.22 through the batch pipeline, of
+        // 64 KiB 0.10 against 1.6, tools/single_encode_sizes.py; a threshold the caller has set below that is the caller's)
+        const uint32_t enc_min = c->big_min < 8192u ? c->big_min : 8192u;
         bool all = true; size_t sb = 0;
         double t_big = 0, t_side = 0;
         for (uint32_t i = 0; all && i < n; i++) {
             const void* g = geom.data() + streams[i].format * alz_encode_geom_size();
-            all = streams[i].format != ALZ_FMT_FASTLZ && alz_encode_big_eligible((int)streams[i].format, g, &streams[i], c->big_min);
+            all = streams[i].format != ALZ_FMT_FASTLZ && alz_encode_big_eligible((int)streams[i].format, g, &streams[i], enc_min);
             if (all) { const size_t b = alz_encode_big_scratch_bytes((int)streams[i].format, g, &streams[i]); if (b > sb) sb = b; }
             const double mib = streams[i].src_len / 1048576.0;
             t_big += 0.10 + 0.10 * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;

@@ -216,8 +216,8 @@ int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
  * output bytes.  So the single-stream call a format class's Decompress(Stream, Stream) makes (Interfaces/ICompressionDecoder.cs:24; the
  * reference's own benchmark is ONE 1 000 KiB stream, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42) does not fall behind the managed
  * decoder.  Results are identical: a stream that path cannot finish -- any malformed one -- is decoded by the exact kernel behind it.
- * The ENCODER has the same switch (csrc/alz_encode_big.h): an alz_encode_batch / _device call of at most eight buffers, each of at least
- * `min_bytes` of one of these formats (and LZ40 / CLZ0 / BLZ / LZHudson; distances within 16 bits), is compressed buffer by buffer on the whole
+ * The ENCODER has the same switch (csrc/alz_encode_big.h): an alz_encode_batch / _device call of at most 32 buffers, each of at least
+ * 8 KiB (or `min_bytes`, if that is less: the batch pipeline gives a buffer one workgroup and one wavefront, and loses from 8 KiB on) of one of these formats (and LZ40 / CLZ0 / BLZ / LZHudson; distances within 16 bits), is compressed buffer by buffer on the whole
  * GPU -- prev() on overlapping segments, the greedy / lazy parse (FindNextBestMatch, MatchFinder/LzChainMatchFinder.cs:157-212) as list ranking
  * over "where would a cursor at p go", the emission by prefix sums -- instead of by one workgroup and one wavefront per buffer: what
  * a format class's Compress(ReadOnlySpan<byte>, Stream) makes of ONE buffer (Interfaces/ICompressionEncoder.cs; the reference's benchmark

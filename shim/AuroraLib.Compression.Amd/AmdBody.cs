@@ -133,7 +133,7 @@ namespace AuroraLib.Compression.Amd
                && AmdContext.Available;
 
         /// <summary>ONE buffer the native encoder runs on the whole GPU (csrc/alz_encode_big.h; alz_encode_big_eligible): a format of that
-        /// path, at least <see cref="AmdContext.BigStreamThreshold"/> bytes, distances within 16-bit links, and a quality at which the path
+        /// path, at least <see cref="AmdContext.BigStreamCompressThreshold"/> bytes, distances within 16-bit links, and a quality at which the path
         /// beats the managed encoder (<see cref="AmdContext.BigStreamCompressMaxQuality"/>).</summary>
         internal static bool BigStreamCompress(AlzFormat format, int sourceLength, CompressionSettings settings, LzProperties? lz = null)
         {
@@ -145,7 +145,7 @@ namespace AuroraLib.Compression.Amd
                 default: return false;
             }
             if (format == AlzFormat.LZSS && lz.HasValue && lz.Value.MaxDistance > 0xFFFF) return false;      // (16-bit links)
-            return (uint)sourceLength >= AmdContext.BigStreamThreshold && sourceLength <= 0x20000000
+            return (uint)sourceLength >= AmdContext.BigStreamCompressThreshold && sourceLength <= 0x20000000
                    && settings.Quality <= AmdContext.BigStreamCompressMaxQuality(format);
         }
 

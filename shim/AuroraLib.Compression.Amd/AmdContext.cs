@@ -42,6 +42,11 @@ namespace AuroraLib.Compression.Amd
         /// 0.6-6 ms at quality 15 (0.16-1.7 GiB/s against 0.06-0.13), so the default is "always" (15) for every format of the path.</summary>
         public static int BigStreamCompressMaxQuality(AlzFormat format) => 15;
 
+        /// <summary>... and from this many source bytes on.  The native library takes its whole-GPU encode path from 8 KiB on (against its own
+        /// batch pipeline); against the MANAGED encoder -- ~5 ms per MB on one core at quality 0, Benchmarks.md -- a call of ~0.2 ms pays from
+        /// about 48 KiB on.</summary>
+        public static uint BigStreamCompressThreshold { get; set; } = 64u << 10;
+
         public static bool Available
         {
             get

@@ -1,5 +1,5 @@
 """-m gpu: ONE big stream on the whole GPU, encoder side (csrc/alz_encode_big.h) against the oracle's restatement of LzChainMatchFinder +
-FlagWriter + CompressHeaderless: a call of at most eight streams, each of at least 96 KiB of a flag-bit format, goes through segmented
+FlagWriter + CompressHeaderless: a call of at most 32 streams, each of at least 8 KiB of one of the formats of the path, goes through segmented
 prev(), list ranking for the parse and prefix-sum emission instead of one workgroup + one wavefront per stream.  The compressed bytes, the
 section offsets and the statuses must be IDENTICAL to the oracle's -- and so to the batch pipeline's, which the same inputs go through with
 the path switched off."""
@@ -92,13 +92,14 @@ def _mixed(size, seed, test_bmp):
 
 @pytest.mark.parametrize("fmt", NORTH)
 def test_sizes_and_the_threshold(fmt, test_bmp):
-    """Both sides of the 96 KiB threshold, the segment (16 384 positions) and tile (1 024 positions) boundaries, 4 MiB; the path is taken from
+    """Both sides of the 8 KiB threshold, the segment (16 384 positions) and tile (1 024 positions) boundaries, 4 MiB; the path is taken from
     the threshold on, never below it, never on a context with the path switched off -- and the bytes are the same either way."""
     with Context(0) as c:
-        for size in (98303, 98304, 98304 + 16384 - 1, 7 * 16384, 7 * 16384 + 1, 7 * 16384 + 4, 131072 + 5, 262144, (1 << 22) + 3):
+        for size in (8191, 8192, 8193, 9215, 9216, 12345, 16383, 16384, 16385, 16384 + 4, 20000, 65536 + 3, 98304 + 16384 - 1, 7 * 16384, 7 * 16384 + 1,
+                     7 * 16384 + 4, 131072 + 5, 262144, (1 << 22) + 3):
             raw = _mixed(size, size, test_bmp)
             q = 8 if size < (1 << 22) else 0
-            a = _encode(c, [(fmt, raw)], q, expect_big=size >= 98304, what="size %d" % size)
+            a = _encode(c, [(fmt, raw)], q, expect_big=size >= 8192, what="size %d" % size)
             c.big_stream(OFF)
             b = _encode(c, [(fmt, raw)], q, expect_big=False, what="size %d, path off" % size)
             c.big_stream(96 << 10)
@@ -232,7 +233,7 @@ def test_big_encode_fuzz(fmt, test_bmp):
     rng = random.Random(seed)
     with Context(0) as c:
         for k in range(6):
-            size = rng.choice([98304, 98304 + rng.randrange(1, 70000), rng.randrange(100000, 400000), rng.randrange(100000, 1500000)])
+            size = rng.choice([8192 + rng.randrange(0, 3000), rng.randrange(8192, 98304), 98304 + rng.randrange(1, 70000), rng.randrange(100000, 400000), rng.randrange(100000, 1500000)])
             raw = _mixed(size, seed * 8 + k, test_bmp)
             if k % 3 == 2:                                         # long repeats: matches beyond kernel B's compare cap
                 piece = raw[:rng.randrange(2100, 9000)]
