@@ -108,7 +108,7 @@ struct alz_ctx {
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
     int variant = 0;                           // alz_ctx_set_kernel_variant
     uint64_t big_enc_launches = 0;             // streams the whole-GPU ENCODE path has taken (alz_encode_big.h)
-    uint32_t big_min = 96u << 10;              // a lone Yay0 / MIO0 stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
+    uint32_t big_min = 24u << 10;              // (24 KiB: tools/single_decode_sizes.py -- 0.18 ms either way at 16 KiB, 0.18 against 0.30 at 32) a lone stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
     uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
     void* d_bigbuf = nullptr; size_t d_bigbuf_cap = 0;   // its scratch for the plans of the host-buffer entry points (grow-only)
     // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
@@ -803,7 +803,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     // As in the decoder (plan_create): one after the other on the whole GPU while that beats side by side with a workgroup + a wavefront
     // each -- measured at quality 0-8 on Test.bmp (tools/mid_batch_encode.py): ~0.10 ms + 0.10 ms per MiB on the whole GPU, ~22 ms per MiB of the LONGEST buffer side by side.
     if (!no_big && n <= ALZ_BIG_MAX_STREAMS && c->big_min != 0xFFFFFFFFu && !c->exact && c->variant == 0) {
-        // (from 8 KiB on -- not the decoder's 96 KiB: ONE buffer of 8 KiB takes 0.08 ms of kernels this way and 0.22 through the batch pipeline, of
+        // (from 8 KiB on -- not the decoder's 24 KiB: ONE buffer of 8 KiB takes 0.08 ms of kernels this way and 0.22 through the batch pipeline, of
         // 64 KiB 0.10 against 1.6, tools/single_encode_sizes.py; a threshold the caller has set below that is the caller's)
         const uint32_t enc_min = c->big_min < 8192u ? c->big_min : 8192u;
         bool all = true; size_t sb = 0;

@@ -207,7 +207,7 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
 int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
 /* ONE big stream: a batch of one -- or of a few, as long as one after the other on the whole GPU beats side by side on wavefronts of their
  * own -- LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4-block / raw-Snappy streams (all eleven
- * north-star bodies) of at least `min_bytes` of output each (default 96 KiB; PRS / LZO / LZ4 / Snappy, which carry no size in the
+ * north-star bodies) of at least `min_bytes` of output each (default 24 KiB -- where the two cross: ONE stream of 32 KiB takes 0.18 ms here and 0.30 on its wavefront, of 256 KiB 0.20 and 1.3; PRS / LZO / LZ4 / Snappy, which carry no size in the
  * descriptor: of dst_cap, with at least 8 KiB of input) is decoded
  * stream by stream by the whole GPU instead of by one or two wavefronts per stream (csrc/alz_big.hip).  Yay0 / MIO0 keep flags, match tokens
  * and literals in three sections (Yay0.cs:99-108, MIO0.cs:105-116): every token's cursors are prefix sums.  The other four interleave them

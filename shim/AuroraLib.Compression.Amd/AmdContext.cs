@@ -25,7 +25,7 @@ namespace AuroraLib.Compression.Amd
         /// three-section formats by prefix sums, the copies by pointer jumping over the output bytes) -- the reference's own benchmark
         /// input, one 1 000 KiB stream of Test.bmp, decodes in 0.27-0.44 ms through <c>alz_decode</c> on host buffers (2.2-3.6 GiB/s)
         /// against 0.32-0.91 GiB/s of the managed loops (Benchmarks.md:30-84).  A single body of these formats with at least this many
-        /// decompressed bytes therefore goes to the GPU by default; the native library takes the whole-GPU path from 96 KiB on.</summary>
+        /// decompressed bytes therefore goes to the GPU by default; the native library takes the whole-GPU path from 24 KiB on (against its own wavefront kernels; against the managed loops the call pays from about here).</summary>
         public static uint BigStreamThreshold { get; set; } = 96u << 10;
 
         /// <summary>The same switch for <c>Compress</c> / <c>CompressHeaderless</c> of ONE buffer: sources shorter than this run on

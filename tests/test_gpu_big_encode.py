@@ -102,7 +102,7 @@ def test_sizes_and_the_threshold(fmt, test_bmp):
             a = _encode(c, [(fmt, raw)], q, expect_big=size >= 8192, what="size %d" % size)
             c.big_stream(OFF)
             b = _encode(c, [(fmt, raw)], q, expect_big=False, what="size %d, path off" % size)
-            c.big_stream(96 << 10)
+            c.big_stream(24 << 10)
             assert a == b
 
 

@@ -19,7 +19,7 @@ for fname in names:
         src = np.frombuffer(raw + bytes(64), dtype=np.uint8)
         row = []
         for mode in os.environ.get("ALZ_SINGLE_MODES", "big,batch").split(","):
-            c.big_stream(96 << 10 if mode == "big" else 0xFFFFFFFF)
+            c.big_stream(24 << 10 if mode == "big" else 0xFFFFFFFF)
             before = c.big_stream()
             c.encode_batch(st, src, n + n // 4 + 128, quality=q)
             t0 = time.perf_counter()

@@ -25,4 +25,4 @@ for fname in sys.argv[1:] or ["lzss", "yaz0", "lz4_block"]:
                 row.append(((time.perf_counter() - t0) / 5 * 1e3, c.last_kernel_ms(), bytes(d[:r[0].dst_len])))
             want = O.encode_stream(fmt, raw, quality=q)[0]
             print("%-9s q%d %7d B: whole-GPU %.3f ms (kernels %.3f) | batch %.3f ms (kernels %.3f) | same bytes %s %s" % (fname, q, n, row[0][0], row[0][1], row[1][0], row[1][1], row[0][2] == want, row[1][2] == want), flush=True)
-c.big_stream(96 << 10)
+c.big_stream(24 << 10)
