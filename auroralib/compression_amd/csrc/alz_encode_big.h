@@ -438,7 +438,12 @@ struct BencLayout {
         a.W = ((u32)g.max_dist + 63u) & ~63u;
         // (a segment costs kernel A its S + W positions; while all segments of the stream are resident at once -- one workgroup per CU --
         // shorter ones finish sooner: a 1 000 KiB Yaz0 stream at quality 8 0.29 -> 0.25 ms of kernels, at quality 15 1.22 -> 0.94)
-        a.S = (a.W <= 8192u && st.src_len <= (2u << 20)) ? 8192u : 16384u;
+        {   // as short as keeps the segments at about one per CU (240 of 256), between 4 Ki and 16 Ki positions
+            u32 S = ((st.src_len / 240u) + 2047u) & ~2047u;
+            if (S < 4096u) S = 4096u;
+            if (S > 16384u || a.W > 8192u) S = 16384u;
+            a.S = S;
+        }
         a.K = ((u32)a.limit + a.S) / a.S;
         a.stride = a.S + a.W + 64u;
         tiles = (a.N + BENC_TILE - 1u) / BENC_TILE + 1u;         // (+ 1: PRS has a token behind the data)
