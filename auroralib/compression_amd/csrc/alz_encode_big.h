@@ -2,18 +2,19 @@
 // EncGeom / match array / MatchSearch).
 //
 // The batch encoder gives a stream one workgroup for prev() (kernel A), and one wavefront for the parse and the emission: a lone
-// 1 000 KiB stream -- what the reference's own benchmark compresses, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42 -- takes 20-60 ms,
-// several times what the managed encoder needs on one CPU core.  Nothing in the pipeline is sequential by nature:
+// 1 000 KiB stream -- what the reference's own benchmark compresses, Benchmarks/Benchmarks/TestAllAlgorithms.cs:41-42 -- takes 20-120 ms,
+// several times what the managed encoder needs on one CPU core; here 0.13-0.4 ms of kernels at quality 0, 0.3-6 at quality 15.  Nothing in the pipeline is sequential by nature:
 //
 //   A'  prev(): the stream is cut into segments of S positions, and kernel A runs on "virtual streams" [j S - W, (j + 1) S) -- W >= maxDistance
 //       positions of warm-up in front of every segment.  A link found inside a virtual stream is the stream's link; one that would reach in
 //       front of it is longer than maxDistance, which ends a chain walk exactly as no link does (LzChainMatchFinder.cs:259-260).  The links
 //       of the warm-up positions are thrown away (the segment before has them right): benc_gather copies the rest into the arrays kernel B
 //       reads, min-length-table links moved from segment to stream positions.
-//   B   MatchSearch for every position: the batch kernel with one position per lane (enc_match_kernel), on as many workgroups as the stream
-//       has blocks.  (Not the two-phase kernel the batches use from maxChain 3 on: it walks every chain to its end before it compares, and on
-//       a lone stream of real data -- Test.bmp: runs, repeated rows -- the walk that ends at the first candidate of full length is the faster
-//       one: 2.7 against 6.1 ms for Yaz0 at quality 15, 0.50 against 1.52 for LZSS.)
+//   B   MatchSearch for every position: the kernels with one position per lane (enc_match_kernel; enc_match_dyn_kernel where matches are
+//       short), on as many workgroups as the stream has blocks; a candidate that cannot win is not measured.  (Not the two-phase kernel the
+//       synthetic batches use from maxChain 3 on: it walks every chain to its end before it compares, and on a lone stream of real data --
+//       Test.bmp: runs, repeated rows -- the walk that ends at the first candidate of full length is the faster one: 2.7 against 6.1 ms for
+//       Yaz0 at quality 15, 0.50 against 1.52 for LZSS.)
 //   C   the greedy / lazy parse (FindNextBestMatch :157-212) is a walk "cursor += jump[cursor]", and jump[p] -- what the parse does IF its
 //       cursor is at p: no match, a match here, or a literal and the better match at p + 1 -- is a pure function of match[p] and match[p + 1].
 //       A linked list through the positions: the cursors are the nodes reachable from 0, found by list ranking (mark + square the jump
