@@ -9,6 +9,10 @@ from auroralib.compression_amd import _abi as A
 from auroralib.compression_amd.batch import Context
 
 bmp = O.container_decompress(A.C_LZSS, open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read(), lz=A.LzProperties.from_bits(10, 6, 2))[0]
+if os.environ.get("ALZ_SINGLE_DATA") == "text":           # program text and prose: the repository's own sources and documents
+    import glob
+    files = sorted(f for pat in ("*.md", "*.hip", "*.h", "*.py", "*.cs", "*.cpp") for f in glob.glob(os.path.join(ROOT, "**", pat), recursive=True) if "gpurun_out" not in f)
+    bmp = b"".join(open(f, "rb").read() for f in files)
 raw = bytes(bmp[:1024000]); n = len(raw)
 c = Context(0)
 names = sys.argv[1:] or ["lzss", "lz10", "lz11", "yaz0", "yay0", "mio0"]
