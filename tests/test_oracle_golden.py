@@ -165,3 +165,17 @@ def test_committed_oracle_vectors(test_bmp):
         name, size, q = key.split(":")
         comp = O.container_compress(getattr(A, "C_" + name), test_bmp[:int(size)], quality=int(q[1:]))
         assert (len(comp), "%016x" % O.xxh64(comp)) == (length, digest), key
+
+
+def test_lzo_two_literal_runs_in_a_row_is_the_reference():
+    """A quirk of the reference that parity keeps: LZO.CompressHeaderless (Formats/Common/LZO.cs:167-188) moves a match that starts within the
+    first three bytes to offset 4 and shortens it; when fewer than three bytes of it are left the match is dropped -- and the literals behind it
+    go out as a SECOND literal-run instruction right behind the first.  In LZO1X a byte below 16 behind a literal run is a match, not a run
+    (LZO.cs:70-95: the run sets plain = 4, and flag code 0 with plain > 3 is "D = 2049-3072, L = 3"), so the reference's own decoder does not read this stream back.  Found on program text (five spaces, then code: a match at
+    offset 1, distance 1, length 4); the bytes below follow from the C# by hand: run of 4 = 0x01 + 4 literals, run of 12 = 0x09 + 12 literals,
+    the end token 0x11 0x00 0x00."""
+    raw = b"     const u32 x"
+    comp, _ = O.encode_stream(A.FMT_LZO, raw, quality=0)
+    assert comp == bytes([0x01]) + raw[:4] + bytes([0x09]) + raw[4:] + bytes([0x11, 0x00, 0x00])
+    out, r = O.decode_stream(A.FMT_LZO, comp, decom_len=0, cap=64)
+    assert out != raw                                              # (what the managed decoder makes of it: not the input)
