@@ -1,5 +1,7 @@
 """Decode throughput on program text and prose: 4 096 windows of 256 KiB of the repository's own sources (1.7 MB, so the windows overlap), encoded
-on the GPU at quality 8, decoded as one device-resident batch -- beside bench.py's realistic_* entries (a bitmap) and the synthetic bodies."""
+on the GPU at quality 8, decoded as one device-resident batch -- beside bench.py's realistic_* entries (a bitmap) and the synthetic bodies.
+(LZO reports "round trip False": some windows start with a short run, where the reference's encoder writes a stream its decoder does not read
+back -- tests/test_oracle_golden.py::test_lzo_two_literal_runs_in_a_row_is_the_reference; the GPU's bytes are the reference's.)"""
 import os, sys, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
