@@ -1,4 +1,6 @@
 """Hand-crafted edge-case streams shared by the CPU (oracle ring vs flat) and GPU parity tests."""
+import numpy as np
+
 from auroralib.compression_amd import _abi as A
 
 
@@ -107,3 +109,19 @@ def unaligned_items():
         items.append(dict(fmt=A.FMT_YAZ0, src=s, decom_len=5000, src_misalign=1, dst_misalign=1))
         items.append(dict(fmt=A.FMT_LZ4_BLOCK, src=O.encode_stream(A.FMT_LZ4_BLOCK, s + s, quality=4)[0], decom_len=0, cap=len(s) * 2, src_misalign=3, dst_misalign=5))
     return items
+
+
+def prose_like(size, seed):
+    """Deterministic prose-like bytes: words of a small vocabulary with a skewed distribution, punctuation, indentation, line breaks --
+    short matches at many distances, frequent lazy-parse decisions (what a bitmap does not have)."""
+    rng = np.random.default_rng(seed)
+    vocab = [bytes(rng.integers(97, 123, int(rng.integers(1, 10)), dtype=np.uint8)) for _ in range(600)]
+    w = 1.0 / np.arange(1, len(vocab) + 1) ** 1.1
+    w /= w.sum()
+    out, total = [], 0
+    while total < size:
+        k = int(rng.integers(3, 14))
+        words = [vocab[i] for i in rng.choice(len(vocab), k, p=w)]
+        line = b" " * (4 * int(rng.integers(0, 4))) + b" ".join(words) + (b";" if rng.random() < 0.3 else b".") + b"\n"
+        out.append(line); total += len(line)
+    return b"".join(out)[:size]

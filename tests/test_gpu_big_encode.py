@@ -11,6 +11,7 @@ import pytest
 import oracle_lib as O
 from auroralib.compression_amd import _abi as A
 from auroralib.compression_amd.batch import Context
+from cases import prose_like
 
 pytestmark = pytest.mark.gpu
 FMTS = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON]
@@ -242,3 +243,14 @@ def test_big_encode_fuzz(fmt, test_bmp):
             want_len = len(O.encode_stream(fmt, raw, quality=q)[0])
             cap = rng.choice([_cap(len(raw)), want_len, want_len + rng.randrange(1, 100), max(1, want_len - rng.randrange(1, 100))])
             _encode(c, [(fmt, raw)], q, caps=[cap], expect_big=True, what="fuzz %d (seed %d)" % (k, seed))
+
+
+@pytest.mark.parametrize("fmt", NORTH)
+def test_prose_like_input_both_paths(fmt):
+    """Text instead of a bitmap, through the whole-GPU path (a call of three buffers) and through the batch pipeline (forty): the oracle's bytes."""
+    with Context(0) as c:
+        for q in (0, 5, 8, 12):
+            three = [(fmt, prose_like(150000 + 7777 * i, 100 * q + i)) for i in range(3)]
+            _encode(c, three, q, expect_big=True, what="text, three")
+            forty = [(fmt, prose_like(9000 + 613 * i, 900 + 40 * q + i)) for i in range(40)]
+            _encode(c, forty, q, expect_big=False, what="text, forty")

@@ -235,3 +235,18 @@ def test_big_stream_fuzz(fmt, test_bmp):
             if cap < 98304:
                 cap = 98304
             _one(c, fmt, bytes(b), decl, aux.aux0, aux.aux1, cap=max(cap, decl) if fmt not in ELEM else cap, what="fuzz %d kind %d" % (k, kind))
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_prose_like_streams(fmt):
+    """Text instead of a bitmap or the synthetic mix: short matches at many distances, three times the tokens per output byte -- one stream on the
+    whole GPU and on its wavefronts, against the oracle."""
+    from cases import prose_like
+    with Context(0) as c:
+        for size, q in ((40000, 0), (300000, 8), (1 << 20, 12)):
+            raw = prose_like(size, size + q)
+            comp, aux = O.encode_stream(fmt, raw, quality=q)
+            _one(c, fmt, comp, size, aux.aux0, aux.aux1, expect_big=fmt not in ELEM or len(comp) >= 8192, what="prose %d" % size)
+            c.big_stream(OFF)
+            _one(c, fmt, comp, size, aux.aux0, aux.aux1, expect_big=False, what="prose %d, wavefront kernels" % size)
+            c.big_stream(24 << 10)
