@@ -250,3 +250,13 @@ def test_prose_like_streams(fmt):
             c.big_stream(OFF)
             _one(c, fmt, comp, size, aux.aux0, aux.aux1, expect_big=False, what="prose %d, wavefront kernels" % size)
             c.big_stream(24 << 10)
+        if fmt == A.FMT_LZO:
+            # the reference's encoder writes two literal runs in a row here (tests/test_oracle_golden.py): its decoder reads the second as a
+            # match from far in front of the stream -- whatever comes out, both paths must produce the oracle's bytes, status and lengths
+            raw = b"     " + prose_like(200000, 5)
+            comp, aux = O.encode_stream(fmt, raw, quality=0)
+            assert O.decode_stream(fmt, comp, decom_len=0, cap=len(raw))[0] != raw
+            _one(c, fmt, comp, len(raw), 0, 0, what="two literal runs")
+            c.big_stream(OFF)
+            _one(c, fmt, comp, len(raw), 0, 0, expect_big=False, what="two literal runs, wavefront kernels")
+            c.big_stream(24 << 10)
