@@ -18,6 +18,21 @@ for f in (sys.argv[1:] or ["yaz0", "lz10"]):
     fmt = A.FORMAT_NAMES.index(f)
     for n in (1, 1024, 3584, 6144, 10000):
         b = synth.make_batch(fmt, n, 262144, synth.seed_for(2))
+        if os.environ.get("ALZ_PHASE_DATA") == "text":         # 16 windows of program text (the repository's own sources), encoded by the oracle at quality 8, repeated
+            import glob
+            import oracle_lib as O
+            files = sorted(f for pat in ("*.md", "*.hip", "*.h", "*.py", "*.cs", "*.cpp") for f in glob.glob(os.path.join(ROOT, "**", pat), recursive=True) if "gpurun_out" not in f and "build/" not in f)
+            text = b"".join(open(f, "rb").read() for f in files)
+            comps = [O.encode_stream(fmt, text[k * 90000:k * 90000 + 262144], quality=8) for k in range(16)]
+            offs, chunks, o = [], [], 0
+            for c_, _a in comps:
+                offs.append(o); chunks.append(c_ + bytes((-len(c_)) % 16)); o += len(chunks[-1])
+            src = np.frombuffer(b"".join(chunks) + bytes(64), dtype=np.uint8).copy()
+            rec = synth.stream_records(b.streams)
+            w = np.arange(n) % 16
+            rec["src_off"] = np.array(offs, dtype=np.uint64)[w]; rec["src_len"] = np.array([len(c_) for c_, _ in comps], dtype=np.uint32)[w]
+            rec["aux0"] = np.array([a.aux0 for _, a in comps], dtype=np.uint32)[w]; rec["aux1"] = np.array([a.aux1 for _, a in comps], dtype=np.uint32)[w]
+            b.src = src
         d_src, d_dst = ctx.malloc(b.src.nbytes + 64), ctx.malloc(b.dst_bytes + 64)
         ctx.h2d(d_src, b.src)
         p = Plan(ctx, b.streams)
