@@ -56,8 +56,9 @@ class Context:
         check(self.lib.alz_ctx_set_kernel_variant(self.h, variant))
 
     def big_stream(self, min_bytes=0):
-        """alz_ctx_big_stream: threshold of the whole-GPU path for ONE Yay0 / MIO0 stream (0 keeps it, 0xFFFFFFFF switches it off);
-        returns how often the path has been taken on this context."""
+        """alz_ctx_big_stream: threshold of the whole-GPU paths for ONE stream of the north-star bodies -- decode from `min_bytes` of output on
+        (default 24 KiB), encode from min(min_bytes, 8 KiB) of input on; 0 keeps the current value, 0xFFFFFFFF switches both paths off.
+        Returns how many streams have taken either path on this context."""
         n = C.c_uint64()
         check(self.lib.alz_ctx_big_stream(self.h, min_bytes, C.byref(n)))
         return n.value
