@@ -684,6 +684,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
     // at a candidate or at the position may run up to four bytes past the stream: inside the staging buffer's slack, never compared
     // (lengths are clamped to cmp_max).
     const u64 head = load64(dp), head2 = load64(dp + 8);
+    u64 own_bl = 0;                                                     // PRUNE: the position's eight bytes up to offset best_l (best_l >= 16)
     bool act = cur != -1, capped = false;
     const int chain = g.max_chain;
     for (int it = 0; it < chain; it++) {
@@ -694,29 +695,32 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
         // (a candidate out of reach is not touched: the previous position with this hash usually lies further back than a 4 KiB window
         //  reaches, anywhere in the stream -- an 8-byte read that misses every cache and is thrown away)
         const int cl = within ? c : pos;
-        u64 cv[2]; __builtin_memcpy(cv, data + cl, 16);                 // (the candidate's sixteen bytes as ONE load: the second eight cost no lookup of their own)
-        const u64 x = head ^ cv[0];
         const int nxt = (within && it + 1 < chain) ? link_at<L16>(p4, cl) : -1;   // (the last candidate's link is never followed: at maxChain 1 that is every one)
-        const bool ok = within && dist >= g.min_dist;                   // closer than minDistance: skipped, the walk goes on  :262-266
+        bool ok = within && dist >= g.min_dist;                         // closer than minDistance: skipped, the walk goes on  :262-266
+        if (PRUNE && g.nprops <= 1) {
+            // A candidate wins only with a LONGER match than the best so far (ScoreMatch :301-321 with one property set is the length, cut to
+            // the distance in CompatibilityMode): one whose eight bytes up to offset best_l differ from the position's cannot, and is not
+            // looked at any further -- one load instead of its sixteen bytes, the compare loop and what follows.  The kernel is bound by the
+            // L1's lookups (a scattered load costs one per lane), and in the runs and repeated rows of real data nearly every candidate
+            // behind the first good one ends here.
+            const bool chk = ok && best_l >= 16;
+            if (__ballot(chk)) {
+                const u64 pb = load64(data + (chk ? cl + best_l - 7 : pos));
+                if (chk && pb != own_bl) ok = false;
+            }
+        }
+        const int cl2 = ok ? cl : pos;                                  // (a candidate that is out: its bytes are not fetched)
+        u64 cv[2]; __builtin_memcpy(cv, data + cl2, 16);                // (the candidate's sixteen bytes as ONE load: the second eight cost no lookup of their own)
+        const u64 x = head ^ cv[0];
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
         if (__ballot(more)) {
             // the second eight bytes the same way (most formats' matches end inside them); the compare loop only behind sixteen
             const u64 y = head2 ^ cv[1];
             if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
-            bool more2 = more && y == 0ull && cmp_max > 16;
-            if (PRUNE && g.nprops <= 1) {
-                // (ONE stream of real data -- alz_encode_big.h: a candidate wins only with a longer match than the best so far, so one whose
-                // bytes around offset best_l differ is not measured -- it counts as sixteen bytes, which cannot win.  In the repeated rows and
-                // runs of Test.bmp every candidate of a chain matches up to the same place, and the compare loop below runs for the whole
-                // wavefront as long as its longest lane: a 1 000 KiB Yaz0 stream at quality 8 0.58 -> 0.29 ms, an LZ4 block at quality 15 15 -> 5.8.)
-                const bool chk = more2 && best_l >= 16;
-                if (__ballot(chk)) {
-                    const int o = chk ? best_l - 7 : 0;
-                    const u64 pa = load64(dp + o), pb = load64(data + (chk ? c : pos) + o);
-                    if (chk && pa != pb) more2 = false;
-                }
-            }
+            const bool more2 = more && y == 0ull && cmp_max > 16;
+            // (the compare loop runs for the whole wavefront as long as its longest lane: with the test above a 1 000 KiB Yaz0 stream at
+            // quality 8 went 0.58 -> 0.29 ms, an LZ4 block at quality 15 15 -> 5.8)
             if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
         }
         if (len > cmp_max) len = cmp_max;
@@ -730,6 +734,7 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
             const int score = l2 - g.min_len;
             const bool better = ok && !hitcap && score > best_score;
             best_score = better ? score : best_score; best_l = better ? l2 : best_l; best_d = better ? dist : best_d;
+            if (PRUNE) { const bool rl = better && best_l >= 16 && best_l < best_possible; if (__ballot(rl)) { const u64 v = load64(dp + (rl ? best_l - 7 : 0)); if (rl) own_bl = v; } }
             capped = capped || hitcap;
             stop = stop || hitcap || (better && l2 == best_possible);
         } else if (ok) {
@@ -1032,7 +1037,7 @@ __global__ __launch_bounds__(256) void enc_match_dyn_kernel(const u8* __restrict
     const int chain = g.max_chain, cap = g.b_cap;
     // lane state: the position (-1: none), its walk
     int pos = -1, cur = -1, it = 0, best_l = 0, best_d = 0, best_score = -1, best_possible = 0, cmp_max = 0;
-    bool capped = false; u64 head = 0, head2 = 0;
+    bool capped = false; u64 head = 0, head2 = 0, own_bl = 0;
     for (;;) {
         const u64 idle = __ballot(pos < 0);
         if (idle && nextp <= wlast) {
@@ -1056,22 +1061,24 @@ __global__ __launch_bounds__(256) void enc_match_dyn_kernel(const u8* __restrict
         const int dist = pos - c;
         const bool within = act && dist <= g.max_dist;
         const int cl = within ? c : (have ? pos : 0);
-        u64 cv[2]; __builtin_memcpy(cv, data + cl, 16);
-        const u64 x = head ^ cv[0];
         const int nxt = (within && it + 1 < chain) ? link_at<true>(p4, cl) : -1;
-        const bool ok = within && dist >= g.min_dist;
+        bool ok = within && dist >= g.min_dist;
+        {   // (a candidate whose eight bytes up to offset best_l differ cannot win: match_search_b)
+            const bool chk = ok && best_l >= 16;
+            if (__ballot(chk)) {
+                const u64 pb = load64(data + (chk ? cl + best_l - 7 : 0));
+                if (chk && pb != own_bl) ok = false;
+            }
+        }
+        const int cl2 = ok ? cl : (have ? pos : 0);
+        u64 cv[2]; __builtin_memcpy(cv, data + cl2, 16);
+        const u64 x = head ^ cv[0];
         int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
         const bool more = ok && x == 0ull && cmp_max > 8;
         if (__ballot(more)) {
             const u64 yv = head2 ^ cv[1];
             if (more) len = 8 + (yv ? (int)(__builtin_ctzll(yv) >> 3) : 8);
-            bool more2 = more && yv == 0ull && cmp_max > 16;
-            const bool chk = more2 && best_l >= 16;
-            if (__ballot(chk)) {
-                const int o = chk ? best_l - 7 : 0;
-                const u64 pa = load64(dp + o), pb = load64(data + (chk ? c : 0) + o);
-                if (chk && pa != pb) more2 = false;
-            }
+            const bool more2 = more && yv == 0ull && cmp_max > 16;
             if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
         }
         if (len > cmp_max) len = cmp_max;
@@ -1081,6 +1088,7 @@ __global__ __launch_bounds__(256) void enc_match_dyn_kernel(const u8* __restrict
         const int score = l2 - g.min_len;
         const bool better = ok && !hitcap && score > best_score;
         best_score = better ? score : best_score; best_l = better ? l2 : best_l; best_d = better ? dist : best_d;
+        { const bool rl = better && best_l >= 16 && best_l < best_possible; if (__ballot(rl)) { const u64 v = load64(dp + (rl ? best_l - 7 : 0)); if (rl) own_bl = v; } }
         capped = capped || hitcap;
         const bool stop = !within || hitcap || (better && l2 == best_possible);
         cur = nxt; it++;
