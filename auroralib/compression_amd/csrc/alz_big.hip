@@ -208,6 +208,26 @@ __global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, co
     if (!(w & BIG_LIT)) *flag_cur = 1u;
 }
 
+// J0: the same inside tiles of 1 024 output bytes, in LDS -- ten rounds; what is left unresolved points in front of its tile, and a chain of such
+// entries crosses at least one tile boundary per hop: ceil(log2 tiles) + 1 rounds of big_jump instead of ceil(log2 tokens) + 1 (11 instead of 19
+// launches for a 1 000 KiB stream -- a launch is ~4 us whatever it does)
+__global__ __launch_bounds__(1024) void big_jump_tile(u32* __restrict__ val, u32 n, const u32* __restrict__ dev_n) {
+    __shared__ u32 V[1024];
+    if (dev_n) { const u32 m = *dev_n; if (m < n) n = m; }
+    const u32 ts = blockIdx.x * 1024u, tid = threadIdx.x, q = ts + tid;
+    if (ts >= n) return;
+    V[tid] = q < n ? val[q] : BIG_LIT;
+    __syncthreads();
+    for (u32 r = 0; r < 10u; r++) {
+        const u32 v = V[tid];
+        const u32 w = (!(v & BIG_LIT) && v >= ts) ? V[v - ts] : v;   // (a source lies in front of its byte)
+        __syncthreads();
+        V[tid] = w;
+        __syncthreads();
+    }
+    if (q < n) val[q] = V[tid];
+}
+
 // W: bytes out, result, gate
 // (DEVSIZE: the output size is ctl[C_SIZE], at most `a.size` = the room in the destination)
 template <bool DEVSIZE>
@@ -849,7 +869,8 @@ static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const
     hipLaunchKernelGGL(big_len_offsets, dim3(L.ttiles), dim3(64), 0, stream, tlen, ctl, tile_lb, toff);
     const u32 nb = (st->decom_len + 255u) / 256u;
     hipLaunchKernelGGL((big_emit_bytes<FMT == ALZ_FMT_LZSS>), dim3(nb), dim3(256), 0, stream, st->decom_len, gm, toff, tlen, tdesc, tend, val, ctl);
-    const u32 rounds = big_rounds(L.max_nt);
+    hipLaunchKernelGGL(big_jump_tile, dim3((st->decom_len + 1023u) / 1024u), dim3(1024), 0, stream, val, st->decom_len, (const u32*)nullptr);
+    const u32 rounds = big_rounds((st->decom_len + 1023u) / 1024u + 1u);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->decom_len, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
@@ -886,7 +907,8 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     // (LZ4 decodes its WHOLE input -- sequences that add no output may follow the last output byte, e.g. a lone zero token --, so
     // source.Position is the end of the input and not the end of the last token with output: found by tools/soak.sh, seed 9488)
     hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src, LZ4);
-    const u32 rounds = big_rounds(L.max_nt);
+    hipLaunchKernelGGL(big_jump_tile, dim3((st->dst_cap + 1023u) / 1024u), dim3(1024), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE));
+    const u32 rounds = big_rounds((st->dst_cap + 1023u) / 1024u + 1u);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
@@ -928,7 +950,8 @@ static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const 
     const u32 nb = (st->dst_cap + 255u) / 256u;
     BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
     hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src, true);
-    const u32 rounds = big_rounds(L.max_nt);
+    hipLaunchKernelGGL(big_jump_tile, dim3((st->dst_cap + 1023u) / 1024u), dim3(1024), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE));
+    const u32 rounds = big_rounds((st->dst_cap + 1023u) / 1024u + 1u);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
@@ -967,7 +990,7 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     u32* tile_l = (u32*)p; p += tl; u32* tile_ob = (u32*)p; p += tl;
     u32* toff = (u32*)p; p += ta; u32* tlen = (u32*)p; p += ta; u32* tdesc = (u32*)p; p += ta; u32* tend = (u32*)p; p += ta;
     u32* ctl = (u32*)p;
-    const u32 rounds = big_rounds(a.ntok);
+    const u32 rounds = big_rounds((a.size + 1023u) / 1024u + 1u);      // (behind big_jump_tile: see there)
     hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_NT), (int)a.ntok, 1, stream);
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);   // round 0 of the jumping always runs: its "previous flag" holds 1
@@ -988,6 +1011,7 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     const u32 nb = (a.size + 255u) / 256u;
     BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
     hipLaunchKernelGGL((big_emit_bytes<false>), dim3(nb), dim3(256), 0, stream, a.size, gm, toff, tlen, tdesc, tend, val, ctl);
+    hipLaunchKernelGGL(big_jump_tile, dim3((a.size + 1023u) / 1024u), dim3(1024), 0, stream, val, a.size, (const u32*)nullptr);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, a.size, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
