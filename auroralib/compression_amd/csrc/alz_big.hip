@@ -208,6 +208,14 @@ __global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, co
     if (!(w & BIG_LIT)) *flag_cur = 1u;
 }
 
+// what a launch sequence needs initialised, in one launch: the control words (zero; flag 0 of the pointer jumping = 1; C_NT / C_TERM as given) and
+// the marks of the list ranking (zero; node 0 = 1)
+__global__ __launch_bounds__(256) void big_init(u32* __restrict__ ctl, u32 nt, u32 term, u8* __restrict__ mark, u32 nmark) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < C_FLAGS + 40u) ctl[i] = i == (u32)C_FLAGS ? 1u : i == (u32)C_NT ? nt : i == (u32)C_TERM ? term : 0u;
+    if (mark && i < nmark) mark[i] = i == 0u ? 1 : 0;
+}
+
 // J0: the same inside tiles of 1 024 output bytes, in LDS -- ten rounds; what is left unresolved points in front of its tile, and a chain of such
 // entries crosses at least one tile boundary per hop: ceil(log2 tiles) + 1 rounds of big_jump instead of ceil(log2 tokens) + 1 (11 instead of 19
 // launches for a 1 000 KiB stream -- a launch is ~4 us whatever it does)
@@ -851,11 +859,7 @@ static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const
     u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
     u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
     u32* tile_l = (u32*)(base + L.tile_l); u32* tile_lb = (u32*)(base + L.tile_lb); u32* ctl = (u32*)(base + L.ctl);
-    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)L.nodes + 64, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);                       // the first group starts at byte 0
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(big_init, dim3((L.nodes + 64u + 255u) / 256u), dim3(256), 0, stream, ctl, 0u, 0u, mark, L.nodes + 64u);   // (the first group starts at byte 0)
     const u32 nbn = (L.nodes + 255u) / 256u;
     u32* next1 = (u32*)(base + L.next1);
     hipLaunchKernelGGL((big_group_sizes<FMT>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, next1);
@@ -885,11 +889,7 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
     u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
     u32* tile_l = (u32*)(base + L.tile_l); u32* tile_lb = (u32*)(base + L.tile_lb); u32* ctl = (u32*)(base + L.ctl);
-    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)L.nodes + 64, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(big_init, dim3((L.nodes + 64u + 255u) / 256u), dim3(256), 0, stream, ctl, 0u, 0u, mark, L.nodes + 64u);   // (the first group starts at byte 0)
     const u32 nbn = (L.nodes + 255u) / 256u;
     u32* next1 = (u32*)(base + L.next1);
     hipLaunchKernelGGL((big_elem_sizes<LZ4>), dim3(nbn), dim3(256), 0, stream, src, st->src_len, next1);
@@ -926,12 +926,7 @@ static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const 
     u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
     u32* tlen = (u32*)(base + L.tlen); u32* tdesc = (u32*)(base + L.tdesc); u32* tend = (u32*)(base + L.tend); u32* toff = (u32*)(base + L.toff);
     u32* tile_l = (u32*)(base + L.tile_l); u32* tile_lb = (u32*)(base + L.tile_lb); u32* ctl = (u32*)(base + L.ctl);
-    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 0, (size_t)L.nodes + 64, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(mark, 1, 1, stream);                       // node (byte 0, nothing pending)
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_TERM), -1, 1, stream);
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(big_init, dim3((L.nodes + 64u + 255u) / 256u), dim3(256), 0, stream, ctl, 0u, 0xFFFFFFFFu, mark, L.nodes + 64u);   // (node (byte 0, nothing pending) starts the chain)
     const u32 nbn = (L.nodes + 255u) / 256u;
     const u32 real_nodes = L.nodes - NST;                         // the nodes of the bytes that exist (the end node is the first behind them)
     u32* next1 = (u32*)(base + L.next1);
@@ -991,10 +986,7 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     u32* toff = (u32*)p; p += ta; u32* tlen = (u32*)p; p += ta; u32* tdesc = (u32*)p; p += ta; u32* tend = (u32*)p; p += ta;
     u32* ctl = (u32*)p;
     const u32 rounds = big_rounds((a.size + 1023u) / 1024u + 1u);      // (behind big_jump_tile: see there)
-    hipError_t e = hipMemsetAsync(ctl, 0, (C_FLAGS + 40) * 4, stream);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_NT), (int)a.ntok, 1, stream);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ctl + C_FLAGS), 1, 1, stream);   // round 0 of the jumping always runs: its "previous flag" holds 1
-    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(big_init, dim3(1), dim3(256), 0, stream, ctl, a.ntok, 0u, (u8*)nullptr, 0u);   // (round 0 of the jumping always runs: its "previous flag" holds 1)
     const bool mio0 = fmt == ALZ_FMT_MIO0;
     hipLaunchKernelGGL(big_count_matches, dim3(a.ntiles), dim3(64), 0, stream, a, tile_m);
     hipLaunchKernelGGL(big_scan, dim3(1), dim3(1024), 0, stream, tile_m, tile_mb, a.ntiles, (u32*)nullptr);
