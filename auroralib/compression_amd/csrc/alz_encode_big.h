@@ -251,9 +251,10 @@ __global__ __launch_bounds__(1024) void benc_tile_exit(BencArgs a, EncGeom g, co
 __global__ __launch_bounds__(256) void benc_rank_round(const u32* __restrict__ jump_a, u32* __restrict__ jump_b, u8* __restrict__ mark, u32 nodes) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= nodes) return;
-    const u32 j = jump_a[p];
-    if (mark[p]) mark[j] = 1;
-    jump_b[p] = jump_a[j];
+    // (TWO rounds per launch: the table to the fourth power, a marked node marks the three nodes on the way -- alz_big.hip)
+    const u32 j1 = jump_a[p], j2 = jump_a[j1], j3 = jump_a[j2];
+    if (mark[p]) { mark[j1] = 1; mark[j2] = 1; mark[j3] = 1; }
+    jump_b[p] = jump_a[j3];
 }
 
 // the last level: the parse enters the tile at the node the rounds marked (at most one; node 0 in the first tile); eleven rounds of the same
@@ -959,7 +960,7 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     u32* next1 = (u32*)(base + L.next1);
     if (caps) hipLaunchKernelGGL((benc_tile_exit<false>), dim3(rtiles), dim3(1024), 0, stream, a, g, match, ml, md, next1, jump_a, sr);
     else hipLaunchKernelGGL((benc_tile_exit<true>), dim3(rtiles), dim3(1024), 0, stream, a, g, match, ml, md, next1, jump_a, sr);
-    const u32 rr = benc_rounds(rtiles + 1u);
+    const u32 rr = (benc_rounds(rtiles + 1u) + 1u) / 2u;           // (a launch is two rounds)
     for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(benc_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, a.nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
     hipLaunchKernelGGL(benc_tile_mark, dim3(rtiles), dim3(1024), 0, stream, a, next1, sr, ml, mark, ctl);
     // D: the tokens
