@@ -38,6 +38,10 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define BIG_TILE 1024u          /* tokens per tile (one wavefront, 16 rounds of 64 tokens) */
+#ifndef BIG_LOG
+#define BIG_LOG 2u              /* rounds of list ranking / pointer jumping per launch (big_rank_round, big_jump) */
+#endif
+#define BIG_HOPS (1u << BIG_LOG)
 #define BIG_LIT 0x80000000u
 
 struct BigArgs {
@@ -203,11 +207,11 @@ __global__ __launch_bounds__(256) void big_jump(u32* __restrict__ val, u32 n, co
     if (q >= n) return;
     const u32 v = val[q];
     if (v & BIG_LIT) return;
-    // (three hops per launch: every entry read spans at least as many hops as all entries did when the launch began, so a launch multiplies
-    // the span by four -- two rounds' worth -- whatever the other threads have or have not written yet)
-    u32 w = __hip_atomic_load(val + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!(w & BIG_LIT)) w = __hip_atomic_load(val + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!(w & BIG_LIT)) w = __hip_atomic_load(val + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (BIG_HOPS - 1 hops per launch: every entry read spans at least as many hops as all entries did when the launch began, so a launch multiplies
+    // the span by BIG_HOPS -- BIG_LOG rounds' worth -- whatever the other threads have or have not written yet)
+    u32 w = v;
+#pragma unroll
+    for (u32 k = 1; k < BIG_HOPS; k++) if (!(w & BIG_LIT)) w = __hip_atomic_load(val + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     val[q] = w;
     if (!(w & BIG_LIT)) *flag_cur = 1u;
 }
@@ -306,14 +310,16 @@ __global__ __launch_bounds__(256) void big_group_sizes(const u8* __restrict__ sr
 }
 
 // P2: one round of list ranking
-// (TWO rounds per launch: the jump table to the fourth power, a marked node marks the three nodes on the way -- four dependent reads of the old table
-// instead of two launches of two; a launch costs ~4 us whatever it does)
+// (BIG_LOG rounds per launch: the jump table to the power BIG_HOPS = 2^BIG_LOG, a marked node marks the nodes on the way -- BIG_HOPS dependent reads of
+// the old table instead of BIG_LOG launches of two; a launch costs ~4 us whatever it does)
 __global__ __launch_bounds__(256) void big_rank_round(const u32* __restrict__ jump_a, u32* __restrict__ jump_b, u8* __restrict__ mark, u32 nodes) {
     const u32 p = blockIdx.x * 256u + threadIdx.x;
     if (p >= nodes) return;
-    const u32 j1 = jump_a[p], j2 = jump_a[j1], j3 = jump_a[j2];
-    if (mark[p]) { mark[j1] = 1; mark[j2] = 1; mark[j3] = 1; }
-    jump_b[p] = jump_a[j3];
+    u32 j = jump_a[p];
+    const bool m = mark[p] != 0;
+#pragma unroll
+    for (u32 k = 1; k < BIG_HOPS; k++) { if (m) mark[j] = 1; j = jump_a[j]; }
+    jump_b[p] = j;
 }
 
 // P2 on two levels (round 4, from the encoder's whole-GPU path, alz_encode_big.h): a round over all nodes is a launch (~4 us whatever it
@@ -799,7 +805,7 @@ static u32 big_rounds(u32 n) { u32 r = 1; while ((1ull << r) < n) r++; return r 
 static void big_rank(hipStream_t stream, const u32* next1, u32* jump_a, u32* jump_b, u8* mark, u32 nodes) {
     const u32 rtiles = (nodes + BIG_RTILE - 1u) / BIG_RTILE, nbn = (nodes + 255u) / 256u;
     hipLaunchKernelGGL(big_tile_exit, dim3(rtiles), dim3(1024), 0, stream, next1, jump_a, nodes);
-    const u32 rr = (big_rounds(rtiles + 1u) + 1u) / 2u;              // (a launch is two rounds)
+    const u32 rr = (big_rounds(rtiles + 1u) + BIG_LOG - 1u) / BIG_LOG;   // (a launch is BIG_LOG rounds)
     for (u32 r = 0; r < rr; r++) { hipLaunchKernelGGL(big_rank_round, dim3(nbn), dim3(256), 0, stream, jump_a, jump_b, mark, nodes); u32* t = jump_a; jump_a = jump_b; jump_b = t; }
     hipLaunchKernelGGL(big_tile_mark, dim3(rtiles), dim3(1024), 0, stream, next1, mark, nodes);
 }
@@ -880,7 +886,7 @@ static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const
     const u32 nb = (st->decom_len + 255u) / 256u;
     hipLaunchKernelGGL((big_emit_bytes<FMT == ALZ_FMT_LZSS>), dim3(nb), dim3(256), 0, stream, st->decom_len, gm, toff, tlen, tdesc, tend, val, ctl);
     hipLaunchKernelGGL(big_jump_tile, dim3((st->decom_len + 1023u) / 1024u), dim3(1024), 0, stream, val, st->decom_len, (const u32*)nullptr);
-    const u32 rounds = (big_rounds((st->decom_len + 1023u) / 1024u + 1u) + 1u) / 2u;   // (a launch of big_jump is two rounds)
+    const u32 rounds = (big_rounds((st->decom_len + 1023u) / 1024u + 1u) + BIG_LOG - 1u) / BIG_LOG;   // (a launch of big_jump is BIG_LOG rounds)
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->decom_len, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
@@ -914,7 +920,7 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     // source.Position is the end of the input and not the end of the last token with output: found by tools/soak.sh, seed 9488)
     hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src, LZ4);
     hipLaunchKernelGGL(big_jump_tile, dim3((st->dst_cap + 1023u) / 1024u), dim3(1024), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE));
-    const u32 rounds = (big_rounds((st->dst_cap + 1023u) / 1024u + 1u) + 1u) / 2u;   // (a launch of big_jump is two rounds)
+    const u32 rounds = (big_rounds((st->dst_cap + 1023u) / 1024u + 1u) + BIG_LOG - 1u) / BIG_LOG;   // (a launch of big_jump is BIG_LOG rounds)
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
@@ -952,7 +958,7 @@ static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const 
     BigGeom gm; gm.length_bits = gm.min_length = gm.windows_start = gm.max_distance = gm.W = 0;
     hipLaunchKernelGGL((big_emit_bytes<false, true>), dim3(nb), dim3(256), 0, stream, st->dst_cap, gm, toff, tlen, tdesc, tend, val, ctl, src, true);
     hipLaunchKernelGGL(big_jump_tile, dim3((st->dst_cap + 1023u) / 1024u), dim3(1024), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE));
-    const u32 rounds = (big_rounds((st->dst_cap + 1023u) / 1024u + 1u) + 1u) / 2u;   // (a launch of big_jump is two rounds)
+    const u32 rounds = (big_rounds((st->dst_cap + 1023u) / 1024u + 1u) + BIG_LOG - 1u) / BIG_LOG;   // (a launch of big_jump is BIG_LOG rounds)
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
@@ -991,7 +997,7 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     u32* tile_l = (u32*)p; p += tl; u32* tile_ob = (u32*)p; p += tl;
     u32* toff = (u32*)p; p += ta; u32* tlen = (u32*)p; p += ta; u32* tdesc = (u32*)p; p += ta; u32* tend = (u32*)p; p += ta;
     u32* ctl = (u32*)p;
-    const u32 rounds = (big_rounds((a.size + 1023u) / 1024u + 1u) + 1u) / 2u;   // (a launch of big_jump is two rounds)      // (behind big_jump_tile: see there)
+    const u32 rounds = (big_rounds((a.size + 1023u) / 1024u + 1u) + BIG_LOG - 1u) / BIG_LOG;   // (a launch of big_jump is BIG_LOG rounds)      // (behind big_jump_tile: see there)
     hipLaunchKernelGGL(big_init, dim3(1), dim3(256), 0, stream, ctl, a.ntok, 0u, (u8*)nullptr, 0u);   // (round 0 of the jumping always runs: its "previous flag" holds 1)
     const bool mio0 = fmt == ALZ_FMT_MIO0;
     hipLaunchKernelGGL(big_count_matches, dim3(a.ntiles), dim3(64), 0, stream, a, tile_m);
