@@ -2290,16 +2290,25 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
         if (start && !fits) fail = true;
         if (fits) {
             F::put_lit_hdr(dst + off, L, M, false);
-            if (L <= ALZ_SEQ_LANE_LIT) for (u32 i = 0; i < L; i++) dst[off + lh + i] = src[before + i];
             F::put_match(dst + off + lh + L, D, M);
         }
-        u64 longs = __ballot(fits && L > ALZ_SEQ_LANE_LIT);                      // longer literal runs: the whole wavefront copies
-        while (longs) {
-            const int l0 = (int)__builtin_ctzll(longs);
-            const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)L, l0);
-            const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), l0);
-            wave_copy(dst + dq, src + so, len, lane);
-            longs &= longs - 1ull;
+        // The literals: every literal POSITION of this window whose sequence starts in this window stores its own byte -- one pass, whatever
+        // the number of runs (as a loop over the runs, each copied by the wavefront, this kernel was the longest of the LZ4 batch at quality 0:
+        // 18.3 of 59 ms -- a dozen runs of a dozen bytes per window).  A lane finds the next start at or behind it with the start mask and
+        // takes that lane's numbers; only the FIRST start of a window can own literals of earlier windows: those the wavefront copies.
+        {
+            const u64 above = (lane < 63 ? sm >> (lane + 1) : 0ull);
+            const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;          // the next start behind me (my own lane: none)
+            const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
+            const u32 sbase = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(off + lh - before));
+            const u32 sfit = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(fits ? 1u : 0u));
+            if (above && !start && sfit && p >= sbef && p < n) dst[sbase + p] = src[p];
+            const int f0 = (int)__builtin_ctzll(sm);                                       // the first start of the window
+            const u32 fbef = (u32)__builtin_amdgcn_readlane((int)before, f0);
+            if (fbef < P && __builtin_amdgcn_readlane((int)(fits ? 1u : 0u), f0)) {
+                const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), f0);
+                wave_copy(dst + dq, src + fbef, P - fbef, lane);
+            }
         }
         obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);

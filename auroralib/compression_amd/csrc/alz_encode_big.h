@@ -556,17 +556,19 @@ __global__ __launch_bounds__(64) void benc_seq(BencArgs a, const u8* __restrict_
                 const u32 off = obase + incl - esz;
                 if (start) {
                     F::put_lit_hdr(dst + off, L, M, false);
-                    if (L <= ALZ_SEQ_LANE_LIT) for (u32 i = 0; i < L; i++) dst[off + lh + i] = a.data[before + i];
                     F::put_match(dst + off + lh + L, D, M);
                 }
-                u64 longs = __ballot(start && L > ALZ_SEQ_LANE_LIT);            // longer literal runs: the whole wavefront copies
-                while (longs) {
-                    const int l0 = (int)__builtin_ctzll(longs);
-                    const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)L, l0);
-                    const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), l0);
-                    wave_copy(dst + dq, a.data + so, len, (int)lane);
-                    longs &= longs - 1ull;
-                }
+                // the literals, as in enc_emit_seq_kernel: every literal position whose sequence starts in this group of 64 stores its own
+                // byte; what the first start owns of earlier groups the wavefront copies
+                const u64 sm = __ballot(start);
+                const u64 above = (lane < 63u ? sm >> (lane + 1u) : 0ull);
+                const int s = above ? (int)lane + 1 + (int)__builtin_ctzll(above) : (int)lane;
+                const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
+                const u32 sbase = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(off + lh - before));
+                if (above && !start && p >= sbef && p < a.N) dst[sbase + p] = a.data[p];
+                const int f0 = (int)__builtin_ctzll(sm);
+                const u32 fbef = (u32)__builtin_amdgcn_readlane((int)before, f0);
+                if (fbef < P) wave_copy(dst + (u32)__builtin_amdgcn_readlane((int)(off + lh), f0), a.data + fbef, P - fbef, (int)lane);
             }
             obase += benc_last(incl);
         }
