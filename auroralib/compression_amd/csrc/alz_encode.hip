@@ -2627,17 +2627,23 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
         if (start && !fits) fail = true;
         if (fits) {
             u32 q = off;
-            if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); if (Lb <= ALZ_LZO_LANE_LIT) for (u32 i = 0; i < Lb; i++) dst[q + i] = src[before + i]; q += Lb; }
+            if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); q += Lb; }
             q += lzo_put_match(dst + q, D, M, emb);
             for (u32 i = 0; i < emb; i++) dst[q + i] = src[mend + i];
         }
-        u64 longs = __ballot(fits && Lb > ALZ_LZO_LANE_LIT);
-        while (longs) {
-            const int l0 = (int)__builtin_ctzll(longs);
-            const u32 so = (u32)__builtin_amdgcn_readlane((int)before, l0), len = (u32)__builtin_amdgcn_readlane((int)Lb, l0);
-            const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lsz), l0);
-            wave_copy(dst + dq, src + so, len, lane);
-            longs &= longs - 1ull;
+        {   // the literal runs (Lb >= 4), as in enc_emit_seq_kernel: every literal position whose unit starts in this window stores its own byte;
+            // what the first start owns of earlier windows the wavefront copies
+            const u64 stm = __ballot(start);
+            const u64 above = (lane < 63 ? stm >> (lane + 1) : 0ull);
+            const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;
+            const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
+            const u32 sbase = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(off + lsz - before));
+            const u32 srun = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)((fits && Lb >= 4u) ? 1u : 0u));
+            if (above && !start && srun && p >= sbef && p < n) dst[sbase + p] = src[p];
+            const int f0 = (int)__builtin_ctzll(stm);
+            const u32 fbef = (u32)__builtin_amdgcn_readlane((int)before, f0);
+            if (fbef < P && __builtin_amdgcn_readlane((int)((fits && Lb >= 4u) ? 1u : 0u), f0))
+                wave_copy(dst + (u32)__builtin_amdgcn_readlane((int)(off + lsz), f0), src + fbef, P - fbef, lane);
         }
         obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
