@@ -2230,6 +2230,9 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
         else { q[0] = (u8)((2u | ((M - 1u) << 2)) & 0xFFu); q[1] = (u8)(D & 0xFFu); q[2] = (u8)((D >> 8) & 0xFFu); }
     }
 };
+#ifndef ALZ_SEQ_PARSE_CAP
+#define ALZ_SEQ_PARSE_CAP 48   /* bytes enc_parse_seq_kernel<LZ4, true> compares per position (kernel B's cap at one candidate per position) */
+#endif
 #ifndef ALZ_SEQ_LANE_LIT
 #define ALZ_SEQ_LANE_LIT 4u      /* literal runs up to this long are copied by their own lane, longer ones by the wavefront (4: 15.8 ms, 16: 17.8) */
 #endif
@@ -2297,6 +2300,248 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
         // 18.3 of 59 ms -- a dozen runs of a dozen bytes per window).  A lane finds the next start at or behind it with the start mask and
         // takes that lane's numbers; only the FIRST start of a window can own literals of earlier windows: those the wavefront copies.
         {
+            const u64 above = (lane < 63 ? sm >> (lane + 1) : 0ull);
+            const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;          // the next start behind me (my own lane: none)
+            const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
+            const u32 sbase = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(off + lh - before));
+            const u32 sfit = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(fits ? 1u : 0u));
+            if (above && !start && sfit && p >= sbef && p < n) dst[sbase + p] = src[p];
+            const int f0 = (int)__builtin_ctzll(sm);                                       // the first start of the window
+            const u32 fbef = (u32)__builtin_amdgcn_readlane((int)before, f0);
+            if (fbef < P && __builtin_amdgcn_readlane((int)(fits ? 1u : 0u), f0)) {
+                const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), f0);
+                wave_copy(dst + dq, src + fbef, P - fbef, lane);
+            }
+        }
+        obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
+        if (wmax > cover) cover = wmax;
+    }
+    // the end: the remaining literals (LZ4: at least five, always a sequence; Snappy: an element only if there are any)
+    const u32 plain = n - cover, lh = (LZ4 || plain) ? F::lit_hdr(plain) : 0u;
+    const u32 total = obase + lh + plain;
+    if (total > cap) fail = true;
+    const bool anyfail = __ballot(fail) != 0ull;
+    if (!anyfail && (LZ4 || plain)) {
+        if (lane == 0) F::put_lit_hdr(dst + obase, plain, 4u, true);
+        wave_copy(dst + obase + lh, src + cover, plain, lane);
+    }
+    if (lane == 0) {
+        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
+        results[sid] = r;
+    }
+}
+
+// LZ4 blocks and raw Snappy in ONE kernel behind kernel A (round 4): the walk of enc_roles_kernel over a window of 64 positions, then the
+// sequences of enc_emit_seq_kernel that start in it, from the same registers -- no start mask, and the match array is read once (the
+// exact matches the walk recomputes for capped positions stay in registers).  SEARCH (one candidate per position -- quality 0 --, one
+// property set, 16-bit links): kernel B is in here too, as in enc_parse_emit_kernel<FMT, true>: the matches of window w + 1 are worked out
+// while window w is parsed, the candidates' bytes of window w + 2 and the links and own bytes of window w + 3 are in flight -- no match
+// array at all.  SEQ_CAP bytes are compared per position; a longer match is measured exactly when the cursor stands on it.
+template <int FMT, bool SEARCH>
+__global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                           u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
+                                                           const int* __restrict__ prev4, const int* __restrict__ prevm,
+                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
+    constexpr int SEQ_CAP = LZ4 ? ALZ_SEQ_PARSE_CAP : 64;                    // (Snappy's longest copy: never capped)
+    __shared__ u8 hopmark[64];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    hopmark[lane] = 0;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u8* data = src;
+    const u32 n = st.src_len;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    if (lane == 0 && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+    if (LZ4 && n < 5u) {                                                      // source.Slice(0, Length - 5) throws
+        if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
+        return;
+    }
+    const int ns = (int)n - (LZ4 ? 5 : 0);                                    // what the finder is given: LZ4 searches source[0 : n-5]  (LZ4.cs:208)
+    const int limit = ns - 4;                                                 // FindNextBestMatch searches up to length - 4  :159
+    const mentry* m = match + pos_off[sid];
+    const int* p4 = prev4 + pos_off[sid];
+    const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
+    u32 cover = 0;          // end of the last match = first literal not yet written
+    u32 obase = 0;          // bytes written before the window
+    bool fail = false;
+    if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
+        const u32 k = n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u;
+        if (k <= cap) { if (lane == 0) { u32 v = n, q = 0; while (v >= 0x80u) { dst[q++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[q] = (u8)v; } } else fail = true;
+        obase = k;
+    }
+    int cur = 0;            // cursor of FindNextBestMatch (absolute position)
+    bool carry = false;     // the window in front found a sequence that starts at this window's first position
+    auto ldm = [&](u32 q) { return (int)q <= limit ? m_unpack(__builtin_nontemporal_load(m + q)) : make_uint2(0, 0); };
+    // ---- SEARCH: the stages of the look-ahead (enc_parse_emit_kernel).  L: link + 32 own bytes of a window; C: the 32 bytes of its candidates.
+    const unsigned short* lk16 = reinterpret_cast<const unsigned short*>(p4);
+    const u32 srange = (u32)(g.max_dist - g.min_dist);
+    u32 lkA = 0, lkB = 0; u64 ownA[4] = {0, 0, 0, 0}, ownB[4] = {0, 0, 0, 0}, cndB[4] = {0, 0, 0, 0};
+    auto clampq = [&](u32 q) { return (int)q <= limit ? q : (u32)(limit > 0 ? limit : 0); };             // (positions behind the last searched one: loads stay inside, results unused)
+    auto loadL = [&](u32 q, u32& lkv, u64 (&own)[4]) { const u32 qq = clampq(q); lkv = (int)q <= limit ? (u32)__builtin_nontemporal_load(lk16 + qq) : 0u; __builtin_memcpy(own, data + qq, 32); };
+    auto loadC = [&](u32 q, u32 lkv, u64 (&cnd)[4]) { const u32 qq = clampq(q); const bool ok = lkv - (u32)g.min_dist <= srange; __builtin_memcpy(cnd, data + qq - (ok ? lkv : 0u), 32); };   // (a candidate out of reach is not touched)
+    auto matchof = [&](u32 q, u32 lkv, const u64 (&own)[4], const u64 (&cnd)[4]) -> uint2 {
+        if ((int)q > limit) return make_uint2(0, 0);
+        const bool ok = lkv - (u32)g.min_dist <= srange;                // a candidate (0: none), within maxDistance, not closer than minDistance  :259-266
+        int best_possible = ns - (int)q; if (best_possible > g.max_len) best_possible = g.max_len;
+        const int cmp_max = best_possible > SEQ_CAP ? SEQ_CAP : best_possible;
+        const u64 x0 = own[0] ^ cnd[0], x1 = own[1] ^ cnd[1], x2 = own[2] ^ cnd[2], x3 = own[3] ^ cnd[3];
+        int len = x0 ? (int)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (int)(__builtin_ctzll(x1) >> 3) : x2 ? 16 + (int)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (int)(__builtin_ctzll(x3) >> 3) : 32;
+        bool go = ok && len == 32 && cmp_max > 32;
+        if (__ballot(go)) {                                              // GetMatchLength behind the prefetched bytes
+            const u8* pa = data + q; const u8* pb = data + q - (go ? lkv : 0u);
+            int l = 32;
+            while (__ballot(go)) {
+                const u64 z = load64(pa + (go ? l : 0)) ^ load64(pb + (go ? l : 0));
+                if (go) { if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; } else { l += 8; if (l >= cmp_max) go = false; } }
+            }
+            if (ok && len == 32 && cmp_max > 32) len = l;
+        }
+        if (len > cmp_max) len = cmp_max;
+        const bool hitcap = ok && len == cmp_max && cmp_max < best_possible;
+        int l2 = len;
+        if (g.no_self_overlap && l2 > (int)lkv) l2 = (int)lkv;          // ScoreMatch  :301-321, one property set
+        const bool take = ok && !hitcap && l2 >= g.min_len;
+        return hitcap ? make_uint2(ALZ_CAPPED, ALZ_CAPPED) : make_uint2(take ? lkv : 0u, take ? (u32)l2 : 0u);
+    };
+    uint2 a_n;
+    if (SEARCH) {
+        loadL((u32)lane, lkB, ownB); loadL(64u + (u32)lane, lkA, ownA);
+        loadC((u32)lane, lkB, cndB);
+        a_n = matchof((u32)lane, lkB, ownB, cndB);                      // window 0
+        lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
+        loadC(64u + (u32)lane, lkB, cndB);                              // window 1's candidates
+        loadL(128u + (u32)lane, lkA, ownA);                             // window 2's links and own bytes
+    } else a_n = ldm((u32)lane);
+    for (u32 P = 0; P < n; P += 64) {
+        const u32 p = P + (u32)lane;
+        uint2 a = a_n;
+        // (a window the cursor has already jumped over -- LZ4 matches have no longest length -- is never looked at: its stage is left out.  The
+        // cursor only moves forward, so a window that IS parsed had all three of its stages)
+        if (SEARCH) {
+            if (cur < (int)P + 128) a_n = matchof(p + 64u, lkB, ownB, cndB);     // window w + 1 (bytes that arrived during the window before)
+            lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
+            if (cur < (int)P + 192) loadC(p + 128u, lkB, cndB);                  // window w + 2's candidates
+            if (cur < (int)P + 256) loadL(p + 192u, lkA, ownA);                  // window w + 3's links and own bytes
+        } else if (cur < (int)P + 128) a_n = ldm(p + 64u);
+        u64 sm = carry ? 1ull : 0ull;
+        carry = false;
+        if (cur < (int)P + 64 && cur <= limit) {
+            // ---- the parse of this window (the body of enc_roles_kernel)
+            uint2 b;
+            b.x = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.x); b.y = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.y);
+            {   // lane 63's neighbour is the first position of the next window
+                const u32 n0x = (u32)__builtin_amdgcn_readlane((int)a_n.x, 0), n0y = (u32)__builtin_amdgcn_readlane((int)a_n.y, 0);
+                if (lane == 63) b = make_uint2(n0x, n0y);
+            }
+            const bool capped = a.y == ALZ_CAPPED || b.y == ALZ_CAPPED;
+            int jump = 1, startrel = 0;   // startrel: 0 no token here, 1 match starts here, 2 literal here + match at p + 1
+            if (!capped && (int)p <= limit && (int)a.y >= g.min_len) {
+                const int l0 = (int)a.y, l1 = (int)b.y, pi = (int)p;
+                const bool lazyc = l0 <= g.lazy && pi + 1 <= limit;
+                if (lazyc && l1 > l0) { startrel = 2; const int e = pi + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 2 > stop ? pi + 2 : stop) - pi; }
+                else { startrel = 1; const int skip = lazyc ? 1 : 0; const int e = pi + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (pi + 1 + skip > stop ? pi + 1 + skip : stop) - pi; }
+            }
+            int rel = cur - (int)P;
+            if (__ballot(capped) == 0) {
+                u64 M = 0; u32 r = (u32)rel, j;
+                const u32 lim = (u32)(limit + 1 - (int)P) < 64u ? (u32)(limit + 1 - (int)P) : 64u;     // (r < lim on entry: cur <= limit)
+                if (lim == 64u) {
+                    // (two tokens per hop, the cursor 64 below zero: enc_parse_emit_kernel)
+                    const u32 tgt = (u32)lane + (u32)jump;                     // where my jump lands (>= 64: outside)
+                    const int jn = __builtin_amdgcn_ds_bpermute((int)((tgt < 64u ? tgt : (u32)lane) << 2), jump);
+                    const int jump2 = tgt < 64u ? jump + jn : jump;
+                    r -= 64u;
+                    asm volatile(
+                        "s_nop 3\n"
+                        "1:\n\t"
+                        "s_bitset1_b64 %[M], %[r]\n\t"
+                        "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                        "s_add_u32 %[r], %[r], %[j]\n\t"
+                        "s_cbranch_scc0 1b\n\t"
+                        : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                        : [jump] "v"(jump2)
+                        : "scc");
+                    r += 64u;
+                    if (((M >> lane) & 1ull) && tgt < 64u) hopmark[tgt] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    const u32 hm = hopmark[lane];
+                    if (hm) hopmark[lane] = 0;
+                    M |= __ballot(hm != 0u);
+                } else
+                asm volatile(
+                    "s_nop 3\n"
+                    "1:\n\t"
+                    "s_bitset1_b64 %[M], %[r]\n\t"
+                    "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                    "s_add_u32 %[r], %[r], %[j]\n\t"
+                    "s_cmp_lt_u32 %[r], %[lim]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                    : [jump] "v"(jump), [lim] "s"(lim)
+                    : "scc");
+                const u64 s1 = __ballot(startrel == 1) & M, s2 = __ballot(startrel == 2) & M;
+                sm |= s1 | (s2 << 1);
+                if (s2 >> 63) carry = true;                                    // start in lane 0 of the next window
+                rel = (int)r;
+            }
+            else while (rel < 64 && (int)P + rel <= limit) {
+                int j, sr;
+                if (__builtin_amdgcn_readlane((int)capped, rel)) {
+                    // a capped candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour, and put both into the
+                    // registers the sequences take their matches from (the neighbour may be the next window's first position)
+                    const int q = (int)P + rel;
+                    int d0, l0, d1 = 0, l1 = 0;
+                    if (g.use_min_table) benc_wave_search<true>(data, ns, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, ns, g, p4, pm, q, d0, l0);
+                    if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, ns, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, ns, g, p4, pm, q + 1, d1, l1); }
+                    if (lane == rel) a = make_uint2((u32)d0, (u32)l0);
+                    if (q + 1 <= limit) {
+                        if (rel + 1 < 64) { if (lane == rel + 1) a = make_uint2((u32)d1, (u32)l1); }
+                        else if (lane == 0) a_n = make_uint2((u32)d1, (u32)l1);
+                    }
+                    j = 1; sr = 0;
+                    if (l0 >= g.min_len) {
+                        const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
+                        if (lazyc && l1 > l0) { sr = 2; const int e = q + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 2 > stop ? q + 2 : stop) - q; }
+                        else { sr = 1; const int skip = lazyc ? 1 : 0; const int e = q + l0; const int stop = e < limit + 1 ? e : limit + 1; j = (q + 1 + skip > stop ? q + 1 + skip : stop) - q; }
+                    }
+                } else {
+                    j = __builtin_amdgcn_readlane(jump, rel);
+                    sr = __builtin_amdgcn_readlane(startrel, rel);
+                }
+                if (sr == 1) sm |= 1ull << rel;
+                else if (sr == 2) { if (rel + 1 < 64) sm |= 1ull << (rel + 1); else carry = true; }   // start in lane 0 of the next window
+                rel += j;
+            }
+            cur = (int)P + rel;
+        }
+        if (sm == 0ull) continue;                                             // (no match starts here: the literals wait for the next one)
+        // ---- the sequences that start in this window (the body of enc_emit_seq_kernel)
+        const bool start = ((sm >> lane) & 1ull) != 0ull;
+        const u32 M = start ? a.y : 0u, D = a.x;
+        const u32 mend = start ? p + M : 0u;
+        const u32 pmax = scan_max(mend);                                       // inclusive
+        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
+        if (before < cover) before = cover;
+        const u32 L = start ? p - before : 0u;
+        const u32 lh = start ? F::lit_hdr(L) : 0u;
+        const u32 esz = start ? lh + L + F::match_size(D, M) : 0u;
+        const u32 incl = scan_add(esz);
+        const u32 off = obase + incl - esz;
+        const bool fits = start && off + esz <= cap;
+        if (start && !fits) fail = true;
+        if (fits) {
+            F::put_lit_hdr(dst + off, L, M, false);
+            F::put_match(dst + off + lh + L, D, M);
+        }
+        {   // (the literals: by their own lanes, enc_emit_seq_kernel)
             const u64 above = (lane < 63 ? sm >> (lane + 1) : 0ull);
             const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;          // the next start behind me (my own lane: none)
             const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
@@ -2677,8 +2922,12 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
 
 // one candidate per position and a format whose parse and emit are one kernel: the search is in that kernel too (no kernel B, no match array)
 static bool searches_in_the_parse(int fmt, const EncGeom& g) {
+#ifdef ALZ_SEQ_TWO_KERNELS
+    if (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW) return false;
+#endif
     const bool par = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
-                     fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+                     fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON ||
+                     fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;                          // (enc_parse_seq_kernel)
     return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
 }
 
@@ -2863,16 +3112,26 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         hipLaunchKernelGGL((enc_emit_prs_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_LZ4_BLOCK: {
+#ifdef ALZ_SEQ_TWO_KERNELS
         hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
         hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+#else
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
+        else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
+#endif
         break; }
     case ALZ_FMT_LZO: {
         hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_SNAPPY_RAW: {
+#ifdef ALZ_SEQ_TWO_KERNELS
         hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+#else
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
+        else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
+#endif
         break; }
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
