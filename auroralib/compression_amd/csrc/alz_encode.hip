@@ -1927,10 +1927,14 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
         uint2 a = a_n;
         const u32 sb = sb_n;
         if (SEARCH) {
-            a_n = matchof(p + 64u, lkB, ownB, cndB);                    // window w + 1 (bytes that arrived during the window before)
+            // (LZ11 / LZ40 -- matches of up to 16 KiB --: a window the cursor has already jumped over is never looked at, its stage is left out
+            // as in enc_parse_seq_kernel: 1 024 windows of Test.bmp 11.65 -> 11.23 ms, 4 096 25.0 -> 23.7.  With Yaz0's 273 bytes -3 % on the
+            // bitmap and +2 % on text; the 18 bytes of LZ10 never skip a window: +1.5 %)
+            constexpr bool SKIPW = FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40;
+            if (!SKIPW || cur < (int)P + 128) a_n = matchof(p + 64u, lkB, ownB, cndB);    // window w + 1 (bytes that arrived during the window before)
             lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
-            loadC(p + 128u, lkB, cndB);                                 // window w + 2's candidates
-            loadL(p + 192u, lkA, ownA);                                 // window w + 3's links and own bytes
+            if (!SKIPW || cur < (int)P + 192) loadC(p + 128u, lkB, cndB);                 // window w + 2's candidates
+            if (!SKIPW || cur < (int)P + 256) loadL(p + 192u, lkA, ownA);                 // window w + 3's links and own bytes
         } else a_n = ldm(p + 64u);
         if (p + 64 < n) sb_n = src[p + 64];
         u64 sm = carry ? 1ull : 0ull;
@@ -2332,66 +2336,47 @@ __global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__
     }
 }
 
-// LZ4 blocks and raw Snappy in ONE kernel behind kernel A (round 4): the walk of enc_roles_kernel over a window of 64 positions, then the
-// sequences of enc_emit_seq_kernel that start in it, from the same registers -- no start mask, and the match array is read once (the
-// exact matches the walk recomputes for capped positions stay in registers).  SEARCH (one candidate per position -- quality 0 --, one
-// property set, 16-bit links): kernel B is in here too, as in enc_parse_emit_kernel<FMT, true>: the matches of window w + 1 are worked out
-// while window w is parsed, the candidates' bytes of window w + 2 and the links and own bytes of window w + 3 are in flight -- no match
-// array at all.  SEQ_CAP bytes are compared per position; a longer match is measured exactly when the cursor stands on it.
-template <int FMT, bool SEARCH>
-__global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
-                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                           u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
-                                                           const int* __restrict__ prev4, const int* __restrict__ prevm,
-                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
-    typedef SeqFmt<FMT> F;
-    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
-    constexpr int SEQ_CAP = LZ4 ? ALZ_SEQ_PARSE_CAP : 64;                    // (Snappy's longest copy: never capped)
-    __shared__ u8 hopmark[64];
-    const u32 bid = blockIdx.x;
-    if (bid >= count) return;
-    const int lane = (int)threadIdx.x;
-    hopmark[lane] = 0;
-    const u32 sid = index_list[bid];
-    const alz_stream st = streams[sid];
-    const u8* src = src_base + st.src_off;
-    const u8* data = src;
-    const u32 n = st.src_len;
-    u8* dst = dst_base + st.dst_off;
-    const u32 cap = st.dst_cap;
-    if (lane == 0 && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
-    if (LZ4 && n < 5u) {                                                      // source.Slice(0, Length - 5) throws
-        if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
-        return;
+// The walk of enc_roles_kernel one window of 64 positions at a time, for kernels that write a window's tokens right behind its parse
+// (enc_parse_seq_kernel, enc_emit_prs_kernel<BIG, true>): no start mask in memory, and the exact matches the walk recomputes for capped
+// positions stay in registers.  SEARCH (one candidate per position -- quality 0 --, one property set, 16-bit links): kernel B is in here
+// too, as in enc_parse_emit_kernel<FMT, true>: the matches of window w + 1 are worked out while window w is parsed, the candidates'
+// bytes of window w + 2 and the links and own bytes of window w + 3 are in flight -- no match array at all.  CAP bytes are compared per
+// position; a longer match is measured exactly when the cursor stands on it.
+template <bool SEARCH, int CAP>
+struct WinParse {
+    const EncGeom& g;
+    const u8* data; int ns, limit, lane;                // ns: the bytes the finder is given; limit = ns - 4: the last searched position  :159
+    const mentry* m; const int* p4; const int* pm;
+    u8* hopmark;                                        // 64 bytes of LDS
+    const unsigned short* lk16; u32 srange;
+    int cur;                                            // cursor of FindNextBestMatch (absolute position)
+    bool carry;                                         // the window in front found a token that starts at this window's first position
+    uint2 a_n;                                          // the matches of the next window
+    // ---- SEARCH: the stages of the look-ahead.  L: link + 32 own bytes of a window; C: the 32 bytes of its candidates.
+    u32 lkA, lkB; u64 ownA[4], ownB[4], cndB[4];
+    __device__ __forceinline__ WinParse(const EncGeom& g_, const u8* data_, int ns_, int lane_, const mentry* m_, const int* p4_, const int* pm_, u8* hopmark_, bool active = true)
+        : g(g_), data(data_), ns(ns_), limit(ns_ - 4), lane(lane_), m(m_), p4(p4_), pm(pm_), hopmark(hopmark_),
+          lk16(reinterpret_cast<const unsigned short*>(p4_)), srange((u32)(g_.max_dist - g_.min_dist)), cur(0), carry(false), lkA(0), lkB(0),
+          ownA{0, 0, 0, 0}, ownB{0, 0, 0, 0}, cndB{0, 0, 0, 0} {
+        if (!active) return;                                                // (a kernel instantiated without the walk: nothing is loaded)
+        if (SEARCH) {
+            loadL((u32)lane, lkB, ownB); loadL(64u + (u32)lane, lkA, ownA);
+            loadC((u32)lane, lkB, cndB);
+            a_n = matchof((u32)lane, lkB, ownB, cndB);                      // window 0
+            lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
+            loadC(64u + (u32)lane, lkB, cndB);                              // window 1's candidates
+            loadL(128u + (u32)lane, lkA, ownA);                             // window 2's links and own bytes
+        } else a_n = ldm((u32)lane);
     }
-    const int ns = (int)n - (LZ4 ? 5 : 0);                                    // what the finder is given: LZ4 searches source[0 : n-5]  (LZ4.cs:208)
-    const int limit = ns - 4;                                                 // FindNextBestMatch searches up to length - 4  :159
-    const mentry* m = match + pos_off[sid];
-    const int* p4 = prev4 + pos_off[sid];
-    const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
-    u32 cover = 0;          // end of the last match = first literal not yet written
-    u32 obase = 0;          // bytes written before the window
-    bool fail = false;
-    if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
-        const u32 k = n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u;
-        if (k <= cap) { if (lane == 0) { u32 v = n, q = 0; while (v >= 0x80u) { dst[q++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[q] = (u8)v; } } else fail = true;
-        obase = k;
-    }
-    int cur = 0;            // cursor of FindNextBestMatch (absolute position)
-    bool carry = false;     // the window in front found a sequence that starts at this window's first position
-    auto ldm = [&](u32 q) { return (int)q <= limit ? m_unpack(__builtin_nontemporal_load(m + q)) : make_uint2(0, 0); };
-    // ---- SEARCH: the stages of the look-ahead (enc_parse_emit_kernel).  L: link + 32 own bytes of a window; C: the 32 bytes of its candidates.
-    const unsigned short* lk16 = reinterpret_cast<const unsigned short*>(p4);
-    const u32 srange = (u32)(g.max_dist - g.min_dist);
-    u32 lkA = 0, lkB = 0; u64 ownA[4] = {0, 0, 0, 0}, ownB[4] = {0, 0, 0, 0}, cndB[4] = {0, 0, 0, 0};
-    auto clampq = [&](u32 q) { return (int)q <= limit ? q : (u32)(limit > 0 ? limit : 0); };             // (positions behind the last searched one: loads stay inside, results unused)
-    auto loadL = [&](u32 q, u32& lkv, u64 (&own)[4]) { const u32 qq = clampq(q); lkv = (int)q <= limit ? (u32)__builtin_nontemporal_load(lk16 + qq) : 0u; __builtin_memcpy(own, data + qq, 32); };
-    auto loadC = [&](u32 q, u32 lkv, u64 (&cnd)[4]) { const u32 qq = clampq(q); const bool ok = lkv - (u32)g.min_dist <= srange; __builtin_memcpy(cnd, data + qq - (ok ? lkv : 0u), 32); };   // (a candidate out of reach is not touched)
-    auto matchof = [&](u32 q, u32 lkv, const u64 (&own)[4], const u64 (&cnd)[4]) -> uint2 {
+    __device__ __forceinline__ uint2 ldm(u32 q) { return (int)q <= limit ? m_unpack(__builtin_nontemporal_load(m + q)) : make_uint2(0, 0); }
+    __device__ __forceinline__ u32 clampq(u32 q) { return (int)q <= limit ? q : (u32)(limit > 0 ? limit : 0); }             // (positions behind the last searched one: loads stay inside, results unused)
+    __device__ __forceinline__ void loadL(u32 q, u32& lkv, u64 (&own)[4]) { const u32 qq = clampq(q); lkv = (int)q <= limit ? (u32)__builtin_nontemporal_load(lk16 + qq) : 0u; __builtin_memcpy(own, data + qq, 32); }
+    __device__ __forceinline__ void loadC(u32 q, u32 lkv, u64 (&cnd)[4]) { const u32 qq = clampq(q); const bool ok = lkv - (u32)g.min_dist <= srange; __builtin_memcpy(cnd, data + qq - (ok ? lkv : 0u), 32); }   // (a candidate out of reach is not touched)
+    __device__ __forceinline__ uint2 matchof(u32 q, u32 lkv, const u64 (&own)[4], const u64 (&cnd)[4]) {
         if ((int)q > limit) return make_uint2(0, 0);
         const bool ok = lkv - (u32)g.min_dist <= srange;                // a candidate (0: none), within maxDistance, not closer than minDistance  :259-266
         int best_possible = ns - (int)q; if (best_possible > g.max_len) best_possible = g.max_len;
-        const int cmp_max = best_possible > SEQ_CAP ? SEQ_CAP : best_possible;
+        const int cmp_max = best_possible > CAP ? CAP : best_possible;
         const u64 x0 = own[0] ^ cnd[0], x1 = own[1] ^ cnd[1], x2 = own[2] ^ cnd[2], x3 = own[3] ^ cnd[3];
         int len = x0 ? (int)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (int)(__builtin_ctzll(x1) >> 3) : x2 ? 16 + (int)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (int)(__builtin_ctzll(x3) >> 3) : 32;
         bool go = ok && len == 32 && cmp_max > 32;
@@ -2410,19 +2395,12 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
         if (g.no_self_overlap && l2 > (int)lkv) l2 = (int)lkv;          // ScoreMatch  :301-321, one property set
         const bool take = ok && !hitcap && l2 >= g.min_len;
         return hitcap ? make_uint2(ALZ_CAPPED, ALZ_CAPPED) : make_uint2(take ? lkv : 0u, take ? (u32)l2 : 0u);
-    };
-    uint2 a_n;
-    if (SEARCH) {
-        loadL((u32)lane, lkB, ownB); loadL(64u + (u32)lane, lkA, ownA);
-        loadC((u32)lane, lkB, cndB);
-        a_n = matchof((u32)lane, lkB, ownB, cndB);                      // window 0
-        lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
-        loadC(64u + (u32)lane, lkB, cndB);                              // window 1's candidates
-        loadL(128u + (u32)lane, lkA, ownA);                             // window 2's links and own bytes
-    } else a_n = ldm((u32)lane);
-    for (u32 P = 0; P < n; P += 64) {
+    }
+    // The window at P (windows are taken in order, none left out): `a` = (distance, length) of the match at each position -- exact where a
+    // token starts --, `sm` = the positions where the parse starts a match token.
+    __device__ __forceinline__ void window(u32 P, uint2& a, u64& sm) {
         const u32 p = P + (u32)lane;
-        uint2 a = a_n;
+        a = a_n;
         // (a window the cursor has already jumped over -- LZ4 matches have no longest length -- is never looked at: its stage is left out.  The
         // cursor only moves forward, so a window that IS parsed had all three of its stages)
         if (SEARCH) {
@@ -2431,7 +2409,7 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
             if (cur < (int)P + 192) loadC(p + 128u, lkB, cndB);                  // window w + 2's candidates
             if (cur < (int)P + 256) loadL(p + 192u, lkA, ownA);                  // window w + 3's links and own bytes
         } else if (cur < (int)P + 128) a_n = ldm(p + 64u);
-        u64 sm = carry ? 1ull : 0ull;
+        sm = carry ? 1ull : 0ull;
         carry = false;
         if (cur < (int)P + 64 && cur <= limit) {
             // ---- the parse of this window (the body of enc_roles_kernel)
@@ -2522,6 +2500,54 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
             }
             cur = (int)P + rel;
         }
+    }
+};
+
+// LZ4 blocks and raw Snappy in ONE kernel behind kernel A (round 4): the walk over a window of 64 positions (WinParse), then the sequences
+// of enc_emit_seq_kernel that start in it, from the same registers; at quality 0 the search as well.
+template <int FMT, bool SEARCH>
+__global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                           u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
+                                                           const int* __restrict__ prev4, const int* __restrict__ prevm,
+                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
+    constexpr int SEQ_CAP = LZ4 ? ALZ_SEQ_PARSE_CAP : 64;                    // (Snappy's longest copy: never capped)
+    __shared__ u8 hopmark[64];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const int lane = (int)threadIdx.x;
+    hopmark[lane] = 0;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u8* data = src;
+    const u32 n = st.src_len;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    if (lane == 0 && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+    if (LZ4 && n < 5u) {                                                      // source.Slice(0, Length - 5) throws
+        if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
+        return;
+    }
+    const int ns = (int)n - (LZ4 ? 5 : 0);                                    // what the finder is given: LZ4 searches source[0 : n-5]  (LZ4.cs:208)
+    const mentry* m = match + pos_off[sid];
+    const int* p4 = prev4 + pos_off[sid];
+    const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
+    u32 cover = 0;          // end of the last match = first literal not yet written
+    u32 obase = 0;          // bytes written before the window
+    bool fail = false;
+    if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
+        const u32 k = n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u;
+        if (k <= cap) { if (lane == 0) { u32 v = n, q = 0; while (v >= 0x80u) { dst[q++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[q] = (u8)v; } } else fail = true;
+        obase = k;
+    }
+    WinParse<SEARCH, SEQ_CAP> ps(g, data, ns, lane, m, p4, pm, hopmark);
+    for (u32 P = 0; P < n; P += 64) {
+        const u32 p = P + (u32)lane;
+        uint2 a; u64 sm;
+        ps.window(P, a, sm);
         if (sm == 0ull) continue;                                             // (no match starts here: the literals wait for the next one)
         // ---- the sequences that start in this window (the body of enc_emit_seq_kernel)
         const bool start = ((sm >> lane) & 1ull) != 0ull;
@@ -2582,14 +2608,17 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
 // So two prefix sums (bits, payload bytes) place everything; flag bytes collect their bits in LDS and are stored by the token that owns
 // their last bit, as in enc_parse_emit_kernel.  A match of length 2 further than 0x100 back is not written as a match (its bytes go out as
 // literals; the parse has moved on behind it either way).
-template <bool BIG>
+// MODE 0: start mask and match array from memory (behind enc_roles_kernel); 1: the walk in here (WinParse); 2: and the one-candidate search
+template <bool BIG, int MODE>
 __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
                                                           u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
                                                           const u64* __restrict__ startmask, alz_result* __restrict__ results,
-                                                          alz_encode_aux* __restrict__ aux) {
+                                                          alz_encode_aux* __restrict__ aux, const int* __restrict__ prev4,
+                                                          const int* __restrict__ prevm, EncGeom g) {
     __shared__ u32 flagacc[64];
     __shared__ u32 gofs[64];
+    __shared__ u8 hopmark[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
@@ -2601,27 +2630,31 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     const u32 cap = st.dst_cap;
     const mentry* m = match + pos_off[sid];
     const u64* mask = startmask + (pos_off[sid] >> 6);
-    flagacc[lane] = 0; gofs[lane] = 0;
+    flagacc[lane] = 0; gofs[lane] = 0; hopmark[lane] = 0;
     __syncthreads();
     u32 bit_base = 0;       // flag bits before the window
     u32 pay_base = 0;       // payload bytes before the window
     u32 cover = 0;          // end of the last match written as a match
     u32 lastk = 0xFFFFFFFFu;    // flag byte of the last payload before the window (none yet)
     bool fail = false;
-    u64 sm_n = n ? mask[0] : 0ull;
-    mentry mt_n = (u32)lane < n ? m[lane] : 0u;
+    u64 sm_n = (MODE == 0 && n) ? mask[0] : 0ull;
+    mentry mt_n = (MODE == 0 && (u32)lane < n) ? m[lane] : 0u;
     u32 sb_n = (u32)lane < n ? src[lane] : 0u;
+    WinParse<MODE == 2, ALZ_SEQ_PARSE_CAP> ps(g, src, (int)n, lane, m, prev4 + pos_off[sid], (MODE != 0 && g.use_min_table) ? prevm + pos_off[sid] : nullptr, hopmark, MODE != 0);
     // one more trip behind the data for the end token (bit 0, two zero bytes, bit 1) on lane 0
     for (u32 P = 0; P < n + 64u; P += 64) {
         const bool tail = P >= n;
         if (tail && P > ((n + 63u) & ~63u)) break;                             // (exactly one trip behind the last window)
         const u32 p = P + (u32)lane;
-        const u64 sm = tail ? 0ull : sm_n;
+        u64 sm = tail ? 0ull : sm_n;
         const mentry mt_raw = mt_n;
         const u32 sb = sb_n;
-        if (!tail) { if (P + 64 < n) sm_n = mask[(P >> 6) + 1]; if (p + 64 < n) { mt_n = m[p + 64]; sb_n = src[p + 64]; } }
+        uint2 mt_all;
+        if (MODE == 0) { if (!tail) { if (P + 64 < n) sm_n = mask[(P >> 6) + 1]; if (p + 64 < n) mt_n = m[p + 64]; } }
+        else if (!tail) ps.window(P, mt_all, sm);
+        if (!tail && p + 64 < n) sb_n = src[p + 64];
         bool start = !tail && ((sm >> lane) & 1ull) && p < n;
-        const uint2 mt_all = m_start<false>(m, p, mt_raw, start);           // (a PRS match has at most 256 bytes)
+        if (MODE == 0) mt_all = m_start<false>(m, p, mt_raw, start);        // (a PRS match has at most 256 bytes)
         uint2 mt = make_uint2(0, 0);
         if (start) mt = mt_all;
         if (start && mt.y == 2u && mt.x > 0x100u) start = false;               // PRS.cs: not worth a long match -- literals
@@ -2923,11 +2956,12 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
 // one candidate per position and a format whose parse and emit are one kernel: the search is in that kernel too (no kernel B, no match array)
 static bool searches_in_the_parse(int fmt, const EncGeom& g) {
 #ifdef ALZ_SEQ_TWO_KERNELS
-    if (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW) return false;
+    if (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE) return false;
 #endif
     const bool par = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
                      fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON ||
-                     fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;                          // (enc_parse_seq_kernel)
+                     fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW ||                        // (enc_parse_seq_kernel)
+                     fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;                                 // (enc_emit_prs_kernel<BIG, 2>)
     return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
 }
 
@@ -3104,12 +3138,22 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
+#ifdef ALZ_SEQ_TWO_KERNELS
         hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-        hipLaunchKernelGGL((enc_emit_prs_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        hipLaunchKernelGGL((enc_emit_prs_kernel<true, 0>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
+#else
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<true, 2>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
+        else hipLaunchKernelGGL((enc_emit_prs_kernel<true, 1>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
+#endif
         break; }
     case ALZ_FMT_PRS_LE: {
+#ifdef ALZ_SEQ_TWO_KERNELS
         hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-        hipLaunchKernelGGL((enc_emit_prs_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        hipLaunchKernelGGL((enc_emit_prs_kernel<false, 0>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
+#else
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<false, 2>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
+        else hipLaunchKernelGGL((enc_emit_prs_kernel<false, 1>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
+#endif
         break; }
     case ALZ_FMT_LZ4_BLOCK: {
 #ifdef ALZ_SEQ_TWO_KERNELS
