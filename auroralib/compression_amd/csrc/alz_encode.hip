@@ -22,11 +22,12 @@
 //   B  enc_match_kernel         one lane per position: the chain walk of MatchSearch/ChainMatches (:214-282) over prev(),
 //                               embarrassingly parallel; writes (distance, length) per position.  From maxChain 3 on
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
-//   C  enc_roles_kernel         the greedy/lazy parse as a walk over the match array (one wavefront per stream): a bit per token
-//                               start; then enc_emit_seq_kernel (LZ4, Snappy), enc_emit_prs_kernel or enc_emit_lzo_kernel place
-//                               every token with prefix sums.  The flag-bit formats (LZSS, LZ10, LZ11, Yaz0, Yay0, MIO0 ...) do both in
-//                               ONE kernel, enc_parse_emit_kernel: the walk over a window, then its tokens, from the same registers.
-//                               enc_emit_kernel: emission on one lane per stream, for the formats that have no parallel emit yet.
+//   C  the greedy/lazy parse as a walk over 64-position windows and the emission of a window's tokens by prefix sums, in ONE kernel from
+//                               the same registers (one wavefront per stream): enc_parse_emit_kernel (the flag-bit formats: LZSS, LZ10, LZ11,
+//                               Yaz0, Yay0, MIO0 ...), enc_parse_seq_kernel (LZ4, Snappy) and enc_emit_prs_kernel, the last two on
+//                               struct WinParse.  At quality 0 (one candidate per position) kernel B is inside them too.
+//      enc_roles_kernel         the walk alone: a bit per token start, in front of enc_emit_lzo_kernel (whose tokens look ahead of the walk) and
+//                               of enc_emit_kernel: emission on one lane per stream, for the formats that have no parallel emit yet.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -2240,104 +2241,8 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
 #ifndef ALZ_SEQ_LANE_LIT
 #define ALZ_SEQ_LANE_LIT 4u      /* literal runs up to this long are copied by their own lane, longer ones by the wavefront (4: 15.8 ms, 16: 17.8) */
 #endif
-template <int FMT>
-__global__ __launch_bounds__(64) void enc_emit_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
-                                                          const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
-                                                          u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
-                                                          const u64* __restrict__ startmask, alz_result* __restrict__ results,
-                                                          alz_encode_aux* __restrict__ aux) {
-    typedef SeqFmt<FMT> F;
-    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
-    const u32 bid = blockIdx.x;
-    if (bid >= count) return;
-    const int lane = (int)threadIdx.x;
-    const u32 sid = index_list[bid];
-    const alz_stream st = streams[sid];
-    const u8* src = src_base + st.src_off;
-    const u32 n = st.src_len;
-    u8* dst = dst_base + st.dst_off;
-    const u32 cap = st.dst_cap;
-    if (lane == 0 && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
-    if (LZ4 && n < 5u) {                                                      // source.Slice(0, Length - 5) throws
-        if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
-        return;
-    }
-    const mentry* m = match + pos_off[sid];
-    const u64* mask = startmask + (pos_off[sid] >> 6);
-    u32 cover = 0;          // end of the last match = first literal not yet written
-    u32 obase = 0;          // bytes written before the window
-    bool fail = false;
-    if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
-        const u32 k = n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u;
-        if (k <= cap) { if (lane == 0) { u32 v = n, q = 0; while (v >= 0x80u) { dst[q++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[q] = (u8)v; } } else fail = true;
-        obase = k;
-    }
-    u64 sm_n = n ? mask[0] : 0ull;
-    mentry mt_n = (u32)lane < n ? m[lane] : 0u;
-    for (u32 P = 0; P < n; P += 64) {
-        const u32 p = P + (u32)lane;
-        const u64 sm = sm_n;
-        const mentry mt_raw = mt_n;
-        if (P + 64 < n) sm_n = mask[(P >> 6) + 1];
-        if (p + 64 < n) mt_n = m[p + 64];
-        if (sm == 0ull) continue;                                             // (no match starts here: the literals wait for the next one)
-        const bool start = ((sm >> lane) & 1ull) != 0ull;
-        const uint2 mt_all = m_start<LZ4>(m, p, mt_raw, start);              // (a Snappy copy has at most 64 bytes)
-        const u32 M = start ? mt_all.y : 0u, D = mt_all.x;
-        const u32 mend = start ? p + M : 0u;
-        const u32 pmax = scan_max(mend);                                       // inclusive
-        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
-        if (before < cover) before = cover;
-        const u32 L = start ? p - before : 0u;
-        const u32 lh = start ? F::lit_hdr(L) : 0u;
-        const u32 esz = start ? lh + L + F::match_size(D, M) : 0u;
-        const u32 incl = scan_add(esz);
-        const u32 off = obase + incl - esz;
-        const bool fits = start && off + esz <= cap;
-        if (start && !fits) fail = true;
-        if (fits) {
-            F::put_lit_hdr(dst + off, L, M, false);
-            F::put_match(dst + off + lh + L, D, M);
-        }
-        // The literals: every literal POSITION of this window whose sequence starts in this window stores its own byte -- one pass, whatever
-        // the number of runs (as a loop over the runs, each copied by the wavefront, this kernel was the longest of the LZ4 batch at quality 0:
-        // 18.3 of 59 ms -- a dozen runs of a dozen bytes per window).  A lane finds the next start at or behind it with the start mask and
-        // takes that lane's numbers; only the FIRST start of a window can own literals of earlier windows: those the wavefront copies.
-        {
-            const u64 above = (lane < 63 ? sm >> (lane + 1) : 0ull);
-            const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;          // the next start behind me (my own lane: none)
-            const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
-            const u32 sbase = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(off + lh - before));
-            const u32 sfit = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)(fits ? 1u : 0u));
-            if (above && !start && sfit && p >= sbef && p < n) dst[sbase + p] = src[p];
-            const int f0 = (int)__builtin_ctzll(sm);                                       // the first start of the window
-            const u32 fbef = (u32)__builtin_amdgcn_readlane((int)before, f0);
-            if (fbef < P && __builtin_amdgcn_readlane((int)(fits ? 1u : 0u), f0)) {
-                const u32 dq = (u32)__builtin_amdgcn_readlane((int)(off + lh), f0);
-                wave_copy(dst + dq, src + fbef, P - fbef, lane);
-            }
-        }
-        obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
-        if (wmax > cover) cover = wmax;
-    }
-    // the end: the remaining literals (LZ4: at least five, always a sequence; Snappy: an element only if there are any)
-    const u32 plain = n - cover, lh = (LZ4 || plain) ? F::lit_hdr(plain) : 0u;
-    const u32 total = obase + lh + plain;
-    if (total > cap) fail = true;
-    const bool anyfail = __ballot(fail) != 0ull;
-    if (!anyfail && (LZ4 || plain)) {
-        if (lane == 0) F::put_lit_hdr(dst + obase, plain, 4u, true);
-        wave_copy(dst + obase + lh, src + cover, plain, lane);
-    }
-    if (lane == 0) {
-        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
-        results[sid] = r;
-    }
-}
-
 // The walk of enc_roles_kernel one window of 64 positions at a time, for kernels that write a window's tokens right behind its parse
-// (enc_parse_seq_kernel, enc_emit_prs_kernel<BIG, true>): no start mask in memory, and the exact matches the walk recomputes for capped
+// (enc_parse_seq_kernel, enc_emit_prs_kernel): no start mask in memory, and the exact matches the walk recomputes for capped
 // positions stay in registers.  SEARCH (one candidate per position -- quality 0 --, one property set, 16-bit links): kernel B is in here
 // too, as in enc_parse_emit_kernel<FMT, true>: the matches of window w + 1 are worked out while window w is parsed, the candidates'
 // bytes of window w + 2 and the links and own bytes of window w + 3 are in flight -- no match array at all.  CAP bytes are compared per
@@ -2354,11 +2259,10 @@ struct WinParse {
     uint2 a_n;                                          // the matches of the next window
     // ---- SEARCH: the stages of the look-ahead.  L: link + 32 own bytes of a window; C: the 32 bytes of its candidates.
     u32 lkA, lkB; u64 ownA[4], ownB[4], cndB[4];
-    __device__ __forceinline__ WinParse(const EncGeom& g_, const u8* data_, int ns_, int lane_, const mentry* m_, const int* p4_, const int* pm_, u8* hopmark_, bool active = true)
+    __device__ __forceinline__ WinParse(const EncGeom& g_, const u8* data_, int ns_, int lane_, const mentry* m_, const int* p4_, const int* pm_, u8* hopmark_)
         : g(g_), data(data_), ns(ns_), limit(ns_ - 4), lane(lane_), m(m_), p4(p4_), pm(pm_), hopmark(hopmark_),
           lk16(reinterpret_cast<const unsigned short*>(p4_)), srange((u32)(g_.max_dist - g_.min_dist)), cur(0), carry(false), lkA(0), lkB(0),
           ownA{0, 0, 0, 0}, ownB{0, 0, 0, 0}, cndB{0, 0, 0, 0} {
-        if (!active) return;                                                // (a kernel instantiated without the walk: nothing is loaded)
         if (SEARCH) {
             loadL((u32)lane, lkB, ownB); loadL(64u + (u32)lane, lkA, ownA);
             loadC((u32)lane, lkB, cndB);
@@ -2504,7 +2408,7 @@ struct WinParse {
 };
 
 // LZ4 blocks and raw Snappy in ONE kernel behind kernel A (round 4): the walk over a window of 64 positions (WinParse), then the sequences
-// of enc_emit_seq_kernel that start in it, from the same registers; at quality 0 the search as well.
+// that start in it, from the same registers; at quality 0 the search as well.
 template <int FMT, bool SEARCH>
 __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                            const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
@@ -2549,7 +2453,7 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
         uint2 a; u64 sm;
         ps.window(P, a, sm);
         if (sm == 0ull) continue;                                             // (no match starts here: the literals wait for the next one)
-        // ---- the sequences that start in this window (the body of enc_emit_seq_kernel)
+        // ---- the sequences that start in this window
         const bool start = ((sm >> lane) & 1ull) != 0ull;
         const u32 M = start ? a.y : 0u, D = a.x;
         const u32 mend = start ? p + M : 0u;
@@ -2567,7 +2471,11 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
             F::put_lit_hdr(dst + off, L, M, false);
             F::put_match(dst + off + lh + L, D, M);
         }
-        {   // (the literals: by their own lanes, enc_emit_seq_kernel)
+        // The literals: every literal POSITION of this window whose sequence starts in this window stores its own byte -- one pass, whatever
+        // the number of runs (as a loop over the runs, each copied by the wavefront, this was the longest kernel of the LZ4 batch at quality 0:
+        // 18.3 of 59 ms -- a dozen runs of a dozen bytes per window).  A lane finds the next start at or behind it with the start mask and
+        // takes that lane's numbers; only the FIRST start of a window can own literals of earlier windows: those the wavefront copies.
+        {
             const u64 above = (lane < 63 ? sm >> (lane + 1) : 0ull);
             const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;          // the next start behind me (my own lane: none)
             const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
@@ -2608,12 +2516,12 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
 // So two prefix sums (bits, payload bytes) place everything; flag bytes collect their bits in LDS and are stored by the token that owns
 // their last bit, as in enc_parse_emit_kernel.  A match of length 2 further than 0x100 back is not written as a match (its bytes go out as
 // literals; the parse has moved on behind it either way).
-// MODE 0: start mask and match array from memory (behind enc_roles_kernel); 1: the walk in here (WinParse); 2: and the one-candidate search
-template <bool BIG, int MODE>
+// The walk is in here (WinParse); SEARCH: the one-candidate search of quality 0 too.
+template <bool BIG, bool SEARCH>
 __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
                                                           u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
-                                                          const u64* __restrict__ startmask, alz_result* __restrict__ results,
+                                                          alz_result* __restrict__ results,
                                                           alz_encode_aux* __restrict__ aux, const int* __restrict__ prev4,
                                                           const int* __restrict__ prevm, EncGeom g) {
     __shared__ u32 flagacc[64];
@@ -2629,7 +2537,6 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
     const mentry* m = match + pos_off[sid];
-    const u64* mask = startmask + (pos_off[sid] >> 6);
     flagacc[lane] = 0; gofs[lane] = 0; hopmark[lane] = 0;
     __syncthreads();
     u32 bit_base = 0;       // flag bits before the window
@@ -2637,24 +2544,19 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     u32 cover = 0;          // end of the last match written as a match
     u32 lastk = 0xFFFFFFFFu;    // flag byte of the last payload before the window (none yet)
     bool fail = false;
-    u64 sm_n = (MODE == 0 && n) ? mask[0] : 0ull;
-    mentry mt_n = (MODE == 0 && (u32)lane < n) ? m[lane] : 0u;
     u32 sb_n = (u32)lane < n ? src[lane] : 0u;
-    WinParse<MODE == 2, ALZ_SEQ_PARSE_CAP> ps(g, src, (int)n, lane, m, prev4 + pos_off[sid], (MODE != 0 && g.use_min_table) ? prevm + pos_off[sid] : nullptr, hopmark, MODE != 0);
+    WinParse<SEARCH, ALZ_SEQ_PARSE_CAP> ps(g, src, (int)n, lane, m, prev4 + pos_off[sid], g.use_min_table ? prevm + pos_off[sid] : nullptr, hopmark);
     // one more trip behind the data for the end token (bit 0, two zero bytes, bit 1) on lane 0
     for (u32 P = 0; P < n + 64u; P += 64) {
         const bool tail = P >= n;
         if (tail && P > ((n + 63u) & ~63u)) break;                             // (exactly one trip behind the last window)
         const u32 p = P + (u32)lane;
-        u64 sm = tail ? 0ull : sm_n;
-        const mentry mt_raw = mt_n;
+        u64 sm = 0ull;
         const u32 sb = sb_n;
-        uint2 mt_all;
-        if (MODE == 0) { if (!tail) { if (P + 64 < n) sm_n = mask[(P >> 6) + 1]; if (p + 64 < n) mt_n = m[p + 64]; } }
-        else if (!tail) ps.window(P, mt_all, sm);
+        uint2 mt_all = make_uint2(0, 0);
+        if (!tail) ps.window(P, mt_all, sm);
         if (!tail && p + 64 < n) sb_n = src[p + 64];
         bool start = !tail && ((sm >> lane) & 1ull) && p < n;
-        if (MODE == 0) mt_all = m_start<false>(m, p, mt_raw, start);        // (a PRS match has at most 256 bytes)
         uint2 mt = make_uint2(0, 0);
         if (start) mt = mt_all;
         if (start && mt.y == 2u && mt.x > 0x100u) start = false;               // PRS.cs: not worth a long match -- literals
@@ -2909,7 +2811,7 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
             q += lzo_put_match(dst + q, D, M, emb);
             for (u32 i = 0; i < emb; i++) dst[q + i] = src[mend + i];
         }
-        {   // the literal runs (Lb >= 4), as in enc_emit_seq_kernel: every literal position whose unit starts in this window stores its own byte;
+        {   // the literal runs (Lb >= 4), as in enc_parse_seq_kernel: every literal position whose unit starts in this window stores its own byte;
             // what the first start owns of earlier windows the wavefront copies
             const u64 stm = __ballot(start);
             const u64 above = (lane < 63 ? stm >> (lane + 1) : 0ull);
@@ -2955,13 +2857,10 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
 
 // one candidate per position and a format whose parse and emit are one kernel: the search is in that kernel too (no kernel B, no match array)
 static bool searches_in_the_parse(int fmt, const EncGeom& g) {
-#ifdef ALZ_SEQ_TWO_KERNELS
-    if (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE) return false;
-#endif
     const bool par = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
                      fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON ||
                      fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW ||                        // (enc_parse_seq_kernel)
-                     fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;                                 // (enc_emit_prs_kernel<BIG, 2>)
+                     fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;                                 // (enc_emit_prs_kernel<BIG, true>)
     return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
 }
 
@@ -3138,44 +3037,24 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
-#ifdef ALZ_SEQ_TWO_KERNELS
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-        hipLaunchKernelGGL((enc_emit_prs_kernel<true, 0>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
-#else
-        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<true, 2>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
-        else hipLaunchKernelGGL((enc_emit_prs_kernel<true, 1>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
-#endif
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<true, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
+        else hipLaunchKernelGGL((enc_emit_prs_kernel<true, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }
     case ALZ_FMT_PRS_LE: {
-#ifdef ALZ_SEQ_TWO_KERNELS
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-        hipLaunchKernelGGL((enc_emit_prs_kernel<false, 0>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
-#else
-        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<false, 2>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
-        else hipLaunchKernelGGL((enc_emit_prs_kernel<false, 1>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux, d_prev4, d_prevm, g);
-#endif
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<false, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
+        else hipLaunchKernelGGL((enc_emit_prs_kernel<false, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }
     case ALZ_FMT_LZ4_BLOCK: {
-#ifdef ALZ_SEQ_TWO_KERNELS
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, tail);
-        hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-#else
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
-#endif
         break; }
     case ALZ_FMT_LZO: {
         hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
         hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
         break; }
     case ALZ_FMT_SNAPPY_RAW: {
-#ifdef ALZ_SEQ_TWO_KERNELS
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-        hipLaunchKernelGGL((enc_emit_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
-#else
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
-#endif
         break; }
     case ALZ_FMT_FASTLZ: launch_emit<ALZ_FMT_FASTLZ>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_HIG: launch_emit<ALZ_FMT_HIG>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;

@@ -490,7 +490,7 @@ static void benc_emit(hipStream_t stream, const BencLayout& L, const BencArgs& a
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// LZ4 blocks and raw Snappy (enc_emit_seq_kernel's formats): a sequence = the literals since the last match + the match, so a match start
+// LZ4 blocks and raw Snappy (enc_parse_seq_kernel's formats): a sequence = the literals since the last match + the match, so a match start
 // needs where the match in front of it ended -- a prefix MAX over the positions -- before its size is known, and the sizes' prefix SUM
 // before it can be written.  Three passes over tiles of 1 024 positions with the same body: 0 the tile's highest match end, 1 the tile's
 // bytes, 2 the bytes themselves; a scan over the tiles between them.  The literals behind the last match (LZ4: always a sequence) go out
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64) void benc_seq(BencArgs a, const u8* __restrict_
                     F::put_lit_hdr(dst + off, L, M, false);
                     F::put_match(dst + off + lh + L, D, M);
                 }
-                // the literals, as in enc_emit_seq_kernel: every literal position whose sequence starts in this group of 64 stores its own
+                // the literals, as in enc_parse_seq_kernel: every literal position whose sequence starts in this group of 64 stores its own
                 // byte; what the first start owns of earlier groups the wavefront copies
                 const u64 sm = __ballot(start);
                 const u64 above = (lane < 63u ? sm >> (lane + 1u) : 0ull);

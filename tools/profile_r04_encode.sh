@@ -20,6 +20,10 @@ for q in 0 8 15; do
   CMD="python3 bench.py --mode encode --quality $q --steps 3 --warmup 1 --no-cpu-baseline"
   run "cfg5 (synthetic, LZSS) at quality $q" rocprofv3 --kernel-trace --stats -d /tmp/pe -o e --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --mode encode --quality $q --steps 3 --warmup 1 --no-cpu-baseline
 done
+for f in lz4_block prs_be; do
+  CMD="python3 bench.py --mode encode --format $f --quality 0 --steps 3 --warmup 1 --no-cpu-baseline --configs none --no-extras"
+  run "cfg5 (synthetic) as $f at quality 0" rocprofv3 --kernel-trace --stats -d /tmp/pe -o e --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --mode encode --format $f --quality 0 --steps 3 --warmup 1 --no-cpu-baseline --configs none --no-extras
+done
 export ALZ_MID_N=1024
 for q in 0 8; do
   export ALZ_MID_Q=$q

@@ -1,6 +1,7 @@
 # LZ4 blocks / raw Snappy / PRS: enc_roles_kernel + the emitter (and kernel B at quality 0) as separate kernels (-DALZ_SEQ_TWO_KERNELS) against
 # the walk -- and at quality 0 the search -- inside the emitter (WinParse), and the bytes it compares per position at quality 0
-# (-DALZ_SEQ_PARSE_CAP=..).  Results: docs/EXPERIMENTS.md 9.9.
+# (-DALZ_SEQ_PARSE_CAP=..).  Results: docs/EXPERIMENTS.md 9.9.  (-DALZ_SEQ_TWO_KERNELS and the kernels behind it exist up to commit 302184c; the
+# default list below only sweeps the cap.)
 cd $GRAFT_REPO_ROOT
 run() {
   touch auroralib/compression_amd/csrc/alz_encode.hip
@@ -14,6 +15,6 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg5 $f q$q', d[
   ALZ_MID_Q=0,8,12 ALZ_MID_N=1024 timeout 600 python tools/mid_batch_encode.py lz4_block snappy_raw prs_be 2>&1 | grep -v amdgpu
   ALZ_MID_DATA=text ALZ_MID_Q=0,8 ALZ_MID_N=256 timeout 600 python tools/mid_batch_encode.py lz4_block prs_be 2>&1 | grep -v amdgpu
 }
-for f in ${ALZ_SEQ_EXPERIMENT_FLAGS:--DALZ_SEQ_TWO_KERNELS none -DALZ_SEQ_PARSE_CAP=32 -DALZ_SEQ_PARSE_CAP=64 -DALZ_SEQ_PARSE_CAP=128}; do
+for f in ${ALZ_SEQ_EXPERIMENT_FLAGS:-none -DALZ_SEQ_PARSE_CAP=32 -DALZ_SEQ_PARSE_CAP=64 -DALZ_SEQ_PARSE_CAP=128}; do
   if [ "$f" = none ]; then run ""; else run "$f"; fi
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage (GPU box): python tools/soak_encode.py [first_seed] [count]
+"""usage (GPU box): [ALZ_SOAK_Q=0] python tools/soak_encode.py [first_seed] [count]      (ALZ_SOAK_Q: one quality for every batch instead of a random one)
 Differential soak of the ENCODER: batches of raw buffers of many shapes (noise, runs, periods of 1..5000, few symbols, bitmap slices,
 mixtures; 1 B .. 3 MB) at qualities 0..15 in several formats, GPU output against the CPU restatement byte for byte.  Aimed at kernel A's
 queue / pass / drain logic (enc_prev_cu_kernel).  Not part of the test suite (minutes)."""
@@ -57,6 +57,8 @@ def main():
         rng = np.random.default_rng(seed)
         for fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_LZ4_BLOCK, A.FMT_LZ11, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO, A.FMT_LZHUDSON, A.FMT_REFPACK):
             q = int(rng.integers(0, 16))
+            if os.environ.get("ALZ_SOAK_Q"):
+                q = int(os.environ["ALZ_SOAK_Q"])
             sizes = [int(rng.choice([1, 3, 4, 5, 63, 64, 65, 2047, 2048, 2049, 3071, 3072, 3073, 24575, 24576, 24577, 32768, 65536, 65537])) for _ in range(6)]
             sizes += [int(rng.integers(1, 400000)) for _ in range(8)] + [int(rng.integers(400000, 3000000))]
             if q >= 10:                                     # (chains of up to 1 024 candidates on the CPU side)
