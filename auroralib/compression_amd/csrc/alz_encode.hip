@@ -24,10 +24,10 @@
 //                               enc_match_dense_kernel: the chains walked first into an LDS list, the pairs compared 64 at a time.
 //   C  the greedy/lazy parse as a walk over 64-position windows and the emission of a window's tokens by prefix sums, in ONE kernel from
 //                               the same registers (one wavefront per stream): enc_parse_emit_kernel (the flag-bit formats: LZSS, LZ10, LZ11,
-//                               Yaz0, Yay0, MIO0 ...), enc_parse_seq_kernel (LZ4, Snappy) and enc_emit_prs_kernel, the last two on
-//                               struct WinParse.  At quality 0 (one candidate per position) kernel B is inside them too.
-//      enc_roles_kernel         the walk alone: a bit per token start, in front of enc_emit_lzo_kernel (whose tokens look ahead of the walk) and
-//                               of enc_emit_kernel: emission on one lane per stream, for the formats that have no parallel emit yet.
+//                               Yaz0, Yay0, MIO0 ...), enc_parse_seq_kernel (LZ4, Snappy), enc_emit_prs_kernel and enc_parse_lzo_kernel,
+//                               the last three on struct WinParse.  At quality 0 (one candidate per position) kernel B is inside them too.
+//      enc_roles_kernel         the walk alone: a bit per token start, in front of enc_emit_kernel: emission on one lane per stream, for the
+//                               formats that have no parallel emit yet.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -490,18 +490,6 @@ typedef u32 mentry;
 #define ALZ_M_CAP 0x7FFu
 __device__ __forceinline__ mentry m_pack(u32 d, u32 l) { return (l << ALZ_M_DBITS) | d; }
 __device__ __forceinline__ uint2 m_unpack(mentry e) { const u32 l = e >> ALZ_M_DBITS; return make_uint2(e & ALZ_M_DMASK, l == ALZ_M_CAP ? ALZ_CAPPED : l); }
-// the (distance, length) of the entry a lane loaded for position p, behind the roles walk (nothing is capped any more); lanes that START
-// a token there get the exact length.  LONGS: the format has matches of 2 046 bytes or more.
-template <bool LONGS>
-__device__ __forceinline__ uint2 m_start(const mentry* m, u32 p, mentry e, bool start) {
-    uint2 r = make_uint2(e & ALZ_M_DMASK, e >> ALZ_M_DBITS);
-    if (LONGS) {
-        const bool lg = start && r.y == ALZ_M_LONG;
-        if (__ballot(lg)) { if (lg) r.y = m[p + 1]; }
-    }
-    return r;
-}
-
 // GetMatchLength  LzChainMatchFinder.cs:338-357
 __device__ __forceinline__ int match_len(const u8* a, const u8* b, int max) {
     int len = 0;
@@ -2242,7 +2230,7 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
 #define ALZ_SEQ_LANE_LIT 4u      /* literal runs up to this long are copied by their own lane, longer ones by the wavefront (4: 15.8 ms, 16: 17.8) */
 #endif
 // The walk of enc_roles_kernel one window of 64 positions at a time, for kernels that write a window's tokens right behind its parse
-// (enc_parse_seq_kernel, enc_emit_prs_kernel): no start mask in memory, and the exact matches the walk recomputes for capped
+// (enc_parse_seq_kernel, enc_emit_prs_kernel, enc_parse_lzo_kernel): no start mask in memory, and the exact matches the walk recomputes for capped
 // positions stay in registers.  SEARCH (one candidate per position -- quality 0 --, one property set, 16-bit links): kernel B is in here
 // too, as in enc_parse_emit_kernel<FMT, true>: the matches of window w + 1 are worked out while window w is parsed, the candidates'
 // bytes of window w + 2 and the links and own bytes of window w + 3 are in flight -- no match array at all.  CAP bytes are compared per
@@ -2644,13 +2632,13 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
     }
 }
 
-// LZO1X (LZO.cs:141-250) from the start mask.  The writer is sequential only at the head of a stream: a match that 1-3 literals precede
-// is cut at its front so that four go out, and a match cut below three bytes is not written -- which can leave 1-3 literals in front of
-// the next one.  Once a match HAS been written the state is clean for good: what follows it is 0-3 literals, which ride in its token
-// and go out right behind it, or four and more, a literal run of its own.  So lane 0 walks the head the reference's way until the first
-// match is out, and from there every match start is one unit -- (a literal run of >= 4, if one precedes it), its token in one of three
-// forms, the 0-3 literals behind it -- whose size follows from its own numbers and the position of the next start: a prefix sum
-// places the units, the wavefront copies the long runs.
+// LZO1X (LZO.cs:141-250), the walk (WinParse) and the writer in one kernel.  The writer is sequential only at the head of a stream: a match
+// that 1-3 literals precede is cut at its front so that four go out, and a match cut below three bytes is not written -- which can leave
+// 1-3 literals in front of the next one.  Once a match HAS been written the state is clean for good: what follows it is 0-3 literals,
+// which ride in its token and go out right behind it, or four and more, a literal run of its own.  So lane 0 walks the head the
+// reference's way until the first match is out, and from there every match start is one unit -- the 0-3 literals in front of it, or a
+// literal run of >= 4, then its token in one of three forms -- whose size follows from its own numbers: a prefix sum places the units, the
+// wavefront copies the long runs.  The count of the 0-3 literals behind a match sits in ITS token: that byte is written by the next unit.
 __device__ __forceinline__ u32 lzo_extn(u32 v) { return 1u + (v - 1u) / 255u; }                       // bytes of LZO.WriteExtendedInt(v), v >= 1
 __device__ __forceinline__ u32 lzo_put_ext(u8* q, u32 v) { u32 k = 0; while (v > 255u) { q[k++] = 0; v -= 255u; } q[k++] = (u8)v; return k; }
 __device__ __forceinline__ u32 lzo_lit_size(u32 L) { return L > 18u ? 1u + lzo_extn(L - 18u) : 1u; }  // the run's length token (L >= 4)
@@ -2681,14 +2669,36 @@ __device__ __forceinline__ u32 lzo_put_match(u8* q, u32 D, u32 M, u32 emb) {    
 #ifndef ALZ_LZO_LANE_LIT
 #define ALZ_LZO_LANE_LIT 4u
 #endif
-__global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+// the same without the byte that holds the count of the literals behind the match: `epos` = where it goes, `ebase` = its other bits
+__device__ __forceinline__ u32 lzo_put_match_def(u8* q, u32 D, u32 M, u32& epos, u32& ebase) {
+    if (M <= 8u && D <= 2048u) {
+        const u32 flag = (((D - 1u) & 7u) << 2) & 0xFFu;
+        ebase = M <= 4u ? (flag | 0x40u | ((M - 3u) << 5)) : (flag | 0x80u | ((M - 5u) << 5)); epos = 0;
+        q[1] = (u8)((D - 1u) >> 3);
+        return 2u;
+    }
+    u32 k;
+    if (D <= 16384u) {
+        if (M > 33u) { q[0] = 0x20; k = 1u + lzo_put_ext(q + 1, M - 33u); } else { q[0] = (u8)(0x20u | (M - 2u)); k = 1u; }
+        ebase = ((D - 1u) << 2) & 0xFFu; epos = k; q[k + 1] = (u8)(((D - 1u) >> 6) & 0xFFu);
+        return k + 2u;
+    }
+    const u32 d2 = D - 0x4000u, flag = (0x10u | ((d2 & 0x4000u) >> 11)) & 0xFFu;
+    if (M > 9u) { q[0] = (u8)flag; k = 1u + lzo_put_ext(q + 1, M - 9u); } else { q[0] = (u8)(flag | (M - 2u)); k = 1u; }
+    ebase = (d2 << 2) & 0xFFu; epos = k; q[k + 1] = (u8)((d2 >> 6) & 0xFFu);
+    return k + 2u;
+}
+template <bool SEARCH>
+__global__ __launch_bounds__(64) void enc_parse_lzo_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                           const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
                                                           u32 count, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
-                                                          const u64* __restrict__ startmask, alz_result* __restrict__ results,
-                                                          alz_encode_aux* __restrict__ aux) {
+                                                          alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux,
+                                                          const int* __restrict__ prev4, const int* __restrict__ prevm, EncGeom g) {
+    __shared__ u8 hopmark[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
+    hopmark[lane] = 0;
     const u32 sid = index_list[bid];
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
@@ -2696,8 +2706,6 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
     u8* dst = dst_base + st.dst_off;
     const u32 cap = st.dst_cap;
     const mentry* m = match + pos_off[sid];
-    const u64* mask = startmask + (pos_off[sid] >> 6);
-    const u32 nwords = n >= 4u ? ((n - 4u) >> 6) + 1u : 0u;                   // mask words that can hold a start
     auto finish = [&](u32 total, bool fail, int status) {
         if (lane == 0) {
             alz_result r; r.dst_len = (fail || status != ALZ_ST_OK) ? 0u : total; r.src_used = n;
@@ -2705,15 +2713,6 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
             results[sid] = r;
             if (aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
         }
-    };
-    // the next start at or behind `from` (n: none)
-    auto next_start = [&](u32 from) -> u32 {
-        for (u32 wi = from >> 6; wi < nwords; wi++) {
-            u64 w = mask[wi];
-            if (wi == (from >> 6)) w &= ~0ull << (from & 63u);
-            if (w) return wi * 64u + (u32)__builtin_ctzll(w);
-        }
-        return n;
     };
     // ---- the head, the reference's way, on lane 0 (everything here is wave-uniform: the other lanes follow along and do not store)
     u32 sp = 0, olen = 0; bool fail = false; int status = ALZ_ST_OK;
@@ -2724,8 +2723,28 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
         finish(olen, fail, status);
         return;
     }
-    u32 mo = next_start(0), ml = 0, md = 0;                                   // mt: offset, length, distance
-    if (mo < n) { uint2 r = m_unpack(m[mo]); if (r.y == ALZ_M_LONG) r.y = m[mo + 1]; md = r.x; ml = r.y; }
+    // The walk, window by window (WinParse): `wa` / `wsm` = the matches and the start bits of the window at wP.  The head asks for one start
+    // after the other (the next one always behind the last), which moves the window forward; the units behind it take the windows in order.
+    WinParse<SEARCH, ALZ_SEQ_PARSE_CAP> ps(g, src, (int)n, lane, m, prev4 + pos_off[sid], g.use_min_table ? prevm + pos_off[sid] : nullptr, hopmark);
+    u32 wP = 0; uint2 wa; u64 wsm;
+    ps.window(0, wa, wsm);
+    // the next start at or behind `from` (n: none), and its match
+    auto next_start = [&](u32 from, u32& d, u32& l) -> u32 {
+        for (;;) {
+            u64 w = wsm;
+            if (from > wP) w = from - wP < 64u ? w & (~0ull << (from - wP)) : 0ull;
+            if (w) {
+                const int b = (int)__builtin_ctzll(w);
+                d = (u32)__builtin_amdgcn_readlane((int)wa.x, b); l = (u32)__builtin_amdgcn_readlane((int)wa.y, b);
+                return wP + (u32)b;
+            }
+            if (wP + 64u >= n) { wsm = 0ull; d = 0; l = 0; return n; }
+            wP += 64u;
+            ps.window(wP, wa, wsm);
+        }
+    };
+    u32 ml = 0, md = 0;                                                       // mt: offset, length, distance
+    u32 mo = next_start(0, md, ml);
     u32 mbit = mo;                                                            // mt's bit in the mask (mo itself may be moved below)
     bool clean = false;
     while (sp != n && !clean) {
@@ -2737,8 +2756,8 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
             copy(sp, plain); sp += plain;
         }
         // the finder's next match: the next bit of the mask
-        u32 no = mbit < n ? next_start(mbit + 1u) : n, nl = 0, nd = 0;
-        if (no < n) { uint2 r = m_unpack(m[no]); if (r.y == ALZ_M_LONG) r.y = m[no + 1]; nd = r.x; nl = r.y; }
+        u32 nl = 0, nd = 0;
+        const u32 no = mbit < n ? next_start(mbit + 1u, nd, nl) : n;
         if (ml >= 3u) {
             sp += ml;
             u32 emb = no - sp;
@@ -2771,17 +2790,18 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
     // ---- the rest: one unit per match start at or behind sp
     const u32 sp0 = sp;
     u32 cover = sp0, obase = olen;
-    const u32 P0 = sp0 & ~63u;
-    u64 sm_n = (P0 >> 6) < nwords ? mask[P0 >> 6] : 0ull;                     // (mask word and matches of a window are loaded one window ahead)
-    mentry mt_n = P0 + (u32)lane < n ? m[P0 + (u32)lane] : 0u;
-    for (u32 P = P0; P < n; P += 64) {
+    // A token carries the count of the 0-3 literals BEHIND it (its low two bits): that is known when the next start is, so the byte that holds
+    // them is written by the NEXT unit (or at the end of the data) -- `pend`: where it goes and its other bits -- and those literals are the
+    // first bytes of that unit.
+    u32 pend_addr = 0xFFFFFFFFu, pend_val = 0;
+    bool held = true;                                                          // the window the head stopped in is in wa / wsm
+    for (u32 P = wP; P < n; P += 64) {
         const u32 p = P + (u32)lane;
-        const u64 sm = sm_n;
-        const mentry mt_raw = mt_n;
-        if (P + 64 < n) { sm_n = ((P >> 6) + 1u) < nwords ? mask[(P >> 6) + 1u] : 0ull; if (p + 64 < n) mt_n = m[p + 64]; }
+        uint2 mt_all; u64 sm;
+        if (held) { mt_all = wa; sm = wsm; held = false; } else ps.window(P, mt_all, sm);
         const bool start = ((sm >> lane) & 1ull) && p >= mo && p < n;          // (mo: the first match not yet written)
-        if (__ballot(start) == 0ull) continue;
-        const uint2 mt_all = m_start<true>(m, p, mt_raw, start);
+        const u64 stm = __ballot(start);
+        if (stm == 0ull) continue;
         uint2 mt = make_uint2(0, 0);
         if (start) mt = mt_all;
         const u32 M = mt.y, D = mt.x;
@@ -2789,31 +2809,33 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
         const u32 pmax = scan_max(mend);
         u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);
         if (before < cover) before = cover;
-        const u32 Lb = start ? p - before : 0u;                                // literals since the match before (0-3: that one carried them)
-        u32 emb = 0;
-        if (start) {                                                           // the next start (or the end of the data) within three bytes behind my match
-#pragma unroll
-            for (u32 kk = 0; kk < 4u; kk++) {
-                const u32 q = mend + kk;
-                const bool hit = q >= n || (((q >> 6) < nwords) && ((mask[q >> 6] >> (q & 63u)) & 1ull));
-                if (hit) { emb = q >= n ? n - mend : kk; break; }
-            }
-        }
-        const u32 lsz = Lb >= 4u ? lzo_lit_size(Lb) : 0u, lcp = Lb >= 4u ? Lb : 0u;
-        const u32 esz = start ? lsz + lcp + lzo_match_size(D, M) + emb : 0u;
+        const u32 Lb = start ? p - before : 0u;                                // literals since the match before (0-3: that one's token counts them)
+        const u32 lsz = Lb >= 4u ? lzo_lit_size(Lb) : 0u;
+        const u32 esz = start ? lsz + Lb + lzo_match_size(D, M) : 0u;
         const u32 incl = scan_add(esz);
         const u32 off = obase + incl - esz;
         const bool fits = start && off + esz <= cap;
         if (start && !fits) fail = true;
+        u32 eaddr = 0xFFFFFFFFu, ebase = 0;
         if (fits) {
             u32 q = off;
             if (Lb >= 4u) { q += lzo_put_lit(dst + q, Lb); q += Lb; }
-            q += lzo_put_match(dst + q, D, M, emb);
-            for (u32 i = 0; i < emb; i++) dst[q + i] = src[mend + i];
+            else { for (u32 i = 0; i < Lb; i++) dst[q + i] = src[before + i]; q += Lb; }
+            u32 epos;
+            (void)lzo_put_match_def(dst + q, D, M, epos, ebase);
+            eaddr = q + epos;
+        }
+        {   // the deferred byte of the token in front of mine (the start below me in this window, or `pend`) with my literal count
+            const u64 below = stm & ((1ull << lane) - 1ull);
+            const int pl = below ? 63 - (int)__builtin_clzll(below) : lane;
+            u32 paddr = (u32)__builtin_amdgcn_ds_bpermute(pl << 2, (int)eaddr), pval = (u32)__builtin_amdgcn_ds_bpermute(pl << 2, (int)ebase);
+            if (!below) { paddr = pend_addr; pval = pend_val; }
+            if (start && paddr < cap) dst[paddr] = (u8)(pval | (Lb <= 3u ? Lb : 0u));
+            const int l0 = 63 - (int)__builtin_clzll(stm);
+            pend_addr = (u32)__builtin_amdgcn_readlane((int)eaddr, l0); pend_val = (u32)__builtin_amdgcn_readlane((int)ebase, l0);
         }
         {   // the literal runs (Lb >= 4), as in enc_parse_seq_kernel: every literal position whose unit starts in this window stores its own byte;
             // what the first start owns of earlier windows the wavefront copies
-            const u64 stm = __ballot(start);
             const u64 above = (lane < 63 ? stm >> (lane + 1) : 0ull);
             const int s = above ? lane + 1 + (int)__builtin_ctzll(above) : lane;
             const u32 sbef = (u32)__builtin_amdgcn_ds_bpermute(s << 2, (int)before);
@@ -2831,7 +2853,11 @@ __global__ __launch_bounds__(64) void enc_emit_lzo_kernel(const u8* __restrict__
     }
     // ---- behind the last match: 0-3 literals went out with it; four and more are a run of their own; then the end token
     u32 rest = n - cover;
-    if (rest <= 3u) rest = 0u;
+    if (rest <= 3u) {                                                          // (they ride in the last token; there is one: the head ends behind a match with >= 4 bytes or a start to go)
+        if (pend_addr < cap && lane == 0) dst[pend_addr] = (u8)(pend_val | rest);
+        if (obase + rest <= cap) { if ((u32)lane < rest) dst[obase + (u32)lane] = src[cover + (u32)lane]; } else fail = true;
+        obase += rest; rest = 0u;
+    } else if (pend_addr < cap && lane == 0) dst[pend_addr] = (u8)pend_val;
     const u32 lsz = rest ? lzo_lit_size(rest) : 0u;
     const u32 total = obase + lsz + rest + 3u;
     if (total > cap) fail = true;
@@ -2860,7 +2886,8 @@ static bool searches_in_the_parse(int fmt, const EncGeom& g) {
     const bool par = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 ||
                      fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON ||
                      fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW ||                        // (enc_parse_seq_kernel)
-                     fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;                                 // (enc_emit_prs_kernel<BIG, true>)
+                     fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE ||                               // (enc_emit_prs_kernel)
+                     fmt == ALZ_FMT_LZO;                                                             // (enc_parse_lzo_kernel)
     return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
 }
 
@@ -3049,8 +3076,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         break; }
     case ALZ_FMT_LZO: {
-        hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, g, 0);
-        hipLaunchKernelGGL(enc_emit_lzo_kernel, dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, (const u64*)d_mask, d_results, d_aux);
+        if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_lzo_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
+        else hipLaunchKernelGGL((enc_parse_lzo_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }
     case ALZ_FMT_SNAPPY_RAW: {
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);

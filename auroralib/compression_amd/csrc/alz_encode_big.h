@@ -718,7 +718,7 @@ static hipError_t benc_emit_prs(hipStream_t stream, const BencLayout& L, const B
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// LZO1X (enc_emit_lzo_kernel's rules, LZO.cs:141-250).  The writer is sequential only at the head of a stream, until the first match is out:
+// LZO1X (enc_parse_lzo_kernel's rules, LZO.cs:141-250).  The writer is sequential only at the head of a stream, until the first match is out:
 // one wavefront walks it the reference's way (benc_lzo_head).  From there every match start is one unit -- a literal run of >= 4 in front
 // of it, its token, the 0-3 literals behind it -- whose size follows from its own numbers, the end of the match in front of it (prefix
 // max) and whether a start or the end of the data lies within three bytes behind it: the three passes of the sequence formats.
