@@ -60,6 +60,34 @@ def test_encode_edge_inputs(fmt):
         _encode_and_compare(fmt, raws, q)
 
 
+def _token_soup(rng, size):
+    """Short literal runs between short and long repeats at short and long distances: token starts on every lane of a 64-position window,
+    literal runs of 0..5 (LZO counts 0-3 of them in the token in front), matches that end in the next window or many windows on."""
+    out = bytearray(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tobytes())
+    while len(out) < size:
+        k = int(rng.integers(0, 10))
+        if k < 3 or len(out) < 8:
+            out += rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8).tobytes()
+        else:
+            d = int(rng.integers(1, min(len(out), 70 if k < 7 else 3000) + 1))
+            ln = int(rng.integers(2, 12)) if k < 8 else int(rng.integers(12, 400))
+            for _ in range(ln):
+                out.append(out[-d])
+    return bytes(out[:size])
+
+
+@pytest.mark.parametrize("fmt", [A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZO, A.FMT_LZ11, A.FMT_LZ40])
+@pytest.mark.parametrize("quality", [0, 3, 8])
+def test_encode_window_edges(fmt, quality):
+    """The kernels that walk and emit 64 positions at a time (WinParse; at quality 0 with the search inside): buffers of every length around
+    one, two and three windows, and token soup that puts starts, carried starts and match ends on every lane."""
+    rng = np.random.default_rng(1000 * fmt + quality)
+    sizes = list(range(1, 24)) + list(range(56, 72)) + list(range(120, 136)) + list(range(184, 200)) + [255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097]
+    raws = [_token_soup(rng, n) for n in sizes] + [_token_soup(rng, int(rng.integers(300, 20000))) for _ in range(40)]
+    raws += [bytes([7]) * n for n in (63, 64, 65, 128, 129, 5000)] + [(b"abcdefg" * 1000)[:n] for n in (64, 65, 127, 4099)]
+    _encode_and_compare(fmt, raws, quality)
+
+
 @pytest.mark.parametrize("fmt", [A.FMT_LZ10, A.FMT_LZ11])
 def test_encode_vram_mode(fmt, test_bmp):
     _encode_and_compare(fmt, [test_bmp[:20000], bytes(300)], 8, min_distance=2)
