@@ -1919,7 +1919,11 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
             // (LZ11 / LZ40 -- matches of up to 16 KiB --: a window the cursor has already jumped over is never looked at, its stage is left out
             // as in enc_parse_seq_kernel: 1 024 windows of Test.bmp 11.65 -> 11.23 ms, 4 096 25.0 -> 23.7.  With Yaz0's 273 bytes -3 % on the
             // bitmap and +2 % on text; the 18 bytes of LZ10 never skip a window: +1.5 %)
+#ifdef ALZ_PARSE_SKIP_ALL                   /* tools/parse_skip_experiment.sh */
+            constexpr bool SKIPW = true;
+#else
             constexpr bool SKIPW = FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40;
+#endif
             if (!SKIPW || cur < (int)P + 128) a_n = matchof(p + 64u, lkB, ownB, cndB);    // window w + 1 (bytes that arrived during the window before)
             lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
             if (!SKIPW || cur < (int)P + 192) loadC(p + 128u, lkB, cndB);                 // window w + 2's candidates

@@ -1,4 +1,5 @@
-# enc_parse_emit_kernel<FMT, true>: the look-ahead stages of windows the cursor has already jumped over left out (-DALZ_PARSE_SKIP).
+# enc_parse_emit_kernel<FMT, true>: the look-ahead stages of windows the cursor has already jumped over left out -- for LZ11 / LZ40 by default, for every
+# flag-bit format with -DALZ_PARSE_SKIP_ALL (docs/EXPERIMENTS.md 9.9).
 cd $GRAFT_REPO_ROOT
 run() {
   touch auroralib/compression_amd/csrc/alz_encode.hip
@@ -13,6 +14,6 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg5 $f q0', d['
   ALZ_MID_DATA=text ALZ_MID_Q=0 ALZ_MID_N=256 timeout 600 python tools/mid_batch_encode.py yaz0 lz11 2>&1 | grep -v amdgpu
 }
 run ""
-run "-DALZ_PARSE_SKIP"
+run "-DALZ_PARSE_SKIP_ALL"
 run ""
-run "-DALZ_PARSE_SKIP"
+run "-DALZ_PARSE_SKIP_ALL"
