@@ -2895,6 +2895,15 @@ static bool searches_in_the_parse(int fmt, const EncGeom& g) {
     return par && g.max_chain == 1 && g.nprops <= 1 && !g.use_min_table && g.link16;
 }
 
+// 1: the format's emitter runs behind enc_roles_kernel and reads its start mask (the formats without a parallel emitter); the others walk inside their emitter
+int alz_encode_format_needs_mask(int fmt) {
+    switch (fmt) {
+    case ALZ_FMT_SMSR00: case ALZ_FMT_FASTLZ: case ALZ_FMT_HIG: case ALZ_FMT_LZSHREK: case ALZ_FMT_WFLZ: case ALZ_FMT_WFLZ_BE: case ALZ_FMT_REFPACK:
+    case ALZ_FMT_LZ02: case ALZ_FMT_CNS: case ALZ_FMT_CNX2: return 1;
+    default: return 0;
+    }
+}
+
 int alz_encode_geom_needs_match(int fmt, const void* geom) { EncGeom g; memcpy(&g, geom, sizeof(g)); return searches_in_the_parse(fmt, g) ? 0 : 1; }
 
 template <int FMT>

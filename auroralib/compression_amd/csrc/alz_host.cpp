@@ -792,7 +792,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
     std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
-    bool any_min = false, any_match = false;
+    bool any_min = false, any_match = false, any_mask = false;
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
@@ -814,6 +814,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
         any_min = any_min || alz_encode_geom_min_table(g);
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
+        any_mask = any_mask || alz_encode_format_needs_mask(lvl2 ? ALZ_FMT_FASTLZ : f);
     }
     // ---- a handful of big streams: each of them on the whole GPU (alz_encode_big.h).  A stream the path declines (too many positions that
     // need an exact second search) sends the whole call through the batch pipeline below.
@@ -910,7 +911,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64, any_match);   // one 32-bit entry per position (alz_encode.hip: mentry); not when every launch searches inside its parse + emit kernel
     if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
-    if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64);
+    if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64, any_mask);          // a bit per position: the start mask of enc_roles_kernel, for the formats whose emitter is a kernel of its own
     void* d_tail = nullptr; uint32_t* d_sel = nullptr;
     if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, !tail_ix.empty());
     { void* skip_big = nullptr; if (e == hipSuccess) e = sc.alloc(&skip_big, 0, false); }        // (slot 11: the whole-GPU path's scratch)
@@ -941,7 +942,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     HIP_TRY(hipMemcpyAsync(d_pos, pos_off.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d_results, 0xFF, (size_t)n * sizeof(alz_result), c->stream));
     HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
-    HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)total / 8 + 64, c->stream));
+    if (any_mask) HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)total / 8 + 64, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
