@@ -118,6 +118,7 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
     const int lane = (int)(threadIdx.x & 63u);
     const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const u32 sid = index_list[bid];
+    if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_words_kernel: unused slots)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
@@ -2918,6 +2919,13 @@ static void launch_emit_par(hipStream_t s, u32 count, const u8* src, u8* dst, co
 static bool uses_win_prev(const EncGeom& g) {
     return g.max_dist <= 8192 && (g.hash_bits > 15 || g.use_min_table);
 }
+static bool narrows_links(const EncGeom& g) {
+#ifdef ALZ_NO_NARROW                         /* tools/narrow_experiment.sh */
+    return false;
+#endif
+    return g.link16 && g.nprops <= 1 && !g.use_min_table && g.hash_bits > 15 && !uses_win_prev(g);
+}
+int alz_encode_geom_narrows(const void* geom) { EncGeom g; memcpy(&g, geom, sizeof(g)); return narrows_links(g) ? 1 : 0; }
 
 // Which kernel B for a stream, from maxChain 3 on?  The two-phase kernel (chains first, the pairs 64 at a time) keeps its lanes busy where
 // candidates are many and short -- the synthetic batches: 94 against 138 ms per 10 000 x 256 KiB at quality 8 --, the one-position-per-lane
@@ -2961,6 +2969,84 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 
 // kernel A: the head table in LDS (hashBits = 15 + floor(sqrt(2 Q)) = 15..20, LzChainMatchFinder.cs:108-119) -- one pass with the
 // tag / link rings where matches reach back at most 8 KiB, otherwise 2^(hashBits - 15) passes (+ 2 for the min-length table)
+// Which way for a stream (see below): the share of DISTINCT 15-bit hashes among 4 x 1 024 consecutive positions.  Flat and repetitive data (few
+// distinct words: the 15-bit chain's first entry is nearly always the one) narrows fast and makes kernel A's passes slow (crowded hash classes):
+// 1 024 windows of Test.bmp as LZ4 blocks at quality 8 48.6 -> 37.3 ms; on data whose words are nearly all distinct (the synthetic batch,
+// program text) a narrowing walk runs through two or three candidates per position and loses against the passes (145 -> 158 ms, 13.6 -> 14.5).
+// Two lists of stream ids (cursor in front, unused slots stay 0xFFFFFFFF): [0] narrow, [pitch] kernel A at the finder's own width.
+#ifndef ALZ_NARROW_THRESH16
+#define ALZ_NARROW_THRESH16 4u      /* narrow below a quarter: Test.bmp 39.5 ms (8: 39.2, every stream: 37.3), program text 13.75 (8: 14.95, kernel A's passes: 13.6), the synthetic batch 147 (12: 161) */
+#endif
+__global__ __launch_bounds__(256) void enc_words_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                        const u32* __restrict__ index_list, int tail_skip, u32* __restrict__ lists, u32 pitch, u32 thresh16) {
+    __shared__ u32 bm[1024];
+    __shared__ u32 cnt[2];
+    const u32 sid = index_list[blockIdx.x];
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int limit = (int)st.src_len - tail_skip - 4;
+    if (threadIdx.x < 2u) cnt[threadIdx.x] = 0;
+    u32 fresh = 0, tot = 0;
+    for (int k = 0; k < 4; k++) {
+        for (u32 i = threadIdx.x; i < 1024u; i += 256u) bm[i] = 0;
+        __syncthreads();
+        const long long base = ((long long)limit + 1) * (2 * k + 1) / 8;
+        for (u32 i = threadIdx.x; i < 1024u; i += 256u) {
+            const long long p = base + i;
+            if (p <= (long long)limit) {
+                const u32 h = (load32(data + p) * 2654435761u) >> 17;
+                const u32 bit = 1u << (h & 31u);
+                if (!(atomicOr(&bm[h >> 5], bit) & bit)) fresh++;
+                tot++;
+            }
+        }
+        __syncthreads();
+    }
+    atomicAdd(&cnt[0], fresh); atomicAdd(&cnt[1], tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool narrow = cnt[1] >= 256u && cnt[0] * 16u < cnt[1] * thresh16;
+        u32* l = lists + (narrow ? 0u : pitch);
+        l[1u + atomicAdd(l, 1u)] = sid;
+    }
+}
+
+// Kernel A at 15 bits for every hash width (round 4).  The finder's hash is the top hashBits bits of ONE product (ComputeHash :288-299), so the
+// positions with my hashBits-bit hash are a subsequence of the positions with my 15-bit hash, in the same order: prev() at hashBits bits is the
+// first position on the 15-bit chain whose product agrees in the top hashBits bits.  Kernel A pays 2^(hashBits - 15) passes over a stream for
+// the wide hash where the head table does not fit the LDS (the formats with windows above 8 KiB: 64.5 against 14.7 ms per 10 000 x 256 KiB as
+// LZ4 blocks at quality 8); one pass at 15 bits and this kernel -- a position per thread walks its 15-bit chain to the first agreeing
+// position, usually the first or second -- cost less.  A link further than maxDistance back is stored as none: that ends a walk either way
+// (LzChainMatchFinder.cs:259-260).  16-bit links, one property set, no min-length table (its links live in the array this kernel writes).
+// Per stream, where it pays: enc_words_kernel above.
+__global__ __launch_bounds__(256) void enc_narrow_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                         const u32* __restrict__ index_list, const int* __restrict__ prev15,
+                                                         int* __restrict__ prevw, const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    const u32 sid = index_list[blockIdx.y];
+    if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_words_kernel: unused slots)
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int limit = (int)st.src_len - tail_skip - 4;
+    const unsigned short* l15 = reinterpret_cast<const unsigned short*>(prev15 + pos_off[sid]);
+    unsigned short* lw = reinterpret_cast<unsigned short*>(prevw + pos_off[sid]);
+    const u32 sh = 32u - (u32)g.hash_bits;
+    for (long long p64 = (long long)blockIdx.x * 256 + threadIdx.x; p64 <= (long long)limit; p64 += (long long)gridDim.x * 256) {
+        // (blocks interleaved over the stream and the two loads of a hop one after the other: a workgroup per contiguous range with both loads in
+        // flight together was slower on the synthetic batch, 158 -> 174 ms, and the same on Test.bmp)
+        const int pos = (int)p64;
+        const u32 own = load32(data + pos) * 2654435761u;
+        u32 link = l15[pos], d = 0, res = 0;
+        while (link != 0u) {
+            d += link;
+            if (d > (u32)g.max_dist) break;
+            const int c = pos - (int)d;
+            if (((load32(data + c) * 2654435761u) ^ own) >> sh == 0u) { res = d; break; }
+            link = l15[c];
+        }
+        lw[pos] = (unsigned short)res;
+    }
+}
+
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
                               int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes = false) {
     if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
@@ -3060,8 +3146,25 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     g.b_cap = choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
-    if (ea != hipSuccess) return ea;
+    if (narrows_links(g) && d_prevm != nullptr && d_sel != nullptr) {
+        // per stream (enc_words_kernel): kernel A at 15 bits and the links of the finder's own hash width narrowed from them, or kernel A at that
+        // width -- either way into the (otherwise unused) array of the min-length table: what follows reads its links there
+        u32* l_narrow = d_sel; u32* l_wide = d_sel + sel_pitch + 2u;                                   // (count + 1 words each; the probe of kernel B takes the array over afterwards)
+        (void)hipMemsetAsync(d_sel, 0xFF, ((size_t)sel_pitch + 2u + count + 1u) * sizeof(u32), stream);
+        (void)hipMemsetAsync(l_narrow, 0, 4, stream); (void)hipMemsetAsync(l_wide, 0, 4, stream);
+        hipLaunchKernelGGL(enc_words_kernel, dim3(count), dim3(256), 0, stream, src, d_streams, d_index, tail, d_sel, sel_pitch + 2u, ALZ_NARROW_THRESH16);
+        EncGeom g15 = g; g15.hash_bits = 15;
+        const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, nullptr, d_pos_off, g15, tail);
+        if (e15 != hipSuccess) return e15;
+        u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
+        hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, l_narrow + 1, d_prev4, d_prevm, d_pos_off, g, tail);
+        const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_prevm, nullptr, d_pos_off, g, tail);
+        if (ew != hipSuccess) return ew;
+        d_prev4 = d_prevm; d_prevm = nullptr;
+    } else {
+        const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+        if (ea != hipSuccess) return ea;
+    }
     if (!searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u, true, d_sel, sel_pitch);
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {

@@ -812,7 +812,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         }
         if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &sf, g, nullptr, lvl2 ? 1 : 0))
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
-        any_min = any_min || alz_encode_geom_min_table(g);
+        any_min = any_min || alz_encode_geom_min_table(g) || alz_encode_geom_narrows(g);
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
         any_mask = any_mask || alz_encode_format_needs_mask(lvl2 ? ALZ_FMT_FASTLZ : f);
     }
@@ -908,7 +908,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int) + 256);   // (+ slack: the look-ahead of the fused parse kernel reads a link of an empty last stream)
-    if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int), any_min);
+    if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int) + 256, any_min);   // the min-length table's links, or the narrowed links (enc_narrow_kernel)
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64, any_match);   // one 32-bit entry per position (alz_encode.hip: mentry); not when every launch searches inside its parse + emit kernel
     if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64, any_mask);          // a bit per position: the start mask of enc_roles_kernel, for the formats whose emitter is a kernel of its own

@@ -27,6 +27,7 @@ size_t alz_encode_geom_size(void);
 int alz_encode_geom_hash_bits(const void* geom);
 int alz_encode_geom_min_table(const void* geom);
 int alz_encode_geom_max_dist(const void* geom);
+int alz_encode_geom_narrows(const void* geom);                  // 1: kernel A links at 15 bits and enc_narrow_kernel writes the finder's own links into the min-length table's array (which must exist)
 int alz_encode_format_needs_mask(int fmt);                      // 1: the format's emitter reads the start mask of enc_roles_kernel (zeroed before the launch)
 int alz_encode_geom_needs_match(int fmt, const void* geom);   // 0: the search runs inside the parse + emit kernel (no kernel B, no match array)
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
