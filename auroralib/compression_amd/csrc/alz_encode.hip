@@ -2923,7 +2923,10 @@ static bool narrows_links(const EncGeom& g) {
 #ifdef ALZ_NO_NARROW                         /* tools/narrow_experiment.sh */
     return false;
 #endif
-    return g.link16 && g.nprops <= 1 && !g.use_min_table && g.hash_bits > 15 && !uses_win_prev(g);
+#ifdef ALZ_NO_NARROW_WIN                     /* tools/narrow_experiment.sh: not for the formats with windows up to 8 KiB */
+    if (uses_win_prev(g)) return false;
+#endif
+    return g.link16 && g.nprops <= 1 && !g.use_min_table && g.hash_bits > 15;
 }
 int alz_encode_geom_narrows(const void* geom) { EncGeom g; memcpy(&g, geom, sizeof(g)); return narrows_links(g) ? 1 : 0; }
 
@@ -3147,19 +3150,27 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     if (narrows_links(g) && d_prevm != nullptr && d_sel != nullptr) {
-        // per stream (enc_words_kernel): kernel A at 15 bits and the links of the finder's own hash width narrowed from them, or kernel A at that
-        // width -- either way into the (otherwise unused) array of the min-length table: what follows reads its links there
-        u32* l_narrow = d_sel; u32* l_wide = d_sel + sel_pitch + 2u;                                   // (count + 1 words each; the probe of kernel B takes the array over afterwards)
-        (void)hipMemsetAsync(d_sel, 0xFF, ((size_t)sel_pitch + 2u + count + 1u) * sizeof(u32), stream);
-        (void)hipMemsetAsync(l_narrow, 0, 4, stream); (void)hipMemsetAsync(l_wide, 0, 4, stream);
-        hipLaunchKernelGGL(enc_words_kernel, dim3(count), dim3(256), 0, stream, src, d_streams, d_index, tail, d_sel, sel_pitch + 2u, ALZ_NARROW_THRESH16);
+        // kernel A at 15 bits and the links of the finder's own hash width narrowed from them, into the (otherwise unused) array of the min-length
+        // table: what follows reads its links there.  Windows up to 8 KiB: every stream (a walk meets a 15-bit collision once in eight positions:
+        // synthetic LZSS batch at quality 8 94.2 -> 91.1 ms, Test.bmp windows -2 %).  64 KiB windows: per stream (enc_words_kernel), the others
+        // through kernel A at the finder's own width.
         EncGeom g15 = g; g15.hash_bits = 15;
-        const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, nullptr, d_pos_off, g15, tail);
-        if (e15 != hipSuccess) return e15;
         u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
-        hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, l_narrow + 1, d_prev4, d_prevm, d_pos_off, g, tail);
-        const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_prevm, nullptr, d_pos_off, g, tail);
-        if (ew != hipSuccess) return ew;
+        if (uses_win_prev(g)) {
+            const hipError_t e15 = launch_prev(stream, src, d_streams, d_index, count, d_prev4, nullptr, d_pos_off, g15, tail);
+            if (e15 != hipSuccess) return e15;
+            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, d_pos_off, g, tail);
+        } else {
+            u32* l_narrow = d_sel; u32* l_wide = d_sel + sel_pitch + 2u;                               // (count + 1 words each; the probe of kernel B takes the array over afterwards)
+            (void)hipMemsetAsync(d_sel, 0xFF, ((size_t)sel_pitch + 2u + count + 1u) * sizeof(u32), stream);
+            (void)hipMemsetAsync(l_narrow, 0, 4, stream); (void)hipMemsetAsync(l_wide, 0, 4, stream);
+            hipLaunchKernelGGL(enc_words_kernel, dim3(count), dim3(256), 0, stream, src, d_streams, d_index, tail, d_sel, sel_pitch + 2u, ALZ_NARROW_THRESH16);
+            const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, nullptr, d_pos_off, g15, tail);
+            if (e15 != hipSuccess) return e15;
+            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, l_narrow + 1, d_prev4, d_prevm, d_pos_off, g, tail);
+            const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_prevm, nullptr, d_pos_off, g, tail);
+            if (ew != hipSuccess) return ew;
+        }
         d_prev4 = d_prevm; d_prevm = nullptr;
     } else {
         const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
