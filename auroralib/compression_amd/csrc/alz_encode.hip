@@ -2977,6 +2977,9 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 // 1 024 windows of Test.bmp as LZ4 blocks at quality 8 48.6 -> 37.3 ms; on data whose words are nearly all distinct (the synthetic batch,
 // program text) a narrowing walk runs through two or three candidates per position and loses against the passes (145 -> 158 ms, 13.6 -> 14.5).
 // Two lists of stream ids (cursor in front, unused slots stay 0xFFFFFFFF): [0] narrow, [pitch] kernel A at the finder's own width.
+#ifndef ALZ_NARROW_WGS
+#define ALZ_NARROW_WGS 4096u      /* 64 KiB windows: workgroups of enc_narrow_kernel per launch, at least (each fetches the 64 KiB behind its range again) */
+#endif
 #ifndef ALZ_NARROW_THRESH16
 #define ALZ_NARROW_THRESH16 4u      /* narrow below a quarter: Test.bmp 39.5 ms (8: 39.2, every stream: 37.3), program text 13.75 (8: 14.95, kernel A's passes: 13.6), the synthetic batch 147 (12: 161) */
 #endif
@@ -3033,9 +3036,11 @@ __global__ __launch_bounds__(256) void enc_narrow_kernel(const u8* __restrict__ 
     const unsigned short* l15 = reinterpret_cast<const unsigned short*>(prev15 + pos_off[sid]);
     unsigned short* lw = reinterpret_cast<unsigned short*>(prevw + pos_off[sid]);
     const u32 sh = 32u - (u32)g.hash_bits;
-    for (long long p64 = (long long)blockIdx.x * 256 + threadIdx.x; p64 <= (long long)limit; p64 += (long long)gridDim.x * 256) {
-        // (blocks interleaved over the stream and the two loads of a hop one after the other: a workgroup per contiguous range with both loads in
-        // flight together was slower on the synthetic batch, 158 -> 174 ms, and the same on Test.bmp)
+    // (a workgroup takes ONE contiguous range of the stream: the window behind it stays in its XCD's L2 -- with the workgroups of a stream interleaved,
+    // every XCD pulled every window of every stream: 50 GB of fetches per 2.6 GB of input for the synthetic LZSS batch at quality 8)
+    const long long per = (((long long)limit + 1 + gridDim.x - 1) / gridDim.x + 255) & ~255ll;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < (long long)limit + 1 ? lo + per : (long long)limit + 1;
+    for (long long p64 = lo + threadIdx.x; p64 < hi; p64 += 256) {
         const int pos = (int)p64;
         const u32 own = load32(data + pos) * 2654435761u;
         u32 link = l15[pos], d = 0, res = 0;
@@ -3155,7 +3160,10 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         // synthetic LZSS batch at quality 8 94.2 -> 91.1 ms, Test.bmp windows -2 %).  64 KiB windows: per stream (enc_words_kernel), the others
         // through kernel A at the finder's own width.
         EncGeom g15 = g; g15.hash_bits = 15;
+        // (workgroups per stream, each with one contiguous range -- and the window behind it fetched again: ranges of 8 KiB for windows up to 8 KiB -- 16 KiB
+        // move the same 15 GB: what is fetched are the lines of the scattered candidate words --; for 64 KiB windows as few as still fill the GPU)
         u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
+        if (!uses_win_prev(g)) { const u32 want = (ALZ_NARROW_WGS + count - 1u) / count; if (bx > want) bx = want; }
         if (uses_win_prev(g)) {
             const hipError_t e15 = launch_prev(stream, src, d_streams, d_index, count, d_prev4, nullptr, d_pos_off, g15, tail);
             if (e15 != hipSuccess) return e15;
