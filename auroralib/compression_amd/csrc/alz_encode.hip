@@ -2926,7 +2926,10 @@ static bool narrows_links(const EncGeom& g) {
 #ifdef ALZ_NO_NARROW_WIN                     /* tools/narrow_experiment.sh: not for the formats with windows up to 8 KiB */
     if (uses_win_prev(g)) return false;
 #endif
-    return g.link16 && g.nprops <= 1 && !g.use_min_table && g.hash_bits > 15;
+#ifdef ALZ_NO_NARROW_MIN                     /* tools/narrow_experiment.sh: not with the min-length table (quality >= 10, matches below four bytes) */
+    if (g.use_min_table) return false;
+#endif
+    return g.link16 && g.nprops <= 1 && g.hash_bits > 15;
 }
 int alz_encode_geom_narrows(const void* geom) { EncGeom g; memcpy(&g, geom, sizeof(g)); return narrows_links(g) ? 1 : 0; }
 
@@ -2977,6 +2980,13 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 // 1 024 windows of Test.bmp as LZ4 blocks at quality 8 48.6 -> 37.3 ms; on data whose words are nearly all distinct (the synthetic batch,
 // program text) a narrowing walk runs through two or three candidates per position and loses against the passes (145 -> 158 ms, 13.6 -> 14.5).
 // Two lists of stream ids (cursor in front, unused slots stay 0xFFFFFFFF): [0] narrow, [pitch] kernel A at the finder's own width.
+#ifndef ALZ_NARROW_SPLIT_MIN
+#define ALZ_NARROW_SPLIT_MIN 2048u    /* streams of a launch from which the choice is per stream (eight rounds of kernel A's workgroups); below: the majority's way for all */
+#endif
+#ifndef ALZ_NARROW_MIN_THRESH16
+#define ALZ_NARROW_MIN_THRESH16 11u  /* windows up to 8 KiB with the min-length table: narrow (behind 1 + 2 passes at 15 bits) from 11 / 16 distinct hashes on, the others through the one-pass kernel with tags.
+                                        (Shares measured on the host: Test.bmp windows 0.01-0.24, a tenth of them -- photographs -- 0.67-0.92; program text 0.44-0.70; the synthetic batch 0.68-0.72.) */
+#endif
 #ifndef ALZ_NARROW_WGS
 #define ALZ_NARROW_WGS 4096u      /* 64 KiB windows: workgroups of enc_narrow_kernel per launch, at least (each fetches the 64 KiB behind its range again) */
 #endif
@@ -2984,7 +2994,7 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 #define ALZ_NARROW_THRESH16 4u      /* narrow below a quarter: Test.bmp 39.5 ms (8: 39.2, every stream: 37.3), program text 13.75 (8: 14.95, kernel A's passes: 13.6), the synthetic batch 147 (12: 161) */
 #endif
 __global__ __launch_bounds__(256) void enc_words_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
-                                                        const u32* __restrict__ index_list, int tail_skip, u32* __restrict__ lists, u32 pitch, u32 thresh16) {
+                                                        const u32* __restrict__ index_list, int tail_skip, u32* __restrict__ lists, u32 pitch, u32 thresh16, bool invert) {
     __shared__ u32 bm[1024];
     __shared__ u32 cnt[2];
     const u32 sid = index_list[blockIdx.x];
@@ -3011,10 +3021,25 @@ __global__ __launch_bounds__(256) void enc_words_kernel(const u8* __restrict__ s
     atomicAdd(&cnt[0], fresh); atomicAdd(&cnt[1], tot);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const bool narrow = cnt[1] >= 256u && cnt[0] * 16u < cnt[1] * thresh16;
+        const bool few = cnt[0] * 16u < cnt[1] * thresh16;
+        const bool narrow = cnt[1] >= 256u && (invert ? !few : few);
         u32* l = lists + (narrow ? 0u : pitch);
         l[1u + atomicAdd(l, 1u)] = sid;
     }
+}
+
+// A launch of few streams does not split: each of the two forms of kernel A would run its own (partly empty) round of workgroups one after the
+// other -- 256 windows of program text as Yaz0 at quality 12 23.5 -> 26.4 ms.  All of them go the way of the majority.
+__global__ __launch_bounds__(256) void enc_words_merge_kernel(u32* __restrict__ lists, u32 pitch) {
+    const u32 na = lists[0], nb = lists[pitch];
+    if (na == 0u || nb == 0u) return;
+    u32* to = na >= nb ? lists : lists + pitch;
+    u32* from = na >= nb ? lists + pitch : lists;
+    const u32 nt = na >= nb ? na : nb, nf = na >= nb ? nb : na;
+    for (u32 i = threadIdx.x; i < nf; i += 256u) { to[1u + nt + i] = from[1u + i]; }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nf; i += 256u) from[1u + i] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) { to[0] = nt + nf; from[0] = 0u; }
 }
 
 // Kernel A at 15 bits for every hash width (round 4).  The finder's hash is the top hashBits bits of ONE product (ComputeHash :288-299), so the
@@ -3056,9 +3081,9 @@ __global__ __launch_bounds__(256) void enc_narrow_kernel(const u8* __restrict__ 
 }
 
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
-                              int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes = false) {
+                              int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes = false, bool no_win = false) {
     if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
-    if (uses_win_prev(g)) hipLaunchKernelGGL((enc_prev_cu_kernel<2, true>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+    if (uses_win_prev(g) && !no_win) hipLaunchKernelGGL((enc_prev_cu_kernel<2, true>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else {
         const u32 passes = (1u << (g.hash_bits - 15)) + (g.use_min_table ? 2u : 0u);       // (as the kernel counts them)
@@ -3146,7 +3171,7 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
 }
 
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
-                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
+                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
                              uint32_t* d_sel, uint32_t sel_pitch) {
     if (count == 0) return hipSuccess;
@@ -3154,9 +3179,9 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     g.b_cap = choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    if (narrows_links(g) && d_prevm != nullptr && d_sel != nullptr) {
-        // kernel A at 15 bits and the links of the finder's own hash width narrowed from them, into the (otherwise unused) array of the min-length
-        // table: what follows reads its links there.  Windows up to 8 KiB: every stream (a walk meets a 15-bit collision once in eight positions:
+    if (narrows_links(g) && d_narrow != nullptr && d_sel != nullptr) {
+        // kernel A at 15 bits and the links of the finder's own hash width narrowed from them, into an array of their own: what
+        // follows reads its links there (the min-length table's links, where there are any, are kernel A's own either way).  Windows up to 8 KiB: every stream (a walk meets a 15-bit collision once in eight positions:
         // synthetic LZSS batch at quality 8 94.2 -> 91.1 ms, Test.bmp windows -2 %).  64 KiB windows: per stream (enc_words_kernel), the others
         // through kernel A at the finder's own width.
         EncGeom g15 = g; g15.hash_bits = 15;
@@ -3164,22 +3189,28 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         // move the same 15 GB: what is fetched are the lines of the scattered candidate words --; for 64 KiB windows as few as still fill the GPU)
         u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
         if (!uses_win_prev(g)) { const u32 want = (ALZ_NARROW_WGS + count - 1u) / count; if (bx > want) bx = want; }
-        if (uses_win_prev(g)) {
-            const hipError_t e15 = launch_prev(stream, src, d_streams, d_index, count, d_prev4, nullptr, d_pos_off, g15, tail);
+        if (uses_win_prev(g) && !g.use_min_table) {
+            const hipError_t e15 = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g15, tail);
             if (e15 != hipSuccess) return e15;
-            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_prevm, d_pos_off, g, tail);
+            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_narrow, d_pos_off, g, tail);
         } else {
+            // (windows up to 8 KiB WITH the min-length table -- quality >= 10 --: the other way round.  Kernel A's alternative there is its one-pass form
+            // with tags, which repetitive data suits -- Test.bmp as Yaz0 at quality 12 121.8 ms against 126.9 behind 1 + 2 passes at 15 bits -- and
+            // data of many distinct words does not: synthetic LZSS batch at quality 15 188.5 -> 176.4 ms.)
+            const bool winm = uses_win_prev(g);
             u32* l_narrow = d_sel; u32* l_wide = d_sel + sel_pitch + 2u;                               // (count + 1 words each; the probe of kernel B takes the array over afterwards)
             (void)hipMemsetAsync(d_sel, 0xFF, ((size_t)sel_pitch + 2u + count + 1u) * sizeof(u32), stream);
             (void)hipMemsetAsync(l_narrow, 0, 4, stream); (void)hipMemsetAsync(l_wide, 0, 4, stream);
-            hipLaunchKernelGGL(enc_words_kernel, dim3(count), dim3(256), 0, stream, src, d_streams, d_index, tail, d_sel, sel_pitch + 2u, ALZ_NARROW_THRESH16);
-            const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, nullptr, d_pos_off, g15, tail);
+            hipLaunchKernelGGL(enc_words_kernel, dim3(count), dim3(256), 0, stream, src, d_streams, d_index, tail, d_sel, sel_pitch + 2u,
+                               winm ? ALZ_NARROW_MIN_THRESH16 : ALZ_NARROW_THRESH16, winm);
+            if (count < ALZ_NARROW_SPLIT_MIN) hipLaunchKernelGGL(enc_words_merge_kernel, dim3(1), dim3(256), 0, stream, d_sel, sel_pitch + 2u);
+            const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, d_prevm, d_pos_off, g15, tail, false, true);
             if (e15 != hipSuccess) return e15;
-            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, l_narrow + 1, d_prev4, d_prevm, d_pos_off, g, tail);
-            const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_prevm, nullptr, d_pos_off, g, tail);
+            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, l_narrow + 1, d_prev4, d_narrow, d_pos_off, g, tail);
+            const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_narrow, d_prevm, d_pos_off, g, tail);
             if (ew != hipSuccess) return ew;
         }
-        d_prev4 = d_prevm; d_prevm = nullptr;
+        d_prev4 = d_narrow;
     } else {
         const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
         if (ea != hipSuccess) return ea;

@@ -122,7 +122,7 @@ struct alz_ctx {
     void* d_plan = nullptr; size_t d_plan_cap = 0;   // plan arrays of the host-buffer entry points (no hipMalloc / hipFree per call)
     // encoder scratch (head tables, prev links, matches, masks ...: ~48 GB for 10 000 x 256 KiB at quality 8), one grow-only slot
     // per purpose: allocating and freeing it per call cost 1-2 s, four times the kernels.  alz_ctx_release_scratch() returns it.
-    void* enc_buf[13] = {nullptr}; size_t enc_cap[13] = {0};
+    void* enc_buf[14] = {nullptr}; size_t enc_cap[14] = {0};
     copy_pool* pool = nullptr;                 // created with the pinned buffers
     std::vector<copy_job> jobs;                // (scratch of the staging loops)
     void copy(uint8_t* dst, const uint8_t* src, size_t len) { jobs.clear(); add_copy(jobs, dst, src, len); pool->run(jobs); }
@@ -743,7 +743,7 @@ struct EncScratch {
     }
 };
 static void release_scratch(alz_ctx* c) {
-    for (int k = 0; k < 13; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
+    for (int k = 0; k < 14; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
     void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan, &c->d_bigbuf};
     size_t* caps[] = {&c->d_src_cap, &c->d_dst_cap, &c->d_items_cap, &c->d_pack_cap, &c->d_plan_cap, &c->d_bigbuf_cap};
     for (int i = 0; i < 6; i++) { if (*bufs[i]) (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
@@ -792,7 +792,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (cnt[ALZ_FMT_LZSS] && (lz.window_bits < 8 || lz.window_bits > 16 || lz.length_bits < 1 || lz.length_bits > 8 || lz.max_distance != (1u << lz.window_bits)))
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
     std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
-    bool any_min = false, any_match = false, any_mask = false;
+    bool any_min = false, any_match = false, any_mask = false, any_narrow = false;
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
@@ -812,7 +812,8 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         }
         if (!alz_encode_geometry(lvl2 ? ALZ_FMT_FASTLZ : f, &lz, &sf, g, nullptr, lvl2 ? 1 : 0))
             return fail(ALZ_E_UNSUPPORTED, "format %d: geometry not supported by the GPU encoder", lvl2 ? ALZ_FMT_FASTLZ : f);
-        any_min = any_min || alz_encode_geom_min_table(g) || alz_encode_geom_narrows(g);
+        any_min = any_min || alz_encode_geom_min_table(g);
+        any_narrow = any_narrow || alz_encode_geom_narrows(g);
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
         any_mask = any_mask || alz_encode_format_needs_mask(lvl2 ? ALZ_FMT_FASTLZ : f);
     }
@@ -908,7 +909,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc((void**)&d_index, (size_t)n * sizeof(uint32_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_pos, (size_t)n * sizeof(uint64_t));
     if (e == hipSuccess) e = sc.alloc((void**)&d_prev4, (size_t)total * sizeof(int) + 256);   // (+ slack: the look-ahead of the fused parse kernel reads a link of an empty last stream)
-    if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int) + 256, any_min);   // the min-length table's links, or the narrowed links (enc_narrow_kernel)
+    if (e == hipSuccess) e = sc.alloc((void**)&d_prevm, (size_t)total * sizeof(int) + 256, any_min);   // the min-length table's links
     if (e == hipSuccess) e = sc.alloc(&d_match, (size_t)total * 4 + 64, any_match);   // one 32-bit entry per position (alz_encode.hip: mentry); not when every launch searches inside its parse + emit kernel
     if (e == hipSuccess) e = sc.alloc(&d_side, (size_t)total * 2 + 64, cnt[ALZ_FMT_YAY0] || cnt[ALZ_FMT_MIO0] || cnt[ALZ_FMT_SMSR00]);   // section buffers
     if (e == hipSuccess) e = sc.alloc(&d_mask, (size_t)total / 8 + 64, any_mask);          // a bit per position: the start mask of enc_roles_kernel, for the formats whose emitter is a kernel of its own
@@ -916,6 +917,8 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, !tail_ix.empty());
     { void* skip_big = nullptr; if (e == hipSuccess) e = sc.alloc(&skip_big, 0, false); }        // (slot 11: the whole-GPU path's scratch)
     if (e == hipSuccess) e = sc.alloc((void**)&d_sel, ((size_t)2 * n + 64) * sizeof(uint32_t), any_match);     // which kernel B per stream (enc_probe_kernel)
+    int* d_narrow = nullptr;
+    if (e == hipSuccess) e = sc.alloc((void**)&d_narrow, (size_t)total * sizeof(int) + 256, any_narrow);   // slot 13: the links of the finder's own hash width, narrowed from 15-bit ones (enc_narrow_kernel)
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
     tm.mark("validate + allocate");
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
@@ -952,7 +955,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         const void* g = geom.data() + f * alz_encode_geom_size();
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
-            e = alz_launch_encode(fmt, c->stream, d_src_base, d_dst_base, d_streams, d_index + first + done, k, max_len, d_prev4, d_prevm,
+            e = alz_launch_encode(fmt, c->stream, d_src_base, d_dst_base, d_streams, d_index + first + done, k, max_len, d_prev4, d_prevm, d_narrow,
                                   d_match, d_pos, d_side, d_mask, d_results, d_aux, g, d_sel, n);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));
         }

@@ -27,11 +27,11 @@ size_t alz_encode_geom_size(void);
 int alz_encode_geom_hash_bits(const void* geom);
 int alz_encode_geom_min_table(const void* geom);
 int alz_encode_geom_max_dist(const void* geom);
-int alz_encode_geom_narrows(const void* geom);                  // 1: kernel A links at 15 bits and enc_narrow_kernel writes the finder's own links into the min-length table's array (which must exist)
+int alz_encode_geom_narrows(const void* geom);                  // 1: kernel A links at 15 bits and enc_narrow_kernel writes the finder's own links into d_narrow (which must exist)
 int alz_encode_format_needs_mask(int fmt);                      // 1: the format's emitter reads the start mask of enc_roles_kernel (zeroed before the launch)
 int alz_encode_geom_needs_match(int fmt, const void* geom);   // 0: the search runs inside the parse + emit kernel (no kernel B, no match array)
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
-                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, void* d_match,
+                             uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
                              uint32_t* d_sel /* which kernel B per stream (enc_probe_kernel): sel_pitch words indexed by stream, then 1 + count words of list; NULL: the two-phase kernel from maxChain 3 on */,
                              uint32_t sel_pitch);

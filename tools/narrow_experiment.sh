@@ -1,6 +1,6 @@
 # Kernel A at 15 bits + enc_narrow_kernel for the streams enc_words_kernel picks (the formats with windows above 8 KiB, hash wider than 15 bits, no
 # min-length table; the formats with windows up to 8 KiB: every stream, -DALZ_NO_NARROW_WIN: not those) against kernel A at the finder's own hash
-# width for all (-DALZ_NO_NARROW), and the threshold of the choice
+# width for all (-DALZ_NO_NARROW; -DALZ_NO_NARROW_MIN: not with the min-length table), and the threshold of the choice
 # (-DALZ_NARROW_THRESH16=t: narrow below t / 16 distinct hashes per sampled position; 17 = always).  Results: docs/EXPERIMENTS.md 9.12.
 cd $GRAFT_REPO_ROOT
 run() {
