@@ -3080,6 +3080,47 @@ __global__ __launch_bounds__(256) void enc_narrow_kernel(const u8* __restrict__ 
     }
 }
 
+// The same for windows up to 8 KiB with the range and the window behind it in LDS: LOOK bytes and links of look-back + LOOK of the range per
+// workgroup (24 KB at 4 KiB windows: six workgroups per CU), every hop of a walk two LDS reads instead of two scattered loads.
+template <int LOOK>
+__global__ __launch_bounds__(256) void enc_narrow_lds_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
+                                                             const u32* __restrict__ index_list, const int* __restrict__ prev15,
+                                                             int* __restrict__ prevw, const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
+    __shared__ __attribute__((aligned(16))) u8 sd[2 * LOOK + 16];
+    __shared__ __attribute__((aligned(16))) unsigned short sl[2 * LOOK];
+    const u32 sid = index_list[blockIdx.y];
+    if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_words_kernel: unused slots)
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const int limit = (int)st.src_len - tail_skip - 4;
+    const unsigned short* l15 = reinterpret_cast<const unsigned short*>(prev15 + pos_off[sid]);
+    unsigned short* lw = reinterpret_cast<unsigned short*>(prevw + pos_off[sid]);
+    const u32 sh = 32u - (u32)g.hash_bits;
+    for (long long lo64 = (long long)blockIdx.x * LOOK; lo64 <= (long long)limit; lo64 += (long long)gridDim.x * LOOK) {
+        const int lo = (int)lo64, lb = lo >= LOOK ? lo - LOOK : 0;
+        const int hi = lo + LOOK <= limit + 1 ? lo + LOOK : limit + 1;       // positions [lo, hi)
+        const int nb = hi + 3 - lb;                                             // bytes [lb, hi + 3): the last position's word
+        __syncthreads();                                                        // (the round before has finished with the arrays)
+        for (int i = 4 * (int)threadIdx.x; i < nb; i += 1024) { const u32 v = load32(data + lb + i); __builtin_memcpy(sd + i, &v, 4); }   // (up to three bytes past hi + 3: inside the stream or its slack)
+        for (int i = 2 * (int)threadIdx.x; i < hi - lb; i += 512) { const u32 v = *reinterpret_cast<const u32*>(l15 + lb + i); *reinterpret_cast<u32*>(sl + i) = v; }
+        __syncthreads();
+        for (int pos = lo + (int)threadIdx.x; pos < hi; pos += 256) {
+            u32 ow; __builtin_memcpy(&ow, sd + (pos - lb), 4);
+            const u32 own = ow * 2654435761u;
+            u32 link = sl[pos - lb], d = 0, res = 0;
+            while (link != 0u) {
+                d += link;
+                if (d > (u32)g.max_dist) break;
+                const int c = pos - (int)d - lb;                                // (>= 0: LOOK >= maxDistance)
+                u32 w; __builtin_memcpy(&w, sd + c, 4);
+                if (((w * 2654435761u) ^ own) >> sh == 0u) { res = d; break; }
+                link = sl[c];
+            }
+            lw[pos] = (unsigned short)res;
+        }
+    }
+}
+
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
                               int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes = false, bool no_win = false) {
     if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
@@ -3189,10 +3230,22 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         // move the same 15 GB: what is fetched are the lines of the scattered candidate words --; for 64 KiB windows as few as still fill the GPU)
         u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
         if (!uses_win_prev(g)) { const u32 want = (ALZ_NARROW_WGS + count - 1u) / count; if (bx > want) bx = want; }
+        auto narrow = [&](const u32* list) {
+#ifndef ALZ_NO_NARROW_LDS
+            if (g.max_dist <= 8192) {                                               // (range and window in LDS)
+                const u32 look = g.max_dist <= 4096 ? 4096u : 8192u;
+                u32 gx = (max_len + look - 1u) / look; if (gx == 0u) gx = 1u; if (gx > 4096u) gx = 4096u;
+                if (look == 4096u) hipLaunchKernelGGL((enc_narrow_lds_kernel<4096>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
+                else hipLaunchKernelGGL((enc_narrow_lds_kernel<8192>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
+                return;
+            }
+#endif
+            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
+        };
         if (uses_win_prev(g) && !g.use_min_table) {
             const hipError_t e15 = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g15, tail);
             if (e15 != hipSuccess) return e15;
-            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, d_index, d_prev4, d_narrow, d_pos_off, g, tail);
+            narrow(d_index);
         } else {
             // (windows up to 8 KiB WITH the min-length table -- quality >= 10 --: the other way round.  Kernel A's alternative there is its one-pass form
             // with tags, which repetitive data suits -- Test.bmp as Yaz0 at quality 12 121.8 ms against 126.9 behind 1 + 2 passes at 15 bits -- and
@@ -3206,7 +3259,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             if (count < ALZ_NARROW_SPLIT_MIN) hipLaunchKernelGGL(enc_words_merge_kernel, dim3(1), dim3(256), 0, stream, d_sel, sel_pitch + 2u);
             const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, d_prevm, d_pos_off, g15, tail, false, true);
             if (e15 != hipSuccess) return e15;
-            hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, l_narrow + 1, d_prev4, d_narrow, d_pos_off, g, tail);
+            narrow(l_narrow + 1);
             const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_narrow, d_prevm, d_pos_off, g, tail);
             if (ew != hipSuccess) return ew;
         }
