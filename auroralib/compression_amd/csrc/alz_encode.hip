@@ -2980,6 +2980,9 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 // 1 024 windows of Test.bmp as LZ4 blocks at quality 8 48.6 -> 37.3 ms; on data whose words are nearly all distinct (the synthetic batch,
 // program text) a narrowing walk runs through two or three candidates per position and loses against the passes (145 -> 158 ms, 13.6 -> 14.5).
 // Two lists of stream ids (cursor in front, unused slots stay 0xFFFFFFFF): [0] narrow, [pitch] kernel A at the finder's own width.
+#ifndef ALZ_NARROW_RANGE
+#define ALZ_NARROW_RANGE 4096         /* positions per workgroup of enc_narrow_lds_kernel at 4 KiB windows */
+#endif
 #ifndef ALZ_NARROW_SPLIT_MIN
 #define ALZ_NARROW_SPLIT_MIN 2048u    /* streams of a launch from which the choice is per stream (eight rounds of kernel A's workgroups); below: the majority's way for all */
 #endif
@@ -3081,13 +3084,13 @@ __global__ __launch_bounds__(256) void enc_narrow_kernel(const u8* __restrict__ 
 }
 
 // The same for windows up to 8 KiB with the range and the window behind it in LDS: LOOK bytes and links of look-back + LOOK of the range per
-// workgroup (24 KB at 4 KiB windows: six workgroups per CU), every hop of a walk two LDS reads instead of two scattered loads.
-template <int LOOK>
+// workgroup (24 KB at 4 KiB windows with ranges of 4 KiB: six workgroups per CU), every hop of a walk two LDS reads instead of two scattered loads.
+template <int LOOK, int RANGE>
 __global__ __launch_bounds__(256) void enc_narrow_lds_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                              const u32* __restrict__ index_list, const int* __restrict__ prev15,
                                                              int* __restrict__ prevw, const u64* __restrict__ pos_off, EncGeom g, int tail_skip) {
-    __shared__ __attribute__((aligned(16))) u8 sd[2 * LOOK + 16];
-    __shared__ __attribute__((aligned(16))) unsigned short sl[2 * LOOK];
+    __shared__ __attribute__((aligned(16))) u8 sd[LOOK + RANGE + 16];
+    __shared__ __attribute__((aligned(16))) unsigned short sl[LOOK + RANGE];
     const u32 sid = index_list[blockIdx.y];
     if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_words_kernel: unused slots)
     const alz_stream st = streams[sid];
@@ -3096,9 +3099,9 @@ __global__ __launch_bounds__(256) void enc_narrow_lds_kernel(const u8* __restric
     const unsigned short* l15 = reinterpret_cast<const unsigned short*>(prev15 + pos_off[sid]);
     unsigned short* lw = reinterpret_cast<unsigned short*>(prevw + pos_off[sid]);
     const u32 sh = 32u - (u32)g.hash_bits;
-    for (long long lo64 = (long long)blockIdx.x * LOOK; lo64 <= (long long)limit; lo64 += (long long)gridDim.x * LOOK) {
+    for (long long lo64 = (long long)blockIdx.x * RANGE; lo64 <= (long long)limit; lo64 += (long long)gridDim.x * RANGE) {
         const int lo = (int)lo64, lb = lo >= LOOK ? lo - LOOK : 0;
-        const int hi = lo + LOOK <= limit + 1 ? lo + LOOK : limit + 1;       // positions [lo, hi)
+        const int hi = lo + RANGE <= limit + 1 ? lo + RANGE : limit + 1;       // positions [lo, hi)
         const int nb = hi + 3 - lb;                                             // bytes [lb, hi + 3): the last position's word
         __syncthreads();                                                        // (the round before has finished with the arrays)
         for (int i = 4 * (int)threadIdx.x; i < nb; i += 1024) { const u32 v = load32(data + lb + i); __builtin_memcpy(sd + i, &v, 4); }   // (up to three bytes past hi + 3: inside the stream or its slack)
@@ -3233,10 +3236,10 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         auto narrow = [&](const u32* list) {
 #ifndef ALZ_NO_NARROW_LDS
             if (g.max_dist <= 8192) {                                               // (range and window in LDS)
-                const u32 look = g.max_dist <= 4096 ? 4096u : 8192u;
-                u32 gx = (max_len + look - 1u) / look; if (gx == 0u) gx = 1u; if (gx > 4096u) gx = 4096u;
-                if (look == 4096u) hipLaunchKernelGGL((enc_narrow_lds_kernel<4096>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
-                else hipLaunchKernelGGL((enc_narrow_lds_kernel<8192>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
+                const u32 look = g.max_dist <= 4096 ? 4096u : 8192u, range = look == 4096u ? ALZ_NARROW_RANGE : 8192u;
+                u32 gx = (max_len + range - 1u) / range; if (gx == 0u) gx = 1u; if (gx > 4096u) gx = 4096u;
+                if (look == 4096u) hipLaunchKernelGGL((enc_narrow_lds_kernel<4096, ALZ_NARROW_RANGE>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
+                else hipLaunchKernelGGL((enc_narrow_lds_kernel<8192, 8192>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
                 return;
             }
 #endif
