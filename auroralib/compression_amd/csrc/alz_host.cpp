@@ -120,7 +120,7 @@ struct alz_ctx {
     void* d_items = nullptr; size_t d_items_cap = 0;
     void* d_pack = nullptr; size_t d_pack_cap = 0;
     void* d_plan = nullptr; size_t d_plan_cap = 0;   // plan arrays of the host-buffer entry points (no hipMalloc / hipFree per call)
-    // encoder scratch (head tables, prev links, matches, masks ...: ~48 GB for 10 000 x 256 KiB at quality 8), one grow-only slot
+    // encoder scratch (prev links, narrowed links, matches, masks ...: ~45 GB for 10 000 x 256 KiB at quality 8), one grow-only slot
     // per purpose: allocating and freeing it per call cost 1-2 s, four times the kernels.  alz_ctx_release_scratch() returns it.
     void* enc_buf[14] = {nullptr}; size_t enc_cap[14] = {0};
     copy_pool* pool = nullptr;                 // created with the pinned buffers

@@ -225,10 +225,11 @@ int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
  * min_bytes: 0 keeps the current threshold, 0xFFFFFFFF switches both paths off; launches_out (may be NULL) receives how many streams have
  * taken either path on this context.  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take them. */
 int         alz_ctx_big_stream(alz_ctx* ctx, uint32_t min_bytes, uint64_t* launches_out);
-/* The host-buffer entry points keep their device staging buffers and the encoder's scratch (per input byte: a 16- or 32-bit link,
- * a 32-bit match entry -- not at quality 0 for the flag-byte formats, whose search runs inside the emit kernel --, two bytes of
- * section buffers for Yay0 / MIO0 / SMSR00, one bit of start mask; the finder's head tables live in LDS) in the context and only
- * ever grow them, so that a caller
+/* The host-buffer entry points keep their device staging buffers and the encoder's scratch (per input byte: a 16- or 32-bit link
+ * in a 32-bit slot -- above quality 0 a second one, the links of the finder's wider hash narrowed from 15-bit ones --, a 32-bit
+ * match entry -- not at quality 0 for the formats whose search runs inside their emit kernel --, two bytes of section buffers for
+ * Yay0 / MIO0 / SMSR00, one bit of start mask for the formats without a parallel emitter; the finder's head tables live in LDS) in
+ * the context and only ever grow them, so that a caller
  * working through batch after batch does not pay a device allocation per call.  This returns all of it to the device (the
  * managed side has no counterpart: ArrayPool<int>.Shared keeps LzChainMatchFinder's tables the same way,
  * MatchFinder/LzChainMatchFinder.cs:85-104, :323-334). */
