@@ -3224,10 +3224,14 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     if (narrows_links(g) && d_narrow != nullptr && d_sel != nullptr) {
-        // kernel A at 15 bits and the links of the finder's own hash width narrowed from them, into an array of their own: what
-        // follows reads its links there (the min-length table's links, where there are any, are kernel A's own either way).  Windows up to 8 KiB: every stream (a walk meets a 15-bit collision once in eight positions:
-        // synthetic LZSS batch at quality 8 94.2 -> 91.1 ms, Test.bmp windows -2 %).  64 KiB windows: per stream (enc_words_kernel), the others
-        // through kernel A at the finder's own width.
+        // Kernel A at 15 bits and the links of the finder's own hash width narrowed from them (enc_narrow_kernel), into an array of their own: what
+        // follows reads its links there (the min-length table's links, where there are any, are kernel A's own either way).  Which streams:
+        //   windows up to 8 KiB, no min-length table (quality 1-9): all -- a 15-bit chain meets a collision once in eight positions, the walk is short
+        //     on any data, and range + window fit the LDS: synthetic LZSS batch at quality 8 94.2 -> 84.5 ms, Test.bmp windows -2 %;
+        //   windows up to 8 KiB with the min-length table (quality >= 10): those of MANY distinct words.  Kernel A's alternative there is its one-pass
+        //     form with tags, which does both tables at once and suits repetitive data (Test.bmp as Yaz0 at quality 12 121.8 ms against 126.9 behind
+        //     1 + 2 passes at 15 bits), data of many distinct words does not (synthetic LZSS batch at quality 15 188.5 -> 175.3 ms);
+        //   64 KiB windows: those of FEW distinct words (enc_words_kernel); the others through kernel A's 2^(hashBits - 15) passes.
         EncGeom g15 = g; g15.hash_bits = 15;
         // (workgroups per stream, each with one contiguous range -- and the window behind it fetched again: ranges of 8 KiB for windows up to 8 KiB -- 16 KiB
         // move the same 15 GB: what is fetched are the lines of the scattered candidate words --; for 64 KiB windows as few as still fill the GPU)
@@ -3250,10 +3254,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             if (e15 != hipSuccess) return e15;
             narrow(d_index);
         } else {
-            // (windows up to 8 KiB WITH the min-length table -- quality >= 10 --: the other way round.  Kernel A's alternative there is its one-pass form
-            // with tags, which repetitive data suits -- Test.bmp as Yaz0 at quality 12 121.8 ms against 126.9 behind 1 + 2 passes at 15 bits -- and
-            // data of many distinct words does not: synthetic LZSS batch at quality 15 188.5 -> 176.4 ms.)
-            const bool winm = uses_win_prev(g);
+            const bool winm = uses_win_prev(g);                                                        // (small windows with the min-length table: the choice the other way round)
             u32* l_narrow = d_sel; u32* l_wide = d_sel + sel_pitch + 2u;                               // (count + 1 words each; the probe of kernel B takes the array over afterwards)
             (void)hipMemsetAsync(d_sel, 0xFF, ((size_t)sel_pitch + 2u + count + 1u) * sizeof(u32), stream);
             (void)hipMemsetAsync(l_narrow, 0, 4, stream); (void)hipMemsetAsync(l_wide, 0, 4, stream);
