@@ -2229,7 +2229,13 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
     }
 };
 #ifndef ALZ_SEQ_PARSE_CAP
-#define ALZ_SEQ_PARSE_CAP 48   /* bytes enc_parse_seq_kernel<LZ4, true> compares per position (kernel B's cap at one candidate per position) */
+#define ALZ_SEQ_PARSE_CAP 32   /* bytes the search inside WinParse compares per position for certain (what the look-ahead holds in registers) ... */
+#endif
+#ifndef ALZ_SEQ_PARSE_CAP_HI
+#define ALZ_SEQ_PARSE_CAP_HI 128  /* ... and up to this many while fewer than ALZ_SEQ_PARSE_MANY lanes of the window are still equal */
+#endif
+#ifndef ALZ_SEQ_PARSE_MANY
+#define ALZ_SEQ_PARSE_MANY 16     /* (Test.bmp / text as LZ4 blocks at quality 0, ms: a fixed cap of 32: 10.6 / 9.3, 48: 11.9 / 8.1, 128: 16.7 / 7.4; 32 .. 128 with 16 lanes: 11.4 / 7.7, with 8: 12.0 / 7.8, 32: 14.6 / 7.5) */
 #endif
 #ifndef ALZ_SEQ_LANE_LIT
 #define ALZ_SEQ_LANE_LIT 4u      /* literal runs up to this long are copied by their own lane, longer ones by the wavefront (4: 15.8 ms, 16: 17.8) */
@@ -2273,18 +2279,25 @@ struct WinParse {
         if ((int)q > limit) return make_uint2(0, 0);
         const bool ok = lkv - (u32)g.min_dist <= srange;                // a candidate (0: none), within maxDistance, not closer than minDistance  :259-266
         int best_possible = ns - (int)q; if (best_possible > g.max_len) best_possible = g.max_len;
-        const int cmp_max = best_possible > CAP ? CAP : best_possible;
+        // CAP bytes are compared for certain, up to CAPHI while only a few lanes of the window are still equal: in a run or a repeated row every
+        // lane is, each trip of the loop below is a memory round trip for the whole wavefront, and the cursor jumps over most of those positions
+        // anyway (Test.bmp wants a small cap); in text a long match is one lane's, and every position that stops at the cap costs a search by
+        // the whole wavefront when the cursor stands on it (text wants a large one).
+        constexpr int CAPHI = CAP >= 64 ? CAP : ALZ_SEQ_PARSE_CAP_HI;
+        int cmp_max = best_possible > CAPHI ? CAPHI : best_possible;
         const u64 x0 = own[0] ^ cnd[0], x1 = own[1] ^ cnd[1], x2 = own[2] ^ cnd[2], x3 = own[3] ^ cnd[3];
         int len = x0 ? (int)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (int)(__builtin_ctzll(x1) >> 3) : x2 ? 16 + (int)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (int)(__builtin_ctzll(x3) >> 3) : 32;
         bool go = ok && len == 32 && cmp_max > 32;
         if (__ballot(go)) {                                              // GetMatchLength behind the prefetched bytes
             const u8* pa = data + q; const u8* pb = data + q - (go ? lkv : 0u);
             int l = 32;
+            const bool went = go;
             while (__ballot(go)) {
                 const u64 z = load64(pa + (go ? l : 0)) ^ load64(pb + (go ? l : 0));
                 if (go) { if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; } else { l += 8; if (l >= cmp_max) go = false; } }
+                if (CAPHI > CAP && l >= CAP && __popcll(__ballot(go)) >= ALZ_SEQ_PARSE_MANY) { if (go) { cmp_max = l; go = false; } }   // (l is wave-uniform among the lanes still equal: eight bytes per trip from 32 on)
             }
-            if (ok && len == 32 && cmp_max > 32) len = l;
+            if (went) len = l;
         }
         if (len > cmp_max) len = cmp_max;
         const bool hitcap = ok && len == cmp_max && cmp_max < best_possible;

@@ -1,6 +1,6 @@
 # LZ4 blocks / raw Snappy / PRS: enc_roles_kernel + the emitter (and kernel B at quality 0) as separate kernels (-DALZ_SEQ_TWO_KERNELS) against
 # the walk -- and at quality 0 the search -- inside the emitter (WinParse), and the bytes it compares per position at quality 0
-# (-DALZ_SEQ_PARSE_CAP=..).  Results: docs/EXPERIMENTS.md 9.9.  (-DALZ_SEQ_TWO_KERNELS and the kernels behind it exist up to commit 302184c; the
+# (-DALZ_SEQ_PARSE_CAP=.. for certain, -DALZ_SEQ_PARSE_CAP_HI=.. while fewer than -DALZ_SEQ_PARSE_MANY=.. lanes of a window are still equal).  Results: docs/EXPERIMENTS.md 9.9.  (-DALZ_SEQ_TWO_KERNELS and the kernels behind it exist up to commit 302184c; the
 # default list below only sweeps the cap.)
 cd $GRAFT_REPO_ROOT
 run() {
