@@ -476,6 +476,12 @@ __global__ __launch_bounds__(1024) void enc_prev_cu_kernel(const u8* __restrict_
 #ifndef ALZ_PARSE_CAP
 #define ALZ_PARSE_CAP 32
 #endif
+#ifndef ALZ_PARSE_CAP_HI
+#define ALZ_PARSE_CAP_HI 128     /* ... and on up to this many while fewer than ALZ_PARSE_MANY lanes of the window are still equal (WinParse::matchof) */
+#endif
+#ifndef ALZ_PARSE_MANY
+#define ALZ_PARSE_MANY 16
+#endif
 #define ALZ_CAPPED 0xFFFFFFFFu
 
 // The match array kernel B hands to the parse and the emitters: ONE 32-bit entry per position (round 3; two words before) -- distance in
@@ -1882,18 +1888,24 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
         if ((int)q > limit) return make_uint2(0, 0);
         const bool ok = lkv - (u32)g.min_dist <= srange;                // a candidate (0: none), within maxDistance, not closer than minDistance (the walk would go on -- and at maxChain 1 it is over)  :259-266
         int best_possible = (int)n - (int)q; if (best_possible > g.max_len) best_possible = g.max_len;
-        const int cmp_max = best_possible > ALZ_PARSE_CAP ? ALZ_PARSE_CAP : best_possible;
+        // (ALZ_PARSE_CAP bytes for certain; LZ11 / LZ40 -- matches of up to 16 KiB -- up to ALZ_PARSE_CAP_HI while only a few lanes of the window are still
+        // equal, as WinParse::matchof: program text 10.3 -> 8.7 ms, Test.bmp 11.3 -> 11.5.  Yaz0 with its 273 bytes: text 8.8 -> 7.8, but Test.bmp 10.5 -> 11.3
+        // whatever the number of lanes -- not there.)
+        constexpr int CAPHI = (FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40) ? ALZ_PARSE_CAP_HI : ALZ_PARSE_CAP;
+        int cmp_max = best_possible > CAPHI ? CAPHI : best_possible;
         const u64 x0 = own[0] ^ cnd[0], x1 = own[1] ^ cnd[1], x2 = own[2] ^ cnd[2], x3 = own[3] ^ cnd[3];
         int len = x0 ? (int)(__builtin_ctzll(x0) >> 3) : x1 ? 8 + (int)(__builtin_ctzll(x1) >> 3) : x2 ? 16 + (int)(__builtin_ctzll(x2) >> 3) : x3 ? 24 + (int)(__builtin_ctzll(x3) >> 3) : 32;
         bool go = ok && len == 32 && cmp_max > 32;
         if (__ballot(go)) {                                              // GetMatchLength behind the prefetched bytes (wave_match_tail's loop)
             const u8* pa = data + q; const u8* pb = data + q - (go ? lkv : 0u);
             int l = 32;
+            const bool went = go;
             while (__ballot(go)) {
+                if (CAPHI > ALZ_PARSE_CAP && __popcll(__ballot(go && l >= ALZ_PARSE_CAP)) >= ALZ_PARSE_MANY) { if (go && l >= ALZ_PARSE_CAP) { cmp_max = l; go = false; } continue; }
                 const u64 z = load64(pa + (go ? l : 0)) ^ load64(pb + (go ? l : 0));
                 if (go) { if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; } else { l += 8; if (l >= cmp_max) go = false; } }
             }
-            if (ok && len == 32 && cmp_max > 32) len = l;
+            if (went) len = l;
         }
         if (len > cmp_max) len = cmp_max;
         const bool hitcap = ok && len == cmp_max && cmp_max < best_possible;
@@ -2293,9 +2305,10 @@ struct WinParse {
             int l = 32;
             const bool went = go;
             while (__ballot(go)) {
+                // (before the trip: with CAP = 32 a window of a run takes none at all; l is wave-uniform among the lanes still equal, eight bytes per trip from 32 on)
+                if (CAPHI > CAP && __popcll(__ballot(go && l >= CAP)) >= ALZ_SEQ_PARSE_MANY) { if (go && l >= CAP) { cmp_max = l; go = false; } continue; }
                 const u64 z = load64(pa + (go ? l : 0)) ^ load64(pb + (go ? l : 0));
                 if (go) { if (z) { l += (int)(__builtin_ctzll(z) >> 3); go = false; } else { l += 8; if (l >= cmp_max) go = false; } }
-                if (CAPHI > CAP && l >= CAP && __popcll(__ballot(go)) >= ALZ_SEQ_PARSE_MANY) { if (go) { cmp_max = l; go = false; } }   // (l is wave-uniform among the lanes still equal: eight bytes per trip from 32 on)
             }
             if (went) len = l;
         }
