@@ -26,7 +26,8 @@ library's host-side partitioner) -- `--scaling strong --format mixed --streams 4
 way there is no data-path collective; value = bytes decoded by all ranks / max time, and every rank checks its first
 1 024 streams byte for byte against the CPU restatement.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints the full record as a `BENCH_DETAIL {...}` line (also written to bench_detail.json) and then, LAST, the small contract
+line (< 4 KB: `contract_line`) -- the one JSON line the driver parses.
 """
 import argparse
 import json
@@ -87,6 +88,9 @@ def spawn_ranks(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    for l in p.stdout.splitlines():
+        if l.startswith("BENCH_DETAIL "):
+            print(l)
     if lines:
         print(lines[-1])
     sys.exit(p.returncode if p.returncode else (0 if lines else 4))
@@ -126,6 +130,94 @@ def roofline(algo_bytes, kernel_ms, traffic=None):
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
+
+
+CONTRACT_LINE_MAX = 4096    # the driver keeps ~8 KB of stdout tail: the round-4 line (39 KB) left BENCH_r04.parsed null
+SINGLE_FORMATS = ["yaz0", "yay0", "mio0", "lz10", "lz11", "lzss", "prs_be", "lzo", "lz4_block", "snappy_raw"]
+DETAIL_PREFIX = "BENCH_DETAIL "
+
+
+def contract_line(full):
+    """The ONE small JSON object the driver parses, built from the full record: the contract's keys, `roofline`, `cpu_baseline`, one
+    short entry per rank and a fixed-size `configs_summary` (name -> [value, ms per launch, roofline.frac]); no prose, no nested blobs.
+    Everything else stays in the detail record (printed as an EARLIER line and written to bench_detail.json)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keep if k in full}
+    c = full.get("config") or {}
+    cfg = {k: c[k] for k in ("workload", "mode", "format", "quality", "streams_this_rank", "streams_whole_job", "stream_bytes", "compressed_bytes_whole_job",
+                             "ratio", "batches_in_flight", "parity_ok", "verified_vs_oracle", "verified_roundtrip_and_vs_oracle") if k in c}
+    cfg["workload"] = str(cfg.get("workload", ""))[:200]
+    cfg["parallelism"] = str(c.get("parallelism", ""))[:96]
+    if c.get("pipelined"):
+        cfg["pipelined"] = {k: c["pipelined"][k] for k in ("value", "ms_per_step", "batches_in_flight") if k in c["pipelined"]}
+    out["config"] = cfg
+    r = full.get("roofline") or {}
+    out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch",
+                                         "issue_frac") if k in r}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "single_thread", "cpu_model", "cgroup_cpu_quota_cores") if k in cb}
+        out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    else:
+        out["cpu_baseline"] = None
+    out["ranks"] = [{k: x[k] for k in ("rank", "local_rank", "device", "pci_domain_id", "pci_bus_id", "pci_device_id", "uuid") if k in x} for x in (full.get("ranks") or [])][:16]
+    for x in out["ranks"]:
+        x["device"] = str(x.get("device", ""))[:48]
+    for k in ("copy_bandwidth", "end_to_end"):
+        if isinstance(full.get(k), dict) and "value" in full[k]:
+            out[k] = {"value": full[k]["value"], "unit": full[k].get("unit")}
+    configs = full.get("configs")
+    if configs:
+        summ, single, bad = {}, {}, []
+        for e in configs:
+            name = e.get("name", "?")
+            if e.get("parity_ok") is False or name == "error":
+                bad.append(name)
+            if name.startswith("single_"):
+                # single_<format>_q<Q> / single_compress_<format>_q<Q>: one row per (direction, quality) in SINGLE_FORMATS order
+                comp = name.startswith("single_compress_")
+                body = name[len("single_compress_" if comp else "single_"):]
+                f, q = body.rsplit("_q", 1)
+                row = single.setdefault(("compress_q" if comp else "decode_q") + q, [None] * len(SINGLE_FORMATS))
+                if f in SINGLE_FORMATS:
+                    row[SINGLE_FORMATS.index(f)] = e.get("value")
+                continue
+            rf = e.get("roofline") or {}
+            ms = rf.get("kernel_ms", e.get("kernel_ms", e.get("ms_per_step")))
+            row = [e.get("value"), ms, rf.get("frac")]
+            if "issue_frac" in rf:
+                row.append(rf["issue_frac"])
+            if e.get("cpu_port"):
+                row.append(e["cpu_port"].get("value"))
+            summ[name] = row
+        out["configs_summary"] = {"columns": ["value (GiB/s)", "kernel ms per launch", "roofline.frac", "(issue_frac)", "(cpu port GiB/s, T = cores)"],
+                                  "rows": summ, "single_stream_GiB_s": {"formats": SINGLE_FORMATS, **single}, "not_ok": bad}
+    out["detail"] = "bench_detail.json + the '%s' stdout line before this one" % DETAIL_PREFIX.strip()
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= CONTRACT_LINE_MAX:          # never let the line outgrow the driver's window again: drop the optional parts, largest first
+        for k in ("configs_summary", "ranks", "end_to_end", "copy_bandwidth"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) < CONTRACT_LINE_MAX:
+                break
+    assert len(line) < CONTRACT_LINE_MAX, len(line)
+    return line
+
+
+def emit(full):
+    """Rank 0's output: the full record first (one 'BENCH_DETAIL {...}' line, and bench_detail.json beside this file / under gpurun_out/
+    when that exists), then -- LAST on stdout -- the small contract line."""
+    detail = json.dumps(full)
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+        except OSError:
+            pass
+    sys.stdout.write(DETAIL_PREFIX + detail + "\n")
+    sys.stdout.write(contract_line(full) + "\n")
+    sys.stdout.flush()
 
 
 class DeviceBatch:
@@ -347,7 +439,7 @@ def main():
         out.update(extras)
         if configs is not None:
             out["configs"] = configs
-        print(json.dumps(out))
+        emit(out)
     main_db.close()
     ctx.close()
     if dist is not None:
@@ -431,16 +523,16 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
             # three bytes is dropped), which the managed decoder misreads (LZO.cs:70-95); parity keeps both.  For such a buffer the
             # check is: the compressed bytes are the restatement's, and the restatement's decoder reads them exactly as the GPU's did.
             bad = np.nonzero(~back_ok)[0]
-            quirk = {"buffers_the_managed_decoder_misreads": int(len(bad)), "checked": int(min(len(bad), 4))}
-            same = True
-            for i in bad[:4]:
+            # Only a buffer that was CHECKED this way is waived; the others stay failures (at most 64 are checked: the quirk is rare).
+            quirk = {"buffers_the_managed_decoder_misreads": int(len(bad)), "checked": int(min(len(bad), 64))}
+            back_ok = back_ok.copy()
+            for i in bad[:64]:
                 raw_i = bytes(ctx.d2h(raw_db.d_dst, target, offset=int(recs["dst_off"][i])))
                 got = bytes(ctx.d2h(d_out, int(er["dst_len"][i]), offset=int(r2["dst_off"][i])))
                 want, _ = O.encode_stream(fmt, raw_i, quality=args.quality)
                 odec, ores = O.decode_stream(fmt, got, decom_len=target, cap=target)
                 gdec = bytes(ctx.d2h(d_back, int(bres["dst_len"][i]), offset=int(recs["dst_off"][i])))
-                same = same and got == want and int(ores.status) == int(bres["status"][i]) and int(ores.dst_len) == int(bres["dst_len"][i]) and odec == gdec
-            back_ok = back_ok | ~back_ok if same else back_ok
+                back_ok[i] = bool(got == want and int(ores.status) == int(bres["status"][i]) and int(ores.dst_len) == int(bres["dst_len"][i]) and odec == gdec)
         verified = bool(back_ok.all())
         for i in range(k):
             a = int(recs["dst_off"][i])
@@ -479,7 +571,7 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
             "cpu_baseline": cpu,
             "ranks": ranks,
         }
-        print(json.dumps(out))
+        emit(out)
     ctx.free(d_out); raw_db.close(); ctx.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -599,6 +691,35 @@ def cpu_baseline_encode(ctx, raw_db, recs, r2, n, target, fmt, args, aff, np, A)
                       "CompressHeaderless (oracle/alz_oracle.c), buffers striped over threads" % (nb_all, n, args.stream_kib, args.quality, reps_all, aff)}
 
 
+def cpu_port_encode(np, A, raw, rec_table, nb, fmt, quality, budget=2.0):
+    """`cpu_port` of a compression entry: the SAME buffers (the first `nb` of the entry's batch, host copy `raw`, descriptors `rec_table`)
+    through oracle_encode_batch -- the C restatement of LzChainMatchFinder + CompressHeaderless -- on T = min(allowed cores, 32) threads,
+    a bounded sample (`budget` seconds).  After the GPU measurement, never inside it."""
+    import ctypes as C
+    import oracle_lib as O
+    st = A.Settings(); st.quality = quality
+    threads = max(1, min(len(os.sched_getaffinity(0)), 32))
+    streams = (A.Stream * nb)()
+    r = np.frombuffer(streams, dtype=rec_table.dtype)
+    r[:] = rec_table[:nb]
+    base = int(r["src_off"].min())
+    r["src_off"] -= np.uint64(base)
+    cap = int(r["dst_cap"].max()); capal = (cap + 255) // 256 * 256
+    r["dst_off"] = np.arange(nb, dtype=np.uint64) * np.uint64(capal)
+    r["format"] = fmt
+    dst = np.ones(nb * capal + 64, dtype=np.uint8)
+    res = (A.Result * nb)(); aux = (A.EncodeAux * nb)()
+    view = raw[base:]
+    reps, t0 = 0, time.perf_counter()
+    while reps < 1 or (time.perf_counter() - t0 < budget and reps < 20):
+        O.lib.oracle_encode_batch(None, C.byref(st), nb, view.ctypes.data, streams, dst.ctypes.data, res, aux, threads)
+        reps += 1
+    dt = time.perf_counter() - t0
+    nbytes = int(r["src_len"].astype(np.int64).sum())
+    return {"value": round(nbytes * reps / dt / 2**30, 3), "unit": "GiB/s of raw input", "cores": threads, "kind": "port",
+            "sample": "first %d buffers of this entry's batch, %d passes" % (nb, reps)}
+
+
 def run_extras(ctx, batch, recs, n, target, decomp_bytes, np, synth, A):
     """Second roofline denominator and the PCIe-inclusive rate (never `value`)."""
     out = {}
@@ -643,7 +764,7 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             out.append(decode_config("cfg4_shard", "BASELINE configs[3], one GPU's shard: 5 000 of the 40 000 mixed LZ10/LZ11/Yaz0/PRS streams x 256 KiB, "
                                      "per-format kernels forked onto side streams", ctx, b, Plan, synth, np, steps, "mixed", 5000, 256))
         if "cfg5" in want:
-            out.extend(cfg5(ctx, np, A, synth, Plan))
+            out.extend(cfg5(ctx, np, A, synth, Plan, with_cpu=not args.no_cpu_baseline))
         if "bodies" in want:
             # every other decode body north_star names, on the metric's own shape (10 000 x 256 KiB synthetic streams, one GPU): the
             # per-format table of docs/EXPERIMENTS.md 4.4 in the driver-run line
@@ -661,7 +782,7 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             # ... and the other direction on that data: the encoder picks kernel B per stream (enc_probe_kernel: real data goes to the
             # one-position-per-lane kernel, the synthetic batches of cfg5 to the two-phase one)
             for f in ("yaz0", "lz4_block"):
-                out.append(realistic_compress(ctx, np, A, synth, f, 8))
+                out.append(realistic_compress(ctx, np, A, synth, f, 8, with_cpu=not args.no_cpu_baseline))
         if "single" in want:
             out.extend(single_stream(ctx, np, A, synth, Plan))
     except Exception as e:                                   # report what ran; the headline line must still come out
@@ -714,7 +835,7 @@ def cfg3(ctx, np, A, synth, Plan):
         plan.close(); ctx.free(d_src); ctx.free(d_dst)
 
 
-def cfg5(ctx, np, A, synth, Plan):
+def cfg5(ctx, np, A, synth, Plan, with_cpu=True):
     """BASELINE configs[4] on one GPU: compression of 10 000 x 256 KiB raw buffers (decoded synthetic LZSS streams, so they are
     compressible; produced on the device and kept there) through alz_encode_batch_device -- LZSS(12,4,2), the configuration's own
     format, at Q0 / Q8 / Q15 (the levels the reference publishes and its default), and Yaz0 and LZ4 blocks at Q0 / Q8.  The kernel time
@@ -767,7 +888,13 @@ def cfg5(ctx, np, A, synth, Plan):
                 a = int(recs["dst_off"][i])
                 ok = ok and bool(np.array_equal(g_raw[a:a + size], g_back[a:a + size]))
             name = ("cfg5_q%d" % q) if fname == "lzss" else ("cfg5_%s_q%d" % (fname, q))
-            out.append({"name": name, "workload": "BASELINE configs[4]: %s compression, parallel hash-chain match-find + emit, 10 000 x 256 KiB, quality %d, 1 GPU, device-resident"
+            cpu_port = None
+            if with_cpu:
+                try:
+                    cpu_port = cpu_port_encode(np, A, g_raw, r2, k, fmt, q)
+                except Exception as e:
+                    cpu_port = {"error": repr(e)}
+            out.append({"name": name, "cpu_port": cpu_port, "workload": "BASELINE configs[4]: %s compression, parallel hash-chain match-find + emit, 10 000 x 256 KiB, quality %d, 1 GPU, device-resident"
                         % ("LZSS(12,4,2)" if fname == "lzss" else fname, q),
                         "value": round(n * size / (kernel_ms * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(kernel_ms, 3),
                         "call_ms": round(call_s * 1e3, 3), "ratio": round(comp / (n * size), 4), "parity_ok": ok,
@@ -929,21 +1056,29 @@ def realistic(ctx, np, A, synth, Plan, steps, fmt_name="yaz0"):
         return {"name": "realistic_" + fmt_name, "workload": "%s decode of the %d 256 KiB windows of Test.bmp (stride 4 KiB, GPU-encoded at Q8, ratio %.3f), repeated to 10 000 streams"
                 % (fmt_name, nw, comp / (n * size)), "value": round(n * size * steps / dt / 2**30, 3), "unit": "GiB/s", "steps": steps,
                 "ms_per_step": round(dt / steps * 1e3, 4), "parity_ok": ok,
+                "input_residency": "the compressed input is %d distinct windows (%.1f MB) read by 10 000 streams: it is served by L2 / MALL, so HBM moves fewer bytes than "
+                                   "the algorithmic count (`roofline.traffic` < `algorithmic_bytes_per_launch`); `frac` prices bytes DECODED against the HBM peak, "
+                                   "not bytes HBM moved" % (nw, float(al.sum()) / 1e6),
                 "roofline": roofline(comp + n * size, kernel_ms, measured_traffic("realistic_" + fmt_name, n, size // 1024))}
     finally:
         db.close()
 
 
-def realistic_compress(ctx, np, A, synth, fmt_name, quality):
-    """1 024 windows of 256 KiB of Test.bmp (device-resident) through alz_encode_batch_device at the default quality: the batch encoder on
-    real data.  Checked by decoding eight of the streams back (the bytes themselves are pinned by tests/test_gpu_encode.py)."""
+def realistic_compress(ctx, np, A, synth, fmt_name, quality, with_cpu=True, n=10000):
+    """10 000 windows of 256 KiB of Test.bmp (evenly spaced starts: ~8 700 distinct windows, 2.4 GiB of raw input resident in HBM) through
+    alz_encode_batch_device at the default quality: the batch encoder on real data, at the metric's own batch size.  Checked by decoding eight
+    of the streams back (the bytes themselves are pinned by tests/test_gpu_encode.py); `cpu_port` = the first 256 of the same windows through
+    the C restatement on min(cores, 32) threads."""
     fmt = A.FORMAT_NAMES.index(fmt_name)
     from auroralib.compression_amd import formats as F
     lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
     bmp = np.frombuffer(lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read()), dtype=np.uint8)
-    n, size = 1024, 262144
+    size = 262144
     starts = [(i * (len(bmp) - size)) // (n - 1) for i in range(n)]
-    raw = np.concatenate([bmp[s:s + size] for s in starts])
+    raw = np.empty(n * size + 64, dtype=np.uint8)
+    for i, s0 in enumerate(starts):
+        raw[i * size:(i + 1) * size] = bmp[s0:s0 + size]
+    raw[n * size:] = 0
     cap = size + size // 4 + 64
     st = (A.Stream * n)()
     r = synth.stream_records(st)
@@ -968,11 +1103,20 @@ def realistic_compress(ctx, np, A, synth, fmt_name, quality):
             ok = ok and dr.status == 0 and got == bytes(raw[i * size:(i + 1) * size])
     finally:
         ctx.free(d_src); ctx.free(d_dst)
+        ctx.release_scratch()
     best = min(ms)
+    comp_total = int(rr["dst_len"].astype(np.int64).sum())
+    cpu_port = None
+    if with_cpu:
+        try:
+            cpu_port = cpu_port_encode(np, A, raw, r, min(n, 256), fmt, quality)
+        except Exception as e:
+            cpu_port = {"error": repr(e)}
     return {"name": "realistic_compress_%s_q%d" % (fmt_name, quality),
             "workload": "%s compression of %d windows of 256 KiB of Test.bmp at quality %d, device-resident (ratio %.3f)"
-                        % (fmt_name, n, quality, float(rr["dst_len"].astype(np.int64).sum()) / (n * size)),
-            "value": round(n * size / (best * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(best, 3), "parity_ok": ok}
+                        % (fmt_name, n, quality, comp_total / (n * size)),
+            "value": round(n * size / (best * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(best, 3), "parity_ok": ok,
+            "roofline": roofline(n * size + comp_total, best), "cpu_port": cpu_port}
 
 
 if __name__ == "__main__":

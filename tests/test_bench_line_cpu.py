@@ -1,0 +1,90 @@
+"""The bench line the driver parses must stay small and LAST on stdout (round 4's 39 KB line left BENCH_r04.parsed null)."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (importing bench.py touches neither HIP nor torch)
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline")
+
+
+def canned(world=1, with_configs=True):
+    """A full record shaped like a real run's, with prose as long as the real one's (or longer)."""
+    prose = "x" * 400
+    roof = {"bound": "hbm", "achieved": 1007.49, "peak": 8000.0, "unit": "GB/s", "frac": 0.12594, "traffic": 3011755181, "traffic_source": prose,
+            "kernel_ms": 2.9567, "algorithmic_bytes_per_launch": 2978822689, "issue_frac": 0.4321}
+    full = {"metric": "decompressed GiB/s (whole job; 10k x 256KiB batch per GPU), one batch in flight", "value": 824.99, "unit": "GiB/s", "n_gpus": world,
+            "steps": 20, "warmup": 3, "ms_per_step": 2.9593, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": prose, "format": "yaz0", "streams_this_rank": 10000, "streams_whole_job": 10000 * world, "stream_bytes": 262144,
+                       "compressed_bytes_whole_job": 357382689 * world, "parallelism": prose, "batches_in_flight": 1,
+                       "pipelined": {"value": 984.196, "unit": "GiB/s", "ms_per_step": 2.4806, "batches_in_flight": 2, "note": prose},
+                       "parity_ok": True, "verified_vs_oracle": True},
+            "roofline": roof,
+            "cpu_baseline": {"value": 14.639, "unit": "GiB/s", "cores": 32, "kind": "port", "single_thread": 0.922, "threads_sweep_GiB_s": {str(t): 1.0 for t in range(64)},
+                             "cpu_model": "AMD EPYC 9575F 64-Core Processor", "cgroup_cpu_quota_cores": 16.0, "sample": prose,
+                             "single_stream_one_thread_GiB_s": {f: 0.7 for f in bench.SINGLE_FORMATS}},
+            "ranks": [{"rank": r, "local_rank": r, "device": "AMD Radeon Graphics (gfx950:sramecc+:xnack-)", "pid": 100000 + r, "pci_domain_id": 0,
+                       "pci_bus_id": 200 + r, "pci_device_id": 0, "uuid": "36343363-6338-3637-6665-646565383062"} for r in range(world)],
+            "copy_bandwidth": {"value": 5928.8, "unit": "GB/s", "what": prose}, "end_to_end": {"value": 41.7, "unit": "GiB/s", "what": prose}}
+    if with_configs:
+        cfgs = []
+        names = ["cfg2", "cfg3", "cfg4_shard"] + ["cfg5_%s" % x for x in ("q0", "q8", "q15", "yaz0_q0", "yaz0_q8", "lz4_block_q0", "lz4_block_q8")] + \
+                ["body_" + f for f in bench.BODIES] + ["realistic_" + f for f in ("yaz0", "lz10", "lz11", "prs_be", "lz4_block")] + \
+                ["realistic_compress_yaz0_q8", "realistic_compress_lz4_block_q8", "mid_batch_yaz0_q8", "extra_one", "extra_two"]
+        for nme in names:
+            cfgs.append({"name": nme, "workload": prose, "value": 123456.789, "unit": "GiB/s", "steps": 10, "ms_per_step": 12345.6789, "parity_ok": True,
+                         "roofline": dict(roof), "cpu_port": {"value": 12.345, "unit": "GiB/s of raw input", "cores": 32, "kind": "port", "sample": prose}})
+        for f in bench.SINGLE_FORMATS:
+            for q in (0, 15):
+                for d in ("single_", "single_compress_"):
+                    cfgs.append({"name": "%s%s_q%d" % (d, f, q), "workload": prose, "value": 3.333, "parity_ok": True, "published_managed": {"where": prose}})
+        full["configs"] = cfgs
+    return full
+
+
+def test_contract_line_is_small_and_complete():
+    for world, wc in ((1, True), (1, False), (8, False), (8, True)):
+        line = bench.contract_line(canned(world, wc))
+        assert len(line) < bench.CONTRACT_LINE_MAX <= 4096, len(line)
+        assert "\n" not in line
+        o = json.loads(line)
+        for k in REQUIRED:
+            assert k in o, k
+        assert o["roofline"]["frac"] == 0.12594 and o["roofline"]["traffic"] == 3011755181 and o["roofline"]["bound"] == "hbm"
+        assert o["cpu_baseline"]["kind"] == "port" and o["cpu_baseline"]["cores"] == 32 and o["cpu_baseline"]["sample"]
+        assert o["config"]["workload"] and "model" not in o["config"]
+        assert len(o["ranks"]) == world and len({r["pci_bus_id"] for r in o["ranks"]}) == world
+        if wc and world == 1:
+            rows = o["configs_summary"]["rows"]
+            assert rows["cfg3"][:3] == [123456.789, 2.9567, 0.12594] and rows["cfg5_q8"][-1] == 12.345
+            assert o["configs_summary"]["single_stream_GiB_s"]["decode_q15"] == [3.333] * len(bench.SINGLE_FORMATS)
+            assert o["configs_summary"]["not_ok"] == []
+
+
+def test_failed_entries_are_named():
+    full = canned()
+    full["configs"][2]["parity_ok"] = False
+    full["configs"].append({"name": "error", "error": "boom"})
+    o = json.loads(bench.contract_line(full))
+    assert o["configs_summary"]["not_ok"] == ["cfg4_shard", "error"]
+
+
+def test_contract_line_is_the_last_stdout_line(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit(canned())
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2
+    assert lines[0].startswith(bench.DETAIL_PREFIX) and not lines[0].startswith("{")
+    assert json.loads(lines[0][len(bench.DETAIL_PREFIX):])["configs"][0]["name"] == "cfg2"       # the full record survives, one line earlier
+    assert lines[-1].startswith("{") and len(lines[-1]) < 4096
+    assert json.loads(lines[-1])["value"] == 824.99
+    assert json.load(open(tmp_path / "bench_detail.json"))["value"] == 824.99
+    # a JSON-line consumer that scans from the end finds the contract line first; one that takes every line starting with "{" finds only it
+    assert [l for l in lines if l.startswith("{")] == [lines[-1]]
