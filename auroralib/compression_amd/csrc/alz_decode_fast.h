@@ -359,7 +359,7 @@ __device__ __forceinline__ bool fast_iter_smsr00(InCache& cin, InCache& uin, OW&
 }
 
 
-struct EmitRet { u32 produced, flushed, ovf, att_lo, att_hi; };
+struct EmitRet { u32 produced, flushed, ovf, att_lo, att_hi, mtag; };
 
 // A queued token is ONE 32-bit word per lane: [31:18] length (1..16383), [17] literal flag, [16:0] match distance /
 // literal byte / low bits of the literal-run cache offset.
@@ -371,12 +371,13 @@ struct EmitRet { u32 produced, flushed, ovf, att_lo, att_hi; };
 // wave-uniform ones are re-scalarised on entry)
 template <class OW, class CFG>
 __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u32 lw_mask, u32 fl, u32 oshift, u32 cap, u32 produced, u32 flushed,
-                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qtok, u32 dirty = 1u) {
+                                                             int lane, u8* segmark, const u8* inlds, u32 W, u32 nt, u32 qtok, u32 mtag, u32 dirty = 1u) {
     OW out;
     out.dst = reinterpret_cast<u8*>(((u64)uni((u32)((u64)dst >> 32)) << 32) | uni((u32)(u64)dst));
     out.win = win; out.lw_mask = uni(lw_mask); out.fl = uni(fl); out.oshift = uni(oshift); out.cap = uni(cap);
     out.produced = uni(produced); out.flushed = uni(flushed); out.lane = lane;
     out.slack_dirty = uni(dirty) != 0u;                      // (the exact parsers' byte-wise writers may have run in between)
+    out.mtag = uni(mtag);                                    // (the byte phase's mark tag lives across calls)
     DecState s; dec_state_init(s);
     const u32 len = qtok >> 18, lo = qtok & 0x1FFFFu;
     u32 desc = lo;
@@ -384,7 +385,7 @@ __device__ __attribute__((noinline)) EmitRet queue_emit_call(u8* dst, u8* win, u
     u32 last;
     fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, lanes_below(uni(nt)), len, desc, 0u, segmark, inlds, lane, last, uni(W));
     EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = s.ovf ? 1u : 0u;
-    r.att_lo = (u32)s.attempted_end; r.att_hi = (u32)(s.attempted_end >> 32);
+    r.att_lo = (u32)s.attempted_end; r.att_hi = (u32)(s.attempted_end >> 32); r.mtag = out.mtag;
     return r;
 }
 
@@ -402,7 +403,7 @@ __device__ __attribute__((noinline)) EmitRet queue_serial_call(u8* dst, u8* win,
         const u32 t = wave_readlane(qtok, j), len = t >> 18, lo = t & 0x1FFFFu;
         if (t & 0x20000u) out.copy_lds(inlds + lo, len); else out.back_copy(lo, len, w);
     }
-    EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = 0; r.att_lo = 0; r.att_hi = 0;
+    EmitRet r; r.produced = out.produced; r.flushed = out.flushed; r.ovf = 0; r.att_lo = 0; r.att_hi = 0; r.mtag = 0;
     return r;
 }
 
@@ -435,8 +436,8 @@ struct QueueSink {
         // ONE out-of-line copy of the byte phase per kernel: the sink operations are inlined at every token site of the
         // parsers, and inlining the byte phase there as well made 100+ KB kernels that thrash the instruction cache
         const EmitRet r = queue_emit_call<OW, CFG>(out.dst, out.win, out.lw_mask, out.fl, out.oshift, out.cap, out.produced, out.flushed,
-                                                   lane, segmark, inlds, W, nt, qtok);
-        out.produced = uni(r.produced); out.flushed = uni(r.flushed);
+                                                   lane, segmark, inlds, W, nt, qtok, out.mtag);
+        out.produced = uni(r.produced); out.flushed = uni(r.flushed); out.mtag = uni(r.mtag);
         if (uni(r.ovf)) { s.ovf = true; s.attempted_end = ((u64)uni(r.att_hi) << 32) | uni(r.att_lo); }
         nt = 0; qbytes = 0;
     }

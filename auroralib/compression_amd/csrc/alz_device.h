@@ -143,12 +143,13 @@ struct OutWin {
     // the ring: kernels that use it allocate ALZ_WIN_SLACK bytes behind the ring that mirror its first bytes.  The byte-wise
     // writers below only touch the ring proper and mark the mirror stale; the chunked phase refreshes it before it reads.
     bool slack_dirty;
+    u32 mtag;        // tag of the byte phase's current mark block (alz_emit_byte.h; wave-uniform, 0 = none yet)
 
     __device__ __forceinline__ void init(u8* dst_, u32 cap_, u8* win_, u32 lw, int lane_, u32 slack = 0) {
         dst = dst_; cap = cap_; win = win_; lw_mask = lw - 1; lane = lane_;
         fl = lw >= 4096 ? 1024u : (lw >> 2);
         oshift = (u32)(reinterpret_cast<uintptr_t>(dst_) & 15u);
-        produced = 0; flushed = 0; slack_dirty = false;
+        produced = 0; flushed = 0; slack_dirty = false; mtag = 0;
         // E2: the reference's rented ring is treated as zero-filled
         for (u32 i = 16u * (u32)lane; i < lw + slack; i += 16u * ALZ_WAVE) *reinterpret_cast<uint4*>(win + i) = make_uint4(0, 0, 0, 0);
         wave_sync();

@@ -68,8 +68,10 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
 //   RUNGLOBAL literal runs are read from the stream's INPUT in global memory (`inlds` is then src + the offset that turns a run's
 //            cache index into an input offset), like a far source: the executing wavefront of a two-wavefront kernel has no
 //            input cache of its own while the parsing wavefront slides its cache as it pleases
-template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_, bool RUNGLOBAL_ = false>
-struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_, RUNGLOBAL = RUNGLOBAL_; };
+//   STEPMARKS the byte phase writes, reads and clears its marks every step (rounds 1-4) instead of once per block of two steps under a tag
+//            (round 5): more LDS instructions, no scalar ones -- the PRS kernels are bound by the CU's scalar unit (alz_emit_byte.h)
+template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_, bool RUNGLOBAL_ = false, bool STEPMARKS_ = false>
+struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_, RUNGLOBAL = RUNGLOBAL_, STEPMARKS = STEPMARKS_; };
 
 typedef u32 alz_v4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 / 8 bytes at a dword-aligned address
 typedef u32 alz_v2 __attribute__((ext_vector_type(2), aligned(4)));

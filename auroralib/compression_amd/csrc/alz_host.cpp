@@ -110,6 +110,7 @@ struct alz_ctx {
     uint64_t big_enc_launches = 0;             // streams the whole-GPU ENCODE path has taken (alz_encode_big.h)
     uint32_t big_min = 24u << 10;              // (24 KiB: tools/single_decode_sizes.py -- 0.18 ms either way at 16 KiB, 0.18 against 0.30 at 32) a lone stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
     uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
+    hipEvent_t big_evt = nullptr; bool big_evt_set = false;   // behind the last whole-GPU decode that used d_bigbuf (plans that borrow it run one after the other)
     void* d_bigbuf = nullptr; size_t d_bigbuf_cap = 0;   // its scratch for the plans of the host-buffer entry points (grow-only)
     // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
     // one piece overlaps the PCIe transfer of the other
@@ -145,6 +146,11 @@ struct alz_plan {
     // (or a few of them, one after the other: n streams through that path take n x ~0.1-0.3 ms, on wavefronts of their own they take as
     // long as the largest of them alone, 1-5 ms per MiB; plan_create weighs the two)
     bool big = false, big_borrowed = false; std::vector<alz_stream> big_streams; std::vector<uint32_t> big_pos; void* d_big = nullptr; uint32_t* d_gate = nullptr;
+    // A big plan owns MUTABLE device state (val / jump / ctl / gate in d_big): two executes in flight on different streams would race on it.
+    // Every execute waits for the event the one before recorded (the context's event when the scratch is the context's: several plans share it).
+    hipEvent_t big_evt = nullptr; bool big_evt_set = false;
+    // the stream of the last execute + an event behind it: alz_plan_results orders its copy behind the caller's own stream too
+    hipEvent_t done_evt = nullptr; bool done_evt_set = false;
 };
 
 static alz_lz_properties effective_lz(const alz_lz_properties* p) {
@@ -210,6 +216,7 @@ void alz_destroy(alz_ctx* c) {
     (void)hipSetDevice(c->device);
     release_scratch(c);
     for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
+    if (c->big_evt) (void)hipEventDestroy(c->big_evt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -283,6 +290,8 @@ void alz_plan_destroy(alz_ctx* c, alz_plan* p) {
         if (p->d_index) (void)hipFree(p->d_index);
     }
     if (p->d_big && !p->big_borrowed) (void)hipFree(p->d_big);
+    if (p->big_evt) (void)hipEventDestroy(p->big_evt);
+    if (p->done_evt) (void)hipEventDestroy(p->done_evt);
     delete p;
 }
 
@@ -340,7 +349,7 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
     // format class's Decompress call pays ~30 us for every synchronisation)
     if (scratch) p->index_host = std::move(index);
     else if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(c->stream); alz_plan_destroy(c, p); return fail(ALZ_E_HIP, "plan upload failed: %s", hipGetErrorString(e)); }
     bool all_big = n >= 1 && n <= ALZ_BIG_MAX_STREAMS && !c->exact && c->variant == 0;
     for (uint32_t i = 0; all_big && i < n; i++) all_big = alz_big_eligible((int)streams[i].format, &streams[i], &lz, c->big_min);
     if (all_big && n > 1) {
@@ -389,11 +398,24 @@ static uint32_t format_latency(uint32_t fmt) {
     default: return 240;                                     // LZO
     }
 }
+// An execute on a stream of the CALLER's leaves an event behind it, so that alz_plan_results (which copies on the context's own,
+// non-blocking stream) is ordered behind those kernels; executes on the context's stream are ordered by the stream itself.
+static int plan_mark_done(alz_plan* p, hipStream_t s, bool foreign) {
+    if (!foreign) { p->done_evt_set = false; return ALZ_OK; }
+    if (!p->done_evt) HIP_TRY(hipEventCreateWithFlags(&p->done_evt, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->done_evt, s));
+    p->done_evt_set = true;
+    return ALZ_OK;
+}
 int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_dst_base, void* hip_stream) {
     if (!c || !p) return fail(ALZ_E_INVALID, "alz_plan_execute: bad argument");
     HIP_TRY(hipSetDevice(c->device));                 // (a host thread may hold contexts of several devices)
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (p->big && !c->exact && c->variant == 0) {
+        hipEvent_t* ev = p->big_borrowed ? &c->big_evt : &p->big_evt;
+        bool* ev_set = p->big_borrowed ? &c->big_evt_set : &p->big_evt_set;
+        if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        if (*ev_set) HIP_TRY(hipStreamWaitEvent(s, *ev, 0));           // (a no-op on the stream that recorded it; orders any other stream behind the last run)
         for (uint32_t i = 0; i < p->n; i++) {
             const int f = (int)p->big_streams[i].format;
             hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_streams[i], &p->lz, p->d_results + i, p->d_big, p->d_gate);
@@ -401,7 +423,8 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
             if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream launch (format %d) failed: %s", f, hipGetErrorString(e));
             c->big_launches++;
         }
-        return ALZ_OK;
+        HIP_TRY(hipEventRecord(*ev, s)); *ev_set = true;
+        return plan_mark_done(p, s, s != c->stream);
     }
     int nfmt = 0;
     for (int f = 0; f < ALZ_FMT_COUNT; f++) nfmt += p->fmt_cnt[f] ? 1 : 0;
@@ -411,7 +434,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
             hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
-        return ALZ_OK;
+        return plan_mark_done(p, s, s != c->stream);
     }
     // mixed batch: one kernel per format, forked onto side streams so that they share the GPU (each format alone may
     // have far fewer streams than the device has wave slots), joined back into the caller's stream -- also when a launch
@@ -450,6 +473,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
         if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join[i], 0);
         if (e != hipSuccess && rc == ALZ_OK) rc = fail(ALZ_E_HIP, "joining the side streams failed: %s", hipGetErrorString(e));
     }
+    if (rc == ALZ_OK) rc = plan_mark_done(p, s, s != c->stream);
     return rc;
 }
 
@@ -470,6 +494,7 @@ int alz_plan_execute_timed(alz_ctx* c, alz_plan* p, const void* d_src_base, void
 int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
     if (!c || !p || (p->n && !results)) return fail(ALZ_E_INVALID, "alz_plan_results: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (p->done_evt_set) HIP_TRY(hipStreamWaitEvent(c->stream, p->done_evt, 0));    // (the last execute ran on a stream of the caller's)
     if (p->n) HIP_TRY(hipMemcpyAsync(results, p->d_results, p->n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ALZ_OK;
@@ -706,11 +731,13 @@ int alz_decode_batch(alz_ctx* c, const alz_lz_properties* props, uint32_t n, con
             if (results[0].dst_len <= spec) { if (results[0].dst_len) memcpy(dst_base + streams[0].dst_off, c->pin[0], results[0].dst_len); }
             else rc = download_outputs(c, n, streams, results, dst_base, false);         // (an overshoot of the declared size: E4)
         }
+        if (rc) (void)hipStreamSynchronize(c->stream);       // (an error path: the plan's pageable upload sources may still be queued)
         alz_plan_destroy(c, p);
         return rc;
     }
     if (!rc) rc = alz_plan_results(c, p, results);
     if (!rc) rc = download_outputs(c, n, streams, results, dst_base, false);   // copy back only what each stream produced
+    if (rc) (void)hipStreamSynchronize(c->stream);
     alz_plan_destroy(c, p);
     return rc;
 }
@@ -1092,6 +1119,7 @@ static int decode_share(alz_ctx* c, const alz_lz_properties* props, const std::v
     std::vector<alz_result> rs(m);
     rc = alz_plan_execute(c, p, c->d_src, c->d_dst, nullptr);
     if (!rc) rc = alz_plan_results(c, p, rs.data());
+    if (rc) (void)hipStreamSynchronize(c->stream);           // (the stream table `ds` and the plan's index list are upload sources)
     alz_plan_destroy(c, p);
     if (rc) return rc;
     std::vector<out_seg> outs; outs.reserve(m);

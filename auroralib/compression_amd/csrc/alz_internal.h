@@ -10,7 +10,7 @@
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams,
                              const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact, uint32_t batch_total = 0, int variant = 0)   /* batch_total: streams of ALL formats of the batch this launch belongs to (0 = count); variant: alz_ctx_set_kernel_variant */;
 int alz_kernel_occupancy(int fmt);
-// the same launch gated by a device word: the kernels return at once while *d_gate == 0 (alz_big.hip: the exact decode behind the
+// the same launch gated by a device word: the kernels return at once while *d_gate == 0 (alz_big.hip: the production -- lane-parallel -- decode, with the reference's error semantics, behind the
 // whole-GPU path of ONE big stream, needed only when that path declined the stream).  The formats of that path only.
 hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                                    uint32_t count, alz_result* d_results, const alz_lz_properties* lz, const uint32_t* d_gate);

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FMT == ALZ_F
     segmark[lane] = 0; segmark[64 + lane] = 0;
     InCache in; in.init(src, src_len, inc_lds, lane, QCH);
     DecState s; dec_state_init(s);
-    typedef EmitCfg<LW - 1u, false, !PRS, FB> CFG;
+    typedef EmitCfg<LW - 1u, false, !PRS, FB, false, PRS> CFG;   // (PRS: bound by the scalar unit -- per-step marks, alz_emit_byte.h)
     typedef QueueSink<OW, CFG> SK;
     SK sk(out, s, segmark, inc_lds, lane, PRS ? 8192u : ((FMT == ALZ_FMT_FASTLZ || FMT == ALZ_FMT_REFPACK) ? 131072u : FMT == ALZ_FMT_HIG ? 32768u : (CNS ? 256u : (SHREK ? 4096u : (CNX ? 2048u : 65536u)))));   // (window of the E2 rule: FastLZ level 2 reaches 0x11FFF back)
     if constexpr (PRS) {
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2_kernel(const u8* __restri
     OW out; out.init(dst, cap, lds + SCR + 256 + QCACHE, LW, lane, 0u);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     DecState s; dec_state_init(s);
-    typedef EmitCfg<LW - 1u, false, false, false> CFG;
+    typedef EmitCfg<LW - 1u, false, false, false, false, true> CFG;
     typedef QueueSink<OW, CFG> SK;
     __builtin_amdgcn_s_setprio(ALZ_PRS_PRIO);
     u32 fl = 1u;

@@ -223,7 +223,7 @@ int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
  * a format class's Compress(ReadOnlySpan<byte>, Stream) makes of ONE buffer (Interfaces/ICompressionEncoder.cs; the reference's benchmark
  * compresses ONE 1 000 KiB buffer, TestAllAlgorithms.cs:44-69).  The bytes are the same either way.
  * min_bytes: 0 keeps the current threshold, 0xFFFFFFFF switches both paths off; launches_out (may be NULL) receives how many streams have
- * taken either path on this context.  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take them. */
+ * been ENQUEUED on either path on this context (a stream that path declines -- any malformed one -- is still counted: the kernel behind the gate decodes it).  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take them. */
 int         alz_ctx_big_stream(alz_ctx* ctx, uint32_t min_bytes, uint64_t* launches_out);
 /* The host-buffer entry points keep their device staging buffers and the encoder's scratch (per input byte: a 16- or 32-bit link
  * in a 32-bit slot -- above quality 0 a second one, the links of the finder's wider hash narrowed from 15-bit ones --, a 32-bit
@@ -277,7 +277,11 @@ int alz_decode(alz_ctx* ctx, uint32_t format, const alz_lz_properties* props,
  * alz_plan_create uploads the descriptor table and groups it per format (one
  * kernel launch per format present).  alz_plan_execute only enqueues kernels
  * on `hip_stream` (a hipStream_t, or NULL for the context's own stream) and
- * does not synchronise.  d_src_base / d_dst_base are DEVICE pointers. */
+ * does not synchronise.  d_src_base / d_dst_base are DEVICE pointers.
+ * One plan may be executed again while an earlier execute is still in flight, also on another stream: a plan of big streams (the
+ * whole-GPU path, alz_ctx_big_stream) owns scratch on the device, so its executes are ordered one behind the other by an event
+ * (they do not overlap); any other plan only reads its tables.  alz_plan_results waits for the last execute, whichever stream it
+ * was enqueued on. */
 int  alz_plan_create(alz_ctx* ctx, const alz_lz_properties* props, uint32_t n,
                      const alz_stream* streams, alz_plan** out);
 int  alz_plan_execute(alz_ctx* ctx, alz_plan* plan, const void* d_src_base, void* d_dst_base, void* hip_stream);

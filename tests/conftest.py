@@ -13,6 +13,46 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# ---- the clean launcher (tests/_launcher.py): started here, at session start, while this process has certainly not touched the GPU
+_LAUNCHER = {"proc": None}
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    if "not gpu" in (session.config.getoption("-m") or ""):
+        return                                     # the CPU suite starts children itself (nothing there initialises HIP)
+    _LAUNCHER["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_launcher.py")], stdin=subprocess.PIPE,
+                                         stdout=subprocess.PIPE, text=True, cwd=ROOT)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = _LAUNCHER["proc"]
+    if p is not None:
+        try:
+            p.stdin.close()
+            p.wait(timeout=10)
+        except Exception:
+            p.kill()
+        _LAUNCHER["proc"] = None
+
+
+@pytest.fixture(scope="session")
+def clean_launcher():
+    """run(cmd, env=None, cwd=None, timeout=900) -> (returncode, stdout, stderr), executed by a helper process that was created before any
+    GPU call of this session and never makes one itself -- independent of test order, -k filters or --lf."""
+    import json
+    p = _LAUNCHER["proc"]
+    if p is None or p.poll() is not None:
+        pytest.skip("no clean launcher process in this session (started only when GPU tests are selected)")
+
+    def run(cmd, env=None, cwd=None, timeout=900):
+        p.stdin.write(json.dumps({"cmd": cmd, "env": env, "cwd": cwd, "timeout": timeout}) + "\n")
+        p.stdin.flush()
+        rep = json.loads(p.stdout.readline())
+        return rep["rc"], rep["stdout"], rep["stderr"]
+    return run
+
+
 @pytest.fixture(scope="session")
 def test_bmp():
     """Test.bmp (the reference's round-trip corpus), recovered by decoding the committed

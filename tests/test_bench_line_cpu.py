@@ -88,3 +88,18 @@ def test_contract_line_is_the_last_stdout_line(tmp_path, monkeypatch):
     assert json.load(open(tmp_path / "bench_detail.json"))["value"] == 824.99
     # a JSON-line consumer that scans from the end finds the contract line first; one that takes every line starting with "{" finds only it
     assert [l for l in lines if l.startswith("{")] == [lines[-1]]
+
+
+def test_clean_launcher_protocol():
+    """tests/_launcher.py (what the -m gpu session uses to start bench.py's ranks from a process that never touched the GPU)."""
+    import subprocess
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_launcher.py")], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    try:
+        for cmd, want_rc, want_out in (([sys.executable, "-c", "print('hello')"], 0, "hello\n"), ([sys.executable, "-c", "import sys; sys.exit(3)"], 3, ""),
+                                       (["/nonexistent/program"], -1, "")):
+            p.stdin.write(json.dumps({"cmd": cmd, "env": None, "cwd": ROOT, "timeout": 30}) + "\n"); p.stdin.flush()
+            rep = json.loads(p.stdout.readline())
+            assert rep["rc"] == want_rc and rep["stdout"] == want_out, rep
+    finally:
+        p.stdin.close()
+        assert p.wait(timeout=10) == 0

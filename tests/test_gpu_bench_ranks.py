@@ -5,7 +5,6 @@ launch); on the one-GPU test box both ranks use device 0 and rendezvous over glo
 is the code the 8-GPU run executes.  The JSON line names every rank's device (`ranks`), so a scaling record proves N distinct GPUs."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
@@ -15,24 +14,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ndev():
-    # (torch's count does not initialise the GPU on this image; alz_device_count() would, and a process that has touched the GPU must
-    # not fork + exec the ranks -- this file sorts first among the -m gpu tests, so the pytest process is still clean here)
+    # (torch's count does not initialise the GPU on this image)
     import torch
     return torch.cuda.device_count()
 
 
-def _bench(*extra):
+@pytest.fixture
+def _bench(clean_launcher):
+    """bench.py --gpus 2 started by the session's clean launcher (tests/conftest.py): a process that has touched the GPU must not
+    fork + exec the ranks, and this one may have -- whatever ran before this file."""
+    def run(*extra):
+        return _bench_via(clean_launcher, *extra)
+    return run
+
+
+def _bench_via(launch, *extra):
     shared = ["--dist-backend", "gloo", "--all-ranks-on-device", "0"] if _ndev() < 2 else []       # >= 2 GPUs: one device per rank, RCCL
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + shared + ["--steps", "2",
            "--warmup", "1", "--configs", "none", "--no-extras", "--no-cpu-baseline", "--inflight", "1"] + list(extra)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    rc, out, err = launch(cmd, env=env, cwd=ROOT, timeout=900)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert rc == 0 and len(lines) == 1, (rc, out[-2000:], err[-3000:])
+    assert out.splitlines()[-1] == lines[0] and len(lines[0]) < 4096          # the contract line: small, and LAST
     return json.loads(lines[0])
 
 
-def test_two_ranks_weak_scaling_every_rank_its_own_batch():
+def test_two_ranks_weak_scaling_every_rank_its_own_batch(_bench):
     d = _bench("--streams", "512", "--scaling", "weak")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["config"]["parity_ok"] is True and d["config"]["verified_vs_oracle"] is True
@@ -46,7 +54,7 @@ def test_two_ranks_weak_scaling_every_rank_its_own_batch():
         assert [r["local_rank"] for r in d["ranks"]] == [0, 1]
 
 
-def test_two_ranks_strong_scaling_one_mixed_batch_partitioned_by_the_library():
+def test_two_ranks_strong_scaling_one_mixed_batch_partitioned_by_the_library(_bench):
     """BASELINE.json configs[3] in small: ONE mixed LZ10 / LZ11 / Yaz0 / PRS batch, alz_partition_batch decides which rank decodes what."""
     d = _bench("--streams", "512", "--scaling", "strong", "--format", "mixed")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
@@ -54,7 +62,7 @@ def test_two_ranks_strong_scaling_one_mixed_batch_partitioned_by_the_library():
     assert d["config"]["streams_whole_job"] == 512 and 0 < d["config"]["streams_this_rank"] < 512
 
 
-def test_two_ranks_compress_their_own_buffers():
+def test_two_ranks_compress_their_own_buffers(_bench):
     """BASELINE.json configs[4] ("LZSS compression ... 1 -> 8 GPUs scaling") as a two-rank job: device-resident encode per rank,
     round trip on the device, the first buffers byte for byte against the oracle's restatement of the managed encoder."""
     d = _bench("--mode", "encode", "--streams", "256", "--quality", "8")
