@@ -254,7 +254,7 @@ __device__ __forceinline__ bool fast_iter_3cursor(InCache& fin_, InCache& cin, I
     // cursors after this token, packed so one readlane recovers both (c: 8 bits is enough for <=128, u: <=64)
     const u32 tend = ((2u * (midx + (lit ? 0u : 1u))) << 8) | (uidx + (usesu ? 1u : 0u));
     u32 last;
-    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, ~0ull, len, desc, tend, segmark, nullptr, lane, last, 4096);
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false, false, false, true>>(out, s, size, ~0ull, len, desc, tend, segmark, nullptr, lane, last, 4096);
     // (selects, not an if / else of "+=" through the references: the compiler sinks those stores into ONE store through a
     // pointer phi of &up / &fp before inlining, and the cursors then live in scratch memory for the whole kernel)
     cp += fin ? (last >> 8) : 2u * (u32)__popcll(~lm);
@@ -352,7 +352,7 @@ __device__ __forceinline__ bool fast_iter_smsr00(InCache& cin, InCache& uin, OW&
     // cursors after this token, packed so one readlane recovers both: code words (<= 68) << 8 | literals (<= 64)
     const u32 tend = ((gstart + 1u + mbefore + (lit ? 0u : 1u)) << 8) | (uidx + (lit ? 1u : 0u));
     u32 last;
-    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false>>(out, s, size, ~0ull, len, desc, tend, segmark, nullptr, lane, last, 4096);
+    const bool fin = fast_emit<OW, EmitCfg<4095u, false, false, false, false, false, true>>(out, s, size, ~0ull, len, desc, tend, segmark, nullptr, lane, last, 4096);
     if (fin) { cp += 2u * (last >> 8); up += last & 0xFFu; }
     else { cp += 2u * gend; up += (u32)__popcll(lm); }
     return fin;

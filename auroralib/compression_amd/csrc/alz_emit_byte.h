@@ -51,6 +51,14 @@ struct Mapper {
     u32 tbase4;      // 4 x (tokens that ended before the next step to be mapped)
     u32 m;           // steps mapped so far in this batch (wave-uniform)
 };
+// The descriptor of token idx4 / 4.  DESCTAB: the descriptors of a batch's tokens live in a 64-entry LDS table behind the marks for the length of
+// the batch -- one ds_read_b32 (2.7 LDS pipeline cycles against the 6.2 of the ds_bpermute_b32 that fetches it from the token lane's register;
+// one ds_write_b32 per batch fills the table; Yay0 2.67 -> 2.60 ms per 10 000 x 256 KiB).
+template <bool DESCTAB>
+__device__ __forceinline__ u32 desc_of(const u8* segmark, u32 idx4, u32 desc) {
+    if (DESCTAB) return *reinterpret_cast<const u32*>(segmark + 128u + idx4);
+    return (u32)__builtin_amdgcn_ds_bpermute((int)idx4, (int)desc);
+}
 template <class OW>
 __device__ __forceinline__ void mark_block(OW& out, u8* segmark, int lane, Mapper& mp) {
     u32 tag = out.mtag + 1u;
@@ -72,11 +80,11 @@ __device__ __forceinline__ u64 step_marks(OW& out, u8* segmark, int lane, Mapper
     const u32 mk = segmark[half + (u32)lane];
     return __ballot(mk == out.mtag);
 }
-template <class OW, int PAR>
+template <class OW, bool DESCTAB, int PAR>
 __device__ __forceinline__ u32 map_one(OW& out, u8* segmark, int lane, u32 desc, Mapper& mp) {
     const u64 M = step_marks<OW, PAR>(out, segmark, lane, mp);
     const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
-    const u32 dsc = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + mp.tbase4), (int)desc);   // match: the distance; literal: bit31 | ...
+    const u32 dsc = desc_of<DESCTAB>(segmark, (cnt << 2) + mp.tbase4, desc);   // match: the distance; literal: bit31 | ...
     mp.tbase4 += 4u * (u32)__popcll(M);
     mp.m += 1u;
     return dsc;
@@ -122,7 +130,7 @@ __device__ __forceinline__ void fused_step(OW& out, u8* segmark, const u8* inlds
     const u32 mk = segmark[64u * (u32)PAR + (u32)lane];      // map side: marks of step k+1
     const u64 M = __ballot(mk == out.mtag);
     const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0u));
-    const u32 dscn = (u32)__builtin_amdgcn_ds_bpermute((int)((cnt << 2) + mp.tbase4), (int)desc);
+    const u32 dscn = desc_of<CFG::DESCTAB>(segmark, (cnt << 2) + mp.tbase4, desc);
     mp.tbase4 += 4u * (u32)__popcll(M);
     mp.m += 1u;
     u32 val;
@@ -152,15 +160,16 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
     Mapper mp;
     mp.tbase4 = 0; mp.m = 0;
     mp.relm = e.kept ? e.off + e.clen - 1u : 0xFFFFFF00u;
+    if (CFG::DESCTAB) reinterpret_cast<u32*>(segmark + 128u)[lane] = desc;    // (ordered before the first read by the wave_sync behind the first block's marks)
     // unpipelined steps: the first W bytes of a stream (E2 test), and one more if that leaves the mapper in the middle of a block
     while (X + 64u <= T && (O + X < W || (mp.m & 1u))) {
-        const u32 d0 = map_one<OW, -1>(out, segmark, lane, desc, mp);
+        const u32 d0 = map_one<OW, CFG::DESCTAB, -1>(out, segmark, lane, desc, mp);
         copy_one<OW, CFG, true, true>(out, inlds, lane, d0, qs, 64u);
         X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks();
     }
     u32 dA = 0, dB = 0; u32 ahead = 0;                        // steps mapped and not yet copied (their descriptors: dA, then dB)
     if (X + 128u <= T) {                                      // the steady state: two steps per trip (descriptor registers ping-pong, no copy)
-        dA = map_one<OW, 0>(out, segmark, lane, desc, mp);
+        dA = map_one<OW, CFG::DESCTAB, 0>(out, segmark, lane, desc, mp);
         ahead = 1;
         do {
             fused_step<OW, CFG, 1>(out, segmark, inlds, lane, desc, mp, qs, dA, dB);
@@ -170,12 +179,12 @@ __device__ __forceinline__ void byte_emit_steps(OW& out, u8* segmark, const u8* 
         } while (X + 128u <= T);
     }
     if (X + 64u <= T) {                                       // one more whole step (fusing it with the mapping of a partial step behind it: Yaz0 2.94 against 2.90 ms)
-        if (!ahead) dA = map_one<OW, -1>(out, segmark, lane, desc, mp);
+        if (!ahead) dA = map_one<OW, CFG::DESCTAB, -1>(out, segmark, lane, desc, mp);
         copy_one<OW, CFG, true, true>(out, inlds, lane, dA, qs, 64u); ahead = 0;
         X += 64u; out.produced = O + X; if (out.produced - out.flushed >= out.fl) out.flush_blocks();
     }
     if (X < T) {
-        if (!ahead) dA = map_one<OW, -1>(out, segmark, lane, desc, mp);
+        if (!ahead) dA = map_one<OW, CFG::DESCTAB, -1>(out, segmark, lane, desc, mp);
         copy_one<OW, CFG, true, false>(out, inlds, lane, dA, qs, T - X);
         out.produced = O + T; if (out.produced - out.flushed >= out.fl) out.flush_blocks();
     }

@@ -28,7 +28,8 @@
 #pragma once
 #include "alz_decode_serial.h"
 
-#define ALZ_EMIT_SCRATCH 640u     /* LDS scratch of the byte phase: 128 B of marks + 64 x 8 B token table */
+#define ALZ_EMIT_SCRATCH 640u     /* LDS scratch of the chunked phase: 128 B of marks + 64 x 8 B token table */
+#define ALZ_BYTE_SCRATCH 384u     /* LDS scratch of the byte phase with CFG::DESCTAB: 128 B of marks + 64 x 4 B descriptor table (128 B of marks without) */
 #define ALZ_LONGTOK 1024u         /* tokens above this run alone (their fields would not fit the table entry) */
 
 __device__ __forceinline__ u64 wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -70,8 +71,12 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v, int lane) {
 //            input cache of its own while the parsing wavefront slides its cache as it pleases
 //   STEPMARKS the byte phase writes, reads and clears its marks every step (rounds 1-4) instead of once per block of two steps under a tag
 //            (round 5): more LDS instructions, no scalar ones -- the PRS kernels are bound by the CU's scalar unit (alz_emit_byte.h)
-template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_, bool RUNGLOBAL_ = false, bool STEPMARKS_ = false>
-struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_, RUNGLOBAL = RUNGLOBAL_, STEPMARKS = STEPMARKS_; };
+//   DESCTAB  the byte phase keeps the batch's descriptors in a 64-entry LDS table behind its marks (the kernel allocates ALZ_BYTE_SCRATCH) and a
+//            byte fetches its token's with a ds_read_b32 instead of a ds_bpermute_b32 from the token lane's register -- for the kernels that
+//            have the 256 bytes to spare: the three-cursor formats (small input caches).  The single-cursor kernels sit 96 bytes below the
+//            allocation step at which a CU holds 24 instead of 25 of their waves (+8 % time; with 512-byte cache chunks the table is worth ~1 %)
+template <u32 OMASK_, bool LZSS_, bool LITRUN_, bool FALLBACK_, bool RUNGLOBAL_ = false, bool STEPMARKS_ = false, bool DESCTAB_ = false>
+struct EmitCfg { static constexpr u32 OMASK = OMASK_; static constexpr bool LZSS = LZSS_, LITRUN = LITRUN_, FALLBACK = FALLBACK_, RUNGLOBAL = RUNGLOBAL_, STEPMARKS = STEPMARKS_, DESCTAB = DESCTAB_; };
 
 typedef u32 alz_v4 __attribute__((ext_vector_type(4), aligned(4)));   // 16 / 8 bytes at a dword-aligned address
 typedef u32 alz_v2 __attribute__((ext_vector_type(2), aligned(4)));

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #endif
     constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    constexpr u32 FSCR = FBK ? ALZ_EMIT_SCRATCH : 128u, FSLACK = FBK ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
+    constexpr u32 FSCR = FBK ? ALZ_EMIT_SCRATCH : (THREE ? ALZ_BYTE_SCRATCH : 128u), FSLACK = FBK ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][FSCR + NC * CACHE + LWMAX + FSLACK];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
@@ -571,7 +571,7 @@ template <int FMT>
 __global__ __launch_bounds__(128) void alz_decode_fast2c_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
                                                                 const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, u32 lw, const u32* __restrict__ gate) {
     if (gate != nullptr && __builtin_nontemporal_load(gate) == 0u) return;   // (alz_launch_decode_gated)
-    constexpr u32 CHUNK = 256u, CACHE = ALZ_INCACHE_SMALL, FSCR = 128u, LWMAX = 4096u;
+    constexpr u32 CHUNK = 256u, CACHE = ALZ_INCACHE_SMALL, FSCR = ALZ_BYTE_SCRATCH, LWMAX = 4096u;
     __shared__ __attribute__((aligned(16))) u8 lds[FSCR + 3u * CACHE + LWMAX + 3u * CACHE + 2u * ALZ_MBOX_WORDS * 4u];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(128) void alz_decode_fast2c_kernel(const u8* __rest
     OWF out; out.init(dst, cap, lds + FSCR + 3u * CACHE, lw, lane, 0u);
     segmark[lane] = 0; segmark[64 + lane] = 0;
     DecState s; dec_state_init(s);
-    typedef EmitCfg<4095u, false, false, false> CFG;
+    typedef EmitCfg<4095u, false, false, false, false, false, true> CFG;   // (FSCR = ALZ_BYTE_SCRATCH: the descriptor table)
     bool fin = false;
     u32 fp = 0, cp = a0, up = a1;
     for (u32 k = 0;; k++) {

@@ -125,11 +125,40 @@ def fmt_array(np, A, name, n, first=0):
 TRAFFIC_SOURCE = "profiles/traffic.json (rocprofv3 --pmc passes of this exact workload, FETCH_SIZE x2 + WRITE_SIZE per launch, committed; not re-measured in this run)"
 
 
-def roofline(algo_bytes, kernel_ms, traffic=None):
+# The instruction-issue ceilings of one CU, measured (tools/ubench_issue.hip, profiles/r05_issue_ceiling.md): wave64 instructions per cycle per CU
+ISSUE_CEILING = {"valu_fast": 1.75, "valu_slow": 0.95, "salu": 0.95, "lds_cycles_per_inst": 4.3, "clock_hz": 2.4e9, "cus": 256}
+
+
+def issue_object(key, kernel_ms):
+    """`roofline.issue`: the launch's instruction counts (profiles/insts.json: committed rocprofv3 --pmc passes of this exact workload) priced against the
+    MEASURED issue ceilings -- the share of each pipe's capacity the launch used.  valu: [all instructions in the 2-cycle class, all in the 4-cycle class];
+    salu: the CU's one scalar pipe; lds: the CU's one LDS pipeline at the byte phase's average of 4.3 pipeline cycles per instruction (an estimate).
+    `issue_frac` = the most loaded pipe, the vector ALU priced half fast, half slow."""
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "insts.json"))).get(key)
+    except Exception:
+        c = None
+    if not c:
+        return None
+    cyc = kernel_ms * 1e-3 * ISSUE_CEILING["clock_hz"] * ISSUE_CEILING["cus"]
+    v, sc, l = c["valu"] / cyc, c["salu"] / cyc, c["lds"] / cyc
+    valu = [round(v / ISSUE_CEILING["valu_fast"], 3), round(v / ISSUE_CEILING["valu_slow"], 3)]
+    salu = round(sc / ISSUE_CEILING["salu"], 3)
+    lds = round(l * ISSUE_CEILING["lds_cycles_per_inst"], 3)
+    mid = v / (2.0 / (1.0 / ISSUE_CEILING["valu_fast"] + 1.0 / ISSUE_CEILING["valu_slow"]))
+    return {"valu": valu, "salu": salu, "lds": lds, "issue_frac": round(max(mid, salu, lds), 3), "counts_from": c.get("source")}
+
+
+def roofline(algo_bytes, kernel_ms, traffic=None, issue_key=None):
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
-            "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
+    r = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+         "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
+         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
+    iss = issue_object(issue_key, kernel_ms) if issue_key else None
+    if iss:
+        r["issue"] = iss
+        r["issue_frac"] = iss["issue_frac"]
+    return r
 
 
 CONTRACT_LINE_MAX = 4096    # the driver keeps ~8 KB of stdout tail: the round-4 line (39 KB) left BENCH_r04.parsed null
@@ -268,7 +297,7 @@ def decode_config(name, workload, ctx, batch, Plan, synth, np, steps, fmt_name, 
         comp = int(recs["src_len"].astype(np.int64).sum()); dec = int(recs["decom_len"].astype(np.int64).sum())
         return {"name": name, "workload": workload, "value": round(dec * steps / dt / 2**30, 3), "unit": "GiB/s", "steps": steps,
                 "ms_per_step": round(dt / steps * 1e3, 4), "timing": "best of two passes of %d steps" % steps, "parity_ok": ok,
-                "roofline": roofline(comp + dec, kernel_ms, measured_traffic(fmt_name, n, kib))}
+                "roofline": roofline(comp + dec, kernel_ms, measured_traffic(fmt_name, n, kib), "%s:%d:%d" % (fmt_name, n, kib))}
     finally:
         db.close()
 
@@ -432,7 +461,7 @@ def main():
                        "format": args.format, "streams_this_rank": n, "streams_whole_job": job_n, "stream_bytes": target,
                        "compressed_bytes_whole_job": int(job_comp), "parallelism": parallelism, "batches_in_flight": 1,
                        "pipelined": pipelined, "parity_ok": ok, "verified_vs_oracle": verified},
-            "roofline": roofline(comp_bytes + decomp_bytes, kernel_ms, measured_traffic(args.format, n, args.stream_kib)),
+            "roofline": roofline(comp_bytes + decomp_bytes, kernel_ms, measured_traffic(args.format, n, args.stream_kib), "%s:%d:%d" % (args.format, n, args.stream_kib)),
             "cpu_baseline": cpu,
             "ranks": ranks,
         }
