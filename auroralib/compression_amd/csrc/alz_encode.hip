@@ -1932,11 +1932,7 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
             // (LZ11 / LZ40 -- matches of up to 16 KiB --: a window the cursor has already jumped over is never looked at, its stage is left out
             // as in enc_parse_seq_kernel: 1 024 windows of Test.bmp 11.65 -> 11.23 ms, 4 096 25.0 -> 23.7.  With Yaz0's 273 bytes -3 % on the
             // bitmap and +2 % on text; the 18 bytes of LZ10 never skip a window: +1.5 %)
-#ifdef ALZ_PARSE_SKIP_ALL                   /* tools/parse_skip_experiment.sh */
-            constexpr bool SKIPW = true;
-#else
-            constexpr bool SKIPW = FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40;
-#endif
+            constexpr bool SKIPW = FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40;     // (for every format: tools/variants/r04_encode_switches.patch, -DALZ_PARSE_SKIP_ALL)
             if (!SKIPW || cur < (int)P + 128) a_n = matchof(p + 64u, lkB, ownB, cndB);    // window w + 1 (bytes that arrived during the window before)
             lkB = lkA; ownB[0] = ownA[0]; ownB[1] = ownA[1]; ownB[2] = ownA[2]; ownB[3] = ownA[3];
             if (!SKIPW || cur < (int)P + 192) loadC(p + 128u, lkB, cndB);                 // window w + 2's candidates
@@ -2946,15 +2942,7 @@ static bool uses_win_prev(const EncGeom& g) {
     return g.max_dist <= 8192 && (g.hash_bits > 15 || g.use_min_table);
 }
 static bool narrows_links(const EncGeom& g) {
-#ifdef ALZ_NO_NARROW                         /* tools/narrow_experiment.sh */
-    return false;
-#endif
-#ifdef ALZ_NO_NARROW_WIN                     /* tools/narrow_experiment.sh: not for the formats with windows up to 8 KiB */
-    if (uses_win_prev(g)) return false;
-#endif
-#ifdef ALZ_NO_NARROW_MIN                     /* tools/narrow_experiment.sh: not with the min-length table (quality >= 10, matches below four bytes) */
-    if (g.use_min_table) return false;
-#endif
+    // (the switches of tools/narrow_experiment.sh live in tools/variants/r04_encode_switches.patch)
     return g.link16 && g.nprops <= 1 && g.hash_bits > 15;
 }
 int alz_encode_geom_narrows(const void* geom) { EncGeom g; memcpy(&g, geom, sizeof(g)); return narrows_links(g) ? 1 : 0; }
@@ -3171,9 +3159,6 @@ static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_strea
 // a visited position costs more than the cap saves and 256 is the better line (LZ11 Q8 92 / 76 / 100).  Formats whose longest match is below 96
 // bytes (Snappy: 64) lose with any cap (Q0 20 -> 30 ms at 48): none.  The synthetic batches (matches of at most 18 bytes) never reach a cap.
 static int choose_b_cap(const EncGeom& g) {
-#ifdef ALZ_BCAP_FORCE                                              /* tools/bcap_sweep.sh: one cap for every quality (a build flag, not an environment variable) */
-    return g.max_len > ALZ_BCAP_FORCE ? ALZ_BCAP_FORCE : ALZ_LEN_CAP;
-#endif
     if (g.max_len < 96) return ALZ_LEN_CAP;
     const int cap = (g.max_chain <= 5 || g.max_chain >= 64) ? 48 : 256;
     return g.max_len > cap ? cap : ALZ_LEN_CAP;
@@ -3264,7 +3249,6 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
         if (!uses_win_prev(g)) { const u32 want = (ALZ_NARROW_WGS + count - 1u) / count; if (bx > want) bx = want; }
         auto narrow = [&](const u32* list) {
-#ifndef ALZ_NO_NARROW_LDS
             if (g.max_dist <= 8192) {                                               // (range and window in LDS)
                 const u32 look = g.max_dist <= 4096 ? 4096u : 8192u, range = look == 4096u ? ALZ_NARROW_RANGE : 8192u;
                 u32 gx = (max_len + range - 1u) / range; if (gx == 0u) gx = 1u; if (gx > 4096u) gx = 4096u;
@@ -3272,7 +3256,6 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
                 else hipLaunchKernelGGL((enc_narrow_lds_kernel<8192, 8192>), dim3(gx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
                 return;
             }
-#endif
             hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
         };
         if (uses_win_prev(g) && !g.use_min_table) {

@@ -936,12 +936,7 @@ hipError_t alz_launch_encode_big(int fmt, hipStream_t stream, const void* d_src_
     else hipLaunchKernelGGL((benc_gather<false>), dim3(nbp), dim3(256), 0, stream, a, seg4, segm, fin4, finm, mark);
     // B: on the real stream (entry K)
     launch_match(stream, (const u8*)d_src_base, vs, vindex + a.K, 1u, st->src_len, fin4, finm, match, vpos, g, tail, 4096u,
-#ifdef ALZ_BENC_DENSE                                              /* experiment: the two-phase kernel here too */
-                 true
-#else
-                 false
-#endif
-                 );
+                 false);                                           // (the two-phase kernel here too: tools/variants/r04_encode_switches.patch, -DALZ_BENC_DENSE)
     // C: the parse
     const u32 nbn = (a.nodes + 255u) / 256u;
     const bool caps = g.max_len > g.b_cap;                        // (only then can kernel B have capped anything)

@@ -3,6 +3,7 @@
 # width for all (-DALZ_NO_NARROW; -DALZ_NO_NARROW_MIN: not with the min-length table), and the threshold of the choice
 # (-DALZ_NARROW_THRESH16=t: narrow below t / 16 distinct hashes per sampled position; 17 = always).  Results: docs/EXPERIMENTS.md 9.12.
 cd $GRAFT_REPO_ROOT
+patch -p1 -N -s < tools/variants/r04_encode_switches.patch || true   # (the compile-time switches this script turns live in a patch, not in the product sources; the GPU box works on a scratch copy)
 run() {
   touch auroralib/compression_amd/csrc/alz_encode.hip
   ALZ_EXTRA_FLAGS="$1" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1
