@@ -1529,11 +1529,11 @@ static void enc_prs(const alz_settings* st, const uint8_t* src, int n, buf_t* ou
             fw_flush_if_necessary(&flag);
         } else {
             if (length > 9) {
-                uint32_t v = (uint32_t)(distance << 3) & 0xFFFF;
+                uint32_t v = ((uint32_t)distance << 3) & 0xFFFF;          /* (distance is negative: C#'s (ushort)(distance << 3) on the two's-complement bits) */
                 if (big) buf_u16be(&flag.buffer, v); else buf_u16le(&flag.buffer, v);
                 buf_u8(&flag.buffer, (uint32_t)(length - 1));
             } else {
-                uint32_t v = (uint32_t)((distance << 3) | (length - 2)) & 0xFFFF;
+                uint32_t v = (((uint32_t)distance << 3) | (uint32_t)(length - 2)) & 0xFFFF;
                 if (big) buf_u16be(&flag.buffer, v); else buf_u16le(&flag.buffer, v);
             }
             fw_bit(&flag, 1);

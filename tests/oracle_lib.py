@@ -8,13 +8,13 @@ import numpy as np
 from auroralib.compression_amd import _abi as A
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "liboracle.so")
+_SO = os.environ.get("ALZ_ORACLE_SO") or os.path.join(_ROOT, "oracle", "liboracle.so")   # (ALZ_ORACLE_SO: the sanitizer build, tests/test_sanitizers_cpu.py)
 
 
 def _load():
     src = os.path.join(_ROOT, "oracle", "alz_oracle.c")
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     lib = C.CDLL(_SO)
     lib.oracle_xxh64.restype = C.c_uint64
     lib.oracle_xxh64.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
