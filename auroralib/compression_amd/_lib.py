@@ -55,6 +55,11 @@ def load():
     lib.alz_plan_results.argtypes = [vp, vp, vp]
     lib.alz_plan_destroy.argtypes = [vp, vp]
     lib.alz_plan_destroy.restype = None
+    lib.alz_plan_create_multi.argtypes = [vp, u32, vp, u32, vp, vp, C.POINTER(vp), vp]
+    lib.alz_plan_execute_multi.argtypes = [vp, vp, vp]
+    lib.alz_plan_results_multi.argtypes = [vp, vp]
+    lib.alz_plan_destroy_multi.argtypes = [vp]
+    lib.alz_plan_destroy_multi.restype = None
     lib.alz_device_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.alz_device_free.argtypes = [vp, vp]
     lib.alz_memcpy_h2d.argtypes = [vp, vp, vp, sz]

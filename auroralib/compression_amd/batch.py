@@ -176,6 +176,40 @@ class Plan:
             self.h = None
 
 
+class MultiPlan:
+    """alz_multi_plan: ONE device-resident batch over several contexts (one per GPU) -- the batch partitioned by the library (or by `part_of`),
+    one plan per context, no host staging, no collective.  A stream's offsets are relative to the device buffers of ITS context."""
+
+    def __init__(self, ctxs, streams, lz=None, part_of=None):
+        self.ctxs, self.n = list(ctxs), len(streams)
+        self.lib = self.ctxs[0].lib
+        arr = (C.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs])
+        part = np.zeros(max(self.n, 1), dtype=np.uint32)
+        given = None
+        if part_of is not None:
+            given = np.ascontiguousarray(part_of, dtype=np.uint32)
+        h = C.c_void_p()
+        check(self.lib.alz_plan_create_multi(arr, len(self.ctxs), C.byref(lz) if lz is not None else None, self.n, streams,
+                                             _vp(given) if given is not None else None, C.byref(h), _vp(part)))
+        self.h, self.part_of = h, part[:self.n]
+
+    def execute(self, d_srcs, d_dsts):
+        k = len(self.ctxs)
+        a = (C.c_void_p * k)(*[p.value if hasattr(p, "value") else p for p in d_srcs])
+        b = (C.c_void_p * k)(*[p.value if hasattr(p, "value") else p for p in d_dsts])
+        check(self.lib.alz_plan_execute_multi(self.h, a, b))
+
+    def results(self):
+        res = (A.Result * self.n)()
+        check(self.lib.alz_plan_results_multi(self.h, res))
+        return res
+
+    def close(self):
+        if self.h:
+            self.lib.alz_plan_destroy_multi(self.h)
+            self.h = None
+
+
 def partition_batch(streams, n_parts):
     """alz_partition_batch: greedy LPT partition of a batch (host code, no GPU).  Returns (part_of np.uint32[n], cost np.uint64[n_parts])."""
     lib = load()

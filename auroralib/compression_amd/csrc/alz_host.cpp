@@ -1169,6 +1169,63 @@ int alz_decode_batch_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_pr
     return ALZ_OK;
 }
 
+// ---------------------------------------------------------------- device-resident batches over several contexts
+struct alz_multi_plan {
+    std::vector<alz_ctx*> ctxs;
+    std::vector<alz_plan*> plans;                  // one per context (NULL: no stream of the batch went there)
+    std::vector<std::vector<uint32_t>> idx;        // the batch indices of every context's streams, ascending
+    uint32_t n = 0;
+};
+void alz_plan_destroy_multi(alz_multi_plan* mp) {
+    if (!mp) return;
+    for (size_t q = 0; q < mp->plans.size(); q++) if (mp->plans[q]) alz_plan_destroy(mp->ctxs[q], mp->plans[q]);
+    delete mp;
+}
+int alz_plan_create_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_properties* props, uint32_t n, const alz_stream* streams,
+                          const uint32_t* part_of, alz_multi_plan** out, uint32_t* part_of_out) {
+    if (!ctxs || n_ctx == 0 || n_ctx > 64 || !out || (n && !streams)) return fail(ALZ_E_INVALID, "alz_plan_create_multi: bad argument");
+    for (uint32_t q = 0; q < n_ctx; q++) {
+        if (!ctxs[q]) return fail(ALZ_E_INVALID, "alz_plan_create_multi: context %u is NULL", q);
+        for (uint32_t r = 0; r < q; r++) if (ctxs[r] == ctxs[q]) return fail(ALZ_E_INVALID, "alz_plan_create_multi: context %u is listed twice (a context is single-threaded)", q);
+    }
+    std::vector<uint32_t> part(n ? n : 1);
+    if (part_of) { for (uint32_t i = 0; i < n; i++) { if (part_of[i] >= n_ctx) return fail(ALZ_E_INVALID, "alz_plan_create_multi: part_of[%u] = %u, %u contexts", i, part_of[i], n_ctx); part[i] = part_of[i]; } }
+    else if (int rc = alz_partition_batch(n, streams, n_ctx, part.data(), nullptr)) return rc;
+    if (part_of_out) for (uint32_t i = 0; i < n; i++) part_of_out[i] = part[i];
+    alz_multi_plan* mp = new (std::nothrow) alz_multi_plan();
+    if (!mp) return fail(ALZ_E_NOMEM, "out of memory");
+    mp->n = n; mp->ctxs.assign(ctxs, ctxs + n_ctx); mp->plans.assign(n_ctx, nullptr); mp->idx.resize(n_ctx);
+    for (uint32_t i = 0; i < n; i++) mp->idx[part[i]].push_back(i);
+    std::vector<alz_stream> share;
+    for (uint32_t q = 0; q < n_ctx; q++) {
+        if (mp->idx[q].empty()) continue;
+        share.clear();
+        for (uint32_t i : mp->idx[q]) share.push_back(streams[i]);
+        if (int rc = alz_plan_create(ctxs[q], props, (uint32_t)share.size(), share.data(), &mp->plans[q])) { alz_plan_destroy_multi(mp); return rc; }
+    }
+    *out = mp;
+    return ALZ_OK;
+}
+int alz_plan_execute_multi(alz_multi_plan* mp, const void* const* d_src_bases, void* const* d_dst_bases) {
+    if (!mp || !d_src_bases || !d_dst_bases) return fail(ALZ_E_INVALID, "alz_plan_execute_multi: bad argument");
+    for (size_t q = 0; q < mp->plans.size(); q++) {
+        if (!mp->plans[q]) continue;
+        if (int rc = alz_plan_execute(mp->ctxs[q], mp->plans[q], d_src_bases[q], d_dst_bases[q], nullptr)) return rc;   // (asynchronous: every device works while the next is being fed)
+    }
+    return ALZ_OK;
+}
+int alz_plan_results_multi(alz_multi_plan* mp, alz_result* results) {
+    if (!mp || (mp->n && !results)) return fail(ALZ_E_INVALID, "alz_plan_results_multi: bad argument");
+    std::vector<alz_result> rs;
+    for (size_t q = 0; q < mp->plans.size(); q++) {
+        if (!mp->plans[q]) continue;
+        rs.resize(mp->idx[q].size());
+        if (int rc = alz_plan_results(mp->ctxs[q], mp->plans[q], rs.data())) return rc;
+        for (size_t j = 0; j < rs.size(); j++) results[mp->idx[q][j]] = rs[j];
+    }
+    return ALZ_OK;
+}
+
 // One context's share of an encode batch: its raw buffers are packed into a device buffer of their own, the compressed streams come
 // back from worst-case-sized slots.
 static int encode_share(alz_ctx* c, const alz_lz_properties* props, const alz_settings* settings, const std::vector<uint32_t>& idx,

@@ -292,6 +292,22 @@ int  alz_plan_execute_timed(alz_ctx* ctx, alz_plan* plan, const void* d_src_base
 int  alz_plan_results(alz_ctx* ctx, alz_plan* plan, alz_result* results); /* synchronises, copies n results */
 void alz_plan_destroy(alz_ctx* ctx, alz_plan* plan);
 
+/* The device-resident path over several contexts = several GPUs of one node, without host staging: what
+ * alz_decode_batch_multi does for host buffers, for a caller whose compressed payload is already in HBM (and whose output stays there).
+ * alz_plan_create_multi partitions the batch (part_of[i] = index into ctxs[] that decodes stream i; NULL: alz_partition_batch decides,
+ * part_of_out -- may be NULL -- receives the choice) and creates one plan per context over that context's streams.  A stream's
+ * src_off / dst_off are relative to the device pointers of ITS context: d_src_bases[q] / d_dst_bases[q] in alz_plan_execute_multi, which
+ * only enqueues every context's kernels on that context's own stream (from the calling thread: launches are asynchronous, no host
+ * threads, no collective -- streams are independent, a fresh LzWindows per Decompress call, Nintendo/LZ10.cs:86) and does not
+ * synchronise.  alz_plan_results_multi waits for all of them and returns the n results in batch order.  ctxs[] must not repeat a
+ * context; two contexts may share a device. */
+typedef struct alz_multi_plan alz_multi_plan;
+int  alz_plan_create_multi(alz_ctx* const* ctxs, uint32_t n_ctx, const alz_lz_properties* props, uint32_t n,
+                           const alz_stream* streams, const uint32_t* part_of, alz_multi_plan** out, uint32_t* part_of_out);
+int  alz_plan_execute_multi(alz_multi_plan* plan, const void* const* d_src_bases, void* const* d_dst_bases);
+int  alz_plan_results_multi(alz_multi_plan* plan, alz_result* results);
+void alz_plan_destroy_multi(alz_multi_plan* plan);
+
 /* ------------------------------------------------------------- encode
  * Replaces the static `CompressHeaderless(ReadOnlySpan<byte>, Stream, CompressionSettings)`
  * bodies (e.g. LZSS.cs:132-160, LZ10.cs:113-137) + LzChainMatchFinder

@@ -217,3 +217,74 @@ def test_multi_uses_distinct_devices_when_the_box_has_them():
     finally:
         for c in ctxs:
             c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The device-resident path over several contexts (alz_plan_create_multi / _execute_multi / _results_multi): no host staging.
+@pytest.mark.parametrize("given_partition", [False, True])
+def test_multi_plan_device_resident_matches_the_oracle(given_partition):
+    """ONE mixed batch, partitioned over 2 (or device_count()) contexts -- on distinct devices where the box has them, otherwise two contexts
+    of device 0 --, every context's share decoded from ITS device buffers, results gathered in batch order: bit-exact against the oracle."""
+    from auroralib.compression_amd.batch import MultiPlan, partition_batch
+    nd = device_count()
+    k = nd if nd >= 2 else 2
+    ctxs = [Context(q if nd >= 2 else 0) for q in range(k)]
+    try:
+        b = _mixed(97 * k + 5, 40000, synth.seed_for(4, 91))
+        o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes, nthreads=8)
+        part_of = None
+        if given_partition:
+            part_of = (np.arange(len(b.streams)) * 7 % k).astype(np.uint32)
+        mp = MultiPlan(ctxs, b.streams, part_of=part_of)
+        if given_partition:
+            assert np.array_equal(mp.part_of, part_of)
+        else:
+            assert np.array_equal(mp.part_of, partition_batch(b.streams, k)[0]) and set(mp.part_of.tolist()) == set(range(k))
+        # every device gets the batch's layout with ONLY its own share's payload in it (the rest stays 0xEE): a stream decoded on the wrong
+        # device, or from the wrong buffer, cannot come out right
+        d_src, d_dst = [], []
+        recs = synth.stream_records(b.streams)
+        for q, c in enumerate(ctxs):
+            mine = np.nonzero(mp.part_of == q)[0]
+            host = np.full(b.src.nbytes, 0xEE, dtype=np.uint8)
+            for i in mine:
+                a, n = int(recs["src_off"][i]), int(recs["src_len"][i])
+                host[a:a + n] = b.src[a:a + n]
+            s, d = c.malloc(b.src.nbytes), c.malloc(b.dst_bytes)
+            c.h2d(s, host); c.memset(d, 0, b.dst_bytes)
+            d_src.append(s); d_dst.append(d)
+        try:
+            mp.execute(d_src, d_dst)
+            res = mp.results()
+            out = np.zeros(b.dst_bytes, dtype=np.uint8)
+            for q, c in enumerate(ctxs):
+                got = c.d2h(d_dst[q], b.dst_bytes)
+                for i in np.nonzero(mp.part_of == q)[0]:
+                    a, n = int(recs["dst_off"][i]), int(res[i].dst_len)
+                    out[a:a + n] = got[a:a + n]
+                # ... and nothing of another context's share was written here
+                for i in np.nonzero(mp.part_of != q)[0][:50]:
+                    a, n = int(recs["dst_off"][i]), int(recs["dst_cap"][i])
+                    assert not got[a:a + n].any(), (q, i)
+            _check(b.streams, out, res, o_dst, o_res, "multi plan over %d contexts" % k)
+        finally:
+            mp.close()
+            for q, c in enumerate(ctxs):
+                c.free(d_src[q]); c.free(d_dst[q])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_multi_plan_rejects_bad_arguments():
+    from auroralib.compression_amd.batch import MultiPlan
+    from auroralib.compression_amd._lib import AlzError
+    c = Context(0)
+    try:
+        b = _mixed(8, 4096, synth.seed_for(4, 5))
+        with pytest.raises(AlzError):
+            MultiPlan([c, c], b.streams)                                         # a context listed twice
+        with pytest.raises(AlzError):
+            MultiPlan([c], b.streams, part_of=np.full(len(b.streams), 3, dtype=np.uint32))   # a part that does not exist
+    finally:
+        c.close()

@@ -69,7 +69,7 @@ def main():
         if g and va:
             cyc = sum(g) / len(g) / 8.0            # counter is summed over the 8 XCDs
             busy = sum(va) / len(va) * 4.0 / 1024.0 / cyc   # SQ_ACTIVE_* count quad-cycles; 1024 SIMDs
-            lines += ["", "derived: %.3g shader cycles per dispatch; VALU busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / cycles = %.0f %%" % (cyc, busy * 100)]
+            lines += ["", "derived: %.3g shader cycles per dispatch; VALU busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / cycles = %.0f %%%s" % (cyc, busy * 100, " (an UPPER bound: the counter is 1 per instruction, and add / sub / and / or / xor / shift-right / mov occupy the SIMD for ~2.2 cycles, not 4 -- profiles/r05_issue_ceiling.md; bench.py's `roofline.issue` prices all three pipes against the measured ceilings)")]
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
