@@ -103,3 +103,17 @@ def test_clean_launcher_protocol():
     finally:
         p.stdin.close()
         assert p.wait(timeout=10) == 0
+
+
+def test_issue_object_prices_counts_against_the_measured_ceilings():
+    """roofline.issue: committed instruction counts (profiles/insts.json) over the launch's CU cycles, per pipe."""
+    r = bench.roofline(2978822689, 2.93, 3011897166, "yaz0:10000:256")
+    iss = r["issue"]
+    cyc = 2.93e-3 * 2.4e9 * 256
+    c = json.load(open(os.path.join(ROOT, "profiles", "insts.json")))["yaz0:10000:256"]
+    assert abs(iss["salu"] - c["salu"] / cyc / 0.95) < 2e-3
+    assert abs(iss["valu"][0] - c["valu"] / cyc / 1.75) < 2e-3 and abs(iss["valu"][1] - c["valu"] / cyc / 0.95) < 2e-3
+    assert abs(iss["lds"] - c["lds"] / cyc * 4.3) < 2e-3
+    assert r["issue_frac"] == iss["issue_frac"] and 0.3 < r["issue_frac"] < 1.2
+    assert iss["counts_from"].startswith("profiles/r05_")
+    assert "issue" not in bench.roofline(1e9, 1.0, None, "no_such_workload:1:1") and "issue" not in bench.roofline(1e9, 1.0)
