@@ -74,6 +74,12 @@ struct InCache {
         store_chunk(0, c0); store_chunk(1, c1);
         wave_sync();
     }
+    // init + seek(p) without the loads of offset 0 (a wavefront that takes a stream over in the middle: alz_decode_fastq_kernel)
+    __device__ __forceinline__ void init_at(const u8* src, u32 len, u8* lds_, int lane_, u32 chunk, u32 p) {
+        u32 ishift = (u32)(reinterpret_cast<uintptr_t>(src) & 15u);
+        gbase = src - ishift; lds = lds_; lo = ishift; hi = ishift + len; lane = lane_; cb = 0; ch = chunk;
+        seek(p);
+    }
     // reposition so that lds[0] is the chunk containing input offset p (used by seeks)
     __device__ __forceinline__ void seek(u32 p) {
         u32 a = p + lo;

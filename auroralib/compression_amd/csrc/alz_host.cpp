@@ -151,6 +151,14 @@ struct alz_plan {
     hipEvent_t big_evt = nullptr; bool big_evt_set = false;
     // the stream of the last execute + an event behind it: alz_plan_results orders its copy behind the caller's own stream too
     hipEvent_t done_evt = nullptr; bool done_evt_set = false;
+    // The flag-byte family as a work queue of (stream, chunk) items (alz_decode_fastq_kernel): for a format whose streams are more than the GPU holds
+    // wavefronts, so that the launch does not end in a partly filled round.  One allocation: [64 control words | a 128-byte line per slot's flag | items | slots].
+    struct chunk_plan { uint32_t n_items = 0, n_slots = 0, lw = 0; void* d_mem = nullptr; uint32_t* d_ctl = nullptr; uint32_t* d_flags = nullptr;
+                        alz_chunk_item* d_items = nullptr; uint8_t* d_slots = nullptr; size_t zero_bytes = 0; };
+    chunk_plan chunk[ALZ_FMT_COUNT];
+    bool no_chunks = false;                  // a bounded spin of the queue kernel ran out once: this plan stays with the one-wavefront-per-stream kernels
+    bool chunk_ran = false;                  // the last execute used the queue for some format: alz_plan_results looks at the timeout words
+    const void* last_src = nullptr; void* last_dst = nullptr;
 };
 
 static alz_lz_properties effective_lz(const alz_lz_properties* p) {
@@ -171,7 +179,7 @@ int alz_ctx_big_stream(alz_ctx* c, uint32_t min_bytes, uint64_t* launches_out) {
     return ALZ_OK;
 }
 int alz_ctx_set_kernel_variant(alz_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 2) return fail(ALZ_E_INVALID, "alz_ctx_set_kernel_variant: bad argument");
+    if (!c || variant < 0 || variant > 3) return fail(ALZ_E_INVALID, "alz_ctx_set_kernel_variant: bad argument");
     c->variant = variant;
     return ALZ_OK;
 }
@@ -182,6 +190,12 @@ int alz_ctx_set_exact_kernels(alz_ctx* c, int on) {
 }
 /* not in the public header: resident waves per CU of the production kernel of `format` (tuning aid) */
 int alz_debug_occupancy(int format) { return alz_kernel_occupancy(format); }
+/* not in the public header: output bytes per chunk of the work-queue kernels */
+int alz_debug_chunk_bytes(void) { return (int)ALZ_CHUNK_OUT; }
+/* not in the public header: the (stream, chunk) items of a plan's work queues (0: the plan decodes with one wavefront per stream) */
+/* not in the public header: the control words of a format's work queue (0: queue head, 32: timeout flag) and, behind them from word 64 on, the flag of every hand-over slot (one per 32 words) */
+int alz_debug_plan_queue_ctl(alz_plan* p, int fmt, uint32_t* out, uint32_t nwords) { if (!p || fmt < 0 || fmt >= ALZ_FMT_COUNT || !p->chunk[fmt].d_ctl) return -1; const uint32_t have = 64u + p->chunk[fmt].n_slots * ALZ_CHUNK_FLAG_STRIDE; if (nwords > have) nwords = have; return hipMemcpy(out, p->chunk[fmt].d_ctl, 4 * (size_t)nwords, hipMemcpyDeviceToHost) == hipSuccess ? (int)nwords : -1; }
+int alz_debug_plan_queue_items(alz_plan* p) { int n = 0; if (p) for (int f = 0; f < ALZ_FMT_COUNT; f++) n += (int)p->chunk[f].n_items; return n; }
 const char* alz_last_error(void) { return g_err; }
 
 int alz_device_count(void) {
@@ -292,6 +306,7 @@ void alz_plan_destroy(alz_ctx* c, alz_plan* p) {
     if (p->d_big && !p->big_borrowed) (void)hipFree(p->d_big);
     if (p->big_evt) (void)hipEventDestroy(p->big_evt);
     if (p->done_evt) (void)hipEventDestroy(p->done_evt);
+    for (int f = 0; f < ALZ_FMT_COUNT; f++) if (p->chunk[f].d_mem) (void)hipFree(p->chunk[f].d_mem);
     delete p;
 }
 
@@ -378,6 +393,41 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
             for (uint32_t k = 0; k < n; k++) p->big_pos[ix[k]] = k;      // where stream i sits in the (per-format, cost-ordered) index list
         }
     }
+    // ---- the work queue of chunks (device-resident plans): a format whose streams are more than the GPU holds of its wavefronts, and
+    // long enough to be cut.  Failing to get the memory only means the one-wavefront-per-stream launch.
+    const bool force_queue = c->variant == 3;     // (plans created while the context is in variant 3 use the queue whatever the number of streams: the parity tests)
+    if (!scratch && !c->exact && (force_queue || (!p->big && c->variant == 0))) {
+        hipDeviceProp_t pr;
+        const bool have_pr = hipGetDeviceProperties(&pr, c->device) == hipSuccess;
+        for (int f = 0; f < ALZ_FMT_COUNT && have_pr; f++) {
+            uint32_t lw = 0;
+            if (!cnt[f] || !alz_chunk_format(f, &lz, &lw)) continue;
+            const int occ = alz_kernel_occupancy(f);
+            if (!force_queue && (occ < 1 || (uint64_t)n <= (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;    // (everything is resident at once: no partly filled round to avoid)
+            // items in chunk-major order over the format's cost-ordered list; a stream's slots are consecutive
+            std::vector<uint32_t> nch(cnt[f]), base(cnt[f]);
+            uint32_t slots = 0, maxch = 0; uint64_t items64 = 0;
+            for (uint32_t k = 0; k < cnt[f]; k++) {
+                const alz_stream& st = streams[index[p->fmt_off[f] + k]];
+                const uint32_t bound = st.decom_len ? (st.decom_len < st.dst_cap ? st.decom_len : st.dst_cap) : st.dst_cap;
+                uint32_t m = (bound + ALZ_CHUNK_OUT - 1u) / ALZ_CHUNK_OUT; if (m == 0) m = 1;
+                nch[k] = m; base[k] = slots; slots += m; items64 += m; if (m > maxch) maxch = m;
+            }
+            if (maxch < 2 || items64 > 0x3FFFFFFFull) continue;
+            std::vector<alz_chunk_item> items; items.reserve((size_t)items64);
+            for (uint32_t ch = 0; ch < maxch; ch++)
+                for (uint32_t k = 0; k < cnt[f]; k++)
+                    if (ch < nch[k]) items.push_back(alz_chunk_item{index[p->fmt_off[f] + k], ch, base[k] + ch, ch + 1u == nch[k] ? 1u : 0u});
+            alz_plan::chunk_plan& cp = p->chunk[f];
+            const size_t zero_bytes = (256 + (size_t)slots * 4 * ALZ_CHUNK_FLAG_STRIDE + 255) & ~(size_t)255, items_bytes = (items.size() * sizeof(alz_chunk_item) + 255) & ~(size_t)255;
+            const size_t slot_bytes = (size_t)slots * (32 + lw);
+            if (hipMalloc(&cp.d_mem, zero_bytes + items_bytes + slot_bytes + 256) != hipSuccess) { cp.d_mem = nullptr; (void)hipGetLastError(); continue; }
+            cp.d_ctl = (uint32_t*)cp.d_mem; cp.d_flags = cp.d_ctl + 64; cp.zero_bytes = zero_bytes;
+            cp.d_items = (alz_chunk_item*)((uint8_t*)cp.d_mem + zero_bytes); cp.d_slots = (uint8_t*)cp.d_mem + zero_bytes + items_bytes;
+            if (hipMemcpy(cp.d_items, items.data(), items.size() * sizeof(alz_chunk_item), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(cp.d_mem); cp = alz_plan::chunk_plan(); (void)hipGetLastError(); continue; }
+            cp.n_items = (uint32_t)items.size(); cp.n_slots = slots; cp.lw = lw;
+        }
+    }
     *out = p;
     return ALZ_OK;
 }
@@ -428,10 +478,22 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     }
     int nfmt = 0;
     for (int f = 0; f < ALZ_FMT_COUNT; f++) nfmt += p->fmt_cnt[f] ? 1 : 0;
+    p->chunk_ran = false; p->last_src = d_src_base; p->last_dst = d_dst_base;
+    // a format's launch: the work queue of chunks where the plan has one (and the context has not been switched to other kernels since), else one wavefront per stream
+    auto launch_format = [&](int f, hipStream_t on) -> hipError_t {
+        alz_plan::chunk_plan& cp = p->chunk[f];
+        if (cp.n_items && !c->exact && (c->variant == 0 || c->variant == 3) && !p->no_chunks) {
+            hipError_t e = hipMemsetAsync(cp.d_ctl, 0, cp.zero_bytes, on);               // queue head, timeout word, every boundary's flag: before EVERY launch
+            if (e == hipSuccess) e = alz_launch_decode_chunked(f, on, d_src_base, d_dst_base, p->d_streams, cp.d_items, cp.n_items, p->d_results, &p->lz, cp.d_ctl, cp.d_flags, cp.d_slots);
+            if (e == hipSuccess) p->chunk_ran = true;
+            return e;
+        }
+        return alz_launch_decode(f, on, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
+    };
     if (nfmt <= 1) {
         for (int f = 0; f < ALZ_FMT_COUNT; f++) {
             if (!p->fmt_cnt[f]) continue;
-            hipError_t e = alz_launch_decode(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
+            hipError_t e = launch_format(f, s);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
         return plan_mark_done(p, s, s != c->stream);
@@ -465,7 +527,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
             if (w != hipSuccess) { rc = fail(ALZ_E_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(w)); break; }
             used[lane] = true;
         }
-        hipError_t e = alz_launch_decode(f, a, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
+        hipError_t e = launch_format(f, a);
         if (e != hipSuccess) rc = fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
     }
     for (int i = 1; i < 4; i++) if (used[i]) {
@@ -495,6 +557,21 @@ int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
     if (!c || !p || (p->n && !results)) return fail(ALZ_E_INVALID, "alz_plan_results: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     if (p->done_evt_set) HIP_TRY(hipStreamWaitEvent(c->stream, p->done_evt, 0));    // (the last execute ran on a stream of the caller's)
+    if (p->chunk_ran) {
+        // the work queue's bounded spins: if one ran out (never seen), the launch is repeated with one wavefront per stream -- the results then are that launch's
+        uint32_t tmo = 0;
+        for (int f = 0; f < ALZ_FMT_COUNT; f++) {
+            if (!p->chunk[f].n_items) continue;
+            uint32_t t = 0;
+            HIP_TRY(hipMemcpyAsync(&t, p->chunk[f].d_ctl + 32, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            tmo |= t;
+        }
+        if (tmo) {
+            p->no_chunks = true;
+            if (int rc = alz_plan_execute(c, p, p->last_src, p->last_dst, nullptr)) return rc;
+        }
+    }
     if (p->n) HIP_TRY(hipMemcpyAsync(results, p->d_results, p->n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ALZ_OK;

@@ -10,6 +10,18 @@
 hipError_t alz_launch_decode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams,
                              const uint32_t* d_index, uint32_t count, alz_result* d_results, const alz_lz_properties* lz, bool exact, uint32_t batch_total = 0, int variant = 0)   /* batch_total: streams of ALL formats of the batch this launch belongs to (0 = count); variant: alz_ctx_set_kernel_variant */;
 int alz_kernel_occupancy(int fmt);
+
+// ---- the flag-byte family as a work queue of (stream, chunk) items (alz_decode_fastq_kernel, alz_kernels.hip)
+struct alz_chunk_item { uint32_t sid, chunk, slot, last; };   // stream, its chunk, the hand-over slot this chunk WRITES (it reads slot - 1), 1 = the stream's last chunk
+#define ALZ_CHUNK_FLAG_STRIDE 32u                             /* words between two flags (= ALZ_CHUNK_FLAG_WORDS of the kernel) */
+#ifndef ALZ_CHUNK_OUT
+#define ALZ_CHUNK_OUT 32768u                                  /* output bytes per chunk (10 000 x 256 KiB as Yaz0, ms per launch: 16 KiB 2.62, 24 KiB 2.57, 32 KiB 2.58, 64 KiB 2.62, 128 KiB 2.76; one wavefront per stream 2.93) */
+#endif
+bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out);   // does the format have the work-queue kernel, and with which LDS window
+// d_ctl: 64 words (0: queue head, 32: timeout flag -- a 128-byte line each), zeroed by the caller before every launch, like d_flags (ALZ_CHUNK_FLAG_STRIDE words per slot: a line of its own);
+// d_slots: n_slots x (32 + lw) bytes
+hipError_t alz_launch_decode_chunked(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const alz_chunk_item* d_items,
+                                     uint32_t n_items, alz_result* d_results, const alz_lz_properties* lz, uint32_t* d_ctl, uint32_t* d_flags, uint8_t* d_slots);
 // the same launch gated by a device word: the kernels return at once while *d_gate == 0 (alz_big.hip: the production -- lane-parallel -- decode, with the reference's error semantics, behind the
 // whole-GPU path of ONE big stream, needed only when that path declined the stream).  The formats of that path only.
 hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,

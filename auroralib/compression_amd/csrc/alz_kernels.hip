@@ -258,6 +258,186 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same decode as a WORK QUEUE of chunks (round 5).  With one wavefront per stream a batch of more streams than the GPU holds
+// wavefronts ends in a partly filled round: 10 000 streams on 6 400 places = one full round and 3 600 streams at 14 waves per CU, where a
+// wave is bound by its own issue rate -- 833 GiB/s for one batch against 1 004 with a second batch filling the tail.  Here a stream is
+// decoded in CHUNKS of ALZ_CHUNK_BYTES of output and the launch is a queue of (stream, chunk) items in chunk-major order, one workgroup
+// each, dispatched in that order: every place stays busy until the queue is empty, and what is left at the end is one chunk's
+// latency, not one stream's.  A chunk ends at the first iteration boundary at or behind its limit (the lane-parallel loop consumes whole
+// flag groups: the state between two iterations is the input offset -- three of them for Yay0 / MIO0 -- and the output position); the wave
+// that decoded it flushes its output, hands the LDS window and that state to whoever pops the stream's next chunk -- through a slot of its own
+// in global memory, written with write-through (sc1) stores, drained, then ONE flag (MI355X_MICROARCH.md, inter-workgroup visibility; the
+// slot is written once per launch, so no L2 can hold an older copy of it) -- and ends.  The workgroup of the next chunk
+// polls that flag (relaxed, one lane, bounded), acquires once, loads the window.  Workgroups start in index order, so the chunk a wave waits
+// for is in the hands of a wave that has started and waits, if at all, for a still earlier item.  The stream's last chunk runs the exact parser over the tail and writes the result; a stream that ends early (an error, a
+// terminator, E5) marks its remaining boundaries "ended" as their items come up.  A bounded spin that runs out sets `tmo`; the host then
+// repeats the launch with the one-wavefront-per-stream kernel (alz_plan_results).
+#define ALZ_CHUNK_BYTES ALZ_CHUNK_OUT     /* (alz_internal.h: the host cuts the streams by the same number) */
+#define ALZ_CHUNK_SPINS (1u << 20)    /* x (sleep + one load): about a second */
+#define ALZ_CHUNK_FLAG_WORDS 32u       /* a flag has a 128-byte line of its own: pollers of one boundary never touch the line another boundary's flag, the queue head or the timeout word lives in */
+typedef __attribute__((address_space(1))) u32 alz_gu32;
+typedef __attribute__((address_space(1))) unsigned long long alz_gu64;
+__device__ __forceinline__ void chunk_store32(void* p, u32 v) { __hip_atomic_store(reinterpret_cast<u32*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 chunk_load32(const void* p) { return __hip_atomic_load(reinterpret_cast<const u32*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One item of the queue: set up from the hand-over slot (or from nothing), decode to the chunk's limit, flush, hand over or finish.
+// Returns the flag the item leaves in its slot: 1 handed over (window + cursors stored write-through into `out_slot`, NOT yet drained),
+// 2 the stream ended here (result written), 0 the stream's last chunk (result written).
+template <int FMT>
+__device__ __forceinline__ u32 fastq_item(const u8* src_base, u8* dst_base, const alz_stream* streams, alz_result* results, const alz_lz_properties& lz,
+                                          u8* lds, u32 lw, u32 sid, u32 c, u32 last, const u8* in_slot, u8* out_slot, u32 p0, u32 p1, u32 p2, u32 start) {
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr int NC = THREE ? 3 : 1;
+    constexpr u32 CHUNK = THREE ? 256u : (u32)ALZ_FAST_CHUNK;
+    constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
+    constexpr u32 FSCR = THREE ? ALZ_BYTE_SCRATCH : 128u;
+    const int lane = lane_id();
+    u8* segmark = lds;
+    u8* inc_lds = lds + FSCR;
+    u8* const win = lds + FSCR + NC * CACHE;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    u8* dst = dst_base + st.dst_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap), size = uni(st.decom_len);
+    // ---- set up: window (zeros, or what the chunk before left), marks, input caches at the hand-over offsets
+    typedef OutWin<false> OWF;
+    OWF out;
+    if (c == 0u) out.init(dst, cap, win, lw, lane, 0u);
+    else {
+        out.dst = dst; out.cap = cap; out.win = win; out.lw_mask = lw - 1u; out.lane = lane;
+        out.fl = lw >= 4096u ? 1024u : (lw >> 2);
+        out.oshift = (u32)(reinterpret_cast<uintptr_t>(dst) & 15u);
+        out.produced = start; out.flushed = start; out.slack_dirty = false; out.mtag = 0;
+        for (u32 i = 16u * (u32)lane; i < lw; i += 1024u) *reinterpret_cast<uint4*>(win + i) = *reinterpret_cast<const uint4*>(in_slot + 32 + i);
+        wave_sync();
+    }
+    segmark[lane] = 0; segmark[64 + lane] = 0;
+    InCache in; in.init_at(src, src_len, inc_lds, lane, CHUNK, c > 0u ? p0 : 0u);
+    DecState s; dec_state_init(s);
+    const u32 limit = last ? 0xFFFFFFFFu : (c + 1u) * ALZ_CHUNK_BYTES;     // (the last chunk runs to the end of the stream)
+    u32 used = 0; bool used_set = false;
+    bool fin = false, handoff = false;
+    if constexpr (!THREE) {
+        if (c > 0u) s.p = p0;
+        FastGeom gm; gm.length_bits = lz.length_bits; gm.min_length = lz.min_length; gm.windows_start = lz.windows_start;
+        gm.max_distance = lz.max_distance; gm.W = 1u << lz.window_bits;
+        bool to_serial = false;
+        while (!fin && !to_serial && out.produced < size && s.p < src_len && out.produced < limit) fin = fast_iter_interleaved<FMT>(in, out, s, size, src_len, to_serial, segmark, lane, gm);
+        handoff = !fin && !to_serial && out.produced < size && s.p < src_len;       // (then the loop stopped at the chunk's limit)
+        if (!handoff && !fin) {
+            typedef DirectSink<OWF> SK;
+            SK sk(out, s);
+            if constexpr (FMT == ALZ_FMT_LZSS) dec_lzss_serial(in, sk, s, src_len, size, lz.length_bits, lz.min_length, lz.windows_start, lz.max_distance, gm.W);
+            else if constexpr (FMT == ALZ_FMT_LZ10) dec_lz1x_serial<SK, false>(in, sk, s, src_len, size);
+            else if constexpr (FMT == ALZ_FMT_LZ11) dec_lz1x_serial<SK, true>(in, sk, s, src_len, size);
+            else if constexpr (FMT == ALZ_FMT_LZ40) dec_lz40_serial(in, sk, s, src_len, size);
+            else if constexpr (FMT == ALZ_FMT_CLZ0) dec_clz0_serial(in, sk, s, src_len, size);
+            else dec_yaz0_serial(in, sk, s, src_len, size);
+        }
+        p0 = s.p;
+    } else {
+        const u32 a0 = uni(st.aux0), a1 = uni(st.aux1);
+        if (FMT == ALZ_FMT_YAY0 && (a0 > src_len || a1 > src_len)) s.eof = true;   // Slice() throws  Yay0.cs:102-103
+        else {
+            InCache cin, uin;
+            u32 fp = 0, cp = a0, up = a1;
+            if (c > 0u) { fp = p0; cp = p1; up = p2; }
+            cin.init_at(src, src_len, inc_lds + CACHE, lane, CHUNK, cp < src_len ? cp : 0);
+            uin.init_at(src, src_len, inc_lds + 2 * CACHE, lane, CHUNK, up < src_len ? up : 0);
+            while (!fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len && out.produced < limit)
+                fin = fast_iter_3cursor<FMT == ALZ_FMT_MIO0>(in, cin, uin, out, s, size, segmark, lane, fp, cp, up);
+            handoff = !fin && out.produced < size && fp + 8u <= src_len && (u64)cp + 128u <= src_len && (u64)up + 64u <= src_len;
+            used = cp > up ? cp : up;
+            if (!handoff && !fin) { typedef DirectSink<OWF> SK; SK sk(out, s); used = dec_3cursor_serial<SK, FMT == ALZ_FMT_MIO0>(in, cin, uin, sk, s, src_len, size, fp, cp, up); }
+            used_set = true;
+            p0 = fp; p1 = cp; p2 = up;
+        }
+    }
+    out.finish();
+    if (handoff) {
+        // ---- hand the stream on: window + cursors into this chunk's slot (write-through; the caller drains and signals)
+        wave_sync();
+        for (u32 i = 16u * (u32)lane; i < lw; i += 1024u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(win + i);
+            __hip_atomic_store(reinterpret_cast<u64*>(out_slot + 32 + i), ((u64)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<u64*>(out_slot + 40 + i), ((u64)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) { chunk_store32(out_slot, p0); chunk_store32(out_slot + 4, p1); chunk_store32(out_slot + 8, p2); chunk_store32(out_slot + 12, out.produced); }
+        return 1u;
+    }
+    const int status = resolve_status(s, true, out.produced, size, cap);
+    write_result(&results[sid], lane, out, used_set ? used : s.p, status, src_len);
+    return last ? 0u : 2u;                                    // the stream ended here: its later chunks have nothing to do
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
+                                                             const alz_stream* __restrict__ streams, const alz_chunk_item* __restrict__ items, u32 n_items,
+                                                             alz_result* __restrict__ results, alz_lz_properties lz, u32 lw,
+                                                             u32* __restrict__ qhead, u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo) {
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr int NC = THREE ? 3 : 1;
+    constexpr u32 LWMAX = 4096u;
+    constexpr u32 CHUNK = THREE ? 256u : (u32)ALZ_FAST_CHUNK;
+    constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
+    constexpr u32 FSCR = THREE ? ALZ_BYTE_SCRATCH : 128u;
+    __shared__ __attribute__((aligned(16))) u8 lds[FSCR + NC * CACHE + LWMAX];
+    const int lane = (int)(threadIdx.x & 63u);
+    const u32 slot_bytes = 32u + lw;                         // a boundary's slot: 8 state words, then the window
+    // ONE item per workgroup, in dispatch order (item = blockIdx.x): workgroups start in index order, so the chunk an item waits for belongs to a
+    // workgroup that has started (and waits, if at all, for a still earlier one).  HIP does not promise that order: it is only what makes the wait short --
+    // a bounded spin that runs out makes the host repeat the launch with one wavefront per stream.  (A persistent wavefront popping items from a
+    // counter in a loop was the first form; its loop came out of the compiler as a divergent one -- exec-masked, a readfirstlane per trip -- and the
+    // decode ran with lanes switched off and never ended: docs/EXPERIMENTS.md 10.7.)
+    const u32 item = blockIdx.x;
+    (void)qhead;
+    if (item >= n_items) return;
+    const alz_chunk_item it = items[item];
+    const u32 sid = uni(it.sid), c = uni(it.chunk), oslot = uni(it.slot), last = uni(it.last);
+    u32 p0 = 0, p1 = 0, p2 = 0, start = 0;
+    u32 flagv = 0;                                        // what this item leaves in its slot's flag: 1 handed over, 2 the stream has ended, 3 a wait ran out
+    bool run = true;
+    const u8* in_slot = slots + (size_t)(oslot ? oslot - 1u : 0u) * slot_bytes;
+    u8* out_slot = slots + (size_t)oslot * slot_bytes;
+    if (c > 0u) {
+        // ---- the chunk before this one: wait for its flag (ONE lane polls ONE word, relaxed), acquire once
+        u32 f = 0;
+        if (lane == 0) {
+            u32 spins = 0;
+            while ((f = chunk_load32(flags + (size_t)(oslot - 1u) * ALZ_CHUNK_FLAG_WORDS)) == 0u) { if (++spins > ALZ_CHUNK_SPINS) break; __builtin_amdgcn_s_sleep(16); }
+        }
+        f = uni(f);
+        if (f == 0u || f == 3u) {                         // never seen: the host repeats the launch the other way; whoever waits for THIS chunk does not wait long
+            if (lane == 0) atomicOr(tmo, 1u);
+            flagv = 3u; run = false;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (f == 2u) { flagv = 2u; run = false; }     // the stream ended in an earlier chunk
+            else {
+                p0 = uni(chunk_load32(in_slot)); p1 = uni(chunk_load32(in_slot + 4)); p2 = uni(chunk_load32(in_slot + 8)); start = uni(chunk_load32(in_slot + 12));
+                if (!last && start >= (c + 1u) * ALZ_CHUNK_BYTES) {
+                    // one iteration of an earlier chunk went past this whole chunk (a long match): pass the state on as it is
+                    for (u32 i = 16u * (u32)lane; i < lw; i += 1024u) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(in_slot + 32 + i);
+                        __hip_atomic_store(reinterpret_cast<u64*>(out_slot + 32 + i), ((u64)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(reinterpret_cast<u64*>(out_slot + 40 + i), ((u64)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (lane == 0) { chunk_store32(out_slot, p0); chunk_store32(out_slot + 4, p1); chunk_store32(out_slot + 8, p2); chunk_store32(out_slot + 12, start); }
+                    flagv = 1u; run = false;
+                }
+            }
+        }
+    }
+    if (run) flagv = fastq_item<FMT>(src_base, dst_base, streams, results, lz, lds, lw, sid, c, last, in_slot, out_slot, p0, p1, p2, start);
+    // ---- the item's ONE flag: every storing lane drains its write-through stores first, then one lane signals
+    if (flagv) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) chunk_store32(flags + (size_t)oslot * ALZ_CHUNK_FLAG_WORDS, flagv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Token-queue kernel (PRS, LZ4, LZO, Snappy, FastLZ, CNX2): lane-assisted / scalar parse into a 64-token queue, lane-parallel
 // execution (pipelined_rounds for the bulk, QueueSink behind the exact parsers).
 template <int FMT>
@@ -977,6 +1157,43 @@ hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src,
         if (W <= 65536 && lz.max_distance == W) return launch_fast<ALZ_FMT_LZSS, 4096, true>(stream, s, d, streams, index, count, results, lz, W, 1, gate);
         return hipErrorInvalidValue;
     }
+    default: return hipErrorInvalidValue;
+    }
+}
+
+bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out) {
+    u32 lw = 4096;
+    switch (fmt) {
+    case ALZ_FMT_LZSS: { const u32 W = 1u << lz->window_bits; if (W > 4096u || W < 256u || lz->max_distance != W) return false; lw = W; break; }
+    case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_CLZ0: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: break;
+    default: return false;
+    }
+    if (lw_out) *lw_out = lw;
+    return true;
+}
+template <int FMT>
+static hipError_t launch_fastq(hipStream_t stream, const u8* s, u8* d, const alz_stream* streams, const alz_chunk_item* items, u32 n_items, alz_result* results,
+                               const alz_lz_properties& lz, u32 lw, u32* ctl, u32* flags, u8* slots) {
+    const u32 grid = n_items;                              // one workgroup per (stream, chunk) item, in queue order
+    hipLaunchKernelGGL((alz_decode_fastq_kernel<FMT>), dim3(grid), dim3(64), 0, stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots, ctl + 32);
+    return hipGetLastError();
+}
+hipError_t alz_launch_decode_chunked(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const alz_chunk_item* items,
+                                     u32 n_items, alz_result* results, const alz_lz_properties* lzp, u32* ctl, u32* flags, u8* slots) {
+    if (n_items == 0) return hipSuccess;
+    u32 lw = 0;
+    if (!alz_chunk_format(fmt, lzp, &lw)) return hipErrorInvalidValue;
+    const u8* s = (const u8*)src; u8* d = (u8*)dst;
+    const alz_lz_properties lz = *lzp;
+    switch (fmt) {
+    case ALZ_FMT_LZSS: return launch_fastq<ALZ_FMT_LZSS>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_LZ10: return launch_fastq<ALZ_FMT_LZ10>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_LZ11: return launch_fastq<ALZ_FMT_LZ11>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_LZ40: return launch_fastq<ALZ_FMT_LZ40>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_CLZ0: return launch_fastq<ALZ_FMT_CLZ0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_YAZ0: return launch_fastq<ALZ_FMT_YAZ0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_YAY0: return launch_fastq<ALZ_FMT_YAY0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_MIO0: return launch_fastq<ALZ_FMT_MIO0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
     default: return hipErrorInvalidValue;
     }
 }

@@ -41,7 +41,7 @@ def _first(mask):
     return int(np.flatnonzero(mask)[0])
 
 
-def canary_decode(streams, src, dst_bytes, lz=None, what="", variants=(0, 1, 2), src_exact=False):
+def canary_decode(streams, src, dst_bytes, lz=None, what="", variants=(0, 1, 2), src_exact=False, queue=False):
     """Runs the batch on every kernel family / wave shape into a canary-filled device buffer and checks the whole buffer."""
     n = len(streams)
     o_dst, o_res = O.decode_batch(streams, src, dst_bytes, lz=lz, nthreads=8)
@@ -58,10 +58,15 @@ def canary_decode(streams, src, dst_bytes, lz=None, what="", variants=(0, 1, 2),
     d_dst = c.malloc(total)
     try:
         c.h2d(d_src, src)
-        plan = Plan(c, streams, lz)
+        if queue:                                        # (a plan CREATED in variant 3 decodes through the work queue of chunks, whatever its size)
+            c.set_kernel_variant(3)
         try:
-            for serial in (1, 0):
-                for variant in (variants if not serial else (0,)):
+            plan = Plan(c, streams, lz)
+        finally:
+            c.set_kernel_variant(0)
+        try:
+            for serial in ((0,) if queue else (1, 0)):
+                for variant in ((3,) if queue else (variants if not serial else (0,))):
                     tag = "%s [%s kernels, variant %d]" % (what, "serial" if serial else "fast", variant)
                     c.set_exact_kernels(serial)
                     c.set_kernel_variant(variant)
