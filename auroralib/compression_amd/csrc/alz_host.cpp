@@ -403,7 +403,11 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
             uint32_t lw = 0;
             if (!cnt[f] || !alz_chunk_format(f, &lz, &lw)) continue;
             const int occ = alz_kernel_occupancy(f);
-            if (!force_queue && (occ < 1 || (uint64_t)n <= (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;    // (everything is resident at once: no partly filled round to avoid)
+            // (from 0.6 of the GPU's wavefront places on: 10 000 x 256 KiB as Yaz0, ms per launch one wavefront per stream / queue -- 3 000 streams 1.12 (two wavefronts each) / 1.33,
+            // 4 000 1.44 / 1.40, 5 000 1.60 / 1.49, 6 400 2.43 / 1.69, 8 000 2.09 (queue); below that everything is resident at once and a stream's own latency decides)
+            // -- counted per FORMAT: in a mixed batch the formats' kernels run side by side, and queues whose items wait for each other take the places the others need (the cfg4 shard, 5 000 mixed
+            // streams: 2.54 ms with one wavefront per stream, 3.20 with its three flag-byte formats as queues)
+            if (!force_queue && (occ < 1 || 10ull * cnt[f] <= 6ull * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
             // items in chunk-major order over the format's cost-ordered list; a stream's slots are consecutive
             std::vector<uint32_t> nch(cnt[f]), base(cnt[f]);
             uint32_t slots = 0, maxch = 0; uint64_t items64 = 0;

@@ -100,7 +100,7 @@ def test_queue_is_what_a_big_plan_runs_by_itself_and_small_plans_do_not():
     c = ctx()
     c.lib.alz_debug_plan_queue_items.argtypes = [C.c_void_p]
     ch = c.lib.alz_debug_chunk_bytes()
-    for n, size, queued in ((9000, 140000, True), (500, 140000, False), (9000, ch - 5, False)):
+    for n, size, queued in ((9000, 140000, True), (4500, 140000, True), (500, 140000, False), (9000, ch - 5, False)):
         b = synth.make_batch(A.FMT_YAZ0, n, size, synth.seed_for(98))
         o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes, nthreads=8)
         d_src, d_dst = c.malloc(b.src.nbytes), c.malloc(b.dst_bytes)
