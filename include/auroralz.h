@@ -208,7 +208,9 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
  * plans: the batch as a WORK QUEUE of 64 KiB chunks popped by as many persistent wavefronts as the GPU holds -- taken by itself (variant 0) when a
  * plan has more streams of such a format than 0.6 of what the GPU holds wavefronts, so that the launch does not end in a partly filled round; 3: plans created in this
  * mode use it whatever their size (the parity tests).  Same results: a chunk ends between two iterations of the lane-parallel loop and hands
- * the LDS window and the cursors on. */
+ * the LDS window and the cursors on.  A wavefront waits for the chunk before its own with a BOUNDED spin; if one ever ran out (workgroups start in
+ * index order on this hardware, which is what keeps the waits short, but HIP does not promise it) alz_plan_results repeats the launch with one wavefront
+ * per stream before it returns: a caller of the device-resident path takes the batch as decoded once alz_plan_results has returned. */
 int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
 /* ONE big stream: a batch of one -- or of a few, as long as one after the other on the whole GPU beats side by side on wavefronts of their
  * own -- LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4-block / raw-Snappy streams (all eleven
