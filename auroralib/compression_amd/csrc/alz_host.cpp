@@ -402,19 +402,23 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
         for (int f = 0; f < ALZ_FMT_COUNT && have_pr; f++) {
             uint32_t lw = 0;
             if (!cnt[f] || !alz_chunk_format(f, &lz, &lw)) continue;
-            const int occ = alz_kernel_occupancy(f);
+            const int occ = alz_chunk_places_per_cu(f);
+            const uint32_t chb = alz_chunk_bytes(f);
             // (from 0.6 of the GPU's wavefront places on: 10 000 x 256 KiB as Yaz0, ms per launch one wavefront per stream / queue -- 3 000 streams 1.12 (two wavefronts each) / 1.33,
             // 4 000 1.44 / 1.40, 5 000 1.60 / 1.49, 6 400 2.43 / 1.69, 8 000 2.09 (queue); below that everything is resident at once and a stream's own latency decides)
             // -- counted per FORMAT: in a mixed batch the formats' kernels run side by side, and queues whose items wait for each other take the places the others need (the cfg4 shard, 5 000 mixed
             // streams: 2.54 ms with one wavefront per stream, 3.20 with its three flag-byte formats as queues)
-            if (!force_queue && (occ < 1 || 10ull * cnt[f] <= 6ull * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
+            // PRS (two wavefronts per stream, bound by the scalar pipe: a stream in a half-empty GPU is fast anyway) only above what the GPU holds: 2 000 / 3 000 / 4 000 / 6 000 / 10 000 streams
+            // 1.39 / 1.69 / 2.72 / 3.43 / 5.50 ms with a workgroup per stream, 1.59 / 1.80 / 2.34 / 3.32 / 5.36 as a queue (3 072 places)
+            const uint64_t tenths = (f == ALZ_FMT_PRS_BE || f == ALZ_FMT_PRS_LE) ? 10ull : 6ull;
+            if (!force_queue && (occ < 1 || 10ull * cnt[f] <= tenths * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
             // items in chunk-major order over the format's cost-ordered list; a stream's slots are consecutive
             std::vector<uint32_t> nch(cnt[f]), base(cnt[f]);
             uint32_t slots = 0, maxch = 0; uint64_t items64 = 0;
             for (uint32_t k = 0; k < cnt[f]; k++) {
                 const alz_stream& st = streams[index[p->fmt_off[f] + k]];
                 const uint32_t bound = st.decom_len ? (st.decom_len < st.dst_cap ? st.decom_len : st.dst_cap) : st.dst_cap;
-                uint32_t m = (bound + ALZ_CHUNK_OUT - 1u) / ALZ_CHUNK_OUT; if (m == 0) m = 1;
+                uint32_t m = (bound + chb - 1u) / chb; if (m == 0) m = 1;
                 nch[k] = m; base[k] = slots; slots += m; items64 += m; if (m > maxch) maxch = m;
             }
             if (maxch < 2 || items64 > 0x3FFFFFFFull) continue;

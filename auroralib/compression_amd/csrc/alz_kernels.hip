@@ -1042,6 +1042,152 @@ void alz_decode_queue2_kernel(const u8* __restrict__ src_base, u8* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (host)
+// PRS as a work queue of chunks (the two-wavefront kernel above, one (stream, chunk) item per workgroup; the hand-over of alz_decode_fastq_kernel
+// with an 8 KiB window and the parser's state -- input offset, flag register -- in the slot).  The PARSING wavefront decides where a chunk ends: the
+// round that takes the output to the chunk's limit carries a mark, the executing wavefront hands over behind it.  A round the lane parser declines
+// sends the executing wavefront on alone, to the end of the stream, as in the kernel above.
+template <int FMT>
+__global__ __launch_bounds__(128) void alz_decode_prs2q_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                               const alz_chunk_item* __restrict__ items, u32 n_items, alz_result* __restrict__ results,
+                                                               u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo) {
+    constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
+    constexpr u32 LW = 8192u, QCH = 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u, SCR = 128u;
+    constexpr u32 MB = 64u + 8u;                              // mailbox slot: 64 tokens + {nt | stop, total, position behind, flag register, terminator, chunk end}
+    constexpr u32 CHB = ALZ_CHUNK_OUT_PRS;
+    __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + 256 + QCACHE + 2u * MB * 4u + 32u];
+    const u32 item = blockIdx.x;
+    if (item >= n_items) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool walker = threadIdx.x < 64u;
+    const alz_chunk_item it = items[item];
+    const u32 sid = uni(it.sid), c = uni(it.chunk), oslot = uni(it.slot), last = uni(it.last);
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 src_len = uni(st.src_len), cap = uni(st.dst_cap);
+    u32* mbox = reinterpret_cast<u32*>(lds + SCR + 256 + QCACHE + LW + 256 + QCACHE);
+    u32* share = mbox + 2u * MB;                              // {go, p, fl, start}: what the chunk before left, from the executing wavefront to the parsing one
+    constexpr u32 slot_bytes = 32u + LW;
+    const u32 limit = last ? 0xFFFFFFFFu : (c + 1u) * CHB;
+    if (walker) {
+        __syncthreads();                                       // [S0] the state is in `share`
+        if (share[0] == 0u) return;
+        u32* stage = reinterpret_cast<u32*>(lds + SCR + 256 + QCACHE + LW);
+        u32 p = share[1], fl = share[2], produced = share[3];
+        InCache in; in.init_at(src, src_len, lds + SCR + 256 + QCACHE + LW + 256, lane, QCH, p);
+        for (u32 k = 0;; k++) {
+            u32 qt = 0, nt = 0, total = 0, adv = 0, fl2 = fl, term = 0;
+            bool ok = (u64)p + QAHEAD <= src_len;
+            if (ok) { in.ensure(p, QCH); ok = prs_parse_round<BIG>(in, p, fl, stage, lane, qt, nt, total, adv, fl2, term); }
+            if (ok && total > cap - produced) ok = false;         // the capacity rule (E5) stays with the exact parser
+            const bool cend = ok && !term && produced + total >= limit;   // this round takes the output to the chunk's limit: the stream is handed over behind it
+            u32* slot = mbox + (k & 1u) * MB;
+            slot[lane] = qt;
+            if (lane == 0) { slot[64] = ok ? nt : 0xFFFFFFFFu; slot[65] = total; slot[66] = ok ? p + adv : p; slot[67] = ok ? fl2 : fl; slot[68] = term; slot[69] = cend ? 1u : 0u; }
+            __syncthreads();                                       // round k is in the mailbox (and round k - 1 has been executed)
+            if (!ok || term || cend) return;
+            p += adv; fl = fl2; produced += total;
+        }
+    }
+    // ---- the executing wavefront: waits for the chunk before, owns the window, hands over
+    u8* dst = dst_base + st.dst_off;
+    u8* segmark = lds;
+    u32* stage = reinterpret_cast<u32*>(lds + SCR);
+    u8* inc_lds = lds + SCR + 256;
+    u8* const win = lds + SCR + 256 + QCACHE;
+    const u8* in_slot = slots + (size_t)(oslot ? oslot - 1u : 0u) * slot_bytes;
+    u8* out_slot = slots + (size_t)oslot * slot_bytes;
+    u32 flagv = 0; bool run = true;
+    u32 p0 = 0, fl = 1u, start = 0;
+    if (c > 0u) {
+        u32 f = 0;
+        if (lane == 0) {
+            u32 spins = 0;
+            while ((f = chunk_load32(flags + (size_t)(oslot - 1u) * ALZ_CHUNK_FLAG_WORDS)) == 0u) { if (++spins > ALZ_CHUNK_SPINS) break; __builtin_amdgcn_s_sleep(16); }
+        }
+        f = uni(f);
+        if (f == 0u || f == 3u) { if (lane == 0) atomicOr(tmo, 1u); flagv = 3u; run = false; }
+        else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (f == 2u) { flagv = 2u; run = false; }
+            else { p0 = uni(chunk_load32(in_slot)); fl = uni(chunk_load32(in_slot + 4)); start = uni(chunk_load32(in_slot + 12)); }
+        }
+    }
+    if (lane == 0) { share[0] = run ? 1u : 0u; share[1] = p0; share[2] = fl; share[3] = start; }
+    __syncthreads();                                           // [S0]
+    if (run) {
+        typedef OutWin<false> OW;
+        OW out;
+        if (c == 0u) out.init(dst, cap, win, LW, lane, 0u);
+        else {
+            out.dst = dst; out.cap = cap; out.win = win; out.lw_mask = LW - 1u; out.lane = lane; out.fl = 1024u;
+            out.oshift = (u32)(reinterpret_cast<uintptr_t>(dst) & 15u);
+            out.produced = start; out.flushed = start; out.slack_dirty = false; out.mtag = 0;
+            for (u32 i = 16u * (u32)lane; i < LW; i += 1024u) *reinterpret_cast<uint4*>(win + i) = *reinterpret_cast<const uint4*>(in_slot + 32 + i);
+            wave_sync();
+        }
+        segmark[lane] = 0; segmark[64 + lane] = 0;
+        DecState s; dec_state_init(s);
+        s.p = p0;
+        typedef EmitCfg<LW - 1u, false, false, false, false, true> CFG;
+        typedef QueueSink<OW, CFG> SK;
+        __builtin_amdgcn_s_setprio(ALZ_PRS_PRIO);
+        bool handoff = false;
+        for (u32 k = 0;; k++) {
+            __syncthreads();
+            const u32* slot = mbox + (k & 1u) * MB;
+            const u32 qt = slot[lane], nt = uni(slot[64]), p2 = uni(slot[66]);
+            fl = uni(slot[67]);
+            const u32 term = uni(slot[68]), cend = uni(slot[69]);
+            s.p = p2;
+            if (nt == 0xFFFFFFFFu) break;                              // the walker stopped in front of this round
+            const u32 len = qt >> 18, lo = qt & 0x1FFFFu;
+            const u32 desc = (qt & 0x20000u) ? ALZ_DESC_LIT(lo & 0xFFu) : lo;
+            u32 lastt;
+            (void)fast_emit<OW, CFG>(out, s, 0xFFFFFFFFu, lanes_below(nt), len, desc, 0u, segmark, inc_lds, lane, lastt, 8192u);
+            if (term) { s.done = true; break; }                        // PRS.cs:78-79: the zero word ends the stream
+            if (cend) { handoff = !s.ovf; break; }
+        }
+        if (handoff) {
+            out.finish();
+            wave_sync();
+            for (u32 i = 16u * (u32)lane; i < LW; i += 1024u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(win + i);
+                __hip_atomic_store(reinterpret_cast<u64*>(out_slot + 32 + i), ((u64)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<u64*>(out_slot + 40 + i), ((u64)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) { chunk_store32(out_slot, s.p); chunk_store32(out_slot + 4, fl); chunk_store32(out_slot + 8, 0u); chunk_store32(out_slot + 12, out.produced); }
+            flagv = 1u;
+        } else {
+            SK sk(out, s, segmark, inc_lds, lane, 8192u);
+            if (!s.done && !s.ovf) {
+                // alone from here, to the end of the stream: the loop of alz_decode_queue_kernel
+                InCache in; in.init_at(src, src_len, inc_lds, lane, QCH, s.p);
+                for (;;) {
+                    if (s.p + QAHEAD <= src_len && !s.done) {
+                        sk.ensure(in, s.p, QCH);
+                        if (sk.nt) { sk.flush(); if (s.ovf) break; }
+                        if (prs_lane_parse<SK, BIG>(in, sk, s, stage, lane, fl)) { if (s.ovf || s.done) break; continue; }
+                    }
+                    const bool tail = s.p + QAHEAD > src_len;
+                    prs_from_norm<BIG>(fl, s.bits, s.flag);
+                    dec_prs_serial<SK, BIG>(in, sk, s, src_len, tail ? 0xFFFFFFFFu : 1u);
+                    fl = prs_to_norm<BIG>(s.bits, s.flag);
+                    if (tail || s.eof || s.ovf || s.bad || s.done) break;
+                }
+            }
+            sk.flush();
+            out.finish();
+            write_result(&results[sid], lane, out, s.p, resolve_status(s, false, out.produced, 0u, cap), src_len, 0u);
+            if (!last) flagv = 2u;
+        }
+    }
+    if (flagv) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) chunk_store32(flags + (size_t)oslot * ALZ_CHUNK_FLAG_WORDS, flagv);
+    }
+}
+
 static thread_local u32 t_batch_total = 0;     // streams of the whole batch the current launch belongs to (alz_launch_decode)
 static thread_local int t_variant = 0;         // alz_ctx_set_kernel_variant: 0 automatic, 1 one wavefront per stream, 2 two where such a kernel exists
 
@@ -1161,11 +1307,18 @@ hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src,
     }
 }
 
+int alz_chunk_places_per_cu(int fmt) {
+    int n = 0;
+    if (fmt == ALZ_FMT_PRS_BE) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_prs2_kernel<ALZ_FMT_PRS_BE>, 128, 0) != hipSuccess) n = 0; return n; }
+    if (fmt == ALZ_FMT_PRS_LE) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>, 128, 0) != hipSuccess) n = 0; return n; }
+    return alz_kernel_occupancy(fmt);
+}
 bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out) {
     u32 lw = 4096;
     switch (fmt) {
     case ALZ_FMT_LZSS: { const u32 W = 1u << lz->window_bits; if (W > 4096u || W < 256u || lz->max_distance != W) return false; lw = W; break; }
     case ALZ_FMT_LZ10: case ALZ_FMT_LZ11: case ALZ_FMT_LZ40: case ALZ_FMT_CLZ0: case ALZ_FMT_YAZ0: case ALZ_FMT_YAY0: case ALZ_FMT_MIO0: break;
+    case ALZ_FMT_PRS_BE: case ALZ_FMT_PRS_LE: lw = 8192; break;
     default: return false;
     }
     if (lw_out) *lw_out = lw;
@@ -1194,6 +1347,8 @@ hipError_t alz_launch_decode_chunked(int fmt, hipStream_t stream, const void* sr
     case ALZ_FMT_YAZ0: return launch_fastq<ALZ_FMT_YAZ0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
     case ALZ_FMT_YAY0: return launch_fastq<ALZ_FMT_YAY0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
     case ALZ_FMT_MIO0: return launch_fastq<ALZ_FMT_MIO0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
+    case ALZ_FMT_PRS_BE: hipLaunchKernelGGL((alz_decode_prs2q_kernel<ALZ_FMT_PRS_BE>), dim3(n_items), dim3(128), 0, stream, s, d, streams, items, n_items, results, flags, slots, ctl + 32); return hipGetLastError();
+    case ALZ_FMT_PRS_LE: hipLaunchKernelGGL((alz_decode_prs2q_kernel<ALZ_FMT_PRS_LE>), dim3(n_items), dim3(128), 0, stream, s, d, streams, items, n_items, results, flags, slots, ctl + 32); return hipGetLastError();
     default: return hipErrorInvalidValue;
     }
 }

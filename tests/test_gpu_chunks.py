@@ -16,7 +16,7 @@ from gpu_common import ctx, pack_streams
 from test_gpu_canary import canary_decode
 
 pytestmark = pytest.mark.gpu
-QUEUE = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0]
+QUEUE = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_PRS_LE]   # (PRS: the two-wavefront kernel, 64 KiB chunks)
 SEED = int(os.environ.get("ALZ_FUZZ_SEED", "1234"))
 
 
@@ -85,7 +85,7 @@ def test_queue_lzss_windows(bits):
 def test_queue_uneven_batch_more_items_than_wavefronts():
     """One batch of 3 000 short and 300 long Yaz0 / LZ10 / MIO0 streams: ~25 000 items on ~6 400 persistent wavefronts, chunks of one stream
     decoded on different CUs one after the other, wavefronts waiting for each other's hand-overs."""
-    fm = np.array([(A.FMT_YAZ0, A.FMT_LZ10, A.FMT_MIO0)[i % 3] for i in range(3300)], dtype=np.uint32)
+    fm = np.array([(A.FMT_YAZ0, A.FMT_LZ10, A.FMT_MIO0, A.FMT_PRS_BE)[i % 4] for i in range(3300)], dtype=np.uint32)
     sizes = np.array([1 << 20 if i % 11 == 0 else 70000 + 517 * (i % 97) for i in range(3300)], dtype=np.uint32)
     b = synth.make_batch(fm, len(fm), sizes, synth.seed_for(99))
     canary_decode(b.streams, b.src, b.dst_bytes, what="queue uneven", queue=True)
