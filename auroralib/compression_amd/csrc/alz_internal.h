@@ -21,7 +21,7 @@ bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out);  
 #define ALZ_CHUNK_OUT_PRS 65536u                              /* PRS hands over an 8 KiB window: larger chunks */
 static inline uint32_t alz_chunk_bytes(int fmt) { return (fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE) ? ALZ_CHUNK_OUT_PRS : ALZ_CHUNK_OUT; }
 int alz_chunk_places_per_cu(int fmt);                        // streams one CU holds of the format's one-workgroup-per-stream kernel (what the work queue is weighed against)
-// d_ctl: 64 words (0: queue head, 32: timeout flag -- a 128-byte line each), zeroed by the caller before every launch, like d_flags (ALZ_CHUNK_FLAG_STRIDE words per slot: a line of its own);
+// d_ctl: 64 words (32: timeout flag, a 128-byte line of its own; 0: unused), zeroed by the caller before every launch, like d_flags (ALZ_CHUNK_FLAG_STRIDE words per slot: a line of its own);
 // d_slots: n_slots x (32 + lw) bytes
 hipError_t alz_launch_decode_chunked(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const alz_chunk_item* d_items,
                                      uint32_t n_items, alz_result* d_results, const alz_lz_properties* lz, uint32_t* d_ctl, uint32_t* d_flags, uint8_t* d_slots);

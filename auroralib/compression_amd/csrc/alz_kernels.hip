@@ -374,7 +374,7 @@ template <int FMT>
 __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
                                                              const alz_stream* __restrict__ streams, const alz_chunk_item* __restrict__ items, u32 n_items,
                                                              alz_result* __restrict__ results, alz_lz_properties lz, u32 lw,
-                                                             u32* __restrict__ qhead, u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo) {
+                                                             u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr int NC = THREE ? 3 : 1;
     constexpr u32 LWMAX = 4096u;
@@ -390,7 +390,6 @@ __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(cons
     // counter in a loop was the first form; its loop came out of the compiler as a divergent one -- exec-masked, a readfirstlane per trip -- and the
     // decode ran with lanes switched off and never ended: docs/EXPERIMENTS.md 10.7.)
     const u32 item = blockIdx.x;
-    (void)qhead;
     if (item >= n_items) return;
     const alz_chunk_item it = items[item];
     const u32 sid = uni(it.sid), c = uni(it.chunk), oslot = uni(it.slot), last = uni(it.last);
@@ -1328,7 +1327,7 @@ template <int FMT>
 static hipError_t launch_fastq(hipStream_t stream, const u8* s, u8* d, const alz_stream* streams, const alz_chunk_item* items, u32 n_items, alz_result* results,
                                const alz_lz_properties& lz, u32 lw, u32* ctl, u32* flags, u8* slots) {
     const u32 grid = n_items;                              // one workgroup per (stream, chunk) item, in queue order
-    hipLaunchKernelGGL((alz_decode_fastq_kernel<FMT>), dim3(grid), dim3(64), 0, stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots, ctl + 32);
+    hipLaunchKernelGGL((alz_decode_fastq_kernel<FMT>), dim3(grid), dim3(64), 0, stream, s, d, streams, items, n_items, results, lz, lw, flags, slots, ctl + 32);
     return hipGetLastError();
 }
 hipError_t alz_launch_decode_chunked(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const alz_chunk_item* items,
