@@ -30,6 +30,9 @@
 // interpretations + a scalar walk over a VGPR-resident window with the flag register in an SGPR).  pipelined_rounds
 // executes the rounds of the first five, overlapping the HBM read-backs of one round with the parse of the next.
 #pragma once
+#ifndef ALZ_DESCTAB_ALL
+#define ALZ_DESCTAB_ALL 0
+#endif
 #include "alz_emit_byte.h"
 #include "alz_prs_table.h"
 
@@ -207,7 +210,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     }
     if (cut && vm == 0) { to_serial = true; return false; }
     u32 last_tend;
-    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB>>(out, s, size, vm, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB, false, false, ALZ_DESCTAB_ALL != 0>>(out, s, size, vm, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
     if (fin) {
         s.p = p + last_tend;
         if (FMT == ALZ_FMT_LZ02) {                                // not the end of an LZ02 stream: the exact parser goes on to the terminator

@@ -1644,12 +1644,22 @@ __device__ __forceinline__ u32 scan_max(u32 v) {            // inclusive wave pr
     return v;
 }
 
+// SEGS (alz_encode_seg.h): the grid's x is a segment of the stream; the walk runs from that segment's synchronisation point (a position every
+// walk lands on, enc_sync_kernel) to the next segment's -- several wavefronts per stream, each exact.  Mask words are OR-ed into memory: the window
+// that holds a synchronisation point is written from both sides (the same bits where they overlap).
+template <bool SEGS>
 __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams,
                                                        const u32* __restrict__ index_list, u32 count, mentry* __restrict__ match,
                                                        const u64* __restrict__ pos_off, const int* __restrict__ prev4,
-                                                       const int* __restrict__ prevm, u64* __restrict__ startmask, EncGeom g, int tail_skip) {
+                                                       const int* __restrict__ prevm, u64* __restrict__ startmask, EncGeom g, int tail_skip,
+                                                       const u32* __restrict__ sync = nullptr, u32 kpitch = 0) {
+    // The match entries come through a tile in LDS: 1 024 positions (+ 64: the neighbour of a window's last lane) per fill, the next tile on its way
+    // in registers meanwhile.  With one window loaded ahead (round 3) every window of 64 positions waited for a load from HBM -- ~1.1 us, whatever the
+    // walk itself took: 1.17 ms per 64 KiB (profiles/r05_mid_batch_encode.md); a tile pays that once per sixteen windows.
+    constexpr int TILE = 1024, TLEN = TILE + 64, TPL = TLEN / 64;
     __shared__ u8 hopmark[64];
-    const u32 bid = blockIdx.x;
+    __shared__ mentry tile[TLEN];
+    const u32 bid = SEGS ? blockIdx.y : blockIdx.x;
     if (bid >= count) return;
     const int lane = (int)threadIdx.x;
     hopmark[lane] = 0;
@@ -1663,30 +1673,55 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
     const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
     u64* mask = startmask + (pos_off[sid] >> 6);
     int cur = 0;                    // cursor of FindNextBestMatch (absolute position)
-    // The window behind the current one is loaded one iteration ahead (the cursor nearly always walks into it: a stream is
-    // 4 096 windows, and the load's latency was exposed once per window), and match[p + 1] comes from the neighbour lane.
-    int Pn = -1;                    // window held in `nx` (-1: none)
-    uint2 nx = make_uint2(0, 0);
+    int wend = 0x7FFFFFFF;          // SEGS: where the next wavefront takes over
+    if (SEGS) {
+        const u32* sy = sync + (size_t)bid * kpitch;
+        const u32 k = blockIdx.x;
+        const u32 s0 = sy[k];
+        if (s0 == 0xFFFFFFFFu) return;                                  // (no synchronisation point in front of this segment: the walk before goes on through it)
+        cur = (int)s0;
+        for (u32 j0 = k + 1u; j0 < kpitch; j0 += 64u) {
+            const u32 j = j0 + (u32)lane;
+            const u32 v = j < kpitch ? sy[j] : 0xFFFFFFFFu;
+            const u64 bal = __ballot(v != 0xFFFFFFFFu);
+            if (bal) { wend = __builtin_amdgcn_readlane((int)v, (int)__builtin_ctzll(bal)); break; }
+        }
+    }
+    auto put_mask = [&](u32 w, u64 bits) {                              // (lane 0)
+        if (SEGS) atomicOr(reinterpret_cast<unsigned long long*>(mask + w), (unsigned long long)bits); else mask[w] = bits;
+    };
+    int tbase = -TILE - TILE;       // first position of the tile in LDS (none yet)
+    int pbase = -1;                 // first position of the tile in `pf` (-1: none)
+    mentry pf[TPL];
+    // (positions above `limit` were never searched: no match -- their entries are whatever an earlier batch left there)
+    auto fetch = [&](int base) {
+#pragma unroll
+        for (int j = 0; j < TPL; j++) { const int q = base + 64 * j + lane; pf[j] = q <= limit ? __builtin_nontemporal_load(m + q) : 0u; }
+        pbase = base;
+    };
+    auto install = [&]() {
+#pragma unroll
+        for (int j = 0; j < TPL; j++) tile[64 * j + lane] = pf[j];
+        tbase = pbase; pbase = -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    };
     u32 carryw = 0xFFFFFFFFu;       // window whose lane 0 starts a token found by the window in front of it (none: ~0)
-    while (cur <= limit) {
+    while (cur <= limit && cur < wend) {
         const int P = cur & ~63;    // window that holds the cursor (windows the cursor jumps over keep their zero mask)
         const int p = P + lane;
         const bool carry_in = carryw == ((u32)P >> 6);
-        if (!carry_in && carryw != 0xFFFFFFFFu && lane == 0) mask[carryw] = 1ull;     // (that window is jumped over: its only bit)
+        if (!carry_in && carryw != 0xFFFFFFFFu && lane == 0) put_mask(carryw, 1ull);  // (that window is jumped over: its only bit)
         carryw = 0xFFFFFFFFu;
-        // match[p] and match[p+1] (positions above `limit` were never searched: no match)
-        uint2 a = make_uint2(0, 0);
-        // (an ALZ_M_LONG entry -- or the raw length behind one -- is never looked at here: both lie at or inside a match this walk has taken)
-        auto ldm = [&](int q) { return m_unpack(__builtin_nontemporal_load(m + q)); };
-        if (P == Pn) a = nx; else if (p <= limit) a = ldm(p);
-        nx = make_uint2(0, 0); Pn = P + 64;
-        if (p + 64 <= limit) nx = ldm(p + 64);
-        uint2 b;
-        b.x = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.x); b.y = (u32)__builtin_amdgcn_ds_bpermute((lane + 1) << 2, (int)a.y);
-        {   // lane 63's neighbour is the first position of the next window
-            const u32 n0x = (u32)__builtin_amdgcn_readlane((int)nx.x, 0), n0y = (u32)__builtin_amdgcn_readlane((int)nx.y, 0);
-            if (lane == 63) b = make_uint2(n0x, n0y);
+        if (P < tbase || P >= tbase + TILE) {                                          // (the cursor only moves forward)
+            const int want = P & ~(TILE - 1);
+            if (pbase != want) fetch(want);
+            install();
+            if (want + TILE <= limit) fetch(want + TILE);
         }
+        // match[p] and match[p+1]
+        // (an ALZ_M_LONG entry -- or the raw length behind one -- is never looked at here: both lie at or inside a match this walk has taken)
+        const uint2 a = m_unpack(tile[P - tbase + lane]);
+        const uint2 b = m_unpack(tile[P - tbase + lane + 1]);
         const bool capped = a.y == ALZ_CAPPED || b.y == ALZ_CAPPED;
         int jump = 1, startrel = 0;   // startrel: 0 no token here, 1 match starts here, 2 literal here + match at p + 1
         if (!capped && p <= limit && (int)a.y >= g.min_len) {
@@ -1754,7 +1789,6 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 // (by the whole wavefront, 4 KiB per trip: as a plain loop on every lane a match of a few hundred bytes took ~10 us per cursor)
                 if (g.use_min_table) benc_wave_search<true>(data, n, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, n, g, p4, pm, q, d0, l0);
                 if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, n, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, n, g, p4, pm, q + 1, d1, l1); }
-                if (q + 1 >= P + 64) Pn = -1;                           // (the window loaded ahead no longer matches memory)
                 j = 1; sr = 0;
                 if (l0 >= g.min_len) {
                     const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
@@ -1764,16 +1798,19 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 // The exact results go back into the array: the match that is TAKEN in full (the emitters read it; 2 046 bytes or more: the
                 // length in the next entry, a position inside the match), the other one as far as an entry holds it -- q's is never looked
                 // at again, q + 1's is if the walk goes there next, and stays "capped" (recomputed then) when it is too long for an entry.
+                // (the tile in LDS gets the lazy neighbour's entry too: the walk may stand on it next.  The tile on its way in `pf` may still hold
+                // kernel B's entry for it -- exact or "capped", in which case it is searched again: the same result)
                 if (lane == 0) {
                     if (sr == 1 && l0 >= (int)ALZ_M_LONG) { m[q] = m_pack((u32)d0, ALZ_M_LONG); m[q + 1] = (u32)l0; }
                     else {
                         m[q] = m_pack((u32)d0, l0 < (int)ALZ_M_LONG ? (u32)l0 : ALZ_M_LONG - 1u);
                         if (q + 1 <= limit) {
-                            if (l1 < (int)ALZ_M_LONG) m[q + 1] = m_pack((u32)d1, (u32)l1);
+                            if (l1 < (int)ALZ_M_LONG) { m[q + 1] = m_pack((u32)d1, (u32)l1); tile[q + 1 - tbase] = m_pack((u32)d1, (u32)l1); }
                             else if (sr == 2) { m[q + 1] = m_pack((u32)d1, ALZ_M_LONG); m[q + 2] = (u32)l1; }
                         }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
             } else {
                 j = __builtin_amdgcn_readlane(jump, rel);
                 sr = __builtin_amdgcn_readlane(startrel, rel);
@@ -1782,11 +1819,57 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
             else if (sr == 2) { if (rel + 1 < 64) bits |= 1ull << (rel + 1); else carryw = ((u32)P >> 6) + 1u; }   // start in lane 0 of the next window
             rel += j;
         }
-        if (bits && lane == 0) mask[P >> 6] = bits;      // (a plain store: the mask array is zeroed before the launch, a window is visited once,
-                                                         //  and the one bit another window contributes travels in `carryw` -- no load per window)
+        if (bits && lane == 0) put_mask((u32)P >> 6, bits);   // (one wavefront per stream: a plain store -- the mask array is zeroed before the launch, a window
+                                                              //  is visited once, and the one bit another window contributes travels in `carryw`: no load per window)
         cur = P + rel;
     }
-    if (carryw != 0xFFFFFFFFu && lane == 0) mask[carryw] = 1ull;
+    if (carryw != 0xFFFFFFFFu && lane == 0) put_mask(carryw, 1ull);
+}
+
+// Synchronisation points of the parse (alz_encode_seg.h): a position s that NO jump from a position in front of it crosses -- max over q < s of
+// q + jump(q) <= s -- is a cursor of every walk, wherever it started: steps are at least 1 and none goes over s.  Per stream and segment boundary
+// S = k * seglen: the last such position in (S - seglen, S], or none (a run, a stretch of repeated rows: one match behind the other for whole segments --
+// the walk in front then carries on through this segment).  One wavefront per boundary: jump(q) for every position of the segment in front and of the
+// longest jump's worth of positions before it, exactly as the walk computes it; a prefix maximum.  A position kernel B has capped has no jump here: nothing behind
+// it counts as a synchronisation point for this boundary.
+__global__ __launch_bounds__(64) void enc_sync_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, const mentry* __restrict__ match,
+                                                      const u64* __restrict__ pos_off, u32* __restrict__ sync, u32 kpitch, u32 seglen, EncGeom g) {
+    const u32 k = blockIdx.x, bid = blockIdx.y;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const int n = (int)streams[sid].src_len;
+    const int limit = n - 4;
+    u32* out = sync + (size_t)bid * kpitch + k;
+    const int S = (int)(k * seglen);
+    if (k == 0u) { if (lane == 0) *out = 0u; return; }
+    if (S > limit) { if (lane == 0) *out = 0xFFFFFFFFu; return; }
+    const mentry* m = match + pos_off[sid];
+    const int hist = (g.max_len + 2 + 63) & ~63;
+    const int lo = S - (int)seglen;
+    const int x0 = lo - hist > 0 ? lo - hist : 0;
+    u32 pmx = 0, best = 0xFFFFFFFFu;
+    auto ldm = [&](int q) { return q <= limit ? m_unpack(m[q]) : make_uint2(0, 0); };
+    for (int P = x0; P < S; P += 64) {
+        const int p = P + lane;
+        const uint2 a = ldm(p), b = ldm(p + 1);
+        int jump = 1;
+        if (a.y == ALZ_CAPPED || b.y == ALZ_CAPPED) jump = 0x40000000;
+        else if ((int)a.y >= g.min_len) {                               // (p < S <= limit: searched)
+            const int l0 = (int)a.y, l1 = (int)b.y;
+            const bool lazyc = l0 <= g.lazy && p + 1 <= limit;
+            if (lazyc && l1 > l0) { const int e = p + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 2 > stop ? p + 2 : stop) - p; }
+            else { const int skip = lazyc ? 1 : 0; const int e = p + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 1 + skip > stop ? p + 1 + skip : stop) - p; }
+        }
+        const u32 incl = scan_max((u32)(p + jump));
+        u32 excl = (u32)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138, 0xF, 0xF, false);     // wave_shr:1 -> max over the lanes below
+        if (excl < pmx) excl = pmx;
+        const u64 bal = __ballot(p > lo && excl <= (u32)p);
+        if (bal) best = (u32)P + 63u - (u32)__builtin_clzll(bal);
+        const u32 wm = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (wm > pmx) pmx = wm;
+    }
+    if (pmx <= (u32)S) best = (u32)S;
+    if (lane == 0) *out = best;
 }
 
 // The payload bytes of a match token of the flag-bit formats: `mt` = (distance, length) of the match that starts at position p.
@@ -2114,6 +2197,8 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
         if (!THREE && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
     }
 }
+
+#include "alz_encode_seg.h"
 
 int isqrt_floor(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) r++; return r; }
 
@@ -2903,7 +2988,7 @@ static void launch_emit(hipStream_t s, u32 count, const u8* src, u8* dst, const 
     // one stream per wavefront (lane 0 parses and emits; 64 streams per wavefront were the union of 64 divergent token paths), the
     // parse from the roles walk's start mask
     const int tail = FMT == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
-    if (mask) hipLaunchKernelGGL(enc_roles_kernel, dim3(count), dim3(64), 0, s, src, streams, index, count, (mentry*)match, pos_off, prev4, prevm, mask, g, tail);
+    if (mask) hipLaunchKernelGGL((enc_roles_kernel<false>), dim3(count), dim3(64), 0, s, src, streams, index, count, (mentry*)match, pos_off, prev4, prevm, mask, g, tail, (const u32*)nullptr, 0u);
     hipLaunchKernelGGL((enc_emit_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, count, match, pos_off, side, results, aux, g, 1u,
                        (const u64*)mask);
 }
@@ -3228,10 +3313,12 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
-                             uint32_t* d_sel, uint32_t sel_pitch) {
+                             uint32_t* d_sel, uint32_t sel_pitch, void* d_seg, uint32_t seg_len, uint32_t seg_kmax) {
     if (count == 0) return hipSuccess;
     EncGeom g; memcpy(&g, geom, sizeof(g));
-    g.b_cap = choose_b_cap(g);
+    // (the segmented path of a small batch, alz_encode_seg.h: no cap -- its longest match is at most 2 040 bytes, kernel B has the GPU to itself, and
+    // every capped position the roles walk stands on costs that ONE wavefront two exact searches: 16 x 64 KiB of Test.bmp as Yaz0 at quality 8 1.17 ms of walk)
+    g.b_cap = (d_seg != nullptr && seg_len != 0u) ? ALZ_LEN_CAP : choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     if (narrows_links(g) && d_narrow != nullptr && d_sel != nullptr) {
@@ -3281,19 +3368,21 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
         if (ea != hipSuccess) return ea;
     }
-    if (!searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u, true, d_sel, sel_pitch);
+    const bool segmented = d_seg != nullptr && seg_len != 0u;                   // (a batch of few buffers: alz_encode_seg.h -- always behind kernel B)
+    if (segmented || !searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u, true, d_sel, sel_pitch);
+#define ALZ_SEG(F) if (segmented) { launch_emit_seg<F>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
-    case ALZ_FMT_LZSS: launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ10: launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZSS: ALZ_SEG(ALZ_FMT_LZSS) launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ10: ALZ_SEG(ALZ_FMT_LZ10) launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ11: launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ40: launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_YAZ0: launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_YAY0: launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_MIO0: launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_CLZ0: launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_BLZ: launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZHUDSON: launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAZ0: ALZ_SEG(ALZ_FMT_YAZ0) launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_YAY0: ALZ_SEG(ALZ_FMT_YAY0) launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_MIO0: ALZ_SEG(ALZ_FMT_MIO0) launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_CLZ0: ALZ_SEG(ALZ_FMT_CLZ0) launch_emit_par<ALZ_FMT_CLZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_BLZ: ALZ_SEG(ALZ_FMT_BLZ) launch_emit_par<ALZ_FMT_BLZ>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZHUDSON: ALZ_SEG(ALZ_FMT_LZHUDSON) launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<true, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
@@ -3326,6 +3415,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_CNX2: launch_emit<ALZ_FMT_CNX2>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     default: return hipErrorInvalidValue;
     }
+#undef ALZ_SEG
     return hipGetLastError();
 }
 

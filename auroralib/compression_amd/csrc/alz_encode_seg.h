@@ -1,0 +1,259 @@
+// alz_encode_seg.h -- the flag-bit emitter for batches of FEW buffers (tens to hundreds of 64 KiB - 1 MiB: a directory of files, the chunks of
+// one archive), included by alz_encode.hip.
+//
+// enc_parse_emit_kernel gives a buffer ONE wavefront for the parse and its tokens: ~1.7 us per window of 64 positions whatever else the GPU is
+// doing, 1.7 ms per 64 KiB, while 256 buffers leave 24 of a CU's 25 places empty (tools/mid_batch_encode.py: 16-256 buffers of 64 KiB as Yaz0 at
+// quality 8 took 1.8-3.4 ms).  Only the WALK of the parse is serial (cursor += jump[cursor]); everything the emitter does with the token starts is
+// prefix sums over positions.  So, for such batches (alz_encode_segmented):
+//   R  enc_roles_kernel       the walk alone, one wavefront per buffer: a bit per position "a match token starts here" (windows the cursor jumps over
+//                             cost nothing; positions kernel B had capped are searched exactly and patched into the match array)
+//   C  enc_seg_kernel<false>  one wavefront per SEGMENT of a buffer (1-8 Ki positions, so that the launch has a few thousand): the tokens, payload
+//                             bytes and literal-section bytes that start in it.  What it needs from the left is the end of the last match that
+//                             starts before the segment: at most maxLength back in the start mask
+//   P  enc_seg_prefix_kernel  exclusive prefix sums over a buffer's segments (one wavefront per buffer)
+//   E  enc_seg_kernel<true>   the same windows again, now with their offsets: payload bytes, and every flag byte whose group of eight tokens
+//                             begins AND ends in the segment
+//   F  enc_seg_flags_kernel   the flag bytes of groups that straddle segments (the bits each side found, OR-ed), the partial last one
+//                             (FlagWriter.Dispose  IO/FlagWriter.cs:141-145), the results
+// Same bytes as enc_parse_emit_kernel by construction: the same per-window arithmetic (LZSS.cs:132-160, LZ10.cs:113-137, Yaz0 / Yay0 / MIO0 ...
+// through flag_payload), the same order.  Formats whose longest match fits 63 windows (not LZ11 / LZ40: 16 KiB).
+
+struct SegRec { u32 tok, pay, unc, head, tailbits, tailofs, fail, pad; };     // counts (C) -> exclusive prefix (P); the flag bits of straddling groups (E)
+
+template <int FMT, bool EMIT>
+__global__ __launch_bounds__(64) void enc_seg_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                     const u32* __restrict__ index_list, const mentry* __restrict__ match, const u64* __restrict__ pos_off,
+                                                     const u64* __restrict__ startmask, SegRec* __restrict__ seg, const u32* __restrict__ stot,
+                                                     u32 kpitch, u32 seglen, EncGeom g) {
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZHUDSON || THREE);
+    constexpr bool MSB = (FMT != ALZ_FMT_LZSS && FMT != ALZ_FMT_CLZ0);
+    constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;
+    __shared__ u32 flagacc[16];
+    __shared__ u32 gofs[16];
+    const u32 k = blockIdx.x, bid = blockIdx.y;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u32 n = st.src_len;
+    const u32 S = k * seglen;
+    if (S >= n) return;
+    const u32 E = S + seglen < n ? S + seglen : n;
+    const int limit = (int)n - 4;
+    const u8* src = src_base + st.src_off;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    const mentry* m = match + pos_off[sid];
+    const u64* mask = startmask + (pos_off[sid] >> 6);
+    SegRec* rec = seg + (size_t)bid * kpitch + k;
+    if (lane < 16) { flagacc[lane] = 0; gofs[lane] = 0; }
+    __syncthreads();
+    // the end of the last match that starts in front of the segment: a match further back than maxLength cannot reach it
+    u32 cover = 0;
+    if (k) {
+        const int w = (int)(S >> 6) - 1 - lane;
+        u32 endv = 0;
+        if (w >= 0 && (u32)lane * 64u < (u32)g.max_len + 64u) {
+            const u64 mw = mask[w];
+            if (mw) { const u32 q = (u32)w * 64u + 63u - (u32)__builtin_clzll(mw); endv = q + m_unpack(m[q]).y; }
+        }
+        cover = (u32)__builtin_amdgcn_readlane((int)scan_max(endv), 63);
+    }
+    u32 tok_base = 0, pay_base = 0, unc_base = 0, nflags = 0, pay_total = 0;
+    if (EMIT) {
+        tok_base = rec->tok; pay_base = rec->pay; unc_base = rec->unc;
+        if (THREE) { nflags = FB * ((stot[4 * (size_t)bid] + FBITS - 1u) / FBITS); pay_total = stot[4 * (size_t)bid + 1]; }
+    }
+    const u32 g0 = tok_base / FBITS;
+    const bool straddle = (tok_base % FBITS) != 0u;          // the first tokens complete a group that began in the segment before
+    bool fail = false;
+    auto ldm = [&](u32 q) { return (int)q <= limit ? m_unpack(m[q]) : make_uint2(0, 0); };
+    // (mask word, match entries and source bytes of a window are loaded while the window before it is worked on)
+    u64 sm_n = mask[S >> 6];
+    uint2 a_n = ldm(S + (u32)lane);
+    u32 sb_n = S + (u32)lane < n ? src[S + (u32)lane] : 0u;
+    for (u32 P = S; P < E; P += 64) {
+        const u32 p = P + (u32)lane;
+        const u64 sm = sm_n; const uint2 a = a_n; const u32 sb = sb_n;
+        if (P + 64 < E) { sm_n = mask[(P + 64) >> 6]; a_n = ldm(p + 64u); sb_n = p + 64u < n ? src[p + 64u] : 0u; }
+        // ---- as enc_parse_emit_kernel: prefix sums over the start mask give every token its flag group and byte offset
+        const bool start = ((sm >> lane) & 1ull) && p < n;
+        uint2 mt = make_uint2(0, 0);
+        if (start) mt = a;
+        const u32 mend = start ? p + mt.y : 0u;
+        const u32 pmax = scan_max(mend);
+        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
+        if (before < cover) before = cover;
+        const bool lit = !start && p < n && p >= before;
+        const bool tok = start || lit;
+        const u64 tm = __ballot(tok);
+        const u32 ti = tok_base + __builtin_amdgcn_mbcnt_hi((u32)(tm >> 32), __builtin_amdgcn_mbcnt_lo((u32)tm, 0u));
+        u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, psize = 0, usize = 0;
+        if (lit) { b0 = sb; psize = 1; }
+        else if (start) flag_payload<FMT>(g, p, mt, b0, b1, b2, b3, psize);
+        if (THREE) {
+            if (lit) { usize = 1; psize = 0; }
+            else if (start && FMT == ALZ_FMT_YAY0 && psize == 3) { usize = 1; psize = 2; }
+        }
+        const u32 pincl = scan_add(psize);
+        const u32 poff = pay_base + pincl - psize;
+        const u32 uincl = THREE ? scan_add(usize) : 0u;
+        const u32 uoff = unc_base + uincl - usize;
+        if (EMIT) {
+            const u32 group = ti / FBITS, bitpos = ti % FBITS;
+            const u32 flag_off = THREE ? group : poff + FB * group;
+            if (tok && bitpos == 0) { gofs[group & 15u] = flag_off; flagacc[group & 15u] = 0; }
+            __syncthreads();
+            if (tok) {
+                const u32 bitv = (lit ? LIT_BIT : !LIT_BIT) ? 1u : 0u;
+                if (bitv) atomicOr(&flagacc[group & 15u], 1u << (MSB ? FBITS - 1u - bitpos : bitpos));
+            }
+            __syncthreads();
+            if (tok) {
+                if (bitpos == FBITS - 1u) {
+                    const u32 acc = flagacc[group & 15u];
+                    if (straddle && group == g0) rec->head = acc;             // (its flag byte lies in the segment before: enc_seg_flags_kernel)
+                    else {
+                        const u32 fo = gofs[group & 15u];
+                        if (fo + FB <= cap) { if (FB == 1u) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc); else { dst[fo] = (u8)(acc >> 24); dst[fo + 1] = (u8)(acc >> 16); dst[fo + 2] = (u8)(acc >> 8); dst[fo + 3] = (u8)acc; } }
+                        else fail = true;
+                    }
+                }
+                if (!THREE) {
+                    const u32 o = poff + FB * (group + 1u);
+                    if (o + psize <= cap) { dst[o] = (u8)b0; if (psize > 1) dst[o + 1] = (u8)b1; if (psize > 2) dst[o + 2] = (u8)b2; if (psize > 3) dst[o + 3] = (u8)b3; }
+                    else fail = true;
+                } else {
+                    // (the sections straight into place: their offsets are known)
+                    const u32 oc = nflags + poff, ou = nflags + pay_total + uoff;
+                    if (lit) { if (ou < cap) dst[ou] = (u8)b0; else fail = true; }
+                    else {
+                        if (oc + 2u <= cap) { dst[oc] = (u8)b0; dst[oc + 1] = (u8)b1; } else fail = true;
+                        if (usize) { if (ou < cap) dst[ou] = (u8)b2; else fail = true; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        tok_base += (u32)__popcll(tm);
+        pay_base += (u32)__builtin_amdgcn_readlane((int)pincl, 63);
+        if (THREE) unc_base += (u32)__builtin_amdgcn_readlane((int)uincl, 63);
+        const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
+        if (wmax > cover) cover = wmax;
+    }
+    if (!EMIT) {
+        if (lane == 0) { SegRec r; r.tok = tok_base; r.pay = pay_base; r.unc = unc_base; r.head = 0; r.tailbits = 0; r.tailofs = 0; r.fail = 0; r.pad = 0; *rec = r; }
+        return;
+    }
+    const bool anyfail = __ballot(fail) != 0ull;
+    if (lane == 0) {
+        const u32 gt = tok_base / FBITS;                                       // (tok_base: one behind the segment's last token)
+        if (straddle && gt == g0) rec->head = flagacc[g0 & 15u];               // still inside the group it began in
+        else if ((tok_base % FBITS) != 0u) { rec->tailbits = flagacc[gt & 15u]; rec->tailofs = gofs[gt & 15u]; }
+        rec->fail = anyfail ? 1u : 0u;
+    }
+}
+
+// P: a buffer's segment counts -> exclusive prefix sums, in place; the totals to stot[4 * buffer ...]
+__global__ __launch_bounds__(64) void enc_seg_prefix_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, SegRec* __restrict__ seg,
+                                                            u32* __restrict__ stot, u32 kpitch, u32 seglen) {
+    const u32 bid = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const u32 n = streams[index_list[bid]].src_len;
+    const u32 K = (n + seglen - 1u) / seglen;
+    SegRec* rec = seg + (size_t)bid * kpitch;
+    u32 ct = 0, cp = 0, cu = 0;
+    for (u32 k0 = 0; k0 < K; k0 += 64) {
+        const u32 k = k0 + (u32)lane;
+        u32 t = 0, p = 0, u = 0;
+        if (k < K) { t = rec[k].tok; p = rec[k].pay; u = rec[k].unc; }
+        const u32 ti = scan_add(t), pi = scan_add(p), ui = scan_add(u);
+        if (k < K) { rec[k].tok = ct + ti - t; rec[k].pay = cp + pi - p; rec[k].unc = cu + ui - u; }
+        ct += (u32)__builtin_amdgcn_readlane((int)ti, 63); cp += (u32)__builtin_amdgcn_readlane((int)pi, 63); cu += (u32)__builtin_amdgcn_readlane((int)ui, 63);
+    }
+    if (lane == 0) { stot[4 * (size_t)bid] = ct; stot[4 * (size_t)bid + 1] = cp; stot[4 * (size_t)bid + 2] = cu; stot[4 * (size_t)bid + 3] = 0; }
+}
+
+// F: the flag bytes of the groups that do not begin and end inside one segment, and the buffer's result
+template <int FMT>
+__global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_base, const alz_stream* __restrict__ streams, const u32* __restrict__ index_list,
+                                                           const SegRec* __restrict__ seg, const u32* __restrict__ stot, u32 kpitch, u32 seglen,
+                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux) {
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;
+    const u32 bid = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const u32 sid = index_list[bid];
+    const alz_stream st = streams[sid];
+    const u32 n = st.src_len, cap = st.dst_cap;
+    u8* dst = dst_base + st.dst_off;
+    const u32 K = (n + seglen - 1u) / seglen;
+    const SegRec* rec = seg + (size_t)bid * kpitch;
+    const u32 tok_total = stot[4 * (size_t)bid], pay_total = stot[4 * (size_t)bid + 1], unc_total = stot[4 * (size_t)bid + 2];
+    bool fail = false;
+    for (u32 k = (u32)lane; k < K; k += 64) {
+        const u32 tb = rec[k].tok, te = k + 1u < K ? rec[k + 1u].tok : tok_total;
+        const u32 g0 = tb / FBITS, gt = te / FBITS;
+        const bool straddle = (tb % FBITS) != 0u;
+        if (rec[k].fail) fail = true;
+        if ((te % FBITS) != 0u && !(straddle && gt == g0)) {                    // a group begins in this segment and does not end in it
+            u32 acc = rec[k].tailbits;
+            const u32 fo = rec[k].tailofs;
+            for (u32 j = k + 1u; j < K && rec[j].tok / FBITS == gt; j++) acc |= rec[j].head;
+            if (fo + FB <= cap) { if (FB == 1u) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc); else { dst[fo] = (u8)(acc >> 24); dst[fo + 1] = (u8)(acc >> 16); dst[fo + 2] = (u8)(acc >> 8); dst[fo + 3] = (u8)acc; } }
+            else fail = true;
+        }
+    }
+    const u32 nflags = FB * ((tok_total + FBITS - 1u) / FBITS);
+    const u32 total = nflags + pay_total + (THREE ? unc_total : 0u);
+    const bool anyfail = __ballot(fail) != 0ull || total > cap;
+    if (lane == 0) {
+        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
+        results[sid] = r;
+        if (aux) { aux[sid].aux0 = THREE ? nflags : 0u; aux[sid].aux1 = THREE ? nflags + pay_total : 0u; }
+    }
+}
+
+// Which launches go this way, and with what segments.  One wavefront per buffer fills the GPU from a few thousand buffers on; below that the five
+// small kernels win as soon as a buffer has a few segments.
+#ifndef ALZ_SEG_MAX_STREAMS
+#define ALZ_SEG_MAX_STREAMS 1024u
+#endif
+#ifndef ALZ_SEG_MIN_LEN
+#define ALZ_SEG_MIN_LEN 8192u
+#endif
+#ifndef ALZ_SEG_WAVES
+#define ALZ_SEG_WAVES 8192u      /* segments a launch aims at */
+#endif
+static u32 g_seg_max_streams = ALZ_SEG_MAX_STREAMS;
+}  // namespace
+void alz_debug_set_seg_max_streams(uint32_t v) { g_seg_max_streams = v; }       // (not in the public header: 0 switches the path off -- tests, tools/mid_batch_encode.py)
+
+int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax) {
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
+                     fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+    if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > g_seg_max_streams || max_len < ALZ_SEG_MIN_LEN) return 0;
+    uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
+    if (want < 1024u) want = 1024u;
+    const u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
+    if (seg_len) *seg_len = sl;
+    if (kmax) *kmax = (max_len + sl - 1u) / sl;
+    return 1;
+}
+size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax) { return (size_t)count * kmax * (sizeof(SegRec) + sizeof(u32)) + (size_t)count * 16u + 64u; }   // records, totals, synchronisation points
+namespace {
+
+template <int FMT>
+static void launch_emit_seg(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
+                            const int* prev4, const int* prevm, u64* mask, void* d_seg, u32 seglen, u32 kmax, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
+    SegRec* seg = (SegRec*)d_seg;
+    u32* stot = (u32*)((u8*)d_seg + (size_t)count * kmax * sizeof(SegRec));
+    u32* sync = stot + 4 * (size_t)count;
+    hipLaunchKernelGGL(enc_sync_kernel, dim3(kmax, count), dim3(64), 0, s, streams, index, (const mentry*)match, pos_off, sync, kmax, seglen, g);
+    hipLaunchKernelGGL((enc_roles_kernel<true>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0, (const u32*)sync, kmax);
+    hipLaunchKernelGGL((enc_seg_kernel<FMT, false>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, (const u32*)stot, kmax, seglen, g);
+    hipLaunchKernelGGL(enc_seg_prefix_kernel, dim3(count), dim3(64), 0, s, streams, index, seg, stot, kmax, seglen);
+    hipLaunchKernelGGL((enc_seg_kernel<FMT, true>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, (const u32*)stot, kmax, seglen, g);
+    hipLaunchKernelGGL((enc_seg_flags_kernel<FMT>), dim3(count), dim3(64), 0, s, dst, streams, index, (const SegRec*)seg, (const u32*)stot, kmax, seglen, results, aux);
+}

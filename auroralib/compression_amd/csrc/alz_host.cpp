@@ -108,6 +108,7 @@ struct alz_ctx {
     bool exact = false;                        // alz_ctx_set_exact_kernels: the exact one-token-at-a-time kernels instead of the lane-parallel ones
     int variant = 0;                           // alz_ctx_set_kernel_variant
     uint64_t big_enc_launches = 0;             // streams the whole-GPU ENCODE path has taken (alz_encode_big.h)
+    uint64_t seg_enc_launches = 0;             // launches of the segmented parse + emit (alz_encode_seg.h)
     uint32_t big_min = 24u << 10;              // (24 KiB: tools/single_decode_sizes.py -- 0.18 ms either way at 16 KiB, 0.18 against 0.30 at 32) a lone stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
     uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
     hipEvent_t big_evt = nullptr; bool big_evt_set = false;   // behind the last whole-GPU decode that used d_bigbuf (plans that borrow it run one after the other)
@@ -123,7 +124,7 @@ struct alz_ctx {
     void* d_plan = nullptr; size_t d_plan_cap = 0;   // plan arrays of the host-buffer entry points (no hipMalloc / hipFree per call)
     // encoder scratch (prev links, narrowed links, matches, masks ...: ~45 GB for 10 000 x 256 KiB at quality 8), one grow-only slot
     // per purpose: allocating and freeing it per call cost 1-2 s, four times the kernels.  alz_ctx_release_scratch() returns it.
-    void* enc_buf[14] = {nullptr}; size_t enc_cap[14] = {0};
+    void* enc_buf[15] = {nullptr}; size_t enc_cap[15] = {0};
     copy_pool* pool = nullptr;                 // created with the pinned buffers
     std::vector<copy_job> jobs;                // (scratch of the staging loops)
     void copy(uint8_t* dst, const uint8_t* src, size_t len) { jobs.clear(); add_copy(jobs, dst, src, len); pool->run(jobs); }
@@ -190,6 +191,9 @@ int alz_ctx_set_exact_kernels(alz_ctx* c, int on) {
 }
 /* not in the public header: resident waves per CU of the production kernel of `format` (tuning aid) */
 int alz_debug_occupancy(int format) { return alz_kernel_occupancy(format); }
+/* not in the public header: the largest batch (buffers of one format) whose parse + emit runs over segments (alz_encode_seg.h; 0: never), and how often a context has gone that way */
+void alz_debug_seg_max_streams(uint32_t v) { alz_debug_set_seg_max_streams(v); }
+uint64_t alz_debug_seg_launches(const alz_ctx* c) { return c ? c->seg_enc_launches : 0; }
 /* not in the public header: output bytes per chunk of the work-queue kernels */
 int alz_debug_chunk_bytes(void) { return (int)ALZ_CHUNK_OUT; }
 /* not in the public header: the (stream, chunk) items of a plan's work queues (0: the plan decodes with one wavefront per stream) */
@@ -855,7 +859,7 @@ struct EncScratch {
     }
 };
 static void release_scratch(alz_ctx* c) {
-    for (int k = 0; k < 14; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
+    for (int k = 0; k < 15; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
     void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan, &c->d_bigbuf};
     size_t* caps[] = {&c->d_src_cap, &c->d_dst_cap, &c->d_items_cap, &c->d_pack_cap, &c->d_plan_cap, &c->d_bigbuf_cap};
     for (int i = 0; i < 6; i++) { if (*bufs[i]) (void)hipFree(*bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
@@ -905,6 +909,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         return fail(ALZ_E_UNSUPPORTED, "LZSS geometry outside the GPU path");
     std::vector<unsigned char> geom((ALZ_FMT_COUNT + 1) * alz_encode_geom_size());   // last slot: FastLZ level 2
     bool any_min = false, any_match = false, any_mask = false, any_narrow = false;
+    std::vector<uint32_t> seg_len(ALZ_FMT_COUNT + 1, 0), seg_kmax(ALZ_FMT_COUNT + 1, 0); size_t seg_bytes = 0;
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         if (lvl2 ? !n_fastlz2 : !(cnt[f] - (f == ALZ_FMT_FASTLZ ? n_fastlz2 : 0u))) continue;
@@ -928,6 +933,11 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         any_narrow = any_narrow || alz_encode_geom_narrows(g);
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
         any_mask = any_mask || alz_encode_format_needs_mask(lvl2 ? ALZ_FMT_FASTLZ : f);
+        // a batch of few buffers of a flag-bit format: parse and emitter over segments (alz_encode_seg.h) -- behind kernel B and the roles walk
+        if (!lvl2 && !c->exact && c->variant == 0 && alz_encode_segmented(f, g, cnt[f], max_len, &seg_len[f], &seg_kmax[f])) {
+            any_match = any_mask = true;
+            const size_t b = alz_encode_seg_bytes(cnt[f], seg_kmax[f]); if (b > seg_bytes) seg_bytes = b;
+        }
     }
     // ---- a handful of big streams: each of them on the whole GPU (alz_encode_big.h).  A stream the path declines (too many positions that
     // need an exact second search) sends the whole call through the batch pipeline below.
@@ -1031,6 +1041,8 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     if (e == hipSuccess) e = sc.alloc((void**)&d_sel, ((size_t)2 * n + 64) * sizeof(uint32_t), any_match);     // which kernel B per stream (enc_probe_kernel)
     int* d_narrow = nullptr;
     if (e == hipSuccess) e = sc.alloc((void**)&d_narrow, (size_t)total * sizeof(int) + 256, any_narrow);   // slot 13: the links of the finder's own hash width, narrowed from 15-bit ones (enc_narrow_kernel)
+    void* d_seg = nullptr;
+    if (e == hipSuccess) e = sc.alloc(&d_seg, seg_bytes, seg_bytes != 0);                                  // slot 14: segment records of alz_encode_seg.h
     if (e != hipSuccess) return fail(ALZ_E_NOMEM, "encoder scratch allocation failed: %s", hipGetErrorString(e));
     tm.mark("validate + allocate");
     std::vector<uint32_t> index(n), foff(ALZ_FMT_COUNT, 0), fill(ALZ_FMT_COUNT, 0);
@@ -1068,8 +1080,9 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
             e = alz_launch_encode(fmt, c->stream, d_src_base, d_dst_base, d_streams, d_index + first + done, k, max_len, d_prev4, d_prevm, d_narrow,
-                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g, d_sel, n);
+                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g, d_sel, n, seg_len[f] ? d_seg : nullptr, seg_len[f], seg_kmax[f]);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));
+            if (seg_len[f]) c->seg_enc_launches++;
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

@@ -45,11 +45,16 @@ int alz_encode_geom_max_dist(const void* geom);
 int alz_encode_geom_narrows(const void* geom);                  // 1: kernel A links at 15 bits and enc_narrow_kernel writes the finder's own links into d_narrow (which must exist)
 int alz_encode_format_needs_mask(int fmt);                      // 1: the format's emitter reads the start mask of enc_roles_kernel (zeroed before the launch)
 int alz_encode_geom_needs_match(int fmt, const void* geom);   // 0: the search runs inside the parse + emit kernel (no kernel B, no match array)
+// a batch of few buffers of a flag-bit format: parse and emitter as five small kernels over segments (alz_encode_seg.h); 1: taken -- then the launch
+// needs the match array, the zeroed start mask and alz_encode_seg_bytes(count, *kmax) of scratch
+int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax);
+size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax);
+void alz_debug_set_seg_max_streams(uint32_t v);
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
                              uint32_t* d_sel /* which kernel B per stream (enc_probe_kernel): sel_pitch words indexed by stream, then 1 + count words of list; NULL: the two-phase kernel from maxChain 3 on */,
-                             uint32_t sel_pitch);
+                             uint32_t sel_pitch, void* d_seg = nullptr /* alz_encode_segmented: its scratch, */, uint32_t seg_len = 0, uint32_t seg_kmax = 0 /* segment length and segments per buffer */);
 // ---- ONE big stream on the whole GPU, encoder side (alz_encode_big.h): the flag-bit formats
 bool alz_encode_big_eligible(int fmt, const void* geom, const alz_stream* st, uint32_t min_bytes);
 size_t alz_encode_big_scratch_bytes(int fmt, const void* geom, const alz_stream* st);

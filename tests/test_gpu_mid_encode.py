@@ -1,0 +1,138 @@
+"""-m gpu: encode batches of FEW buffers (tens to hundreds: a directory of files, the chunks of an archive) of the flag-bit formats --
+csrc/alz_encode_seg.h: the roles walk alone per buffer, then tokens and flag bytes by prefix sums over SEGMENTS of the buffers, five small kernels
+instead of one wavefront per buffer for parse + emit.  The compressed bytes, section offsets and statuses must be IDENTICAL to the oracle's
+(LzChainMatchFinder + FlagWriter + CompressHeaderless restated) and to what the same call returns with the path switched off."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from auroralib.compression_amd import _abi as A
+from auroralib.compression_amd.batch import Context
+from test_gpu_big_encode import _encode, _mixed
+
+pytestmark = pytest.mark.gpu
+FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON]
+OFF = 0xFFFFFFFF
+G = 4096
+
+
+def _seg(c):
+    c.lib.alz_debug_seg_launches.restype = C.c_uint64
+    c.lib.alz_debug_seg_launches.argtypes = [C.c_void_p]
+    return int(c.lib.alz_debug_seg_launches(c.h))
+
+
+def _both_ways(c, items, quality, what, **kw):
+    """One call on the segmented path (asserted), one with it switched off (asserted): the same bytes, both equal to the oracle's."""
+    c.big_stream(OFF)                                   # (a handful of buffers would otherwise go one by one through the whole-GPU path)
+    try:
+        before = _seg(c)
+        a = _encode(c, items, quality, expect_big=False, what=what, **kw)
+        assert _seg(c) > before, what
+        c.lib.alz_debug_seg_max_streams(0)
+        try:
+            before = _seg(c)
+            b = _encode(c, items, quality, expect_big=False, what=what + ", path off", **kw)
+            assert _seg(c) == before, what
+        finally:
+            c.lib.alz_debug_seg_max_streams(1024)
+    finally:
+        c.big_stream(24 << 10)
+    assert a == b, what
+    return a
+
+
+@pytest.mark.parametrize("fmt", FAMILY)
+@pytest.mark.parametrize("quality", [0, 4, 8, 12])
+def test_ragged_batch(fmt, quality, test_bmp):
+    """Forty buffers of every kind of length -- empty, shorter than the finder's four bytes, one window of 64 positions more or less, the segment
+    length (1 024 here) more or less, one buffer long enough for the path to be taken -- of bitmap rows, runs, noise and prose-like bytes."""
+    sizes = [0, 1, 3, 4, 5, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 1024 + 63, 2047, 2048, 2049, 3071, 3072, 4095, 4096, 4097, 8191, 8192, 8193,
+             10000, 12288, 12288 + 1, 16384 - 3, 20000, 33333, 40000, 50001, 65536, 70000, 9, 300, 5000, 70001]
+    items = [(fmt, _mixed(s, 1000 + s, test_bmp) if s else b"") for s in sizes]
+    with Context(0) as c:
+        _both_ways(c, items, quality, "ragged")
+
+
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON])
+def test_segment_lengths(fmt, test_bmp):
+    """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 1 000 x 24 KiB
+    3 008; windows of Test.bmp 4 KiB apart."""
+    with Context(0) as c:
+        for n, size in ((300, 65536), (1000, 24000), (64, 262144 + 77)):
+            items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - size):][:size - (i % 7)]) for i in range(n)]
+            _both_ways(c, items, 0, "%d x %d" % (n, size))
+        items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - 65536):][:65536]) for i in range(256)]
+        _both_ways(c, items, 8, "256 x 64 KiB, quality 8")
+
+
+@pytest.mark.parametrize("fmt", FAMILY)
+def test_degenerate_buffers(fmt):
+    """Runs (one 273-byte match behind the other, no literal for whole segments; positions beyond kernel B's compare cap), two-byte periods, noise
+    (nothing but literals: flag groups of eight literals, the output larger than the input), a buffer that ends inside a match / on a literal,
+    literals only in the last segment."""
+    rng = np.random.default_rng(5)
+    raws = [bytes(100000), b"ab" * 40000, bytes(rng.integers(0, 256, 60000, dtype=np.uint8)), bytes(rng.integers(0, 3, 90000, dtype=np.uint8)),
+            bytes(50000) + b"abc", bytes(rng.integers(0, 256, 30000, dtype=np.uint8)) + bytes(30000), b"\xff" * 33000 + bytes(rng.integers(0, 256, 7, dtype=np.uint8)),
+            bytes(rng.integers(0, 256, 9, dtype=np.uint8)) * 5000, bytes(8192), bytes(8193), bytes(16384 + 2)]
+    with Context(0) as c:
+        for q in (0, 8, 15):
+            _both_ways(c, [(fmt, r) for r in raws], q, "degenerate")
+
+
+def test_settings_and_mixed_formats(test_bmp):
+    """LZSS geometries, CompatibilityMode, VRAM mode; a call of several formats, some on the path (each with its own segments) and some not."""
+    raw = test_bmp[:150000]
+    with Context(0) as c:
+        for bits in [(10, 6, 2), (12, 4, 2), (8, 4, 2), (12, 4, 3)]:
+            lz = A.LzProperties.from_bits(*bits)
+            _both_ways(c, [(A.FMT_LZSS, raw[i * 999:i * 999 + 20000 + i]) for i in range(40)], 8, "lzss %r" % (bits,), lz=lz)
+        _both_ways(c, [(A.FMT_LZSS, raw), (A.FMT_LZSS, b"ab" * 60000)] * 20, 8, "compat", strategy=1)
+        _both_ways(c, [(A.FMT_LZ10, raw), (A.FMT_LZ10, bytes(100000))] * 20, 8, "vram", min_distance=2)
+        mixed = [([A.FMT_YAZ0, A.FMT_LZ11, A.FMT_LZ4_BLOCK, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_LZ10][i % 6], test_bmp[i * 3000:i * 3000 + 30000 + 100 * i]) for i in range(60)]
+        _both_ways(c, mixed, 8, "mixed formats")
+        for q in range(16):
+            _both_ways(c, [(A.FMT_YAZ0, raw[:40000]), (A.FMT_YAZ0, raw[100000:140000])] * 17, q, "quality %d" % q)
+
+
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON])
+def test_capacity_and_canary_device_resident(fmt, test_bmp):
+    """alz_encode_batch_device with the whole destination compared (0xA5 canary, guard regions): destinations of exactly the compressed size are
+    filled and nothing else; one byte less is OUTPUT_CAPACITY with dst_len 0 and no byte outside the buffer's own range."""
+    n = 48
+    raws = [test_bmp[4096 * i:4096 * i + 30001 + 17 * i] for i in range(n)]
+    with Context(0) as c:
+        c.big_stream(OFF)
+        for q in (0, 8):
+            wants = [O.encode_stream(fmt, r, quality=q) for r in raws]
+            caps = [len(w[0]) - (1 if i % 3 == 1 else 0) + (777 if i % 3 == 2 else 0) for i, w in enumerate(wants)]
+            caps[5] = 100
+            src = np.frombuffer(b"".join(raws), dtype=np.uint8)
+            st = (A.Stream * n)()
+            so, do = 0, G
+            for i in range(n):
+                st[i] = A.Stream(so, do, len(raws[i]), caps[i], 0, 0, 0, fmt)
+                so += len(raws[i]); do += caps[i] + G
+            d_src, d_dst = c.malloc(len(src)), c.malloc(do)
+            try:
+                c.h2d(d_src, src); c.memset(d_dst, 0xA5, do)
+                before = _seg(c)
+                res, aux = c.encode_batch_device(st, d_src, len(src), d_dst, do, quality=q)
+                assert _seg(c) > before
+                buf = c.d2h(d_dst, do)
+            finally:
+                c.free(d_src); c.free(d_dst)
+            assert np.all(buf[:G] == 0xA5)
+            for i in range(n):
+                want, waux = wants[i]
+                o, tag = st[i].dst_off, (A.FORMAT_NAMES[fmt], q, i, caps[i] - len(want))
+                assert np.all(buf[o + caps[i]:o + caps[i] + G] == 0xA5), tag
+                if caps[i] >= len(want):
+                    assert (res[i].status, res[i].dst_len, res[i].src_used) == (A.ST_OK, len(want), len(raws[i])), tag
+                    assert bytes(buf[o:o + len(want)]) == want, tag
+                    assert np.all(buf[o + len(want):o + caps[i]] == 0xA5), tag
+                    assert (aux[i].aux0, aux[i].aux1) == (waux.aux0, waux.aux1), tag
+                else:
+                    assert (res[i].status, res[i].dst_len) == (A.ST_OUTPUT_CAPACITY, 0), tag

@@ -19,6 +19,9 @@ if os.environ.get("ALZ_MID_DATA") == "text":              # the repository's own
     print("text corpus: %d files, %d bytes" % (len(files), len(bmp)))
 size = int(os.environ.get("ALZ_MID_SIZE", str(262144)))
 c = Context(0)
+import ctypes as C
+c.lib.alz_debug_seg_launches.restype = C.c_uint64; c.lib.alz_debug_seg_launches.argtypes = [C.c_void_p]
+if os.environ.get("ALZ_MID_SEG") is not None: c.lib.alz_debug_seg_max_streams(int(os.environ["ALZ_MID_SEG"]))      # (0: the segmented parse + emit off)
 for fname in sys.argv[1:] or ["lzss", "yaz0"]:
     fmt = A.FORMAT_NAMES.index(fname)
     for q in [int(x) for x in os.environ.get("ALZ_MID_Q", "0,8").split(",")]:
@@ -35,13 +38,13 @@ for fname in sys.argv[1:] or ["lzss", "yaz0"]:
             d_src, d_dst = c.malloc(raw.nbytes + 64), c.malloc(dst_bytes)
             try:
                 c.h2d(d_src, raw)
-                before = c.big_stream()
+                before = c.big_stream(); seg0 = c.lib.alz_debug_seg_launches(c.h)
                 c.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=q)
                 ms = []
                 for _ in range(3):
                     res, aux = c.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=q); ms.append(c.last_kernel_ms())
-                big = c.big_stream() - before
+                big = c.big_stream() - before; seg = c.lib.alz_debug_seg_launches(c.h) - seg0
             finally:
                 c.free(d_src); c.free(d_dst)
             ok = all(x.status == 0 for x in res)
-            print("%-6s q%d %5d x %d KiB: %8.3f ms kernels = %7.2f GiB/s  (whole-GPU path: %s, ok %s)" % (fname, q, n, size >> 10, min(ms), n * size / min(ms) / 2**30 * 1e3, big > 0, ok), flush=True)
+            print("%-6s q%d %5d x %d KiB: %8.3f ms kernels = %7.2f GiB/s  (whole-GPU path: %s, segments: %s, ok %s)" % (fname, q, n, size >> 10, min(ms), n * size / min(ms) / 2**30 * 1e3, big > 0, seg > 0, ok), flush=True)
