@@ -2608,6 +2608,8 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
     }
 }
 
+#include "alz_encode_seg_seq.h"
+
 // PRS (PRS.cs:104-159) from the start mask: tokens of one, two or four flag bits.  With B = the flag bits written before a token's
 // payload is handed to the flag writer (a literal's before its bit, a short match's behind its four bits, a long match's between its two)
 // the payload lands behind floor(B / 8) + 1 flag bytes -- the byte its bits belong to is in place before it -- except for the offset byte
@@ -3369,7 +3371,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         if (ea != hipSuccess) return ea;
     }
     const bool segmented = d_seg != nullptr && seg_len != 0u;                   // (a batch of few buffers: alz_encode_seg.h -- always behind kernel B)
-    if (segmented || !searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, 32u, true, d_sel, sel_pitch);
+    const u32 wgc = !segmented ? 32u : count < 128u ? 128u : 64u;           // (workgroups per buffer in kernel B: 64 buffers of 64 KiB at quality 8 0.92 -> 0.79 ms with 128, 256 buffers 2.15 -> 2.08 with 64)
+    if (segmented || !searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, wgc, true, d_sel, sel_pitch);
 #define ALZ_SEG(F) if (segmented) { launch_emit_seg<F>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
@@ -3401,6 +3404,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         else hipLaunchKernelGGL((enc_parse_lzo_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }
     case ALZ_FMT_SNAPPY_RAW: {
+        if (segmented) { launch_emit_seg_seq<ALZ_FMT_SNAPPY_RAW>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_SNAPPY_RAW, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         break; }

@@ -214,26 +214,28 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
     }
 }
 
-// Which launches go this way, and with what segments.  One wavefront per buffer fills the GPU from a few thousand buffers on; below that the five
-// small kernels win as soon as a buffer has a few segments.
-#ifndef ALZ_SEG_MAX_STREAMS
-#define ALZ_SEG_MAX_STREAMS 1024u
-#endif
+// Which launches go this way, and with what segments.  One wavefront per buffer takes len / 64 x ~1.7 us whatever the batch; this path is bound by
+// kernel B's throughput (it needs the match array even at quality 0, and runs B without a compare cap).  Where the two cross, in buffers of one format per
+// call (tools/mid_batch_encode.py on 64 KiB and 256 KiB windows of Test.bmp and of program text, profiles/r05_mid_batch_encode.md): quality 0 -- the other
+// side searches inside its parse, no match array -- ~800; quality 1-10 ~1 500-2 000 (Yaz0 wins through 2 048, LZ10 through 1 024); quality 11-15 -- chains of
+// 64 and more candidates, where the cap saves kernel B most -- ~700.
 #ifndef ALZ_SEG_MIN_LEN
 #define ALZ_SEG_MIN_LEN 8192u
 #endif
 #ifndef ALZ_SEG_WAVES
 #define ALZ_SEG_WAVES 8192u      /* segments a launch aims at */
 #endif
-static u32 g_seg_max_streams = ALZ_SEG_MAX_STREAMS;
+static u32 g_seg_max_streams = 0xFFFFFFFFu;       // 0: the path is off; ~0: the rule above; anything else: that many buffers instead of the rule
 }  // namespace
-void alz_debug_set_seg_max_streams(uint32_t v) { g_seg_max_streams = v; }       // (not in the public header: 0 switches the path off -- tests, tools/mid_batch_encode.py)
+void alz_debug_set_seg_max_streams(uint32_t v) { g_seg_max_streams = v; }       // (not in the public header -- tests, tools/mid_batch_encode.py)
 
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
-                     fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
-    if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > g_seg_max_streams || max_len < ALZ_SEG_MIN_LEN) return 0;
+                     fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW;        // (raw Snappy: alz_encode_seg_seq.h)
+    const u32 rule = g.max_chain == 1 ? 768u : g.max_chain < 64 ? 1536u : 512u;
+    const u32 most = g_seg_max_streams == 0xFFFFFFFFu ? rule : g_seg_max_streams;
+    if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
     uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
     if (want < 1024u) want = 1024u;
     const u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);

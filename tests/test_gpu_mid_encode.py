@@ -13,7 +13,7 @@ from auroralib.compression_amd.batch import Context
 from test_gpu_big_encode import _encode, _mixed
 
 pytestmark = pytest.mark.gpu
-FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON]
+FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW]
 OFF = 0xFFFFFFFF
 G = 4096
 
@@ -37,7 +37,7 @@ def _both_ways(c, items, quality, what, **kw):
             b = _encode(c, items, quality, expect_big=False, what=what + ", path off", **kw)
             assert _seg(c) == before, what
         finally:
-            c.lib.alz_debug_seg_max_streams(1024)
+            c.lib.alz_debug_seg_max_streams(0xFFFFFFFF)
     finally:
         c.big_stream(24 << 10)
     assert a == b, what
@@ -56,12 +56,12 @@ def test_ragged_batch(fmt, quality, test_bmp):
         _both_ways(c, items, quality, "ragged")
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW])
 def test_segment_lengths(fmt, test_bmp):
-    """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 1 000 x 24 KiB
-    3 008; windows of Test.bmp 4 KiB apart."""
+    """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 700 x 24 KiB
+    2 112; windows of Test.bmp 4 KiB apart."""
     with Context(0) as c:
-        for n, size in ((300, 65536), (1000, 24000), (64, 262144 + 77)):
+        for n, size in ((300, 65536), (700, 24000), (64, 262144 + 77)):
             items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - size):][:size - (i % 7)]) for i in range(n)]
             _both_ways(c, items, 0, "%d x %d" % (n, size))
         items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - 65536):][:65536]) for i in range(256)]
@@ -91,13 +91,13 @@ def test_settings_and_mixed_formats(test_bmp):
             _both_ways(c, [(A.FMT_LZSS, raw[i * 999:i * 999 + 20000 + i]) for i in range(40)], 8, "lzss %r" % (bits,), lz=lz)
         _both_ways(c, [(A.FMT_LZSS, raw), (A.FMT_LZSS, b"ab" * 60000)] * 20, 8, "compat", strategy=1)
         _both_ways(c, [(A.FMT_LZ10, raw), (A.FMT_LZ10, bytes(100000))] * 20, 8, "vram", min_distance=2)
-        mixed = [([A.FMT_YAZ0, A.FMT_LZ11, A.FMT_LZ4_BLOCK, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_LZ10][i % 6], test_bmp[i * 3000:i * 3000 + 30000 + 100 * i]) for i in range(60)]
+        mixed = [([A.FMT_YAZ0, A.FMT_LZ11, A.FMT_LZ4_BLOCK, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW][i % 6], test_bmp[i * 3000:i * 3000 + 30000 + 100 * i]) for i in range(60)]
         _both_ways(c, mixed, 8, "mixed formats")
         for q in range(16):
             _both_ways(c, [(A.FMT_YAZ0, raw[:40000]), (A.FMT_YAZ0, raw[100000:140000])] * 17, q, "quality %d" % q)
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW])
 def test_capacity_and_canary_device_resident(fmt, test_bmp):
     """alz_encode_batch_device with the whole destination compared (0xA5 canary, guard regions): destinations of exactly the compressed size are
     filled and nothing else; one byte less is OUTPUT_CAPACITY with dst_len 0 and no byte outside the buffer's own range."""
