@@ -1706,6 +1706,7 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     };
     u32 carryw = 0xFFFFFFFFu;       // window whose lane 0 starts a token found by the window in front of it (none: ~0)
+    bool lone = false;              // SEGS: the next cursor is taken on its own (below)
     while (cur <= limit && cur < wend) {
         const int P = cur & ~63;    // window that holds the cursor (windows the cursor jumps over keep their zero mask)
         const int p = P + lane;
@@ -1717,6 +1718,28 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
             if (pbase != want) fetch(want);
             install();
             if (want + TILE <= limit) fetch(want + TILE);
+        }
+        if (SEGS && lone) {
+            // ONE cursor, not a window: in a run or a stretch of repeated rows a jump leaves its window (273 bytes: four windows on), and the window
+            // machinery below -- 64 jumps, the hop loop, the marks, three ballots: ~2 000 cycles for a lone wavefront -- would run once per token.  The
+            // cursor's two entries come from the tile at a uniform address.  Back to windows at the first short jump or capped entry.
+            const uint2 ca = m_unpack(tile[cur - tbase]), cb = m_unpack(tile[cur + 1 - tbase]);
+            if (ca.y != ALZ_CAPPED && cb.y != ALZ_CAPPED) {
+                int cj = 1, csr = 0;
+                if ((int)ca.y >= g.min_len) {
+                    const int l0 = (int)ca.y, l1 = (int)cb.y;
+                    const bool lazyc = l0 <= g.lazy && cur + 1 <= limit;
+                    if (lazyc && l1 > l0) { csr = 2; const int e = cur + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; cj = (cur + 2 > stop ? cur + 2 : stop) - cur; }
+                    else { csr = 1; const int skip = lazyc ? 1 : 0; const int e = cur + l0; const int stop = e < limit + 1 ? e : limit + 1; cj = (cur + 1 + skip > stop ? cur + 1 + skip : stop) - cur; }
+                }
+                cj = __builtin_amdgcn_readfirstlane(cj); csr = __builtin_amdgcn_readfirstlane(csr);
+                if (carry_in && lane == 0) put_mask((u32)P >> 6, 1ull);
+                if (csr && lane == 0) { const u32 bp = (u32)cur + (csr == 2 ? 1u : 0u); put_mask(bp >> 6, 1ull << (bp & 63u)); }
+                cur += cj;
+                if (cj < 64) lone = false;
+                continue;
+            }
+            lone = false;
         }
         // match[p] and match[p+1]
         // (an ALZ_M_LONG entry -- or the raw length behind one -- is never looked at here: both lie at or inside a match this walk has taken)
@@ -1779,6 +1802,7 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
             bits |= s1 | (s2 << 1);
             if (s2 >> 63) carryw = ((u32)P >> 6) + 1u;                         // start in lane 0 of the next window
             rel = (int)r;
+            if (SEGS && __popcll(M) <= 2) lone = true;                         // (a window of one or two tokens: the next cursor on its own)
         }
         else while (rel < 64 && P + rel <= limit) {
             int j, sr;

@@ -812,6 +812,9 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             # one-position-per-lane kernel, the synthetic batches of cfg5 to the two-phase one)
             for f in ("yaz0", "lz4_block"):
                 out.append(realistic_compress(ctx, np, A, synth, f, 8, with_cpu=not args.no_cpu_baseline))
+            # ... and batches of FEW buffers (16 / 256 windows of 64 KiB): parse and emitter over segments, csrc/alz_encode_seg.h
+            for f, q, nb in (("yaz0", 8, 256), ("yaz0", 8, 16), ("yaz0", 0, 256), ("snappy_raw", 0, 256)):
+                out.append(realistic_compress(ctx, np, A, synth, f, q, with_cpu=not args.no_cpu_baseline, n=nb, size=65536, prefix="mid_compress"))
         if "single" in want:
             out.extend(single_stream(ctx, np, A, synth, Plan))
     except Exception as e:                                   # report what ran; the headline line must still come out
@@ -1093,16 +1096,17 @@ def realistic(ctx, np, A, synth, Plan, steps, fmt_name="yaz0"):
         db.close()
 
 
-def realistic_compress(ctx, np, A, synth, fmt_name, quality, with_cpu=True, n=10000):
+def realistic_compress(ctx, np, A, synth, fmt_name, quality, with_cpu=True, n=10000, size=262144, prefix="realistic_compress"):
     """10 000 windows of 256 KiB of Test.bmp (evenly spaced starts: ~8 700 distinct windows, 2.4 GiB of raw input resident in HBM) through
     alz_encode_batch_device at the default quality: the batch encoder on real data, at the metric's own batch size.  Checked by decoding eight
     of the streams back (the bytes themselves are pinned by tests/test_gpu_encode.py); `cpu_port` = the first 256 of the same windows through
-    the C restatement on min(cores, 32) threads."""
+    the C restatement on min(cores, 32) threads.
+    `mid_compress_*` (n = 16 / 256, size = 64 KiB): a batch of FEW buffers -- the chunks of one archive, a directory of files --, where one wavefront per
+    buffer leaves the GPU idle: parse and emitter over segments (csrc/alz_encode_seg.h)."""
     fmt = A.FORMAT_NAMES.index(fmt_name)
     from auroralib.compression_amd import formats as F
     lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
     bmp = np.frombuffer(lz.Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read()), dtype=np.uint8)
-    size = 262144
     starts = [(i * (len(bmp) - size)) // (n - 1) for i in range(n)]
     raw = np.empty(n * size + 64, dtype=np.uint8)
     for i, s0 in enumerate(starts):
@@ -1125,7 +1129,7 @@ def realistic_compress(ctx, np, A, synth, fmt_name, quality, with_cpu=True, n=10
             ms.append(ctx.last_kernel_ms())
         rr = synth.result_records(res)
         ok = bool((rr["status"] == 0).all())
-        for i in range(0, n, n // 8):
+        for i in range(0, n, max(1, n // 8)):
             comp = bytes(ctx.d2h(d_dst, int(rr["dst_len"][i]), offset=int(r["dst_off"][i])))
             sized = fmt_name not in ("lz4_block", "prs_be", "lzo", "snappy_raw")
             got, dr = ctx.decode(fmt, comp, decom_len=size if sized else 0, cap=size, aux0=aux[i].aux0, aux1=aux[i].aux1)
@@ -1141,9 +1145,9 @@ def realistic_compress(ctx, np, A, synth, fmt_name, quality, with_cpu=True, n=10
             cpu_port = cpu_port_encode(np, A, raw, r, min(n, 256), fmt, quality)
         except Exception as e:
             cpu_port = {"error": repr(e)}
-    return {"name": "realistic_compress_%s_q%d" % (fmt_name, quality),
-            "workload": "%s compression of %d windows of 256 KiB of Test.bmp at quality %d, device-resident (ratio %.3f)"
-                        % (fmt_name, n, quality, comp_total / (n * size)),
+    return {"name": "%s_%s_q%d" % (prefix, fmt_name, quality) + ("" if n == 10000 else "_%dx%dk" % (n, size >> 10)),
+            "workload": "%s compression of %d windows of %d KiB of Test.bmp at quality %d, device-resident (ratio %.3f)"
+                        % (fmt_name, n, size >> 10, quality, comp_total / (n * size)),
             "value": round(n * size / (best * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(best, 3), "parity_ok": ok,
             "roofline": roofline(n * size + comp_total, best), "cpu_port": cpu_port}
 
