@@ -658,11 +658,16 @@ __device__ __forceinline__ void benc_wave_search(const u8* data, int n, const En
     }
 }
 
+__device__ __forceinline__ u32 benc_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 // The same function as kernel B runs it (the exact recomputations inside the roles / emit kernels keep the plain form above: the
 // serial emit kernels, one lane per wavefront, ran 12 % slower with this body inlined).  MatchSearch :214-246 with ChainMatches
 // :248-282; returns false when CAP > 0 and a
 // candidate still matched after CAP bytes
-template <bool MINT, bool L16, bool PRUNE = false>
+// WAVEPOS: the wavefront's lanes hold 64 CONSECUTIVE positions (enc_match_kernel).  In a run or a stretch of repeated rows their candidates lie at ONE distance d, and
+// 64 lanes each comparing up to 273 bytes compare the same 337 bytes 64 times over (68 loads per position -- the kernel is bound by the L1's lookups).  Then the mismatches of
+// [P, P + 512) against [P - d, ...) are found once, eight bytes per lane, and every lane reads its length off the mismatch bits: the first one at or behind its own position.
+template <bool MINT, bool L16, bool PRUNE = false, bool WAVEPOS = false>
 __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, const int* p4, const int* pm, const EncGeom& g, int cap,
                                              int& best_d, int& best_l) {
     const u8* dp = data + pos;
@@ -705,19 +710,53 @@ __device__ __forceinline__ bool match_search_b(const u8* data, int n, int pos, c
                 if (chk && pb != own_bl) ok = false;
             }
         }
-        const int cl2 = ok ? cl : pos;                                  // (a candidate that is out: its bytes are not fetched)
+        int len = 0;
+        bool shared = false;                                            // my candidate was measured with the wavefront's (below)
+        if (WAVEPOS) {
+            // (all 64 lanes here; classes of eight or more lanes with one distance, one class after the other while there are such; nobody compares more than
+            // the 512 - 63 bytes the bits reach)
+            u64 todo = __ballot(ok && cmp_max <= 448);
+            const int lane = (int)benc_lane_id();
+            if (__ballot(true) == ~0ull)
+            while (__popcll(todo) >= 8) {
+                const int d0 = __builtin_amdgcn_readlane(dist, (int)__builtin_ctzll(todo));
+                const bool mine = ((todo >> lane) & 1ull) && dist == d0;
+                const u64 same = __ballot(mine);
+                if (__popcll(same) < 8 || pos - lane < d0) break;       // (P - d inside the stream: no group of eight bytes straddles its start)
+                const int x0 = pos - lane + 8 * lane;                    // my eight bytes of [P, P + 512), P = the position of lane 0
+                u64 xr = ~0ull;
+                if (x0 < n) xr = load64(data + x0) ^ load64(data + x0 - d0);     // (up to seven bytes behind n: the buffer's slack; never counted -- cmp_max ends at n)
+                u32 lo = (u32)xr, hi = (u32)(xr >> 32);
+                lo |= lo >> 4; lo |= lo >> 2; lo |= lo >> 1; lo &= 0x01010101u;
+                hi |= hi >> 4; hi |= hi >> 2; hi |= hi >> 1; hi &= 0x01010101u;
+                const u32 bm = (((lo * 0x01020408u) >> 24) & 0xFu) | ((((hi * 0x01020408u) >> 24) & 0xFu) << 4);   // bit b: my byte b differs
+                const u64 nz = __ballot(bm != 0u);
+                const int g0 = lane >> 3, off = lane & 7;
+                const u32 b0 = (u32)__builtin_amdgcn_ds_bpermute(g0 << 2, (int)bm) >> off;
+                const u64 rest = g0 < 63 ? nz >> (g0 + 1) : 0ull;
+                const int g1 = rest ? g0 + 1 + (int)__builtin_ctzll(rest) : 63;
+                const u32 b1 = (u32)__builtin_amdgcn_ds_bpermute(g1 << 2, (int)bm);
+                if (mine) { len = b0 ? (int)__builtin_ctz(b0) : rest ? 8 * g1 + (int)__builtin_ctz(b1) - lane : 512 - lane; shared = true; }
+                todo &= ~same;
+            }
+        }
+        const bool okc = ok && !shared;                                 // the others: each lane its own candidate
+        if (__ballot(okc)) {
+        const int cl2 = okc ? cl : pos;                                 // (a candidate that is out: its bytes are not fetched)
         u64 cv[2]; __builtin_memcpy(cv, data + cl2, 16);                // (the candidate's sixteen bytes as ONE load: the second eight cost no lookup of their own)
         const u64 x = head ^ cv[0];
-        int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-        const bool more = ok && x == 0ull && cmp_max > 8;
+        int len1 = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+        const bool more = okc && x == 0ull && cmp_max > 8;
         if (__ballot(more)) {
             // the second eight bytes the same way (most formats' matches end inside them); the compare loop only behind sixteen
             const u64 y = head2 ^ cv[1];
-            if (more) len = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
+            if (more) len1 = 8 + (y ? (int)(__builtin_ctzll(y) >> 3) : 8);
             const bool more2 = more && y == 0ull && cmp_max > 16;
             // (the compare loop runs for the whole wavefront as long as its longest lane: with the test above a 1 000 KiB Yaz0 stream at
             // quality 8 went 0.58 -> 0.29 ms, an LZ4 block at quality 15 15 -> 5.8)
-            if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len = l3; }
+            if (__ballot(more2)) { const int l3 = wave_match_tail(dp, data + (more2 ? c : 0), cmp_max, more2); if (more2) len1 = l3; }
+        }
+        if (!shared) len = len1;
         }
         if (len > cmp_max) len = cmp_max;
         bool stop = !within;
@@ -998,7 +1037,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
     const int last = first + span - 1 < limit ? first + span - 1 : limit;
     for (int pos = first + (int)threadIdx.x; pos <= last; pos += 256) {
         int bd, bl;
-        const bool okm = match_search_b<MINT, L16, PRUNE>(data, n, pos, p4, pm, g, g.b_cap, bd, bl);
+        const bool okm = match_search_b<MINT, L16, PRUNE, true>(data, n, pos, p4, pm, g, g.b_cap, bd, bl);       // (256 threads, positions in thread order: a wavefront's are consecutive)
         __builtin_nontemporal_store(okm ? m_pack((u32)bd, (u32)bl) : 0xFFFFFFFFu, m + pos);   // (written once, read by the next kernel: past the caches)
     }
   }
