@@ -136,3 +136,49 @@ def test_capacity_and_canary_device_resident(fmt, test_bmp):
                     assert (aux[i].aux0, aux[i].aux1) == (waux.aux0, waux.aux1), tag
                 else:
                     assert (res[i].status, res[i].dst_len) == (A.ST_OUTPUT_CAPACITY, 0), tag
+
+
+@pytest.mark.parametrize("fmt", FAMILY)
+def test_fuzz_path_on_against_path_off(fmt, test_bmp):
+    """Random batches under ALZ_FUZZ_SEED (tools/soak.sh repeats this under other seeds): 2-70 buffers of 0-200 KB of bitmap windows, noise, runs and
+    periodic bytes, any quality, some destinations too small -- the segmented path and one wavefront per buffer must return the same bytes, lengths and
+    statuses (the latter is pinned against the oracle by tests/test_gpu_encode.py), and decode back to the input."""
+    import os
+    seed = int(os.environ.get("ALZ_FUZZ_SEED", "1234")) * 41 + fmt
+    rng = np.random.default_rng(seed)
+    with Context(0) as c:
+        c.big_stream(OFF)
+        for trial in range(6):
+            n = int(rng.integers(2, 70))
+            q = int(rng.integers(0, 16))
+            sizes = [int(2 ** rng.uniform(0, 17.6)) - 1 for _ in range(n)]
+            sizes[int(rng.integers(0, n))] = int(rng.integers(8192, 200000))                 # (long enough for the path to be taken)
+            raws = [_mixed(s, seed * 1000 + trial * 100 + i, test_bmp) if s else b"" for i, s in enumerate(sizes)]
+            caps = [len(r) + len(r) // 4 + 64 if rng.integers(0, 10) else int(rng.integers(0, max(2, len(r) // 2))) for r in raws]
+            streams = (A.Stream * n)()
+            so = do = 0
+            for i, r in enumerate(raws):
+                streams[i] = A.Stream(so, do, len(r), caps[i], 0, 0, 0, fmt)
+                so += (len(r) + 15) // 16 * 16; do += (caps[i] + 15) // 16 * 16
+            src = np.zeros(so + 64, dtype=np.uint8)
+            for i, r in enumerate(raws):
+                src[streams[i].src_off:streams[i].src_off + len(r)] = np.frombuffer(r, dtype=np.uint8)
+            got = []
+            for off in (False, True):
+                if off:
+                    c.lib.alz_debug_seg_max_streams(0)
+                try:
+                    before = _seg(c)
+                    dst, res, aux = c.encode_batch(streams, src, do + 64, quality=q)
+                    assert (_seg(c) > before) == (not off), (seed, trial)
+                finally:
+                    c.lib.alz_debug_seg_max_streams(0xFFFFFFFF)
+                got.append([(res[i].status, res[i].dst_len, res[i].src_used, aux[i].aux0, aux[i].aux1,
+                             bytes(dst[streams[i].dst_off:streams[i].dst_off + res[i].dst_len])) for i in range(n)])
+            for i in range(n):
+                assert got[0][i] == got[1][i], (seed, trial, i, A.FORMAT_NAMES[fmt], q, len(raws[i]), caps[i], got[0][i][:5], got[1][i][:5])
+            i = int(np.argmax([len(r) for r in raws]))
+            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW):
+                sized = fmt != A.FMT_SNAPPY_RAW
+                back, dr = c.decode(fmt, got[0][i][5], decom_len=len(raws[i]) if sized else 0, cap=len(raws[i]), aux0=got[0][i][3], aux1=got[0][i][4])
+                assert dr.status == 0 and back == raws[i], (seed, trial, i)

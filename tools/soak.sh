@@ -6,5 +6,5 @@ cd $GRAFT_REPO_ROOT
 s0=${1:-5000}; n=${2:-20}
 for i in $(seq 0 $((n-1))); do
   seed=$((s0 + 97 * i))
-  ALZ_FUZZ_SEED=$seed timeout 600 python -m pytest tests/test_gpu_decode.py tests/test_gpu_canary.py tests/test_gpu_big_stream.py tests/test_gpu_big_encode.py -q -m gpu -k "fuzz or canary_lzss" 2>&1 | grep -E "^FAILED|AssertionError|passed|failed" | sed "s/^/seed $seed: /" | head -8
+  ALZ_FUZZ_SEED=$seed timeout 600 python -m pytest tests/test_gpu_decode.py tests/test_gpu_canary.py tests/test_gpu_big_stream.py tests/test_gpu_big_encode.py tests/test_gpu_mid_encode.py -q -m gpu -k "fuzz or canary_lzss" 2>&1 | grep -E "^FAILED|AssertionError|passed|failed" | sed "s/^/seed $seed: /" | head -8
 done
