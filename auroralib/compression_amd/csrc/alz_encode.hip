@@ -3451,10 +3451,12 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     case ALZ_FMT_LZHUDSON: ALZ_SEG(ALZ_FMT_LZHUDSON) launch_emit_par<ALZ_FMT_LZHUDSON>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_SMSR00: launch_emit<ALZ_FMT_SMSR00>(stream, count, src, dst, d_streams, d_index, m, d_pos_off, d_prev4, d_prevm, side, d_results, d_aux, g, (u64*)d_mask); break;
     case ALZ_FMT_PRS_BE: {
+        if (segmented) { launch_emit_seg_prs<true>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<true, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         else hipLaunchKernelGGL((enc_emit_prs_kernel<true, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }
     case ALZ_FMT_PRS_LE: {
+        if (segmented) { launch_emit_seg_prs<false>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_emit_prs_kernel<false, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         else hipLaunchKernelGGL((enc_emit_prs_kernel<false, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }

@@ -16,7 +16,7 @@
 //   F  enc_seg_flags_kernel   the flag bytes of groups that straddle segments (the bits each side found, OR-ed), the partial last one
 //                             (FlagWriter.Dispose  IO/FlagWriter.cs:141-145), the results
 // Same bytes as enc_parse_emit_kernel by construction: the same per-window arithmetic (LZSS.cs:132-160, LZ10.cs:113-137, Yaz0 / Yay0 / MIO0 ...
-// through flag_payload), the same order.  Formats whose longest match fits 63 windows (not LZ11 / LZ40: 16 KiB).
+// through flag_payload), the same order.  Formats whose longest match fits 63 windows (not LZ11 / LZ40: 16 KiB); raw Snappy and PRS: alz_encode_seg_seq.h.
 
 struct SegRec { u32 tok, pay, unc, head, tailbits, tailofs, fail, pad; };     // counts (C) -> exclusive prefix (P); the flag bits of straddling groups (E)
 
@@ -232,7 +232,7 @@ void alz_debug_set_seg_max_streams(uint32_t v) { g_seg_max_streams = v; }       
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
-                     fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW;        // (raw Snappy: alz_encode_seg_seq.h)
+                     fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
     const u32 rule = g.max_chain == 1 ? 768u : g.max_chain < 64 ? 1536u : 512u;
     const u32 most = g_seg_max_streams == 0xFFFFFFFFu ? rule : g_seg_max_streams;
     if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;

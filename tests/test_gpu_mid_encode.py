@@ -13,7 +13,7 @@ from auroralib.compression_amd.batch import Context
 from test_gpu_big_encode import _encode, _mixed
 
 pytestmark = pytest.mark.gpu
-FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW]
+FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE]
 OFF = 0xFFFFFFFF
 G = 4096
 
@@ -56,7 +56,7 @@ def test_ragged_batch(fmt, quality, test_bmp):
         _both_ways(c, items, quality, "ragged")
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE])
 def test_segment_lengths(fmt, test_bmp):
     """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 700 x 24 KiB
     2 112; windows of Test.bmp 4 KiB apart."""
@@ -91,13 +91,13 @@ def test_settings_and_mixed_formats(test_bmp):
             _both_ways(c, [(A.FMT_LZSS, raw[i * 999:i * 999 + 20000 + i]) for i in range(40)], 8, "lzss %r" % (bits,), lz=lz)
         _both_ways(c, [(A.FMT_LZSS, raw), (A.FMT_LZSS, b"ab" * 60000)] * 20, 8, "compat", strategy=1)
         _both_ways(c, [(A.FMT_LZ10, raw), (A.FMT_LZ10, bytes(100000))] * 20, 8, "vram", min_distance=2)
-        mixed = [([A.FMT_YAZ0, A.FMT_LZ11, A.FMT_LZ4_BLOCK, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW][i % 6], test_bmp[i * 3000:i * 3000 + 30000 + 100 * i]) for i in range(60)]
+        mixed = [([A.FMT_YAZ0, A.FMT_LZ11, A.FMT_LZ4_BLOCK, A.FMT_MIO0, A.FMT_LZO, A.FMT_SNAPPY_RAW][i % 6], test_bmp[i * 3000:i * 3000 + 30000 + 100 * i]) for i in range(60)]
         _both_ways(c, mixed, 8, "mixed formats")
         for q in range(16):
             _both_ways(c, [(A.FMT_YAZ0, raw[:40000]), (A.FMT_YAZ0, raw[100000:140000])] * 17, q, "quality %d" % q)
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_LE])
 def test_capacity_and_canary_device_resident(fmt, test_bmp):
     """alz_encode_batch_device with the whole destination compared (0xA5 canary, guard regions): destinations of exactly the compressed size are
     filled and nothing else; one byte less is OUTPUT_CAPACITY with dst_len 0 and no byte outside the buffer's own range."""
@@ -178,7 +178,7 @@ def test_fuzz_path_on_against_path_off(fmt, test_bmp):
             for i in range(n):
                 assert got[0][i] == got[1][i], (seed, trial, i, A.FORMAT_NAMES[fmt], q, len(raws[i]), caps[i], got[0][i][:5], got[1][i][:5])
             i = int(np.argmax([len(r) for r in raws]))
-            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW):
-                sized = fmt != A.FMT_SNAPPY_RAW
+            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE):
+                sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE)
                 back, dr = c.decode(fmt, got[0][i][5], decom_len=len(raws[i]) if sized else 0, cap=len(raws[i]), aux0=got[0][i][3], aux1=got[0][i][4])
                 assert dr.status == 0 and back == raws[i], (seed, trial, i)
