@@ -2261,6 +2261,91 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
     }
 }
 
+// Where a segment has no synchronisation point in front of it, the cursor that enters it still follows from the one that entered the segment before:
+// exit(e) = the first cursor at or behind the next boundary B on the chain from e, for every e a jump can land on behind the boundary in front (the
+// first `hist` positions of the segment).  One wavefront per segment sweeps it right to left: exit(p) = p + jump(p) if that is >= B, else exit(p + jump(p)) --
+// from a ring in LDS when the target lies in a window already done, by pointer doubling among the 64 lanes when it lies in the same window.  If the next
+// boundary HAS a synchronisation point s, the sweep stops at the window that holds s and hands exit(s) over directly: no chain through this segment.
+// enc_compose_kernel then strings the entries together (one table lookup per boundary without a synchronisation point), and every wavefront of
+// enc_roles_kernel<true> walks exactly one segment: from the cursor that enters it to the cursor that enters the next.
+#define ALZ_ENTRY_NONE 0xFFFFFFFFu
+#define ALZ_ENTRY_TABLE 0xFFFFFFFEu
+__global__ __launch_bounds__(64) void enc_exit_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, const mentry* __restrict__ match,
+                                                      const u64* __restrict__ pos_off, const u32* __restrict__ sync, u32* __restrict__ direct, u32* __restrict__ ftab,
+                                                      u32 kpitch, u32 seglen, u32 hist, EncGeom g) {
+    __shared__ u32 ring[4096];
+    const u32 k = blockIdx.x, bid = blockIdx.y;
+    const int lane = (int)threadIdx.x;
+    if (k + 1u >= kpitch) return;
+    const u32 sid = index_list[bid];
+    const int n = (int)streams[sid].src_len;
+    const int limit = n - 4;
+    const size_t o = (size_t)bid * kpitch + k + 1u;
+    const int S = (int)(k * seglen), B = S + (int)seglen;
+    if (B > limit) { if (lane == 0) direct[o] = ALZ_ENTRY_NONE; return; }
+    const u32 s = sync[o];
+    if (s == (u32)B) { if (lane == 0) direct[o] = (u32)B; return; }
+    const mentry* m = match + pos_off[sid];
+    const int lo = s != ALZ_ENTRY_NONE ? (int)(s & ~63u) : S;
+    auto ldm = [&](int q) { return q <= limit ? m_unpack(m[q]) : make_uint2(0, 0); };
+    bool bad = false;
+    u32 dval = ALZ_ENTRY_NONE;
+    uint2 a_n = ldm(B - 64 + lane), b_n = ldm(B - 64 + lane + 1);
+    for (int P = B - 64; P >= lo; P -= 64) {
+        const int p = P + lane;
+        const uint2 a = a_n, b = b_n;
+        if (P - 64 >= lo) { a_n = ldm(p - 64); b_n = ldm(p - 63); }
+        if (__ballot(a.y == ALZ_CAPPED || b.y == ALZ_CAPPED)) { bad = true; break; }
+        int jump = 1;
+        if ((int)a.y >= g.min_len) {                                    // (p < B <= limit: searched)
+            const int l0 = (int)a.y, l1 = (int)b.y;
+            const bool lazyc = l0 <= g.lazy && p + 1 <= limit;
+            if (lazyc && l1 > l0) { const int e = p + 1 + l1; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 2 > stop ? p + 2 : stop) - p; }
+            else { const int skip = lazyc ? 1 : 0; const int e = p + l0; const int stop = e < limit + 1 ? e : limit + 1; jump = (p + 1 + skip > stop ? p + 1 + skip : stop) - p; }
+        }
+        const int t = p + jump;
+        u32 val = (u32)t; int res = 1, tl = lane;
+        if (t < B) { if (t >= P + 64) val = ring[t & 4095]; else { res = 0; tl = t - P; } }
+        while (__ballot(res == 0)) {
+            const u32 tv = (u32)__builtin_amdgcn_ds_bpermute(tl << 2, (int)val);
+            const int tr = __builtin_amdgcn_ds_bpermute(tl << 2, res), tt = __builtin_amdgcn_ds_bpermute(tl << 2, tl);
+            if (res == 0) { if (tr) { val = tv; res = 1; } else tl = tt; }
+        }
+        ring[p & 4095] = val;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (s != ALZ_ENTRY_NONE && P == lo) dval = (u32)__builtin_amdgcn_readlane((int)val, (int)(s - (u32)P));
+    }
+    if (s != ALZ_ENTRY_NONE) { if (lane == 0) direct[o] = bad ? ALZ_ENTRY_NONE : dval; return; }
+    if (lane == 0) direct[o] = bad ? ALZ_ENTRY_NONE : ALZ_ENTRY_TABLE;
+    if (!bad) {
+        u32* tab = ftab + ((size_t)bid * kpitch + k) * hist;
+        for (u32 i = (u32)lane; i < hist; i += 64) tab[i] = ring[((u32)S + i) & 4095u];      // (hist <= seglen: all of them swept)
+    }
+}
+
+// the cursor that enters every segment: 0; exit(synchronisation point) where the boundary has one; else the table of the segment in front at the cursor that entered IT
+__global__ __launch_bounds__(64) void enc_compose_kernel(const u32* __restrict__ direct, const u32* __restrict__ ftab, u32* __restrict__ entry, u32 kpitch, u32 seglen, u32 hist) {
+    __shared__ u32 d[8192];
+    const u32 bid = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const size_t base = (size_t)bid * kpitch;
+    for (u32 k = (u32)lane; k < kpitch; k += 64) d[k] = k ? direct[base + k] : 0u;
+    __syncthreads();
+    if (lane != 0) return;
+    u32 c = 0; bool known = true;
+    entry[base] = 0u;
+    for (u32 k = 1; k < kpitch; k++) {
+        const u32 v = d[k];
+        u32 e = ALZ_ENTRY_NONE;
+        if (v == ALZ_ENTRY_TABLE) {
+            if (known) { const u32 i = c - (k - 1u) * seglen; e = i < hist ? ftab[(base + k - 1u) * hist + i] : ALZ_ENTRY_NONE; }
+            if (e == ALZ_ENTRY_NONE) known = false; else c = e;
+        } else if (v != ALZ_ENTRY_NONE) { e = v; c = v; known = true; }
+        else known = false;                                             // (behind the last searched position, or a capped entry in the segment: the walk in front carries on)
+        entry[base + k] = e;
+    }
+}
+
 #include "alz_encode_seg.h"
 
 int isqrt_floor(int v) { int r = 0; while ((r + 1) * (r + 1) <= v) r++; return r; }

@@ -229,7 +229,7 @@ static u32 g_seg_max_streams = 0xFFFFFFFFu;       // 0: the path is off; ~0: the
 }  // namespace
 void alz_debug_set_seg_max_streams(uint32_t v) { g_seg_max_streams = v; }       // (not in the public header -- tests, tools/mid_batch_encode.py)
 
-int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax) {
+int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
                      fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
@@ -238,13 +238,29 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
     uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
     if (want < 1024u) want = 1024u;
-    const u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
+    u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
+    const u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;                  // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
+    if (sl < hist) sl = hist;
+    if (hist_out) *hist_out = hist;
     if (seg_len) *seg_len = sl;
     if (kmax) *kmax = (max_len + sl - 1u) / sl;
     return 1;
 }
-size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax) { return (size_t)count * kmax * (sizeof(SegRec) + sizeof(u32)) + (size_t)count * 16u + 64u; }   // records, totals, synchronisation points
+size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax, uint32_t hist) { return (size_t)count * kmax * (sizeof(SegRec) + (3u + hist) * sizeof(u32)) + (size_t)count * 16u + 64u; }   // records, totals; synchronisation points, direct exits, entries, exit tables
 namespace {
+
+// the parse of a launch on this path: synchronisation points, exits, the cursor that enters every segment, the walk -- the start mask is complete behind it
+static void launch_seg_walk(hipStream_t s, u32 count, const u8* src, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
+                            const int* prev4, const int* prevm, u64* mask, u32* sync, u32 seglen, u32 kmax, const EncGeom& g) {
+    const u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;
+    u32* direct = sync + (size_t)count * kmax;
+    u32* entry = direct + (size_t)count * kmax;
+    u32* ftab = entry + (size_t)count * kmax;
+    hipLaunchKernelGGL(enc_sync_kernel, dim3(kmax, count), dim3(64), 0, s, streams, index, (const mentry*)match, pos_off, sync, kmax, seglen, g);
+    hipLaunchKernelGGL(enc_exit_kernel, dim3(kmax, count), dim3(64), 0, s, streams, index, (const mentry*)match, pos_off, (const u32*)sync, direct, ftab, kmax, seglen, hist, g);
+    hipLaunchKernelGGL(enc_compose_kernel, dim3(count), dim3(64), 0, s, (const u32*)direct, (const u32*)ftab, entry, kmax, seglen, hist);
+    hipLaunchKernelGGL((enc_roles_kernel<true>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0, (const u32*)entry, kmax);
+}
 
 template <int FMT>
 static void launch_emit_seg(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
@@ -252,8 +268,7 @@ static void launch_emit_seg(hipStream_t s, u32 count, const u8* src, u8* dst, co
     SegRec* seg = (SegRec*)d_seg;
     u32* stot = (u32*)((u8*)d_seg + (size_t)count * kmax * sizeof(SegRec));
     u32* sync = stot + 4 * (size_t)count;
-    hipLaunchKernelGGL(enc_sync_kernel, dim3(kmax, count), dim3(64), 0, s, streams, index, (const mentry*)match, pos_off, sync, kmax, seglen, g);
-    hipLaunchKernelGGL((enc_roles_kernel<true>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0, (const u32*)sync, kmax);
+    launch_seg_walk(s, count, src, streams, index, match, pos_off, prev4, prevm, mask, sync, seglen, kmax, g);
     hipLaunchKernelGGL((enc_seg_kernel<FMT, false>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, (const u32*)stot, kmax, seglen, g);
     hipLaunchKernelGGL(enc_seg_prefix_kernel, dim3(count), dim3(64), 0, s, streams, index, seg, stot, kmax, seglen);
     hipLaunchKernelGGL((enc_seg_kernel<FMT, true>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, (const u32*)stot, kmax, seglen, g);

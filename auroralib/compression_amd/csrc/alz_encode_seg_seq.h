@@ -165,8 +165,7 @@ static void launch_emit_seg_seq(hipStream_t s, u32 count, const u8* src, u8* dst
     SegRec* seg = (SegRec*)d_seg;
     u32* stot = (u32*)((u8*)d_seg + (size_t)count * kmax * sizeof(SegRec));
     u32* sync = stot + 4 * (size_t)count;
-    hipLaunchKernelGGL(enc_sync_kernel, dim3(kmax, count), dim3(64), 0, s, streams, index, (const mentry*)match, pos_off, sync, kmax, seglen, g);
-    hipLaunchKernelGGL((enc_roles_kernel<true>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0, (const u32*)sync, kmax);
+    launch_seg_walk(s, count, src, streams, index, match, pos_off, prev4, prevm, mask, sync, seglen, kmax, g);
     hipLaunchKernelGGL((enc_seq_seg_kernel<FMT, false>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, kmax, seglen, g);
     hipLaunchKernelGGL((enc_seq_prefix_kernel<FMT>), dim3(count), dim3(64), 0, s, streams, index, seg, stot, kmax, seglen);
     hipLaunchKernelGGL((enc_seq_seg_kernel<FMT, true>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, kmax, seglen, g);
@@ -399,8 +398,7 @@ static void launch_emit_seg_prs(hipStream_t s, u32 count, const u8* src, u8* dst
     SegRec* seg = (SegRec*)d_seg;
     u32* stot = (u32*)((u8*)d_seg + (size_t)count * kmax * sizeof(SegRec));
     u32* sync = stot + 4 * (size_t)count;
-    hipLaunchKernelGGL(enc_sync_kernel, dim3(kmax, count), dim3(64), 0, s, streams, index, (const mentry*)match, pos_off, sync, kmax, seglen, g);
-    hipLaunchKernelGGL((enc_roles_kernel<true>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, count, match, pos_off, prev4, prevm, mask, g, 0, (const u32*)sync, kmax);
+    launch_seg_walk(s, count, src, streams, index, match, pos_off, prev4, prevm, mask, sync, seglen, kmax, g);
     hipLaunchKernelGGL((enc_prs_seg_kernel<BIG, false>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, kmax, seglen, g);
     hipLaunchKernelGGL(enc_prs_prefix_kernel, dim3(count), dim3(64), 0, s, streams, index, seg, stot, kmax, seglen);
     hipLaunchKernelGGL((enc_prs_seg_kernel<BIG, true>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, kmax, seglen, g);

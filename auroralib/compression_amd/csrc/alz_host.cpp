@@ -934,9 +934,10 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         any_match = any_match || alz_encode_geom_needs_match(lvl2 ? ALZ_FMT_FASTLZ : f, g);
         any_mask = any_mask || alz_encode_format_needs_mask(lvl2 ? ALZ_FMT_FASTLZ : f);
         // a batch of few buffers of a flag-bit format: parse and emitter over segments (alz_encode_seg.h) -- behind kernel B and the roles walk
-        if (!lvl2 && !c->exact && c->variant == 0 && alz_encode_segmented(f, g, cnt[f], max_len, &seg_len[f], &seg_kmax[f])) {
+        uint32_t seg_hist = 0;
+        if (!lvl2 && !c->exact && c->variant == 0 && alz_encode_segmented(f, g, cnt[f], max_len, &seg_len[f], &seg_kmax[f], &seg_hist)) {
             any_match = any_mask = true;
-            const size_t b = alz_encode_seg_bytes(cnt[f], seg_kmax[f]); if (b > seg_bytes) seg_bytes = b;
+            const size_t b = alz_encode_seg_bytes(cnt[f], seg_kmax[f], seg_hist); if (b > seg_bytes) seg_bytes = b;
         }
     }
     // ---- a handful of big streams: each of them on the whole GPU (alz_encode_big.h).  A stream the path declines (too many positions that

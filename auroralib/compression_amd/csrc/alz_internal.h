@@ -46,9 +46,9 @@ int alz_encode_geom_narrows(const void* geom);                  // 1: kernel A l
 int alz_encode_format_needs_mask(int fmt);                      // 1: the format's emitter reads the start mask of enc_roles_kernel (zeroed before the launch)
 int alz_encode_geom_needs_match(int fmt, const void* geom);   // 0: the search runs inside the parse + emit kernel (no kernel B, no match array)
 // a batch of few buffers of a flag-bit format: parse and emitter as five small kernels over segments (alz_encode_seg.h); 1: taken -- then the launch
-// needs the match array, the zeroed start mask and alz_encode_seg_bytes(count, *kmax) of scratch
-int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax);
-size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax);
+// needs the match array, the zeroed start mask and alz_encode_seg_bytes(count, *kmax, *hist) of scratch
+int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist);
+size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax, uint32_t hist);
 void alz_debug_set_seg_max_streams(uint32_t v);
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
