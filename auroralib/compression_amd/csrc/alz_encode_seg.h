@@ -4,9 +4,12 @@
 // enc_parse_emit_kernel gives a buffer ONE wavefront for the parse and its tokens: ~1.7 us per window of 64 positions whatever else the GPU is
 // doing, 1.7 ms per 64 KiB, while 256 buffers leave 24 of a CU's 25 places empty (tools/mid_batch_encode.py: 16-256 buffers of 64 KiB as Yaz0 at
 // quality 8 took 1.8-3.4 ms).  Only the WALK of the parse is serial (cursor += jump[cursor]); everything the emitter does with the token starts is
-// prefix sums over positions.  So, for such batches (alz_encode_segmented):
-//   R  enc_roles_kernel       the walk alone, one wavefront per buffer: a bit per position "a match token starts here" (windows the cursor jumps over
-//                             cost nothing; positions kernel B had capped are searched exactly and patched into the match array)
+// prefix sums over positions -- and the walk itself has points every walk passes.  So, for such batches (alz_encode_segmented):
+//   S  enc_sync_kernel        per segment boundary the last SYNCHRONISATION POINT in front of it: a position no jump crosses, which every walk lands on
+//   X  enc_exit_kernel        per segment exit(e), the first cursor behind the next boundary on the chain from e, by a right-to-left sweep (down to the boundary's
+//      enc_compose_kernel     synchronisation point, or over the whole segment into a table); the cursor that enters every segment, strung together per buffer
+//   R  enc_roles_kernel<true> the walk, one wavefront per segment: a bit per position "a match token starts here" (kernel B runs without a compare cap on this
+//                             path: no position is left for the walk to search)
 //   C  enc_seg_kernel<false>  one wavefront per SEGMENT of a buffer (1-8 Ki positions, so that the launch has a few thousand): the tokens, payload
 //                             bytes and literal-section bytes that start in it.  What it needs from the left is the end of the last match that
 //                             starts before the segment: at most maxLength back in the start mask
@@ -216,9 +219,10 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 
 // Which launches go this way, and with what segments.  One wavefront per buffer takes len / 64 x ~1.7 us whatever the batch; this path is bound by
 // kernel B's throughput (it needs the match array even at quality 0, and runs B without a compare cap).  Where the two cross, in buffers of one format per
-// call (tools/mid_batch_encode.py on 64 KiB and 256 KiB windows of Test.bmp and of program text, profiles/r05_mid_batch_encode.md): quality 0 -- the other
-// side searches inside its parse, no match array -- ~800; quality 1-10 ~1 500-2 000 (Yaz0 wins through 2 048, LZ10 through 1 024); quality 11-15 -- chains of
-// 64 and more candidates, where the cap saves kernel B most -- ~700.
+// call (tools/mid_batch_encode.py on 64 KiB and 256 KiB windows of Test.bmp and of program text, profiles/r05_mid_batch_encode_sweep2.txt): quality 0 -- the other
+// side searches inside its parse, no match array -- between 1 024 (Yaz0 2.53 -> 2.06 ms, LZ10 2.05 -> 1.84, Snappy 2.88 -> 1.88) and 2 048 (3.43 -> 4.13);
+// quality 1-10 around 2 048 (Yaz0 still wins: 12.7 -> 11.8 at quality 8; LZ10 loses: 5.3 -> 5.7); quality 11-15 -- chains of 64 and more candidates, where
+// the cap saves kernel B most -- between 512 (23.4 -> 17.7) and 1 024 (29.2 -> 34.1).
 #ifndef ALZ_SEG_MIN_LEN
 #define ALZ_SEG_MIN_LEN 8192u
 #endif
@@ -233,7 +237,7 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
                      fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
-    const u32 rule = g.max_chain == 1 ? 768u : g.max_chain < 64 ? 1536u : 512u;
+    const u32 rule = g.max_chain == 1 ? 1280u : g.max_chain < 64 ? 1536u : 512u;
     const u32 most = g_seg_max_streams == 0xFFFFFFFFu ? rule : g_seg_max_streams;
     if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
     uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;

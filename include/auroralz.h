@@ -229,7 +229,7 @@ int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
  * over "where would a cursor at p go", the emission by prefix sums -- instead of by one workgroup and one wavefront per buffer: what
  * a format class's Compress(ReadOnlySpan<byte>, Stream) makes of ONE buffer (Interfaces/ICompressionEncoder.cs; the reference's benchmark
  * compresses ONE 1 000 KiB buffer, TestAllAlgorithms.cs:44-69).  The bytes are the same either way.
- * Between the two -- more buffers than that, fewer than fill the GPU with a wavefront each (768 / 1 536 / 512 of a format per call at quality 0 / 1-10 / 11-15), the longest
+ * Between the two -- more buffers than that, fewer than fill the GPU with a wavefront each (1 280 / 1 536 / 512 of a format per call at quality 0 / 1-10 / 11-15), the longest
  * of at least 8 KiB: the chunks of one archive, a directory of files -- the flag-bit formats with a bounded match length (LZSS, LZ10, Yaz0, Yay0, MIO0, CLZ0, BLZ, LZHudson),
  * raw Snappy and PRS parse from one synchronisation point of the walk to the next (a position no jump crosses) with a wavefront each and emit per segment
  * (csrc/alz_encode_seg.h).  No switch: the bytes are the same, and a context in exact or forced-variant mode never goes that way.
