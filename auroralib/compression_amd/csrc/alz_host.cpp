@@ -957,6 +957,16 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
             const double mib = streams[i].src_len / 1048576.0;
             t_big += 0.10 + 0.10 * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;
         }
+        // (side by side is no longer one wavefront per buffer where the segmented parse + emit takes the launch, alz_encode_seg.h: kernel A's one workgroup per
+        // buffer is what is left of the longest buffer's serial time, ~2.2 ms per MiB, + ~0.14 ms of small kernels per format + ~0.05 ms per MiB of the whole call --
+        // tools/mid_batch_encode.py with ALZ_MID_BIG=on / off, profiles/r05_mid_big_vs_seg.txt: 4 x 64 KiB 0.37 one by one against 0.24, 8 x 256 KiB 0.96 / 0.90,
+        // 16 x 1 MB 3.33 / 3.50)
+        {
+            bool seg_all = true; int nf = 0; double mib_all = 0;
+            for (int f = 0; f < ALZ_FMT_COUNT; f++) if (cnt[f]) { nf++; seg_all = seg_all && seg_len[f] != 0; }
+            for (uint32_t i = 0; i < n; i++) mib_all += streams[i].src_len / 1048576.0;
+            if (seg_all) { const double t_seg = 0.14 * nf + 2.2 * (max_len / 1048576.0) + 0.05 * mib_all; if (t_seg < t_side) t_side = t_seg; }
+        }
         all = all && t_big < t_side;
         if (all) {
             HIP_TRY(hipSetDevice(c->device));

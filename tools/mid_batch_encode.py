@@ -21,6 +21,7 @@ size = int(os.environ.get("ALZ_MID_SIZE", str(262144)))
 c = Context(0)
 import ctypes as C
 c.lib.alz_debug_seg_launches.restype = C.c_uint64; c.lib.alz_debug_seg_launches.argtypes = [C.c_void_p]
+if os.environ.get("ALZ_MID_BIG") == "off": c.big_stream(0xFFFFFFFF)                                # (the whole-GPU path of ONE buffer at a time off)
 if os.environ.get("ALZ_MID_SEG") is not None: c.lib.alz_debug_seg_max_streams(int(os.environ["ALZ_MID_SEG"]))      # (0: the segmented parse + emit off)
 for fname in sys.argv[1:] or ["lzss", "yaz0"]:
     fmt = A.FORMAT_NAMES.index(fname)
