@@ -3373,6 +3373,24 @@ __global__ __launch_bounds__(256) void enc_narrow_lds_kernel(const u8* __restric
     }
 }
 
+// kernel A over segments (alz_encode_seg.h): `aseg` = the scratch behind the launch's segment records, 0 = one workgroup per buffer
+struct AsegPlan { void* mem; u32 SA, ka, W, stride; };
+static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
+                              int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes, bool no_win);
+static hipError_t launch_prev_aseg(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count, uint32_t max_len,
+                                   int* d_prev4, const uint64_t* d_pos_off, const EncGeom& g15, const AsegPlan& a) {
+    const size_t V = (size_t)count * a.ka;
+    u8* base = (u8*)a.mem;
+    alz_stream* vs = (alz_stream*)base; base += V * sizeof(alz_stream);
+    u64* vpos = (u64*)base; base += V * sizeof(u64);
+    u32* vindex = (u32*)base; base += ((V * sizeof(u32)) + 63u) & ~(size_t)63u;
+    int* seg4 = (int*)base;
+    hipLaunchKernelGGL(enc_aseg_setup_kernel, dim3((u32)((V + 255u) / 256u)), dim3(256), 0, stream, d_streams, d_index, count, vs, vindex, vpos, a.ka, a.SA, a.W, a.stride);
+    const hipError_t e = launch_prev(stream, src, vs, vindex, (u32)V, seg4, nullptr, vpos, g15, 0, false, true);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(enc_aseg_gather_kernel, dim3((max_len + 255u) / 256u, count), dim3(256), 0, stream, d_streams, d_index, (const int*)seg4, d_prev4, d_pos_off, a.ka, a.SA, a.W, a.stride);
+    return hipSuccess;
+}
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
                               int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes = false, bool no_win = false) {
     if (g.hash_bits < 15 || g.hash_bits > 20) return hipErrorInvalidValue;
@@ -3471,6 +3489,12 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     g.b_cap = (d_seg != nullptr && seg_len != 0u) ? ALZ_LEN_CAP : choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
+    AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
+    if (d_seg != nullptr && seg_len != 0u && tail == 0) {
+        size_t ab = 0; u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;
+        if (alz_encode_aseg(geom, count, max_len, &aseg.SA, &aseg.ka, &aseg.W, &aseg.stride, &ab))
+            aseg.mem = (u8*)d_seg + ((alz_encode_seg_bytes(count, seg_kmax, hist) + 255u) & ~(size_t)255u);
+    }
     if (narrows_links(g) && d_narrow != nullptr && d_sel != nullptr) {
         // Kernel A at 15 bits and the links of the finder's own hash width narrowed from them (enc_narrow_kernel), into an array of their own: what
         // follows reads its links there (the min-length table's links, where there are any, are kernel A's own either way).  Which streams:
@@ -3496,7 +3520,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
         };
         if (uses_win_prev(g) && !g.use_min_table) {
-            const hipError_t e15 = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g15, tail);
+            const hipError_t e15 = aseg.mem ? launch_prev_aseg(stream, src, d_streams, d_index, count, max_len, d_prev4, d_pos_off, g15, aseg)
+                                            : launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g15, tail);
             if (e15 != hipSuccess) return e15;
             narrow(d_index);
         } else {
@@ -3515,7 +3540,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         }
         d_prev4 = d_narrow;
     } else {
-        const hipError_t ea = launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+        const hipError_t ea = (aseg.mem && g.hash_bits == 15) ? launch_prev_aseg(stream, src, d_streams, d_index, count, max_len, d_prev4, d_pos_off, g, aseg)
+                                                              : launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
         if (ea != hipSuccess) return ea;
     }
     const bool segmented = d_seg != nullptr && seg_len != 0u;                   // (a batch of few buffers: alz_encode_seg.h -- always behind kernel B)

@@ -253,6 +253,58 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
 size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax, uint32_t hist) { return (size_t)count * kmax * (sizeof(SegRec) + (3u + hist) * sizeof(u32)) + (size_t)count * 16u + 64u; }   // records, totals; synchronisation points, direct exits, entries, exit tables
 namespace {
 
+// ---- kernel A for a batch that does not even fill the CUs with a workgroup per buffer (at most 128 buffers): over overlapping SEGMENTS of the buffers, as
+// alz_encode_big.h does it for ONE buffer.  Segment j of a buffer is hashed from W = maxDistance (whole windows) in front of j * SA on: a link that would
+// reach in front of the warm-up is longer than maxDistance, which ends a chain walk exactly as no link does (LzChainMatchFinder.cs:259-260; the narrowing
+// of 15-bit chains stops there too).  The segments are "virtual streams" of enc_prev_cu_kernel (descriptors written on the device); the 16-bit links --
+// distances, so they need no rebasing -- are gathered into the buffer's own array.  One workgroup per buffer took 1.55 us per KiB of the LONGEST buffer.
+__global__ __launch_bounds__(256) void enc_aseg_setup_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, u32 count, alz_stream* __restrict__ vs,
+                                                             u32* __restrict__ vindex, u64* __restrict__ vpos, u32 ka, u32 SA, u32 W, u32 stride) {
+    const u32 t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count * ka) return;
+    const u32 bid = t / ka, j = t % ka;
+    alz_stream s = streams[index_list[bid]];
+    const int limit = (int)s.src_len - 4;
+    const u32 first = j * SA;
+    if ((int)first > limit) { vindex[t] = 0xFFFFFFFFu; return; }          // (no such segment: kernel A leaves the slot alone)
+    const u32 start = first >= W ? first - W : 0u;
+    u32 end = first + SA; if (end > (u32)limit + 1u) end = (u32)limit + 1u;
+    s.src_off += start;
+    s.src_len = end - start + 3u;                                          // the last hashed position is end - 1: four bytes
+    vs[t] = s; vindex[t] = t; vpos[t] = (u64)t * stride;
+}
+__global__ __launch_bounds__(256) void enc_aseg_gather_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, const int* __restrict__ seg4,
+                                                              int* __restrict__ fin4, const u64* __restrict__ pos_off, u32 ka, u32 SA, u32 W, u32 stride) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x, bid = blockIdx.y;
+    const u32 sid = index_list[bid];
+    const int limit = (int)streams[sid].src_len - 4;
+    if ((int)p > limit) return;
+    const u32 j = p / SA, first = j * SA, start = first >= W ? first - W : 0u, local = p - start;
+    reinterpret_cast<unsigned short*>(fin4 + pos_off[sid])[p] = reinterpret_cast<const unsigned short*>(seg4 + (size_t)(bid * ka + j) * stride)[local];
+}
+#ifndef ALZ_ASEG_MAX_STREAMS
+#define ALZ_ASEG_MAX_STREAMS 128u
+#endif
+}  // namespace
+// 1: kernel A of such a launch runs over segments; *bytes: its scratch (behind alz_encode_seg_bytes in the same allocation)
+int alz_encode_aseg(const void* geom, uint32_t count, uint32_t max_len, uint32_t* sa_out, uint32_t* ka_out, uint32_t* w_out, uint32_t* stride_out, size_t* bytes) {
+    EncGeom g; memcpy(&g, geom, sizeof(g));
+    if (bytes) *bytes = 0;
+    const u32 W = ((u32)g.max_dist + 63u) & ~63u;
+    // (16-bit links, no min-length table -- quality < 10 --, and a kernel A of ONE pass at 15 bits: the finder's own 15 bits, or narrowed afterwards in windows up to 8 KiB)
+    const bool plain = g.hash_bits == 15, narrowed = g.link16 && g.nprops <= 1 && g.hash_bits > 15 && g.max_dist <= 8192;
+    if (!g.link16 || g.use_min_table || !(plain || narrowed) || count == 0 || count > ALZ_ASEG_MAX_STREAMS || max_len < 4u * W) return 0;
+    uint64_t sa = ((uint64_t)count * max_len + 511u) / 512u;              // ~512 workgroups: two per CU
+    if (sa < 2u * W) sa = 2u * W;
+    const u32 SA = (u32)((sa + 63u) & ~(uint64_t)63u), ka = (max_len + SA - 1u) / SA, stride = (SA + W) / 2u + 16u;
+    const uint64_t b = (uint64_t)count * ka * ((uint64_t)stride * 4u + sizeof(alz_stream) + 4u + 8u) + 256u;
+    if (b > (1ull << 30)) return 0;
+    if (sa_out) *sa_out = SA; if (ka_out) *ka_out = ka; if (w_out) *w_out = W; if (stride_out) *stride_out = stride;
+    if (bytes) *bytes = (size_t)b;
+    return 1;
+}
+namespace {
+
 // the parse of a launch on this path: synchronisation points, exits, the cursor that enters every segment, the walk -- the start mask is complete behind it
 static void launch_seg_walk(hipStream_t s, u32 count, const u8* src, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
                             const int* prev4, const int* prevm, u64* mask, u32* sync, u32 seglen, u32 kmax, const EncGeom& g) {

@@ -937,7 +937,8 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         uint32_t seg_hist = 0;
         if (!lvl2 && !c->exact && c->variant == 0 && alz_encode_segmented(f, g, cnt[f], max_len, &seg_len[f], &seg_kmax[f], &seg_hist)) {
             any_match = any_mask = true;
-            const size_t b = alz_encode_seg_bytes(cnt[f], seg_kmax[f], seg_hist); if (b > seg_bytes) seg_bytes = b;
+            size_t ab = 0; (void)alz_encode_aseg(g, cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, &ab);
+            const size_t b = ((alz_encode_seg_bytes(cnt[f], seg_kmax[f], seg_hist) + 255) & ~(size_t)255) + ab; if (b > seg_bytes) seg_bytes = b;
         }
     }
     // ---- a handful of big streams: each of them on the whole GPU (alz_encode_big.h).  A stream the path declines (too many positions that
@@ -957,15 +958,19 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
             const double mib = streams[i].src_len / 1048576.0;
             t_big += 0.10 + 0.10 * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;
         }
-        // (side by side is no longer one wavefront per buffer where the segmented parse + emit takes the launch, alz_encode_seg.h: kernel A's one workgroup per
-        // buffer is what is left of the longest buffer's serial time, ~2.2 ms per MiB, + ~0.14 ms of small kernels per format + ~0.05 ms per MiB of the whole call --
-        // tools/mid_batch_encode.py with ALZ_MID_BIG=on / off, profiles/r05_mid_big_vs_seg.txt: 4 x 64 KiB 0.37 one by one against 0.24, 8 x 256 KiB 0.96 / 0.90,
-        // 16 x 1 MB 3.33 / 3.50)
+        // (side by side is no longer one wavefront per buffer where the segmented parse + emit takes the launch, alz_encode_seg.h: what is left of the longest
+        // buffer's serial time is kernel A -- over segments too, for these few buffers: ~0.9 ms per MiB; one workgroup per buffer where that does not apply: 2.2 --
+        // + ~0.14 ms of small kernels per format + ~0.08 ms per MiB of the whole call.  tools/mid_batch_encode.py with ALZ_MID_BIG=on / off,
+        // profiles/r05_mid_big_vs_seg.txt: 4 x 256 KiB at quality 8 0.47 ms one by one against 0.42, 8 x 1 MB 1.66 / 1.73, 16 x 1 MB 3.33 / 2.18)
         {
-            bool seg_all = true; int nf = 0; double mib_all = 0;
-            for (int f = 0; f < ALZ_FMT_COUNT; f++) if (cnt[f]) { nf++; seg_all = seg_all && seg_len[f] != 0; }
+            bool seg_all = true, aseg_all = true; int nf = 0; double mib_all = 0;
+            for (int f = 0; f < ALZ_FMT_COUNT; f++) if (cnt[f]) {
+                nf++; seg_all = seg_all && seg_len[f] != 0;
+                aseg_all = aseg_all && alz_encode_aseg(geom.data() + f * alz_encode_geom_size(), cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, nullptr);
+            }
             for (uint32_t i = 0; i < n; i++) mib_all += streams[i].src_len / 1048576.0;
-            if (seg_all) { const double t_seg = 0.14 * nf + 2.2 * (max_len / 1048576.0) + 0.05 * mib_all; if (t_seg < t_side) t_side = t_seg; }
+            const bool q0 = st.quality == 0;                                  // (no narrowing behind kernel A, one candidate per position in kernel B: 8 x 1 MB 0.99 one by one / 0.68)
+            if (seg_all) { const double t_seg = 0.14 * nf + (aseg_all ? (q0 ? 0.45 : 0.9) : 2.2) * (max_len / 1048576.0) + (q0 ? 0.03 : 0.08) * mib_all; if (t_seg < t_side) t_side = t_seg; }
         }
         all = all && t_big < t_side;
         if (all) {

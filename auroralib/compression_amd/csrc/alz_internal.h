@@ -50,6 +50,7 @@ int alz_encode_geom_needs_match(int fmt, const void* geom);   // 0: the search r
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist);
 size_t alz_encode_seg_bytes(uint32_t count, uint32_t kmax, uint32_t hist);
 void alz_debug_set_seg_max_streams(uint32_t v);
+int alz_encode_aseg(const void* geom, uint32_t count, uint32_t max_len, uint32_t* sa, uint32_t* ka, uint32_t* w, uint32_t* stride, size_t* bytes);   // kernel A over segments for at most 128 buffers (alz_encode_seg.h)
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
