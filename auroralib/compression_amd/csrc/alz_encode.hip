@@ -3398,7 +3398,10 @@ static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_strea
     else if (g.hash_bits == 15 && !g.use_min_table) hipLaunchKernelGGL((enc_prev_cu_kernel<2, false>), dim3(count), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     else {
         const u32 passes = (1u << (g.hash_bits - 15)) + (g.use_min_table ? 2u : 0u);       // (as the kernel counts them)
-        hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count, split_passes ? passes : 1u), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
+        // (a workgroup per (stream, pass) where a workgroup per stream leaves CUs idle: 16 x 64 KiB as raw Snappy at quality 8 -- 16 passes -- 383 -> 32 us of the
+        // call's 560; from 256 streams on the two arrangements are the same work on the same CUs)
+        const bool split = split_passes || count < 256u;
+        hipLaunchKernelGGL((enc_prev_cu_kernel<3, false>), dim3(count, split ? passes : 1u), dim3(1024), 0, stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
     }
     return hipSuccess;
 }
