@@ -245,6 +245,7 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
     const u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;                  // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
     if (sl < hist) sl = hist;
+    while ((max_len + sl - 1u) / sl > 8192u) sl += 64u;                     // (enc_compose_kernel holds a buffer's boundaries in LDS; never reached: a launch aims at 8 192 segments in all)
     if (hist_out) *hist_out = hist;
     if (seg_len) *seg_len = sl;
     if (kmax) *kmax = (max_len + sl - 1u) / sl;

@@ -182,3 +182,14 @@ def test_fuzz_path_on_against_path_off(fmt, test_bmp):
                 sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE)
                 back, dr = c.decode(fmt, got[0][i][5], decom_len=len(raws[i]) if sized else 0, cap=len(raws[i]), aux0=got[0][i][3], aux1=got[0][i][4])
                 assert dr.status == 0 and back == raws[i], (seed, trial, i)
+
+
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW, A.FMT_MIO0])
+def test_a_few_large_buffers(fmt, test_bmp):
+    """Four buffers of 1-5 MB (the whole-GPU path off): more than a thousand segments per buffer, kernel A over segments of its own length, exit tables
+    chained across hundreds of boundaries."""
+    big = (test_bmp * 5)[:5 * 1000 * 1000 + 123]
+    items = [(fmt, big), (fmt, _mixed(3000000, 77, test_bmp)), (fmt, bytes(1500000) + test_bmp[:200000]), (fmt, test_bmp[:1000001])]
+    with Context(0) as c:
+        _both_ways(c, items, 0, "large")
+        _both_ways(c, items[1:], 8, "large, quality 8")
