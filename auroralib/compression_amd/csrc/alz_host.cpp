@@ -109,6 +109,7 @@ struct alz_ctx {
     int variant = 0;                           // alz_ctx_set_kernel_variant
     uint64_t big_enc_launches = 0;             // streams the whole-GPU ENCODE path has taken (alz_encode_big.h)
     uint64_t seg_enc_launches = 0;             // launches of the segmented parse + emit (alz_encode_seg.h)
+    uint64_t chunk_repeats = 0;                // executes alz_plan_results repeated without the work queue (a bounded spin ran out)
     uint32_t big_min = 24u << 10;              // (24 KiB: tools/single_decode_sizes.py -- 0.18 ms either way at 16 KiB, 0.18 against 0.30 at 32) a lone stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
     uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
     hipEvent_t big_evt = nullptr; bool big_evt_set = false;   // behind the last whole-GPU decode that used d_bigbuf (plans that borrow it run one after the other)
@@ -194,6 +195,8 @@ int alz_debug_occupancy(int format) { return alz_kernel_occupancy(format); }
 /* not in the public header: the largest batch (buffers of one format) whose parse + emit runs over segments (alz_encode_seg.h; 0: never), and how often a context has gone that way */
 void alz_debug_seg_max_streams(uint32_t v) { alz_debug_set_seg_max_streams(v); }
 uint64_t alz_debug_seg_launches(const alz_ctx* c) { return c ? c->seg_enc_launches : 0; }
+/* not in the public header: how often alz_plan_results has repeated a launch without the work queue on this context (expected: never) */
+uint64_t alz_debug_chunk_repeats(const alz_ctx* c) { return c ? c->chunk_repeats : 0; }
 /* not in the public header: output bytes per chunk of the work-queue kernels */
 int alz_debug_chunk_bytes(void) { return (int)ALZ_CHUNK_OUT; }
 /* not in the public header: the (stream, chunk) items of a plan's work queues (0: the plan decodes with one wavefront per stream) */
@@ -580,7 +583,7 @@ int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
             tmo |= t;
         }
         if (tmo) {
-            p->no_chunks = true;
+            p->no_chunks = true; c->chunk_repeats++;
             if (int rc = alz_plan_execute(c, p, p->last_src, p->last_dst, nullptr)) return rc;
         }
     }

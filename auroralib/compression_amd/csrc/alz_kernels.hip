@@ -276,7 +276,9 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 // terminator, E5) marks its remaining boundaries "ended" as their items come up.  A bounded spin that runs out sets `tmo`; the host then
 // repeats the launch with the one-wavefront-per-stream kernel (alz_plan_results).
 #define ALZ_CHUNK_BYTES ALZ_CHUNK_OUT     /* (alz_internal.h: the host cuts the streams by the same number) */
-#define ALZ_CHUNK_SPINS (1u << 20)    /* x (sleep + one load): about a second */
+#ifndef ALZ_CHUNK_SPINS
+#define ALZ_CHUNK_SPINS (1u << 20)    /* x (sleep + one load): about a second.  (-DALZ_CHUNK_SPINS=0: every wait that is not over at once runs out -- the test of the repeat path, tools/variants/README.md) */
+#endif
 #define ALZ_CHUNK_FLAG_WORDS 32u       /* a flag has a 128-byte line of its own: pollers of one boundary never touch the line another boundary's flag, the queue head or the timeout word lives in */
 typedef __attribute__((address_space(1))) u32 alz_gu32;
 typedef __attribute__((address_space(1))) unsigned long long alz_gu64;
