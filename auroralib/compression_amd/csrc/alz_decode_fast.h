@@ -33,8 +33,14 @@
 #ifndef ALZ_DESCTAB_ALL
 #define ALZ_DESCTAB_ALL 0
 #endif
+// The descriptor table (EmitCfg::DESCTAB) with 512-byte input-cache chunks for the single-cursor formats it pays for: behind the work queue of chunks Yaz0 2.58 -> 2.55 ms
+// (two batches in flight 980 -> 996 GiB/s), LZ11 2.636 -> 2.620; LZ10 and LZSS lose a few tenths of a percent and keep 1 024-byte chunks without the table (EXP 10.3).
+#ifndef ALZ_TAB512
+#define ALZ_TAB512 1
+#endif
 #include "alz_emit_byte.h"
 #include "alz_prs_table.h"
+template <int FMT> struct alz_tab512 { static constexpr bool value = ALZ_DESCTAB_ALL != 0 || (ALZ_TAB512 != 0 && (FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZ11)); };
 
 #ifndef ALZ_QRUN
 #define ALZ_QRUN 200u   /* longest literal run / element a lane-parallel round takes: window (256) + element stay inside one 512-byte cache chunk */
@@ -210,7 +216,7 @@ __device__ __forceinline__ bool fast_iter_interleaved(InCache& in, OW& out, DecS
     }
     if (cut && vm == 0) { to_serial = true; return false; }
     u32 last_tend;
-    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB, false, false, ALZ_DESCTAB_ALL != 0>>(out, s, size, vm, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
+    const bool fin = fast_emit<OW, EmitCfg<((FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_BLZ) ? 0u : 4095u), FMT == ALZ_FMT_LZSS, false, OW::FB, false, false, alz_tab512<FMT>::value>>(out, s, size, vm, len, desc, tend, segmark, nullptr, lane, last_tend, gm.W);
     if (fin) {
         s.p = p + last_tend;
         if (FMT == ALZ_FMT_LZ02) {                                // not the end of an LZ02 stream: the exact parser goes on to the terminator

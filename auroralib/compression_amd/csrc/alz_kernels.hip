@@ -164,9 +164,9 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 #ifndef ALZ_DESCTAB_ALL
 #define ALZ_DESCTAB_ALL 0       // (experiment: the descriptor table for the single-cursor kernels too)
 #endif
-    constexpr u32 CHUNK = THREE ? 256u : (LWMAX > 4096 ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
+    constexpr u32 CHUNK = THREE ? 256u : ((LWMAX > 4096 || alz_tab512<FMT>::value) ? 512u : (u32)ALZ_FAST_CHUNK);      // (8 KiB windows: 17 instead of 15 waves per CU)
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    constexpr u32 FSCR = FBK ? ALZ_EMIT_SCRATCH : ((THREE || ALZ_DESCTAB_ALL) ? ALZ_BYTE_SCRATCH : 128u), FSLACK = FBK ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
+    constexpr u32 FSCR = FBK ? ALZ_EMIT_SCRATCH : ((THREE || alz_tab512<FMT>::value) ? ALZ_BYTE_SCRATCH : 128u), FSLACK = FBK ? ALZ_WIN_SLACK : 0u;   // (chunked byte phase: token table + ring mirror)
     __shared__ __attribute__((aligned(16))) u8 lds_all[ALZ_WPB][FSCR + NC * CACHE + LWMAX + FSLACK];
     const u32 wid = ALZ_WPB == 1 ? 0u : (u32)threadIdx.x >> 6;   // (constant 0: LDS addresses stay immediates)
     u8* const lds = lds_all[wid];
@@ -293,9 +293,9 @@ __device__ __forceinline__ u32 fastq_item(const u8* src_base, u8* dst_base, cons
                                           u8* lds, u32 lw, u32 sid, u32 c, u32 last, const u8* in_slot, u8* out_slot, u32 p0, u32 p1, u32 p2, u32 start) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr int NC = THREE ? 3 : 1;
-    constexpr u32 CHUNK = THREE ? 256u : (u32)ALZ_FAST_CHUNK;
+    constexpr u32 CHUNK = THREE ? 256u : (alz_tab512<FMT>::value ? 512u : (u32)ALZ_FAST_CHUNK);
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    constexpr u32 FSCR = (THREE || ALZ_DESCTAB_ALL) ? ALZ_BYTE_SCRATCH : 128u;
+    constexpr u32 FSCR = (THREE || alz_tab512<FMT>::value) ? ALZ_BYTE_SCRATCH : 128u;
     const int lane = lane_id();
     u8* segmark = lds;
     u8* inc_lds = lds + FSCR;
@@ -383,9 +383,9 @@ __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(cons
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr int NC = THREE ? 3 : 1;
     constexpr u32 LWMAX = 4096u;
-    constexpr u32 CHUNK = THREE ? 256u : (u32)ALZ_FAST_CHUNK;
+    constexpr u32 CHUNK = THREE ? 256u : (alz_tab512<FMT>::value ? 512u : (u32)ALZ_FAST_CHUNK);
     constexpr u32 CACHE = THREE ? ALZ_INCACHE_SMALL : 2u * CHUNK + 32u;
-    constexpr u32 FSCR = (THREE || ALZ_DESCTAB_ALL) ? ALZ_BYTE_SCRATCH : 128u;
+    constexpr u32 FSCR = (THREE || alz_tab512<FMT>::value) ? ALZ_BYTE_SCRATCH : 128u;
     __shared__ __attribute__((aligned(16))) u8 lds[FSCR + NC * CACHE + LWMAX];
     const int lane = (int)(threadIdx.x & 63u);
     const u32 slot_bytes = 32u + lw;                         // a boundary's slot: 8 state words, then the window
