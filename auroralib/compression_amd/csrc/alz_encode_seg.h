@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 #define ALZ_SEG_MIN_LEN 8192u
 #endif
 #ifndef ALZ_SEG_WAVES
-#define ALZ_SEG_WAVES 8192u      /* segments a launch aims at */
+#define ALZ_SEG_WAVES 8192u      /* segments a launch aims at (4 096: 5-20 % slower from 256 buffers on -- 256 x 64 KiB as Yaz0 at quality 0 0.59 -> 0.67 ms --; 16 384: within 2 % either way) */
 #endif
 static u32 g_seg_max_streams = 0xFFFFFFFFu;       // 0: the path is off; ~0: the rule above; anything else: that many buffers instead of the rule
 }  // namespace
