@@ -86,7 +86,7 @@ def test_settings_and_mixed_formats(test_bmp):
     """LZSS geometries, CompatibilityMode, VRAM mode; a call of several formats, some on the path (each with its own segments) and some not."""
     raw = test_bmp[:150000]
     with Context(0) as c:
-        for bits in [(10, 6, 2), (12, 4, 2), (8, 4, 2), (12, 4, 3)]:
+        for bits in [(10, 6, 2), (12, 4, 2), (8, 4, 2), (12, 4, 3), (15, 4, 3), (16, 8, 3)]:      # (the last: 64 KiB distances do not fit the 16-bit links)
             lz = A.LzProperties.from_bits(*bits)
             _both_ways(c, [(A.FMT_LZSS, raw[i * 999:i * 999 + 20000 + i]) for i in range(40)], 8, "lzss %r" % (bits,), lz=lz)
         _both_ways(c, [(A.FMT_LZSS, raw), (A.FMT_LZSS, b"ab" * 60000)] * 20, 8, "compat", strategy=1)
