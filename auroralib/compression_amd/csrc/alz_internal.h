@@ -15,10 +15,14 @@ int alz_kernel_occupancy(int fmt);
 struct alz_chunk_item { uint32_t sid, chunk, slot, last; };   // stream, its chunk, the hand-over slot this chunk WRITES (it reads slot - 1), 1 = the stream's last chunk
 #define ALZ_CHUNK_FLAG_STRIDE 32u                             /* words between two flags (= ALZ_CHUNK_FLAG_WORDS of the kernel) */
 #ifndef ALZ_CHUNK_OUT
-#define ALZ_CHUNK_OUT 32768u                                  /* output bytes per chunk (10 000 x 256 KiB as Yaz0, ms per launch: 16 KiB 2.62, 24 KiB 2.57, 32 KiB 2.58, 64 KiB 2.62, 128 KiB 2.76; one wavefront per stream 2.93) */
+#define ALZ_CHUNK_OUT 40960u                                  /* output bytes per chunk.  NOT a power of two: streams of 64 KiB, 256 KiB, 1 MiB then end in a SHORT last chunk, and the last chunks are what a launch
+                                                                 drains at its end (10 000 x 256 KiB as Yaz0, ms per launch: 24 KiB 2.69, 32 KiB 2.55, 40 KiB 2.51, 48 KiB 2.56; every queue format gains 1.5-3 % over 32 KiB, cfg2's 64 KiB streams 2 %;
+                                                                 before the descriptor table: 16 KiB 2.62, 24 KiB 2.57, 32 KiB 2.58, 64 KiB 2.62, 128 KiB 2.76; one wavefront per stream 2.93) */
 #endif
 bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out);   // does the format have the work-queue kernel, and with which LDS window
-#define ALZ_CHUNK_OUT_PRS 65536u                              /* PRS hands over an 8 KiB window: larger chunks */
+#ifndef ALZ_CHUNK_OUT_PRS
+#define ALZ_CHUNK_OUT_PRS 81920u                              /* PRS hands over an 8 KiB window: larger chunks (10 000 x 256 KiB, ms per launch: 48 KiB 5.44, 64 KiB 5.36, 80 KiB 5.31) */
+#endif
 static inline uint32_t alz_chunk_bytes(int fmt) { return (fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE) ? ALZ_CHUNK_OUT_PRS : ALZ_CHUNK_OUT; }
 int alz_chunk_places_per_cu(int fmt);                        // streams one CU holds of the format's one-workgroup-per-stream kernel (what the work queue is weighed against)
 // d_ctl: 64 words (32: timeout flag, a 128-byte line of its own; 0: unused), zeroed by the caller before every launch, like d_flags (ALZ_CHUNK_FLAG_STRIDE words per slot: a line of its own);

@@ -1,4 +1,4 @@
-"""-m gpu: the flag-byte family as a WORK QUEUE of chunks (32 KiB of output each) (alz_decode_fastq_kernel; include/auroralz.h, alz_ctx_set_kernel_variant 3).
+"""-m gpu: the flag-byte family as a WORK QUEUE of chunks (40 KiB of output each; PRS 80 KiB) (alz_decode_fastq_kernel; include/auroralz.h, alz_ctx_set_kernel_variant 3).
 A plan created in variant 3 decodes through the queue whatever its size: every case below goes through tests/test_gpu_canary.py's checker --
 status / dst_len / src_used against the oracle, the WHOLE canary-filled destination buffer byte for byte -- with streams long enough to be cut:
 chunk limits at multiples of the chunk size, streams that end in their first / a middle / their last chunk (errors, truncation, capacity), matches longer
@@ -16,13 +16,15 @@ from gpu_common import ctx, pack_streams
 from test_gpu_canary import canary_decode
 
 pytestmark = pytest.mark.gpu
-QUEUE = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_PRS_LE]   # (PRS: the two-wavefront kernel, 64 KiB chunks)
+QUEUE = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_CLZ0, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_PRS_BE, A.FMT_PRS_LE]   # (PRS: the two-wavefront kernel, 80 KiB chunks)
 SEED = int(os.environ.get("ALZ_FUZZ_SEED", "1234"))
 
 
 @pytest.mark.parametrize("fmt", QUEUE)
 def test_queue_synthetic_sizes_around_the_chunk_limits(fmt):
-    sizes = np.array([1, 4095, 32767, 32768, 32769, 65535, 65536, 65537, 100000, 131071, 131072, 131073, 196608, 200001, 262144, 300001, 524288, 1 << 20, 70001, 3, 262143] * 3, dtype=np.uint32)
+    # (chunks of 40 KiB -- PRS 80 KiB --; the powers of two of the first build's 32 / 64 KiB chunks stay in the list)
+    sizes = np.array([1, 4095, 32767, 32768, 32769, 40959, 40960, 40961, 65535, 65536, 65537, 81919, 81920, 81921, 100000, 122880, 131071, 131072, 131073, 163839, 163840, 163841, 196608, 200001, 245760, 245761,
+                      262144, 300001, 327680, 524288, 1 << 20, 70001, 3, 262143] * 2, dtype=np.uint32)
     b = synth.make_batch(fmt, len(sizes), sizes, synth.seed_for(70 + fmt), dst_align=1)
     canary_decode(b.streams, b.src, b.dst_bytes, what="queue sizes " + A.FORMAT_NAMES[fmt], queue=True)
 
