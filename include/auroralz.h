@@ -205,7 +205,7 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
  * library chooses by the size of the batch; 1 / 2: always the one- / two-wavefront shape where both exist.  Results are
  * identical; a tuning and verification hook (the library reads no environment variable for kernel selection).
  * A third shape exists for the flag-byte family (LZSS with windows up to 4 KiB, LZ10, LZ11, LZ40, CLZ0, Yaz0, Yay0, MIO0) and PRS on device-resident
- * plans: the batch as a WORK QUEUE of 32 KiB chunks (PRS: 64 KiB) popped by as many persistent wavefronts as the GPU holds -- taken by itself (variant 0) when a
+ * plans: the batch as a WORK QUEUE of 40 KiB chunks (PRS: 80 KiB) popped by as many persistent wavefronts as the GPU holds -- taken by itself (variant 0) when a
  * plan has more streams of such a format than 0.6 of what the GPU holds wavefronts, so that the launch does not end in a partly filled round; 3: plans created in this
  * mode use it whatever their size (the parity tests).  Same results: a chunk ends between two iterations of the lane-parallel loop and hands
  * the LDS window and the cursors on.  A wavefront waits for the chunk before its own with a BOUNDED spin; if one ever ran out (workgroups start in
