@@ -16,7 +16,7 @@ struct alz_chunk_item { uint32_t sid, chunk, slot, last; };   // stream, its chu
 #define ALZ_CHUNK_FLAG_STRIDE 32u                             /* words between two flags (= ALZ_CHUNK_FLAG_WORDS of the kernel) */
 #ifndef ALZ_CHUNK_OUT
 #define ALZ_CHUNK_OUT 40960u                                  /* output bytes per chunk.  NOT a power of two: streams of 64 KiB, 256 KiB, 1 MiB then end in a SHORT last chunk, and the last chunks are what a launch
-                                                                 drains at its end (10 000 x 256 KiB as Yaz0, ms per launch: 24 KiB 2.69, 32 KiB 2.55, 40 KiB 2.51, 48 KiB 2.56; every queue format gains 1.5-3 % over 32 KiB, cfg2's 64 KiB streams 2 %;
+                                                                 drains at its end (10 000 x 256 KiB as Yaz0, ms per launch: 24 KiB 2.69, 32 KiB 2.55, 36 KiB 2.55, 40 KiB 2.49-2.51, 42 KiB 2.55, 48 KiB 2.56, 51 KiB 2.57 -- a last chunk of 16 KiB beats one of 4 KiB too; every queue format gains 1.5-3 % over 32 KiB, cfg2's 64 KiB streams 2 %;
                                                                  before the descriptor table: 16 KiB 2.62, 24 KiB 2.57, 32 KiB 2.58, 64 KiB 2.62, 128 KiB 2.76; one wavefront per stream 2.93) */
 #endif
 bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out);   // does the format have the work-queue kernel, and with which LDS window
