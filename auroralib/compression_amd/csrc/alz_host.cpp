@@ -417,8 +417,10 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
             // streams: 2.54 ms with one wavefront per stream, 3.20 with its three flag-byte formats as queues)
             // PRS (two wavefronts per stream, bound by the scalar pipe: a stream in a half-empty GPU is fast anyway) only above what the GPU holds: 2 000 / 3 000 / 4 000 / 6 000 / 10 000 streams
             // 1.39 / 1.69 / 2.72 / 3.43 / 5.50 ms with a workgroup per stream, 1.59 / 1.80 / 2.34 / 3.32 / 5.36 as a queue (3 072 places)
-            const uint64_t tenths = (f == ALZ_FMT_PRS_BE || f == ALZ_FMT_PRS_LE) ? 10ull : 6ull;
-            if (!force_queue && (occ < 1 || 10ull * cnt[f] <= tenths * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
+            // (with 40 KiB chunks and the descriptor table -- 29 places per CU for Yaz0 / LZ11 -- the queue wins earlier: 3 600 / 4 200 streams 1.44 / 1.58 ms one wavefront per stream, 1.37 / 1.42 as a
+            // queue: from 0.4 of the places on, and never where two wavefronts share a stream -- up to 3 072 streams: 3 000 streams 1.14 that way, 1.31 as a queue)
+            const uint64_t tenths = (f == ALZ_FMT_PRS_BE || f == ALZ_FMT_PRS_LE) ? 10ull : 4ull;
+            if (!force_queue && (occ < 1 || cnt[f] <= 3072u || 10ull * cnt[f] <= tenths * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
             // items in chunk-major order over the format's cost-ordered list; a stream's slots are consecutive
             std::vector<uint32_t> nch(cnt[f]), base(cnt[f]);
             uint32_t slots = 0, maxch = 0; uint64_t items64 = 0;
