@@ -247,12 +247,12 @@ __global__ __launch_bounds__(1024) void big_jump_tile(u32* __restrict__ val, u32
 // W: bytes out, result, gate
 // (DEVSIZE: the output size is ctl[C_SIZE], at most `a.size` = the room in the destination)
 template <bool DEVSIZE>
-__global__ __launch_bounds__(256) void big_write(BigArgs a, const u32* __restrict__ val, const u32* __restrict__ ctl, alz_result* __restrict__ result, u32* __restrict__ gate) {
+__global__ __launch_bounds__(256) void big_write(BigArgs a, const u32* __restrict__ val, const u32* __restrict__ ctl, alz_result* __restrict__ result, u32* __restrict__ gate, u32* __restrict__ acc) {
     const u32 size = DEVSIZE ? ctl[C_SIZE] : a.size;
     const bool ok = ctl[C_BAD] == 0u && ctl[C_END] == 1u && ctl[C_TOTAL] >= size && size <= a.size && (!DEVSIZE || size != 0u);
     const u32 q = blockIdx.x * 256u + threadIdx.x;
     if (q == 0) {
-        if (ok) { alz_result r; r.dst_len = size; r.src_used = ctl[C_USED]; r.status = ALZ_ST_OK; r.reserved = 0; *result = r; *gate = 0u; }
+        if (ok) { alz_result r; r.dst_len = size; r.src_used = ctl[C_USED]; r.status = ALZ_ST_OK; r.reserved = 0; *result = r; *gate = 0u; atomicAdd(acc, 1u); }   // (acc: the context's count of streams this path has ACCEPTED, alz_ctx_big_stream)
         else *gate = 1u;
     }
     if (!ok || q >= size) return;
@@ -865,7 +865,7 @@ size_t alz_big_scratch_bytes(int fmt, const alz_stream* st) {
 }
 
 template <int FMT>
-static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, const BigGeom& gm, alz_result* d_result, u8* base, u32* d_gate) {
+static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, const BigGeom& gm, alz_result* d_result, u8* base, u32* d_gate, u32* d_acc) {
     const InterLayout L(*st);
     u32* val = (u32*)(base + L.val); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b); u8* mark = base + L.mark;
     u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
@@ -890,12 +890,12 @@ static hipError_t launch_inter(hipStream_t stream, const u8* src, u8* dst, const
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->decom_len, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->decom_len; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
-    hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate, d_acc);
     return hipGetLastError();
 }
 
 template <bool LZ4>
-static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate) {
+static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate, u32* d_acc) {
     const InterLayout L(*st, LZ4 ? ALZ_FMT_LZ4_BLOCK : ALZ_FMT_SNAPPY_RAW);
     u32* val = (u32*)(base + L.val); u32* jump_a = (u32*)(base + L.jump_a); u32* jump_b = (u32*)(base + L.jump_b); u8* mark = base + L.mark;
     u32* tile_c = (u32*)(base + L.tile_c); u32* tile_cb = (u32*)(base + L.tile_cb); u32* gpos = (u32*)(base + L.gpos);
@@ -924,13 +924,13 @@ static hipError_t launch_elem(hipStream_t stream, const u8* src, u8* dst, const 
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
-    hipLaunchKernelGGL((big_write<true>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    hipLaunchKernelGGL((big_write<true>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate, d_acc);
     return hipGetLastError();
 }
 
 // KIND 0 / 1: PRS little / big endian; 2: LZO -- the formats whose stream ends at a terminator token
 template <int KIND>
-static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate) {
+static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const alz_stream* st, alz_result* d_result, u8* base, u32* d_gate, u32* d_acc) {
     constexpr bool BIG = KIND == 1;
     constexpr u32 NST = KIND == 2 ? BIG_LZO_STATES : ALZ_PRS_STATES;
     const InterLayout L(*st, KIND == 2 ? ALZ_FMT_LZO : (BIG ? ALZ_FMT_PRS_BE : ALZ_FMT_PRS_LE));
@@ -962,26 +962,26 @@ static hipError_t launch_term(hipStream_t stream, const u8* src, u8* dst, const 
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, st->dst_cap, (const u32*)(ctl + C_SIZE), ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
     BigArgs a; a.src = src; a.dst = dst; a.src_len = st->src_len; a.size = st->dst_cap; a.aux0 = a.aux1 = 0; a.ntok = 0; a.ntiles = 0;
-    hipLaunchKernelGGL((big_write<true>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    hipLaunchKernelGGL((big_write<true>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate, d_acc);
     return hipGetLastError();
 }
 
 hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, void* d_dst_base, const alz_stream* st, const alz_lz_properties* lz,
-                          alz_result* d_result, void* d_scratch, uint32_t* d_gate) {
+                          alz_result* d_result, void* d_scratch, uint32_t* d_gate, uint32_t* d_acc) {
     const u8* src = (const u8*)d_src_base + st->src_off; u8* dst = (u8*)d_dst_base + st->dst_off;
-    if (fmt == ALZ_FMT_PRS_BE) return launch_term<1>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
-    if (fmt == ALZ_FMT_PRS_LE) return launch_term<0>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
-    if (fmt == ALZ_FMT_LZO) return launch_term<2>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
-    if (fmt == ALZ_FMT_LZ4_BLOCK) return launch_elem<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
-    if (fmt == ALZ_FMT_SNAPPY_RAW) return launch_elem<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate);
+    if (fmt == ALZ_FMT_PRS_BE) return launch_term<1>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate, d_acc);
+    if (fmt == ALZ_FMT_PRS_LE) return launch_term<0>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate, d_acc);
+    if (fmt == ALZ_FMT_LZO) return launch_term<2>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate, d_acc);
+    if (fmt == ALZ_FMT_LZ4_BLOCK) return launch_elem<true>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate, d_acc);
+    if (fmt == ALZ_FMT_SNAPPY_RAW) return launch_elem<false>(stream, src, dst, st, d_result, (u8*)d_scratch, d_gate, d_acc);
     if (big_inter(fmt)) {
         BigGeom gm; gm.length_bits = lz->length_bits; gm.min_length = lz->min_length; gm.windows_start = lz->windows_start;
         gm.max_distance = lz->max_distance; gm.W = 1u << lz->window_bits;
         switch (fmt) {
-        case ALZ_FMT_LZSS: return launch_inter<ALZ_FMT_LZSS>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
-        case ALZ_FMT_LZ10: return launch_inter<ALZ_FMT_LZ10>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
-        case ALZ_FMT_LZ11: return launch_inter<ALZ_FMT_LZ11>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
-        default: return launch_inter<ALZ_FMT_YAZ0>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate);
+        case ALZ_FMT_LZSS: return launch_inter<ALZ_FMT_LZSS>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate, d_acc);
+        case ALZ_FMT_LZ10: return launch_inter<ALZ_FMT_LZ10>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate, d_acc);
+        case ALZ_FMT_LZ11: return launch_inter<ALZ_FMT_LZ11>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate, d_acc);
+        default: return launch_inter<ALZ_FMT_YAZ0>(stream, src, dst, st, gm, d_result, (u8*)d_scratch, d_gate, d_acc);
         }
     }
     BigArgs a;
@@ -1018,6 +1018,6 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
     hipLaunchKernelGGL(big_jump_tile, dim3((a.size + 1023u) / 1024u), dim3(1024), 0, stream, val, a.size, (const u32*)nullptr);
     for (u32 r = 0; r < rounds; r++)
         hipLaunchKernelGGL(big_jump, dim3(nb), dim3(256), 0, stream, val, a.size, (const u32*)nullptr, ctl + C_FLAGS + r, ctl + C_FLAGS + r + 1);
-    hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate);
+    hipLaunchKernelGGL((big_write<false>), dim3(nb), dim3(256), 0, stream, a, val, ctl, d_result, d_gate, d_acc);
     return hipGetLastError();
 }

@@ -658,6 +658,64 @@ __device__ __forceinline__ void benc_wave_search(const u8* data, int n, const En
     }
 }
 
+// MatchSearch (:214-246, ChainMatches :248-282) exactly, by the whole wavefront, WITHOUT links (round 6): prev() chains are the positions below `pos` with pos's hash, nearest first,
+// and the walk ends at the first one further back than maxDistance (:259-260) -- so the candidates are exactly the positions of [pos - maxDistance, pos) whose four bytes hash
+// like pos's (ComputeHash :288-299: the top hashBits bits of one product), in descending order, at most maxChain of them.  The wavefront finds them by SCANNING the window
+// behind the cursor, a block of 1 024 positions at a time, nearest block first (16 positions per lane: 20 bytes, one multiply per position), and measures the candidates of a
+// block before it looks at the next: in a run or a stretch of repeated rows the nearest candidate already reaches the longest possible match and the walk ends in the first
+// block.  No kernel A, no kernel B, no match array -- for the streams whose parse visits few positions (enc_scan_select_kernel): kernel B searches EVERY position, the
+// managed parse only the ones its cursor stands on (FindNextBestMatch :157-212), and on the flat windows of Test.bmp that is one position in a hundred.
+// One property set, no min-length table (quality < 10).
+__device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l) {
+    const int lane = (int)benc_lane();
+    const u8* dp = data + pos;
+    const u32 sh = 32u - (u32)g.hash_bits;
+    const u32 own = load32(dp) * 2654435761u;
+    int best_possible = n - pos; if (best_possible > g.max_len) best_possible = g.max_len;
+    best_d = 0; best_l = 0; int best_score = -1;
+    int attempts = g.max_chain;
+    const int lo = pos - g.max_dist > 0 ? pos - g.max_dist : 0;          // candidates: [lo, pos)
+    bool done = false;
+    for (int top = pos; top > lo && !done; top -= 1024) {
+        // my sixteen positions of the block [top - 1024, top): [base, base + 16), read from b0 = max(base, 0) on (nothing is read in front of the stream)
+        const int base = top - 1024 + 16 * lane;
+        const int b0 = base > 0 ? base : 0;
+        u32 m16 = 0;
+        if (base + 16 > lo) {
+            u32 w[5];
+            __builtin_memcpy(w, data + b0, 20);                           // (up to pos + 2: inside the stream, pos <= n - 4)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u32 v = (u32)((((u64)w[(k >> 2) + 1] << 32) | w[k >> 2]) >> (8 * (k & 3)));
+                if (((v * 2654435761u) ^ own) >> sh == 0u) m16 |= 1u << k;
+            }
+            // valid: absolute position a = b0 + k with lo <= a < base + 16
+            const int hi = base + 16 - b0;                                // (16, fewer where the block starts in front of the stream)
+            if (hi < 16) m16 &= (1u << (hi > 0 ? hi : 0)) - 1u;
+            if (b0 < lo) { const int cut = lo - b0; m16 = cut >= 16 ? 0u : (m16 >> cut) << cut; }
+        }
+        u64 any = __ballot(m16 != 0u);
+        while (any && !done) {
+            const int L = 63 - (int)__builtin_clzll(any);
+            u32 mm = (u32)__builtin_amdgcn_readlane((int)m16, L);
+            const int b0L = __builtin_amdgcn_readlane(b0, L);
+            while (mm && !done) {
+                const int k = 31 - (int)__builtin_clz(mm);
+                mm &= ~(1u << k);
+                if (attempts-- <= 0) { done = true; break; }              // while (cur != -1 && attempts-- > 0)  :255
+                const int c = b0L + k, dist = pos - c;
+                if (dist < g.min_dist) continue;                           // :262-266 (the attempt is spent)
+                if (best_l > 0 && dp[best_l] != data[c + best_l]) continue;   // (cannot be longer than the best so far: benc_wave_search)
+                int len = benc_wave_match_len(dp, data + c, best_possible);
+                const int score = score_match(g, len, dist);
+                if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) done = true; }
+            }
+            any &= ~(1ull << L);
+        }
+        if (attempts <= 0) done = true;
+    }
+}
+
 __device__ __forceinline__ u32 benc_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // The same function as kernel B runs it (the exact recomputations inside the roles / emit kernels keep the plain form above: the
@@ -823,6 +881,7 @@ __global__ __launch_bounds__(64) void enc_match_dense_kernel(const u8* __restric
     __shared__ unsigned long long best[ALZ_DENSE_POS];
     __shared__ u32 capf[ALZ_DENSE_POS];
     const u32 sid = index_list[blockIdx.y];
+    if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_scan_select_kernel: the stream goes the other way)
     const u32 selv = sel ? sel[sid] : 0u;         // (read together with the descriptor: as a test of its own in front of it, ten million workgroups paid one more round trip each)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
@@ -1022,6 +1081,7 @@ __global__ __launch_bounds__(256) void enc_match_kernel(const u8* __restrict__ s
   const u32 ny = list ? list[0] : gridDim.y;
   for (u32 y = blockIdx.y; y < ny; y += gridDim.y) {
     const u32 sid = list ? list[1u + y] : index_list[y];
+    if (sid == 0xFFFFFFFFu) continue;             // (enc_scan_select_kernel's list: the stream goes the other way)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
@@ -1055,6 +1115,7 @@ __global__ __launch_bounds__(256) void enc_match_dyn_kernel(const u8* __restrict
   const u32 ny = list ? list[0] : gridDim.y;
   for (u32 y = blockIdx.y; y < ny; y += gridDim.y) {
     const u32 sid = list ? list[1u + y] : index_list[y];
+    if (sid == 0xFFFFFFFFu) continue;             // (enc_scan_select_kernel's list: the stream goes the other way)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip;
@@ -1996,6 +2057,7 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
     const int lane = (int)threadIdx.x;
     hopmark[lane] = 0;
     const u32 sid = index_list[bid];
+    if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_scan_select_kernel: the stream goes the other way)
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
     const u8* data = src;
@@ -2234,6 +2296,139 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
         if (THREE) unc_base += (u32)__builtin_amdgcn_readlane((int)uincl, 63);
         const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
         if (wmax > cover) cover = wmax;
+    }
+    // Dispose(): a partial flag byte is written with its unused bits zero (FlagWriter.cs:141-145)
+    const u32 nflags = FB * ((tok_base + FBITS - 1u) / FBITS);          // (bytes)
+    if ((tok_base % FBITS) != 0 && lane == 0) {
+        const u32 gi = tok_base / FBITS; const u32 fo = gofs[gi & 15u], acc = flagacc[gi & 15u];
+        if (fo + FB <= cap) { if (FB == 1u) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc); else { dst[fo] = (u8)(acc >> 24); dst[fo + 1] = (u8)(acc >> 16); dst[fo + 2] = (u8)(acc >> 8); dst[fo + 3] = (u8)acc; } }
+        else fail = true;
+    }
+    u32 total;
+    if (!THREE) total = pay_base + nflags;
+    else {
+        total = nflags + pay_base + unc_base;
+        if (total <= cap) {
+            for (u32 i = (u32)lane; i < pay_base; i += 64) dst[nflags + i] = compb[i];
+            for (u32 i = (u32)lane; i < unc_base; i += 64) dst[nflags + pay_base + i] = uncb[i];
+        } else fail = true;
+        if (lane == 0 && aux) { aux[sid].aux0 = nflags; aux[sid].aux1 = nflags + pay_base; }
+    }
+    if (total > cap) fail = true;
+    const bool anyfail = __ballot(fail) != 0;
+    if (lane == 0) {
+        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
+        results[sid] = r;
+        if (!THREE && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+    }
+}
+
+// The streams enc_scan_select_kernel picked (round 6): parse + emission WITHOUT links or a match array, one wavefront per stream.  The walk is FindNextBestMatch itself
+// (:157-212): the position the cursor stands on -- and its neighbour where the lazy rule looks at it (:175-190) -- is searched exactly by the whole wavefront
+// (benc_wave_scan_search), and what it finds goes into a list of tokens, one per lane: a match (position, distance, length) or a literal (a position the cursor stepped
+// over, or one in front of a lazily taken match, or what is left behind the last match).  64 tokens are emitted at once, with enc_parse_emit_kernel's arithmetic: flag group
+// and bit from the token's number, payload offsets by prefix sums, a flag byte in front of its group's first payload.  (The first form of this path walked
+// enc_parse_emit_kernel's 64-POSITION windows with every position "capped": one emission pass per token where tokens lie a hundred bytes apart -- 2 000 flat windows 18.5 ms.)
+template <int FMT>
+__global__ __launch_bounds__(64) void enc_scan_emit_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                           const u32* __restrict__ index_list, u32 count, const u64* __restrict__ pos_off, u8* __restrict__ side,
+                                                           alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+    constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
+    constexpr bool LIT_BIT = (FMT == ALZ_FMT_LZSS || FMT == ALZ_FMT_YAZ0 || FMT == ALZ_FMT_LZHUDSON || THREE);   // flag bit of a literal token
+    constexpr bool MSB = (FMT != ALZ_FMT_LZSS && FMT != ALZ_FMT_CLZ0);
+    constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;
+    __shared__ u32 flagacc[16];
+    __shared__ u32 gofs[16];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const u32 sid = index_list[bid];
+    if (sid == 0xFFFFFFFFu) return;               // (the stream went the other way)
+    const int lane = (int)threadIdx.x;
+    const alz_stream st = streams[sid];
+    const u8* data = src_base + st.src_off;
+    const u32 n = st.src_len;
+    const int limit = (int)n - 4;                                        // FindNextBestMatch searches up to length - 4  :159
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    u8* compb = THREE ? side + 2 * pos_off[sid] : nullptr;            // token section (Yay0 / MIO0)
+    u8* uncb = THREE ? side + 2 * pos_off[sid] + n + 16 : nullptr;    // literal section
+    if (lane < 16) { flagacc[lane] = 0; gofs[lane] = 0; }
+    __syncthreads();
+    u32 tok_base = 0, pay_base = 0, unc_base = 0;
+    bool fail = false;
+    int cur = 0;                                                         // the cursor (Position)
+    u32 cover = 0;                                                       // end of the last match
+    u32 tail = 0;                                                        // behind the walk: the next position of what is left (literals)
+    bool walk = limit >= 0;
+    if (!walk) tail = 0;
+    for (;;) {
+        // ---- up to 64 tokens: lane k holds token k -- (position, distance, length), length 0 = a literal
+        u32 tp = 0; uint2 tm2 = make_uint2(0, 0);
+        int k = 0;
+        while (walk && k <= 62) {
+            if (cur > limit) { walk = false; tail = (u32)cur > cover ? (u32)cur : cover; break; }
+            int d0, l0, d1 = 0, l1 = 0;
+            benc_wave_scan_search(data, (int)n, g, cur, d0, l0);
+            if (l0 < g.min_len) { if (lane == k) { tp = (u32)cur; tm2 = make_uint2(0, 0); } k++; cur++; continue; }      // :166-170
+            const bool lazyc = l0 <= g.lazy && cur + 1 <= limit;
+            if (lazyc) benc_wave_scan_search(data, (int)n, g, cur + 1, d1, l1);
+            int mp = cur, md = d0, ml = l0, skip = lazyc ? 1 : 0;
+            if (lazyc && l1 > l0) { if (lane == k) { tp = (u32)cur; tm2 = make_uint2(0, 0); } k++; mp = cur + 1; md = d1; ml = l1; skip = 0; }   // the byte in front becomes a literal  :181-186
+            if (lane == k) { tp = (u32)mp; tm2 = make_uint2((u32)md, (u32)ml); }
+            k++;
+            const int e = mp + ml, stop = e < limit + 1 ? e : limit + 1;  // :195-203
+            cur = mp + 1 + skip > stop ? mp + 1 + skip : stop;
+            cover = (u32)e;
+        }
+        if (!walk) {
+            // what is left behind the last match: literals (the last three bytes are never searched; a stream shorter than four bytes is all of this)
+            while (k < 64 && tail < n) { if (lane == k) { tp = tail; tm2 = make_uint2(0, 0); } k++; tail++; }
+        }
+        if (k == 0) break;
+        // ---- the tokens of this batch (the arithmetic of enc_parse_emit_kernel: prefix sums over the tokens)
+        const bool tok = lane < k;
+        const bool start = tok && tm2.y != 0u, lit = tok && tm2.y == 0u;
+        const u32 ti = tok_base + (u32)lane;
+        u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, psize = 0, usize = 0;
+        if (lit) { b0 = data[tp]; psize = 1; }
+        else if (start) flag_payload<FMT>(g, tp, tm2, b0, b1, b2, b3, psize);
+        if (THREE) {   // literals (and Yay0's long-length byte) live in their own section
+            if (lit) { usize = 1; psize = 0; }
+            else if (start && FMT == ALZ_FMT_YAY0 && psize == 3) { usize = 1; psize = 2; }
+        }
+        const u32 pincl = scan_add(psize);
+        const u32 poff = pay_base + pincl - psize;
+        const u32 uincl = THREE ? scan_add(usize) : 0u;
+        const u32 uoff = unc_base + uincl - usize;
+        const u32 group = ti / FBITS, bitpos = ti % FBITS;
+        const u32 flag_off = THREE ? group : poff + FB * group;        // interleaved: flag g sits right before the payload of its first token
+        if (tok && bitpos == 0) { gofs[group & 15u] = flag_off; flagacc[group & 15u] = 0; }
+        __syncthreads();
+        if (tok) {
+            const u32 bitv = (lit ? LIT_BIT : !LIT_BIT) ? 1u : 0u;
+            if (bitv) atomicOr(&flagacc[group & 15u], 1u << (MSB ? FBITS - 1u - bitpos : bitpos));
+        }
+        __syncthreads();
+        if (tok) {
+            if (bitpos == FBITS - 1u) {
+                const u32 fo = gofs[group & 15u], acc = flagacc[group & 15u];
+                if (fo + FB <= cap) { if (FB == 1u) dst[fo] = (u8)(FMT == ALZ_FMT_LZ40 ? 0u - acc : acc); else { dst[fo] = (u8)(acc >> 24); dst[fo + 1] = (u8)(acc >> 16); dst[fo + 2] = (u8)(acc >> 8); dst[fo + 3] = (u8)acc; } }
+                else fail = true;
+            }
+            if (!THREE) {
+                const u32 o = poff + FB * (group + 1u);
+                if (o + psize <= cap) { dst[o] = (u8)b0; if (psize > 1) dst[o + 1] = (u8)b1; if (psize > 2) dst[o + 2] = (u8)b2; if (psize > 3) dst[o + 3] = (u8)b3; }
+                else fail = true;
+            } else {
+                if (lit) uncb[uoff] = (u8)b0;
+                else { compb[poff] = (u8)b0; compb[poff + 1] = (u8)b1; if (usize) uncb[uoff] = (u8)b2; }
+            }
+        }
+        __syncthreads();
+        tok_base += (u32)k;
+        pay_base += (u32)__builtin_amdgcn_readlane((int)pincl, 63);
+        if (THREE) unc_base += (u32)__builtin_amdgcn_readlane((int)uincl, 63);
+        if (!walk && tail >= n) break;
     }
     // Dispose(): a partial flag byte is written with its unused bits zero (FlagWriter.cs:141-145)
     const u32 nflags = FB * ((tok_base + FBITS - 1u) / FBITS);          // (bytes)
@@ -3197,6 +3392,7 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
                                                        const int* __restrict__ prev4, const u64* __restrict__ pos_off, EncGeom g, int tail_skip,
                                                        u32* __restrict__ sel, u32* __restrict__ list, u32 thresh16) {
     const u32 sid = index_list[blockIdx.x];
+    if (sid == 0xFFFFFFFFu) return;               // (enc_scan_select_kernel's list: the stream goes the other way)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int n = (int)st.src_len - tail_skip, limit = n - 4;
@@ -3219,6 +3415,56 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
         const u32 mine = hit * 16u >= tot * thresh16 ? 1u : 0u;
         sel[sid] = mine | ((tot ? hit * 1000u / tot : 0u) << 8);
         if (mine) list[1u + atomicAdd(list, 1u)] = sid;
+    }
+}
+
+// Which streams go WITHOUT kernels A and B (round 6): the ones whose parse visits few positions.  Kernel B searches every position of a stream -- 46 CU-cycles per position at quality 8
+// whatever the data (a wavefront walks on until the last of its 64 chains ends): 2 000 copies of a flat 256 KiB window of Test.bmp took it 38-52 ms, as long as a mixed window --, the
+// managed parse searches only where its cursor stands (FindNextBestMatch :157-212): ~2 600 of the 262 144 positions of such a window.  But the scan walk is ONE wavefront per stream
+// and serial: ~3-6 us per search, so what it costs is the stream's own latency (a mixed window with its ~50 000 searches: 141 ms against 26 us of kernel B's throughput), hidden behind the
+// other streams' kernels A / B / parse on a second HIP stream.  The probe walks the real greedy / lazy parse (scan searches) from eight places of the stream, up to 16 searches and 2 KiB
+// each, and adds up searches PER KiB place by place (a stream that is flat here and photographic there is as slow as its photographic part): up to ALZ_SCAN_MAX_PER_KIB on average the
+// stream takes enc_parse_emit_kernel<FMT, false, true> -- the choice decides time only, the bytes are MatchSearch's either way.  Writes two lists over the launch's streams, each with
+// 0xFFFFFFFF where the stream went the other way.
+#ifndef ALZ_SCAN_MAX_PER_KIB
+#define ALZ_SCAN_MAX_PER_KIB 20
+#endif
+#ifndef ALZ_SCAN_MIN_LEN
+#define ALZ_SCAN_MIN_LEN 16384     /* shorter buffers: whichever (the regular way) */
+#endif
+__global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, u32 count,
+                                                             EncGeom g, int force, u32* __restrict__ idx_regular, u32* __restrict__ idx_scan, u32* __restrict__ taken) {
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const u32 sid = index_list[bid];
+    bool take = force != 0;
+    if (!take && sid != 0xFFFFFFFFu) {
+        const alz_stream st = streams[sid];
+        const u8* data = src_base + st.src_off;
+        const int n = (int)st.src_len, limit = n - 4;
+        if (n >= ALZ_SCAN_MIN_LEN) {
+            int per_kib = 0;                                          // searches per KiB, summed over the eight places
+            for (int k = 0; k < 8; k++) {
+                const int start = (int)(((long long)limit * (2 * k + 1)) >> 4);
+                const int end = start + 2048 < limit + 1 ? start + 2048 : limit + 1;
+                int cur = start, cnt = 0;
+                while (cur < end && cnt < 16) {
+                    int d0, l0, d1, l1;
+                    benc_wave_scan_search(data, n, g, cur, d0, l0); cnt++;
+                    if (l0 < g.min_len) { cur++; continue; }
+                    if (l0 <= g.lazy && cur + 1 <= limit) { benc_wave_scan_search(data, n, g, cur + 1, d1, l1); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
+                    else cur += l0;
+                }
+                per_kib += (cnt << 10) / (cur > start ? cur - start : 1);
+            }
+            take = per_kib <= 8 * ALZ_SCAN_MAX_PER_KIB;
+        }
+    }
+    if (threadIdx.x == 0) {
+        const bool s2 = take && sid != 0xFFFFFFFFu;
+        idx_regular[bid] = s2 ? 0xFFFFFFFFu : sid;
+        idx_scan[bid] = s2 ? sid : 0xFFFFFFFFu;
+        if (s2 && taken) atomicAdd(taken, 1u);                           // (the context's count of streams that went this way: alz_debug_scan_streams)
     }
 }
 
@@ -3250,6 +3496,7 @@ __global__ __launch_bounds__(256) void enc_words_kernel(const u8* __restrict__ s
     __shared__ u32 bm[1024];
     __shared__ u32 cnt[2];
     const u32 sid = index_list[blockIdx.x];
+    if (sid == 0xFFFFFFFFu) return;               // (enc_scan_select_kernel's list: the stream goes the other way)
     const alz_stream st = streams[sid];
     const u8* data = src_base + st.src_off;
     const int limit = (int)st.src_len - tail_skip - 4;
@@ -3484,7 +3731,7 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
 hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, void* d_dst, const alz_stream* d_streams, const uint32_t* d_index,
                              uint32_t count, uint32_t max_len, int* d_prev4, int* d_prevm, int* d_narrow, void* d_match,
                              const uint64_t* d_pos_off, void* d_side, void* d_mask, alz_result* d_results, alz_encode_aux* d_aux, const void* geom,
-                             uint32_t* d_sel, uint32_t sel_pitch, void* d_seg, uint32_t seg_len, uint32_t seg_kmax) {
+                             uint32_t* d_sel, uint32_t sel_pitch, void* d_seg, uint32_t seg_len, uint32_t seg_kmax, int scan_mode, uint32_t* d_scan_taken, const alz_encode_side* side_q) {
     if (count == 0) return hipSuccess;
     EncGeom g; memcpy(&g, geom, sizeof(g));
     // (the segmented path of a small batch, alz_encode_seg.h: no cap -- its longest match is at most 2 040 bytes, kernel B has the GPU to itself, and
@@ -3492,6 +3739,34 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     g.b_cap = (d_seg != nullptr && seg_len != 0u) ? ALZ_LEN_CAP : choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
+    // ---- the streams whose parse visits few positions go without kernels A and B (enc_scan_select_kernel; scan_mode 0: the probe decides, 1: every stream, 2: none).
+    // The flag-bit formats of enc_parse_emit_kernel with windows up to 8 KiB, one property set, no min-length table (quality 2-9), a full batch (not the segmented path).
+    const u32* d_index_scan = nullptr;
+    bool scan_joined = true; const alz_encode_side* scan_side = nullptr;
+    {
+        const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 ||
+                         fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+        if (scan_mode != 2 && fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 && g.max_dist <= 8192 &&
+            g.link16 && !searches_in_the_parse(fmt, g)) {
+            u32* idx_regular = d_sel + 2u * (size_t)sel_pitch + 64u;      // (behind the probe's and the narrowing's lists; sel_pitch words each)
+            u32* idx_scan = idx_regular + sel_pitch;
+            hipLaunchKernelGGL(enc_scan_select_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, g, scan_mode == 1 ? 1 : 0, idx_regular, idx_scan, d_scan_taken);
+            d_index = idx_regular; d_index_scan = idx_scan;
+            // the scan streams' ONE kernel: on the side stream where there is one (a wavefront per stream walking serially -- latency, not throughput -- beside the other streams'
+            // kernels A / B / parse, which fill the GPU), joined at the end of this launch
+            hipStream_t sq = stream;
+            if (side_q && side_q->s && side_q->fork && side_q->join && hipEventRecord(side_q->fork, stream) == hipSuccess && hipStreamWaitEvent(side_q->s, side_q->fork, 0) == hipSuccess) sq = side_q->s;
+            u8* side = (u8*)d_side;
+#define ALZ_SCANK(F) case F: hipLaunchKernelGGL((enc_scan_emit_kernel<F>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, d_pos_off, side, d_results, d_aux, g); break;
+            switch (fmt) {
+            ALZ_SCANK(ALZ_FMT_LZSS) ALZ_SCANK(ALZ_FMT_LZ10) ALZ_SCANK(ALZ_FMT_LZ11) ALZ_SCANK(ALZ_FMT_LZ40) ALZ_SCANK(ALZ_FMT_YAZ0) ALZ_SCANK(ALZ_FMT_YAY0) ALZ_SCANK(ALZ_FMT_MIO0)
+            ALZ_SCANK(ALZ_FMT_CLZ0) ALZ_SCANK(ALZ_FMT_BLZ) ALZ_SCANK(ALZ_FMT_LZHUDSON)
+            default: break;
+            }
+#undef ALZ_SCANK
+            if (sq != stream) { if (hipEventRecord(side_q->join, sq) != hipSuccess) return hipGetLastError(); scan_joined = false; scan_side = side_q; }
+        }
+    }
     AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
     if (d_seg != nullptr && seg_len != 0u && tail == 0) {
         size_t ab = 0; u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;
@@ -3599,6 +3874,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     default: return hipErrorInvalidValue;
     }
 #undef ALZ_SEG
+    if (!scan_joined && hipStreamWaitEvent(stream, scan_side->join, 0) != hipSuccess) return hipGetLastError();      // (the scan streams' kernel)
     return hipGetLastError();
 }
 

@@ -229,16 +229,16 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 #ifndef ALZ_SEG_WAVES
 #define ALZ_SEG_WAVES 8192u      /* segments a launch aims at (4 096: 5-20 % slower from 256 buffers on -- 256 x 64 KiB as Yaz0 at quality 0 0.59 -> 0.67 ms --; 16 384: within 2 % either way) */
 #endif
-static u32 g_seg_max_streams = 0xFFFFFFFFu;       // 0: the path is off; ~0: the rule above; anything else: that many buffers instead of the rule
 }  // namespace
-void alz_debug_set_seg_max_streams(uint32_t v) { g_seg_max_streams = v; }       // (not in the public header -- tests, tools/mid_batch_encode.py)
 
-int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
+// max_streams: 0xFFFFFFFF: the rule above; 0: the path is off; anything else: that many buffers instead of the rule (a context's debug override, alz_debug_seg_max_streams:
+// tests, tools/mid_batch_encode.py) -- never more than one launch of encode_core takes (65 535 buffers: the scratch is laid out for the launch's own count)
+int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t max_streams, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
                      fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
     const u32 rule = g.max_chain == 1 ? 1280u : g.max_chain < 64 ? 1536u : 512u;
-    const u32 most = g_seg_max_streams == 0xFFFFFFFFu ? rule : g_seg_max_streams;
+    const u32 most = max_streams == 0xFFFFFFFFu ? rule : (max_streams < 65535u ? max_streams : 65535u);
     if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
     uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
     if (want < 1024u) want = 1024u;

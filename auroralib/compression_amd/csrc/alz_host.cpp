@@ -109,9 +109,12 @@ struct alz_ctx {
     int variant = 0;                           // alz_ctx_set_kernel_variant
     uint64_t big_enc_launches = 0;             // streams the whole-GPU ENCODE path has taken (alz_encode_big.h)
     uint64_t seg_enc_launches = 0;             // launches of the segmented parse + emit (alz_encode_seg.h)
+    int scan_mode = 0;                         // alz_debug_scan_mode: the encoder's scan path (enc_scan_select_kernel) -- 0 its probe decides, 1 every eligible stream, 2 off
+    uint32_t seg_max_streams = 0xFFFFFFFFu;    // alz_debug_seg_max_streams: ~0 the rule, 0 the path off, else that many buffers instead of the rule -- of THIS context
     uint64_t chunk_repeats = 0;                // executes alz_plan_results repeated without the work queue (a bounded spin ran out)
     uint32_t big_min = 24u << 10;              // (24 KiB: tools/single_decode_sizes.py -- 0.18 ms either way at 16 KiB, 0.18 against 0.30 at 32) a lone stream of at least this many output bytes goes to the whole-GPU path (alz_big.hip)
-    uint64_t big_launches = 0;                 // how often that path was enqueued (alz_ctx_big_stream)
+    uint64_t big_launches = 0;                 // how often that path was enqueued
+    uint32_t* d_big_accepted = nullptr;        // device words: [0] streams that path has ACCEPTED -- decoded itself, gate left closed (big_write bumps it; alz_ctx_big_stream reports it); [1] streams the encoder's scan path has taken
     hipEvent_t big_evt = nullptr; bool big_evt_set = false;   // behind the last whole-GPU decode that used d_bigbuf (plans that borrow it run one after the other)
     void* d_bigbuf = nullptr; size_t d_bigbuf_cap = 0;   // its scratch for the plans of the host-buffer entry points (grow-only)
     // two pinned staging buffers: host-buffer calls move the caller's (pageable) bytes through them, so that the memcpy of
@@ -156,11 +159,17 @@ struct alz_plan {
     // The flag-byte family as a work queue of (stream, chunk) items (alz_decode_fastq_kernel): for a format whose streams are more than the GPU holds
     // wavefronts, so that the launch does not end in a partly filled round.  One allocation: [64 control words | a 128-byte line per slot's flag | items | slots].
     struct chunk_plan { uint32_t n_items = 0, n_slots = 0, lw = 0; void* d_mem = nullptr; uint32_t* d_ctl = nullptr; uint32_t* d_flags = nullptr;
-                        alz_chunk_item* d_items = nullptr; uint8_t* d_slots = nullptr; size_t zero_bytes = 0; };
+                        alz_chunk_item* d_items = nullptr; uint8_t* d_slots = nullptr; size_t zero_bytes = 0; alz_queue_bounds bounds{}; };
     chunk_plan chunk[ALZ_FMT_COUNT];
+    // A queue plan owns MUTABLE device state too (queue heads, flags, hand-over slots): its executes are ordered one behind the other by `q_evt`, on whatever streams
+    // the caller enqueues them (round 6; big plans: `big_evt`).  `d_tmo`: one STICKY word per format outside the region an execute zeroes -- a bounded spin that ran out
+    // sets it, the gated launch enqueued behind every queue launch then decodes that format again with one wavefront per stream IN STREAM ORDER (so every execute is
+    // whole when its stream gets past it, whichever buffers it ran on), nothing ever clears it, and alz_plan_results, seeing it, moves the plan off the queue for good.
+    uint32_t* d_tmo = nullptr;
+    hipEvent_t q_evt = nullptr; bool q_evt_set = false;     // q_evt_set: the event stands behind the last execute on a stream of the CALLER's
+    bool q_ctx_pending = false;              // an execute went onto the context's own stream since: ordered by that stream itself, its event is recorded only when another stream needs it
+    uint32_t epoch = 0;                      // of the last queue launch (1 .. 2^30 - 1; flags and heads are zeroed once, at creation, and again when the counter wraps)
     bool no_chunks = false;                  // a bounded spin of the queue kernel ran out once: this plan stays with the one-wavefront-per-stream kernels
-    bool chunk_ran = false;                  // the last execute used the queue for some format: alz_plan_results looks at the timeout words
-    const void* last_src = nullptr; void* last_dst = nullptr;
 };
 
 static alz_lz_properties effective_lz(const alz_lz_properties* p) {
@@ -177,7 +186,15 @@ int alz_abi_version(void) { return ALZ_ABI_VERSION; }
 int alz_ctx_big_stream(alz_ctx* c, uint32_t min_bytes, uint64_t* launches_out) {
     if (!c) return fail(ALZ_E_INVALID, "alz_ctx_big_stream: ctx is NULL");
     if (min_bytes) c->big_min = min_bytes;
-    if (launches_out) *launches_out = c->big_launches + c->big_enc_launches;
+    if (launches_out) {
+        // streams the two whole-GPU paths have TAKEN: the decode side counts on the device, where the path decides (a stream it declines goes to the kernel behind the gate
+        // and is not counted); everything enqueued so far on any stream is waited for, so the number is exact when the caller asks
+        uint32_t acc = 0;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->d_big_accepted) HIP_TRY(hipMemcpy(&acc, c->d_big_accepted, sizeof(acc), hipMemcpyDeviceToHost));
+        *launches_out = (uint64_t)acc + c->big_enc_launches;
+    }
     return ALZ_OK;
 }
 int alz_ctx_set_kernel_variant(alz_ctx* c, int variant) {
@@ -193,15 +210,33 @@ int alz_ctx_set_exact_kernels(alz_ctx* c, int on) {
 /* not in the public header: resident waves per CU of the production kernel of `format` (tuning aid) */
 int alz_debug_occupancy(int format) { return alz_kernel_occupancy(format); }
 /* not in the public header: the largest batch (buffers of one format) whose parse + emit runs over segments (alz_encode_seg.h; 0: never), and how often a context has gone that way */
-void alz_debug_seg_max_streams(uint32_t v) { alz_debug_set_seg_max_streams(v); }
+void alz_debug_seg_max_streams(alz_ctx* c, uint32_t v) { if (c) c->seg_max_streams = v; }
+/* not in the public header: the encoder's scan path (streams whose parse visits few positions go without kernels A and B): 0 the probe decides, 1 every eligible stream, 2 off */
+void alz_debug_scan_mode(alz_ctx* c, int mode) { if (c && mode >= 0 && mode <= 2) c->scan_mode = mode; }
+/* ... and how many streams have gone that way on this context (counted on the device, where the probe decides; waits for the device) */
+uint64_t alz_debug_scan_streams(alz_ctx* c) {
+    uint32_t v = 0;
+    if (!c || !c->d_big_accepted || hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, c->d_big_accepted + 1, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return v;
+}
 uint64_t alz_debug_seg_launches(const alz_ctx* c) { return c ? c->seg_enc_launches : 0; }
 /* not in the public header: how often alz_plan_results has repeated a launch without the work queue on this context (expected: never) */
 uint64_t alz_debug_chunk_repeats(const alz_ctx* c) { return c ? c->chunk_repeats : 0; }
 /* not in the public header: output bytes per chunk of the work-queue kernels */
 int alz_debug_chunk_bytes(void) { return (int)ALZ_CHUNK_OUT; }
 /* not in the public header: the (stream, chunk) items of a plan's work queues (0: the plan decodes with one wavefront per stream) */
-/* not in the public header: the control words of a format's work queue (0: queue head, 32: timeout flag) and, behind them from word 64 on, the flag of every hand-over slot (one per 32 words) */
-int alz_debug_plan_queue_ctl(alz_plan* p, int fmt, uint32_t* out, uint32_t nwords) { if (!p || fmt < 0 || fmt >= ALZ_FMT_COUNT || !p->chunk[fmt].d_ctl) return -1; const uint32_t have = 64u + p->chunk[fmt].n_slots * ALZ_CHUNK_FLAG_STRIDE; if (nwords > have) nwords = have; return hipMemcpy(out, p->chunk[fmt].d_ctl, 4 * (size_t)nwords, hipMemcpyDeviceToHost) == hipSuccess ? (int)nwords : -1; }
+/* not in the public header: the control words of a format's work queue (256 (e & 1) + 32 q, q < 8: the head of sub-queue q in the set launch e drew from = tickets drawn; word 1: the plan's sticky
+   timeout word for the format, which lives elsewhere and is shown here) and, behind them from word ALZ_CHUNK_CTL_WORDS = 512 on, the flag of every hand-over slot (one per 32 words), reduced to the
+   state the LAST launch left */
+int alz_debug_plan_queue_ctl(alz_plan* p, int fmt, uint32_t* out, uint32_t nwords) {
+    if (!p || fmt < 0 || fmt >= ALZ_FMT_COUNT || !p->chunk[fmt].d_ctl) return -1;
+    const uint32_t have = ALZ_CHUNK_CTL_WORDS + p->chunk[fmt].n_slots * ALZ_CHUNK_FLAG_STRIDE;
+    if (nwords > have) nwords = have;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, p->chunk[fmt].d_ctl, 4 * (size_t)nwords, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (uint32_t k = ALZ_CHUNK_CTL_WORDS; k < nwords; k += ALZ_CHUNK_FLAG_STRIDE) out[k] = (out[k] >> 2) == p->epoch ? (out[k] & 3u) : 0u;   // (flags of the LAST launch: 0 not set, 1 handed over, 2 ended, 3 timed out)
+    if (nwords > 1u && p->d_tmo && hipMemcpy(out + 1, p->d_tmo + fmt, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)nwords;
+}
 int alz_debug_plan_queue_items(alz_plan* p) { int n = 0; if (p) for (int f = 0; f < ALZ_FMT_COUNT; f++) n += (int)p->chunk[f].n_items; return n; }
 const char* alz_last_error(void) { return g_err; }
 
@@ -226,6 +261,8 @@ int alz_create(int device, alz_ctx** out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming);
     for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->join[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_big_accepted, 256);
+    if (e == hipSuccess) e = hipMemset(c->d_big_accepted, 0, 256);
     if (e != hipSuccess) { alz_destroy(c); return fail(ALZ_E_HIP, "context creation failed: %s", hipGetErrorString(e)); }   // (what was created so far goes with it)
     *out = c;
     return ALZ_OK;
@@ -238,6 +275,7 @@ void alz_destroy(alz_ctx* c) {
     release_scratch(c);
     for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); }
     if (c->big_evt) (void)hipEventDestroy(c->big_evt);
+    if (c->d_big_accepted) (void)hipFree(c->d_big_accepted);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->fork) (void)hipEventDestroy(c->fork);
@@ -312,6 +350,8 @@ void alz_plan_destroy(alz_ctx* c, alz_plan* p) {
     }
     if (p->d_big && !p->big_borrowed) (void)hipFree(p->d_big);
     if (p->big_evt) (void)hipEventDestroy(p->big_evt);
+    if (p->q_evt) (void)hipEventDestroy(p->q_evt);
+    if (p->d_tmo) (void)hipFree(p->d_tmo);
     if (p->done_evt) (void)hipEventDestroy(p->done_evt);
     for (int f = 0; f < ALZ_FMT_COUNT; f++) if (p->chunk[f].d_mem) (void)hipFree(p->chunk[f].d_mem);
     delete p;
@@ -420,7 +460,7 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
             // (with 40 KiB chunks and the descriptor table -- 29 places per CU for Yaz0 / LZ11 -- the queue wins earlier: 3 600 / 4 200 streams 1.44 / 1.58 ms one wavefront per stream, 1.37 / 1.42 as a
             // queue: from 0.4 of the places on, and never where two wavefronts share a stream -- up to 3 072 streams: 3 000 streams 1.14 that way, 1.31 as a queue)
             const uint64_t tenths = (f == ALZ_FMT_PRS_BE || f == ALZ_FMT_PRS_LE) ? 10ull : 4ull;
-            if (!force_queue && (occ < 1 || cnt[f] <= 3072u || 10ull * cnt[f] <= tenths * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
+            if (!force_queue && (occ < 1 || cnt[f] <= alz_two_wave_max() || 10ull * cnt[f] <= tenths * (uint64_t)occ * (uint64_t)pr.multiProcessorCount)) continue;
             // items in chunk-major order over the format's cost-ordered list; a stream's slots are consecutive
             std::vector<uint32_t> nch(cnt[f]), base(cnt[f]);
             uint32_t slots = 0, maxch = 0; uint64_t items64 = 0;
@@ -431,18 +471,31 @@ static int plan_create(alz_ctx* c, const alz_lz_properties* props, uint32_t n, c
                 nch[k] = m; base[k] = slots; slots += m; items64 += m; if (m > maxch) maxch = m;
             }
             if (maxch < 2 || items64 > 0x3FFFFFFFull) continue;
+            // ALZ_QUEUE_SHARDS sub-queues, one behind the other: stream k of the cost-ordered list goes to sub-queue k mod 8 (every sub-queue gets its share of the costly
+            // streams, and the sub-queues come out equally long: workgroups are dealt round-robin over the XCDs and each prefers its XCD's sub-queue), chunk-major inside
             std::vector<alz_chunk_item> items; items.reserve((size_t)items64);
-            for (uint32_t ch = 0; ch < maxch; ch++)
-                for (uint32_t k = 0; k < cnt[f]; k++)
-                    if (ch < nch[k]) items.push_back(alz_chunk_item{index[p->fmt_off[f] + k], ch, base[k] + ch, ch + 1u == nch[k] ? 1u : 0u});
+            alz_queue_bounds qb{};
+            for (uint32_t q = 0; q < ALZ_QUEUE_SHARDS; q++) {
+                qb.off[q] = (uint32_t)items.size();
+                for (uint32_t ch = 0; ch < maxch; ch++)
+                    for (uint32_t k = q; k < cnt[f]; k += ALZ_QUEUE_SHARDS)
+                        if (ch < nch[k]) items.push_back(alz_chunk_item{index[p->fmt_off[f] + k], ch, base[k] + ch, ch + 1u == nch[k] ? 1u : 0u});
+            }
+            qb.off[ALZ_QUEUE_SHARDS] = (uint32_t)items.size();
             alz_plan::chunk_plan& cp = p->chunk[f];
-            const size_t zero_bytes = (256 + (size_t)slots * 4 * ALZ_CHUNK_FLAG_STRIDE + 255) & ~(size_t)255, items_bytes = (items.size() * sizeof(alz_chunk_item) + 255) & ~(size_t)255;
+            const size_t zero_bytes = (4 * (size_t)ALZ_CHUNK_CTL_WORDS + (size_t)slots * 4 * ALZ_CHUNK_FLAG_STRIDE + 255) & ~(size_t)255, items_bytes = (items.size() * sizeof(alz_chunk_item) + 255) & ~(size_t)255;
             const size_t slot_bytes = (size_t)slots * (32 + lw);
             if (hipMalloc(&cp.d_mem, zero_bytes + items_bytes + slot_bytes + 256) != hipSuccess) { cp.d_mem = nullptr; (void)hipGetLastError(); continue; }
-            cp.d_ctl = (uint32_t*)cp.d_mem; cp.d_flags = cp.d_ctl + 64; cp.zero_bytes = zero_bytes;
+            cp.d_ctl = (uint32_t*)cp.d_mem; cp.d_flags = cp.d_ctl + ALZ_CHUNK_CTL_WORDS; cp.zero_bytes = zero_bytes; cp.bounds = qb;
             cp.d_items = (alz_chunk_item*)((uint8_t*)cp.d_mem + zero_bytes); cp.d_slots = (uint8_t*)cp.d_mem + zero_bytes + items_bytes;
-            if (hipMemcpy(cp.d_items, items.data(), items.size() * sizeof(alz_chunk_item), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(cp.d_mem); cp = alz_plan::chunk_plan(); (void)hipGetLastError(); continue; }
+            if (hipMemset(cp.d_mem, 0, zero_bytes) != hipSuccess || hipMemcpy(cp.d_items, items.data(), items.size() * sizeof(alz_chunk_item), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(cp.d_mem); cp = alz_plan::chunk_plan(); (void)hipGetLastError(); continue; }
             cp.n_items = (uint32_t)items.size(); cp.n_slots = slots; cp.lw = lw;
+            if (!p->d_tmo) {                                   // the sticky timeout words, one per format (zeroed ONCE, here)
+                if (hipMalloc((void**)&p->d_tmo, 256) != hipSuccess || hipMemset(p->d_tmo, 0, 256) != hipSuccess) {
+                    if (p->d_tmo) (void)hipFree(p->d_tmo);
+                    p->d_tmo = nullptr; (void)hipFree(cp.d_mem); cp = alz_plan::chunk_plan(); (void)hipGetLastError();
+                }
+            }
         }
     }
     *out = p;
@@ -485,7 +538,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
         if (*ev_set) HIP_TRY(hipStreamWaitEvent(s, *ev, 0));           // (a no-op on the stream that recorded it; orders any other stream behind the last run)
         for (uint32_t i = 0; i < p->n; i++) {
             const int f = (int)p->big_streams[i].format;
-            hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_streams[i], &p->lz, p->d_results + i, p->d_big, p->d_gate);
+            hipError_t e = alz_launch_big(f, s, d_src_base, d_dst_base, &p->big_streams[i], &p->lz, p->d_results + i, p->d_big, p->d_gate, c->d_big_accepted);
             if (e == hipSuccess) e = alz_launch_decode_gated(f, s, d_src_base, d_dst_base, p->d_streams, p->d_index + p->big_pos[i], 1, p->d_results, &p->lz, p->d_gate);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "big-stream launch (format %d) failed: %s", f, hipGetErrorString(e));
             c->big_launches++;
@@ -495,14 +548,31 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
     }
     int nfmt = 0;
     for (int f = 0; f < ALZ_FMT_COUNT; f++) nfmt += p->fmt_cnt[f] ? 1 : 0;
-    p->chunk_ran = false; p->last_src = d_src_base; p->last_dst = d_dst_base;
+    // The work queues of this plan are in use by this execute: it starts behind the execute before it (the queue heads, flags and slots are the plan's, one set),
+    // wherever that one was enqueued, and leaves the event for the next.  Plans without a queue only read their tables.
+    const bool queued = p->d_tmo && !c->exact && (c->variant == 0 || c->variant == 3) && !p->no_chunks;
+    const bool foreign = s != c->stream;
+    if (queued) {
+        // (executes on the context's own stream -- the usual case, and bench.py's -- are ordered by the stream and cost no event: a record per execute is a
+        // barrier packet between the kernels of a 0.7 ms launch.  A stream of the caller's may be gone by the next call, so its event is recorded at once.)
+        if (!p->q_evt) HIP_TRY(hipEventCreateWithFlags(&p->q_evt, hipEventDisableTiming));
+        if (foreign && p->q_ctx_pending) { HIP_TRY(hipEventRecord(p->q_evt, c->stream)); p->q_evt_set = true; p->q_ctx_pending = false; }
+        if (p->q_evt_set) { HIP_TRY(hipStreamWaitEvent(s, p->q_evt, 0)); if (!foreign) p->q_evt_set = false; }
+        // this launch's epoch: what makes a hand-over flag count, and which of the two sets of queue heads is drawn from -- nothing is zeroed per launch.  When the
+        // 30-bit counter comes round (a billion executes) everything is zeroed once, as at creation.
+        if (p->epoch >= 0x3FFFFFFFu) {
+            for (int f = 0; f < ALZ_FMT_COUNT; f++) if (p->chunk[f].n_items) HIP_TRY(hipMemsetAsync(p->chunk[f].d_ctl, 0, p->chunk[f].zero_bytes, s));
+            p->epoch = 0;
+        }
+        p->epoch++;
+    }
     // a format's launch: the work queue of chunks where the plan has one (and the context has not been switched to other kernels since), else one wavefront per stream
     auto launch_format = [&](int f, hipStream_t on) -> hipError_t {
         alz_plan::chunk_plan& cp = p->chunk[f];
-        if (cp.n_items && !c->exact && (c->variant == 0 || c->variant == 3) && !p->no_chunks) {
-            hipError_t e = hipMemsetAsync(cp.d_ctl, 0, cp.zero_bytes, on);               // queue head, timeout word, every boundary's flag: before EVERY launch
-            if (e == hipSuccess) e = alz_launch_decode_chunked(f, on, d_src_base, d_dst_base, p->d_streams, cp.d_items, cp.n_items, p->d_results, &p->lz, cp.d_ctl, cp.d_flags, cp.d_slots);
-            if (e == hipSuccess) p->chunk_ran = true;
+        if (cp.n_items && queued) {
+            hipError_t e = alz_launch_decode_chunked(f, on, d_src_base, d_dst_base, p->d_streams, cp.d_items, cp.n_items, &cp.bounds, p->d_results, &p->lz, cp.d_ctl, cp.d_flags, cp.d_slots, p->d_tmo + f, p->epoch);
+            // ... and behind it the same streams with one wavefront per stream, gated by that word: workgroups that return at once (always, so far), or the whole repair in stream order
+            if (e == hipSuccess) e = alz_launch_decode_gated(f, on, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, p->d_tmo + f);
             return e;
         }
         return alz_launch_decode(f, on, d_src_base, d_dst_base, p->d_streams, p->d_index + p->fmt_off[f], p->fmt_cnt[f], p->d_results, &p->lz, c->exact, p->n, c->variant);
@@ -513,6 +583,7 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
             hipError_t e = launch_format(f, s);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "kernel launch (format %d) failed: %s", f, hipGetErrorString(e));
         }
+        if (queued) { if (foreign) { HIP_TRY(hipEventRecord(p->q_evt, s)); p->q_evt_set = true; } else p->q_ctx_pending = true; }
         return plan_mark_done(p, s, s != c->stream);
     }
     // mixed batch: one kernel per format, forked onto side streams so that they share the GPU (each format alone may
@@ -552,6 +623,10 @@ int alz_plan_execute(alz_ctx* c, alz_plan* p, const void* d_src_base, void* d_ds
         if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join[i], 0);
         if (e != hipSuccess && rc == ALZ_OK) rc = fail(ALZ_E_HIP, "joining the side streams failed: %s", hipGetErrorString(e));
     }
+    if (queued) {
+        if (!foreign) p->q_ctx_pending = true;
+        else { hipError_t e = hipEventRecord(p->q_evt, s); if (e == hipSuccess) p->q_evt_set = true; else if (rc == ALZ_OK) rc = fail(ALZ_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)); }
+    }
     if (rc == ALZ_OK) rc = plan_mark_done(p, s, s != c->stream);
     return rc;
 }
@@ -574,23 +649,14 @@ int alz_plan_results(alz_ctx* c, alz_plan* p, alz_result* results) {
     if (!c || !p || (p->n && !results)) return fail(ALZ_E_INVALID, "alz_plan_results: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     if (p->done_evt_set) HIP_TRY(hipStreamWaitEvent(c->stream, p->done_evt, 0));    // (the last execute ran on a stream of the caller's)
-    if (p->chunk_ran) {
-        // the work queue's bounded spins: if one ran out (never seen), the launch is repeated with one wavefront per stream -- the results then are that launch's
-        uint32_t tmo = 0;
-        for (int f = 0; f < ALZ_FMT_COUNT; f++) {
-            if (!p->chunk[f].n_items) continue;
-            uint32_t t = 0;
-            HIP_TRY(hipMemcpyAsync(&t, p->chunk[f].d_ctl + 32, sizeof(t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            tmo |= t;
-        }
-        if (tmo) {
-            p->no_chunks = true; c->chunk_repeats++;
-            if (int rc = alz_plan_execute(c, p, p->last_src, p->last_dst, nullptr)) return rc;
-        }
-    }
+    // the work queue's bounded spins: if one ever ran out (never seen), the gated launch behind that execute has already decoded the format again with one wavefront per
+    // stream -- in stream order, so the results and every execute's bytes are whole -- and the word stays set: the plan leaves the queue for good
+    uint32_t tmo[ALZ_FMT_COUNT] = {0};
+    const bool look = p->d_tmo && !p->no_chunks;
+    if (look) HIP_TRY(hipMemcpyAsync(tmo, p->d_tmo, sizeof(tmo), hipMemcpyDeviceToHost, c->stream));
     if (p->n) HIP_TRY(hipMemcpyAsync(results, p->d_results, p->n * sizeof(alz_result), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (look) for (int f = 0; f < ALZ_FMT_COUNT; f++) if (tmo[f]) { p->no_chunks = true; c->chunk_repeats++; break; }
     return ALZ_OK;
 }
 
@@ -940,7 +1006,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         any_mask = any_mask || alz_encode_format_needs_mask(lvl2 ? ALZ_FMT_FASTLZ : f);
         // a batch of few buffers of a flag-bit format: parse and emitter over segments (alz_encode_seg.h) -- behind kernel B and the roles walk
         uint32_t seg_hist = 0;
-        if (!lvl2 && !c->exact && c->variant == 0 && alz_encode_segmented(f, g, cnt[f], max_len, &seg_len[f], &seg_kmax[f], &seg_hist)) {
+        if (!lvl2 && !c->exact && c->variant == 0 && alz_encode_segmented(f, g, cnt[f], max_len, c->seg_max_streams, &seg_len[f], &seg_kmax[f], &seg_hist)) {
             any_match = any_mask = true;
             size_t ab = 0; (void)alz_encode_aseg(g, cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, &ab);
             const size_t b = ((alz_encode_seg_bytes(cnt[f], seg_kmax[f], seg_hist) + 255) & ~(size_t)255) + ab; if (b > seg_bytes) seg_bytes = b;
@@ -1059,7 +1125,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     void* d_tail = nullptr; uint32_t* d_sel = nullptr;
     if (e == hipSuccess) e = sc.alloc(&d_tail, tail_bytes, !tail_ix.empty());
     { void* skip_big = nullptr; if (e == hipSuccess) e = sc.alloc(&skip_big, 0, false); }        // (slot 11: the whole-GPU path's scratch)
-    if (e == hipSuccess) e = sc.alloc((void**)&d_sel, ((size_t)2 * n + 64) * sizeof(uint32_t), any_match);     // which kernel B per stream (enc_probe_kernel)
+    if (e == hipSuccess) e = sc.alloc((void**)&d_sel, ((size_t)4 * n + 128) * sizeof(uint32_t), any_match);     // which kernel B per stream (enc_probe_kernel); behind it the two lists of enc_scan_select_kernel
     int* d_narrow = nullptr;
     if (e == hipSuccess) e = sc.alloc((void**)&d_narrow, (size_t)total * sizeof(int) + 256, any_narrow);   // slot 13: the links of the finder's own hash width, narrowed from 15-bit ones (enc_narrow_kernel)
     void* d_seg = nullptr;
@@ -1092,6 +1158,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
     HIP_TRY(hipMemsetAsync(d_aux, 0, (size_t)n * sizeof(alz_encode_aux), c->stream));
     if (any_mask) HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)total / 8 + 64, c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const alz_encode_side side_q = { c->aux[0], c->fork, c->join[1] };      // (the scan streams' kernel runs beside the others: alz_launch_encode)
     for (int f = 0; f <= ALZ_FMT_COUNT; f++) {
         const bool lvl2 = f == ALZ_FMT_COUNT;
         const int fmt = lvl2 ? ALZ_FMT_FASTLZ : f;
@@ -1101,7 +1168,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         for (uint32_t done = 0; done < count; done += CH) {
             const uint32_t k = count - done < CH ? count - done : CH;
             e = alz_launch_encode(fmt, c->stream, d_src_base, d_dst_base, d_streams, d_index + first + done, k, max_len, d_prev4, d_prevm, d_narrow,
-                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g, d_sel, n, seg_len[f] ? d_seg : nullptr, seg_len[f], seg_kmax[f]);
+                                  d_match, d_pos, d_side, d_mask, d_results, d_aux, g, d_sel, n, seg_len[f] ? d_seg : nullptr, seg_len[f], seg_kmax[f], (c->exact || c->variant != 0) ? 2 : c->scan_mode, c->d_big_accepted ? c->d_big_accepted + 1 : nullptr, &side_q);
             if (e != hipSuccess) return fail(ALZ_E_HIP, "encode launch (format %d) failed: %s", fmt, hipGetErrorString(e));
             if (seg_len[f]) c->seg_enc_launches++;
         }

@@ -285,6 +285,54 @@ typedef __attribute__((address_space(1))) unsigned long long alz_gu64;
 __device__ __forceinline__ void chunk_store32(void* p, u32 v) { __hip_atomic_store(reinterpret_cast<u32*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 chunk_load32(const void* p) { return __hip_atomic_load(reinterpret_cast<const u32*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The workgroup's item.  The queue is ALZ_QUEUE_SHARDS sub-queues (a stream's chunks all in one of them, chunk-major inside it), each with its own head word on its own
+// 128-byte line: ONE head word serves ~88 returning device-scope atomics per microsecond (MI355X_MICROARCH.md, "dequeue"), so the ~6 400 workgroups a launch starts with
+// spent the first ~70 us queueing for their tickets (measured: the Yaz0 launch 2.509 -> 2.574 ms with one head), eight heads serve them in ~9.  A workgroup prefers the
+// sub-queue of the XCD it runs on (HW_REG_XCC_ID: workgroups are dealt round-robin over the XCDs, so the eight heads are drawn from at the same rate) and goes round the
+// others when that one is exhausted -- preference and placement are for speed only.  What correctness rests on: inside a sub-queue tickets are handed out in order to
+// workgroups that HAVE started, and the chunk an item waits for is an earlier item of the SAME sub-queue; so the waiting item with the smallest ticket of its sub-queue
+// always waits for a running (or finished) workgroup, which waits, if at all, for a still smaller ticket: no cycle, whatever the dispatch order.
+// Every workgroup draws at most one ticket per sub-queue and the launch has exactly as many workgroups as items, so every item is taken.
+// Nothing of the queue is zeroed between launches (round 6: a memset in front of every launch was a third serialised operation per execute): the launch carries the
+// plan's EPOCH -- a hand-over flag counts only when it holds this launch's epoch (queue_flag_* below) --, and the heads exist twice: launch e draws from set e & 1, and
+// the workgroup that draws ticket 0 of a sub-queue zeroes that sub-queue's head in the OTHER set, which the launch before left behind and the next one will draw from
+// (launches of one plan never overlap: alz_plan_execute orders them by an event).
+__device__ __forceinline__ u32 queue_ticket(u32* ctl, u32 epoch, const alz_queue_bounds& qb, int lane) {
+    const u32 xcc = (u32)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & (ALZ_QUEUE_SHARDS - 1u);    // hwreg(HW_REG_XCC_ID, 0, 4)
+    u32* const head = ctl + (epoch & 1u) * (ALZ_CHUNK_CTL_WORDS / 2u);
+    u32* const other = ctl + ((epoch & 1u) ^ 1u) * (ALZ_CHUNK_CTL_WORDS / 2u);
+    u32 item = 0xFFFFFFFFu;
+#pragma unroll
+    for (u32 j = 0; j < ALZ_QUEUE_SHARDS; j++) {
+        if (item == 0xFFFFFFFFu) {                               // (wave-uniform: `item` comes out of readfirstlane)
+            const u32 q = (xcc + j) & (ALZ_QUEUE_SHARDS - 1u);
+            const u32 lo = qb.off[q], hi = qb.off[q + 1u];
+            if (lo < hi) {
+                u32 t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(head + 32u * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t = uni(t);
+                if (t == 0u && lane == 0) chunk_store32(other + 32u * q, 0u);
+                if (t < hi - lo) item = lo + t;
+            }
+        }
+    }
+    return item;
+}
+// A hand-over flag: (epoch << 2) | state, state 1 handed over, 2 the stream has ended, 3 a wait ran out.  A word of another epoch (0: never written) is "not yet".
+__device__ __forceinline__ u32 queue_flag_wait(const u32* flag, u32 epoch, int lane) {
+    u32 f = 0;
+    if (lane == 0) {
+        u32 spins = 0;
+        for (;;) {
+            const u32 w = chunk_load32(flag);
+            if ((w >> 2) == epoch) { f = w & 3u; break; }
+            if (++spins > ALZ_CHUNK_SPINS) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    return uni(f);
+}
+
 // One item of the queue: set up from the hand-over slot (or from nothing), decode to the chunk's limit, flush, hand over or finish.
 // Returns the flag the item leaves in its slot: 1 handed over (window + cursors stored write-through into `out_slot`, NOT yet drained),
 // 2 the stream ended here (result written), 0 the stream's last chunk (result written).
@@ -377,9 +425,9 @@ __device__ __forceinline__ u32 fastq_item(const u8* src_base, u8* dst_base, cons
 
 template <int FMT>
 __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base,
-                                                             const alz_stream* __restrict__ streams, const alz_chunk_item* __restrict__ items, u32 n_items,
+                                                             const alz_stream* __restrict__ streams, const alz_chunk_item* __restrict__ items, alz_queue_bounds qb,
                                                              alz_result* __restrict__ results, alz_lz_properties lz, u32 lw,
-                                                             u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo) {
+                                                             u32* __restrict__ head, u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo, u32 epoch) {
     constexpr bool THREE = (FMT == ALZ_FMT_YAY0 || FMT == ALZ_FMT_MIO0);
     constexpr int NC = THREE ? 3 : 1;
     constexpr u32 LWMAX = 4096u;
@@ -389,13 +437,10 @@ __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(cons
     __shared__ __attribute__((aligned(16))) u8 lds[FSCR + NC * CACHE + LWMAX];
     const int lane = (int)(threadIdx.x & 63u);
     const u32 slot_bytes = 32u + lw;                         // a boundary's slot: 8 state words, then the window
-    // ONE item per workgroup, in dispatch order (item = blockIdx.x): workgroups start in index order, so the chunk an item waits for belongs to a
-    // workgroup that has started (and waits, if at all, for a still earlier one).  HIP does not promise that order: it is only what makes the wait short --
-    // a bounded spin that runs out makes the host repeat the launch with one wavefront per stream.  (A persistent wavefront popping items from a
-    // counter in a loop was the first form; its loop came out of the compiler as a divergent one -- exec-masked, a readfirstlane per trip -- and the
-    // decode ran with lanes switched off and never ended: docs/EXPERIMENTS.md 10.7.)
-    const u32 item = blockIdx.x;
-    if (item >= n_items) return;
+    // ONE item per workgroup, taken as a TICKET when the workgroup starts (round 6; round 5 used item = blockIdx.x and relied on workgroups being dispatched in
+    // index order, which HIP does not promise): queue_ticket draws the next number of a sub-queue, once per sub-queue at most, no loop around the decode.
+    const u32 item = queue_ticket(head, epoch, qb, lane);
+    if (item == 0xFFFFFFFFu) return;
     const alz_chunk_item it = items[item];
     const u32 sid = uni(it.sid), c = uni(it.chunk), oslot = uni(it.slot), last = uni(it.last);
     u32 p0 = 0, p1 = 0, p2 = 0, start = 0;
@@ -405,12 +450,7 @@ __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(cons
     u8* out_slot = slots + (size_t)oslot * slot_bytes;
     if (c > 0u) {
         // ---- the chunk before this one: wait for its flag (ONE lane polls ONE word, relaxed), acquire once
-        u32 f = 0;
-        if (lane == 0) {
-            u32 spins = 0;
-            while ((f = chunk_load32(flags + (size_t)(oslot - 1u) * ALZ_CHUNK_FLAG_WORDS)) == 0u) { if (++spins > ALZ_CHUNK_SPINS) break; __builtin_amdgcn_s_sleep(16); }
-        }
-        f = uni(f);
+        const u32 f = queue_flag_wait(flags + (size_t)(oslot - 1u) * ALZ_CHUNK_FLAG_WORDS, epoch, lane);
         if (f == 0u || f == 3u) {                         // never seen: the host repeats the launch the other way; whoever waits for THIS chunk does not wait long
             if (lane == 0) atomicOr(tmo, 1u);
             flagv = 3u; run = false;
@@ -437,7 +477,7 @@ __global__ __launch_bounds__(64) ALZ_FAST_ATTR void alz_decode_fastq_kernel(cons
     // ---- the item's ONE flag: every storing lane drains its write-through stores first, then one lane signals
     if (flagv) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) chunk_store32(flags + (size_t)oslot * ALZ_CHUNK_FLAG_WORDS, flagv);
+        if (lane == 0) chunk_store32(flags + (size_t)oslot * ALZ_CHUNK_FLAG_WORDS, (epoch << 2) | flagv);
     }
 }
 
@@ -1052,17 +1092,21 @@ void alz_decode_queue2_kernel(const u8* __restrict__ src_base, u8* __restrict__ 
 // sends the executing wavefront on alone, to the end of the stream, as in the kernel above.
 template <int FMT>
 __global__ __launch_bounds__(128) void alz_decode_prs2q_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
-                                                               const alz_chunk_item* __restrict__ items, u32 n_items, alz_result* __restrict__ results,
-                                                               u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo) {
+                                                               const alz_chunk_item* __restrict__ items, alz_queue_bounds qb, alz_result* __restrict__ results,
+                                                               u32* __restrict__ head, u32* __restrict__ flags, u8* __restrict__ slots, u32* __restrict__ tmo, u32 epoch) {
     constexpr bool BIG = (FMT == ALZ_FMT_PRS_BE);
     constexpr u32 LW = 8192u, QCH = 512u, QCACHE = 2u * QCH + 32u, QAHEAD = QCH + 76u, SCR = 128u;
     constexpr u32 MB = 64u + 8u;                              // mailbox slot: 64 tokens + {nt | stop, total, position behind, flag register, terminator, chunk end}
     constexpr u32 CHB = ALZ_CHUNK_OUT_PRS;
     __shared__ __attribute__((aligned(16))) u8 lds[SCR + 256 + QCACHE + LW + 256 + QCACHE + 2u * MB * 4u + 32u];
-    const u32 item = blockIdx.x;
-    if (item >= n_items) return;
     const int lane = (int)(threadIdx.x & 63u);
     const bool walker = threadIdx.x < 64u;
+    // the workgroup's item: a ticket drawn by the first wavefront (queue_ticket, above alz_decode_fastq_kernel), shared with the other one through LDS
+    u32* const ticket = reinterpret_cast<u32*>(lds + SCR + 256 + QCACHE + LW + 256 + QCACHE) + 2u * MB + 4u;
+    if (threadIdx.x < 64u) { const u32 t = queue_ticket(head, epoch, qb, lane); if (lane == 0) *ticket = t; }
+    __syncthreads();
+    const u32 item = uni(*ticket);
+    if (item == 0xFFFFFFFFu) return;
     const alz_chunk_item it = items[item];
     const u32 sid = uni(it.sid), c = uni(it.chunk), oslot = uni(it.slot), last = uni(it.last);
     const alz_stream st = streams[sid];
@@ -1103,12 +1147,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2q_kernel(const u8* __restr
     u32 flagv = 0; bool run = true;
     u32 p0 = 0, fl = 1u, start = 0;
     if (c > 0u) {
-        u32 f = 0;
-        if (lane == 0) {
-            u32 spins = 0;
-            while ((f = chunk_load32(flags + (size_t)(oslot - 1u) * ALZ_CHUNK_FLAG_WORDS)) == 0u) { if (++spins > ALZ_CHUNK_SPINS) break; __builtin_amdgcn_s_sleep(16); }
-        }
-        f = uni(f);
+        const u32 f = queue_flag_wait(flags + (size_t)(oslot - 1u) * ALZ_CHUNK_FLAG_WORDS, epoch, lane);
         if (f == 0u || f == 3u) { if (lane == 0) atomicOr(tmo, 1u); flagv = 3u; run = false; }
         else {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1188,7 +1227,7 @@ __global__ __launch_bounds__(128) void alz_decode_prs2q_kernel(const u8* __restr
     }
     if (flagv) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) chunk_store32(flags + (size_t)oslot * ALZ_CHUNK_FLAG_WORDS, flagv);
+        if (lane == 0) chunk_store32(flags + (size_t)oslot * ALZ_CHUNK_FLAG_WORDS, (epoch << 2) | flagv);
     }
 }
 
@@ -1199,7 +1238,15 @@ static thread_local int t_variant = 0;         // alz_ctx_set_kernel_variant: 0 
 static bool prs_two_waves(u32 count) { (void)count; return t_variant != 1; }
 // the flag-byte formats: two wavefronts per stream for launches that cannot fill the GPU with one -- below this many streams in the
 // whole batch a launch is bound by the time of ONE stream (a mixed batch fills the GPU with all its formats together)
-static bool fast_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= 3072u); }
+// Up to this many streams in a launch two wavefronts share a stream: 12 per CU (3 072 on the 256 CUs of an MI355X, where the crossings were measured), from the current device's CU count
+uint32_t alz_two_wave_max(void) {
+    static uint32_t cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 3072u;
+    if (!cached[dev]) { int cus = 0; cached[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 12u * (uint32_t)cus : 3072u; }
+    return cached[dev];
+}
+static bool fast_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= alz_two_wave_max()); }
 
 template <int FMT, bool FB>
 static hipError_t launch_serial(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count,
@@ -1237,7 +1284,7 @@ static hipError_t launch_fast(hipStream_t stream, const u8* src, u8* dst, const 
 #ifndef ALZ_QUEUE2_MAX
 #define ALZ_QUEUE2_MAX 3072u   /* 2 500 streams: LZ4 2.15 against 2.44 ms, LZO 2.97 / 3.48, Snappy 2.45 / 3.17; 4 000: 3.59 / 2.74, 4.46 / 4.02, 3.97 / 3.54 */
 #endif
-static bool queue_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= ALZ_QUEUE2_MAX); }
+static bool queue_two_waves() { return t_variant == 2 || (t_variant == 0 && t_batch_total <= (ALZ_QUEUE2_MAX == 3072u ? alz_two_wave_max() : ALZ_QUEUE2_MAX)); }
 template <int FMT>
 static hipError_t launch_queue2(hipStream_t stream, const u8* src, u8* dst, const alz_stream* streams, const u32* index, u32 count, alz_result* results, const u32* gate = nullptr) {
     hipLaunchKernelGGL((alz_decode_queue2_kernel<FMT>), dim3(count), dim3(128), 0, stream, src, dst, streams, index, count, results, gate);
@@ -1294,6 +1341,8 @@ hipError_t alz_launch_decode_gated(int fmt, hipStream_t stream, const void* src,
     case ALZ_FMT_MIO0: return launch_fast<ALZ_FMT_MIO0>(stream, s, d, streams, index, count, results, lz, 4096, 3, gate);
     case ALZ_FMT_LZ10: return launch_fast<ALZ_FMT_LZ10>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_LZ11: return launch_fast<ALZ_FMT_LZ11>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_LZ40: return launch_fast<ALZ_FMT_LZ40>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
+    case ALZ_FMT_CLZ0: return launch_fast<ALZ_FMT_CLZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_YAZ0: return launch_fast<ALZ_FMT_YAZ0>(stream, s, d, streams, index, count, results, lz, 4096, 1, gate);
     case ALZ_FMT_PRS_BE: hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_BE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, gate); return hipGetLastError();
     case ALZ_FMT_PRS_LE: hipLaunchKernelGGL((alz_decode_prs2_kernel<ALZ_FMT_PRS_LE>), dim3(count), dim3(128), 0, stream, s, d, streams, index, count, results, gate); return hipGetLastError();
@@ -1329,30 +1378,32 @@ bool alz_chunk_format(int fmt, const alz_lz_properties* lz, uint32_t* lw_out) {
     return true;
 }
 template <int FMT>
-static hipError_t launch_fastq(hipStream_t stream, const u8* s, u8* d, const alz_stream* streams, const alz_chunk_item* items, u32 n_items, alz_result* results,
-                               const alz_lz_properties& lz, u32 lw, u32* ctl, u32* flags, u8* slots) {
+static hipError_t launch_fastq(hipStream_t stream, const u8* s, u8* d, const alz_stream* streams, const alz_chunk_item* items, u32 n_items, const alz_queue_bounds& qb, alz_result* results,
+                               const alz_lz_properties& lz, u32 lw, u32* ctl, u32* flags, u8* slots, u32* tmo, u32 epoch) {
     const u32 grid = n_items;                              // one workgroup per (stream, chunk) item, in queue order
-    hipLaunchKernelGGL((alz_decode_fastq_kernel<FMT>), dim3(grid), dim3(64), 0, stream, s, d, streams, items, n_items, results, lz, lw, flags, slots, ctl + 32);
+    hipLaunchKernelGGL((alz_decode_fastq_kernel<FMT>), dim3(grid), dim3(64), 0, stream, s, d, streams, items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
     return hipGetLastError();
 }
 hipError_t alz_launch_decode_chunked(int fmt, hipStream_t stream, const void* src, void* dst, const alz_stream* streams, const alz_chunk_item* items,
-                                     u32 n_items, alz_result* results, const alz_lz_properties* lzp, u32* ctl, u32* flags, u8* slots) {
+                                     u32 n_items, const alz_queue_bounds* bounds, alz_result* results, const alz_lz_properties* lzp, u32* ctl, u32* flags, u8* slots, u32* tmo, u32 epoch) {
     if (n_items == 0) return hipSuccess;
     u32 lw = 0;
     if (!alz_chunk_format(fmt, lzp, &lw)) return hipErrorInvalidValue;
     const u8* s = (const u8*)src; u8* d = (u8*)dst;
     const alz_lz_properties lz = *lzp;
+    const alz_queue_bounds qb = *bounds;
+    if (qb.off[0] != 0u || qb.off[ALZ_QUEUE_SHARDS] != n_items || epoch == 0u || epoch > 0x3FFFFFFFu) return hipErrorInvalidValue;
     switch (fmt) {
-    case ALZ_FMT_LZSS: return launch_fastq<ALZ_FMT_LZSS>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_LZ10: return launch_fastq<ALZ_FMT_LZ10>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_LZ11: return launch_fastq<ALZ_FMT_LZ11>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_LZ40: return launch_fastq<ALZ_FMT_LZ40>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_CLZ0: return launch_fastq<ALZ_FMT_CLZ0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_YAZ0: return launch_fastq<ALZ_FMT_YAZ0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_YAY0: return launch_fastq<ALZ_FMT_YAY0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_MIO0: return launch_fastq<ALZ_FMT_MIO0>(stream, s, d, streams, items, n_items, results, lz, lw, ctl, flags, slots);
-    case ALZ_FMT_PRS_BE: hipLaunchKernelGGL((alz_decode_prs2q_kernel<ALZ_FMT_PRS_BE>), dim3(n_items), dim3(128), 0, stream, s, d, streams, items, n_items, results, flags, slots, ctl + 32); return hipGetLastError();
-    case ALZ_FMT_PRS_LE: hipLaunchKernelGGL((alz_decode_prs2q_kernel<ALZ_FMT_PRS_LE>), dim3(n_items), dim3(128), 0, stream, s, d, streams, items, n_items, results, flags, slots, ctl + 32); return hipGetLastError();
+    case ALZ_FMT_LZSS: return launch_fastq<ALZ_FMT_LZSS>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_LZ10: return launch_fastq<ALZ_FMT_LZ10>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_LZ11: return launch_fastq<ALZ_FMT_LZ11>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_LZ40: return launch_fastq<ALZ_FMT_LZ40>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_CLZ0: return launch_fastq<ALZ_FMT_CLZ0>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_YAZ0: return launch_fastq<ALZ_FMT_YAZ0>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_YAY0: return launch_fastq<ALZ_FMT_YAY0>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_MIO0: return launch_fastq<ALZ_FMT_MIO0>(stream, s, d, streams, items, n_items, qb, results, lz, lw, ctl, flags, slots, tmo, epoch);
+    case ALZ_FMT_PRS_BE: hipLaunchKernelGGL((alz_decode_prs2q_kernel<ALZ_FMT_PRS_BE>), dim3(n_items), dim3(128), 0, stream, s, d, streams, items, qb, results, ctl, flags, slots, tmo, epoch); return hipGetLastError();
+    case ALZ_FMT_PRS_LE: hipLaunchKernelGGL((alz_decode_prs2q_kernel<ALZ_FMT_PRS_LE>), dim3(n_items), dim3(128), 0, stream, s, d, streams, items, qb, results, ctl, flags, slots, tmo, epoch); return hipGetLastError();
     default: return hipErrorInvalidValue;
     }
 }

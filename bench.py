@@ -149,7 +149,31 @@ def issue_object(key, kernel_ms):
     return {"valu": valu, "salu": salu, "lds": lds, "issue_frac": round(max(mid, salu, lds), 3), "counts_from": c.get("source")}
 
 
-def roofline(algo_bytes, kernel_ms, traffic=None, issue_key=None):
+def _kernel_hash_tool():
+    """tools/kernel_hash.py as a module (tools/ is not a package): the hash that ties profiles/traffic.json / insts.json to the kernel sources they were measured on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("alz_kernel_hash", os.path.join(ROOT, "tools", "kernel_hash.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+_STALE = {}
+
+
+def counters_stale(family):
+    """True when the committed counter files were collected on OTHER kernel sources than this checkout's (`_kernel_hash` of profiles/traffic.json and insts.json against
+    sha256 over csrc's kernel files, tools/kernel_hash.py): `traffic` / `issue` of the line are then figures of an earlier kernel.  family: "decode" | "encode"."""
+    if family not in _STALE:
+        try:
+            kh = _kernel_hash_tool()
+            _STALE[family] = bool(kh.stale("traffic.json", family) or (family == "decode" and kh.stale("insts.json", family)))
+        except Exception:
+            _STALE[family] = True
+    return _STALE[family]
+
+
+def roofline(algo_bytes, kernel_ms, traffic=None, issue_key=None, family="decode"):
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
          "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None,
@@ -158,6 +182,8 @@ def roofline(algo_bytes, kernel_ms, traffic=None, issue_key=None):
     if iss:
         r["issue"] = iss
         r["issue_frac"] = iss["issue_frac"]
+    if traffic is not None or iss:
+        r["counters_stale"] = counters_stale(family)
     return r
 
 
@@ -182,7 +208,7 @@ def contract_line(full):
     out["config"] = cfg
     r = full.get("roofline") or {}
     out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch",
-                                         "issue_frac") if k in r}
+                                         "issue_frac", "counters_stale") if k in r}
     cb = full.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "single_thread", "cpu_model", "cgroup_cpu_quota_cores") if k in cb}
@@ -596,7 +622,7 @@ def run_encode_mode(args, np, A, synth, Context, Plan, shard_seed, reduce_step_t
                        "mode": "encode", "format": args.format, "quality": args.quality, "streams_this_rank": n, "streams_whole_job": job_n, "stream_bytes": target,
                        "compressed_bytes_whole_job": int(job_comp), "ratio": round(job_comp / job_raw, 4), "parallelism": parallelism,
                        "parity_ok": ok, "verified_roundtrip_and_vs_oracle": verified, "lzo_reference_quirk": quirk if not args.no_verify else None},
-            "roofline": roofline(raw_bytes + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (args.format, args.quality), n, args.stream_kib)),
+            "roofline": roofline(raw_bytes + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (args.format, args.quality), n, args.stream_kib), family="encode"),
             "cpu_baseline": cpu,
             "ranks": ranks,
         }
@@ -930,7 +956,7 @@ def cfg5(ctx, np, A, synth, Plan, with_cpu=True):
                         % ("LZSS(12,4,2)" if fname == "lzss" else fname, q),
                         "value": round(n * size / (kernel_ms * 1e-3) / 2**30, 3), "unit": "GiB/s of raw input (kernels)", "kernel_ms": round(kernel_ms, 3),
                         "call_ms": round(call_s * 1e3, 3), "ratio": round(comp / (n * size), 4), "parity_ok": ok,
-                        "roofline": roofline(n * size + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (fname, q), n, size // 1024))})
+                        "roofline": roofline(n * size + comp, kernel_ms, measured_traffic("%s_encode_q%d" % (fname, q), n, size // 1024), family="encode")})
     finally:
         if d_out is not None:
             ctx.free(d_out)

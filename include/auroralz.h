@@ -205,12 +205,14 @@ int         alz_ctx_set_exact_kernels(alz_ctx* ctx, int on);
  * library chooses by the size of the batch; 1 / 2: always the one- / two-wavefront shape where both exist.  Results are
  * identical; a tuning and verification hook (the library reads no environment variable for kernel selection).
  * A third shape exists for the flag-byte family (LZSS with windows up to 4 KiB, LZ10, LZ11, LZ40, CLZ0, Yaz0, Yay0, MIO0) and PRS on device-resident
- * plans: the batch as a WORK QUEUE of 40 KiB chunks (PRS: 80 KiB) popped by as many persistent wavefronts as the GPU holds -- taken by itself (variant 0) when a
- * plan has more streams of such a format than 0.6 of what the GPU holds wavefronts, so that the launch does not end in a partly filled round; 3: plans created in this
+ * plans: the batch as a WORK QUEUE of (stream, chunk) items -- 40 KiB of output per chunk, PRS 80 KiB --, ONE workgroup per item, each drawing its item as a ticket from the queue head
+ * when it starts -- taken by itself (variant 0) when a plan has more streams of such a format than 0.4 of what the GPU holds of that format's wavefronts (and more than fit the two-wavefront
+ * shape: half the GPU's places; PRS: more than the GPU holds), so that the launch does not end in a partly filled round; 3: plans created in this
  * mode use it whatever their size (the parity tests).  Same results: a chunk ends between two iterations of the lane-parallel loop and hands
- * the LDS window and the cursors on.  A wavefront waits for the chunk before its own with a BOUNDED spin; if one ever ran out (workgroups start in
- * index order on this hardware, which is what keeps the waits short, but HIP does not promise it) alz_plan_results repeats the launch with one wavefront
- * per stream before it returns: a caller of the device-resident path takes the batch as decoded once alz_plan_results has returned. */
+ * the LDS window and the cursors on.  An item waits for the chunk before its own; tickets are drawn in start order, so that chunk is always in the hands of a workgroup that is
+ * already running (progress does not depend on the order in which the hardware dispatches workgroups).  The wait is still a BOUNDED spin; if one ever ran out (a fault: never
+ * seen) a sticky word of the plan is set, and the gated launch that alz_plan_execute enqueues behind every queue launch decodes that format's streams again with one wavefront
+ * per stream -- on the same stream, in order: work the caller chained behind the execute sees whole output either way.  alz_plan_results then moves the plan off the queue. */
 int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
 /* ONE big stream: a batch of one -- or of a few, as long as one after the other on the whole GPU beats side by side on wavefronts of their
  * own -- LZSS / LZ10 / LZ11 / Yaz0 / Yay0 / MIO0 / PRS / LZO / LZ4-block / raw-Snappy streams (all eleven
@@ -233,8 +235,9 @@ int         alz_ctx_set_kernel_variant(alz_ctx* ctx, int variant);
  * of at least 8 KiB: the chunks of one archive, a directory of files -- the flag-bit formats with a bounded match length (LZSS, LZ10, Yaz0, Yay0, MIO0, CLZ0, BLZ, LZHudson),
  * raw Snappy and PRS parse from one synchronisation point of the walk to the next (a position no jump crosses) with a wavefront each and emit per segment
  * (csrc/alz_encode_seg.h).  No switch: the bytes are the same, and a context in exact or forced-variant mode never goes that way.
- * min_bytes: 0 keeps the current threshold, 0xFFFFFFFF switches both paths off; launches_out (may be NULL) receives how many streams have
- * been ENQUEUED on either path on this context (a stream that path declines -- any malformed one -- is still counted: the kernel behind the gate decodes it).  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take them. */
+ * min_bytes: 0 keeps the current threshold, 0xFFFFFFFF switches both paths off; launches_out (may be NULL) receives how many streams the two paths have TAKEN on this
+ * context: the decode side counts on the device, where the path decides -- a stream it declines (any malformed one) is decoded by the kernel behind the gate and NOT counted --,
+ * and asking waits for everything enqueued on the device so far.  Contexts in exact or forced-variant mode (alz_ctx_set_exact_kernels / alz_ctx_set_kernel_variant) never take them. */
 int         alz_ctx_big_stream(alz_ctx* ctx, uint32_t min_bytes, uint64_t* launches_out);
 /* The host-buffer entry points keep their device staging buffers and the encoder's scratch (per input byte: a 16- or 32-bit link
  * in a 32-bit slot -- above quality 0 a second one, the links of the finder's wider hash narrowed from 15-bit ones --, a 32-bit
@@ -289,10 +292,11 @@ int alz_decode(alz_ctx* ctx, uint32_t format, const alz_lz_properties* props,
  * kernel launch per format present).  alz_plan_execute only enqueues kernels
  * on `hip_stream` (a hipStream_t, or NULL for the context's own stream) and
  * does not synchronise.  d_src_base / d_dst_base are DEVICE pointers.
- * One plan may be executed again while an earlier execute is still in flight, also on another stream: a plan of big streams (the
- * whole-GPU path, alz_ctx_big_stream) owns scratch on the device, so its executes are ordered one behind the other by an event
- * (they do not overlap); any other plan only reads its tables.  alz_plan_results waits for the last execute, whichever stream it
- * was enqueued on. */
+ * One plan may be executed again while an earlier execute is still in flight, also on another stream and into other buffers.  Two kinds of plan own MUTABLE state on the
+ * device -- a plan of big streams (the whole-GPU path, alz_ctx_big_stream: its scratch) and a plan that runs a format as a work queue of chunks (alz_ctx_set_kernel_variant:
+ * queue heads, hand-over flags and slots) -- so their executes are ordered one behind the other by an event, whichever streams they are enqueued on (they do not
+ * overlap; a caller who wants two batches in flight creates two plans); any other plan only reads its tables.  Every plan has ONE result table: alz_plan_results
+ * returns the results of the LAST execute and waits for it, whichever stream it was enqueued on. */
 int  alz_plan_create(alz_ctx* ctx, const alz_lz_properties* props, uint32_t n,
                      const alz_stream* streams, alz_plan** out);
 int  alz_plan_execute(alz_ctx* ctx, alz_plan* plan, const void* d_src_base, void* d_dst_base, void* hip_stream);

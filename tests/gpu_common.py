@@ -64,3 +64,28 @@ def pack_streams(items, dst_align=16, dst_slack=0):
         do += (cap + dst_slack + dst_align - 1) // dst_align * dst_align + it.get("dst_misalign", 0)
     src = np.frombuffer(b"".join(chunks) + bytes(64), dtype=np.uint8).copy()
     return streams, src, do + 64
+
+
+def hip_streams(k):
+    """k HIP streams of the CALLER's (hipStreamCreateWithFlags, non-blocking) as ctypes void pointers, plus a function that destroys them: what a
+    host program hands alz_plan_execute as `hip_stream`.  The runtime is the one libauroralz.so is bound to (already loaded by its soname)."""
+    import ctypes as C
+    ctx()                                                    # (the library, and with it the runtime, is loaded)
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    out = []
+    for _ in range(k):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+        out.append(s)
+
+    def sync():
+        for s in out:
+            assert hip.hipStreamSynchronize(s) == 0
+
+    def destroy():
+        for s in out:
+            hip.hipStreamDestroy(s)
+    return out, sync, destroy

@@ -251,10 +251,10 @@ def test_prose_like_input_both_paths(fmt):
     with Context(0) as c:
         for q in (0, 5, 8, 12):
             three = [(fmt, prose_like(150000 + 7777 * i, 100 * q + i)) for i in range(3)]
-            c.lib.alz_debug_seg_max_streams(0)              # (three buffers of a format the segmented batch path takes would go side by side: csrc/alz_encode_seg.h)
+            c.lib.alz_debug_seg_max_streams(c.h, 0)              # (three buffers of a format the segmented batch path takes would go side by side: csrc/alz_encode_seg.h)
             try:
                 _encode(c, three, q, expect_big=True, what="text, three")
             finally:
-                c.lib.alz_debug_seg_max_streams(0xFFFFFFFF)
+                c.lib.alz_debug_seg_max_streams(c.h, 0xFFFFFFFF)
             forty = [(fmt, prose_like(9000 + 613 * i, 900 + 40 * q + i)) for i in range(40)]
             _encode(c, forty, q, expect_big=False, what="text, forty")

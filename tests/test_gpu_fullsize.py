@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 CORES = os.cpu_count() or 8
 
 
-def _decode_and_compare(fmt, n, size, seed):
+def _decode_and_compare(fmt, n, size, seed, queue_formats=None):
+    """Host-buffer entry point AND (queue_formats is not None) the device-resident plan -- the path bench.py times -- against the oracle.
+    queue_formats: the formats expected to run as a work queue of chunks in the resident plan (alz_decode_fastq_kernel; () = none must)."""
     b = synth.make_batch(fmt, n, size, seed)
     o_dst, o_res = O.decode_batch(b.streams, b.src, b.dst_bytes, nthreads=CORES)
     g_dst, g_res = ctx().decode_batch(b.streams, b.src, b.dst_bytes)
@@ -31,16 +33,71 @@ def _decode_and_compare(fmt, n, size, seed):
     sums = [O.xxh64(bytes(g_dst[int(recs["dst_off"][i]):int(recs["dst_off"][i]) + size])) for i in range(0, n, step)]
     assert O.xxh64(np.array(sums, dtype=np.uint64).tobytes()) == O.xxh64(np.array(
         [O.xxh64(bytes(o_dst[int(recs["dst_off"][i]):int(recs["dst_off"][i]) + size])) for i in range(0, n, step)], dtype=np.uint64).tobytes())
+    if queue_formats is not None:
+        _resident_plan_and_compare(b, o_dst, orr, size, queue_formats)
     return b, g_dst
 
 
+def _resident_plan_and_compare(b, o_dst, orr, size, queue_formats):
+    """The kernel bench.py TIMES, under test at the full size: alz_plan_create on the device-resident batch (which, unlike the host-buffer entry point above, may plan
+    a format as a work queue of (stream, chunk) items), the number of items the plan holds against what the cut by alz_debug_chunk_bytes() predicts, two executes into a
+    destination filled with 0xA5 between guard regions, and then EVERY byte of the buffer -- inside the streams the oracle's, outside them still 0xA5 -- plus status,
+    length and src_used of every stream."""
+    import ctypes as C
+    from auroralib.compression_amd.batch import Plan
+    c = ctx()
+    c.lib.alz_debug_plan_queue_items.argtypes = [C.c_void_p]
+    c.lib.alz_debug_chunk_repeats.restype = C.c_uint64; c.lib.alz_debug_chunk_repeats.argtypes = [C.c_void_p]
+    recs = synth.stream_records(b.streams)
+    GUARD, CANARY = 8192, 0xA5
+    total = GUARD + b.dst_bytes + GUARD
+    want_items = 0
+    for f in queue_formats:
+        ch = 81920 if f in (A.FMT_PRS_BE, A.FMT_PRS_LE) else c.lib.alz_debug_chunk_bytes()
+        want_items += int(((recs["decom_len"][recs["format"] == f].astype(np.int64) + ch - 1) // ch).sum())
+    d_src, d_dst = c.malloc(b.src.nbytes + 64), c.malloc(total)
+    plan = None
+    try:
+        c.h2d(d_src, b.src)
+        plan = Plan(c, b.streams)
+        assert c.lib.alz_debug_plan_queue_items(plan.h) == want_items, (c.lib.alz_debug_plan_queue_items(plan.h), want_items)
+        repeats = c.lib.alz_debug_chunk_repeats(c.h)
+        c.memset(d_dst, CANARY, total)
+        plan.execute(d_src, C.c_void_p(d_dst.value + GUARD))
+        plan.execute(d_src, C.c_void_p(d_dst.value + GUARD))     # (again, behind the first: every queue head and flag is set up anew)
+        gr = synth.result_records(plan.results())
+        assert c.lib.alz_debug_chunk_repeats(c.h) == repeats       # (no bounded spin ran out: the bytes below are the queue kernel's, not the repair's)
+        for f in ("status", "dst_len", "src_used"):
+            assert np.array_equal(gr[f], orr[f]), f
+        # the whole buffer, in pieces of 256 MiB: the oracle's bytes inside [dst_off, dst_off + dst_len) of every stream, the canary everywhere else
+        offs, lens = recs["dst_off"].astype(np.int64), orr["dst_len"].astype(np.int64)
+        order = np.argsort(offs, kind="stable")
+        piece = 256 << 20
+        for a in range(0, total, piece):
+            e = min(total, a + piece)
+            g = c.d2h(d_dst, e - a, offset=a)
+            want = np.full(e - a, CANARY, dtype=np.uint8)
+            for i in order[np.searchsorted(offs[order] + lens[order], a - GUARD, side="right"):np.searchsorted(offs[order], e - GUARD, side="left")]:
+                lo, hi = max(int(offs[i]), a - GUARD), min(int(offs[i] + lens[i]), e - GUARD)      # (destination offsets)
+                if lo < hi:
+                    want[lo + GUARD - a:hi + GUARD - a] = o_dst[lo:hi]
+            if not np.array_equal(g, want):
+                at = int(np.flatnonzero(g != want)[0]) + a - GUARD
+                raise AssertionError("resident plan: device buffer differs at offset %d of the destination (gpu 0x%02X, expected 0x%02X; %d bytes differ in this piece)"
+                                     % (at, int(g[at + GUARD - a]), int(want[at + GUARD - a]), int((g != want).sum())))
+    finally:
+        if plan is not None:
+            plan.close()
+        c.free(d_src); c.free(d_dst)
+
+
 def test_cfg2_yaz0_10000_x_64k():
-    _decode_and_compare(A.FMT_YAZ0, 10000, 65536, synth.seed_for(2, 7))
+    _decode_and_compare(A.FMT_YAZ0, 10000, 65536, synth.seed_for(2, 7), queue_formats=(A.FMT_YAZ0,))
 
 
 def test_metric_config_yaz0_10000_x_256k():
     """The batch bench.py times by default (same generator seed)."""
-    _decode_and_compare(A.FMT_YAZ0, 10000, 262144, synth.seed_for(2))
+    _decode_and_compare(A.FMT_YAZ0, 10000, 262144, synth.seed_for(2), queue_formats=(A.FMT_YAZ0,))
 
 
 def test_cfg3_lz4_blocks_256k():
@@ -103,7 +160,7 @@ def test_cfg4_mixed_shard():
     """What each of 8 GPUs gets of cfg4's 40 000 mixed streams: 5 000, formats interleaved, per-format kernel dispatch."""
     n = 5000
     fm = np.array([[A.FMT_LZ10, A.FMT_LZ11, A.FMT_YAZ0, A.FMT_PRS_BE][i % 4] for i in range(n)], dtype=np.uint32)
-    _decode_and_compare(fm, n, 262144, synth.seed_for(4))
+    _decode_and_compare(fm, n, 262144, synth.seed_for(4), queue_formats=())        # (1 250 streams per format: everything resident at once, no queue -- DESIGN 4.2)
 
 
 @pytest.mark.parametrize("quality", [0, 8])

@@ -31,13 +31,13 @@ def _both_ways(c, items, quality, what, **kw):
         before = _seg(c)
         a = _encode(c, items, quality, expect_big=False, what=what, **kw)
         assert _seg(c) > before, what
-        c.lib.alz_debug_seg_max_streams(0)
+        c.lib.alz_debug_seg_max_streams(c.h, 0)
         try:
             before = _seg(c)
             b = _encode(c, items, quality, expect_big=False, what=what + ", path off", **kw)
             assert _seg(c) == before, what
         finally:
-            c.lib.alz_debug_seg_max_streams(0xFFFFFFFF)
+            c.lib.alz_debug_seg_max_streams(c.h, 0xFFFFFFFF)
     finally:
         c.big_stream(24 << 10)
     assert a == b, what
@@ -166,13 +166,13 @@ def test_fuzz_path_on_against_path_off(fmt, test_bmp):
             got = []
             for off in (False, True):
                 if off:
-                    c.lib.alz_debug_seg_max_streams(0)
+                    c.lib.alz_debug_seg_max_streams(c.h, 0)
                 try:
                     before = _seg(c)
                     dst, res, aux = c.encode_batch(streams, src, do + 64, quality=q)
                     assert (_seg(c) > before) == (not off), (seed, trial)
                 finally:
-                    c.lib.alz_debug_seg_max_streams(0xFFFFFFFF)
+                    c.lib.alz_debug_seg_max_streams(c.h, 0xFFFFFFFF)
                 got.append([(res[i].status, res[i].dst_len, res[i].src_used, aux[i].aux0, aux[i].aux1,
                              bytes(dst[streams[i].dst_off:streams[i].dst_off + res[i].dst_len])) for i in range(n)])
             for i in range(n):

@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/bcap_sweep.sh [qualities]  -- kernel B's compare cap against quality on 1 024 windows of Test.bmp per format; ms of
 # kernels per call.  One build per cap (-DALZ_BCAP_FORCE=<cap> overrides choose_b_cap); the default build is restored at the end.
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 patch -p1 -N -s < tools/variants/r04_encode_switches.patch || true   # (the compile-time switches this script turns live in a patch, not in the product sources; the GPU box works on a scratch copy)
 for cap in 2040 256 96 48; do
   touch auroralib/compression_amd/csrc/alz_encode.hip

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for lg in 2 3 4; do
   touch auroralib/compression_amd/csrc/alz_big.hip
   ALZ_EXTRA_FLAGS="-DBIG_LOG=${lg}u" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 patch -p1 -N -s < tools/variants/r04_encode_switches.patch || true   # (the compile-time switches this script turns live in a patch, not in the product sources; the GPU box works on a scratch copy)
 export ALZ_SINGLE_MODES=big ALZ_SINGLE_Q=4,8,12
 for fl in "" "-DALZ_BENC_DENSE=1"; do

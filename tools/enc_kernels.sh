@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/enc_kernels.sh fmt quality -- per-kernel times of one encode call (rocprofv3 --kernel-trace --stats)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 D=gpurun_out/enc_k_$1_q$2; rm -rf $D; mkdir -p $D
 cat > $D/run.py <<PY

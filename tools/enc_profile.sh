@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/enc_profile.sh  -- kernel stats of the compression path (cfg5) at Q0, Q8 and Q15 -> gpurun_out/r03_encode.md
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/r03_encode.md
 echo "# rocprofv3 summary: compression path (cfg5: LZSS(12,4,2), 10 000 x 256 KiB)" > $OUT

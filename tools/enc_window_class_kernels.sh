@@ -1,0 +1,38 @@
+# usage (GPU box): bash tools/enc_window_class_kernels.sh fmt quality window [n] -- per-kernel times of ONE device-resident encode call over n (2 000) COPIES of one 256 KiB window of Test.bmp
+# (window w starts at byte 4096 w; 0: photographic, 40: mixed, 96 / 176: flat -- profiles/r04_jump_stats.txt): where the batch encoder's time goes by kind of data
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
+export TMPDIR=/tmp
+N=${4:-2000}
+D=gpurun_out/encw_k_$1_q$2_w$3; rm -rf $D; mkdir -p $D
+cat > $D/run.py <<PY
+import os, sys, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from auroralib.compression_amd import _abi as A, synth, formats as F
+from auroralib.compression_amd.batch import Context
+fmt = A.FORMAT_NAMES.index("$1"); n, size = $N, 262144
+ctx = Context(0)
+lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
+bmp = np.frombuffer(lz.Decompress(open("tests/golden/Test.lz", "rb").read()), dtype=np.uint8)
+raw = np.zeros(n * size + 64, dtype=np.uint8)
+for i in range(n): raw[i * size:(i + 1) * size] = bmp[$3 * 4096:$3 * 4096 + size]
+cap = size + size // 4 + 64
+st = (A.Stream * n)(); r = synth.stream_records(st)
+r["src_off"], r["src_len"] = np.arange(n, dtype=np.uint64) * np.uint64(size), size
+r["dst_off"] = np.arange(n, dtype=np.uint64) * np.uint64((cap + 255) // 256 * 256)
+r["dst_cap"], r["format"] = cap, fmt
+dst_bytes = int(r["dst_off"][-1]) + cap + 64
+d_src, d_dst = ctx.malloc(raw.nbytes + 64), ctx.malloc(dst_bytes)
+ctx.h2d(d_src, raw)
+for _ in range(2):
+    res, aux = ctx.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=$2)
+    print("window $3: kernel ms", ctx.last_kernel_ms(), "compressed", res[0].dst_len, flush=True)
+PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $D/run.py > $D/log.txt 2>&1
+grep "kernel ms" $D/log.txt | tail -1
+python3 - $D <<'PY'
+import csv,glob,sys
+for fn in glob.glob(sys.argv[1]+'/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(fn)):
+        if 'enc_' in r['Name']: print('   %-60s calls %s total %.2f ms' % (r['Name'][r['Name'].find('enc_'):][:60], r['Calls'], float(r['TotalDurationNs'])/1e6))
+PY
+find $D -name "*.csv" -size +1M -delete

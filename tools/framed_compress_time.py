@@ -11,7 +11,7 @@ for name, data in (("Test.bmp (1 MB, 16 chunks)", bmp), ("16 x Test.bmp (16 MB, 
     for s, sname in ((F.CompressionSettings.Fastest, "Fastest"), (F.CompressionSettings.Balanced, "Balanced")):
         row = []
         for seg in (0, 0xFFFFFFFF):
-            lib.alz_debug_seg_max_streams(seg)
+            lib.alz_debug_seg_max_streams(F._context().h, seg)
             f = F.Snappy()
             out = f.Compress(data, s)
             ts = []

@@ -1,6 +1,6 @@
 # usage (on the GPU box): bash tools/gpu_profile.sh NAME FORMAT [extra bench args]
 # kernel stats + separate PMC passes (never combined with other trace domains); summary lands in gpurun_out/NAME.md
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 NAME=$1; FMT=$2; shift 2
 export TMPDIR=/tmp
 D=gpurun_out/prof_$NAME

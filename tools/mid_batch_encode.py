@@ -22,7 +22,7 @@ c = Context(0)
 import ctypes as C
 c.lib.alz_debug_seg_launches.restype = C.c_uint64; c.lib.alz_debug_seg_launches.argtypes = [C.c_void_p]
 if os.environ.get("ALZ_MID_BIG") == "off": c.big_stream(0xFFFFFFFF)                                # (the whole-GPU path of ONE buffer at a time off)
-if os.environ.get("ALZ_MID_SEG") is not None: c.lib.alz_debug_seg_max_streams(int(os.environ["ALZ_MID_SEG"]))      # (0: the segmented parse + emit off)
+if os.environ.get("ALZ_MID_SEG") is not None: c.lib.alz_debug_seg_max_streams(c.h, int(os.environ["ALZ_MID_SEG"]))      # (0: the segmented parse + emit off)
 for fname in sys.argv[1:] or ["lzss", "yaz0"]:
     fmt = A.FORMAT_NAMES.index(fname)
     for q in [int(x) for x in os.environ.get("ALZ_MID_Q", "0,8").split(",")]:

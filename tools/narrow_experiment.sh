@@ -2,7 +2,7 @@
 # min-length table; the formats with windows up to 8 KiB: every stream, -DALZ_NO_NARROW_WIN: not those) against kernel A at the finder's own hash
 # width for all (-DALZ_NO_NARROW; -DALZ_NO_NARROW_MIN: not with the min-length table), and the threshold of the choice
 # (-DALZ_NARROW_THRESH16=t: narrow below t / 16 distinct hashes per sampled position; 17 = always).  Results: docs/EXPERIMENTS.md 9.12.
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 patch -p1 -N -s < tools/variants/r04_encode_switches.patch || true   # (the compile-time switches this script turns live in a patch, not in the product sources; the GPU box works on a scratch copy)
 run() {
   touch auroralib/compression_amd/csrc/alz_encode.hip

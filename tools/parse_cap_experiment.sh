@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for cap in 2040 128 64 48 32; do
   touch auroralib/compression_amd/csrc/alz_encode.hip
   ALZ_EXTRA_FLAGS="-DALZ_PARSE_CAP=$cap" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1

@@ -1,6 +1,6 @@
 # enc_parse_emit_kernel<FMT, true>: the look-ahead stages of windows the cursor has already jumped over left out -- for LZ11 / LZ40 by default, for every
 # flag-bit format with -DALZ_PARSE_SKIP_ALL (docs/EXPERIMENTS.md 9.9).
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 patch -p1 -N -s < tools/variants/r04_encode_switches.patch || true   # (the compile-time switches this script turns live in a patch, not in the product sources; the GPU box works on a scratch copy)
 run() {
   touch auroralib/compression_amd/csrc/alz_encode.hip

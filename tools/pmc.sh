@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/pmc.sh TAG "COUNTER COUNTER ..." <bench.py args...>  -- one rocprofv3 --pmc pass with the given counters; mean per launch of
 # every alz_* kernel with >= 1000 workgroups
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 TAG=$1; CTRS=$2; shift; shift
 D=gpurun_out/pmc_$TAG; rm -rf $D; mkdir -p $D

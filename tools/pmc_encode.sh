@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/pmc_encode.sh [quality] -- instruction / busy counters of the encoder kernels (cfg5 shape)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 q=${1:-8}
 i=0

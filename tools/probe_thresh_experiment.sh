@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/probe_thresh_experiment.sh  -- the synthetic cfg5 batch with EVERY stream on the one-position-per-lane kernels
 # (-DALZ_PROBE_THRESH16=0) against the default (the probe sends synthetic streams to the two-phase kernel)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 for thr in 4 0; do
   touch auroralib/compression_amd/csrc/alz_encode.hip
   ALZ_EXTRA_FLAGS="-DALZ_PROBE_THRESH16=$thr" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1

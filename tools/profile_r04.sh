@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/profile_r04.sh [fmt...]  -- round-4 evidence: per format tools/gpu_profile.sh (kernel stats + separate PMC passes)
 # -> gpurun_out/r04_<fmt>.md; then the named configurations (cfg2, cfg3 at 100 000 blocks, the cfg4 shard, the Test.bmp windows): kernel stats +
 # FETCH_SIZE / WRITE_SIZE passes -> gpurun_out/r04_cfg*.md and the traffic.json lines
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 for f in ${@:-yaz0 lz10 lz11 yay0 mio0 lzss prs_be lz4_block lzo snappy_raw mixed}; do
   bash tools/gpu_profile.sh r04_$f $f > /dev/null 2>&1

@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/quick_bench.sh "cfg list" [pytest -k expr]  -- decode parity tests (optionally filtered), then bench.py with the given configs; one line per entry
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 timeout 900 python -m pytest tests/test_gpu_decode.py tests/test_gpu_canary.py tests/test_kat.py -m gpu -q -x ${2:+-k "$2"} 2>&1 | tail -2
 timeout 900 python bench.py --no-cpu-baseline --no-extras --configs "${1:-cfg2,cfg4,bodies,realistic}" --steps 20 > gpurun_out/qb.json 2>gpurun_out/qb.err
 python3 - <<PY

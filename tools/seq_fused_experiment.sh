@@ -2,7 +2,7 @@
 # the walk -- and at quality 0 the search -- inside the emitter (WinParse), and the bytes it compares per position at quality 0
 # (-DALZ_SEQ_PARSE_CAP=.. for certain, -DALZ_SEQ_PARSE_CAP_HI=.. while fewer than -DALZ_SEQ_PARSE_MANY=.. lanes of a window are still equal).  Results: docs/EXPERIMENTS.md 9.9.  (-DALZ_SEQ_TWO_KERNELS and the kernels behind it exist up to commit 302184c; the
 # default list below only sweeps the cap.)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 run() {
   touch auroralib/compression_amd/csrc/alz_encode.hip
   ALZ_EXTRA_FLAGS="$1" bash auroralib/compression_amd/csrc/build.sh > /dev/null 2>&1

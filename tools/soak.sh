@@ -2,7 +2,7 @@
 # parity test (test_gpu_decode.py, fuzz) and the device-resident canary tests (test_gpu_canary.py: whole destination buffer compared,
 # both kernel families, both wave shapes), the whole-GPU decode of ONE mutated stream (test_gpu_big_stream.py) and the whole-GPU ENCODE of
 # random inputs (test_gpu_big_encode.py)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 s0=${1:-5000}; n=${2:-20}
 for i in $(seq 0 $((n-1))); do
   seed=$((s0 + 97 * i))

@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/traffic.sh TAG <bench.py args...>  -- HBM traffic per launch of every alz_* kernel of the run with >= 1000 workgroups:
 # two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950)
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 TAG=$1; shift
 for c in FETCH_SIZE WRITE_SIZE; do

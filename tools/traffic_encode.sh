@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/traffic_encode.sh -- HBM traffic of the compression kernels (cfg5, Q0 and Q8): FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 for q in 0 8 15; do
   for c in FETCH_SIZE WRITE_SIZE; do
