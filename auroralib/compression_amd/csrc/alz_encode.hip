@@ -66,6 +66,7 @@ __device__ __forceinline__ u32 load32(const u8* p) { u32 v; __builtin_memcpy(&v,
 __device__ __forceinline__ u64 load64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 
 __device__ __forceinline__ u32 scan_add(u32 v);
+__device__ __forceinline__ u32 scan_max(u32 v);
 
 
 // ---------------------------------------------------------------------------------------------- kernel A
@@ -666,7 +667,13 @@ __device__ __forceinline__ void benc_wave_search(const u8* data, int n, const En
 // block.  No kernel A, no kernel B, no match array -- for the streams whose parse visits few positions (enc_scan_select_kernel): kernel B searches EVERY position, the
 // managed parse only the ones its cursor stands on (FindNextBestMatch :157-212), and on the flat windows of Test.bmp that is one position in a hundred.
 // One property set, no min-length table (quality < 10).
-__device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l) {
+// A block's candidates go into a list (`cl`: 64 halfwords of LDS), nearest first, as many as there are attempts left, and ALL of them are measured at once: four lanes per
+// candidate (two from 17 candidates on), 32 bytes per lane and round, a candidate drops out of the rounds at its first mismatch (a quad minimum over DPP).  ChainMatches
+// keeps the FIRST candidate of the best score (a later one must be strictly better, :271-279) and ends at one that reaches the longest possible match -- nothing behind it could be
+// strictly better --, so the result is the maximum over the list of (score, nearest first): one wave maximum.  (Measured one after the other, nearest first, with a byte test
+// in front of each -- the managed order -- a flat window of Test.bmp cost 1 400 instructions and 37 loads per search, 8 us: its pixels repeat at distance 4, every search meets
+// maxChain candidates, and in a gradient each of them is a little longer than the one before.)
+__device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l, unsigned short* cl) {
     const int lane = (int)benc_lane();
     const u8* dp = data + pos;
     const u32 sh = 32u - (u32)g.hash_bits;
@@ -675,8 +682,7 @@ __device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, con
     best_d = 0; best_l = 0; int best_score = -1;
     int attempts = g.max_chain;
     const int lo = pos - g.max_dist > 0 ? pos - g.max_dist : 0;          // candidates: [lo, pos)
-    bool done = false;
-    for (int top = pos; top > lo && !done; top -= 1024) {
+    for (int top = pos; top > lo && attempts > 0; top -= 1024) {
         // my sixteen positions of the block [top - 1024, top): [base, base + 16), read from b0 = max(base, 0) on (nothing is read in front of the stream)
         const int base = top - 1024 + 16 * lane;
         const int b0 = base > 0 ? base : 0;
@@ -694,25 +700,59 @@ __device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, con
             if (hi < 16) m16 &= (1u << (hi > 0 ? hi : 0)) - 1u;
             if (b0 < lo) { const int cut = lo - b0; m16 = cut >= 16 ? 0u : (m16 >> cut) << cut; }
         }
-        u64 any = __ballot(m16 != 0u);
-        while (any && !done) {
-            const int L = 63 - (int)__builtin_clzll(any);
-            u32 mm = (u32)__builtin_amdgcn_readlane((int)m16, L);
-            const int b0L = __builtin_amdgcn_readlane(b0, L);
-            while (mm && !done) {
-                const int k = 31 - (int)__builtin_clz(mm);
-                mm &= ~(1u << k);
-                if (attempts-- <= 0) { done = true; break; }              // while (cur != -1 && attempts-- > 0)  :255
-                const int c = b0L + k, dist = pos - c;
-                if (dist < g.min_dist) continue;                           // :262-266 (the attempt is spent)
-                if (best_l > 0 && dp[best_l] != data[c + best_l]) continue;   // (cannot be longer than the best so far: benc_wave_search)
-                int len = benc_wave_match_len(dp, data + c, best_possible);
-                const int score = score_match(g, len, dist);
-                if (score > best_score) { best_score = score; best_l = len; best_d = dist; if (best_l == best_possible) done = true; }
-            }
-            any &= ~(1ull << L);
+        if (__ballot(m16 != 0u) == 0ull) continue;
+        // ---- the block's candidates, nearest first: rank = candidates in the lanes above mine + those above the bit in my own word
+        const u32 mine = (u32)__popc(m16);
+        const u32 incl = scan_add(mine);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 above = total - incl;
+        u32 nc = total < (u32)attempts ? total : (u32)attempts;           // while (cur != -1 && attempts-- > 0)  :255 -- every listed candidate spends an attempt
+        if (nc > 64u) nc = 64u;                                           // (maxChain is at most 24 below quality 10)
+        {
+            u32 mm = m16, r = above;
+            while (mm && r < nc) { const int k = 31 - (int)__builtin_clz(mm); mm &= ~(1u << k); cl[r++] = (unsigned short)(b0 + k - (top - 1024)); }
         }
-        if (attempts <= 0) done = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        const u32 gsh = nc <= 16u ? 2u : nc <= 32u ? 1u : 0u;             // lanes per candidate: 4 / 2 / 1
+        const u32 j = (u32)lane >> gsh, t = (u32)lane & ((1u << gsh) - 1u);
+        const int c = j < nc ? top - 1024 + (int)cl[j] : pos;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        attempts -= (int)nc;
+        const int dist = pos - c;
+        const bool valid = j < nc && dist >= g.min_dist;                  // closer than minDistance: skipped, the attempt is spent  :262-266
+        // GetMatchLength (:338-357) of every candidate: rounds of 32 bytes per lane (a round is a memory round trip: 128 bytes per candidate with four lanes each)
+        int len = best_possible;
+        bool go = valid;
+        const int stride = 32 << gsh;
+        for (int off = 0; off < best_possible && __ballot(go); off += stride) {
+            const int o = off + 32 * (int)t;
+            const bool ld = go && o < best_possible;
+            u64 va[4], vb[4];
+            __builtin_memcpy(va, dp + (ld ? o : 0), 32); __builtin_memcpy(vb, data + c + (ld ? o : 0), 32);   // (up to 31 bytes behind best_possible: the slack behind every source buffer)
+            const u64 x0 = va[0] ^ vb[0], x1 = va[1] ^ vb[1], x2 = va[2] ^ vb[2], x3 = va[3] ^ vb[3];
+            // where my 32 bytes end the match (0x7FFFFFFF: they do not); lanes behind best_possible end it where they start
+            u32 key = !ld ? (u32)o : x0 ? (u32)o + (u32)(__builtin_ctzll(x0) >> 3) : x1 ? (u32)o + 8u + (u32)(__builtin_ctzll(x1) >> 3)
+                                   : x2 ? (u32)o + 16u + (u32)(__builtin_ctzll(x2) >> 3) : x3 ? (u32)o + 24u + (u32)(__builtin_ctzll(x3) >> 3) : 0x7FFFFFFFu;
+            if (gsh >= 1u) { const u32 k2 = (u32)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xF, 0xF, false); key = k2 < key ? k2 : key; }   // quad_perm [1,0,3,2]
+            if (gsh >= 2u) { const u32 k2 = (u32)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xF, 0xF, false); key = k2 < key ? k2 : key; }   // quad_perm [2,3,0,1]
+            if (go && key != 0x7FFFFFFFu) { len = (int)key < best_possible ? (int)key : best_possible; go = false; }
+        }
+        // ChainMatches' choice: the first candidate of the best score (ScoreMatch :301-321, one property set: the length, cut to the distance in CompatibilityMode)
+        int l2 = len;
+        if (g.no_self_overlap && l2 > dist) l2 = dist;
+        const int score = l2 - g.min_len;
+        const u32 skey = (valid && t == 0u && score >= 0) ? (((u32)score + 1u) << 8) | (255u - j) : 0u;
+        const u32 smax = (u32)__builtin_amdgcn_readlane((int)scan_max(skey), 63);
+        if (smax != 0u) {
+            const int sc = (int)(smax >> 8) - 1;
+            if (sc > best_score) {
+                const int jb = 255 - (int)(smax & 255u);
+                best_score = sc;
+                best_l = __builtin_amdgcn_readlane(l2, jb << gsh);
+                best_d = __builtin_amdgcn_readlane(dist, jb << gsh);
+                if (best_l == best_possible) break;
+            }
+        }
     }
 }
 
@@ -2339,6 +2379,7 @@ __global__ __launch_bounds__(64) void enc_scan_emit_kernel(const u8* __restrict_
     constexpr u32 FBITS = FMT == ALZ_FMT_LZHUDSON ? 32u : 8u, FB = FBITS / 8u;
     __shared__ u32 flagacc[16];
     __shared__ u32 gofs[16];
+    __shared__ unsigned short candl[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const u32 sid = index_list[bid];
@@ -2360,7 +2401,6 @@ __global__ __launch_bounds__(64) void enc_scan_emit_kernel(const u8* __restrict_
     u32 cover = 0;                                                       // end of the last match
     u32 tail = 0;                                                        // behind the walk: the next position of what is left (literals)
     bool walk = limit >= 0;
-    if (!walk) tail = 0;
     for (;;) {
         // ---- up to 64 tokens: lane k holds token k -- (position, distance, length), length 0 = a literal
         u32 tp = 0; uint2 tm2 = make_uint2(0, 0);
@@ -2368,10 +2408,10 @@ __global__ __launch_bounds__(64) void enc_scan_emit_kernel(const u8* __restrict_
         while (walk && k <= 62) {
             if (cur > limit) { walk = false; tail = (u32)cur > cover ? (u32)cur : cover; break; }
             int d0, l0, d1 = 0, l1 = 0;
-            benc_wave_scan_search(data, (int)n, g, cur, d0, l0);
+            benc_wave_scan_search(data, (int)n, g, cur, d0, l0, candl);
             if (l0 < g.min_len) { if (lane == k) { tp = (u32)cur; tm2 = make_uint2(0, 0); } k++; cur++; continue; }      // :166-170
             const bool lazyc = l0 <= g.lazy && cur + 1 <= limit;
-            if (lazyc) benc_wave_scan_search(data, (int)n, g, cur + 1, d1, l1);
+            if (lazyc) benc_wave_scan_search(data, (int)n, g, cur + 1, d1, l1, candl);
             int mp = cur, md = d0, ml = l0, skip = lazyc ? 1 : 0;
             if (lazyc && l1 > l0) { if (lane == k) { tp = (u32)cur; tm2 = make_uint2(0, 0); } k++; mp = cur + 1; md = d1; ml = l1; skip = 0; }   // the byte in front becomes a literal  :181-186
             if (lane == k) { tp = (u32)mp; tm2 = make_uint2((u32)md, (u32)ml); }
@@ -3427,13 +3467,14 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 // stream takes enc_parse_emit_kernel<FMT, false, true> -- the choice decides time only, the bytes are MatchSearch's either way.  Writes two lists over the launch's streams, each with
 // 0xFFFFFFFF where the stream went the other way.
 #ifndef ALZ_SCAN_MAX_PER_KIB
-#define ALZ_SCAN_MAX_PER_KIB 20
+#define ALZ_SCAN_MAX_PER_KIB 40   /* 10 000 windows of 256 KiB of Test.bmp as Yaz0 at quality 8, ms per call: 20 -> 126.9, 40 -> 109.5, 80 -> 112.1, 120 -> 159.6 (262 without the path) */
 #endif
 #ifndef ALZ_SCAN_MIN_LEN
 #define ALZ_SCAN_MIN_LEN 16384     /* shorter buffers: whichever (the regular way) */
 #endif
 __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, u32 count,
                                                              EncGeom g, int force, u32* __restrict__ idx_regular, u32* __restrict__ idx_scan, u32* __restrict__ taken) {
+    __shared__ unsigned short candl[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
     const u32 sid = index_list[bid];
@@ -3450,12 +3491,13 @@ __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restric
                 int cur = start, cnt = 0;
                 while (cur < end && cnt < 16) {
                     int d0, l0, d1, l1;
-                    benc_wave_scan_search(data, n, g, cur, d0, l0); cnt++;
+                    benc_wave_scan_search(data, n, g, cur, d0, l0, candl); cnt++;
                     if (l0 < g.min_len) { cur++; continue; }
-                    if (l0 <= g.lazy && cur + 1 <= limit) { benc_wave_scan_search(data, n, g, cur + 1, d1, l1); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
+                    if (l0 <= g.lazy && cur + 1 <= limit) { benc_wave_scan_search(data, n, g, cur + 1, d1, l1, candl); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
                     else cur += l0;
                 }
                 per_kib += (cnt << 10) / (cur > start ? cur - start : 1);
+                if (per_kib > 8 * ALZ_SCAN_MAX_PER_KIB) break;             // (already over: the synthetic batches leave after two places)
             }
             take = per_kib <= 8 * ALZ_SCAN_MAX_PER_KIB;
         }
