@@ -673,7 +673,8 @@ __device__ __forceinline__ void benc_wave_search(const u8* data, int n, const En
 // strictly better --, so the result is the maximum over the list of (score, nearest first): one wave maximum.  (Measured one after the other, nearest first, with a byte test
 // in front of each -- the managed order -- a flat window of Test.bmp cost 1 400 instructions and 37 loads per search, 8 us: its pixels repeat at distance 4, every search meets
 // maxChain candidates, and in a gradient each of them is a little longer than the one before.)
-__device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l, unsigned short* cl) {
+// Returns the blocks it looked at (what a search costs beside its fixed part: the probe's measure).
+__device__ __forceinline__ int benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l, unsigned short* cl) {
     const int lane = (int)benc_lane();
     const u8* dp = data + pos;
     const u32 sh = 32u - (u32)g.hash_bits;
@@ -682,7 +683,9 @@ __device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, con
     best_d = 0; best_l = 0; int best_score = -1;
     int attempts = g.max_chain;
     const int lo = pos - g.max_dist > 0 ? pos - g.max_dist : 0;          // candidates: [lo, pos)
+    int blocks = 0;
     for (int top = pos; top > lo && attempts > 0; top -= 1024) {
+        blocks++;
         // my sixteen positions of the block [top - 1024, top): [base, base + 16), read from b0 = max(base, 0) on (nothing is read in front of the stream)
         const int base = top - 1024 + 16 * lane;
         const int b0 = base > 0 ? base : 0;
@@ -754,6 +757,7 @@ __device__ __forceinline__ void benc_wave_scan_search(const u8* data, int n, con
             }
         }
     }
+    return blocks;
 }
 
 __device__ __forceinline__ u32 benc_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -2907,6 +2911,7 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
     const int lane = (int)threadIdx.x;
     hopmark[lane] = 0;
     const u32 sid = index_list[bid];
+    if (sid == 0xFFFFFFFFu) return;               // (a list written on the device, enc_scan_select_kernel: the stream goes the other way)
     const alz_stream st = streams[sid];
     const u8* src = src_base + st.src_off;
     const u8* data = src;
@@ -2975,6 +2980,101 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
         obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u32 wmax = (u32)__builtin_amdgcn_readlane((int)pmax, 63);
         if (wmax > cover) cover = wmax;
+    }
+    // the end: the remaining literals (LZ4: at least five, always a sequence; Snappy: an element only if there are any)
+    const u32 plain = n - cover, lh = (LZ4 || plain) ? F::lit_hdr(plain) : 0u;
+    const u32 total = obase + lh + plain;
+    if (total > cap) fail = true;
+    const bool anyfail = __ballot(fail) != 0ull;
+    if (!anyfail && (LZ4 || plain)) {
+        if (lane == 0) F::put_lit_hdr(dst + obase, plain, 4u, true);
+        wave_copy(dst + obase + lh, src + cover, plain, lane);
+    }
+    if (lane == 0) {
+        alz_result r; r.dst_len = anyfail ? 0u : total; r.src_used = n; r.status = anyfail ? ALZ_ST_OUTPUT_CAPACITY : ALZ_ST_OK; r.reserved = 0;
+        results[sid] = r;
+    }
+}
+
+// LZ4 blocks and raw Snappy for the streams enc_scan_select_kernel picked (round 6): enc_scan_emit_kernel's walk -- every position the cursor stands on searched exactly by the
+// whole wavefront, no links, no match array --, the matches into a list, one per lane, and 64 sequences emitted at once with enc_parse_seq_kernel's arithmetic: a sequence is the
+// literals since the end of the match before it, then the match; sizes by prefix sums.  Literal runs are copied by the wavefront, one after the other (few and short where this
+// path is taken).
+template <int FMT>
+__global__ __launch_bounds__(64) void enc_scan_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
+                                                          const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+    typedef SeqFmt<FMT> F;
+    constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
+    __shared__ unsigned short candl[64];
+    const u32 bid = blockIdx.x;
+    if (bid >= count) return;
+    const u32 sid = index_list[bid];
+    if (sid == 0xFFFFFFFFu) return;               // (the stream went the other way)
+    const int lane = (int)threadIdx.x;
+    const alz_stream st = streams[sid];
+    const u8* src = src_base + st.src_off;
+    const u32 n = st.src_len;
+    u8* dst = dst_base + st.dst_off;
+    const u32 cap = st.dst_cap;
+    if (lane == 0 && aux) { aux[sid].aux0 = 0; aux[sid].aux1 = 0; }
+    if (LZ4 && n < 5u) {                                                      // source.Slice(0, Length - 5) throws
+        if (lane == 0) { alz_result r; r.dst_len = 0; r.src_used = n; r.status = ALZ_ST_BAD_TOKEN; r.reserved = 0; results[sid] = r; }
+        return;
+    }
+    const int ns = (int)n - (LZ4 ? 5 : 0);                                    // what the finder is given: LZ4 searches source[0 : n-5]  (LZ4.cs:208)
+    const int limit = ns - 4;
+    u32 cover = 0, obase = 0;
+    bool fail = false;
+    if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
+        const u32 k = n < 0x80u ? 1u : n < 0x4000u ? 2u : n < 0x200000u ? 3u : n < 0x10000000u ? 4u : 5u;
+        if (k <= cap) { if (lane == 0) { u32 v = n, q = 0; while (v >= 0x80u) { dst[q++] = (u8)((v | 0x80u) & 0xFFu); v >>= 7; } dst[q] = (u8)v; } } else fail = true;
+        obase = k;
+    }
+    int cur = 0;
+    bool walk = limit >= 0;
+    while (walk) {
+        // ---- up to 64 matches: lane k holds match k (position, distance, length)
+        u32 tp = 0, D = 0, M = 0;
+        int k = 0;
+        while (k < 64) {
+            if (cur > limit) { walk = false; break; }
+            int d0, l0, d1 = 0, l1 = 0;
+            (void)benc_wave_scan_search(src, ns, g, cur, d0, l0, candl);
+            if (l0 < g.min_len) { cur++; continue; }                            // :166-170
+            const bool lazyc = l0 <= g.lazy && cur + 1 <= limit;
+            if (lazyc) (void)benc_wave_scan_search(src, ns, g, cur + 1, d1, l1, candl);
+            int mp = cur, md = d0, ml = l0, skip = lazyc ? 1 : 0;
+            if (lazyc && l1 > l0) { mp = cur + 1; md = d1; ml = l1; skip = 0; }   // :181-186
+            if (lane == k) { tp = (u32)mp; D = (u32)md; M = (u32)ml; }
+            k++;
+            const int e = mp + ml, stop = e < limit + 1 ? e : limit + 1;         // :195-203
+            cur = mp + 1 + skip > stop ? mp + 1 + skip : stop;
+        }
+        if (k == 0) break;
+        // ---- the sequences of this batch
+        const bool start = lane < k;
+        const u32 mend = start ? tp + M : 0u;
+        u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)mend, 0x138, 0xF, 0xF, false);     // wave_shr:1 -> the end of the match before mine
+        if (lane == 0) before = cover;
+        const u32 L = start ? tp - before : 0u;
+        const u32 lh = start ? F::lit_hdr(L) : 0u;
+        const u32 esz = start ? lh + L + F::match_size(D, M) : 0u;
+        const u32 incl = scan_add(esz);
+        const u32 off = obase + incl - esz;
+        const bool fits = start && off + esz <= cap;
+        if (start && !fits) fail = true;
+        if (fits) {
+            F::put_lit_hdr(dst + off, L, M, false);
+            F::put_match(dst + off + lh + L, D, M);
+        }
+        u64 runs = __ballot(fits && L != 0u);
+        while (runs) {
+            const int j = (int)__builtin_ctzll(runs);
+            runs &= runs - 1ull;
+            wave_copy(dst + (u32)__builtin_amdgcn_readlane((int)(off + lh), j), src + (u32)__builtin_amdgcn_readlane((int)before, j), (u32)__builtin_amdgcn_readlane((int)L, j), lane);
+        }
+        obase += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        cover = (u32)__builtin_amdgcn_readlane((int)mend, k - 1);
     }
     // the end: the remaining literals (LZ4: at least five, always a sequence; Snappy: an element only if there are any)
     const u32 plain = n - cover, lh = (LZ4 || plain) ? F::lit_hdr(plain) : 0u;
@@ -3464,16 +3564,17 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 // and serial: ~3-6 us per search, so what it costs is the stream's own latency (a mixed window with its ~50 000 searches: 141 ms against 26 us of kernel B's throughput), hidden behind the
 // other streams' kernels A / B / parse on a second HIP stream.  The probe walks the real greedy / lazy parse (scan searches) from eight places of the stream, up to 16 searches and 2 KiB
 // each, and adds up searches PER KiB place by place (a stream that is flat here and photographic there is as slow as its photographic part): up to ALZ_SCAN_MAX_PER_KIB on average the
-// stream takes enc_parse_emit_kernel<FMT, false, true> -- the choice decides time only, the bytes are MatchSearch's either way.  Writes two lists over the launch's streams, each with
+// stream takes enc_scan_emit_kernel<FMT> (LZ4 blocks, raw Snappy: enc_scan_seq_kernel<FMT>) -- the choice decides time only, the bytes are MatchSearch's either way.  Writes two lists over the launch's streams, each with
 // 0xFFFFFFFF where the stream went the other way.
 #ifndef ALZ_SCAN_MAX_PER_KIB
-#define ALZ_SCAN_MAX_PER_KIB 40   /* 10 000 windows of 256 KiB of Test.bmp as Yaz0 at quality 8, ms per call: 20 -> 126.9, 40 -> 109.5, 80 -> 112.1, 120 -> 159.6 (262 without the path) */
+#define ALZ_SCAN_MAX_PER_KIB 72     /* searches per KiB, a search that looks at ONE block of 1 024 positions counting 1 (4 + blocks quarters: the formats with 32 / 64 KiB windows look at up to 32 / 64) */
+                                    /* 10 000 windows of 256 KiB of Test.bmp as Yaz0 at quality 8, ms per call: 40 -> 117.2, 56 -> 111.0, 72 -> 109.6 (262 without the path; counted in plain searches: 20 -> 126.9, 40 -> 109.5, 80 -> 112.1, 120 -> 159.6) */
 #endif
 #ifndef ALZ_SCAN_MIN_LEN
 #define ALZ_SCAN_MIN_LEN 16384     /* shorter buffers: whichever (the regular way) */
 #endif
 __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, u32 count,
-                                                             EncGeom g, int force, u32* __restrict__ idx_regular, u32* __restrict__ idx_scan, u32* __restrict__ taken) {
+                                                             EncGeom g, int tail_skip, int force, u32* __restrict__ idx_regular, u32* __restrict__ idx_scan, u32* __restrict__ taken) {
     __shared__ unsigned short candl[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
@@ -3482,21 +3583,21 @@ __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restric
     if (!take && sid != 0xFFFFFFFFu) {
         const alz_stream st = streams[sid];
         const u8* data = src_base + st.src_off;
-        const int n = (int)st.src_len, limit = n - 4;
+        const int n = (int)st.src_len - tail_skip, limit = n - 4;           // (what the finder is given: LZ4 searches source[0 : n - 5], LZ4.cs:208)
         if (n >= ALZ_SCAN_MIN_LEN) {
             int per_kib = 0;                                          // searches per KiB, summed over the eight places
             for (int k = 0; k < 8; k++) {
                 const int start = (int)(((long long)limit * (2 * k + 1)) >> 4);
                 const int end = start + 2048 < limit + 1 ? start + 2048 : limit + 1;
-                int cur = start, cnt = 0;
+                int cur = start, cnt = 0, cost = 0;
                 while (cur < end && cnt < 16) {
                     int d0, l0, d1, l1;
-                    benc_wave_scan_search(data, n, g, cur, d0, l0, candl); cnt++;
+                    cost += 3 + benc_wave_scan_search(data, n, g, cur, d0, l0, candl); cnt++;
                     if (l0 < g.min_len) { cur++; continue; }
-                    if (l0 <= g.lazy && cur + 1 <= limit) { benc_wave_scan_search(data, n, g, cur + 1, d1, l1, candl); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
+                    if (l0 <= g.lazy && cur + 1 <= limit) { cost += 3 + benc_wave_scan_search(data, n, g, cur + 1, d1, l1, candl); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
                     else cur += l0;
                 }
-                per_kib += (cnt << 10) / (cur > start ? cur - start : 1);
+                per_kib += (cost << 8) / (cur > start ? cur - start : 1);   // (quarters of a one-block search, per KiB)
                 if (per_kib > 8 * ALZ_SCAN_MAX_PER_KIB) break;             // (already over: the synthetic batches leave after two places)
             }
             take = per_kib <= 8 * ALZ_SCAN_MAX_PER_KIB;
@@ -3786,13 +3887,14 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     const u32* d_index_scan = nullptr;
     bool scan_joined = true; const alz_encode_side* scan_side = nullptr;
     {
-        const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 ||
+        const bool seqf = fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;      // (enc_scan_seq_kernel; windows of 64 / 32 KiB: a search looks at up to 64 / 32 blocks)
+        const bool fam = seqf || fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 ||
                          fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
-        if (scan_mode != 2 && fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 && g.max_dist <= 8192 &&
+        if (scan_mode != 2 && fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 && (seqf || g.max_dist <= 8192) &&
             g.link16 && !searches_in_the_parse(fmt, g)) {
             u32* idx_regular = d_sel + 2u * (size_t)sel_pitch + 64u;      // (behind the probe's and the narrowing's lists; sel_pitch words each)
             u32* idx_scan = idx_regular + sel_pitch;
-            hipLaunchKernelGGL(enc_scan_select_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, g, scan_mode == 1 ? 1 : 0, idx_regular, idx_scan, d_scan_taken);
+            hipLaunchKernelGGL(enc_scan_select_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, g, tail, scan_mode == 1 ? 1 : 0, idx_regular, idx_scan, d_scan_taken);
             d_index = idx_regular; d_index_scan = idx_scan;
             // the scan streams' ONE kernel: on the side stream where there is one (a wavefront per stream walking serially -- latency, not throughput -- beside the other streams'
             // kernels A / B / parse, which fill the GPU), joined at the end of this launch
@@ -3803,6 +3905,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             switch (fmt) {
             ALZ_SCANK(ALZ_FMT_LZSS) ALZ_SCANK(ALZ_FMT_LZ10) ALZ_SCANK(ALZ_FMT_LZ11) ALZ_SCANK(ALZ_FMT_LZ40) ALZ_SCANK(ALZ_FMT_YAZ0) ALZ_SCANK(ALZ_FMT_YAY0) ALZ_SCANK(ALZ_FMT_MIO0)
             ALZ_SCANK(ALZ_FMT_CLZ0) ALZ_SCANK(ALZ_FMT_BLZ) ALZ_SCANK(ALZ_FMT_LZHUDSON)
+            case ALZ_FMT_LZ4_BLOCK: hipLaunchKernelGGL((enc_scan_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, d_results, d_aux, g); break;
+            case ALZ_FMT_SNAPPY_RAW: hipLaunchKernelGGL((enc_scan_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, d_results, d_aux, g); break;
             default: break;
             }
 #undef ALZ_SCANK

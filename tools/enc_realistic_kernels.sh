@@ -28,7 +28,7 @@ for _ in range(2):
     res, aux = ctx.encode_batch_device(st, d_src, raw.nbytes, d_dst, dst_bytes, quality=$2)
     print("kernel ms", ctx.last_kernel_ms(), flush=True)
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $D/run.py > $D/log.txt 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $D/run.py > $D/log.txt 2>&1
 grep "kernel ms" $D/log.txt
 python3 - $D <<'PY'
 import csv,glob,sys
