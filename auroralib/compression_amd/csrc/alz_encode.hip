@@ -710,7 +710,7 @@ __device__ __forceinline__ int benc_wave_scan_search(const u8* data, int n, cons
         const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u32 above = total - incl;
         u32 nc = total < (u32)attempts ? total : (u32)attempts;           // while (cur != -1 && attempts-- > 0)  :255 -- every listed candidate spends an attempt
-        if (nc > 64u) nc = 64u;                                           // (maxChain is at most 24 below quality 10)
+        if (nc > 32u) nc = 32u;                                           // (never: the path is taken up to maxChain 32 -- quality 10 -- only, alz_launch_encode)
         {
             u32 mm = m16, r = above;
             while (mm && r < nc) { const int k = 31 - (int)__builtin_clz(mm); mm &= ~(1u << k); cl[r++] = (unsigned short)(b0 + k - (top - 1024)); }
@@ -3890,8 +3890,10 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         const bool seqf = fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;      // (enc_scan_seq_kernel; windows of 64 / 32 KiB: a search looks at up to 64 / 32 blocks)
         const bool fam = seqf || fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 ||
                          fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
-        if (scan_mode != 2 && fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 && (seqf || g.max_dist <= 8192) &&
-            g.link16 && !searches_in_the_parse(fmt, g)) {
+        if (scan_mode != 2 && fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 && g.max_chain <= 32 /* (a block's candidates are measured at once, two lanes each at least) */ && (seqf || g.max_dist <= 8192) &&
+            g.link16 && !searches_in_the_parse(fmt, g) &&
+            (scan_mode == 1 || g.max_len >= 64) /* (matches of at most 18 bytes -- LZ10, MIO0, the default LZSS -- keep kernel B's compares short and every stream above the probe's line: 10 000
+                                                    windows of Test.bmp at quality 8 as LZ10 86.7 ms without the path, 95.0 with it; LZSS 86.5 / 106.1.  Forced: the parity tests.) */) {
             u32* idx_regular = d_sel + 2u * (size_t)sel_pitch + 64u;      // (behind the probe's and the narrowing's lists; sel_pitch words each)
             u32* idx_scan = idx_regular + sel_pitch;
             hipLaunchKernelGGL(enc_scan_select_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, g, tail, scan_mode == 1 ? 1 : 0, idx_regular, idx_scan, d_scan_taken);

@@ -129,11 +129,14 @@ def test_probe_chooses_per_stream_and_off_is_off(test_bmp):
     for fmt, q in ((A.FMT_YAZ0, 8), (A.FMT_LZ11, 8), (A.FMT_YAY0, 5), (A.FMT_LZ4_BLOCK, 8)):
         _check(fmt, raws, q, mode=0, expect_taken=lambda t: 0 < t < len(raws))
         _check(fmt, raws, q, mode=2, expect_taken=lambda t: t == 0)
-    # (matches of at most 18 bytes are more than twenty searches per KiB on any data: the probe never sends an LZ10 / MIO0 stream that way)
+    # (formats whose matches end at 18 bytes are not sent that way unless forced: kernel B is fast on them)
     _check(A.FMT_LZ10, raws, 8, mode=0, expect_taken=lambda t: t == 0)
+    _check(A.FMT_MIO0, raws, 8, mode=0, expect_taken=lambda t: t == 0)
     # qualities / formats the path does not cover go the regular way even when forced
     _check(A.FMT_YAZ0, raws[:6], 12, mode=1, expect_taken=lambda t: t == 0)
     _check(A.FMT_YAZ0, raws[:6], 0, mode=1, expect_taken=lambda t: t == 0)
+    _check(A.FMT_LZ4_BLOCK, raws[:6], 11, mode=1, expect_taken=lambda t: t == 0)       # (maxChain 64: more candidates than the lanes measure at once)
+    _check(A.FMT_LZ4_BLOCK, raws[:6] + [bytes(70000) + b"x" + bytes(30000)], 10, mode=1, expect_taken=lambda t: t == 7)   # (maxChain 32: the most the path takes)
 
 
 def test_forced_scan_capacity_one_byte_short_with_canary(test_bmp):
