@@ -3822,7 +3822,10 @@ static void launch_match(hipStream_t stream, const u8* src, const alz_stream* d_
     if (dense_ok && g.max_chain >= 3 && g.max_chain <= 4095 && g.max_dist < (1 << 28)) {        // (from maxChain 3 on: the chains first, the pairs 64 at a time)
         const bool dyn = g.max_chain >= 8;
         u32 bd = dyn ? (max_len + 255u) / 256u : (max_len + 63u) / 64u; if (bd == 0) bd = 1; if (bd > 4096u) bd = 4096u;
-        u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? 2u : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)
+#ifndef ALZ_DENSE_XLOG
+#define ALZ_DENSE_XLOG 3u    /* runs of eight blocks per XCD (round 6, cfg5 at quality 8, kernel B ms / fetch x 2 GB: runs of 4 45.1 / 40.5, of 8 45.3 / 23.2, of 16 47.7 / 15.4, of 64 53.2 / 9.7: profiles/r06_cfg5_traffic.md) */
+#endif
+        u32 xlog = !dyn ? 7u : g.max_chain <= 128 ? ALZ_DENSE_XLOG : 0u;        //           // runs of consecutive blocks per XCD (enc_match_dense_kernel; the longest chains lose with them: 104.9 -> 113.7 ms at quality 15, while quality 12 gains 85.0 -> 83.6)
         while (xlog && (8u << xlog) > bd) xlog--;
         if (xlog) bd = (bd + (8u << xlog) - 1u) / (8u << xlog) * (8u << xlog);
         // (per stream: the two-phase kernel or the one-position-per-lane one -- enc_probe_kernel; both are launched, each leaves the other's streams alone)
