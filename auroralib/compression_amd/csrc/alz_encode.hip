@@ -673,8 +673,59 @@ __device__ __forceinline__ void benc_wave_search(const u8* data, int n, const En
 // strictly better --, so the result is the maximum over the list of (score, nearest first): one wave maximum.  (Measured one after the other, nearest first, with a byte test
 // in front of each -- the managed order -- a flat window of Test.bmp cost 1 400 instructions and 37 loads per search, 8 us: its pixels repeat at distance 4, every search meets
 // maxChain candidates, and in a gradient each of them is a little longer than the one before.)
-// Returns the blocks it looked at (what a search costs beside its fixed part: the probe's measure).
-__device__ __forceinline__ int benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l, unsigned short* cl) {
+// The listed candidates -- cl[j] = the distance of candidate j, nearest first, nc <= 32 of them -- measured at once and ChainMatches' choice among them folded into the
+// best so far: GetMatchLength (:338-357) in rounds of 32 bytes per lane (a round is a memory round trip: 128 bytes per candidate with four lanes each), a candidate drops out
+// at its first mismatch; the first candidate of the best score wins and must beat the best of the blocks before (strictly: :271-279).  True: that match is the longest possible.
+__device__ __forceinline__ bool benc_scan_measure(const u8* data, const EncGeom& g, int pos, int best_possible, const unsigned short* cl, u32 nc, int lane, int& best_score, int& best_d, int& best_l) {
+    const u8* dp = data + pos;
+    const u32 gsh = nc <= 16u ? 2u : nc <= 32u ? 1u : 0u;             // lanes per candidate: 4 / 2 / 1
+    const u32 j = (u32)lane >> gsh, t = (u32)lane & ((1u << gsh) - 1u);
+    const int dist = j < nc ? (int)cl[j] : 0;
+    const int c = pos - dist;
+    const bool valid = j < nc && dist >= g.min_dist;                  // closer than minDistance: skipped, the attempt is spent  :262-266
+    int len = best_possible;
+    bool go = valid;
+    const int stride = 32 << gsh;
+    for (int off = 0; off < best_possible && __ballot(go); off += stride) {
+        const int o = off + 32 * (int)t;
+        const bool ld = go && o < best_possible;
+        u64 va[4], vb[4];
+        __builtin_memcpy(va, dp + (ld ? o : 0), 32); __builtin_memcpy(vb, data + c + (ld ? o : 0), 32);   // (up to 31 bytes behind best_possible: the slack behind every source buffer)
+        const u64 x0 = va[0] ^ vb[0], x1 = va[1] ^ vb[1], x2 = va[2] ^ vb[2], x3 = va[3] ^ vb[3];
+        // where my 32 bytes end the match (0x7FFFFFFF: they do not); lanes behind best_possible end it where they start
+        u32 key = !ld ? (u32)o : x0 ? (u32)o + (u32)(__builtin_ctzll(x0) >> 3) : x1 ? (u32)o + 8u + (u32)(__builtin_ctzll(x1) >> 3)
+                               : x2 ? (u32)o + 16u + (u32)(__builtin_ctzll(x2) >> 3) : x3 ? (u32)o + 24u + (u32)(__builtin_ctzll(x3) >> 3) : 0x7FFFFFFFu;
+        if (gsh >= 1u) { const u32 k2 = (u32)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xF, 0xF, false); key = k2 < key ? k2 : key; }   // quad_perm [1,0,3,2]
+        if (gsh >= 2u) { const u32 k2 = (u32)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xF, 0xF, false); key = k2 < key ? k2 : key; }   // quad_perm [2,3,0,1]
+        if (go && key != 0x7FFFFFFFu) { len = (int)key < best_possible ? (int)key : best_possible; go = false; }
+    }
+    // ChainMatches' choice: the first candidate of the best score (ScoreMatch :301-321, one property set: the length, cut to the distance in CompatibilityMode)
+    int l2 = len;
+    if (g.no_self_overlap && l2 > dist) l2 = dist;
+    const int score = l2 - g.min_len;
+    const u32 skey = (valid && t == 0u && score >= 0) ? (((u32)score + 1u) << 8) | (255u - j) : 0u;
+    const u32 smax = (u32)__builtin_amdgcn_readlane((int)scan_max(skey), 63);
+    if (smax != 0u) {
+        const int sc = (int)(smax >> 8) - 1;
+        if (sc > best_score) {
+            const int jb = 255 - (int)(smax & 255u);
+            best_score = sc;
+            best_l = __builtin_amdgcn_readlane(l2, jb << gsh);
+            best_d = __builtin_amdgcn_readlane(dist, jb << gsh);
+            if (best_l == best_possible) return true;
+        }
+    }
+    return false;
+}
+
+// `p4` (LZ4 blocks, raw Snappy: windows of 64 / 32 KiB): kernel A's links.  The nearest ALZ_SCAN_NEAR blocks are scanned -- in a run or a stretch of repeated rows that is where the candidates
+// are --, and what lies further back is reached by FOLLOWING the chain from the farthest candidate seen (from the position itself where the scan found none): a position with few candidates
+// would otherwise look at all 64 blocks of its window.
+// Returns what the search cost beside its fixed part: the blocks it looked at + the links it followed (the probe's measure).
+#ifndef ALZ_SCAN_NEAR
+#define ALZ_SCAN_NEAR 2   /* (10 000 windows of Test.bmp at quality 8, ms per call, LZ4 blocks / raw Snappy: 1 -> 144.5 / 126.8, 2 -> 144.4 / 121.5, 4 -> 153.0 / 126.0, 8 -> 160.9 / 131.7; every block: 263.7 / 162.0) */
+#endif
+__device__ __forceinline__ int benc_wave_scan_search(const u8* data, int n, const EncGeom& g, int pos, int& best_d, int& best_l, unsigned short* cl, const int* p4 = nullptr) {
     const int lane = (int)benc_lane();
     const u8* dp = data + pos;
     const u32 sh = 32u - (u32)g.hash_bits;
@@ -684,7 +735,9 @@ __device__ __forceinline__ int benc_wave_scan_search(const u8* data, int n, cons
     int attempts = g.max_chain;
     const int lo = pos - g.max_dist > 0 ? pos - g.max_dist : 0;          // candidates: [lo, pos)
     int blocks = 0;
-    for (int top = pos; top > lo && attempts > 0; top -= 1024) {
+    int far = pos;                                                       // the farthest candidate seen (the chain goes on from it)
+    int top = pos;
+    for (; top > lo && attempts > 0 && (p4 == nullptr || blocks < ALZ_SCAN_NEAR); top -= 1024) {
         blocks++;
         // my sixteen positions of the block [top - 1024, top): [base, base + 16), read from b0 = max(base, 0) on (nothing is read in front of the stream)
         const int base = top - 1024 + 16 * lane;
@@ -713,48 +766,32 @@ __device__ __forceinline__ int benc_wave_scan_search(const u8* data, int n, cons
         if (nc > 32u) nc = 32u;                                           // (never: the path is taken up to maxChain 32 -- quality 10 -- only, alz_launch_encode)
         {
             u32 mm = m16, r = above;
-            while (mm && r < nc) { const int k = 31 - (int)__builtin_clz(mm); mm &= ~(1u << k); cl[r++] = (unsigned short)(b0 + k - (top - 1024)); }
+            while (mm && r < nc) { const int k = 31 - (int)__builtin_clz(mm); mm &= ~(1u << k); cl[r++] = (unsigned short)(pos - (b0 + k)); }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        const u32 gsh = nc <= 16u ? 2u : nc <= 32u ? 1u : 0u;             // lanes per candidate: 4 / 2 / 1
-        const u32 j = (u32)lane >> gsh, t = (u32)lane & ((1u << gsh) - 1u);
-        const int c = j < nc ? top - 1024 + (int)cl[j] : pos;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         attempts -= (int)nc;
-        const int dist = pos - c;
-        const bool valid = j < nc && dist >= g.min_dist;                  // closer than minDistance: skipped, the attempt is spent  :262-266
-        // GetMatchLength (:338-357) of every candidate: rounds of 32 bytes per lane (a round is a memory round trip: 128 bytes per candidate with four lanes each)
-        int len = best_possible;
-        bool go = valid;
-        const int stride = 32 << gsh;
-        for (int off = 0; off < best_possible && __ballot(go); off += stride) {
-            const int o = off + 32 * (int)t;
-            const bool ld = go && o < best_possible;
-            u64 va[4], vb[4];
-            __builtin_memcpy(va, dp + (ld ? o : 0), 32); __builtin_memcpy(vb, data + c + (ld ? o : 0), 32);   // (up to 31 bytes behind best_possible: the slack behind every source buffer)
-            const u64 x0 = va[0] ^ vb[0], x1 = va[1] ^ vb[1], x2 = va[2] ^ vb[2], x3 = va[3] ^ vb[3];
-            // where my 32 bytes end the match (0x7FFFFFFF: they do not); lanes behind best_possible end it where they start
-            u32 key = !ld ? (u32)o : x0 ? (u32)o + (u32)(__builtin_ctzll(x0) >> 3) : x1 ? (u32)o + 8u + (u32)(__builtin_ctzll(x1) >> 3)
-                                   : x2 ? (u32)o + 16u + (u32)(__builtin_ctzll(x2) >> 3) : x3 ? (u32)o + 24u + (u32)(__builtin_ctzll(x3) >> 3) : 0x7FFFFFFFu;
-            if (gsh >= 1u) { const u32 k2 = (u32)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xF, 0xF, false); key = k2 < key ? k2 : key; }   // quad_perm [1,0,3,2]
-            if (gsh >= 2u) { const u32 k2 = (u32)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xF, 0xF, false); key = k2 < key ? k2 : key; }   // quad_perm [2,3,0,1]
-            if (go && key != 0x7FFFFFFFu) { len = (int)key < best_possible ? (int)key : best_possible; go = false; }
+        far = pos - (int)cl[nc - 1u];
+        const bool full = benc_scan_measure(data, g, pos, best_possible, cl, nc, lane, best_score, best_d, best_l);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (full) return blocks;
+    }
+    if (p4 != nullptr && attempts > 0 && top > lo) {
+        // ---- behind the scanned blocks: the chain itself (ChainMatches :248-282 with 16-bit links), as many candidates as there are attempts left, then measured like a block's
+        u32 nc = 0; int hops = 0;
+        int cur = link_at<true>(p4, far);
+        while (cur != -1 && attempts > 0) {
+            attempts--; hops++;
+            const int dist = pos - cur;
+            if (dist > g.max_dist) break;                                  // :259-260
+            if (lane == 0) cl[nc] = (unsigned short)dist;
+            nc++;
+            cur = link_at<true>(p4, cur);
         }
-        // ChainMatches' choice: the first candidate of the best score (ScoreMatch :301-321, one property set: the length, cut to the distance in CompatibilityMode)
-        int l2 = len;
-        if (g.no_self_overlap && l2 > dist) l2 = dist;
-        const int score = l2 - g.min_len;
-        const u32 skey = (valid && t == 0u && score >= 0) ? (((u32)score + 1u) << 8) | (255u - j) : 0u;
-        const u32 smax = (u32)__builtin_amdgcn_readlane((int)scan_max(skey), 63);
-        if (smax != 0u) {
-            const int sc = (int)(smax >> 8) - 1;
-            if (sc > best_score) {
-                const int jb = 255 - (int)(smax & 255u);
-                best_score = sc;
-                best_l = __builtin_amdgcn_readlane(l2, jb << gsh);
-                best_d = __builtin_amdgcn_readlane(dist, jb << gsh);
-                if (best_l == best_possible) break;
-            }
+        blocks += hops;
+        if (nc) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            (void)benc_scan_measure(data, g, pos, best_possible, cl, nc, lane, best_score, best_d, best_l);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
     return blocks;
@@ -3002,7 +3039,8 @@ __global__ __launch_bounds__(64) void enc_parse_seq_kernel(const u8* __restrict_
 // path is taken).
 template <int FMT>
 __global__ __launch_bounds__(64) void enc_scan_seq_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,
-                                                          const u32* __restrict__ index_list, u32 count, alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
+                                                          const u32* __restrict__ index_list, u32 count, const int* __restrict__ prev4, const u64* __restrict__ pos_off,
+                                                          alz_result* __restrict__ results, alz_encode_aux* __restrict__ aux, EncGeom g) {
     typedef SeqFmt<FMT> F;
     constexpr bool LZ4 = FMT == ALZ_FMT_LZ4_BLOCK;
     __shared__ unsigned short candl[64];
@@ -3023,6 +3061,7 @@ __global__ __launch_bounds__(64) void enc_scan_seq_kernel(const u8* __restrict__
     }
     const int ns = (int)n - (LZ4 ? 5 : 0);                                    // what the finder is given: LZ4 searches source[0 : n-5]  (LZ4.cs:208)
     const int limit = ns - 4;
+    const int* p4 = prev4 + pos_off[sid];                                     // kernel A's links: what lies behind the nearest blocks is reached through them
     u32 cover = 0, obase = 0;
     bool fail = false;
     if (!LZ4) {                                                               // Snappy: the decompressed length as a varint  :126-135
@@ -3039,10 +3078,10 @@ __global__ __launch_bounds__(64) void enc_scan_seq_kernel(const u8* __restrict__
         while (k < 64) {
             if (cur > limit) { walk = false; break; }
             int d0, l0, d1 = 0, l1 = 0;
-            (void)benc_wave_scan_search(src, ns, g, cur, d0, l0, candl);
+            (void)benc_wave_scan_search(src, ns, g, cur, d0, l0, candl, p4);
             if (l0 < g.min_len) { cur++; continue; }                            // :166-170
             const bool lazyc = l0 <= g.lazy && cur + 1 <= limit;
-            if (lazyc) (void)benc_wave_scan_search(src, ns, g, cur + 1, d1, l1, candl);
+            if (lazyc) (void)benc_wave_scan_search(src, ns, g, cur + 1, d1, l1, candl, p4);
             int mp = cur, md = d0, ml = l0, skip = lazyc ? 1 : 0;
             if (lazyc && l1 > l0) { mp = cur + 1; md = d1; ml = l1; skip = 0; }   // :181-186
             if (lane == k) { tp = (u32)mp; D = (u32)md; M = (u32)ml; }
@@ -3574,7 +3613,8 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 #define ALZ_SCAN_MIN_LEN 16384     /* shorter buffers: whichever (the regular way) */
 #endif
 __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restrict__ src_base, const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, u32 count,
-                                                             EncGeom g, int tail_skip, int force, u32* __restrict__ idx_regular, u32* __restrict__ idx_scan, u32* __restrict__ taken) {
+                                                             EncGeom g, int tail_skip, int force, u32* __restrict__ idx_regular, u32* __restrict__ idx_scan, u32* __restrict__ taken,
+                                                             const int* __restrict__ prev4, const u64* __restrict__ pos_off) {
     __shared__ unsigned short candl[64];
     const u32 bid = blockIdx.x;
     if (bid >= count) return;
@@ -3584,6 +3624,7 @@ __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restric
         const alz_stream st = streams[sid];
         const u8* data = src_base + st.src_off;
         const int n = (int)st.src_len - tail_skip, limit = n - 4;           // (what the finder is given: LZ4 searches source[0 : n - 5], LZ4.cs:208)
+        const int* p4 = prev4 ? prev4 + pos_off[sid] : nullptr;             // (the formats with 32 / 64 KiB windows: the search follows kernel A's links behind the nearest blocks)
         if (n >= ALZ_SCAN_MIN_LEN) {
             int per_kib = 0;                                          // searches per KiB, summed over the eight places
             for (int k = 0; k < 8; k++) {
@@ -3592,9 +3633,9 @@ __global__ __launch_bounds__(64) void enc_scan_select_kernel(const u8* __restric
                 int cur = start, cnt = 0, cost = 0;
                 while (cur < end && cnt < 16) {
                     int d0, l0, d1, l1;
-                    cost += 3 + benc_wave_scan_search(data, n, g, cur, d0, l0, candl); cnt++;
+                    cost += 3 + benc_wave_scan_search(data, n, g, cur, d0, l0, candl, p4); cnt++;
                     if (l0 < g.min_len) { cur++; continue; }
-                    if (l0 <= g.lazy && cur + 1 <= limit) { cost += 3 + benc_wave_scan_search(data, n, g, cur + 1, d1, l1, candl); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
+                    if (l0 <= g.lazy && cur + 1 <= limit) { cost += 3 + benc_wave_scan_search(data, n, g, cur + 1, d1, l1, candl, p4); cnt++; cur += l1 > l0 ? 1 + l1 : l0; }
                     else cur += l0;
                 }
                 per_kib += (cost << 8) / (cur > start ? cur - start : 1);   // (quarters of a one-block search, per KiB)
@@ -3889,35 +3930,37 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     // The flag-bit formats of enc_parse_emit_kernel with windows up to 8 KiB, one property set, no min-length table (quality 2-9), a full batch (not the segmented path).
     const u32* d_index_scan = nullptr;
     bool scan_joined = true; const alz_encode_side* scan_side = nullptr;
-    {
-        const bool seqf = fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;      // (enc_scan_seq_kernel; windows of 64 / 32 KiB: a search looks at up to 64 / 32 blocks)
-        const bool fam = seqf || fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 ||
-                         fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
-        if (scan_mode != 2 && fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 && g.max_chain <= 32 /* (a block's candidates are measured at once, two lanes each at least) */ && (seqf || g.max_dist <= 8192) &&
-            g.link16 && !searches_in_the_parse(fmt, g) &&
-            (scan_mode == 1 || g.max_len >= 64) /* (matches of at most 18 bytes -- LZ10, MIO0, the default LZSS -- keep kernel B's compares short and every stream above the probe's line: 10 000
-                                                    windows of Test.bmp at quality 8 as LZ10 86.7 ms without the path, 95.0 with it; LZSS 86.5 / 106.1.  Forced: the parity tests.) */) {
-            u32* idx_regular = d_sel + 2u * (size_t)sel_pitch + 64u;      // (behind the probe's and the narrowing's lists; sel_pitch words each)
-            u32* idx_scan = idx_regular + sel_pitch;
-            hipLaunchKernelGGL(enc_scan_select_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, g, tail, scan_mode == 1 ? 1 : 0, idx_regular, idx_scan, d_scan_taken);
-            d_index = idx_regular; d_index_scan = idx_scan;
-            // the scan streams' ONE kernel: on the side stream where there is one (a wavefront per stream walking serially -- latency, not throughput -- beside the other streams'
-            // kernels A / B / parse, which fill the GPU), joined at the end of this launch
-            hipStream_t sq = stream;
-            if (side_q && side_q->s && side_q->fork && side_q->join && hipEventRecord(side_q->fork, stream) == hipSuccess && hipStreamWaitEvent(side_q->s, side_q->fork, 0) == hipSuccess) sq = side_q->s;
-            u8* side = (u8*)d_side;
+    const bool seqf = fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_SNAPPY_RAW;          // (enc_scan_seq_kernel; windows of 64 / 32 KiB: the nearest blocks scanned, kernel A's links behind them)
+    const bool scan_fam = seqf || fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 ||
+                          fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
+    const bool scan_ok = scan_mode != 2 && scan_fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 &&
+                         g.max_chain <= 32 /* (a block's candidates are measured at once, two lanes each at least) */ && (seqf || g.max_dist <= 8192) && g.link16 && !searches_in_the_parse(fmt, g) &&
+                         (scan_mode == 1 || g.max_len >= 64);  /* (matches of at most 18 bytes -- LZ10, MIO0, the default LZSS -- keep kernel B's compares short and every stream above the probe's
+                                                                  line: 10 000 windows of Test.bmp at quality 8 as LZ10 86.7 ms without the path, 95.0 with it; LZSS 86.5 / 106.1.  Forced: the parity tests.) */
+    // (`links`: kernel A's, for the formats whose search follows them behind the nearest blocks -- their select + scan kernels are launched behind kernel A, which then runs for every stream)
+    auto launch_scan = [&](const int* links) -> hipError_t {
+        u32* idx_regular = d_sel + 2u * (size_t)sel_pitch + 64u;      // (behind the probe's and the narrowing's lists; sel_pitch words each)
+        u32* idx_scan = idx_regular + sel_pitch;
+        hipLaunchKernelGGL(enc_scan_select_kernel, dim3(count), dim3(64), 0, stream, src, d_streams, d_index, count, g, tail, scan_mode == 1 ? 1 : 0, idx_regular, idx_scan, d_scan_taken, links, d_pos_off);
+        d_index = idx_regular; d_index_scan = idx_scan;
+        // the scan streams' ONE kernel: on the side stream where there is one (a wavefront per stream walking serially -- latency, not throughput -- beside the other streams'
+        // kernels A / B / parse, which fill the GPU), joined at the end of this launch
+        hipStream_t sq = stream;
+        if (side_q && side_q->s && side_q->fork && side_q->join && hipEventRecord(side_q->fork, stream) == hipSuccess && hipStreamWaitEvent(side_q->s, side_q->fork, 0) == hipSuccess) sq = side_q->s;
+        u8* side = (u8*)d_side;
 #define ALZ_SCANK(F) case F: hipLaunchKernelGGL((enc_scan_emit_kernel<F>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, d_pos_off, side, d_results, d_aux, g); break;
-            switch (fmt) {
-            ALZ_SCANK(ALZ_FMT_LZSS) ALZ_SCANK(ALZ_FMT_LZ10) ALZ_SCANK(ALZ_FMT_LZ11) ALZ_SCANK(ALZ_FMT_LZ40) ALZ_SCANK(ALZ_FMT_YAZ0) ALZ_SCANK(ALZ_FMT_YAY0) ALZ_SCANK(ALZ_FMT_MIO0)
-            ALZ_SCANK(ALZ_FMT_CLZ0) ALZ_SCANK(ALZ_FMT_BLZ) ALZ_SCANK(ALZ_FMT_LZHUDSON)
-            case ALZ_FMT_LZ4_BLOCK: hipLaunchKernelGGL((enc_scan_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, d_results, d_aux, g); break;
-            case ALZ_FMT_SNAPPY_RAW: hipLaunchKernelGGL((enc_scan_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, d_results, d_aux, g); break;
-            default: break;
-            }
-#undef ALZ_SCANK
-            if (sq != stream) { if (hipEventRecord(side_q->join, sq) != hipSuccess) return hipGetLastError(); scan_joined = false; scan_side = side_q; }
+        switch (fmt) {
+        ALZ_SCANK(ALZ_FMT_LZSS) ALZ_SCANK(ALZ_FMT_LZ10) ALZ_SCANK(ALZ_FMT_LZ11) ALZ_SCANK(ALZ_FMT_LZ40) ALZ_SCANK(ALZ_FMT_YAZ0) ALZ_SCANK(ALZ_FMT_YAY0) ALZ_SCANK(ALZ_FMT_MIO0)
+        ALZ_SCANK(ALZ_FMT_CLZ0) ALZ_SCANK(ALZ_FMT_BLZ) ALZ_SCANK(ALZ_FMT_LZHUDSON)
+        case ALZ_FMT_LZ4_BLOCK: hipLaunchKernelGGL((enc_scan_seq_kernel<ALZ_FMT_LZ4_BLOCK>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, links, d_pos_off, d_results, d_aux, g); break;
+        case ALZ_FMT_SNAPPY_RAW: hipLaunchKernelGGL((enc_scan_seq_kernel<ALZ_FMT_SNAPPY_RAW>), dim3(count), dim3(64), 0, sq, src, dst, d_streams, d_index_scan, count, links, d_pos_off, d_results, d_aux, g); break;
+        default: break;
         }
-    }
+#undef ALZ_SCANK
+        if (sq != stream) { if (hipEventRecord(side_q->join, sq) != hipSuccess) return hipGetLastError(); scan_joined = false; scan_side = side_q; }
+        return hipSuccess;
+    };
+    if (scan_ok && !seqf) { const hipError_t es = launch_scan(nullptr); if (es != hipSuccess) return es; }
     AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
     if (d_seg != nullptr && seg_len != 0u && tail == 0) {
         size_t ab = 0; u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;
@@ -3973,6 +4016,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
                                                               : launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
         if (ea != hipSuccess) return ea;
     }
+    if (scan_ok && seqf) { const hipError_t es = launch_scan(d_prev4); if (es != hipSuccess) return es; }
     const bool segmented = d_seg != nullptr && seg_len != 0u;                   // (a batch of few buffers: alz_encode_seg.h -- always behind kernel B)
     const u32 wgc = !segmented ? 32u : count < 128u ? 128u : 64u;           // (workgroups per buffer in kernel B: 64 buffers of 64 KiB at quality 8 0.92 -> 0.79 ms with 128, 256 buffers 2.15 -> 2.08 with 64)
     if (segmented || !searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, wgc, true, d_sel, sel_pitch);
