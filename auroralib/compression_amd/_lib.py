@@ -7,6 +7,15 @@ from . import _abi as A
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libauroralz.so")
 _lib = None
+# Set when this process first makes a call that initialises HIP (alz_create, alz_device_count ...).  From then on nothing here starts a compiler: on the GPU pool a process that has
+# touched the GPU must not fork + exec (the lazy builders of synth.py and tests/oracle_lib.py check this and ask for `__graft_entry__.build()` instead).
+GPU_TOUCHED = False
+
+
+def refuse_build_after_gpu(what):
+    if GPU_TOUCHED:
+        raise RuntimeError("%s is missing or older than its source, and this process has already initialised the GPU: build first "
+                           "(python -c 'import __graft_entry__ as g; g.build()'), a compiler is not started from here" % what)
 
 
 class AlzError(RuntimeError):

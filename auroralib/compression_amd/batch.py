@@ -4,6 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi as A
+from . import _lib as _libmod
 from ._lib import check, load
 
 
@@ -17,6 +18,7 @@ def _vp(a):
 
 def device_count():
     """alz_device_count: HIP devices visible to this process (0 without a GPU)."""
+    _libmod.GPU_TOUCHED = True
     return int(load().alz_device_count())
 
 
@@ -26,6 +28,7 @@ class Context:
     def __init__(self, device=0):
         self.lib = load()
         h = C.c_void_p()
+        _libmod.GPU_TOUCHED = True
         check(self.lib.alz_create(device, C.byref(h)))
         self.h = h
         self.device = device

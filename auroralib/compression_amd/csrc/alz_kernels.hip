@@ -261,20 +261,20 @@ __global__ __launch_bounds__(64 * ALZ_WPB) ALZ_FAST_ATTR void alz_decode_fast_ke
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same decode as a WORK QUEUE of chunks (round 5).  With one wavefront per stream a batch of more streams than the GPU holds
+// The same decode as a WORK QUEUE of chunks (round 5; tickets, epochs and the in-order repair: round 6).  With one wavefront per stream a batch of more streams than the GPU holds
 // wavefronts ends in a partly filled round: 10 000 streams on 6 400 places = one full round and 3 600 streams at 14 waves per CU, where a
 // wave is bound by its own issue rate -- 833 GiB/s for one batch against 1 004 with a second batch filling the tail.  Here a stream is
-// decoded in CHUNKS of ALZ_CHUNK_BYTES of output and the launch is a queue of (stream, chunk) items in chunk-major order, one workgroup
-// each, dispatched in that order: every place stays busy until the queue is empty, and what is left at the end is one chunk's
+// decoded in CHUNKS of ALZ_CHUNK_BYTES of output and the launch is a queue of (stream, chunk) items -- eight sub-queues, chunk-major inside each --, one workgroup
+// per item, each drawing its item as a ticket when it starts (queue_ticket): every place stays busy until the queue is empty, and what is left at the end is one chunk's
 // latency, not one stream's.  A chunk ends at the first iteration boundary at or behind its limit (the lane-parallel loop consumes whole
 // flag groups: the state between two iterations is the input offset -- three of them for Yay0 / MIO0 -- and the output position); the wave
-// that decoded it flushes its output, hands the LDS window and that state to whoever pops the stream's next chunk -- through a slot of its own
-// in global memory, written with write-through (sc1) stores, drained, then ONE flag (MI355X_MICROARCH.md, inter-workgroup visibility; the
+// that decoded it flushes its output, hands the LDS window and that state to whoever holds the stream's next chunk -- through a slot of its own
+// in global memory, written with write-through (sc1) stores, drained, then ONE flag carrying the launch's epoch (MI355X_MICROARCH.md, inter-workgroup visibility; the
 // slot is written once per launch, so no L2 can hold an older copy of it) -- and ends.  The workgroup of the next chunk
-// polls that flag (relaxed, one lane, bounded), acquires once, loads the window.  Workgroups start in index order, so the chunk a wave waits
-// for is in the hands of a wave that has started and waits, if at all, for a still earlier item.  The stream's last chunk runs the exact parser over the tail and writes the result; a stream that ends early (an error, a
-// terminator, E5) marks its remaining boundaries "ended" as their items come up.  A bounded spin that runs out sets `tmo`; the host then
-// repeats the launch with the one-wavefront-per-stream kernel (alz_plan_results).
+// polls that flag (relaxed, one lane, bounded), acquires once, loads the window.  Tickets of a sub-queue go out in order to workgroups that have started, so the chunk an item waits
+// for is in the hands of a running workgroup that waits, if at all, for a still earlier item.  The stream's last chunk runs the exact parser over the tail and writes the result; a stream that ends early (an error, a
+// terminator, E5) marks its remaining boundaries "ended" as their items come up.  A bounded spin that runs out (a fault: never seen) sets the plan's sticky word `tmo`; the gated
+// launch the host enqueues behind this kernel then decodes the format's streams again with one wavefront per stream, in stream order (alz_plan_execute).
 #define ALZ_CHUNK_BYTES ALZ_CHUNK_OUT     /* (alz_internal.h: the host cuts the streams by the same number) */
 #ifndef ALZ_CHUNK_SPINS
 #define ALZ_CHUNK_SPINS (1u << 20)    /* x (sleep + one load): about a second.  (-DALZ_CHUNK_SPINS=0: every wait that is not over at once runs out -- the test of the repeat path, tools/variants/README.md) */

@@ -19,6 +19,8 @@ _lib = None
 def build_synth(force=False):
     inc = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include")
     if force or not os.path.exists(_SO) or (os.path.exists(_SRC) and os.path.getmtime(_SO) < os.path.getmtime(_SRC)):
+        from . import _lib as _libmod
+        _libmod.refuse_build_after_gpu(_SO)
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-I", inc, "-o", _SO, _SRC, "-lpthread", "-lm"])
     return _SO
 

@@ -126,7 +126,20 @@ TRAFFIC_SOURCE = "profiles/traffic.json (rocprofv3 --pmc passes of this exact wo
 
 
 # The instruction-issue ceilings of one CU, measured (tools/ubench_issue.hip, profiles/r05_issue_ceiling.md): wave64 instructions per cycle per CU
-ISSUE_CEILING = {"valu_fast": 1.75, "valu_slow": 0.95, "salu": 0.95, "lds_cycles_per_inst": 4.3, "clock_hz": 2.4e9, "cus": 256}
+ISSUE_CEILING = {"valu_fast": 1.75, "valu_slow": 0.95, "salu": 0.95, "lds_cycles_per_inst": 4.3, "clock_hz": 2.4e9, "cus": 256}     # (clock / CUs: an MI355X; main() takes them from the device it runs on)
+
+
+def set_device_shape(torch, device_index):
+    """CU count and shader clock of the device the bench runs on, for `roofline.issue` (the per-CU ceilings themselves were measured on an MI355X)."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        if getattr(p, "multi_processor_count", 0):
+            ISSUE_CEILING["cus"] = int(p.multi_processor_count)
+        khz = getattr(p, "clock_rate", 0)
+        if khz:
+            ISSUE_CEILING["clock_hz"] = float(khz) * 1e3
+    except Exception:
+        pass
 
 
 def issue_object(key, kernel_ms):
@@ -363,6 +376,7 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
     red_dev = "cuda" if (dist is not None and args.dist_backend == "nccl") else None
+    set_device_shape(torch, local_rank)
 
     target = args.stream_kib * 1024
     if args.mode == "encode":

@@ -14,6 +14,8 @@ _SO = os.environ.get("ALZ_ORACLE_SO") or os.path.join(_ROOT, "oracle", "liboracl
 def _load():
     src = os.path.join(_ROOT, "oracle", "alz_oracle.c")
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        from auroralib.compression_amd import _lib as _libmod        # (a process that has initialised the GPU must not start a compiler: __graft_entry__.build() first)
+        _libmod.refuse_build_after_gpu(_SO)
         subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle"), os.path.basename(_SO)], stdout=subprocess.DEVNULL)
     lib = C.CDLL(_SO)
     lib.oracle_xxh64.restype = C.c_uint64

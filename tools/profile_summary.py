@@ -51,18 +51,26 @@ def main():
         rs = [r for r in rows(d, "counter_collection.csv") if "alz_" in r["Kernel_Name"] and r["Counter_Name"] == label]
         if not rs:
             continue
-        vals = [float(r["Counter_Value"]) for r in rs]
-        avg = sum(vals) / len(vals)
+        # a launch may be several kernels (a work-queue launch has its gated repair kernel behind it, a mixed batch one kernel per format): per kernel the mean over
+        # its dispatches, per launch their sum
+        import collections
+        per = collections.OrderedDict()
+        for r in rs:
+            per.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+        avg = sum(sum(v) / len(v) for v in per.values())
         lines += ["", "## %s (separate `--pmc %s` pass)" % (label, label), "",
-                  "dispatches of alz_* kernels: %d; mean raw counter = %.1f KiB; corrected bytes per launch = %.0f (x%.0f, gfx950 rule)" % (len(vals), avg, avg * 1024 * mult, mult)]
+                  "dispatches of alz_* kernels: %d (%d kernels per launch); mean raw counter per launch = %.1f KiB; corrected bytes per launch = %.0f (x%.0f, gfx950 rule)" % (len(rs), len(per), avg, avg * 1024 * mult, mult)]
     if a.pmc:
         import collections
         acc = collections.OrderedDict()
+        perk = collections.OrderedDict()
         for d in a.pmc:
             for r in rows(d, "counter_collection.csv"):
                 if "alz_" in r["Kernel_Name"]:
-                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-        lines += ["", "## PMC counters (separate `--pmc` passes, mean per dispatch of the alz_* kernel)", "", "| counter | mean |", "|---|---|"]
+                    perk.setdefault(r["Counter_Name"], collections.OrderedDict()).setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+        for k, kk in perk.items():
+            acc[k] = [sum(sum(v) / len(v) for v in kk.values())]          # per launch: the kernels' means added up
+        lines += ["", "## PMC counters (separate `--pmc` passes, mean per LAUNCH: the alz_* kernels of a launch added up)", "", "| counter | mean |", "|---|---|"]
         for k, v in acc.items():
             lines.append("| %s | %.4g |" % (k, sum(v) / len(v)))
         g = acc.get("GRBM_GUI_ACTIVE"); va = acc.get("SQ_ACTIVE_INST_VALU"); vi = acc.get("SQ_INSTS_VALU")
