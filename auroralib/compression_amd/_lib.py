@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libauroralz.so")
 _lib = None
 # Set when this process first makes a call that initialises HIP (alz_create, alz_device_count ...).  From then on nothing here starts a compiler: on the GPU pool a process that has
-# touched the GPU must not fork + exec (the lazy builders of synth.py and tests/oracle_lib.py check this and ask for `__graft_entry__.build()` instead).
+# touched the GPU must not fork + exec (the lazy builders -- synth.py here, the checker library of the tests -- ask this and tell the caller to run `__graft_entry__.build()` instead).
 GPU_TOUCHED = False
 
 
