@@ -115,5 +115,21 @@ def test_issue_object_prices_counts_against_the_measured_ceilings():
     assert abs(iss["valu"][0] - c["valu"] / cyc / 1.75) < 2e-3 and abs(iss["valu"][1] - c["valu"] / cyc / 0.95) < 2e-3
     assert abs(iss["lds"] - c["lds"] / cyc * 4.3) < 2e-3
     assert r["issue_frac"] == iss["issue_frac"] and 0.3 < r["issue_frac"] < 1.2
-    assert iss["counts_from"].startswith("profiles/r05_")
+    assert iss["counts_from"].startswith("profiles/r0")
     assert "issue" not in bench.roofline(1e9, 1.0, None, "no_such_workload:1:1") and "issue" not in bench.roofline(1e9, 1.0)
+
+
+def test_committed_counters_belong_to_the_kernels_at_head():
+    """profiles/traffic.json and profiles/insts.json carry a hash of the kernel sources they were measured on (tools/kernel_hash.py, written by tools/update_counters.py on the
+    checkout the counters came from): at HEAD it equals the tree's, so `roofline.counters_stale` of the bench line is false -- a kernel change without a re-profile turns this red."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("alz_kernel_hash", os.path.join(ROOT, "tools", "kernel_hash.py"))
+    kh = importlib.util.module_from_spec(spec); spec.loader.exec_module(kh)
+    cur = kh.current()
+    for name in ("traffic.json", "insts.json"):
+        assert kh.recorded(name).get("decode") == cur["decode"], (name, kh.recorded(name), cur)
+    bench._STALE.clear()
+    r = bench.roofline(2978822689, 2.5, bench.measured_traffic("yaz0", 10000, 256), "yaz0:10000:256")
+    assert r["counters_stale"] is False and r["traffic"] is not None and "issue" in r
+    line = json.loads(bench.contract_line({"metric": "m", "value": 1.0, "unit": "u", "roofline": r, "config": {"workload": "w"}}))
+    assert line["roofline"]["counters_stale"] is False

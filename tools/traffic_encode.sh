@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 for q in 0 8 15; do
   for c in FETCH_SIZE WRITE_SIZE; do
     D=gpurun_out/traffic_enc_q${q}_$c; rm -rf $D; mkdir -p $D
-    rocprofv3 --pmc $c --output-format csv -d $D -- python3 tools/bench_encode.py --quality $q --reps 1 > $D/log.txt 2>&1
+    timeout 600 rocprofv3 --pmc $c --output-format csv -d $D -- python3 tools/bench_encode.py --quality $q --reps 1 > $D/log.txt 2>&1
   done
   python3 - $q <<'PY'
 import csv,glob,sys,collections
