@@ -174,3 +174,35 @@ def test_forced_scan_capacity_one_byte_short_with_canary(test_bmp):
                     assert res[i].status == A.ST_OK and res[i].dst_len == len(want[i])
                     expect[streams[i].dst_off:streams[i].dst_off + len(want[i])] = np.frombuffer(want[i], dtype=np.uint8)
             assert np.array_equal(buf, expect), A.FORMAT_NAMES[fmt]
+
+
+@pytest.mark.parametrize("fmt", FAM)
+def test_forced_scan_fuzz(fmt, test_bmp):
+    """Random inputs under ALZ_FUZZ_SEED (tools/soak.sh repeats this under other seeds): token soup, slices of Test.bmp with noise spliced in, runs with a defect, at a random quality 2..9
+    (LZ4 blocks / raw Snappy: up to 10), forced through the scan path -- bytes, lengths and section offsets the oracle's."""
+    import os
+    seed = int(os.environ.get("ALZ_FUZZ_SEED", "1234")) * 43 + fmt
+    rng = np.random.default_rng(seed)
+    raws = []
+    for _ in range(24):
+        kind = int(rng.integers(0, 4))
+        n = int(rng.integers(1, 90000))
+        if kind == 0:
+            raws.append(_token_soup(rng, n))
+        elif kind == 1:
+            a = int(rng.integers(0, len(test_bmp) - n))
+            b = bytearray(test_bmp[a:a + n])
+            for _k in range(int(rng.integers(0, 6))):
+                p = int(rng.integers(0, n)); m = int(rng.integers(1, 200))
+                b[p:p + m] = rng.integers(0, 256, len(b[p:p + m]), dtype=np.uint8).tobytes()
+            raws.append(bytes(b))
+        elif kind == 2:
+            b = bytearray([int(rng.integers(0, 256))] * n)
+            for _k in range(int(rng.integers(0, 4))):
+                b[int(rng.integers(0, n))] ^= 0x55
+            raws.append(bytes(b))
+        else:
+            unit = rng.integers(0, 256, int(rng.integers(1, 5000)), dtype=np.uint8).tobytes()
+            raws.append((unit * (n // len(unit) + 1))[:n])
+    q = int(rng.integers(2, 11 if fmt in (A.FMT_LZ4_BLOCK, A.FMT_SNAPPY_RAW) else 10))
+    _check(fmt, raws, q, expect_taken=lambda t: t == len(raws))
