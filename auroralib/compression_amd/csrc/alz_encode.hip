@@ -3963,7 +3963,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (scan_ok && !seqf) { const hipError_t es = launch_scan(nullptr); if (es != hipSuccess) return es; }
     AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
     if (d_seg != nullptr && seg_len != 0u && tail == 0) {
-        size_t ab = 0; u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;
+        size_t ab = 0; u32 hist = seg_table_hist(g);
         if (alz_encode_aseg(geom, count, max_len, &aseg.SA, &aseg.ka, &aseg.W, &aseg.stride, &ab))
             aseg.mem = (u8*)d_seg + ((alz_encode_seg_bytes(count, seg_kmax, hist) + 255u) & ~(size_t)255u);
     }
@@ -4025,8 +4025,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     switch (fmt) {
     case ALZ_FMT_LZSS: ALZ_SEG(ALZ_FMT_LZSS) launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ10: ALZ_SEG(ALZ_FMT_LZ10) launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ11: launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ40: launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ11: ALZ_SEG(ALZ_FMT_LZ11) launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ40: ALZ_SEG(ALZ_FMT_LZ40) launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAZ0: ALZ_SEG(ALZ_FMT_YAZ0) launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAY0: ALZ_SEG(ALZ_FMT_YAY0) launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_MIO0: ALZ_SEG(ALZ_FMT_MIO0) launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;

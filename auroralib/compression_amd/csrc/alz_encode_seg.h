@@ -21,6 +21,11 @@
 // Same bytes as enc_parse_emit_kernel by construction: the same per-window arithmetic (LZSS.cs:132-160, LZ10.cs:113-137, Yaz0 / Yay0 / MIO0 ...
 // through flag_payload), the same order.  Formats whose longest match fits 63 windows (not LZ11 / LZ40: 16 KiB); raw Snappy and PRS: alz_encode_seg_seq.h.
 
+// The longest jump the walk's tables have to hold: a match entry kernel B wrote is shorter than its compare cap (ALZ_LEN_CAP, what the segmented path runs it with) or CAPPED, and a
+// capped entry makes its stretch of the buffer the serial walker's -- so for LZ11 / LZ40, whose matches reach 16 KiB (round 6), the exit tables and the ring are those of a 2 040-byte
+// format, and only enc_sync_kernel looks back the full 16 KiB (a capped position that far in front may jump over the boundary).
+static inline u32 seg_table_hist(const EncGeom& g) { const u32 jl = g.max_len > ALZ_LEN_CAP ? (u32)ALZ_LEN_CAP : (u32)g.max_len; return (jl + 2u + 63u) & ~63u; }
+
 struct SegRec { u32 tok, pay, unc, head, tailbits, tailofs, fail, pad; };     // counts (C) -> exclusive prefix (P); the flag bits of straddling groups (E)
 
 template <int FMT, bool EMIT>
@@ -54,13 +59,17 @@ __global__ __launch_bounds__(64) void enc_seg_kernel(const u8* __restrict__ src_
     // the end of the last match that starts in front of the segment: a match further back than maxLength cannot reach it
     u32 cover = 0;
     if (k) {
-        const int w = (int)(S >> 6) - 1 - lane;
-        u32 endv = 0;
-        if (w >= 0 && (u32)lane * 64u < (u32)g.max_len + 64u) {
-            const u64 mw = mask[w];
-            if (mw) { const u32 q = (u32)w * 64u + 63u - (u32)__builtin_clzll(mw); endv = q + m_unpack(m[q]).y; }
+        // (64 windows per round: one round for the formats up to 2 040 bytes, five for LZ11 / LZ40; a taken match of 2 046 bytes or more has its length in the NEXT entry)
+        for (u32 r0 = 0; r0 * 64u < (u32)g.max_len + 64u; r0 += 64u) {
+            const int w = (int)(S >> 6) - 1 - (int)r0 - lane;
+            u32 endv = 0;
+            if (w >= 0 && (r0 + (u32)lane) * 64u < (u32)g.max_len + 64u) {
+                const u64 mw = mask[w];
+                if (mw) { const u32 q = (u32)w * 64u + 63u - (u32)__builtin_clzll(mw); u32 ml = m_unpack(m[q]).y; if (ml == ALZ_M_LONG) ml = m[q + 1]; endv = q + ml; }
+            }
+            const u32 cv = (u32)__builtin_amdgcn_readlane((int)scan_max(endv), 63);
+            if (cv > cover) cover = cv;
         }
-        cover = (u32)__builtin_amdgcn_readlane((int)scan_max(endv), 63);
     }
     u32 tok_base = 0, pay_base = 0, unc_base = 0, nflags = 0, pay_total = 0;
     if (EMIT) {
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(64) void enc_seg_kernel(const u8* __restrict__ src_
         const bool start = ((sm >> lane) & 1ull) && p < n;
         uint2 mt = make_uint2(0, 0);
         if (start) mt = a;
+        if (FMT == ALZ_FMT_LZ11 || FMT == ALZ_FMT_LZ40) { if (start && mt.y == ALZ_M_LONG) mt.y = m[p + 1]; }     // (a taken match of 2 046 bytes or more: the walk left its length in the next entry)
         const u32 mend = start ? p + mt.y : 0u;
         const u32 pmax = scan_max(mend);
         u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)pmax, 0x138, 0xF, 0xF, false);   // wave_shr:1 -> max over lanes below
@@ -235,15 +245,19 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 // tests, tools/mid_batch_encode.py) -- never more than one launch of encode_core takes (65 535 buffers: the scratch is laid out for the launch's own count)
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t max_streams, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
-    const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 ||
+    const bool long11 = fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40;                                                                                          // (matches of up to 16 KiB: round 6, seg_table_hist)
+    const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || long11 ||
                      fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
     const u32 rule = g.max_chain == 1 ? 1280u : g.max_chain < 64 ? 1536u : 512u;
-    const u32 most = max_streams == 0xFFFFFFFFu ? rule : (max_streams < 65535u ? max_streams : 65535u);
-    if (!fam || g.max_len > 2040 || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
+    // (LZ11 / LZ40: enc_sync_kernel looks back 16 KiB per boundary and the stretches with capped entries stay serial -- 64 KiB windows of Test.bmp, ms per call, one wavefront per
+    // buffer -> segments: 16 buffers 1.83 / 2.13 -> 0.42 / 0.44 at quality 0 / 8, 64: 1.84 / 2.57 -> 0.75 / 1.07, 256: 1.92 / 3.16 -> 1.57 / 2.78, 1 024: 2.71 / 5.19 -> 4.26 / 8.67)
+    const u32 rule2 = (long11 && rule > 256u) ? 256u : rule;
+    const u32 most = max_streams == 0xFFFFFFFFu ? rule2 : (max_streams < 65535u ? max_streams : 65535u);
+    if (!fam || (g.max_len > 2040 && !long11) || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
     uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
     if (want < 1024u) want = 1024u;
     u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
-    const u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;                  // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
+    const u32 hist = seg_table_hist(g);                                    // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
     if (sl < hist) sl = hist;
     while ((max_len + sl - 1u) / sl > 8192u) sl += 64u;                     // (enc_compose_kernel holds a buffer's boundaries in LDS; never reached: a launch aims at 8 192 segments in all)
     if (hist_out) *hist_out = hist;
@@ -309,7 +323,7 @@ namespace {
 // the parse of a launch on this path: synchronisation points, exits, the cursor that enters every segment, the walk -- the start mask is complete behind it
 static void launch_seg_walk(hipStream_t s, u32 count, const u8* src, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
                             const int* prev4, const int* prevm, u64* mask, u32* sync, u32 seglen, u32 kmax, const EncGeom& g) {
-    const u32 hist = ((u32)g.max_len + 2u + 63u) & ~63u;
+    const u32 hist = seg_table_hist(g);
     u32* direct = sync + (size_t)count * kmax;
     u32* entry = direct + (size_t)count * kmax;
     u32* ftab = entry + (size_t)count * kmax;

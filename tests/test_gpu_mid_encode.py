@@ -13,7 +13,8 @@ from auroralib.compression_amd.batch import Context
 from test_gpu_big_encode import _encode, _mixed
 
 pytestmark = pytest.mark.gpu
-FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE]
+FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE,
+          A.FMT_LZ11, A.FMT_LZ40]        # (round 6: matches of up to 16 KiB -- a capped match entry hands its stretch of the buffer to the serial walker)
 OFF = 0xFFFFFFFF
 G = 4096
 
@@ -56,12 +57,13 @@ def test_ragged_batch(fmt, quality, test_bmp):
         _both_ways(c, items, quality, "ragged")
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_LZ11, A.FMT_LZ40])
 def test_segment_lengths(fmt, test_bmp):
     """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 700 x 24 KiB
     2 112; windows of Test.bmp 4 KiB apart."""
     with Context(0) as c:
-        for n, size in ((300, 65536), (700, 24000), (64, 262144 + 77)):
+        long11 = fmt in (A.FMT_LZ11, A.FMT_LZ40)                   # (their batches take the path up to 256 buffers)
+        for n, size in (((200, 65536), (250, 24000), (64, 262144 + 77)) if long11 else ((300, 65536), (700, 24000), (64, 262144 + 77))):
             items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - size):][:size - (i % 7)]) for i in range(n)]
             _both_ways(c, items, 0, "%d x %d" % (n, size))
         items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - 65536):][:65536]) for i in range(256)]
@@ -178,13 +180,13 @@ def test_fuzz_path_on_against_path_off(fmt, test_bmp):
             for i in range(n):
                 assert got[0][i] == got[1][i], (seed, trial, i, A.FORMAT_NAMES[fmt], q, len(raws[i]), caps[i], got[0][i][:5], got[1][i][:5])
             i = int(np.argmax([len(r) for r in raws]))
-            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE):
+            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE):
                 sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE)
                 back, dr = c.decode(fmt, got[0][i][5], decom_len=len(raws[i]) if sized else 0, cap=len(raws[i]), aux0=got[0][i][3], aux1=got[0][i][4])
                 assert dr.status == 0 and back == raws[i], (seed, trial, i)
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW, A.FMT_MIO0])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW, A.FMT_MIO0, A.FMT_LZ11, A.FMT_LZ40])
 def test_a_few_large_buffers(fmt, test_bmp):
     """Four buffers of 1-5 MB (the whole-GPU path off): more than a thousand segments per buffer, kernel A over segments of its own length, exit tables
     chained across hundreds of boundaries."""
