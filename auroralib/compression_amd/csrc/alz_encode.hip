@@ -3609,6 +3609,12 @@ __global__ __launch_bounds__(64) void enc_probe_kernel(const u8* __restrict__ sr
 #define ALZ_SCAN_MAX_PER_KIB 72     /* searches per KiB, a search that looks at ONE block of 1 024 positions counting 1 (4 + blocks quarters: the formats with 32 / 64 KiB windows look at up to 32 / 64) */
                                     /* 10 000 windows of 256 KiB of Test.bmp as Yaz0 at quality 8, ms per call: 40 -> 117.2, 56 -> 111.0, 72 -> 109.6 (262 without the path; counted in plain searches: 20 -> 126.9, 40 -> 109.5, 80 -> 112.1, 120 -> 159.6) */
 #endif
+#ifndef ALZ_SCAN_MIN_STREAMS
+#define ALZ_SCAN_MIN_STREAMS 2048u  /* a scan stream costs its own LATENCY (a flat 256 KiB window ~30 ms, a 64 KiB one ~4), hidden only behind a launch whose other streams keep the GPU busy that
+                                       long.  Windows of 256 KiB of Test.bmp as LZ4 blocks at quality 8 / 5, ms per call without -> with the path: 128 buffers 11.5 / 8.1 -> 23.9 / 27.7, 512: 22.2 / 13.8 ->
+                                       33.8 / 31.2, 1 024: 36.4 / 21.8 -> 38.7 / 35.8, 10 000: 294 / 158 -> 144 / 109 (tools/scan_on_off.py with N=...); 64 KiB windows cross at ~256 buffers.  Below this
+                                       many buffers of a format in a call: not taken. */
+#endif
 #ifndef ALZ_SCAN_MIN_LEN
 #define ALZ_SCAN_MIN_LEN 16384     /* shorter buffers: whichever (the regular way) */
 #endif
@@ -3935,7 +3941,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
                           fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON;
     const bool scan_ok = scan_mode != 2 && scan_fam && d_sel != nullptr && !(d_seg != nullptr && seg_len != 0u) && g.nprops <= 1 && !g.use_min_table && g.max_chain >= 3 &&
                          g.max_chain <= 32 /* (a block's candidates are measured at once, two lanes each at least) */ && (seqf || g.max_dist <= 8192) && g.link16 && !searches_in_the_parse(fmt, g) &&
-                         (scan_mode == 1 || g.max_len >= 64);  /* (matches of at most 18 bytes -- LZ10, MIO0, the default LZSS -- keep kernel B's compares short and every stream above the probe's
+                         (scan_mode == 1 || (g.max_len >= 64 && count >= ALZ_SCAN_MIN_STREAMS));  /* (matches of at most 18 bytes -- LZ10, MIO0, the default LZSS -- keep kernel B's compares short and every stream above the probe's
                                                                   line: 10 000 windows of Test.bmp at quality 8 as LZ10 86.7 ms without the path, 95.0 with it; LZSS 86.5 / 106.1.  Forced: the parity tests.) */
     // (`links`: kernel A's, for the formats whose search follows them behind the nearest blocks -- their select + scan kernels are launched behind kernel A, which then runs for every stream)
     auto launch_scan = [&](const int* links) -> hipError_t {

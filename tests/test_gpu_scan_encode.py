@@ -124,19 +124,21 @@ def test_forced_scan_settings(test_bmp):
 
 
 def test_probe_chooses_per_stream_and_off_is_off(test_bmp):
-    """Mode 0 on 48 windows of 64 KiB from all over Test.bmp (photographic at the top, flat further down): the probe sends some streams each way; mode 2 none; bytes the oracle's."""
-    raws = [test_bmp[i * 20000:i * 20000 + 65536] for i in range(48)]
-    for fmt, q in ((A.FMT_YAZ0, 8), (A.FMT_LZ11, 8), (A.FMT_YAY0, 5), (A.FMT_LZ4_BLOCK, 8)):
+    """Mode 0 on 2 100 windows of 32 KiB from all over Test.bmp (photographic at the top, flat further down; the path is only taken from 2 048 buffers of a format on: a scan stream costs its
+    own latency, which only a launch that keeps the GPU busy hides): the probe sends some streams each way; mode 2 none; a small batch none; bytes the oracle's."""
+    raws = [test_bmp[(i * 457) % (len(test_bmp) - 32768):][:32768] for i in range(2100)]
+    for fmt, q in ((A.FMT_YAZ0, 8), (A.FMT_LZ11, 5), (A.FMT_LZ4_BLOCK, 8)):
         _check(fmt, raws, q, mode=0, expect_taken=lambda t: 0 < t < len(raws))
-        _check(fmt, raws, q, mode=2, expect_taken=lambda t: t == 0)
+    _check(A.FMT_YAZ0, raws, 8, mode=2, expect_taken=lambda t: t == 0)
+    _check(A.FMT_YAZ0, raws[:1000], 8, mode=0, expect_taken=lambda t: t == 0)
     # (formats whose matches end at 18 bytes are not sent that way unless forced: kernel B is fast on them)
     _check(A.FMT_LZ10, raws, 8, mode=0, expect_taken=lambda t: t == 0)
-    _check(A.FMT_MIO0, raws, 8, mode=0, expect_taken=lambda t: t == 0)
     # qualities / formats the path does not cover go the regular way even when forced
-    _check(A.FMT_YAZ0, raws[:6], 12, mode=1, expect_taken=lambda t: t == 0)
-    _check(A.FMT_YAZ0, raws[:6], 0, mode=1, expect_taken=lambda t: t == 0)
-    _check(A.FMT_LZ4_BLOCK, raws[:6], 11, mode=1, expect_taken=lambda t: t == 0)       # (maxChain 64: more candidates than the lanes measure at once)
-    _check(A.FMT_LZ4_BLOCK, raws[:6] + [bytes(70000) + b"x" + bytes(30000)], 10, mode=1, expect_taken=lambda t: t == 7)   # (maxChain 32: the most the path takes)
+    small = [test_bmp[i * 20000:i * 20000 + 65536] for i in range(6)]
+    _check(A.FMT_YAZ0, small, 12, mode=1, expect_taken=lambda t: t == 0)
+    _check(A.FMT_YAZ0, small, 0, mode=1, expect_taken=lambda t: t == 0)
+    _check(A.FMT_LZ4_BLOCK, small, 11, mode=1, expect_taken=lambda t: t == 0)       # (maxChain 64: more candidates than the lanes measure at once)
+    _check(A.FMT_LZ4_BLOCK, small + [bytes(70000) + b"x" + bytes(30000)], 10, mode=1, expect_taken=lambda t: t == 7)   # (maxChain 32: the most the path takes)
 
 
 def test_forced_scan_capacity_one_byte_short_with_canary(test_bmp):
