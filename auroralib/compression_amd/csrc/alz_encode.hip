@@ -2745,6 +2745,41 @@ template <> struct SeqFmt<ALZ_FMT_SNAPPY_RAW> {
         else { q[0] = (u8)((2u | ((M - 1u) << 2)) & 0xFFu); q[1] = (u8)(D & 0xFFu); q[2] = (u8)((D >> 8) & 0xFFu); }
     }
 };
+__device__ __forceinline__ u32 lzo_extn(u32 v) { return 1u + (v - 1u) / 255u; }                       // bytes of LZO.WriteExtendedInt(v), v >= 1
+__device__ __forceinline__ u32 lzo_put_ext(u8* q, u32 v) { u32 k = 0; while (v > 255u) { q[k++] = 0; v -= 255u; } q[k++] = (u8)v; return k; }
+__device__ __forceinline__ u32 lzo_lit_size(u32 L) { return L > 18u ? 1u + lzo_extn(L - 18u) : 1u; }  // the run's length token (L >= 4)
+__device__ __forceinline__ u32 lzo_put_lit(u8* q, u32 L) { if (L > 18u) { q[0] = 0; return 1u + lzo_put_ext(q + 1, L - 18u); } q[0] = (u8)(L - 3u); return 1u; }
+__device__ __forceinline__ u32 lzo_match_size(u32 D, u32 M) {
+    if (M <= 8u && D <= 2048u) return 2u;
+    if (D <= 16384u) return (M > 33u ? 1u + lzo_extn(M - 33u) : 1u) + 2u;
+    return (M > 9u ? 1u + lzo_extn(M - 9u) : 1u) + 2u;
+}
+__device__ __forceinline__ u32 lzo_put_match(u8* q, u32 D, u32 M, u32 emb) {                          // emb: the 0-3 literals that follow, in the token's low bits
+    if (M <= 8u && D <= 2048u) {
+        const u32 flag = (emb | (((D - 1u) & 7u) << 2)) & 0xFFu;
+        q[0] = (u8)(M <= 4u ? (flag | 0x40u | ((M - 3u) << 5)) : (flag | 0x80u | ((M - 5u) << 5)));
+        q[1] = (u8)((D - 1u) >> 3);
+        return 2u;
+    }
+    u32 k;
+    if (D <= 16384u) {
+        if (M > 33u) { q[0] = 0x20; k = 1u + lzo_put_ext(q + 1, M - 33u); } else { q[0] = (u8)(0x20u | (M - 2u)); k = 1u; }
+        q[k] = (u8)((emb | ((D - 1u) << 2)) & 0xFFu); q[k + 1] = (u8)(((D - 1u) >> 6) & 0xFFu);
+        return k + 2u;
+    }
+    const u32 d2 = D - 0x4000u, flag = (0x10u | ((d2 & 0x4000u) >> 11)) & 0xFFu;
+    if (M > 9u) { q[0] = (u8)flag; k = 1u + lzo_put_ext(q + 1, M - 9u); } else { q[0] = (u8)(flag | (M - 2u)); k = 1u; }
+    q[k] = (u8)((emb | (d2 << 2)) & 0xFFu); q[k + 1] = (u8)((d2 >> 6) & 0xFFu);
+    return k + 2u;
+}
+// LZO over segments (alz_encode_seg_seq.h, round 6): a unit -- the literal run in front of a match (four and more: a run with its own length token; 0-3: bare, counted in the
+// token of the match in front) and the match's token -- as a sequence of enc_seq_seg_kernel; `emb`: the count of the 0-3 literals BEHIND the match, in its token's low bits
+template <> struct SeqFmt<ALZ_FMT_LZO> {
+    static __device__ __forceinline__ u32 lit_hdr(u32 L) { return L >= 4u ? lzo_lit_size(L) : 0u; }
+    static __device__ __forceinline__ u32 match_size(u32 D, u32 M) { return lzo_match_size(D, M); }
+    static __device__ __forceinline__ void put_lit_hdr(u8* q, u32 L, u32, bool) { if (L >= 4u) (void)lzo_put_lit(q, L); }
+    static __device__ __forceinline__ void put_match(u8* q, u32 D, u32 M, u32 emb = 0u) { (void)lzo_put_match(q, D, M, emb); }
+};
 #ifndef ALZ_SEQ_PARSE_CAP
 #define ALZ_SEQ_PARSE_CAP 32   /* bytes the search inside WinParse compares per position for certain (what the look-ahead holds in registers) ... */
 #endif
@@ -3275,33 +3310,7 @@ __global__ __launch_bounds__(64) void enc_emit_prs_kernel(const u8* __restrict__
 // reference's way until the first match is out, and from there every match start is one unit -- the 0-3 literals in front of it, or a
 // literal run of >= 4, then its token in one of three forms -- whose size follows from its own numbers: a prefix sum places the units, the
 // wavefront copies the long runs.  The count of the 0-3 literals behind a match sits in ITS token: that byte is written by the next unit.
-__device__ __forceinline__ u32 lzo_extn(u32 v) { return 1u + (v - 1u) / 255u; }                       // bytes of LZO.WriteExtendedInt(v), v >= 1
-__device__ __forceinline__ u32 lzo_put_ext(u8* q, u32 v) { u32 k = 0; while (v > 255u) { q[k++] = 0; v -= 255u; } q[k++] = (u8)v; return k; }
-__device__ __forceinline__ u32 lzo_lit_size(u32 L) { return L > 18u ? 1u + lzo_extn(L - 18u) : 1u; }  // the run's length token (L >= 4)
-__device__ __forceinline__ u32 lzo_put_lit(u8* q, u32 L) { if (L > 18u) { q[0] = 0; return 1u + lzo_put_ext(q + 1, L - 18u); } q[0] = (u8)(L - 3u); return 1u; }
-__device__ __forceinline__ u32 lzo_match_size(u32 D, u32 M) {
-    if (M <= 8u && D <= 2048u) return 2u;
-    if (D <= 16384u) return (M > 33u ? 1u + lzo_extn(M - 33u) : 1u) + 2u;
-    return (M > 9u ? 1u + lzo_extn(M - 9u) : 1u) + 2u;
-}
-__device__ __forceinline__ u32 lzo_put_match(u8* q, u32 D, u32 M, u32 emb) {                          // emb: the 0-3 literals that follow, in the token's low bits
-    if (M <= 8u && D <= 2048u) {
-        const u32 flag = (emb | (((D - 1u) & 7u) << 2)) & 0xFFu;
-        q[0] = (u8)(M <= 4u ? (flag | 0x40u | ((M - 3u) << 5)) : (flag | 0x80u | ((M - 5u) << 5)));
-        q[1] = (u8)((D - 1u) >> 3);
-        return 2u;
-    }
-    u32 k;
-    if (D <= 16384u) {
-        if (M > 33u) { q[0] = 0x20; k = 1u + lzo_put_ext(q + 1, M - 33u); } else { q[0] = (u8)(0x20u | (M - 2u)); k = 1u; }
-        q[k] = (u8)((emb | ((D - 1u) << 2)) & 0xFFu); q[k + 1] = (u8)(((D - 1u) >> 6) & 0xFFu);
-        return k + 2u;
-    }
-    const u32 d2 = D - 0x4000u, flag = (0x10u | ((d2 & 0x4000u) >> 11)) & 0xFFu;
-    if (M > 9u) { q[0] = (u8)flag; k = 1u + lzo_put_ext(q + 1, M - 9u); } else { q[0] = (u8)(flag | (M - 2u)); k = 1u; }
-    q[k] = (u8)((emb | (d2 << 2)) & 0xFFu); q[k + 1] = (u8)((d2 >> 6) & 0xFFu);
-    return k + 2u;
-}
+// (lzo_extn .. lzo_put_match: in front of SeqFmt<ALZ_FMT_LZO>, above)
 #ifndef ALZ_LZO_LANE_LIT
 #define ALZ_LZO_LANE_LIT 4u
 #endif
@@ -3929,7 +3938,9 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     EncGeom g; memcpy(&g, geom, sizeof(g));
     // (the segmented path of a small batch, alz_encode_seg.h: no cap -- its longest match is at most 2 040 bytes, kernel B has the GPU to itself, and
     // every capped position the roles walk stands on costs that ONE wavefront two exact searches: 16 x 64 KiB of Test.bmp as Yaz0 at quality 8 1.17 ms of walk)
-    g.b_cap = (d_seg != nullptr && seg_len != 0u) ? ALZ_LEN_CAP : choose_b_cap(g);
+    // (LZ4 blocks and LZO keep the cap: their segments are walked all at once -- alz_encode_seg_seq.h, enc_spec_walk_kernel --, so the exact searches of capped cursors run side by side,
+    // while no cap means every position of a flat stretch compared over 2 040 bytes: 256 x 64 KiB of Test.bmp at quality 8, kernel B 1.70 ms of the call's 3.37)
+    g.b_cap = (d_seg != nullptr && seg_len != 0u && fmt != ALZ_FMT_LZ4_BLOCK && fmt != ALZ_FMT_LZO) ? ALZ_LEN_CAP : choose_b_cap(g);
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
     const int tail = fmt == ALZ_FMT_LZ4_BLOCK ? 5 : 0;
     // ---- the streams whose parse visits few positions go without kernels A and B (enc_scan_select_kernel; scan_mode 0: the probe decides, 1: every stream, 2: none).
@@ -3969,7 +3980,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (scan_ok && !seqf) { const hipError_t es = launch_scan(nullptr); if (es != hipSuccess) return es; }
     AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
     if (d_seg != nullptr && seg_len != 0u && tail == 0) {
-        size_t ab = 0; u32 hist = seg_table_hist(g);
+        size_t ab = 0; const u32 hist = (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO) ? 1u + (seg_len >> 5) : seg_table_hist(g);      // (as alz_encode_segmented sized the records)
         if (alz_encode_aseg(geom, count, max_len, &aseg.SA, &aseg.ka, &aseg.W, &aseg.stride, &ab))
             aseg.mem = (u8*)d_seg + ((alz_encode_seg_bytes(count, seg_kmax, hist) + 255u) & ~(size_t)255u);
     }
@@ -4051,10 +4062,12 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         else hipLaunchKernelGGL((enc_emit_prs_kernel<false, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }
     case ALZ_FMT_LZ4_BLOCK: {
+        if (segmented) { launch_emit_seg_spec<ALZ_FMT_LZ4_BLOCK>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         else hipLaunchKernelGGL((enc_parse_seq_kernel<ALZ_FMT_LZ4_BLOCK, false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_prev4, d_prevm, d_results, d_aux, g);
         break; }
     case ALZ_FMT_LZO: {
+        if (segmented) { launch_emit_seg_spec<ALZ_FMT_LZO>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
         if (searches_in_the_parse(fmt, g)) hipLaunchKernelGGL((enc_parse_lzo_kernel<true>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         else hipLaunchKernelGGL((enc_parse_lzo_kernel<false>), dim3(count), dim3(64), 0, stream, src, dst, d_streams, d_index, count, m, d_pos_off, d_results, d_aux, d_prev4, d_prevm, g);
         break; }

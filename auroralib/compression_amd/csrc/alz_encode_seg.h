@@ -245,21 +245,32 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 // tests, tools/mid_batch_encode.py) -- never more than one launch of encode_core takes (65 535 buffers: the scratch is laid out for the launch's own count)
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t max_streams, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
+    // LZ4 blocks, LZO (round 6): no synchronisation points -- every segment walked speculatively, the true walk strung together behind (alz_encode_seg_seq.h: enc_spec_walk_kernel)
+    const bool spec4 = fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO;
     const bool long11 = fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40;                                                                                          // (matches of up to 16 KiB: round 6, seg_table_hist)
-    const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || long11 ||
+    const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || long11 || spec4 ||
                      fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
     const u32 rule = g.max_chain == 1 ? 1280u : g.max_chain < 64 ? 1536u : 512u;
     // (LZ11 / LZ40: enc_sync_kernel looks back 16 KiB per boundary and the stretches with capped entries stay serial -- 64 KiB windows of Test.bmp, ms per call, one wavefront per
     // buffer -> segments: 16 buffers 1.83 / 2.13 -> 0.42 / 0.44 at quality 0 / 8, 64: 1.84 / 2.57 -> 0.75 / 1.07, 256: 1.92 / 3.16 -> 1.57 / 2.78, 1 024: 2.71 / 5.19 -> 4.26 / 8.67)
-    const u32 rule2 = (long11 && rule > 256u) ? 256u : rule;
+    // (LZ4 blocks, 64 KiB windows of Test.bmp 4 KiB apart, ms per call without / with the path -- quality 8: 16 buffers 1.74 / 0.42, 64 2.62 / 1.06, 256 3.43 / 2.22, 512 4.95 / 3.94,
+    // 1 024 8.04 / 7.59; quality 0 at 256: 1.90 / 0.82; quality 12: 19.8 / 5.2, quality 15: 66.5 / 20.4; 1 500 x 16 KiB at quality 8: 2.71 / 2.93 -- up to 1 024 buffers)
+    const u32 rule2 = (long11 && rule > 256u) ? 256u : (spec4 && rule > 1024u) ? 1024u : rule;
     const u32 most = max_streams == 0xFFFFFFFFu ? rule2 : (max_streams < 65535u ? max_streams : 65535u);
-    if (!fam || (g.max_len > 2040 && !long11) || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
+    if (!fam || (g.max_len > 2040 && !long11 && !spec4) || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
     uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
     if (want < 1024u) want = 1024u;
     u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
-    const u32 hist = seg_table_hist(g);                                    // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
+    u32 hist = seg_table_hist(g);                                          // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
+    if (spec4) {
+        // (a segment's masks live in LDS -- at most 8 192 positions --, and its record is SpecRec + the cursor mask: `hist` words behind three -- alz_encode_seg_bytes)
+        if (sl > 8192u) sl = 8192u;
+        if ((max_len + sl - 1u) / sl > 8192u) return 0;
+        hist = 1u + (sl >> 5);
+    } else {
     if (sl < hist) sl = hist;
     while ((max_len + sl - 1u) / sl > 8192u) sl += 64u;                     // (enc_compose_kernel holds a buffer's boundaries in LDS; never reached: a launch aims at 8 192 segments in all)
+    }
     if (hist_out) *hist_out = hist;
     if (seg_len) *seg_len = sl;
     if (kmax) *kmax = (max_len + sl - 1u) / sl;

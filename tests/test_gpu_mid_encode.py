@@ -14,7 +14,8 @@ from test_gpu_big_encode import _encode, _mixed
 
 pytestmark = pytest.mark.gpu
 FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE,
-          A.FMT_LZ11, A.FMT_LZ40]        # (round 6: matches of up to 16 KiB -- a capped match entry hands its stretch of the buffer to the serial walker)
+          A.FMT_LZ11, A.FMT_LZ40,        # (round 6: matches of up to 16 KiB -- a capped match entry hands its stretch of the buffer to the serial walker)
+          A.FMT_LZ4_BLOCK, A.FMT_LZO]    # (round 6: every segment walked speculatively, the true walk strung together behind -- alz_encode_seg_seq.h)
 OFF = 0xFFFFFFFF
 G = 4096
 
@@ -52,12 +53,14 @@ def test_ragged_batch(fmt, quality, test_bmp):
     length (1 024 here) more or less, one buffer long enough for the path to be taken -- of bitmap rows, runs, noise and prose-like bytes."""
     sizes = [0, 1, 3, 4, 5, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 1024 + 63, 2047, 2048, 2049, 3071, 3072, 4095, 4096, 4097, 8191, 8192, 8193,
              10000, 12288, 12288 + 1, 16384 - 3, 20000, 33333, 40000, 50001, 65536, 70000, 9, 300, 5000, 70001]
+    if fmt == A.FMT_LZ4_BLOCK:
+        sizes = [s for s in sizes if s >= 5]                       # (a block ends in five literals: the reference cannot write a shorter one -- tests/test_gpu_encode.py has that case)
     items = [(fmt, _mixed(s, 1000 + s, test_bmp) if s else b"") for s in sizes]
     with Context(0) as c:
         _both_ways(c, items, quality, "ragged")
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_LZ11, A.FMT_LZ40])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_LZ10, A.FMT_YAY0, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_LZ11, A.FMT_LZ40, A.FMT_LZ4_BLOCK, A.FMT_LZO])
 def test_segment_lengths(fmt, test_bmp):
     """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 700 x 24 KiB
     2 112; windows of Test.bmp 4 KiB apart."""
@@ -82,6 +85,30 @@ def test_degenerate_buffers(fmt):
     with Context(0) as c:
         for q in (0, 8, 15):
             _both_ways(c, [(fmt, r) for r in raws], q, "degenerate")
+
+
+@pytest.mark.parametrize("fmt", [A.FMT_LZ4_BLOCK, A.FMT_LZO, A.FMT_LZ11, A.FMT_LZ40, A.FMT_SNAPPY_RAW])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_long_runs_across_segments(fmt, seed):
+    """Runs of one to six thousand equal bytes (or of a short period) with a little noise between them: matches longer than a segment, longer than kernel B's
+    compare cap and than the 2 046 bytes a match entry can hold, starting and ending anywhere relative to the segment boundaries -- the walk that enters a
+    segment stands inside, on or just behind what the walk of the segment in front searched exactly."""
+    rng = np.random.default_rng(900 + seed)
+    raws = []
+    for b in range(24):
+        parts, total = [], 0
+        while total < 30000 + 2000 * b:
+            kind = int(rng.integers(0, 4))
+            ln = int(rng.integers(1, 6000))
+            if kind == 0: part = bytes([int(rng.integers(0, 256))]) * ln
+            elif kind == 1: part = (bytes(rng.integers(0, 256, int(rng.integers(2, 9)), dtype=np.uint8)) * ln)[:ln]
+            elif kind == 2: part = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+            else: part = b"".join(parts)[-ln:] if parts else b"x"          # (a copy of what lies right in front)
+            parts.append(part); total += len(part)
+        raws.append(b"".join(parts))
+    with Context(0) as c:
+        for q in (0, 6, 8, 11):
+            _both_ways(c, [(fmt, r) for r in raws], q, "long runs, seed %d, quality %d" % (seed, q))
 
 
 def test_settings_and_mixed_formats(test_bmp):
@@ -180,13 +207,13 @@ def test_fuzz_path_on_against_path_off(fmt, test_bmp):
             for i in range(n):
                 assert got[0][i] == got[1][i], (seed, trial, i, A.FORMAT_NAMES[fmt], q, len(raws[i]), caps[i], got[0][i][:5], got[1][i][:5])
             i = int(np.argmax([len(r) for r in raws]))
-            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE):
-                sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE)
+            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK, A.FMT_LZO):
+                sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK, A.FMT_LZO)
                 back, dr = c.decode(fmt, got[0][i][5], decom_len=len(raws[i]) if sized else 0, cap=len(raws[i]), aux0=got[0][i][3], aux1=got[0][i][4])
                 assert dr.status == 0 and back == raws[i], (seed, trial, i)
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW, A.FMT_MIO0, A.FMT_LZ11, A.FMT_LZ40])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_PRS_BE, A.FMT_SNAPPY_RAW, A.FMT_MIO0, A.FMT_LZ11, A.FMT_LZ40, A.FMT_LZ4_BLOCK, A.FMT_LZO])
 def test_a_few_large_buffers(fmt, test_bmp):
     """Four buffers of 1-5 MB (the whole-GPU path off): more than a thousand segments per buffer, kernel A over segments of its own length, exit tables
     chained across hundreds of boundaries."""

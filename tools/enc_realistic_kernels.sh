@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/enc_realistic_kernels.sh fmt quality [n] [size] -- per-kernel times of ONE device-resident encode call over n (10 000) windows of size (262144) bytes of Test.bmp
-# (bench.py's realistic_compress_<fmt>_q<Q> workload; rocprofv3 --kernel-trace --stats)
+# (bench.py's realistic_compress_<fmt>_q<Q> workload; rocprofv3 --kernel-trace --stats; ALZ_SEG=0: without the segmented parse + emit of a small batch)
 cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export TMPDIR=/tmp
 N=${3:-10000}; SZ=${4:-262144}
@@ -11,6 +11,7 @@ from auroralib.compression_amd import _abi as A, synth, formats as F
 from auroralib.compression_amd.batch import Context
 fmt = A.FORMAT_NAMES.index("$1"); n, size = $N, $SZ
 ctx = Context(0)
+if os.environ.get("ALZ_SEG") is not None: ctx.lib.alz_debug_seg_max_streams(ctx.h, int(os.environ["ALZ_SEG"]))      # (0: the segmented parse + emit off)
 lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
 bmp = np.frombuffer(lz.Decompress(open("tests/golden/Test.lz", "rb").read()), dtype=np.uint8)
 starts = [(i * (len(bmp) - size)) // max(n - 1, 1) for i in range(n)]
