@@ -659,6 +659,22 @@ __device__ __forceinline__ void benc_wave_search(const u8* data, int n, const En
     }
 }
 
+// The exact matches FindNextBestMatch needs at a cursor q one of whose two entries is capped (:157-212): q's own -- searched only if ITS entry is the capped one (c0) -- and the lazy
+// neighbour's, which the finder looks at only behind a match no longer than the lazy threshold (:180-190).  A capped entry is a match of the compare cap or more, far above that
+// threshold: until round 6 both positions were searched whatever the first one found, and on flat data -- where the cursor lands on capped positions all the time, each search tens
+// of KiB of compares -- half of the exact searches were for a neighbour nobody asked about.  e0 / e1: the two entries as the caller holds them (wave-uniform); s0 / s1: searched here.
+template <bool MINT>
+__device__ __forceinline__ void benc_capped_cursor(const u8* data, int n, const EncGeom& g, const int* p4, const int* pm, int q, int limit, uint2 e0, bool c0, uint2 e1, bool c1,
+                                                   int& d0, int& l0, int& d1, int& l1, bool& s0, bool& s1) {
+    s0 = c0;
+    if (s0) benc_wave_search<MINT>(data, n, g, p4, pm, q, d0, l0); else { d0 = (int)e0.x; l0 = (int)e0.y; }
+    d1 = 0; l1 = 0; s1 = false;
+    if (l0 >= g.min_len && l0 <= g.lazy && q + 1 <= limit) {
+        s1 = c1;
+        if (s1) benc_wave_search<MINT>(data, n, g, p4, pm, q + 1, d1, l1); else { d1 = (int)e1.x; l1 = (int)e1.y; }
+    }
+}
+
 // MatchSearch (:214-246, ChainMatches :248-282) exactly, by the whole wavefront, WITHOUT links (round 6): prev() chains are the positions below `pos` with pos's hash, nearest first,
 // and the walk ends at the first one further back than maxDistance (:259-260) -- so the candidates are exactly the positions of [pos - maxDistance, pos) whose four bytes hash
 // like pos's (ComputeHash :288-299: the top hashBits bits of one product), in descending order, at most maxChain of them.  The wavefront finds them by SCANNING the window
@@ -1990,10 +2006,11 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
             if (__builtin_amdgcn_readlane((int)capped, rel)) {
                 // kernel B capped a candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour
                 const int q = P + rel;
-                int d0, l0, d1 = 0, l1 = 0;
+                int d0, l0, d1 = 0, l1 = 0; bool s0, s1;
                 // (by the whole wavefront, 4 KiB per trip: as a plain loop on every lane a match of a few hundred bytes took ~10 us per cursor)
-                if (g.use_min_table) benc_wave_search<true>(data, n, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, n, g, p4, pm, q, d0, l0);
-                if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, n, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, n, g, p4, pm, q + 1, d1, l1); }
+                const uint2 e0 = m_unpack(tile[q - tbase]), e1 = m_unpack(tile[q + 1 - tbase]);
+                if (g.use_min_table) benc_capped_cursor<true>(data, n, g, p4, pm, q, limit, e0, e0.y == ALZ_CAPPED, e1, e1.y == ALZ_CAPPED, d0, l0, d1, l1, s0, s1);
+                else benc_capped_cursor<false>(data, n, g, p4, pm, q, limit, e0, e0.y == ALZ_CAPPED, e1, e1.y == ALZ_CAPPED, d0, l0, d1, l1, s0, s1);
                 j = 1; sr = 0;
                 if (l0 >= g.min_len) {
                     const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
@@ -2005,14 +2022,15 @@ __global__ __launch_bounds__(64) void enc_roles_kernel(const u8* __restrict__ sr
                 // at again, q + 1's is if the walk goes there next, and stays "capped" (recomputed then) when it is too long for an entry.
                 // (the tile in LDS gets the lazy neighbour's entry too: the walk may stand on it next.  The tile on its way in `pf` may still hold
                 // kernel B's entry for it -- exact or "capped", in which case it is searched again: the same result)
+                // (only what was searched here: an entry that was exact stays -- and the neighbour is searched only behind a match of the lazy threshold or less, never a long one)
                 if (lane == 0) {
-                    if (sr == 1 && l0 >= (int)ALZ_M_LONG) { m[q] = m_pack((u32)d0, ALZ_M_LONG); m[q + 1] = (u32)l0; }
-                    else {
-                        m[q] = m_pack((u32)d0, l0 < (int)ALZ_M_LONG ? (u32)l0 : ALZ_M_LONG - 1u);
-                        if (q + 1 <= limit) {
-                            if (l1 < (int)ALZ_M_LONG) { m[q + 1] = m_pack((u32)d1, (u32)l1); tile[q + 1 - tbase] = m_pack((u32)d1, (u32)l1); }
-                            else if (sr == 2) { m[q + 1] = m_pack((u32)d1, ALZ_M_LONG); m[q + 2] = (u32)l1; }
-                        }
+                    if (s0) {
+                        if (sr == 1 && l0 >= (int)ALZ_M_LONG) { m[q] = m_pack((u32)d0, ALZ_M_LONG); m[q + 1] = (u32)l0; }
+                        else m[q] = m_pack((u32)d0, l0 < (int)ALZ_M_LONG ? (u32)l0 : ALZ_M_LONG - 1u);
+                    }
+                    if (s1) {
+                        if (l1 < (int)ALZ_M_LONG) { m[q + 1] = m_pack((u32)d1, (u32)l1); tile[q + 1 - tbase] = m_pack((u32)d1, (u32)l1); }
+                        else if (sr == 2) { m[q + 1] = m_pack((u32)d1, ALZ_M_LONG); m[q + 2] = (u32)l1; }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -2298,11 +2316,14 @@ __global__ __launch_bounds__(64) void enc_parse_emit_kernel(const u8* __restrict
                     // kernel B capped a candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour, and put both
                     // into the registers the emitter takes its matches from (the neighbour may be the next window's first position)
                     const int q = (int)P + rel;
-                    int d0, l0, d1 = 0, l1 = 0;
-                    if (g.use_min_table) benc_wave_search<true>(data, (int)n, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, (int)n, g, p4, pm, q, d0, l0);
-                    if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, (int)n, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, (int)n, g, p4, pm, q + 1, d1, l1); }
-                    if (lane == rel) a = make_uint2((u32)d0, (u32)l0);
-                    if (q + 1 <= limit) {
+                    int d0, l0, d1 = 0, l1 = 0; bool s0, s1;
+                    const uint2 e0 = make_uint2((u32)__builtin_amdgcn_readlane((int)a.x, rel), (u32)__builtin_amdgcn_readlane((int)a.y, rel));
+                    const uint2 e1 = rel + 1 < 64 ? make_uint2((u32)__builtin_amdgcn_readlane((int)a.x, (rel + 1) & 63), (u32)__builtin_amdgcn_readlane((int)a.y, (rel + 1) & 63))
+                                                  : make_uint2((u32)__builtin_amdgcn_readlane((int)a_n.x, 0), (u32)__builtin_amdgcn_readlane((int)a_n.y, 0));
+                    if (g.use_min_table) benc_capped_cursor<true>(data, (int)n, g, p4, pm, q, limit, e0, e0.y == ALZ_CAPPED, e1, e1.y == ALZ_CAPPED, d0, l0, d1, l1, s0, s1);
+                    else benc_capped_cursor<false>(data, (int)n, g, p4, pm, q, limit, e0, e0.y == ALZ_CAPPED, e1, e1.y == ALZ_CAPPED, d0, l0, d1, l1, s0, s1);
+                    if (s0 && lane == rel) a = make_uint2((u32)d0, (u32)l0);
+                    if (s1) {
                         if (rel + 1 < 64) { if (lane == rel + 1) a = make_uint2((u32)d1, (u32)l1); }
                         else if (lane == 0) a_n = make_uint2((u32)d1, (u32)l1);
                     }
@@ -2939,11 +2960,14 @@ struct WinParse {
                     // a capped candidate here: redo MatchSearch exactly for this cursor and its lazy neighbour, and put both into the
                     // registers the sequences take their matches from (the neighbour may be the next window's first position)
                     const int q = (int)P + rel;
-                    int d0, l0, d1 = 0, l1 = 0;
-                    if (g.use_min_table) benc_wave_search<true>(data, ns, g, p4, pm, q, d0, l0); else benc_wave_search<false>(data, ns, g, p4, pm, q, d0, l0);
-                    if (q + 1 <= limit) { if (g.use_min_table) benc_wave_search<true>(data, ns, g, p4, pm, q + 1, d1, l1); else benc_wave_search<false>(data, ns, g, p4, pm, q + 1, d1, l1); }
-                    if (lane == rel) a = make_uint2((u32)d0, (u32)l0);
-                    if (q + 1 <= limit) {
+                    int d0, l0, d1 = 0, l1 = 0; bool s0, s1;
+                    const uint2 e0 = make_uint2((u32)__builtin_amdgcn_readlane((int)a.x, rel), (u32)__builtin_amdgcn_readlane((int)a.y, rel));
+                    const uint2 e1 = rel + 1 < 64 ? make_uint2((u32)__builtin_amdgcn_readlane((int)a.x, (rel + 1) & 63), (u32)__builtin_amdgcn_readlane((int)a.y, (rel + 1) & 63))
+                                                  : make_uint2((u32)__builtin_amdgcn_readlane((int)a_n.x, 0), (u32)__builtin_amdgcn_readlane((int)a_n.y, 0));
+                    if (g.use_min_table) benc_capped_cursor<true>(data, ns, g, p4, pm, q, limit, e0, e0.y == ALZ_CAPPED, e1, e1.y == ALZ_CAPPED, d0, l0, d1, l1, s0, s1);
+                    else benc_capped_cursor<false>(data, ns, g, p4, pm, q, limit, e0, e0.y == ALZ_CAPPED, e1, e1.y == ALZ_CAPPED, d0, l0, d1, l1, s0, s1);
+                    if (s0 && lane == rel) a = make_uint2((u32)d0, (u32)l0);
+                    if (s1) {
                         if (rel + 1 < 64) { if (lane == rel + 1) a = make_uint2((u32)d1, (u32)l1); }
                         else if (lane == 0) a_n = make_uint2((u32)d1, (u32)l1);
                     }
@@ -3980,7 +4004,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     if (scan_ok && !seqf) { const hipError_t es = launch_scan(nullptr); if (es != hipSuccess) return es; }
     AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
     if (d_seg != nullptr && seg_len != 0u && tail == 0) {
-        size_t ab = 0; const u32 hist = (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO) ? 1u + (seg_len >> 5) : seg_table_hist(g);      // (as alz_encode_segmented sized the records)
+        size_t ab = 0; const u32 hist = seg_rec_hist(fmt, g, seg_len);      // (as alz_encode_segmented sized the records)
         if (alz_encode_aseg(geom, count, max_len, &aseg.SA, &aseg.ka, &aseg.W, &aseg.stride, &ab))
             aseg.mem = (u8*)d_seg + ((alz_encode_seg_bytes(count, seg_kmax, hist) + 255u) & ~(size_t)255u);
     }

@@ -243,6 +243,11 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 
 // max_streams: 0xFFFFFFFF: the rule above; 0: the path is off; anything else: that many buffers instead of the rule (a context's debug override, alz_debug_seg_max_streams:
 // tests, tools/mid_batch_encode.py) -- never more than one launch of encode_core takes (65 535 buffers: the scratch is laid out for the launch's own count)
+// the words a segment's record holds behind its three fixed ones (alz_encode_seg_bytes): the exit table of the longest jump -- or, for the formats of the speculative walk
+// (LZ4 blocks, LZO: alz_encode_seg_seq.h), SpecRec and the segment's cursor mask.  ONE function for the host's sizing and the launch's layout.
+static inline u32 seg_rec_hist(int fmt, const EncGeom& g, u32 seg_len) {
+    return (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO) ? 1u + (seg_len >> 5) : seg_table_hist(g);
+}
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t max_streams, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     // LZ4 blocks, LZO (round 6): no synchronisation points -- every segment walked speculatively, the true walk strung together behind (alz_encode_seg_seq.h: enc_spec_walk_kernel)
@@ -266,7 +271,7 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
         // (a segment's masks live in LDS -- at most 8 192 positions --, and its record is SpecRec + the cursor mask: `hist` words behind three -- alz_encode_seg_bytes)
         if (sl > 8192u) sl = 8192u;
         if ((max_len + sl - 1u) / sl > 8192u) return 0;
-        hist = 1u + (sl >> 5);
+        hist = seg_rec_hist(fmt, g, sl);
     } else {
     if (sl < hist) sl = hist;
     while ((max_len + sl - 1u) / sl > 8192u) sl += 64u;                     // (enc_compose_kernel holds a buffer's boundaries in LDS; never reached: a launch aims at 8 192 segments in all)

@@ -255,9 +255,10 @@ __device__ __forceinline__ int spec_walk(const u8* data, int ns, int limit, cons
             int j, sr;
             if (__builtin_amdgcn_readlane((int)capped, rel)) {
                 const int q = P + rel;
-                int d0, l0, d1 = 0, l1 = 0;
-                benc_wave_search<MINT>(data, ns, g, p4, pm, q, d0, l0);
-                if (q + 1 <= limit) benc_wave_search<MINT>(data, ns, g, p4, pm, q + 1, d1, l1);
+                int d0, l0, d1 = 0, l1 = 0; bool s0, s1;
+                const uint2 e0 = make_uint2((u32)__builtin_amdgcn_readlane((int)a.x, rel), (u32)__builtin_amdgcn_readlane((int)a.y, rel));
+                const uint2 e1 = make_uint2((u32)__builtin_amdgcn_readlane((int)b.x, rel), (u32)__builtin_amdgcn_readlane((int)b.y, rel));
+                benc_capped_cursor<MINT>(data, ns, g, p4, pm, q, limit, e0, e0.y >= ALZ_M_LONG, e1, e1.y >= ALZ_M_LONG, d0, l0, d1, l1, s0, s1);
                 j = 1; sr = 0;
                 if (l0 >= g.min_len) {
                     const bool lazyc = l0 <= g.lazy && q + 1 <= limit;
@@ -266,8 +267,8 @@ __device__ __forceinline__ int spec_walk(const u8* data, int ns, int limit, cons
                 }
                 // the exact matches go into the array -- what MatchSearch returns for q and q + 1, whoever asks -- a length of 2 046 or more as its code only
                 if (lane == 0) {
-                    m[q] = m_pack((u32)d0, l0 < (int)ALZ_M_LONG ? (u32)l0 : ALZ_M_LONG);
-                    if (q + 1 <= limit) m[q + 1] = m_pack((u32)d1, l1 < (int)ALZ_M_LONG ? (u32)l1 : ALZ_M_LONG);
+                    if (s0) m[q] = m_pack((u32)d0, l0 < (int)ALZ_M_LONG ? (u32)l0 : ALZ_M_LONG);
+                    if (s1) m[q + 1] = m_pack((u32)d1, l1 < (int)ALZ_M_LONG ? (u32)l1 : ALZ_M_LONG);
                 }
             } else { j = __builtin_amdgcn_readlane(jump, rel); sr = __builtin_amdgcn_readlane(startrel, rel); }
             if (sr == 1) sb |= 1ull << rel;

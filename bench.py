@@ -853,7 +853,8 @@ def run_configs(args, ctx, np, A, synth, Plan, Context):
             for f in ("yaz0", "lz4_block"):
                 out.append(realistic_compress(ctx, np, A, synth, f, 8, with_cpu=not args.no_cpu_baseline))
             # ... and batches of FEW buffers (16 / 256 windows of 64 KiB): parse and emitter over segments, csrc/alz_encode_seg.h
-            for f, q, nb in (("yaz0", 8, 256), ("yaz0", 8, 16), ("yaz0", 0, 256), ("snappy_raw", 0, 256)):
+            # (LZ4 blocks, LZO: round 6, the speculative walk per segment of csrc/alz_encode_seg_seq.h)
+            for f, q, nb in (("yaz0", 8, 256), ("yaz0", 8, 16), ("yaz0", 0, 256), ("snappy_raw", 0, 256), ("lz4_block", 8, 256), ("lzo", 8, 256)):
                 out.append(realistic_compress(ctx, np, A, synth, f, q, with_cpu=not args.no_cpu_baseline, n=nb, size=65536, prefix="mid_compress"))
         if "single" in want:
             out.extend(single_stream(ctx, np, A, synth, Plan))
