@@ -100,7 +100,7 @@ class Context:
         dst = C.create_string_buffer(max(cap, 1))
         r = A.Result()
         check(self.lib.alz_decode(self.h, fmt, C.byref(lz) if lz is not None else None, src, len(src), decom_len, aux0, aux1, dst, cap, C.byref(r)))
-        return dst.raw[:r.dst_len], r
+        return C.string_at(dst, r.dst_len), r
 
     # ---- host-buffer encode
     def encode_batch(self, streams, src, dst_bytes, quality=8, lz=None, strategy=0, min_distance=0, max_window_bits=0):

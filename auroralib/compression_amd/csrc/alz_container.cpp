@@ -8,6 +8,7 @@
 // (INTEGRATION.md); hosts without the managed library use these entry points instead.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -342,11 +343,22 @@ int lz4_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* d
 
 // Compresses `n` bytes as independent blocks of `block` bytes in ONE GPU batch; block i's compressed bytes land at
 // tmp + i * slot.  (LZ4: a new LzChainMatchFinder per block, LZ4.cs:205; Snappy: matchFinder.Reset() per chunk, :86)
-int encode_blocks(alz_ctx* ctx, uint32_t fmt, const alz_settings* st, const uint8_t* src, size_t n, size_t block, std::vector<uint8_t>& tmp, size_t& slot,
+// (the slots of the compressed blocks: memory nobody has touched -- a std::vector would write nb * slot zeros first, 21 MB for 16 MB of 64 KiB blocks, and only the compressed
+// bytes are ever written and read)
+struct BlockSlots {
+    uint8_t* p = nullptr; size_t n = 0;
+    BlockSlots() {}
+    BlockSlots(const BlockSlots&) = delete; BlockSlots& operator=(const BlockSlots&) = delete;
+    ~BlockSlots() { free(p); }
+    bool resize(size_t bytes) { free(p); p = (uint8_t*)malloc(bytes ? bytes : 1); n = p ? bytes : 0; return p != nullptr; }
+    uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+};
+int encode_blocks(alz_ctx* ctx, uint32_t fmt, const alz_settings* st, const uint8_t* src, size_t n, size_t block, BlockSlots& tmp, size_t& slot,
                   std::vector<alz_result>& rs) {
     const size_t nb = (n + block - 1) / block;
     slot = (block + block / 4 + 64 + 255) & ~(size_t)255;
-    tmp.resize(nb * slot + 64);
+    if (!tmp.resize(nb * slot + 64)) return ALZ_E_NOMEM;
     std::vector<alz_stream> ss(nb); rs.resize(nb);
     for (size_t i = 0; i < nb; i++) {
         memset(&ss[i], 0, sizeof(alz_stream));
@@ -369,7 +381,7 @@ int lz4_file_compress(alz_ctx* ctx, bool legacy, uint32_t block_size, const alz_
         wr32(dst, 0x184D2204u, false); dst[4] = 0x40; dst[5] = bdb; dst[6] = (uint8_t)((xxh32(dst + 4, 2, 0) >> 8) & 0xFF); o = 7;
     }
     if (n && n % block_size != 0 && n % block_size < 5) return ALZ_E_INVALID;            // source.Slice(0, Length - 5) throws  LZ4.cs:208
-    std::vector<uint8_t> tmp; std::vector<alz_result> rs; size_t slot = 0;
+    BlockSlots tmp; std::vector<alz_result> rs; size_t slot = 0;
     int rc = encode_blocks(ctx, ALZ_FMT_LZ4_BLOCK, st, src, n, block_size, tmp, slot, rs);
     if (rc != ALZ_OK) return rc;
     for (size_t i = 0; i < rs.size(); i++) {
@@ -453,7 +465,7 @@ int snappy_file_compress(alz_ctx* ctx, const alz_settings* st, const uint8_t* sr
     if (cap < 10) return ALZ_E_NOMEM;
     memcpy(dst, kSnappyId, 10);
     size_t o = 10;
-    std::vector<uint8_t> tmp; std::vector<alz_result> rs; size_t slot = 0;
+    BlockSlots tmp; std::vector<alz_result> rs; size_t slot = 0;
     int rc = encode_blocks(ctx, ALZ_FMT_SNAPPY_RAW, st, src, n, 0x10000, tmp, slot, rs);
     if (rc != ALZ_OK) return rc;
     for (size_t i = 0; i < rs.size(); i++) {
@@ -1046,7 +1058,7 @@ int alz_container_compress(alz_ctx* ctx, uint32_t container, const alz_container
         wr32(dst + 4, (uint32_t)type | ((uint32_t)n << 8), false);
         std::vector<alz_stream> stv(segs); std::vector<alz_result> rs(segs);
         const size_t slot = chunk + chunk / 4 + 64;
-        std::vector<uint8_t> tmp(segs * slot);
+        BlockSlots tmp; if (!tmp.resize(segs * slot)) return ALZ_E_NOMEM;
         alz_settings st2; if (settings) st2 = *settings; else { st2.quality = 8; st2.max_window_bits = 0; st2.strategy = 0; }
         st2.min_distance = 2;                                                                // new LZ10(): GbaVramCompatibilityMode = true
         for (size_t i = 0; i < segs; i++) {

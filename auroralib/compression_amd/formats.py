@@ -140,7 +140,7 @@ class _Format:
             raise ValueError("bad token")
         check(rc)
         self.last_src_used = su.value
-        return dst.raw[:dl.value]
+        return C.string_at(dst, dl.value)             # (dst.raw would copy the whole capacity first)
 
     def Compress(self, data, settings=None):
         data = bytes(data)
@@ -155,7 +155,7 @@ class _Format:
         dl = C.c_size_t()
         lib.alz_container_compress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         check(lib.alz_container_compress(_context().h, self.container, C.byref(o), C.byref(st), data, len(data), dst, cap, C.byref(dl)))
-        return dst.raw[:dl.value]
+        return C.string_at(dst, dl.value)             # (dst.raw would copy the whole capacity first)
 
 
 class LZSS(_Format):

@@ -1,5 +1,6 @@
 """usage (GPU box): python tools/framed_compress_time.py  -- what a FRAMED container's Compress costs end to end (host buffers in, container bytes out, wall clock): raw Snappy chunks of 64 KiB
-behind the framing format (Snappy.cs:86: a new finder per chunk) are a batch of tens to hundreds of buffers -- the segmented encode of csrc/alz_encode_seg.h -- with the path on and off."""
+behind the framing format (Snappy.cs:86: a new finder per chunk) are a batch of tens to hundreds of buffers -- the segmented encode of csrc/alz_encode_seg.h -- with the path on and off.
+Round 6: the LZ4 frame writer too (LZ4.Frame.cs:107-174: blocks of 64 KiB - 4 MiB, each compressed on its own), whose blocks take the speculative walk per segment of csrc/alz_encode_seg_seq.h."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -7,18 +8,37 @@ from auroralib.compression_amd import _abi as A, formats as F
 from auroralib.compression_amd._lib import load
 lib = load()
 bmp = F.LZSS(A.LzProperties.from_bits(10, 6, 2)).Decompress(open(os.path.join(ROOT, "tests", "golden", "Test.lz"), "rb").read())
+import statistics
+ctx = F._context()
+
+
+def measure(make, data, s, check):
+    """Path off / on in turns (the host side of a call -- page faults of fresh buffers, the allocator's state -- moves by milliseconds from call to call: eleven calls each, minimum and
+    median of the wall clock, and the kernels' own time, which is what the path changes)."""
+    rows = {0: ([], []), 0xFFFFFFFF: ([], [])}
+    size = None
+    for seg in (0, 0xFFFFFFFF):
+        lib.alz_debug_seg_max_streams(ctx.h, seg)
+        out = make().Compress(data, s)
+        assert check(out) == data
+        assert size is None or size == len(out)
+        size = len(out)
+    for _ in range(11):
+        for seg in (0, 0xFFFFFFFF):
+            lib.alz_debug_seg_max_streams(ctx.h, seg)
+            f = make()
+            t0 = time.perf_counter(); out = f.Compress(data, s); rows[seg][0].append((time.perf_counter() - t0) * 1e3); rows[seg][1].append(ctx.last_kernel_ms())
+    lib.alz_debug_seg_max_streams(ctx.h, 0xFFFFFFFF)
+    a, b = rows[0], rows[0xFFFFFFFF]
+    return "wall min / median %6.2f / %6.2f -> %6.2f / %6.2f ms, kernels %5.2f -> %5.2f ms (%d bytes either way)" % (
+        min(a[0]), statistics.median(a[0]), min(b[0]), statistics.median(b[0]), statistics.median(a[1]), statistics.median(b[1]), size)
+
+
+print("one wavefront per block -> segments")
 for name, data in (("Test.bmp (1 MB, 16 chunks)", bmp), ("16 x Test.bmp (16 MB, 245 chunks)", bmp * 16)):
     for s, sname in ((F.CompressionSettings.Fastest, "Fastest"), (F.CompressionSettings.Balanced, "Balanced")):
-        row = []
-        for seg in (0, 0xFFFFFFFF):
-            lib.alz_debug_seg_max_streams(F._context().h, seg)
-            f = F.Snappy()
-            out = f.Compress(data, s)
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter(); out = f.Compress(data, s); ts.append((time.perf_counter() - t0) * 1e3)
-            assert F.Snappy().Decompress(out) == data
-            row.append((min(ts), len(out)))
-        assert row[0][1] == row[1][1]
-        print("Snappy framing, %-34s %-8s: %7.2f ms one wavefront per chunk -> %7.2f ms segments (%.0f -> %.0f MB/s of raw input; %d bytes either way)" %
-              (name, sname, row[0][0], row[1][0], len(data) / row[0][0] / 1e3, len(data) / row[1][0] / 1e3, row[0][1]), flush=True)
+        print("Snappy framing, %-34s %-8s: %s" % (name, sname, measure(F.Snappy, data, s, lambda o: F.Snappy().Decompress(o))), flush=True)
+for bs, bname in ((0x10000, "64 KiB blocks"), (0x40000, "256 KiB blocks")):
+    for name, data in (("Test.bmp (1 MB)", bmp), ("16 x Test.bmp (16 MB)", bmp * 16)):
+        for s, sname in ((F.CompressionSettings.Fastest, "Fastest"), (F.CompressionSettings.Balanced, "Balanced")):
+            print("LZ4 frame, %-14s %-22s %-8s: %s" % (bname, name, sname, measure(lambda: F.LZ4(bs), data, s, lambda o: F.LZ4().Decompress(o))), flush=True)
