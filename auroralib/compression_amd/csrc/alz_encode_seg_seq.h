@@ -11,6 +11,11 @@
 //   P  enc_seq_prefix_kernel<FMT>       per buffer: the end of the last match in front of each segment, the first sequences' sizes, the byte offsets
 //   E  enc_seq_seg_kernel<FMT, true>    the sequences, with enc_parse_seq_kernel's arithmetic (literals of earlier windows and segments go with the first start behind them)
 //   F  enc_seq_finish_kernel<FMT>       the length varint, the literals behind the last match, the result
+// LZ4 blocks and LZO (round 6), in place of sync + walk, in front of C:
+//   W  enc_spec_walk_kernel<FMT>        per segment: the walk from the segment's first position, as if a cursor stood there -- start mask, cursor mask, exit
+//   X  enc_spec_fix_kernel<FMT>         per buffer: the true cursor through every segment until it stands on one of W's cursors; the start mask made the true walk's
+//   L  enc_spec_long_kernel<FMT>        per segment: the raw lengths of the true walk's matches of 2 046 bytes and more, behind their entries
+//   H  enc_lzo_head_kernel              LZO, per buffer: the head of the stream the reference's way, until a match has been written (LZO.cs:141-250)
 
 template <int FMT, bool EMIT>
 __global__ __launch_bounds__(64) void enc_seq_seg_kernel(const u8* __restrict__ src_base, u8* __restrict__ dst_base, const alz_stream* __restrict__ streams,

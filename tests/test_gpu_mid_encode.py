@@ -126,7 +126,7 @@ def test_settings_and_mixed_formats(test_bmp):
             _both_ways(c, [(A.FMT_YAZ0, raw[:40000]), (A.FMT_YAZ0, raw[100000:140000])] * 17, q, "quality %d" % q)
 
 
-@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_LE])
+@pytest.mark.parametrize("fmt", [A.FMT_YAZ0, A.FMT_YAY0, A.FMT_LZ10, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK, A.FMT_LZO, A.FMT_LZ11])
 def test_capacity_and_canary_device_resident(fmt, test_bmp):
     """alz_encode_batch_device with the whole destination compared (0xA5 canary, guard regions): destinations of exactly the compressed size are
     filled and nothing else; one byte less is OUTPUT_CAPACITY with dst_len 0 and no byte outside the buffer's own range."""
@@ -163,6 +163,49 @@ def test_capacity_and_canary_device_resident(fmt, test_bmp):
                     assert bytes(buf[o:o + len(want)]) == want, tag
                     assert np.all(buf[o + len(want):o + caps[i]] == 0xA5), tag
                     assert (aux[i].aux0, aux[i].aux1) == (waux.aux0, waux.aux1), tag
+                else:
+                    assert (res[i].status, res[i].dst_len) == (A.ST_OUTPUT_CAPACITY, 0), tag
+
+
+def test_lzo_head_capacity_and_canary(test_bmp):
+    """LZO's head kernel writes whole streams by itself -- noise (no match at all: one literal run, copied by the wavefront), buffers under 16 bytes, a buffer whose first match
+    comes late -- and hands the others over after their first match: destinations of exactly the compressed size, one byte less and far too small, with the whole
+    destination compared against a 0xA5 canary."""
+    rng = np.random.default_rng(77)
+    noise = lambda k: bytes(rng.integers(0, 256, k, dtype=np.uint8))
+    raws = [noise(40000), noise(15), noise(16), noise(3), b"", noise(20000) + test_bmp[:30000], test_bmp[:50000], noise(2) + bytes(30000), noise(5) + b"abcabcabc" * 3000,
+            noise(70) + noise(70)[:60] * 400, bytes(9000), test_bmp[100000:160000]] * 3
+    n = len(raws)
+    with Context(0) as c:
+        c.big_stream(OFF)
+        for q in (0, 8):
+            wants = [O.encode_stream(A.FMT_LZO, r, quality=q) for r in raws]
+            caps = [max(0, len(w[0]) - (1 if i // 12 == 1 else 0)) if i // 12 < 2 else min(len(w[0]) // 2, 37) for i, w in enumerate(wants)]
+            caps[6] = len(wants[6][0]) + 555                                   # (one long buffer that fits, so that the path is taken whatever else fails)
+            src = np.frombuffer(b"".join(raws) + bytes(64), dtype=np.uint8)
+            st = (A.Stream * n)()
+            so, do = 0, G
+            for i in range(n):
+                st[i] = A.Stream(so, do, len(raws[i]), caps[i], 0, 0, 0, A.FMT_LZO)
+                so += len(raws[i]); do += caps[i] + G
+            d_src, d_dst = c.malloc(len(src)), c.malloc(do)
+            try:
+                c.h2d(d_src, src); c.memset(d_dst, 0xA5, do)
+                before = _seg(c)
+                res, aux = c.encode_batch_device(st, d_src, len(src), d_dst, do, quality=q)
+                assert _seg(c) > before
+                buf = c.d2h(d_dst, do)
+            finally:
+                c.free(d_src); c.free(d_dst)
+            assert np.all(buf[:G] == 0xA5)
+            for i in range(n):
+                want = wants[i][0]
+                o, tag = st[i].dst_off, (q, i, len(raws[i]), caps[i] - len(want))
+                assert np.all(buf[o + caps[i]:o + caps[i] + G] == 0xA5), tag
+                if caps[i] >= len(want):
+                    assert (res[i].status, res[i].dst_len, res[i].src_used) == (A.ST_OK, len(want), len(raws[i])), tag
+                    assert bytes(buf[o:o + len(want)]) == want, tag
+                    assert np.all(buf[o + len(want):o + caps[i]] == 0xA5), tag
                 else:
                     assert (res[i].status, res[i].dst_len) == (A.ST_OUTPUT_CAPACITY, 0), tag
 
