@@ -263,7 +263,19 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     const u32 rule2 = (long11 && rule > 256u) ? 256u : (spec4 && rule > 1024u) ? 1024u : rule;
     const u32 most = max_streams == 0xFFFFFFFFu ? rule2 : (max_streams < 65535u ? max_streams : 65535u);
     if (!fam || (g.max_len > 2040 && !long11 && !spec4) || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
-    uint64_t want = ((uint64_t)count * max_len + ALZ_SEG_WAVES - 1u) / ALZ_SEG_WAVES;
+#ifndef ALZ_SPEC_WAVES
+#define ALZ_SPEC_WAVES 12288u    /* the speculative walk's segments (its kernel holds 7 wavefronts per SIMD: 7 168 places, so 8 192 segments are two rounds of unequal length) -- 256 x 64 KiB of Test.bmp as LZ4
+                                    blocks, ms per call at 4 096 / 6 144 / 7 168 / 8 192 / 12 288 / 16 384: quality 0 0.95 / 0.70 / 0.71 / 0.74 / 0.65 / 0.70, quality 8 2.28 / 2.10 / 2.11 / 2.21 / 2.05 / 2.12; windows
+                                    spread over the whole file at quality 8, 8 192 / 12 288 / 16 384: LZ4 2.67 / 2.23 / 2.43, LZO 2.72 / 2.26 / 2.44; 1 024 buffers 7.73 / 7.16 / 7.67.  But every segment is one step of the
+                                    serial fix-up of its buffer: 64 x 256 KiB 3.10 / 3.36 / 3.41 -- the finer cut only while a buffer has at most 64 segments */
+#endif
+    u32 waves = ALZ_SEG_WAVES;
+    if (spec4) {
+        uint64_t w2 = ((uint64_t)count * max_len + ALZ_SPEC_WAVES - 1u) / ALZ_SPEC_WAVES;
+        if (w2 < 1024u) w2 = 1024u;
+        if ((max_len + w2 - 1u) / w2 <= 64u) waves = ALZ_SPEC_WAVES;
+    }
+    uint64_t want = ((uint64_t)count * max_len + waves - 1u) / waves;
     if (want < 1024u) want = 1024u;
     u32 sl = (u32)((want + 63u) & ~(uint64_t)63u);
     u32 hist = seg_table_hist(g);                                          // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
