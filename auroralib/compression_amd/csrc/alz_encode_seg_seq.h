@@ -254,7 +254,34 @@ __device__ __forceinline__ int spec_walk(const u8* data, int ns, int limit, cons
         const u64 stopw = stop ? stop[(u32)(P - S) >> 6] : 0ull;
         u64 sb = 0, cb = 0; bool nextbit = false;
         int rel = cur - P;
-        while (rel < 64 && P + rel <= limit && P + rel < End) {
+        if (__ballot(capped) == 0ull) {
+            // no capped entry in the window: the hops as five scalar instructions each, the visited lanes collected as a bit mask and the token starts read off two
+            // ballots (enc_roles_kernel's loop -- written in C++ a hop is ~40 instructions of the CU's one scalar unit, which seven wavefronts per SIMD share: the walk
+            // kernel of 256 x 64 KiB at quality 0 took 0.23 ms of the call's 0.64)
+            u64 M = 0; u32 r = (u32)rel, j;
+            u32 lim = (u32)(limit + 1 - P) < 64u ? (u32)(limit + 1 - P) : 64u;     // (r < lim on entry: cur <= limit and cur < End)
+            if ((u32)(End - P) < lim) lim = (u32)(End - P);
+            lim = (u32)__builtin_amdgcn_readfirstlane((int)lim); r = (u32)__builtin_amdgcn_readfirstlane((int)r);      // (wave-uniform by construction: into scalar registers)
+            asm volatile(
+                "s_nop 3\n"
+                "1:\n\t"
+                "s_bitset1_b64 %[M], %[r]\n\t"
+                "v_readlane_b32 %[j], %[jump], %[r]\n\t"
+                "s_add_u32 %[r], %[r], %[j]\n\t"
+                "s_cmp_lt_u32 %[r], %[lim]\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                : [M] "+s"(M), [r] "+s"(r), [j] "=&s"(j)
+                : [jump] "v"(jump), [lim] "s"(lim)
+                : "scc");
+            if (M & stopw) {                                                       // the first cursor the speculative walk stood on as well: the walks are one from here
+                const u32 b0 = (u32)__builtin_ctzll(M & stopw);
+                met = true; M &= (1ull << b0) - 1ull; r = b0;
+            }
+            const u64 s1 = __ballot(startrel == 1) & M, s2 = __ballot(startrel == 2) & M;
+            sb = s1 | (s2 << 1); nextbit = (s2 >> 63) != 0ull; cb = M;
+            rel = (int)r;
+        }
+        else while (rel < 64 && P + rel <= limit && P + rel < End) {
             if ((stopw >> rel) & 1ull) { met = true; break; }
             cb |= 1ull << rel;
             int j, sr;
