@@ -259,8 +259,11 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     // (LZ11 / LZ40: enc_sync_kernel looks back 16 KiB per boundary and the stretches with capped entries stay serial -- 64 KiB windows of Test.bmp, ms per call, one wavefront per
     // buffer -> segments: 16 buffers 1.83 / 2.13 -> 0.42 / 0.44 at quality 0 / 8, 64: 1.84 / 2.57 -> 0.75 / 1.07, 256: 1.92 / 3.16 -> 1.57 / 2.78, 1 024: 2.71 / 5.19 -> 4.26 / 8.67)
     // (LZ4 blocks, 64 KiB windows of Test.bmp 4 KiB apart, ms per call without / with the path -- quality 8: 16 buffers 1.74 / 0.42, 64 2.62 / 1.06, 256 3.43 / 2.22, 512 4.95 / 3.94,
-    // 1 024 8.04 / 7.59; quality 0 at 256: 1.90 / 0.82; quality 12: 19.8 / 5.2, quality 15: 66.5 / 20.4; 1 500 x 16 KiB at quality 8: 2.71 / 2.93 -- up to 1 024 buffers)
-    const u32 rule2 = (long11 && rule > 256u) ? 256u : (spec4 && rule > 1024u) ? 1024u : rule;
+    // 1 024 8.04 / 7.59; quality 0 at 256: 1.90 / 0.82; quality 12: 19.8 / 5.2, quality 15: 66.5 / 20.4; 1 500 x 16 KiB at quality 8: 2.71 / 2.93 -- up to 1 024 buffers then)
+    // (... since the walk's hops are scalar loops and the segments are cut finer: 1 024 / 1 536 / 2 048 x 64 KiB without / with the path, quality 0 2.16 / 2.42 / 2.74 against 1.69 / 2.53 / 3.23,
+    // quality 8 7.53 / 10.35 / 8.94 -- from 2 048 buffers on the scan path -- against 6.62 / 9.61 / 13.30, quality 12 15.8 / -- / 24.4 against 11.0 / -- / 20.7; 1 500 x 16 KiB at quality 8 2.63 against 2.41:
+    // the common line, and 2 048 buffers for the long chains)
+    const u32 rule2 = (long11 && rule > 256u) ? 256u : (spec4 && g.max_chain >= 64) ? 2048u : rule;
     const u32 most = max_streams == 0xFFFFFFFFu ? rule2 : (max_streams < 65535u ? max_streams : 65535u);
     if (!fam || (g.max_len > 2040 && !long11 && !spec4) || g.nprops > 1 || count == 0 || count > most || max_len < ALZ_SEG_MIN_LEN) return 0;
 #ifndef ALZ_SPEC_WAVES
