@@ -3964,7 +3964,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     // every capped position the roles walk stands on costs that ONE wavefront two exact searches: 16 x 64 KiB of Test.bmp as Yaz0 at quality 8 1.17 ms of walk)
     // (LZ4 blocks and LZO keep the cap: their segments are walked all at once -- alz_encode_seg_seq.h, enc_spec_walk_kernel --, so the exact searches of capped cursors run side by side,
     // while no cap means every position of a flat stretch compared over 2 040 bytes: 256 x 64 KiB of Test.bmp at quality 8, kernel B 1.70 ms of the call's 3.37)
-    g.b_cap = (d_seg != nullptr && seg_len != 0u && fmt != ALZ_FMT_LZ4_BLOCK && fmt != ALZ_FMT_LZO) ? ALZ_LEN_CAP : choose_b_cap(g);
+    g.b_cap = (d_seg != nullptr && seg_len != 0u && !seg_spec_format(fmt)) ? ALZ_LEN_CAP : choose_b_cap(g);
     // (a lower cap for them, -DALZ_SPEC_BCAP=48 / 96 / 128 against choose_b_cap's 256 at quality 8, 256 x 64 KiB of Test.bmp, ms per call: windows 4 KiB apart 2.10 / 2.04 / 2.07 against 2.23,
     // windows spread over the whole file -- flat stretches, where the true cursor lands on capped positions and its searches stay serial per buffer -- 6.37 / 3.67 / 3.78 against 2.69: not taken)
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;
@@ -4063,13 +4063,14 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     const bool segmented = d_seg != nullptr && seg_len != 0u;                   // (a batch of few buffers: alz_encode_seg.h -- always behind kernel B)
     const u32 wgc = !segmented ? 32u : count < 128u ? 128u : 64u;           // (workgroups per buffer in kernel B: 64 buffers of 64 KiB at quality 8 0.92 -> 0.79 ms with 128, 256 buffers 2.15 -> 2.08 with 64)
     if (segmented || !searches_in_the_parse(fmt, g)) launch_match(stream, src, d_streams, d_index, count, max_len, d_prev4, d_prevm, d_match, d_pos_off, g, tail, wgc, true, d_sel, sel_pitch);
-#define ALZ_SEG(F) if (segmented) { launch_emit_seg<F>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
+#define ALZ_SEG(F) if (segmented) { launch_emit_seg_long<F>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
+#define ALZ_SEGL(F) if (segmented) { launch_emit_seg_long<F>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, d_seg, seg_len, seg_kmax, d_results, d_aux, g); break; }
     const mentry* m = (const mentry*)d_match; u8* side = (u8*)d_side;
     switch (fmt) {
     case ALZ_FMT_LZSS: ALZ_SEG(ALZ_FMT_LZSS) launch_emit_par<ALZ_FMT_LZSS>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_LZ10: ALZ_SEG(ALZ_FMT_LZ10) launch_emit_par<ALZ_FMT_LZ10>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ11: ALZ_SEG(ALZ_FMT_LZ11) launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
-    case ALZ_FMT_LZ40: ALZ_SEG(ALZ_FMT_LZ40) launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ11: ALZ_SEGL(ALZ_FMT_LZ11) launch_emit_par<ALZ_FMT_LZ11>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
+    case ALZ_FMT_LZ40: ALZ_SEGL(ALZ_FMT_LZ40) launch_emit_par<ALZ_FMT_LZ40>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAZ0: ALZ_SEG(ALZ_FMT_YAZ0) launch_emit_par<ALZ_FMT_YAZ0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_YAY0: ALZ_SEG(ALZ_FMT_YAY0) launch_emit_par<ALZ_FMT_YAY0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;
     case ALZ_FMT_MIO0: ALZ_SEG(ALZ_FMT_MIO0) launch_emit_par<ALZ_FMT_MIO0>(stream, count, src, dst, d_streams, d_index, (mentry*)d_match, d_pos_off, d_prev4, d_prevm, (u64*)d_mask, side, d_results, d_aux, g); break;

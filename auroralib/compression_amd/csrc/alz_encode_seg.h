@@ -245,14 +245,29 @@ __global__ __launch_bounds__(64) void enc_seg_flags_kernel(u8* __restrict__ dst_
 // tests, tools/mid_batch_encode.py) -- never more than one launch of encode_core takes (65 535 buffers: the scratch is laid out for the launch's own count)
 // the words a segment's record holds behind its three fixed ones (alz_encode_seg_bytes): the exit table of the longest jump -- or, for the formats of the speculative walk
 // (LZ4 blocks, LZO: alz_encode_seg_seq.h), SpecRec and the segment's cursor mask.  ONE function for the host's sizing and the launch's layout.
+#ifndef ALZ_SPEC_LONG11
+#define ALZ_SPEC_LONG11 1     /* LZ11 / LZ40 (matches of up to 16 KiB and more) on the speculative walk as well -- 0: synchronisation points with a 16 KiB look-back, up to 256 buffers.  64 KiB windows of
+                                 Test.bmp as LZ11, ms per call, 0 / 1: quality 8 16 buffers 0.44 / 0.33, 64 1.06 / 0.70, 256 2.77 / 1.82, 512 4.46 (one wavefront per buffer) / 3.13, 1 024 6.92 / 5.93; quality 0 at 256
+                                 1.56 / 0.61; quality 12 at 64 / 256: 6.1 / 2.0, 22.9 / 3.8 (the stretches with capped entries were walked serially) */
+#endif
+// the formats whose segments are walked speculatively (alz_encode_seg_seq.h): no longest match that a look-back could be bounded by
+#ifndef ALZ_SPEC_FLAG
+#define ALZ_SPEC_FLAG 0       /* the flag-bit formats with matches of at most 273 bytes on it too: measured, not taken -- 16 / 256 / 1 024 x 64 KiB as Yaz0 at quality 8 0.19 / 1.74 / 5.96 ms with the synchronisation
+                                 points against 0.32 / 1.81 / 5.83 (every segment is a step of its buffer's serial fix-up: 64 steps of ~2 us for a 64 KiB buffer, which the synchronisation points do not have),
+                                 quality 12 at 64 buffers 2.66 against 9.65 */
+#endif
+static inline bool seg_spec_format(int fmt) {
+    if (ALZ_SPEC_FLAG && (fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON)) return true;
+    return fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO || (ALZ_SPEC_LONG11 && (fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40));
+}
 static inline u32 seg_rec_hist(int fmt, const EncGeom& g, u32 seg_len) {
-    return (fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO) ? 1u + (seg_len >> 5) : seg_table_hist(g);
+    return seg_spec_format(fmt) ? 1u + (seg_len >> 5) : seg_table_hist(g);
 }
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t max_streams, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     // LZ4 blocks, LZO (round 6): no synchronisation points -- every segment walked speculatively, the true walk strung together behind (alz_encode_seg_seq.h: enc_spec_walk_kernel)
-    const bool spec4 = fmt == ALZ_FMT_LZ4_BLOCK || fmt == ALZ_FMT_LZO;
-    const bool long11 = fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40;                                                                                          // (matches of up to 16 KiB: round 6, seg_table_hist)
+    const bool spec4 = seg_spec_format(fmt);
+    const bool long11 = !spec4 && (fmt == ALZ_FMT_LZ11 || fmt == ALZ_FMT_LZ40);                                                                                          // (matches of up to 16 KiB: round 6, seg_table_hist)
     const bool fam = fmt == ALZ_FMT_LZSS || fmt == ALZ_FMT_LZ10 || fmt == ALZ_FMT_YAZ0 || fmt == ALZ_FMT_YAY0 || fmt == ALZ_FMT_MIO0 || fmt == ALZ_FMT_CLZ0 || long11 || spec4 ||
                      fmt == ALZ_FMT_BLZ || fmt == ALZ_FMT_LZHUDSON || fmt == ALZ_FMT_SNAPPY_RAW || fmt == ALZ_FMT_PRS_BE || fmt == ALZ_FMT_PRS_LE;        // (raw Snappy, PRS: alz_encode_seg_seq.h)
     const u32 rule = g.max_chain == 1 ? 1280u : g.max_chain < 64 ? 1536u : 512u;

@@ -549,6 +549,25 @@ static void launch_emit_seg_spec(hipStream_t s, u32 count, const u8* src, u8* ds
     hipLaunchKernelGGL((enc_seq_finish_kernel<FMT>), dim3(count), dim3(64), 0, s, src, dst, streams, index, (const SegRec*)seg, (const u32*)stot, kmax, seglen, results, aux);
 }
 
+// LZ11 / LZ40 (flag-bit formats whose matches reach 16 KiB and more): the speculative walk in front of alz_encode_seg.h's token / flag emitters -- or, with -DALZ_SPEC_LONG11=0, that
+// file's synchronisation points with their 16 KiB look-back
+template <int FMT>
+static void launch_emit_seg_long(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
+                                 const int* prev4, const int* prevm, u64* mask, void* d_seg, u32 seglen, u32 kmax, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {
+    if (!seg_spec_format(FMT)) { launch_emit_seg<FMT>(s, count, src, dst, streams, index, match, pos_off, prev4, prevm, mask, d_seg, seglen, kmax, results, aux, g); return; }
+    SegRec* seg = (SegRec*)d_seg;
+    u32* stot = (u32*)((u8*)d_seg + (size_t)count * kmax * sizeof(SegRec));
+    u32* spec = stot + 4 * (size_t)count;
+    const u32 recw = 4u + (seglen >> 5);
+    hipLaunchKernelGGL((enc_spec_walk_kernel<FMT>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, match, pos_off, prev4, prevm, mask, spec, kmax, seglen, recw, g);
+    hipLaunchKernelGGL((enc_spec_fix_kernel<FMT>), dim3(count), dim3(64), 0, s, src, streams, index, match, pos_off, prev4, prevm, mask, (const u32*)spec, kmax, seglen, recw, g);
+    hipLaunchKernelGGL((enc_spec_long_kernel<FMT>), dim3(kmax, count), dim3(64), 0, s, src, streams, index, match, pos_off, prev4, prevm, (const u64*)mask, seglen, g);
+    hipLaunchKernelGGL((enc_seg_kernel<FMT, false>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, (const u32*)stot, kmax, seglen, g);
+    hipLaunchKernelGGL(enc_seg_prefix_kernel, dim3(count), dim3(64), 0, s, streams, index, seg, stot, kmax, seglen);
+    hipLaunchKernelGGL((enc_seg_kernel<FMT, true>), dim3(kmax, count), dim3(64), 0, s, src, dst, streams, index, (const mentry*)match, pos_off, (const u64*)mask, seg, (const u32*)stot, kmax, seglen, g);
+    hipLaunchKernelGGL((enc_seg_flags_kernel<FMT>), dim3(count), dim3(64), 0, s, dst, streams, index, (const SegRec*)seg, (const u32*)stot, kmax, seglen, results, aux);
+}
+
 template <int FMT>
 static void launch_emit_seg_seq(hipStream_t s, u32 count, const u8* src, u8* dst, const alz_stream* streams, const u32* index, mentry* match, const u64* pos_off,
                                 const int* prev4, const int* prevm, u64* mask, void* d_seg, u32 seglen, u32 kmax, alz_result* results, alz_encode_aux* aux, const EncGeom& g) {

@@ -14,7 +14,7 @@ from test_gpu_big_encode import _encode, _mixed
 
 pytestmark = pytest.mark.gpu
 FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE,
-          A.FMT_LZ11, A.FMT_LZ40,        # (round 6: matches of up to 16 KiB -- a capped match entry hands its stretch of the buffer to the serial walker)
+          A.FMT_LZ11, A.FMT_LZ40,        # (round 6: matches of up to 16 KiB and more -- on the speculative walk as well, in front of the token / flag emitters)
           A.FMT_LZ4_BLOCK, A.FMT_LZO]    # (round 6: every segment walked speculatively, the true walk strung together behind -- alz_encode_seg_seq.h)
 OFF = 0xFFFFFFFF
 G = 4096
@@ -65,8 +65,7 @@ def test_segment_lengths(fmt, test_bmp):
     """The segment length follows from buffers x longest buffer (a launch aims at 8 192 segments): 300 x 64 KiB gives 2 432 positions, 700 x 24 KiB
     2 112; windows of Test.bmp 4 KiB apart."""
     with Context(0) as c:
-        long11 = fmt in (A.FMT_LZ11, A.FMT_LZ40)                   # (their batches take the path up to 256 buffers)
-        for n, size in (((200, 65536), (250, 24000), (64, 262144 + 77)) if long11 else ((300, 65536), (700, 24000), (64, 262144 + 77))):
+        for n, size in ((300, 65536), (700, 24000), (64, 262144 + 77)):
             items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - size):][:size - (i % 7)]) for i in range(n)]
             _both_ways(c, items, 0, "%d x %d" % (n, size))
         items = [(fmt, test_bmp[(i * 4096) % (len(test_bmp) - 65536):][:65536]) for i in range(256)]
