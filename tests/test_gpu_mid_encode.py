@@ -14,7 +14,7 @@ from test_gpu_big_encode import _encode, _mixed
 
 pytestmark = pytest.mark.gpu
 FAMILY = [A.FMT_LZSS, A.FMT_LZ10, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_CLZ0, A.FMT_BLZ, A.FMT_LZHUDSON, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE,
-          A.FMT_LZ11, A.FMT_LZ40,        # (round 6: matches of up to 16 KiB and more -- on the speculative walk as well, in front of the token / flag emitters)
+          A.FMT_LZ11, A.FMT_LZ40,        # (round 6: matches of up to 16 KiB -- on the speculative walk as well, in front of the token / flag emitters)
           A.FMT_LZ4_BLOCK, A.FMT_LZO]    # (round 6: every segment walked speculatively, the true walk strung together behind -- alz_encode_seg_seq.h)
 OFF = 0xFFFFFFFF
 G = 4096
