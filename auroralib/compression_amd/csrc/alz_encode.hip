@@ -3965,6 +3965,10 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     // (LZ4 blocks and LZO keep the cap: their segments are walked all at once -- alz_encode_seg_seq.h, enc_spec_walk_kernel --, so the exact searches of capped cursors run side by side,
     // while no cap means every position of a flat stretch compared over 2 040 bytes: 256 x 64 KiB of Test.bmp at quality 8, kernel B 1.70 ms of the call's 3.37)
     g.b_cap = (d_seg != nullptr && seg_len != 0u && !seg_spec_format(fmt)) ? ALZ_LEN_CAP : choose_b_cap(g);
+#ifndef ALZ_SPEC_BCAP_SHORT
+#define ALZ_SPEC_BCAP_SHORT 48
+#endif
+    if (d_seg != nullptr && seg_len != 0u && seg_spec_format(fmt) && g.max_chain <= 5 && g.max_len > ALZ_SPEC_BCAP_SHORT) g.b_cap = ALZ_SPEC_BCAP_SHORT;
     // (a lower cap for them, -DALZ_SPEC_BCAP=48 / 96 / 128 against choose_b_cap's 256 at quality 8, 256 x 64 KiB of Test.bmp, ms per call: windows 4 KiB apart 2.10 / 2.04 / 2.07 against 2.23,
     // windows spread over the whole file -- flat stretches, where the true cursor lands on capped positions and its searches stay serial per buffer -- 6.37 / 3.67 / 3.78 against 2.69: not taken)
     const u8* src = (const u8*)d_src; u8* dst = (u8*)d_dst;

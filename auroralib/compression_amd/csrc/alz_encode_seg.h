@@ -263,6 +263,7 @@ static inline bool seg_spec_format(int fmt) {
 static inline u32 seg_rec_hist(int fmt, const EncGeom& g, u32 seg_len) {
     return seg_spec_format(fmt) ? 1u + (seg_len >> 5) : seg_table_hist(g);
 }
+int alz_encode_seg_spec_format(int fmt) { return seg_spec_format(fmt) ? 1 : 0; }
 int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max_len, uint32_t max_streams, uint32_t* seg_len, uint32_t* kmax, uint32_t* hist_out) {
     EncGeom g; memcpy(&g, geom, sizeof(g));
     // LZ4 blocks, LZO (round 6): no synchronisation points -- every segment walked speculatively, the true walk strung together behind (alz_encode_seg_seq.h: enc_spec_walk_kernel)
@@ -300,6 +301,13 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     if (spec4) {
         // (a segment's masks live in LDS -- at most 8 192 positions --, and its record is SpecRec + the cursor mask: `hist` words behind three -- alz_encode_seg_bytes)
         if (sl > 8192u) sl = 8192u;
+#ifndef ALZ_SPEC_ODD
+#define ALZ_SPEC_ODD 1
+#endif
+        // An ODD number of windows per segment.  Every speculative walk starts on a segment boundary, and a boundary that falls on the same column of every row of a bitmap (2 048 bytes a
+        // row, 2 048 positions a segment: 16 x 1 MiB of Test.bmp) finds the same thing there row after row -- in one stretch of 124 KB a match that swallows the whole segment, which the
+        // true cursor, two bytes further on, does not have: 238 segments in a row without one speculative cursor to meet, all of them walked by the serial fix-up (8.4 ms instead of 3.4).
+        if (ALZ_SPEC_ODD && ((sl >> 6) & 1u) == 0u) sl = sl >= 8192u ? sl - 64u : sl + 64u;
         if ((max_len + sl - 1u) / sl > 8192u) return 0;
         hist = seg_rec_hist(fmt, g, sl);
     } else {

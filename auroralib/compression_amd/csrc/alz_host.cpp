@@ -1022,26 +1022,32 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         const uint32_t enc_min = c->big_min < 8192u ? c->big_min : 8192u;
         bool all = true; size_t sb = 0;
         double t_big = 0, t_side = 0;
+        const bool q0 = st.quality == 0;                                      // (no narrowing behind kernel A, one candidate per position in kernel B: 8 x 1 MB 0.99 one by one / 0.68)
         for (uint32_t i = 0; all && i < n; i++) {
             const void* g = geom.data() + streams[i].format * alz_encode_geom_size();
             all = streams[i].format != ALZ_FMT_FASTLZ && alz_encode_big_eligible((int)streams[i].format, g, &streams[i], enc_min);
             if (all) { const size_t b = alz_encode_big_scratch_bytes((int)streams[i].format, g, &streams[i]); if (b > sb) sb = b; }
             const double mib = streams[i].src_len / 1048576.0;
-            t_big += 0.10 + 0.10 * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;
+            // (round 6, 2-32 x 1 MiB of Test.bmp one by one, ms per MiB: LZ4 blocks / LZO -- 64 KiB windows -- 0.32 at quality 0 and 0.80 at quality 8, LZ11 / LZ40 0.21 / 0.37)
+            const bool wide = alz_encode_geom_max_dist(g) > 8192, l11 = streams[i].format == ALZ_FMT_LZ11 || streams[i].format == ALZ_FMT_LZ40;
+            const double rate = wide ? (q0 ? 0.22 : 0.70) : (l11 && !q0) ? 0.27 : 0.10;
+            t_big += 0.10 + rate * mib; if (22.0 * mib > t_side) t_side = 22.0 * mib;
         }
         // (side by side is no longer one wavefront per buffer where the segmented parse + emit takes the launch, alz_encode_seg.h: what is left of the longest
         // buffer's serial time is kernel A -- over segments too, for these few buffers: ~0.9 ms per MiB; one workgroup per buffer where that does not apply: 2.2 --
         // + ~0.14 ms of small kernels per format + ~0.08 ms per MiB of the whole call.  tools/mid_batch_encode.py with ALZ_MID_BIG=on / off,
         // profiles/r05_mid_big_vs_seg.txt: 4 x 256 KiB at quality 8 0.47 ms one by one against 0.42, 8 x 1 MB 1.66 / 1.73, 16 x 1 MB 3.33 / 2.18)
         {
-            bool seg_all = true, aseg_all = true; int nf = 0; double mib_all = 0;
+            bool seg_all = true, aseg_all = true, spec_any = false; int nf = 0; double mib_all = 0;
             for (int f = 0; f < ALZ_FMT_COUNT; f++) if (cnt[f]) {
-                nf++; seg_all = seg_all && seg_len[f] != 0;
-                aseg_all = aseg_all && alz_encode_aseg(geom.data() + f * alz_encode_geom_size(), cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, nullptr);
+                nf++; seg_all = seg_all && seg_len[f] != 0; spec_any = spec_any || alz_encode_seg_spec_format(f);
+                aseg_all = aseg_all && f != ALZ_FMT_LZ4_BLOCK /* (alz_launch_encode: not for a format that keeps bytes back at the end of a buffer) */ &&
+                           alz_encode_aseg(geom.data() + f * alz_encode_geom_size(), cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, nullptr);
             }
             for (uint32_t i = 0; i < n; i++) mib_all += streams[i].src_len / 1048576.0;
-            const bool q0 = st.quality == 0;                                  // (no narrowing behind kernel A, one candidate per position in kernel B: 8 x 1 MB 0.99 one by one / 0.68)
-            if (seg_all) { const double t_seg = 0.14 * nf + (aseg_all ? (q0 ? 0.45 : 0.9) : 2.2) * (max_len / 1048576.0) + (q0 ? 0.03 : 0.08) * mib_all; if (t_seg < t_side) t_side = t_seg; }
+            // (the formats of the speculative walk -- alz_encode_seg_seq.h -- have one serial step per segment of the longest buffer behind that: ~1.2 ms per MiB; 2 / 8 / 16 / 32 x 1 MiB
+            // side by side, ms: LZ4 blocks at quality 0 3.27 / 3.40 / 3.23 / 3.14, at quality 8 4.06 / 4.63 / 4.96 / 6.93; LZ11 at quality 0 -- / 2.14 / 1.98 / 2.01, at quality 8 -- / 3.41 / 3.40 / 4.57)
+            if (seg_all) { const double t_seg = 0.14 * nf + ((aseg_all ? (q0 ? 0.45 : 0.9) : 2.2) + (spec_any ? 1.2 : 0.0)) * (max_len / 1048576.0) + (q0 ? 0.03 : 0.08) * mib_all; if (t_seg < t_side) t_side = t_seg; }
         }
         all = all && t_big < t_side;
         if (all) {
