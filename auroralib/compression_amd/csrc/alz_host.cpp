@@ -929,6 +929,8 @@ struct EncScratch {
         return hipSuccess;
     }
 };
+// (alz_encode_seg.h) 1: a small batch of this format is walked speculatively per segment (alz_encode_seg_seq.h), not from synchronisation points
+extern "C++" int alz_encode_seg_spec_format(int fmt);
 static void release_scratch(alz_ctx* c) {
     for (int k = 0; k < 15; k++) { if (c->enc_buf[k]) (void)hipFree(c->enc_buf[k]); c->enc_buf[k] = nullptr; c->enc_cap[k] = 0; }
     void** bufs[] = {&c->d_src, &c->d_dst, &c->d_items, &c->d_pack, &c->d_plan, &c->d_bigbuf};

@@ -51,7 +51,6 @@ hipError_t alz_launch_big(int fmt, hipStream_t stream, const void* d_src_base, v
 // ---- encoder (alz_encode.hip)
 bool alz_encode_geometry(int fmt, const alz_lz_properties* lz, const alz_settings* st, void* out_geom, int* window_bits, int variant = 0);   // variant 1: FastLZ level 2
 size_t alz_encode_geom_size(void);
-int alz_encode_seg_spec_format(int fmt);                        // 1: a small batch of this format is walked speculatively per segment (alz_encode_seg_seq.h), not from synchronisation points
 int alz_encode_geom_hash_bits(const void* geom);
 int alz_encode_geom_min_table(const void* geom);
 int alz_encode_geom_max_dist(const void* geom);
