@@ -3848,17 +3848,17 @@ struct AsegPlan { void* mem; u32 SA, ka, W, stride; };
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
                               int* d_prev4, int* d_prevm, const uint64_t* d_pos_off, const EncGeom& g, int tail, bool split_passes, bool no_win);
 static hipError_t launch_prev_aseg(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count, uint32_t max_len,
-                                   int* d_prev4, const uint64_t* d_pos_off, const EncGeom& g15, const AsegPlan& a) {
+                                   int* d_prev4, const uint64_t* d_pos_off, const EncGeom& g15, const AsegPlan& a, int tail) {
     const size_t V = (size_t)count * a.ka;
     u8* base = (u8*)a.mem;
     alz_stream* vs = (alz_stream*)base; base += V * sizeof(alz_stream);
     u64* vpos = (u64*)base; base += V * sizeof(u64);
     u32* vindex = (u32*)base; base += ((V * sizeof(u32)) + 63u) & ~(size_t)63u;
     int* seg4 = (int*)base;
-    hipLaunchKernelGGL(enc_aseg_setup_kernel, dim3((u32)((V + 255u) / 256u)), dim3(256), 0, stream, d_streams, d_index, count, vs, vindex, vpos, a.ka, a.SA, a.W, a.stride);
+    hipLaunchKernelGGL(enc_aseg_setup_kernel, dim3((u32)((V + 255u) / 256u)), dim3(256), 0, stream, d_streams, d_index, count, vs, vindex, vpos, a.ka, a.SA, a.W, a.stride, tail);
     const hipError_t e = launch_prev(stream, src, vs, vindex, (u32)V, seg4, nullptr, vpos, g15, 0, false, true);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(enc_aseg_gather_kernel, dim3((max_len + 255u) / 256u, count), dim3(256), 0, stream, d_streams, d_index, (const int*)seg4, d_prev4, d_pos_off, a.ka, a.SA, a.W, a.stride);
+    hipLaunchKernelGGL(enc_aseg_gather_kernel, dim3((max_len + 255u) / 256u, count), dim3(256), 0, stream, d_streams, d_index, (const int*)seg4, d_prev4, d_pos_off, a.ka, a.SA, a.W, a.stride, tail);
     return hipSuccess;
 }
 static hipError_t launch_prev(hipStream_t stream, const u8* src, const alz_stream* d_streams, const uint32_t* d_index, uint32_t count,
@@ -4009,7 +4009,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
     };
     if (scan_ok && !seqf) { const hipError_t es = launch_scan(nullptr); if (es != hipSuccess) return es; }
     AsegPlan aseg = { nullptr, 0, 0, 0, 0 };                                   // (kernel A over segments: a launch on the segmented path with at most 128 buffers)
-    if (d_seg != nullptr && seg_len != 0u && tail == 0) {
+    if (d_seg != nullptr && seg_len != 0u) {
         size_t ab = 0; const u32 hist = seg_rec_hist(fmt, g, seg_len);      // (as alz_encode_segmented sized the records)
         if (alz_encode_aseg(geom, count, max_len, &aseg.SA, &aseg.ka, &aseg.W, &aseg.stride, &ab))
             aseg.mem = (u8*)d_seg + ((alz_encode_seg_bytes(count, seg_kmax, hist) + 255u) & ~(size_t)255u);
@@ -4039,7 +4039,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             hipLaunchKernelGGL(enc_narrow_kernel, dim3(bx, count), dim3(256), 0, stream, src, d_streams, list, d_prev4, d_narrow, d_pos_off, g, tail);
         };
         if (uses_win_prev(g) && !g.use_min_table) {
-            const hipError_t e15 = aseg.mem ? launch_prev_aseg(stream, src, d_streams, d_index, count, max_len, d_prev4, d_pos_off, g15, aseg)
+            const hipError_t e15 = aseg.mem ? launch_prev_aseg(stream, src, d_streams, d_index, count, max_len, d_prev4, d_pos_off, g15, aseg, tail)
                                             : launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g15, tail);
             if (e15 != hipSuccess) return e15;
             narrow(d_index);
@@ -4059,7 +4059,7 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         }
         d_prev4 = d_narrow;
     } else {
-        const hipError_t ea = (aseg.mem && g.hash_bits == 15) ? launch_prev_aseg(stream, src, d_streams, d_index, count, max_len, d_prev4, d_pos_off, g, aseg)
+        const hipError_t ea = (aseg.mem && g.hash_bits == 15) ? launch_prev_aseg(stream, src, d_streams, d_index, count, max_len, d_prev4, d_pos_off, g, aseg, tail)
                                                               : launch_prev(stream, src, d_streams, d_index, count, d_prev4, d_prevm, d_pos_off, g, tail);
         if (ea != hipSuccess) return ea;
     }

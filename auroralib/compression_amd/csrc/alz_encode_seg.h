@@ -328,12 +328,12 @@ namespace {
 // of 15-bit chains stops there too).  The segments are "virtual streams" of enc_prev_cu_kernel (descriptors written on the device); the 16-bit links --
 // distances, so they need no rebasing -- are gathered into the buffer's own array.  One workgroup per buffer took 1.55 us per KiB of the LONGEST buffer.
 __global__ __launch_bounds__(256) void enc_aseg_setup_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, u32 count, alz_stream* __restrict__ vs,
-                                                             u32* __restrict__ vindex, u64* __restrict__ vpos, u32 ka, u32 SA, u32 W, u32 stride) {
+                                                             u32* __restrict__ vindex, u64* __restrict__ vpos, u32 ka, u32 SA, u32 W, u32 stride, int tail_skip) {
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     if (t >= count * ka) return;
     const u32 bid = t / ka, j = t % ka;
     alz_stream s = streams[index_list[bid]];
-    const int limit = (int)s.src_len - 4;
+    const int limit = (int)s.src_len - tail_skip - 4;                      // (tail_skip: the bytes an LZ4 block keeps back -- the last segment ends in front of them)
     const u32 first = j * SA;
     if ((int)first > limit) { vindex[t] = 0xFFFFFFFFu; return; }          // (no such segment: kernel A leaves the slot alone)
     const u32 start = first >= W ? first - W : 0u;
@@ -343,10 +343,10 @@ __global__ __launch_bounds__(256) void enc_aseg_setup_kernel(const alz_stream* _
     vs[t] = s; vindex[t] = t; vpos[t] = (u64)t * stride;
 }
 __global__ __launch_bounds__(256) void enc_aseg_gather_kernel(const alz_stream* __restrict__ streams, const u32* __restrict__ index_list, const int* __restrict__ seg4,
-                                                              int* __restrict__ fin4, const u64* __restrict__ pos_off, u32 ka, u32 SA, u32 W, u32 stride) {
+                                                              int* __restrict__ fin4, const u64* __restrict__ pos_off, u32 ka, u32 SA, u32 W, u32 stride, int tail_skip) {
     const u32 p = blockIdx.x * 256u + threadIdx.x, bid = blockIdx.y;
     const u32 sid = index_list[bid];
-    const int limit = (int)streams[sid].src_len - 4;
+    const int limit = (int)streams[sid].src_len - tail_skip - 4;
     if ((int)p > limit) return;
     const u32 j = p / SA, first = j * SA, start = first >= W ? first - W : 0u, local = p - start;
     reinterpret_cast<unsigned short*>(fin4 + pos_off[sid])[p] = reinterpret_cast<const unsigned short*>(seg4 + (size_t)(bid * ka + j) * stride)[local];

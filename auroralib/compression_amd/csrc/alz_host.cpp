@@ -1043,8 +1043,7 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
             bool seg_all = true, aseg_all = true, spec_any = false; int nf = 0; double mib_all = 0;
             for (int f = 0; f < ALZ_FMT_COUNT; f++) if (cnt[f]) {
                 nf++; seg_all = seg_all && seg_len[f] != 0; spec_any = spec_any || alz_encode_seg_spec_format(f);
-                aseg_all = aseg_all && f != ALZ_FMT_LZ4_BLOCK /* (alz_launch_encode: not for a format that keeps bytes back at the end of a buffer) */ &&
-                           alz_encode_aseg(geom.data() + f * alz_encode_geom_size(), cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, nullptr);
+                aseg_all = aseg_all && alz_encode_aseg(geom.data() + f * alz_encode_geom_size(), cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, nullptr);
             }
             for (uint32_t i = 0; i < n; i++) mib_all += streams[i].src_len / 1048576.0;
             // (the formats of the speculative walk -- alz_encode_seg_seq.h -- have one serial step per segment of the longest buffer behind that: ~1.2 ms per MiB; 2 / 8 / 16 / 32 x 1 MiB

@@ -14,6 +14,7 @@ ctx = Context(0)
 if os.environ.get("ALZ_SEG") is not None: ctx.lib.alz_debug_seg_max_streams(ctx.h, int(os.environ["ALZ_SEG"]))      # (0: the segmented parse + emit off)
 lz = F.LZSS(A.LzProperties.from_bits(10, 6, 2))
 bmp = np.frombuffer(lz.Decompress(open("tests/golden/Test.lz", "rb").read()), dtype=np.uint8)
+if os.environ.get("ALZ_REPEAT"): bmp = np.tile(bmp, int(os.environ["ALZ_REPEAT"]))                     # (the file so many times over: windows larger than it)
 starts = [(i * (len(bmp) - size)) // max(n - 1, 1) for i in range(n)]
 if os.environ.get("ALZ_STEP"): starts = [(i * int(os.environ["ALZ_STEP"])) % (len(bmp) - size) for i in range(n)]      # (windows ALZ_STEP bytes apart, as tools/mid_batch_encode.py takes them)
 raw = np.zeros(n * size + 64, dtype=np.uint8)
