@@ -4051,7 +4051,8 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
             hipLaunchKernelGGL(enc_words_kernel, dim3(count), dim3(256), 0, stream, src, d_streams, d_index, tail, d_sel, sel_pitch + 2u,
                                winm ? ALZ_NARROW_MIN_THRESH16 : ALZ_NARROW_THRESH16, winm);
             if (count < ALZ_NARROW_SPLIT_MIN) hipLaunchKernelGGL(enc_words_merge_kernel, dim3(1), dim3(256), 0, stream, d_sel, sel_pitch + 2u);
-            const hipError_t e15 = launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, d_prevm, d_pos_off, g15, tail, false, true);
+            const hipError_t e15 = (aseg.mem && !winm) ? launch_prev_aseg(stream, src, d_streams, l_narrow + 1, count, max_len, d_prev4, d_pos_off, g15, aseg, tail)
+                                                       : launch_prev(stream, src, d_streams, l_narrow + 1, count, d_prev4, d_prevm, d_pos_off, g15, tail, false, true);
             if (e15 != hipSuccess) return e15;
             narrow(l_narrow + 1);
             const hipError_t ew = launch_prev(stream, src, d_streams, l_wide + 1, count, d_narrow, d_prevm, d_pos_off, g, tail);

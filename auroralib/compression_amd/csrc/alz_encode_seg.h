@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void enc_aseg_setup_kernel(const alz_stream* _
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     if (t >= count * ka) return;
     const u32 bid = t / ka, j = t % ka;
-    alz_stream s = streams[index_list[bid]];
+    const u32 sid0 = index_list[bid];
+    if (sid0 == 0xFFFFFFFFu) { vindex[t] = 0xFFFFFFFFu; return; }           // (a list written on the device -- enc_words_kernel: the streams whose links are narrowed -- with unused slots)
+    alz_stream s = streams[sid0];
     const int limit = (int)s.src_len - tail_skip - 4;                      // (tail_skip: the bytes an LZ4 block keeps back -- the last segment ends in front of them)
     const u32 first = j * SA;
     if ((int)first > limit) { vindex[t] = 0xFFFFFFFFu; return; }          // (no such segment: kernel A leaves the slot alone)
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(256) void enc_aseg_gather_kernel(const alz_stream* 
                                                               int* __restrict__ fin4, const u64* __restrict__ pos_off, u32 ka, u32 SA, u32 W, u32 stride, int tail_skip) {
     const u32 p = blockIdx.x * 256u + threadIdx.x, bid = blockIdx.y;
     const u32 sid = index_list[bid];
+    if (sid == 0xFFFFFFFFu) return;
     const int limit = (int)streams[sid].src_len - tail_skip - 4;
     if ((int)p > limit) return;
     const u32 j = p / SA, first = j * SA, start = first >= W ? first - W : 0u, local = p - start;
@@ -361,7 +364,8 @@ int alz_encode_aseg(const void* geom, uint32_t count, uint32_t max_len, uint32_t
     if (bytes) *bytes = 0;
     const u32 W = ((u32)g.max_dist + 63u) & ~63u;
     // (16-bit links, no min-length table -- quality < 10 --, and a kernel A of ONE pass at 15 bits: the finder's own 15 bits, or narrowed afterwards in windows up to 8 KiB)
-    const bool plain = g.hash_bits == 15, narrowed = g.link16 && g.nprops <= 1 && g.hash_bits > 15 && g.max_dist <= 8192;
+    // (round 6: the 64 KiB windows too -- LZ4 blocks, LZO, raw Snappy above quality 0 --, whose launch narrows the streams of ONE of enc_words_kernel's two lists: unused slots of the list stay out)
+    const bool plain = g.hash_bits == 15, narrowed = g.link16 && g.nprops <= 1 && g.hash_bits > 15;
     if (!g.link16 || g.use_min_table || !(plain || narrowed) || count == 0 || count > ALZ_ASEG_MAX_STREAMS || max_len < 4u * W) return 0;
     uint64_t sa = ((uint64_t)count * max_len + 511u) / 512u;              // ~512 workgroups: two per CU
     if (sa < 2u * W) sa = 2u * W;
