@@ -4026,8 +4026,13 @@ hipError_t alz_launch_encode(int fmt, hipStream_t stream, const void* d_src, voi
         EncGeom g15 = g; g15.hash_bits = 15;
         // (workgroups per stream, each with one contiguous range -- and the window behind it fetched again: ranges of 8 KiB for windows up to 8 KiB -- 16 KiB
         // move the same 15 GB: what is fetched are the lines of the scattered candidate words --; for 64 KiB windows as few as still fill the GPU)
-        u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u; if (bx > 32u) bx = 32u;
-        if (!uses_win_prev(g)) { const u32 want = (ALZ_NARROW_WGS + count - 1u) / count; if (bx > want) bx = want; }
+        u32 bx = (max_len + 255u) / 256u; if (bx == 0u) bx = 1u;
+#ifndef ALZ_NARROW_BX_MAX
+#define ALZ_NARROW_BX_MAX 256u
+#endif
+        // (... and for a handful of long buffers more than 32 each: 16 x 4 MiB as LZ4 blocks at quality 8 were 512 workgroups, two wavefronts per SIMD for a kernel of dependent loads)
+        if (!uses_win_prev(g)) { const u32 want = (ALZ_NARROW_WGS + count - 1u) / count; if (bx > want) bx = want; if (bx > ALZ_NARROW_BX_MAX) bx = ALZ_NARROW_BX_MAX; }
+        else if (bx > 32u) bx = 32u;
         auto narrow = [&](const u32* list) {
             if (g.max_dist <= 8192) {                                               // (range and window in LDS)
                 const u32 look = g.max_dist <= 4096 ? 4096u : 8192u, range = look == 4096u ? ALZ_NARROW_RANGE : 8192u;
