@@ -300,6 +300,14 @@ int alz_encode_segmented(int fmt, const void* geom, uint32_t count, uint32_t max
     u32 hist = seg_table_hist(g);                                          // the longest jump, in whole windows: what a segment's exit table covers (enc_exit_kernel)
     if (spec4) {
         // (a segment's masks live in LDS -- at most 8 192 positions --, and its record is SpecRec + the cursor mask: `hist` words behind three -- alz_encode_seg_bytes)
+#ifndef ALZ_SPEC_SLMIN_K
+#define ALZ_SPEC_SLMIN_K 32u     /* a segment is at least sqrt(K x longest buffer) positions: a walk costs ~1 us a window, the serial fix-up ~2 us a segment of the buffer, and while the launch does not fill the GPU both are
+                                    latency -- 16 x 256 KiB as LZ4 blocks at quality 0, ms per call at K = 0 / 32 / 64 / 128: 0.90 / 0.74 / 0.76 / 0.81; 16 x 64 KiB 0.32 / 0.32 / 0.33 / 0.36; from 256 buffers on nothing moves */
+#endif
+        if (ALZ_SPEC_SLMIN_K) {
+            u32 lo = 64u; while ((uint64_t)lo * lo < (uint64_t)ALZ_SPEC_SLMIN_K * max_len) lo += 64u;
+            if (sl < lo) sl = lo;
+        }
         if (sl > 8192u) sl = 8192u;
 #ifndef ALZ_SPEC_ODD
 #define ALZ_SPEC_ODD 1
