@@ -236,7 +236,8 @@ struct SpecRec { u32 exit, carried, pad0, pad1; };      // the first cursor behi
 // smw, cursor bits into cmw (both LDS, relative to S).  Returns the cursor it ended on; met: it ended on a cursor of `stop`; carried: its last step left a token on position End.
 template <bool MINT>
 __device__ __forceinline__ int spec_walk(const u8* data, int ns, int limit, const EncGeom& g, mentry* m, const int* p4, const int* pm, int S, int End, int cur, const u64* stop,
-                                         u64* smw, u64* cmw, int lane, bool& met, bool& carried) {
+                                         u64* smw, u64* cmw, int lane, bool& met, bool& carried, bool has0 = false, u64 stop0 = 0ull) {
+    // (has0 / stop0: the caller holds the first word of `stop` already -- the fix-up, which has every segment's in LDS)
     met = false; carried = false;
     auto ldm = [&](int q) { return q <= limit ? m_unpack(m[q]) : make_uint2(0, 0); };
     while (cur <= limit && cur < End) {
@@ -251,7 +252,7 @@ __device__ __forceinline__ int spec_walk(const u8* data, int ns, int limit, cons
             if (lazyc && l1 > l0) { startrel = 2; const int e = p + 1 + l1; const int stop2 = e < limit + 1 ? e : limit + 1; jump = (p + 2 > stop2 ? p + 2 : stop2) - p; }
             else { startrel = 1; const int skip = lazyc ? 1 : 0; const int e = p + l0; const int stop2 = e < limit + 1 ? e : limit + 1; jump = (p + 1 + skip > stop2 ? p + 1 + skip : stop2) - p; }
         }
-        const u64 stopw = stop ? stop[(u32)(P - S) >> 6] : 0ull;
+        const u64 stopw = !stop ? 0ull : (has0 && P == S) ? stop0 : stop[(u32)(P - S) >> 6];
         u64 sb = 0, cb = 0; bool nextbit = false;
         int rel = cur - P;
         if (__ballot(capped) == 0ull) {
@@ -352,6 +353,13 @@ __global__ __launch_bounds__(64) void enc_spec_fix_kernel(const u8* __restrict__
                                                           mentry* __restrict__ match, const u64* __restrict__ pos_off, const int* __restrict__ prev4, const int* __restrict__ prevm,
                                                           u64* __restrict__ startmask, const u32* __restrict__ spec, u32 kpitch, u32 seglen, u32 recw, EncGeom g) {
     __shared__ u64 nbw[ALZ_SPEC_MAXW], ncw[ALZ_SPEC_MAXW];
+    // Every step of this loop is latency -- one wavefront, one segment after the other --, so what a step needs from the speculative walk's records is in LDS before the first one:
+    // exit, carried and the first words of the cursor mask and of the start mask (the true cursor nearly always enters a segment in its first window) of up to ALZ_SPEC_PRE segments.
+    // A step was ~450 instructions on this one wavefront, ~2 us -- 45 steps for a 64 KiB buffer, a quarter of a call of 16 buffers.  (The match entries of the windows the segments
+    // will most likely be entered in, fetched 96 segments at a time into LDS as well: measured, nothing -- the steps that walk are bound by their instructions, not by that load.)
+    constexpr u32 ALZ_SPEC_PRE = 1024u;
+    __shared__ u32 exL[ALZ_SPEC_PRE], caL[ALZ_SPEC_PRE];
+    __shared__ u64 c0L[ALZ_SPEC_PRE], m0L[ALZ_SPEC_PRE];                           // (m0L: the first word of the segment's start mask, as the speculative walk left it)
     const u32 bid = blockIdx.x;
     const int lane = (int)threadIdx.x;
     const u32 sid = index_list[bid];
@@ -360,16 +368,29 @@ __global__ __launch_bounds__(64) void enc_spec_fix_kernel(const u8* __restrict__
     if (limit < 0) return;
     const u32 nw = seglen >> 6;
     const u32 K = ((u32)n + seglen - 1u) / seglen;
+    u64* mask0 = startmask + (pos_off[sid] >> 6);
+    for (u32 k = (u32)lane; k < K && k < ALZ_SPEC_PRE; k += 64) {
+        const u32* r = spec + ((size_t)bid * kpitch + k) * recw;
+        if ((int)(k * seglen) <= limit) { exL[k] = r[0]; caL[k] = r[1]; c0L[k] = *reinterpret_cast<const u64*>(r + 4); m0L[k] = mask0[(k * seglen) >> 6]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     const u8* data = src_base + st.src_off;
     mentry* m = match + pos_off[sid];
     const int* p4 = prev4 + pos_off[sid];
     const int* pm = g.use_min_table ? prevm + pos_off[sid] : nullptr;
-    u64* mask0 = startmask + (pos_off[sid] >> 6);
     int e = 0;                                                                   // the cursor that enters the segment
     bool carry_in = false;                                                       // the walk in front left a token on this segment's first position
     for (u32 k = 0; k < K; k++) {
         const int S = (int)(k * seglen), End = S + (int)seglen;
         if (S > limit) break;
+        // Three steps in four, the cursor that enters the segment is one the speculative walk stood on as well, in the segment's first window: nothing to walk -- the speculative
+        // walk's starts below it go, a token the segment in front put on the first position comes in (a store, nothing read: ~30 instructions instead of ~450 on this one wavefront)
+        if (k < ALZ_SPEC_PRE && e >= S && e - S < 64 && ((c0L[k] >> (u32)(e - S)) & 1ull)) {
+            if ((e > S || carry_in) && lane == 0) mask0[(u32)S >> 6] = (m0L[k] & (~0ull << (u32)(e - S))) | (carry_in ? 1ull : 0ull);
+            carry_in = caL[k] != 0u;
+            e = (int)exL[k];
+            continue;
+        }
         const u32* rec = spec + ((size_t)bid * kpitch + k) * recw;
         const u64* cm = reinterpret_cast<const u64*>(rec + 4);
         u64* mask = mask0 + ((u32)S >> 6);
@@ -379,19 +400,22 @@ __global__ __launch_bounds__(64) void enc_spec_fix_kernel(const u8* __restrict__
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         if (e < End) {
             bool met;
-            const int cur = g.use_min_table ? spec_walk<true>(data, ns, limit, g, m, p4, pm, S, End, e, cm, nbw, ncw, lane, met, carried)
-                                            : spec_walk<false>(data, ns, limit, g, m, p4, pm, S, End, e, cm, nbw, ncw, lane, met, carried);
-            if (met) { c = cur; x = (int)uni(rec[0]); carried = uni(rec[1]) != 0u; }
+            const bool pre = k < ALZ_SPEC_PRE;
+            const u64 stop0 = pre ? c0L[k] : 0ull;
+            const int cur = g.use_min_table ? spec_walk<true>(data, ns, limit, g, m, p4, pm, S, End, e, cm, nbw, ncw, lane, met, carried, pre, stop0)
+                                            : spec_walk<false>(data, ns, limit, g, m, p4, pm, S, End, e, cm, nbw, ncw, lane, met, carried, pre, stop0);
+            if (met) { c = cur; x = (int)(pre ? exL[k] : uni(rec[0])); carried = (pre ? caL[k] : uni(rec[1])) != 0u; }
             else { c = End; x = cur; }
         }
-        // the segment's start mask: the speculative walk's starts from c on, the true cursor's in front of it, the token carried in from the segment before
+        // the segment's start mask: the speculative walk's starts from c on, the true cursor's in front of it, the token carried in from the segment before.  Only the word
+        // c lies in is read; the words in front of it are the true cursor's alone, the words behind it stay as they are (but for a token this walk put on c itself or carried in)
         for (u32 w = (u32)lane; w < nw; w += 64) {
             if ((u32)S + 64u * w >= (u32)n) continue;
             const int lo = S + 64 * (int)w;
-            const u64 keep = c <= lo ? ~0ull : c >= lo + 64 ? 0ull : ~0ull << (u32)(c - lo);
-            u64 v = (mask[w] & keep) | nbw[w];
-            if (w == 0u && carry_in) v |= 1ull;
-            mask[w] = v;
+            const u64 mine = nbw[w] | ((w == 0u && carry_in) ? 1ull : 0ull);
+            if (c >= lo + 64) mask[w] = mine;
+            else if (c > lo) mask[w] = (mask[w] & (~0ull << (u32)(c - lo))) | mine;
+            else if (mine) mask[w] |= mine;
         }
         carry_in = carried;
         e = x;

