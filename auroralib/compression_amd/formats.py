@@ -6,6 +6,8 @@ csrc/alz_container.cpp, bodies on the GPU.  No CPU fallback.
 """
 import ctypes as C
 
+import numpy as np
+
 from . import _abi as A
 from ._lib import AlzError, check, load
 
@@ -82,6 +84,10 @@ class _Format:
         data = bytes(data)
         return bool(load().alz_container_is_match(self.container, data, len(data)))
 
+    def _capacity_hint(self, data):
+        """An upper bound on the decompressed size that the container's framing gives away without decoding (None: none)."""
+        return None
+
     def GetDecompressedSize(self, data):
         if not self.provides_size:
             raise NotImplementedError("%s does not implement IProvidesDecompressedSize" % type(self).__name__)
@@ -98,6 +104,12 @@ class _Format:
         Formats without a size field grow the destination until it fits (a managed Stream grows by itself)."""
         data = bytes(data)
         if capacity is None and not self.provides_size:
+            hint = self._capacity_hint(data)
+            if hint is not None:
+                try:
+                    return self.Decompress(data, hint)
+                except BufferError:
+                    pass                                   # (a frame whose blocks decode to more than their nominal size: grow as for any other)
             cap = max(len(data) * 8, 1 << 16)
             while True:
                 try:
@@ -121,7 +133,8 @@ class _Format:
         if capacity is None:
             capacity = self.GetDecompressedSize(data) + 273
         o = self._opt()
-        dst = C.create_string_buffer(max(capacity, 1))
+        dst_arr = np.empty(max(capacity, 1), dtype=np.uint8)       # (untouched memory: create_string_buffer writes the whole capacity first -- 68 MB of zeros for a 67 MB frame)
+        dst = dst_arr.ctypes.data_as(C.c_void_p)
         dl, su, st = C.c_size_t(), C.c_size_t(), C.c_int32()
         lib = load()
         lib.alz_container_decompress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -140,7 +153,7 @@ class _Format:
             raise ValueError("bad token")
         check(rc)
         self.last_src_used = su.value
-        return C.string_at(dst, dl.value)             # (dst.raw would copy the whole capacity first)
+        return dst_arr[:dl.value].tobytes()
 
     def Compress(self, data, settings=None):
         data = bytes(data)
@@ -151,11 +164,12 @@ class _Format:
         lib.alz_container_compress_bound.restype = C.c_size_t
         lib.alz_container_compress_bound.argtypes = [C.c_uint32, C.c_size_t]
         cap = lib.alz_container_compress_bound(self.container, len(data))
-        dst = C.create_string_buffer(cap)
+        dst_arr = np.empty(max(cap, 1), dtype=np.uint8)
+        dst = dst_arr.ctypes.data_as(C.c_void_p)
         dl = C.c_size_t()
         lib.alz_container_compress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         check(lib.alz_container_compress(_context().h, self.container, C.byref(o), C.byref(st), data, len(data), dst, cap, C.byref(dl)))
-        return C.string_at(dst, dl.value)             # (dst.raw would copy the whole capacity first)
+        return dst_arr[:dl.value].tobytes()
 
 
 class LZSS(_Format):
@@ -320,6 +334,25 @@ class LZ4(_Format):
     def __init__(self, BlockSize=0):
         super().__init__()
         self.ChunkSize = BlockSize
+
+    def _capacity_hint(self, data):
+        # blocks x the frame's maximum block size (LZ4.Frame.cs:107-174: FLG, BD, optional content size / dictionary id, header checksum; then u32 sizes) --
+        # a 67 MB frame made the growing loop decode twice, the second time into 256 MB
+        total, pos, n = 0, 0, len(data)
+        while pos + 7 <= n and int.from_bytes(data[pos:pos + 4], "little") == 0x184D2204:
+            flg, bd = data[pos + 4], data[pos + 5]
+            bmax = {4: 0x10000, 5: 0x40000, 6: 0x100000, 7: 0x400000}.get((bd >> 4) & 7)
+            if bmax is None:
+                return None
+            pos += 7 + (8 if flg & 8 else 0) + (4 if flg & 1 else 0)
+            while pos + 4 <= n:
+                bsz = int.from_bytes(data[pos:pos + 4], "little"); pos += 4
+                if bsz == 0:
+                    break
+                total += bmax
+                pos += (bsz & 0x7FFFFFFF) + (4 if flg & 16 else 0)
+            pos += 4 if flg & 4 else 0
+        return total + 64 if total else None
 
 
 class LZ4Legacy(_Format):

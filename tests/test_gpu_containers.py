@@ -200,6 +200,15 @@ def test_lz4_independent_blocks_are_one_batch(test_bmp):
     blocks = [O.encode_stream(A.FMT_LZ4_BLOCK, p, quality=4)[0] for p in pieces]
     assert F.LZ4().Decompress(FC.lz4_frame(blocks, O.xxh32, flg=0x60, bd=0x40)) == b"".join(pieces)
     assert F.LZ4Legacy().Decompress(FC.lz4_legacy(blocks)) == b"".join(pieces)
+    # the same frames WITHOUT the flag -- what the reference's own writer produces (LZ4.Frame.cs:184 clears it; every block has a finder of its own, LZ4.cs:205): no block
+    # reaches back, so they are one batch as well (round 6: 16 MB in 64 KiB blocks took 112 ms one launch after the other, 3.3 as a batch); short blocks in the middle
+    # fall back to in-order decoding, and a linked frame whose blocks DO reach back still decodes in order (test_lz4_linked_frames)
+    plain = O.container_compress(A.C_LZ4_FRAME, raw, quality=0, chunk_size=0x10000)
+    assert plain[4] & 32 == 0 and F.LZ4().Decompress(plain) == raw
+    assert F.LZ4().Decompress(FC.lz4_frame(blocks, O.xxh32, flg=0x40, bd=0x40)) == b"".join(pieces)
+    many = (test_bmp * 3)[:40 * 0x10000 + 1234]
+    frame40 = O.container_compress(A.C_LZ4_FRAME, many, quality=8, chunk_size=0x10000)
+    assert frame40[4] & 32 == 0 and F.LZ4().Decompress(frame40) == many == O.container_decompress(A.C_LZ4_FRAME, frame40, cap=len(many) + 16)[0]
     # legacy at its real block size (8 MiB): two blocks, nominal offsets hold
     big = (test_bmp[:4096] * 2200)[:0x800000 + 300000]
     comp = O.container_compress(A.C_LZ4_LEGACY, big, quality=0)
