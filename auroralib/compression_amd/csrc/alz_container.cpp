@@ -186,6 +186,16 @@ static bool lz4_block_reaches_back(const uint8_t* b, uint32_t n) {
 
 struct Lz4Block { size_t off; uint32_t len; bool raw; };
 
+// A block's destination as the whole-GPU decode path of ONE stream wants it (alz_big_eligible: no more than 32 x the input + 64 KiB -- its launches are sized by the room in the
+// destination): the frame's block maximum is 4 MiB whatever the block holds, and a 1 MB file in one block had 33 x its 126 KB of input to decode into -- 3.7 ms on two wavefronts
+// instead of 0.28.  A block that does not fit the tighter room (it compressed better than 32 : 1) reports OUTPUT_CAPACITY and is decoded again with all of it.
+inline uint32_t lz4_tight_cap(uint32_t cap, uint32_t src_len) {
+    const uint64_t t = 32ull * src_len + 65536ull;
+    return t < cap ? (uint32_t)t : cap;
+}
+// (worth the whole GPU by itself: plan_create's own test, restated for the split below -- a wrong guess costs time, not bytes)
+inline bool lz4_long_block(const alz_stream& s) { return s.src_len >= 8192u && s.dst_cap >= (24u << 10); }
+
 // LZ4.Decompress  Formats/Common/LZ4.cs:50-93 (+ ReadLZ4L :96-111, DecompressLZ4FrameHeader  LZ4.Frame.cs:107-174).
 // The file and the output stay in HBM for the whole call.  Blocks that cannot reference each other (legacy frames:
 // a fresh LzWindows per block, LZ4.cs:164; frames with the block-independence flag) go to the GPU as ONE batch at
@@ -223,7 +233,10 @@ int lz4_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* d
             ss[0].src_off = bl[i].off; ss[0].src_len = bl[i].len; ss[0].dst_off = out; ss[0].dst_cap = clamp32(out < cap ? cap - out : 0);
             if ((uint64_t)ss[0].dst_cap + hist > 0xFFFFFF00ull) return ALZ_E_UNSUPPORTED;
             ss[0].aux0 = (uint32_t)hist; ss[0].format = ALZ_FMT_LZ4_BLOCK;
+            const uint32_t full = ss[0].dst_cap;
+            if (!linked) ss[0].dst_cap = lz4_tight_cap(full, ss[0].src_len);
             int e = run(ss, rs); if (e != ALZ_OK) return e;
+            if (rs[0].status == ALZ_ST_OUTPUT_CAPACITY && ss[0].dst_cap < full) { ss[0].dst_cap = full; e = run(ss, rs); if (e != ALZ_OK) return e; }   // (a block that compressed more than 32 : 1)
             out += rs[0].dst_len;
             if (rs[0].status != ALZ_ST_OK) st = rs[0].status;
         }
@@ -234,17 +247,32 @@ int lz4_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* d
     auto run_independent = [&](const std::vector<Lz4Block>& bl, uint32_t nominal) -> int {
         if (bl.size() <= 1) return run_sequential(bl, 0, out, false);
         const size_t origin = out;
-        std::vector<alz_stream> ss; std::vector<size_t> idx;
+        std::vector<alz_stream> ss; std::vector<size_t> idx; std::vector<bool> tightened;
         for (size_t i = 0; i < bl.size(); i++) {
             const size_t o = origin + i * (size_t)nominal;
             if (bl[i].raw) continue;
             alz_stream s; memset(&s, 0, sizeof(s));
             s.src_off = bl[i].off; s.src_len = bl[i].len; s.dst_off = o < cap ? o : cap;
             s.dst_cap = clamp32(o < cap ? (cap - o < nominal ? cap - o : nominal) : 0); s.format = ALZ_FMT_LZ4_BLOCK;
+            tightened.push_back(lz4_tight_cap(s.dst_cap, s.src_len) < s.dst_cap);
+            s.dst_cap = lz4_tight_cap(s.dst_cap, s.src_len);
             ss.push_back(s); idx.push_back(i);
         }
-        std::vector<alz_result> rs;
-        if (!ss.empty()) { int e = run(ss, rs); if (e != ALZ_OK) return e; }
+        // A plan takes its streams one after the other on the whole GPU only when ALL of them are worth it (plan_create), and the last block of a file is usually a
+        // short one: 16 MB in 4 MiB blocks -- four of them and 2 KB -- decoded every block on wavefronts of its own, 14 ms for the 4 MiB ones instead of 0.5 each.
+        // The long blocks and the short ones go out as two plans.
+        std::vector<alz_result> rs(ss.size());
+        {
+            std::vector<alz_stream> sa, sb; std::vector<size_t> ia, ib;
+            for (size_t k = 0; k < ss.size(); k++) { if (lz4_long_block(ss[k])) { sa.push_back(ss[k]); ia.push_back(k); } else { sb.push_back(ss[k]); ib.push_back(k); } }
+            if (!sa.empty() && !sb.empty() && sa.size() <= 32) {
+                std::vector<alz_result> ra, rb;
+                int e = run(sa, ra); if (e != ALZ_OK) return e;
+                e = run(sb, rb); if (e != ALZ_OK) return e;
+                for (size_t k = 0; k < ia.size(); k++) rs[ia[k]] = ra[k];
+                for (size_t k = 0; k < ib.size(); k++) rs[ib[k]] = rb[k];
+            } else if (!ss.empty()) { int e = run(ss, rs); if (e != ALZ_OK) return e; }
+        }
         size_t k = 0;
         for (size_t i = 0; i < bl.size(); i++) {
             const size_t o = origin + i * (size_t)nominal;
@@ -253,7 +281,12 @@ int lz4_file_decompress(alz_ctx* ctx, const uint8_t* src, size_t len, uint8_t* d
                 produced = bl[i].len;
                 if (out != o || out + produced > cap) return run_sequential(bl, i, origin, false);
                 int e = alz_memcpy_h2d(ctx, (uint8_t*)d_dst.p + out, src + bl[i].off, produced); if (e != ALZ_OK) return e;
-            } else { produced = rs[k].dst_len; bst = rs[k].status; k++; if (out != o) return run_sequential(bl, i, origin, false); }
+            } else {
+                produced = rs[k].dst_len; bst = rs[k].status;
+                const bool tight = tightened[k]; k++;
+                if (out != o) return run_sequential(bl, i, origin, false);
+                if (bst == ALZ_ST_OUTPUT_CAPACITY && tight) return run_sequential(bl, i, origin, false);             // it compressed better than 32 : 1: again, with all the room there is
+            }
             if (bst == ALZ_ST_OUTPUT_CAPACITY && o + nominal <= cap) return run_sequential(bl, i, origin, false);   // the block is larger than nominal
             out = o + produced;
             if (bst != ALZ_ST_OK) { st = bst; return ALZ_OK; }

@@ -336,9 +336,25 @@ class LZ4(_Format):
         self.ChunkSize = BlockSize
 
     def _capacity_hint(self, data):
-        # blocks x the frame's maximum block size (LZ4.Frame.cs:107-174: FLG, BD, optional content size / dictionary id, header checksum; then u32 sizes) --
-        # a 67 MB frame made the growing loop decode twice, the second time into 256 MB
+        return _lz4_capacity_hint(data)
+
+
+def _lz4_capacity_hint(data):
+        """blocks x the frame's maximum block size (LZ4.Frame.cs:107-174: FLG, BD, optional content size / dictionary id, header checksum; then u32 sizes; a legacy file:
+        blocks of at most 8 MiB, LZ4.cs:96-111) -- a 67 MB frame made the growing loop decode twice, the second time into 256 MB.  None: not a file this walk understands."""
         total, pos, n = 0, 0, len(data)
+        if n >= 8 and int.from_bytes(data[:4], "little") == 0x184C2102:
+            pos = 4
+            while pos + 4 <= n:
+                bs = int.from_bytes(data[pos:pos + 4], "little")
+                if bs in (0x184D2204, 0x184C2102) or (bs & 0xFFFFFFF0) == 0x184D2A50:
+                    return None                            # (another file behind this one: the growing loop's)
+                if pos + 4 + bs > n:
+                    break
+                total += 0x800000; pos += 4 + bs
+                if pos < n and data[pos] == 0xFF:
+                    break
+            return total + 64 if total else None
         while pos + 7 <= n and int.from_bytes(data[pos:pos + 4], "little") == 0x184D2204:
             flg, bd = data[pos + 4], data[pos + 5]
             bmax = {4: 0x10000, 5: 0x40000, 6: 0x100000, 7: 0x400000}.get((bd >> 4) & 7)
@@ -359,6 +375,9 @@ class LZ4Legacy(_Format):
     """src/AuroraLib.Compression/Formats/Common/LZ4Legacy.cs"""
     container = A.C_LZ4_LEGACY
     provides_size = False
+
+    def _capacity_hint(self, data):
+        return _lz4_capacity_hint(data)
 
 
 class Snappy(_Format):
