@@ -402,7 +402,10 @@ typedef enum alz_container {
     ALZ_C_LZ77   = 20, /* "LZ77"+type: LZ10 / LZ11 / ChunkLZ10 (independent 4 KiB chunks = one GPU batch)  Nintendo/LZ77.cs:56-153 */
     ALZ_C_LEVEL5 = 21, /* u32 type|size<<3: OnlySave / LZ10   src/AuroraLib.Compression.Nintendo/Level5/Level5.cs:62-146 */
     ALZ_C_LZ4_FRAME = 22, /* LZ4: frame 0x184D2204 (descriptor, linked or independent blocks, xxHash32 block / content
-                             checksums), legacy and skippable frames, concatenated   LZ4.cs:50-93, LZ4.Frame.cs:107-215 */
+                             checksums), legacy and skippable frames, concatenated   LZ4.cs:50-93, LZ4.Frame.cs:107-215.
+                             Decoding: a frame none of whose blocks reaches in front of itself (a host walk over the sequences)
+                             is ONE GPU batch whatever its block-independence flag says -- the reference's own writer clears
+                             the flag and compresses every block on its own --; any other frame decodes block after block */
     /* more header-only wrappers (the reference's .Extended assembly) */
     ALZ_C_MDB4   = 23, /* "MDB4"+(n+1)+n+csize+16 zero bytes + LZSS   src/AuroraLib.Compression-Extended/Specialized/MDB4.cs:33-72 */
     ALZ_C_FCMP   = 24, /* "FCMP"+n+0x12340000 + LZSS               src/AuroraLib.Compression-Extended/Marvelous/FCMP.cs:36-50    */
