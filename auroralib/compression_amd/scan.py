@@ -3,6 +3,8 @@ ScanDecompressCommand (scan a file for embedded streams) and BruteForceCommand (
 Thin ctypes wrappers over alz_container_scan / alz_brute_force (include/auroralz.h)."""
 import ctypes as C
 
+import numpy as np
+
 from . import _abi as A
 from ._lib import check, load
 from .formats import _context
@@ -28,7 +30,8 @@ def scan(data, formats, big_endian=True, lz=None, max_hits=1 << 16, dst_cap=None
     lib.alz_container_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     while True:
-        dst = C.create_string_buffer(cap)
+        dst_arr = np.empty(cap, dtype=np.uint8)              # (untouched memory; a ctypes buffer's .raw copies the WHOLE capacity on every access -- once per hit, below)
+        dst = dst_arr.ctypes.data_as(C.c_void_p)
         hits = (ScanHit * max_hits)()
         n, used = C.c_uint32(), C.c_size_t()
         rc = lib.alz_container_scan(_context().h, arr, len(ids), C.byref(o), data, len(data), dst, cap, hits, max_hits, C.byref(n), C.byref(used))
@@ -36,7 +39,7 @@ def scan(data, formats, big_endian=True, lz=None, max_hits=1 << 16, dst_cap=None
             cap *= 4
             continue
         check(rc)
-        return [(h.start, h.end, h.container, dst.raw[h.dst_off:h.dst_off + h.dst_len]) for h in hits[:n.value]]
+        return [(h.start, h.end, h.container, dst_arr[h.dst_off:h.dst_off + h.dst_len].tobytes()) for h in hits[:n.value]]
 
 
 def brute_force(raw, expected_size):
@@ -46,7 +49,8 @@ def brute_force(raw, expected_size):
     lib = load()
     nd = 19
     slot = max(expected_size, 1)
-    dst = C.create_string_buffer(slot * nd)
+    dst_arr = np.empty(slot * nd, dtype=np.uint8)
+    dst = dst_arr.ctypes.data_as(C.c_void_p)
     res = (A.Result * nd)()
     lib.alz_brute_force.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.alz_brute_decoder_name.restype = C.c_char_p
@@ -55,5 +59,5 @@ def brute_force(raw, expected_size):
     for i in range(nd):
         name = lib.alz_brute_decoder_name(i).decode()
         ok = res[i].status == A.ST_OK and res[i].dst_len == expected_size
-        out[name] = (ok, res[i].status, dst.raw[i * slot:i * slot + res[i].dst_len])
+        out[name] = (ok, res[i].status, dst_arr[i * slot:i * slot + res[i].dst_len].tobytes())
     return out
