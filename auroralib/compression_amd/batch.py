@@ -97,10 +97,10 @@ class Context:
     def decode(self, fmt, src, decom_len=0, cap=None, aux0=0, aux1=0, lz=None):
         src = bytes(src)
         cap = decom_len if cap is None else cap
-        dst = C.create_string_buffer(max(cap, 1))
+        dst = np.empty(max(cap, 1), dtype=np.uint8)          # (untouched memory: a ctypes buffer would be written full of zeros first)
         r = A.Result()
-        check(self.lib.alz_decode(self.h, fmt, C.byref(lz) if lz is not None else None, src, len(src), decom_len, aux0, aux1, dst, cap, C.byref(r)))
-        return C.string_at(dst, r.dst_len), r
+        check(self.lib.alz_decode(self.h, fmt, C.byref(lz) if lz is not None else None, src, len(src), decom_len, aux0, aux1, _vp(dst), cap, C.byref(r)))
+        return dst[:r.dst_len].tobytes(), r
 
     # ---- host-buffer encode
     def encode_batch(self, streams, src, dst_bytes, quality=8, lz=None, strategy=0, min_distance=0, max_window_bits=0):
