@@ -1040,15 +1040,19 @@ static int encode_core(alz_ctx* c, const alz_lz_properties* props, const alz_set
         // + ~0.14 ms of small kernels per format + ~0.08 ms per MiB of the whole call.  tools/mid_batch_encode.py with ALZ_MID_BIG=on / off,
         // profiles/r05_mid_big_vs_seg.txt: 4 x 256 KiB at quality 8 0.47 ms one by one against 0.42, 8 x 1 MB 1.66 / 1.73, 16 x 1 MB 3.33 / 2.18)
         {
-            bool seg_all = true, aseg_all = true, spec_any = false; int nf = 0; double mib_all = 0;
+            bool seg_all = true, aseg_all = true, spec_any = false, wide_any = false; int nf = 0; double mib_all = 0;
             for (int f = 0; f < ALZ_FMT_COUNT; f++) if (cnt[f]) {
                 nf++; seg_all = seg_all && seg_len[f] != 0; spec_any = spec_any || alz_encode_seg_spec_format(f);
+                wide_any = wide_any || alz_encode_geom_max_dist(geom.data() + f * alz_encode_geom_size()) > 8192;
                 aseg_all = aseg_all && alz_encode_aseg(geom.data() + f * alz_encode_geom_size(), cnt[f], max_len, nullptr, nullptr, nullptr, nullptr, nullptr);
             }
             for (uint32_t i = 0; i < n; i++) mib_all += streams[i].src_len / 1048576.0;
-            // (the formats of the speculative walk -- alz_encode_seg_seq.h -- have one serial step per segment of the longest buffer behind that: ~1.2 ms per MiB; 2 / 8 / 16 / 32 x 1 MiB
-            // side by side, ms: LZ4 blocks at quality 0 3.27 / 3.40 / 3.23 / 3.14, at quality 8 4.06 / 4.63 / 4.96 / 6.93; LZ11 at quality 0 -- / 2.14 / 1.98 / 2.01, at quality 8 -- / 3.41 / 3.40 / 4.57)
-            if (seg_all) { const double t_seg = 0.14 * nf + ((aseg_all ? (q0 ? 0.45 : 0.9) : 2.2) + (spec_any ? 1.2 : 0.0)) * (max_len / 1048576.0) + (q0 ? 0.03 : 0.08) * mib_all; if (t_seg < t_side) t_side = t_seg; }
+            // (the formats of the speculative walk -- alz_encode_seg_seq.h -- have one serial step per segment of the longest buffer behind that, and the 64 KiB windows above quality 0 their
+            // words / narrowing passes: ~0.4 / 2.0 ms per MiB; 2 / 4 / 8 / 16 x 1 MiB at the end of round 6, ms, one by one | side by side: LZ4 blocks at quality 0 0.65 / 1.28 / 2.53 / 5.09 |
+            // 0.99 / 1.03 / 1.11 / 1.60, at quality 8 1.61 / 3.19 / 6.39 / 12.8 | 2.93 / 3.06 / 3.43 / 4.63; LZ11 at quality 0 0.42 / 0.84 / 1.64 / 3.27 | 0.72 / 0.79 / 0.90 / 1.42, at quality 8
+            // 0.76 / 1.47 / 2.92 / 5.89 | 1.65 / 1.84 / 2.07 / 2.95)
+            const double t_spec = spec_any ? ((wide_any && !q0) ? 2.0 : 0.4) : 0.0;
+            if (seg_all) { const double t_seg = 0.14 * nf + ((aseg_all ? (q0 ? 0.45 : 0.9) : 2.2) + t_spec) * (max_len / 1048576.0) + (q0 ? 0.03 : 0.08) * mib_all; if (t_seg < t_side) t_side = t_seg; }
         }
         all = all && t_big < t_side;
         if (all) {
