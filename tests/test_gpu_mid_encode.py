@@ -166,6 +166,16 @@ def test_capacity_and_canary_device_resident(fmt, test_bmp):
                     assert (res[i].status, res[i].dst_len) == (A.ST_OUTPUT_CAPACITY, 0), tag
 
 
+@pytest.mark.parametrize("fmt", [A.FMT_LZ4_BLOCK, A.FMT_LZ11])
+def test_more_segments_than_the_fixup_keeps_in_lds(fmt, test_bmp):
+    """A buffer of 9 MB is more than 1 024 segments of the longest kind (8 128 positions): the fix-up of the speculative walk holds the records of the first 1 024 in LDS and
+    reads the others where they are; a short buffer beside it, so that the launch is a batch."""
+    big = (test_bmp * 9)[:9 * 1000 * 1000 + 321]
+    items = [(fmt, big), (fmt, test_bmp[:300000]), (fmt, bytes(200000) + test_bmp[5000:90000])]
+    with Context(0) as c:
+        _both_ways(c, items, 0, "9 MB")
+
+
 def test_lzo_head_capacity_and_canary(test_bmp):
     """LZO's head kernel writes whole streams by itself -- noise (no match at all: one literal run, copied by the wavefront), buffers under 16 bytes, a buffer whose first match
     comes late -- and hands the others over after their first match: destinations of exactly the compressed size, one byte less and far too small, with the whole
