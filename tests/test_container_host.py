@@ -232,3 +232,22 @@ def test_lz4_linked_frame_oracle():
     e1 = FC.lz4_linked_blocks(7, 1, 30000)[1]
     out, st = O.container_decompress(A.C_LZ4_FRAME, cat, cap=len(e1) + 2 * len(e2) + 16)
     assert st == A.ST_OK and out == e1 + e2 + e2
+
+
+def test_lz4_capacity_hint_of_the_wrapper(test_bmp):
+    """formats._lz4_capacity_hint: blocks x the frame's block maximum (a legacy file: x 8 MiB) -- an upper bound the wrapper decodes into before it falls back to growing a
+    buffer; never below the true size for files the library's own writer (= the reference's) produces, None for what it does not understand."""
+    raw = test_bmp[:300000]
+    for bs, bmax in ((0x10000, 0x10000), (0x40000, 0x40000), (0, 0x400000)):
+        frame = O.container_compress(A.C_LZ4_FRAME, raw, quality=0, chunk_size=bs)
+        nblocks = (len(raw) + bmax - 1) // bmax
+        assert F._lz4_capacity_hint(frame) == nblocks * bmax + 64 >= len(raw)
+        assert F._lz4_capacity_hint(frame + frame) == 2 * nblocks * bmax + 64           # frames concatenate (LZ4.cs:50-93)
+    legacy = O.container_compress(A.C_LZ4_LEGACY, raw, quality=0)
+    assert F._lz4_capacity_hint(legacy) == 0x800000 + 64
+    assert legacy[-1] == 0xFF                                                            # the EOF flag: what follows it is not read (LZ4.cs:96-111)
+    assert F._lz4_capacity_hint(legacy + O.container_compress(A.C_LZ4_FRAME, raw, quality=0)) == 0x800000 + 64
+    assert F._lz4_capacity_hint(legacy[:-1] + O.container_compress(A.C_LZ4_FRAME, raw, quality=0)) is None   # another file right behind the last block: the growing loop's
+    assert F._lz4_capacity_hint(b"") is None and F._lz4_capacity_hint(b"\x00" * 64) is None and F._lz4_capacity_hint(raw[:100]) is None
+    blocks, expect = FC.lz4_linked_blocks(7, 5, 30000)
+    assert F._lz4_capacity_hint(FC.lz4_frame(blocks, O.xxh32, flg=0x40 | 4 | 8 | 16, bd=0x40, content=expect)) == 5 * 0x10000 + 64
